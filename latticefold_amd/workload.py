@@ -1,0 +1,138 @@
+"""Deterministic synthetic LatticeFold workloads (numpy only; no oracle, no GPU).
+
+Mirrors the shape of the reference's own benchmark generator
+(crates/latticefold/benches/utils.rs:136-171 "non-scalar" R1CS, arith/r1cs.rs:155-201,289-308):
+x_len = 1, x = (1), h = 1, R1CS with A = B = identity rows (1 nnz/row), C = diag(z), padded to
+m = N = wit_len*L rows; S = {{0,1},{2}}, c = (1,-1).  Differences, all deliberate:
+the witness slots and the Ajtai matrix are i.i.d. uniform from an indexable SplitMix64 stream
+(the reference's `AjtaiCommitmentScheme::rand` yields ONE element repeated kappa*n times,
+commitment_scheme.rs:30-32).  The same stream is produced on-device by lf_util_fill_uniform.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+P = 2**64 - 2**32 + 1
+RE = 24  # u64 words per ring element (8 slots x 3 coords / 24 coefficients)
+
+CONFIGS = {
+    # name: (s, wit_len, L, B, b, K, kappa)   -- SURVEY.md 8.0
+    "T8": (8, 64, 4, 1 << 16, 2, 16, 4),       # tiny, unit tests
+    "T10": (10, 256, 4, 1 << 16, 2, 16, 6),    # small parity case
+    "C1": (10, 256, 4, 1 << 16, 2, 16, 21),    # BASELINE configs[0]
+    "T12": (12, 1024, 4, 1 << 16, 2, 16, 8),
+    "T14": (14, 4096, 4, 1 << 16, 2, 16, 12),
+    "C2": (16, 1 << 14, 4, 1 << 16, 2, 16, 25),  # BASELINE configs[1]
+    "T18": (18, 1 << 16, 4, 1 << 16, 2, 16, 26),
+    "C4": (20, 1 << 18, 4, 1 << 16, 2, 16, 26),  # BASELINE configs[3] / metric config
+    # GoldilocksDP of the reference unit tests (decomposition_parameters.rs:89-96): N not a power of 2
+    "G5": (9, 64, 5, 1 << 15, 2, 15, 5),
+}
+
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_G = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix_fq(seed: int, start: int, count: int) -> np.ndarray:
+    """count canonical Goldilocks residues; word i = splitmix64(seed + (start+i+1)*G) folded into [0,p)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed & (2**64 - 1)) + idx * _G
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+        z = np.where(z >= np.uint64(P), z - np.uint64(P), z)
+    return z
+
+
+def diag(v: int) -> np.ndarray:
+    """R::from(u128): every slot = (v,0,0)."""
+    e = np.zeros(RE, dtype=np.uint64)
+    e[0::3] = np.uint64(v % P)
+    return e
+
+
+@dataclass
+class Workload:
+    name: str
+    s: int
+    wit_len: int
+    L: int
+    B: int
+    b: int
+    K: int
+    kappa: int
+    l: int = 1
+    t: int = 3
+    q: int = 2
+    d: int = 2
+    seed: int = 0
+    rowptr: list = field(default_factory=list)
+    col: list = field(default_factory=list)
+    val: list = field(default_factory=list)
+    S_off: np.ndarray = None
+    S_idx: np.ndarray = None
+    c: np.ndarray = None
+    x_ccs: np.ndarray = None
+    w_ccs: np.ndarray = None
+
+    @property
+    def N(self):
+        return self.wit_len * self.L
+
+    @property
+    def m(self):
+        return 1 << self.s
+
+    @property
+    def n(self):
+        return self.l + 1 + self.wit_len
+
+    @property
+    def tau(self):
+        return 3
+
+    def ajtai_seed(self):
+        return 0xA17A1 + self.seed
+
+    def ajtai_matrix(self, row0=0, rows=None) -> np.ndarray:
+        """kappa x N ring elements (NTT form), i.i.d. uniform words."""
+        rows = self.kappa - row0 if rows is None else rows
+        per_row = self.N * RE
+        return splitmix_fq(self.ajtai_seed(), row0 * per_row, rows * per_row).reshape(rows, self.N, RE)
+
+    def z(self) -> np.ndarray:
+        return np.concatenate([self.x_ccs, diag(1)[None, :], self.w_ccs], axis=0)
+
+    def alg_bytes(self) -> int:
+        """ALGORITHMIC bytes of one fold step, SURVEY.md 8(d) formula (E = 192 B)."""
+        E, N, t, K, L, kap, tau = RE * 8, self.m, self.t, self.K, self.L, self.kappa, self.tau
+        P_L, P_F = t + 1, 5 + 2 * K * tau
+        lin = t * N * E + (N // L) * E + 3 * P_L * N * E + (tau + t) * N * E
+        dec = ((1 + K) * N * E + 2 * K * N * E + (kap + K - 1) * N * E + K * N * E
+               + (K * t + K) * N * E + K * t * N * E)
+        fold = ((2 * K * t + 2) * N * E + (2 * K + 2) * N * E + 3 * P_F * N * E
+                + (2 * K + 2 * K * t) * N * E + (2 * K + 1) * N * E + 2 * N * E)
+        return lin + 2 * dec + fold
+
+
+def make_workload(name: str, seed: int = 0, kappa: int = None) -> Workload:
+    s, wit_len, L, B, b, K, kap = CONFIGS[name]
+    wl = Workload(name=name, s=s, wit_len=wit_len, L=L, B=B, b=b, K=K, kappa=kappa or kap, seed=seed)
+    assert wl.N <= wl.m, "sanity_check (nifs.rs:165-173): m must be >= wit_len*L"
+    wl.x_ccs = np.tile(diag(1), (wl.l, 1))
+    wl.w_ccs = splitmix_fq(0x4C460001 + seed, 0, wit_len * RE).reshape(wit_len, RE)
+    z = wl.z()
+    n, m = wl.n, wl.m
+    rows = min(n, m)
+    rp = np.minimum(np.arange(m + 1, dtype=np.uint32), np.uint32(rows)).astype(np.uint32)
+    ci = np.arange(rows, dtype=np.uint32)
+    ident = np.tile(diag(1), (rows, 1))
+    wl.rowptr = [rp, rp.copy(), rp.copy()]
+    wl.col = [ci, ci.copy(), ci.copy()]
+    wl.val = [ident, ident.copy(), np.ascontiguousarray(z[:rows])]
+    wl.S_off = np.array([0, 2, 3], dtype=np.uint32)
+    wl.S_idx = np.array([0, 1, 2], dtype=np.uint32)
+    wl.c = np.stack([diag(1), diag(P - 1)])
+    return wl

@@ -1,0 +1,864 @@
+/* lfo_protocol.c -- ORACLE (test infrastructure only): CPU restatement of the LatticeFold
+ * prover path `NIFSProver::prove` and of `NIFSVerifier::verify` (crates/latticefold/src).
+ * Structure deliberately follows the reference (materialised f-hat tables, generic sumcheck
+ * with a comb callback, successive fix_variables for MLE evaluation) -- it is the checker,
+ * not the product.  OpenMP is used only so that bench.py's cpu_baseline leg can quote the
+ * reference's Rayon-style data parallelism on the host cores.
+ *
+ * Flat layouts (ring elements of 24 u64):
+ *   LCCCS : r[s] | v[tau] | cm[kappa] | u[t] | x_w[l] | h
+ *   CCCS  : cm[kappa] | x_ccs[l]
+ *   proof : LIN  msgs[s][d+2] | v[tau] | u[t]
+ *           DECL u_s[K][t] | v_s[K][tau] | x_s[K][l+1] | y_s[K][kappa]
+ *           DECR (same)
+ *           FOLD msgs[s][2b+1] | theta[2K][tau] | eta[2K][t]
+ */
+#include "lfo_field.h"
+#include <stdio.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TAU LFO_TAU
+#define RE 24 /* words per ring element */
+
+int lfo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static u64 *ralloc(size_t n_elems) {
+    u64 *p = (u64 *)calloc(n_elems ? n_elems : 1, RE * sizeof(u64));
+    if (!p) { fprintf(stderr, "lfo: out of memory (%zu ring elements)\n", n_elems); abort(); }
+    return p;
+}
+
+size_t lfo_lcccs_len(const lfo_params *p) { return (size_t)p->s + TAU + p->kappa + p->t + p->l + 1; }
+size_t lfo_cccs_len(const lfo_params *p) { return (size_t)p->kappa + p->l; }
+static size_t lin_proof_len(const lfo_params *p) { return (size_t)p->s * (p->d + 2) + TAU + p->t; }
+static size_t dec_proof_len(const lfo_params *p) { return (size_t)p->K * (p->t + TAU + p->l + 1 + p->kappa); }
+static size_t fold_proof_len(const lfo_params *p) { return (size_t)p->s * (2 * p->b + 1) + 2 * (size_t)p->K * (TAU + p->t); }
+size_t lfo_proof_len(const lfo_params *p) { return lin_proof_len(p) + 2 * dec_proof_len(p) + fold_proof_len(p); }
+
+/* ---------------------------------------------------------------------------------------- */
+/* Ajtai: commitment_scheme.rs:37-54 -> Matrix::checked_mul_vec (slot-wise products)        */
+int lfo_ajtai_commit(const u64 *A, u32 kappa, size_t n, const u64 *f, u64 *out) {
+    for (u32 i = 0; i < kappa; i++) {
+        u64 acc[RE] = {0};
+        const u64 *row = A + (size_t)i * n * RE;
+#ifdef _OPENMP
+#pragma omp parallel
+        {
+            u64 loc[RE] = {0}, t[RE];
+#pragma omp for schedule(static) nowait
+            for (size_t j = 0; j < n; j++) {
+                rq_mul(t, row + j * RE, f + j * RE);
+                rq_add(loc, loc, t);
+            }
+#pragma omp critical
+            rq_add(acc, acc, loc);
+        }
+#else
+        u64 t[RE];
+        for (size_t j = 0; j < n; j++) {
+            rq_mul(t, row + j * RE, f + j * RE);
+            rq_add(acc, acc, t);
+        }
+#endif
+        rq_copy(out + (size_t)i * RE, acc);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* MLE helpers.  Points are ring elements exactly as in the reference (`&[R]`).             */
+
+/* build_eq_x_r_helper, utils/sumcheck/utils.rs:134-170 (recursion unrolled from the tail) */
+void lfo_build_eq(const u64 *r, u32 nv, u64 *out) {
+    u64 one[RE];
+    rq_from_u64(one, 1);
+    /* innermost: r[nv-1] */
+    rq_sub(out, one, r + (size_t)(nv - 1) * RE);
+    rq_copy(out + RE, r + (size_t)(nv - 1) * RE);
+    size_t len = 2;
+    u64 *buf = ralloc((size_t)1 << nv);
+    for (int i = (int)nv - 2; i >= 0; i--) {
+        memcpy(buf, out, len * RE * sizeof(u64));
+        const u64 *ri = r + (size_t)i * RE;
+#pragma omp parallel for schedule(static)
+        for (size_t j = 0; j < len; j++) {
+            u64 tmp[RE];
+            rq_mul(tmp, ri, buf + j * RE);
+            rq_sub(out + (2 * j) * RE, buf + j * RE, tmp);
+            rq_copy(out + (2 * j + 1) * RE, tmp);
+        }
+        len <<= 1;
+    }
+    free(buf);
+}
+
+/* DenseMultilinearExtension::fix_variables(&[r]) (stark-rings-poly; semantics per
+ * sumcheck/prover.rs:70-72,112-123): new[j] = old[2j] + r*(old[2j+1]-old[2j]).  Replaces *pt. */
+static void mle_fix(u64 **pt, size_t len, const u64 *r) {
+    size_t half = len / 2;
+    const u64 *src = *pt;
+    u64 *dst = ralloc(half);
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < half; j++) {
+        u64 d[RE];
+        rq_sub(d, src + (2 * j + 1) * RE, src + (2 * j) * RE);
+        rq_mul(d, d, r);
+        rq_add(dst + j * RE, src + (2 * j) * RE, d);
+    }
+    free(*pt);
+    *pt = dst;
+}
+
+/* evaluate(): nv successive fixes of a zero-padded copy (mle_helpers.rs:21-62) */
+void lfo_mle_eval(const u64 *table, size_t len, const u64 *r, u32 nv, u64 *out) {
+    size_t full = (size_t)1 << nv;
+    u64 *t = ralloc(full);
+    memcpy(t, table, (len < full ? len : full) * RE * sizeof(u64));
+    size_t cur = full;
+    for (u32 i = 0; i < nv; i++) {
+        mle_fix(&t, cur, r + (size_t)i * RE);
+        cur >>= 1;
+    }
+    rq_copy(out, t);
+    free(t);
+}
+
+/* eq_eval, utils/sumcheck/utils.rs:78-92 */
+static void eq_eval(const u64 *x, const u64 *y, u32 n, u64 *out) {
+    u64 one[RE], res[RE], t[RE], u[RE];
+    rq_from_u64(one, 1);
+    rq_copy(res, one);
+    for (u32 i = 0; i < n; i++) {
+        rq_mul(t, x + (size_t)i * RE, y + (size_t)i * RE);
+        rq_add(u, t, t);
+        rq_sub(u, u, x + (size_t)i * RE);
+        rq_sub(u, u, y + (size_t)i * RE);
+        rq_add(u, u, one);
+        rq_mul(res, res, u);
+    }
+    rq_copy(out, res);
+}
+
+/* mat_vec_mul, arith/utils.rs:52-65; output zero-padded to m rows */
+static void spmv(const lfo_params *p, const lfo_ccs *ccs, u32 j, const u64 *z, u64 *out) {
+    size_t m = (size_t)1 << p->s;
+    const u32 *rp = ccs->rowptr[j];
+    const u32 *ci = ccs->col[j];
+    const u64 *va = ccs->val[j];
+#pragma omp parallel for schedule(static)
+    for (size_t row = 0; row < m; row++) {
+        u64 acc[RE] = {0}, t[RE];
+        for (u32 k = rp[row]; k < rp[row + 1]; k++) {
+            rq_mul(t, va + (size_t)k * RE, z + (size_t)ci[k] * RE);
+            rq_add(acc, acc, t);
+        }
+        rq_copy(out + row * RE, acc);
+    }
+}
+
+/* Witness::get_fhat, arith.rs:273-297: table d, entry i, slot k = (coeff[8d+k],0,0); zero-padded to m */
+static void build_fhat(const u64 *f_coeff, size_t N, size_t m, u64 **tables /*TAU*/) {
+    for (int d = 0; d < TAU; d++) {
+        tables[d] = ralloc(m);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < N; i++)
+            for (int k = 0; k < 8; k++) tables[d][i * RE + 3 * k] = f_coeff[i * RE + 8 * d + k];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* transcript helpers */
+static u64 label_to_fq(const char *s) { /* from_be_bytes_mod_order */
+    u128 v = 0;
+    for (; *s; s++) v = ((v << 8) | (unsigned char)*s) % LFO_P;
+    return (u64)v;
+}
+static void absorb_label(lfo_transcript *tr, const char *s) { /* absorb_field_element(from_base_prime_field(label)) */
+    u64 e[RE];
+    rq_from_u64(e, label_to_fq(s));
+    lfo_transcript_absorb_ring(tr, e, 1);
+}
+static void get_challenges_ring(lfo_transcript *tr, u32 n, u64 *out) { /* get_challenges(n).map(R::from) */
+    for (u32 i = 0; i < n; i++) {
+        u64 c[3];
+        lfo_transcript_get_challenge(tr, c);
+        fq3 v = {{c[0], c[1], c[2]}};
+        rq_from_fq3(out + (size_t)i * RE, v);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* sumcheck prover: utils/sumcheck.rs:53-80 + utils/sumcheck/prover.rs:56-162              */
+typedef void (*comb_fn)(const u64 *vals, u64 *out, const void *ctx);
+
+static void sumcheck_prove(lfo_transcript *tr, u64 **tables, u32 P, u32 nv, u32 degree, comb_fn comb,
+                           const void *ctx, u64 *msgs /* nv*(degree+1) */, u64 *point /* nv ring elems */) {
+    u64 e[RE];
+    rq_from_u64(e, nv);
+    lfo_transcript_absorb_ring(tr, e, 1);
+    rq_from_u64(e, degree);
+    lfo_transcript_absorb_ring(tr, e, 1);
+    size_t len = (size_t)1 << nv;
+    for (u32 round = 1; round <= nv; round++) {
+        if (round > 1) {
+            for (u32 k = 0; k < P; k++) mle_fix(&tables[k], len, point + (size_t)(round - 2) * RE);
+            len >>= 1;
+        }
+        size_t pairs = len / 2;
+        u64 *evals = msgs + (size_t)(round - 1) * (degree + 1) * RE;
+        memset(evals, 0, (size_t)(degree + 1) * RE * sizeof(u64));
+#pragma omp parallel
+        {
+            u64 *vals0 = (u64 *)malloc((size_t)P * RE * sizeof(u64));
+            u64 *vals1 = (u64 *)malloc((size_t)P * RE * sizeof(u64));
+            u64 *steps = (u64 *)malloc((size_t)P * RE * sizeof(u64));
+            u64 *loc = (u64 *)calloc((size_t)(degree + 1) * RE, sizeof(u64));
+            u64 lev[RE];
+#pragma omp for schedule(static) nowait
+            for (size_t b = 0; b < pairs; b++) {
+                for (u32 k = 0; k < P; k++) {
+                    rq_copy(vals0 + (size_t)k * RE, tables[k] + (2 * b) * RE);
+                    rq_copy(vals1 + (size_t)k * RE, tables[k] + (2 * b + 1) * RE);
+                }
+                comb(vals0, lev, ctx);
+                rq_add(loc, loc, lev);
+                comb(vals1, lev, ctx);
+                rq_add(loc + RE, loc + RE, lev);
+                for (u32 k = 0; k < P; k++) rq_sub(steps + (size_t)k * RE, vals1 + (size_t)k * RE, vals0 + (size_t)k * RE);
+                /* vals := vals1, then vals += steps per extra point */
+                for (u32 pt = 2; pt <= degree; pt++) {
+                    for (u32 k = 0; k < P; k++) rq_add(vals1 + (size_t)k * RE, vals1 + (size_t)k * RE, steps + (size_t)k * RE);
+                    comb(vals1, lev, ctx);
+                    rq_add(loc + (size_t)pt * RE, loc + (size_t)pt * RE, lev);
+                }
+            }
+#pragma omp critical
+            for (u32 pt = 0; pt <= degree; pt++) rq_add(evals + (size_t)pt * RE, evals + (size_t)pt * RE, loc + (size_t)pt * RE);
+            free(vals0); free(vals1); free(steps); free(loc);
+        }
+        lfo_transcript_absorb_ring(tr, evals, degree + 1);
+        get_challenges_ring(tr, 1, point + (size_t)(round - 1) * RE); /* sample_round */
+        lfo_transcript_absorb_ring(tr, point + (size_t)(round - 1) * RE, 1); /* absorb(r.into()) */
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* linearization comb: nifs/linearization/utils.rs:90-107 */
+typedef struct { const lfo_params *p; const lfo_ccs *ccs; } lin_ctx;
+static void comb_lin(const u64 *vals, u64 *out, const void *vctx) {
+    const lin_ctx *c = (const lin_ctx *)vctx;
+    u64 res[RE] = {0}, term[RE];
+    for (u32 i = 0; i < c->p->q; i++) {
+        const u64 *ci = c->ccs->c + (size_t)i * RE;
+        if (rq_is_zero(ci)) continue;
+        rq_copy(term, ci);
+        for (u32 k = c->ccs->S_off[i]; k < c->ccs->S_off[i + 1]; k++) rq_mul(term, term, vals + (size_t)c->ccs->S_idx[k] * RE);
+        rq_add(res, res, term);
+    }
+    rq_mul(out, res, vals + (size_t)c->p->t * RE); /* eq is the last table */
+}
+
+/* check S concatenated == 0..t-1 (the reference indexes vals[j] by matrix index) */
+static int ccs_shape_ok(const lfo_params *p, const lfo_ccs *ccs) {
+    u32 next = 0;
+    for (u32 i = 0; i < p->q; i++) {
+        if (rq_is_zero(ccs->c + (size_t)i * RE)) return 0;
+        for (u32 k = ccs->S_off[i]; k < ccs->S_off[i + 1]; k++)
+            if (ccs->S_idx[k] != next++) return 0;
+    }
+    return next == p->t;
+}
+
+static void f_to_w_ccs(const lfo_params *p, const u64 *f_coeff, u64 *f_ntt /*N, may be NULL*/, u64 *w_ccs /*wit_len*/) {
+    size_t N = (size_t)p->wit_len * p->L;
+    u64 *f = f_ntt ? f_ntt : ralloc(N);
+    lfo_crt(f_coeff, f, N);
+    lfo_recompose(f, p->wit_len, p->B, p->L, w_ccs); /* gadget_recompose, arith.rs:330 */
+    if (!f_ntt) free(f);
+}
+
+void lfo_witness_from_w_ccs(const lfo_params *p, const u64 *w_ccs, u64 *f_coeff) {
+    u64 *wc = ralloc(p->wit_len);
+    lfo_icrt(w_ccs, wc, p->wit_len);
+    lfo_decompose(wc, p->wit_len, p->B, p->L, 0, f_coeff);
+    free(wc);
+}
+
+int lfo_linearize(const lfo_params *p, const lfo_ccs *ccs, lfo_transcript *tr, const u64 *cccs,
+                  const u64 *f_coeff, u64 *lcccs_out, u64 *proof) {
+    if (!ccs_shape_ok(p, ccs)) return -2;
+    size_t m = (size_t)1 << p->s, N = (size_t)p->wit_len * p->L;
+    if (N > m) return -3;
+    u32 n = p->l + 1 + p->wit_len;
+    /* z = x_ccs || 1 || w_ccs  (arith.rs:399-409) */
+    u64 *z = ralloc(n);
+    memcpy(z, cccs + (size_t)p->kappa * RE, (size_t)p->l * RE * sizeof(u64));
+    rq_from_u64(z + (size_t)p->l * RE, 1);
+    f_to_w_ccs(p, f_coeff, NULL, z + (size_t)(p->l + 1) * RE);
+
+    absorb_label(tr, "beta_s");
+    u64 *beta = ralloc(p->s);
+    get_challenges_ring(tr, p->s, beta);
+
+    u32 P = p->t + 1;
+    u64 **mz = (u64 **)malloc(sizeof(u64 *) * p->t);
+    u64 **tabs = (u64 **)malloc(sizeof(u64 *) * P);
+    for (u32 j = 0; j < p->t; j++) {
+        mz[j] = ralloc(m);
+        spmv(p, ccs, j, z, mz[j]);
+        tabs[j] = ralloc(m);
+        memcpy(tabs[j], mz[j], m * RE * sizeof(u64));
+    }
+    tabs[p->t] = ralloc(m);
+    lfo_build_eq(beta, p->s, tabs[p->t]);
+
+    lin_ctx ctx = {p, ccs};
+    u64 *msgs = proof;
+    u64 *point = lcccs_out; /* r */
+    sumcheck_prove(tr, tabs, P, p->s, p->d + 1, comb_lin, &ctx, msgs, point);
+
+    u64 *v = proof + (size_t)p->s * (p->d + 2) * RE;
+    u64 *u = v + TAU * RE;
+    u64 *fh[TAU];
+    build_fhat(f_coeff, N, m, fh);
+    for (int d = 0; d < TAU; d++) lfo_mle_eval(fh[d], m, point, p->s, v + (size_t)d * RE);
+    for (u32 j = 0; j < p->t; j++) lfo_mle_eval(mz[j], m, point, p->s, u + (size_t)j * RE);
+    lfo_transcript_absorb_ring(tr, v, TAU);
+    lfo_transcript_absorb_ring(tr, u, p->t);
+
+    u64 *o = lcccs_out + (size_t)p->s * RE;
+    memcpy(o, v, TAU * RE * sizeof(u64)); o += TAU * RE;
+    memcpy(o, cccs, (size_t)p->kappa * RE * sizeof(u64)); o += (size_t)p->kappa * RE;
+    memcpy(o, u, (size_t)p->t * RE * sizeof(u64)); o += (size_t)p->t * RE;
+    memcpy(o, cccs + (size_t)p->kappa * RE, (size_t)p->l * RE * sizeof(u64)); o += (size_t)p->l * RE;
+    rq_from_u64(o, 1);
+
+    for (int d = 0; d < TAU; d++) free(fh[d]);
+    for (u32 j = 0; j < p->t; j++) { free(mz[j]); free(tabs[j]); }
+    free(tabs[p->t]); free(tabs); free(mz); free(beta); free(z);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* decomposition: nifs/decomposition.rs:33-88                                               */
+typedef struct {
+    u64 *f_ntt;        /* K x N */
+    u64 *fhat[64][TAU]; /* K x TAU tables of m */
+    u64 **mz;          /* K*t tables of m */
+    u64 *lcccs;        /* K flat LCCCS */
+} dec_out;
+
+/* decompose_big_vec_into_k_vec_and_compose_back, nifs/decomposition/utils.rs:12-42 */
+static void compute_x_s(const lfo_params *p, const u64 *x /* l+1 NTT */, u64 *x_s /* K*(l+1) */) {
+    u32 cnt = p->l + 1;
+    u64 *co = ralloc(cnt), *dB = ralloc((size_t)cnt * p->L), *dk = ralloc((size_t)cnt * p->L * p->K), *rc = ralloc(cnt);
+    lfo_icrt(x, co, cnt);
+    lfo_decompose(co, cnt, p->B, p->L, 0, dB);                       /* gadget_decompose */
+    lfo_decompose(dB, (size_t)cnt * p->L, p->b, p->K, 1, dk);         /* decompose_to_vec.transpose */
+    for (u32 k = 0; k < p->K; k++) {
+        lfo_recompose(dk + (size_t)k * cnt * p->L * RE, cnt, p->B, p->L, rc); /* chunks(L).recompose(B) */
+        lfo_crt(rc, x_s + (size_t)k * cnt * RE, cnt);
+    }
+    free(co); free(dB); free(dk); free(rc);
+}
+
+static int decompose_prove(const lfo_params *p, const lfo_ccs *ccs, const u64 *A, lfo_transcript *tr,
+                           const u64 *lcccs, const u64 *f_coeff, dec_out *o, u64 *proof) {
+    size_t m = (size_t)1 << p->s, N = (size_t)p->wit_len * p->L;
+    u32 K = p->K, n = p->l + 1 + p->wit_len;
+    const u64 *r = lcccs;
+    const u64 *cm = lcccs + ((size_t)p->s + TAU) * RE;
+    const u64 *xw_h = lcccs + ((size_t)p->s + TAU + p->kappa + p->t) * RE; /* x_w || h */
+
+    u64 *u_s = proof;
+    u64 *v_s = u_s + (size_t)K * p->t * RE;
+    u64 *x_s = v_s + (size_t)K * TAU * RE;
+    u64 *y_s = x_s + (size_t)K * (p->l + 1) * RE;
+
+    /* decompose_witness: decomposition.rs:162-167 */
+    u64 *f_s = ralloc((size_t)K * N);
+    lfo_decompose(f_coeff, N, p->b, K, 1, f_s);
+    o->f_ntt = ralloc((size_t)K * N);
+    u64 *w_s = ralloc((size_t)K * p->wit_len);
+    for (u32 k = 0; k < K; k++) {
+        f_to_w_ccs(p, f_s + (size_t)k * N * RE, o->f_ntt + (size_t)k * N * RE, w_s + (size_t)k * p->wit_len * RE);
+        build_fhat(f_s + (size_t)k * N * RE, N, m, o->fhat[k]);
+    }
+    compute_x_s(p, xw_h, x_s);
+
+    /* commit_witnesses: decomposition.rs:178-201 */
+    for (u32 k = 1; k < K; k++) lfo_ajtai_commit(A, p->kappa, N, o->f_ntt + (size_t)k * N * RE, y_s + (size_t)k * p->kappa * RE);
+    {
+        u64 bb[RE];
+        rq_from_u64(bb, p->b);
+        u64 *acc = ralloc(p->kappa);
+        for (int k = (int)K - 1; k >= 1; k--)
+            for (u32 i = 0; i < p->kappa; i++) {
+                rq_add(acc + (size_t)i * RE, acc + (size_t)i * RE, y_s + ((size_t)k * p->kappa + i) * RE);
+                rq_mul(acc + (size_t)i * RE, acc + (size_t)i * RE, bb);
+            }
+        for (u32 i = 0; i < p->kappa; i++) rq_sub(y_s + (size_t)i * RE, cm + (size_t)i * RE, acc + (size_t)i * RE);
+        free(acc);
+    }
+    /* compute_v_s */
+    for (u32 k = 0; k < K; k++)
+        for (int d = 0; d < TAU; d++) lfo_mle_eval(o->fhat[k][d], m, r, p->s, v_s + ((size_t)k * TAU + d) * RE);
+    /* compute_mz_mles + compute_u_s */
+    o->mz = (u64 **)malloc(sizeof(u64 *) * K * p->t);
+    u64 *z = ralloc(n);
+    for (u32 k = 0; k < K; k++) {
+        memcpy(z, x_s + (size_t)k * (p->l + 1) * RE, (size_t)(p->l + 1) * RE * sizeof(u64));
+        memcpy(z + (size_t)(p->l + 1) * RE, w_s + (size_t)k * p->wit_len * RE, (size_t)p->wit_len * RE * sizeof(u64));
+        for (u32 j = 0; j < p->t; j++) {
+            u64 *tb = ralloc(m);
+            spmv(p, ccs, j, z, tb);
+            o->mz[k * p->t + j] = tb;
+            lfo_mle_eval(tb, m, r, p->s, u_s + ((size_t)k * p->t + j) * RE);
+        }
+    }
+    free(z);
+    /* absorb + build the K LCCCS */
+    size_t ll = lfo_lcccs_len(p);
+    o->lcccs = ralloc((size_t)K * ll);
+    for (u32 k = 0; k < K; k++) {
+        const u64 *xk = x_s + (size_t)k * (p->l + 1) * RE, *yk = y_s + (size_t)k * p->kappa * RE;
+        const u64 *uk = u_s + (size_t)k * p->t * RE, *vk = v_s + (size_t)k * TAU * RE;
+        lfo_transcript_absorb_ring(tr, xk, p->l + 1);
+        lfo_transcript_absorb_ring(tr, yk, p->kappa);
+        lfo_transcript_absorb_ring(tr, uk, p->t);
+        lfo_transcript_absorb_ring(tr, vk, TAU);
+        u64 *o2 = o->lcccs + (size_t)k * ll * RE;
+        memcpy(o2, r, (size_t)p->s * RE * sizeof(u64)); o2 += (size_t)p->s * RE;
+        memcpy(o2, vk, TAU * RE * sizeof(u64)); o2 += TAU * RE;
+        memcpy(o2, yk, (size_t)p->kappa * RE * sizeof(u64)); o2 += (size_t)p->kappa * RE;
+        memcpy(o2, uk, (size_t)p->t * RE * sizeof(u64)); o2 += (size_t)p->t * RE;
+        memcpy(o2, xk, (size_t)(p->l + 1) * RE * sizeof(u64)); /* x_w || h */
+    }
+    free(f_s); free(w_s);
+    return 0;
+}
+
+static void dec_free(const lfo_params *p, dec_out *o) {
+    free(o->f_ntt);
+    for (u32 k = 0; k < p->K; k++)
+        for (int d = 0; d < TAU; d++) free(o->fhat[k][d]);
+    for (u32 i = 0; i < p->K * p->t; i++) free(o->mz[i]);
+    free(o->mz);
+    free(o->lcccs);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* folding comb: nifs/folding/utils.rs:273-325 (zero short-cuts dropped: value-preserving)  */
+typedef struct { const lfo_params *p; const u64 *mu; } fold_ctx;
+static void comb_fold(const u64 *vals, u64 *out, const void *vctx) {
+    const fold_ctx *c = (const fold_ctx *)vctx;
+    const lfo_params *p = c->p;
+    u64 res[RE], t[RE], inter[RE], ev[RE], sq[RE], mult[RE], bb[RE];
+    rq_mul(res, vals, vals + RE);
+    rq_mul(t, vals + 2 * RE, vals + 3 * RE);
+    rq_add(res, res, t);
+    for (u32 k = 0; k < 2 * p->K; k++) {
+        const u64 *mu = c->mu + (size_t)k * RE;
+        rq_zero(inter);
+        for (int d = TAU - 1; d >= 0; d--) {
+            const u64 *f = vals + (size_t)(5 + k * TAU + d) * RE;
+            rq_copy(ev, vals + 4 * RE);
+            rq_mul(sq, f, f);
+            for (u32 b = 1; b < p->b; b++) {
+                rq_from_u64(bb, (u64)b * b);
+                rq_sub(mult, sq, bb);
+                rq_mul(ev, ev, mult);
+            }
+            rq_mul(ev, ev, f);
+            rq_add(inter, inter, ev);
+            rq_mul(inter, inter, mu);
+        }
+        rq_add(res, res, inter);
+    }
+    rq_copy(out, res);
+}
+
+/* Horner-combine tables: for T in rev: acc += T; acc *= ch  (folding.rs:208-226, utils.rs:524-546) */
+static void horner_add(u64 *dst, u64 *const *tabs, u32 cnt, const u64 *ch, size_t m) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < m; i++) {
+        u64 acc[RE] = {0};
+        for (int j = (int)cnt - 1; j >= 0; j--) {
+            rq_add(acc, acc, tabs[j] + i * RE);
+            rq_mul(acc, acc, ch);
+        }
+        rq_add(dst + i * RE, dst + i * RE, acc);
+    }
+}
+
+int lfo_fold_step(const lfo_params *p, const lfo_ccs *ccs, const u64 *A, lfo_transcript *tr,
+                  const u64 *acc, const u64 *w_acc_f_coeff, const u64 *cm_i, const u64 *w_i_f_coeff,
+                  u64 *lcccs_out, u64 *f0_out, u64 *proof) {
+    if (!ccs_shape_ok(p, ccs)) return -2;
+    if (p->K > 32) return -4;
+    size_t m = (size_t)1 << p->s, N = (size_t)p->wit_len * p->L;
+    if (N > m) return -3; /* sanity_check, nifs.rs:165-173 */
+    u32 K = p->K, K2 = 2 * p->K;
+    size_t ll = lfo_lcccs_len(p);
+
+    /* absorb_public_input, nifs.rs:175-197 */
+    absorb_label(tr, "acc");
+    lfo_transcript_absorb_ring(tr, acc, ll); /* r, v, cm, u, x_w, h in order */
+    absorb_label(tr, "cm_i");
+    lfo_transcript_absorb_ring(tr, cm_i, lfo_cccs_len(p));
+
+    u64 *lin_proof = proof;
+    u64 *decl_proof = lin_proof + lin_proof_len(p) * RE;
+    u64 *decr_proof = decl_proof + dec_proof_len(p) * RE;
+    u64 *fold_proof = decr_proof + dec_proof_len(p) * RE;
+
+    u64 *lin_lcccs = ralloc(ll);
+    int rc = lfo_linearize(p, ccs, tr, cm_i, w_i_f_coeff, lin_lcccs, lin_proof);
+    if (rc) return rc;
+    dec_out dl, dr;
+    decompose_prove(p, ccs, A, tr, acc, w_acc_f_coeff, &dl, decl_proof);
+    decompose_prove(p, ccs, A, tr, lin_lcccs, w_i_f_coeff, &dr, decr_proof);
+
+    /* ---- folding, nifs/folding.rs:42-130 ---- */
+    u64 *alpha = ralloc(K2), *zeta = ralloc(K2), *mu = ralloc(K2), *beta = ralloc(p->s);
+    absorb_label(tr, "alpha_s"); get_challenges_ring(tr, K2, alpha);
+    absorb_label(tr, "zeta_s");  get_challenges_ring(tr, K2, zeta);
+    absorb_label(tr, "mu_s");    get_challenges_ring(tr, K2 - 1, mu);
+    rq_from_u64(mu + (size_t)(K2 - 1) * RE, 1);
+    absorb_label(tr, "beta_s");  get_challenges_ring(tr, p->s, beta);
+
+    u32 P = 5 + K2 * TAU;
+    u64 **tabs = (u64 **)malloc(sizeof(u64 *) * P);
+    for (u32 i = 0; i < P; i++) tabs[i] = ralloc(m);
+    for (int side = 0; side < 2; side++) {
+        dec_out *d = side ? &dr : &dl;
+        lfo_build_eq(d->lcccs /* r of the first decomposed LCCCS */, p->s, tabs[2 * side]);
+        u64 *g = tabs[2 * side + 1];
+        for (u32 k = 0; k < K; k++) horner_add(g, d->fhat[k], TAU, alpha + (size_t)(side * K + k) * RE, m);
+        for (u32 k = 0; k < K; k++) horner_add(g, d->mz + (size_t)k * p->t, p->t, zeta + (size_t)(side * K + k) * RE, m);
+        for (u32 k = 0; k < K; k++)
+            for (int dd = 0; dd < TAU; dd++) memcpy(tabs[5 + (side * K + k) * TAU + dd], d->fhat[k][dd], m * RE * sizeof(u64));
+    }
+    lfo_build_eq(beta, p->s, tabs[4]);
+
+    fold_ctx fctx = {p, mu};
+    u64 *msgs = fold_proof;
+    u64 *r0 = lcccs_out;
+    sumcheck_prove(tr, tabs, P, p->s, 2 * p->b, comb_fold, &fctx, msgs, r0);
+    for (u32 i = 0; i < P; i++) free(tabs[i]);
+    free(tabs);
+
+    u64 *theta = fold_proof + (size_t)p->s * (2 * p->b + 1) * RE;
+    u64 *eta = theta + (size_t)K2 * TAU * RE;
+    for (u32 i = 0; i < K2; i++) {
+        dec_out *d = i < K ? &dl : &dr;
+        u32 k = i % K;
+        for (int dd = 0; dd < TAU; dd++) lfo_mle_eval(d->fhat[k][dd], m, r0, p->s, theta + ((size_t)i * TAU + dd) * RE);
+        for (u32 j = 0; j < p->t; j++) lfo_mle_eval(d->mz[k * p->t + j], m, r0, p->s, eta + ((size_t)i * p->t + j) * RE);
+    }
+    lfo_transcript_absorb_ring(tr, theta, (size_t)K2 * TAU);
+    lfo_transcript_absorb_ring(tr, eta, (size_t)K2 * p->t);
+
+    /* get_rhos, folding/utils.rs:116-131 */
+    absorb_label(tr, "rho_s");
+    u64 *rho_c = ralloc(K2), *rho = ralloc(K2);
+    for (u32 i = 0; i + 1 < K2; i++) lfo_transcript_get_short_challenge(tr, rho_c + (size_t)i * RE);
+    rho_c[(size_t)(K2 - 1) * RE] = 1; /* CoefficientRepresentation::ONE */
+    lfo_crt(rho_c, rho, K2);
+
+    /* compute_f_0, folding.rs:258-268 */
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < N; j++) {
+        u64 a[RE] = {0}, t[RE];
+        for (u32 i = 0; i < K2; i++) {
+            const u64 *fi = (i < K ? dl.f_ntt : dr.f_ntt) + ((size_t)(i % K) * N + j) * RE;
+            rq_mul(t, rho + (size_t)i * RE, fi);
+            rq_add(a, a, t);
+        }
+        rq_copy(f0_out + j * RE, a);
+    }
+
+    /* compute_v0_u0_x0_cm_0, folding/utils.rs:460-521 */
+    u64 *o = lcccs_out + (size_t)p->s * RE;
+    lfo_rot_lin_combination(rho_c, theta, K2, TAU, o); /* v_0 */
+    o += TAU * RE;
+    u64 t[RE];
+    for (u32 c = 0; c < p->kappa; c++) { /* cm_0 */
+        u64 a[RE] = {0};
+        for (u32 i = 0; i < K2; i++) {
+            const u64 *li = (i < K ? dl.lcccs : dr.lcccs) + (size_t)(i % K) * ll * RE;
+            rq_mul(t, li + ((size_t)p->s + TAU + c) * RE, rho + (size_t)i * RE);
+            rq_add(a, a, t);
+        }
+        rq_copy(o + (size_t)c * RE, a);
+    }
+    o += (size_t)p->kappa * RE;
+    for (u32 j = 0; j < p->t; j++) { /* u_0 */
+        u64 a[RE] = {0};
+        for (u32 i = 0; i < K2; i++) {
+            rq_mul(t, rho + (size_t)i * RE, eta + ((size_t)i * p->t + j) * RE);
+            rq_add(a, a, t);
+        }
+        rq_copy(o + (size_t)j * RE, a);
+    }
+    o += (size_t)p->t * RE;
+    for (u32 c = 0; c < p->l + 1; c++) { /* x_0 = x_w || h */
+        u64 a[RE] = {0};
+        for (u32 i = 0; i < K2; i++) {
+            const u64 *li = (i < K ? dl.lcccs : dr.lcccs) + (size_t)(i % K) * ll * RE;
+            rq_mul(t, rho + (size_t)i * RE, li + ((size_t)p->s + TAU + p->kappa + p->t + c) * RE);
+            rq_add(a, a, t);
+        }
+        rq_copy(o + (size_t)c * RE, a);
+    }
+
+    dec_free(p, &dl); dec_free(p, &dr);
+    free(alpha); free(zeta); free(mu); free(beta); free(rho_c); free(rho); free(lin_lcccs);
+    return 0;
+}
+
+/* ======================================================================================== */
+/* verifier: nifs.rs:117-163                                                                 */
+
+static fq3 fq3_inv(fq3 a) {
+    u64 nr = lfo_NONRES;
+    u64 t0 = fq_sub(fq_mul(a.c[0], a.c[0]), fq_mul(nr, fq_mul(a.c[1], a.c[2])));
+    u64 t1 = fq_sub(fq_mul(nr, fq_mul(a.c[2], a.c[2])), fq_mul(a.c[0], a.c[1]));
+    u64 t2 = fq_sub(fq_mul(a.c[1], a.c[1]), fq_mul(a.c[0], a.c[2]));
+    u64 norm = fq_add(fq_mul(a.c[0], t0), fq_mul(nr, fq_add(fq_mul(a.c[2], t1), fq_mul(a.c[1], t2))));
+    u64 ni = fq_inv(norm);
+    fq3 r = {{fq_mul(t0, ni), fq_mul(t1, ni), fq_mul(t2, ni)}};
+    return r;
+}
+
+/* interpolate_uni_poly (utils/sumcheck/verifier.rs:141-257): Lagrange through x=0..len-1 */
+static void interpolate(const u64 *p_i, u32 len, fq3 at, u64 *out) {
+    u64 res[RE] = {0}, t[RE];
+    for (u32 i = 0; i < len; i++) {
+        fq3 num = fq3_one(), den = fq3_one();
+        for (u32 j = 0; j < len; j++) {
+            if (j == i) continue;
+            num = fq3_mul(num, fq3_sub(at, fq3_from_fq(j)));
+            den = fq3_mul(den, fq3_sub(fq3_from_fq(i), fq3_from_fq(j)));
+        }
+        fq3 w = fq3_mul(num, fq3_inv(den));
+        rq_mul_fq3(t, p_i + (size_t)i * RE, w);
+        rq_add(res, res, t);
+    }
+    rq_copy(out, res);
+}
+
+/* verify_as_subprotocol + check_and_generate_subclaim */
+static int sumcheck_verify(lfo_transcript *tr, u32 nv, u32 degree, const u64 *claimed, const u64 *msgs,
+                           u64 *point, u64 *expected_out) {
+    u64 e[RE], expected[RE], s[RE];
+    rq_from_u64(e, nv); lfo_transcript_absorb_ring(tr, e, 1);
+    rq_from_u64(e, degree); lfo_transcript_absorb_ring(tr, e, 1);
+    for (u32 i = 0; i < nv; i++) {
+        lfo_transcript_absorb_ring(tr, msgs + (size_t)i * (degree + 1) * RE, degree + 1);
+        get_challenges_ring(tr, 1, point + (size_t)i * RE);
+        lfo_transcript_absorb_ring(tr, point + (size_t)i * RE, 1);
+    }
+    rq_copy(expected, claimed);
+    for (u32 i = 0; i < nv; i++) {
+        const u64 *ev = msgs + (size_t)i * (degree + 1) * RE;
+        rq_add(s, ev, ev + RE);
+        if (!rq_eq(s, expected)) return -1;
+        interpolate(ev, degree + 1, rq_slot(point + (size_t)i * RE, 0), expected);
+    }
+    rq_copy(expected_out, expected);
+    return 0;
+}
+
+static int verify_linearization(const lfo_params *p, const lfo_ccs *ccs, lfo_transcript *tr, const u64 *cccs,
+                                const u64 *proof, u64 *lcccs_out) {
+    absorb_label(tr, "beta_s");
+    u64 *beta = ralloc(p->s);
+    get_challenges_ring(tr, p->s, beta);
+    u64 zero[RE] = {0}, s[RE], e[RE], sum[RE] = {0}, term[RE];
+    u64 *point = lcccs_out;
+    if (sumcheck_verify(tr, p->s, p->d + 1, zero, proof, point, s)) { free(beta); return -10; }
+    const u64 *v = proof + (size_t)p->s * (p->d + 2) * RE, *u = v + TAU * RE;
+    eq_eval(point, beta, p->s, e);
+    for (u32 i = 0; i < p->q; i++) {
+        rq_copy(term, ccs->c + (size_t)i * RE);
+        for (u32 k = ccs->S_off[i]; k < ccs->S_off[i + 1]; k++) rq_mul(term, term, u + (size_t)ccs->S_idx[k] * RE);
+        rq_add(sum, sum, term);
+    }
+    rq_mul(sum, sum, e);
+    free(beta);
+    if (!rq_eq(sum, s)) return -11;
+    lfo_transcript_absorb_ring(tr, v, TAU);
+    lfo_transcript_absorb_ring(tr, u, p->t);
+    u64 *o = lcccs_out + (size_t)p->s * RE;
+    memcpy(o, v, TAU * RE * sizeof(u64)); o += TAU * RE;
+    memcpy(o, cccs, (size_t)p->kappa * RE * sizeof(u64)); o += (size_t)p->kappa * RE;
+    memcpy(o, u, (size_t)p->t * RE * sizeof(u64)); o += (size_t)p->t * RE;
+    memcpy(o, cccs + (size_t)p->kappa * RE, (size_t)p->l * RE * sizeof(u64)); o += (size_t)p->l * RE;
+    rq_from_u64(o, 1);
+    return 0;
+}
+
+/* LFDecompositionVerifier::verify, decomposition.rs:90-157 */
+static int verify_decomposition(const lfo_params *p, lfo_transcript *tr, const u64 *lcccs, const u64 *proof, u64 *out_K) {
+    u32 K = p->K;
+    size_t ll = lfo_lcccs_len(p);
+    const u64 *u_s = proof, *v_s = u_s + (size_t)K * p->t * RE, *x_s = v_s + (size_t)K * TAU * RE, *y_s = x_s + (size_t)K * (p->l + 1) * RE;
+    for (u32 k = 0; k < K; k++) {
+        const u64 *xk = x_s + (size_t)k * (p->l + 1) * RE, *yk = y_s + (size_t)k * p->kappa * RE;
+        const u64 *uk = u_s + (size_t)k * p->t * RE, *vk = v_s + (size_t)k * TAU * RE;
+        lfo_transcript_absorb_ring(tr, xk, p->l + 1);
+        lfo_transcript_absorb_ring(tr, yk, p->kappa);
+        lfo_transcript_absorb_ring(tr, uk, p->t);
+        lfo_transcript_absorb_ring(tr, vk, TAU);
+        u64 *o = out_K + (size_t)k * ll * RE;
+        memcpy(o, lcccs, (size_t)p->s * RE * sizeof(u64)); o += (size_t)p->s * RE;
+        memcpy(o, vk, TAU * RE * sizeof(u64)); o += TAU * RE;
+        memcpy(o, yk, (size_t)p->kappa * RE * sizeof(u64)); o += (size_t)p->kappa * RE;
+        memcpy(o, uk, (size_t)p->t * RE * sizeof(u64)); o += (size_t)p->t * RE;
+        memcpy(o, xk, (size_t)(p->l + 1) * RE * sizeof(u64));
+    }
+    /* recomposition checks with b^k */
+    struct { const u64 *parts; u32 cnt; const u64 *want; } chk[4] = {
+        {y_s, p->kappa, lcccs + ((size_t)p->s + TAU) * RE},
+        {v_s, TAU, lcccs + (size_t)p->s * RE},
+        {u_s, p->t, lcccs + ((size_t)p->s + TAU + p->kappa) * RE},
+        {x_s, p->l + 1, lcccs + ((size_t)p->s + TAU + p->kappa + p->t) * RE},
+    };
+    for (int c = 0; c < 4; c++)
+        for (u32 j = 0; j < chk[c].cnt; j++) {
+            u64 a[RE] = {0}, t[RE], bk[RE];
+            u64 pw = 1;
+            for (u32 k = 0; k < K; k++) {
+                rq_from_u64(bk, pw);
+                rq_mul(t, chk[c].parts + ((size_t)k * chk[c].cnt + j) * RE, bk);
+                rq_add(a, a, t);
+                pw = fq_mul(pw, p->b);
+            }
+            if (!rq_eq(a, chk[c].want + (size_t)j * RE)) return -20 - c;
+        }
+    return 0;
+}
+
+int lfo_verify(const lfo_params *p, const lfo_ccs *ccs, lfo_transcript *tr, const u64 *acc, const u64 *cm_i,
+               const u64 *proof, u64 *lcccs_out) {
+    u32 K = p->K, K2 = 2 * K;
+    size_t ll = lfo_lcccs_len(p);
+    absorb_label(tr, "acc");
+    lfo_transcript_absorb_ring(tr, acc, ll);
+    absorb_label(tr, "cm_i");
+    lfo_transcript_absorb_ring(tr, cm_i, lfo_cccs_len(p));
+    const u64 *lin_proof = proof;
+    const u64 *decl_proof = lin_proof + lin_proof_len(p) * RE;
+    const u64 *decr_proof = decl_proof + dec_proof_len(p) * RE;
+    const u64 *fold_proof = decr_proof + dec_proof_len(p) * RE;
+
+    u64 *lin = ralloc(ll), *parts = ralloc((size_t)K2 * ll);
+    int rc = verify_linearization(p, ccs, tr, cm_i, lin_proof, lin);
+    if (!rc) rc = verify_decomposition(p, tr, acc, decl_proof, parts);
+    if (!rc) { rc = verify_decomposition(p, tr, lin, decr_proof, parts + (size_t)K * ll * RE); if (rc) rc -= 10; }
+    if (rc) { free(lin); free(parts); return rc; }
+
+    /* LFFoldingVerifier::verify, folding.rs:132-195 */
+    u64 *alpha = ralloc(K2), *zeta = ralloc(K2), *mu = ralloc(K2), *beta = ralloc(p->s);
+    absorb_label(tr, "alpha_s"); get_challenges_ring(tr, K2, alpha);
+    absorb_label(tr, "zeta_s");  get_challenges_ring(tr, K2, zeta);
+    absorb_label(tr, "mu_s");    get_challenges_ring(tr, K2 - 1, mu);
+    rq_from_u64(mu + (size_t)(K2 - 1) * RE, 1);
+    absorb_label(tr, "beta_s");  get_challenges_ring(tr, p->s, beta);
+
+    /* calculate_claims: sum_i sum_j alpha_i^{j+1} v_ij + zeta_i^{j+1} u_ij */
+    u64 claim[RE] = {0}, pw[RE], t[RE];
+    for (u32 i = 0; i < K2; i++) {
+        const u64 *li = parts + (size_t)i * ll * RE;
+        rq_copy(pw, alpha + (size_t)i * RE);
+        for (int d = 0; d < TAU; d++) {
+            rq_mul(t, pw, li + ((size_t)p->s + d) * RE); rq_add(claim, claim, t);
+            rq_mul(pw, pw, alpha + (size_t)i * RE);
+        }
+        rq_copy(pw, zeta + (size_t)i * RE);
+        for (u32 j = 0; j < p->t; j++) {
+            rq_mul(t, pw, li + ((size_t)p->s + TAU + p->kappa + j) * RE); rq_add(claim, claim, t);
+            rq_mul(pw, pw, zeta + (size_t)i * RE);
+        }
+    }
+    u64 *r0 = lcccs_out, expected[RE];
+    rc = sumcheck_verify(tr, p->s, 2 * p->b, claim, fold_proof, r0, expected);
+    if (rc) rc = -40;
+    const u64 *theta = fold_proof + (size_t)p->s * (2 * p->b + 1) * RE, *eta = theta + (size_t)K2 * TAU * RE;
+    if (!rc) { /* verify_evaluation / compute_sumcheck_claim_expected_value, folding/utils.rs:366-413 */
+        u64 e_ast[RE], e_i[RE], total[RE] = {0}, s1[RE], s2[RE], s3[RE], th2[RE], prod[RE], bb[RE], m2[RE];
+        eq_eval(beta, r0, p->s, e_ast);
+        for (u32 i = 0; i < K2; i++) {
+            const u64 *li = parts + (size_t)i * ll * RE;
+            eq_eval(li, r0, p->s, e_i);
+            rq_zero(s1); rq_zero(s2); rq_zero(s3);
+            rq_copy(pw, alpha + (size_t)i * RE);
+            for (int d = 0; d < TAU; d++) {
+                rq_mul(t, pw, e_i); rq_mul(t, t, theta + ((size_t)i * TAU + d) * RE); rq_add(s1, s1, t);
+                rq_mul(pw, pw, alpha + (size_t)i * RE);
+            }
+            rq_copy(pw, mu + (size_t)i * RE);
+            for (int d = 0; d < TAU; d++) {
+                const u64 *th = theta + ((size_t)i * TAU + d) * RE;
+                rq_mul(th2, th, th);
+                rq_from_u64(prod, 1);
+                for (u32 b = 1; b < p->b; b++) { rq_from_u64(bb, (u64)b * b); rq_sub(m2, th2, bb); rq_mul(prod, prod, m2); }
+                rq_mul(t, pw, th); rq_mul(t, t, prod); rq_add(s2, s2, t);
+                rq_mul(pw, pw, mu + (size_t)i * RE);
+            }
+            rq_mul(s2, s2, e_ast);
+            rq_copy(pw, zeta + (size_t)i * RE);
+            for (u32 j = 0; j < p->t; j++) {
+                rq_mul(t, pw, eta + ((size_t)i * p->t + j) * RE); rq_add(s3, s3, t);
+                rq_mul(pw, pw, zeta + (size_t)i * RE);
+            }
+            rq_mul(s3, s3, e_i);
+            rq_add(total, total, s1); rq_add(total, total, s2); rq_add(total, total, s3);
+        }
+        if (!rq_eq(total, expected)) rc = -41;
+    }
+    if (!rc) {
+        lfo_transcript_absorb_ring(tr, theta, (size_t)K2 * TAU);
+        lfo_transcript_absorb_ring(tr, eta, (size_t)K2 * p->t);
+        absorb_label(tr, "rho_s");
+        u64 *rho_c = ralloc(K2), *rho = ralloc(K2);
+        for (u32 i = 0; i + 1 < K2; i++) lfo_transcript_get_short_challenge(tr, rho_c + (size_t)i * RE);
+        rho_c[(size_t)(K2 - 1) * RE] = 1;
+        lfo_crt(rho_c, rho, K2);
+        u64 *o = lcccs_out + (size_t)p->s * RE;
+        lfo_rot_lin_combination(rho_c, theta, K2, TAU, o);
+        o += TAU * RE;
+        struct { size_t off; u32 cnt; } fld[2] = {{(size_t)p->s + TAU, p->kappa}, {(size_t)p->s + TAU + p->kappa + p->t, p->l + 1}};
+        /* cm_0 */
+        for (u32 c = 0; c < fld[0].cnt; c++) {
+            u64 a[RE] = {0};
+            for (u32 i = 0; i < K2; i++) { rq_mul(t, parts + ((size_t)i * ll + fld[0].off + c) * RE, rho + (size_t)i * RE); rq_add(a, a, t); }
+            rq_copy(o + (size_t)c * RE, a);
+        }
+        o += (size_t)p->kappa * RE;
+        for (u32 j = 0; j < p->t; j++) {
+            u64 a[RE] = {0};
+            for (u32 i = 0; i < K2; i++) { rq_mul(t, rho + (size_t)i * RE, eta + ((size_t)i * p->t + j) * RE); rq_add(a, a, t); }
+            rq_copy(o + (size_t)j * RE, a);
+        }
+        o += (size_t)p->t * RE;
+        for (u32 c = 0; c < fld[1].cnt; c++) {
+            u64 a[RE] = {0};
+            for (u32 i = 0; i < K2; i++) { rq_mul(t, rho + (size_t)i * RE, parts + ((size_t)i * ll + fld[1].off + c) * RE); rq_add(a, a, t); }
+            rq_copy(o + (size_t)c * RE, a);
+        }
+        free(rho_c); free(rho);
+    }
+    free(alpha); free(zeta); free(mu); free(beta); free(lin); free(parts);
+    return rc;
+}

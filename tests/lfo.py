@@ -1,0 +1,249 @@
+"""ctypes binding of the CPU oracle (oracle/liblfo.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(_HERE, "..", "oracle")
+_SO = os.path.join(_ORACLE_DIR, "liblfo.so")
+
+P = 2**64 - 2**32 + 1
+RE = 24
+TAU = 3
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+
+def build(force=False):
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+    return _SO
+
+
+class Params(C.Structure):
+    _fields_ = [("s", C.c_uint32), ("wit_len", C.c_uint32), ("l", C.c_uint32), ("L", C.c_uint32),
+                ("K", C.c_uint32), ("b", C.c_uint32), ("B", C.c_uint64), ("kappa", C.c_uint32),
+                ("t", C.c_uint32), ("q", C.c_uint32), ("d", C.c_uint32)]
+
+
+class Ccs(C.Structure):
+    _fields_ = [("rowptr", C.POINTER(u32p)), ("col", C.POINTER(u32p)), ("val", C.POINTER(u64p)),
+                ("S_off", u32p), ("S_idx", u32p), ("c", u64p)]
+
+
+def _p64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _p32(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.lfo_set_ring.restype = C.c_int
+        L.lfo_set_ring.argtypes = [C.c_uint64, u64p]
+        L.lfo_lcccs_len.restype = C.c_size_t
+        L.lfo_cccs_len.restype = C.c_size_t
+        L.lfo_proof_len.restype = C.c_size_t
+        L.lfo_transcript_new.restype = C.c_void_p
+        for f in ("lfo_transcript_free", "lfo_transcript_absorb_fq", "lfo_transcript_absorb_ring",
+                  "lfo_transcript_get_challenge", "lfo_transcript_get_short_challenge"):
+            getattr(L, f).restype = None
+        L.lfo_transcript_free.argtypes = [C.c_void_p]
+        L.lfo_transcript_absorb_fq.argtypes = [C.c_void_p, u64p, C.c_size_t]
+        L.lfo_transcript_absorb_ring.argtypes = [C.c_void_p, u64p, C.c_size_t]
+        L.lfo_transcript_get_challenge.argtypes = [C.c_void_p, u64p]
+        L.lfo_transcript_get_short_challenge.argtypes = [C.c_void_p, u64p]
+        L.lfo_crt.argtypes = [u64p, u64p, C.c_size_t]
+        L.lfo_icrt.argtypes = [u64p, u64p, C.c_size_t]
+        L.lfo_decompose.argtypes = [u64p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int, u64p]
+        L.lfo_recompose.argtypes = [u64p, C.c_size_t, C.c_uint64, C.c_uint32, u64p]
+        L.lfo_ajtai_commit.argtypes = [u64p, C.c_uint32, C.c_size_t, u64p, u64p]
+        L.lfo_build_eq.argtypes = [u64p, C.c_uint32, u64p]
+        L.lfo_mle_eval.argtypes = [u64p, C.c_size_t, u64p, C.c_uint32, u64p]
+        L.lfo_rot_lin_combination.argtypes = [u64p, u64p, C.c_uint32, C.c_uint32, u64p]
+        L.lfo_short_challenge_from_bytes.argtypes = [C.c_char_p, C.c_size_t, u64p]
+        L.lfo_witness_from_w_ccs.argtypes = [C.POINTER(Params), u64p, u64p]
+        L.lfo_linearize.argtypes = [C.POINTER(Params), C.POINTER(Ccs), C.c_void_p, u64p, u64p, u64p, u64p]
+        L.lfo_fold_step.argtypes = [C.POINTER(Params), C.POINTER(Ccs), u64p, C.c_void_p, u64p, u64p, u64p, u64p,
+                                    u64p, u64p, u64p]
+        L.lfo_verify.argtypes = [C.POINTER(Params), C.POINTER(Ccs), C.c_void_p, u64p, u64p, u64p, u64p]
+        _lib = L
+    return _lib
+
+
+# ---------------------------------------------------------------------------------------------
+class Transcript:
+    def __init__(self):
+        self.h = lib().lfo_transcript_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lfo_transcript_free(self.h)
+            self.h = None
+
+    def absorb_fq(self, xs):
+        a = np.ascontiguousarray(xs, dtype=np.uint64)
+        lib().lfo_transcript_absorb_fq(self.h, _p64(a), a.size)
+
+    def absorb_ring(self, e):
+        a = np.ascontiguousarray(e, dtype=np.uint64).reshape(-1)
+        assert a.size % RE == 0
+        lib().lfo_transcript_absorb_ring(self.h, _p64(a), a.size // RE)
+
+    def challenge(self):
+        o = np.zeros(3, dtype=np.uint64)
+        lib().lfo_transcript_get_challenge(self.h, _p64(o))
+        return o
+
+    def short_challenge(self):
+        o = np.zeros(RE, dtype=np.uint64)
+        lib().lfo_transcript_get_short_challenge(self.h, _p64(o))
+        return o
+
+
+def crt(x):
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    o = np.empty_like(x)
+    lib().lfo_crt(_p64(x), _p64(o), x.size // RE)
+    return o
+
+
+def icrt(x):
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    o = np.empty_like(x)
+    lib().lfo_icrt(_p64(x), _p64(o), x.size // RE)
+    return o
+
+
+def decompose(x, base, digits, layout):
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    cnt = x.size // RE
+    o = np.zeros(cnt * digits * RE, dtype=np.uint64)
+    lib().lfo_decompose(_p64(x), cnt, base, digits, layout, _p64(o))
+    return o.reshape(-1, RE)
+
+
+def recompose(x, base, digits):
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    cnt = x.size // RE // digits
+    o = np.zeros(cnt * RE, dtype=np.uint64)
+    lib().lfo_recompose(_p64(x), cnt, base, digits, _p64(o))
+    return o.reshape(-1, RE)
+
+
+def ajtai_commit(A, kappa, n, f):
+    A = np.ascontiguousarray(A, dtype=np.uint64)
+    f = np.ascontiguousarray(f, dtype=np.uint64)
+    o = np.zeros(kappa * RE, dtype=np.uint64)
+    lib().lfo_ajtai_commit(_p64(A), kappa, n, _p64(f), _p64(o))
+    return o.reshape(kappa, RE)
+
+
+def build_eq(r_ring):
+    r = np.ascontiguousarray(r_ring, dtype=np.uint64).reshape(-1, RE)
+    nv = r.shape[0]
+    o = np.zeros((1 << nv) * RE, dtype=np.uint64)
+    lib().lfo_build_eq(_p64(r), nv, _p64(o))
+    return o.reshape(-1, RE)
+
+
+def mle_eval(table, r_ring):
+    t = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, RE)
+    r = np.ascontiguousarray(r_ring, dtype=np.uint64).reshape(-1, RE)
+    o = np.zeros(RE, dtype=np.uint64)
+    lib().lfo_mle_eval(_p64(t), t.shape[0], _p64(r), r.shape[0], _p64(o))
+    return o
+
+
+def rot_lin_combination(rho_coeff, theta, n, tau_elems=3):
+    a = np.ascontiguousarray(rho_coeff, dtype=np.uint64).reshape(-1)
+    b = np.ascontiguousarray(theta, dtype=np.uint64).reshape(-1)
+    o = np.zeros(tau_elems * RE, dtype=np.uint64)
+    lib().lfo_rot_lin_combination(_p64(a), _p64(b), n, tau_elems, _p64(o))
+    return o.reshape(tau_elems, RE)
+
+
+def short_challenge_from_bytes(bs):
+    o = np.zeros(RE, dtype=np.uint64)
+    rc = lib().lfo_short_challenge_from_bytes(bytes(bs), len(bs), _p64(o))
+    assert rc == 0
+    return o
+
+
+# ---------------------------------------------------------------------------------------------
+class Instance:
+    """Holds Params + CCS (CSR) + Ajtai matrix in the oracle's C layout."""
+
+    def __init__(self, wl):
+        """wl: latticefold_amd.workload.Workload"""
+        self.wl = wl
+        self.params = Params(wl.s, wl.wit_len, wl.l, wl.L, wl.K, wl.b, wl.B, wl.kappa, wl.t, wl.q, wl.d)
+        t = wl.t
+        self._rp = [np.ascontiguousarray(a, dtype=np.uint32) for a in wl.rowptr]
+        self._ci = [np.ascontiguousarray(a, dtype=np.uint32) for a in wl.col]
+        self._va = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1) for a in wl.val]
+        self._soff = np.ascontiguousarray(wl.S_off, dtype=np.uint32)
+        self._sidx = np.ascontiguousarray(wl.S_idx, dtype=np.uint32)
+        self._c = np.ascontiguousarray(wl.c, dtype=np.uint64).reshape(-1)
+        self._rpp = (u32p * t)(*[_p32(a) for a in self._rp])
+        self._cip = (u32p * t)(*[_p32(a) for a in self._ci])
+        self._vap = (u64p * t)(*[_p64(a) for a in self._va])
+        self.ccs = Ccs(C.cast(self._rpp, C.POINTER(u32p)), C.cast(self._cip, C.POINTER(u32p)),
+                       C.cast(self._vap, C.POINTER(u64p)), _p32(self._soff), _p32(self._sidx), _p64(self._c))
+        self.lcccs_len = lib().lfo_lcccs_len(C.byref(self.params))
+        self.cccs_len = lib().lfo_cccs_len(C.byref(self.params))
+        self.proof_len = lib().lfo_proof_len(C.byref(self.params))
+
+    def witness_from_w_ccs(self, w_ccs):
+        w = np.ascontiguousarray(w_ccs, dtype=np.uint64).reshape(-1)
+        o = np.zeros(self.wl.N * RE, dtype=np.uint64)
+        lib().lfo_witness_from_w_ccs(C.byref(self.params), _p64(w), _p64(o))
+        return o.reshape(-1, RE)
+
+    def linearize(self, tr, cccs, f_coeff):
+        cccs = np.ascontiguousarray(cccs, dtype=np.uint64).reshape(-1)
+        f = np.ascontiguousarray(f_coeff, dtype=np.uint64).reshape(-1)
+        lc = np.zeros(self.lcccs_len * RE, dtype=np.uint64)
+        wl = self.wl
+        pr = np.zeros((wl.s * (wl.d + 2) + TAU + wl.t) * RE, dtype=np.uint64)
+        rc = lib().lfo_linearize(C.byref(self.params), C.byref(self.ccs), tr.h, _p64(cccs), _p64(f), _p64(lc), _p64(pr))
+        assert rc == 0, rc
+        return lc.reshape(-1, RE), pr.reshape(-1, RE)
+
+    def fold_step(self, tr, A, acc, w_acc, cm_i, w_i):
+        A = np.ascontiguousarray(A, dtype=np.uint64).reshape(-1)
+        acc = np.ascontiguousarray(acc, dtype=np.uint64).reshape(-1)
+        w_acc = np.ascontiguousarray(w_acc, dtype=np.uint64).reshape(-1)
+        cm_i = np.ascontiguousarray(cm_i, dtype=np.uint64).reshape(-1)
+        w_i = np.ascontiguousarray(w_i, dtype=np.uint64).reshape(-1)
+        lc = np.zeros(self.lcccs_len * RE, dtype=np.uint64)
+        f0 = np.zeros(self.wl.N * RE, dtype=np.uint64)
+        pr = np.zeros(self.proof_len * RE, dtype=np.uint64)
+        rc = lib().lfo_fold_step(C.byref(self.params), C.byref(self.ccs), _p64(A), tr.h, _p64(acc), _p64(w_acc),
+                                 _p64(cm_i), _p64(w_i), _p64(lc), _p64(f0), _p64(pr))
+        assert rc == 0, rc
+        return lc.reshape(-1, RE), f0.reshape(-1, RE), pr.reshape(-1, RE)
+
+    def verify(self, tr, acc, cm_i, proof):
+        acc = np.ascontiguousarray(acc, dtype=np.uint64).reshape(-1)
+        cm_i = np.ascontiguousarray(cm_i, dtype=np.uint64).reshape(-1)
+        proof = np.ascontiguousarray(proof, dtype=np.uint64).reshape(-1)
+        lc = np.zeros(self.lcccs_len * RE, dtype=np.uint64)
+        rc = lib().lfo_verify(C.byref(self.params), C.byref(self.ccs), tr.h, _p64(acc), _p64(cm_i), _p64(proof), _p64(lc))
+        return rc, lc.reshape(-1, RE)

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Extract known-answer-test VECTORS (numbers only) from the reference's own unit tests.
+
+Run in the build container (where /root/reference exists):
+    python tests/tools/extract_kats.py
+Writes tests/golden/kats.json.  Only numeric inputs / expected outputs are taken; no
+reference source text is stored.  Each entry names the reference test it came from.
+"""
+import json, os, re, sys
+
+REF = os.environ.get("LF_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(__file__), "..", "golden", "kats.json")
+
+
+def read(rel):
+    with open(os.path.join(REF, rel)) as f:
+        return f.read()
+
+
+def between(src, start, end=None):
+    i = src.index(start)
+    j = src.index(end, i) if end else len(src)
+    return src[i:j]
+
+
+def main():
+    kats = {}
+
+    # --- crates/cyclotomic-rings/src/rotation.rs:174-775  test_rot_lin_combination
+    src = between(read("crates/cyclotomic-rings/src/rotation.rs"), "fn test_rot_lin_combination")
+    nums = [int(x) for x in re.findall(r"Fq::from\((\d+)u64\)", src)]
+    assert len(nums) == 72 + 216 + 72, len(nums)
+    kats["rot_lin_combination"] = {
+        "source": "crates/cyclotomic-rings/src/rotation.rs:174-775",
+        "rho_coeff": [nums[24 * i:24 * (i + 1)] for i in range(3)],
+        # theta[i][j] = NTT-form ring element, 8 slots x 3 coords, slot-major
+        "theta": [[nums[72 + 72 * i + 24 * j: 72 + 72 * i + 24 * (j + 1)] for j in range(3)] for i in range(3)],
+        "expected": [nums[288 + 24 * i: 288 + 24 * (i + 1)] for i in range(3)],
+    }
+
+    # --- crates/cyclotomic-rings/src/rings/goldilocks.rs:78-115
+    src = between(read("crates/cyclotomic-rings/src/rings/goldilocks.rs"), "fn test_small_challenge_from_random_bytes")
+    bs = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{2})", between(src, "short_challenge_from_random_bytes(&[", "])"))]
+    co = [int(x) for x in re.findall(r"BigInt\(\[(\d+)\]\)", src)]
+    assert len(bs) == 18 and len(co) == 24
+    kats["goldilocks_small_challenge_from_bytes"] = {
+        "source": "crates/cyclotomic-rings/src/rings/goldilocks.rs:78-115",
+        "bytes": bs, "coeffs": co,
+    }
+
+    # --- crates/latticefold/src/transcript/poseidon.rs:85-142
+    src = read("crates/latticefold/src/transcript/poseidon.rs")
+    big = between(src, "fn test_get_big_challenge", "fn test_get_small_challenge")
+    small = between(src, "fn test_get_small_challenge")
+    kats["poseidon_big_challenge"] = {
+        "source": "crates/latticefold/src/transcript/poseidon.rs:85-103",
+        "absorb": [0xFF],
+        "expected_fq3": [int(x) for x in re.findall(r"BigInt\(\[(\d+)\]\)", big)],
+    }
+    kats["poseidon_small_challenge"] = {
+        "source": "crates/latticefold/src/transcript/poseidon.rs:105-142",
+        "absorb": [0xFF],
+        "expected_coeffs": [int(x) for x in re.findall(r"BigInt\(\[(\d+)\]\)", small)],
+    }
+    assert len(kats["poseidon_big_challenge"]["expected_fq3"]) == 3
+    assert len(kats["poseidon_small_challenge"]["expected_coeffs"]) == 24
+
+    # --- Poseidon round constants: spot values + count, to pin the Grain-LFSR regeneration
+    # crates/cyclotomic-rings/src/rings/poseidon/goldilocks.rs:7-1425
+    src = read("crates/cyclotomic-rings/src/rings/poseidon/goldilocks.rs")
+    vals = [int(x, 16) for x in re.findall(r"Fq::from\(0x([0-9a-f]+)_i128\)", src)]
+    assert len(vals) == 30 * 24 + 24 * 24
+    p = 2**64 - 2**32 + 1
+    kats["poseidon_goldilocks_params"] = {
+        "source": "crates/cyclotomic-rings/src/rings/poseidon/goldilocks.rs:7-1425",
+        "full_rounds": 8, "partial_rounds": 22, "alpha": 7, "rate": 20, "capacity": 4,
+        "n_ark": 720, "n_mds": 576,
+        "ark_first": vals[:4], "ark_last": vals[716:720],
+        "mds_first": vals[720:724], "mds_last": vals[-4:],
+        # order-sensitive checksums of the full tables: sum_i (i+1)*v_i mod p
+        "ark_checksum": sum((i + 1) * v for i, v in enumerate(vals[:720])) % p,
+        "mds_checksum": sum((i + 1) * v for i, v in enumerate(vals[720:])) % p,
+    }
+
+    # --- crates/latticefold/src/arith.rs:455-502  test_get_fhat (inputs are written as code there;
+    # restated here as data: coefficient vectors and the expected slot values)
+    kats["get_fhat"] = {
+        "source": "crates/latticefold/src/arith.rs:455-502",
+        "f_coeff": [[1, 2, 3] + [0] * 21, [4, 5, 6] + [1] * 21],
+        # fhat[j][i] = 8 base-field slot values (each embedded as (c,0,0))
+        "fhat_slots": [
+            [[1, 2, 3, 0, 0, 0, 0, 0], [4, 5, 6, 1, 1, 1, 1, 1]],
+            [[0] * 8, [1] * 8],
+            [[0] * 8, [1] * 8],
+        ],
+    }
+
+    # --- crates/latticefold/src/commitment/commitment_scheme.rs:122-159 test_commit_ntt
+    kats["commit_ntt"] = {
+        "source": "crates/latticefold/src/commitment/commitment_scheme.rs:122-159",
+        "kappa": 9, "n": 1 << 15,
+        "matrix_entry": "diag(i*n + j)", "witness_entry": "diag(2)",
+        "expected_formula": "n*(2*i*n + (n-1))",
+    }
+
+    # --- decomposition parameter sets used by the reference tests/benches
+    kats["decomposition_params"] = {
+        "source": "crates/latticefold/src/decomposition_parameters.rs:89-105; benches/config.toml:156,163",
+        "GoldilocksDP": {"B": 1 << 15, "L": 5, "b": 2, "K": 15},
+        "C2": {"B": 1 << 16, "L": 4, "b": 2, "K": 16, "kappa": 25, "wit_len": 16384},
+        "C4": {"B": 1 << 16, "L": 4, "b": 2, "K": 16, "kappa": 26, "wit_len": 1 << 18},
+    }
+
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(OUT, "w") as f:
+        json.dump(kats, f, indent=1)
+    print("wrote", os.path.normpath(OUT), "with", len(kats), "KAT groups")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
