@@ -1,0 +1,160 @@
+/*
+ * lfhip.h -- C ABI of liblfhip.so: the MI355X (gfx950) LatticeFold prover hot path.
+ *
+ * This is the drop-in boundary for NethermindEth/latticefold's `NIFSProver::prove`
+ * (crates/latticefold/src/nifs.rs:48-103).  The reference is 100 % safe Rust with
+ * `#![forbid(unsafe_code)]` (crates/latticefold/src/lib.rs:4), so these entry points are what
+ * a new `latticefold-hip-sys` crate would bind (INTEGRATION.md shows the stub); each one cites
+ * the reference interface it replaces.
+ *
+ * Data format: flat little-endian uint64_t CANONICAL residues in [0,p), p = 2^64 - 2^32 + 1.
+ * Ring element = 24 words.  Coefficient form: X^0..X^23 of Z_p[X]/(X^24 - X^12 + 1).  NTT form:
+ * slot-major, slot k = words [3k,3k+3) = (c0,c1,c2) of an F_{p^3} element -- the order
+ * `coeffs().flat_map(to_base_prime_field_elements)` yields (transcript/poseidon.rs:40-47).
+ * (arkworks stores Montgomery form internally; the Rust shim converts with into_bigint/from.)
+ *
+ * Ownership: the caller owns every host buffer; the context owns all device memory.  All
+ * pointers below are HOST pointers.  Every function returns 0 on success or a negative
+ * LF_ERR_* code (lf_strerror); nothing aborts.  A context serialises its own calls
+ * (internal mutex), so it may be shared between threads (the reference calls `commit` from
+ * Rayon workers, nifs/decomposition.rs:185-187); use the batched entry points to collapse
+ * such loops into one call.
+ */
+#ifndef LFHIP_H
+#define LFHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_RING_WORDS 24
+
+enum {
+    LF_OK = 0,
+    LF_ERR_INVALID = -1,        /* bad argument / CommitmentError::WrongWitnessLength (commitment.rs:14-27),
+                                   MleEvaluationError::IncorrectLength (utils/mle_helpers.rs:13-17) */
+    LF_ERR_HIP = -2,            /* HIP runtime failure (no GPU, out of memory, ...) */
+    LF_ERR_UNSUPPORTED = -3,    /* parameter outside what the kernels implement */
+    LF_ERR_BAD_TABLES = -4,     /* ring tables are not a ring isomorphism */
+    LF_ERR_NORM = -5,           /* witness coefficient exceeds the decomposition bound */
+    LF_ERR_SIZE_BOUNDS = -6,    /* CSError::InvalidSizeBounds (nifs.rs:165-173) */
+    LF_ERR_STATE = -7,          /* call sequence misuse (the reference panics: sumcheck/prover.rs:41,63,75,81) */
+};
+const char *lf_strerror(int code);
+
+typedef struct lf_ctx lf_ctx;
+typedef struct lf_witness lf_witness;       /* device-resident Witness (arith.rs:213-223): centred f_coeff */
+typedef struct lf_transcript lf_transcript; /* PoseidonTranscript (transcript/poseidon.rs:17-75), host */
+
+/* ---- context ------------------------------------------------------------------------------- */
+int lf_ctx_create(lf_ctx **out, int device);
+void lf_ctx_destroy(lf_ctx *);
+/* The CRT slot map, the F_{p^3} non-residue and the digit rule live in the un-vendored crate
+ * stark-rings @ 886a89f and are DATA here: y[8*3] = image of X in slot k.  Defaults are installed
+ * by lf_ctx_create.  tools/probe_stark_rings.rs prints the true tables. */
+int lf_set_ring_tables(lf_ctx *, uint64_t nonres, const uint64_t *y);
+int lf_get_ring_tables(lf_ctx *, uint64_t *nonres, uint64_t *y);
+int lf_device_synchronize(lf_ctx *);
+
+/* ---- a1/a2: CRT::elementwise_crt / ICRT::elementwise_icrt (arith.rs:232,238,300,327) -------- */
+int lf_ntt_fwd(lf_ctx *, const uint64_t *in, uint64_t *out, size_t count); /* in/out may alias */
+int lf_ntt_inv(lf_ctx *, const uint64_t *in, uint64_t *out, size_t count);
+
+/* ---- a3: balanced decomposition (stark_rings::balanced_decomposition) ------------------------
+ * layout 0 = gadget_decompose (element i -> out[i*digits + j], arith.rs:235);
+ * layout 1 = decompose_to_vec(..).transpose() (digit table j at out + j*count*24,
+ *            nifs/decomposition/utils.rs:45-49).  Power-of-two bases only. */
+int lf_decompose(lf_ctx *, const uint64_t *coeff_in, size_t count, uint64_t base, unsigned digits, int layout,
+                 uint64_t *out);
+/* gadget_recompose / recompose (arith.rs:305,330): out[i] = sum_j base^j in[i*digits + j] */
+int lf_recompose(lf_ctx *, const uint64_t *in, size_t count_out, uint64_t base, unsigned digits, uint64_t *out);
+/* a15: l-infinity norm of ICRT(f) with centred representatives.  *ok = (max < bound);
+ * *max_out (optional) receives the maximum.  `unsigned_variant` != 0 instead reproduces the literal
+ * `Witness::within_bound` (arith.rs:372-386): every canonical coefficient < bound. */
+int lf_linf_check(lf_ctx *, const uint64_t *f_ntt, size_t count, uint64_t bound, int unsigned_variant, int *ok,
+                  uint64_t *max_out);
+
+/* ---- a5: AjtaiCommitmentScheme::{new, commit, commit_ntt} (commitment_scheme.rs:23-77) -------- */
+int lf_ajtai_load(lf_ctx *, const uint64_t *A /* kappa*n ring elements, row-major, NTT form */, size_t kappa, size_t n);
+/* synthetic i.i.d. matrix generated on the device (bench; same stream as workload.Workload.ajtai_matrix) */
+int lf_ajtai_generate(lf_ctx *, uint64_t seed, size_t kappa, size_t n);
+/* out[b*kappa + i] = sum_j A[i][j] (.) f[b*n + j];  n != width -> LF_ERR_INVALID (WrongWitnessLength) */
+int lf_ajtai_commit(lf_ctx *, const uint64_t *f, size_t n, size_t batch, uint64_t *out);
+
+/* ---- a8/a9/a11: eq table and batched MLE evaluation (sumcheck/utils.rs:100-170, mle_helpers.rs:65-88) */
+/* point = nv challenges in F_{p^3} (3 words each): the reference's points are always diagonal embeddings
+ * of transcript challenges (linearization/utils.rs:119-122, folding/utils.rs:59-92). */
+int lf_build_eq(lf_ctx *, const uint64_t *point, unsigned nv, uint64_t *out /* (1<<nv)*3 */);
+int lf_mle_eval_batch(lf_ctx *, const uint64_t *tables /* ntables x len ring elems (NTT) */, size_t ntables, size_t len,
+                      const uint64_t *point, unsigned nv, uint64_t *out /* ntables ring elems */);
+
+/* ---- a7, a16: CCS statement (arith.rs:50-74) ---------------------------------------------------- */
+typedef struct {
+    uint32_t s;       /* log2 m */
+    uint32_t wit_len; /* ring elements in w_ccs */
+    uint32_t l;       /* x_len */
+    uint32_t L, K, b; /* DecompositionParams (decomposition_parameters.rs:11-20) */
+    uint64_t B;
+    uint32_t kappa;
+    uint32_t t, q, d; /* #matrices, #multisets, degree */
+} lf_params;
+/* matrices in CSR (rows m = 1<<s, cols n = l + 1 + wit_len), values = NTT-form ring elements */
+int lf_ccs_load(lf_ctx *, const lf_params *, const uint32_t *const *rowptr, const uint32_t *const *col,
+                const uint64_t *const *val, const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *c);
+/* mat_vec_mul (arith/utils.rs:52-65): out (m ring elements) = M_j * z (n ring elements) */
+int lf_spmv(lf_ctx *, unsigned j, const uint64_t *z, uint64_t *out);
+
+size_t lf_lcccs_len(const lf_params *); /* ring elements: r[s] v[3] cm[kappa] u[t] x_w[l] h */
+size_t lf_cccs_len(const lf_params *);  /* cm[kappa] x_ccs[l] */
+size_t lf_proof_len(const lf_params *); /* LFProof flat, see DESIGN.md */
+
+/* ---- Witness (arith.rs:230-338) ------------------------------------------------------------------ */
+int lf_witness_from_w_ccs(lf_ctx *, const uint64_t *w_ccs /* wit_len NTT */, lf_witness **out); /* from_w_ccs */
+int lf_witness_from_f_coeff(lf_ctx *, const uint64_t *f_coeff /* N coeff-form */, lf_witness **out);
+int lf_witness_from_f(lf_ctx *, const uint64_t *f_ntt /* N NTT */, lf_witness **out);           /* from_f */
+int lf_witness_get_f_coeff(lf_ctx *, const lf_witness *, uint64_t *out /* N */);
+int lf_witness_get_f(lf_ctx *, const lf_witness *, uint64_t *out /* N, NTT */);
+int lf_witness_get_w_ccs(lf_ctx *, const lf_witness *, uint64_t *out /* wit_len, NTT */);
+int lf_witness_commit(lf_ctx *, const lf_witness *, uint64_t *cm_out /* kappa */);              /* Witness::commit */
+void lf_witness_free(lf_witness *);
+
+/* ---- transcript (transcript.rs:13-51) --------------------------------------------------------------- */
+lf_transcript *lf_transcript_new(void);
+lf_transcript *lf_transcript_clone(const lf_transcript *);
+void lf_transcript_free(lf_transcript *);
+void lf_transcript_absorb_fq(lf_transcript *, const uint64_t *x, size_t n);       /* sponge.absorb */
+void lf_transcript_absorb_ring(lf_transcript *, const uint64_t *elems, size_t n); /* absorb_slice */
+void lf_transcript_get_challenge(lf_transcript *, uint64_t *fq3_out);
+void lf_transcript_get_short_challenge(lf_transcript *, uint64_t *coeff_out);
+void lf_poseidon_params(uint64_t *ark /* 720 */, uint64_t *mds /* 576 */);
+
+/* ---- sumcheck split at the transcript (utils/sumcheck.rs:53-80, sumcheck/prover.rs:56-162) ---------
+ * Generic entry for the linearization-shaped polynomial  comb = (sum_i c_i prod_{j in S_i} T_j) * T_last
+ * over t ring tables + one slot-constant table: begin / round / end.  Rounds must be called in order;
+ * r_prev = NULL in round 1.  (The folding sumcheck runs inside lf_fold_step on virtual f-hat tables.) */
+int lf_sumcheck_lin_begin(lf_ctx *, const uint64_t *tables /* t x m ring elems */, const uint64_t *eq_point /* s*3 */);
+int lf_sumcheck_lin_round(lf_ctx *, const uint64_t *r_prev /* 3 words or NULL */, uint64_t *evals_out /* (d+2) ring elems */);
+int lf_sumcheck_lin_end(lf_ctx *);
+
+/* ---- the path itself ----------------------------------------------------------------------------------- */
+/* LFLinearizationProver::prove (nifs/linearization.rs:145-189) */
+int lf_linearize(lf_ctx *, lf_transcript *, const uint64_t *cccs, const lf_witness *wit, uint64_t *lcccs_out,
+                 uint64_t *lin_proof_out /* s*(d+2) + 3 + t ring elems */);
+/* NIFSProver::prove (nifs.rs:48-103): one fold step.  w_out receives the folded witness handle. */
+int lf_fold_step(lf_ctx *, lf_transcript *, const uint64_t *acc_lcccs, const lf_witness *w_acc, const uint64_t *cm_i_cccs,
+                 const lf_witness *w_i, uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof_out);
+
+/* ---- measurement hooks (bench.py): HIP-event time of the last fold step, per phase, in ms ------------ */
+#define LF_N_PHASES 8
+int lf_last_phase_ms(lf_ctx *, float *out /* LF_N_PHASES */);
+const char *lf_phase_name(int i);
+/* dominant-kernel timing: total HIP-event time and launch count of the folding-sumcheck round kernel and of
+ * the Ajtai kernel in the last fold step */
+int lf_last_kernel_stats(lf_ctx *, float *fold_round_ms, int *fold_round_launches, float *ajtai_ms, int *ajtai_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,419 @@
+"""Host-side mirror of the reference's interface for the prover hot path, over the C ABI of liblfhip.so.
+
+Names follow crates/latticefold: `AjtaiCommitmentScheme` (commitment/commitment_scheme.rs:17-114),
+`Witness` (arith.rs:213-362), `PoseidonTranscript` (transcript/poseidon.rs), `DecompositionParams`
+(decomposition_parameters.rs:11-20), `NIFSProver.prove` (nifs.rs:48-103), `CCS` (arith.rs:50-74).
+All bulk data are numpy uint64 arrays of canonical residues, shape (..., 24) per ring element.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is present every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+RE = 24
+P = 2**64 - 2**32 + 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblfhip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+
+class LfError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = _lib().lf_strerror(code).decode() if _LIB is not None else str(code)
+        super().__init__(f"liblfhip {where}: {msg} ({code})")
+
+
+class CommitmentError(LfError):
+    """CommitmentError::WrongWitnessLength (commitment.rs:14-27)"""
+
+
+class Params(C.Structure):
+    """lf_params == DecompositionParams {B, L, B_SMALL=b, K} + CCS shape + kappa."""
+    _fields_ = [("s", C.c_uint32), ("wit_len", C.c_uint32), ("l", C.c_uint32), ("L", C.c_uint32),
+                ("K", C.c_uint32), ("b", C.c_uint32), ("B", C.c_uint64), ("kappa", C.c_uint32),
+                ("t", C.c_uint32), ("q", C.c_uint32), ("d", C.c_uint32)]
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is required; there is no CPU fallback)")
+        L = C.CDLL(_SO)
+        vp = C.c_void_p
+        L.lf_strerror.restype = C.c_char_p
+        L.lf_strerror.argtypes = [C.c_int]
+        L.lf_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.lf_ctx_destroy.argtypes = [vp]
+        L.lf_ctx_destroy.restype = None
+        L.lf_set_ring_tables.argtypes = [vp, C.c_uint64, u64p]
+        L.lf_get_ring_tables.argtypes = [vp, u64p, u64p]
+        L.lf_device_synchronize.argtypes = [vp]
+        L.lf_ntt_fwd.argtypes = [vp, u64p, u64p, C.c_size_t]
+        L.lf_ntt_inv.argtypes = [vp, u64p, u64p, C.c_size_t]
+        L.lf_decompose.argtypes = [vp, u64p, C.c_size_t, C.c_uint64, C.c_uint, C.c_int, u64p]
+        L.lf_recompose.argtypes = [vp, u64p, C.c_size_t, C.c_uint64, C.c_uint, u64p]
+        L.lf_linf_check.argtypes = [vp, u64p, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_int), u64p]
+        L.lf_ajtai_load.argtypes = [vp, u64p, C.c_size_t, C.c_size_t]
+        L.lf_ajtai_generate.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t]
+        L.lf_ajtai_commit.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p]
+        L.lf_build_eq.argtypes = [vp, u64p, C.c_uint, u64p]
+        L.lf_mle_eval_batch.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p, C.c_uint, u64p]
+        L.lf_ccs_load.argtypes = [vp, C.POINTER(Params), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u64p), u32p, u32p, u64p]
+        L.lf_spmv.argtypes = [vp, C.c_uint, u64p, u64p]
+        for f in ("lf_lcccs_len", "lf_cccs_len", "lf_proof_len"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [C.POINTER(Params)]
+        L.lf_witness_from_w_ccs.argtypes = [vp, u64p, C.POINTER(vp)]
+        L.lf_witness_from_f_coeff.argtypes = [vp, u64p, C.POINTER(vp)]
+        L.lf_witness_from_f.argtypes = [vp, u64p, C.POINTER(vp)]
+        L.lf_witness_get_f_coeff.argtypes = [vp, vp, u64p]
+        L.lf_witness_get_f.argtypes = [vp, vp, u64p]
+        L.lf_witness_get_w_ccs.argtypes = [vp, vp, u64p]
+        L.lf_witness_commit.argtypes = [vp, vp, u64p]
+        L.lf_witness_free.argtypes = [vp]
+        L.lf_witness_free.restype = None
+        L.lf_transcript_new.restype = vp
+        L.lf_transcript_clone.restype = vp
+        L.lf_transcript_clone.argtypes = [vp]
+        L.lf_transcript_free.argtypes = [vp]
+        L.lf_transcript_free.restype = None
+        L.lf_transcript_absorb_fq.argtypes = [vp, u64p, C.c_size_t]
+        L.lf_transcript_absorb_fq.restype = None
+        L.lf_transcript_absorb_ring.argtypes = [vp, u64p, C.c_size_t]
+        L.lf_transcript_absorb_ring.restype = None
+        L.lf_transcript_get_challenge.argtypes = [vp, u64p]
+        L.lf_transcript_get_challenge.restype = None
+        L.lf_transcript_get_short_challenge.argtypes = [vp, u64p]
+        L.lf_transcript_get_short_challenge.restype = None
+        L.lf_poseidon_params.argtypes = [u64p, u64p]
+        L.lf_poseidon_params.restype = None
+        L.lf_sumcheck_lin_begin.argtypes = [vp, u64p, u64p]
+        L.lf_sumcheck_lin_round.argtypes = [vp, u64p, u64p]
+        L.lf_sumcheck_lin_end.argtypes = [vp]
+        L.lf_linearize.argtypes = [vp, vp, u64p, vp, u64p, u64p]
+        L.lf_fold_step.argtypes = [vp, vp, u64p, vp, u64p, vp, u64p, C.POINTER(vp), u64p]
+        L.lf_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.lf_phase_name.restype = C.c_char_p
+        L.lf_phase_name.argtypes = [C.c_int]
+        L.lf_last_kernel_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def exported_symbols():
+    """Every symbol include/lfhip.h declares (used by the CPU-side ABI test)."""
+    import re
+    hdr = open(os.path.join(_HERE, "..", "include", "lfhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(lf_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def _a64(x):
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    return a, a.ctypes.data_as(u64p)
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise LfError(rc, where)
+
+
+class Context:
+    """Owns the device memory (lf_ctx).  One per GPU / process."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(_lib().lf_ctx_create(C.byref(self.h), device), "lf_ctx_create")
+        self.params = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib().lf_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ring tables -------------------------------------------------------------------
+    def set_ring_tables(self, nonres, y):
+        a, p = _a64(y)
+        _chk(_lib().lf_set_ring_tables(self.h, nonres, p), "lf_set_ring_tables")
+
+    def get_ring_tables(self):
+        nr = C.c_uint64()
+        y = np.zeros(24, dtype=np.uint64)
+        _chk(_lib().lf_get_ring_tables(self.h, C.cast(C.byref(nr), u64p), y.ctypes.data_as(u64p)), "lf_get_ring_tables")
+        return nr.value, y
+
+    def synchronize(self):
+        _chk(_lib().lf_device_synchronize(self.h), "lf_device_synchronize")
+
+    # ---- element-wise ops ----------------------------------------------------------------
+    def crt(self, coeff):  # CRT::elementwise_crt
+        a, p = _a64(coeff)
+        o = np.empty_like(a)
+        _chk(_lib().lf_ntt_fwd(self.h, p, o.ctypes.data_as(u64p), a.size // RE), "lf_ntt_fwd")
+        return o
+
+    def icrt(self, ntt):  # ICRT::elementwise_icrt
+        a, p = _a64(ntt)
+        o = np.empty_like(a)
+        _chk(_lib().lf_ntt_inv(self.h, p, o.ctypes.data_as(u64p), a.size // RE), "lf_ntt_inv")
+        return o
+
+    def decompose(self, coeff, base, digits, layout):
+        a, p = _a64(coeff)
+        cnt = a.size // RE
+        o = np.zeros((cnt * digits, RE), dtype=np.uint64)
+        _chk(_lib().lf_decompose(self.h, p, cnt, base, digits, layout, o.ctypes.data_as(u64p)), "lf_decompose")
+        return o
+
+    def recompose(self, x, base, digits):
+        a, p = _a64(x)
+        cnt = a.size // RE // digits
+        o = np.zeros((cnt, RE), dtype=np.uint64)
+        _chk(_lib().lf_recompose(self.h, p, cnt, base, digits, o.ctypes.data_as(u64p)), "lf_recompose")
+        return o
+
+    def linf_check(self, f_ntt, bound, unsigned_variant=False):
+        a, p = _a64(f_ntt)
+        ok = C.c_int()
+        mx = C.c_uint64()
+        _chk(_lib().lf_linf_check(self.h, p, a.size // RE, bound, int(unsigned_variant), C.byref(ok), C.cast(C.byref(mx), u64p)), "lf_linf_check")
+        return bool(ok.value), mx.value
+
+    def build_eq(self, point):
+        a, p = _a64(point)
+        nv = a.size // 3
+        o = np.zeros(((1 << nv), 3), dtype=np.uint64)
+        _chk(_lib().lf_build_eq(self.h, p, nv, o.ctypes.data_as(u64p)), "lf_build_eq")
+        return o
+
+    def evaluate_mles(self, tables, point):  # utils/mle_helpers.rs:65-88
+        a, p = _a64(tables)
+        nt, ln = a.shape[0], a.shape[1]
+        b, q = _a64(point)
+        o = np.zeros((nt, RE), dtype=np.uint64)
+        _chk(_lib().lf_mle_eval_batch(self.h, p, nt, ln, q, b.size // 3, o.ctypes.data_as(u64p)), "lf_mle_eval_batch")
+        return o
+
+    # ---- CCS -------------------------------------------------------------------------------
+    def load_ccs(self, wl):
+        """wl: latticefold_amd.workload.Workload (params + CSR matrices)."""
+        self.params = Params(wl.s, wl.wit_len, wl.l, wl.L, wl.K, wl.b, wl.B, wl.kappa, wl.t, wl.q, wl.d)
+        t = wl.t
+        rp = [np.ascontiguousarray(a, dtype=np.uint32) for a in wl.rowptr]
+        ci = [np.ascontiguousarray(a, dtype=np.uint32) for a in wl.col]
+        va = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1) for a in wl.val]
+        so = np.ascontiguousarray(wl.S_off, dtype=np.uint32)
+        si = np.ascontiguousarray(wl.S_idx, dtype=np.uint32)
+        cc = np.ascontiguousarray(wl.c, dtype=np.uint64).reshape(-1)
+        rpp = (u32p * t)(*[a.ctypes.data_as(u32p) for a in rp])
+        cip = (u32p * t)(*[a.ctypes.data_as(u32p) for a in ci])
+        vap = (u64p * t)(*[a.ctypes.data_as(u64p) for a in va])
+        _chk(_lib().lf_ccs_load(self.h, C.byref(self.params), C.cast(rpp, C.POINTER(u32p)), C.cast(cip, C.POINTER(u32p)),
+                                C.cast(vap, C.POINTER(u64p)), so.ctypes.data_as(u32p), si.ctypes.data_as(u32p),
+                                cc.ctypes.data_as(u64p)), "lf_ccs_load")
+        self.lcccs_len = _lib().lf_lcccs_len(C.byref(self.params))
+        self.cccs_len = _lib().lf_cccs_len(C.byref(self.params))
+        self.proof_len = _lib().lf_proof_len(C.byref(self.params))
+        self.N = wl.N
+        self.m = wl.m
+        self.n = wl.n
+
+    def mat_vec_mul(self, j, z):  # arith/utils.rs:52-65
+        a, p = _a64(z)
+        o = np.zeros((self.m, RE), dtype=np.uint64)
+        _chk(_lib().lf_spmv(self.h, j, p, o.ctypes.data_as(u64p)), "lf_spmv")
+        return o
+
+    def phase_ms(self):
+        out = (C.c_float * 8)()
+        _chk(_lib().lf_last_phase_ms(self.h, out), "lf_last_phase_ms")
+        return {_lib().lf_phase_name(i).decode(): float(out[i]) for i in range(8)}
+
+    def kernel_stats(self):
+        f, a = C.c_float(), C.c_float()
+        fn, an = C.c_int(), C.c_int()
+        _chk(_lib().lf_last_kernel_stats(self.h, C.byref(f), C.byref(fn), C.byref(a), C.byref(an)), "lf_last_kernel_stats")
+        return {"fold_round_ms": f.value, "fold_round_launches": fn.value, "ajtai_ms": a.value, "ajtai_launches": an.value}
+
+
+class AjtaiCommitmentScheme:
+    """commitment/commitment_scheme.rs:17-114.  The matrix lives on the device."""
+
+    def __init__(self, ctx, matrix=None, kappa=None, n=None, seed=None):
+        self.ctx = ctx
+        if matrix is not None:  # AjtaiCommitmentScheme::new
+            a, p = _a64(matrix)
+            self._kappa, self._n = a.shape[0], a.shape[1]
+            _chk(_lib().lf_ajtai_load(ctx.h, p, self._kappa, self._n), "lf_ajtai_load")
+        else:                    # synthetic i.i.d. matrix generated on the device (bench)
+            self._kappa, self._n = kappa, n
+            _chk(_lib().lf_ajtai_generate(ctx.h, seed, kappa, n), "lf_ajtai_generate")
+
+    def kappa(self):
+        return self._kappa
+
+    def width(self):
+        return self._n
+
+    def commit_ntt(self, f):
+        """commit / commit_ntt: f is (n,24) or (batch,n,24)."""
+        a, p = _a64(f)
+        batch = 1 if a.ndim == 2 else a.shape[0]
+        n = a.shape[-2]
+        o = np.zeros((batch, self._kappa, RE), dtype=np.uint64)
+        rc = _lib().lf_ajtai_commit(self.ctx.h, p, n, batch, o.ctypes.data_as(u64p))
+        if rc == -1:
+            raise CommitmentError(rc, f"WrongWitnessLength({n}, {self._n})")
+        _chk(rc, "lf_ajtai_commit")
+        return o[0] if a.ndim == 2 else o
+
+    commit = commit_ntt
+
+
+class Witness:
+    """arith.rs:213-362; device-resident (centred f_coeff planes)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @classmethod
+    def from_w_ccs(cls, ctx, w_ccs):
+        a, p = _a64(w_ccs)
+        h = C.c_void_p()
+        _chk(_lib().lf_witness_from_w_ccs(ctx.h, p, C.byref(h)), "lf_witness_from_w_ccs")
+        return cls(ctx, h)
+
+    @classmethod
+    def from_f_coeff(cls, ctx, f_coeff):
+        a, p = _a64(f_coeff)
+        h = C.c_void_p()
+        _chk(_lib().lf_witness_from_f_coeff(ctx.h, p, C.byref(h)), "lf_witness_from_f_coeff")
+        return cls(ctx, h)
+
+    @classmethod
+    def from_f(cls, ctx, f_ntt):
+        a, p = _a64(f_ntt)
+        h = C.c_void_p()
+        _chk(_lib().lf_witness_from_f(ctx.h, p, C.byref(h)), "lf_witness_from_f")
+        return cls(ctx, h)
+
+    def _get(self, fn, count):
+        o = np.zeros((count, RE), dtype=np.uint64)
+        _chk(fn(self.ctx.h, self.h, o.ctypes.data_as(u64p)), "lf_witness_get")
+        return o
+
+    @property
+    def f_coeff(self):
+        return self._get(_lib().lf_witness_get_f_coeff, self.ctx.N)
+
+    @property
+    def f(self):
+        return self._get(_lib().lf_witness_get_f, self.ctx.N)
+
+    @property
+    def w_ccs(self):
+        return self._get(_lib().lf_witness_get_w_ccs, self.ctx.params.wit_len)
+
+    def commit(self, scheme):
+        o = np.zeros((scheme.kappa(), RE), dtype=np.uint64)
+        _chk(_lib().lf_witness_commit(self.ctx.h, self.h, o.ctypes.data_as(u64p)), "lf_witness_commit")
+        return o
+
+    def free(self):
+        if self.h:
+            _lib().lf_witness_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PoseidonTranscript:
+    """transcript/poseidon.rs:17-75 (host)."""
+
+    def __init__(self, handle=None):
+        self.h = handle or C.c_void_p(_lib().lf_transcript_new())
+
+    def clone(self):
+        return PoseidonTranscript(C.c_void_p(_lib().lf_transcript_clone(self.h)))
+
+    def absorb_fq(self, xs):
+        a, p = _a64(xs)
+        _lib().lf_transcript_absorb_fq(self.h, p, a.size)
+
+    def absorb_slice(self, elems):
+        a, p = _a64(elems)
+        _lib().lf_transcript_absorb_ring(self.h, p, a.size // RE)
+
+    absorb = absorb_slice
+
+    def get_challenge(self):
+        o = np.zeros(3, dtype=np.uint64)
+        _lib().lf_transcript_get_challenge(self.h, o.ctypes.data_as(u64p))
+        return o
+
+    def get_short_challenge(self):
+        o = np.zeros(RE, dtype=np.uint64)
+        _lib().lf_transcript_get_short_challenge(self.h, o.ctypes.data_as(u64p))
+        return o
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib().lf_transcript_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def poseidon_params():
+    ark = np.zeros(720, dtype=np.uint64)
+    mds = np.zeros(576, dtype=np.uint64)
+    _lib().lf_poseidon_params(ark.ctypes.data_as(u64p), mds.ctypes.data_as(u64p))
+    return ark, mds
+
+
+class LFLinearizationProver:
+    @staticmethod
+    def prove(ctx, cm_i, wit, transcript):
+        """nifs/linearization.rs:145-189 -> (lcccs flat, linearization proof flat)."""
+        a, p = _a64(cm_i)
+        lc = np.zeros((ctx.lcccs_len, RE), dtype=np.uint64)
+        prm = ctx.params
+        pr = np.zeros((prm.s * (prm.d + 2) + 3 + prm.t, RE), dtype=np.uint64)
+        _chk(_lib().lf_linearize(ctx.h, transcript.h, p, wit.h, lc.ctypes.data_as(u64p), pr.ctypes.data_as(u64p)), "lf_linearize")
+        return lc, pr
+
+
+class NIFSProver:
+    @staticmethod
+    def prove(ctx, acc, w_acc, cm_i, w_i, transcript):
+        """nifs.rs:48-103 -> (folded LCCCS flat, folded Witness, LFProof flat).  `ccs` and `scheme` of the
+        reference signature are the ones loaded into ctx (load_ccs / AjtaiCommitmentScheme)."""
+        a, pa = _a64(acc)
+        b, pb = _a64(cm_i)
+        lc = np.zeros((ctx.lcccs_len, RE), dtype=np.uint64)
+        pr = np.zeros((ctx.proof_len, RE), dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(_lib().lf_fold_step(ctx.h, transcript.h, pa, w_acc.h, pb, w_i.h, lc.ctypes.data_as(u64p), C.byref(h),
+                                 pr.ctypes.data_as(u64p)), "lf_fold_step")
+        return lc, Witness(ctx, h), pr

@@ -1,0 +1,1256 @@
+// lf_capi.cpp -- context, device-resident witnesses, the host driver that replays
+// `NIFSProver::prove` (crates/latticefold/src/nifs.rs:48-103) on the GPU kernels, and the C ABI (include/lfhip.h).
+//
+// Host <-> device traffic inside a fold step is O(proof size): per sumcheck round (D+1) ring elements come back
+// and one F_{p^3} challenge goes down; everything of size N stays in HBM.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lfhip.h"
+#include "lf_kernels.h"
+
+using namespace lf;
+
+namespace lf {
+void launch_fix_many(const DevCrt &t, const u64 *in, size_t ld_in, u64 *out, size_t ld_out, size_t n_in, u32 rows3, Fq3Const r, hipStream_t s);
+}
+
+#define HIPCHK(x)                                    \
+    do {                                             \
+        hipError_t e__ = (x);                        \
+        if (e__ != hipSuccess) return LF_ERR_HIP;    \
+    } while (0)
+#define RET(x)                      \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != LF_OK) return rc__; \
+    } while (0)
+
+#include <stdio.h>
+#include <stdlib.h>
+static bool lf_trace_on() { static int v = -1; if (v < 0) v = getenv("LF_TRACE") ? 1 : 0; return v == 1; }
+#define LF_TRACE(c, msg)                                                              \
+    do {                                                                              \
+        if (lf_trace_on()) {                                                          \
+            hipError_t e_ = hipStreamSynchronize((c)->st);                            \
+            fprintf(stderr, "[lf] %s:%d %s -> %s\n", __func__, __LINE__, msg, hipGetErrorString(e_)); \
+            fflush(stderr);                                                           \
+        }                                                                             \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t b) {
+        if (b <= bytes) return LF_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = b + (b >> 3) + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            if (hipMalloc(&p, b) != hipSuccess) return LF_ERR_HIP;
+            want = b;
+        }
+        bytes = want;
+        return LF_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct lf_witness {
+    lf_ctx *ctx;
+    int32_t *planes;  // [24][N] centred coefficients
+    size_t N;
+};
+struct lf_transcript {
+    Transcript t;
+};
+
+static const char *PHASE_NAMES[LF_N_PHASES] = {"linearization", "decomp_crt_commit", "decomp_evals", "fold_prepare",
+                                                "fold_sumcheck", "fold_finish", "host_transcript", "total"};
+
+struct EvPair { hipEvent_t a, b; };
+
+struct lf_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::mutex mu;
+    HostRing ring;
+    DevCrt dcrt;
+    u64 *d_icrt = nullptr;
+    // Ajtai
+    u64 *dA = nullptr;
+    u32 kappa = 0;
+    size_t nA = 0;
+    // CCS
+    bool have_ccs = false;
+    lf_params P{};
+    size_t N = 0, m = 0, n = 0;
+    std::vector<u32 *> d_rowptr, d_col, d_colptr, d_rowidx;
+    std::vector<u64 *> d_val, d_valT;
+    LinCombDesc desc{};
+    std::map<std::string, DevBuf> bufs;
+    u64 *h_pin = nullptr;
+    size_t h_pin_words = 0;
+    // lin sumcheck ABI state
+    int sc_round = -1;
+    size_t sc_n = 0;
+    int sc_cur = 0;
+    // measurement
+    float phase_ms[LF_N_PHASES] = {0};
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<int, size_t>> ev_tags;  // (tag, event index)
+    float k_fold_ms = 0, k_ajtai_ms = 0;
+    int k_fold_n = 0, k_ajtai_n = 0;
+    double host_tr_ms = 0;
+
+    int buf(const std::string &name, size_t bytes, void **out) {
+        DevBuf &b = bufs[name];
+        int rc = b.ensure(bytes);
+        *out = b.p;
+        return rc;
+    }
+    template <class T>
+    int tbuf(const std::string &name, size_t count, T **out) {
+        void *p;
+        int rc = buf(name, count * sizeof(T), &p);
+        *out = (T *)p;
+        return rc;
+    }
+    int pin(size_t words) {
+        if (words <= h_pin_words) return LF_OK;
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr;
+        if (hipHostMalloc((void **)&h_pin, words * 8) != hipSuccess) return LF_ERR_HIP;
+        h_pin_words = words;
+        return LF_OK;
+    }
+    // timed-launch helpers: tag 0 = fold round kernels, 1 = ajtai, 10+i = phase i
+    size_t ev_begin(int tag) {
+        if (ev_used == ev_pool.size()) {
+            EvPair e;
+            (void)hipEventCreate(&e.a);
+            (void)hipEventCreate(&e.b);
+            ev_pool.push_back(e);
+        }
+        size_t i = ev_used++;
+        (void)hipEventRecord(ev_pool[i].a, st);
+        ev_tags.push_back({tag, i});
+        return i;
+    }
+    void ev_end(size_t i) { (void)hipEventRecord(ev_pool[i].b, st); }
+    void ev_reset() {
+        ev_used = 0;
+        ev_tags.clear();
+    }
+    void ev_collect() {
+        (void)hipStreamSynchronize(st);
+        k_fold_ms = k_ajtai_ms = 0;
+        k_fold_n = k_ajtai_n = 0;
+        for (int i = 0; i < LF_N_PHASES; i++) phase_ms[i] = 0;
+        for (auto &tg : ev_tags) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev_pool[tg.second].a, ev_pool[tg.second].b);
+            if (tg.first == 0) { k_fold_ms += ms; k_fold_n++; }
+            else if (tg.first == 1) { k_ajtai_ms += ms; k_ajtai_n++; }
+            else if (tg.first >= 10 && tg.first < 10 + LF_N_PHASES) phase_ms[tg.first - 10] += ms;
+        }
+        phase_ms[6] = (float)host_tr_ms;
+    }
+};
+
+const char *lf_strerror(int code) {
+    switch (code) {
+        case LF_OK: return "ok";
+        case LF_ERR_INVALID: return "invalid argument / wrong length";
+        case LF_ERR_HIP: return "HIP runtime error (no GPU or out of device memory)";
+        case LF_ERR_UNSUPPORTED: return "unsupported parameter";
+        case LF_ERR_BAD_TABLES: return "ring tables are not a ring isomorphism";
+        case LF_ERR_NORM: return "witness coefficient exceeds the decomposition bound";
+        case LF_ERR_SIZE_BOUNDS: return "invalid size bounds (m must be >= wit_len*L, power of two)";
+        case LF_ERR_STATE: return "call sequence misuse";
+    }
+    return "unknown error";
+}
+const char *lf_phase_name(int i) { return (i >= 0 && i < LF_N_PHASES) ? PHASE_NAMES[i] : ""; }
+
+// ---------------------------------------------------------------------------------------------------------------
+static int install_tables(lf_ctx *c, u64 nonres, const u64 *y) {
+    CrtTables T;
+    if (build_crt_tables(nonres, y, T) != 0) return LF_ERR_BAD_TABLES;
+    c->ring.T = T;
+    c->dcrt = make_dev_crt(T);
+    if (!c->d_icrt) HIPCHK(hipMalloc((void **)&c->d_icrt, 576 * 8));
+    HIPCHK(hipMemcpy(c->d_icrt, &T.icrt[0][0], 576 * 8, hipMemcpyHostToDevice));
+    return LF_OK;
+}
+
+int lf_ctx_create(lf_ctx **out, int device) {
+    if (!out) return LF_ERR_INVALID;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device < 0 || device >= cnt) return LF_ERR_HIP;
+    HIPCHK(hipSetDevice(device));
+    lf_ctx *c = new lf_ctx();
+    c->device = device;
+    if (hipStreamCreate(&c->st) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    u64 nr, y[24];
+    default_ring(&nr, y);
+    int rc = install_tables(c, nr, y);
+    if (rc != LF_OK) { delete c; return rc; }
+    *out = c;
+    return LF_OK;
+}
+static void free_ccs(lf_ctx *c) {
+    for (auto p : c->d_rowptr) (void)hipFree(p);
+    for (auto p : c->d_col) (void)hipFree(p);
+    for (auto p : c->d_val) (void)hipFree(p);
+    for (auto p : c->d_colptr) (void)hipFree(p);
+    for (auto p : c->d_rowidx) (void)hipFree(p);
+    for (auto p : c->d_valT) (void)hipFree(p);
+    c->d_rowptr.clear(); c->d_col.clear(); c->d_val.clear(); c->d_colptr.clear(); c->d_rowidx.clear(); c->d_valT.clear();
+    c->have_ccs = false;
+}
+void lf_ctx_destroy(lf_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    free_ccs(c);
+    for (auto &kv : c->bufs) kv.second.release();
+    if (c->dA) (void)hipFree(c->dA);
+    if (c->d_icrt) (void)hipFree(c->d_icrt);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    (void)hipStreamDestroy(c->st);
+    delete c;
+}
+int lf_set_ring_tables(lf_ctx *c, uint64_t nonres, const uint64_t *y) {
+    if (!c || !y) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return install_tables(c, nonres, y);
+}
+int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
+    if (!c || !nonres || !y) return LF_ERR_INVALID;
+    *nonres = c->ring.T.nu;
+    for (int k = 0; k < 8; k++)
+        for (int q = 0; q < 3; q++) y[3 * k + q] = c->ring.T.y[k].c[q];
+    return LF_OK;
+}
+int lf_device_synchronize(lf_ctx *c) {
+    if (!c) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return LF_OK;
+}
+
+// ---- host<->device staging of AoS ring-element arrays ----------------------------------------------------------
+// upload n ring elements (AoS) into a plane table dst [24][n]
+static int up_ring(lf_ctx *c, const u64 *host, size_t n, u64 *dst) {
+    if (!n) return LF_OK;
+    u64 *tmp;
+    RET(c->tbuf("stage_aos", n * 24, &tmp));
+    HIPCHK(hipMemcpyAsync(tmp, host, n * 24 * 8, hipMemcpyHostToDevice, c->st));
+    launch_aos_to_soa(tmp, dst, n, c->st);
+    return LF_OK;
+}
+static int down_ring(lf_ctx *c, const u64 *src, size_t n, u64 *host) {
+    if (!n) return LF_OK;
+    u64 *tmp;
+    RET(c->tbuf("stage_aos", n * 24, &tmp));
+    launch_soa_to_aos(src, tmp, n, c->st);
+    HIPCHK(hipMemcpyAsync(host, tmp, n * 24 * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return LF_OK;
+}
+// small device array -> host (through pinned memory)
+static int down_small(lf_ctx *c, const u64 *dsrc, size_t words, u64 *host) {
+    RET(c->pin(words));
+    HIPCHK(hipMemcpyAsync(c->h_pin, dsrc, words * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    memcpy(host, c->h_pin, words * 8);
+    return LF_OK;
+}
+static Fq3Const f3c(Fq3 a) { Fq3Const r; r.c[0] = a.c[0]; r.c[1] = a.c[1]; r.c[2] = a.c[2]; return r; }
+
+// ---- a1/a2 --------------------------------------------------------------------------------------------------------
+int lf_ntt_fwd(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
+    if (!c || (!in && count) || (!out && count)) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *a, *b;
+    RET(c->tbuf("io_a", count * 24, &a));
+    RET(c->tbuf("io_b", count * 24, &b));
+    RET(up_ring(c, in, count, a));
+    launch_crt_fwd(c->dcrt, a, b, count, c->st);
+    return down_ring(c, b, count, out);
+}
+int lf_ntt_inv(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
+    if (!c || (!in && count) || (!out && count)) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *a, *b;
+    RET(c->tbuf("io_a", count * 24, &a));
+    RET(c->tbuf("io_b", count * 24, &b));
+    RET(up_ring(c, in, count, a));
+    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    return down_ring(c, b, count, out);
+}
+static bool pow2(u64 b) { return b >= 2 && (b & (b - 1)) == 0; }
+int lf_decompose(lf_ctx *c, const uint64_t *in, size_t count, uint64_t base, unsigned digits, int layout, uint64_t *out) {
+    if (!c || !in || !out || digits == 0 || digits > 64 || (layout != 0 && layout != 1)) return LF_ERR_INVALID;
+    if (!pow2(base)) return LF_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *a, *b;
+    RET(c->tbuf("io_a", count * 24, &a));
+    RET(c->tbuf("io_b", count * digits * 24, &b));
+    RET(up_ring(c, in, count, a));
+    launch_decompose(a, count, base, digits, layout, b, c->st);
+    if (layout == 0) return down_ring(c, b, count * digits, out);
+    for (unsigned k = 0; k < digits; k++) RET(down_ring(c, b + (size_t)k * 24 * count, count, out + (size_t)k * count * 24));
+    return LF_OK;
+}
+int lf_recompose(lf_ctx *c, const uint64_t *in, size_t count_out, uint64_t base, unsigned digits, uint64_t *out) {
+    if (!c || !in || !out || digits == 0) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *a, *b;
+    RET(c->tbuf("io_a", count_out * digits * 24, &a));
+    RET(c->tbuf("io_b", count_out * 24, &b));
+    RET(up_ring(c, in, count_out * digits, a));
+    launch_recompose(a, count_out, base, digits, b, c->st);
+    return down_ring(c, b, count_out, out);
+}
+int lf_linf_check(lf_ctx *c, const uint64_t *f_ntt, size_t count, uint64_t bound, int unsigned_variant, int *ok, uint64_t *max_out) {
+    if (!c || !f_ntt || !ok) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *a, *b, *mx;
+    RET(c->tbuf("io_a", count * 24, &a));
+    RET(c->tbuf("io_b", count * 24, &b));
+    RET(c->tbuf("small_dev", 4096, &mx));
+    RET(up_ring(c, f_ntt, count, a));
+    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    if (unsigned_variant) {
+        // literal Witness::within_bound: canonical coefficient < bound  <=>  max canonical < bound; reuse the
+        // centred kernel on a table where "negative" values are impossible: compare canonical values on host
+        // through a max reduction of min(v, p-1-v)?  Not equivalent -- do it exactly: download max canonical.
+        std::vector<u64> h(count * 24);
+        HIPCHK(hipMemcpyAsync(h.data(), b, count * 24 * 8, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(hipStreamSynchronize(c->st));
+        u64 m = 0;
+        for (u64 v : h) m = v > m ? v : m;
+        if (max_out) *max_out = m;
+        *ok = m < bound;
+        return LF_OK;
+    }
+    launch_linf(b, count, mx, c->st);
+    u64 m = 0;
+    RET(down_small(c, mx, 1, &m));
+    if (max_out) *max_out = m;
+    *ok = m < bound;
+    return LF_OK;
+}
+
+// ---- a5 -----------------------------------------------------------------------------------------------------------
+int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
+    if (!c || !A || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * 24 * 8));
+    for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + i * n * 24, n, c->dA + i * 24 * n));
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->kappa = (u32)kappa;
+    c->nA = n;
+    return LF_OK;
+}
+int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
+    if (!c || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * 24 * 8));
+    launch_fill_ajtai(c->dA, (u32)kappa, n, seed, c->st);
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->kappa = (u32)kappa;
+    c->nA = n;
+    return LF_OK;
+}
+static u32 ajtai_splits(size_t n) {
+    // one block per (split, slot); aim for >= 4 blocks per CU, each split a multiple of the LDS tile
+    size_t s = n / 256;
+    if (s < 1) s = 1;
+    if (s > 128) s = 128;
+    return (u32)s;
+}
+// F: [batch][24][n] device; out_dev: [batch][kappa][24] device AoS
+static int commit_dev(lf_ctx *c, const u64 *F, u32 batch, u64 *out_dev, bool timed) {
+    u32 maxb = 512 / c->kappa;
+    if (maxb > 64 - c->kappa) maxb = 64 - c->kappa;
+    if (maxb < 1) return LF_ERR_UNSUPPORTED;
+    u32 splits = ajtai_splits(c->nA);
+    u64 *partial;
+    RET(c->tbuf("ajtai_partial", ajtai_partial_words(c->kappa, maxb, splits), &partial));
+    for (u32 b0 = 0; b0 < batch; b0 += maxb) {
+        u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
+        size_t ev = timed ? c->ev_begin(1) : 0;
+        launch_ajtai(c->dcrt, c->dA, c->kappa, c->nA, F + (size_t)b0 * 24 * c->nA, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * 24, c->st);
+        if (timed) c->ev_end(ev);
+    }
+    return LF_OK;
+}
+int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
+    if (!c || !f || !out || !batch) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->dA) return LF_ERR_STATE;
+    if (n != c->nA) return LF_ERR_INVALID;  // CommitmentError::WrongWitnessLength(n, width)
+    HIPCHK(hipSetDevice(c->device));
+    u64 *F, *o;
+    RET(c->tbuf("io_a", batch * n * 24, &F));
+    RET(c->tbuf("io_b", batch * c->kappa * 24, &o));
+    for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * 24, n, F + b * 24 * n));
+    RET(commit_dev(c, F, (u32)batch, o, false));
+    return down_small(c, o, batch * c->kappa * 24, out);
+}
+
+// ---- a8/a9/a11 ------------------------------------------------------------------------------------------------------
+static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {
+    Fq3Const *rd;
+    RET(c->tbuf("eq_point", 64, &rd));
+    std::vector<Fq3Const> h(nv);
+    for (u32 i = 0; i < nv; i++) h[i] = f3c(pt[i]);
+    HIPCHK(hipMemcpyAsync(rd, h.data(), nv * sizeof(Fq3Const), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));  // h is a stack-lifetime buffer
+    launch_build_eq(c->dcrt, rd, nv, eq_dev, c->st);
+    return LF_OK;
+}
+int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {
+    if (!c || !point || !out || nv == 0 || nv > 40) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    size_t n = (size_t)1 << nv;
+    u64 *eq;
+    RET(c->tbuf("io_a", 3 * n, &eq));
+    std::vector<Fq3> pt(nv);
+    for (unsigned i = 0; i < nv; i++) pt[i] = fq3_make(point[3 * i], point[3 * i + 1], point[3 * i + 2]);
+    RET(build_eq_dev(c, pt.data(), nv, eq));
+    std::vector<u64> h(3 * n);
+    HIPCHK(hipMemcpyAsync(h.data(), eq, 3 * n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (size_t i = 0; i < n; i++)
+        for (int q = 0; q < 3; q++) out[3 * i + q] = h[(size_t)q * n + i];
+    return LF_OK;
+}
+int lf_mle_eval_batch(lf_ctx *c, const uint64_t *tables, size_t ntables, size_t len, const uint64_t *point, unsigned nv, uint64_t *out) {
+    if (!c || !tables || !point || !out || !ntables || nv == 0 || nv > 40) return LF_ERR_INVALID;
+    size_t n = (size_t)1 << nv;
+    if (len > n || len == 0) return LF_ERR_INVALID;  // MleEvaluationError::IncorrectLength
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *eq, *X, *partial, *o;
+    RET(c->tbuf("io_eq", 3 * n, &eq));
+    RET(c->tbuf("io_a", ntables * len * 24, &X));
+    RET(c->tbuf("red_partial", 256 * (ntables * 24 > 4096 ? ntables * 24 : 4096), &partial));
+    RET(c->tbuf("io_b", ntables * 24, &o));
+    std::vector<Fq3> pt(nv);
+    for (unsigned i = 0; i < nv; i++) pt[i] = fq3_make(point[3 * i], point[3 * i + 1], point[3 * i + 2]);
+    RET(build_eq_dev(c, pt.data(), nv, eq));
+    for (size_t a = 0; a < ntables; a++) RET(up_ring(c, tables + a * len * 24, len, X + a * 24 * len));
+    launch_dot_eq(c->dcrt, X, len, (u32)ntables, eq, n, len, partial, o, c->st);
+    return down_small(c, o, ntables * 24, out);
+}
+
+// ---- CCS -------------------------------------------------------------------------------------------------------------
+size_t lf_lcccs_len(const lf_params *p) { return (size_t)p->s + 3 + p->kappa + p->t + p->l + 1; }
+size_t lf_cccs_len(const lf_params *p) { return (size_t)p->kappa + p->l; }
+static size_t lin_proof_len(const lf_params *p) { return (size_t)p->s * (p->d + 2) + 3 + p->t; }
+static size_t dec_proof_len(const lf_params *p) { return (size_t)p->K * (p->t + 3 + p->l + 1 + p->kappa); }
+static size_t fold_proof_len(const lf_params *p) { return (size_t)p->s * (2 * p->b + 1) + 2 * (size_t)p->K * (3 + p->t); }
+size_t lf_proof_len(const lf_params *p) { return lin_proof_len(p) + 2 * dec_proof_len(p) + fold_proof_len(p); }
+
+int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
+                const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *cc) {
+    if (!c || !p || !rowptr || !col || !val || !S_off || !S_idx || !cc) return LF_ERR_INVALID;
+    if (p->s == 0 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 16 || p->L == 0 || p->L > 8 ||
+        p->d + 1 > 4 || p->wit_len == 0)
+        return LF_ERR_UNSUPPORTED;
+    if (p->b != 2) return LF_ERR_UNSUPPORTED;  // folding comb is specialised to b = 2 (all reference Goldilocks rows)
+    if (!pow2(p->B) || p->B > (1ULL << 31)) return LF_ERR_UNSUPPORTED;
+    {   // K base-2 digits must cover |coeff| <= B/2
+        u64 half = p->B / 2;
+        u32 need = 0;
+        while ((half >> need) != 0) need++;
+        if (need > p->K) return LF_ERR_UNSUPPORTED;
+    }
+    size_t m = (size_t)1 << p->s, N = (size_t)p->wit_len * p->L, n = (size_t)p->l + 1 + p->wit_len;
+    if (N > m) return LF_ERR_SIZE_BOUNDS;  // sanity_check, nifs.rs:165-173
+    // the reference indexes comb values by matrix index: multisets must concatenate to 0..t-1
+    {
+        u32 next = 0;
+        for (u32 i = 0; i < p->q; i++)
+            for (u32 k = S_off[i]; k < S_off[i + 1]; k++)
+                if (S_idx[k] != next++) return LF_ERR_UNSUPPORTED;
+        if (next != p->t || S_off[p->q] > 16) return LF_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    free_ccs(c);
+    c->P = *p; c->N = N; c->m = m; c->n = n;
+    memset(&c->desc, 0, sizeof(c->desc));
+    c->desc.t = p->t; c->desc.q = p->q;
+    for (u32 i = 0; i <= p->q; i++) c->desc.S_off[i] = S_off[i];
+    for (u32 k = 0; k < S_off[p->q]; k++) c->desc.S_idx[k] = S_idx[k];
+    for (u32 i = 0; i < p->q; i++) memcpy(c->desc.c[i], cc + (size_t)i * 24, 24 * 8);
+    for (u32 j = 0; j < p->t; j++) {
+        size_t nnz = rowptr[j][m];
+        for (size_t k = 0; k < nnz; k++)
+            if (col[j][k] >= n) return LF_ERR_INVALID;
+        u32 *drp, *dci, *dcp, *dri;
+        u64 *dv, *dvT;
+        HIPCHK(hipMalloc((void **)&drp, (m + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dci, (nnz + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dv, (nnz + 1) * 24 * 8));
+        HIPCHK(hipMemcpy(drp, rowptr[j], (m + 1) * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dci, col[j], nnz * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dv, val[j], nnz * 24 * 8, hipMemcpyHostToDevice));
+        // CSC
+        std::vector<u32> cp(n + 1, 0), ri(nnz);
+        std::vector<u64> vT(nnz * 24);
+        for (size_t k = 0; k < nnz; k++) cp[col[j][k] + 1]++;
+        for (size_t i = 0; i < n; i++) cp[i + 1] += cp[i];
+        std::vector<u32> fill(cp.begin(), cp.end() - 1);
+        for (size_t r = 0; r < m; r++)
+            for (u32 k = rowptr[j][r]; k < rowptr[j][r + 1]; k++) {
+                u32 pos = fill[col[j][k]]++;
+                ri[pos] = (u32)r;
+                memcpy(&vT[(size_t)pos * 24], val[j] + (size_t)k * 24, 24 * 8);
+            }
+        HIPCHK(hipMalloc((void **)&dcp, (n + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dri, (nnz + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dvT, (nnz + 1) * 24 * 8));
+        HIPCHK(hipMemcpy(dcp, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dri, ri.data(), nnz * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dvT, vT.data(), nnz * 24 * 8, hipMemcpyHostToDevice));
+        c->d_rowptr.push_back(drp); c->d_col.push_back(dci); c->d_val.push_back(dv);
+        c->d_colptr.push_back(dcp); c->d_rowidx.push_back(dri); c->d_valT.push_back(dvT);
+    }
+    c->have_ccs = true;
+    return LF_OK;
+}
+int lf_spmv(lf_ctx *c, unsigned j, const uint64_t *z, uint64_t *out) {
+    if (!c || !z || !out) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    if (j >= c->P.t) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    u64 *zd, *od;
+    RET(c->tbuf("io_a", c->n * 24, &zd));
+    RET(c->tbuf("io_b", c->m * 24, &od));
+    RET(up_ring(c, z, c->n, zd));
+    launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], zd, c->n, od, c->m, 0, c->st);
+    return down_ring(c, od, c->m, out);
+}
+
+// ---- witnesses ---------------------------------------------------------------------------------------------------------
+static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] canonical */, lf_witness **out) {
+    int32_t *pl;
+    HIPCHK(hipMalloc((void **)&pl, c->N * 24 * 4));
+    int *viol;
+    if (c->tbuf("small_dev", 4096, (u64 **)&viol) != LF_OK) { (void)hipFree(pl); return LF_ERR_HIP; }
+    (void)hipMemsetAsync(viol, 0, 4, c->st);
+    launch_coef_to_i32(coef_dev, pl, c->N, (u32)(c->P.B / 2), viol, c->st);
+    int hv = 0;
+    if (hipMemcpyAsync(&hv, viol, 4, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) {
+        (void)hipFree(pl);
+        return LF_ERR_HIP;
+    }
+    if (hv) { (void)hipFree(pl); return LF_ERR_NORM; }
+    lf_witness *w = new lf_witness{c, pl, c->N};
+    *out = w;
+    return LF_OK;
+}
+int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
+    if (!c || !w_ccs || !out) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    // Witness::from_w_ccs, arith.rs:230-248: ICRT -> gadget_decompose(B, L)
+    u64 *a, *b, *d;
+    RET(c->tbuf("io_a", (size_t)c->P.wit_len * 24, &a));
+    RET(c->tbuf("io_b", (size_t)c->P.wit_len * 24, &b));
+    RET(c->tbuf("io_c", c->N * 24, &d));
+    RET(up_ring(c, w_ccs, c->P.wit_len, a));
+    launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->st);
+    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->st);
+    return witness_from_coef_table(c, d, out);
+}
+int lf_witness_from_f_coeff(lf_ctx *c, const uint64_t *f_coeff, lf_witness **out) {
+    if (!c || !f_coeff || !out) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    u64 *d;
+    RET(c->tbuf("io_c", c->N * 24, &d));
+    RET(up_ring(c, f_coeff, c->N, d));
+    return witness_from_coef_table(c, d, out);
+}
+int lf_witness_from_f(lf_ctx *c, const uint64_t *f_ntt, lf_witness **out) {
+    if (!c || !f_ntt || !out) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    u64 *a, *d;
+    RET(c->tbuf("io_a", c->N * 24, &a));
+    RET(c->tbuf("io_c", c->N * 24, &d));
+    RET(up_ring(c, f_ntt, c->N, a));
+    launch_icrt_dense(c->d_icrt, a, d, c->N, c->st);
+    return witness_from_coef_table(c, d, out);
+}
+int lf_witness_get_f_coeff(lf_ctx *c, const lf_witness *w, uint64_t *out) {
+    if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *d;
+    RET(c->tbuf("io_c", w->N * 24, &d));
+    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    return down_ring(c, d, w->N, out);
+}
+int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
+    if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *d, *e;
+    RET(c->tbuf("io_c", w->N * 24, &d));
+    RET(c->tbuf("io_b", w->N * 24, &e));
+    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    launch_crt_fwd(c->dcrt, d, e, w->N, c->st);
+    return down_ring(c, e, w->N, out);
+}
+int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
+    if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    u64 *e;
+    RET(c->tbuf("io_b", (size_t)c->P.wit_len * 24, &e));
+    launch_recompose_crt(c->dcrt, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->st);
+    return down_ring(c, e, c->P.wit_len, out);
+}
+int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
+    if (!c || !w || !cm_out || w->ctx != c) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->dA) return LF_ERR_STATE;
+    if (w->N != c->nA) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    u64 *d, *e, *o;
+    RET(c->tbuf("io_c", w->N * 24, &d));
+    RET(c->tbuf("io_b", w->N * 24, &e));
+    RET(c->tbuf("io_o", (size_t)c->kappa * 24, &o));
+    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    launch_crt_fwd(c->dcrt, d, e, w->N, c->st);
+    RET(commit_dev(c, e, 1, o, false));
+    return down_small(c, o, (size_t)c->kappa * 24, cm_out);
+}
+void lf_witness_free(lf_witness *w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipFree(w->planes);
+    delete w;
+}
+
+// ---- transcript ------------------------------------------------------------------------------------------------------------
+lf_transcript *lf_transcript_new(void) { return new lf_transcript(); }
+lf_transcript *lf_transcript_clone(const lf_transcript *t) { return t ? new lf_transcript(*t) : nullptr; }
+void lf_transcript_free(lf_transcript *t) { delete t; }
+void lf_transcript_absorb_fq(lf_transcript *t, const uint64_t *x, size_t n) { t->t.absorb_fq(x, n); }
+void lf_transcript_absorb_ring(lf_transcript *t, const uint64_t *e, size_t n) { t->t.absorb_ring(e, n); }
+void lf_transcript_get_challenge(lf_transcript *t, uint64_t *o) {
+    Fq3 c = t->t.get_challenge();
+    o[0] = c.c[0]; o[1] = c.c[1]; o[2] = c.c[2];
+}
+void lf_transcript_get_short_challenge(lf_transcript *t, uint64_t *o) { t->t.get_short_challenge(o); }
+void lf_poseidon_params(uint64_t *ark, uint64_t *mds) {
+    const u64 *a, *m;
+    Transcript::params(&a, &m);
+    memcpy(ark, a, 720 * 8);
+    memcpy(mds, m, 576 * 8);
+}
+
+// =================================================================================================================================
+// the driver
+struct HostTimer {
+    lf_ctx *c;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(lf_ctx *cc) : c(cc), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { c->host_tr_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// sumcheck transcript prologue: absorb R::from(nvars), R::from(degree)  (utils/sumcheck.rs:60-62)
+static void sc_prologue(Transcript &tr, u32 nv, u32 deg) {
+    tr.absorb_u64_as_ring(nv);
+    tr.absorb_u64_as_ring(deg);
+}
+static Fq3 sc_round_transcript(Transcript &tr, const u64 *evals, u32 npts) {
+    tr.absorb_ring(evals, npts);
+    Fq3 r = tr.get_challenge();
+    tr.absorb_fq3_as_ring(r);
+    return r;
+}
+
+// linearization sumcheck on device tables mz [t][24][m] (left intact) and eq_beta [3][m]
+static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 *eqb, u64 *msgs /* s*(d+2) ring */, Fq3 *point) {
+    const lf_params &P = c->P;
+    u32 deg = P.d + 1;
+    size_t m = c->m;
+    u64 *fx[2], *fe[2], *partial, *od;
+    RET(c->tbuf("lin_fix0", (size_t)P.t * 24 * (m / 2), &fx[0]));
+    RET(c->tbuf("lin_fix1", (size_t)P.t * 24 * (m / 4 ? m / 4 : 1), &fx[1]));
+    RET(c->tbuf("lin_efix0", 3 * (m / 2), &fe[0]));
+    RET(c->tbuf("lin_efix1", 3 * (m / 4 ? m / 4 : 1), &fe[1]));
+    RET(c->tbuf("round_partial", round_partial_words(), &partial));
+    RET(c->tbuf("round_out", 5 * 24, &od));
+    { HostTimer ht(c); sc_prologue(tr, P.s, deg); }
+    const u64 *cur = mz, *cure = eqb;
+    size_t n = m;
+    int flip = 0;
+    for (u32 round = 1; round <= P.s; round++) {
+        if (round > 1) {
+            Fq3Const r = f3c(point[round - 2]);
+            launch_fix_many(c->dcrt, cur, n, fx[flip], n / 2, n, P.t * 8, r, c->st);
+            launch_fix_many(c->dcrt, cure, n, fe[flip], n / 2, n, 1, r, c->st);
+            cur = fx[flip]; cure = fe[flip];
+            flip ^= 1;
+            n /= 2;
+        }
+        launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->st);
+        u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * 24;
+        RET(down_small(c, od, (size_t)(deg + 1) * 24, ev));
+        HostTimer ht(c);
+        point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
+    }
+    return LF_OK;
+}
+
+// z = head (x.. , h) || w where w comes from the planes; K = 1 & mode 0 for the full witness
+static int build_z(lf_ctx *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads /* K*(l+1) ring AoS host */, u64 *z /* [K][24][n] */) {
+    const lf_params &P = c->P;
+    u32 hl = P.l + 1;
+    launch_recompose_crt(c->dcrt, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->st);
+    // heads: write plane entries 0..l of each table
+    std::vector<u64> h((size_t)K * 24 * hl);
+    for (u32 k = 0; k < K; k++)
+        for (u32 i = 0; i < hl; i++)
+            for (int w = 0; w < 24; w++) h[((size_t)k * 24 + w) * hl + i] = heads[((size_t)k * hl + i) * 24 + w];
+    u64 *stage;
+    RET(c->tbuf("z_heads", h.size(), &stage));
+    HIPCHK(hipMemcpyAsync(stage, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpy2DAsync(z, c->n * 8, stage, hl * 8, hl * 8, (size_t)K * 24, hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return LF_OK;
+}
+
+struct LinOut {
+    std::vector<Fq3> r;  // point
+};
+
+static bool lcccs_point(const lf_params &P, const u64 *lcccs, std::vector<Fq3> &pt) {
+    pt.resize(P.s);
+    for (u32 i = 0; i < P.s; i++)
+        if (!HostRing::is_diag(lcccs + (size_t)i * 24, &pt[i])) return false;
+    return true;
+}
+
+static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_witness *wit, u64 *lcccs_out, u64 *proof, u64 **eq_r_keep) {
+    const lf_params &P = c->P;
+    size_t m = c->m, n = c->n;
+    size_t ph = c->ev_begin(10);
+    // z = x_ccs || 1 || w_ccs (arith.rs:399-409)
+    std::vector<u64> head((size_t)(P.l + 1) * 24);
+    memcpy(head.data(), cccs + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
+    HostRing::from_u64(1, head.data() + (size_t)P.l * 24);
+    u64 *z, *mz, *eqb, *eqr, *partial, *od;
+    RET(c->tbuf("lin_z", 24 * n, &z));
+    RET(c->tbuf("lin_mz", (size_t)P.t * 24 * m, &mz));
+    RET(c->tbuf("lin_eqb", 3 * m, &eqb));
+    RET(c->tbuf("eq_r_R", 3 * m, &eqr));
+    RET(c->tbuf("red_partial", 256 * 4096, &partial));
+    RET(c->tbuf("lin_small", 4096, &od));
+    RET(build_z(c, wit->planes, 1, 0, head.data(), z));
+    std::vector<Fq3> beta(P.s);
+    {
+        HostTimer ht(c);
+        tr.absorb_label("beta_s");
+        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
+    }
+    RET(build_eq_dev(c, beta.data(), P.s, eqb));
+    for (u32 j = 0; j < P.t; j++)
+        launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->st);
+    std::vector<Fq3> pt(P.s);
+    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data()));
+    // v, u at the sumcheck point (linearization.rs:126-139)
+    RET(build_eq_dev(c, pt.data(), P.s, eqr));
+    u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;
+    launch_coef_eval(c->dcrt, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->st);
+    RET(down_small(c, od, 72, v));  // T[24][3] flat == v[3][8 slots][3]
+    launch_dot_eq(c->dcrt, mz, m, P.t, eqr, m, m, partial, od, c->st);
+    RET(down_small(c, od, (size_t)P.t * 24, u));
+    {
+        HostTimer ht(c);
+        tr.absorb_ring(v, 3);
+        tr.absorb_ring(u, P.t);
+    }
+    u64 *o = lcccs_out;
+    for (u32 i = 0; i < P.s; i++, o += 24) HostRing::from_fq3(pt[i], o);
+    memcpy(o, v, 72 * 8); o += 72;
+    memcpy(o, cccs, (size_t)P.kappa * 24 * 8); o += (size_t)P.kappa * 24;
+    memcpy(o, u, (size_t)P.t * 24 * 8); o += (size_t)P.t * 24;
+    memcpy(o, cccs + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8); o += (size_t)P.l * 24;
+    HostRing::from_u64(1, o);
+    if (eq_r_keep) *eq_r_keep = eqr;
+    c->ev_end(ph);
+    return LF_OK;
+}
+
+// decompose_big_vec_into_k_vec_and_compose_back (nifs/decomposition/utils.rs:12-42) on l+1 elements, host
+static void compute_x_s(const lf_ctx *c, const u64 *xh /* (l+1) NTT */, u64 *x_s /* K*(l+1) NTT */) {
+    const lf_params &P = c->P;
+    u32 cnt = P.l + 1;
+    std::vector<u64> co(24);
+    for (u32 i = 0; i < cnt; i++) {
+        c->ring.icrt(xh + (size_t)i * 24, co.data());
+        // per coefficient: L digits base B, each K digits base b
+        std::vector<int64_t> dB(P.L), dk(P.K);
+        std::vector<std::vector<u64>> part(P.K, std::vector<u64>(24, 0));
+        for (int cc = 0; cc < 24; cc++) {
+            balanced_digits(co[cc], P.B, P.L, dB.data());
+            u64 pw = 1;
+            for (u32 l = 0; l < P.L; l++) {
+                balanced_digits(fq_from_i64(dB[l]), P.b, P.K, dk.data());
+                for (u32 k = 0; k < P.K; k++) {
+                    u64 term = fq_mul(pw, fq_from_i64(dk[k]));
+                    part[k][cc] = fq_add(part[k][cc], term);
+                }
+                pw = fq_mul(pw, P.B % LF_P);
+            }
+        }
+        for (u32 k = 0; k < P.K; k++) c->ring.crt(part[k].data(), x_s + ((size_t)k * cnt + i) * 24);
+    }
+}
+
+struct SideState {
+    const int32_t *planes;
+    u64 *z;       // [K][24][n]
+    u64 *eq_r;    // [3][m]
+    std::vector<u64> lcccs;  // K flat LCCCS (host)
+};
+
+// LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
+static int decompose_impl(lf_ctx *c, Transcript &tr, const u64 *lcccs, const std::vector<Fq3> &rpt, const lf_witness *wit, const char *side,
+                          u64 *eq_r /* built already or nullptr */, SideState &S, u64 *proof) {
+    const lf_params &P = c->P;
+    size_t m = c->m, n = c->n, N = c->N;
+    u32 K = P.K;
+    std::string sd(side);
+    const u64 *cm = lcccs + ((size_t)P.s + 3) * 24;
+    const u64 *xh = lcccs + ((size_t)P.s + 3 + P.kappa + P.t) * 24;
+    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24, *x_s = v_s + (size_t)K * 72, *y_s = x_s + (size_t)K * (P.l + 1) * 24;
+
+    u64 *Fh, *yd, *partial, *od, *z, *q;
+    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * N, &Fh));
+    RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &yd));
+    RET(c->tbuf("red_partial", 256 * 4096, &partial));
+    RET(c->tbuf("dec_small", 16 * 72 + 16 * 4 * 24 + 64, &od));
+    RET(c->tbuf("z_" + sd, (size_t)K * 24 * n, &z));
+    RET(c->tbuf("dec_q", (size_t)P.t * 24 * n, &q));
+    if (!eq_r) {
+        RET(c->tbuf("eq_r_" + sd, 3 * m, &eq_r));
+        RET(build_eq_dev(c, rpt.data(), P.s, eq_r));
+    }
+    S.planes = wit->planes; S.z = z; S.eq_r = eq_r;
+
+    // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
+    size_t ph = c->ev_begin(11);
+    LF_TRACE(c, "dec start");
+    launch_bitplane_crt(c->dcrt, wit->planes, N, 1, K, Fh, c->st);
+    LF_TRACE(c, "bitplane_crt");
+    RET(commit_dev(c, Fh, K - 1, yd, true));
+    LF_TRACE(c, "commit");
+    RET(down_small(c, yd, (size_t)(K - 1) * P.kappa * 24, y_s + (size_t)P.kappa * 24));
+    c->ev_end(ph);
+    {   // y_0 = cm - sum_{k>=1} b^k y_k, as the reference's fold (acc + y_i) * b
+        std::vector<u64> acc((size_t)P.kappa * 24, 0);
+        u64 bb[24];
+        HostRing::from_u64(P.b, bb);
+        for (int k = (int)K - 1; k >= 1; k--)
+            for (u32 i = 0; i < P.kappa; i++) {
+                HostRing::add(&acc[(size_t)i * 24], y_s + ((size_t)k * P.kappa + i) * 24, &acc[(size_t)i * 24]);
+                c->ring.mul_ntt(&acc[(size_t)i * 24], bb, &acc[(size_t)i * 24]);
+            }
+        for (u32 i = 0; i < P.kappa; i++) HostRing::sub(cm + (size_t)i * 24, &acc[(size_t)i * 24], y_s + (size_t)i * 24);
+    }
+    ph = c->ev_begin(12);
+    compute_x_s(c, xh, x_s);
+    LF_TRACE(c, "x_s");
+    // v_s (decomposition.rs:204-211) from the coefficient planes
+    launch_coef_eval(c->dcrt, wit->planes, N, eq_r, m, K, 1, partial, od, c->st);
+    RET(down_small(c, od, (size_t)K * 72, v_s));
+    LF_TRACE(c, "v_s");
+    // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
+    RET(build_z(c, wit->planes, K, 1, x_s, z));
+    LF_TRACE(c, "build_z");
+    for (u32 j = 0; j < P.t; j++)
+        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->st);
+    u64 *dpart;
+    RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
+    launch_dot_batch(c->dcrt, z, n, K, q, n, P.t, n, dpart, od, c->st);
+    RET(down_small(c, od, (size_t)K * P.t * 24, u_s));
+    LF_TRACE(c, "u_s");
+    c->ev_end(ph);
+
+    size_t ll = lf_lcccs_len(&P);
+    S.lcccs.assign((size_t)K * ll * 24, 0);
+    HostTimer ht(c);
+    for (u32 k = 0; k < K; k++) {
+        const u64 *xk = x_s + (size_t)k * (P.l + 1) * 24, *yk = y_s + (size_t)k * P.kappa * 24;
+        const u64 *uk = u_s + (size_t)k * P.t * 24, *vk = v_s + (size_t)k * 72;
+        tr.absorb_ring(xk, P.l + 1);
+        tr.absorb_ring(yk, P.kappa);
+        tr.absorb_ring(uk, P.t);
+        tr.absorb_ring(vk, 3);
+        u64 *o = &S.lcccs[(size_t)k * ll * 24];
+        memcpy(o, lcccs, (size_t)P.s * 24 * 8); o += (size_t)P.s * 24;
+        memcpy(o, vk, 72 * 8); o += 72;
+        memcpy(o, yk, (size_t)P.kappa * 24 * 8); o += (size_t)P.kappa * 24;
+        memcpy(o, uk, (size_t)P.t * 24 * 8); o += (size_t)P.t * 24;
+        memcpy(o, xk, (size_t)(P.l + 1) * 24 * 8);
+    }
+    return LF_OK;
+}
+
+static int upload_consts(lf_ctx *c, const std::string &name, const std::vector<Fq3Const> &v, Fq3Const **out) {
+    RET(c->tbuf(name, v.size() + 8, out));
+    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(Fq3Const), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return LF_OK;
+}
+
+// LFFoldingProver::prove (nifs/folding.rs:42-130)
+static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcccs_out, lf_witness **w_out, u64 *proof) {
+    const lf_params &P = c->P;
+    size_t m = c->m, n = c->n, N = c->N;
+    u32 K = P.K, K2 = 2 * K, deg = 2 * P.b;
+    size_t ll = lf_lcccs_len(&P);
+    std::vector<Fq3> alpha(K2), zeta(K2), mu(K2), beta(P.s);
+    {
+        HostTimer ht(c);
+        tr.absorb_label("alpha_s");
+        for (u32 i = 0; i < K2; i++) alpha[i] = tr.get_challenge();
+        tr.absorb_label("zeta_s");
+        for (u32 i = 0; i < K2; i++) zeta[i] = tr.get_challenge();
+        tr.absorb_label("mu_s");
+        for (u32 i = 0; i + 1 < K2; i++) mu[i] = tr.get_challenge();
+        mu[K2 - 1] = fq3_one();
+        tr.absorb_label("beta_s");
+        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
+    }
+    size_t ph = c->ev_begin(13);
+    // powers x^{j+1}
+    std::vector<Fq3Const> mu_pow((size_t)K2 * 3), a_pow((size_t)K2 * 3), z_pow((size_t)K2 * P.t);
+    for (u32 i = 0; i < K2; i++) {
+        Fq3 pm = mu[i], pa = alpha[i], pz = zeta[i];
+        for (u32 d = 0; d < 3; d++) {
+            mu_pow[(size_t)i * 3 + d] = f3c(pm); a_pow[(size_t)i * 3 + d] = f3c(pa);
+            pm = c->ring.mul3(pm, mu[i]); pa = c->ring.mul3(pa, alpha[i]);
+        }
+        for (u32 j = 0; j < P.t; j++) { z_pow[(size_t)i * P.t + j] = f3c(pz); pz = c->ring.mul3(pz, zeta[i]); }
+    }
+    Fq3Const *d_mu, *d_ap, *d_zp;
+    RET(upload_consts(c, "c_mu", mu_pow, &d_mu));
+    RET(upload_consts(c, "c_ap", a_pow, &d_ap));
+    RET(upload_consts(c, "c_zp", z_pow, &d_zp));
+    u64 *G[2], *eqb, *zz, *partial, *od;
+    RET(c->tbuf("fold_G1", 24 * m, &G[0]));
+    RET(c->tbuf("fold_G2", 24 * m, &G[1]));
+    RET(c->tbuf("fold_eqb", 3 * m, &eqb));
+    RET(c->tbuf("fold_zz", (size_t)P.t * 24 * n, &zz));
+    RET(c->tbuf("round_partial", round_partial_words(), &partial));
+    RET(c->tbuf("round_out", 5 * 24, &od));
+    for (int sd = 0; sd < 2; sd++) {
+        // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}
+        launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->st);
+        for (u32 j = 0; j < P.t; j++)
+            launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], zz + (size_t)j * 24 * n, n, G[sd], m, j > 0, c->st);
+        launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, c->st);
+    }
+    RET(build_eq_dev(c, beta.data(), P.s, eqb));
+    LF_TRACE(c, "fold prepare");
+    c->ev_end(ph);
+
+    ph = c->ev_begin(14);
+    u64 *msgs = proof;
+    std::vector<Fq3> pt(P.s);
+    { HostTimer ht(c); sc_prologue(tr, P.s, deg); }
+    // working tables (ping-pong): 5 special tables + materialised f-hat
+    u64 *F[2], *T5[2];
+    size_t half = m / 2;
+    RET(c->tbuf("fold_F0", (size_t)K2 * 3 * 24 * (half ? half : 1), &F[0]));
+    RET(c->tbuf("fold_F1", (size_t)K2 * 3 * 24 * (half / 2 ? half / 2 : 1), &F[1]));
+    // T5 layout per buffer: eqL[3] eqR[3] eqB[3] G1[24] G2[24] = 57 planes
+    RET(c->tbuf("fold_T0", 57 * (half ? half : 1), &T5[0]));
+    RET(c->tbuf("fold_T1", 57 * (half / 2 ? half / 2 : 1), &T5[1]));
+    FoldRoundArgs a;
+    a.eqL = S[0].eq_r; a.eqR = S[1].eq_r; a.eqB = eqb; a.G1 = G[0]; a.G2 = G[1]; a.ld = m; a.n = m;
+    const u64 *curF = nullptr;
+    size_t ldF = 0;
+    int flip = 0;
+    for (u32 round = 1; round <= P.s; round++) {
+        if (round > 1) {
+            Fq3Const r = f3c(pt[round - 2]);
+            size_t nn = a.n / 2;
+            u64 *dst = T5[flip];
+            launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, c->st);
+            launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, c->st);
+            launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->st);
+            launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->st);
+            launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->st);
+            if (round == 2) {
+                launch_fold_materialize(c->dcrt, S[0].planes, S[1].planes, N, m, K, r, F[0], c->st);
+                curF = F[0]; ldF = nn;
+            } else {
+                u64 *fd = F[(round & 1) ? 1 : 0];  // round 3 -> F[1], round 4 -> F[0], ...
+                launch_fix_many(c->dcrt, curF, ldF, fd, nn, a.n, K2 * 3 * 8, r, c->st);
+                curF = fd; ldF = nn;
+            }
+            a.eqL = dst; a.eqR = dst + 3 * nn; a.eqB = dst + 6 * nn; a.G1 = dst + 9 * nn; a.G2 = dst + 33 * nn;
+            a.ld = nn; a.n = nn;
+            flip ^= 1;
+        }
+        size_t ev = c->ev_begin(0);
+        if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->st);
+        else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->st);
+        c->ev_end(ev);
+        LF_TRACE(c, "fold round");
+        u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * 24;
+        RET(down_small(c, od, (size_t)(deg + 1) * 24, evs));
+        HostTimer ht(c);
+        pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
+    }
+    c->ev_end(ph);
+
+    ph = c->ev_begin(15);
+    // theta, eta at r_0 (folding.rs:236-256)
+    u64 *theta = proof + (size_t)P.s * (deg + 1) * 24, *eta = theta + (size_t)K2 * 72;
+    u64 *eq0, *q, *red, *sm, *dpart;
+    RET(c->tbuf("fold_eq0", 3 * m, &eq0));
+    RET(c->tbuf("dec_q", (size_t)P.t * 24 * n, &q));
+    RET(c->tbuf("red_partial", 256 * 4096, &red));
+    RET(c->tbuf("dec_small", 16 * 72 + 16 * 4 * 24 + 64, &sm));
+    RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
+    RET(build_eq_dev(c, pt.data(), P.s, eq0));
+    for (u32 j = 0; j < P.t; j++)
+        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, c->st);
+    for (int sd = 0; sd < 2; sd++) {
+        launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, sm, c->st);
+        RET(down_small(c, sm, (size_t)K * 72, theta + (size_t)sd * K * 72));
+        launch_dot_batch(c->dcrt, S[sd].z, n, K, q, n, P.t, n, dpart, sm, c->st);
+        RET(down_small(c, sm, (size_t)K * P.t * 24, eta + (size_t)sd * K * P.t * 24));
+    }
+    std::vector<u64> rho_c((size_t)K2 * 24, 0), rho((size_t)K2 * 24);
+    std::vector<int8_t> rho8((size_t)K2 * 24, 0);
+    {
+        HostTimer ht(c);
+        tr.absorb_ring(theta, (size_t)K2 * 3);
+        tr.absorb_ring(eta, (size_t)K2 * P.t);
+        // get_rhos (folding/utils.rs:116-131)
+        tr.absorb_label("rho_s");
+        for (u32 i = 0; i + 1 < K2; i++) tr.get_short_challenge(&rho_c[(size_t)i * 24]);
+        rho_c[(size_t)(K2 - 1) * 24] = 1;
+        for (u32 i = 0; i < K2; i++) {
+            c->ring.crt(&rho_c[(size_t)i * 24], &rho[(size_t)i * 24]);
+            for (int q2 = 0; q2 < 24; q2++) {
+                u64 v = rho_c[(size_t)i * 24 + q2];
+                rho8[(size_t)i * 24 + q2] = (int8_t)(v > LF_P / 2 ? -(int64_t)(LF_P - v) : (int64_t)v);
+            }
+        }
+    }
+    // f_0 in the coefficient domain -> new witness
+    int8_t *d_rho;
+    RET(c->tbuf("c_rho", (size_t)K2 * 24 + 64, &d_rho));
+    HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->st));
+    int32_t *npl;
+    HIPCHK(hipMalloc((void **)&npl, N * 24 * 4));
+    LF_TRACE(c, "theta/eta");
+    launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->st);
+    LF_TRACE(c, "fold_witness");
+    HIPCHK(hipStreamSynchronize(c->st));
+    *w_out = new lf_witness{c, npl, N};
+    c->ev_end(ph);
+
+    // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521), host
+    HostTimer ht(c);
+    u64 *o = lcccs_out;
+    for (u32 i = 0; i < P.s; i++, o += 24) HostRing::from_fq3(pt[i], o);
+    {   // v_0 = rot_lin_combination(rho_coeff, theta) (cyclotomic-rings/src/rotation.rs:85-104)
+        Fq3 res[24];
+        for (int j = 0; j < 24; j++) res[j] = fq3_zero();
+        for (u32 i = 0; i < K2; i++) {
+            u64 rot[24];
+            memcpy(rot, &rho_c[(size_t)i * 24], sizeof(rot));
+            const u64 *th = theta + (size_t)i * 72;
+            for (int bi = 0; bi < 24; bi++) {
+                Fq3 b = fq3_make(th[3 * bi], th[3 * bi + 1], th[3 * bi + 2]);
+                for (int j = 0; j < 24; j++)
+                    if (rot[j]) res[j] = fq3_add(res[j], fq3_mul_fq(b, rot[j]));
+                // multiply by X modulo X^24 - X^12 + 1
+                u64 top = rot[23];
+                for (int j = 23; j > 0; j--) rot[j] = rot[j - 1];
+                rot[0] = fq_neg(top);
+                rot[12] = fq_add(rot[12], top);
+            }
+        }
+        for (int j = 0; j < 24; j++) { o[3 * j] = res[j].c[0]; o[3 * j + 1] = res[j].c[1]; o[3 * j + 2] = res[j].c[2]; }
+        o += 72;
+    }
+    u64 tmp[24];
+    auto part = [&](u32 i) { return &S[i < K ? 0 : 1].lcccs[(size_t)(i % K) * ll * 24]; };
+    for (u32 q2 = 0; q2 < P.kappa; q2++, o += 24) {
+        memset(o, 0, 24 * 8);
+        for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(part(i) + ((size_t)P.s + 3 + q2) * 24, &rho[(size_t)i * 24], tmp); HostRing::add(o, tmp, o); }
+    }
+    for (u32 j = 0; j < P.t; j++, o += 24) {
+        memset(o, 0, 24 * 8);
+        for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * 24], eta + ((size_t)i * P.t + j) * 24, tmp); HostRing::add(o, tmp, o); }
+    }
+    for (u32 q2 = 0; q2 < P.l + 1; q2++, o += 24) {
+        memset(o, 0, 24 * 8);
+        for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * 24], part(i) + ((size_t)P.s + 3 + P.kappa + P.t + q2) * 24, tmp); HostRing::add(o, tmp, o); }
+    }
+    return LF_OK;
+}
+
+int lf_linearize(lf_ctx *c, lf_transcript *t, const uint64_t *cccs, const lf_witness *wit, uint64_t *lcccs_out, uint64_t *lin_proof_out) {
+    if (!c || !t || !cccs || !wit || !lcccs_out || !lin_proof_out || wit->ctx != c) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    if (wit->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    int rc = linearize_impl(c, t->t, cccs, wit, lcccs_out, lin_proof_out, nullptr);
+    c->ev_collect();
+    return rc;
+}
+
+int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witness *w_acc, const uint64_t *cm_i, const lf_witness *w_i,
+                 uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof) {
+    if (!c || !t || !acc || !w_acc || !cm_i || !w_i || !lcccs_out || !w_out || !proof) return LF_ERR_INVALID;
+    if (w_acc->ctx != c || w_i->ctx != c) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    const lf_params &P = c->P;
+    if (c->kappa != P.kappa || c->nA != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<Fq3> rL;
+    if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;  // evaluation points are always diagonal challenges
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    size_t tot = c->ev_begin(17);
+    Transcript &tr = t->t;
+    size_t ll = lf_lcccs_len(&P);
+    {   // absorb_public_input (nifs.rs:175-197)
+        HostTimer ht(c);
+        tr.absorb_label("acc");
+        tr.absorb_ring(acc, ll);
+        tr.absorb_label("cm_i");
+        tr.absorb_ring(cm_i, lf_cccs_len(&P));
+    }
+    u64 *lin_proof = proof, *decl = lin_proof + lin_proof_len(&P) * 24, *decr = decl + dec_proof_len(&P) * 24, *foldp = decr + dec_proof_len(&P) * 24;
+    std::vector<u64> lin(ll * 24);
+    u64 *eq_r_R = nullptr;
+    int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    SideState S[2];
+    std::vector<Fq3> rR;
+    if (rc == LF_OK) { lcccs_point(P, lin.data(), rR); rc = decompose_impl(c, tr, acc, rL, w_acc, "L", nullptr, S[0], decl); }
+    if (rc == LF_OK) rc = decompose_impl(c, tr, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
+    if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
+    c->ev_end(tot);
+    c->ev_collect();
+    return rc;
+}
+
+// ---- generic linearization-shaped sumcheck through the ABI (tests / SURVEY 8b) -------------------------------------------------
+int lf_sumcheck_lin_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *eq_point) {
+    if (!c || !tables || !eq_point) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    size_t m = c->m;
+    u64 *mz, *eqb;
+    RET(c->tbuf("sc_tab0", (size_t)P.t * 24 * m, &mz));
+    RET(c->tbuf("sc_eq0", 3 * m, &eqb));
+    for (u32 j = 0; j < P.t; j++) RET(up_ring(c, tables + (size_t)j * m * 24, m, mz + (size_t)j * 24 * m));
+    std::vector<Fq3> pt(P.s);
+    for (u32 i = 0; i < P.s; i++) pt[i] = fq3_make(eq_point[3 * i], eq_point[3 * i + 1], eq_point[3 * i + 2]);
+    RET(build_eq_dev(c, pt.data(), P.s, eqb));
+    c->sc_round = 0; c->sc_n = m; c->sc_cur = 0;
+    return LF_OK;
+}
+int lf_sumcheck_lin_round(lf_ctx *c, const uint64_t *r_prev, uint64_t *evals_out) {
+    if (!c || !evals_out) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->sc_round < 0 || c->sc_round >= (int)c->P.s) return LF_ERR_STATE;  // "Prover is not active"
+    if ((c->sc_round == 0) != (r_prev == nullptr)) return LF_ERR_STATE;      // "first round should be prover first" / "verifier message is empty"
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    size_t m = c->m;
+    u64 *tab[2], *eq[2], *partial, *od;
+    RET(c->tbuf("sc_tab0", (size_t)P.t * 24 * m, &tab[0]));
+    RET(c->tbuf("sc_tab1", (size_t)P.t * 24 * (m / 2 ? m / 2 : 1), &tab[1]));
+    RET(c->tbuf("sc_eq0", 3 * m, &eq[0]));
+    RET(c->tbuf("sc_eq1", 3 * (m / 2 ? m / 2 : 1), &eq[1]));
+    RET(c->tbuf("round_partial", round_partial_words(), &partial));
+    RET(c->tbuf("round_out", 5 * 24, &od));
+    if (r_prev) {
+        Fq3Const r; r.c[0] = r_prev[0]; r.c[1] = r_prev[1]; r.c[2] = r_prev[2];
+        int src = c->sc_cur, dst = src ^ 1;
+        launch_fix_many(c->dcrt, tab[src], c->sc_n, tab[dst], c->sc_n / 2, c->sc_n, P.t * 8, r, c->st);
+        launch_fix_many(c->dcrt, eq[src], c->sc_n, eq[dst], c->sc_n / 2, c->sc_n, 1, r, c->st);
+        c->sc_cur = dst; c->sc_n /= 2;
+    }
+    launch_lin_round(c->dcrt, c->desc, tab[c->sc_cur], c->sc_n, eq[c->sc_cur], c->sc_n, c->sc_n, P.d + 1, partial, od, c->st);
+    c->sc_round++;
+    return down_small(c, od, (size_t)(P.d + 2) * 24, evals_out);
+}
+int lf_sumcheck_lin_end(lf_ctx *c) {
+    if (!c) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->sc_round = -1;
+    return LF_OK;
+}
+
+int lf_last_phase_ms(lf_ctx *c, float *out) {
+    if (!c || !out) return LF_ERR_INVALID;
+    for (int i = 0; i < LF_N_PHASES; i++) out[i] = c->phase_ms[i];
+    return LF_OK;
+}
+int lf_last_kernel_stats(lf_ctx *c, float *fold_ms, int *fold_n, float *aj_ms, int *aj_n) {
+    if (!c) return LF_ERR_INVALID;
+    if (fold_ms) *fold_ms = c->k_fold_ms;
+    if (fold_n) *fold_n = c->k_fold_n;
+    if (aj_ms) *aj_ms = c->k_ajtai_ms;
+    if (aj_n) *aj_n = c->k_ajtai_n;
+    return LF_OK;
+}

@@ -1,0 +1,165 @@
+// lf_field.cuh -- Goldilocks F_p (p = 2^64 - 2^32 + 1) and F_{p^3} = F_p[Y]/(Y^3 - NU) arithmetic for
+// gfx950, shared by device kernels and the host driver.
+//
+// Replaces ark-ff 0.4.2 `Fp64<MontBackend>` / `Fp3` as used through stark-rings (reference call sites:
+// crates/cyclotomic-rings/src/rings/goldilocks.rs:1-25).  Values are canonical residues in [0,p) at every
+// kernel boundary; inside kernels "loose" values in [0,2^64) are allowed where noted.
+//
+// gfx950 has no 64x64->128 multiply: a product is four v_mad_u64_u32 (quarter rate, measured 15.7 T lane-op/s,
+// profiles/r01_microbench.txt) plus a shift/add reduction that uses 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+#define LF_P 0xFFFFFFFF00000001ULL
+#define LF_EPS 0xFFFFFFFFULL /* 2^32 - 1 = 2^64 mod p */
+
+#define LF_HD __host__ __device__ __forceinline__
+
+namespace lf {
+
+// ---- F_p ------------------------------------------------------------------------------------------------
+LF_HD u64 fq_canon(u64 a) { return a >= LF_P ? a - LF_P : a; }  // loose -> canonical
+LF_HD u64 fq_add(u64 a, u64 b) {                                 // canonical in, canonical out
+    u64 r = a + b;
+    if (r < a || r >= LF_P) r -= LF_P;
+    return r;
+}
+LF_HD u64 fq_sub(u64 a, u64 b) { return a >= b ? a - b : a + (LF_P - b); }
+LF_HD u64 fq_neg(u64 a) { return a ? LF_P - a : 0; }
+
+// (hi:lo) mod p, result loose (in [0,2^64)); one conditional subtract canonicalises.
+LF_HD u64 fq_reduce128_loose(u64 lo, u64 hi) {
+    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= LF_EPS;            // borrow: + p (mod 2^64)
+    u32 nz = hl != 0;
+    u64 t1 = ((u64)(hl - nz) << 32) | (u32)(0u - hl);  // hl * (2^32 - 1) without a multiply
+    u64 r = t0 + t1;
+    if (r < t1) r += LF_EPS;              // carry: - p (mod 2^64)
+    return r;
+}
+LF_HD void mul64wide(u64 a, u64 b, u64 &lo, u64 &hi) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    lo = (p10 << 32) | (u32)p00;
+}
+LF_HD u64 fq_mul_loose(u64 a, u64 b) {  // any u64 inputs, loose output
+    u64 lo, hi;
+    mul64wide(a, b, lo, hi);
+    return fq_reduce128_loose(lo, hi);
+}
+LF_HD u64 fq_mul(u64 a, u64 b) { return fq_canon(fq_mul_loose(a, b)); }
+// a * 2^40 mod p (NU = 2^40 fast path): (a << 40) is a 104-bit value
+LF_HD u64 fq_mul_2p40(u64 a) { return fq_canon(fq_reduce128_loose(a << 40, a >> 24)); }
+// small signed integer -> canonical
+LF_HD u64 fq_from_i64(int64_t v) { return v >= 0 ? (u64)v : LF_P - (u64)(-v); }  // |v| < p assumed
+
+LF_HD u64 fq_pow(u64 a, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = fq_mul(r, a);
+        a = fq_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+LF_HD u64 fq_inv(u64 a) { return fq_pow(a, LF_P - 2); }
+
+// ---- F_{p^3} ----------------------------------------------------------------------------------------------
+struct Fq3 {
+    u64 c[3];
+};
+LF_HD Fq3 fq3_make(u64 a, u64 b, u64 c) { Fq3 r; r.c[0] = a; r.c[1] = b; r.c[2] = c; return r; }
+LF_HD Fq3 fq3_zero() { return fq3_make(0, 0, 0); }
+LF_HD Fq3 fq3_one() { return fq3_make(1, 0, 0); }
+LF_HD Fq3 fq3_add(Fq3 a, Fq3 b) { return fq3_make(fq_add(a.c[0], b.c[0]), fq_add(a.c[1], b.c[1]), fq_add(a.c[2], b.c[2])); }
+LF_HD Fq3 fq3_sub(Fq3 a, Fq3 b) { return fq3_make(fq_sub(a.c[0], b.c[0]), fq_sub(a.c[1], b.c[1]), fq_sub(a.c[2], b.c[2])); }
+LF_HD Fq3 fq3_neg(Fq3 a) { return fq3_make(fq_neg(a.c[0]), fq_neg(a.c[1]), fq_neg(a.c[2])); }
+LF_HD bool fq3_eq(Fq3 a, Fq3 b) { return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2]; }
+
+// multiply by the non-residue.  NU2P40 = true: NU = 2^40 (shift); else generic runtime constant.
+template <bool NU2P40>
+LF_HD u64 fq_mul_nu(u64 a, u64 nu) { return NU2P40 ? fq_mul_2p40(a) : fq_mul(a, nu); }
+
+// 128-bit + carry accumulator for sums of up to 3 products < 2^128
+struct Acc {
+    u64 lo, hi;
+    u32 ov;
+};
+LF_HD void acc_set(Acc &s, u64 a, u64 b) { mul64wide(a, b, s.lo, s.hi); s.ov = 0; }
+LF_HD void acc_mad(Acc &s, u64 a, u64 b) {
+    u64 lo, hi;
+    mul64wide(a, b, lo, hi);
+    u64 nlo = s.lo + lo;
+    u64 c = nlo < lo;
+    u64 nhi = s.hi + hi;
+    u32 c2 = nhi < hi;
+    nhi += c;
+    c2 += (nhi < c);
+    s.lo = nlo; s.hi = nhi; s.ov += c2;
+}
+// (ov:hi:lo) mod p, canonical.  2^128 = 2^64 * 2^64 = (2^32-1)^2 = 2^64 - 2^33 + 1 = -2^32 (mod p)
+LF_HD u64 acc_reduce(const Acc &s) {
+    u64 r = fq_canon(fq_reduce128_loose(s.lo, s.hi));
+    if (s.ov) r = fq_sub(r, (u64)s.ov << 32);
+    return r;
+}
+
+// schoolbook product, 9 base multiplications, lazy 128-bit column sums, 5 reductions
+template <bool NU2P40>
+LF_HD Fq3 fq3_mul(Fq3 a, Fq3 b, u64 nu) {
+    Acc s0, s1, s2, s3, s4;
+    acc_set(s0, a.c[0], b.c[0]);
+    acc_set(s1, a.c[0], b.c[1]); acc_mad(s1, a.c[1], b.c[0]);
+    acc_set(s2, a.c[0], b.c[2]); acc_mad(s2, a.c[1], b.c[1]); acc_mad(s2, a.c[2], b.c[0]);
+    acc_set(s3, a.c[1], b.c[2]); acc_mad(s3, a.c[2], b.c[1]);
+    acc_set(s4, a.c[2], b.c[2]);
+    Fq3 r;
+    r.c[0] = fq_add(acc_reduce(s0), fq_mul_nu<NU2P40>(acc_reduce(s3), nu));
+    r.c[1] = fq_add(acc_reduce(s1), fq_mul_nu<NU2P40>(acc_reduce(s4), nu));
+    r.c[2] = acc_reduce(s2);
+    return r;
+}
+// square: 6 base multiplications
+template <bool NU2P40>
+LF_HD Fq3 fq3_sqr(Fq3 a, u64 nu) {
+    u64 d01 = fq_add(a.c[0], a.c[0]), d1 = fq_add(a.c[1], a.c[1]);
+    Acc s0, s1, s2, s3, s4;
+    acc_set(s0, a.c[0], a.c[0]);
+    acc_set(s1, d01, a.c[1]);
+    acc_set(s2, d01, a.c[2]); acc_mad(s2, a.c[1], a.c[1]);
+    acc_set(s3, d1, a.c[2]);
+    acc_set(s4, a.c[2], a.c[2]);
+    Fq3 r;
+    r.c[0] = fq_add(acc_reduce(s0), fq_mul_nu<NU2P40>(acc_reduce(s3), nu));
+    r.c[1] = fq_add(acc_reduce(s1), fq_mul_nu<NU2P40>(acc_reduce(s4), nu));
+    r.c[2] = acc_reduce(s2);
+    return r;
+}
+LF_HD Fq3 fq3_mul_fq(Fq3 a, u64 s) { return fq3_make(fq_mul(a.c[0], s), fq_mul(a.c[1], s), fq_mul(a.c[2], s)); }
+// times a small signed integer |k| < 2^31
+LF_HD Fq3 fq3_mul_small(Fq3 a, int k) {
+    u64 m = (u64)(k < 0 ? -k : k);
+    Fq3 r = fq3_make(fq_mul(a.c[0], m), fq_mul(a.c[1], m), fq_mul(a.c[2], m));
+    return k < 0 ? fq3_neg(r) : r;
+}
+
+template <bool NU2P40>
+LF_HD Fq3 fq3_inv(Fq3 a, u64 nu) {
+    // norm-based inverse of a cubic extension element
+    u64 t0 = fq_sub(fq_mul(a.c[0], a.c[0]), fq_mul_nu<NU2P40>(fq_mul(a.c[1], a.c[2]), nu));
+    u64 t1 = fq_sub(fq_mul_nu<NU2P40>(fq_mul(a.c[2], a.c[2]), nu), fq_mul(a.c[0], a.c[1]));
+    u64 t2 = fq_sub(fq_mul(a.c[1], a.c[1]), fq_mul(a.c[0], a.c[2]));
+    u64 n = fq_add(fq_mul(a.c[0], t0), fq_mul_nu<NU2P40>(fq_add(fq_mul(a.c[2], t1), fq_mul(a.c[1], t2)), nu));
+    u64 ni = fq_inv(n);
+    return fq3_make(fq_mul(t0, ni), fq_mul(t1, ni), fq_mul(t2, ni));
+}
+
+}  // namespace lf

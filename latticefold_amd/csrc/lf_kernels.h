@@ -1,0 +1,124 @@
+// lf_kernels.h -- launchers of the gfx950 kernels (lf_kernels.hip).  All pointers are DEVICE pointers.
+//
+// Device layouts (DESIGN.md "HBM layout"):
+//   ring table   : u64 [24][n]   plane w = 3*slot + coord (NTT form) or coefficient index (coefficient form)
+//   fq3 table    : u64 [3][n]    slot-constant values (eq tables)
+//   coef planes  : i32 [24][n]   centred coefficients of a B-short witness (|v| <= B/2 <= 2^15)
+//   Ajtai matrix : u64 [kappa][24][n]
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lf_host.h"
+
+namespace lf {
+
+struct DevCrt {  // compact copy of CrtTables passed by value as a kernel argument
+    u64 nu;
+    int nu2p40;
+    u64 w4, w2, w10, w1, w7, w5, w11;
+    int slot_of_pos[8], pos1[8], pos2[8];
+    u64 tw1[8], tw2[8];
+};
+DevCrt make_dev_crt(const CrtTables &T);
+
+struct Fq3Const { u64 c[3]; };
+
+// ---- layout / utility --------------------------------------------------------------------------------------
+void launch_aos_to_soa(const u64 *aos, u64 *soa, size_t n, hipStream_t s);   // [n][24] -> [24][n]
+void launch_soa_to_aos(const u64 *soa, u64 *aos, size_t n, hipStream_t s);
+void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStream_t s);  // SplitMix64 stream (workload.py)
+// Ajtai matrix generated in place in plane layout, equal to AoS stream splitmix(seed)[((i*n+j)*24+w)]
+void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, u64 seed, hipStream_t s);
+
+// ---- CRT / ICRT (a1, a2) ---------------------------------------------------------------------------------------
+void launch_crt_fwd(const DevCrt &t, const u64 *coef, u64 *ntt, size_t n, hipStream_t s);
+void launch_icrt_dense(const u64 *icrt_mat /*24*24 dev*/, const u64 *ntt, u64 *coef, size_t n, hipStream_t s);
+
+// ---- decomposition (a3) ----------------------------------------------------------------------------------------
+// generic balanced digits on canonical coefficient tables: out has `digits` tables; layout 0: element i ->
+// out index i*digits+k (n_out = n*digits), layout 1: table k at out + k*24*n
+void launch_decompose(const u64 *coef, size_t n, u64 base, u32 digits, int layout, u64 *out, hipStream_t s);
+void launch_recompose(const u64 *in, size_t n_out, u64 base, u32 digits, u64 *out, hipStream_t s);
+// canonical coefficients -> centred i32 planes; *viol is set to 1 if some |v| > bound
+void launch_coef_to_i32(const u64 *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s);
+void launch_i32_to_coef(const int32_t *planes, u64 *coef, size_t n, hipStream_t s);
+// NTT of bit-plane k (k0 <= k < k1) of every element: out[(k-k0)][24][n]
+void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s);
+// z-vector tails: out_k[off + i] = CRT( sum_l B^l * digit_k(planes[i*L + l]) ) for k < K (mode_bits = 1), or the
+// full value (mode_bits = 0, K = 1).  out_k = out + k*24*ldz.
+void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K,
+                          int mode_bits, u64 *out, size_t ldz, size_t off, hipStream_t s);
+// l-infinity norm (a15): max |centred coefficient| of canonical coefficient table -> *out_max (u64)
+void launch_linf(const u64 *coef, size_t n, u64 *out_max, hipStream_t s);
+
+// ---- Ajtai commit (a5) -----------------------------------------------------------------------------------------
+// partial[split][slot][i][k][3]; then reduce -> out AoS-ish [k][i][24] (device), canonical
+size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits);
+void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
+                  u64 *partial, u64 *out, hipStream_t s);
+
+// ---- MLE / eq (a8, a9, a11) --------------------------------------------------------------------------------------
+void launch_build_eq(const DevCrt &t, const Fq3Const *r_dev /*nv*/, u32 nv, u64 *eq /*[3][1<<nv]*/, hipStream_t s);
+// sparse mat-vec (a7): CSR rows m; z ring table [24][n]; out ring table [24][m]; accumulate != 0 adds into out
+void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *val /*[nnz][24] AoS*/, const u64 *z,
+                 size_t ldz, u64 *out, size_t m, int accumulate, hipStream_t s);
+// q[col] = sum_{rows} eq[row] * val  (CSC: colptr over n columns, rowidx, val AoS)
+void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
+                      u64 *q, size_t n, hipStream_t s);
+// dots: out[a][b] = sum_i X_a[i] (.) Y_b[i] (ring tables, slot-wise), a < na, b < nb -> out AoS [na][nb][24]
+void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n,
+                      u64 *partial, u64 *out, hipStream_t s);
+size_t dot_partial_words(u32 na, u32 nb);
+// ring table (.) fq3 table: out[a] = sum_i eq[i] * X_a[i]  -> AoS [na][24]
+void launch_dot_eq(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *eq, size_t ldeq, size_t n, u64 *partial,
+                   u64 *out, hipStream_t s);
+// T[k][c] = sum_i eq[i] * digit_k(planes[c][i]) (K bit-planes) or full value (mode_bits = 0): out AoS fq3 [K][24][3]
+void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits,
+                      u64 *partial, u64 *out, hipStream_t s);
+size_t coef_eval_partial_words(u32 K);
+// zz_j = sum_k coef[k][j] * z_k  (fq3 scalars; z tables [K][24][ldz]) -> out [t][24][ldz]
+void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev /*K*tt*/, u32 tt, size_t n,
+                      u64 *out, hipStream_t s);
+// G[row][slot] += sum_{k<K} sum_{d<3} apow[k][d] * digit_k(planes[8d+slot][row])   (rows < n_planes)
+void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow_dev /*K*3*/,
+                          u64 *G, size_t m, hipStream_t s);
+
+// ---- sumcheck (a10) ---------------------------------------------------------------------------------------------
+// generic in-place-free fix: ring tables and fq3 tables, new[j] = old[2j] + r*(old[2j+1]-old[2j])
+void launch_fix_ring(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s);
+void launch_fix_fq3(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s);
+
+struct LinCombDesc {  // CCS multiset structure for the linearization comb (nifs/linearization/utils.rs:90-107)
+    u32 t, q;
+    u32 S_off[9];
+    u32 S_idx[16];
+    u64 c[8][24];  // coefficients c_i (ring elements, AoS)
+};
+// round message of the linearization sumcheck: tables Mz [t][24][ld], eq [3][ld]; n = current length
+// out: (deg+1) ring elements AoS, deg = d+1 <= 4
+void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
+                      u32 deg, u64 *partial, u64 *out, hipStream_t s);
+
+struct FoldRoundArgs {
+    const u64 *eqL, *eqR, *eqB;  // fq3 tables [3][ld]
+    const u64 *G1, *G2;          // ring tables [24][ld]
+    size_t ld;                   // leading dimension of the tables above
+    size_t n;                    // current table length
+};
+// round 1 of the folding sumcheck straight from the coefficient planes (f-hat virtual, b = 2)
+void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                        u32 K, const Fq3Const *mu_pow_dev /*2K*3*/, u64 *partial, u64 *out, hipStream_t s);
+// after r_1: materialise fixed f-hat tables F[2K*3][24][n/2] = f0 + r1*(f1-f0)
+void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+                             Fq3Const r1, u64 *F, hipStream_t s);
+// general round on materialised tables F [2K*3][24][ldF] (b = 2)
+void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev,
+                       u64 *partial, u64 *out, hipStream_t s);
+size_t round_partial_words();
+
+// ---- folded witness (a13 in coefficient domain) ---------------------------------------------------------------
+// out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c)  with rho_i small-coefficient polynomials (i8 [2K][24])
+void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev, int32_t *out,
+                         hipStream_t s);
+
+}  // namespace lf

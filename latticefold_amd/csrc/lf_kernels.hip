@@ -1,0 +1,993 @@
+// lf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LatticeFold prover hot path.
+//
+// Every kernel works on plane-major (SoA) tables so that lane <-> consecutive element index gives coalesced
+// 8/16-byte accesses; cross-lane reductions use wave64 shuffles + one LDS hop per 256-thread block; the Ajtai
+// mat-vec stages (A, witness) tiles through LDS.  No MFMA: the arithmetic is 64-bit modular (four
+// v_mad_u64_u32 per product, see lf_field.cuh).  Reference semantics each kernel replaces are cited inline.
+#include "lf_kernels.h"
+
+namespace lf {
+
+#define NUARG t.nu
+template <bool NU> __device__ __forceinline__ Fq3 M3(Fq3 a, Fq3 b, u64 nu) { return fq3_mul<NU>(a, b, nu); }
+template <bool NU> __device__ __forceinline__ Fq3 S3(Fq3 a, u64 nu) { return fq3_sqr<NU>(a, nu); }
+
+#define LF_LAUNCH(KERNEL, nuflag, grid, block, stream, ...)                                   \
+    do {                                                                                      \
+        if (nuflag) hipLaunchKernelGGL((KERNEL<true>), grid, block, 0, stream, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((KERNEL<false>), grid, block, 0, stream, __VA_ARGS__);        \
+    } while (0)
+
+DevCrt make_dev_crt(const CrtTables &T) {
+    DevCrt d;
+    d.nu = T.nu; d.nu2p40 = T.nu_is_2p40;
+    d.w4 = T.w4; d.w2 = T.w2; d.w10 = T.w10; d.w1 = T.w1; d.w7 = T.w7; d.w5 = T.w5; d.w11 = T.w11;
+    for (int p = 0; p < 8; p++) {
+        d.slot_of_pos[p] = T.slot_of_pos[p]; d.pos1[p] = T.pos1[p]; d.pos2[p] = T.pos2[p];
+        d.tw1[p] = T.tw1[p]; d.tw2[p] = T.tw2[p];
+    }
+    return d;
+}
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+static inline unsigned grid_for(size_t n, unsigned cap = 2048) {
+    size_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reductions
+__device__ __forceinline__ u64 wave_sum_fq(u64 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        u64 o = __shfl_down((unsigned long long)v, off, 64);
+        v = fq_add(v, o);
+    }
+    return v;
+}
+// sum `v[0..NV)` over the 256 threads of the block, write to dst[0..NV) (thread-0-side); values canonical
+template <int NV>
+__device__ __forceinline__ void block_sum_store(u64 (&v)[NV], u64 *dst) {
+    __shared__ u64 sm[4][NV];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        u64 s = wave_sum_fq(v[i]);
+        if (lane == 0) sm[wave][i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256) dst[i] = fq_add(fq_add(sm[0][i], sm[1][i]), fq_add(sm[2][i], sm[3][i]));
+}
+// out[i] = sum_b partial[b*nv + i]; one block per i
+__global__ void __launch_bounds__(256) k_reduce_rows(const u64 *partial, u32 nblocks, u32 nv, u64 *out) {
+    u32 i = blockIdx.x;
+    u64 acc[1] = {0};
+    for (u32 b = threadIdx.x; b < nblocks; b += 256) acc[0] = fq_add(acc[0], partial[(size_t)b * nv + i]);
+    block_sum_store<1>(acc, out + i);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// layout
+__global__ void __launch_bounds__(256) k_aos_to_soa(const u64 *aos, u64 *soa, size_t n) {
+    __shared__ u64 tile[64][25];
+    size_t base = (size_t)blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * 24; idx += 256) {
+        size_t e = base + idx / 24;
+        tile[idx / 24][idx % 24] = e < n ? aos[e * 24 + idx % 24] : 0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 24; idx += 256) {
+        int w = idx / 64, j = idx % 64;
+        if (base + j < n) soa[(size_t)w * n + base + j] = tile[j][w];
+    }
+}
+__global__ void __launch_bounds__(256) k_soa_to_aos(const u64 *soa, u64 *aos, size_t n) {
+    __shared__ u64 tile[64][25];
+    size_t base = (size_t)blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * 24; idx += 256) {
+        int w = idx / 64, j = idx % 64;
+        tile[j][w] = base + j < n ? soa[(size_t)w * n + base + j] : 0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 24; idx += 256) {
+        size_t e = base + idx / 24;
+        if (e < n) aos[e * 24 + idx % 24] = tile[idx / 24][idx % 24];
+    }
+}
+void launch_aos_to_soa(const u64 *aos, u64 *soa, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_aos_to_soa, dim3(cdiv(n, 64)), dim3(256), 0, s, aos, soa, n);
+}
+void launch_soa_to_aos(const u64 *soa, u64 *aos, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_soa_to_aos, dim3(cdiv(n, 64)), dim3(256), 0, s, soa, aos, n);
+}
+
+__device__ __forceinline__ u64 splitmix_fq(u64 seed, u64 index) {
+    u64 z = seed + (index + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return z >= LF_P ? z - LF_P : z;
+}
+__global__ void __launch_bounds__(256) k_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < words; i += st) dst[i] = splitmix_fq(seed, start + i);
+}
+void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_uniform, dim3(grid_for(words, 4096)), dim3(256), 0, s, dst, words, seed, start);
+}
+__global__ void __launch_bounds__(256) k_fill_ajtai(u64 *A, u32 kappa, size_t n, u64 seed) {
+    size_t total = (size_t)kappa * 24 * n;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < total; i += st) {
+        size_t j = i % n, w = (i / n) % 24, row = i / (24 * n);
+        A[i] = splitmix_fq(seed, (row * n + j) * 24 + w);
+    }
+}
+void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, u64 seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_ajtai, dim3(4096), dim3(256), 0, s, A, kappa, n, seed);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CRT: structured forward transform.  a(X) = sum_u X^u A_u(X^3); A_u is evaluated at the 8 primitive 24th
+// roots by three radix-2 layers over Y^8 - Y^4 + 1 = (Y^4 - w^4)(Y^4 - w^20), then the per-slot monomial
+// twist maps F_p[X]/(X^3 - zeta_k) onto F_p[Y]/(Y^3 - nu).  (stark-rings CRT; call sites arith.rs:238,327.)
+__device__ __forceinline__ void crt8(const u64 x[8], u64 o[8], const DevCrt &t) {
+    u64 lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 tt = fq_mul(t.w4, x[i + 4]);
+        lo[i] = fq_add(x[i], tt);
+        hi[i] = fq_sub(fq_add(x[i], x[i + 4]), tt);
+    }
+    u64 l0[2], l1[2], h0[2], h1[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        u64 tt = fq_mul(t.w2, lo[i + 2]);
+        l0[i] = fq_add(lo[i], tt); l1[i] = fq_sub(lo[i], tt);
+        u64 uu = fq_mul(t.w10, hi[i + 2]);
+        h0[i] = fq_add(hi[i], uu); h1[i] = fq_sub(hi[i], uu);
+    }
+    u64 a = fq_mul(t.w1, l0[1]);  o[0] = fq_add(l0[0], a); o[1] = fq_sub(l0[0], a);
+    u64 b = fq_mul(t.w7, l1[1]);  o[2] = fq_add(l1[0], b); o[3] = fq_sub(l1[0], b);
+    u64 c = fq_mul(t.w5, h0[1]);  o[4] = fq_add(h0[0], c); o[5] = fq_sub(h0[0], c);
+    u64 d = fq_mul(t.w11, h1[1]); o[6] = fq_add(h1[0], d); o[7] = fq_sub(h1[0], d);
+}
+// coefficients a[24] (canonical) -> stores the 24 NTT words of element j into plane table `out` (ld = n)
+__device__ __forceinline__ void crt_store(const u64 a[24], u64 *out, size_t ld, size_t j, const DevCrt &t) {
+    u64 x[8], A0[8], A1[8], A2[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) x[v] = a[3 * v];
+    crt8(x, A0, t);
+#pragma unroll
+    for (int v = 0; v < 8; v++) x[v] = a[3 * v + 1];
+    crt8(x, A1, t);
+#pragma unroll
+    for (int v = 0; v < 8; v++) x[v] = a[3 * v + 2];
+    crt8(x, A2, t);
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        int s3 = 3 * t.slot_of_pos[p];
+        out[(size_t)s3 * ld + j] = A0[p];
+        out[(size_t)(s3 + t.pos1[p]) * ld + j] = fq_mul(t.tw1[p], A1[p]);
+        out[(size_t)(s3 + t.pos2[p]) * ld + j] = fq_mul(t.tw2[p], A2[p]);
+    }
+}
+__global__ void __launch_bounds__(256) k_crt_fwd(DevCrt t, const u64 *coef, u64 *ntt, size_t n) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    u64 a[24];
+#pragma unroll
+    for (int c = 0; c < 24; c++) a[c] = coef[(size_t)c * n + j];
+    crt_store(a, ntt, n, j, t);
+}
+void launch_crt_fwd(const DevCrt &t, const u64 *coef, u64 *ntt, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_crt_fwd, dim3(cdiv(n, 256)), dim3(256), 0, s, t, coef, ntt, n);
+}
+// ICRT as the dense 24x24 F_p matrix (rare: ingest / export only)
+__global__ void __launch_bounds__(256) k_icrt_dense(const u64 *mat, const u64 *ntt, u64 *coef, size_t n) {
+    __shared__ u64 M[24 * 24];
+    for (int i = threadIdx.x; i < 576; i += 256) M[i] = mat[i];
+    __syncthreads();
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    u64 x[24];
+#pragma unroll
+    for (int c = 0; c < 24; c++) x[c] = ntt[(size_t)c * n + j];
+    for (int i = 0; i < 24; i++) {
+        Acc a;
+        acc_set(a, M[i * 24], x[0]);
+#pragma unroll
+        for (int c = 1; c < 24; c++) acc_mad(a, M[i * 24 + c], x[c]);
+        coef[(size_t)i * n + j] = acc_reduce(a);
+    }
+}
+void launch_icrt_dense(const u64 *mat, const u64 *ntt, u64 *coef, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_icrt_dense, dim3(cdiv(n, 256)), dim3(256), 0, s, mat, ntt, coef, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// balanced decomposition on canonical coefficients, power-of-two base (stark_rings::balanced_decomposition;
+// call sites arith.rs:235, decomposition/utils.rs:23-31,48).  Sign-magnitude, |digit| <= base/2, ties kept.
+__global__ void __launch_bounds__(256) k_decompose(const u64 *coef, size_t n, u32 log_base, u32 digits, int layout, u64 *out) {
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * 24) return;
+    size_t c = idx / n, i = idx % n;
+    u64 v = coef[idx];
+    bool neg = v > (LF_P - 1) / 2;
+    u64 mag = neg ? LF_P - v : v;
+    u64 half = 1ULL << (log_base - 1), mask = (1ULL << log_base) - 1;
+    size_t n_out = layout == 0 ? n * digits : n;
+    for (u32 k = 0; k < digits; k++) {
+        u64 rem = mag & mask;
+        mag >>= log_base;
+        int64_t dg;
+        if (rem > half) { dg = (int64_t)rem - (int64_t)(mask + 1); mag += 1; }
+        else dg = (int64_t)rem;
+        if (neg) dg = -dg;
+        size_t o = layout == 0 ? (c * n_out + i * digits + k) : ((size_t)k * 24 * n + c * n + i);
+        out[o] = fq_from_i64(dg);
+    }
+}
+void launch_decompose(const u64 *coef, size_t n, u64 base, u32 digits, int layout, u64 *out, hipStream_t s) {
+    u32 lb = 0;
+    while ((1ULL << lb) < base) lb++;
+    if (n) hipLaunchKernelGGL(k_decompose, dim3(cdiv(n * 24, 256)), dim3(256), 0, s, coef, n, lb, digits, layout, out);
+}
+// out[i] = sum_j base^j in[i*digits + j] on any table (linear, either form)
+__global__ void __launch_bounds__(256) k_recompose(const u64 *in, size_t n_out, u64 base, u32 digits, u64 *out) {
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_out * 24) return;
+    size_t w = idx / n_out, i = idx % n_out;
+    size_t n_in = n_out * digits;
+    u64 acc = 0, pw = 1;
+    for (u32 j = 0; j < digits; j++) {
+        acc = fq_add(acc, fq_mul(in[w * n_in + i * digits + j], pw));
+        pw = fq_mul(pw, base);
+    }
+    out[idx] = acc;
+}
+void launch_recompose(const u64 *in, size_t n_out, u64 base, u32 digits, u64 *out, hipStream_t s) {
+    if (n_out) hipLaunchKernelGGL(k_recompose, dim3(cdiv(n_out * 24, 256)), dim3(256), 0, s, in, n_out, base % LF_P, digits, out);
+}
+__global__ void __launch_bounds__(256) k_coef_to_i32(const u64 *coef, int32_t *planes, size_t total, u32 bound, int *viol) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    int bad = 0;
+    for (; i < total; i += st) {
+        u64 v = coef[i];
+        bool neg = v > (LF_P - 1) / 2;
+        u64 mag = neg ? LF_P - v : v;
+        if (mag > bound) { bad = 1; mag = 0; }
+        planes[i] = neg ? -(int32_t)mag : (int32_t)mag;
+    }
+    if (bad) atomicOr(viol, 1);
+}
+void launch_coef_to_i32(const u64 *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s) {
+    hipLaunchKernelGGL(k_coef_to_i32, dim3(grid_for(n * 24, 4096)), dim3(256), 0, s, coef, planes, n * 24, bound, viol);
+}
+__global__ void __launch_bounds__(256) k_i32_to_coef(const int32_t *planes, u64 *coef, size_t total) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < total; i += st) coef[i] = fq_from_i64(planes[i]);
+}
+void launch_i32_to_coef(const int32_t *planes, u64 *coef, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_i32_to_coef, dim3(grid_for(n * 24, 4096)), dim3(256), 0, s, planes, coef, n * 24);
+}
+__global__ void __launch_bounds__(256) k_linf(const u64 *coef, size_t total, unsigned long long *out_max) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    u64 mx = 0;
+    for (; i < total; i += st) {
+        u64 v = coef[i];
+        u64 mag = v > (LF_P - 1) / 2 ? LF_P - v : v;
+        mx = mag > mx ? mag : mx;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        u64 o = __shfl_down((unsigned long long)mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_max, (unsigned long long)mx);
+}
+void launch_linf(const u64 *coef, size_t n, u64 *out_max, hipStream_t s) {
+    hipMemsetAsync(out_max, 0, 8, s);
+    hipLaunchKernelGGL(k_linf, dim3(grid_for(n * 24, 4096)), dim3(256), 0, s, coef, n * 24, (unsigned long long *)out_max);
+}
+
+// bit-plane k of a centred small value: sign(v) * bit_k(|v|)   (base-2 balanced digits, decomposition.rs:159-167)
+__device__ __forceinline__ int digit2(int32_t v, u32 k) {
+    int32_t m = v < 0 ? -v : v;
+    int d = (m >> k) & 1;
+    return v < 0 ? -d : d;
+}
+__device__ __forceinline__ u64 fq_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? 1 : LF_P - 1); }
+
+__global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *planes, size_t n, u32 k0, u32 k1, u64 *out) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int32_t v[24];
+#pragma unroll
+    for (int c = 0; c < 24; c++) v[c] = planes[(size_t)c * n + j];
+    for (u32 k = k0; k < k1; k++) {
+        u64 a[24];
+#pragma unroll
+        for (int c = 0; c < 24; c++) a[c] = fq_from_digit(digit2(v[c], k));
+        crt_store(a, out + (size_t)(k - k0) * 24 * n, n, j, t);
+    }
+}
+void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s) {
+    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256)), dim3(256), 0, s, t, planes, n, k0, k1, out);
+}
+
+struct BPow { u64 v[8]; };
+__global__ void __launch_bounds__(256) k_recompose_crt(DevCrt t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, BPow bp,
+                                                        u32 K, int mode_bits, u64 *out, size_t ldz, size_t off) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 k = blockIdx.y;
+    if (i >= wit_len) return;
+    u64 a[24];
+#pragma unroll
+    for (int c = 0; c < 24; c++) {
+        u64 acc = 0;
+        for (u32 l = 0; l < L; l++) {
+            int32_t v = planes[(size_t)c * n_planes + i * L + l];
+            if (mode_bits) {
+                int d = digit2(v, k);
+                if (d > 0) acc = fq_add(acc, bp.v[l]);
+                else if (d < 0) acc = fq_sub(acc, bp.v[l]);
+            } else {
+                u64 mag = (u64)(v < 0 ? -v : v);
+                u64 term = fq_mul(bp.v[l], mag);
+                acc = v < 0 ? fq_sub(acc, term) : fq_add(acc, term);
+            }
+        }
+        a[c] = acc;
+    }
+    crt_store(a, out + (size_t)k * 24 * ldz, ldz, off + i, t);
+}
+void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K, int mode_bits,
+                          u64 *out, size_t ldz, size_t off, hipStream_t s) {
+    BPow bp;
+    u64 pw = 1;
+    for (int l = 0; l < 8; l++) { bp.v[l] = pw; pw = fq_mul(pw, B % LF_P); }
+    hipLaunchKernelGGL(k_recompose_crt, dim3(cdiv(wit_len, 256), K), dim3(256), 0, s, t, planes, n_planes, wit_len, L, bp, K, mode_bits,
+                       out, ldz, off);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ajtai commit (commitment_scheme.rs:37-54 -> Matrix::checked_mul_vec): C[k][i] = sum_j A[i][j] (.) F_k[j].
+// Per slot this is a skinny GEMM (kappa x n) * (n x batch) over F_{p^3}.  Block = one slot x one j-split;
+// (A,F) tiles of JT columns are staged in LDS with coalesced loads; each thread owns up to two (i,k) outputs
+// and keeps the five schoolbook column sums of the F_{p^3} product as un-reduced 160-bit accumulators for the
+// whole j-range (one reduction per output at the very end).
+constexpr int AJ_JT = 32;
+constexpr int AJ_MAXROWS = 64;   // kappa + batch <= 64 per launch
+struct Acc5 { Acc s[5]; };
+__device__ __forceinline__ void acc5_zero(Acc5 &a) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) { a.s[i].lo = 0; a.s[i].hi = 0; a.s[i].ov = 0; }
+}
+__device__ __forceinline__ void acc5_mac(Acc5 &a, const u64 x[3], const u64 y[3]) {
+    acc_mad(a.s[0], x[0], y[0]);
+    acc_mad(a.s[1], x[0], y[1]); acc_mad(a.s[1], x[1], y[0]);
+    acc_mad(a.s[2], x[0], y[2]); acc_mad(a.s[2], x[1], y[1]); acc_mad(a.s[2], x[2], y[0]);
+    acc_mad(a.s[3], x[1], y[2]); acc_mad(a.s[3], x[2], y[1]);
+    acc_mad(a.s[4], x[2], y[2]);
+}
+template <bool NU>
+__device__ __forceinline__ Fq3 acc5_finish(const Acc5 &a, u64 nu) {
+    Fq3 r;
+    r.c[0] = fq_add(acc_reduce(a.s[0]), fq_mul_nu<NU>(acc_reduce(a.s[3]), nu));
+    r.c[1] = fq_add(acc_reduce(a.s[1]), fq_mul_nu<NU>(acc_reduce(a.s[4]), nu));
+    r.c[2] = acc_reduce(a.s[2]);
+    return r;
+}
+template <bool NU>
+__global__ void __launch_bounds__(256) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
+                                               u64 *partial) {
+    __shared__ u64 sA[AJ_MAXROWS][3][AJ_JT];  // rows 0..kappa-1 = A, kappa.. = F
+    const u32 slot = blockIdx.y, split = blockIdx.x;
+    const u32 rows = kappa + batch;
+    const u32 nout = kappa * batch;
+    size_t per = (n + splits - 1) / splits;
+    per = (per + AJ_JT - 1) / AJ_JT * AJ_JT;
+    size_t j0 = (size_t)split * per, j1 = j0 + per < n ? j0 + per : n;
+    Acc5 acc[2];
+    acc5_zero(acc[0]); acc5_zero(acc[1]);
+    u32 o0 = threadIdx.x, o1 = threadIdx.x + 256;
+    u32 i0 = o0 / batch, k0 = o0 % batch, i1 = o1 / batch, k1 = o1 % batch;
+    for (size_t jt = j0; jt < j1; jt += AJ_JT) {
+        __syncthreads();
+        for (u32 idx = threadIdx.x; idx < rows * 3 * AJ_JT; idx += 256) {
+            u32 jj = idx % AJ_JT, rc = idx / AJ_JT, c = rc % 3, r = rc / 3;
+            size_t j = jt + jj;
+            u64 v = 0;
+            if (j < j1) {
+                const u64 *src = r < kappa ? A + ((size_t)r * 24 + 3 * slot + c) * n : F + ((size_t)(r - kappa) * 24 + 3 * slot + c) * n;
+                v = src[j];
+            }
+            sA[r][c][jj] = v;
+        }
+        __syncthreads();
+        if (o0 < nout) {
+            for (int jj = 0; jj < AJ_JT; jj++) {
+                u64 x[3] = {sA[i0][0][jj], sA[i0][1][jj], sA[i0][2][jj]};
+                u64 y[3] = {sA[kappa + k0][0][jj], sA[kappa + k0][1][jj], sA[kappa + k0][2][jj]};
+                acc5_mac(acc[0], x, y);
+                if (o1 < nout) {
+                    u64 x1[3] = {sA[i1][0][jj], sA[i1][1][jj], sA[i1][2][jj]};
+                    u64 y1[3] = {sA[kappa + k1][0][jj], sA[kappa + k1][1][jj], sA[kappa + k1][2][jj]};
+                    acc5_mac(acc[1], x1, y1);
+                }
+            }
+        }
+    }
+    // partial[split][slot][o][3]
+    u64 *dst = partial + ((size_t)split * 8 + slot) * nout * 3;
+    if (o0 < nout) {
+        Fq3 r = acc5_finish<NU>(acc[0], t.nu);
+        dst[(size_t)o0 * 3] = r.c[0]; dst[(size_t)o0 * 3 + 1] = r.c[1]; dst[(size_t)o0 * 3 + 2] = r.c[2];
+    }
+    if (o1 < nout) {
+        Fq3 r = acc5_finish<NU>(acc[1], t.nu);
+        dst[(size_t)o1 * 3] = r.c[0]; dst[(size_t)o1 * 3 + 1] = r.c[1]; dst[(size_t)o1 * 3 + 2] = r.c[2];
+    }
+}
+// out[k][i][3*slot+c] = sum_split partial[split][slot][i*batch+k][c]
+__global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, u32 kappa, u32 batch, u32 splits, u64 *out) {
+    u32 idx = blockIdx.x * 256 + threadIdx.x;
+    u32 nout = kappa * batch;
+    if (idx >= 8 * nout * 3) return;
+    u32 c = idx % 3, o = (idx / 3) % nout, slot = idx / (3 * nout);
+    u64 acc = 0;
+    for (u32 sp = 0; sp < splits; sp++) acc = fq_add(acc, partial[(((size_t)sp * 8 + slot) * nout + o) * 3 + c]);
+    u32 i = o / batch, k = o % batch;
+    out[((size_t)k * kappa + i) * 24 + 3 * slot + c] = acc;
+}
+size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) { return (size_t)splits * 8 * kappa * batch * 3; }
+void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits, u64 *partial, u64 *out,
+                  hipStream_t s) {
+    LF_LAUNCH(k_ajtai, t.nu2p40, dim3(splits, 8), dim3(256), s, t, A, kappa, n, F, batch, splits, partial);
+    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// eq(x, r) table, LSB-first (build_eq_x_r, utils/sumcheck/utils.rs:100-170): eq[i] = prod_j (i_j ? r_j : 1-r_j)
+template <bool NU>
+__global__ void __launch_bounds__(256) k_build_eq(DevCrt t, const Fq3Const *r, u32 nv, u64 *eq) {
+    __shared__ u64 sr[64][2][3];
+    for (u32 idx = threadIdx.x; idx < nv * 3; idx += 256) {
+        u32 j = idx / 3, c = idx % 3;
+        u64 rv = r[j].c[c];
+        sr[j][1][c] = rv;
+        sr[j][0][c] = fq_sub(c == 0 ? 1 : 0, rv);
+    }
+    __syncthreads();
+    size_t n = (size_t)1 << nv;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fq3 acc = fq3_one();
+    for (u32 j = 0; j < nv; j++) {
+        u32 b = (i >> j) & 1;
+        acc = M3<NU>(acc, fq3_make(sr[j][b][0], sr[j][b][1], sr[j][b][2]), t.nu);
+    }
+    eq[i] = acc.c[0]; eq[n + i] = acc.c[1]; eq[2 * n + i] = acc.c[2];
+}
+void launch_build_eq(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *eq, hipStream_t s) {
+    LF_LAUNCH(k_build_eq, t.nu2p40, dim3(cdiv((size_t)1 << nv, 256)), dim3(256), s, t, r_dev, nv, eq);
+}
+
+__device__ __forceinline__ Fq3 ld3(const u64 *tab, size_t ld, u32 slot, size_t i) {
+    return fq3_make(tab[(size_t)(3 * slot) * ld + i], tab[(size_t)(3 * slot + 1) * ld + i], tab[(size_t)(3 * slot + 2) * ld + i]);
+}
+__device__ __forceinline__ void st3(u64 *tab, size_t ld, u32 slot, size_t i, Fq3 v) {
+    tab[(size_t)(3 * slot) * ld + i] = v.c[0]; tab[(size_t)(3 * slot + 1) * ld + i] = v.c[1]; tab[(size_t)(3 * slot + 2) * ld + i] = v.c[2];
+}
+
+// mat_vec_mul (arith/utils.rs:52-65) on CSR
+template <bool NU>
+__global__ void __launch_bounds__(256) k_spmv(DevCrt t, const u32 *rowptr, const u32 *col, const u64 *val, const u64 *z, size_t ldz,
+                                              u64 *out, size_t m, int accumulate) {
+    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (row >= m) return;
+    Fq3 acc = accumulate ? ld3(out, m, slot, row) : fq3_zero();
+    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) {
+        const u64 *v = val + (size_t)k * 24 + 3 * slot;
+        acc = fq3_add(acc, M3<NU>(fq3_make(v[0], v[1], v[2]), ld3(z, ldz, slot, col[k]), t.nu));
+    }
+    st3(out, m, slot, row, acc);
+}
+void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *val, const u64 *z, size_t ldz, u64 *out, size_t m,
+                 int accumulate, hipStream_t s) {
+    LF_LAUNCH(k_spmv, t.nu2p40, dim3(cdiv(m, 256), 8), dim3(256), s, t, rowptr, col, val, z, ldz, out, m, accumulate);
+}
+template <bool NU>
+__global__ void __launch_bounds__(256) k_spmv_t_eq(DevCrt t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
+                                                   u64 *q, size_t n) {
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (c >= n) return;
+    Fq3 acc = fq3_zero();
+    for (u32 k = colptr[c]; k < colptr[c + 1]; k++) {
+        const u64 *v = val + (size_t)k * 24 + 3 * slot;
+        size_t r = rowidx[k];
+        acc = fq3_add(acc, M3<NU>(fq3_make(v[0], v[1], v[2]), fq3_make(eq[r], eq[m + r], eq[2 * m + r]), t.nu));
+    }
+    st3(q, n, slot, c, acc);
+}
+void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m, u64 *q, size_t n,
+                      hipStream_t s) {
+    LF_LAUNCH(k_spmv_t_eq, t.nu2p40, dim3(cdiv(n, 256), 8), dim3(256), s, t, colptr, rowidx, val, eq, m, q, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// batched inner products (evaluate_mles, utils/mle_helpers.rs:65-88, restructured as dot products)
+constexpr u32 RED_BLOCKS = 256;
+template <bool NU>
+__global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, size_t n,
+                                                   u64 *partial) {
+    // grid (RED_BLOCKS, 8 slots, nb); accumulators for up to 16 a's
+    u32 slot = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
+    Acc5 acc[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) acc5_zero(acc[a]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        Fq3 y = ld3(Y + (size_t)b * 24 * ldy, ldy, slot, i);
+#pragma unroll
+        for (int a = 0; a < 16; a++)
+            if ((u32)a < na) {
+                Fq3 x = ld3(X + (size_t)a * 24 * ldx, ldx, slot, i);
+                acc5_mac(acc[a], x.c, y.c);
+            }
+    }
+    u64 v[48];
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        Fq3 r = (u32)a < na ? acc5_finish<NU>(acc[a], t.nu) : fq3_zero();
+        v[3 * a] = r.c[0]; v[3 * a + 1] = r.c[1]; v[3 * a + 2] = r.c[2];
+    }
+    // partial[block][ (a*nb + b)*24 + 3*slot + c ]
+    __shared__ u64 red[48];
+    block_sum_store<48>(v, red);
+    __syncthreads();
+    for (u32 idx = threadIdx.x; idx < na * 3; idx += 256) {
+        u32 a = idx / 3, c = idx % 3;
+        partial[(size_t)blockIdx.x * (16 * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[idx];
+    }
+}
+size_t dot_partial_words(u32 na, u32 nb) { return (size_t)RED_BLOCKS * 16 * nb * 24; }
+void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *partial,
+                      u64 *out, hipStream_t s) {
+    u32 gb = (u32)((n + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    LF_LAUNCH(k_dot_batch, t.nu2p40, dim3(gb, 8, nb), dim3(256), s, t, X, ldx, na, Y, ldy, n, partial);
+    // rows of width 16*nb*24; only the first na*nb*24 entries are meaningful (a-major): reduce all na*nb*24
+    hipLaunchKernelGGL(k_reduce_rows, dim3(na * nb * 24), dim3(256), 0, s, partial, gb, 16 * nb * 24, out);
+}
+template <bool NU>
+__global__ void __launch_bounds__(256) k_dot_eq(DevCrt t, const u64 *X, size_t ldx, const u64 *eq, size_t ldeq, size_t n, u64 *partial) {
+    // grid (RED_BLOCKS, 8 slots, na)
+    u32 slot = blockIdx.y, a = blockIdx.z, na = gridDim.z;
+    Acc5 acc;
+    acc5_zero(acc);
+    const u64 *Xa = X + (size_t)a * 24 * ldx;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        Fq3 x = ld3(Xa, ldx, slot, i);
+        u64 e[3] = {eq[i], eq[ldeq + i], eq[2 * ldeq + i]};
+        acc5_mac(acc, x.c, e);
+    }
+    Fq3 r = acc5_finish<NU>(acc, t.nu);
+    u64 v[3] = {r.c[0], r.c[1], r.c[2]};
+    block_sum_store<3>(v, partial + (size_t)blockIdx.x * (na * 24) + (size_t)a * 24 + 3 * slot);
+}
+void launch_dot_eq(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *eq, size_t ldeq, size_t n, u64 *partial, u64 *out,
+                   hipStream_t s) {
+    u32 gb = (u32)((n + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    LF_LAUNCH(k_dot_eq, t.nu2p40, dim3(gb, 8, na), dim3(256), s, t, X, ldx, eq, ldeq, n, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(na * 24), dim3(256), 0, s, partial, gb, na * 24, out);
+}
+
+// f-hat evaluations without materialising f-hat (Witness::get_fhat, arith.rs:273-297, is a re-layout of
+// f_coeff): T[k][c] = sum_i eq[i] * digit_k(f[i][c]);  v_d slot s = T[k][8d+s].
+__global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits,
+                                                   u64 *partial) {
+    // grid (RED_BLOCKS, 24 coefficients)
+    u32 c = blockIdx.y;
+    u64 acc[48];
+#pragma unroll
+    for (int i = 0; i < 48; i++) acc[i] = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int32_t v = planes[(size_t)c * n + i];
+        u64 e0 = eq[i], e1 = eq[ldeq + i], e2 = eq[2 * ldeq + i];
+        if (mode_bits) {
+            int32_t mg = v < 0 ? -v : v;
+            bool neg = v < 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if ((mg >> k) & 1) {
+                    acc[3 * k] = neg ? fq_sub(acc[3 * k], e0) : fq_add(acc[3 * k], e0);
+                    acc[3 * k + 1] = neg ? fq_sub(acc[3 * k + 1], e1) : fq_add(acc[3 * k + 1], e1);
+                    acc[3 * k + 2] = neg ? fq_sub(acc[3 * k + 2], e2) : fq_add(acc[3 * k + 2], e2);
+                }
+            }
+        } else {
+            u64 mg = (u64)(v < 0 ? -v : v);
+            u64 t0 = fq_mul(e0, mg), t1 = fq_mul(e1, mg), t2 = fq_mul(e2, mg);
+            acc[0] = v < 0 ? fq_sub(acc[0], t0) : fq_add(acc[0], t0);
+            acc[1] = v < 0 ? fq_sub(acc[1], t1) : fq_add(acc[1], t1);
+            acc[2] = v < 0 ? fq_sub(acc[2], t2) : fq_add(acc[2], t2);
+        }
+    }
+    // partial[block][k][c][3]
+    __shared__ u64 red[48];
+    block_sum_store<48>(acc, red);
+    __syncthreads();
+    for (u32 idx = threadIdx.x; idx < K * 3; idx += 256) {
+        u32 k = idx / 3, q = idx % 3;
+        partial[(size_t)blockIdx.x * (K * 72) + ((size_t)k * 24 + c) * 3 + q] = red[idx];
+    }
+}
+size_t coef_eval_partial_words(u32 K) { return (size_t)RED_BLOCKS * K * 72; }
+void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial,
+                      u64 *out, hipStream_t s) {
+    u32 gb = (u32)((n + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_coef_eval, dim3(gb, 24), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(K * 72), dim3(256), 0, s, partial, gb, K * 72, out);
+}
+
+template <bool NU>
+__global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef, u32 tt, size_t n,
+                                                   u64 *out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (i >= n) return;
+    Fq3 acc[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
+    for (u32 k = 0; k < K; k++) {
+        Fq3 x = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i);
+        for (u32 j = 0; j < tt; j++) {
+            Fq3Const cc = coef[k * tt + j];
+            acc[j] = fq3_add(acc[j], M3<NU>(x, fq3_make(cc.c[0], cc.c[1], cc.c[2]), t.nu));
+        }
+    }
+    for (u32 j = 0; j < tt; j++) st3(out + (size_t)j * 24 * ldz, ldz, slot, i, acc[j]);
+}
+void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev, u32 tt, size_t n, u64 *out, hipStream_t s) {
+    LF_LAUNCH(k_lincomb_z, t.nu2p40, dim3(cdiv(n, 256), 8), dim3(256), s, t, z, ldz, K, coef_dev, tt, n, out);
+}
+
+__global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow, u64 *G, size_t m) {
+    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (row >= n_planes) return;
+    Fq3 acc = ld3(G, m, slot, row);
+    for (int d = 0; d < 3; d++) {
+        int32_t v = planes[(size_t)(8 * d + slot) * n_planes + row];
+        int32_t mg = v < 0 ? -v : v;
+        for (u32 k = 0; k < K; k++) {
+            if ((mg >> k) & 1) {
+                Fq3Const a = apow[k * 3 + d];
+                Fq3 av = fq3_make(a.c[0], a.c[1], a.c[2]);
+                acc = v < 0 ? fq3_sub(acc, av) : fq3_add(acc, av);
+            }
+        }
+    }
+    st3(G, m, slot, row, acc);
+}
+void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow_dev, u64 *G, size_t m,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_add_fhat_comb, dim3(cdiv(n_planes, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fix_variables (DenseMultilinearExtension, sumcheck/prover.rs:70-72): new[j] = old[2j] + r*(old[2j+1]-old[2j])
+// `rows3` independent F_{p^3} rows (8 per ring table, 1 per eq table), planes of leading dimension ld.
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fix(DevCrt t, const u64 *in, size_t ld_in, u64 *out, size_t ld_out, size_t n_out, Fq3Const r) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t row = blockIdx.y;
+    if (j >= n_out) return;
+    const u64 *p = in + row * 3 * ld_in;
+    Fq3 rr = fq3_make(r.c[0], r.c[1], r.c[2]);
+    ulonglong2 a0 = *(const ulonglong2 *)(p + 2 * j), a1 = *(const ulonglong2 *)(p + ld_in + 2 * j), a2 = *(const ulonglong2 *)(p + 2 * ld_in + 2 * j);
+    Fq3 v0 = fq3_make(a0.x, a1.x, a2.x), v1 = fq3_make(a0.y, a1.y, a2.y);
+    Fq3 res = fq3_add(v0, M3<NU>(fq3_sub(v1, v0), rr, t.nu));
+    u64 *q = out + row * 3 * ld_out;
+    q[j] = res.c[0]; q[ld_out + j] = res.c[1]; q[2 * ld_out + j] = res.c[2];
+}
+void launch_fix_ring(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s) {
+    size_t n_out = n_in / 2;
+    LF_LAUNCH(k_fix, t.nu2p40, dim3(cdiv(n_out, 256), 8), dim3(256), s, t, in, n_in, out, n_out, n_out, r);
+}
+void launch_fix_fq3(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s) {
+    size_t n_out = n_in / 2;
+    LF_LAUNCH(k_fix, t.nu2p40, dim3(cdiv(n_out, 256), 1), dim3(256), s, t, in, n_in, out, n_out, n_out, r);
+}
+// many tables at once: tables [ntab][24][ld] -> [ntab][24][ld/2]
+void launch_fix_many(const DevCrt &t, const u64 *in, size_t ld_in, u64 *out, size_t ld_out, size_t n_in, u32 rows3, Fq3Const r, hipStream_t s) {
+    size_t n_out = n_in / 2;
+    LF_LAUNCH(k_fix, t.nu2p40, dim3(cdiv(n_out, 256), rows3), dim3(256), s, t, in, ld_in, out, ld_out, n_out, r);
+}
+
+// evaluate a quadratic/cubic given by coefficients at X = 0..deg and add into acc
+template <int NP>
+__device__ __forceinline__ void add_poly_evals(Fq3 (&acc)[NP], const Fq3 *co, int ncoef) {
+#pragma unroll
+    for (int X = 0; X < NP; X++) {
+        Fq3 v = co[ncoef - 1];
+        for (int e = ncoef - 2; e >= 0; e--) v = fq3_add(fq3_mul_small(v, X), co[e]);
+        acc[X] = fq3_add(acc[X], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// linearization sumcheck round (sumcheck/prover.rs:56-162 with comb = linearization/utils.rs:90-107)
+template <bool NU>
+__global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
+                                                   u32 deg, u64 *partial) {
+    u32 slot = blockIdx.y;
+    size_t pairs = n / 2;
+    Fq3 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+        Fq3 v[8], st[8];
+        for (u32 j = 0; j < desc.t; j++) {
+            const u64 *tb = mz + ((size_t)j * 24 + 3 * slot) * ld;
+            ulonglong2 a0 = *(const ulonglong2 *)(tb + 2 * p), a1 = *(const ulonglong2 *)(tb + ld + 2 * p), a2 = *(const ulonglong2 *)(tb + 2 * ld + 2 * p);
+            v[j] = fq3_make(a0.x, a1.x, a2.x);
+            st[j] = fq3_sub(fq3_make(a0.y, a1.y, a2.y), v[j]);
+        }
+        ulonglong2 e0 = *(const ulonglong2 *)(eq + 2 * p), e1 = *(const ulonglong2 *)(eq + ldeq + 2 * p), e2 = *(const ulonglong2 *)(eq + 2 * ldeq + 2 * p);
+        Fq3 ev = fq3_make(e0.x, e1.x, e2.x), es = fq3_sub(fq3_make(e0.y, e1.y, e2.y), ev);
+        for (u32 X = 0; X <= deg; X++) {
+            Fq3 res = fq3_zero();
+            for (u32 i = 0; i < desc.q; i++) {
+                Fq3 term = fq3_make(desc.c[i][3 * slot], desc.c[i][3 * slot + 1], desc.c[i][3 * slot + 2]);
+                for (u32 k = desc.S_off[i]; k < desc.S_off[i + 1]; k++) term = M3<NU>(term, v[desc.S_idx[k]], t.nu);
+                res = fq3_add(res, term);
+            }
+            acc[X] = fq3_add(acc[X], M3<NU>(res, ev, t.nu));
+            for (u32 j = 0; j < desc.t; j++) v[j] = fq3_add(v[j], st[j]);
+            ev = fq3_add(ev, es);
+        }
+    }
+    u64 vv[15];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { vv[3 * i] = acc[i].c[0]; vv[3 * i + 1] = acc[i].c[1]; vv[3 * i + 2] = acc[i].c[2]; }
+    // partial[block][X][3*slot+c]
+    __shared__ u64 red[15];
+    block_sum_store<15>(vv, red);
+    __syncthreads();
+    if (threadIdx.x < 15) partial[(size_t)blockIdx.x * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
+}
+size_t round_partial_words() { return (size_t)RED_BLOCKS * 120; }
+void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n, u32 deg,
+                      u64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    LF_LAUNCH(k_lin_round, t.nu2p40, dim3(gb, 8), dim3(256), s, t, desc, mz, ld, eq, ldeq, n, deg, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((deg + 1) * 24), dim3(256), 0, s, partial, gb, 120, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// folding sumcheck (comb = nifs/folding/utils.rs:273-325, b = 2):
+//   g(X) = eqL*G1 + eqR*G2 + eqB * sum_{k,d} mu_k^{d+1} * fhat_kd (fhat_kd^2 - 1)
+// Both kernels evaluate the pair-polynomials in coefficient form (exact in F_p, identical sums).
+template <bool NU>
+__device__ __forceinline__ void fold_g13(Fq3 (&acc)[5], const FoldRoundArgs &a, u32 slot, size_t p, u64 nu) {
+    // (e0 + X de)(g0 + X dg) for the two halves
+    for (int h = 0; h < 2; h++) {
+        const u64 *eq = h ? a.eqR : a.eqL;
+        const u64 *G = h ? a.G2 : a.G1;
+        ulonglong2 e0 = *(const ulonglong2 *)(eq + 2 * p), e1 = *(const ulonglong2 *)(eq + a.ld + 2 * p), e2 = *(const ulonglong2 *)(eq + 2 * a.ld + 2 * p);
+        const u64 *gp = G + (size_t)(3 * slot) * a.ld;
+        ulonglong2 g0 = *(const ulonglong2 *)(gp + 2 * p), g1 = *(const ulonglong2 *)(gp + a.ld + 2 * p), g2 = *(const ulonglong2 *)(gp + 2 * a.ld + 2 * p);
+        Fq3 ea = fq3_make(e0.x, e1.x, e2.x), eb = fq3_make(e0.y, e1.y, e2.y);
+        Fq3 ga = fq3_make(g0.x, g1.x, g2.x), gb = fq3_make(g0.y, g1.y, g2.y);
+        Fq3 co[3];
+        co[0] = M3<NU>(ea, ga, nu);
+        co[2] = M3<NU>(fq3_sub(eb, ea), fq3_sub(gb, ga), nu);
+        co[1] = fq3_sub(fq3_sub(M3<NU>(eb, gb, nu), co[0]), co[2]);
+        add_poly_evals<5>(acc, co, 3);
+    }
+}
+template <bool NU>
+__device__ __forceinline__ void fold_g2_finish(Fq3 (&acc)[5], const Fq3 Q[4], const FoldRoundArgs &a, size_t p, u64 nu) {
+    ulonglong2 b0 = *(const ulonglong2 *)(a.eqB + 2 * p), b1 = *(const ulonglong2 *)(a.eqB + a.ld + 2 * p), b2 = *(const ulonglong2 *)(a.eqB + 2 * a.ld + 2 * p);
+    Fq3 ea = fq3_make(b0.x, b1.x, b2.x), es = fq3_sub(fq3_make(b0.y, b1.y, b2.y), ea);
+#pragma unroll
+    for (int X = 0; X < 5; X++) {
+        Fq3 v = Q[3];
+        for (int e = 2; e >= 0; e--) v = fq3_add(fq3_mul_small(v, X), Q[e]);
+        acc[X] = fq3_add(acc[X], M3<NU>(v, ea, nu));
+        ea = fq3_add(ea, es);
+    }
+}
+__device__ __forceinline__ void store_round_partial(Fq3 (&acc)[5], u32 slot, u64 *partial) {
+    u64 vv[15];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { vv[3 * i] = acc[i].c[0]; vv[3 * i + 1] = acc[i].c[1]; vv[3 * i + 2] = acc[i].c[2]; }
+    __shared__ u64 red[15];
+    block_sum_store<15>(vv, red);
+    __syncthreads();
+    if (threadIdx.x < 15) partial[(size_t)blockIdx.x * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
+}
+
+// round 1: f-hat entries are base-field digits in {-1,0,1}; P(f(X)) = f^3 - f is a small integer, so the
+// mu-weighted sum is accumulated as exact 64-bit integer dot products (no modular multiply in the inner loop).
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                                                     u32 K, const Fq3Const *mu_pow, u64 *partial) {
+    u32 slot = blockIdx.y;
+    size_t pairs = a.n / 2;
+    Fq3 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+        fold_g13<NU>(acc, a, slot, p, t.nu);
+        // cubic coefficients of sum_kd mu_kd * P(f0 + X*df): integer parts split in lo/hi 32-bit halves of mu
+        int64_t lo[4][3], hi[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { lo[e][c] = 0; hi[e][c] = 0; }
+        if (2 * p < n_planes) {
+            for (int side = 0; side < 2; side++) {
+                const int32_t *pl = side ? planesR : planesL;
+                for (int d = 0; d < 3; d++) {
+                    const int32_t *src = pl + (size_t)(8 * d + slot) * n_planes + 2 * p;
+                    int32_t v0 = src[0], v1 = (2 * p + 1 < n_planes) ? src[1] : 0;
+                    for (u32 k = 0; k < K; k++) {
+                        int f0 = digit2(v0, k), df = digit2(v1, k) - f0;
+                        // P(f0 + X df) = (f0^3 - f0) + (3 f0^2 - 1) df X + 3 f0 df^2 X^2 + df^3 X^3
+                        int c0 = f0 * f0 * f0 - f0, c1 = (3 * f0 * f0 - 1) * df, c2 = 3 * f0 * df * df, c3 = df * df * df;
+                        Fq3Const m = mu_pow[(side * K + k) * 3 + d];
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            int64_t ml = (int64_t)(u32)m.c[c], mh = (int64_t)(m.c[c] >> 32);
+                            lo[0][c] += ml * c0; hi[0][c] += mh * c0;
+                            lo[1][c] += ml * c1; hi[1][c] += mh * c1;
+                            lo[2][c] += ml * c2; hi[2][c] += mh * c2;
+                            lo[3][c] += ml * c3; hi[3][c] += mh * c3;
+                        }
+                    }
+                }
+            }
+        }
+        Fq3 Q[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Q[e].c[c] = fq_add(fq_from_i64(lo[e][c]), fq_mul(fq_from_i64(hi[e][c]), 1ULL << 32));
+        fold_g2_finish<NU>(acc, Q, a, p, t.nu);
+    }
+    store_round_partial(acc, slot, partial);
+}
+void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                        const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    LF_LAUNCH(k_fold_round1, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, planesL, planesR, n_planes, K, mu_pow_dev, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
+}
+
+// F[(side*K+k)*3+d][3*slot+c][j] = f0 + r1*(f1-f0), j < m/2  (first fix of the virtual f-hat tables)
+__global__ void __launch_bounds__(256) k_fold_materialize(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+                                                          Fq3Const r1, u64 *F) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 cidx = blockIdx.y;  // coefficient 0..23 -> d = cidx/8, slot = cidx%8
+    size_t half = m / 2;
+    if (j >= half) return;
+    u32 d = cidx / 8, slot = cidx % 8;
+    // multiples -2..2 of r1
+    u64 mul[5][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        u64 r = r1.c[c], r2 = fq_add(r, r);
+        mul[0][c] = fq_neg(r2); mul[1][c] = fq_neg(r); mul[2][c] = 0; mul[3][c] = r; mul[4][c] = r2;
+    }
+    for (int side = 0; side < 2; side++) {
+        const int32_t *pl = (side ? planesR : planesL) + (size_t)cidx * n_planes;
+        int32_t v0 = 2 * j < n_planes ? pl[2 * j] : 0, v1 = 2 * j + 1 < n_planes ? pl[2 * j + 1] : 0;
+        for (u32 k = 0; k < K; k++) {
+            int f0 = digit2(v0, k), df = digit2(v1, k) - f0;
+            u64 *dst = F + (((size_t)(side * K + k) * 3 + d) * 24 + 3 * slot) * half + j;
+            dst[0] = fq_add(fq_from_digit(f0), mul[df + 2][0]);
+            dst[half] = mul[df + 2][1];
+            dst[2 * half] = mul[df + 2][2];
+        }
+    }
+}
+void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, Fq3Const r1,
+                             u64 *F, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_materialize, dim3(cdiv(m / 2, 256), 24), dim3(256), 0, s, planesL, planesR, n_planes, m, K, r1, F);
+}
+
+// general round on materialised f-hat tables
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow,
+                                                    u64 *partial) {
+    u32 slot = blockIdx.y;
+    size_t pairs = a.n / 2;
+    const u64 nu = t.nu;
+    Fq3 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+        fold_g13<NU>(acc, a, slot, p, nu);
+        Fq3 Q[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
+        for (u32 kd = 0; kd < 2 * K * 3; kd++) {
+            const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
+            ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
+            Fq3 f0 = fq3_make(x0.x, x1.x, x2.x), df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
+            // P(f0 + X df), P(f) = f^3 - f
+            Fq3 f0s = S3<NU>(f0, nu), dfs = S3<NU>(df, nu);
+            Fq3 c0 = fq3_sub(M3<NU>(f0s, f0, nu), f0);
+            Fq3 c3 = M3<NU>(dfs, df, nu);
+            Fq3 t1 = M3<NU>(f0s, df, nu), t2 = M3<NU>(dfs, f0, nu);
+            Fq3 c1 = fq3_sub(fq3_add(fq3_add(t1, t1), t1), df);
+            Fq3 c2 = fq3_add(fq3_add(t2, t2), t2);
+            Fq3Const mc = mu_pow[kd];
+            Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
+            Q[0] = fq3_add(Q[0], M3<NU>(c0, mu, nu));
+            Q[1] = fq3_add(Q[1], M3<NU>(c1, mu, nu));
+            Q[2] = fq3_add(Q[2], M3<NU>(c2, mu, nu));
+            Q[3] = fq3_add(Q[3], M3<NU>(c3, mu, nu));
+        }
+        fold_g2_finish<NU>(acc, Q, a, p, nu);
+    }
+    store_round_partial(acc, slot, partial);
+}
+void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
+                       u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    LF_LAUNCH(k_fold_round, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, F, ldF, K, mu_pow_dev, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compute_f_0 (folding.rs:258-268) in the coefficient domain: ICRT(sum_i rho_i (.) f_i) = sum_i rho_i * f_i mod
+// Phi_72 exactly, with rho_i in [-32,32)^24 and f_i the bit-planes -> plain int32 convolutions.
+__global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho,
+                                                      int32_t *out) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int32_t acc[47];
+#pragma unroll
+    for (int i = 0; i < 47; i++) acc[i] = 0;
+    for (int side = 0; side < 2; side++) {
+        const int32_t *pl = side ? planesR : planesL;
+        int32_t v[24];
+#pragma unroll
+        for (int c = 0; c < 24; c++) v[c] = pl[(size_t)c * n + j];
+        for (u32 k = 0; k < K; k++) {
+            const int8_t *rk = rho + (size_t)(side * K + k) * 24;
+            int dg[24];
+#pragma unroll
+            for (int c = 0; c < 24; c++) dg[c] = digit2(v[c], k);
+#pragma unroll
+            for (int a = 0; a < 24; a++) {
+                int ra = rk[a];
+#pragma unroll
+                for (int c = 0; c < 24; c++) acc[a + c] += ra * dg[c];
+            }
+        }
+    }
+    // X^24 = X^12 - 1
+#pragma unroll
+    for (int i = 46; i >= 24; i--) { acc[i - 12] += acc[i]; acc[i - 24] -= acc[i]; }
+#pragma unroll
+    for (int c = 0; c < 24; c++) out[(size_t)c * n + j] = acc[c];
+}
+void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_witness, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho_dev, out);
+}
+
+}  // namespace lf

@@ -51,7 +51,7 @@ int lfo_ajtai_commit(const u64 *A, u32 kappa, size_t n, const u64 *f, u64 *out) 
         u64 acc[RE] = {0};
         const u64 *row = A + (size_t)i * n * RE;
 #ifdef _OPENMP
-#pragma omp parallel
+#pragma omp parallel if (n >= 4096)
         {
             u64 loc[RE] = {0}, t[RE];
 #pragma omp for schedule(static) nowait
@@ -89,7 +89,7 @@ void lfo_build_eq(const u64 *r, u32 nv, u64 *out) {
     for (int i = (int)nv - 2; i >= 0; i--) {
         memcpy(buf, out, len * RE * sizeof(u64));
         const u64 *ri = r + (size_t)i * RE;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (len >= 4096)
         for (size_t j = 0; j < len; j++) {
             u64 tmp[RE];
             rq_mul(tmp, ri, buf + j * RE);
@@ -107,7 +107,7 @@ static void mle_fix(u64 **pt, size_t len, const u64 *r) {
     size_t half = len / 2;
     const u64 *src = *pt;
     u64 *dst = ralloc(half);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (half >= 4096)
     for (size_t j = 0; j < half; j++) {
         u64 d[RE];
         rq_sub(d, src + (2 * j + 1) * RE, src + (2 * j) * RE);
@@ -154,7 +154,7 @@ static void spmv(const lfo_params *p, const lfo_ccs *ccs, u32 j, const u64 *z, u
     const u32 *rp = ccs->rowptr[j];
     const u32 *ci = ccs->col[j];
     const u64 *va = ccs->val[j];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m >= 4096)
     for (size_t row = 0; row < m; row++) {
         u64 acc[RE] = {0}, t[RE];
         for (u32 k = rp[row]; k < rp[row + 1]; k++) {
@@ -169,7 +169,7 @@ static void spmv(const lfo_params *p, const lfo_ccs *ccs, u32 j, const u64 *z, u
 static void build_fhat(const u64 *f_coeff, size_t N, size_t m, u64 **tables /*TAU*/) {
     for (int d = 0; d < TAU; d++) {
         tables[d] = ralloc(m);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N >= 4096)
         for (size_t i = 0; i < N; i++)
             for (int k = 0; k < 8; k++) tables[d][i * RE + 3 * k] = f_coeff[i * RE + 8 * d + k];
     }
@@ -216,7 +216,7 @@ static void sumcheck_prove(lfo_transcript *tr, u64 **tables, u32 P, u32 nv, u32 
         size_t pairs = len / 2;
         u64 *evals = msgs + (size_t)(round - 1) * (degree + 1) * RE;
         memset(evals, 0, (size_t)(degree + 1) * RE * sizeof(u64));
-#pragma omp parallel
+#pragma omp parallel if (pairs >= 64)
         {
             u64 *vals0 = (u64 *)malloc((size_t)P * RE * sizeof(u64));
             u64 *vals1 = (u64 *)malloc((size_t)P * RE * sizeof(u64));
@@ -489,7 +489,7 @@ static void comb_fold(const u64 *vals, u64 *out, const void *vctx) {
 
 /* Horner-combine tables: for T in rev: acc += T; acc *= ch  (folding.rs:208-226, utils.rs:524-546) */
 static void horner_add(u64 *dst, u64 *const *tabs, u32 cnt, const u64 *ch, size_t m) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m >= 4096)
     for (size_t i = 0; i < m; i++) {
         u64 acc[RE] = {0};
         for (int j = (int)cnt - 1; j >= 0; j--) {
@@ -576,7 +576,7 @@ int lfo_fold_step(const lfo_params *p, const lfo_ccs *ccs, const u64 *A, lfo_tra
     lfo_crt(rho_c, rho, K2);
 
     /* compute_f_0, folding.rs:258-268 */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N >= 4096)
     for (size_t j = 0; j < N; j++) {
         u64 a[RE] = {0}, t[RE];
         for (u32 i = 0; i < K2; i++) {

@@ -124,7 +124,7 @@ void lfo_fq3_mul(const u64 *a, const u64 *b, u64 *out) {
 /* CRT: slot_k = a(y_k) evaluated in F_{p^3} */
 void lfo_crt(const u64 *in, u64 *out, size_t count) {
     ensure_init();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (count >= 4096)
     for (size_t e = 0; e < count; e++) {
         const u64 *a = in + 24 * e;
         u64 res[24];
@@ -140,7 +140,7 @@ void lfo_crt(const u64 *in, u64 *out, size_t count) {
 
 void lfo_icrt(const u64 *in, u64 *out, size_t count) {
     ensure_init();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (count >= 4096)
     for (size_t e = 0; e < count; e++) {
         const u64 *x = in + 24 * e;
         u64 res[24];
@@ -209,7 +209,7 @@ static void decompose_coeff(u64 v, u64 base, u32 digits, int64_t *out) {
 }
 
 void lfo_decompose(const u64 *in, size_t count, u64 base, u32 digits, int layout, u64 *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (count >= 4096)
     for (size_t e = 0; e < count; e++) {
         int64_t dg[64];
         for (int c = 0; c < 24; c++) {
@@ -223,7 +223,7 @@ void lfo_decompose(const u64 *in, size_t count, u64 base, u32 digits, int layout
 }
 
 void lfo_recompose(const u64 *in, size_t count_out, u64 base, u32 digits, u64 *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (count_out >= 4096)
     for (size_t e = 0; e < count_out; e++) {
         u64 acc[24] = {0};
         u64 pw = 1;

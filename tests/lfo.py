@@ -50,11 +50,30 @@ def _p32(a):
 _lib = None
 
 
+def default_threads():
+    """OpenMP threads for the oracle: the usable cores (cgroup/affinity aware), capped at 32 -- the restatement's
+    parallel loops are short and 256 spinning threads on a quota-limited box make it crawl."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(default_threads()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         build()
         L = C.CDLL(_SO)
+        L.lfo_num_threads.restype = C.c_int
         L.lfo_set_ring.restype = C.c_int
         L.lfo_set_ring.argtypes = [C.c_uint64, u64p]
         L.lfo_lcccs_len.restype = C.c_size_t
