@@ -133,6 +133,7 @@ int lfo_verify(const lfo_params *, const lfo_ccs *, lfo_transcript *, const u64 
                const u64 *cm_i, const u64 *proof, u64 *lcccs_out);
 
 int lfo_num_threads(void);
+void lfo_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,14 @@
 #define TAU LFO_TAU
 #define RE 24 /* words per ring element */
 
+void lfo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int lfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -74,6 +74,8 @@ def lib():
         build()
         L = C.CDLL(_SO)
         L.lfo_num_threads.restype = C.c_int
+        L.lfo_set_num_threads.argtypes = [C.c_int]
+        L.lfo_set_num_threads(int(os.environ["OMP_NUM_THREADS"]))  # explicit: another runtime (torch) may have initialised OpenMP already
         L.lfo_set_ring.restype = C.c_int
         L.lfo_set_ring.argtypes = [C.c_uint64, u64p]
         L.lfo_lcccs_len.restype = C.c_size_t
