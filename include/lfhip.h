@@ -129,6 +129,9 @@ void lf_transcript_absorb_ring(lf_transcript *, const uint64_t *elems, size_t n)
 void lf_transcript_get_challenge(lf_transcript *, uint64_t *fq3_out);
 void lf_transcript_get_short_challenge(lf_transcript *, uint64_t *coeff_out);
 void lf_poseidon_params(uint64_t *ark /* 720 */, uint64_t *mds /* 576 */);
+/* one Poseidon permutation on 24 words; plain != 0 selects the textbook round loop instead of the
+ * (output-identical) sparse-matrix partial rounds the transcript uses */
+void lf_poseidon_permute(uint64_t *state, int plain);
 
 /* ---- sumcheck split at the transcript (utils/sumcheck.rs:53-80, sumcheck/prover.rs:56-162) ---------
  * Generic entry for the linearization-shaped polynomial  comb = (sum_i c_i prod_{j in S_i} T_j) * T_last

@@ -97,6 +97,8 @@ def _lib():
         L.lf_transcript_get_short_challenge.restype = None
         L.lf_poseidon_params.argtypes = [u64p, u64p]
         L.lf_poseidon_params.restype = None
+        L.lf_poseidon_permute.argtypes = [u64p, C.c_int]
+        L.lf_poseidon_permute.restype = None
         L.lf_sumcheck_lin_begin.argtypes = [vp, u64p, u64p]
         L.lf_sumcheck_lin_round.argtypes = [vp, u64p, u64p]
         L.lf_sumcheck_lin_end.argtypes = [vp]
@@ -390,6 +392,12 @@ def poseidon_params():
     mds = np.zeros(576, dtype=np.uint64)
     _lib().lf_poseidon_params(ark.ctypes.data_as(u64p), mds.ctypes.data_as(u64p))
     return ark, mds
+
+
+def poseidon_permute(state, plain=False):
+    a = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    _lib().lf_poseidon_permute(a.ctypes.data_as(u64p), int(plain))
+    return a
 
 
 class LFLinearizationProver:

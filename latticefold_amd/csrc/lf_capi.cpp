@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <future>
 #include <map>
 #include <mutex>
 #include <string>
@@ -681,6 +682,10 @@ void lf_transcript_get_challenge(lf_transcript *t, uint64_t *o) {
     o[0] = c.c[0]; o[1] = c.c[1]; o[2] = c.c[2];
 }
 void lf_transcript_get_short_challenge(lf_transcript *t, uint64_t *o) { t->t.get_short_challenge(o); }
+void lf_poseidon_permute(uint64_t *state, int plain) {
+    if (plain) Transcript::permute_plain(state);
+    else Transcript::permute(state);
+}
 void lf_poseidon_params(uint64_t *ark, uint64_t *mds) {
     const u64 *a, *m;
     Transcript::params(&a, &m);
@@ -919,9 +924,17 @@ static int decompose_impl(lf_ctx *c, Transcript &tr, const u64 *lcccs, const std
     LF_TRACE(c, "u_s");
     c->ev_end(ph);
 
+    return LF_OK;
+}
+
+// transcript part of the decomposition (decomposition.rs:65-83): absorb x_k, y_k, u_k, v_k and build the K LCCCS.
+// No challenge is drawn here, so for the left instance it runs on a host thread while the GPU decomposes the right one.
+static double absorb_decomposition(const lf_params &P, Transcript &tr, const u64 *lcccs, const u64 *proof, SideState &S) {
+    auto t0 = std::chrono::steady_clock::now();
+    u32 K = P.K;
+    const u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24, *x_s = v_s + (size_t)K * 72, *y_s = x_s + (size_t)K * (P.l + 1) * 24;
     size_t ll = lf_lcccs_len(&P);
     S.lcccs.assign((size_t)K * ll * 24, 0);
-    HostTimer ht(c);
     for (u32 k = 0; k < K; k++) {
         const u64 *xk = x_s + (size_t)k * (P.l + 1) * 24, *yk = y_s + (size_t)k * P.kappa * 24;
         const u64 *uk = u_s + (size_t)k * P.t * 24, *vk = v_s + (size_t)k * 72;
@@ -936,7 +949,7 @@ static int decompose_impl(lf_ctx *c, Transcript &tr, const u64 *lcccs, const std
         memcpy(o, uk, (size_t)P.t * 24 * 8); o += (size_t)P.t * 24;
         memcpy(o, xk, (size_t)(P.l + 1) * 24 * 8);
     }
-    return LF_OK;
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 static int upload_consts(lf_ctx *c, const std::string &name, const std::vector<Fq3Const> &v, Fq3Const **out) {
@@ -1183,7 +1196,13 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     SideState S[2];
     std::vector<Fq3> rR;
     if (rc == LF_OK) { lcccs_point(P, lin.data(), rR); rc = decompose_impl(c, tr, acc, rL, w_acc, "L", nullptr, S[0], decl); }
-    if (rc == LF_OK) rc = decompose_impl(c, tr, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
+    if (rc == LF_OK) {
+        std::future<double> fl = std::async(std::launch::async, [&] { return absorb_decomposition(P, tr, acc, decl, S[0]); });
+        rc = decompose_impl(c, tr, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
+        double hidden = fl.get();
+        (void)hidden;  // overlapped with GPU work: not on the critical path
+        if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
+    }
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->ev_end(tot);
     c->ev_collect();

@@ -112,6 +112,43 @@ LF_HD u64 acc_reduce(const Acc &s) {
     return r;
 }
 
+// ---- partial-product accumulator --------------------------------------------------------------------------
+// A sum of 64x64 products is kept as three 64-bit sums of 32x32 partial products (weights 2^0, 2^32, 2^64) plus
+// carry counters.  On gfx950 one partial product costs exactly two instructions: v_mad_u64_u32 (multiply-add with
+// carry-out in VCC) + v_addc_co_u32 into the counter -- no shifting/recombination, no reduction until the end.
+struct AccP {
+    u64 s00, s01, s11;
+    u32 c00, c01, c11;
+};
+LF_HD void accp_zero(AccP &a) { a.s00 = a.s01 = a.s11 = 0; a.c00 = a.c01 = a.c11 = 0; }
+LF_HD void mad_cc(u64 &acc, u32 &cnt, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+#else
+    u64 p = (u64)a * b, n = acc + p;
+    cnt += (n < p);
+    acc = n;
+#endif
+}
+LF_HD void accp_mad(AccP &s, u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    mad_cc(s.s00, s.c00, a0, b0);
+    mad_cc(s.s01, s.c01, a0, b1);
+    mad_cc(s.s01, s.c01, a1, b0);
+    mad_cc(s.s11, s.c11, a1, b1);
+}
+// value mod p, canonical:  s00 + s01*2^32 + s11*2^64 + c00*2^64 + c01*2^96 + c11*2^128
+// with 2^64 = 2^32-1, 2^96 = -1, 2^128 = -2^32 (mod p)
+LF_HD u64 accp_reduce(const AccP &s) {
+    u64 r = fq_canon(s.s00);
+    r = fq_add(r, fq_canon(fq_reduce128_loose(s.s01 << 32, s.s01 >> 32)));
+    r = fq_add(r, fq_canon(fq_reduce128_loose(0, s.s11)));
+    r = fq_add(r, ((u64)s.c00 << 32) - s.c00);          // c00 * (2^32 - 1) < p
+    r = fq_sub(r, (u64)s.c01);
+    r = fq_sub(r, (u64)s.c11 << 32);
+    return r;
+}
+
 // schoolbook product, 9 base multiplications, lazy 128-bit column sums, 5 reductions
 template <bool NU2P40>
 LF_HD Fq3 fq3_mul(Fq3 a, Fq3 b, u64 nu) {

@@ -7,6 +7,9 @@
 #include <string.h>
 
 #include <mutex>
+#include <utility>
+#include <vector>
+#include <stdlib.h>
 
 namespace lf {
 
@@ -232,16 +235,109 @@ inline u64 sbox(u64 x) {
     u64 x2 = fq_mul(x, x), x3 = fq_mul(x2, x), x4 = fq_mul(x2, x2);
     return fq_mul(x4, x3);
 }
+typedef unsigned __int128 u128;
+// sum_j a[j]*b[j] mod p for n <= 2^32 terms: low and high 64-bit halves of the products are summed separately
+inline u64 dot_fq(const u64 *a, const u64 *b, int n) {
+    u128 lo = 0, hi = 0;
+    for (int j = 0; j < n; j++) {
+        u128 pr = (u128)a[j] * b[j];
+        lo += (u64)pr;
+        hi += (u64)(pr >> 64);
+    }
+    u64 l = fq_canon(fq_reduce128_loose((u64)lo, (u64)(lo >> 64)));
+    u64 h = fq_canon(fq_reduce128_loose((u64)hi, (u64)(hi >> 64)));
+    return fq_add(l, fq_mul(h, LF_EPS));  // 2^64 = 2^32 - 1 (mod p)
+}
+
+// Partial rounds through the sparse factorisation M*diag(1,E) = diag(1,E') * [[e00, row],[col, I]] (Poseidon paper,
+// appendix on optimised partial rounds): identical output, 47 instead of 576 multiplications per partial round.
+struct PartialOpt {
+    u64 cst[RP][W];       // round constants pulled through the deferred block-diagonal factor
+    u64 e00[RP];
+    u64 row[RP][W - 1];
+    u64 col[RP][W - 1];
+    u64 post[W - 1][W - 1];  // deferred factor applied once after the last partial round
+};
+PartialOpt g_opt;
+
+bool mat_inv(const u64 *in, u64 *out, int n) {  // Gauss-Jordan over F_p
+    std::vector<u64> M((size_t)n * 2 * n, 0);
+    for (int r = 0; r < n; r++) {
+        for (int c = 0; c < n; c++) M[(size_t)r * 2 * n + c] = in[r * n + c];
+        M[(size_t)r * 2 * n + n + r] = 1;
+    }
+    for (int col = 0; col < n; col++) {
+        int piv = -1;
+        for (int r = col; r < n; r++)
+            if (M[(size_t)r * 2 * n + col]) { piv = r; break; }
+        if (piv < 0) return false;
+        if (piv != col)
+            for (int c = 0; c < 2 * n; c++) std::swap(M[(size_t)piv * 2 * n + c], M[(size_t)col * 2 * n + c]);
+        u64 inv = fq_inv(M[(size_t)col * 2 * n + col]);
+        for (int c = 0; c < 2 * n; c++) M[(size_t)col * 2 * n + c] = fq_mul(M[(size_t)col * 2 * n + c], inv);
+        for (int r = 0; r < n; r++) {
+            u64 f = M[(size_t)r * 2 * n + col];
+            if (r == col || !f) continue;
+            for (int c = 0; c < 2 * n; c++) M[(size_t)r * 2 * n + c] = fq_sub(M[(size_t)r * 2 * n + c], fq_mul(f, M[(size_t)col * 2 * n + c]));
+        }
+    }
+    for (int r = 0; r < n; r++)
+        for (int c = 0; c < n; c++) out[r * n + c] = M[(size_t)r * 2 * n + n + c];
+    return true;
+}
+
+void partial_opt_init() {
+    const int n = W - 1;
+    std::vector<u64> Eprev((size_t)n * n, 0), EprevInv((size_t)n * n, 0), eff((size_t)W * W), Eh((size_t)n * n), Ei((size_t)n * n);
+    for (int i = 0; i < n; i++) Eprev[(size_t)i * n + i] = EprevInv[(size_t)i * n + i] = 1;
+    for (int r = 0; r < RP; r++) {
+        const u64 *c = g_ark + (size_t)(RF / 2 + r) * W;
+        // constants: c' = diag(1, Eprev^-1) c
+        g_opt.cst[r][0] = c[0];
+        for (int i = 0; i < n; i++) g_opt.cst[r][1 + i] = dot_fq(&EprevInv[(size_t)i * n], c + 1, n);
+        // eff = M * diag(1, Eprev)
+        for (int i = 0; i < W; i++) {
+            eff[(size_t)i * W] = g_mds[i * W];
+            for (int j = 0; j < n; j++) {
+                u64 acc = 0;
+                for (int k = 0; k < n; k++) acc = fq_add(acc, fq_mul(g_mds[i * W + 1 + k], Eprev[(size_t)k * n + j]));
+                eff[(size_t)i * W + 1 + j] = acc;
+            }
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) Eh[(size_t)i * n + j] = eff[(size_t)(1 + i) * W + 1 + j];
+        if (!mat_inv(Eh.data(), Ei.data(), n)) abort();
+        g_opt.e00[r] = eff[0];
+        for (int j = 0; j < n; j++) g_opt.row[r][j] = eff[1 + j];
+        for (int i = 0; i < n; i++) {
+            u64 acc = 0;
+            for (int k = 0; k < n; k++) acc = fq_add(acc, fq_mul(Ei[(size_t)i * n + k], eff[(size_t)(1 + k) * W]));
+            g_opt.col[r][i] = acc;
+        }
+        Eprev = Eh;
+        EprevInv = Ei;
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) g_opt.post[i][j] = Eprev[(size_t)i * n + j];
+}
+
+inline void full_round(u64 st[W], const u64 *ark) {
+    u64 nw[W];
+    for (int i = 0; i < W; i++) st[i] = sbox(fq_add(st[i], ark[i]));
+    for (int i = 0; i < W; i++) nw[i] = dot_fq(st, g_mds + i * W, W);
+    memcpy(st, nw, sizeof(nw));
+}
 }  // namespace
 
 void Transcript::params(const u64 **ark, const u64 **mds) {
-    std::call_once(g_once, poseidon_init);
+    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
     *ark = g_ark;
     *mds = g_mds;
 }
 
-void Transcript::permute(u64 st[24]) {
-    std::call_once(g_once, poseidon_init);
+// plain definition (arkworks PoseidonSponge::permute): used by the self-test
+void Transcript::permute_plain(u64 st[24]) {
+    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
     u64 nw[W];
     for (int r = 0; r < RF + RP; r++) {
         const u64 *ark = g_ark + r * W;
@@ -249,19 +345,42 @@ void Transcript::permute(u64 st[24]) {
         for (int i = 0; i < W; i++) st[i] = fq_add(st[i], ark[i]);
         if (full) for (int i = 0; i < W; i++) st[i] = sbox(st[i]);
         else st[0] = sbox(st[0]);
-        for (int i = 0; i < W; i++) {
-            // 24 products < 2^128 each: accumulate (hi, lo, overflow) lazily, one reduction per row
-            Acc a;
-            acc_set(a, st[0], g_mds[i * W]);
-            for (int j = 1; j < W; j++) acc_mad(a, st[j], g_mds[i * W + j]);
-            nw[i] = acc_reduce(a);
-        }
+        for (int i = 0; i < W; i++) nw[i] = dot_fq(st, g_mds + i * W, W);
         memcpy(st, nw, sizeof(nw));
     }
 }
 
+void Transcript::permute(u64 st[24]) {
+    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
+    for (int r = 0; r < RF / 2; r++) full_round(st, g_ark + r * W);
+    for (int r = 0; r < RP; r++) {
+        for (int i = 0; i < W; i++) st[i] = fq_add(st[i], g_opt.cst[r][i]);
+        st[0] = sbox(st[0]);
+        u64 x0 = st[0];
+        // y0 = e00*x0 + row.x[1..] ; y_i = col_i*x0 + x_i
+        u128 lo = (u128)g_opt.e00[r] * x0, hi = 0;
+        hi = (u64)(lo >> 64);
+        lo = (u64)lo;
+        for (int j = 0; j < W - 1; j++) {
+            u128 pr = (u128)g_opt.row[r][j] * st[1 + j];
+            lo += (u64)pr;
+            hi += (u64)(pr >> 64);
+        }
+        u64 l = fq_canon(fq_reduce128_loose((u64)lo, (u64)(lo >> 64)));
+        u64 h = fq_canon(fq_reduce128_loose((u64)hi, (u64)(hi >> 64)));
+        for (int i = 0; i < W - 1; i++) st[1 + i] = fq_add(st[1 + i], fq_mul(g_opt.col[r][i], x0));
+        st[0] = fq_add(l, fq_mul(h, LF_EPS));
+    }
+    {   // deferred block-diagonal factor
+        u64 nw[W - 1];
+        for (int i = 0; i < W - 1; i++) nw[i] = dot_fq(g_opt.post[i], st + 1, W - 1);
+        memcpy(st + 1, nw, sizeof(nw));
+    }
+    for (int r = RF / 2 + RP; r < RF + RP; r++) full_round(st, g_ark + r * W);
+}
+
 Transcript::Transcript() : squeezing_(false), idx_(0) {
-    std::call_once(g_once, poseidon_init);
+    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
     memset(st_, 0, sizeof(st_));
 }
 

@@ -359,43 +359,46 @@ void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_plane
 // whole j-range (one reduction per output at the very end).
 constexpr int AJ_JT = 32;
 constexpr int AJ_MAXROWS = 64;   // kappa + batch <= 64 per launch
-struct Acc5 { Acc s[5]; };
+struct Acc5 { AccP s[5]; };  // the five schoolbook column sums of an F_{p^3} product, un-reduced
 __device__ __forceinline__ void acc5_zero(Acc5 &a) {
 #pragma unroll
-    for (int i = 0; i < 5; i++) { a.s[i].lo = 0; a.s[i].hi = 0; a.s[i].ov = 0; }
+    for (int i = 0; i < 5; i++) accp_zero(a.s[i]);
 }
 __device__ __forceinline__ void acc5_mac(Acc5 &a, const u64 x[3], const u64 y[3]) {
-    acc_mad(a.s[0], x[0], y[0]);
-    acc_mad(a.s[1], x[0], y[1]); acc_mad(a.s[1], x[1], y[0]);
-    acc_mad(a.s[2], x[0], y[2]); acc_mad(a.s[2], x[1], y[1]); acc_mad(a.s[2], x[2], y[0]);
-    acc_mad(a.s[3], x[1], y[2]); acc_mad(a.s[3], x[2], y[1]);
-    acc_mad(a.s[4], x[2], y[2]);
+    accp_mad(a.s[0], x[0], y[0]);
+    accp_mad(a.s[1], x[0], y[1]); accp_mad(a.s[1], x[1], y[0]);
+    accp_mad(a.s[2], x[0], y[2]); accp_mad(a.s[2], x[1], y[1]); accp_mad(a.s[2], x[2], y[0]);
+    accp_mad(a.s[3], x[1], y[2]); accp_mad(a.s[3], x[2], y[1]);
+    accp_mad(a.s[4], x[2], y[2]);
 }
 template <bool NU>
 __device__ __forceinline__ Fq3 acc5_finish(const Acc5 &a, u64 nu) {
     Fq3 r;
-    r.c[0] = fq_add(acc_reduce(a.s[0]), fq_mul_nu<NU>(acc_reduce(a.s[3]), nu));
-    r.c[1] = fq_add(acc_reduce(a.s[1]), fq_mul_nu<NU>(acc_reduce(a.s[4]), nu));
-    r.c[2] = acc_reduce(a.s[2]);
+    r.c[0] = fq_add(accp_reduce(a.s[0]), fq_mul_nu<NU>(accp_reduce(a.s[3]), nu));
+    r.c[1] = fq_add(accp_reduce(a.s[1]), fq_mul_nu<NU>(accp_reduce(a.s[4]), nu));
+    r.c[2] = accp_reduce(a.s[2]);
     return r;
 }
+constexpr int AJ_THREADS = 448;  // 7 waves: 26 x 15 = 390 outputs -> 87 % of the lanes busy
 template <bool NU>
-__global__ void __launch_bounds__(256) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
-                                               u64 *partial) {
-    __shared__ u64 sA[AJ_MAXROWS][3][AJ_JT];  // rows 0..kappa-1 = A, kappa.. = F
+__global__ void __launch_bounds__(AJ_THREADS) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
+                                                      u64 *partial) {
+    __shared__ u64 sA[AJ_MAXROWS][3][AJ_JT + 1];  // rows 0..kappa-1 = A, kappa.. = F ; +1 pad: rows land on different banks
     const u32 slot = blockIdx.y, split = blockIdx.x;
     const u32 rows = kappa + batch;
     const u32 nout = kappa * batch;
     size_t per = (n + splits - 1) / splits;
     per = (per + AJ_JT - 1) / AJ_JT * AJ_JT;
     size_t j0 = (size_t)split * per, j1 = j0 + per < n ? j0 + per : n;
-    Acc5 acc[2];
-    acc5_zero(acc[0]); acc5_zero(acc[1]);
-    u32 o0 = threadIdx.x, o1 = threadIdx.x + 256;
-    u32 i0 = o0 / batch, k0 = o0 % batch, i1 = o1 / batch, k1 = o1 % batch;
+    Acc5 acc;
+    acc5_zero(acc);
+    const u32 o0 = threadIdx.x;
+    const u32 i0 = o0 / batch, k0 = o0 % batch;
+    const bool active = o0 < nout;
+    const u32 ra = active ? i0 : 0, rf = active ? kappa + k0 : kappa;
     for (size_t jt = j0; jt < j1; jt += AJ_JT) {
         __syncthreads();
-        for (u32 idx = threadIdx.x; idx < rows * 3 * AJ_JT; idx += 256) {
+        for (u32 idx = threadIdx.x; idx < rows * 3 * AJ_JT; idx += AJ_THREADS) {
             u32 jj = idx % AJ_JT, rc = idx / AJ_JT, c = rc % 3, r = rc / 3;
             size_t j = jt + jj;
             u64 v = 0;
@@ -406,28 +409,20 @@ __global__ void __launch_bounds__(256) k_ajtai(DevCrt t, const u64 *A, u32 kappa
             sA[r][c][jj] = v;
         }
         __syncthreads();
-        if (o0 < nout) {
+        if (active) {
+#pragma unroll 4
             for (int jj = 0; jj < AJ_JT; jj++) {
-                u64 x[3] = {sA[i0][0][jj], sA[i0][1][jj], sA[i0][2][jj]};
-                u64 y[3] = {sA[kappa + k0][0][jj], sA[kappa + k0][1][jj], sA[kappa + k0][2][jj]};
-                acc5_mac(acc[0], x, y);
-                if (o1 < nout) {
-                    u64 x1[3] = {sA[i1][0][jj], sA[i1][1][jj], sA[i1][2][jj]};
-                    u64 y1[3] = {sA[kappa + k1][0][jj], sA[kappa + k1][1][jj], sA[kappa + k1][2][jj]};
-                    acc5_mac(acc[1], x1, y1);
-                }
+                u64 x[3] = {sA[ra][0][jj], sA[ra][1][jj], sA[ra][2][jj]};
+                u64 y[3] = {sA[rf][0][jj], sA[rf][1][jj], sA[rf][2][jj]};
+                acc5_mac(acc, x, y);
             }
         }
     }
     // partial[split][slot][o][3]
     u64 *dst = partial + ((size_t)split * 8 + slot) * nout * 3;
-    if (o0 < nout) {
-        Fq3 r = acc5_finish<NU>(acc[0], t.nu);
+    if (active) {
+        Fq3 r = acc5_finish<NU>(acc, t.nu);
         dst[(size_t)o0 * 3] = r.c[0]; dst[(size_t)o0 * 3 + 1] = r.c[1]; dst[(size_t)o0 * 3 + 2] = r.c[2];
-    }
-    if (o1 < nout) {
-        Fq3 r = acc5_finish<NU>(acc[1], t.nu);
-        dst[(size_t)o1 * 3] = r.c[0]; dst[(size_t)o1 * 3 + 1] = r.c[1]; dst[(size_t)o1 * 3 + 2] = r.c[2];
     }
 }
 // out[k][i][3*slot+c] = sum_split partial[split][slot][i*batch+k][c]
@@ -444,7 +439,7 @@ __global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, u32 ka
 size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) { return (size_t)splits * 8 * kappa * batch * 3; }
 void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits, u64 *partial, u64 *out,
                   hipStream_t s) {
-    LF_LAUNCH(k_ajtai, t.nu2p40, dim3(splits, 8), dim3(256), s, t, A, kappa, n, F, batch, splits, partial);
+    LF_LAUNCH(k_ajtai, t.nu2p40, dim3(splits, 8), dim3(AJ_THREADS), s, t, A, kappa, n, F, batch, splits, partial);
     hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
 }
 
@@ -522,35 +517,35 @@ void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, con
 // batched inner products (evaluate_mles, utils/mle_helpers.rs:65-88, restructured as dot products)
 constexpr u32 RED_BLOCKS = 256;
 template <bool NU>
-__global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, size_t n,
+__global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n,
                                                    u64 *partial) {
-    // grid (RED_BLOCKS, 8 slots, nb); accumulators for up to 16 a's
-    u32 slot = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
-    Acc5 acc[16];
+    // grid (RED_BLOCKS, 8 slots, nb * ceil(na/4)); each block accumulates 4 a's against one b
+    u32 slot = blockIdx.y, b = blockIdx.z % nb, a0 = (blockIdx.z / nb) * 4;
+    Acc5 acc[4];
 #pragma unroll
-    for (int a = 0; a < 16; a++) acc5_zero(acc[a]);
+    for (int a = 0; a < 4; a++) acc5_zero(acc[a]);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         Fq3 y = ld3(Y + (size_t)b * 24 * ldy, ldy, slot, i);
 #pragma unroll
-        for (int a = 0; a < 16; a++)
-            if ((u32)a < na) {
-                Fq3 x = ld3(X + (size_t)a * 24 * ldx, ldx, slot, i);
+        for (int a = 0; a < 4; a++)
+            if (a0 + a < na) {
+                Fq3 x = ld3(X + (size_t)(a0 + a) * 24 * ldx, ldx, slot, i);
                 acc5_mac(acc[a], x.c, y.c);
             }
     }
-    u64 v[48];
+    u64 v[12];
 #pragma unroll
-    for (int a = 0; a < 16; a++) {
-        Fq3 r = (u32)a < na ? acc5_finish<NU>(acc[a], t.nu) : fq3_zero();
+    for (int a = 0; a < 4; a++) {
+        Fq3 r = a0 + a < na ? acc5_finish<NU>(acc[a], t.nu) : fq3_zero();
         v[3 * a] = r.c[0]; v[3 * a + 1] = r.c[1]; v[3 * a + 2] = r.c[2];
     }
     // partial[block][ (a*nb + b)*24 + 3*slot + c ]
-    __shared__ u64 red[48];
-    block_sum_store<48>(v, red);
+    __shared__ u64 red[12];
+    block_sum_store<12>(v, red);
     __syncthreads();
-    for (u32 idx = threadIdx.x; idx < na * 3; idx += 256) {
-        u32 a = idx / 3, c = idx % 3;
-        partial[(size_t)blockIdx.x * (16 * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[idx];
+    if (threadIdx.x < 12) {
+        u32 a = a0 + threadIdx.x / 3, c = threadIdx.x % 3;
+        if (a < na) partial[(size_t)blockIdx.x * (16 * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[threadIdx.x];
     }
 }
 size_t dot_partial_words(u32 na, u32 nb) { return (size_t)RED_BLOCKS * 16 * nb * 24; }
@@ -559,7 +554,7 @@ void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u
     u32 gb = (u32)((n + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
-    LF_LAUNCH(k_dot_batch, t.nu2p40, dim3(gb, 8, nb), dim3(256), s, t, X, ldx, na, Y, ldy, n, partial);
+    LF_LAUNCH(k_dot_batch, t.nu2p40, dim3(gb, 8, nb * ((na + 3) / 4)), dim3(256), s, t, X, ldx, na, Y, ldy, nb, n, partial);
     // rows of width 16*nb*24; only the first na*nb*24 entries are meaningful (a-major): reduce all na*nb*24
     hipLaunchKernelGGL(k_reduce_rows, dim3(na * nb * 24), dim3(256), 0, s, partial, gb, 16 * nb * 24, out);
 }
@@ -962,11 +957,13 @@ __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, co
     int32_t acc[47];
 #pragma unroll
     for (int i = 0; i < 47; i++) acc[i] = 0;
+#pragma unroll 1
     for (int side = 0; side < 2; side++) {
         const int32_t *pl = side ? planesR : planesL;
         int32_t v[24];
 #pragma unroll
         for (int c = 0; c < 24; c++) v[c] = pl[(size_t)c * n + j];
+#pragma unroll 1
         for (u32 k = 0; k < K; k++) {
             const int8_t *rk = rho + (size_t)(side * K + k) * 24;
             int dg[24];
@@ -974,9 +971,9 @@ __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, co
             for (int c = 0; c < 24; c++) dg[c] = digit2(v[c], k);
 #pragma unroll
             for (int a = 0; a < 24; a++) {
-                int ra = rk[a];
+                int ra = rk[a];  // wave-uniform: scalar load
 #pragma unroll
-                for (int c = 0; c < 24; c++) acc[a + c] += ra * dg[c];
+                for (int c = 0; c < 24; c++) acc[a + c] += __mul24(ra, dg[c]);
             }
         }
     }

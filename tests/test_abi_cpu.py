@@ -49,6 +49,19 @@ def test_product_transcript_matches_oracle_on_long_streams():
     assert (c.get_challenge() == a.get_challenge()).all()
 
 
+def test_sparse_partial_rounds_equal_plain_permutation():
+    import time
+    import lfo
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        st = rng.integers(0, 2**63, size=24, dtype=np.uint64)
+        o = st.copy()
+        lfo.lib().lfo_poseidon_permute(lfo._p64(o))
+        assert (api.poseidon_permute(st, plain=True) == o).all()
+        assert (api.poseidon_permute(st, plain=False) == o).all()
+    assert (api.poseidon_permute(np.zeros(24, dtype=np.uint64)) == api.poseidon_permute(np.zeros(24, dtype=np.uint64), True)).all()
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
