@@ -484,7 +484,7 @@ size_t lf_proof_len(const lf_params *p) { return lin_proof_len(p) + 2 * dec_proo
 int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
                 const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *cc) {
     if (!c || !p || !rowptr || !col || !val || !S_off || !S_idx || !cc) return LF_ERR_INVALID;
-    if (p->s == 0 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 16 || p->L == 0 || p->L > 8 ||
+    if (p->s < 3 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 16 || p->L == 0 || p->L > 8 ||
         p->d + 1 > 4 || p->wit_len == 0)
         return LF_ERR_UNSUPPORTED;
     if (p->b != 2) return LF_ERR_UNSUPPORTED;  // folding comb is specialised to b = 2 (all reference Goldilocks rows)
@@ -1018,8 +1018,8 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // working tables (ping-pong): 5 special tables + materialised f-hat
     u64 *F[2], *T5[2];
     size_t half = m / 2;
-    RET(c->tbuf("fold_F0", (size_t)K2 * 3 * 24 * (half ? half : 1), &F[0]));
-    RET(c->tbuf("fold_F1", (size_t)K2 * 3 * 24 * (half / 2 ? half / 2 : 1), &F[1]));
+    RET(c->tbuf("fold_F0", (size_t)K2 * 3 * 24 * (m / 4 ? m / 4 : 1), &F[0]));   // f-hat is materialised only after two rounds
+    RET(c->tbuf("fold_F1", (size_t)K2 * 3 * 24 * (m / 8 ? m / 8 : 1), &F[1]));
     // T5 layout per buffer: eqL[3] eqR[3] eqB[3] G1[24] G2[24] = 57 planes
     RET(c->tbuf("fold_T0", 57 * (half ? half : 1), &T5[0]));
     RET(c->tbuf("fold_T1", 57 * (half / 2 ? half / 2 : 1), &T5[1]));
@@ -1038,11 +1038,14 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->st);
             launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->st);
             launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->st);
-            if (round == 2) {
-                launch_fold_materialize(c->dcrt, S[0].planes, S[1].planes, N, m, K, r, F[0], c->st);
+            if (round == 3) {
+                // W_b = eq((r1, r2), b), b = b0 + 2 b1 (LSB-first)
+                Fq3 r1 = pt[0], r2 = pt[1], o1 = fq3_sub(fq3_one(), r1), o2 = fq3_sub(fq3_one(), r2);
+                Fq3Const W[4] = {f3c(c->ring.mul3(o1, o2)), f3c(c->ring.mul3(r1, o2)), f3c(c->ring.mul3(o1, r2)), f3c(c->ring.mul3(r1, r2))};
+                launch_fold_materialize2(c->dcrt, S[0].planes, S[1].planes, N, m, K, W, F[0], c->st);
                 curF = F[0]; ldF = nn;
-            } else {
-                u64 *fd = F[(round & 1) ? 1 : 0];  // round 3 -> F[1], round 4 -> F[0], ...
+            } else if (round > 3) {
+                u64 *fd = F[(round & 1) ? 0 : 1];  // round 4 -> F[1], round 5 -> F[0], ...
                 launch_fix_many(c->dcrt, curF, ldF, fd, nn, a.n, K2 * 3 * 8, r, c->st);
                 curF = fd; ldF = nn;
             }
@@ -1052,6 +1055,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         }
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->st);
+        else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->st);
         else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->st);
         c->ev_end(ev);
         LF_TRACE(c, "fold round");

@@ -111,6 +111,12 @@ void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *
 // after r_1: materialise fixed f-hat tables F[2K*3][24][n/2] = f0 + r1*(f1-f0)
 void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
                              Fq3Const r1, u64 *F, hipStream_t s);
+// round 2, still from the planes: entries are d_a + (d_b - d_a) r1 (a.* are the once-fixed tables, a.n = m/2)
+void launch_fold_round2(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                        const Fq3Const *mu_pow_dev, Fq3Const r1, u64 *partial, u64 *out, hipStream_t s);
+// after r_2: F[2K*3][24][m/4] = sum_b W_b * digit(f[4j+b]), W = eq((r1,r2), b)
+void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+                              const Fq3Const W[4], u64 *F, hipStream_t s);
 // general round on materialised tables F [2K*3][24][ldF] (b = 2)
 void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev,
                        u64 *partial, u64 *out, hipStream_t s);

@@ -871,6 +871,126 @@ void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *
     hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
 }
 
+// round 2: after one fix the virtual f-hat entries are  d_a + (d_b - d_a) * r1  with digits d in {-1,0,1}.  For a pair
+// f(X) = u(X) + v(X) r1 with small-integer linear u, v, so  f^3 - f = (u^3-u) + (3u^2 v - v) r1 + 3 u v^2 r1^2 + v^3 r1^3
+// and the mu-weighted sums of the 16 integer coefficients are exact 64-bit integer dot products again.
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_round2(DevCrt t, FoldRoundArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                                                     u32 K, const Fq3Const *mu_pow, Fq3Const r1c, u64 *partial) {
+    u32 slot = blockIdx.y;
+    size_t pairs = a.n / 2;
+    const u64 nu = t.nu;
+    const Fq3 r1 = fq3_make(r1c.c[0], r1c.c[1], r1c.c[2]);
+    const Fq3 r1s = S3<NU>(r1, nu), r1c3 = M3<NU>(r1s, r1, nu);
+    Fq3 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+        fold_g13<NU>(acc, a, slot, p, nu);
+        Fq3 Q[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
+        if (4 * p < n_planes) {
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {  // pass 0: powers r1^0, r1^1 ; pass 1: r1^2, r1^3
+                int64_t lo[2][4][3], hi[2][4][3];
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) { lo[e][j][c] = 0; hi[e][j][c] = 0; }
+                for (int side = 0; side < 2; side++) {
+                    const int32_t *pl = side ? planesR : planesL;
+                    for (int d = 0; d < 3; d++) {
+                        const int32_t *src = pl + (size_t)(8 * d + slot) * n_planes + 4 * p;
+                        int32_t w0 = src[0];
+                        int32_t w1 = 4 * p + 1 < n_planes ? src[1] : 0, w2 = 4 * p + 2 < n_planes ? src[2] : 0, w3 = 4 * p + 3 < n_planes ? src[3] : 0;
+                        for (u32 k = 0; k < K; k++) {
+                            int d0 = digit2(w0, k), d1 = digit2(w1, k), d2 = digit2(w2, k), d3 = digit2(w3, k);
+                            int u0 = d0, u1 = d2 - d0, v0 = d1 - d0, v1 = (d3 - d2) - v0;
+                            int cf[2][4];
+                            if (pass == 0) {
+                                int u0s = u0 * u0;
+                                cf[0][0] = u0s * u0 - u0; cf[0][1] = 3 * u0s * u1 - u1; cf[0][2] = 3 * u0 * u1 * u1; cf[0][3] = u1 * u1 * u1;
+                                cf[1][0] = 3 * u0s * v0 - v0; cf[1][1] = 3 * (u0s * v1 + 2 * u0 * u1 * v0) - v1;
+                                cf[1][2] = 3 * (2 * u0 * u1 * v1 + u1 * u1 * v0); cf[1][3] = 3 * u1 * u1 * v1;
+                            } else {
+                                int v0s = v0 * v0, v1s = v1 * v1;
+                                cf[0][0] = 3 * u0 * v0s; cf[0][1] = 3 * (2 * u0 * v0 * v1 + u1 * v0s); cf[0][2] = 3 * (u0 * v1s + 2 * u1 * v0 * v1);
+                                cf[0][3] = 3 * u1 * v1s;
+                                cf[1][0] = v0s * v0; cf[1][1] = 3 * v0s * v1; cf[1][2] = 3 * v0 * v1s; cf[1][3] = v1s * v1;
+                            }
+                            Fq3Const m = mu_pow[(side * K + k) * 3 + d];
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                int64_t ml = (int64_t)(u32)m.c[c], mh = (int64_t)(m.c[c] >> 32);
+#pragma unroll
+                                for (int e = 0; e < 2; e++)
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) { lo[e][j][c] += ml * cf[e][j]; hi[e][j][c] += mh * cf[e][j]; }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        Fq3 T;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) T.c[c] = fq_add(fq_from_i64(lo[e][j][c]), fq_mul(fq_from_i64(hi[e][j][c]), 1ULL << 32));
+                        if (pass == 0 && e == 0) Q[j] = fq3_add(Q[j], T);
+                        else Q[j] = fq3_add(Q[j], M3<NU>(T, pass == 0 ? r1 : (e == 0 ? r1s : r1c3), nu));
+                    }
+            }
+        }
+        fold_g2_finish<NU>(acc, Q, a, p, nu);
+    }
+    store_round_partial(acc, slot, partial);
+}
+void launch_fold_round2(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                        const Fq3Const *mu_pow_dev, Fq3Const r1, u64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    LF_LAUNCH(k_fold_round2, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, planesL, planesR, n_planes, K, mu_pow_dev, r1, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
+}
+
+// after r_2: F[(side*K+k)*3+d][3*slot+c][j] = sum_{b<4} W_b * digit(f[4j+b]),  W = eq((r1,r2), .),  j < m/4
+__global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+                                                           Fq3Const W0, Fq3Const W1, Fq3Const W2, Fq3Const W3, u64 *F) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 cidx = blockIdx.y;
+    size_t q = m / 4;
+    if (j >= q) return;
+    u32 d = cidx / 8, slot = cidx % 8;
+    const Fq3Const W[4] = {W0, W1, W2, W3};
+    for (int side = 0; side < 2; side++) {
+        const int32_t *pl = (side ? planesR : planesL) + (size_t)cidx * n_planes;
+        int32_t v[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) v[b] = 4 * j + b < n_planes ? pl[4 * j + b] : 0;
+        for (u32 k = 0; k < K; k++) {
+            u64 acc[3] = {0, 0, 0};
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int dg = digit2(v[b], k);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    u64 w = W[b].c[c];
+                    acc[c] = dg > 0 ? fq_add(acc[c], w) : (dg < 0 ? fq_sub(acc[c], w) : acc[c]);
+                }
+            }
+            u64 *dst = F + (((size_t)(side * K + k) * 3 + d) * 24 + 3 * slot) * q + j;
+            dst[0] = acc[0]; dst[q] = acc[1]; dst[2 * q] = acc[2];
+        }
+    }
+}
+void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+                              const Fq3Const W[4], u64 *F, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_materialize2, dim3(cdiv(m / 4, 256), 24), dim3(256), 0, s, planesL, planesR, n_planes, m, K, W[0], W[1], W[2], W[3], F);
+}
+
 // F[(side*K+k)*3+d][3*slot+c][j] = f0 + r1*(f1-f0), j < m/2  (first fix of the virtual f-hat tables)
 __global__ void __launch_bounds__(256) k_fold_materialize(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
                                                           Fq3Const r1, u64 *F) {
