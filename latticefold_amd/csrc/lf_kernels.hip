@@ -587,40 +587,41 @@ void launch_dot_eq(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 
 // f_coeff): T[k][c] = sum_i eq[i] * digit_k(f[i][c]);  v_d slot s = T[k][8d+s].
 __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits,
                                                    u64 *partial) {
-    // grid (RED_BLOCKS, 24 coefficients)
-    u32 c = blockIdx.y;
-    u64 acc[48];
+    // grid (RED_BLOCKS, 24 coefficients, K-groups of 4 bit-planes)
+    u32 c = blockIdx.y, kg = blockIdx.z * 4;
+    u64 acc[12];
 #pragma unroll
-    for (int i = 0; i < 48; i++) acc[i] = 0;
+    for (int i = 0; i < 12; i++) acc[i] = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         int32_t v = planes[(size_t)c * n + i];
-        u64 e0 = eq[i], e1 = eq[ldeq + i], e2 = eq[2 * ldeq + i];
+        u64 e[3] = {eq[i], eq[ldeq + i], eq[2 * ldeq + i]};
+        bool neg = v < 0;
+        u32 mg = (u32)(neg ? -v : v);
         if (mode_bits) {
-            int32_t mg = v < 0 ? -v : v;
-            bool neg = v < 0;
+            // +-eq[i] selected by the sign once, then masked (branch-free) adds per bit-plane
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if ((mg >> k) & 1) {
-                    acc[3 * k] = neg ? fq_sub(acc[3 * k], e0) : fq_add(acc[3 * k], e0);
-                    acc[3 * k + 1] = neg ? fq_sub(acc[3 * k + 1], e1) : fq_add(acc[3 * k + 1], e1);
-                    acc[3 * k + 2] = neg ? fq_sub(acc[3 * k + 2], e2) : fq_add(acc[3 * k + 2], e2);
-                }
+            for (int q = 0; q < 3; q++) e[q] = neg ? fq_neg(e[q]) : e[q];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u64 mask = (u64)0 - (u64)((mg >> (kg + k)) & 1);
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc[3 * k + q] = fq_add(acc[3 * k + q], e[q] & mask);
             }
         } else {
-            u64 mg = (u64)(v < 0 ? -v : v);
-            u64 t0 = fq_mul(e0, mg), t1 = fq_mul(e1, mg), t2 = fq_mul(e2, mg);
-            acc[0] = v < 0 ? fq_sub(acc[0], t0) : fq_add(acc[0], t0);
-            acc[1] = v < 0 ? fq_sub(acc[1], t1) : fq_add(acc[1], t1);
-            acc[2] = v < 0 ? fq_sub(acc[2], t2) : fq_add(acc[2], t2);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                u64 tq = fq_mul(e[q], (u64)mg);
+                acc[q] = neg ? fq_sub(acc[q], tq) : fq_add(acc[q], tq);
+            }
         }
     }
     // partial[block][k][c][3]
-    __shared__ u64 red[48];
-    block_sum_store<48>(acc, red);
+    __shared__ u64 red[12];
+    block_sum_store<12>(acc, red);
     __syncthreads();
-    for (u32 idx = threadIdx.x; idx < K * 3; idx += 256) {
-        u32 k = idx / 3, q = idx % 3;
-        partial[(size_t)blockIdx.x * (K * 72) + ((size_t)k * 24 + c) * 3 + q] = red[idx];
+    if (threadIdx.x < 12) {
+        u32 k = kg + threadIdx.x / 3, q = threadIdx.x % 3;
+        if (k < K) partial[(size_t)blockIdx.x * (K * 72) + ((size_t)k * 24 + c) * 3 + q] = red[threadIdx.x];
     }
 }
 size_t coef_eval_partial_words(u32 K) { return (size_t)RED_BLOCKS * K * 72; }
@@ -629,7 +630,7 @@ void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u6
     u32 gb = (u32)((n + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(k_coef_eval, dim3(gb, 24), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
+    hipLaunchKernelGGL(k_coef_eval, dim3(gb, 24, mode_bits ? (K + 3) / 4 : 1), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(K * 72), dim3(256), 0, s, partial, gb, K * 72, out);
 }
 
@@ -1023,20 +1024,24 @@ void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int3
     hipLaunchKernelGGL(k_fold_materialize, dim3(cdiv(m / 2, 256), 24), dim3(256), 0, s, planesL, planesR, n_planes, m, K, r1, F);
 }
 
-// general round on materialised f-hat tables
+// general round on materialised f-hat tables.  grid = (pair blocks, 8 slots, kd chunks): when few pairs remain the
+// 2K*3 tables are split over blockIdx.z -- the round message is linear in the per-chunk partial sums Q, so each chunk
+// contributes eqB(X)*Q_chunk(X) and chunk 0 adds the g1/g3 products.
 template <bool NU>
 __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow,
                                                     u64 *partial) {
     u32 slot = blockIdx.y;
     size_t pairs = a.n / 2;
     const u64 nu = t.nu;
+    const u32 nkd = 2 * K * 3, per = (nkd + gridDim.z - 1) / gridDim.z;
+    const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
-        fold_g13<NU>(acc, a, slot, p, nu);
+        if (blockIdx.z == 0) fold_g13<NU>(acc, a, slot, p, nu);
         Fq3 Q[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
-        for (u32 kd = 0; kd < 2 * K * 3; kd++) {
+        for (u32 kd = kd0; kd < kd1; kd++) {
             const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
             ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
             Fq3 f0 = fq3_make(x0.x, x1.x, x2.x), df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
@@ -1056,15 +1061,33 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
         }
         fold_g2_finish<NU>(acc, Q, a, p, nu);
     }
-    store_round_partial(acc, slot, partial);
+    // partial row = blockIdx.x + gridDim.x * blockIdx.z
+    u64 vv[15];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { vv[3 * i] = acc[i].c[0]; vv[3 * i + 1] = acc[i].c[1]; vv[3 * i + 2] = acc[i].c[2]; }
+    __shared__ u64 red[15];
+    block_sum_store<15>(vv, red);
+    __syncthreads();
+    size_t row = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z;
+    if (threadIdx.x < 15) partial[row * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
 }
 void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
                        u64 *out, hipStream_t s) {
-    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    size_t pairs = a.n / 2;
+    u32 gb = (u32)((pairs + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
-    LF_LAUNCH(k_fold_round, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, F, ldF, K, mu_pow_dev, partial);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
+    // aim for >= 64k threads: split the 2K*3 tables when pairs*8 is small (chunk count divides into RED_BLOCKS rows)
+    u32 nkd = 2 * K * 3, chunks = 1;
+    static const u32 cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 96};
+    for (u32 cc : cand) {
+        if (cc > nkd) break;
+        chunks = cc;
+        if (pairs * 8 * cc >= 65536) break;
+    }
+    while (gb * chunks > RED_BLOCKS && chunks > 1) chunks--;
+    LF_LAUNCH(k_fold_round, t.nu2p40, dim3(gb, 8, chunks), dim3(256), s, t, a, F, ldF, K, mu_pow_dev, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb * chunks, 120, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------

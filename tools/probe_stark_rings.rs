@@ -1,0 +1,54 @@
+// tools/probe_stark_rings.rs -- prints the conventions of stark-rings @ 886a89f that no in-tree reference test pins
+// (SURVEY.md App. C), in the form lf_set_ring_tables / the oracle's lfo_set_ring expect.
+//
+// NOT built here (no Rust toolchain in the image).  Usage on a machine with the reference workspace:
+//   cp tools/probe_stark_rings.rs /path/to/latticefold/crates/cyclotomic-rings/examples/probe.rs
+//   cargo run -p cyclotomic-rings --example probe > stark_rings_tables.json
+use ark_ff::{Field, PrimeField, Zero, One};
+use stark_rings::{
+    balanced_decomposition::DecomposeToVec,
+    cyclotomic_ring::{models::goldilocks::{Fq, Fq3, RqNTT, RqPoly}, CRT, ICRT},
+    PolyRing,
+};
+
+fn c(x: Fq) -> u64 { x.into_bigint().0[0] }
+
+fn main() {
+    // 1. non-residue: Y^3 where Y = (0,1,0)
+    let y = Fq3::new(Fq::zero(), Fq::one(), Fq::zero());
+    let y3 = y * y * y;
+    let bp: Vec<Fq> = y3.to_base_prime_field_elements().collect();
+    println!("{{\"nonres\": {},", c(bp[0]));
+
+    // 2. image of X in every slot: CRT of the monomial X
+    let mut x = vec![Fq::zero(); 24];
+    x[1] = Fq::one();
+    let xn: RqNTT = RqPoly::from(x).crt();
+    let slots: Vec<Vec<u64>> = xn.coeffs().iter().map(|s| s.to_base_prime_field_elements().map(c).collect()).collect();
+    println!(" \"y\": {:?},", slots);
+
+    // 3. full CRT matrix (unit monomials) as a cross-check of the (nonres, y) parametrisation
+    let mut rows = vec![];
+    for j in 0..24 {
+        let mut e = vec![Fq::zero(); 24];
+        e[j] = Fq::one();
+        let n: RqNTT = RqPoly::from(e).crt();
+        let w: Vec<u64> = n.coeffs().iter().flat_map(|s| s.to_base_prime_field_elements()).map(c).collect();
+        rows.push(w);
+    }
+    println!(" \"crt_of_monomials\": {:?},", rows);
+
+    // 4. balanced digits on edge coefficients, bases 2^16 (4 digits) and 2 (16 digits)
+    let p: u128 = 18446744069414584321;
+    let cases: Vec<u128> = vec![0, 1, p - 1, 32767, 32768, 32769, p - 32768, p - 32769, (p - 1) / 2, (p + 1) / 2, 65535, 65536];
+    let mut out = vec![];
+    for v in cases {
+        let mut e = vec![Fq::zero(); 24];
+        e[0] = Fq::from(v);
+        let el = vec![RqPoly::from(e)];
+        let d16: Vec<u64> = el.decompose_to_vec(1u128 << 16, 4)[0].iter().map(|r| c(r.coeffs()[0])).collect();
+        let d2: Vec<u64> = el.decompose_to_vec(2u128, 16)[0].iter().map(|r| c(r.coeffs()[0])).collect();
+        out.push((v as u64, d16, d2));
+    }
+    println!(" \"digit_cases\": {:?}}}", out);
+}
