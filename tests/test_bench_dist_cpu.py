@@ -28,7 +28,7 @@ WORKER = textwrap.dedent('''
     digest = 0
     for _ in range(steps):
         lc, pr = inst.linearize(lfo.Transcript(), cccs, f)
-        digest = int(pr[0, 0])
+        digest = int(pr[2, 0]) ^ int(pr[-1, 0])   # p_1(2) and the last u (p_1(0) = p_1(1) = 0 for a satisfied CCS)
     dist.barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     dg = [None] * world
