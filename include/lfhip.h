@@ -57,6 +57,9 @@ void lf_ctx_destroy(lf_ctx *);
 int lf_set_ring_tables(lf_ctx *, uint64_t nonres, const uint64_t *y);
 int lf_get_ring_tables(lf_ctx *, uint64_t *nonres, uint64_t *y);
 int lf_device_synchronize(lf_ctx *);
+/* device arithmetic self-test: fast F_{p^3} product / lazy accumulators vs the generic schoolbook path on n pseudo-random
+ * and edge operand sets; *mismatches must come back 0 */
+int lf_selftest_field(lf_ctx *, uint64_t seed, uint32_t n, uint64_t *mismatches);
 
 /* ---- a1/a2: CRT::elementwise_crt / ICRT::elementwise_icrt (arith.rs:232,238,300,327) -------- */
 int lf_ntt_fwd(lf_ctx *, const uint64_t *in, uint64_t *out, size_t count); /* in/out may alias */

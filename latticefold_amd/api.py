@@ -58,6 +58,7 @@ def _lib():
         L.lf_set_ring_tables.argtypes = [vp, C.c_uint64, u64p]
         L.lf_get_ring_tables.argtypes = [vp, u64p, u64p]
         L.lf_device_synchronize.argtypes = [vp]
+        L.lf_selftest_field.argtypes = [vp, C.c_uint64, C.c_uint32, u64p]
         L.lf_ntt_fwd.argtypes = [vp, u64p, u64p, C.c_size_t]
         L.lf_ntt_inv.argtypes = [vp, u64p, u64p, C.c_size_t]
         L.lf_decompose.argtypes = [vp, u64p, C.c_size_t, C.c_uint64, C.c_uint, C.c_int, u64p]
@@ -159,6 +160,11 @@ class Context:
         y = np.zeros(24, dtype=np.uint64)
         _chk(_lib().lf_get_ring_tables(self.h, C.cast(C.byref(nr), u64p), y.ctypes.data_as(u64p)), "lf_get_ring_tables")
         return nr.value, y
+
+    def selftest_field(self, seed=1, n=1 << 20):
+        m = C.c_uint64(1)
+        _chk(_lib().lf_selftest_field(self.h, seed, n, C.cast(C.byref(m), u64p)), "lf_selftest_field")
+        return m.value
 
     def synchronize(self):
         _chk(_lib().lf_device_synchronize(self.h), "lf_device_synchronize")

@@ -284,6 +284,16 @@ static int down_small(lf_ctx *c, const u64 *dsrc, size_t words, u64 *host) {
 }
 static Fq3Const f3c(Fq3 a) { Fq3Const r; r.c[0] = a.c[0]; r.c[1] = a.c[1]; r.c[2] = a.c[2]; return r; }
 
+int lf_selftest_field(lf_ctx *c, uint64_t seed, uint32_t n, uint64_t *mismatches) {
+    if (!c || !mismatches) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *d;
+    RET(c->tbuf("small_dev", 4096, &d));
+    launch_selftest_field(seed, n, d, c->st);
+    return down_small(c, d, 1, mismatches);
+}
+
 // ---- a1/a2 --------------------------------------------------------------------------------------------------------
 int lf_ntt_fwd(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
     if (!c || (!in && count) || (!out && count)) return LF_ERR_INVALID;

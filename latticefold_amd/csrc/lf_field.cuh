@@ -130,6 +130,15 @@ LF_HD void mad_cc(u64 &acc, u32 &cnt, u32 a, u32 b) {
     acc = n;
 #endif
 }
+// first product of a sum: no carries can occur yet (compiler keeps untouched counters as constants)
+LF_HD void accp_set(AccP &s, u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    s.s00 = (u64)a0 * b0;
+    s.s01 = (u64)a0 * b1;
+    s.s11 = (u64)a1 * b1;
+    s.c00 = 0; s.c01 = 0; s.c11 = 0;
+    mad_cc(s.s01, s.c01, a1, b0);
+}
 LF_HD void accp_mad(AccP &s, u64 a, u64 b) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     mad_cc(s.s00, s.c00, a0, b0);
@@ -149,9 +158,104 @@ LF_HD u64 accp_reduce(const AccP &s) {
     return r;
 }
 
-// schoolbook product, 9 base multiplications, lazy 128-bit column sums, 5 reductions
+// ---- fast F_{p^3} product for NU = 2^40 ---------------------------------------------------------------------
+// A column sum S (AccP) is congruent to L + 2^32 H with small signed L, H:
+//   S = a0 + 2^32 a1 + 2^32 b0 + 2^64 (b1 + d0 + c00) + 2^96 (d1 + c01) + 2^128 c11     (32-bit halves of s00,s01,s11)
+//     = L + 2^32 H,  L = a0 - T - U,  H = a1 + b0 + T - c11,  T = b1 + d0 + c00,  U = d1 + c01
+// using 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p).  Multiplying by NU = 2^40 is a shift of that linear form:
+//   2^40 (L + 2^32 H) = 2^40 (L + H) - 2^8 H     (2^72 = 2^40 - 2^8).
+struct LH {
+    int64_t l, h;
+};
+LF_HD LH accp_lh(const AccP &s) {
+    int64_t T = (int64_t)(s.s01 >> 32) + (int64_t)(u32)s.s11 + (int64_t)s.c00;
+    int64_t U = (int64_t)(s.s11 >> 32) + (int64_t)s.c01;
+    LH r;
+    r.l = (int64_t)(u32)s.s00 - T - U;
+    r.h = (int64_t)(s.s00 >> 32) + (int64_t)(u32)s.s01 + T - (int64_t)s.c11;
+    return r;
+}
+// signed value  lo64 + 2^64 * hi  (|hi| small) -> canonical residue
+LF_HD u64 fq_from_s128(u64 lo, int64_t hi) {
+    // 2^64 = eps: add hi*eps to lo, fix the single possible wrap in either direction
+    int64_t t = (int64_t)((u64)hi << 32) - hi;  // hi * (2^32 - 1), |hi| < 2^30 -> no overflow
+    u64 s = lo + (u64)t;
+    if (t >= 0) {
+        if (s < lo) s += LF_EPS;       // wrapped past 2^64: -p
+    } else {
+        if (s > lo) s -= LF_EPS;       // wrapped below 0: +p
+    }
+    return fq_canon(s);
+}
+// value = base + 2^32 * h32 + 2^40 * h40 as a signed 128-bit integer, reduced (all inputs small signed, < 2^40)
+LF_HD u64 fq_from_lin(int64_t base, int64_t h32, int64_t h40) {
+    typedef __int128 i128;
+    i128 v = (i128)base + ((i128)h32 << 32) + ((i128)h40 << 40);
+    return fq_from_s128((u64)v, (int64_t)(v >> 64));
+}
+LF_HD Fq3 fq3_from_columns_2p40(const AccP *s) {
+    LH c0 = accp_lh(s[0]), c1 = accp_lh(s[1]), c2 = accp_lh(s[2]), c3 = accp_lh(s[3]), c4 = accp_lh(s[4]);
+    Fq3 r;
+    r.c[0] = fq_from_lin(c0.l - (c3.h << 8), c0.h, c3.l + c3.h);
+    r.c[1] = fq_from_lin(c1.l - (c4.h << 8), c1.h, c4.l + c4.h);
+    r.c[2] = fq_from_lin(c2.l, c2.h, 0);
+    return r;
+}
+LF_HD Fq3 fq3_mul_2p40(Fq3 a, Fq3 b) {
+    AccP s[5];
+    accp_set(s[0], a.c[0], b.c[0]);
+    accp_set(s[1], a.c[0], b.c[1]); accp_mad(s[1], a.c[1], b.c[0]);
+    accp_set(s[2], a.c[0], b.c[2]); accp_mad(s[2], a.c[1], b.c[1]); accp_mad(s[2], a.c[2], b.c[0]);
+    accp_set(s[3], a.c[1], b.c[2]); accp_mad(s[3], a.c[2], b.c[1]);
+    accp_set(s[4], a.c[2], b.c[2]);
+    return fq3_from_columns_2p40(s);
+}
+
+// Lazy sum of F_{p^3} products for NU = 2^40: each product's five columns are folded to their (L,H) linear forms and
+// added as plain 64-bit integers (|L|,|H| < 2^36 per product -> 2^27 products fit); one reduction at the very end.
+struct LH5 {
+    LH c[5];
+};
+LF_HD void lh5_zero(LH5 &a) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) { a.c[i].l = 0; a.c[i].h = 0; }
+}
+LF_HD void lh5_mac(LH5 &acc, Fq3 a, Fq3 b) {
+    AccP s[5];
+    accp_set(s[0], a.c[0], b.c[0]);
+    accp_set(s[1], a.c[0], b.c[1]); accp_mad(s[1], a.c[1], b.c[0]);
+    accp_set(s[2], a.c[0], b.c[2]); accp_mad(s[2], a.c[1], b.c[1]); accp_mad(s[2], a.c[2], b.c[0]);
+    accp_set(s[3], a.c[1], b.c[2]); accp_mad(s[3], a.c[2], b.c[1]);
+    accp_set(s[4], a.c[2], b.c[2]);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        LH t = accp_lh(s[i]);
+        acc.c[i].l += t.l;
+        acc.c[i].h += t.h;
+    }
+}
+// signed wide value base + 2^32 h32 + 2^40 h40 with |terms| up to ~2^62: split before shifting
+LF_HD u64 fq_from_lin_wide(int64_t base, int64_t h32, int64_t h40) {
+    typedef __int128 i128;
+    i128 v = (i128)base + ((i128)h32 << 32) + ((i128)h40 << 40);   // |v| < 2^103
+    // fold the high part: v = lo + 2^64 hi, hi up to 2^39 -> hi*eps needs 71 bits: fold twice
+    u64 lo = (u64)v;
+    i128 hi = v >> 64;
+    i128 w = (i128)lo + (hi << 32) - hi;                            // |w| < 2^72
+    return fq_from_s128((u64)w, (int64_t)(w >> 64));
+}
+LF_HD Fq3 lh5_finish(const LH5 &a) {
+    Fq3 r;
+    r.c[0] = fq_from_lin_wide(a.c[0].l - (a.c[3].h << 8), a.c[0].h, a.c[3].l + a.c[3].h);
+    r.c[1] = fq_from_lin_wide(a.c[1].l - (a.c[4].h << 8), a.c[1].h, a.c[4].l + a.c[4].h);
+    r.c[2] = fq_from_lin_wide(a.c[2].l, a.c[2].h, 0);
+    return r;
+}
+
+// generic-NU product: schoolbook, 9 base multiplications, lazy 128-bit column sums, 5 reductions
 template <bool NU2P40>
 LF_HD Fq3 fq3_mul(Fq3 a, Fq3 b, u64 nu) {
+    if (NU2P40) return fq3_mul_2p40(a, b);
     Acc s0, s1, s2, s3, s4;
     acc_set(s0, a.c[0], b.c[0]);
     acc_set(s1, a.c[0], b.c[1]); acc_mad(s1, a.c[1], b.c[0]);
@@ -164,9 +268,10 @@ LF_HD Fq3 fq3_mul(Fq3 a, Fq3 b, u64 nu) {
     r.c[2] = acc_reduce(s2);
     return r;
 }
-// square: 6 base multiplications
+// square
 template <bool NU2P40>
 LF_HD Fq3 fq3_sqr(Fq3 a, u64 nu) {
+    if (NU2P40) return fq3_mul_2p40(a, a);
     u64 d01 = fq_add(a.c[0], a.c[0]), d1 = fq_add(a.c[1], a.c[1]);
     Acc s0, s1, s2, s3, s4;
     acc_set(s0, a.c[0], a.c[0]);

@@ -30,6 +30,8 @@ void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStre
 // Ajtai matrix generated in place in plane layout, equal to AoS stream splitmix(seed)[((i*n+j)*24+w)]
 void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, u64 seed, hipStream_t s);
 
+void launch_selftest_field(u64 seed, u32 n, u64 *mism_dev, hipStream_t s);  // arithmetic self-test, see lf_kernels.hip
+
 // ---- CRT / ICRT (a1, a2) ---------------------------------------------------------------------------------------
 void launch_crt_fwd(const DevCrt &t, const u64 *coef, u64 *ntt, size_t n, hipStream_t s);
 void launch_icrt_dense(const u64 *icrt_mat /*24*24 dev*/, const u64 *ntt, u64 *coef, size_t n, hipStream_t s);

@@ -36,6 +36,8 @@ static inline unsigned grid_for(size_t n, unsigned cap = 2048) {
     return (unsigned)(g > cap ? cap : g);
 }
 
+__device__ __forceinline__ u64 splitmix_fq(u64 seed, u64 index);
+
 // ---------------------------------------------------------------------------------------------------------
 // reductions
 __device__ __forceinline__ u64 wave_sum_fq(u64 v) {
@@ -441,6 +443,44 @@ void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 
                   hipStream_t s) {
     LF_LAUNCH(k_ajtai, t.nu2p40, dim3(splits, 8), dim3(AJ_THREADS), s, t, A, kappa, n, F, batch, splits, partial);
     hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// arithmetic self-test: the fast NU = 2^40 product, the lazy (L,H) accumulator and the partial-product accumulator
+// against the generic schoolbook path on pseudo-random and edge operands; counts mismatching words.
+__global__ void __launch_bounds__(256) k_selftest_field(u64 seed, u32 n, unsigned long long *mism) {
+    u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 edge[8] = {0, 1, LF_P - 1, LF_P - 2, 0xFFFFFFFFULL, 0xFFFFFFFF00000000ULL, 1ULL << 32, (LF_P - 1) / 2};
+    u64 w[6];
+    for (int k = 0; k < 6; k++) {
+        u64 v = splitmix_fq(seed, (u64)i * 6 + k);
+        if (((v >> 7) & 3) == 0) v = edge[(v >> 3) & 7];  // a quarter of the operands are edge values
+        w[k] = v;
+    }
+    Fq3 a = fq3_make(w[0], w[1], w[2]), b = fq3_make(w[3], w[4], w[5]);
+    const u64 nu = 1ULL << 40;
+    Fq3 ref = fq3_mul<false>(a, b, nu), fast = fq3_mul_2p40(a, b);
+    unsigned bad = !fq3_eq(ref, fast);
+    // lazy sums of 37 products (with repeated operands) vs reduced sums
+    LH5 lz; lh5_zero(lz);
+    Acc5 ap; acc5_zero(ap);
+    Fq3 sum = fq3_zero();
+    Fq3 x = a, y = b;
+    for (int r = 0; r < 37; r++) {
+        lh5_mac(lz, x, y);
+        acc5_mac(ap, x.c, y.c);
+        sum = fq3_add(sum, fq3_mul<false>(x, y, nu));
+        Fq3 t = fq3_add(x, y); x = y; y = t;
+    }
+    bad += !fq3_eq(sum, lh5_finish(lz));
+    bad += !fq3_eq(sum, acc5_finish<true>(ap, nu));
+    bad += !fq3_eq(sum, acc5_finish<false>(ap, nu));
+    if (bad) atomicAdd(mism, (unsigned long long)bad);
+}
+void launch_selftest_field(u64 seed, u32 n, u64 *mism_dev, hipStream_t s) {
+    hipMemsetAsync(mism_dev, 0, 8, s);
+    hipLaunchKernelGGL(k_selftest_field, dim3(cdiv(n, 256)), dim3(256), 0, s, seed, n, (unsigned long long *)mism_dev);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1040,24 +1080,48 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
         if (blockIdx.z == 0) fold_g13<NU>(acc, a, slot, p, nu);
-        Fq3 Q[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
-        for (u32 kd = kd0; kd < kd1; kd++) {
-            const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
-            ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
-            Fq3 f0 = fq3_make(x0.x, x1.x, x2.x), df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
-            // P(f0 + X df), P(f) = f^3 - f
-            Fq3 f0s = S3<NU>(f0, nu), dfs = S3<NU>(df, nu);
-            Fq3 c0 = fq3_sub(M3<NU>(f0s, f0, nu), f0);
-            Fq3 c3 = M3<NU>(dfs, df, nu);
-            Fq3 t1 = M3<NU>(f0s, df, nu), t2 = M3<NU>(dfs, f0, nu);
-            Fq3 c1 = fq3_sub(fq3_add(fq3_add(t1, t1), t1), df);
-            Fq3 c2 = fq3_add(fq3_add(t2, t2), t2);
-            Fq3Const mc = mu_pow[kd];
-            Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
-            Q[0] = fq3_add(Q[0], M3<NU>(c0, mu, nu));
-            Q[1] = fq3_add(Q[1], M3<NU>(c1, mu, nu));
-            Q[2] = fq3_add(Q[2], M3<NU>(c2, mu, nu));
-            Q[3] = fq3_add(Q[3], M3<NU>(c3, mu, nu));
+        Fq3 Q[4];
+        if (NU) {
+            // sum_kd mu (f0 + X df)^3 - mu (f0 + X df):  with p = mu f0, q = mu df the cubic coefficients are
+            //   sum p f0^2,  3 sum q f0^2,  3 sum p df^2,  sum q df^2   -- four LAZY sums, 4 reduced products per table
+            LH5 A0, A1, A2, A3;
+            lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
+            Fq3 sp = fq3_zero(), sq = fq3_zero();
+            for (u32 kd = kd0; kd < kd1; kd++) {
+                const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
+                ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
+                Fq3 f0 = fq3_make(x0.x, x1.x, x2.x), df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
+                Fq3Const mc = mu_pow[kd];
+                Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
+                Fq3 f0s = fq3_mul_2p40(f0, f0), dfs = fq3_mul_2p40(df, df);
+                Fq3 pp = fq3_mul_2p40(mu, f0), qq = fq3_mul_2p40(mu, df);
+                lh5_mac(A0, pp, f0s); lh5_mac(A1, qq, f0s); lh5_mac(A2, pp, dfs); lh5_mac(A3, qq, dfs);
+                sp = fq3_add(sp, pp); sq = fq3_add(sq, qq);
+            }
+            Fq3 t1 = lh5_finish(A1), t2 = lh5_finish(A2);
+            Q[0] = fq3_sub(lh5_finish(A0), sp);
+            Q[1] = fq3_sub(fq3_add(fq3_add(t1, t1), t1), sq);
+            Q[2] = fq3_add(fq3_add(t2, t2), t2);
+            Q[3] = lh5_finish(A3);
+        } else {
+            Q[0] = Q[1] = Q[2] = Q[3] = fq3_zero();
+            for (u32 kd = kd0; kd < kd1; kd++) {
+                const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
+                ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
+                Fq3 f0 = fq3_make(x0.x, x1.x, x2.x), df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
+                Fq3 f0s = S3<NU>(f0, nu), dfs = S3<NU>(df, nu);
+                Fq3 c0 = fq3_sub(M3<NU>(f0s, f0, nu), f0);
+                Fq3 c3 = M3<NU>(dfs, df, nu);
+                Fq3 t1 = M3<NU>(f0s, df, nu), t2 = M3<NU>(dfs, f0, nu);
+                Fq3 c1 = fq3_sub(fq3_add(fq3_add(t1, t1), t1), df);
+                Fq3 c2 = fq3_add(fq3_add(t2, t2), t2);
+                Fq3Const mc = mu_pow[kd];
+                Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
+                Q[0] = fq3_add(Q[0], M3<NU>(c0, mu, nu));
+                Q[1] = fq3_add(Q[1], M3<NU>(c1, mu, nu));
+                Q[2] = fq3_add(Q[2], M3<NU>(c2, mu, nu));
+                Q[3] = fq3_add(Q[3], M3<NU>(c3, mu, nu));
+            }
         }
         fold_g2_finish<NU>(acc, Q, a, p, nu);
     }

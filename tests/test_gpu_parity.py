@@ -31,6 +31,12 @@ def setup_case(ctx, name, seed=0):
     return wl, inst, A, scheme
 
 
+def test_device_arithmetic_selftest(ctx):
+    """fast NU=2^40 F_{p^3} product, (L,H) lazy sums and partial-product accumulators vs the generic path, 4M operand sets"""
+    for seed in (1, 2, 3, 4):
+        assert ctx.selftest_field(seed, 1 << 20) == 0
+
+
 # ---- element-wise kernels ------------------------------------------------------------------------------
 @pytest.mark.parametrize("count", [1, 7, 256, 1000])
 def test_crt_icrt(ctx, count):
