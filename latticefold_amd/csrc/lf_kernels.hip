@@ -359,7 +359,7 @@ void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_plane
 // (A,F) tiles of JT columns are staged in LDS with coalesced loads; each thread owns up to two (i,k) outputs
 // and keeps the five schoolbook column sums of the F_{p^3} product as un-reduced 160-bit accumulators for the
 // whole j-range (one reduction per output at the very end).
-constexpr int AJ_JT = 32;
+constexpr int AJ_JT = 16;  // (kept for the split rounding in the host helper)
 constexpr int AJ_MAXROWS = 64;   // kappa + batch <= 64 per launch
 struct Acc5 { AccP s[5]; };  // the five schoolbook column sums of an F_{p^3} product, un-reduced
 __device__ __forceinline__ void acc5_zero(Acc5 &a) {
@@ -382,49 +382,69 @@ __device__ __forceinline__ Fq3 acc5_finish(const Acc5 &a, u64 nu) {
     return r;
 }
 constexpr int AJ_THREADS = 448;  // 7 waves: 26 x 15 = 390 outputs -> 87 % of the lanes busy
+// Karatsuba at the F_{p^3} level with lazy accumulation: with P0=a0b0, P1=a1b1, P2=a2b2, P01=(a0+a1)(b0+b1),
+// P02=(a0+a2)(b0+b2), P12=(a1+a2)(b1+b2):  c0 = P0 + nu(P12-P1-P2), c1 = P01-P0-P1 + nu P2, c2 = P02-P0-P2 + P1.
+// All six products are summed over the whole j-range un-reduced (AccP), so a MAC is 24 (not 36) v_mad_u64_u32; the
+// operand sums are formed once per staged element while the tile is written to LDS.
+struct Acc6 { AccP s[6]; };
+// LDS tile: one 48-byte record {c0,c1,c2,c0+c1,c0+c2,c1+c2} per (row, column), read back as three ds_read_b128.
+// Row stride = AJ_JT*48 + 16 bytes: rows of one 16-lane read group fall into distinct 16-byte slots (conflict-free).
+constexpr int AJ_T = 16;                          // columns per tile
+constexpr int AJ_ROWB = AJ_T * 48 + 16;           // bytes per row
 template <bool NU>
-__global__ void __launch_bounds__(AJ_THREADS) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
-                                                      u64 *partial) {
-    __shared__ u64 sA[AJ_MAXROWS][3][AJ_JT + 1];  // rows 0..kappa-1 = A, kappa.. = F ; +1 pad: rows land on different banks
+__global__ void __launch_bounds__(AJ_THREADS, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
+                                                         u64 *partial) {
+    extern __shared__ __align__(16) unsigned char smem[];
     const u32 slot = blockIdx.y, split = blockIdx.x;
     const u32 rows = kappa + batch;
     const u32 nout = kappa * batch;
     size_t per = (n + splits - 1) / splits;
-    per = (per + AJ_JT - 1) / AJ_JT * AJ_JT;
+    per = (per + AJ_T - 1) / AJ_T * AJ_T;
     size_t j0 = (size_t)split * per, j1 = j0 + per < n ? j0 + per : n;
-    Acc5 acc;
-    acc5_zero(acc);
+    Acc6 acc;
+#pragma unroll
+    for (int i = 0; i < 6; i++) accp_zero(acc.s[i]);
     const u32 o0 = threadIdx.x;
     const u32 i0 = o0 / batch, k0 = o0 % batch;
     const bool active = o0 < nout;
-    const u32 ra = active ? i0 : 0, rf = active ? kappa + k0 : kappa;
-    for (size_t jt = j0; jt < j1; jt += AJ_JT) {
+    const unsigned char *pa = smem + (size_t)(active ? i0 : 0) * AJ_ROWB;
+    const unsigned char *pf = smem + (size_t)(active ? kappa + k0 : kappa) * AJ_ROWB;
+    for (size_t jt = j0; jt < j1; jt += AJ_T) {
         __syncthreads();
-        for (u32 idx = threadIdx.x; idx < rows * 3 * AJ_JT; idx += AJ_THREADS) {
-            u32 jj = idx % AJ_JT, rc = idx / AJ_JT, c = rc % 3, r = rc / 3;
+        for (u32 idx = threadIdx.x; idx < rows * AJ_T; idx += AJ_THREADS) {
+            u32 jj = idx % AJ_T, r = idx / AJ_T;
             size_t j = jt + jj;
-            u64 v = 0;
+            u64 v0 = 0, v1 = 0, v2 = 0;
             if (j < j1) {
-                const u64 *src = r < kappa ? A + ((size_t)r * 24 + 3 * slot + c) * n : F + ((size_t)(r - kappa) * 24 + 3 * slot + c) * n;
-                v = src[j];
+                const u64 *src = r < kappa ? A + ((size_t)r * 24 + 3 * slot) * n : F + ((size_t)(r - kappa) * 24 + 3 * slot) * n;
+                v0 = src[j]; v1 = src[n + j]; v2 = src[2 * n + j];
             }
-            sA[r][c][jj] = v;
+            ulonglong2 *dstp = (ulonglong2 *)(smem + (size_t)r * AJ_ROWB + jj * 48);
+            dstp[0] = make_ulonglong2(v0, v1);
+            dstp[1] = make_ulonglong2(v2, fq_add(v0, v1));
+            dstp[2] = make_ulonglong2(fq_add(v0, v2), fq_add(v1, v2));
         }
         __syncthreads();
         if (active) {
 #pragma unroll 4
-            for (int jj = 0; jj < AJ_JT; jj++) {
-                u64 x[3] = {sA[ra][0][jj], sA[ra][1][jj], sA[ra][2][jj]};
-                u64 y[3] = {sA[rf][0][jj], sA[rf][1][jj], sA[rf][2][jj]};
-                acc5_mac(acc, x, y);
+            for (int jj = 0; jj < AJ_T; jj++) {
+                const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
+                ulonglong2 x0 = xa[0], x1 = xa[1], x2 = xa[2], y0 = yf[0], y1 = yf[1], y2 = yf[2];
+                accp_mad(acc.s[0], x0.x, y0.x); accp_mad(acc.s[1], x0.y, y0.y);
+                accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
+                accp_mad(acc.s[4], x2.x, y2.x); accp_mad(acc.s[5], x2.y, y2.y);
             }
         }
     }
     // partial[split][slot][o][3]
     u64 *dst = partial + ((size_t)split * 8 + slot) * nout * 3;
     if (active) {
-        Fq3 r = acc5_finish<NU>(acc, t.nu);
-        dst[(size_t)o0 * 3] = r.c[0]; dst[(size_t)o0 * 3 + 1] = r.c[1]; dst[(size_t)o0 * 3 + 2] = r.c[2];
+        u64 r0 = accp_reduce(acc.s[0]), r1 = accp_reduce(acc.s[1]), r2 = accp_reduce(acc.s[2]);
+        u64 r01 = accp_reduce(acc.s[3]), r02 = accp_reduce(acc.s[4]), r12 = accp_reduce(acc.s[5]);
+        u64 c0 = fq_add(r0, fq_mul_nu<NU>(fq_sub(fq_sub(r12, r1), r2), t.nu));
+        u64 c1 = fq_add(fq_sub(fq_sub(r01, r0), r1), fq_mul_nu<NU>(r2, t.nu));
+        u64 c2 = fq_add(fq_sub(fq_sub(r02, r0), r2), r1);
+        dst[(size_t)o0 * 3] = c0; dst[(size_t)o0 * 3 + 1] = c1; dst[(size_t)o0 * 3 + 2] = c2;
     }
 }
 // out[k][i][3*slot+c] = sum_split partial[split][slot][i*batch+k][c]
@@ -441,7 +461,9 @@ __global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, u32 ka
 size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) { return (size_t)splits * 8 * kappa * batch * 3; }
 void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits, u64 *partial, u64 *out,
                   hipStream_t s) {
-    LF_LAUNCH(k_ajtai, t.nu2p40, dim3(splits, 8), dim3(AJ_THREADS), s, t, A, kappa, n, F, batch, splits, partial);
+    size_t shm = (size_t)(kappa + batch) * AJ_ROWB;
+    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
+    else hipLaunchKernelGGL((k_ajtai<false>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
     hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
 }
 
