@@ -523,7 +523,13 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
     c->desc.t = p->t; c->desc.q = p->q;
     for (u32 i = 0; i <= p->q; i++) c->desc.S_off[i] = S_off[i];
     for (u32 k = 0; k < S_off[p->q]; k++) c->desc.S_idx[k] = S_idx[k];
-    for (u32 i = 0; i < p->q; i++) memcpy(c->desc.c[i], cc + (size_t)i * 24, 24 * 8);
+    for (u32 i = 0; i < p->q; i++) {
+        memcpy(c->desc.c[i], cc + (size_t)i * 24, 24 * 8);
+        u64 one[24], mone[24];
+        HostRing::from_u64(1, one);
+        HostRing::from_u64(LF_P - 1, mone);
+        c->desc.c_unit[i] = !memcmp(c->desc.c[i], one, sizeof(one)) ? 1 : (!memcmp(c->desc.c[i], mone, sizeof(mone)) ? -1 : 0);
+    }
     for (u32 j = 0; j < p->t; j++) {
         size_t nnz = rowptr[j][m];
         for (size_t k = 0; k < nnz; k++)

@@ -95,6 +95,7 @@ struct LinCombDesc {  // CCS multiset structure for the linearization comb (nifs
     u32 S_off[9];
     u32 S_idx[16];
     u64 c[8][24];  // coefficients c_i (ring elements, AoS)
+    int c_unit[8]; // +1 / -1 when c_i is the ring element +-1 (multiplication skipped), else 0
 };
 // round message of the linearization sumcheck: tables Mz [t][24][ld], eq [3][ld]; n = current length
 // out: (deg+1) ring elements AoS, deg = d+1 <= 4

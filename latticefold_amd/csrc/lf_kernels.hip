@@ -581,33 +581,34 @@ constexpr u32 RED_BLOCKS = 256;
 template <bool NU>
 __global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n,
                                                    u64 *partial) {
-    // grid (RED_BLOCKS, 8 slots, nb * ceil(na/4)); each block accumulates 4 a's against one b
-    u32 slot = blockIdx.y, b = blockIdx.z % nb, a0 = (blockIdx.z / nb) * 4;
+    // grid (RED_BLOCKS, 8 slots, na); each block streams its X_a once against all nb <= 4 tables Y_b (Y stays in L2/MALL)
+    u32 slot = blockIdx.y, a = blockIdx.z;
     Acc5 acc[4];
 #pragma unroll
-    for (int a = 0; a < 4; a++) acc5_zero(acc[a]);
+    for (int b = 0; b < 4; b++) acc5_zero(acc[b]);
+    const u64 *Xa = X + (size_t)a * 24 * ldx;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        Fq3 y = ld3(Y + (size_t)b * 24 * ldy, ldy, slot, i);
+        Fq3 x = ld3(Xa, ldx, slot, i);
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-            if (a0 + a < na) {
-                Fq3 x = ld3(X + (size_t)(a0 + a) * 24 * ldx, ldx, slot, i);
-                acc5_mac(acc[a], x.c, y.c);
+        for (int b = 0; b < 4; b++)
+            if ((u32)b < nb) {
+                Fq3 y = ld3(Y + (size_t)b * 24 * ldy, ldy, slot, i);
+                acc5_mac(acc[b], x.c, y.c);
             }
     }
     u64 v[12];
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        Fq3 r = a0 + a < na ? acc5_finish<NU>(acc[a], t.nu) : fq3_zero();
-        v[3 * a] = r.c[0]; v[3 * a + 1] = r.c[1]; v[3 * a + 2] = r.c[2];
+    for (int b = 0; b < 4; b++) {
+        Fq3 r = (u32)b < nb ? acc5_finish<NU>(acc[b], t.nu) : fq3_zero();
+        v[3 * b] = r.c[0]; v[3 * b + 1] = r.c[1]; v[3 * b + 2] = r.c[2];
     }
     // partial[block][ (a*nb + b)*24 + 3*slot + c ]
     __shared__ u64 red[12];
     block_sum_store<12>(v, red);
     __syncthreads();
     if (threadIdx.x < 12) {
-        u32 a = a0 + threadIdx.x / 3, c = threadIdx.x % 3;
-        if (a < na) partial[(size_t)blockIdx.x * (16 * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[threadIdx.x];
+        u32 b = threadIdx.x / 3, c = threadIdx.x % 3;
+        if (b < nb) partial[(size_t)blockIdx.x * (16 * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[threadIdx.x];
     }
 }
 size_t dot_partial_words(u32 na, u32 nb) { return (size_t)RED_BLOCKS * 16 * nb * 24; }
@@ -616,8 +617,7 @@ void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u
     u32 gb = (u32)((n + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
-    LF_LAUNCH(k_dot_batch, t.nu2p40, dim3(gb, 8, nb * ((na + 3) / 4)), dim3(256), s, t, X, ldx, na, Y, ldy, nb, n, partial);
-    // rows of width 16*nb*24; only the first na*nb*24 entries are meaningful (a-major): reduce all na*nb*24
+    LF_LAUNCH(k_dot_batch, t.nu2p40, dim3(gb, 8, na), dim3(256), s, t, X, ldx, na, Y, ldy, nb, n, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(na * nb * 24), dim3(256), 0, s, partial, gb, 16 * nb * 24, out);
 }
 template <bool NU>
@@ -803,9 +803,15 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
         for (u32 X = 0; X <= deg; X++) {
             Fq3 res = fq3_zero();
             for (u32 i = 0; i < desc.q; i++) {
-                Fq3 term = fq3_make(desc.c[i][3 * slot], desc.c[i][3 * slot + 1], desc.c[i][3 * slot + 2]);
-                for (u32 k = desc.S_off[i]; k < desc.S_off[i + 1]; k++) term = M3<NU>(term, v[desc.S_idx[k]], t.nu);
-                res = fq3_add(res, term);
+                u32 k = desc.S_off[i], ke = desc.S_off[i + 1];
+                Fq3 term;
+                if (desc.c_unit[i] != 0 && k < ke) {            // c_i = +-1: start from the first factor
+                    term = v[desc.S_idx[k++]];
+                } else {
+                    term = fq3_make(desc.c[i][3 * slot], desc.c[i][3 * slot + 1], desc.c[i][3 * slot + 2]);
+                }
+                for (; k < ke; k++) term = M3<NU>(term, v[desc.S_idx[k]], t.nu);
+                res = desc.c_unit[i] < 0 ? fq3_sub(res, term) : fq3_add(res, term);
             }
             acc[X] = fq3_add(acc[X], M3<NU>(res, ev, t.nu));
             for (u32 j = 0; j < desc.t; j++) v[j] = fq3_add(v[j], st[j]);
@@ -889,6 +895,7 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, 
         fold_g13<NU>(acc, a, slot, p, t.nu);
         // cubic coefficients of sum_kd mu_kd * P(f0 + X*df): integer parts split in lo/hi 32-bit halves of mu
         int64_t lo[4][3], hi[4][3];
+        int32_t cs[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -904,13 +911,15 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, 
                         // P(f0 + X df) = (f0^3 - f0) + (3 f0^2 - 1) df X + 3 f0 df^2 X^2 + df^3 X^3
                         int c0 = f0 * f0 * f0 - f0, c1 = (3 * f0 * f0 - 1) * df, c2 = 3 * f0 * df * df, c3 = df * df * df;
                         Fq3Const m = mu_pow[(side * K + k) * 3 + d];
+                        cs[0] += c0; cs[1] += c1; cs[2] += c2; cs[3] += c3;
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
-                            int64_t ml = (int64_t)(u32)m.c[c], mh = (int64_t)(m.c[c] >> 32);
-                            lo[0][c] += ml * c0; hi[0][c] += mh * c0;
-                            lo[1][c] += ml * c1; hi[1][c] += mh * c1;
-                            lo[2][c] += ml * c2; hi[2][c] += mh * c2;
-                            lo[3][c] += ml * c3; hi[3][c] += mh * c3;
+                            // signed 32x32->64 multiply-adds (v_mad_i64_i32): word - 2^31, corrected with 2^31 * sum(coef)
+                            int32_t ml = (int32_t)((u32)m.c[c] ^ 0x80000000u), mh = (int32_t)((u32)(m.c[c] >> 32) ^ 0x80000000u);
+                            lo[0][c] += (int64_t)ml * c0; hi[0][c] += (int64_t)mh * c0;
+                            lo[1][c] += (int64_t)ml * c1; hi[1][c] += (int64_t)mh * c1;
+                            lo[2][c] += (int64_t)ml * c2; hi[2][c] += (int64_t)mh * c2;
+                            lo[3][c] += (int64_t)ml * c3; hi[3][c] += (int64_t)mh * c3;
                         }
                     }
                 }
@@ -920,7 +929,10 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, 
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) Q[e].c[c] = fq_add(fq_from_i64(lo[e][c]), fq_mul(fq_from_i64(hi[e][c]), 1ULL << 32));
+            for (int c = 0; c < 3; c++) {
+                int64_t off = (int64_t)cs[e] << 31;
+                Q[e].c[c] = fq_add(fq_from_i64(lo[e][c] + off), fq_mul(fq_from_i64(hi[e][c] + off), 1ULL << 32));
+            }
         fold_g2_finish<NU>(acc, Q, a, p, t.nu);
     }
     store_round_partial(acc, slot, partial);
@@ -955,12 +967,15 @@ __global__ void __launch_bounds__(256) k_fold_round2(DevCrt t, FoldRoundArgs a, 
 #pragma unroll 1
             for (int pass = 0; pass < 2; pass++) {  // pass 0: powers r1^0, r1^1 ; pass 1: r1^2, r1^3
                 int64_t lo[2][4][3], hi[2][4][3];
+                int32_t cs[2][4];
 #pragma unroll
                 for (int e = 0; e < 2; e++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < 4; j++) {
+                        cs[e][j] = 0;
 #pragma unroll
                         for (int c = 0; c < 3; c++) { lo[e][j][c] = 0; hi[e][j][c] = 0; }
+                    }
                 for (int side = 0; side < 2; side++) {
                     const int32_t *pl = side ? planesR : planesL;
                     for (int d = 0; d < 3; d++) {
@@ -984,12 +999,16 @@ __global__ void __launch_bounds__(256) k_fold_round2(DevCrt t, FoldRoundArgs a, 
                             }
                             Fq3Const m = mu_pow[(side * K + k) * 3 + d];
 #pragma unroll
+                            for (int e = 0; e < 2; e++)
+#pragma unroll
+                                for (int j = 0; j < 4; j++) cs[e][j] += cf[e][j];
+#pragma unroll
                             for (int c = 0; c < 3; c++) {
-                                int64_t ml = (int64_t)(u32)m.c[c], mh = (int64_t)(m.c[c] >> 32);
+                                int32_t ml = (int32_t)((u32)m.c[c] ^ 0x80000000u), mh = (int32_t)((u32)(m.c[c] >> 32) ^ 0x80000000u);
 #pragma unroll
                                 for (int e = 0; e < 2; e++)
 #pragma unroll
-                                    for (int j = 0; j < 4; j++) { lo[e][j][c] += ml * cf[e][j]; hi[e][j][c] += mh * cf[e][j]; }
+                                    for (int j = 0; j < 4; j++) { lo[e][j][c] += (int64_t)ml * cf[e][j]; hi[e][j][c] += (int64_t)mh * cf[e][j]; }
                             }
                         }
                     }
@@ -1000,7 +1019,10 @@ __global__ void __launch_bounds__(256) k_fold_round2(DevCrt t, FoldRoundArgs a, 
                     for (int j = 0; j < 4; j++) {
                         Fq3 T;
 #pragma unroll
-                        for (int c = 0; c < 3; c++) T.c[c] = fq_add(fq_from_i64(lo[e][j][c]), fq_mul(fq_from_i64(hi[e][j][c]), 1ULL << 32));
+                        for (int c = 0; c < 3; c++) {
+                            int64_t off = (int64_t)cs[e][j] << 31;
+                            T.c[c] = fq_add(fq_from_i64(lo[e][j][c] + off), fq_mul(fq_from_i64(hi[e][j][c] + off), 1ULL << 32));
+                        }
                         if (pass == 0 && e == 0) Q[j] = fq3_add(Q[j], T);
                         else Q[j] = fq3_add(Q[j], M3<NU>(T, pass == 0 ? r1 : (e == 0 ? r1s : r1c3), nu));
                     }
