@@ -51,7 +51,7 @@ def cpu_baseline(target_wl, budget_s=25.0):
 
     s = 10
     t = run(s)
-    while s + 2 <= min(target_wl.s, 14) and t * 4.2 < budget_s:
+    while s + 2 <= min(target_wl.s, 18) and t * 4.2 < budget_s:
         s += 2
         t = run(s)
     scale = (1 << target_wl.s) / (1 << s)

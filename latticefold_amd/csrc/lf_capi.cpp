@@ -408,7 +408,7 @@ static u32 ajtai_splits(size_t n) {
 }
 // F: [batch][24][n] device; out_dev: [batch][kappa][24] device AoS
 static int commit_dev(lf_ctx *c, const u64 *F, u32 batch, u64 *out_dev, bool timed) {
-    u32 maxb = 512 / c->kappa;
+    u32 maxb = 448 / c->kappa;
     if (maxb > 64 - c->kappa) maxb = 64 - c->kappa;
     if (maxb < 1) return LF_ERR_UNSUPPORTED;
     u32 splits = ajtai_splits(c->nA);
@@ -523,6 +523,8 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
     c->desc.t = p->t; c->desc.q = p->q;
     for (u32 i = 0; i <= p->q; i++) c->desc.S_off[i] = S_off[i];
     for (u32 k = 0; k < S_off[p->q]; k++) c->desc.S_idx[k] = S_idx[k];
+    for (u32 i = 0; i < p->q; i++)
+        for (u32 k = S_off[i]; k < S_off[i + 1]; k++) { c->desc.ms[k] = i; c->desc.first[k] = (k == S_off[i]); }
     for (u32 i = 0; i < p->q; i++) {
         memcpy(c->desc.c[i], cc + (size_t)i * 24, 24 * 8);
         u64 one[24], mone[24];

@@ -43,6 +43,12 @@ LF_HD u64 fq_reduce128_loose(u64 lo, u64 hi) {
     return r;
 }
 LF_HD void mul64wide(u64 a, u64 b, u64 &lo, u64 &hi) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    unsigned __int128 pr = (unsigned __int128)a * b;  // host: one mulq
+    lo = (u64)pr;
+    hi = (u64)(pr >> 64);
+    return;
+#endif
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 p01 = (u64)a0 * b1 + (p00 >> 32);

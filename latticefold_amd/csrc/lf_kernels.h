@@ -96,6 +96,8 @@ struct LinCombDesc {  // CCS multiset structure for the linearization comb (nifs
     u32 S_idx[16];
     u64 c[8][24];  // coefficients c_i (ring elements, AoS)
     int c_unit[8]; // +1 / -1 when c_i is the ring element +-1 (multiplication skipped), else 0
+    u32 first[4];  // table j starts a new multiset
+    u32 ms[4];     // multiset of table j
 };
 // round message of the linearization sumcheck: tables Mz [t][24][ld], eq [3][ld]; n = current length
 // out: (deg+1) ring elements AoS, deg = d+1 <= 4

@@ -353,6 +353,13 @@ void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_plane
                        out, ldz, off);
 }
 
+__device__ __forceinline__ Fq3 ld3(const u64 *tab, size_t ld, u32 slot, size_t i) {
+    return fq3_make(tab[(size_t)(3 * slot) * ld + i], tab[(size_t)(3 * slot + 1) * ld + i], tab[(size_t)(3 * slot + 2) * ld + i]);
+}
+__device__ __forceinline__ void st3(u64 *tab, size_t ld, u32 slot, size_t i, Fq3 v) {
+    tab[(size_t)(3 * slot) * ld + i] = v.c[0]; tab[(size_t)(3 * slot + 1) * ld + i] = v.c[1]; tab[(size_t)(3 * slot + 2) * ld + i] = v.c[2];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Ajtai commit (commitment_scheme.rs:37-54 -> Matrix::checked_mul_vec): C[k][i] = sum_j A[i][j] (.) F_k[j].
 // Per slot this is a skinny GEMM (kappa x n) * (n x batch) over F_{p^3}.  Block = one slot x one j-split;
@@ -360,7 +367,8 @@ void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_plane
 // and keeps the five schoolbook column sums of the F_{p^3} product as un-reduced 160-bit accumulators for the
 // whole j-range (one reduction per output at the very end).
 constexpr int AJ_JT = 16;  // (kept for the split rounding in the host helper)
-constexpr int AJ_MAXROWS = 64;   // kappa + batch <= 64 per launch
+constexpr int AJ_MAXROWS = 64;
+constexpr u32 RED_BLOCKS_AJ = 128;   // kappa + batch <= 64 per launch
 struct Acc5 { AccP s[5]; };  // the five schoolbook column sums of an F_{p^3} product, un-reduced
 __device__ __forceinline__ void acc5_zero(Acc5 &a) {
 #pragma unroll
@@ -381,7 +389,7 @@ __device__ __forceinline__ Fq3 acc5_finish(const Acc5 &a, u64 nu) {
     r.c[2] = accp_reduce(a.s[2]);
     return r;
 }
-constexpr int AJ_THREADS = 448;  // 7 waves: 26 x 15 = 390 outputs -> 87 % of the lanes busy
+constexpr int AJ_THREADS = 448;  // 7 waves: 26 x 15 = 390 outputs (a 6-full-wave + tail-kernel split measured slower)
 // Karatsuba at the F_{p^3} level with lazy accumulation: with P0=a0b0, P1=a1b1, P2=a2b2, P01=(a0+a1)(b0+b1),
 // P02=(a0+a2)(b0+b2), P12=(a1+a2)(b1+b2):  c0 = P0 + nu(P12-P1-P2), c1 = P01-P0-P1 + nu P2, c2 = P02-P0-P2 + P1.
 // All six products are summed over the whole j-range un-reduced (AccP), so a MAC is 24 (not 36) v_mad_u64_u32; the
@@ -406,7 +414,7 @@ __global__ void __launch_bounds__(AJ_THREADS, 4) k_ajtai(DevCrt t, const u64 *A,
     for (int i = 0; i < 6; i++) accp_zero(acc.s[i]);
     const u32 o0 = threadIdx.x;
     const u32 i0 = o0 / batch, k0 = o0 % batch;
-    const bool active = o0 < nout;
+    const bool active = o0 < nout;   // blockDim.x <= nout rounded: every launched lane is active unless nout < 64
     const unsigned char *pa = smem + (size_t)(active ? i0 : 0) * AJ_ROWB;
     const unsigned char *pf = smem + (size_t)(active ? kappa + k0 : kappa) * AJ_ROWB;
     for (size_t jt = j0; jt < j1; jt += AJ_T) {
@@ -436,7 +444,7 @@ __global__ void __launch_bounds__(AJ_THREADS, 4) k_ajtai(DevCrt t, const u64 *A,
             }
         }
     }
-    // partial[split][slot][o][3]
+    // partial[split][slot][o][3]   (only outputs o < blockDim.x are produced here)
     u64 *dst = partial + ((size_t)split * 8 + slot) * nout * 3;
     if (active) {
         u64 r0 = accp_reduce(acc.s[0]), r1 = accp_reduce(acc.s[1]), r2 = accp_reduce(acc.s[2]);
@@ -447,24 +455,65 @@ __global__ void __launch_bounds__(AJ_THREADS, 4) k_ajtai(DevCrt t, const u64 *A,
         dst[(size_t)o0 * 3] = c0; dst[(size_t)o0 * 3 + 1] = c1; dst[(size_t)o0 * 3 + 2] = c2;
     }
 }
-// out[k][i][3*slot+c] = sum_split partial[split][slot][i*batch+k][c]
-__global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, u32 kappa, u32 batch, u32 splits, u64 *out) {
+// out[k][i][3*slot+c] = sum_split partial   (outputs o < nmain)
+__global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, u32 kappa, u32 batch, u32 splits, u32 nmain, u64 *out) {
     u32 idx = blockIdx.x * 256 + threadIdx.x;
     u32 nout = kappa * batch;
-    if (idx >= 8 * nout * 3) return;
-    u32 c = idx % 3, o = (idx / 3) % nout, slot = idx / (3 * nout);
+    if (idx >= 8 * nmain * 3) return;
+    u32 c = idx % 3, o = (idx / 3) % nmain, slot = idx / (3 * nmain);
     u64 acc = 0;
     for (u32 sp = 0; sp < splits; sp++) acc = fq_add(acc, partial[(((size_t)sp * 8 + slot) * nout + o) * 3 + c]);
     u32 i = o / batch, k = o % batch;
     out[((size_t)k * kappa + i) * 24 + 3 * slot + c] = acc;
 }
-size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) { return (size_t)splits * 8 * kappa * batch * 3; }
+// the nout - nmain outputs that do not fill a wave: plain lazy dot products over j, one (output, slot) per block column
+template <bool NU>
+__global__ void __launch_bounds__(256) k_ajtai_tail(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 o_start, u64 *partial) {
+    u32 slot = blockIdx.y, o = o_start + blockIdx.z;
+    u32 i = o / batch, k = o % batch;
+    const u64 *Ai = A + (size_t)i * 24 * n, *Fk = F + (size_t)k * 24 * n;
+    Acc5 acc;
+    acc5_zero(acc);
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
+        Fq3 x = ld3(Ai, n, slot, j), y = ld3(Fk, n, slot, j);
+        acc5_mac(acc, x.c, y.c);
+    }
+    Fq3 r = acc5_finish<NU>(acc, t.nu);
+    u64 v[3] = {r.c[0], r.c[1], r.c[2]};
+    // partial[block][ tail_index*24 + 3*slot + c ]
+    block_sum_store<3>(v, partial + (size_t)blockIdx.x * (gridDim.z * 24) + (size_t)blockIdx.z * 24 + 3 * slot);
+}
+__global__ void __launch_bounds__(256) k_ajtai_tail_reduce(const u64 *partial, u32 nblocks, u32 ntail, u32 o_start, u32 kappa, u32 batch, u64 *out) {
+    u32 idx = blockIdx.x;  // one block per (tail output, word)
+    u32 tix = idx / 24, w = idx % 24;
+    u64 acc[1] = {0};
+    for (u32 b = threadIdx.x; b < nblocks; b += 256) acc[0] = fq_add(acc[0], partial[(size_t)b * (ntail * 24) + idx]);
+    u32 o = o_start + tix, i = o / batch, k = o % batch;
+    block_sum_store<1>(acc, out + ((size_t)k * kappa + i) * 24 + w);
+}
+size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) {
+    size_t a = (size_t)splits * 8 * kappa * batch * 3, b = (size_t)RED_BLOCKS_AJ * 64 * 24;
+    return a + b;
+}
 void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits, u64 *partial, u64 *out,
                   hipStream_t s) {
+    u32 nout = kappa * batch;
+    // full waves in the tiled kernel; a small remainder (< 32 outputs) is cheaper as plain dot products
+    // outputs beyond AJ_THREADS (only for kappa*batch > 448) go to the dot-product tail kernel
+    u32 nmain = nout < (u32)AJ_THREADS ? nout : (u32)AJ_THREADS;
+    u32 threads = AJ_THREADS;
     size_t shm = (size_t)(kappa + batch) * AJ_ROWB;
-    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
-    else hipLaunchKernelGGL((k_ajtai<false>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
-    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
+    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true>), dim3(splits, 8), dim3(threads), shm, s, t, A, kappa, n, F, batch, splits, partial);
+    else hipLaunchKernelGGL((k_ajtai<false>), dim3(splits, 8), dim3(threads), shm, s, t, A, kappa, n, F, batch, splits, partial);
+    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * nmain * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, nmain, out);
+    if (nmain < nout) {
+        u32 ntail = nout - nmain;
+        u64 *tp = partial + (size_t)splits * 8 * kappa * batch * 3;
+        u32 gb = (u32)((n + 255) / 256);
+        if (gb > RED_BLOCKS_AJ) gb = RED_BLOCKS_AJ;
+        LF_LAUNCH(k_ajtai_tail, t.nu2p40, dim3(gb, 8, ntail), dim3(256), s, t, A, kappa, n, F, batch, nmain, tp);
+        hipLaunchKernelGGL(k_ajtai_tail_reduce, dim3(ntail * 24), dim3(256), 0, s, tp, gb, ntail, nmain, kappa, batch, out);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -531,13 +580,6 @@ void launch_build_eq(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *eq, hi
     LF_LAUNCH(k_build_eq, t.nu2p40, dim3(cdiv((size_t)1 << nv, 256)), dim3(256), s, t, r_dev, nv, eq);
 }
 
-__device__ __forceinline__ Fq3 ld3(const u64 *tab, size_t ld, u32 slot, size_t i) {
-    return fq3_make(tab[(size_t)(3 * slot) * ld + i], tab[(size_t)(3 * slot + 1) * ld + i], tab[(size_t)(3 * slot + 2) * ld + i]);
-}
-__device__ __forceinline__ void st3(u64 *tab, size_t ld, u32 slot, size_t i, Fq3 v) {
-    tab[(size_t)(3 * slot) * ld + i] = v.c[0]; tab[(size_t)(3 * slot + 1) * ld + i] = v.c[1]; tab[(size_t)(3 * slot + 2) * ld + i] = v.c[2];
-}
-
 // mat_vec_mul (arith/utils.rs:52-65) on CSR
 template <bool NU>
 __global__ void __launch_bounds__(256) k_spmv(DevCrt t, const u32 *rowptr, const u32 *col, const u64 *val, const u64 *z, size_t ldz,
@@ -583,9 +625,10 @@ __global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_
                                                    u64 *partial) {
     // grid (RED_BLOCKS, 8 slots, na); each block streams its X_a once against all nb <= 4 tables Y_b (Y stays in L2/MALL)
     u32 slot = blockIdx.y, a = blockIdx.z;
-    Acc5 acc[4];
+    LH5 acc[4];
+    Fq3 accg[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
 #pragma unroll
-    for (int b = 0; b < 4; b++) acc5_zero(acc[b]);
+    for (int b = 0; b < 4; b++) lh5_zero(acc[b]);
     const u64 *Xa = X + (size_t)a * 24 * ldx;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         Fq3 x = ld3(Xa, ldx, slot, i);
@@ -593,13 +636,14 @@ __global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_
         for (int b = 0; b < 4; b++)
             if ((u32)b < nb) {
                 Fq3 y = ld3(Y + (size_t)b * 24 * ldy, ldy, slot, i);
-                acc5_mac(acc[b], x.c, y.c);
+                if (NU) lh5_mac(acc[b], x, y);
+                else accg[b] = fq3_add(accg[b], M3<NU>(x, y, t.nu));
             }
     }
     u64 v[12];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-        Fq3 r = (u32)b < nb ? acc5_finish<NU>(acc[b], t.nu) : fq3_zero();
+        Fq3 r = (u32)b < nb ? (NU ? lh5_finish(acc[b]) : accg[b]) : fq3_zero();
         v[3 * b] = r.c[0]; v[3 * b + 1] = r.c[1]; v[3 * b + 2] = r.c[2];
     }
     // partial[block][ (a*nb + b)*24 + 3*slot + c ]
@@ -702,15 +746,24 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y;
     if (i >= n) return;
-    Fq3 acc[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
+    LH5 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) lh5_zero(acc[j]);
+    Fq3 accg[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
     for (u32 k = 0; k < K; k++) {
         Fq3 x = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i);
-        for (u32 j = 0; j < tt; j++) {
-            Fq3Const cc = coef[k * tt + j];
-            acc[j] = fq3_add(acc[j], M3<NU>(x, fq3_make(cc.c[0], cc.c[1], cc.c[2]), t.nu));
-        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((u32)j < tt) {
+                Fq3Const cc = coef[k * tt + j];
+                Fq3 cv = fq3_make(cc.c[0], cc.c[1], cc.c[2]);
+                if (NU) lh5_mac(acc[j], x, cv);
+                else accg[j] = fq3_add(accg[j], M3<NU>(x, cv, t.nu));
+            }
     }
-    for (u32 j = 0; j < tt; j++) st3(out + (size_t)j * 24 * ldz, ldz, slot, i, acc[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((u32)j < tt) st3(out + (size_t)j * 24 * ldz, ldz, slot, i, NU ? lh5_finish(acc[j]) : accg[j]);
 }
 void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev, u32 tt, size_t n, u64 *out, hipStream_t s) {
     LF_LAUNCH(k_lincomb_z, t.nu2p40, dim3(cdiv(n, 256), 8), dim3(256), s, t, z, ldz, K, coef_dev, tt, n, out);
@@ -791,31 +844,41 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
-        Fq3 v[8], st[8];
-        for (u32 j = 0; j < desc.t; j++) {
-            const u64 *tb = mz + ((size_t)j * 24 + 3 * slot) * ld;
-            ulonglong2 a0 = *(const ulonglong2 *)(tb + 2 * p), a1 = *(const ulonglong2 *)(tb + ld + 2 * p), a2 = *(const ulonglong2 *)(tb + 2 * ld + 2 * p);
-            v[j] = fq3_make(a0.x, a1.x, a2.x);
-            st[j] = fq3_sub(fq3_make(a0.y, a1.y, a2.y), v[j]);
+        Fq3 v[4], st[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((u32)j < desc.t) {
+                const u64 *tb = mz + ((size_t)j * 24 + 3 * slot) * ld;
+                ulonglong2 a0 = *(const ulonglong2 *)(tb + 2 * p), a1 = *(const ulonglong2 *)(tb + ld + 2 * p), a2 = *(const ulonglong2 *)(tb + 2 * ld + 2 * p);
+                v[j] = fq3_make(a0.x, a1.x, a2.x);
+                st[j] = fq3_sub(fq3_make(a0.y, a1.y, a2.y), v[j]);
+            } else { v[j] = fq3_zero(); st[j] = fq3_zero(); }
         }
         ulonglong2 e0 = *(const ulonglong2 *)(eq + 2 * p), e1 = *(const ulonglong2 *)(eq + ldeq + 2 * p), e2 = *(const ulonglong2 *)(eq + 2 * ldeq + 2 * p);
         Fq3 ev = fq3_make(e0.x, e1.x, e2.x), es = fq3_sub(fq3_make(e0.y, e1.y, e2.y), ev);
-        for (u32 X = 0; X <= deg; X++) {
-            Fq3 res = fq3_zero();
-            for (u32 i = 0; i < desc.q; i++) {
-                u32 k = desc.S_off[i], ke = desc.S_off[i + 1];
-                Fq3 term;
-                if (desc.c_unit[i] != 0 && k < ke) {            // c_i = +-1: start from the first factor
-                    term = v[desc.S_idx[k++]];
-                } else {
-                    term = fq3_make(desc.c[i][3 * slot], desc.c[i][3 * slot + 1], desc.c[i][3 * slot + 2]);
+#pragma unroll
+        for (int X = 0; X < 5; X++) {
+            if ((u32)X <= deg) {
+                // comb = (sum_i c_i prod_{j in S_i} v_j) * eq ; table j belongs to multiset ms[j], first[j] marks its start
+                Fq3 res = fq3_zero(), term = fq3_zero();
+                int sgn = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if ((u32)j < desc.t) {
+                        if (desc.first[j]) {  // wave-uniform
+                            if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
+                            u32 i = desc.ms[j];
+                            if (desc.c_unit[i]) { term = v[j]; sgn = desc.c_unit[i]; }
+                            else { term = M3<NU>(fq3_make(desc.c[i][3 * slot], desc.c[i][3 * slot + 1], desc.c[i][3 * slot + 2]), v[j], t.nu); sgn = 1; }
+                        } else term = M3<NU>(term, v[j], t.nu);
+                    }
                 }
-                for (; k < ke; k++) term = M3<NU>(term, v[desc.S_idx[k]], t.nu);
-                res = desc.c_unit[i] < 0 ? fq3_sub(res, term) : fq3_add(res, term);
+                if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
+                acc[X] = fq3_add(acc[X], M3<NU>(res, ev, t.nu));
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = fq3_add(v[j], st[j]);
+                ev = fq3_add(ev, es);
             }
-            acc[X] = fq3_add(acc[X], M3<NU>(res, ev, t.nu));
-            for (u32 j = 0; j < desc.t; j++) v[j] = fq3_add(v[j], st[j]);
-            ev = fq3_add(ev, es);
         }
     }
     u64 vv[15];
