@@ -397,7 +397,7 @@ constexpr int AJ_THREADS = 448;  // 7 waves: 26 x 15 = 390 outputs (a 6-full-wav
 struct Acc6 { AccP s[6]; };
 // LDS tile: one 48-byte record {c0,c1,c2,c0+c1,c0+c2,c1+c2} per (row, column), read back as three ds_read_b128.
 // Row stride = AJ_JT*48 + 16 bytes: rows of one 16-lane read group fall into distinct 16-byte slots (conflict-free).
-constexpr int AJ_T = 16;                          // columns per tile
+constexpr int AJ_T = 32;                          // columns per tile
 constexpr int AJ_ROWB = AJ_T * 48 + 16;           // bytes per row
 template <bool NU>
 __global__ void __launch_bounds__(AJ_THREADS, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
