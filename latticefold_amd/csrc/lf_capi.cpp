@@ -39,7 +39,7 @@ static bool lf_trace_on() { static int v = -1; if (v < 0) v = getenv("LF_TRACE")
 #define LF_TRACE(c, msg)                                                              \
     do {                                                                              \
         if (lf_trace_on()) {                                                          \
-            hipError_t e_ = hipStreamSynchronize((c)->st);                            \
+            hipError_t e_ = hipStreamSynchronize((c)->stream());                            \
             fprintf(stderr, "[lf] %s:%d %s -> %s\n", __func__, __LINE__, msg, hipGetErrorString(e_)); \
             fflush(stderr);                                                           \
         }                                                                             \
@@ -68,6 +68,8 @@ struct DevBuf {
     }
 };
 
+static thread_local int t_lane = 0;  // 0 = caller thread, 1 = helper thread running the left decomposition
+
 struct lf_witness {
     lf_ctx *ctx;
     int32_t *planes;  // [24][N] centred coefficients
@@ -84,8 +86,9 @@ struct EvPair { hipEvent_t a, b; };
 
 struct lf_ctx {
     int device = 0;
-    hipStream_t st = nullptr;
-    std::mutex mu;
+    hipStream_t st_lane[2] = {nullptr, nullptr};
+    std::mutex mu, buf_mu, ev_mu;
+    hipStream_t stream() const { return st_lane[t_lane]; }
     HostRing ring;
     DevCrt dcrt;
     u64 *d_icrt = nullptr;
@@ -101,8 +104,8 @@ struct lf_ctx {
     std::vector<u64 *> d_val, d_valT;
     LinCombDesc desc{};
     std::map<std::string, DevBuf> bufs;
-    u64 *h_pin = nullptr;
-    size_t h_pin_words = 0;
+    u64 *h_pin_lane[2] = {nullptr, nullptr};
+    size_t h_pin_words_lane[2] = {0, 0};
     // lin sumcheck ABI state
     int sc_round = -1;
     size_t sc_n = 0;
@@ -117,9 +120,13 @@ struct lf_ctx {
     double host_tr_ms = 0;
 
     int buf(const std::string &name, size_t bytes, void **out) {
-        DevBuf &b = bufs[name];
-        int rc = b.ensure(bytes);
-        *out = b.p;
+        DevBuf *b;
+        {
+            std::lock_guard<std::mutex> g(buf_mu);
+            b = &bufs[t_lane ? "lane1:" + name : name];  // std::map nodes are stable
+        }
+        int rc = b->ensure(bytes);
+        *out = b->p;
         return rc;
     }
     template <class T>
@@ -129,16 +136,21 @@ struct lf_ctx {
         *out = (T *)p;
         return rc;
     }
+    u64 *&h_pin_ref() { return h_pin_lane[t_lane]; }
     int pin(size_t words) {
-        if (words <= h_pin_words) return LF_OK;
-        if (h_pin) (void)hipHostFree(h_pin);
-        h_pin = nullptr;
-        if (hipHostMalloc((void **)&h_pin, words * 8) != hipSuccess) return LF_ERR_HIP;
-        h_pin_words = words;
+        u64 *&hp = h_pin_lane[t_lane];
+        size_t &hw = h_pin_words_lane[t_lane];
+        if (words <= hw) return LF_OK;
+        if (hp) (void)hipHostFree(hp);
+        hp = nullptr;
+        if (words < 8192) words = 8192;
+        if (hipHostMalloc((void **)&hp, words * 8) != hipSuccess) return LF_ERR_HIP;
+        hw = words;
         return LF_OK;
     }
     // timed-launch helpers: tag 0 = fold round kernels, 1 = ajtai, 10+i = phase i
     size_t ev_begin(int tag) {
+        std::lock_guard<std::mutex> g(ev_mu);
         if (ev_used == ev_pool.size()) {
             EvPair e;
             (void)hipEventCreate(&e.a);
@@ -146,17 +158,21 @@ struct lf_ctx {
             ev_pool.push_back(e);
         }
         size_t i = ev_used++;
-        (void)hipEventRecord(ev_pool[i].a, st);
+        (void)hipEventRecord(ev_pool[i].a, stream());
         ev_tags.push_back({tag, i});
         return i;
     }
-    void ev_end(size_t i) { (void)hipEventRecord(ev_pool[i].b, st); }
+    void ev_end(size_t i) {
+        std::lock_guard<std::mutex> g(ev_mu);
+        (void)hipEventRecord(ev_pool[i].b, stream());
+    }
     void ev_reset() {
         ev_used = 0;
         ev_tags.clear();
     }
     void ev_collect() {
-        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(st_lane[0]);
+        (void)hipStreamSynchronize(st_lane[1]);
         k_fold_ms = k_ajtai_ms = 0;
         k_fold_n = k_ajtai_n = 0;
         for (int i = 0; i < LF_N_PHASES; i++) phase_ms[i] = 0;
@@ -204,7 +220,7 @@ int lf_ctx_create(lf_ctx **out, int device) {
     HIPCHK(hipSetDevice(device));
     lf_ctx *c = new lf_ctx();
     c->device = device;
-    if (hipStreamCreate(&c->st) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    if (hipStreamCreate(&c->st_lane[0]) != hipSuccess || hipStreamCreate(&c->st_lane[1]) != hipSuccess) { delete c; return LF_ERR_HIP; }
     u64 nr, y[24];
     default_ring(&nr, y);
     int rc = install_tables(c, nr, y);
@@ -225,14 +241,17 @@ static void free_ccs(lf_ctx *c) {
 void lf_ctx_destroy(lf_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->st);
+    (void)hipStreamSynchronize(c->st_lane[0]);
+    (void)hipStreamSynchronize(c->st_lane[1]);
     free_ccs(c);
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
-    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    for (int l = 0; l < 2; l++)
+        if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    (void)hipStreamDestroy(c->st);
+    (void)hipStreamDestroy(c->st_lane[0]);
+    (void)hipStreamDestroy(c->st_lane[1]);
     delete c;
 }
 int lf_set_ring_tables(lf_ctx *c, uint64_t nonres, const uint64_t *y) {
@@ -251,7 +270,7 @@ int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
 int lf_device_synchronize(lf_ctx *c) {
     if (!c) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
 }
 
@@ -261,25 +280,25 @@ static int up_ring(lf_ctx *c, const u64 *host, size_t n, u64 *dst) {
     if (!n) return LF_OK;
     u64 *tmp;
     RET(c->tbuf("stage_aos", n * 24, &tmp));
-    HIPCHK(hipMemcpyAsync(tmp, host, n * 24 * 8, hipMemcpyHostToDevice, c->st));
-    launch_aos_to_soa(tmp, dst, n, c->st);
+    HIPCHK(hipMemcpyAsync(tmp, host, n * 24 * 8, hipMemcpyHostToDevice, c->stream()));
+    launch_aos_to_soa(tmp, dst, n, c->stream());
     return LF_OK;
 }
 static int down_ring(lf_ctx *c, const u64 *src, size_t n, u64 *host) {
     if (!n) return LF_OK;
     u64 *tmp;
     RET(c->tbuf("stage_aos", n * 24, &tmp));
-    launch_soa_to_aos(src, tmp, n, c->st);
-    HIPCHK(hipMemcpyAsync(host, tmp, n * 24 * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    launch_soa_to_aos(src, tmp, n, c->stream());
+    HIPCHK(hipMemcpyAsync(host, tmp, n * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
 }
 // small device array -> host (through pinned memory)
 static int down_small(lf_ctx *c, const u64 *dsrc, size_t words, u64 *host) {
     RET(c->pin(words));
-    HIPCHK(hipMemcpyAsync(c->h_pin, dsrc, words * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    memcpy(host, c->h_pin, words * 8);
+    HIPCHK(hipMemcpyAsync(c->h_pin_ref(), dsrc, words * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    memcpy(host, c->h_pin_ref(), words * 8);
     return LF_OK;
 }
 static Fq3Const f3c(Fq3 a) { Fq3Const r; r.c[0] = a.c[0]; r.c[1] = a.c[1]; r.c[2] = a.c[2]; return r; }
@@ -290,7 +309,7 @@ int lf_selftest_field(lf_ctx *c, uint64_t seed, uint32_t n, uint64_t *mismatches
     HIPCHK(hipSetDevice(c->device));
     u64 *d;
     RET(c->tbuf("small_dev", 4096, &d));
-    launch_selftest_field(seed, n, d, c->st);
+    launch_selftest_field(seed, n, d, c->stream());
     return down_small(c, d, 1, mismatches);
 }
 
@@ -303,7 +322,7 @@ int lf_ntt_fwd(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
     RET(c->tbuf("io_a", count * 24, &a));
     RET(c->tbuf("io_b", count * 24, &b));
     RET(up_ring(c, in, count, a));
-    launch_crt_fwd(c->dcrt, a, b, count, c->st);
+    launch_crt_fwd(c->dcrt, a, b, count, c->stream());
     return down_ring(c, b, count, out);
 }
 int lf_ntt_inv(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
@@ -314,7 +333,7 @@ int lf_ntt_inv(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
     RET(c->tbuf("io_a", count * 24, &a));
     RET(c->tbuf("io_b", count * 24, &b));
     RET(up_ring(c, in, count, a));
-    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    launch_icrt_dense(c->d_icrt, a, b, count, c->stream());
     return down_ring(c, b, count, out);
 }
 static bool pow2(u64 b) { return b >= 2 && (b & (b - 1)) == 0; }
@@ -327,7 +346,7 @@ int lf_decompose(lf_ctx *c, const uint64_t *in, size_t count, uint64_t base, uns
     RET(c->tbuf("io_a", count * 24, &a));
     RET(c->tbuf("io_b", count * digits * 24, &b));
     RET(up_ring(c, in, count, a));
-    launch_decompose(a, count, base, digits, layout, b, c->st);
+    launch_decompose(a, count, base, digits, layout, b, c->stream());
     if (layout == 0) return down_ring(c, b, count * digits, out);
     for (unsigned k = 0; k < digits; k++) RET(down_ring(c, b + (size_t)k * 24 * count, count, out + (size_t)k * count * 24));
     return LF_OK;
@@ -340,7 +359,7 @@ int lf_recompose(lf_ctx *c, const uint64_t *in, size_t count_out, uint64_t base,
     RET(c->tbuf("io_a", count_out * digits * 24, &a));
     RET(c->tbuf("io_b", count_out * 24, &b));
     RET(up_ring(c, in, count_out * digits, a));
-    launch_recompose(a, count_out, base, digits, b, c->st);
+    launch_recompose(a, count_out, base, digits, b, c->stream());
     return down_ring(c, b, count_out, out);
 }
 int lf_linf_check(lf_ctx *c, const uint64_t *f_ntt, size_t count, uint64_t bound, int unsigned_variant, int *ok, uint64_t *max_out) {
@@ -352,21 +371,21 @@ int lf_linf_check(lf_ctx *c, const uint64_t *f_ntt, size_t count, uint64_t bound
     RET(c->tbuf("io_b", count * 24, &b));
     RET(c->tbuf("small_dev", 4096, &mx));
     RET(up_ring(c, f_ntt, count, a));
-    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    launch_icrt_dense(c->d_icrt, a, b, count, c->stream());
     if (unsigned_variant) {
         // literal Witness::within_bound: canonical coefficient < bound  <=>  max canonical < bound; reuse the
         // centred kernel on a table where "negative" values are impossible: compare canonical values on host
         // through a max reduction of min(v, p-1-v)?  Not equivalent -- do it exactly: download max canonical.
         std::vector<u64> h(count * 24);
-        HIPCHK(hipMemcpyAsync(h.data(), b, count * 24 * 8, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(hipStreamSynchronize(c->st));
+        HIPCHK(hipMemcpyAsync(h.data(), b, count * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
+        HIPCHK(hipStreamSynchronize(c->stream()));
         u64 m = 0;
         for (u64 v : h) m = v > m ? v : m;
         if (max_out) *max_out = m;
         *ok = m < bound;
         return LF_OK;
     }
-    launch_linf(b, count, mx, c->st);
+    launch_linf(b, count, mx, c->stream());
     u64 m = 0;
     RET(down_small(c, mx, 1, &m));
     if (max_out) *max_out = m;
@@ -382,7 +401,7 @@ int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
     HIPCHK(hipMalloc((void **)&c->dA, kappa * n * 24 * 8));
     for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + i * n * 24, n, c->dA + i * 24 * n));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = n;
     return LF_OK;
@@ -393,8 +412,8 @@ int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
     HIPCHK(hipSetDevice(c->device));
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
     HIPCHK(hipMalloc((void **)&c->dA, kappa * n * 24 * 8));
-    launch_fill_ajtai(c->dA, (u32)kappa, n, seed, c->st);
-    HIPCHK(hipStreamSynchronize(c->st));
+    launch_fill_ajtai(c->dA, (u32)kappa, n, seed, c->stream());
+    HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = n;
     return LF_OK;
@@ -417,7 +436,7 @@ static int commit_dev(lf_ctx *c, const u64 *F, u32 batch, u64 *out_dev, bool tim
     for (u32 b0 = 0; b0 < batch; b0 += maxb) {
         u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
         size_t ev = timed ? c->ev_begin(1) : 0;
-        launch_ajtai(c->dcrt, c->dA, c->kappa, c->nA, F + (size_t)b0 * 24 * c->nA, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * 24, c->st);
+        launch_ajtai(c->dcrt, c->dA, c->kappa, c->nA, F + (size_t)b0 * 24 * c->nA, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * 24, c->stream());
         if (timed) c->ev_end(ev);
     }
     return LF_OK;
@@ -442,9 +461,9 @@ static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {
     RET(c->tbuf("eq_point", 64, &rd));
     std::vector<Fq3Const> h(nv);
     for (u32 i = 0; i < nv; i++) h[i] = f3c(pt[i]);
-    HIPCHK(hipMemcpyAsync(rd, h.data(), nv * sizeof(Fq3Const), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));  // h is a stack-lifetime buffer
-    launch_build_eq(c->dcrt, rd, nv, eq_dev, c->st);
+    HIPCHK(hipMemcpyAsync(rd, h.data(), nv * sizeof(Fq3Const), hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));  // h is a stack-lifetime buffer
+    launch_build_eq(c->dcrt, rd, nv, eq_dev, c->stream());
     return LF_OK;
 }
 int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {
@@ -458,8 +477,8 @@ int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {
     for (unsigned i = 0; i < nv; i++) pt[i] = fq3_make(point[3 * i], point[3 * i + 1], point[3 * i + 2]);
     RET(build_eq_dev(c, pt.data(), nv, eq));
     std::vector<u64> h(3 * n);
-    HIPCHK(hipMemcpyAsync(h.data(), eq, 3 * n * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(h.data(), eq, 3 * n * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     for (size_t i = 0; i < n; i++)
         for (int q = 0; q < 3; q++) out[3 * i + q] = h[(size_t)q * n + i];
     return LF_OK;
@@ -479,7 +498,7 @@ int lf_mle_eval_batch(lf_ctx *c, const uint64_t *tables, size_t ntables, size_t 
     for (unsigned i = 0; i < nv; i++) pt[i] = fq3_make(point[3 * i], point[3 * i + 1], point[3 * i + 2]);
     RET(build_eq_dev(c, pt.data(), nv, eq));
     for (size_t a = 0; a < ntables; a++) RET(up_ring(c, tables + a * len * 24, len, X + a * 24 * len));
-    launch_dot_eq(c->dcrt, X, len, (u32)ntables, eq, n, len, partial, o, c->st);
+    launch_dot_eq(c->dcrt, X, len, (u32)ntables, eq, n, len, partial, o, c->stream());
     return down_small(c, o, ntables * 24, out);
 }
 
@@ -578,7 +597,7 @@ int lf_spmv(lf_ctx *c, unsigned j, const uint64_t *z, uint64_t *out) {
     RET(c->tbuf("io_a", c->n * 24, &zd));
     RET(c->tbuf("io_b", c->m * 24, &od));
     RET(up_ring(c, z, c->n, zd));
-    launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], zd, c->n, od, c->m, 0, c->st);
+    launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], zd, c->n, od, c->m, 0, c->stream());
     return down_ring(c, od, c->m, out);
 }
 
@@ -588,10 +607,10 @@ static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] can
     HIPCHK(hipMalloc((void **)&pl, c->N * 24 * 4));
     int *viol;
     if (c->tbuf("small_dev", 4096, (u64 **)&viol) != LF_OK) { (void)hipFree(pl); return LF_ERR_HIP; }
-    (void)hipMemsetAsync(viol, 0, 4, c->st);
-    launch_coef_to_i32(coef_dev, pl, c->N, (u32)(c->P.B / 2), viol, c->st);
+    (void)hipMemsetAsync(viol, 0, 4, c->stream());
+    launch_coef_to_i32(coef_dev, pl, c->N, (u32)(c->P.B / 2), viol, c->stream());
     int hv = 0;
-    if (hipMemcpyAsync(&hv, viol, 4, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) {
+    if (hipMemcpyAsync(&hv, viol, 4, hipMemcpyDeviceToHost, c->stream()) != hipSuccess || hipStreamSynchronize(c->stream()) != hipSuccess) {
         (void)hipFree(pl);
         return LF_ERR_HIP;
     }
@@ -611,8 +630,8 @@ int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
     RET(c->tbuf("io_b", (size_t)c->P.wit_len * 24, &b));
     RET(c->tbuf("io_c", c->N * 24, &d));
     RET(up_ring(c, w_ccs, c->P.wit_len, a));
-    launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->st);
-    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->st);
+    launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->stream());
+    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->stream());
     return witness_from_coef_table(c, d, out);
 }
 int lf_witness_from_f_coeff(lf_ctx *c, const uint64_t *f_coeff, lf_witness **out) {
@@ -634,7 +653,7 @@ int lf_witness_from_f(lf_ctx *c, const uint64_t *f_ntt, lf_witness **out) {
     RET(c->tbuf("io_a", c->N * 24, &a));
     RET(c->tbuf("io_c", c->N * 24, &d));
     RET(up_ring(c, f_ntt, c->N, a));
-    launch_icrt_dense(c->d_icrt, a, d, c->N, c->st);
+    launch_icrt_dense(c->d_icrt, a, d, c->N, c->stream());
     return witness_from_coef_table(c, d, out);
 }
 int lf_witness_get_f_coeff(lf_ctx *c, const lf_witness *w, uint64_t *out) {
@@ -643,7 +662,7 @@ int lf_witness_get_f_coeff(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     HIPCHK(hipSetDevice(c->device));
     u64 *d;
     RET(c->tbuf("io_c", w->N * 24, &d));
-    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    launch_i32_to_coef(w->planes, d, w->N, c->stream());
     return down_ring(c, d, w->N, out);
 }
 int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
@@ -653,8 +672,8 @@ int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     u64 *d, *e;
     RET(c->tbuf("io_c", w->N * 24, &d));
     RET(c->tbuf("io_b", w->N * 24, &e));
-    launch_i32_to_coef(w->planes, d, w->N, c->st);
-    launch_crt_fwd(c->dcrt, d, e, w->N, c->st);
+    launch_i32_to_coef(w->planes, d, w->N, c->stream());
+    launch_crt_fwd(c->dcrt, d, e, w->N, c->stream());
     return down_ring(c, e, w->N, out);
 }
 int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
@@ -664,7 +683,7 @@ int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     HIPCHK(hipSetDevice(c->device));
     u64 *e;
     RET(c->tbuf("io_b", (size_t)c->P.wit_len * 24, &e));
-    launch_recompose_crt(c->dcrt, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->st);
+    launch_recompose_crt(c->dcrt, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->stream());
     return down_ring(c, e, c->P.wit_len, out);
 }
 int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
@@ -677,8 +696,8 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     RET(c->tbuf("io_c", w->N * 24, &d));
     RET(c->tbuf("io_b", w->N * 24, &e));
     RET(c->tbuf("io_o", (size_t)c->kappa * 24, &o));
-    launch_i32_to_coef(w->planes, d, w->N, c->st);
-    launch_crt_fwd(c->dcrt, d, e, w->N, c->st);
+    launch_i32_to_coef(w->planes, d, w->N, c->stream());
+    launch_crt_fwd(c->dcrt, d, e, w->N, c->stream());
     RET(commit_dev(c, e, 1, o, false));
     return down_small(c, o, (size_t)c->kappa * 24, cm_out);
 }
@@ -751,13 +770,13 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     for (u32 round = 1; round <= P.s; round++) {
         if (round > 1) {
             Fq3Const r = f3c(point[round - 2]);
-            launch_fix_many(c->dcrt, cur, n, fx[flip], n / 2, n, P.t * 8, r, c->st);
-            launch_fix_many(c->dcrt, cure, n, fe[flip], n / 2, n, 1, r, c->st);
+            launch_fix_many(c->dcrt, cur, n, fx[flip], n / 2, n, P.t * 8, r, c->stream());
+            launch_fix_many(c->dcrt, cure, n, fe[flip], n / 2, n, 1, r, c->stream());
             cur = fx[flip]; cure = fe[flip];
             flip ^= 1;
             n /= 2;
         }
-        launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->st);
+        launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->stream());
         u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * 24;
         RET(down_small(c, od, (size_t)(deg + 1) * 24, ev));
         HostTimer ht(c);
@@ -770,7 +789,7 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
 static int build_z(lf_ctx *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads /* K*(l+1) ring AoS host */, u64 *z /* [K][24][n] */) {
     const lf_params &P = c->P;
     u32 hl = P.l + 1;
-    launch_recompose_crt(c->dcrt, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->st);
+    launch_recompose_crt(c->dcrt, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->stream());
     // heads: write plane entries 0..l of each table
     std::vector<u64> h((size_t)K * 24 * hl);
     for (u32 k = 0; k < K; k++)
@@ -778,9 +797,9 @@ static int build_z(lf_ctx *c, const int32_t *planes, u32 K, int mode_bits, const
             for (int w = 0; w < 24; w++) h[((size_t)k * 24 + w) * hl + i] = heads[((size_t)k * hl + i) * 24 + w];
     u64 *stage;
     RET(c->tbuf("z_heads", h.size(), &stage));
-    HIPCHK(hipMemcpyAsync(stage, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpy2DAsync(z, c->n * 8, stage, hl * 8, hl * 8, (size_t)K * 24, hipMemcpyDeviceToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(stage, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipMemcpy2DAsync(z, c->n * 8, stage, hl * 8, hl * 8, (size_t)K * 24, hipMemcpyDeviceToDevice, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
 }
 
@@ -819,15 +838,15 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     for (u32 j = 0; j < P.t; j++)
-        launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->st);
+        launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->stream());
     std::vector<Fq3> pt(P.s);
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data()));
     // v, u at the sumcheck point (linearization.rs:126-139)
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;
-    launch_coef_eval(c->dcrt, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->st);
+    launch_coef_eval(c->dcrt, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());
     RET(down_small(c, od, 72, v));  // T[24][3] flat == v[3][8 slots][3]
-    launch_dot_eq(c->dcrt, mz, m, P.t, eqr, m, m, partial, od, c->st);
+    launch_dot_eq(c->dcrt, mz, m, P.t, eqr, m, m, partial, od, c->stream());
     RET(down_small(c, od, (size_t)P.t * 24, u));
     {
         HostTimer ht(c);
@@ -906,7 +925,7 @@ static int decompose_impl(lf_ctx *c, Transcript &tr, const u64 *lcccs, const std
     // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
     size_t ph = c->ev_begin(11);
     LF_TRACE(c, "dec start");
-    launch_bitplane_crt(c->dcrt, wit->planes, N, 1, K, Fh, c->st);
+    launch_bitplane_crt(c->dcrt, wit->planes, N, 1, K, Fh, c->stream());
     LF_TRACE(c, "bitplane_crt");
     RET(commit_dev(c, Fh, K - 1, yd, true));
     LF_TRACE(c, "commit");
@@ -927,17 +946,17 @@ static int decompose_impl(lf_ctx *c, Transcript &tr, const u64 *lcccs, const std
     compute_x_s(c, xh, x_s);
     LF_TRACE(c, "x_s");
     // v_s (decomposition.rs:204-211) from the coefficient planes
-    launch_coef_eval(c->dcrt, wit->planes, N, eq_r, m, K, 1, partial, od, c->st);
+    launch_coef_eval(c->dcrt, wit->planes, N, eq_r, m, K, 1, partial, od, c->stream());
     RET(down_small(c, od, (size_t)K * 72, v_s));
     LF_TRACE(c, "v_s");
     // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     RET(build_z(c, wit->planes, K, 1, x_s, z));
     LF_TRACE(c, "build_z");
     for (u32 j = 0; j < P.t; j++)
-        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->st);
+        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->stream());
     u64 *dpart;
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
-    launch_dot_batch(c->dcrt, z, n, K, q, n, P.t, n, dpart, od, c->st);
+    launch_dot_batch(c->dcrt, z, n, K, q, n, P.t, n, dpart, od, c->stream());
     RET(down_small(c, od, (size_t)K * P.t * 24, u_s));
     LF_TRACE(c, "u_s");
     c->ev_end(ph);
@@ -972,8 +991,8 @@ static double absorb_decomposition(const lf_params &P, Transcript &tr, const u64
 
 static int upload_consts(lf_ctx *c, const std::string &name, const std::vector<Fq3Const> &v, Fq3Const **out) {
     RET(c->tbuf(name, v.size() + 8, out));
-    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(Fq3Const), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(Fq3Const), hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
 }
 
@@ -1020,10 +1039,10 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("round_out", 5 * 24, &od));
     for (int sd = 0; sd < 2; sd++) {
         // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}
-        launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->st);
+        launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
         for (u32 j = 0; j < P.t; j++)
-            launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], zz + (size_t)j * 24 * n, n, G[sd], m, j > 0, c->st);
-        launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, c->st);
+            launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], zz + (size_t)j * 24 * n, n, G[sd], m, j > 0, c->stream());
+        launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, c->stream());
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     LF_TRACE(c, "fold prepare");
@@ -1051,20 +1070,20 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             Fq3Const r = f3c(pt[round - 2]);
             size_t nn = a.n / 2;
             u64 *dst = T5[flip];
-            launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, c->st);
-            launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, c->st);
-            launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->st);
-            launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->st);
-            launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->st);
+            launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, c->stream());
+            launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, c->stream());
+            launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->stream());
+            launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->stream());
+            launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->stream());
             if (round == 3) {
                 // W_b = eq((r1, r2), b), b = b0 + 2 b1 (LSB-first)
                 Fq3 r1 = pt[0], r2 = pt[1], o1 = fq3_sub(fq3_one(), r1), o2 = fq3_sub(fq3_one(), r2);
                 Fq3Const W[4] = {f3c(c->ring.mul3(o1, o2)), f3c(c->ring.mul3(r1, o2)), f3c(c->ring.mul3(o1, r2)), f3c(c->ring.mul3(r1, r2))};
-                launch_fold_materialize2(c->dcrt, S[0].planes, S[1].planes, N, m, K, W, F[0], c->st);
+                launch_fold_materialize2(c->dcrt, S[0].planes, S[1].planes, N, m, K, W, F[0], c->stream());
                 curF = F[0]; ldF = nn;
             } else if (round > 3) {
                 u64 *fd = F[(round & 1) ? 0 : 1];  // round 4 -> F[1], round 5 -> F[0], ...
-                launch_fix_many(c->dcrt, curF, ldF, fd, nn, a.n, K2 * 3 * 8, r, c->st);
+                launch_fix_many(c->dcrt, curF, ldF, fd, nn, a.n, K2 * 3 * 8, r, c->stream());
                 curF = fd; ldF = nn;
             }
             a.eqL = dst; a.eqR = dst + 3 * nn; a.eqB = dst + 6 * nn; a.G1 = dst + 9 * nn; a.G2 = dst + 33 * nn;
@@ -1072,9 +1091,9 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             flip ^= 1;
         }
         size_t ev = c->ev_begin(0);
-        if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->st);
-        else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->st);
-        else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->st);
+        if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
+        else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->stream());
+        else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->stream());
         c->ev_end(ev);
         LF_TRACE(c, "fold round");
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * 24;
@@ -1095,11 +1114,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
     for (u32 j = 0; j < P.t; j++)
-        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, c->st);
+        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, c->stream());
     for (int sd = 0; sd < 2; sd++) {
-        launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, sm, c->st);
+        launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, sm, c->stream());
         RET(down_small(c, sm, (size_t)K * 72, theta + (size_t)sd * K * 72));
-        launch_dot_batch(c->dcrt, S[sd].z, n, K, q, n, P.t, n, dpart, sm, c->st);
+        launch_dot_batch(c->dcrt, S[sd].z, n, K, q, n, P.t, n, dpart, sm, c->stream());
         RET(down_small(c, sm, (size_t)K * P.t * 24, eta + (size_t)sd * K * P.t * 24));
     }
     std::vector<u64> rho_c((size_t)K2 * 24, 0), rho((size_t)K2 * 24);
@@ -1123,13 +1142,13 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // f_0 in the coefficient domain -> new witness
     int8_t *d_rho;
     RET(c->tbuf("c_rho", (size_t)K2 * 24 + 64, &d_rho));
-    HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->stream()));
     int32_t *npl;
     HIPCHK(hipMalloc((void **)&npl, N * 24 * 4));
     LF_TRACE(c, "theta/eta");
-    launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->st);
+    launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     LF_TRACE(c, "fold_witness");
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c, npl, N};
     c->ev_end(ph);
 
@@ -1214,10 +1233,19 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     u64 *lin_proof = proof, *decl = lin_proof + lin_proof_len(&P) * 24, *decr = decl + dec_proof_len(&P) * 24, *foldp = decr + dec_proof_len(&P) * 24;
     std::vector<u64> lin(ll * 24);
     u64 *eq_r_R = nullptr;
-    int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
     SideState S[2];
+    // The left decomposition (acc, w_acc) needs nothing from the linearization -- only the transcript order is
+    // fixed -- so its GPU work runs on a second stream / host thread while the latency-bound linearization rounds go on.
+    std::future<int> fdl = std::async(std::launch::async, [&]() -> int {
+        t_lane = 1;
+        if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
+        return decompose_impl(c, tr, acc, rL, w_acc, "L", nullptr, S[0], decl);
+    });
+    int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    int rcl = fdl.get();
+    if (rc == LF_OK) rc = rcl;
     std::vector<Fq3> rR;
-    if (rc == LF_OK) { lcccs_point(P, lin.data(), rR); rc = decompose_impl(c, tr, acc, rL, w_acc, "L", nullptr, S[0], decl); }
+    if (rc == LF_OK) lcccs_point(P, lin.data(), rR);
     if (rc == LF_OK) {
         std::future<double> fl = std::async(std::launch::async, [&] { return absorb_decomposition(P, tr, acc, decl, S[0]); });
         rc = decompose_impl(c, tr, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
@@ -1267,11 +1295,11 @@ int lf_sumcheck_lin_round(lf_ctx *c, const uint64_t *r_prev, uint64_t *evals_out
     if (r_prev) {
         Fq3Const r; r.c[0] = r_prev[0]; r.c[1] = r_prev[1]; r.c[2] = r_prev[2];
         int src = c->sc_cur, dst = src ^ 1;
-        launch_fix_many(c->dcrt, tab[src], c->sc_n, tab[dst], c->sc_n / 2, c->sc_n, P.t * 8, r, c->st);
-        launch_fix_many(c->dcrt, eq[src], c->sc_n, eq[dst], c->sc_n / 2, c->sc_n, 1, r, c->st);
+        launch_fix_many(c->dcrt, tab[src], c->sc_n, tab[dst], c->sc_n / 2, c->sc_n, P.t * 8, r, c->stream());
+        launch_fix_many(c->dcrt, eq[src], c->sc_n, eq[dst], c->sc_n / 2, c->sc_n, 1, r, c->stream());
         c->sc_cur = dst; c->sc_n /= 2;
     }
-    launch_lin_round(c->dcrt, c->desc, tab[c->sc_cur], c->sc_n, eq[c->sc_cur], c->sc_n, c->sc_n, P.d + 1, partial, od, c->st);
+    launch_lin_round(c->dcrt, c->desc, tab[c->sc_cur], c->sc_n, eq[c->sc_cur], c->sc_n, c->sc_n, P.d + 1, partial, od, c->stream());
     c->sc_round++;
     return down_small(c, od, (size_t)(P.d + 2) * 24, evals_out);
 }

@@ -249,6 +249,42 @@ inline u64 dot_fq(const u64 *a, const u64 *b, int n) {
     return fq_add(l, fq_mul(h, LF_EPS));  // 2^64 = 2^32 - 1 (mod p)
 }
 
+// out = M x for a row-major n x n matrix (ld = row stride): RB rows at a time with independent 192-bit accumulators
+// (add / adc / adc per product), one reduction per row; 2^128 = -2^32 (mod p).
+#ifndef LF_MATVEC_RB
+#define LF_MATVEC_RB 2   /* measured on EPYC 9575F: 0/1/2/3/4 -> 5.2/4.05/4.14/4.10/7.5 us per permutation */
+#endif
+template <int RB>
+inline void matvec_fq_t(const u64 *M, int ld, int n, const u64 *x, u64 *out) {
+    int i = 0;
+    for (; i + RB <= n; i += RB) {
+        u64 lo[RB], mid[RB], hi[RB];
+        for (int r = 0; r < RB; r++) lo[r] = mid[r] = hi[r] = 0;
+        const u64 *row = M + (size_t)i * ld;
+        for (int j = 0; j < n; j++) {
+            u64 xv = x[j];
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                u128 pr = (u128)xv * row[(size_t)r * ld + j];
+                u128 t = (u128)lo[r] + (u64)pr;
+                lo[r] = (u64)t;
+                t = (u128)mid[r] + (u64)(pr >> 64) + (u64)(t >> 64);
+                mid[r] = (u64)t;
+                hi[r] += (u64)(t >> 64);
+            }
+        }
+        for (int r = 0; r < RB; r++) out[i + r] = fq_sub(fq_canon(fq_reduce128_loose(lo[r], mid[r])), hi[r] << 32);
+    }
+    for (; i < n; i++) out[i] = dot_fq(x, M + (size_t)i * ld, n);
+}
+inline void matvec_fq(const u64 *M, int ld, int n, const u64 *x, u64 *out) {
+#if LF_MATVEC_RB == 0
+    for (int i = 0; i < n; i++) out[i] = dot_fq(x, M + (size_t)i * ld, n);
+#else
+    matvec_fq_t<LF_MATVEC_RB>(M, ld, n, x, out);
+#endif
+}
+
 // Partial rounds through the sparse factorisation M*diag(1,E) = diag(1,E') * [[e00, row],[col, I]] (Poseidon paper,
 // appendix on optimised partial rounds): identical output, 47 instead of 576 multiplications per partial round.
 struct PartialOpt {
@@ -324,7 +360,7 @@ void partial_opt_init() {
 inline void full_round(u64 st[W], const u64 *ark) {
     u64 nw[W];
     for (int i = 0; i < W; i++) st[i] = sbox(fq_add(st[i], ark[i]));
-    for (int i = 0; i < W; i++) nw[i] = dot_fq(st, g_mds + i * W, W);
+    matvec_fq(g_mds, W, W, st, nw);
     memcpy(st, nw, sizeof(nw));
 }
 }  // namespace
@@ -373,7 +409,7 @@ void Transcript::permute(u64 st[24]) {
     }
     {   // deferred block-diagonal factor
         u64 nw[W - 1];
-        for (int i = 0; i < W - 1; i++) nw[i] = dot_fq(g_opt.post[i], st + 1, W - 1);
+        matvec_fq(&g_opt.post[0][0], W - 1, W - 1, st + 1, nw);
         memcpy(st + 1, nw, sizeof(nw));
     }
     for (int r = RF / 2 + RP; r < RF + RP; r++) full_round(st, g_ark + r * W);
