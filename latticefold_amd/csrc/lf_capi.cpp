@@ -899,19 +899,52 @@ struct SideState {
 };
 
 // LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
-static int decompose_impl(lf_ctx *c, Transcript &tr, const u64 *lcccs, const std::vector<Fq3> &rpt, const lf_witness *wit, const char *side,
-                          u64 *eq_r /* built already or nullptr */, SideState &S, u64 *proof) {
+// commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A, then
+// y_0 = cm - sum_{k>=1} b^k y_k on the host.  Depends only on the witness and on cm -- not on the evaluation point.
+// `enqueue_only`: leave the result in flight on the lane's stream (finished later by decompose_commit_finish).
+static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_out, size_t *ev_out) {
+    const lf_params &P = c->P;
+    size_t N = c->N;
+    u32 K = P.K;
+    u64 *Fh, *yd;
+    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * N, &Fh));
+    RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &yd));
+    size_t ph = c->ev_begin(11);
+    launch_bitplane_crt(c->dcrt, wit->planes, N, 1, K, Fh, c->stream());
+    RET(commit_dev(c, Fh, K - 1, yd, true));
+    *yd_out = yd;
+    *ev_out = ph;
+    return LF_OK;
+}
+static int decompose_commit_finish(lf_ctx *c, const u64 *cm, u64 *yd, size_t ev, u64 *proof) {
+    const lf_params &P = c->P;
+    u32 K = P.K;
+    u64 *y_s = proof + (size_t)K * P.t * 24 + (size_t)K * 72 + (size_t)K * (P.l + 1) * 24;
+    RET(down_small(c, yd, (size_t)(K - 1) * P.kappa * 24, y_s + (size_t)P.kappa * 24));
+    c->ev_end(ev);
+    // y_0 = cm - sum_{k>=1} b^k y_k, as the reference's fold (acc + y_i) * b
+    std::vector<u64> acc((size_t)P.kappa * 24, 0);
+    u64 bb[24];
+    HostRing::from_u64(P.b, bb);
+    for (int k = (int)K - 1; k >= 1; k--)
+        for (u32 i = 0; i < P.kappa; i++) {
+            HostRing::add(&acc[(size_t)i * 24], y_s + ((size_t)k * P.kappa + i) * 24, &acc[(size_t)i * 24]);
+            c->ring.mul_ntt(&acc[(size_t)i * 24], bb, &acc[(size_t)i * 24]);
+        }
+    for (u32 i = 0; i < P.kappa; i++) HostRing::sub(cm + (size_t)i * 24, &acc[(size_t)i * 24], y_s + (size_t)i * 24);
+    return LF_OK;
+}
+
+// the point-dependent half of LFDecompositionProver::prove (decomposition.rs:33-88): x_s, v_s, z_k, u_s
+static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &rpt, const lf_witness *wit, const char *side,
+                           u64 *eq_r /* built already or nullptr */, SideState &S, u64 *proof) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n, N = c->N;
     u32 K = P.K;
     std::string sd(side);
-    const u64 *cm = lcccs + ((size_t)P.s + 3) * 24;
     const u64 *xh = lcccs + ((size_t)P.s + 3 + P.kappa + P.t) * 24;
-    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24, *x_s = v_s + (size_t)K * 72, *y_s = x_s + (size_t)K * (P.l + 1) * 24;
-
-    u64 *Fh, *yd, *partial, *od, *z, *q;
-    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * N, &Fh));
-    RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &yd));
+    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24, *x_s = v_s + (size_t)K * 72;
+    u64 *partial, *od, *z, *q;
     RET(c->tbuf("red_partial", 256 * 4096, &partial));
     RET(c->tbuf("dec_small", 16 * 72 + 16 * 4 * 24 + 64, &od));
     RET(c->tbuf("z_" + sd, (size_t)K * 24 * n, &z));
@@ -921,46 +954,21 @@ static int decompose_impl(lf_ctx *c, Transcript &tr, const u64 *lcccs, const std
         RET(build_eq_dev(c, rpt.data(), P.s, eq_r));
     }
     S.planes = wit->planes; S.z = z; S.eq_r = eq_r;
-
-    // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
-    size_t ph = c->ev_begin(11);
-    LF_TRACE(c, "dec start");
-    launch_bitplane_crt(c->dcrt, wit->planes, N, 1, K, Fh, c->stream());
-    LF_TRACE(c, "bitplane_crt");
-    RET(commit_dev(c, Fh, K - 1, yd, true));
-    LF_TRACE(c, "commit");
-    RET(down_small(c, yd, (size_t)(K - 1) * P.kappa * 24, y_s + (size_t)P.kappa * 24));
-    c->ev_end(ph);
-    {   // y_0 = cm - sum_{k>=1} b^k y_k, as the reference's fold (acc + y_i) * b
-        std::vector<u64> acc((size_t)P.kappa * 24, 0);
-        u64 bb[24];
-        HostRing::from_u64(P.b, bb);
-        for (int k = (int)K - 1; k >= 1; k--)
-            for (u32 i = 0; i < P.kappa; i++) {
-                HostRing::add(&acc[(size_t)i * 24], y_s + ((size_t)k * P.kappa + i) * 24, &acc[(size_t)i * 24]);
-                c->ring.mul_ntt(&acc[(size_t)i * 24], bb, &acc[(size_t)i * 24]);
-            }
-        for (u32 i = 0; i < P.kappa; i++) HostRing::sub(cm + (size_t)i * 24, &acc[(size_t)i * 24], y_s + (size_t)i * 24);
-    }
-    ph = c->ev_begin(12);
+    size_t ph = c->ev_begin(12);
     compute_x_s(c, xh, x_s);
-    LF_TRACE(c, "x_s");
     // v_s (decomposition.rs:204-211) from the coefficient planes
     launch_coef_eval(c->dcrt, wit->planes, N, eq_r, m, K, 1, partial, od, c->stream());
     RET(down_small(c, od, (size_t)K * 72, v_s));
-    LF_TRACE(c, "v_s");
     // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     RET(build_z(c, wit->planes, K, 1, x_s, z));
-    LF_TRACE(c, "build_z");
     for (u32 j = 0; j < P.t; j++)
         launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->stream());
     u64 *dpart;
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
     launch_dot_batch(c->dcrt, z, n, K, q, n, P.t, n, dpart, od, c->stream());
     RET(down_small(c, od, (size_t)K * P.t * 24, u_s));
-    LF_TRACE(c, "u_s");
+    LF_TRACE(c, "decompose evals");
     c->ev_end(ph);
-
     return LF_OK;
 }
 
@@ -1234,25 +1242,35 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     std::vector<u64> lin(ll * 24);
     u64 *eq_r_R = nullptr;
     SideState S[2];
-    // The left decomposition (acc, w_acc) needs nothing from the linearization -- only the transcript order is
-    // fixed -- so its GPU work runs on a second stream / host thread while the latency-bound linearization rounds go on.
-    std::future<int> fdl = std::async(std::launch::async, [&]() -> int {
+    // Schedule (transcript order is fixed, compute order is not):
+    //   lane 1 (helper thread, own stream): left decomposition (needs nothing from the linearization), then the RIGHT commit
+    //           (depends only on w_i and cm_i), and -- while that commit runs on the GPU -- the host absorbs of the left part;
+    //   lane 0 (this thread): linearization (latency-bound rounds), then the right evaluations at the new point.
+    std::promise<int> lin_done_p;
+    std::shared_future<int> lin_done = lin_done_p.get_future().share();
+    std::future<int> flane1 = std::async(std::launch::async, [&]() -> int {
         t_lane = 1;
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
-        return decompose_impl(c, tr, acc, rL, w_acc, "L", nullptr, S[0], decl);
+        u64 *yd = nullptr;
+        size_t ev = 0;
+        RET(decompose_commit_enqueue(c, w_acc, &yd, &ev));
+        RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));
+        RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+        RET(decompose_commit_enqueue(c, w_i, &yd, &ev));               // right commit in flight ...
+        if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
+        absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
+        return decompose_commit_finish(c, cm_i, yd, ev, decr);          // cm of the linearized instance = cm_i.cm
     });
     int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
-    int rcl = fdl.get();
-    if (rc == LF_OK) rc = rcl;
+    lin_done_p.set_value(rc);
     std::vector<Fq3> rR;
-    if (rc == LF_OK) lcccs_point(P, lin.data(), rR);
     if (rc == LF_OK) {
-        std::future<double> fl = std::async(std::launch::async, [&] { return absorb_decomposition(P, tr, acc, decl, S[0]); });
-        rc = decompose_impl(c, tr, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
-        double hidden = fl.get();
-        (void)hidden;  // overlapped with GPU work: not on the critical path
-        if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
+        lcccs_point(P, lin.data(), rR);
+        rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
     }
+    int rc1 = flane1.get();
+    if (rc == LF_OK) rc = rc1;
+    if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->ev_end(tot);
     c->ev_collect();
