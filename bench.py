@@ -156,8 +156,17 @@ def main():
         }
         dom = "k_ajtai" if aj_ms >= fr_ms else "k_fold_round(+round1)"
         peak = 8000.0
+        # HBM traffic of the dominant kernel from the PMC passes (collected separately, as rocprofv3 requires; see profiles/)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c4.json")))["kernels"]
+            if wl.name == "C4" and dom == "k_ajtai":
+                k = pmc["k_ajtai<true>"]
+                traffic = k["fetch_bytes_max_corrected"] + k["write_bytes_max"]
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": peak, "unit": "GB/s",
-                "frac": kernels[dom]["achieved_GBps"] / peak, "traffic": None,
+                "frac": kernels[dom]["achieved_GBps"] / peak, "traffic": traffic,
                 "note": "integer-ALU-bound path (64-bit modular multiply = 4 quarter-rate v_mad_u64_u32); whole-step algorithmic "
                         "rate = %.1f GB/s = %.3f of peak" % (alg * steps_per_s / world / 1e9, alg * steps_per_s / world / 1e9 / peak),
                 "kernels": kernels}
