@@ -431,3 +431,27 @@ class NIFSProver:
         _chk(_lib().lf_fold_step(ctx.h, transcript.h, pa, w_acc.h, pb, w_i.h, lc.ctypes.data_as(u64p), C.byref(h),
                                  pr.ctypes.data_as(u64p)), "lf_fold_step")
         return lc, Witness(ctx, h), pr
+
+
+class MLSumcheckLin:
+    """utils/sumcheck.rs:53-80 split at the transcript, for the linearization-shaped polynomial (lf_sumcheck_lin_*)."""
+
+    def __init__(self, ctx, tables, eq_point):
+        self.ctx = ctx
+        a, p = _a64(tables)
+        b, q = _a64(eq_point)
+        _chk(_lib().lf_sumcheck_lin_begin(ctx.h, p, q), "lf_sumcheck_lin_begin")
+
+    def prove_round(self, r_prev=None):
+        prm = self.ctx.params
+        o = np.zeros((prm.d + 2, RE), dtype=np.uint64)
+        if r_prev is None:
+            rc = _lib().lf_sumcheck_lin_round(self.ctx.h, None, o.ctypes.data_as(u64p))
+        else:
+            a, p = _a64(r_prev)
+            rc = _lib().lf_sumcheck_lin_round(self.ctx.h, p, o.ctypes.data_as(u64p))
+        _chk(rc, "lf_sumcheck_lin_round")
+        return o
+
+    def end(self):
+        _chk(_lib().lf_sumcheck_lin_end(self.ctx.h), "lf_sumcheck_lin_end")

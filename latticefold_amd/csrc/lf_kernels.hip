@@ -6,6 +6,8 @@
 // v_mad_u64_u32 per product, see lf_field.cuh).  Reference semantics each kernel replaces are cited inline.
 #include "lf_kernels.h"
 
+#include <stdlib.h>
+
 namespace lf {
 
 #define NUARG t.nu
@@ -399,8 +401,8 @@ struct Acc6 { AccP s[6]; };
 // Row stride = AJ_JT*48 + 16 bytes: rows of one 16-lane read group fall into distinct 16-byte slots (conflict-free).
 constexpr int AJ_T = 32;                          // columns per tile
 constexpr int AJ_ROWB = AJ_T * 48 + 16;           // bytes per row
-template <bool NU>
-__global__ void __launch_bounds__(AJ_THREADS, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
+template <bool NU, int NT>
+__global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
                                                          u64 *partial) {
     extern __shared__ __align__(16) unsigned char smem[];
     const u32 slot = blockIdx.y, split = blockIdx.x;
@@ -414,12 +416,12 @@ __global__ void __launch_bounds__(AJ_THREADS, 4) k_ajtai(DevCrt t, const u64 *A,
     for (int i = 0; i < 6; i++) accp_zero(acc.s[i]);
     const u32 o0 = threadIdx.x;
     const u32 i0 = o0 / batch, k0 = o0 % batch;
-    const bool active = o0 < nout;   // blockDim.x <= nout rounded: every launched lane is active unless nout < 64
+    const bool active = o0 < nout;
     const unsigned char *pa = smem + (size_t)(active ? i0 : 0) * AJ_ROWB;
     const unsigned char *pf = smem + (size_t)(active ? kappa + k0 : kappa) * AJ_ROWB;
     for (size_t jt = j0; jt < j1; jt += AJ_T) {
         __syncthreads();
-        for (u32 idx = threadIdx.x; idx < rows * AJ_T; idx += AJ_THREADS) {
+        for (u32 idx = threadIdx.x; idx < rows * AJ_T; idx += NT) {
             u32 jj = idx % AJ_T, r = idx / AJ_T;
             size_t j = jt + jj;
             u64 v0 = 0, v1 = 0, v2 = 0;
@@ -499,12 +501,19 @@ void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 
                   hipStream_t s) {
     u32 nout = kappa * batch;
     // full waves in the tiled kernel; a small remainder (< 32 outputs) is cheaper as plain dot products
-    // outputs beyond AJ_THREADS (only for kappa*batch > 448) go to the dot-product tail kernel
-    u32 nmain = nout < (u32)AJ_THREADS ? nout : (u32)AJ_THREADS;
-    u32 threads = AJ_THREADS;
+    // full waves in the tiled kernel when the remainder is small (it then goes to the dot-product tail kernel)
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("LF_AJTAI_TAIL"); mode = e ? atoi(e) : 0; }
+    bool use384 = mode == 1 && nout > 384 && nout - 384 < 32;
+    u32 nmain = use384 ? 384 : (nout < (u32)AJ_THREADS ? nout : (u32)AJ_THREADS);
     size_t shm = (size_t)(kappa + batch) * AJ_ROWB;
-    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true>), dim3(splits, 8), dim3(threads), shm, s, t, A, kappa, n, F, batch, splits, partial);
-    else hipLaunchKernelGGL((k_ajtai<false>), dim3(splits, 8), dim3(threads), shm, s, t, A, kappa, n, F, batch, splits, partial);
+    if (use384) {
+        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, batch, splits, partial);
+        else hipLaunchKernelGGL((k_ajtai<false, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, batch, splits, partial);
+    } else {
+        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
+        else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
+    }
     hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * nmain * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, nmain, out);
     if (nmain < nout) {
         u32 ntail = nout - nmain;

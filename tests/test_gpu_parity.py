@@ -214,3 +214,66 @@ def test_fold_step_parity(ctx, name, seed):
     lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, api.PoseidonTranscript())
     lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
     assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
+
+
+# ---- sumcheck through the ABI, split at the transcript -----------------------------------------------
+def test_sumcheck_lin_abi_matches_oracle_proof(ctx):
+    """drive lf_sumcheck_lin_{begin,round,end} with a Python-side replay of the Fiat-Shamir schedule (App. B) and
+    compare every round message with the oracle's LinearizationProof; also the state-machine errors."""
+    wl, inst, A, scheme = setup_case(ctx, "T10")
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    cm = lfo.ajtai_commit(A, wl.kappa, wl.N, lfo.crt(f_coeff))
+    cccs = np.concatenate([cm, wl.x_ccs])
+    lc_o, pr_o = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    # replay: beta challenges
+    tr = api.PoseidonTranscript()
+    label = int.from_bytes(b"beta_s", "big") % P
+    tr.absorb_slice(diag(label)[None, :])
+    beta = np.stack([tr.get_challenge() for _ in range(wl.s)])
+    z = wl.z()
+    tables = np.stack([ctx.mat_vec_mul(j, z) for j in range(wl.t)])
+    sc = api.MLSumcheckLin(ctx, tables, beta)
+    with pytest.raises(api.LfError) as e:
+        sc.prove_round(r_prev=np.zeros(3, dtype=np.uint64))      # "first round should be prover first"
+    assert e.value.code == -7
+    tr.absorb_slice(diag(wl.s)[None, :]); tr.absorb_slice(diag(wl.d + 1)[None, :])
+    npts = wl.d + 2
+    r = None
+    for rnd in range(wl.s):
+        msg = sc.prove_round(r)
+        assert (msg == pr_o[rnd * npts:(rnd + 1) * npts]).all(), rnd
+        tr.absorb_slice(msg)
+        r = tr.get_challenge()
+        ring_r = np.zeros(RE, dtype=np.uint64)
+        for k in range(8):
+            ring_r[3 * k:3 * k + 3] = r
+        tr.absorb_slice(ring_r[None, :])
+        assert (ring_r == lc_o[rnd]).all()
+    with pytest.raises(api.LfError):
+        sc.prove_round(r)                                          # "Prover is not active"
+    sc.end()
+
+
+def test_parameter_and_state_errors(ctx):
+    wl = make_workload("T8")
+    bad = make_workload("T8"); bad.b = 4
+    with pytest.raises(api.LfError) as e:
+        ctx.load_ccs(bad)
+    assert e.value.code == -3                                      # LF_ERR_UNSUPPORTED (b != 2)
+    bad = make_workload("T8"); bad.wit_len = 100; bad.w_ccs = bad.w_ccs[:100]
+    with pytest.raises(api.LfError) as e:
+        ctx.load_ccs(bad)                                          # N = 400 > m = 256: CSError::InvalidSizeBounds
+    assert e.value.code in (-6, -1)
+    ctx.load_ccs(wl)
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa + 1, n=wl.N, seed=1)   # kappa mismatch with the loaded CCS
+    acc = np.zeros((ctx.lcccs_len, RE), dtype=np.uint64)
+    cccs = np.zeros((ctx.cccs_len, RE), dtype=np.uint64)
+    with pytest.raises(api.LfError) as e:
+        api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+    assert e.value.code == -1
+    api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=1)
+    nondiag = acc.copy(); nondiag[0, 3] = 5                         # evaluation point that is not a diagonal challenge
+    with pytest.raises(api.LfError) as e:
+        api.NIFSProver.prove(ctx, nondiag, wit, cccs, wit, api.PoseidonTranscript())
+    assert e.value.code == -3
