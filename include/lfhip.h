@@ -86,6 +86,12 @@ int lf_ajtai_generate(lf_ctx *, uint64_t seed, size_t kappa, size_t n);
 /* out[b*kappa + i] = sum_j A[i][j] (.) f[b*n + j];  n != width -> LF_ERR_INVALID (WrongWitnessLength) */
 int lf_ajtai_commit(lf_ctx *, const uint64_t *f, size_t n, size_t batch, uint64_t *out);
 
+/* Multi-GPU: a rank that holds only a COLUMN SLICE of A (lf_ajtai_load / lf_ajtai_generate on that slice)
+ * gets the partial commitment of its slice from lf_ajtai_commit; partial commitments are exchanged with one all-gather
+ * and added with lf_modsum (canonical residues; plain ncclSum would wrap mod 2^64, not mod p).
+ * parts = nparts x words canonical words, out = words. */
+int lf_modsum(const uint64_t *parts, size_t nparts, size_t words, uint64_t *out);
+
 /* ---- a8/a9/a11: eq table and batched MLE evaluation (sumcheck/utils.rs:100-170, mle_helpers.rs:65-88) */
 /* point = nv challenges in F_{p^3} (3 words each): the reference's points are always diagonal embeddings
  * of transcript challenges (linearization/utils.rs:119-122, folding/utils.rs:59-92). */

@@ -67,6 +67,7 @@ def _lib():
         L.lf_ajtai_load.argtypes = [vp, u64p, C.c_size_t, C.c_size_t]
         L.lf_ajtai_generate.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t]
         L.lf_ajtai_commit.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p]
+        L.lf_modsum.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
         L.lf_build_eq.argtypes = [vp, u64p, C.c_uint, u64p]
         L.lf_mle_eval_batch.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p, C.c_uint, u64p]
         L.lf_ccs_load.argtypes = [vp, C.POINTER(Params), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u64p), u32p, u32p, u64p]

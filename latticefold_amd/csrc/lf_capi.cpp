@@ -455,6 +455,23 @@ int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64
     return down_small(c, o, batch * c->kappa * 24, out);
 }
 
+// column-sharded commit: the context holds only columns [col0, col0+n_local) of A (loaded with lf_ajtai_load on
+// that slice); f is the matching slice of each witness.  The result is the PARTIAL commitment of this shard; the caller
+// exchanges partials (all-gather) and adds them mod p -- lf_modsum -- because RCCL has no modular reduction.
+int lf_modsum(const uint64_t *parts, size_t nparts, size_t words, uint64_t *out) {
+    if (!parts || !out || !nparts) return LF_ERR_INVALID;
+    for (size_t w = 0; w < words; w++) {
+        u64 acc = 0;
+        for (size_t g = 0; g < nparts; g++) {
+            u64 v = parts[g * words + w];
+            if (v >= LF_P) return LF_ERR_INVALID;
+            acc = fq_add(acc, v);
+        }
+        out[w] = acc;
+    }
+    return LF_OK;
+}
+
 // ---- a8/a9/a11 ------------------------------------------------------------------------------------------------------
 static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {
     Fq3Const *rd;

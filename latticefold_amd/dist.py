@@ -1,0 +1,43 @@
+"""Multi-GPU exchange for the column-sharded Ajtai commitment (BASELINE configs[3]).
+
+Each rank holds A[:, shard] and the matching slice of every witness; `sharded_commit` computes the partial commitment on the
+rank's GPU, exchanges the partials with ONE all-gather (RCCL over xGMI with backend "nccl"; "gloo" in the CPU tests) and adds
+them mod p locally -- RCCL has no modular reduction and ncclSum on canonical u64 residues would wrap mod 2^64.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+
+def column_shard(n, rank, world):
+    """contiguous column range of rank (high index bits: keeps sumcheck pairs (2j,2j+1) local)"""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def allgather_modsum(partial, group=None):
+    """partial: uint64 array of canonical residues (any shape) -> elementwise sum over ranks mod p."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    flat = np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1)
+    t = torch.from_numpy(flat.view(np.int64).copy())            # bit pattern; torch has no uint64 collectives
+    if backend == "nccl":
+        t = t.cuda()
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    stacked = torch.stack(parts).cpu().numpy().view(np.uint64)
+    out = np.zeros_like(flat)
+    rc = api._lib().lf_modsum(stacked.ctypes.data_as(api.u64p), world, flat.size, out.ctypes.data_as(api.u64p))
+    if rc != 0:
+        raise api.LfError(rc, "lf_modsum")
+    return out.reshape(np.shape(partial))
+
+
+def sharded_commit(scheme_shard, f_shard, group=None):
+    """scheme_shard: api.AjtaiCommitmentScheme over this rank's column slice; f_shard: (n_local,24) or (batch,n_local,24)."""
+    return allgather_modsum(scheme_shard.commit_ntt(f_shard), group)
