@@ -57,6 +57,7 @@ void lf_ctx_destroy(lf_ctx *);
 int lf_set_ring_tables(lf_ctx *, uint64_t nonres, const uint64_t *y);
 int lf_get_ring_tables(lf_ctx *, uint64_t *nonres, uint64_t *y);
 int lf_device_synchronize(lf_ctx *);
+int lf_mem_info(lf_ctx *, size_t *free_bytes, size_t *total_bytes); /* hipMemGetInfo of the context's device */
 /* device arithmetic self-test: fast F_{p^3} product / lazy accumulators vs the generic schoolbook path on n pseudo-random
  * and edge operand sets; *mismatches must come back 0 */
 int lf_selftest_field(lf_ctx *, uint64_t seed, uint32_t n, uint64_t *mismatches);

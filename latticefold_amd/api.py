@@ -58,6 +58,7 @@ def _lib():
         L.lf_set_ring_tables.argtypes = [vp, C.c_uint64, u64p]
         L.lf_get_ring_tables.argtypes = [vp, u64p, u64p]
         L.lf_device_synchronize.argtypes = [vp]
+        L.lf_mem_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.lf_selftest_field.argtypes = [vp, C.c_uint64, C.c_uint32, u64p]
         L.lf_ntt_fwd.argtypes = [vp, u64p, u64p, C.c_size_t]
         L.lf_ntt_inv.argtypes = [vp, u64p, u64p, C.c_size_t]
@@ -166,6 +167,11 @@ class Context:
         m = C.c_uint64(1)
         _chk(_lib().lf_selftest_field(self.h, seed, n, C.cast(C.byref(m), u64p)), "lf_selftest_field")
         return m.value
+
+    def mem_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        _chk(_lib().lf_mem_info(self.h, C.byref(f), C.byref(t)), "lf_mem_info")
+        return f.value, t.value
 
     def synchronize(self):
         _chk(_lib().lf_device_synchronize(self.h), "lf_device_synchronize")

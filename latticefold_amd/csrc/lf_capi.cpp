@@ -267,6 +267,12 @@ int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
         for (int q = 0; q < 3; q++) y[3 * k + q] = c->ring.T.y[k].c[q];
     return LF_OK;
 }
+int lf_mem_info(lf_ctx *c, size_t *free_bytes, size_t *total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
+    return LF_OK;
+}
 int lf_device_synchronize(lf_ctx *c) {
     if (!c) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));

@@ -13,7 +13,7 @@ from latticefold_amd.workload import P, RE, make_workload
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["C1", "T14", "C2"])
+@pytest.mark.parametrize("name", ["C1", "T14", "C2", "C4"])
 def test_fold_step_properties_at_scale(name):
     wl = make_workload(name)
     ctx = api.Context(0)
@@ -38,5 +38,43 @@ def test_fold_step_properties_at_scale(name):
         # (4) deterministic
         lc2, w02, proof2 = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
         assert (proof2 == proof).all()
+    finally:
+        ctx.close()
+
+
+def test_repeated_steps_are_stable_and_chain():
+    """20 chained fold steps at C1 (IVC style: the folded accumulator/witness feed the next step): every step verifies,
+    the witness norm stays below B/2, device memory does not grow (handles freed), results are reproducible."""
+    wl = make_workload("C1")
+    ctx = api.Context(0)
+    try:
+        ctx.load_ccs(wl)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        inst = lfo.Instance(wl)
+
+        def chain(steps):
+            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+            w = wit
+            digests = []
+            for i in range(steps):
+                lc, w_next, proof = api.NIFSProver.prove(ctx, acc, w, cccs, wit, api.PoseidonTranscript())
+                rc, lc_v = inst.verify(lfo.Transcript(), acc, cccs, proof)
+                assert rc == 0 and (lc_v == lc).all(), i
+                ok, mx = ctx.linf_check(w_next.f, wl.B // 2)
+                assert ok, (i, mx)
+                digests.append(int(proof[-1, 0]) ^ int(lc[wl.s, 0]))
+                if w is not wit:
+                    w.free()
+                acc, w = lc, w_next
+            return digests
+
+        d1 = chain(20)
+        free1 = ctx.mem_info()[0]
+        d2 = chain(20)
+        free2 = ctx.mem_info()[0]
+        assert d1 == d2
+        assert abs(free1 - free2) < 64 << 20      # no growth beyond allocator noise
     finally:
         ctx.close()
