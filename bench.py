@@ -91,12 +91,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (there is no CPU fallback)", file=sys.stderr)
         sys.exit(3)
+    # test hooks (single-GPU boxes): LF_FORCE_DEVICE pins every rank to one GPU, LF_DIST_BACKEND=gloo replaces RCCL
+    if "LF_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["LF_FORCE_DEVICE"])
+    backend = os.environ.get("LF_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     # ---- setup (untimed): everything resident in HBM --------------------------------------------------------
     wl = make_workload(args.workload, seed=rank)
@@ -117,7 +124,10 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -132,7 +142,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -196,7 +206,10 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 
