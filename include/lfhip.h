@@ -92,6 +92,14 @@ int lf_ajtai_commit(lf_ctx *, const uint64_t *f, size_t n, size_t batch, uint64_
  * and added with lf_modsum (canonical residues; plain ncclSum would wrap mod 2^64, not mod p).
  * parts = nparts x words canonical words, out = words. */
 int lf_modsum(const uint64_t *parts, size_t nparts, size_t words, uint64_t *out);
+/* Intra-step sharding of one fold step over `world` (power of two) ranks, one GPU each.  Must be set before the Ajtai matrix is
+ * loaded/generated: each rank then keeps columns [rank*n/world, (rank+1)*n/world) of A.  Witnesses, CCS and all O(n) vectors are
+ * replicated; sharded are the Ajtai commitments (partial commitments all-gathered + added mod p) and the folding-sumcheck rounds
+ * (index slice by the high bits; partial round messages all-gathered + added; f-hat slices gathered once < 64 pairs per rank remain).
+ * Every rank runs the identical transcript and returns the identical proof.  `cb` must all-gather `words` u64 from every rank
+ * into recv_all[world*words] in rank order and return 0 (RCCL/xGMI via torch.distributed in latticefold_amd/dist.py). */
+typedef int (*lf_exchange_fn)(void *user, const uint64_t *send, uint64_t *recv_all, size_t words);
+int lf_set_sharding(lf_ctx *, int rank, int world, lf_exchange_fn cb, void *user);
 
 /* ---- a8/a9/a11: eq table and batched MLE evaluation (sumcheck/utils.rs:100-170, mle_helpers.rs:65-88) */
 /* point = nv challenges in F_{p^3} (3 words each): the reference's points are always diagonal embeddings

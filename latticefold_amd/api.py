@@ -21,6 +21,9 @@ u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, u64p, C.c_size_t)   # lf_exchange_fn
+
+
 class LfError(RuntimeError):
     def __init__(self, code, where=""):
         self.code = code
@@ -69,6 +72,7 @@ def _lib():
         L.lf_ajtai_generate.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t]
         L.lf_ajtai_commit.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p]
         L.lf_modsum.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
+        L.lf_set_sharding.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
         L.lf_build_eq.argtypes = [vp, u64p, C.c_uint, u64p]
         L.lf_mle_eval_batch.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p, C.c_uint, u64p]
         L.lf_ccs_load.argtypes = [vp, C.POINTER(Params), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u64p), u32p, u32p, u64p]
@@ -167,6 +171,23 @@ class Context:
         m = C.c_uint64(1)
         _chk(_lib().lf_selftest_field(self.h, seed, n, C.cast(C.byref(m), u64p)), "lf_selftest_field")
         return m.value
+
+    def set_sharding(self, rank, world, allgather):
+        """Intra-step sharding (lf_set_sharding); call before creating the AjtaiCommitmentScheme.
+        allgather(np.uint64[words]) -> np.uint64[world, words] in rank order (see latticefold_amd.dist.make_allgather)."""
+        def _cb(user, send, recv, words):
+            try:
+                mine = np.ctypeslib.as_array(send, shape=(words,)).copy()
+                out = np.ascontiguousarray(allgather(mine), dtype=np.uint64).reshape(world * words)
+                C.memmove(recv, out.ctypes.data, world * words * 8)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                import sys
+                print("lf exchange callback failed:", repr(e), file=sys.stderr)
+                return -1
+        self._exchange_cb = EXCHANGE_FN(_cb) if world > 1 else EXCHANGE_FN(0)
+        _chk(_lib().lf_set_sharding(self.h, rank, world, self._exchange_cb, None), "lf_set_sharding")
+        self.shard = (rank, world)
 
     def mem_info(self):
         f, t = C.c_size_t(), C.c_size_t()

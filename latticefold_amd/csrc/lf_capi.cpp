@@ -92,10 +92,14 @@ struct lf_ctx {
     HostRing ring;
     DevCrt dcrt;
     u64 *d_icrt = nullptr;
-    // Ajtai
+    // Ajtai (nA = columns held by this rank, starting at global column A_col0 of nA_total)
     u64 *dA = nullptr;
     u32 kappa = 0;
-    size_t nA = 0;
+    size_t nA = 0, nA_total = 0, A_col0 = 0;
+    // intra-step sharding: rank/world and the all-gather callback supplied by the host language
+    int sh_rank = 0, sh_world = 1;
+    lf_exchange_fn sh_cb = nullptr;
+    void *sh_user = nullptr;
     // CCS
     bool have_ccs = false;
     lf_params P{};
@@ -267,6 +271,20 @@ int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
         for (int q = 0; q < 3; q++) y[3 * k + q] = c->ring.T.y[k].c[q];
     return LF_OK;
 }
+int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *user) {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->dA) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
+    c->sh_rank = rank; c->sh_world = world; c->sh_cb = cb; c->sh_user = user;
+    return LF_OK;
+}
+// all-gather `words` canonical words from every rank and add them mod p (RCCL has no modular reduction)
+static int exchange_modsum(lf_ctx *c, u64 *inout, size_t words) {
+    if (c->sh_world <= 1) return LF_OK;
+    std::vector<u64> all((size_t)c->sh_world * words);
+    if (c->sh_cb(c->sh_user, inout, all.data(), words) != 0) return LF_ERR_HIP;
+    return lf_modsum(all.data(), (size_t)c->sh_world, words, inout);
+}
 int lf_mem_info(lf_ctx *c, size_t *free_bytes, size_t *total_bytes) {
     if (!c || !free_bytes || !total_bytes) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
@@ -400,28 +418,38 @@ int lf_linf_check(lf_ctx *c, const uint64_t *f_ntt, size_t count, uint64_t bound
 }
 
 // ---- a5 -----------------------------------------------------------------------------------------------------------
+static int shard_columns(lf_ctx *c, size_t n, size_t *col0, size_t *cnt) {
+    if (n % (size_t)c->sh_world) return LF_ERR_UNSUPPORTED;
+    *cnt = n / c->sh_world;
+    *col0 = *cnt * c->sh_rank;
+    return LF_OK;
+}
 int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
     if (!c || !A || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    size_t col0, cnt;
+    RET(shard_columns(c, n, &col0, &cnt));   // a sharded rank keeps only its column slice of the caller's matrix
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * 24 * 8));
-    for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + i * n * 24, n, c->dA + i * 24 * n));
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * 24 * 8));
+    for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + (i * n + col0) * 24, cnt, c->dA + i * 24 * cnt));
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
-    c->nA = n;
+    c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
     return LF_OK;
 }
 int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
     if (!c || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    size_t col0, cnt;
+    RET(shard_columns(c, n, &col0, &cnt));
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * 24 * 8));
-    launch_fill_ajtai(c->dA, (u32)kappa, n, seed, c->stream());
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * 24 * 8));
+    launch_fill_ajtai(c->dA, (u32)kappa, cnt, n, col0, seed, c->stream());
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
-    c->nA = n;
+    c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
     return LF_OK;
 }
 static u32 ajtai_splits(size_t n) {
@@ -431,8 +459,8 @@ static u32 ajtai_splits(size_t n) {
     if (s > 128) s = 128;
     return (u32)s;
 }
-// F: [batch][24][n] device; out_dev: [batch][kappa][24] device AoS
-static int commit_dev(lf_ctx *c, const u64 *F, u32 batch, u64 *out_dev, bool timed) {
+// F: [batch][24][ldF] device, pointing at this rank's first column; out_dev: [batch][kappa][24] device AoS (PARTIAL when sharded)
+static int commit_dev(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
     u32 maxb = 448 / c->kappa;
     if (maxb > 64 - c->kappa) maxb = 64 - c->kappa;
     if (maxb < 1) return LF_ERR_UNSUPPORTED;
@@ -442,23 +470,28 @@ static int commit_dev(lf_ctx *c, const u64 *F, u32 batch, u64 *out_dev, bool tim
     for (u32 b0 = 0; b0 < batch; b0 += maxb) {
         u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
         size_t ev = timed ? c->ev_begin(1) : 0;
-        launch_ajtai(c->dcrt, c->dA, c->kappa, c->nA, F + (size_t)b0 * 24 * c->nA, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * 24, c->stream());
+        launch_ajtai(c->dcrt, c->dA, c->kappa, c->nA, F + (size_t)b0 * 24 * ldF, ldF, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * 24, c->stream());
         if (timed) c->ev_end(ev);
     }
     return LF_OK;
+}
+// download a (partial) commitment and, when sharded, all-gather + add the partials mod p
+static int commit_download(lf_ctx *c, const u64 *dev, size_t words, u64 *host) {
+    RET(down_small(c, dev, words, host));
+    return exchange_modsum(c, host, words);
 }
 int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
     if (!c || !f || !out || !batch) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->dA) return LF_ERR_STATE;
-    if (n != c->nA) return LF_ERR_INVALID;  // CommitmentError::WrongWitnessLength(n, width)
+    if (n != c->nA_total) return LF_ERR_INVALID;  // CommitmentError::WrongWitnessLength(n, width)
     HIPCHK(hipSetDevice(c->device));
     u64 *F, *o;
     RET(c->tbuf("io_a", batch * n * 24, &F));
     RET(c->tbuf("io_b", batch * c->kappa * 24, &o));
     for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * 24, n, F + b * 24 * n));
-    RET(commit_dev(c, F, (u32)batch, o, false));
-    return down_small(c, o, batch * c->kappa * 24, out);
+    RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, false));
+    return commit_download(c, o, batch * c->kappa * 24, out);
 }
 
 // column-sharded commit: the context holds only columns [col0, col0+n_local) of A (loaded with lf_ajtai_load on
@@ -713,7 +746,7 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     if (!c || !w || !cm_out || w->ctx != c) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->dA) return LF_ERR_STATE;
-    if (w->N != c->nA) return LF_ERR_INVALID;
+    if (w->N != c->nA_total) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
     u64 *d, *e, *o;
     RET(c->tbuf("io_c", w->N * 24, &d));
@@ -721,8 +754,8 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     RET(c->tbuf("io_o", (size_t)c->kappa * 24, &o));
     launch_i32_to_coef(w->planes, d, w->N, c->stream());
     launch_crt_fwd(c->dcrt, d, e, w->N, c->stream());
-    RET(commit_dev(c, e, 1, o, false));
-    return down_small(c, o, (size_t)c->kappa * 24, cm_out);
+    RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));
+    return commit_download(c, o, (size_t)c->kappa * 24, cm_out);
 }
 void lf_witness_free(lf_witness *w) {
     if (!w) return;
@@ -930,11 +963,12 @@ static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_o
     size_t N = c->N;
     u32 K = P.K;
     u64 *Fh, *yd;
-    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * N, &Fh));
+    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * c->nA, &Fh));
     RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &yd));
     size_t ph = c->ev_begin(11);
-    launch_bitplane_crt(c->dcrt, wit->planes, N, 1, K, Fh, c->stream());
-    RET(commit_dev(c, Fh, K - 1, yd, true));
+    // bit-plane NTTs of this rank's column slice only (all columns when not sharded)
+    launch_bitplane_crt(c->dcrt, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());
+    RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
     *yd_out = yd;
     *ev_out = ph;
     return LF_OK;
@@ -943,7 +977,7 @@ static int decompose_commit_finish(lf_ctx *c, const u64 *cm, u64 *yd, size_t ev,
     const lf_params &P = c->P;
     u32 K = P.K;
     u64 *y_s = proof + (size_t)K * P.t * 24 + (size_t)K * 72 + (size_t)K * (P.l + 1) * 24;
-    RET(down_small(c, yd, (size_t)(K - 1) * P.kappa * 24, y_s + (size_t)P.kappa * 24));
+    RET(commit_download(c, yd, (size_t)(K - 1) * P.kappa * 24, y_s + (size_t)P.kappa * 24));
     c->ev_end(ev);
     // y_0 = cm - sum_{k>=1} b^k y_k, as the reference's fold (acc + y_i) * b
     std::vector<u64> acc((size_t)P.kappa * 24, 0);
@@ -1093,9 +1127,15 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("fold_T1", 57 * (half / 2 ? half / 2 : 1), &T5[1]));
     FoldRoundArgs a;
     a.eqL = S[0].eq_r; a.eqR = S[1].eq_r; a.eqB = eqb; a.G1 = G[0]; a.G2 = G[1]; a.ld = m; a.n = m;
+    a.p0 = 0; a.pcnt = m / 2; a.pF0 = 0;
     const u64 *curF = nullptr;
     size_t ldF = 0;
     int flip = 0;
+    // Sharded rounds: rank g evaluates the pairs of its index slice (high bits: pairs (2j,2j+1) stay local, the
+    // f-hat tables exist only for that slice), the (D+1)-element partial messages are all-gathered and added mod p, every rank
+    // runs the same transcript.  Once fewer than 64 pairs per rank remain the f-hat slices are gathered and the tail is replicated.
+    const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
+    bool sharded = Gw > 1;
     for (u32 round = 1; round <= P.s; round++) {
         if (round > 1) {
             Fq3Const r = f3c(pt[round - 2]);
@@ -1106,21 +1146,52 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->stream());
             launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->stream());
             launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->stream());
+            if (sharded && nn / 2 < Gw * 64) {
+                // transition to the replicated tail: gather the fixed f-hat slices (if they exist yet)
+                if (round > 3) {
+                    u64 *fd = F[(round & 1) ? 0 : 1];
+                    size_t lcl = ldF / 2;  // local entries after this fix
+                    launch_fix_many(c->dcrt, curF, ldF, fd, lcl, ldF, K2 * 3 * 8, r, c->stream());
+                    size_t planes = (size_t)K2 * 3 * 24, words = planes * lcl;
+                    std::vector<u64> mine(words), all(words * Gw), full(planes * nn);
+                    HIPCHK(hipMemcpyAsync(mine.data(), fd, words * 8, hipMemcpyDeviceToHost, c->stream()));
+                    HIPCHK(hipStreamSynchronize(c->stream()));
+                    if (c->sh_cb(c->sh_user, mine.data(), all.data(), words) != 0) return LF_ERR_HIP;
+                    for (size_t rk = 0; rk < Gw; rk++)
+                        for (size_t w = 0; w < planes; w++)
+                            memcpy(&full[w * nn + rk * lcl], &all[rk * words + w * lcl], lcl * 8);
+                    u64 *fo = fd;  // same parity as an ordinary fix output, so the ping-pong of the following rounds stays valid
+                    HIPCHK(hipMemcpyAsync(fo, full.data(), full.size() * 8, hipMemcpyHostToDevice, c->stream()));
+                    HIPCHK(hipStreamSynchronize(c->stream()));
+                    curF = fo; ldF = nn;
+                    sharded = false;
+                    a.eqL = dst; a.eqR = dst + 3 * nn; a.eqB = dst + 6 * nn; a.G1 = dst + 9 * nn; a.G2 = dst + 33 * nn;
+                    a.ld = nn; a.n = nn; a.p0 = 0; a.pcnt = nn / 2; a.pF0 = 0;
+                    flip ^= 1;
+                    goto tables_ready;
+                }
+                sharded = false;
+            }
             if (round == 3) {
                 // W_b = eq((r1, r2), b), b = b0 + 2 b1 (LSB-first)
                 Fq3 r1 = pt[0], r2 = pt[1], o1 = fq3_sub(fq3_one(), r1), o2 = fq3_sub(fq3_one(), r2);
                 Fq3Const W[4] = {f3c(c->ring.mul3(o1, o2)), f3c(c->ring.mul3(r1, o2)), f3c(c->ring.mul3(o1, r2)), f3c(c->ring.mul3(r1, r2))};
-                launch_fold_materialize2(c->dcrt, S[0].planes, S[1].planes, N, m, K, W, F[0], c->stream());
-                curF = F[0]; ldF = nn;
+                size_t q = sharded ? nn / Gw : nn, j0 = sharded ? gr * q : 0;   // this rank's slice of the m/4 entries
+                launch_fold_materialize2(c->dcrt, S[0].planes, S[1].planes, N, j0, q, K, W, F[0], c->stream());
+                curF = F[0]; ldF = q;
             } else if (round > 3) {
                 u64 *fd = F[(round & 1) ? 0 : 1];  // round 4 -> F[1], round 5 -> F[0], ...
-                launch_fix_many(c->dcrt, curF, ldF, fd, nn, a.n, K2 * 3 * 8, r, c->stream());
-                curF = fd; ldF = nn;
+                launch_fix_many(c->dcrt, curF, ldF, fd, ldF / 2, ldF, K2 * 3 * 8, r, c->stream());
+                curF = fd; ldF = ldF / 2;
             }
             a.eqL = dst; a.eqR = dst + 3 * nn; a.eqB = dst + 6 * nn; a.G1 = dst + 9 * nn; a.G2 = dst + 33 * nn;
             a.ld = nn; a.n = nn;
             flip ^= 1;
         }
+        if (sharded && a.n / 2 < Gw * 64) sharded = false;   // (round 1 of a tiny instance)
+        if (sharded) { a.pcnt = a.n / 2 / Gw; a.p0 = gr * a.pcnt; a.pF0 = a.p0; }
+        else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
+    tables_ready:
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->stream());
@@ -1129,6 +1200,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         LF_TRACE(c, "fold round");
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * 24;
         RET(down_small(c, od, (size_t)(deg + 1) * 24, evs));
+        if (sharded) RET(exchange_modsum(c, evs, (size_t)(deg + 1) * 24));
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
     }
@@ -1245,7 +1317,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
     const lf_params &P = c->P;
-    if (c->kappa != P.kappa || c->nA != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
+    if (c->kappa != P.kappa || c->nA_total != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
     std::vector<Fq3> rL;
     if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;  // evaluation points are always diagonal challenges

@@ -28,7 +28,8 @@ void launch_aos_to_soa(const u64 *aos, u64 *soa, size_t n, hipStream_t s);   // 
 void launch_soa_to_aos(const u64 *soa, u64 *aos, size_t n, hipStream_t s);
 void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStream_t s);  // SplitMix64 stream (workload.py)
 // Ajtai matrix generated in place in plane layout, equal to AoS stream splitmix(seed)[((i*n+j)*24+w)]
-void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, u64 seed, hipStream_t s);
+// columns [col0, col0+n) of the n_total-column matrix
+void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s);
 
 void launch_selftest_field(u64 seed, u32 n, u64 *mism_dev, hipStream_t s);  // arithmetic self-test, see lf_kernels.hip
 
@@ -45,7 +46,7 @@ void launch_recompose(const u64 *in, size_t n_out, u64 base, u32 digits, u64 *ou
 void launch_coef_to_i32(const u64 *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s);
 void launch_i32_to_coef(const int32_t *planes, u64 *coef, size_t n, hipStream_t s);
 // NTT of bit-plane k (k0 <= k < k1) of every element: out[(k-k0)][24][n]
-void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s);
+void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s);
 // z-vector tails: out_k[off + i] = CRT( sum_l B^l * digit_k(planes[i*L + l]) ) for k < K (mode_bits = 1), or the
 // full value (mode_bits = 0, K = 1).  out_k = out + k*24*ldz.
 void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K,
@@ -56,7 +57,7 @@ void launch_linf(const u64 *coef, size_t n, u64 *out_max, hipStream_t s);
 // ---- Ajtai commit (a5) -----------------------------------------------------------------------------------------
 // partial[split][slot][i][k][3]; then reduce -> out AoS-ish [k][i][24] (device), canonical
 size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits);
-void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
+void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits,
                   u64 *partial, u64 *out, hipStream_t s);
 
 // ---- MLE / eq (a8, a9, a11) --------------------------------------------------------------------------------------
@@ -109,6 +110,8 @@ struct FoldRoundArgs {
     const u64 *G1, *G2;          // ring tables [24][ld]
     size_t ld;                   // leading dimension of the tables above
     size_t n;                    // current table length
+    size_t p0, pcnt;             // pair range handled by this launch (all pairs: 0, n/2; a rank's slice when sharded)
+    size_t pF0;                  // first pair held by the materialised f-hat buffer
 };
 // round 1 of the folding sumcheck straight from the coefficient planes (f-hat virtual, b = 2)
 void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
@@ -120,7 +123,7 @@ void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int3
 void launch_fold_round2(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const Fq3Const *mu_pow_dev, Fq3Const r1, u64 *partial, u64 *out, hipStream_t s);
 // after r_2: F[2K*3][24][m/4] = sum_b W_b * digit(f[4j+b]), W = eq((r1,r2), b)
-void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t j0, size_t q, u32 K,
                               const Fq3Const W[4], u64 *F, hipStream_t s);
 // general round on materialised tables F [2K*3][24][ldF] (b = 2)
 void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev,

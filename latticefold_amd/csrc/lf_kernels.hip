@@ -120,16 +120,16 @@ __global__ void __launch_bounds__(256) k_fill_uniform(u64 *dst, size_t words, u6
 void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_uniform, dim3(grid_for(words, 4096)), dim3(256), 0, s, dst, words, seed, start);
 }
-__global__ void __launch_bounds__(256) k_fill_ajtai(u64 *A, u32 kappa, size_t n, u64 seed) {
+__global__ void __launch_bounds__(256) k_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed) {
     size_t total = (size_t)kappa * 24 * n;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
     for (; i < total; i += st) {
         size_t j = i % n, w = (i / n) % 24, row = i / (24 * n);
-        A[i] = splitmix_fq(seed, (row * n + j) * 24 + w);
+        A[i] = splitmix_fq(seed, (row * n_total + col0 + j) * 24 + w);
     }
 }
-void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, u64 seed, hipStream_t s) {
-    hipLaunchKernelGGL(k_fill_ajtai, dim3(4096), dim3(256), 0, s, A, kappa, n, seed);
+void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_ajtai, dim3(4096), dim3(256), 0, s, A, kappa, n, n_total, col0, seed);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -303,12 +303,12 @@ __device__ __forceinline__ int digit2(int32_t v, u32 k) {
 }
 __device__ __forceinline__ u64 fq_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? 1 : LF_P - 1); }
 
-__global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *planes, size_t n, u32 k0, u32 k1, u64 *out) {
+__global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out) {
     size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     int32_t v[24];
 #pragma unroll
-    for (int c = 0; c < 24; c++) v[c] = planes[(size_t)c * n + j];
+    for (int c = 0; c < 24; c++) v[c] = planes[(size_t)c * ld + j];
     for (u32 k = k0; k < k1; k++) {
         u64 a[24];
 #pragma unroll
@@ -316,8 +316,8 @@ __global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *p
         crt_store(a, out + (size_t)(k - k0) * 24 * n, n, j, t);
     }
 }
-void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s) {
-    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256)), dim3(256), 0, s, t, planes, n, k0, k1, out);
+void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s) {
+    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256)), dim3(256), 0, s, t, planes, ld, n, k0, k1, out);
 }
 
 struct BPow { u64 v[8]; };
@@ -402,7 +402,7 @@ struct Acc6 { AccP s[6]; };
 constexpr int AJ_T = 32;                          // columns per tile
 constexpr int AJ_ROWB = AJ_T * 48 + 16;           // bytes per row
 template <bool NU, int NT>
-__global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits,
+__global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits,
                                                          u64 *partial) {
     extern __shared__ __align__(16) unsigned char smem[];
     const u32 slot = blockIdx.y, split = blockIdx.x;
@@ -426,8 +426,10 @@ __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kap
             size_t j = jt + jj;
             u64 v0 = 0, v1 = 0, v2 = 0;
             if (j < j1) {
-                const u64 *src = r < kappa ? A + ((size_t)r * 24 + 3 * slot) * n : F + ((size_t)(r - kappa) * 24 + 3 * slot) * n;
-                v0 = src[j]; v1 = src[n + j]; v2 = src[2 * n + j];
+                const bool isA = r < kappa;
+                const size_t ldr = isA ? n : ldF;
+                const u64 *src = isA ? A + ((size_t)r * 24 + 3 * slot) * n : F + ((size_t)(r - kappa) * 24 + 3 * slot) * ldF;
+                v0 = src[j]; v1 = src[ldr + j]; v2 = src[2 * ldr + j];
             }
             ulonglong2 *dstp = (ulonglong2 *)(smem + (size_t)r * AJ_ROWB + jj * 48);
             dstp[0] = make_ulonglong2(v0, v1);
@@ -470,14 +472,14 @@ __global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, u32 ka
 }
 // the nout - nmain outputs that do not fill a wave: plain lazy dot products over j, one (output, slot) per block column
 template <bool NU>
-__global__ void __launch_bounds__(256) k_ajtai_tail(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 o_start, u64 *partial) {
+__global__ void __launch_bounds__(256) k_ajtai_tail(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 o_start, u64 *partial) {
     u32 slot = blockIdx.y, o = o_start + blockIdx.z;
     u32 i = o / batch, k = o % batch;
-    const u64 *Ai = A + (size_t)i * 24 * n, *Fk = F + (size_t)k * 24 * n;
+    const u64 *Ai = A + (size_t)i * 24 * n, *Fk = F + (size_t)k * 24 * ldF;
     Acc5 acc;
     acc5_zero(acc);
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
-        Fq3 x = ld3(Ai, n, slot, j), y = ld3(Fk, n, slot, j);
+        Fq3 x = ld3(Ai, n, slot, j), y = ld3(Fk, ldF, slot, j);
         acc5_mac(acc, x.c, y.c);
     }
     Fq3 r = acc5_finish<NU>(acc, t.nu);
@@ -497,7 +499,7 @@ size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) {
     size_t a = (size_t)splits * 8 * kappa * batch * 3, b = (size_t)RED_BLOCKS_AJ * 64 * 24;
     return a + b;
 }
-void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, u32 batch, u32 splits, u64 *partial, u64 *out,
+void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits, u64 *partial, u64 *out,
                   hipStream_t s) {
     u32 nout = kappa * batch;
     // full waves in the tiled kernel; a small remainder (< 32 outputs) is cheaper as plain dot products
@@ -508,11 +510,11 @@ void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 
     u32 nmain = use384 ? 384 : (nout < (u32)AJ_THREADS ? nout : (u32)AJ_THREADS);
     size_t shm = (size_t)(kappa + batch) * AJ_ROWB;
     if (use384) {
-        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, batch, splits, partial);
-        else hipLaunchKernelGGL((k_ajtai<false, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, batch, splits, partial);
+        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
+        else hipLaunchKernelGGL((k_ajtai<false, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
     } else {
-        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
-        else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, batch, splits, partial);
+        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
+        else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
     }
     hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * nmain * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, nmain, out);
     if (nmain < nout) {
@@ -520,7 +522,7 @@ void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 
         u64 *tp = partial + (size_t)splits * 8 * kappa * batch * 3;
         u32 gb = (u32)((n + 255) / 256);
         if (gb > RED_BLOCKS_AJ) gb = RED_BLOCKS_AJ;
-        LF_LAUNCH(k_ajtai_tail, t.nu2p40, dim3(gb, 8, ntail), dim3(256), s, t, A, kappa, n, F, batch, nmain, tp);
+        LF_LAUNCH(k_ajtai_tail, t.nu2p40, dim3(gb, 8, ntail), dim3(256), s, t, A, kappa, n, F, ldF, batch, nmain, tp);
         hipLaunchKernelGGL(k_ajtai_tail_reduce, dim3(ntail * 24), dim3(256), 0, s, tp, gb, ntail, nmain, kappa, batch, out);
     }
 }
@@ -959,11 +961,11 @@ template <bool NU>
 __global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                                      u32 K, const Fq3Const *mu_pow, u64 *partial) {
     u32 slot = blockIdx.y;
-    size_t pairs = a.n / 2;
+    const size_t pend = a.p0 + a.pcnt;
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
-    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+    for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
         fold_g13<NU>(acc, a, slot, p, t.nu);
         // cubic coefficients of sum_kd mu_kd * P(f0 + X*df): integer parts split in lo/hi 32-bit halves of mu
         int64_t lo[4][3], hi[4][3];
@@ -1011,7 +1013,7 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, 
 }
 void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
-    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    u32 gb = (u32)((a.pcnt + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     LF_LAUNCH(k_fold_round1, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, planesL, planesR, n_planes, K, mu_pow_dev, partial);
@@ -1025,14 +1027,14 @@ template <bool NU>
 __global__ void __launch_bounds__(256) k_fold_round2(DevCrt t, FoldRoundArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                                      u32 K, const Fq3Const *mu_pow, Fq3Const r1c, u64 *partial) {
     u32 slot = blockIdx.y;
-    size_t pairs = a.n / 2;
+    const size_t pend = a.p0 + a.pcnt;
     const u64 nu = t.nu;
     const Fq3 r1 = fq3_make(r1c.c[0], r1c.c[1], r1c.c[2]);
     const Fq3 r1s = S3<NU>(r1, nu), r1c3 = M3<NU>(r1s, r1, nu);
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
-    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+    for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
         fold_g13<NU>(acc, a, slot, p, nu);
         Fq3 Q[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
         if (4 * p < n_planes) {
@@ -1106,7 +1108,7 @@ __global__ void __launch_bounds__(256) k_fold_round2(DevCrt t, FoldRoundArgs a, 
 }
 void launch_fold_round2(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const Fq3Const *mu_pow_dev, Fq3Const r1, u64 *partial, u64 *out, hipStream_t s) {
-    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    u32 gb = (u32)((a.pcnt + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     LF_LAUNCH(k_fold_round2, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, planesL, planesR, n_planes, K, mu_pow_dev, r1, partial);
@@ -1114,12 +1116,12 @@ void launch_fold_round2(const DevCrt &t, const FoldRoundArgs &a, const int32_t *
 }
 
 // after r_2: F[(side*K+k)*3+d][3*slot+c][j] = sum_{b<4} W_b * digit(f[4j+b]),  W = eq((r1,r2), .),  j < m/4
-__global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+__global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t j0, size_t q, u32 K,
                                                            Fq3Const W0, Fq3Const W1, Fq3Const W2, Fq3Const W3, u64 *F) {
-    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t jl = (size_t)blockIdx.x * 256 + threadIdx.x;   // local entry; global entry j = j0 + jl, F holds q local entries
     u32 cidx = blockIdx.y;
-    size_t q = m / 4;
-    if (j >= q) return;
+    if (jl >= q) return;
+    size_t j = j0 + jl;
     u32 d = cidx / 8, slot = cidx % 8;
     const Fq3Const W[4] = {W0, W1, W2, W3};
     for (int side = 0; side < 2; side++) {
@@ -1138,14 +1140,14 @@ __global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planes
                     acc[c] = dg > 0 ? fq_add(acc[c], w) : (dg < 0 ? fq_sub(acc[c], w) : acc[c]);
                 }
             }
-            u64 *dst = F + (((size_t)(side * K + k) * 3 + d) * 24 + 3 * slot) * q + j;
+            u64 *dst = F + (((size_t)(side * K + k) * 3 + d) * 24 + 3 * slot) * q + jl;
             dst[0] = acc[0]; dst[q] = acc[1]; dst[2 * q] = acc[2];
         }
     }
 }
-void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t j0, size_t q, u32 K,
                               const Fq3Const W[4], u64 *F, hipStream_t s) {
-    hipLaunchKernelGGL(k_fold_materialize2, dim3(cdiv(m / 4, 256), 24), dim3(256), 0, s, planesL, planesR, n_planes, m, K, W[0], W[1], W[2], W[3], F);
+    hipLaunchKernelGGL(k_fold_materialize2, dim3(cdiv(q, 256), 24), dim3(256), 0, s, planesL, planesR, n_planes, j0, q, K, W[0], W[1], W[2], W[3], F);
 }
 
 // F[(side*K+k)*3+d][3*slot+c][j] = f0 + r1*(f1-f0), j < m/2  (first fix of the virtual f-hat tables)
@@ -1187,14 +1189,15 @@ template <bool NU>
 __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow,
                                                     u64 *partial) {
     u32 slot = blockIdx.y;
-    size_t pairs = a.n / 2;
+    const size_t pend = a.p0 + a.pcnt;
     const u64 nu = t.nu;
     const u32 nkd = 2 * K * 3, per = (nkd + gridDim.z - 1) / gridDim.z;
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
+    F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
-    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+    for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
         if (blockIdx.z == 0) fold_g13<NU>(acc, a, slot, p, nu);
         Fq3 Q[4];
         if (NU) {
@@ -1253,7 +1256,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
 }
 void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
                        u64 *out, hipStream_t s) {
-    size_t pairs = a.n / 2;
+    size_t pairs = a.pcnt;
     u32 gb = (u32)((pairs + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;

@@ -41,3 +41,21 @@ def allgather_modsum(partial, group=None):
 def sharded_commit(scheme_shard, f_shard, group=None):
     """scheme_shard: api.AjtaiCommitmentScheme over this rank's column slice; f_shard: (n_local,24) or (batch,n_local,24)."""
     return allgather_modsum(scheme_shard.commit_ntt(f_shard), group)
+
+
+def make_allgather(group=None):
+    """all-gather of a uint64 vector for Context.set_sharding: RCCL on device tensors with backend "nccl", host tensors with gloo."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+
+    def allgather(vec):
+        t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.uint64).view(np.int64).copy())
+        if backend == "nccl":
+            t = t.cuda()
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        return torch.stack(parts).cpu().numpy().view(np.uint64)
+
+    return allgather

@@ -1,0 +1,71 @@
+"""Intra-step sharding: a fold step sharded over 2 and 4 ranks must return, on EVERY rank, the bit-identical proof,
+folded LCCCS and folded witness of the unsharded run (which test_gpu_parity pins to the oracle).  Ranks share cuda:0 here and
+exchange through gloo; on a multi-GPU node the same code runs one rank per GPU over RCCL (bench.py --parallelism shard)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+pytestmark = pytest.mark.gpu
+
+WORKER = textwrap.dedent('''
+    import os, sys, json, hashlib
+    sys.path.insert(0, os.environ["LF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["LF_ROOT"], "tests"))
+    import numpy as np, torch.distributed as dist
+    from latticefold_amd import api, dist as lfd
+    from latticefold_amd.workload import make_workload
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    out = {}
+    for name in os.environ["LF_CASES"].split(","):
+        wl = make_workload(name)
+        def run(sharded):
+            ctx = api.Context(0)
+            if sharded:
+                ctx.set_sharding(rank, world, lfd.make_allgather())
+            ctx.load_ccs(wl)
+            scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+            wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+            cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+            lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+            lc2, w1, proof2 = api.NIFSProver.prove(ctx, lc, w0, cccs, wit, api.PoseidonTranscript())   # chained step
+            h = hashlib.sha256()
+            for a in (cccs, acc, lc, proof, w0.f_coeff, lc2, proof2, w1.f_coeff):
+                h.update(np.ascontiguousarray(a).tobytes())
+            ctx.close()
+            return h.hexdigest()
+        ref = run(False) if rank == 0 else None
+        got = run(True)
+        allg = [None] * world
+        dist.all_gather_object(allg, got)
+        if rank == 0:
+            out[name] = {"ref": ref, "ranks": allg}
+    if rank == 0:
+        print(json.dumps(out))
+    dist.destroy_process_group()
+''')
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("world,cases", [(2, "T10,G5,T12"), (4, "T12")])
+def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, LF_ROOT=ROOT, OMP_NUM_THREADS="2", LF_CASES=cases)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for name, r in d.items():
+        assert len(r["ranks"]) == world
+        assert all(x == r["ref"] for x in r["ranks"]), (name, r)
