@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallelism", choices=["replicas", "shard"], default=os.environ.get("LF_PARALLELISM", "replicas"),
+                    help="N>1: 'replicas' = one independent fold stream per GPU (weak scaling, default); 'shard' = ONE fold stream whose "
+                         "Ajtai commitments and folding-sumcheck rounds are sharded over the GPUs (strong scaling, SURVEY 8e)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,8 +109,12 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     # ---- setup (untimed): everything resident in HBM --------------------------------------------------------
-    wl = make_workload(args.workload, seed=rank)
+    shard = world > 1 and args.parallelism == "shard"
+    wl = make_workload(args.workload, seed=0 if shard else rank)
     ctx = api.Context(local_rank)
+    if shard:
+        from latticefold_amd import dist as lfd
+        ctx.set_sharding(rank, world, lfd.make_allgather())   # RCCL all-gather of the partial commitments / round messages
     ctx.load_ccs(wl)
     scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())  # generated on the device
     wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
@@ -148,7 +155,7 @@ def main():
 
     if rank == 0:
         E = 192
-        steps_per_s = world * args.steps / elapsed
+        steps_per_s = (1 if shard else world) * args.steps / elapsed
         alg = wl.alg_bytes()
         # dominant kernels, live HIP-event timing on the library's stream (lf_last_kernel_stats)
         fr_ms = sum(k["fold_round_ms"] for k in kstats)
@@ -189,12 +196,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: GoldilocksRingNTT R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
-                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": f"replicas x{world}",
+                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world} (column-sharded commits + sharded sumcheck rounds, one fold stream)" if shard else f"replicas x{world}"),
                        "alg_bytes_per_step": alg, "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
             "roofline": roof,
             "phases_ms_per_step": {k: v / args.steps for k, v in phases_acc.items()},
