@@ -392,13 +392,14 @@ __device__ __forceinline__ Fq3 acc5_finish(const Acc5 &a, u64 nu) {
     return r;
 }
 constexpr int AJ_THREADS = 448;  // 7 waves: 26 x 15 = 390 outputs (a 6-full-wave + tail-kernel split measured slower)
-// Karatsuba at the F_{p^3} level with lazy accumulation: with P0=a0b0, P1=a1b1, P2=a2b2, P01=(a0+a1)(b0+b1),
-// P02=(a0+a2)(b0+b2), P12=(a1+a2)(b1+b2):  c0 = P0 + nu(P12-P1-P2), c1 = P01-P0-P1 + nu P2, c2 = P02-P0-P2 + P1.
-// All six products are summed over the whole j-range un-reduced (AccP), so a MAC is 24 (not 36) v_mad_u64_u32; the
-// operand sums are formed once per staged element while the tile is written to LDS.
-struct Acc6 { AccP s[6]; };
-// LDS tile: one 48-byte record {c0,c1,c2,c0+c1,c0+c2,c1+c2} per (row, column), read back as three ds_read_b128.
-// Row stride = AJ_JT*48 + 16 bytes: rows of one 16-lane read group fall into distinct 16-byte slots (conflict-free).
+// Toom-3 at the F_{p^3} level with lazy accumulation.  For a = a0 + a1 Y + a2 Y^2 (same for b) the product
+// r(Y) = a(Y) b(Y) (degree 4) is determined by the five pointwise products at Y = 0, 1, -1, 2, inf.  Those five products are
+// summed over the whole j-range un-reduced (AccP), so one multiply-accumulate costs 20 v_mad_u64_u32 (schoolbook 36,
+// Karatsuba 24); the evaluations a(1), a(-1), a(2) are formed once per staged element while the tile is written to LDS, and
+// the interpolation (with its divisions by 2 and 3) plus the reduction Y^3 = nu happen once per output at the very end.
+struct Acc6 { AccP s[5]; };
+// LDS tile: one 48-byte record {a(0), a(1), a(-1), a(2), a(inf), pad} per (row, column): two ds_read_b128 + one ds_read_b64.
+// Row stride = AJ_T*48 + 16 bytes: rows of one 16-lane read group fall into distinct 16-byte slots (conflict-free).
 constexpr int AJ_T = 32;                          // columns per tile
 constexpr int AJ_ROWB = AJ_T * 48 + 16;           // bytes per row
 template <bool NU, int NT>
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kap
     size_t j0 = (size_t)split * per, j1 = j0 + per < n ? j0 + per : n;
     Acc6 acc;
 #pragma unroll
-    for (int i = 0; i < 6; i++) accp_zero(acc.s[i]);
+    for (int i = 0; i < 5; i++) accp_zero(acc.s[i]);
     const u32 o0 = threadIdx.x;
     const u32 i0 = o0 / batch, k0 = o0 % batch;
     const bool active = o0 < nout;
@@ -431,31 +432,45 @@ __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kap
                 const u64 *src = isA ? A + ((size_t)r * 24 + 3 * slot) * n : F + ((size_t)(r - kappa) * 24 + 3 * slot) * ldF;
                 v0 = src[j]; v1 = src[ldr + j]; v2 = src[2 * ldr + j];
             }
+            u64 e02 = fq_add(v0, v2);                                   // a0 + a2
+            u64 d1 = fq_add(v1, v1), q2 = fq_add(v2, v2);
+            u64 at2 = fq_add(fq_add(v0, d1), fq_add(q2, q2));           // a(2) = a0 + 2 a1 + 4 a2
             ulonglong2 *dstp = (ulonglong2 *)(smem + (size_t)r * AJ_ROWB + jj * 48);
-            dstp[0] = make_ulonglong2(v0, v1);
-            dstp[1] = make_ulonglong2(v2, fq_add(v0, v1));
-            dstp[2] = make_ulonglong2(fq_add(v0, v2), fq_add(v1, v2));
+            dstp[0] = make_ulonglong2(v0, fq_add(e02, v1));             // a(0), a(1)
+            dstp[1] = make_ulonglong2(fq_sub(e02, v1), at2);            // a(-1), a(2)
+            *(u64 *)(dstp + 2) = v2;                                    // a(inf)
         }
         __syncthreads();
         if (active) {
 #pragma unroll 4
             for (int jj = 0; jj < AJ_T; jj++) {
                 const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
-                ulonglong2 x0 = xa[0], x1 = xa[1], x2 = xa[2], y0 = yf[0], y1 = yf[1], y2 = yf[2];
+                ulonglong2 x0 = xa[0], x1 = xa[1], y0 = yf[0], y1 = yf[1];
+                u64 x2 = *(const u64 *)(xa + 2), y2 = *(const u64 *)(yf + 2);
                 accp_mad(acc.s[0], x0.x, y0.x); accp_mad(acc.s[1], x0.y, y0.y);
                 accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
-                accp_mad(acc.s[4], x2.x, y2.x); accp_mad(acc.s[5], x2.y, y2.y);
+                accp_mad(acc.s[4], x2, y2);
             }
         }
     }
     // partial[split][slot][o][3]   (only outputs o < blockDim.x are produced here)
     u64 *dst = partial + ((size_t)split * 8 + slot) * nout * 3;
     if (active) {
-        u64 r0 = accp_reduce(acc.s[0]), r1 = accp_reduce(acc.s[1]), r2 = accp_reduce(acc.s[2]);
-        u64 r01 = accp_reduce(acc.s[3]), r02 = accp_reduce(acc.s[4]), r12 = accp_reduce(acc.s[5]);
-        u64 c0 = fq_add(r0, fq_mul_nu<NU>(fq_sub(fq_sub(r12, r1), r2), t.nu));
-        u64 c1 = fq_add(fq_sub(fq_sub(r01, r0), r1), fq_mul_nu<NU>(r2, t.nu));
-        u64 c2 = fq_add(fq_sub(fq_sub(r02, r0), r2), r1);
+        const u64 INV2 = 0x7FFFFFFF80000001ULL;   // (p+1)/2
+        const u64 INV3 = 0xAAAAAAAA00000001ULL;   // (2p+1)/3
+        u64 p0 = accp_reduce(acc.s[0]), p1 = accp_reduce(acc.s[1]), pm1 = accp_reduce(acc.s[2]);
+        u64 p2 = accp_reduce(acc.s[3]), pinf = accp_reduce(acc.s[4]);
+        u64 r0 = p0, r4 = pinf;
+        u64 r2 = fq_sub(fq_sub(fq_mul(fq_add(p1, pm1), INV2), r0), r4);
+        u64 t2 = fq_mul(fq_sub(p1, pm1), INV2);                                            // r1 + r3
+        u64 r2x4 = fq_add(fq_add(r2, r2), fq_add(r2, r2));
+        u64 r4x16 = fq_mul(r4, 16);
+        u64 t3 = fq_mul(fq_sub(fq_sub(fq_sub(p2, r0), r2x4), r4x16), INV2);                // r1 + 4 r3
+        u64 r3 = fq_mul(fq_sub(t3, t2), INV3);
+        u64 r1 = fq_sub(t2, r3);
+        u64 c0 = fq_add(r0, fq_mul_nu<NU>(r3, t.nu));
+        u64 c1 = fq_add(r1, fq_mul_nu<NU>(r4, t.nu));
+        u64 c2 = r2;
         dst[(size_t)o0 * 3] = c0; dst[(size_t)o0 * 3 + 1] = c1; dst[(size_t)o0 * 3 + 2] = c2;
     }
 }
