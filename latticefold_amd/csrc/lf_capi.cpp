@@ -79,6 +79,24 @@ struct lf_transcript {
     Transcript t;
 };
 
+// wall-clock timeline of the calling thread (LF_TIMELINE=1): printed at the end of lf_fold_step
+struct Timeline {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    std::vector<std::pair<const char *, double>> marks;
+    Timeline() : on(getenv("LF_TIMELINE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (on) marks.push_back({what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()});
+    }
+    void dump() {
+        if (!on) return;
+        double prev = 0;
+        for (auto &m : marks) { fprintf(stderr, "[timeline] %-28s at %8.3f ms  (+%7.3f)\n", m.first, m.second, m.second - prev); prev = m.second; }
+    }
+};
+static thread_local Timeline *t_tl = nullptr;
+#define TL_MARK(x) do { if (t_tl) t_tl->mark(x); } while (0)
+
 static const char *PHASE_NAMES[LF_N_PHASES] = {"linearization", "decomp_crt_commit", "decomp_evals", "fold_prepare",
                                                 "fold_sumcheck", "fold_finish", "host_transcript", "total"};
 
@@ -1080,6 +1098,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         tr.absorb_label("beta_s");
         for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
     }
+    TL_MARK(" fold challenges");
     size_t ph = c->ev_begin(13);
     // powers x^{j+1}
     std::vector<Fq3Const> mu_pow((size_t)K2 * 3), a_pow((size_t)K2 * 3), z_pow((size_t)K2 * P.t);
@@ -1112,6 +1131,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     LF_TRACE(c, "fold prepare");
     c->ev_end(ph);
+    if (t_tl && t_tl->on) { (void)hipStreamSynchronize(c->stream()); TL_MARK(" fold prepare (synced)"); }
 
     ph = c->ev_begin(14);
     u64 *msgs = proof;
@@ -1203,7 +1223,13 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         if (sharded) RET(exchange_modsum(c, evs, (size_t)(deg + 1) * 24));
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
+        if (round == 1) TL_MARK("  round 1");
+        if (round == 2) TL_MARK("  round 2");
+        if (round == 3) TL_MARK("  round 3");
+        if (round == 6) TL_MARK("  round 6");
+        if (round == 10) TL_MARK("  round 10");
     }
+    TL_MARK(" fold sumcheck");
     c->ev_end(ph);
 
     ph = c->ev_begin(15);
@@ -1224,6 +1250,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         launch_dot_batch(c->dcrt, S[sd].z, n, K, q, n, P.t, n, dpart, sm, c->stream());
         RET(down_small(c, sm, (size_t)K * P.t * 24, eta + (size_t)sd * K * P.t * 24));
     }
+    TL_MARK(" theta/eta");
     std::vector<u64> rho_c((size_t)K2 * 24, 0), rho((size_t)K2 * 24);
     std::vector<int8_t> rho8((size_t)K2 * 24, 0);
     {
@@ -1253,6 +1280,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     LF_TRACE(c, "fold_witness");
     HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c, npl, N};
+    TL_MARK(" rho + fold_witness");
     c->ev_end(ph);
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521), host
@@ -1321,6 +1349,8 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     HIPCHK(hipSetDevice(c->device));
     std::vector<Fq3> rL;
     if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;  // evaluation points are always diagonal challenges
+    Timeline tl;
+    t_tl = &tl;
     c->ev_reset();
     c->host_tr_ms = 0;
     size_t tot = c->ev_begin(17);
@@ -1356,17 +1386,25 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
         return decompose_commit_finish(c, cm_i, yd, ev, decr);          // cm of the linearized instance = cm_i.cm
     });
+    TL_MARK("public input absorbed");
     int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    TL_MARK("linearization done");
     lin_done_p.set_value(rc);
     std::vector<Fq3> rR;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
         rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
     }
+    TL_MARK("right evals done");
     int rc1 = flane1.get();
+    TL_MARK("lane 1 joined");
     if (rc == LF_OK) rc = rc1;
     if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
+    TL_MARK("right absorb done");
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
+    TL_MARK("fold done");
+    tl.dump();
+    t_tl = nullptr;
     c->ev_end(tot);
     c->ev_collect();
     return rc;

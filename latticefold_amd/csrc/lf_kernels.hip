@@ -132,6 +132,8 @@ void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0,
     hipLaunchKernelGGL(k_fill_ajtai, dim3(4096), dim3(256), 0, s, A, kappa, n, n_total, col0, seed);
 }
 
+__device__ __forceinline__ u64 fq_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? 1 : LF_P - 1); }
+
 // ---------------------------------------------------------------------------------------------------------
 // CRT: structured forward transform.  a(X) = sum_u X^u A_u(X^3); A_u is evaluated at the 8 primitive 24th
 // roots by three radix-2 layers over Y^8 - Y^4 + 1 = (Y^4 - w^4)(Y^4 - w^20), then the per-slot monomial
@@ -156,6 +158,50 @@ __device__ __forceinline__ void crt8(const u64 x[8], u64 o[8], const DevCrt &t) 
     u64 b = fq_mul(t.w7, l1[1]);  o[2] = fq_add(l1[0], b); o[3] = fq_sub(l1[0], b);
     u64 c = fq_mul(t.w5, h0[1]);  o[4] = fq_add(h0[0], c); o[5] = fq_sub(h0[0], c);
     u64 d = fq_mul(t.w11, h1[1]); o[6] = fq_add(h1[0], d); o[7] = fq_sub(h1[0], d);
+}
+// same butterflies for a TERNARY input (digits in {-1,0,1}): the first layer needs no multiplication (+-w4 or 0)
+__device__ __forceinline__ void crt8_ternary(const int x[8], u64 o[8], const DevCrt &t) {
+    u64 lo[4], hi[4];
+    const u64 nw4 = LF_P - t.w4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 a = fq_from_digit(x[i]), b = fq_from_digit(x[i + 4]);
+        u64 tt = x[i + 4] == 0 ? 0 : (x[i + 4] > 0 ? t.w4 : nw4);
+        lo[i] = fq_add(a, tt);
+        hi[i] = fq_sub(fq_add(a, b), tt);
+    }
+    u64 l0[2], l1[2], h0[2], h1[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        u64 tt = fq_mul(t.w2, lo[i + 2]);
+        l0[i] = fq_add(lo[i], tt); l1[i] = fq_sub(lo[i], tt);
+        u64 uu = fq_mul(t.w10, hi[i + 2]);
+        h0[i] = fq_add(hi[i], uu); h1[i] = fq_sub(hi[i], uu);
+    }
+    u64 a = fq_mul(t.w1, l0[1]);  o[0] = fq_add(l0[0], a); o[1] = fq_sub(l0[0], a);
+    u64 b = fq_mul(t.w7, l1[1]);  o[2] = fq_add(l1[0], b); o[3] = fq_sub(l1[0], b);
+    u64 c = fq_mul(t.w5, h0[1]);  o[4] = fq_add(h0[0], c); o[5] = fq_sub(h0[0], c);
+    u64 d = fq_mul(t.w11, h1[1]); o[6] = fq_add(h1[0], d); o[7] = fq_sub(h1[0], d);
+}
+__device__ __forceinline__ void crt_store_ternary(const int dg[24], u64 *out, size_t ld, size_t j, const DevCrt &t) {
+    int x[8];
+    u64 A0[8], A1[8], A2[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) x[v] = dg[3 * v];
+    crt8_ternary(x, A0, t);
+#pragma unroll
+    for (int v = 0; v < 8; v++) x[v] = dg[3 * v + 1];
+    crt8_ternary(x, A1, t);
+#pragma unroll
+    for (int v = 0; v < 8; v++) x[v] = dg[3 * v + 2];
+    crt8_ternary(x, A2, t);
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        int s3 = 3 * t.slot_of_pos[p];
+        out[(size_t)s3 * ld + j] = A0[p];
+        out[(size_t)(s3 + t.pos1[p]) * ld + j] = fq_mul(t.tw1[p], A1[p]);
+        out[(size_t)(s3 + t.pos2[p]) * ld + j] = fq_mul(t.tw2[p], A2[p]);
+    }
 }
 // coefficients a[24] (canonical) -> stores the 24 NTT words of element j into plane table `out` (ld = n)
 __device__ __forceinline__ void crt_store(const u64 a[24], u64 *out, size_t ld, size_t j, const DevCrt &t) {
@@ -301,7 +347,6 @@ __device__ __forceinline__ int digit2(int32_t v, u32 k) {
     int d = (m >> k) & 1;
     return v < 0 ? -d : d;
 }
-__device__ __forceinline__ u64 fq_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? 1 : LF_P - 1); }
 
 __global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out) {
     size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -310,10 +355,10 @@ __global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *p
 #pragma unroll
     for (int c = 0; c < 24; c++) v[c] = planes[(size_t)c * ld + j];
     for (u32 k = k0; k < k1; k++) {
-        u64 a[24];
+        int dg[24];
 #pragma unroll
-        for (int c = 0; c < 24; c++) a[c] = fq_from_digit(digit2(v[c], k));
-        crt_store(a, out + (size_t)(k - k0) * 24 * n, n, j, t);
+        for (int c = 0; c < 24; c++) dg[c] = digit2(v[c], k);
+        crt_store_ternary(dg, out + (size_t)(k - k0) * 24 * n, n, j, t);
     }
 }
 void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s) {
