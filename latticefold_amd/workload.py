@@ -15,6 +15,10 @@ import numpy as np
 P = 2**64 - 2**32 + 1
 RE = 24  # u64 words per ring element (8 slots x 3 coords / 24 coefficients)
 
+# ring id -> (modulus, ring degree d = words per element, tau); ids match include/lfhip.h LF_RING_*
+RINGS = {"goldilocks": (P, 24, 3), "babybear": (15 * 2**27 + 1, 72, 9)}
+RING_IDS = {"goldilocks": 0, "babybear": 1}
+
 CONFIGS = {
     # name: (s, wit_len, L, B, b, K, kappa)   -- SURVEY.md 8.0
     "T8": (8, 64, 4, 1 << 16, 2, 16, 4),       # tiny, unit tests
@@ -27,6 +31,14 @@ CONFIGS = {
     "C4": (20, 1 << 18, 4, 1 << 16, 2, 16, 26),  # BASELINE configs[3] / metric config
     # GoldilocksDP of the reference unit tests (decomposition_parameters.rs:89-96): N not a power of 2
     "G5": (9, 64, 5, 1 << 15, 2, 15, 5),
+    # ---- BabyBearRingNTT (d = 72, tau = 9; B^L = 2^32 > p)
+    "B6": (6, 32, 2, 1 << 16, 2, 16, 3, "babybear"),      # tiny, unit tests
+    "B8": (8, 128, 2, 1 << 16, 2, 16, 4, "babybear"),
+    "B10": (10, 512, 2, 1 << 16, 2, 16, 6, "babybear"),
+    "B14": (14, 1 << 13, 2, 1 << 16, 2, 16, 16, "babybear"),
+    "C3": (18, 1 << 17, 2, 1 << 16, 2, 16, 16, "babybear"),  # BASELINE configs[2]
+    # BabyBearDP of the reference unit tests (decomposition_parameters.rs:98-105): B 2^8, L 4, K 8
+    "BDP": (7, 32, 4, 1 << 8, 2, 8, 4, "babybear"),
 }
 
 _M1 = np.uint64(0xBF58476D1CE4E5B9)
@@ -34,22 +46,27 @@ _M2 = np.uint64(0x94D049BB133111EB)
 _G = np.uint64(0x9E3779B97F4A7C15)
 
 
-def splitmix_fq(seed: int, start: int, count: int) -> np.ndarray:
-    """count canonical Goldilocks residues; word i = splitmix64(seed + (start+i+1)*G) folded into [0,p)."""
+def splitmix_fq(seed: int, start: int, count: int, ring: str = "goldilocks") -> np.ndarray:
+    """count canonical residues; word i = splitmix64(seed + (start+i+1)*G) folded into [0,p) (Goldilocks: one
+    conditional subtraction; BabyBear: the top 32 bits of the word mod p)."""
     with np.errstate(over="ignore"):
         idx = np.arange(start + 1, start + count + 1, dtype=np.uint64)
         z = np.uint64(seed & (2**64 - 1)) + idx * _G
         z = (z ^ (z >> np.uint64(30))) * _M1
         z = (z ^ (z >> np.uint64(27))) * _M2
         z = z ^ (z >> np.uint64(31))
-        z = np.where(z >= np.uint64(P), z - np.uint64(P), z)
+        if ring == "goldilocks":
+            z = np.where(z >= np.uint64(P), z - np.uint64(P), z)
+        else:
+            z = (z >> np.uint64(32)) % np.uint64(RINGS[ring][0])
     return z
 
 
-def diag(v: int) -> np.ndarray:
-    """R::from(u128): every slot = (v,0,0)."""
-    e = np.zeros(RE, dtype=np.uint64)
-    e[0::3] = np.uint64(v % P)
+def diag(v: int, ring: str = "goldilocks") -> np.ndarray:
+    """R::from(u128): every slot = (v,0,..,0)."""
+    p, d, tau = RINGS[ring]
+    e = np.zeros(d, dtype=np.uint64)
+    e[0::tau] = np.uint64(v % p)
     return e
 
 
@@ -68,6 +85,7 @@ class Workload:
     q: int = 2
     d: int = 2
     seed: int = 0
+    ring: str = "goldilocks"
     rowptr: list = field(default_factory=list)
     col: list = field(default_factory=list)
     val: list = field(default_factory=list)
@@ -91,7 +109,19 @@ class Workload:
 
     @property
     def tau(self):
-        return 3
+        return RINGS[self.ring][2]
+
+    @property
+    def RE(self):
+        return RINGS[self.ring][1]
+
+    @property
+    def P(self):
+        return RINGS[self.ring][0]
+
+    @property
+    def ring_id(self):
+        return RING_IDS[self.ring]
 
     def ajtai_seed(self):
         return 0xA17A1 + self.seed
@@ -99,15 +129,16 @@ class Workload:
     def ajtai_matrix(self, row0=0, rows=None) -> np.ndarray:
         """kappa x N ring elements (NTT form), i.i.d. uniform words."""
         rows = self.kappa - row0 if rows is None else rows
-        per_row = self.N * RE
-        return splitmix_fq(self.ajtai_seed(), row0 * per_row, rows * per_row).reshape(rows, self.N, RE)
+        per_row = self.N * self.RE
+        return splitmix_fq(self.ajtai_seed(), row0 * per_row, rows * per_row, self.ring).reshape(rows, self.N, self.RE)
 
     def z(self) -> np.ndarray:
-        return np.concatenate([self.x_ccs, diag(1)[None, :], self.w_ccs], axis=0)
+        return np.concatenate([self.x_ccs, diag(1, self.ring)[None, :], self.w_ccs], axis=0)
 
     def alg_bytes(self) -> int:
-        """ALGORITHMIC bytes of one fold step, SURVEY.md 8(d) formula (E = 192 B)."""
-        E, N, t, K, L, kap, tau = RE * 8, self.m, self.t, self.K, self.L, self.kappa, self.tau
+        """ALGORITHMIC bytes of one fold step, SURVEY.md 8(d) formula (E = 192 B Goldilocks, 288 B BabyBear as u32)."""
+        E = 192 if self.ring == "goldilocks" else 288
+        N, t, K, L, kap, tau = self.m, self.t, self.K, self.L, self.kappa, self.tau
         P_L, P_F = t + 1, 5 + 2 * K * tau
         lin = t * N * E + (N // L) * E + 3 * P_L * N * E + (tau + t) * N * E
         dec = ((1 + K) * N * E + 2 * K * N * E + (kap + K - 1) * N * E + K * N * E
@@ -118,21 +149,24 @@ class Workload:
 
 
 def make_workload(name: str, seed: int = 0, kappa: int = None) -> Workload:
-    s, wit_len, L, B, b, K, kap = CONFIGS[name]
-    wl = Workload(name=name, s=s, wit_len=wit_len, L=L, B=B, b=b, K=K, kappa=kappa or kap, seed=seed)
+    cfg = CONFIGS[name]
+    s, wit_len, L, B, b, K, kap = cfg[:7]
+    ring = cfg[7] if len(cfg) > 7 else "goldilocks"
+    p, RE, _tau = RINGS[ring]
+    wl = Workload(name=name, s=s, wit_len=wit_len, L=L, B=B, b=b, K=K, kappa=kappa or kap, seed=seed, ring=ring)
     assert wl.N <= wl.m, "sanity_check (nifs.rs:165-173): m must be >= wit_len*L"
-    wl.x_ccs = np.tile(diag(1), (wl.l, 1))
-    wl.w_ccs = splitmix_fq(0x4C460001 + seed, 0, wit_len * RE).reshape(wit_len, RE)
+    wl.x_ccs = np.tile(diag(1, ring), (wl.l, 1))
+    wl.w_ccs = splitmix_fq(0x4C460001 + seed, 0, wit_len * RE, ring).reshape(wit_len, RE)
     z = wl.z()
     n, m = wl.n, wl.m
     rows = min(n, m)
     rp = np.minimum(np.arange(m + 1, dtype=np.uint32), np.uint32(rows)).astype(np.uint32)
     ci = np.arange(rows, dtype=np.uint32)
-    ident = np.tile(diag(1), (rows, 1))
+    ident = np.tile(diag(1, ring), (rows, 1))
     wl.rowptr = [rp, rp.copy(), rp.copy()]
     wl.col = [ci, ci.copy(), ci.copy()]
     wl.val = [ident, ident.copy(), np.ascontiguousarray(z[:rows])]
     wl.S_off = np.array([0, 2, 3], dtype=np.uint32)
     wl.S_idx = np.array([0, 1, 2], dtype=np.uint32)
-    wl.c = np.stack([diag(1), diag(P - 1)])
+    wl.c = np.stack([diag(1, ring), diag(p - 1, ring)])
     return wl

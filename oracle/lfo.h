@@ -18,8 +18,8 @@
  * => "parity unpinned" for exactly those three items; everything else is KAT-pinned.
  *
  * Data format everywhere: flat little-endian uint64_t canonical residues in [0,p).
- * Ring element = 24 words.  Coefficient form: X^0..X^23.  NTT form: slot-major, slot k =
- * words [3k,3k+3) = (c0,c1,c2) of an F_{p^3} element (the order
+ * Ring element = d words (24 Goldilocks / 72 BabyBear).  Coefficient form: X^0..X^{d-1}.  NTT form:
+ * slot-major, slot k = words [tau*k, tau*k+tau) = coordinates of an F_{p^tau} element (the order
  * `coeffs().flat_map(to_base_prime_field_elements)` yields, transcript/poseidon.rs:40-47).
  */
 #ifndef LFO_H
@@ -34,10 +34,24 @@ extern "C" {
 typedef uint64_t u64;
 typedef uint32_t u32;
 
+/* Ring selection at compile time: default GoldilocksRingNTT; -DLFO_RING_BABYBEAR builds
+ * liblfo_bb.so for BabyBearRingNTT (cyclotomic-rings/src/rings/babybear.rs:1-25): p = 15*2^27+1,
+ * Phi_216 = X^72 - X^36 + 1 = prod over the 8 primitive 24th roots zeta of (X^9 - zeta). */
+#ifdef LFO_RING_BABYBEAR
+#define LFO_P 2013265921ULL
+#define LFO_D 72
+#define LFO_TAU 9
+#define LFO_MOD_BITS 31
+#else
 #define LFO_P 0xFFFFFFFF00000001ULL /* Goldilocks 2^64 - 2^32 + 1 */
 #define LFO_D 24                    /* ring degree (Phi_72 = X^24 - X^12 + 1) */
-#define LFO_SLOTS 8
 #define LFO_TAU 3
+#define LFO_MOD_BITS 64
+#endif
+#define LFO_SLOTS 8
+int lfo_ring_degree(void);  /* LFO_D of this build */
+int lfo_ring_tau(void);
+u64 lfo_modulus(void);
 
 /* ---- ring tables (data, see header comment) ------------------------------------------ */
 /* nonres: F_{p^3} = F_p[Y]/(Y^3 - nonres).  y[8][3]: image of X in slot k (y_k^3 must be a

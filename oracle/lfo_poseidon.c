@@ -60,16 +60,24 @@ static void poseidon_init(void) {
     if (g_pinit) return;
     grain g;
     grain_init(&g, 64, W, RF, RP);
+    /* The reference's BabyBear table (rings/poseidon/babybear.rs) holds the SAME 64-bit constants as the
+     * Goldilocks one (generated for a 64-bit prime), embedded with Fq::from(i128), i.e. reduced mod p_BB:
+     * so generate over Goldilocks and reduce. */
+    const u64 PG = 0xFFFFFFFF00000001ULL;
     for (int i = 0; i < (RF + RP) * W; i++) { /* rejection sampling */
         u64 v;
-        do v = grain_bits64(&g); while (v >= LFO_P);
-        g_ark[i] = v;
+        do v = grain_bits64(&g); while (v >= PG);
+        g_ark[i] = v % LFO_P;
     }
     u64 xs[W], ys[W];
-    for (int i = 0; i < W; i++) xs[i] = grain_bits64(&g) % LFO_P;
-    for (int i = 0; i < W; i++) ys[i] = grain_bits64(&g) % LFO_P;
+    for (int i = 0; i < W; i++) xs[i] = grain_bits64(&g) % PG;
+    for (int i = 0; i < W; i++) ys[i] = grain_bits64(&g) % PG;
     for (int i = 0; i < W; i++)
-        for (int j = 0; j < W; j++) g_mds[i * W + j] = fq_inv(fq_add(xs[i], ys[j])); /* Cauchy */
+        for (int j = 0; j < W; j++) { /* Cauchy over Goldilocks */
+            u128 sm = ((u128)xs[i] + ys[j]) % PG, r = 1, bs = sm;
+            for (u64 e = PG - 2; e; e >>= 1) { if (e & 1) r = (u128)(((u128)(u64)r * (u64)bs) % PG); bs = (u128)(((u128)(u64)bs * (u64)bs) % PG); }
+            g_mds[i * W + j] = (u64)r % LFO_P;
+        }
     g_pinit = 1;
 }
 
@@ -171,21 +179,23 @@ static void squeeze_fq(lfo_transcript *t, u64 *out, size_t n) {
 
 /* Transcript::absorb(R): the 24 base-field words of each element, slot-major */
 void lfo_transcript_absorb_ring(lfo_transcript *t, const u64 *e, size_t count) {
-    for (size_t i = 0; i < count; i++) lfo_transcript_absorb_fq(t, e + 24 * i, 24);
+    for (size_t i = 0; i < count; i++) lfo_transcript_absorb_fq(t, e + (size_t)RE * i, RE);
 }
 
 /* get_challenge: squeeze tau words, absorb them back (poseidon.rs:49-57) */
 void lfo_transcript_get_challenge(lfo_transcript *t, u64 *out) {
-    squeeze_fq(t, out, 3);
-    lfo_transcript_absorb_fq(t, out, 3);
+    squeeze_fq(t, out, TAU);
+    lfo_transcript_absorb_fq(t, out, TAU);
 }
 
-/* squeeze_bytes(18): ceil(18/7)=3 elements, 7 low LE bytes each; then the challenge-set decoder */
+/* squeeze_bytes(18) (ark-crypto-primitives 0.4.0 PoseidonSponge): usable = (MODULUS_BIT_SIZE-1)/8 low LE
+ * bytes per element (7 Goldilocks, 3 BabyBear), ceil(18/usable) elements; then the challenge-set decoder */
 void lfo_transcript_get_short_challenge(lfo_transcript *t, u64 *coeff_out) {
-    u64 e[3];
-    uint8_t bs[21];
-    squeeze_fq(t, e, 3);
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 7; j++) bs[7 * i + j] = (uint8_t)(e[i] >> (8 * j));
+    enum { UB = (LFO_MOD_BITS - 1) / 8, NE = (18 + UB - 1) / UB };
+    u64 e[NE];
+    uint8_t bs[NE * UB];
+    squeeze_fq(t, e, NE);
+    for (int i = 0; i < NE; i++)
+        for (int j = 0; j < UB; j++) bs[UB * i + j] = (uint8_t)(e[i] >> (8 * j));
     lfo_short_challenge_from_bytes(bs, 18, coeff_out);
 }

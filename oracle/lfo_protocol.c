@@ -5,7 +5,7 @@
  * not the product.  OpenMP is used only so that bench.py's cpu_baseline leg can quote the
  * reference's Rayon-style data parallelism on the host cores.
  *
- * Flat layouts (ring elements of 24 u64):
+ * Flat layouts (ring elements of d u64; d = 24 Goldilocks, 72 BabyBear):
  *   LCCCS : r[s] | v[tau] | cm[kappa] | u[t] | x_w[l] | h
  *   CCCS  : cm[kappa] | x_ccs[l]
  *   proof : LIN  msgs[s][d+2] | v[tau] | u[t]
@@ -20,8 +20,6 @@
 #include <omp.h>
 #endif
 
-#define TAU LFO_TAU
-#define RE 24 /* words per ring element */
 
 void lfo_set_num_threads(int n) {
 #ifdef _OPENMP
@@ -173,13 +171,13 @@ static void spmv(const lfo_params *p, const lfo_ccs *ccs, u32 j, const u64 *z, u
     }
 }
 
-/* Witness::get_fhat, arith.rs:273-297: table d, entry i, slot k = (coeff[8d+k],0,0); zero-padded to m */
+/* Witness::get_fhat, arith.rs:273-297: table d, entry i, slot k = (coeff[8d+k],0,..,0); zero-padded to m */
 static void build_fhat(const u64 *f_coeff, size_t N, size_t m, u64 **tables /*TAU*/) {
     for (int d = 0; d < TAU; d++) {
         tables[d] = ralloc(m);
 #pragma omp parallel for schedule(static) if (N >= 4096)
         for (size_t i = 0; i < N; i++)
-            for (int k = 0; k < 8; k++) tables[d][i * RE + 3 * k] = f_coeff[i * RE + 8 * d + k];
+            for (int k = 0; k < 8; k++) tables[d][i * RE + TAU * k] = f_coeff[i * RE + 8 * d + k];
     }
 }
 
@@ -197,10 +195,9 @@ static void absorb_label(lfo_transcript *tr, const char *s) { /* absorb_field_el
 }
 static void get_challenges_ring(lfo_transcript *tr, u32 n, u64 *out) { /* get_challenges(n).map(R::from) */
     for (u32 i = 0; i < n; i++) {
-        u64 c[3];
+        u64 c[TAU];
         lfo_transcript_get_challenge(tr, c);
-        fq3 v = {{c[0], c[1], c[2]}};
-        rq_from_fq3(out + (size_t)i * RE, v);
+        rq_from_fqe(out + (size_t)i * RE, fqe_load(c));
     }
 }
 
@@ -637,29 +634,48 @@ int lfo_fold_step(const lfo_params *p, const lfo_ccs *ccs, const u64 *A, lfo_tra
 /* ======================================================================================== */
 /* verifier: nifs.rs:117-163                                                                 */
 
-static fq3 fq3_inv(fq3 a) {
-    u64 nr = lfo_NONRES;
-    u64 t0 = fq_sub(fq_mul(a.c[0], a.c[0]), fq_mul(nr, fq_mul(a.c[1], a.c[2])));
-    u64 t1 = fq_sub(fq_mul(nr, fq_mul(a.c[2], a.c[2])), fq_mul(a.c[0], a.c[1]));
-    u64 t2 = fq_sub(fq_mul(a.c[1], a.c[1]), fq_mul(a.c[0], a.c[2]));
-    u64 norm = fq_add(fq_mul(a.c[0], t0), fq_mul(nr, fq_add(fq_mul(a.c[2], t1), fq_mul(a.c[1], t2))));
-    u64 ni = fq_inv(norm);
-    fq3 r = {{fq_mul(t0, ni), fq_mul(t1, ni), fq_mul(t2, ni)}};
+/* inverse in F_{p^tau}: solve (multiplication-by-a matrix) x = 1 by Gauss-Jordan over F_p */
+static fqe fqe_inv(fqe a) {
+    u64 M[TAU][TAU + 1];
+    fqe col = fqe_one();
+    fqe yb = fqe_zero();
+    if (TAU > 1) yb.c[1] = 1;
+    fqe cur = a; /* a * Y^j */
+    for (int j = 0; j < TAU; j++) {
+        for (int i = 0; i < TAU; i++) M[i][j] = cur.c[i];
+        cur = fqe_mul(cur, yb);
+    }
+    for (int i = 0; i < TAU; i++) M[i][TAU] = col.c[i];
+    for (int c = 0; c < TAU; c++) {
+        int piv = -1;
+        for (int r = c; r < TAU; r++) if (M[r][c]) { piv = r; break; }
+        if (piv < 0) return fqe_zero();
+        if (piv != c) for (int k = 0; k <= TAU; k++) { u64 t = M[piv][k]; M[piv][k] = M[c][k]; M[c][k] = t; }
+        u64 inv = fq_inv(M[c][c]);
+        for (int k = 0; k <= TAU; k++) M[c][k] = fq_mul(M[c][k], inv);
+        for (int r = 0; r < TAU; r++) {
+            if (r == c || !M[r][c]) continue;
+            u64 f = M[r][c];
+            for (int k = 0; k <= TAU; k++) M[r][k] = fq_sub(M[r][k], fq_mul(f, M[c][k]));
+        }
+    }
+    fqe r;
+    for (int i = 0; i < TAU; i++) r.c[i] = M[i][TAU];
     return r;
 }
 
 /* interpolate_uni_poly (utils/sumcheck/verifier.rs:141-257): Lagrange through x=0..len-1 */
-static void interpolate(const u64 *p_i, u32 len, fq3 at, u64 *out) {
+static void interpolate(const u64 *p_i, u32 len, fqe at, u64 *out) {
     u64 res[RE] = {0}, t[RE];
     for (u32 i = 0; i < len; i++) {
-        fq3 num = fq3_one(), den = fq3_one();
+        fqe num = fqe_one(), den = fqe_one();
         for (u32 j = 0; j < len; j++) {
             if (j == i) continue;
-            num = fq3_mul(num, fq3_sub(at, fq3_from_fq(j)));
-            den = fq3_mul(den, fq3_sub(fq3_from_fq(i), fq3_from_fq(j)));
+            num = fqe_mul(num, fqe_sub(at, fqe_from_fq(j)));
+            den = fqe_mul(den, fqe_sub(fqe_from_fq(i), fqe_from_fq(j)));
         }
-        fq3 w = fq3_mul(num, fq3_inv(den));
-        rq_mul_fq3(t, p_i + (size_t)i * RE, w);
+        fqe w = fqe_mul(num, fqe_inv(den));
+        rq_mul_fqe(t, p_i + (size_t)i * RE, w);
         rq_add(res, res, t);
     }
     rq_copy(out, res);

@@ -3,66 +3,84 @@
 #include "lfo_field.h"
 #include <stdlib.h>
 
-u64 lfo_NONRES = 1ULL << 40; /* default: 2^40, a primitive 24th root of unity (order checked in init) */
+u64 lfo_NONRES = 0; /* set by default_ring(): a primitive 24th root of unity (Goldilocks: 2^40) */
+
+int lfo_ring_degree(void) { return LFO_D; }
+int lfo_ring_tau(void) { return LFO_TAU; }
+u64 lfo_modulus(void) { return LFO_P; }
 
 static int g_digit_mode = 0;
 static int g_init = 0;
-static fq3 g_y[8];        /* image of X in slot k */
-static fq3 g_ypow[8][24]; /* y_k^i */
-static u64 g_icrt[24][24]; /* inverse of the 24x24 F_p matrix of CRT */
+static fqe g_y[8];         /* image of X in slot k */
+static fqe g_ypow[8][RE];  /* y_k^i */
+static u64 g_icrt[RE][RE]; /* inverse of the d x d F_p matrix of CRT */
 
-static fq3 fq3_pow_small(fq3 a, unsigned e) {
-    fq3 r = fq3_one();
-    while (e--) r = fq3_mul(r, a);
+static fqe fqe_pow_small(fqe a, unsigned e) {
+    fqe r = fqe_one();
+    while (e--) r = fqe_mul(r, a);
     return r;
 }
 
 static int build_tables(void) {
     /* CRT as an F_p-linear map: out[3k+c] = sum_i a_i * (y_k^i).c   */
-    static u64 M[24][48];
+    static u64 M[RE][2 * RE];
     for (int k = 0; k < 8; k++) {
-        fq3 p = fq3_one();
-        for (int i = 0; i < 24; i++) {
+        fqe p = fqe_one();
+        for (int i = 0; i < RE; i++) {
             g_ypow[k][i] = p;
-            for (int c = 0; c < 3; c++) M[3 * k + c][i] = p.c[c];
-            p = fq3_mul(p, g_y[k]);
+            for (int c = 0; c < TAU; c++) M[TAU * k + c][i] = p.c[c];
+            p = fqe_mul(p, g_y[k]);
         }
     }
-    for (int r = 0; r < 24; r++)
-        for (int c = 0; c < 24; c++) M[r][24 + c] = (r == c);
+    for (int r = 0; r < RE; r++)
+        for (int c = 0; c < RE; c++) M[r][RE + c] = (r == c);
     /* Gauss-Jordan over F_p */
-    for (int col = 0; col < 24; col++) {
+    for (int col = 0; col < RE; col++) {
         int piv = -1;
-        for (int r = col; r < 24; r++)
+        for (int r = col; r < RE; r++)
             if (M[r][col]) { piv = r; break; }
         if (piv < 0) return -1; /* not an isomorphism */
         if (piv != col)
-            for (int c = 0; c < 48; c++) { u64 t = M[piv][c]; M[piv][c] = M[col][c]; M[col][c] = t; }
+            for (int c = 0; c < 2 * RE; c++) { u64 t = M[piv][c]; M[piv][c] = M[col][c]; M[col][c] = t; }
         u64 inv = fq_inv(M[col][col]);
-        for (int c = 0; c < 48; c++) M[col][c] = fq_mul(M[col][c], inv);
-        for (int r = 0; r < 24; r++) {
+        for (int c = 0; c < 2 * RE; c++) M[col][c] = fq_mul(M[col][c], inv);
+        for (int r = 0; r < RE; r++) {
             if (r == col || !M[r][col]) continue;
             u64 f = M[r][col];
-            for (int c = 0; c < 48; c++) M[r][c] = fq_sub(M[r][c], fq_mul(f, M[col][c]));
+            for (int c = 0; c < 2 * RE; c++) M[r][c] = fq_sub(M[r][c], fq_mul(f, M[col][c]));
         }
     }
-    for (int r = 0; r < 24; r++)
-        for (int c = 0; c < 24; c++) g_icrt[r][c] = M[r][24 + c];
+    for (int r = 0; r < RE; r++)
+        for (int c = 0; c < RE; c++) g_icrt[r][c] = M[r][RE + c];
     return 0;
 }
 
+/* smallest primitive 24th root of unity found from generator candidates (BabyBear); Goldilocks uses 2^40 */
+static u64 default_zeta(void) {
+#ifdef LFO_RING_BABYBEAR
+    for (u64 g = 2;; g++) {
+        u64 z = fq_pow(g, (LFO_P - 1) / 24);
+        if (fq_pow(z, 12) != 1 && fq_pow(z, 8) != 1) return z; /* order exactly 24 */
+    }
+#else
+    return 1ULL << 40;
+#endif
+}
+
 static void default_ring(void) {
-    /* Phi_72(X) = prod_{e in (Z/24)^*} (X^3 - zeta^e), zeta = 2^40 (order 24).  With
-     * F_{p^3} = F_p[Y]/(Y^3 - zeta):  slot for e = 1 mod 3 uses X -> zeta^((e-1)/3) * Y,
-     * slot for e = 2 mod 3 uses X -> zeta^((e-2)/3) * Y^2.  Slots in ascending e. */
+    /* Phi(X) = prod_{e in (Z/24)^*} (X^tau - zeta^e), zeta of order 24, tau in {3, 9}.  With
+     * F_{p^tau} = F_p[Y]/(Y^tau - zeta): slot e = 1 mod 3 uses X -> zeta^a * Y, slot e = 2 mod 3 uses
+     * X -> zeta^a * Y^2, where tau*a = (e - g) mod 24, g = e mod 3 (so that (zeta^a Y^g)^tau = zeta^e).
+     * Slots in ascending e.  For tau = 3 this is a = (e-g)/3 (the map used since round 1). */
     static const int E[8] = {1, 5, 7, 11, 13, 17, 19, 23};
-    u64 zeta = 1ULL << 40;
+    u64 zeta = default_zeta();
     lfo_NONRES = zeta;
     for (int k = 0; k < 8; k++) {
-        int e = E[k];
-        fq3 y = fq3_zero();
-        if (e % 3 == 1) y.c[1] = fq_pow(zeta, (e - 1) / 3);
-        else y.c[2] = fq_pow(zeta, (e - 2) / 3);
+        int e = E[k], g = e % 3, a = -1;
+        for (int t = 0; t < 24; t++)
+            if ((TAU * t) % 24 == (e - g) % 24) { a = t; break; }
+        fqe y = fqe_zero();
+        y.c[g] = fq_pow(zeta, (u64)a);
         g_y[k] = y;
     }
 }
@@ -77,16 +95,17 @@ static void ensure_init(void) {
 int lfo_set_ring(u64 nonres, const u64 *y) {
     ensure_init();
     u64 old_nr = lfo_NONRES;
-    fq3 old_y[8];
+    fqe old_y[8];
     memcpy(old_y, g_y, sizeof(old_y));
     lfo_NONRES = nonres % LFO_P;
     int ok = 1;
     u64 roots[8];
     for (int k = 0; k < 8 && ok; k++) {
-        fq3 v = {{y[3 * k] % LFO_P, y[3 * k + 1] % LFO_P, y[3 * k + 2] % LFO_P}};
+        fqe v;
+        for (int c = 0; c < TAU; c++) v.c[c] = y[TAU * k + c] % LFO_P;
         g_y[k] = v;
-        fq3 cube = fq3_pow_small(v, 3);
-        if (cube.c[1] || cube.c[2]) ok = 0;
+        fqe cube = fqe_pow_small(v, TAU);
+        for (int c = 1; c < TAU; c++) if (cube.c[c]) ok = 0;
         u64 z = cube.c[0];
         roots[k] = z;
         /* z must be a root of Phi_24(Y) = Y^8 - Y^4 + 1 */
@@ -109,16 +128,14 @@ void lfo_get_ring(u64 *nonres, u64 *y) {
     ensure_init();
     *nonres = lfo_NONRES;
     for (int k = 0; k < 8; k++)
-        for (int c = 0; c < 3; c++) y[3 * k + c] = g_y[k].c[c];
+        for (int c = 0; c < TAU; c++) y[TAU * k + c] = g_y[k].c[c];
 }
 
 void lfo_set_digit_mode(int mode) { g_digit_mode = mode; }
 
-void lfo_fq3_mul(const u64 *a, const u64 *b, u64 *out) {
+void lfo_fq3_mul(const u64 *a, const u64 *b, u64 *out) { /* F_{p^tau} product (name kept from the Goldilocks build) */
     ensure_init();
-    fq3 x = {{a[0], a[1], a[2]}}, y = {{b[0], b[1], b[2]}};
-    fq3 r = fq3_mul(x, y);
-    out[0] = r.c[0]; out[1] = r.c[1]; out[2] = r.c[2];
+    fqe_store(out, fqe_mul(fqe_load(a), fqe_load(b)));
 }
 
 /* CRT: slot_k = a(y_k) evaluated in F_{p^3} */
@@ -126,15 +143,15 @@ void lfo_crt(const u64 *in, u64 *out, size_t count) {
     ensure_init();
 #pragma omp parallel for schedule(static) if (count >= 4096)
     for (size_t e = 0; e < count; e++) {
-        const u64 *a = in + 24 * e;
-        u64 res[24];
+        const u64 *a = in + RE * e;
+        u64 res[RE];
         for (int k = 0; k < 8; k++) {
-            fq3 acc = fq3_zero();
-            for (int i = 0; i < 24; i++)
-                if (a[i]) acc = fq3_add(acc, fq3_mul_fq(g_ypow[k][i], a[i]));
+            fqe acc = fqe_zero();
+            for (int i = 0; i < RE; i++)
+                if (a[i]) acc = fqe_add(acc, fqe_mul_fq(g_ypow[k][i], a[i]));
             rq_set_slot(res, k, acc);
         }
-        memcpy(out + 24 * e, res, sizeof(res));
+        memcpy(out + RE * e, res, sizeof(res));
     }
 }
 
@@ -142,36 +159,36 @@ void lfo_icrt(const u64 *in, u64 *out, size_t count) {
     ensure_init();
 #pragma omp parallel for schedule(static) if (count >= 4096)
     for (size_t e = 0; e < count; e++) {
-        const u64 *x = in + 24 * e;
-        u64 res[24];
-        for (int i = 0; i < 24; i++) {
+        const u64 *x = in + RE * e;
+        u64 res[RE];
+        for (int i = 0; i < RE; i++) {
             u64 acc = 0;
-            for (int j = 0; j < 24; j++)
+            for (int j = 0; j < RE; j++)
                 if (x[j]) acc = fq_add(acc, fq_mul(g_icrt[i][j], x[j]));
             res[i] = acc;
         }
-        memcpy(out + 24 * e, res, sizeof(res));
+        memcpy(out + RE * e, res, sizeof(res));
     }
 }
 
 void lfo_ring_mul_ntt(const u64 *a, const u64 *b, u64 *out, size_t count) {
     ensure_init();
-    for (size_t e = 0; e < count; e++) rq_mul(out + 24 * e, a + 24 * e, b + 24 * e);
+    for (size_t e = 0; e < count; e++) rq_mul(out + RE * e, a + RE * e, b + RE * e);
 }
 
-/* multiply by X in Z_p[X]/(X^24 - X^12 + 1) */
+/* multiply by X in Z_p[X]/(X^d - X^(d/2) + 1) */
 static void rot_x(u64 *a) {
-    u64 top = a[23];
-    for (int i = 23; i > 0; i--) a[i] = a[i - 1];
+    u64 top = a[RE - 1];
+    for (int i = RE - 1; i > 0; i--) a[i] = a[i - 1];
     a[0] = fq_neg(top);
-    a[12] = fq_add(a[12], top);
+    a[RE / 2] = fq_add(a[RE / 2], top);
 }
 
 void lfo_ring_mul_coeff(const u64 *a, const u64 *b, u64 *out) {
-    u64 rot[24], acc[24] = {0};
+    u64 rot[RE], acc[RE] = {0};
     memcpy(rot, a, sizeof(rot));
-    for (int i = 0; i < 24; i++) {
-        for (int j = 0; j < 24; j++) acc[j] = fq_add(acc[j], fq_mul(rot[j], b[i]));
+    for (int i = 0; i < RE; i++) {
+        for (int j = 0; j < RE; j++) acc[j] = fq_add(acc[j], fq_mul(rot[j], b[i]));
         rot_x(rot);
     }
     memcpy(out, acc, sizeof(acc));
@@ -212,11 +229,11 @@ void lfo_decompose(const u64 *in, size_t count, u64 base, u32 digits, int layout
 #pragma omp parallel for schedule(static) if (count >= 4096)
     for (size_t e = 0; e < count; e++) {
         int64_t dg[64];
-        for (int c = 0; c < 24; c++) {
-            decompose_coeff(in[24 * e + c], base, digits, dg);
+        for (int c = 0; c < RE; c++) {
+            decompose_coeff(in[RE * e + c], base, digits, dg);
             for (u32 k = 0; k < digits; k++) {
                 size_t idx = layout == 0 ? e * digits + k : (size_t)k * count + e;
-                out[24 * idx + c] = fq_from_i64(dg[k]);
+                out[RE * idx + c] = fq_from_i64(dg[k]);
             }
         }
     }
@@ -225,14 +242,14 @@ void lfo_decompose(const u64 *in, size_t count, u64 base, u32 digits, int layout
 void lfo_recompose(const u64 *in, size_t count_out, u64 base, u32 digits, u64 *out) {
 #pragma omp parallel for schedule(static) if (count_out >= 4096)
     for (size_t e = 0; e < count_out; e++) {
-        u64 acc[24] = {0};
+        u64 acc[RE] = {0};
         u64 pw = 1;
         for (u32 j = 0; j < digits; j++) {
-            const u64 *x = in + 24 * (e * digits + j);
-            for (int c = 0; c < 24; c++) acc[c] = fq_add(acc[c], fq_mul(x[c], pw));
+            const u64 *x = in + RE * (e * digits + j);
+            for (int c = 0; c < RE; c++) acc[c] = fq_add(acc[c], fq_mul(x[c], pw));
             pw = fq_mul(pw, base % LFO_P);
         }
-        memcpy(out + 24 * e, acc, sizeof(acc));
+        memcpy(out + RE * e, acc, sizeof(acc));
     }
 }
 
@@ -241,26 +258,28 @@ void lfo_recompose(const u64 *in, size_t count_out, u64 base, u32 digits, u64 *o
  * (KAT-verified); result: tau_elems NTT-form elements. */
 void lfo_rot_lin_combination(const u64 *rho_coeff, const u64 *theta, u32 n, u32 tau_elems, u64 *out) {
     ensure_init();
-    u32 flat = tau_elems * 8; /* number of F_{p^3} entries; must equal ring degree 24 */
-    fq3 res[24];
-    for (int j = 0; j < 24; j++) res[j] = fq3_zero();
+    u32 flat = tau_elems * 8; /* number of F_{p^tau} entries; must equal the ring degree */
+    static fqe res[RE];
+    for (int j = 0; j < RE; j++) res[j] = fqe_zero();
     for (u32 i = 0; i < n; i++) {
-        u64 rot[24];
-        memcpy(rot, rho_coeff + 24 * i, sizeof(rot));
-        const u64 *th = theta + (size_t)24 * tau_elems * i;
-        for (u32 bi = 0; bi < flat && bi < 24; bi++) {
-            fq3 b = {{th[3 * bi], th[3 * bi + 1], th[3 * bi + 2]}};
-            for (int j = 0; j < 24; j++) res[j] = fq3_add(res[j], fq3_mul_fq(b, rot[j]));
+        u64 rot[RE];
+        memcpy(rot, rho_coeff + (size_t)RE * i, sizeof(rot));
+        const u64 *th = theta + (size_t)RE * tau_elems * i;
+        for (u32 bi = 0; bi < flat && bi < RE; bi++) {
+            fqe b = fqe_load(th + TAU * bi);
+            for (int j = 0; j < RE; j++) res[j] = fqe_add(res[j], fqe_mul_fq(b, rot[j]));
             rot_x(rot);
         }
     }
-    for (int j = 0; j < 24; j++) { out[3 * j] = res[j].c[0]; out[3 * j + 1] = res[j].c[1]; out[3 * j + 2] = res[j].c[2]; }
+    for (int j = 0; j < RE; j++) fqe_store(out + TAU * j, res[j]);
 }
 
-/* GoldilocksChallengeSet::short_challenge_from_random_bytes, rings/goldilocks.rs:36-68:
- * 24 six-bit fields, LSB-first within each 3-byte group, each minus 32. */
+/* {Goldilocks,BabyBear}ChallengeSet::short_challenge_from_random_bytes, rings/goldilocks.rs:36-68,
+ * rings/babybear.rs:36-68: 24 six-bit fields, LSB-first within each 3-byte group, each minus 32;
+ * BabyBear builds the degree-72 polynomial from these 24 coefficients (higher ones zero). */
 int lfo_short_challenge_from_bytes(const uint8_t *bs, size_t n, u64 *coeff_out) {
     if (n != 18) return -1;
+    memset(coeff_out, 0, RE * sizeof(u64));
     for (int g = 0; g < 6; g++) {
         u32 w = (u32)bs[3 * g] | ((u32)bs[3 * g + 1] << 8) | ((u32)bs[3 * g + 2] << 16);
         for (int j = 0; j < 4; j++) coeff_out[4 * g + j] = fq_from_i64((int64_t)((w >> (6 * j)) & 63) - 32);

@@ -1,6 +1,8 @@
 """ctypes binding of the CPU oracle (oracle/liblfo.so).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+This module binds the GoldilocksRingNTT build; tests/lfo_bb.py re-executes the same source with
+_RING = "babybear" to bind oracle/liblfo_bb.so (BabyBearRingNTT, d = 72, tau = 9).
 """
 import ctypes as C
 import os
@@ -10,11 +12,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_DIR = os.path.join(_HERE, "..", "oracle")
-_SO = os.path.join(_ORACLE_DIR, "liblfo.so")
+_RING = globals().get("_RING", "goldilocks")
+_SO = os.path.join(_ORACLE_DIR, "liblfo.so" if _RING == "goldilocks" else "liblfo_bb.so")
 
-P = 2**64 - 2**32 + 1
-RE = 24
-TAU = 3
+P, RE, TAU = {"goldilocks": (2**64 - 2**32 + 1, 24, 3), "babybear": (15 * 2**27 + 1, 72, 9)}[_RING]
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
 
@@ -73,6 +74,8 @@ def lib():
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         build()
         L = C.CDLL(_SO)
+        L.lfo_modulus.restype = C.c_uint64
+        assert L.lfo_modulus() == P and L.lfo_ring_degree() == RE and L.lfo_ring_tau() == TAU
         L.lfo_num_threads.restype = C.c_int
         L.lfo_set_num_threads.argtypes = [C.c_int]
         L.lfo_set_num_threads(int(os.environ["OMP_NUM_THREADS"]))  # explicit: another runtime (torch) may have initialised OpenMP already
@@ -128,7 +131,7 @@ class Transcript:
         lib().lfo_transcript_absorb_ring(self.h, _p64(a), a.size // RE)
 
     def challenge(self):
-        o = np.zeros(3, dtype=np.uint64)
+        o = np.zeros(TAU, dtype=np.uint64)
         lib().lfo_transcript_get_challenge(self.h, _p64(o))
         return o
 
@@ -192,7 +195,7 @@ def mle_eval(table, r_ring):
     return o
 
 
-def rot_lin_combination(rho_coeff, theta, n, tau_elems=3):
+def rot_lin_combination(rho_coeff, theta, n, tau_elems=TAU):
     a = np.ascontiguousarray(rho_coeff, dtype=np.uint64).reshape(-1)
     b = np.ascontiguousarray(theta, dtype=np.uint64).reshape(-1)
     o = np.zeros(tau_elems * RE, dtype=np.uint64)

@@ -48,6 +48,16 @@ def main():
         "bytes": bs, "coeffs": co,
     }
 
+    # --- crates/cyclotomic-rings/src/rings/babybear.rs:77-114
+    src = between(read("crates/cyclotomic-rings/src/rings/babybear.rs"), "fn test_small_challenge_from_random_bytes")
+    bs = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{2})", between(src, "short_challenge_from_random_bytes(&[", "])"))]
+    co = [int(x) for x in re.findall(r"BigInt\(\[(\d+)\]\)", src)]
+    assert len(bs) == 18 and len(co) == 24
+    kats["babybear_small_challenge_from_bytes"] = {
+        "source": "crates/cyclotomic-rings/src/rings/babybear.rs:77-114",
+        "bytes": bs, "coeffs": co,
+    }
+
     # --- crates/latticefold/src/transcript/poseidon.rs:85-142
     src = read("crates/latticefold/src/transcript/poseidon.rs")
     big = between(src, "fn test_get_big_challenge", "fn test_get_small_challenge")
@@ -82,6 +92,21 @@ def main():
         "mds_checksum": sum((i + 1) * v for i, v in enumerate(vals[720:])) % p,
     }
 
+    # BabyBear table (rings/poseidon/babybear.rs:7-1425): the same 64-bit literals, embedded with Fq::from(i128)
+    # (i.e. reduced mod p_BB = 15*2^27+1) -- pinned by checksums of the reduced values
+    srcb = read("crates/cyclotomic-rings/src/rings/poseidon/babybear.rs")
+    valsb = [int(x, 16) for x in re.findall(r"Fq::from\(0x([0-9a-f]+)_i128\)", srcb)]
+    assert len(valsb) == 30 * 24 + 24 * 24
+    pb = 15 * 2**27 + 1
+    kats["poseidon_babybear_params"] = {
+        "source": "crates/cyclotomic-rings/src/rings/poseidon/babybear.rs:7-1425",
+        "full_rounds": 8, "partial_rounds": 22, "alpha": 7, "rate": 20, "capacity": 4,
+        "same_literals_as_goldilocks": valsb == vals,
+        "ark_first": [v % pb for v in valsb[:4]], "mds_last": [v % pb for v in valsb[-4:]],
+        "ark_checksum": sum((i + 1) * (v % pb) for i, v in enumerate(valsb[:720])) % pb,
+        "mds_checksum": sum((i + 1) * (v % pb) for i, v in enumerate(valsb[720:])) % pb,
+    }
+
     # --- crates/latticefold/src/arith.rs:455-502  test_get_fhat (inputs are written as code there;
     # restated here as data: coefficient vectors and the expected slot values)
     kats["get_fhat"] = {
@@ -107,6 +132,8 @@ def main():
     kats["decomposition_params"] = {
         "source": "crates/latticefold/src/decomposition_parameters.rs:89-105; benches/config.toml:156,163",
         "GoldilocksDP": {"B": 1 << 15, "L": 5, "b": 2, "K": 15},
+        "BabyBearDP": {"B": 1 << 8, "L": 4, "b": 2, "K": 8},
+        "C3": {"B": 1 << 16, "L": 2, "b": 2, "K": 16, "kappa": 16, "wit_len": 1 << 17},
         "C2": {"B": 1 << 16, "L": 4, "b": 2, "K": 16, "kappa": 25, "wit_len": 16384},
         "C4": {"B": 1 << 16, "L": 4, "b": 2, "K": 16, "kappa": 26, "wit_len": 1 << 18},
     }
