@@ -49,7 +49,19 @@ typedef struct lf_witness lf_witness;       /* device-resident Witness (arith.rs
 typedef struct lf_transcript lf_transcript; /* PoseidonTranscript (transcript/poseidon.rs:17-75), host */
 
 /* ---- context ------------------------------------------------------------------------------- */
-int lf_ctx_create(lf_ctx **out, int device);
+int lf_ctx_create(lf_ctx **out, int device);   /* GoldilocksRingNTT */
+/* Ring selection (cyclotomic-rings/src/rings/{goldilocks,babybear}.rs:1-25).  A context, its witnesses and the transcripts
+ * used with it belong to ONE ring; every entry point below then works on ring elements of lf_ring_words(ring) u64 words
+ * (24 / 72) and F_{p^tau} challenges of lf_ring_tau(ring) words (3 / 9), canonical residues of lf_ring_modulus(ring).
+ * BabyBearRingNTT (BASELINE configs[2]): p = 15*2^27+1, Phi_216 = X^72 - X^36 + 1, 8 slots of F_{p^9}; on the device the
+ * words are 31-bit centred Montgomery residues.  Not available for BabyBear: lf_set_ring_tables, intra-step sharding. */
+#define LF_RING_GOLDILOCKS 0
+#define LF_RING_BABYBEAR 1
+int lf_ctx_create_ring(lf_ctx **out, int device, int ring);
+int lf_ctx_ring(const lf_ctx *);
+int lf_ring_words(int ring);
+int lf_ring_tau(int ring);
+uint64_t lf_ring_modulus(int ring);
 void lf_ctx_destroy(lf_ctx *);
 /* The CRT slot map, the F_{p^3} non-residue and the digit rule live in the un-vendored crate
  * stark-rings @ 886a89f and are DATA here: y[8*3] = image of X in slot k.  Defaults are installed
@@ -127,6 +139,9 @@ int lf_spmv(lf_ctx *, unsigned j, const uint64_t *z, uint64_t *out);
 size_t lf_lcccs_len(const lf_params *); /* ring elements: r[s] v[3] cm[kappa] u[t] x_w[l] h */
 size_t lf_cccs_len(const lf_params *);  /* cm[kappa] x_ccs[l] */
 size_t lf_proof_len(const lf_params *); /* LFProof flat, see DESIGN.md */
+size_t lf_lcccs_len_ring(const lf_params *, int ring); /* same layouts with v[tau]: tau = 9 for BabyBear */
+size_t lf_cccs_len_ring(const lf_params *, int ring);
+size_t lf_proof_len_ring(const lf_params *, int ring);
 
 /* ---- Witness (arith.rs:230-338) ------------------------------------------------------------------ */
 int lf_witness_from_w_ccs(lf_ctx *, const uint64_t *w_ccs /* wit_len NTT */, lf_witness **out); /* from_w_ccs */
@@ -140,6 +155,7 @@ void lf_witness_free(lf_witness *);
 
 /* ---- transcript (transcript.rs:13-51) --------------------------------------------------------------- */
 lf_transcript *lf_transcript_new(void);
+lf_transcript *lf_transcript_new_ring(int ring);
 lf_transcript *lf_transcript_clone(const lf_transcript *);
 void lf_transcript_free(lf_transcript *);
 void lf_transcript_absorb_fq(lf_transcript *, const uint64_t *x, size_t n);       /* sponge.absorb */
@@ -150,6 +166,8 @@ void lf_poseidon_params(uint64_t *ark /* 720 */, uint64_t *mds /* 576 */);
 /* one Poseidon permutation on 24 words; plain != 0 selects the textbook round loop instead of the
  * (output-identical) sparse-matrix partial rounds the transcript uses */
 void lf_poseidon_permute(uint64_t *state, int plain);
+void lf_poseidon_params_ring(uint64_t *ark, uint64_t *mds, int ring);
+void lf_poseidon_permute_ring(uint64_t *state, int plain, int ring);
 
 /* ---- sumcheck split at the transcript (utils/sumcheck.rs:53-80, sumcheck/prover.rs:56-162) ---------
  * Generic entry for the linearization-shaped polynomial  comb = (sum_i c_i prod_{j in S_i} T_j) * T_last

@@ -3,7 +3,8 @@
 Names follow crates/latticefold: `AjtaiCommitmentScheme` (commitment/commitment_scheme.rs:17-114),
 `Witness` (arith.rs:213-362), `PoseidonTranscript` (transcript/poseidon.rs), `DecompositionParams`
 (decomposition_parameters.rs:11-20), `NIFSProver.prove` (nifs.rs:48-103), `CCS` (arith.rs:50-74).
-All bulk data are numpy uint64 arrays of canonical residues, shape (..., 24) per ring element.
+All bulk data are numpy uint64 arrays of canonical residues, shape (..., d) per ring element: d = 24 for
+GoldilocksRingNTT (default), d = 72 for BabyBearRingNTT (`Context(device, ring="babybear")`, `PoseidonTranscript(ring=..)`).
 
 There is NO CPU fallback: if the HIP library is missing or no GPU is present every call raises.
 """
@@ -14,6 +15,9 @@ import numpy as np
 
 RE = 24
 P = 2**64 - 2**32 + 1
+RING_IDS = {"goldilocks": 0, "babybear": 1}   # LF_RING_* of include/lfhip.h
+RING_WORDS = {"goldilocks": 24, "babybear": 72}
+RING_TAU = {"goldilocks": 3, "babybear": 9}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liblfhip.so")
 
@@ -56,6 +60,19 @@ def _lib():
         L.lf_strerror.restype = C.c_char_p
         L.lf_strerror.argtypes = [C.c_int]
         L.lf_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.lf_ctx_create_ring.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        L.lf_ctx_ring.argtypes = [vp]
+        L.lf_ring_modulus.restype = C.c_uint64
+        L.lf_ring_modulus.argtypes = [C.c_int]
+        for f in ("lf_lcccs_len_ring", "lf_cccs_len_ring", "lf_proof_len_ring"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [C.POINTER(Params), C.c_int]
+        L.lf_transcript_new_ring.restype = vp
+        L.lf_transcript_new_ring.argtypes = [C.c_int]
+        L.lf_poseidon_params_ring.argtypes = [u64p, u64p, C.c_int]
+        L.lf_poseidon_params_ring.restype = None
+        L.lf_poseidon_permute_ring.argtypes = [u64p, C.c_int, C.c_int]
+        L.lf_poseidon_permute_ring.restype = None
         L.lf_ctx_destroy.argtypes = [vp]
         L.lf_ctx_destroy.restype = None
         L.lf_set_ring_tables.argtypes = [vp, C.c_uint64, u64p]
@@ -140,9 +157,13 @@ def _chk(rc, where):
 class Context:
     """Owns the device memory (lf_ctx).  One per GPU / process."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, ring="goldilocks"):
         self.h = C.c_void_p()
-        _chk(_lib().lf_ctx_create(C.byref(self.h), device), "lf_ctx_create")
+        self.ring = ring
+        self.ring_id = RING_IDS[ring]
+        self.RE = RING_WORDS[ring]
+        self.TAU = RING_TAU[ring]
+        _chk(_lib().lf_ctx_create_ring(C.byref(self.h), device, self.ring_id), "lf_ctx_create_ring")
         self.params = None
 
     def close(self):
@@ -163,7 +184,7 @@ class Context:
 
     def get_ring_tables(self):
         nr = C.c_uint64()
-        y = np.zeros(24, dtype=np.uint64)
+        y = np.zeros(8 * self.TAU, dtype=np.uint64)
         _chk(_lib().lf_get_ring_tables(self.h, C.cast(C.byref(nr), u64p), y.ctypes.data_as(u64p)), "lf_get_ring_tables")
         return nr.value, y
 
@@ -201,26 +222,26 @@ class Context:
     def crt(self, coeff):  # CRT::elementwise_crt
         a, p = _a64(coeff)
         o = np.empty_like(a)
-        _chk(_lib().lf_ntt_fwd(self.h, p, o.ctypes.data_as(u64p), a.size // RE), "lf_ntt_fwd")
+        _chk(_lib().lf_ntt_fwd(self.h, p, o.ctypes.data_as(u64p), a.size // self.RE), "lf_ntt_fwd")
         return o
 
     def icrt(self, ntt):  # ICRT::elementwise_icrt
         a, p = _a64(ntt)
         o = np.empty_like(a)
-        _chk(_lib().lf_ntt_inv(self.h, p, o.ctypes.data_as(u64p), a.size // RE), "lf_ntt_inv")
+        _chk(_lib().lf_ntt_inv(self.h, p, o.ctypes.data_as(u64p), a.size // self.RE), "lf_ntt_inv")
         return o
 
     def decompose(self, coeff, base, digits, layout):
         a, p = _a64(coeff)
-        cnt = a.size // RE
-        o = np.zeros((cnt * digits, RE), dtype=np.uint64)
+        cnt = a.size // self.RE
+        o = np.zeros((cnt * digits, self.RE), dtype=np.uint64)
         _chk(_lib().lf_decompose(self.h, p, cnt, base, digits, layout, o.ctypes.data_as(u64p)), "lf_decompose")
         return o
 
     def recompose(self, x, base, digits):
         a, p = _a64(x)
-        cnt = a.size // RE // digits
-        o = np.zeros((cnt, RE), dtype=np.uint64)
+        cnt = a.size // self.RE // digits
+        o = np.zeros((cnt, self.RE), dtype=np.uint64)
         _chk(_lib().lf_recompose(self.h, p, cnt, base, digits, o.ctypes.data_as(u64p)), "lf_recompose")
         return o
 
@@ -228,13 +249,13 @@ class Context:
         a, p = _a64(f_ntt)
         ok = C.c_int()
         mx = C.c_uint64()
-        _chk(_lib().lf_linf_check(self.h, p, a.size // RE, bound, int(unsigned_variant), C.byref(ok), C.cast(C.byref(mx), u64p)), "lf_linf_check")
+        _chk(_lib().lf_linf_check(self.h, p, a.size // self.RE, bound, int(unsigned_variant), C.byref(ok), C.cast(C.byref(mx), u64p)), "lf_linf_check")
         return bool(ok.value), mx.value
 
     def build_eq(self, point):
         a, p = _a64(point)
-        nv = a.size // 3
-        o = np.zeros(((1 << nv), 3), dtype=np.uint64)
+        nv = a.size // self.TAU
+        o = np.zeros(((1 << nv), self.TAU), dtype=np.uint64)
         _chk(_lib().lf_build_eq(self.h, p, nv, o.ctypes.data_as(u64p)), "lf_build_eq")
         return o
 
@@ -242,8 +263,8 @@ class Context:
         a, p = _a64(tables)
         nt, ln = a.shape[0], a.shape[1]
         b, q = _a64(point)
-        o = np.zeros((nt, RE), dtype=np.uint64)
-        _chk(_lib().lf_mle_eval_batch(self.h, p, nt, ln, q, b.size // 3, o.ctypes.data_as(u64p)), "lf_mle_eval_batch")
+        o = np.zeros((nt, self.RE), dtype=np.uint64)
+        _chk(_lib().lf_mle_eval_batch(self.h, p, nt, ln, q, b.size // self.TAU, o.ctypes.data_as(u64p)), "lf_mle_eval_batch")
         return o
 
     # ---- CCS -------------------------------------------------------------------------------
@@ -263,16 +284,16 @@ class Context:
         _chk(_lib().lf_ccs_load(self.h, C.byref(self.params), C.cast(rpp, C.POINTER(u32p)), C.cast(cip, C.POINTER(u32p)),
                                 C.cast(vap, C.POINTER(u64p)), so.ctypes.data_as(u32p), si.ctypes.data_as(u32p),
                                 cc.ctypes.data_as(u64p)), "lf_ccs_load")
-        self.lcccs_len = _lib().lf_lcccs_len(C.byref(self.params))
-        self.cccs_len = _lib().lf_cccs_len(C.byref(self.params))
-        self.proof_len = _lib().lf_proof_len(C.byref(self.params))
+        self.lcccs_len = _lib().lf_lcccs_len_ring(C.byref(self.params), self.ring_id)
+        self.cccs_len = _lib().lf_cccs_len_ring(C.byref(self.params), self.ring_id)
+        self.proof_len = _lib().lf_proof_len_ring(C.byref(self.params), self.ring_id)
         self.N = wl.N
         self.m = wl.m
         self.n = wl.n
 
     def mat_vec_mul(self, j, z):  # arith/utils.rs:52-65
         a, p = _a64(z)
-        o = np.zeros((self.m, RE), dtype=np.uint64)
+        o = np.zeros((self.m, self.RE), dtype=np.uint64)
         _chk(_lib().lf_spmv(self.h, j, p, o.ctypes.data_as(u64p)), "lf_spmv")
         return o
 
@@ -308,11 +329,11 @@ class AjtaiCommitmentScheme:
         return self._n
 
     def commit_ntt(self, f):
-        """commit / commit_ntt: f is (n,24) or (batch,n,24)."""
+        """commit / commit_ntt: f is (n,d) or (batch,n,d)."""
         a, p = _a64(f)
         batch = 1 if a.ndim == 2 else a.shape[0]
         n = a.shape[-2]
-        o = np.zeros((batch, self._kappa, RE), dtype=np.uint64)
+        o = np.zeros((batch, self._kappa, self.ctx.RE), dtype=np.uint64)
         rc = _lib().lf_ajtai_commit(self.ctx.h, p, n, batch, o.ctypes.data_as(u64p))
         if rc == -1:
             raise CommitmentError(rc, f"WrongWitnessLength({n}, {self._n})")
@@ -350,7 +371,7 @@ class Witness:
         return cls(ctx, h)
 
     def _get(self, fn, count):
-        o = np.zeros((count, RE), dtype=np.uint64)
+        o = np.zeros((count, self.ctx.RE), dtype=np.uint64)
         _chk(fn(self.ctx.h, self.h, o.ctypes.data_as(u64p)), "lf_witness_get")
         return o
 
@@ -367,7 +388,7 @@ class Witness:
         return self._get(_lib().lf_witness_get_w_ccs, self.ctx.params.wit_len)
 
     def commit(self, scheme):
-        o = np.zeros((scheme.kappa(), RE), dtype=np.uint64)
+        o = np.zeros((scheme.kappa(), self.ctx.RE), dtype=np.uint64)
         _chk(_lib().lf_witness_commit(self.ctx.h, self.h, o.ctypes.data_as(u64p)), "lf_witness_commit")
         return o
 
@@ -386,11 +407,13 @@ class Witness:
 class PoseidonTranscript:
     """transcript/poseidon.rs:17-75 (host)."""
 
-    def __init__(self, handle=None):
-        self.h = handle or C.c_void_p(_lib().lf_transcript_new())
+    def __init__(self, handle=None, ring="goldilocks"):
+        self.ring = ring
+        self.RE, self.TAU = RING_WORDS[ring], RING_TAU[ring]
+        self.h = handle or C.c_void_p(_lib().lf_transcript_new_ring(RING_IDS[ring]))
 
     def clone(self):
-        return PoseidonTranscript(C.c_void_p(_lib().lf_transcript_clone(self.h)))
+        return PoseidonTranscript(C.c_void_p(_lib().lf_transcript_clone(self.h)), ring=self.ring)
 
     def absorb_fq(self, xs):
         a, p = _a64(xs)
@@ -398,17 +421,17 @@ class PoseidonTranscript:
 
     def absorb_slice(self, elems):
         a, p = _a64(elems)
-        _lib().lf_transcript_absorb_ring(self.h, p, a.size // RE)
+        _lib().lf_transcript_absorb_ring(self.h, p, a.size // self.RE)
 
     absorb = absorb_slice
 
     def get_challenge(self):
-        o = np.zeros(3, dtype=np.uint64)
+        o = np.zeros(self.TAU, dtype=np.uint64)
         _lib().lf_transcript_get_challenge(self.h, o.ctypes.data_as(u64p))
         return o
 
     def get_short_challenge(self):
-        o = np.zeros(RE, dtype=np.uint64)
+        o = np.zeros(self.RE, dtype=np.uint64)
         _lib().lf_transcript_get_short_challenge(self.h, o.ctypes.data_as(u64p))
         return o
 
@@ -421,16 +444,16 @@ class PoseidonTranscript:
             pass
 
 
-def poseidon_params():
+def poseidon_params(ring="goldilocks"):
     ark = np.zeros(720, dtype=np.uint64)
     mds = np.zeros(576, dtype=np.uint64)
-    _lib().lf_poseidon_params(ark.ctypes.data_as(u64p), mds.ctypes.data_as(u64p))
+    _lib().lf_poseidon_params_ring(ark.ctypes.data_as(u64p), mds.ctypes.data_as(u64p), RING_IDS[ring])
     return ark, mds
 
 
-def poseidon_permute(state, plain=False):
+def poseidon_permute(state, plain=False, ring="goldilocks"):
     a = np.ascontiguousarray(state, dtype=np.uint64).copy()
-    _lib().lf_poseidon_permute(a.ctypes.data_as(u64p), int(plain))
+    _lib().lf_poseidon_permute_ring(a.ctypes.data_as(u64p), int(plain), RING_IDS[ring])
     return a
 
 
@@ -439,9 +462,9 @@ class LFLinearizationProver:
     def prove(ctx, cm_i, wit, transcript):
         """nifs/linearization.rs:145-189 -> (lcccs flat, linearization proof flat)."""
         a, p = _a64(cm_i)
-        lc = np.zeros((ctx.lcccs_len, RE), dtype=np.uint64)
+        lc = np.zeros((ctx.lcccs_len, ctx.RE), dtype=np.uint64)
         prm = ctx.params
-        pr = np.zeros((prm.s * (prm.d + 2) + 3 + prm.t, RE), dtype=np.uint64)
+        pr = np.zeros((prm.s * (prm.d + 2) + ctx.TAU + prm.t, ctx.RE), dtype=np.uint64)
         _chk(_lib().lf_linearize(ctx.h, transcript.h, p, wit.h, lc.ctypes.data_as(u64p), pr.ctypes.data_as(u64p)), "lf_linearize")
         return lc, pr
 
@@ -453,8 +476,8 @@ class NIFSProver:
         reference signature are the ones loaded into ctx (load_ccs / AjtaiCommitmentScheme)."""
         a, pa = _a64(acc)
         b, pb = _a64(cm_i)
-        lc = np.zeros((ctx.lcccs_len, RE), dtype=np.uint64)
-        pr = np.zeros((ctx.proof_len, RE), dtype=np.uint64)
+        lc = np.zeros((ctx.lcccs_len, ctx.RE), dtype=np.uint64)
+        pr = np.zeros((ctx.proof_len, ctx.RE), dtype=np.uint64)
         h = C.c_void_p()
         _chk(_lib().lf_fold_step(ctx.h, transcript.h, pa, w_acc.h, pb, w_i.h, lc.ctypes.data_as(u64p), C.byref(h),
                                  pr.ctypes.data_as(u64p)), "lf_fold_step")
@@ -472,7 +495,7 @@ class MLSumcheckLin:
 
     def prove_round(self, r_prev=None):
         prm = self.ctx.params
-        o = np.zeros((prm.d + 2, RE), dtype=np.uint64)
+        o = np.zeros((prm.d + 2, self.ctx.RE), dtype=np.uint64)
         if r_prev is None:
             rc = _lib().lf_sumcheck_lin_round(self.ctx.h, None, o.ctypes.data_as(u64p))
         else:

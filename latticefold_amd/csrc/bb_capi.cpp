@@ -1,0 +1,1198 @@
+// bb_capi.cpp -- BabyBearRingNTT backend of the C ABI: context, device-resident witnesses and the host driver that replays
+// `NIFSProver::prove` (crates/latticefold/src/nifs.rs:48-103) on the kernels of bb_kernels.hip.  Same structure as the
+// Goldilocks driver in lf_capi.cpp (f-hat virtual, Mz restructured, f_0 in the coefficient domain), one stream, no
+// intra-step sharding.  Host <-> device traffic inside a fold step is O(proof size).
+#include "bb_capi.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bb_kernels.h"
+#include "lf_common.h"
+
+namespace lfbb {
+
+static const int NPH = LF_N_PHASES;
+
+struct EvPair { hipEvent_t a, b; };
+
+struct BbCtxImpl {
+    lf_ctx *owner = nullptr;
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::mutex mu;
+    BbHostRing ring;
+    DevBb dev;
+    fe *d_icrt = nullptr;
+    fe *dA = nullptr;
+    u32 kappa = 0;
+    size_t nA = 0;
+    bool have_ccs = false;
+    lf_params P{};
+    size_t N = 0, m = 0, n = 0;
+    std::vector<u32 *> d_rowptr, d_col, d_colptr, d_rowidx;
+    std::vector<fe *> d_val, d_valT;
+    LinDesc desc{};
+    std::map<std::string, DevBuf> bufs;
+    u64 *h_pin = nullptr;
+    size_t h_pin_words = 0;
+    int sc_round = -1;
+    size_t sc_n = 0;
+    int sc_cur = 0;
+    // measurement
+    float phase_ms[NPH] = {0};
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<int, size_t>> ev_tags;
+    float k_fold_ms = 0, k_ajtai_ms = 0;
+    int k_fold_n = 0, k_ajtai_n = 0;
+    double host_tr_ms = 0;
+
+    hipStream_t stream() const { return st; }
+    int buf(const std::string &name, size_t bytes, void **out) {
+        DevBuf &b = bufs[name];
+        int rc = b.ensure(bytes);
+        *out = b.p;
+        return rc;
+    }
+    template <class T>
+    int tbuf(const std::string &name, size_t count, T **out) {
+        void *q;
+        int rc = buf(name, count * sizeof(T), &q);
+        *out = (T *)q;
+        return rc;
+    }
+    int pin(size_t words) {
+        if (words <= h_pin_words) return LF_OK;
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr;
+        if (words < 16384) words = 16384;
+        if (hipHostMalloc((void **)&h_pin, words * 8) != hipSuccess) return LF_ERR_HIP;
+        h_pin_words = words;
+        return LF_OK;
+    }
+    size_t ev_begin(int tag) {
+        if (ev_used == ev_pool.size()) {
+            EvPair e;
+            (void)hipEventCreate(&e.a);
+            (void)hipEventCreate(&e.b);
+            ev_pool.push_back(e);
+        }
+        size_t i = ev_used++;
+        (void)hipEventRecord(ev_pool[i].a, st);
+        ev_tags.push_back({tag, i});
+        return i;
+    }
+    void ev_end(size_t i) { (void)hipEventRecord(ev_pool[i].b, st); }
+    void ev_reset() { ev_used = 0; ev_tags.clear(); }
+    void ev_collect() {
+        (void)hipStreamSynchronize(st);
+        k_fold_ms = k_ajtai_ms = 0;
+        k_fold_n = k_ajtai_n = 0;
+        for (int i = 0; i < NPH; i++) phase_ms[i] = 0;
+        for (auto &tg : ev_tags) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev_pool[tg.second].a, ev_pool[tg.second].b);
+            if (tg.first == 0) { k_fold_ms += ms; k_fold_n++; }
+            else if (tg.first == 1) { k_ajtai_ms += ms; k_ajtai_n++; }
+            else if (tg.first >= 10 && tg.first < 10 + NPH) phase_ms[tg.first - 10] += ms;
+        }
+        phase_ms[6] = (float)host_tr_ms;
+    }
+};
+typedef BbCtxImpl C;
+
+struct HostTimer {
+    C *c;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(C *cc) : c(cc), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { c->host_tr_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+size_t bb_lcccs_len(const lf_params *p) { return (size_t)p->s + TAU + p->kappa + p->t + p->l + 1; }
+size_t bb_cccs_len(const lf_params *p) { return (size_t)p->kappa + p->l; }
+static size_t lin_proof_len(const lf_params *p) { return (size_t)p->s * (p->d + 2) + TAU + p->t; }
+static size_t dec_proof_len(const lf_params *p) { return (size_t)p->K * (p->t + TAU + p->l + 1 + p->kappa); }
+static size_t fold_proof_len(const lf_params *p) { return (size_t)p->s * (2 * p->b + 1) + 2 * (size_t)p->K * (TAU + p->t); }
+size_t bb_proof_len(const lf_params *p) { return lin_proof_len(p) + 2 * dec_proof_len(p) + fold_proof_len(p); }
+
+// ---------------------------------------------------------------------------------------------------------------
+static int install_tables(C *c, u64 nonres, const u64 *y) {
+    static thread_local BbTables T;
+    if (bb_build_tables(nonres, y, T) != 0) return LF_ERR_BAD_TABLES;
+    c->ring.T = T;
+    c->dev = make_dev_bb(T);
+    std::vector<fe> mat((size_t)D * D);
+    for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++) mat[(size_t)i * D + j] = from_canon(T.icrt[i][j]);
+    if (!c->d_icrt) HIPCHK(hipMalloc((void **)&c->d_icrt, mat.size() * sizeof(fe)));
+    HIPCHK(hipMemcpy(c->d_icrt, mat.data(), mat.size() * sizeof(fe), hipMemcpyHostToDevice));
+    return LF_OK;
+}
+int BbCtx::create(BbCtx **out, lf_ctx *owner, int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device < 0 || device >= cnt) return LF_ERR_HIP;
+    HIPCHK(hipSetDevice(device));
+    C *c = new C();
+    c->owner = owner;
+    c->device = device;
+    if (hipStreamCreate(&c->st) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    u64 nr, y[8 * TAU];
+    bb_default_ring(&nr, y);
+    int rc = install_tables(c, nr, y);
+    if (rc != LF_OK) { delete c; return rc; }
+    BbCtx *b = new BbCtx();
+    b->p = c;
+    *out = b;
+    return LF_OK;
+}
+static void free_ccs(C *c) {
+    for (auto q : c->d_rowptr) (void)hipFree(q);
+    for (auto q : c->d_col) (void)hipFree(q);
+    for (auto q : c->d_val) (void)hipFree(q);
+    for (auto q : c->d_colptr) (void)hipFree(q);
+    for (auto q : c->d_rowidx) (void)hipFree(q);
+    for (auto q : c->d_valT) (void)hipFree(q);
+    c->d_rowptr.clear(); c->d_col.clear(); c->d_val.clear(); c->d_colptr.clear(); c->d_rowidx.clear(); c->d_valT.clear();
+    c->have_ccs = false;
+}
+void BbCtx::destroy() {
+    C *c = p;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    free_ccs(c);
+    for (auto &kv : c->bufs) kv.second.release();
+    if (c->dA) (void)hipFree(c->dA);
+    if (c->d_icrt) (void)hipFree(c->d_icrt);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    (void)hipStreamDestroy(c->st);
+    delete c;
+    delete this;
+}
+int BbCtx::get_ring_tables(uint64_t *nonres, uint64_t *y) {
+    *nonres = p->ring.T.nu;
+    for (int k = 0; k < 8; k++)
+        for (int q = 0; q < TAU; q++) y[TAU * k + q] = p->ring.T.y[k].c[q];
+    return LF_OK;
+}
+int BbCtx::synchronize() {
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->st));
+    return LF_OK;
+}
+int BbCtx::mem_info(size_t *f, size_t *t) {
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemGetInfo(f, t));
+    return LF_OK;
+}
+
+// ---- host<->device staging of AoS ring-element arrays (canonical u64 at the ABI, Montgomery planes on the device) -----
+static int up_ring(C *c, const u64 *host, size_t n, fe *dst) {
+    if (!n) return LF_OK;
+    u64 *tmp;
+    RET(c->tbuf("stage_aos", n * RE, &tmp));
+    HIPCHK(hipMemcpyAsync(tmp, host, n * RE * 8, hipMemcpyHostToDevice, c->st));
+    launch_aos_to_soa(tmp, dst, n, c->st);
+    return LF_OK;
+}
+static int down_ring(C *c, const fe *src, size_t n, u64 *host) {
+    if (!n) return LF_OK;
+    u64 *tmp;
+    RET(c->tbuf("stage_aos", n * RE, &tmp));
+    launch_soa_to_aos(src, tmp, n, c->st);
+    HIPCHK(hipMemcpyAsync(host, tmp, n * RE * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return LF_OK;
+}
+static int down_small(C *c, const u64 *dsrc, size_t words, u64 *host) {
+    RET(c->pin(words));
+    HIPCHK(hipMemcpyAsync(c->h_pin, dsrc, words * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    memcpy(host, c->h_pin, words * 8);
+    return LF_OK;
+}
+static H9 h9_load(const u64 *w) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = w[i] % BB_P; return r; }
+static H9 h9_one() { H9 r; memset(&r, 0, sizeof(r)); r.c[0] = 1; return r; }
+static H9 h9_sub(const H9 &a, const H9 &b) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = hsub(a.c[i], b.c[i]); return r; }
+static bool is_diag(const u64 *e, H9 *out) {
+    for (int k = 1; k < 8; k++)
+        if (memcmp(e + TAU * k, e, TAU * 8)) return false;
+    if (out) *out = h9_load(e);
+    return true;
+}
+
+int BbCtx::selftest_field(uint64_t seed, uint32_t n, uint64_t *mismatches) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<u64> in((size_t)n * 18), out((size_t)n * 12);
+    u64 s = seed * 0x9E3779B97F4A7C15ULL + 1;
+    for (size_t i = 0; i < in.size(); i++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        in[i] = s % BB_P;
+    }
+    // edge operands in the first elements
+    for (int q = 0; q < 18 && n > 2; q++) { in[q] = (BB_P - 1) / 2; in[18 + q] = q < 9 ? (BB_P - 1) / 2 : (BB_P + 1) / 2; in[36 + q] = BB_P - 1; }
+    u64 *di, *dout;
+    RET(c->tbuf("io_a", in.size() * 2, (fe **)&di));
+    RET(c->tbuf("io_b", out.size() * 2, (fe **)&dout));
+    HIPCHK(hipMemcpyAsync(di, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->st));
+    launch_selftest(di, dout, n, c->dev.nu, c->st);
+    HIPCHK(hipMemcpyAsync(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    u64 bad = 0;
+    for (u32 i = 0; i < n; i++) {
+        H9 a = h9_load(&in[(size_t)i * 18]), b = h9_load(&in[(size_t)i * 18 + 9]);
+        H9 pr = c->ring.mul9(a, b);
+        for (int q = 0; q < TAU; q++) bad += out[(size_t)i * 12 + q] != pr.c[q];
+        bad += out[(size_t)i * 12 + 9] != hadd(a.c[0], b.c[0]);
+        bad += out[(size_t)i * 12 + 10] != hsub(a.c[0], b.c[0]);
+        bad += out[(size_t)i * 12 + 11] != hmul(a.c[0], b.c[0]);
+    }
+    *mismatches = bad;
+    return LF_OK;
+}
+
+// ---- a1/a2/a3 --------------------------------------------------------------------------------------------------------
+int BbCtx::ntt_fwd(const uint64_t *in, uint64_t *out, size_t count) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *a, *b;
+    RET(c->tbuf("io_a", count * RE, &a));
+    RET(c->tbuf("io_b", count * RE, &b));
+    RET(up_ring(c, in, count, a));
+    launch_crt_fwd(c->dev, a, b, count, c->st);
+    return down_ring(c, b, count, out);
+}
+int BbCtx::ntt_inv(const uint64_t *in, uint64_t *out, size_t count) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *a, *b;
+    RET(c->tbuf("io_a", count * RE, &a));
+    RET(c->tbuf("io_b", count * RE, &b));
+    RET(up_ring(c, in, count, a));
+    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    return down_ring(c, b, count, out);
+}
+static bool pow2(u64 b) { return b >= 2 && (b & (b - 1)) == 0; }
+int BbCtx::decompose(const uint64_t *in, size_t count, uint64_t base, unsigned digits, int layout, uint64_t *out) {
+    C *c = p;
+    if (!pow2(base)) return LF_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *a, *b;
+    RET(c->tbuf("io_a", count * RE, &a));
+    RET(c->tbuf("io_b", count * digits * RE, &b));
+    RET(up_ring(c, in, count, a));
+    launch_decompose(a, count, base, digits, layout, b, c->st);
+    if (layout == 0) return down_ring(c, b, count * digits, out);
+    for (unsigned k = 0; k < digits; k++) RET(down_ring(c, b + (size_t)k * RE * count, count, out + (size_t)k * count * RE));
+    return LF_OK;
+}
+int BbCtx::recompose(const uint64_t *in, size_t count_out, uint64_t base, unsigned digits, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *a, *b;
+    RET(c->tbuf("io_a", count_out * digits * RE, &a));
+    RET(c->tbuf("io_b", count_out * RE, &b));
+    RET(up_ring(c, in, count_out * digits, a));
+    launch_recompose(a, count_out, base, digits, b, c->st);
+    return down_ring(c, b, count_out, out);
+}
+int BbCtx::linf_check(const uint64_t *f_ntt, size_t count, uint64_t bound, int unsigned_variant, int *ok, uint64_t *max_out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *a, *b;
+    u64 *mx;
+    RET(c->tbuf("io_a", count * RE, &a));
+    RET(c->tbuf("io_b", count * RE, &b));
+    RET(c->tbuf("small_dev", 4096, &mx));
+    RET(up_ring(c, f_ntt, count, a));
+    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    if (unsigned_variant) {   // literal Witness::within_bound (arith.rs:372-386): canonical coefficient < bound
+        std::vector<u64> h(count * RE);
+        RET(down_ring(c, b, count, h.data()));
+        u64 m = 0;
+        for (u64 v : h) m = v > m ? v : m;
+        if (max_out) *max_out = m;
+        *ok = m < bound;
+        return LF_OK;
+    }
+    launch_linf(b, count, mx, c->st);
+    u64 m = 0;
+    RET(down_small(c, mx, 1, &m));
+    if (max_out) *max_out = m;
+    *ok = m < bound;
+    return LF_OK;
+}
+
+// ---- a5 ----------------------------------------------------------------------------------------------------------------
+int BbCtx::ajtai_load(const uint64_t *A, size_t kappa, size_t n) {
+    C *c = p;
+    if (kappa > 32) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * RE * sizeof(fe)));
+    for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + i * n * RE, n, c->dA + i * RE * n));
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->kappa = (u32)kappa;
+    c->nA = n;
+    return LF_OK;
+}
+int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
+    C *c = p;
+    if (kappa > 32) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * RE * sizeof(fe)));
+    launch_fill_ajtai(c->dA, (u32)kappa, n, n, 0, seed, c->st);
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->kappa = (u32)kappa;
+    c->nA = n;
+    return LF_OK;
+}
+static u32 ajtai_splits(size_t n) {
+    size_t s = n / 256;
+    if (s < 1) s = 1;
+    if (s > 128) s = 128;
+    return (u32)s;
+}
+// F: [batch][72][ldF]; out_dev: canonical u64 [batch][kappa][72]
+static int commit_dev(C *c, const fe *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
+    u32 maxb = 256 / c->kappa;
+    if (maxb > 16) maxb = 16;    // LDS: (kappa + 2*batch) rows of 289 words
+    if (maxb < 1) return LF_ERR_UNSUPPORTED;
+    u32 splits = ajtai_splits(c->nA);
+    i64 *partial;
+    RET(c->tbuf("ajtai_partial", ajtai_partial_words(c->kappa, maxb, splits), &partial));
+    for (u32 b0 = 0; b0 < batch; b0 += maxb) {
+        u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
+        size_t ev = timed ? c->ev_begin(1) : 0;
+        launch_ajtai(c->dev, c->dA, c->kappa, c->nA, F + (size_t)b0 * RE * ldF, ldF, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * RE, c->st);
+        if (timed) c->ev_end(ev);
+    }
+    return LF_OK;
+}
+int BbCtx::ajtai_commit(const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->dA) return LF_ERR_STATE;
+    if (n != c->nA) return LF_ERR_INVALID;   // CommitmentError::WrongWitnessLength(n, width)
+    HIPCHK(hipSetDevice(c->device));
+    fe *F;
+    u64 *o;
+    RET(c->tbuf("io_a", batch * n * RE, &F));
+    RET(c->tbuf("io_o", batch * c->kappa * RE, &o));
+    for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * RE, n, F + b * RE * n));
+    RET(commit_dev(c, F, n, (u32)batch, o, false));
+    return down_small(c, o, batch * c->kappa * RE, out);
+}
+
+// ---- a8/a9/a11 ---------------------------------------------------------------------------------------------------------
+static int build_eq_dev(C *c, const H9 *pt, u32 nv, fe *eq_dev) {
+    E9PreC *rd;
+    RET(c->tbuf("eq_point", 2 * 64, &rd));
+    std::vector<E9PreC> h(2 * (size_t)nv);
+    for (u32 i = 0; i < nv; i++) {
+        h[i] = e9pre_from_h9(pt[i], c->ring.T.nu);
+        h[nv + i] = e9pre_from_h9(h9_sub(h9_one(), pt[i]), c->ring.T.nu);
+    }
+    HIPCHK(hipMemcpyAsync(rd, h.data(), h.size() * sizeof(E9PreC), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    launch_build_eq(c->dev, rd, rd + nv, nv, eq_dev, c->st);
+    return LF_OK;
+}
+int BbCtx::build_eq(const uint64_t *point, unsigned nv, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    size_t n = (size_t)1 << nv;
+    fe *eq;
+    RET(c->tbuf("io_a", TAU * n, &eq));
+    std::vector<H9> pt(nv);
+    for (unsigned i = 0; i < nv; i++) pt[i] = h9_load(point + (size_t)TAU * i);
+    RET(build_eq_dev(c, pt.data(), nv, eq));
+    std::vector<fe> h(TAU * n);
+    HIPCHK(hipMemcpyAsync(h.data(), eq, h.size() * sizeof(fe), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (size_t i = 0; i < n; i++)
+        for (int q = 0; q < TAU; q++) out[TAU * i + q] = to_canon(h[(size_t)q * n + i]);
+    return LF_OK;
+}
+int BbCtx::mle_eval_batch(const uint64_t *tables, size_t ntables, size_t len, const uint64_t *point, unsigned nv, uint64_t *out) {
+    C *c = p;
+    size_t n = (size_t)1 << nv;
+    if (len > n || len == 0) return LF_ERR_INVALID;   // MleEvaluationError::IncorrectLength
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *eq, *X;
+    i64 *partial;
+    u64 *o;
+    RET(c->tbuf("io_eq", TAU * n, &eq));
+    RET(c->tbuf("io_a", ntables * len * RE, &X));
+    RET(c->tbuf("red_partial", red_partial_words((u32)(ntables * RE > 16 * RE * TAU ? ntables * RE : 16 * RE * TAU)), &partial));
+    RET(c->tbuf("io_o", ntables * RE, &o));
+    std::vector<H9> pt(nv);
+    for (unsigned i = 0; i < nv; i++) pt[i] = h9_load(point + (size_t)TAU * i);
+    RET(build_eq_dev(c, pt.data(), nv, eq));
+    for (size_t a = 0; a < ntables; a++) RET(up_ring(c, tables + a * len * RE, len, X + a * RE * len));
+    launch_dot_eq(c->dev, X, len, (u32)ntables, eq, n, len, partial, o, c->st);
+    return down_small(c, o, ntables * RE, out);
+}
+
+// ---- CCS ------------------------------------------------------------------------------------------------------------------
+int BbCtx::ccs_load(const lf_params *P, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
+                    const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *cc) {
+    C *c = p;
+    if (P->s < 3 || P->s > 28 || P->t == 0 || P->t > 4 || P->q == 0 || P->q > 8 || P->K == 0 || P->K > 16 || P->L == 0 || P->L > 8 ||
+        P->d + 1 > 3 || P->wit_len == 0)
+        return LF_ERR_UNSUPPORTED;
+    if (P->b != 2) return LF_ERR_UNSUPPORTED;
+    if (!pow2(P->B) || P->B > (1ULL << 30)) return LF_ERR_UNSUPPORTED;
+    {
+        u64 half = P->B / 2;
+        u32 need = 0;
+        while ((half >> need) != 0) need++;
+        if (need > P->K) return LF_ERR_UNSUPPORTED;
+    }
+    size_t m = (size_t)1 << P->s, N = (size_t)P->wit_len * P->L, n = (size_t)P->l + 1 + P->wit_len;
+    if (N > m) return LF_ERR_SIZE_BOUNDS;   // sanity_check, nifs.rs:165-173
+    {
+        u32 next = 0;
+        for (u32 i = 0; i < P->q; i++)
+            for (u32 k = S_off[i]; k < S_off[i + 1]; k++)
+                if (S_idx[k] != next++) return LF_ERR_UNSUPPORTED;
+        if (next != P->t || S_off[P->q] > 16) return LF_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    free_ccs(c);
+    c->P = *P; c->N = N; c->m = m; c->n = n;
+    memset(&c->desc, 0, sizeof(c->desc));
+    c->desc.t = P->t; c->desc.q = P->q;
+    for (u32 i = 0; i <= P->q; i++) c->desc.S_off[i] = S_off[i];
+    for (u32 k = 0; k < S_off[P->q]; k++) c->desc.S_idx[k] = S_idx[k];
+    for (u32 i = 0; i < P->q; i++) {
+        u64 one[RE], mone[RE];
+        BbHostRing::from_u64(1, one);
+        BbHostRing::from_u64(BB_P - 1, mone);
+        const u64 *ci = cc + (size_t)i * RE;
+        for (int w = 0; w < RE; w++) c->desc.c[i][w] = from_canon(ci[w]);
+        c->desc.c_unit[i] = !memcmp(ci, one, sizeof(one)) ? 1 : (!memcmp(ci, mone, sizeof(mone)) ? -1 : 0);
+    }
+    for (u32 j = 0; j < P->t; j++) {
+        size_t nnz = rowptr[j][m];
+        for (size_t k = 0; k < nnz; k++)
+            if (col[j][k] >= n) return LF_ERR_INVALID;
+        u32 *drp, *dci, *dcp, *dri;
+        fe *dv, *dvT;
+        std::vector<fe> v(nnz * RE + 1), vT(nnz * RE + 1);
+        for (size_t k = 0; k < nnz * RE; k++) v[k] = from_canon(val[j][k]);
+        std::vector<u32> cp(n + 1, 0), ri(nnz + 1);
+        for (size_t k = 0; k < nnz; k++) cp[col[j][k] + 1]++;
+        for (size_t i = 0; i < n; i++) cp[i + 1] += cp[i];
+        std::vector<u32> fill(cp.begin(), cp.end() - 1);
+        for (size_t r = 0; r < m; r++)
+            for (u32 k = rowptr[j][r]; k < rowptr[j][r + 1]; k++) {
+                u32 pos = fill[col[j][k]]++;
+                ri[pos] = (u32)r;
+                memcpy(&vT[(size_t)pos * RE], &v[(size_t)k * RE], RE * sizeof(fe));
+            }
+        HIPCHK(hipMalloc((void **)&drp, (m + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dci, (nnz + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dv, (nnz + 1) * RE * sizeof(fe)));
+        HIPCHK(hipMalloc((void **)&dcp, (n + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dri, (nnz + 1) * 4));
+        HIPCHK(hipMalloc((void **)&dvT, (nnz + 1) * RE * sizeof(fe)));
+        HIPCHK(hipMemcpy(drp, rowptr[j], (m + 1) * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dci, col[j], nnz * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dv, v.data(), nnz * RE * sizeof(fe), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dcp, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dri, ri.data(), nnz * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dvT, vT.data(), nnz * RE * sizeof(fe), hipMemcpyHostToDevice));
+        c->d_rowptr.push_back(drp); c->d_col.push_back(dci); c->d_val.push_back(dv);
+        c->d_colptr.push_back(dcp); c->d_rowidx.push_back(dri); c->d_valT.push_back(dvT);
+    }
+    c->have_ccs = true;
+    return LF_OK;
+}
+int BbCtx::spmv(unsigned j, const uint64_t *z, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    if (j >= c->P.t) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    fe *zd, *od;
+    RET(c->tbuf("io_a", c->n * RE, &zd));
+    RET(c->tbuf("io_b", c->m * RE, &od));
+    RET(up_ring(c, z, c->n, zd));
+    launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], zd, c->n, od, c->m, 0, c->st);
+    return down_ring(c, od, c->m, out);
+}
+
+// ---- witnesses -----------------------------------------------------------------------------------------------------------
+static int witness_from_coef_table(C *c, const fe *coef_dev, lf_witness **out) {
+    int32_t *pl;
+    HIPCHK(hipMalloc((void **)&pl, c->N * RE * 4));
+    int *viol;
+    if (c->tbuf("small_dev", 4096, (u64 **)&viol) != LF_OK) { (void)hipFree(pl); return LF_ERR_HIP; }
+    (void)hipMemsetAsync(viol, 0, 4, c->st);
+    launch_coef_to_i32(coef_dev, pl, c->N, (u32)(c->P.B / 2), viol, c->st);
+    int hv = 0;
+    if (hipMemcpyAsync(&hv, viol, 4, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) {
+        (void)hipFree(pl);
+        return LF_ERR_HIP;
+    }
+    if (hv) { (void)hipFree(pl); return LF_ERR_NORM; }
+    *out = new lf_witness{c->owner, pl, c->N};
+    return LF_OK;
+}
+int BbCtx::witness_from_w_ccs(const uint64_t *w_ccs, lf_witness **out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    fe *a, *b, *d;   // Witness::from_w_ccs, arith.rs:230-248: ICRT -> gadget_decompose(B, L)
+    RET(c->tbuf("io_a", (size_t)c->P.wit_len * RE, &a));
+    RET(c->tbuf("io_b", (size_t)c->P.wit_len * RE, &b));
+    RET(c->tbuf("io_c", c->N * RE, &d));
+    RET(up_ring(c, w_ccs, c->P.wit_len, a));
+    launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->st);
+    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->st);
+    return witness_from_coef_table(c, d, out);
+}
+int BbCtx::witness_from_f_coeff(const uint64_t *f_coeff, lf_witness **out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    fe *d;
+    RET(c->tbuf("io_c", c->N * RE, &d));
+    RET(up_ring(c, f_coeff, c->N, d));
+    return witness_from_coef_table(c, d, out);
+}
+int BbCtx::witness_from_f(const uint64_t *f_ntt, lf_witness **out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    fe *a, *d;
+    RET(c->tbuf("io_a", c->N * RE, &a));
+    RET(c->tbuf("io_c", c->N * RE, &d));
+    RET(up_ring(c, f_ntt, c->N, a));
+    launch_icrt_dense(c->d_icrt, a, d, c->N, c->st);
+    return witness_from_coef_table(c, d, out);
+}
+int BbCtx::witness_get_f_coeff(const lf_witness *w, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *d;
+    RET(c->tbuf("io_c", w->N * RE, &d));
+    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    return down_ring(c, d, w->N, out);
+}
+int BbCtx::witness_get_f(const lf_witness *w, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *d, *e;
+    RET(c->tbuf("io_c", w->N * RE, &d));
+    RET(c->tbuf("io_b", w->N * RE, &e));
+    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    launch_crt_fwd(c->dev, d, e, w->N, c->st);
+    return down_ring(c, e, w->N, out);
+}
+int BbCtx::witness_get_w_ccs(const lf_witness *w, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    fe *e;
+    RET(c->tbuf("io_b", (size_t)c->P.wit_len * RE, &e));
+    launch_recompose_crt(c->dev, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->st);
+    return down_ring(c, e, c->P.wit_len, out);
+}
+int BbCtx::witness_commit(const lf_witness *w, uint64_t *cm_out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->dA) return LF_ERR_STATE;
+    if (w->N != c->nA) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    fe *d, *e;
+    u64 *o;
+    RET(c->tbuf("io_c", w->N * RE, &d));
+    RET(c->tbuf("io_b", w->N * RE, &e));
+    RET(c->tbuf("io_o", (size_t)c->kappa * RE, &o));
+    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    launch_crt_fwd(c->dev, d, e, w->N, c->st);
+    RET(commit_dev(c, e, w->N, 1, o, false));
+    return down_small(c, o, (size_t)c->kappa * RE, cm_out);
+}
+
+// =================================================================================================================================
+// the driver
+static void sc_prologue(BbTranscript &tr, u32 nv, u32 deg) {   // utils/sumcheck.rs:60-62
+    tr.absorb_u64_as_ring(nv);
+    tr.absorb_u64_as_ring(deg);
+}
+static H9 sc_round_transcript(BbTranscript &tr, const u64 *evals, u32 npts) {
+    tr.absorb_ring(evals, npts);
+    H9 r = tr.get_challenge();
+    tr.absorb_h9_as_ring(r);
+    return r;
+}
+static size_t atl(size_t x) { return x < 2 ? 2 : x; }   // leading dimensions stay even (8-byte pair loads)
+
+// linearization sumcheck on device tables mz [t][72][m] (left intact) and eq_beta [9][m]
+static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb, u64 *msgs, H9 *point) {
+    const lf_params &P = c->P;
+    u32 deg = P.d + 1;
+    size_t m = c->m;
+    fe *fx[2], *fq[2];
+    i64 *partial;
+    u64 *od;
+    RET(c->tbuf("lin_fix0", (size_t)P.t * RE * atl(m / 2), &fx[0]));
+    RET(c->tbuf("lin_fix1", (size_t)P.t * RE * atl(m / 4), &fx[1]));
+    RET(c->tbuf("lin_efix0", TAU * atl(m / 2), &fq[0]));
+    RET(c->tbuf("lin_efix1", TAU * atl(m / 4), &fq[1]));
+    RET(c->tbuf("round_partial", red_partial_words(5 * RE), &partial));
+    RET(c->tbuf("round_out", 5 * RE, &od));
+    { HostTimer ht(c); sc_prologue(tr, P.s, deg); }
+    const fe *cur = mz, *cure = eqb;
+    size_t n = m;
+    int flip = 0;
+    for (u32 round = 1; round <= P.s; round++) {
+        if (round > 1) {
+            E9PreC r = e9pre_from_h9(point[round - 2], c->ring.T.nu);
+            launch_fix(c->dev, cur, n, fx[flip], atl(n / 2), n, P.t * 8, r, c->st);
+            launch_fix(c->dev, cure, n, fq[flip], atl(n / 2), n, 1, r, c->st);
+            cur = fx[flip]; cure = fq[flip];
+            flip ^= 1;
+            n /= 2;
+        }
+        size_t ld = round == 1 ? m : atl(n);
+        launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->st);
+        u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * RE;
+        RET(down_small(c, od, (size_t)(deg + 1) * RE, ev));
+        HostTimer ht(c);
+        point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
+    }
+    return LF_OK;
+}
+
+// z tables: head (x.., h) || w, w from the planes
+static int build_z(C *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads /* K*(l+1) ring AoS host */, fe *z /* [K][72][n] */) {
+    const lf_params &P = c->P;
+    u32 hl = P.l + 1;
+    launch_recompose_crt(c->dev, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->st);
+    std::vector<fe> h((size_t)K * RE * hl);
+    for (u32 k = 0; k < K; k++)
+        for (u32 i = 0; i < hl; i++)
+            for (int w = 0; w < RE; w++) h[((size_t)k * RE + w) * hl + i] = from_canon(heads[((size_t)k * hl + i) * RE + w]);
+    fe *stage;
+    RET(c->tbuf("z_heads", h.size(), &stage));
+    HIPCHK(hipMemcpyAsync(stage, h.data(), h.size() * sizeof(fe), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpy2DAsync(z, c->n * sizeof(fe), stage, hl * sizeof(fe), hl * sizeof(fe), (size_t)K * RE, hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return LF_OK;
+}
+static bool lcccs_point(const lf_params &P, const u64 *lcccs, std::vector<H9> &pt) {
+    pt.resize(P.s);
+    for (u32 i = 0; i < P.s; i++)
+        if (!is_diag(lcccs + (size_t)i * RE, &pt[i])) return false;
+    return true;
+}
+
+// LFLinearizationProver::prove (nifs/linearization.rs:145-189)
+static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witness *wit, u64 *lcccs_out, u64 *proof, fe **eq_r_keep) {
+    const lf_params &P = c->P;
+    size_t m = c->m, n = c->n;
+    size_t ph = c->ev_begin(10);
+    std::vector<u64> head((size_t)(P.l + 1) * RE);   // z = x_ccs || 1 || w_ccs (arith.rs:399-409)
+    memcpy(head.data(), cccs + (size_t)P.kappa * RE, (size_t)P.l * RE * 8);
+    BbHostRing::from_u64(1, head.data() + (size_t)P.l * RE);
+    fe *z, *mz, *eqb, *eqr;
+    i64 *partial;
+    u64 *od;
+    RET(c->tbuf("lin_z", RE * n, &z));
+    RET(c->tbuf("lin_mz", (size_t)P.t * RE * m, &mz));
+    RET(c->tbuf("lin_eqb", TAU * m, &eqb));
+    RET(c->tbuf("eq_r_R", TAU * m, &eqr));
+    RET(c->tbuf("red_partial", red_partial_words(16 * RE * TAU), &partial));
+    RET(c->tbuf("lin_small", 16 * RE * TAU, &od));
+    RET(build_z(c, wit->planes, 1, 0, head.data(), z));
+    std::vector<H9> beta(P.s);
+    {
+        HostTimer ht(c);
+        tr.absorb_label("beta_s");
+        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
+    }
+    RET(build_eq_dev(c, beta.data(), P.s, eqb));
+    for (u32 j = 0; j < P.t; j++) launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * RE * m, m, 0, c->st);
+    std::vector<H9> pt(P.s);
+    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data()));
+    // v, u at the sumcheck point (linearization.rs:126-139)
+    RET(build_eq_dev(c, pt.data(), P.s, eqr));
+    u64 *v = proof + (size_t)P.s * (P.d + 2) * RE, *u = v + (size_t)TAU * RE;
+    launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->st);
+    RET(down_small(c, od, (size_t)TAU * RE, v));   // T[72][9] flat == v[9][8 slots][9]
+    launch_dot_eq(c->dev, mz, m, P.t, eqr, m, m, partial, od, c->st);
+    RET(down_small(c, od, (size_t)P.t * RE, u));
+    {
+        HostTimer ht(c);
+        tr.absorb_ring(v, TAU);
+        tr.absorb_ring(u, P.t);
+    }
+    u64 *o = lcccs_out;
+    for (u32 i = 0; i < P.s; i++, o += RE) BbHostRing::from_h9(pt[i], o);
+    memcpy(o, v, (size_t)TAU * RE * 8); o += (size_t)TAU * RE;
+    memcpy(o, cccs, (size_t)P.kappa * RE * 8); o += (size_t)P.kappa * RE;
+    memcpy(o, u, (size_t)P.t * RE * 8); o += (size_t)P.t * RE;
+    memcpy(o, cccs + (size_t)P.kappa * RE, (size_t)P.l * RE * 8); o += (size_t)P.l * RE;
+    BbHostRing::from_u64(1, o);
+    if (eq_r_keep) *eq_r_keep = eqr;
+    c->ev_end(ph);
+    return LF_OK;
+}
+
+// decompose_big_vec_into_k_vec_and_compose_back (nifs/decomposition/utils.rs:12-42) on l+1 elements, host
+static void compute_x_s(const C *c, const u64 *xh, u64 *x_s) {
+    const lf_params &P = c->P;
+    u32 cnt = P.l + 1;
+    std::vector<u64> co(RE);
+    for (u32 i = 0; i < cnt; i++) {
+        c->ring.icrt(xh + (size_t)i * RE, co.data());
+        std::vector<int64_t> dB(P.L), dk(P.K);
+        std::vector<std::vector<u64>> part(P.K, std::vector<u64>(RE, 0));
+        for (int cc = 0; cc < RE; cc++) {
+            bb_balanced_digits(co[cc], P.B, P.L, dB.data());
+            u64 pw = 1;
+            for (u32 l = 0; l < P.L; l++) {
+                bb_balanced_digits(hfrom_i64(dB[l]), P.b, P.K, dk.data());
+                for (u32 k = 0; k < P.K; k++) part[k][cc] = hadd(part[k][cc], hmul(pw, hfrom_i64(dk[k])));
+                pw = hmul(pw, P.B % BB_P);
+            }
+        }
+        for (u32 k = 0; k < P.K; k++) c->ring.crt(part[k].data(), x_s + ((size_t)k * cnt + i) * RE);
+    }
+}
+
+struct SideState {
+    const int32_t *planes;
+    fe *z;      // [K][72][n]
+    fe *eq_r;   // [9][m]
+    std::vector<u64> lcccs;   // K flat LCCCS (host)
+};
+
+// LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
+static int decompose_impl(C *c, BbTranscript &tr, const u64 *lcccs, const std::vector<H9> &rpt, const lf_witness *wit, const char *side,
+                          fe *eq_r, SideState &S, u64 *proof) {
+    const lf_params &P = c->P;
+    size_t m = c->m, n = c->n, N = c->N;
+    u32 K = P.K;
+    std::string sd(side);
+    const u64 *cm = lcccs + ((size_t)P.s + TAU) * RE;
+    const u64 *xh = lcccs + ((size_t)P.s + TAU + P.kappa + P.t) * RE;
+    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * RE, *x_s = v_s + (size_t)K * TAU * RE, *y_s = x_s + (size_t)K * (P.l + 1) * RE;
+    fe *Fh, *z, *q;
+    i64 *partial;
+    u64 *od, *yd;
+    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * N, &Fh));
+    RET(c->tbuf("dec_y", (size_t)K * P.kappa * RE, &yd));
+    RET(c->tbuf("red_partial", red_partial_words(16 * RE * TAU), &partial));
+    RET(c->tbuf("dec_small", 16 * RE * TAU + 16 * 4 * RE, &od));
+    RET(c->tbuf("z_" + sd, (size_t)K * RE * n, &z));
+    RET(c->tbuf("dec_q", (size_t)P.t * RE * n, &q));
+    if (!eq_r) {
+        RET(c->tbuf("eq_r_" + sd, TAU * m, &eq_r));
+        RET(build_eq_dev(c, rpt.data(), P.s, eq_r));
+    }
+    S.planes = wit->planes; S.z = z; S.eq_r = eq_r;
+    // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
+    size_t ph = c->ev_begin(11);
+    launch_bitplane_crt(c->dev, wit->planes, N, N, 1, K, Fh, c->st);
+    RET(commit_dev(c, Fh, N, K - 1, yd, true));
+    RET(down_small(c, yd, (size_t)(K - 1) * P.kappa * RE, y_s + (size_t)P.kappa * RE));
+    c->ev_end(ph);
+    {   // y_0 = cm - sum_{k>=1} b^k y_k, as the reference's fold (acc + y_i) * b
+        std::vector<u64> acc((size_t)P.kappa * RE, 0);
+        u64 bb[RE];
+        BbHostRing::from_u64(P.b, bb);
+        for (int k = (int)K - 1; k >= 1; k--)
+            for (u32 i = 0; i < P.kappa; i++) {
+                BbHostRing::add(&acc[(size_t)i * RE], y_s + ((size_t)k * P.kappa + i) * RE, &acc[(size_t)i * RE]);
+                c->ring.mul_ntt(&acc[(size_t)i * RE], bb, &acc[(size_t)i * RE]);
+            }
+        for (u32 i = 0; i < P.kappa; i++) BbHostRing::sub(cm + (size_t)i * RE, &acc[(size_t)i * RE], y_s + (size_t)i * RE);
+    }
+    ph = c->ev_begin(12);
+    compute_x_s(c, xh, x_s);
+    // v_s (decomposition.rs:204-211) from the coefficient planes
+    launch_coef_eval(c->dev, wit->planes, N, eq_r, m, K, 1, partial, od, c->st);
+    RET(down_small(c, od, (size_t)K * TAU * RE, v_s));
+    // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
+    RET(build_z(c, wit->planes, K, 1, x_s, z));
+    for (u32 j = 0; j < P.t; j++)
+        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * RE * n, n, c->st);
+    launch_dot_batch(c->dev, z, n, K, q, n, P.t, n, partial, od, c->st);
+    RET(down_small(c, od, (size_t)K * P.t * RE, u_s));
+    c->ev_end(ph);
+    // transcript (decomposition.rs:65-83): absorb x_k, y_k, u_k, v_k and build the K LCCCS
+    HostTimer ht(c);
+    size_t ll = bb_lcccs_len(&P);
+    S.lcccs.assign((size_t)K * ll * RE, 0);
+    for (u32 k = 0; k < K; k++) {
+        const u64 *xk = x_s + (size_t)k * (P.l + 1) * RE, *yk = y_s + (size_t)k * P.kappa * RE;
+        const u64 *uk = u_s + (size_t)k * P.t * RE, *vk = v_s + (size_t)k * TAU * RE;
+        tr.absorb_ring(xk, P.l + 1);
+        tr.absorb_ring(yk, P.kappa);
+        tr.absorb_ring(uk, P.t);
+        tr.absorb_ring(vk, TAU);
+        u64 *o = &S.lcccs[(size_t)k * ll * RE];
+        memcpy(o, lcccs, (size_t)P.s * RE * 8); o += (size_t)P.s * RE;
+        memcpy(o, vk, (size_t)TAU * RE * 8); o += (size_t)TAU * RE;
+        memcpy(o, yk, (size_t)P.kappa * RE * 8); o += (size_t)P.kappa * RE;
+        memcpy(o, uk, (size_t)P.t * RE * 8); o += (size_t)P.t * RE;
+        memcpy(o, xk, (size_t)(P.l + 1) * RE * 8);
+    }
+    return LF_OK;
+}
+
+template <class T>
+static int upload_consts(C *c, const std::string &name, const std::vector<T> &v, T **out) {
+    RET(c->tbuf(name, v.size() + 8, out));
+    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return LF_OK;
+}
+
+// LFFoldingProver::prove (nifs/folding.rs:42-130)
+static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_witness **w_out, u64 *proof) {
+    const lf_params &P = c->P;
+    size_t m = c->m, n = c->n, N = c->N;
+    u32 K = P.K, K2 = 2 * K, deg = 2 * P.b;
+    size_t ll = bb_lcccs_len(&P);
+    const u64 nu = c->ring.T.nu;
+    std::vector<H9> alpha(K2), zeta(K2), mu(K2), beta(P.s);
+    {
+        HostTimer ht(c);
+        tr.absorb_label("alpha_s");
+        for (u32 i = 0; i < K2; i++) alpha[i] = tr.get_challenge();
+        tr.absorb_label("zeta_s");
+        for (u32 i = 0; i < K2; i++) zeta[i] = tr.get_challenge();
+        tr.absorb_label("mu_s");
+        for (u32 i = 0; i + 1 < K2; i++) mu[i] = tr.get_challenge();
+        mu[K2 - 1] = h9_one();
+        tr.absorb_label("beta_s");
+        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
+    }
+    size_t ph = c->ev_begin(13);
+    // powers x^{j+1}
+    std::vector<E9C> mu_c((size_t)K2 * TAU), a_pow((size_t)K2 * TAU);
+    std::vector<E9PreC> mu_pre((size_t)K2 * TAU), z_pow((size_t)K2 * P.t);
+    for (u32 i = 0; i < K2; i++) {
+        H9 pm = mu[i], pa = alpha[i], pz = zeta[i];
+        for (u32 d = 0; d < (u32)TAU; d++) {
+            mu_c[(size_t)i * TAU + d] = e9c_from_h9(pm);
+            mu_pre[(size_t)i * TAU + d] = e9pre_from_h9(pm, nu);
+            a_pow[(size_t)i * TAU + d] = e9c_from_h9(pa);
+            pm = c->ring.mul9(pm, mu[i]); pa = c->ring.mul9(pa, alpha[i]);
+        }
+        for (u32 j = 0; j < P.t; j++) { z_pow[(size_t)i * P.t + j] = e9pre_from_h9(pz, nu); pz = c->ring.mul9(pz, zeta[i]); }
+    }
+    E9C *d_mu, *d_ap;
+    E9PreC *d_mup, *d_zp;
+    RET(upload_consts(c, "c_mu", mu_c, &d_mu));
+    RET(upload_consts(c, "c_mup", mu_pre, &d_mup));
+    RET(upload_consts(c, "c_ap", a_pow, &d_ap));
+    RET(upload_consts(c, "c_zp", z_pow, &d_zp));
+    fe *G[2], *eqb, *zz;
+    i64 *partial;
+    u64 *od;
+    RET(c->tbuf("fold_G1", RE * m, &G[0]));
+    RET(c->tbuf("fold_G2", RE * m, &G[1]));
+    RET(c->tbuf("fold_eqb", TAU * m, &eqb));
+    RET(c->tbuf("fold_zz", (size_t)P.t * RE * n, &zz));
+    RET(c->tbuf("round_partial", red_partial_words(5 * RE), &partial));
+    RET(c->tbuf("round_out", 5 * RE, &od));
+    for (int sd = 0; sd < 2; sd++) {
+        // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}   (folding.rs:208-226, utils.rs:524-546)
+        launch_lincomb_z(c->dev, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->st);
+        for (u32 j = 0; j < P.t; j++)
+            launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], zz + (size_t)j * RE * n, n, G[sd], m, j > 0, c->st);
+        launch_add_fhat_comb(c->dev, S[sd].planes, N, K, d_ap + (size_t)sd * K * TAU, G[sd], m, c->st);
+    }
+    RET(build_eq_dev(c, beta.data(), P.s, eqb));
+    c->ev_end(ph);
+
+    ph = c->ev_begin(14);
+    u64 *msgs = proof;
+    std::vector<H9> pt(P.s);
+    { HostTimer ht(c); sc_prologue(tr, P.s, deg); }
+    // working tables (ping-pong): 5 special tables (eqL eqR eqB G1 G2 = 171 planes) + the 2K*9 materialised f-hat tables
+    const size_t T5P = 3 * TAU + 2 * RE;
+    fe *F[2], *T5[2];
+    RET(c->tbuf("fold_F0", (size_t)K2 * TAU * RE * atl(m / 2), &F[0]));
+    RET(c->tbuf("fold_F1", (size_t)K2 * TAU * RE * atl(m / 4), &F[1]));
+    RET(c->tbuf("fold_T0", T5P * atl(m / 2), &T5[0]));
+    RET(c->tbuf("fold_T1", T5P * atl(m / 4), &T5[1]));
+    FoldArgs a;
+    a.eqL = S[0].eq_r; a.eqR = S[1].eq_r; a.eqB = eqb; a.G1 = G[0]; a.G2 = G[1]; a.ld = m; a.n = m;
+    const fe *curF = nullptr;
+    size_t ldF = 0;
+    int flip = 0;
+    for (u32 round = 1; round <= P.s; round++) {
+        if (round > 1) {
+            H9 rh = pt[round - 2];
+            E9PreC r = e9pre_from_h9(rh, nu);
+            size_t nn = a.n / 2, ldn = atl(nn);
+            fe *dst = T5[flip];
+            launch_fix(c->dev, a.eqL, a.ld, dst, ldn, a.n, 1, r, c->st);
+            launch_fix(c->dev, a.eqR, a.ld, dst + (size_t)TAU * ldn, ldn, a.n, 1, r, c->st);
+            launch_fix(c->dev, a.eqB, a.ld, dst + (size_t)2 * TAU * ldn, ldn, a.n, 1, r, c->st);
+            launch_fix(c->dev, a.G1, a.ld, dst + (size_t)3 * TAU * ldn, ldn, a.n, 8, r, c->st);
+            launch_fix(c->dev, a.G2, a.ld, dst + (size_t)(3 * TAU + RE) * ldn, ldn, a.n, 8, r, c->st);
+            if (round == 2) {
+                launch_fold_materialize(c->dev, S[0].planes, S[1].planes, N, m, K, e9c_from_h9(rh), F[0], c->st);
+                curF = F[0]; ldF = atl(m / 2);
+            } else {
+                fe *fd = F[(round & 1) ? 1 : 0];   // round 3 -> F[1], round 4 -> F[0], ...
+                launch_fix(c->dev, curF, ldF, fd, ldn, a.n, K2 * TAU * 8, r, c->st);
+                curF = fd; ldF = ldn;
+            }
+            a.eqL = dst; a.eqR = dst + (size_t)TAU * ldn; a.eqB = dst + (size_t)2 * TAU * ldn;
+            a.G1 = dst + (size_t)3 * TAU * ldn; a.G2 = dst + (size_t)(3 * TAU + RE) * ldn;
+            a.ld = ldn; a.n = nn;
+            flip ^= 1;
+        }
+        size_t ev = c->ev_begin(0);
+        if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->st);
+        else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->st);
+        c->ev_end(ev);
+        u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;
+        RET(down_small(c, od, (size_t)(deg + 1) * RE, evs));
+        HostTimer ht(c);
+        pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
+    }
+    c->ev_end(ph);
+
+    ph = c->ev_begin(15);
+    // theta, eta at r_0 (folding.rs:236-256)
+    u64 *theta = proof + (size_t)P.s * (deg + 1) * RE, *eta = theta + (size_t)K2 * TAU * RE;
+    fe *eq0, *q;
+    i64 *red;
+    u64 *sm;
+    RET(c->tbuf("fold_eq0", TAU * m, &eq0));
+    RET(c->tbuf("dec_q", (size_t)P.t * RE * n, &q));
+    RET(c->tbuf("red_partial", red_partial_words(16 * RE * TAU), &red));
+    RET(c->tbuf("dec_small", 16 * RE * TAU + 16 * 4 * RE, &sm));
+    RET(build_eq_dev(c, pt.data(), P.s, eq0));
+    for (u32 j = 0; j < P.t; j++)
+        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * RE * n, n, c->st);
+    for (int sd = 0; sd < 2; sd++) {
+        launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, sm, c->st);
+        RET(down_small(c, sm, (size_t)K * TAU * RE, theta + (size_t)sd * K * TAU * RE));
+        launch_dot_batch(c->dev, S[sd].z, n, K, q, n, P.t, n, red, sm, c->st);
+        RET(down_small(c, sm, (size_t)K * P.t * RE, eta + (size_t)sd * K * P.t * RE));
+    }
+    std::vector<u64> rho_c((size_t)K2 * RE, 0), rho((size_t)K2 * RE);
+    std::vector<int8_t> rho8((size_t)K2 * 24, 0);
+    {
+        HostTimer ht(c);
+        tr.absorb_ring(theta, (size_t)K2 * TAU);
+        tr.absorb_ring(eta, (size_t)K2 * P.t);
+        tr.absorb_label("rho_s");   // get_rhos (folding/utils.rs:116-131)
+        for (u32 i = 0; i + 1 < K2; i++) tr.get_short_challenge(&rho_c[(size_t)i * RE]);
+        rho_c[(size_t)(K2 - 1) * RE] = 1;
+        for (u32 i = 0; i < K2; i++) {
+            c->ring.crt(&rho_c[(size_t)i * RE], &rho[(size_t)i * RE]);
+            for (int q2 = 0; q2 < 24; q2++) {
+                u64 v = rho_c[(size_t)i * RE + q2];
+                rho8[(size_t)i * 24 + q2] = (int8_t)(v > BB_P / 2 ? -(int64_t)(BB_P - v) : (int64_t)v);
+            }
+        }
+    }
+    // f_0 in the coefficient domain -> new witness
+    int8_t *d_rho;
+    RET(c->tbuf("c_rho", (size_t)K2 * 24 + 64, &d_rho));
+    HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->st));
+    int32_t *npl;
+    HIPCHK(hipMalloc((void **)&npl, N * RE * 4));
+    launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->st);
+    HIPCHK(hipStreamSynchronize(c->st));
+    *w_out = new lf_witness{c->owner, npl, N};
+    c->ev_end(ph);
+
+    // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521), host
+    HostTimer ht(c);
+    u64 *o = lcccs_out;
+    for (u32 i = 0; i < P.s; i++, o += RE) BbHostRing::from_h9(pt[i], o);
+    {   // v_0 = rot_lin_combination(rho_coeff, theta) (cyclotomic-rings/src/rotation.rs:85-104)
+        std::vector<u64> res((size_t)RE * TAU, 0);   // res[j] in F_{p^9}
+        for (u32 i = 0; i < K2; i++) {
+            u64 rot[RE];
+            memcpy(rot, &rho_c[(size_t)i * RE], sizeof(rot));
+            const u64 *th = theta + (size_t)i * TAU * RE;
+            for (int bi = 0; bi < RE; bi++) {
+                const u64 *b = th + (size_t)TAU * bi;
+                for (int j = 0; j < RE; j++)
+                    if (rot[j])
+                        for (int q2 = 0; q2 < TAU; q2++) res[(size_t)j * TAU + q2] = hadd(res[(size_t)j * TAU + q2], hmul(b[q2], rot[j]));
+                u64 top = rot[RE - 1];   // multiply by X modulo X^72 - X^36 + 1
+                for (int j = RE - 1; j > 0; j--) rot[j] = rot[j - 1];
+                rot[0] = top ? BB_P - top : 0;
+                rot[RE / 2] = hadd(rot[RE / 2], top);
+            }
+        }
+        memcpy(o, res.data(), res.size() * 8);
+        o += (size_t)TAU * RE;
+    }
+    u64 tmp[RE];
+    auto part = [&](u32 i) { return &S[i < K ? 0 : 1].lcccs[(size_t)(i % K) * ll * RE]; };
+    for (u32 q2 = 0; q2 < P.kappa; q2++, o += RE) {
+        memset(o, 0, RE * 8);
+        for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(part(i) + ((size_t)P.s + TAU + q2) * RE, &rho[(size_t)i * RE], tmp); BbHostRing::add(o, tmp, o); }
+    }
+    for (u32 j = 0; j < P.t; j++, o += RE) {
+        memset(o, 0, RE * 8);
+        for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * RE], eta + ((size_t)i * P.t + j) * RE, tmp); BbHostRing::add(o, tmp, o); }
+    }
+    for (u32 q2 = 0; q2 < P.l + 1; q2++, o += RE) {
+        memset(o, 0, RE * 8);
+        for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * RE], part(i) + ((size_t)P.s + TAU + P.kappa + P.t + q2) * RE, tmp); BbHostRing::add(o, tmp, o); }
+    }
+    return LF_OK;
+}
+
+int BbCtx::linearize(BbTranscript &tr, const uint64_t *cccs, const lf_witness *wit, uint64_t *lcccs_out, uint64_t *lin_proof_out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    if (wit->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    int rc = linearize_impl(c, tr, cccs, wit, lcccs_out, lin_proof_out, nullptr);
+    c->ev_collect();
+    return rc;
+}
+
+int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_acc, const uint64_t *cm_i, const lf_witness *w_i,
+                     uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    const lf_params &P = c->P;
+    if (c->kappa != P.kappa || c->nA != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<H9> rL;
+    if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;   // evaluation points are always diagonal challenges
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    size_t tot = c->ev_begin(17);
+    size_t ll = bb_lcccs_len(&P);
+    {   // absorb_public_input (nifs.rs:175-197)
+        HostTimer ht(c);
+        tr.absorb_label("acc");
+        tr.absorb_ring(acc, ll);
+        tr.absorb_label("cm_i");
+        tr.absorb_ring(cm_i, bb_cccs_len(&P));
+    }
+    u64 *lin_proof = proof, *decl = lin_proof + lin_proof_len(&P) * RE, *decr = decl + dec_proof_len(&P) * RE, *foldp = decr + dec_proof_len(&P) * RE;
+    std::vector<u64> lin(ll * RE);
+    fe *eq_r_R = nullptr;
+    SideState S[2];
+    int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    if (rc == LF_OK) rc = decompose_impl(c, tr, acc, rL, w_acc, "L", nullptr, S[0], decl);
+    std::vector<H9> rR;
+    if (rc == LF_OK) {
+        lcccs_point(P, lin.data(), rR);
+        rc = decompose_impl(c, tr, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
+    }
+    if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
+    c->ev_end(tot);
+    c->ev_collect();
+    return rc;
+}
+
+// ---- generic linearization-shaped sumcheck through the ABI -----------------------------------------------------------------------
+int BbCtx::sumcheck_lin_begin(const uint64_t *tables, const uint64_t *eq_point) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    size_t m = c->m;
+    fe *mz, *eqb;
+    RET(c->tbuf("sc_tab0", (size_t)P.t * RE * m, &mz));
+    RET(c->tbuf("sc_eq0", TAU * m, &eqb));
+    for (u32 j = 0; j < P.t; j++) RET(up_ring(c, tables + (size_t)j * m * RE, m, mz + (size_t)j * RE * m));
+    std::vector<H9> pt(P.s);
+    for (u32 i = 0; i < P.s; i++) pt[i] = h9_load(eq_point + (size_t)TAU * i);
+    RET(build_eq_dev(c, pt.data(), P.s, eqb));
+    c->sc_round = 0; c->sc_n = m; c->sc_cur = 0;
+    return LF_OK;
+}
+int BbCtx::sumcheck_lin_round(const uint64_t *r_prev, uint64_t *evals_out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->sc_round < 0 || c->sc_round >= (int)c->P.s) return LF_ERR_STATE;
+    if ((c->sc_round == 0) != (r_prev == nullptr)) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    size_t m = c->m;
+    fe *tab[2], *eq[2];
+    i64 *partial;
+    u64 *od;
+    RET(c->tbuf("sc_tab0", (size_t)P.t * RE * m, &tab[0]));
+    RET(c->tbuf("sc_tab1", (size_t)P.t * RE * atl(m / 2), &tab[1]));
+    RET(c->tbuf("sc_eq0", TAU * m, &eq[0]));
+    RET(c->tbuf("sc_eq1", TAU * atl(m / 2), &eq[1]));
+    RET(c->tbuf("round_partial", red_partial_words(5 * RE), &partial));
+    RET(c->tbuf("round_out", 5 * RE, &od));
+    if (r_prev) {
+        E9PreC r = e9pre_from_h9(h9_load(r_prev), c->ring.T.nu);
+        int src = c->sc_cur, dst = src ^ 1;
+        size_t ldi = c->sc_n == m ? m : atl(c->sc_n);
+        launch_fix(c->dev, tab[src], ldi, tab[dst], atl(c->sc_n / 2), c->sc_n, P.t * 8, r, c->st);
+        launch_fix(c->dev, eq[src], ldi, eq[dst], atl(c->sc_n / 2), c->sc_n, 1, r, c->st);
+        c->sc_cur = dst; c->sc_n /= 2;
+    }
+    size_t ld = c->sc_n == m ? m : atl(c->sc_n);
+    launch_lin_round(c->dev, c->desc, tab[c->sc_cur], ld, eq[c->sc_cur], ld, c->sc_n, P.d + 1, partial, od, c->st);
+    c->sc_round++;
+    return down_small(c, od, (size_t)(P.d + 2) * RE, evals_out);
+}
+int BbCtx::sumcheck_lin_end() {
+    std::lock_guard<std::mutex> g(p->mu);
+    p->sc_round = -1;
+    return LF_OK;
+}
+int BbCtx::last_phase_ms(float *out) {
+    for (int i = 0; i < NPH; i++) out[i] = p->phase_ms[i];
+    return LF_OK;
+}
+int BbCtx::last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_n) {
+    if (fold_ms) *fold_ms = p->k_fold_ms;
+    if (fold_n) *fold_n = p->k_fold_n;
+    if (aj_ms) *aj_ms = p->k_ajtai_ms;
+    if (aj_n) *aj_n = p->k_ajtai_n;
+    return LF_OK;
+}
+
+}  // namespace lfbb

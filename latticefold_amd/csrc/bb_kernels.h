@@ -1,0 +1,107 @@
+// bb_kernels.h -- launchers of the gfx950 kernels of the BabyBearRingNTT backend (bb_kernels.hip).  All pointers are
+// DEVICE pointers.  Words are centred Montgomery int32 (bb_field.cuh).
+//
+// Device layouts (DESIGN.md "BabyBear backend"):
+//   ring table   : fe  [72][n]   plane w = 9*slot + coord (NTT form) or coefficient index (coefficient form)
+//   fq9 table    : fe  [9][n]    slot-constant values (eq tables)
+//   coef planes  : i32 [72][n]   centred integer coefficients of a B-short witness (NOT Montgomery)
+//   Ajtai matrix : fe  [kappa][72][n]
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bb_host.h"
+
+namespace lfbb {
+
+struct DevBb {   // compact device copy of BbTables, passed by value
+    fe nu;
+    fe w4, w2, w10, w1, w7, w5, w11;
+    int slot_of_pos[8];
+    int pos[TAU][8];
+    fe tw[TAU][8];
+};
+DevBb make_dev_bb(const BbTables &T);
+struct E9C { fe c[TAU]; };                 // kernel-argument constant
+struct E9PreC { fe v[TAU], vn[TAU]; };     // constant with its nu-multiple
+E9C e9c_from_h9(const H9 &h);
+E9PreC e9pre_from_h9(const H9 &h, u64 nu);
+
+// ---- layout / utility ------------------------------------------------------------------------------------------
+void launch_aos_to_soa(const u64 *aos_canon, fe *soa, size_t n, hipStream_t s);     // [n][72] canonical u64 -> [72][n] fe
+void launch_soa_to_aos(const fe *soa, u64 *aos_canon, size_t n, hipStream_t s);
+void launch_fill_ajtai(fe *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s);
+void launch_selftest(const u64 *in_canon /*[n][18]*/, u64 *out_canon /*[n][12]*/, u32 n, fe nu, hipStream_t s);
+// i64 partial sums [nblocks][nv] -> canonical u64 [nv]
+void launch_reduce_rows(const i64 *partial, u32 nblocks, u32 nv, u64 *out_canon, hipStream_t s);
+
+// ---- CRT / ICRT ------------------------------------------------------------------------------------------------
+void launch_crt_fwd(const DevBb &t, const fe *coef, fe *ntt, size_t n, hipStream_t s);
+void launch_icrt_dense(const fe *icrt_mat /*72*72*/, const fe *ntt, fe *coef, size_t n, hipStream_t s);
+
+// ---- decomposition ---------------------------------------------------------------------------------------------
+void launch_decompose(const fe *coef, size_t n, u64 base, u32 digits, int layout, fe *out, hipStream_t s);
+void launch_recompose(const fe *in, size_t n_out, u64 base, u32 digits, fe *out, hipStream_t s);
+void launch_coef_to_i32(const fe *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s);
+void launch_i32_to_coef(const int32_t *planes, fe *coef, size_t n, hipStream_t s);
+void launch_bitplane_crt(const DevBb &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out, hipStream_t s);
+void launch_recompose_crt(const DevBb &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K, int mode_bits,
+                          fe *out, size_t ldz, size_t off, hipStream_t s);
+void launch_linf(const fe *coef, size_t n, u64 *out_max, hipStream_t s);
+
+// ---- Ajtai -----------------------------------------------------------------------------------------------------
+size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits);
+// out: canonical u64 AoS [batch][kappa][72]
+void launch_ajtai(const DevBb &t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits, i64 *partial,
+                  u64 *out, hipStream_t s);
+
+// ---- MLE / eq ----------------------------------------------------------------------------------------------------
+void launch_build_eq(const DevBb &t, const E9PreC *r_dev /*nv*/, const E9PreC *omr_dev /*nv: 1-r*/, u32 nv, fe *eq, hipStream_t s);
+void launch_spmv(const DevBb &t, const u32 *rowptr, const u32 *col, const fe *val /*[nnz][72]*/, const fe *z, size_t ldz, fe *out,
+                 size_t m, int accumulate, hipStream_t s);
+void launch_spmv_t_eq(const DevBb &t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m, fe *q, size_t n,
+                      hipStream_t s);
+size_t red_partial_words(u32 nv);
+void launch_dot_batch(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial,
+                      u64 *out /*[na][nb][72] canonical*/, hipStream_t s);
+void launch_dot_eq(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *eq, size_t ldeq, size_t n, i64 *partial,
+                   u64 *out /*[na][72]*/, hipStream_t s);
+// T[k][c] = sum_i eq[i] * digit_k(planes[c][i]) (mode_bits) or the full value (K = 1): out canonical [K][72][9]
+void launch_coef_eval(const DevBb &t, const int32_t *planes, size_t n, const fe *eq, size_t ldeq, u32 K, int mode_bits, i64 *partial,
+                      u64 *out, hipStream_t s);
+void launch_lincomb_z(const DevBb &t, const fe *z, size_t ldz, u32 K, const E9PreC *coef_dev /*K*tt*/, u32 tt, size_t n, fe *out,
+                      hipStream_t s);
+void launch_add_fhat_comb(const DevBb &t, const int32_t *planes, size_t n_planes, u32 K, const E9C *apow_dev /*K*9*/, fe *G, size_t m,
+                          hipStream_t s);
+
+// ---- sumcheck ------------------------------------------------------------------------------------------------------
+// rows9 groups of 9 planes: out[g][c][j] = in[g][c][2j] + r * (in[g][c][2j+1] - in[g][c][2j])
+void launch_fix(const DevBb &t, const fe *in, size_t ld_in, fe *out, size_t ld_out, size_t n_in, u32 rows9, const E9PreC &r, hipStream_t s);
+
+struct LinDesc {   // CCS multiset structure (nifs/linearization/utils.rs:90-107)
+    u32 t, q;
+    u32 S_off[9];
+    u32 S_idx[16];
+    fe c[8][RE];     // coefficients c_i, NTT form, Montgomery
+    int c_unit[8];   // +1 / -1 when c_i = +-1
+};
+void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg,
+                      i64 *partial, u64 *out, hipStream_t s);
+
+struct FoldArgs {
+    const fe *eqL, *eqR, *eqB;   // fq9 tables [9][ld]
+    const fe *G1, *G2;           // ring tables [72][ld]
+    size_t ld, n;                // leading dimension / current length
+};
+// round 1 straight from the coefficient planes (f-hat virtual, b = 2); Mc = mu_k^(d+1), [2K][9] constants
+void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                        const E9C *Mc_dev, i64 *partial, u64 *out, hipStream_t s);
+// F[(k*9+d)][72][m/2] = f0 + r1 * (f1 - f0)
+void launch_fold_materialize(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
+                             const E9C &r1, fe *F, hipStream_t s);
+void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre_dev, i64 *partial, u64 *out,
+                       hipStream_t s);
+// folded witness in the coefficient domain: out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c) mod X^72 - X^36 + 1
+void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev /*[2K][24]*/, int32_t *out,
+                         hipStream_t s);
+
+}  // namespace lfbb

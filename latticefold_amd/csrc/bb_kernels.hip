@@ -1,0 +1,1044 @@
+// bb_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the BabyBearRingNTT backend (BASELINE configs[2]:
+// "alt-prime 31-bit Montgomery path").  Same data-flow as the Goldilocks kernels (lf_kernels.hip): plane-major (SoA)
+// tables, lane <-> consecutive element index, cross-lane reductions by wave64 shuffles + one LDS hop, the Ajtai mat-vec
+// staged through LDS.  Arithmetic: centred Montgomery int32 words; an F_{p^9} product is 81 v_mad_i64_i32 into nine
+// signed 64-bit column sums (9 * H^2 < 2^63) + nine Montgomery reductions (bb_field.cuh).  No MFMA.
+#include "bb_kernels.h"
+
+#include <stdlib.h>
+
+namespace lfbb {
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+static inline unsigned grid_for(size_t n, unsigned cap = 2048) {
+    size_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+DevBb make_dev_bb(const BbTables &T) {
+    DevBb d;
+    d.nu = from_canon(T.nu);
+    d.w4 = from_canon(T.w4); d.w2 = from_canon(T.w2); d.w10 = from_canon(T.w10); d.w1 = from_canon(T.w1);
+    d.w7 = from_canon(T.w7); d.w5 = from_canon(T.w5); d.w11 = from_canon(T.w11);
+    for (int p = 0; p < 8; p++) {
+        d.slot_of_pos[p] = T.slot_of_pos[p];
+        for (int r = 0; r < TAU; r++) { d.pos[r][p] = T.pos[r][p]; d.tw[r][p] = from_canon(T.tw[r][p]); }
+    }
+    return d;
+}
+E9C e9c_from_h9(const H9 &h) { E9C r; for (int i = 0; i < TAU; i++) r.c[i] = from_canon(h.c[i]); return r; }
+E9PreC e9pre_from_h9(const H9 &h, u64 nu) {
+    E9PreC r;
+    for (int i = 0; i < TAU; i++) { r.v[i] = from_canon(h.c[i]); r.vn[i] = from_canon(hmul(h.c[i] % BB_P, nu)); }
+    return r;
+}
+
+__device__ __forceinline__ E9 ld9(const fe *tab, size_t ld, u32 slot, size_t i) {
+    E9 r;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) r.c[c] = tab[(size_t)(TAU * slot + c) * ld + i];
+    return r;
+}
+__device__ __forceinline__ void st9(fe *tab, size_t ld, u32 slot, size_t i, const E9 &v) {
+#pragma unroll
+    for (int c = 0; c < TAU; c++) tab[(size_t)(TAU * slot + c) * ld + i] = v.c[c];
+}
+__device__ __forceinline__ E9 e9c(const E9C &k) { E9 r; for (int i = 0; i < TAU; i++) r.c[i] = k.c[i]; return r; }
+__device__ __forceinline__ E9Pre e9p(const E9PreC &k) { E9Pre r; for (int i = 0; i < TAU; i++) { r.v.c[i] = k.v[i]; r.vn.c[i] = k.vn[i]; } return r; }
+// reduce a signed 64-bit sum of residues to a centred word
+__device__ __forceinline__ fe fred(i64 s) { return centre((int32_t)(s % (i64)BB_P)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// reductions: every thread holds NV signed 64-bit partial sums (of centred words)
+__device__ __forceinline__ i64 wave_sum(i64 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down((long long)v, off, 64);
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ void block_sum_store(i64 (&v)[NV], i64 *dst) {
+    __shared__ i64 sm[4][NV];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        i64 s = wave_sum(v[i]);
+        if (lane == 0) sm[wave][i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256) dst[i] = sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i];
+}
+// out[i] = canonical( sum_b partial[b*nv + i] ); values are Montgomery words
+__global__ void __launch_bounds__(256) k_reduce_rows(const i64 *partial, u32 nblocks, u32 nv, u64 *out) {
+    u32 i = blockIdx.x;
+    i64 acc[1] = {0};
+    for (u32 b = threadIdx.x; b < nblocks; b += 256) acc[0] += partial[(size_t)b * nv + i] % (i64)BB_P;
+    __shared__ i64 res[1];
+    block_sum_store<1>(acc, res);
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] = to_canon(fred(res[0]));
+}
+void launch_reduce_rows(const i64 *partial, u32 nblocks, u32 nv, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_rows, dim3(nv), dim3(256), 0, s, partial, nblocks, nv, out);
+}
+constexpr u32 RED_BLOCKS = 256;
+size_t red_partial_words(u32 nv) { return (size_t)RED_BLOCKS * nv; }
+
+// ---------------------------------------------------------------------------------------------------------
+// layout + Montgomery conversion at the ABI
+__global__ void __launch_bounds__(256) k_aos_to_soa(const u64 *aos, fe *soa, size_t n) {
+    __shared__ fe tile[64][RE + 1];
+    size_t base = (size_t)blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * RE; idx += 256) {
+        size_t e = base + idx / RE;
+        tile[idx / RE][idx % RE] = e < n ? from_canon(aos[e * RE + idx % RE]) : 0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * RE; idx += 256) {
+        int w = idx / 64, j = idx % 64;
+        if (base + j < n) soa[(size_t)w * n + base + j] = tile[j][w];
+    }
+}
+__global__ void __launch_bounds__(256) k_soa_to_aos(const fe *soa, u64 *aos, size_t n) {
+    __shared__ fe tile[64][RE + 1];
+    size_t base = (size_t)blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * RE; idx += 256) {
+        int w = idx / 64, j = idx % 64;
+        tile[j][w] = base + j < n ? soa[(size_t)w * n + base + j] : 0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * RE; idx += 256) {
+        size_t e = base + idx / RE;
+        if (e < n) aos[e * RE + idx % RE] = to_canon(tile[idx / RE][idx % RE]);
+    }
+}
+void launch_aos_to_soa(const u64 *aos, fe *soa, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_aos_to_soa, dim3(cdiv(n, 64)), dim3(256), 0, s, aos, soa, n);
+}
+void launch_soa_to_aos(const fe *soa, u64 *aos, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_soa_to_aos, dim3(cdiv(n, 64)), dim3(256), 0, s, soa, aos, n);
+}
+// workload.py splitmix_fq(ring="babybear"): top 32 bits of SplitMix64 word (index+1), mod p
+__device__ __forceinline__ u64 splitmix_bb(u64 seed, u64 index) {
+    u64 z = seed + (index + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (z >> 32) % BB_P;
+}
+__global__ void __launch_bounds__(256) k_fill_ajtai(fe *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed) {
+    size_t total = (size_t)kappa * RE * n;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < total; i += st) {
+        size_t j = i % n, w = (i / n) % RE, row = i / (RE * n);
+        A[i] = from_canon(splitmix_bb(seed, (row * n_total + col0 + j) * RE + w));
+    }
+}
+void launch_fill_ajtai(fe *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_ajtai, dim3(4096), dim3(256), 0, s, A, kappa, n, n_total, col0, seed);
+}
+// arithmetic self-test: in[i] = (a[9], b[9]) canonical; out[i] = (a*b [9], a0+b0, a0-b0, a0*b0) canonical.
+// The host recomputes with plain % arithmetic (bb_host.cpp) and compares.
+__global__ void __launch_bounds__(256) k_selftest(const u64 *in, u64 *out, u32 n, fe nu) {
+    u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    E9 a, b;
+    for (int c = 0; c < TAU; c++) { a.c[c] = from_canon(in[(size_t)i * 18 + c]); b.c[c] = from_canon(in[(size_t)i * 18 + 9 + c]); }
+    E9 p = e9_mul(a, b, nu);
+    for (int c = 0; c < TAU; c++) out[(size_t)i * 12 + c] = to_canon(p.c[c]);
+    out[(size_t)i * 12 + 9] = to_canon(fadd(a.c[0], b.c[0]));
+    out[(size_t)i * 12 + 10] = to_canon(fsub(a.c[0], b.c[0]));
+    out[(size_t)i * 12 + 11] = to_canon(fmul(a.c[0], b.c[0]));
+}
+void launch_selftest(const u64 *in, u64 *out, u32 n, fe nu, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest, dim3(cdiv(n, 256)), dim3(256), 0, s, in, out, n, nu);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CRT: a(X) = sum_{r<9} X^r A_r(X^9); A_r is evaluated at the 8 primitive 24th roots by three radix-2 layers over
+// U^8 - U^4 + 1 = (U^4 - w^4)(U^4 - w^20); the per-slot monomial twist X^r -> tw[r] Y^pos[r] maps F_p[X]/(X^9 - zeta_k)
+// onto F_p[Y]/(Y^9 - nu).  (stark-rings CRT; call sites arith.rs:238,327.)
+__device__ __forceinline__ void crt8(const fe x[8], fe o[8], const DevBb &t) {
+    fe lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        fe tt = fmul(t.w4, x[i + 4]);
+        lo[i] = fadd(x[i], tt);
+        hi[i] = fsub(fadd(x[i], x[i + 4]), tt);
+    }
+    fe l0[2], l1[2], h0[2], h1[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        fe tt = fmul(t.w2, lo[i + 2]);
+        l0[i] = fadd(lo[i], tt); l1[i] = fsub(lo[i], tt);
+        fe uu = fmul(t.w10, hi[i + 2]);
+        h0[i] = fadd(hi[i], uu); h1[i] = fsub(hi[i], uu);
+    }
+    fe a = fmul(t.w1, l0[1]);  o[0] = fadd(l0[0], a); o[1] = fsub(l0[0], a);
+    fe b = fmul(t.w7, l1[1]);  o[2] = fadd(l1[0], b); o[3] = fsub(l1[0], b);
+    fe c = fmul(t.w5, h0[1]);  o[4] = fadd(h0[0], c); o[5] = fsub(h0[0], c);
+    fe d = fmul(t.w11, h1[1]); o[6] = fadd(h1[0], d); o[7] = fsub(h1[0], d);
+}
+// coefficients a[72] (Montgomery) -> the 72 NTT words of element j of plane table `out`
+__device__ __forceinline__ void crt_store(const fe a[RE], fe *out, size_t ld, size_t j, const DevBb &t) {
+#pragma unroll
+    for (int r = 0; r < TAU; r++) {
+        fe x[8], A[8];
+#pragma unroll
+        for (int v = 0; v < 8; v++) x[v] = a[r + TAU * v];
+        crt8(x, A, t);
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            int plane = TAU * t.slot_of_pos[p] + t.pos[r][p];
+            out[(size_t)plane * ld + j] = r == 0 ? A[p] : fmul(t.tw[r][p], A[p]);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_crt_fwd(DevBb t, const fe *coef, fe *ntt, size_t n) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    fe a[RE];
+#pragma unroll
+    for (int c = 0; c < RE; c++) a[c] = coef[(size_t)c * n + j];
+    crt_store(a, ntt, n, j, t);
+}
+void launch_crt_fwd(const DevBb &t, const fe *coef, fe *ntt, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_crt_fwd, dim3(cdiv(n, 256)), dim3(256), 0, s, t, coef, ntt, n);
+}
+// ICRT as the dense 72x72 F_p matrix (rare: ingest / export only)
+__global__ void __launch_bounds__(256) k_icrt_dense(const fe *mat, const fe *ntt, fe *coef, size_t n) {
+    __shared__ fe M[RE * RE];
+    for (int i = threadIdx.x; i < RE * RE; i += 256) M[i] = mat[i];
+    __syncthreads();
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    fe x[RE];
+#pragma unroll
+    for (int c = 0; c < RE; c++) x[c] = ntt[(size_t)c * n + j];
+    for (int i = 0; i < RE; i++) {
+        i64 tot = 0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {   // 9 products per exact 64-bit group
+            i64 acc = 0;
+#pragma unroll
+            for (int c = 0; c < 9; c++) acc += (i64)M[i * RE + 9 * g + c] * (i64)x[9 * g + c];
+            tot += mred(acc);
+        }
+        coef[(size_t)i * n + j] = fred(tot);
+    }
+}
+void launch_icrt_dense(const fe *mat, const fe *ntt, fe *coef, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_icrt_dense, dim3(cdiv(n, 256)), dim3(256), 0, s, mat, ntt, coef, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// balanced decomposition on coefficient tables, power-of-two base (stark_rings::balanced_decomposition; call sites
+// arith.rs:235, decomposition/utils.rs:23-31,48).  Sign-magnitude, |digit| <= base/2, ties kept.
+__global__ void __launch_bounds__(256) k_decompose(const fe *coef, size_t n, u32 log_base, u32 digits, int layout, fe *out) {
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * RE) return;
+    size_t c = idx / n, i = idx % n;
+    u32 v = to_canon(coef[idx]);
+    bool neg = v > (BB_P - 1) / 2;
+    u64 mag = neg ? BB_P - v : v;
+    u64 half = 1ULL << (log_base - 1), mask = (1ULL << log_base) - 1;
+    size_t n_out = layout == 0 ? n * digits : n;
+    for (u32 k = 0; k < digits; k++) {
+        u64 rem = mag & mask;
+        mag >>= log_base;
+        int64_t dg;
+        if (rem > half) { dg = (int64_t)rem - (int64_t)(mask + 1); mag += 1; }
+        else dg = (int64_t)rem;
+        if (neg) dg = -dg;
+        size_t o = layout == 0 ? (c * n_out + i * digits + k) : ((size_t)k * RE * n + c * n + i);
+        out[o] = from_small((int32_t)dg);
+    }
+}
+void launch_decompose(const fe *coef, size_t n, u64 base, u32 digits, int layout, fe *out, hipStream_t s) {
+    u32 lb = 0;
+    while ((1ULL << lb) < base) lb++;
+    if (n) hipLaunchKernelGGL(k_decompose, dim3(cdiv(n * RE, 256)), dim3(256), 0, s, coef, n, lb, digits, layout, out);
+}
+__global__ void __launch_bounds__(256) k_recompose(const fe *in, size_t n_out, fe base, u32 digits, fe *out) {
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_out * RE) return;
+    size_t w = idx / n_out, i = idx % n_out;
+    size_t n_in = n_out * digits;
+    fe acc = 0, pw = BB_ONE;
+    for (u32 j = 0; j < digits; j++) {
+        acc = fadd(acc, fmul(in[w * n_in + i * digits + j], pw));
+        pw = fmul(pw, base);
+    }
+    out[idx] = acc;
+}
+void launch_recompose(const fe *in, size_t n_out, u64 base, u32 digits, fe *out, hipStream_t s) {
+    if (n_out) hipLaunchKernelGGL(k_recompose, dim3(cdiv(n_out * RE, 256)), dim3(256), 0, s, in, n_out, from_canon(base % BB_P), digits, out);
+}
+__global__ void __launch_bounds__(256) k_coef_to_i32(const fe *coef, int32_t *planes, size_t total, u32 bound, int *viol) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    int bad = 0;
+    for (; i < total; i += st) {
+        u32 v = to_canon(coef[i]);
+        bool neg = v > (BB_P - 1) / 2;
+        u32 mag = neg ? BB_P - v : v;
+        if (mag > bound) { bad = 1; mag = 0; }
+        planes[i] = neg ? -(int32_t)mag : (int32_t)mag;
+    }
+    if (bad) atomicOr(viol, 1);
+}
+void launch_coef_to_i32(const fe *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s) {
+    hipLaunchKernelGGL(k_coef_to_i32, dim3(grid_for(n * RE, 4096)), dim3(256), 0, s, coef, planes, n * RE, bound, viol);
+}
+__global__ void __launch_bounds__(256) k_i32_to_coef(const int32_t *planes, fe *coef, size_t total) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < total; i += st) coef[i] = from_small(planes[i]);
+}
+void launch_i32_to_coef(const int32_t *planes, fe *coef, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_i32_to_coef, dim3(grid_for(n * RE, 4096)), dim3(256), 0, s, planes, coef, n * RE);
+}
+__global__ void __launch_bounds__(256) k_linf(const fe *coef, size_t total, unsigned long long *out_max) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    u64 mx = 0;
+    for (; i < total; i += st) {
+        u32 v = to_canon(coef[i]);
+        u64 mag = v > (BB_P - 1) / 2 ? BB_P - v : v;
+        mx = mag > mx ? mag : mx;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        u64 o = __shfl_down((unsigned long long)mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_max, (unsigned long long)mx);
+}
+void launch_linf(const fe *coef, size_t n, u64 *out_max, hipStream_t s) {
+    hipMemsetAsync(out_max, 0, 8, s);
+    hipLaunchKernelGGL(k_linf, dim3(grid_for(n * RE, 4096)), dim3(256), 0, s, coef, n * RE, (unsigned long long *)out_max);
+}
+
+// bit-plane k of a centred small value: sign(v) * bit_k(|v|)   (base-2 balanced digits, decomposition.rs:159-167)
+__device__ __forceinline__ int digit2(int32_t v, u32 k) {
+    int32_t m = v < 0 ? -v : v;
+    int d = (m >> k) & 1;
+    return v < 0 ? -d : d;
+}
+__device__ __forceinline__ fe fe_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? BB_ONE : -BB_ONE); }
+
+__global__ void __launch_bounds__(128) k_bitplane_crt(DevBb t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out) {
+    size_t j = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (j >= n) return;
+    int32_t v[RE];
+#pragma unroll
+    for (int c = 0; c < RE; c++) v[c] = planes[(size_t)c * ld + j];
+    for (u32 k = k0; k < k1; k++) {
+        fe a[RE];
+#pragma unroll
+        for (int c = 0; c < RE; c++) a[c] = fe_from_digit(digit2(v[c], k));
+        crt_store(a, out + (size_t)(k - k0) * RE * n, n, j, t);
+    }
+}
+void launch_bitplane_crt(const DevBb &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out, hipStream_t s) {
+    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 128)), dim3(128), 0, s, t, planes, ld, n, k0, k1, out);
+}
+
+struct BPow { fe v[8]; };
+__global__ void __launch_bounds__(128) k_recompose_crt(DevBb t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, BPow bp, u32 K,
+                                                        int mode_bits, fe *out, size_t ldz, size_t off) {
+    size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
+    u32 k = blockIdx.y;
+    if (i >= wit_len) return;
+    fe a[RE];
+#pragma unroll
+    for (int c = 0; c < RE; c++) {
+        fe acc = 0;
+        for (u32 l = 0; l < L; l++) {
+            int32_t v = planes[(size_t)c * n_planes + i * L + l];
+            if (mode_bits) {
+                int d = digit2(v, k);
+                if (d > 0) acc = fadd(acc, bp.v[l]);
+                else if (d < 0) acc = fsub(acc, bp.v[l]);
+            } else {
+                acc = fadd(acc, fmul(bp.v[l], from_small(v)));
+            }
+        }
+        a[c] = acc;
+    }
+    crt_store(a, out + (size_t)k * RE * ldz, ldz, off + i, t);
+}
+void launch_recompose_crt(const DevBb &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K, int mode_bits, fe *out,
+                          size_t ldz, size_t off, hipStream_t s) {
+    BPow bp;
+    u64 pw = 1;
+    for (int l = 0; l < 8; l++) { bp.v[l] = from_canon(pw); pw = hmul(pw, B % BB_P); }
+    hipLaunchKernelGGL(k_recompose_crt, dim3(cdiv(wit_len, 128), K), dim3(128), 0, s, t, planes, n_planes, wit_len, L, bp, K, mode_bits, out,
+                       ldz, off);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ajtai commit (commitment_scheme.rs:37-54 -> Matrix::checked_mul_vec): C[k][i] = sum_j A[i][j] (.) F_k[j].  Per slot a
+// skinny GEMM (kappa x n) * (n x batch) over F_{p^9}.  Block = one slot x one j-split; tiles of AJ_T columns of A, F and
+// nu*F are staged in LDS with coalesced loads (the nu pre-multiplication is amortised over the kappa uses); thread
+// (i,k) runs the 81-mad column products from LDS and keeps nine signed 64-bit sums of reduced words.
+constexpr int AJ_T = 32;
+constexpr int AJ_REC = TAU;                  // words per (row, column) record
+constexpr int AJ_ROW = AJ_T * AJ_REC + 1;    // +1 word: rows of consecutive k fall into different LDS banks
+__global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits,
+                                               i64 *partial) {
+    extern __shared__ fe lds[];
+    fe *sA = lds;                                    // [kappa][AJ_ROW]
+    fe *sF = sA + (size_t)kappa * AJ_ROW;            // [batch][AJ_ROW]
+    fe *sFn = sF + (size_t)batch * AJ_ROW;           // nu * F
+    u32 slot = blockIdx.y, split = blockIdx.x;
+    size_t per = (n + splits - 1) / splits;
+    per = (per + AJ_T - 1) / AJ_T * AJ_T;
+    size_t j0 = (size_t)split * per, j1 = j0 + per < n ? j0 + per : n;
+    u32 nout = kappa * batch;
+    u32 oi = threadIdx.x / batch, ok = threadIdx.x % batch;
+    bool active = threadIdx.x < nout;
+    i64 acc[TAU];
+#pragma unroll
+    for (int c = 0; c < TAU; c++) acc[c] = 0;
+    for (size_t jt = j0; jt < j1; jt += AJ_T) {
+        u32 rowsA = kappa * TAU;
+        for (u32 idx = threadIdx.x; idx < rowsA * AJ_T; idx += 256) {
+            u32 jj = idx % AJ_T, r = idx / AJ_T, i = r / TAU, c = r % TAU;
+            size_t j = jt + jj;
+            sA[(size_t)i * AJ_ROW + jj * AJ_REC + c] = j < j1 ? A[((size_t)i * RE + TAU * slot + c) * n + j] : 0;
+        }
+        u32 rowsF = batch * TAU;
+        for (u32 idx = threadIdx.x; idx < rowsF * AJ_T; idx += 256) {
+            u32 jj = idx % AJ_T, r = idx / AJ_T, k = r / TAU, c = r % TAU;
+            size_t j = jt + jj;
+            fe v = j < j1 ? F[((size_t)k * RE + TAU * slot + c) * ldF + j] : 0;
+            sF[(size_t)k * AJ_ROW + jj * AJ_REC + c] = v;
+            sFn[(size_t)k * AJ_ROW + jj * AJ_REC + c] = fmul(v, t.nu);
+        }
+        __syncthreads();
+        if (active) {
+            const fe *pa = sA + (size_t)oi * AJ_ROW, *pf = sF + (size_t)ok * AJ_ROW, *pn = sFn + (size_t)ok * AJ_ROW;
+#pragma unroll 2
+            for (int jj = 0; jj < AJ_T; jj++) {
+                E9 a, b, bn;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) { a.c[c] = pa[jj * AJ_REC + c]; b.c[c] = pf[jj * AJ_REC + c]; bn.c[c] = pn[jj * AJ_REC + c]; }
+                E9 p = e9_mul_pre(a, b, bn);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) acc[c] += p.c[c];
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        // partial[split][slot][i][k][9]
+        i64 *o = partial + ((((size_t)split * 8 + slot) * kappa + oi) * batch + ok) * TAU;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) o[c] = acc[c];
+    }
+}
+// out[k][i][9*slot+c] = canonical sum over splits
+__global__ void __launch_bounds__(256) k_ajtai_reduce(const i64 *partial, u32 kappa, u32 batch, u32 splits, u64 *out) {
+    u32 idx = blockIdx.x * 256 + threadIdx.x;
+    u32 total = 8 * kappa * batch * TAU;
+    if (idx >= total) return;
+    u32 c = idx % TAU, k = (idx / TAU) % batch, i = (idx / (TAU * batch)) % kappa, slot = idx / (TAU * batch * kappa);
+    i64 acc = 0;
+    for (u32 s = 0; s < splits; s++) acc += partial[((((size_t)s * 8 + slot) * kappa + i) * batch + k) * TAU + c] % (i64)BB_P;
+    out[((size_t)k * kappa + i) * RE + TAU * slot + c] = to_canon(fred(acc));
+}
+size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) { return (size_t)splits * 8 * kappa * batch * TAU; }
+void launch_ajtai(const DevBb &t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits, i64 *partial, u64 *out,
+                  hipStream_t s) {
+    size_t shm = ((size_t)kappa + 2 * (size_t)batch) * AJ_ROW * sizeof(fe);
+    hipLaunchKernelGGL(k_ajtai, dim3(splits, 8), dim3(256), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
+    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * TAU, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// eq(x, r) table over {0,1}^nv, LSB-first (build_eq_x_r, utils/sumcheck/utils.rs:100-170): entry i =
+// prod_j (bit_j(i) ? r_j : 1 - r_j); one thread per entry, nv products by pre-multiplied constants.
+__global__ void __launch_bounds__(256) k_build_eq(DevBb t, const E9PreC *r, const E9PreC *omr, u32 nv, fe *eq) {
+    size_t n = (size_t)1 << nv;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    E9 acc = e9_from_fe(BB_ONE);
+    for (u32 j = 0; j < nv; j++) {
+        const E9PreC &f = ((i >> j) & 1) ? r[j] : omr[j];
+        acc = e9_mul(acc, e9p(f));
+    }
+#pragma unroll
+    for (int c = 0; c < TAU; c++) eq[(size_t)c * n + i] = acc.c[c];
+}
+void launch_build_eq(const DevBb &t, const E9PreC *r, const E9PreC *omr, u32 nv, fe *eq, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_eq, dim3(cdiv((size_t)1 << nv, 256)), dim3(256), 0, s, t, r, omr, nv, eq);
+}
+
+// sparse mat-vec (mat_vec_mul, arith/utils.rs:52-65): out[row] = sum_k val_k (.) z[col_k]
+__global__ void __launch_bounds__(256) k_spmv(DevBb t, const u32 *rowptr, const u32 *col, const fe *val, const fe *z, size_t ldz, fe *out,
+                                              size_t m, int accumulate) {
+    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (row >= m) return;
+    E9 acc = accumulate ? ld9(out, m, slot, row) : e9_zero();
+    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) {
+        E9 v;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) v.c[c] = val[(size_t)k * RE + TAU * slot + c];
+        acc = e9_add(acc, e9_mul(v, ld9(z, ldz, slot, col[k]), t.nu));
+    }
+    st9(out, m, slot, row, acc);
+}
+void launch_spmv(const DevBb &t, const u32 *rowptr, const u32 *col, const fe *val, const fe *z, size_t ldz, fe *out, size_t m,
+                 int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_spmv, dim3(cdiv(m, 256), 8), dim3(256), 0, s, t, rowptr, col, val, z, ldz, out, m, accumulate);
+}
+// q[col] = sum_{rows} eq[row] * val  (CSC)
+__global__ void __launch_bounds__(256) k_spmv_t_eq(DevBb t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m,
+                                                   fe *q, size_t n) {
+    size_t c0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (c0 >= n) return;
+    E9 acc = e9_zero();
+    for (u32 k = colptr[c0]; k < colptr[c0 + 1]; k++) {
+        E9 v, e;
+        size_t r = rowidx[k];
+#pragma unroll
+        for (int c = 0; c < TAU; c++) { v.c[c] = val[(size_t)k * RE + TAU * slot + c]; e.c[c] = eq[(size_t)c * m + r]; }
+        acc = e9_add(acc, e9_mul(v, e, t.nu));
+    }
+    st9(q, n, slot, c0, acc);
+}
+void launch_spmv_t_eq(const DevBb &t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m, fe *q, size_t n,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_spmv_t_eq, dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, colptr, rowidx, val, eq, m, q, n);
+}
+
+// batched inner products (evaluate_mles, utils/mle_helpers.rs:65-88, restructured as dot products)
+template <int NB>
+__global__ void __launch_bounds__(256) k_dot_batch(DevBb t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, size_t n, i64 *partial) {
+    // grid (blocks, 8 slots, na); partial[block][(a*NB + b)*72 + 9*slot + c]
+    u32 slot = blockIdx.y, a = blockIdx.z;
+    i64 acc[NB * TAU];
+#pragma unroll
+    for (int i = 0; i < NB * TAU; i++) acc[i] = 0;
+    const fe *Xa = X + (size_t)a * RE * ldx;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        E9 x = ld9(Xa, ldx, slot, i);
+        E9 xn = e9_times_nu(x, t.nu);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            E9 y = ld9(Y + (size_t)b * RE * ldy, ldy, slot, i);
+            E9 p = e9_mul_pre(y, x, xn);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) acc[b * TAU + c] += p.c[c];
+        }
+    }
+    __shared__ i64 red[NB * TAU];
+    block_sum_store<NB * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < NB * TAU) {
+        u32 b = threadIdx.x / TAU, c = threadIdx.x % TAU;
+        partial[(size_t)blockIdx.x * ((size_t)gridDim.z * NB * RE) + ((size_t)a * NB + b) * RE + TAU * slot + c] = red[threadIdx.x];
+    }
+}
+void launch_dot_batch(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial, u64 *out,
+                      hipStream_t s) {
+    u32 gb = (u32)((n + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    dim3 g(gb, 8, na);
+    switch (nb) {
+        case 1: hipLaunchKernelGGL((k_dot_batch<1>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
+        case 2: hipLaunchKernelGGL((k_dot_batch<2>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
+        case 3: hipLaunchKernelGGL((k_dot_batch<3>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
+        default: hipLaunchKernelGGL((k_dot_batch<4>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
+    }
+    launch_reduce_rows(partial, gb, na * nb * RE, out, s);
+}
+__global__ void __launch_bounds__(256) k_dot_eq(DevBb t, const fe *X, size_t ldx, const fe *eq, size_t ldeq, size_t n, i64 *partial) {
+    u32 slot = blockIdx.y, a = blockIdx.z, na = gridDim.z;
+    i64 acc[TAU];
+#pragma unroll
+    for (int i = 0; i < TAU; i++) acc[i] = 0;
+    const fe *Xa = X + (size_t)a * RE * ldx;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        E9 x = ld9(Xa, ldx, slot, i), e;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) e.c[c] = eq[(size_t)c * ldeq + i];
+        E9 p = e9_mul(x, e, t.nu);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) acc[c] += p.c[c];
+    }
+    __shared__ i64 red[TAU];
+    block_sum_store<TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < TAU) partial[(size_t)blockIdx.x * ((size_t)na * RE) + (size_t)a * RE + TAU * slot + threadIdx.x] = red[threadIdx.x];
+}
+void launch_dot_eq(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *eq, size_t ldeq, size_t n, i64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((n + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_dot_eq, dim3(gb, 8, na), dim3(256), 0, s, t, X, ldx, eq, ldeq, n, partial);
+    launch_reduce_rows(partial, gb, na * RE, out, s);
+}
+
+// f-hat evaluations without materialising f-hat (Witness::get_fhat, arith.rs:273-297, is a re-layout of f_coeff):
+// T[k][c] = sum_i eq[i] * digit_k(f[i][c]);  v_d slot s = T[k][8d+s].
+__global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t n, const fe *eq, size_t ldeq, u32 K, int mode_bits,
+                                                   i64 *partial) {
+    // grid (blocks, 72 coefficients, K-groups of 4 bit-planes); partial[block][(k*72 + c)*9 + q]
+    u32 c = blockIdx.y, kg = blockIdx.z * 4;
+    i64 acc[4 * TAU];
+#pragma unroll
+    for (int i = 0; i < 4 * TAU; i++) acc[i] = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int32_t v = planes[(size_t)c * n + i];
+        fe e[TAU];
+#pragma unroll
+        for (int q = 0; q < TAU; q++) e[q] = eq[(size_t)q * ldeq + i];
+        bool neg = v < 0;
+        u32 mg = (u32)(neg ? -v : v);
+        if (mode_bits) {
+#pragma unroll
+            for (int q = 0; q < TAU; q++) e[q] = neg ? -e[q] : e[q];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int32_t mask = -(int32_t)((mg >> (kg + k)) & 1);
+#pragma unroll
+                for (int q = 0; q < TAU; q++) acc[TAU * k + q] += (i64)(e[q] & mask);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < TAU; q++) acc[q] += (i64)e[q] * (i64)v;   // integer scaling keeps the Montgomery form
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * TAU; i++) acc[i] = acc[i] % (i64)BB_P;
+    __shared__ i64 red[4 * TAU];
+    block_sum_store<4 * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < 4 * TAU) {
+        u32 k = kg + threadIdx.x / TAU, q = threadIdx.x % TAU;
+        if (k < K) partial[(size_t)blockIdx.x * ((size_t)K * RE * TAU) + ((size_t)k * RE + c) * TAU + q] = red[threadIdx.x];
+    }
+}
+void launch_coef_eval(const DevBb &t, const int32_t *planes, size_t n, const fe *eq, size_t ldeq, u32 K, int mode_bits, i64 *partial, u64 *out,
+                      hipStream_t s) {
+    u32 gb = (u32)((n + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_coef_eval, dim3(gb, RE, (K + 3) / 4), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
+    launch_reduce_rows(partial, gb, K * RE * TAU, out, s);
+}
+
+// zz_j = sum_k coef[k][j] * z_k   (Mz restructuring: G += sum_j M_j zz_j)
+__global__ void __launch_bounds__(256) k_lincomb_z(DevBb t, const fe *z, size_t ldz, u32 K, const E9PreC *coef, u32 tt, size_t n, fe *out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (i >= n) return;
+    i64 acc[4 * TAU];
+#pragma unroll
+    for (int q = 0; q < 4 * TAU; q++) acc[q] = 0;
+#pragma unroll 1
+    for (u32 k = 0; k < K; k++) {
+        E9 zk = ld9(z + (size_t)k * RE * ldz, ldz, slot, i);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((u32)j < tt) {
+                E9 p = e9_mul(zk, e9p(coef[k * tt + j]));
+#pragma unroll
+                for (int c = 0; c < TAU; c++) acc[j * TAU + c] += p.c[c];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((u32)j < tt) {
+#pragma unroll
+            for (int c = 0; c < TAU; c++) out[((size_t)j * RE + TAU * slot + c) * ldz + i] = fred(acc[j * TAU + c]);
+        }
+}
+void launch_lincomb_z(const DevBb &t, const fe *z, size_t ldz, u32 K, const E9PreC *coef, u32 tt, size_t n, fe *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_lincomb_z, dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef, tt, n, out);
+}
+// G[row][slot] += sum_{k<K} sum_{d<9} apow[k][d] * digit_k(planes[8d+slot][row])   (rows < n_planes)
+__global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, size_t n_planes, u32 K, const E9C *apow, fe *G, size_t m) {
+    __shared__ fe sc[32 * TAU * TAU];
+    for (u32 i = threadIdx.x; i < K * TAU * TAU; i += 256) sc[i] = apow[i / TAU].c[i % TAU];
+    __syncthreads();
+    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (row >= n_planes) return;
+    i64 acc[TAU];
+#pragma unroll
+    for (int c = 0; c < TAU; c++) acc[c] = 0;
+#pragma unroll 1
+    for (int d = 0; d < TAU; d++) {
+        int32_t v = planes[(size_t)(8 * d + slot) * n_planes + row];
+        bool neg = v < 0;
+        u32 mg = (u32)(neg ? -v : v);
+        i64 loc[TAU];
+#pragma unroll
+        for (int c = 0; c < TAU; c++) loc[c] = 0;
+        for (u32 k = 0; k < K; k++) {
+            int32_t mask = -(int32_t)((mg >> k) & 1);
+            const fe *ap = sc + ((size_t)k * TAU + d) * TAU;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) loc[c] += (i64)(ap[c] & mask);
+        }
+#pragma unroll
+        for (int c = 0; c < TAU; c++) acc[c] += neg ? -loc[c] : loc[c];
+    }
+#pragma unroll
+    for (int c = 0; c < TAU; c++) {
+        size_t o = (size_t)(TAU * slot + c) * m + row;
+        G[o] = fred(acc[c] + (i64)G[o]);
+    }
+}
+void launch_add_fhat_comb(const DevBb &t, const int32_t *planes, size_t n_planes, u32 K, const E9C *apow, fe *G, size_t m, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_fhat_comb, dim3(cdiv(n_planes, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow, G, m);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DenseMultilinearExtension::fix_variables (sumcheck/prover.rs:70-72,112-123): new[j] = old[2j] + r (old[2j+1] - old[2j])
+__global__ void __launch_bounds__(256) k_fix(DevBb t, const fe *in, size_t ld_in, fe *out, size_t ld_out, size_t n_in, E9PreC r) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t g = blockIdx.y;
+    if (j >= n_in / 2) return;
+    const fe *pi = in + g * TAU * ld_in;
+    E9 a, b;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) {
+        int2 v = *reinterpret_cast<const int2 *>(pi + (size_t)c * ld_in + 2 * j);
+        a.c[c] = v.x; b.c[c] = v.y;
+    }
+    E9 d = e9_mul(e9_sub(b, a), e9p(r));
+    E9 o = e9_add(a, d);
+    fe *po = out + g * TAU * ld_out;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) po[(size_t)c * ld_out + j] = o.c[c];
+}
+void launch_fix(const DevBb &t, const fe *in, size_t ld_in, fe *out, size_t ld_out, size_t n_in, u32 rows9, const E9PreC &r, hipStream_t s) {
+    if (n_in < 2 || !rows9) return;
+    u32 gy = rows9;
+    // grid.y is limited to 65535: split very tall tables
+    for (u32 g0 = 0; g0 < gy; g0 += 32768) {
+        u32 cnt = gy - g0 < 32768 ? gy - g0 : 32768;
+        hipLaunchKernelGGL(k_fix, dim3(cdiv(n_in / 2, 256), cnt), dim3(256), 0, s, t, in + (size_t)g0 * TAU * ld_in, ld_in,
+                           out + (size_t)g0 * TAU * ld_out, ld_out, n_in, r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// linearization sumcheck round (comb fn nifs/linearization/utils.rs:90-107): g(X) = eq(X) * sum_i c_i prod_{j in S_i} Mz_j(X),
+// evaluated at X = 0..deg on every index pair by stepping vals += (v1 - v0)  (sumcheck/prover.rs:111-160)
+__device__ __forceinline__ E9 pick4(const E9 (&v)[4], u32 idx) {
+    E9 r;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) r.c[c] = idx == 0 ? v[0].c[c] : (idx == 1 ? v[1].c[c] : (idx == 2 ? v[2].c[c] : v[3].c[c]));
+    return r;
+}
+__global__ void __launch_bounds__(256) k_lin_round(DevBb t, LinDesc desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg,
+                                                   i64 *partial) {
+    u32 slot = blockIdx.y;
+    i64 acc[4 * TAU];
+#pragma unroll
+    for (int i = 0; i < 4 * TAU; i++) acc[i] = 0;
+    size_t pairs = n / 2;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+        E9 v[4], st[4], e, es;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if ((u32)q < desc.t) {
+                E9 a = ld9(mz + (size_t)q * RE * ld, ld, slot, 2 * j), b = ld9(mz + (size_t)q * RE * ld, ld, slot, 2 * j + 1);
+                v[q] = a; st[q] = e9_sub(b, a);
+            } else { v[q] = e9_zero(); st[q] = e9_zero(); }
+        }
+        {
+            E9 a, b;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) { a.c[c] = eq[(size_t)c * ldeq + 2 * j]; b.c[c] = eq[(size_t)c * ldeq + 2 * j + 1]; }
+            e = a; es = e9_sub(b, a);
+        }
+        for (u32 X = 0; X <= deg; X++) {
+            if (X) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if ((u32)q < desc.t) v[q] = e9_add(v[q], st[q]);
+                e = e9_add(e, es);
+            }
+            E9 sum = e9_zero();
+            for (u32 i = 0; i < desc.q; i++) {
+                E9 term;
+                u32 k0 = desc.S_off[i], k1 = desc.S_off[i + 1];
+                term = pick4(v, desc.S_idx[k0]);
+                for (u32 k = k0 + 1; k < k1; k++) term = e9_mul(term, pick4(v, desc.S_idx[k]), t.nu);
+                if (desc.c_unit[i] == 1) sum = e9_add(sum, term);
+                else if (desc.c_unit[i] == -1) sum = e9_sub(sum, term);
+                else {
+                    E9 cc;
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) cc.c[c] = desc.c[i][TAU * slot + c];
+                    sum = e9_add(sum, e9_mul(term, cc, t.nu));
+                }
+            }
+            E9 g = e9_mul(sum, e, t.nu);
+#pragma unroll
+            for (int c = 0; c < TAU; c++)
+                if (X == 0) acc[c] += g.c[c];
+                else if (X == 1) acc[TAU + c] += g.c[c];
+                else if (X == 2) acc[2 * TAU + c] += g.c[c];
+                else acc[3 * TAU + c] += g.c[c];
+        }
+    }
+    __shared__ i64 red[4 * TAU];
+    block_sum_store<4 * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < 4 * TAU) {
+        u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
+        partial[(size_t)blockIdx.x * (4 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
+    }
+}
+void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg, i64 *partial,
+                      u64 *out, hipStream_t s) {
+    u32 gb = (u32)((n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_lin_round, dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial);
+    launch_reduce_rows(partial, gb, 4 * RE, out, s);   // X = deg+1.. rows stay zero
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// folding sumcheck (comb fn nifs/folding/utils.rs:273-325, b = 2):
+//   g(X) = eqL G1 + eqR G2 + eqB * sum_{k<2K} sum_{d<9} mu_k^{d+1} h(f_{k,d}),  h(f) = f (f^2 - 1)
+__device__ __forceinline__ E9 ldq(const fe *eq, size_t ld, size_t i) {
+    E9 r;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) r.c[c] = eq[(size_t)c * ld + i];
+    return r;
+}
+// the eqL*G1 + eqR*G2 part at X = 0..4, added into acc[X][9]
+__device__ __forceinline__ void fold_linear_part(const DevBb &t, const FoldArgs &a, u32 slot, size_t j, i64 (&acc)[5 * TAU]) {
+#pragma unroll 1
+    for (int side = 0; side < 2; side++) {
+        const fe *eq = side ? a.eqR : a.eqL;
+        const fe *G = side ? a.G2 : a.G1;
+        E9 e0 = ldq(eq, a.ld, 2 * j), e1 = ldq(eq, a.ld, 2 * j + 1);
+        E9 g0 = ld9(G, a.ld, slot, 2 * j), g1 = ld9(G, a.ld, slot, 2 * j + 1);
+        E9 es = e9_sub(e1, e0), gs = e9_sub(g1, g0);
+        E9 e = e0, g = g0;
+#pragma unroll
+        for (int X = 0; X < 5; X++) {
+            if (X) { e = e9_add(e, es); g = e9_add(g, gs); }
+            E9 p = e9_mul(e, g, t.nu);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) acc[X * TAU + c] += p.c[c];
+        }
+    }
+}
+__device__ __forceinline__ void fold_store(i64 (&acc)[5 * TAU], u32 slot, i64 *partial) {
+    __shared__ i64 red[5 * TAU];
+    block_sum_store<5 * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < 5 * TAU) {
+        u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
+        partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
+    }
+}
+// round 1: f-hat entries are the base-2 digits themselves, so h(f0 + X (f1 - f0)) is a small integer (|.| <= 720) and
+// vanishes at X = 0, 1; S(X) = sum M[k][d] * h is accumulated as exact integer multiples of the (uniform) constants.
+__global__ void __launch_bounds__(256) k_fold_round1(DevBb t, FoldArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                                                     const E9C *Mc, i64 *partial) {
+    u32 slot = blockIdx.y;
+    i64 acc[5 * TAU];
+#pragma unroll
+    for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
+    size_t pairs = a.n / 2;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+        fold_linear_part(t, a, slot, j, acc);
+        i64 S[3 * TAU];
+#pragma unroll
+        for (int i = 0; i < 3 * TAU; i++) S[i] = 0;
+        bool in = 2 * j + 1 < n_planes || 2 * j < n_planes;
+        if (in) {
+#pragma unroll 1
+            for (int side = 0; side < 2; side++) {
+                const int32_t *pl = side ? planesR : planesL;
+#pragma unroll 1
+                for (int d = 0; d < TAU; d++) {
+                    size_t base = (size_t)(8 * d + slot) * n_planes;
+                    int32_t v0 = 2 * j < n_planes ? pl[base + 2 * j] : 0;
+                    int32_t v1 = 2 * j + 1 < n_planes ? pl[base + 2 * j + 1] : 0;
+#pragma unroll 1
+                    for (u32 k = 0; k < K; k++) {
+                        int f0 = digit2(v0, k), df = digit2(v1, k) - f0;
+                        int f2 = f0 + 2 * df, f3 = f2 + df, f4 = f3 + df;
+                        int h2 = f2 * (f2 * f2 - 1), h3 = f3 * (f3 * f3 - 1), h4 = f4 * (f4 * f4 - 1);
+                        const E9C &M = Mc[(size_t)(side * K + k) * TAU + d];
+#pragma unroll
+                        for (int c = 0; c < TAU; c++) {
+                            i64 mc = (i64)M.c[c];
+                            S[c] += mc * h2; S[TAU + c] += mc * h3; S[2 * TAU + c] += mc * h4;
+                        }
+                    }
+                }
+            }
+            E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1);
+            E9 es = e9_sub(e1, e0);
+            E9 e = e9_add(e1, es);   // X = 2
+#pragma unroll
+            for (int X = 2; X < 5; X++) {
+                if (X > 2) e = e9_add(e, es);
+                E9 sv;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) sv.c[c] = fred(S[(X - 2) * TAU + c]);
+                E9 p = e9_mul(sv, e, t.nu);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) acc[X * TAU + c] += p.c[c];
+            }
+        }
+    }
+    fold_store(acc, slot, partial);
+}
+void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                        const E9C *Mc, i64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_fold_round1, dim3(gb, 8), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, Mc, partial);
+    launch_reduce_rows(partial, gb, 5 * RE, out, s);
+}
+// after r_1: F[(side*K+k)*9+d][9*slot+c][j] = f0 + r1*(f1-f0), digits f0,f1 in {-1,0,1}
+struct R1Mul { fe v[5][TAU]; };   // r1 * delta for delta = -2..2
+__global__ void __launch_bounds__(256) k_fold_materialize(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t half, u32 K,
+                                                          R1Mul rm, fe *F) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y % 8, d = blockIdx.y / 8, side = blockIdx.z;
+    if (j >= half) return;
+    const int32_t *pl = side ? planesR : planesL;
+    size_t base = (size_t)(8 * d + slot) * n_planes;
+    int32_t v0 = 2 * j < n_planes ? pl[base + 2 * j] : 0;
+    int32_t v1 = 2 * j + 1 < n_planes ? pl[base + 2 * j + 1] : 0;
+    for (u32 k = 0; k < K; k++) {
+        int f0 = digit2(v0, k), df = digit2(v1, k) - f0;
+        fe *o = F + ((size_t)((side * K + k) * TAU + d) * RE + TAU * slot) * half + j;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) {
+            fe val = rm.v[df + 2][c];
+            if (c == 0) val = fadd(val, fe_from_digit(f0));
+            o[(size_t)c * half] = val;
+        }
+    }
+}
+void launch_fold_materialize(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, const E9C &r1,
+                             fe *F, hipStream_t s) {
+    R1Mul rm;
+    for (int dl = -2; dl <= 2; dl++)
+        for (int c = 0; c < TAU; c++) rm.v[dl + 2][c] = fmul(r1.c[c], from_small(dl));
+    size_t half = m / 2;
+    hipLaunchKernelGGL(k_fold_materialize, dim3(cdiv(half, 256), 8 * TAU, 2), dim3(256), 0, s, planesL, planesR, n_planes, half, K, rm, F);
+}
+// general round on the materialised tables: per table h(f0 + X df) = c0 + c1 X + c2 X^2 + c3 X^3 with
+//   M c0 = p (f0^2 - 1), M c1 = q (3 f0^2 - 1), M c2 = 3 p df^2, M c3 = q df^2,   p = M f0, q = M df
+__global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial) {
+    u32 slot = blockIdx.y;
+    i64 acc[5 * TAU];
+#pragma unroll
+    for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
+    size_t pairs = a.n / 2;
+    const fe three = from_small(3);
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+        fold_linear_part(t, a, slot, j, acc);
+        i64 C[4 * TAU];
+#pragma unroll
+        for (int i = 0; i < 4 * TAU; i++) C[i] = 0;
+#pragma unroll 1
+        for (u32 tb = 0; tb < 2 * K * TAU; tb++) {
+            const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
+            E9 f0, f1;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) {
+                int2 v = *reinterpret_cast<const int2 *>(Ft + (size_t)c * ldF + 2 * j);
+                f0.c[c] = v.x; f1.c[c] = v.y;
+            }
+            E9 df = e9_sub(f1, f0);
+            E9Pre M = e9p(Mpre[tb]);
+            E9 p = e9_mul(f0, M), q = e9_mul(df, M);
+            E9 s0 = e9_sqr(f0, t.nu), sd = e9_sqr(df, t.nu);
+            E9 u = s0; u.c[0] = fsub(u.c[0], BB_ONE);                 // f0^2 - 1
+            E9 w = e9_mul_fe(s0, three); w.c[0] = fsub(w.c[0], BB_ONE); // 3 f0^2 - 1
+            E9 sdn = e9_times_nu(sd, t.nu);
+            E9 m0 = e9_mul(p, u, t.nu), m1 = e9_mul(q, w, t.nu), m2 = e9_mul_pre(p, sd, sdn), m3 = e9_mul_pre(q, sd, sdn);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) { C[c] += m0.c[c]; C[TAU + c] += m1.c[c]; C[2 * TAU + c] += m2.c[c]; C[3 * TAU + c] += m3.c[c]; }
+        }
+        // S(X) = C0 + C1 X + 3 C2 X^2 + C3 X^3
+        E9 c0, c1, c2, c3;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) { c0.c[c] = fred(C[c]); c1.c[c] = fred(C[TAU + c]); c2.c[c] = fred(3 * C[2 * TAU + c]); c3.c[c] = fred(C[3 * TAU + c]); }
+        E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1);
+        E9 es = e9_sub(e1, e0), e = e0;
+#pragma unroll
+        for (int X = 0; X < 5; X++) {
+            if (X) e = e9_add(e, es);
+            E9 sv;
+#pragma unroll
+            for (int c = 0; c < TAU; c++)
+                sv.c[c] = fred((i64)c0.c[c] + (i64)c1.c[c] * X + (i64)c2.c[c] * (X * X) + (i64)c3.c[c] * (X * X * X));
+            E9 pr = e9_mul(sv, e, t.nu);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) acc[X * TAU + c] += pr.c[c];
+        }
+    }
+    fold_store(acc, slot, partial);
+}
+void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
+                       hipStream_t s) {
+    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_fold_round, dim3(gb, 8), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
+    launch_reduce_rows(partial, gb, 5 * RE, out, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compute_f_0 (folding.rs:258-268) in the coefficient domain: f_0[j] = sum_i rho_i * f_i[j] with rho_i a short challenge
+// (24 coefficients in [-32,32), rings/babybear.rs:36-68) and f_i the i-th bit-plane; X^72 = X^36 - 1.
+// One thread per (element j, output third): out coefficients [24*part, 24*part+24).
+__global__ void __launch_bounds__(128) k_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho, int32_t *out) {
+    size_t j = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (j >= n) return;
+    int32_t acc[RE];
+#pragma unroll
+    for (int c = 0; c < RE; c++) acc[c] = 0;
+#pragma unroll 1
+    for (int side = 0; side < 2; side++) {
+        const int32_t *pl = side ? planesR : planesL;
+        int32_t v[RE];
+#pragma unroll
+        for (int c = 0; c < RE; c++) v[c] = pl[(size_t)c * n + j];
+#pragma unroll 1
+        for (u32 k = 0; k < K; k++) {
+            const int8_t *rh = rho + (size_t)(side * K + k) * 24;
+            int32_t d[RE];
+#pragma unroll
+            for (int c = 0; c < RE; c++) d[c] = digit2(v[c], k);
+            // prod[e] = sum_a rho_a d[e-a], e < 96; fold X^e (e >= 72) = X^(e-36) - X^(e-72)
+#pragma unroll
+            for (int aa = 0; aa < 24; aa++) {
+                int32_t ra = rh[aa];
+#pragma unroll
+                for (int c = 0; c < RE; c++) {
+                    int e = c + aa;
+                    int32_t pr = __mul24(ra, d[c]);
+                    if (e < RE) acc[e] += pr;
+                    else { acc[e - 36] += pr; acc[e - 72] -= pr; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < RE; c++) out[(size_t)c * n + j] = acc[c];
+}
+void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_witness, dim3(cdiv(n, 128)), dim3(128), 0, s, planesL, planesR, n, K, rho, out);
+}
+
+}  // namespace lfbb

@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../include/lfhip.h"
+#include "bb_capi.h"
+#include "lf_common.h"
 #include "lf_kernels.h"
 
 using namespace lf;
@@ -21,17 +23,6 @@ using namespace lf;
 namespace lf {
 void launch_fix_many(const DevCrt &t, const u64 *in, size_t ld_in, u64 *out, size_t ld_out, size_t n_in, u32 rows3, Fq3Const r, hipStream_t s);
 }
-
-#define HIPCHK(x)                                    \
-    do {                                             \
-        hipError_t e__ = (x);                        \
-        if (e__ != hipSuccess) return LF_ERR_HIP;    \
-    } while (0)
-#define RET(x)                      \
-    do {                            \
-        int rc__ = (x);             \
-        if (rc__ != LF_OK) return rc__; \
-    } while (0)
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,38 +36,14 @@ static bool lf_trace_on() { static int v = -1; if (v < 0) v = getenv("LF_TRACE")
         }                                                                             \
     } while (0)
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t b) {
-        if (b <= bytes) return LF_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        size_t want = b + (b >> 3) + 256;
-        if (hipMalloc(&p, want) != hipSuccess) {
-            if (hipMalloc(&p, b) != hipSuccess) return LF_ERR_HIP;
-            want = b;
-        }
-        bytes = want;
-        return LF_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-};
-
 static thread_local int t_lane = 0;  // 0 = caller thread, 1 = helper thread running the left decomposition
 
-struct lf_witness {
-    lf_ctx *ctx;
-    int32_t *planes;  // [24][N] centred coefficients
-    size_t N;
-};
 struct lf_transcript {
     Transcript t;
+    lfbb::BbTranscript *bb = nullptr;   // BabyBear transcripts live here (ring 1); t is unused then
+    lf_transcript() {}
+    lf_transcript(const lf_transcript &o) : t(o.t), bb(o.bb ? new lfbb::BbTranscript(*o.bb) : nullptr) {}
+    ~lf_transcript() { delete bb; }
 };
 
 // wall-clock timeline of the calling thread (LF_TIMELINE=1): printed at the end of lf_fold_step
@@ -103,6 +70,7 @@ static const char *PHASE_NAMES[LF_N_PHASES] = {"linearization", "decomp_crt_comm
 struct EvPair { hipEvent_t a, b; };
 
 struct lf_ctx {
+    lfbb::BbCtx *bb = nullptr;   // BabyBearRingNTT backend (ring 1): every entry point forwards to it
     int device = 0;
     hipStream_t st_lane[2] = {nullptr, nullptr};
     std::mutex mu, buf_mu, ev_mu;
@@ -235,6 +203,21 @@ static int install_tables(lf_ctx *c, u64 nonres, const u64 *y) {
     return LF_OK;
 }
 
+int lf_ctx_create_ring(lf_ctx **out, int device, int ring) {
+    if (ring == LF_RING_GOLDILOCKS) return lf_ctx_create(out, device);
+    if (!out || ring != LF_RING_BABYBEAR) return LF_ERR_INVALID;
+    lf_ctx *c = new lf_ctx();
+    c->device = device;
+    int rc = lfbb::BbCtx::create(&c->bb, c, device);
+    if (rc != LF_OK) { delete c; return rc; }
+    *out = c;
+    return LF_OK;
+}
+int lf_ctx_ring(const lf_ctx *c) { return c && c->bb ? LF_RING_BABYBEAR : LF_RING_GOLDILOCKS; }
+int lf_ring_words(int ring) { return ring == LF_RING_BABYBEAR ? 72 : (ring == LF_RING_GOLDILOCKS ? 24 : 0); }
+int lf_ring_tau(int ring) { return ring == LF_RING_BABYBEAR ? 9 : (ring == LF_RING_GOLDILOCKS ? 3 : 0); }
+uint64_t lf_ring_modulus(int ring) { return ring == LF_RING_BABYBEAR ? (uint64_t)lfbb::BB_P : (ring == LF_RING_GOLDILOCKS ? LF_P : 0); }
+
 int lf_ctx_create(lf_ctx **out, int device) {
     if (!out) return LF_ERR_INVALID;
     int cnt = 0;
@@ -262,6 +245,7 @@ static void free_ccs(lf_ctx *c) {
 }
 void lf_ctx_destroy(lf_ctx *c) {
     if (!c) return;
+    if (c->bb) { c->bb->destroy(); delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st_lane[0]);
     (void)hipStreamSynchronize(c->st_lane[1]);
@@ -278,12 +262,14 @@ void lf_ctx_destroy(lf_ctx *c) {
 }
 int lf_set_ring_tables(lf_ctx *c, uint64_t nonres, const uint64_t *y) {
     if (!c || !y) return LF_ERR_INVALID;
+    if (c->bb) return LF_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     return install_tables(c, nonres, y);
 }
 int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
     if (!c || !nonres || !y) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->get_ring_tables(nonres, y);
     *nonres = c->ring.T.nu;
     for (int k = 0; k < 8; k++)
         for (int q = 0; q < 3; q++) y[3 * k + q] = c->ring.T.y[k].c[q];
@@ -291,6 +277,7 @@ int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
 }
 int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *user) {
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
+    if (c->bb) return world == 1 ? LF_OK : LF_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> g(c->mu);
     if (c->dA) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
     c->sh_rank = rank; c->sh_world = world; c->sh_cb = cb; c->sh_user = user;
@@ -305,12 +292,14 @@ static int exchange_modsum(lf_ctx *c, u64 *inout, size_t words) {
 }
 int lf_mem_info(lf_ctx *c, size_t *free_bytes, size_t *total_bytes) {
     if (!c || !free_bytes || !total_bytes) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->mem_info(free_bytes, total_bytes);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
     return LF_OK;
 }
 int lf_device_synchronize(lf_ctx *c) {
     if (!c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->synchronize();
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
@@ -347,6 +336,7 @@ static Fq3Const f3c(Fq3 a) { Fq3Const r; r.c[0] = a.c[0]; r.c[1] = a.c[1]; r.c[2
 
 int lf_selftest_field(lf_ctx *c, uint64_t seed, uint32_t n, uint64_t *mismatches) {
     if (!c || !mismatches) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->selftest_field(seed, n, mismatches);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     u64 *d;
@@ -358,6 +348,7 @@ int lf_selftest_field(lf_ctx *c, uint64_t seed, uint32_t n, uint64_t *mismatches
 // ---- a1/a2 --------------------------------------------------------------------------------------------------------
 int lf_ntt_fwd(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
     if (!c || (!in && count) || (!out && count)) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->ntt_fwd(in, out, count);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     u64 *a, *b;
@@ -369,6 +360,7 @@ int lf_ntt_fwd(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
 }
 int lf_ntt_inv(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
     if (!c || (!in && count) || (!out && count)) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->ntt_inv(in, out, count);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     u64 *a, *b;
@@ -381,6 +373,7 @@ int lf_ntt_inv(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
 static bool pow2(u64 b) { return b >= 2 && (b & (b - 1)) == 0; }
 int lf_decompose(lf_ctx *c, const uint64_t *in, size_t count, uint64_t base, unsigned digits, int layout, uint64_t *out) {
     if (!c || !in || !out || digits == 0 || digits > 64 || (layout != 0 && layout != 1)) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->decompose(in, count, base, digits, layout, out);
     if (!pow2(base)) return LF_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
@@ -395,6 +388,7 @@ int lf_decompose(lf_ctx *c, const uint64_t *in, size_t count, uint64_t base, uns
 }
 int lf_recompose(lf_ctx *c, const uint64_t *in, size_t count_out, uint64_t base, unsigned digits, uint64_t *out) {
     if (!c || !in || !out || digits == 0) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->recompose(in, count_out, base, digits, out);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     u64 *a, *b;
@@ -406,6 +400,7 @@ int lf_recompose(lf_ctx *c, const uint64_t *in, size_t count_out, uint64_t base,
 }
 int lf_linf_check(lf_ctx *c, const uint64_t *f_ntt, size_t count, uint64_t bound, int unsigned_variant, int *ok, uint64_t *max_out) {
     if (!c || !f_ntt || !ok) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->linf_check(f_ntt, count, bound, unsigned_variant, ok, max_out);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     u64 *a, *b, *mx;
@@ -444,6 +439,7 @@ static int shard_columns(lf_ctx *c, size_t n, size_t *col0, size_t *cnt) {
 }
 int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
     if (!c || !A || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->ajtai_load(A, kappa, n);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     size_t col0, cnt;
@@ -458,6 +454,7 @@ int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
 }
 int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
     if (!c || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->ajtai_generate(seed, kappa, n);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     size_t col0, cnt;
@@ -500,6 +497,7 @@ static int commit_download(lf_ctx *c, const u64 *dev, size_t words, u64 *host) {
 }
 int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
     if (!c || !f || !out || !batch) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->ajtai_commit(f, n, batch, out);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->dA) return LF_ERR_STATE;
     if (n != c->nA_total) return LF_ERR_INVALID;  // CommitmentError::WrongWitnessLength(n, width)
@@ -542,6 +540,7 @@ static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {
 }
 int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {
     if (!c || !point || !out || nv == 0 || nv > 40) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->build_eq(point, nv, out);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     size_t n = (size_t)1 << nv;
@@ -559,6 +558,7 @@ int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {
 }
 int lf_mle_eval_batch(lf_ctx *c, const uint64_t *tables, size_t ntables, size_t len, const uint64_t *point, unsigned nv, uint64_t *out) {
     if (!c || !tables || !point || !out || !ntables || nv == 0 || nv > 40) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->mle_eval_batch(tables, ntables, len, point, nv, out);
     size_t n = (size_t)1 << nv;
     if (len > n || len == 0) return LF_ERR_INVALID;  // MleEvaluationError::IncorrectLength
     std::lock_guard<std::mutex> g(c->mu);
@@ -577,6 +577,9 @@ int lf_mle_eval_batch(lf_ctx *c, const uint64_t *tables, size_t ntables, size_t 
 }
 
 // ---- CCS -------------------------------------------------------------------------------------------------------------
+size_t lf_lcccs_len_ring(const lf_params *p, int ring) { return ring == LF_RING_BABYBEAR ? lfbb::bb_lcccs_len(p) : lf_lcccs_len(p); }
+size_t lf_cccs_len_ring(const lf_params *p, int ring) { return ring == LF_RING_BABYBEAR ? lfbb::bb_cccs_len(p) : lf_cccs_len(p); }
+size_t lf_proof_len_ring(const lf_params *p, int ring) { return ring == LF_RING_BABYBEAR ? lfbb::bb_proof_len(p) : lf_proof_len(p); }
 size_t lf_lcccs_len(const lf_params *p) { return (size_t)p->s + 3 + p->kappa + p->t + p->l + 1; }
 size_t lf_cccs_len(const lf_params *p) { return (size_t)p->kappa + p->l; }
 static size_t lin_proof_len(const lf_params *p) { return (size_t)p->s * (p->d + 2) + 3 + p->t; }
@@ -587,6 +590,7 @@ size_t lf_proof_len(const lf_params *p) { return lin_proof_len(p) + 2 * dec_proo
 int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
                 const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *cc) {
     if (!c || !p || !rowptr || !col || !val || !S_off || !S_idx || !cc) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->ccs_load(p, rowptr, col, val, S_off, S_idx, cc);
     if (p->s < 3 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 16 || p->L == 0 || p->L > 8 ||
         p->d + 1 > 4 || p->wit_len == 0)
         return LF_ERR_UNSUPPORTED;
@@ -663,6 +667,7 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
 }
 int lf_spmv(lf_ctx *c, unsigned j, const uint64_t *z, uint64_t *out) {
     if (!c || !z || !out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->spmv(j, z, out);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     if (j >= c->P.t) return LF_ERR_INVALID;
@@ -695,6 +700,7 @@ static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] can
 }
 int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
     if (!c || !w_ccs || !out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_from_w_ccs(w_ccs, out);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
@@ -710,6 +716,7 @@ int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
 }
 int lf_witness_from_f_coeff(lf_ctx *c, const uint64_t *f_coeff, lf_witness **out) {
     if (!c || !f_coeff || !out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_from_f_coeff(f_coeff, out);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
@@ -720,6 +727,7 @@ int lf_witness_from_f_coeff(lf_ctx *c, const uint64_t *f_coeff, lf_witness **out
 }
 int lf_witness_from_f(lf_ctx *c, const uint64_t *f_ntt, lf_witness **out) {
     if (!c || !f_ntt || !out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_from_f(f_ntt, out);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
@@ -732,6 +740,7 @@ int lf_witness_from_f(lf_ctx *c, const uint64_t *f_ntt, lf_witness **out) {
 }
 int lf_witness_get_f_coeff(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_get_f_coeff(w, out);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     u64 *d;
@@ -741,6 +750,7 @@ int lf_witness_get_f_coeff(lf_ctx *c, const lf_witness *w, uint64_t *out) {
 }
 int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_get_f(w, out);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     u64 *d, *e;
@@ -752,6 +762,7 @@ int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
 }
 int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_get_w_ccs(w, out);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
@@ -762,6 +773,7 @@ int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
 }
 int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     if (!c || !w || !cm_out || w->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_commit(w, cm_out);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->dA) return LF_ERR_STATE;
     if (w->N != c->nA_total) return LF_ERR_INVALID;
@@ -784,22 +796,56 @@ void lf_witness_free(lf_witness *w) {
 
 // ---- transcript ------------------------------------------------------------------------------------------------------------
 lf_transcript *lf_transcript_new(void) { return new lf_transcript(); }
+lf_transcript *lf_transcript_new_ring(int ring) {
+    if (ring == LF_RING_GOLDILOCKS) return new lf_transcript();
+    if (ring != LF_RING_BABYBEAR) return nullptr;
+    lf_transcript *t = new lf_transcript();
+    t->bb = new lfbb::BbTranscript();
+    return t;
+}
 lf_transcript *lf_transcript_clone(const lf_transcript *t) { return t ? new lf_transcript(*t) : nullptr; }
 void lf_transcript_free(lf_transcript *t) { delete t; }
-void lf_transcript_absorb_fq(lf_transcript *t, const uint64_t *x, size_t n) { t->t.absorb_fq(x, n); }
-void lf_transcript_absorb_ring(lf_transcript *t, const uint64_t *e, size_t n) { t->t.absorb_ring(e, n); }
+void lf_transcript_absorb_fq(lf_transcript *t, const uint64_t *x, size_t n) {
+    if (t->bb) t->bb->absorb_fq(x, n);
+    else t->t.absorb_fq(x, n);
+}
+void lf_transcript_absorb_ring(lf_transcript *t, const uint64_t *e, size_t n) {
+    if (t->bb) t->bb->absorb_ring(e, n);
+    else t->t.absorb_ring(e, n);
+}
 void lf_transcript_get_challenge(lf_transcript *t, uint64_t *o) {
+    if (t->bb) {
+        lfbb::H9 c = t->bb->get_challenge();
+        memcpy(o, c.c, sizeof(c.c));
+        return;
+    }
     Fq3 c = t->t.get_challenge();
     o[0] = c.c[0]; o[1] = c.c[1]; o[2] = c.c[2];
 }
-void lf_transcript_get_short_challenge(lf_transcript *t, uint64_t *o) { t->t.get_short_challenge(o); }
+void lf_transcript_get_short_challenge(lf_transcript *t, uint64_t *o) {
+    if (t->bb) t->bb->get_short_challenge(o);
+    else t->t.get_short_challenge(o);
+}
 void lf_poseidon_permute(uint64_t *state, int plain) {
     if (plain) Transcript::permute_plain(state);
     else Transcript::permute(state);
 }
+void lf_poseidon_permute_ring(uint64_t *state, int plain, int ring) {
+    if (ring == LF_RING_BABYBEAR) {
+        if (plain) lfbb::BbTranscript::permute_plain(state);
+        else lfbb::BbTranscript::permute(state);
+    } else lf_poseidon_permute(state, plain);
+}
 void lf_poseidon_params(uint64_t *ark, uint64_t *mds) {
     const u64 *a, *m;
     Transcript::params(&a, &m);
+    memcpy(ark, a, 720 * 8);
+    memcpy(mds, m, 576 * 8);
+}
+void lf_poseidon_params_ring(uint64_t *ark, uint64_t *mds, int ring) {
+    const u64 *a, *m;
+    if (ring == LF_RING_BABYBEAR) lfbb::BbTranscript::params(&a, &m);
+    else Transcript::params(&a, &m);
     memcpy(ark, a, 720 * 8);
     memcpy(mds, m, 576 * 8);
 }
@@ -1327,6 +1373,8 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
 
 int lf_linearize(lf_ctx *c, lf_transcript *t, const uint64_t *cccs, const lf_witness *wit, uint64_t *lcccs_out, uint64_t *lin_proof_out) {
     if (!c || !t || !cccs || !wit || !lcccs_out || !lin_proof_out || wit->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return t->bb ? c->bb->linearize(*t->bb, cccs, wit, lcccs_out, lin_proof_out) : LF_ERR_INVALID;
+    if (t->bb) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     if (wit->N != c->N) return LF_ERR_INVALID;
@@ -1342,6 +1390,8 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
                  uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof) {
     if (!c || !t || !acc || !w_acc || !cm_i || !w_i || !lcccs_out || !w_out || !proof) return LF_ERR_INVALID;
     if (w_acc->ctx != c || w_i->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return t->bb ? c->bb->fold_step(*t->bb, acc, w_acc, cm_i, w_i, lcccs_out, w_out, proof) : LF_ERR_INVALID;
+    if (t->bb) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
     const lf_params &P = c->P;
@@ -1413,6 +1463,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
 // ---- generic linearization-shaped sumcheck through the ABI (tests / SURVEY 8b) -------------------------------------------------
 int lf_sumcheck_lin_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *eq_point) {
     if (!c || !tables || !eq_point) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->sumcheck_lin_begin(tables, eq_point);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
@@ -1430,6 +1481,7 @@ int lf_sumcheck_lin_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *eq_
 }
 int lf_sumcheck_lin_round(lf_ctx *c, const uint64_t *r_prev, uint64_t *evals_out) {
     if (!c || !evals_out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->sumcheck_lin_round(r_prev, evals_out);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->sc_round < 0 || c->sc_round >= (int)c->P.s) return LF_ERR_STATE;  // "Prover is not active"
     if ((c->sc_round == 0) != (r_prev == nullptr)) return LF_ERR_STATE;      // "first round should be prover first" / "verifier message is empty"
@@ -1456,6 +1508,7 @@ int lf_sumcheck_lin_round(lf_ctx *c, const uint64_t *r_prev, uint64_t *evals_out
 }
 int lf_sumcheck_lin_end(lf_ctx *c) {
     if (!c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->sumcheck_lin_end();
     std::lock_guard<std::mutex> g(c->mu);
     c->sc_round = -1;
     return LF_OK;
@@ -1463,11 +1516,13 @@ int lf_sumcheck_lin_end(lf_ctx *c) {
 
 int lf_last_phase_ms(lf_ctx *c, float *out) {
     if (!c || !out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->last_phase_ms(out);
     for (int i = 0; i < LF_N_PHASES; i++) out[i] = c->phase_ms[i];
     return LF_OK;
 }
 int lf_last_kernel_stats(lf_ctx *c, float *fold_ms, int *fold_n, float *aj_ms, int *aj_n) {
     if (!c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->last_kernel_stats(fold_ms, fold_n, aj_ms, aj_n);
     if (fold_ms) *fold_ms = c->k_fold_ms;
     if (fold_n) *fold_n = c->k_fold_n;
     if (aj_ms) *aj_ms = c->k_ajtai_ms;

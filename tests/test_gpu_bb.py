@@ -1,0 +1,239 @@
+"""GPU parity tests of the BabyBearRingNTT backend (BASELINE configs[2]): every HIP path, called through the C ABI with
+ring = LF_RING_BABYBEAR, must be BIT-EXACT against the BabyBear build of the CPU oracle (oracle/liblfo_bb.so) on the
+same seeded inputs.  Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+import lfo_bb as lfo
+from latticefold_amd import api
+from latticefold_amd.workload import diag, make_workload, splitmix_fq
+
+pytestmark = pytest.mark.gpu
+RING = "babybear"
+P, RE, TAU = lfo.P, lfo.RE, lfo.TAU
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0, ring=RING)
+    yield c
+    c.close()
+
+
+def rnd(seed, *shape):
+    n = int(np.prod(shape))
+    return splitmix_fq(seed, 0, n, RING).reshape(shape)
+
+
+def tr_new():
+    return api.PoseidonTranscript(ring=RING)
+
+
+def setup_case(ctx, name, seed=0):
+    wl = make_workload(name, seed)
+    inst = lfo.Instance(wl)
+    ctx.load_ccs(wl)
+    A = wl.ajtai_matrix()
+    scheme = api.AjtaiCommitmentScheme(ctx, matrix=A)
+    return wl, inst, A, scheme
+
+
+def test_device_arithmetic_selftest(ctx):
+    """centred Montgomery words: F_p add/sub/mul and the 81-mad F_{p^9} product vs host % arithmetic, incl. edge operands"""
+    for seed in (1, 2, 3):
+        assert ctx.selftest_field(seed, 1 << 18) == 0
+
+
+def test_ring_tables_match_oracle(ctx):
+    nr, y = ctx.get_ring_tables()
+    import ctypes as C
+    onr = C.c_uint64()
+    oy = np.zeros(8 * TAU, dtype=np.uint64)
+    lfo.lib().lfo_get_ring(C.byref(onr), lfo._p64(oy))
+    assert nr == onr.value and (y == oy).all()
+    with pytest.raises(api.LfError):
+        ctx.set_ring_tables(nr, y)          # data-driven tables: Goldilocks only for now
+
+
+@pytest.mark.parametrize("count", [1, 7, 256, 1000])
+def test_crt_icrt(ctx, count):
+    x = rnd(11 + count, count, RE)
+    assert (ctx.crt(x) == lfo.crt(x)).all()
+    assert (ctx.icrt(x) == lfo.icrt(x)).all()
+    assert (ctx.icrt(ctx.crt(x)) == x).all()
+
+
+def test_decompose_recompose(ctx):
+    x = rnd(3, 200, RE)
+    x[0, :6] = [0, 1, P - 1, (P - 1) // 2, (P + 1) // 2, 2**15]
+    for base, digits in ((1 << 16, 2), (1 << 8, 4), (2, 16)):
+        src = x if base != 2 else lfo.decompose(x, 1 << 16, 2, 0)[:64]
+        for layout in (0, 1):
+            assert (ctx.decompose(src, base, digits, layout) == lfo.decompose(src, base, digits, layout)).all(), (base, layout)
+        d = ctx.decompose(src, base, digits, 0)
+        assert (ctx.recompose(d, base, digits) == src).all()
+        assert (ctx.recompose(d, base, digits) == lfo.recompose(d, base, digits)).all()
+
+
+def test_linf_check(ctx):
+    c = np.zeros((50, RE), dtype=np.uint64)
+    c[3, 5] = 70; c[9, 60] = P - 123
+    f = lfo.crt(c)
+    ok, mx = ctx.linf_check(f, 124)
+    assert ok and mx == 123
+    ok, mx = ctx.linf_check(f, 123)
+    assert not ok
+    ok, mx = ctx.linf_check(f, 1 << 20, unsigned_variant=True)
+    assert not ok
+
+
+@pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 2048, 1), (16, 1024, 15), (3, 64, 2), (16, 300, 20)])
+def test_ajtai_commit(ctx, kappa, n, batch):
+    A = rnd(100 + kappa, kappa, n, RE)
+    f = rnd(200 + n, batch, n, RE)
+    s = api.AjtaiCommitmentScheme(ctx, matrix=A)
+    got = s.commit_ntt(f)
+    for b in range(batch):
+        assert (got[b] == lfo.ajtai_commit(A, kappa, n, f[b])).all()
+    with pytest.raises(api.CommitmentError):
+        s.commit_ntt(f[0][:-1])
+
+
+def test_ajtai_closed_form(ctx):
+    """test_commit_ntt (commitment_scheme.rs:141-159) shape on BabyBear: diagonal scalars, closed form mod p"""
+    kappa, n = 9, 1 << 12
+    idx = (np.arange(kappa * n, dtype=np.uint64)).reshape(kappa, n)
+    A = np.zeros((kappa, n, RE), dtype=np.uint64)
+    A[:, :, 0::TAU] = idx[:, :, None]
+    f = np.tile(diag(2, RING), (n, 1))
+    got = api.AjtaiCommitmentScheme(ctx, matrix=A).commit_ntt(f)
+    for i in range(kappa):
+        assert (got[i] == diag(n * (2 * i * n + (n - 1)), RING)).all()
+
+
+def test_ajtai_generate_matches_workload_stream(ctx):
+    wl = make_workload("B8")
+    A = wl.ajtai_matrix()
+    f = rnd(9, wl.N, RE)
+    dev = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+    assert (dev.commit_ntt(f) == lfo.ajtai_commit(A, wl.kappa, wl.N, f)).all()
+
+
+def test_eq_and_mle_eval(ctx):
+    for nv in (1, 5, 9):
+        pt = rnd(nv, nv, TAU)
+        ring_pt = np.tile(pt, (1, 8))
+        eq = ctx.build_eq(pt)
+        oeq = lfo.build_eq(ring_pt)
+        assert (eq == oeq[:, 0:TAU]).all()
+        for ln in ((1 << nv), max(1, (1 << nv) - 3)):
+            tabs = rnd(50 + nv, 3, ln, RE)
+            got = ctx.evaluate_mles(tabs, pt)
+            for a in range(3):
+                assert (got[a] == lfo.mle_eval(tabs[a], ring_pt)).all()
+    with pytest.raises(api.LfError):
+        ctx.evaluate_mles(rnd(1, 1, 40, RE), rnd(2, 5, TAU))
+
+
+@pytest.mark.parametrize("name", ["B6", "BDP"])
+def test_witness_roundtrips(ctx, name):
+    wl, inst, A, scheme = setup_case(ctx, name)
+    w = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    assert (w.f_coeff == f_coeff).all()
+    assert (w.f == lfo.crt(f_coeff)).all()
+    assert (w.w_ccs == wl.w_ccs).all()
+    assert (w.commit(scheme) == lfo.ajtai_commit(A, wl.kappa, wl.N, lfo.crt(f_coeff))).all()
+    assert (api.Witness.from_f(ctx, lfo.crt(f_coeff)).f_coeff == f_coeff).all()
+    assert (api.Witness.from_f_coeff(ctx, f_coeff).f == w.f).all()
+    big = f_coeff.copy(); big[0, 0] = wl.B
+    with pytest.raises(api.LfError) as e:
+        api.Witness.from_f_coeff(ctx, big)
+    assert e.value.code == -5
+    z = wl.z()
+    for j in range(wl.t):
+        got = ctx.mat_vec_mul(j, z)
+        rows = min(wl.n, wl.m)
+        exp = np.zeros((wl.m, RE), dtype=np.uint64)
+        prod = np.zeros((rows, RE), dtype=np.uint64)
+        lfo.lib().lfo_ring_mul_ntt(lfo._p64(np.ascontiguousarray(wl.val[j])), lfo._p64(np.ascontiguousarray(z[:rows])), lfo._p64(prod), rows)
+        exp[:rows] = prod
+        assert (got == exp).all()
+
+
+def run_both(ctx, name, seed=0):
+    wl, inst, A, scheme = setup_case(ctx, name, seed)
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    acc_g, linpr_g = api.LFLinearizationProver.prove(ctx, cccs, wit, tr_new())
+    acc_o, linpr_o = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    return wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o
+
+
+@pytest.mark.parametrize("name", ["B6", "BDP", "B8"])
+def test_linearization_parity(ctx, name):
+    wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o = run_both(ctx, name)
+    assert (linpr_g == linpr_o).all()
+    assert (acc_g == acc_o).all()
+
+
+@pytest.mark.parametrize("name,seed", [("B6", 0), ("B6", 3), ("BDP", 0), ("B8", 1)])
+def test_fold_step_parity(ctx, name, seed):
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, seed)
+    lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    lin = wl.s * (wl.d + 2) + TAU + wl.t
+    dec = wl.K * (wl.t + TAU + wl.l + 1 + wl.kappa)
+    bad = np.nonzero((proof_g != proof_o).any(axis=1))[0]
+    assert bad.size == 0, f"first differing proof elements {bad[:5]} (lin<{lin}, decL<{lin + dec}, decR<{lin + 2 * dec})"
+    assert (lc_g == lc_o).all()
+    assert (w0.f == f0_o).all()
+    assert (w0.f_coeff == lfo.icrt(f0_o)).all()
+    rc, lc_v = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)   # the restated NIFSVerifier accepts the GPU proof
+    assert rc == 0 and (lc_v == lc_g).all()
+    if name == "B6":   # chained step: the folded accumulator/witness are valid inputs of the next fold
+        lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, tr_new())
+        lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
+        assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
+
+
+def test_sumcheck_lin_abi(ctx):
+    wl, inst, A, scheme = setup_case(ctx, "B8")
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    cm = lfo.ajtai_commit(A, wl.kappa, wl.N, lfo.crt(f_coeff))
+    cccs = np.concatenate([cm, wl.x_ccs])
+    lc_o, pr_o = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    tr = tr_new()
+    label = int.from_bytes(b"beta_s", "big") % P
+    tr.absorb_slice(diag(label, RING)[None, :])
+    beta = np.stack([tr.get_challenge() for _ in range(wl.s)])
+    z = wl.z()
+    tables = np.stack([ctx.mat_vec_mul(j, z) for j in range(wl.t)])
+    sc = api.MLSumcheckLin(ctx, tables, beta)
+    with pytest.raises(api.LfError) as e:
+        sc.prove_round(r_prev=np.zeros(TAU, dtype=np.uint64))
+    assert e.value.code == -7
+    tr.absorb_slice(diag(wl.s, RING)[None, :]); tr.absorb_slice(diag(wl.d + 1, RING)[None, :])
+    npts = wl.d + 2
+    r = None
+    for rd in range(wl.s):
+        msg = sc.prove_round(r)
+        assert (msg == pr_o[rd * npts:(rd + 1) * npts]).all(), rd
+        tr.absorb_slice(msg)
+        r = tr.get_challenge()
+        ring_r = np.tile(r, 8)
+        tr.absorb_slice(ring_r[None, :])
+        assert (ring_r == lc_o[rd]).all()
+    sc.end()
+
+
+def test_ring_mismatch_errors(ctx):
+    wl, inst, A, scheme = setup_case(ctx, "B6")
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    with pytest.raises(api.LfError) as e:      # a Goldilocks transcript cannot drive a BabyBear context
+        api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+    assert e.value.code == -1
+    with pytest.raises(api.LfError):
+        ctx.set_sharding(0, 2, lambda x: np.stack([x, x]))
