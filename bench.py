@@ -28,7 +28,10 @@ def cpu_baseline(target_wl, budget_s=25.0):
     one fold step of the same parameter set at a smaller m; the fold step is linear in m, so steps/s scales by m'/m."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    import lfo
+    if target_wl.ring == "babybear":
+        import lfo_bb as lfo
+    else:
+        import lfo
     from latticefold_amd.workload import CONFIGS, Workload, make_workload
 
     lib = lfo.lib()
@@ -37,7 +40,7 @@ def cpu_baseline(target_wl, budget_s=25.0):
     def run(s):
         name = f"_cpu{s}"
         base = CONFIGS[target_wl.name]
-        CONFIGS[name] = (s, (1 << s) // base[2], base[2], base[3], base[4], base[5], base[6])
+        CONFIGS[name] = (s, (1 << s) // base[2], base[2], base[3], base[4], base[5], base[6]) + tuple(base[7:])
         wl = make_workload(name)
         inst = lfo.Instance(wl)
         A = wl.ajtai_matrix()
@@ -49,7 +52,7 @@ def cpu_baseline(target_wl, budget_s=25.0):
         inst.fold_step(lfo.Transcript(), A, acc, f_coeff, cccs, f_coeff)
         return time.perf_counter() - t0
 
-    s = 10
+    s = 10 if target_wl.ring == "goldilocks" else 6
     t = run(s)
     while s + 2 <= min(target_wl.s, 18) and t * 4.2 < budget_s:
         s += 2
@@ -111,7 +114,7 @@ def main():
     # ---- setup (untimed): everything resident in HBM --------------------------------------------------------
     shard = world > 1 and args.parallelism == "shard"
     wl = make_workload(args.workload, seed=0 if shard else rank)
-    ctx = api.Context(local_rank)
+    ctx = api.Context(local_rank, ring=wl.ring)
     if shard:
         from latticefold_amd import dist as lfd
         ctx.set_sharding(rank, world, lfd.make_allgather())   # RCCL all-gather of the partial commitments / round messages
@@ -119,7 +122,7 @@ def main():
     scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())  # generated on the device
     wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
     cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
-    tr0 = api.PoseidonTranscript()
+    tr0 = api.PoseidonTranscript(ring=wl.ring)
     acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr0)  # accumulator = linearized copy (benches/utils.rs:637-655)
 
     def step():
@@ -154,7 +157,7 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        E = 192
+        E = 192 if wl.ring == "goldilocks" else 288
         steps_per_s = (1 if shard else world) * args.steps / elapsed
         alg = wl.alg_bytes()
         # dominant kernels, live HIP-event timing on the library's stream (lf_last_kernel_stats)
@@ -162,7 +165,7 @@ def main():
         fr_n = sum(k["fold_round_launches"] for k in kstats)
         aj_ms = sum(k["ajtai_ms"] for k in kstats)
         aj_n = sum(k["ajtai_launches"] for k in kstats)
-        P_F = 5 + 2 * wl.K * 3
+        P_F = 5 + 2 * wl.K * wl.tau
         fr_bytes = sum(P_F * (wl.m >> i) * E for i in range(wl.s)) / wl.s     # round i reads P*(N/2^(i-1))*E
         aj_bytes = (wl.kappa + wl.K - 1) * wl.N * E                              # batched commit: A once + K-1 witnesses
         kernels = {
@@ -184,11 +187,11 @@ def main():
             traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": peak, "unit": "GB/s",
                 "frac": kernels[dom]["achieved_GBps"] / peak, "traffic": traffic,
-                "note": "integer-ALU-bound path (64-bit modular multiply = 4 quarter-rate v_mad_u64_u32); whole-step algorithmic "
+                "note": "integer-ALU-bound path (modular multiply from quarter-rate v_mad_*64_*32); whole-step algorithmic "
                         "rate = %.1f GB/s = %.3f of peak" % (alg * steps_per_s / world / 1e9, alg * steps_per_s / world / 1e9 / peak),
                 "kernels": kernels}
         out = {
-            "metric": "folding-prover steps/sec (one NIFSProver::prove per step), GoldilocksRingNTT",
+            "metric": "folding-prover steps/sec (one NIFSProver::prove per step), " + ("GoldilocksRingNTT" if wl.ring == "goldilocks" else "BabyBearRingNTT"),
             "value": steps_per_s,
             "unit": "steps/s",
             "n_gpus": world,
@@ -198,9 +201,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": "u64" if wl.ring == "goldilocks" else "u32 (31-bit Montgomery)",
             "data": "synthetic",
-            "config": {"workload": f"{wl.name}: GoldilocksRingNTT R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
+            "config": {"workload": f"{wl.name}: {'GoldilocksRingNTT' if wl.ring == 'goldilocks' else 'BabyBearRingNTT'} R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
                                    f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world} (column-sharded commits + sharded sumcheck rounds, one fold stream)" if shard else f"replicas x{world}"),
                        "alg_bytes_per_step": alg, "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
             "roofline": roof,

@@ -85,6 +85,9 @@ static void default_ring(void) {
     }
 }
 
+/* runs when the library is loaded: lfo_NONRES and the ring tables are valid before any entry point is used
+ * (the protocol functions multiply in F_{p^tau} before they ever reach lfo_crt) */
+static void ensure_init(void) __attribute__((constructor));
 static void ensure_init(void) {
     if (g_init) return;
     default_ring();

@@ -78,3 +78,36 @@ def test_repeated_steps_are_stable_and_chain():
         assert abs(free1 - free2) < 64 << 20      # no growth beyond allocator noise
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["B10", "B14", "C3"])
+def test_babybear_fold_step_properties_at_scale(name):
+    """BASELINE configs[2] (BabyBearRingNTT, 2^18 rows, kappa = 16) and two smaller BabyBear cases: same size-independent
+    properties as above, checked with the BabyBear build of the oracle's verifier on the O(proof-size) data."""
+    import lfo_bb
+    wl = make_workload(name)
+    ctx = api.Context(0, ring="babybear")
+    try:
+        ctx.load_ccs(wl)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        assert (wit.w_ccs == wl.w_ccs).all()
+        cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        tr = lambda: api.PoseidonTranscript(ring="babybear")
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+        lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+        inst = lfo_bb.Instance(wl)
+        rc, lc_v = inst.verify(lfo_bb.Transcript(), acc, cccs, proof)
+        assert rc == 0 and (lc_v == lc).all()
+        cm0 = lc[wl.s + 9: wl.s + 9 + wl.kappa]
+        assert (w0.commit(scheme) == cm0).all()
+        ok, mx = ctx.linf_check(w0.f, wl.B // 2)
+        assert ok, mx
+        lc2, w02, proof2 = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+        assert (proof2 == proof).all()
+        # chained step
+        lc3, w3, proof3 = api.NIFSProver.prove(ctx, lc, w0, cccs, wit, tr())
+        rc, lc_v = inst.verify(lfo_bb.Transcript(), lc, cccs, proof3)
+        assert rc == 0 and (lc_v == lc3).all()
+    finally:
+        ctx.close()
