@@ -947,8 +947,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // working tables (ping-pong): 5 special tables (eqL eqR eqB G1 G2 = 171 planes) + the 2K*9 materialised f-hat tables
     const size_t T5P = 3 * TAU + 2 * RE;
     fe *F[2], *T5[2];
-    RET(c->tbuf("fold_F0", (size_t)K2 * TAU * RE * atl(m / 2), &F[0]));
-    RET(c->tbuf("fold_F1", (size_t)K2 * TAU * RE * atl(m / 4), &F[1]));
+    RET(c->tbuf("fold_F0", (size_t)K2 * TAU * RE * atl(m / 4), &F[0]));   // f-hat is materialised only after two rounds
+    RET(c->tbuf("fold_F1", (size_t)K2 * TAU * RE * atl(m / 8), &F[1]));
     RET(c->tbuf("fold_T0", T5P * atl(m / 2), &T5[0]));
     RET(c->tbuf("fold_T1", T5P * atl(m / 4), &T5[1]));
     FoldArgs a;
@@ -967,11 +967,11 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             launch_fix(c->dev, a.eqB, a.ld, dst + (size_t)2 * TAU * ldn, ldn, a.n, 1, r, c->st);
             launch_fix(c->dev, a.G1, a.ld, dst + (size_t)3 * TAU * ldn, ldn, a.n, 8, r, c->st);
             launch_fix(c->dev, a.G2, a.ld, dst + (size_t)(3 * TAU + RE) * ldn, ldn, a.n, 8, r, c->st);
-            if (round == 2) {
-                launch_fold_materialize(c->dev, S[0].planes, S[1].planes, N, m, K, e9c_from_h9(rh), F[0], c->st);
-                curF = F[0]; ldF = atl(m / 2);
-            } else {
-                fe *fd = F[(round & 1) ? 1 : 0];   // round 3 -> F[1], round 4 -> F[0], ...
+            if (round == 3) {
+                launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, m, K, pt[0], pt[1], c->ring, F[0], c->st);
+                curF = F[0]; ldF = atl(m / 4);
+            } else if (round > 3) {
+                fe *fd = F[(round & 1) ? 0 : 1];   // round 4 -> F[1], round 5 -> F[0], ...
                 launch_fix(c->dev, curF, ldF, fd, ldn, a.n, K2 * TAU * 8, r, c->st);
                 curF = fd; ldF = ldn;
             }
@@ -982,6 +982,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         }
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->st);
+        else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->st);
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->st);
         c->ev_end(ev);
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;

@@ -95,9 +95,12 @@ struct FoldArgs {
 // round 1 straight from the coefficient planes (f-hat virtual, b = 2); Mc = mu_k^(d+1), [2K][9] constants
 void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const E9C *Mc_dev, i64 *partial, u64 *out, hipStream_t s);
-// F[(k*9+d)][72][m/2] = f0 + r1 * (f1 - f0)
-void launch_fold_materialize(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
-                             const E9C &r1, fe *F, hipStream_t s);
+// round 2, still from the planes (entries a + b r1 with small integers a, b); a.* are the once-fixed tables (a.n = m/2)
+void launch_fold_round2(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                        const E9C *Mc_dev, const H9 &r1, const BbHostRing &ring, i64 *partial, u64 *out, hipStream_t s);
+// after r_2: F[(k*9+d)][72][m/4] = sum_b eq((r1,r2), b) * digit(f[4j+b])
+void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, const H9 &r1,
+                              const H9 &r2, const BbHostRing &ring, fe *F, hipStream_t s);
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre_dev, i64 *partial, u64 *out,
                        hipStream_t s);
 // folded witness in the coefficient domain: out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c) mod X^72 - X^36 + 1

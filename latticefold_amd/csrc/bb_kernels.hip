@@ -47,7 +47,8 @@ __device__ __forceinline__ void st9(fe *tab, size_t ld, u32 slot, size_t i, cons
 __device__ __forceinline__ E9 e9c(const E9C &k) { E9 r; for (int i = 0; i < TAU; i++) r.c[i] = k.c[i]; return r; }
 __device__ __forceinline__ E9Pre e9p(const E9PreC &k) { E9Pre r; for (int i = 0; i < TAU; i++) { r.v.c[i] = k.v[i]; r.vn.c[i] = k.vn[i]; } return r; }
 // reduce a signed 64-bit sum of residues to a centred word
-__device__ __forceinline__ fe fred(i64 s) { return centre((int32_t)(s % (i64)BB_P)); }
+// |s| <= 9 H^2: two Montgomery steps (s * R^-1, then * R^2 * R^-1) instead of a 64-bit modulo
+__device__ __forceinline__ fe fred(i64 s) { return fmul(mred(s), BB_R2C); }
 
 // ---------------------------------------------------------------------------------------------------------
 // reductions: every thread holds NV signed 64-bit partial sums (of centred words)
@@ -610,8 +611,7 @@ __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t
             for (int q = 0; q < TAU; q++) acc[q] += (i64)e[q] * (i64)v;   // integer scaling keeps the Montgomery form
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4 * TAU; i++) acc[i] = acc[i] % (i64)BB_P;
+    // per-thread sums are < 2^50 (a few elements each): no reduction needed before the block sum
     __shared__ i64 red[4 * TAU];
     block_sum_store<4 * TAU>(acc, red);
     __syncthreads();
@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t
 }
 void launch_coef_eval(const DevBb &t, const int32_t *planes, size_t n, const fe *eq, size_t ldeq, u32 K, int mode_bits, i64 *partial, u64 *out,
                       hipStream_t s) {
-    u32 gb = (u32)((n + 255) / 256);
+    u32 gb = (u32)((n + 256 * 16 - 1) / (256 * 16));   // >= 16 elements per thread: the 36-value block reduction is the fixed cost
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     hipLaunchKernelGGL(k_coef_eval, dim3(gb, RE, (K + 3) / 4), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
@@ -905,52 +905,154 @@ void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planes
     hipLaunchKernelGGL(k_fold_round1, dim3(gb, 8), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, Mc, partial);
     launch_reduce_rows(partial, gb, 5 * RE, out, s);
 }
-// after r_1: F[(side*K+k)*9+d][9*slot+c][j] = f0 + r1*(f1-f0), digits f0,f1 in {-1,0,1}
-struct R1Mul { fe v[5][TAU]; };   // r1 * delta for delta = -2..2
-__global__ void __launch_bounds__(256) k_fold_materialize(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t half, u32 K,
-                                                          R1Mul rm, fe *F) {
+// round 2, still from the planes: after fixing the first variable every f-hat entry is a + b r1 with small integers
+// (a = d0, b = d1 - d0), so h(f(X)) = c0 + c1 r1 + c2 r1^2 + c3 r1^3 with small integer c_i and
+//   sum_tb M_tb h = T0 + r1 T1 + r1^2 T2 + r1^3 T3,  T_i = sum_tb M_tb c_i(tb)   (exact integer multiples of the constants).
+// One thread per (pair, slot, evaluation point X = blockIdx.z); a.* are the once-fixed tables (a.n = m/2).
+struct R1Pow { E9PreC r1, r2, r3; };
+__global__ void __launch_bounds__(256) k_fold_round2(DevBb t, FoldArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                                                     const E9C *Mc, R1Pow rp, i64 *partial) {
+    u32 slot = blockIdx.y;
+    const int X = blockIdx.z;
+    i64 acc[TAU];
+#pragma unroll
+    for (int i = 0; i < TAU; i++) acc[i] = 0;
+    size_t pairs = a.n / 2;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+        // linear part at this X
+#pragma unroll 1
+        for (int side = 0; side < 2; side++) {
+            const fe *eq = side ? a.eqR : a.eqL;
+            const fe *G = side ? a.G2 : a.G1;
+            E9 e0 = ldq(eq, a.ld, 2 * j), e1 = ldq(eq, a.ld, 2 * j + 1);
+            E9 g0 = ld9(G, a.ld, slot, 2 * j), g1 = ld9(G, a.ld, slot, 2 * j + 1);
+            E9 e, g;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) {
+                e.c[c] = fred((i64)e0.c[c] + (i64)X * ((i64)e1.c[c] - (i64)e0.c[c]));
+                g.c[c] = fred((i64)g0.c[c] + (i64)X * ((i64)g1.c[c] - (i64)g0.c[c]));
+            }
+            E9 pr = e9_mul(e, g, t.nu);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) acc[c] += pr.c[c];
+        }
+        if (4 * j < n_planes) {
+            i64 T[4 * TAU];
+#pragma unroll
+            for (int i = 0; i < 4 * TAU; i++) T[i] = 0;
+#pragma unroll 1
+            for (int side = 0; side < 2; side++) {
+                const int32_t *pl = side ? planesR : planesL;
+#pragma unroll 1
+                for (int d = 0; d < TAU; d++) {
+                    size_t base = (size_t)(8 * d + slot) * n_planes + 4 * j;
+                    int32_t v0 = pl[base], v1 = 4 * j + 1 < n_planes ? pl[base + 1] : 0;
+                    int32_t v2 = 4 * j + 2 < n_planes ? pl[base + 2] : 0, v3 = 4 * j + 3 < n_planes ? pl[base + 3] : 0;
+#pragma unroll 1
+                    for (u32 k = 0; k < K; k++) {
+                        int d0 = digit2(v0, k), d1 = digit2(v1, k), d2 = digit2(v2, k), d3 = digit2(v3, k);
+                        int A0 = d0, B0 = d1 - d0, A1 = d2, B1 = d3 - d2;
+                        int A = A0 + X * (A1 - A0), B = B0 + X * (B1 - B0);
+                        int c0 = A * (A * A - 1), c1 = B * (3 * A * A - 1), c2 = 3 * A * B * B, c3 = B * B * B;
+                        const E9C &M = Mc[(size_t)(side * K + k) * TAU + d];
+#pragma unroll
+                        for (int c = 0; c < TAU; c++) {
+                            i64 mc = (i64)M.c[c];
+                            T[c] += mc * c0; T[TAU + c] += mc * c1; T[2 * TAU + c] += mc * c2; T[3 * TAU + c] += mc * c3;
+                        }
+                    }
+                }
+            }
+            E9 t0, t1, t2, t3;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) { t0.c[c] = fred(T[c]); t1.c[c] = fred(T[TAU + c]); t2.c[c] = fred(T[2 * TAU + c]); t3.c[c] = fred(T[3 * TAU + c]); }
+            E9 sv = e9_add(e9_add(t0, e9_mul(t1, e9p(rp.r1))), e9_add(e9_mul(t2, e9p(rp.r2)), e9_mul(t3, e9p(rp.r3))));
+            E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1), e;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) e.c[c] = fred((i64)e0.c[c] + (i64)X * ((i64)e1.c[c] - (i64)e0.c[c]));
+            E9 pr = e9_mul(sv, e, t.nu);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) acc[c] += pr.c[c];
+        }
+    }
+    __shared__ i64 red[TAU];
+    block_sum_store<TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < TAU) partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + threadIdx.x] = red[threadIdx.x];
+}
+void launch_fold_round2(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                        const E9C *Mc, const H9 &r1, const BbHostRing &ring, i64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    R1Pow rp;
+    H9 r2 = ring.mul9(r1, r1), r3 = ring.mul9(r2, r1);
+    rp.r1 = e9pre_from_h9(r1, ring.T.nu); rp.r2 = e9pre_from_h9(r2, ring.T.nu); rp.r3 = e9pre_from_h9(r3, ring.T.nu);
+    hipLaunchKernelGGL(k_fold_round2, dim3(gb, 8, 5), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, Mc, rp, partial);
+    launch_reduce_rows(partial, gb, 5 * RE, out, s);
+}
+// after r_2: F[(side*K+k)*9+d][9*slot+c][j] = sum_{b<4} W_b * digit(f[4j+b]),  W_b = eq((r1,r2), b) (b = b0 + 2 b1, LSB first)
+struct W4 { fe v[4][TAU]; };
+__global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t quarter, u32 K,
+                                                           W4 w, fe *F) {
     size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y % 8, d = blockIdx.y / 8, side = blockIdx.z;
-    if (j >= half) return;
+    if (j >= quarter) return;
     const int32_t *pl = side ? planesR : planesL;
-    size_t base = (size_t)(8 * d + slot) * n_planes;
-    int32_t v0 = 2 * j < n_planes ? pl[base + 2 * j] : 0;
-    int32_t v1 = 2 * j + 1 < n_planes ? pl[base + 2 * j + 1] : 0;
+    size_t base = (size_t)(8 * d + slot) * n_planes + 4 * j;
+    int32_t v[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) v[b] = 4 * j + b < n_planes ? pl[base + b] : 0;
     for (u32 k = 0; k < K; k++) {
-        int f0 = digit2(v0, k), df = digit2(v1, k) - f0;
-        fe *o = F + ((size_t)((side * K + k) * TAU + d) * RE + TAU * slot) * half + j;
+        fe *o = F + ((size_t)((side * K + k) * TAU + d) * RE + TAU * slot) * quarter + j;
+        int dg[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) dg[b] = digit2(v[b], k);
 #pragma unroll
         for (int c = 0; c < TAU; c++) {
-            fe val = rm.v[df + 2][c];
-            if (c == 0) val = fadd(val, fe_from_digit(f0));
-            o[(size_t)c * half] = val;
+            fe x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                fe term = dg[b] == 0 ? 0 : (dg[b] > 0 ? w.v[b][c] : -w.v[b][c]);
+                x = fadd(x, term);
+            }
+            o[(size_t)c * quarter] = x;
         }
     }
 }
-void launch_fold_materialize(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, const E9C &r1,
-                             fe *F, hipStream_t s) {
-    R1Mul rm;
-    for (int dl = -2; dl <= 2; dl++)
-        for (int c = 0; c < TAU; c++) rm.v[dl + 2][c] = fmul(r1.c[c], from_small(dl));
-    size_t half = m / 2;
-    hipLaunchKernelGGL(k_fold_materialize, dim3(cdiv(half, 256), 8 * TAU, 2), dim3(256), 0, s, planesL, planesR, n_planes, half, K, rm, F);
+void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, const H9 &r1,
+                              const H9 &r2, const BbHostRing &ring, fe *F, hipStream_t s) {
+    H9 one;
+    for (int i = 0; i < TAU; i++) one.c[i] = i == 0;
+    H9 o1, o2;
+    for (int i = 0; i < TAU; i++) { o1.c[i] = hsub(one.c[i], r1.c[i]); o2.c[i] = hsub(one.c[i], r2.c[i]); }
+    H9 Wb[4] = {ring.mul9(o1, o2), ring.mul9(r1, o2), ring.mul9(o1, r2), ring.mul9(r1, r2)};
+    W4 w;
+    for (int b = 0; b < 4; b++)
+        for (int c = 0; c < TAU; c++) w.v[b][c] = from_canon(Wb[b].c[c]);
+    size_t quarter = m / 4;
+    hipLaunchKernelGGL(k_fold_materialize2, dim3(cdiv(quarter, 256), 8 * TAU, 2), dim3(256), 0, s, planesL, planesR, n_planes, quarter, K, w, F);
 }
 // general round on the materialised tables: per table h(f0 + X df) = c0 + c1 X + c2 X^2 + c3 X^3 with
 //   M c0 = p (f0^2 - 1), M c1 = q (3 f0^2 - 1), M c2 = 3 p df^2, M c3 = q df^2,   p = M f0, q = M df
+// Small rounds are latency-bound if one thread walks all 2K*9 tables, so the table range is split over blockIdx.z
+// (every part is linear in the tables, including the final product with eqB).
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial) {
     u32 slot = blockIdx.y;
+    const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
+    const u32 tb0 = blockIdx.z * per, tb1 = tb0 + per < ntab ? tb0 + per : ntab;
     i64 acc[5 * TAU];
 #pragma unroll
     for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
     size_t pairs = a.n / 2;
     const fe three = from_small(3);
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
-        fold_linear_part(t, a, slot, j, acc);
+        if (blockIdx.z == 0) fold_linear_part(t, a, slot, j, acc);
         i64 C[4 * TAU];
 #pragma unroll
         for (int i = 0; i < 4 * TAU; i++) C[i] = 0;
 #pragma unroll 1
-        for (u32 tb = 0; tb < 2 * K * TAU; tb++) {
+        for (u32 tb = tb0; tb < tb1; tb++) {
             const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
             E9 f0, f1;
 #pragma unroll
@@ -962,10 +1064,14 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             E9Pre M = e9p(Mpre[tb]);
             E9 p = e9_mul(f0, M), q = e9_mul(df, M);
             E9 s0 = e9_sqr(f0, t.nu), sd = e9_sqr(df, t.nu);
-            E9 u = s0; u.c[0] = fsub(u.c[0], BB_ONE);                 // f0^2 - 1
-            E9 w = e9_mul_fe(s0, three); w.c[0] = fsub(w.c[0], BB_ONE); // 3 f0^2 - 1
+            E9 u = s0; u.c[0] = fsub(u.c[0], BB_ONE);                    // f0^2 - 1
+            E9 un = e9_times_nu(u, t.nu);
+            E9 w = e9_mul_fe(s0, three); w.c[0] = fsub(w.c[0], BB_ONE);  // 3 f0^2 - 1 = 3 u + 2
+            E9 wn;                                                       // nu * w = 3 (nu u) + 2 nu   (linear: no second pre-multiplication)
+#pragma unroll
+            for (int c = 0; c < TAU; c++) wn.c[c] = fred(3 * (i64)un.c[c] + (c == 0 ? 2 * (i64)t.nu : 0));
             E9 sdn = e9_times_nu(sd, t.nu);
-            E9 m0 = e9_mul(p, u, t.nu), m1 = e9_mul(q, w, t.nu), m2 = e9_mul_pre(p, sd, sdn), m3 = e9_mul_pre(q, sd, sdn);
+            E9 m0 = e9_mul_pre(p, u, un), m1 = e9_mul_pre(q, w, wn), m2 = e9_mul_pre(p, sd, sdn), m3 = e9_mul_pre(q, sd, sdn);
 #pragma unroll
             for (int c = 0; c < TAU; c++) { C[c] += m0.c[c]; C[TAU + c] += m1.c[c]; C[2 * TAU + c] += m2.c[c]; C[3 * TAU + c] += m3.c[c]; }
         }
@@ -987,15 +1093,26 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             for (int c = 0; c < TAU; c++) acc[X * TAU + c] += pr.c[c];
         }
     }
-    fold_store(acc, slot, partial);
+    __shared__ i64 red[5 * TAU];
+    block_sum_store<5 * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < 5 * TAU) {
+        u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
+        partial[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
+    }
 }
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                        hipStream_t s) {
-    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    size_t pairs = a.n / 2;
+    u32 gb = (u32)((pairs + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(k_fold_round, dim3(gb, 8), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
-    launch_reduce_rows(partial, gb, 5 * RE, out, s);
+    // enough threads to fill the chip (~128k): split the 2K*9 tables when there are few pairs
+    u32 tch = 1;
+    while (tch < 32 && pairs * 8 * tch < (1u << 17)) tch *= 2;
+    while (gb * tch > RED_BLOCKS) tch /= 2;
+    hipLaunchKernelGGL(k_fold_round, dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
+    launch_reduce_rows(partial, gb * tch, 5 * RE, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
