@@ -216,6 +216,28 @@ inline u64 dot(const u64 *a, const u64 *b, int n) {
     for (; j < n; j++) acc += a[j] * b[j] % BB_P;
     return acc % BB_P;
 }
+// out = M x for an n x n matrix stored TRANSPOSED (MT[j][i] = M[i][j], row stride 24) on 31-bit words: the 64-bit products are
+// split into 32-bit halves that accumulate without overflow (n <= 24 terms), so the inner loop is a plain vpmuludq/vpaddq
+// stream (auto-vectorised: AVX2 under -march=x86-64-v3); one reduction per output.
+constexpr u64 R32 = (1ull << 32) % BB_P;
+template <int N>
+inline void matvec_t(const u32 (*MT)[24], const u64 *x, u64 *out) {
+    u64 lo[24] = {0}, hi[24] = {0};
+    for (int j = 0; j < N; j++) {
+        const u64 xj = (u32)x[j];
+        const u32 *row = MT[j];
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int i = 0; i < 24; i++) {
+            u64 pr = xj * (u64)row[i];
+            lo[i] += pr & 0xffffffffull;
+            hi[i] += pr >> 32;
+        }
+    }
+    for (int i = 0; i < N; i++) out[i] = ((hi[i] % BB_P) * R32 + lo[i]) % BB_P;
+}
+u32 g_mdsT[24][24];       // MDS transposed
+u32 g_postT[24][24];      // deferred factor of the sparse partial rounds, transposed (23 x 23 used)
+
 bool mat_inv(const u64 *in, u64 *out, int n) {
     std::vector<u64> M((size_t)n * 2 * n, 0);
     for (int r = 0; r < n; r++) {
@@ -277,11 +299,17 @@ void init_all() {
     }
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) g_opt.post[i][j] = Eprev[(size_t)i * n + j];
+    memset(g_mdsT, 0, sizeof(g_mdsT));
+    memset(g_postT, 0, sizeof(g_postT));
+    for (int i = 0; i < W; i++)
+        for (int j = 0; j < W; j++) g_mdsT[j][i] = (u32)g_mds[i * W + j];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) g_postT[j][i] = (u32)g_opt.post[i][j];
 }
 inline void full_round(u64 st[W], const u64 *ark) {
     u64 nw[W];
     for (int i = 0; i < W; i++) st[i] = sbox(hadd(st[i], ark[i]));
-    for (int i = 0; i < W; i++) nw[i] = dot(st, g_mds + i * W, W);
+    matvec_t<W>(g_mdsT, st, nw);
     memcpy(st, nw, sizeof(nw));
 }
 }  // namespace
@@ -316,9 +344,9 @@ void BbTranscript::permute(u64 st[24]) {
         st[0] = y0;
     }
     {
-        u64 nw[W - 1];
-        for (int i = 0; i < W - 1; i++) nw[i] = dot(&g_opt.post[i][0], st + 1, W - 1);
-        memcpy(st + 1, nw, sizeof(nw));
+        u64 nw[W];
+        matvec_t<W - 1>(g_postT, st + 1, nw);
+        memcpy(st + 1, nw, (W - 1) * sizeof(u64));
     }
     for (int r = RF / 2 + RP; r < RF + RP; r++) full_round(st, g_ark + r * W);
 }
