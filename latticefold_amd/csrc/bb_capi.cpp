@@ -26,7 +26,8 @@ struct EvPair { hipEvent_t a, b; };
 struct BbCtxImpl {
     lf_ctx *owner = nullptr;
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st_lane[2] = {nullptr, nullptr};
+    int lane = 0;   // 0 = main work, 1 = left decomposition running concurrently (own stream, "lane1:" buffers, own pinned arena)
     std::mutex mu;
     BbHostRing ring;
     DevBb dev;
@@ -43,6 +44,9 @@ struct BbCtxImpl {
     std::map<std::string, DevBuf> bufs;
     u64 *h_pin = nullptr;
     size_t h_pin_words = 0;
+    u64 *arena[2] = {nullptr, nullptr};   // pinned staging for the asynchronous decompositions (bump-allocated per step)
+    size_t arena_words = 0, arena_used[2] = {0, 0};
+    hipEvent_t ev_side[2] = {nullptr, nullptr};
     int sc_round = -1;
     size_t sc_n = 0;
     int sc_cur = 0;
@@ -55,9 +59,15 @@ struct BbCtxImpl {
     int k_fold_n = 0, k_ajtai_n = 0;
     double host_tr_ms = 0;
 
-    hipStream_t stream() const { return st; }
+    hipStream_t stream() const { return st_lane[lane]; }
+    u64 *arena_alloc(size_t words) {   // nullptr when exhausted
+        if (arena_used[lane] + words > arena_words) return nullptr;
+        u64 *r = arena[lane] + arena_used[lane];
+        arena_used[lane] += words;
+        return r;
+    }
     int buf(const std::string &name, size_t bytes, void **out) {
-        DevBuf &b = bufs[name];
+        DevBuf &b = bufs[lane ? "lane1:" + name : name];
         int rc = b.ensure(bytes);
         *out = b.p;
         return rc;
@@ -86,14 +96,15 @@ struct BbCtxImpl {
             ev_pool.push_back(e);
         }
         size_t i = ev_used++;
-        (void)hipEventRecord(ev_pool[i].a, st);
+        (void)hipEventRecord(ev_pool[i].a, stream());
         ev_tags.push_back({tag, i});
         return i;
     }
-    void ev_end(size_t i) { (void)hipEventRecord(ev_pool[i].b, st); }
+    void ev_end(size_t i) { (void)hipEventRecord(ev_pool[i].b, stream()); }
     void ev_reset() { ev_used = 0; ev_tags.clear(); }
     void ev_collect() {
-        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(st_lane[0]);
+        (void)hipStreamSynchronize(st_lane[1]);
         k_fold_ms = k_ajtai_ms = 0;
         k_fold_n = k_ajtai_n = 0;
         for (int i = 0; i < NPH; i++) phase_ms[i] = 0;
@@ -143,7 +154,12 @@ int BbCtx::create(BbCtx **out, lf_ctx *owner, int device) {
     C *c = new C();
     c->owner = owner;
     c->device = device;
-    if (hipStreamCreate(&c->st) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    if (hipStreamCreate(&c->st_lane[0]) != hipSuccess || hipStreamCreate(&c->st_lane[1]) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    c->arena_words = (size_t)1 << 19;   // 4 MiB per lane
+    for (int l = 0; l < 2; l++) {
+        if (hipHostMalloc((void **)&c->arena[l], c->arena_words * 8) != hipSuccess) { delete c; return LF_ERR_HIP; }
+        if (hipEventCreateWithFlags(&c->ev_side[l], hipEventDisableTiming) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    }
     u64 nr, y[8 * TAU];
     bb_default_ring(&nr, y);
     int rc = install_tables(c, nr, y);
@@ -166,14 +182,19 @@ static void free_ccs(C *c) {
 void BbCtx::destroy() {
     C *c = p;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->st);
+    (void)hipStreamSynchronize(c->st_lane[0]);
+    (void)hipStreamSynchronize(c->st_lane[1]);
     free_ccs(c);
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    (void)hipStreamDestroy(c->st);
+    for (int l = 0; l < 2; l++) {
+        if (c->arena[l]) (void)hipHostFree(c->arena[l]);
+        if (c->ev_side[l]) (void)hipEventDestroy(c->ev_side[l]);
+        (void)hipStreamDestroy(c->st_lane[l]);
+    }
     delete c;
     delete this;
 }
@@ -185,7 +206,8 @@ int BbCtx::get_ring_tables(uint64_t *nonres, uint64_t *y) {
 }
 int BbCtx::synchronize() {
     HIPCHK(hipSetDevice(p->device));
-    HIPCHK(hipStreamSynchronize(p->st));
+    HIPCHK(hipStreamSynchronize(p->st_lane[0]));
+    HIPCHK(hipStreamSynchronize(p->st_lane[1]));
     return LF_OK;
 }
 int BbCtx::mem_info(size_t *f, size_t *t) {
@@ -199,23 +221,23 @@ static int up_ring(C *c, const u64 *host, size_t n, fe *dst) {
     if (!n) return LF_OK;
     u64 *tmp;
     RET(c->tbuf("stage_aos", n * RE, &tmp));
-    HIPCHK(hipMemcpyAsync(tmp, host, n * RE * 8, hipMemcpyHostToDevice, c->st));
-    launch_aos_to_soa(tmp, dst, n, c->st);
+    HIPCHK(hipMemcpyAsync(tmp, host, n * RE * 8, hipMemcpyHostToDevice, c->stream()));
+    launch_aos_to_soa(tmp, dst, n, c->stream());
     return LF_OK;
 }
 static int down_ring(C *c, const fe *src, size_t n, u64 *host) {
     if (!n) return LF_OK;
     u64 *tmp;
     RET(c->tbuf("stage_aos", n * RE, &tmp));
-    launch_soa_to_aos(src, tmp, n, c->st);
-    HIPCHK(hipMemcpyAsync(host, tmp, n * RE * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    launch_soa_to_aos(src, tmp, n, c->stream());
+    HIPCHK(hipMemcpyAsync(host, tmp, n * RE * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
 }
 static int down_small(C *c, const u64 *dsrc, size_t words, u64 *host) {
     RET(c->pin(words));
-    HIPCHK(hipMemcpyAsync(c->h_pin, dsrc, words * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(c->h_pin, dsrc, words * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     memcpy(host, c->h_pin, words * 8);
     return LF_OK;
 }
@@ -244,10 +266,10 @@ int BbCtx::selftest_field(uint64_t seed, uint32_t n, uint64_t *mismatches) {
     u64 *di, *dout;
     RET(c->tbuf("io_a", in.size() * 2, (fe **)&di));
     RET(c->tbuf("io_b", out.size() * 2, (fe **)&dout));
-    HIPCHK(hipMemcpyAsync(di, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->st));
-    launch_selftest(di, dout, n, c->dev.nu, c->st);
-    HIPCHK(hipMemcpyAsync(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(di, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream()));
+    launch_selftest(di, dout, n, c->dev.nu, c->stream());
+    HIPCHK(hipMemcpyAsync(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     u64 bad = 0;
     for (u32 i = 0; i < n; i++) {
         H9 a = h9_load(&in[(size_t)i * 18]), b = h9_load(&in[(size_t)i * 18 + 9]);
@@ -270,7 +292,7 @@ int BbCtx::ntt_fwd(const uint64_t *in, uint64_t *out, size_t count) {
     RET(c->tbuf("io_a", count * RE, &a));
     RET(c->tbuf("io_b", count * RE, &b));
     RET(up_ring(c, in, count, a));
-    launch_crt_fwd(c->dev, a, b, count, c->st);
+    launch_crt_fwd(c->dev, a, b, count, c->stream());
     return down_ring(c, b, count, out);
 }
 int BbCtx::ntt_inv(const uint64_t *in, uint64_t *out, size_t count) {
@@ -281,7 +303,7 @@ int BbCtx::ntt_inv(const uint64_t *in, uint64_t *out, size_t count) {
     RET(c->tbuf("io_a", count * RE, &a));
     RET(c->tbuf("io_b", count * RE, &b));
     RET(up_ring(c, in, count, a));
-    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    launch_icrt_dense(c->d_icrt, a, b, count, c->stream());
     return down_ring(c, b, count, out);
 }
 static bool pow2(u64 b) { return b >= 2 && (b & (b - 1)) == 0; }
@@ -294,7 +316,7 @@ int BbCtx::decompose(const uint64_t *in, size_t count, uint64_t base, unsigned d
     RET(c->tbuf("io_a", count * RE, &a));
     RET(c->tbuf("io_b", count * digits * RE, &b));
     RET(up_ring(c, in, count, a));
-    launch_decompose(a, count, base, digits, layout, b, c->st);
+    launch_decompose(a, count, base, digits, layout, b, c->stream());
     if (layout == 0) return down_ring(c, b, count * digits, out);
     for (unsigned k = 0; k < digits; k++) RET(down_ring(c, b + (size_t)k * RE * count, count, out + (size_t)k * count * RE));
     return LF_OK;
@@ -307,7 +329,7 @@ int BbCtx::recompose(const uint64_t *in, size_t count_out, uint64_t base, unsign
     RET(c->tbuf("io_a", count_out * digits * RE, &a));
     RET(c->tbuf("io_b", count_out * RE, &b));
     RET(up_ring(c, in, count_out * digits, a));
-    launch_recompose(a, count_out, base, digits, b, c->st);
+    launch_recompose(a, count_out, base, digits, b, c->stream());
     return down_ring(c, b, count_out, out);
 }
 int BbCtx::linf_check(const uint64_t *f_ntt, size_t count, uint64_t bound, int unsigned_variant, int *ok, uint64_t *max_out) {
@@ -320,7 +342,7 @@ int BbCtx::linf_check(const uint64_t *f_ntt, size_t count, uint64_t bound, int u
     RET(c->tbuf("io_b", count * RE, &b));
     RET(c->tbuf("small_dev", 4096, &mx));
     RET(up_ring(c, f_ntt, count, a));
-    launch_icrt_dense(c->d_icrt, a, b, count, c->st);
+    launch_icrt_dense(c->d_icrt, a, b, count, c->stream());
     if (unsigned_variant) {   // literal Witness::within_bound (arith.rs:372-386): canonical coefficient < bound
         std::vector<u64> h(count * RE);
         RET(down_ring(c, b, count, h.data()));
@@ -330,7 +352,7 @@ int BbCtx::linf_check(const uint64_t *f_ntt, size_t count, uint64_t bound, int u
         *ok = m < bound;
         return LF_OK;
     }
-    launch_linf(b, count, mx, c->st);
+    launch_linf(b, count, mx, c->stream());
     u64 m = 0;
     RET(down_small(c, mx, 1, &m));
     if (max_out) *max_out = m;
@@ -347,7 +369,7 @@ int BbCtx::ajtai_load(const uint64_t *A, size_t kappa, size_t n) {
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
     HIPCHK(hipMalloc((void **)&c->dA, kappa * n * RE * sizeof(fe)));
     for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + i * n * RE, n, c->dA + i * RE * n));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = n;
     return LF_OK;
@@ -359,8 +381,8 @@ int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
     HIPCHK(hipSetDevice(c->device));
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
     HIPCHK(hipMalloc((void **)&c->dA, kappa * n * RE * sizeof(fe)));
-    launch_fill_ajtai(c->dA, (u32)kappa, n, n, 0, seed, c->st);
-    HIPCHK(hipStreamSynchronize(c->st));
+    launch_fill_ajtai(c->dA, (u32)kappa, n, n, 0, seed, c->stream());
+    HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = n;
     return LF_OK;
@@ -382,7 +404,7 @@ static int commit_dev(C *c, const fe *F, size_t ldF, u32 batch, u64 *out_dev, bo
     for (u32 b0 = 0; b0 < batch; b0 += maxb) {
         u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
         size_t ev = timed ? c->ev_begin(1) : 0;
-        launch_ajtai(c->dev, c->dA, c->kappa, c->nA, F + (size_t)b0 * RE * ldF, ldF, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * RE, c->st);
+        launch_ajtai(c->dev, c->dA, c->kappa, c->nA, F + (size_t)b0 * RE * ldF, ldF, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * RE, c->stream());
         if (timed) c->ev_end(ev);
     }
     return LF_OK;
@@ -403,6 +425,23 @@ int BbCtx::ajtai_commit(const uint64_t *f, size_t n, size_t batch, uint64_t *out
 }
 
 // ---- a8/a9/a11 ---------------------------------------------------------------------------------------------------------
+// no host synchronisation: constants are staged in the lane's pinned arena (valid until the next fold step)
+static int build_eq_async(C *c, const H9 *pt, u32 nv, fe *eq_dev) {
+    E9PreC *rd;
+    RET(c->tbuf("eq_point_async", 2 * 64, &rd));
+    size_t words = (2 * (size_t)nv * sizeof(E9PreC) + 7) / 8;
+    E9PreC *h = (E9PreC *)c->arena_alloc(words);
+    if (!h) return LF_ERR_HIP;
+    for (u32 i = 0; i < nv; i++) {
+        h[i] = e9pre_from_h9(pt[i], c->ring.T.nu);
+        H9 om;
+        for (int q = 0; q < TAU; q++) om.c[q] = hsub(q == 0 ? 1 : 0, pt[i].c[q]);
+        h[nv + i] = e9pre_from_h9(om, c->ring.T.nu);
+    }
+    HIPCHK(hipMemcpyAsync(rd, h, 2 * (size_t)nv * sizeof(E9PreC), hipMemcpyHostToDevice, c->stream()));
+    launch_build_eq(c->dev, rd, rd + nv, nv, eq_dev, c->stream());
+    return LF_OK;
+}
 static int build_eq_dev(C *c, const H9 *pt, u32 nv, fe *eq_dev) {
     E9PreC *rd;
     RET(c->tbuf("eq_point", 2 * 64, &rd));
@@ -411,9 +450,9 @@ static int build_eq_dev(C *c, const H9 *pt, u32 nv, fe *eq_dev) {
         h[i] = e9pre_from_h9(pt[i], c->ring.T.nu);
         h[nv + i] = e9pre_from_h9(h9_sub(h9_one(), pt[i]), c->ring.T.nu);
     }
-    HIPCHK(hipMemcpyAsync(rd, h.data(), h.size() * sizeof(E9PreC), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    launch_build_eq(c->dev, rd, rd + nv, nv, eq_dev, c->st);
+    HIPCHK(hipMemcpyAsync(rd, h.data(), h.size() * sizeof(E9PreC), hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    launch_build_eq(c->dev, rd, rd + nv, nv, eq_dev, c->stream());
     return LF_OK;
 }
 int BbCtx::build_eq(const uint64_t *point, unsigned nv, uint64_t *out) {
@@ -427,8 +466,8 @@ int BbCtx::build_eq(const uint64_t *point, unsigned nv, uint64_t *out) {
     for (unsigned i = 0; i < nv; i++) pt[i] = h9_load(point + (size_t)TAU * i);
     RET(build_eq_dev(c, pt.data(), nv, eq));
     std::vector<fe> h(TAU * n);
-    HIPCHK(hipMemcpyAsync(h.data(), eq, h.size() * sizeof(fe), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(h.data(), eq, h.size() * sizeof(fe), hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     for (size_t i = 0; i < n; i++)
         for (int q = 0; q < TAU; q++) out[TAU * i + q] = to_canon(h[(size_t)q * n + i]);
     return LF_OK;
@@ -450,7 +489,7 @@ int BbCtx::mle_eval_batch(const uint64_t *tables, size_t ntables, size_t len, co
     for (unsigned i = 0; i < nv; i++) pt[i] = h9_load(point + (size_t)TAU * i);
     RET(build_eq_dev(c, pt.data(), nv, eq));
     for (size_t a = 0; a < ntables; a++) RET(up_ring(c, tables + a * len * RE, len, X + a * RE * len));
-    launch_dot_eq(c->dev, X, len, (u32)ntables, eq, n, len, partial, o, c->st);
+    launch_dot_eq(c->dev, X, len, (u32)ntables, eq, n, len, partial, o, c->stream());
     return down_small(c, o, ntables * RE, out);
 }
 
@@ -540,7 +579,7 @@ int BbCtx::spmv(unsigned j, const uint64_t *z, uint64_t *out) {
     RET(c->tbuf("io_a", c->n * RE, &zd));
     RET(c->tbuf("io_b", c->m * RE, &od));
     RET(up_ring(c, z, c->n, zd));
-    launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], zd, c->n, od, c->m, 0, c->st);
+    launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], zd, c->n, od, c->m, 0, c->stream());
     return down_ring(c, od, c->m, out);
 }
 
@@ -550,10 +589,10 @@ static int witness_from_coef_table(C *c, const fe *coef_dev, lf_witness **out) {
     HIPCHK(hipMalloc((void **)&pl, c->N * RE * 4));
     int *viol;
     if (c->tbuf("small_dev", 4096, (u64 **)&viol) != LF_OK) { (void)hipFree(pl); return LF_ERR_HIP; }
-    (void)hipMemsetAsync(viol, 0, 4, c->st);
-    launch_coef_to_i32(coef_dev, pl, c->N, (u32)(c->P.B / 2), viol, c->st);
+    (void)hipMemsetAsync(viol, 0, 4, c->stream());
+    launch_coef_to_i32(coef_dev, pl, c->N, (u32)(c->P.B / 2), viol, c->stream());
     int hv = 0;
-    if (hipMemcpyAsync(&hv, viol, 4, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) {
+    if (hipMemcpyAsync(&hv, viol, 4, hipMemcpyDeviceToHost, c->stream()) != hipSuccess || hipStreamSynchronize(c->stream()) != hipSuccess) {
         (void)hipFree(pl);
         return LF_ERR_HIP;
     }
@@ -571,8 +610,8 @@ int BbCtx::witness_from_w_ccs(const uint64_t *w_ccs, lf_witness **out) {
     RET(c->tbuf("io_b", (size_t)c->P.wit_len * RE, &b));
     RET(c->tbuf("io_c", c->N * RE, &d));
     RET(up_ring(c, w_ccs, c->P.wit_len, a));
-    launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->st);
-    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->st);
+    launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->stream());
+    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->stream());
     return witness_from_coef_table(c, d, out);
 }
 int BbCtx::witness_from_f_coeff(const uint64_t *f_coeff, lf_witness **out) {
@@ -594,7 +633,7 @@ int BbCtx::witness_from_f(const uint64_t *f_ntt, lf_witness **out) {
     RET(c->tbuf("io_a", c->N * RE, &a));
     RET(c->tbuf("io_c", c->N * RE, &d));
     RET(up_ring(c, f_ntt, c->N, a));
-    launch_icrt_dense(c->d_icrt, a, d, c->N, c->st);
+    launch_icrt_dense(c->d_icrt, a, d, c->N, c->stream());
     return witness_from_coef_table(c, d, out);
 }
 int BbCtx::witness_get_f_coeff(const lf_witness *w, uint64_t *out) {
@@ -603,7 +642,7 @@ int BbCtx::witness_get_f_coeff(const lf_witness *w, uint64_t *out) {
     HIPCHK(hipSetDevice(c->device));
     fe *d;
     RET(c->tbuf("io_c", w->N * RE, &d));
-    launch_i32_to_coef(w->planes, d, w->N, c->st);
+    launch_i32_to_coef(w->planes, d, w->N, c->stream());
     return down_ring(c, d, w->N, out);
 }
 int BbCtx::witness_get_f(const lf_witness *w, uint64_t *out) {
@@ -613,8 +652,8 @@ int BbCtx::witness_get_f(const lf_witness *w, uint64_t *out) {
     fe *d, *e;
     RET(c->tbuf("io_c", w->N * RE, &d));
     RET(c->tbuf("io_b", w->N * RE, &e));
-    launch_i32_to_coef(w->planes, d, w->N, c->st);
-    launch_crt_fwd(c->dev, d, e, w->N, c->st);
+    launch_i32_to_coef(w->planes, d, w->N, c->stream());
+    launch_crt_fwd(c->dev, d, e, w->N, c->stream());
     return down_ring(c, e, w->N, out);
 }
 int BbCtx::witness_get_w_ccs(const lf_witness *w, uint64_t *out) {
@@ -624,7 +663,7 @@ int BbCtx::witness_get_w_ccs(const lf_witness *w, uint64_t *out) {
     HIPCHK(hipSetDevice(c->device));
     fe *e;
     RET(c->tbuf("io_b", (size_t)c->P.wit_len * RE, &e));
-    launch_recompose_crt(c->dev, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->st);
+    launch_recompose_crt(c->dev, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->stream());
     return down_ring(c, e, c->P.wit_len, out);
 }
 int BbCtx::witness_commit(const lf_witness *w, uint64_t *cm_out) {
@@ -638,8 +677,8 @@ int BbCtx::witness_commit(const lf_witness *w, uint64_t *cm_out) {
     RET(c->tbuf("io_c", w->N * RE, &d));
     RET(c->tbuf("io_b", w->N * RE, &e));
     RET(c->tbuf("io_o", (size_t)c->kappa * RE, &o));
-    launch_i32_to_coef(w->planes, d, w->N, c->st);
-    launch_crt_fwd(c->dev, d, e, w->N, c->st);
+    launch_i32_to_coef(w->planes, d, w->N, c->stream());
+    launch_crt_fwd(c->dev, d, e, w->N, c->stream());
     RET(commit_dev(c, e, w->N, 1, o, false));
     return down_small(c, o, (size_t)c->kappa * RE, cm_out);
 }
@@ -679,14 +718,14 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
     for (u32 round = 1; round <= P.s; round++) {
         if (round > 1) {
             E9PreC r = e9pre_from_h9(point[round - 2], c->ring.T.nu);
-            launch_fix(c->dev, cur, n, fx[flip], atl(n / 2), n, P.t * 8, r, c->st);
-            launch_fix(c->dev, cure, n, fq[flip], atl(n / 2), n, 1, r, c->st);
+            launch_fix(c->dev, cur, n, fx[flip], atl(n / 2), n, P.t * 8, r, c->stream());
+            launch_fix(c->dev, cure, n, fq[flip], atl(n / 2), n, 1, r, c->stream());
             cur = fx[flip]; cure = fq[flip];
             flip ^= 1;
             n /= 2;
         }
         size_t ld = round == 1 ? m : atl(n);
-        launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->st);
+        launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->stream());
         u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * RE;
         RET(down_small(c, od, (size_t)(deg + 1) * RE, ev));
         HostTimer ht(c);
@@ -699,16 +738,32 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
 static int build_z(C *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads /* K*(l+1) ring AoS host */, fe *z /* [K][72][n] */) {
     const lf_params &P = c->P;
     u32 hl = P.l + 1;
-    launch_recompose_crt(c->dev, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->st);
+    launch_recompose_crt(c->dev, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->stream());
     std::vector<fe> h((size_t)K * RE * hl);
     for (u32 k = 0; k < K; k++)
         for (u32 i = 0; i < hl; i++)
             for (int w = 0; w < RE; w++) h[((size_t)k * RE + w) * hl + i] = from_canon(heads[((size_t)k * hl + i) * RE + w]);
     fe *stage;
     RET(c->tbuf("z_heads", h.size(), &stage));
-    HIPCHK(hipMemcpyAsync(stage, h.data(), h.size() * sizeof(fe), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpy2DAsync(z, c->n * sizeof(fe), stage, hl * sizeof(fe), hl * sizeof(fe), (size_t)K * RE, hipMemcpyDeviceToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(stage, h.data(), h.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipMemcpy2DAsync(z, c->n * sizeof(fe), stage, hl * sizeof(fe), hl * sizeof(fe), (size_t)K * RE, hipMemcpyDeviceToDevice, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    return LF_OK;
+}
+static int build_z_async(C *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads, fe *z) {
+    const lf_params &P = c->P;
+    u32 hl = P.l + 1;
+    launch_recompose_crt(c->dev, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->stream());
+    size_t cnt = (size_t)K * RE * hl;
+    fe *h = (fe *)c->arena_alloc((cnt * sizeof(fe) + 7) / 8);
+    if (!h) return LF_ERR_HIP;
+    for (u32 k = 0; k < K; k++)
+        for (u32 i = 0; i < hl; i++)
+            for (int w = 0; w < RE; w++) h[((size_t)k * RE + w) * hl + i] = from_canon(heads[((size_t)k * hl + i) * RE + w]);
+    fe *stage;
+    RET(c->tbuf("z_heads_async", cnt, &stage));
+    HIPCHK(hipMemcpyAsync(stage, h, cnt * sizeof(fe), hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipMemcpy2DAsync(z, c->n * sizeof(fe), stage, hl * sizeof(fe), hl * sizeof(fe), (size_t)K * RE, hipMemcpyDeviceToDevice, c->stream()));
     return LF_OK;
 }
 static bool lcccs_point(const lf_params &P, const u64 *lcccs, std::vector<H9> &pt) {
@@ -743,15 +798,15 @@ static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witn
         for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
-    for (u32 j = 0; j < P.t; j++) launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * RE * m, m, 0, c->st);
+    for (u32 j = 0; j < P.t; j++) launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * RE * m, m, 0, c->stream());
     std::vector<H9> pt(P.s);
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data()));
     // v, u at the sumcheck point (linearization.rs:126-139)
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * RE, *u = v + (size_t)TAU * RE;
-    launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->st);
+    launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());
     RET(down_small(c, od, (size_t)TAU * RE, v));   // T[72][9] flat == v[9][8 slots][9]
-    launch_dot_eq(c->dev, mz, m, P.t, eqr, m, m, partial, od, c->st);
+    launch_dot_eq(c->dev, mz, m, P.t, eqr, m, m, partial, od, c->stream());
     RET(down_small(c, od, (size_t)P.t * RE, u));
     {
         HostTimer ht(c);
@@ -799,16 +854,22 @@ struct SideState {
     std::vector<u64> lcccs;   // K flat LCCCS (host)
 };
 
-// LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
-static int decompose_impl(C *c, BbTranscript &tr, const u64 *lcccs, const std::vector<H9> &rpt, const lf_witness *wit, const char *side,
-                          fe *eq_r, SideState &S, u64 *proof) {
+// LFDecompositionProver::prove (nifs/decomposition.rs:33-88), split so that the GPU work of one side can run while the
+// host does something else: `dec_enqueue` launches everything on the current lane's stream and queues the downloads into
+// the lane's pinned arena (no host synchronisation), `dec_finish` waits for it, finishes y_0 on the host and absorbs.
+struct DecPending {
+    u64 *h_y = nullptr, *h_v = nullptr, *h_u = nullptr;   // pinned results
+    int lane = 0;
+    size_t ph_commit = 0, ph_evals = 0;
+};
+static int dec_enqueue(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const lf_witness *wit, const char *side, fe *eq_r, SideState &S,
+                       u64 *proof, DecPending &pd) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n, N = c->N;
     u32 K = P.K;
     std::string sd(side);
-    const u64 *cm = lcccs + ((size_t)P.s + TAU) * RE;
     const u64 *xh = lcccs + ((size_t)P.s + TAU + P.kappa + P.t) * RE;
-    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * RE, *x_s = v_s + (size_t)K * TAU * RE, *y_s = x_s + (size_t)K * (P.l + 1) * RE;
+    u64 *x_s = proof + (size_t)K * P.t * RE + (size_t)K * TAU * RE;
     fe *Fh, *z, *q;
     i64 *partial;
     u64 *od, *yd;
@@ -820,15 +881,46 @@ static int decompose_impl(C *c, BbTranscript &tr, const u64 *lcccs, const std::v
     RET(c->tbuf("dec_q", (size_t)P.t * RE * n, &q));
     if (!eq_r) {
         RET(c->tbuf("eq_r_" + sd, TAU * m, &eq_r));
-        RET(build_eq_dev(c, rpt.data(), P.s, eq_r));
+        RET(build_eq_async(c, rpt.data(), P.s, eq_r));
     }
     S.planes = wit->planes; S.z = z; S.eq_r = eq_r;
+    pd.lane = c->lane;
+    pd.h_y = c->arena_alloc((size_t)(K - 1) * P.kappa * RE);
+    pd.h_v = c->arena_alloc((size_t)K * TAU * RE);
+    pd.h_u = c->arena_alloc((size_t)K * P.t * RE);
+    if (!pd.h_y || !pd.h_v || !pd.h_u) return LF_ERR_HIP;
     // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
-    size_t ph = c->ev_begin(11);
-    launch_bitplane_crt(c->dev, wit->planes, N, N, 1, K, Fh, c->st);
+    pd.ph_commit = c->ev_begin(11);
+    launch_bitplane_crt(c->dev, wit->planes, N, N, 1, K, Fh, c->stream());
     RET(commit_dev(c, Fh, N, K - 1, yd, true));
-    RET(down_small(c, yd, (size_t)(K - 1) * P.kappa * RE, y_s + (size_t)P.kappa * RE));
-    c->ev_end(ph);
+    HIPCHK(hipMemcpyAsync(pd.h_y, yd, (size_t)(K - 1) * P.kappa * RE * 8, hipMemcpyDeviceToHost, c->stream()));
+    c->ev_end(pd.ph_commit);
+    pd.ph_evals = c->ev_begin(12);
+    compute_x_s(c, xh, x_s);   // host, O(l) elements
+    // v_s (decomposition.rs:204-211) from the coefficient planes
+    launch_coef_eval(c->dev, wit->planes, N, eq_r, m, K, 1, partial, od, c->stream());
+    HIPCHK(hipMemcpyAsync(pd.h_v, od, (size_t)K * TAU * RE * 8, hipMemcpyDeviceToHost, c->stream()));
+    // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
+    RET(build_z_async(c, wit->planes, K, 1, x_s, z));
+    for (u32 j = 0; j < P.t; j++)
+        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * RE * n, n, c->stream());
+    u64 *od2 = od + 16 * RE * TAU;
+    launch_dot_batch(c->dev, z, n, K, q, n, P.t, n, partial, od2, c->stream());
+    HIPCHK(hipMemcpyAsync(pd.h_u, od2, (size_t)K * P.t * RE * 8, hipMemcpyDeviceToHost, c->stream()));
+    c->ev_end(pd.ph_evals);
+    HIPCHK(hipEventRecord(c->ev_side[pd.lane], c->stream()));
+    return LF_OK;
+}
+static int dec_finish(C *c, BbTranscript &tr, const u64 *lcccs, SideState &S, u64 *proof, DecPending &pd) {
+    const lf_params &P = c->P;
+    u32 K = P.K;
+    const u64 *cm = lcccs + ((size_t)P.s + TAU) * RE;
+    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * RE, *x_s = v_s + (size_t)K * TAU * RE, *y_s = x_s + (size_t)K * (P.l + 1) * RE;
+    HIPCHK(hipEventSynchronize(c->ev_side[pd.lane]));
+    memcpy(y_s + (size_t)P.kappa * RE, pd.h_y, (size_t)(K - 1) * P.kappa * RE * 8);
+    memcpy(v_s, pd.h_v, (size_t)K * TAU * RE * 8);
+    memcpy(u_s, pd.h_u, (size_t)K * P.t * RE * 8);
+    HostTimer ht(c);
     {   // y_0 = cm - sum_{k>=1} b^k y_k, as the reference's fold (acc + y_i) * b
         std::vector<u64> acc((size_t)P.kappa * RE, 0);
         u64 bb[RE];
@@ -840,20 +932,7 @@ static int decompose_impl(C *c, BbTranscript &tr, const u64 *lcccs, const std::v
             }
         for (u32 i = 0; i < P.kappa; i++) BbHostRing::sub(cm + (size_t)i * RE, &acc[(size_t)i * RE], y_s + (size_t)i * RE);
     }
-    ph = c->ev_begin(12);
-    compute_x_s(c, xh, x_s);
-    // v_s (decomposition.rs:204-211) from the coefficient planes
-    launch_coef_eval(c->dev, wit->planes, N, eq_r, m, K, 1, partial, od, c->st);
-    RET(down_small(c, od, (size_t)K * TAU * RE, v_s));
-    // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
-    RET(build_z(c, wit->planes, K, 1, x_s, z));
-    for (u32 j = 0; j < P.t; j++)
-        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * RE * n, n, c->st);
-    launch_dot_batch(c->dev, z, n, K, q, n, P.t, n, partial, od, c->st);
-    RET(down_small(c, od, (size_t)K * P.t * RE, u_s));
-    c->ev_end(ph);
     // transcript (decomposition.rs:65-83): absorb x_k, y_k, u_k, v_k and build the K LCCCS
-    HostTimer ht(c);
     size_t ll = bb_lcccs_len(&P);
     S.lcccs.assign((size_t)K * ll * RE, 0);
     for (u32 k = 0; k < K; k++) {
@@ -876,8 +955,8 @@ static int decompose_impl(C *c, BbTranscript &tr, const u64 *lcccs, const std::v
 template <class T>
 static int upload_consts(C *c, const std::string &name, const std::vector<T> &v, T **out) {
     RET(c->tbuf(name, v.size() + 8, out));
-    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
 }
 
@@ -932,10 +1011,10 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("round_out", 5 * RE, &od));
     for (int sd = 0; sd < 2; sd++) {
         // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}   (folding.rs:208-226, utils.rs:524-546)
-        launch_lincomb_z(c->dev, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->st);
+        launch_lincomb_z(c->dev, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
         for (u32 j = 0; j < P.t; j++)
-            launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], zz + (size_t)j * RE * n, n, G[sd], m, j > 0, c->st);
-        launch_add_fhat_comb(c->dev, S[sd].planes, N, K, d_ap + (size_t)sd * K * TAU, G[sd], m, c->st);
+            launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], zz + (size_t)j * RE * n, n, G[sd], m, j > 0, c->stream());
+        launch_add_fhat_comb(c->dev, S[sd].planes, N, K, d_ap + (size_t)sd * K * TAU, G[sd], m, c->stream());
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     c->ev_end(ph);
@@ -962,17 +1041,17 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             E9PreC r = e9pre_from_h9(rh, nu);
             size_t nn = a.n / 2, ldn = atl(nn);
             fe *dst = T5[flip];
-            launch_fix(c->dev, a.eqL, a.ld, dst, ldn, a.n, 1, r, c->st);
-            launch_fix(c->dev, a.eqR, a.ld, dst + (size_t)TAU * ldn, ldn, a.n, 1, r, c->st);
-            launch_fix(c->dev, a.eqB, a.ld, dst + (size_t)2 * TAU * ldn, ldn, a.n, 1, r, c->st);
-            launch_fix(c->dev, a.G1, a.ld, dst + (size_t)3 * TAU * ldn, ldn, a.n, 8, r, c->st);
-            launch_fix(c->dev, a.G2, a.ld, dst + (size_t)(3 * TAU + RE) * ldn, ldn, a.n, 8, r, c->st);
+            launch_fix(c->dev, a.eqL, a.ld, dst, ldn, a.n, 1, r, c->stream());
+            launch_fix(c->dev, a.eqR, a.ld, dst + (size_t)TAU * ldn, ldn, a.n, 1, r, c->stream());
+            launch_fix(c->dev, a.eqB, a.ld, dst + (size_t)2 * TAU * ldn, ldn, a.n, 1, r, c->stream());
+            launch_fix(c->dev, a.G1, a.ld, dst + (size_t)3 * TAU * ldn, ldn, a.n, 8, r, c->stream());
+            launch_fix(c->dev, a.G2, a.ld, dst + (size_t)(3 * TAU + RE) * ldn, ldn, a.n, 8, r, c->stream());
             if (round == 3) {
-                launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, m, K, pt[0], pt[1], c->ring, F[0], c->st);
+                launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, m, K, pt[0], pt[1], c->ring, F[0], c->stream());
                 curF = F[0]; ldF = atl(m / 4);
             } else if (round > 3) {
                 fe *fd = F[(round & 1) ? 0 : 1];   // round 4 -> F[1], round 5 -> F[0], ...
-                launch_fix(c->dev, curF, ldF, fd, ldn, a.n, K2 * TAU * 8, r, c->st);
+                launch_fix(c->dev, curF, ldF, fd, ldn, a.n, K2 * TAU * 8, r, c->stream());
                 curF = fd; ldF = ldn;
             }
             a.eqL = dst; a.eqR = dst + (size_t)TAU * ldn; a.eqB = dst + (size_t)2 * TAU * ldn;
@@ -981,9 +1060,9 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             flip ^= 1;
         }
         size_t ev = c->ev_begin(0);
-        if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->st);
-        else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->st);
-        else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->st);
+        if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
+        else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
+        else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());
         c->ev_end(ev);
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;
         RET(down_small(c, od, (size_t)(deg + 1) * RE, evs));
@@ -1004,11 +1083,11 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("dec_small", 16 * RE * TAU + 16 * 4 * RE, &sm));
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
     for (u32 j = 0; j < P.t; j++)
-        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * RE * n, n, c->st);
+        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * RE * n, n, c->stream());
     for (int sd = 0; sd < 2; sd++) {
-        launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, sm, c->st);
+        launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, sm, c->stream());
         RET(down_small(c, sm, (size_t)K * TAU * RE, theta + (size_t)sd * K * TAU * RE));
-        launch_dot_batch(c->dev, S[sd].z, n, K, q, n, P.t, n, red, sm, c->st);
+        launch_dot_batch(c->dev, S[sd].z, n, K, q, n, P.t, n, red, sm, c->stream());
         RET(down_small(c, sm, (size_t)K * P.t * RE, eta + (size_t)sd * K * P.t * RE));
     }
     std::vector<u64> rho_c((size_t)K2 * RE, 0), rho((size_t)K2 * RE);
@@ -1031,11 +1110,11 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // f_0 in the coefficient domain -> new witness
     int8_t *d_rho;
     RET(c->tbuf("c_rho", (size_t)K2 * 24 + 64, &d_rho));
-    HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->stream()));
     int32_t *npl;
     HIPCHK(hipMalloc((void **)&npl, N * RE * 4));
-    launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->st);
-    HIPCHK(hipStreamSynchronize(c->st));
+    launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
+    HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c->owner, npl, N};
     c->ev_end(ph);
 
@@ -1118,13 +1197,23 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     std::vector<u64> lin(ll * RE);
     fe *eq_r_R = nullptr;
     SideState S[2];
-    int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
-    if (rc == LF_OK) rc = decompose_impl(c, tr, acc, rL, w_acc, "L", nullptr, S[0], decl);
+    // Schedule (transcript order is fixed, compute order is not): the left decomposition needs nothing from the linearization,
+    // so its GPU work is queued on lane 1 first; the latency-bound linearization rounds run on lane 0 meanwhile; then the right
+    // decomposition is queued (lane 0) and the host absorbs the left one while the GPU works on the right one.
+    c->arena_used[0] = c->arena_used[1] = 0;
+    DecPending pdL, pdR;
+    c->lane = 1;
+    int rc = dec_enqueue(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
+    c->lane = 0;
+    if (rc == LF_OK) rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
     std::vector<H9> rR;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
-        rc = decompose_impl(c, tr, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
+        rc = dec_enqueue(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr, pdR);
     }
+    if (rc == LF_OK) rc = dec_finish(c, tr, acc, S[0], decl, pdL);
+    if (rc == LF_OK) rc = dec_finish(c, tr, lin.data(), S[1], decr, pdR);
+    (void)hipStreamSynchronize(c->st_lane[1]);
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->ev_end(tot);
     c->ev_collect();
@@ -1170,12 +1259,12 @@ int BbCtx::sumcheck_lin_round(const uint64_t *r_prev, uint64_t *evals_out) {
         E9PreC r = e9pre_from_h9(h9_load(r_prev), c->ring.T.nu);
         int src = c->sc_cur, dst = src ^ 1;
         size_t ldi = c->sc_n == m ? m : atl(c->sc_n);
-        launch_fix(c->dev, tab[src], ldi, tab[dst], atl(c->sc_n / 2), c->sc_n, P.t * 8, r, c->st);
-        launch_fix(c->dev, eq[src], ldi, eq[dst], atl(c->sc_n / 2), c->sc_n, 1, r, c->st);
+        launch_fix(c->dev, tab[src], ldi, tab[dst], atl(c->sc_n / 2), c->sc_n, P.t * 8, r, c->stream());
+        launch_fix(c->dev, eq[src], ldi, eq[dst], atl(c->sc_n / 2), c->sc_n, 1, r, c->stream());
         c->sc_cur = dst; c->sc_n /= 2;
     }
     size_t ld = c->sc_n == m ? m : atl(c->sc_n);
-    launch_lin_round(c->dev, c->desc, tab[c->sc_cur], ld, eq[c->sc_cur], ld, c->sc_n, P.d + 1, partial, od, c->st);
+    launch_lin_round(c->dev, c->desc, tab[c->sc_cur], ld, eq[c->sc_cur], ld, c->sc_n, P.d + 1, partial, od, c->stream());
     c->sc_round++;
     return down_small(c, od, (size_t)(P.d + 2) * RE, evals_out);
 }

@@ -97,6 +97,17 @@ BB_HD E9 e9_mul_pre(const E9 &a, const E9 &b, const E9 &bn) {
     }
     return r;
 }
+// the nine un-reduced column sums of a * b (each |T_k| <= 9 H^2); callers that add many products keep the high and low
+// 32-bit halves of T_k in separate 64-bit sums and reduce once (mred(hi * 2^32 + lo) = hi + lo * 2^-32)
+BB_HD void e9_mul_cols(const E9 &a, const E9 &b, const E9 &bn, i64 (&T)[TAU]) {
+#pragma unroll
+    for (int k = 0; k < TAU; k++) {
+        i64 acc = 0;
+#pragma unroll
+        for (int i = 0; i < TAU; i++) acc += (i64)a.c[i] * (i64)(i <= k ? b.c[k - i] : bn.c[k + TAU - i]);
+        T[k] = acc;
+    }
+}
 BB_HD E9 e9_mul(const E9 &a, const E9 &b, fe nu) { return e9_mul_pre(a, b, e9_times_nu(b, nu)); }
 BB_HD E9 e9_sqr(const E9 &a, fe nu) { return e9_mul_pre(a, a, e9_times_nu(a, nu)); }
 // a * s where s is a plain small integer

@@ -50,6 +50,11 @@ __device__ __forceinline__ E9Pre e9p(const E9PreC &k) { E9Pre r; for (int i = 0;
 // |s| <= 9 H^2: two Montgomery steps (s * R^-1, then * R^2 * R^-1) instead of a 64-bit modulo
 __device__ __forceinline__ fe fred(i64 s) { return fmul(mred(s), BB_R2C); }
 
+// sum of un-reduced product columns kept as (sum of high halves, sum of low halves); value = Montgomery-reduced total
+struct HL { i64 hi, lo; };
+__device__ __forceinline__ void hl_add(HL &a, i64 T) { a.hi += (T >> 32); a.lo += (i64)(u32)T; }
+__device__ __forceinline__ fe hl_finish(const HL &a) { return fadd(fred(a.hi), mred(a.lo)); }   // |hi|,|lo| sums < 2^62
+
 // ---------------------------------------------------------------------------------------------------------
 // reductions: every thread holds NV signed 64-bit partial sums (of centred words)
 __device__ __forceinline__ i64 wave_sum(i64 v) {
@@ -395,9 +400,9 @@ __global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, 
     u32 nout = kappa * batch;
     u32 oi = threadIdx.x / batch, ok = threadIdx.x % batch;
     bool active = threadIdx.x < nout;
-    i64 acc[TAU];
+    HL acc[TAU];   // lazy: no Montgomery reduction inside the column loop
 #pragma unroll
-    for (int c = 0; c < TAU; c++) acc[c] = 0;
+    for (int c = 0; c < TAU; c++) { acc[c].hi = 0; acc[c].lo = 0; }
     for (size_t jt = j0; jt < j1; jt += AJ_T) {
         u32 rowsA = kappa * TAU;
         for (u32 idx = threadIdx.x; idx < rowsA * AJ_T; idx += 256) {
@@ -421,9 +426,10 @@ __global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, 
                 E9 a, b, bn;
 #pragma unroll
                 for (int c = 0; c < TAU; c++) { a.c[c] = pa[jj * AJ_REC + c]; b.c[c] = pf[jj * AJ_REC + c]; bn.c[c] = pn[jj * AJ_REC + c]; }
-                E9 p = e9_mul_pre(a, b, bn);
+                i64 T[TAU];
+                e9_mul_cols(a, b, bn, T);
 #pragma unroll
-                for (int c = 0; c < TAU; c++) acc[c] += p.c[c];
+                for (int c = 0; c < TAU; c++) hl_add(acc[c], T[c]);
             }
         }
         __syncthreads();
@@ -432,7 +438,7 @@ __global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, 
         // partial[split][slot][i][k][9]
         i64 *o = partial + ((((size_t)split * 8 + slot) * kappa + oi) * batch + ok) * TAU;
 #pragma unroll
-        for (int c = 0; c < TAU; c++) o[c] = acc[c];
+        for (int c = 0; c < TAU; c++) o[c] = hl_finish(acc[c]);
     }
 }
 // out[k][i][9*slot+c] = canonical sum over splits
