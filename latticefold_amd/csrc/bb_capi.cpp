@@ -498,7 +498,7 @@ int BbCtx::ccs_load(const lf_params *P, const uint32_t *const *rowptr, const uin
                     const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *cc) {
     C *c = p;
     if (P->s < 3 || P->s > 28 || P->t == 0 || P->t > 4 || P->q == 0 || P->q > 8 || P->K == 0 || P->K > 16 || P->L == 0 || P->L > 8 ||
-        P->d + 1 > 3 || P->wit_len == 0)
+        P->d + 1 > 4 || P->wit_len == 0)
         return LF_ERR_UNSUPPORTED;
     if (P->b != 2) return LF_ERR_UNSUPPORTED;
     if (!pow2(P->B) || P->B > (1ULL << 30)) return LF_ERR_UNSUPPORTED;

@@ -744,9 +744,9 @@ __device__ __forceinline__ E9 pick4(const E9 (&v)[4], u32 idx) {
 __global__ void __launch_bounds__(256) k_lin_round(DevBb t, LinDesc desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg,
                                                    i64 *partial) {
     u32 slot = blockIdx.y;
-    i64 acc[4 * TAU];
+    i64 acc[5 * TAU];
 #pragma unroll
-    for (int i = 0; i < 4 * TAU; i++) acc[i] = 0;
+    for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
     size_t pairs = n / 2;
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
         E9 v[4], st[4], e, es;
@@ -791,15 +791,16 @@ __global__ void __launch_bounds__(256) k_lin_round(DevBb t, LinDesc desc, const 
                 if (X == 0) acc[c] += g.c[c];
                 else if (X == 1) acc[TAU + c] += g.c[c];
                 else if (X == 2) acc[2 * TAU + c] += g.c[c];
-                else acc[3 * TAU + c] += g.c[c];
+                else if (X == 3) acc[3 * TAU + c] += g.c[c];
+                else acc[4 * TAU + c] += g.c[c];
         }
     }
-    __shared__ i64 red[4 * TAU];
-    block_sum_store<4 * TAU>(acc, red);
+    __shared__ i64 red[5 * TAU];
+    block_sum_store<5 * TAU>(acc, red);
     __syncthreads();
-    if (threadIdx.x < 4 * TAU) {
+    if (threadIdx.x < 5 * TAU) {
         u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
-        partial[(size_t)blockIdx.x * (4 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
+        partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
     }
 }
 void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg, i64 *partial,
@@ -808,7 +809,7 @@ void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t 
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     hipLaunchKernelGGL(k_lin_round, dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial);
-    launch_reduce_rows(partial, gb, 4 * RE, out, s);   // X = deg+1.. rows stay zero
+    launch_reduce_rows(partial, gb, 5 * RE, out, s);   // X = deg+1.. rows stay zero
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -70,6 +70,45 @@ def diag(v: int, ring: str = "goldilocks") -> np.ndarray:
     return e
 
 
+def default_nonres(ring: str) -> int:
+    """extension-field non-residue of the DEFAULT ring tables (DESIGN.md "CRT map is data"): 2^40 for Goldilocks, the first
+    g^((p-1)/24) of exact order 24 (g = 2, 3, ..) for BabyBear"""
+    p = RINGS[ring][0]
+    if ring == "goldilocks":
+        return 1 << 40
+    g = 2
+    while True:
+        z = pow(g, (p - 1) // 24, p)
+        if pow(z, 12, p) != 1 and pow(z, 8, p) != 1:
+            return z
+        g += 1
+
+
+def ring_mul_ntt(a: np.ndarray, b: np.ndarray, ring: str = "goldilocks") -> np.ndarray:
+    """slot-wise product of NTT-form ring elements (a, b: (..., d) uint64) in F_{p^tau} = F_p[Y]/(Y^tau - nonres);
+    plain Python integers -- for building small test workloads only"""
+    p, d, tau = RINGS[ring]
+    nu = default_nonres(ring)
+    a2 = np.asarray(a, dtype=np.uint64).reshape(-1, 8, tau)
+    b2 = np.asarray(b, dtype=np.uint64).reshape(-1, 8, tau)
+    out = np.zeros_like(a2)
+    for e in range(a2.shape[0]):
+        for k in range(8):
+            x = [int(v) for v in a2[e, k]]
+            y = [int(v) for v in b2[e, k]]
+            r = [0] * tau
+            for i in range(tau):
+                if not x[i]:
+                    continue
+                for j in range(tau):
+                    if i + j < tau:
+                        r[i + j] += x[i] * y[j]
+                    else:
+                        r[i + j - tau] += nu * x[i] * y[j]
+            out[e, k] = [v % p for v in r]
+    return out.reshape(np.asarray(a).shape)
+
+
 @dataclass
 class Workload:
     name: str
@@ -148,7 +187,12 @@ class Workload:
         return lin + 2 * dec + fold
 
 
-def make_workload(name: str, seed: int = 0, kappa: int = None) -> Workload:
+def make_workload(name: str, seed: int = 0, kappa: int = None, ccs: str = "r1cs") -> Workload:
+    """ccs = "r1cs": the reference bench shape (A = B = I, C = diag(z); 1 nnz/row);
+       ccs = "deg3": the reference's degree-three non-scalar CCS (arith/ccs.rs:14-43): t = 4, M = (I, I, I, diag(z^2)),
+                     S = {{0,1,2},{3}}, c = (1,-1), d = 3;
+       ccs = "multi": an R1CS with 2 nnz/row and non-identity values: (A z)_i = z_i + z_{i+1}, B = I,
+                      (C z)_i = z_i * (z_i + z_{i+1})  (satisfied by construction).  Small sizes only (Python integers)."""
     cfg = CONFIGS[name]
     s, wit_len, L, B, b, K, kap = cfg[:7]
     ring = cfg[7] if len(cfg) > 7 else "goldilocks"
@@ -169,4 +213,24 @@ def make_workload(name: str, seed: int = 0, kappa: int = None) -> Workload:
     wl.S_off = np.array([0, 2, 3], dtype=np.uint32)
     wl.S_idx = np.array([0, 1, 2], dtype=np.uint32)
     wl.c = np.stack([diag(1, ring), diag(p - 1, ring)])
+    if ccs == "deg3":
+        zsq = ring_mul_ntt(z[:rows], z[:rows], ring)
+        wl.t, wl.q, wl.d = 4, 2, 3
+        wl.rowptr = [rp, rp.copy(), rp.copy(), rp.copy()]
+        wl.col = [ci, ci.copy(), ci.copy(), ci.copy()]
+        wl.val = [ident, ident.copy(), ident.copy(), np.ascontiguousarray(zsq)]
+        wl.S_off = np.array([0, 3, 4], dtype=np.uint32)
+        wl.S_idx = np.array([0, 1, 2, 3], dtype=np.uint32)
+    elif ccs == "multi":
+        assert rows >= 2
+        nxt = (np.arange(rows, dtype=np.uint32) + 1) % np.uint32(rows)
+        rp2 = np.minimum(2 * np.arange(m + 1, dtype=np.uint64), np.uint64(2 * rows)).astype(np.uint32)
+        ci2 = np.stack([ci, nxt], axis=1).reshape(-1).astype(np.uint32)
+        vA = np.tile(diag(1, ring), (2 * rows, 1))
+        zc = np.repeat(z[:rows], 2, axis=0)                       # C row i: z_i at columns i and i+1
+        wl.rowptr = [rp2, rp.copy(), rp2.copy()]
+        wl.col = [ci2, ci.copy(), ci2.copy()]
+        wl.val = [vA, ident.copy(), np.ascontiguousarray(zc)]
+    elif ccs != "r1cs":
+        raise ValueError(ccs)
     return wl

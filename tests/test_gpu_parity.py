@@ -277,3 +277,24 @@ def test_parameter_and_state_errors(ctx):
     with pytest.raises(api.LfError) as e:
         api.NIFSProver.prove(ctx, nondiag, wit, cccs, wit, api.PoseidonTranscript())
     assert e.value.code == -3
+
+
+# ---- general CCS shapes (arbitrary SparseMatrix rows, degree-3 CCS of arith/ccs.rs:14-43) -------------------
+@pytest.mark.parametrize("name,ccs", [("T8", "deg3"), ("T8", "multi"), ("G5", "deg3"), ("T10", "multi")])
+def test_fold_step_parity_general_ccs(ctx, name, ccs):
+    wl = make_workload(name, ccs=ccs)
+    inst = lfo.Instance(wl)
+    ctx.load_ccs(wl)
+    A = wl.ajtai_matrix()
+    scheme = api.AjtaiCommitmentScheme(ctx, matrix=A)
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    acc_g, linpr_g = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+    acc_o, linpr_o = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    assert (linpr_g == linpr_o).all() and (acc_g == acc_o).all()
+    lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+    rc, lc_v = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)
+    assert rc == 0 and (lc_v == lc_g).all()
