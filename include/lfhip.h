@@ -40,6 +40,7 @@ enum {
     LF_ERR_BAD_TABLES = -4,     /* ring tables are not a ring isomorphism */
     LF_ERR_NORM = -5,           /* witness coefficient exceeds the decomposition bound */
     LF_ERR_SIZE_BOUNDS = -6,    /* CSError::InvalidSizeBounds (nifs.rs:165-173) */
+    LF_ERR_REJECT = -8,         /* lf_verify_host: the proof does not verify */
     LF_ERR_STATE = -7,          /* call sequence misuse (the reference panics: sumcheck/prover.rs:41,63,75,81) */
 };
 const char *lf_strerror(int code);
@@ -192,6 +193,15 @@ const char *lf_phase_name(int i);
 /* dominant-kernel timing: total HIP-event time and launch count of the folding-sumcheck round kernel and of
  * the Ajtai kernel in the last fold step */
 int lf_last_kernel_stats(lf_ctx *, float *fold_round_ms, int *fold_round_launches, float *ajtai_ms, int *ajtai_launches);
+
+/* NIFSVerifier::verify (nifs.rs:117-163) on the host: O(proof size), NO GPU and no lf_ctx needed.  The CCS enters only
+ * through its shape (lf_params), the multisets S (S_off[q+1], S_idx) and the coefficients c (q ring elements) -- the
+ * verifier never touches the matrices (linearization.rs:220-243).  `t` is a transcript of the same ring in the state the
+ * prover's transcript had before lf_fold_step.  Returns LF_OK and the folded LCCCS, or LF_ERR_REJECT with *failed_stage =
+ * 1 linearization sumcheck, 2 linearization claim, 3 / 4 left / right decomposition recomposition, 5 folding sumcheck,
+ * 6 folding claim.  Uses the default ring tables of the ring. */
+int lf_verify_host(int ring, const lf_params *, const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *c, lf_transcript *t,
+                   const uint64_t *acc_lcccs, const uint64_t *cm_i_cccs, const uint64_t *proof, uint64_t *lcccs_out, int *failed_stage);
 
 #ifdef __cplusplus
 }

@@ -131,6 +131,7 @@ def _lib():
         L.lf_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.lf_phase_name.restype = C.c_char_p
         L.lf_phase_name.argtypes = [C.c_int]
+        L.lf_verify_host.argtypes = [C.c_int, C.POINTER(Params), u32p, u32p, u64p, vp, u64p, u64p, u64p, u64p, C.POINTER(C.c_int)]
         L.lf_last_kernel_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
@@ -482,6 +483,29 @@ class NIFSProver:
         _chk(_lib().lf_fold_step(ctx.h, transcript.h, pa, w_acc.h, pb, w_i.h, lc.ctypes.data_as(u64p), C.byref(h),
                                  pr.ctypes.data_as(u64p)), "lf_fold_step")
         return lc, Witness(ctx, h), pr
+
+
+class NIFSVerifier:
+    @staticmethod
+    def verify(wl, acc, cm_i, proof, transcript):
+        """nifs.rs:117-163 on the host (no GPU): wl gives the CCS shape (params, S, c).  Returns (ok, folded LCCCS flat,
+        failed_stage)."""
+        ring = wl.ring
+        rid, RE_ = RING_IDS[ring], RING_WORDS[ring]
+        prm = Params(wl.s, wl.wit_len, wl.l, wl.L, wl.K, wl.b, wl.B, wl.kappa, wl.t, wl.q, wl.d)
+        so = np.ascontiguousarray(wl.S_off, dtype=np.uint32)
+        si = np.ascontiguousarray(wl.S_idx, dtype=np.uint32)
+        cc, pc = _a64(np.ascontiguousarray(wl.c).reshape(-1))
+        a, pa = _a64(acc)
+        b, pb = _a64(cm_i)
+        pr, pp = _a64(proof)
+        lc = np.zeros((_lib().lf_lcccs_len_ring(C.byref(prm), rid), RE_), dtype=np.uint64)
+        st = C.c_int(0)
+        rc = _lib().lf_verify_host(rid, C.byref(prm), so.ctypes.data_as(u32p), si.ctypes.data_as(u32p), pc, transcript.h, pa, pb, pp,
+                                   lc.ctypes.data_as(u64p), C.byref(st))
+        if rc not in (0, -8):
+            raise LfError(rc, "lf_verify_host")
+        return rc == 0, lc, st.value
 
 
 class MLSumcheckLin:

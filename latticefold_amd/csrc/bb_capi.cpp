@@ -16,6 +16,7 @@
 
 #include "bb_kernels.h"
 #include "lf_common.h"
+#include "lf_verify.h"
 
 namespace lfbb {
 
@@ -1283,6 +1284,79 @@ int BbCtx::last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_
     if (aj_ms) *aj_ms = p->k_ajtai_ms;
     if (aj_n) *aj_n = p->k_ajtai_n;
     return LF_OK;
+}
+
+// ---- host-side verifier ------------------------------------------------------------------------------------------------------------
+namespace {
+struct BbV {
+    static constexpr int RE = lfbb::RE, TAU = lfbb::TAU;
+    typedef H9 Ext;
+    typedef BbTranscript Tr;
+    BbHostRing ring;
+    void mul(const u64 *a, const u64 *b, u64 *o) const { ring.mul_ntt(a, b, o); }
+    void mul_ext(const u64 *a, const Ext &s, u64 *o) const { ring.mul_h9(a, s, o); }
+    static void add(const u64 *a, const u64 *b, u64 *o) { BbHostRing::add(a, b, o); }
+    static void sub(const u64 *a, const u64 *b, u64 *o) { BbHostRing::sub(a, b, o); }
+    static void from_u64(u64 v, u64 *o) { BbHostRing::from_u64(v, o); }
+    static void from_ext(const Ext &e, u64 *o) { BbHostRing::from_h9(e, o); }
+    static Ext ext_of(const u64 *e) { return h9_load(e); }
+    static Ext ext_from_u64(u64 v) { Ext r; memset(&r, 0, sizeof(r)); r.c[0] = v % BB_P; return r; }
+    Ext ext_mul(const Ext &a, const Ext &b) const { return ring.mul9(a, b); }
+    static Ext ext_add(const Ext &a, const Ext &b) { Ext r; for (int i = 0; i < TAU; i++) r.c[i] = hadd(a.c[i], b.c[i]); return r; }
+    static Ext ext_sub(const Ext &a, const Ext &b) { return h9_sub(a, b); }
+    Ext ext_inv(const Ext &a) const {   // solve (multiplication-by-a) x = 1 over F_p
+        u64 M[TAU][TAU + 1];
+        Ext yb = ext_from_u64(0);
+        yb.c[1] = 1;
+        Ext cur = a;
+        for (int j = 0; j < TAU; j++) {
+            for (int i = 0; i < TAU; i++) M[i][j] = cur.c[i];
+            cur = ring.mul9(cur, yb);
+        }
+        for (int i = 0; i < TAU; i++) M[i][TAU] = i == 0;
+        for (int c = 0; c < TAU; c++) {
+            int piv = -1;
+            for (int r = c; r < TAU; r++) if (M[r][c]) { piv = r; break; }
+            if (piv < 0) return ext_from_u64(0);
+            if (piv != c) for (int k = 0; k <= TAU; k++) std::swap(M[piv][k], M[c][k]);
+            u64 inv = hinv(M[c][c]);
+            for (int k = 0; k <= TAU; k++) M[c][k] = hmul(M[c][k], inv);
+            for (int r = 0; r < TAU; r++) {
+                if (r == c || !M[r][c]) continue;
+                u64 f = M[r][c];
+                for (int k = 0; k <= TAU; k++) M[r][k] = hsub(M[r][k], hmul(f, M[c][k]));
+            }
+        }
+        Ext r;
+        for (int i = 0; i < TAU; i++) r.c[i] = M[i][TAU];
+        return r;
+    }
+    static void absorb_ext(Tr &tr, const Ext &e) { tr.absorb_h9_as_ring(e); }
+    void crt(const u64 *c, u64 *o) const { ring.crt(c, o); }
+    static u64 fmul(u64 a, u64 b) { return hmul(a % BB_P, b % BB_P); }
+    static u64 fadd(u64 a, u64 b) { return hadd(a, b); }
+    static void rot_x(u64 *a) {   // multiply by X modulo X^72 - X^36 + 1
+        u64 top = a[RE - 1];
+        for (int j = RE - 1; j > 0; j--) a[j] = a[j - 1];
+        a[0] = top ? BB_P - top : 0;
+        a[RE / 2] = hadd(a[RE / 2], top);
+    }
+};
+}  // namespace
+
+int bb_verify_host(const lf_params *p, const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *c, BbTranscript &tr, const uint64_t *acc,
+                   const uint64_t *cm_i, const uint64_t *proof, uint64_t *lcccs_out, int *failed_stage) {
+    static const BbV *bv = [] {
+        BbV *g = new BbV();
+        u64 nr, y[8 * TAU];
+        bb_default_ring(&nr, y);
+        bb_build_tables(nr, y, g->ring.T);
+        return g;
+    }();
+    lfv::Verifier<BbV> V(*bv, *p, S_off, S_idx, c);
+    int rc = V.verify(tr, acc, cm_i, proof, lcccs_out);
+    if (failed_stage) *failed_stage = V.stage;
+    return rc;
 }
 
 }  // namespace lfbb

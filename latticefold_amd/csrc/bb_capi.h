@@ -53,6 +53,8 @@ struct BbCtx {
     int last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_n);
 };
 
+int bb_verify_host(const lf_params *p, const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *c, BbTranscript &tr, const uint64_t *acc,
+                   const uint64_t *cm_i, const uint64_t *proof, uint64_t *lcccs_out, int *failed_stage);
 size_t bb_lcccs_len(const lf_params *p);
 size_t bb_cccs_len(const lf_params *p);
 size_t bb_proof_len(const lf_params *p);

@@ -17,6 +17,7 @@
 #include "bb_capi.h"
 #include "lf_common.h"
 #include "lf_kernels.h"
+#include "lf_verify.h"
 
 using namespace lf;
 
@@ -187,6 +188,7 @@ const char *lf_strerror(int code) {
         case LF_ERR_NORM: return "witness coefficient exceeds the decomposition bound";
         case LF_ERR_SIZE_BOUNDS: return "invalid size bounds (m must be >= wit_len*L, power of two)";
         case LF_ERR_STATE: return "call sequence misuse";
+        case LF_ERR_REJECT: return "verifier rejected the proof";
     }
     return "unknown error";
 }
@@ -1528,4 +1530,57 @@ int lf_last_kernel_stats(lf_ctx *c, float *fold_ms, int *fold_n, float *aj_ms, i
     if (aj_ms) *aj_ms = c->k_ajtai_ms;
     if (aj_n) *aj_n = c->k_ajtai_n;
     return LF_OK;
+}
+
+// ---- host-side verifier ---------------------------------------------------------------------------------------
+namespace {
+struct GoldV {
+    static constexpr int RE = 24, TAU = 3;
+    typedef Fq3 Ext;
+    typedef Transcript Tr;
+    HostRing ring;
+    void mul(const u64 *a, const u64 *b, u64 *o) const { ring.mul_ntt(a, b, o); }
+    void mul_ext(const u64 *a, Ext s, u64 *o) const { ring.mul_fq3(a, s, o); }
+    static void add(const u64 *a, const u64 *b, u64 *o) { HostRing::add(a, b, o); }
+    static void sub(const u64 *a, const u64 *b, u64 *o) { HostRing::sub(a, b, o); }
+    static void from_u64(u64 v, u64 *o) { HostRing::from_u64(v, o); }
+    static void from_ext(Ext e, u64 *o) { HostRing::from_fq3(e, o); }
+    static Ext ext_of(const u64 *e) { return fq3_make(e[0], e[1], e[2]); }
+    static Ext ext_from_u64(u64 v) { return fq3_make(v % LF_P, 0, 0); }
+    Ext ext_mul(Ext a, Ext b) const { return ring.mul3(a, b); }
+    static Ext ext_add(Ext a, Ext b) { return fq3_add(a, b); }
+    static Ext ext_sub(Ext a, Ext b) { return fq3_sub(a, b); }
+    Ext ext_inv(Ext a) const { return ring.inv3(a); }
+    static void absorb_ext(Tr &tr, Ext e) { tr.absorb_fq3_as_ring(e); }
+    void crt(const u64 *c, u64 *o) const { ring.crt(c, o); }
+    static u64 fmul(u64 a, u64 b) { return fq_mul(a % LF_P, b % LF_P); }
+    static u64 fadd(u64 a, u64 b) { return fq_add(a, b); }
+    static void rot_x(u64 *a) {   // multiply by X modulo X^24 - X^12 + 1
+        u64 top = a[23];
+        for (int j = 23; j > 0; j--) a[j] = a[j - 1];
+        a[0] = fq_neg(top);
+        a[12] = fq_add(a[12], top);
+    }
+};
+}  // namespace
+
+int lf_verify_host(int ring, const lf_params *p, const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *c, lf_transcript *t,
+                   const uint64_t *acc, const uint64_t *cm_i, const uint64_t *proof, uint64_t *lcccs_out, int *failed_stage) {
+    if (!p || !S_off || !S_idx || !c || !t || !acc || !cm_i || !proof || !lcccs_out) return LF_ERR_INVALID;
+    if (p->s == 0 || p->s > 40 || p->K == 0 || p->K > 32 || p->q == 0 || p->q > 8 || p->t == 0 || p->t > 16) return LF_ERR_UNSUPPORTED;
+    if (((size_t)1 << p->s) < (size_t)p->wit_len * p->L) return LF_ERR_SIZE_BOUNDS;   // sanity_check, nifs.rs:165-173
+    if (failed_stage) *failed_stage = 0;
+    if (ring == LF_RING_BABYBEAR) return t->bb ? lfbb::bb_verify_host(p, S_off, S_idx, c, *t->bb, acc, cm_i, proof, lcccs_out, failed_stage) : LF_ERR_INVALID;
+    if (ring != LF_RING_GOLDILOCKS || t->bb) return LF_ERR_INVALID;
+    static const GoldV *gv = [] {
+        GoldV *g = new GoldV();
+        u64 nr, y[24];
+        default_ring(&nr, y);
+        build_crt_tables(nr, y, g->ring.T);
+        return g;
+    }();
+    lfv::Verifier<GoldV> V(*gv, *p, S_off, S_idx, c);
+    int rc = V.verify(t->t, acc, cm_i, proof, lcccs_out);
+    if (failed_stage) *failed_stage = V.stage;
+    return rc;
 }

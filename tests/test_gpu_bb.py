@@ -192,6 +192,8 @@ def test_fold_step_parity(ctx, name, seed):
     assert (w0.f_coeff == lfo.icrt(f0_o)).all()
     rc, lc_v = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)   # the restated NIFSVerifier accepts the GPU proof
     assert rc == 0 and (lc_v == lc_g).all()
+    ok, lc_p, _ = api.NIFSVerifier.verify(wl, acc_g, cccs, proof_g, tr_new())   # ... and so does the product's own host verifier
+    assert ok and (lc_p == lc_g).all()
     if name == "B6":   # chained step: the folded accumulator/witness are valid inputs of the next fold
         lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, tr_new())
         lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
