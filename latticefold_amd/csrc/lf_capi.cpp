@@ -127,6 +127,17 @@ struct lf_ctx {
         *out = (T *)p;
         return rc;
     }
+    hipEvent_t ev_theta = nullptr;
+    hipEvent_t ev_block = nullptr;   // hipEventBlockingSync: lane 1 (long waits) yields its CPU instead of spinning
+    int lane_sync() {
+        if (t_lane == 1 && ev_block) {
+            HIPCHK(hipEventRecord(ev_block, st_lane[1]));
+            HIPCHK(hipEventSynchronize(ev_block));
+            return LF_OK;
+        }
+        HIPCHK(hipStreamSynchronize(stream()));
+        return LF_OK;
+    }
     u64 *&h_pin_ref() { return h_pin_lane[t_lane]; }
     int pin(size_t words) {
         u64 *&hp = h_pin_lane[t_lane];
@@ -228,6 +239,7 @@ int lf_ctx_create(lf_ctx **out, int device) {
     lf_ctx *c = new lf_ctx();
     c->device = device;
     if (hipStreamCreate(&c->st_lane[0]) != hipSuccess || hipStreamCreate(&c->st_lane[1]) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    if (!getenv("LF_SPIN_ALL")) (void)hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming);
     u64 nr, y[24];
     default_ring(&nr, y);
     int rc = install_tables(c, nr, y);
@@ -258,6 +270,8 @@ void lf_ctx_destroy(lf_ctx *c) {
     for (int l = 0; l < 2; l++)
         if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->ev_block) (void)hipEventDestroy(c->ev_block);
+    if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
     delete c;
@@ -330,7 +344,7 @@ static int down_ring(lf_ctx *c, const u64 *src, size_t n, u64 *host) {
 static int down_small(lf_ctx *c, const u64 *dsrc, size_t words, u64 *host) {
     RET(c->pin(words));
     HIPCHK(hipMemcpyAsync(c->h_pin_ref(), dsrc, words * 8, hipMemcpyDeviceToHost, c->stream()));
-    HIPCHK(hipStreamSynchronize(c->stream()));
+    RET(c->lane_sync());
     memcpy(host, c->h_pin_ref(), words * 8);
     return LF_OK;
 }
@@ -1292,18 +1306,31 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
     for (u32 j = 0; j < P.t; j++)
         launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, c->stream());
-    for (int sd = 0; sd < 2; sd++) {
-        launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, sm, c->stream());
-        RET(down_small(c, sm, (size_t)K * 72, theta + (size_t)sd * K * 72));
-        launch_dot_batch(c->dcrt, S[sd].z, n, K, q, n, P.t, n, dpart, sm, c->stream());
-        RET(down_small(c, sm, (size_t)K * P.t * 24, eta + (size_t)sd * K * P.t * 24));
+    // theta for both sides first, then eta; the host absorbs theta while the GPU still computes the eta dot products
+    u64 *fsm;
+    RET(c->tbuf("fold_small", (size_t)K2 * 72 + (size_t)K2 * P.t * 24 + 64, &fsm));
+    RET(c->pin((size_t)K2 * 72 + (size_t)K2 * P.t * 24));
+    u64 *hp = c->h_pin_ref();
+    u64 *d_theta = fsm, *d_eta = fsm + (size_t)K2 * 72;
+    for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * 72, c->stream());
+    HIPCHK(hipMemcpyAsync(hp, d_theta, (size_t)K2 * 72 * 8, hipMemcpyDeviceToHost, c->stream()));
+    if (!c->ev_theta) HIPCHK(hipEventCreateWithFlags(&c->ev_theta, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->ev_theta, c->stream()));
+    for (int sd = 0; sd < 2; sd++) launch_dot_batch(c->dcrt, S[sd].z, n, K, q, n, P.t, n, dpart, d_eta + (size_t)sd * K * P.t * 24, c->stream());
+    HIPCHK(hipMemcpyAsync(hp + (size_t)K2 * 72, d_eta, (size_t)K2 * P.t * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipEventSynchronize(c->ev_theta));
+    memcpy(theta, hp, (size_t)K2 * 72 * 8);
+    {
+        HostTimer ht(c);
+        tr.absorb_ring(theta, (size_t)K2 * 3);
     }
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    memcpy(eta, hp + (size_t)K2 * 72, (size_t)K2 * P.t * 24 * 8);
     TL_MARK(" theta/eta");
     std::vector<u64> rho_c((size_t)K2 * 24, 0), rho((size_t)K2 * 24);
     std::vector<int8_t> rho8((size_t)K2 * 24, 0);
     {
         HostTimer ht(c);
-        tr.absorb_ring(theta, (size_t)K2 * 3);
         tr.absorb_ring(eta, (size_t)K2 * P.t);
         // get_rhos (folding/utils.rs:116-131)
         tr.absorb_label("rho_s");
