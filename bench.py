@@ -179,10 +179,14 @@ def main():
         # HBM traffic of the dominant kernel from the PMC passes (collected separately, as rocprofv3 requires; see profiles/)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c4.json")))["kernels"]
-            if wl.name == "C4" and dom == "k_ajtai":
-                k = pmc["k_ajtai<true>"]
-                traffic = k["fetch_bytes_max_corrected"] + k["write_bytes_max"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_e_pmc_{wl.name.lower()}.json")))["kernels"]
+            want = ("bb::" if wl.ring == "babybear" else "") + ("k_ajtai" if dom == "k_ajtai" else "k_fold_round")
+            for name, k in pmc.items():
+                base = name.split("<")[0]
+                if base == want and k["fetch_bytes_max_corrected"] is not None:
+                    # per launch like `achieved`: the largest launch for k_ajtai (the K-1 batch), the mean over the rounds for k_fold_round
+                    sel = "max" if dom == "k_ajtai" else "mean"
+                    traffic = k[f"fetch_bytes_{sel}_corrected"] + k[f"write_bytes_{sel}"]
         except Exception:
             traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": peak, "unit": "GB/s",
