@@ -300,3 +300,21 @@ def test_fold_step_parity_general_ccs(ctx, name, ccs):
     assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
     rc, lc_v = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)
     assert rc == 0 and (lc_v == lc_g).all()
+
+
+def test_empty_and_degenerate_inputs(ctx):
+    """count = 0 / single-element calls through the ABI (the reference's element-wise maps accept empty vectors)"""
+    e = np.zeros((0, RE), dtype=np.uint64)
+    assert ctx.crt(e).shape == (0, RE) and ctx.icrt(e).shape == (0, RE)
+    one = rnd(77, 1, RE)
+    assert (ctx.icrt(ctx.crt(one)) == one).all()
+    d = ctx.decompose(one, 1 << 16, 4, 1)
+    assert (ctx.recompose(ctx.decompose(one, 1 << 16, 4, 0), 1 << 16, 4) == one).all() and d.shape == (4, RE)
+    ok, mx = ctx.linf_check(lfo.crt(np.zeros((1, RE), dtype=np.uint64)), 1)
+    assert ok and mx == 0
+    A = rnd(5, 2, 1, RE)
+    s = api.AjtaiCommitmentScheme(ctx, matrix=A)           # a single column
+    f = rnd(6, 1, RE)
+    assert (s.commit_ntt(f) == lfo.ajtai_commit(A, 2, 1, f)).all()
+    pt = rnd(8, 1, 3)
+    assert (ctx.evaluate_mles(rnd(9, 2, 1, RE), pt)[0] == lfo.mle_eval(rnd(9, 2, 1, RE)[0], np.tile(pt, (1, 8)))).all()
