@@ -1085,17 +1085,31 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
     for (u32 j = 0; j < P.t; j++)
         launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * RE * n, n, c->stream());
-    for (int sd = 0; sd < 2; sd++) {
-        launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, sm, c->stream());
-        RET(down_small(c, sm, (size_t)K * TAU * RE, theta + (size_t)sd * K * TAU * RE));
-        launch_dot_batch(c->dev, S[sd].z, n, K, q, n, P.t, n, red, sm, c->stream());
-        RET(down_small(c, sm, (size_t)K * P.t * RE, eta + (size_t)sd * K * P.t * RE));
+    // theta for both sides first, then eta; the host absorbs theta while the GPU still computes the eta dot products
+    u64 *fsm;
+    size_t nth = (size_t)K2 * TAU * RE, net = (size_t)K2 * P.t * RE;
+    RET(c->tbuf("fold_small", nth + net + 64, &fsm));
+    u64 *hp = c->arena_alloc(nth + net);
+    if (!hp) return LF_ERR_HIP;
+    u64 *d_theta = fsm, *d_eta = fsm + nth;
+    (void)sm;
+    for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * TAU * RE, c->stream());
+    HIPCHK(hipMemcpyAsync(hp, d_theta, nth * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipEventRecord(c->ev_side[0], c->stream()));
+    for (int sd = 0; sd < 2; sd++) launch_dot_batch(c->dev, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE, c->stream());
+    HIPCHK(hipMemcpyAsync(hp + nth, d_eta, net * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipEventSynchronize(c->ev_side[0]));
+    memcpy(theta, hp, nth * 8);
+    {
+        HostTimer ht(c);
+        tr.absorb_ring(theta, (size_t)K2 * TAU);
     }
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    memcpy(eta, hp + nth, net * 8);
     std::vector<u64> rho_c((size_t)K2 * RE, 0), rho((size_t)K2 * RE);
     std::vector<int8_t> rho8((size_t)K2 * 24, 0);
     {
         HostTimer ht(c);
-        tr.absorb_ring(theta, (size_t)K2 * TAU);
         tr.absorb_ring(eta, (size_t)K2 * P.t);
         tr.absorb_label("rho_s");   // get_rhos (folding/utils.rs:116-131)
         for (u32 i = 0; i + 1 < K2; i++) tr.get_short_challenge(&rho_c[(size_t)i * RE]);
