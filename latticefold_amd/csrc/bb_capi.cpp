@@ -199,6 +199,13 @@ void BbCtx::destroy() {
     delete c;
     delete this;
 }
+int BbCtx::set_ring_tables(uint64_t nonres, const uint64_t *y) {
+    std::lock_guard<std::mutex> g(p->mu);
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->st_lane[0]));
+    HIPCHK(hipStreamSynchronize(p->st_lane[1]));
+    return install_tables(p, nonres, y);
+}
 int BbCtx::get_ring_tables(uint64_t *nonres, uint64_t *y) {
     *nonres = p->ring.T.nu;
     for (int k = 0; k < 8; k++)

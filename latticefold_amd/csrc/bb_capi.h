@@ -19,6 +19,7 @@ struct BbCtx {
     static int create(BbCtx **out, lf_ctx *owner, int device);
     void destroy();
 
+    int set_ring_tables(uint64_t nonres, const uint64_t *y);
     int get_ring_tables(uint64_t *nonres, uint64_t *y);
     int synchronize();
     int mem_info(size_t *free_bytes, size_t *total_bytes);

@@ -278,7 +278,7 @@ void lf_ctx_destroy(lf_ctx *c) {
 }
 int lf_set_ring_tables(lf_ctx *c, uint64_t nonres, const uint64_t *y) {
     if (!c || !y) return LF_ERR_INVALID;
-    if (c->bb) return LF_ERR_UNSUPPORTED;
+    if (c->bb) return c->bb->set_ring_tables(nonres, y);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     return install_tables(c, nonres, y);

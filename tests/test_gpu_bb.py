@@ -51,8 +51,37 @@ def test_ring_tables_match_oracle(ctx):
     oy = np.zeros(8 * TAU, dtype=np.uint64)
     lfo.lib().lfo_get_ring(C.byref(onr), lfo._p64(oy))
     assert nr == onr.value and (y == oy).all()
+
+
+def test_crt_with_other_ring_tables(ctx):
+    """the CRT map is data for BabyBear too: permuted slots + another 9th root per slot must still match the oracle"""
+    nr, y = ctx.get_ring_tables()
+    y2 = y.reshape(8, TAU)[[3, 0, 6, 1, 7, 2, 5, 4]].copy()
+    w3 = pow(31, (P - 1) // 3, P)           # a primitive cube root of unity: w3^9 = 1, so (w3 y)^9 = y^9
+    assert w3 != 1
+    y2 = np.array([[int(v) * pow(w3, k % 3, P) % P for v in row] for k, row in enumerate(y2)], dtype=np.uint64)
+    try:
+        ctx.set_ring_tables(nr, y2.reshape(-1))
+        assert lfo.lib().lfo_set_ring(nr, lfo._p64(np.ascontiguousarray(y2.reshape(-1)))) == 0
+        x = rnd(5, 300, RE)
+        g = ctx.crt(x)
+        assert (g == lfo.crt(x)).all()
+        assert (ctx.icrt(g) == x).all()
+        wl, inst, A, scheme = setup_case(ctx, "B6")      # and a whole fold step under the other map
+        f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        acc_g, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr_new())
+        acc_o, _ = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+        lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+        lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+        assert (acc_g == acc_o).all() and (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+    finally:
+        ctx.set_ring_tables(nr, y)
+        lfo.lib().lfo_set_ring(nr, lfo._p64(np.ascontiguousarray(y)))
     with pytest.raises(api.LfError):
-        ctx.set_ring_tables(nr, y)          # data-driven tables: Goldilocks only for now
+        bad = y.copy(); bad[1] = (int(bad[1]) + 1) % P
+        ctx.set_ring_tables(nr, bad)
 
 
 @pytest.mark.parametrize("count", [1, 7, 256, 1000])
