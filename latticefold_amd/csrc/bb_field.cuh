@@ -109,7 +109,26 @@ BB_HD void e9_mul_cols(const E9 &a, const E9 &b, const E9 &bn, i64 (&T)[TAU]) {
     }
 }
 BB_HD E9 e9_mul(const E9 &a, const E9 &b, fe nu) { return e9_mul_pre(a, b, e9_times_nu(b, nu)); }
-BB_HD E9 e9_sqr(const E9 &a, fe nu) { return e9_mul_pre(a, a, e9_times_nu(a, nu)); }
+// a^2 with an = nu * a: symmetric terms are formed once and doubled (45 instead of 81 mads); the column bound is unchanged
+// (every ordered pair (i,j) still contributes |a_i a_j| once)
+BB_HD E9 e9_sqr_pre(const E9 &a, const E9 &an) {
+    E9 r;
+#pragma unroll
+    for (int k = 0; k < TAU; k++) {
+        i64 off = 0, diag = 0;
+#pragma unroll
+        for (int i = 0; i < TAU; i++) {
+            // ordered pairs (i, j) with i + j = k (j = k - i >= 0) or i + j = k + 9 (j = k + 9 - i <= 8)
+            int j = i <= k ? k - i : k + TAU - i;
+            fe bj = i <= k ? a.c[j] : an.c[j];
+            if (i < j) off += (i64)a.c[i] * (i64)bj;
+            else if (i == j) diag += (i64)a.c[i] * (i64)bj;
+        }
+        r.c[k] = mred(2 * off + diag);
+    }
+    return r;
+}
+BB_HD E9 e9_sqr(const E9 &a, fe nu) { return e9_sqr_pre(a, e9_times_nu(a, nu)); }
 // a * s where s is a plain small integer
 BB_HD E9 e9_mul_small(const E9 &a, int32_t s) { return e9_mul_fe(a, from_small(s)); }
 BB_HD bool e9_eq(const E9 &a, const E9 &b) { for (int i = 0; i < TAU; i++) if (a.c[i] != b.c[i]) return false; return true; }
