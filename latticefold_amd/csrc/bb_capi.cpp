@@ -1208,13 +1208,6 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     c->host_tr_ms = 0;
     size_t tot = c->ev_begin(17);
     size_t ll = bb_lcccs_len(&P);
-    {   // absorb_public_input (nifs.rs:175-197)
-        HostTimer ht(c);
-        tr.absorb_label("acc");
-        tr.absorb_ring(acc, ll);
-        tr.absorb_label("cm_i");
-        tr.absorb_ring(cm_i, bb_cccs_len(&P));
-    }
     u64 *lin_proof = proof, *decl = lin_proof + lin_proof_len(&P) * RE, *decr = decl + dec_proof_len(&P) * RE, *foldp = decr + dec_proof_len(&P) * RE;
     std::vector<u64> lin(ll * RE);
     fe *eq_r_R = nullptr;
@@ -1227,6 +1220,13 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     c->lane = 1;
     int rc = dec_enqueue(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
     c->lane = 0;
+    {   // absorb_public_input (nifs.rs:175-197) -- while the GPU already works on the left decomposition
+        HostTimer ht(c);
+        tr.absorb_label("acc");
+        tr.absorb_ring(acc, ll);
+        tr.absorb_label("cm_i");
+        tr.absorb_ring(cm_i, bb_cccs_len(&P));
+    }
     if (rc == LF_OK) rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
     std::vector<H9> rR;
     if (rc == LF_OK) {

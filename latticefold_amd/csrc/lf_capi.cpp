@@ -1435,13 +1435,6 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     size_t tot = c->ev_begin(17);
     Transcript &tr = t->t;
     size_t ll = lf_lcccs_len(&P);
-    {   // absorb_public_input (nifs.rs:175-197)
-        HostTimer ht(c);
-        tr.absorb_label("acc");
-        tr.absorb_ring(acc, ll);
-        tr.absorb_label("cm_i");
-        tr.absorb_ring(cm_i, lf_cccs_len(&P));
-    }
     u64 *lin_proof = proof, *decl = lin_proof + lin_proof_len(&P) * 24, *decr = decl + dec_proof_len(&P) * 24, *foldp = decr + dec_proof_len(&P) * 24;
     std::vector<u64> lin(ll * 24);
     u64 *eq_r_R = nullptr;
@@ -1465,6 +1458,13 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
         return decompose_commit_finish(c, cm_i, yd, ev, decr);          // cm of the linearized instance = cm_i.cm
     });
+    {   // absorb_public_input (nifs.rs:175-197) -- after lane 1 has been started: the left decomposition does not depend on it
+        HostTimer ht(c);
+        tr.absorb_label("acc");
+        tr.absorb_ring(acc, ll);
+        tr.absorb_label("cm_i");
+        tr.absorb_ring(cm_i, lf_cccs_len(&P));
+    }
     TL_MARK("public input absorbed");
     int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
     TL_MARK("linearization done");
