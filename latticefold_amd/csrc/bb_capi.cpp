@@ -1049,11 +1049,15 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             E9PreC r = e9pre_from_h9(rh, nu);
             size_t nn = a.n / 2, ldn = atl(nn);
             fe *dst = T5[flip];
-            launch_fix(c->dev, a.eqL, a.ld, dst, ldn, a.n, 1, r, c->stream());
-            launch_fix(c->dev, a.eqR, a.ld, dst + (size_t)TAU * ldn, ldn, a.n, 1, r, c->stream());
-            launch_fix(c->dev, a.eqB, a.ld, dst + (size_t)2 * TAU * ldn, ldn, a.n, 1, r, c->stream());
-            launch_fix(c->dev, a.G1, a.ld, dst + (size_t)3 * TAU * ldn, ldn, a.n, 8, r, c->stream());
-            launch_fix(c->dev, a.G2, a.ld, dst + (size_t)(3 * TAU + RE) * ldn, ldn, a.n, 8, r, c->stream());
+            if (round == 2) {   // sources are the five separate full-size tables
+                launch_fix(c->dev, a.eqL, a.ld, dst, ldn, a.n, 1, r, c->stream());
+                launch_fix(c->dev, a.eqR, a.ld, dst + (size_t)TAU * ldn, ldn, a.n, 1, r, c->stream());
+                launch_fix(c->dev, a.eqB, a.ld, dst + (size_t)2 * TAU * ldn, ldn, a.n, 1, r, c->stream());
+                launch_fix(c->dev, a.G1, a.ld, dst + (size_t)3 * TAU * ldn, ldn, a.n, 8, r, c->stream());
+                launch_fix(c->dev, a.G2, a.ld, dst + (size_t)(3 * TAU + RE) * ldn, ldn, a.n, 8, r, c->stream());
+            } else {            // source is the previous 171-plane buffer (same layout): one launch over its 19 F_{p^9} rows
+                launch_fix(c->dev, a.eqL, a.ld, dst, ldn, a.n, 19, r, c->stream());
+            }
             if (round == 3) {
                 launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, m, K, pt[0], pt[1], c->ring, F[0], c->stream());
                 curF = F[0]; ldF = atl(m / 4);

@@ -1223,11 +1223,15 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             Fq3Const r = f3c(pt[round - 2]);
             size_t nn = a.n / 2;
             u64 *dst = T5[flip];
-            launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, c->stream());
-            launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, c->stream());
-            launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->stream());
-            launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->stream());
-            launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->stream());
+            if (round == 2) {   // sources are the five separate full-size tables
+                launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, c->stream());
+                launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, c->stream());
+                launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->stream());
+                launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->stream());
+                launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->stream());
+            } else {            // source is the previous 57-plane buffer (same layout): one launch over its 19 F_{p^3} rows
+                launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 19, r, c->stream());
+            }
             if (sharded && nn / 2 < Gw * 64) {
                 // transition to the replicated tail: gather the fixed f-hat slices (if they exist yet)
                 if (round > 3) {
