@@ -8,6 +8,10 @@
 #include <utility>
 
 #include "lf_host.h"   // lf::Transcript::params: the Grain-generated 64-bit Poseidon table shared by both rings
+#if defined(__AVX2__) && !defined(__HIP_DEVICE_COMPILE__)
+#include "bb_poseidon_simd.h"
+#define BB_POSEIDON_SIMD 1
+#endif
 
 namespace lfbb {
 
@@ -235,6 +239,9 @@ inline void matvec_t(const u32 (*MT)[24], const u64 *x, u64 *out) {
     }
     for (int i = 0; i < N; i++) out[i] = ((hi[i] % BB_P) * R32 + lo[i]) % BB_P;
 }
+#ifdef BB_POSEIDON_SIMD
+simd::Tables g_simd;
+#endif
 u32 g_mdsT[24][24];       // MDS transposed
 u32 g_postT[24][24];      // deferred factor of the sparse partial rounds, transposed (23 x 23 used)
 
@@ -305,6 +312,9 @@ void init_all() {
         for (int j = 0; j < W; j++) g_mdsT[j][i] = (u32)g_mds[i * W + j];
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) g_postT[j][i] = (u32)g_opt.post[i][j];
+#ifdef BB_POSEIDON_SIMD
+    simd::build_tables(g_simd, g_ark, g_mds, g_opt.cst, g_opt.e00, g_opt.row, g_opt.col, g_opt.post);
+#endif
 }
 inline void full_round(u64 st[W], const u64 *ark) {
     u64 nw[W];
@@ -333,6 +343,14 @@ void BbTranscript::permute_plain(u64 st[24]) {
     }
 }
 void BbTranscript::permute(u64 st[24]) {
+    std::call_once(g_once, init_all);
+#ifdef BB_POSEIDON_SIMD
+    simd::permute(g_simd, st);
+#else
+    permute_scalar(st);
+#endif
+}
+void BbTranscript::permute_scalar(u64 st[24]) {
     std::call_once(g_once, init_all);
     for (int r = 0; r < RF / 2; r++) full_round(st, g_ark + r * W);
     for (int r = 0; r < RP; r++) {

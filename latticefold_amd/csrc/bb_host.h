@@ -58,7 +58,8 @@ class BbTranscript {
     void absorb_u64_as_ring(u64 v);
     H9 get_challenge();                            // squeeze tau words, absorb them back
     void get_short_challenge(u64 coeff_out[D]);    // 18 bytes -> 24 coefficients in [-32,32), zero-padded to degree 72
-    static void permute(u64 st[24]);               // sparse-factorised partial rounds
+    static void permute(u64 st[24]);               // sparse-factorised partial rounds; AVX2 Montgomery lanes when available
+    static void permute_scalar(u64 st[24]);        // same factorisation, scalar (reference for the SIMD path)
     static void permute_plain(u64 st[24]);
     static void params(const u64 **ark, const u64 **mds);
 
