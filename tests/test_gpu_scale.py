@@ -111,3 +111,81 @@ def test_babybear_fold_step_properties_at_scale(name):
         assert rc == 0 and (lc_v == lc3).all()
     finally:
         ctx.close()
+
+
+def test_babybear_repeated_steps_are_stable():
+    """10 chained BabyBear fold steps at B10: every step verifies (product verifier), norm stays below B/2, no device-memory growth"""
+    wl = make_workload("B10")
+    ctx = api.Context(0, ring="babybear")
+    try:
+        ctx.load_ccs(wl)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        tr = lambda: api.PoseidonTranscript(ring="babybear")
+
+        def chain(steps):
+            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+            w = wit
+            dig = []
+            for i in range(steps):
+                lc, w_next, proof = api.NIFSProver.prove(ctx, acc, w, cccs, wit, tr())
+                ok, lc_v, stage = api.NIFSVerifier.verify(wl, acc, cccs, proof, tr())
+                assert ok and (lc_v == lc).all(), (i, stage)
+                good, mx = ctx.linf_check(w_next.f, wl.B // 2)
+                assert good, (i, mx)
+                dig.append(int(proof[-1, 0]) ^ int(lc[wl.s, 0]))
+                if w is not wit:
+                    w.free()
+                acc, w = lc, w_next
+            return dig
+
+        d1 = chain(10)
+        free1 = ctx.mem_info()[0]
+        d2 = chain(10)
+        free2 = ctx.mem_info()[0]
+        assert d1 == d2
+        assert abs(free1 - free2) < 64 << 20
+    finally:
+        ctx.close()
+
+
+def test_contexts_are_thread_safe():
+    """SURVEY 8(b) "Threading": reference callers may hit the ABI from several Rayon workers at once.  Four threads hammer
+    one Goldilocks context and one BabyBear context concurrently (element-wise ops + commits); results must equal the
+    single-threaded ones."""
+    import threading
+    g = api.Context(0)
+    b = api.Context(0, ring="babybear")
+    try:
+        from latticefold_amd.workload import splitmix_fq
+        xg = splitmix_fq(1, 0, 300 * 24).reshape(300, 24)
+        xb = splitmix_fq(2, 0, 200 * 72, "babybear").reshape(200, 72)
+        Ag = splitmix_fq(3, 0, 4 * 512 * 24).reshape(4, 512, 24)
+        Ab = splitmix_fq(4, 0, 3 * 256 * 72, "babybear").reshape(3, 256, 72)
+        sg = api.AjtaiCommitmentScheme(g, matrix=Ag)
+        sb = api.AjtaiCommitmentScheme(b, matrix=Ab)
+        fg = splitmix_fq(5, 0, 512 * 24).reshape(512, 24)
+        fb = splitmix_fq(6, 0, 256 * 72, "babybear").reshape(256, 72)
+        want = (g.crt(xg), g.icrt(xg), sg.commit_ntt(fg), b.crt(xb), b.icrt(xb), sb.commit_ntt(fb))
+        errs = []
+
+        def work(tid):
+            try:
+                for it in range(15):
+                    got = (g.crt(xg), g.icrt(xg), sg.commit_ntt(fg), b.crt(xb), b.icrt(xb), sb.commit_ntt(fb))
+                    for a, w in zip(got, want):
+                        if not (a == w).all():
+                            errs.append((tid, it))
+            except Exception as e:  # noqa: BLE001
+                errs.append((tid, repr(e)))
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs[:3]
+    finally:
+        g.close()
+        b.close()
