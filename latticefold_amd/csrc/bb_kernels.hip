@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) k_linf(const fe *coef, size_t total, unsi
     if ((threadIdx.x & 63) == 0) atomicMax(out_max, (unsigned long long)mx);
 }
 void launch_linf(const fe *coef, size_t n, u64 *out_max, hipStream_t s) {
-    hipMemsetAsync(out_max, 0, 8, s);
+    (void)hipMemsetAsync(out_max, 0, 8, s);
     hipLaunchKernelGGL(k_linf, dim3(grid_for(n * RE, 4096)), dim3(256), 0, s, coef, n * RE, (unsigned long long *)out_max);
 }
 

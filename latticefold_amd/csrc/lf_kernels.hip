@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256) k_linf(const u64 *coef, size_t total, uns
     if ((threadIdx.x & 63) == 0) atomicMax(out_max, (unsigned long long)mx);
 }
 void launch_linf(const u64 *coef, size_t n, u64 *out_max, hipStream_t s) {
-    hipMemsetAsync(out_max, 0, 8, s);
+    (void)hipMemsetAsync(out_max, 0, 8, s);
     hipLaunchKernelGGL(k_linf, dim3(grid_for(n * 24, 4096)), dim3(256), 0, s, coef, n * 24, (unsigned long long *)out_max);
 }
 
@@ -413,8 +413,6 @@ __device__ __forceinline__ void st3(u64 *tab, size_t ld, u32 slot, size_t i, Fq3
 // (A,F) tiles of JT columns are staged in LDS with coalesced loads; each thread owns up to two (i,k) outputs
 // and keeps the five schoolbook column sums of the F_{p^3} product as un-reduced 160-bit accumulators for the
 // whole j-range (one reduction per output at the very end).
-constexpr int AJ_JT = 16;  // (kept for the split rounding in the host helper)
-constexpr int AJ_MAXROWS = 64;
 constexpr u32 RED_BLOCKS_AJ = 128;   // kappa + batch <= 64 per launch
 struct Acc5 { AccP s[5]; };  // the five schoolbook column sums of an F_{p^3} product, un-reduced
 __device__ __forceinline__ void acc5_zero(Acc5 &a) {
@@ -562,20 +560,11 @@ size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) {
 void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits, u64 *partial, u64 *out,
                   hipStream_t s) {
     u32 nout = kappa * batch;
-    // full waves in the tiled kernel; a small remainder (< 32 outputs) is cheaper as plain dot products
-    // full waves in the tiled kernel when the remainder is small (it then goes to the dot-product tail kernel)
-    static int mode = -1;
-    if (mode < 0) { const char *e = getenv("LF_AJTAI_TAIL"); mode = e ? atoi(e) : 0; }
-    bool use384 = mode == 1 && nout > 384 && nout - 384 < 32;
-    u32 nmain = use384 ? 384 : (nout < (u32)AJ_THREADS ? nout : (u32)AJ_THREADS);
+    // one (i,k) output per thread; callers keep kappa*batch <= AJ_THREADS (commit_dev), any excess goes to the dot-product tail
+    u32 nmain = nout < (u32)AJ_THREADS ? nout : (u32)AJ_THREADS;
     size_t shm = (size_t)(kappa + batch) * AJ_ROWB;
-    if (use384) {
-        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-        else hipLaunchKernelGGL((k_ajtai<false, 384>), dim3(splits, 8), dim3(384), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-    } else {
-        if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-        else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-    }
+    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
+    else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
     hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * nmain * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, nmain, out);
     if (nmain < nout) {
         u32 ntail = nout - nmain;
@@ -621,7 +610,7 @@ __global__ void __launch_bounds__(256) k_selftest_field(u64 seed, u32 n, unsigne
     if (bad) atomicAdd(mism, (unsigned long long)bad);
 }
 void launch_selftest_field(u64 seed, u32 n, u64 *mism_dev, hipStream_t s) {
-    hipMemsetAsync(mism_dev, 0, 8, s);
+    (void)hipMemsetAsync(mism_dev, 0, 8, s);
     hipLaunchKernelGGL(k_selftest_field, dim3(cdiv(n, 256)), dim3(256), 0, s, seed, n, (unsigned long long *)mism_dev);
 }
 
