@@ -83,8 +83,21 @@ BB_HD E9 e9_add(const E9 &a, const E9 &b) { E9 r; for (int i = 0; i < TAU; i++) 
 BB_HD E9 e9_sub(const E9 &a, const E9 &b) { E9 r; for (int i = 0; i < TAU; i++) r.c[i] = fsub(a.c[i], b.c[i]); return r; }
 BB_HD E9 e9_neg(const E9 &a) { E9 r; for (int i = 0; i < TAU; i++) r.c[i] = -a.c[i]; return r; }
 BB_HD E9 e9_mul_fe(const E9 &a, fe s) { E9 r; for (int i = 0; i < TAU; i++) r.c[i] = fmul(a.c[i], s); return r; }
-// b pre-multiplied by nu (hoist when b is loop invariant)
-BB_HD E9 e9_times_nu(const E9 &b, fe nu) { return e9_mul_fe(b, nu); }
+// b pre-multiplied by nu (hoist when b is loop invariant).  The default tables use nu = 2 (a non-cube mod p, so Y^9 - 2 is
+// irreducible): the pre-multiplication is then a doubling + centring instead of a Montgomery product.  `nu` is a kernel
+// argument, so the test is a uniform scalar branch; any other (data) nu takes the generic path.
+constexpr fe BB_TWO = ccentre((2 * BB_R) % BB_P);   // Montgomery form of 2
+template <bool NU2>
+BB_HD E9 e9_times_nu_t(const E9 &b, fe nu) {
+    E9 r;
+    if (NU2) {
+        for (int i = 0; i < TAU; i++) r.c[i] = centre(2 * b.c[i]);
+    } else {
+        for (int i = 0; i < TAU; i++) r.c[i] = fmul(b.c[i], nu);
+    }
+    return r;
+}
+BB_HD E9 e9_times_nu(const E9 &b, fe nu) { return e9_times_nu_t<false>(b, nu); }
 // a * b with bn = nu * b:  c_k = sum_{i<=k} a_i b_{k-i} + sum_{i>k} a_i bn_{k+9-i}   (9 terms per column, one reduction)
 BB_HD E9 e9_mul_pre(const E9 &a, const E9 &b, const E9 &bn) {
     E9 r;
@@ -129,6 +142,8 @@ BB_HD E9 e9_sqr_pre(const E9 &a, const E9 &an) {
     return r;
 }
 BB_HD E9 e9_sqr(const E9 &a, fe nu) { return e9_sqr_pre(a, e9_times_nu(a, nu)); }
+template <bool NU2> BB_HD E9 e9_mul_t(const E9 &a, const E9 &b, fe nu) { return e9_mul_pre(a, b, e9_times_nu_t<NU2>(b, nu)); }
+template <bool NU2> BB_HD E9 e9_sqr_t(const E9 &a, fe nu) { return e9_sqr_pre(a, e9_times_nu_t<NU2>(a, nu)); }
 // a * s where s is a plain small integer
 BB_HD E9 e9_mul_small(const E9 &a, int32_t s) { return e9_mul_fe(a, from_small(s)); }
 BB_HD bool e9_eq(const E9 &a, const E9 &b) { for (int i = 0; i < TAU; i++) if (a.c[i] != b.c[i]) return false; return true; }

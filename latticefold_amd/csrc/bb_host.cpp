@@ -42,21 +42,30 @@ static H9 h9_mul_nu(const H9 &a, const H9 &b, u64 nu) {
 }
 
 void bb_default_ring(u64 *nonres, u64 *y) {
-    // zeta = first g^((p-1)/24), g = 2,3,.. of exact order 24; F_{p^9} = F_p[Y]/(Y^9 - zeta); slot e (ascending over
-    // (Z/24)^*) maps X -> zeta^a Y^g with g = e mod 3 and 9a = e - g (mod 24)   [same rule as the Goldilocks ring]
+    // F_{p^9} = F_p[Y]/(Y^9 - 2): 2 is a non-cube mod p (3 | p-1, 9 does not), so the binomial is irreducible, and multiplying by
+    // the non-residue is a doubling.  zeta = first g^((p-1)/24), g = 2,3,.., of exact order 24; slot e (ascending over (Z/24)^*)
+    // maps X -> c Y^g with g in {1,2} the class for which zeta^e / 2^g is a cube, and c its 9th root inside the cube subgroup
+    // (x -> x^9 is a bijection there: the subgroup has order (p-1)/3 = 5 * 2^27, coprime to 9).
     static const int E[8] = {1, 5, 7, 11, 13, 17, 19, 23};
     u64 zeta = 0;
     for (u64 g = 2;; g++) {
         u64 z = hpow(g, (BB_P - 1) / 24);
         if (hpow(z, 12) != 1 && hpow(z, 8) != 1) { zeta = z; break; }
     }
-    *nonres = zeta;
+    *nonres = 2;
+    const u64 sub = (BB_P - 1) / 3;
+    u64 e9 = 0;   // 9^-1 mod (p-1)/3
+    for (u64 k = 1; k < 9; k++)
+        if ((k * sub + 1) % 9 == 0) { e9 = (k * sub + 1) / 9; break; }
     memset(y, 0, 8 * TAU * sizeof(u64));
     for (int k = 0; k < 8; k++) {
-        int e = E[k], g = e % 3, a = -1;
-        for (int t = 0; t < 24; t++)
-            if ((TAU * t) % 24 == (e - g) % 24) { a = t; break; }
-        y[TAU * k + g] = hpow(zeta, (u64)a);
+        u64 ze = hpow(zeta, (u64)E[k]);
+        for (int g = 1; g <= 2; g++) {
+            u64 w = hmul(ze, hinv(hpow(2, (u64)g)));
+            if (hpow(w, sub) != 1) continue;   // not a cube
+            y[TAU * k + g] = hpow(w, e9);
+            break;
+        }
     }
 }
 

@@ -387,6 +387,7 @@ void launch_recompose_crt(const DevBb &t, const int32_t *planes, size_t n_planes
 constexpr int AJ_T = 32;
 constexpr int AJ_REC = TAU;                  // words per (row, column) record
 constexpr int AJ_ROW = AJ_T * AJ_REC + 1;    // +1 word: rows of consecutive k fall into different LDS banks
+template <bool NU2>
 __global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits,
                                                i64 *partial) {
     extern __shared__ fe lds[];
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, 
             size_t j = jt + jj;
             fe v = j < j1 ? F[((size_t)k * RE + TAU * slot + c) * ldF + j] : 0;
             sF[(size_t)k * AJ_ROW + jj * AJ_REC + c] = v;
-            sFn[(size_t)k * AJ_ROW + jj * AJ_REC + c] = fmul(v, t.nu);
+            sFn[(size_t)k * AJ_ROW + jj * AJ_REC + c] = NU2 ? centre(2 * v) : fmul(v, t.nu);
         }
         __syncthreads();
         if (active) {
@@ -455,7 +456,8 @@ size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) { return (size_t)sp
 void launch_ajtai(const DevBb &t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits, i64 *partial, u64 *out,
                   hipStream_t s) {
     size_t shm = ((size_t)kappa + 2 * (size_t)batch) * AJ_ROW * sizeof(fe);
-    hipLaunchKernelGGL(k_ajtai, dim3(splits, 8), dim3(256), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
+    if (t.nu == BB_TWO) hipLaunchKernelGGL((k_ajtai<true>), dim3(splits, 8), dim3(256), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
+    else hipLaunchKernelGGL((k_ajtai<false>), dim3(splits, 8), dim3(256), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
     hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * TAU, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
 }
 
@@ -519,7 +521,7 @@ void launch_spmv_t_eq(const DevBb &t, const u32 *colptr, const u32 *rowidx, cons
 }
 
 // batched inner products (evaluate_mles, utils/mle_helpers.rs:65-88, restructured as dot products)
-template <int NB>
+template <int NB, bool NU2>
 __global__ void __launch_bounds__(256) k_dot_batch(DevBb t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, size_t n, i64 *partial) {
     // grid (blocks, 8 slots, na); partial[block][(a*NB + b)*72 + 9*slot + c]
     u32 slot = blockIdx.y, a = blockIdx.z;
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(256) k_dot_batch(DevBb t, const fe *X, size_t 
     const fe *Xa = X + (size_t)a * RE * ldx;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         E9 x = ld9(Xa, ldx, slot, i);
-        E9 xn = e9_times_nu(x, t.nu);
+        E9 xn = e9_times_nu_t<NU2>(x, t.nu);
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             E9 y = ld9(Y + (size_t)b * RE * ldy, ldy, slot, i);
@@ -552,12 +554,18 @@ void launch_dot_batch(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe 
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     dim3 g(gb, 8, na);
+#define BB_DOT(NBV)                                                                                                    \
+    do {                                                                                                               \
+        if (t.nu == BB_TWO) hipLaunchKernelGGL((k_dot_batch<NBV, true>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial);  \
+        else hipLaunchKernelGGL((k_dot_batch<NBV, false>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial);        \
+    } while (0)
     switch (nb) {
-        case 1: hipLaunchKernelGGL((k_dot_batch<1>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
-        case 2: hipLaunchKernelGGL((k_dot_batch<2>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
-        case 3: hipLaunchKernelGGL((k_dot_batch<3>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
-        default: hipLaunchKernelGGL((k_dot_batch<4>), g, dim3(256), 0, s, t, X, ldx, na, Y, ldy, n, partial); break;
+        case 1: BB_DOT(1); break;
+        case 2: BB_DOT(2); break;
+        case 3: BB_DOT(3); break;
+        default: BB_DOT(4); break;
     }
+#undef BB_DOT
     launch_reduce_rows(partial, gb, na * nb * RE, out, s);
 }
 __global__ void __launch_bounds__(256) k_dot_eq(DevBb t, const fe *X, size_t ldx, const fe *eq, size_t ldeq, size_t n, i64 *partial) {
@@ -1044,6 +1052,7 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 //   M c0 = p (f0^2 - 1), M c1 = q (3 f0^2 - 1), M c2 = 3 p df^2, M c3 = q df^2,   p = M f0, q = M df
 // Small rounds are latency-bound if one thread walks all 2K*9 tables, so the table range is split over blockIdx.z
 // (every part is linear in the tables, including the final product with eqB).
+template <bool NU2>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial) {
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
@@ -1070,14 +1079,14 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             E9 df = e9_sub(f1, f0);
             E9Pre M = e9p(Mpre[tb]);
             E9 p = e9_mul(f0, M), q = e9_mul(df, M);
-            E9 s0 = e9_sqr(f0, t.nu), sd = e9_sqr(df, t.nu);
+            E9 s0 = e9_sqr_t<NU2>(f0, t.nu), sd = e9_sqr_t<NU2>(df, t.nu);
             E9 u = s0; u.c[0] = fsub(u.c[0], BB_ONE);                    // f0^2 - 1
-            E9 un = e9_times_nu(u, t.nu);
+            E9 un = e9_times_nu_t<NU2>(u, t.nu);
             E9 w = e9_mul_fe(s0, three); w.c[0] = fsub(w.c[0], BB_ONE);  // 3 f0^2 - 1 = 3 u + 2
             E9 wn;                                                       // nu * w = 3 (nu u) + 2 nu   (linear: no second pre-multiplication)
 #pragma unroll
             for (int c = 0; c < TAU; c++) wn.c[c] = fred(3 * (i64)un.c[c] + (c == 0 ? 2 * (i64)t.nu : 0));
-            E9 sdn = e9_times_nu(sd, t.nu);
+            E9 sdn = e9_times_nu_t<NU2>(sd, t.nu);
             E9 m0 = e9_mul_pre(p, u, un), m1 = e9_mul_pre(q, w, wn), m2 = e9_mul_pre(p, sd, sdn), m3 = e9_mul_pre(q, sd, sdn);
 #pragma unroll
             for (int c = 0; c < TAU; c++) { C[c] += m0.c[c]; C[TAU + c] += m1.c[c]; C[2 * TAU + c] += m2.c[c]; C[3 * TAU + c] += m3.c[c]; }
@@ -1095,7 +1104,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
 #pragma unroll
             for (int c = 0; c < TAU; c++)
                 sv.c[c] = fred((i64)c0.c[c] + (i64)c1.c[c] * X + (i64)c2.c[c] * (X * X) + (i64)c3.c[c] * (X * X * X));
-            E9 pr = e9_mul(sv, e, t.nu);
+            E9 pr = e9_mul_t<NU2>(sv, e, t.nu);
 #pragma unroll
             for (int c = 0; c < TAU; c++) acc[X * TAU + c] += pr.c[c];
         }
@@ -1118,7 +1127,8 @@ void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ld
     u32 tch = 1;
     while (tch < 32 && pairs * 8 * tch < (1u << 17)) tch *= 2;
     while (gb * tch > RED_BLOCKS) tch /= 2;
-    hipLaunchKernelGGL(k_fold_round, dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
+    if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_round<true>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
+    else hipLaunchKernelGGL((k_fold_round<false>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
     launch_reduce_rows(partial, gb * tch, 5 * RE, out, s);
 }
 

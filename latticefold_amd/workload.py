@@ -71,17 +71,9 @@ def diag(v: int, ring: str = "goldilocks") -> np.ndarray:
 
 
 def default_nonres(ring: str) -> int:
-    """extension-field non-residue of the DEFAULT ring tables (DESIGN.md "CRT map is data"): 2^40 for Goldilocks, the first
-    g^((p-1)/24) of exact order 24 (g = 2, 3, ..) for BabyBear"""
-    p = RINGS[ring][0]
-    if ring == "goldilocks":
-        return 1 << 40
-    g = 2
-    while True:
-        z = pow(g, (p - 1) // 24, p)
-        if pow(z, 12, p) != 1 and pow(z, 8, p) != 1:
-            return z
-        g += 1
+    """extension-field non-residue of the DEFAULT ring tables (DESIGN.md "CRT map is data"): 2^40 for Goldilocks
+    (F_{p^3} = F_p[Y]/(Y^3 - 2^40)), 2 for BabyBear (F_{p^9} = F_p[Y]/(Y^9 - 2))"""
+    return 1 << 40 if ring == "goldilocks" else 2
 
 
 def ring_mul_ntt(a: np.ndarray, b: np.ndarray, ring: str = "goldilocks") -> np.ndarray:

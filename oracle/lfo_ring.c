@@ -68,12 +68,32 @@ static u64 default_zeta(void) {
 }
 
 static void default_ring(void) {
-    /* Phi(X) = prod_{e in (Z/24)^*} (X^tau - zeta^e), zeta of order 24, tau in {3, 9}.  With
-     * F_{p^tau} = F_p[Y]/(Y^tau - zeta): slot e = 1 mod 3 uses X -> zeta^a * Y, slot e = 2 mod 3 uses
-     * X -> zeta^a * Y^2, where tau*a = (e - g) mod 24, g = e mod 3 (so that (zeta^a Y^g)^tau = zeta^e).
-     * Slots in ascending e.  For tau = 3 this is a = (e-g)/3 (the map used since round 1). */
+    /* Phi(X) = prod_{e in (Z/24)^*} (X^tau - zeta^e), zeta of order 24, tau in {3, 9}; slots in ascending e.
+     * Goldilocks: F_{p^3} = F_p[Y]/(Y^3 - zeta), zeta = 2^40; slot e = 1 mod 3 uses X -> zeta^a * Y, e = 2 mod 3 uses
+     * X -> zeta^a * Y^2 with 3a = e - g (the map used since round 1).
+     * BabyBear: F_{p^9} = F_p[Y]/(Y^9 - 2) (2 is a non-cube mod p, so the binomial is irreducible); slot e maps X -> c * Y^g
+     * with g in {1,2} the class for which zeta^e / 2^g is a cube and c its 9th root inside the cube subgroup
+     * (order (p-1)/3 = 5*2^27, coprime to 9). */
     static const int E[8] = {1, 5, 7, 11, 13, 17, 19, 23};
     u64 zeta = default_zeta();
+#ifdef LFO_RING_BABYBEAR
+    lfo_NONRES = 2;
+    const u64 sub = (LFO_P - 1) / 3;
+    u64 e9 = 0;
+    for (u64 k = 1; k < 9; k++)
+        if ((k * sub + 1) % 9 == 0) { e9 = (k * sub + 1) / 9; break; }
+    for (int k = 0; k < 8; k++) {
+        u64 ze = fq_pow(zeta, (u64)E[k]);
+        fqe y = fqe_zero();
+        for (int g = 1; g <= 2; g++) {
+            u64 w = fq_mul(ze, fq_inv(fq_pow(2, (u64)g)));
+            if (fq_pow(w, sub) != 1) continue;
+            y.c[g] = fq_pow(w, e9);
+            break;
+        }
+        g_y[k] = y;
+    }
+#else
     lfo_NONRES = zeta;
     for (int k = 0; k < 8; k++) {
         int e = E[k], g = e % 3, a = -1;
@@ -83,6 +103,7 @@ static void default_ring(void) {
         y.c[g] = fq_pow(zeta, (u64)a);
         g_y[k] = y;
     }
+#endif
 }
 
 /* runs when the library is loaded: lfo_NONRES and the ring tables are valid before any entry point is used
