@@ -305,3 +305,26 @@ def test_empty_and_degenerate_inputs(ctx):
     assert (s.commit_ntt(f) == lfo.ajtai_commit(A, 2, 1, f)).all()
     pt = rnd(8, 1, TAU)
     assert (ctx.evaluate_mles(rnd(9, 2, 1, RE), pt)[0] == lfo.mle_eval(rnd(9, 2, 1, RE)[0], np.tile(pt, (1, 8)))).all()
+
+
+def test_fold_real_circuit_from_r1cs(ctx):
+    """the reference's own test circuit x^3 + x + 5 = y (arith/r1cs.rs:128-151) through CCS::from_r1cs_padded; m = 8 rows (s = 3)"""
+    from latticefold_amd import ccs
+    A3, B3, C3 = ccs.vitalik_r1cs()
+    z = ccs.vitalik_z_ntt(RING)
+    wl = ccs.workload_from_r1cs(A3, B3, C3, 1, z[0:1], z[2:], ring=RING, L=2, Bbase=1 << 16, K=16, kappa=3, name="vitalik_bb")
+    inst = lfo.Instance(wl)
+    ctx.load_ccs(wl)
+    A = wl.ajtai_matrix()
+    scheme = api.AjtaiCommitmentScheme(ctx, matrix=A)
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    assert (wit.w_ccs == wl.w_ccs).all()
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    acc_g, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr_new())
+    acc_o, _ = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    assert (acc_g == acc_o).all() and (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+    ok, lc_p, _ = api.NIFSVerifier.verify(wl, acc_g, cccs, proof_g, tr_new())
+    assert ok and (lc_p == lc_g).all()
