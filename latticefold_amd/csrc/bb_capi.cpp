@@ -48,6 +48,11 @@ struct BbCtxImpl {
     u64 *arena[2] = {nullptr, nullptr};   // pinned staging for the asynchronous decompositions (bump-allocated per step)
     size_t arena_words = 0, arena_used[2] = {0, 0};
     hipEvent_t ev_side[2] = {nullptr, nullptr};
+    u64 *h_round = nullptr;   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
+    u64 *round_out() {
+        if (!h_round && hipHostMalloc((void **)&h_round, 5 * RE * 8 * 2, hipHostMallocMapped) != hipSuccess) h_round = nullptr;
+        return h_round;
+    }
     int sc_round = -1;
     size_t sc_n = 0;
     int sc_cur = 0;
@@ -190,6 +195,7 @@ void BbCtx::destroy() {
     if (c->dA) (void)hipFree(c->dA);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_round) (void)hipHostFree(c->h_round);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int l = 0; l < 2; l++) {
         if (c->arena[l]) (void)hipHostFree(c->arena[l]);
@@ -718,7 +724,8 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
     RET(c->tbuf("lin_efix0", TAU * atl(m / 2), &fq[0]));
     RET(c->tbuf("lin_efix1", TAU * atl(m / 4), &fq[1]));
     RET(c->tbuf("round_partial", red_partial_words(5 * RE), &partial));
-    RET(c->tbuf("round_out", 5 * RE, &od));
+    od = c->round_out();
+    if (!od) return LF_ERR_HIP;
     { HostTimer ht(c); sc_prologue(tr, P.s, deg); }
     const fe *cur = mz, *cure = eqb;
     size_t n = m;
@@ -735,7 +742,8 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
         size_t ld = round == 1 ? m : atl(n);
         launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->stream());
         u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * RE;
-        RET(down_small(c, od, (size_t)(deg + 1) * RE, ev));
+        HIPCHK(hipStreamSynchronize(c->stream()));            // the reduce kernel wrote the message into mapped host memory
+        memcpy(ev, od, (size_t)(deg + 1) * RE * 8);
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
     }
@@ -1016,7 +1024,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("fold_eqb", TAU * m, &eqb));
     RET(c->tbuf("fold_zz", (size_t)P.t * RE * n, &zz));
     RET(c->tbuf("round_partial", red_partial_words(5 * RE), &partial));
-    RET(c->tbuf("round_out", 5 * RE, &od));
+    od = c->round_out();
+    if (!od) return LF_ERR_HIP;
     for (int sd = 0; sd < 2; sd++) {
         // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}   (folding.rs:208-226, utils.rs:524-546)
         launch_lincomb_z(c->dev, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
@@ -1077,7 +1086,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());
         c->ev_end(ev);
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;
-        RET(down_small(c, od, (size_t)(deg + 1) * RE, evs));
+        HIPCHK(hipStreamSynchronize(c->stream()));            // message is in mapped host memory
+        memcpy(evs, od, (size_t)(deg + 1) * RE * 8);
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
     }

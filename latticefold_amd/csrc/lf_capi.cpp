@@ -127,6 +127,12 @@ struct lf_ctx {
         *out = (T *)p;
         return rc;
     }
+    u64 *h_round[2] = {nullptr, nullptr};   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
+    u64 *round_out() {
+        u64 *&p = h_round[t_lane];
+        if (!p && hipHostMalloc((void **)&p, 5 * 24 * 8 * 2, hipHostMallocMapped) != hipSuccess) p = nullptr;
+        return p;
+    }
     hipEvent_t ev_theta = nullptr;
     hipEvent_t ev_block = nullptr;   // hipEventBlockingSync: lane 1 (long waits) yields its CPU instead of spinning
     int lane_sync() {
@@ -270,6 +276,8 @@ void lf_ctx_destroy(lf_ctx *c) {
     for (int l = 0; l < 2; l++)
         if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int l = 0; l < 2; l++)
+        if (c->h_round[l]) (void)hipHostFree(c->h_round[l]);
     if (c->ev_block) (void)hipEventDestroy(c->ev_block);
     if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
     (void)hipStreamDestroy(c->st_lane[0]);
@@ -898,7 +906,8 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     RET(c->tbuf("lin_efix0", 3 * (m / 2), &fe[0]));
     RET(c->tbuf("lin_efix1", 3 * (m / 4 ? m / 4 : 1), &fe[1]));
     RET(c->tbuf("round_partial", round_partial_words(), &partial));
-    RET(c->tbuf("round_out", 5 * 24, &od));
+    od = c->round_out();
+    if (!od) return LF_ERR_HIP;
     { HostTimer ht(c); sc_prologue(tr, P.s, deg); }
     const u64 *cur = mz, *cure = eqb;
     size_t n = m;
@@ -914,7 +923,8 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
         }
         launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->stream());
         u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * 24;
-        RET(down_small(c, od, (size_t)(deg + 1) * 24, ev));
+        RET(c->lane_sync());                                  // the reduce kernel wrote the message into mapped host memory
+        memcpy(ev, od, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
     }
@@ -1182,7 +1192,8 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("fold_eqb", 3 * m, &eqb));
     RET(c->tbuf("fold_zz", (size_t)P.t * 24 * n, &zz));
     RET(c->tbuf("round_partial", round_partial_words(), &partial));
-    RET(c->tbuf("round_out", 5 * 24, &od));
+    od = c->round_out();
+    if (!od) return LF_ERR_HIP;
     for (int sd = 0; sd < 2; sd++) {
         // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}
         launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
@@ -1285,7 +1296,8 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         c->ev_end(ev);
         LF_TRACE(c, "fold round");
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * 24;
-        RET(down_small(c, od, (size_t)(deg + 1) * 24, evs));
+        RET(c->lane_sync());                                  // message is in mapped host memory
+        memcpy(evs, od, (size_t)(deg + 1) * 24 * 8);
         if (sharded) RET(exchange_modsum(c, evs, (size_t)(deg + 1) * 24));
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
