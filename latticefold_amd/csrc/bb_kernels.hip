@@ -1061,7 +1061,6 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
 #pragma unroll
     for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
     size_t pairs = a.n / 2;
-    const fe three = from_small(3);
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
         if (blockIdx.z == 0) fold_linear_part(t, a, slot, j, acc);
         i64 C[4 * TAU];
@@ -1082,10 +1081,13 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             E9 s0 = e9_sqr_t<NU2>(f0, t.nu), sd = e9_sqr_t<NU2>(df, t.nu);
             E9 u = s0; u.c[0] = fsub(u.c[0], BB_ONE);                    // f0^2 - 1
             E9 un = e9_times_nu_t<NU2>(u, t.nu);
-            E9 w = e9_mul_fe(s0, three); w.c[0] = fsub(w.c[0], BB_ONE);  // 3 f0^2 - 1 = 3 u + 2
-            E9 wn;                                                       // nu * w = 3 (nu u) + 2 nu   (linear: no second pre-multiplication)
+            E9 w = e9_add(e9_add(s0, s0), s0); w.c[0] = fsub(w.c[0], BB_ONE);   // 3 f0^2 - 1 (two centred additions per word)
+            E9 wn;
+            if (NU2) wn = e9_times_nu_t<true>(w, t.nu);                  // doubling
+            else {                                                       // nu * w = 3 (nu u) + 2 nu   (linear: no second pre-multiplication)
 #pragma unroll
-            for (int c = 0; c < TAU; c++) wn.c[c] = fred(3 * (i64)un.c[c] + (c == 0 ? 2 * (i64)t.nu : 0));
+                for (int c = 0; c < TAU; c++) wn.c[c] = fred(3 * (i64)un.c[c] + (c == 0 ? 2 * (i64)t.nu : 0));
+            }
             E9 sdn = e9_times_nu_t<NU2>(sd, t.nu);
             E9 m0 = e9_mul_pre(p, u, un), m1 = e9_mul_pre(q, w, wn), m2 = e9_mul_pre(p, sd, sdn), m3 = e9_mul_pre(q, sd, sdn);
 #pragma unroll
