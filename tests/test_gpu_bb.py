@@ -328,3 +328,37 @@ def test_fold_real_circuit_from_r1cs(ctx):
     assert (acc_g == acc_o).all() and (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
     ok, lc_p, _ = api.NIFSVerifier.verify(wl, acc_g, cccs, proof_g, tr_new())
     assert ok and (lc_p == lc_g).all()
+
+
+def test_fold_step_with_another_nonresidue(ctx):
+    """nu is data: F_{p^9} = F_p[Y]/(Y^9 - zeta) (zeta a primitive 24th root of unity instead of 2) switches the kernels to
+    their generic-nu instantiation (Montgomery pre-multiplications instead of doublings)"""
+    nr, y = ctx.get_ring_tables()
+    g0 = 2
+    while True:
+        zeta = pow(g0, (P - 1) // 24, P)
+        if pow(zeta, 12, P) != 1 and pow(zeta, 8, P) != 1:
+            break
+        g0 += 1
+    E = [1, 5, 7, 11, 13, 17, 19, 23]
+    y2 = np.zeros((8, TAU), dtype=np.uint64)
+    for k, e in enumerate(E):
+        g = e % 3                                     # (zeta^a Y^g)^9 = zeta^(9a + g) = zeta^e
+        a = next(t for t in range(24) if (9 * t) % 24 == (e - g) % 24)
+        y2[k, g] = pow(zeta, a, P)
+    try:
+        ctx.set_ring_tables(zeta, y2.reshape(-1))
+        assert lfo.lib().lfo_set_ring(zeta, lfo._p64(np.ascontiguousarray(y2.reshape(-1)))) == 0
+        x = rnd(5, 200, RE)
+        assert (ctx.crt(x) == lfo.crt(x)).all() and (ctx.icrt(ctx.crt(x)) == x).all()
+        assert ctx.selftest_field(7, 1 << 14) == 0
+        wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o = run_both(ctx, "B6")
+        assert (linpr_g == linpr_o).all() and (acc_g == acc_o).all()
+        lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+        lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+        assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+        rc, _ = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)
+        assert rc == 0
+    finally:
+        ctx.set_ring_tables(nr, y)
+        lfo.lib().lfo_set_ring(nr, lfo._p64(np.ascontiguousarray(y)))

@@ -341,3 +341,34 @@ def test_fold_real_circuit_from_r1cs(ctx):
     assert (acc_g == acc_o).all() and (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
     ok, lc_p, _ = api.NIFSVerifier.verify(wl, acc_g, cccs, proof_g, api.PoseidonTranscript())
     assert ok and (lc_p == lc_g).all()
+
+
+def test_fold_step_with_another_nonresidue(ctx):
+    """nu is data too: F_{p^3} = F_p[Y]/(Y^3 - w^5) (w = 2^40) switches every kernel to its generic-nu instantiation
+    (no 2^40 shift tricks); CRT and a whole fold step must still match the oracle under the same tables."""
+    nr, y = ctx.get_ring_tables()
+    w = 1 << 40
+    nu2 = pow(w, 5, P)
+    E = [1, 5, 7, 11, 13, 17, 19, 23]
+    y2 = np.zeros((8, 3), dtype=np.uint64)
+    for k, e in enumerate(E):
+        g = 1 if e % 3 == 2 else 2                   # (c Y^g)^3 = c^3 nu^g = w^e  needs  3 | e - 5 g
+        a = ((e - 5 * g) % 24) // 3
+        assert (e - 5 * g) % 3 == 0
+        y2[k, g] = pow(w, a, P)
+    try:
+        ctx.set_ring_tables(nu2, y2.reshape(-1))
+        assert lfo.lib().lfo_set_ring(nu2, lfo._p64(np.ascontiguousarray(y2.reshape(-1)))) == 0
+        x = rnd(5, 200, RE)
+        assert (ctx.crt(x) == lfo.crt(x)).all() and (ctx.icrt(ctx.crt(x)) == x).all()
+        assert ctx.selftest_field(7, 1 << 16) == 0
+        wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o = run_both(ctx, "T8")
+        assert (linpr_g == linpr_o).all() and (acc_g == acc_o).all()
+        lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+        assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+        rc, _ = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)
+        assert rc == 0
+    finally:
+        ctx.set_ring_tables(nr, y)
+        lfo.lib().lfo_set_ring(nr, lfo._p64(np.ascontiguousarray(y)))
