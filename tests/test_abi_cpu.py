@@ -84,3 +84,27 @@ def test_sizes_match_oracle_layout():
         assert L.lf_lcccs_len(C.byref(p)) == inst.lcccs_len
         assert L.lf_cccs_len(C.byref(p)) == inst.cccs_len
         assert L.lf_proof_len(C.byref(p)) == inst.proof_len
+
+
+def test_ring_helpers_and_sizes():
+    """ring-selection helpers of the ABI need no GPU: words / tau / modulus per ring and the flat sizes with v[tau]"""
+    import ctypes as C
+    from latticefold_amd import api
+    L = api._lib()
+    L.lf_ring_words.argtypes = [C.c_int]
+    L.lf_ring_tau.argtypes = [C.c_int]
+    assert (L.lf_ring_words(0), L.lf_ring_tau(0), L.lf_ring_modulus(0)) == (24, 3, 2**64 - 2**32 + 1)
+    assert (L.lf_ring_words(1), L.lf_ring_tau(1), L.lf_ring_modulus(1)) == (72, 9, 15 * 2**27 + 1)
+    assert L.lf_ring_words(7) == 0
+    p = api.Params(10, 256, 1, 4, 16, 2, 1 << 16, 21, 3, 2, 2)
+    for ring, tau in ((0, 3), (1, 9)):
+        assert L.lf_lcccs_len_ring(C.byref(p), ring) == 10 + tau + 21 + 3 + 1 + 1
+        assert L.lf_cccs_len_ring(C.byref(p), ring) == 21 + 1
+        lin = 10 * 4 + tau + 3
+        dec = 16 * (3 + tau + 2 + 21)
+        fold = 10 * 5 + 2 * 16 * (tau + 3)
+        assert L.lf_proof_len_ring(C.byref(p), ring) == lin + 2 * dec + fold
+    assert L.lf_lcccs_len(C.byref(p)) == L.lf_lcccs_len_ring(C.byref(p), 0)
+    assert L.lf_transcript_new_ring(5) is None
+    L.lf_strerror.restype = C.c_char_p
+    assert b"reject" in L.lf_strerror(-8)
