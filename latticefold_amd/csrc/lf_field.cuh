@@ -129,7 +129,10 @@ struct AccP {
 LF_HD void accp_zero(AccP &a) { a.s00 = a.s01 = a.s11 = 0; a.c00 = a.c01 = a.c11 = 0; }
 LF_HD void mad_cc(u64 &acc, u32 &cnt, u32 a, u32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+    // carry through a compiler-allocated SGPR pair (VOP3 forms) instead of VCC: independent accumulator chains do not
+    // serialise on the single VCC register and can be interleaved by the scheduler
+    unsigned long long cy;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(acc), "+v"(cnt), "=&s"(cy) : "v"(a), "v"(b));
 #else
     u64 p = (u64)a * b, n = acc + p;
     cnt += (n < p);
