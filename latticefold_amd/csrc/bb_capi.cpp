@@ -1023,7 +1023,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("fold_G2", RE * m, &G[1]));
     RET(c->tbuf("fold_eqb", TAU * m, &eqb));
     RET(c->tbuf("fold_zz", (size_t)P.t * RE * n, &zz));
-    RET(c->tbuf("round_partial", red_partial_words(5 * RE), &partial));
+    RET(c->tbuf("round_partial", fold_partial_words(m), &partial));
     od = c->round_out();
     if (!od) return LF_ERR_HIP;
     for (int sd = 0; sd < 2; sd++) {

@@ -101,6 +101,7 @@ void launch_fold_round2(const DevBb &t, const FoldArgs &a, const int32_t *planes
 // after r_2: F[(k*9+d)][72][m/4] = sum_b eq((r1,r2), b) * digit(f[4j+b])
 void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, const H9 &r1,
                               const H9 &r2, const BbHostRing &ring, fe *F, hipStream_t s);
+size_t fold_partial_words(size_t m);   // i64 words of `partial` the general rounds need
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre_dev, i64 *partial, u64 *out,
                        hipStream_t s);
 // folded witness in the coefficient domain: out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c) mod X^72 - X^36 + 1

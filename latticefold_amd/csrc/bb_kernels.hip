@@ -1052,51 +1052,69 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 //   M c0 = p (f0^2 - 1), M c1 = q (3 f0^2 - 1), M c2 = 3 p df^2, M c3 = q df^2,   p = M f0, q = M df
 // Small rounds are latency-bound if one thread walks all 2K*9 tables, so the table range is split over blockIdx.z
 // (every part is linear in the tables, including the final product with eqB).
+// One pair per thread (the grid covers all pairs), so nothing but the table-loop state is live inside the loop and the four
+// sums of products can be kept as lazy (high, low) column sums: no Montgomery reduction per product, one per sum at the end.
 template <bool NU2>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial) {
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
     const u32 tb0 = blockIdx.z * per, tb1 = tb0 + per < ntab ? tb0 + per : ntab;
+    const size_t pairs = a.n / 2;
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < pairs;
+    const size_t jj = live ? j : 0;
+    HL C[4 * TAU];
+#pragma unroll
+    for (int i = 0; i < 4 * TAU; i++) { C[i].hi = 0; C[i].lo = 0; }
+#pragma unroll 1
+    for (u32 tb = tb0; tb < tb1; tb++) {
+        const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
+        E9 f0, f1;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) {
+            int2 v = *reinterpret_cast<const int2 *>(Ft + (size_t)c * ldF + 2 * jj);
+            f0.c[c] = v.x; f1.c[c] = v.y;
+        }
+        E9 df = e9_sub(f1, f0);
+        E9Pre M = e9p(Mpre[tb]);
+        E9 p = e9_mul(f0, M), q = e9_mul(df, M);
+        E9 s0 = e9_sqr_t<NU2>(f0, t.nu), sd = e9_sqr_t<NU2>(df, t.nu);
+        E9 u = s0; u.c[0] = fsub(u.c[0], BB_ONE);                    // f0^2 - 1
+        E9 un = e9_times_nu_t<NU2>(u, t.nu);
+        E9 w = e9_add(e9_add(s0, s0), s0); w.c[0] = fsub(w.c[0], BB_ONE);   // 3 f0^2 - 1 (two centred additions per word)
+        E9 wn;
+        if (NU2) wn = e9_times_nu_t<true>(w, t.nu);                  // doubling
+        else {                                                       // nu * w = 3 (nu u) + 2 nu   (linear: no second pre-multiplication)
+#pragma unroll
+            for (int c = 0; c < TAU; c++) wn.c[c] = fred(3 * (i64)un.c[c] + (c == 0 ? 2 * (i64)t.nu : 0));
+        }
+        E9 sdn = e9_times_nu_t<NU2>(sd, t.nu);
+        i64 T[TAU];
+        e9_mul_cols(p, u, un, T);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) hl_add(C[c], T[c]);
+        e9_mul_cols(q, w, wn, T);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) hl_add(C[TAU + c], T[c]);
+        e9_mul_cols(p, sd, sdn, T);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) hl_add(C[2 * TAU + c], T[c]);
+        e9_mul_cols(q, sd, sdn, T);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) hl_add(C[3 * TAU + c], T[c]);
+    }
     i64 acc[5 * TAU];
 #pragma unroll
     for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
-    size_t pairs = a.n / 2;
-    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+    if (live) {
         if (blockIdx.z == 0) fold_linear_part(t, a, slot, j, acc);
-        i64 C[4 * TAU];
-#pragma unroll
-        for (int i = 0; i < 4 * TAU; i++) C[i] = 0;
-#pragma unroll 1
-        for (u32 tb = tb0; tb < tb1; tb++) {
-            const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
-            E9 f0, f1;
-#pragma unroll
-            for (int c = 0; c < TAU; c++) {
-                int2 v = *reinterpret_cast<const int2 *>(Ft + (size_t)c * ldF + 2 * j);
-                f0.c[c] = v.x; f1.c[c] = v.y;
-            }
-            E9 df = e9_sub(f1, f0);
-            E9Pre M = e9p(Mpre[tb]);
-            E9 p = e9_mul(f0, M), q = e9_mul(df, M);
-            E9 s0 = e9_sqr_t<NU2>(f0, t.nu), sd = e9_sqr_t<NU2>(df, t.nu);
-            E9 u = s0; u.c[0] = fsub(u.c[0], BB_ONE);                    // f0^2 - 1
-            E9 un = e9_times_nu_t<NU2>(u, t.nu);
-            E9 w = e9_add(e9_add(s0, s0), s0); w.c[0] = fsub(w.c[0], BB_ONE);   // 3 f0^2 - 1 (two centred additions per word)
-            E9 wn;
-            if (NU2) wn = e9_times_nu_t<true>(w, t.nu);                  // doubling
-            else {                                                       // nu * w = 3 (nu u) + 2 nu   (linear: no second pre-multiplication)
-#pragma unroll
-                for (int c = 0; c < TAU; c++) wn.c[c] = fred(3 * (i64)un.c[c] + (c == 0 ? 2 * (i64)t.nu : 0));
-            }
-            E9 sdn = e9_times_nu_t<NU2>(sd, t.nu);
-            E9 m0 = e9_mul_pre(p, u, un), m1 = e9_mul_pre(q, w, wn), m2 = e9_mul_pre(p, sd, sdn), m3 = e9_mul_pre(q, sd, sdn);
-#pragma unroll
-            for (int c = 0; c < TAU; c++) { C[c] += m0.c[c]; C[TAU + c] += m1.c[c]; C[2 * TAU + c] += m2.c[c]; C[3 * TAU + c] += m3.c[c]; }
-        }
         // S(X) = C0 + C1 X + 3 C2 X^2 + C3 X^3
         E9 c0, c1, c2, c3;
 #pragma unroll
-        for (int c = 0; c < TAU; c++) { c0.c[c] = fred(C[c]); c1.c[c] = fred(C[TAU + c]); c2.c[c] = fred(3 * C[2 * TAU + c]); c3.c[c] = fred(C[3 * TAU + c]); }
+        for (int c = 0; c < TAU; c++) {
+            c0.c[c] = hl_finish(C[c]); c1.c[c] = hl_finish(C[TAU + c]);
+            c2.c[c] = fred(3 * (i64)hl_finish(C[2 * TAU + c])); c3.c[c] = hl_finish(C[3 * TAU + c]);
+        }
         E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1);
         E9 es = e9_sub(e1, e0), e = e0;
 #pragma unroll
@@ -1119,16 +1137,21 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         partial[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
     }
 }
+// rows of `partial` a general round may write (one block per 256 pairs, times the table chunks)
+size_t fold_partial_words(size_t m) {
+    size_t rows = m / 8 / 256;          // the largest general round (round 3) has m/8 pairs
+    if (rows < RED_BLOCKS) rows = RED_BLOCKS;
+    return rows * 5 * RE;
+}
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                        hipStream_t s) {
     size_t pairs = a.n / 2;
     u32 gb = (u32)((pairs + 255) / 256);
-    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     // enough threads to fill the chip (~128k): split the 2K*9 tables when there are few pairs
     u32 tch = 1;
     while (tch < 32 && pairs * 8 * tch < (1u << 17)) tch *= 2;
-    while (gb * tch > RED_BLOCKS) tch /= 2;
+    while (tch > 1 && (size_t)gb * tch > RED_BLOCKS) tch /= 2;
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_round<true>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
     else hipLaunchKernelGGL((k_fold_round<false>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
     launch_reduce_rows(partial, gb * tch, 5 * RE, out, s);
