@@ -179,7 +179,7 @@ class Workload:
         return lin + 2 * dec + fold
 
 
-def make_workload(name: str, seed: int = 0, kappa: int = None, ccs: str = "r1cs") -> Workload:
+def make_workload(name: str, seed: int = 0, kappa: int = None, ccs: str = "r1cs", l: int = 1) -> Workload:
     """ccs = "r1cs": the reference bench shape (A = B = I, C = diag(z); 1 nnz/row);
        ccs = "deg3": the reference's degree-three non-scalar CCS (arith/ccs.rs:14-43): t = 4, M = (I, I, I, diag(z^2)),
                      S = {{0,1,2},{3}}, c = (1,-1), d = 3;
@@ -189,9 +189,12 @@ def make_workload(name: str, seed: int = 0, kappa: int = None, ccs: str = "r1cs"
     s, wit_len, L, B, b, K, kap = cfg[:7]
     ring = cfg[7] if len(cfg) > 7 else "goldilocks"
     p, RE, _tau = RINGS[ring]
-    wl = Workload(name=name, s=s, wit_len=wit_len, L=L, B=B, b=b, K=K, kappa=kappa or kap, seed=seed, ring=ring)
+    wl = Workload(name=name, s=s, wit_len=wit_len, L=L, B=B, b=b, K=K, kappa=kappa or kap, l=l, seed=seed, ring=ring)
     assert wl.N <= wl.m, "sanity_check (nifs.rs:165-173): m must be >= wit_len*L"
     wl.x_ccs = np.tile(diag(1, ring), (wl.l, 1))
+    if wl.l > 1:   # distinct public inputs (slot-constant scalars 2, 3, ..) so that x_s / x_0 handling is really exercised
+        for i in range(1, wl.l):
+            wl.x_ccs[i] = diag(i + 1, ring)
     wl.w_ccs = splitmix_fq(0x4C460001 + seed, 0, wit_len * RE, ring).reshape(wit_len, RE)
     z = wl.z()
     n, m = wl.n, wl.m

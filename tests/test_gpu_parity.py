@@ -372,3 +372,22 @@ def test_fold_step_with_another_nonresidue(ctx):
     finally:
         ctx.set_ring_tables(nr, y)
         lfo.lib().lfo_set_ring(nr, lfo._p64(np.ascontiguousarray(y)))
+
+
+def test_fold_step_with_several_public_inputs(ctx):
+    """x_len = 3 (all bench workloads use 1): x_s decomposition, z heads, x_0 folding with l + 1 = 4 head elements"""
+    wl = make_workload("T8", l=3)
+    inst = lfo.Instance(wl)
+    ctx.load_ccs(wl)
+    A = wl.ajtai_matrix()
+    scheme = api.AjtaiCommitmentScheme(ctx, matrix=A)
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    acc_g, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+    acc_o, _ = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    assert (acc_g == acc_o).all() and (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+    ok, lc_p, _ = api.NIFSVerifier.verify(wl, acc_g, cccs, proof_g, api.PoseidonTranscript())
+    assert ok and (lc_p == lc_g).all()
