@@ -96,7 +96,7 @@ def test_linf_check(ctx):
     assert not ok
 
 
-@pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 4096, 1), (26, 1024, 15), (3, 64, 2)])
+@pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 4096, 1), (26, 1024, 15), (3, 64, 2), (26, 512, 40)])
 def test_ajtai_commit(ctx, kappa, n, batch):
     A = rnd(100 + kappa, kappa, n, RE)
     f = rnd(200 + n, batch, n, RE)
