@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
+                         "stream does --steps steps, value counts all of them.  Default 1 = one prover, latency-honest ms_per_step")
     ap.add_argument("--parallelism", choices=["replicas", "shard"], default=os.environ.get("LF_PARALLELISM", "replicas"),
                     help="N>1: 'replicas' = one independent fold stream per GPU (weak scaling, default); 'shard' = ONE fold stream whose "
                          "Ajtai commitments and folding-sumcheck rounds are sharded over the GPUs (strong scaling, SURVEY 8e)")
@@ -130,8 +133,31 @@ def main():
         w0.free()
         return proof
 
+    # extra streams (opt-in): independent instances with their own context, witness and accumulator on the same GPU
+    extra = []
+    for sidx in range(1, max(1, args.streams)):
+        if shard:
+            raise SystemExit("--streams > 1 is a replicas-only mode")
+        wl_s = make_workload(args.workload, seed=1000 * sidx + rank)
+        ctx_s = api.Context(local_rank, ring=wl_s.ring)
+        ctx_s.load_ccs(wl_s)
+        sch_s = api.AjtaiCommitmentScheme(ctx_s, kappa=wl_s.kappa, n=wl_s.N, seed=wl_s.ajtai_seed())
+        wit_s = api.Witness.from_w_ccs(ctx_s, wl_s.w_ccs)
+        cccs_s = np.concatenate([wit_s.commit(sch_s), wl_s.x_ccs])
+        tr_s = api.PoseidonTranscript(ring=wl_s.ring)
+        acc_s, _ = api.LFLinearizationProver.prove(ctx_s, cccs_s, wit_s, tr_s)
+        extra.append((ctx_s, acc_s, wit_s, cccs_s, tr_s, sch_s))
+
+    def run_stream(st, n):
+        ctx_s, acc_s, wit_s, cccs_s, tr_s, _ = st
+        for _ in range(n):
+            lc, w0, proof = api.NIFSProver.prove(ctx_s, acc_s, wit_s, cccs_s, wit_s, tr_s.clone())
+            w0.free()
+
     def sync():
         ctx.synchronize()
+        for st in extra:
+            st[0].synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             if backend == "nccl":
@@ -139,16 +165,24 @@ def main():
             else:
                 dist.barrier()
 
+    import threading
     for _ in range(args.warmup):
         step()
+    for st in extra:
+        run_stream(st, args.warmup)
     sync()
     t0 = time.perf_counter()
     phases_acc, kstats = {}, []
+    threads = [threading.Thread(target=run_stream, args=(st, args.steps)) for st in extra]
+    for th in threads:
+        th.start()
     for _ in range(args.steps):
         step()
         for k, v in ctx.phase_ms().items():
             phases_acc[k] = phases_acc.get(k, 0.0) + v
         kstats.append(ctx.kernel_stats())
+    for th in threads:
+        th.join()
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -158,7 +192,7 @@ def main():
 
     if rank == 0:
         E = 192 if wl.ring == "goldilocks" else 288
-        steps_per_s = (1 if shard else world) * args.steps / elapsed
+        steps_per_s = (1 if shard else world) * max(1, args.streams) * args.steps / elapsed
         alg = wl.alg_bytes()
         # dominant kernels, live HIP-event timing on the library's stream (lf_last_kernel_stats)
         fr_ms = sum(k["fold_round_ms"] for k in kstats)
@@ -208,7 +242,7 @@ def main():
             "dtype": "u64" if wl.ring == "goldilocks" else "u32 (31-bit Montgomery)",
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: {'GoldilocksRingNTT' if wl.ring == 'goldilocks' else 'BabyBearRingNTT'} R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
-                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world} (column-sharded commits + sharded sumcheck rounds, one fold stream)" if shard else f"replicas x{world}"),
+                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world} (column-sharded commits + sharded sumcheck rounds, one fold stream)" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
                        "alg_bytes_per_step": alg, "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
             "roofline": roof,
             "phases_ms_per_step": {k: v / args.steps for k, v in phases_acc.items()},
@@ -225,6 +259,8 @@ def main():
         else:
             dist.barrier()
         dist.destroy_process_group()
+    for st in extra:
+        st[0].close()
     ctx.close()
 
 

@@ -38,3 +38,14 @@ def test_bench_two_ranks_one_gpu(mode, workload):
     # value is the whole-job aggregate: replicas count both ranks' steps
     per_rank = d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)
     assert abs(d["value"] - (2 if mode == "replicas" else 1) * per_rank) / d["value"] < 1e-6
+
+
+def test_bench_streams_mode_single_rank():
+    """opt-in throughput mode: 2 independent fold streams on one GPU from one process"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "T12", "--streams", "2",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "2 independent streams" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
