@@ -223,7 +223,14 @@ def main():
                     traffic = k[f"fetch_bytes_{sel}_corrected"] + k[f"write_bytes_{sel}"]
         except Exception:
             traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": peak, "unit": "GB/s",
+        # the binding roofline of this path is the integer multiplier (v_mad_*64_*32: 15.7e12 lane-ops/s measured, profiles/r01_microbench.txt):
+        # multiply-accumulates of one batched commit = kappa*(K-1)*N*8 slots, 20 mads each (Toom-3 over F_{p^3}) / 81 (F_{p^9} schoolbook)
+        mads_per_mac = 20 if wl.ring == "goldilocks" else 81
+        aj_mads = wl.kappa * (wl.K - 1) * wl.N * 8 * mads_per_mac
+        alu = {"kernel": "k_ajtai", "unit": "v_mad lane-op/s", "peak": 15.7e12,
+               "achieved": aj_mads / (aj_ms / max(aj_n, 1) * 1e-3) if aj_ms else 0.0}
+        alu["frac"] = alu["achieved"] / alu["peak"]
+        roof = {"bound": "hbm", "kernel": dom, "integer_alu": alu, "achieved": kernels[dom]["achieved_GBps"], "peak": peak, "unit": "GB/s",
                 "frac": kernels[dom]["achieved_GBps"] / peak, "traffic": traffic,
                 "note": "integer-ALU-bound path (modular multiply from quarter-rate v_mad_*64_*32); whole-step algorithmic "
                         "rate = %.1f GB/s = %.3f of peak" % (alg * steps_per_s / world / 1e9, alg * steps_per_s / world / 1e9 / peak),
