@@ -55,8 +55,7 @@ int lf_ctx_create(lf_ctx **out, int device);   /* GoldilocksRingNTT */
  * used with it belong to ONE ring; every entry point below then works on ring elements of lf_ring_words(ring) u64 words
  * (24 / 72) and F_{p^tau} challenges of lf_ring_tau(ring) words (3 / 9), canonical residues of lf_ring_modulus(ring).
  * BabyBearRingNTT (BASELINE configs[2]): p = 15*2^27+1, Phi_216 = X^72 - X^36 + 1, 8 slots of F_{p^9}; on the device the
- * words are 31-bit centred Montgomery residues.  Not available for BabyBear: intra-step sharding.  lf_set_ring_tables takes
- * y[8][tau] (tau = 9 words per slot for BabyBear). */
+ * words are 31-bit centred Montgomery residues.  lf_set_ring_tables takes y[8][tau] (tau = 9 words per slot for BabyBear). */
 #define LF_RING_GOLDILOCKS 0
 #define LF_RING_BABYBEAR 1
 int lf_ctx_create_ring(lf_ctx **out, int device, int ring);

@@ -35,7 +35,11 @@ struct BbCtxImpl {
     fe *d_icrt = nullptr;
     fe *dA = nullptr;
     u32 kappa = 0;
-    size_t nA = 0;
+    size_t nA = 0, nA_total = 0, A_col0 = 0;   // columns held by this rank / of the whole matrix / first held column
+    // intra-step sharding, same scheme as the Goldilocks backend
+    int sh_rank = 0, sh_world = 1;
+    lf_exchange_fn sh_cb = nullptr;
+    void *sh_user = nullptr;
     bool have_ccs = false;
     lf_params P{};
     size_t N = 0, m = 0, n = 0;
@@ -212,6 +216,13 @@ int BbCtx::set_ring_tables(uint64_t nonres, const uint64_t *y) {
     HIPCHK(hipStreamSynchronize(p->st_lane[1]));
     return install_tables(p, nonres, y);
 }
+int BbCtx::set_sharding(int rank, int world, lf_exchange_fn cb, void *user) {
+    if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(p->mu);
+    if (p->dA) return LF_ERR_STATE;   // choose the sharding before loading/generating the Ajtai matrix
+    p->sh_rank = rank; p->sh_world = world; p->sh_cb = cb; p->sh_user = user;
+    return LF_OK;
+}
 int BbCtx::get_ring_tables(uint64_t *nonres, uint64_t *y) {
     *nonres = p->ring.T.nu;
     for (int k = 0; k < 8; k++)
@@ -253,6 +264,28 @@ static int down_small(C *c, const u64 *dsrc, size_t words, u64 *host) {
     HIPCHK(hipMemcpyAsync(c->h_pin, dsrc, words * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipStreamSynchronize(c->stream()));
     memcpy(host, c->h_pin, words * 8);
+    return LF_OK;
+}
+// all-gather `words` canonical words from every rank and add them mod p (RCCL has no modular reduction)
+static int exchange_modsum(C *c, u64 *inout, size_t words) {
+    if (c->sh_world <= 1) return LF_OK;
+    std::vector<u64> all((size_t)c->sh_world * words);
+    if (c->sh_cb(c->sh_user, inout, all.data(), words) != 0) return LF_ERR_HIP;
+    for (size_t w = 0; w < words; w++) {
+        u64 acc = 0;
+        for (int g = 0; g < c->sh_world; g++) {
+            u64 v = all[(size_t)g * words + w];
+            if (v >= BB_P) return LF_ERR_INVALID;
+            acc = hadd(acc, v);
+        }
+        inout[w] = acc;
+    }
+    return LF_OK;
+}
+static int shard_columns(C *c, size_t n, size_t *col0, size_t *cnt) {
+    if (n % (size_t)c->sh_world) return LF_ERR_UNSUPPORTED;
+    *cnt = n / c->sh_world;
+    *col0 = *cnt * c->sh_rank;
     return LF_OK;
 }
 static H9 h9_load(const u64 *w) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = w[i] % BB_P; return r; }
@@ -380,12 +413,14 @@ int BbCtx::ajtai_load(const uint64_t *A, size_t kappa, size_t n) {
     if (kappa > 32) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    size_t col0, cnt;
+    RET(shard_columns(c, n, &col0, &cnt));   // a sharded rank keeps only its column slice of the caller's matrix
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * RE * sizeof(fe)));
-    for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + i * n * RE, n, c->dA + i * RE * n));
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * RE * sizeof(fe)));
+    for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + (i * n + col0) * RE, cnt, c->dA + i * RE * cnt));
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
-    c->nA = n;
+    c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
     return LF_OK;
 }
 int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
@@ -393,12 +428,14 @@ int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
     if (kappa > 32) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    size_t col0, cnt;
+    RET(shard_columns(c, n, &col0, &cnt));
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * n * RE * sizeof(fe)));
-    launch_fill_ajtai(c->dA, (u32)kappa, n, n, 0, seed, c->stream());
+    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * RE * sizeof(fe)));
+    launch_fill_ajtai(c->dA, (u32)kappa, cnt, n, col0, seed, c->stream());
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
-    c->nA = n;
+    c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
     return LF_OK;
 }
 static u32 ajtai_splits(size_t n) {
@@ -427,15 +464,16 @@ int BbCtx::ajtai_commit(const uint64_t *f, size_t n, size_t batch, uint64_t *out
     C *c = p;
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->dA) return LF_ERR_STATE;
-    if (n != c->nA) return LF_ERR_INVALID;   // CommitmentError::WrongWitnessLength(n, width)
+    if (n != c->nA_total) return LF_ERR_INVALID;   // CommitmentError::WrongWitnessLength(n, width)
     HIPCHK(hipSetDevice(c->device));
     fe *F;
     u64 *o;
     RET(c->tbuf("io_a", batch * n * RE, &F));
     RET(c->tbuf("io_o", batch * c->kappa * RE, &o));
     for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * RE, n, F + b * RE * n));
-    RET(commit_dev(c, F, n, (u32)batch, o, false));
-    return down_small(c, o, batch * c->kappa * RE, out);
+    RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, false));
+    RET(down_small(c, o, batch * c->kappa * RE, out));
+    return exchange_modsum(c, out, batch * c->kappa * RE);
 }
 
 // ---- a8/a9/a11 ---------------------------------------------------------------------------------------------------------
@@ -684,7 +722,7 @@ int BbCtx::witness_commit(const lf_witness *w, uint64_t *cm_out) {
     C *c = p;
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->dA) return LF_ERR_STATE;
-    if (w->N != c->nA) return LF_ERR_INVALID;
+    if (w->N != c->nA_total) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
     fe *d, *e;
     u64 *o;
@@ -693,8 +731,9 @@ int BbCtx::witness_commit(const lf_witness *w, uint64_t *cm_out) {
     RET(c->tbuf("io_o", (size_t)c->kappa * RE, &o));
     launch_i32_to_coef(w->planes, d, w->N, c->stream());
     launch_crt_fwd(c->dev, d, e, w->N, c->stream());
-    RET(commit_dev(c, e, w->N, 1, o, false));
-    return down_small(c, o, (size_t)c->kappa * RE, cm_out);
+    RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));
+    RET(down_small(c, o, (size_t)c->kappa * RE, cm_out));
+    return exchange_modsum(c, cm_out, (size_t)c->kappa * RE);
 }
 
 // =================================================================================================================================
@@ -889,7 +928,7 @@ static int dec_enqueue(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const
     fe *Fh, *z, *q;
     i64 *partial;
     u64 *od, *yd;
-    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * N, &Fh));
+    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * c->nA, &Fh));
     RET(c->tbuf("dec_y", (size_t)K * P.kappa * RE, &yd));
     RET(c->tbuf("red_partial", red_partial_words(16 * RE * TAU), &partial));
     RET(c->tbuf("dec_small", 16 * RE * TAU + 16 * 4 * RE, &od));
@@ -907,8 +946,8 @@ static int dec_enqueue(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const
     if (!pd.h_y || !pd.h_v || !pd.h_u) return LF_ERR_HIP;
     // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
     pd.ph_commit = c->ev_begin(11);
-    launch_bitplane_crt(c->dev, wit->planes, N, N, 1, K, Fh, c->stream());
-    RET(commit_dev(c, Fh, N, K - 1, yd, true));
+    launch_bitplane_crt(c->dev, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());   // this rank's column slice only
+    RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
     HIPCHK(hipMemcpyAsync(pd.h_y, yd, (size_t)(K - 1) * P.kappa * RE * 8, hipMemcpyDeviceToHost, c->stream()));
     c->ev_end(pd.ph_commit);
     pd.ph_evals = c->ev_begin(12);
@@ -934,6 +973,7 @@ static int dec_finish(C *c, BbTranscript &tr, const u64 *lcccs, SideState &S, u6
     u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * RE, *x_s = v_s + (size_t)K * TAU * RE, *y_s = x_s + (size_t)K * (P.l + 1) * RE;
     HIPCHK(hipEventSynchronize(c->ev_side[pd.lane]));
     memcpy(y_s + (size_t)P.kappa * RE, pd.h_y, (size_t)(K - 1) * P.kappa * RE * 8);
+    RET(exchange_modsum(c, y_s + (size_t)P.kappa * RE, (size_t)(K - 1) * P.kappa * RE));   // partial commitments of the column shards
     memcpy(v_s, pd.h_v, (size_t)K * TAU * RE * 8);
     memcpy(u_s, pd.h_u, (size_t)K * P.t * RE * 8);
     HostTimer ht(c);
@@ -1049,9 +1089,15 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("fold_T1", T5P * atl(m / 4), &T5[1]));
     FoldArgs a;
     a.eqL = S[0].eq_r; a.eqR = S[1].eq_r; a.eqB = eqb; a.G1 = G[0]; a.G2 = G[1]; a.ld = m; a.n = m;
+    a.p0 = 0; a.pcnt = m / 2; a.pF0 = 0;
     const fe *curF = nullptr;
     size_t ldF = 0;
     int flip = 0;
+    // Sharded rounds (same scheme as the Goldilocks driver): rank g evaluates the pairs of its index slice (high bits:
+    // pairs (2j,2j+1) stay local, the f-hat tables exist only for that slice), the 5-element partial messages are all-gathered and
+    // added mod p, every rank runs the same transcript.  Below 64 pairs per rank the f-hat slices are gathered and the tail is replicated.
+    const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
+    bool sharded = Gw > 1;
     for (u32 round = 1; round <= P.s; round++) {
         if (round > 1) {
             H9 rh = pt[round - 2];
@@ -1067,19 +1113,49 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             } else {            // source is the previous 171-plane buffer (same layout): one launch over its 19 F_{p^9} rows
                 launch_fix(c->dev, a.eqL, a.ld, dst, ldn, a.n, 19, r, c->stream());
             }
-            if (round == 3) {
-                launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, m, K, pt[0], pt[1], c->ring, F[0], c->stream());
-                curF = F[0]; ldF = atl(m / 4);
-            } else if (round > 3) {
-                fe *fd = F[(round & 1) ? 0 : 1];   // round 4 -> F[1], round 5 -> F[0], ...
-                launch_fix(c->dev, curF, ldF, fd, ldn, a.n, K2 * TAU * 8, r, c->stream());
-                curF = fd; ldF = ldn;
+            bool gathered = false;
+            if (sharded && nn / 2 < Gw * 64) {
+                // transition to the replicated tail: gather the fixed f-hat slices (if they exist yet)
+                if (round > 3) {
+                    fe *fd = F[(round & 1) ? 0 : 1];
+                    size_t lcl = ldF / 2;   // local entries after this fix
+                    launch_fix(c->dev, curF, ldF, fd, lcl, ldF, K2 * TAU * 8, r, c->stream());
+                    size_t planes = (size_t)K2 * TAU * RE, cnt = planes * lcl, words = (cnt + 1) / 2;   // two 32-bit words per u64
+                    std::vector<u64> mine(words, 0), all(words * Gw);
+                    std::vector<fe> full(planes * nn);
+                    HIPCHK(hipMemcpyAsync(mine.data(), fd, cnt * sizeof(fe), hipMemcpyDeviceToHost, c->stream()));
+                    HIPCHK(hipStreamSynchronize(c->stream()));
+                    if (c->sh_cb(c->sh_user, mine.data(), all.data(), words) != 0) return LF_ERR_HIP;
+                    for (size_t rk = 0; rk < Gw; rk++) {
+                        const fe *src = (const fe *)&all[rk * words];
+                        for (size_t w = 0; w < planes; w++) memcpy(&full[w * nn + rk * lcl], src + w * lcl, lcl * sizeof(fe));
+                    }
+                    HIPCHK(hipMemcpyAsync(fd, full.data(), full.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream()));
+                    HIPCHK(hipStreamSynchronize(c->stream()));
+                    curF = fd; ldF = nn;
+                    gathered = true;
+                }
+                sharded = false;
+            }
+            if (!gathered) {
+                if (round == 3) {
+                    size_t q = sharded ? nn / Gw : nn, j0 = sharded ? gr * q : 0;   // this rank's slice of the m/4 entries
+                    launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, j0, q, K, pt[0], pt[1], c->ring, F[0], c->stream());
+                    curF = F[0]; ldF = atl(q);
+                } else if (round > 3) {
+                    fe *fd = F[(round & 1) ? 0 : 1];   // round 4 -> F[1], round 5 -> F[0], ...
+                    launch_fix(c->dev, curF, ldF, fd, atl(ldF / 2), ldF, K2 * TAU * 8, r, c->stream());
+                    curF = fd; ldF = atl(ldF / 2);
+                }
             }
             a.eqL = dst; a.eqR = dst + (size_t)TAU * ldn; a.eqB = dst + (size_t)2 * TAU * ldn;
             a.G1 = dst + (size_t)3 * TAU * ldn; a.G2 = dst + (size_t)(3 * TAU + RE) * ldn;
             a.ld = ldn; a.n = nn;
             flip ^= 1;
         }
+        if (sharded && a.n / 2 < Gw * 64) sharded = false;   // (round 1 of a tiny instance)
+        if (sharded) { a.pcnt = a.n / 2 / Gw; a.p0 = gr * a.pcnt; a.pF0 = a.p0; }
+        else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
@@ -1088,6 +1164,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;
         HIPCHK(hipStreamSynchronize(c->stream()));            // message is in mapped host memory
         memcpy(evs, od, (size_t)(deg + 1) * RE * 8);
+        if (sharded) RET(exchange_modsum(c, evs, (size_t)(deg + 1) * RE));
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
     }
@@ -1214,7 +1291,7 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
     const lf_params &P = c->P;
-    if (c->kappa != P.kappa || c->nA != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
+    if (c->kappa != P.kappa || c->nA_total != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
     std::vector<H9> rL;
     if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;   // evaluation points are always diagonal challenges

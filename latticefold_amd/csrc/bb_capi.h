@@ -19,6 +19,7 @@ struct BbCtx {
     static int create(BbCtx **out, lf_ctx *owner, int device);
     void destroy();
 
+    int set_sharding(int rank, int world, lf_exchange_fn cb, void *user);
     int set_ring_tables(uint64_t nonres, const uint64_t *y);
     int get_ring_tables(uint64_t *nonres, uint64_t *y);
     int synchronize();

@@ -91,6 +91,8 @@ struct FoldArgs {
     const fe *eqL, *eqR, *eqB;   // fq9 tables [9][ld]
     const fe *G1, *G2;           // ring tables [72][ld]
     size_t ld, n;                // leading dimension / current length
+    size_t p0, pcnt;             // pair range handled by this launch (all pairs: 0, n/2; a rank's slice when sharded)
+    size_t pF0;                  // first pair held by the materialised f-hat buffer (general rounds)
 };
 // round 1 straight from the coefficient planes (f-hat virtual, b = 2); Mc = mu_k^(d+1), [2K][9] constants
 void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
@@ -99,8 +101,9 @@ void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planes
 void launch_fold_round2(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const E9C *Mc_dev, const H9 &r1, const BbHostRing &ring, i64 *partial, u64 *out, hipStream_t s);
 // after r_2: F[(k*9+d)][72][m/4] = sum_b eq((r1,r2), b) * digit(f[4j+b])
-void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, const H9 &r1,
-                              const H9 &r2, const BbHostRing &ring, fe *F, hipStream_t s);
+// entries j0 <= j < j0 + q of the m/4-entry tables, stored with leading dimension q
+void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t j0, size_t q, u32 K,
+                              const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *F, hipStream_t s);
 size_t fold_partial_words(size_t m);   // i64 words of `partial` the general rounds need
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre_dev, i64 *partial, u64 *out,
                        hipStream_t s);

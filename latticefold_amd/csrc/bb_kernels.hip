@@ -865,8 +865,8 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevBb t, FoldArgs a, const 
     i64 acc[5 * TAU];
 #pragma unroll
     for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
-    size_t pairs = a.n / 2;
-    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+    const size_t pend = a.p0 + a.pcnt;
+    for (size_t j = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; j < pend; j += (size_t)gridDim.x * 256) {
         fold_linear_part(t, a, slot, j, acc);
         i64 S[3 * TAU];
 #pragma unroll
@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevBb t, FoldArgs a, const 
 }
 void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const E9C *Mc, i64 *partial, u64 *out, hipStream_t s) {
-    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    u32 gb = (u32)((a.pcnt + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     hipLaunchKernelGGL(k_fold_round1, dim3(gb, 8), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, Mc, partial);
@@ -932,8 +932,8 @@ __global__ void __launch_bounds__(256) k_fold_round2(DevBb t, FoldArgs a, const 
     i64 acc[TAU];
 #pragma unroll
     for (int i = 0; i < TAU; i++) acc[i] = 0;
-    size_t pairs = a.n / 2;
-    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+    const size_t pend = a.p0 + a.pcnt;
+    for (size_t j = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; j < pend; j += (size_t)gridDim.x * 256) {
         // linear part at this X
 #pragma unroll 1
         for (int side = 0; side < 2; side++) {
@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(256) k_fold_round2(DevBb t, FoldArgs a, const 
 }
 void launch_fold_round2(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const E9C *Mc, const H9 &r1, const BbHostRing &ring, i64 *partial, u64 *out, hipStream_t s) {
-    u32 gb = (u32)((a.n / 2 + 255) / 256);
+    u32 gb = (u32)((a.pcnt + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     R1Pow rp;
@@ -1008,18 +1008,19 @@ void launch_fold_round2(const DevBb &t, const FoldArgs &a, const int32_t *planes
 }
 // after r_2: F[(side*K+k)*9+d][9*slot+c][j] = sum_{b<4} W_b * digit(f[4j+b]),  W_b = eq((r1,r2), b) (b = b0 + 2 b1, LSB first)
 struct W4 { fe v[4][TAU]; };
-__global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t quarter, u32 K,
-                                                           W4 w, fe *F) {
-    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t j0, size_t quarter,
+                                                           u32 K, W4 w, fe *F) {
+    size_t jl = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y % 8, d = blockIdx.y / 8, side = blockIdx.z;
-    if (j >= quarter) return;
+    if (jl >= quarter) return;
+    const size_t j = j0 + jl;   // global entry; stored at local index jl with leading dimension `quarter`
     const int32_t *pl = side ? planesR : planesL;
     size_t base = (size_t)(8 * d + slot) * n_planes + 4 * j;
     int32_t v[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) v[b] = 4 * j + b < n_planes ? pl[base + b] : 0;
     for (u32 k = 0; k < K; k++) {
-        fe *o = F + ((size_t)((side * K + k) * TAU + d) * RE + TAU * slot) * quarter + j;
+        fe *o = F + ((size_t)((side * K + k) * TAU + d) * RE + TAU * slot) * quarter + jl;
         int dg[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) dg[b] = digit2(v[b], k);
@@ -1035,8 +1036,8 @@ __global__ void __launch_bounds__(256) k_fold_materialize2(const int32_t *planes
         }
     }
 }
-void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K, const H9 &r1,
-                              const H9 &r2, const BbHostRing &ring, fe *F, hipStream_t s) {
+void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t j0, size_t q, u32 K,
+                              const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *F, hipStream_t s) {
     H9 one;
     for (int i = 0; i < TAU; i++) one.c[i] = i == 0;
     H9 o1, o2;
@@ -1045,8 +1046,7 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
     W4 w;
     for (int b = 0; b < 4; b++)
         for (int c = 0; c < TAU; c++) w.v[b][c] = from_canon(Wb[b].c[c]);
-    size_t quarter = m / 4;
-    hipLaunchKernelGGL(k_fold_materialize2, dim3(cdiv(quarter, 256), 8 * TAU, 2), dim3(256), 0, s, planesL, planesR, n_planes, quarter, K, w, F);
+    hipLaunchKernelGGL(k_fold_materialize2, dim3(cdiv(q, 256), 8 * TAU, 2), dim3(256), 0, s, planesL, planesR, n_planes, j0, q, K, w, F);
 }
 // general round on the materialised tables: per table h(f0 + X df) = c0 + c1 X + c2 X^2 + c3 X^3 with
 //   M c0 = p (f0^2 - 1), M c1 = q (3 f0^2 - 1), M c2 = 3 p df^2, M c3 = q df^2,   p = M f0, q = M df
@@ -1059,10 +1059,9 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
     const u32 tb0 = blockIdx.z * per, tb1 = tb0 + per < ntab ? tb0 + per : ntab;
-    const size_t pairs = a.n / 2;
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = j < pairs;
-    const size_t jj = live ? j : 0;
+    const size_t j = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < a.p0 + a.pcnt;
+    const size_t jj = live ? j - a.pF0 : 0;   // index into the f-hat buffer (it starts at pair a.pF0 when sharded)
     HL C[4 * TAU];
 #pragma unroll
     for (int i = 0; i < 4 * TAU; i++) { C[i].hi = 0; C[i].lo = 0; }
@@ -1145,7 +1144,7 @@ size_t fold_partial_words(size_t m) {
 }
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                        hipStream_t s) {
-    size_t pairs = a.n / 2;
+    size_t pairs = a.pcnt;
     u32 gb = (u32)((pairs + 255) / 256);
     if (gb < 1) gb = 1;
     // enough threads to fill the chip (~128k): split the 2K*9 tables when there are few pairs

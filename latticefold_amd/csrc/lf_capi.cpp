@@ -301,7 +301,7 @@ int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
 }
 int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *user) {
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
-    if (c->bb) return world == 1 ? LF_OK : LF_ERR_UNSUPPORTED;
+    if (c->bb) return c->bb->set_sharding(rank, world, cb, user);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->dA) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
     c->sh_rank = rank; c->sh_world = world; c->sh_cb = cb; c->sh_user = user;

@@ -17,7 +17,7 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("mode,workload", [("replicas", "T12"), ("shard", "T14"), ("replicas", "B10")])
+@pytest.mark.parametrize("mode,workload", [("replicas", "T12"), ("shard", "T14"), ("replicas", "B10"), ("shard", "B14")])
 def test_bench_two_ranks_one_gpu(mode, workload):
     env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",

@@ -1,4 +1,4 @@
-"""Intra-step sharding: a fold step sharded over 2 and 4 ranks must return, on EVERY rank, the bit-identical proof,
+"""Intra-step sharding, both rings: a fold step sharded over 2 and 4 ranks must return, on EVERY rank, the bit-identical proof,
 folded LCCCS and folded witness of the unsharded run (which test_gpu_parity pins to the oracle).  Ranks share cuda:0 here and
 exchange through gloo; on a multi-GPU node the same code runs one rank per GPU over RCCL (bench.py --parallelism shard)."""
 import json
@@ -25,16 +25,17 @@ WORKER = textwrap.dedent('''
     for name in os.environ["LF_CASES"].split(","):
         wl = make_workload(name)
         def run(sharded):
-            ctx = api.Context(0)
+            ctx = api.Context(0, ring=wl.ring)
+            tr = lambda: api.PoseidonTranscript(ring=wl.ring)
             if sharded:
                 ctx.set_sharding(rank, world, lfd.make_allgather())
             ctx.load_ccs(wl)
             scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
             wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
             cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
-            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
-            lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
-            lc2, w1, proof2 = api.NIFSProver.prove(ctx, lc, w0, cccs, wit, api.PoseidonTranscript())   # chained step
+            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+            lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+            lc2, w1, proof2 = api.NIFSProver.prove(ctx, lc, w0, cccs, wit, tr())   # chained step
             h = hashlib.sha256()
             for a in (cccs, acc, lc, proof, w0.f_coeff, lc2, proof2, w1.f_coeff):
                 h.update(np.ascontiguousarray(a).tobytes())
@@ -56,7 +57,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,cases", [(2, "T10,G5,T12"), (4, "T12")])
+@pytest.mark.parametrize("world,cases", [(2, "T10,G5,T12"), (4, "T12"), (2, "B8,B10,BDP"), (4, "B14")])
 def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
