@@ -164,8 +164,9 @@ void lf_transcript_absorb_ring(lf_transcript *, const uint64_t *elems, size_t n)
 void lf_transcript_get_challenge(lf_transcript *, uint64_t *fq3_out);
 void lf_transcript_get_short_challenge(lf_transcript *, uint64_t *coeff_out);
 void lf_poseidon_params(uint64_t *ark /* 720 */, uint64_t *mds /* 576 */);
-/* one Poseidon permutation on 24 words; plain != 0 selects the textbook round loop instead of the
- * (output-identical) sparse-matrix partial rounds the transcript uses */
+/* one Poseidon permutation on 24 words; plain = 0: the transcript's path (sparse-matrix partial rounds; AVX-512 IFMA / AVX2
+ * lanes chosen at run time, LF_POSEIDON_SCALAR=1 disables them), 1: the textbook round loop, 2: the scalar sparse-matrix code.
+ * All three give the same output. */
 void lf_poseidon_permute(uint64_t *state, int plain);
 void lf_poseidon_params_ring(uint64_t *ark, uint64_t *mds, int ring);
 void lf_poseidon_permute_ring(uint64_t *state, int plain, int ring);

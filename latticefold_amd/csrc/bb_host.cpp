@@ -15,6 +15,12 @@
 
 namespace lfbb {
 
+namespace simd512 {   // bb_poseidon_avx512.cc (host-only translation unit, entered after a cpuid check)
+bool supported();
+void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const u64 *row, const u64 *col, const u64 *post);
+void permute(u64 st[24]);
+}  // namespace simd512
+
 u64 hpow(u64 a, u64 e) {
     u64 r = 1;
     a %= BB_P;
@@ -251,6 +257,7 @@ inline void matvec_t(const u32 (*MT)[24], const u64 *x, u64 *out) {
 #ifdef BB_POSEIDON_SIMD
 simd::Tables g_simd;
 #endif
+int g_path = 0;           // 0 scalar, 1 AVX2 (bb_poseidon_simd.h), 2 AVX-512 IFMA (bb_poseidon_avx512.cc)
 u32 g_mdsT[24][24];       // MDS transposed
 u32 g_postT[24][24];      // deferred factor of the sparse partial rounds, transposed (23 x 23 used)
 
@@ -321,9 +328,15 @@ void init_all() {
         for (int j = 0; j < W; j++) g_mdsT[j][i] = (u32)g_mds[i * W + j];
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) g_postT[j][i] = (u32)g_opt.post[i][j];
+    if (getenv("LF_POSEIDON_SCALAR")) return;
 #ifdef BB_POSEIDON_SIMD
     simd::build_tables(g_simd, g_ark, g_mds, g_opt.cst, g_opt.e00, g_opt.row, g_opt.col, g_opt.post);
+    g_path = 1;
 #endif
+    if (simd512::supported() && !getenv("LF_POSEIDON_AVX2")) {
+        simd512::build(g_ark, g_mds, &g_opt.cst[0][0], g_opt.e00, &g_opt.row[0][0], &g_opt.col[0][0], &g_opt.post[0][0]);
+        g_path = 2;
+    }
 }
 inline void full_round(u64 st[W], const u64 *ark) {
     u64 nw[W];
@@ -353,11 +366,11 @@ void BbTranscript::permute_plain(u64 st[24]) {
 }
 void BbTranscript::permute(u64 st[24]) {
     std::call_once(g_once, init_all);
+    if (g_path == 2) { simd512::permute(st); return; }
 #ifdef BB_POSEIDON_SIMD
-    simd::permute(g_simd, st);
-#else
-    permute_scalar(st);
+    if (g_path == 1) { simd::permute(g_simd, st); return; }
 #endif
+    permute_scalar(st);
 }
 void BbTranscript::permute_scalar(u64 st[24]) {
     std::call_once(g_once, init_all);

@@ -851,12 +851,14 @@ void lf_transcript_get_short_challenge(lf_transcript *t, uint64_t *o) {
     else t->t.get_short_challenge(o);
 }
 void lf_poseidon_permute(uint64_t *state, int plain) {
-    if (plain) Transcript::permute_plain(state);
+    if (plain == 2) Transcript::permute_scalar(state);
+    else if (plain) Transcript::permute_plain(state);
     else Transcript::permute(state);
 }
 void lf_poseidon_permute_ring(uint64_t *state, int plain, int ring) {
     if (ring == LF_RING_BABYBEAR) {
-        if (plain) lfbb::BbTranscript::permute_plain(state);
+        if (plain == 2) lfbb::BbTranscript::permute_scalar(state);
+        else if (plain) lfbb::BbTranscript::permute_plain(state);
         else lfbb::BbTranscript::permute(state);
     } else lf_poseidon_permute(state, plain);
 }

@@ -3,6 +3,7 @@
 // (challenge set), rings/poseidon/goldilocks.rs:7-1425 (Poseidon parameters: regenerated, not copied),
 // latticefold/src/transcript/poseidon.rs:29-75 (transcript), ark-crypto-primitives 0.4.0 PoseidonSponge.
 #include "lf_host.h"
+#include "lf_poseidon_simd.h"
 
 #include <string.h>
 
@@ -357,6 +358,17 @@ void partial_opt_init() {
         for (int j = 0; j < n; j++) g_opt.post[i][j] = Eprev[(size_t)i * n + j];
 }
 
+// AVX-512 IFMA lanes (lf_poseidon_simd.cc) when the CPU has them; LF_POSEIDON_SCALAR=1 keeps the scalar path
+bool g_simd = false;
+void init_all() {
+    poseidon_init();
+    partial_opt_init();
+    if (psimd::supported() && !getenv("LF_POSEIDON_SCALAR")) {
+        psimd::build(g_ark, g_mds, &g_opt.cst[0][0], g_opt.e00, &g_opt.row[0][0], &g_opt.col[0][0], &g_opt.post[0][0]);
+        g_simd = true;
+    }
+}
+
 inline void full_round(u64 st[W], const u64 *ark) {
     u64 nw[W];
     for (int i = 0; i < W; i++) st[i] = sbox(fq_add(st[i], ark[i]));
@@ -366,14 +378,14 @@ inline void full_round(u64 st[W], const u64 *ark) {
 }  // namespace
 
 void Transcript::params(const u64 **ark, const u64 **mds) {
-    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
+    std::call_once(g_once, init_all);
     *ark = g_ark;
     *mds = g_mds;
 }
 
 // plain definition (arkworks PoseidonSponge::permute): used by the self-test
 void Transcript::permute_plain(u64 st[24]) {
-    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
+    std::call_once(g_once, init_all);
     u64 nw[W];
     for (int r = 0; r < RF + RP; r++) {
         const u64 *ark = g_ark + r * W;
@@ -387,7 +399,12 @@ void Transcript::permute_plain(u64 st[24]) {
 }
 
 void Transcript::permute(u64 st[24]) {
-    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
+    std::call_once(g_once, init_all);
+    if (g_simd) { psimd::permute(st); return; }
+    permute_scalar(st);
+}
+void Transcript::permute_scalar(u64 st[24]) {
+    std::call_once(g_once, init_all);
     for (int r = 0; r < RF / 2; r++) full_round(st, g_ark + r * W);
     for (int r = 0; r < RP; r++) {
         for (int i = 0; i < W; i++) st[i] = fq_add(st[i], g_opt.cst[r][i]);
@@ -416,7 +433,7 @@ void Transcript::permute(u64 st[24]) {
 }
 
 Transcript::Transcript() : squeezing_(false), idx_(0) {
-    std::call_once(g_once, [] { poseidon_init(); partial_opt_init(); });
+    std::call_once(g_once, init_all);
     memset(st_, 0, sizeof(st_));
 }
 

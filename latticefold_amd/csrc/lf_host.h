@@ -71,7 +71,8 @@ class Transcript {
     void absorb_u64_as_ring(u64 v);                       // absorb(R::from(v as u128))
     Fq3 get_challenge();                                  // squeeze tau words, absorb them back
     void get_short_challenge(u64 coeff_out[24]);          // TranscriptWithShortChallenges (Goldilocks set)
-    static void permute(u64 st[24]);        // sparse-factorised partial rounds (same output)
+    static void permute(u64 st[24]);        // sparse-factorised partial rounds (same output); AVX-512 IFMA lanes when available
+    static void permute_scalar(u64 st[24]); // the same factorisation, scalar (reference for the SIMD path)
     static void permute_plain(u64 st[24]);  // textbook definition, for the self-test
     static void params(const u64 **ark, const u64 **mds);
 

@@ -62,6 +62,35 @@ def test_sparse_partial_rounds_equal_plain_permutation():
     assert (api.poseidon_permute(np.zeros(24, dtype=np.uint64)) == api.poseidon_permute(np.zeros(24, dtype=np.uint64), True)).all()
 
 
+def test_simd_permutation_equals_scalar_and_plain():
+    """plain = 0: transcript path (AVX-512 IFMA lanes when the CPU has them), 2: scalar sparse factorisation, 1: textbook loop."""
+    P = 0xFFFFFFFF00000001
+    edge = [0, 1, P - 1, P - 2, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 32, (P - 1) // 2]
+    rng = np.random.default_rng(11)
+    for it in range(400):
+        if it < 40:
+            st = np.array([edge[(it * 7 + i * 3 + (i * it) % 5) % 8] for i in range(24)], dtype=np.uint64)
+        else:
+            st = (rng.integers(0, 2**63, 24, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 24, dtype=np.uint64)) % np.uint64(P)
+        a = api.poseidon_permute(st, 0)
+        assert (a == api.poseidon_permute(st, 2)).all()
+        if it < 80:
+            assert (a == api.poseidon_permute(st, 1)).all()
+        assert (a < np.uint64(P)).all()
+
+
+def test_scalar_transcript_env_gives_same_challenges():
+    import subprocess, sys, os
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from latticefold_amd import api; t = api.PoseidonTranscript(); "
+            "t.absorb(np.arange(24 * 50, dtype=np.uint64).reshape(50, 24)); print(' '.join(str(int(v)) for v in t.get_challenge()))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for env in ({}, {"LF_POSEIDON_SCALAR": "1"}):
+        e = dict(os.environ); e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0].split()) == 3
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

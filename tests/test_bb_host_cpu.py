@@ -24,6 +24,30 @@ def test_poseidon_params_and_sparse_equals_plain(kats):
         assert (a == b).all() and (a == o).all()
 
 
+def test_simd_permutation_paths_agree():
+    """transcript path (AVX-512 IFMA or AVX2 lanes, chosen at run time) vs scalar sparse factorisation vs textbook loop,
+    including edge words; and the same digest from subprocesses that force the AVX2 and the scalar path."""
+    import os, subprocess, sys
+    edge = [0, 1, PB - 1, PB - 2, (PB - 1) // 2, (PB + 1) // 2, 2**27, 2**31 - 1 - PB + PB - 2**27]
+    rng = np.random.default_rng(12)
+    for it in range(300):
+        st = (np.array([edge[(it * 5 + i * 3 + (i * it) % 7) % 8] % PB for i in range(24)], dtype=np.uint64) if it < 40
+              else rng.integers(0, PB, size=24, dtype=np.uint64))
+        a = api.poseidon_permute(st, 0, "babybear")
+        assert (a == api.poseidon_permute(st, 2, "babybear")).all() and (a < PB).all()
+        if it < 80:
+            assert (a == api.poseidon_permute(st, 1, "babybear")).all()
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from latticefold_amd import api; "
+            "s = np.arange(24, dtype=np.uint64) * np.uint64(77777);\n"
+            "for _ in range(5): s = api.poseidon_permute(s, 0, 'babybear')\n"
+            "print(' '.join(str(int(v)) for v in s))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for env in ({}, {"LF_POSEIDON_AVX2": "1"}, {"LF_POSEIDON_SCALAR": "1"}):
+        e = dict(os.environ); e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0].split()) == 24
+
+
 def test_transcript_matches_oracle(kats):
     t, o = api.PoseidonTranscript(ring="babybear"), lfo.Transcript()
     rng = np.random.default_rng(9)
