@@ -471,7 +471,9 @@ int BbCtx::ajtai_commit(const uint64_t *f, size_t n, size_t batch, uint64_t *out
     RET(c->tbuf("io_a", batch * n * RE, &F));
     RET(c->tbuf("io_o", batch * c->kappa * RE, &o));
     for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * RE, n, F + b * RE * n));
-    RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, false));
+    c->ev_reset();
+    RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
+    c->ev_collect();
     RET(down_small(c, o, batch * c->kappa * RE, out));
     return exchange_modsum(c, out, batch * c->kappa * RE);
 }

@@ -530,7 +530,9 @@ int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64
     RET(c->tbuf("io_a", batch * n * 24, &F));
     RET(c->tbuf("io_b", batch * c->kappa * 24, &o));
     for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * 24, n, F + b * 24 * n));
-    RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, false));
+    c->ev_reset();
+    RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
+    c->ev_collect();
     return commit_download(c, o, batch * c->kappa * 24, out);
 }
 

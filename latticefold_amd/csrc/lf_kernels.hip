@@ -434,7 +434,7 @@ __device__ __forceinline__ Fq3 acc5_finish(const Acc5 &a, u64 nu) {
     r.c[2] = accp_reduce(a.s[2]);
     return r;
 }
-constexpr int AJ_THREADS = 448;  // 7 waves: 26 x 15 = 390 outputs (a 6-full-wave + tail-kernel split measured slower)
+constexpr int AJ_THREADS = 512;  // 8 waves per block, two blocks per CU (LDS): four wave-slots per SIMD
 // Toom-3 at the F_{p^3} level with lazy accumulation.  For a = a0 + a1 Y + a2 Y^2 (same for b) the product
 // r(Y) = a(Y) b(Y) (degree 4) is determined by the five pointwise products at Y = 0, 1, -1, 2, inf.  Those five products are
 // summed over the whole j-range un-reduced (AccP), so one multiply-accumulate costs 20 v_mad_u64_u32 (schoolbook 36,
@@ -445,9 +445,17 @@ struct Acc6 { AccP s[5]; };
 // Row stride = AJ_T*48 + 16 bytes: rows of one 16-lane read group fall into distinct 16-byte slots (conflict-free).
 constexpr int AJ_T = 32;                          // columns per tile
 constexpr int AJ_ROWB = AJ_T * 48 + 16;           // bytes per row
+// SIMD balance.  A CU places the waves of a workgroup round-robin on its four SIMDs (tools/wave_place.hip): two co-resident
+// 7-wave blocks (26 x 15 = 390 outputs, one thread each) always leave two SIMDs with four full-cost waves and two with
+// three, i.e. 12.2 useful wave-loads on 16 wave-slots.  Layout used instead when 384 <= nout <= 448: 8 waves per block;
+// waves 0-3 carry 256 outputs, one thread each (`nfull`); waves 4-7 carry the next 128 outputs (`rem`) on TQ = 2 lanes each,
+// lane q taking columns q, q+2, .. of the tile -- half the multiply phase.  Every SIMD then holds 2 x (1 + 1/2) = 3
+// wave-loads.  The TQ partial sums of such an output are separate rows of `tailp` and are added by k_ajtai_reduce (the
+// interpolation is linear); outputs beyond nfull + rem (6 of 390) go to the dot-product kernel k_ajtai_tail.
+// TQ = 1 / rem = 0 is the plain one-thread-per-output map used for every other shape.
 template <bool NU, int NT>
 __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits,
-                                                         u64 *partial) {
+                                                         u32 nfull, u32 rem, u32 TQ, u64 *partial, u64 *tailp) {
     extern __shared__ __align__(16) unsigned char smem[];
     const u32 slot = blockIdx.y, split = blockIdx.x;
     const u32 rows = kappa + batch;
@@ -458,14 +466,17 @@ __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kap
     Acc6 acc;
 #pragma unroll
     for (int i = 0; i < 5; i++) accp_zero(acc.s[i]);
-    const u32 o0 = threadIdx.x;
+    const bool is_tail = threadIdx.x >= nfull;                 // wave-uniform (nfull is a multiple of 64)
+    const u32 tl = threadIdx.x - nfull, tq = is_tail ? tl % TQ : 0;
+    const u32 o0 = is_tail ? nfull + tl / TQ : threadIdx.x;
     const u32 i0 = o0 / batch, k0 = o0 % batch;
-    const bool active = o0 < nout;
+    const bool active = is_tail ? tl < rem * TQ : true;
     const unsigned char *pa = smem + (size_t)(active ? i0 : 0) * AJ_ROWB;
     const unsigned char *pf = smem + (size_t)(active ? kappa + k0 : kappa) * AJ_ROWB;
+    const u32 nthr = blockDim.x;
     for (size_t jt = j0; jt < j1; jt += AJ_T) {
         __syncthreads();
-        for (u32 idx = threadIdx.x; idx < rows * AJ_T; idx += NT) {
+        for (u32 idx = threadIdx.x; idx < rows * AJ_T; idx += nthr) {
             u32 jj = idx % AJ_T, r = idx / AJ_T;
             size_t j = jt + jj;
             u64 v0 = 0, v1 = 0, v2 = 0;
@@ -484,7 +495,7 @@ __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kap
             *(u64 *)(dstp + 2) = v2;                                    // a(inf)
         }
         __syncthreads();
-        if (active) {
+        if (!is_tail) {
 #pragma unroll 4
             for (int jj = 0; jj < AJ_T; jj++) {
                 const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
@@ -494,10 +505,29 @@ __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kap
                 accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
                 accp_mad(acc.s[4], x2, y2);
             }
+        } else if (active && TQ == 2) {
+#pragma unroll 4
+            for (int jj = (int)tq; jj < AJ_T; jj += 2) {
+                const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
+                ulonglong2 x0 = xa[0], x1 = xa[1], y0 = yf[0], y1 = yf[1];
+                u64 x2 = *(const u64 *)(xa + 2), y2 = *(const u64 *)(yf + 2);
+                accp_mad(acc.s[0], x0.x, y0.x); accp_mad(acc.s[1], x0.y, y0.y);
+                accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
+                accp_mad(acc.s[4], x2, y2);
+            }
+        } else if (active) {
+            for (u32 jj = tq; jj < (u32)AJ_T; jj += TQ) {
+                const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
+                ulonglong2 x0 = xa[0], x1 = xa[1], y0 = yf[0], y1 = yf[1];
+                u64 x2 = *(const u64 *)(xa + 2), y2 = *(const u64 *)(yf + 2);
+                accp_mad(acc.s[0], x0.x, y0.x); accp_mad(acc.s[1], x0.y, y0.y);
+                accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
+                accp_mad(acc.s[4], x2, y2);
+            }
         }
     }
-    // partial[split][slot][o][3]   (only outputs o < blockDim.x are produced here)
-    u64 *dst = partial + ((size_t)split * 8 + slot) * nout * 3;
+    // full waves: partial[split][slot][o][3];  ragged wave: tailp[split*TQ + q][slot][o - nfull][3]
+    u64 *dst = is_tail ? tailp + (((size_t)split * TQ + tq) * 8 + slot) * rem * 3 - (size_t)nfull * 3 : partial + ((size_t)split * 8 + slot) * nout * 3;
     if (active) {
         const u64 INV2 = 0x7FFFFFFF80000001ULL;   // (p+1)/2
         const u64 INV3 = 0xAAAAAAAA00000001ULL;   // (2p+1)/3
@@ -517,14 +547,20 @@ __global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kap
         dst[(size_t)o0 * 3] = c0; dst[(size_t)o0 * 3 + 1] = c1; dst[(size_t)o0 * 3 + 2] = c2;
     }
 }
-// out[k][i][3*slot+c] = sum_split partial   (outputs o < nmain)
-__global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, u32 kappa, u32 batch, u32 splits, u32 nmain, u64 *out) {
+// out[k][i][3*slot+c] = sum_split partial   (outputs o < nmain; those >= nfull have splits * TQ rows in tailp)
+__global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, const u64 *tailp, u32 kappa, u32 batch, u32 splits, u32 nmain, u32 nfull,
+                                                      u32 TQ, u64 *out) {
     u32 idx = blockIdx.x * 256 + threadIdx.x;
     u32 nout = kappa * batch;
     if (idx >= 8 * nmain * 3) return;
     u32 c = idx % 3, o = (idx / 3) % nmain, slot = idx / (3 * nmain);
     u64 acc = 0;
-    for (u32 sp = 0; sp < splits; sp++) acc = fq_add(acc, partial[(((size_t)sp * 8 + slot) * nout + o) * 3 + c]);
+    if (o < nfull) {
+        for (u32 sp = 0; sp < splits; sp++) acc = fq_add(acc, partial[(((size_t)sp * 8 + slot) * nout + o) * 3 + c]);
+    } else {
+        u32 rem = nmain - nfull;
+        for (u32 sp = 0; sp < splits * TQ; sp++) acc = fq_add(acc, tailp[(((size_t)sp * 8 + slot) * rem + (o - nfull)) * 3 + c]);
+    }
     u32 i = o / batch, k = o % batch;
     out[((size_t)k * kappa + i) * 24 + 3 * slot + c] = acc;
 }
@@ -554,18 +590,21 @@ __global__ void __launch_bounds__(256) k_ajtai_tail_reduce(const u64 *partial, u
     block_sum_store<1>(acc, out + ((size_t)k * kappa + i) * 24 + w);
 }
 size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) {
-    size_t a = (size_t)splits * 8 * kappa * batch * 3, b = (size_t)RED_BLOCKS_AJ * 64 * 24;
-    return a + b;
+    size_t a = (size_t)splits * 8 * kappa * batch * 3, b = (size_t)RED_BLOCKS_AJ * 64 * 24, tl = (size_t)splits * 512 * 8 * 3;
+    return a + b + tl;
 }
 void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits, u64 *partial, u64 *out,
                   hipStream_t s) {
     u32 nout = kappa * batch;
-    // one (i,k) output per thread; callers keep kappa*batch <= AJ_THREADS (commit_dev), any excess goes to the dot-product tail
-    u32 nmain = nout < (u32)AJ_THREADS ? nout : (u32)AJ_THREADS;
+    // one (i,k) output per thread; callers keep kappa*batch <= 448 (commit_dev), any excess goes to the dot-product tail
+    u32 nmain = nout < 448u ? nout : 448u;
     size_t shm = (size_t)(kappa + batch) * AJ_ROWB;
-    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-    else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(AJ_THREADS), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * nmain * 3, 256)), dim3(256), 0, s, partial, kappa, batch, splits, nmain, out);
+    u32 nfull = nmain, rem = 0, TQ = 1, nthr = (nmain + 63) / 64 * 64;
+    if (nout >= 384 && nout <= 448) { nfull = 256; rem = 128; TQ = 2; nthr = 512; nmain = 384; }   // SIMD-balanced layout (see k_ajtai)
+    u64 *tailp = partial + (size_t)splits * 8 * kappa * batch * 3 + (size_t)RED_BLOCKS_AJ * 64 * 24;
+    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(nthr), shm, s, t, A, kappa, n, F, ldF, batch, splits, nfull, rem, TQ, partial, tailp);
+    else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(nthr), shm, s, t, A, kappa, n, F, ldF, batch, splits, nfull, rem, TQ, partial, tailp);
+    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * nmain * 3, 256)), dim3(256), 0, s, partial, tailp, kappa, batch, splits, nmain, nfull, TQ, out);
     if (nmain < nout) {
         u32 ntail = nout - nmain;
         u64 *tp = partial + (size_t)splits * 8 * kappa * batch * 3;
