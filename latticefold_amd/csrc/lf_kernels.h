@@ -128,6 +128,10 @@ void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int
 // general round on materialised tables F [2K*3][24][ldF] (b = 2)
 void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev,
                        u64 *partial, u64 *out, hipStream_t s);
+// the same round with fix_variables of the previous round's tables fused in (unsharded driver, large rounds): reads entries
+// 4p..4p+3 of Fprev, stores the fixed pair to Fout for the next round
+void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *Fprev, size_t ldprev, Fq3Const r, u64 *Fout, size_t ldout, u32 K,
+                           const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s);
 size_t round_partial_words();
 
 // ---- folded witness (a13 in coefficient domain) ---------------------------------------------------------------

@@ -1273,20 +1273,54 @@ void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int3
 // general round on materialised f-hat tables.  grid = (pair blocks, 8 slots, kd chunks): when few pairs remain the
 // 2K*3 tables are split over blockIdx.z -- the round message is linear in the per-chunk partial sums Q, so each chunk
 // contributes eqB(X)*Q_chunk(X) and chunk 0 adds the g1/g3 products.
-template <bool NU>
+//
+// MODE selects where a pair (f0, f1) of table kd comes from (the multiply phase is ALU-bound, so the producer's memory
+// traffic hides under it and the separate memory-bound pass disappears):
+//   0  F holds the current tables:                         f0 = F[2p], f1 = F[2p+1]
+//   1  fused fix_variables: Fsrc.F holds the PREVIOUS round's tables,  f0 = F[4p] + r (F[4p+1] - F[4p]),  f1 likewise from
+//      4p+2, 4p+3; the fixed pair is also stored to Fsrc.out (ld = Fsrc.ldo) for the next round
+// (Fusing the round-3 materialisation from the coefficient planes the same way measured slower than k_fold_materialize2 + mode 0:
+// the digit extraction costs more ALU than the 4.8 GB pass it saves.)
+struct FoldSrc {
+    u64 *out; size_t ldo;                 // mode 1: where the fixed pair is written (entries 2p, 2p+1)
+    Fq3Const r;
+};
+template <bool NU, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow,
-                                                    u64 *partial) {
+                                                    FoldSrc src, u64 *partial) {
     u32 slot = blockIdx.y;
     const size_t pend = a.p0 + a.pcnt;
     const u64 nu = t.nu;
     const u32 nkd = 2 * K * 3, per = (nkd + gridDim.z - 1) / gridDim.z;
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
-    F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
+    if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
+    const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
     for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
         if (blockIdx.z == 0) fold_g13<NU>(acc, a, slot, p, nu);
+        // pair of table kd
+        auto load_pair = [&](u32 kd, Fq3 &f0, Fq3 &df) {
+            if (MODE == 0) {
+                const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
+                ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
+                f0 = fq3_make(x0.x, x1.x, x2.x);
+                df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
+            } else if (MODE == 1) {
+                const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF + 4 * p;
+                ulonglong2 a0 = *(const ulonglong2 *)(fp), a1 = *(const ulonglong2 *)(fp + ldF), a2 = *(const ulonglong2 *)(fp + 2 * ldF);
+                ulonglong2 b0 = *(const ulonglong2 *)(fp + 2), b1 = *(const ulonglong2 *)(fp + ldF + 2), b2 = *(const ulonglong2 *)(fp + 2 * ldF + 2);
+                Fq3 lo = fq3_make(a0.x, a1.x, a2.x), hi = fq3_make(b0.x, b1.x, b2.x);
+                f0 = fq3_add(lo, M3<NU>(fq3_sub(fq3_make(a0.y, a1.y, a2.y), lo), rfix, nu));
+                Fq3 f1 = fq3_add(hi, M3<NU>(fq3_sub(fq3_make(b0.y, b1.y, b2.y), hi), rfix, nu));
+                u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
+                *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
+                *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
+                *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
+                df = fq3_sub(f1, f0);
+            }
+        };
         Fq3 Q[4];
         if (NU) {
             // sum_kd mu (f0 + X df)^3 - mu (f0 + X df):  with p = mu f0, q = mu df the cubic coefficients are
@@ -1295,9 +1329,8 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
             Fq3 sp = fq3_zero(), sq = fq3_zero();
             for (u32 kd = kd0; kd < kd1; kd++) {
-                const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
-                ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
-                Fq3 f0 = fq3_make(x0.x, x1.x, x2.x), df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
+                Fq3 f0, df;
+                load_pair(kd, f0, df);
                 Fq3Const mc = mu_pow[kd];
                 Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
                 Fq3 f0s = fq3_mul_2p40(f0, f0), dfs = fq3_mul_2p40(df, df);
@@ -1313,9 +1346,8 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
         } else {
             Q[0] = Q[1] = Q[2] = Q[3] = fq3_zero();
             for (u32 kd = kd0; kd < kd1; kd++) {
-                const u64 *fp = F + ((size_t)kd * 24 + 3 * slot) * ldF;
-                ulonglong2 x0 = *(const ulonglong2 *)(fp + 2 * p), x1 = *(const ulonglong2 *)(fp + ldF + 2 * p), x2 = *(const ulonglong2 *)(fp + 2 * ldF + 2 * p);
-                Fq3 f0 = fq3_make(x0.x, x1.x, x2.x), df = fq3_sub(fq3_make(x0.y, x1.y, x2.y), f0);
+                Fq3 f0, df;
+                load_pair(kd, f0, df);
                 Fq3 f0s = S3<NU>(f0, nu), dfs = S3<NU>(df, nu);
                 Fq3 c0 = fq3_sub(M3<NU>(f0s, f0, nu), f0);
                 Fq3 c3 = M3<NU>(dfs, df, nu);
@@ -1342,8 +1374,9 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     size_t row = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z;
     if (threadIdx.x < 15) partial[row * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
 }
-void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
-                       u64 *out, hipStream_t s) {
+template <int MODE>
+static void launch_fold_round_mode(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev,
+                                   const FoldSrc &src, u64 *partial, u64 *out, hipStream_t s) {
     size_t pairs = a.pcnt;
     u32 gb = (u32)((pairs + 255) / 256);
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
@@ -1357,8 +1390,21 @@ void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, si
         if (pairs * 8 * cc >= 65536) break;
     }
     while (gb * chunks > RED_BLOCKS && chunks > 1) chunks--;
-    LF_LAUNCH(k_fold_round, t.nu2p40, dim3(gb, 8, chunks), dim3(256), s, t, a, F, ldF, K, mu_pow_dev, partial);
+    if (t.nu2p40) hipLaunchKernelGGL((k_fold_round<true, MODE>), dim3(gb, 8, chunks), dim3(256), 0, s, t, a, F, ldF, K, mu_pow_dev, src, partial);
+    else hipLaunchKernelGGL((k_fold_round<false, MODE>), dim3(gb, 8, chunks), dim3(256), 0, s, t, a, F, ldF, K, mu_pow_dev, src, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb * chunks, 120, out);
+}
+void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
+                       u64 *out, hipStream_t s) {
+    FoldSrc src = {};
+    launch_fold_round_mode<0>(t, a, F, ldF, K, mu_pow_dev, src, partial, out, s);
+}
+// round message + fused fix_variables: Fprev [2K*3][24][ldprev] (entries 4p..4p+3 of every pair p) -> Fout [..][ldout]
+void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *Fprev, size_t ldprev, Fq3Const r, u64 *Fout, size_t ldout, u32 K,
+                           const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
+    FoldSrc src = {};
+    src.out = Fout; src.ldo = ldout; src.r = r;
+    launch_fold_round_mode<1>(t, a, Fprev, ldprev, K, mu_pow_dev, src, partial, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
