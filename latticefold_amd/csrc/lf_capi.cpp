@@ -1236,6 +1236,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // Unsharded, rounds >= 4 with many pairs: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel,
     // so the separate memory-bound pass over them vanishes (rounds 4-6 at 2^20 rows: 6.25 -> 5.6 ms).
     const bool fused = Gw == 1 && !getenv("LF_FOLD_UNFUSED");
+    const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 65536;   // entries; tests lower it
     int fmode = 0;                 // producer of this round's pairs: 0 tables, 1 fused fix
     const u64 *prevF = nullptr;
     size_t prevld = 0;
@@ -1289,7 +1290,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                 curF = F[0]; ldF = q;
             } else if (round > 3) {
                 u64 *fd = F[(round & 1) ? 0 : 1];  // round 4 -> F[1], round 5 -> F[0], ...
-                if (fused && ldF >= 65536) { prevF = curF; prevld = ldF; fmode = 1; }
+                if (fused && ldF >= fuse_min && ldF >= 4) { prevF = curF; prevld = ldF; fmode = 1; }
                 else launch_fix_many(c->dcrt, curF, ldF, fd, ldF / 2, ldF, K2 * 3 * 8, r, c->stream());
                 curF = fd; ldF = ldF / 2;
             }

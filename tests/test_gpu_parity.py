@@ -96,7 +96,10 @@ def test_linf_check(ctx):
     assert not ok
 
 
-@pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 4096, 1), (26, 1024, 15), (3, 64, 2), (26, 512, 40)])
+# kappa*batch in [384, 448] takes the SIMD-balanced 8-wave layout of k_ajtai (two lanes per output on waves 4-7, dot-product
+# kernel for the outputs beyond 384); the other shapes the one-thread-per-output map
+@pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 4096, 1), (26, 1024, 15), (3, 64, 2), (26, 512, 40),
+                                           (24, 333, 16), (28, 97, 16), (25, 650, 16)])
 def test_ajtai_commit(ctx, kappa, n, batch):
     A = rnd(100 + kappa, kappa, n, RE)
     f = rnd(200 + n, batch, n, RE)
@@ -216,6 +219,22 @@ def test_fold_step_parity(ctx, name, seed):
     lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, api.PoseidonTranscript())
     lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
     assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
+
+
+@pytest.mark.parametrize("name", ["T10", "G5"])
+def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
+    """rounds >= 4 of the folding sumcheck with fix_variables fused into the round kernel (the driver uses it from 2^16
+    table entries on; LF_FOLD_FUSE_MIN lowers the threshold so the oracle-sized cases take that path) and with the
+    separate k_fix pass: identical proofs, both equal to the oracle's."""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
+    lc_f, w_f, proof_f = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    monkeypatch.delenv("LF_FOLD_FUSE_MIN")
+    monkeypatch.setenv("LF_FOLD_UNFUSED", "1")
+    lc_u, w_u, proof_u = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    assert (proof_f == proof_o).all() and (lc_f == lc_o).all() and (w_f.f == f0_o).all()
+    assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
 
 
 # ---- sumcheck through the ABI, split at the transcript (SURVEY 8b) -----------------------------------------------
