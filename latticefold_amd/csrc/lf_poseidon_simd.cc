@@ -24,40 +24,54 @@ namespace {
 constexpr int W = 24, RF = 8, RP = 22;
 constexpr u64 P = 0xFFFFFFFF00000001ULL, EPS = 0xFFFFFFFFULL;
 
+constexpr int NX = W + RP;   // columns of the closing map: 24 state words + 22 S-box outputs
 struct Tables {
     alignas(64) u64 mds0[W][W], mds1[W][W];     // [j][i] = M[i][j] and its top 12 bits
-    alignas(64) u64 post0[W][W], post1[W][W];   // the deferred factor embedded as diag(1, post)
     alignas(64) u64 arkf[RF][W];                // constants of the full rounds
-    alignas(64) u64 cst[RP][W];                 // partial-round constants, lane 0 cleared (kept in cst0)
-    alignas(64) u64 row0[RP][W], row1[RP][W];   // lane 0 cleared (e00 is applied on the scalar side)
-    alignas(64) u64 col0[RP][W], col1[RP][W];   // lane 0 cleared
-    u64 cst0[RP], e00[RP];
+    // partial rounds in scalar form (see permute): D = SX x, s0_{r+1} = D_r + K_r + sum_{i<=r} G[r][i] X_i,
+    // closing map  state' = FIN [x ; X] + FK
+    alignas(64) u64 sx0[W][W], sx1[W][W];       // [j][r] = coefficient of state word j in D_r (column 0 and lanes >= 22 zero)
+    alignas(64) u64 fin0[NX][W], fin1[NX][W];   // [j][i]: columns 0..23 state words, 24..45 the S-box outputs X_r; lane 0 zero
+    alignas(64) u64 fk0[W], fk1[W];             // constant of the closing map (52-bit / top-12-bit halves)
+    u64 cst0[RP], K[RP], G[RP][RP];
 };
 Tables T;
 
-inline u64 canon(u64 a) { return a >= P ? a - P : a; }
-inline u64 reduce128(u64 lo, u64 hi) {   // canonical
+// scalar helpers.  The word-0 chain of the partial rounds is latency bound, so its products are reduced only "loosely" (any
+// value below 2^64 is a valid multiplicand) with the shortest dependent sequence: the borrow of lo - hh is predictably absent
+// (it needs lo < 2^32) and is a branch, the carry of the final add is data dependent and handled with a mask.
+inline u64 canon(u64 a) { return a - (P & (0 - (u64)(a >= P))); }
+inline u64 reduce128_loose(u64 lo, u64 hi) {
     u64 hh = hi >> 32, hl = hi & EPS;
-    u64 t0 = lo - hh;
-    if (lo < hh) t0 -= EPS;
+    u64 t0 = lo - hh, r;
+    if (__builtin_expect(lo < hh, 0)) t0 -= EPS;
     u64 t1 = (hl << 32) - hl;
-    u64 r = t0 + t1;
-    if (r < t1) r += EPS;
-    return canon(r);
+    u64 c = __builtin_add_overflow(t0, t1, &r);
+    return r + (EPS & (0 - c));
 }
-inline u64 mulmod(u64 a, u64 b) {
+inline u64 reduce128(u64 lo, u64 hi) { return canon(reduce128_loose(lo, hi)); }
+inline u64 mulmod(u64 a, u64 b) {   // canonical
     u128 pr = (u128)a * b;
     return reduce128((u64)pr, (u64)(pr >> 64));
 }
-inline u64 addmod(u64 a, u64 b) {
-    u64 r = a + b;
-    if (r < a || r >= P) r -= P;
-    return r;
+inline u64 mul_loose(u64 a, u64 b) {   // any a, b; result below 2^64
+    u128 pr = (u128)a * b;
+    return reduce128_loose((u64)pr, (u64)(pr >> 64));
 }
-inline u64 submod(u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
-inline u64 sbox(u64 x) {
-    u64 x2 = mulmod(x, x), x3 = mulmod(x2, x), x4 = mulmod(x2, x2);
-    return mulmod(x4, x3);
+inline u64 addmod(u64 a, u64 b) {   // canonical operands
+    u64 r;
+    u64 c = __builtin_add_overflow(a, b, &r);
+    return r - (P & (0 - (c | (u64)(r >= P))));
+}
+inline u64 add_loose(u64 a, u64 b) {   // a below 2^64, b canonical; result below 2^64
+    u64 r;
+    u64 c = __builtin_add_overflow(a, b, &r);
+    return r + (EPS & (0 - c));
+}
+inline u64 submod(u64 a, u64 b) { return a - b + (P & (0 - (u64)(a < b))); }
+inline u64 sbox_loose(u64 x) {
+    u64 x2 = mul_loose(x, x), x3 = mul_loose(x2, x), x4 = mul_loose(x2, x2);
+    return mul_loose(x4, x3);
 }
 
 // W0 (< 2^60) + 2^52 W52 (W52 < 2^60) - 2^8 W104 (W104 < 2^30)  ->  canonical residue
@@ -104,17 +118,17 @@ inline V vadd(V a, V b) {   // canonical + canonical -> canonical
     return _mm512_mask_sub_epi64(r, (__mmask8)(g & ~c), r, pp);
 }
 
-// x <- M x for a 24 x 24 matrix given column-wise (t0[j] = column j, t1[j] = its top 12 bits)
-inline void matvec(const u64 (*t0)[W], const u64 (*t1)[W], V x[3]) {
-    alignas(64) u64 xl[W], xh[W];
-    for (int g = 0; g < 3; g++) {
-        _mm512_store_si512((void *)(xl + 8 * g), x[g]);
-        _mm512_store_si512((void *)(xh + 8 * g), _mm512_srli_epi64(x[g], 52));
-    }
+// out = sum_j col_j * x_j (+ seed) for ncols columns given column-wise (t0[j] = column j, t1[j] = its top 12 bits);
+// xl/xh = the words x_j and their top 12 bits
+inline void matvec_n(const u64 (*t0)[W], const u64 (*t1)[W], int ncols, const u64 *xl, const u64 *xh, const V *seed0, const V *seed52, V out[3]) {
     const V z = _mm512_setzero_si512();
     V a0[3], a52[3], a52b[3], a52c[3], a104[3], a104b[3], a104c[3];
-    for (int g = 0; g < 3; g++) a0[g] = a52[g] = a52b[g] = a52c[g] = a104[g] = a104b[g] = a104c[g] = z;
-    for (int j = 0; j < W; j++) {
+    for (int g = 0; g < 3; g++) {
+        a0[g] = seed0 ? seed0[g] : z;
+        a52[g] = seed52 ? seed52[g] : z;
+        a52b[g] = a52c[g] = a104[g] = a104b[g] = a104c[g] = z;
+    }
+    for (int j = 0; j < ncols; j++) {
         V b = _mm512_set1_epi64((long long)xl[j]), b1 = _mm512_set1_epi64((long long)xh[j]);
 #pragma GCC unroll 3
         for (int g = 0; g < 3; g++) {
@@ -129,8 +143,20 @@ inline void matvec(const u64 (*t0)[W], const u64 (*t1)[W], V x[3]) {
         }
     }
     for (int g = 0; g < 3; g++)
-        x[g] = reduce(a0[g], _mm512_add_epi64(_mm512_add_epi64(a52[g], a52b[g]), a52c[g]),
-                      _mm512_add_epi64(_mm512_add_epi64(a104[g], a104b[g]), a104c[g]));
+        out[g] = reduce(a0[g], _mm512_add_epi64(_mm512_add_epi64(a52[g], a52b[g]), a52c[g]),
+                        _mm512_add_epi64(_mm512_add_epi64(a104[g], a104b[g]), a104c[g]));
+}
+inline void split_words(const V x[3], u64 *xl, u64 *xh) {
+    for (int g = 0; g < 3; g++) {
+        _mm512_store_si512((void *)(xl + 8 * g), x[g]);
+        _mm512_store_si512((void *)(xh + 8 * g), _mm512_srli_epi64(x[g], 52));
+    }
+}
+// x <- M x for a 24 x 24 matrix
+inline void matvec(const u64 (*t0)[W], const u64 (*t1)[W], V x[3]) {
+    alignas(64) u64 xl[W], xh[W];
+    split_words(x, xl, xh);
+    matvec_n(t0, t1, W, xl, xh, nullptr, nullptr, x);
 }
 
 inline void full_round(V x[3], const u64 *ark) {
@@ -155,76 +181,94 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
         for (int j = 0; j < W; j++) {
             T.mds0[j][i] = mds[i * W + j];
             T.mds1[j][i] = mds[i * W + j] >> 52;
-            u64 e = (i == 0 || j == 0) ? (u64)(i == j) : post[(i - 1) * (W - 1) + (j - 1)];
-            T.post0[j][i] = e;
-            T.post1[j][i] = e >> 52;
         }
     for (int r = 0; r < RF; r++) {
         int src = r < RF / 2 ? r : RP + r;
         memcpy(T.arkf[r], ark + (size_t)src * W, W * 8);
     }
+    // Symbolic run of the 22 sparse partial rounds.  Every state word 1..23 is an affine form over
+    //   [ x_1..x_23 (words on entry) | X_0..X_21 (S-box outputs of word 0) | 1 ]
+    // because a partial round is  xs = state[1..] + cst_r,  X_r = sbox(s0 + c0_r),  s0' = e00_r X_r + row_r . xs,
+    // state'[1..] = xs + col_r X_r -- linear except for the S-box.  Collecting coefficients turns the rounds into
+    //   D = SX x (one mat-vec up front),  s0_{r+1} = D_r + K_r + sum_{i<=r} G[r][i] X_i (scalar chain),
+    //   state' = diag(1, post) [s0_22 ; x + CX X + ck] (one closing mat-vec over [x ; X]).
+    const int n = W - 1, NB = n + RP + 1;   // basis size
+    static u64 form[W - 1][W - 1 + RP + 1];
+    memset(form, 0, sizeof(form));
+    for (int i = 0; i < n; i++) { form[i][i] = 1; form[i][NB - 1] = cst[0 * W + 1 + i]; }
     for (int r = 0; r < RP; r++) {
         T.cst0[r] = cst[r * W];
-        T.e00[r] = e00[r];
-        for (int i = 1; i < W; i++) {
-            T.cst[r][i] = cst[r * W + i];
-            T.row0[r][i] = row[r * (W - 1) + i - 1];
-            T.row1[r][i] = T.row0[r][i] >> 52;
-            T.col0[r][i] = col[r * (W - 1) + i - 1];
-            T.col1[r][i] = T.col0[r][i] >> 52;
+        u64 dotf[W - 1 + RP + 1];
+        for (int b = 0; b < NB; b++) {
+            u64 a = 0;
+            for (int i = 0; i < n; i++) a = addmod(a, mulmod(row[r * n + i], form[i][b]));
+            dotf[b] = a;
+        }
+        for (int j = 0; j < n; j++) { T.sx0[1 + j][r] = dotf[j]; T.sx1[1 + j][r] = dotf[j] >> 52; }
+        for (int i = 0; i < r; i++) T.G[r][i] = dotf[n + i];
+        T.G[r][r] = e00[r];
+        T.K[r] = dotf[NB - 1];
+        for (int i = 0; i < n; i++) {
+            form[i][n + r] = addmod(form[i][n + r], col[r * n + i]);
+            if (r + 1 < RP) form[i][NB - 1] = addmod(form[i][NB - 1], cst[(r + 1) * W + 1 + i]);
         }
     }
+    // closing map: words 1..23 = post * form
+    for (int i = 0; i < n; i++)
+        for (int b = 0; b < NB; b++) {
+            u64 a = 0;
+            for (int k = 0; k < n; k++) a = addmod(a, mulmod(post[i * n + k], form[k][b]));
+            if (b < n) { T.fin0[1 + b][1 + i] = a; T.fin1[1 + b][1 + i] = a >> 52; }
+            else if (b < n + RP) { T.fin0[W + (b - n)][1 + i] = a; T.fin1[W + (b - n)][1 + i] = a >> 52; }
+            else { T.fk0[1 + i] = a & ((1ULL << 52) - 1); T.fk1[1 + i] = a >> 52; }
+        }
 }
 
 void permute(u64 st[24]) {
     V x[3];
     for (int g = 0; g < 3; g++) x[g] = _mm512_loadu_si512((const void *)(st + 8 * g));
     for (int r = 0; r < RF / 2; r++) full_round(x, T.arkf[r]);
-    // partial rounds: word 0 lives in a scalar register, lane 0 of x[0] is kept at zero
-    u64 s0 = (u64)_mm_cvtsi128_si64(_mm512_castsi512_si128(x[0]));
-    x[0] = _mm512_maskz_mov_epi64(0xFE, x[0]);
-    const V z = _mm512_setzero_si512(), m52 = _mm512_set1_epi64((long long)((1ULL << 52) - 1));
+    // Partial rounds (tables: see build).  The only sequential part is the scalar chain of word 0: three dependent multiplies
+    // of the S-box and one more per round; the contributions of X_r to the later rounds are pushed into their lazy
+    // 192-bit accumulators off the critical path.
+    alignas(64) u64 xl[NX], xh[NX], d[W];
+    split_words(x, xl, xh);
+    V dv[3];
+    matvec_n(T.sx0, T.sx1, W, xl, xh, nullptr, nullptr, dv);
+    for (int g = 0; g < 3; g++) _mm512_store_si512((void *)(d + 8 * g), dv[g]);
+    u64 lo[RP], mid[RP], hi[RP];
     for (int r = 0; r < RP; r++) {
-        V xs[3], xh[3];
-        for (int g = 0; g < 3; g++) {
-            xs[g] = vadd(x[g], _mm512_load_si512((const void *)(T.cst[r] + 8 * g)));
-            xh[g] = _mm512_srli_epi64(xs[g], 52);
-        }
-        // row . xs (lanes 1..23), independent of the S-box of word 0
-        V d0 = z, d52 = z, d52b = z, d52c = z, d104 = z, d104b = z, d104c = z;
-        for (int g = 0; g < 3; g++) {
-            V m = _mm512_load_si512((const void *)(T.row0[r] + 8 * g)), m1 = _mm512_load_si512((const void *)(T.row1[r] + 8 * g));
-            d0 = _mm512_madd52lo_epu64(d0, m, xs[g]);
-            d52 = _mm512_madd52hi_epu64(d52, m, xs[g]);
-            d52b = _mm512_madd52lo_epu64(d52b, m, xh[g]);
-            d52c = _mm512_madd52lo_epu64(d52c, m1, xs[g]);
-            d104 = _mm512_madd52hi_epu64(d104, m, xh[g]);
-            d104b = _mm512_madd52hi_epu64(d104b, m1, xs[g]);
-            d104c = _mm512_madd52lo_epu64(d104c, m1, xh[g]);
-        }
-        u64 w0 = (u64)_mm512_reduce_add_epi64(d0);
-        u64 w52 = (u64)_mm512_reduce_add_epi64(_mm512_add_epi64(_mm512_add_epi64(d52, d52b), d52c));
-        u64 w104 = (u64)_mm512_reduce_add_epi64(_mm512_add_epi64(_mm512_add_epi64(d104, d104b), d104c));
-        u128 dv = (u128)w0 + ((u128)w52 << 52);
-        u64 dot = submod(reduce128((u64)dv, (u64)(dv >> 64)), w104 << 8);
-        // S-box of word 0, then y0 = e00 x0 + dot, y_i = col_i x0 + xs_i
-        u64 x0 = sbox(addmod(s0, T.cst0[r]));
-        V b = _mm512_set1_epi64((long long)x0), b1 = _mm512_set1_epi64((long long)(x0 >> 52));
-        for (int g = 0; g < 3; g++) {
-            V m = _mm512_load_si512((const void *)(T.col0[r] + 8 * g)), m1 = _mm512_load_si512((const void *)(T.col1[r] + 8 * g));
-            V a0 = _mm512_madd52lo_epu64(_mm512_and_si512(xs[g], m52), m, b);
-            V a52 = _mm512_madd52hi_epu64(xh[g], m, b);
-            V a52b = _mm512_madd52lo_epu64(z, m, b1);
-            V a52c = _mm512_madd52lo_epu64(z, m1, b);
-            V a104 = _mm512_madd52hi_epu64(z, m, b1);
-            V a104b = _mm512_madd52hi_epu64(z, m1, b);
-            V a104c = _mm512_madd52lo_epu64(z, m1, b1);
-            x[g] = reduce(a0, _mm512_add_epi64(_mm512_add_epi64(a52, a52b), a52c), _mm512_add_epi64(_mm512_add_epi64(a104, a104b), a104c));
-        }
-        s0 = addmod(mulmod(T.e00[r], x0), dot);
+        u128 t = (u128)d[r] + T.K[r];
+        lo[r] = (u64)t; mid[r] = (u64)(t >> 64); hi[r] = 0;
     }
-    x[0] = _mm512_mask_set1_epi64(x[0], 0x01, (long long)s0);
-    matvec(T.post0, T.post1, x);
+    u64 s0 = xl[0];
+    for (int r = 0; r < RP; r++) {
+        u64 X = sbox_loose(add_loose(s0, T.cst0[r]));
+        xl[W + r] = X; xh[W + r] = X >> 52;
+        {   // this round's own term closes s0_{r+1}
+            u128 pr = (u128)T.G[r][r] * X;
+            u128 t = (u128)lo[r] + (u64)pr;
+            u128 t2 = (u128)mid[r] + (u64)(pr >> 64) + (u64)(t >> 64);
+            u64 h = hi[r] + (u64)(t2 >> 64);
+            u64 v = reduce128_loose((u64)t, (u64)t2), sh = h << 32;   // minus h * 2^32: 2^128 = -2^32 (mod p)
+            s0 = v - sh - (EPS & (0 - (u64)(v < sh)));                 // borrow: the wrap added 2^64 = eps
+        }
+        for (int q = r + 1; q < RP; q++) {
+            u128 pr = (u128)T.G[q][r] * X;
+            u128 t = (u128)lo[q] + (u64)pr;
+            lo[q] = (u64)t;
+            t = (u128)mid[q] + (u64)(pr >> 64) + (u64)(t >> 64);
+            mid[q] = (u64)t;
+            hi[q] += (u64)(t >> 64);
+        }
+    }
+    V seed0[3], seed52[3];
+    for (int g = 0; g < 3; g++) {
+        seed0[g] = _mm512_load_si512((const void *)(T.fk0 + 8 * g));
+        seed52[g] = _mm512_load_si512((const void *)(T.fk1 + 8 * g));
+    }
+    matvec_n(T.fin0, T.fin1, NX, xl, xh, seed0, seed52, x);      // lane 0 of every column is zero
+    x[0] = _mm512_mask_set1_epi64(x[0], 0x01, (long long)canon(s0));
     for (int r = RF / 2; r < RF; r++) full_round(x, T.arkf[r]);
     for (int g = 0; g < 3; g++) _mm512_storeu_si512((void *)(st + 8 * g), x[g]);
 }
