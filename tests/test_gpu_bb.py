@@ -116,7 +116,7 @@ def test_linf_check(ctx):
     assert not ok
 
 
-@pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 2048, 1), (16, 1024, 15), (3, 64, 2), (16, 300, 20)])
+@pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 2048, 1), (16, 1024, 15), (3, 64, 2), (16, 300, 20), (32, 70, 9)])
 def test_ajtai_commit(ctx, kappa, n, batch):
     A = rnd(100 + kappa, kappa, n, RE)
     f = rnd(200 + n, batch, n, RE)

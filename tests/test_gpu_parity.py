@@ -99,7 +99,7 @@ def test_linf_check(ctx):
 # kappa*batch in [384, 448] takes the SIMD-balanced 8-wave layout of k_ajtai (two lanes per output on waves 4-7, dot-product
 # kernel for the outputs beyond 384); the other shapes the one-thread-per-output map
 @pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 4096, 1), (26, 1024, 15), (3, 64, 2), (26, 512, 40),
-                                           (24, 333, 16), (28, 97, 16), (25, 650, 16)])
+                                           (24, 333, 16), (28, 97, 16), (25, 650, 16), (48, 70, 9)])   # last: the ABI maximum kappa, 57 LDS rows (88 KB of the 160 KB)
 def test_ajtai_commit(ctx, kappa, n, batch):
     A = rnd(100 + kappa, kappa, n, RE)
     f = rnd(200 + n, batch, n, RE)
