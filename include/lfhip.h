@@ -205,6 +205,18 @@ int lf_last_kernel_stats(lf_ctx *, float *fold_round_ms, int *fold_round_launche
 int lf_verify_host(int ring, const lf_params *, const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *c, lf_transcript *t,
                    const uint64_t *acc_lcccs, const uint64_t *cm_i_cccs, const uint64_t *proof, uint64_t *lcccs_out, int *failed_stage);
 
+/* ---- wire format -------------------------------------------------------------------------------------
+ * Bytes of an LFProof as the reference's derived CanonicalSerialize writes them with Compress::Yes (nifs.rs:28-34 and the
+ * structs it contains; round trip in nifs/folding/tests/mod.rs:656-680): fields in declaration order, every Vec prefixed by
+ * its u64 little-endian length, ring elements as their d base-field words (8 bytes LE each, canonical) in the flat order of
+ * this ABI.  The ring-element serializer itself is in the un-vendored stark-rings crate: that part of the layout is an
+ * assumption (parity unpinned), see lf_wire.cpp.  `proof` is the flat proof of lf_fold_step.
+ * serialize: non-canonical word or cap < lf_proof_wire_size -> LF_ERR_INVALID.  deserialize: any length prefix that differs
+ * from the parameters, a non-canonical word, truncated or trailing bytes -> LF_ERR_INVALID (Validate::Yes). */
+size_t lf_proof_wire_size(const lf_params *, int ring);
+int lf_proof_serialize(const lf_params *, int ring, const uint64_t *proof, uint8_t *out, size_t cap);
+int lf_proof_deserialize(const lf_params *, int ring, const uint8_t *in, size_t len, uint64_t *proof);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,10 @@ def _lib():
         L.lf_transcript_new_ring.argtypes = [C.c_int]
         L.lf_poseidon_params_ring.argtypes = [u64p, u64p, C.c_int]
         L.lf_poseidon_params_ring.restype = None
+        L.lf_proof_wire_size.argtypes = [C.POINTER(Params), C.c_int]
+        L.lf_proof_wire_size.restype = C.c_size_t
+        L.lf_proof_serialize.argtypes = [C.POINTER(Params), C.c_int, u64p, C.c_void_p, C.c_size_t]
+        L.lf_proof_deserialize.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_size_t, u64p]
         L.lf_poseidon_permute_ring.argtypes = [u64p, C.c_int, C.c_int]
         L.lf_poseidon_permute_ring.restype = None
         L.lf_ctx_destroy.argtypes = [vp]
@@ -506,6 +510,31 @@ class NIFSVerifier:
         if rc not in (0, -8):
             raise LfError(rc, "lf_verify_host")
         return rc == 0, lc, st.value
+
+
+def _wl_params(wl):
+    return Params(wl.s, wl.wit_len, wl.l, wl.L, wl.K, wl.b, wl.B, wl.kappa, wl.t, wl.q, wl.d)
+
+
+def proof_to_bytes(wl, proof):
+    """LFProof::serialize_with_mode(Compress::Yes) (nifs.rs:28-34) of a flat proof; layout notes in include/lfhip.h."""
+    prm, rid = _wl_params(wl), RING_IDS[wl.ring]
+    a, p = _a64(proof)
+    n = _lib().lf_proof_wire_size(C.byref(prm), rid)
+    if a.size != _lib().lf_proof_len_ring(C.byref(prm), rid) * RING_WORDS[wl.ring]:
+        raise LfError(-1, "proof_to_bytes: wrong proof length")
+    buf = (C.c_uint8 * n)()
+    _chk(_lib().lf_proof_serialize(C.byref(prm), rid, p, buf, n), "lf_proof_serialize")
+    return bytes(buf)
+
+
+def proof_from_bytes(wl, data):
+    """LFProof::deserialize_with_mode(Compress::Yes, Validate::Yes) -> flat proof (ring elements x words)."""
+    prm, rid = _wl_params(wl), RING_IDS[wl.ring]
+    out = np.zeros((_lib().lf_proof_len_ring(C.byref(prm), rid), RING_WORDS[wl.ring]), dtype=np.uint64)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data) if len(data) else (C.c_uint8 * 1)()
+    _chk(_lib().lf_proof_deserialize(C.byref(prm), rid, buf, len(data), out.ctypes.data_as(u64p)), "lf_proof_deserialize")
+    return out
 
 
 class MLSumcheckLin:
