@@ -5,6 +5,7 @@
 //   cp tools/probe_stark_rings.rs /path/to/latticefold/crates/cyclotomic-rings/examples/probe.rs
 //   cargo run -p cyclotomic-rings --example probe > stark_rings_tables.json
 use ark_ff::{Field, PrimeField, Zero, One};
+use ark_serialize::{CanonicalSerialize, Compress};
 use stark_rings::{
     balanced_decomposition::DecomposeToVec,
     cyclotomic_ring::{models::goldilocks::{Fq, Fq3, RqNTT, RqPoly}, CRT, ICRT},
@@ -50,5 +51,14 @@ fn main() {
         let d2: Vec<u64> = el.decompose_to_vec(2u128, 16)[0].iter().map(|r| c(r.coeffs()[0])).collect();
         out.push((v as u64, d16, d2));
     }
-    println!(" \"digit_cases\": {:?}}}", out);
+    println!(" \"digit_cases\": {:?},", out);
+
+    // 5. bytes of ONE serialized ring element (the per-element layout lf_wire.cpp assumes: 24 words x 8 bytes LE, no prefix)
+    let mut e = vec![Fq::zero(); 24];
+    for (i, v) in e.iter_mut().enumerate() { *v = Fq::from(1000u64 + i as u64); }
+    let n: RqNTT = RqPoly::from(e).crt();
+    let mut bytes = vec![];
+    n.serialize_with_mode(&mut bytes, Compress::Yes).unwrap();
+    let words: Vec<u64> = n.coeffs().iter().flat_map(|s| s.to_base_prime_field_elements()).map(c).collect();
+    println!(" \"serialized_element\": {{\"len\": {}, \"bytes\": {:?}, \"flat_words\": {:?}}}}}", bytes.len(), bytes, words);
 }
