@@ -215,6 +215,7 @@ def test_fold_step_parity(ctx, name, seed):
     assert rc == 0 and (lc_v == lc_g).all()
     ok, lc_p, _ = api.NIFSVerifier.verify(wl, acc_g, cccs, proof_g, api.PoseidonTranscript())   # ... and so does the product's own host verifier
     assert ok and (lc_p == lc_g).all()
+    assert (api.proof_from_bytes(wl, api.proof_to_bytes(wl, proof_g)) == proof_g).all()   # wire format round trip of a GPU proof
     # fold again: the folded accumulator/witness are valid inputs of the next step (IVC chaining)
     lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, api.PoseidonTranscript())
     lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
