@@ -758,7 +758,7 @@ size_t dot_partial_words(u32 na, u32 nb) { return (size_t)RED_BLOCKS * 16 * nb *
 void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *partial,
                       u64 *out, hipStream_t s) {
     u32 gb = (u32)((n + 255) / 256);
-    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb > 64) gb = 64;   // fatter threads: the 12-value block reduction per block is not free
     if (gb < 1) gb = 1;
     LF_LAUNCH(k_dot_batch, t.nu2p40, dim3(gb, 8, na), dim3(256), s, t, X, ldx, na, Y, ldy, nb, n, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(na * nb * 24), dim3(256), 0, s, partial, gb, 16 * nb * 24, out);
@@ -790,13 +790,17 @@ void launch_dot_eq(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 
 
 // f-hat evaluations without materialising f-hat (Witness::get_fhat, arith.rs:273-297, is a re-layout of
 // f_coeff): T[k][c] = sum_i eq[i] * digit_k(f[i][c]);  v_d slot s = T[k][8d+s].
+// KG bit-planes per thread: the kernel is bound by the cache traffic of eq (every (coefficient, plane-group) block streams it
+// again), so one thread takes all K <= 16 planes of its coefficient and eq is read once per (coefficient, element).
+template <int KG>
 __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits,
                                                    u64 *partial) {
-    // grid (RED_BLOCKS, 24 coefficients, K-groups of 4 bit-planes)
-    u32 c = blockIdx.y, kg = blockIdx.z * 4;
-    u64 acc[12];
+    // grid (RED_BLOCKS, 24 coefficients, K-groups of KG bit-planes)
+    u32 c = blockIdx.y, kg = blockIdx.z * KG;
+    u64 acc[3 * KG];
+    u32 cy[3 * KG];   // mode_bits: lazy 64-bit sums with carry counters (add, add-with-carry, count) instead of a modular add per term
 #pragma unroll
-    for (int i = 0; i < 12; i++) acc[i] = 0;
+    for (int i = 0; i < 3 * KG; i++) { acc[i] = 0; cy[i] = 0; }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         int32_t v = planes[(size_t)c * n + i];
         u64 e[3] = {eq[i], eq[ldeq + i], eq[2 * ldeq + i]};
@@ -807,10 +811,14 @@ __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t
 #pragma unroll
             for (int q = 0; q < 3; q++) e[q] = neg ? fq_neg(e[q]) : e[q];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < KG; k++) {
                 u64 mask = (u64)0 - (u64)((mg >> (kg + k)) & 1);
 #pragma unroll
-                for (int q = 0; q < 3; q++) acc[3 * k + q] = fq_add(acc[3 * k + q], e[q] & mask);
+                for (int q = 0; q < 3; q++) {
+                    u64 tq = e[q] & mask, sum = acc[3 * k + q] + tq;
+                    cy[3 * k + q] += sum < tq;
+                    acc[3 * k + q] = sum;
+                }
             }
         } else {
 #pragma unroll
@@ -820,11 +828,15 @@ __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t
             }
         }
     }
+    if (mode_bits) {
+#pragma unroll
+        for (int i = 0; i < 3 * KG; i++) acc[i] = fq_canon(fq_reduce128_loose(acc[i], (u64)cy[i]));   // lo + 2^64 * carries
+    }
     // partial[block][k][c][3]
-    __shared__ u64 red[12];
-    block_sum_store<12>(acc, red);
+    __shared__ u64 red[3 * KG];
+    block_sum_store<3 * KG>(acc, red);
     __syncthreads();
-    if (threadIdx.x < 12) {
+    if (threadIdx.x < 3 * KG) {
         u32 k = kg + threadIdx.x / 3, q = threadIdx.x % 3;
         if (k < K) partial[(size_t)blockIdx.x * (K * 72) + ((size_t)k * 24 + c) * 3 + q] = red[threadIdx.x];
     }
@@ -833,9 +845,9 @@ size_t coef_eval_partial_words(u32 K) { return (size_t)RED_BLOCKS * K * 72; }
 void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial,
                       u64 *out, hipStream_t s) {
     u32 gb = (u32)((n + 255) / 256);
-    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb > 64) gb = 64;   // >= 64 elements per thread at 2^20: the 12-value block reduction is a third of the work otherwise
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(k_coef_eval, dim3(gb, 24, mode_bits ? (K + 3) / 4 : 1), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
+    hipLaunchKernelGGL(k_coef_eval<4>, dim3(gb, 24, mode_bits ? (K + 3) / 4 : 1), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(K * 72), dim3(256), 0, s, partial, gb, K * 72, out);
 }
 
