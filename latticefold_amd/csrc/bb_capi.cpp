@@ -1100,7 +1100,13 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // added mod p, every rank runs the same transcript.  Below 64 pairs per rank the f-hat slices are gathered and the tail is replicated.
     const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
     bool sharded = Gw > 1;
+    // unsharded, rounds >= 4 with many entries: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel
+    const bool fused = Gw == 1 && !getenv("LF_FOLD_UNFUSED");
+    const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 16384;   // entries; tests lower it
+    const fe *prevF = nullptr;
+    size_t prevld = 0;
     for (u32 round = 1; round <= P.s; round++) {
+        bool fix_fused = false;
         if (round > 1) {
             H9 rh = pt[round - 2];
             E9PreC r = e9pre_from_h9(rh, nu);
@@ -1146,7 +1152,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                     curF = F[0]; ldF = atl(q);
                 } else if (round > 3) {
                     fe *fd = F[(round & 1) ? 0 : 1];   // round 4 -> F[1], round 5 -> F[0], ...
-                    launch_fix(c->dev, curF, ldF, fd, atl(ldF / 2), ldF, K2 * TAU * 8, r, c->stream());
+                    if (fused && ldF >= fuse_min && ldF >= 4 && nn * 2 == ldF) { prevF = curF; prevld = ldF; fix_fused = true; }
+                    else launch_fix(c->dev, curF, ldF, fd, atl(ldF / 2), ldF, K2 * TAU * 8, r, c->stream());
                     curF = fd; ldF = atl(ldF / 2);
                 }
             }
@@ -1161,6 +1168,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
+        else if (fix_fused) launch_fold_round_fix(c->dev, a, prevF, prevld, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());
         c->ev_end(ev);
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;

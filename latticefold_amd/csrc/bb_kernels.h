@@ -107,6 +107,10 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 size_t fold_partial_words(size_t m);   // i64 words of `partial` the general rounds need
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre_dev, i64 *partial, u64 *out,
                        hipStream_t s);
+// the same round with fix_variables of the previous round's tables fused in (unsharded large rounds): reads entries 4j..4j+3
+// of Fprev, stores the fixed pair to Fout for the next round
+void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, size_t ldprev, const H9 &r, const BbHostRing &ring, fe *Fout,
+                           size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);
 // folded witness in the coefficient domain: out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c) mod X^72 - X^36 + 1
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev /*[2K][24]*/, int32_t *out,
                          hipStream_t s);

@@ -1054,8 +1054,12 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 // (every part is linear in the tables, including the final product with eqB).
 // One pair per thread (the grid covers all pairs), so nothing but the table-loop state is live inside the loop and the four
 // sums of products can be kept as lazy (high, low) column sums: no Montgomery reduction per product, one per sum at the end.
-template <bool NU2>
-__global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial) {
+// FIX: fix_variables of the previous round fused in (unsharded large rounds): F holds the PREVIOUS tables, the pair is
+//   f0 = F[4j] + r (F[4j+1] - F[4j]),  f1 = F[4j+2] + r (F[4j+3] - F[4j+2])  and is stored to Fout[2j], Fout[2j+1] for the next round;
+// the round kernel is ALU-bound, so the table traffic of the separate memory-bound k_fix pass disappears under it.
+template <bool NU2, bool FIX>
+__global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
+                                                    fe *Fout, size_t ldo, i64 *partial) {
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
     const u32 tb0 = blockIdx.z * per, tb1 = tb0 + per < ntab ? tb0 + per : ntab;
@@ -1069,10 +1073,27 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
     for (u32 tb = tb0; tb < tb1; tb++) {
         const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
         E9 f0, f1;
+        if (FIX) {
+            E9 a0, a1, b0, b1;
 #pragma unroll
-        for (int c = 0; c < TAU; c++) {
-            int2 v = *reinterpret_cast<const int2 *>(Ft + (size_t)c * ldF + 2 * jj);
-            f0.c[c] = v.x; f1.c[c] = v.y;
+            for (int c = 0; c < TAU; c++) {
+                int4 v = *reinterpret_cast<const int4 *>(Ft + (size_t)c * ldF + 4 * jj);
+                a0.c[c] = v.x; a1.c[c] = v.y; b0.c[c] = v.z; b1.c[c] = v.w;
+            }
+            E9Pre R = e9p(rfix);
+            f0 = e9_add(a0, e9_mul(e9_sub(a1, a0), R));
+            f1 = e9_add(b0, e9_mul(e9_sub(b1, b0), R));
+            if (live) {
+                fe *Fo = Fout + ((size_t)tb * RE + TAU * slot) * ldo;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(Fo + (size_t)c * ldo + 2 * jj) = make_int2(f0.c[c], f1.c[c]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < TAU; c++) {
+                int2 v = *reinterpret_cast<const int2 *>(Ft + (size_t)c * ldF + 2 * jj);
+                f0.c[c] = v.x; f1.c[c] = v.y;
+            }
         }
         E9 df = e9_sub(f1, f0);
         E9Pre M = e9p(Mpre[tb]);
@@ -1142,8 +1163,8 @@ size_t fold_partial_words(size_t m) {
     if (rows < RED_BLOCKS) rows = RED_BLOCKS;
     return rows * 5 * RE;
 }
-void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
-                       hipStream_t s) {
+static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, bool fix, E9PreC rfix,
+                                   fe *Fout, size_t ldo, i64 *partial, u64 *out, hipStream_t s) {
     size_t pairs = a.pcnt;
     u32 gb = (u32)((pairs + 255) / 256);
     if (gb < 1) gb = 1;
@@ -1151,9 +1172,21 @@ void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ld
     u32 tch = 1;
     while (tch < 32 && pairs * 8 * tch < (1u << 17)) tch *= 2;
     while (tch > 1 && (size_t)gb * tch > RED_BLOCKS) tch /= 2;
-    if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_round<true>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
-    else hipLaunchKernelGGL((k_fold_round<false>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, partial);
+    const bool nu2 = t.nu == BB_TWO;
+#define BB_FR(N2, FX) hipLaunchKernelGGL((k_fold_round<N2, FX>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, rfix, Fout, ldo, partial)
+    if (nu2) { if (fix) BB_FR(true, true); else BB_FR(true, false); }
+    else { if (fix) BB_FR(false, true); else BB_FR(false, false); }
+#undef BB_FR
     launch_reduce_rows(partial, gb * tch, 5 * RE, out, s);
+}
+void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
+                       hipStream_t s) {
+    E9PreC none = {};
+    launch_fold_round_impl(t, a, F, ldF, K, Mpre, false, none, nullptr, 0, partial, out, s);
+}
+void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, size_t ldprev, const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout,
+                           u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
+    launch_fold_round_impl(t, a, Fprev, ldprev, K, Mpre, true, e9pre_from_h9(r, ring.T.nu), Fout, ldout, partial, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------

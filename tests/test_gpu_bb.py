@@ -229,6 +229,21 @@ def test_fold_step_parity(ctx, name, seed):
         assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
 
 
+@pytest.mark.parametrize("name", ["B8", "BDP"])
+def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
+    """rounds >= 4 with fix_variables fused into the round kernel (threshold lowered to reach it at oracle sizes) and with the
+    separate k_fix pass: identical proofs, equal to the oracle's"""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
+    lc_f, w_f, proof_f = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    monkeypatch.delenv("LF_FOLD_FUSE_MIN")
+    monkeypatch.setenv("LF_FOLD_UNFUSED", "1")
+    lc_u, w_u, proof_u = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    assert (proof_f == proof_o).all() and (lc_f == lc_o).all() and (w_f.f == f0_o).all()
+    assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
+
+
 def test_sumcheck_lin_abi(ctx):
     wl, inst, A, scheme = setup_case(ctx, "B8")
     f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
