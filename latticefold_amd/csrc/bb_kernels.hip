@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) k_dot_batch(DevBb t, const fe *X, size_t 
 }
 void launch_dot_batch(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial, u64 *out,
                       hipStream_t s) {
-    u32 gb = (u32)((n + 255) / 256);
+    u32 gb = (u32)((n + 256 * 16 - 1) / (256 * 16));   // >= 16 elements per thread: the 27-value block reduction is a fixed cost
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     dim3 g(gb, 8, na);
