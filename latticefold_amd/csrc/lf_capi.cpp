@@ -561,7 +561,11 @@ static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {
     for (u32 i = 0; i < nv; i++) h[i] = f3c(pt[i]);
     HIPCHK(hipMemcpyAsync(rd, h.data(), nv * sizeof(Fq3Const), hipMemcpyHostToDevice, c->stream()));
     HIPCHK(hipStreamSynchronize(c->stream()));  // h is a stack-lifetime buffer
-    launch_build_eq(c->dcrt, rd, nv, eq_dev, c->stream());
+    if (nv >= 6) {   // two-level: one product per entry
+        u64 *scr;
+        RET(c->tbuf("eq_scratch", build_eq_scratch_words(nv), &scr));
+        launch_build_eq2(c->dcrt, rd, nv, scr, eq_dev, c->stream());
+    } else launch_build_eq(c->dcrt, rd, nv, eq_dev, c->stream());
     return LF_OK;
 }
 int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {

@@ -62,6 +62,9 @@ void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 
 
 // ---- MLE / eq (a8, a9, a11) --------------------------------------------------------------------------------------
 void launch_build_eq(const DevCrt &t, const Fq3Const *r_dev /*nv*/, u32 nv, u64 *eq /*[3][1<<nv]*/, hipStream_t s);
+// the same table as an outer product of two half-size tables (scratch: build_eq_scratch_words(nv) words)
+size_t build_eq_scratch_words(u32 nv);
+void launch_build_eq2(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *scratch, u64 *eq, hipStream_t s);
 // sparse mat-vec (a7): CSR rows m; z ring table [24][n]; out ring table [24][m]; accumulate != 0 adds into out
 void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *val /*[nnz][24] AoS*/, const u64 *z,
                  size_t ldz, u64 *out, size_t m, int accumulate, hipStream_t s);

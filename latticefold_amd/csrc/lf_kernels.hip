@@ -678,6 +678,25 @@ __global__ void __launch_bounds__(256) k_build_eq(DevCrt t, const Fq3Const *r, u
 void launch_build_eq(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *eq, hipStream_t s) {
     LF_LAUNCH(k_build_eq, t.nu2p40, dim3(cdiv((size_t)1 << nv, 256)), dim3(256), s, t, r_dev, nv, eq);
 }
+// eq(r, i) = eq(r_lo, i mod 2^hl) * eq(r_hi, i >> hl): one product per entry instead of nv (field arithmetic is exact, so the
+// table is identical to k_build_eq's)
+template <bool NU>
+__global__ void __launch_bounds__(256) k_eq_outer(DevCrt t, const u64 *lo, u32 hl, const u64 *hi, u32 hh, u64 *eq) {
+    size_t n = (size_t)1 << (hl + hh), nl = (size_t)1 << hl, nh = (size_t)1 << hh;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    size_t a = i & (nl - 1), b = i >> hl;
+    Fq3 r = M3<NU>(fq3_make(lo[a], lo[nl + a], lo[2 * nl + a]), fq3_make(hi[b], hi[nh + b], hi[2 * nh + b]), t.nu);
+    eq[i] = r.c[0]; eq[n + i] = r.c[1]; eq[2 * n + i] = r.c[2];
+}
+size_t build_eq_scratch_words(u32 nv) { u32 hl = nv / 2; return 3 * (((size_t)1 << hl) + ((size_t)1 << (nv - hl))); }
+void launch_build_eq2(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *scratch, u64 *eq, hipStream_t s) {
+    u32 hl = nv / 2, hh = nv - hl;
+    u64 *lo = scratch, *hi = scratch + 3 * ((size_t)1 << hl);
+    LF_LAUNCH(k_build_eq, t.nu2p40, dim3(cdiv((size_t)1 << hl, 256)), dim3(256), s, t, r_dev, hl, lo);
+    LF_LAUNCH(k_build_eq, t.nu2p40, dim3(cdiv((size_t)1 << hh, 256)), dim3(256), s, t, r_dev + hl, hh, hi);
+    LF_LAUNCH(k_eq_outer, t.nu2p40, dim3(cdiv((size_t)1 << nv, 256)), dim3(256), s, t, lo, hl, hi, hh, eq);
+}
 
 // mat_vec_mul (arith/utils.rs:52-65) on CSR
 template <bool NU>

@@ -133,7 +133,7 @@ def test_ajtai_generate_matches_workload_stream(ctx):
 
 
 def test_eq_and_mle_eval(ctx):
-    for nv in (1, 5, 10):
+    for nv in (1, 5, 6, 7, 10, 13):   # nv >= 6 takes the two-level (outer product) build, odd nv splits unevenly
         pt = rnd(nv, nv, 3)
         ring_pt = np.zeros((nv, RE), dtype=np.uint64)
         for k in range(8):
