@@ -106,6 +106,7 @@ int lf_ajtai_commit(lf_ctx *, const uint64_t *f, size_t n, size_t batch, uint64_
  * and added with lf_modsum (canonical residues; plain ncclSum would wrap mod 2^64, not mod p).
  * parts = nparts x words canonical words, out = words. */
 int lf_modsum(const uint64_t *parts, size_t nparts, size_t words, uint64_t *out);
+int lf_modsum_ring(const uint64_t *parts, size_t nparts, size_t words, uint64_t *out, int ring);   /* the same for either modulus */
 /* Intra-step sharding of one fold step over `world` (power of two) ranks, one GPU each.  Must be set before the Ajtai matrix is
  * loaded/generated: each rank then keeps columns [rank*n/world, (rank+1)*n/world) of A.  Witnesses, CCS and all O(n) vectors are
  * replicated; sharded are the Ajtai commitments (partial commitments all-gathered + added mod p) and the folding-sumcheck rounds

@@ -93,6 +93,7 @@ def _lib():
         L.lf_ajtai_generate.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t]
         L.lf_ajtai_commit.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p]
         L.lf_modsum.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
+        L.lf_modsum_ring.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p, C.c_int]
         L.lf_set_sharding.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
         L.lf_build_eq.argtypes = [vp, u64p, C.c_uint, u64p]
         L.lf_mle_eval_batch.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p, C.c_uint, u64p]

@@ -552,6 +552,20 @@ int lf_modsum(const uint64_t *parts, size_t nparts, size_t words, uint64_t *out)
     }
     return LF_OK;
 }
+int lf_modsum_ring(const uint64_t *parts, size_t nparts, size_t words, uint64_t *out, int ring) {
+    if (ring == LF_RING_GOLDILOCKS) return lf_modsum(parts, nparts, words, out);
+    if (ring != LF_RING_BABYBEAR || !parts || !out || !nparts) return LF_ERR_INVALID;
+    for (size_t w = 0; w < words; w++) {
+        u64 acc = 0;
+        for (size_t g = 0; g < nparts; g++) {
+            u64 v = parts[g * words + w];
+            if (v >= lfbb::BB_P) return LF_ERR_INVALID;
+            acc += v;                         // nparts * p < 2^64 for any realistic rank count
+        }
+        out[w] = acc % lfbb::BB_P;
+    }
+    return LF_OK;
+}
 
 // ---- a8/a9/a11 ------------------------------------------------------------------------------------------------------
 static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {

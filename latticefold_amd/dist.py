@@ -18,8 +18,8 @@ def column_shard(n, rank, world):
     return lo, min(n, lo + per)
 
 
-def allgather_modsum(partial, group=None):
-    """partial: uint64 array of canonical residues (any shape) -> elementwise sum over ranks mod p."""
+def allgather_modsum(partial, group=None, ring="goldilocks"):
+    """partial: uint64 array of canonical residues (any shape) -> elementwise sum over ranks mod p (of `ring`)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -32,15 +32,15 @@ def allgather_modsum(partial, group=None):
     dist.all_gather(parts, t, group=group)
     stacked = torch.stack(parts).cpu().numpy().view(np.uint64)
     out = np.zeros_like(flat)
-    rc = api._lib().lf_modsum(stacked.ctypes.data_as(api.u64p), world, flat.size, out.ctypes.data_as(api.u64p))
+    rc = api._lib().lf_modsum_ring(stacked.ctypes.data_as(api.u64p), world, flat.size, out.ctypes.data_as(api.u64p), api.RING_IDS[ring])
     if rc != 0:
-        raise api.LfError(rc, "lf_modsum")
+        raise api.LfError(rc, "lf_modsum_ring")
     return out.reshape(np.shape(partial))
 
 
 def sharded_commit(scheme_shard, f_shard, group=None):
     """scheme_shard: api.AjtaiCommitmentScheme over this rank's column slice; f_shard: (n_local,24) or (batch,n_local,24)."""
-    return allgather_modsum(scheme_shard.commit_ntt(f_shard), group)
+    return allgather_modsum(scheme_shard.commit_ntt(f_shard), group, scheme_shard.ctx.ring if hasattr(scheme_shard.ctx, "ring") else "goldilocks")
 
 
 def make_allgather(group=None):

@@ -79,3 +79,11 @@ def test_modsum_rejects_non_canonical():
     assert out.tolist() == [0, 4]
     bad = np.array([[P, 0]], dtype=np.uint64)
     assert api._lib().lf_modsum(bad.ctypes.data_as(api.u64p), 1, 2, out.ctypes.data_as(api.u64p)) == -1
+    # the BabyBear modulus through the ring-aware entry point
+    PB = 15 * 2**27 + 1
+    parts = np.array([[1, PB - 1], [PB - 1, 5]], dtype=np.uint64)
+    assert api._lib().lf_modsum_ring(parts.ctypes.data_as(api.u64p), 2, 2, out.ctypes.data_as(api.u64p), 1) == 0
+    assert out.tolist() == [0, 4]
+    bad = np.array([[PB, 0]], dtype=np.uint64)
+    assert api._lib().lf_modsum_ring(bad.ctypes.data_as(api.u64p), 1, 2, out.ctypes.data_as(api.u64p), 1) == -1
+    assert api._lib().lf_modsum_ring(parts.ctypes.data_as(api.u64p), 2, 2, out.ctypes.data_as(api.u64p), 7) == -1
