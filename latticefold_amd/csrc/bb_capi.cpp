@@ -164,7 +164,14 @@ int BbCtx::create(BbCtx **out, lf_ctx *owner, int device) {
     C *c = new C();
     c->owner = owner;
     c->device = device;
-    if (hipStreamCreate(&c->st_lane[0]) != hipSuccess || hipStreamCreate(&c->st_lane[1]) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    {   // lane 1 carries the critical chain of a fold step (two commits back to back); its kernels get dispatch priority over
+        // lane 0's latency-bound linearization, which has slack (LF_NO_PRIO=1: equal priorities)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const bool prio = !getenv("LF_NO_PRIO");
+        if (hipStreamCreateWithPriority(&c->st_lane[0], hipStreamDefault, prio ? least : 0) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->st_lane[1], hipStreamDefault, prio ? greatest : 0) != hipSuccess) { delete c; return LF_ERR_HIP; }
+    }
     c->arena_words = (size_t)1 << 19;   // 4 MiB per lane
     for (int l = 0; l < 2; l++) {
         if (hipHostMalloc((void **)&c->arena[l], c->arena_words * 8) != hipSuccess) { delete c; return LF_ERR_HIP; }

@@ -105,8 +105,10 @@ struct LinCombDesc {  // CCS multiset structure for the linearization comb (nifs
 };
 // round message of the linearization sumcheck: tables Mz [t][24][ld], eq [3][ld]; n = current length
 // out: (deg+1) ring elements AoS, deg = d+1 <= 4
+// max_blocks (0 = default 256 per slot) bounds the grid: inside a fold step the linearization shares the GPU with the commit chain
+// of the other lane, which is the critical path, and yields to it by running on fewer workgroups
 void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
-                      u32 deg, u64 *partial, u64 *out, hipStream_t s);
+                      u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
 
 struct FoldRoundArgs {
     const u64 *eqL, *eqR, *eqB;  // fq3 tables [3][ld]

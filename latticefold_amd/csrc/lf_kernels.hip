@@ -1022,9 +1022,10 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
 }
 size_t round_partial_words() { return (size_t)RED_BLOCKS * 120; }
 void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n, u32 deg,
-                      u64 *partial, u64 *out, hipStream_t s) {
+                      u64 *partial, u64 *out, hipStream_t s, u32 max_blocks) {
     u32 gb = (u32)((n / 2 + 255) / 256);
-    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    const u32 cap = max_blocks && max_blocks < RED_BLOCKS ? max_blocks : RED_BLOCKS;
+    if (gb > cap) gb = cap;
     if (gb < 1) gb = 1;
     LF_LAUNCH(k_lin_round, t.nu2p40, dim3(gb, 8), dim3(256), s, t, desc, mz, ld, eq, ldeq, n, deg, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3((deg + 1) * 24), dim3(256), 0, s, partial, gb, 120, out);
