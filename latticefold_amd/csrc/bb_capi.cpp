@@ -52,6 +52,8 @@ struct BbCtxImpl {
     u64 *arena[2] = {nullptr, nullptr};   // pinned staging for the asynchronous decompositions (bump-allocated per step)
     size_t arena_words = 0, arena_used[2] = {0, 0};
     hipEvent_t ev_side[2] = {nullptr, nullptr};
+    hipEvent_t ev_dec[4] = {nullptr, nullptr, nullptr, nullptr};   // decomposition milestones: [2*side + (0 commit, 1 evaluations)]
+    u32 lin_blocks = 0;   // grid bound of the linearization rounds while the commit chain runs on the other lane (0 = none)
     u64 *h_round = nullptr;   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
     u64 *round_out() {
         if (!h_round && hipHostMalloc((void **)&h_round, 5 * RE * 8 * 2, hipHostMallocMapped) != hipSuccess) h_round = nullptr;
@@ -177,6 +179,8 @@ int BbCtx::create(BbCtx **out, lf_ctx *owner, int device) {
         if (hipHostMalloc((void **)&c->arena[l], c->arena_words * 8) != hipSuccess) { delete c; return LF_ERR_HIP; }
         if (hipEventCreateWithFlags(&c->ev_side[l], hipEventDisableTiming) != hipSuccess) { delete c; return LF_ERR_HIP; }
     }
+    for (int l = 0; l < 4; l++)
+        if (hipEventCreateWithFlags(&c->ev_dec[l], hipEventDisableTiming) != hipSuccess) { delete c; return LF_ERR_HIP; }
     u64 nr, y[8 * TAU];
     bb_default_ring(&nr, y);
     int rc = install_tables(c, nr, y);
@@ -213,6 +217,8 @@ void BbCtx::destroy() {
         if (c->ev_side[l]) (void)hipEventDestroy(c->ev_side[l]);
         (void)hipStreamDestroy(c->st_lane[l]);
     }
+    for (int l = 0; l < 4; l++)
+        if (c->ev_dec[l]) (void)hipEventDestroy(c->ev_dec[l]);
     delete c;
     delete this;
 }
@@ -788,7 +794,7 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
             n /= 2;
         }
         size_t ld = round == 1 ? m : atl(n);
-        launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->stream());
+        launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->stream(), c->lin_blocks);
         u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * RE;
         HIPCHK(hipStreamSynchronize(c->stream()));            // the reduce kernel wrote the message into mapped host memory
         memcpy(ev, od, (size_t)(deg + 1) * RE * 8);
@@ -923,22 +929,42 @@ struct SideState {
 // the lane's pinned arena (no host synchronisation), `dec_finish` waits for it, finishes y_0 on the host and absorbs.
 struct DecPending {
     u64 *h_y = nullptr, *h_v = nullptr, *h_u = nullptr;   // pinned results
-    int lane = 0;
+    int side = 0;                                           // 0 left, 1 right: selects the milestone events ev_dec[2*side + ..]
     size_t ph_commit = 0, ph_evals = 0;
 };
-static int dec_enqueue(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const lf_witness *wit, const char *side, fe *eq_r, SideState &S,
-                       u64 *proof, DecPending &pd) {
+// The decomposition of one side is queued in two independent parts: the commitment of the K-1 upper bit-planes (a function of
+// the witness only) and the evaluations at the point r (for the right side r comes out of the linearization).  Both run on the
+// stream of the lane that is current when they are queued.
+static int dec_enqueue_commit(C *c, const lf_witness *wit, DecPending &pd) {
+    const lf_params &P = c->P;
+    size_t N = c->N;
+    u32 K = P.K;
+    fe *Fh;
+    u64 *yd;
+    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * c->nA, &Fh));
+    RET(c->tbuf("dec_y", (size_t)K * P.kappa * RE, &yd));
+    pd.h_y = c->arena_alloc((size_t)(K - 1) * P.kappa * RE);
+    if (!pd.h_y) return LF_ERR_HIP;
+    // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
+    pd.ph_commit = c->ev_begin(11);
+    launch_bitplane_crt(c->dev, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());   // this rank's column slice only
+    RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
+    HIPCHK(hipMemcpyAsync(pd.h_y, yd, (size_t)(K - 1) * P.kappa * RE * 8, hipMemcpyDeviceToHost, c->stream()));
+    c->ev_end(pd.ph_commit);
+    HIPCHK(hipEventRecord(c->ev_dec[2 * pd.side], c->stream()));
+    return LF_OK;
+}
+static int dec_enqueue_evals(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const lf_witness *wit, const char *side, fe *eq_r, SideState &S,
+                             u64 *proof, DecPending &pd) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n, N = c->N;
     u32 K = P.K;
     std::string sd(side);
     const u64 *xh = lcccs + ((size_t)P.s + TAU + P.kappa + P.t) * RE;
     u64 *x_s = proof + (size_t)K * P.t * RE + (size_t)K * TAU * RE;
-    fe *Fh, *z, *q;
+    fe *z, *q;
     i64 *partial;
-    u64 *od, *yd;
-    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * c->nA, &Fh));
-    RET(c->tbuf("dec_y", (size_t)K * P.kappa * RE, &yd));
+    u64 *od;
     RET(c->tbuf("red_partial", red_partial_words(16 * RE * TAU), &partial));
     RET(c->tbuf("dec_small", 16 * RE * TAU + 16 * 4 * RE, &od));
     RET(c->tbuf("z_" + sd, (size_t)K * RE * n, &z));
@@ -948,17 +974,9 @@ static int dec_enqueue(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const
         RET(build_eq_async(c, rpt.data(), P.s, eq_r));
     }
     S.planes = wit->planes; S.z = z; S.eq_r = eq_r;
-    pd.lane = c->lane;
-    pd.h_y = c->arena_alloc((size_t)(K - 1) * P.kappa * RE);
     pd.h_v = c->arena_alloc((size_t)K * TAU * RE);
     pd.h_u = c->arena_alloc((size_t)K * P.t * RE);
-    if (!pd.h_y || !pd.h_v || !pd.h_u) return LF_ERR_HIP;
-    // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
-    pd.ph_commit = c->ev_begin(11);
-    launch_bitplane_crt(c->dev, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());   // this rank's column slice only
-    RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
-    HIPCHK(hipMemcpyAsync(pd.h_y, yd, (size_t)(K - 1) * P.kappa * RE * 8, hipMemcpyDeviceToHost, c->stream()));
-    c->ev_end(pd.ph_commit);
+    if (!pd.h_v || !pd.h_u) return LF_ERR_HIP;
     pd.ph_evals = c->ev_begin(12);
     compute_x_s(c, xh, x_s);   // host, O(l) elements
     // v_s (decomposition.rs:204-211) from the coefficient planes
@@ -972,7 +990,7 @@ static int dec_enqueue(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const
     launch_dot_batch(c->dev, z, n, K, q, n, P.t, n, partial, od2, c->stream());
     HIPCHK(hipMemcpyAsync(pd.h_u, od2, (size_t)K * P.t * RE * 8, hipMemcpyDeviceToHost, c->stream()));
     c->ev_end(pd.ph_evals);
-    HIPCHK(hipEventRecord(c->ev_side[pd.lane], c->stream()));
+    HIPCHK(hipEventRecord(c->ev_dec[2 * pd.side + 1], c->stream()));
     return LF_OK;
 }
 static int dec_finish(C *c, BbTranscript &tr, const u64 *lcccs, SideState &S, u64 *proof, DecPending &pd) {
@@ -980,7 +998,8 @@ static int dec_finish(C *c, BbTranscript &tr, const u64 *lcccs, SideState &S, u6
     u32 K = P.K;
     const u64 *cm = lcccs + ((size_t)P.s + TAU) * RE;
     u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * RE, *x_s = v_s + (size_t)K * TAU * RE, *y_s = x_s + (size_t)K * (P.l + 1) * RE;
-    HIPCHK(hipEventSynchronize(c->ev_side[pd.lane]));
+    HIPCHK(hipEventSynchronize(c->ev_dec[2 * pd.side]));
+    HIPCHK(hipEventSynchronize(c->ev_dec[2 * pd.side + 1]));
     memcpy(y_s + (size_t)P.kappa * RE, pd.h_y, (size_t)(K - 1) * P.kappa * RE * 8);
     RET(exchange_modsum(c, y_s + (size_t)P.kappa * RE, (size_t)(K - 1) * P.kappa * RE));   // partial commitments of the column shards
     memcpy(v_s, pd.h_v, (size_t)K * TAU * RE * 8);
@@ -1320,14 +1339,19 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     std::vector<u64> lin(ll * RE);
     fe *eq_r_R = nullptr;
     SideState S[2];
-    // Schedule (transcript order is fixed, compute order is not): the left decomposition needs nothing from the linearization,
-    // so its GPU work is queued on lane 1 first; the latency-bound linearization rounds run on lane 0 meanwhile; then the right
-    // decomposition is queued (lane 0) and the host absorbs the left one while the GPU works on the right one.
+    // Schedule (transcript order is fixed, compute order is not).  Lane 1 (high-priority stream) gets everything that does not
+    // depend on the linearization, queued up front: the left decomposition and the RIGHT commit (a function of w_i only); lane 0
+    // runs the latency-bound linearization rounds meanwhile and then the right evaluations at the new point; the host absorbs the
+    // left decomposition while the GPU still works on the right one.
     c->arena_used[0] = c->arena_used[1] = 0;
     DecPending pdL, pdR;
+    pdL.side = 0; pdR.side = 1;
     c->lane = 1;
-    int rc = dec_enqueue(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
+    int rc = dec_enqueue_commit(c, w_acc, pdL);
+    if (rc == LF_OK) rc = dec_enqueue_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
+    if (rc == LF_OK) rc = dec_enqueue_commit(c, w_i, pdR);
     c->lane = 0;
+    c->lin_blocks = getenv("LF_LIN_BLOCKS") ? (u32)atoi(getenv("LF_LIN_BLOCKS")) : 0u;
     {   // absorb_public_input (nifs.rs:175-197) -- while the GPU already works on the left decomposition
         HostTimer ht(c);
         tr.absorb_label("acc");
@@ -1339,8 +1363,9 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     std::vector<H9> rR;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
-        rc = dec_enqueue(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr, pdR);
+        rc = dec_enqueue_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr, pdR);
     }
+    c->lin_blocks = 0;
     if (rc == LF_OK) rc = dec_finish(c, tr, acc, S[0], decl, pdL);
     if (rc == LF_OK) rc = dec_finish(c, tr, lin.data(), S[1], decr, pdR);
     (void)hipStreamSynchronize(c->st_lane[1]);

@@ -85,7 +85,7 @@ struct LinDesc {   // CCS multiset structure (nifs/linearization/utils.rs:90-107
     int c_unit[8];   // +1 / -1 when c_i = +-1
 };
 void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg,
-                      i64 *partial, u64 *out, hipStream_t s);
+                      i64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
 
 struct FoldArgs {
     const fe *eqL, *eqR, *eqB;   // fq9 tables [9][ld]

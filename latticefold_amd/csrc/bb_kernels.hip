@@ -812,9 +812,10 @@ __global__ void __launch_bounds__(256) k_lin_round(DevBb t, LinDesc desc, const 
     }
 }
 void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg, i64 *partial,
-                      u64 *out, hipStream_t s) {
+                      u64 *out, hipStream_t s, u32 max_blocks) {
     u32 gb = (u32)((n / 2 + 255) / 256);
-    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    const u32 cap = max_blocks && max_blocks < RED_BLOCKS ? max_blocks : RED_BLOCKS;
+    if (gb > cap) gb = cap;
     if (gb < 1) gb = 1;
     hipLaunchKernelGGL(k_lin_round, dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial);
     launch_reduce_rows(partial, gb, 5 * RE, out, s);   // X = deg+1.. rows stay zero
