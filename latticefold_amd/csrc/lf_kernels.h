@@ -68,6 +68,9 @@ void launch_build_eq2(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *scrat
 // sparse mat-vec (a7): CSR rows m; z ring table [24][n]; out ring table [24][m]; accumulate != 0 adds into out
 void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *val /*[nnz][24] AoS*/, const u64 *z,
                  size_t ldz, u64 *out, size_t m, int accumulate, hipStream_t s);
+// out = sum_{j<nm} M_j z_j (nm <= 4), z_j = z + j*z_stride: one launch, one write of out
+void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z,
+                     size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s);
 // q[col] = sum_{rows} eq[row] * val  (CSC: colptr over n columns, rowidx, val AoS)
 void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
                       u64 *q, size_t n, hipStream_t s);

@@ -716,6 +716,34 @@ void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *
                  int accumulate, hipStream_t s) {
     LF_LAUNCH(k_spmv, t.nu2p40, dim3(cdiv(m, 256), 8), dim3(256), s, t, rowptr, col, val, z, ldz, out, m, accumulate);
 }
+// out = sum_{j<nm} M_j z_j in one pass (fold prepare: G = sum_j M_j (sum_k zeta_k^{j+1} z_k)): one launch and one write of the
+// output instead of nm launches that each read-modify-write it
+struct SpmvSet { const u32 *rowptr[4]; const u32 *col[4]; const u64 *val[4]; const u64 *z[4]; u32 nm; };
+template <bool NU>
+__global__ void __launch_bounds__(256) k_spmv_sum(DevCrt t, SpmvSet ms, size_t ldz, u64 *out, size_t m) {
+    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (row >= m) return;
+    Fq3 acc = fq3_zero();
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        if (j < ms.nm) {
+            const u32 *rp = ms.rowptr[j], *cl = ms.col[j];
+            for (u32 k = rp[row]; k < rp[row + 1]; k++) {
+                const u64 *v = ms.val[j] + (size_t)k * 24 + 3 * slot;
+                acc = fq3_add(acc, M3<NU>(fq3_make(v[0], v[1], v[2]), ld3(ms.z[j], ldz, slot, cl[k]), t.nu));
+            }
+        }
+    }
+    st3(out, m, slot, row, acc);
+}
+void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z,
+                     size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s) {
+    SpmvSet ms = {};
+    ms.nm = nm;
+    for (u32 j = 0; j < nm && j < 4; j++) { ms.rowptr[j] = rowptr[j]; ms.col[j] = col[j]; ms.val[j] = val[j]; ms.z[j] = z + (size_t)j * z_stride; }
+    LF_LAUNCH(k_spmv_sum, t.nu2p40, dim3(cdiv(m, 256), 8), dim3(256), s, t, ms, ldz, out, m);
+}
 template <bool NU>
 __global__ void __launch_bounds__(256) k_spmv_t_eq(DevCrt t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
                                                    u64 *q, size_t n) {
