@@ -1097,8 +1097,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     for (int sd = 0; sd < 2; sd++) {
         // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}   (folding.rs:208-226, utils.rs:524-546)
         launch_lincomb_z(c->dev, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
-        for (u32 j = 0; j < P.t; j++)
-            launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], zz + (size_t)j * RE * n, n, G[sd], m, j > 0, c->stream());
+        launch_spmv_sum(c->dev, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zz, (size_t)RE * n, n, G[sd], m, c->stream());
         launch_add_fhat_comb(c->dev, S[sd].planes, N, K, d_ap + (size_t)sd * K * TAU, G[sd], m, c->stream());
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));

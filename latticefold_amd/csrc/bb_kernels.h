@@ -58,6 +58,9 @@ void launch_ajtai(const DevBb &t, const fe *A, u32 kappa, size_t n, const fe *F,
 void launch_build_eq(const DevBb &t, const E9PreC *r_dev /*nv*/, const E9PreC *omr_dev /*nv: 1-r*/, u32 nv, fe *eq, hipStream_t s);
 void launch_spmv(const DevBb &t, const u32 *rowptr, const u32 *col, const fe *val /*[nnz][72]*/, const fe *z, size_t ldz, fe *out,
                  size_t m, int accumulate, hipStream_t s);
+// out = sum_{j<nm} M_j z_j (nm <= 4), z_j = z + j*z_stride: one launch, one write of out
+void launch_spmv_sum(const DevBb &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const fe *const *val, const fe *z, size_t z_stride,
+                     size_t ldz, fe *out, size_t m, hipStream_t s);
 void launch_spmv_t_eq(const DevBb &t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m, fe *q, size_t n,
                       hipStream_t s);
 size_t red_partial_words(u32 nv);

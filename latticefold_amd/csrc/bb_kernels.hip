@@ -499,6 +499,34 @@ void launch_spmv(const DevBb &t, const u32 *rowptr, const u32 *col, const fe *va
                  int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(k_spmv, dim3(cdiv(m, 256), 8), dim3(256), 0, s, t, rowptr, col, val, z, ldz, out, m, accumulate);
 }
+// out = sum_{j<nm} M_j z_j in one pass (fold prepare): one launch and one write of the output instead of nm read-modify-write passes
+struct SpmvSet { const u32 *rowptr[4]; const u32 *col[4]; const fe *val[4]; const fe *z[4]; u32 nm; };
+__global__ void __launch_bounds__(256) k_spmv_sum(DevBb t, SpmvSet ms, size_t ldz, fe *out, size_t m) {
+    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 slot = blockIdx.y;
+    if (row >= m) return;
+    E9 acc = e9_zero();
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        if (j < ms.nm) {
+            const u32 *rp = ms.rowptr[j], *cl = ms.col[j];
+            for (u32 k = rp[row]; k < rp[row + 1]; k++) {
+                E9 v;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) v.c[c] = ms.val[j][(size_t)k * RE + TAU * slot + c];
+                acc = e9_add(acc, e9_mul(v, ld9(ms.z[j], ldz, slot, cl[k]), t.nu));
+            }
+        }
+    }
+    st9(out, m, slot, row, acc);
+}
+void launch_spmv_sum(const DevBb &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const fe *const *val, const fe *z, size_t z_stride,
+                     size_t ldz, fe *out, size_t m, hipStream_t s) {
+    SpmvSet ms = {};
+    ms.nm = nm;
+    for (u32 j = 0; j < nm && j < 4; j++) { ms.rowptr[j] = rowptr[j]; ms.col[j] = col[j]; ms.val[j] = val[j]; ms.z[j] = z + (size_t)j * z_stride; }
+    hipLaunchKernelGGL(k_spmv_sum, dim3(cdiv(m, 256), 8), dim3(256), 0, s, t, ms, ldz, out, m);
+}
 // q[col] = sum_{rows} eq[row] * val  (CSC)
 __global__ void __launch_bounds__(256) k_spmv_t_eq(DevBb t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m,
                                                    fe *q, size_t n) {
