@@ -1172,7 +1172,7 @@ void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *
 // f(X) = u(X) + v(X) r1 with small-integer linear u, v, so  f^3 - f = (u^3-u) + (3u^2 v - v) r1 + 3 u v^2 r1^2 + v^3 r1^3
 // and the mu-weighted sums of the 16 integer coefficients are exact 64-bit integer dot products again.
 template <bool NU>
-__global__ void __launch_bounds__(256) k_fold_round2(DevCrt t, FoldRoundArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+__global__ void __launch_bounds__(256, 2) k_fold_round2(DevCrt t, FoldRoundArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                                      u32 K, const Fq3Const *mu_pow, Fq3Const r1c, u64 *partial) {
     u32 slot = blockIdx.y;
     const size_t pend = a.p0 + a.pcnt;
