@@ -888,7 +888,7 @@ __device__ __forceinline__ void fold_store(i64 (&acc)[5 * TAU], u32 slot, i64 *p
 }
 // round 1: f-hat entries are the base-2 digits themselves, so h(f0 + X (f1 - f0)) is a small integer (|.| <= 720) and
 // vanishes at X = 0, 1; S(X) = sum M[k][d] * h is accumulated as exact integer multiples of the (uniform) constants.
-__global__ void __launch_bounds__(256) k_fold_round1(DevBb t, FoldArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+__global__ void __launch_bounds__(256, 2) k_fold_round1(DevBb t, FoldArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                                                      const E9C *Mc, i64 *partial) {
     u32 slot = blockIdx.y;
     i64 acc[5 * TAU];
