@@ -766,37 +766,37 @@ void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, con
 // ---------------------------------------------------------------------------------------------------------
 // batched inner products (evaluate_mles, utils/mle_helpers.rs:65-88, restructured as dot products)
 constexpr u32 RED_BLOCKS = 256;
-template <bool NU>
+// NB = number of Y tables (compile time: the accumulators of unused tables would otherwise cost a wave of occupancy)
+template <bool NU, int NB>
 __global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n,
                                                    u64 *partial) {
     // grid (RED_BLOCKS, 8 slots, na); each block streams its X_a once against all nb <= 4 tables Y_b (Y stays in L2/MALL)
     u32 slot = blockIdx.y, a = blockIdx.z;
-    LH5 acc[4];
-    Fq3 accg[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
+    LH5 acc[NB];
+    Fq3 accg[NB];
 #pragma unroll
-    for (int b = 0; b < 4; b++) lh5_zero(acc[b]);
+    for (int b = 0; b < NB; b++) { lh5_zero(acc[b]); accg[b] = fq3_zero(); }
     const u64 *Xa = X + (size_t)a * 24 * ldx;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         Fq3 x = ld3(Xa, ldx, slot, i);
 #pragma unroll
-        for (int b = 0; b < 4; b++)
-            if ((u32)b < nb) {
-                Fq3 y = ld3(Y + (size_t)b * 24 * ldy, ldy, slot, i);
-                if (NU) lh5_mac(acc[b], x, y);
-                else accg[b] = fq3_add(accg[b], M3<NU>(x, y, t.nu));
-            }
+        for (int b = 0; b < NB; b++) {
+            Fq3 y = ld3(Y + (size_t)b * 24 * ldy, ldy, slot, i);
+            if (NU) lh5_mac(acc[b], x, y);
+            else accg[b] = fq3_add(accg[b], M3<NU>(x, y, t.nu));
+        }
     }
-    u64 v[12];
+    u64 v[3 * NB];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        Fq3 r = (u32)b < nb ? (NU ? lh5_finish(acc[b]) : accg[b]) : fq3_zero();
+    for (int b = 0; b < NB; b++) {
+        Fq3 r = NU ? lh5_finish(acc[b]) : accg[b];
         v[3 * b] = r.c[0]; v[3 * b + 1] = r.c[1]; v[3 * b + 2] = r.c[2];
     }
     // partial[block][ (a*nb + b)*24 + 3*slot + c ]
-    __shared__ u64 red[12];
-    block_sum_store<12>(v, red);
+    __shared__ u64 red[3 * NB];
+    block_sum_store<3 * NB>(v, red);
     __syncthreads();
-    if (threadIdx.x < 12) {
+    if (threadIdx.x < 3 * NB) {
         u32 b = threadIdx.x / 3, c = threadIdx.x % 3;
         if (b < nb) partial[(size_t)blockIdx.x * (16 * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[threadIdx.x];
     }
@@ -807,7 +807,18 @@ void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u
     u32 gb = (u32)((n + 255) / 256);
     if (gb > 64) gb = 64;   // fatter threads: the 12-value block reduction per block is not free
     if (gb < 1) gb = 1;
-    LF_LAUNCH(k_dot_batch, t.nu2p40, dim3(gb, 8, na), dim3(256), s, t, X, ldx, na, Y, ldy, nb, n, partial);
+#define LF_DB(N)                                                                                                                           \
+    do {                                                                                                                                \
+        if (t.nu2p40) hipLaunchKernelGGL((k_dot_batch<true, N>), dim3(gb, 8, na), dim3(256), 0, s, t, X, ldx, na, Y, ldy, nb, n, partial);        \
+        else hipLaunchKernelGGL((k_dot_batch<false, N>), dim3(gb, 8, na), dim3(256), 0, s, t, X, ldx, na, Y, ldy, nb, n, partial);                \
+    } while (0)
+    switch (nb) {
+        case 1: LF_DB(1); break;
+        case 2: LF_DB(2); break;
+        case 3: LF_DB(3); break;
+        default: LF_DB(4); break;
+    }
+#undef LF_DB
     hipLaunchKernelGGL(k_reduce_rows, dim3(na * nb * 24), dim3(256), 0, s, partial, gb, 16 * nb * 24, out);
 }
 template <bool NU>
