@@ -1262,9 +1262,14 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // so the separate memory-bound pass over them vanishes (rounds 4-6 at 2^20 rows: 6.25 -> 5.6 ms).
     const bool fused = Gw == 1 && !getenv("LF_FOLD_UNFUSED");
     const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 65536;   // entries; tests lower it
-    int fmode = 0;                 // producer of this round's pairs: 0 tables, 1 fused fix
+    int fmode = 0;                 // producer of this round's pairs: 0 tables, 1 fused fix, 3 / 4 digit look-up table (rounds 3 / 4)
     const u64 *prevF = nullptr;
     size_t prevld = 0;
+    // Rounds 3 and 4 of large unsharded instances never materialise the m/4-entry tables: their entries are one of 81 values
+    // (four ternary digits) and come from a look-up table in LDS (k_fold_round modes 3 and 4); P.s >= 4 and m/4 >= lut_min entries.
+    const size_t lut_min = getenv("LF_FOLD_LUT_MIN") ? (size_t)atoll(getenv("LF_FOLD_LUT_MIN")) : ((size_t)1 << 17);
+    const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !getenv("LF_FOLD_NO_LUT");
+    u64 *d_lut = nullptr;
     for (u32 round = 1; round <= P.s; round++) {
         fmode = 0;
         if (round > 1) {
@@ -1311,11 +1316,32 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                 Fq3 r1 = pt[0], r2 = pt[1], o1 = fq3_sub(fq3_one(), r1), o2 = fq3_sub(fq3_one(), r2);
                 Fq3Const W[4] = {f3c(c->ring.mul3(o1, o2)), f3c(c->ring.mul3(r1, o2)), f3c(c->ring.mul3(o1, r2)), f3c(c->ring.mul3(r1, r2))};
                 size_t q = sharded ? nn / Gw : nn, j0 = sharded ? gr * q : 0;   // this rank's slice of the m/4 entries
-                launch_fold_materialize2(c->dcrt, S[0].planes, S[1].planes, N, j0, q, K, W, F[0], c->stream());
-                curF = F[0]; ldF = q;
+                if (use_lut) {
+                    // lut[code] = sum_b (t_b - 1) W_b, code = sum_b t_b 3^b
+                    std::vector<u64> lut(81 * 3);
+                    for (int code = 0; code < 81; code++) {
+                        Fq3 v = fq3_zero();
+                        int cc = code;
+                        for (int b = 0; b < 4; b++, cc /= 3) {
+                            Fq3 wb = fq3_make(W[b].c[0], W[b].c[1], W[b].c[2]);
+                            if (cc % 3 == 2) v = fq3_add(v, wb);
+                            else if (cc % 3 == 0) v = fq3_sub(v, wb);
+                        }
+                        lut[3 * code] = v.c[0]; lut[3 * code + 1] = v.c[1]; lut[3 * code + 2] = v.c[2];
+                    }
+                    RET(c->tbuf("fold_lut", 81 * 3 + 8, &d_lut));
+                    HIPCHK(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream()));
+                    HIPCHK(hipStreamSynchronize(c->stream()));   // lut is a stack-lifetime buffer
+                    fmode = 3;
+                    curF = nullptr; ldF = q;
+                } else {
+                    launch_fold_materialize2(c->dcrt, S[0].planes, S[1].planes, N, j0, q, K, W, F[0], c->stream());
+                    curF = F[0]; ldF = q;
+                }
             } else if (round > 3) {
                 u64 *fd = F[(round & 1) ? 0 : 1];  // round 4 -> F[1], round 5 -> F[0], ...
-                if (fused && ldF >= fuse_min && ldF >= 4) { prevF = curF; prevld = ldF; fmode = 1; }
+                if (use_lut && round == 4) fmode = 4;
+                else if (fused && ldF >= fuse_min && ldF >= 4) { prevF = curF; prevld = ldF; fmode = 1; }
                 else launch_fix_many(c->dcrt, curF, ldF, fd, ldF / 2, ldF, K2 * 3 * 8, r, c->stream());
                 curF = fd; ldF = ldF / 2;
             }
@@ -1330,6 +1356,8 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->stream());
+        else if (fmode == 3) launch_fold_round_lut(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, K, d_mu, partial, od, c->stream());
+        else if (fmode == 4) launch_fold_round_lut_fix(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else if (fmode == 1) launch_fold_round_fix(c->dcrt, a, prevF, prevld, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->stream());
         c->ev_end(ev);

@@ -1350,12 +1350,31 @@ void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int3
 //   0  F holds the current tables:                         f0 = F[2p], f1 = F[2p+1]
 //   1  fused fix_variables: Fsrc.F holds the PREVIOUS round's tables,  f0 = F[4p] + r (F[4p+1] - F[4p]),  f1 likewise from
 //      4p+2, 4p+3; the fixed pair is also stored to Fsrc.out (ld = Fsrc.ldo) for the next round
-// (Fusing the round-3 materialisation from the coefficient planes the same way measured slower than k_fold_materialize2 + mode 0:
-// the digit extraction costs more ALU than the 4.8 GB pass it saves.)
+//   3  round 3 without materialised tables: after two rounds an entry of table (side,k,d) is sum_b W_b * digit_k(plane[4j+b]) with
+//      four ternary digits, i.e. one of 81 values that do not depend on the table or the slot -- a look-up table in LDS indexed by
+//      the digit code replaces both the 4.8 GB k_fold_materialize2 pass and the table reads of this round
+//   4  round 4 on top of mode 3: the four round-3 entries 4p..4p+3 come from the same look-up table, are fixed with r and the pair
+//      is stored to Fsrc.out like in mode 1 (the first materialised tables are the m/8-entry ones)
+// (An earlier variant of mode 3 that rebuilt the entries with conditional modular additions measured slower than the separate pass.)
 struct FoldSrc {
-    u64 *out; size_t ldo;                 // mode 1: where the fixed pair is written (entries 2p, 2p+1)
+    u64 *out; size_t ldo;                 // modes 1, 4: where the fixed pair is written (entries 2p, 2p+1)
     Fq3Const r;
+    const int32_t *planesL, *planesR;     // modes 3, 4
+    size_t n_planes;
+    const u64 *lut;                       // [81][3]: sum_b (t_b - 1) W_b for code = sum_b t_b 3^b
 };
+// digit code of four consecutive plane entries at bit k: 40 + sum_b sign_b * bit_k(|v_b|) * 3^b
+__device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
+    int code = 40;
+    const int w[4] = {1, 3, 9, 27};
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int32_t x = v[b], mg = x < 0 ? -x : x;
+        int bit = (mg >> k) & 1;
+        code += x < 0 ? -bit * w[b] : bit * w[b];
+    }
+    return (u32)code;
+}
 template <bool NU, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow,
                                                     FoldSrc src, u64 *partial) {
@@ -1366,6 +1385,12 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
     const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
+    __shared__ u64 slut[MODE >= 3 ? 81 * 3 : 1];
+    if (MODE >= 3) {
+        for (u32 i = threadIdx.x; i < 81 * 3; i += 256) slut[i] = src.lut[i];
+        __syncthreads();
+    }
+    auto lut3 = [&](u32 code) { return fq3_make(slut[3 * code], slut[3 * code + 1], slut[3 * code + 2]); };
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
@@ -1390,6 +1415,35 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
                 *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
                 df = fq3_sub(f1, f0);
+            } else {
+                constexpr int NE = MODE == 3 ? 8 : 16;      // plane entries behind one pair
+                const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
+                const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)NE * p;
+                int32_t v[NE];
+                if ((size_t)NE * p + NE <= src.n_planes && (src.n_planes & 3) == 0) {
+#pragma unroll
+                    for (int q = 0; q < NE / 4; q++) {
+                        int4 w = *(const int4 *)(pl + 4 * q);
+                        v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NE; q++) v[q] = (size_t)NE * p + q < src.n_planes ? pl[q] : 0;
+                }
+                if (MODE == 3) {
+                    f0 = lut3(digit_code4(v, k));
+                    df = fq3_sub(lut3(digit_code4(v + 4, k)), f0);
+                } else {
+                    Fq3 g0 = lut3(digit_code4(v, k)), g1 = lut3(digit_code4(v + 4, k));
+                    Fq3 g2 = lut3(digit_code4(v + 8, k)), g3 = lut3(digit_code4(v + 12, k));
+                    f0 = fq3_add(g0, M3<NU>(fq3_sub(g1, g0), rfix, nu));
+                    Fq3 f1 = fq3_add(g2, M3<NU>(fq3_sub(g3, g2), rfix, nu));
+                    u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
+                    *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
+                    *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
+                    *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
+                    df = fq3_sub(f1, f0);
+                }
             }
         };
         Fq3 Q[4];
@@ -1461,6 +1515,7 @@ static void launch_fold_round_mode(const DevCrt &t, const FoldRoundArgs &a, cons
         if (pairs * 8 * cc >= 65536) break;
     }
     while (gb * chunks > RED_BLOCKS && chunks > 1) chunks--;
+    if (MODE >= 3) chunks = 1;   // the planes of one (side, d) serve all K tables: no table split (the driver uses these modes on large rounds only)
     if (t.nu2p40) hipLaunchKernelGGL((k_fold_round<true, MODE>), dim3(gb, 8, chunks), dim3(256), 0, s, t, a, F, ldF, K, mu_pow_dev, src, partial);
     else hipLaunchKernelGGL((k_fold_round<false, MODE>), dim3(gb, 8, chunks), dim3(256), 0, s, t, a, F, ldF, K, mu_pow_dev, src, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb * chunks, 120, out);
@@ -1469,6 +1524,22 @@ void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, si
                        u64 *out, hipStream_t s) {
     FoldSrc src = {};
     launch_fold_round_mode<0>(t, a, F, ldF, K, mu_pow_dev, src, partial, out, s);
+}
+// rounds 3 and 4 straight from the coefficient planes through the 81-entry digit look-up table (lut_dev: [81][3], see FoldSrc):
+// round 3 touches no table at all, round 4 fixes with r and writes the first materialised tables Fout [2K*3][24][ldout]
+void launch_fold_round_lut(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                           const u64 *lut_dev, u32 K, const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
+    FoldSrc src = {};
+    src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
+    launch_fold_round_mode<3>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
+}
+void launch_fold_round_lut_fix(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                               const u64 *lut_dev, Fq3Const r, u64 *Fout, size_t ldout, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
+                               u64 *out, hipStream_t s) {
+    FoldSrc src = {};
+    src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
+    src.out = Fout; src.ldo = ldout; src.r = r;
+    launch_fold_round_mode<4>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
 }
 // round message + fused fix_variables: Fprev [2K*3][24][ldprev] (entries 4p..4p+3 of every pair p) -> Fout [..][ldout]
 void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *Fprev, size_t ldprev, Fq3Const r, u64 *Fout, size_t ldout, u32 K,
