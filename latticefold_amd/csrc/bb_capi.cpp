@@ -1130,8 +1130,14 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 16384;   // entries; tests lower it
     const fe *prevF = nullptr;
     size_t prevld = 0;
+    // rounds 3 and 4 of large unsharded instances never materialise the m/4-entry tables (k_fold_round modes 3 and 4)
+    const size_t lut_min = getenv("LF_FOLD_LUT_MIN") ? (size_t)atoll(getenv("LF_FOLD_LUT_MIN")) : ((size_t)1 << 15);
+    const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !getenv("LF_FOLD_NO_LUT");
+    fe *d_lut = nullptr;
+    int lut_mode = 0;
     for (u32 round = 1; round <= P.s; round++) {
         bool fix_fused = false;
+        lut_mode = 0;
         if (round > 1) {
             H9 rh = pt[round - 2];
             E9PreC r = e9pre_from_h9(rh, nu);
@@ -1173,11 +1179,22 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             if (!gathered) {
                 if (round == 3) {
                     size_t q = sharded ? nn / Gw : nn, j0 = sharded ? gr * q : 0;   // this rank's slice of the m/4 entries
-                    launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, j0, q, K, pt[0], pt[1], c->ring, F[0], c->stream());
-                    curF = F[0]; ldF = atl(q);
+                    if (use_lut) {
+                        std::vector<fe> lut(81 * TAU);
+                        build_fold_lut(pt[0], pt[1], c->ring, lut.data());
+                        RET(c->tbuf("fold_lut", 81 * TAU + 8, &d_lut));
+                        HIPCHK(hipMemcpyAsync(d_lut, lut.data(), lut.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream()));
+                        HIPCHK(hipStreamSynchronize(c->stream()));   // lut is a stack-lifetime buffer
+                        lut_mode = 3;
+                        curF = nullptr; ldF = atl(q);
+                    } else {
+                        launch_fold_materialize2(c->dev, S[0].planes, S[1].planes, N, j0, q, K, pt[0], pt[1], c->ring, F[0], c->stream());
+                        curF = F[0]; ldF = atl(q);
+                    }
                 } else if (round > 3) {
                     fe *fd = F[(round & 1) ? 0 : 1];   // round 4 -> F[1], round 5 -> F[0], ...
-                    if (fused && ldF >= fuse_min && ldF >= 4 && nn * 2 == ldF) { prevF = curF; prevld = ldF; fix_fused = true; }
+                    if (use_lut && round == 4) lut_mode = 4;
+                    else if (fused && ldF >= fuse_min && ldF >= 4 && nn * 2 == ldF) { prevF = curF; prevld = ldF; fix_fused = true; }
                     else launch_fix(c->dev, curF, ldF, fd, atl(ldF / 2), ldF, K2 * TAU * 8, r, c->stream());
                     curF = fd; ldF = atl(ldF / 2);
                 }
@@ -1193,6 +1210,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
+        else if (lut_mode == 3) launch_fold_round_lut(c->dev, a, S[0].planes, S[1].planes, N, d_lut, K, d_mup, partial, od, c->stream());
+        else if (lut_mode == 4) launch_fold_round_lut_fix(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else if (fix_fused) launch_fold_round_fix(c->dev, a, prevF, prevld, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());
         c->ev_end(ev);

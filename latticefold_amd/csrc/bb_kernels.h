@@ -114,6 +114,14 @@ void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ld
 // of Fprev, stores the fixed pair to Fout for the next round
 void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, size_t ldprev, const H9 &r, const BbHostRing &ring, fe *Fout,
                            size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);
+// rounds 3 / 4 straight from the coefficient planes through the 81-entry digit look-up table (build_fold_lut, device copy lut_dev):
+// round 3 touches no table, round 4 fixes with r3 and writes the m/8-entry tables
+void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 81 * 9 */);
+void launch_fold_round_lut(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                           u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);
+void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                               const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
+                               hipStream_t s);
 // folded witness in the coefficient domain: out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c) mod X^72 - X^36 + 1
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev /*[2K][24]*/, int32_t *out,
                          hipStream_t s);

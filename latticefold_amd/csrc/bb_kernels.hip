@@ -1086,9 +1086,31 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 // FIX: fix_variables of the previous round fused in (unsharded large rounds): F holds the PREVIOUS tables, the pair is
 //   f0 = F[4j] + r (F[4j+1] - F[4j]),  f1 = F[4j+2] + r (F[4j+3] - F[4j+2])  and is stored to Fout[2j], Fout[2j+1] for the next round;
 // the round kernel is ALU-bound, so the table traffic of the separate memory-bound k_fix pass disappears under it.
-template <bool NU2, bool FIX>
+// MODE 3 / 4 (rounds 3 / 4 of large unsharded instances): no m/4-entry tables at all.  After two rounds an entry of table (side,k,d) is
+// sum_b W_b * digit_k(plane[4j+b]) with four ternary digits -- one of 81 values independent of table and slot -- and comes from a look-up
+// table in LDS indexed by the digit code (lut: [81][9] words); mode 4 also fixes the four round-3 entries of a pair with r and stores the
+// first materialised tables (m/8 entries) like mode 1.  MODE 0: plain tables, MODE 1: fused fix (above).
+struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; };
+__device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
+    int code = 40;
+    const int w[4] = {1, 3, 9, 27};
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int32_t x = v[b], mg = x < 0 ? -x : x;
+        int bit = (mg >> k) & 1;
+        code += x < 0 ? -bit * w[b] : bit * w[b];
+    }
+    return (u32)code;
+}
+template <bool NU2, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
-                                                    fe *Fout, size_t ldo, i64 *partial) {
+                                                    fe *Fout, size_t ldo, FoldLut lt, i64 *partial) {
+    constexpr bool FIX = MODE == 1;
+    __shared__ fe slut[MODE >= 3 ? 81 * TAU : 1];
+    if (MODE >= 3) {
+        for (u32 i = threadIdx.x; i < 81 * TAU; i += 256) slut[i] = lt.lut[i];
+        __syncthreads();
+    }
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
     const u32 tb0 = blockIdx.z * per, tb1 = tb0 + per < ntab ? tb0 + per : ntab;
@@ -1102,7 +1124,41 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
     for (u32 tb = tb0; tb < tb1; tb++) {
         const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
         E9 f0, f1;
-        if (FIX) {
+        if (MODE >= 3) {
+            constexpr int NE = MODE == 3 ? 8 : 16;      // plane entries behind one pair
+            const u32 side = tb / (TAU * K), k = (tb / TAU) % K, d = tb % TAU;
+            const int32_t *pl = (side ? lt.planesR : lt.planesL) + (size_t)(8 * d + slot) * lt.n_planes + (size_t)NE * jj;
+            int32_t v[NE];
+            if ((size_t)NE * jj + NE <= lt.n_planes && (lt.n_planes & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < NE / 4; q++) {
+                    int4 w4 = *reinterpret_cast<const int4 *>(pl + 4 * q);
+                    v[4 * q] = w4.x; v[4 * q + 1] = w4.y; v[4 * q + 2] = w4.z; v[4 * q + 3] = w4.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NE; q++) v[q] = (size_t)NE * jj + q < lt.n_planes ? pl[q] : 0;
+            }
+            if (MODE == 3) {
+                const fe *l0 = slut + TAU * digit_code4(v, k), *l1 = slut + TAU * digit_code4(v + 4, k);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) { f0.c[c] = l0[c]; f1.c[c] = l1[c]; }
+            } else {
+                const fe *l0 = slut + TAU * digit_code4(v, k), *l1 = slut + TAU * digit_code4(v + 4, k);
+                const fe *l2 = slut + TAU * digit_code4(v + 8, k), *l3 = slut + TAU * digit_code4(v + 12, k);
+                E9 a0, a1, b0, b1;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) { a0.c[c] = l0[c]; a1.c[c] = l1[c]; b0.c[c] = l2[c]; b1.c[c] = l3[c]; }
+                E9Pre R = e9p(rfix);
+                f0 = e9_add(a0, e9_mul(e9_sub(a1, a0), R));
+                f1 = e9_add(b0, e9_mul(e9_sub(b1, b0), R));
+                if (live) {
+                    fe *Fo = Fout + ((size_t)tb * RE + TAU * slot) * ldo;
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(Fo + (size_t)c * ldo + 2 * jj) = make_int2(f0.c[c], f1.c[c]);
+                }
+            }
+        } else if (FIX) {
             E9 a0, a1, b0, b1;
 #pragma unroll
             for (int c = 0; c < TAU; c++) {
@@ -1192,8 +1248,8 @@ size_t fold_partial_words(size_t m) {
     if (rows < RED_BLOCKS) rows = RED_BLOCKS;
     return rows * 5 * RE;
 }
-static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, bool fix, E9PreC rfix,
-                                   fe *Fout, size_t ldo, i64 *partial, u64 *out, hipStream_t s) {
+static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, int mode, E9PreC rfix,
+                                   fe *Fout, size_t ldo, FoldLut lt, i64 *partial, u64 *out, hipStream_t s) {
     size_t pairs = a.pcnt;
     u32 gb = (u32)((pairs + 255) / 256);
     if (gb < 1) gb = 1;
@@ -1202,20 +1258,58 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
     while (tch < 32 && pairs * 8 * tch < (1u << 17)) tch *= 2;
     while (tch > 1 && (size_t)gb * tch > RED_BLOCKS) tch /= 2;
     const bool nu2 = t.nu == BB_TWO;
-#define BB_FR(N2, FX) hipLaunchKernelGGL((k_fold_round<N2, FX>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, rfix, Fout, ldo, partial)
-    if (nu2) { if (fix) BB_FR(true, true); else BB_FR(true, false); }
-    else { if (fix) BB_FR(false, true); else BB_FR(false, false); }
+    if (mode >= 3) tch = 1;   // the planes of one (side, d) serve all K tables: no table split (large rounds only)
+#define BB_FR(N2, MD) hipLaunchKernelGGL((k_fold_round<N2, MD>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, rfix, Fout, ldo, lt, partial)
+#define BB_FRM(N2)                                                              \
+    do {                                                                        \
+        if (mode == 1) BB_FR(N2, 1); else if (mode == 3) BB_FR(N2, 3);          \
+        else if (mode == 4) BB_FR(N2, 4); else BB_FR(N2, 0);                    \
+    } while (0)
+    if (nu2) BB_FRM(true); else BB_FRM(false);
+#undef BB_FRM
 #undef BB_FR
     launch_reduce_rows(partial, gb * tch, 5 * RE, out, s);
 }
 void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                        hipStream_t s) {
     E9PreC none = {};
-    launch_fold_round_impl(t, a, F, ldF, K, Mpre, false, none, nullptr, 0, partial, out, s);
+    FoldLut nl = {};
+    launch_fold_round_impl(t, a, F, ldF, K, Mpre, 0, none, nullptr, 0, nl, partial, out, s);
+}
+void launch_fold_round_lut(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                           u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
+    E9PreC none = {};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev};
+    launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 3, none, nullptr, 0, lt, partial, out, s);
+}
+void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                               const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
+                               hipStream_t s) {
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev};
+    launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 4, e9pre_from_h9(r, ring.T.nu), Fout, ldout, lt, partial, out, s);
+}
+// the 81-entry table of modes 3 / 4: lut[code][c] = sum_b (t_b - 1) W_b[c], code = sum_b t_b 3^b, W = eq((r1, r2), .)
+void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 81 * 9 */) {
+    H9 one;
+    for (int i = 0; i < TAU; i++) one.c[i] = i == 0;
+    H9 o1, o2;
+    for (int i = 0; i < TAU; i++) { o1.c[i] = hsub(one.c[i], r1.c[i]); o2.c[i] = hsub(one.c[i], r2.c[i]); }
+    H9 Wb[4] = {ring.mul9(o1, o2), ring.mul9(r1, o2), ring.mul9(o1, r2), ring.mul9(r1, r2)};
+    for (int code = 0; code < 81; code++)
+        for (int c = 0; c < TAU; c++) {
+            u64 v = 0;
+            int cc = code;
+            for (int b = 0; b < 4; b++, cc /= 3) {
+                if (cc % 3 == 2) v = hadd(v, Wb[b].c[c]);
+                else if (cc % 3 == 0) v = hsub(v, Wb[b].c[c]);
+            }
+            lut_host[code * TAU + c] = from_canon(v);
+        }
 }
 void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, size_t ldprev, const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout,
                            u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
-    launch_fold_round_impl(t, a, Fprev, ldprev, K, Mpre, true, e9pre_from_h9(r, ring.T.nu), Fout, ldout, partial, out, s);
+    FoldLut nl = {};
+    launch_fold_round_impl(t, a, Fprev, ldprev, K, Mpre, 1, e9pre_from_h9(r, ring.T.nu), Fout, ldout, nl, partial, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -236,11 +236,18 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
     lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
     monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
+    monkeypatch.setenv("LF_FOLD_NO_LUT", "1")
     lc_f, w_f, proof_f = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    # rounds 3 and 4 from the 81-entry digit look-up table instead of materialised m/4-entry tables (large instances by default)
+    monkeypatch.delenv("LF_FOLD_NO_LUT")
+    monkeypatch.setenv("LF_FOLD_LUT_MIN", "1")
+    lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    monkeypatch.delenv("LF_FOLD_LUT_MIN")
     monkeypatch.delenv("LF_FOLD_FUSE_MIN")
     monkeypatch.setenv("LF_FOLD_UNFUSED", "1")
     lc_u, w_u, proof_u = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
     assert (proof_f == proof_o).all() and (lc_f == lc_o).all() and (w_f.f == f0_o).all()
+    assert (proof_l == proof_o).all() and (lc_l == lc_o).all() and (w_l.f == f0_o).all()
     assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
 
 
