@@ -1279,7 +1279,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("c_rho", (size_t)K2 * 24 + 64, &d_rho));
     HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->stream()));
     int32_t *npl;
-    HIPCHK(hipMalloc((void **)&npl, N * RE * 4));
+    RET(lf_planes_alloc(c->owner, N * RE * 4, &npl));
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c->owner, npl, N};

@@ -271,10 +271,12 @@ static void free_ccs(lf_ctx *c) {
     c->d_rowptr.clear(); c->d_col.clear(); c->d_val.clear(); c->d_colptr.clear(); c->d_rowidx.clear(); c->d_valT.clear();
     c->have_ccs = false;
 }
+static void planes_pool_drop(int device);
 void lf_ctx_destroy(lf_ctx *c) {
     if (!c) return;
-    if (c->bb) { c->bb->destroy(); delete c; return; }
     (void)hipSetDevice(c->device);
+    planes_pool_drop(c->device);
+    if (c->bb) { c->bb->destroy(); delete c; return; }
     (void)hipStreamSynchronize(c->st_lane[0]);
     (void)hipStreamSynchronize(c->st_lane[1]);
     free_ccs(c);
@@ -839,10 +841,43 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));
     return commit_download(c, o, (size_t)c->kappa * 24, cm_out);
 }
+// pool of recycled witness-plane buffers: process-wide (a witness may be freed after its context), keyed by device and size
+namespace {
+struct PoolEnt { int device; size_t bytes; int32_t *p; };
+std::mutex g_pool_mu;
+std::vector<PoolEnt> g_pool;
+}  // namespace
+int lf_planes_alloc(lf_ctx *c, size_t bytes, int32_t **out) {
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].device == c->device && g_pool[i].bytes == bytes) {
+                *out = g_pool[i].p;
+                g_pool.erase(g_pool.begin() + (long)i);
+                return LF_OK;
+            }
+    }
+    return hipMalloc((void **)out, bytes) == hipSuccess ? LF_OK : LF_ERR_HIP;
+}
+static void planes_release_dev(int device, size_t bytes, int32_t *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        if (g_pool.size() < 3) { g_pool.push_back({device, bytes, p}); return; }
+    }
+    (void)hipFree(p);
+}
+void lf_planes_release(lf_ctx *c, size_t bytes, int32_t *p) { planes_release_dev(c->device, bytes, p); }
+static void planes_pool_drop(int device) {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size();)
+        if (g_pool[i].device == device) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + (long)i); }
+        else i++;
+}
 void lf_witness_free(lf_witness *w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipFree(w->planes);
+    lf_planes_release(w->ctx, w->N * (size_t)lf_ring_words(lf_ctx_ring(w->ctx)) * 4, w->planes);
     delete w;
 }
 
@@ -1432,7 +1467,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("c_rho", (size_t)K2 * 24 + 64, &d_rho));
     HIPCHK(hipMemcpyAsync(d_rho, rho8.data(), rho8.size(), hipMemcpyHostToDevice, c->stream()));
     int32_t *npl;
-    HIPCHK(hipMalloc((void **)&npl, N * 24 * 4));
+    RET(lf_planes_alloc(c, N * 24 * 4, &npl));
     LF_TRACE(c, "theta/eta");
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     LF_TRACE(c, "fold_witness");

@@ -43,3 +43,9 @@ struct lf_witness {
     int32_t *planes;  // [d][N] centred integer coefficients (d = 24 Goldilocks, 72 BabyBear)
     size_t N;
 };
+
+// Device buffers of witness planes are recycled through a small per-context pool: a fold step produces one folded witness and
+// its caller frees one, and hipMalloc / hipFree of ~100 MB cost several hundred microseconds (hipFree synchronises the device).
+int lf_planes_alloc(lf_ctx *ctx, size_t bytes, int32_t **out);
+void lf_planes_release(lf_ctx *ctx, size_t bytes, int32_t *p);
+
