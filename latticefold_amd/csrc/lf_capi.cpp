@@ -1353,7 +1353,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                 size_t q = sharded ? nn / Gw : nn, j0 = sharded ? gr * q : 0;   // this rank's slice of the m/4 entries
                 if (use_lut) {
                     // lut[code] = sum_b (t_b - 1) W_b, code = sum_b t_b 3^b
-                    std::vector<u64> lut(81 * 3);
+                    std::vector<u64> lut(2 * 81 * 3);   // the 81 values, then their squares
                     for (int code = 0; code < 81; code++) {
                         Fq3 v = fq3_zero();
                         int cc = code;
@@ -1363,8 +1363,10 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                             else if (cc % 3 == 0) v = fq3_sub(v, wb);
                         }
                         lut[3 * code] = v.c[0]; lut[3 * code + 1] = v.c[1]; lut[3 * code + 2] = v.c[2];
+                        Fq3 sq = c->ring.mul3(v, v);
+                        lut[3 * (81 + code)] = sq.c[0]; lut[3 * (81 + code) + 1] = sq.c[1]; lut[3 * (81 + code) + 2] = sq.c[2];
                     }
-                    RET(c->tbuf("fold_lut", 81 * 3 + 8, &d_lut));
+                    RET(c->tbuf("fold_lut", 2 * 81 * 3 + 8, &d_lut));
                     HIPCHK(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream()));
                     HIPCHK(hipStreamSynchronize(c->stream()));   // lut is a stack-lifetime buffer
                     fmode = 3;

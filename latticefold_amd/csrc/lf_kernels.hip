@@ -1361,7 +1361,7 @@ struct FoldSrc {
     Fq3Const r;
     const int32_t *planesL, *planesR;     // modes 3, 4
     size_t n_planes;
-    const u64 *lut;                       // [81][3]: sum_b (t_b - 1) W_b for code = sum_b t_b 3^b
+    const u64 *lut;                       // [2][81][3]: sum_b (t_b - 1) W_b for code = sum_b t_b 3^b, then the squares of those
 };
 // digit code of four consecutive plane entries at bit k: 40 + sum_b sign_b * bit_k(|v_b|) * 3^b
 __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
@@ -1385,9 +1385,9 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
     const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
-    __shared__ u64 slut[MODE >= 3 ? 81 * 3 : 1];
+    __shared__ u64 slut[MODE >= 3 ? 2 * 81 * 3 : 1];   // the 81 values, then their squares
     if (MODE >= 3) {
-        for (u32 i = threadIdx.x; i < 81 * 3; i += 256) slut[i] = src.lut[i];
+        for (u32 i = threadIdx.x; i < 2 * 81 * 3; i += 256) slut[i] = src.lut[i];
         __syncthreads();
     }
     auto lut3 = [&](u32 code) { return fq3_make(slut[3 * code], slut[3 * code + 1], slut[3 * code + 2]); };
@@ -1447,7 +1447,42 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             }
         };
         Fq3 Q[4];
-        if (NU) {
+        if (NU && MODE == 3) {
+            // Both ends of a pair are look-up values, so their squares are too: with t = mu f0, u = mu f1 the four lazy sums
+            //   P0 = sum t f0^2, P1 = sum u f0^2, P2 = sum t f1^2, P3 = sum u f1^2   (= sum mu f0^3, mu f0^2 f1, mu f0 f1^2, mu f1^3)
+            // need two reduced products per table instead of four; the cubic coefficients in df = f1 - f0 follow by binomials.
+            LH5 A0, A1, A2, A3;
+            lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
+            Fq3 sp = fq3_zero(), su = fq3_zero();
+            for (u32 kd = kd0; kd < kd1; kd++) {
+                const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
+                const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)8 * p;
+                int32_t v[8];
+                if ((size_t)8 * p + 8 <= src.n_planes && (src.n_planes & 3) == 0) {
+                    int4 w0 = *(const int4 *)pl, w1 = *(const int4 *)(pl + 4);
+                    v[0] = w0.x; v[1] = w0.y; v[2] = w0.z; v[3] = w0.w; v[4] = w1.x; v[5] = w1.y; v[6] = w1.z; v[7] = w1.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = (size_t)8 * p + q < src.n_planes ? pl[q] : 0;
+                }
+                const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k);
+                Fq3 f0 = lut3(c0), f1 = lut3(c1), s0 = lut3(81 + c0), s1 = lut3(81 + c1);
+                Fq3Const mc = mu_pow[kd];
+                Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
+                Fq3 tt = fq3_mul_2p40(mu, f0), uu = fq3_mul_2p40(mu, f1);
+                lh5_mac(A0, tt, s0); lh5_mac(A1, uu, s0); lh5_mac(A2, tt, s1); lh5_mac(A3, uu, s1);
+                sp = fq3_add(sp, tt); su = fq3_add(su, uu);
+            }
+            Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2), P3 = lh5_finish(A3);
+            Fq3 a1 = fq3_sub(P1, P0);                                           // sum mu f0^2 df
+            Fq3 a2 = fq3_add(fq3_sub(P2, fq3_add(P1, P1)), P0);                 // sum mu f0 df^2
+            Fq3 p12 = fq3_sub(P1, P2);
+            Fq3 a3 = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12)); // sum mu df^3 = P3 - 3 P2 + 3 P1 - P0
+            Q[0] = fq3_sub(P0, sp);
+            Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
+            Q[2] = fq3_add(fq3_add(a2, a2), a2);
+            Q[3] = a3;
+        } else if (NU) {
             // sum_kd mu (f0 + X df)^3 - mu (f0 + X df):  with p = mu f0, q = mu df the cubic coefficients are
             //   sum p f0^2,  3 sum q f0^2,  3 sum p df^2,  sum q df^2   -- four LAZY sums, 4 reduced products per table
             LH5 A0, A1, A2, A3;
