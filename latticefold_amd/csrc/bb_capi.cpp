@@ -1180,9 +1180,9 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                 if (round == 3) {
                     size_t q = sharded ? nn / Gw : nn, j0 = sharded ? gr * q : 0;   // this rank's slice of the m/4 entries
                     if (use_lut) {
-                        std::vector<fe> lut(81 * TAU);
+                        std::vector<fe> lut(2 * 81 * TAU);
                         build_fold_lut(pt[0], pt[1], c->ring, lut.data());
-                        RET(c->tbuf("fold_lut", 81 * TAU + 8, &d_lut));
+                        RET(c->tbuf("fold_lut", 2 * 81 * TAU + 8, &d_lut));
                         HIPCHK(hipMemcpyAsync(d_lut, lut.data(), lut.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream()));
                         HIPCHK(hipStreamSynchronize(c->stream()));   // lut is a stack-lifetime buffer
                         lut_mode = 3;

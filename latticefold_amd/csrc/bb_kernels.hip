@@ -1106,10 +1106,15 @@ template <bool NU2, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
                                                     fe *Fout, size_t ldo, FoldLut lt, i64 *partial) {
     constexpr bool FIX = MODE == 1;
-    __shared__ fe slut[MODE >= 3 ? 81 * TAU : 1];
+    __shared__ fe slut[MODE >= 3 ? 2 * 81 * TAU : 1];   // the 81 values, then their squares
     if (MODE >= 3) {
-        for (u32 i = threadIdx.x; i < 81 * TAU; i += 256) slut[i] = lt.lut[i];
+        for (u32 i = threadIdx.x; i < 2 * 81 * TAU; i += 256) slut[i] = lt.lut[i];
         __syncthreads();
+    }
+    i64 SP[MODE == 3 ? TAU : 1], SU[MODE == 3 ? TAU : 1];   // mode 3: sum M f0, sum M f1
+    if (MODE == 3) {
+#pragma unroll
+        for (int c = 0; c < TAU; c++) { SP[c] = 0; SU[c] = 0; }
     }
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
@@ -1140,9 +1145,31 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
                 for (int q = 0; q < NE; q++) v[q] = (size_t)NE * jj + q < lt.n_planes ? pl[q] : 0;
             }
             if (MODE == 3) {
-                const fe *l0 = slut + TAU * digit_code4(v, k), *l1 = slut + TAU * digit_code4(v + 4, k);
+                // both ends of the pair and their squares are look-up values: with t = M f0, u = M f1 the lazy sums
+                //   P0 = sum t f0^2, P1 = sum u f0^2, P2 = sum t f1^2, P3 = sum u f1^2
+                // take two products by M and four lazy products per table (no squarings); C0..C3 follow by binomials after the loop
+                const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k);
+                const fe *l0 = slut + TAU * c0, *l1 = slut + TAU * c1, *q0 = slut + TAU * (81 + c0), *q1 = slut + TAU * (81 + c1);
+                E9 s0, s1;
 #pragma unroll
-                for (int c = 0; c < TAU; c++) { f0.c[c] = l0[c]; f1.c[c] = l1[c]; }
+                for (int c = 0; c < TAU; c++) { f0.c[c] = l0[c]; f1.c[c] = l1[c]; s0.c[c] = q0[c]; s1.c[c] = q1[c]; }
+                E9Pre M = e9p(Mpre[tb]);
+                E9 tt = e9_mul(f0, M), uu = e9_mul(f1, M);
+                E9 s0n = e9_times_nu_t<NU2>(s0, t.nu), s1n = e9_times_nu_t<NU2>(s1, t.nu);
+                i64 T[TAU];
+                e9_mul_cols(tt, s0, s0n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) hl_add(C[c], T[c]);
+                e9_mul_cols(uu, s0, s0n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) hl_add(C[TAU + c], T[c]);
+                e9_mul_cols(tt, s1, s1n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) hl_add(C[2 * TAU + c], T[c]);
+                e9_mul_cols(uu, s1, s1n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) { hl_add(C[3 * TAU + c], T[c]); SP[c] += tt.c[c]; SU[c] += uu.c[c]; }
+                continue;
             } else {
                 const fe *l0 = slut + TAU * digit_code4(v, k), *l1 = slut + TAU * digit_code4(v + 4, k);
                 const fe *l2 = slut + TAU * digit_code4(v + 8, k), *l3 = slut + TAU * digit_code4(v + 12, k);
@@ -1217,8 +1244,16 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         E9 c0, c1, c2, c3;
 #pragma unroll
         for (int c = 0; c < TAU; c++) {
-            c0.c[c] = hl_finish(C[c]); c1.c[c] = hl_finish(C[TAU + c]);
-            c2.c[c] = fred(3 * (i64)hl_finish(C[2 * TAU + c])); c3.c[c] = hl_finish(C[3 * TAU + c]);
+            if (MODE == 3) {
+                // C0 = P0 - sp, C1 = 3 (P1 - P0) - (su - sp), 3 C2 = 3 (P2 - 2 P1 + P0), C3 = P3 - 3 P2 + 3 P1 - P0   (values of a few p: one reduction)
+                i64 P0 = hl_finish(C[c]), P1 = hl_finish(C[TAU + c]), P2 = hl_finish(C[2 * TAU + c]), P3 = hl_finish(C[3 * TAU + c]);
+                i64 sp = fred(SP[c]), su = fred(SU[c]);
+                c0.c[c] = fred(P0 - sp); c1.c[c] = fred(3 * (P1 - P0) - (su - sp));
+                c2.c[c] = fred(3 * (P2 - 2 * P1 + P0)); c3.c[c] = fred(P3 - 3 * P2 + 3 * P1 - P0);
+            } else {
+                c0.c[c] = hl_finish(C[c]); c1.c[c] = hl_finish(C[TAU + c]);
+                c2.c[c] = fred(3 * (i64)hl_finish(C[2 * TAU + c])); c3.c[c] = hl_finish(C[3 * TAU + c]);
+            }
         }
         E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1);
         E9 es = e9_sub(e1, e0), e = e0;
@@ -1289,13 +1324,14 @@ void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t 
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 4, e9pre_from_h9(r, ring.T.nu), Fout, ldout, lt, partial, out, s);
 }
 // the 81-entry table of modes 3 / 4: lut[code][c] = sum_b (t_b - 1) W_b[c], code = sum_b t_b 3^b, W = eq((r1, r2), .)
-void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 81 * 9 */) {
+void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 2 * 81 * 9: values, then squares */) {
     H9 one;
     for (int i = 0; i < TAU; i++) one.c[i] = i == 0;
     H9 o1, o2;
     for (int i = 0; i < TAU; i++) { o1.c[i] = hsub(one.c[i], r1.c[i]); o2.c[i] = hsub(one.c[i], r2.c[i]); }
     H9 Wb[4] = {ring.mul9(o1, o2), ring.mul9(r1, o2), ring.mul9(o1, r2), ring.mul9(r1, r2)};
-    for (int code = 0; code < 81; code++)
+    for (int code = 0; code < 81; code++) {
+        H9 val;
         for (int c = 0; c < TAU; c++) {
             u64 v = 0;
             int cc = code;
@@ -1303,8 +1339,12 @@ void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_
                 if (cc % 3 == 2) v = hadd(v, Wb[b].c[c]);
                 else if (cc % 3 == 0) v = hsub(v, Wb[b].c[c]);
             }
+            val.c[c] = v;
             lut_host[code * TAU + c] = from_canon(v);
         }
+        H9 sq = ring.mul9(val, val);
+        for (int c = 0; c < TAU; c++) lut_host[(81 + code) * TAU + c] = from_canon(sq.c[c]);
+    }
 }
 void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, size_t ldprev, const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout,
                            u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
