@@ -1106,10 +1106,21 @@ template <bool NU2, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
                                                     fe *Fout, size_t ldo, FoldLut lt, i64 *partial) {
     constexpr bool FIX = MODE == 1;
-    __shared__ fe slut[MODE >= 3 ? 2 * 81 * TAU : 1];   // the 81 values, then their squares
+    __shared__ fe slut[MODE >= 3 ? 3 * 81 * TAU : 1];   // the 81 values, their squares, (mode 4) r times the values
     if (MODE >= 3) {
         for (u32 i = threadIdx.x; i < 2 * 81 * TAU; i += 256) slut[i] = lt.lut[i];
         __syncthreads();
+        if (MODE == 4) {   // fix_variables on look-up values needs no product per entry: f = g0 + r g1 - r g0
+            if (threadIdx.x < 81) {
+                E9 g;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) g.c[c] = slut[TAU * threadIdx.x + c];
+                E9 rv = e9_mul(g, e9p(rfix));
+#pragma unroll
+                for (int c = 0; c < TAU; c++) slut[TAU * (162 + threadIdx.x) + c] = rv.c[c];
+            }
+            __syncthreads();
+        }
     }
     i64 SP[MODE == 3 ? TAU : 1], SU[MODE == 3 ? TAU : 1];   // mode 3: sum M f0, sum M f1
     if (MODE == 3) {
@@ -1171,14 +1182,14 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
                 for (int c = 0; c < TAU; c++) { hl_add(C[3 * TAU + c], T[c]); SP[c] += tt.c[c]; SU[c] += uu.c[c]; }
                 continue;
             } else {
-                const fe *l0 = slut + TAU * digit_code4(v, k), *l1 = slut + TAU * digit_code4(v + 4, k);
-                const fe *l2 = slut + TAU * digit_code4(v + 8, k), *l3 = slut + TAU * digit_code4(v + 12, k);
-                E9 a0, a1, b0, b1;
+                const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k), c2 = digit_code4(v + 8, k), c3 = digit_code4(v + 12, k);
+                const fe *g0 = slut + TAU * c0, *g2 = slut + TAU * c2;
+                const fe *r0 = slut + TAU * (162 + c0), *r1 = slut + TAU * (162 + c1), *r2 = slut + TAU * (162 + c2), *r3 = slut + TAU * (162 + c3);
 #pragma unroll
-                for (int c = 0; c < TAU; c++) { a0.c[c] = l0[c]; a1.c[c] = l1[c]; b0.c[c] = l2[c]; b1.c[c] = l3[c]; }
-                E9Pre R = e9p(rfix);
-                f0 = e9_add(a0, e9_mul(e9_sub(a1, a0), R));
-                f1 = e9_add(b0, e9_mul(e9_sub(b1, b0), R));
+                for (int c = 0; c < TAU; c++) {
+                    f0.c[c] = fadd(g0[c], fsub(r1[c], r0[c]));
+                    f1.c[c] = fadd(g2[c], fsub(r3[c], r2[c]));
+                }
                 if (live) {
                     fe *Fo = Fout + ((size_t)tb * RE + TAU * slot) * ldo;
 #pragma unroll

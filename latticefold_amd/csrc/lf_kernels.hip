@@ -1385,10 +1385,17 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
     const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
-    __shared__ u64 slut[MODE >= 3 ? 2 * 81 * 3 : 1];   // the 81 values, then their squares
+    __shared__ u64 slut[MODE >= 3 ? 3 * 81 * 3 : 1];   // the 81 values, their squares, (mode 4) r times the values
     if (MODE >= 3) {
         for (u32 i = threadIdx.x; i < 2 * 81 * 3; i += 256) slut[i] = src.lut[i];
         __syncthreads();
+        if (MODE == 4) {   // fix_variables on look-up values needs no product per entry: f = g0 + r g1 - r g0
+            if (threadIdx.x < 81) {
+                Fq3 rv = M3<NU>(fq3_make(slut[3 * threadIdx.x], slut[3 * threadIdx.x + 1], slut[3 * threadIdx.x + 2]), rfix, nu);
+                slut[3 * (162 + threadIdx.x)] = rv.c[0]; slut[3 * (162 + threadIdx.x) + 1] = rv.c[1]; slut[3 * (162 + threadIdx.x) + 2] = rv.c[2];
+            }
+            __syncthreads();
+        }
     }
     auto lut3 = [&](u32 code) { return fq3_make(slut[3 * code], slut[3 * code + 1], slut[3 * code + 2]); };
     Fq3 acc[5];
@@ -1434,10 +1441,9 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                     f0 = lut3(digit_code4(v, k));
                     df = fq3_sub(lut3(digit_code4(v + 4, k)), f0);
                 } else {
-                    Fq3 g0 = lut3(digit_code4(v, k)), g1 = lut3(digit_code4(v + 4, k));
-                    Fq3 g2 = lut3(digit_code4(v + 8, k)), g3 = lut3(digit_code4(v + 12, k));
-                    f0 = fq3_add(g0, M3<NU>(fq3_sub(g1, g0), rfix, nu));
-                    Fq3 f1 = fq3_add(g2, M3<NU>(fq3_sub(g3, g2), rfix, nu));
+                    const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k), c2 = digit_code4(v + 8, k), c3 = digit_code4(v + 12, k);
+                    f0 = fq3_add(lut3(c0), fq3_sub(lut3(162 + c1), lut3(162 + c0)));
+                    Fq3 f1 = fq3_add(lut3(c2), fq3_sub(lut3(162 + c3), lut3(162 + c2)));
                     u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
                     *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
                     *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
