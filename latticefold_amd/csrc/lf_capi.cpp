@@ -1393,7 +1393,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->stream());
-        else if (fmode == 3) launch_fold_round_lut(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, K, d_mu, partial, od, c->stream());
+        else if (fmode == 3 && c->dcrt.nu2p40 && !getenv("LF_FOLD_NO_MUTAB")) {
+            u64 *mutab;
+            RET(c->tbuf("fold_mutab", (size_t)3 * K2 * 3 * 81 * 4, &mutab));
+            launch_fold_round_lut_mu(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, mutab, K, d_mu, partial, od, c->stream());
+        } else if (fmode == 3) launch_fold_round_lut(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, K, d_mu, partial, od, c->stream());
         else if (fmode == 4) launch_fold_round_lut_fix(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else if (fmode == 1) launch_fold_round_fix(c->dcrt, a, prevF, prevld, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->stream());

@@ -144,6 +144,10 @@ void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *F
 // sum_b t_b 3^b = sum_b (t_b - 1) W_b, W = eq((r1,r2), .)); round 4 also fixes with r3 and writes the m/8-entry tables
 void launch_fold_round_lut(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                            const u64 *lut_dev, u32 K, const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s);
+// round 3 with per-table products mu_kd * {value, value^2, value^3} of the look-up values (mutab_dev: 3 * 2K*3 * 81 * 4 words,
+// filled by this call): two lazy products per table.  Only for the default non-residue (nu = 2^40).
+void launch_fold_round_lut_mu(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                              const u64 *lut_dev, u64 *mutab_dev, u32 K, const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s);
 void launch_fold_round_lut_fix(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                const u64 *lut_dev, Fq3Const r, u64 *Fout, size_t ldout, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
                                u64 *out, hipStream_t s);

@@ -1362,7 +1362,23 @@ struct FoldSrc {
     const int32_t *planesL, *planesR;     // modes 3, 4
     size_t n_planes;
     const u64 *lut;                       // [2][81][3]: sum_b (t_b - 1) W_b for code = sum_b t_b 3^b, then the squares of those
+    const u64 *mutab;                     // mode 5: [3][2K*3][81][4] = mu_kd * value, mu_kd * value^2, mu_kd * value^3 (k_fold_mutab)
 };
+// per-table products of the 81 look-up values with mu_kd (round 3, mode 5): with them a table costs two lazy products instead of six
+template <bool NU>
+__global__ void __launch_bounds__(128) k_fold_mutab(DevCrt t, const u64 *lut, const Fq3Const *mu_pow, u32 nkd, u64 *mutab) {
+    u32 kd = blockIdx.x, code = threadIdx.x;
+    if (code >= 81) return;
+    Fq3 L = fq3_make(lut[3 * code], lut[3 * code + 1], lut[3 * code + 2]);
+    Fq3Const mc = mu_pow[kd];
+    Fq3 m1 = M3<NU>(fq3_make(mc.c[0], mc.c[1], mc.c[2]), L, t.nu), m2 = M3<NU>(m1, L, t.nu), m3 = M3<NU>(m2, L, t.nu);
+    const Fq3 v[3] = {m1, m2, m3};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        u64 *o = mutab + (((size_t)q * nkd + kd) * 81 + code) * 4;
+        o[0] = v[q].c[0]; o[1] = v[q].c[1]; o[2] = v[q].c[2]; o[3] = 0;
+    }
+}
 // digit code of four consecutive plane entries at bit k: 40 + sum_b sign_b * bit_k(|v_b|) * 3^b
 __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
     int code = 40;
@@ -1385,7 +1401,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
     const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
-    __shared__ u64 slut[MODE >= 3 ? 3 * 81 * 3 : 1];   // the 81 values, their squares, (mode 4) r times the values
+    __shared__ u64 slut[MODE >= 3 ? 3 * 81 * 3 : 1];   // (mode 5 uses the values only)   // the 81 values, their squares, (mode 4) r times the values
     if (MODE >= 3) {
         for (u32 i = threadIdx.x; i < 2 * 81 * 3; i += 256) slut[i] = src.lut[i];
         __syncthreads();
@@ -1423,7 +1439,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
                 df = fq3_sub(f1, f0);
             } else {
-                constexpr int NE = MODE == 3 ? 8 : 16;      // plane entries behind one pair
+                constexpr int NE = MODE == 4 ? 16 : 8;      // plane entries behind one pair
                 const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
                 const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)NE * p;
                 int32_t v[NE];
@@ -1437,7 +1453,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
 #pragma unroll
                     for (int q = 0; q < NE; q++) v[q] = (size_t)NE * p + q < src.n_planes ? pl[q] : 0;
                 }
-                if (MODE == 3) {
+                if (MODE != 4) {
                     f0 = lut3(digit_code4(v, k));
                     df = fq3_sub(lut3(digit_code4(v + 4, k)), f0);
                 } else {
@@ -1453,7 +1469,56 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             }
         };
         Fq3 Q[4];
-        if (NU && MODE == 3) {
+        if (NU && MODE == 5) {
+            // Round 3 with per-table products of the look-up values (k_fold_mutab): with T1 = mu L, T2 = mu L^2, T3 = mu L^3
+            //   P0 = sum T3[c0], P3 = sum T3[c1]  (look-ups and additions),  P1 = sum T2[c0] * L[c1],  P2 = sum T2[c1] * L[c0]  (two lazy products)
+            LH5 A1, A2;
+            lh5_zero(A1); lh5_zero(A2);
+            u64 s64[12];     // lazy 64-bit sums with carry counters: P0, P3, sp, su (3 words each)
+            u32 scy[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) { s64[i] = 0; scy[i] = 0; }
+            auto ladd = [&](int base, const ulonglong2 &a, u64 b) {
+                const u64 w[3] = {a.x, a.y, b};
+#pragma unroll
+                for (int q = 0; q < 3; q++) { u64 sm = s64[base + q] + w[q]; scy[base + q] += sm < w[q]; s64[base + q] = sm; }
+            };
+            const u32 nkd_all = 2 * K * 3;
+            for (u32 kd = kd0; kd < kd1; kd++) {
+                const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
+                const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)8 * p;
+                int32_t v[8];
+                if ((size_t)8 * p + 8 <= src.n_planes && (src.n_planes & 3) == 0) {
+                    int4 w0 = *(const int4 *)pl, w1 = *(const int4 *)(pl + 4);
+                    v[0] = w0.x; v[1] = w0.y; v[2] = w0.z; v[3] = w0.w; v[4] = w1.x; v[5] = w1.y; v[6] = w1.z; v[7] = w1.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = (size_t)8 * p + q < src.n_planes ? pl[q] : 0;
+                }
+                const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k);
+                const u64 *t1 = src.mutab + ((size_t)kd * 81) * 4, *t2 = t1 + (size_t)nkd_all * 81 * 4, *t3 = t2 + (size_t)nkd_all * 81 * 4;
+                ulonglong2 m10 = *(const ulonglong2 *)(t1 + 4 * c0), m11 = *(const ulonglong2 *)(t1 + 4 * c1);
+                ulonglong2 m20 = *(const ulonglong2 *)(t2 + 4 * c0), m21 = *(const ulonglong2 *)(t2 + 4 * c1);
+                ulonglong2 m30 = *(const ulonglong2 *)(t3 + 4 * c0), m31 = *(const ulonglong2 *)(t3 + 4 * c1);
+                u64 m10c = t1[4 * c0 + 2], m11c = t1[4 * c1 + 2], m20c = t2[4 * c0 + 2], m21c = t2[4 * c1 + 2], m30c = t3[4 * c0 + 2], m31c = t3[4 * c1 + 2];
+                ladd(0, m30, m30c); ladd(3, m31, m31c); ladd(6, m10, m10c); ladd(9, m11, m11c);
+                lh5_mac(A1, fq3_make(m20.x, m20.y, m20c), lut3(c1));
+                lh5_mac(A2, fq3_make(m21.x, m21.y, m21c), lut3(c0));
+            }
+            auto lfin = [&](int base) {
+                return fq3_make(fq_canon(fq_reduce128_loose(s64[base], (u64)scy[base])), fq_canon(fq_reduce128_loose(s64[base + 1], (u64)scy[base + 1])),
+                                fq_canon(fq_reduce128_loose(s64[base + 2], (u64)scy[base + 2])));
+            };
+            Fq3 P0 = lfin(0), P3 = lfin(3), sp = lfin(6), su = lfin(9), P1 = lh5_finish(A1), P2 = lh5_finish(A2);
+            Fq3 a1 = fq3_sub(P1, P0);
+            Fq3 a2 = fq3_add(fq3_sub(P2, fq3_add(P1, P1)), P0);
+            Fq3 p12 = fq3_sub(P1, P2);
+            Fq3 a3 = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12));
+            Q[0] = fq3_sub(P0, sp);
+            Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
+            Q[2] = fq3_add(fq3_add(a2, a2), a2);
+            Q[3] = a3;
+        } else if (NU && MODE == 3) {
             // Both ends of a pair are look-up values, so their squares are too: with t = mu f0, u = mu f1 the four lazy sums
             //   P0 = sum t f0^2, P1 = sum u f0^2, P2 = sum t f1^2, P3 = sum u f1^2   (= sum mu f0^3, mu f0^2 f1, mu f0 f1^2, mu f1^3)
             // need two reduced products per table instead of four; the cubic coefficients in df = f1 - f0 follow by binomials.
@@ -1573,6 +1638,14 @@ void launch_fold_round_lut(const DevCrt &t, const FoldRoundArgs &a, const int32_
     FoldSrc src = {};
     src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
     launch_fold_round_mode<3>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
+}
+// round 3 with the per-table mu products (mutab_dev: 3 * 2K*3 * 81 * 4 words, filled here from lut_dev and mu_pow_dev); NU = 2^40 only
+void launch_fold_round_lut_mu(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                              const u64 *lut_dev, u64 *mutab_dev, u32 K, const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
+    LF_LAUNCH(k_fold_mutab, t.nu2p40, dim3(2 * K * 3), dim3(128), s, t, lut_dev, mu_pow_dev, 2 * K * 3, mutab_dev);
+    FoldSrc src = {};
+    src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev; src.mutab = mutab_dev;
+    launch_fold_round_mode<5>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
 }
 void launch_fold_round_lut_fix(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                const u64 *lut_dev, Fq3Const r, u64 *Fout, size_t ldout, u32 K, const Fq3Const *mu_pow_dev, u64 *partial,
