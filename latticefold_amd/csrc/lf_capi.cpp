@@ -1303,6 +1303,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // Rounds 3 and 4 of large unsharded instances never materialise the m/4-entry tables: their entries are one of 81 values
     // (four ternary digits) and come from a look-up table in LDS (k_fold_round modes 3 and 4); P.s >= 4 and m/4 >= lut_min entries.
     const size_t lut_min = getenv("LF_FOLD_LUT_MIN") ? (size_t)atoll(getenv("LF_FOLD_LUT_MIN")) : ((size_t)1 << 17);
+    const size_t tab_min = getenv("LF_FOLD_TAB_MIN") ? (size_t)atoll(getenv("LF_FOLD_TAB_MIN")) : 16384;   // pairs; rounds 1-2 as table look-ups above this
     const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !getenv("LF_FOLD_NO_LUT");
     u64 *d_lut = nullptr;
     for (u32 round = 1; round <= P.s; round++) {
@@ -1391,7 +1392,34 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
     tables_ready:
         size_t ev = c->ev_begin(0);
-        if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
+        if ((round == 2 || (round == 1 && getenv("LF_FOLD_TAB_R1"))) && a.pcnt >= tab_min) {
+            // round 2 (round 1 only on request: its integer kernel is faster than the gathers) as table look-ups: coefficient quadruples of h^3 - h for the 9 / 81 digit codes of a pair (host), times mu_kd (device)
+            const int nd = round == 1 ? 2 : 4, ncode = round == 1 ? 9 : 81;
+            std::vector<u64> poly((size_t)ncode * 12);
+            const Fq3 one = fq3_one(), r1v = round == 2 ? pt[0] : fq3_zero();
+            auto small = [&](int v) { return v == 0 ? fq3_zero() : (v > 0 ? (v == 1 ? one : fq3_add(one, one)) : (v == -1 ? fq3_neg(one) : fq3_neg(fq3_add(one, one)))); };
+            for (int code = 0; code < ncode; code++) {
+                int dg[4] = {0, 0, 0, 0}, cc = code;
+                for (int b = 0; b < nd; b++, cc /= 3) dg[b] = cc % 3 - 1;
+                Fq3 f0, f1;
+                if (round == 1) { f0 = small(dg[0]); f1 = small(dg[1]); }
+                else {   // entries d_a + (d_b - d_a) r1
+                    f0 = fq3_add(small(dg[0]), c->ring.mul3(small(dg[1] - dg[0]), r1v));
+                    f1 = fq3_add(small(dg[2]), c->ring.mul3(small(dg[3] - dg[2]), r1v));
+                }
+                Fq3 df = fq3_sub(f1, f0), f0s = c->ring.mul3(f0, f0), dfs = c->ring.mul3(df, df);
+                Fq3 t1 = c->ring.mul3(f0s, df), t2 = c->ring.mul3(f0, dfs);
+                Fq3 q[4] = {fq3_sub(c->ring.mul3(f0s, f0), f0), fq3_sub(fq3_add(fq3_add(t1, t1), t1), df), fq3_add(fq3_add(t2, t2), t2), c->ring.mul3(dfs, df)};
+                for (int e = 0; e < 4; e++)
+                    for (int w = 0; w < 3; w++) poly[(size_t)code * 12 + 3 * e + w] = q[e].c[w];
+            }
+            u64 *d_poly, *d_tp;
+            RET(c->tbuf("fold_poly", 81 * 12 + 8, &d_poly));
+            RET(c->tbuf("fold_tp", (size_t)K2 * 3 * 81 * 12, &d_tp));
+            HIPCHK(hipMemcpyAsync(d_poly, poly.data(), poly.size() * 8, hipMemcpyHostToDevice, c->stream()));
+            HIPCHK(hipStreamSynchronize(c->stream()));   // poly is a stack-lifetime buffer
+            launch_fold_round_tab(c->dcrt, (int)round, a, S[0].planes, S[1].planes, N, K, d_mu, d_poly, d_tp, partial, od, c->stream());
+        } else if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->stream());
         else if (fmode == 3 && c->dcrt.nu2p40 && !getenv("LF_FOLD_NO_MUTAB")) {
             u64 *mutab;

@@ -130,6 +130,10 @@ void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int3
 // round 2, still from the planes: entries are d_a + (d_b - d_a) r1 (a.* are the once-fixed tables, a.n = m/2)
 void launch_fold_round2(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const Fq3Const *mu_pow_dev, Fq3Const r1, u64 *partial, u64 *out, hipStream_t s);
+// rounds 1 / 2 as table look-ups (large rounds): poly_dev [ncode][4][3] = coefficients of h^3 - h for the 9 / 81 digit codes of a pair,
+// tp_dev (2K*3 * ncode * 12 words) receives mu_kd * poly; the round kernel gathers and adds, no multiplication per table
+void launch_fold_round_tab(const DevCrt &t, int round, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                           const Fq3Const *mu_pow_dev, const u64 *poly_dev, u64 *tp_dev, u64 *partial, u64 *out, hipStream_t s);
 // after r_2: F[2K*3][24][m/4] = sum_b W_b * digit(f[4j+b]), W = eq((r1,r2), b)
 void launch_fold_materialize2(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t j0, size_t q, u32 K,
                               const Fq3Const W[4], u64 *F, hipStream_t s);

@@ -1179,6 +1179,96 @@ void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *
     hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
 }
 
+// Rounds 1 and 2 as table look-ups.  Before round 3 a table entry is a function of one (round 1) or two (round 2) ternary digits, so
+// the cubic mu_kd * (h^3 - h), h = f0 + X (f1 - f0), of a pair depends only on mu_kd and the 2 / 4 digits behind the pair: 9 / 81
+// possible coefficient quadruples per table.  k_fold_polytab multiplies the (host-built) quadruples Poly[code][4] with every mu_kd once
+// per round; the round kernel then only gathers TP[kd][code] (96 bytes) and adds -- no multiplication in the table loop.
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_polytab(DevCrt t, const u64 *poly /*[ncode][12]*/, const Fq3Const *mu_pow, u32 ncode, u64 *tp) {
+    u32 kd = blockIdx.x;
+    Fq3Const mc = mu_pow[kd];
+    Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
+    for (u32 i = threadIdx.x; i < ncode * 4; i += 256) {
+        Fq3 v = M3<NU>(mu, fq3_make(poly[3 * i], poly[3 * i + 1], poly[3 * i + 2]), t.nu);
+        u64 *o = tp + ((size_t)kd * ncode * 4 + i) * 3;
+        o[0] = v.c[0]; o[1] = v.c[1]; o[2] = v.c[2];
+    }
+}
+__device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k);
+__device__ __forceinline__ u32 digit_code2(const int32_t *v, u32 k) {   // 4 + sign_0 bit_0 + 3 sign_1 bit_1
+    int code = 4;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        int32_t x = v[b], mg = x < 0 ? -x : x;
+        int bit = (mg >> k) & 1, w = b ? 3 : 1;
+        code += x < 0 ? -bit * w : bit * w;
+    }
+    return (u32)code;
+}
+template <bool NU, int R>
+__global__ void __launch_bounds__(256) k_fold_round_tab(DevCrt t, FoldRoundArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                                                        u32 K, const u64 *tp, u64 *partial) {
+    constexpr int E = R == 1 ? 2 : 4;          // plane entries behind one pair
+    constexpr u32 NC = R == 1 ? 9 : 81;
+    u32 slot = blockIdx.y;
+    const size_t pend = a.p0 + a.pcnt;
+    Fq3 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
+        fold_g13<NU>(acc, a, slot, p, t.nu);
+        u64 s64[12];      // lazy 64-bit sums with carry counters
+        u32 scy[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) { s64[i] = 0; scy[i] = 0; }
+        if ((size_t)E * p < n_planes) {
+            for (int side = 0; side < 2; side++) {
+                const int32_t *pl = side ? planesR : planesL;
+                for (int d = 0; d < 3; d++) {
+                    const int32_t *src = pl + (size_t)(8 * d + slot) * n_planes + (size_t)E * p;
+                    int32_t v[E];
+#pragma unroll
+                    for (int q = 0; q < E; q++) v[q] = (size_t)E * p + q < n_planes ? src[q] : 0;
+                    for (u32 k = 0; k < K; k++) {
+                        const u32 code = R == 1 ? digit_code2(v, k) : digit_code4(v, k);
+                        const ulonglong2 *e = (const ulonglong2 *)(tp + ((size_t)((side * K + k) * 3 + d) * NC + code) * 12);
+#pragma unroll
+                        for (int q = 0; q < 6; q++) {
+                            ulonglong2 w = e[q];
+                            u64 sm = s64[2 * q] + w.x; scy[2 * q] += sm < w.x; s64[2 * q] = sm;
+                            sm = s64[2 * q + 1] + w.y; scy[2 * q + 1] += sm < w.y; s64[2 * q + 1] = sm;
+                        }
+                    }
+                }
+            }
+        }
+        Fq3 Q[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Q[e].c[c] = fq_canon(fq_reduce128_loose(s64[3 * e + c], (u64)scy[3 * e + c]));
+        fold_g2_finish<NU>(acc, Q, a, p, t.nu);
+    }
+    store_round_partial(acc, slot, partial);
+}
+// poly_dev: [ncode][4][3] coefficient quadruples (c0..c3 of h^3 - h) of the 9 (round 1) / 81 (round 2) digit codes; tp_dev: 2K*3 * ncode * 12 words
+void launch_fold_round_tab(const DevCrt &t, int round, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
+                           const Fq3Const *mu_pow_dev, const u64 *poly_dev, u64 *tp_dev, u64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.pcnt + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    const u32 ncode = round == 1 ? 9 : 81;
+    LF_LAUNCH(k_fold_polytab, t.nu2p40, dim3(2 * K * 3), dim3(256), s, t, poly_dev, mu_pow_dev, ncode, tp_dev);
+    if (round == 1) {
+        if (t.nu2p40) hipLaunchKernelGGL((k_fold_round_tab<true, 1>), dim3(gb, 8), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, tp_dev, partial);
+        else hipLaunchKernelGGL((k_fold_round_tab<false, 1>), dim3(gb, 8), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, tp_dev, partial);
+    } else {
+        if (t.nu2p40) hipLaunchKernelGGL((k_fold_round_tab<true, 2>), dim3(gb, 8), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, tp_dev, partial);
+        else hipLaunchKernelGGL((k_fold_round_tab<false, 2>), dim3(gb, 8), dim3(256), 0, s, t, a, planesL, planesR, n_planes, K, tp_dev, partial);
+    }
+    hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
+}
+
 // round 2: after one fix the virtual f-hat entries are  d_a + (d_b - d_a) * r1  with digits d in {-1,0,1}.  For a pair
 // f(X) = u(X) + v(X) r1 with small-integer linear u, v, so  f^3 - f = (u^3-u) + (3u^2 v - v) r1 + 3 u v^2 r1^2 + v^3 r1^3
 // and the mu-weighted sums of the 16 integer coefficients are exact 64-bit integer dot products again.

@@ -235,8 +235,12 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     # rounds 3 and 4 from the 81-entry digit look-up table instead of materialised m/4-entry tables (large instances by default)
     monkeypatch.delenv("LF_FOLD_NO_LUT")
     monkeypatch.setenv("LF_FOLD_LUT_MIN", "1")
+    monkeypatch.setenv("LF_FOLD_TAB_MIN", "1")     # ... and rounds 1-2 as gathers from the per-table coefficient tables
+    monkeypatch.setenv("LF_FOLD_TAB_R1", "1")
     lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
     monkeypatch.delenv("LF_FOLD_LUT_MIN")
+    monkeypatch.delenv("LF_FOLD_TAB_MIN")
+    monkeypatch.delenv("LF_FOLD_TAB_R1")
     monkeypatch.delenv("LF_FOLD_FUSE_MIN")
     monkeypatch.setenv("LF_FOLD_UNFUSED", "1")
     lc_u, w_u, proof_u = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
