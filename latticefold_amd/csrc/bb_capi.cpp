@@ -1210,7 +1210,11 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
-        else if (lut_mode == 3) launch_fold_round_lut(c->dev, a, S[0].planes, S[1].planes, N, d_lut, K, d_mup, partial, od, c->stream());
+        else if (lut_mode == 3 && !getenv("LF_FOLD_NO_MUTAB")) {
+            fe *mutab;
+            RET(c->tbuf("fold_mutab", (size_t)3 * K2 * TAU * 81 * 12, &mutab));
+            launch_fold_round_lut_mu(c->dev, a, S[0].planes, S[1].planes, N, d_lut, mutab, K, d_mup, partial, od, c->stream());
+        } else if (lut_mode == 3) launch_fold_round_lut(c->dev, a, S[0].planes, S[1].planes, N, d_lut, K, d_mup, partial, od, c->stream());
         else if (lut_mode == 4) launch_fold_round_lut_fix(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else if (fix_fused) launch_fold_round_fix(c->dev, a, prevF, prevld, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());

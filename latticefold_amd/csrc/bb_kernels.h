@@ -119,6 +119,9 @@ void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, s
 void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 81 * 9 */);
 void launch_fold_round_lut(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                            u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);
+// round 3 with per-table products M_tb * {value, value^2, value^3} of the look-up values (mutab_dev: 3 * 2K*9 * 81 * 12 words, filled here)
+void launch_fold_round_lut_mu(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                              fe *mutab_dev, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);
 void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                                hipStream_t s);

@@ -1090,7 +1090,7 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 // sum_b W_b * digit_k(plane[4j+b]) with four ternary digits -- one of 81 values independent of table and slot -- and comes from a look-up
 // table in LDS indexed by the digit code (lut: [81][9] words); mode 4 also fixes the four round-3 entries of a pair with r and stores the
 // first materialised tables (m/8 entries) like mode 1.  MODE 0: plain tables, MODE 1: fused fix (above).
-struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; };
+struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; const fe *mutab; };   // mutab: mode 5, [3][2K*9][81][12]
 __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
     int code = 40;
     const int w[4] = {1, 3, 9, 27};
@@ -1101,6 +1101,24 @@ __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
         code += x < 0 ? -bit * w[b] : bit * w[b];
     }
     return (u32)code;
+}
+// mode 5 (round 3): per-table products M_tb * {value, value^2, value^3} of the 81 look-up values; with them a table costs two lazy
+// products (the mixed terms), the pure cubes are look-ups
+template <bool NU2>
+__global__ void __launch_bounds__(128) k_fold_mutab(DevBb t, const fe *lut, const E9PreC *Mpre, u32 ntab, fe *mutab) {
+    u32 tb = blockIdx.x, code = threadIdx.x;
+    if (code >= 81) return;
+    E9 L;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) L.c[c] = lut[TAU * code + c];
+    E9 m1 = e9_mul(L, e9p(Mpre[tb])), m2 = e9_mul_t<NU2>(m1, L, t.nu), m3 = e9_mul_t<NU2>(m2, L, t.nu);
+    const E9 v[3] = {m1, m2, m3};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        fe *o = mutab + (((size_t)q * ntab + tb) * 81 + code) * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) o[c] = c < TAU ? v[q].c[c] : 0;
+    }
 }
 template <bool NU2, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
@@ -1122,10 +1140,15 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             __syncthreads();
         }
     }
-    i64 SP[MODE == 3 ? TAU : 1], SU[MODE == 3 ? TAU : 1];   // mode 3: sum M f0, sum M f1
-    if (MODE == 3) {
+    i64 SP[MODE == 3 || MODE == 5 ? TAU : 1], SU[MODE == 3 || MODE == 5 ? TAU : 1];   // modes 3, 5: sum M f0, sum M f1
+    i64 P0s[MODE == 5 ? TAU : 1], P3s[MODE == 5 ? TAU : 1];                            // mode 5: sum M f0^3, sum M f1^3 (look-ups)
+    if (MODE == 3 || MODE == 5) {
 #pragma unroll
         for (int c = 0; c < TAU; c++) { SP[c] = 0; SU[c] = 0; }
+    }
+    if (MODE == 5) {
+#pragma unroll
+        for (int c = 0; c < TAU; c++) { P0s[c] = 0; P3s[c] = 0; }
     }
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
@@ -1141,7 +1164,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
         E9 f0, f1;
         if (MODE >= 3) {
-            constexpr int NE = MODE == 3 ? 8 : 16;      // plane entries behind one pair
+            constexpr int NE = MODE == 4 ? 16 : 8;      // plane entries behind one pair
             const u32 side = tb / (TAU * K), k = (tb / TAU) % K, d = tb % TAU;
             const int32_t *pl = (side ? lt.planesR : lt.planesL) + (size_t)(8 * d + slot) * lt.n_planes + (size_t)NE * jj;
             int32_t v[NE];
@@ -1155,7 +1178,34 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
 #pragma unroll
                 for (int q = 0; q < NE; q++) v[q] = (size_t)NE * jj + q < lt.n_planes ? pl[q] : 0;
             }
-            if (MODE == 3) {
+            if (MODE == 5) {
+                // per-table products of the look-up values: T1 = M L, T2 = M L^2, T3 = M L^3 (k_fold_mutab)
+                //   P0 = sum T3[c0], P3 = sum T3[c1] (additions), P1 = sum T2[c0] * L[c1], P2 = sum T2[c1] * L[c0] (two lazy products)
+                const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k);
+                const fe *t1 = lt.mutab + ((size_t)tb * 81) * 12, *t2 = t1 + (size_t)ntab * 81 * 12, *t3 = t2 + (size_t)ntab * 81 * 12;
+                auto ld = [&](const fe *base, u32 code, E9 &o) {
+                    const int4 *q = reinterpret_cast<const int4 *>(base + 12 * code);
+                    int4 a0 = q[0], a1 = q[1], a2 = q[2];
+                    o.c[0] = a0.x; o.c[1] = a0.y; o.c[2] = a0.z; o.c[3] = a0.w; o.c[4] = a1.x; o.c[5] = a1.y; o.c[6] = a1.z; o.c[7] = a1.w; o.c[8] = a2.x;
+                };
+                E9 m10, m11, m20, m21, m30, m31, L0, L1;
+                ld(t1, c0, m10); ld(t1, c1, m11); ld(t2, c0, m20); ld(t2, c1, m21); ld(t3, c0, m30); ld(t3, c1, m31);
+                const fe *l0 = slut + TAU * c0, *l1 = slut + TAU * c1;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) { L0.c[c] = l0[c]; L1.c[c] = l1[c]; }
+                E9 L0n = e9_times_nu_t<NU2>(L0, t.nu), L1n = e9_times_nu_t<NU2>(L1, t.nu);
+                i64 T[TAU];
+                e9_mul_cols(m20, L1, L1n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) hl_add(C[TAU + c], T[c]);
+                e9_mul_cols(m21, L0, L0n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) {
+                    hl_add(C[2 * TAU + c], T[c]);
+                    P0s[c] += m30.c[c]; P3s[c] += m31.c[c]; SP[c] += m10.c[c]; SU[c] += m11.c[c];
+                }
+                continue;
+            } else if (MODE == 3) {
                 // both ends of the pair and their squares are look-up values: with t = M f0, u = M f1 the lazy sums
                 //   P0 = sum t f0^2, P1 = sum u f0^2, P2 = sum t f1^2, P3 = sum u f1^2
                 // take two products by M and four lazy products per table (no squarings); C0..C3 follow by binomials after the loop
@@ -1255,9 +1305,10 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         E9 c0, c1, c2, c3;
 #pragma unroll
         for (int c = 0; c < TAU; c++) {
-            if (MODE == 3) {
+            if (MODE == 3 || MODE == 5) {
                 // C0 = P0 - sp, C1 = 3 (P1 - P0) - (su - sp), 3 C2 = 3 (P2 - 2 P1 + P0), C3 = P3 - 3 P2 + 3 P1 - P0   (values of a few p: one reduction)
-                i64 P0 = hl_finish(C[c]), P1 = hl_finish(C[TAU + c]), P2 = hl_finish(C[2 * TAU + c]), P3 = hl_finish(C[3 * TAU + c]);
+                i64 P0 = MODE == 5 ? (i64)fred(P0s[c]) : (i64)hl_finish(C[c]), P1 = hl_finish(C[TAU + c]), P2 = hl_finish(C[2 * TAU + c]);
+                i64 P3 = MODE == 5 ? (i64)fred(P3s[c]) : (i64)hl_finish(C[3 * TAU + c]);
                 i64 sp = fred(SP[c]), su = fred(SU[c]);
                 c0.c[c] = fred(P0 - sp); c1.c[c] = fred(3 * (P1 - P0) - (su - sp));
                 c2.c[c] = fred(3 * (P2 - 2 * P1 + P0)); c3.c[c] = fred(P3 - 3 * P2 + 3 * P1 - P0);
@@ -1309,7 +1360,8 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
 #define BB_FRM(N2)                                                              \
     do {                                                                        \
         if (mode == 1) BB_FR(N2, 1); else if (mode == 3) BB_FR(N2, 3);          \
-        else if (mode == 4) BB_FR(N2, 4); else BB_FR(N2, 0);                    \
+        else if (mode == 4) BB_FR(N2, 4); else if (mode == 5) BB_FR(N2, 5);     \
+        else BB_FR(N2, 0);                                                      \
     } while (0)
     if (nu2) BB_FRM(true); else BB_FRM(false);
 #undef BB_FRM
@@ -1325,13 +1377,23 @@ void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ld
 void launch_fold_round_lut(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                            u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
     E9PreC none = {};
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 3, none, nullptr, 0, lt, partial, out, s);
+}
+// round 3 with per-table products of the look-up values (mutab_dev: 3 * 2K*9 * 81 * 12 words, filled by this call)
+void launch_fold_round_lut_mu(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                              fe *mutab_dev, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
+    const u32 ntab = 2 * K * TAU;
+    if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_mutab<true>), dim3(ntab), dim3(128), 0, s, t, lut_dev, Mpre, ntab, mutab_dev);
+    else hipLaunchKernelGGL((k_fold_mutab<false>), dim3(ntab), dim3(128), 0, s, t, lut_dev, Mpre, ntab, mutab_dev);
+    E9PreC none = {};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, mutab_dev};
+    launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 5, none, nullptr, 0, lt, partial, out, s);
 }
 void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                                hipStream_t s) {
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 4, e9pre_from_h9(r, ring.T.nu), Fout, ldout, lt, partial, out, s);
 }
 // the 81-entry table of modes 3 / 4: lut[code][c] = sum_b (t_b - 1) W_b[c], code = sum_b t_b 3^b, W = eq((r1, r2), .)
