@@ -352,7 +352,7 @@ def test_fold_real_circuit_from_r1cs(ctx):
     assert ok and (lc_p == lc_g).all()
 
 
-def test_fold_step_with_another_nonresidue(ctx):
+def test_fold_step_with_another_nonresidue(ctx, monkeypatch):
     """nu is data: F_{p^9} = F_p[Y]/(Y^9 - zeta) (zeta a primitive 24th root of unity instead of 2) switches the kernels to
     their generic-nu instantiation (Montgomery pre-multiplications instead of doublings)"""
     nr, y = ctx.get_ring_tables()
@@ -381,7 +381,14 @@ def test_fold_step_with_another_nonresidue(ctx):
         assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
         rc, _ = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)
         assert rc == 0
+        # the look-up-table / fused forms of rounds 3-6 in their generic-nu instantiations
+        monkeypatch.setenv("LF_FOLD_LUT_MIN", "1")
+        monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
+        lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+        assert (proof_l == proof_o).all() and (lc_l == lc_o).all() and (w_l.f == f0_o).all()
     finally:
+        monkeypatch.delenv("LF_FOLD_LUT_MIN", raising=False)
+        monkeypatch.delenv("LF_FOLD_FUSE_MIN", raising=False)
         ctx.set_ring_tables(nr, y)
         lfo.lib().lfo_set_ring(nr, lfo._p64(np.ascontiguousarray(y)))
 

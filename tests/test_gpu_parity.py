@@ -374,7 +374,7 @@ def test_fold_real_circuit_from_r1cs(ctx):
     assert ok and (lc_p == lc_g).all()
 
 
-def test_fold_step_with_another_nonresidue(ctx):
+def test_fold_step_with_another_nonresidue(ctx, monkeypatch):
     """nu is data too: F_{p^3} = F_p[Y]/(Y^3 - w^5) (w = 2^40) switches every kernel to its generic-nu instantiation
     (no 2^40 shift tricks); CRT and a whole fold step must still match the oracle under the same tables."""
     nr, y = ctx.get_ring_tables()
@@ -400,7 +400,15 @@ def test_fold_step_with_another_nonresidue(ctx):
         assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
         rc, _ = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)
         assert rc == 0
+        # the look-up-table / fused forms of rounds 2-6 in their generic-nu instantiations
+        for k in ("LF_FOLD_LUT_MIN", "LF_FOLD_TAB_MIN", "LF_FOLD_TAB_R1"):
+            monkeypatch.setenv(k, "1")
+        monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
+        lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        assert (proof_l == proof_o).all() and (lc_l == lc_o).all() and (w_l.f == f0_o).all()
     finally:
+        for k in ("LF_FOLD_LUT_MIN", "LF_FOLD_TAB_MIN", "LF_FOLD_TAB_R1", "LF_FOLD_FUSE_MIN"):
+            monkeypatch.delenv(k, raising=False)
         ctx.set_ring_tables(nr, y)
         lfo.lib().lfo_set_ring(nr, lfo._p64(np.ascontiguousarray(y)))
 
