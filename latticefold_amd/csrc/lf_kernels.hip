@@ -1756,8 +1756,22 @@ void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *F
 // ---------------------------------------------------------------------------------------------------------
 // compute_f_0 (folding.rs:258-268) in the coefficient domain: ICRT(sum_i rho_i (.) f_i) = sum_i rho_i * f_i mod
 // Phi_72 exactly, with rho_i in [-32,32)^24 and f_i the bit-planes -> plain int32 convolutions.
+// Nibble tables.  For one side, sum_k rho_k[a] * digit_k(v_c) = sign(v_c) * sum_nibbles R[nibble][value][a] with
+// R[q][val][a] = sum_{b<4} bit_b(val) rho_{4q+b}[a]: four look-ups of a 24-vector and 24 additions per coefficient c replace the
+// 16 x 24 multiply-adds over the bit-planes.  The tables (both signs, both sides: 2*2*4*16*24 int32 = 24 KB) are built in LDS per block.
 __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho,
                                                       int32_t *out) {
+    __shared__ __align__(16) int32_t R[2][2][4][16][28];   // [side][sign][nibble][value][a]; rows padded to 28 words (bank spread)
+    for (u32 idx = threadIdx.x; idx < 2 * 4 * 16 * 24; idx += 256) {
+        u32 a = idx % 24, val = (idx / 24) % 16, q = (idx / (24 * 16)) % 4, side = idx / (24 * 16 * 4);
+        int sum = 0;
+#pragma unroll
+        for (u32 b = 0; b < 4; b++)
+            if (4 * q + b < K && ((val >> b) & 1)) sum += rho[(size_t)(side * K + 4 * q + b) * 24 + a];
+        R[side][0][q][val][a] = sum;
+        R[side][1][q][val][a] = -sum;
+    }
+    __syncthreads();
     size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     int32_t acc[47];
@@ -1766,20 +1780,18 @@ __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, co
 #pragma unroll 1
     for (int side = 0; side < 2; side++) {
         const int32_t *pl = side ? planesR : planesL;
-        int32_t v[24];
 #pragma unroll
-        for (int c = 0; c < 24; c++) v[c] = pl[(size_t)c * n + j];
-#pragma unroll 1
-        for (u32 k = 0; k < K; k++) {
-            const int8_t *rk = rho + (size_t)(side * K + k) * 24;
-            int dg[24];
+        for (int c = 0; c < 24; c++) {
+            int32_t v = pl[(size_t)c * n + j];
+            u32 mg = (u32)(v < 0 ? -v : v), sg = v < 0;
 #pragma unroll
-            for (int c = 0; c < 24; c++) dg[c] = digit2(v[c], k);
+            for (int q = 0; q < 4; q++) {
+                const int4 *t = (const int4 *)R[side][sg][q][(mg >> (4 * q)) & 15];
 #pragma unroll
-            for (int a = 0; a < 24; a++) {
-                int ra = rk[a];  // wave-uniform: scalar load
-#pragma unroll
-                for (int c = 0; c < 24; c++) acc[a + c] += __mul24(ra, dg[c]);
+                for (int w = 0; w < 6; w++) {
+                    int4 x = t[w];
+                    acc[c + 4 * w] += x.x; acc[c + 4 * w + 1] += x.y; acc[c + 4 * w + 2] += x.z; acc[c + 4 * w + 3] += x.w;
+                }
             }
         }
     }
