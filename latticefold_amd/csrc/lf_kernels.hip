@@ -938,21 +938,36 @@ void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq
     LF_LAUNCH(k_lincomb_z, t.nu2p40, dim3(cdiv(n, 256), 8), dim3(256), s, t, z, ldz, K, coef_dev, tt, n, out);
 }
 
+// Nibble tables: sum_k apow[k][d] * digit_k(v) = sign(v) * sum_q T[d][q][(|v| >> 4q) & 15], T[d][q][val] = sum_{b<4, bit b of val} apow[4q+b][d]
+// (192 F_{p^3} values built in LDS per block): 12 look-ups and additions per row and slot instead of a 48-iteration bit loop.
 __global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow, u64 *G, size_t m) {
+    __shared__ u64 T[3 * 4 * 16][4];
+    if (threadIdx.x < 192) {
+        u32 val = threadIdx.x % 16, q = (threadIdx.x / 16) % 4, d = threadIdx.x / 64;
+        Fq3 sum = fq3_zero();
+        for (u32 b = 0; b < 4; b++)
+            if (4 * q + b < K && ((val >> b) & 1)) {
+                Fq3Const a = apow[(4 * q + b) * 3 + d];
+                sum = fq3_add(sum, fq3_make(a.c[0], a.c[1], a.c[2]));
+            }
+        T[threadIdx.x][0] = sum.c[0]; T[threadIdx.x][1] = sum.c[1]; T[threadIdx.x][2] = sum.c[2]; T[threadIdx.x][3] = 0;
+    }
+    __syncthreads();
     size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y;
     if (row >= n_planes) return;
     Fq3 acc = ld3(G, m, slot, row);
+#pragma unroll
     for (int d = 0; d < 3; d++) {
         int32_t v = planes[(size_t)(8 * d + slot) * n_planes + row];
-        int32_t mg = v < 0 ? -v : v;
-        for (u32 k = 0; k < K; k++) {
-            if ((mg >> k) & 1) {
-                Fq3Const a = apow[k * 3 + d];
-                Fq3 av = fq3_make(a.c[0], a.c[1], a.c[2]);
-                acc = v < 0 ? fq3_sub(acc, av) : fq3_add(acc, av);
-            }
+        u32 mg = (u32)(v < 0 ? -v : v);
+        Fq3 part = fq3_zero();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 *e = T[(d * 4 + q) * 16 + ((mg >> (4 * q)) & 15)];
+            part = fq3_add(part, fq3_make(e[0], e[1], e[2]));
         }
+        acc = v < 0 ? fq3_sub(acc, part) : fq3_add(acc, part);
     }
     st3(G, m, slot, row, acc);
 }
