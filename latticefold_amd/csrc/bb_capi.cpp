@@ -1249,7 +1249,12 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     if (!hp) return LF_ERR_HIP;
     u64 *d_theta = fsm, *d_eta = fsm + nth;
     (void)sm;
-    for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * TAU * RE, c->stream());
+    // theta = f-hat_{k,d}(r_o): the sumcheck's f-hat tables, fixed at r_1..r_{s-1}, have two entries left -- one more fix gives the
+    // evaluations (exact arithmetic: the same words as evaluate_mles on the witness).  LF_THETA_EVAL=1 / fewer than 4 variables:
+    // stand-alone evaluation.
+    if (P.s >= 4 && curF && ldF == 2 && !getenv("LF_THETA_EVAL")) launch_fix_final(c->dev, curF, ldF, K2 * TAU * 8, e9pre_from_h9(pt[P.s - 1], c->ring.T.nu), d_theta, c->stream());
+    else
+        for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * TAU * RE, c->stream());
     HIPCHK(hipMemcpyAsync(hp, d_theta, nth * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventRecord(c->ev_side[0], c->stream()));
     for (int sd = 0; sd < 2; sd++) launch_dot_batch(c->dev, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE, c->stream());

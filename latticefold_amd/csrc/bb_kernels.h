@@ -79,6 +79,7 @@ void launch_add_fhat_comb(const DevBb &t, const int32_t *planes, size_t n_planes
 // ---- sumcheck ------------------------------------------------------------------------------------------------------
 // rows9 groups of 9 planes: out[g][c][j] = in[g][c][2j] + r * (in[g][c][2j+1] - in[g][c][2j])
 void launch_fix(const DevBb &t, const fe *in, size_t ld_in, fe *out, size_t ld_out, size_t n_in, u32 rows9, const E9PreC &r, hipStream_t s);
+void launch_fix_final(const DevBb &t, const fe *in, size_t ld_in, u32 rows9, const E9PreC &r, u64 *out /* [rows9][9] canonical */, hipStream_t s);
 
 struct LinDesc {   // CCS multiset structure (nifs/linearization/utils.rs:90-107)
     u32 t, q;

@@ -768,6 +768,23 @@ void launch_fix(const DevBb &t, const fe *in, size_t ld_in, fe *out, size_t ld_o
     }
 }
 
+// last fix of the folding sumcheck's f-hat tables (two entries per row): the fully fixed tables are theta = f-hat(r_o)
+// (folding.rs:236-242); canonical words in theta's flat order [row][9]
+__global__ void __launch_bounds__(256) k_fix_final(DevBb t, const fe *in, size_t ld_in, u32 rows9, E9PreC r, u64 *out) {
+    u32 g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= rows9) return;
+    const fe *pi = in + (size_t)g * TAU * ld_in;
+    E9 a, b;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) { a.c[c] = pi[(size_t)c * ld_in]; b.c[c] = pi[(size_t)c * ld_in + 1]; }
+    E9 o = e9_add(a, e9_mul(e9_sub(b, a), e9p(r)));
+#pragma unroll
+    for (int c = 0; c < TAU; c++) out[(size_t)g * TAU + c] = to_canon(o.c[c]);
+}
+void launch_fix_final(const DevBb &t, const fe *in, size_t ld_in, u32 rows9, const E9PreC &r, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_fix_final, dim3(cdiv(rows9, 256)), dim3(256), 0, s, t, in, ld_in, rows9, r, out);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // linearization sumcheck round (comb fn nifs/linearization/utils.rs:90-107): g(X) = eq(X) * sum_i c_i prod_{j in S_i} Mz_j(X),
 // evaluated at X = 0..deg on every index pair by stepping vals += (v1 - v0)  (sumcheck/prover.rs:111-160)

@@ -1464,7 +1464,12 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->pin((size_t)K2 * 72 + (size_t)K2 * P.t * 24));
     u64 *hp = c->h_pin_ref();
     u64 *d_theta = fsm, *d_eta = fsm + (size_t)K2 * 72;
-    for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * 72, c->stream());
+    // theta = f-hat_{k,d}(r_o): the f-hat tables of the sumcheck, fixed at r_1..r_{s-1}, have two entries left, so one more fix gives
+    // the evaluations evaluate_mles would recompute from the witness (exact arithmetic: the same words).  Instances with fewer than
+    // 4 variables never materialise the tables, and LF_THETA_EVAL=1 keeps the stand-alone evaluation (masked +-eq sums).
+    if (P.s >= 4 && curF && ldF == 2 && !getenv("LF_THETA_EVAL")) launch_fix_final(c->dcrt, curF, K2 * 3 * 8, f3c(pt[P.s - 1]), d_theta, c->stream());
+    else
+        for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * 72, c->stream());
     HIPCHK(hipMemcpyAsync(hp, d_theta, (size_t)K2 * 72 * 8, hipMemcpyDeviceToHost, c->stream()));
     if (!c->ev_theta) HIPCHK(hipEventCreateWithFlags(&c->ev_theta, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c->ev_theta, c->stream()));

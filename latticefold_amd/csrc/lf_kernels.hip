@@ -1006,6 +1006,23 @@ void launch_fix_many(const DevCrt &t, const u64 *in, size_t ld_in, u64 *out, siz
     LF_LAUNCH(k_fix, t.nu2p40, dim3(cdiv(n_out, 256), rows3), dim3(256), s, t, in, ld_in, out, ld_out, n_out, r);
 }
 
+// last fix of the folding sumcheck's f-hat tables (2 entries per row): the fully fixed tables ARE the evaluations theta = f-hat(r_o)
+// that folding.rs:236-242 recomputes with evaluate_mles; canonical words, laid out [row][3] = theta's flat order.
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fix_final(DevCrt t, const u64 *in, u32 rows3, Fq3Const r, u64 *out) {
+    u32 row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows3) return;
+    const u64 *p = in + (size_t)row * 6;
+    Fq3 rr = fq3_make(r.c[0], r.c[1], r.c[2]);
+    Fq3 v0 = fq3_make(p[0], p[2], p[4]), v1 = fq3_make(p[1], p[3], p[5]);
+    Fq3 res = fq3_add(v0, M3<NU>(fq3_sub(v1, v0), rr, t.nu));
+#pragma unroll
+    for (int q = 0; q < 3; q++) out[(size_t)row * 3 + q] = fq_canon(res.c[q]);
+}
+void launch_fix_final(const DevCrt &t, const u64 *in, u32 rows3, Fq3Const r, u64 *out, hipStream_t s) {
+    LF_LAUNCH(k_fix_final, t.nu2p40, dim3(cdiv(rows3, 256)), dim3(256), s, t, in, rows3, r, out);
+}
+
 // evaluate a quadratic/cubic given by coefficients at X = 0..deg and add into acc
 template <int NP>
 __device__ __forceinline__ void add_poly_evals(Fq3 (&acc)[NP], const Fq3 *co, int ncoef) {
