@@ -766,7 +766,8 @@ static H9 sc_round_transcript(BbTranscript &tr, const u64 *evals, u32 npts) {
 static size_t atl(size_t x) { return x < 2 ? 2 : x; }   // leading dimensions stay even (8-byte pair loads)
 
 // linearization sumcheck on device tables mz [t][72][m] (left intact) and eq_beta [9][m]
-static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb, u64 *msgs, H9 *point) {
+// `u_dev` (optional): u_j = Mz_j(r), t ring elements (canonical), from the last fix of the tables the rounds work on
+static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb, u64 *msgs, H9 *point, u64 *u_dev = nullptr) {
     const lf_params &P = c->P;
     u32 deg = P.d + 1;
     size_t m = c->m;
@@ -801,6 +802,7 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
     }
+    if (u_dev) launch_fix_final(c->dev, cur, 2, P.t * 8, e9pre_from_h9(point[P.s - 1], c->ring.T.nu), u_dev, c->stream());   // two entries per row left
     return LF_OK;
 }
 
@@ -870,14 +872,18 @@ static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witn
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     for (u32 j = 0; j < P.t; j++) launch_spmv(c->dev, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * RE * m, m, 0, c->stream());
     std::vector<H9> pt(P.s);
-    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data()));
-    // v, u at the sumcheck point (linearization.rs:126-139)
+    // v, u at the sumcheck point (linearization.rs:126-139): u from the fully fixed Mz tables of the sumcheck (LF_LIN_U_EVAL=1: dot
+    // products with eq(r) over the full tables), v from the witness planes
+    const bool u_eval = getenv("LF_LIN_U_EVAL") != nullptr;
+    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + (size_t)TAU * RE));
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
-    u64 *v = proof + (size_t)P.s * (P.d + 2) * RE, *u = v + (size_t)TAU * RE;
-    launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());
-    RET(down_small(c, od, (size_t)TAU * RE, v));   // T[72][9] flat == v[9][8 slots][9]
-    launch_dot_eq(c->dev, mz, m, P.t, eqr, m, m, partial, od, c->stream());
-    RET(down_small(c, od, (size_t)P.t * RE, u));
+    u64 *v = proof + (size_t)P.s * (P.d + 2) * RE, *u = v + (size_t)TAU * RE;   // contiguous
+    launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());   // T[72][9] flat == v[9][8 slots][9]
+    if (u_eval) {
+        RET(down_small(c, od, (size_t)TAU * RE, v));
+        launch_dot_eq(c->dev, mz, m, P.t, eqr, m, m, partial, od, c->stream());
+        RET(down_small(c, od, (size_t)P.t * RE, u));
+    } else RET(down_small(c, od, (size_t)TAU * RE + (size_t)P.t * RE, v));
     {
         HostTimer ht(c);
         tr.absorb_ring(v, TAU);

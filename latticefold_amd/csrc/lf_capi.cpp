@@ -961,7 +961,9 @@ static Fq3 sc_round_transcript(Transcript &tr, const u64 *evals, u32 npts) {
 }
 
 // linearization sumcheck on device tables mz [t][24][m] (left intact) and eq_beta [3][m]
-static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 *eqb, u64 *msgs /* s*(d+2) ring */, Fq3 *point) {
+// `u_dev` (optional): the Mz tables fixed at the whole point, i.e. u_j = Mz_j(r) (t ring elements, canonical) -- the last fix of the
+// tables the rounds work on, so linearization.rs:136's evaluate_mles pass over the full tables is not needed.
+static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 *eqb, u64 *msgs /* s*(d+2) ring */, Fq3 *point, u64 *u_dev = nullptr) {
     const lf_params &P = c->P;
     u32 deg = P.d + 1;
     size_t m = c->m;
@@ -993,6 +995,7 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
     }
+    if (u_dev) launch_fix_final(c->dcrt, cur, P.t * 8, f3c(point[P.s - 1]), u_dev, c->stream());   // n == 2 here (ld 2)
     return LF_OK;
 }
 
@@ -1051,14 +1054,18 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     for (u32 j = 0; j < P.t; j++)
         launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->stream());
     std::vector<Fq3> pt(P.s);
-    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data()));
-    // v, u at the sumcheck point (linearization.rs:126-139)
+    // v, u at the sumcheck point (linearization.rs:126-139): u from the fully fixed Mz tables of the sumcheck (LF_LIN_U_EVAL=1: dot
+    // products with eq(r) over the full tables), v from the witness planes
+    const bool u_eval = getenv("LF_LIN_U_EVAL") != nullptr;
+    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72));
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
-    u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;
-    launch_coef_eval(c->dcrt, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());
-    RET(down_small(c, od, 72, v));  // T[24][3] flat == v[3][8 slots][3]
-    launch_dot_eq(c->dcrt, mz, m, P.t, eqr, m, m, partial, od, c->stream());
-    RET(down_small(c, od, (size_t)P.t * 24, u));
+    u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;   // contiguous: v[3 ring] u[t ring]
+    launch_coef_eval(c->dcrt, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());   // T[24][3] flat == v[3][8 slots][3]
+    if (u_eval) {
+        RET(down_small(c, od, 72, v));
+        launch_dot_eq(c->dcrt, mz, m, P.t, eqr, m, m, partial, od, c->stream());
+        RET(down_small(c, od, (size_t)P.t * 24, u));
+    } else RET(down_small(c, od, 72 + (size_t)P.t * 24, v));
     {
         HostTimer ht(c);
         tr.absorb_ring(v, 3);

@@ -246,6 +246,7 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     monkeypatch.delenv("LF_FOLD_FUSE_MIN")
     monkeypatch.setenv("LF_FOLD_UNFUSED", "1")
     monkeypatch.setenv("LF_THETA_EVAL", "1")       # theta from evaluate_mles-style sums instead of the last fix of the sumcheck tables
+    monkeypatch.setenv("LF_LIN_U_EVAL", "1")       # likewise u of the linearization
     lc_u, w_u, proof_u = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
     assert (proof_f == proof_o).all() and (lc_f == lc_o).all() and (w_f.f == f0_o).all()
     assert (proof_l == proof_o).all() and (lc_l == lc_o).all() and (w_l.f == f0_o).all()
