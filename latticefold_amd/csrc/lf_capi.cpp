@@ -1303,7 +1303,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // Unsharded, rounds >= 4 with many pairs: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel,
     // so the separate memory-bound pass over them vanishes (rounds 4-6 at 2^20 rows: 6.25 -> 5.6 ms).
     const bool fused = Gw == 1 && !getenv("LF_FOLD_UNFUSED");
-    const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 65536;   // entries; tests lower it
+    const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 16384;   // entries (measured: 65536 -> 16384 = -0.3 ms at 2^20 rows); tests lower it
     int fmode = 0;                 // producer of this round's pairs: 0 tables, 1 fused fix, 3 / 4 digit look-up table (rounds 3 / 4)
     const u64 *prevF = nullptr;
     size_t prevld = 0;

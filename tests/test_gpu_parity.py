@@ -224,7 +224,7 @@ def test_fold_step_parity(ctx, name, seed):
 
 @pytest.mark.parametrize("name", ["T10", "G5"])
 def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
-    """rounds >= 4 of the folding sumcheck with fix_variables fused into the round kernel (the driver uses it from 2^16
+    """rounds >= 4 of the folding sumcheck with fix_variables fused into the round kernel (the driver uses it from 2^14
     table entries on; LF_FOLD_FUSE_MIN lowers the threshold so the oracle-sized cases take that path) and with the
     separate k_fix pass: identical proofs, both equal to the oracle's."""
     wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
