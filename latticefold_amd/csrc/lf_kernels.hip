@@ -567,19 +567,21 @@ __global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, const 
 // the nout - nmain outputs that do not fill a wave: plain lazy dot products over j, one (output, slot) per block column
 template <bool NU>
 __global__ void __launch_bounds__(256) k_ajtai_tail(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 o_start, u64 *partial) {
-    u32 slot = blockIdx.y, o = o_start + blockIdx.z;
+    // grid (8 slots, tail outputs, column blocks): the linear workgroup id is slot + 8 * (tail + ntail * block), so the tail outputs of one
+    // (slot, column block) -- which usually share their row of A -- run back to back on the same XCD and find that row in its L2
+    u32 slot = blockIdx.x, o = o_start + blockIdx.y;
     u32 i = o / batch, k = o % batch;
     const u64 *Ai = A + (size_t)i * 24 * n, *Fk = F + (size_t)k * 24 * ldF;
     Acc5 acc;
     acc5_zero(acc);
-    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
+    for (size_t j = (size_t)blockIdx.z * 256 + threadIdx.x; j < n; j += (size_t)gridDim.z * 256) {
         Fq3 x = ld3(Ai, n, slot, j), y = ld3(Fk, ldF, slot, j);
         acc5_mac(acc, x.c, y.c);
     }
     Fq3 r = acc5_finish<NU>(acc, t.nu);
     u64 v[3] = {r.c[0], r.c[1], r.c[2]};
     // partial[block][ tail_index*24 + 3*slot + c ]
-    block_sum_store<3>(v, partial + (size_t)blockIdx.x * (gridDim.z * 24) + (size_t)blockIdx.z * 24 + 3 * slot);
+    block_sum_store<3>(v, partial + (size_t)blockIdx.z * (gridDim.y * 24) + (size_t)blockIdx.y * 24 + 3 * slot);
 }
 __global__ void __launch_bounds__(256) k_ajtai_tail_reduce(const u64 *partial, u32 nblocks, u32 ntail, u32 o_start, u32 kappa, u32 batch, u64 *out) {
     u32 idx = blockIdx.x;  // one block per (tail output, word)
@@ -610,7 +612,7 @@ void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 
         u64 *tp = partial + (size_t)splits * 8 * kappa * batch * 3;
         u32 gb = (u32)((n + 255) / 256);
         if (gb > RED_BLOCKS_AJ) gb = RED_BLOCKS_AJ;
-        LF_LAUNCH(k_ajtai_tail, t.nu2p40, dim3(gb, 8, ntail), dim3(256), s, t, A, kappa, n, F, ldF, batch, nmain, tp);
+        LF_LAUNCH(k_ajtai_tail, t.nu2p40, dim3(8, ntail, gb), dim3(256), s, t, A, kappa, n, F, ldF, batch, nmain, tp);
         hipLaunchKernelGGL(k_ajtai_tail_reduce, dim3(ntail * 24), dim3(256), 0, s, tp, gb, ntail, nmain, kappa, batch, out);
     }
 }
