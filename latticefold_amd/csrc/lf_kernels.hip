@@ -391,8 +391,51 @@ __global__ void __launch_bounds__(256) k_recompose_crt(DevCrt t, const int32_t *
     }
     crt_store(a, out + (size_t)k * 24 * ldz, ldz, off + i, t);
 }
+// bit-plane mode with L = 4 and B^3 < 2^61: the recomposed coefficient sum_l digit_l B^l is an exact signed 64-bit integer (one
+// conversion to a canonical residue instead of four conditional modular additions), the four digits' plane entries come in one 16-byte load
+struct BInt4 { long long v[4]; };
+__global__ void __launch_bounds__(256) k_recompose_crt_b4(DevCrt t, const int32_t *planes, size_t n_planes, u32 wit_len, BInt4 bi, u64 *out,
+                                                           size_t ldz, size_t off) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32 k = blockIdx.y;
+    if (i >= wit_len) return;
+    u64 *o = out + (size_t)k * 24 * ldz;
+    const size_t jj = off + i;
+    // one residue class u of the coefficient index at a time (a(X) = sum_u X^u A_u(X^3), see crt_store): 8 loads in flight, not 24
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        u64 x[8], A[8];
+#pragma unroll
+        for (int v8 = 0; v8 < 8; v8++) {
+            int4 w = *(const int4 *)(planes + (size_t)(3 * v8 + u) * n_planes + 4 * i);
+            const int32_t v[4] = {w.x, w.y, w.z, w.w};
+            long long sacc = 0;
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                int d = digit2(v[l], k);
+                sacc += d > 0 ? bi.v[l] : (d < 0 ? -bi.v[l] : 0ll);
+            }
+            x[v8] = sacc < 0 ? LF_P - (u64)(-sacc) : (u64)sacc;
+        }
+        crt8(x, A, t);
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            int s3 = 3 * t.slot_of_pos[p];
+            if (u == 0) o[(size_t)s3 * ldz + jj] = A[p];
+            else if (u == 1) o[(size_t)(s3 + t.pos1[p]) * ldz + jj] = fq_mul(t.tw1[p], A[p]);
+            else o[(size_t)(s3 + t.pos2[p]) * ldz + jj] = fq_mul(t.tw2[p], A[p]);
+        }
+    }
+}
 void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K, int mode_bits,
                           u64 *out, size_t ldz, size_t off, hipStream_t s) {
+    if (mode_bits && L == 4 && B < ((u64)1 << 20) && (n_planes & 3) == 0 && ((uintptr_t)planes & 15) == 0) {
+        BInt4 bi;
+        bi.v[0] = 1;
+        for (int l = 1; l < 4; l++) bi.v[l] = bi.v[l - 1] * (long long)B;
+        hipLaunchKernelGGL(k_recompose_crt_b4, dim3(cdiv(wit_len, 256), K), dim3(256), 0, s, t, planes, n_planes, wit_len, bi, out, ldz, off);
+        return;
+    }
     BPow bp;
     u64 pw = 1;
     for (int l = 0; l < 8; l++) { bp.v[l] = pw; pw = fq_mul(pw, B % LF_P); }
