@@ -1447,44 +1447,75 @@ void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, s
 // ---------------------------------------------------------------------------------------------------------
 // compute_f_0 (folding.rs:258-268) in the coefficient domain: f_0[j] = sum_i rho_i * f_i[j] with rho_i a short challenge
 // (24 coefficients in [-32,32), rings/babybear.rs:36-68) and f_i the i-th bit-plane; X^72 = X^36 - 1.
-// One thread per (element j, output third): out coefficients [24*part, 24*part+24).
-__global__ void __launch_bounds__(128) k_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho, int32_t *out) {
-    size_t j = (size_t)blockIdx.x * 128 + threadIdx.x;
-    if (j >= n) return;
-    int32_t acc[RE];
+// Nibble tables (as in the Goldilocks kernel): for one side, sum_k rho_k[a] * digit_k(v_c) = sign(v_c) * sum_q R[q][nibble_q(|v_c|)][a] with
+// R[q][val][a] = sum_{b<4} bit_b(val) rho_{4q+b}[a] -- four look-ups of a 24-vector per coefficient c instead of 16 x 24 multiply-adds.
+// Tables for both signs and sides (2*2*4*16*24 int32 = 24 KB) are built in LDS per block; one thread per element.  The coefficient loop
+// runs in groups of 8 with a scheduling barrier between groups, so only 8 plane loads are in flight next to the 95 accumulators.
+// Sliding window: coefficient c only touches output positions c..c+23, so with both sides handled per group of 8 coefficients the
+// positions C0..C0+7 are final after the group -- they are stored (before the X^72 wrap) and leave the registers; 31 live accumulators
+// instead of 95.  The wrap X^72 = X^36 - 1 of positions 72..94 is applied to the stored values at the end.
+template <int C0>
+__device__ __forceinline__ void fw_group8(int32_t (&win)[31], const int32_t *pL, const int32_t *pR, size_t n, size_t j,
+                                          const int32_t (*R)[2][4][16][28], int32_t *out) {
 #pragma unroll
-    for (int c = 0; c < RE; c++) acc[c] = 0;
-#pragma unroll 1
     for (int side = 0; side < 2; side++) {
-        const int32_t *pl = side ? planesR : planesL;
-        int32_t v[RE];
+        const int32_t *pl = side ? pR : pL;
+        int32_t vv[8];
 #pragma unroll
-        for (int c = 0; c < RE; c++) v[c] = pl[(size_t)c * n + j];
-#pragma unroll 1
-        for (u32 k = 0; k < K; k++) {
-            const int8_t *rh = rho + (size_t)(side * K + k) * 24;
-            int32_t d[RE];
+        for (int i = 0; i < 8; i++) vv[i] = pl[(size_t)(C0 + i) * n + j];
 #pragma unroll
-            for (int c = 0; c < RE; c++) d[c] = digit2(v[c], k);
-            // prod[e] = sum_a rho_a d[e-a], e < 96; fold X^e (e >= 72) = X^(e-36) - X^(e-72)
+        for (int i = 0; i < 8; i++) {
+            int32_t v = vv[i];
+            u32 mg = (u32)(v < 0 ? -v : v), sg = v < 0;
 #pragma unroll
-            for (int aa = 0; aa < 24; aa++) {
-                int32_t ra = rh[aa];
+            for (int q = 0; q < 4; q++) {
+                const int4 *t = (const int4 *)R[side][sg][q][(mg >> (4 * q)) & 15];
 #pragma unroll
-                for (int c = 0; c < RE; c++) {
-                    int e = c + aa;
-                    int32_t pr = __mul24(ra, d[c]);
-                    if (e < RE) acc[e] += pr;
-                    else { acc[e - 36] += pr; acc[e - 72] -= pr; }
+                for (int w = 0; w < 6; w++) {
+                    int4 x = t[w];
+                    win[i + 4 * w] += x.x; win[i + 4 * w + 1] += x.y; win[i + 4 * w + 2] += x.z; win[i + 4 * w + 3] += x.w;
                 }
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < RE; c++) out[(size_t)c * n + j] = acc[c];
+    for (int i = 0; i < 8; i++) out[(size_t)(C0 + i) * n + j] = win[i];
+#pragma unroll
+    for (int i = 0; i < 23; i++) win[i] = win[i + 8];
+#pragma unroll
+    for (int i = 23; i < 31; i++) win[i] = 0;
+}
+__global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho, int32_t *out) {
+    __shared__ __align__(16) int32_t R[2][2][4][16][28];   // [side][sign][nibble][value][a]; rows padded to 28 words (bank spread)
+    for (u32 idx = threadIdx.x; idx < 2 * 4 * 16 * 24; idx += 256) {
+        u32 a = idx % 24, val = (idx / 24) % 16, q = (idx / (24 * 16)) % 4, side = idx / (24 * 16 * 4);
+        int sum = 0;
+#pragma unroll
+        for (u32 b = 0; b < 4; b++)
+            if (4 * q + b < K && ((val >> b) & 1)) sum += rho[(size_t)(side * K + 4 * q + b) * 24 + a];
+        R[side][0][q][val][a] = sum;
+        R[side][1][q][val][a] = -sum;
+    }
+    __syncthreads();
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int32_t win[31];
+#pragma unroll
+    for (int i = 0; i < 31; i++) win[i] = 0;
+    fw_group8<0>(win, planesL, planesR, n, j, R, out);  fw_group8<8>(win, planesL, planesR, n, j, R, out);
+    fw_group8<16>(win, planesL, planesR, n, j, R, out); fw_group8<24>(win, planesL, planesR, n, j, R, out);
+    fw_group8<32>(win, planesL, planesR, n, j, R, out); fw_group8<40>(win, planesL, planesR, n, j, R, out);
+    fw_group8<48>(win, planesL, planesR, n, j, R, out); fw_group8<56>(win, planesL, planesR, n, j, R, out);
+    fw_group8<64>(win, planesL, planesR, n, j, R, out);
+    // win[i] = position 72 + i;  X^72 = X^36 - 1
+#pragma unroll
+    for (int i = 0; i < 23; i++) {
+        out[(size_t)(36 + i) * n + j] += win[i];
+        out[(size_t)i * n + j] -= win[i];
+    }
 }
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho, int32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_fold_witness, dim3(cdiv(n, 128)), dim3(128), 0, s, planesL, planesR, n, K, rho, out);
+    hipLaunchKernelGGL(k_fold_witness, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho, out);
 }
 
 }  // namespace lfbb
