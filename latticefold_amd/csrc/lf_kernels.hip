@@ -1838,6 +1838,39 @@ void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *F
 // Nibble tables.  For one side, sum_k rho_k[a] * digit_k(v_c) = sign(v_c) * sum_nibbles R[nibble][value][a] with
 // R[q][val][a] = sum_{b<4} bit_b(val) rho_{4q+b}[a]: four look-ups of a 24-vector and 24 additions per coefficient c replace the
 // 16 x 24 multiply-adds over the bit-planes.  The tables (both signs, both sides: 2*2*4*16*24 int32 = 24 KB) are built in LDS per block.
+// Sliding window: coefficient c only touches positions c..c+23, so with both sides handled per group of 8 coefficients the positions
+// C0..C0+7 are final after the group; they are stored (before the X^24 wrap) and leave the registers -- 31 live accumulators, not 47.
+template <int C0>
+__device__ __forceinline__ void fw_group8(int32_t (&win)[31], const int32_t *pL, const int32_t *pR, size_t n, size_t j,
+                                          const int32_t (*R)[2][4][16][28], int32_t *out) {
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const int32_t *pl = side ? pR : pL;
+        int32_t vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) vv[i] = pl[(size_t)(C0 + i) * n + j];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int32_t v = vv[i];
+            u32 mg = (u32)(v < 0 ? -v : v), sg = v < 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int4 *t = (const int4 *)R[side][sg][q][(mg >> (4 * q)) & 15];
+#pragma unroll
+                for (int w = 0; w < 6; w++) {
+                    int4 x = t[w];
+                    win[i + 4 * w] += x.x; win[i + 4 * w + 1] += x.y; win[i + 4 * w + 2] += x.z; win[i + 4 * w + 3] += x.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[(size_t)(C0 + i) * n + j] = win[i];
+#pragma unroll
+    for (int i = 0; i < 23; i++) win[i] = win[i + 8];
+#pragma unroll
+    for (int i = 23; i < 31; i++) win[i] = 0;
+}
 __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho,
                                                       int32_t *out) {
     __shared__ __align__(16) int32_t R[2][2][4][16][28];   // [side][sign][nibble][value][a]; rows padded to 28 words (bank spread)
@@ -1853,32 +1886,22 @@ __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, co
     __syncthreads();
     size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    int32_t acc[47];
+    int32_t win[31];
 #pragma unroll
-    for (int i = 0; i < 47; i++) acc[i] = 0;
-#pragma unroll 1
-    for (int side = 0; side < 2; side++) {
-        const int32_t *pl = side ? planesR : planesL;
+    for (int i = 0; i < 31; i++) win[i] = 0;
+    fw_group8<0>(win, planesL, planesR, n, j, R, out);
+    fw_group8<8>(win, planesL, planesR, n, j, R, out);
+    fw_group8<16>(win, planesL, planesR, n, j, R, out);
+    // win[i] = position 24 + i;  X^24 = X^12 - 1, applied top down (positions >= 36 land on positions >= 24 first)
+    int32_t delta[24];
 #pragma unroll
-        for (int c = 0; c < 24; c++) {
-            int32_t v = pl[(size_t)c * n + j];
-            u32 mg = (u32)(v < 0 ? -v : v), sg = v < 0;
+    for (int i = 0; i < 24; i++) delta[i] = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int4 *t = (const int4 *)R[side][sg][q][(mg >> (4 * q)) & 15];
+    for (int i = 22; i >= 12; i--) { win[i - 12] += win[i]; delta[i] -= win[i]; }
 #pragma unroll
-                for (int w = 0; w < 6; w++) {
-                    int4 x = t[w];
-                    acc[c + 4 * w] += x.x; acc[c + 4 * w + 1] += x.y; acc[c + 4 * w + 2] += x.z; acc[c + 4 * w + 3] += x.w;
-                }
-            }
-        }
-    }
-    // X^24 = X^12 - 1
+    for (int i = 11; i >= 0; i--) { delta[12 + i] += win[i]; delta[i] -= win[i]; }
 #pragma unroll
-    for (int i = 46; i >= 24; i--) { acc[i - 12] += acc[i]; acc[i - 24] -= acc[i]; }
-#pragma unroll
-    for (int c = 0; c < 24; c++) out[(size_t)c * n + j] = acc[c];
+    for (int c = 0; c < 24; c++) out[(size_t)c * n + j] += delta[c];
 }
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev, int32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(k_fold_witness, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho_dev, out);
