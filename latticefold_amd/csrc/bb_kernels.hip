@@ -329,35 +329,48 @@ __device__ __forceinline__ int digit2(int32_t v, u32 k) {
 }
 __device__ __forceinline__ fe fe_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? BB_ONE : -BB_ONE); }
 
-__global__ void __launch_bounds__(128) k_bitplane_crt(DevBb t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out) {
-    size_t j = (size_t)blockIdx.x * 128 + threadIdx.x;
+// One thread per (element j, residue class r of the coefficient index): a(X) = sum_r X^r A_r(X^9) and the CRT works class by class
+// (crt_store), so a thread needs only the 8 plane entries c = r + 9 v; it walks the bit-planes k and writes 8 words per plane.
+// 9x the threads of an element-per-thread layout and ~40 registers instead of 174: the kernel runs at the HBM write rate.
+__global__ void __launch_bounds__(256) k_bitplane_crt(DevBb t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 r = blockIdx.y;
     if (j >= n) return;
-    int32_t v[RE];
+    int32_t v[8];
 #pragma unroll
-    for (int c = 0; c < RE; c++) v[c] = planes[(size_t)c * ld + j];
+    for (int q = 0; q < 8; q++) v[q] = planes[(size_t)(r + TAU * q) * ld + j];
+    int plane[8];
+    fe tw[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) { plane[p] = TAU * t.slot_of_pos[p] + t.pos[r][p]; tw[p] = t.tw[r][p]; }
     for (u32 k = k0; k < k1; k++) {
-        fe a[RE];
+        fe x[8], A[8];
 #pragma unroll
-        for (int c = 0; c < RE; c++) a[c] = fe_from_digit(digit2(v[c], k));
-        crt_store(a, out + (size_t)(k - k0) * RE * n, n, j, t);
+        for (int q = 0; q < 8; q++) x[q] = fe_from_digit(digit2(v[q], k));
+        crt8(x, A, t);
+        fe *o = out + (size_t)(k - k0) * RE * n;
+#pragma unroll
+        for (int p = 0; p < 8; p++) o[(size_t)plane[p] * n + j] = r == 0 ? A[p] : fmul(tw[p], A[p]);
     }
 }
 void launch_bitplane_crt(const DevBb &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out, hipStream_t s) {
-    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 128)), dim3(128), 0, s, t, planes, ld, n, k0, k1, out);
+    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256), TAU), dim3(256), 0, s, t, planes, ld, n, k0, k1, out);
 }
 
 struct BPow { fe v[8]; };
-__global__ void __launch_bounds__(128) k_recompose_crt(DevBb t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, BPow bp, u32 K,
+// thread = (element i, residue class r of the coefficient index, table k): 8 coefficients c = r + 9 q, one crt8 (see k_bitplane_crt)
+__global__ void __launch_bounds__(256) k_recompose_crt(DevBb t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, BPow bp, u32 K,
                                                         int mode_bits, fe *out, size_t ldz, size_t off) {
-    size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
-    u32 k = blockIdx.y;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 r = blockIdx.y, k = blockIdx.z;
     if (i >= wit_len) return;
-    fe a[RE];
+    fe x[8], A[8];
 #pragma unroll
-    for (int c = 0; c < RE; c++) {
+    for (int q = 0; q < 8; q++) {
+        const int32_t *pc = planes + (size_t)(r + TAU * q) * n_planes + i * L;
         fe acc = 0;
         for (u32 l = 0; l < L; l++) {
-            int32_t v = planes[(size_t)c * n_planes + i * L + l];
+            int32_t v = pc[l];
             if (mode_bits) {
                 int d = digit2(v, k);
                 if (d > 0) acc = fadd(acc, bp.v[l]);
@@ -366,16 +379,23 @@ __global__ void __launch_bounds__(128) k_recompose_crt(DevBb t, const int32_t *p
                 acc = fadd(acc, fmul(bp.v[l], from_small(v)));
             }
         }
-        a[c] = acc;
+        x[q] = acc;
     }
-    crt_store(a, out + (size_t)k * RE * ldz, ldz, off + i, t);
+    crt8(x, A, t);
+    fe *o = out + (size_t)k * RE * ldz;
+    const size_t jj = off + i;
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        int plane = TAU * t.slot_of_pos[p] + t.pos[r][p];
+        o[(size_t)plane * ldz + jj] = r == 0 ? A[p] : fmul(t.tw[r][p], A[p]);
+    }
 }
 void launch_recompose_crt(const DevBb &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K, int mode_bits, fe *out,
                           size_t ldz, size_t off, hipStream_t s) {
     BPow bp;
     u64 pw = 1;
     for (int l = 0; l < 8; l++) { bp.v[l] = from_canon(pw); pw = hmul(pw, B % BB_P); }
-    hipLaunchKernelGGL(k_recompose_crt, dim3(cdiv(wit_len, 128), K), dim3(128), 0, s, t, planes, n_planes, wit_len, L, bp, K, mode_bits, out,
+    hipLaunchKernelGGL(k_recompose_crt, dim3(cdiv(wit_len, 256), TAU, K), dim3(256), 0, s, t, planes, n_planes, wit_len, L, bp, K, mode_bits, out,
                        ldz, off);
 }
 
