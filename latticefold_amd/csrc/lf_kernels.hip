@@ -348,21 +348,36 @@ __device__ __forceinline__ int digit2(int32_t v, u32 k) {
     return v < 0 ? -d : d;
 }
 
+// thread = (element j, residue class u of the coefficient index): a(X) = sum_u X^u A_u(X^3) is transformed class by class
+// (crt_store_ternary), so a thread needs the 8 plane entries c = 3 v + u only and writes 8 words per bit-plane
 __global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out) {
     size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 u = blockIdx.y;
     if (j >= n) return;
-    int32_t v[24];
+    int32_t v[8];
 #pragma unroll
-    for (int c = 0; c < 24; c++) v[c] = planes[(size_t)c * ld + j];
+    for (int q = 0; q < 8; q++) v[q] = planes[(size_t)(3 * q + u) * ld + j];
+    int plane[8];
+    u64 tw[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        int s3 = 3 * t.slot_of_pos[p];
+        plane[p] = u == 0 ? s3 : (u == 1 ? s3 + t.pos1[p] : s3 + t.pos2[p]);
+        tw[p] = u == 1 ? t.tw1[p] : t.tw2[p];
+    }
     for (u32 k = k0; k < k1; k++) {
-        int dg[24];
+        int x[8];
+        u64 A[8];
 #pragma unroll
-        for (int c = 0; c < 24; c++) dg[c] = digit2(v[c], k);
-        crt_store_ternary(dg, out + (size_t)(k - k0) * 24 * n, n, j, t);
+        for (int q = 0; q < 8; q++) x[q] = digit2(v[q], k);
+        crt8_ternary(x, A, t);
+        u64 *o = out + (size_t)(k - k0) * 24 * n;
+#pragma unroll
+        for (int p = 0; p < 8; p++) o[(size_t)plane[p] * n + j] = u == 0 ? A[p] : fq_mul(tw[p], A[p]);
     }
 }
 void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s) {
-    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256)), dim3(256), 0, s, t, planes, ld, n, k0, k1, out);
+    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256), 3), dim3(256), 0, s, t, planes, ld, n, k0, k1, out);
 }
 
 struct BPow { u64 v[8]; };
