@@ -215,7 +215,7 @@ def main():
         # HBM traffic of the dominant kernel from the PMC passes (collected separately, as rocprofv3 requires; see profiles/)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_o_pmc_{wl.name.lower()}.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_p_pmc_{wl.name.lower()}.json")))["kernels"]
             want = ("bb::" if wl.ring == "babybear" else "") + ("k_ajtai" if dom == "k_ajtai" else "k_fold_round")
             for name, k in pmc.items():
                 base = name.split("<")[0]
