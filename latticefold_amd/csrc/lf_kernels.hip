@@ -971,33 +971,42 @@ void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u6
     hipLaunchKernelGGL(k_reduce_rows, dim3(K * 72), dim3(256), 0, s, partial, gb, K * 72, out);
 }
 
-template <bool NU>
-__global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef, u32 tt, size_t n,
-                                                   u64 *out) {
+template <bool NU, int TT>
+__global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef, size_t n, u64 *out) {
+    // TT output tables (compile time: only the accumulators that are used occupy registers)
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y;
     if (i >= n) return;
-    LH5 acc[4];
+    LH5 acc[TT];
+    Fq3 accg[TT];
 #pragma unroll
-    for (int j = 0; j < 4; j++) lh5_zero(acc[j]);
-    Fq3 accg[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
+    for (int j = 0; j < TT; j++) { lh5_zero(acc[j]); accg[j] = fq3_zero(); }
     for (u32 k = 0; k < K; k++) {
         Fq3 x = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if ((u32)j < tt) {
-                Fq3Const cc = coef[k * tt + j];
-                Fq3 cv = fq3_make(cc.c[0], cc.c[1], cc.c[2]);
-                if (NU) lh5_mac(acc[j], x, cv);
-                else accg[j] = fq3_add(accg[j], M3<NU>(x, cv, t.nu));
-            }
+        for (int j = 0; j < TT; j++) {
+            Fq3Const cc = coef[k * TT + j];
+            Fq3 cv = fq3_make(cc.c[0], cc.c[1], cc.c[2]);
+            if (NU) lh5_mac(acc[j], x, cv);
+            else accg[j] = fq3_add(accg[j], M3<NU>(x, cv, t.nu));
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-        if ((u32)j < tt) st3(out + (size_t)j * 24 * ldz, ldz, slot, i, NU ? lh5_finish(acc[j]) : accg[j]);
+    for (int j = 0; j < TT; j++) st3(out + (size_t)j * 24 * ldz, ldz, slot, i, NU ? lh5_finish(acc[j]) : accg[j]);
 }
 void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev, u32 tt, size_t n, u64 *out, hipStream_t s) {
-    LF_LAUNCH(k_lincomb_z, t.nu2p40, dim3(cdiv(n, 256), 8), dim3(256), s, t, z, ldz, K, coef_dev, tt, n, out);
+#define LF_LZ(N)                                                                                                                              \
+    do {                                                                                                                                      \
+        if (t.nu2p40) hipLaunchKernelGGL((k_lincomb_z<true, N>), dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef_dev, n, out);    \
+        else hipLaunchKernelGGL((k_lincomb_z<false, N>), dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef_dev, n, out);            \
+    } while (0)
+    switch (tt) {
+        case 1: LF_LZ(1); break;
+        case 2: LF_LZ(2); break;
+        case 3: LF_LZ(3); break;
+        default: LF_LZ(4); break;   // callers keep tt <= 4
+    }
+#undef LF_LZ
 }
 
 // Nibble tables: sum_k apow[k][d] * digit_k(v) = sign(v) * sum_q T[d][q][(|v| >> 4q) & 15], T[d][q][val] = sum_{b<4, bit b of val} apow[4q+b][d]
