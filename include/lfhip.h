@@ -181,6 +181,23 @@ int lf_sumcheck_lin_begin(lf_ctx *, const uint64_t *tables /* t x m ring elems *
 int lf_sumcheck_lin_round(lf_ctx *, const uint64_t *r_prev /* 3 words or NULL */, uint64_t *evals_out /* (d+2) ring elems */);
 int lf_sumcheck_lin_end(lf_ctx *);
 
+/* The folding sumcheck, same split: MLSumcheck::prove_as_subprotocol (utils/sumcheck.rs:53-80) with the comb function of
+ * nifs/folding/utils.rs:273-325 (b = 2).  `tables` = the mle list create_sumcheck_polynomial builds (folding/utils.rs:200-259):
+ * [eq(r_L), G_L, eq(r_R), G_R, eq(beta), f-hat_{0,0} .. f-hat_{2K-1,tau-1}], (5 + 2K*tau) x m ring elements (NTT); the three eq
+ * tables must be slot-constant (else LF_ERR_UNSUPPORTED); mu = 2K challenges of tau words (the last one is ONE in the protocol).
+ * Each round returns 2b+1 = 5 ring elements.  (lf_fold_step itself runs this sumcheck on virtual f-hat tables.) */
+int lf_sumcheck_fold_begin(lf_ctx *, const uint64_t *tables, const uint64_t *mu);
+int lf_sumcheck_fold_round(lf_ctx *, const uint64_t *r_prev /* tau words or NULL */, uint64_t *evals_out /* (2b+1) ring elems */);
+int lf_sumcheck_fold_end(lf_ctx *);
+/* compute_f_0 (nifs/folding.rs:258-268): out[j] = sum_{i<n_terms} coef_i (.) tables_i[j]; coef = n_terms ring elements (NTT, e.g. the
+ * CRT of the short challenges rho_i), tables = n_terms x len ring elements (NTT) */
+int lf_lincomb(lf_ctx *, const uint64_t *coef, const uint64_t *tables, size_t n_terms, size_t len, uint64_t *out);
+/* calculate_challenged_mz_mle (nifs/folding.rs:208-226) / prepare_g1_and_3_k_mles_list (nifs/folding/utils.rs:524-546):
+ * out[x] = sum_{i<groups} sum_{j<per_group} c_i^(j+1) T_{i,j}[x]; tables = groups x per_group x len ring elements (NTT),
+ * challenges = groups x tau words */
+int lf_horner_combine(lf_ctx *, const uint64_t *tables, size_t groups, size_t per_group, size_t len, const uint64_t *challenges,
+                      uint64_t *out);
+
 /* ---- the path itself ----------------------------------------------------------------------------------- */
 /* LFLinearizationProver::prove (nifs/linearization.rs:145-189) */
 int lf_linearize(lf_ctx *, lf_transcript *, const uint64_t *cccs, const lf_witness *wit, uint64_t *lcccs_out,
@@ -188,6 +205,18 @@ int lf_linearize(lf_ctx *, lf_transcript *, const uint64_t *cccs, const lf_witne
 /* NIFSProver::prove (nifs.rs:48-103): one fold step.  w_out receives the folded witness handle. */
 int lf_fold_step(lf_ctx *, lf_transcript *, const uint64_t *acc_lcccs, const lf_witness *w_acc, const uint64_t *cm_i_cccs,
                  const lf_witness *w_i, uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof_out);
+
+/* The two other sub-provers of the reference as entry points of their own (the reference exposes all three as public traits).
+ * LFDecompositionProver::prove (nifs/decomposition.rs:33-88): dec_proof_out = u_s[K][t] | v_s[K][tau] | x_s[K][l+1] | y_s[K][kappa]
+ * ring elements; lcccs_s_out (optional) = the K decomposed LCCCS, flat; the K decomposed witnesses stay virtual (base-b parts of
+ * `wit`).  Needs the CCS and the Ajtai matrix. */
+int lf_decomposition_prove(lf_ctx *, lf_transcript *, const uint64_t *lcccs, const lf_witness *wit, uint64_t *lcccs_s_out,
+                           uint64_t *dec_proof_out);
+/* LFFoldingProver::prove (nifs/folding.rs:42-130): lcccs_s = 2K LCCCS (K parts of the accumulator's decomposition, then K of the
+ * linearized instance's), w_left / w_right = the witnesses those are the base-b parts of.  fold_proof_out =
+ * msgs[s][2b+1] | theta[2K][tau] | eta[2K][t] ring elements. */
+int lf_folding_prove(lf_ctx *, lf_transcript *, const uint64_t *lcccs_s, const lf_witness *w_left, const lf_witness *w_right,
+                     uint64_t *lcccs_out, lf_witness **w_out, uint64_t *fold_proof_out);
 
 /* ---- measurement hooks (bench.py): HIP-event time of the last fold step, per phase, in ms ------------ */
 #define LF_N_PHASES 8

@@ -133,6 +133,13 @@ def _lib():
         L.lf_sumcheck_lin_end.argtypes = [vp]
         L.lf_linearize.argtypes = [vp, vp, u64p, vp, u64p, u64p]
         L.lf_fold_step.argtypes = [vp, vp, u64p, vp, u64p, vp, u64p, C.POINTER(vp), u64p]
+        L.lf_sumcheck_fold_begin.argtypes = [vp, u64p, u64p]
+        L.lf_sumcheck_fold_round.argtypes = [vp, u64p, u64p]
+        L.lf_sumcheck_fold_end.argtypes = [vp]
+        L.lf_lincomb.argtypes = [vp, u64p, u64p, C.c_size_t, C.c_size_t, u64p]
+        L.lf_horner_combine.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, u64p]
+        L.lf_decomposition_prove.argtypes = [vp, vp, u64p, vp, u64p, u64p]
+        L.lf_folding_prove.argtypes = [vp, vp, u64p, vp, vp, u64p, C.POINTER(vp), u64p]
         L.lf_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.lf_phase_name.restype = C.c_char_p
         L.lf_phase_name.argtypes = [C.c_int]
@@ -475,6 +482,35 @@ class LFLinearizationProver:
         return lc, pr
 
 
+class LFDecompositionProver:
+    @staticmethod
+    def prove(ctx, lcccs, wit, transcript):
+        """nifs/decomposition.rs:33-88 -> (K decomposed LCCCS flat [K*lcccs_len], decomposition proof flat).  The K decomposed
+        witnesses are the base-b parts of `wit` and stay virtual on the device."""
+        a, p = _a64(lcccs)
+        prm = ctx.params
+        lcs = np.zeros((prm.K * ctx.lcccs_len, ctx.RE), dtype=np.uint64)
+        pr = np.zeros((prm.K * (prm.t + ctx.TAU + prm.l + 1 + prm.kappa), ctx.RE), dtype=np.uint64)
+        _chk(_lib().lf_decomposition_prove(ctx.h, transcript.h, p, wit.h, lcs.ctypes.data_as(u64p), pr.ctypes.data_as(u64p)),
+             "lf_decomposition_prove")
+        return lcs, pr
+
+
+class LFFoldingProver:
+    @staticmethod
+    def prove(ctx, lcccs_s, w_left, w_right, transcript):
+        """nifs/folding.rs:42-130: lcccs_s = the 2K decomposed LCCCS, w_left / w_right the witnesses they are parts of
+        -> (folded LCCCS flat, folded Witness, folding proof flat)."""
+        a, p = _a64(lcccs_s)
+        prm = ctx.params
+        lc = np.zeros((ctx.lcccs_len, ctx.RE), dtype=np.uint64)
+        pr = np.zeros((prm.s * (2 * prm.b + 1) + 2 * prm.K * (ctx.TAU + prm.t), ctx.RE), dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(_lib().lf_folding_prove(ctx.h, transcript.h, p, w_left.h, w_right.h, lc.ctypes.data_as(u64p), C.byref(h),
+                                     pr.ctypes.data_as(u64p)), "lf_folding_prove")
+        return lc, Witness(ctx, h), pr
+
+
 class NIFSProver:
     @staticmethod
     def prove(ctx, acc, w_acc, cm_i, w_i, transcript):
@@ -560,3 +596,48 @@ class MLSumcheckLin:
 
     def end(self):
         _chk(_lib().lf_sumcheck_lin_end(self.ctx.h), "lf_sumcheck_lin_end")
+
+
+class MLSumcheckFold:
+    """utils/sumcheck.rs:53-80 split at the transcript, for the folding polynomial (nifs/folding/utils.rs:200-325):
+    tables = [eq_L, G_L, eq_R, G_R, eq_beta, f-hat ...] ((5 + 2K*tau) x m ring elements), mu = 2K challenges (lf_sumcheck_fold_*)."""
+
+    def __init__(self, ctx, tables, mu):
+        self.ctx = ctx
+        a, p = _a64(tables)
+        b, q = _a64(mu)
+        _chk(_lib().lf_sumcheck_fold_begin(ctx.h, p, q), "lf_sumcheck_fold_begin")
+
+    def prove_round(self, r_prev=None):
+        prm = self.ctx.params
+        o = np.zeros((2 * prm.b + 1, self.ctx.RE), dtype=np.uint64)
+        if r_prev is None:
+            rc = _lib().lf_sumcheck_fold_round(self.ctx.h, None, o.ctypes.data_as(u64p))
+        else:
+            a, p = _a64(r_prev)
+            rc = _lib().lf_sumcheck_fold_round(self.ctx.h, p, o.ctypes.data_as(u64p))
+        _chk(rc, "lf_sumcheck_fold_round")
+        return o
+
+    def end(self):
+        _chk(_lib().lf_sumcheck_fold_end(self.ctx.h), "lf_sumcheck_fold_end")
+
+
+def lincomb(ctx, coef, tables):
+    """compute_f_0 (nifs/folding.rs:258-268): sum_i coef_i (.) tables_i; coef (n, RE), tables (n, len, RE)"""
+    t = np.ascontiguousarray(tables, dtype=np.uint64)
+    n, ln = t.shape[0], t.shape[1]
+    a, p = _a64(coef)
+    o = np.zeros((ln, ctx.RE), dtype=np.uint64)
+    _chk(_lib().lf_lincomb(ctx.h, p, t.ctypes.data_as(u64p), n, ln, o.ctypes.data_as(u64p)), "lf_lincomb")
+    return o
+
+
+def horner_combine(ctx, tables, challenges):
+    """calculate_challenged_mz_mle (nifs/folding.rs:208-226): tables (groups, per_group, len, RE), challenges (groups, TAU)"""
+    t = np.ascontiguousarray(tables, dtype=np.uint64)
+    g, pg, ln = t.shape[0], t.shape[1], t.shape[2]
+    a, p = _a64(challenges)
+    o = np.zeros((ln, ctx.RE), dtype=np.uint64)
+    _chk(_lib().lf_horner_combine(ctx.h, t.ctypes.data_as(u64p), g, pg, ln, p, o.ctypes.data_as(u64p)), "lf_horner_combine")
+    return o

@@ -53,6 +53,7 @@ struct BbCtxImpl {
     size_t arena_words = 0, arena_used[2] = {0, 0};
     hipEvent_t ev_side[2] = {nullptr, nullptr};
     hipEvent_t ev_dec[4] = {nullptr, nullptr, nullptr, nullptr};   // decomposition milestones: [2*side + (0 commit, 1 evaluations)]
+    Tunables tn;          // environment switches, re-read at the start of every linearize / fold_step
     u32 lin_blocks = 0;   // grid bound of the linearization rounds while the commit chain runs on the other lane (0 = none)
     u64 *h_round = nullptr;   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
     u64 *round_out() {
@@ -62,6 +63,9 @@ struct BbCtxImpl {
     int sc_round = -1;
     size_t sc_n = 0;
     int sc_cur = 0;
+    int sf_round = -1;   // folding-sumcheck ABI state
+    size_t sf_n = 0;
+    int sf_cur = 0;
     // measurement
     float phase_ms[NPH] = {0};
     std::vector<EvPair> ev_pool;
@@ -584,6 +588,9 @@ int BbCtx::ccs_load(const lf_params *P, const uint32_t *const *rowptr, const uin
                 if (S_idx[k] != next++) return LF_ERR_UNSUPPORTED;
         if (next != P->t || S_off[P->q] > 16) return LF_ERR_UNSUPPORTED;
     }
+    RET(lf_validate_csr(P->t, m, n, rowptr, col, val, RE, BB_P));   // before any context state is touched
+    for (size_t k = 0; k < (size_t)P->q * RE; k++)
+        if (cc[k] >= BB_P) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     free_ccs(c);
@@ -600,12 +607,14 @@ int BbCtx::ccs_load(const lf_params *P, const uint32_t *const *rowptr, const uin
         for (int w = 0; w < RE; w++) c->desc.c[i][w] = from_canon(ci[w]);
         c->desc.c_unit[i] = !memcmp(ci, one, sizeof(one)) ? 1 : (!memcmp(ci, mone, sizeof(mone)) ? -1 : 0);
     }
+    auto dalloc = [](auto &vec, size_t bytes) -> void * {   // registered in the context at once: a failure half-way leaks nothing
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, bytes) != hipSuccess) return nullptr;
+        vec.push_back((typename std::remove_reference<decltype(vec)>::type::value_type)ptr);
+        return ptr;
+    };
     for (u32 j = 0; j < P->t; j++) {
         size_t nnz = rowptr[j][m];
-        for (size_t k = 0; k < nnz; k++)
-            if (col[j][k] >= n) return LF_ERR_INVALID;
-        u32 *drp, *dci, *dcp, *dri;
-        fe *dv, *dvT;
         std::vector<fe> v(nnz * RE + 1), vT(nnz * RE + 1);
         for (size_t k = 0; k < nnz * RE; k++) v[k] = from_canon(val[j][k]);
         std::vector<u32> cp(n + 1, 0), ri(nnz + 1);
@@ -618,20 +627,15 @@ int BbCtx::ccs_load(const lf_params *P, const uint32_t *const *rowptr, const uin
                 ri[pos] = (u32)r;
                 memcpy(&vT[(size_t)pos * RE], &v[(size_t)k * RE], RE * sizeof(fe));
             }
-        HIPCHK(hipMalloc((void **)&drp, (m + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dci, (nnz + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dv, (nnz + 1) * RE * sizeof(fe)));
-        HIPCHK(hipMalloc((void **)&dcp, (n + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dri, (nnz + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dvT, (nnz + 1) * RE * sizeof(fe)));
+        void *drp = dalloc(c->d_rowptr, (m + 1) * 4), *dci = dalloc(c->d_col, (nnz + 1) * 4), *dv = dalloc(c->d_val, (nnz + 1) * RE * sizeof(fe));
+        void *dcp = dalloc(c->d_colptr, (n + 1) * 4), *dri = dalloc(c->d_rowidx, (nnz + 1) * 4), *dvT = dalloc(c->d_valT, (nnz + 1) * RE * sizeof(fe));
+        if (!drp || !dci || !dv || !dcp || !dri || !dvT) return LF_ERR_HIP;
         HIPCHK(hipMemcpy(drp, rowptr[j], (m + 1) * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dci, col[j], nnz * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dv, v.data(), nnz * RE * sizeof(fe), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dcp, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dri, ri.data(), nnz * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dvT, vT.data(), nnz * RE * sizeof(fe), hipMemcpyHostToDevice));
-        c->d_rowptr.push_back(drp); c->d_col.push_back(dci); c->d_val.push_back(dv);
-        c->d_colptr.push_back(dcp); c->d_rowidx.push_back(dri); c->d_valT.push_back(dvT);
     }
     c->have_ccs = true;
     return LF_OK;
@@ -664,7 +668,7 @@ static int witness_from_coef_table(C *c, const fe *coef_dev, lf_witness **out) {
         return LF_ERR_HIP;
     }
     if (hv) { (void)hipFree(pl); return LF_ERR_NORM; }
-    *out = new lf_witness{c->owner, pl, c->N};
+    *out = new lf_witness{c->owner, pl, c->N, lf_ctx_device(c->owner), c->N * RE * 4};
     return LF_OK;
 }
 int BbCtx::witness_from_w_ccs(const uint64_t *w_ccs, lf_witness **out) {
@@ -874,7 +878,7 @@ static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witn
     std::vector<H9> pt(P.s);
     // v, u at the sumcheck point (linearization.rs:126-139): u from the fully fixed Mz tables of the sumcheck (LF_LIN_U_EVAL=1: dot
     // products with eq(r) over the full tables), v from the witness planes
-    const bool u_eval = getenv("LF_LIN_U_EVAL") != nullptr;
+    const bool u_eval = c->tn.lin_u_eval;
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + (size_t)TAU * RE));
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * RE, *u = v + (size_t)TAU * RE;   // contiguous
@@ -1132,13 +1136,13 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
     bool sharded = Gw > 1;
     // unsharded, rounds >= 4 with many entries: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel
-    const bool fused = Gw == 1 && !getenv("LF_FOLD_UNFUSED");
-    const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 16384;   // entries; tests lower it
+    const bool fused = Gw == 1 && !c->tn.fold_unfused;
+    const size_t fuse_min = c->tn.fuse_min;   // entries; tests lower it
     const fe *prevF = nullptr;
     size_t prevld = 0;
     // rounds 3 and 4 of large unsharded instances never materialise the m/4-entry tables (k_fold_round modes 3 and 4)
-    const size_t lut_min = getenv("LF_FOLD_LUT_MIN") ? (size_t)atoll(getenv("LF_FOLD_LUT_MIN")) : ((size_t)1 << 15);
-    const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !getenv("LF_FOLD_NO_LUT");
+    const size_t lut_min = c->tn.lut_min;   // default 2^15
+    const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !c->tn.fold_no_lut;
     fe *d_lut = nullptr;
     int lut_mode = 0;
     for (u32 round = 1; round <= P.s; round++) {
@@ -1216,7 +1220,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         size_t ev = c->ev_begin(0);
         if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
-        else if (lut_mode == 3 && !getenv("LF_FOLD_NO_MUTAB")) {
+        else if (lut_mode == 3 && !c->tn.fold_no_mutab) {
             fe *mutab;
             RET(c->tbuf("fold_mutab", (size_t)3 * K2 * TAU * 81 * 12, &mutab));
             launch_fold_round_lut_mu(c->dev, a, S[0].planes, S[1].planes, N, d_lut, mutab, K, d_mup, partial, od, c->stream());
@@ -1258,7 +1262,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // theta = f-hat_{k,d}(r_o): the sumcheck's f-hat tables, fixed at r_1..r_{s-1}, have two entries left -- one more fix gives the
     // evaluations (exact arithmetic: the same words as evaluate_mles on the witness).  LF_THETA_EVAL=1 / fewer than 4 variables:
     // stand-alone evaluation.
-    if (P.s >= 4 && curF && ldF == 2 && !getenv("LF_THETA_EVAL")) launch_fix_final(c->dev, curF, ldF, K2 * TAU * 8, e9pre_from_h9(pt[P.s - 1], c->ring.T.nu), d_theta, c->stream());
+    if (P.s >= 4 && curF && ldF == 2 && !c->tn.theta_eval) launch_fix_final(c->dev, curF, ldF, K2 * TAU * 8, e9pre_from_h9(pt[P.s - 1], c->ring.T.nu), d_theta, c->stream());
     else
         for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * TAU * RE, c->stream());
     HIPCHK(hipMemcpyAsync(hp, d_theta, nth * 8, hipMemcpyDeviceToHost, c->stream()));
@@ -1297,7 +1301,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(lf_planes_alloc(c->owner, N * RE * 4, &npl));
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     HIPCHK(hipStreamSynchronize(c->stream()));
-    *w_out = new lf_witness{c->owner, npl, N};
+    *w_out = new lf_witness{c->owner, npl, N, lf_ctx_device(c->owner), N * RE * 4};
     c->ev_end(ph);
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521), host
@@ -1347,6 +1351,7 @@ int BbCtx::linearize(BbTranscript &tr, const uint64_t *cccs, const lf_witness *w
     if (!c->have_ccs) return LF_ERR_STATE;
     if (wit->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
+    c->tn = Tunables::read((size_t)1 << 15);
     c->ev_reset();
     c->host_tr_ms = 0;
     int rc = linearize_impl(c, tr, cccs, wit, lcccs_out, lin_proof_out, nullptr);
@@ -1364,6 +1369,7 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     HIPCHK(hipSetDevice(c->device));
     std::vector<H9> rL;
     if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;   // evaluation points are always diagonal challenges
+    c->tn = Tunables::read((size_t)1 << 15);
     c->ev_reset();
     c->host_tr_ms = 0;
     size_t tot = c->ev_begin(17);
@@ -1384,7 +1390,7 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     if (rc == LF_OK) rc = dec_enqueue_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
     if (rc == LF_OK) rc = dec_enqueue_commit(c, w_i, pdR);
     c->lane = 0;
-    c->lin_blocks = getenv("LF_LIN_BLOCKS") ? (u32)atoi(getenv("LF_LIN_BLOCKS")) : 0u;
+    c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : 0u;
     {   // absorb_public_input (nifs.rs:175-197) -- while the GPU already works on the left decomposition
         HostTimer ht(c);
         tr.absorb_label("acc");
@@ -1404,6 +1410,72 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     (void)hipStreamSynchronize(c->st_lane[1]);
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->ev_end(tot);
+    c->ev_collect();
+    return rc;
+}
+
+// LFDecompositionProver::prove (nifs/decomposition.rs:33-88) as its own entry point
+int BbCtx::decomposition_prove(BbTranscript &tr, const uint64_t *lcccs, const lf_witness *wit, uint64_t *lcccs_s_out, uint64_t *dec_proof_out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    const lf_params &P = c->P;
+    if (c->kappa != P.kappa || c->nA_total != c->N || wit->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<H9> r;
+    if (!lcccs_point(P, lcccs, r)) return LF_ERR_UNSUPPORTED;
+    c->tn = Tunables::read((size_t)1 << 15);
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    c->arena_used[0] = c->arena_used[1] = 0;
+    c->lane = 0;
+    DecPending pd;
+    pd.side = 0;
+    SideState S;
+    RET(dec_enqueue_commit(c, wit, pd));
+    RET(dec_enqueue_evals(c, lcccs, r, wit, "L", nullptr, S, dec_proof_out, pd));
+    RET(dec_finish(c, tr, lcccs, S, dec_proof_out, pd));
+    if (lcccs_s_out) memcpy(lcccs_s_out, S.lcccs.data(), S.lcccs.size() * 8);
+    c->ev_collect();
+    return LF_OK;
+}
+
+// LFFoldingProver::prove (nifs/folding.rs:42-130) as its own entry point (see lf_folding_prove)
+int BbCtx::folding_prove(BbTranscript &tr, const uint64_t *lcccs_s, const lf_witness *w_left, const lf_witness *w_right, uint64_t *lcccs_out,
+                         lf_witness **w_out, uint64_t *fold_proof_out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    const lf_params &P = c->P;
+    if (w_left->N != c->N || w_right->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    c->tn = Tunables::read((size_t)1 << 15);
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    c->arena_used[0] = c->arena_used[1] = 0;
+    c->lane = 0;
+    const size_t ll = bb_lcccs_len(&P);
+    const u32 K = P.K, hl = P.l + 1;
+    SideState S[2];
+    for (int sd = 0; sd < 2; sd++) {
+        const u64 *base = lcccs_s + (size_t)sd * K * ll * RE;
+        std::vector<H9> r;
+        if (!lcccs_point(P, base, r)) return LF_ERR_UNSUPPORTED;
+        for (u32 k = 1; k < K; k++)
+            if (memcmp(base, base + (size_t)k * ll * RE, (size_t)P.s * RE * 8) != 0) return LF_ERR_INVALID;
+        const lf_witness *w = sd ? w_right : w_left;
+        fe *z, *eq_r;
+        RET(c->tbuf(sd ? "z_R" : "z_L", (size_t)K * RE * c->n, &z));
+        RET(c->tbuf(sd ? "eq_r_R" : "eq_r_L", TAU * c->m, &eq_r));
+        std::vector<u64> heads((size_t)K * hl * RE);
+        for (u32 k = 0; k < K; k++)
+            memcpy(&heads[(size_t)k * hl * RE], base + ((size_t)k * ll + P.s + TAU + P.kappa + P.t) * RE, (size_t)hl * RE * 8);
+        RET(build_z(c, w->planes, K, 1, heads.data(), z));
+        RET(build_eq_dev(c, r.data(), P.s, eq_r));
+        S[sd].planes = w->planes; S[sd].z = z; S[sd].eq_r = eq_r;
+        S[sd].lcccs.assign(base, base + (size_t)K * ll * RE);
+    }
+    int rc = fold_impl(c, tr, S, lcccs_out, w_out, fold_proof_out);
     c->ev_collect();
     return rc;
 }
@@ -1456,6 +1528,126 @@ int BbCtx::sumcheck_lin_round(const uint64_t *r_prev, uint64_t *evals_out) {
     c->sc_round++;
     return down_small(c, od, (size_t)(P.d + 2) * RE, evals_out);
 }
+// ---- the folding sumcheck through the ABI (see lf_sumcheck_fold_* in lf_capi.cpp / include/lfhip.h) -----------------------------
+int BbCtx::sumcheck_fold_begin(const uint64_t *tables, const uint64_t *mu) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    const size_t m = c->m;
+    if (m < 2) return LF_ERR_UNSUPPORTED;
+    const u32 K2 = 2 * P.K;
+    static const int eq_idx[3] = {0, 2, 4};
+    for (int e = 0; e < 3; e++) {
+        const u64 *tb = tables + (size_t)eq_idx[e] * m * RE;
+        for (size_t i = 0; i < m; i++)
+            for (int sl = 1; sl < 8; sl++)
+                if (memcmp(tb + i * RE, tb + i * RE + TAU * sl, TAU * 8) != 0) return LF_ERR_UNSUPPORTED;
+    }
+    const size_t T5P = 3 * TAU + 2 * RE;
+    fe *T, *F, *tmp;
+    RET(c->tbuf("sf_T0", T5P * m, &T));
+    RET(c->tbuf("sf_F0", (size_t)K2 * TAU * RE * m, &F));
+    RET(c->tbuf("sf_tmp", RE * m, &tmp));
+    for (int e = 0; e < 3; e++) {
+        RET(up_ring(c, tables + (size_t)eq_idx[e] * m * RE, m, tmp));
+        HIPCHK(hipMemcpyAsync(T + (size_t)TAU * e * m, tmp, TAU * m * sizeof(fe), hipMemcpyDeviceToDevice, c->stream()));
+        HIPCHK(hipStreamSynchronize(c->stream()));
+    }
+    RET(up_ring(c, tables + (size_t)1 * m * RE, m, T + (size_t)3 * TAU * m));
+    RET(up_ring(c, tables + (size_t)3 * m * RE, m, T + (size_t)(3 * TAU + RE) * m));
+    for (u32 i = 0; i < K2 * TAU; i++) RET(up_ring(c, tables + (size_t)(5 + i) * m * RE, m, F + (size_t)i * RE * m));
+    std::vector<E9PreC> mu_pre((size_t)K2 * TAU);
+    for (u32 i = 0; i < K2; i++) {
+        H9 mi = h9_load(mu + (size_t)TAU * i), pm = mi;
+        for (u32 d = 0; d < (u32)TAU; d++) { mu_pre[(size_t)i * TAU + d] = e9pre_from_h9(pm, c->ring.T.nu); pm = c->ring.mul9(pm, mi); }
+    }
+    E9PreC *d_mup;
+    RET(upload_consts(c, "sf_mup", mu_pre, &d_mup));
+    c->sf_round = 0; c->sf_n = m; c->sf_cur = 0;
+    return LF_OK;
+}
+int BbCtx::sumcheck_fold_round(const uint64_t *r_prev, uint64_t *evals_out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->sf_round < 0 || c->sf_round >= (int)c->P.s) return LF_ERR_STATE;
+    if ((c->sf_round == 0) != (r_prev == nullptr)) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    const size_t m = c->m;
+    const u32 K2 = 2 * P.K;
+    const size_t T5P = 3 * TAU + 2 * RE;
+    fe *T[2], *F[2];
+    i64 *partial;
+    u64 *od;
+    E9PreC *d_mup;
+    RET(c->tbuf("sf_T0", T5P * m, &T[0]));
+    RET(c->tbuf("sf_T1", T5P * atl(m / 2), &T[1]));
+    RET(c->tbuf("sf_F0", (size_t)K2 * TAU * RE * m, &F[0]));
+    RET(c->tbuf("sf_F1", (size_t)K2 * TAU * RE * atl(m / 2), &F[1]));
+    RET(c->tbuf("sf_mup", (size_t)K2 * TAU + 8, &d_mup));
+    RET(c->tbuf("round_partial", fold_partial_words(m), &partial));
+    RET(c->tbuf("round_out", 5 * RE, &od));
+    if (r_prev) {
+        E9PreC r = e9pre_from_h9(h9_load(r_prev), c->ring.T.nu);
+        int src = c->sf_cur, dst = src ^ 1;
+        size_t ldi = c->sf_n == m ? m : atl(c->sf_n), ldo = atl(c->sf_n / 2);
+        launch_fix(c->dev, T[src], ldi, T[dst], ldo, c->sf_n, 19, r, c->stream());
+        launch_fix(c->dev, F[src], ldi, F[dst], ldo, c->sf_n, K2 * TAU * 8, r, c->stream());
+        c->sf_cur = dst; c->sf_n /= 2;
+    }
+    const size_t n = c->sf_n, ld = n == m ? m : atl(n);
+    const fe *t5 = T[c->sf_cur];
+    FoldArgs a;
+    a.eqL = t5; a.eqR = t5 + (size_t)TAU * ld; a.eqB = t5 + (size_t)2 * TAU * ld; a.G1 = t5 + (size_t)3 * TAU * ld; a.G2 = t5 + (size_t)(3 * TAU + RE) * ld;
+    a.ld = ld; a.n = n; a.p0 = 0; a.pcnt = n / 2; a.pF0 = 0;
+    launch_fold_round(c->dev, a, F[c->sf_cur], ld, P.K, d_mup, partial, od, c->stream());
+    c->sf_round++;
+    return down_small(c, od, (size_t)(2 * P.b + 1) * RE, evals_out);
+}
+int BbCtx::sumcheck_fold_end() {
+    std::lock_guard<std::mutex> g(p->mu);
+    p->sf_round = -1;
+    return LF_OK;
+}
+// compute_f_0 (nifs/folding.rs:258-268) with ring-element coefficients
+int BbCtx::lincomb(const uint64_t *coef, const uint64_t *tables, size_t n_terms, size_t len, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    fe *X, *o;
+    RET(c->tbuf("io_a", n_terms * len * RE, &X));
+    RET(c->tbuf("io_b", len * RE, &o));
+    for (size_t i = 0; i < n_terms; i++) RET(up_ring(c, tables + i * len * RE, len, X + i * RE * len));
+    std::vector<E9PreC> cf(n_terms * 8);
+    for (size_t i = 0; i < n_terms; i++)
+        for (int sl = 0; sl < 8; sl++) cf[i * 8 + sl] = e9pre_from_h9(h9_load(coef + i * RE + (size_t)TAU * sl), c->ring.T.nu);
+    E9PreC *d_cf;
+    RET(upload_consts(c, "lc_coef", cf, &d_cf));
+    launch_lincomb_z(c->dev, X, len, (u32)n_terms, d_cf, 1, len, o, c->stream(), 1);
+    return down_ring(c, o, len, out);
+}
+// calculate_challenged_mz_mle (nifs/folding.rs:208-226) / prepare_g1_and_3_k_mles_list (folding/utils.rs:524-546)
+int BbCtx::horner_combine(const uint64_t *tables, size_t groups, size_t per_group, size_t len, const uint64_t *challenges, uint64_t *out) {
+    C *c = p;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nt = groups * per_group;
+    fe *X, *o;
+    RET(c->tbuf("io_a", nt * len * RE, &X));
+    RET(c->tbuf("io_b", len * RE, &o));
+    for (size_t i = 0; i < nt; i++) RET(up_ring(c, tables + i * len * RE, len, X + i * RE * len));
+    std::vector<E9PreC> cf(nt);
+    for (size_t i = 0; i < groups; i++) {
+        H9 ci = h9_load(challenges + (size_t)TAU * i), pw = ci;
+        for (size_t j = 0; j < per_group; j++) { cf[i * per_group + j] = e9pre_from_h9(pw, c->ring.T.nu); pw = c->ring.mul9(pw, ci); }
+    }
+    E9PreC *d_cf;
+    RET(upload_consts(c, "lc_coef", cf, &d_cf));
+    launch_lincomb_z(c->dev, X, len, (u32)nt, d_cf, 1, len, o, c->stream(), 0);
+    return down_ring(c, o, len, out);
+}
 int BbCtx::sumcheck_lin_end() {
     std::lock_guard<std::mutex> g(p->mu);
     p->sc_round = -1;
@@ -1477,6 +1669,7 @@ int BbCtx::last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_
 namespace {
 struct BbV {
     static constexpr int RE = lfbb::RE, TAU = lfbb::TAU;
+    static u64 modulus() { return BB_P; }
     typedef H9 Ext;
     typedef BbTranscript Tr;
     BbHostRing ring;

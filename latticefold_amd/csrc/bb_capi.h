@@ -48,9 +48,17 @@ struct BbCtx {
     int sumcheck_lin_begin(const uint64_t *tables, const uint64_t *eq_point);
     int sumcheck_lin_round(const uint64_t *r_prev, uint64_t *evals_out);
     int sumcheck_lin_end();
+    int sumcheck_fold_begin(const uint64_t *tables, const uint64_t *mu);
+    int sumcheck_fold_round(const uint64_t *r_prev, uint64_t *evals_out);
+    int sumcheck_fold_end();
+    int lincomb(const uint64_t *coef, const uint64_t *tables, size_t n_terms, size_t len, uint64_t *out);
+    int horner_combine(const uint64_t *tables, size_t groups, size_t per_group, size_t len, const uint64_t *challenges, uint64_t *out);
     int linearize(BbTranscript &tr, const uint64_t *cccs, const lf_witness *wit, uint64_t *lcccs_out, uint64_t *lin_proof_out);
     int fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_acc, const uint64_t *cm_i, const lf_witness *w_i,
                   uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof);
+    int decomposition_prove(BbTranscript &tr, const uint64_t *lcccs, const lf_witness *wit, uint64_t *lcccs_s_out, uint64_t *dec_proof_out);
+    int folding_prove(BbTranscript &tr, const uint64_t *lcccs_s, const lf_witness *w_left, const lf_witness *w_right, uint64_t *lcccs_out,
+                      lf_witness **w_out, uint64_t *fold_proof_out);
     int last_phase_ms(float *out);
     int last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_n);
 };

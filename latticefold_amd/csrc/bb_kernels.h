@@ -71,8 +71,9 @@ void launch_dot_eq(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *eq
 // T[k][c] = sum_i eq[i] * digit_k(planes[c][i]) (mode_bits) or the full value (K = 1): out canonical [K][72][9]
 void launch_coef_eval(const DevBb &t, const int32_t *planes, size_t n, const fe *eq, size_t ldeq, u32 K, int mode_bits, i64 *partial,
                       u64 *out, hipStream_t s);
+// per_slot != 0: coef_dev holds K*tt*8 constants, one per slot (ring-element coefficients)
 void launch_lincomb_z(const DevBb &t, const fe *z, size_t ldz, u32 K, const E9PreC *coef_dev /*K*tt*/, u32 tt, size_t n, fe *out,
-                      hipStream_t s);
+                      hipStream_t s, u32 per_slot = 0);
 void launch_add_fhat_comb(const DevBb &t, const int32_t *planes, size_t n_planes, u32 K, const E9C *apow_dev /*K*9*/, fe *G, size_t m,
                           hipStream_t s);
 

@@ -359,6 +359,44 @@ void launch_bitplane_crt(const DevBb &t, const int32_t *planes, size_t ld, size_
 
 struct BPow { fe v[8]; };
 // thread = (element i, residue class r of the coefficient index, table k): 8 coefficients c = r + 9 q, one crt8 (see k_bitplane_crt)
+// thread = (element i, residue class r of the coefficient index); in bit-plane mode the 8 x L plane entries are loaded once and all
+// K bit-planes are produced from registers (planes read once per launch, not K times)
+template <int LL>
+__global__ void __launch_bounds__(256) k_recompose_crt_bits(DevBb t, const int32_t *planes, size_t n_planes, u32 wit_len, BPow bp, u32 K,
+                                                             fe *out, size_t ldz, size_t off) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 r = blockIdx.y;
+    if (i >= wit_len) return;
+    int32_t v[8][LL];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int32_t *pc = planes + (size_t)(r + TAU * q) * n_planes + i * LL;
+#pragma unroll
+        for (int l = 0; l < LL; l++) v[q][l] = pc[l];
+    }
+    int plane[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) plane[p] = TAU * t.slot_of_pos[p] + t.pos[r][p];
+    const size_t jj = off + i;
+    for (u32 k = 0; k < K; k++) {
+        fe x[8], A[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            fe acc = 0;
+#pragma unroll
+            for (int l = 0; l < LL; l++) {
+                int d = digit2(v[q][l], k);
+                if (d > 0) acc = fadd(acc, bp.v[l]);
+                else if (d < 0) acc = fsub(acc, bp.v[l]);
+            }
+            x[q] = acc;
+        }
+        crt8(x, A, t);
+        fe *o = out + (size_t)k * RE * ldz;
+#pragma unroll
+        for (int p = 0; p < 8; p++) o[(size_t)plane[p] * ldz + jj] = r == 0 ? A[p] : fmul(t.tw[r][p], A[p]);
+    }
+}
 __global__ void __launch_bounds__(256) k_recompose_crt(DevBb t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, BPow bp, u32 K,
                                                         int mode_bits, fe *out, size_t ldz, size_t off) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -395,6 +433,11 @@ void launch_recompose_crt(const DevBb &t, const int32_t *planes, size_t n_planes
     BPow bp;
     u64 pw = 1;
     for (int l = 0; l < 8; l++) { bp.v[l] = from_canon(pw); pw = hmul(pw, B % BB_P); }
+    if (mode_bits && (L == 2 || L == 4)) {
+        if (L == 2) hipLaunchKernelGGL(k_recompose_crt_bits<2>, dim3(cdiv(wit_len, 256), TAU), dim3(256), 0, s, t, planes, n_planes, wit_len, bp, K, out, ldz, off);
+        else hipLaunchKernelGGL(k_recompose_crt_bits<4>, dim3(cdiv(wit_len, 256), TAU), dim3(256), 0, s, t, planes, n_planes, wit_len, bp, K, out, ldz, off);
+        return;
+    }
     hipLaunchKernelGGL(k_recompose_crt, dim3(cdiv(wit_len, 256), TAU, K), dim3(256), 0, s, t, planes, n_planes, wit_len, L, bp, K, mode_bits, out,
                        ldz, off);
 }
@@ -694,7 +737,7 @@ void launch_coef_eval(const DevBb &t, const int32_t *planes, size_t n, const fe 
 }
 
 // zz_j = sum_k coef[k][j] * z_k   (Mz restructuring: G += sum_j M_j zz_j)
-__global__ void __launch_bounds__(256) k_lincomb_z(DevBb t, const fe *z, size_t ldz, u32 K, const E9PreC *coef, u32 tt, size_t n, fe *out) {
+__global__ void __launch_bounds__(256) k_lincomb_z(DevBb t, const fe *z, size_t ldz, u32 K, const E9PreC *coef, u32 tt, size_t n, fe *out, u32 per_slot) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y;
     if (i >= n) return;
@@ -707,7 +750,7 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevBb t, const fe *z, size_t 
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if ((u32)j < tt) {
-                E9 p = e9_mul(zk, e9p(coef[k * tt + j]));
+                E9 p = e9_mul(zk, e9p(coef[per_slot ? (size_t)(k * tt + j) * 8 + slot : (size_t)(k * tt + j)]));
 #pragma unroll
                 for (int c = 0; c < TAU; c++) acc[j * TAU + c] += p.c[c];
             }
@@ -719,8 +762,8 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevBb t, const fe *z, size_t 
             for (int c = 0; c < TAU; c++) out[((size_t)j * RE + TAU * slot + c) * ldz + i] = fred(acc[j * TAU + c]);
         }
 }
-void launch_lincomb_z(const DevBb &t, const fe *z, size_t ldz, u32 K, const E9PreC *coef, u32 tt, size_t n, fe *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_lincomb_z, dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef, tt, n, out);
+void launch_lincomb_z(const DevBb &t, const fe *z, size_t ldz, u32 K, const E9PreC *coef, u32 tt, size_t n, fe *out, hipStream_t s, u32 per_slot) {
+    hipLaunchKernelGGL(k_lincomb_z, dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef, tt, n, out, per_slot);
 }
 // G[row][slot] += sum_{k<K} sum_{d<9} apow[k][d] * digit_k(planes[8d+slot][row])   (rows < n_planes)
 __global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, size_t n_planes, u32 K, const E9C *apow, fe *G, size_t m) {

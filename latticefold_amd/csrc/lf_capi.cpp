@@ -74,6 +74,7 @@ struct lf_ctx {
     lfbb::BbCtx *bb = nullptr;   // BabyBearRingNTT backend (ring 1): every entry point forwards to it
     int device = 0;
     hipStream_t st_lane[2] = {nullptr, nullptr};
+    Tunables tn;          // environment switches, re-read at the start of every lf_linearize / lf_fold_step
     u32 lin_blocks = 0;   // grid bound of the linearization rounds while a fold step's commit chain runs on the other lane (0 = none)
     std::mutex mu, buf_mu, ev_mu;
     hipStream_t stream() const { return st_lane[t_lane]; }
@@ -102,6 +103,9 @@ struct lf_ctx {
     int sc_round = -1;
     size_t sc_n = 0;
     int sc_cur = 0;
+    int sf_round = -1;   // folding-sumcheck ABI state (lf_sumcheck_fold_*)
+    size_t sf_n = 0;
+    int sf_cur = 0;
     // measurement
     float phase_ms[LF_N_PHASES] = {0};
     std::vector<EvPair> ev_pool;
@@ -233,6 +237,7 @@ int lf_ctx_create_ring(lf_ctx **out, int device, int ring) {
     *out = c;
     return LF_OK;
 }
+int lf_ctx_device(const lf_ctx *c) { return c->device; }
 int lf_ctx_ring(const lf_ctx *c) { return c && c->bb ? LF_RING_BABYBEAR : LF_RING_GOLDILOCKS; }
 int lf_ring_words(int ring) { return ring == LF_RING_BABYBEAR ? 72 : (ring == LF_RING_GOLDILOCKS ? 24 : 0); }
 int lf_ring_tau(int ring) { return ring == LF_RING_BABYBEAR ? 9 : (ring == LF_RING_GOLDILOCKS ? 3 : 0); }
@@ -666,6 +671,9 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
                 if (S_idx[k] != next++) return LF_ERR_UNSUPPORTED;
         if (next != p->t || S_off[p->q] > 16) return LF_ERR_UNSUPPORTED;
     }
+    RET(lf_validate_csr(p->t, m, n, rowptr, col, val, 24, LF_P));   // before any context state is touched
+    for (size_t k = 0; k < (size_t)p->q * 24; k++)
+        if (cc[k] >= LF_P) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
     free_ccs(c);
@@ -683,15 +691,18 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
         HostRing::from_u64(LF_P - 1, mone);
         c->desc.c_unit[i] = !memcmp(c->desc.c[i], one, sizeof(one)) ? 1 : (!memcmp(c->desc.c[i], mone, sizeof(mone)) ? -1 : 0);
     }
+    // every device array is registered in the context as soon as it exists, so a failure half-way leaks nothing (free_ccs frees them)
+    auto dalloc = [](auto &vec, size_t bytes) -> void * {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, bytes) != hipSuccess) return nullptr;
+        vec.push_back((typename std::remove_reference<decltype(vec)>::type::value_type)ptr);
+        return ptr;
+    };
     for (u32 j = 0; j < p->t; j++) {
         size_t nnz = rowptr[j][m];
-        for (size_t k = 0; k < nnz; k++)
-            if (col[j][k] >= n) return LF_ERR_INVALID;
-        u32 *drp, *dci, *dcp, *dri;
-        u64 *dv, *dvT;
-        HIPCHK(hipMalloc((void **)&drp, (m + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dci, (nnz + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dv, (nnz + 1) * 24 * 8));
+        void *drp = dalloc(c->d_rowptr, (m + 1) * 4), *dci = dalloc(c->d_col, (nnz + 1) * 4), *dv = dalloc(c->d_val, (nnz + 1) * 24 * 8);
+        void *dcp = dalloc(c->d_colptr, (n + 1) * 4), *dri = dalloc(c->d_rowidx, (nnz + 1) * 4), *dvT = dalloc(c->d_valT, (nnz + 1) * 24 * 8);
+        if (!drp || !dci || !dv || !dcp || !dri || !dvT) return LF_ERR_HIP;
         HIPCHK(hipMemcpy(drp, rowptr[j], (m + 1) * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dci, col[j], nnz * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dv, val[j], nnz * 24 * 8, hipMemcpyHostToDevice));
@@ -707,14 +718,9 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
                 ri[pos] = (u32)r;
                 memcpy(&vT[(size_t)pos * 24], val[j] + (size_t)k * 24, 24 * 8);
             }
-        HIPCHK(hipMalloc((void **)&dcp, (n + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dri, (nnz + 1) * 4));
-        HIPCHK(hipMalloc((void **)&dvT, (nnz + 1) * 24 * 8));
         HIPCHK(hipMemcpy(dcp, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dri, ri.data(), nnz * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dvT, vT.data(), nnz * 24 * 8, hipMemcpyHostToDevice));
-        c->d_rowptr.push_back(drp); c->d_col.push_back(dci); c->d_val.push_back(dv);
-        c->d_colptr.push_back(dcp); c->d_rowidx.push_back(dri); c->d_valT.push_back(dvT);
     }
     c->have_ccs = true;
     return LF_OK;
@@ -748,7 +754,7 @@ static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] can
         return LF_ERR_HIP;
     }
     if (hv) { (void)hipFree(pl); return LF_ERR_NORM; }
-    lf_witness *w = new lf_witness{c, pl, c->N};
+    lf_witness *w = new lf_witness{c, pl, c->N, c->device, c->N * 24 * 4};
     *out = w;
     return LF_OK;
 }
@@ -876,8 +882,9 @@ static void planes_pool_drop(int device) {
 }
 void lf_witness_free(lf_witness *w) {
     if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    lf_planes_release(w->ctx, w->N * (size_t)lf_ring_words(lf_ctx_ring(w->ctx)) * 4, w->planes);
+    // the context may be gone already (callers close contexts before their witnesses): use only what the handle itself carries
+    (void)hipSetDevice(w->device);
+    planes_release_dev(w->device, w->plane_bytes, w->planes);
     delete w;
 }
 
@@ -1056,7 +1063,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     std::vector<Fq3> pt(P.s);
     // v, u at the sumcheck point (linearization.rs:126-139): u from the fully fixed Mz tables of the sumcheck (LF_LIN_U_EVAL=1: dot
     // products with eq(r) over the full tables), v from the witness planes
-    const bool u_eval = getenv("LF_LIN_U_EVAL") != nullptr;
+    const bool u_eval = c->tn.lin_u_eval;
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72));
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;   // contiguous: v[3 ring] u[t ring]
@@ -1302,16 +1309,16 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     bool sharded = Gw > 1;
     // Unsharded, rounds >= 4 with many pairs: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel,
     // so the separate memory-bound pass over them vanishes (rounds 4-6 at 2^20 rows: 6.25 -> 5.6 ms).
-    const bool fused = Gw == 1 && !getenv("LF_FOLD_UNFUSED");
-    const size_t fuse_min = getenv("LF_FOLD_FUSE_MIN") ? (size_t)atoll(getenv("LF_FOLD_FUSE_MIN")) : 16384;   // entries (measured: 65536 -> 16384 = -0.3 ms at 2^20 rows); tests lower it
+    const bool fused = Gw == 1 && !c->tn.fold_unfused;
+    const size_t fuse_min = c->tn.fuse_min;   // entries (measured: 65536 -> 16384 = -0.3 ms at 2^20 rows); tests lower it
     int fmode = 0;                 // producer of this round's pairs: 0 tables, 1 fused fix, 3 / 4 digit look-up table (rounds 3 / 4)
     const u64 *prevF = nullptr;
     size_t prevld = 0;
     // Rounds 3 and 4 of large unsharded instances never materialise the m/4-entry tables: their entries are one of 81 values
     // (four ternary digits) and come from a look-up table in LDS (k_fold_round modes 3 and 4); P.s >= 4 and m/4 >= lut_min entries.
-    const size_t lut_min = getenv("LF_FOLD_LUT_MIN") ? (size_t)atoll(getenv("LF_FOLD_LUT_MIN")) : ((size_t)1 << 17);
-    const size_t tab_min = getenv("LF_FOLD_TAB_MIN") ? (size_t)atoll(getenv("LF_FOLD_TAB_MIN")) : 16384;   // pairs; rounds 1-2 as table look-ups above this
-    const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !getenv("LF_FOLD_NO_LUT");
+    const size_t lut_min = c->tn.lut_min;   // default 2^17
+    const size_t tab_min = c->tn.tab_min;   // pairs; rounds 1-2 as table look-ups above this
+    const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !c->tn.fold_no_lut;
     u64 *d_lut = nullptr;
     for (u32 round = 1; round <= P.s; round++) {
         fmode = 0;
@@ -1399,7 +1406,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
     tables_ready:
         size_t ev = c->ev_begin(0);
-        if ((round == 2 || (round == 1 && getenv("LF_FOLD_TAB_R1"))) && a.pcnt >= tab_min) {
+        if ((round == 2 || (round == 1 && c->tn.fold_tab_r1)) && a.pcnt >= tab_min) {
             // round 2 (round 1 only on request: its integer kernel is faster than the gathers) as table look-ups: coefficient quadruples of h^3 - h for the 9 / 81 digit codes of a pair (host), times mu_kd (device)
             const int nd = round == 1 ? 2 : 4, ncode = round == 1 ? 9 : 81;
             std::vector<u64> poly((size_t)ncode * 12);
@@ -1428,7 +1435,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             launch_fold_round_tab(c->dcrt, (int)round, a, S[0].planes, S[1].planes, N, K, d_mu, d_poly, d_tp, partial, od, c->stream());
         } else if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->stream());
-        else if (fmode == 3 && c->dcrt.nu2p40 && !getenv("LF_FOLD_NO_MUTAB")) {
+        else if (fmode == 3 && c->dcrt.nu2p40 && !c->tn.fold_no_mutab) {
             u64 *mutab;
             RET(c->tbuf("fold_mutab", (size_t)3 * K2 * 3 * 81 * 4, &mutab));
             launch_fold_round_lut_mu(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, mutab, K, d_mu, partial, od, c->stream());
@@ -1474,7 +1481,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // theta = f-hat_{k,d}(r_o): the f-hat tables of the sumcheck, fixed at r_1..r_{s-1}, have two entries left, so one more fix gives
     // the evaluations evaluate_mles would recompute from the witness (exact arithmetic: the same words).  Instances with fewer than
     // 4 variables never materialise the tables, and LF_THETA_EVAL=1 keeps the stand-alone evaluation (masked +-eq sums).
-    if (P.s >= 4 && curF && ldF == 2 && !getenv("LF_THETA_EVAL")) launch_fix_final(c->dcrt, curF, K2 * 3 * 8, f3c(pt[P.s - 1]), d_theta, c->stream());
+    if (P.s >= 4 && curF && ldF == 2 && !c->tn.theta_eval) launch_fix_final(c->dcrt, curF, K2 * 3 * 8, f3c(pt[P.s - 1]), d_theta, c->stream());
     else
         for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * 72, c->stream());
     HIPCHK(hipMemcpyAsync(hp, d_theta, (size_t)K2 * 72 * 8, hipMemcpyDeviceToHost, c->stream()));
@@ -1518,7 +1525,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     LF_TRACE(c, "fold_witness");
     HIPCHK(hipStreamSynchronize(c->stream()));
-    *w_out = new lf_witness{c, npl, N};
+    *w_out = new lf_witness{c, npl, N, c->device, N * 24 * 4};
     TL_MARK(" rho + fold_witness");
     c->ev_end(ph);
 
@@ -1572,6 +1579,7 @@ int lf_linearize(lf_ctx *c, lf_transcript *t, const uint64_t *cccs, const lf_wit
     if (!c->have_ccs) return LF_ERR_STATE;
     if (wit->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
+    c->tn = Tunables::read((size_t)1 << 17);
     c->ev_reset();
     c->host_tr_ms = 0;
     int rc = linearize_impl(c, t->t, cccs, wit, lcccs_out, lin_proof_out, nullptr);
@@ -1592,6 +1600,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     HIPCHK(hipSetDevice(c->device));
     std::vector<Fq3> rL;
     if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;  // evaluation points are always diagonal challenges
+    c->tn = Tunables::read((size_t)1 << 17);
     Timeline tl;
     t_tl = &tl;
     c->ev_reset();
@@ -1611,7 +1620,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     std::shared_future<int> lin_done = lin_done_p.get_future().share();
     // Large instances: lane 1 (two commits back to back) is the critical path and lane 0 has several ms of slack, so the
     // linearization rounds run on 16 workgroups per slot and leave the CUs to the commit kernels (C4: 44.6 -> 43.7 ms/step).
-    c->lin_blocks = getenv("LF_LIN_BLOCKS") ? (u32)atoi(getenv("LF_LIN_BLOCKS")) : (c->N >= ((size_t)1 << 19) ? 16u : 0u);
+    c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : (c->N >= ((size_t)1 << 19) ? 16u : 0u);
     std::future<int> flane1 = std::async(std::launch::async, [&]() -> int {
         t_lane = 1;
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
@@ -1653,6 +1662,76 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     tl.dump();
     t_tl = nullptr;
     c->ev_end(tot);
+    c->ev_collect();
+    return rc;
+}
+
+// LFDecompositionProver::prove (nifs/decomposition.rs:33-88) as its own entry point: the reference exposes the three sub-provers as
+// public traits; this is the middle one.  The K decomposed witnesses stay virtual (bit-planes of `wit`).
+int lf_decomposition_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs, const lf_witness *wit, uint64_t *lcccs_s_out, uint64_t *dec_proof_out) {
+    if (!c || !t || !lcccs || !wit || !dec_proof_out || wit->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return t->bb ? c->bb->decomposition_prove(*t->bb, lcccs, wit, lcccs_s_out, dec_proof_out) : LF_ERR_INVALID;
+    if (t->bb) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    const lf_params &P = c->P;
+    if (c->kappa != P.kappa || c->nA_total != c->N || wit->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<Fq3> r;
+    if (!lcccs_point(P, lcccs, r)) return LF_ERR_UNSUPPORTED;
+    c->tn = Tunables::read((size_t)1 << 17);
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    u64 *yd = nullptr;
+    size_t ev = 0;
+    SideState S;
+    RET(decompose_commit_enqueue(c, wit, &yd, &ev));
+    RET(decompose_commit_finish(c, lcccs + ((size_t)P.s + 3) * 24, yd, ev, dec_proof_out));
+    RET(decompose_evals(c, lcccs, r, wit, "L", nullptr, S, dec_proof_out));
+    c->host_tr_ms += absorb_decomposition(P, t->t, lcccs, dec_proof_out, S);
+    if (lcccs_s_out) memcpy(lcccs_s_out, S.lcccs.data(), S.lcccs.size() * 8);
+    c->ev_collect();
+    return LF_OK;
+}
+
+// LFFoldingProver::prove (nifs/folding.rs:42-130) as its own entry point.  lcccs_s = the 2K decomposed LCCCS (K of the accumulator's
+// decomposition, then K of the linearized instance's), w_left / w_right = the witnesses whose base-b parts they commit to.
+int lf_folding_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs_s, const lf_witness *w_left, const lf_witness *w_right,
+                     uint64_t *lcccs_out, lf_witness **w_out, uint64_t *fold_proof_out) {
+    if (!c || !t || !lcccs_s || !w_left || !w_right || !lcccs_out || !w_out || !fold_proof_out) return LF_ERR_INVALID;
+    if (w_left->ctx != c || w_right->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return t->bb ? c->bb->folding_prove(*t->bb, lcccs_s, w_left, w_right, lcccs_out, w_out, fold_proof_out) : LF_ERR_INVALID;
+    if (t->bb) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    const lf_params &P = c->P;
+    if (w_left->N != c->N || w_right->N != c->N) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    c->tn = Tunables::read((size_t)1 << 17);
+    c->ev_reset();
+    c->host_tr_ms = 0;
+    const size_t ll = lf_lcccs_len(&P);
+    const u32 K = P.K, hl = P.l + 1;
+    SideState S[2];
+    for (int sd = 0; sd < 2; sd++) {
+        const u64 *base = lcccs_s + (size_t)sd * K * ll * 24;
+        std::vector<Fq3> r;
+        if (!lcccs_point(P, base, r)) return LF_ERR_UNSUPPORTED;
+        for (u32 k = 1; k < K; k++)   // the K parts of one side share r (folding/utils.rs:232-250)
+            if (memcmp(base, base + (size_t)k * ll * 24, (size_t)P.s * 24 * 8) != 0) return LF_ERR_INVALID;
+        const lf_witness *w = sd ? w_right : w_left;
+        u64 *z, *eq_r;
+        RET(c->tbuf(sd ? "z_R" : "z_L", (size_t)K * 24 * c->n, &z));
+        RET(c->tbuf(sd ? "eq_r_R" : "eq_r_L", 3 * c->m, &eq_r));
+        std::vector<u64> heads((size_t)K * hl * 24);
+        for (u32 k = 0; k < K; k++)
+            memcpy(&heads[(size_t)k * hl * 24], base + ((size_t)k * ll + P.s + 3 + P.kappa + P.t) * 24, (size_t)hl * 24 * 8);
+        RET(build_z(c, w->planes, K, 1, heads.data(), z));
+        RET(build_eq_dev(c, r.data(), P.s, eq_r));
+        S[sd].planes = w->planes; S[sd].z = z; S[sd].eq_r = eq_r;
+        S[sd].lcccs.assign(base, base + (size_t)K * ll * 24);
+    }
+    int rc = fold_impl(c, t->t, S, lcccs_out, w_out, fold_proof_out);
     c->ev_collect();
     return rc;
 }
@@ -1711,6 +1790,132 @@ int lf_sumcheck_lin_end(lf_ctx *c) {
     return LF_OK;
 }
 
+// ---- the folding sumcheck through the ABI: MLSumcheck::prove_as_subprotocol (utils/sumcheck.rs:53-80) with the comb
+// function of nifs/folding/utils.rs:273-325, split at the transcript.  `tables` is the reference's mle list of
+// create_sumcheck_polynomial (folding/utils.rs:200-259): [eq(r_L), G_L, eq(r_R), G_R, eq(beta), f-hat_{0,0} .. f-hat_{2K-1,tau-1}],
+// P = 5 + 2K*tau tables of m ring elements; the three eq tables must be slot-constant (they are diagonal embeddings in the reference).
+int lf_sumcheck_fold_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *mu) {
+    if (!c || !tables || !mu) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->sumcheck_fold_begin(tables, mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    const size_t m = c->m;
+    const u32 K2 = 2 * P.K;
+    static const int eq_idx[3] = {0, 2, 4};
+    for (int e = 0; e < 3; e++) {   // slot-constant check of the eq tables
+        const u64 *tb = tables + (size_t)eq_idx[e] * m * 24;
+        for (size_t i = 0; i < m; i++)
+            for (int sl = 1; sl < 8; sl++)
+                if (memcmp(tb + i * 24, tb + i * 24 + 3 * sl, 24) != 0) return LF_ERR_UNSUPPORTED;
+    }
+    u64 *T, *F, *tmp;
+    RET(c->tbuf("sf_T0", 57 * m, &T));
+    RET(c->tbuf("sf_F0", (size_t)K2 * 3 * 24 * m, &F));
+    RET(c->tbuf("sf_tmp", 24 * m, &tmp));
+    for (int e = 0; e < 3; e++) {   // eqL, eqR, eqB -> fq3 tables (slot 0 of the ring table)
+        RET(up_ring(c, tables + (size_t)eq_idx[e] * m * 24, m, tmp));
+        HIPCHK(hipMemcpyAsync(T + (size_t)3 * e * m, tmp, 3 * m * 8, hipMemcpyDeviceToDevice, c->stream()));
+    }
+    RET(up_ring(c, tables + (size_t)1 * m * 24, m, T + 9 * m));
+    RET(up_ring(c, tables + (size_t)3 * m * 24, m, T + 33 * m));
+    for (u32 i = 0; i < K2 * 3; i++) RET(up_ring(c, tables + (size_t)(5 + i) * m * 24, m, F + (size_t)i * 24 * m));
+    std::vector<Fq3Const> mu_pow((size_t)K2 * 3);
+    for (u32 i = 0; i < K2; i++) {
+        Fq3 mi = fq3_make(mu[3 * i], mu[3 * i + 1], mu[3 * i + 2]), pm = mi;
+        for (u32 d = 0; d < 3; d++) { mu_pow[(size_t)i * 3 + d] = f3c(pm); pm = c->ring.mul3(pm, mi); }
+    }
+    Fq3Const *d_mu;
+    RET(upload_consts(c, "sf_mu", mu_pow, &d_mu));
+    c->sf_round = 0; c->sf_n = m; c->sf_cur = 0;
+    return LF_OK;
+}
+int lf_sumcheck_fold_round(lf_ctx *c, const uint64_t *r_prev, uint64_t *evals_out) {
+    if (!c || !evals_out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->sumcheck_fold_round(r_prev, evals_out);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->sf_round < 0 || c->sf_round >= (int)c->P.s) return LF_ERR_STATE;   // "Prover is not active" (sumcheck/prover.rs:63)
+    if ((c->sf_round == 0) != (r_prev == nullptr)) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const lf_params &P = c->P;
+    const size_t m = c->m;
+    const u32 K2 = 2 * P.K;
+    u64 *T[2], *F[2], *partial, *od;
+    Fq3Const *d_mu;
+    RET(c->tbuf("sf_T0", 57 * m, &T[0]));
+    RET(c->tbuf("sf_T1", 57 * (m / 2 ? m / 2 : 1), &T[1]));
+    RET(c->tbuf("sf_F0", (size_t)K2 * 3 * 24 * m, &F[0]));
+    RET(c->tbuf("sf_F1", (size_t)K2 * 3 * 24 * (m / 2 ? m / 2 : 1), &F[1]));
+    RET(c->tbuf("sf_mu", (size_t)K2 * 3 + 8, &d_mu));
+    RET(c->tbuf("round_partial", round_partial_words(), &partial));
+    RET(c->tbuf("round_out", 5 * 24, &od));
+    if (r_prev) {
+        Fq3Const r; r.c[0] = r_prev[0]; r.c[1] = r_prev[1]; r.c[2] = r_prev[2];
+        int src = c->sf_cur, dst = src ^ 1;
+        launch_fix_many(c->dcrt, T[src], c->sf_n, T[dst], c->sf_n / 2, c->sf_n, 19, r, c->stream());
+        launch_fix_many(c->dcrt, F[src], c->sf_n, F[dst], c->sf_n / 2, c->sf_n, K2 * 3 * 8, r, c->stream());
+        c->sf_cur = dst; c->sf_n /= 2;
+    }
+    const size_t n = c->sf_n;
+    const u64 *t5 = T[c->sf_cur];
+    FoldRoundArgs a;
+    a.eqL = t5; a.eqR = t5 + 3 * n; a.eqB = t5 + 6 * n; a.G1 = t5 + 9 * n; a.G2 = t5 + 33 * n;
+    a.ld = n; a.n = n; a.p0 = 0; a.pcnt = n / 2; a.pF0 = 0;
+    launch_fold_round(c->dcrt, a, F[c->sf_cur], n, P.K, d_mu, partial, od, c->stream());
+    c->sf_round++;
+    return down_small(c, od, (size_t)(2 * P.b + 1) * 24, evals_out);
+}
+int lf_sumcheck_fold_end(lf_ctx *c) {
+    if (!c) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->sumcheck_fold_end();
+    std::lock_guard<std::mutex> g(c->mu);
+    c->sf_round = -1;
+    return LF_OK;
+}
+
+// compute_f_0 (nifs/folding.rs:258-268): out[j] = sum_i coef_i (.) tables_i[j] with ring-element coefficients (8 distinct slots)
+int lf_lincomb(lf_ctx *c, const uint64_t *coef, const uint64_t *tables, size_t n_terms, size_t len, uint64_t *out) {
+    if (!c || !coef || !tables || !out || !n_terms || !len) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->lincomb(coef, tables, n_terms, len, out);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    u64 *X, *o;
+    RET(c->tbuf("io_a", n_terms * len * 24, &X));
+    RET(c->tbuf("io_b", len * 24, &o));
+    for (size_t i = 0; i < n_terms; i++) RET(up_ring(c, tables + i * len * 24, len, X + i * 24 * len));
+    std::vector<Fq3Const> cf(n_terms * 8);
+    for (size_t i = 0; i < n_terms; i++)
+        for (int sl = 0; sl < 8; sl++)
+            for (int q = 0; q < 3; q++) cf[i * 8 + sl].c[q] = coef[i * 24 + 3 * sl + q];
+    Fq3Const *d_cf;
+    RET(upload_consts(c, "lc_coef", cf, &d_cf));
+    launch_lincomb_z(c->dcrt, X, len, (u32)n_terms, d_cf, 1, len, o, c->stream(), 1);
+    return down_ring(c, o, len, out);
+}
+// calculate_challenged_mz_mle (nifs/folding.rs:208-226) and the f-hat half of prepare_g1_and_3_k_mles_list (folding/utils.rs:524-546):
+// out[x] = sum_{i<groups} sum_{j<per_group} c_i^{j+1} T_{i,j}[x] (the reference's Horner loop `mle += M; mle *= c_i` over j reversed)
+int lf_horner_combine(lf_ctx *c, const uint64_t *tables, size_t groups, size_t per_group, size_t len, const uint64_t *challenges, uint64_t *out) {
+    if (!c || !tables || !challenges || !out || !groups || !per_group || !len) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->horner_combine(tables, groups, per_group, len, challenges, out);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nt = groups * per_group;
+    u64 *X, *o;
+    RET(c->tbuf("io_a", nt * len * 24, &X));
+    RET(c->tbuf("io_b", len * 24, &o));
+    for (size_t i = 0; i < nt; i++) RET(up_ring(c, tables + i * len * 24, len, X + i * 24 * len));
+    std::vector<Fq3Const> cf(nt);
+    for (size_t i = 0; i < groups; i++) {
+        Fq3 ci = fq3_make(challenges[3 * i], challenges[3 * i + 1], challenges[3 * i + 2]), pw = ci;
+        for (size_t j = 0; j < per_group; j++) { cf[i * per_group + j] = f3c(pw); pw = c->ring.mul3(pw, ci); }
+    }
+    Fq3Const *d_cf;
+    RET(upload_consts(c, "lc_coef", cf, &d_cf));
+    launch_lincomb_z(c->dcrt, X, len, (u32)nt, d_cf, 1, len, o, c->stream(), 0);
+    return down_ring(c, o, len, out);
+}
+
 int lf_last_phase_ms(lf_ctx *c, float *out) {
     if (!c || !out) return LF_ERR_INVALID;
     if (c->bb) return c->bb->last_phase_ms(out);
@@ -1731,6 +1936,7 @@ int lf_last_kernel_stats(lf_ctx *c, float *fold_ms, int *fold_n, float *aj_ms, i
 namespace {
 struct GoldV {
     static constexpr int RE = 24, TAU = 3;
+    static u64 modulus() { return LF_P; }
     typedef Fq3 Ext;
     typedef Transcript Tr;
     HostRing ring;

@@ -86,8 +86,9 @@ void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u6
                       u64 *partial, u64 *out, hipStream_t s);
 size_t coef_eval_partial_words(u32 K);
 // zz_j = sum_k coef[k][j] * z_k  (fq3 scalars; z tables [K][24][ldz]) -> out [t][24][ldz]
+// per_slot != 0: coef_dev holds K*tt*8 constants, one per slot (ring-element coefficients, folding.rs:258-268)
 void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev /*K*tt*/, u32 tt, size_t n,
-                      u64 *out, hipStream_t s);
+                      u64 *out, hipStream_t s, u32 per_slot = 0);
 // G[row][slot] += sum_{k<K} sum_{d<3} apow[k][d] * digit_k(planes[8d+slot][row])   (rows < n_planes)
 void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow_dev /*K*3*/,
                           u64 *G, size_t m, hipStream_t s);

@@ -409,21 +409,31 @@ __global__ void __launch_bounds__(256) k_recompose_crt(DevCrt t, const int32_t *
 // bit-plane mode with L = 4 and B^3 < 2^61: the recomposed coefficient sum_l digit_l B^l is an exact signed 64-bit integer (one
 // conversion to a canonical residue instead of four conditional modular additions), the four digits' plane entries come in one 16-byte load
 struct BInt4 { long long v[4]; };
-__global__ void __launch_bounds__(256) k_recompose_crt_b4(DevCrt t, const int32_t *planes, size_t n_planes, u32 wit_len, BInt4 bi, u64 *out,
-                                                           size_t ldz, size_t off) {
+// thread = (element i, residue class u of the coefficient index), as in k_bitplane_crt: the 8 x 4 plane entries it needs are loaded
+// ONCE and all K bit-planes are produced from registers (the planes are read once per launch instead of K times: at 2^20 rows
+// 2.40 -> 0.92 GB of traffic per call)
+__global__ void __launch_bounds__(256) k_recompose_crt_b4(DevCrt t, const int32_t *planes, size_t n_planes, u32 wit_len, BInt4 bi, u32 K,
+                                                           u64 *out, size_t ldz, size_t off) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    u32 k = blockIdx.y;
+    const u32 u = blockIdx.y;
     if (i >= wit_len) return;
-    u64 *o = out + (size_t)k * 24 * ldz;
     const size_t jj = off + i;
-    // one residue class u of the coefficient index at a time (a(X) = sum_u X^u A_u(X^3), see crt_store): 8 loads in flight, not 24
+    int4 w[8];
 #pragma unroll
-    for (int u = 0; u < 3; u++) {
+    for (int v8 = 0; v8 < 8; v8++) w[v8] = *(const int4 *)(planes + (size_t)(3 * v8 + u) * n_planes + 4 * i);
+    int plane[8];
+    u64 tw[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        int s3 = 3 * t.slot_of_pos[p];
+        plane[p] = u == 0 ? s3 : (u == 1 ? s3 + t.pos1[p] : s3 + t.pos2[p]);
+        tw[p] = u == 1 ? t.tw1[p] : t.tw2[p];
+    }
+    for (u32 k = 0; k < K; k++) {
         u64 x[8], A[8];
 #pragma unroll
         for (int v8 = 0; v8 < 8; v8++) {
-            int4 w = *(const int4 *)(planes + (size_t)(3 * v8 + u) * n_planes + 4 * i);
-            const int32_t v[4] = {w.x, w.y, w.z, w.w};
+            const int32_t v[4] = {w[v8].x, w[v8].y, w[v8].z, w[v8].w};
             long long sacc = 0;
 #pragma unroll
             for (int l = 0; l < 4; l++) {
@@ -433,13 +443,9 @@ __global__ void __launch_bounds__(256) k_recompose_crt_b4(DevCrt t, const int32_
             x[v8] = sacc < 0 ? LF_P - (u64)(-sacc) : (u64)sacc;
         }
         crt8(x, A, t);
+        u64 *o = out + (size_t)k * 24 * ldz;
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
-            int s3 = 3 * t.slot_of_pos[p];
-            if (u == 0) o[(size_t)s3 * ldz + jj] = A[p];
-            else if (u == 1) o[(size_t)(s3 + t.pos1[p]) * ldz + jj] = fq_mul(t.tw1[p], A[p]);
-            else o[(size_t)(s3 + t.pos2[p]) * ldz + jj] = fq_mul(t.tw2[p], A[p]);
-        }
+        for (int p = 0; p < 8; p++) o[(size_t)plane[p] * ldz + jj] = u == 0 ? A[p] : fq_mul(tw[p], A[p]);
     }
 }
 void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K, int mode_bits,
@@ -448,7 +454,7 @@ void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_plane
         BInt4 bi;
         bi.v[0] = 1;
         for (int l = 1; l < 4; l++) bi.v[l] = bi.v[l - 1] * (long long)B;
-        hipLaunchKernelGGL(k_recompose_crt_b4, dim3(cdiv(wit_len, 256), K), dim3(256), 0, s, t, planes, n_planes, wit_len, bi, out, ldz, off);
+        hipLaunchKernelGGL(k_recompose_crt_b4, dim3(cdiv(wit_len, 256), 3), dim3(256), 0, s, t, planes, n_planes, wit_len, bi, K, out, ldz, off);
         return;
     }
     BPow bp;
@@ -972,7 +978,7 @@ void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u6
 }
 
 template <bool NU, int TT>
-__global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef, size_t n, u64 *out) {
+__global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef, size_t n, u64 *out, u32 per_slot) {
     // TT output tables (compile time: only the accumulators that are used occupy registers)
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y;
@@ -985,7 +991,7 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_
         Fq3 x = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i);
 #pragma unroll
         for (int j = 0; j < TT; j++) {
-            Fq3Const cc = coef[k * TT + j];
+            Fq3Const cc = coef[per_slot ? (size_t)(k * TT + j) * 8 + slot : (size_t)(k * TT + j)];   // per_slot: ring-element coefficients
             Fq3 cv = fq3_make(cc.c[0], cc.c[1], cc.c[2]);
             if (NU) lh5_mac(acc[j], x, cv);
             else accg[j] = fq3_add(accg[j], M3<NU>(x, cv, t.nu));
@@ -994,11 +1000,11 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_
 #pragma unroll
     for (int j = 0; j < TT; j++) st3(out + (size_t)j * 24 * ldz, ldz, slot, i, NU ? lh5_finish(acc[j]) : accg[j]);
 }
-void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev, u32 tt, size_t n, u64 *out, hipStream_t s) {
+void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev, u32 tt, size_t n, u64 *out, hipStream_t s, u32 per_slot) {
 #define LF_LZ(N)                                                                                                                              \
     do {                                                                                                                                      \
-        if (t.nu2p40) hipLaunchKernelGGL((k_lincomb_z<true, N>), dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef_dev, n, out);    \
-        else hipLaunchKernelGGL((k_lincomb_z<false, N>), dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef_dev, n, out);            \
+        if (t.nu2p40) hipLaunchKernelGGL((k_lincomb_z<true, N>), dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef_dev, n, out, per_slot);    \
+        else hipLaunchKernelGGL((k_lincomb_z<false, N>), dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef_dev, n, out, per_slot);            \
     } while (0)
     switch (tt) {
         case 1: LF_LZ(1); break;

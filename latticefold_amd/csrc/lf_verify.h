@@ -160,7 +160,37 @@ struct Verifier {
     }
 
     // returns LF_OK / LF_ERR_REJECT; lcccs_out = folded instance
+    // Input validation (untrusted proof bytes): parameter envelope, multiset structure, canonical residues everywhere, diagonal
+    // evaluation point.  The arithmetic and the equality checks below assume canonical words; arkworks' deserializer rejects
+    // non-canonical field elements the same way (Validate::Yes).
+    int validate(const u64 *acc, const u64 *cm_i, const u64 *proof) const {
+        if (P.s == 0 || P.s > 40 || P.K == 0 || P.K > 32 || P.q == 0 || P.q > 8 || P.t == 0 || P.t > 16 || P.d == 0 || P.d > 8 ||
+            P.b < 2 || P.b > 64 || P.kappa == 0 || P.kappa > 4096 || P.l > 4096 || P.L == 0 || P.L > 64)
+            return LF_ERR_UNSUPPORTED;
+        if (S_off[0] != 0) return LF_ERR_INVALID;
+        for (u32 i = 0; i < P.q; i++)
+            if (S_off[i + 1] < S_off[i] || S_off[i + 1] - S_off[i] > P.d) return LF_ERR_INVALID;
+        if (S_off[P.q] > 64) return LF_ERR_INVALID;
+        for (u32 k = 0; k < S_off[P.q]; k++)
+            if (S_idx[k] >= P.t) return LF_ERR_INVALID;
+        const u64 p = V::modulus();
+        auto canon = [p](const u64 *w, size_t n) {
+            for (size_t i = 0; i < n; i++)
+                if (w[i] >= p) return false;
+            return true;
+        };
+        const size_t proof_len = lin_len() + 2 * dec_len() + (size_t)P.s * (2 * P.b + 1) + 2 * (size_t)P.K * (TAU + P.t);
+        if (!canon(cc, (size_t)P.q * RE) || !canon(acc, lcccs_len() * RE) || !canon(cm_i, cccs_len() * RE) || !canon(proof, proof_len * RE))
+            return LF_ERR_INVALID;
+        for (u32 i = 0; i < P.s; i++)   // acc.r: diagonal embeddings of F_{p^tau} challenges (eq_eval below reads slot 0 only)
+            for (int sl = 1; sl < 8; sl++)
+                if (memcmp(acc + (size_t)i * RE, acc + (size_t)i * RE + (size_t)TAU * sl, TAU * sizeof(u64)) != 0) return LF_ERR_UNSUPPORTED;
+        return LF_OK;
+    }
+
     int verify(Tr &tr, const u64 *acc, const u64 *cm_i, const u64 *proof, u64 *lcccs_out) {
+        int vrc = validate(acc, cm_i, proof);
+        if (vrc != LF_OK) return vrc;
         u32 K = P.K, K2 = 2 * K;
         size_t ll = lcccs_len();
         tr.absorb_label("acc");   // absorb_public_input, nifs.rs:175-197

@@ -146,6 +146,18 @@ int lfo_fold_step(const lfo_params *, const lfo_ccs *, const u64 *A, lfo_transcr
 int lfo_verify(const lfo_params *, const lfo_ccs *, lfo_transcript *, const u64 *acc,
                const u64 *cm_i, const u64 *proof, u64 *lcccs_out);
 
+/* LFDecompositionProver::prove (nifs/decomposition.rs:33-88) alone: dec_proof_out = u_s[K][t] | v_s[K][tau] | x_s[K][l+1] | y_s[K][kappa],
+ * lcccs_s_out (optional) = the K decomposed LCCCS flat */
+int lfo_decomposition_prove(const lfo_params *, const lfo_ccs *, const u64 *A, lfo_transcript *, const u64 *lcccs,
+                            const u64 *f_coeff, u64 *dec_proof_out, u64 *lcccs_s_out);
+/* building blocks of LFFoldingProver::prove on their own (ABI parity tests): the folding sumcheck (utils/sumcheck.rs:53-80 with the
+ * comb of folding/utils.rs:273-325) on a caller-supplied mle list, the Horner combine (folding.rs:208-226) and compute_f_0 (258-268) */
+int lfo_sumcheck_fold(const lfo_params *, lfo_transcript *, const u64 *tables, const u64 *mu, u64 *msgs_out, u64 *point_out);
+void lfo_horner_combine(const u64 *tables, u32 groups, u32 per_group, size_t len, const u64 *ch, u64 *out);
+void lfo_lincomb(const u64 *coef, const u64 *tables, u32 n_terms, size_t len, u64 *out);
+/* workload.py::splitmix_fq in C (synthetic benchmark inputs) */
+void lfo_splitmix_fill(u64 seed, u64 start, size_t count, u64 *out);
+
 int lfo_num_threads(void);
 void lfo_set_num_threads(int n);
 

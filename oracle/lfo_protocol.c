@@ -461,6 +461,39 @@ static void dec_free(const lfo_params *p, dec_out *o) {
     free(o->lcccs);
 }
 
+/* LFDecompositionProver::prove (nifs/decomposition.rs:33-88) on its own: decomposition proof of one (LCCCS, witness) pair and
+ * the K decomposed LCCCS (flat, K*lcccs_len ring elements).  Used by the component-level parity tests at BASELINE sizes. */
+int lfo_decomposition_prove(const lfo_params *p, const lfo_ccs *ccs, const u64 *A, lfo_transcript *tr, const u64 *lcccs,
+                            const u64 *f_coeff, u64 *dec_proof_out, u64 *lcccs_s_out) {
+    if (!ccs_shape_ok(p, ccs)) return -1;
+    dec_out o;
+    memset(&o, 0, sizeof(o));
+    int rc = decompose_prove(p, ccs, A, tr, lcccs, f_coeff, &o, dec_proof_out);
+    if (rc == 0 && lcccs_s_out) memcpy(lcccs_s_out, o.lcccs, (size_t)p->K * lfo_lcccs_len(p) * RE * sizeof(u64));
+    dec_free(p, &o);
+    return rc;
+}
+
+/* the indexable SplitMix64 stream of latticefold_amd/workload.py::splitmix_fq (synthetic Ajtai matrices / witnesses of the
+ * benchmarks): word i = splitmix64(seed + (start+i+1)*G) folded into [0,p).  Here so that the oracle side of the BASELINE-size
+ * tests does not spend minutes in numpy. */
+void lfo_splitmix_fill(u64 seed, u64 start, size_t count, u64 *out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (size_t i = 0; i < count; i++) {
+        u64 z = seed + (start + (u64)i + 1) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+#ifdef LFO_RING_BABYBEAR
+        out[i] = (z >> 32) % LFO_P;
+#else
+        out[i] = z >= LFO_P ? z - LFO_P : z;
+#endif
+    }
+}
+
 /* ---------------------------------------------------------------------------------------- */
 /* folding comb: nifs/folding/utils.rs:273-325 (zero short-cuts dropped: value-preserving)  */
 typedef struct { const lfo_params *p; const u64 *mu; } fold_ctx;
@@ -503,6 +536,48 @@ static void horner_add(u64 *dst, u64 *const *tabs, u32 cnt, const u64 *ch, size_
         }
         rq_add(dst + i * RE, dst + i * RE, acc);
     }
+}
+
+/* ---- stand-alone restatements of the folding prover's building blocks (ABI parity tests of lf_sumcheck_fold_*, lf_horner_combine,
+ * lf_lincomb) ---- */
+/* MLSumcheck::prove_as_subprotocol (utils/sumcheck.rs:53-80) on the folding polynomial (folding/utils.rs:200-325): tables = the mle list
+ * [eq_L, G_L, eq_R, G_R, eq_beta, f-hat ...] (P = 5 + 2K*tau tables of m = 2^s ring elements, copied: the caller's data stay intact),
+ * mu = 2K ring elements.  msgs_out: s*(2b+1) ring elements, point_out: s ring elements. */
+int lfo_sumcheck_fold(const lfo_params *p, lfo_transcript *tr, const u64 *tables, const u64 *mu, u64 *msgs_out, u64 *point_out) {
+    size_t m = (size_t)1 << p->s;
+    u32 P = 5 + 2 * p->K * TAU;
+    u64 **tb = (u64 **)malloc(sizeof(u64 *) * P);
+    for (u32 k = 0; k < P; k++) {
+        tb[k] = ralloc(m);
+        memcpy(tb[k], tables + (size_t)k * m * RE, m * RE * sizeof(u64));
+    }
+    fold_ctx fc;
+    fc.p = p;
+    fc.mu = mu;
+    sumcheck_prove(tr, tb, P, p->s, 2 * p->b, comb_fold, &fc, msgs_out, point_out);
+    for (u32 k = 0; k < P; k++) free(tb[k]);
+    free(tb);
+    return 0;
+}
+/* calculate_challenged_mz_mle (folding.rs:208-226): out = sum_i horner(tables_i[0..per_group), ch_i); ch = groups ring elements */
+void lfo_horner_combine(const u64 *tables, u32 groups, u32 per_group, size_t len, const u64 *ch, u64 *out) {
+    memset(out, 0, len * RE * sizeof(u64));
+    u64 **tabs = (u64 **)malloc(sizeof(u64 *) * per_group);
+    for (u32 i = 0; i < groups; i++) {
+        for (u32 j = 0; j < per_group; j++) tabs[j] = (u64 *)(tables + ((size_t)i * per_group + j) * len * RE);
+        horner_add(out, tabs, per_group, ch + (size_t)i * RE, len);
+    }
+    free(tabs);
+}
+/* compute_f_0 (folding.rs:258-268): out[j] = sum_i rho_i * f_i[j] */
+void lfo_lincomb(const u64 *coef, const u64 *tables, u32 n_terms, size_t len, u64 *out) {
+    memset(out, 0, len * RE * sizeof(u64));
+    for (u32 i = 0; i < n_terms; i++)
+        for (size_t j = 0; j < len; j++) {
+            u64 t[RE];
+            rq_mul(t, coef + (size_t)i * RE, tables + ((size_t)i * len + j) * RE);
+            rq_add(out + j * RE, out + j * RE, t);
+        }
 }
 
 int lfo_fold_step(const lfo_params *p, const lfo_ccs *ccs, const u64 *A, lfo_transcript *tr,

@@ -107,6 +107,14 @@ def lib():
         L.lfo_fold_step.argtypes = [C.POINTER(Params), C.POINTER(Ccs), u64p, C.c_void_p, u64p, u64p, u64p, u64p,
                                     u64p, u64p, u64p]
         L.lfo_verify.argtypes = [C.POINTER(Params), C.POINTER(Ccs), C.c_void_p, u64p, u64p, u64p, u64p]
+        L.lfo_decomposition_prove.argtypes = [C.POINTER(Params), C.POINTER(Ccs), u64p, C.c_void_p, u64p, u64p, u64p, u64p]
+        L.lfo_sumcheck_fold.argtypes = [C.POINTER(Params), C.c_void_p, u64p, u64p, u64p, u64p]
+        L.lfo_horner_combine.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_size_t, u64p, u64p]
+        L.lfo_horner_combine.restype = None
+        L.lfo_lincomb.argtypes = [u64p, u64p, C.c_uint32, C.c_size_t, u64p]
+        L.lfo_lincomb.restype = None
+        L.lfo_splitmix_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, u64p]
+        L.lfo_splitmix_fill.restype = None
         _lib = L
     return _lib
 
@@ -264,6 +272,36 @@ class Instance:
         assert rc == 0, rc
         return lc.reshape(-1, RE), f0.reshape(-1, RE), pr.reshape(-1, RE)
 
+    def decomposition_prove(self, tr, A, lcccs, f_coeff):
+        """LFDecompositionProver::prove alone -> (K decomposed LCCCS flat, decomposition proof flat)"""
+        A = np.ascontiguousarray(A, dtype=np.uint64).reshape(-1)
+        lcccs = np.ascontiguousarray(lcccs, dtype=np.uint64).reshape(-1)
+        f = np.ascontiguousarray(f_coeff, dtype=np.uint64).reshape(-1)
+        wl = self.wl
+        pr = np.zeros(wl.K * (wl.t + TAU + wl.l + 1 + wl.kappa) * RE, dtype=np.uint64)
+        lcs = np.zeros(wl.K * self.lcccs_len * RE, dtype=np.uint64)
+        rc = lib().lfo_decomposition_prove(C.byref(self.params), C.byref(self.ccs), _p64(A), tr.h, _p64(lcccs), _p64(f), _p64(pr), _p64(lcs))
+        assert rc == 0, rc
+        return lcs.reshape(-1, RE), pr.reshape(-1, RE)
+
+    def sumcheck_fold(self, tr, tables, mu_ring):
+        """the folding sumcheck on a caller-supplied mle list -> (msgs [s*(2b+1)], point [s]) as ring elements"""
+        t = np.ascontiguousarray(tables, dtype=np.uint64).reshape(-1)
+        mu = np.ascontiguousarray(mu_ring, dtype=np.uint64).reshape(-1)
+        wl = self.wl
+        msgs = np.zeros(wl.s * (2 * wl.b + 1) * RE, dtype=np.uint64)
+        pt = np.zeros(wl.s * RE, dtype=np.uint64)
+        rc = lib().lfo_sumcheck_fold(C.byref(self.params), tr.h, _p64(t), _p64(mu), _p64(msgs), _p64(pt))
+        assert rc == 0
+        return msgs.reshape(-1, RE), pt.reshape(-1, RE)
+
+    def ajtai_matrix(self):
+        """the workload's synthetic Ajtai matrix (workload.Workload.ajtai_matrix) generated by the oracle's C splitmix"""
+        wl = self.wl
+        out = np.empty(wl.kappa * wl.N * RE, dtype=np.uint64)
+        lib().lfo_splitmix_fill(wl.ajtai_seed(), 0, out.size, _p64(out))
+        return out.reshape(wl.kappa, wl.N, RE)
+
     def verify(self, tr, acc, cm_i, proof):
         acc = np.ascontiguousarray(acc, dtype=np.uint64).reshape(-1)
         cm_i = np.ascontiguousarray(cm_i, dtype=np.uint64).reshape(-1)
@@ -271,3 +309,21 @@ class Instance:
         lc = np.zeros(self.lcccs_len * RE, dtype=np.uint64)
         rc = lib().lfo_verify(C.byref(self.params), C.byref(self.ccs), tr.h, _p64(acc), _p64(cm_i), _p64(proof), _p64(lc))
         return rc, lc.reshape(-1, RE)
+
+
+def horner_combine(tables, ch_ring):
+    t = np.ascontiguousarray(tables, dtype=np.uint64)
+    g, pg, ln = t.shape[0], t.shape[1], t.shape[2]
+    ch = np.ascontiguousarray(ch_ring, dtype=np.uint64).reshape(-1)
+    o = np.zeros(ln * RE, dtype=np.uint64)
+    lib().lfo_horner_combine(_p64(t.reshape(-1)), g, pg, ln, _p64(ch), _p64(o))
+    return o.reshape(-1, RE)
+
+
+def lincomb(coef, tables):
+    t = np.ascontiguousarray(tables, dtype=np.uint64)
+    n, ln = t.shape[0], t.shape[1]
+    cf = np.ascontiguousarray(coef, dtype=np.uint64).reshape(-1)
+    o = np.zeros(ln * RE, dtype=np.uint64)
+    lib().lfo_lincomb(_p64(cf), _p64(t.reshape(-1)), n, ln, _p64(o))
+    return o.reshape(-1, RE)

@@ -1,0 +1,162 @@
+"""Bit-exact GPU-vs-oracle parity AT THE BASELINE SIZES (the small-size word-for-word tests are tests/test_gpu_parity.py and
+tests/test_gpu_bb.py).  Three kinds of check, all through the C ABI:
+
+  * live oracle, complete fold step, word for word: C2 (BASELINE configs[1], 2^16 rows) -- `NIFSProver::prove`, nifs.rs:48-103;
+  * live oracle, component level at C4 (BASELINE configs[3] / the metric config, 2^20 rows): the full linearization proof and one
+    complete decomposition (all 15 batched Ajtai commits y_s, v_s, u_s, x_s) -- nifs/linearization.rs:145-189,
+    nifs/decomposition.rs:33-88;
+  * committed oracle fixtures (tests/golden/scale_digests.json, produced by tests/tools/make_scale_digests.py with the oracle
+    only): SHA-256 of every section of a complete fold step at C2, T18 (2^18), C4 (2^20), B14 and C3 (BabyBear 2^18).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from latticefold_amd import api
+from latticefold_amd.workload import make_workload
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scale_digests.json")
+
+
+def _oracle(ring):
+    if ring == "goldilocks":
+        import lfo as O
+    else:
+        import lfo_bb as O
+    return O
+
+
+def _setup(name):
+    wl = make_workload(name)
+    ctx = api.Context(0, ring=wl.ring)
+    ctx.load_ccs(wl)
+    scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())   # same stream as wl.ajtai_matrix()
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    return wl, ctx, scheme, wit, cccs
+
+
+def test_fold_step_bit_exact_vs_oracle_C2():
+    wl, ctx, scheme, wit, cccs = _setup("C2")
+    O = _oracle(wl.ring)
+    try:
+        tr = lambda: api.PoseidonTranscript(ring=wl.ring)
+        acc, lin_pr = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+        lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+        inst = O.Instance(wl)
+        A = inst.ajtai_matrix()
+        f = inst.witness_from_w_ccs(wl.w_ccs)
+        assert (wit.f_coeff == f).all()
+        cm_o = O.ajtai_commit(A, wl.kappa, wl.N, O.crt(f))
+        assert (cm_o == cccs[:wl.kappa]).all()
+        acc_o, lin_o = inst.linearize(O.Transcript(), cccs, f)
+        assert (acc == acc_o).all() and (lin_pr == lin_o).all()
+        lc_o, f0_o, proof_o = inst.fold_step(O.Transcript(), A, acc_o, f, cccs, f)
+        assert (proof == proof_o).all()
+        assert (lc == lc_o).all()
+        assert (w0.f == f0_o).all()
+    finally:
+        ctx.close()
+
+
+def test_components_bit_exact_vs_oracle_C4():
+    """2^20 rows, kappa 26, K 16: linearization proof + one whole decomposition (15 batched commits over the 5 GB matrix,
+    48 v_s and 48 u_s evaluations) against the oracle, word for word."""
+    wl, ctx, scheme, wit, cccs = _setup("C4")
+    O = _oracle(wl.ring)
+    try:
+        tr = lambda: api.PoseidonTranscript(ring=wl.ring)
+        inst = O.Instance(wl)
+        A = inst.ajtai_matrix()
+        f = inst.witness_from_w_ccs(wl.w_ccs)
+        assert (wit.f_coeff == f).all()
+        acc, lin_pr = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+        acc_o, lin_o = inst.linearize(O.Transcript(), cccs, f)
+        assert (lin_pr == lin_o).all() and (acc == acc_o).all()
+        lcs, dec_pr = api.LFDecompositionProver.prove(ctx, acc, wit, tr())
+        lcs_o, dec_o = inst.decomposition_prove(O.Transcript(), A, acc_o, f)
+        K, t, tau, l, kap = wl.K, wl.t, wl.tau, wl.l, wl.kappa
+        u_s, v_s, x_s, y_s = np.split(dec_pr, np.cumsum([K * t, K * tau, K * (l + 1)]))
+        u_o, v_o, x_o, y_o = np.split(dec_o, np.cumsum([K * t, K * tau, K * (l + 1)]))
+        assert (y_s == y_o).all(), "batched Ajtai commits differ"
+        assert (v_s == v_o).all() and (u_s == u_o).all() and (x_s == x_o).all()
+        assert (lcs == lcs_o).all()
+    finally:
+        ctx.close()
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
+
+
+def _digests(wl, acc, lc, f0, proof):
+    tau = wl.tau
+    lin = wl.s * (wl.d + 2) + tau + wl.t
+    dec = wl.K * (wl.t + tau + wl.l + 1 + wl.kappa)
+    fm = wl.s * (2 * wl.b + 1)
+    p = np.asarray(proof).reshape(-1, wl.RE)
+    o = lin + 2 * dec
+    return {"acc": _sha(acc), "lcccs_out": _sha(lc), "f0_ntt": _sha(f0), "proof_lin": _sha(p[:lin]),
+            "proof_dec_left": _sha(p[lin:lin + dec]), "proof_dec_right": _sha(p[lin + dec:o]), "proof_fold_msgs": _sha(p[o:o + fm]),
+            "proof_theta": _sha(p[o + fm:o + fm + 2 * wl.K * tau]), "proof_eta": _sha(p[o + fm + 2 * wl.K * tau:]), "proof": _sha(p)}
+
+
+def _gold(name):
+    if not os.path.exists(GOLD):
+        pytest.skip("tests/golden/scale_digests.json missing (tests/tools/make_scale_digests.py)")
+    g = json.load(open(GOLD))
+    if name not in g:
+        pytest.skip(f"no golden digest for {name}")
+    return {k: v for k, v in g[name].items() if k.startswith(("acc", "lcccs", "f0", "proof"))}
+
+
+@pytest.mark.parametrize("name", ["C2", "T18", "C4", "B14", "C3"])
+def test_fold_step_matches_committed_oracle_digests(name):
+    """complete fold step at the BASELINE sizes vs the committed oracle-only fixtures, section by section"""
+    want = _gold(name)
+    wl, ctx, scheme, wit, cccs = _setup(name)
+    try:
+        tr = lambda: api.PoseidonTranscript(ring=wl.ring)
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+        lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+        got = _digests(wl, acc, lc, w0.f, proof)
+        bad = [k for k in want if got[k] != want[k]]
+        assert not bad, f"{name}: sections differing from the oracle fixture: {bad}"
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", ["T14", "B10"])
+def test_sub_provers_chain_to_fold_step(name):
+    """LFDecompositionProver / LFFoldingProver entry points (lf_decomposition_prove, lf_folding_prove): vs the oracle's
+    decomposition, and chained after the linearization they reproduce NIFSProver::prove (nifs.rs:59-103) bit for bit"""
+    wl, ctx, scheme, wit, cccs = _setup(name)
+    O = _oracle(wl.ring)
+    try:
+        tr = lambda: api.PoseidonTranscript(ring=wl.ring)
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+        lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+        inst = O.Instance(wl)
+        A = wl.ajtai_matrix()
+        f = inst.witness_from_w_ccs(wl.w_ccs)
+        lcs, dec_pr = api.LFDecompositionProver.prove(ctx, acc, wit, tr())
+        lcs_o, dec_o = inst.decomposition_prove(O.Transcript(), A, acc, f)
+        assert (dec_pr == dec_o).all() and (lcs == lcs_o).all()
+        # replay nifs.rs:59-103 with the three sub-provers on one transcript
+        t1 = tr()
+        lbl = lambda s: np.array([int.from_bytes(s.encode(), "big") % wl.P], dtype=np.uint64)
+        from latticefold_amd.workload import diag
+        t1.absorb_slice(diag(int(lbl("acc")[0]), wl.ring)); t1.absorb_slice(acc)
+        t1.absorb_slice(diag(int(lbl("cm_i")[0]), wl.ring)); t1.absorb_slice(cccs)
+        lin_lc, lin_pr = api.LFLinearizationProver.prove(ctx, cccs, wit, t1)
+        lcs_l, dec_l = api.LFDecompositionProver.prove(ctx, acc, wit, t1)
+        lcs_r, dec_r = api.LFDecompositionProver.prove(ctx, lin_lc, wit, t1)
+        lc2, w02, fold_pr = api.LFFoldingProver.prove(ctx, np.concatenate([lcs_l, lcs_r]), wit, wit, t1)
+        assert (np.concatenate([lin_pr, dec_l, dec_r, fold_pr]) == proof).all()
+        assert (lc2 == lc).all() and (w02.f == w0.f).all()
+    finally:
+        ctx.close()
