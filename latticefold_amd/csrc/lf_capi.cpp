@@ -138,6 +138,26 @@ struct lf_ctx {
         if (!p && hipHostMalloc((void **)&p, 5 * 24 * 8 * 2, hipHostMallocMapped) != hipSuccess) p = nullptr;
         return p;
     }
+    // persistent sumcheck tail (k_fold_tail): host-mapped mailbox + device scratch, created on first use
+    TailMail *tail_mail = nullptr;
+    u32 *tail_counters = nullptr;      // device, TAIL_MAX_ROUNDS u32 (zeroed once; self-resetting) followed by dev_chal
+    u64 *tail_dev_chal = nullptr;
+    u32 tail_epoch = 0;
+    int num_cus = 0;
+    int tail_setup() {
+        if (tail_mail) return LF_OK;
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, device));
+        num_cus = pr.multiProcessorCount;
+        void *d = nullptr;
+        HIPCHK(hipMalloc(&d, 4096));
+        HIPCHK(hipMemset(d, 0, 4096));
+        tail_counters = (u32 *)d;
+        tail_dev_chal = (u64 *)((char *)d + 1024);
+        HIPCHK(hipHostMalloc((void **)&tail_mail, sizeof(TailMail), hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: the kernel and this thread talk through it while the kernel runs
+        memset(tail_mail, 0, sizeof(TailMail));
+        return LF_OK;
+    }
     hipEvent_t ev_theta = nullptr;
     hipEvent_t ev_block = nullptr;   // hipEventBlockingSync: lane 1 (long waits) yields its CPU instead of spinning
     int lane_sync() {
@@ -294,6 +314,8 @@ void lf_ctx_destroy(lf_ctx *c) {
     for (int l = 0; l < 2; l++)
         if (c->h_round[l]) (void)hipHostFree(c->h_round[l]);
     if (c->ev_block) (void)hipEventDestroy(c->ev_block);
+    if (c->tail_mail) (void)hipHostFree(c->tail_mail);
+    if (c->tail_counters) (void)hipFree(c->tail_counters);
     if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
@@ -1230,6 +1252,68 @@ static int upload_consts(lf_ctx *c, const std::string &name, const std::vector<F
     return LF_OK;
 }
 
+// Tail rounds `round`..s of the folding sumcheck in one persistent kernel (lf_kernels.hip: k_fold_tail).  On entry `a` / `curF`
+// describe the tables of round-1 (a.n entries each, leading dimension a.n) and pt[round-2] is the challenge that fixes them.
+// The host side of the mailbox protocol: poll the message of a round, run the transcript, write the challenge back.
+static int fold_tail_rounds(lf_ctx *c, Transcript &tr, const FoldRoundArgs &a, u64 *curF, u64 *const Fbuf[2], u64 *T_other, const Fq3Const *d_mu,
+                            u64 *partial, u32 round, std::vector<Fq3> &pt, u64 *msgs, u32 deg) {
+    const lf_params &P = c->P;
+    RET(c->tail_setup());
+    const u32 nr = P.s - round + 1;
+    FoldTailArgs A;
+    A.T[0] = (u64 *)a.eqL; A.T[1] = T_other;
+    A.F[0] = curF; A.F[1] = curF == Fbuf[0] ? Fbuf[1] : Fbuf[0];
+    A.n0 = a.n; A.rounds = nr; A.K = P.K; A.mu_pow = d_mu; A.partial = partial;
+    A.counters = c->tail_counters; A.dev_chal = c->tail_dev_chal;
+    RET(c->tbuf("tail_eqpriv", fold_tail_eqpriv_words(a.n, P.K), &A.eqpriv));
+    HIPCHK(hipHostGetDevicePointer((void **)&A.mail, c->tail_mail, 0));
+    if (++c->tail_epoch >= (1u << 30)) c->tail_epoch = 1;
+    A.epoch = c->tail_epoch;
+    A.r_first = f3c(pt[round - 2]);
+    TailMail *mail = c->tail_mail;
+    if (launch_fold_tail(c->dcrt, A, c->num_cus, c->stream()) == 0) return LF_ERR_UNSUPPORTED;
+    if (hipGetLastError() != hipSuccess) return LF_ERR_HIP;
+    const auto t_start = std::chrono::steady_clock::now();
+    double host_us = 0, wait_us = 0;
+    auto t_mark = t_start;
+    for (u32 i = 0; i < nr; i++) {
+        u32 spins = 0;
+        while (__atomic_load_n(&mail->msg_seq[i], __ATOMIC_ACQUIRE) != A.epoch) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfff) == 0) {
+                if (__atomic_load_n(&mail->err, __ATOMIC_RELAXED) == A.epoch ||
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 10.0) {
+                    __atomic_store_n(&mail->abort_seq, A.epoch, __ATOMIC_RELEASE);   // the kernel gives up at its next wait
+                    (void)hipStreamSynchronize(c->stream());
+                    return LF_ERR_HIP;
+                }
+            }
+        }
+        if (t_tl && t_tl->on) { auto nw = std::chrono::steady_clock::now(); wait_us += std::chrono::duration<double, std::micro>(nw - t_mark).count(); t_mark = nw; }
+        u64 *evs = msgs + (size_t)(round + i - 1) * (deg + 1) * 24;
+        memcpy(evs, (const void *)mail->msg[i], (size_t)(deg + 1) * 24 * 8);
+        HostTimer ht(c);
+        Fq3 r = sc_round_transcript(tr, evs, deg + 1);
+        pt[round + i - 1] = r;
+        if (t_tl && t_tl->on) { static const char *nm[] = {"   tail r0", "   tail r1", "   tail r2", "   tail r3", "   tail r4", "   tail r5", "   tail r6", "   tail r7", "   tail r8", "   tail r9", "   tail r10", "   tail r11", "   tail r12", "   tail r13"}; if (i < 14) TL_MARK(nm[i]); }
+        if (i + 1 < nr) {
+            mail->chal[i][0] = r.c[0]; mail->chal[i][1] = r.c[1]; mail->chal[i][2] = r.c[2];
+            __atomic_store_n(&mail->chal_seq[i], A.epoch, __ATOMIC_RELEASE);
+        }
+        if (t_tl && t_tl->on) { auto nw = std::chrono::steady_clock::now(); host_us += std::chrono::duration<double, std::micro>(nw - t_mark).count(); t_mark = nw; }
+    }
+#ifdef LF_TAIL_DEBUG
+    if (t_tl && t_tl->on)
+        for (u32 i = 1; i < nr; i++) {
+            const u64 *d = (const u64 *)mail->dbg[i];
+            fprintf(stderr, "[taildbg] rd %u: host-flag seen -> published %.2f us, -> round start %.2f, compute %.2f, partial+count %.2f, last-block start +%.2f, rows read %.2f, mailed %.2f\n", i,
+                    (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0, ((double)d[5] - (double)d[4]) / 100.0, (d[6] - d[5]) / 100.0, (d[7] - d[6]) / 100.0);
+        }
+#endif
+    if (t_tl && t_tl->on) fprintf(stderr, "[timeline]    tail: %u rounds, host transcript %.1f us, waiting for the GPU %.1f us\n", nr, host_us, wait_us);
+    return LF_OK;
+}
+
 // LFFoldingProver::prove (nifs/folding.rs:42-130)
 static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcccs_out, lf_witness **w_out, u64 *proof) {
     const lf_params &P = c->P;
@@ -1322,6 +1406,18 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     u64 *d_lut = nullptr;
     for (u32 round = 1; round <= P.s; round++) {
         fmode = 0;
+        // Persistent tail: once the materialised tables are small, ONE kernel runs all remaining rounds and exchanges messages /
+        // challenges with this thread through a host-mapped mailbox (k_fold_tail) -- no launches and no stream sync per round.
+        if (!sharded && Gw == 1 && !c->tn.no_tail && round >= 5 && fmode == 0 && curF && ldF == a.n && a.n <= c->tn.tail_n && a.n >= 4 &&
+            P.s - round + 1 <= TAIL_MAX_ROUNDS) {
+            int trc = fold_tail_rounds(c, tr, a, (u64 *)curF, F, T5[flip], d_mu, partial, round, pt, msgs, deg);
+            if (trc == LF_OK) {
+                curF = (u64 *)curF == F[0] ? F[1] : F[0];   // the tail leaves the fully fixed tables (2 entries per row) in the other buffer
+                ldF = 2;
+                break;
+            }
+            if (trc != LF_ERR_UNSUPPORTED) return trc;   // LF_ERR_UNSUPPORTED: not launchable here -> ordinary rounds
+        }
         if (round > 1) {
             Fq3Const r = f3c(pt[round - 2]);
             size_t nn = a.n / 2;

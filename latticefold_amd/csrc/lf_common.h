@@ -61,6 +61,7 @@ struct Tunables {
     bool lin_u_eval = false, fold_unfused = false, fold_no_lut = false, fold_tab_r1 = false, fold_no_mutab = false, theta_eval = false;
     bool no_tail = false;            // LF_NO_TAIL: keep one launch set + stream sync per tail round instead of the persistent tail kernel
     size_t fuse_min = 16384, lut_min = (size_t)1 << 17, tab_min = 16384;
+    size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
     long lin_blocks = -1;            // -1: automatic
     static Tunables read(size_t lut_min_default) {
         Tunables t;
@@ -77,6 +78,7 @@ struct Tunables {
         if ((e = getenv("LF_FOLD_LUT_MIN"))) t.lut_min = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_TAB_MIN"))) t.tab_min = (size_t)atoll(e);
         if ((e = getenv("LF_LIN_BLOCKS"))) t.lin_blocks = atol(e);
+        if ((e = getenv("LF_TAIL_N"))) t.tail_n = (size_t)atoll(e);
         return t;
     }
 };

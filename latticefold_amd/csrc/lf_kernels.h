@@ -159,6 +159,35 @@ void launch_fold_round_lut_fix(const DevCrt &t, const FoldRoundArgs &a, const in
                                u64 *out, hipStream_t s);
 size_t round_partial_words();
 
+// ---- persistent sumcheck tail (no host hop per round; see k_fold_tail) ------------------------------------------------
+constexpr u32 TAIL_MAX_ROUNDS = 32;
+struct TailMail {   // host-mapped mailbox (hipHostMallocMapped): GPU -> host round messages, host -> GPU challenges
+    u64 msg[TAIL_MAX_ROUNDS][128];     // message of tail round i (5 x 24 words used), valid once msg_seq[i] == epoch
+    u32 msg_seq[TAIL_MAX_ROUNDS];
+    u64 chal[TAIL_MAX_ROUNDS][4];      // challenge answering tail round i (3 words used), valid once chal_seq[i] == epoch
+    u32 chal_seq[TAIL_MAX_ROUNDS];
+    u32 abort_seq;                     // host: = epoch to make the kernel give up
+    u32 err;                           // device: = epoch when a wait timed out
+    u64 dbg[TAIL_MAX_ROUNDS][8];       // LF_TAIL_DEBUG builds: wall-clock stamps (100 MHz) of the round's stages
+};
+struct FoldTailArgs {
+    u64 *T[2];            // T[0]: the 57-plane special-table buffer (eqL eqR eqB G1 G2) of the round BEFORE the tail (n0 entries, ld n0); T[1] unused
+    u64 *F[2];            // F[0]: f-hat tables [2K*3][24][n0] of that round; F[1]: receives the fully fixed tables [2K*3][24][2]
+    size_t n0;
+    u32 rounds, K;
+    const Fq3Const *mu_pow;
+    u64 *partial;         // round_partial_words()
+    u64 *eqpriv;          // fold_tail_eqpriv_words(n0, K): private working sets of the workgroups (128-byte aligned)
+    u32 *counters;        // [TAIL_MAX_ROUNDS], zero before the first launch (self-resetting)
+    u64 *dev_chal;        // [TAIL_MAX_ROUNDS][4] device scratch
+    TailMail *mail;       // device address of the mapped mailbox
+    u32 epoch;            // > 0, different for every launch
+    Fq3Const r_first;     // challenge answering the round before the tail
+};
+constexpr u32 FOLD_TAIL_MAX_BLOCKS = 256;
+size_t fold_tail_eqpriv_words(size_t n0, u32 K);
+u32 launch_fold_tail(const DevCrt &t, const FoldTailArgs &A, int num_cus, hipStream_t s);
+
 // ---- folded witness (a13 in coefficient domain) ---------------------------------------------------------------
 // out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c)  with rho_i small-coefficient polynomials (i8 [2K][24])
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev, int32_t *out,

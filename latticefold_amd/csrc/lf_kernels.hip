@@ -1830,6 +1830,277 @@ void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, si
     FoldSrc src = {};
     launch_fold_round_mode<0>(t, a, F, ldF, K, mu_pow_dev, src, partial, out, s);
 }
+// ---------------------------------------------------------------------------------------------------------
+// Persistent tail of the folding sumcheck (no host hop per round).  Once the tables are small the per-round cost
+// is launches + stream synchronisation, not arithmetic (a round >= 11 at 2^20 rows: ~100 us of wall clock for ~5 us of wave
+// time).  k_fold_tail runs ALL remaining rounds in one launch: per round it fixes the previous tables with the challenge (fused
+// into the pair loads, like MODE 1 above, here for the five special tables too), evaluates the round polynomial, the last
+// workgroup to finish reduces the partial sums and writes the message into host-mapped memory; the host -- which still owns the
+// Poseidon transcript (a permutation is a serial chain of ~900 dependent 64-bit modmuls: 1.5 us on a host core, >8 us on a GPU
+// wave) -- polls that mailbox, absorbs, squeezes and writes the challenge back; workgroup 0 polls it over PCIe and republishes it
+// in device memory for the others.
+//
+// Data flow is workgroup-local by construction: workgroup (slot, z) owns the F_{p^3} rows (table kd, slot) of its table chunk and,
+// for z = 0, the G rows of its slot, for ALL pairs and all rounds; the slot-constant eq tables are kept as private copies per
+// workgroup (eqpriv).  So tables never travel between workgroups -- on this GPU that would mean between the eight XCDs' L2
+// caches, and every agent-scope release/acquire fence writes back / invalidates a whole L2 (measured: ~300 us per round with
+// fences in 256 workgroups).  What does cross workgroups -- 15 partial sums each, the round counter, the republished challenge --
+// moves through agent-scope atomics only (memory-side, coherent without fences); the host mailbox through system-scope atomics.
+// All workgroups must be co-resident (launch_fold_tail sizes the grid from the occupancy query); every wait is bounded by a wall
+// clock timeout that aborts the whole kernel (mail->err), so a lost host cannot hang the GPU.
+__device__ __forceinline__ u32 ld_sys_u32(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64 ld_sys_u64(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64 ld_dev_u64(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev_u64(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_mem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }   // all of this wave's memory operations have completed
+constexpr u64 TAIL_TIMEOUT_TICKS = 400000000ull;   // wall_clock64 runs at 100 MHz: 4 s
+constexpr u64 TAIL_ABORT_BIT = 1ull << 40;
+#ifdef LF_TAIL_DEBUG
+#define TAIL_STAMP(mail, rd, k) __hip_atomic_store((u64 *)&(mail)->dbg[rd][k], (u64)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#else
+#define TAIL_STAMP(mail, rd, k) do { } while (0)
+#endif
+
+// wait for challenge `idx` of this launch (epoch): returns false on abort/timeout.  Called by thread 0 of every workgroup.
+__device__ bool tail_wait_challenge(TailMail *mail, u64 *dev_chal, u32 idx, u32 epoch, bool leader, u64 *r_out) {
+    u64 *slot = dev_chal + (size_t)idx * 4;
+    const u64 t0 = wall_clock64();
+    if (leader) {
+        u32 st = 0;
+        for (u32 it = 0;; it++) {
+            if (ld_sys_u32((const u32 *)&mail->chal_seq[idx]) == epoch) { st = 1; TAIL_STAMP(mail, idx + 1, 0); break; }
+            if ((it & 63) == 63) {
+                if (ld_sys_u32((const u32 *)&mail->abort_seq) == epoch) break;
+                if (wall_clock64() - t0 > TAIL_TIMEOUT_TICKS) { __hip_atomic_store((u32 *)&mail->err, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+        if (st) {
+            u64 v[3];
+            for (int q = 0; q < 3; q++) v[q] = ld_sys_u64((const u64 *)&mail->chal[idx][q]);   // issued after the flag was seen; the host wrote them before it
+            for (int q = 0; q < 3; q++) st_dev_u64(slot + q, v[q]);
+        }
+        wait_mem();
+        st_dev_u64(slot + 3, st ? (u64)epoch : ((u64)epoch | TAIL_ABORT_BIT));
+        TAIL_STAMP(mail, idx + 1, 1);
+    }
+    for (u32 it = 0;; it++) {
+        u64 v = ld_dev_u64(slot + 3);
+        if (v == (u64)epoch) break;
+        if (v == ((u64)epoch | TAIL_ABORT_BIT)) return false;
+        if ((it & 255) == 255 && wall_clock64() - t0 > 2 * TAIL_TIMEOUT_TICKS) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    for (int q = 0; q < 3; q++) r_out[q] = ld_dev_u64(slot + q);
+    return true;
+}
+
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_tail(DevCrt t, FoldTailArgs A) {
+    const u32 slot = blockIdx.y;
+    const u64 nu = t.nu;
+    const u32 nkd = 2 * A.K * 3, per = (nkd + gridDim.z - 1) / gridDim.z;
+    const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
+    const u32 nblocks = gridDim.y * gridDim.z, bid = blockIdx.z * gridDim.y + blockIdx.y;
+    const bool leader = bid == 0;
+    __shared__ u64 s_r[3];
+    __shared__ u32 s_flag;
+    __shared__ u64 red[15];
+    // Private working set of this workgroup, 128-byte aligned so that no line is shared with another workgroup: rows
+    // 0 eqL, 1 eqR, 2 eqB, 3 G1[slot], 4 G2[slot], 5.. the tables kd0..kd1 (each row = 3 planes), two buffers (ping-pong).
+    const size_t half0 = A.n0 / 2, row_words = 3 * half0, nrow = 5 + per;
+    const size_t buf_words = (nrow * row_words + 15) & ~(size_t)15;
+    u64 *const priv = A.eqpriv + (size_t)bid * 2 * buf_words;
+    size_t n_prev = A.n0;
+    Fq3 r = fq3_make(A.r_first.c[0], A.r_first.c[1], A.r_first.c[2]);
+    for (u32 rd = 0; rd < A.rounds; rd++) {
+        if (rd > 0) {
+            if (threadIdx.x == 0) {
+                u64 rr[3] = {0, 0, 0};
+                bool ok = tail_wait_challenge(A.mail, A.dev_chal, rd - 1, A.epoch, leader, rr);
+                s_r[0] = rr[0]; s_r[1] = rr[1]; s_r[2] = rr[2];
+                s_flag = ok ? 1u : 0u;
+            }
+            __syncthreads();   // also orders this workgroup's table stores of the previous round before the loads below
+            if (!s_flag) return;
+            r = fq3_make(s_r[0], s_r[1], s_r[2]);
+            __syncthreads();   // s_flag / s_r are rewritten below only after every wave has read them
+            if (leader && threadIdx.x == 0) TAIL_STAMP(A.mail, rd, 2);
+        }
+        const size_t n = n_prev / 2, pairs = n / 2, ldp = n_prev;
+        const bool first = rd == 0, last = rd + 1 == A.rounds;
+        const u64 *Pp = priv + (size_t)((rd + 1) & 1) * buf_words;   // previous round's private buffer (rows of leading dimension ldp)
+        u64 *Pn = priv + (size_t)(rd & 1) * buf_words;               // this round's (leading dimension n)
+        // source row q of the previous tables: the shared layout in the first tail round, the private buffer afterwards
+        auto src_row = [&](u32 q) -> const u64 * {
+            if (!first) return Pp + (size_t)q * 3 * ldp;
+            if (q < 3) return A.T[0] + (size_t)q * 3 * ldp;
+            if (q < 5) return A.T[0] + (size_t)(3 + 8 * (q - 3) + slot) * 3 * ldp;
+            return A.F[0] + ((size_t)(kd0 + (q - 5)) * 24 + 3 * slot) * ldp;
+        };
+        // fix entries 4p..4p+3 of an F_{p^3} row (three planes of leading dimension ldp) -> pair (2p, 2p+1)
+        auto fix_pair = [&](const u64 *row, size_t p, Fq3 &f0, Fq3 &f1) {
+            const u64 *fp = row + 4 * p;
+            ulonglong2 a0 = *(const ulonglong2 *)(fp), a1 = *(const ulonglong2 *)(fp + ldp), a2 = *(const ulonglong2 *)(fp + 2 * ldp);
+            ulonglong2 b0 = *(const ulonglong2 *)(fp + 2), b1 = *(const ulonglong2 *)(fp + ldp + 2), b2 = *(const ulonglong2 *)(fp + 2 * ldp + 2);
+            Fq3 lo = fq3_make(a0.x, a1.x, a2.x), hi = fq3_make(b0.x, b1.x, b2.x);
+            f0 = fq3_add(lo, M3<NU>(fq3_sub(fq3_make(a0.y, a1.y, a2.y), lo), r, nu));
+            f1 = fq3_add(hi, M3<NU>(fq3_sub(fq3_make(b0.y, b1.y, b2.y), hi), r, nu));
+        };
+        auto store_pair = [&](u32 q, size_t p, const Fq3 &f0, const Fq3 &f1) {   // private row q: plain 16-byte stores (stay in this XCD's L2)
+            u64 *op = Pn + (size_t)q * 3 * n + 2 * p;
+            *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
+            *(ulonglong2 *)(op + n) = make_ulonglong2(f0.c[1], f1.c[1]);
+            *(ulonglong2 *)(op + 2 * n) = make_ulonglong2(f0.c[2], f1.c[2]);
+        };
+        Fq3 acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+        // work items = (pair, task): task 0/1 (z = 0 only) = the eq_L G_L / eq_R G_R products, the others one table each.  The round
+        // polynomial is linear in the per-table sums, so every item adds its own contribution to acc and the items of a pair can sit
+        // in different waves: late rounds (a handful of pairs) are a latency chain, and this cuts it to one table per thread.
+        const u32 ntab = kd1 > kd0 ? kd1 - kd0 : 0u, gt = blockIdx.z == 0 ? 2u : 0u;   // (2K*3 need not be a multiple of the chunk count)
+        const size_t items = pairs * (size_t)(ntab + gt);
+        for (size_t it = threadIdx.x; it < items; it += 256) {
+            const size_t p = it % pairs;
+            const u32 task = (u32)(it / pairs);
+            if (task < gt) {
+                const u32 h = task;
+                Fq3 ea, eb, ga, gb;
+                fix_pair(src_row(h), p, ea, eb);
+                fix_pair(src_row(3 + h), p, ga, gb);
+                store_pair(h, p, ea, eb);
+                store_pair(3 + h, p, ga, gb);
+                Fq3 co[3];
+                co[0] = M3<NU>(ea, ga, nu);
+                co[2] = M3<NU>(fq3_sub(eb, ea), fq3_sub(gb, ga), nu);
+                co[1] = fq3_sub(fq3_sub(M3<NU>(eb, gb, nu), co[0]), co[2]);
+                add_poly_evals<5>(acc, co, 3);
+                continue;
+            }
+            const u32 q = task - gt, kd = kd0 + q;
+            Fq3 bq0, bq1;
+            fix_pair(src_row(2), p, bq0, bq1);
+            if (q == 0) store_pair(2, p, bq0, bq1);
+            // mu_kd ((f0 + X df)^3 - (f0 + X df)) of this table (same algebra as k_fold_round)
+            Fq3 f0, f1;
+            fix_pair(src_row(5 + q), p, f0, f1);
+            store_pair(5 + q, p, f0, f1);
+            if (last) {
+                // the fully fixed tables (2 entries) go back to the shared layout for the theta kernel: WRITE-THROUGH stores.  Rows of
+                // different workgroups share 128-byte lines there, the eight L2s are not coherent with each other, and a line that
+                // was read and then partly written with plain stores is written back as a whole at kernel end -- stale neighbour
+                // bytes included (seen: theta wrong in random slots).
+                u64 *op = A.F[1] + ((size_t)kd * 24 + 3 * slot) * n + 2 * p;
+                st_dev_u64(op, f0.c[0]); st_dev_u64(op + 1, f1.c[0]);
+                st_dev_u64(op + n, f0.c[1]); st_dev_u64(op + n + 1, f1.c[1]);
+                st_dev_u64(op + 2 * n, f0.c[2]); st_dev_u64(op + 2 * n + 1, f1.c[2]);
+            }
+            const Fq3 df = fq3_sub(f1, f0);
+            const Fq3Const mc = A.mu_pow[kd];
+            const Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
+            const Fq3 f0s = S3<NU>(f0, nu), dfs = S3<NU>(df, nu);
+            const Fq3 c0 = fq3_sub(M3<NU>(f0s, f0, nu), f0);
+            const Fq3 c3 = M3<NU>(dfs, df, nu);
+            const Fq3 t1 = M3<NU>(f0s, df, nu), t2 = M3<NU>(dfs, f0, nu);
+            const Fq3 c1 = fq3_sub(fq3_add(fq3_add(t1, t1), t1), df);
+            const Fq3 c2 = fq3_add(fq3_add(t2, t2), t2);
+            const Fq3 Q[4] = {M3<NU>(c0, mu, nu), M3<NU>(c1, mu, nu), M3<NU>(c2, mu, nu), M3<NU>(c3, mu, nu)};
+            Fq3 ea = bq0, es = fq3_sub(bq1, bq0);
+#pragma unroll
+            for (int X = 0; X < 5; X++) {
+                Fq3 v = Q[3];
+                for (int e = 2; e >= 0; e--) v = fq3_add(fq3_mul_small(v, X), Q[e]);
+                acc[X] = fq3_add(acc[X], M3<NU>(v, ea, nu));
+                ea = fq3_add(ea, es);
+            }
+        }
+        if (leader && threadIdx.x == 0) TAIL_STAMP(A.mail, rd, 3);
+        // workgroup partial -> row z (columns of this slot); the last workgroup of the round reduces the rows and mails the message
+        u64 vv[15];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { vv[3 * i] = acc[i].c[0]; vv[3 * i + 1] = acc[i].c[1]; vv[3 * i + 2] = acc[i].c[2]; }
+        __syncthreads();            // red[] of the previous round is no longer read
+        block_sum_store<15>(vv, red);
+        __syncthreads();
+        if (threadIdx.x < 15) st_dev_u64(A.partial + (size_t)blockIdx.z * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3, red[threadIdx.x]);
+        wait_mem();                 // the partial sums (and, in the last round, the tables) have reached memory ...
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&A.counters[rd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1 ? 1u : 0u;   // ... before the count
+        __syncthreads();
+        if (leader && threadIdx.x == 0) TAIL_STAMP(A.mail, rd, 4);
+        if (s_flag) {
+            if (threadIdx.x == 0) TAIL_STAMP(A.mail, rd, 5);
+            // rows are read with memory-side loads (~2 us each): keep eight in flight per thread, two threads per column
+            __shared__ u64 s_half[128];
+            {
+                const u32 col = threadIdx.x & 127, hf = threadIdx.x >> 7, nz = gridDim.z, per_h = (nz + 1) / 2;
+                const u32 b0 = hf * per_h, b1 = b0 + per_h < nz ? b0 + per_h : nz;
+                u64 sum = 0;
+                if (col < 120) {
+                    for (u32 b = b0; b < b1; b += 8) {
+                        u64 v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) v[q] = b + q < b1 ? ld_dev_u64(A.partial + (size_t)(b + q) * 120 + col) : 0;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) sum = fq_add(sum, v[q]);
+                    }
+                }
+                if (hf == 1) s_half[col] = sum;
+                __syncthreads();
+                if (hf == 0 && col < 120)
+                    __hip_atomic_store((u64 *)&A.mail->msg[rd][col], fq_add(sum, s_half[col]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (threadIdx.x == 0) TAIL_STAMP(A.mail, rd, 6);
+            wait_mem();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                TAIL_STAMP(A.mail, rd, 7);
+                __hip_atomic_store(&A.counters[rd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-resetting for the next launch
+                __hip_atomic_store((u32 *)&A.mail->msg_seq[rd], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        n_prev = n;
+    }
+}
+// private working sets: per workgroup two buffers of (5 + tables per workgroup) rows x 3 planes x n0/2 entries; sized for the smallest
+// chunk count the launcher may pick (8 workgroups per chunk), which needs the most rows
+size_t fold_tail_eqpriv_words(size_t n0, u32 K) {
+    size_t worst = 0;
+    static const u32 cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 96};
+    for (u32 cc : cand) {
+        if (8 * cc > FOLD_TAIL_MAX_BLOCKS) break;
+        size_t per = (2 * (size_t)K * 3 + cc - 1) / cc, buf = (((5 + per) * 3 * (n0 / 2)) + 15) & ~(size_t)15;
+        size_t tot = (size_t)8 * cc * 2 * buf;
+        if (tot > worst) worst = tot;
+    }
+    return worst + 16;
+}
+// grid = (1, 8 slots, table chunks); returns the number of workgroups (0: the tail cannot run here, the caller falls back to
+// per-round launches).  A.eqpriv must hold fold_tail_eqpriv_words(n0, K) words, 128-byte aligned; the fully fixed tables
+// (2 entries per row) are left in A.F[1] whatever the number of rounds.
+u32 launch_fold_tail(const DevCrt &t, const FoldTailArgs &A, int num_cus, hipStream_t s) {
+    static int occ_nu = -1, occ_g = -1;
+    if (occ_nu < 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_nu, (const void *)k_fold_tail<true>, 256, 0) != hipSuccess) occ_nu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_g, (const void *)k_fold_tail<false>, 256, 0) != hipSuccess) occ_g = 0;
+    }
+    const int occ = t.nu2p40 ? occ_nu : occ_g;
+    if (occ < 1 || num_cus < 1 || A.n0 < 4 || A.rounds < 1 || A.rounds > TAIL_MAX_ROUNDS) return 0;
+    size_t max_blocks = (size_t)occ * (size_t)num_cus / 2;   // half of what could be resident: other streams keep running
+    if (max_blocks > FOLD_TAIL_MAX_BLOCKS) max_blocks = FOLD_TAIL_MAX_BLOCKS;
+    if (max_blocks < 8) return 0;
+    const u32 nkd = 2 * A.K * 3;
+    u32 chunks = 1;
+    static const u32 cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 96};
+    for (u32 cc : cand) {
+        if (cc > nkd || (size_t)8 * cc > max_blocks) break;
+        chunks = cc;
+    }
+    if (t.nu2p40) hipLaunchKernelGGL((k_fold_tail<true>), dim3(1, 8, chunks), dim3(256), 0, s, t, A);
+    else hipLaunchKernelGGL((k_fold_tail<false>), dim3(1, 8, chunks), dim3(256), 0, s, t, A);
+    return 8 * chunks;
+}
+
 // rounds 3 and 4 straight from the coefficient planes through the 81-entry digit look-up table (lut_dev: [81][3], see FoldSrc):
 // round 3 touches no table at all, round 4 fixes with r and writes the first materialised tables Fout [2K*3][24][ldout]
 void launch_fold_round_lut(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,

@@ -229,6 +229,7 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     separate k_fix pass: identical proofs, both equal to the oracle's."""
     wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
     lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    monkeypatch.setenv("LF_NO_TAIL", "1")          # per-round launches for every round (the persistent tail has its own test below)
     monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
     monkeypatch.setenv("LF_FOLD_NO_LUT", "1")
     lc_f, w_f, proof_f = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
@@ -249,6 +250,30 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     assert (proof_f == proof_o).all() and (lc_f == lc_o).all() and (w_f.f == f0_o).all()
     assert (proof_l == proof_o).all() and (lc_l == lc_o).all() and (w_l.f == f0_o).all()
     assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
+
+
+@pytest.mark.parametrize("name", ["T10", "G5", "T8"])
+def test_fold_step_persistent_tail_matches_oracle(ctx, name, monkeypatch):
+    """the persistent tail kernel (k_fold_tail: all remaining folding-sumcheck rounds in one launch, messages and challenges through
+    a host-mapped mailbox) taking over at different rounds, with and without the look-up-table rounds before it: identical proofs,
+    all equal to the oracle's"""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 5)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    for tail_n, lut in (("16384", False), ("16", False), ("4", False), ("64", True), ("0", False)):
+        monkeypatch.setenv("LF_TAIL_N", tail_n)
+        if lut:
+            monkeypatch.setenv("LF_FOLD_LUT_MIN", "1")
+            monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
+        lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        if lut:
+            monkeypatch.delenv("LF_FOLD_LUT_MIN")
+            monkeypatch.delenv("LF_FOLD_FUSE_MIN")
+        assert (proof == proof_o).all() and (lc == lc_o).all() and (w.f == f0_o).all(), (tail_n, lut)
+    # twice in a row on the same context (mailbox epochs, self-resetting counters)
+    monkeypatch.setenv("LF_TAIL_N", "16384")
+    for _ in range(3):
+        lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        assert (proof == proof_o).all()
 
 
 # ---- sumcheck through the ABI, split at the transcript (SURVEY 8b) -----------------------------------------------
