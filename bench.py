@@ -69,6 +69,9 @@ def cpu_baseline(target_wl, budget_s=25.0):
     }
 
 
+PMC_FILE = "r02_pmc_{}.json"   # profiles/: HBM traffic per kernel from the PMC passes (falls back to null when absent)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,9 +82,11 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
                          "stream does --steps steps, value counts all of them.  Default 1 = one prover, latency-honest ms_per_step")
-    ap.add_argument("--parallelism", choices=["replicas", "shard"], default=os.environ.get("LF_PARALLELISM", "replicas"),
-                    help="N>1: 'replicas' = one independent fold stream per GPU (weak scaling, default); 'shard' = ONE fold stream whose "
-                         "Ajtai commitments and folding-sumcheck rounds are sharded over the GPUs (strong scaling, SURVEY 8e)")
+    ap.add_argument("--parallelism", choices=["auto", "replicas", "shard"], default=os.environ.get("LF_PARALLELISM", "auto"),
+                    help="N>1: 'shard' = ONE fold stream sharded over the GPUs (BASELINE configs[3]: column-sharded Ajtai commitments, "
+                         "index-sharded sumcheck rounds and evaluations, RCCL exchanges; strong scaling, SURVEY 8e) -- the default ('auto') "
+                         "for N>1, which also reports the replicas rate as an extra key; 'replicas' = one independent fold stream per GPU "
+                         "(weak scaling) only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,81 +119,106 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    # ---- setup (untimed): everything resident in HBM --------------------------------------------------------
-    shard = world > 1 and args.parallelism == "shard"
-    wl = make_workload(args.workload, seed=0 if shard else rank)
-    ctx = api.Context(local_rank, ring=wl.ring)
-    if shard:
-        from latticefold_amd import dist as lfd
-        ctx.set_sharding(rank, world, lfd.make_allgather())   # RCCL all-gather of the partial commitments / round messages
-    ctx.load_ccs(wl)
-    scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())  # generated on the device
-    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
-    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
-    tr0 = api.PoseidonTranscript(ring=wl.ring)
-    acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr0)  # accumulator = linearized copy (benches/utils.rs:637-655)
-
-    def step():
-        lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr0.clone())
-        w0.free()
-        return proof
-
-    # extra streams (opt-in): independent instances with their own context, witness and accumulator on the same GPU
-    extra = []
-    for sidx in range(1, max(1, args.streams)):
-        if shard:
-            raise SystemExit("--streams > 1 is a replicas-only mode")
-        wl_s = make_workload(args.workload, seed=1000 * sidx + rank)
-        ctx_s = api.Context(local_rank, ring=wl_s.ring)
-        ctx_s.load_ccs(wl_s)
-        sch_s = api.AjtaiCommitmentScheme(ctx_s, kappa=wl_s.kappa, n=wl_s.N, seed=wl_s.ajtai_seed())
-        wit_s = api.Witness.from_w_ccs(ctx_s, wl_s.w_ccs)
-        cccs_s = np.concatenate([wit_s.commit(sch_s), wl_s.x_ccs])
-        tr_s = api.PoseidonTranscript(ring=wl_s.ring)
-        acc_s, _ = api.LFLinearizationProver.prove(ctx_s, cccs_s, wit_s, tr_s)
-        extra.append((ctx_s, acc_s, wit_s, cccs_s, tr_s, sch_s))
-
-    def run_stream(st, n):
-        ctx_s, acc_s, wit_s, cccs_s, tr_s, _ = st
-        for _ in range(n):
-            lc, w0, proof = api.NIFSProver.prove(ctx_s, acc_s, wit_s, cccs_s, wit_s, tr_s.clone())
-            w0.free()
-
-    def sync():
-        ctx.synchronize()
-        for st in extra:
-            st[0].synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            if backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
-
     import threading
-    for _ in range(args.warmup):
-        step()
-    for st in extra:
-        run_stream(st, args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    phases_acc, kstats = {}, []
-    threads = [threading.Thread(target=run_stream, args=(st, args.steps)) for st in extra]
-    for th in threads:
-        th.start()
-    for _ in range(args.steps):
-        step()
-        for k, v in ctx.phase_ms().items():
-            phases_acc[k] = phases_acc.get(k, 0.0) + v
-        kstats.append(ctx.kernel_stats())
-    for th in threads:
-        th.join()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+
+    def measure(shard):
+        """setup (untimed: everything resident in HBM), W warm-up steps, K timed steps bracketed by barrier + synchronize; max over ranks"""
+        wl = make_workload(args.workload, seed=0 if shard else rank)
+        ctx = api.Context(local_rank, ring=wl.ring)
+        transport = None
+        if shard:
+            from latticefold_amd import dist as lfd
+            # RCCL communicators owned by the library (device-buffer all-gathers + modular-sum kernel); LF_DIST_BACKEND=gloo: host transport
+            transport = lfd.init_sharding(ctx, rank, world, "auto")
+        ctx.load_ccs(wl)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())  # generated on the device
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        tr0 = api.PoseidonTranscript(ring=wl.ring)
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr0)  # accumulator = linearized copy (benches/utils.rs:637-655)
+
+        def step():
+            lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr0.clone())
+            w0.free()
+            return proof
+
+        # extra streams (opt-in): independent instances with their own context, witness and accumulator on the same GPU
+        extra = []
+        for sidx in range(1, max(1, args.streams)):
+            if shard:
+                raise SystemExit("--streams > 1 is a replicas-only mode")
+            wl_s = make_workload(args.workload, seed=1000 * sidx + rank)
+            ctx_s = api.Context(local_rank, ring=wl_s.ring)
+            ctx_s.load_ccs(wl_s)
+            sch_s = api.AjtaiCommitmentScheme(ctx_s, kappa=wl_s.kappa, n=wl_s.N, seed=wl_s.ajtai_seed())
+            wit_s = api.Witness.from_w_ccs(ctx_s, wl_s.w_ccs)
+            cccs_s = np.concatenate([wit_s.commit(sch_s), wl_s.x_ccs])
+            tr_s = api.PoseidonTranscript(ring=wl_s.ring)
+            acc_s, _ = api.LFLinearizationProver.prove(ctx_s, cccs_s, wit_s, tr_s)
+            extra.append((ctx_s, acc_s, wit_s, cccs_s, tr_s, sch_s))
+
+        def run_stream(st, n):
+            ctx_s, acc_s, wit_s, cccs_s, tr_s, _ = st
+            for _ in range(n):
+                lc, w0, proof = api.NIFSProver.prove(ctx_s, acc_s, wit_s, cccs_s, wit_s, tr_s.clone())
+                w0.free()
+
+        def sync():
+            ctx.synchronize()
+            for st in extra:
+                st[0].synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                if backend == "nccl":
+                    dist.barrier(device_ids=[local_rank])
+                else:
+                    dist.barrier()
+
+        for _ in range(args.warmup):
+            step()
+        for st in extra:
+            run_stream(st, args.warmup)
+        if shard:
+            ctx.dist_stats(reset=True)
+        sync()
+        t0 = time.perf_counter()
+        phases_acc, kstats = {}, []
+        threads = [threading.Thread(target=run_stream, args=(st, args.steps)) for st in extra]
+        for th in threads:
+            th.start()
+        for _ in range(args.steps):
+            step()
+            for k, v in ctx.phase_ms().items():
+                phases_acc[k] = phases_acc.get(k, 0.0) + v
+            kstats.append(ctx.kernel_stats())
+        for th in threads:
+            th.join()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        ex = None
+        if shard:
+            n_ex, us_tot, us_max = ctx.dist_stats()
+            ex = {"transport": transport, "exchanges_per_step": n_ex / args.steps, "mean_us": us_tot / max(n_ex, 1), "max_us": us_max,
+                  "note": "host-side latency of one exchange (enqueue of ncclAllGather + modular-sum kernel when the transport is rccl; the whole blocking "
+                          "round trip for the host transport)"}
+        for st in extra:
+            st[0].close()
+        wit.free()
+        ctx.close()
+        return wl, elapsed, phases_acc, kstats, ex
+
+    mode = args.parallelism
+    shard = world > 1 and mode in ("auto", "shard")
+    wl, elapsed, phases_acc, kstats, exch = measure(shard)
+    replicas_extra = None
+    if shard and mode == "auto":   # the independent-streams rate of the same GPUs, reported next to the sharded headline
+        _, el_r, _, _, _ = measure(False)
+        replicas_extra = {"value": world * args.steps / el_r, "unit": "steps/s", "ms_per_step": el_r / args.steps * 1e3, "scaling": "weak",
+                          "parallelism": f"replicas x{world}: one independent fold stream per GPU, no data-path collective"}
 
     if rank == 0:
         E = 192 if wl.ring == "goldilocks" else 288
@@ -215,7 +245,7 @@ def main():
         # HBM traffic of the dominant kernel from the PMC passes (collected separately, as rocprofv3 requires; see profiles/)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_p_pmc_{wl.name.lower()}.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(wl.name.lower()))))["kernels"]
             want = ("bb::" if wl.ring == "babybear" else "") + ("k_ajtai" if dom == "k_ajtai" else "k_fold_round")
             for name, k in pmc.items():
                 base = name.split("<")[0]
@@ -232,8 +262,10 @@ def main():
         alu = {"kernel": "k_ajtai", "unit": "v_mad lane-op/s", "peak": 15.7e12,
                "achieved": aj_mads / (aj_ms / max(aj_n, 1) * 1e-3) if aj_ms else 0.0}
         alu["frac"] = alu["achieved"] / alu["peak"]
-        roof = {"bound": "hbm", "kernel": dom, "integer_alu": alu, "achieved": kernels[dom]["achieved_GBps"], "peak": peak, "unit": "GB/s",
+        roof = {"bound": "valu_int64", "bound_note": "neither HBM nor MFMA binds: the kernel is issue-bound on 64-bit integer multiply-adds (integer_alu below); "
+                "achieved / peak / frac are the HBM figures the bench contract asks for", "kernel": dom, "integer_alu": alu, "achieved": kernels[dom]["achieved_GBps"], "peak": peak, "unit": "GB/s",
                 "frac": kernels[dom]["achieved_GBps"] / peak, "traffic": traffic,
+                "traffic_source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc.sh; not re-measured in this run)" % PMC_FILE.format(wl.name.lower()),
                 "note": "integer-ALU-bound path (modular multiply from quarter-rate v_mad_*64_*32); whole-step algorithmic "
                         "rate = %.1f GB/s = %.3f of peak" % (alg * steps_per_s / world / 1e9, alg * steps_per_s / world / 1e9 / peak),
                 "kernels": kernels}
@@ -251,11 +283,15 @@ def main():
             "dtype": "u64" if wl.ring == "goldilocks" else "u32 (31-bit Montgomery)",
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: {'GoldilocksRingNTT' if wl.ring == 'goldilocks' else 'BabyBearRingNTT'} R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
-                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world} (column-sharded commits + sharded sumcheck rounds, one fold stream)" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
+                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world}: one fold stream, witness columns / table rows sharded by the high index bits (Ajtai commits, linearization and folding sumcheck rounds, v/u/eta evaluations), RCCL all-gather + modular sum per exchange" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
                        "alg_bytes_per_step": alg, "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
             "roofline": roof,
             "phases_ms_per_step": {k: v / args.steps for k, v in phases_acc.items()},
         }
+        if exch is not None:
+            out["exchanges"] = exch
+        if replicas_extra is not None:
+            out["replicas"] = replicas_extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl)
@@ -268,9 +304,6 @@ def main():
         else:
             dist.barrier()
         dist.destroy_process_group()
-    for st in extra:
-        st[0].close()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -115,6 +115,20 @@ int lf_modsum_ring(const uint64_t *parts, size_t nparts, size_t words, uint64_t 
  * into recv_all[world*words] in rank order and return 0 (RCCL/xGMI via torch.distributed in latticefold_amd/dist.py). */
 typedef int (*lf_exchange_fn)(void *user, const uint64_t *send, uint64_t *recv_all, size_t words);
 int lf_set_sharding(lf_ctx *, int rank, int world, lf_exchange_fn cb, void *user);
+/* The production transport: one RCCL communicator per context (one rank per GPU, xGMI), created from a 128-byte ncclUniqueId that rank 0
+ * obtains with lf_dist_unique_id (called twice, see lf_dist_init) and the launcher distributes (MPI, torch.distributed store, a file ...).  Exchanges then run on DEVICE
+ * buffers in the context's streams: ncclAllGather + a modular-sum kernel, no host hop and no callback.  RCCL is loaded with dlopen (the
+ * library has no link-time dependency on it); LF_ERR_UNSUPPORTED if it is not installed.  Same ordering rule as lf_set_sharding: before the
+ * Ajtai matrix is loaded.  A rank whose step fails aborts the communicator so that its peers error out instead of waiting forever. */
+int lf_dist_unique_id(uint8_t *id128);
+/* ids = TWO unique ids (2 x 128 bytes): the two lanes of a fold step exchange concurrently and each gets its own communicator */
+int lf_dist_init(lf_ctx *, int rank, int world, const uint8_t *ids);
+/* host transport with one callback per lane (the callbacks run on different threads, possibly at the same time: give each its own
+ * ordered channel, e.g. two process groups); lf_set_sharding installs the same callback for both, which is only safe if it is
+ * order-independent */
+int lf_set_sharding_lanes(lf_ctx *, int rank, int world, lf_exchange_fn cb0, void *user0, lf_exchange_fn cb1, void *user1);
+/* exchange log of the context: number of exchanges, summed and maximal host-side latency in microseconds (reset != 0 clears it) */
+int lf_dist_stats(lf_ctx *, uint64_t *n_exchanges, double *total_us, double *max_us, int reset);
 
 /* ---- a8/a9/a11: eq table and batched MLE evaluation (sumcheck/utils.rs:100-170, mle_helpers.rs:65-88) */
 /* point = nv challenges in F_{p^3} (3 words each): the reference's points are always diagonal embeddings

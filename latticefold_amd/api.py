@@ -95,6 +95,10 @@ def _lib():
         L.lf_modsum.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
         L.lf_modsum_ring.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p, C.c_int]
         L.lf_set_sharding.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
+        L.lf_set_sharding_lanes.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp, EXCHANGE_FN, vp]
+        L.lf_dist_unique_id.argtypes = [C.c_void_p]
+        L.lf_dist_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+        L.lf_dist_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
         L.lf_build_eq.argtypes = [vp, u64p, C.c_uint, u64p]
         L.lf_mle_eval_batch.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p, C.c_uint, u64p]
         L.lf_ccs_load.argtypes = [vp, C.POINTER(Params), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u64p), u32p, u32p, u64p]
@@ -147,6 +151,16 @@ def _lib():
         L.lf_last_kernel_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
+
+
+def dist_unique_ids():
+    """two ncclUniqueIds (256 bytes) for Context.dist_init: one RCCL communicator per lane of the fold step"""
+    out = b""
+    for _ in range(2):
+        buf = (C.c_uint8 * 128)()
+        _chk(_lib().lf_dist_unique_id(buf), "lf_dist_unique_id")
+        out += bytes(buf)
+    return out
 
 
 def exported_symbols():
@@ -206,22 +220,42 @@ class Context:
         _chk(_lib().lf_selftest_field(self.h, seed, n, C.cast(C.byref(m), u64p)), "lf_selftest_field")
         return m.value
 
-    def set_sharding(self, rank, world, allgather):
-        """Intra-step sharding (lf_set_sharding); call before creating the AjtaiCommitmentScheme.
-        allgather(np.uint64[words]) -> np.uint64[world, words] in rank order (see latticefold_amd.dist.make_allgather)."""
-        def _cb(user, send, recv, words):
-            try:
-                mine = np.ctypeslib.as_array(send, shape=(words,)).copy()
-                out = np.ascontiguousarray(allgather(mine), dtype=np.uint64).reshape(world * words)
-                C.memmove(recv, out.ctypes.data, world * words * 8)
-                return 0
-            except Exception as e:  # never let an exception cross the C boundary
-                import sys
-                print("lf exchange callback failed:", repr(e), file=sys.stderr)
-                return -1
-        self._exchange_cb = EXCHANGE_FN(_cb) if world > 1 else EXCHANGE_FN(0)
-        _chk(_lib().lf_set_sharding(self.h, rank, world, self._exchange_cb, None), "lf_set_sharding")
+    def set_sharding(self, rank, world, allgather, allgather_lane1=None):
+        """Intra-step sharding over a HOST transport (lf_set_sharding_lanes); call before creating the AjtaiCommitmentScheme.
+        allgather(np.uint64[words]) -> np.uint64[world, words] in rank order (see latticefold_amd.dist.make_allgather).  The two lanes
+        of a fold step exchange concurrently from two threads: pass a second callable with its own ordered channel (its own process
+        group) as allgather_lane1."""
+        def mk(fn):
+            def _cb(user, send, recv, words):
+                try:
+                    mine = np.ctypeslib.as_array(send, shape=(words,)).copy()
+                    out = np.ascontiguousarray(fn(mine), dtype=np.uint64).reshape(world * words)
+                    C.memmove(recv, out.ctypes.data, world * words * 8)
+                    return 0
+                except Exception as e:  # never let an exception cross the C boundary
+                    import sys
+                    print("lf exchange callback failed:", repr(e), file=sys.stderr)
+                    return -1
+            return EXCHANGE_FN(_cb)
+        self._exchange_cb = mk(allgather) if world > 1 else EXCHANGE_FN(0)
+        self._exchange_cb1 = mk(allgather_lane1) if (world > 1 and allgather_lane1 is not None) else EXCHANGE_FN(0)
+        _chk(_lib().lf_set_sharding_lanes(self.h, rank, world, self._exchange_cb, None, self._exchange_cb1, None), "lf_set_sharding_lanes")
         self.shard = (rank, world)
+
+    def dist_init(self, rank, world, ids):
+        """Intra-step sharding over RCCL (lf_dist_init): ids = bytes of TWO ncclUniqueIds (api.dist_unique_ids() on rank 0, broadcast by
+        the launcher).  Exchanges then run on device buffers in the library's own streams (ncclAllGather + modular-sum kernel)."""
+        ids = bytes(ids)
+        assert len(ids) == 256
+        buf = (C.c_uint8 * 256).from_buffer_copy(ids)
+        _chk(_lib().lf_dist_init(self.h, rank, world, buf), "lf_dist_init")
+        self.shard = (rank, world)
+
+    def dist_stats(self, reset=False):
+        """(number of exchanges, total us, max us) of the context's exchange log"""
+        n, tot, mx = C.c_uint64(), C.c_double(), C.c_double()
+        _chk(_lib().lf_dist_stats(self.h, C.byref(n), C.byref(tot), C.byref(mx), int(reset)), "lf_dist_stats")
+        return n.value, tot.value, mx.value
 
     def mem_info(self):
         f, t = C.c_size_t(), C.c_size_t()

@@ -16,6 +16,7 @@
 
 #include "bb_kernels.h"
 #include "lf_common.h"
+#include "lf_dist.h"
 #include "lf_verify.h"
 
 namespace lfbb {
@@ -37,9 +38,8 @@ struct BbCtxImpl {
     u32 kappa = 0;
     size_t nA = 0, nA_total = 0, A_col0 = 0;   // columns held by this rank / of the whole matrix / first held column
     // intra-step sharding, same scheme as the Goldilocks backend
-    int sh_rank = 0, sh_world = 1;
-    lf_exchange_fn sh_cb = nullptr;
-    void *sh_user = nullptr;
+    int sh_rank = 0, sh_world = 1;   // mirror comm.rank / comm.world
+    lfdist::Comm comm;               // exchange layer (lf_dist.h): RCCL communicator or host callback
     bool have_ccs = false;
     lf_params P{};
     size_t N = 0, m = 0, n = 0;
@@ -210,6 +210,7 @@ void BbCtx::destroy() {
     (void)hipStreamSynchronize(c->st_lane[0]);
     (void)hipStreamSynchronize(c->st_lane[1]);
     free_ccs(c);
+    c->comm.destroy();
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
@@ -237,9 +238,20 @@ int BbCtx::set_sharding(int rank, int world, lf_exchange_fn cb, void *user) {
     if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(p->mu);
     if (p->dA) return LF_ERR_STATE;   // choose the sharding before loading/generating the Ajtai matrix
-    p->sh_rank = rank; p->sh_world = world; p->sh_cb = cb; p->sh_user = user;
+    p->comm.destroy();
+    p->comm.rank = p->sh_rank = rank; p->comm.world = p->sh_world = world; p->comm.cb = cb; p->comm.user = user;
     return LF_OK;
 }
+int BbCtx::dist_init(int rank, int world, const uint8_t *id128) {
+    std::lock_guard<std::mutex> g(p->mu);
+    if (p->dA) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(p->device));
+    p->comm.destroy();
+    RET(lfdist::rccl_init(p->comm, rank, world, id128));
+    p->sh_rank = rank; p->sh_world = world;
+    return LF_OK;
+}
+lfdist::Comm *BbCtx::comm() { return &p->comm; }
 int BbCtx::get_ring_tables(uint64_t *nonres, uint64_t *y) {
     *nonres = p->ring.T.nu;
     for (int k = 0; k < 8; k++)
@@ -287,7 +299,7 @@ static int down_small(C *c, const u64 *dsrc, size_t words, u64 *host) {
 static int exchange_modsum(C *c, u64 *inout, size_t words) {
     if (c->sh_world <= 1) return LF_OK;
     std::vector<u64> all((size_t)c->sh_world * words);
-    if (c->sh_cb(c->sh_user, inout, all.data(), words) != 0) return LF_ERR_HIP;
+    RET(c->comm.allgather_host(inout, all.data(), words, c->stream()));
     for (size_t w = 0; w < words; w++) {
         u64 acc = 0;
         for (int g = 0; g < c->sh_world; g++) {
@@ -1174,7 +1186,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                     std::vector<fe> full(planes * nn);
                     HIPCHK(hipMemcpyAsync(mine.data(), fd, cnt * sizeof(fe), hipMemcpyDeviceToHost, c->stream()));
                     HIPCHK(hipStreamSynchronize(c->stream()));
-                    if (c->sh_cb(c->sh_user, mine.data(), all.data(), words) != 0) return LF_ERR_HIP;
+                    RET(c->comm.allgather_host(mine.data(), all.data(), words, c->stream()));
                     for (size_t rk = 0; rk < Gw; rk++) {
                         const fe *src = (const fe *)&all[rk * words];
                         for (size_t w = 0; w < planes; w++) memcpy(&full[w * nn + rk * lcl], src + w * lcl, lcl * sizeof(fe));

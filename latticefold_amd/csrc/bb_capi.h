@@ -9,6 +9,7 @@
 #include "bb_host.h"
 
 struct lf_witness;
+namespace lfdist { struct Comm; }
 
 namespace lfbb {
 
@@ -20,6 +21,8 @@ struct BbCtx {
     void destroy();
 
     int set_sharding(int rank, int world, lf_exchange_fn cb, void *user);
+    int dist_init(int rank, int world, const uint8_t *id128);
+    lfdist::Comm *comm();
     int set_ring_tables(uint64_t nonres, const uint64_t *y);
     int get_ring_tables(uint64_t *nonres, uint64_t *y);
     int synchronize();

@@ -16,6 +16,7 @@
 #include "../../include/lfhip.h"
 #include "bb_capi.h"
 #include "lf_common.h"
+#include "lf_dist.h"
 #include "lf_kernels.h"
 #include "lf_verify.h"
 
@@ -86,9 +87,11 @@ struct lf_ctx {
     u32 kappa = 0;
     size_t nA = 0, nA_total = 0, A_col0 = 0;
     // intra-step sharding: rank/world and the all-gather callback supplied by the host language
-    int sh_rank = 0, sh_world = 1;
-    lf_exchange_fn sh_cb = nullptr;
-    void *sh_user = nullptr;
+    int sh_rank = 0, sh_world = 1;   // mirror comm.rank / comm.world
+    // exchange layer, one per lane: the two lanes of a fold step exchange concurrently (lane 0: linearization rounds and right evaluations,
+    // lane 1: commits and left evaluations) and collectives of ONE communicator must be issued in the same order on every rank
+    lfdist::Comm comm[2];
+    lfdist::Comm &cm() { return comm[t_lane]; }
     // CCS
     bool have_ccs = false;
     lf_params P{};
@@ -314,6 +317,8 @@ void lf_ctx_destroy(lf_ctx *c) {
     for (int l = 0; l < 2; l++)
         if (c->h_round[l]) (void)hipHostFree(c->h_round[l]);
     if (c->ev_block) (void)hipEventDestroy(c->ev_block);
+    c->comm[0].destroy();
+    c->comm[1].destroy();
     if (c->tail_mail) (void)hipHostFree(c->tail_mail);
     if (c->tail_counters) (void)hipFree(c->tail_counters);
     if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
@@ -341,15 +346,66 @@ int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *use
     if (c->bb) return c->bb->set_sharding(rank, world, cb, user);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->dA) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
-    c->sh_rank = rank; c->sh_world = world; c->sh_cb = cb; c->sh_user = user;
+    for (int l = 0; l < 2; l++) {
+        c->comm[l].destroy();
+        c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = cb; c->comm[l].user = user;
+    }
+    c->sh_rank = rank; c->sh_world = world;
     return LF_OK;
 }
-// all-gather `words` canonical words from every rank and add them mod p (RCCL has no modular reduction)
+// all-gather `words` canonical words from every rank and add them mod p (RCCL has no modular reduction): host buffer ...
 static int exchange_modsum(lf_ctx *c, u64 *inout, size_t words) {
     if (c->sh_world <= 1) return LF_OK;
     std::vector<u64> all((size_t)c->sh_world * words);
-    if (c->sh_cb(c->sh_user, inout, all.data(), words) != 0) return LF_ERR_HIP;
+    RET(c->cm().allgather_host(inout, all.data(), words, c->stream()));
     return lf_modsum(all.data(), (size_t)c->sh_world, words, inout);
+}
+// ... and device buffer, ordered on the lane's stream (RCCL: no host synchronisation; the reduction is k_modsum)
+static int exchange_modsum_dev(lf_ctx *c, u64 *inout_dev, size_t words) {
+    if (c->sh_world <= 1 && !(c->tn.force_exchange && c->cm().nccl)) return LF_OK;   // LF_DIST_FORCE_EXCHANGE: a 1-rank communicator still runs the collectives (RCCL plumbing test on one GPU)
+    u64 *g;
+    RET(c->tbuf("sh_gather", (size_t)c->sh_world * words, &g));
+    RET(c->cm().allgather_dev(inout_dev, g, words, c->stream()));
+    launch_modsum(g, (u32)c->sh_world, words, inout_dev, c->stream());
+    return LF_OK;
+}
+int lf_dist_unique_id(uint8_t *id128) { return lfdist::rccl_unique_id(id128); }
+int lf_dist_init(lf_ctx *c, int rank, int world, const uint8_t *ids) {
+    if (!c || !ids || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->dist_init(rank, world, ids);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->dA) return LF_ERR_STATE;   // choose the sharding before loading/generating the Ajtai matrix
+    HIPCHK(hipSetDevice(c->device));
+    for (int l = 0; l < 2; l++) {
+        c->comm[l].destroy();
+        RET(lfdist::rccl_init(c->comm[l], rank, world, ids + 128 * l));
+    }
+    c->sh_rank = rank; c->sh_world = world;
+    return LF_OK;
+}
+// per-lane callbacks (host transport): the two lanes of a fold step exchange concurrently, so each needs its own ordered channel
+int lf_set_sharding_lanes(lf_ctx *c, int rank, int world, lf_exchange_fn cb0, void *user0, lf_exchange_fn cb1, void *user1) {
+    int rc = lf_set_sharding(c, rank, world, cb0, user0);
+    if (rc != LF_OK || !cb1) return rc;
+    if (c->bb) return LF_OK;   // the BabyBear driver exchanges from one thread only
+    std::lock_guard<std::mutex> g(c->mu);
+    c->comm[1].cb = cb1; c->comm[1].user = user1;
+    return LF_OK;
+}
+int lf_dist_stats(lf_ctx *c, uint64_t *n_exchanges, double *total_us, double *max_us, int reset) {
+    if (!c) return LF_ERR_INVALID;
+    lfdist::Comm *ms[2] = {c->bb ? c->bb->comm() : &c->comm[0], c->bb ? nullptr : &c->comm[1]};
+    uint64_t n = 0;
+    double tot = 0, mx = 0;
+    for (auto *m : ms)
+        if (m) {
+            n += m->n_exchanges; tot += m->us_total; mx = m->us_max > mx ? m->us_max : mx;
+            if (reset) { m->n_exchanges = 0; m->us_total = 0; m->us_max = 0; }
+        }
+    if (n_exchanges) *n_exchanges = n;
+    if (total_us) *total_us = tot;
+    if (max_us) *max_us = mx;
+    return LF_OK;
 }
 int lf_mem_info(lf_ctx *c, size_t *free_bytes, size_t *total_bytes) {
     if (!c || !free_bytes || !total_bytes) return LF_ERR_INVALID;
@@ -553,8 +609,28 @@ static int commit_dev(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, u64 *out_d
 }
 // download a (partial) commitment and, when sharded, all-gather + add the partials mod p
 static int commit_download(lf_ctx *c, const u64 *dev, size_t words, u64 *host) {
-    RET(down_small(c, dev, words, host));
-    return exchange_modsum(c, host, words);
+    RET(exchange_modsum_dev(c, (u64 *)dev, words));   // sharded: ncclAllGather of the partial commitments + k_modsum, in stream
+    return down_small(c, dev, words, host);
+}
+// index slice of this rank: [*i0, *i0 + *cnt) of n items (the last rank takes the remainder)
+static void shard_slice(const lf_ctx *c, size_t n, size_t *i0, size_t *cnt) {
+    size_t per = (n + (size_t)c->sh_world - 1) / (size_t)c->sh_world;
+    size_t lo = per * (size_t)c->sh_rank;
+    if (lo > n) lo = n;
+    *i0 = lo;
+    *cnt = lo + per > n ? n - lo : per;
+}
+// all-gather the ranks' column slices of `planes` tables stored with GLOBAL layout [plane][n] (rank g holds entries
+// [g*n/G, (g+1)*n/G) of every plane) and fill in the others' slices
+static int gather_slices(lf_ctx *c, u64 *buf, size_t planes, size_t n) {
+    const size_t Gw = (size_t)c->sh_world, lcl = n / Gw, words = planes * lcl;
+    u64 *gall, *gtmp;
+    RET(c->tbuf("sh_gather_tab", words * Gw, &gall));
+    RET(c->tbuf("sh_gather_tmp", words, &gtmp));
+    HIPCHK(hipMemcpy2DAsync(gtmp, lcl * 8, buf + (size_t)c->sh_rank * lcl, n * 8, lcl * 8, planes, hipMemcpyDeviceToDevice, c->stream()));
+    RET(c->cm().allgather_dev(gtmp, gall, words, c->stream()));
+    launch_gather_relayout(gall, (u32)Gw, planes, lcl, buf, c->stream());
+    return LF_OK;
 }
 int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
     if (!c || !f || !out || !batch) return LF_ERR_INVALID;
@@ -567,6 +643,7 @@ int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64
     RET(c->tbuf("io_a", batch * n * 24, &F));
     RET(c->tbuf("io_b", batch * c->kappa * 24, &o));
     for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * 24, n, F + b * 24 * n));
+    c->tn = Tunables::read((size_t)1 << 17);
     c->ev_reset();
     RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
     c->ev_collect();
@@ -1008,18 +1085,41 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     const u64 *cur = mz, *cure = eqb;
     size_t n = m;
     int flip = 0;
+    // Sharded rounds: rank g owns the entries [g*n/G, (g+1)*n/G) of every table (high index bits: pairs stay local), fixes
+    // and evaluates only those; the (deg+1)-element partial messages are all-gathered and added mod p on the device.  Below 64 pairs per
+    // rank the slices are gathered and the tail rounds are replicated.
+    const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
+    bool sharded = Gw > 1 && m / 2 >= Gw * 64;
+    u64 *od_dev = nullptr;
+    if (Gw > 1) RET(c->tbuf("lin_round_out", 5 * 24 + 8, &od_dev));
     for (u32 round = 1; round <= P.s; round++) {
         if (round > 1) {
             Fq3Const r = f3c(point[round - 2]);
-            launch_fix_many(c->dcrt, cur, n, fx[flip], n / 2, n, P.t * 8, r, c->stream());
-            launch_fix_many(c->dcrt, cure, n, fe[flip], n / 2, n, 1, r, c->stream());
+            if (sharded) {
+                const size_t e0 = gr * (n / Gw), ecnt = n / Gw;   // this rank's entries of the previous tables -> entries [e0/2, (e0+ecnt)/2)
+                launch_fix_many(c->dcrt, cur + e0, n, fx[flip] + e0 / 2, n / 2, ecnt, P.t * 8, r, c->stream());
+                launch_fix_many(c->dcrt, cure + e0, n, fe[flip] + e0 / 2, n / 2, ecnt, 1, r, c->stream());
+            } else {
+                launch_fix_many(c->dcrt, cur, n, fx[flip], n / 2, n, P.t * 8, r, c->stream());
+                launch_fix_many(c->dcrt, cure, n, fe[flip], n / 2, n, 1, r, c->stream());
+            }
             cur = fx[flip]; cure = fe[flip];
             flip ^= 1;
             n /= 2;
+            if (sharded && n / 2 < Gw * 64) {   // hand-over to the replicated tail
+                RET(gather_slices(c, (u64 *)cur, (size_t)P.t * 24, n));
+                RET(gather_slices(c, (u64 *)cure, 3, n));
+                sharded = false;
+            }
         }
-        launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->stream(), c->lin_blocks);
         u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * 24;
-        RET(c->lane_sync());                                  // the reduce kernel wrote the message into mapped host memory
+        if (sharded) {
+            const size_t p0 = gr * (n / 2 / Gw), pcnt = n / 2 / Gw;
+            launch_lin_round(c->dcrt, c->desc, cur + 2 * p0, n, cure + 2 * p0, n, 2 * pcnt, deg, partial, od_dev, c->stream(), c->lin_blocks);
+            RET(exchange_modsum_dev(c, od_dev, (size_t)(deg + 1) * 24));
+            HIPCHK(hipMemcpyAsync(od, od_dev, (size_t)(deg + 1) * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
+        } else launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->stream(), c->lin_blocks);
+        RET(c->lane_sync());                                  // the message is in mapped host memory
         memcpy(ev, od, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
@@ -1089,7 +1189,12 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72));
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;   // contiguous: v[3 ring] u[t ring]
-    launch_coef_eval(c->dcrt, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());   // T[24][3] flat == v[3][8 slots][3]
+    {   // T[24][3] flat == v[3][8 slots][3]; sharded: each rank sums its index slice, partial sums exchanged on the device
+        size_t i0, cnt;
+        shard_slice(c, c->N, &i0, &cnt);
+        launch_coef_eval(c->dcrt, wit->planes + i0, cnt, eqr + i0, m, 1, 0, partial, od, c->stream(), c->N);
+        RET(exchange_modsum_dev(c, od, 72));
+    }
     if (u_eval) {
         RET(down_small(c, od, 72, v));
         launch_dot_eq(c->dcrt, mz, m, P.t, eqr, m, m, partial, od, c->stream());
@@ -1205,7 +1310,12 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     size_t ph = c->ev_begin(12);
     compute_x_s(c, xh, x_s);
     // v_s (decomposition.rs:204-211) from the coefficient planes
-    launch_coef_eval(c->dcrt, wit->planes, N, eq_r, m, K, 1, partial, od, c->stream());
+    {
+        size_t i0, cnt;
+        shard_slice(c, N, &i0, &cnt);   // sharded: this rank's index slice; partial sums exchanged on the device
+        launch_coef_eval(c->dcrt, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od, c->stream(), N);
+        RET(exchange_modsum_dev(c, od, (size_t)K * 72));
+    }
     RET(down_small(c, od, (size_t)K * 72, v_s));
     // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     RET(build_z(c, wit->planes, K, 1, x_s, z));
@@ -1213,7 +1323,12 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
         launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->stream());
     u64 *dpart;
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
-    launch_dot_batch(c->dcrt, z, n, K, q, n, P.t, n, dpart, od, c->stream());
+    {
+        size_t c0, cnt;
+        shard_slice(c, n, &c0, &cnt);   // sharded: dot products over this rank's column slice of z_k and q_j
+        launch_dot_batch(c->dcrt, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od, c->stream());
+        RET(exchange_modsum_dev(c, od, (size_t)K * P.t * 24));
+    }
     RET(down_small(c, od, (size_t)K * P.t * 24, u_s));
     LF_TRACE(c, "decompose evals");
     c->ev_end(ph);
@@ -1357,6 +1472,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("round_partial", round_partial_words(), &partial));
     od = c->round_out();
     if (!od) return LF_ERR_HIP;
+    u64 *const od_host = od, *od_shard = nullptr;
+    if (c->sh_world > 1) {   // the round kernels of a sharded step leave their partial message in device memory (exchanged there)
+        RET(c->tbuf("fold_round_out", 5 * 24 + 8, &od_shard));
+        od = od_shard;
+    }
     for (int sd = 0; sd < 2; sd++) {
         // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}
         launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
@@ -1438,16 +1558,14 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                     size_t lcl = ldF / 2;  // local entries after this fix
                     launch_fix_many(c->dcrt, curF, ldF, fd, lcl, ldF, K2 * 3 * 8, r, c->stream());
                     size_t planes = (size_t)K2 * 3 * 24, words = planes * lcl;
-                    std::vector<u64> mine(words), all(words * Gw), full(planes * nn);
-                    HIPCHK(hipMemcpyAsync(mine.data(), fd, words * 8, hipMemcpyDeviceToHost, c->stream()));
-                    HIPCHK(hipStreamSynchronize(c->stream()));
-                    if (c->sh_cb(c->sh_user, mine.data(), all.data(), words) != 0) return LF_ERR_HIP;
-                    for (size_t rk = 0; rk < Gw; rk++)
-                        for (size_t w = 0; w < planes; w++)
-                            memcpy(&full[w * nn + rk * lcl], &all[rk * words + w * lcl], lcl * 8);
+                    // all-gather the ranks' slices on the device (RCCL over xGMI) and interleave them into full tables
+                    u64 *gall, *gtmp;
+                    RET(c->tbuf("sh_gather_tab", words * Gw, &gall));
+                    RET(c->tbuf("sh_gather_tmp", words, &gtmp));
+                    HIPCHK(hipMemcpyAsync(gtmp, fd, words * 8, hipMemcpyDeviceToDevice, c->stream()));   // fd is also the destination
+                    RET(c->cm().allgather_dev(gtmp, gall, words, c->stream()));
                     u64 *fo = fd;  // same parity as an ordinary fix output, so the ping-pong of the following rounds stays valid
-                    HIPCHK(hipMemcpyAsync(fo, full.data(), full.size() * 8, hipMemcpyHostToDevice, c->stream()));
-                    HIPCHK(hipStreamSynchronize(c->stream()));
+                    launch_gather_relayout(gall, (u32)Gw, planes, lcl, fo, c->stream());
                     curF = fo; ldF = nn;
                     sharded = false;
                     a.eqL = dst; a.eqR = dst + 3 * nn; a.eqB = dst + 6 * nn; a.G1 = dst + 9 * nn; a.G2 = dst + 33 * nn;
@@ -1542,9 +1660,12 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         c->ev_end(ev);
         LF_TRACE(c, "fold round");
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * 24;
+        if (od == od_shard) {   // sharded step: partial message in device memory -> all-gather + modular sum in stream -> host
+            if (sharded) RET(exchange_modsum_dev(c, od, (size_t)(deg + 1) * 24));
+            HIPCHK(hipMemcpyAsync(od_host, od, (size_t)(deg + 1) * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
+        }
         RET(c->lane_sync());                                  // message is in mapped host memory
-        memcpy(evs, od, (size_t)(deg + 1) * 24 * 8);
-        if (sharded) RET(exchange_modsum(c, evs, (size_t)(deg + 1) * 24));
+        memcpy(evs, od_host, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
         if (round == 1) TL_MARK("  round 1");
@@ -1579,11 +1700,21 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // 4 variables never materialise the tables, and LF_THETA_EVAL=1 keeps the stand-alone evaluation (masked +-eq sums).
     if (P.s >= 4 && curF && ldF == 2 && !c->tn.theta_eval) launch_fix_final(c->dcrt, curF, K2 * 3 * 8, f3c(pt[P.s - 1]), d_theta, c->stream());
     else
-        for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dcrt, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * 72, c->stream());
+    {
+        size_t i0, cnt;
+        shard_slice(c, N, &i0, &cnt);
+        for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dcrt, S[sd].planes + i0, cnt, eq0 + i0, m, K, 1, red, d_theta + (size_t)sd * K * 72, c->stream(), N);
+        RET(exchange_modsum_dev(c, d_theta, (size_t)K2 * 72));
+    }
     HIPCHK(hipMemcpyAsync(hp, d_theta, (size_t)K2 * 72 * 8, hipMemcpyDeviceToHost, c->stream()));
     if (!c->ev_theta) HIPCHK(hipEventCreateWithFlags(&c->ev_theta, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c->ev_theta, c->stream()));
-    for (int sd = 0; sd < 2; sd++) launch_dot_batch(c->dcrt, S[sd].z, n, K, q, n, P.t, n, dpart, d_eta + (size_t)sd * K * P.t * 24, c->stream());
+    {
+        size_t c0, cnt;
+        shard_slice(c, n, &c0, &cnt);
+        for (int sd = 0; sd < 2; sd++) launch_dot_batch(c->dcrt, S[sd].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta + (size_t)sd * K * P.t * 24, c->stream());
+        RET(exchange_modsum_dev(c, d_eta, (size_t)K2 * P.t * 24));
+    }
     HIPCHK(hipMemcpyAsync(hp + (size_t)K2 * 72, d_eta, (size_t)K2 * P.t * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventSynchronize(c->ev_theta));
     memcpy(theta, hp, (size_t)K2 * 72 * 8);
@@ -1759,6 +1890,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     t_tl = nullptr;
     c->ev_end(tot);
     c->ev_collect();
+    if (rc != LF_OK && c->sh_world > 1) { c->comm[0].abort_peers(); c->comm[1].abort_peers(); }   // peers blocked in a collective error out instead of waiting forever
     return rc;
 }
 

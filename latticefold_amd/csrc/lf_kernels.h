@@ -31,6 +31,10 @@ void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStre
 // columns [col0, col0+n) of the n_total-column matrix
 void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s);
 
+// sharded exchanges: modular sum of all-gathered partial vectors; re-layout of all-gathered table slices
+void launch_modsum(const u64 *parts, u32 nparts, size_t words, u64 *out, hipStream_t s);
+void launch_gather_relayout(const u64 *all, u32 nranks, size_t planes, size_t lcl, u64 *full, hipStream_t s);
+
 void launch_selftest_field(u64 seed, u32 n, u64 *mism_dev, hipStream_t s);  // arithmetic self-test, see lf_kernels.hip
 
 // ---- CRT / ICRT (a1, a2) ---------------------------------------------------------------------------------------
@@ -82,8 +86,9 @@ size_t dot_partial_words(u32 na, u32 nb);
 void launch_dot_eq(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *eq, size_t ldeq, size_t n, u64 *partial,
                    u64 *out, hipStream_t s);
 // T[k][c] = sum_i eq[i] * digit_k(planes[c][i]) (K bit-planes) or full value (mode_bits = 0): out AoS fq3 [K][24][3]
+// ldp = leading dimension of the planes (0: n); a rank of a sharded step passes its index slice (planes + i0, eq + i0, n = count)
 void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits,
-                      u64 *partial, u64 *out, hipStream_t s);
+                      u64 *partial, u64 *out, hipStream_t s, size_t ldp = 0);
 size_t coef_eval_partial_words(u32 K);
 // zz_j = sum_k coef[k][j] * z_k  (fq3 scalars; z tables [K][24][ldz]) -> out [t][24][ldz]
 // per_slot != 0: coef_dev holds K*tt*8 constants, one per slot (ring-element coefficients, folding.rs:258-268)

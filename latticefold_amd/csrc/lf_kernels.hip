@@ -71,6 +71,29 @@ __global__ void __launch_bounds__(256) k_reduce_rows(const u64 *partial, u32 nbl
     block_sum_store<1>(acc, out + i);
 }
 
+// sharded exchanges: out[w] = sum_g parts[g*words + w] mod p after the all-gather of the ranks' partial vectors
+__global__ void __launch_bounds__(256) k_modsum(const u64 *parts, u32 nparts, size_t words, u64 *out) {
+    size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= words) return;
+    u64 acc = 0;
+    for (u32 g = 0; g < nparts; g++) acc = fq_add(acc, fq_canon(parts[(size_t)g * words + w]));
+    out[w] = acc;
+}
+void launch_modsum(const u64 *parts, u32 nparts, size_t words, u64 *out, hipStream_t s) {
+    if (words) hipLaunchKernelGGL(k_modsum, dim3(cdiv(words, 256)), dim3(256), 0, s, parts, nparts, words, out);
+}
+// all-gathered table slices [rank][plane][lcl] -> full tables [plane][nranks*lcl]
+__global__ void __launch_bounds__(256) k_gather_relayout(const u64 *all, u32 nranks, size_t planes, size_t lcl, u64 *full) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, tot = (size_t)nranks * planes * lcl;
+    if (i >= tot) return;
+    size_t j = i % lcl, w = (i / lcl) % planes, rk = i / (lcl * planes);
+    full[w * (nranks * lcl) + rk * lcl + j] = all[i];
+}
+void launch_gather_relayout(const u64 *all, u32 nranks, size_t planes, size_t lcl, u64 *full, hipStream_t s) {
+    size_t tot = (size_t)nranks * planes * lcl;
+    if (tot) hipLaunchKernelGGL(k_gather_relayout, dim3(cdiv(tot, 256)), dim3(256), 0, s, all, nranks, planes, lcl, full);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // layout
 __global__ void __launch_bounds__(256) k_aos_to_soa(const u64 *aos, u64 *soa, size_t n) {
@@ -919,7 +942,7 @@ void launch_dot_eq(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 
 // KG bit-planes per thread: the kernel is bound by the cache traffic of eq (every (coefficient, plane-group) block streams it
 // again), so one thread takes all K <= 16 planes of its coefficient and eq is read once per (coefficient, element).
 template <int KG>
-__global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits,
+__global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t ldp, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits,
                                                    u64 *partial) {
     // grid (RED_BLOCKS, 24 coefficients, K-groups of KG bit-planes)
     u32 c = blockIdx.y, kg = blockIdx.z * KG;
@@ -928,7 +951,7 @@ __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t
 #pragma unroll
     for (int i = 0; i < 3 * KG; i++) { acc[i] = 0; cy[i] = 0; }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        int32_t v = planes[(size_t)c * n + i];
+        int32_t v = planes[(size_t)c * ldp + i];
         u64 e[3] = {eq[i], eq[ldeq + i], eq[2 * ldeq + i]};
         bool neg = v < 0;
         u32 mg = (u32)(neg ? -v : v);
@@ -969,11 +992,12 @@ __global__ void __launch_bounds__(256) k_coef_eval(const int32_t *planes, size_t
 }
 size_t coef_eval_partial_words(u32 K) { return (size_t)RED_BLOCKS * K * 72; }
 void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial,
-                      u64 *out, hipStream_t s) {
+                      u64 *out, hipStream_t s, size_t ldp) {
+    if (!ldp) ldp = n;
     u32 gb = (u32)((n + 255) / 256);
     if (gb > 64) gb = 64;   // >= 64 elements per thread at 2^20: the 12-value block reduction is a third of the work otherwise
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(k_coef_eval<4>, dim3(gb, 24, mode_bits ? (K + 3) / 4 : 1), dim3(256), 0, s, planes, n, eq, ldeq, K, mode_bits, partial);
+    hipLaunchKernelGGL(k_coef_eval<4>, dim3(gb, 24, mode_bits ? (K + 3) / 4 : 1), dim3(256), 0, s, planes, ldp, n, eq, ldeq, K, mode_bits, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(K * 72), dim3(256), 0, s, partial, gb, K * 72, out);
 }
 

@@ -43,6 +43,26 @@ def sharded_commit(scheme_shard, f_shard, group=None):
     return allgather_modsum(scheme_shard.commit_ntt(f_shard), group, scheme_shard.ctx.ring if hasattr(scheme_shard.ctx, "ring") else "goldilocks")
 
 
+def init_sharding(ctx, rank, world, transport="auto"):
+    """Put `ctx` into intra-step sharding mode over the default torch.distributed process group.
+    transport "rccl": the library's own RCCL communicators (lf_dist_init; device buffers, no Python in the data path) -- the ids are
+    created on rank 0 and broadcast through torch.distributed; "host": torch.distributed all_gather through a Python callback, one
+    process group per lane (gloo in the CPU/one-GPU tests); "auto": rccl when the backend is nccl, else host."""
+    import torch
+    import torch.distributed as dist
+    if transport == "auto":
+        transport = "rccl" if dist.get_backend() == "nccl" else "host"
+    if transport == "rccl":
+        ids = [api.dist_unique_ids() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.dist_init(rank, world, ids[0])
+    else:
+        g0, g1 = dist.new_group(), dist.new_group()   # collective calls: every rank creates both groups in the same order
+        ctx.set_sharding(rank, world, make_allgather(g0), make_allgather(g1))
+        ctx._lf_groups = (g0, g1)
+    return transport
+
+
 def make_allgather(group=None):
     """all-gather of a uint64 vector for Context.set_sharding: RCCL on device tensors with backend "nccl", host tensors with gloo."""
     import torch

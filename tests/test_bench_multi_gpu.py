@@ -40,6 +40,59 @@ def test_bench_two_ranks_one_gpu(mode, workload):
     assert abs(d["value"] - (2 if mode == "replicas" else 1) * per_rank) / d["value"] < 1e-6
 
 
+def test_bench_default_for_n_gpus_is_the_sharded_config():
+    """`bench.py --gpus 2` with no --parallelism runs BASELINE configs[3]'s shape: ONE fold stream sharded over the ranks
+    (strong scaling), logs its exchanges and reports the replicas rate of the same GPUs as an extra key"""
+    env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "T14"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("shard x2")
+    assert d["exchanges"]["exchanges_per_step"] > 10 and d["exchanges"]["transport"] == "host"
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
+
+
+def test_rccl_transport_single_rank_forced_exchanges():
+    """the library's own RCCL transport (lf_dist_init: dlopen'ed librccl, ncclCommInitRank, in-stream ncclAllGather on device buffers
+    + k_modsum) on the one GPU this box has: a 1-rank communicator with LF_DIST_FORCE_EXCHANGE=1 runs every exchange of a sharded
+    fold step; the proof must equal the unsharded one (RCCL refuses two ranks on one device, so multi-rank runs use the host
+    transport in tests/test_dist_shard.py)"""
+    code = """
+import os, sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+from latticefold_amd import api
+from latticefold_amd.workload import make_workload
+def run(rccl):
+    wl = make_workload("T12")
+    ctx = api.Context(0)
+    if rccl:
+        ctx.dist_init(0, 1, api.dist_unique_ids())
+        os.environ["LF_DIST_FORCE_EXCHANGE"] = "1"
+    ctx.load_ccs(wl)
+    scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+    lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+    n = ctx.dist_stats()[0]
+    h = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in (cccs, acc, lc, proof, w0.f_coeff))).hexdigest()
+    os.environ.pop("LF_DIST_FORCE_EXCHANGE", None)
+    ctx.close()
+    return h, n
+a, _ = run(False)
+b, n = run(True)
+print(json.dumps({"same": a == b, "exchanges": n}))
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["same"] and d["exchanges"] >= 8, d
+
+
 def test_bench_streams_mode_single_rank():
     """opt-in throughput mode: 2 independent fold streams on one GPU from one process"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "T12", "--streams", "2",

@@ -28,7 +28,7 @@ WORKER = textwrap.dedent('''
             ctx = api.Context(0, ring=wl.ring)
             tr = lambda: api.PoseidonTranscript(ring=wl.ring)
             if sharded:
-                ctx.set_sharding(rank, world, lfd.make_allgather())
+                lfd.init_sharding(ctx, rank, world, os.environ.get("LF_TRANSPORT", "host"))
             ctx.load_ccs(wl)
             scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
             wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
