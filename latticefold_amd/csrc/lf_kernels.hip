@@ -997,7 +997,11 @@ void launch_coef_eval(const DevCrt &t, const int32_t *planes, size_t n, const u6
     u32 gb = (u32)((n + 255) / 256);
     if (gb > 64) gb = 64;   // >= 64 elements per thread at 2^20: the 12-value block reduction is a third of the work otherwise
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(k_coef_eval<4>, dim3(gb, 24, mode_bits ? (K + 3) / 4 : 1), dim3(256), 0, s, planes, ldp, n, eq, ldeq, K, mode_bits, partial);
+    static int kg = -1;
+    if (kg < 0) { const char *e = getenv("LF_COEF_KG"); kg = e ? atoi(e) : 8; }   // planes per thread: 8 halves the HBM re-reads of the 4-plane version at the same speed (16 spills into the latency chain: slower)
+    if (mode_bits && kg == 16) hipLaunchKernelGGL(k_coef_eval<16>, dim3(gb, 24, (K + 15) / 16), dim3(256), 0, s, planes, ldp, n, eq, ldeq, K, mode_bits, partial);
+    else if (mode_bits && kg == 8) hipLaunchKernelGGL(k_coef_eval<8>, dim3(gb, 24, (K + 7) / 8), dim3(256), 0, s, planes, ldp, n, eq, ldeq, K, mode_bits, partial);
+    else hipLaunchKernelGGL(k_coef_eval<4>, dim3(gb, 24, mode_bits ? (K + 3) / 4 : 1), dim3(256), 0, s, planes, ldp, n, eq, ldeq, K, mode_bits, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(K * 72), dim3(256), 0, s, partial, gb, K * 72, out);
 }
 

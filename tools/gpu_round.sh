@@ -1,0 +1,19 @@
+#!/bin/bash
+# (GPU box) the judged artefacts of a round: default bench line (C4 with cpu_baseline), C2 / C3 lines, rocprofv3 kernel stats of the
+# same command, HBM traffic from separate PMC passes.  usage: tools/gpu_round.sh <tag>   -> gpurun_out/<tag>_*
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+tag=${1:-r02}
+mkdir -p $R/gpurun_out
+python $R/bench.py > $R/gpurun_out/${tag}_bench_c4.json 2> $R/gpurun_out/${tag}_bench_c4.err
+python $R/bench.py --workload C2 --steps 20 --warmup 3 > $R/gpurun_out/${tag}_bench_c2.json 2>/dev/null
+python $R/bench.py --workload C3 --steps 5 --warmup 2 > $R/gpurun_out/${tag}_bench_c3.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+for wl in C4 C3; do
+  rm -rf /tmp/prof_$wl
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -o p -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline >/dev/null 2>&1
+  f=$(find /tmp/prof_$wl -name '*kernel_stats.csv' | head -1)
+  cp "$f" $R/gpurun_out/${tag}_$(echo $wl | tr A-Z a-z)_kernel_stats.csv
+done
+bash $R/tools/gpu_pmc.sh $tag C4
+bash $R/tools/gpu_pmc.sh $tag C3
+LF_TIMELINE=1 python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline 2>&1 | grep timeline | tail -32 > $R/gpurun_out/${tag}_timeline_c4.txt
