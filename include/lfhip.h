@@ -187,6 +187,14 @@ void lf_poseidon_permute(uint64_t *state, int plain);
 void lf_poseidon_params_ring(uint64_t *ark, uint64_t *mds, int ring);
 void lf_poseidon_permute_ring(uint64_t *state, int plain, int ring);
 
+/* PoseidonSponge on the DEVICE (Goldilocks): runs a script of absorb / squeeze operations on a fresh sponge in one
+ * wave -- ops[i] = (kind << 24) | count, kind 0 = absorb the next `count` words of absorb_words, 1 = squeeze `count` words.  Same
+ * duplex semantics as lf_transcript_* (transcript/poseidon.rs:29-75); pinned by the reference's challenge KATs.  state_out (optional):
+ * 24 state words, rate index, mode.  The fold step's default transcript is the host one (a permutation is a serial chain: ~20 us on
+ * a GPU wave, 1.5 us on a host core); LF_DEVICE_TRANSCRIPT=1 moves the tail rounds' transcript into the persistent kernel. */
+int lf_device_sponge(lf_ctx *, const uint32_t *ops, size_t nops, const uint64_t *absorb_words, size_t n_words, uint64_t *squeezed_out,
+                     size_t n_out, uint64_t *state_out);
+
 /* ---- sumcheck split at the transcript (utils/sumcheck.rs:53-80, sumcheck/prover.rs:56-162) ---------
  * Generic entry for the linearization-shaped polynomial  comb = (sum_i c_i prod_{j in S_i} T_j) * T_last
  * over t ring tables + one slot-constant table: begin / round / end.  Rounds must be called in order;

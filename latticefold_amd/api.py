@@ -137,6 +137,7 @@ def _lib():
         L.lf_sumcheck_lin_end.argtypes = [vp]
         L.lf_linearize.argtypes = [vp, vp, u64p, vp, u64p, u64p]
         L.lf_fold_step.argtypes = [vp, vp, u64p, vp, u64p, vp, u64p, C.POINTER(vp), u64p]
+        L.lf_device_sponge.argtypes = [vp, u32p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u64p]
         L.lf_sumcheck_fold_begin.argtypes = [vp, u64p, u64p]
         L.lf_sumcheck_fold_round.argtypes = [vp, u64p, u64p]
         L.lf_sumcheck_fold_end.argtypes = [vp]
@@ -675,3 +676,29 @@ def horner_combine(ctx, tables, challenges):
     o = np.zeros((ln, ctx.RE), dtype=np.uint64)
     _chk(_lib().lf_horner_combine(ctx.h, t.ctypes.data_as(u64p), g, pg, ln, p, o.ctypes.data_as(u64p)), "lf_horner_combine")
     return o
+
+
+def device_sponge(ctx, ops):
+    """PoseidonSponge on the device (lf_device_sponge): ops = list of ("absorb", words) / ("squeeze", n) on a fresh sponge.
+    Returns (list of squeezed arrays, state[26])."""
+    codes, words, nout = [], [], 0
+    for kind, arg in ops:
+        if kind == "absorb":
+            a = np.ascontiguousarray(arg, dtype=np.uint64).reshape(-1)
+            codes.append(a.size)
+            words.append(a)
+        else:
+            codes.append((1 << 24) | int(arg))
+            nout += int(arg)
+    cw = np.array(codes, dtype=np.uint32)
+    w = np.concatenate(words) if words else np.zeros(0, dtype=np.uint64)
+    out = np.zeros(max(nout, 1), dtype=np.uint64)
+    st = np.zeros(26, dtype=np.uint64)
+    _chk(_lib().lf_device_sponge(ctx.h, cw.ctypes.data_as(u32p), cw.size, w.ctypes.data_as(u64p), w.size, out.ctypes.data_as(u64p), nout,
+                                 st.ctypes.data_as(u64p)), "lf_device_sponge")
+    res, o = [], 0
+    for kind, arg in ops:
+        if kind != "absorb":
+            res.append(out[o:o + int(arg)].copy())
+            o += int(arg)
+    return res, st

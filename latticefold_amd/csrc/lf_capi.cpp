@@ -161,6 +161,16 @@ struct lf_ctx {
         memset(tail_mail, 0, sizeof(TailMail));
         return LF_OK;
     }
+    u64 *d_poseidon = nullptr;   // device copy of the Poseidon constants: ark [720] then mds [576]
+    int poseidon_setup() {
+        if (d_poseidon) return LF_OK;
+        const u64 *a, *m;
+        Transcript::params(&a, &m);
+        HIPCHK(hipMalloc((void **)&d_poseidon, (720 + 576) * 8));
+        HIPCHK(hipMemcpy(d_poseidon, a, 720 * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_poseidon + 720, m, 576 * 8, hipMemcpyHostToDevice));
+        return LF_OK;
+    }
     hipEvent_t ev_theta = nullptr;
     hipEvent_t ev_block = nullptr;   // hipEventBlockingSync: lane 1 (long waits) yields its CPU instead of spinning
     int lane_sync() {
@@ -321,6 +331,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     c->comm[1].destroy();
     if (c->tail_mail) (void)hipHostFree(c->tail_mail);
     if (c->tail_counters) (void)hipFree(c->tail_counters);
+    if (c->d_poseidon) (void)hipFree(c->d_poseidon);
     if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
@@ -1385,6 +1396,17 @@ static int fold_tail_rounds(lf_ctx *c, Transcript &tr, const FoldRoundArgs &a, u
     if (++c->tail_epoch >= (1u << 30)) c->tail_epoch = 1;
     A.epoch = c->tail_epoch;
     A.r_first = f3c(pt[round - 2]);
+    A.dev_transcript = c->tn.device_transcript ? 1u : 0u;
+    A.pos_ark = A.pos_mds = nullptr; A.sponge_state = nullptr;
+    if (A.dev_transcript) {   // LF_DEVICE_TRANSCRIPT=1: hand the sponge to the device for the tail rounds
+        RET(c->poseidon_setup());
+        A.pos_ark = c->d_poseidon; A.pos_mds = c->d_poseidon + 720;
+        A.sponge_state = c->tail_dev_chal + 4 * TAIL_MAX_ROUNDS;   // behind the published challenges (same 4 KB scratch)
+        u64 st[26];
+        tr.get_state(st);
+        HIPCHK(hipMemcpyAsync(A.sponge_state, st, sizeof(st), hipMemcpyHostToDevice, c->stream()));
+        HIPCHK(hipStreamSynchronize(c->stream()));   // st is a stack buffer
+    }
     TailMail *mail = c->tail_mail;
     if (launch_fold_tail(c->dcrt, A, c->num_cus, c->stream()) == 0) return LF_ERR_UNSUPPORTED;
     if (hipGetLastError() != hipSuccess) return LF_ERR_HIP;
@@ -1408,10 +1430,12 @@ static int fold_tail_rounds(lf_ctx *c, Transcript &tr, const FoldRoundArgs &a, u
         u64 *evs = msgs + (size_t)(round + i - 1) * (deg + 1) * 24;
         memcpy(evs, (const void *)mail->msg[i], (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
-        Fq3 r = sc_round_transcript(tr, evs, deg + 1);
+        Fq3 r;
+        if (A.dev_transcript) r = fq3_make(mail->chal_out[i][0], mail->chal_out[i][1], mail->chal_out[i][2]);   // drawn by the device sponge
+        else r = sc_round_transcript(tr, evs, deg + 1);
         pt[round + i - 1] = r;
         if (t_tl && t_tl->on) { static const char *nm[] = {"   tail r0", "   tail r1", "   tail r2", "   tail r3", "   tail r4", "   tail r5", "   tail r6", "   tail r7", "   tail r8", "   tail r9", "   tail r10", "   tail r11", "   tail r12", "   tail r13"}; if (i < 14) TL_MARK(nm[i]); }
-        if (i + 1 < nr) {
+        if (i + 1 < nr && !A.dev_transcript) {
             mail->chal[i][0] = r.c[0]; mail->chal[i][1] = r.c[1]; mail->chal[i][2] = r.c[2];
             __atomic_store_n(&mail->chal_seq[i], A.epoch, __ATOMIC_RELEASE);
         }
@@ -1425,6 +1449,7 @@ static int fold_tail_rounds(lf_ctx *c, Transcript &tr, const FoldRoundArgs &a, u
                     (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0, ((double)d[5] - (double)d[4]) / 100.0, (d[6] - d[5]) / 100.0, (d[7] - d[6]) / 100.0);
         }
 #endif
+    if (A.dev_transcript) tr.set_state((const u64 *)mail->sponge);   // the host transcript continues where the device sponge stopped
     if (t_tl && t_tl->on) fprintf(stderr, "[timeline]    tail: %u rounds, host transcript %.1f us, waiting for the GPU %.1f us\n", nr, host_us, wait_us);
     return LF_OK;
 }
@@ -2015,6 +2040,40 @@ int lf_sumcheck_lin_end(lf_ctx *c) {
     if (c->bb) return c->bb->sumcheck_lin_end();
     std::lock_guard<std::mutex> g(c->mu);
     c->sc_round = -1;
+    return LF_OK;
+}
+
+// PoseidonSponge on the device: a script of absorb / squeeze operations on a fresh sponge, one wave.  ops[i] =
+// (kind << 24) | count: kind 0 absorbs the next `count` words of absorb_words, kind 1 squeezes `count` words into squeezed_out.
+// state_out (optional, 26 words): the 24 state words, the rate index and the mode (1 = squeezing) afterwards.
+int lf_device_sponge(lf_ctx *c, const uint32_t *ops, size_t nops, const uint64_t *absorb_words, size_t n_words, uint64_t *squeezed_out,
+                     size_t n_out, uint64_t *state_out) {
+    if (!c || !ops || !nops || (!absorb_words && n_words) || (!squeezed_out && n_out)) return LF_ERR_INVALID;
+    if (c->bb) return LF_ERR_UNSUPPORTED;   // the BabyBear transcript stays on the host
+    size_t na = 0, ns = 0;
+    for (size_t i = 0; i < nops; i++) {
+        if ((ops[i] >> 24) > 1) return LF_ERR_INVALID;
+        ((ops[i] >> 24) ? ns : na) += ops[i] & 0xffffff;
+    }
+    if (na != n_words || ns != n_out) return LF_ERR_INVALID;
+    for (size_t i = 0; i < n_words; i++)
+        if (absorb_words[i] >= LF_P) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    RET(c->poseidon_setup());
+    u64 *dw, *dout;
+    u32 *dops;
+    RET(c->tbuf("sp_words", n_words + 8, &dw));
+    RET(c->tbuf("sp_out", n_out + 32, &dout));
+    RET(c->tbuf("sp_ops", nops + 8, &dops));
+    if (n_words) HIPCHK(hipMemcpyAsync(dw, absorb_words, n_words * 8, hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipMemcpyAsync(dops, ops, nops * 4, hipMemcpyHostToDevice, c->stream()));
+    launch_sponge_script(c->d_poseidon, c->d_poseidon + 720, dops, (u32)nops, dw, dout, dout + n_out, c->stream());
+    std::vector<u64> h(n_out + 26);
+    HIPCHK(hipMemcpyAsync(h.data(), dout, (n_out + 26) * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    if (n_out) memcpy(squeezed_out, h.data(), n_out * 8);
+    if (state_out) memcpy(state_out, h.data() + n_out, 26 * 8);
     return LF_OK;
 }
 

@@ -75,6 +75,9 @@ class Transcript {
     static void permute_scalar(u64 st[24]); // the same factorisation, scalar (reference for the SIMD path)
     static void permute_plain(u64 st[24]);  // textbook definition, for the self-test
     static void params(const u64 **ark, const u64 **mds);
+    // sponge state hand-over to / from the device sponge (lf_kernels.hip): 24 state words, rate index, mode (1 = squeezing)
+    void get_state(u64 out[26]) const { for (int i = 0; i < 24; i++) out[i] = st_[i]; out[24] = (u64)idx_; out[25] = squeezing_ ? 1 : 0; }
+    void set_state(const u64 in[26]) { for (int i = 0; i < 24; i++) st_[i] = in[i]; idx_ = (int)in[24]; squeezing_ = in[25] != 0; }
 
   private:
     void squeeze(u64 *out, size_t n);

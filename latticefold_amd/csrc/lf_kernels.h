@@ -164,6 +164,9 @@ void launch_fold_round_lut_fix(const DevCrt &t, const FoldRoundArgs &a, const in
                                u64 *out, hipStream_t s);
 size_t round_partial_words();
 
+// ---- Poseidon sponge on the device (one wave per sponge; ark [30][24], mds [24][24] canonical words in device memory) ----------
+void launch_sponge_script(const u64 *ark, const u64 *mds, const u32 *ops, u32 nops, const u64 *words, u64 *out, u64 *state_out, hipStream_t s);
+
 // ---- persistent sumcheck tail (no host hop per round; see k_fold_tail) ------------------------------------------------
 constexpr u32 TAIL_MAX_ROUNDS = 32;
 struct TailMail {   // host-mapped mailbox (hipHostMallocMapped): GPU -> host round messages, host -> GPU challenges
@@ -173,6 +176,8 @@ struct TailMail {   // host-mapped mailbox (hipHostMallocMapped): GPU -> host ro
     u32 chal_seq[TAIL_MAX_ROUNDS];
     u32 abort_seq;                     // host: = epoch to make the kernel give up
     u32 err;                           // device: = epoch when a wait timed out
+    u64 chal_out[TAIL_MAX_ROUNDS][4];  // device-transcript mode: the challenge the device sponge drew after tail round i (for the host's record)
+    u64 sponge[32];                    // device-transcript mode: the sponge after the last round (24 state words, rate index, mode)
     u64 dbg[TAIL_MAX_ROUNDS][8];       // LF_TAIL_DEBUG builds: wall-clock stamps (100 MHz) of the round's stages
 };
 struct FoldTailArgs {
@@ -188,6 +193,10 @@ struct FoldTailArgs {
     TailMail *mail;       // device address of the mapped mailbox
     u32 epoch;            // > 0, different for every launch
     Fq3Const r_first;     // challenge answering the round before the tail
+    // LF_DEVICE_TRANSCRIPT=1: the Fiat-Shamir transcript of the tail rounds runs on the device (sponge_*_wave): no host round trip at all
+    u32 dev_transcript;
+    const u64 *pos_ark, *pos_mds;   // Poseidon constants in device memory
+    u64 *sponge_state;    // device [26]: the sponge when the tail starts (written by the host), updated every round
 };
 constexpr u32 FOLD_TAIL_MAX_BLOCKS = 256;
 size_t fold_tail_eqpriv_words(size_t n0, u32 K);

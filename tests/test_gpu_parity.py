@@ -269,6 +269,14 @@ def test_fold_step_persistent_tail_matches_oracle(ctx, name, monkeypatch):
             monkeypatch.delenv("LF_FOLD_LUT_MIN")
             monkeypatch.delenv("LF_FOLD_FUSE_MIN")
         assert (proof == proof_o).all() and (lc == lc_o).all() and (w.f == f0_o).all(), (tail_n, lut)
+    # the tail rounds' Fiat-Shamir transcript on the DEVICE sponge (no host round trip at all); the host transcript
+    # takes the sponge back afterwards (theta / eta absorbs, rho challenges), so any divergence shows in the proof and the folded instance
+    monkeypatch.setenv("LF_DEVICE_TRANSCRIPT", "1")
+    for tail_n in ("16384", "16"):
+        monkeypatch.setenv("LF_TAIL_N", tail_n)
+        lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        assert (proof == proof_o).all() and (lc == lc_o).all() and (w.f == f0_o).all(), ("device transcript", tail_n)
+    monkeypatch.delenv("LF_DEVICE_TRANSCRIPT")
     # twice in a row on the same context (mailbox epochs, self-resetting counters)
     monkeypatch.setenv("LF_TAIL_N", "16384")
     for _ in range(3):
