@@ -94,7 +94,8 @@ int lf_linf_check(lf_ctx *, const uint64_t *f_ntt, size_t count, uint64_t bound,
                   uint64_t *max_out);
 
 /* ---- a5: AjtaiCommitmentScheme::{new, commit, commit_ntt} (commitment_scheme.rs:23-77) -------- */
-/* kappa <= 48 (Goldilocks) / 32 (BabyBear): one LDS tile holds kappa + batch rows; larger -> LF_ERR_INVALID */
+/* kappa <= 128 (Goldilocks: more than 48 rows of A are committed in equal row chunks, one LDS tile each) / 32 (BabyBear);
+ * larger -> LF_ERR_INVALID */
 int lf_ajtai_load(lf_ctx *, const uint64_t *A /* kappa*n ring elements, row-major, NTT form */, size_t kappa, size_t n);
 /* synthetic i.i.d. matrix generated on the device (bench; same stream as workload.Workload.ajtai_matrix) */
 int lf_ajtai_generate(lf_ctx *, uint64_t seed, size_t kappa, size_t n);

@@ -566,7 +566,7 @@ static int shard_columns(lf_ctx *c, size_t n, size_t *col0, size_t *cnt) {
     return LF_OK;
 }
 int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
-    if (!c || !A || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
+    if (!c || !A || !kappa || !n || kappa > 128) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ajtai_load(A, kappa, n);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
@@ -581,7 +581,7 @@ int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
     return LF_OK;
 }
 int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
-    if (!c || !kappa || !n || kappa > 48) return LF_ERR_INVALID;
+    if (!c || !kappa || !n || kappa > 128) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ajtai_generate(seed, kappa, n);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
@@ -604,17 +604,26 @@ static u32 ajtai_splits(size_t n) {
 }
 // F: [batch][24][ldF] device, pointing at this rank's first column; out_dev: [batch][kappa][24] device AoS (PARTIAL when sharded)
 static int commit_dev(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
-    u32 maxb = 448 / c->kappa;
-    if (maxb > 64 - c->kappa) maxb = 64 - c->kappa;
+    // One LDS tile holds the (A, F) rows of a launch: at most 48 rows of A (kappa up to 128 -- the reference's Goldilocks rows go up to
+    // kappa = 99, benches/config.toml:158 -- is cut into equal row chunks) and as many witnesses as fit next to them.
+    const u32 nch = (c->kappa + 47) / 48, kc = (c->kappa + nch - 1) / nch;
+    u32 maxb = 448 / kc;
+    if (maxb > 64 - kc) maxb = 64 - kc;
     if (maxb < 1) return LF_ERR_UNSUPPORTED;
     u32 splits = ajtai_splits(c->nA);
-    u64 *partial;
-    RET(c->tbuf("ajtai_partial", ajtai_partial_words(c->kappa, maxb, splits), &partial));
-    for (u32 b0 = 0; b0 < batch; b0 += maxb) {
-        u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
-        size_t ev = timed ? c->ev_begin(1) : 0;
-        launch_ajtai(c->dcrt, c->dA, c->kappa, c->nA, F + (size_t)b0 * 24 * ldF, ldF, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * 24, c->stream());
-        if (timed) c->ev_end(ev);
+    u64 *partial, *tmp = nullptr;
+    RET(c->tbuf("ajtai_partial", ajtai_partial_words(kc, maxb, splits), &partial));
+    if (nch > 1) RET(c->tbuf("ajtai_chunk_out", (size_t)maxb * kc * 24, &tmp));
+    for (u32 i0 = 0; i0 < c->kappa; i0 += kc) {
+        const u32 kn = c->kappa - i0 < kc ? c->kappa - i0 : kc;
+        for (u32 b0 = 0; b0 < batch; b0 += maxb) {
+            u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
+            size_t ev = timed ? c->ev_begin(1) : 0;
+            u64 *dst = nch > 1 ? tmp : out_dev + (size_t)b0 * c->kappa * 24;
+            launch_ajtai(c->dcrt, c->dA + (size_t)i0 * 24 * c->nA, kn, c->nA, F + (size_t)b0 * 24 * ldF, ldF, nb, splits, partial, dst, c->stream());
+            if (nch > 1) launch_scatter_rows(tmp, nb, kn, c->kappa, i0, out_dev + (size_t)b0 * c->kappa * 24, c->stream());
+            if (timed) c->ev_end(ev);
+        }
     }
     return LF_OK;
 }
@@ -760,7 +769,7 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
                 const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *cc) {
     if (!c || !p || !rowptr || !col || !val || !S_off || !S_idx || !cc) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ccs_load(p, rowptr, col, val, S_off, S_idx, cc);
-    if (p->s < 3 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 16 || p->L == 0 || p->L > 8 ||
+    if (p->s < 3 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 31 || p->L == 0 || p->L > 8 ||
         p->d + 1 > 4 || p->wit_len == 0)
         return LF_ERR_UNSUPPORTED;
     if (p->b != 2) return LF_ERR_UNSUPPORTED;  // folding comb is specialised to b = 2 (all reference Goldilocks rows)
@@ -1310,7 +1319,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24, *x_s = v_s + (size_t)K * 72;
     u64 *partial, *od, *z, *q;
     RET(c->tbuf("red_partial", 256 * 4096, &partial));
-    RET(c->tbuf("dec_small", 16 * 72 + 16 * 4 * 24 + 64, &od));
+    RET(c->tbuf("dec_small", 32 * 72 + 32 * 4 * 24 + 64, &od));
     RET(c->tbuf("z_" + sd, (size_t)K * 24 * n, &z));
     RET(c->tbuf("dec_q", (size_t)P.t * 24 * n, &q));
     if (!eq_r) {
@@ -1709,7 +1718,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("fold_eq0", 3 * m, &eq0));
     RET(c->tbuf("dec_q", (size_t)P.t * 24 * n, &q));
     RET(c->tbuf("red_partial", 256 * 4096, &red));
-    RET(c->tbuf("dec_small", 16 * 72 + 16 * 4 * 24 + 64, &sm));
+    RET(c->tbuf("dec_small", 32 * 72 + 32 * 4 * 24 + 64, &sm));
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
     for (u32 j = 0; j < P.t; j++)

@@ -61,6 +61,8 @@ void launch_linf(const u64 *coef, size_t n, u64 *out_max, hipStream_t s);
 // ---- Ajtai commit (a5) -----------------------------------------------------------------------------------------
 // partial[split][slot][i][k][3]; then reduce -> out AoS-ish [k][i][24] (device), canonical
 size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits);
+// row-chunked commits (kappa > 48): tmp [batch][kc][24] -> out [batch][kappa][24] at row i0
+void launch_scatter_rows(const u64 *tmp, u32 batch, u32 kc, u32 kappa, u32 i0, u64 *out, hipStream_t s);
 void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits,
                   u64 *partial, u64 *out, hipStream_t s);
 

@@ -855,6 +855,7 @@ void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, con
 // ---------------------------------------------------------------------------------------------------------
 // batched inner products (evaluate_mles, utils/mle_helpers.rs:65-88, restructured as dot products)
 constexpr u32 RED_BLOCKS = 256;
+constexpr u32 DOT_NA_MAX = 32;   // left-hand tables of k_dot_batch (K <= 32 bit-planes)
 // NB = number of Y tables (compile time: the accumulators of unused tables would otherwise cost a wave of occupancy)
 template <bool NU, int NB>
 __global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n,
@@ -889,10 +890,10 @@ __global__ void __launch_bounds__(256) k_dot_batch(DevCrt t, const u64 *X, size_
     __syncthreads();
     if (threadIdx.x < 3 * NB) {
         u32 b = threadIdx.x / 3, c = threadIdx.x % 3;
-        if (b < nb) partial[(size_t)bx * (16 * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[threadIdx.x];
+        if (b < nb) partial[(size_t)bx * (DOT_NA_MAX * nb * 24) + ((size_t)a * nb + b) * 24 + 3 * slot + c] = red[threadIdx.x];
     }
 }
-size_t dot_partial_words(u32 na, u32 nb) { return (size_t)RED_BLOCKS * 16 * nb * 24; }
+size_t dot_partial_words(u32 na, u32 nb) { return (size_t)RED_BLOCKS * DOT_NA_MAX * nb * 24; }
 void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *partial,
                       u64 *out, hipStream_t s) {
     u32 gb = (u32)((n + 255) / 256);
@@ -910,7 +911,7 @@ void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u
         default: LF_DB(4); break;
     }
 #undef LF_DB
-    hipLaunchKernelGGL(k_reduce_rows, dim3(na * nb * 24), dim3(256), 0, s, partial, gb, 16 * nb * 24, out);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(na * nb * 24), dim3(256), 0, s, partial, gb, DOT_NA_MAX * nb * 24, out);
 }
 template <bool NU>
 __global__ void __launch_bounds__(256) k_dot_eq(DevCrt t, const u64 *X, size_t ldx, const u64 *eq, size_t ldeq, size_t n, u64 *partial) {
@@ -1045,17 +1046,18 @@ void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq
 
 // Nibble tables: sum_k apow[k][d] * digit_k(v) = sign(v) * sum_q T[d][q][(|v| >> 4q) & 15], T[d][q][val] = sum_{b<4, bit b of val} apow[4q+b][d]
 // (192 F_{p^3} values built in LDS per block): 12 look-ups and additions per row and slot instead of a 48-iteration bit loop.
+template <int NQ>   // nibbles of |v|: 4 for K <= 16 bit-planes, 8 for K <= 32
 __global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow, u64 *G, size_t m) {
-    __shared__ u64 T[3 * 4 * 16][4];
-    if (threadIdx.x < 192) {
-        u32 val = threadIdx.x % 16, q = (threadIdx.x / 16) % 4, d = threadIdx.x / 64;
+    __shared__ u64 T[3 * NQ * 16][4];
+    for (u32 e = threadIdx.x; e < 3 * NQ * 16; e += 256) {
+        u32 val = e % 16, q = (e / 16) % NQ, d = e / (16 * NQ);
         Fq3 sum = fq3_zero();
         for (u32 b = 0; b < 4; b++)
             if (4 * q + b < K && ((val >> b) & 1)) {
                 Fq3Const a = apow[(4 * q + b) * 3 + d];
                 sum = fq3_add(sum, fq3_make(a.c[0], a.c[1], a.c[2]));
             }
-        T[threadIdx.x][0] = sum.c[0]; T[threadIdx.x][1] = sum.c[1]; T[threadIdx.x][2] = sum.c[2]; T[threadIdx.x][3] = 0;
+        T[e][0] = sum.c[0]; T[e][1] = sum.c[1]; T[e][2] = sum.c[2]; T[e][3] = 0;
     }
     __syncthreads();
     size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1068,8 +1070,8 @@ __global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, si
         u32 mg = (u32)(v < 0 ? -v : v);
         Fq3 part = fq3_zero();
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const u64 *e = T[(d * 4 + q) * 16 + ((mg >> (4 * q)) & 15)];
+        for (int q = 0; q < NQ; q++) {
+            const u64 *e = T[(d * NQ + q) * 16 + ((mg >> (4 * q)) & 15)];
             part = fq3_add(part, fq3_make(e[0], e[1], e[2]));
         }
         acc = v < 0 ? fq3_sub(acc, part) : fq3_add(acc, part);
@@ -1078,7 +1080,8 @@ __global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, si
 }
 void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow_dev, u64 *G, size_t m,
                           hipStream_t s) {
-    hipLaunchKernelGGL(k_add_fhat_comb, dim3(cdiv(n_planes, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m);
+    if (K <= 16) hipLaunchKernelGGL(k_add_fhat_comb<4>, dim3(cdiv(n_planes, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m);
+    else hipLaunchKernelGGL(k_add_fhat_comb<8>, dim3(cdiv(n_planes, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2307,9 +2310,9 @@ void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *F
 // 16 x 24 multiply-adds over the bit-planes.  The tables (both signs, both sides: 2*2*4*16*24 int32 = 24 KB) are built in LDS per block.
 // Sliding window: coefficient c only touches positions c..c+23, so with both sides handled per group of 8 coefficients the positions
 // C0..C0+7 are final after the group; they are stored (before the X^24 wrap) and leave the registers -- 31 live accumulators, not 47.
-template <int C0>
+template <int C0, int NQ>
 __device__ __forceinline__ void fw_group8(int32_t (&win)[31], const int32_t *pL, const int32_t *pR, size_t n, size_t j,
-                                          const int32_t (*R)[2][4][16][28], int32_t *out) {
+                                          const int32_t (*R)[2][NQ][16][28], int32_t *out) {
 #pragma unroll
     for (int side = 0; side < 2; side++) {
         const int32_t *pl = side ? pR : pL;
@@ -2321,7 +2324,7 @@ __device__ __forceinline__ void fw_group8(int32_t (&win)[31], const int32_t *pL,
             int32_t v = vv[i];
             u32 mg = (u32)(v < 0 ? -v : v), sg = v < 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NQ; q++) {
                 const int4 *t = (const int4 *)R[side][sg][q][(mg >> (4 * q)) & 15];
 #pragma unroll
                 for (int w = 0; w < 6; w++) {
@@ -2338,11 +2341,12 @@ __device__ __forceinline__ void fw_group8(int32_t (&win)[31], const int32_t *pL,
 #pragma unroll
     for (int i = 23; i < 31; i++) win[i] = 0;
 }
+template <int NQ>   // nibbles of |v|: 4 for K <= 16 bit-planes, 8 for K <= 32
 __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho,
                                                       int32_t *out) {
-    __shared__ __align__(16) int32_t R[2][2][4][16][28];   // [side][sign][nibble][value][a]; rows padded to 28 words (bank spread)
-    for (u32 idx = threadIdx.x; idx < 2 * 4 * 16 * 24; idx += 256) {
-        u32 a = idx % 24, val = (idx / 24) % 16, q = (idx / (24 * 16)) % 4, side = idx / (24 * 16 * 4);
+    __shared__ __align__(16) int32_t R[2][2][NQ][16][28];   // [side][sign][nibble][value][a]; rows padded to 28 words (bank spread)
+    for (u32 idx = threadIdx.x; idx < 2 * NQ * 16 * 24; idx += 256) {
+        u32 a = idx % 24, val = (idx / 24) % 16, q = (idx / (24 * 16)) % NQ, side = idx / (24 * 16 * NQ);
         int sum = 0;
 #pragma unroll
         for (u32 b = 0; b < 4; b++)
@@ -2356,9 +2360,9 @@ __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, co
     int32_t win[31];
 #pragma unroll
     for (int i = 0; i < 31; i++) win[i] = 0;
-    fw_group8<0>(win, planesL, planesR, n, j, R, out);
-    fw_group8<8>(win, planesL, planesR, n, j, R, out);
-    fw_group8<16>(win, planesL, planesR, n, j, R, out);
+    fw_group8<0, NQ>(win, planesL, planesR, n, j, R, out);
+    fw_group8<8, NQ>(win, planesL, planesR, n, j, R, out);
+    fw_group8<16, NQ>(win, planesL, planesR, n, j, R, out);
     // win[i] = position 24 + i;  X^24 = X^12 - 1, applied top down (positions >= 36 land on positions >= 24 first)
     int32_t delta[24];
 #pragma unroll
@@ -2371,7 +2375,18 @@ __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, co
     for (int c = 0; c < 24; c++) out[(size_t)c * n + j] += delta[c];
 }
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev, int32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_fold_witness, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho_dev, out);
+    if (K <= 16) hipLaunchKernelGGL(k_fold_witness<4>, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho_dev, out);
+    else hipLaunchKernelGGL(k_fold_witness<8>, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho_dev, out);
+}
+// commitments of a row chunk [i0, i0 + kc) of A computed into tmp [batch][kc][24] -> their place in out [batch][kappa][24]
+__global__ void __launch_bounds__(256) k_scatter_rows(const u64 *tmp, u32 batch, u32 kc, u32 kappa, u32 i0, u64 *out) {
+    u32 i = blockIdx.x * 256 + threadIdx.x, tot = batch * kc * 24;
+    if (i >= tot) return;
+    u32 w = i % 24, r = (i / 24) % kc, b = i / (24 * kc);
+    out[((size_t)b * kappa + i0 + r) * 24 + w] = tmp[i];
+}
+void launch_scatter_rows(const u64 *tmp, u32 batch, u32 kc, u32 kappa, u32 i0, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_rows, dim3(cdiv((size_t)batch * kc * 24, 256)), dim3(256), 0, s, tmp, batch, kc, kappa, i0, out);
 }
 
 }  // namespace lf

@@ -29,6 +29,11 @@ CONFIGS = {
     "C2": (16, 1 << 14, 4, 1 << 16, 2, 16, 25),  # BASELINE configs[1]
     "T18": (18, 1 << 16, 4, 1 << 16, 2, 16, 26),
     "C4": (20, 1 << 18, 4, 1 << 16, 2, 16, 26),  # BASELINE configs[3] / metric config
+    # the reference's own wider Goldilocks rows at small wit_len (benches/config.toml:150-165): kappa 42-44 / B 2^22 / L 3 / K 22,
+    # kappa 99 (row-chunked commits), and the widest digits the int32 witness planes hold (B 2^31, K 31)
+    "E22": (10, 256, 3, 1 << 22, 2, 22, 43),
+    "E99": (9, 64, 4, 1 << 16, 2, 16, 99),
+    "E31": (9, 64, 3, 1 << 31, 2, 31, 50),
     # GoldilocksDP of the reference unit tests (decomposition_parameters.rs:89-96): N not a power of 2
     "G5": (9, 64, 5, 1 << 15, 2, 15, 5),
     # ---- BabyBearRingNTT (d = 72, tau = 9; B^L = 2^32 > p)

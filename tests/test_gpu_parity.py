@@ -99,7 +99,8 @@ def test_linf_check(ctx):
 # kappa*batch in [384, 448] takes the SIMD-balanced 8-wave layout of k_ajtai (two lanes per output on waves 4-7, dot-product
 # kernel for the outputs beyond 384); the other shapes the one-thread-per-output map
 @pytest.mark.parametrize("kappa,n,batch", [(5, 777, 3), (9, 4096, 1), (26, 1024, 15), (3, 64, 2), (26, 512, 40),
-                                           (24, 333, 16), (28, 97, 16), (25, 650, 16), (48, 70, 9)])   # last: the ABI maximum kappa, 57 LDS rows (88 KB of the 160 KB)
+                                           (24, 333, 16), (28, 97, 16), (25, 650, 16), (48, 70, 9),    # 48 rows of A: one LDS tile (57 rows, 88 KB of the 160 KB)
+                                           (99, 200, 31), (49, 130, 5), (128, 64, 2)])                   # kappa > 48: equal row chunks (3 x 33, 2 x 25 / 24, 3 x 43 / 42) + scatter
 def test_ajtai_commit(ctx, kappa, n, batch):
     A = rnd(100 + kappa, kappa, n, RE)
     f = rnd(200 + n, batch, n, RE)
@@ -217,6 +218,23 @@ def test_fold_step_parity(ctx, name, seed):
     assert ok and (lc_p == lc_g).all()
     assert (api.proof_from_bytes(wl, api.proof_to_bytes(wl, proof_g)) == proof_g).all()   # wire format round trip of a GPU proof
     # fold again: the folded accumulator/witness are valid inputs of the next step (IVC chaining)
+    lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, api.PoseidonTranscript())
+    lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
+    assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
+
+
+@pytest.mark.parametrize("name", ["E22", "E99", "E31"])
+def test_fold_step_parity_wider_reference_rows(ctx, name):
+    """the reference's wider Goldilocks parameter rows (benches/config.toml:150-165) at small wit_len: kappa 43 / B 2^22 / L 3 / K 22,
+    kappa 99 (commit cut into row chunks), and B 2^31 / K 31 (the widest digits the int32 witness planes hold): complete fold steps
+    word for word against the oracle, chained once"""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o = run_both(ctx, name)
+    assert (acc_g == acc_o).all() and (linpr_g == linpr_o).all()
+    lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+    rc, lc_v = inst.verify(lfo.Transcript(), acc_g, cccs, proof_g)
+    assert rc == 0 and (lc_v == lc_g).all()
     lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, api.PoseidonTranscript())
     lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
     assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
