@@ -34,15 +34,19 @@ def _pad_rows(csr, m):
     return rp, ci, va
 
 
-def workload_from_r1cs(A, B, C, l, x_ccs, w_ccs, *, ring="goldilocks", L, Bbase, b=2, K, kappa, name="r1cs", seed=0):
-    """CCS::from_r1cs_padded + the parameter set, packaged as a Workload (what Context.load_ccs / the oracle take).
-    A, B, C: dense integer matrices (rows x n) or CSR triples; x_ccs: (l, d) ring elements; w_ccs: (wit_len, d)."""
+def workload_from_r1cs(A, B, C, l, x_ccs, w_ccs, *, ring="goldilocks", L, Bbase, b=2, K, kappa, name="r1cs", seed=0, W=None):
+    """CCS::from_r1cs_padded(r1cs, W, L) (arith.rs:144-149) + the parameter set, packaged as a Workload (what Context.load_ccs / the
+    oracle take).  A, B, C: dense integer matrices (rows x n) or CSR triples; x_ccs: (l, d) ring elements; w_ccs: (wit_len, d).
+    W is the reference's caller-supplied row count m of `from_r1cs` (arith.rs:122-140), default = the R1CS row count; the CCS is then
+    padded to max((n - l - 1) * L, W).next_power_of_two() rows exactly as the reference does."""
     p, d, tau = RINGS[ring]
     csr = [m if isinstance(m, tuple) else _csr_from_dense(np.asarray(m), ring) for m in (A, B, C)]
     rows = len(csr[0][0]) - 1
     wit_len = len(w_ccs)
     n = l + 1 + wit_len
-    m = max(wit_len * L, rows)
+    W = rows if W is None else int(W)
+    assert W >= rows, "W (CCS::from_r1cs's m) must cover the R1CS rows"
+    m = max((n - l - 1) * L, W)                 # (ccs.n - ccs.l - 1) * L = wit_len * L
     m = 1 << (m - 1).bit_length()               # next_power_of_two
     s = m.bit_length() - 1
     wl = Workload(name=name, s=s, wit_len=wit_len, L=L, B=Bbase, b=b, K=K, kappa=kappa, l=l, t=3, q=2, d=2, seed=seed, ring=ring)
