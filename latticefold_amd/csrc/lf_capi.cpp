@@ -1882,6 +1882,38 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     // Large instances: lane 1 (two commits back to back) is the critical path and lane 0 has several ms of slack, so the
     // linearization rounds run on 16 workgroups per slot and leave the CUs to the commit kernels (C4: 44.6 -> 43.7 ms/step).
     c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : (c->N >= ((size_t)1 << 19) ? 16u : 0u);
+    int rc;
+    std::vector<Fq3> rR;
+    if (c->sh_world > 1 && !c->tn.shard_two_lanes) {
+        // Sharded step: ONE host thread issues every exchange in program order (collectives of the ranks can then never cross), the two
+        // streams still overlap the right commit with the linearization rounds on the GPU.  (LF_SHARD_TWO_LANES=1: the threaded schedule
+        // below with one communicator per lane.)
+        auto on_lane1 = [&](auto &&fn) -> int { t_lane = 1; int r = fn(); t_lane = 0; return r; };
+        u64 *ydL = nullptr, *ydR = nullptr;
+        size_t evL = 0, evR = 0;
+        rc = on_lane1([&]() -> int {
+            RET(decompose_commit_enqueue(c, w_acc, &ydL, &evL));
+            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, evL, decl));
+            RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+            return decompose_commit_enqueue(c, w_i, &ydR, &evR);               // right commit in flight on stream 1 ...
+        });
+        {
+            HostTimer ht(c);
+            tr.absorb_label("acc");
+            tr.absorb_ring(acc, ll);
+            tr.absorb_label("cm_i");
+            tr.absorb_ring(cm_i, lf_cccs_len(&P));
+        }
+        if (rc == LF_OK) rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);   // ... while the linearization runs on stream 0
+        if (rc == LF_OK) {
+            lcccs_point(P, lin.data(), rR);
+            rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
+        }
+        if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, acc, decl, S[0]);
+        if (rc == LF_OK) rc = on_lane1([&]() -> int { return decompose_commit_finish(c, cm_i, ydR, evR, decr); });
+        c->lin_blocks = 0;
+        if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
+    } else {
     std::future<int> flane1 = std::async(std::launch::async, [&]() -> int {
         t_lane = 1;
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
@@ -1903,10 +1935,9 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         tr.absorb_ring(cm_i, lf_cccs_len(&P));
     }
     TL_MARK("public input absorbed");
-    int rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
     TL_MARK("linearization done");
     lin_done_p.set_value(rc);
-    std::vector<Fq3> rR;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
         rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
@@ -1917,6 +1948,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     TL_MARK("lane 1 joined");
     if (rc == LF_OK) rc = rc1;
     if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
+    }
     TL_MARK("right absorb done");
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     TL_MARK("fold done");

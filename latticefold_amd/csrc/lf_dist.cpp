@@ -25,10 +25,16 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
-            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // prefer a copy that is already mapped (PyTorch brings its own librccl.so): one RCCL runtime per process
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (r.h) break;
         }
+        if (!r.h)
+            for (const char *name : {"librccl.so.1", "librccl.so"}) {
+                r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.h) break;
+            }
         if (!r.h) return;
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");

@@ -53,10 +53,18 @@ def init_sharding(ctx, rank, world, transport="auto"):
     if transport == "auto":
         transport = "rccl" if dist.get_backend() == "nccl" else "host"
     if transport == "rccl":
-        ids = [api.dist_unique_ids() if rank == 0 else None]
+        ids = [None]
+        if rank == 0:
+            try:
+                ids = [api.dist_unique_ids()]
+            except api.LfError:          # RCCL not loadable on this box: every rank falls back to the host transport together
+                ids = [b""]
         dist.broadcast_object_list(ids, src=0)
-        ctx.dist_init(rank, world, ids[0])
-    else:
+        if ids[0]:
+            ctx.dist_init(rank, world, ids[0])
+            return "rccl"
+        transport = "host"
+    if transport == "host":
         g0, g1 = dist.new_group(), dist.new_group()   # collective calls: every rank creates both groups in the same order
         ctx.set_sharding(rank, world, make_allgather(g0), make_allgather(g1))
         ctx._lf_groups = (g0, g1)

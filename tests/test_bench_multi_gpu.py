@@ -64,6 +64,7 @@ def test_rccl_transport_single_rank_forced_exchanges():
 import os, sys, json, hashlib
 sys.path.insert(0, %r)
 import numpy as np
+import torch                      # as in bench.py: PyTorch's own librccl.so is mapped first and the library must reuse it
 from latticefold_amd import api
 from latticefold_amd.workload import make_workload
 def run(rccl):

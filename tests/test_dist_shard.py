@@ -57,11 +57,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,cases", [(2, "T10,G5,T12"), (4, "T12"), (2, "B8,B10,BDP"), (4, "B14")])
-def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases):
+@pytest.mark.parametrize("world,cases,two_lanes", [(2, "T10,G5,T12", False), (4, "T12", False), (2, "T12", True), (2, "B8,B10,BDP", False), (4, "B14", False)])
+def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, LF_ROOT=ROOT, OMP_NUM_THREADS="2", LF_CASES=cases)
+    if two_lanes:   # the threaded two-lane schedule with one exchange channel per lane (default in a sharded step: one host thread)
+        env["LF_SHARD_TWO_LANES"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
