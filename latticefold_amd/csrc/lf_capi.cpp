@@ -1086,6 +1086,8 @@ static Fq3 sc_round_transcript(Transcript &tr, const u64 *evals, u32 npts) {
     return r;
 }
 
+static int lin_tail_rounds(lf_ctx *c, Transcript &tr, const u64 *cur, const u64 *cure, size_t n, u64 *tout, u64 *partial, u32 round, Fq3 *point,
+                           u64 *msgs, u32 deg);
 // linearization sumcheck on device tables mz [t][24][m] (left intact) and eq_beta [3][m]
 // `u_dev` (optional): the Mz tables fixed at the whole point, i.e. u_j = Mz_j(r) (t ring elements, canonical) -- the last fix of the
 // tables the rounds work on, so linearization.rs:136's evaluate_mles pass over the full tables is not needed.
@@ -1113,6 +1115,12 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     u64 *od_dev = nullptr;
     if (Gw > 1) RET(c->tbuf("lin_round_out", 5 * 24 + 8, &od_dev));
     for (u32 round = 1; round <= P.s; round++) {
+        // persistent tail (k_lin_tail): all remaining rounds in one launch once the tables are small, as in the folding sumcheck
+        if (Gw == 1 && !c->tn.no_tail && round >= 2 && n <= c->tn.tail_n && n >= 4 && P.s - round + 1 <= TAIL_MAX_ROUNDS) {
+            int trc = lin_tail_rounds(c, tr, cur, cure, n, fx[flip], partial, round, point, msgs, deg);
+            if (trc == LF_OK) { cur = fx[flip]; n = 2; break; }
+            if (trc != LF_ERR_UNSUPPORTED) return trc;
+        }
         if (round > 1) {
             Fq3Const r = f3c(point[round - 2]);
             if (sharded) {
@@ -1387,6 +1395,78 @@ static int upload_consts(lf_ctx *c, const std::string &name, const std::vector<F
     return LF_OK;
 }
 
+// Host side of the mailbox protocol of a persistent tail kernel (k_fold_tail / k_lin_tail): per round poll the message, run the transcript
+// (unless the device sponge does), write the challenge back.  msgs = slot of the first tail round's message, pt = its challenge.
+static int tail_host_rounds(lf_ctx *c, Transcript &tr, u32 epoch, u32 nr, u32 npts, bool dev_transcript, u64 *msgs, Fq3 *pt) {
+    TailMail *mail = c->tail_mail;
+    const auto t_start = std::chrono::steady_clock::now();
+    double host_us = 0, wait_us = 0;
+    auto t_mark = t_start;
+    const bool tl_on = t_tl && t_tl->on;
+    for (u32 i = 0; i < nr; i++) {
+        u32 spins = 0;
+        while (__atomic_load_n(&mail->msg_seq[i], __ATOMIC_ACQUIRE) != epoch) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfff) == 0) {
+                if (__atomic_load_n(&mail->err, __ATOMIC_RELAXED) == epoch ||
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 10.0) {
+                    __atomic_store_n(&mail->abort_seq, epoch, __ATOMIC_RELEASE);   // the kernel gives up at its next wait
+                    (void)hipStreamSynchronize(c->stream());
+                    return LF_ERR_HIP;
+                }
+            }
+        }
+        if (tl_on) { auto nw = std::chrono::steady_clock::now(); wait_us += std::chrono::duration<double, std::micro>(nw - t_mark).count(); t_mark = nw; }
+        u64 *evs = msgs + (size_t)i * npts * 24;
+        memcpy(evs, (const void *)mail->msg[i], (size_t)npts * 24 * 8);
+        HostTimer ht(c);
+        Fq3 r;
+        if (dev_transcript) r = fq3_make(mail->chal_out[i][0], mail->chal_out[i][1], mail->chal_out[i][2]);   // drawn by the device sponge
+        else r = sc_round_transcript(tr, evs, npts);
+        pt[i] = r;
+        if (i + 1 < nr && !dev_transcript) {
+            mail->chal[i][0] = r.c[0]; mail->chal[i][1] = r.c[1]; mail->chal[i][2] = r.c[2];
+            __atomic_store_n(&mail->chal_seq[i], epoch, __ATOMIC_RELEASE);
+        }
+        if (tl_on) { auto nw = std::chrono::steady_clock::now(); host_us += std::chrono::duration<double, std::micro>(nw - t_mark).count(); t_mark = nw; }
+    }
+    if (dev_transcript) tr.set_state((const u64 *)mail->sponge);   // the host transcript continues where the device sponge stopped
+    if (tl_on) fprintf(stderr, "[timeline]    tail: %u rounds, host transcript %.1f us, waiting for the GPU %.1f us\n", nr, host_us, wait_us);
+    return LF_OK;
+}
+// device-transcript mode: hand the sponge to the device (state_out = device [26])
+static int tail_sponge_to_device(lf_ctx *c, Transcript &tr, u64 **state_out) {
+    RET(c->poseidon_setup());
+    *state_out = c->tail_dev_chal + 4 * TAIL_MAX_ROUNDS;   // behind the published challenges (same 4 KB scratch)
+    u64 st[26];
+    tr.get_state(st);
+    HIPCHK(hipMemcpyAsync(*state_out, st, sizeof(st), hipMemcpyHostToDevice, c->stream()));
+    HIPCHK(hipStreamSynchronize(c->stream()));   // st is a stack buffer
+    return LF_OK;
+}
+// Tail rounds `round`..s of the linearization sumcheck (k_lin_tail).  cur / cure = the Mz and eq tables of round-1 (n entries, ld n).
+static int lin_tail_rounds(lf_ctx *c, Transcript &tr, const u64 *cur, const u64 *cure, size_t n, u64 *tout, u64 *partial, u32 round, Fq3 *point,
+                           u64 *msgs, u32 deg) {
+    const lf_params &P = c->P;
+    RET(c->tail_setup());
+    LinTailArgs A;
+    A.T = cur; A.E = cure; A.Tout = tout; A.n0 = n; A.rounds = P.s - round + 1; A.deg = deg; A.partial = partial;
+    RET(c->tbuf("lin_tail_priv", lin_tail_priv_words(n, P.t), &A.priv));
+    A.counters = c->tail_counters; A.dev_chal = c->tail_dev_chal;
+    HIPCHK(hipHostGetDevicePointer((void **)&A.mail, c->tail_mail, 0));
+    if (++c->tail_epoch >= (1u << 30)) c->tail_epoch = 1;
+    A.epoch = c->tail_epoch;
+    A.r_first = f3c(point[round - 2]);
+    A.dev_transcript = c->tn.device_transcript ? 1u : 0u;
+    A.pos_ark = A.pos_mds = nullptr; A.sponge_state = nullptr;
+    if (A.dev_transcript) {
+        RET(tail_sponge_to_device(c, tr, &A.sponge_state));
+        A.pos_ark = c->d_poseidon; A.pos_mds = c->d_poseidon + 720;
+    }
+    if (launch_lin_tail(c->dcrt, c->desc, A, c->stream()) == 0) return LF_ERR_UNSUPPORTED;
+    if (hipGetLastError() != hipSuccess) return LF_ERR_HIP;
+    return tail_host_rounds(c, tr, A.epoch, A.rounds, deg + 1, A.dev_transcript != 0, msgs + (size_t)(round - 1) * (deg + 1) * 24, &point[round - 1]);
+}
 // Tail rounds `round`..s of the folding sumcheck in one persistent kernel (lf_kernels.hip: k_fold_tail).  On entry `a` / `curF`
 // describe the tables of round-1 (a.n entries each, leading dimension a.n) and pt[round-2] is the challenge that fixes them.
 // The host side of the mailbox protocol: poll the message of a round, run the transcript, write the challenge back.
@@ -1408,59 +1488,12 @@ static int fold_tail_rounds(lf_ctx *c, Transcript &tr, const FoldRoundArgs &a, u
     A.dev_transcript = c->tn.device_transcript ? 1u : 0u;
     A.pos_ark = A.pos_mds = nullptr; A.sponge_state = nullptr;
     if (A.dev_transcript) {   // LF_DEVICE_TRANSCRIPT=1: hand the sponge to the device for the tail rounds
-        RET(c->poseidon_setup());
+        RET(tail_sponge_to_device(c, tr, &A.sponge_state));
         A.pos_ark = c->d_poseidon; A.pos_mds = c->d_poseidon + 720;
-        A.sponge_state = c->tail_dev_chal + 4 * TAIL_MAX_ROUNDS;   // behind the published challenges (same 4 KB scratch)
-        u64 st[26];
-        tr.get_state(st);
-        HIPCHK(hipMemcpyAsync(A.sponge_state, st, sizeof(st), hipMemcpyHostToDevice, c->stream()));
-        HIPCHK(hipStreamSynchronize(c->stream()));   // st is a stack buffer
     }
-    TailMail *mail = c->tail_mail;
     if (launch_fold_tail(c->dcrt, A, c->num_cus, c->stream()) == 0) return LF_ERR_UNSUPPORTED;
     if (hipGetLastError() != hipSuccess) return LF_ERR_HIP;
-    const auto t_start = std::chrono::steady_clock::now();
-    double host_us = 0, wait_us = 0;
-    auto t_mark = t_start;
-    for (u32 i = 0; i < nr; i++) {
-        u32 spins = 0;
-        while (__atomic_load_n(&mail->msg_seq[i], __ATOMIC_ACQUIRE) != A.epoch) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xfff) == 0) {
-                if (__atomic_load_n(&mail->err, __ATOMIC_RELAXED) == A.epoch ||
-                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 10.0) {
-                    __atomic_store_n(&mail->abort_seq, A.epoch, __ATOMIC_RELEASE);   // the kernel gives up at its next wait
-                    (void)hipStreamSynchronize(c->stream());
-                    return LF_ERR_HIP;
-                }
-            }
-        }
-        if (t_tl && t_tl->on) { auto nw = std::chrono::steady_clock::now(); wait_us += std::chrono::duration<double, std::micro>(nw - t_mark).count(); t_mark = nw; }
-        u64 *evs = msgs + (size_t)(round + i - 1) * (deg + 1) * 24;
-        memcpy(evs, (const void *)mail->msg[i], (size_t)(deg + 1) * 24 * 8);
-        HostTimer ht(c);
-        Fq3 r;
-        if (A.dev_transcript) r = fq3_make(mail->chal_out[i][0], mail->chal_out[i][1], mail->chal_out[i][2]);   // drawn by the device sponge
-        else r = sc_round_transcript(tr, evs, deg + 1);
-        pt[round + i - 1] = r;
-        if (t_tl && t_tl->on) { static const char *nm[] = {"   tail r0", "   tail r1", "   tail r2", "   tail r3", "   tail r4", "   tail r5", "   tail r6", "   tail r7", "   tail r8", "   tail r9", "   tail r10", "   tail r11", "   tail r12", "   tail r13"}; if (i < 14) TL_MARK(nm[i]); }
-        if (i + 1 < nr && !A.dev_transcript) {
-            mail->chal[i][0] = r.c[0]; mail->chal[i][1] = r.c[1]; mail->chal[i][2] = r.c[2];
-            __atomic_store_n(&mail->chal_seq[i], A.epoch, __ATOMIC_RELEASE);
-        }
-        if (t_tl && t_tl->on) { auto nw = std::chrono::steady_clock::now(); host_us += std::chrono::duration<double, std::micro>(nw - t_mark).count(); t_mark = nw; }
-    }
-#ifdef LF_TAIL_DEBUG
-    if (t_tl && t_tl->on)
-        for (u32 i = 1; i < nr; i++) {
-            const u64 *d = (const u64 *)mail->dbg[i];
-            fprintf(stderr, "[taildbg] rd %u: host-flag seen -> published %.2f us, -> round start %.2f, compute %.2f, partial+count %.2f, last-block start +%.2f, rows read %.2f, mailed %.2f\n", i,
-                    (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0, ((double)d[5] - (double)d[4]) / 100.0, (d[6] - d[5]) / 100.0, (d[7] - d[6]) / 100.0);
-        }
-#endif
-    if (A.dev_transcript) tr.set_state((const u64 *)mail->sponge);   // the host transcript continues where the device sponge stopped
-    if (t_tl && t_tl->on) fprintf(stderr, "[timeline]    tail: %u rounds, host transcript %.1f us, waiting for the GPU %.1f us\n", nr, host_us, wait_us);
-    return LF_OK;
+    return tail_host_rounds(c, tr, A.epoch, nr, deg + 1, A.dev_transcript != 0, msgs + (size_t)(round - 1) * (deg + 1) * 24, &pt[round - 1]);
 }
 
 // LFFoldingProver::prove (nifs/folding.rs:42-130)

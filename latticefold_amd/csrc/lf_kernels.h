@@ -200,6 +200,25 @@ struct FoldTailArgs {
     const u64 *pos_ark, *pos_mds;   // Poseidon constants in device memory
     u64 *sponge_state;    // device [26]: the sponge when the tail starts (written by the host), updated every round
 };
+struct LinTailArgs {     // persistent tail of the linearization sumcheck (k_lin_tail): same mailbox protocol
+    const u64 *T;         // Mz tables [t][24][n0] of the round BEFORE the tail
+    const u64 *E;         // eq table [3][n0] of that round
+    u64 *Tout;            // receives the fully fixed Mz tables [t][24][2]
+    size_t n0;
+    u32 rounds, deg;      // deg = degree of the round polynomial (deg + 1 evaluations per message)
+    u64 *partial;         // 128 words
+    u64 *priv;            // lin_tail_priv_words(n0, t)
+    u32 *counters;
+    u64 *dev_chal;
+    TailMail *mail;
+    u32 epoch;
+    Fq3Const r_first;
+    u32 dev_transcript;
+    const u64 *pos_ark, *pos_mds;
+    u64 *sponge_state;
+};
+size_t lin_tail_priv_words(size_t n0, u32 t);
+u32 launch_lin_tail(const DevCrt &t, const LinCombDesc &desc, const LinTailArgs &A, hipStream_t s);
 constexpr u32 FOLD_TAIL_MAX_BLOCKS = 256;
 size_t fold_tail_eqpriv_words(size_t n0, u32 K);
 u32 launch_fold_tail(const DevCrt &t, const FoldTailArgs &A, int num_cus, hipStream_t s);

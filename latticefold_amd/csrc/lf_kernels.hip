@@ -2231,6 +2231,179 @@ __global__ void __launch_bounds__(256) k_fold_tail(DevCrt t, FoldTailArgs A) {
         n_prev = n;
     }
 }
+// The same for the linearization sumcheck (comb = linearization/utils.rs:90-107): one workgroup per slot owns the t Mz rows of its slot and
+// a private copy of the eq table; a work item is a pair.  T = the Mz tables [t][24][n0], E = the eq table [3][n0] of the round before the
+// tail; the fully fixed Mz tables (2 entries per row) are left in Tout ([t][24][2], write-through) for u = Mz(r) (k_fix_final).
+template <bool NU>
+__global__ void __launch_bounds__(256) k_lin_tail(DevCrt t, LinCombDesc desc, LinTailArgs A) {
+    const u32 slot = blockIdx.y;
+    const u64 nu = t.nu;
+    const u32 nblocks = gridDim.y, bid = blockIdx.y, nt = desc.t, npts = A.deg + 1;
+    const bool leader = bid == 0;
+    __shared__ u64 s_r[3];
+    __shared__ u32 s_flag;
+    __shared__ u64 red[15];
+    const size_t half0 = A.n0 / 2, row_words = 3 * half0, nrow = 1 + nt;   // rows: 0 eq, 1.. the Mz tables of this slot
+    const size_t buf_words = (nrow * row_words + 15) & ~(size_t)15;
+    u64 *const priv = A.priv + (size_t)bid * 2 * buf_words;
+    size_t n_prev = A.n0;
+    Fq3 r = fq3_make(A.r_first.c[0], A.r_first.c[1], A.r_first.c[2]);
+    for (u32 rd = 0; rd < A.rounds; rd++) {
+        if (rd > 0) {
+            if (threadIdx.x == 0) {
+                u64 rr[3] = {0, 0, 0};
+                bool ok = tail_wait_challenge(A.mail, A.dev_chal, rd - 1, A.epoch, leader && !A.dev_transcript, rr);
+                s_r[0] = rr[0]; s_r[1] = rr[1]; s_r[2] = rr[2];
+                s_flag = ok ? 1u : 0u;
+            }
+            __syncthreads();
+            if (!s_flag) return;
+            r = fq3_make(s_r[0], s_r[1], s_r[2]);
+            __syncthreads();
+        }
+        const size_t n = n_prev / 2, pairs = n / 2, ldp = n_prev;
+        const bool first = rd == 0, last = rd + 1 == A.rounds;
+        const u64 *Pp = priv + (size_t)((rd + 1) & 1) * buf_words;
+        u64 *Pn = priv + (size_t)(rd & 1) * buf_words;
+        auto src_row = [&](u32 q) -> const u64 * {
+            if (!first) return Pp + (size_t)q * 3 * ldp;
+            if (q == 0) return A.E;
+            return A.T + ((size_t)(q - 1) * 24 + 3 * slot) * ldp;
+        };
+        auto fix_pair = [&](const u64 *row, size_t p, Fq3 &f0, Fq3 &f1) {
+            const u64 *fp = row + 4 * p;
+            ulonglong2 a0 = *(const ulonglong2 *)(fp), a1 = *(const ulonglong2 *)(fp + ldp), a2 = *(const ulonglong2 *)(fp + 2 * ldp);
+            ulonglong2 b0 = *(const ulonglong2 *)(fp + 2), b1 = *(const ulonglong2 *)(fp + ldp + 2), b2 = *(const ulonglong2 *)(fp + 2 * ldp + 2);
+            Fq3 lo = fq3_make(a0.x, a1.x, a2.x), hi = fq3_make(b0.x, b1.x, b2.x);
+            f0 = fq3_add(lo, M3<NU>(fq3_sub(fq3_make(a0.y, a1.y, a2.y), lo), r, nu));
+            f1 = fq3_add(hi, M3<NU>(fq3_sub(fq3_make(b0.y, b1.y, b2.y), hi), r, nu));
+        };
+        auto store_pair = [&](u32 q, size_t p, const Fq3 &f0, const Fq3 &f1) {
+            u64 *op = Pn + (size_t)q * 3 * n + 2 * p;
+            *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
+            *(ulonglong2 *)(op + n) = make_ulonglong2(f0.c[1], f1.c[1]);
+            *(ulonglong2 *)(op + 2 * n) = make_ulonglong2(f0.c[2], f1.c[2]);
+        };
+        Fq3 acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+        for (size_t p = threadIdx.x; p < pairs; p += 256) {
+            Fq3 v[4], st[4], ev, e1;
+            fix_pair(src_row(0), p, ev, e1);
+            store_pair(0, p, ev, e1);
+            Fq3 es = fq3_sub(e1, ev);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((u32)j < nt) {
+                    Fq3 f0, f1;
+                    fix_pair(src_row(1 + j), p, f0, f1);
+                    store_pair(1 + j, p, f0, f1);
+                    if (last) {   // write-through: the rows of the eight workgroups share cache lines in the shared layout (see k_fold_tail)
+                        u64 *op = A.Tout + ((size_t)j * 24 + 3 * slot) * n + 2 * p;
+                        st_dev_u64(op, f0.c[0]); st_dev_u64(op + 1, f1.c[0]);
+                        st_dev_u64(op + n, f0.c[1]); st_dev_u64(op + n + 1, f1.c[1]);
+                        st_dev_u64(op + 2 * n, f0.c[2]); st_dev_u64(op + 2 * n + 1, f1.c[2]);
+                    }
+                    v[j] = f0; st[j] = fq3_sub(f1, f0);
+                } else { v[j] = fq3_zero(); st[j] = fq3_zero(); }
+            }
+#pragma unroll
+            for (int X = 0; X < 5; X++) {
+                if ((u32)X < npts) {
+                    Fq3 res = fq3_zero(), term = fq3_zero();
+                    int sgn = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((u32)j < nt) {
+                            if (desc.first[j]) {
+                                if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
+                                u32 i = desc.ms[j];
+                                if (desc.c_unit[i]) { term = v[j]; sgn = desc.c_unit[i]; }
+                                else { term = M3<NU>(fq3_make(desc.c[i][3 * slot], desc.c[i][3 * slot + 1], desc.c[i][3 * slot + 2]), v[j], nu); sgn = 1; }
+                            } else term = M3<NU>(term, v[j], nu);
+                        }
+                    }
+                    if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
+                    acc[X] = fq3_add(acc[X], M3<NU>(res, ev, nu));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = fq3_add(v[j], st[j]);
+                    ev = fq3_add(ev, es);
+                }
+            }
+        }
+        u64 vv[15];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { vv[3 * i] = acc[i].c[0]; vv[3 * i + 1] = acc[i].c[1]; vv[3 * i + 2] = acc[i].c[2]; }
+        __syncthreads();
+        block_sum_store<15>(vv, red);
+        __syncthreads();
+        if (threadIdx.x < 15) st_dev_u64(A.partial + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3, red[threadIdx.x]);
+        wait_mem();
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&A.counters[rd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1 ? 1u : 0u;
+        __syncthreads();
+        if (s_flag) {
+            __shared__ u64 s_msg[128];
+            if (threadIdx.x < 120) {
+                const u64 tot = threadIdx.x < npts * 24 ? fq_canon(ld_dev_u64(A.partial + threadIdx.x)) : 0;
+                s_msg[threadIdx.x] = tot;
+                __hip_atomic_store((u64 *)&A.mail->msg[rd][threadIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (A.dev_transcript) {
+                __shared__ u64 sp_st[24], sp_tmp[24], sp_c[24];
+                __syncthreads();
+                if (threadIdx.x < 64) {
+                    const int lane = threadIdx.x;
+                    if (lane < 24) sp_st[lane] = ld_dev_u64(A.sponge_state + lane);
+                    SpongeDev sp;
+                    sp.idx = (int)ld_dev_u64(A.sponge_state + 24);
+                    sp.squeezing = (int)ld_dev_u64(A.sponge_state + 25);
+                    wave_lds_sync();
+                    for (u32 e = 0; e < npts; e++) sponge_absorb_wave(sp, sp_st, sp_tmp, A.pos_ark, A.pos_mds, s_msg + 24 * e, 24);
+                    sponge_squeeze_wave(sp, sp_st, sp_tmp, A.pos_ark, A.pos_mds, sp_c, 3);
+                    sponge_absorb_wave(sp, sp_st, sp_tmp, A.pos_ark, A.pos_mds, sp_c, 3);
+                    const u64 c0 = sp_c[0], c1 = sp_c[1], c2 = sp_c[2];
+                    wave_lds_sync();
+                    if (lane < 24) sp_c[lane] = lane % 3 == 0 ? c0 : (lane % 3 == 1 ? c1 : c2);
+                    wave_lds_sync();
+                    sponge_absorb_wave(sp, sp_st, sp_tmp, A.pos_ark, A.pos_mds, sp_c, 24);
+                    if (lane < 24) st_dev_u64(A.sponge_state + lane, sp_st[lane]);
+                    if (lane == 0) { st_dev_u64(A.sponge_state + 24, (u64)sp.idx); st_dev_u64(A.sponge_state + 25, (u64)sp.squeezing); }
+                    if (lane < 3) {
+                        const u64 cv = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
+                        __hip_atomic_store((u64 *)&A.mail->chal_out[rd][lane], cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        st_dev_u64(A.dev_chal + (size_t)rd * 4 + lane, cv);
+                    }
+                    if (rd + 1 == A.rounds) {
+                        if (lane < 24) __hip_atomic_store((u64 *)&A.mail->sponge[lane], sp_st[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (lane == 0) {
+                            __hip_atomic_store((u64 *)&A.mail->sponge[24], (u64)sp.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store((u64 *)&A.mail->sponge[25], (u64)sp.squeezing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
+                    wait_mem();
+                    if (lane == 0) st_dev_u64(A.dev_chal + (size_t)rd * 4 + 3, (u64)A.epoch);
+                }
+            }
+            wait_mem();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&A.counters[rd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((u32 *)&A.mail->msg_seq[rd], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        n_prev = n;
+    }
+}
+size_t lin_tail_priv_words(size_t n0, u32 t) { return (size_t)8 * 2 * ((((1 + (size_t)t) * 3 * (n0 / 2)) + 15) & ~(size_t)15) + 16; }
+// eight workgroups (one per slot); returns 0 when the tail cannot run (the caller keeps per-round launches)
+u32 launch_lin_tail(const DevCrt &t, const LinCombDesc &desc, const LinTailArgs &A, hipStream_t s) {
+    if (A.n0 < 4 || A.rounds < 1 || A.rounds > TAIL_MAX_ROUNDS || A.deg + 1 > 5) return 0;
+    if (t.nu2p40) hipLaunchKernelGGL((k_lin_tail<true>), dim3(1, 8), dim3(256), 0, s, t, desc, A);
+    else hipLaunchKernelGGL((k_lin_tail<false>), dim3(1, 8), dim3(256), 0, s, t, desc, A);
+    return 8;
+}
+
 // private working sets: per workgroup two buffers of (5 + tables per workgroup) rows x 3 planes x n0/2 entries; sized for the smallest
 // chunk count the launcher may pick (8 workgroups per chunk), which needs the most rows
 size_t fold_tail_eqpriv_words(size_t n0, u32 K) {
