@@ -150,10 +150,22 @@ LF_HD void accp_set(AccP &s, u64 a, u64 b) {
 }
 LF_HD void accp_mad(AccP &s, u64 a, u64 b) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LF_ACCP_SPLIT_ASM)
+    // the four partial products of one 64x64 product in ONE asm statement: the compiler pads every asm statement that defines an SGPR
+    // with an s_nop (hazard recogniser), which cost 4 s_nop per product with one statement per partial product
+    unsigned long long cy;
+    asm("v_mad_u64_u32 %0, %6, %7, %9, %0\n\tv_addc_co_u32_e64 %3, %6, 0, %3, %6\n\t"
+        "v_mad_u64_u32 %1, %6, %7, %10, %1\n\tv_addc_co_u32_e64 %4, %6, 0, %4, %6\n\t"
+        "v_mad_u64_u32 %1, %6, %8, %9, %1\n\tv_addc_co_u32_e64 %4, %6, 0, %4, %6\n\t"
+        "v_mad_u64_u32 %2, %6, %8, %10, %2\n\tv_addc_co_u32_e64 %5, %6, 0, %5, %6"
+        : "+v"(s.s00), "+v"(s.s01), "+v"(s.s11), "+v"(s.c00), "+v"(s.c01), "+v"(s.c11), "=&s"(cy)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+#else
     mad_cc(s.s00, s.c00, a0, b0);
     mad_cc(s.s01, s.c01, a0, b1);
     mad_cc(s.s01, s.c01, a1, b0);
     mad_cc(s.s11, s.c11, a1, b1);
+#endif
 }
 // value mod p, canonical:  s00 + s01*2^32 + s11*2^64 + c00*2^64 + c01*2^96 + c11*2^128
 // with 2^64 = 2^32-1, 2^96 = -1, 2^128 = -2^32 (mod p)
