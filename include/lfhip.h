@@ -69,6 +69,24 @@ void lf_ctx_destroy(lf_ctx *);
  * by lf_ctx_create.  tools/probe_stark_rings.rs prints the true tables. */
 int lf_set_ring_tables(lf_ctx *, uint64_t nonres, const uint64_t *y);
 int lf_get_ring_tables(lf_ctx *, uint64_t *nonres, uint64_t *y);
+/* External coordinate basis of F_{p^tau} (the other half of "conventions are data"): the kernels compute in the binomial basis
+ * 1, Y, .., Y^(tau-1) of F_p[Y]/(Y^tau - nonres) -- `nonres` and `y` above are expressed in it -- while the caller's library may keep
+ * field elements in another F_p-basis: a tower basis F_{p^3}[Z]/(Z^3 - Y) with coordinates ordered 3j+i (a permutation), a rescaled
+ * or entirely different basis.  T (tau x tau, row-major, canonical words) maps internal to external coordinates, ext = T * int, and
+ * must fix 1 (first column = e_0; the base field is coordinate 0 in both bases).  From then on every NTT-form ring element and every
+ * F_{p^tau} challenge crossing this ABI is in EXTERNAL coordinates -- inputs are converted on entry, outputs on exit -- and the
+ * Fiat-Shamir transcript absorbs / squeezes external coordinates, so proofs are those of a prover computing natively in that basis.
+ * The multiplication (structure) tensor the caller's field has is then T applied to the binomial one; tools/probe_stark_rings.rs prints
+ * it.  Identity T switches the feature off (default; no cost).  LF_ERR_BAD_TABLES if T is singular or does not fix 1.  lf_verify_host
+ * keeps the default basis. */
+int lf_set_ext_basis(lf_ctx *, const uint64_t *T);
+/* The balanced-digit rule of stark_rings::balanced_decomposition, the third unpinned convention, as data: mode 0 (default) = truncate
+ * toward zero and move |rem| > base/2 to the other side (ties +-base/2 keep the sign of the value); mode 1 = floor rule, digits in
+ * [-base/2, base/2) (a tie becomes -base/2 with a carry).  Applies to every base-B decomposition on the path (lf_decompose, the gadget
+ * decomposition of Witness::from_w_ccs, x_s); for base 2 the digits are {-1, 0, 1} = sign and bits of the magnitude under either mode
+ * (the floor rule does not terminate on positive values in base 2).  tools/probe_stark_rings.rs prints the edge cases that tell the
+ * modes apart. */
+int lf_set_digit_mode(lf_ctx *, int mode);
 int lf_device_synchronize(lf_ctx *);
 int lf_mem_info(lf_ctx *, size_t *free_bytes, size_t *total_bytes); /* hipMemGetInfo of the context's device */
 /* device arithmetic self-test: fast F_{p^3} product / lazy accumulators vs the generic schoolbook path on n pseudo-random

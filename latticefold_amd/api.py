@@ -80,6 +80,8 @@ def _lib():
         L.lf_ctx_destroy.argtypes = [vp]
         L.lf_ctx_destroy.restype = None
         L.lf_set_ring_tables.argtypes = [vp, C.c_uint64, u64p]
+        L.lf_set_ext_basis.argtypes = [vp, u64p]
+        L.lf_set_digit_mode.argtypes = [vp, C.c_int]
         L.lf_get_ring_tables.argtypes = [vp, u64p, u64p]
         L.lf_device_synchronize.argtypes = [vp]
         L.lf_mem_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -220,6 +222,16 @@ class Context:
         m = C.c_uint64(1)
         _chk(_lib().lf_selftest_field(self.h, seed, n, C.cast(C.byref(m), u64p)), "lf_selftest_field")
         return m.value
+
+    def set_digit_mode(self, mode):
+        """lf_set_digit_mode: 0 = sign-magnitude truncation (default), 1 = floor rule (digits in [-base/2, base/2))"""
+        _chk(_lib().lf_set_digit_mode(self.h, int(mode)), "lf_set_digit_mode")
+
+    def set_ext_basis(self, T):
+        """lf_set_ext_basis: T (tau x tau) maps the internal binomial-basis coordinates of F_{p^tau} to the caller's external ones"""
+        a, p = _a64(np.ascontiguousarray(T, dtype=np.uint64).reshape(-1))
+        assert a.size == self.TAU * self.TAU
+        _chk(_lib().lf_set_ext_basis(self.h, p), "lf_set_ext_basis")
 
     def set_sharding(self, rank, world, allgather, allgather_lane1=None):
         """Intra-step sharding over a HOST transport (lf_set_sharding_lanes); call before creating the AjtaiCommitmentScheme.

@@ -53,6 +53,7 @@ struct BbCtxImpl {
     size_t arena_words = 0, arena_used[2] = {0, 0};
     hipEvent_t ev_side[2] = {nullptr, nullptr};
     hipEvent_t ev_dec[4] = {nullptr, nullptr, nullptr, nullptr};   // decomposition milestones: [2*side + (0 commit, 1 evaluations)]
+    int digit_mode = 0;   // balanced-digit rule (lf_set_digit_mode)
     Tunables tn;          // environment switches, re-read at the start of every linearize / fold_step
     u32 lin_blocks = 0;   // grid bound of the linearization rounds while the commit chain runs on the other lane (0 = none)
     u64 *h_round = nullptr;   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
@@ -252,6 +253,13 @@ int BbCtx::dist_init(int rank, int world, const uint8_t *id128) {
     return LF_OK;
 }
 lfdist::Comm *BbCtx::comm() { return &p->comm; }
+void BbCtx::set_digit_mode(int mode) { p->digit_mode = mode; }
+bool BbCtx::have_ccs() const { return p->have_ccs; }
+const lf_params &BbCtx::params() const { return p->P; }
+size_t BbCtx::dim_n() const { return p->n; }
+size_t BbCtx::dim_m() const { return p->m; }
+size_t BbCtx::dim_N() const { return p->N; }
+uint32_t BbCtx::kappa() const { return p->kappa; }
 int BbCtx::get_ring_tables(uint64_t *nonres, uint64_t *y) {
     *nonres = p->ring.T.nu;
     for (int k = 0; k < 8; k++)
@@ -392,7 +400,7 @@ int BbCtx::decompose(const uint64_t *in, size_t count, uint64_t base, unsigned d
     RET(c->tbuf("io_a", count * RE, &a));
     RET(c->tbuf("io_b", count * digits * RE, &b));
     RET(up_ring(c, in, count, a));
-    launch_decompose(a, count, base, digits, layout, b, c->stream());
+    launch_decompose(a, count, base, digits, layout, b, c->stream(), c->digit_mode);
     if (layout == 0) return down_ring(c, b, count * digits, out);
     for (unsigned k = 0; k < digits; k++) RET(down_ring(c, b + (size_t)k * RE * count, count, out + (size_t)k * count * RE));
     return LF_OK;
@@ -694,7 +702,7 @@ int BbCtx::witness_from_w_ccs(const uint64_t *w_ccs, lf_witness **out) {
     RET(c->tbuf("io_c", c->N * RE, &d));
     RET(up_ring(c, w_ccs, c->P.wit_len, a));
     launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->stream());
-    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->stream());
+    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->stream(), c->digit_mode);
     return witness_from_coef_table(c, d, out);
 }
 int BbCtx::witness_from_f_coeff(const uint64_t *f_coeff, lf_witness **out) {
@@ -927,10 +935,10 @@ static void compute_x_s(const C *c, const u64 *xh, u64 *x_s) {
         std::vector<int64_t> dB(P.L), dk(P.K);
         std::vector<std::vector<u64>> part(P.K, std::vector<u64>(RE, 0));
         for (int cc = 0; cc < RE; cc++) {
-            bb_balanced_digits(co[cc], P.B, P.L, dB.data());
+            bb_balanced_digits(co[cc], P.B, P.L, dB.data(), c->digit_mode);
             u64 pw = 1;
             for (u32 l = 0; l < P.L; l++) {
-                bb_balanced_digits(hfrom_i64(dB[l]), P.b, P.K, dk.data());
+                bb_balanced_digits(hfrom_i64(dB[l]), P.b, P.K, dk.data(), c->digit_mode);
                 for (u32 k = 0; k < P.K; k++) part[k][cc] = hadd(part[k][cc], hmul(pw, hfrom_i64(dk[k])));
                 pw = hmul(pw, P.B % BB_P);
             }

@@ -23,6 +23,13 @@ struct BbCtx {
     int set_sharding(int rank, int world, lf_exchange_fn cb, void *user);
     int dist_init(int rank, int world, const uint8_t *id128);
     lfdist::Comm *comm();
+    void set_digit_mode(int mode);
+    bool have_ccs() const;
+    const lf_params &params() const;
+    size_t dim_n() const;
+    size_t dim_m() const;
+    size_t dim_N() const;
+    uint32_t kappa() const;
     int set_ring_tables(uint64_t nonres, const uint64_t *y);
     int get_ring_tables(uint64_t *nonres, uint64_t *y);
     int synchronize();

@@ -191,15 +191,21 @@ void BbHostRing::from_h9(const H9 &s, u64 *out) { for (int k = 0; k < 8; k++) st
 
 // stark_rings::balanced_decomposition as recollected (convention is DATA-level "unpinned"): centred lift,
 // truncating remainder, |rem| <= b/2 kept, otherwise rem -+ b with carry +-1, zero padded.
-void bb_balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out) {
+void bb_balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out, int mode) {
     int64_t b = (int64_t)base, half = b / 2;
     int64_t cur = v <= (BB_P - 1) / 2 ? (int64_t)v : (int64_t)v - (int64_t)BB_P;
     for (unsigned k = 0; k < digits; k++) {
         int64_t rem = cur % b, q = cur / b;
-        int64_t ar = rem < 0 ? -rem : rem;
-        if (ar > half) {
-            if (rem < 0) { rem += b; q -= 1; }
-            else { rem -= b; q += 1; }
+        if (mode == 1 && base > 2) {   // floor rule: digits in [-base/2, base/2)
+            if (rem < 0) rem += b;
+            if (rem >= half) rem -= b;
+            q = (cur - rem) / b;
+        } else {
+            int64_t ar = rem < 0 ? -rem : rem;
+            if (ar > half) {
+                if (rem < 0) { rem += b; q -= 1; }
+                else { rem -= b; q += 1; }
+            }
         }
         out[k] = rem;
         cur = q;
@@ -438,8 +444,23 @@ void BbTranscript::squeeze(u64 *out, size_t n) {
         out += take; n -= take; idx = 0;
     }
 }
+static void basis9(const u64 *M, const u64 *v, u64 *o) {   // o = M v over F_p, 9x9 (words < 2^31)
+    for (int i = 0; i < TAU; i++) {
+        u64 acc = 0;
+        for (int j = 0; j < TAU; j++) acc += (M[TAU * i + j] * v[j]) % BB_P;
+        o[i] = acc % BB_P;
+    }
+}
 void BbTranscript::absorb_ring(const u64 *e, size_t count) {
-    for (size_t i = 0; i < count; i++) absorb_fq(e + (size_t)D * i, D);
+    if (!bT_) {
+        for (size_t i = 0; i < count; i++) absorb_fq(e + (size_t)D * i, D);
+        return;
+    }
+    for (size_t i = 0; i < count; i++) {   // internal -> external basis, slot by slot
+        u64 x[D];
+        for (int sl = 0; sl < 8; sl++) basis9(bT_, e + (size_t)D * i + TAU * sl, x + TAU * sl);
+        absorb_fq(x, D);
+    }
 }
 void BbTranscript::absorb_label(const char *s) {
     u64 v = 0;
@@ -449,17 +470,18 @@ void BbTranscript::absorb_label(const char *s) {
 void BbTranscript::absorb_h9_as_ring(const H9 &c) {
     u64 e[D];
     BbHostRing::from_h9(c, e);
-    absorb_fq(e, D);
+    absorb_ring(e, 1);
 }
 void BbTranscript::absorb_u64_as_ring(u64 v) {
     u64 e[D];
     BbHostRing::from_u64(v, e);
-    absorb_fq(e, D);
+    absorb_ring(e, 1);
 }
 H9 BbTranscript::get_challenge() {
     H9 c;
     squeeze(c.c, TAU);
-    absorb_fq(c.c, TAU);
+    absorb_fq(c.c, TAU);      // the squeezed words are the EXTERNAL coordinates and go back as they are
+    if (bTi_) { H9 o; basis9(bTi_, c.c, o.c); return o; }
     return c;
 }
 void BbTranscript::get_short_challenge(u64 out[D]) {

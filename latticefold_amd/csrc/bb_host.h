@@ -46,7 +46,7 @@ struct BbHostRing {
     static void from_u64(u64 v, u64 *out);
     static void from_h9(const H9 &s, u64 *out);
 };
-void bb_balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out);
+void bb_balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out, int mode = 0);
 
 class BbTranscript {
   public:
@@ -62,12 +62,15 @@ class BbTranscript {
     static void permute_scalar(u64 st[24]);        // same factorisation, scalar (reference for the SIMD path)
     static void permute_plain(u64 st[24]);
     static void params(const u64 **ark, const u64 **mds);
+    // external-basis hook, as lf::Transcript::set_basis (T, Ti: 9x9 row-major, ext = T int; nullptr = off)
+    void set_basis(const u64 *T, const u64 *Ti) { bT_ = T; bTi_ = Ti; }
 
   private:
     void squeeze(u64 *out, size_t n);
     u64 st_[24];
     bool squeezing_;
     int idx_;
+    const u64 *bT_ = nullptr, *bTi_ = nullptr;
 };
 
 }  // namespace lfbb

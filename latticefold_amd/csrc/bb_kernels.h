@@ -39,7 +39,7 @@ void launch_crt_fwd(const DevBb &t, const fe *coef, fe *ntt, size_t n, hipStream
 void launch_icrt_dense(const fe *icrt_mat /*72*72*/, const fe *ntt, fe *coef, size_t n, hipStream_t s);
 
 // ---- decomposition ---------------------------------------------------------------------------------------------
-void launch_decompose(const fe *coef, size_t n, u64 base, u32 digits, int layout, fe *out, hipStream_t s);
+void launch_decompose(const fe *coef, size_t n, u64 base, u32 digits, int layout, fe *out, hipStream_t s, int mode = 0);
 void launch_recompose(const fe *in, size_t n_out, u64 base, u32 digits, fe *out, hipStream_t s);
 void launch_coef_to_i32(const fe *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s);
 void launch_i32_to_coef(const int32_t *planes, fe *coef, size_t n, hipStream_t s);

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <future>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -75,10 +76,18 @@ struct lf_ctx {
     lfbb::BbCtx *bb = nullptr;   // BabyBearRingNTT backend (ring 1): every entry point forwards to it
     int device = 0;
     hipStream_t st_lane[2] = {nullptr, nullptr};
+    int digit_mode = 0;   // balanced-digit rule of base-B decompositions (lf_set_digit_mode)
+    ExtBasis xb;          // external coordinate basis of F_{p^tau} (lf_set_ext_basis); identity by default
     Tunables tn;          // environment switches, re-read at the start of every lf_linearize / lf_fold_step
     u32 lin_blocks = 0;   // grid bound of the linearization rounds while a fold step's commit chain runs on the other lane (0 = none)
     std::mutex mu, buf_mu, ev_mu;
     hipStream_t stream() const { return st_lane[t_lane]; }
+    // the same facts for either backend (the external-basis marshalling is ring-agnostic)
+    bool have_ccs_any() const { return bb ? bb->have_ccs() : have_ccs; }
+    const lf_params &params_any() const { return bb ? bb->params() : P; }
+    size_t n_any() const { return bb ? bb->dim_n() : n; }
+    size_t m_any() const { return bb ? bb->dim_m() : m; }
+    size_t N_any() const { return bb ? bb->dim_N() : N; }
     HostRing ring;
     DevCrt dcrt;
     u64 *d_icrt = nullptr;
@@ -352,6 +361,56 @@ int lf_get_ring_tables(lf_ctx *c, uint64_t *nonres, uint64_t *y) {
         for (int q = 0; q < 3; q++) y[3 * k + q] = c->ring.T.y[k].c[q];
     return LF_OK;
 }
+// ---- external coordinate basis: marshalling of one ABI call ---------------------------------------------------------
+// With a non-identity basis every entry point below first re-enters itself on converted copies of its NTT-form inputs (external ->
+// internal coordinates), converts its outputs back in place, and -- for the prover entry points -- switches the transcript into
+// "absorb internal, speak external" mode for the duration of the call.
+static thread_local bool t_xb_active = false;
+struct XB {
+    lf_ctx *c;
+    size_t RE, TAU;
+    std::vector<std::unique_ptr<std::vector<u64>>> keep;
+    lf_transcript *tr = nullptr;
+    explicit XB(lf_ctx *cc) : c(cc), RE((size_t)lf_ring_words(lf_ctx_ring(cc))), TAU((size_t)lf_ring_tau(lf_ctx_ring(cc))) { t_xb_active = true; }
+    ~XB() {
+        t_xb_active = false;
+        if (tr) { tr->t.set_basis(nullptr, nullptr); if (tr->bb) tr->bb->set_basis(nullptr, nullptr); }
+    }
+    const u64 *ring_in(const u64 *p, size_t elems) {   // NTT-form ring elements, external -> internal (copy)
+        if (!p) return p;
+        keep.emplace_back(new std::vector<u64>(p, p + elems * RE));
+        c->xb.to_int(keep.back()->data(), elems * 8);
+        return keep.back()->data();
+    }
+    const u64 *ext_in(const u64 *p, size_t n) {        // F_{p^tau} elements (tau words each)
+        if (!p) return p;
+        keep.emplace_back(new std::vector<u64>(p, p + n * TAU));
+        c->xb.to_int(keep.back()->data(), n);
+        return keep.back()->data();
+    }
+    void ring_out(u64 *p, size_t elems) { if (p) c->xb.to_ext(p, elems * 8); }
+    void ext_out(u64 *p, size_t n) { if (p) c->xb.to_ext(p, n); }
+    void transcript(lf_transcript *t) {
+        tr = t;
+        if (t->bb) t->bb->set_basis(c->xb.T, c->xb.Ti);
+        else t->t.set_basis(c->xb.T, c->xb.Ti);
+    }
+};
+#define LF_XB(c) ((c) && (c)->xb.on && !t_xb_active)
+
+int lf_set_digit_mode(lf_ctx *c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->digit_mode = mode;
+    if (c->bb) c->bb->set_digit_mode(mode);
+    return LF_OK;
+}
+int lf_set_ext_basis(lf_ctx *c, const uint64_t *T) {
+    if (!c || !T) return LF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    const int ring = lf_ctx_ring(c);
+    return c->xb.set(T, lf_ring_tau(ring), lf_ring_modulus(ring));
+}
 int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *user) {
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
     if (c->bb) return c->bb->set_sharding(rank, world, cb, user);
@@ -475,6 +534,7 @@ int lf_selftest_field(lf_ctx *c, uint64_t seed, uint32_t n, uint64_t *mismatches
 
 // ---- a1/a2 --------------------------------------------------------------------------------------------------------
 int lf_ntt_fwd(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
+    if (LF_XB(c)) { XB x(c); int rc = lf_ntt_fwd(c, in, out, count); if (rc == LF_OK) x.ring_out(out, count); return rc; }
     if (!c || (!in && count) || (!out && count)) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ntt_fwd(in, out, count);
     std::lock_guard<std::mutex> g(c->mu);
@@ -487,6 +547,7 @@ int lf_ntt_fwd(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
     return down_ring(c, b, count, out);
 }
 int lf_ntt_inv(lf_ctx *c, const uint64_t *in, uint64_t *out, size_t count) {
+    if (LF_XB(c) && in) { XB x(c); return lf_ntt_inv(c, x.ring_in(in, count), out, count); }
     if (!c || (!in && count) || (!out && count)) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ntt_inv(in, out, count);
     std::lock_guard<std::mutex> g(c->mu);
@@ -509,7 +570,7 @@ int lf_decompose(lf_ctx *c, const uint64_t *in, size_t count, uint64_t base, uns
     RET(c->tbuf("io_a", count * 24, &a));
     RET(c->tbuf("io_b", count * digits * 24, &b));
     RET(up_ring(c, in, count, a));
-    launch_decompose(a, count, base, digits, layout, b, c->stream());
+    launch_decompose(a, count, base, digits, layout, b, c->stream(), c->digit_mode);
     if (layout == 0) return down_ring(c, b, count * digits, out);
     for (unsigned k = 0; k < digits; k++) RET(down_ring(c, b + (size_t)k * 24 * count, count, out + (size_t)k * count * 24));
     return LF_OK;
@@ -527,6 +588,7 @@ int lf_recompose(lf_ctx *c, const uint64_t *in, size_t count_out, uint64_t base,
     return down_ring(c, b, count_out, out);
 }
 int lf_linf_check(lf_ctx *c, const uint64_t *f_ntt, size_t count, uint64_t bound, int unsigned_variant, int *ok, uint64_t *max_out) {
+    if (LF_XB(c) && f_ntt) { XB x(c); return lf_linf_check(c, x.ring_in(f_ntt, count), count, bound, unsigned_variant, ok, max_out); }
     if (!c || !f_ntt || !ok) return LF_ERR_INVALID;
     if (c->bb) return c->bb->linf_check(f_ntt, count, bound, unsigned_variant, ok, max_out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -566,6 +628,7 @@ static int shard_columns(lf_ctx *c, size_t n, size_t *col0, size_t *cnt) {
     return LF_OK;
 }
 int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
+    if (LF_XB(c) && A && kappa <= 128) { XB x(c); return lf_ajtai_load(c, x.ring_in(A, kappa * n), kappa, n); }
     if (!c || !A || !kappa || !n || kappa > 128) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ajtai_load(A, kappa, n);
     std::lock_guard<std::mutex> g(c->mu);
@@ -653,6 +716,13 @@ static int gather_slices(lf_ctx *c, u64 *buf, size_t planes, size_t n) {
     return LF_OK;
 }
 int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
+    if (LF_XB(c) && f && out) {
+        XB x(c);
+        u32 kap = c->bb ? 0 : c->kappa;
+        int rc = lf_ajtai_commit(c, x.ring_in(f, n * batch), n, batch, out);
+        if (rc == LF_OK) x.ring_out(out, batch * (c->bb ? c->bb->kappa() : kap));
+        return rc;
+    }
     if (!c || !f || !out || !batch) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ajtai_commit(f, n, batch, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -717,6 +787,7 @@ static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {
     return LF_OK;
 }
 int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {
+    if (LF_XB(c) && point && out && nv && nv <= 40) { XB x(c); int rc = lf_build_eq(c, x.ext_in(point, nv), nv, out); if (rc == LF_OK) x.ext_out(out, (size_t)1 << nv); return rc; }
     if (!c || !point || !out || nv == 0 || nv > 40) return LF_ERR_INVALID;
     if (c->bb) return c->bb->build_eq(point, nv, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -735,6 +806,12 @@ int lf_build_eq(lf_ctx *c, const uint64_t *point, unsigned nv, uint64_t *out) {
     return LF_OK;
 }
 int lf_mle_eval_batch(lf_ctx *c, const uint64_t *tables, size_t ntables, size_t len, const uint64_t *point, unsigned nv, uint64_t *out) {
+    if (LF_XB(c) && tables && point && out) {
+        XB x(c);
+        int rc = lf_mle_eval_batch(c, x.ring_in(tables, ntables * len), ntables, len, x.ext_in(point, nv), nv, out);
+        if (rc == LF_OK) x.ring_out(out, ntables);
+        return rc;
+    }
     if (!c || !tables || !point || !out || !ntables || nv == 0 || nv > 40) return LF_ERR_INVALID;
     if (c->bb) return c->bb->mle_eval_batch(tables, ntables, len, point, nv, out);
     size_t n = (size_t)1 << nv;
@@ -767,6 +844,16 @@ size_t lf_proof_len(const lf_params *p) { return lin_proof_len(p) + 2 * dec_proo
 
 int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
                 const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *cc) {
+    if (LF_XB(c) && p && rowptr && col && val && S_off && S_idx && cc && p->t >= 1 && p->t <= 4 && p->s <= 30 && p->q <= 8) {
+        XB x(c);
+        const size_t m = (size_t)1 << p->s;
+        const uint64_t *v2[4];
+        for (u32 j = 0; j < p->t; j++) {
+            if (!rowptr[j] || !val[j]) return LF_ERR_INVALID;
+            v2[j] = x.ring_in(val[j], rowptr[j][m]);
+        }
+        return lf_ccs_load(c, p, rowptr, col, v2, S_off, S_idx, x.ring_in(cc, p->q));
+    }
     if (!c || !p || !rowptr || !col || !val || !S_off || !S_idx || !cc) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ccs_load(p, rowptr, col, val, S_off, S_idx, cc);
     if (p->s < 3 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 31 || p->L == 0 || p->L > 8 ||
@@ -845,6 +932,7 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
     return LF_OK;
 }
 int lf_spmv(lf_ctx *c, unsigned j, const uint64_t *z, uint64_t *out) {
+    if (LF_XB(c) && z && out && c->have_ccs_any()) { XB x(c); int rc = lf_spmv(c, j, x.ring_in(z, c->n_any()), out); if (rc == LF_OK) x.ring_out(out, c->m_any()); return rc; }
     if (!c || !z || !out) return LF_ERR_INVALID;
     if (c->bb) return c->bb->spmv(j, z, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -878,6 +966,7 @@ static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] can
     return LF_OK;
 }
 int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
+    if (LF_XB(c) && w_ccs && c->have_ccs_any()) { XB x(c); return lf_witness_from_w_ccs(c, x.ring_in(w_ccs, c->params_any().wit_len), out); }
     if (!c || !w_ccs || !out) return LF_ERR_INVALID;
     if (c->bb) return c->bb->witness_from_w_ccs(w_ccs, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -890,7 +979,7 @@ int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
     RET(c->tbuf("io_c", c->N * 24, &d));
     RET(up_ring(c, w_ccs, c->P.wit_len, a));
     launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->stream());
-    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->stream());
+    launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->stream(), c->digit_mode);
     return witness_from_coef_table(c, d, out);
 }
 int lf_witness_from_f_coeff(lf_ctx *c, const uint64_t *f_coeff, lf_witness **out) {
@@ -905,6 +994,7 @@ int lf_witness_from_f_coeff(lf_ctx *c, const uint64_t *f_coeff, lf_witness **out
     return witness_from_coef_table(c, d, out);
 }
 int lf_witness_from_f(lf_ctx *c, const uint64_t *f_ntt, lf_witness **out) {
+    if (LF_XB(c) && f_ntt && c->have_ccs_any()) { XB x(c); return lf_witness_from_f(c, x.ring_in(f_ntt, c->N_any()), out); }
     if (!c || !f_ntt || !out) return LF_ERR_INVALID;
     if (c->bb) return c->bb->witness_from_f(f_ntt, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -928,6 +1018,7 @@ int lf_witness_get_f_coeff(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     return down_ring(c, d, w->N, out);
 }
 int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
+    if (LF_XB(c) && w && out) { XB x(c); int rc = lf_witness_get_f(c, w, out); if (rc == LF_OK) x.ring_out(out, w->N); return rc; }
     if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return c->bb->witness_get_f(w, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -940,6 +1031,7 @@ int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     return down_ring(c, e, w->N, out);
 }
 int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
+    if (LF_XB(c) && w && out && c->have_ccs_any()) { XB x(c); int rc = lf_witness_get_w_ccs(c, w, out); if (rc == LF_OK) x.ring_out(out, c->params_any().wit_len); return rc; }
     if (!c || !w || !out || w->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return c->bb->witness_get_w_ccs(w, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -951,6 +1043,7 @@ int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     return down_ring(c, e, c->P.wit_len, out);
 }
 int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
+    if (LF_XB(c) && w && cm_out) { XB x(c); int rc = lf_witness_commit(c, w, cm_out); if (rc == LF_OK) x.ring_out(cm_out, c->bb ? c->bb->kappa() : c->kappa); return rc; }
     if (!c || !w || !cm_out || w->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return c->bb->witness_commit(w, cm_out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -1256,10 +1349,10 @@ static void compute_x_s(const lf_ctx *c, const u64 *xh /* (l+1) NTT */, u64 *x_s
         std::vector<int64_t> dB(P.L), dk(P.K);
         std::vector<std::vector<u64>> part(P.K, std::vector<u64>(24, 0));
         for (int cc = 0; cc < 24; cc++) {
-            balanced_digits(co[cc], P.B, P.L, dB.data());
+            balanced_digits(co[cc], P.B, P.L, dB.data(), c->digit_mode);
             u64 pw = 1;
             for (u32 l = 0; l < P.L; l++) {
-                balanced_digits(fq_from_i64(dB[l]), P.b, P.K, dk.data());
+                balanced_digits(fq_from_i64(dB[l]), P.b, P.K, dk.data(), c->digit_mode);
                 for (u32 k = 0; k < P.K; k++) {
                     u64 term = fq_mul(pw, fq_from_i64(dk[k]));
                     part[k][cc] = fq_add(part[k][cc], term);
@@ -1457,7 +1550,7 @@ static int lin_tail_rounds(lf_ctx *c, Transcript &tr, const u64 *cur, const u64 
     if (++c->tail_epoch >= (1u << 30)) c->tail_epoch = 1;
     A.epoch = c->tail_epoch;
     A.r_first = f3c(point[round - 2]);
-    A.dev_transcript = c->tn.device_transcript ? 1u : 0u;
+    A.dev_transcript = (c->tn.device_transcript && !c->xb.on) ? 1u : 0u;   // the device sponge absorbs internal-basis words
     A.pos_ark = A.pos_mds = nullptr; A.sponge_state = nullptr;
     if (A.dev_transcript) {
         RET(tail_sponge_to_device(c, tr, &A.sponge_state));
@@ -1485,7 +1578,7 @@ static int fold_tail_rounds(lf_ctx *c, Transcript &tr, const FoldRoundArgs &a, u
     if (++c->tail_epoch >= (1u << 30)) c->tail_epoch = 1;
     A.epoch = c->tail_epoch;
     A.r_first = f3c(pt[round - 2]);
-    A.dev_transcript = c->tn.device_transcript ? 1u : 0u;
+    A.dev_transcript = (c->tn.device_transcript && !c->xb.on) ? 1u : 0u;   // the device sponge absorbs internal-basis words
     A.pos_ark = A.pos_mds = nullptr; A.sponge_state = nullptr;
     if (A.dev_transcript) {   // LF_DEVICE_TRANSCRIPT=1: hand the sponge to the device for the tail rounds
         RET(tail_sponge_to_device(c, tr, &A.sponge_state));
@@ -1866,6 +1959,15 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
 }
 
 int lf_linearize(lf_ctx *c, lf_transcript *t, const uint64_t *cccs, const lf_witness *wit, uint64_t *lcccs_out, uint64_t *lin_proof_out) {
+    if (LF_XB(c) && t && cccs && lcccs_out && lin_proof_out && c->have_ccs_any()) {
+        XB x(c);
+        const lf_params &P = c->params_any();
+        const int ring = lf_ctx_ring(c);
+        x.transcript(t);
+        int rc = lf_linearize(c, t, x.ring_in(cccs, lf_cccs_len_ring(&P, ring)), wit, lcccs_out, lin_proof_out);
+        if (rc == LF_OK) { x.ring_out(lcccs_out, lf_lcccs_len_ring(&P, ring)); x.ring_out(lin_proof_out, (size_t)P.s * (P.d + 2) + x.TAU + P.t); }
+        return rc;
+    }
     if (!c || !t || !cccs || !wit || !lcccs_out || !lin_proof_out || wit->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return t->bb ? c->bb->linearize(*t->bb, cccs, wit, lcccs_out, lin_proof_out) : LF_ERR_INVALID;
     if (t->bb) return LF_ERR_INVALID;
@@ -1883,6 +1985,15 @@ int lf_linearize(lf_ctx *c, lf_transcript *t, const uint64_t *cccs, const lf_wit
 
 int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witness *w_acc, const uint64_t *cm_i, const lf_witness *w_i,
                  uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof) {
+    if (LF_XB(c) && t && acc && cm_i && lcccs_out && proof && c->have_ccs_any()) {
+        XB x(c);
+        const lf_params &P = c->params_any();
+        const int ring = lf_ctx_ring(c);
+        x.transcript(t);
+        int rc = lf_fold_step(c, t, x.ring_in(acc, lf_lcccs_len_ring(&P, ring)), w_acc, x.ring_in(cm_i, lf_cccs_len_ring(&P, ring)), w_i, lcccs_out, w_out, proof);
+        if (rc == LF_OK) { x.ring_out(lcccs_out, lf_lcccs_len_ring(&P, ring)); x.ring_out(proof, lf_proof_len_ring(&P, ring)); }
+        return rc;
+    }
     if (!c || !t || !acc || !w_acc || !cm_i || !w_i || !lcccs_out || !w_out || !proof) return LF_ERR_INVALID;
     if (w_acc->ctx != c || w_i->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return t->bb ? c->bb->fold_step(*t->bb, acc, w_acc, cm_i, w_i, lcccs_out, w_out, proof) : LF_ERR_INVALID;
@@ -1996,6 +2107,16 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
 // LFDecompositionProver::prove (nifs/decomposition.rs:33-88) as its own entry point: the reference exposes the three sub-provers as
 // public traits; this is the middle one.  The K decomposed witnesses stay virtual (bit-planes of `wit`).
 int lf_decomposition_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs, const lf_witness *wit, uint64_t *lcccs_s_out, uint64_t *dec_proof_out) {
+    if (LF_XB(c) && t && lcccs && dec_proof_out && c->have_ccs_any()) {
+        XB x(c);
+        const lf_params &P = c->params_any();
+        const int ring = lf_ctx_ring(c);
+        const size_t ll = lf_lcccs_len_ring(&P, ring);
+        x.transcript(t);
+        int rc = lf_decomposition_prove(c, t, x.ring_in(lcccs, ll), wit, lcccs_s_out, dec_proof_out);
+        if (rc == LF_OK) { x.ring_out(lcccs_s_out, (size_t)P.K * ll); x.ring_out(dec_proof_out, (size_t)P.K * (P.t + x.TAU + P.l + 1 + P.kappa)); }
+        return rc;
+    }
     if (!c || !t || !lcccs || !wit || !dec_proof_out || wit->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return t->bb ? c->bb->decomposition_prove(*t->bb, lcccs, wit, lcccs_s_out, dec_proof_out) : LF_ERR_INVALID;
     if (t->bb) return LF_ERR_INVALID;
@@ -2025,6 +2146,16 @@ int lf_decomposition_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs, c
 // decomposition, then K of the linearized instance's), w_left / w_right = the witnesses whose base-b parts they commit to.
 int lf_folding_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs_s, const lf_witness *w_left, const lf_witness *w_right,
                      uint64_t *lcccs_out, lf_witness **w_out, uint64_t *fold_proof_out) {
+    if (LF_XB(c) && t && lcccs_s && lcccs_out && fold_proof_out && c->have_ccs_any()) {
+        XB x(c);
+        const lf_params &P = c->params_any();
+        const int ring = lf_ctx_ring(c);
+        const size_t ll = lf_lcccs_len_ring(&P, ring);
+        x.transcript(t);
+        int rc = lf_folding_prove(c, t, x.ring_in(lcccs_s, 2 * (size_t)P.K * ll), w_left, w_right, lcccs_out, w_out, fold_proof_out);
+        if (rc == LF_OK) { x.ring_out(lcccs_out, ll); x.ring_out(fold_proof_out, (size_t)P.s * (2 * P.b + 1) + 2 * (size_t)P.K * (x.TAU + P.t)); }
+        return rc;
+    }
     if (!c || !t || !lcccs_s || !w_left || !w_right || !lcccs_out || !w_out || !fold_proof_out) return LF_ERR_INVALID;
     if (w_left->ctx != c || w_right->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return t->bb ? c->bb->folding_prove(*t->bb, lcccs_s, w_left, w_right, lcccs_out, w_out, fold_proof_out) : LF_ERR_INVALID;
@@ -2065,6 +2196,7 @@ int lf_folding_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs_s, const
 
 // ---- generic linearization-shaped sumcheck through the ABI (tests / SURVEY 8b) -------------------------------------------------
 int lf_sumcheck_lin_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *eq_point) {
+    if (LF_XB(c) && tables && eq_point && c->have_ccs_any()) { XB x(c); const lf_params &P = c->params_any(); return lf_sumcheck_lin_begin(c, x.ring_in(tables, (size_t)P.t * c->m_any()), x.ext_in(eq_point, P.s)); }
     if (!c || !tables || !eq_point) return LF_ERR_INVALID;
     if (c->bb) return c->bb->sumcheck_lin_begin(tables, eq_point);
     std::lock_guard<std::mutex> g(c->mu);
@@ -2083,6 +2215,7 @@ int lf_sumcheck_lin_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *eq_
     return LF_OK;
 }
 int lf_sumcheck_lin_round(lf_ctx *c, const uint64_t *r_prev, uint64_t *evals_out) {
+    if (LF_XB(c) && evals_out) { XB x(c); int rc = lf_sumcheck_lin_round(c, x.ext_in(r_prev, 1), evals_out); if (rc == LF_OK) x.ring_out(evals_out, c->params_any().d + 2); return rc; }
     if (!c || !evals_out) return LF_ERR_INVALID;
     if (c->bb) return c->bb->sumcheck_lin_round(r_prev, evals_out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -2156,6 +2289,7 @@ int lf_device_sponge(lf_ctx *c, const uint32_t *ops, size_t nops, const uint64_t
 // create_sumcheck_polynomial (folding/utils.rs:200-259): [eq(r_L), G_L, eq(r_R), G_R, eq(beta), f-hat_{0,0} .. f-hat_{2K-1,tau-1}],
 // P = 5 + 2K*tau tables of m ring elements; the three eq tables must be slot-constant (they are diagonal embeddings in the reference).
 int lf_sumcheck_fold_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *mu) {
+    if (LF_XB(c) && tables && mu && c->have_ccs_any()) { XB x(c); const lf_params &P = c->params_any(); return lf_sumcheck_fold_begin(c, x.ring_in(tables, (size_t)(5 + 2 * P.K * x.TAU) * c->m_any()), x.ext_in(mu, 2 * P.K)); }
     if (!c || !tables || !mu) return LF_ERR_INVALID;
     if (c->bb) return c->bb->sumcheck_fold_begin(tables, mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -2193,6 +2327,7 @@ int lf_sumcheck_fold_begin(lf_ctx *c, const uint64_t *tables, const uint64_t *mu
     return LF_OK;
 }
 int lf_sumcheck_fold_round(lf_ctx *c, const uint64_t *r_prev, uint64_t *evals_out) {
+    if (LF_XB(c) && evals_out) { XB x(c); int rc = lf_sumcheck_fold_round(c, x.ext_in(r_prev, 1), evals_out); if (rc == LF_OK) x.ring_out(evals_out, 2 * c->params_any().b + 1); return rc; }
     if (!c || !evals_out) return LF_ERR_INVALID;
     if (c->bb) return c->bb->sumcheck_fold_round(r_prev, evals_out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -2237,6 +2372,7 @@ int lf_sumcheck_fold_end(lf_ctx *c) {
 
 // compute_f_0 (nifs/folding.rs:258-268): out[j] = sum_i coef_i (.) tables_i[j] with ring-element coefficients (8 distinct slots)
 int lf_lincomb(lf_ctx *c, const uint64_t *coef, const uint64_t *tables, size_t n_terms, size_t len, uint64_t *out) {
+    if (LF_XB(c) && coef && tables && out) { XB x(c); int rc = lf_lincomb(c, x.ring_in(coef, n_terms), x.ring_in(tables, n_terms * len), n_terms, len, out); if (rc == LF_OK) x.ring_out(out, len); return rc; }
     if (!c || !coef || !tables || !out || !n_terms || !len) return LF_ERR_INVALID;
     if (c->bb) return c->bb->lincomb(coef, tables, n_terms, len, out);
     std::lock_guard<std::mutex> g(c->mu);
@@ -2257,6 +2393,7 @@ int lf_lincomb(lf_ctx *c, const uint64_t *coef, const uint64_t *tables, size_t n
 // calculate_challenged_mz_mle (nifs/folding.rs:208-226) and the f-hat half of prepare_g1_and_3_k_mles_list (folding/utils.rs:524-546):
 // out[x] = sum_{i<groups} sum_{j<per_group} c_i^{j+1} T_{i,j}[x] (the reference's Horner loop `mle += M; mle *= c_i` over j reversed)
 int lf_horner_combine(lf_ctx *c, const uint64_t *tables, size_t groups, size_t per_group, size_t len, const uint64_t *challenges, uint64_t *out) {
+    if (LF_XB(c) && tables && challenges && out) { XB x(c); int rc = lf_horner_combine(c, x.ring_in(tables, groups * per_group * len), groups, per_group, len, x.ext_in(challenges, groups), out); if (rc == LF_OK) x.ring_out(out, len); return rc; }
     if (!c || !tables || !challenges || !out || !groups || !per_group || !len) return LF_ERR_INVALID;
     if (c->bb) return c->bb->horner_combine(tables, groups, per_group, len, challenges, out);
     std::lock_guard<std::mutex> g(c->mu);

@@ -106,3 +106,58 @@ static inline int lf_validate_csr(unsigned t, size_t m, size_t n, const uint32_t
     }
     return LF_OK;
 }
+
+// External coordinate basis of F_{p^tau} (SURVEY 8c "conventions are data"): the kernels compute in the binomial basis 1, Y, .., Y^(tau-1) of
+// F_p[Y]/(Y^tau - nu); the caller's library may present field elements in another F_p-basis (a tower basis, a permuted order ...):
+// ext = T * int, per slot.  Everything that crosses the ABI in NTT form and everything the transcript absorbs / squeezes is converted
+// with T / T^-1; T = identity (the default) costs nothing.
+struct ExtBasis {
+    bool on = false;
+    int tau = 0;
+    uint64_t p = 0;
+    uint64_t T[81], Ti[81];
+    static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)(((unsigned __int128)a * b) % p); }
+    void apply(const uint64_t *M, uint64_t *v) const {   // v (tau words) <- M v
+        uint64_t o[9];
+        for (int i = 0; i < tau; i++) {
+            unsigned __int128 acc = 0;
+            for (int j = 0; j < tau; j++) acc += (unsigned __int128)mulmod(M[i * tau + j], v[j], p);
+            o[i] = (uint64_t)(acc % p);
+        }
+        for (int i = 0; i < tau; i++) v[i] = o[i];
+    }
+    void to_ext(uint64_t *v, size_t slots) const { if (on) for (size_t s = 0; s < slots; s++) apply(T, v + s * tau); }
+    void to_int(uint64_t *v, size_t slots) const { if (on) for (size_t s = 0; s < slots; s++) apply(Ti, v + s * tau); }
+    // returns LF_ERR_BAD_TABLES when T is singular or does not fix 1 (the base field must sit in coordinate 0 of both bases)
+    int set(const uint64_t *Tin, int tau_, uint64_t p_) {
+        tau = tau_; p = p_;
+        uint64_t M[9][18];
+        bool ident = true;
+        for (int i = 0; i < tau; i++)
+            for (int j = 0; j < tau; j++) {
+                uint64_t v = Tin[i * tau + j] % p;
+                T[i * tau + j] = v; M[i][j] = v; M[i][tau + j] = i == j;
+                if (v != (uint64_t)(i == j)) ident = false;
+            }
+        for (int i = 0; i < tau; i++)
+            if (T[i * tau] != (uint64_t)(i == 0)) return LF_ERR_BAD_TABLES;
+        auto inv = [&](uint64_t a) { uint64_t r = 1, e = p - 2; while (e) { if (e & 1) r = mulmod(r, a, p); a = mulmod(a, a, p); e >>= 1; } return r; };
+        for (int c = 0; c < tau; c++) {
+            int piv = -1;
+            for (int r = c; r < tau; r++) if (M[r][c]) { piv = r; break; }
+            if (piv < 0) return LF_ERR_BAD_TABLES;
+            if (piv != c) for (int k = 0; k < 2 * tau; k++) { uint64_t t = M[piv][k]; M[piv][k] = M[c][k]; M[c][k] = t; }
+            uint64_t iv = inv(M[c][c]);
+            for (int k = 0; k < 2 * tau; k++) M[c][k] = mulmod(M[c][k], iv, p);
+            for (int r = 0; r < tau; r++) {
+                if (r == c || !M[r][c]) continue;
+                uint64_t f = M[r][c];
+                for (int k = 0; k < 2 * tau; k++) { uint64_t t = mulmod(f, M[c][k], p); M[r][k] = M[r][k] >= t ? M[r][k] - t : M[r][k] + (p - t); }   // (no a + p: p is 64 bits wide for Goldilocks)
+            }
+        }
+        for (int i = 0; i < tau; i++)
+            for (int j = 0; j < tau; j++) Ti[i * tau + j] = M[i][tau + j];
+        on = !ident;
+        return LF_OK;
+    }
+};

@@ -162,15 +162,21 @@ bool HostRing::is_diag(const u64 *e, Fq3 *out) {
 
 // stark_rings::balanced_decomposition as recollected (source absent; convention is DATA-level "unpinned"):
 // centred lift, truncating remainder, |rem| <= b/2 kept, otherwise rem -+ b with carry +-1, zero padded.
-void balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out) {
+void balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out, int mode) {
     __int128 b = (__int128)base, half = b / 2;
     __int128 cur = v <= (LF_P - 1) / 2 ? (__int128)v : (__int128)v - (__int128)LF_P;
     for (unsigned k = 0; k < digits; k++) {
         __int128 rem = cur % b, q = cur / b;
-        __int128 ar = rem < 0 ? -rem : rem;
-        if (ar > half) {
-            if (rem < 0) { rem += b; q -= 1; }
-            else { rem -= b; q += 1; }
+        if (mode == 1 && base > 2) {   // floor rule: digits in [-base/2, base/2)
+            if (rem < 0) rem += b;
+            if (rem >= half) rem -= b;
+            q = (cur - rem) / b;
+        } else {
+            __int128 ar = rem < 0 ? -rem : rem;
+            if (ar > half) {
+                if (rem < 0) { rem += b; q -= 1; }
+                else { rem -= b; q += 1; }
+            }
         }
         out[k] = (int64_t)rem;
         cur = q;
@@ -482,8 +488,19 @@ void Transcript::squeeze(u64 *out, size_t n) {
     }
 }
 
+static void basis3(const u64 *M, const u64 *v, u64 *o) {   // o = M v over F_p, 3x3
+    for (int i = 0; i < 3; i++) o[i] = fq_add(fq_add(fq_mul(M[3 * i], v[0]), fq_mul(M[3 * i + 1], v[1])), fq_mul(M[3 * i + 2], v[2]));
+}
 void Transcript::absorb_ring(const u64 *e, size_t count) {
-    for (size_t i = 0; i < count; i++) absorb_fq(e + 24 * i, 24);
+    if (!bT_) {
+        for (size_t i = 0; i < count; i++) absorb_fq(e + 24 * i, 24);
+        return;
+    }
+    for (size_t i = 0; i < count; i++) {   // internal -> external basis, slot by slot
+        u64 x[24];
+        for (int sl = 0; sl < 8; sl++) basis3(bT_, e + 24 * i + 3 * sl, x + 3 * sl);
+        absorb_fq(x, 24);
+    }
 }
 void Transcript::absorb_label(const char *s) {
     unsigned __int128 v = 0;
@@ -493,17 +510,18 @@ void Transcript::absorb_label(const char *s) {
 void Transcript::absorb_fq3_as_ring(Fq3 c) {
     u64 e[24];
     HostRing::from_fq3(c, e);
-    absorb_fq(e, 24);
+    absorb_ring(e, 1);
 }
 void Transcript::absorb_u64_as_ring(u64 v) {
     u64 e[24];
     HostRing::from_u64(v, e);
-    absorb_fq(e, 24);
+    absorb_ring(e, 1);
 }
 Fq3 Transcript::get_challenge() {
     u64 c[3];
     squeeze(c, 3);
-    absorb_fq(c, 3);
+    absorb_fq(c, 3);          // the squeezed words are the EXTERNAL coordinates and go back as they are
+    if (bTi_) { u64 o[3]; basis3(bTi_, c, o); return fq3_make(o[0], o[1], o[2]); }
     return fq3_make(c[0], c[1], c[2]);
 }
 void Transcript::get_short_challenge(u64 out[24]) {

@@ -58,7 +58,7 @@ struct HostRing {
 };
 
 // balanced digits of one canonical coefficient (stark_rings::balanced_decomposition)
-void balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out);
+void balanced_digits(u64 v, u64 base, unsigned digits, int64_t *out, int mode = 0);   // mode: see lf_set_digit_mode
 
 // ---- Poseidon + transcript (crates/latticefold/src/transcript/poseidon.rs:29-75) ------------------------------
 class Transcript {
@@ -77,6 +77,10 @@ class Transcript {
     static void params(const u64 **ark, const u64 **mds);
     // sponge state hand-over to / from the device sponge (lf_kernels.hip): 24 state words, rate index, mode (1 = squeezing)
     void get_state(u64 out[26]) const { for (int i = 0; i < 24; i++) out[i] = st_[i]; out[24] = (u64)idx_; out[25] = squeezing_ ? 1 : 0; }
+    // External-basis hook (lf_set_ext_basis): while set, ring elements / challenges handed to absorb_ring / absorb_fq3_as_ring /
+    // absorb_u64_as_ring are INTERNAL-basis words and are converted to the external basis before the sponge sees them, and get_challenge
+    // returns the internal coordinates of the squeezed (external) challenge.  T, Ti: 3x3 row-major, ext = T int; nullptr = off.
+    void set_basis(const u64 *T, const u64 *Ti) { bT_ = T; bTi_ = Ti; }
     void set_state(const u64 in[26]) { for (int i = 0; i < 24; i++) st_[i] = in[i]; idx_ = (int)in[24]; squeezing_ = in[25] != 0; }
 
   private:
@@ -84,6 +88,7 @@ class Transcript {
     u64 st_[24];
     bool squeezing_;
     int idx_;
+    const u64 *bT_ = nullptr, *bTi_ = nullptr;
 };
 
 }  // namespace lf

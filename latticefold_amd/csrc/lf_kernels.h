@@ -44,7 +44,8 @@ void launch_icrt_dense(const u64 *icrt_mat /*24*24 dev*/, const u64 *ntt, u64 *c
 // ---- decomposition (a3) ----------------------------------------------------------------------------------------
 // generic balanced digits on canonical coefficient tables: out has `digits` tables; layout 0: element i ->
 // out index i*digits+k (n_out = n*digits), layout 1: table k at out + k*24*n
-void launch_decompose(const u64 *coef, size_t n, u64 base, u32 digits, int layout, u64 *out, hipStream_t s);
+// mode: balanced-digit rule (0 = sign-magnitude truncation, ties kept; 1 = floor rule, digits in [-base/2, base/2); base 2 always 0)
+void launch_decompose(const u64 *coef, size_t n, u64 base, u32 digits, int layout, u64 *out, hipStream_t s, int mode = 0);
 void launch_recompose(const u64 *in, size_t n_out, u64 base, u32 digits, u64 *out, hipStream_t s);
 // canonical coefficients -> centred i32 planes; *viol is set to 1 if some |v| > bound
 void launch_coef_to_i32(const u64 *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s);

@@ -282,7 +282,7 @@ void launch_icrt_dense(const u64 *mat, const u64 *ntt, u64 *coef, size_t n, hipS
 // ---------------------------------------------------------------------------------------------------------
 // balanced decomposition on canonical coefficients, power-of-two base (stark_rings::balanced_decomposition;
 // call sites arith.rs:235, decomposition/utils.rs:23-31,48).  Sign-magnitude, |digit| <= base/2, ties kept.
-__global__ void __launch_bounds__(256) k_decompose(const u64 *coef, size_t n, u32 log_base, u32 digits, int layout, u64 *out) {
+__global__ void __launch_bounds__(256) k_decompose(const u64 *coef, size_t n, u32 log_base, u32 digits, int layout, u64 *out, int mode) {
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * 24) return;
     size_t c = idx / n, i = idx % n;
@@ -291,21 +291,30 @@ __global__ void __launch_bounds__(256) k_decompose(const u64 *coef, size_t n, u3
     u64 mag = neg ? LF_P - v : v;
     u64 half = 1ULL << (log_base - 1), mask = (1ULL << log_base) - 1;
     size_t n_out = layout == 0 ? n * digits : n;
+    int64_t cur = neg ? -(int64_t)mag : (int64_t)mag;   // |centred lift| <= (p-1)/2 < 2^63
     for (u32 k = 0; k < digits; k++) {
-        u64 rem = mag & mask;
-        mag >>= log_base;
         int64_t dg;
-        if (rem > half) { dg = (int64_t)rem - (int64_t)(mask + 1); mag += 1; }
-        else dg = (int64_t)rem;
-        if (neg) dg = -dg;
+        if (mode == 1 && log_base > 1) {
+            // digit mode 1 (data, lf_set_digit_mode): floor / Euclidean rule, digits in [-base/2, base/2): rem = cur mod base, minus base if >= base/2
+            int64_t rem = (int64_t)((u64)cur & mask);
+            if ((u64)rem >= half) rem -= (int64_t)(mask + 1);
+            cur = (cur - rem) >> log_base;
+            dg = rem;
+        } else {
+            u64 rem = mag & mask;
+            mag >>= log_base;
+            if (rem > half) { dg = (int64_t)rem - (int64_t)(mask + 1); mag += 1; }
+            else dg = (int64_t)rem;
+            if (neg) dg = -dg;
+        }
         size_t o = layout == 0 ? (c * n_out + i * digits + k) : ((size_t)k * 24 * n + c * n + i);
         out[o] = fq_from_i64(dg);
     }
 }
-void launch_decompose(const u64 *coef, size_t n, u64 base, u32 digits, int layout, u64 *out, hipStream_t s) {
+void launch_decompose(const u64 *coef, size_t n, u64 base, u32 digits, int layout, u64 *out, hipStream_t s, int mode) {
     u32 lb = 0;
     while ((1ULL << lb) < base) lb++;
-    if (n) hipLaunchKernelGGL(k_decompose, dim3(cdiv(n * 24, 256)), dim3(256), 0, s, coef, n, lb, digits, layout, out);
+    if (n) hipLaunchKernelGGL(k_decompose, dim3(cdiv(n * 24, 256)), dim3(256), 0, s, coef, n, lb, digits, layout, out, mode);
 }
 // out[i] = sum_j base^j in[i*digits + j] on any table (linear, either form)
 __global__ void __launch_bounds__(256) k_recompose(const u64 *in, size_t n_out, u64 base, u32 digits, u64 *out) {

@@ -58,6 +58,11 @@ u64 lfo_modulus(void);
  * primitive 24th root of unity in F_p, all distinct).  Returns 0 or <0 if inconsistent. */
 int lfo_set_ring(u64 nonres, const u64 *y /* 8*3 */);
 void lfo_get_ring(u64 *nonres, u64 *y /* 8*3 */);
+/* the fully general data form of SURVEY 8(c): CRT as a dense d x d matrix (row r = slot-major output coordinate, column c = coefficient
+ * index) and the structure constants of F_{p^tau} in an arbitrary F_p-basis with e_0 = 1 (tau^3 words, e_i e_j = sum_k t[i][j][k] e_k).
+ * Returns 0, or <0 if e_0 is not the unit / the matrix is singular / the map is not multiplicative.  lfo_set_ring returns to the
+ * binomial form. */
+int lfo_set_ring_general(const u64 *crt_matrix, const u64 *tensor);
 void lfo_set_digit_mode(int mode); /* 0 = sign-magnitude truncation (default), 1 = floor/Euclid */
 
 /* ---- element-wise ring ops ------------------------------------------------------------ */

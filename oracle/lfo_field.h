@@ -15,6 +15,9 @@ typedef unsigned __int128 u128;
 typedef struct { u64 c[TAU]; } fqe;
 
 extern u64 lfo_NONRES; /* F_{p^tau} = F_p[Y]/(Y^tau - NONRES) */
+/* general mode (lfo_set_ring_general): structure constants of F_{p^tau} in an arbitrary F_p-basis e_0 = 1, e_1, ..:
+ * e_i * e_j = sum_k TENSOR[(i*tau + j)*tau + k] e_k.  NULL = the binomial basis above. */
+extern const u64 *lfo_TENSOR;
 
 static inline u64 fq_add(u64 a, u64 b) {
     u64 r = a + b;
@@ -63,6 +66,20 @@ static inline fqe fqe_add(fqe a, fqe b) { fqe r; for (int i = 0; i < TAU; i++) r
 static inline fqe fqe_sub(fqe a, fqe b) { fqe r; for (int i = 0; i < TAU; i++) r.c[i] = fq_sub(a.c[i], b.c[i]); return r; }
 /* schoolbook product modulo Y^tau = NONRES */
 static inline fqe fqe_mul(fqe a, fqe b) {
+    if (lfo_TENSOR) {
+        fqe r = fqe_zero();
+        for (int i = 0; i < TAU; i++) {
+            if (!a.c[i]) continue;
+            for (int j = 0; j < TAU; j++) {
+                if (!b.c[j]) continue;
+                u64 pr = fq_mul(a.c[i], b.c[j]);
+                const u64 *t = lfo_TENSOR + (size_t)(i * TAU + j) * TAU;
+                for (int k = 0; k < TAU; k++)
+                    if (t[k]) r.c[k] = fq_add(r.c[k], fq_mul(pr, t[k]));
+            }
+        }
+        return r;
+    }
     u64 lo[TAU], hi[TAU];
     memset(lo, 0, sizeof(lo));
     memset(hi, 0, sizeof(hi));

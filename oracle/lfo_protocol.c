@@ -713,12 +713,11 @@ int lfo_fold_step(const lfo_params *p, const lfo_ccs *ccs, const u64 *A, lfo_tra
 static fqe fqe_inv(fqe a) {
     u64 M[TAU][TAU + 1];
     fqe col = fqe_one();
-    fqe yb = fqe_zero();
-    if (TAU > 1) yb.c[1] = 1;
-    fqe cur = a; /* a * Y^j */
-    for (int j = 0; j < TAU; j++) {
+    for (int j = 0; j < TAU; j++) { /* column j = a * e_j (any basis) */
+        fqe ej = fqe_zero();
+        ej.c[j] = 1;
+        fqe cur = fqe_mul(a, ej);
         for (int i = 0; i < TAU; i++) M[i][j] = cur.c[i];
-        cur = fqe_mul(cur, yb);
     }
     for (int i = 0; i < TAU; i++) M[i][TAU] = col.c[i];
     for (int c = 0; c < TAU; c++) {

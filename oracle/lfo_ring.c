@@ -10,6 +10,10 @@ int lfo_ring_tau(void) { return LFO_TAU; }
 u64 lfo_modulus(void) { return LFO_P; }
 
 static int g_digit_mode = 0;
+const u64 *lfo_TENSOR = NULL;
+static u64 g_tensor[TAU * TAU * TAU];
+static int g_general = 0;        /* CRT given as a dense d x d matrix (lfo_set_ring_general) */
+static u64 g_crt[RE][RE];
 static int g_init = 0;
 static fqe g_y[8];         /* image of X in slot k */
 static fqe g_ypow[8][RE];  /* y_k^i */
@@ -24,6 +28,10 @@ static fqe fqe_pow_small(fqe a, unsigned e) {
 static int build_tables(void) {
     /* CRT as an F_p-linear map: out[3k+c] = sum_i a_i * (y_k^i).c   */
     static u64 M[RE][2 * RE];
+    if (g_general) {
+        for (int r = 0; r < RE; r++)
+            for (int i = 0; i < RE; i++) M[r][i] = g_crt[r][i];
+    } else
     for (int k = 0; k < 8; k++) {
         fqe p = fqe_one();
         for (int i = 0; i < RE; i++) {
@@ -116,8 +124,35 @@ static void ensure_init(void) {
     g_init = 1;
 }
 
+/* SURVEY 8(c) "conventions are data", the fully general form: CRT as a dense d x d matrix over F_p (out[r] = sum_c crt[r*d + c] coef[c],
+ * rows in slot-major coordinate order) and the structure constants of F_{p^tau} in the caller's basis (e_0 = 1).  Checked: e_0 is the
+ * unit, the map is invertible and multiplicative on X * X^j (ring homomorphism on the monomials). */
+int lfo_set_ring_general(const u64 *crt, const u64 *tensor) {
+    ensure_init();
+    for (int j = 0; j < TAU; j++)
+        for (int k = 0; k < TAU; k++)
+            if (tensor[(size_t)(0 * TAU + j) * TAU + k] % LFO_P != (u64)(j == k) || tensor[(size_t)(j * TAU + 0) * TAU + k] % LFO_P != (u64)(j == k)) return -1;
+    for (int i = 0; i < TAU * TAU * TAU; i++) g_tensor[i] = tensor[i] % LFO_P;
+    for (int r = 0; r < RE; r++)
+        for (int c = 0; c < RE; c++) g_crt[r][c] = crt[(size_t)r * RE + c] % LFO_P;
+    lfo_TENSOR = g_tensor;
+    g_general = 1;
+    if (build_tables() != 0) { lfo_TENSOR = NULL; g_general = 0; build_tables(); return -1; }
+    /* CRT(X^i) (.) CRT(X) == CRT(X^(i+1)) for i + 1 < d */
+    for (int i = 0; i + 1 < RE; i++)
+        for (int k = 0; k < 8; k++) {
+            fqe a, x, w;
+            for (int c = 0; c < TAU; c++) { a.c[c] = g_crt[TAU * k + c][i]; x.c[c] = g_crt[TAU * k + c][1]; w.c[c] = g_crt[TAU * k + c][i + 1]; }
+            fqe pr = fqe_mul(a, x);
+            if (memcmp(pr.c, w.c, sizeof(pr.c)) != 0) { lfo_TENSOR = NULL; g_general = 0; build_tables(); return -2; }
+        }
+    return 0;
+}
+
 int lfo_set_ring(u64 nonres, const u64 *y) {
     ensure_init();
+    lfo_TENSOR = NULL;
+    g_general = 0;
     u64 old_nr = lfo_NONRES;
     fqe old_y[8];
     memcpy(old_y, g_y, sizeof(old_y));
@@ -169,6 +204,14 @@ void lfo_crt(const u64 *in, u64 *out, size_t count) {
     for (size_t e = 0; e < count; e++) {
         const u64 *a = in + RE * e;
         u64 res[RE];
+        if (g_general) {
+            for (int r = 0; r < RE; r++) {
+                u64 acc = 0;
+                for (int i = 0; i < RE; i++)
+                    if (a[i]) acc = fq_add(acc, fq_mul(g_crt[r][i], a[i]));
+                res[r] = acc;
+            }
+        } else
         for (int k = 0; k < 8; k++) {
             fqe acc = fqe_zero();
             for (int i = 0; i < RE; i++)
@@ -230,7 +273,7 @@ static void decompose_coeff(u64 v, u64 base, u32 digits, int64_t *out) {
     __int128 curr = v <= (LFO_P - 1) / 2 ? (__int128)v : (__int128)v - (__int128)LFO_P;
     for (u32 k = 0; k < digits; k++) {
         __int128 rem, q;
-        if (g_digit_mode == 0) {
+        if (g_digit_mode == 0 || b == 2) { /* base 2: sign and bits of the magnitude under either mode (the floor rule does not terminate) */
             rem = curr % b;
             q = curr / b;
             __int128 arem = rem < 0 ? -rem : rem;

@@ -108,6 +108,12 @@ def lib():
                                     u64p, u64p, u64p]
         L.lfo_verify.argtypes = [C.POINTER(Params), C.POINTER(Ccs), C.c_void_p, u64p, u64p, u64p, u64p]
         L.lfo_decomposition_prove.argtypes = [C.POINTER(Params), C.POINTER(Ccs), u64p, C.c_void_p, u64p, u64p, u64p, u64p]
+        L.lfo_set_ring_general.restype = C.c_int
+        L.lfo_set_ring_general.argtypes = [u64p, u64p]
+        L.lfo_get_ring.restype = None
+        L.lfo_get_ring.argtypes = [u64p, u64p]
+        L.lfo_set_digit_mode.argtypes = [C.c_int]
+        L.lfo_set_digit_mode.restype = None
         L.lfo_sumcheck_fold.argtypes = [C.POINTER(Params), C.c_void_p, u64p, u64p, u64p, u64p]
         L.lfo_horner_combine.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_size_t, u64p, u64p]
         L.lfo_horner_combine.restype = None
@@ -327,3 +333,28 @@ def lincomb(coef, tables):
     o = np.zeros(ln * RE, dtype=np.uint64)
     lib().lfo_lincomb(_p64(cf), _p64(t.reshape(-1)), n, ln, _p64(o))
     return o.reshape(-1, RE)
+
+
+def get_ring():
+    """(nonres, y[8][TAU]) of the binomial form currently installed"""
+    nr = C.c_uint64()
+    y = np.zeros(8 * TAU, dtype=np.uint64)
+    lib().lfo_get_ring(C.cast(C.byref(nr), u64p), _p64(y))
+    return int(nr.value), y.reshape(8, TAU)
+
+
+def set_ring(nonres, y):
+    a = np.ascontiguousarray(y, dtype=np.uint64).reshape(-1)
+    return lib().lfo_set_ring(int(nonres), _p64(a))
+
+
+def set_ring_general(crt_matrix, tensor):
+    """dense CRT matrix (RE x RE) + structure tensor (TAU^3) -- SURVEY 8(c)'s data form; set_ring(..) goes back"""
+    a = np.ascontiguousarray(crt_matrix, dtype=np.uint64).reshape(-1)
+    t = np.ascontiguousarray(tensor, dtype=np.uint64).reshape(-1)
+    assert a.size == RE * RE and t.size == TAU ** 3
+    return lib().lfo_set_ring_general(_p64(a), _p64(t))
+
+
+def set_digit_mode(mode):
+    lib().lfo_set_digit_mode(int(mode))

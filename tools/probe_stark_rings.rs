@@ -53,6 +53,36 @@ fn main() {
     }
     println!(" \"digit_cases\": {:?},", out);
 
+    // 4b. structure constants of the extension fields in the crate's OWN coordinate basis: e_i * e_j for the unit vectors of
+    //     to_base_prime_field_elements order.  Goldilocks Fq3 (tau = 3) and BabyBear Fq9 (tau = 9; a tower basis shows up here as a
+    //     permuted binomial table).  lf_set_ext_basis wants T with ext = T * int; for a permutation it can be read off the table:
+    //     find the generator g (a unit vector with g^tau in the base field) and list the unit vector each power g^k lands on.
+    fn tensor<F: Field>(tau: usize, name: &str) {
+        let unit = |i: usize| F::from_base_prime_field_elems(&(0..tau).map(|k| if k == i { F::BasePrimeField::one() } else { F::BasePrimeField::zero() }).collect::<Vec<_>>()).unwrap();
+        let mut t = vec![];
+        for i in 0..tau { for j in 0..tau {
+            let pr = unit(i) * unit(j);
+            let w: Vec<String> = pr.to_base_prime_field_elements().map(|x| x.into_bigint().to_string()).collect();
+            t.push(w);
+        } }
+        println!(" \"ext_mul_tensor_{}\": {:?},", name, t);
+    }
+    tensor::<Fq3>(3, "goldilocks_fq3");
+    {
+        use stark_rings::cyclotomic_ring::models::babybear::{Fq9, RqNTT as BbNTT, RqPoly as BbPoly, Fq as BbFq};
+        tensor::<Fq9>(9, "babybear_fq9");
+        // BabyBear CRT of the 72 unit monomials (dense 72 x 72 matrix, columns = coefficient index)
+        let mut rows = vec![];
+        for j in 0..72 {
+            let mut e = vec![BbFq::zero(); 72];
+            e[j] = BbFq::one();
+            let n: BbNTT = BbPoly::from(e).crt();
+            let w: Vec<u64> = n.coeffs().iter().flat_map(|s| s.to_base_prime_field_elements()).map(|x| x.into_bigint().0[0]).collect();
+            rows.push(w);
+        }
+        println!(" \"babybear_crt_of_monomials\": {:?},", rows);
+    }
+
     // 5. bytes of ONE serialized ring element (the per-element layout lf_wire.cpp assumes: 24 words x 8 bytes LE, no prefix)
     let mut e = vec![Fq::zero(); 24];
     for (i, v) in e.iter_mut().enumerate() { *v = Fq::from(1000u64 + i as u64); }
