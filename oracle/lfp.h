@@ -1,0 +1,47 @@
+/*
+ * lfp.h -- CPU ORACLE of the LatticeFold+ double-commitment construction (TEST INFRASTRUCTURE ONLY, same rule as lfo.h: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the product never links it).
+ *
+ * Restates, for the ring the reference runs LatticeFold+ on -- FrogRing RqPoly, coefficient form, Z_p[X]/(X^16 + 1),
+ * p = 15912092521325583641 (cyclotomic-rings/src/rings/frog.rs:1-25):
+ *   tensor / tensor_product           crates/latticefold-plus/src/utils.rs:45-83   (KATs utils.rs:118-131 -> tests/golden/kats.json "lfp_tensor")
+ *   split                             utils.rs:12-43
+ *   RgInstance::from_f                rgchk.rs:260-331   (the "double commitment": benches/double_commitment.rs:53-82)
+ *
+ * PARITY STATUS: **unpinned beyond the two tensor KATs**.  The arithmetic of this path lives in stark-rings @ 886a89f (absent):
+ * `exp`, `decompose_to_vec`, `gadget_decompose`, `Matrix::{try_mul_mat, try_mul_vec, hconcat}`.  Restated here from their call sites
+ * and from the LatticeFold+ paper (section 4): exp(a) = sgn(a) X^a in Z_p[X]/(X^d + 1), i.e. X^a for a >= 0 and X^(d+a) for
+ * -d/2 < a < 0 (always a positive unit monomial); balanced digits as in lfo_ring.c mode 0; gadget_decompose maps element e of a row to
+ * positions [e*l, (e+1)*l), least significant digit first; hconcat keeps the k blocks of d columns in order.  Coefficient-form ring
+ * products (negacyclic convolutions) are convention-free.
+ */
+#ifndef LFP_H
+#define LFP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define LFP_P 15912092521325583641ULL
+#define LFP_D 16
+
+void lfp_ring_mul(const uint64_t *a, const uint64_t *b, uint64_t *out);           /* mod X^16 + 1, mod p */
+void lfp_tensor_product(const uint64_t *a, size_t m, const uint64_t *b, size_t n, uint64_t *out);   /* utils.rs:45-66 over F_p */
+void lfp_tensor(const uint64_t *r, size_t n, uint64_t *out /* 2^n */);             /* utils.rs:68-83 */
+void lfp_balanced_digits(uint64_t v, uint64_t base, unsigned digits, int64_t *out);
+int lfp_exp(int64_t c, uint64_t *out /* 16 */);                                    /* unit monomial of a digit, -d/2 < c < d/2 (else -1) */
+/* A: kappa x n ring elements row-major, f: n ring elements (16 canonical words each, coefficient form) */
+void lfp_commit(const uint64_t *A, uint32_t kappa, size_t n, const uint64_t *f, uint64_t *out /* kappa*16 */);   /* Matrix::try_mul_vec */
+/* RgInstance::from_f (rgchk.rs:260-331).  Outputs:
+ *   Df      k*n*16 digits (D_f[k_i][n_i][d_i], int8)
+ *   comMf   k * kappa * 16 ring elements: comM_f[k_i][row i][column c] = sum_j A[i][j] * exp(D_f[k_i][j][c])
+ *   tau     n base-ring values (canonical), = split(hconcat(comM_f), n, d/2, l)
+ *   cm_f, C_Mf, cm_mtau   kappa ring elements each
+ * returns 0, -1 if a digit is outside the exp domain, -2 if tau does not fit n (the reference panics) */
+int lfp_rg_from_f(const uint64_t *f, size_t n, const uint64_t *A, uint32_t kappa, uint64_t b, uint32_t k, uint32_t l, int8_t *Df, uint64_t *comMf,
+                  uint64_t *tau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau);
+void lfp_splitmix_fill(uint64_t seed, uint64_t start, size_t count, uint64_t *out);   /* uniform words < p (workload generator) */
+#ifdef __cplusplus
+}
+#endif
+#endif

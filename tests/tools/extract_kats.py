@@ -138,6 +138,28 @@ def main():
         "C4": {"B": 1 << 16, "L": 4, "b": 2, "K": 16, "kappa": 26, "wit_len": 1 << 18},
     }
 
+    # --- crates/latticefold-plus/src/utils.rs:118-131 test_tensor_product / test_tensor (plain integers; negative products are written as
+    #     products of literals in the source and evaluated here)
+    src = read("crates/latticefold-plus/src/utils.rs")
+    tp = between(src, "fn test_tensor_product", "fn test_tensor()")
+    vecs = [[int(x) for x in re.findall(r"-?\d+", v)] for v in re.findall(r"vec!\[([^\]]*)\]", tp)]
+    assert len(vecs) == 3
+    tt = between(src, "fn test_tensor()")
+    vv = re.findall(r"vec!\[([^\]]*)\]", tt)
+    r_in = [int(x) for x in re.findall(r"-?\d+", vv[0])]
+    exp_terms = [t.strip() for t in vv[1].split(",")]
+    expected = []
+    for t in exp_terms:
+        prod = 1
+        for fct in t.split("*"):
+            prod *= int(fct.strip())
+        expected.append(prod)
+    kats["lfp_tensor"] = {
+        "source": "crates/latticefold-plus/src/utils.rs:118-131",
+        "tensor_product": {"a": vecs[0], "b": vecs[1], "expected": vecs[2]},
+        "tensor": {"r": r_in, "expected": expected},
+    }
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1)
