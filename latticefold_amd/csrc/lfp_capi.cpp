@@ -1,0 +1,319 @@
+// lfp_capi.cpp -- host driver + C ABI (include/lfplus.h) of the LatticeFold+ double commitment on the Frog ring.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/lfplus.h"
+#include "lfp_kernels.h"
+
+using lfp::u32;
+using lfp::u64;
+
+struct lfplus_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    u64 *A = nullptr, *f = nullptr;
+    u32 kappa = 0;
+    u64 n = 0, nf = 0;
+    // results of the last from_f
+    int8_t *Df = nullptr, *mtau = nullptr;
+    u64 *comMf = nullptr, *tau = nullptr, *coms = nullptr;   // coms: cm_f | C_Mf | cm_mtau, kappa*16 each
+    u32 k = 0, l = 0;
+    size_t Df_cap = 0, comMf_cap = 0;
+    // partial sums
+    u64 *part = nullptr;
+    size_t part_cap = 0;
+    u32 *err_d = nullptr;
+    bool have = false;
+};
+
+#define HIPCHK(c, x)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess) {                                                             \
+            (c)->err = std::string(#x) + ": " + hipGetErrorString(e_);                      \
+            return LFPLUS_E_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+static int fail(lfplus_ctx *c, int rc, const std::string &m) {
+    if (c) c->err = m;
+    return rc;
+}
+static bool canonical(const u64 *w, size_t n) {
+    for (size_t i = 0; i < n; i++)
+        if (w[i] >= lfp::P) return false;
+    return true;
+}
+
+extern "C" int lfplus_ctx_create(int device, lfplus_ctx **out) {
+    if (!out) return LFPLUS_E_ARG;
+    *out = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt) return LFPLUS_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LFPLUS_E_NO_DEVICE;
+    lfplus_ctx *c = new lfplus_ctx;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->err_d, 4) != hipSuccess) {
+        delete c;
+        return LFPLUS_E_HIP;
+    }
+    *out = c;
+    return LFPLUS_OK;
+}
+extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    for (void *p : {(void *)c->A, (void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
+                    (void *)c->err_d})
+        if (p) (void)hipFree(p);
+    (void)hipStreamDestroy(c->st);
+    delete c;
+}
+extern "C" const char *lfplus_last_error(const lfplus_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+static int upload(lfplus_ctx *c, u64 **dst, const u64 *src, size_t words) {
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    HIPCHK(c, hipMalloc(dst, words * 8));
+    HIPCHK(c, hipMemcpyAsync(*dst, src, words * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kappa, uint64_t n) {
+    if (!c || !A || !kappa || kappa > 64 || !n || n > (1ull << 32)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: bad shape");
+    if (!canonical(A, (size_t)kappa * n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: non-canonical word");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have = false;
+    int rc = upload(c, &c->A, A, (size_t)kappa * n * 16);
+    if (rc) return rc;
+    c->kappa = kappa;
+    c->n = n;
+    for (u64 **p : {&c->tau, &c->coms})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (c->mtau) { (void)hipFree(c->mtau); c->mtau = nullptr; }
+    HIPCHK(c, hipMalloc(&c->tau, n * 8));
+    HIPCHK(c, hipMalloc(&c->mtau, n));
+    HIPCHK(c, hipMalloc(&c->coms, (size_t)3 * kappa * 16 * 8));
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) {
+    if (!c || !f || !n) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: bad arguments");
+    if (!canonical(f, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: non-canonical word");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have = false;
+    int rc = upload(c, &c->f, f, (size_t)n * 16);
+    if (rc) return rc;
+    c->nf = n;
+    return LFPLUS_OK;
+}
+
+static int log2_exact(u64 b) { return (b && !(b & (b - 1))) ? __builtin_ctzll(b) : -1; }
+struct Plan {
+    u32 J, nblk;
+    size_t nout_m, nout_f;
+};
+static Plan plan_for(u64 n, u32 kappa, u32 k) {
+    Plan p;
+    u64 J = (n + 511) / 512;
+    J = (J + lfp::TJ - 1) / lfp::TJ * lfp::TJ;
+    p.J = (u32)J;
+    p.nblk = (u32)((n + J - 1) / J);
+    p.nout_m = (size_t)k * kappa * 256;
+    p.nout_f = (size_t)kappa * 16;
+    return p;
+}
+static int ensure_part(lfplus_ctx *c, size_t words) {
+    if (c->part_cap >= words) return LFPLUS_OK;
+    if (c->part) (void)hipFree(c->part);
+    c->part = nullptr;
+    c->part_cap = 0;
+    HIPCHK(c, hipMalloc(&c->part, words * 8));
+    c->part_cap = words;
+    return LFPLUS_OK;
+}
+// phase 1 over an arbitrary vector v (v == c->f for from_f); k == 0: only A v
+static void enqueue_phase1(lfplus_ctx *c, const u64 *v, u64 b, u32 k, const Plan &p, u64 *pm_lo, u64 *pm_hi, u64 *pf) {
+    for (u32 i0 = 0; i0 < c->kappa; i0 += lfp::IG) {
+        u32 k0 = 0;
+        do {
+            lfp::Phase1Args a;
+            a.f = v; a.A = c->A; a.n = c->n; a.kappa = c->kappa;
+            a.i0 = i0; a.icnt = std::min<u32>(lfp::IG, c->kappa - i0);
+            a.k = k; a.k0 = k0; a.kcnt = std::min<u32>(lfp::KG, k - k0);
+            a.b = b; a.sh = log2_exact(b); a.J = p.J;
+            a.Df = c->Df; a.pm_lo = pm_lo; a.pm_hi = pm_hi;
+            a.pf0 = pf; a.pf1 = pf + (size_t)p.nblk * p.nout_f; a.pf2 = pf + 2 * (size_t)p.nblk * p.nout_f;
+            a.err = c->err_d;
+            a.write_df = i0 == 0; a.do_f = k0 == 0;
+            lfp::launch_phase1(a, p.nblk, c->st);
+            k0 += lfp::KG;
+        } while (k0 < k);
+    }
+}
+static int check_params(lfplus_ctx *c, u64 b, u32 k, u32 l) {
+    if (!c) return LFPLUS_E_ARG;
+    if (!c->A || !c->f) return fail(c, LFPLUS_E_ARG, "lfplus_rg_from_f: matrix / witness not set");
+    if (c->nf != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_rg_from_f: witness length differs from the matrix width");
+    if (b < 2 || b > (1ull << 31) || !k || k > 16 || !l || l > 64) return fail(c, LFPLUS_E_ARG, "lfplus_rg_from_f: parameters outside the envelope");
+    unsigned __int128 need = (unsigned __int128)c->kappa * k * 16 * l * 16;
+    if (need >= c->n) return fail(c, LFPLUS_E_SMALL_N, "lfplus_rg_from_f: small n unsupported, must be > kappa*k*d*l*d (utils.rs:33-39)");
+    return LFPLUS_OK;
+}
+static int prepare(lfplus_ctx *c, u32 k, const Plan &p) {
+    size_t dfb = (size_t)k * c->n * 16, cmw = p.nout_m;
+    if (c->Df_cap < dfb) {
+        if (c->Df) (void)hipFree(c->Df);
+        c->Df = nullptr; c->Df_cap = 0;
+        HIPCHK(c, hipMalloc(&c->Df, dfb));
+        c->Df_cap = dfb;
+    }
+    if (c->comMf_cap < cmw) {
+        if (c->comMf) (void)hipFree(c->comMf);
+        c->comMf = nullptr; c->comMf_cap = 0;
+        HIPCHK(c, hipMalloc(&c->comMf, cmw * 8));
+        c->comMf_cap = cmw;
+    }
+    return ensure_part(c, (size_t)p.nblk * (2 * p.nout_m + 3 * p.nout_f + 5 * p.nout_f));
+}
+static void enqueue_from_f(lfplus_ctx *c, u64 b, u32 k, u32 l, const Plan &p) {
+    u64 *pm_lo = c->part, *pm_hi = pm_lo + (size_t)p.nblk * p.nout_m, *pf = pm_hi + (size_t)p.nblk * p.nout_m;
+    u64 *pc = pf + 3 * (size_t)p.nblk * p.nout_f, *pt = pc + 3 * (size_t)p.nblk * p.nout_f;
+    u64 *cm_f = c->coms, *C_Mf = cm_f + p.nout_f, *cm_mtau = C_Mf + p.nout_f;
+    (void)hipMemsetAsync(c->err_d, 0, 4, c->st);
+    (void)hipMemsetAsync(c->tau, 0, c->n * 8, c->st);
+    enqueue_phase1(c, c->f, b, k, p, pm_lo, pm_hi, pf);
+    lfp::launch_reduce(pm_lo, pm_hi, nullptr, p.nblk, (u32)p.nout_m, c->comMf, c->st);
+    lfp::launch_reduce(pf, pf + (size_t)p.nblk * p.nout_f, pf + 2 * (size_t)p.nblk * p.nout_f, p.nblk, (u32)p.nout_f, cm_f, c->st);
+    lfp::launch_split(c->comMf, c->kappa, k, lfp::D / 2, l, c->tau, c->st);
+    for (u32 i0 = 0; i0 < c->kappa; i0 += lfp::IG) {
+        lfp::Phase2Args a;
+        a.A = c->A; a.tau = c->tau; a.n = c->n; a.kappa = c->kappa;
+        a.i0 = i0; a.icnt = std::min<u32>(lfp::IG, c->kappa - i0); a.J = p.J;
+        a.mtau = c->mtau;
+        a.pc0 = pc; a.pc1 = pc + (size_t)p.nblk * p.nout_f; a.pc2 = pc + 2 * (size_t)p.nblk * p.nout_f;
+        a.pt_lo = pt; a.pt_hi = pt + (size_t)p.nblk * p.nout_f;
+        a.err = c->err_d;
+        lfp::launch_phase2(a, p.nblk, c->st);
+    }
+    lfp::launch_reduce(pc, pc + (size_t)p.nblk * p.nout_f, pc + 2 * (size_t)p.nblk * p.nout_f, p.nblk, (u32)p.nout_f, C_Mf, c->st);
+    lfp::launch_reduce(pt, pt + (size_t)p.nblk * p.nout_f, nullptr, p.nblk, (u32)p.nout_f, cm_mtau, c->st);
+}
+static int finish(lfplus_ctx *c) {
+    u32 flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->err_d, 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    if (flag) return fail(c, LFPLUS_E_EXP_DOMAIN, flag & 1 ? "lfplus_rg_from_f: a digit of f is outside (-d/2, d/2)" : "lfplus_rg_from_f: tau outside (-d/2, d/2)");
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_rg_from_f(lfplus_ctx *c, uint64_t b, uint32_t k, uint32_t l) {
+    int rc = check_params(c, b, k, l);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have = false;
+    Plan p = plan_for(c->n, c->kappa, k);
+    if ((rc = prepare(c, k, p))) return rc;
+    enqueue_from_f(c, b, k, l, p);
+    if ((rc = finish(c))) return rc;
+    c->k = k;
+    c->l = l;
+    c->have = true;
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_rg_from_f_timed(lfplus_ctx *c, uint64_t b, uint32_t k, uint32_t l, uint32_t iters, double *ms_avg) {
+    if (!ms_avg || !iters) return fail(c, LFPLUS_E_ARG, "lfplus_rg_from_f_timed: bad arguments");
+    int rc = lfplus_rg_from_f(c, b, k, l);   // warm-up + validation
+    if (rc) return rc;
+    Plan p = plan_for(c->n, c->kappa, k);
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->st));
+    for (u32 it = 0; it < iters; it++) enqueue_from_f(c, b, k, l, p);
+    HIPCHK(c, hipEventRecord(e1, c->st));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_avg = (double)ms / iters;
+    return finish(c);
+}
+extern "C" int lfplus_rg_read(lfplus_ctx *c, int8_t *Df, uint64_t *comMf, uint64_t *tau, int8_t *mtau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau) {
+    if (!c) return LFPLUS_E_ARG;
+    if (!c->have) return fail(c, LFPLUS_E_ARG, "lfplus_rg_read: no result (run lfplus_rg_from_f first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t cw = (size_t)c->kappa * 16;
+    if (Df) HIPCHK(c, hipMemcpyAsync(Df, c->Df, (size_t)c->k * c->n * 16, hipMemcpyDeviceToHost, c->st));
+    if (comMf) HIPCHK(c, hipMemcpyAsync(comMf, c->comMf, (size_t)c->k * c->kappa * 256 * 8, hipMemcpyDeviceToHost, c->st));
+    if (tau) HIPCHK(c, hipMemcpyAsync(tau, c->tau, c->n * 8, hipMemcpyDeviceToHost, c->st));
+    if (mtau) HIPCHK(c, hipMemcpyAsync(mtau, c->mtau, c->n, hipMemcpyDeviceToHost, c->st));
+    if (cm_f) HIPCHK(c, hipMemcpyAsync(cm_f, c->coms, cw * 8, hipMemcpyDeviceToHost, c->st));
+    if (C_Mf) HIPCHK(c, hipMemcpyAsync(C_Mf, c->coms + cw, cw * 8, hipMemcpyDeviceToHost, c->st));
+    if (cm_mtau) HIPCHK(c, hipMemcpyAsync(cm_mtau, c->coms + 2 * cw, cw * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint64_t *out) {
+    if (!c || !v || !out) return fail(c, LFPLUS_E_ARG, "lfplus_commit: null argument");
+    if (!c->A || n != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_commit: matrix not set / length mismatch");
+    if (!canonical(v, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_commit: non-canonical word");
+    HIPCHK(c, hipSetDevice(c->device));
+    Plan p = plan_for(c->n, c->kappa, 0);
+    int rc = ensure_part(c, (size_t)p.nblk * 3 * p.nout_f + p.nout_f);
+    if (rc) return rc;
+    u64 *dv = nullptr;
+    HIPCHK(c, hipMalloc(&dv, (size_t)n * 16 * 8));
+    (void)hipMemcpyAsync(dv, v, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st);
+    u64 *pf = c->part, *res = pf + 3 * (size_t)p.nblk * p.nout_f;
+    enqueue_phase1(c, dv, 2, 0, p, nullptr, nullptr, pf);
+    lfp::launch_reduce(pf, pf + (size_t)p.nblk * p.nout_f, pf + 2 * (size_t)p.nblk * p.nout_f, p.nblk, (u32)p.nout_f, res, c->st);
+    (void)hipMemcpyAsync(out, res, p.nout_f * 8, hipMemcpyDeviceToHost, c->st);
+    hipError_t e = hipStreamSynchronize(c->st);
+    (void)hipFree(dv);
+    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_tensor(lfplus_ctx *c, const uint64_t *r, uint32_t n, uint64_t *out) {
+    if (!c || !out || (n && !r) || n > 28) return fail(c, LFPLUS_E_ARG, "lfplus_tensor: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    u64 *buf = nullptr;
+    size_t len = (size_t)1 << n;
+    HIPCHK(c, hipMalloc(&buf, 2 * len * 8));
+    u64 *cur = buf, *nxt = buf + len, one = 1;
+    (void)hipMemcpyAsync(cur, &one, 8, hipMemcpyHostToDevice, c->st);
+    for (u32 i = 0; i < n; i++) {
+        lfp::launch_tensor_level(cur, (u64)1 << i, r[i] % lfp::P, nxt, c->st);
+        std::swap(cur, nxt);
+    }
+    (void)hipMemcpyAsync(out, cur, len * 8, hipMemcpyDeviceToHost, c->st);
+    hipError_t e = hipStreamSynchronize(c->st);
+    (void)hipFree(buf);
+    HIPCHK(c, e);
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_tensor_product(lfplus_ctx *c, const uint64_t *a, uint64_t m, const uint64_t *b, uint64_t n, uint64_t *out) {
+    if (!c || !out || (m && !a) || (n && !b)) return fail(c, LFPLUS_E_ARG, "lfplus_tensor_product: null argument");
+    if (!m || !n) {   // an empty side returns the other (utils.rs:52-57)
+        const u64 *src = m ? a : b;
+        for (u64 i = 0; i < m + n; i++) out[i] = src[i];
+        return LFPLUS_OK;
+    }
+    if (m * n > (1ull << 30)) return fail(c, LFPLUS_E_ARG, "lfplus_tensor_product: too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    u64 *buf = nullptr;
+    HIPCHK(c, hipMalloc(&buf, (m + n + m * n) * 8));
+    std::vector<u64> ha(a, a + m), hb(b, b + n);
+    for (auto &x : ha) x %= lfp::P;
+    for (auto &x : hb) x %= lfp::P;
+    (void)hipMemcpyAsync(buf, ha.data(), m * 8, hipMemcpyHostToDevice, c->st);
+    (void)hipMemcpyAsync(buf + m, hb.data(), n * 8, hipMemcpyHostToDevice, c->st);
+    lfp::launch_tensor_product(buf, m, buf + m, n, buf + m + n, c->st);
+    (void)hipMemcpyAsync(out, buf + m + n, m * n * 8, hipMemcpyDeviceToHost, c->st);
+    hipError_t e = hipStreamSynchronize(c->st);
+    (void)hipFree(buf);
+    HIPCHK(c, e);
+    return LFPLUS_OK;
+}

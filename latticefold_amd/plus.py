@@ -1,0 +1,181 @@
+"""LatticeFold+ slice: Python mirror of the reference interface over the C ABI include/lfplus.h (ctypes, liblfhip.so).
+
+Reference (crates/latticefold-plus): `RgInstance::from_f(f, &A, &DecompParameters{b, k, l})` (src/rgchk.rs:260-331), the double
+commitment benchmarked by benches/double_commitment.rs; `utils::tensor` / `tensor_product` (src/utils.rs:45-83).  Ring: FrogRing
+RqPoly, Z_p[X]/(X^16 + 1) in coefficient form, 16 canonical u64 words per element.  GPU only: there is no CPU path."""
+import ctypes as C
+import math
+import re
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import api
+
+P = 15912092521325583641
+D = 16
+u64p = C.POINTER(C.c_uint64)
+i8p = C.POINTER(C.c_int8)
+_READY = False
+
+
+class LfPlusError(RuntimeError):
+    def __init__(self, code, msg):
+        self.code = code
+        super().__init__(f"liblfhip (lfplus): {msg} ({code})")
+
+
+E_ARG, E_NO_DEVICE, E_HIP, E_EXP_DOMAIN, E_SMALL_N = -1, -2, -3, -4, -5
+
+
+def exported_symbols():
+    """every symbol include/lfplus.h declares"""
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "lfplus.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(lfplus_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def _lib():
+    global _READY
+    L = api._lib()
+    if not _READY:
+        vp = C.c_void_p
+        L.lfplus_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.lfplus_ctx_destroy.argtypes = [vp]
+        L.lfplus_ctx_destroy.restype = None
+        L.lfplus_last_error.argtypes = [vp]
+        L.lfplus_last_error.restype = C.c_char_p
+        L.lfplus_set_matrix.argtypes = [vp, u64p, C.c_uint32, C.c_uint64]
+        L.lfplus_set_witness.argtypes = [vp, u64p, C.c_uint64]
+        L.lfplus_rg_from_f.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.lfplus_rg_read.argtypes = [vp, i8p, u64p, u64p, i8p, u64p, u64p, u64p]
+        L.lfplus_rg_from_f_timed.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+        L.lfplus_commit.argtypes = [vp, u64p, C.c_uint64, u64p]
+        L.lfplus_tensor.argtypes = [vp, u64p, C.c_uint32, u64p]
+        L.lfplus_tensor_product.argtypes = [vp, u64p, C.c_uint64, u64p, C.c_uint64, u64p]
+        _READY = True
+    return L
+
+
+def _w(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(u64p)
+
+
+@dataclass
+class DecompParameters:
+    """rgchk.rs:20-24"""
+    b: int
+    k: int
+    l: int
+
+    @staticmethod
+    def for_frog(k, b=D // 2):
+        """l = ceil(log_{d/2} q) as every reference call site computes it (rgchk.rs:369-371, benches/double_commitment.rs:68-70)"""
+        return DecompParameters(b, k, math.ceil(math.log(float(P)) / math.log(D / 2)))
+
+
+class PlusContext:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = _lib().lfplus_ctx_create(device, C.byref(self.h))
+        if rc:
+            raise LfPlusError(rc, "lfplus_ctx_create: no usable HIP device (the library has no CPU path)")
+        self.kappa = self.n = 0
+
+    def _chk(self, rc):
+        if rc:
+            raise LfPlusError(rc, _lib().lfplus_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            _lib().lfplus_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def set_matrix(self, A):
+        """A: (kappa, n, 16) canonical words (Matrix<R>, coefficient form)"""
+        A, p = _w(A)
+        assert A.ndim == 3 and A.shape[2] == D
+        self._chk(_lib().lfplus_set_matrix(self.h, p, A.shape[0], A.shape[1]))
+        self.kappa, self.n = A.shape[0], A.shape[1]
+
+    def set_witness(self, f):
+        f, p = _w(f)
+        assert f.ndim == 2 and f.shape[1] == D
+        self._chk(_lib().lfplus_set_witness(self.h, p, f.shape[0]))
+
+    def commit(self, v):
+        """Matrix::try_mul_vec"""
+        v, p = _w(v)
+        out = np.zeros((self.kappa, D), dtype=np.uint64)
+        self._chk(_lib().lfplus_commit(self.h, p, v.shape[0], out.ctypes.data_as(u64p)))
+        return out
+
+    def tensor(self, r):
+        r, p = _w([int(x) % P for x in r])
+        out = np.zeros(1 << r.size, dtype=np.uint64)
+        self._chk(_lib().lfplus_tensor(self.h, p, r.size, out.ctypes.data_as(u64p)))
+        return out
+
+    def tensor_product(self, a, b):
+        a, pa = _w([int(x) % P for x in a])
+        b, pb = _w([int(x) % P for x in b])
+        out = np.zeros(a.size * b.size if a.size and b.size else a.size + b.size, dtype=np.uint64)
+        self._chk(_lib().lfplus_tensor_product(self.h, pa, a.size, pb, b.size, out.ctypes.data_as(u64p)))
+        return out
+
+    def time_rg_from_f(self, dparams, iters):
+        ms = C.c_double()
+        self._chk(_lib().lfplus_rg_from_f_timed(self.h, dparams.b, dparams.k, dparams.l, iters, C.byref(ms)))
+        return ms.value
+
+
+@dataclass
+class FComs:
+    """rgchk.rs:26-31"""
+    cm_f: np.ndarray
+    C_Mf: np.ndarray
+    cm_mtau: np.ndarray
+
+
+@dataclass
+class RgInstance:
+    """rgchk.rs:40-48.  M_f / m_tau are unit monomials, held as their exponent digits D_f / centred tau (exp(a) = X^a, X^(d+a) for a < 0)."""
+    D_f: np.ndarray      # (k, n, 16) int8
+    tau: np.ndarray      # (n,)
+    m_tau_exp: np.ndarray  # (n,) int8
+    f: np.ndarray
+    comM_f: np.ndarray   # (k, kappa, 16, 16): comM_f[k_i] is a kappa x d matrix of ring elements
+    fcoms: FComs
+
+    @staticmethod
+    def from_f(ctx, f, A, dparams):
+        """RgInstance::from_f(f, &A, &decomp) (rgchk.rs:260-331).  A = None keeps the matrix already resident in ctx."""
+        if A is not None:
+            ctx.set_matrix(A)
+        ctx.set_witness(f)
+        ctx._chk(_lib().lfplus_rg_from_f(ctx.h, dparams.b, dparams.k, dparams.l))
+        k, n, kappa = dparams.k, ctx.n, ctx.kappa
+        Df = np.zeros((k, n, D), dtype=np.int8)
+        com = np.zeros((k, kappa, D, D), dtype=np.uint64)
+        tau = np.zeros(n, dtype=np.uint64)
+        mt = np.zeros(n, dtype=np.int8)
+        c = [np.zeros((kappa, D), dtype=np.uint64) for _ in range(3)]
+        ctx._chk(_lib().lfplus_rg_read(ctx.h, Df.ctypes.data_as(i8p), com.ctypes.data_as(u64p), tau.ctypes.data_as(u64p), mt.ctypes.data_as(i8p),
+                                       *[x.ctypes.data_as(u64p) for x in c]))
+        return RgInstance(Df, tau, mt, np.asarray(f), com, FComs(*c))
+
+    def M_f(self, ki, rows=slice(None)):
+        """dense monomial matrix exp(D_f[ki]) for the given rows: (rows, 16 columns, 16 words)"""
+        return exp(self.D_f[ki, rows])
+
+
+def exp(digits):
+    """stark_rings exp: digit a in (-d/2, d/2) -> the unit monomial X^a (a >= 0) / X^(d + a) (a < 0), as 16-word elements"""
+    dg = np.asarray(digits, dtype=np.int64)
+    if (np.abs(dg) >= D // 2).any():
+        raise ValueError("exp: digit outside (-d/2, d/2)")
+    out = np.zeros(dg.shape + (D,), dtype=np.uint64)
+    np.put_along_axis(out, np.where(dg >= 0, dg, D + dg)[..., None], 1, axis=-1)
+    return out

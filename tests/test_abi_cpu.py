@@ -16,6 +16,21 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 40
     for n in names:
         assert hasattr(lib, n), f"liblfhip.so does not export {n}"
+    from latticefold_amd import plus
+    names = plus.exported_symbols()                      # include/lfplus.h (LatticeFold+ slice)
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(plus._lib(), n), f"liblfhip.so does not export {n}"
+
+
+def test_lfplus_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from latticefold_amd import plus
+    with pytest.raises(plus.LfPlusError) as e:
+        plus.PlusContext(0)
+    assert e.value.code == plus.E_NO_DEVICE
 
 
 def test_product_poseidon_params_and_kats(kats):
