@@ -1,5 +1,6 @@
 // lfp_capi.cpp -- host driver + C ABI (include/lfplus.h) of the LatticeFold+ double commitment on the Frog ring.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/lfplus.h"
@@ -110,15 +111,26 @@ extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) 
 
 static int log2_exact(u64 b) { return (b && !(b & (b - 1))) ? __builtin_ctzll(b) : -1; }
 struct Plan {
-    u32 J, nblk;
+    u32 J, nblk;      // phase 1: rows per block, blocks
+    u32 J2, nblk2;    // phase 2
     size_t nout_m, nout_f;
 };
 static Plan plan_for(u64 n, u32 kappa, u32 k) {
     Plan p;
+    // phase 1 is register-bound at 2 waves / SIMD (176 VGPRs for 2 rows x 4 digit planes): two blocks per CU = 512 blocks (measured
+    // best of 512 / 768 / 1024, LFP_BLOCKS1 overrides), and not below 128 rows per block (a block's partial sums are k*kappa*256 words:
+    // fewer, longer blocks keep that traffic well under the input's)
+    static const long env1 = getenv("LFP_BLOCKS1") ? atol(getenv("LFP_BLOCKS1")) : 0, env2 = getenv("LFP_BLOCKS2") ? atol(getenv("LFP_BLOCKS2")) : 0;
     u64 J = (n + 511) / 512;
+    if (J < 128) J = 128;
+    if (env1 > 0) J = (n + env1 - 1) / env1;
     J = (J + lfp::TJ - 1) / lfp::TJ * lfp::TJ;
     p.J = (u32)J;
     p.nblk = (u32)((n + J - 1) / J);
+    u64 J2 = (n + (env2 > 0 ? env2 : 1024) - 1) / (env2 > 0 ? env2 : 1024);     // phase 2 is a streaming pass: up to 1024 blocks, rows per block a multiple of the unrolled step
+    J2 = (J2 + 127) / 128 * 128;
+    p.J2 = (u32)J2;
+    p.nblk2 = (u32)((n + J2 - 1) / J2);
     p.nout_m = (size_t)k * kappa * 256;
     p.nout_f = (size_t)kappa * 16;
     return p;
@@ -133,22 +145,22 @@ static int ensure_part(lfplus_ctx *c, size_t words) {
     return LFPLUS_OK;
 }
 // phase 1 over an arbitrary vector v (v == c->f for from_f); k == 0: only A v
-static void enqueue_phase1(lfplus_ctx *c, const u64 *v, u64 b, u32 k, const Plan &p, u64 *pm_lo, u64 *pm_hi, u64 *pf) {
-    for (u32 i0 = 0; i0 < c->kappa; i0 += lfp::IG) {
-        u32 k0 = 0;
+static void enqueue_phase1(lfplus_ctx *c, const u64 *v, u64 b, u32 k, const Plan &p, u64 *part) {
+    for (u32 i0 = 0; i0 < c->kappa;) {
+        u32 icnt = lfp::group_size(c->kappa - i0), k0 = 0;
         do {
             lfp::Phase1Args a;
             a.f = v; a.A = c->A; a.n = c->n; a.kappa = c->kappa;
-            a.i0 = i0; a.icnt = std::min<u32>(lfp::IG, c->kappa - i0);
-            a.k = k; a.k0 = k0; a.kcnt = std::min<u32>(lfp::KG, k - k0);
+            a.i0 = i0; a.icnt = icnt;
+            a.k = k; a.k0 = k0; a.kcnt = k ? lfp::group_size(k - k0) : 0;
             a.b = b; a.sh = log2_exact(b); a.J = p.J;
-            a.Df = c->Df; a.pm_lo = pm_lo; a.pm_hi = pm_hi;
-            a.pf0 = pf; a.pf1 = pf + (size_t)p.nblk * p.nout_f; a.pf2 = pf + 2 * (size_t)p.nblk * p.nout_f;
+            a.Df = c->Df; a.part = part;
             a.err = c->err_d;
             a.write_df = i0 == 0; a.do_f = k0 == 0;
             lfp::launch_phase1(a, p.nblk, c->st);
-            k0 += lfp::KG;
+            k0 += a.kcnt;
         } while (k0 < k);
+        i0 += icnt;
     }
 }
 static int check_params(lfplus_ctx *c, u64 b, u32 k, u32 l) {
@@ -161,7 +173,7 @@ static int check_params(lfplus_ctx *c, u64 b, u32 k, u32 l) {
     return LFPLUS_OK;
 }
 static int prepare(lfplus_ctx *c, u32 k, const Plan &p) {
-    size_t dfb = (size_t)k * c->n * 16, cmw = p.nout_m;
+    size_t dfb = (size_t)k * c->n * 16, cmw = p.nout_m + p.nout_f;
     if (c->Df_cap < dfb) {
         if (c->Df) (void)hipFree(c->Df);
         c->Df = nullptr; c->Df_cap = 0;
@@ -174,30 +186,27 @@ static int prepare(lfplus_ctx *c, u32 k, const Plan &p) {
         HIPCHK(c, hipMalloc(&c->comMf, cmw * 8));
         c->comMf_cap = cmw;
     }
-    return ensure_part(c, (size_t)p.nblk * (2 * p.nout_m + 3 * p.nout_f + 5 * p.nout_f));
+    return ensure_part(c, (size_t)p.nblk * (p.nout_m + p.nout_f) + (size_t)p.nblk2 * 2 * p.nout_f);
 }
+// c->comMf: [comM_f (k, kappa, 16, 16) | cm_f (kappa, 16)];  c->coms: [C_Mf | cm_mtau]
 static void enqueue_from_f(lfplus_ctx *c, u64 b, u32 k, u32 l, const Plan &p) {
-    u64 *pm_lo = c->part, *pm_hi = pm_lo + (size_t)p.nblk * p.nout_m, *pf = pm_hi + (size_t)p.nblk * p.nout_m;
-    u64 *pc = pf + 3 * (size_t)p.nblk * p.nout_f, *pt = pc + 3 * (size_t)p.nblk * p.nout_f;
-    u64 *cm_f = c->coms, *C_Mf = cm_f + p.nout_f, *cm_mtau = C_Mf + p.nout_f;
+    u64 *part1 = c->part, *part2 = part1 + (size_t)p.nblk * (p.nout_m + p.nout_f);
+    size_t need = (size_t)c->kappa * k * 16 * l * 16;
     (void)hipMemsetAsync(c->err_d, 0, 4, c->st);
-    (void)hipMemsetAsync(c->tau, 0, c->n * 8, c->st);
-    enqueue_phase1(c, c->f, b, k, p, pm_lo, pm_hi, pf);
-    lfp::launch_reduce(pm_lo, pm_hi, nullptr, p.nblk, (u32)p.nout_m, c->comMf, c->st);
-    lfp::launch_reduce(pf, pf + (size_t)p.nblk * p.nout_f, pf + 2 * (size_t)p.nblk * p.nout_f, p.nblk, (u32)p.nout_f, cm_f, c->st);
-    lfp::launch_split(c->comMf, c->kappa, k, lfp::D / 2, l, c->tau, c->st);
-    for (u32 i0 = 0; i0 < c->kappa; i0 += lfp::IG) {
+    (void)hipMemsetAsync(c->tau + need, 0, (c->n - need) * 8, c->st);
+    enqueue_phase1(c, c->f, b, k, p, part1);
+    lfp::launch_reduce(part1, p.nblk, (u32)(p.nout_m + p.nout_f), c->comMf, (u32)p.nout_m, c->kappa, k, lfp::D / 2, l, c->tau, c->st);
+    for (u32 i0 = 0; i0 < c->kappa;) {
         lfp::Phase2Args a;
         a.A = c->A; a.tau = c->tau; a.n = c->n; a.kappa = c->kappa;
-        a.i0 = i0; a.icnt = std::min<u32>(lfp::IG, c->kappa - i0); a.J = p.J;
+        a.i0 = i0; a.icnt = lfp::group_size(c->kappa - i0); a.J = p.J2;
         a.mtau = c->mtau;
-        a.pc0 = pc; a.pc1 = pc + (size_t)p.nblk * p.nout_f; a.pc2 = pc + 2 * (size_t)p.nblk * p.nout_f;
-        a.pt_lo = pt; a.pt_hi = pt + (size_t)p.nblk * p.nout_f;
+        a.part = part2;
         a.err = c->err_d;
-        lfp::launch_phase2(a, p.nblk, c->st);
+        lfp::launch_phase2(a, p.nblk2, c->st);
+        i0 += a.icnt;
     }
-    lfp::launch_reduce(pc, pc + (size_t)p.nblk * p.nout_f, pc + 2 * (size_t)p.nblk * p.nout_f, p.nblk, (u32)p.nout_f, C_Mf, c->st);
-    lfp::launch_reduce(pt, pt + (size_t)p.nblk * p.nout_f, nullptr, p.nblk, (u32)p.nout_f, cm_mtau, c->st);
+    lfp::launch_reduce(part2, p.nblk2, (u32)(2 * p.nout_f), c->coms, 0, c->kappa, k, 2, 0, nullptr, c->st);
 }
 static int finish(lfplus_ctx *c) {
     u32 flag = 0;
@@ -249,9 +258,9 @@ extern "C" int lfplus_rg_read(lfplus_ctx *c, int8_t *Df, uint64_t *comMf, uint64
     if (comMf) HIPCHK(c, hipMemcpyAsync(comMf, c->comMf, (size_t)c->k * c->kappa * 256 * 8, hipMemcpyDeviceToHost, c->st));
     if (tau) HIPCHK(c, hipMemcpyAsync(tau, c->tau, c->n * 8, hipMemcpyDeviceToHost, c->st));
     if (mtau) HIPCHK(c, hipMemcpyAsync(mtau, c->mtau, c->n, hipMemcpyDeviceToHost, c->st));
-    if (cm_f) HIPCHK(c, hipMemcpyAsync(cm_f, c->coms, cw * 8, hipMemcpyDeviceToHost, c->st));
-    if (C_Mf) HIPCHK(c, hipMemcpyAsync(C_Mf, c->coms + cw, cw * 8, hipMemcpyDeviceToHost, c->st));
-    if (cm_mtau) HIPCHK(c, hipMemcpyAsync(cm_mtau, c->coms + 2 * cw, cw * 8, hipMemcpyDeviceToHost, c->st));
+    if (cm_f) HIPCHK(c, hipMemcpyAsync(cm_f, c->comMf + (size_t)c->k * c->kappa * 256, cw * 8, hipMemcpyDeviceToHost, c->st));
+    if (C_Mf) HIPCHK(c, hipMemcpyAsync(C_Mf, c->coms, cw * 8, hipMemcpyDeviceToHost, c->st));
+    if (cm_mtau) HIPCHK(c, hipMemcpyAsync(cm_mtau, c->coms + cw, cw * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     return LFPLUS_OK;
 }
@@ -261,14 +270,14 @@ extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint6
     if (!canonical(v, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_commit: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
     Plan p = plan_for(c->n, c->kappa, 0);
-    int rc = ensure_part(c, (size_t)p.nblk * 3 * p.nout_f + p.nout_f);
+    int rc = ensure_part(c, (size_t)p.nblk * p.nout_f + p.nout_f);
     if (rc) return rc;
     u64 *dv = nullptr;
     HIPCHK(c, hipMalloc(&dv, (size_t)n * 16 * 8));
     (void)hipMemcpyAsync(dv, v, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st);
-    u64 *pf = c->part, *res = pf + 3 * (size_t)p.nblk * p.nout_f;
-    enqueue_phase1(c, dv, 2, 0, p, nullptr, nullptr, pf);
-    lfp::launch_reduce(pf, pf + (size_t)p.nblk * p.nout_f, pf + 2 * (size_t)p.nblk * p.nout_f, p.nblk, (u32)p.nout_f, res, c->st);
+    u64 *res = c->part + (size_t)p.nblk * p.nout_f;
+    enqueue_phase1(c, dv, 2, 0, p, c->part);
+    lfp::launch_reduce(c->part, p.nblk, (u32)p.nout_f, res, 0, c->kappa, 0, 2, 0, nullptr, c->st);
     (void)hipMemcpyAsync(out, res, p.nout_f * 8, hipMemcpyDeviceToHost, c->st);
     hipError_t e = hipStreamSynchronize(c->st);
     (void)hipFree(dv);

@@ -11,7 +11,7 @@ constexpr int D = 16;
 constexpr int TJ = 32;        // witness rows per LDS tile
 constexpr int IG = 4;         // commitment-matrix rows per launch group
 constexpr int KG = 4;         // digit planes per launch group
-constexpr int RED_WAVES = 8;  // waves per block of the partial-sum reduction
+constexpr int RED_WAVES = 16;  // waves per block of the partial-sum reduction
 
 struct Phase1Args {
     const u64 *f;       // n x 16 canonical words
@@ -23,8 +23,7 @@ struct Phase1Args {
     int sh;             // log2(b) when b is a power of two, else -1
     u32 J;              // rows per block (multiple of TJ)
     int8_t *Df;         // [k][n][16], written when write_df
-    u64 *pm_lo, *pm_hi; // [nblk][k*kappa*256] partial sums of the monomial products (128-bit)
-    u64 *pf0, *pf1, *pf2; // [nblk][kappa*16] partial sums of A f (192-bit)
+    u64 *part;          // [nblk][k*kappa*256 + kappa*16] partial sums mod p: comM_f coefficients, then A f
     u32 *err;
     int write_df, do_f;
 };
@@ -35,16 +34,16 @@ struct Phase2Args {
     u32 kappa, i0, icnt;
     u32 J;
     int8_t *mtau;       // n exponents (centred tau), written when i0 == 0
-    u64 *pc0, *pc1, *pc2;  // [nblk][kappa*16]  A * tau       (192-bit)
-    u64 *pt_lo, *pt_hi;    // [nblk][kappa*16]  A * exp(tau)  (128-bit)
+    u64 *part;          // [nblk][2*kappa*16] partial sums mod p: A tau, then A exp(tau)
     u32 *err;
 };
 void launch_phase1(const Phase1Args &a, u32 nblk, hipStream_t s);
 void launch_phase2(const Phase2Args &a, u32 nblk, hipStream_t s);
-// out[o] = (sum over blocks of the 128/192-bit partials) mod p;  w2 may be null
-void launch_reduce(const u64 *w0, const u64 *w1, const u64 *w2, u32 nblk, u32 nout, u64 *out, hipStream_t s);
-// tau = split(hconcat(comM_f), n, base, l) (utils.rs:12-43): comMf [k][kappa][16][16] -> tau positions [0, kappa*k*16*l*16)
-void launch_split(const u64 *comMf, u32 kappa, u32 k, u64 base, u32 l, u64 *tau, hipStream_t s);
+// out[o] = sum over blocks of part[blk][o] mod p; with l != 0 the first nsplit outputs (comM_f, [k][kappa][16][16]) are also cut into
+// their l gadget digits: tau = split(hconcat(comM_f), n, base, l) (utils.rs:12-43), positions [0, kappa*k*16*l*16)
+void launch_reduce(const u64 *part, u32 nblk, u32 nout, u64 *out, u32 nsplit, u32 kappa, u32 k, u64 base, u32 l, u64 *tau, hipStream_t s);
+// largest launch group (1, 2 or 4) not above `left`
+inline u32 group_size(u32 left) { return left >= 4 ? 4 : left >= 2 ? 2 : 1; }
 void launch_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt, hipStream_t s);
 void launch_tensor_product(const u64 *a, u64 m, const u64 *b, u64 n, u64 *out, hipStream_t s);
 }  // namespace lfp

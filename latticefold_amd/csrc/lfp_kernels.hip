@@ -18,10 +18,13 @@ namespace lfp {
 using lf::AccP;
 using lf::accp_mad;
 
-__device__ __forceinline__ void add96(u64 &lo, u32 &hi, u64 v) {
-    u64 s = lo + v;
-    hi += (u32)(s < v);
-    lo = s;
+// acc (96 bits in three VGPRs) += v
+__device__ __forceinline__ void add96(u32 &a0, u32 &a1, u32 &a2, u64 v) {
+    u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+    asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+        : "+v"(a0), "+v"(a1), "+v"(a2)
+        : "v"(v0), "v"(v1)
+        : "vcc");
 }
 struct U192 {
     u64 w0, w1, w2;
@@ -50,11 +53,44 @@ __device__ __forceinline__ void accp_zero(AccP &s) {
     s.s00 = s.s01 = s.s11 = 0;
     s.c00 = s.c01 = s.c11 = 0;
 }
+
+// ---- F_p: Montgomery products (R = 2^64) for the final reductions and for tensor / tensor_product
+constexpr u64 mont_pinv() {   // -p^{-1} mod 2^64
+    u64 x = 1;
+    for (int i = 0; i < 6; i++) x *= 2 - P * x;
+    return ~x + 1;
+}
+constexpr u64 mont_r2() {     // 2^128 mod p
+    unsigned __int128 r = 1;
+    for (int i = 0; i < 128; i++) { r <<= 1; if (r >= P) r -= P; }
+    return (u64)r;
+}
+constexpr u64 PINV = mont_pinv(), R2 = mont_r2();   // forced compile-time evaluation: called in a device function the loops would run per thread
+static_assert((u64)(P * (0 - PINV)) == 1, "mont_pinv");
+__device__ __forceinline__ u64 mont_mul(u64 a, u64 b) {   // a b 2^-64 mod p, a, b < p
+    u64 lo = a * b, hi = __umul64hi(a, b);
+    u64 m = lo * PINV;
+    u64 mh = __umul64hi(m, P), ml = m * P;
+    u64 cy = (lo + ml) < lo;      // the low word cancels to 0 (mod 2^64); only its carry matters
+    u64 u = hi + mh, o1 = u < hi;
+    u64 v = u + cy, o2 = v < cy;
+    if (o1 || o2 || v >= P) v -= P;
+    return v;
+}
+__device__ __forceinline__ u64 mul_p(u64 a, u64 b) { return mont_mul(mont_mul(a, b), R2); }
+__device__ __forceinline__ u64 add_p(u64 a, u64 b) {
+    u64 s = a + b;
+    if (s < a || s >= P) s -= P;
+    return s;
+}
+// (r 2^64 + w) mod p for r < p: mont_mul(r, 2^128) = r 2^64
+__device__ __forceinline__ u64 red_word(u64 r, u64 w) { return add_p(mont_mul(r, R2), w >= P ? w - P : w); }
+__device__ __forceinline__ u64 mod_p_192(U192 x) { return red_word(red_word(x.w2 % P, x.w1), x.w0); }
+
 // balanced digit step (stark_rings::balanced_decomposition as restated in oracle/lfp.c: truncating remainder, |rem| <= b/2 kept)
-template <bool POW2>
 __device__ __forceinline__ int64_t digit_step(int64_t &cur, u64 b, int sh) {
     int64_t q, rem;
-    if (POW2) {
+    if (sh >= 0) {
         q = (cur + ((cur >> 63) & (int64_t)(b - 1))) >> sh;
         rem = cur - (q << sh);
     } else {
@@ -71,59 +107,82 @@ __device__ __forceinline__ int64_t digit_step(int64_t &cur, u64 b, int sh) {
 }
 __device__ __forceinline__ int64_t centre(u64 v) { return v <= (P - 1) / 2 ? (int64_t)v : -(int64_t)(P - v); }
 
-template <bool POW2>
+// sum over the 16 row lanes (tid >> 4) of a value mod p held by thread (jl, t): two 16-lane shuffles inside each wave, LDS across waves;
+// valid in threads tid < 16
+__device__ __forceinline__ u64 sum_over_row_lanes(u64 v, u64 (*sh)[16], int tid) {
+    v = add_p(v, __shfl_xor(v, 16));
+    v = add_p(v, __shfl_xor(v, 32));
+    __syncthreads();
+    if ((tid & 63) < 16) sh[tid >> 6][tid & 15] = v;
+    __syncthreads();
+    u64 r = 0;
+    if (tid < 16) r = add_p(add_p(sh[0][tid], sh[1][tid]), add_p(sh[2][tid], sh[3][tid]));
+    return r;
+}
+// ICNT rows of A and KCNT digit planes per launch, both compile-time: the inner loops carry no predicates, so the LDS reads of a
+// whole 8-row group are in flight together.  The next tile's global loads are issued before the current tile is consumed.
+template <int ICNT, int KCNT>
 __global__ __launch_bounds__(256) void k_rg_phase1(Phase1Args a) {
+    constexpr int KX = KCNT ? KCNT : 1;
     __shared__ u64 ftab[TJ][32];
-    __shared__ u64 atab[IG][TJ][32];
-    __shared__ unsigned long long ex[KG][D][TJ / 8];   // byte jj of (ki, c): 8 * exponent
+    __shared__ u64 atab[ICNT][TJ][32];
+    __shared__ unsigned long long ex[KX][D][TJ / 8];   // byte jj of (ki, c): 8 * exponent
     const int tid = threadIdx.x, t = tid & 15, hi4 = tid >> 4;
     const u32 blk = blockIdx.x;
     const u64 jb = (u64)blk * a.J;
-    const u32 nout_m = a.k * a.kappa * 256, nout_f = a.kappa * 16;
+    const u32 nout = a.k * a.kappa * 256 + a.kappa * 16;
 
-    u64 mlo[KG][IG];
-    u32 mhi[KG][IG];
-    AccP fa[IG];
+    u32 m0[KX][ICNT], m1[KX][ICNT], m2[KX][ICNT];
+    AccP fa[ICNT];
 #pragma unroll
-    for (int q = 0; q < KG; q++)
+    for (int q = 0; q < KX; q++)
 #pragma unroll
-        for (int i = 0; i < IG; i++) { mlo[q][i] = 0; mhi[q][i] = 0; }
+        for (int i = 0; i < ICNT; i++) m0[q][i] = m1[q][i] = m2[q][i] = 0;
 #pragma unroll
-    for (int i = 0; i < IG; i++) accp_zero(fa[i]);
+    for (int i = 0; i < ICNT; i++) accp_zero(fa[i]);
 
+    u64 nf[2], na[ICNT][2];
+    auto fetch = [&](u64 j0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            int idx = tid + 256 * h;
+            u64 j = j0 + (idx >> 4);
+            bool in = j < a.n;
+            nf[h] = in ? a.f[j * D + (idx & 15)] : 0;
+#pragma unroll
+            for (int i = 0; i < ICNT; i++) na[i][h] = in ? a.A[((u64)(a.i0 + i) * a.n + j) * D + (idx & 15)] : 0;
+        }
+    };
+    fetch(jb);
     for (u32 tj = 0; tj < a.J; tj += TJ) {
         const u64 j0 = jb + tj;
         if (j0 >= a.n) break;
         __syncthreads();
-        // ---- f tile: digits, exponent bytes, +-f table
+        // ---- tile -> LDS: +-f table, digits (D_f out, exponent bytes), +-A tables
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             int idx = tid + 256 * h, jj = idx >> 4, c = idx & 15;
-            u64 j = j0 + jj;
-            u64 v = j < a.n ? a.f[j * D + c] : 0;
+            u64 j = j0 + jj, v = nf[h];
             ftab[jj][c] = v;
             ftab[jj][16 + c] = P - v;
-            if (a.kcnt) {
+#pragma unroll
+            for (int i = 0; i < ICNT; i++) {
+                atab[i][jj][c] = na[i][h];
+                atab[i][jj][16 + c] = P - na[i][h];
+            }
+            if (KCNT) {
                 int64_t cur = centre(v);
-                for (u32 ki = 0; ki < a.k0 + a.kcnt; ki++) {
-                    int64_t dg = digit_step<POW2>(cur, a.b, a.sh);
+                for (u32 ki = 0; ki < a.k0 + KCNT; ki++) {
+                    int64_t dg = digit_step(cur, a.b, a.sh);
                     if (dg <= -(D / 2) || dg >= D / 2) { atomicOr(a.err, 1u); dg = 0; }
-                    if (a.write_df && j < a.n && ki >= a.k0) a.Df[((u64)ki * a.n + j) * D + c] = (int8_t)dg;
-                    if (ki >= a.k0) ((unsigned char *)&ex[ki - a.k0][c][0])[jj] = (unsigned char)(((int)dg & 15) << 3);
+                    if (ki >= a.k0) {
+                        if (a.write_df && j < a.n) a.Df[((u64)ki * a.n + j) * D + c] = (int8_t)dg;
+                        ((unsigned char *)&ex[ki - a.k0][c][0])[jj] = (unsigned char)(((int)dg & 15) << 3);
+                    }
                 }
             }
         }
-        // ---- A tiles of the row group
-        for (u32 ii = 0; ii < a.icnt; ii++) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                int idx = tid + 256 * h, jj = idx >> 4, c = idx & 15;
-                u64 j = j0 + jj;
-                u64 v = j < a.n ? a.A[((u64)(a.i0 + ii) * a.n + j) * D + c] : 0;
-                atab[ii][jj][c] = v;
-                atab[ii][jj][16 + c] = P - v;
-            }
-        }
+        if (tj + TJ < a.J && j0 + TJ < a.n) fetch(j0 + TJ);
         __syncthreads();
         // ---- cm_f: thread (jl = hi4, t) owns output coefficient t of rows jl, jl + 16 of the tile
         if (a.do_f) {
@@ -134,194 +193,147 @@ __global__ __launch_bounds__(256) void k_rg_phase1(Phase1Args a) {
                 for (int s = 0; s < D; s++) {
                     u64 fv = ftab[jj][(t - s) & 31];
 #pragma unroll
-                    for (int i = 0; i < IG; i++)
-                        if (i < (int)a.icnt) accp_mad(fa[i], atab[i][jj][s], fv);
+                    for (int i = 0; i < ICNT; i++) accp_mad(fa[i], atab[i][jj][s], fv);
                 }
             }
         }
         // ---- comM_f: thread (c = hi4, t) owns coefficient t of column c
-        const u32 t8 = (u32)t << 3;
+        if (KCNT) {
+            const u32 t8 = (u32)t << 3;
 #pragma unroll
-        for (int q = 0; q < KG; q++) {
-            if (q < (int)a.kcnt) {
+            for (int q = 0; q < KCNT; q++) {
 #pragma unroll
                 for (int w = 0; w < TJ / 8; w++) {
                     unsigned long long eb = ex[q][hi4][w];
+                    u64 vals[8][ICNT];
 #pragma unroll
                     for (int m = 0; m < 8; m++) {
-                        u32 e8 = (u32)(eb >> (8 * m)) & 0xFFu;
-                        u32 u8 = (t8 - e8) & 0xF8u;
-                        const int jj = w * 8 + m;
+                        u32 u8 = (t8 - ((u32)(eb >> (8 * m)) & 0xFFu)) & 0xF8u;
 #pragma unroll
-                        for (int i = 0; i < IG; i++)
-                            if (i < (int)a.icnt) add96(mlo[q][i], mhi[q][i], *(const u64 *)((const char *)&atab[i][jj][0] + u8));
+                        for (int i = 0; i < ICNT; i++) vals[m][i] = *(const u64 *)((const char *)&atab[i][w * 8 + m][0] + u8);
                     }
+#pragma unroll
+                    for (int m = 0; m < 8; m++)
+#pragma unroll
+                        for (int i = 0; i < ICNT; i++) add96(m0[q][i], m1[q][i], m2[q][i], vals[m][i]);
                 }
             }
         }
     }
-    // ---- partial sums of the block
+    // ---- partial sums of the block, reduced mod p: [blk][ comM_f (k, kappa, 16, 16) | cm_f (kappa, 16) ]
+    u64 *part = a.part + (u64)blk * nout;
+    if (KCNT) {
 #pragma unroll
-    for (int q = 0; q < KG; q++)
+        for (int q = 0; q < KCNT; q++)
 #pragma unroll
-        for (int i = 0; i < IG; i++)
-            if (q < (int)a.kcnt && i < (int)a.icnt) {
-                u64 o = (u64)blk * nout_m + (((u64)(a.k0 + q) * a.kappa + a.i0 + i) * D + hi4) * D + t;
-                a.pm_lo[o] = mlo[q][i];
-                a.pm_hi[o] = mhi[q][i];
-            }
+            for (int i = 0; i < ICNT; i++)
+                part[(((u64)(a.k0 + q) * a.kappa + a.i0 + i) * D + hi4) * D + t] = red_word(m2[q][i], ((u64)m1[q][i] << 32) | m0[q][i]);
+    }
     if (a.do_f) {
-        U192 *red = (U192 *)&atab[0][0][0];   // 256 * 24 B
+        u64 (*sh)[16] = (u64 (*)[16]) & ftab[0][0];
 #pragma unroll
-        for (int i = 0; i < IG; i++) {
-            if (i < (int)a.icnt) {
-                __syncthreads();
-                red[tid] = accp_to_u192(fa[i]);
-                __syncthreads();
-                if (tid < 16) {
-                    U192 s = red[tid];
-                    for (int l = 1; l < 16; l++) u192_add(s, red[l * 16 + tid]);
-                    u64 o = (u64)blk * nout_f + (a.i0 + i) * D + tid;
-                    a.pf0[o] = s.w0;
-                    a.pf1[o] = s.w1;
-                    a.pf2[o] = s.w2;
-                }
-            }
+        for (int i = 0; i < ICNT; i++) {
+            u64 r = sum_over_row_lanes(mod_p_192(accp_to_u192(fa[i])), sh, tid);
+            if (tid < 16) part[(u64)a.k * a.kappa * 256 + (a.i0 + i) * D + tid] = r;
         }
     }
 }
 
+// second pass over A: C_Mf = A tau (scalar multiples), cm_mtau = A exp(tau) (rotation = 16-lane shuffle); thread (jl, t), rows jl + 16 m
+template <int ICNT>
 __global__ __launch_bounds__(256) void k_rg_phase2(Phase2Args a) {
-    __shared__ U192 red[256];
-    __shared__ u64 redm[256][2];
+    __shared__ u64 sh[4][16];
     const int tid = threadIdx.x, t = tid & 15, jl = tid >> 4;
     const u32 blk = blockIdx.x;
-    const u64 jb = (u64)blk * a.J, je = jb + a.J < a.n ? jb + a.J : a.n;
-    const u32 nout = a.kappa * 16;
-    AccP ca[IG];
-    u64 tlo[IG];
-    u32 thi[IG];
+    const u64 jb = (u64)blk * a.J;
+    const u32 nout = 2 * a.kappa * 16;
+    AccP ca[ICNT];
+    u32 t0[ICNT], t1[ICNT], t2[ICNT];
 #pragma unroll
-    for (int i = 0; i < IG; i++) { accp_zero(ca[i]); tlo[i] = 0; thi[i] = 0; }
-    for (u64 j = jb + jl; j < je; j += 16) {
-        u64 tv = a.tau[j];
-        int64_t tc = centre(tv);
-        if (tc <= -(D / 2) || tc >= D / 2) { atomicOr(a.err, 2u); tc = 0; }
-        if (a.i0 == 0 && t == 0) a.mtau[j] = (int8_t)tc;
-        const int src = t - ((int)tc & 15);
+    for (int i = 0; i < ICNT; i++) { accp_zero(ca[i]); t0[i] = t1[i] = t2[i] = 0; }
+    constexpr int U = ICNT == 4 ? 4 : 8;
+    for (u32 it = 0; it < a.J; it += 16 * U) {
+        u64 tv[U], av[U][ICNT];
 #pragma unroll
-        for (int i = 0; i < IG; i++) {
-            if (i < (int)a.icnt) {
-                u64 av = a.A[((u64)(a.i0 + i) * a.n + j) * D + t];
-                accp_mad(ca[i], av, tv);
-                u64 r = __shfl(av, src & 15, 16);
-                add96(tlo[i], thi[i], src < 0 ? P - r : r);
+        for (int u = 0; u < U; u++) {
+            u64 j = jb + it + 16 * u + jl;
+            bool in = it + 16 * u + jl < a.J && j < a.n;
+            tv[u] = in ? a.tau[j] : 0;
+#pragma unroll
+            for (int i = 0; i < ICNT; i++) av[u][i] = in ? a.A[((u64)(a.i0 + i) * a.n + j) * D + t] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u64 j = jb + it + 16 * u + jl;
+            int64_t tc = centre(tv[u]);
+            if (tc <= -(D / 2) || tc >= D / 2) { atomicOr(a.err, 2u); tc = 0; }
+            if (a.i0 == 0 && t == 0 && it + 16 * u + jl < a.J && j < a.n) a.mtau[j] = (int8_t)tc;
+            const int src = t - ((int)tc & 15);
+#pragma unroll
+            for (int i = 0; i < ICNT; i++) {
+                accp_mad(ca[i], av[u][i], tv[u]);
+                u64 r = __shfl(av[u][i], src & 15, 16);
+                add96(t0[i], t1[i], t2[i], src < 0 ? P - r : r);
             }
         }
     }
+    u64 *part = a.part + (u64)blk * nout;
 #pragma unroll
-    for (int i = 0; i < IG; i++) {
-        if (i < (int)a.icnt) {
-            __syncthreads();
-            red[tid] = accp_to_u192(ca[i]);
-            redm[tid][0] = tlo[i];
-            redm[tid][1] = thi[i];
-            __syncthreads();
-            if (tid < 16) {
-                U192 s = red[tid], m = {redm[tid][0], redm[tid][1], 0};
-                for (int l = 1; l < 16; l++) {
-                    u192_add(s, red[l * 16 + tid]);
-                    U192 x = {redm[l * 16 + tid][0], redm[l * 16 + tid][1], 0};
-                    u192_add(m, x);
-                }
-                u64 o = (u64)blk * nout + (a.i0 + i) * D + tid;
-                a.pc0[o] = s.w0; a.pc1[o] = s.w1; a.pc2[o] = s.w2;
-                a.pt_lo[o] = m.w0; a.pt_hi[o] = m.w1;
-            }
+    for (int i = 0; i < ICNT; i++) {
+        u64 c = sum_over_row_lanes(mod_p_192(accp_to_u192(ca[i])), sh, tid);
+        u64 m = sum_over_row_lanes(red_word(t2[i], ((u64)t1[i] << 32) | t0[i]), sh, tid);
+        if (tid < 16) {
+            part[(a.i0 + i) * D + tid] = c;                      // C_Mf
+            part[a.kappa * 16 + (a.i0 + i) * D + tid] = m;       // cm_mtau
         }
     }
 }
 
-// (w3 w2 w1 w0) mod p by shift-subtract (a few hundred outputs per call: not worth a Barrett constant)
-__device__ u64 mod_p_256(u64 w0, u64 w1, u64 w2, u64 w3) {
-    u64 w[4] = {w0, w1, w2, w3};
-    u64 r = 0;
-    for (int k = 3; k >= 0; k--) {
-        if (k && !w[k] && !r) continue;
-        for (int bit = 63; bit >= 0; bit--) {
-            u64 top = r >> 63;
-            r = (r << 1) | ((w[k] >> bit) & 1);
-            if (top || r >= P) r -= P;
-        }
-    }
-    return r;
-}
-__global__ __launch_bounds__(64 * RED_WAVES) void k_reduce(const u64 *w0, const u64 *w1, const u64 *w2, u32 nblk, u32 nout, u64 *out) {
-    __shared__ u64 part[RED_WAVES][64][4];
+// out[o] = sum over blocks of part[blk][o] mod p.  With split_l != 0 the first nsplit outputs are comM_f coefficients (k, kappa, 16, 16)
+// and the thread that finishes one also writes its l gadget digits into tau = split(hconcat(comM_f), n, base, l) (utils.rs:12-43:
+// element e of row i -> positions [e l, (e + 1) l) of the decomposed row, digit j of coefficient t at (e l + j) 16 + t).
+__global__ __launch_bounds__(64 * RED_WAVES) void k_reduce(const u64 *part, u32 nblk, u32 nout, u64 *out, u32 nsplit, u32 kappa, u32 k, u64 base,
+                                                           int sh, u32 l, u64 *tau) {
+    __shared__ u64 ps[RED_WAVES][64][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u32 o = blockIdx.x * 64 + lane;
-    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (o < nout)
-        for (u32 b = wv; b < nblk; b += RED_WAVES) {
-            u64 i = (u64)b * nout + o;
-            u64 x0 = w0[i], x1 = w1[i], x2 = w2 ? w2[i] : 0;
-            u64 a0 = s0 + x0, c0 = a0 < x0;
-            u64 a1 = s1 + x1, c1 = a1 < x1;
-            u64 a1b = a1 + c0; c1 += a1b < c0;
-            u64 a2 = s2 + x2, c2 = a2 < x2;
-            u64 a2b = a2 + c1; c2 += a2b < c1;
-            s0 = a0; s1 = a1b; s2 = a2b; s3 += c2;
+    u64 s0 = 0, s1 = 0;
+    if (o < nout) {
+        u32 b = wv;
+        for (; b + 7 * RED_WAVES < nblk; b += 8 * RED_WAVES) {
+            u64 x[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) x[q] = part[(u64)(b + q * RED_WAVES) * nout + o];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { s0 += x[q]; s1 += s0 < x[q]; }
         }
-    part[wv][lane][0] = s0; part[wv][lane][1] = s1; part[wv][lane][2] = s2; part[wv][lane][3] = s3;
+        for (; b < nblk; b += RED_WAVES) {
+            u64 x = part[(u64)b * nout + o];
+            s0 += x; s1 += s0 < x;
+        }
+    }
+    ps[wv][lane][0] = s0;
+    ps[wv][lane][1] = s1;
     __syncthreads();
     if (wv == 0 && o < nout) {
         for (int v = 1; v < RED_WAVES; v++) {
-            u64 x0 = part[v][lane][0], x1 = part[v][lane][1], x2 = part[v][lane][2], x3 = part[v][lane][3];
-            u64 a0 = s0 + x0, c0 = a0 < x0;
-            u64 a1 = s1 + x1, c1 = a1 < x1;
-            u64 a1b = a1 + c0; c1 += a1b < c0;
-            u64 a2 = s2 + x2, c2 = a2 < x2;
-            u64 a2b = a2 + c1; c2 += a2b < c1;
-            s0 = a0; s1 = a1b; s2 = a2b; s3 += x3 + c2;
+            u64 x = ps[v][lane][0];
+            s0 += x; s1 += (s0 < x) + ps[v][lane][1];
         }
-        out[o] = mod_p_256(s0, s1, s2, s3);
+        u64 r = red_word(s1, s0);
+        out[o] = r;
+        if (l && o < nsplit) {
+            u32 t = o & 15, c = (o >> 4) & 15, ik = o >> 8, i = ik % kappa, ki = ik / kappa;
+            int64_t cur = centre(r);
+            u64 pos = (((u64)i * k + ki) * D + c) * (u64)l * D + t;
+            for (u32 j = 0; j < l; j++) {
+                int64_t dg = digit_step(cur, base, sh);
+                tau[pos + (u64)j * D] = dg >= 0 ? (u64)dg : P - (u64)(-dg);
+            }
+        }
     }
 }
 
-__global__ void k_split(const u64 *comMf, u32 kappa, u32 k, u64 base, int sh, u32 l, u64 *tau) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= kappa * k * 256) return;
-    u32 t = g & 15, c = (g >> 4) & 15, ik = g >> 8, ki = ik % k, i = ik / k;
-    int64_t cur = centre(comMf[(((u64)ki * kappa + i) * D + c) * D + t]);
-    u64 pos = (((u64)i * k + ki) * D + c) * (u64)l * D + t;
-    for (u32 j = 0; j < l; j++) {
-        int64_t dg = sh >= 0 ? digit_step<true>(cur, base, sh) : digit_step<false>(cur, base, sh);
-        tau[pos + (u64)j * D] = dg >= 0 ? (u64)dg : P - (u64)(-dg);
-    }
-}
-
-// ---- F_p products for tensor / tensor_product (utils.rs:45-83): Montgomery, R = 2^64
-constexpr u64 mont_pinv() {   // -p^{-1} mod 2^64
-    u64 x = 1;
-    for (int i = 0; i < 6; i++) x *= 2 - P * x;
-    return ~x + 1;
-}
-constexpr u64 mont_r2() {     // 2^128 mod p
-    unsigned __int128 r = 1;
-    for (int i = 0; i < 128; i++) { r <<= 1; if (r >= P) r -= P; }
-    return (u64)r;
-}
-__device__ __forceinline__ u64 mont_mul(u64 a, u64 b) {
-    u64 lo = a * b, hi = __umul64hi(a, b);
-    u64 m = lo * mont_pinv();
-    u64 mh = __umul64hi(m, P), ml = m * P;
-    u64 cy = (lo + ml) < lo;      // the low word cancels to 0 (mod 2^64); only its carry matters
-    u64 u = hi + mh, o1 = u < hi;
-    u64 v = u + cy, o2 = v < cy;
-    if (o1 || o2 || v >= P) v -= P;
-    return v;
-}
-__device__ __forceinline__ u64 mul_p(u64 a, u64 b) { return mont_mul(mont_mul(a, b), mont_r2()); }
 __global__ void k_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= len) return;
@@ -336,17 +348,28 @@ __global__ void k_tensor_product(const u64 *a, u64 m, const u64 *b, u64 n, u64 *
 }
 
 static int log2_exact(u64 b) { return (b && !(b & (b - 1))) ? __builtin_ctzll(b) : -1; }
+template <int ICNT>
+static void launch_phase1_i(const Phase1Args &a, u32 nblk, hipStream_t s) {
+    switch (a.kcnt) {
+    case 0: hipLaunchKernelGGL((k_rg_phase1<ICNT, 0>), dim3(nblk), dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((k_rg_phase1<ICNT, 1>), dim3(nblk), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_rg_phase1<ICNT, 2>), dim3(nblk), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_rg_phase1<ICNT, 4>), dim3(nblk), dim3(256), 0, s, a); break;
+    }
+}
+// icnt in {1, 2, 4}, kcnt in {0, 1, 2, 4} (group_size() cuts kappa and k into such groups)
 void launch_phase1(const Phase1Args &a, u32 nblk, hipStream_t s) {
-    if (a.sh >= 0) hipLaunchKernelGGL(k_rg_phase1<true>, dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_rg_phase1<false>, dim3(nblk), dim3(256), 0, s, a);
+    if (a.icnt == 1) launch_phase1_i<1>(a, nblk, s);
+    else if (a.icnt == 2) launch_phase1_i<2>(a, nblk, s);
+    else launch_phase1_i<4>(a, nblk, s);
 }
-void launch_phase2(const Phase2Args &a, u32 nblk, hipStream_t s) { hipLaunchKernelGGL(k_rg_phase2, dim3(nblk), dim3(256), 0, s, a); }
-void launch_reduce(const u64 *w0, const u64 *w1, const u64 *w2, u32 nblk, u32 nout, u64 *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce, dim3((nout + 63) / 64), dim3(64 * RED_WAVES), 0, s, w0, w1, w2, nblk, nout, out);
+void launch_phase2(const Phase2Args &a, u32 nblk, hipStream_t s) {
+    if (a.icnt == 1) hipLaunchKernelGGL(k_rg_phase2<1>, dim3(nblk), dim3(256), 0, s, a);
+    else if (a.icnt == 2) hipLaunchKernelGGL(k_rg_phase2<2>, dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_rg_phase2<4>, dim3(nblk), dim3(256), 0, s, a);
 }
-void launch_split(const u64 *comMf, u32 kappa, u32 k, u64 base, u32 l, u64 *tau, hipStream_t s) {
-    u32 th = kappa * k * 256;
-    hipLaunchKernelGGL(k_split, dim3((th + 255) / 256), dim3(256), 0, s, comMf, kappa, k, base, log2_exact(base), l, tau);
+void launch_reduce(const u64 *part, u32 nblk, u32 nout, u64 *out, u32 nsplit, u32 kappa, u32 k, u64 base, u32 l, u64 *tau, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce, dim3((nout + 63) / 64), dim3(64 * RED_WAVES), 0, s, part, nblk, nout, out, nsplit, kappa, k, base, log2_exact(base), l, tau);
 }
 void launch_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt, hipStream_t s) {
     hipLaunchKernelGGL(k_tensor_level, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, cur, len, r, nxt);
