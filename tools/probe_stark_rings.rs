@@ -83,6 +83,25 @@ fn main() {
         println!(" \"babybear_crt_of_monomials\": {:?},", rows);
     }
 
+    // 6. LatticeFold+ conventions on the Frog ring (oracle/lfp.h restates them): exp, decompose_to_vec, gadget digits
+    {
+        use stark_rings::cyclotomic_ring::models::frog_ring::{Fq as FrogFq, RqPoly as FrogPoly};
+        use stark_rings::{balanced_decomposition::GadgetDecompose, exp};
+        use stark_rings_linalg::Matrix;
+        let sgn = |v: i64| if v >= 0 { FrogFq::from(v as u64) } else { -FrogFq::from((-v) as u64) };
+        let show = |r: &FrogPoly| r.coeffs().iter().map(|x| x.into_bigint().0[0]).collect::<Vec<u64>>();
+        let exps: Vec<Vec<u64>> = [-7i64, -3, -1, 0, 1, 3, 7].iter().map(|a| show(&exp::<FrogPoly>(sgn(*a)).unwrap())).collect();
+        println!(" \"frog_exp\": {:?},", exps);
+        let vals: Vec<FrogFq> = [4i64, -4, 5, -5, 12, -12, 28, -28, 31, -31].iter().map(|v| sgn(*v)).collect();
+        let digs: Vec<Vec<u64>> = vals.decompose_to_vec(8u128, 2).iter().map(|d| d.iter().map(|x| x.into_bigint().0[0]).collect()).collect();
+        println!(" \"frog_digits_b8_k2\": {:?},", digs);
+        let mut e = vec![FrogFq::zero(); 16];
+        for (i, v) in e.iter_mut().enumerate() { *v = FrogFq::from(123456789u64 * (i as u64 + 1)); }
+        let m: Matrix<FrogPoly> = vec![vec![FrogPoly::from(e), FrogPoly::from(vec![FrogFq::one(); 16])]].into();
+        let g = m.gadget_decompose(8u128, 22);
+        println!(" \"frog_gadget_row\": {:?},", g.vals[0].iter().map(|r| show(r)).collect::<Vec<_>>());
+    }
+
     // 5. bytes of ONE serialized ring element (the per-element layout lf_wire.cpp assumes: 24 words x 8 bytes LE, no prefix)
     let mut e = vec![Fq::zero(); 24];
     for (i, v) in e.iter_mut().enumerate() { *v = Fq::from(1000u64 + i as u64); }
