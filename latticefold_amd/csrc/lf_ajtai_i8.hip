@@ -1,0 +1,292 @@
+// lf_ajtai_i8.hip -- Ajtai commitments of the base-2 digit planes of a witness on the int8 matrix cores (gfx950 v_mfma_i32_16x16x64_i8).
+//
+// The decomposition step (nifs/decomposition.rs:178-201) commits to K-1 witnesses whose coefficients are the balanced binary digits
+// (-1, 0, 1) of one coefficient vector.  y_k[i] = sum_j A[i][j] * f_k[j] in R = Z_p[X]/(X^24 - X^12 + 1) is a genuine matrix product --
+// (kappa x N) . (N x (K-1)) over the ring -- and with f_k that small it needs no modular arithmetic at all until the very end:
+//   * ring product in COEFFICIENT form: (a * f)[c_out] = sum_{c_in} a[c_in] * Rot(f)[c_in][c_out], Rot(f)[c_in] = X^c_in * f mod Phi,
+//     whose entries are sums of at most three digits (|.| <= 3);
+//   * the 64-bit coefficients of A are cut into 8 bytes (biased by -128 to fit int8): A becomes a (8 kappa) x (24 N) int8 matrix,
+//     Rot(f_k) a (24 N) x (24 (K-1)) int8 matrix, the product an exact int32 GEMM per column chunk;
+//   * y = sum_u 2^(8u) (C[(i,u)] + 128 * colsum) mod p, once per output (k_ajtai_i8_reduce), then one CRT of kappa (K-1) elements.
+// kappa = 26, K = 16 at 2^20 columns: 208 x 360 outputs, 1.9e12 int8 MACs per decomposition instead of 1.6e10 lazy 64 x 64 MACs on the
+// quarter-rate integer multiplier (k_ajtai: 7.1 ms, VALU-issue-bound).  No bit-plane NTTs are needed either (k_bitplane_crt).
+//
+// Operands.  A is repacked ONCE per matrix (k_ajtai_pack_i8) into MFMA operand order, so a tile of 8 columns (192 inner elements =
+// 3 K-steps of 64) is one contiguous block copied to LDS.  Rot(f) is never materialised: X^c_in * f is Toeplitz in (c_out - c_in) apart
+// from the two wrap rules of Phi, so per (digit plane, 8 columns) two 47-entry vectors of 8 packed bytes
+//     H[d] = f[d] + f[d + 12]               (outputs c_out >= 12)
+//     L[d] = f[d] - f[d + 24] - f[d + 36]   (outputs c_out <  12)        (terms outside 0..23 dropped)
+// are built with SWAR byte arithmetic, and the B operand of a lane is the two adjacent entries d = c_out - c_in, c_out - c_in - 1.
+#include <hip/hip_runtime.h>
+#include "lf_field.cuh"
+#include "lf_kernels.h"
+
+namespace lf {
+static inline size_t cdiv(size_t a, size_t b) { return (a + b - 1) / b; }
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned long long ull;
+
+constexpr int I8_WAVES = 8;          // 2 row groups x 4 column groups
+constexpr int I8_NTW = 6;            // column tiles per wave (4 groups x 6 = 24 >= ceil(24 * 16 / 16))
+constexpr ull M7 = 0x7f7f7f7f7f7f7f7full, M8 = 0x8080808080808080ull;
+__device__ __forceinline__ ull swar_add(ull a, ull b) { return ((a & M7) + (b & M7)) ^ ((a ^ b) & M8); }
+__device__ __forceinline__ ull swar_sub(ull a, ull b) { return ((a | M8) - (b & M7)) ^ ((a ^ ~b) & M8); }
+__device__ __forceinline__ int digit2_i8(int32_t v, u32 k) {
+    int32_t m = v < 0 ? -v : v;
+    int d = (m >> k) & 1;
+    return v < 0 ? -d : d;
+}
+
+// one launch per row of A: coefficient table [24][n] of row i -> bytes in operand order
+// Ab[((T*3 + s)*MT + mt)*1024 + lane*16 + t],  row m = 8 i + u = 16 mt + (lane & 15),  c_in = 8 s + 2 (lane >> 4) + (t >> 3),  column 8 T + (t & 7)
+__global__ void __launch_bounds__(256) k_ajtai_pack_i8(const u64 *coef, size_t n, u32 i, u32 MT, size_t ntiles, unsigned char *Ab) {
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= ntiles * 96) return;
+    const u32 u = gid & 7, g = (gid >> 3) & 3, s = (u32)((gid >> 5) % 3);
+    const size_t T = gid / 96;
+    const u32 m = 8 * i + u, mt = m >> 4, lane = g * 16 + (m & 15), c0 = 8 * s + 2 * g;
+    unsigned char b[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        size_t j = T * 8 + (t & 7);
+        u64 v = j < n ? coef[(size_t)(c0 + (t >> 3)) * n + j] : 0;
+        b[t] = (unsigned char)(((v >> (8 * u)) & 0xFF) ^ 0x80);
+    }
+    uint4 w;
+    w.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((u32)b[3] << 24);
+    w.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((u32)b[7] << 24);
+    w.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((u32)b[11] << 24);
+    w.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((u32)b[15] << 24);
+    *(uint4 *)(Ab + ((T * 3 + s) * MT + mt) * 1024 + lane * 16) = w;
+}
+void launch_ajtai_pack_i8(const u64 *coef, size_t n, u32 i, u32 MT, unsigned char *Ab, hipStream_t s) {
+    size_t ntiles = (n + 7) / 8;
+    hipLaunchKernelGGL(k_ajtai_pack_i8, dim3((unsigned)cdiv(ntiles * 96, 256)), dim3(256), 0, s, coef, n, i, MT, ntiles, Ab);
+}
+
+struct AjtaiI8Args {
+    const unsigned char *Ab;
+    const int32_t *planes;   // [24][ld], already offset to this rank's first column
+    size_t ld, n;
+    u32 MT, NT, k0, NP;
+    u32 ntiles, tiles_per_wg;
+    int32_t *part;           // [wg][MT][NT][64][4]
+    int32_t *dsum;           // [wg][NP][24]
+};
+
+// dynamic LDS: A tiles 2 x (3*MT KB) | V 2 x NP x 96 x 8 | D NP x 24 x 8 | w 2 x 24 x 8 x 4
+template <int MTW>
+__global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave >> 2, ng = wave & 3;
+    const u32 MT = a.MT, NT = a.NT, NP = a.NP;
+    const size_t a_tile = (size_t)3 * MT * 1024;
+    unsigned char *Al = smem;                                   // [2][3][MT][64][16]
+    ull *V = (ull *)(smem + 2 * a_tile);                        // [2][NP][2][48]
+    ull *Dl = V + 2 * (size_t)NP * 96;                          // [NP][24]
+    int32_t *wl = (int32_t *)(Dl + (size_t)NP * 24);            // [2][24][8]
+    // this wave's tiles
+    const u32 mh = (MT + 1) / 2, m_lo = mg ? mh : 0, mcnt = mg ? MT - mh : mh;
+    const u32 n_lo = ng * I8_NTW, ncnt = n_lo >= NT ? 0 : (NT - n_lo < I8_NTW ? NT - n_lo : I8_NTW);
+    // B operand base offsets (bytes into one V buffer) at K-step 0: entry e0 = 23 - c_out + 2 g of (plane, c_out >= 12)
+    u32 vb[I8_NTW];
+#pragma unroll
+    for (int ni = 0; ni < I8_NTW; ni++) {
+        u32 n = (n_lo + ni) * 16 + (lane & 15);
+        if (n >= 24 * NP) n = 24 * NP - 1;
+        u32 p = n / 24, co = n % 24;
+        vb[ni] = ((p * 2 + (co >= 12 ? 0u : 1u)) * 48 + (23 - co + 2 * (lane >> 4))) * 8;
+    }
+    v4i acc[MTW][I8_NTW];
+#pragma unroll
+    for (int mi = 0; mi < MTW; mi++)
+#pragma unroll
+        for (int ni = 0; ni < I8_NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
+    int dacc = 0;                                               // sum of the digits of (plane, c) = tid over this workgroup's columns
+
+    const u32 T0 = blockIdx.x * a.tiles_per_wg;
+    const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
+    constexpr int ACH = 5;                                      // 16-byte chunks of an A tile per thread: 3 * MT * 64 <= 5 * 512 for MT <= 13 .. see host check
+    uint4 areg[ACH];
+    int32_t wreg = 0;
+    auto load_a = [&](u32 T) {
+#pragma unroll
+        for (int q = 0; q < ACH; q++) {
+            u32 idx = tid + 512 * q;
+            if (idx < 3 * MT * 64) areg[q] = *(const uint4 *)(a.Ab + (size_t)T * a_tile + (size_t)idx * 16);
+        }
+    };
+    auto store_a = [&](u32 buf) {
+#pragma unroll
+        for (int q = 0; q < ACH; q++) {
+            u32 idx = tid + 512 * q;
+            if (idx < 3 * MT * 64) *(uint4 *)(Al + buf * a_tile + (size_t)idx * 16) = areg[q];
+        }
+    };
+    auto load_w = [&](u32 T) {
+        if (tid < 192) {
+            size_t j = (size_t)T * 8 + (tid & 7);
+            wreg = (T < T1 && j < a.n) ? a.planes[(size_t)(tid >> 3) * a.ld + j] : 0;
+        }
+    };
+    auto store_w = [&](u32 buf) { if (tid < 192) wl[buf * 192 + tid] = wreg; };
+    auto gen_d = [&](u32 buf) {
+        if (tid < NP * 24) {
+            const u32 p = tid / 24, c = tid % 24;
+            const int4 w0 = *(const int4 *)(wl + buf * 192 + c * 8), w1 = *(const int4 *)(wl + buf * 192 + c * 8 + 4);
+            const int32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            ull d = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                int dg = digit2_i8(w[q], a.k0 + p);
+                dacc += dg;
+                d |= (ull)(unsigned char)dg << (8 * q);
+            }
+            Dl[tid] = d;
+        }
+    };
+    auto gen_v = [&](u32 buf) {
+        for (u32 idx = tid; idx < NP * 96; idx += 512) {
+            const u32 p = idx / 96, r = idx % 96, hl = r / 48, e = r % 48;
+            const int dl = 23 - (int)e;
+            const ull *D = Dl + p * 24;
+            ull v = 0;
+            if (hl == 0) {          // H: outputs c_out >= 12
+                if (dl >= -11 && dl <= 23) {
+                    v = dl >= 0 ? D[dl] : 0;
+                    if (dl <= 11) v = swar_add(v, D[dl + 12]);
+                }
+            } else {                // L: outputs c_out < 12
+                if (dl >= -23 && dl <= 11) {
+                    v = dl >= 0 ? D[dl] : 0;
+                    if (dl <= -1) v = swar_sub(v, D[dl + 24]);
+                    if (dl <= -13) v = swar_sub(v, D[dl + 36]);
+                }
+            }
+            V[(size_t)buf * NP * 96 + idx] = v;
+        }
+    };
+    if (T0 < T1) {
+        // ---- prologue: A[T0], w[T0], w[T0+1] -> LDS; D[T0]; V[0]
+        load_a(T0);
+        load_w(T0);
+        store_w(0);
+        load_w(T0 + 1);
+        store_w(1);
+        store_a(0);
+        __syncthreads();
+        gen_d(0);
+        __syncthreads();
+        gen_v(0);
+        __syncthreads();
+        for (u32 T = T0; T < T1; T++) {
+            const u32 cur = (T - T0) & 1, nxt = cur ^ 1;
+            const bool more = T + 1 < T1;
+            if (more) { load_a(T + 1); load_w(T + 2); gen_d(nxt); }
+            __syncthreads();
+            if (more) gen_v(nxt);
+            // ---- 3 K-steps of 64 inner elements
+            const unsigned char *Ac = Al + cur * a_tile;
+            const unsigned char *Vc = (const unsigned char *)(V + (size_t)cur * NP * 96);
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                v4i b[I8_NTW];
+#pragma unroll
+                for (int ni = 0; ni < I8_NTW; ni++) {
+                    const ull *q = (const ull *)(Vc + vb[ni] + s * 64);
+                    ull lo = q[0], hi = q[1];
+                    b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
+                }
+#pragma unroll
+                for (int mi = 0; mi < MTW; mi++) {
+                    if (mi < (int)mcnt) {
+                        v4i av = *(const v4i *)(Ac + ((size_t)(s * MT + m_lo + mi) * 64 + lane) * 16);
+#pragma unroll
+                        for (int ni = 0; ni < I8_NTW; ni++)
+                            if (ni < (int)ncnt) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) { store_a(nxt); store_w(cur); }   // w[T+2] goes where w[T] was (read by gen_d one iteration ago)
+            __syncthreads();
+        }
+    }
+    // ---- partial results of the workgroup
+#pragma unroll
+    for (int mi = 0; mi < MTW; mi++)
+#pragma unroll
+        for (int ni = 0; ni < I8_NTW; ni++)
+            if (mi < (int)mcnt && ni < (int)ncnt)
+                *(v4i *)(a.part + ((((size_t)blockIdx.x * MT + m_lo + mi) * NT + n_lo + ni) * 64 + lane) * 4) = acc[mi][ni];
+    if (tid < NP * 24) a.dsum[(size_t)blockIdx.x * NP * 24 + tid] = dacc;
+}
+
+// y[plane][i][c_out] (coefficient form, SoA [24][NP*kappa], element index plane*kappa + i) from the workgroup partials
+__global__ void __launch_bounds__(256) k_ajtai_i8_reduce(const int32_t *part, const int32_t *dsum, u32 nwg, u32 MT, u32 NT, u32 NP, u32 kappa, u32 row0,
+                                                         u32 kappa_total, u64 *coef_out) {
+    const u32 o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= NP * kappa * 24) return;
+    const u32 co = o % 24, i = (o / 24) % kappa, p = o / (24 * kappa);
+    const u32 n = p * 24 + co, nt = n >> 4, col = n & 15;
+    // T = sum over inner elements of Rot(F)[.][c_out], F = sum over columns of the digit polynomials: the "-128" bias of the bytes of A
+    long long F[24];
+    for (int c = 0; c < 24; c++) {
+        long long s = 0;
+        for (u32 w = 0; w < nwg; w++) s += dsum[((size_t)w * NP + p) * 24 + c];
+        F[c] = s;
+    }
+    long long Tsum = 0;
+    for (int ci = 0; ci < 24; ci++) {
+        int d = (int)co - ci;
+        if (co >= 12) {
+            if (d >= 0) Tsum += F[d];
+            if (d <= 11) Tsum += F[d + 12];
+        } else {
+            if (d >= 0) Tsum += F[d];
+            if (d <= -1) Tsum -= F[d + 24];
+            if (d <= -13) Tsum -= F[d + 36];
+        }
+    }
+    __int128 tot = 0;
+    for (u32 u = 0; u < 8; u++) {
+        const u32 m = 8 * i + u, mt = m >> 4, r = m & 15, ln = col + 16 * (r >> 2), reg = r & 3;
+        long long s = 0;
+        for (u32 w = 0; w < nwg; w++) s += part[((((size_t)w * MT + mt) * NT + nt) * 64 + ln) * 4 + reg];
+        tot += (__int128)(s + 128 * Tsum) << (8 * u);
+    }
+    coef_out[(size_t)co * ((size_t)NP * kappa_total) + (size_t)p * kappa_total + row0 + i] = fq_from_s128((u64)tot, (int64_t)(tot >> 64));
+}
+
+size_t ajtai_i8_lds_bytes(u32 MT, u32 NP) { return 2 * (size_t)3 * MT * 1024 + 2 * (size_t)NP * 96 * 8 + (size_t)NP * 24 * 8 + 2 * 192 * 4; }
+u32 ajtai_i8_row_tiles(u32 kappa) { return (8 * kappa + 15) / 16; }
+u32 ajtai_i8_col_tiles(u32 NP) { return (24 * NP + 15) / 16; }
+// partial buffer words (int32) for nwg workgroups
+size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT) { return (size_t)nwg * MT * NT * 256; }
+
+int launch_ajtai_i8(const unsigned char *Ab, u32 MT, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total, u32 k0, u32 NP, u32 nwg,
+                    int32_t *part, int32_t *dsum, u64 *coef_out, hipStream_t s) {
+    AjtaiI8Args a;
+    a.Ab = Ab; a.planes = planes; a.ld = ld; a.n = n;
+    a.MT = MT; a.NT = ajtai_i8_col_tiles(NP); a.k0 = k0; a.NP = NP;
+    a.ntiles = (u32)((n + 7) / 8);
+    a.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
+    a.part = part; a.dsum = dsum;
+    if (a.MT > 13 || 8 * kappa > 16 * MT || NP > 16 || NP == 0) return -1;   // 3 * MT * 64 sixteen-byte chunks of an A tile <= 5 per thread
+    const u32 grid = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    const size_t lds = ajtai_i8_lds_bytes(a.MT, NP);
+    const u32 mh = (a.MT + 1) / 2;
+#define LF_I8_LAUNCH(MTW)                                                                                                          \
+    do {                                                                                                                           \
+        static bool attr_set = false;                                                                                              \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL(k_ajtai_i8<MTW>, dim3(grid), dim3(64 * I8_WAVES), lds, s, a);                                           \
+    } while (0)
+    if (mh <= 2) LF_I8_LAUNCH(2);
+    else if (mh <= 4) LF_I8_LAUNCH(4);
+    else LF_I8_LAUNCH(7);
+#undef LF_I8_LAUNCH
+    hipLaunchKernelGGL(k_ajtai_i8_reduce, dim3(cdiv((size_t)NP * kappa * 24, 256)), dim3(256), 0, s, part, dsum, grid, a.MT, a.NT, NP, kappa, row0, kappa_total,
+                       coef_out);
+    return (int)grid;
+}
+}  // namespace lf

@@ -93,6 +93,8 @@ struct lf_ctx {
     u64 *d_icrt = nullptr;
     // Ajtai (nA = columns held by this rank, starting at global column A_col0 of nA_total)
     u64 *dA = nullptr;
+    unsigned char *dAb = nullptr;   // the same matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 26
+    u32 i8_nch = 0, i8_kc = 0;
     u32 kappa = 0;
     size_t nA = 0, nA_total = 0, A_col0 = 0;
     // intra-step sharding: rank/world and the all-gather callback supplied by the host language
@@ -329,6 +331,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     free_ccs(c);
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
+    if (c->dAb) (void)hipFree(c->dAb);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
     for (int l = 0; l < 2; l++)
         if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
@@ -627,6 +630,56 @@ static int shard_columns(lf_ctx *c, size_t n, size_t *col0, size_t *cnt) {
     *col0 = *cnt * c->sh_rank;
     return LF_OK;
 }
+// The int8 matrix-core commit kernel wants A in coefficient form, cut into bytes, in MFMA operand order: built once per matrix.
+static int prep_ajtai_i8(lf_ctx *c) {
+    if (c->dAb) { (void)hipFree(c->dAb); c->dAb = nullptr; }
+    c->i8_nch = 0;
+    if (getenv("LF_AJTAI_VALU")) return LF_OK;
+    const u32 nch = (c->kappa + 25) / 26, kc = (c->kappa + nch - 1) / nch;
+    const size_t ntiles = (c->nA + 7) / 8;
+    const u32 MT = ajtai_i8_row_tiles(kc);
+    const size_t chunk_bytes = ntiles * 3 * MT * 1024;
+    HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch));
+    HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch, c->stream()));
+    u64 *coef;
+    RET(c->tbuf("i8_prep_coef", 24 * c->nA, &coef));
+    for (u32 i = 0; i < c->kappa; i++) {
+        launch_icrt_dense(c->d_icrt, c->dA + (size_t)i * 24 * c->nA, coef, c->nA, c->stream());
+        launch_ajtai_pack_i8(coef, c->nA, i % kc, MT, c->dAb + (size_t)(i / kc) * chunk_bytes, c->stream());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    c->i8_nch = nch;
+    c->i8_kc = kc;
+    return LF_OK;
+}
+// digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev [NP][kappa][24] NTT form (PARTIAL when sharded)
+static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev) {
+    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(kc);
+    const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * 3 * MT * 1024;
+    u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 256;
+    if (nwg > ntiles) nwg = (u32)ntiles;
+    int32_t *part, *dsum;
+    u64 *coef, *ntt;
+    RET(c->tbuf("i8_part", ajtai_i8_part_words(nwg, MT, ajtai_i8_col_tiles(16)), &part));
+    RET(c->tbuf("i8_dsum", (size_t)nwg * 16 * 24, &dsum));
+    RET(c->tbuf("i8_coef", (size_t)24 * NP * c->kappa, &coef));
+    RET(c->tbuf("i8_ntt", (size_t)24 * NP * c->kappa, &ntt));
+    for (u32 p0 = 0; p0 < NP; p0 += 16) {
+        const u32 np = NP - p0 < 16 ? NP - p0 : 16;
+        u64 *cf = coef + (size_t)24 * p0 * c->kappa;   // SoA block of this plane group: [24][np*kappa]
+        for (u32 ch = 0; ch < nch; ch++) {
+            const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
+            size_t ev = c->ev_begin(1);
+            int g = launch_ajtai_i8(c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, cf, c->stream());
+            c->ev_end(ev);
+            if (g < 0) return LF_ERR_UNSUPPORTED;
+        }
+        const size_t ne = (size_t)np * c->kappa;
+        launch_crt_fwd(c->dcrt, cf, ntt, ne, c->stream());
+        launch_soa_to_aos(ntt, out_dev + (size_t)p0 * c->kappa * 24, ne, c->stream());
+    }
+    return LF_OK;
+}
 int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
     if (LF_XB(c) && A && kappa <= 128) { XB x(c); return lf_ajtai_load(c, x.ring_in(A, kappa * n), kappa, n); }
     if (!c || !A || !kappa || !n || kappa > 128) return LF_ERR_INVALID;
@@ -641,7 +694,7 @@ int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
-    return LF_OK;
+    return prep_ajtai_i8(c);
 }
 int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
     if (!c || !kappa || !n || kappa > 128) return LF_ERR_INVALID;
@@ -656,7 +709,7 @@ int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
-    return LF_OK;
+    return prep_ajtai_i8(c);
 }
 static u32 ajtai_splits(size_t n) {
     // one block per (split, slot); aim for >= 4 blocks per CU, each split a multiple of the LDS tile
@@ -1380,12 +1433,16 @@ static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_o
     size_t N = c->N;
     u32 K = P.K;
     u64 *Fh, *yd;
-    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * c->nA, &Fh));
     RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &yd));
     size_t ph = c->ev_begin(11);
-    // bit-plane NTTs of this rank's column slice only (all columns when not sharded)
-    launch_bitplane_crt(c->dcrt, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());
-    RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
+    if (c->i8_nch && !c->tn.ajtai_valu) {
+        // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
+        RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd));
+    } else {
+        RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * c->nA, &Fh));
+        launch_bitplane_crt(c->dcrt, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());
+        RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
+    }
     *yd_out = yd;
     *ev_out = ph;
     return LF_OK;

@@ -62,6 +62,8 @@ struct Tunables {
     bool force_exchange = false;     // LF_DIST_FORCE_EXCHANGE: run the sharded exchanges even with a 1-rank RCCL communicator (test hook)
     bool device_transcript = false;  // LF_DEVICE_TRANSCRIPT: Poseidon sponge of the tail rounds on the device (opt-in: slower than the host's)
     bool shard_two_lanes = false;    // LF_SHARD_TWO_LANES: threaded two-lane schedule also in a sharded step (default there: one host thread)
+    bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
+    long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
     bool no_tail = false;            // LF_NO_TAIL: keep one launch set + stream sync per tail round instead of the persistent tail kernel
     size_t fuse_min = 16384, lut_min = (size_t)1 << 17, tab_min = 16384;
     size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
@@ -77,6 +79,8 @@ struct Tunables {
         t.fold_no_mutab = getenv("LF_FOLD_NO_MUTAB") != nullptr;
         t.theta_eval = getenv("LF_THETA_EVAL") != nullptr;
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;
+        t.ajtai_valu = getenv("LF_AJTAI_VALU") != nullptr;
+        if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
         t.shard_two_lanes = getenv("LF_SHARD_TWO_LANES") != nullptr;
         t.device_transcript = getenv("LF_DEVICE_TRANSCRIPT") != nullptr;
         t.force_exchange = getenv("LF_DIST_FORCE_EXCHANGE") != nullptr;
