@@ -18,6 +18,7 @@
 //     L[d] = f[d] - f[d + 24] - f[d + 36]   (outputs c_out <  12)        (terms outside 0..23 dropped)
 // are built with SWAR byte arithmetic, and the B operand of a lane is the two adjacent entries d = c_out - c_in, c_out - c_in - 1.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "lf_field.cuh"
 #include "lf_kernels.h"
 
@@ -31,6 +32,9 @@ constexpr int I8_NTW = 6;            // column tiles per wave (4 groups x 6 = 24
 constexpr ull M7 = 0x7f7f7f7f7f7f7f7full, M8 = 0x8080808080808080ull;
 __device__ __forceinline__ ull swar_add(ull a, ull b) { return ((a & M7) + (b & M7)) ^ ((a ^ b) & M8); }
 __device__ __forceinline__ ull swar_sub(ull a, ull b) { return ((a | M8) - (b & M7)) ^ ((a ^ ~b) & M8); }
+// workgroup barrier that waits for LDS traffic only: __syncthreads() also drains the vector-memory counter, which would stall on the
+// prefetch of the next A tile at every barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int digit2_i8(int32_t v, u32 k) {
     int32_t m = v < 0 ? -v : v;
     int d = (m >> k) & 1;
@@ -72,17 +76,30 @@ struct AjtaiI8Args {
     u32 ntiles, tiles_per_wg;
     int32_t *part;           // [wg][MT][NT][64][4]
     int32_t *dsum;           // [wg][NP][24]
+    u32 dbg;
 };
 
-// dynamic LDS: A tiles 2 x (3*MT KB) | V 2 x NP x 96 x 8 | D NP x 24 x 8 | w 2 x 24 x 8 x 4
-template <int MTW>
+// dynamic LDS: A tiles 2 x a_lds | V 2 x NP x 96 x 8 | D NP x 24 x 8 | w 2 x 24 x 8 x 4
+//
+// Per tile of 8 columns: stage A[T+1] (registers) and w[T+2], digits D[T+1], barrier, Toeplitz vectors V[T+1], 3 K-steps of MFMAs on
+// A[T] / V[T], A[T+1] -> LDS, barrier.  Notes from the tuning (profiles/r02b_i8_notes.txt):
+//  * the 168 accumulators + 32 operand registers + 20 staging registers of a wave fill the 256-register budget of 2 waves / SIMD; every
+//    deeper pipeline tried (one barrier per tile, G / M order alternating between the two waves of a SIMD, AGPR-targeted asm loads)
+//    spilled 50 - 480 registers, and control flow around the MFMA block makes the compiler copy the tied accumulators;
+//  * LDS-DMA (global_load_lds) sustained 2.8 B/clk/CU on this stream against 5.4 TB/s for dwordx4 loads, so A is staged through registers;
+//    the compiler parks the staged tile in AGPRs straight after loading it, i.e. waits for the load at the top of every iteration (an L2
+//    prefetch by touch loads was tried: a VGPR-less touch needs LDS-DMA, and an asm load into a dead register hangs the kernel);
+//  * loads carry no control flow (a guarded load is waited for at its join): the copy of a tile is unconditional and padded, tiles /
+//    columns out of range are clamped to valid addresses and masked after the load;
+template <int MTW, int ACH>
 __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave >> 2, ng = wave & 3;
     const u32 MT = a.MT, NT = a.NT, NP = a.NP;
-    const size_t a_tile = (size_t)3 * MT * 1024;
-    unsigned char *Al = smem;                                   // [2][3][MT][64][16]
-    ull *V = (ull *)(smem + 2 * a_tile);                        // [2][NP][2][48]
+    const size_t a_tile = (size_t)3 * MT * 1024;               // bytes of a tile in HBM
+    constexpr size_t a_lds = (size_t)ACH * 512 * 16;           // ... and its padded stride in LDS
+    unsigned char *Al = smem;                                   // [2][a_lds]
+    ull *V = (ull *)(smem + 2 * a_lds);                        // [2][NP][2][48]
     ull *Dl = V + 2 * (size_t)NP * 96;                          // [NP][24]
     int32_t *wl = (int32_t *)(Dl + (size_t)NP * 24);            // [2][24][8]
     // this wave's tiles
@@ -97,6 +114,7 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
         u32 p = n / 24, co = n % 24;
         vb[ni] = ((p * 2 + (co >= 12 ? 0u : 1u)) * 48 + (23 - co + 2 * (lane >> 4))) * 8;
     }
+    const u32 ab0 = (m_lo * 64 + lane) * 16;   // A operand: this lane in row tile m_lo of a K-step; tile mi adds mi KB
     v4i acc[MTW][I8_NTW];
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
@@ -106,28 +124,24 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
 
     const u32 T0 = blockIdx.x * a.tiles_per_wg;
     const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
-    constexpr int ACH = 5;                                      // 16-byte chunks of an A tile per thread: 3 * MT * 64 <= 5 * 512 for MT <= 13 .. see host check
     uint4 areg[ACH];
     int32_t wreg = 0;
+    const u32 Tlast = a.ntiles - 1;
     auto load_a = [&](u32 T) {
+        const unsigned char *src = a.Ab + (size_t)(T < Tlast ? T : Tlast) * a_tile + (size_t)tid * 16;
 #pragma unroll
-        for (int q = 0; q < ACH; q++) {
-            u32 idx = tid + 512 * q;
-            if (idx < 3 * MT * 64) areg[q] = *(const uint4 *)(a.Ab + (size_t)T * a_tile + (size_t)idx * 16);
-        }
+        for (int q = 0; q < ACH; q++) areg[q] = *(const uint4 *)(src + (size_t)q * 8192);
     };
     auto store_a = [&](u32 buf) {
 #pragma unroll
-        for (int q = 0; q < ACH; q++) {
-            u32 idx = tid + 512 * q;
-            if (idx < 3 * MT * 64) *(uint4 *)(Al + buf * a_tile + (size_t)idx * 16) = areg[q];
-        }
+        for (int q = 0; q < ACH; q++) *(uint4 *)(Al + buf * a_lds + (size_t)(tid + 512 * q) * 16) = areg[q];
     };
+    const u32 wc = (tid >> 3) < 24 ? (tid >> 3) : 23;
     auto load_w = [&](u32 T) {
-        if (tid < 192) {
-            size_t j = (size_t)T * 8 + (tid & 7);
-            wreg = (T < T1 && j < a.n) ? a.planes[(size_t)(tid >> 3) * a.ld + j] : 0;
-        }
+        size_t j = (size_t)T * 8 + (tid & 7);
+        const bool ok = T < T1 && j < a.n;
+        int32_t v = a.planes[(size_t)wc * a.ld + (ok ? j : 0)];
+        wreg = ok ? v : 0;
     };
     auto store_w = [&](u32 buf) { if (tid < 192) wl[buf * 192 + tid] = wreg; };
     auto gen_d = [&](u32 buf) {
@@ -174,22 +188,24 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
         load_w(T0 + 1);
         store_w(1);
         store_a(0);
-        __syncthreads();
+        lds_barrier();
         gen_d(0);
-        __syncthreads();
+        lds_barrier();
         gen_v(0);
-        __syncthreads();
+        lds_barrier();
         for (u32 T = T0; T < T1; T++) {
             const u32 cur = (T - T0) & 1, nxt = cur ^ 1;
             const bool more = T + 1 < T1;
-            if (more) { load_a(T + 1); load_w(T + 2); gen_d(nxt); }
-            __syncthreads();
-            if (more) gen_v(nxt);
+            if (!(a.dbg & 1)) load_a(T + 1);
+            load_w(T + 2);
+            if (more && !(a.dbg & 2)) gen_d(nxt);
+            lds_barrier();
+            if (more && !(a.dbg & 2)) gen_v(nxt);
             // ---- 3 K-steps of 64 inner elements
-            const unsigned char *Ac = Al + cur * a_tile;
+            const unsigned char *Ac = Al + cur * a_lds;
             const unsigned char *Vc = (const unsigned char *)(V + (size_t)cur * NP * 96);
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
+            for (int s = 0; s < ((a.dbg & 4) ? 0 : 3); s++) {
                 v4i b[I8_NTW];
 #pragma unroll
                 for (int ni = 0; ni < I8_NTW; ni++) {
@@ -199,16 +215,17 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
                 }
 #pragma unroll
                 for (int mi = 0; mi < MTW; mi++) {
-                    if (mi < (int)mcnt) {
-                        v4i av = *(const v4i *)(Ac + ((size_t)(s * MT + m_lo + mi) * 64 + lane) * 16);
+                    if (mi < (int)mcnt) {   // (wave-uniform; a branch-free block over clamped tiles costs 27 spilled registers and 3.7x the time)
+                        v4i av = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + mi * 1024);
 #pragma unroll
                         for (int ni = 0; ni < I8_NTW; ni++)
                             if (ni < (int)ncnt) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                     }
                 }
             }
-            if (more) { store_a(nxt); store_w(cur); }   // w[T+2] goes where w[T] was (read by gen_d one iteration ago)
-            __syncthreads();
+            if (!(a.dbg & 1)) store_a(nxt);
+            store_w(cur);   // w[T+2] goes where w[T] was (read by gen_d one iteration ago)
+            lds_barrier();
         }
     }
     // ---- partial results of the workgroup
@@ -221,20 +238,33 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
     if (tid < NP * 24) a.dsum[(size_t)blockIdx.x * NP * 24 + tid] = dacc;
 }
 
-// y[plane][i][c_out] (coefficient form, SoA [24][NP*kappa], element index plane*kappa + i) from the workgroup partials
-__global__ void __launch_bounds__(256) k_ajtai_i8_reduce(const int32_t *part, const int32_t *dsum, u32 nwg, u32 MT, u32 NT, u32 NP, u32 kappa, u32 row0,
-                                                         u32 kappa_total, u64 *coef_out) {
+// stage 1 of the reduction: element-wise sum of the workgroups' partial tiles (and of their digit sums) -- coalesced across threads
+__global__ void __launch_bounds__(256) k_ajtai_i8_sum(const int32_t *part, size_t per_wg, const int32_t *dsum, u32 per_wg_d, u32 nwg, long long *sum) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per_wg + per_wg_d) return;
+    const int32_t *src = e < per_wg ? part + e : dsum + (e - per_wg);
+    const size_t stride = e < per_wg ? per_wg : per_wg_d;
+    long long s = 0;
+    u32 w = 0;
+    for (; w + 8 <= nwg; w += 8) {
+        int32_t x[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = src[(size_t)(w + q) * stride];
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += x[q];
+    }
+    for (; w < nwg; w++) s += src[(size_t)w * stride];
+    sum[e] = s;
+}
+// stage 2: y[plane][i][c_out] (coefficient form, SoA [24][NP*kappa_total], element index plane*kappa_total + row0 + i)
+__global__ void __launch_bounds__(256) k_ajtai_i8_finish(const long long *sum, size_t per_wg, u32 MT, u32 NT, u32 NP, u32 kappa, u32 row0, u32 kappa_total,
+                                                         u64 *coef_out) {
     const u32 o = blockIdx.x * 256 + threadIdx.x;
     if (o >= NP * kappa * 24) return;
     const u32 co = o % 24, i = (o / 24) % kappa, p = o / (24 * kappa);
     const u32 n = p * 24 + co, nt = n >> 4, col = n & 15;
     // T = sum over inner elements of Rot(F)[.][c_out], F = sum over columns of the digit polynomials: the "-128" bias of the bytes of A
-    long long F[24];
-    for (int c = 0; c < 24; c++) {
-        long long s = 0;
-        for (u32 w = 0; w < nwg; w++) s += dsum[((size_t)w * NP + p) * 24 + c];
-        F[c] = s;
-    }
+    const long long *F = sum + per_wg + (size_t)p * 24;
     long long Tsum = 0;
     for (int ci = 0; ci < 24; ci++) {
         int d = (int)co - ci;
@@ -250,42 +280,45 @@ __global__ void __launch_bounds__(256) k_ajtai_i8_reduce(const int32_t *part, co
     __int128 tot = 0;
     for (u32 u = 0; u < 8; u++) {
         const u32 m = 8 * i + u, mt = m >> 4, r = m & 15, ln = col + 16 * (r >> 2), reg = r & 3;
-        long long s = 0;
-        for (u32 w = 0; w < nwg; w++) s += part[((((size_t)w * MT + mt) * NT + nt) * 64 + ln) * 4 + reg];
-        tot += (__int128)(s + 128 * Tsum) << (8 * u);
+        tot += (__int128)(sum[(((size_t)mt * NT + nt) * 64 + ln) * 4 + reg] + 128 * Tsum) << (8 * u);
     }
     coef_out[(size_t)co * ((size_t)NP * kappa_total) + (size_t)p * kappa_total + row0 + i] = fq_from_s128((u64)tot, (int64_t)(tot >> 64));
 }
 
-size_t ajtai_i8_lds_bytes(u32 MT, u32 NP) { return 2 * (size_t)3 * MT * 1024 + 2 * (size_t)NP * 96 * 8 + (size_t)NP * 24 * 8 + 2 * 192 * 4; }
+static size_t ajtai_i8_ach(u32 MT) { u32 mh = (MT + 1) / 2; return mh <= 2 ? 2 : (mh <= 4 ? 3 : 5); }
+size_t ajtai_i8_lds_bytes(u32 MT, u32 NP) { return 2 * ajtai_i8_ach(MT) * 8192 + 2 * (size_t)NP * 96 * 8 + (size_t)NP * 24 * 8 + 2 * 192 * 4; }
+size_t ajtai_i8_slack_bytes() { return 5 * 8192; }   // readable bytes required behind the packed matrix
 u32 ajtai_i8_row_tiles(u32 kappa) { return (8 * kappa + 15) / 16; }
 u32 ajtai_i8_col_tiles(u32 NP) { return (24 * NP + 15) / 16; }
 // partial buffer words (int32) for nwg workgroups
 size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT) { return (size_t)nwg * MT * NT * 256; }
 
 int launch_ajtai_i8(const unsigned char *Ab, u32 MT, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total, u32 k0, u32 NP, u32 nwg,
-                    int32_t *part, int32_t *dsum, u64 *coef_out, hipStream_t s) {
+                    int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s) {
     AjtaiI8Args a;
     a.Ab = Ab; a.planes = planes; a.ld = ld; a.n = n;
     a.MT = MT; a.NT = ajtai_i8_col_tiles(NP); a.k0 = k0; a.NP = NP;
     a.ntiles = (u32)((n + 7) / 8);
     a.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
     a.part = part; a.dsum = dsum;
+    a.dbg = getenv("LF_I8_DBG") ? (u32)atoi(getenv("LF_I8_DBG")) : 0;
     if (a.MT > 13 || 8 * kappa > 16 * MT || NP > 16 || NP == 0) return -1;   // 3 * MT * 64 sixteen-byte chunks of an A tile <= 5 per thread
     const u32 grid = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     const size_t lds = ajtai_i8_lds_bytes(a.MT, NP);
     const u32 mh = (a.MT + 1) / 2;
-#define LF_I8_LAUNCH(MTW)                                                                                                          \
+#define LF_I8_LAUNCH(MTW, ACH)                                                                                                     \
     do {                                                                                                                           \
         static bool attr_set = false;                                                                                              \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL(k_ajtai_i8<MTW>, dim3(grid), dim3(64 * I8_WAVES), lds, s, a);                                           \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<MTW, ACH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((k_ajtai_i8<MTW, ACH>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);                                    \
     } while (0)
-    if (mh <= 2) LF_I8_LAUNCH(2);
-    else if (mh <= 4) LF_I8_LAUNCH(4);
-    else LF_I8_LAUNCH(7);
+    if (mh <= 2) LF_I8_LAUNCH(2, 2);
+    else if (mh <= 4) LF_I8_LAUNCH(4, 3);
+    else LF_I8_LAUNCH(7, 5);
 #undef LF_I8_LAUNCH
-    hipLaunchKernelGGL(k_ajtai_i8_reduce, dim3(cdiv((size_t)NP * kappa * 24, 256)), dim3(256), 0, s, part, dsum, grid, a.MT, a.NT, NP, kappa, row0, kappa_total,
+    const size_t per_wg = (size_t)a.MT * a.NT * 256;
+    hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * 24, 256)), dim3(256), 0, s, part, per_wg, dsum, NP * 24, grid, sum);
+    hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * 24, 256)), dim3(256), 0, s, sum, per_wg, a.MT, a.NT, NP, kappa, row0, kappa_total,
                        coef_out);
     return (int)grid;
 }

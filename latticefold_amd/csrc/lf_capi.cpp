@@ -639,8 +639,8 @@ static int prep_ajtai_i8(lf_ctx *c) {
     const size_t ntiles = (c->nA + 7) / 8;
     const u32 MT = ajtai_i8_row_tiles(kc);
     const size_t chunk_bytes = ntiles * 3 * MT * 1024;
-    HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch));
-    HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch, c->stream()));
+    HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch + ajtai_i8_slack_bytes()));
+    HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch + ajtai_i8_slack_bytes(), c->stream()));
     u64 *coef;
     RET(c->tbuf("i8_prep_coef", 24 * c->nA, &coef));
     for (u32 i = 0; i < c->kappa; i++) {
@@ -662,6 +662,8 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
     u64 *coef, *ntt;
     RET(c->tbuf("i8_part", ajtai_i8_part_words(nwg, MT, ajtai_i8_col_tiles(16)), &part));
     RET(c->tbuf("i8_dsum", (size_t)nwg * 16 * 24, &dsum));
+    long long *sum;
+    RET(c->tbuf("i8_sum", (size_t)MT * ajtai_i8_col_tiles(16) * 256 + 16 * 24, &sum));
     RET(c->tbuf("i8_coef", (size_t)24 * NP * c->kappa, &coef));
     RET(c->tbuf("i8_ntt", (size_t)24 * NP * c->kappa, &ntt));
     for (u32 p0 = 0; p0 < NP; p0 += 16) {
@@ -670,7 +672,7 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
         for (u32 ch = 0; ch < nch; ch++) {
             const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
             size_t ev = c->ev_begin(1);
-            int g = launch_ajtai_i8(c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, cf, c->stream());
+            int g = launch_ajtai_i8(c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, cf, c->stream());
             c->ev_end(ev);
             if (g < 0) return LF_ERR_UNSUPPORTED;
         }
