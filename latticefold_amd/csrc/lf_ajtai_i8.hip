@@ -124,18 +124,29 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
 
     const u32 T0 = blockIdx.x * a.tiles_per_wg;
     const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
-    uint4 areg[ACH];
+    // staging registers as five scalars and macros, not an array captured by lambdas: the array ends up on the stack (80 bytes of scratch
+    // per thread, written and re-read every tile -- 3.5 GB of HBM writes per launch in the PMC pass -- and waited for straight after the load)
+    uint4 ar0 = {0, 0, 0, 0}, ar1 = ar0, ar2 = ar0, ar3 = ar0, ar4 = ar0;
     int32_t wreg = 0;
     const u32 Tlast = a.ntiles - 1;
-    auto load_a = [&](u32 T) {
-        const unsigned char *src = a.Ab + (size_t)(T < Tlast ? T : Tlast) * a_tile + (size_t)tid * 16;
-#pragma unroll
-        for (int q = 0; q < ACH; q++) areg[q] = *(const uint4 *)(src + (size_t)q * 8192);
-    };
-    auto store_a = [&](u32 buf) {
-#pragma unroll
-        for (int q = 0; q < ACH; q++) *(uint4 *)(Al + buf * a_lds + (size_t)(tid + 512 * q) * 16) = areg[q];
-    };
+#define LF_I8_LOAD_A(T_)                                                                                            \
+    do {                                                                                                            \
+        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + (size_t)tid * 16;       \
+        ar0 = *(const uint4 *)(src_);                                                                               \
+        ar1 = *(const uint4 *)(src_ + 8192);                                                                        \
+        if (ACH > 2) ar2 = *(const uint4 *)(src_ + 2 * 8192);                                                       \
+        if (ACH > 3) ar3 = *(const uint4 *)(src_ + 3 * 8192);                                                       \
+        if (ACH > 4) ar4 = *(const uint4 *)(src_ + 4 * 8192);                                                       \
+    } while (0)
+#define LF_I8_STORE_A(buf_)                                                                                         \
+    do {                                                                                                            \
+        unsigned char *dst_ = Al + (buf_) * a_lds + (size_t)tid * 16;                                               \
+        *(uint4 *)(dst_) = ar0;                                                                                     \
+        *(uint4 *)(dst_ + 8192) = ar1;                                                                              \
+        if (ACH > 2) *(uint4 *)(dst_ + 2 * 8192) = ar2;                                                             \
+        if (ACH > 3) *(uint4 *)(dst_ + 3 * 8192) = ar3;                                                             \
+        if (ACH > 4) *(uint4 *)(dst_ + 4 * 8192) = ar4;                                                             \
+    } while (0)
     const u32 wc = (tid >> 3) < 24 ? (tid >> 3) : 23;
     auto load_w = [&](u32 T) {
         size_t j = (size_t)T * 8 + (tid & 7);
@@ -182,12 +193,12 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
     };
     if (T0 < T1) {
         // ---- prologue: A[T0], w[T0], w[T0+1] -> LDS; D[T0]; V[0]
-        load_a(T0);
+        LF_I8_LOAD_A(T0);
         load_w(T0);
         store_w(0);
         load_w(T0 + 1);
         store_w(1);
-        store_a(0);
+        LF_I8_STORE_A(0);
         lds_barrier();
         gen_d(0);
         lds_barrier();
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
         for (u32 T = T0; T < T1; T++) {
             const u32 cur = (T - T0) & 1, nxt = cur ^ 1;
             const bool more = T + 1 < T1;
-            if (!(a.dbg & 1)) load_a(T + 1);
+            if (!(a.dbg & 1)) LF_I8_LOAD_A(T + 1);
             load_w(T + 2);
             if (more && !(a.dbg & 2)) gen_d(nxt);
             lds_barrier();
@@ -223,11 +234,13 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
                     }
                 }
             }
-            if (!(a.dbg & 1)) store_a(nxt);
+            if (!(a.dbg & 1)) LF_I8_STORE_A(nxt);
             store_w(cur);   // w[T+2] goes where w[T] was (read by gen_d one iteration ago)
             lds_barrier();
         }
     }
+#undef LF_I8_LOAD_A
+#undef LF_I8_STORE_A
     // ---- partial results of the workgroup
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
