@@ -656,7 +656,10 @@ static int prep_ajtai_i8(lf_ctx *c) {
 static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev) {
     const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(kc);
     const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * 3 * MT * 1024;
-    u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 256;
+    // One persistent workgroup per CU fills its LDS (157 KB): on a fully occupied chip the latency-bound round kernels of the other lane
+    // cannot be placed until a commit workgroup retires.  7/8 of the CUs (28 of 32 per XCD) leaves them room: C4 26.1 -> 25.0 ms/step
+    // (measured 256 / 240 / 224 / 192 / 160 / 128 workgroups: 26.1 / 26.3 / 25.0 / 25.1 / 26.1 / 28.2 ms).
+    u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 224;
     if (nwg > ntiles) nwg = (u32)ntiles;
     int32_t *part, *dsum;
     u64 *coef, *ntt;
@@ -2084,7 +2087,8 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     std::shared_future<int> lin_done = lin_done_p.get_future().share();
     // Large instances: lane 1 (two commits back to back) is the critical path and lane 0 has several ms of slack, so the
     // linearization rounds run on 16 workgroups per slot and leave the CUs to the commit kernels (C4: 44.6 -> 43.7 ms/step).
-    c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : (c->N >= ((size_t)1 << 19) ? 16u : 0u);
+    // (with the digit-plane commits on the matrix cores lane 1 is no longer the critical path: no bound then -- C4 27.2 -> 26.1 ms/step)
+    c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : ((c->N >= ((size_t)1 << 19) && !(c->i8_nch && !c->tn.ajtai_valu)) ? 16u : 0u);
     int rc;
     std::vector<Fq3> rR;
     if (c->sh_world > 1 && !c->tn.shard_two_lanes) {
