@@ -7,7 +7,10 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <thread>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -72,6 +75,53 @@ static const char *PHASE_NAMES[LF_N_PHASES] = {"linearization", "decomp_crt_comm
 
 struct EvPair { hipEvent_t a, b; };
 
+// The helper lane of a fold step: ONE thread per context, created at the first step and parked on a condition variable between steps
+// (a std::async thread per step cost a thread creation + join every 7-30 ms).
+struct LaneWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, stop = false;
+    int rc = 0;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || stop; });
+            if (stop) return;
+            std::function<int()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            int r = j();
+            lk.lock();
+            rc = r;
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> j) {
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        job = std::move(j);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+    ~LaneWorker() {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct lf_ctx {
     lfbb::BbCtx *bb = nullptr;   // BabyBearRingNTT backend (ring 1): every entry point forwards to it
     int device = 0;
@@ -92,6 +142,7 @@ struct lf_ctx {
     DevCrt dcrt;
     u64 *d_icrt = nullptr;
     // Ajtai (nA = columns held by this rank, starting at global column A_col0 of nA_total)
+    LaneWorker lane1;
     u64 *dA = nullptr;
     unsigned char *dAb = nullptr;   // the same matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 26
     u32 i8_nch = 0, i8_kc = 0;
@@ -145,6 +196,30 @@ struct lf_ctx {
         int rc = buf(name, count * sizeof(T), &p);
         *out = (T *)p;
         return rc;
+    }
+    // Small host-to-device uploads inside a step (challenge powers, look-up tables, evaluation points) go through a pinned ring per lane:
+    // the copy is truly asynchronous and the caller's stack / vector buffer is free at once -- no stream synchronisation per upload.
+    unsigned char *stage[2] = {nullptr, nullptr};
+    size_t stage_off[2] = {0, 0};
+    static constexpr size_t STAGE_BYTES = (size_t)1 << 20;
+    int h2d_small(void *dst, const void *src, size_t bytes) {
+        unsigned char *&ring = stage[t_lane];
+        if (!ring && hipHostMalloc((void **)&ring, STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { ring = nullptr; return LF_ERR_HIP; }
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (need > STAGE_BYTES) {   // not small: plain blocking copy
+            HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()));
+            HIPCHK(hipStreamSynchronize(stream()));
+            return LF_OK;
+        }
+        if (stage_off[t_lane] + need > STAGE_BYTES) {   // wrap: everything staged so far must have left the ring
+            HIPCHK(hipStreamSynchronize(stream()));
+            stage_off[t_lane] = 0;
+        }
+        unsigned char *slot = ring + stage_off[t_lane];
+        stage_off[t_lane] += need;
+        memcpy(slot, src, bytes);
+        HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream()));
+        return LF_OK;
     }
     u64 *h_round[2] = {nullptr, nullptr};   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
     u64 *round_out() {
@@ -332,6 +407,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
     if (c->dAb) (void)hipFree(c->dAb);
+    for (int l = 0; l < 2; l++) if (c->stage[l]) (void)hipHostFree(c->stage[l]);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
     for (int l = 0; l < 2; l++)
         if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
@@ -835,8 +911,7 @@ static int build_eq_dev(lf_ctx *c, const Fq3 *pt, u32 nv, u64 *eq_dev) {
     RET(c->tbuf("eq_point", 64, &rd));
     std::vector<Fq3Const> h(nv);
     for (u32 i = 0; i < nv; i++) h[i] = f3c(pt[i]);
-    HIPCHK(hipMemcpyAsync(rd, h.data(), nv * sizeof(Fq3Const), hipMemcpyHostToDevice, c->stream()));
-    HIPCHK(hipStreamSynchronize(c->stream()));  // h is a stack-lifetime buffer
+    RET(c->h2d_small(rd, h.data(), nv * sizeof(Fq3Const)));
     if (nv >= 6) {   // two-level: one product per entry
         u64 *scr;
         RET(c->tbuf("eq_scratch", build_eq_scratch_words(nv), &scr));
@@ -1545,9 +1620,7 @@ static double absorb_decomposition(const lf_params &P, Transcript &tr, const u64
 
 static int upload_consts(lf_ctx *c, const std::string &name, const std::vector<Fq3Const> &v, Fq3Const **out) {
     RET(c->tbuf(name, v.size() + 8, out));
-    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(Fq3Const), hipMemcpyHostToDevice, c->stream()));
-    HIPCHK(hipStreamSynchronize(c->stream()));
-    return LF_OK;
+    return c->h2d_small(*out, v.data(), v.size() * sizeof(Fq3Const));
 }
 
 // Host side of the mailbox protocol of a persistent tail kernel (k_fold_tail / k_lin_tail): per round poll the message, run the transcript
@@ -1818,8 +1891,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                         lut[3 * (81 + code)] = sq.c[0]; lut[3 * (81 + code) + 1] = sq.c[1]; lut[3 * (81 + code) + 2] = sq.c[2];
                     }
                     RET(c->tbuf("fold_lut", 2 * 81 * 3 + 8, &d_lut));
-                    HIPCHK(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream()));
-                    HIPCHK(hipStreamSynchronize(c->stream()));   // lut is a stack-lifetime buffer
+                    RET(c->h2d_small(d_lut, lut.data(), lut.size() * 8));
                     fmode = 3;
                     curF = nullptr; ldF = q;
                 } else {
@@ -1866,8 +1938,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             u64 *d_poly, *d_tp;
             RET(c->tbuf("fold_poly", 81 * 12 + 8, &d_poly));
             RET(c->tbuf("fold_tp", (size_t)K2 * 3 * 81 * 12, &d_tp));
-            HIPCHK(hipMemcpyAsync(d_poly, poly.data(), poly.size() * 8, hipMemcpyHostToDevice, c->stream()));
-            HIPCHK(hipStreamSynchronize(c->stream()));   // poly is a stack-lifetime buffer
+            RET(c->h2d_small(d_poly, poly.data(), poly.size() * 8));
             launch_fold_round_tab(c->dcrt, (int)round, a, S[0].planes, S[1].planes, N, K, d_mu, d_poly, d_tp, partial, od, c->stream());
         } else if (round == 1) launch_fold_round1(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dcrt, a, S[0].planes, S[1].planes, N, K, d_mu, f3c(pt[0]), partial, od, c->stream());
@@ -2121,7 +2192,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         c->lin_blocks = 0;
         if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
     } else {
-    std::future<int> flane1 = std::async(std::launch::async, [&]() -> int {
+    c->lane1.submit([&]() -> int {
         t_lane = 1;
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
         u64 *yd = nullptr;
@@ -2150,7 +2221,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
     }
     TL_MARK("right evals done");
-    int rc1 = flane1.get();
+    int rc1 = c->lane1.wait();
     c->lin_blocks = 0;
     TL_MARK("lane 1 joined");
     if (rc == LF_OK) rc = rc1;
