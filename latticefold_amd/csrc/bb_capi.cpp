@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "bb_kernels.h"
+#include "lf_ajtai_i8.h"
 #include "lf_common.h"
 #include "lf_dist.h"
 #include "lf_verify.h"
@@ -35,6 +36,8 @@ struct BbCtxImpl {
     DevBb dev;
     fe *d_icrt = nullptr;
     fe *dA = nullptr;
+    unsigned char *dAb = nullptr;   // the same matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 16
+    u32 i8_nch = 0, i8_kc = 0;
     u32 kappa = 0;
     size_t nA = 0, nA_total = 0, A_col0 = 0;   // columns held by this rank / of the whole matrix / first held column
     // intra-step sharding, same scheme as the Goldilocks backend
@@ -214,6 +217,7 @@ void BbCtx::destroy() {
     c->comm.destroy();
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
+    if (c->dAb) (void)hipFree(c->dAb);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_round) (void)hipHostFree(c->h_round);
@@ -445,6 +449,70 @@ int BbCtx::linf_check(const uint64_t *f_ntt, size_t count, uint64_t bound, int u
 }
 
 // ---- a5 ----------------------------------------------------------------------------------------------------------------
+// The int8 matrix-core commit kernel (lf_ajtai_i8.hip, shared with the Goldilocks backend) wants A in coefficient form, cut into its 4
+// bytes, in MFMA operand order: built once per matrix.
+static int prep_ajtai_i8(C *c) {
+    if (c->dAb) { (void)hipFree(c->dAb); c->dAb = nullptr; }
+    c->i8_nch = 0;
+    if (getenv("LF_AJTAI_VALU")) return LF_OK;
+    const lf::AjtaiI8Ring R = lf::ajtai_i8_babybear();
+    const u32 maxr = lf::ajtai_i8_max_rows(R), nch = (c->kappa + maxr - 1) / maxr, kc = (c->kappa + nch - 1) / nch;
+    const size_t ntiles = (c->nA + 7) / 8;
+    const u32 MT = lf::ajtai_i8_row_tiles(R, kc);
+    const size_t chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
+    HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch + lf::ajtai_i8_slack_bytes()));
+    HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch + lf::ajtai_i8_slack_bytes(), c->stream()));
+    fe *coef;
+    u64 *canon;
+    RET(c->tbuf("i8_prep_coef", (size_t)RE * c->nA, &coef));
+    RET(c->tbuf("i8_prep_canon", (size_t)RE * c->nA, &canon));
+    for (u32 i = 0; i < c->kappa; i++) {
+        launch_icrt_dense(c->d_icrt, c->dA + (size_t)i * RE * c->nA, coef, c->nA, c->stream());
+        launch_soa_to_aos(coef, canon, c->nA, c->stream());   // canonical u64, element-major
+        lf::launch_ajtai_pack_i8(canon, 1, RE, c->nA, i % kc, MT, R.RD, R.NL, c->dAb + (size_t)(i / kc) * chunk_bytes, c->stream());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    c->i8_nch = nch;
+    c->i8_kc = kc;
+    return LF_OK;
+}
+// digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev canonical u64 [NP][kappa][72], NTT form (PARTIAL when sharded)
+static int commit_planes_i8(C *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev) {
+    const lf::AjtaiI8Ring R = lf::ajtai_i8_babybear();
+    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = lf::ajtai_i8_row_tiles(R, kc), maxp = lf::ajtai_i8_max_planes(R);
+    const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
+    u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 224;   // 7/8 of the CUs: see the Goldilocks backend
+    if (nwg > ntiles) nwg = (u32)ntiles;
+    int32_t *part, *dsum;
+    long long *sum;
+    u64 *coef;
+    fe *cf, *ntt;
+    const u32 NTmax = lf::ajtai_i8_col_tiles(R, maxp);
+    RET(c->tbuf("i8_part", lf::ajtai_i8_part_words(nwg, MT, NTmax), &part));
+    RET(c->tbuf("i8_dsum", (size_t)nwg * maxp * R.RD, &dsum));
+    RET(c->tbuf("i8_sum", lf::ajtai_i8_sum_words(R, MT, NTmax, maxp), &sum));
+    RET(c->tbuf("i8_coef", (size_t)RE * NP * c->kappa, &coef));
+    RET(c->tbuf("i8_cf", (size_t)RE * NP * c->kappa, &cf));
+    RET(c->tbuf("i8_ntt", (size_t)RE * NP * c->kappa, &ntt));
+    for (u32 p0 = 0; p0 < NP; p0 += maxp) {
+        const u32 np = NP - p0 < maxp ? NP - p0 : maxp;
+        u64 *co = coef + (size_t)RE * p0 * c->kappa;   // element-major block of this plane group: [np*kappa][72] canonical
+        for (u32 ch = 0; ch < nch; ch++) {
+            const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
+            size_t ev = c->ev_begin(1);
+            int g = lf::launch_ajtai_i8(R, c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, co,
+                                        c->stream());
+            c->ev_end(ev);
+            if (g < 0) return LF_ERR_UNSUPPORTED;
+        }
+        const size_t ne = (size_t)np * c->kappa;
+        launch_aos_to_soa(co, cf, ne, c->stream());            // canonical -> Montgomery planes
+        launch_crt_fwd(c->dev, cf, ntt, ne, c->stream());
+        launch_soa_to_aos(ntt, out_dev + (size_t)p0 * c->kappa * RE, ne, c->stream());
+    }
+    return LF_OK;
+}
+
 int BbCtx::ajtai_load(const uint64_t *A, size_t kappa, size_t n) {
     C *c = p;
     if (kappa > 32) return LF_ERR_INVALID;
@@ -458,7 +526,7 @@ int BbCtx::ajtai_load(const uint64_t *A, size_t kappa, size_t n) {
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
-    return LF_OK;
+    return prep_ajtai_i8(c);
 }
 int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
     C *c = p;
@@ -473,7 +541,7 @@ int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
     c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
-    return LF_OK;
+    return prep_ajtai_i8(c);
 }
 static u32 ajtai_splits(size_t n) {
     size_t s = n / 256;
@@ -971,14 +1039,19 @@ static int dec_enqueue_commit(C *c, const lf_witness *wit, DecPending &pd) {
     u32 K = P.K;
     fe *Fh;
     u64 *yd;
-    RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * c->nA, &Fh));
     RET(c->tbuf("dec_y", (size_t)K * P.kappa * RE, &yd));
     pd.h_y = c->arena_alloc((size_t)(K - 1) * P.kappa * RE);
     if (!pd.h_y) return LF_ERR_HIP;
     // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
     pd.ph_commit = c->ev_begin(11);
-    launch_bitplane_crt(c->dev, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());   // this rank's column slice only
-    RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
+    if (c->i8_nch && !c->tn.ajtai_valu && P.b == 2) {
+        // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
+        RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd));
+    } else {
+        RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * c->nA, &Fh));
+        launch_bitplane_crt(c->dev, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());   // this rank's column slice only
+        RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
+    }
     HIPCHK(hipMemcpyAsync(pd.h_y, yd, (size_t)(K - 1) * P.kappa * RE * 8, hipMemcpyDeviceToHost, c->stream()));
     c->ev_end(pd.ph_commit);
     HIPCHK(hipEventRecord(c->ev_dec[2 * pd.side], c->stream()));

@@ -1,0 +1,28 @@
+// lf_ajtai_i8.h -- digit-plane Ajtai commitments on the int8 matrix cores (lf_ajtai_i8.hip), shared by the two ring backends.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+namespace lf {
+struct AjtaiI8Ring {
+    uint32_t RD, NL;      // ring degree (24 / 72), bytes per canonical coefficient (8 / 4)
+    uint64_t p_small;     // modulus when it is below 2^32, 0 = Goldilocks
+    int soa_out;          // coefficient-form results as SoA [RD][elements] (1) or AoS [elements][RD] (0); canonical u64 either way
+};
+inline AjtaiI8Ring ajtai_i8_goldilocks() { return AjtaiI8Ring{24, 8, 0, 1}; }
+inline AjtaiI8Ring ajtai_i8_babybear() { return AjtaiI8Ring{72, 4, 2013265921ull, 0}; }
+// A repacked once per matrix: row i of a row chunk (canonical coefficients, element (c, j) at coef[c*cs + j*js]) -> bytes in MFMA operand
+// order, MT = ajtai_i8_row_tiles(rows of the chunk)
+void launch_ajtai_pack_i8(const uint64_t *coef, size_t cs, size_t js, size_t n, uint32_t i, uint32_t MT, uint32_t RD, uint32_t NL, unsigned char *Ab, hipStream_t s);
+uint32_t ajtai_i8_row_tiles(const AjtaiI8Ring &R, uint32_t kappa);
+uint32_t ajtai_i8_col_tiles(const AjtaiI8Ring &R, uint32_t NP);
+uint32_t ajtai_i8_max_rows(const AjtaiI8Ring &R);
+uint32_t ajtai_i8_max_planes(const AjtaiI8Ring &R);
+size_t ajtai_i8_slack_bytes();   // readable bytes required behind the packed matrix (the tile copy of the kernel is unconditional)
+size_t ajtai_i8_part_words(uint32_t nwg, uint32_t MT, uint32_t NT);
+size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, uint32_t MT, uint32_t NT, uint32_t NP);
+// commitments of the digit planes k0 .. k0+NP-1 of `planes` ([RD][ld] int32) under rows [row0, row0+kappa) of A (one packed row chunk with MT
+// row tiles): coefficient-form results into coef_out (element plane*kappa_total + row).  Returns the grid size or -1.
+int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const int32_t *planes, size_t ld, size_t n, uint32_t kappa, uint32_t row0,
+                    uint32_t kappa_total, uint32_t k0, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s);
+}  // namespace lf

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include "lf_field.cuh"
 #include "lf_kernels.h"
+#include "lf_ajtai_i8.h"
 
 namespace lf {
 static inline size_t cdiv(size_t a, size_t b) { return (a + b - 1) / b; }
@@ -28,7 +29,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned long long ull;
 
 constexpr int I8_WAVES = 8;          // 2 row groups x 4 column groups
-constexpr int I8_NTW = 6;            // column tiles per wave (4 groups x 6 = 24 >= ceil(24 * 16 / 16))
 constexpr ull M7 = 0x7f7f7f7f7f7f7f7full, M8 = 0x8080808080808080ull;
 __device__ __forceinline__ ull swar_add(ull a, ull b) { return ((a & M7) + (b & M7)) ^ ((a ^ b) & M8); }
 __device__ __forceinline__ ull swar_sub(ull a, ull b) { return ((a | M8) - (b & M7)) ^ ((a ^ ~b) & M8); }
@@ -41,19 +41,28 @@ __device__ __forceinline__ int digit2_i8(int32_t v, u32 k) {
     return v < 0 ? -d : d;
 }
 
-// one launch per row of A: coefficient table [24][n] of row i -> bytes in operand order
-// Ab[((T*3 + s)*MT + mt)*1024 + lane*16 + t],  row m = 8 i + u = 16 mt + (lane & 15),  c_in = 8 s + 2 (lane >> 4) + (t >> 3),  column 8 T + (t & 7)
-__global__ void __launch_bounds__(256) k_ajtai_pack_i8(const u64 *coef, size_t n, u32 i, u32 MT, size_t ntiles, unsigned char *Ab) {
+// ---- ring geometry -----------------------------------------------------------------------------------------------------------------
+// RD = ring degree (24: Z_p[X]/(X^24 - X^12 + 1), 64-bit p;  72: Z_p[X]/(X^72 - X^36 + 1), 31-bit p), NL = bytes per coefficient (8 / 4).
+// Both rings have the form X^RD = X^(RD/2) - 1, so X^c_in * f is Toeplitz in d = c_out - c_in up to the same two wrap rules:
+//     H[d] = f[d] + f[d + RD/2]                (outputs c_out >= RD/2)
+//     L[d] = f[d] - f[d + RD] - f[d + 3RD/2]   (outputs c_out <  RD/2)        (terms outside 0..RD-1 dropped)
+// A tile = 8 columns = 8 RD inner elements = RD/8 K-steps of 64 (a K-step covers 8 consecutive c_in of the 8 columns).
+
+// one launch per row of A: coefficients of row i (element (c, j) at coef[c * cs + j * js], canonical) -> bytes in operand order
+// Ab[((T*KS + s)*MT + mt)*1024 + lane*16 + t],  row m = NL i + u = 16 mt + (lane & 15),  c_in = 8 s + 2 (lane >> 4) + (t >> 3),  column 8 T + (t & 7)
+__global__ void __launch_bounds__(256) k_ajtai_pack_i8(const u64 *coef, size_t cs, size_t js, size_t n, u32 i, u32 MT, u32 KS, u32 NL, size_t ntiles,
+                                                       unsigned char *Ab) {
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= ntiles * 96) return;
-    const u32 u = gid & 7, g = (gid >> 3) & 3, s = (u32)((gid >> 5) % 3);
-    const size_t T = gid / 96;
-    const u32 m = 8 * i + u, mt = m >> 4, lane = g * 16 + (m & 15), c0 = 8 * s + 2 * g;
+    const u32 per_tile = KS * 4 * NL;
+    if (gid >= ntiles * per_tile) return;
+    const u32 r = (u32)(gid % per_tile), u = r % NL, g = (r / NL) & 3, s = r / (4 * NL);
+    const size_t T = gid / per_tile;
+    const u32 m = NL * i + u, mt = m >> 4, lane = g * 16 + (m & 15), c0 = 8 * s + 2 * g;
     unsigned char b[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         size_t j = T * 8 + (t & 7);
-        u64 v = j < n ? coef[(size_t)(c0 + (t >> 3)) * n + j] : 0;
+        u64 v = j < n ? coef[(size_t)(c0 + (t >> 3)) * cs + j * js] : 0;
         b[t] = (unsigned char)(((v >> (8 * u)) & 0xFF) ^ 0x80);
     }
     uint4 w;
@@ -61,73 +70,74 @@ __global__ void __launch_bounds__(256) k_ajtai_pack_i8(const u64 *coef, size_t n
     w.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((u32)b[7] << 24);
     w.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((u32)b[11] << 24);
     w.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((u32)b[15] << 24);
-    *(uint4 *)(Ab + ((T * 3 + s) * MT + mt) * 1024 + lane * 16) = w;
+    *(uint4 *)(Ab + ((T * KS + s) * MT + mt) * 1024 + lane * 16) = w;
 }
-void launch_ajtai_pack_i8(const u64 *coef, size_t n, u32 i, u32 MT, unsigned char *Ab, hipStream_t s) {
+void launch_ajtai_pack_i8(const u64 *coef, size_t cs, size_t js, size_t n, u32 i, u32 MT, u32 RD, u32 NL, unsigned char *Ab, hipStream_t s) {
     size_t ntiles = (n + 7) / 8;
-    hipLaunchKernelGGL(k_ajtai_pack_i8, dim3((unsigned)cdiv(ntiles * 96, 256)), dim3(256), 0, s, coef, n, i, MT, ntiles, Ab);
+    const u32 KS = RD / 8;
+    hipLaunchKernelGGL(k_ajtai_pack_i8, dim3((unsigned)cdiv(ntiles * KS * 4 * NL, 256)), dim3(256), 0, s, coef, cs, js, n, i, MT, KS, NL, ntiles, Ab);
 }
 
 struct AjtaiI8Args {
     const unsigned char *Ab;
-    const int32_t *planes;   // [24][ld], already offset to this rank's first column
+    const int32_t *planes;   // [RD][ld], already offset to this rank's first column
     size_t ld, n;
     u32 MT, NT, k0, NP;
     u32 ntiles, tiles_per_wg;
     int32_t *part;           // [wg][MT][NT][64][4]
-    int32_t *dsum;           // [wg][NP][24]
-    u32 dbg;
+    int32_t *dsum;           // [wg][NP][RD]
 };
 
-// dynamic LDS: A tiles 2 x a_lds | V 2 x NP x 96 x 8 | D NP x 24 x 8 | w 2 x 24 x 8 x 4
+// dynamic LDS: A tiles 2 x a_lds | V 2 x NP x 2 x 2RD x 8 | D NP x RD x 8 | w 2 x RD x 8 x 4
 //
-// Per tile of 8 columns: stage A[T+1] (registers) and w[T+2], digits D[T+1], barrier, Toeplitz vectors V[T+1], 3 K-steps of MFMAs on
-// A[T] / V[T], A[T+1] -> LDS, barrier.  Notes from the tuning (profiles/r02b_i8_notes.txt):
+// Per tile of 8 columns: stage A[T+1] (registers) and w[T+2], digits D[T+1], barrier, Toeplitz vectors V[T+1], RD/8 K-steps of MFMAs on
+// A[T] / V[T], A[T+1] -> LDS, barrier.  Notes from the tuning (profiles/r02b_i8_notes.txt), Goldilocks shape (RG 2 x CG 4 waves, 7 x 6 tiles):
 //  * the 168 accumulators + 32 operand registers + 20 staging registers of a wave fill the 256-register budget of 2 waves / SIMD; every
-//    deeper pipeline tried (one barrier per tile, G / M order alternating between the two waves of a SIMD, AGPR-targeted asm loads)
-//    spilled 50 - 480 registers, and control flow around the MFMA block makes the compiler copy the tied accumulators;
+//    deeper pipeline tried (one barrier per tile, G / M order alternating between the two waves of a SIMD, AGPR-targeted asm loads, a
+//    branch-free MFMA block over clamped tiles) spilled 27 - 480 registers: control flow around the MFMA block makes the compiler copy
+//    the tied accumulators;
 //  * LDS-DMA (global_load_lds) sustained 2.8 B/clk/CU on this stream against 5.4 TB/s for dwordx4 loads, so A is staged through registers;
-//    the compiler parks the staged tile in AGPRs straight after loading it, i.e. waits for the load at the top of every iteration (an L2
-//    prefetch by touch loads was tried: a VGPR-less touch needs LDS-DMA, and an asm load into a dead register hangs the kernel);
 //  * loads carry no control flow (a guarded load is waited for at its join): the copy of a tile is unconditional and padded, tiles /
 //    columns out of range are clamped to valid addresses and masked after the load;
-template <int MTW, int ACH>
+//  * the staging registers are scalars and macros, not an array captured by lambdas (that array lived in scratch: 3.5 GB of writes / launch).
+// Template: ring degree RD, row groups RG (x 8/RG column groups = 8 waves), MTW x NTW tiles per wave, ACH 16-byte chunks of an A tile per thread.
+template <int RD, int RG, int MTW, int NTW, int ACH>
 __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
+    constexpr int KS = RD / 8, VS = 2 * RD, HALF = RD / 2, CG = I8_WAVES / RG;
+    constexpr int WR = (RD * 8 + 511) / 512;                    // staged witness words per thread and tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave >> 2, ng = wave & 3;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave / CG, ng = wave % CG;
     const u32 MT = a.MT, NT = a.NT, NP = a.NP;
-    const size_t a_tile = (size_t)3 * MT * 1024;               // bytes of a tile in HBM
+    const size_t a_tile = (size_t)KS * MT * 1024;              // bytes of a tile in HBM
     constexpr size_t a_lds = (size_t)ACH * 512 * 16;           // ... and its padded stride in LDS
     unsigned char *Al = smem;                                   // [2][a_lds]
-    ull *V = (ull *)(smem + 2 * a_lds);                        // [2][NP][2][48]
-    ull *Dl = V + 2 * (size_t)NP * 96;                          // [NP][24]
-    int32_t *wl = (int32_t *)(Dl + (size_t)NP * 24);            // [2][24][8]
+    ull *V = (ull *)(smem + 2 * a_lds);                         // [2][NP][2][VS]
+    ull *Dl = V + 2 * (size_t)NP * 2 * VS;                      // [NP][RD]
+    int32_t *wl = (int32_t *)(Dl + (size_t)NP * RD);            // [2][RD][8]
     // this wave's tiles
-    const u32 mh = (MT + 1) / 2, m_lo = mg ? mh : 0, mcnt = mg ? MT - mh : mh;
-    const u32 n_lo = ng * I8_NTW, ncnt = n_lo >= NT ? 0 : (NT - n_lo < I8_NTW ? NT - n_lo : I8_NTW);
-    // B operand base offsets (bytes into one V buffer) at K-step 0: entry e0 = 23 - c_out + 2 g of (plane, c_out >= 12)
-    u32 vb[I8_NTW];
+    const u32 mh = (MT + RG - 1) / RG, m_lo = mg * mh, mcnt = m_lo >= MT ? 0 : (MT - m_lo < mh ? MT - m_lo : mh);
+    const u32 n_lo = ng * NTW, ncnt = n_lo >= NT ? 0 : (NT - n_lo < NTW ? NT - n_lo : NTW);
+    // B operand base offsets (bytes into one V buffer) at K-step 0: entry e0 = RD-1 - c_out + 2 g of (plane, H / L); columns past the end clamp
+    u32 vb[NTW];
 #pragma unroll
-    for (int ni = 0; ni < I8_NTW; ni++) {
+    for (int ni = 0; ni < NTW; ni++) {
         u32 n = (n_lo + ni) * 16 + (lane & 15);
-        if (n >= 24 * NP) n = 24 * NP - 1;
-        u32 p = n / 24, co = n % 24;
-        vb[ni] = ((p * 2 + (co >= 12 ? 0u : 1u)) * 48 + (23 - co + 2 * (lane >> 4))) * 8;
+        if (n >= RD * NP) n = RD * NP - 1;
+        u32 p = n / RD, co = n % RD;
+        vb[ni] = ((p * 2 + (co >= HALF ? 0u : 1u)) * VS + (RD - 1 - co + 2 * (lane >> 4))) * 8;
     }
     const u32 ab0 = (m_lo * 64 + lane) * 16;   // A operand: this lane in row tile m_lo of a K-step; tile mi adds mi KB
-    v4i acc[MTW][I8_NTW];
+    v4i acc[MTW][NTW];
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
 #pragma unroll
-        for (int ni = 0; ni < I8_NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
-    int dacc = 0;                                               // sum of the digits of (plane, c) = tid over this workgroup's columns
+        for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
+    int dacc0 = 0, dacc1 = 0;                                   // digit sums of (plane, c) = tid and tid + 512 over this workgroup's columns
 
     const u32 T0 = blockIdx.x * a.tiles_per_wg;
     const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
-    // staging registers as five scalars and macros, not an array captured by lambdas: the array ends up on the stack (80 bytes of scratch
-    // per thread, written and re-read every tile -- 3.5 GB of HBM writes per launch in the PMC pass -- and waited for straight after the load)
     uint4 ar0 = {0, 0, 0, 0}, ar1 = ar0, ar2 = ar0, ar3 = ar0, ar4 = ar0;
-    int32_t wreg = 0;
+    int32_t wreg0 = 0, wreg1 = 0;
     const u32 Tlast = a.ntiles - 1;
 #define LF_I8_LOAD_A(T_)                                                                                            \
     do {                                                                                                            \
@@ -147,48 +157,62 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
         if (ACH > 3) *(uint4 *)(dst_ + 3 * 8192) = ar3;                                                             \
         if (ACH > 4) *(uint4 *)(dst_ + 4 * 8192) = ar4;                                                             \
     } while (0)
-    const u32 wc = (tid >> 3) < 24 ? (tid >> 3) : 23;
+    // staged witness words: word idx = tid (+ 512) of the tile's [RD][8] block
+    const u32 wc0 = (tid >> 3) < (u32)RD ? (tid >> 3) : RD - 1, wc1 = ((tid + 512) >> 3) < (u32)RD ? ((tid + 512) >> 3) : RD - 1;
     auto load_w = [&](u32 T) {
         size_t j = (size_t)T * 8 + (tid & 7);
         const bool ok = T < T1 && j < a.n;
-        int32_t v = a.planes[(size_t)wc * a.ld + (ok ? j : 0)];
-        wreg = ok ? v : 0;
+        int32_t v0 = a.planes[(size_t)wc0 * a.ld + (ok ? j : 0)];
+        wreg0 = ok ? v0 : 0;
+        if (WR > 1) {
+            int32_t v1 = a.planes[(size_t)wc1 * a.ld + (ok ? j : 0)];
+            wreg1 = ok ? v1 : 0;
+        }
     };
-    auto store_w = [&](u32 buf) { if (tid < 192) wl[buf * 192 + tid] = wreg; };
+    auto store_w = [&](u32 buf) {
+        if (tid < (u32)RD * 8) wl[buf * RD * 8 + tid] = wreg0;
+        if (WR > 1 && tid + 512 < (u32)RD * 8) wl[buf * RD * 8 + tid + 512] = wreg1;
+    };
     auto gen_d = [&](u32 buf) {
-        if (tid < NP * 24) {
-            const u32 p = tid / 24, c = tid % 24;
-            const int4 w0 = *(const int4 *)(wl + buf * 192 + c * 8), w1 = *(const int4 *)(wl + buf * 192 + c * 8 + 4);
-            const int32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            ull d = 0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                int dg = digit2_i8(w[q], a.k0 + p);
-                dacc += dg;
-                d |= (ull)(unsigned char)dg << (8 * q);
+        for (int r = 0; r < 2; r++) {
+            const u32 idx = tid + 512 * r;
+            if (idx < NP * RD) {
+                const u32 p = idx / RD, c = idx % RD;
+                const int4 w0 = *(const int4 *)(wl + buf * RD * 8 + c * 8), w1 = *(const int4 *)(wl + buf * RD * 8 + c * 8 + 4);
+                const int32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                ull d = 0;
+                int sacc = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    int dg = digit2_i8(w[q], a.k0 + p);
+                    sacc += dg;
+                    d |= (ull)(unsigned char)dg << (8 * q);
+                }
+                Dl[idx] = d;
+                if (r == 0) dacc0 += sacc; else dacc1 += sacc;
             }
-            Dl[tid] = d;
         }
     };
     auto gen_v = [&](u32 buf) {
-        for (u32 idx = tid; idx < NP * 96; idx += 512) {
-            const u32 p = idx / 96, r = idx % 96, hl = r / 48, e = r % 48;
-            const int dl = 23 - (int)e;
-            const ull *D = Dl + p * 24;
+        for (u32 idx = tid; idx < NP * 2 * VS; idx += 512) {
+            const u32 p = idx / (2 * VS), r = idx % (2 * VS), hl = r / VS, e = r % VS;
+            const int dl = RD - 1 - (int)e;
+            const ull *D = Dl + p * RD;
             ull v = 0;
-            if (hl == 0) {          // H: outputs c_out >= 12
-                if (dl >= -11 && dl <= 23) {
+            if (hl == 0) {          // H: outputs c_out >= RD/2
+                if (dl >= -(HALF - 1) && dl <= RD - 1) {
                     v = dl >= 0 ? D[dl] : 0;
-                    if (dl <= 11) v = swar_add(v, D[dl + 12]);
+                    if (dl <= HALF - 1) v = swar_add(v, D[dl + HALF]);
                 }
-            } else {                // L: outputs c_out < 12
-                if (dl >= -23 && dl <= 11) {
+            } else {                // L: outputs c_out < RD/2
+                if (dl >= -(RD - 1) && dl <= HALF - 1) {
                     v = dl >= 0 ? D[dl] : 0;
-                    if (dl <= -1) v = swar_sub(v, D[dl + 24]);
-                    if (dl <= -13) v = swar_sub(v, D[dl + 36]);
+                    if (dl <= -1) v = swar_sub(v, D[dl + RD]);
+                    if (dl <= -(HALF + 1)) v = swar_sub(v, D[dl + RD + HALF]);
                 }
             }
-            V[(size_t)buf * NP * 96 + idx] = v;
+            V[(size_t)buf * NP * 2 * VS + idx] = v;
         }
     };
     if (T0 < T1) {
@@ -207,19 +231,19 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
         for (u32 T = T0; T < T1; T++) {
             const u32 cur = (T - T0) & 1, nxt = cur ^ 1;
             const bool more = T + 1 < T1;
-            if (!(a.dbg & 1)) LF_I8_LOAD_A(T + 1);
+            LF_I8_LOAD_A(T + 1);
             load_w(T + 2);
-            if (more && !(a.dbg & 2)) gen_d(nxt);
+            if (more) gen_d(nxt);
             lds_barrier();
-            if (more && !(a.dbg & 2)) gen_v(nxt);
-            // ---- 3 K-steps of 64 inner elements
+            if (more) gen_v(nxt);
+            // ---- RD/8 K-steps of 64 inner elements
             const unsigned char *Ac = Al + cur * a_lds;
-            const unsigned char *Vc = (const unsigned char *)(V + (size_t)cur * NP * 96);
+            const unsigned char *Vc = (const unsigned char *)(V + (size_t)cur * NP * 2 * VS);
 #pragma unroll
-            for (int s = 0; s < ((a.dbg & 4) ? 0 : 3); s++) {
-                v4i b[I8_NTW];
+            for (int s = 0; s < KS; s++) {
+                v4i b[NTW];
 #pragma unroll
-                for (int ni = 0; ni < I8_NTW; ni++) {
+                for (int ni = 0; ni < NTW; ni++) {
                     const ull *q = (const ull *)(Vc + vb[ni] + s * 64);
                     ull lo = q[0], hi = q[1];
                     b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
@@ -229,12 +253,12 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
                     if (mi < (int)mcnt) {   // (wave-uniform; a branch-free block over clamped tiles costs 27 spilled registers and 3.7x the time)
                         v4i av = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + mi * 1024);
 #pragma unroll
-                        for (int ni = 0; ni < I8_NTW; ni++)
+                        for (int ni = 0; ni < NTW; ni++)
                             if (ni < (int)ncnt) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                     }
                 }
             }
-            if (!(a.dbg & 1)) LF_I8_STORE_A(nxt);
+            LF_I8_STORE_A(nxt);
             store_w(cur);   // w[T+2] goes where w[T] was (read by gen_d one iteration ago)
             lds_barrier();
         }
@@ -245,10 +269,11 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
 #pragma unroll
-        for (int ni = 0; ni < I8_NTW; ni++)
+        for (int ni = 0; ni < NTW; ni++)
             if (mi < (int)mcnt && ni < (int)ncnt)
                 *(v4i *)(a.part + ((((size_t)blockIdx.x * MT + m_lo + mi) * NT + n_lo + ni) * 64 + lane) * 4) = acc[mi][ni];
-    if (tid < NP * 24) a.dsum[(size_t)blockIdx.x * NP * 24 + tid] = dacc;
+    if (tid < NP * RD) a.dsum[(size_t)blockIdx.x * NP * RD + tid] = dacc0;
+    if (tid + 512 < NP * RD) a.dsum[(size_t)blockIdx.x * NP * RD + tid + 512] = dacc1;
 }
 
 // stage 1 of the reduction: element-wise sum of the workgroups' partial tiles (and of their digit sums) -- coalesced across threads
@@ -269,70 +294,97 @@ __global__ void __launch_bounds__(256) k_ajtai_i8_sum(const int32_t *part, size_
     for (; w < nwg; w++) s += src[(size_t)w * stride];
     sum[e] = s;
 }
-// stage 2: y[plane][i][c_out] (coefficient form, SoA [24][NP*kappa_total], element index plane*kappa_total + row0 + i)
+// signed 128-bit value mod p for a modulus below 2^32
+__device__ __forceinline__ u64 s128_mod_small(__int128 v, u64 p) {
+    const bool neg = v < 0;
+    unsigned __int128 t = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    const u64 lo = (u64)t, hi = (u64)(t >> 64);
+    const u64 two64 = ((0xFFFFFFFFFFFFFFFFull % p) + 1) % p;
+    u64 r = ((hi % p) * two64 + lo % p) % p;
+    return neg ? (p - r) % p : r;
+}
+// stage 2: y[plane][row][c_out] in coefficient form, canonical.  Element index e = plane * kappa_total + row0 + i;
+// soa != 0: out[c_out * NE + e] (NE = NP * kappa_total), else out[e * RD + c_out].  p_small = 0: the Goldilocks modulus.
 __global__ void __launch_bounds__(256) k_ajtai_i8_finish(const long long *sum, size_t per_wg, u32 MT, u32 NT, u32 NP, u32 kappa, u32 row0, u32 kappa_total,
-                                                         u64 *coef_out) {
+                                                         u32 RD, u32 NL, u64 p_small, int soa, u64 *coef_out) {
     const u32 o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= NP * kappa * 24) return;
-    const u32 co = o % 24, i = (o / 24) % kappa, p = o / (24 * kappa);
-    const u32 n = p * 24 + co, nt = n >> 4, col = n & 15;
+    if (o >= NP * kappa * RD) return;
+    const u32 co = o % RD, i = (o / RD) % kappa, p = o / (RD * kappa), HALF = RD / 2;
+    const u32 n = p * RD + co, nt = n >> 4, col = n & 15;
     // T = sum over inner elements of Rot(F)[.][c_out], F = sum over columns of the digit polynomials: the "-128" bias of the bytes of A
-    const long long *F = sum + per_wg + (size_t)p * 24;
+    const long long *F = sum + per_wg + (size_t)p * RD;
     long long Tsum = 0;
-    for (int ci = 0; ci < 24; ci++) {
+    for (int ci = 0; ci < (int)RD; ci++) {
         int d = (int)co - ci;
-        if (co >= 12) {
+        if (co >= HALF) {
             if (d >= 0) Tsum += F[d];
-            if (d <= 11) Tsum += F[d + 12];
+            if (d <= (int)HALF - 1) Tsum += F[d + HALF];
         } else {
             if (d >= 0) Tsum += F[d];
-            if (d <= -1) Tsum -= F[d + 24];
-            if (d <= -13) Tsum -= F[d + 36];
+            if (d <= -1) Tsum -= F[d + RD];
+            if (d <= -(int)HALF - 1) Tsum -= F[d + RD + HALF];
         }
     }
     __int128 tot = 0;
-    for (u32 u = 0; u < 8; u++) {
-        const u32 m = 8 * i + u, mt = m >> 4, r = m & 15, ln = col + 16 * (r >> 2), reg = r & 3;
+    for (u32 u = 0; u < NL; u++) {
+        const u32 m = NL * i + u, mt = m >> 4, r = m & 15, ln = col + 16 * (r >> 2), reg = r & 3;
         tot += (__int128)(sum[(((size_t)mt * NT + nt) * 64 + ln) * 4 + reg] + 128 * Tsum) << (8 * u);
     }
-    coef_out[(size_t)co * ((size_t)NP * kappa_total) + (size_t)p * kappa_total + row0 + i] = fq_from_s128((u64)tot, (int64_t)(tot >> 64));
+    const u64 val = p_small ? s128_mod_small(tot, p_small) : fq_from_s128((u64)tot, (int64_t)(tot >> 64));
+    const size_t e = (size_t)p * kappa_total + row0 + i;
+    if (soa) coef_out[(size_t)co * ((size_t)NP * kappa_total) + e] = val;
+    else coef_out[e * RD + co] = val;
 }
 
-static size_t ajtai_i8_ach(u32 MT) { u32 mh = (MT + 1) / 2; return mh <= 2 ? 2 : (mh <= 4 ? 3 : 5); }
-size_t ajtai_i8_lds_bytes(u32 MT, u32 NP) { return 2 * ajtai_i8_ach(MT) * 8192 + 2 * (size_t)NP * 96 * 8 + (size_t)NP * 24 * 8 + 2 * 192 * 4; }
+static u32 ach_for(u32 RD, u32 MT) {   // 16-byte chunks of an A tile per thread, instantiated values only
+    const size_t bytes = (size_t)(RD / 8) * MT * 1024;
+    return bytes <= 2 * 8192 ? 2 : (bytes <= 3 * 8192 ? 3 : 5);
+}
+size_t ajtai_i8_lds_bytes(const AjtaiI8Ring &R, u32 MT, u32 NP) {
+    return 2 * (size_t)ach_for(R.RD, MT) * 8192 + 2 * (size_t)NP * 2 * (2 * R.RD) * 8 + (size_t)NP * R.RD * 8 + 2 * (size_t)R.RD * 8 * 4;
+}
 size_t ajtai_i8_slack_bytes() { return 5 * 8192; }   // readable bytes required behind the packed matrix
-u32 ajtai_i8_row_tiles(u32 kappa) { return (8 * kappa + 15) / 16; }
-u32 ajtai_i8_col_tiles(u32 NP) { return (24 * NP + 15) / 16; }
+u32 ajtai_i8_row_tiles(const AjtaiI8Ring &R, u32 kappa) { return (R.NL * kappa + 15) / 16; }
+u32 ajtai_i8_col_tiles(const AjtaiI8Ring &R, u32 NP) { return (R.RD * NP + 15) / 16; }
+u32 ajtai_i8_max_rows(const AjtaiI8Ring &R) { return R.RD == 24 ? 26 : 16; }      // rows of A per launch (13 / 4 row tiles)
+u32 ajtai_i8_max_planes(const AjtaiI8Ring &R) { return R.RD == 24 ? 16 : 8; }     // digit planes per launch (accumulators and LDS)
 // partial buffer words (int32) for nwg workgroups
 size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT) { return (size_t)nwg * MT * NT * 256; }
+size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, u32 MT, u32 NT, u32 NP) { return (size_t)MT * NT * 256 + (size_t)NP * R.RD; }
 
-int launch_ajtai_i8(const unsigned char *Ab, u32 MT, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total, u32 k0, u32 NP, u32 nwg,
-                    int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s) {
+int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total,
+                    u32 k0, u32 NP, u32 nwg, int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s) {
     AjtaiI8Args a;
     a.Ab = Ab; a.planes = planes; a.ld = ld; a.n = n;
-    a.MT = MT; a.NT = ajtai_i8_col_tiles(NP); a.k0 = k0; a.NP = NP;
+    a.MT = MT; a.NT = ajtai_i8_col_tiles(R, NP); a.k0 = k0; a.NP = NP;
     a.ntiles = (u32)((n + 7) / 8);
     a.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
     a.part = part; a.dsum = dsum;
-    a.dbg = getenv("LF_I8_DBG") ? (u32)atoi(getenv("LF_I8_DBG")) : 0;
-    if (a.MT > 13 || 8 * kappa > 16 * MT || NP > 16 || NP == 0) return -1;   // 3 * MT * 64 sixteen-byte chunks of an A tile <= 5 per thread
+    if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
     const u32 grid = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-    const size_t lds = ajtai_i8_lds_bytes(a.MT, NP);
-    const u32 mh = (a.MT + 1) / 2;
-#define LF_I8_LAUNCH(MTW, ACH)                                                                                                     \
+    const size_t lds = ajtai_i8_lds_bytes(R, MT, NP);
+#define LF_I8_LAUNCH(RD, RG, MTW, NTW, ACH)                                                                                        \
     do {                                                                                                                           \
         static bool attr_set = false;                                                                                              \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<MTW, ACH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL((k_ajtai_i8<MTW, ACH>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);                                    \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<RD, RG, MTW, NTW, ACH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((k_ajtai_i8<RD, RG, MTW, NTW, ACH>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);                       \
     } while (0)
-    if (mh <= 2) LF_I8_LAUNCH(2, 2);
-    else if (mh <= 4) LF_I8_LAUNCH(4, 3);
-    else LF_I8_LAUNCH(7, 5);
+    if (R.RD == 24) {   // 2 row groups x 4 column groups of 6 tiles (24 x 16 planes = 24 tiles)
+        const u32 mh = (MT + 1) / 2;
+        if (mh <= 2) LF_I8_LAUNCH(24, 2, 2, 6, 2);
+        else if (mh <= 4) LF_I8_LAUNCH(24, 2, 4, 6, 3);
+        else LF_I8_LAUNCH(24, 2, 7, 6, 5);
+    } else {            // 1 row group (<= 4 row tiles) x 8 column groups of 5 tiles (72 x 8 planes = 36 tiles)
+        if (MT <= 1) LF_I8_LAUNCH(72, 1, 1, 5, 2);
+        else if (MT <= 2) LF_I8_LAUNCH(72, 1, 2, 5, 3);
+        else if (MT <= 4) LF_I8_LAUNCH(72, 1, 4, 5, 5);
+        else return -1;
+    }
 #undef LF_I8_LAUNCH
-    const size_t per_wg = (size_t)a.MT * a.NT * 256;
-    hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * 24, 256)), dim3(256), 0, s, part, per_wg, dsum, NP * 24, grid, sum);
-    hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * 24, 256)), dim3(256), 0, s, sum, per_wg, a.MT, a.NT, NP, kappa, row0, kappa_total,
-                       coef_out);
+    const size_t per_wg = (size_t)MT * a.NT * 256;
+    hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * R.RD, 256)), dim3(256), 0, s, part, per_wg, dsum, NP * R.RD, grid, sum);
+    hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * R.RD, 256)), dim3(256), 0, s, sum, per_wg, MT, a.NT, NP, kappa, row0,
+                       kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out);
     return (int)grid;
 }
 }  // namespace lf

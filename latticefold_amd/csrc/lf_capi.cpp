@@ -711,17 +711,18 @@ static int prep_ajtai_i8(lf_ctx *c) {
     if (c->dAb) { (void)hipFree(c->dAb); c->dAb = nullptr; }
     c->i8_nch = 0;
     if (getenv("LF_AJTAI_VALU")) return LF_OK;
-    const u32 nch = (c->kappa + 25) / 26, kc = (c->kappa + nch - 1) / nch;
+    const AjtaiI8Ring R = ajtai_i8_goldilocks();
+    const u32 maxr = ajtai_i8_max_rows(R), nch = (c->kappa + maxr - 1) / maxr, kc = (c->kappa + nch - 1) / nch;
     const size_t ntiles = (c->nA + 7) / 8;
-    const u32 MT = ajtai_i8_row_tiles(kc);
-    const size_t chunk_bytes = ntiles * 3 * MT * 1024;
+    const u32 MT = ajtai_i8_row_tiles(R, kc);
+    const size_t chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
     HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch + ajtai_i8_slack_bytes()));
     HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch + ajtai_i8_slack_bytes(), c->stream()));
     u64 *coef;
     RET(c->tbuf("i8_prep_coef", 24 * c->nA, &coef));
     for (u32 i = 0; i < c->kappa; i++) {
         launch_icrt_dense(c->d_icrt, c->dA + (size_t)i * 24 * c->nA, coef, c->nA, c->stream());
-        launch_ajtai_pack_i8(coef, c->nA, i % kc, MT, c->dAb + (size_t)(i / kc) * chunk_bytes, c->stream());
+        launch_ajtai_pack_i8(coef, c->nA, 1, c->nA, i % kc, MT, R.RD, R.NL, c->dAb + (size_t)(i / kc) * chunk_bytes, c->stream());
     }
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->i8_nch = nch;
@@ -730,28 +731,30 @@ static int prep_ajtai_i8(lf_ctx *c) {
 }
 // digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev [NP][kappa][24] NTT form (PARTIAL when sharded)
 static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev) {
-    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(kc);
-    const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * 3 * MT * 1024;
+    const AjtaiI8Ring R = ajtai_i8_goldilocks();
+    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc), maxp = ajtai_i8_max_planes(R);
+    const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
     // One persistent workgroup per CU fills its LDS (157 KB): on a fully occupied chip the latency-bound round kernels of the other lane
     // cannot be placed until a commit workgroup retires.  7/8 of the CUs (28 of 32 per XCD) leaves them room: C4 26.1 -> 25.0 ms/step
     // (measured 256 / 240 / 224 / 192 / 160 / 128 workgroups: 26.1 / 26.3 / 25.0 / 25.1 / 26.1 / 28.2 ms).
     u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 224;
     if (nwg > ntiles) nwg = (u32)ntiles;
     int32_t *part, *dsum;
-    u64 *coef, *ntt;
-    RET(c->tbuf("i8_part", ajtai_i8_part_words(nwg, MT, ajtai_i8_col_tiles(16)), &part));
-    RET(c->tbuf("i8_dsum", (size_t)nwg * 16 * 24, &dsum));
     long long *sum;
-    RET(c->tbuf("i8_sum", (size_t)MT * ajtai_i8_col_tiles(16) * 256 + 16 * 24, &sum));
+    u64 *coef, *ntt;
+    const u32 NTmax = ajtai_i8_col_tiles(R, maxp);
+    RET(c->tbuf("i8_part", ajtai_i8_part_words(nwg, MT, NTmax), &part));
+    RET(c->tbuf("i8_dsum", (size_t)nwg * maxp * R.RD, &dsum));
+    RET(c->tbuf("i8_sum", ajtai_i8_sum_words(R, MT, NTmax, maxp), &sum));
     RET(c->tbuf("i8_coef", (size_t)24 * NP * c->kappa, &coef));
     RET(c->tbuf("i8_ntt", (size_t)24 * NP * c->kappa, &ntt));
-    for (u32 p0 = 0; p0 < NP; p0 += 16) {
-        const u32 np = NP - p0 < 16 ? NP - p0 : 16;
+    for (u32 p0 = 0; p0 < NP; p0 += maxp) {
+        const u32 np = NP - p0 < maxp ? NP - p0 : maxp;
         u64 *cf = coef + (size_t)24 * p0 * c->kappa;   // SoA block of this plane group: [24][np*kappa]
         for (u32 ch = 0; ch < nch; ch++) {
             const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
             size_t ev = c->ev_begin(1);
-            int g = launch_ajtai_i8(c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, cf, c->stream());
+            int g = launch_ajtai_i8(R, c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, cf, c->stream());
             c->ev_end(ev);
             if (g < 0) return LF_ERR_UNSUPPORTED;
         }

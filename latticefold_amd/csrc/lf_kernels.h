@@ -6,6 +6,7 @@
 //   coef planes  : i32 [24][n]   centred coefficients of a B-short witness (|v| <= B/2 <= 2^15)
 //   Ajtai matrix : u64 [kappa][24][n]
 #pragma once
+#include "lf_ajtai_i8.h"
 #include <hip/hip_runtime.h>
 
 #include "lf_host.h"
@@ -41,17 +42,7 @@ void launch_selftest_field(u64 seed, u32 n, u64 *mism_dev, hipStream_t s);  // a
 void launch_crt_fwd(const DevCrt &t, const u64 *coef, u64 *ntt, size_t n, hipStream_t s);
 void launch_icrt_dense(const u64 *icrt_mat /*24*24 dev*/, const u64 *ntt, u64 *coef, size_t n, hipStream_t s);
 
-// ---- digit-plane commitments on the int8 matrix cores (lf_ajtai_i8.hip) ------------------------------------------------
-// A repacked once per matrix: row i (coefficient table [24][n]) -> bytes in MFMA operand order, MT = ajtai_i8_row_tiles(rows of the chunk)
-void launch_ajtai_pack_i8(const u64 *coef, size_t n, u32 i, u32 MT, unsigned char *Ab, hipStream_t s);
-u32 ajtai_i8_row_tiles(u32 kappa);
-size_t ajtai_i8_slack_bytes();   // readable bytes required behind the packed matrix (the tile copy of the kernel is unconditional)
-u32 ajtai_i8_col_tiles(u32 NP);
-size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT);
-// commitments of the digit planes k0 .. k0+NP-1 (NP <= 16) of `planes` ([24][ld] int32) under rows [row0, row0+kappa) (kappa <= 26) of A:
-// coefficient-form results into coef_out (SoA [24][NP*kappa_total], element plane*kappa_total + row).  Returns the grid size or -1.
-int launch_ajtai_i8(const unsigned char *Ab, u32 MT /* row tiles of the packed chunk */, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total, u32 k0, u32 NP, u32 nwg,
-                    int32_t *part, int32_t *dsum, long long *sum /* MT*NT*256 + 24*NP words */, u64 *coef_out, hipStream_t s);
+// ---- digit-plane commitments on the int8 matrix cores: lf_ajtai_i8.h
 
 // ---- decomposition (a3) ----------------------------------------------------------------------------------------
 // generic balanced digits on canonical coefficient tables: out has `digits` tables; layout 0: element i ->
