@@ -240,14 +240,14 @@ def main():
         }
         # the batched commit is the largest single kernel (two launches per step); the twenty fold-round launches together are of the same order and are
         # listed next to it in `kernels`.  Fixed choice: the two totals are within a few per cent of each other, so a max() would flip from run to run.
-        i8 = wl.ring == "goldilocks" and not os.environ.get("LF_AJTAI_VALU")   # digit-plane commits on the int8 matrix cores (lf_ajtai_i8.hip)
+        i8 = wl.b == 2 and not os.environ.get("LF_AJTAI_VALU")   # digit-plane commits on the int8 matrix cores (lf_ajtai_i8.hip), both rings
         dom = "k_ajtai"
         peak = 8000.0
         # HBM traffic of the dominant kernel from the PMC passes (collected separately, as rocprofv3 requires; see profiles/)
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(wl.name.lower()))))["kernels"]
-            want = ("bb::" if wl.ring == "babybear" else "") + ("k_ajtai_i8" if i8 else "k_ajtai")
+            want = "k_ajtai_i8" if i8 else ("bb::" if wl.ring == "babybear" else "") + "k_ajtai"
             for name, k in pmc.items():
                 base = name.split("<")[0]
                 if base == want and k["fetch_bytes_max_corrected"] is not None:
@@ -257,11 +257,14 @@ def main():
         aj_t = aj_ms / max(aj_n, 1) * 1e-3
         src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc.sh; not re-measured in this run)" % PMC_FILE.format(wl.name.lower())
         if i8:
-            # One launch = the K-1 digit-plane commitments of a decomposition as ONE int8 GEMM: (8 kappa) x (24 N) bytes of A times (24 N) x (24 (K-1)) digits.
-            # Useful MACs exclude the padding of the 16-wide MFMA tiles (13 x 23 tiles for 208 x 360 outputs at C4).  Peak: dense int8 = 2 x the dense bf16
-            # rate of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF -> 5 POP/s; its own microbenchmark ceiling is >= 3.94 POP/s).
-            macs = 8 * wl.kappa * 24 * (wl.K - 1) * 24 * wl.N
-            a_bytes = 8 * wl.kappa * 24 * wl.N + 24 * 4 * wl.N                  # A as bytes (read once per launch) + the int32 coefficient planes
+            # The K-1 digit-plane commitments of a decomposition as int8 GEMMs: (NL kappa) x (RD N) bytes of A times (RD N) x (RD planes) digits per launch
+            # (Goldilocks: all 15 planes and 26 rows in one launch; BabyBear: plane groups of 8 + 7).  Useful MACs exclude the padding of the 16-wide MFMA
+            # tiles.  Peak: dense int8 = 2 x the dense bf16 rate of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF -> 5 POP/s; its microbenchmark
+            # ceiling is >= 3.94 POP/s).
+            RD, NL, maxp, maxr = (24, 8, 16, 26) if wl.ring == "goldilocks" else (72, 4, 8, 16)
+            launches_per_side = -(-(wl.K - 1) // maxp) * -(-wl.kappa // maxr)
+            macs = NL * wl.kappa * RD * (wl.K - 1) * RD * wl.N / launches_per_side          # average per launch
+            a_bytes = NL * wl.kappa * RD * wl.N / -(-wl.kappa // maxr) + RD * 4 * wl.N       # A row chunk as bytes (read once per launch) + the int32 planes
             kernels["k_ajtai"]["alg_bytes_per_launch"] = a_bytes
             kernels["k_ajtai"]["achieved_GBps"] = a_bytes / aj_t / 1e9 if aj_ms else 0.0
             kernels["k_ajtai_i8"] = kernels.pop("k_ajtai")
@@ -270,9 +273,9 @@ def main():
             roof = {"bound": "mfma", "kernel": dom, "achieved": tops, "peak": 5000.0, "unit": "TOP/s (int8, 2 ops per MAC)", "frac": tops / 5000.0,
                     "flops_per_launch": 2 * macs, "traffic": traffic, "traffic_source": src,
                     "hbm": {"achieved_GBps": kernels[dom]["achieved_GBps"], "peak": peak, "frac": kernels[dom]["achieved_GBps"] / peak,
-                            "note": "the same launch against the HBM roof: A streams once as bytes (8 kappa 24 N), floor about 1 ms at C4"},
-                    "note": "dominant kernel = the batched digit-plane commit, an exact int8 GEMM on v_mfma_i32_16x16x64_i8 (was k_ajtai on the 64-bit integer multiplier: "
-                            "7.1 ms / launch at C4); the rest of the step stays integer-ALU-bound; whole-step algorithmic rate = %.1f GB/s = %.3f of the HBM peak"
+                            "note": "the same launch against the HBM roof: A streams once per launch as bytes (NL kappa RD N; floor about 1 ms at C4)"},
+                    "note": "dominant kernel = the batched digit-plane commit, an exact int8 GEMM on v_mfma_i32_16x16x64_i8 (was k_ajtai on the integer multiplier: "
+                            "7.1 ms / launch at C4, 4.0 ms at C3); the rest of the step stays integer-ALU-bound; whole-step algorithmic rate = %.1f GB/s = %.3f of the HBM peak"
                             % (alg * steps_per_s / world / 1e9, alg * steps_per_s / world / 1e9 / peak),
                     "kernels": kernels}
         else:
