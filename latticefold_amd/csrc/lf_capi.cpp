@@ -1809,9 +1809,9 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // runs the same transcript.  Once fewer than 64 pairs per rank remain the f-hat slices are gathered and the tail is replicated.
     const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
     bool sharded = Gw > 1;
-    // Unsharded, rounds >= 4 with many pairs: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel,
+    // Rounds >= 4 with many pairs: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel,
     // so the separate memory-bound pass over them vanishes (rounds 4-6 at 2^20 rows: 6.25 -> 5.6 ms).
-    const bool fused = Gw == 1 && !c->tn.fold_unfused;
+    const bool fused = !c->tn.fold_unfused && (Gw == 1 || !c->tn.shard_plain_rounds);   // (sharded: the kernels offset their table pointers by the rank's first pair)
     const size_t fuse_min = c->tn.fuse_min;   // entries (measured: 65536 -> 16384 = -0.3 ms at 2^20 rows); tests lower it
     int fmode = 0;                 // producer of this round's pairs: 0 tables, 1 fused fix, 3 / 4 digit look-up table (rounds 3 / 4)
     const u64 *prevF = nullptr;

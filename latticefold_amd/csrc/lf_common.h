@@ -61,6 +61,7 @@ struct Tunables {
     bool lin_u_eval = false, fold_unfused = false, fold_no_lut = false, fold_tab_r1 = false, fold_no_mutab = false, theta_eval = false;
     bool force_exchange = false;     // LF_DIST_FORCE_EXCHANGE: run the sharded exchanges even with a 1-rank RCCL communicator (test hook)
     bool device_transcript = false;  // LF_DEVICE_TRANSCRIPT: Poseidon sponge of the tail rounds on the device (opt-in: slower than the host's)
+    bool shard_plain_rounds = false; // LF_SHARD_PLAIN_ROUNDS: sharded folding rounds on materialised tables only (no fused fix / look-up-table rounds)
     bool shard_two_lanes = false;    // LF_SHARD_TWO_LANES: threaded two-lane schedule also in a sharded step (default there: one host thread)
     bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
@@ -82,6 +83,7 @@ struct Tunables {
         t.ajtai_valu = getenv("LF_AJTAI_VALU") != nullptr;
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
         t.shard_two_lanes = getenv("LF_SHARD_TWO_LANES") != nullptr;
+        t.shard_plain_rounds = getenv("LF_SHARD_PLAIN_ROUNDS") != nullptr;
         t.device_transcript = getenv("LF_DEVICE_TRANSCRIPT") != nullptr;
         t.force_exchange = getenv("LF_DIST_FORCE_EXCHANGE") != nullptr;
         if ((e = getenv("LF_FOLD_FUSE_MIN"))) t.fuse_min = (size_t)atoll(e);

@@ -1639,6 +1639,8 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     const u32 nkd = 2 * K * 3, per = (nkd + gridDim.z - 1) / gridDim.z;
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
+    if (MODE == 1) { F -= 4 * a.pF0; src.out -= 2 * a.pF0; }   // fused fix: previous tables from entry 4 pF0, the fixed ones from entry 2 pF0
+    if (MODE == 4) src.out -= 2 * a.pF0;                         // first materialised tables of a rank's slice
     const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
     __shared__ u64 slut[MODE >= 3 ? 3 * 81 * 3 : 1];   // (mode 5 uses the values only)   // the 81 values, their squares, (mode 4) r times the values
     if (MODE >= 3) {

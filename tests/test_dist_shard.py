@@ -57,12 +57,19 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,cases,two_lanes", [(2, "T10,G5,T12", False), (4, "T12", False), (2, "T12", True), (2, "B8,B10,BDP", False), (4, "B14", False)])
+# "big": the thresholds of the large-instance round modes (fused fix, look-up-table rounds 2-4) lowered so that a 2^12 / 2^14-row instance takes
+# them -- in the sharded run on the ranks' pair slices, in the unsharded reference on whole tables
+@pytest.mark.parametrize("world,cases,two_lanes", [(2, "T10,G5,T12", False), (4, "T12", False), (2, "T12", True), (2, "B8,B10,BDP", False), (4, "B14", False),
+                                                   (2, "T12,T14", "big"), (4, "T14", "big"), (2, "T12", "plain")])
 def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, LF_ROOT=ROOT, OMP_NUM_THREADS="2", LF_CASES=cases)
-    if two_lanes:   # the threaded two-lane schedule with one exchange channel per lane (default in a sharded step: one host thread)
+    if two_lanes == "big":
+        env.update(LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
+    elif two_lanes == "plain":
+        env.update(LF_SHARD_PLAIN_ROUNDS="1", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
+    elif two_lanes:   # the threaded two-lane schedule with one exchange channel per lane (default in a sharded step: one host thread)
         env["LF_SHARD_TWO_LANES"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
