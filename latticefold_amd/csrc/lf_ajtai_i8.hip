@@ -101,11 +101,13 @@ struct AjtaiI8Args {
 //    columns out of range are clamped to valid addresses and masked after the load;
 //  * the staging registers are scalars and macros, not an array captured by lambdas (that array lived in scratch: 3.5 GB of writes / launch).
 // Template: ring degree RD, row groups RG (x 8/RG column groups = 8 waves), MTW x NTW tiles per wave, ACH 16-byte chunks of an A tile per thread.
-template <int RD, int RG, int MTW, int NTW, int ACH>
-__global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
+// EXACT: every wave that takes this instantiation owns exactly MTW row tiles (and computes all NTW column tiles, clamped past the end):
+// the MFMA block is branch-free -- the compiler may then hoist operand loads across it, which sched_barriers after every second row tile
+// keep within the register budget (without them: 62 - 85 spilled registers).
+template <int RD, int RG, int MTW, int NTW, int ACH, bool EXACT>
+__device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem) {
     constexpr int KS = RD / 8, VS = 2 * RD, HALF = RD / 2, CG = I8_WAVES / RG;
     constexpr int WR = (RD * 8 + 511) / 512;                    // staged witness words per thread and tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave / CG, ng = wave % CG;
     const u32 MT = a.MT, NT = a.NT, NP = a.NP;
     const size_t a_tile = (size_t)KS * MT * 1024;              // bytes of a tile in HBM
@@ -250,13 +252,19 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
                 }
 #pragma unroll
                 for (int mi = 0; mi < MTW; mi++) {
-                    if (mi < (int)mcnt) {   // (wave-uniform; a branch-free block over clamped tiles costs 27 spilled registers and 3.7x the time)
+                    if (EXACT) {
+                        v4i av = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + mi * 1024);
+#pragma unroll
+                        for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                        if (mi & 1) __builtin_amdgcn_sched_barrier(0);
+                    } else if (mi < (int)mcnt) {   // (wave-uniform guards)
                         v4i av = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + mi * 1024);
 #pragma unroll
                         for (int ni = 0; ni < NTW; ni++)
                             if (ni < (int)ncnt) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                     }
                 }
+                if (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
             LF_I8_STORE_A(nxt);
             store_w(cur);   // w[T+2] goes where w[T] was (read by gen_d one iteration ago)
@@ -274,6 +282,19 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
                 *(v4i *)(a.part + ((((size_t)blockIdx.x * MT + m_lo + mi) * NT + n_lo + ni) * 64 + lane) * 4) = acc[mi][ni];
     if (tid < NP * RD) a.dsum[(size_t)blockIdx.x * NP * RD + tid] = dacc0;
     if (tid + 512 < NP * RD) a.dsum[(size_t)blockIdx.x * NP * RD + tid + 512] = dacc1;
+}
+
+// Kernel: row group 0 runs the MTWA instantiation, the other row groups MTWB (two copies of the whole loop when they differ: each has its
+// own accumulators -- an if / else INSIDE the loop would make the compiler copy them; s_barrier counts waves, not program counters).
+template <int RD, int RG, int MTWA, int MTWB, int NTW, int ACH, bool EXACT>
+__global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (MTWA == MTWB) i8_run<RD, RG, MTWA, NTW, ACH, EXACT>(a, smem);
+    else {
+        constexpr int CG = I8_WAVES / RG;
+        if ((threadIdx.x >> 6) / CG == 0) i8_run<RD, RG, MTWA, NTW, ACH, EXACT>(a, smem);
+        else i8_run<RD, RG, MTWB, NTW, ACH, EXACT>(a, smem);
+    }
 }
 
 // stage 1 of the reduction: element-wise sum of the workgroups' partial tiles (and of their digit sums) -- coalesced across threads
@@ -363,21 +384,24 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
     const u32 grid = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     const size_t lds = ajtai_i8_lds_bytes(R, MT, NP);
-#define LF_I8_LAUNCH(RD, RG, MTW, NTW, ACH)                                                                                        \
+#define LF_I8_LAUNCH(RD, RG, MTWA, MTWB, NTW, ACH, EXACT)                                                                           \
     do {                                                                                                                           \
         static bool attr_set = false;                                                                                              \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<RD, RG, MTW, NTW, ACH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL((k_ajtai_i8<RD, RG, MTW, NTW, ACH>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);                       \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<RD, RG, MTWA, MTWB, NTW, ACH, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((k_ajtai_i8<RD, RG, MTWA, MTWB, NTW, ACH, EXACT>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);         \
     } while (0)
+    const bool guarded = getenv("LF_I8_GUARDED") != nullptr;   // A/B switch: the generic guarded instantiation for every shape
     if (R.RD == 24) {   // 2 row groups x 4 column groups of 6 tiles (24 x 16 planes = 24 tiles)
         const u32 mh = (MT + 1) / 2;
-        if (mh <= 2) LF_I8_LAUNCH(24, 2, 2, 6, 2);
-        else if (mh <= 4) LF_I8_LAUNCH(24, 2, 4, 6, 3);
-        else LF_I8_LAUNCH(24, 2, 7, 6, 5);
+        if (MT == 13 && !guarded) LF_I8_LAUNCH(24, 2, 7, 6, 6, 5, true);    // kappa 25 / 26: 7 + 6 row tiles, branch-free
+        else if (mh <= 2) LF_I8_LAUNCH(24, 2, 2, 2, 6, 2, false);
+        else if (mh <= 4) LF_I8_LAUNCH(24, 2, 4, 4, 6, 3, false);
+        else LF_I8_LAUNCH(24, 2, 7, 7, 6, 5, false);
     } else {            // 1 row group (<= 4 row tiles) x 8 column groups of 5 tiles (72 x 8 planes = 36 tiles)
-        if (MT <= 1) LF_I8_LAUNCH(72, 1, 1, 5, 2);
-        else if (MT <= 2) LF_I8_LAUNCH(72, 1, 2, 5, 3);
-        else if (MT <= 4) LF_I8_LAUNCH(72, 1, 4, 5, 5);
+        if (MT == 4 && !guarded) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5, true);     // kappa 13 .. 16
+        else if (MT <= 1) LF_I8_LAUNCH(72, 1, 1, 1, 5, 2, false);
+        else if (MT <= 2) LF_I8_LAUNCH(72, 1, 2, 2, 5, 3, false);
+        else if (MT <= 4) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5, false);
         else return -1;
     }
 #undef LF_I8_LAUNCH
