@@ -114,6 +114,10 @@ int lf_linf_check(lf_ctx *, const uint64_t *f_ntt, size_t count, uint64_t bound,
 /* ---- a5: AjtaiCommitmentScheme::{new, commit, commit_ntt} (commitment_scheme.rs:23-77) -------- */
 /* kappa <= 128 (Goldilocks: more than 48 rows of A are committed in equal row chunks, one LDS tile each) / 32 (BabyBear);
  * larger -> LF_ERR_INVALID */
+/* Besides the NTT-form copy (general commitments) both calls build a second resident form of A for the digit-plane commitments of
+ * the decomposition step (decomposition.rs:178-201): coefficient form, cut into bytes, in int8-MFMA operand order (lf_ajtai_i8.hip) --
+ * 8*24*kappa*n bytes more for Goldilocks (4*72*kappa*n for BabyBear), built once here, never per step.  LF_AJTAI_VALU=1 in the
+ * environment skips it and keeps those commitments on the integer-multiplier kernel. */
 int lf_ajtai_load(lf_ctx *, const uint64_t *A /* kappa*n ring elements, row-major, NTT form */, size_t kappa, size_t n);
 /* synthetic i.i.d. matrix generated on the device (bench; same stream as workload.Workload.ajtai_matrix) */
 int lf_ajtai_generate(lf_ctx *, uint64_t seed, size_t kappa, size_t n);
