@@ -1345,7 +1345,7 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     if (Gw > 1) RET(c->tbuf("lin_round_out", 5 * 24 + 8, &od_dev));
     for (u32 round = 1; round <= P.s; round++) {
         // persistent tail (k_lin_tail): all remaining rounds in one launch once the tables are small, as in the folding sumcheck
-        if (Gw == 1 && !c->tn.no_tail && round >= 2 && n <= c->tn.tail_n && n >= 4 && P.s - round + 1 <= TAIL_MAX_ROUNDS) {
+        if (!sharded && !c->tn.no_tail && round >= 2 && n <= c->tn.tail_n && n >= 4 && P.s - round + 1 <= TAIL_MAX_ROUNDS) {
             int trc = lin_tail_rounds(c, tr, cur, cure, n, fx[flip], partial, round, point, msgs, deg);
             if (trc == LF_OK) { cur = fx[flip]; n = 2; break; }
             if (trc != LF_ERR_UNSUPPORTED) return trc;
@@ -1826,7 +1826,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         fmode = 0;
         // Persistent tail: once the materialised tables are small, ONE kernel runs all remaining rounds and exchanges messages /
         // challenges with this thread through a host-mapped mailbox (k_fold_tail) -- no launches and no stream sync per round.
-        if (!sharded && Gw == 1 && !c->tn.no_tail && round >= 5 && fmode == 0 && curF && ldF == a.n && a.n <= c->tn.tail_n && a.n >= 4 &&
+        if (!sharded && !c->tn.no_tail && round >= 5 && fmode == 0 && curF && ldF == a.n && a.n <= c->tn.tail_n && a.n >= 4 &&   // (a sharded step: once its tables are replicated, every rank runs its own tail)
             P.s - round + 1 <= TAIL_MAX_ROUNDS) {
             int trc = fold_tail_rounds(c, tr, a, (u64 *)curF, F, T5[flip], d_mu, partial, round, pt, msgs, deg);
             if (trc == LF_OK) {
