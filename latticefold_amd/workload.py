@@ -44,6 +44,8 @@ CONFIGS = {
     "C3": (18, 1 << 17, 2, 1 << 16, 2, 16, 16, "babybear"),  # BASELINE configs[2]
     # BabyBearDP of the reference unit tests (decomposition_parameters.rs:98-105): B 2^8, L 4, K 8
     "BDP": (7, 32, 4, 1 << 8, 2, 8, 4, "babybear"),
+    "B21": (8, 128, 2, 1 << 16, 2, 16, 21, "babybear"),    # kappa > 16: two row chunks of the int8 commit kernel (11 + 10 rows -> 3 row tiles each)
+    "B32": (7, 64, 2, 1 << 16, 2, 16, 32, "babybear"),     # the backend's largest kappa: 2 x 16 rows
 }
 
 _M1 = np.uint64(0xBF58476D1CE4E5B9)

@@ -19,39 +19,48 @@ def _y_s(ctx, wl, wit, acc):
 
 
 def _setup(name, valu, env=None):
-    for k in ("LF_AJTAI_VALU", "LF_I8_WGS"):
+    for k in ("LF_AJTAI_VALU", "LF_I8_WGS", "LF_I8_GUARDED"):
         os.environ.pop(k, None)
     if valu:
         os.environ["LF_AJTAI_VALU"] = "1"
     for k, v in (env or {}).items():
         os.environ[k] = v
     wl = make_workload(name)
-    ctx = api.Context(0)
+    ctx = api.Context(0, ring=wl.ring)
     ctx.load_ccs(wl)
     scheme = api.AjtaiCommitmentScheme(ctx, matrix=wl.ajtai_matrix())
     return wl, ctx, scheme
 
 
-@pytest.mark.parametrize("name", ["T8", "T10", "G5", "E22", "E99"])
+@pytest.mark.parametrize("name", ["T8", "T10", "G5", "E22", "E99", "T14", "B6", "B10", "BDP", "B21", "B32", "B14"])
 def test_digit_plane_commits_match_valu_kernel_and_oracle(name):
-    import lfo
+    """both rings: the exact-count instantiations (13 row tiles: the 25-row chunks of E99; BabyBear kappa 13..16 -> 4 row tiles: B14),
+    the generic guarded ones (everything else), row chunks (E99: 4 x 25 rows; B21 / B32: 2 chunks) and plane groups (E22: 16 + 5; BabyBear: 8 + 7)"""
+    wl0 = make_workload(name)
+    if wl0.ring == "goldilocks":
+        import lfo as O
+    else:
+        import lfo_bb as O
+    tr = lambda: api.PoseidonTranscript(ring=wl0.ring)
     out = {}
     try:
-        for valu in (False, True):
-            wl, ctx, scheme = _setup(name, valu)
+        for mode in ("i8", "valu", "guarded"):
+            wl, ctx, scheme = _setup(name, mode == "valu", {"LF_I8_GUARDED": "1"} if mode == "guarded" else None)
             wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
             cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
-            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
-            out[valu] = _y_s(ctx, wl, wit, acc)
+            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+            out[mode] = api.LFDecompositionProver.prove(ctx, acc, wit, tr())
             ctx.close()
-        assert (out[False][0] == out[True][0]).all() and (out[False][1] == out[True][1]).all()
-        inst = lfo.Instance(wl)
+        for mode in ("valu", "guarded"):
+            assert (out["i8"][0] == out[mode][0]).all() and (out["i8"][1] == out[mode][1]).all(), mode
+        inst = O.Instance(wl)
         f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
-        acc_o, _ = inst.linearize(lfo.Transcript(), cccs, f_coeff)
-        want = inst.decomposition_prove(lfo.Transcript(), wl.ajtai_matrix(), acc_o, f_coeff)
-        assert (out[False][1] == want[1]).all() and (out[False][0] == want[0]).all()
+        acc_o, _ = inst.linearize(O.Transcript(), cccs, f_coeff)
+        want = inst.decomposition_prove(O.Transcript(), wl.ajtai_matrix(), acc_o, f_coeff)
+        assert (out["i8"][1] == want[1]).all() and (out["i8"][0] == want[0]).all()
     finally:
-        os.environ.pop("LF_AJTAI_VALU", None)
+        for k in ("LF_AJTAI_VALU", "LF_I8_GUARDED"):
+            os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize("pattern", ["plus", "minus", "alternating", "random"])
