@@ -992,11 +992,13 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
     }
     if (!c || !p || !rowptr || !col || !val || !S_off || !S_idx || !cc) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ccs_load(p, rowptr, col, val, S_off, S_idx, cc);
-    if (p->s < 3 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 31 || p->L == 0 || p->L > 8 ||
+    if (p->s < 3 || p->s > 30 || p->t == 0 || p->t > 4 || p->q == 0 || p->q > 8 || p->K == 0 || p->K > 32 || p->L == 0 || p->L > 8 ||
         p->d + 1 > 4 || p->wit_len == 0)
         return LF_ERR_UNSUPPORTED;
     if (p->b != 2) return LF_ERR_UNSUPPORTED;  // folding comb is specialised to b = 2 (all reference Goldilocks rows)
-    if (!pow2(p->B) || p->B > (1ULL << 31)) return LF_ERR_UNSUPPORTED;
+    // B = 2^32 (config.toml:158): balanced digits lie in [-2^31, 2^31]; the int32 planes hold all of them but +2^31 exactly, which the ingest
+    // rejects (LF_ERR_UNSUPPORTED) -- one value in 2^32 per digit
+    if (!pow2(p->B) || p->B > (1ULL << 32)) return LF_ERR_UNSUPPORTED;
     {   // K base-2 digits must cover |coeff| <= B/2
         u64 half = p->B / 2;
         u32 need = 0;
@@ -1096,7 +1098,7 @@ static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] can
         (void)hipFree(pl);
         return LF_ERR_HIP;
     }
-    if (hv) { (void)hipFree(pl); return LF_ERR_NORM; }
+    if (hv) { (void)hipFree(pl); return (hv & 1) ? LF_ERR_NORM : LF_ERR_UNSUPPORTED; }
     lf_witness *w = new lf_witness{c, pl, c->N, c->device, c->N * 24 * 4};
     *out = w;
     return LF_OK;

@@ -339,10 +339,11 @@ __global__ void __launch_bounds__(256) k_coef_to_i32(const u64 *coef, int32_t *p
         u64 v = coef[i];
         bool neg = v > (LF_P - 1) / 2;
         u64 mag = neg ? LF_P - v : v;
-        if (mag > bound) { bad = 1; mag = 0; }
-        planes[i] = neg ? -(int32_t)mag : (int32_t)mag;
+        if (mag > bound) { bad |= 1; mag = 0; }
+        if (!neg && mag > 0x7fffffffull) { bad |= 2; mag = 0; }   // +2^31 (possible only with B = 2^32) has no int32 representation
+        planes[i] = neg ? (int32_t)(0u - (u32)mag) : (int32_t)mag;
     }
-    if (bad) atomicOr(viol, 1);
+    if (bad) atomicOr(viol, bad);
 }
 void launch_coef_to_i32(const u64 *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s) {
     hipLaunchKernelGGL(k_coef_to_i32, dim3(grid_for(n * 24, 4096)), dim3(256), 0, s, coef, planes, n * 24, bound, viol);

@@ -34,6 +34,7 @@ CONFIGS = {
     "E22": (10, 256, 3, 1 << 22, 2, 22, 43),
     "E99": (9, 64, 4, 1 << 16, 2, 16, 99),
     "E31": (9, 64, 3, 1 << 31, 2, 31, 50),
+    "E32": (9, 64, 2, 1 << 32, 2, 32, 99),      # benches/config.toml:158: kappa 99, B 2^32, K 32
     # GoldilocksDP of the reference unit tests (decomposition_parameters.rs:89-96): N not a power of 2
     "G5": (9, 64, 5, 1 << 15, 2, 15, 5),
     # ---- BabyBearRingNTT (d = 72, tau = 9; B^L = 2^32 > p)

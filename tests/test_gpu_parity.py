@@ -223,7 +223,7 @@ def test_fold_step_parity(ctx, name, seed):
     assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
 
 
-@pytest.mark.parametrize("name", ["E22", "E99", "E31"])
+@pytest.mark.parametrize("name", ["E22", "E99", "E31", "E32"])
 def test_fold_step_parity_wider_reference_rows(ctx, name):
     """the reference's wider Goldilocks parameter rows (benches/config.toml:150-165) at small wit_len: kappa 43 / B 2^22 / L 3 / K 22,
     kappa 99 (commit cut into row chunks), and B 2^31 / K 31 (the widest digits the int32 witness planes hold): complete fold steps
@@ -238,6 +238,45 @@ def test_fold_step_parity_wider_reference_rows(ctx, name):
     lc2_g, w2, proof2_g = api.NIFSProver.prove(ctx, lc_g, w0, cccs, wit, api.PoseidonTranscript())
     lc2_o, f2_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f_coeff)
     assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
+
+
+def test_b_2_32_edge_digits(ctx):
+    """B = 2^32 (benches/config.toml:158): balanced base-B digits lie in [-2^31, 2^31].  The int32 witness planes hold -2^31 (all K = 32
+    bit-planes of INT32_MIN must come out right in every kernel that cuts digits: commits, evaluations, look-up codes, compute_f_0) and
+    every other value; +2^31 exactly is rejected at ingest (LF_ERR_UNSUPPORTED), never mis-folded."""
+    wl = make_workload("E32")
+    P = api.P
+    h = 1 << 31
+    coeff = lfo.icrt(wl.w_ccs)
+    coeff[0, 0] = np.uint64(P - h)                       # digit -2^31
+    coeff[1, 0] = np.uint64(h - 1)                       # 2^31 - 1
+    coeff[2, 1] = np.uint64(P - (h + (h << 31)))         # digits (-2^31, -2^30)
+    coeff[3, 5] = np.uint64((h - 1) + ((h >> 1) << 32))  # digits (2^31 - 1, 2^30)
+    coeff[4, 7] = np.uint64(P - ((1 << 40) + h))         # digits (-2^31, -2^8)
+    wl.w_ccs = lfo.crt(coeff)
+    wl.val[2] = np.ascontiguousarray(wl.z()[:min(wl.n, wl.m)])     # C = diag(z) of the modified witness: the CCS stays satisfied
+    inst = lfo.Instance(wl)
+    ctx.load_ccs(wl)
+    A = wl.ajtai_matrix()
+    scheme = api.AjtaiCommitmentScheme(ctx, matrix=A)
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    assert (f_coeff == P - h).sum() >= 3 and not (f_coeff == h).any()          # -2^31 digits are present, +2^31 is not
+    assert (wit.f_coeff == f_coeff).all()
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    acc, lin = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+    acc_o, lin_o = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    assert (acc == acc_o).all() and (lin == lin_o).all()
+    lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    assert (proof == proof_o).all() and (lc == lc_o).all() and (w0.f == f0_o).all()
+    rc, _ = inst.verify(lfo.Transcript(), acc, cccs, proof)
+    assert rc == 0
+    # +2^31: the one digit value the planes cannot hold (here as the tie (2^31 - 2) 2^32 + 2^31, which the balanced rule keeps at +B/2)
+    coeff[5, 2] = np.uint64(((h - 2) << 32) + h)
+    with pytest.raises(api.LfError) as e:
+        api.Witness.from_w_ccs(ctx, lfo.crt(coeff))
+    assert e.value.code == -3
 
 
 @pytest.mark.parametrize("name", ["T10", "G5"])
