@@ -870,7 +870,7 @@ int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64
     RET(c->tbuf("io_a", batch * n * 24, &F));
     RET(c->tbuf("io_b", batch * c->kappa * 24, &o));
     for (size_t b = 0; b < batch; b++) RET(up_ring(c, f + b * n * 24, n, F + b * 24 * n));
-    c->tn = Tunables::read((size_t)1 << 17);
+    c->tn = Tunables::read((size_t)1 << 14);
     c->ev_reset();
     RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
     c->ev_collect();
@@ -1820,7 +1820,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     size_t prevld = 0;
     // Rounds 3 and 4 of large unsharded instances never materialise the m/4-entry tables: their entries are one of 81 values
     // (four ternary digits) and come from a look-up table in LDS (k_fold_round modes 3 and 4); P.s >= 4 and m/4 >= lut_min entries.
-    const size_t lut_min = c->tn.lut_min;   // default 2^17
+    const size_t lut_min = c->tn.lut_min;   // default 2^14 entries (measured: C2 6.65 -> 6.52 ms, 2^18 rows 10.7 -> 9.6 ms against 2^17)
     const size_t tab_min = c->tn.tab_min;   // pairs; rounds 1-2 as table look-ups above this
     const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !c->tn.fold_no_lut;
     u64 *d_lut = nullptr;
@@ -2113,7 +2113,7 @@ int lf_linearize(lf_ctx *c, lf_transcript *t, const uint64_t *cccs, const lf_wit
     if (!c->have_ccs) return LF_ERR_STATE;
     if (wit->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    c->tn = Tunables::read((size_t)1 << 17);
+    c->tn = Tunables::read((size_t)1 << 14);
     c->ev_reset();
     c->host_tr_ms = 0;
     int rc = linearize_impl(c, t->t, cccs, wit, lcccs_out, lin_proof_out, nullptr);
@@ -2143,7 +2143,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     HIPCHK(hipSetDevice(c->device));
     std::vector<Fq3> rL;
     if (!lcccs_point(P, acc, rL)) return LF_ERR_UNSUPPORTED;  // evaluation points are always diagonal challenges
-    c->tn = Tunables::read((size_t)1 << 17);
+    c->tn = Tunables::read((size_t)1 << 14);
     Timeline tl;
     t_tl = &tl;
     c->ev_reset();
@@ -2266,7 +2266,7 @@ int lf_decomposition_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs, c
     HIPCHK(hipSetDevice(c->device));
     std::vector<Fq3> r;
     if (!lcccs_point(P, lcccs, r)) return LF_ERR_UNSUPPORTED;
-    c->tn = Tunables::read((size_t)1 << 17);
+    c->tn = Tunables::read((size_t)1 << 14);
     c->ev_reset();
     c->host_tr_ms = 0;
     u64 *yd = nullptr;
@@ -2304,7 +2304,7 @@ int lf_folding_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs_s, const
     const lf_params &P = c->P;
     if (w_left->N != c->N || w_right->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    c->tn = Tunables::read((size_t)1 << 17);
+    c->tn = Tunables::read((size_t)1 << 14);
     c->ev_reset();
     c->host_tr_ms = 0;
     const size_t ll = lf_lcccs_len(&P);
