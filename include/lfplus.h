@@ -10,6 +10,7 @@
  *     tau = split(hconcat(comM_f), n, d/2, l)        rgchk.rs:304-306, utils.rs:12-43
  *     m_tau = exp(tau); cm_f, C_Mf, cm_mtau          rgchk.rs:308-320
  *   Matrix::try_mul_vec (Ajtai commitment, coefficient form)   stark-rings-linalg, call sites rgchk.rs:313-319
+ *   Decomp::decompose(&A, B)                         src/decomp.rs:32-99
  *   utils::tensor / tensor_product                   src/utils.rs:45-83 (KATs utils.rs:118-131)
  *
  * M_f and m_tau are matrices / vectors of unit monomials; they cross this boundary as their EXPONENT digits (int8 in (-d/2, d/2)):
@@ -58,6 +59,15 @@ int lfplus_rg_from_f(lfplus_ctx *ctx, uint64_t b, uint32_t k, uint32_t l);
 int lfplus_rg_read(lfplus_ctx *ctx, int8_t *Df, uint64_t *comMf, uint64_t *tau, int8_t *mtau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau);
 /* the same computation `iters` times back to back, timed with HIP events on the library's stream (inputs resident): average ms */
 int lfplus_rg_from_f_timed(lfplus_ctx *ctx, uint64_t b, uint32_t k, uint32_t l, uint32_t iters, double *ms_avg);
+
+/* Decomp::decompose(&A, B) (src/decomp.rs:32-99; no transcript) on the resident (A, f), n a power of two:
+ *   F = f.decompose_to_vec(B, 2).transpose() -> (F0, F1);  C_i = A F_i;
+ *   v_i = [(mle(F_i)(r_a), mle(F_i)(r_b)), then per matrix M_j (mle(M_j F_i)(r_a), mle(M_j F_i)(r_b))]
+ * r_a / r_b: log2(n) ring elements each (the components of Decomp::r); the nm matrices have n rows, CSR with ring-element coefficients
+ * (val[j]: 16 words per non-zero).  Outputs (any may be NULL): F0, F1 n*16 words; C0, C1 kappa*16; v0, v1 (1+nm)*2*16. */
+int lfplus_decompose(lfplus_ctx *ctx, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
+                     const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1, uint64_t *v0,
+                     uint64_t *v1);
 
 /* Matrix::try_mul_vec: out (kappa*16 words) = A * v for a general vector of n ring elements (host pointer) */
 int lfplus_commit(lfplus_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *out);

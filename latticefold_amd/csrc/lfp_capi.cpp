@@ -285,6 +285,108 @@ extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint6
     HIPCHK(c, hipGetLastError());
     return LFPLUS_OK;
 }
+// r 2^64 mod p (Montgomery form) on the host
+static u64 to_mont(u64 a) { return (u64)((((unsigned __int128)a) << 64) % lfp::P); }
+extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
+                                const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1, uint64_t *v0,
+                                uint64_t *v1) {
+    if (!c || !r_a || !r_b || (nm && (!rowptr || !col || !val))) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: null argument");
+    if (!c->A || !c->f || c->nf != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: matrix / witness not set or of different length");
+    const u64 n = c->n;
+    if (n & (n - 1)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: n must be a power of two (nvars = log2(A.ncols))");
+    if (B < 2 || B > (1ull << 62) || nm > 64) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: parameters outside the envelope");
+    u32 nvars = 0;
+    while (((u64)1 << nvars) < n) nvars++;
+    if (!canonical(r_a, (size_t)nvars * 16) || !canonical(r_b, (size_t)nvars * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: non-canonical point");
+    for (u32 j = 0; j < nm; j++) {
+        if (!rowptr[j] || !col[j] || !val[j] || rowptr[j][0] != 0) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: bad CSR");
+        for (u64 r = 0; r < n; r++)
+            if (rowptr[j][r + 1] < rowptr[j][r]) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: rowptr not monotone");
+        const u32 nnz = rowptr[j][n];
+        for (u32 k = 0; k < nnz; k++)
+            if (col[j][k] >= n) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: column index out of range");
+        if (!canonical(val[j], (size_t)nnz * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: non-canonical coefficient");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const u32 E = 2 * (1 + nm), T = 2 * E;        // vectors (F0, M_j F0 .., F1, M_j F1 ..), tables = one per vector and point
+    const size_t vw = (size_t)n * 16;
+    u64 *buf = nullptr;
+    // F0 | F1 | tables T*n | ping T*n/2 | rM nvars*32
+    const size_t words = 2 * vw + (size_t)T * vw + (size_t)T * vw / 2 + (size_t)nvars * 32 + 64;
+    HIPCHK(c, hipMalloc(&buf, words * 8));
+    u64 *dF0 = buf, *dF1 = dF0 + vw, *tab = dF1 + vw, *ping = tab + (size_t)T * vw, *drM = ping + (size_t)T * vw / 2;
+    int rc = LFPLUS_OK;
+    std::vector<void *> tofree;
+    auto cleanup = [&]() { for (void *q : tofree) (void)hipFree(q); (void)hipFree(buf); };
+#define HIPCHK2(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(e_); cleanup(); return LFPLUS_E_HIP; } } while (0)
+    {
+        std::vector<u64> rM((size_t)nvars * 32);
+        for (u32 k = 0; k < nvars; k++)
+            for (int w = 0; w < 16; w++) {
+                rM[(size_t)k * 32 + w] = to_mont(r_a[(size_t)k * 16 + w]);
+                rM[(size_t)k * 32 + 16 + w] = to_mont(r_b[(size_t)k * 16 + w]);
+            }
+        HIPCHK2(hipMemcpyAsync(drM, rM.data(), rM.size() * 8, hipMemcpyHostToDevice, c->st));
+        HIPCHK2(hipStreamSynchronize(c->st));
+    }
+    lfp::launch_decompose2(c->f, vw, B, dF0, dF1, c->st);
+    for (int s = 0; s < 2; s++) {
+        const u64 *Fi = s ? dF1 : dF0;
+        lfp::launch_replicate(Fi, vw, 2, tab + (size_t)(s * (1 + nm)) * 2 * vw, c->st);
+    }
+    for (u32 j = 0; j < nm; j++) {
+        const u32 nnz = rowptr[j][n];
+        u32 *drp = nullptr, *dci = nullptr;
+        u64 *dv = nullptr, *dy = nullptr;
+        HIPCHK2(hipMalloc(&drp, (n + 1) * 4)); tofree.push_back(drp);
+        HIPCHK2(hipMalloc(&dci, (size_t)(nnz ? nnz : 1) * 4)); tofree.push_back(dci);
+        HIPCHK2(hipMalloc(&dv, (size_t)(nnz ? nnz : 1) * 16 * 8)); tofree.push_back(dv);
+        HIPCHK2(hipMalloc(&dy, vw * 8)); tofree.push_back(dy);
+        std::vector<u64> vM((size_t)nnz * 16);
+        for (size_t i = 0; i < vM.size(); i++) vM[i] = to_mont(val[j][i]);
+        HIPCHK2(hipMemcpyAsync(drp, rowptr[j], (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+        HIPCHK2(hipMemcpyAsync(dci, col[j], (size_t)nnz * 4, hipMemcpyHostToDevice, c->st));
+        HIPCHK2(hipMemcpyAsync(dv, vM.data(), vM.size() * 8, hipMemcpyHostToDevice, c->st));
+        HIPCHK2(hipStreamSynchronize(c->st));   // vM is a local buffer
+        for (int s = 0; s < 2; s++) {
+            lfp::launch_spmv_ring(drp, dci, dv, s ? dF1 : dF0, n, dy, c->st);
+            lfp::launch_replicate(dy, vw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * vw, c->st);
+        }
+    }
+    // fix_variables, variable 0 first, all T tables at once
+    {
+        u64 *cur = tab, *nxt = ping;
+        size_t len = n;
+        for (u32 k = 0; k < nvars; k++) {
+            lfp::launch_ring_fix(cur, nxt, T, len, drM + (size_t)k * 32, c->st);
+            std::swap(cur, nxt);
+            len /= 2;
+        }
+        // cur: T ring elements, table index = (s*(1+nm) + j)*2 + point
+        if (v0) HIPCHK2(hipMemcpyAsync(v0, cur, (size_t)(1 + nm) * 2 * 16 * 8, hipMemcpyDeviceToHost, c->st));
+        if (v1) HIPCHK2(hipMemcpyAsync(v1, cur + (size_t)(1 + nm) * 2 * 16, (size_t)(1 + nm) * 2 * 16 * 8, hipMemcpyDeviceToHost, c->st));
+    }
+    // commitments of the two parts
+    {
+        Plan p = plan_for(c->n, c->kappa, 0);
+        rc = ensure_part(c, (size_t)p.nblk * p.nout_f + 2 * p.nout_f);
+        if (rc) { cleanup(); return rc; }
+        u64 *res = c->part + (size_t)p.nblk * p.nout_f;
+        for (int s = 0; s < 2; s++) {
+            enqueue_phase1(c, s ? dF1 : dF0, 2, 0, p, c->part);
+            lfp::launch_reduce(c->part, p.nblk, (u32)p.nout_f, res + (size_t)s * p.nout_f, 0, c->kappa, 0, 2, 0, nullptr, c->st);
+        }
+        if (C0) HIPCHK2(hipMemcpyAsync(C0, res, p.nout_f * 8, hipMemcpyDeviceToHost, c->st));
+        if (C1) HIPCHK2(hipMemcpyAsync(C1, res + p.nout_f, p.nout_f * 8, hipMemcpyDeviceToHost, c->st));
+    }
+    if (F0) HIPCHK2(hipMemcpyAsync(F0, dF0, vw * 8, hipMemcpyDeviceToHost, c->st));
+    if (F1) HIPCHK2(hipMemcpyAsync(F1, dF1, vw * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK2(hipStreamSynchronize(c->st));
+    HIPCHK2(hipGetLastError());
+#undef HIPCHK2
+    cleanup();
+    return LFPLUS_OK;
+}
 extern "C" int lfplus_tensor(lfplus_ctx *c, const uint64_t *r, uint32_t n, uint64_t *out) {
     if (!c || !out || (n && !r) || n > 28) return fail(c, LFPLUS_E_ARG, "lfplus_tensor: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));

@@ -44,6 +44,11 @@ void launch_phase2(const Phase2Args &a, u32 nblk, hipStream_t s);
 void launch_reduce(const u64 *part, u32 nblk, u32 nout, u64 *out, u32 nsplit, u32 kappa, u32 k, u64 base, u32 l, u64 *tau, hipStream_t s);
 // largest launch group (1, 2 or 4) not above `left`
 inline u32 group_size(u32 left) { return left >= 4 ? 4 : left >= 2 ? 2 : 1; }
+// Decomp::decompose (decomp.rs:32-99): base-B split, fix_variables over ring tables, sparse mat-vec with ring coefficients
+void launch_decompose2(const u64 *f, size_t words, u64 B, u64 *F0, u64 *F1, hipStream_t s);
+void launch_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM /* [2][16] Montgomery */, hipStream_t s);
+void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s);
+void launch_replicate(const u64 *src, size_t words, u32 copies, u64 *dst, hipStream_t s);
 void launch_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt, hipStream_t s);
 void launch_tensor_product(const u64 *a, u64 m, const u64 *b, u64 n, u64 *out, hipStream_t s);
 }  // namespace lfp

@@ -334,6 +334,66 @@ __global__ __launch_bounds__(64 * RED_WAVES) void k_reduce(const u64 *part, u32 
     }
 }
 
+// ---- Decomp::decompose (decomp.rs:32-99) ---------------------------------------------------------------------------------------
+// two balanced base-B digits of every coefficient: f = F0 + B F1
+__global__ void __launch_bounds__(256) k_decompose2(const u64 *f, size_t words, u64 B, int sh, u64 *F0, u64 *F1) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    int64_t cur = centre(f[i]);
+    int64_t d0 = digit_step(cur, B, sh), d1 = digit_step(cur, B, sh);
+    F0[i] = d0 >= 0 ? (u64)d0 : P - (u64)(-d0);
+    F1[i] = d1 >= 0 ? (u64)d1 : P - (u64)(-d1);
+}
+// coefficient t of a * b in Z_p[X]/(X^16 + 1) for the 16 lanes of a group: lane t holds b[t], aM = a in Montgomery form (a 2^64 mod p)
+__device__ __forceinline__ u64 ring_mul_lane(const u64 *aM, u64 b_t, int t) {
+    u64 acc = 0;
+#pragma unroll
+    for (int s = 0; s < D; s++) {
+        const u64 bv = __shfl(b_t, (t - s) & 15, 16);
+        const u64 pr = mont_mul(aM[s], bv);
+        acc = (t - s) < 0 ? (acc >= pr ? acc - pr : acc + (P - pr)) : add_p(acc, pr);
+    }
+    return acc;
+}
+// one fix_variables step of `ntab` tables of `len` ring elements each (table tab evaluates at point tab & 1):
+// out[tab][j] = in[tab][2j] + r * (in[tab][2j+1] - in[tab][2j]),  rM = [2][16] Montgomery words of this variable's coordinate
+__global__ void __launch_bounds__(256) k_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM) {
+    __shared__ u64 r_s[2][D];
+    if (threadIdx.x < 2 * D) r_s[threadIdx.x / D][threadIdx.x % D] = rM[threadIdx.x];
+    __syncthreads();
+    const size_t g = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4), half = len / 2;
+    const int t = threadIdx.x & 15;
+    if (g >= (size_t)ntab * half) return;
+    const u32 tab = (u32)(g / half);
+    const size_t j = g % half;
+    const u64 *src = in + ((size_t)tab * len + 2 * j) * D;
+    const u64 lo = src[t], hi = src[D + t];
+    const u64 diff = hi >= lo ? hi - lo : hi + (P - lo);
+    out[((size_t)tab * half + j) * D + t] = add_p(lo, ring_mul_lane(r_s[tab & 1], diff, t));
+}
+// y = M x for a CSR matrix with ring-element coefficients (valM in Montgomery form); 16 lanes per row
+__global__ void __launch_bounds__(256) k_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y) {
+    const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int t = threadIdx.x & 15;
+    if (row >= nrows) return;
+    u64 acc = 0;
+    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) {
+        const u64 xv = x[(size_t)col[k] * D + t];
+        u64 aM[D];
+#pragma unroll
+        for (int s = 0; s < D; s++) aM[s] = valM[(size_t)k * D + s];
+        acc = add_p(acc, ring_mul_lane(aM, xv, t));
+    }
+    y[row * D + t] = acc;
+}
+// dst[tab] = src for tab in 0..copies-1 (the tables of one vector, one per evaluation point)
+__global__ void __launch_bounds__(256) k_replicate(const u64 *src, size_t words, u32 copies, u64 *dst) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    const u64 v = src[i];
+    for (u32 c = 0; c < copies; c++) dst[(size_t)c * words + i] = v;
+}
+
 __global__ void k_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= len) return;
@@ -370,6 +430,19 @@ void launch_phase2(const Phase2Args &a, u32 nblk, hipStream_t s) {
 }
 void launch_reduce(const u64 *part, u32 nblk, u32 nout, u64 *out, u32 nsplit, u32 kappa, u32 k, u64 base, u32 l, u64 *tau, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3((nout + 63) / 64), dim3(64 * RED_WAVES), 0, s, part, nblk, nout, out, nsplit, kappa, k, base, log2_exact(base), l, tau);
+}
+void launch_decompose2(const u64 *f, size_t words, u64 B, u64 *F0, u64 *F1, hipStream_t s) {
+    hipLaunchKernelGGL(k_decompose2, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, f, words, B, log2_exact(B), F0, F1);
+}
+void launch_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM, hipStream_t s) {
+    const size_t groups = (size_t)ntab * (len / 2);
+    hipLaunchKernelGGL(k_ring_fix, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, in, out, ntab, len, rM);
+}
+void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s) {
+    hipLaunchKernelGGL(k_spmv_ring, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, s, rowptr, col, valM, x, nrows, y);
+}
+void launch_replicate(const u64 *src, size_t words, u32 copies, u64 *dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_replicate, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src, words, copies, dst);
 }
 void launch_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt, hipStream_t s) {
     hipLaunchKernelGGL(k_tensor_level, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, cur, len, r, nxt);

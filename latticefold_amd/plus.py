@@ -52,6 +52,8 @@ def _lib():
         L.lfplus_rg_read.argtypes = [vp, i8p, u64p, u64p, i8p, u64p, u64p, u64p]
         L.lfplus_rg_from_f_timed.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         L.lfplus_commit.argtypes = [vp, u64p, C.c_uint64, u64p]
+        u32pp, u64pp = C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64p)
+        L.lfplus_decompose.argtypes = [vp, C.c_uint64, u64p, u64p, C.c_uint32, u32pp, u32pp, u64pp, u64p, u64p, u64p, u64p, u64p, u64p]
         L.lfplus_tensor.argtypes = [vp, u64p, C.c_uint32, u64p]
         L.lfplus_tensor_product.argtypes = [vp, u64p, C.c_uint64, u64p, C.c_uint64, u64p]
         _READY = True
@@ -123,6 +125,27 @@ class PlusContext:
         b, pb = _w([int(x) % P for x in b])
         out = np.zeros(a.size * b.size if a.size and b.size else a.size + b.size, dtype=np.uint64)
         self._chk(_lib().lfplus_tensor_product(self.h, pa, a.size, pb, b.size, out.ctypes.data_as(u64p)))
+        return out
+
+    def decompose(self, f, A, B, r, M=()):
+        """Decomp{f, r, M}.decompose(&A, B) (decomp.rs:32-99).  r: (nvars, 2, 16) pairs of ring elements; M: CSR matrices (rowptr, col, val[nnz][16]).
+        -> dict(F0, F1 (n,16); C0, C1 (kappa,16); v0, v1 (1+len(M), 2, 16)): ((LinB0, LinB1), DecompProof) of the reference, flat"""
+        if A is not None:
+            self.set_matrix(A)
+        self.set_witness(f)
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        r_a, r_b = np.ascontiguousarray(r[:, 0]), np.ascontiguousarray(r[:, 1])
+        keep = [(np.ascontiguousarray(a, dtype=np.uint32), np.ascontiguousarray(b, dtype=np.uint32), np.ascontiguousarray(v, dtype=np.uint64)) for a, b, v in M]
+        u32p = C.POINTER(C.c_uint32)
+        nm = len(keep)
+        rp = (u32p * max(1, nm))(*[k[0].ctypes.data_as(u32p) for k in keep])
+        cp = (u32p * max(1, nm))(*[k[1].ctypes.data_as(u32p) for k in keep])
+        vp_ = (u64p * max(1, nm))(*[k[2].ctypes.data_as(u64p) for k in keep])
+        n, kappa = self.n, self.kappa
+        out = {"F0": np.zeros((n, D), dtype=np.uint64), "F1": np.zeros((n, D), dtype=np.uint64), "C0": np.zeros((kappa, D), dtype=np.uint64),
+               "C1": np.zeros((kappa, D), dtype=np.uint64), "v0": np.zeros((1 + nm, 2, D), dtype=np.uint64), "v1": np.zeros((1 + nm, 2, D), dtype=np.uint64)}
+        self._chk(_lib().lfplus_decompose(self.h, B, r_a.ctypes.data_as(u64p), r_b.ctypes.data_as(u64p), nm, rp, cp, vp_,
+                                          *[out[k].ctypes.data_as(u64p) for k in ("F0", "F1", "C0", "C1", "v0", "v1")]))
         return out
 
     def time_rg_from_f(self, dparams, iters):

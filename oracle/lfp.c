@@ -154,3 +154,63 @@ void lfp_splitmix_fill(u64 seed, u64 start, size_t count, u64 *out) {
         out[i] = z % P;
     }
 }
+
+/* ---- Decomp::decompose (crates/latticefold-plus/src/decomp.rs:32-99): transcript-free --------------------------------------------
+ * F = f.decompose_to_vec(B, 2).transpose() -> (F0, F1), f = F0 + B F1 coefficient-wise with balanced digits;
+ * v_i = [ (mle(F_i)(r_a), mle(F_i)(r_b)), then for every matrix M_j: (mle(M_j F_i)(r_a), mle(M_j F_i)(r_b)) ];  C_i = A F_i.
+ * MLE evaluation = fix_variables, variable 0 (index bit 0) first: new[j] = old[2j] + r (old[2j+1] - old[2j]) with RING products (the
+ * point's coordinates are ring elements).  Matrices in CSR with ring-element coefficients (stark_rings_linalg::SparseMatrix rows of
+ * (value, column)); every matrix has n rows.  n must be a power of two (nvars = log2(A.ncols)). */
+static void ring_add(u64 *d, const u64 *a, const u64 *b) { for (int i = 0; i < D; i++) d[i] = fadd(a[i], b[i]); }
+static void ring_sub(u64 *d, const u64 *a, const u64 *b) { for (int i = 0; i < D; i++) d[i] = fsub(a[i], b[i]); }
+static void mle_eval(const u64 *tab, size_t n, unsigned nvars, const u64 *r /* nvars x 16 */, u64 *out) {
+    u64 *cur = (u64 *)malloc(n * D * sizeof(u64));
+    memcpy(cur, tab, n * D * sizeof(u64));
+    size_t len = n;
+    for (unsigned k = 0; k < nvars; k++) {
+        for (size_t j = 0; j < len / 2; j++) {
+            u64 diff[D], pr[D];
+            ring_sub(diff, cur + (2 * j + 1) * D, cur + (2 * j) * D);
+            lfp_ring_mul(r + (size_t)k * D, diff, pr);
+            ring_add(cur + j * D, cur + (2 * j) * D, pr);
+        }
+        len /= 2;
+    }
+    memcpy(out, cur, D * sizeof(u64));
+    free(cur);
+}
+int lfp_decompose(const u64 *f, size_t n, const u64 *A, uint32_t kappa, u64 B, const u64 *r_a, const u64 *r_b, uint32_t nm,
+                  const uint32_t *const *rowptr, const uint32_t *const *col, const u64 *const *val, u64 *F0, u64 *F1, u64 *C0, u64 *C1, u64 *v0,
+                  u64 *v1) {
+    if (!n || (n & (n - 1))) return -1;
+    unsigned nvars = 0;
+    while (((size_t)1 << nvars) < n) nvars++;
+    int64_t dg[2];
+    for (size_t i = 0; i < n * D; i++) {
+        lfp_balanced_digits(f[i], B, 2, dg);
+        F0[i] = from_i64(dg[0]);
+        F1[i] = from_i64(dg[1]);
+    }
+    u64 *mv = (u64 *)malloc(n * D * sizeof(u64));
+    for (int s = 0; s < 2; s++) {
+        const u64 *Fi = s ? F1 : F0;
+        u64 *v = s ? v1 : v0;
+        mle_eval(Fi, n, nvars, r_a, v);
+        mle_eval(Fi, n, nvars, r_b, v + D);
+        for (uint32_t j = 0; j < nm; j++) {
+            for (size_t row = 0; row < n; row++) {
+                u64 acc[D] = {0}, t[D];
+                for (uint32_t k = rowptr[j][row]; k < rowptr[j][row + 1]; k++) {
+                    lfp_ring_mul(val[j] + (size_t)k * D, Fi + (size_t)col[j][k] * D, t);
+                    ring_add(acc, acc, t);
+                }
+                memcpy(mv + row * D, acc, sizeof(acc));
+            }
+            mle_eval(mv, n, nvars, r_a, v + (size_t)(1 + j) * 2 * D);
+            mle_eval(mv, n, nvars, r_b, v + (size_t)(1 + j) * 2 * D + D);
+        }
+        lfp_commit(A, kappa, n, Fi, s ? C1 : C0);
+    }
+    free(mv);
+    return 0;
+}

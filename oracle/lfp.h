@@ -7,6 +7,7 @@
  *   tensor / tensor_product           crates/latticefold-plus/src/utils.rs:45-83   (KATs utils.rs:118-131 -> tests/golden/kats.json "lfp_tensor")
  *   split                             utils.rs:12-43
  *   RgInstance::from_f                rgchk.rs:260-331   (the "double commitment": benches/double_commitment.rs:53-82)
+ *   Decomp::decompose                 decomp.rs:32-99    (base-B split into two parts, their commitments and MLE evaluations; no transcript)
  *
  * PARITY STATUS: **unpinned beyond the two tensor KATs**.  The arithmetic of this path lives in stark-rings @ 886a89f (absent):
  * `exp`, `decompose_to_vec`, `gadget_decompose`, `Matrix::{try_mul_mat, try_mul_vec, hconcat}`.  Restated here from their call sites
@@ -40,6 +41,12 @@ void lfp_commit(const uint64_t *A, uint32_t kappa, size_t n, const uint64_t *f, 
  * returns 0, -1 if a digit is outside the exp domain, -2 if tau does not fit n (the reference panics) */
 int lfp_rg_from_f(const uint64_t *f, size_t n, const uint64_t *A, uint32_t kappa, uint64_t b, uint32_t k, uint32_t l, int8_t *Df, uint64_t *comMf,
                   uint64_t *tau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau);
+/* Decomp::decompose (decomp.rs:32-99).  r_a / r_b: log2(n) ring elements each (the two components of the evaluation point pairs);
+ * nm matrices with n rows in CSR form, coefficients = ring elements (16 words per non-zero).  Outputs: F0, F1 n ring elements;
+ * C0, C1 kappa; v0, v1: (1 + nm) pairs (value at r_a, value at r_b) of ring elements.  returns -1 unless n is a power of two */
+int lfp_decompose(const uint64_t *f, size_t n, const uint64_t *A, uint32_t kappa, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm,
+                  const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1,
+                  uint64_t *v0, uint64_t *v1);
 void lfp_splitmix_fill(uint64_t seed, uint64_t start, size_t count, uint64_t *out);   /* uniform words < p (workload generator) */
 #ifdef __cplusplus
 }

@@ -112,3 +112,35 @@ def test_tensor_kats_on_the_device(ctx):
     assert (ctx.tensor(r) == O.tensor(r)).all()
     a, b = O.splitmix(10, 0, 37), O.splitmix(11, 0, 53)
     assert (ctx.tensor_product(a, b) == O.tensor_product(a, b)).all()
+
+
+def _sparse(seed, n, per_row):
+    rowptr = np.arange(n + 1, dtype=np.uint32) * per_row
+    col = np.zeros(n * per_row, dtype=np.uint32)
+    val = np.zeros((n * per_row, D), dtype=np.uint64)
+    rnd = O.splitmix(seed, 0, n * per_row * (D + 1)).reshape(n * per_row, D + 1)
+    col[:] = (rnd[:, 0] % np.uint64(n)).astype(np.uint32)
+    val[:] = rnd[:, 1:]
+    col[::per_row] = np.arange(n, dtype=np.uint32)          # first entry of a row: the diagonal, coefficient 1 (2 in row 0: decomp.rs:167-169)
+    val[::per_row] = 0
+    val[::per_row, 0] = 1
+    val[0, 0] = 2
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("n,kappa,B,nm", [(1 << 15, 2, 50, 3), (1 << 12, 1, 3989010971, 1), (1 << 10, 3, 7, 0)])
+def test_decompose_matches_the_oracle(ctx, n, kappa, B, nm):
+    """Decomp::decompose (decomp.rs:32-99) at the reference's test shape (n = 2^15, kappa 2, B = 50: decomp.rs:159-163; B = ceil(sqrt q) + 1:
+    decomp.rs:197-200), word for word against the oracle, and the identities DecompProof::verify checks"""
+    A = O.splitmix(41, 0, kappa * n * D).reshape(kappa, n, D)
+    bound = min(B * B // 2 - 1, P // 2)
+    f = small_f(42, n, min(bound, 1 << 40)) if bound < (1 << 62) else O.splitmix(42, 0, n * D).reshape(n, D)
+    nv = n.bit_length() - 1
+    r = O.splitmix(43, 0, nv * 2 * D).reshape(nv, 2, D)
+    mats = [_sparse(50 + j, n, 1 + j) for j in range(nm)]
+    got = ctx.decompose(f, A, B, r, mats)
+    want = O.decompose(f, A, B, r[:, 0], r[:, 1], mats)
+    for k in ("F0", "F1", "C0", "C1", "v0", "v1"):
+        assert (got[k] == want[k]).all(), k
+    rec = lambda x0, x1: (x0.astype(object) + B * x1.astype(object)) % P
+    assert (rec(got["C0"], got["C1"]) == ctx.commit(f).astype(object)).all()

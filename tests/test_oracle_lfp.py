@@ -76,3 +76,49 @@ def test_rg_from_f_is_consistent():
     for j in range(n):
         e = int(tc[j]); m_tau[j, e if e >= 0 else D + e] = 1
     assert (r["cm_mtau"] == lfp.commit(A, m_tau)).all()
+
+
+def _sparse(seed, n, per_row, scale_first=True):
+    """n x n CSR with ring-element coefficients: identity plus (per_row - 1) random off-diagonal ring elements per row; entry (0, 0) doubled as in the
+    reference's tests (decomp.rs:167-169)"""
+    rowptr = np.arange(n + 1, dtype=np.uint32) * per_row
+    col = np.zeros(n * per_row, dtype=np.uint32)
+    val = np.zeros((n * per_row, D), dtype=np.uint64)
+    rnd = lfp.splitmix(seed, 0, n * per_row * (D + 1))
+    for r in range(n):
+        col[r * per_row] = r
+        val[r * per_row, 0] = 1
+        for k in range(1, per_row):
+            i = (r * per_row + k) * (D + 1)
+            col[r * per_row + k] = int(rnd[i]) % n
+            val[r * per_row + k] = rnd[i + 1:i + 1 + D]
+    if scale_first:
+        val[0, 0] = 2
+    return rowptr, col, val
+
+
+def test_decompose_recomposes():
+    """DecompProof::verify (decomp.rs:101-123): recompose([C0, C1], B) = A f and recompose([v0, v1], B) = the evaluations of f (and of M_j f)"""
+    n, kappa, B = 256, 2, 50
+    A = lfp.splitmix(21, 0, kappa * n * D).reshape(kappa, n, D)
+    small = (lfp.splitmix(22, 0, n * D) % np.uint64(2 * 1200 + 1)).astype(np.int64) - 1200          # |coefficient| <= 1200 < B^2 / 2
+    f = np.array([int(v) % P for v in small], dtype=np.uint64).reshape(n, D)
+    r_a, r_b = lfp.splitmix(23, 0, 8 * D).reshape(8, D), lfp.splitmix(24, 0, 8 * D).reshape(8, D)
+    mats = [_sparse(31, n, 1), _sparse(32, n, 3)]
+    d = lfp.decompose(f, A, B, r_a, r_b, mats)
+    # digits: f = F0 + B F1 with |digit| <= B / 2
+    c = lambda x: np.where(x > P // 2, x.astype(object) - P, x.astype(object))
+    assert (c(d["F0"]) + B * c(d["F1"]) == small.reshape(n, D)).all() and max(abs(int(v)) for v in c(d["F0"]).reshape(-1)) <= B // 2
+    rec = lambda x0, x1: (x0.astype(object) + B * x1.astype(object)) % P
+    assert (rec(d["C0"], d["C1"]) == lfp.commit(A, f).astype(object)).all()
+    # the same decomposition of the "whole" vector: evaluations are linear, so decompose(f) with B large enough that F1 = 0 gives them directly
+    whole = lfp.decompose(f, A, 1 << 40, r_a, r_b, mats)
+    assert not whole["F1"].any() and (whole["F0"] == f).all()
+    assert (rec(d["v0"], d["v1"]) == whole["v0"].astype(object)).all()
+    # an evaluation by hand: at a Boolean point the MLE returns the table entry (variable 0 = index bit 0)
+    idx = 0b10110101
+    pt = np.zeros((8, D), dtype=np.uint64)
+    for k in range(8):
+        pt[k, 0] = (idx >> k) & 1
+    e = lfp.decompose(f, A, 1 << 40, pt, pt, [])
+    assert (e["v0"][0, 0] == f[idx]).all()
