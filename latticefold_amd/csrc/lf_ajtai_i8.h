@@ -25,4 +25,10 @@ size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, uint32_t MT, uint32_t NT, uint32
 // row tiles): coefficient-form results into coef_out (element plane*kappa_total + row).  Returns the grid size or -1.
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const int32_t *planes, size_t ld, size_t n, uint32_t kappa, uint32_t row0,
                     uint32_t kappa_total, uint32_t k0, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s);
+// v[k][c][q] = sum_j eq[q][j] * digit_k(planes[c][j]) on the matrix cores (Goldilocks; see lf_ajtai_i8.hip).  mode_bits: K binary digit planes,
+// out[(k*24+c)*3+q]; mode 0: the coefficients themselves (|.| <= bound), out[c*3+q].  Returns 0, or -1 if the shape is not handled.
+size_t coef_eval_i8_eb_bytes(size_t n);
+size_t coef_eval_i8_part_words(uint32_t nwg);
+int launch_coef_eval_i8(const int32_t *planes, size_t ldp, size_t n, const uint64_t *eq, size_t ldeq, uint32_t K, int mode_bits, uint64_t bound, unsigned char *EB,
+                        uint32_t nwg, int32_t *part, long long *sum /* 24*2*256 words */, uint64_t *out, hipStream_t s);
 }  // namespace lf

@@ -411,4 +411,176 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
                        kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out);
     return (int)grid;
 }
+
+// =====================================================================================================================================
+// MLE evaluations of the witness digit planes on the same matrix cores (Goldilocks):  v[k][c][q] = sum_j eq[q][j] * digit_k(planes[c][j])
+// (decomposition.rs:204-211 v_s, and the linearization's v with the coefficients themselves as digits).  An int8 GEMM again: rows =
+// (coefficient c, plane k) -- one 16-row MFMA tile per coefficient, its rows the planes -- inner dimension = columns j, columns = the 8
+// bytes of the three eq words (biased by -128) plus a column of ones that yields the row sums the bias needs.  No LDS: the A operand is cut
+// from 16 consecutive plane entries in registers (the 16 plane lanes of a tile share the loads), the B operand is one 16-byte load from
+// the byte-packed eq table (k_eq_pack_i8, once per evaluation point).  Was k_coef_eval: masked +-eq additions on the VALU, 0.72 ms per call
+// at 2^20 columns.
+// =====================================================================================================================================
+// EB[(8 q + u)][n] = byte u of eq[q][j] ^ 0x80;  thread = (16 columns, one of the 24 byte planes)
+__global__ void __launch_bounds__(256) k_eq_pack_i8(const u64 *eq, size_t ld, size_t n, size_t ldb, unsigned char *EB) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, groups = (n + 15) / 16;
+    if (gid >= groups * 24) return;
+    const u32 col = (u32)(gid / groups), q = col >> 3, u = col & 7;
+    const size_t j0 = (gid % groups) * 16;
+    unsigned char b[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) b[t] = j0 + t < n ? (unsigned char)(((eq[(size_t)q * ld + j0 + t] >> (8 * u)) & 0xFF) ^ 0x80) : 0x80;   // 0x80 = biased zero
+    uint4 w;
+    w.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((u32)b[3] << 24);
+    w.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((u32)b[7] << 24);
+    w.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((u32)b[11] << 24);
+    w.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((u32)b[15] << 24);
+    *(uint4 *)(EB + (size_t)col * ldb + j0) = w;
+}
+// digit of a row: MODE 1 = balanced binary digit k0 + k of |v| with the sign of v (row = plane k, one tile per coefficient);
+// MODE 0 = balanced base-256 digit (row & 3) of v: v = sum_k b_k 256^k with b_k in [-128, 127] (4 digits cover |v| <= 127 (256^4 - 1) / 255
+// >= 2^31; a tile = 4 coefficients x 4 digits)
+template <int MODE>
+__device__ __forceinline__ int ce_digit(int32_t v, u32 k, u32 k0) {
+    if (MODE) return digit2_i8(v, k0 + k);
+    int x = v, d = 0;
+#pragma unroll
+    for (u32 i = 0; i < 4; i++) {
+        const int lb = x & 0xFF;
+        const int b = lb >= 128 ? lb - 256 : lb;
+        d = i == k ? b : d;
+        x = (x >> 8) + (lb >= 128 ? 1 : 0);
+    }
+    return d;
+}
+struct CoefEvalI8Args {
+    const int32_t *planes;      // [24][ldp], offset to the first column of this call
+    size_t ldp, n;
+    const unsigned char *EB;    // [24][ldb] packed eq bytes of the same columns
+    size_t ldb;
+    u32 k0, rows;               // first plane of this launch, rows used (<= 16)
+    u32 steps_per_wg;           // K-steps (64 columns) per workgroup
+    int32_t *part;              // [wg][24][2][64][4]
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) k_coef_eval_i8(CoefEvalI8Args a) {
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, g = lane >> 4;
+    const size_t nsteps = (a.n + 63) / 64;
+    const size_t s0 = (size_t)blockIdx.x * a.steps_per_wg, s1 = s0 + a.steps_per_wg < nsteps ? s0 + a.steps_per_wg : nsteps;
+    v4i acc[6][2];
+#pragma unroll
+    for (int mi = 0; mi < 6; mi++) { acc[mi][0] = v4i{0, 0, 0, 0}; acc[mi][1] = v4i{0, 0, 0, 0}; }
+    const bool full16 = (a.ldp & 3) == 0 && (((size_t)a.planes) & 15) == 0;
+    for (size_t st = s0; st < s1; st++) {
+        const size_t j0 = st * 64 + 16 * g;           // this lane's 16 columns
+        // B operands: tile 0 = eq byte planes 0..15, tile 1 = planes 16..23, then the ones column, then zeros
+        v4i b0, b1;
+        {
+            const bool in = j0 + 16 <= a.n;
+            const u32 c1 = 16 + row;
+            if (in) {
+                b0 = *(const v4i *)(a.EB + (size_t)row * a.ldb + j0);
+                b1 = c1 < 24 ? *(const v4i *)(a.EB + (size_t)c1 * a.ldb + j0) : (c1 == 24 ? v4i{0x01010101, 0x01010101, 0x01010101, 0x01010101} : v4i{0, 0, 0, 0});
+            } else {   // ragged end: the packed table is padded to a multiple of 16 columns with biased zeros; columns past n carry digit 0 anyway
+                const size_t jc = j0 < a.ldb ? j0 : 0;
+                const bool ok = j0 < a.ldb;
+                b0 = ok ? *(const v4i *)(a.EB + (size_t)row * a.ldb + jc) : v4i{0, 0, 0, 0};
+                b1 = c1 < 24 ? (ok ? *(const v4i *)(a.EB + (size_t)c1 * a.ldb + jc) : v4i{0, 0, 0, 0}) : (c1 == 24 ? v4i{0x01010101, 0x01010101, 0x01010101, 0x01010101} : v4i{0, 0, 0, 0});
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < (MODE ? 6 : 2); mi++) {
+            // MODE 1: tile = coefficient c, rows = planes;  MODE 0: tile = wave + 4 mi (6 tiles of 4 coefficients x 4 byte digits)
+            const u32 tile = MODE ? wave * 6 + mi : wave + 4 * mi;
+            if (!MODE && tile >= 6) continue;
+            const u32 c = MODE ? tile : tile * 4 + (row >> 2);
+            const int32_t *pl = a.planes + (size_t)c * a.ldp + j0;
+            int32_t v[16];
+            if (full16 && j0 + 16 <= a.n) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int4 w = *(const int4 *)(pl + 4 * q);
+                    v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = j0 + q < a.n ? pl[q] : 0;
+            }
+            u32 w4[4] = {0, 0, 0, 0};
+            if (MODE ? row < a.rows : (row & 3) < a.rows) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) w4[q >> 2] |= (u32)(unsigned char)ce_digit<MODE>(v[q], MODE ? row : (row & 3), a.k0) << (8 * (q & 3));
+            }
+            const v4i av = v4i{(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
+            acc[mi][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b0, acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b1, acc[mi][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < (MODE ? 6 : 2); mi++) {
+        const u32 tile = MODE ? wave * 6 + mi : wave + 4 * mi;
+        if (!MODE && tile >= 6) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) *(v4i *)(a.part + ((((size_t)blockIdx.x * 24 + tile) * 2 + nt) * 64 + lane) * 4) = acc[mi][nt];
+    }
+}
+// out[(k*24 + c)*3 + q] (MODE 1, k = k0 + row) or out[c*3 + q] accumulated over the byte rows (MODE 0), canonical Goldilocks words
+__global__ void __launch_bounds__(256) k_coef_eval_i8_finish(const long long *sum, u32 k0, u32 rows, int mode_bits, u32 nbytes, u64 *out) {
+    const u32 o = blockIdx.x * 256 + threadIdx.x;
+    const u32 total = mode_bits ? rows * 72 : 72;
+    if (o >= total) return;
+    const u32 q = o % 3, c = (o / 3) % 24, r = mode_bits ? o / 72 : 0;
+    auto cell = [&](u32 rr, u32 col) {   // C[row][col] in the tile layout: mode_bits: tile c, row rr;  mode 0: tile c / 4, row 4 (c % 4) + rr
+        const u32 tile = mode_bits ? c : c >> 2, trow = mode_bits ? rr : 4 * (c & 3) + rr;
+        const u32 nt = col >> 4, cl = col & 15, ln = cl + 16 * (trow >> 2), reg = trow & 3;
+        return sum[(((size_t)tile * 2 + nt) * 64 + ln) * 4 + reg];
+    };
+    u64 val = 0, pw = 1;                              // mode 0: value = sum over the byte rows of 256^row * (row's sum), in the field
+    const u32 r_lo = mode_bits ? r : 0, r_hi = mode_bits ? r + 1 : nbytes;
+    for (u32 rr = r_lo; rr < r_hi; rr++) {
+        const long long ones = cell(rr, 24);          // sum of the digits of this row: the "-128" bias of the eq bytes
+        __int128 t = 0;
+        for (u32 u = 0; u < 8; u++) t += (__int128)(cell(rr, 8 * q + u) + 128 * ones) << (8 * u);
+        val = fq_add(val, fq_mul(fq_from_s128((u64)t, (int64_t)(t >> 64)), pw));
+        pw = fq_mul(pw, 256);
+    }
+    if (mode_bits) out[((size_t)(k0 + r) * 24 + c) * 3 + q] = val;
+    else out[(size_t)c * 3 + q] = val;
+}
+size_t coef_eval_i8_eb_bytes(size_t n) { return 24 * ((n + 15) / 16 * 16) + 64; }
+size_t coef_eval_i8_part_words(u32 nwg) { return (size_t)nwg * 24 * 2 * 256; }
+// planes [24][ldp] (n columns from the pointer), eq [3][ldeq] (same columns), K planes (mode_bits) or the coefficients themselves (mode 0, bound =
+// max |coefficient|).  EB / part / sum: scratch (coef_eval_i8_eb_bytes, coef_eval_i8_part_words(nwg), 24*2*256 words).  Returns 0, or -1 if the
+// shape is not handled (caller falls back to k_coef_eval).
+int launch_coef_eval_i8(const int32_t *planes, size_t ldp, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 bound, unsigned char *EB, u32 nwg,
+                        int32_t *part, long long *sum, u64 *out, hipStream_t s) {
+    if (!n || (mode_bits && K == 0)) return -1;
+    u32 nbytes = 0;
+    if (!mode_bits) {   // balanced base-256 digits needed for |v| <= bound
+        u64 cap = 127;
+        nbytes = 1;
+        while (cap < bound && nbytes < 4) { cap = cap * 256 + 127; nbytes++; }
+        if (cap < bound) return -1;
+    }
+    const size_t ldb = (n + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_eq_pack_i8, dim3((unsigned)cdiv((n + 15) / 16 * 24, 256)), dim3(256), 0, s, eq, ldeq, n, ldb, EB);
+    const size_t nsteps = (n + 63) / 64;
+    if (nwg > nsteps) nwg = (u32)nsteps;
+    CoefEvalI8Args a;
+    a.planes = planes; a.ldp = ldp; a.n = n; a.EB = EB; a.ldb = ldb;
+    a.steps_per_wg = (u32)((nsteps + nwg - 1) / nwg);
+    const u32 grid = (u32)((nsteps + a.steps_per_wg - 1) / a.steps_per_wg);
+    a.part = part;
+    const size_t per_wg = 24 * 2 * 256;
+    const u32 total_rows = mode_bits ? K : nbytes;
+    for (u32 k0 = 0; k0 < total_rows; k0 += 16) {
+        a.k0 = k0;
+        a.rows = total_rows - k0 < 16 ? total_rows - k0 : 16;
+        if (mode_bits) hipLaunchKernelGGL(k_coef_eval_i8<1>, dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_coef_eval_i8<0>, dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg, 256)), dim3(256), 0, s, part, per_wg, part, 0u, grid, sum);
+        hipLaunchKernelGGL(k_coef_eval_i8_finish, dim3((unsigned)cdiv(mode_bits ? a.rows * 72 : 72, 256)), dim3(256), 0, s, sum, k0, a.rows, mode_bits, nbytes, out);
+    }
+    return 0;
+}
 }  // namespace lf

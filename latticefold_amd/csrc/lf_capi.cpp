@@ -1416,6 +1416,7 @@ static bool lcccs_point(const lf_params &P, const u64 *lcccs, std::vector<Fq3> &
     return true;
 }
 
+static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial, u64 *od, size_t ldp);
 static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_witness *wit, u64 *lcccs_out, u64 *proof, u64 **eq_r_keep) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n;
@@ -1451,7 +1452,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     {   // T[24][3] flat == v[3][8 slots][3]; sharded: each rank sums its index slice, partial sums exchanged on the device
         size_t i0, cnt;
         shard_slice(c, c->N, &i0, &cnt);
-        launch_coef_eval(c->dcrt, wit->planes + i0, cnt, eqr + i0, m, 1, 0, partial, od, c->stream(), c->N);
+        RET(coef_eval_dev(c, wit->planes + i0, cnt, eqr + i0, m, 1, 0, partial, od, c->N));
         RET(exchange_modsum_dev(c, od, 72));
     }
     if (u_eval) {
@@ -1551,6 +1552,23 @@ static int decompose_commit_finish(lf_ctx *c, const u64 *cm, u64 *yd, size_t ev,
     return LF_OK;
 }
 
+// v / v_s / theta: sum_j eq[j] * (digit planes or coefficients of the witness planes) -> od (device, canonical).  On the int8 matrix cores
+// (launch_coef_eval_i8) unless LF_COEF_VALU is set or the shape is not handled there.
+static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial, u64 *od, size_t ldp) {
+    if (!c->tn.coef_valu && n >= 64) {
+        unsigned char *EB;
+        int32_t *part;
+        long long *sum;
+        const u32 nwg = 512;
+        RET(c->tbuf("ce_eb", coef_eval_i8_eb_bytes(n), &EB));
+        RET(c->tbuf("ce_part", coef_eval_i8_part_words(nwg), &part));
+        RET(c->tbuf("ce_sum", (size_t)24 * 2 * 256, &sum));
+        if (launch_coef_eval_i8(planes, ldp ? ldp : n, n, eq, ldeq, K, mode_bits, c->P.B / 2, EB, nwg, part, sum, od, c->stream()) == 0) return LF_OK;
+    }
+    launch_coef_eval(c->dcrt, planes, n, eq, ldeq, K, mode_bits, partial, od, c->stream(), ldp);
+    return LF_OK;
+}
+
 // the point-dependent half of LFDecompositionProver::prove (decomposition.rs:33-88): x_s, v_s, z_k, u_s
 static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &rpt, const lf_witness *wit, const char *side,
                            u64 *eq_r /* built already or nullptr */, SideState &S, u64 *proof) {
@@ -1576,7 +1594,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     {
         size_t i0, cnt;
         shard_slice(c, N, &i0, &cnt);   // sharded: this rank's index slice; partial sums exchanged on the device
-        launch_coef_eval(c->dcrt, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od, c->stream(), N);
+        RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od, N));
         RET(exchange_modsum_dev(c, od, (size_t)K * 72));
     }
     RET(down_small(c, od, (size_t)K * 72, v_s));
@@ -2001,7 +2019,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     {
         size_t i0, cnt;
         shard_slice(c, N, &i0, &cnt);
-        for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dcrt, S[sd].planes + i0, cnt, eq0 + i0, m, K, 1, red, d_theta + (size_t)sd * K * 72, c->stream(), N);
+        for (int sd = 0; sd < 2; sd++) RET(coef_eval_dev(c, S[sd].planes + i0, cnt, eq0 + i0, m, K, 1, red, d_theta + (size_t)sd * K * 72, N));
         RET(exchange_modsum_dev(c, d_theta, (size_t)K2 * 72));
     }
     HIPCHK(hipMemcpyAsync(hp, d_theta, (size_t)K2 * 72 * 8, hipMemcpyDeviceToHost, c->stream()));

@@ -64,6 +64,7 @@ struct Tunables {
     bool shard_plain_rounds = false; // LF_SHARD_PLAIN_ROUNDS: sharded folding rounds on materialised tables only (no fused fix / look-up-table rounds)
     bool shard_two_lanes = false;    // LF_SHARD_TWO_LANES: threaded two-lane schedule also in a sharded step (default there: one host thread)
     bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
+    bool coef_valu = false;          // LF_COEF_VALU: v / v_s / theta evaluations of the digit planes on the VALU kernel (k_coef_eval) instead of the matrix cores
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
     bool no_tail = false;            // LF_NO_TAIL: keep one launch set + stream sync per tail round instead of the persistent tail kernel
     size_t fuse_min = 16384, lut_min = (size_t)1 << 17, tab_min = 16384;
@@ -81,6 +82,7 @@ struct Tunables {
         t.theta_eval = getenv("LF_THETA_EVAL") != nullptr;
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;
         t.ajtai_valu = getenv("LF_AJTAI_VALU") != nullptr;
+        t.coef_valu = getenv("LF_COEF_VALU") != nullptr;
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
         t.shard_two_lanes = getenv("LF_SHARD_TWO_LANES") != nullptr;
         t.shard_plain_rounds = getenv("LF_SHARD_PLAIN_ROUNDS") != nullptr;
