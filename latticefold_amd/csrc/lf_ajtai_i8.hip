@@ -421,21 +421,22 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
 // the byte-packed eq table (k_eq_pack_i8, once per evaluation point).  Was k_coef_eval: masked +-eq additions on the VALU, 0.72 ms per call
 // at 2^20 columns.
 // =====================================================================================================================================
-// EB[(8 q + u)][n] = byte u of eq[q][j] ^ 0x80;  thread = (16 columns, one of the 24 byte planes)
+// EB[(8 q + u)][n] = byte u of eq[q][j] ^ 0x80;  thread = (16 columns, word q): 16 words in, the 8 byte planes of that word out
 __global__ void __launch_bounds__(256) k_eq_pack_i8(const u64 *eq, size_t ld, size_t n, size_t ldb, unsigned char *EB) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, groups = (n + 15) / 16;
-    if (gid >= groups * 24) return;
-    const u32 col = (u32)(gid / groups), q = col >> 3, u = col & 7;
+    if (gid >= groups * 3) return;
+    const u32 q = (u32)(gid / groups);
     const size_t j0 = (gid % groups) * 16;
-    unsigned char b[16];
+    u64 w[16];
 #pragma unroll
-    for (int t = 0; t < 16; t++) b[t] = j0 + t < n ? (unsigned char)(((eq[(size_t)q * ld + j0 + t] >> (8 * u)) & 0xFF) ^ 0x80) : 0x80;   // 0x80 = biased zero
-    uint4 w;
-    w.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((u32)b[3] << 24);
-    w.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((u32)b[7] << 24);
-    w.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((u32)b[11] << 24);
-    w.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((u32)b[15] << 24);
-    *(uint4 *)(EB + (size_t)col * ldb + j0) = w;
+    for (int t = 0; t < 16; t++) w[t] = j0 + t < n ? eq[(size_t)q * ld + j0 + t] ^ 0x8080808080808080ull : 0x8080808080808080ull;   // 0x80 = biased zero
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 16; t++) o[t >> 2] |= (u32)((w[t] >> (8 * u)) & 0xFF) << (8 * (t & 3));
+        *(uint4 *)(EB + (size_t)(8 * q + u) * ldb + j0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 // digit of a row: MODE 1 = balanced binary digit k0 + k of |v| with the sign of v (row = plane k, one tile per coefficient);
 // MODE 0 = balanced base-256 digit (row & 3) of v: v = sum_k b_k 256^k with b_k in [-128, 127] (4 digits cover |v| <= 127 (256^4 - 1) / 255
@@ -563,7 +564,7 @@ int launch_coef_eval_i8(const int32_t *planes, size_t ldp, size_t n, const u64 *
         if (cap < bound) return -1;
     }
     const size_t ldb = (n + 15) / 16 * 16;
-    hipLaunchKernelGGL(k_eq_pack_i8, dim3((unsigned)cdiv((n + 15) / 16 * 24, 256)), dim3(256), 0, s, eq, ldeq, n, ldb, EB);
+    hipLaunchKernelGGL(k_eq_pack_i8, dim3((unsigned)cdiv((n + 15) / 16 * 3, 256)), dim3(256), 0, s, eq, ldeq, n, ldb, EB);
     const size_t nsteps = (n + 63) / 64;
     if (nwg > nsteps) nwg = (u32)nsteps;
     CoefEvalI8Args a;
