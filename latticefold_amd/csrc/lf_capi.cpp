@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -1399,9 +1400,8 @@ static int build_z(lf_ctx *c, const int32_t *planes, u32 K, int mode_bits, const
             for (int w = 0; w < 24; w++) h[((size_t)k * 24 + w) * hl + i] = heads[((size_t)k * hl + i) * 24 + w];
     u64 *stage;
     RET(c->tbuf("z_heads", h.size(), &stage));
-    HIPCHK(hipMemcpyAsync(stage, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream()));
+    RET(c->h2d_small(stage, h.data(), h.size() * 8));   // pinned ring: no synchronisation for the stack buffer
     HIPCHK(hipMemcpy2DAsync(z, c->n * 8, stage, hl * 8, hl * 8, (size_t)K * 24, hipMemcpyDeviceToDevice, c->stream()));
-    HIPCHK(hipStreamSynchronize(c->stream()));
     return LF_OK;
 }
 
@@ -1504,10 +1504,14 @@ static void compute_x_s(const lf_ctx *c, const u64 *xh /* (l+1) NTT */, u64 *x_s
 }
 
 struct SideState {
-    const int32_t *planes;
-    u64 *z;       // [K][24][n]
-    u64 *eq_r;    // [3][m]
+    const int32_t *planes = nullptr;
+    u64 *z = nullptr;       // [K][24][n]
+    u64 *eq_r = nullptr;    // [3][m]
     std::vector<u64> lcccs;  // K flat LCCCS (host)
+    // z_k (and x_s in the proof) may be built ahead of the evaluation point by the other lane (decompose_prepare_z): 1 = published
+    // (z, x_s valid once z_ev has completed), -1 = that lane failed, 0 = nobody built it yet
+    std::atomic<int> z_state{0};
+    hipEvent_t z_ev = nullptr;
 };
 
 // LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
@@ -1570,6 +1574,23 @@ static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *
 }
 
 // the point-dependent half of LFDecompositionProver::prove (decomposition.rs:33-88): x_s, v_s, z_k, u_s
+// The part of a decomposition's evaluations that does not depend on the evaluation point: x_s (host, into the proof) and the K vectors
+// z_k = x_s[k] || w_k on the device.  Runs on the calling lane; another lane's consumer waits for S.z_ev on its own stream.
+static int decompose_prepare_z(lf_ctx *c, const u64 *xh /* (l+1) elements: x_w || h */, const lf_witness *wit, const char *side, SideState &S, u64 *proof) {
+    const lf_params &P = c->P;
+    u32 K = P.K;
+    u64 *x_s = proof + (size_t)K * P.t * 24 + (size_t)K * 72, *z;
+    int rc = c->tbuf("z_" + std::string(side), (size_t)K * 24 * c->n, &z);
+    if (rc == LF_OK) {
+        compute_x_s(c, xh, x_s);
+        rc = build_z(c, wit->planes, K, 1, x_s, z);
+    }
+    if (rc == LF_OK && !S.z_ev && hipEventCreateWithFlags(&S.z_ev, hipEventDisableTiming) != hipSuccess) rc = LF_ERR_HIP;
+    if (rc == LF_OK && hipEventRecord(S.z_ev, c->stream()) != hipSuccess) rc = LF_ERR_HIP;
+    S.z = z;
+    S.z_state.store(rc == LF_OK ? 1 : -1, std::memory_order_release);
+    return rc;
+}
 static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &rpt, const lf_witness *wit, const char *side,
                            u64 *eq_r /* built already or nullptr */, SideState &S, u64 *proof) {
     const lf_params &P = c->P;
@@ -1577,29 +1598,30 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     u32 K = P.K;
     std::string sd(side);
     const u64 *xh = lcccs + ((size_t)P.s + 3 + P.kappa + P.t) * 24;
-    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24, *x_s = v_s + (size_t)K * 72;
-    u64 *partial, *od, *z, *q;
+    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24;
+    u64 *partial, *od, *q;
     RET(c->tbuf("red_partial", 256 * 4096, &partial));
     RET(c->tbuf("dec_small", 32 * 72 + 32 * 4 * 24 + 64, &od));
-    RET(c->tbuf("z_" + sd, (size_t)K * 24 * n, &z));
     RET(c->tbuf("dec_q", (size_t)P.t * 24 * n, &q));
+    u64 *od_v = od, *od_u = od + 32 * 72;
     if (!eq_r) {
         RET(c->tbuf("eq_r_" + sd, 3 * m, &eq_r));
         RET(build_eq_dev(c, rpt.data(), P.s, eq_r));
     }
-    S.planes = wit->planes; S.z = z; S.eq_r = eq_r;
+    S.planes = wit->planes; S.eq_r = eq_r;
     size_t ph = c->ev_begin(12);
-    compute_x_s(c, xh, x_s);
+    // z_k: built here unless the other lane has published it already (it does not depend on the point)
+    if (S.z_state.load(std::memory_order_acquire) == 1) HIPCHK(hipStreamWaitEvent(c->stream(), S.z_ev, 0));
+    else RET(decompose_prepare_z(c, xh, wit, side, S, proof));
+    u64 *z = S.z;
     // v_s (decomposition.rs:204-211) from the coefficient planes
     {
         size_t i0, cnt;
         shard_slice(c, N, &i0, &cnt);   // sharded: this rank's index slice; partial sums exchanged on the device
-        RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od, N));
-        RET(exchange_modsum_dev(c, od, (size_t)K * 72));
+        RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od_v, N));
+        RET(exchange_modsum_dev(c, od_v, (size_t)K * 72));
     }
-    RET(down_small(c, od, (size_t)K * 72, v_s));
-    // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
-    RET(build_z(c, wit->planes, K, 1, x_s, z));
+    // u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     for (u32 j = 0; j < P.t; j++)
         launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->stream());
     u64 *dpart;
@@ -1607,10 +1629,18 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     {
         size_t c0, cnt;
         shard_slice(c, n, &c0, &cnt);   // sharded: dot products over this rank's column slice of z_k and q_j
-        launch_dot_batch(c->dcrt, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od, c->stream());
-        RET(exchange_modsum_dev(c, od, (size_t)K * P.t * 24));
+        launch_dot_batch(c->dcrt, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od_u, c->stream());
+        RET(exchange_modsum_dev(c, od_u, (size_t)K * P.t * 24));
     }
-    RET(down_small(c, od, (size_t)K * P.t * 24, u_s));
+    // one download (one stream synchronisation) for both result sets
+    {
+        const size_t words = (size_t)32 * 72 + (size_t)K * P.t * 24;
+        RET(c->pin(words));
+        HIPCHK(hipMemcpyAsync(c->h_pin_ref(), od, words * 8, hipMemcpyDeviceToHost, c->stream()));
+        RET(c->lane_sync());
+        memcpy(v_s, c->h_pin_ref(), (size_t)K * 72 * 8);
+        memcpy(u_s, c->h_pin_ref() + 32 * 72, (size_t)K * P.t * 24 * 8);
+    }
     LF_TRACE(c, "decompose evals");
     c->ev_end(ph);
     return LF_OK;
@@ -2217,6 +2247,10 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     } else {
     c->lane1.submit([&]() -> int {
         t_lane = 1;
+        struct Publish {   // whatever path this lane takes, the main thread learns whether the right side's z_k are coming
+            SideState &s;
+            ~Publish() { int e = 0; s.z_state.compare_exchange_strong(e, -1, std::memory_order_release); }
+        } publish{S[1]};
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
         u64 *yd = nullptr;
         size_t ev = 0;
@@ -2224,6 +2258,12 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));
         RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
         RET(decompose_commit_enqueue(c, w_i, &yd, &ev));               // right commit in flight ...
+        {   // ... and the right side's z_k behind it: they depend on the witness and on x_w || h = x_ccs || 1 only, not on the point r
+            std::vector<u64> xh((size_t)(P.l + 1) * 24);
+            memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
+            HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
+            (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
+        }
         if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
         return decompose_commit_finish(c, cm_i, yd, ev, decr);          // cm of the linearized instance = cm_i.cm
@@ -2241,6 +2281,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     lin_done_p.set_value(rc);
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
+        while (S[1].z_state.load(std::memory_order_acquire) == 0) std::this_thread::yield();   // published by lane 1 within its first millisecond (or -1)
         rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
     }
     TL_MARK("right evals done");
