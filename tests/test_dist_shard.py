@@ -60,7 +60,7 @@ def _free_port():
 # "big": the thresholds of the large-instance round modes (fused fix, look-up-table rounds 2-4) lowered so that a 2^12 / 2^14-row instance takes
 # them -- in the sharded run on the ranks' pair slices, in the unsharded reference on whole tables
 @pytest.mark.parametrize("world,cases,two_lanes", [(2, "T10,G5,T12", False), (4, "T12", False), (2, "T12", True), (2, "B8,B10,BDP", False), (4, "B14", False),
-                                                   (2, "T12,T14", "big"), (4, "T14", "big"), (2, "T12", "plain")])
+                                                   (2, "T12,T14", "big"), (4, "T14", "big"), (2, "T12", "plain"), (8, "T14", "big")])
 def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
