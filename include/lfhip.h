@@ -271,6 +271,9 @@ const char *lf_phase_name(int i);
  * the Ajtai kernel in the last fold step */
 int lf_last_kernel_stats(lf_ctx *, float *fold_round_ms, int *fold_round_launches, float *ajtai_ms, int *ajtai_launches);
 
+/* which rounds of the last folding sumcheck ran as int8 matrix-core GEMMs (bit i-1 = round i; lf_sv_rounds.h) -- test hook */
+int lf_last_fold_paths(lf_ctx *, unsigned *sv_round_mask);
+
 /* NIFSVerifier::verify (nifs.rs:117-163) on the host: O(proof size), NO GPU and no lf_ctx needed.  The CCS enters only
  * through its shape (lf_params), the multisets S (S_off[q+1], S_idx) and the coefficients c (q ring elements) -- the
  * verifier never touches the matrices (linearization.rs:220-243).  `t` is a transcript of the same ring in the state the

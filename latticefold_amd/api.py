@@ -151,6 +151,7 @@ def _lib():
         L.lf_phase_name.restype = C.c_char_p
         L.lf_phase_name.argtypes = [C.c_int]
         L.lf_verify_host.argtypes = [C.c_int, C.POINTER(Params), u32p, u32p, u64p, vp, u64p, u64p, u64p, u64p, C.POINTER(C.c_int)]
+        L.lf_last_fold_paths.argtypes = [vp, C.POINTER(C.c_uint)]
         L.lf_last_kernel_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
@@ -361,6 +362,11 @@ class Context:
         out = (C.c_float * 8)()
         _chk(_lib().lf_last_phase_ms(self.h, out), "lf_last_phase_ms")
         return {_lib().lf_phase_name(i).decode(): float(out[i]) for i in range(8)}
+
+    def fold_paths(self):
+        m = C.c_uint()
+        _chk(_lib().lf_last_fold_paths(self.h, C.byref(m)), "lf_last_fold_paths")
+        return m.value
 
     def kernel_stats(self):
         f, a = C.c_float(), C.c_float()

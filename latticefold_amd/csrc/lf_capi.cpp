@@ -180,6 +180,7 @@ struct lf_ctx {
     float k_fold_ms = 0, k_ajtai_ms = 0;
     int k_fold_n = 0, k_ajtai_n = 0;
     double host_tr_ms = 0;
+    unsigned sv_round_mask = 0;      // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
 
     int buf(const std::string &name, size_t bytes, void **out) {
         DevBuf *b;
@@ -1777,6 +1778,55 @@ static int fold_tail_rounds(lf_ctx *c, Transcript &tr, const FoldRoundArgs &a, u
     return tail_host_rounds(c, tr, A.epoch, nr, deg + 1, A.dev_transcript != 0, msgs + (size_t)(round - 1) * (deg + 1) * 24, &pt[round - 1]);
 }
 
+// C_pi(X) of lf_sv_rounds.h for the V weights W_b = eq((r_1..), b): coefficient table [pairs][4][3] (internal basis words)
+static void sv_build_coef(lf_ctx *c, int V, const Fq3 *W, std::vector<u64> &out) {
+    const int NX = 2 * V, NPR = sv_num_pairs(V);
+    std::vector<Fq3> C((size_t)NPR * 4, fq3_zero());
+    std::vector<SvPair> prs(NPR);
+    for (int i = 0; i < NPR; i++) prs[i] = sv_pair(V, i);
+    auto find = [&](unsigned s, unsigned b) {
+        for (int i = 0; i < NPR; i++)
+            if (prs[i].s == s && prs[i].b == b) return i;
+        return -1;
+    };
+    // w_x(X) = wa_x + wb_x X
+    std::vector<Fq3> wa(NX), wb(NX);
+    for (int x = 0; x < NX; x++) {
+        if (x < V) { wa[x] = W[x]; wb[x] = fq3_neg(W[x]); }
+        else { wa[x] = fq3_zero(); wb[x] = W[x - V]; }
+    }
+    // h^3: multisets {x <= y <= z} with their multinomial multiplicity
+    for (int x = 0; x < NX; x++)
+        for (int y = x; y < NX; y++) {
+            const Fq3 p2[3] = {c->ring.mul3(wa[x], wa[y]), fq3_add(c->ring.mul3(wa[x], wb[y]), c->ring.mul3(wb[x], wa[y])), c->ring.mul3(wb[x], wb[y])};
+            for (int z = y; z < NX; z++) {
+                Fq3 p3[4];
+                p3[0] = c->ring.mul3(p2[0], wa[z]);
+                p3[1] = fq3_add(c->ring.mul3(p2[0], wb[z]), c->ring.mul3(p2[1], wa[z]));
+                p3[2] = fq3_add(c->ring.mul3(p2[1], wb[z]), c->ring.mul3(p2[2], wa[z]));
+                p3[3] = c->ring.mul3(p2[2], wb[z]);
+                int mult, idx;
+                if (x == y && y == z) { mult = 1; idx = find(1u << x, 1u << x); }
+                else if (x == y) { mult = 3; idx = find(1u << z, (1u << x) | (1u << z)); }      // y_x^2 y_z = b_x y_z
+                else if (y == z) { mult = 3; idx = find(1u << x, (1u << x) | (1u << y)); }      // y_x y_y^2 = y_x b_y
+                else { mult = 6; const unsigned mk = (1u << x) | (1u << y) | (1u << z); idx = find(mk, mk); }
+                for (int e = 0; e < 4; e++) {
+                    Fq3 t = p3[e], acc = fq3_zero();
+                    for (int i = 0; i < mult; i++) acc = fq3_add(acc, t);
+                    C[(size_t)idx * 4 + e] = fq3_add(C[(size_t)idx * 4 + e], acc);
+                }
+            }
+        }
+    for (int x = 0; x < NX; x++) {   // - h
+        const int idx = find(1u << x, 1u << x);
+        C[(size_t)idx * 4] = fq3_sub(C[(size_t)idx * 4], wa[x]);
+        C[(size_t)idx * 4 + 1] = fq3_sub(C[(size_t)idx * 4 + 1], wb[x]);
+    }
+    out.resize((size_t)NPR * 12);
+    for (size_t i = 0; i < (size_t)NPR * 4; i++)
+        for (int q = 0; q < 3; q++) out[i * 3 + q] = C[i].c[q];
+}
+
 // LFFoldingProver::prove (nifs/folding.rs:42-130)
 static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcccs_out, lf_witness **w_out, u64 *proof) {
     const lf_params &P = c->P;
@@ -1872,6 +1922,9 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     const size_t tab_min = c->tn.tab_min;   // pairs; rounds 1-2 as table look-ups above this
     const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !c->tn.fold_no_lut;
     u64 *d_lut = nullptr;
+    c->sv_round_mask = 0;
+    u32 *sv_bits[2] = {nullptr, nullptr};
+    const bool use_sv = Gw == 1 && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && !c->tn.fold_tab_r1;
     for (u32 round = 1; round <= P.s; round++) {
         fmode = 0;
         // Persistent tail: once the materialised tables are small, ONE kernel runs all remaining rounds and exchanges messages /
@@ -1967,6 +2020,34 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
     tables_ready:
         size_t ev = c->ev_begin(0);
+        const int svV = 1 << (round - 1);
+        if (use_sv && !sharded && (int)round <= c->tn.sv_rounds && round <= 3 && a.p0 == 0 && a.pcnt >= c->tn.sv_min && sv_shape_ok(svV, a.pcnt, K)) {
+            // rounds 1..3 as exact int8 GEMMs on the matrix cores (lf_sv_rounds.h): G part on the VALU, norm part from the witness planes
+            std::vector<Fq3> W((size_t)svV, fq3_one());
+            for (int b = 0; b < svV; b++)
+                for (u32 j = 0; j + 1 < round; j++) W[b] = c->ring.mul3(W[b], ((b >> j) & 1) ? pt[j] : fq3_sub(fq3_one(), pt[j]));
+            std::vector<u64> coef;
+            sv_build_coef(c, svV, W.data(), coef);
+            u64 *d_coef, *gtmp, *svtp;
+            unsigned char *sveb;
+            int32_t *svpart, *svtot;
+            RET(c->tbuf("sv_coef", coef.size() + 8, &d_coef));
+            RET(c->tbuf("sv_gtmp", 128, &gtmp));
+            RET(c->tbuf("sv_tp", sv_tp_words(K), &svtp));
+            RET(c->tbuf("sv_eb", sv_eb_bytes(a.pcnt), &sveb));
+            RET(c->tbuf("sv_part", sv_part_words(svV, a.pcnt, K), &svpart));
+            RET(c->tbuf("sv_tot", sv_tot_words(svV, K), &svtot));
+            RET(c->h2d_small(d_coef, coef.data(), coef.size() * 8));
+            if (!sv_bits[0])   // bit-plane form of the two witnesses, once per step
+                for (int sd = 0; sd < 2; sd++) {
+                    RET(c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(N, K), &sv_bits[sd]));
+                    launch_sv_bits(S[sd].planes, N, N, K, sv_bits[sd], c->stream());
+                }
+            launch_fold_round_g(c->dcrt, a, partial, gtmp, c->stream());
+            if (launch_sv_round(c->dcrt, svV, sv_bits[0], sv_bits[1], N, a.eqB, a.ld, a.pcnt, K, d_mu, d_coef, sveb, svpart, svtot, svtp, gtmp, od, c->stream()) != 0)
+                return LF_ERR_UNSUPPORTED;
+            c->sv_round_mask |= 1u << (round - 1);
+        } else
         if ((round == 2 || (round == 1 && c->tn.fold_tab_r1)) && a.pcnt >= tab_min) {
             // round 2 (round 1 only on request: its integer kernel is faster than the gathers) as table look-ups: coefficient quadruples of h^3 - h for the 9 / 81 digit codes of a pair (host), times mu_kd (device)
             const int nd = round == 1 ? 2 : 4, ncode = round == 1 ? 9 : 81;
@@ -2616,6 +2697,11 @@ int lf_last_phase_ms(lf_ctx *c, float *out) {
     if (!c || !out) return LF_ERR_INVALID;
     if (c->bb) return c->bb->last_phase_ms(out);
     for (int i = 0; i < LF_N_PHASES; i++) out[i] = c->phase_ms[i];
+    return LF_OK;
+}
+int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
+    if (!c || !sv_round_mask) return LF_ERR_INVALID;
+    *sv_round_mask = c->bb ? 0u : c->sv_round_mask;
     return LF_OK;
 }
 int lf_last_kernel_stats(lf_ctx *c, float *fold_ms, int *fold_n, float *aj_ms, int *aj_n) {

@@ -66,6 +66,9 @@ struct Tunables {
     bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
     bool coef_valu = false;          // LF_COEF_VALU: v / v_s / theta evaluations of the digit planes on the VALU kernel (k_coef_eval) instead of the matrix cores
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
+    bool fold_no_sv = false;         // LF_FOLD_NO_SV: rounds 1-3 of the folding sumcheck on the VALU kernels instead of the int8 matrix-core GEMMs (lf_sv_rounds.hip)
+    size_t sv_min = 8192;            // LF_FOLD_SV_MIN: pairs of a round from which the GEMM form is used
+    int sv_rounds = 3;               // LF_FOLD_SV_ROUNDS: last round in GEMM form (1..3)
     bool no_tail = false;            // LF_NO_TAIL: keep one launch set + stream sync per tail round instead of the persistent tail kernel
     size_t fuse_min = 16384, lut_min = (size_t)1 << 17, tab_min = 16384;
     size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
@@ -81,6 +84,9 @@ struct Tunables {
         t.fold_no_mutab = getenv("LF_FOLD_NO_MUTAB") != nullptr;
         t.theta_eval = getenv("LF_THETA_EVAL") != nullptr;
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;
+        t.fold_no_sv = getenv("LF_FOLD_NO_SV") != nullptr;
+        if ((e = getenv("LF_FOLD_SV_MIN"))) t.sv_min = (size_t)atoll(e);
+        if ((e = getenv("LF_FOLD_SV_ROUNDS"))) t.sv_rounds = atoi(e);
         t.ajtai_valu = getenv("LF_AJTAI_VALU") != nullptr;
         t.coef_valu = getenv("LF_COEF_VALU") != nullptr;
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);

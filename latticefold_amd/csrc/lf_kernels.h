@@ -7,6 +7,7 @@
 //   Ajtai matrix : u64 [kappa][24][n]
 #pragma once
 #include "lf_ajtai_i8.h"
+#include "lf_sv_rounds.h"
 #include <hip/hip_runtime.h>
 
 #include "lf_host.h"
@@ -137,6 +138,8 @@ struct FoldRoundArgs {
 // round 1 of the folding sumcheck straight from the coefficient planes (f-hat virtual, b = 2)
 void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                         u32 K, const Fq3Const *mu_pow_dev /*2K*3*/, u64 *partial, u64 *out, hipStream_t s);
+// G part (eqL*G1 + eqR*G2) of a round message: out[X*24 + 3*slot + q], X = 0..4 (the norm part: lf_sv_rounds.h)
+void launch_fold_round_g(const DevCrt &t, const FoldRoundArgs &a, u64 *partial, u64 *out, hipStream_t s);
 // after r_1: materialise fixed f-hat tables F[2K*3][24][n/2] = f0 + r1*(f1-f0)
 void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int32_t *planesR, size_t n_planes, size_t m, u32 K,
                              Fq3Const r1, u64 *F, hipStream_t s);

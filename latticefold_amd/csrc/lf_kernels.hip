@@ -1224,9 +1224,29 @@ void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, s
 // folding sumcheck (comb = nifs/folding/utils.rs:273-325, b = 2):
 //   g(X) = eqL*G1 + eqR*G2 + eqB * sum_{k,d} mu_k^{d+1} * fhat_kd (fhat_kd^2 - 1)
 // Both kernels evaluate the pair-polynomials in coefficient form (exact in F_p, identical sums).
+// G part in coefficient form: gco += coefficients of (e0 + X de)(g0 + X dg) for the two halves.  The callers evaluate the accumulated
+// quadratic at X = 0..4 ONCE per thread (add_poly_evals) instead of once per pair (was: 36 small-constant field products per pair and slot).
 template <bool NU>
-__device__ __forceinline__ void fold_g13(Fq3 (&acc)[5], const FoldRoundArgs &a, u32 slot, size_t p, u64 nu) {
-    // (e0 + X de)(g0 + X dg) for the two halves
+__device__ __forceinline__ void fold_g13(Fq3 (&gco)[3], const FoldRoundArgs &a, u32 slot, size_t p, u64 nu) {
+    for (int h = 0; h < 2; h++) {
+        const u64 *eq = h ? a.eqR : a.eqL;
+        const u64 *G = h ? a.G2 : a.G1;
+        ulonglong2 e0 = *(const ulonglong2 *)(eq + 2 * p), e1 = *(const ulonglong2 *)(eq + a.ld + 2 * p), e2 = *(const ulonglong2 *)(eq + 2 * a.ld + 2 * p);
+        const u64 *gp = G + (size_t)(3 * slot) * a.ld;
+        ulonglong2 g0 = *(const ulonglong2 *)(gp + 2 * p), g1 = *(const ulonglong2 *)(gp + a.ld + 2 * p), g2 = *(const ulonglong2 *)(gp + 2 * a.ld + 2 * p);
+        Fq3 ea = fq3_make(e0.x, e1.x, e2.x), eb = fq3_make(e0.y, e1.y, e2.y);
+        Fq3 ga = fq3_make(g0.x, g1.x, g2.x), gb = fq3_make(g0.y, g1.y, g2.y);
+        Fq3 co[3];
+        co[0] = M3<NU>(ea, ga, nu);
+        co[2] = M3<NU>(fq3_sub(eb, ea), fq3_sub(gb, ga), nu);
+        co[1] = fq3_sub(fq3_sub(M3<NU>(eb, gb, nu), co[0]), co[2]);
+#pragma unroll
+        for (int e = 0; e < 3; e++) gco[e] = fq3_add(gco[e], co[e]);
+    }
+}
+// the same with the evaluations at X = 0..4 added per pair (k_fold_round: no registers to spare for the coefficient accumulators)
+template <bool NU>
+__device__ __forceinline__ void fold_g13_evals(Fq3 (&acc)[5], const FoldRoundArgs &a, u32 slot, size_t p, u64 nu) {
     for (int h = 0; h < 2; h++) {
         const u64 *eq = h ? a.eqR : a.eqL;
         const u64 *G = h ? a.G2 : a.G1;
@@ -1274,8 +1294,9 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, 
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    Fq3 gco[3] = {fq3_zero(), fq3_zero(), fq3_zero()};   // G part, coefficient form
     for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
-        fold_g13<NU>(acc, a, slot, p, t.nu);
+        fold_g13<NU>(gco, a, slot, p, t.nu);
         // cubic coefficients of sum_kd mu_kd * P(f0 + X*df): integer parts split in lo/hi 32-bit halves of mu
         int64_t lo[4][3], hi[4][3];
         int32_t cs[4] = {0, 0, 0, 0};
@@ -1318,6 +1339,7 @@ __global__ void __launch_bounds__(256) k_fold_round1(DevCrt t, FoldRoundArgs a, 
             }
         fold_g2_finish<NU>(acc, Q, a, p, t.nu);
     }
+    add_poly_evals<5>(acc, gco, 3);
     store_round_partial(acc, slot, partial);
 }
 void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
@@ -1326,6 +1348,27 @@ void launch_fold_round1(const DevCrt &t, const FoldRoundArgs &a, const int32_t *
     if (gb > RED_BLOCKS) gb = RED_BLOCKS;
     if (gb < 1) gb = 1;
     LF_LAUNCH(k_fold_round1, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, planesL, planesR, n_planes, K, mu_pow_dev, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
+}
+
+// G part of a round message only (eqL*G1 + eqR*G2): the norm part comes from the int8 GEMM of lf_sv_rounds.hip
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_round_g(DevCrt t, FoldRoundArgs a, u64 *partial) {
+    u32 slot = blockIdx.y;
+    const size_t pend = a.p0 + a.pcnt;
+    Fq3 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    Fq3 gco[3] = {fq3_zero(), fq3_zero(), fq3_zero()};   // G part, coefficient form
+    for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) fold_g13<NU>(gco, a, slot, p, t.nu);
+    add_poly_evals<5>(acc, gco, 3);
+    store_round_partial(acc, slot, partial);
+}
+void launch_fold_round_g(const DevCrt &t, const FoldRoundArgs &a, u64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.pcnt + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    LF_LAUNCH(k_fold_round_g, t.nu2p40, dim3(gb, 8), dim3(256), s, t, a, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb, 120, out);
 }
 
@@ -1365,8 +1408,9 @@ __global__ void __launch_bounds__(256) k_fold_round_tab(DevCrt t, FoldRoundArgs 
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    Fq3 gco[3] = {fq3_zero(), fq3_zero(), fq3_zero()};   // G part, coefficient form
     for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
-        fold_g13<NU>(acc, a, slot, p, t.nu);
+        fold_g13<NU>(gco, a, slot, p, t.nu);
         u64 s64[12];      // lazy 64-bit sums with carry counters
         u32 scy[12];
 #pragma unroll
@@ -1399,6 +1443,7 @@ __global__ void __launch_bounds__(256) k_fold_round_tab(DevCrt t, FoldRoundArgs 
             for (int c = 0; c < 3; c++) Q[e].c[c] = fq_canon(fq_reduce128_loose(s64[3 * e + c], (u64)scy[3 * e + c]));
         fold_g2_finish<NU>(acc, Q, a, p, t.nu);
     }
+    add_poly_evals<5>(acc, gco, 3);
     store_round_partial(acc, slot, partial);
 }
 // poly_dev: [ncode][4][3] coefficient quadruples (c0..c3 of h^3 - h) of the 9 (round 1) / 81 (round 2) digit codes; tp_dev: 2K*3 * ncode * 12 words
@@ -1433,8 +1478,9 @@ __global__ void __launch_bounds__(256, 2) k_fold_round2(DevCrt t, FoldRoundArgs 
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    Fq3 gco[3] = {fq3_zero(), fq3_zero(), fq3_zero()};   // G part, coefficient form
     for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
-        fold_g13<NU>(acc, a, slot, p, nu);
+        fold_g13<NU>(gco, a, slot, p, nu);
         Fq3 Q[4] = {fq3_zero(), fq3_zero(), fq3_zero(), fq3_zero()};
         if (4 * p < n_planes) {
 #pragma unroll 1
@@ -1503,6 +1549,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_round2(DevCrt t, FoldRoundArgs 
         }
         fold_g2_finish<NU>(acc, Q, a, p, nu);
     }
+    add_poly_evals<5>(acc, gco, 3);
     store_round_partial(acc, slot, partial);
 }
 void launch_fold_round2(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
@@ -1660,7 +1707,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
     for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
-        if (blockIdx.z == 0) fold_g13<NU>(acc, a, slot, p, nu);
+        if (blockIdx.z == 0) fold_g13_evals<NU>(acc, a, slot, p, nu);   // per pair here: three more live F_{p^3} accumulators cost this kernel its occupancy (rounds 4-6: 5.0 -> 6.7 ms)
         // pair of table kd
         auto load_pair = [&](u32 kd, Fq3 &f0, Fq3 &df) {
             if (MODE == 0) {

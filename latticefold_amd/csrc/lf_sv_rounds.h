@@ -1,0 +1,64 @@
+// lf_sv_rounds.h -- the first rounds of the folding sumcheck as exact int8 GEMMs on the matrix cores (lf_sv_rounds.hip).
+//
+// Before round i of the folding sumcheck (nifs/folding/utils.rs:273-325, b = 2) an f-hat entry is  sum_b W_b y_b  with V = 2^(i-1) weights
+// W_b = eq((r_1..r_{i-1}), b) and ternary digits y_b; a pair of entries therefore depends on 2V "signed bits" y_x = s_x b_x (x < V: the even
+// entry, x >= V: the odd one) of 2V consecutive witness positions, and its cubic
+//     (h^3 - h)(X),   h(X) = sum_x w_x(X) y_x,   w_x = W_x (1 - X)  (x < V),   W_{x-V} X  (x >= V)
+// is a sum over "pairs" pi = (sigma, beta): a product of an odd number of signs times an AND of bits (y^2 = b, y^3 = y), with a polynomial
+// coefficient C_pi(X) that depends on the challenges only.  The round message needs
+//     sum_p eqB(p)(X) sum_tables mu_T sum_pi C_pi(X) sigma_pi(T,p) beta_pi(T,p)
+// and the inner sums over p,  M_pi[T] = sum_p eqB(2p | 2p+1) * (+-1 | 0),  are an int8 GEMM: rows = the 16 digit planes of a
+// (side, coefficient) group, inner dimension = pairs p, columns = the byte planes of eqB(2p), eqB(2p+1) (biased by -128) and a column of ones.
+// No modular multiplication touches the 2^20-entry tables any more; the field work is 2 M_pi per (table, pair).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+namespace lf {
+struct SvPair {
+    unsigned char s, b;   // subset of the 2V signed bits whose signs are multiplied / whose magnitude bits are ANDed
+};
+constexpr int sv_num_pairs(int V) { return 2 * V + 2 * V * (2 * V - 1) + 2 * V * (2 * V - 1) * (2 * V - 2) / 6; }
+// canonical order: for every z: ({z},{z}), then ({z},{q,z}) for q != z (all pairs with one sign first, grouped by that sign), then the triples
+constexpr SvPair sv_pair(int V, int idx) {
+    const int NX = 2 * V;
+    int i = 0;
+    for (int z = 0; z < NX; z++) {
+        if (i == idx) return SvPair{(unsigned char)(1u << z), (unsigned char)(1u << z)};
+        i++;
+        for (int q = 0; q < NX; q++) {
+            if (q == z) continue;
+            if (i == idx) return SvPair{(unsigned char)(1u << z), (unsigned char)((1u << z) | (1u << q))};
+            i++;
+        }
+    }
+    for (int x = 0; x < NX; x++)
+        for (int y = x + 1; y < NX; y++)
+            for (int z = y + 1; z < NX; z++) {
+                if (i == idx) {
+                    const unsigned char m = (unsigned char)((1u << x) | (1u << y) | (1u << z));
+                    return SvPair{m, m};
+                }
+                i++;
+            }
+    return SvPair{0, 0};
+}
+constexpr int sv_pairs_per_wave(int V) { return V == 1 ? 4 : (V == 2 ? 10 : 12); }
+
+bool sv_shape_ok(int V, size_t npairs, uint32_t K);
+size_t sv_eb_bytes(size_t npairs);                    // packed eqB pair bytes [48][padded pairs]
+size_t sv_part_words(int V, size_t npairs, uint32_t K);   // int32 words of the per-chunk partial tiles
+size_t sv_tot_words(int V, uint32_t K);               // int32 words of their sums
+size_t sv_tp_words(uint32_t K);                       // u64 words of the per-table polynomials
+// bit-plane form of a witness ([24][ldp] int32 planes, n positions, |v| < 2^K): rows of magnitude bits + one row of signs per coefficient
+size_t sv_bits_words(size_t n, uint32_t K);
+void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uint32_t *bits, hipStream_t s);
+// norm part of round log2(V)+1:  out[X*24 + 3*slot + q] = gpart[...] + sum_tables mu_T sum_p eqB(p)(X) (h_T^3 - h_T)(p)(X),  X = 0..4.
+// bitsL / bitsR: launch_sv_bits forms of the two witnesses (nplanes positions); eqB: [3][ldeq] with 2*npairs entries;
+// coef: [sv_num_pairs(V)][4][3] words C_pi (device); mu_pow: [2K*3].  Returns 0, or -1 if the shape is not handled.
+struct DevCrt;
+struct Fq3Const;
+int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t npairs, uint32_t K,
+                    const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
+                    hipStream_t s);
+}  // namespace lf

@@ -309,6 +309,31 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
 
 
+@pytest.mark.parametrize("name", ["T10", "T8", "E32"])
+def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
+    """rounds 1..3 of the folding sumcheck as exact int8 GEMMs on the matrix cores (lf_sv_rounds.hip; the driver uses them from 8192
+    pairs on, LF_FOLD_SV_MIN lowers the threshold): one, two and three rounds in that form, followed by the look-up-table rounds, the
+    fused-fix rounds or plain tables -- identical proofs, all equal to the oracle's"""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    monkeypatch.setenv("LF_FOLD_SV_MIN", "64")
+    m = 1 << wl.s
+    for rounds, extra in ((1, {}), (2, {}), (3, {}), (2, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}), (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}),
+                          (3, {"LF_NO_TAIL": "1", "LF_FOLD_UNFUSED": "1"})):
+        monkeypatch.setenv("LF_FOLD_SV_ROUNDS", str(rounds))
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        for k in extra:
+            monkeypatch.delenv(k)
+        want = sum(1 << (r - 1) for r in range(1, rounds + 1) if (m >> r) >= 64)
+        assert ctx.fold_paths() == want, (rounds, extra, ctx.fold_paths())
+        assert (proof == proof_o).all() and (lc == lc_o).all() and (w.f == f0_o).all(), (rounds, extra)
+    monkeypatch.setenv("LF_FOLD_NO_SV", "1")
+    lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    assert ctx.fold_paths() == 0 and (proof == proof_o).all()
+
+
 @pytest.mark.parametrize("name", ["T10", "G5", "T8"])
 def test_fold_step_persistent_tail_matches_oracle(ctx, name, monkeypatch):
     """the persistent tail kernel (k_fold_tail: all remaining folding-sumcheck rounds in one launch, messages and challenges through
