@@ -1513,6 +1513,7 @@ struct SideState {
     // (z, x_s valid once z_ev has completed), -1 = that lane failed, 0 = nobody built it yet
     std::atomic<int> z_state{0};
     hipEvent_t z_ev = nullptr;
+    u32 *sv_bits = nullptr;  // bit-plane form of the witness planes for the GEMM rounds of the folding sumcheck (lf_sv_rounds.h), if built ahead
 };
 
 // LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
@@ -2038,8 +2039,9 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             RET(c->tbuf("sv_part", sv_part_words(svV, a.pcnt, K), &svpart));
             RET(c->tbuf("sv_tot", sv_tot_words(svV, K), &svtot));
             RET(c->h2d_small(d_coef, coef.data(), coef.size() * 8));
-            if (!sv_bits[0])   // bit-plane form of the two witnesses, once per step
+            if (!sv_bits[0])   // bit-plane form of the two witnesses, once per step (the fold step builds it ahead on the other lane)
                 for (int sd = 0; sd < 2; sd++) {
+                    if (S[sd].sv_bits) { sv_bits[sd] = S[sd].sv_bits; continue; }
                     RET(c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(N, K), &sv_bits[sd]));
                     launch_sv_bits(S[sd].planes, N, N, K, sv_bits[sd], c->stream());
                 }
@@ -2344,6 +2346,17 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
             HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
             (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
+        }
+        if (!c->tn.fold_no_sv && c->N <= c->m && (c->N & 3) == 0 && !c->tn.fold_tab_r1 && (c->m >> 1) >= c->tn.sv_min) {
+            // bit-plane form of both witnesses for the GEMM rounds of the folding sumcheck, behind the commit on this lane's stream
+            // (decompose_commit_finish below synchronises it)
+            const lf_witness *ws[2] = {w_acc, w_i};
+            for (int sd = 0; sd < 2; sd++) {
+                u32 *bits;
+                if (c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(c->N, P.K), &bits) != LF_OK) break;
+                launch_sv_bits(ws[sd]->planes, c->N, c->N, P.K, bits, c->stream());
+                S[sd].sv_bits = bits;
+            }
         }
         if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition

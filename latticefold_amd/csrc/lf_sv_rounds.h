@@ -8,7 +8,7 @@
 // coefficient C_pi(X) that depends on the challenges only.  The round message needs
 //     sum_p eqB(p)(X) sum_tables mu_T sum_pi C_pi(X) sigma_pi(T,p) beta_pi(T,p)
 // and the inner sums over p,  M_pi[T] = sum_p eqB(2p | 2p+1) * (+-1 | 0),  are an int8 GEMM: rows = the 16 digit planes of a
-// (side, coefficient) group, inner dimension = pairs p, columns = the byte planes of eqB(2p), eqB(2p+1) (biased by -128) and a column of ones.
+// (side, coefficient) group, inner dimension = pairs p, columns = the 24 + 24 balanced base-256 digits of eqB(2p), eqB(2p+1).
 // No modular multiplication touches the 2^20-entry tables any more; the field work is 2 M_pi per (table, pair).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -43,7 +43,7 @@ constexpr SvPair sv_pair(int V, int idx) {
             }
     return SvPair{0, 0};
 }
-constexpr int sv_pairs_per_wave(int V) { return V == 1 ? 4 : (V == 2 ? 10 : 12); }
+constexpr int sv_pairs_per_wave(int V) { return V == 1 ? 4 : (V == 2 ? 10 : 20); }
 
 bool sv_shape_ok(int V, size_t npairs, uint32_t K);
 size_t sv_eb_bytes(size_t npairs);                    // packed eqB pair bytes [48][padded pairs]

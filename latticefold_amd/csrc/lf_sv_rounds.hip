@@ -4,9 +4,9 @@
 //   k_sv_gemm<V,PG> one wave = one (side, coefficient, 16 digit planes) group x one chunk of pairs x one group of PW (sigma, beta) pairs:
 //                  per K-step of 64 pairs it cuts the 2V signed bits of its 16 pairs from the int32 witness planes (the 16 plane lanes
 //                  of a tile share the loads), builds the +-1 / 0 operand bytes of every (sigma, beta) with byte-wise AND / XOR, and
-//                  issues 4 MFMAs per pair (column tiles: eqB(2p) bytes 0-15, 16-23 | eqB(2p+1) 0-7, 8-23, ones).  No LDS, no barrier.
-//   k_sv_sum       element-wise sum of the chunks' partial tiles (int32: |sum| <= 128 * npairs < 2^31 up to 2^24 pairs);
-//   k_sv_finish1   per table T: M_pi = sum_u 2^(8u) (C_u + 128 ones) mod p for eqB(2p) and eqB(2p+1), the table's degree-4 polynomial
+//                  issues 3 MFMAs per pair (column tiles: the balanced base-256 digits of eqB(2p) 0-15, 16-23 | eqB(2p+1) 0-7, 8-23).
+//   k_sv_sum       element-wise sum of the chunks' partial tiles (int32: |sum| <= 128 * npairs < 2^31 up to 2^23 pairs);
+//   k_sv_finish1   per table T: M_pi = sum_u 2^(8u) C_u mod p for eqB(2p) and eqB(2p+1), the table's degree-4 polynomial
 //                  sum_pi C_pi(X) (M0 + X (M1 - M0)), times mu_T;
 //   k_sv_finish2   sum over the tables of a slot, evaluation at X = 0..4, plus the G part of the message.
 #include <hip/hip_runtime.h>
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_sv_bits(const int32_t *planes, size_t l
 // a register are ONE shift + mask of a bit-plane word ((w >> s) & 0x01010101 picks bits s + 8 q)
 __host__ __device__ constexpr int sv_slot_pair(int V, int j, int q) { return (j / (4 / V)) * (16 / V) + (j % (4 / V)) + (4 / V) * q; }
 
-// EB[(24 h + 8 q + u)][slot] = byte u of eqB[q][2 pair + h] ^ 0x80 in slot order;  thread = (16 pairs, word q, half h);  ld = padded pairs
+// EB[(24 h + 8 q + u)][slot] = balanced base-256 digit u of eqB[q][2 pair + h] in slot order;  thread = (16 pairs, word q, half h);  ld = padded pairs
 __global__ void __launch_bounds__(256) k_sv_pack_eq(const u64 *eq, size_t ld, size_t npairs, size_t ldeb, int V, unsigned char *EB) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, groups = ldeb / 16;
     if (gid >= groups * 6) return;
@@ -80,7 +80,12 @@ __global__ void __launch_bounds__(256) k_sv_pack_eq(const u64 *eq, size_t ld, si
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const size_t pr = p0 + (size_t)sv_slot_pair(V, t >> 2, t & 3);
-        w[t] = (pr < npairs ? eq[(size_t)q * ld + 2 * pr + h] : 0) ^ 0x8080808080808080ull;
+        // balanced base-256 digits d_u in [-128, 127] of a representative of the word mod p: sum_u d_u 256^u = E or E - p.  With
+        // s = E' + 0x80..80 in [0, 2^64) the digits are (byte_u(s) - 128), i.e. byte_u(s) ^ 0x80 as int8 -- no bias column in the GEMM
+        const u64 e = pr < npairs ? eq[(size_t)q * ld + 2 * pr + h] : 0;
+        u64 sb = e + 0x8080808080808080ull;
+        if (sb < e) sb += 0xFFFFFFFFull;          // wrapped past 2^64: take E - p instead (2^64 - p = 2^32 - 1)
+        w[t] = sb ^ 0x8080808080808080ull;
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -106,7 +111,7 @@ struct SvGemmArgs {
     size_t ldeb;
     u32 ktiles;                 // tiles of 16 digit planes
     u32 nsuper, super_per_chunk;   // super-steps of 512 positions (256 / V pairs)
-    int32_t *part;              // [chunk][group][pair][4][64][4]
+    int32_t *part;              // [chunk][group][pair][3][64][4]
 };
 
 // operand register j of pair IDX:  +-1 where every bit of beta is set, sign = product of the signs of sigma
@@ -125,7 +130,7 @@ __device__ __forceinline__ u32 sv_operand(const u32 (&Xf)[2 * V][4], const u32 (
     }
 }
 template <int V, int BASE, int I>
-__device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][4], const v4i (&b)[4], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
+__device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][3], const v4i (&b)[3], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                              const u32 (&D)[2 * V][4]) {
     v4i av;
     av.x = (int)sv_operand<V, BASE + I>(Xf, S, D, 0);
@@ -133,18 +138,18 @@ __device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][4]
     av.z = (int)sv_operand<V, BASE + I>(Xf, S, D, 2);
     av.w = (int)sv_operand<V, BASE + I>(Xf, S, D, 3);
 #pragma unroll
-    for (int nt = 0; nt < 4; nt++) acc[I][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[I][nt], 0, 0, 0);
+    for (int nt = 0; nt < 3; nt++) acc[I][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[I][nt], 0, 0, 0);
 }
 template <int V, int BASE, int... I>
-__device__ __forceinline__ void sv_mfma_all(v4i (&acc)[sv_pairs_per_wave(V)][4], const v4i (&b)[4], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
+__device__ __forceinline__ void sv_mfma_all(v4i (&acc)[sv_pairs_per_wave(V)][3], const v4i (&b)[3], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                             const u32 (&D)[2 * V][4], std::integer_sequence<int, I...>) {
     (sv_mfma_pair<V, BASE, I>(acc, b, Xf, S, D), ...);
 }
 
 // waves per block = groups that share the eqB bytes of a super-step through LDS (every group needs all of them: read from L2 once per block)
-constexpr int sv_waves(int V) { return V == 1 ? 8 : 4; }
+constexpr int sv_waves(int V) { return V <= 2 ? 8 : 4; }
 template <int V, int PG>
-__global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_per_eu(V == 1 ? 2 : 1, V == 1 ? 2 : 1))) k_sv_gemm(SvGemmArgs a) {
+__global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_per_eu(V <= 2 ? 2 : 1, V <= 2 ? 2 : 1))) k_sv_gemm(SvGemmArgs a) {
     constexpr int NX = 2 * V, PW = sv_pairs_per_wave(V), NPR = sv_num_pairs(V), SS = 4 / V, RPW = 4 / V;   // sub-steps per super-step, registers per word
     constexpr int NW = sv_waves(V), NTH = 64 * NW;
     constexpr int SPAIRS = 256 / V, LROW = SPAIRS + 16;            // pairs (= bytes per eqB row) of a super-step; padded LDS row: conflict-free b128 reads
@@ -156,13 +161,12 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
     const u32 kt = grp % a.ktiles, c = (grp / a.ktiles) % 24, side = grp / (a.ktiles * 24);
     const u32 *mrow = a.bits[side] + ((size_t)c * a.rows + 16 * kt + row) * a.nw;
     const u32 *srow = a.bits[side] + ((size_t)c * a.rows + a.rows - 1) * a.nw;
-    v4i acc[PW][4];
+    v4i acc[PW][3];
 #pragma unroll
     for (int i = 0; i < PW; i++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) acc[i][nt] = v4i{0, 0, 0, 0};
+        for (int nt = 0; nt < 3; nt++) acc[i][nt] = v4i{0, 0, 0, 0};
     const u32 u0 = chunk * a.super_per_chunk, u1 = u0 + a.super_per_chunk < a.nsuper ? u0 + a.super_per_chunk : a.nsuper;
-    const v4i ones_col = row == 0 ? v4i{(int)ONES4, (int)ONES4, (int)ONES4, (int)ONES4} : v4i{0, 0, 0, 0};
     // staging of the eqB bytes: piece t = 16 bytes of row t / (SPAIRS/16)
     v4i st[PPT];
     auto stage_load = [&](u32 u) {
@@ -192,12 +196,11 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
         ws4 = *(const uint4 *)(srow + ((size_t)un * 4 + g) * 4);
 #pragma unroll
         for (int ss = 0; ss < SS; ss++) {
-            v4i b[4];
+            v4i b[3];
             const unsigned char *lb = &lds[buf][row][g * (64 / V) + 16 * ss];
             b[0] = *(const v4i *)lb;
             b[1] = *(const v4i *)(lb + 16 * LROW);
             b[2] = *(const v4i *)(lb + 32 * LROW);
-            b[3] = ones_col;
             u32 Xf[NX][4], S[NX][4], D[NX][4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -216,11 +219,11 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
         stage_store(buf ^ 1);
         __syncthreads();
     }
-    int32_t *o = a.part + (((size_t)chunk * ngroups + grp) * NPR + (size_t)PG * PW) * 1024;
+    int32_t *o = a.part + (((size_t)chunk * ngroups + grp) * NPR + (size_t)PG * PW) * 768;
 #pragma unroll
     for (int i = 0; i < PW; i++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) *(v4i *)(o + ((size_t)i * 4 + nt) * 256 + lane * 4) = acc[i][nt];
+        for (int nt = 0; nt < 3; nt++) *(v4i *)(o + ((size_t)i * 3 + nt) * 256 + lane * 4) = acc[i][nt];
 }
 
 __global__ void __launch_bounds__(256) k_sv_sum(const int32_t *part, size_t words, u32 chunks, int32_t *tot) {
@@ -242,16 +245,15 @@ __global__ void __launch_bounds__(128) k_sv_finish1(DevCrt t, const int32_t *tot
 #pragma unroll
     for (int e = 0; e < 5; e++) P[e] = fq3_zero();
     if (pi < npr) {
-        const int32_t *base = tot + ((size_t)grp * npr + pi) * 1024;
+        const int32_t *base = tot + ((size_t)grp * npr + pi) * 768;
         auto cell = [&](u32 bp) { return (long long)base[(bp >> 4) * 256 + ((bp & 15) + 16 * (krow >> 2)) * 4 + (krow & 3)]; };
-        const long long ones = cell(48);
         Fq3 M[2];
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 __int128 v = 0;
-                for (u32 u = 0; u < 8; u++) v += (__int128)(cell(24 * h + 8 * q + u) + 128 * ones) << (8 * u);
+                for (u32 u = 0; u < 8; u++) v += (__int128)cell(24 * h + 8 * q + u) << (8 * u);
                 M[h].c[q] = fq_from_s128((u64)v, (int64_t)(v >> 64));
             }
         const Fq3 dM = fq3_sub(M[1], M[0]);
@@ -282,21 +284,31 @@ __global__ void __launch_bounds__(128) k_sv_finish1(DevCrt t, const int32_t *tot
         for (int q = 0; q < 3; q++) tp[((size_t)T * 5 + e) * 3 + q] = fq_canon(r.c[q]);
     }
 }
-// thread = (X, slot, q): out[X*24 + 3*slot + q] = gpart[..] + sum_{side,k,d} TP[(side,k,8d+slot)](X)
-__global__ void __launch_bounds__(128) k_sv_finish2(const u64 *tp, u32 K, const u64 *gpart, u64 *out) {
-    const u32 i = threadIdx.x;
-    if (i >= 120) return;
+// thread = (output i = X*24 + 3*slot + q, part j of 8): out[i] = gpart[i] + sum_{side,k,d} TP[(side,k,8d+slot)](X)
+__global__ void __launch_bounds__(1024) k_sv_finish2(const u64 *tp, u32 K, const u64 *gpart, u64 *out) {
+    __shared__ u64 sm[8][128];
+    const u32 i = threadIdx.x & 127, j = threadIdx.x >> 7;
     const u32 X = i / 24, slot = (i % 24) / 3, q = i % 3;
-    u64 co[5] = {0, 0, 0, 0, 0};
-    for (u32 sk = 0; sk < 2 * K; sk++)
-        for (u32 d = 0; d < 3; d++) {
-            const u64 *p = tp + ((size_t)(sk * 24 + 8 * d + slot) * 5) * 3 + q;
+    u64 v = 0;
+    if (i < 120) {
+        u64 co[5] = {0, 0, 0, 0, 0};
+        for (u32 sk = j; sk < 2 * K; sk += 8)
+            for (u32 d = 0; d < 3; d++) {
+                const u64 *p = tp + ((size_t)(sk * 24 + 8 * d + slot) * 5) * 3 + q;
 #pragma unroll
-            for (int e = 0; e < 5; e++) co[e] = fq_add(co[e], p[3 * e]);
-        }
-    u64 v = co[4];
-    for (int e = 3; e >= 0; e--) v = fq_add(fq_mul(v, (u64)X), co[e]);
-    out[i] = fq_canon(fq_add(fq_canon(gpart[i]), v));
+                for (int e = 0; e < 5; e++) co[e] = fq_add(co[e], p[3 * e]);
+            }
+        v = co[4];
+        for (int e = 3; e >= 0; e--) v = fq_add(fq_mul(v, (u64)X), co[e]);
+    }
+    sm[j][i] = v;
+    __syncthreads();
+    if (j == 0 && i < 120) {
+        u64 s = fq_canon(gpart[i]);
+#pragma unroll
+        for (int w = 0; w < 8; w++) s = fq_add(s, sm[w][i]);
+        out[i] = fq_canon(s);
+    }
 }
 
 template <int V, int PG>
@@ -307,7 +319,7 @@ void launch_gemm_pg(const SvGemmArgs &a, u32 grid, hipStream_t s) {
 }  // namespace
 
 bool sv_shape_ok(int V, size_t npairs, uint32_t K) {
-    return (V == 1 || V == 2 || V == 4) && npairs >= 64 && npairs % 16 == 0 && npairs <= ((size_t)1 << 24) && K >= 1 && K <= 32;
+    return (V == 1 || V == 2 || V == 4) && npairs >= 64 && npairs % 16 == 0 && npairs <= ((size_t)1 << 23) && K >= 1 && K <= 32;
 }
 static size_t sv_ldeb(size_t npairs) { return (npairs + 255) / 256 * 256; }
 size_t sv_eb_bytes(size_t npairs) { return 48 * sv_ldeb(npairs) + 64; }
@@ -327,7 +339,7 @@ uint32_t sv_chunks(int V, size_t nsuper, uint32_t K) {
     const size_t spc = cdiv(nsuper, want);
     return (u32)cdiv(nsuper, spc);
 }
-size_t sv_tot_words(int V, uint32_t K) { return (size_t)48 * ((K + 15) / 16) * sv_num_pairs(V) * 1024; }
+size_t sv_tot_words(int V, uint32_t K) { return (size_t)48 * ((K + 15) / 16) * sv_num_pairs(V) * 768; }
 size_t sv_part_words(int V, size_t npairs, uint32_t K) { return sv_tot_words(V, K) * sv_chunks(V, cdiv(npairs * V, 256), K); }
 size_t sv_tp_words(uint32_t K) { return (size_t)2 * K * 24 * 15; }
 
@@ -358,7 +370,7 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     const u32 npr = (u32)sv_num_pairs(V);
     if (t.nu2p40) hipLaunchKernelGGL((k_sv_finish1<true>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp);
     else hipLaunchKernelGGL((k_sv_finish1<false>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp);
-    hipLaunchKernelGGL(k_sv_finish2, dim3(1), dim3(128), 0, s, tp, K, gpart, out);
+    hipLaunchKernelGGL(k_sv_finish2, dim3(1), dim3(1024), 0, s, tp, K, gpart, out);
     return 0;
 }
 }  // namespace lf
