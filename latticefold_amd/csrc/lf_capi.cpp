@@ -180,6 +180,11 @@ struct lf_ctx {
     float k_fold_ms = 0, k_ajtai_ms = 0;
     int k_fold_n = 0, k_ajtai_n = 0;
     double host_tr_ms = 0;
+    // v_s of the linearized instance computed inside the linearization (v = sum_k 2^k v_s[k]); reused by the right decomposition of the same step
+    const lf_witness *vs_wit = nullptr;
+    bool vs_keep = false;            // set by the fold step around its linearization: only there the decomposition that follows uses the same point
+    const u64 *vs_eq = nullptr;
+    u64 *vs_dev = nullptr;
     unsigned sv_round_mask = 0;      // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
 
     int buf(const std::string &name, size_t bytes, void **out) {
@@ -1453,8 +1458,19 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     {   // T[24][3] flat == v[3][8 slots][3]; sharded: each rank sums its index slice, partial sums exchanged on the device
         size_t i0, cnt;
         shard_slice(c, c->N, &i0, &cnt);
-        RET(coef_eval_dev(c, wit->planes + i0, cnt, eqr + i0, m, 1, 0, partial, od, c->N));
-        RET(exchange_modsum_dev(c, od, 72));
+        c->vs_wit = nullptr;
+        if (P.b == 2 && c->sh_world == 1 && !c->tn.lin_v_direct) {
+            // the K digit-plane evaluations v_s[k] (needed by the decomposition of this instance at the same point anyway) instead of the
+            // evaluation of the full coefficients: v = sum_k 2^k v_s[k]
+            u64 *vs;
+            RET(c->tbuf("lin_vs", (size_t)P.K * 72 + 8, &vs));
+            RET(coef_eval_dev(c, wit->planes, c->N, eqr, m, P.K, 1, partial, vs, c->N));
+            launch_vs_combine(vs, P.K, od, c->stream());
+            if (c->vs_keep) { c->vs_wit = wit; c->vs_eq = eqr; c->vs_dev = vs; }
+        } else {
+            RET(coef_eval_dev(c, wit->planes + i0, cnt, eqr + i0, m, 1, 0, partial, od, c->N));
+            RET(exchange_modsum_dev(c, od, 72));
+        }
     }
     if (u_eval) {
         RET(down_small(c, od, 72, v));
@@ -1620,8 +1636,13 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     {
         size_t i0, cnt;
         shard_slice(c, N, &i0, &cnt);   // sharded: this rank's index slice; partial sums exchanged on the device
-        RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od_v, N));
-        RET(exchange_modsum_dev(c, od_v, (size_t)K * 72));
+        if (c->vs_wit == wit && c->vs_eq == eq_r && c->sh_world == 1) {   // computed by the linearization of this step at this very point
+            HIPCHK(hipMemcpyAsync(od_v, c->vs_dev, (size_t)K * 72 * 8, hipMemcpyDeviceToDevice, c->stream()));
+            c->vs_wit = nullptr;
+        } else {
+            RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od_v, N));
+            RET(exchange_modsum_dev(c, od_v, (size_t)K * 72));
+        }
     }
     // u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     for (u32 j = 0; j < P.t; j++)
@@ -2370,7 +2391,9 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         tr.absorb_ring(cm_i, lf_cccs_len(&P));
     }
     TL_MARK("public input absorbed");
+    c->vs_keep = true;
     rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    c->vs_keep = false;
     TL_MARK("linearization done");
     lin_done_p.set_value(rc);
     if (rc == LF_OK) {
@@ -2378,6 +2401,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         while (S[1].z_state.load(std::memory_order_acquire) == 0) std::this_thread::yield();   // published by lane 1 within its first millisecond (or -1)
         rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
     }
+    c->vs_wit = nullptr;
     TL_MARK("right evals done");
     int rc1 = c->lane1.wait();
     c->lin_blocks = 0;

@@ -109,6 +109,7 @@ void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_plane
 // generic in-place-free fix: ring tables and fq3 tables, new[j] = old[2j] + r*(old[2j+1]-old[2j])
 void launch_fix_ring(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s);
 void launch_fix_fq3(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s);
+void launch_vs_combine(const u64 *vs /* [K][72] */, u32 K, u64 *v /* [72] */, hipStream_t s);   // v = sum_k 2^k v_s[k]
 void launch_fix_final(const DevCrt &t, const u64 *in /* [rows3][3][2] */, u32 rows3, Fq3Const r, u64 *out /* [rows3][3] canonical */, hipStream_t s);
 
 struct LinCombDesc {  // CCS multiset structure for the linearization comb (nifs/linearization/utils.rs:90-107)

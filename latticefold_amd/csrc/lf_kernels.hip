@@ -1137,6 +1137,19 @@ __global__ void __launch_bounds__(256) k_fix_final(DevCrt t, const u64 *in, u32 
 #pragma unroll
     for (int q = 0; q < 3; q++) out[(size_t)row * 3 + q] = fq_canon(res.c[q]);
 }
+// v = sum_k 2^k v_s[k]: the MLE evaluation of the witness coefficients from the evaluations of their K binary digit planes
+// (linearization.rs:126-139 v and decomposition.rs:204-211 v_s at the same point are the same sums)
+__global__ void __launch_bounds__(128) k_vs_combine(const u64 *vs, u32 K, u64 *v) {
+    const u32 i = threadIdx.x;
+    if (i >= 72) return;
+    u64 acc = 0, pw = 1;
+    for (u32 k = 0; k < K; k++) {
+        acc = fq_add(acc, fq_mul(fq_canon(vs[(size_t)k * 72 + i]), pw));
+        pw = fq_add(pw, pw);
+    }
+    v[i] = fq_canon(acc);
+}
+void launch_vs_combine(const u64 *vs, u32 K, u64 *v, hipStream_t s) { hipLaunchKernelGGL(k_vs_combine, dim3(1), dim3(128), 0, s, vs, K, v); }
 void launch_fix_final(const DevCrt &t, const u64 *in, u32 rows3, Fq3Const r, u64 *out, hipStream_t s) {
     LF_LAUNCH(k_fix_final, t.nu2p40, dim3(cdiv(rows3, 256)), dim3(256), s, t, in, rows3, r, out);
 }
