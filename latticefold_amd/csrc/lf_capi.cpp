@@ -1459,7 +1459,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
         size_t i0, cnt;
         shard_slice(c, c->N, &i0, &cnt);
         c->vs_wit = nullptr;
-        if (P.b == 2 && c->sh_world == 1 && !c->tn.lin_v_direct) {
+        if (P.b == 2 && c->sh_world == 1 && !c->tn.force_exchange && !c->tn.lin_v_direct) {
             // the K digit-plane evaluations v_s[k] (needed by the decomposition of this instance at the same point anyway) instead of the
             // evaluation of the full coefficients: v = sum_k 2^k v_s[k]
             u64 *vs;
@@ -1946,7 +1946,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     u64 *d_lut = nullptr;
     c->sv_round_mask = 0;
     u32 *sv_bits[2] = {nullptr, nullptr};
-    const bool use_sv = Gw == 1 && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && !c->tn.fold_tab_r1;
+    const bool use_sv = Gw == 1 && !c->tn.force_exchange && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && !c->tn.fold_tab_r1;
     for (u32 round = 1; round <= P.s; round++) {
         fmode = 0;
         // Persistent tail: once the materialised tables are small, ONE kernel runs all remaining rounds and exchanges messages /
@@ -2368,7 +2368,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
             (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
         }
-        if (!c->tn.fold_no_sv && c->N <= c->m && (c->N & 3) == 0 && !c->tn.fold_tab_r1 && (c->m >> 1) >= c->tn.sv_min) {
+        if (!c->tn.fold_no_sv && !c->tn.force_exchange && c->N <= c->m && (c->N & 3) == 0 && !c->tn.fold_tab_r1 && (c->m >> 1) >= c->tn.sv_min) {
             // bit-plane form of both witnesses for the GEMM rounds of the folding sumcheck, behind the commit on this lane's stream
             // (decompose_commit_finish below synchronises it)
             const lf_witness *ws[2] = {w_acc, w_i};
