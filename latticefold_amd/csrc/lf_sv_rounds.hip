@@ -17,8 +17,7 @@
 #include "lf_sv_rounds.h"
 
 namespace lf {
-namespace {
-inline size_t cdiv(size_t a, size_t b) { return (a + b - 1) / b; }
+static inline size_t cdiv(size_t a, size_t b) { return (a + b - 1) / b; }
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr u32 ONES4 = 0x01010101u;
 constexpr int ctz8(unsigned m) { int i = 0; while (i < 8 && !((m >> i) & 1)) i++; return i; }
@@ -316,7 +315,6 @@ void launch_gemm_pg(const SvGemmArgs &a, u32 grid, hipStream_t s) {
     hipLaunchKernelGGL((k_sv_gemm<V, PG>), dim3(grid), dim3(64 * sv_waves(V)), 0, s, a);
     if constexpr (PG + 1 < sv_num_pairs(V) / sv_pairs_per_wave(V)) launch_gemm_pg<V, PG + 1>(a, grid, s);
 }
-}  // namespace
 
 bool sv_shape_ok(int V, size_t npairs, uint32_t K) {
     return (V == 1 || V == 2 || V == 4) && npairs >= 64 && npairs % 16 == 0 && npairs <= ((size_t)1 << 23) && K >= 1 && K <= 32;
