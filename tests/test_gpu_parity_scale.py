@@ -130,10 +130,13 @@ def test_fold_step_matches_committed_oracle_digests(name):
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["T14", "B10"])
-def test_sub_provers_chain_to_fold_step(name):
+@pytest.mark.parametrize("name,gemm_rounds", [("T14", False), ("B10", False), ("T14", True)])
+def test_sub_provers_chain_to_fold_step(name, gemm_rounds, monkeypatch):
     """LFDecompositionProver / LFFoldingProver entry points (lf_decomposition_prove, lf_folding_prove): vs the oracle's
-    decomposition, and chained after the linearization they reproduce NIFSProver::prove (nifs.rs:59-103) bit for bit"""
+    decomposition, and chained after the linearization they reproduce NIFSProver::prove (nifs.rs:59-103) bit for bit.  gemm_rounds: the
+    stand-alone folding prover with rounds 1-3 of its sumcheck as int8 GEMMs (it builds the bit planes of the witnesses itself)"""
+    if gemm_rounds:
+        monkeypatch.setenv("LF_FOLD_SV_MIN", "64")
     wl, ctx, scheme, wit, cccs = _setup(name)
     O = _oracle(wl.ring)
     try:
@@ -158,5 +161,7 @@ def test_sub_provers_chain_to_fold_step(name):
         lc2, w02, fold_pr = api.LFFoldingProver.prove(ctx, np.concatenate([lcs_l, lcs_r]), wit, wit, t1)
         assert (np.concatenate([lin_pr, dec_l, dec_r, fold_pr]) == proof).all()
         assert (lc2 == lc).all() and (w02.f == w0.f).all()
+        if wl.ring == "goldilocks":
+            assert ctx.fold_paths() == (7 if gemm_rounds else 0)
     finally:
         ctx.close()
