@@ -1946,7 +1946,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     u64 *d_lut = nullptr;
     c->sv_round_mask = 0;
     u32 *sv_bits[2] = {nullptr, nullptr};
-    const bool use_sv = Gw == 1 && !c->tn.force_exchange && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && !c->tn.fold_tab_r1;
+    const bool use_sv = !c->tn.force_exchange && !c->tn.fold_no_sv && (Gw == 1 || !c->tn.shard_plain_rounds) && N <= m && (N & 3) == 0 && !c->tn.fold_tab_r1;
     for (u32 round = 1; round <= P.s; round++) {
         fmode = 0;
         // Persistent tail: once the materialised tables are small, ONE kernel runs all remaining rounds and exchanges messages /
@@ -2043,7 +2043,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     tables_ready:
         size_t ev = c->ev_begin(0);
         const int svV = 1 << (round - 1);
-        if (use_sv && !sharded && (int)round <= c->tn.sv_rounds && round <= 3 && a.p0 == 0 && a.pcnt >= c->tn.sv_min && sv_shape_ok(svV, a.pcnt, K)) {
+        if (use_sv && (int)round <= c->tn.sv_rounds && round <= 3 && a.pcnt >= c->tn.sv_min && sv_shape_ok(svV, a.pcnt, K) && (a.p0 * (size_t)svV) % 256 == 0) {
             // rounds 1..3 as exact int8 GEMMs on the matrix cores (lf_sv_rounds.h): G part on the VALU, norm part from the witness planes
             std::vector<Fq3> W((size_t)svV, fq3_one());
             for (int b = 0; b < svV; b++)
@@ -2067,7 +2067,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                     launch_sv_bits(S[sd].planes, N, N, K, sv_bits[sd], c->stream());
                 }
             launch_fold_round_g(c->dcrt, a, partial, gtmp, c->stream());
-            if (launch_sv_round(c->dcrt, svV, sv_bits[0], sv_bits[1], N, a.eqB, a.ld, a.pcnt, K, d_mu, d_coef, sveb, svpart, svtot, svtp, gtmp, od, c->stream()) != 0)
+            if (launch_sv_round(c->dcrt, svV, sv_bits[0], sv_bits[1], N, a.eqB, a.ld, a.p0, a.pcnt, K, d_mu, d_coef, sveb, svpart, svtot, svtp, gtmp, od, c->stream()) != 0)
                 return LF_ERR_UNSUPPORTED;
             c->sv_round_mask |= 1u << (round - 1);
         } else

@@ -54,11 +54,12 @@ size_t sv_tp_words(uint32_t K);                       // u64 words of the per-ta
 size_t sv_bits_words(size_t n, uint32_t K);
 void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uint32_t *bits, hipStream_t s);
 // norm part of round log2(V)+1:  out[X*24 + 3*slot + q] = gpart[...] + sum_tables mu_T sum_p eqB(p)(X) (h_T^3 - h_T)(p)(X),  X = 0..4.
-// bitsL / bitsR: launch_sv_bits forms of the two witnesses (nplanes positions); eqB: [3][ldeq] with 2*npairs entries;
+// bitsL / bitsR: launch_sv_bits forms of the two witnesses (nplanes positions); eqB: [3][ldeq]; the launch covers the pairs [pair0, pair0 + npairs)
+// (a rank's slice of a sharded step: the partial messages of the ranks add up; gpart = the same slice's G part);
 // coef: [sv_num_pairs(V)][4][3] words C_pi (device); mu_pow: [2K*3].  Returns 0, or -1 if the shape is not handled.
 struct DevCrt;
 struct Fq3Const;
-int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t npairs, uint32_t K,
+int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
                     const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
                     hipStream_t s);
 }  // namespace lf

@@ -110,6 +110,7 @@ struct SvGemmArgs {
     size_t ldeb;
     u32 ktiles;                 // tiles of 16 digit planes
     u32 nsuper, super_per_chunk;   // super-steps of 512 positions (256 / V pairs)
+    u32 super0;                 // first super-step of the bit planes (a rank's pair slice of a sharded step; the eqB bytes start at its first pair)
     int32_t *part;              // [chunk][group][pair][3][64][4]
 };
 
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
     };
     if (u0 < u1) { stage_load(u0); stage_store(0); }
     uint4 wm4 = make_uint4(0, 0, 0, 0), ws4 = wm4;
+    mrow += (size_t)a.super0 * 16; srow += (size_t)a.super0 * 16;
     if (u0 < u1) { wm4 = *(const uint4 *)(mrow + ((size_t)u0 * 4 + g) * 4); ws4 = *(const uint4 *)(srow + ((size_t)u0 * 4 + g) * 4); }
     __syncthreads();
     for (u32 u = u0; u < u1; u++) {
@@ -331,6 +333,7 @@ void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uin
 // is one batch of at most 256 blocks
 uint32_t sv_chunks(int V, size_t nsuper, uint32_t K) {
     const u32 ktiles = (K + 15) / 16, per_chunk = 48 * ktiles / (u32)sv_waves(V);
+    if (nsuper == 0) return 1;
     size_t want = 256 / per_chunk;
     if (want > nsuper) want = nsuper;
     if (want < 1) want = 1;
@@ -341,14 +344,15 @@ size_t sv_tot_words(int V, uint32_t K) { return (size_t)48 * ((K + 15) / 16) * s
 size_t sv_part_words(int V, size_t npairs, uint32_t K) { return sv_tot_words(V, K) * sv_chunks(V, cdiv(npairs * V, 256), K); }
 size_t sv_tp_words(uint32_t K) { return (size_t)2 * K * 24 * 15; }
 
-int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t npairs, uint32_t K,
+int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
                     const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
                     hipStream_t s) {
-    // pairs behind which witness positions exist (positions >= nplanes are zero digits: nothing to add)
-    const size_t wpairs = cdiv(nplanes, 2 * (size_t)V) < npairs ? cdiv(nplanes, 2 * (size_t)V) : npairs;
-    if (!sv_shape_ok(V, npairs, K) || wpairs < 1) return -1;
+    // pairs of the slice behind which witness positions exist (positions >= nplanes are zero digits: nothing to add)
+    const size_t wall = cdiv(nplanes, 2 * (size_t)V);
+    const size_t wpairs = pair0 >= wall ? 0 : (wall - pair0 < npairs ? wall - pair0 : npairs);
+    if (!sv_shape_ok(V, npairs, K) || (pair0 * V) % 256) return -1;
     const size_t ldeb = sv_ldeb(npairs);
-    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eqB, ldeq, npairs, ldeb, V, EB);
+    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eqB + 2 * pair0, ldeq, npairs, ldeb, V, EB);
     SvGemmArgs a;
     a.bits[0] = bitsL; a.bits[1] = bitsR;
     a.ktiles = (K + 15) / 16;
@@ -356,6 +360,7 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     a.nw = sv_npad(nplanes) / 32;
     a.EB = EB; a.ldeb = ldeb;
     a.nsuper = (u32)cdiv(wpairs * V, 256);
+    a.super0 = (u32)(pair0 * V / 256);
     const u32 chunks = sv_chunks(V, a.nsuper, K);
     a.super_per_chunk = (u32)cdiv(a.nsuper, chunks);
     a.part = part;

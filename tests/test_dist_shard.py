@@ -39,8 +39,9 @@ WORKER = textwrap.dedent('''
             h = hashlib.sha256()
             for a in (cccs, acc, lc, proof, w0.f_coeff, lc2, proof2, w1.f_coeff):
                 h.update(np.ascontiguousarray(a).tobytes())
+            paths = ctx.fold_paths()
             ctx.close()
-            return h.hexdigest()
+            return h.hexdigest() + ":%d" % paths
         ref = run(False) if rank == 0 else None
         got = run(True)
         allg = [None] * world
@@ -60,13 +61,16 @@ def _free_port():
 # "big": the thresholds of the large-instance round modes (fused fix, look-up-table rounds 2-4) lowered so that a 2^12 / 2^14-row instance takes
 # them -- in the sharded run on the ranks' pair slices, in the unsharded reference on whole tables
 @pytest.mark.parametrize("world,cases,two_lanes", [(2, "T10,G5,T12", False), (4, "T12", False), (2, "T12", True), (2, "B8,B10,BDP", False), (4, "B14", False),
-                                                   (2, "T12,T14", "big"), (4, "T14", "big"), (2, "T12", "plain"), (8, "T14", "big")])
+                                                   (2, "T12,T14", "big"), (4, "T14", "big"), (2, "T12", "plain"), (8, "T14", "big"),
+                                                   (2, "T14", "gemm"), (8, "T14", "gemm")])
 def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, LF_ROOT=ROOT, OMP_NUM_THREADS="2", LF_CASES=cases)
     if two_lanes == "big":
         env.update(LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
+    elif two_lanes == "gemm":   # rounds 1-3 of the folding sumcheck as int8 GEMMs on the ranks' pair slices (lf_sv_rounds.h), then the large-instance modes
+        env.update(LF_FOLD_SV_MIN="64", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
     elif two_lanes == "plain":
         env.update(LF_SHARD_PLAIN_ROUNDS="1", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
     elif two_lanes:   # the threaded two-lane schedule with one exchange channel per lane (default in a sharded step: one host thread)
@@ -79,3 +83,5 @@ def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     for name, r in d.items():
         assert len(r["ranks"]) == world
         assert all(x == r["ref"] for x in r["ranks"]), (name, r)
+        if two_lanes == "gemm":   # every rank (and the unsharded reference) ran rounds 1-3 as GEMMs
+            assert r["ref"].endswith(":7"), r
