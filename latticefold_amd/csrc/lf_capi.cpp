@@ -1591,6 +1591,25 @@ static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *
     return LF_OK;
 }
 
+// <X_a, Y_b> for na vectors X and nb vectors Y of n columns -> od (device, canonical): on the int8 matrix cores (lf_dot_i8.hip) unless
+// LF_DOT_VALU is set or the shape is not handled there
+static int dot_batch_dev(lf_ctx *c, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *dpart, u64 *od) {
+    if (!c->tn.dot_valu && n >= 4096 && nb <= 3) {
+        unsigned char *yb;
+        int32_t *part;
+        long long *tot;
+        RET(c->tbuf("dot_yb", dot_i8_yb_bytes(n), &yb));
+        RET(c->tbuf("dot_i8_part", dot_i8_part_words(n), &part));
+        RET(c->tbuf("dot_i8_tot", dot_i8_tot_words(), &tot));
+        bool ok = true;
+        for (u32 a0 = 0; a0 < na && ok; a0 += 16)
+            ok = launch_dot_batch_i8(c->dcrt, X + (size_t)a0 * 24 * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * 24,
+                                     c->stream()) == 0;
+        if (ok) return LF_OK;
+    }
+    launch_dot_batch(c->dcrt, X, ldx, na, Y, ldy, nb, n, dpart, od, c->stream());
+    return LF_OK;
+}
 // the point-dependent half of LFDecompositionProver::prove (decomposition.rs:33-88): x_s, v_s, z_k, u_s
 // The part of a decomposition's evaluations that does not depend on the evaluation point: x_s (host, into the proof) and the K vectors
 // z_k = x_s[k] || w_k on the device.  Runs on the calling lane; another lane's consumer waits for S.z_ev on its own stream.
@@ -1652,7 +1671,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     {
         size_t c0, cnt;
         shard_slice(c, n, &c0, &cnt);   // sharded: dot products over this rank's column slice of z_k and q_j
-        launch_dot_batch(c->dcrt, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od_u, c->stream());
+        RET(dot_batch_dev(c, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od_u));
         RET(exchange_modsum_dev(c, od_u, (size_t)K * P.t * 24));
     }
     // one download (one stream synchronisation) for both result sets
@@ -2162,7 +2181,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     {
         size_t c0, cnt;
         shard_slice(c, n, &c0, &cnt);
-        for (int sd = 0; sd < 2; sd++) launch_dot_batch(c->dcrt, S[sd].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta + (size_t)sd * K * P.t * 24, c->stream());
+        for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta + (size_t)sd * K * P.t * 24));
         RET(exchange_modsum_dev(c, d_eta, (size_t)K2 * P.t * 24));
     }
     HIPCHK(hipMemcpyAsync(hp + (size_t)K2 * 72, d_eta, (size_t)K2 * P.t * 24 * 8, hipMemcpyDeviceToHost, c->stream()));

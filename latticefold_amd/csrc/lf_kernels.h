@@ -109,6 +109,13 @@ void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_plane
 // generic in-place-free fix: ring tables and fq3 tables, new[j] = old[2j] + r*(old[2j+1]-old[2j])
 void launch_fix_ring(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s);
 void launch_fix_fq3(const DevCrt &t, const u64 *in, u64 *out, size_t n_in, Fq3Const r, hipStream_t s);
+// batched inner products on the int8 matrix cores (lf_dot_i8.hip): out[(a*nb + b)*24 + 3*slot + q] = sum_i X_a[slot][i] * Y_b[slot][i], na <= 16, nb <= 3.
+// YB / part / tot: scratch (dot_i8_yb_bytes(n), dot_i8_part_words(n) int32, dot_i8_tot_words() int64).  Returns 0, or -1 if the shape is not handled.
+size_t dot_i8_yb_bytes(size_t n);
+size_t dot_i8_part_words(size_t n);
+size_t dot_i8_tot_words();
+int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
+                        long long *tot, u64 *out, hipStream_t s);
 void launch_vs_combine(const u64 *vs /* [K][72] */, u32 K, u64 *v /* [72] */, hipStream_t s);   // v = sum_k 2^k v_s[k]
 void launch_fix_final(const DevCrt &t, const u64 *in /* [rows3][3][2] */, u32 rows3, Fq3Const r, u64 *out /* [rows3][3] canonical */, hipStream_t s);
 
