@@ -185,6 +185,7 @@ struct lf_ctx {
     bool vs_keep = false;            // set by the fold step around its linearization: only there the decomposition that follows uses the same point
     const u64 *vs_eq = nullptr;
     u64 *vs_dev = nullptr;
+    hipEvent_t ev_prep[2] = {nullptr, nullptr};   // fold prepare: fork / join of the right side's chain on the helper lane's stream
     unsigned sv_round_mask = 0;      // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
 
     int buf(const std::string &name, size_t bytes, void **out) {
@@ -428,6 +429,8 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->tail_counters) (void)hipFree(c->tail_counters);
     if (c->d_poseidon) (void)hipFree(c->d_poseidon);
     if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
+    for (int i = 0; i < 2; i++)
+        if (c->ev_prep[i]) (void)hipEventDestroy(c->ev_prep[i]);
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
     delete c;
@@ -1916,11 +1919,28 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         RET(c->tbuf("fold_round_out", 5 * 24 + 8, &od_shard));
         od = od_shard;
     }
-    for (int sd = 0; sd < 2; sd++) {
-        // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}
-        launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
-        launch_spmv_sum(c->dcrt, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zz, (size_t)24 * n, n, G[sd], m, c->stream());
-        launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, c->stream());
+    {
+        // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}: the two sides are independent chains -- the right one runs on
+        // the (idle) stream of the helper lane next to the left one: the SpMV gathers of one side overlap the multiply-bound combination of the other
+        hipStream_t s0 = c->stream(), s1 = (t_lane == 0 && !c->tn.prep_one_stream) ? c->st_lane[1] : s0;
+        u64 *zz1 = zz;
+        if (s1 != s0) {
+            RET(c->tbuf("fold_zz1", (size_t)P.t * 24 * n, &zz1));
+            if (!c->ev_prep[0]) { HIPCHK(hipEventCreateWithFlags(&c->ev_prep[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_prep[1], hipEventDisableTiming)); }
+            HIPCHK(hipEventRecord(c->ev_prep[0], s0));           // the challenge powers were uploaded on s0
+            HIPCHK(hipStreamWaitEvent(s1, c->ev_prep[0], 0));
+        }
+        for (int sd = 0; sd < 2; sd++) {
+            hipStream_t st = sd ? s1 : s0;
+            u64 *zb = sd ? zz1 : zz;
+            launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zb, st);
+            launch_spmv_sum(c->dcrt, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zb, (size_t)24 * n, n, G[sd], m, st);
+            launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, st);
+        }
+        if (s1 != s0) {
+            HIPCHK(hipEventRecord(c->ev_prep[1], s1));
+            HIPCHK(hipStreamWaitEvent(s0, c->ev_prep[1], 0));
+        }
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     LF_TRACE(c, "fold prepare");
