@@ -69,7 +69,7 @@ def cpu_baseline(target_wl, budget_s=25.0):
     }
 
 
-PMC_FILE = "r02c_pmc_{}.json"   # profiles/: HBM traffic per kernel from the PMC passes (falls back to null when absent)
+PMC_FILE = "r02d_pmc_{}.json"   # profiles/: HBM traffic per kernel from the PMC passes (falls back to null when absent)
 
 
 def main():
