@@ -169,31 +169,34 @@ __global__ void __launch_bounds__(256) k_dot_i8_sum(const int32_t *part, u32 chu
     tot[(size_t)unit * 10240 + e] = s;
 }
 
-// thread = output (a, b, slot, comp): out[(a*nb + b)*24 + 3*slot + comp] = sum over (cz, cq) with cz + cq = comp (mod 3) of nu^[cz+cq >= 3] *
-// sum_{u,v} 256^(u+v) tot[slot, cz][u][a][(b, cq, v)]
-__global__ void __launch_bounds__(256) k_dot_i8_finish(const long long *tot, u32 na, u32 nb, u64 nu, u64 *out) {
-    const u32 o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= na * nb * 24) return;
+// block = output (a, b, slot, comp), thread = (cz, digit u):  out[(a*nb + b)*24 + 3*slot + comp] = sum over (cz, cq) with cz + cq = comp (mod 3) of
+// nu^[cz+cq >= 3] * sum_{u,v} 256^(u+v) tot[slot, cz][u][a][(b, cq, v)]
+__global__ void __launch_bounds__(32) k_dot_i8_finish(const long long *tot, u32 na, u32 nb, u64 nu, u64 *out) {
+    __shared__ u64 sm[24];
+    const u32 o = blockIdx.x, t = threadIdx.x;
     const u32 comp = o % 3, slot = (o % 24) / 3, b = (o / 24) % nb, av = o / (24 * nb);
-    u64 res = 0;
-    for (u32 cz = 0; cz < 3; cz++) {
-        const u32 cq = (comp + 3 - cz) % 3;
+    if (t < 24) {
+        const u32 cz = t >> 3, u = t & 7, cq = (comp + 3 - cz) % 3;
         const long long *tu = tot + (size_t)(slot * 3 + cz) * 10240;
-        u64 val = 0, pw = 1;
-        for (u32 u = 0; u < 8; u++) {
-            __int128 inner = 0;
-            for (u32 v = 0; v < 8; v++) {
-                const u32 col = (b * 3 + cq) * 8 + v, nt = col >> 4, cl = col & 15;
-                const long long cell = tu[((size_t)u * 5 + nt) * 256 + (cl + 16 * (av >> 2)) * 4 + (av & 3)];
-                inner += (__int128)cell << (8 * v);
-            }
-            val = fq_add(val, fq_mul(fq_from_s128((u64)inner, (int64_t)(inner >> 64)), pw));
-            pw = fq_mul(pw, 256);
+        __int128 inner = 0;
+#pragma unroll
+        for (u32 v = 0; v < 8; v++) {
+            const u32 col = (b * 3 + cq) * 8 + v, nt = col >> 4, cl = col & 15;
+            inner += (__int128)tu[((size_t)u * 5 + nt) * 256 + (cl + 16 * (av >> 2)) * 4 + (av & 3)] << (8 * v);
         }
+        u64 val = fq_from_s128((u64)inner, (int64_t)(inner >> 64));
+        u64 pw = 1;
+        for (u32 i = 0; i < u; i++) pw = fq_mul(pw, 256);
+        val = fq_mul(val, pw);
         if (cz + cq >= 3) val = fq_mul(val, nu);
-        res = fq_add(res, val);
+        sm[t] = val;
     }
-    out[o] = fq_canon(res);
+    __syncthreads();
+    if (t == 0) {
+        u64 res = 0;
+        for (int i = 0; i < 24; i++) res = fq_add(res, sm[i]);
+        out[o] = fq_canon(res);
+    }
 }
 
 size_t dot_i8_yb_bytes(size_t n) { return (size_t)8 * 72 * (dcdiv(n, 64) * 64) + 64; }
@@ -219,7 +222,7 @@ int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const
     a.part = part;
     hipLaunchKernelGGL(k_dot_i8, dim3((unsigned)dcdiv(a.chunks, 4), 24), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_dot_i8_sum, dim3(40, 24), dim3(256), 0, s, part, a.chunks, tot);
-    hipLaunchKernelGGL(k_dot_i8_finish, dim3((unsigned)dcdiv((size_t)na * nb * 24, 256)), dim3(256), 0, s, tot, na, nb, t.nu, out);
+    hipLaunchKernelGGL(k_dot_i8_finish, dim3(na * nb * 24), dim3(32), 0, s, tot, na, nb, t.nu, out);
     return 0;
 }
 }  // namespace lf
