@@ -1985,6 +1985,8 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     u64 *d_lut = nullptr;
     c->sv_round_mask = 0;
     u32 *sv_bits[2] = {nullptr, nullptr};
+    const bool sv_two_streams = t_lane == 0 && !c->tn.prep_one_stream && Gw == 1;
+    hipStream_t sv_g_stream = c->stream();
     const bool use_sv = !c->tn.force_exchange && !c->tn.fold_no_sv && (Gw == 1 || !c->tn.shard_plain_rounds) && N <= m && (N & 3) == 0 && !c->tn.fold_tab_r1;
     for (u32 round = 1; round <= P.s; round++) {
         fmode = 0;
@@ -2004,12 +2006,22 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             Fq3Const r = f3c(pt[round - 2]);
             size_t nn = a.n / 2;
             u64 *dst = T5[flip];
+            // GEMM rounds (below): the norm part needs eqB only, the G part the other four tables -- their fixes (and the G kernel) run on the
+            // helper lane's idle stream next to the GEMM chain
+            hipStream_t sg = c->stream();
+            if (use_sv && sv_two_streams && !sharded && (int)round <= c->tn.sv_rounds && round <= 3 && nn / 2 >= c->tn.sv_min && sv_shape_ok(1 << (round - 1), nn / 2, K))
+                sg = c->st_lane[1];
+            sv_g_stream = sg;
             if (round == 2) {   // sources are the five separate full-size tables
-                launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, c->stream());
-                launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, c->stream());
+                launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, sg);
+                launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, sg);
                 launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->stream());
-                launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, c->stream());
-                launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, c->stream());
+                launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 8, r, sg);
+                launch_fix_many(c->dcrt, a.G2, a.ld, dst + 33 * nn, nn, a.n, 8, r, sg);
+            } else if (sg != c->stream()) {   // the 57-plane buffer in three pieces: eqL eqR | eqB | G1 G2
+                launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 2, r, sg);
+                launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->stream());
+                launch_fix_many(c->dcrt, a.G1, a.ld, dst + 9 * nn, nn, a.n, 16, r, sg);
             } else {            // source is the previous 57-plane buffer (same layout): one launch over its 19 F_{p^3} rows
                 launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 19, r, c->stream());
             }
@@ -2105,8 +2117,21 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                     RET(c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(N, K), &sv_bits[sd]));
                     launch_sv_bits(S[sd].planes, N, N, K, sv_bits[sd], c->stream());
                 }
-            launch_fold_round_g(c->dcrt, a, partial, gtmp, c->stream());
-            if (launch_sv_round(c->dcrt, svV, sv_bits[0], sv_bits[1], N, a.eqB, a.ld, a.p0, a.pcnt, K, d_mu, d_coef, sveb, svpart, svtot, svtp, gtmp, od, c->stream()) != 0)
+            hipStream_t sg = round == 1 ? (sv_two_streams && !sharded ? c->st_lane[1] : c->stream()) : sv_g_stream;
+            hipEvent_t g_ready = nullptr;
+            if (sg != c->stream()) {
+                if (!c->ev_prep[0]) { HIPCHK(hipEventCreateWithFlags(&c->ev_prep[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_prep[1], hipEventDisableTiming)); }
+                if (round == 1) {   // the tables of round 1 come from fold prepare, whose left chain ran on this lane's stream: the other stream has not seen it
+                    HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));
+                    HIPCHK(hipStreamWaitEvent(sg, c->ev_prep[0], 0));
+                }
+            }
+            launch_fold_round_g(c->dcrt, a, partial, gtmp, sg);
+            if (sg != c->stream()) {
+                HIPCHK(hipEventRecord(c->ev_prep[1], sg));
+                g_ready = c->ev_prep[1];
+            }
+            if (launch_sv_round(c->dcrt, svV, sv_bits[0], sv_bits[1], N, a.eqB, a.ld, a.p0, a.pcnt, K, d_mu, d_coef, sveb, svpart, svtot, svtp, gtmp, od, c->stream(), g_ready) != 0)
                 return LF_ERR_UNSUPPORTED;
             c->sv_round_mask |= 1u << (round - 1);
         } else

@@ -61,5 +61,5 @@ struct DevCrt;
 struct Fq3Const;
 int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
                     const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
-                    hipStream_t s);
+                    hipStream_t s, hipEvent_t gpart_ready = nullptr);
 }  // namespace lf

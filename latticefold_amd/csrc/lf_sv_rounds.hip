@@ -346,7 +346,7 @@ size_t sv_tp_words(uint32_t K) { return (size_t)2 * K * 24 * 15; }
 
 int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
                     const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
-                    hipStream_t s) {
+                    hipStream_t s, hipEvent_t gpart_ready) {
     // pairs of the slice behind which witness positions exist (positions >= nplanes are zero digits: nothing to add)
     const size_t wall = cdiv(nplanes, 2 * (size_t)V);
     const size_t wpairs = pair0 >= wall ? 0 : (wall - pair0 < npairs ? wall - pair0 : npairs);
@@ -373,6 +373,7 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     const u32 npr = (u32)sv_num_pairs(V);
     if (t.nu2p40) hipLaunchKernelGGL((k_sv_finish1<true>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp);
     else hipLaunchKernelGGL((k_sv_finish1<false>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp);
+    if (gpart_ready) (void)hipStreamWaitEvent(s, gpart_ready, 0);   // the G part was computed on another stream
     hipLaunchKernelGGL(k_sv_finish2, dim3(1), dim3(1024), 0, s, tp, K, gpart, out);
     return 0;
 }
