@@ -1,10 +1,13 @@
 // lf_sv_rounds.hip -- rounds 1..3 of the folding sumcheck as exact int8 GEMMs (gfx950 v_mfma_i32_16x16x64_i8); see lf_sv_rounds.h for
 // the algebra.  Kernels:
-//   k_sv_pack_eq   eqB[3][2 npairs] -> byte planes EB[48][npairs] (bytes of eqB(2p) and eqB(2p+1), biased by -128), MFMA B operand;
+//   k_sv_bits      int32 witness planes -> bit planes (one row of magnitude bits per digit plane + one row of sign bits per coefficient);
+//   k_sv_pack_eq   eqB[3][2 npairs] -> digit planes EB[48][padded pairs] (balanced base-256 digits of eqB(2p) and eqB(2p+1), in the slot
+//                  order of the A operand), MFMA B operand;
 //   k_sv_gemm<V,PG> one wave = one (side, coefficient, 16 digit planes) group x one chunk of pairs x one group of PW (sigma, beta) pairs:
-//                  per K-step of 64 pairs it cuts the 2V signed bits of its 16 pairs from the int32 witness planes (the 16 plane lanes
-//                  of a tile share the loads), builds the +-1 / 0 operand bytes of every (sigma, beta) with byte-wise AND / XOR, and
-//                  issues 3 MFMAs per pair (column tiles: the balanced base-256 digits of eqB(2p) 0-15, 16-23 | eqB(2p+1) 0-7, 8-23).
+//                  per K-step of 64 pairs it expands the 2V signed bits of its 16 pairs from one word of magnitude bits and one of sign
+//                  bits per V (shift + mask), builds the +-1 / 0 operand bytes of every (sigma, beta) with byte-wise AND / XOR, and
+//                  issues 3 MFMAs per pair (column tiles: the digits of eqB(2p) 0-15, 16-23 | eqB(2p+1) 0-7, 8-23); the waves of a block
+//                  share the eqB digits of a super-step (512 positions) through a double-buffered LDS tile;
 //   k_sv_sum       element-wise sum of the chunks' partial tiles (int32: |sum| <= 128 * npairs < 2^31 up to 2^23 pairs);
 //   k_sv_finish1   per table T: M_pi = sum_u 2^(8u) C_u mod p for eqB(2p) and eqB(2p+1), the table's degree-4 polynomial
 //                  sum_pi C_pi(X) (M0 + X (M1 - M0)), times mu_T;
