@@ -82,6 +82,6 @@ def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     for name, r in d.items():
         assert len(r["ranks"]) == world
-        assert all(x == r["ref"] for x in r["ranks"]), (name, r)
-        if two_lanes == "gemm":   # every rank (and the unsharded reference) ran rounds 1-3 as GEMMs
-            assert r["ref"].endswith(":7"), r
+        assert all(x.split(":")[0] == r["ref"].split(":")[0] for x in r["ranks"]), (name, r)
+        if two_lanes == "gemm":   # every rank and the unsharded reference ran rounds 1-3 as GEMMs (fold_paths mask behind the digest)
+            assert r["ref"].endswith(":7") and all(x.endswith(":7") for x in r["ranks"]), r
