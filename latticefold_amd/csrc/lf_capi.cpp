@@ -1597,12 +1597,12 @@ static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *
 // <X_a, Y_b> for na vectors X and nb vectors Y of n columns -> od (device, canonical): on the int8 matrix cores (lf_dot_i8.hip) unless
 // LF_DOT_VALU is set or the shape is not handled there
 static int dot_batch_dev(lf_ctx *c, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *dpart, u64 *od) {
-    if (!c->tn.dot_valu && n >= 4096 && nb <= 3) {
+    if (!c->tn.dot_valu && n >= c->tn.dot_min && nb <= 3) {
         unsigned char *yb;
         int32_t *part;
         long long *tot;
-        RET(c->tbuf("dot_yb", dot_i8_yb_bytes(n), &yb));
-        RET(c->tbuf("dot_i8_part", dot_i8_part_words(n), &part));
+        RET(c->tbuf("dot_yb", dot_i8_yb_bytes(n + 1), &yb));            // (+1: an odd column slice starts one column early)
+        RET(c->tbuf("dot_i8_part", dot_i8_part_words(n + 1), &part));
         RET(c->tbuf("dot_i8_tot", dot_i8_tot_words(), &tot));
         bool ok = true;
         for (u32 a0 = 0; a0 < na && ok; a0 += 16)

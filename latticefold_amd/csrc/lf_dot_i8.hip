@@ -34,7 +34,7 @@ __device__ __forceinline__ u64 dot_digits(u64 w) {
 
 // YB[slot][(b*3 + cq)*8 + v][.] = digit v of Y_b[3 slot + cq][i] in the operand order of dot_load_x per block of 64 columns, zero beyond n
 // (ldq columns per row); wave = (word plane, 64 columns)
-__global__ void __launch_bounds__(256) k_dot_pack_y(const u64 *Y, size_t ldy, u32 nb, size_t n, size_t ldq, unsigned char *YB) {
+__global__ void __launch_bounds__(256) k_dot_pack_y(const u64 *Y, size_t ldy, u32 nb, size_t n, size_t lead, size_t ldq, unsigned char *YB) {
     __shared__ u64 sm[4][64];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr u32 PER_WAVE = 8;                                   // blocks of 64 columns per wave
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_dot_pack_y(const u64 *Y, size_t ldy, u3
         const size_t blk = (wid % groups) * PER_WAVE + k;
         if (blk >= blocks) break;
         const size_t i0 = blk * 64, i = i0 + lane;
-        sm[wave][lane] = i < n ? dot_digits(src_row[i]) : 0;
+        sm[wave][lane] = (i >= lead && i < n) ? dot_digits(src_row[i]) : 0;   // (the first `lead` columns belong to the neighbour slice: zero digits)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         u64 o = 0;
@@ -211,9 +211,13 @@ size_t dot_i8_tot_words() { return (size_t)24 * 10240; }
 // X [na][24][ldx], Y [nb][24][ldy], n columns; out[(a*nb + b)*24 + 3*slot + comp] canonical.  Returns 0, or -1 if the shape is not handled.
 int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
                         long long *tot, u64 *out, hipStream_t s) {
-    if (na < 1 || na > 16 || nb < 1 || nb > 3 || n < 64 || (ldx & 1) || (((size_t)X) & 15)) return -1;
+    if (na < 1 || na > 16 || nb < 1 || nb > 3 || n < 64 || (ldx & 1) || (((size_t)X) & 7)) return -1;
+    // a column slice that starts at an odd column (a rank's slice of a sharded step): start one column earlier (16-byte aligned loads) and
+    // give that column zero digits on the Y side
+    const size_t lead = (((size_t)X) & 15) ? 1 : 0;
+    X -= lead; Y -= lead; n += lead;
     const size_t ldq = dcdiv(n, 64) * 64;
-    hipLaunchKernelGGL(k_dot_pack_y, dim3((unsigned)dcdiv((size_t)nb * 24 * dcdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, ldq, YB);
+    hipLaunchKernelGGL(k_dot_pack_y, dim3((unsigned)dcdiv((size_t)nb * 24 * dcdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
     DotI8Args a;
     a.X = X; a.ldx = ldx; a.n = n; a.na = na; a.YB = YB; a.ldq = ldq; a.nrows_y = 24 * nb;
     a.nsteps = (u32)(ldq / 64);

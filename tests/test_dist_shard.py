@@ -70,7 +70,7 @@ def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     if two_lanes == "big":
         env.update(LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
     elif two_lanes == "gemm":   # rounds 1-3 of the folding sumcheck as int8 GEMMs on the ranks' pair slices (lf_sv_rounds.h), then the large-instance modes
-        env.update(LF_FOLD_SV_MIN="64", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
+        env.update(LF_FOLD_SV_MIN="64", LF_DOT_MIN="64", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")   # (LF_DOT_MIN: the int8 inner products on the ranks' column slices, odd first columns included)
     elif two_lanes == "plain":
         env.update(LF_SHARD_PLAIN_ROUNDS="1", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
     elif two_lanes:   # the threaded two-lane schedule with one exchange channel per lane (default in a sharded step: one host thread)

@@ -317,6 +317,7 @@ def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
     wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
     lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
     monkeypatch.setenv("LF_FOLD_SV_MIN", "64")
+    monkeypatch.setenv("LF_DOT_MIN", "64")          # ... and the u_s / eta inner products as int8 GEMMs at this size too
     m = 1 << wl.s
     for rounds, extra in ((1, {}), (2, {}), (3, {}), (2, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}), (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}),
                           (3, {"LF_NO_TAIL": "1", "LF_FOLD_UNFUSED": "1"})):
