@@ -185,6 +185,10 @@ struct lf_ctx {
     bool vs_keep = false;            // set by the fold step around its linearization: only there the decomposition that follows uses the same point
     const u64 *vs_eq = nullptr;
     u64 *vs_dev = nullptr;
+    // bit-plane forms of the two witnesses of the running fold step (lf_sv_rounds.h), enqueued on the helper lane's stream before anything else
+    const lf_witness *bits_wit[2] = {nullptr, nullptr};
+    u32 *bits_ptr[2] = {nullptr, nullptr};
+    hipEvent_t bits_ev[2] = {nullptr, nullptr};
     hipEvent_t ev_prep[2] = {nullptr, nullptr};   // fold prepare: fork / join of the right side's chain on the helper lane's stream
     unsigned sv_round_mask = 0;      // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
 
@@ -429,8 +433,10 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->tail_counters) (void)hipFree(c->tail_counters);
     if (c->d_poseidon) (void)hipFree(c->d_poseidon);
     if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
         if (c->ev_prep[i]) (void)hipEventDestroy(c->ev_prep[i]);
+        if (c->bits_ev[i]) (void)hipEventDestroy(c->bits_ev[i]);
+    }
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
     delete c;
@@ -1425,7 +1431,8 @@ static bool lcccs_point(const lf_params &P, const u64 *lcccs, std::vector<Fq3> &
     return true;
 }
 
-static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial, u64 *od, size_t ldp);
+static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial, u64 *od, size_t ldp,
+                         const lf_witness *wit = nullptr);
 static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_witness *wit, u64 *lcccs_out, u64 *proof, u64 **eq_r_keep) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n;
@@ -1467,7 +1474,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
             // evaluation of the full coefficients: v = sum_k 2^k v_s[k]
             u64 *vs;
             RET(c->tbuf("lin_vs", (size_t)P.K * 72 + 8, &vs));
-            RET(coef_eval_dev(c, wit->planes, c->N, eqr, m, P.K, 1, partial, vs, c->N));
+            RET(coef_eval_dev(c, wit->planes, c->N, eqr, m, P.K, 1, partial, vs, c->N, wit));
             launch_vs_combine(vs, P.K, od, c->stream());
             if (c->vs_keep) { c->vs_wit = wit; c->vs_eq = eqr; c->vs_dev = vs; }
         } else {
@@ -1579,7 +1586,22 @@ static int decompose_commit_finish(lf_ctx *c, const u64 *cm, u64 *yd, size_t ev,
 
 // v / v_s / theta: sum_j eq[j] * (digit planes or coefficients of the witness planes) -> od (device, canonical).  On the int8 matrix cores
 // (launch_coef_eval_i8) unless LF_COEF_VALU is set or the shape is not handled there.
-static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial, u64 *od, size_t ldp) {
+static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *eq, size_t ldeq, u32 K, int mode_bits, u64 *partial, u64 *od, size_t ldp,
+                         const lf_witness *wit) {
+    // the whole witness of a running fold step, digit planes: from its bit-plane form with the round-1 GEMM of lf_sv_rounds.hip (the digit
+    // cutting of k_coef_eval_i8 from the int32 planes is what that kernel spends its time on)
+    if (wit && mode_bits && !c->tn.coef_valu && !c->tn.coef_planes && planes == wit->planes && n == c->N)
+        for (int sd = 0; sd < 2; sd++)
+            if (c->bits_wit[sd] == wit && c->bits_ptr[sd]) {
+                unsigned char *EB;
+                int32_t *part, *tot;
+                RET(c->tbuf("vs_eb", sv_eb_bytes(n / 2), &EB));
+                RET(c->tbuf("vs_part", sv_vs_part_words(n, K), &part));
+                RET(c->tbuf("vs_tot", sv_vs_tot_words(K), &tot));
+                if (c->stream() != c->st_lane[1]) HIPCHK(hipStreamWaitEvent(c->stream(), c->bits_ev[sd], 0));
+                if (launch_sv_vs(c->bits_ptr[sd], n, eq, ldeq, K, EB, part, tot, od, c->stream()) == 0) return LF_OK;
+                break;
+            }
     if (!c->tn.coef_valu && n >= 64) {
         unsigned char *EB;
         int32_t *part;
@@ -1662,7 +1684,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
             HIPCHK(hipMemcpyAsync(od_v, c->vs_dev, (size_t)K * 72 * 8, hipMemcpyDeviceToDevice, c->stream()));
             c->vs_wit = nullptr;
         } else {
-            RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od_v, N));
+            RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od_v, N, c->sh_world == 1 ? wit : nullptr));
             RET(exchange_modsum_dev(c, od_v, (size_t)K * 72));
         }
     }
@@ -2413,6 +2435,21 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         c->lin_blocks = 0;
         if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
     } else {
+    c->bits_wit[0] = c->bits_wit[1] = nullptr;
+    if (!c->tn.fold_no_sv && !c->tn.force_exchange && c->N <= c->m && (c->N & 3) == 0 && !c->tn.fold_tab_r1 && (c->m >> 1) >= c->tn.sv_min) {
+        // bit-plane form of both witnesses (GEMM rounds of the folding sumcheck, v_s evaluations): first thing on the helper lane's stream,
+        // enqueued from here so that the events below are recorded before anybody can wait for them
+        const lf_witness *ws[2] = {w_acc, w_i};
+        for (int sd = 0; sd < 2; sd++) {
+            u32 *bits;
+            if (c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(c->N, P.K), &bits) != LF_OK) break;
+            if (!c->bits_ev[sd] && hipEventCreateWithFlags(&c->bits_ev[sd], hipEventDisableTiming) != hipSuccess) break;
+            launch_sv_bits(ws[sd]->planes, c->N, c->N, P.K, bits, c->st_lane[1]);
+            if (hipEventRecord(c->bits_ev[sd], c->st_lane[1]) != hipSuccess) break;
+            c->bits_wit[sd] = ws[sd]; c->bits_ptr[sd] = bits;
+            S[sd].sv_bits = bits;
+        }
+    }
     c->lane1.submit([&]() -> int {
         t_lane = 1;
         struct Publish {   // whatever path this lane takes, the main thread learns whether the right side's z_k are coming
@@ -2431,17 +2468,6 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
             HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
             (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
-        }
-        if (!c->tn.fold_no_sv && !c->tn.force_exchange && c->N <= c->m && (c->N & 3) == 0 && !c->tn.fold_tab_r1 && (c->m >> 1) >= c->tn.sv_min) {
-            // bit-plane form of both witnesses for the GEMM rounds of the folding sumcheck, behind the commit on this lane's stream
-            // (decompose_commit_finish below synchronises it)
-            const lf_witness *ws[2] = {w_acc, w_i};
-            for (int sd = 0; sd < 2; sd++) {
-                u32 *bits;
-                if (c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(c->N, P.K), &bits) != LF_OK) break;
-                launch_sv_bits(ws[sd]->planes, c->N, c->N, P.K, bits, c->stream());
-                S[sd].sv_bits = bits;
-            }
         }
         if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
@@ -2475,6 +2501,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     }
     TL_MARK("right absorb done");
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
+    c->bits_wit[0] = c->bits_wit[1] = nullptr;
     TL_MARK("fold done");
     tl.dump();
     t_tl = nullptr;

@@ -68,6 +68,7 @@ struct Tunables {
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
     bool prep_one_stream = false;    // LF_PREP_ONE_STREAM: both sides of fold prepare on one stream
     size_t dot_min = 4096;           // LF_DOT_MIN: columns from which the int8 form of the inner products is used
+    bool coef_planes = false;        // LF_COEF_PLANES: v_s of a fold step from the int32 planes (k_coef_eval_i8) instead of the bit planes (launch_sv_vs)
     bool dot_valu = false;           // LF_DOT_VALU: u_s / eta inner products on the 64-bit VALU kernel (k_dot_batch) instead of the int8 matrix cores
     bool lin_v_direct = false;       // LF_LIN_V_DIRECT: v of the linearization from the full coefficients instead of sum_k 2^k v_s[k]
     bool fold_no_sv = false;         // LF_FOLD_NO_SV: rounds 1-3 of the folding sumcheck on the VALU kernels instead of the int8 matrix-core GEMMs (lf_sv_rounds.hip)
@@ -91,6 +92,7 @@ struct Tunables {
         t.fold_no_sv = getenv("LF_FOLD_NO_SV") != nullptr;
         t.lin_v_direct = getenv("LF_LIN_V_DIRECT") != nullptr;
         t.dot_valu = getenv("LF_DOT_VALU") != nullptr;
+        t.coef_planes = getenv("LF_COEF_PLANES") != nullptr;
         if ((e = getenv("LF_DOT_MIN"))) t.dot_min = (size_t)atoll(e);
         t.prep_one_stream = getenv("LF_PREP_ONE_STREAM") != nullptr;
         if ((e = getenv("LF_FOLD_SV_MIN"))) t.sv_min = (size_t)atoll(e);

@@ -112,6 +112,7 @@ struct SvGemmArgs {
     const unsigned char *EB;    // [48][ldeb]
     size_t ldeb;
     u32 ktiles;                 // tiles of 16 digit planes
+    u32 nsides;                 // 2 witnesses (round GEMMs) or 1 (launch_sv_vs)
     u32 nsuper, super_per_chunk;   // super-steps of 512 positions (256 / V pairs)
     u32 super0;                 // first super-step of the bit planes (a rank's pair slice of a sharded step; the eqB bytes start at its first pair)
     int32_t *part;              // [chunk][group][pair][3][64][4]
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
     constexpr int PIECES = 48 * SPAIRS / 16, PPT = (PIECES + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][48][LROW];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, g = lane >> 4;
-    const u32 ngroups = 48 * a.ktiles, gq = ngroups / NW;
+    const u32 ngroups = 24 * a.nsides * a.ktiles, gq = ngroups / NW;
     const u32 grp = (blockIdx.x % gq) * NW + wave, chunk = blockIdx.x / gq;
     const u32 kt = grp % a.ktiles, c = (grp / a.ktiles) % 24, side = grp / (a.ktiles * 24);
     const u32 *mrow = a.bits[side] + ((size_t)c * a.rows + 16 * kt + row) * a.nw;
@@ -334,8 +335,8 @@ void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uin
 }
 // chunks of super-steps (512 positions): the launches of the pair groups run one after the other, a block fills a CU (registers), so one launch
 // is one batch of at most 256 blocks
-uint32_t sv_chunks(int V, size_t nsuper, uint32_t K) {
-    const u32 ktiles = (K + 15) / 16, per_chunk = 48 * ktiles / (u32)sv_waves(V);
+static uint32_t sv_chunks_n(int V, size_t nsuper, uint32_t K, uint32_t nsides) {
+    const u32 ktiles = (K + 15) / 16, per_chunk = 24 * nsides * ktiles / (u32)sv_waves(V);
     if (nsuper == 0) return 1;
     size_t want = 256 / per_chunk;
     if (want > nsuper) want = nsuper;
@@ -343,6 +344,7 @@ uint32_t sv_chunks(int V, size_t nsuper, uint32_t K) {
     const size_t spc = cdiv(nsuper, want);
     return (u32)cdiv(nsuper, spc);
 }
+uint32_t sv_chunks(int V, size_t nsuper, uint32_t K) { return sv_chunks_n(V, nsuper, K, 2); }
 size_t sv_tot_words(int V, uint32_t K) { return (size_t)48 * ((K + 15) / 16) * sv_num_pairs(V) * 768; }
 size_t sv_part_words(int V, size_t npairs, uint32_t K) { return sv_tot_words(V, K) * sv_chunks(V, cdiv(npairs * V, 256), K); }
 size_t sv_tp_words(uint32_t K) { return (size_t)2 * K * 24 * 15; }
@@ -359,6 +361,7 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     SvGemmArgs a;
     a.bits[0] = bitsL; a.bits[1] = bitsR;
     a.ktiles = (K + 15) / 16;
+    a.nsides = 2;
     a.rows = 16 * a.ktiles + 1;
     a.nw = sv_npad(nplanes) / 32;
     a.EB = EB; a.ldeb = ldeb;
@@ -378,6 +381,54 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     else hipLaunchKernelGGL((k_sv_finish1<false>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp);
     if (gpart_ready) (void)hipStreamWaitEvent(s, gpart_ready, 0);   // the G part was computed on another stream
     hipLaunchKernelGGL(k_sv_finish2, dim3(1), dim3(1024), 0, s, tp, K, gpart, out);
+    return 0;
+}
+
+// v_s[k][c][q] = sum_i eq[q][i] * digit_k(planes[c][i]) (decomposition.rs:204-211) from the bit-plane form of ONE witness with the round-1
+// GEMM: its two single pairs ({x},{x}), x = 0 / 1, against the digits of eq(2p) / eq(2p+1) are the even / odd halves of that sum.
+// thread = output (k, c, q): out[(k*24 + c)*3 + q]
+__global__ void __launch_bounds__(256) k_sv_vs_finish(const int32_t *tot, u32 K, u32 ktiles, u64 *out) {
+    const u32 o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= K * 72) return;
+    const u32 q = o % 3, c = (o / 3) % 24, k = o / 72;
+    const u32 grp = c * ktiles + k / 16, krow = k & 15;
+    __int128 v = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int32_t *base = tot + ((size_t)grp * 4 + (h ? 2 : 0)) * 768;   // pair 0 = ({0},{0}), pair 2 = ({1},{1}) in the canonical order of V = 1
+        for (u32 u = 0; u < 8; u++) {
+            const u32 bp = 24 * h + 8 * q + u;
+            v += (__int128)base[(bp >> 4) * 256 + ((bp & 15) + 16 * (krow >> 2)) * 4 + (krow & 3)] << (8 * u);
+        }
+    }
+    out[o] = fq_from_s128((u64)v, (int64_t)(v >> 64));
+}
+size_t sv_vs_part_words(size_t n, uint32_t K) { return sv_tot_words(1, K) / 2 * sv_chunks_n(1, cdiv(n / 2, 256), K, 1); }
+size_t sv_vs_tot_words(uint32_t K) { return sv_tot_words(1, K) / 2; }
+// bits: launch_sv_bits form of the witness (n positions, n even); eq [3][ldeq]; EB / part / tot: scratch (sv_eb_bytes(n / 2), sv_vs_part_words, sv_vs_tot_words).
+// Returns 0, or -1 if the shape is not handled.
+int launch_sv_vs(const uint32_t *bits, size_t n, const uint64_t *eq, size_t ldeq, uint32_t K, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *out, hipStream_t s) {
+    static_assert(sv_pair(1, 0).s == 1 && sv_pair(1, 0).b == 1 && sv_pair(1, 2).s == 2 && sv_pair(1, 2).b == 2, "single pairs of V = 1");
+    const size_t npairs = n / 2;
+    if ((n & 1) || !sv_shape_ok(1, npairs, K)) return -1;
+    const size_t ldeb = sv_ldeb(npairs);
+    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eq, ldeq, npairs, ldeb, 1, EB);
+    SvGemmArgs a;
+    a.bits[0] = bits; a.bits[1] = bits;
+    a.ktiles = (K + 15) / 16;
+    a.nsides = 1;
+    a.rows = 16 * a.ktiles + 1;
+    a.nw = sv_npad(n) / 32;
+    a.EB = EB; a.ldeb = ldeb;
+    a.nsuper = (u32)cdiv(npairs, 256);
+    a.super0 = 0;
+    const u32 chunks = sv_chunks_n(1, a.nsuper, K, 1);
+    a.super_per_chunk = (u32)cdiv(a.nsuper, chunks);
+    a.part = part;
+    hipLaunchKernelGGL((k_sv_gemm<1, 0>), dim3(24 * a.ktiles / (u32)sv_waves(1) * chunks), dim3(64 * sv_waves(1)), 0, s, a);
+    const size_t words = sv_vs_tot_words(K);
+    hipLaunchKernelGGL(k_sv_sum, dim3((unsigned)cdiv(words / 4, 256)), dim3(256), 0, s, part, words, chunks, tot);
+    hipLaunchKernelGGL(k_sv_vs_finish, dim3((unsigned)cdiv((size_t)K * 72, 256)), dim3(256), 0, s, tot, K, a.ktiles, out);
     return 0;
 }
 }  // namespace lf
