@@ -1057,6 +1057,26 @@ static int dec_enqueue_commit(C *c, const lf_witness *wit, DecPending &pd) {
     HIPCHK(hipEventRecord(c->ev_dec[2 * pd.side], c->stream()));
     return LF_OK;
 }
+// <X_a, Y_b> for na vectors X and nb vectors Y of n columns -> od (device, canonical): on the int8 matrix cores (bb_dot_i8.hip) unless
+// LF_DOT_VALU is set or the shape is not handled there
+static int dot_batch_dev(BbCtxImpl *c, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial, u64 *od) {
+    if (!c->tn.dot_valu && n >= c->tn.dot_min && nb <= 3) {
+        unsigned char *yb;
+        int32_t *part;
+        long long *tot;
+        RET(c->tbuf("dot_yb", bbdot_i8_yb_bytes(n + 1), &yb));
+        RET(c->tbuf("dot_i8_part", bbdot_i8_part_words(n + 1), &part));
+        RET(c->tbuf("dot_i8_tot", bbdot_i8_tot_words(), &tot));
+        bool ok = true;
+        for (u32 a0 = 0; a0 < na && ok; a0 += 16)
+            ok = launch_dot_batch_i8(c->dev, X + (size_t)a0 * RE * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * RE,
+                                     c->stream()) == 0;
+        if (ok) return LF_OK;
+    }
+    launch_dot_batch(c->dev, X, ldx, na, Y, ldy, nb, n, partial, od, c->stream());
+    return LF_OK;
+}
+
 static int dec_enqueue_evals(C *c, const u64 *lcccs, const std::vector<H9> &rpt, const lf_witness *wit, const char *side, fe *eq_r, SideState &S,
                              u64 *proof, DecPending &pd) {
     const lf_params &P = c->P;
@@ -1090,7 +1110,7 @@ static int dec_enqueue_evals(C *c, const u64 *lcccs, const std::vector<H9> &rpt,
     for (u32 j = 0; j < P.t; j++)
         launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * RE * n, n, c->stream());
     u64 *od2 = od + 16 * RE * TAU;
-    launch_dot_batch(c->dev, z, n, K, q, n, P.t, n, partial, od2, c->stream());
+    RET(dot_batch_dev(c, z, n, K, q, n, P.t, n, partial, od2));
     HIPCHK(hipMemcpyAsync(pd.h_u, od2, (size_t)K * P.t * RE * 8, hipMemcpyDeviceToHost, c->stream()));
     c->ev_end(pd.ph_evals);
     HIPCHK(hipEventRecord(c->ev_dec[2 * pd.side + 1], c->stream()));
@@ -1360,7 +1380,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * TAU * RE, c->stream());
     HIPCHK(hipMemcpyAsync(hp, d_theta, nth * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventRecord(c->ev_side[0], c->stream()));
-    for (int sd = 0; sd < 2; sd++) launch_dot_batch(c->dev, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE, c->stream());
+    for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE));
     HIPCHK(hipMemcpyAsync(hp + nth, d_eta, net * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventSynchronize(c->ev_side[0]));
     memcpy(theta, hp, nth * 8);

@@ -64,6 +64,13 @@ void launch_spmv_sum(const DevBb &t, u32 nm, const u32 *const *rowptr, const u32
 void launch_spmv_t_eq(const DevBb &t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m, fe *q, size_t n,
                       hipStream_t s);
 size_t red_partial_words(u32 nv);
+// the same on the int8 matrix cores (bb_dot_i8.hip), na <= 16, nb <= 3; scratch: YB bbdot_i8_yb_bytes(n), part bbdot_i8_part_words(n) int32,
+// tot bbdot_i8_tot_words() int64.  Returns 0, or -1 if the shape is not handled.
+size_t bbdot_i8_yb_bytes(size_t n);
+size_t bbdot_i8_part_words(size_t n);
+size_t bbdot_i8_tot_words();
+int launch_dot_batch_i8(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
+                        long long *tot, u64 *out, hipStream_t s);
 void launch_dot_batch(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial,
                       u64 *out /*[na][nb][72] canonical*/, hipStream_t s);
 void launch_dot_eq(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *eq, size_t ldeq, size_t n, i64 *partial,
