@@ -253,6 +253,20 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
 
 
+@pytest.mark.parametrize("name", ["B6", "B10", "BDP"])
+def test_fold_step_int8_inner_products_match_oracle(ctx, name, monkeypatch):
+    """u_s / eta as int8 GEMMs on the matrix cores (bb_dot_i8.hip; the driver uses them from 4096 columns on, LF_DOT_MIN lowers the
+    threshold) and on the VALU kernel: identical proofs, equal to the oracle's"""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 3)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    monkeypatch.setenv("LF_DOT_MIN", "64")
+    lc_i, w_i, proof_i = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    monkeypatch.setenv("LF_DOT_VALU", "1")
+    lc_v, w_v, proof_v = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    assert (proof_i == proof_o).all() and (lc_i == lc_o).all() and (w_i.f == f0_o).all()
+    assert (proof_v == proof_o).all() and (lc_v == lc_o).all()
+
+
 def test_sumcheck_lin_abi(ctx):
     wl, inst, A, scheme = setup_case(ctx, "B8")
     f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
