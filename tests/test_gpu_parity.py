@@ -309,7 +309,7 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
 
 
-@pytest.mark.parametrize("name", ["T10", "T8", "E32"])
+@pytest.mark.parametrize("name", ["T10", "T8", "E32", "E22"])
 def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
     """rounds 1..3 of the folding sumcheck as exact int8 GEMMs on the matrix cores (lf_sv_rounds.hip; the driver uses them from 8192
     pairs on, LF_FOLD_SV_MIN lowers the threshold): one, two and three rounds in that form, followed by the look-up-table rounds, the
