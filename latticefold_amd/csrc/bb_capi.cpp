@@ -58,6 +58,11 @@ struct BbCtxImpl {
     hipEvent_t ev_dec[4] = {nullptr, nullptr, nullptr, nullptr};   // decomposition milestones: [2*side + (0 commit, 1 evaluations)]
     int digit_mode = 0;   // balanced-digit rule (lf_set_digit_mode)
     Tunables tn;          // environment switches, re-read at the start of every linearize / fold_step
+    // v_s of the linearized instance computed inside the linearization (v = sum_k 2^k v_s[k]); reused by the right decomposition of the same fold step
+    const lf_witness *vs_wit = nullptr;
+    const fe *vs_eq = nullptr;
+    u64 *vs_dev = nullptr;
+    bool vs_keep = false;
     u32 lin_blocks = 0;   // grid bound of the linearization rounds while the commit chain runs on the other lane (0 = none)
     u64 *h_round = nullptr;   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
     u64 *round_out() {
@@ -970,7 +975,16 @@ static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witn
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + (size_t)TAU * RE));
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * RE, *u = v + (size_t)TAU * RE;   // contiguous
-    launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());   // T[72][9] flat == v[9][8 slots][9]
+    c->vs_wit = nullptr;
+    if (P.b == 2 && P.K <= 16 && !c->tn.lin_v_direct) {
+        // the K digit-plane evaluations v_s[k] (the decomposition of this instance needs them at the same point anyway): v = sum_k 2^k v_s[k]
+        u64 *vs;
+        RET(c->tbuf("lin_vs", (size_t)P.K * TAU * RE + 8, &vs));
+        launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, P.K, 1, partial, vs, c->stream());
+        launch_vs_combine(vs, P.K, TAU * RE, od, c->stream());
+        if (c->vs_keep) { c->vs_wit = wit; c->vs_eq = eqr; c->vs_dev = vs; }
+    } else
+        launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, 1, 0, partial, od, c->stream());   // T[72][9] flat == v[9][8 slots][9]
     if (u_eval) {
         RET(down_small(c, od, (size_t)TAU * RE, v));
         launch_dot_eq(c->dev, mz, m, P.t, eqr, m, m, partial, od, c->stream());
@@ -1103,7 +1117,11 @@ static int dec_enqueue_evals(C *c, const u64 *lcccs, const std::vector<H9> &rpt,
     pd.ph_evals = c->ev_begin(12);
     compute_x_s(c, xh, x_s);   // host, O(l) elements
     // v_s (decomposition.rs:204-211) from the coefficient planes
-    launch_coef_eval(c->dev, wit->planes, N, eq_r, m, K, 1, partial, od, c->stream());
+    if (c->vs_wit == wit && c->vs_eq == eq_r) {   // computed by the linearization of this step at this very point
+        HIPCHK(hipMemcpyAsync(od, c->vs_dev, (size_t)K * TAU * RE * 8, hipMemcpyDeviceToDevice, c->stream()));
+        c->vs_wit = nullptr;
+    } else
+        launch_coef_eval(c->dev, wit->planes, N, eq_r, m, K, 1, partial, od, c->stream());
     HIPCHK(hipMemcpyAsync(pd.h_v, od, (size_t)K * TAU * RE * 8, hipMemcpyDeviceToHost, c->stream()));
     // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     RET(build_z_async(c, wit->planes, K, 1, x_s, z));
@@ -1511,12 +1529,15 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
         tr.absorb_label("cm_i");
         tr.absorb_ring(cm_i, bb_cccs_len(&P));
     }
+    c->vs_keep = true;
     if (rc == LF_OK) rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    c->vs_keep = false;
     std::vector<H9> rR;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
         rc = dec_enqueue_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr, pdR);
     }
+    c->vs_wit = nullptr;
     c->lin_blocks = 0;
     if (rc == LF_OK) rc = dec_finish(c, tr, acc, S[0], decl, pdL);
     if (rc == LF_OK) rc = dec_finish(c, tr, lin.data(), S[1], decr, pdR);

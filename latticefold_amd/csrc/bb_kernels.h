@@ -75,6 +75,7 @@ void launch_dot_batch(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe 
                       u64 *out /*[na][nb][72] canonical*/, hipStream_t s);
 void launch_dot_eq(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *eq, size_t ldeq, size_t n, i64 *partial,
                    u64 *out /*[na][72]*/, hipStream_t s);
+void launch_vs_combine(const u64 *vs /* [K][nv] canonical */, u32 K, u32 nv, u64 *v, hipStream_t s);   // v = sum_k 2^k v_s[k]
 // T[k][c] = sum_i eq[i] * digit_k(planes[c][i]) (mode_bits) or the full value (K = 1): out canonical [K][72][9]
 void launch_coef_eval(const DevBb &t, const int32_t *planes, size_t n, const fe *eq, size_t ldeq, u32 K, int mode_bits, i64 *partial,
                       u64 *out, hipStream_t s);

@@ -84,6 +84,18 @@ __global__ void __launch_bounds__(256) k_reduce_rows(const i64 *partial, u32 nbl
     __syncthreads();
     if (threadIdx.x == 0) out[i] = to_canon(fred(res[0]));
 }
+// v = sum_k 2^k v_s[k] (canonical words): the MLE evaluation of the witness coefficients from the evaluations of their K binary digit planes
+__global__ void __launch_bounds__(256) k_vs_combine(const u64 *vs, u32 K, u32 nv, u64 *v) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nv) return;
+    u64 acc = 0, pw = 1;
+    for (u32 k = 0; k < K; k++) {
+        acc = (acc + vs[(size_t)k * nv + i] % BB_P * pw) % BB_P;
+        pw = pw * 2 % BB_P;
+    }
+    v[i] = acc;
+}
+void launch_vs_combine(const u64 *vs, u32 K, u32 nv, u64 *v, hipStream_t s) { hipLaunchKernelGGL(k_vs_combine, dim3((nv + 255) / 256), dim3(256), 0, s, vs, K, nv, v); }
 void launch_reduce_rows(const i64 *partial, u32 nblocks, u32 nv, u64 *out, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce_rows, dim3(nv), dim3(256), 0, s, partial, nblocks, nv, out);
 }
