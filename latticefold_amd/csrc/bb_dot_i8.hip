@@ -187,7 +187,8 @@ static u32 bbdot_chunks(size_t nsteps) {
     const size_t spc = bdiv(nsteps, want);
     return (u32)bdiv(nsteps, spc);
 }
-size_t bbdot_i8_part_words(size_t n) { return (size_t)72 * bbdot_chunks(bdiv(n, 64)) * 7168; }
+// sized for the largest chunk count (bbdot_chunks is not monotone in the step count; the launcher may start a slice one column early)
+size_t bbdot_i8_part_words(size_t) { return (size_t)72 * 12 * 7168; }
 size_t bbdot_i8_tot_words() { return (size_t)72 * 7168; }
 static u64 bb_powmod(u64 a, u64 e) {
     u64 r = 1;
@@ -203,6 +204,8 @@ int launch_dot_batch_i8(const DevBb &t, const fe *X, size_t ldx, u32 na, const f
     const size_t lead = (((size_t)X) & 7) / 4;
     X -= lead; Y -= lead; n += lead;
     const size_t ldq = bdiv(n, 64) * 64;
+    // exactness: a wave adds steps_per_chunk * 64 digit products of at most 2^14 into an int32 accumulator
+    if (bdiv(ldq / 64, bbdot_chunks(ldq / 64)) >= 2048) return -1;
     hipLaunchKernelGGL(k_bbdot_pack_y, dim3((unsigned)bdiv((size_t)nb * RE * bdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
     BbDotArgs a;
     a.X = X; a.ldx = ldx; a.n = n; a.na = na; a.YB = YB; a.ldq = ldq; a.nrows_y = 36 * nb;

@@ -36,8 +36,8 @@ __device__ __forceinline__ ull swar_sub(ull a, ull b) { return ((a | M8) - (b & 
 // prefetch of the next A tile at every barrier
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int digit2_i8(int32_t v, u32 k) {
-    int32_t m = v < 0 ? -v : v;
-    int d = (m >> k) & 1;
+    const u32 m = v < 0 ? 0u - (u32)v : (u32)v;   // unsigned: v = INT32_MIN is a legal digit (B = 2^32)
+    int d = (int)((m >> k) & 1);
     return v < 0 ? -d : d;
 }
 
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) k_eq_pack_i8(const u64 *eq, size_t ld, si
 }
 // digit of a row: MODE 1 = balanced binary digit k0 + k of |v| with the sign of v (row = plane k, one tile per coefficient);
 // MODE 0 = balanced base-256 digit (row & 3) of v: v = sum_k b_k 256^k with b_k in [-128, 127] (4 digits cover |v| <= 127 (256^4 - 1) / 255
-// >= 2^31; a tile = 4 coefficients x 4 digits)
+// = 2139062143 < 2^31: larger values take the VALU kernel, see `cap` in the launcher; a tile = 4 coefficients x 4 digits)
 template <int MODE>
 __device__ __forceinline__ int ce_digit(int32_t v, u32 k, u32 k0) {
     if (MODE) return digit2_i8(v, k0 + k);

@@ -513,7 +513,7 @@ int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *use
     if (c->dA) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
     for (int l = 0; l < 2; l++) {
         c->comm[l].destroy();
-        c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = cb; c->comm[l].user = user;
+        c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = cb; c->comm[l].user = user; c->comm[l].poisoned = false;
     }
     c->sh_rank = rank; c->sh_world = world;
     return LF_OK;

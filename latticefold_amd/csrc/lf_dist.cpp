@@ -72,7 +72,7 @@ int rccl_init(Comm &c, int rank, int world, const uint8_t *id128) {
     memcpy(id.internal, id128, 128);
     ncclComm_t comm = nullptr;
     if (r.CommInitRank(&comm, world, id, rank) != ncclSuccess) return LF_ERR_HIP;
-    c.rank = rank; c.world = world; c.cb = nullptr; c.user = nullptr; c.nccl = comm;
+    c.rank = rank; c.world = world; c.cb = nullptr; c.user = nullptr; c.nccl = comm; c.poisoned = false;
     return LF_OK;
 }
 int Comm::ensure_stage(size_t words) {
@@ -91,6 +91,7 @@ int Comm::ensure_stage(size_t words) {
     return LF_OK;
 }
 int Comm::allgather_dev(const uint64_t *send_dev, uint64_t *recv_all_dev, size_t words, hipStream_t s) {
+    if (poisoned) return LF_ERR_STATE;
     if (world <= 1 && !nccl) return hipMemcpyAsync(recv_all_dev, send_dev, words * 8, hipMemcpyDeviceToDevice, s) == hipSuccess ? LF_OK : LF_ERR_HIP;
     Stopwatch sw(*this);
     if (nccl) {   // in-stream: no host synchronisation at all
@@ -107,6 +108,7 @@ int Comm::allgather_dev(const uint64_t *send_dev, uint64_t *recv_all_dev, size_t
     return LF_OK;
 }
 int Comm::allgather_host(const uint64_t *send, uint64_t *recv_all, size_t words, hipStream_t s) {
+    if (poisoned) return LF_ERR_STATE;
     if (world <= 1) { memcpy(recv_all, send, words * 8); return LF_OK; }
     Stopwatch sw(*this);
     if (nccl) {
@@ -125,7 +127,10 @@ int Comm::allgather_host(const uint64_t *send, uint64_t *recv_all, size_t words,
     return cb(user, send, recv_all, words) == 0 ? LF_OK : LF_ERR_HIP;
 }
 void Comm::abort_peers() {
-    if (nccl && rccl().CommAbort) { (void)rccl().CommAbort((ncclComm_t)nccl); nccl = nullptr; world = 1; rank = 0; }
+    // the context keeps its shard geometry (sh_world / sh_rank), so the communicator keeps world / rank too and refuses further exchanges;
+    // with the host-callback transport the peers are the host language's to release (the callback has no abort message)
+    if (world > 1) poisoned = true;
+    if (nccl && rccl().CommAbort) { (void)rccl().CommAbort((ncclComm_t)nccl); nccl = nullptr; }
 }
 void Comm::destroy() {
     if (nccl) { (void)rccl().CommDestroy((ncclComm_t)nccl); nccl = nullptr; }

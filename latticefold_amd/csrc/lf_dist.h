@@ -19,6 +19,7 @@ struct Comm {
     lf_exchange_fn cb = nullptr;     // host transport (lf_set_sharding)
     void *user = nullptr;
     void *nccl = nullptr;            // ncclComm_t (lf_dist_init)
+    bool poisoned = false;           // set by abort_peers(): every later exchange returns LF_ERR_STATE (the step that failed is lost; shard a fresh context)
     uint64_t *d_stage = nullptr;     // device staging for host-buffer exchanges over RCCL / device-buffer exchanges over the callback
     size_t d_stage_words = 0;
     uint64_t *h_stage = nullptr;     // pinned

@@ -210,7 +210,9 @@ static u32 dot_i8_chunks(size_t nsteps) {
     const size_t spc = dcdiv(nsteps, want);
     return (u32)dcdiv(nsteps, spc);
 }
-size_t dot_i8_part_words(size_t n) { return (size_t)24 * dot_i8_chunks(dcdiv(n, 64)) * 10240; }
+// sized for the largest chunk count: dot_i8_chunks is not monotone in the step count (80 steps -> 40 chunks, 81 -> 27), and the launcher may
+// start a slice one column early
+size_t dot_i8_part_words(size_t) { return (size_t)24 * 40 * 10240; }
 size_t dot_i8_tot_words() { return (size_t)24 * 10240; }
 // X [na][24][ldx], Y [nb][24][ldy], n columns; out[(a*nb + b)*24 + 3*slot + comp] canonical.  Returns 0, or -1 if the shape is not handled.
 int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
@@ -221,6 +223,8 @@ int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const
     const size_t lead = (((size_t)X) & 15) ? 1 : 0;
     X -= lead; Y -= lead; n += lead;
     const size_t ldq = dcdiv(n, 64) * 64;
+    // exactness: a wave adds steps_per_chunk * 64 digit products of at most 2^14 into an int32 accumulator
+    if (dcdiv(ldq / 64, dot_i8_chunks(ldq / 64)) >= 2048) return -1;
     hipLaunchKernelGGL(k_dot_pack_y, dim3((unsigned)dcdiv((size_t)nb * 24 * dcdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
     DotI8Args a;
     a.X = X; a.ldx = ldx; a.n = n; a.na = na; a.YB = YB; a.ldq = ldq; a.nrows_y = 24 * nb;

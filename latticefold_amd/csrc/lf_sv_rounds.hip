@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_sv_bits(const int32_t *planes, size_t l
     for (int it = 0; it < 8; it++) {
         const size_t pos = base + (size_t)it * 64 + lane;
         const int32_t v = pos < n ? planes[(size_t)c * ldp + pos] : 0;
-        u32 m = (u32)(v < 0 ? -v : v);
+        u32 m = v < 0 ? 0u - (u32)v : (u32)v;   // unsigned: v = INT32_MIN is a legal digit (B = 2^32)
         klo[it] = 0; khi[it] = 0;
         // row r of the wave's 64 positions = ballot of bit r; lane r receives it (v_writelane: no compare / select per row)
         const unsigned long long sg = __ballot(v < 0);
@@ -346,7 +346,13 @@ static uint32_t sv_chunks_n(int V, size_t nsuper, uint32_t K, uint32_t nsides) {
 }
 uint32_t sv_chunks(int V, size_t nsuper, uint32_t K) { return sv_chunks_n(V, nsuper, K, 2); }
 size_t sv_tot_words(int V, uint32_t K) { return (size_t)48 * ((K + 15) / 16) * sv_num_pairs(V) * 768; }
-size_t sv_part_words(int V, size_t npairs, uint32_t K) { return sv_tot_words(V, K) * sv_chunks(V, cdiv(npairs * V, 256), K); }
+// sized for the largest chunk count of the shape: the launch clamps the pairs to the witness length and sv_chunks_n is not monotone in the
+// number of super-steps
+static uint32_t sv_max_chunks(int V, uint32_t K, uint32_t nsides) {
+    const u32 per_chunk = 24 * nsides * ((K + 15) / 16) / (u32)sv_waves(V);
+    return per_chunk >= 256 ? 1 : 256 / per_chunk;
+}
+size_t sv_part_words(int V, size_t, uint32_t K) { return sv_tot_words(V, K) * sv_max_chunks(V, K, 2); }
 size_t sv_tp_words(uint32_t K) { return (size_t)2 * K * 24 * 15; }
 
 int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
@@ -403,7 +409,7 @@ __global__ void __launch_bounds__(256) k_sv_vs_finish(const int32_t *tot, u32 K,
     }
     out[o] = fq_from_s128((u64)v, (int64_t)(v >> 64));
 }
-size_t sv_vs_part_words(size_t n, uint32_t K) { return sv_tot_words(1, K) / 2 * sv_chunks_n(1, cdiv(n / 2, 256), K, 1); }
+size_t sv_vs_part_words(size_t, uint32_t K) { return sv_tot_words(1, K) / 2 * sv_max_chunks(1, K, 1); }
 size_t sv_vs_tot_words(uint32_t K) { return sv_tot_words(1, K) / 2; }
 // bits: launch_sv_bits form of the witness (n positions, n even); eq [3][ldeq]; EB / part / tot: scratch (sv_eb_bytes(n / 2), sv_vs_part_words, sv_vs_tot_words).
 // Returns 0, or -1 if the shape is not handled.

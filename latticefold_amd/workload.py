@@ -37,6 +37,10 @@ CONFIGS = {
     "E32": (9, 64, 2, 1 << 32, 2, 32, 99),      # benches/config.toml:158: kappa 99, B 2^32, K 32
     # GoldilocksDP of the reference unit tests (decomposition_parameters.rs:89-96): N not a power of 2
     "G5": (9, 64, 5, 1 << 15, 2, 15, 5),
+    # n = l + 1 + wit_len = 5120 / 10240 columns: step counts where the chunking of the int8 inner products is not monotone (80 steps ->
+    # 40 chunks, 81 -> 27; lf_dot_i8.hip) -- the scratch must be sized for the larger count
+    "D5120": (15, 5118, 4, 1 << 16, 2, 16, 5),
+    "D10240": (15, 10238, 3, 1 << 22, 2, 22, 5),
     # ---- BabyBearRingNTT (d = 72, tau = 9; B^L = 2^32 > p)
     "B6": (6, 32, 2, 1 << 16, 2, 16, 3, "babybear"),      # tiny, unit tests
     "B8": (8, 128, 2, 1 << 16, 2, 16, 4, "babybear"),
@@ -47,6 +51,7 @@ CONFIGS = {
     "BDP": (7, 32, 4, 1 << 8, 2, 8, 4, "babybear"),
     "B21": (8, 128, 2, 1 << 16, 2, 16, 21, "babybear"),    # kappa > 16: two row chunks of the int8 commit kernel (11 + 10 rows -> 3 row tiles each)
     "B32": (7, 64, 2, 1 << 16, 2, 16, 32, "babybear"),     # the backend's largest kappa: 2 x 16 rows
+    "BD768": (12, 766, 2, 1 << 16, 2, 16, 4, "babybear"),   # n = 768: 12 chunks of the int8 inner products where n + 1 gives 7 (bb_dot_i8.hip)
 }
 
 _M1 = np.uint64(0xBF58476D1CE4E5B9)

@@ -253,7 +253,7 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
 
 
-@pytest.mark.parametrize("name", ["B6", "B10", "BDP"])
+@pytest.mark.parametrize("name", ["B6", "B10", "BDP", "BD768"])
 def test_fold_step_int8_inner_products_match_oracle(ctx, name, monkeypatch):
     """u_s / eta as int8 GEMMs on the matrix cores (bb_dot_i8.hip; the driver uses them from 4096 columns on, LF_DOT_MIN lowers the
     threshold) and on the VALU kernel: identical proofs, equal to the oracle's"""

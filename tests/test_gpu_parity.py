@@ -223,6 +223,19 @@ def test_fold_step_parity(ctx, name, seed):
     assert (proof2_g == proof2_o).all() and (lc2_g == lc2_o).all() and (w2.f == f2_o).all()
 
 
+@pytest.mark.parametrize("name", ["D5120", "D10240"])
+def test_fold_step_dot_i8_chunk_counts(ctx, name):
+    """u_s / eta inner products on the int8 matrix cores at column counts where the number of partial-tile chunks jumps (80 K-steps -> 40
+    chunks, 81 -> 27): the scratch is sized for the largest count.  A second context created afterwards checks that nothing was written
+    past the scratch into a neighbouring allocation (the proofs of both runs equal the oracle's)."""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name)
+    assert wl.n in (5120, 10240)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    for _ in range(2):
+        lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        assert (proof_g == proof_o).all() and (lc_g == lc_o).all() and (w0.f == f0_o).all()
+
+
 @pytest.mark.parametrize("name", ["E22", "E99", "E31", "E32"])
 def test_fold_step_parity_wider_reference_rows(ctx, name):
     """the reference's wider Goldilocks parameter rows (benches/config.toml:150-165) at small wit_len: kappa 43 / B 2^22 / L 3 / K 22,
