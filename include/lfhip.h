@@ -271,6 +271,11 @@ const char *lf_phase_name(int i);
  * the Ajtai kernel in the last fold step */
 int lf_last_kernel_stats(lf_ctx *, float *fold_round_ms, int *fold_round_launches, float *ajtai_ms, int *ajtai_launches);
 
+/* wall-clock marks of the calling thread during the last lf_fold_step (measurement only; bench.py's `roofline.phases`): mark i has its
+ * name (NUL-terminated, <= 31 characters) at names + 32 i and ms[i] = milliseconds since the start of the step.  Returns the number of marks
+ * written (<= max_marks), or an error code < 0 */
+int lf_last_timeline(lf_ctx *, char *names /* 32 * max_marks */, double *ms, int max_marks);
+
 /* which rounds of the last folding sumcheck ran as int8 matrix-core GEMMs (bit i-1 = round i; lf_sv_rounds.h) -- test hook */
 int lf_last_fold_paths(lf_ctx *, unsigned *sv_round_mask);
 

@@ -152,6 +152,7 @@ def _lib():
         L.lf_phase_name.argtypes = [C.c_int]
         L.lf_verify_host.argtypes = [C.c_int, C.POINTER(Params), u32p, u32p, u64p, vp, u64p, u64p, u64p, u64p, C.POINTER(C.c_int)]
         L.lf_last_fold_paths.argtypes = [vp, C.POINTER(C.c_uint)]
+        L.lf_last_timeline.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.c_int]
         L.lf_last_kernel_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
@@ -367,6 +368,14 @@ class Context:
         m = C.c_uint()
         _chk(_lib().lf_last_fold_paths(self.h, C.byref(m)), "lf_last_fold_paths")
         return m.value
+
+    def timeline(self):
+        """[(mark, ms since the start of the step)] of the last fold step (wall clock of the calling thread)"""
+        names, ms = C.create_string_buffer(32 * 64), (C.c_double * 64)()
+        n = _lib().lf_last_timeline(self.h, names, ms, 64)
+        if n < 0:
+            raise LfError(n, "lf_last_timeline")
+        return [(names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode(), float(ms[i])) for i in range(n)]
 
     def kernel_stats(self):
         f, a = C.c_float(), C.c_float()

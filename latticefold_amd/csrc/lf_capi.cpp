@@ -59,8 +59,8 @@ struct Timeline {
     std::chrono::steady_clock::time_point t0;
     std::vector<std::pair<const char *, double>> marks;
     Timeline() : on(getenv("LF_TIMELINE") != nullptr), t0(std::chrono::steady_clock::now()) {}
-    void mark(const char *what) {
-        if (on) marks.push_back({what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()});
+    void mark(const char *what) {   // always recorded (lf_last_timeline); printed only with LF_TIMELINE
+        marks.push_back({what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()});
     }
     void dump() {
         if (!on) return;
@@ -174,6 +174,7 @@ struct lf_ctx {
     int sf_cur = 0;
     // measurement
     float phase_ms[LF_N_PHASES] = {0};
+    std::vector<std::pair<const char *, double>> tl_marks;   // wall-clock marks of the last fold step (lf_last_timeline)
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<int, size_t>> ev_tags;  // (tag, event index)
@@ -2504,6 +2505,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     c->bits_wit[0] = c->bits_wit[1] = nullptr;
     TL_MARK("fold done");
     tl.dump();
+    c->tl_marks = tl.marks;
     t_tl = nullptr;
     c->ev_end(tot);
     c->ev_collect();
@@ -2826,6 +2828,21 @@ int lf_last_phase_ms(lf_ctx *c, float *out) {
     if (c->bb) return c->bb->last_phase_ms(out);
     for (int i = 0; i < LF_N_PHASES; i++) out[i] = c->phase_ms[i];
     return LF_OK;
+}
+// wall-clock marks of the caller thread during the last lf_fold_step (Goldilocks driver): name i (NUL-terminated, at most 31 characters) at
+// names + 32 i, ms[i] = milliseconds since the start of the step.  Returns the number of marks written (<= max_marks), < 0 on error.
+int lf_last_timeline(lf_ctx *c, char *names, double *ms, int max_marks) {
+    if (!c || !names || !ms || max_marks < 0) return LF_ERR_INVALID;
+    if (c->bb) return 0;
+    int n = 0;
+    for (auto &m : c->tl_marks) {
+        if (n >= max_marks) break;
+        const char *w = m.first;
+        while (*w == ' ') w++;
+        snprintf(names + 32 * n, 32, "%s", w);
+        ms[n++] = m.second;
+    }
+    return n;
 }
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
