@@ -400,13 +400,13 @@ def main():
             # tiles.  Peak: dense int8 = 2 x the dense bf16 rate of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF -> 5 POP/s; its microbenchmark
             # ceiling is >= 3.94 POP/s).
             RD, NL, maxp, maxr = (24, 8, 16, 26) if wl.ring == "goldilocks" else (72, 4, 8, 16)
-            launches_per_side = -(-(wl.K - 1) // maxp) * -(-wl.kappa // maxr)
-            macs = NL * wl.kappa * RD * (wl.K - 1) * RD * wl.N / launches_per_side          # average per launch
-            a_bytes = NL * wl.kappa * RD * wl.N / -(-wl.kappa // maxr) + RD * 4 * wl.N       # A row chunk as bytes (read once per launch) + the int32 planes
+            row_chunks = -(-wl.kappa // maxr)
+            lps = aj_n / args.steps if aj_n else 2.0                                         # launches per step (measured): 1 per row chunk and plane group
+            sides_per_launch = 2.0 * -(-(wl.K - 1) // maxp) * row_chunks / lps               # 2 = both decompositions' planes in one launch (paired workgroups)
+            macs = 2 * NL * wl.kappa * RD * (wl.K - 1) * RD * wl.N / lps                     # average per launch
+            a_bytes = NL * wl.kappa * RD * wl.N / row_chunks + sides_per_launch * RD * 4 * wl.N   # A row chunk as bytes (from HBM once per launch) + the int32 planes
             # SURVEY 8(d)'s own figure for the same launch -- element bytes E, not byte planes: the rows of A this launch streams + the digit-plane
             # witnesses it commits, (kappa_launch + planes_launch) N E  (= (kappa + K - 1) N E when one launch covers a whole decomposition)
-            row_chunks = -(-wl.kappa // maxr)
-            lps = aj_n / args.steps if aj_n else 2.0
             bytes_8d = (wl.kappa / row_chunks + 2 * (wl.K - 1) * row_chunks / lps) * wl.N * E
             kernels["k_ajtai"]["alg_bytes_8d_per_launch"] = bytes_8d
             kernels["k_ajtai"]["alg_bytes_per_launch"] = a_bytes

@@ -23,8 +23,11 @@ size_t ajtai_i8_part_words(uint32_t nwg, uint32_t MT, uint32_t NT);
 size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, uint32_t MT, uint32_t NT, uint32_t NP);
 // commitments of the digit planes k0 .. k0+NP-1 of `planes` ([RD][ld] int32) under rows [row0, row0+kappa) of A (one packed row chunk with MT
 // row tiles): coefficient-form results into coef_out (element plane*kappa_total + row).  Returns the grid size or -1.
+// planes2 / coef_out2 (optional): the same planes of a SECOND witness in the same launch -- nwg / 2 column chunks, each run by a pair of
+// workgroups placed on one XCD, so that A is fetched from HBM once for both (the two decompositions of a fold step).
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const int32_t *planes, size_t ld, size_t n, uint32_t kappa, uint32_t row0,
-                    uint32_t kappa_total, uint32_t k0, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s);
+                    uint32_t kappa_total, uint32_t k0, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s,
+                    const int32_t *planes2 = nullptr, uint64_t *coef_out2 = nullptr);
 // v[k][c][q] = sum_j eq[q][j] * digit_k(planes[c][j]) on the matrix cores (Goldilocks; see lf_ajtai_i8.hip).  mode_bits: K binary digit planes,
 // out[(k*24+c)*3+q]; mode 0: the coefficients themselves (|.| <= bound), out[c*3+q].  Returns 0, or -1 if the shape is not handled.
 size_t coef_eval_i8_eb_bytes(size_t n);

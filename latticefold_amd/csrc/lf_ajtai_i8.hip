@@ -81,6 +81,8 @@ void launch_ajtai_pack_i8(const u64 *coef, size_t cs, size_t js, size_t n, u32 i
 struct AjtaiI8Args {
     const unsigned char *Ab;
     const int32_t *planes;   // [RD][ld], already offset to this rank's first column
+    const int32_t *planes2;  // sides == 2: the second witness (same geometry)
+    u32 sides, nchunks;      // workgroups = sides * nchunks; workgroup (side, chunk) writes slot side * nchunks + chunk of part / dsum
     size_t ld, n;
     u32 MT, NT, k0, NP;
     u32 ntiles, tiles_per_wg;
@@ -110,6 +112,13 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
     constexpr int WR = (RD * 8 + 511) / 512;                    // staged witness words per thread and tile
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave / CG, ng = wave % CG;
     const u32 MT = a.MT, NT = a.NT, NP = a.NP;
+    // Two witnesses in one launch (both decompositions of a fold step): the workgroups (0, chunk) and (1, chunk) stream the same tiles of A.
+    // Block ids 16 q + 8 side + x land on the same XCD (round-robin over 8) eight dispatch slots apart, so the second one finds the tiles in
+    // that XCD's L2: A leaves HBM once per step instead of twice.
+    u32 side = 0, chunk = blockIdx.x;
+    if (a.sides == 2) { side = (blockIdx.x >> 3) & 1; chunk = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7); }
+    const int32_t *planes = side ? a.planes2 : a.planes;
+    const u32 slot = side * a.nchunks + chunk;
     const size_t a_tile = (size_t)KS * MT * 1024;              // bytes of a tile in HBM
     constexpr size_t a_lds = (size_t)ACH * 512 * 16;           // ... and its padded stride in LDS
     unsigned char *Al = smem;                                   // [2][a_lds]
@@ -136,7 +145,7 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
         for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
     int dacc0 = 0, dacc1 = 0;                                   // digit sums of (plane, c) = tid and tid + 512 over this workgroup's columns
 
-    const u32 T0 = blockIdx.x * a.tiles_per_wg;
+    const u32 T0 = chunk * a.tiles_per_wg;
     const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
     uint4 ar0 = {0, 0, 0, 0}, ar1 = ar0, ar2 = ar0, ar3 = ar0, ar4 = ar0;
     int32_t wreg0 = 0, wreg1 = 0;
@@ -164,10 +173,10 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
     auto load_w = [&](u32 T) {
         size_t j = (size_t)T * 8 + (tid & 7);
         const bool ok = T < T1 && j < a.n;
-        int32_t v0 = a.planes[(size_t)wc0 * a.ld + (ok ? j : 0)];
+        int32_t v0 = planes[(size_t)wc0 * a.ld + (ok ? j : 0)];
         wreg0 = ok ? v0 : 0;
         if (WR > 1) {
-            int32_t v1 = a.planes[(size_t)wc1 * a.ld + (ok ? j : 0)];
+            int32_t v1 = planes[(size_t)wc1 * a.ld + (ok ? j : 0)];
             wreg1 = ok ? v1 : 0;
         }
     };
@@ -279,9 +288,9 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
 #pragma unroll
         for (int ni = 0; ni < NTW; ni++)
             if (mi < (int)mcnt && ni < (int)ncnt)
-                *(v4i *)(a.part + ((((size_t)blockIdx.x * MT + m_lo + mi) * NT + n_lo + ni) * 64 + lane) * 4) = acc[mi][ni];
-    if (tid < NP * RD) a.dsum[(size_t)blockIdx.x * NP * RD + tid] = dacc0;
-    if (tid + 512 < NP * RD) a.dsum[(size_t)blockIdx.x * NP * RD + tid + 512] = dacc1;
+                *(v4i *)(a.part + ((((size_t)slot * MT + m_lo + mi) * NT + n_lo + ni) * 64 + lane) * 4) = acc[mi][ni];
+    if (tid < NP * RD) a.dsum[(size_t)slot * NP * RD + tid] = dacc0;
+    if (tid + 512 < NP * RD) a.dsum[(size_t)slot * NP * RD + tid + 512] = dacc1;
 }
 
 // Kernel: row group 0 runs the MTWA instantiation, the other row groups MTWB (two copies of the whole loop when they differ: each has its
@@ -298,9 +307,13 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
 }
 
 // stage 1 of the reduction: element-wise sum of the workgroups' partial tiles (and of their digit sums) -- coalesced across threads
+// (blockIdx.y = side: the slots of side s start at s * nwg, its sums at s * (per_wg + per_wg_d))
 __global__ void __launch_bounds__(256) k_ajtai_i8_sum(const int32_t *part, size_t per_wg, const int32_t *dsum, u32 per_wg_d, u32 nwg, long long *sum) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= per_wg + per_wg_d) return;
+    part += (size_t)blockIdx.y * nwg * per_wg;
+    dsum += (size_t)blockIdx.y * nwg * per_wg_d;
+    sum += (size_t)blockIdx.y * (per_wg + per_wg_d);
     const int32_t *src = e < per_wg ? part + e : dsum + (e - per_wg);
     const size_t stride = e < per_wg ? per_wg : per_wg_d;
     long long s = 0;
@@ -327,9 +340,10 @@ __device__ __forceinline__ u64 s128_mod_small(__int128 v, u64 p) {
 // stage 2: y[plane][row][c_out] in coefficient form, canonical.  Element index e = plane * kappa_total + row0 + i;
 // soa != 0: out[c_out * NE + e] (NE = NP * kappa_total), else out[e * RD + c_out].  p_small = 0: the Goldilocks modulus.
 __global__ void __launch_bounds__(256) k_ajtai_i8_finish(const long long *sum, size_t per_wg, u32 MT, u32 NT, u32 NP, u32 kappa, u32 row0, u32 kappa_total,
-                                                         u32 RD, u32 NL, u64 p_small, int soa, u64 *coef_out) {
+                                                         u32 RD, u32 NL, u64 p_small, int soa, u64 *coef_out, u64 *coef_out2) {
     const u32 o = blockIdx.x * 256 + threadIdx.x;
     if (o >= NP * kappa * RD) return;
+    if (blockIdx.y) { sum += per_wg + (size_t)NP * RD; coef_out = coef_out2; }   // second witness of a two-sided launch
     const u32 co = o % RD, i = (o / RD) % kappa, p = o / (RD * kappa), HALF = RD / 2;
     const u32 n = p * RD + co, nt = n >> 4, col = n & 15;
     // T = sum over inner elements of Rot(F)[.][c_out], F = sum over columns of the digit polynomials: the "-128" bias of the bytes of A
@@ -371,18 +385,28 @@ u32 ajtai_i8_max_rows(const AjtaiI8Ring &R) { return R.RD == 24 ? 26 : 16; }    
 u32 ajtai_i8_max_planes(const AjtaiI8Ring &R) { return R.RD == 24 ? 16 : 8; }     // digit planes per launch (accumulators and LDS)
 // partial buffer words (int32) for nwg workgroups
 size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT) { return (size_t)nwg * MT * NT * 256; }
-size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, u32 MT, u32 NT, u32 NP) { return (size_t)MT * NT * 256 + (size_t)NP * R.RD; }
+size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, u32 MT, u32 NT, u32 NP) { return 2 * ((size_t)MT * NT * 256 + (size_t)NP * R.RD); }   // (two sides)
 
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total,
-                    u32 k0, u32 NP, u32 nwg, int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s) {
+                    u32 k0, u32 NP, u32 nwg, int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s, const int32_t *planes2, u64 *coef_out2) {
     AjtaiI8Args a;
-    a.Ab = Ab; a.planes = planes; a.ld = ld; a.n = n;
+    a.Ab = Ab; a.planes = planes; a.planes2 = planes2; a.ld = ld; a.n = n;
     a.MT = MT; a.NT = ajtai_i8_col_tiles(R, NP); a.k0 = k0; a.NP = NP;
     a.ntiles = (u32)((n + 7) / 8);
-    a.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
     a.part = part; a.dsum = dsum;
     if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
-    const u32 grid = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    // two witnesses: nwg / 2 chunks of columns (a multiple of 8, see i8_run), each run by a pair of workgroups
+    const u32 sides = planes2 ? 2 : 1;
+    u32 per_side = nwg / sides;
+    if (sides == 2) {
+        per_side &= ~7u;
+        if (per_side == 0 || !coef_out2) return -1;
+    }
+    a.tiles_per_wg = (a.ntiles + per_side - 1) / per_side;
+    u32 nchunks = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    if (sides == 2) nchunks = (nchunks + 7) & ~7u;   // (trailing chunks past the last tile run empty)
+    a.sides = sides; a.nchunks = nchunks;
+    const u32 grid = sides * nchunks;
     const size_t lds = ajtai_i8_lds_bytes(R, MT, NP);
 #define LF_I8_LAUNCH(RD, RG, MTWA, MTWB, NTW, ACH, EXACT)                                                                           \
     do {                                                                                                                           \
@@ -406,9 +430,9 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     }
 #undef LF_I8_LAUNCH
     const size_t per_wg = (size_t)MT * a.NT * 256;
-    hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * R.RD, 256)), dim3(256), 0, s, part, per_wg, dsum, NP * R.RD, grid, sum);
-    hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * R.RD, 256)), dim3(256), 0, s, sum, per_wg, MT, a.NT, NP, kappa, row0,
-                       kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out);
+    hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * R.RD, 256), sides), dim3(256), 0, s, part, per_wg, dsum, NP * R.RD, nchunks, sum);
+    hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * R.RD, 256), sides), dim3(256), 0, s, sum, per_wg, MT, a.NT, NP, kappa, row0,
+                       kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out, coef_out2);
     return (int)grid;
 }
 

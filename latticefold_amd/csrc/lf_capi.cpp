@@ -747,7 +747,8 @@ static int prep_ajtai_i8(lf_ctx *c) {
     return LF_OK;
 }
 // digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev [NP][kappa][24] NTT form (PARTIAL when sharded)
-static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev) {
+// planes2 / out_dev2 (optional): the same planes of a second witness, committed in the same launches (A streamed from HBM once for both)
+static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev, const int32_t *planes2 = nullptr, u64 *out_dev2 = nullptr) {
     const AjtaiI8Ring R = ajtai_i8_goldilocks();
     const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc), maxp = ajtai_i8_max_planes(R);
     const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
@@ -763,21 +764,31 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
     RET(c->tbuf("i8_part", ajtai_i8_part_words(nwg, MT, NTmax), &part));
     RET(c->tbuf("i8_dsum", (size_t)nwg * maxp * R.RD, &dsum));
     RET(c->tbuf("i8_sum", ajtai_i8_sum_words(R, MT, NTmax, maxp), &sum));
-    RET(c->tbuf("i8_coef", (size_t)24 * NP * c->kappa, &coef));
-    RET(c->tbuf("i8_ntt", (size_t)24 * NP * c->kappa, &ntt));
+    const size_t side_words = (size_t)24 * NP * c->kappa;
+    RET(c->tbuf("i8_coef", 2 * side_words, &coef));
+    RET(c->tbuf("i8_ntt", 2 * side_words, &ntt));
+    if (planes2 && (nwg / 2 < 8 || !out_dev2)) {   // too few column tiles for paired workgroups: one witness after the other
+        RET(commit_planes_i8(c, planes, ld, k0, NP, out_dev));
+        return commit_planes_i8(c, planes2, ld, k0, NP, out_dev2);
+    }
     for (u32 p0 = 0; p0 < NP; p0 += maxp) {
         const u32 np = NP - p0 < maxp ? NP - p0 : maxp;
         u64 *cf = coef + (size_t)24 * p0 * c->kappa;   // SoA block of this plane group: [24][np*kappa]
         for (u32 ch = 0; ch < nch; ch++) {
             const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
             size_t ev = c->ev_begin(1);
-            int g = launch_ajtai_i8(R, c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, cf, c->stream());
+            int g = launch_ajtai_i8(R, c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, cf, c->stream(),
+                                    planes2, planes2 ? cf + side_words : nullptr);
             c->ev_end(ev);
             if (g < 0) return LF_ERR_UNSUPPORTED;
         }
         const size_t ne = (size_t)np * c->kappa;
         launch_crt_fwd(c->dcrt, cf, ntt, ne, c->stream());
         launch_soa_to_aos(ntt, out_dev + (size_t)p0 * c->kappa * 24, ne, c->stream());
+        if (planes2) {
+            launch_crt_fwd(c->dcrt, cf + side_words, ntt + side_words, ne, c->stream());
+            launch_soa_to_aos(ntt + side_words, out_dev2 + (size_t)p0 * c->kappa * 24, ne, c->stream());
+        }
     }
     return LF_OK;
 }
@@ -1563,6 +1574,24 @@ static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_o
         RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
     }
     *yd_out = yd;
+    *ev_out = ph;
+    return LF_OK;
+}
+// commit_witnesses of BOTH decompositions of a fold step in one pass over A (they depend on the two witnesses only): the digit planes of
+// wit_l and wit_r through the same launches of the int8 kernel, paired workgroups sharing the tiles of A in L2.  false: the shape / mode has no
+// such form (the caller commits one side after the other).
+static bool commit_pair_possible(lf_ctx *c) {
+    return c->i8_nch && !c->tn.ajtai_valu && !c->tn.i8_no_pair && (c->nA + 7) / 8 >= 16;
+}
+static int decompose_commit_enqueue_pair(lf_ctx *c, const lf_witness *wit_l, const lf_witness *wit_r, u64 **ydl_out, u64 **ydr_out, size_t *ev_out) {
+    const lf_params &P = c->P;
+    u32 K = P.K;
+    u64 *ydl, *ydr;
+    RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &ydl));
+    RET(c->tbuf("dec_y2", (size_t)K * P.kappa * 24, &ydr));
+    size_t ph = c->ev_begin(11);
+    RET(commit_planes_i8(c, wit_l->planes + c->A_col0, c->N, 1, K - 1, ydl, wit_r->planes + c->A_col0, ydr));
+    *ydl_out = ydl; *ydr_out = ydr;
     *ev_out = ph;
     return LF_OK;
 }
@@ -2458,12 +2487,19 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             ~Publish() { int e = 0; s.z_state.compare_exchange_strong(e, -1, std::memory_order_release); }
         } publish{S[1]};
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
-        u64 *yd = nullptr;
+        u64 *yd = nullptr, *ydL = nullptr;
         size_t ev = 0;
-        RET(decompose_commit_enqueue(c, w_acc, &yd, &ev));
-        RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));
-        RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
-        RET(decompose_commit_enqueue(c, w_i, &yd, &ev));               // right commit in flight ...
+        if (commit_pair_possible(c)) {
+            // both decompositions' commits in one pass over A, first thing on this lane; the right side's result waits on the device
+            RET(decompose_commit_enqueue_pair(c, w_acc, w_i, &ydL, &yd, &ev));
+            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, ev, decl));
+            RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+        } else {
+            RET(decompose_commit_enqueue(c, w_acc, &yd, &ev));
+            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));
+            RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+            RET(decompose_commit_enqueue(c, w_i, &yd, &ev));               // right commit in flight ...
+        }
         {   // ... and the right side's z_k behind it: they depend on the witness and on x_w || h = x_ccs || 1 only, not on the point r
             std::vector<u64> xh((size_t)(P.l + 1) * 24);
             memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
@@ -2472,6 +2508,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         }
         if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
+        if (ydL) ev = c->ev_begin(11);                                  // (paired commit: its phase timer was closed with the left side)
         return decompose_commit_finish(c, cm_i, yd, ev, decr);          // cm of the linearized instance = cm_i.cm
     });
     {   // absorb_public_input (nifs.rs:175-197) -- after lane 1 has been started: the left decomposition does not depend on it

@@ -102,3 +102,38 @@ def test_extreme_digit_patterns(pattern, wgs):
     finally:
         for k in ("LF_AJTAI_VALU", "LF_I8_WGS"):
             os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("name", ["T8", "T10", "G5", "E22", "E99", "T14"])
+def test_paired_commit_of_both_decompositions(name):
+    """lf_fold_step commits the digit planes of BOTH witnesses in one pass over A (paired workgroups, lf_ajtai_i8.hip `sides`): the chained
+    step -- left witness = the folded witness of the first step, right witness = w_i, so the two sides differ -- must equal the run with one
+    launch per decomposition (LF_I8_NO_PAIR) for several workgroup counts (odd chunk counts, empty trailing chunks), and the oracle."""
+    import lfo
+    out = {}
+    try:
+        for mode, env in (("pair", None), ("nopair", {"LF_I8_NO_PAIR": "1"}), ("pair16", {"LF_I8_WGS": "16"}), ("pair40", {"LF_I8_WGS": "40"}),
+                          ("pair250", {"LF_I8_WGS": "250"})):
+            os.environ.pop("LF_I8_NO_PAIR", None)
+            wl, ctx, scheme = _setup(name, False, env)
+            wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+            cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+            lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+            lc2, w1, proof2 = api.NIFSProver.prove(ctx, lc, w0, cccs, wit, api.PoseidonTranscript())
+            out[mode] = (proof, lc, proof2, lc2, w1.f)
+            ctx.close()
+        for mode in out:
+            for a, b in zip(out["nopair"], out[mode]):
+                assert (a == b).all(), mode
+        if name in ("T8", "T10", "G5"):
+            inst = lfo.Instance(wl)
+            f = inst.witness_from_w_ccs(wl.w_ccs)
+            A = wl.ajtai_matrix()
+            acc_o, _ = inst.linearize(lfo.Transcript(), cccs, f)
+            lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f, cccs, f)
+            lc2_o, f1_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f)
+            assert (out["pair"][2] == proof2_o).all() and (out["pair"][3] == lc2_o).all() and (out["pair"][4] == f1_o).all()
+    finally:
+        for k in ("LF_I8_NO_PAIR", "LF_I8_WGS"):
+            os.environ.pop(k, None)
