@@ -28,6 +28,8 @@ size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, uint32_t MT, uint32_t NT, uint32
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const int32_t *planes, size_t ld, size_t n, uint32_t kappa, uint32_t row0,
                     uint32_t kappa_total, uint32_t k0, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s,
                     const int32_t *planes2 = nullptr, uint64_t *coef_out2 = nullptr);
+// measurement: per-phase shader-clock totals of the last launch made with LF_I8_PROF set (out64[8 waves][8]: 7 phases + tile count of workgroup 0)
+int ajtai_i8_read_prof(unsigned long long *out64);
 // v[k][c][q] = sum_j eq[q][j] * digit_k(planes[c][j]) on the matrix cores (Goldilocks; see lf_ajtai_i8.hip).  mode_bits: K binary digit planes,
 // out[(k*24+c)*3+q]; mode 0: the coefficients themselves (|.| <= bound), out[c*3+q].  Returns 0, or -1 if the shape is not handled.
 size_t coef_eval_i8_eb_bytes(size_t n);

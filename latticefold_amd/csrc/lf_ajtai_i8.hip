@@ -19,6 +19,7 @@
 // are built with SWAR byte arithmetic, and the B operand of a lane is the two adjacent entries d = c_out - c_in, c_out - c_in - 1.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "lf_field.cuh"
 #include "lf_kernels.h"
 #include "lf_ajtai_i8.h"
@@ -106,12 +107,33 @@ struct AjtaiI8Args {
 // EXACT: every wave that takes this instantiation owns exactly MTW row tiles (and computes all NTW column tiles, clamped past the end):
 // the MFMA block is branch-free -- the compiler may then hoist operand loads across it, which sched_barriers after every second row tile
 // keep within the register budget (without them: 62 - 85 spilled registers).
-template <int RD, int RG, int MTW, int NTW, int ACH, bool EXACT>
+// PROF: per-phase shader-clock totals of every wave of workgroup 0 into g_i8_prof (LF_I8_PROF=1; a measurement instantiation, tools/i8_prof.py)
+__device__ unsigned long long g_i8_prof[8][8];
+// Round 3: ONE barrier per tile and nothing but the stores of the staged tile outside the MFMA block.  In-kernel clocks of the round-2 loop
+// (profiles/r03_i8prof_before.txt, cycles per tile and wave at C4): issuing the tile copy's loads 2000 (the eight waves issue them together and
+// block on the full vector-memory queue), barrier 500, Toeplitz vectors 2700 (index divisions + LDS latency chains), MFMA block 3750 - 4600,
+// LDS stores 400, barrier 100 - 1100: the matrix pipe was busy 43 % of the time.  Now
+//   * digits D are double-buffered and built two tiles ahead, so the vectors of tile T+1 (from D[T+1]) and the digits of tile T+2 need no
+//     barrier between them and both sit BETWEEN the K-steps of tile T (the partner wave of the SIMD keeps the matrix pipe busy meanwhile);
+//   * every (plane, H/L, entry) of the vectors belongs to a fixed thread: its three source offsets (a zero word stands in for "no term") and its
+//     sign are computed once, outside the tile loop;
+//   * the waves 0-3 issue their share of the next tile's loads at the top of the iteration, the waves 4-7 (the other wave of each SIMD) after the
+//     first K-step (LATE): one wave of a SIMD computes while the other waits in the memory queue.
+// MTT: row tiles of the whole workgroup when EXACT (a compile-time constant: LDS operand offsets become instruction immediates), else 0.
+template <int RD, int RG, int MTW, int NTW, int ACH, bool EXACT, bool LATE, int MTT, bool PROF = false>
 __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem) {
     constexpr int KS = RD / 8, VS = 2 * RD, HALF = RD / 2, CG = I8_WAVES / RG;
     constexpr int WR = (RD * 8 + 511) / 512;                    // staged witness words per thread and tile
+    constexpr int MAXNP = RD == 24 ? 15 : 8;                    // digit planes per launch (ajtai_i8_max_planes): 3 / 8 full rounds of the vector build
+    constexpr int DS = RD + 1;                                  // a row of D: RD packed digit words + one zero word
+    constexpr int EPP = 2 * VS;                                 // vector entries per plane (H and L)
+    // The operand build (digits, vectors) is the work of all 512 threads, in KS pieces between the K-steps.  (Measured and dropped,
+    // profiles/r03_i8_notes.txt: the build by the waves 4-7 alone, or split between the wave groups with the waves 4-7 building BEFORE their
+    // K-steps so that one wave of a SIMD builds while the other has the matrix pipe: 8300 - 10400 cycles per tile against 7000 -- the wave
+    // that starts its K-steps later gets the leftovers of the pipe -- and every branch-free / batched form of the build spilled registers.)
+    constexpr int PPR = 512 / EPP;                              // planes per round of the vector build (5 / 1)
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave / CG, ng = wave % CG;
-    const u32 MT = a.MT, NT = a.NT, NP = a.NP;
+    const u32 MT = EXACT ? (u32)MTT : a.MT, NT = a.NT, NP = a.NP;
     // Two witnesses in one launch (both decompositions of a fold step): the workgroups (0, chunk) and (1, chunk) stream the same tiles of A.
     // Block ids 16 q + 8 side + x land on the same XCD (round-robin over 8) eight dispatch slots apart, so the second one finds the tiles in
     // that XCD's L2: A leaves HBM once per step instead of twice.
@@ -122,20 +144,29 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
     const size_t a_tile = (size_t)KS * MT * 1024;              // bytes of a tile in HBM
     constexpr size_t a_lds = (size_t)ACH * 512 * 16;           // ... and its padded stride in LDS
     unsigned char *Al = smem;                                   // [2][a_lds]
-    ull *V = (ull *)(smem + 2 * a_lds);                         // [2][NP][2][VS]
-    ull *Dl = V + 2 * (size_t)NP * 2 * VS;                      // [NP][RD]
-    int32_t *wl = (int32_t *)(Dl + (size_t)NP * RD);            // [2][RD][8]
+    // (strides of the MAXNP-plane shape whatever NP is: buffer offsets are buffer index x compile-time constant)
+    constexpr int VB = MAXNP * 2 * VS, DB = MAXNP * DS;        // words of one V / D buffer
+    ull *V = (ull *)(smem + 2 * a_lds);                         // [2][MAXNP][2][VS]
+    ull *Dl = V + 2 * VB;                                       // [2][MAXNP][DS]
+    int32_t *wl = (int32_t *)(Dl + 2 * DB);                     // [3][RD][8]
+    // Per-thread loop constants and the digit sums live in LDS, not in registers: the MFMA block owns the register file (168 accumulators +
+    // 24 + 4 operand + 20 staging registers of 256), and what the compiler spills goes to scratch, whose reloads wait -- in order -- for the
+    // tile copy's loads in flight.  LDS reads in the operand-build gaps cost a few cycles.
+    u32 *cst = (u32 *)(wl + 3 * RD * 8);                        // [GDR][512]: digit sums
     // this wave's tiles
     const u32 mh = (MT + RG - 1) / RG, m_lo = mg * mh, mcnt = m_lo >= MT ? 0 : (MT - m_lo < mh ? MT - m_lo : mh);
     const u32 n_lo = ng * NTW, ncnt = n_lo >= NT ? 0 : (NT - n_lo < NTW ? NT - n_lo : NTW);
     // B operand base offsets (bytes into one V buffer) at K-step 0: entry e0 = RD-1 - c_out + 2 g of (plane, H / L); columns past the end clamp
-    u32 vb[NTW];
+    // (two 16-bit offsets per register: a V buffer has 2 NP VS 8 <= 36 KB)
+    static_assert(2 * MAXNP * VS * 8 < 65536, "16-bit B operand offsets");
+    u32 vbp[(NTW + 1) / 2];
 #pragma unroll
     for (int ni = 0; ni < NTW; ni++) {
         u32 n = (n_lo + ni) * 16 + (lane & 15);
         if (n >= RD * NP) n = RD * NP - 1;
         u32 p = n / RD, co = n % RD;
-        vb[ni] = ((p * 2 + (co >= HALF ? 0u : 1u)) * VS + (RD - 1 - co + 2 * (lane >> 4))) * 8;
+        const u32 off = ((p * 2 + (co >= HALF ? 0u : 1u)) * VS + (RD - 1 - co + 2 * (lane >> 4))) * 8;
+        if (ni & 1) vbp[ni >> 1] |= off << 16; else vbp[ni >> 1] = off;
     }
     const u32 ab0 = (m_lo * 64 + lane) * 16;   // A operand: this lane in row tile m_lo of a K-step; tile mi adds mi KB
     v4i acc[MTW][NTW];
@@ -143,7 +174,8 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
     for (int mi = 0; mi < MTW; mi++)
 #pragma unroll
         for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
-    int dacc0 = 0, dacc1 = 0;                                   // digit sums of (plane, c) = tid and tid + 512 over this workgroup's columns
+    constexpr int GDR = (MAXNP * RD + 511) / 512;               // rounds of the digit build (1 / 2)
+    constexpr int C_DACC = 0;                                   // rows of cst
 
     const u32 T0 = chunk * a.tiles_per_wg;
     const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
@@ -170,13 +202,16 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
     } while (0)
     // staged witness words: word idx = tid (+ 512) of the tile's [RD][8] block
     const u32 wc0 = (tid >> 3) < (u32)RD ? (tid >> 3) : RD - 1, wc1 = ((tid + 512) >> 3) < (u32)RD ? ((tid + 512) >> 3) : RD - 1;
+    // (32-bit byte offsets from the uniform base: a plane set is at most RD ld 4 < 2^32 bytes, checked by the launcher)
+    const u32 wo0 = (u32)((size_t)wc0 * a.ld * 4), wo1 = (u32)((size_t)wc1 * a.ld * 4);
     auto load_w = [&](u32 T) {
         size_t j = (size_t)T * 8 + (tid & 7);
         const bool ok = T < T1 && j < a.n;
-        int32_t v0 = planes[(size_t)wc0 * a.ld + (ok ? j : 0)];
+        const u32 jo = ok ? (u32)j * 4 : 0;
+        int32_t v0 = *(const int32_t *)((const char *)planes + (wo0 + jo));
         wreg0 = ok ? v0 : 0;
         if (WR > 1) {
-            int32_t v1 = planes[(size_t)wc1 * a.ld + (ok ? j : 0)];
+            int32_t v1 = *(const int32_t *)((const char *)planes + (wo1 + jo));
             wreg1 = ok ? v1 : 0;
         }
     };
@@ -184,88 +219,128 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
         if (tid < (u32)RD * 8) wl[buf * RD * 8 + tid] = wreg0;
         if (WR > 1 && tid + 512 < (u32)RD * 8) wl[buf * RD * 8 + tid + 512] = wreg1;
     };
-    auto gen_d = [&](u32 buf) {
+    // digits of a tile: thread idx = tid + 512 r owns (plane p, coefficient c) = (idx / RD, idx % RD) -- recomputed where needed: a
+    // division by a constant is a handful of instructions, cheaper than an LDS round trip, and there is no register to keep it in
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const u32 idx = tid + 512 * r;
-            if (idx < NP * RD) {
-                const u32 p = idx / RD, c = idx % RD;
-                const int4 w0 = *(const int4 *)(wl + buf * RD * 8 + c * 8), w1 = *(const int4 *)(wl + buf * RD * 8 + c * 8 + 4);
+    for (int r = 0; r < GDR; r++) cst[(C_DACC + r) * 512 + tid] = 0;   // digit sums of (plane, c) = idx over this workgroup's columns
+    auto gen_d = [&](u32 wbuf, u32 dbuf) {
+#pragma unroll
+        for (int r = 0; r < GDR; r++) {
+            if (tid + 512 * r < NP * RD) {
+                u32 idx = tid + 512 * r;
+                asm volatile("" : "+v"(idx));   // (opaque: keeps the compiler from hoisting p, c out of the tile loop into registers it does not have)
+                const u32 gp = idx / RD, gc = idx % RD;
+                const int32_t *wp = wl + wbuf * RD * 8 + gc * 8;
+                const int4 w0 = *(const int4 *)(wp), w1 = *(const int4 *)(wp + 4);
                 const int32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
                 ull d = 0;
                 int sacc = 0;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    int dg = digit2_i8(w[q], a.k0 + p);
+                    int dg = digit2_i8(w[q], a.k0 + gp);
                     sacc += dg;
                     d |= (ull)(unsigned char)dg << (8 * q);
                 }
-                Dl[idx] = d;
-                if (r == 0) dacc0 += sacc; else dacc1 += sacc;
+                Dl[dbuf * DB + gp * DS + gc] = d;
+                cst[(C_DACC + r) * 512 + tid] += (u32)sacc;
             }
         }
     };
-    auto gen_v = [&](u32 buf) {
-        for (u32 idx = tid; idx < NP * 2 * VS; idx += 512) {
-            const u32 p = idx / (2 * VS), r = idx % (2 * VS), hl = r / VS, e = r % VS;
-            const int dl = RD - 1 - (int)e;
-            const ull *D = Dl + p * RD;
-            ull v = 0;
-            if (hl == 0) {          // H: outputs c_out >= RD/2
-                if (dl >= -(HALF - 1) && dl <= RD - 1) {
-                    v = dl >= 0 ? D[dl] : 0;
-                    if (dl <= HALF - 1) v = swar_add(v, D[dl + HALF]);
-                }
-            } else {                // L: outputs c_out < RD/2
-                if (dl >= -(RD - 1) && dl <= HALF - 1) {
-                    v = dl >= 0 ? D[dl] : 0;
-                    if (dl <= -1) v = swar_sub(v, D[dl + RD]);
-                    if (dl <= -(HALF + 1)) v = swar_sub(v, D[dl + RD + HALF]);
-                }
+    // vectors of a tile: thread tid < PPR * EPP owns entry (H / L, e) = (gr / VS, gr % VS), gr = tid % EPP, of the planes tid / EPP + PPR * round;
+    // v = D[o0] + D[o1] (H) or D[o0] - D[o1] - D[o2] (L), a missing term reads the zero word at index RD
+    auto gen_v_round = [&](u32 dbuf, u32 vbuf, u32 round) {
+        // planes tid / EPP + PPR * round < NP; the destination entry (tid / EPP) * EPP + tid % EPP is tid itself
+        u32 tv = tid;
+        asm volatile("" : "+v"(tv));            // (opaque: as in gen_d)
+        const u32 gv_p = tv / EPP, gv_pd = gv_p * DS * 8;
+        if (!(tv < (u32)(PPR * EPP) && gv_pd < (NP - PPR * round) * (u32)(DS * 8))) return;
+        const u32 gv_r = tv - gv_p * EPP;
+        u32 gv_o0 = RD, gv_o1 = RD, gv_o2 = RD;
+        const bool gv_sub = gv_r >= (u32)VS;
+        const int dl = RD - 1 - (int)(gv_r % VS);
+        if (!gv_sub) {          // H: outputs c_out >= RD/2
+            if (dl >= -(HALF - 1) && dl <= RD - 1) {
+                if (dl >= 0) gv_o0 = dl;
+                if (dl <= HALF - 1) gv_o1 = dl + HALF;
             }
-            V[(size_t)buf * NP * 2 * VS + idx] = v;
+        } else {                // L: outputs c_out < RD/2
+            if (dl >= -(RD - 1) && dl <= HALF - 1) {
+                if (dl >= 0) gv_o0 = dl;
+                if (dl <= -1) gv_o1 = dl + RD;
+                if (dl <= -(HALF + 1)) gv_o2 = dl + RD + HALF;
+            }
         }
+        const unsigned char *D = (const unsigned char *)(Dl + dbuf * DB + round * PPR * DS) + gv_pd;
+        const ull x0 = *(const ull *)(D + gv_o0 * 8), x1 = *(const ull *)(D + gv_o1 * 8), x2 = *(const ull *)(D + gv_o2 * 8);
+        const ull t = swar_add(x1, x2);
+        V[vbuf * VB + round * PPR * EPP + tv] = gv_sub ? swar_sub(x0, t) : swar_add(x0, t);
+    };
+    const u32 gv_rounds = (NP + PPR - 1) / PPR;
+    auto gen_v_gap = [&](u32 dbuf, u32 vbuf, u32 gap) {   // the rounds of K-step gap `gap`
+        for (u32 round = gap; round < gv_rounds; round += KS) gen_v_round(dbuf, vbuf, round);
     };
     if (T0 < T1) {
-        // ---- prologue: A[T0], w[T0], w[T0+1] -> LDS; D[T0]; V[0]
+        // ---- prologue: A[T0], w[T0 .. T0+2] -> LDS; zero words; D[T0], D[T0+1]; V[T0]
         LF_I8_LOAD_A(T0);
         load_w(T0);
         store_w(0);
         load_w(T0 + 1);
         store_w(1);
+        load_w(T0 + 2);
+        store_w(2);
         LF_I8_STORE_A(0);
+        if (tid < 2 * MAXNP) Dl[tid * DS + RD] = 0;
         lds_barrier();
-        gen_d(0);
+        gen_d(0, 0);
+        gen_d(1, 1);
         lds_barrier();
-        gen_v(0);
+        for (u32 g = 0; g < (u32)KS; g++) gen_v_gap(0, 0, g);
         lds_barrier();
+        unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
+#define LF_I8_STAMP(i_)                                                                  \
+    if (PROF) {                                                                          \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+        pt[i_] += now_ - pc;                                                             \
+        pc = now_;                                                                       \
+    }
+        if (PROF) pc = __builtin_amdgcn_s_memtime();
+        u32 w3 = 0;                                            // (T - T0) % 3: the w slot of tile T; T+2 is in slot (w3 + 2) % 3, T+3 replaces T
         for (u32 T = T0; T < T1; T++) {
             const u32 cur = (T - T0) & 1, nxt = cur ^ 1;
-            const bool more = T + 1 < T1;
-            LF_I8_LOAD_A(T + 1);
-            load_w(T + 2);
-            if (more) gen_d(nxt);
-            lds_barrier();
-            if (more) gen_v(nxt);
-            // ---- RD/8 K-steps of 64 inner elements
+            // state: A[cur], V[cur] = tile T;  D[nxt] = digits of tile T+1;  w slots hold T, T+1, T+2
+            if (!LATE) { LF_I8_LOAD_A(T + 1); load_w(T + 3); }
+            LF_I8_STAMP(0);     // early loads
+
+            // ---- RD/8 K-steps of 64 inner elements, the next tile's operand build between them
             const unsigned char *Ac = Al + cur * a_lds;
-            const unsigned char *Vc = (const unsigned char *)(V + (size_t)cur * NP * 2 * VS);
+            const unsigned char *Vc = (const unsigned char *)(V + cur * VB);
+            // the operand build of the next tiles, cut into KS pieces, piece s after K-step s.  (Running the late waves' pieces BEFORE their
+            // K-steps, so that the two waves of a SIMD alternate between the matrix pipe and the VALU / LDS work, cost 22 spilled registers.)
+            auto build = [&](int s) {
+                if (s == 0) gen_d(w3 >= 1 ? w3 - 1 : 2, cur);       // digits of tile T+2 (w slot (w3 + 2) % 3) replace those of tile T
+                gen_v_gap(nxt, nxt, (u32)s);                          // vectors of tile T+1
+            };
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 v4i b[NTW];
 #pragma unroll
                 for (int ni = 0; ni < NTW; ni++) {
-                    const ull *q = (const ull *)(Vc + vb[ni] + s * 64);
+                    const ull *q = (const ull *)(Vc + ((ni & 1) ? vbp[ni >> 1] >> 16 : vbp[ni >> 1] & 0xFFFF) + s * 64);
                     ull lo = q[0], hi = q[1];
                     b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
                 }
+                // EXACT: the A operand of row tile mi+1 is read while the MFMAs of row tile mi run (a rolling pair of operand registers; the
+                // sched_barrier after every row tile pins that order and keeps the compiler from hoisting more than one read ahead)
+                v4i avn = v4i{0, 0, 0, 0};
+                if (EXACT) avn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0);
 #pragma unroll
                 for (int mi = 0; mi < MTW; mi++) {
                     if (EXACT) {
-                        v4i av = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + mi * 1024);
+                        const v4i av = avn;
+                        if (mi + 1 < MTW) avn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + (mi + 1) * 1024);
 #pragma unroll
                         for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
-                        if (mi & 1) __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_sched_barrier(0);
                     } else if (mi < (int)mcnt) {   // (wave-uniform guards)
                         v4i av = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + mi * 1024);
 #pragma unroll
@@ -273,13 +348,29 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
                             if (ni < (int)ncnt) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                     }
                 }
-                if (EXACT) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s == 0) LF_I8_STAMP(1);     // K-step 0
+                build(s);
+                if (s == 0 && LATE) { LF_I8_LOAD_A(T + 1); load_w(T + 3); }   // (after the build: the staging registers are dead until here)
+                if (s == 0) LF_I8_STAMP(2);     // first build piece (+ late loads)
+                __builtin_amdgcn_sched_barrier(0);
             }
+            LF_I8_STAMP(3);     // K-steps 1.. + vectors
+            if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            LF_I8_STAMP(4);     // wait for the tile copy's loads
             LF_I8_STORE_A(nxt);
-            store_w(cur);   // w[T+2] goes where w[T] was (read by gen_d one iteration ago)
+            store_w(w3);        // w[T+3] goes where w[T] was
+            LF_I8_STAMP(5);     // LDS stores
             lds_barrier();
+            LF_I8_STAMP(6);     // barrier
+            w3 = w3 == 2 ? 0 : w3 + 1;
+        }
+        if (PROF && blockIdx.x == 0 && lane == 0) {
+            for (int i = 0; i < 7; i++) g_i8_prof[wave][i] = pt[i];
+            g_i8_prof[wave][7] = T1 - T0;
         }
     }
+#undef LF_I8_STAMP
 #undef LF_I8_LOAD_A
 #undef LF_I8_STORE_A
     // ---- partial results of the workgroup
@@ -289,22 +380,25 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
         for (int ni = 0; ni < NTW; ni++)
             if (mi < (int)mcnt && ni < (int)ncnt)
                 *(v4i *)(a.part + ((((size_t)slot * MT + m_lo + mi) * NT + n_lo + ni) * 64 + lane) * 4) = acc[mi][ni];
-    if (tid < NP * RD) a.dsum[(size_t)slot * NP * RD + tid] = dacc0;
-    if (tid + 512 < NP * RD) a.dsum[(size_t)slot * NP * RD + tid + 512] = dacc1;
+#pragma unroll
+    for (int r = 0; r < GDR; r++)
+        if (tid + 512 * r < NP * RD) a.dsum[(size_t)slot * NP * RD + tid + 512 * r] = (int)cst[(C_DACC + r) * 512 + tid];
 }
 
-// Kernel: row group 0 runs the MTWA instantiation, the other row groups MTWB (two copies of the whole loop when they differ: each has its
-// own accumulators -- an if / else INSIDE the loop would make the compiler copy them; s_barrier counts waves, not program counters).
-template <int RD, int RG, int MTWA, int MTWB, int NTW, int ACH, bool EXACT>
+// Kernel: waves 0-3 run the (MTWA, early loads) instantiation, waves 4-7 -- the second wave of every SIMD -- the (MTWB, late loads) one: two
+// copies of the whole loop, each with its own accumulators (an if / else INSIDE the loop would make the compiler copy them; s_barrier counts
+// waves, not program counters).  With two row groups of four waves the split is the row-group split (7 + 6 row tiles).
+template <int RD, int RG, int MTWA, int MTWB, int NTW, int ACH, bool EXACT, bool PROF = false>
 __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (MTWA == MTWB) i8_run<RD, RG, MTWA, NTW, ACH, EXACT>(a, smem);
-    else {
-        constexpr int CG = I8_WAVES / RG;
-        if ((threadIdx.x >> 6) / CG == 0) i8_run<RD, RG, MTWA, NTW, ACH, EXACT>(a, smem);
-        else i8_run<RD, RG, MTWB, NTW, ACH, EXACT>(a, smem);
-    }
+    static_assert(RG == 1 || RG == 2, "waves 0-3 / 4-7 are the two row groups");
+    static_assert(RG == 2 || MTWA == MTWB, "one row group: one tile count");
+    constexpr int MTT = EXACT ? (RG == 2 ? MTWA + MTWB : MTWA) : 0;
+    if ((threadIdx.x >> 6) < I8_WAVES / 2) i8_run<RD, RG, MTWA, NTW, ACH, EXACT, false, MTT, PROF>(a, smem);
+    else i8_run<RD, RG, MTWB, NTW, ACH, EXACT, true, MTT, PROF>(a, smem);
 }
+// copies the per-phase clock totals of the last PROF launch: out[wave][0..6] cycles per phase, out[wave][7] = tiles
+int ajtai_i8_read_prof(unsigned long long *out64) { return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_i8_prof), sizeof(g_i8_prof)) == hipSuccess ? 0 : -1; }
 
 // stage 1 of the reduction: element-wise sum of the workgroups' partial tiles (and of their digit sums) -- coalesced across threads
 // (blockIdx.y = side: the slots of side s start at s * nwg, its sums at s * (per_wg + per_wg_d))
@@ -375,14 +469,16 @@ static u32 ach_for(u32 RD, u32 MT) {   // 16-byte chunks of an A tile per thread
     const size_t bytes = (size_t)(RD / 8) * MT * 1024;
     return bytes <= 2 * 8192 ? 2 : (bytes <= 3 * 8192 ? 3 : 5);
 }
+u32 ajtai_i8_max_planes(const AjtaiI8Ring &R) { return R.RD == 24 ? 15 : 8; }     // digit planes per launch (accumulators, LDS, rounds of the vector build)
 size_t ajtai_i8_lds_bytes(const AjtaiI8Ring &R, u32 MT, u32 NP) {
-    return 2 * (size_t)ach_for(R.RD, MT) * 8192 + 2 * (size_t)NP * 2 * (2 * R.RD) * 8 + (size_t)NP * R.RD * 8 + 2 * (size_t)R.RD * 8 * 4;
+    (void)NP;   // the buffers have the strides of the largest plane count
+    const size_t maxnp = ajtai_i8_max_planes(R);
+    return 2 * (size_t)ach_for(R.RD, MT) * 8192 + 2 * maxnp * 2 * (2 * R.RD) * 8 + 2 * maxnp * (R.RD + 1) * 8 + 3 * (size_t)R.RD * 8 * 4 + 6 * 512 * 4;
 }
 size_t ajtai_i8_slack_bytes() { return 5 * 8192; }   // readable bytes required behind the packed matrix
 u32 ajtai_i8_row_tiles(const AjtaiI8Ring &R, u32 kappa) { return (R.NL * kappa + 15) / 16; }
 u32 ajtai_i8_col_tiles(const AjtaiI8Ring &R, u32 NP) { return (R.RD * NP + 15) / 16; }
 u32 ajtai_i8_max_rows(const AjtaiI8Ring &R) { return R.RD == 24 ? 26 : 16; }      // rows of A per launch (13 / 4 row tiles)
-u32 ajtai_i8_max_planes(const AjtaiI8Ring &R) { return R.RD == 24 ? 16 : 8; }     // digit planes per launch (accumulators and LDS)
 // partial buffer words (int32) for nwg workgroups
 size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT) { return (size_t)nwg * MT * NT * 256; }
 size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, u32 MT, u32 NT, u32 NP) { return 2 * ((size_t)MT * NT * 256 + (size_t)NP * R.RD); }   // (two sides)
@@ -394,6 +490,7 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     a.MT = MT; a.NT = ajtai_i8_col_tiles(R, NP); a.k0 = k0; a.NP = NP;
     a.ntiles = (u32)((n + 7) / 8);
     a.part = part; a.dsum = dsum;
+    if ((size_t)R.RD * ld * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit plane offsets in the kernel
     if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
     // two witnesses: nwg / 2 chunks of columns (a multiple of 8, see i8_run), each run by a pair of workgroups
     const u32 sides = planes2 ? 2 : 1;
@@ -406,6 +503,7 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     u32 nchunks = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     if (sides == 2) nchunks = (nchunks + 7) & ~7u;   // (trailing chunks past the last tile run empty)
     a.sides = sides; a.nchunks = nchunks;
+
     const u32 grid = sides * nchunks;
     const size_t lds = ajtai_i8_lds_bytes(R, MT, NP);
 #define LF_I8_LAUNCH(RD, RG, MTWA, MTWB, NTW, ACH, EXACT)                                                                           \
@@ -417,7 +515,12 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     const bool guarded = getenv("LF_I8_GUARDED") != nullptr;   // A/B switch: the generic guarded instantiation for every shape
     if (R.RD == 24) {   // 2 row groups x 4 column groups of 6 tiles (24 x 16 planes = 24 tiles)
         const u32 mh = (MT + 1) / 2;
-        if (MT == 13 && !guarded) LF_I8_LAUNCH(24, 2, 7, 6, 6, 5, true);    // kappa 25 / 26: 7 + 6 row tiles, branch-free
+        static const bool prof = getenv("LF_I8_PROF") != nullptr;
+        if (MT == 13 && !guarded && prof) {
+            static bool attr_p = false;
+            if (!attr_p) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<24, 2, 7, 6, 6, 5, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_p = true; }
+            hipLaunchKernelGGL((k_ajtai_i8<24, 2, 7, 6, 6, 5, true, true>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);
+        } else if (MT == 13 && !guarded) LF_I8_LAUNCH(24, 2, 7, 6, 6, 5, true);    // kappa 25 / 26: 7 + 6 row tiles, branch-free
         else if (mh <= 2) LF_I8_LAUNCH(24, 2, 2, 2, 6, 2, false);
         else if (mh <= 4) LF_I8_LAUNCH(24, 2, 4, 4, 6, 3, false);
         else LF_I8_LAUNCH(24, 2, 7, 7, 6, 5, false);

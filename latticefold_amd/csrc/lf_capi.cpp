@@ -1581,7 +1581,7 @@ static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_o
 // wit_l and wit_r through the same launches of the int8 kernel, paired workgroups sharing the tiles of A in L2.  false: the shape / mode has no
 // such form (the caller commits one side after the other).
 static bool commit_pair_possible(lf_ctx *c) {
-    return c->i8_nch && !c->tn.ajtai_valu && !c->tn.i8_no_pair && (c->nA + 7) / 8 >= 16;
+    return c->i8_nch && !c->tn.ajtai_valu && c->tn.i8_pair && (c->nA + 7) / 8 >= 16;
 }
 static int decompose_commit_enqueue_pair(lf_ctx *c, const lf_witness *wit_l, const lf_witness *wit_r, u64 **ydl_out, u64 **ydr_out, size_t *ev_out) {
     const lf_params &P = c->P;
@@ -2490,10 +2490,10 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         u64 *yd = nullptr, *ydL = nullptr;
         size_t ev = 0;
         if (commit_pair_possible(c)) {
-            // both decompositions' commits in one pass over A, first thing on this lane; the right side's result waits on the device
-            RET(decompose_commit_enqueue_pair(c, w_acc, w_i, &ydL, &yd, &ev));
-            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, ev, decl));
+            // both decompositions' commits in one pass over A.  Nothing needs y_L before the left decomposition is absorbed -- after the
+            // linearization -- so the left evaluations go first and the commit's results wait on the device
             RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+            RET(decompose_commit_enqueue_pair(c, w_acc, w_i, &ydL, &yd, &ev));
         } else {
             RET(decompose_commit_enqueue(c, w_acc, &yd, &ev));
             RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));
@@ -2506,9 +2506,12 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
             (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
         }
+        if (ydL) {                                                      // paired commit: y_L from the device now (its phase timer closes here)
+            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, ev, decl));
+            ev = c->ev_begin(11);
+        }
         if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
-        if (ydL) ev = c->ev_begin(11);                                  // (paired commit: its phase timer was closed with the left side)
         return decompose_commit_finish(c, cm_i, yd, ev, decr);          // cm of the linearized instance = cm_i.cm
     });
     {   // absorb_public_input (nifs.rs:175-197) -- after lane 1 has been started: the left decomposition does not depend on it
@@ -2881,6 +2884,9 @@ int lf_last_timeline(lf_ctx *c, char *names, double *ms, int max_marks) {
     }
     return n;
 }
+// measurement hook of tools/gpu_i8prof.sh (not part of the prover interface, not declared in lfhip.h): per-phase clock totals of the last commit
+// launch made with LF_I8_PROF set
+extern "C" int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_prof((unsigned long long *)out64) : LF_ERR_INVALID; }
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
     *sv_round_mask = c->bb ? 0u : c->sv_round_mask;

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""(GPU box) per-phase shader-clock profile of k_ajtai_i8 (LF_I8_PROF instantiation): one fold step at C4, then the totals of workgroup 0"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["LF_I8_PROF"] = "1"
+import numpy as np
+from latticefold_amd import api
+from latticefold_amd.workload import make_workload
+wl = make_workload(sys.argv[1] if len(sys.argv) > 1 else "C4")
+ctx = api.Context(0)
+ctx.load_ccs(wl)
+scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=7)
+wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+for _ in range(2):
+    api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+out = (C.c_uint64 * 64)()
+lib = api._lib()
+lib.lf_debug_i8_prof.argtypes = [C.POINTER(C.c_uint64)]
+assert lib.lf_debug_i8_prof(out) == 0
+a = np.array(out[:], dtype=np.float64).reshape(8, 8)
+names = ["load issue + digits", "barrier 1", "Toeplitz vectors", "MFMA block", "wait vmcnt", "LDS stores", "barrier 2"]
+print("tiles per workgroup:", a[:, 7], " kernel stats:", ctx.kernel_stats())
+print("cycles per tile and wave (shader clock), waves 0..7:")
+for i, n in enumerate(names):
+    print("  %-22s" % n, " ".join("%7.0f" % (a[w, i] / max(a[w, 7], 1)) for w in range(8)))
+print("  %-22s" % "sum", " ".join("%7.0f" % (a[w, :7].sum() / max(a[w, 7], 1)) for w in range(8)))
