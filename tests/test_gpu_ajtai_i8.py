@@ -106,15 +106,15 @@ def test_extreme_digit_patterns(pattern, wgs):
 
 @pytest.mark.parametrize("name", ["T8", "T10", "G5", "E22", "E99", "T14"])
 def test_paired_commit_of_both_decompositions(name):
-    """lf_fold_step commits the digit planes of BOTH witnesses in one pass over A (paired workgroups, lf_ajtai_i8.hip `sides`): the chained
-    step -- left witness = the folded witness of the first step, right witness = w_i, so the two sides differ -- must equal the run with one
-    launch per decomposition (LF_I8_NO_PAIR) for several workgroup counts (odd chunk counts, empty trailing chunks), and the oracle."""
+    """LF_I8_PAIR: lf_fold_step commits the digit planes of BOTH witnesses in one pass over A (paired workgroups, lf_ajtai_i8.hip `sides`):
+    the chained step -- left witness = the folded witness of the first step, right witness = w_i, so the two sides differ -- must equal the
+    default run with one launch per decomposition for several workgroup counts (odd chunk counts, empty trailing chunks), and the oracle."""
     import lfo
     out = {}
     try:
-        for mode, env in (("pair", None), ("nopair", {"LF_I8_NO_PAIR": "1"}), ("pair16", {"LF_I8_WGS": "16"}), ("pair40", {"LF_I8_WGS": "40"}),
-                          ("pair250", {"LF_I8_WGS": "250"})):
-            os.environ.pop("LF_I8_NO_PAIR", None)
+        for mode, env in (("pair", {"LF_I8_PAIR": "1"}), ("nopair", None), ("pair16", {"LF_I8_PAIR": "1", "LF_I8_WGS": "16"}),
+                          ("pair40", {"LF_I8_PAIR": "1", "LF_I8_WGS": "40"}), ("pair250", {"LF_I8_PAIR": "1", "LF_I8_WGS": "250"})):
+            os.environ.pop("LF_I8_PAIR", None)
             wl, ctx, scheme = _setup(name, False, env)
             wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
             cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
@@ -135,5 +135,5 @@ def test_paired_commit_of_both_decompositions(name):
             lc2_o, f1_o, proof2_o = inst.fold_step(lfo.Transcript(), A, lc_o, lfo.icrt(f0_o), cccs, f)
             assert (out["pair"][2] == proof2_o).all() and (out["pair"][3] == lc2_o).all() and (out["pair"][4] == f1_o).all()
     finally:
-        for k in ("LF_I8_NO_PAIR", "LF_I8_WGS"):
+        for k in ("LF_I8_PAIR", "LF_I8_WGS"):
             os.environ.pop(k, None)
