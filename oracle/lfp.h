@@ -8,6 +8,7 @@
  *   split                             utils.rs:12-43
  *   RgInstance::from_f                rgchk.rs:260-331   (the "double commitment": benches/double_commitment.rs:53-82)
  *   Decomp::decompose                 decomp.rs:32-99    (base-B split into two parts, their commitments and MLE evaluations; no transcript)
+ *   PoseidonTranscript, set check, range check (prover and verifier): lfp_protocol.c (transcript.rs, setchk.rs, rgchk.rs:81-258)
  *
  * PARITY STATUS: **unpinned beyond the two tensor KATs**.  The arithmetic of this path lives in stark-rings @ 886a89f (absent):
  * `exp`, `decompose_to_vec`, `gadget_decompose`, `Matrix::{try_mul_mat, try_mul_vec, hconcat}`.  Restated here from their call sites
@@ -48,6 +49,33 @@ int lfp_decompose(const uint64_t *f, size_t n, const uint64_t *A, uint32_t kappa
                   const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1,
                   uint64_t *v0, uint64_t *v1);
 void lfp_splitmix_fill(uint64_t seed, uint64_t start, size_t count, uint64_t *out);   /* uniform words < p (workload generator) */
+
+/* ---- lfp_protocol.c: the transcript-driven part (PoseidonTranscript<RqPoly>, set check, range check), prover AND verifier ------------ */
+typedef struct lfp_tr lfp_tr;
+lfp_tr *lfp_tr_new(void);                                          /* PoseidonTranscript::empty::<FrogPoseidonConfig>() (transcript.rs:20-32) */
+void lfp_tr_free(lfp_tr *t);
+lfp_tr *lfp_tr_clone(const lfp_tr *t);
+void lfp_tr_absorb(lfp_tr *t, const uint64_t *ring, size_t count); /* Transcript::absorb / absorb_slice: 16 words per element */
+uint64_t lfp_tr_challenge(lfp_tr *t);                              /* get_challenge: one F_p word (squeezed, absorbed back) */
+void lfp_tr_squeeze_bytes(lfp_tr *t, size_t n, uint8_t *out);
+void lfp_short_challenge(lfp_tr *t, uint64_t *out16);              /* utils::short_challenge(128, ..) (utils.rs:87-101) */
+void lfp_short_challenge_from_bytes(const uint8_t *bs16, uint64_t *out16);   /* = FrogChallengeSet decoding (rings/frog.rs:35-55, KAT :66-96) */
+void lfp_poseidon_params(uint64_t *ark720, uint64_t *mds576);      /* regenerated table (checksums: kats.json "poseidon_frog_params") */
+void lfp_poseidon_permute(uint64_t *state24);
+void lfp_psi(uint64_t *out16);                                     /* psi with ct(psi exp(a)) = a, -d/2 < a < d/2 */
+uint64_t lfp_ct_psi_mul(const uint64_t *b16);
+/* In::set_check (setchk.rs:65-262) / Out::verify (:266-340); shapes in lfp_protocol.c */
+int lfp_set_check(lfp_tr *tr, unsigned nvars, const uint64_t *msets, unsigned nmat, unsigned ncols, const uint64_t *vsets, unsigned nvec, unsigned nM,
+                  const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out,
+                  uint64_t *b_out);
+int lfp_set_check_verify(lfp_tr *tr, unsigned nvars, unsigned nmat, unsigned ncols, unsigned nvec, unsigned nM, const uint64_t *msgs, const uint64_t *e,
+                         const uint64_t *b, uint64_t *r_out);
+/* Rg::range_check (rgchk.rs:81-186) / Dcom::verify (:193-258) */
+int lfp_range_check(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, const uint64_t *const *Mf, const uint64_t *const *tau, const uint64_t *const *mtau,
+                    const uint64_t *const *f, unsigned nM, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
+                    uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out);
+int lfp_range_check_verify(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned nM, const uint64_t *msgs, const uint64_t *e, const uint64_t *b,
+                           const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c, uint64_t *r_out);
 #ifdef __cplusplus
 }
 #endif

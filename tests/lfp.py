@@ -17,7 +17,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        srcs = [os.path.join(_DIR, f) for f in ("lfp.c", "lfp.h")]
+        srcs = [os.path.join(_DIR, f) for f in ("lfp.c", "lfp_protocol.c", "lfp.h")]
         if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
             subprocess.check_call(["make", "-C", _DIR, "-s", "liblfp.so"])
         L = C.CDLL(_SO)
@@ -124,3 +124,143 @@ def decompose(f, A, B, r_a, r_b, mats=()):
     if rc != 0:
         raise ValueError(f"lfp_decompose: {rc}")
     return {"F0": F0, "F1": F1, "C0": C0, "C1": C1, "v0": v0, "v1": v1}
+
+
+# ---- transcript-driven part (oracle/lfp_protocol.c): PoseidonTranscript<RqPoly>, set check, range check ------------------------------
+def _plib():
+    L = lib()
+    if not getattr(L, "_proto", False):
+        vp = C.c_void_p
+        u8p = C.POINTER(C.c_uint8)
+        u32pp, u64pp = C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64p)
+        L.lfp_tr_new.restype = vp
+        L.lfp_tr_clone.restype = vp
+        L.lfp_tr_clone.argtypes = [vp]
+        L.lfp_tr_free.argtypes = [vp]
+        L.lfp_tr_absorb.argtypes = [vp, u64p, C.c_size_t]
+        L.lfp_tr_challenge.argtypes = [vp]
+        L.lfp_tr_challenge.restype = C.c_uint64
+        L.lfp_tr_squeeze_bytes.argtypes = [vp, C.c_size_t, u8p]
+        L.lfp_short_challenge.argtypes = [vp, u64p]
+        L.lfp_short_challenge_from_bytes.argtypes = [u8p, u64p]
+        L.lfp_poseidon_params.argtypes = [u64p, u64p]
+        L.lfp_poseidon_permute.argtypes = [u64p]
+        L.lfp_psi.argtypes = [u64p]
+        L.lfp_ct_psi_mul.argtypes = [u64p]
+        L.lfp_ct_psi_mul.restype = C.c_uint64
+        L.lfp_set_check.argtypes = [vp, C.c_uint, u64p, C.c_uint, C.c_uint, u64p, C.c_uint, C.c_uint, u32pp, u32pp, u64pp, u64p, u64p, u64p, u64p]
+        L.lfp_set_check_verify.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, u64p, u64p, u64p, u64p]
+        L.lfp_range_check.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, u64pp, u64pp, u64pp, u64pp, C.c_uint, u32pp, u32pp, u64pp] + [u64p] * 8
+        L.lfp_range_check_verify.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint] + [u64p] * 8
+        L._proto = True
+    return L
+
+
+class Transcript:
+    """PoseidonTranscript::empty::<FrogPoseidonConfig>() (latticefold-plus/src/transcript.rs)"""
+
+    def __init__(self, h=None):
+        self.h = h if h is not None else _plib().lfp_tr_new()
+
+    def clone(self):
+        return Transcript(_plib().lfp_tr_clone(self.h))
+
+    def absorb(self, ring):
+        a = np.ascontiguousarray(ring, dtype=np.uint64).reshape(-1, D)
+        _plib().lfp_tr_absorb(self.h, _p(a.reshape(-1)), a.shape[0])
+
+    def challenge(self):
+        return int(_plib().lfp_tr_challenge(self.h))
+
+    def squeeze_bytes(self, n):
+        o = np.zeros(n, dtype=np.uint8)
+        _plib().lfp_tr_squeeze_bytes(self.h, n, o.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return o
+
+    def short_challenge(self):
+        o = np.zeros(D, dtype=np.uint64)
+        _plib().lfp_short_challenge(self.h, _p(o))
+        return o
+
+    def __del__(self):
+        try:
+            _plib().lfp_tr_free(self.h)
+        except Exception:
+            pass
+
+
+def poseidon_params():
+    ark, mds = np.zeros(720, dtype=np.uint64), np.zeros(576, dtype=np.uint64)
+    _plib().lfp_poseidon_params(_p(ark), _p(mds))
+    return ark, mds
+
+
+def short_challenge_from_bytes(bs):
+    b = np.ascontiguousarray(bs, dtype=np.uint8)
+    o = np.zeros(D, dtype=np.uint64)
+    _plib().lfp_short_challenge_from_bytes(b.ctypes.data_as(C.POINTER(C.c_uint8)), _p(o))
+    return o
+
+
+def psi():
+    o = np.zeros(D, dtype=np.uint64)
+    _plib().lfp_psi(_p(o))
+    return o
+
+
+def exp_dense(digits):
+    """exp() of an int8 array of digits in (-8, 8): one-hot ring elements, shape digits.shape + (16,)"""
+    d = np.asarray(digits).astype(np.int64)
+    e = np.where(d >= 0, d, D + d)
+    out = np.zeros(d.shape + (D,), dtype=np.uint64)
+    np.put_along_axis(out, e[..., None], 1, axis=-1)
+    return out
+
+
+def set_check(tr, nvars, msets, vsets=None, mats=()):
+    """In::set_check.  msets (nmat, n, ncols, 16), vsets (nvec, n, 16) -> dict(r, msgs (nvars,4,16), e (1+nM, nmat, ncols, 16), b (nvec,16))"""
+    msets = np.ascontiguousarray(msets, dtype=np.uint64)
+    nmat, n, ncols = msets.shape[:3]
+    vsets = np.zeros((0, n, D), dtype=np.uint64) if vsets is None else np.ascontiguousarray(vsets, dtype=np.uint64)
+    nvec, nM = vsets.shape[0], len(mats)
+    keep, rp, cp, vp = csr_args(mats)
+    r, msgs = np.zeros(nvars, dtype=np.uint64), np.zeros((nvars, 4, D), dtype=np.uint64)
+    e, b = np.zeros((1 + nM, nmat, ncols, D), dtype=np.uint64), np.zeros((max(nvec, 1), D), dtype=np.uint64)
+    vs = vsets if nvec else np.zeros((1, 1, D), dtype=np.uint64)
+    rc = _plib().lfp_set_check(tr.h, nvars, _p(msets.reshape(-1)), nmat, ncols, _p(vs.reshape(-1)), nvec, nM, rp, cp, vp, _p(r), _p(msgs.reshape(-1)),
+                               _p(e.reshape(-1)), _p(b.reshape(-1)))
+    if rc:
+        raise ValueError(f"lfp_set_check: {rc}")
+    return {"r": r, "msgs": msgs, "e": e, "b": b[:nvec]}
+
+
+def set_check_verify(tr, nvars, out, nM=0):
+    e, b, msgs = (np.ascontiguousarray(out[k], dtype=np.uint64) for k in ("e", "b", "msgs"))
+    nmat, ncols, nvec = e.shape[1], e.shape[2], b.shape[0]
+    bb = b if nvec else np.zeros((1, D), dtype=np.uint64)
+    r = np.zeros(nvars, dtype=np.uint64)
+    return _plib().lfp_set_check_verify(tr.h, nvars, nmat, ncols, nvec, nM, _p(msgs.reshape(-1)), _p(e.reshape(-1)), _p(bb.reshape(-1)), _p(r)), r
+
+
+def range_check(tr, nvars, instances, k, mats=()):
+    """Rg::range_check.  instances: dicts with Mf (k, n, 16, 16), tau (n,), mtau (n, 16), f (n, 16) -> dict of the Dcom fields"""
+    L, nM = len(instances), len(mats)
+    keep, rp, cp, vp = csr_args(mats)
+    arrs = {key: [np.ascontiguousarray(i[key], dtype=np.uint64) for i in instances] for key in ("Mf", "tau", "mtau", "f")}
+    ptrs = {key: (u64p * L)(*[_p(a.reshape(-1)) for a in v]) for key, v in arrs.items()}
+    r, msgs = np.zeros(nvars, dtype=np.uint64), np.zeros((nvars, 4, D), dtype=np.uint64)
+    e, b = np.zeros((1 + nM, L * k, D, D), dtype=np.uint64), np.zeros((L, D), dtype=np.uint64)
+    v, a = np.zeros((L, D), dtype=np.uint64), np.zeros((L, 1 + nM), dtype=np.uint64)
+    bb, c = np.zeros((L, 1 + nM, D), dtype=np.uint64), np.zeros((L, 1 + nM, D), dtype=np.uint64)
+    rc = _plib().lfp_range_check(tr.h, nvars, L, k, ptrs["Mf"], ptrs["tau"], ptrs["mtau"], ptrs["f"], nM, rp, cp, vp, _p(r), _p(msgs.reshape(-1)),
+                                 _p(e.reshape(-1)), _p(b.reshape(-1)), _p(v.reshape(-1)), _p(a.reshape(-1)), _p(bb.reshape(-1)), _p(c.reshape(-1)))
+    if rc:
+        raise ValueError(f"lfp_range_check: {rc}")
+    return {"r": r, "msgs": msgs, "e": e, "b": b, "v": v, "a": a, "bb": bb, "c": c}
+
+
+def range_check_verify(tr, nvars, d, k):
+    arr = {key: np.ascontiguousarray(d[key], dtype=np.uint64) for key in ("msgs", "e", "b", "v", "a", "bb", "c")}
+    L, nM = arr["b"].shape[0], arr["a"].shape[1] - 1
+    r = np.zeros(nvars, dtype=np.uint64)
+    return _plib().lfp_range_check_verify(tr.h, nvars, L, k, nM, *[_p(arr[key].reshape(-1)) for key in ("msgs", "e", "b", "v", "a", "bb", "c")], _p(r)), r

@@ -160,6 +160,34 @@ def main():
         "tensor": {"r": r_in, "expected": expected},
     }
 
+    # --- Frog ring (the ring latticefold-plus runs on): Poseidon table (rings/poseidon/frog.rs:7-1425) = the same 64-bit literals again, embedded
+    #     with Fq::from(i128), i.e. reduced mod p_frog; and the challenge-set decoding KAT rings/frog.rs:66-96 (byte - 128 per coefficient), which
+    #     is also the map of latticefold-plus' utils::short_challenge(128, ..) (utils.rs:87-101: u = 2^(128/16) = 256, b % u - u/2)
+    pf = 15912092521325583641
+    srcf = read("crates/cyclotomic-rings/src/rings/poseidon/frog.rs")
+    valsf = [int(x, 16) for x in re.findall(r"Fq::from\(0x([0-9a-f]+)_i128\)", srcf)]
+    assert len(valsf) == 30 * 24 + 24 * 24
+    cfg = re.search(r"PoseidonConfig::<Fq>::new\(full_rounds, partial_rounds, alpha, mds, ark, (\d+), (\d+)\)", srcf)
+    kats["poseidon_frog_params"] = {
+        "source": "crates/cyclotomic-rings/src/rings/poseidon/frog.rs:7-1425",
+        "modulus": pf,
+        "full_rounds": int(re.search(r"full_rounds = (\d+)", srcf).group(1)), "partial_rounds": int(re.search(r"partial_rounds = (\d+)", srcf).group(1)),
+        "alpha": int(re.search(r"alpha = (\d+)", srcf).group(1)), "rate": int(cfg.group(1)), "capacity": int(cfg.group(2)),
+        "same_literals_as_goldilocks": valsf == vals,
+        "literals_at_or_above_modulus": sum(1 for v in valsf if v >= pf),
+        "ark_first": [v % pf for v in valsf[:4]], "mds_last": [v % pf for v in valsf[-4:]],
+        "ark_checksum": sum((i + 1) * (v % pf) for i, v in enumerate(valsf[:720])) % pf,
+        "mds_checksum": sum((i + 1) * (v % pf) for i, v in enumerate(valsf[720:])) % pf,
+    }
+    srcr = read("crates/cyclotomic-rings/src/rings/frog.rs")
+    tst = between(srcr, "fn test_small_challenge_from_random_bytes")
+    kats["frog_short_challenge"] = {
+        "source": "crates/cyclotomic-rings/src/rings/frog.rs:66-96",
+        "bytes": [int(x, 16) for x in re.findall(r"0x([0-9a-f]{2})\b", tst)],
+        "expected_coeffs": [int(x) for x in re.findall(r"BigInt\(\[(\d+)\]\)", tst)],
+    }
+    assert len(kats["frog_short_challenge"]["bytes"]) == 16 and len(kats["frog_short_challenge"]["expected_coeffs"]) == 16
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1)
