@@ -118,7 +118,7 @@ def test_range_check_completeness_and_soundness(L, nM):
     assert rc == 0 and (r == d["r"]).all()
     assert (d["v"] == d["c"][:, 0]).all()                    # "v is equal to c[0]" (rgchk.rs:123)
     # (c[0] is only absorbed by Dcom::verify -- rgchk.rs:241-251 compares v for ni = 0 and c[ni] for the M_i rows -- so tamper c where it is checked)
-    for key, idx in (("a", (0, 0)), ("bb", (0, 0, 3)), ("v", (0, 5)), ("e", (nM, 1, 3, 0))) + ((("c", (0, nM, 2)),) if nM else ()):
+    for key, idx in (("a", (0, 0)), ("bb", (0, 0, 3)), ("v", (0, 5)), ("e", (nM, 1, 3, 1))) + ((("c", (0, nM, 2)),) if nM else ()):
         t = {kk: vv.copy() for kk, vv in d.items()}
         t[key][idx] = (int(t[key][idx]) + 1) % P
         assert lfp.range_check_verify(lfp.Transcript(), nvars, t, k)[0] != 0, key
