@@ -12,6 +12,9 @@
  *   Matrix::try_mul_vec (Ajtai commitment, coefficient form)   stark-rings-linalg, call sites rgchk.rs:313-319
  *   Decomp::decompose(&A, B)                         src/decomp.rs:32-99
  *   utils::tensor / tensor_product                   src/utils.rs:45-83 (KATs utils.rs:118-131)
+ *   PoseidonTranscript<RqPoly>, utils::short_challenge       src/transcript.rs:20-78, src/utils.rs:87-101
+ *   In::set_check / Out::verify                      src/setchk.rs:65-262 / 266-340
+ *   Rg::range_check / Dcom::verify                   src/rgchk.rs:81-186 / 193-258
  *
  * M_f and m_tau are matrices / vectors of unit monomials; they cross this boundary as their EXPONENT digits (int8 in (-d/2, d/2)):
  * exp(a) = X^a for a >= 0 and X^(d + a) for a < 0.  The Rust binding rebuilds Matrix<R> from them if a caller needs the dense form
@@ -38,8 +41,10 @@ enum {
     LFPLUS_E_NO_DEVICE = -2,  /* no HIP device: the library has no CPU path */
     LFPLUS_E_HIP = -3,
     LFPLUS_E_EXP_DOMAIN = -4, /* a digit of f or of tau is outside (-d/2, d/2): the reference's exp() returns None and from_f panics */
-    LFPLUS_E_SMALL_N = -5     /* kappa*k*d*l*d >= n: the reference's split() panics ("small n unsupported") */
+    LFPLUS_E_SMALL_N = -5,    /* kappa*k*d*l*d >= n: the reference's split() panics ("small n unsupported") */
+    LFPLUS_E_REJECT = -6      /* a verifier rejected the proof (*stage says where) */
 };
+#define LFPLUS_ABSENT (-128)  /* exponent digit of a zero entry of a monomial set (an absent sparse-matrix coefficient) */
 
 typedef struct lfplus_ctx lfplus_ctx;
 int lfplus_ctx_create(int device, lfplus_ctx **out);
@@ -75,6 +80,41 @@ int lfplus_commit(lfplus_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *out)
 /* utils::tensor(r) over the base field: out has 2^n words (n <= 28); utils::tensor_product: out has m*n words (or the non-empty side) */
 int lfplus_tensor(lfplus_ctx *ctx, const uint64_t *r, uint32_t n, uint64_t *out);
 int lfplus_tensor_product(lfplus_ctx *ctx, const uint64_t *a, uint64_t m, const uint64_t *b, uint64_t n, uint64_t *out);
+
+/* ---- the transcript-driven part: PoseidonTranscript<RqPoly>, monomial set check, range check (prover on the GPU, verifier on the host) ----
+ * PoseidonTranscript::empty::<FrogPoseidonConfig>() (src/transcript.rs:20-78; table cyclotomic-rings/src/rings/poseidon/frog.rs): a host
+ * object.  absorb = Transcript::absorb / absorb_slice (16 words per ring element), challenge = get_challenge (ONE F_p word: RqPoly's base ring
+ * has extension degree 1; squeezed and absorbed back), squeeze_bytes as arkworks (7 bytes per element), short_challenge =
+ * utils::short_challenge(128, ..) (utils.rs:87-101). */
+typedef struct lfplus_transcript lfplus_transcript;
+lfplus_transcript *lfplus_transcript_new(void);
+lfplus_transcript *lfplus_transcript_clone(const lfplus_transcript *t);
+void lfplus_transcript_free(lfplus_transcript *t);
+int lfplus_transcript_absorb(lfplus_transcript *t, const uint64_t *ring, size_t count);
+int lfplus_transcript_challenge(lfplus_transcript *t, uint64_t *out);
+int lfplus_transcript_squeeze_bytes(lfplus_transcript *t, size_t n, uint8_t *out);
+int lfplus_short_challenge(lfplus_transcript *t, uint64_t *out16);
+int lfplus_poseidon_params(uint64_t *ark720, uint64_t *mds576);   /* the regenerated Frog table (checksummed against the reference's) */
+
+/* In::set_check (src/setchk.rs:65-262): nmat matrix sets of n x ncols unit monomials and nvec vector sets of n, n = 2^nvars, as exponent
+ * digits (int8 in (-8, 8); LFPLUS_ABSENT = zero entry); nM matrices (n x n, CSR, ring coefficients) for the M_i f rows of Step 3.
+ * Outputs: r (nvars words), msgs (nvars * 4 ring elements: the sumcheck messages, constants), e ((1 + nM) * nmat * ncols ring elements,
+ * e[q][set][column]), b (nvec ring elements).  The transcript advances exactly as the reference's. */
+int lfplus_set_check(lfplus_ctx *ctx, lfplus_transcript *t, uint32_t nvars, const int8_t *mat_digits, uint32_t nmat, uint32_t ncols, const int8_t *vec_digits,
+                     uint32_t nvec, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out,
+                     uint64_t *msgs, uint64_t *e_out, uint64_t *b_out);
+/* Out::verify (setchk.rs:266-340), host only.  LFPLUS_OK, or LFPLUS_E_REJECT with *stage = 1 / 2 (sumcheck) or 3 (final evaluation). */
+int lfplus_set_check_verify(lfplus_transcript *t, uint32_t nvars, uint32_t nmat, uint32_t ncols, uint32_t nvec, uint32_t nM, const uint64_t *msgs, const uint64_t *e,
+                            const uint64_t *b, uint64_t *r_out, int *stage);
+/* Rg::range_check (src/rgchk.rs:81-186) over L instances: ctxs[l] holds witness f_l and its lfplus_rg_from_f results (same device, n = 2^nvars,
+ * k).  Outputs: the set check's r, msgs, e ((1 + nM) * (L k) * 16 ring elements), b (L), and per instance v (16 words), a (1 + nM words),
+ * bb (1 + nM ring elements: DcomEvals::b), c (1 + nM ring elements). */
+int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *t, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col,
+                       const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out,
+                       uint64_t *bb_out, uint64_t *c_out);
+/* Dcom::verify (rgchk.rs:193-258), host only: stages 1-3 set check, 4 ct(psi b) != a, 5 ct(psi sum_i (d/2)^i u_i) != v / c */
+int lfplus_range_check_verify(lfplus_transcript *t, uint32_t nvars, uint32_t L, uint32_t k, uint32_t nM, const uint64_t *msgs, const uint64_t *e, const uint64_t *b,
+                              const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c, uint64_t *r_out, int *stage);
 
 #ifdef __cplusplus
 }

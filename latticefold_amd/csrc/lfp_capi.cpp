@@ -5,47 +5,8 @@
 #include <vector>
 #include "../../include/lfplus.h"
 #include "lfp_kernels.h"
+#include "lfp_ctx.h"
 
-using lfp::u32;
-using lfp::u64;
-
-struct lfplus_ctx {
-    int device = 0;
-    hipStream_t st = nullptr;
-    std::string err;
-    u64 *A = nullptr, *f = nullptr;
-    u32 kappa = 0;
-    u64 n = 0, nf = 0;
-    // results of the last from_f
-    int8_t *Df = nullptr, *mtau = nullptr;
-    u64 *comMf = nullptr, *tau = nullptr, *coms = nullptr;   // coms: cm_f | C_Mf | cm_mtau, kappa*16 each
-    u32 k = 0, l = 0;
-    size_t Df_cap = 0, comMf_cap = 0;
-    // partial sums
-    u64 *part = nullptr;
-    size_t part_cap = 0;
-    u32 *err_d = nullptr;
-    bool have = false;
-};
-
-#define HIPCHK(c, x)                                                                        \
-    do {                                                                                    \
-        hipError_t e_ = (x);                                                                \
-        if (e_ != hipSuccess) {                                                             \
-            (c)->err = std::string(#x) + ": " + hipGetErrorString(e_);                      \
-            return LFPLUS_E_HIP;                                                            \
-        }                                                                                   \
-    } while (0)
-
-static int fail(lfplus_ctx *c, int rc, const std::string &m) {
-    if (c) c->err = m;
-    return rc;
-}
-static bool canonical(const u64 *w, size_t n) {
-    for (size_t i = 0; i < n; i++)
-        if (w[i] >= lfp::P) return false;
-    return true;
-}
 
 extern "C" int lfplus_ctx_create(int device, lfplus_ctx **out) {
     if (!out) return LFPLUS_E_ARG;

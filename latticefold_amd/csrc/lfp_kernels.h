@@ -49,6 +49,24 @@ void launch_decompose2(const u64 *f, size_t words, u64 B, u64 *F0, u64 *F1, hipS
 void launch_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM /* [2][16] Montgomery */, hipStream_t s);
 void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s);
 void launch_replicate(const u64 *src, size_t words, u32 copies, u64 *dst, hipStream_t s);
+// ---- set check / range check (lfp_rgchk.hip; setchk.rs:65-262, rgchk.rs:81-186) ----------------------------------------------------------
+constexpr int8_t LFP_ABSENT = -128;   // a zero entry of a monomial set (an absent sparse-matrix coefficient)
+struct PwTab { u64 p[16], q[16]; };   // beta^t and beta^(2t), Montgomery
+struct EqPt { u64 c[32], nc[32], one; };   // c_j, 1 - c_j and 1, Montgomery
+struct ScDesc { u32 nmat, ncols, nvec, nsets_eff; };   // nsets_eff: sets entering the sumcheck polynomial (setchk.rs:160-197: all, or the first matrix set alone without a batching challenge)
+void launch_sc_tables(const int8_t *dig, size_t n, u32 ncols, const PwTab &pw, u64 *tab, size_t ld, hipStream_t s);
+void launch_eq_build(const EqPt &pt, u32 nv, u64 *eq, hipStream_t s);
+u32 sc_round_blocks(size_t half);
+void launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part /* sc_round_blocks * 4 */, hipStream_t s);
+void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u64 rM, hipStream_t s);
+u32 eval_chunks(size_t n);
+// out[col][16] = sum_row w[row] X^e(dig[row][col]); wstride 1: scalar Montgomery weights (out canonical), 16: canonical ring weights.  part: eval_chunks(n) * ncols * 16
+void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s);
+// out[16] = sum_row w[row] f[row]; part: eval_chunks(n) * 16
+void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s);
+// out[0] = sum_i x[i xstride] y[i]; part: eval_chunks(n) * 4
+void launch_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part, u64 *out, hipStream_t s);
+void launch_spmvT_eq(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s);
 void launch_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt, hipStream_t s);
 void launch_tensor_product(const u64 *a, u64 m, const u64 *b, u64 n, u64 *out, hipStream_t s);
 }  // namespace lfp

@@ -1,0 +1,494 @@
+// lfp_protocol.cpp -- the transcript-driven part of the LatticeFold+ slice (include/lfplus.h) on the Frog ring:
+//   PoseidonTranscript<RqPoly>          crates/latticefold-plus/src/transcript.rs:20-78 (host; parameters rings/poseidon/frog.rs)
+//   In::set_check / Out::verify         src/setchk.rs:65-262 / 266-340   (prover on the GPU: lfp_rgchk.hip; verifier on the host)
+//   Rg::range_check / Dcom::verify      src/rgchk.rs:81-186 / 193-258
+// The Fiat-Shamir transcript stays on the host (one width-24 Poseidon permutation per 20 absorbed words; a sumcheck round moves four words
+// up and one down); every table and every evaluation lives on the device.  No CPU fallback: the provers return LFPLUS_E_NO_DEVICE / _HIP.
+#include <cstring>
+#include <memory>
+#include "lf_host.h"
+#include "lfp_ctx.h"
+
+namespace {
+typedef unsigned __int128 u128;
+constexpr u64 P = lfp::P;
+constexpr int D = 16, W = 24, RATE = 20, CAP = 4, RF = 8, RP = 22;
+inline u64 fadd(u64 a, u64 b) { u128 s = (u128)a + b; return (u64)(s >= P ? s - P : s); }
+inline u64 fsub(u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
+inline u64 fmul(u64 a, u64 b) { return (u64)(((u128)a * b) % P); }
+u64 fpow(u64 a, u64 e) { u64 r = 1; while (e) { if (e & 1) r = fmul(r, a); a = fmul(a, a); e >>= 1; } return r; }
+inline u64 to_mont(u64 a) { return (u64)((((u128)a) << 64) % P); }
+const u64 RINV = fpow(to_mont(1), P - 2);   // 2^-64 mod p
+inline u64 from_mont(u64 a) { return fmul(a, RINV); }
+
+// The reference's Frog table (rings/poseidon/frog.rs:7-1425) is the Grain-LFSR table of the 64-bit Goldilocks prime embedded with
+// Fq::from(i128): the generator of lf_host.cpp, reduced mod p_frog (pinned by the reference's checksums in tests/golden/kats.json)
+struct Params {
+    u64 ark[(RF + RP) * W], mds[W * W];
+    Params() {
+        const u64 *a, *m;
+        lf::Transcript::params(&a, &m);
+        for (int i = 0; i < (RF + RP) * W; i++) ark[i] = a[i] % P;
+        for (int i = 0; i < W * W; i++) mds[i] = m[i] % P;
+    }
+};
+const Params &params() { static const Params p; return p; }
+inline u64 pow7(u64 x) { u64 x2 = fmul(x, x), x4 = fmul(x2, x2); return fmul(fmul(x4, x2), x); }
+void permute(u64 *st) {
+    const Params &pp = params();
+    u64 nw[W];
+    for (int r = 0; r < RF + RP; r++) {
+        for (int i = 0; i < W; i++) st[i] = fadd(st[i], pp.ark[r * W + i]);
+        if (r < RF / 2 || r >= RF / 2 + RP) for (int i = 0; i < W; i++) st[i] = pow7(st[i]);
+        else st[0] = pow7(st[0]);
+        for (int i = 0; i < W; i++) {
+            u64 acc = 0;
+            for (int j = 0; j < W; j++) acc = fadd(acc, fmul(st[j], pp.mds[i * W + j]));
+            nw[i] = acc;
+        }
+        memcpy(st, nw, sizeof(nw));
+    }
+}
+}  // namespace
+
+// ark-crypto-primitives 0.4.0 PoseidonSponge (duplex): state[0..4) capacity, [4..24) rate
+struct lfplus_transcript {
+    u64 st[W] = {0};
+    bool squeezing = false;
+    int idx = 0;
+    void absorb_fq(const u64 *x, size_t n) {
+        if (!n) return;
+        int i0;
+        if (!squeezing) { i0 = idx; if (i0 == RATE) { permute(st); i0 = 0; } }
+        else { permute(st); i0 = 0; }
+        for (;;) {
+            if ((size_t)i0 + n <= RATE) {
+                for (size_t i = 0; i < n; i++) st[CAP + i0 + i] = fadd(st[CAP + i0 + i], x[i] % P);
+                squeezing = false;
+                idx = i0 + (int)n;
+                return;
+            }
+            const size_t take = RATE - i0;
+            for (size_t i = 0; i < take; i++) st[CAP + i0 + i] = fadd(st[CAP + i0 + i], x[i] % P);
+            permute(st);
+            x += take; n -= take; i0 = 0;
+        }
+    }
+    void squeeze_fq(u64 *out, size_t n) {
+        int i0;
+        if (!squeezing) { permute(st); i0 = 0; }
+        else { i0 = idx; if (i0 == RATE) { permute(st); i0 = 0; } }
+        for (;;) {
+            if ((size_t)i0 + n <= RATE) {
+                memcpy(out, st + CAP + i0, n * sizeof(u64));
+                squeezing = true;
+                idx = i0 + (int)n;
+                return;
+            }
+            const size_t take = RATE - i0;
+            memcpy(out, st + CAP + i0, take * sizeof(u64));
+            if (n != RATE) permute(st);
+            out += take; n -= take; i0 = 0;
+        }
+    }
+    void absorb_ring(const u64 *e, size_t count) { for (size_t i = 0; i < count; i++) absorb_fq(e + i * D, D); }   // Transcript::absorb: the 16 coefficients
+    void absorb_const(u64 c) { u64 e[D] = {0}; e[0] = c % P; absorb_ring(e, 1); }                                   // absorb(&R::from(c))
+    u64 challenge() { u64 c; squeeze_fq(&c, 1); absorb_fq(&c, 1); return c; }                                       // transcript.rs:44-53
+    void squeeze_bytes(size_t n, uint8_t *out) {                                                                    // 7 low LE bytes per element
+        std::vector<u64> e((n + 6) / 7);
+        squeeze_fq(e.data(), e.size());
+        for (size_t i = 0; i < n; i++) out[i] = (uint8_t)(e[i / 7] >> (8 * (i % 7)));
+    }
+};
+
+extern "C" {
+lfplus_transcript *lfplus_transcript_new(void) { return new lfplus_transcript; }
+lfplus_transcript *lfplus_transcript_clone(const lfplus_transcript *t) { return t ? new lfplus_transcript(*t) : nullptr; }
+void lfplus_transcript_free(lfplus_transcript *t) { delete t; }
+int lfplus_transcript_absorb(lfplus_transcript *t, const uint64_t *ring, size_t count) {
+    if (!t || (!ring && count)) return LFPLUS_E_ARG;
+    t->absorb_ring(ring, count);
+    return LFPLUS_OK;
+}
+int lfplus_transcript_challenge(lfplus_transcript *t, uint64_t *out) {
+    if (!t || !out) return LFPLUS_E_ARG;
+    *out = t->challenge();
+    return LFPLUS_OK;
+}
+int lfplus_transcript_squeeze_bytes(lfplus_transcript *t, size_t n, uint8_t *out) {
+    if (!t || (!out && n)) return LFPLUS_E_ARG;
+    t->squeeze_bytes(n, out);
+    return LFPLUS_OK;
+}
+// utils::short_challenge(128, ..) (utils.rs:87-101): 16 bytes, coefficient = byte % 256 - 128
+int lfplus_short_challenge(lfplus_transcript *t, uint64_t *out16) {
+    if (!t || !out16) return LFPLUS_E_ARG;
+    uint8_t bs[D];
+    t->squeeze_bytes(D, bs);
+    for (int i = 0; i < D; i++) { const int v = (int)bs[i] - 128; out16[i] = v >= 0 ? (u64)v : P - (u64)(-v); }
+    return LFPLUS_OK;
+}
+int lfplus_poseidon_params(uint64_t *ark720, uint64_t *mds576) {
+    if (!ark720 || !mds576) return LFPLUS_E_ARG;
+    memcpy(ark720, params().ark, sizeof(params().ark));
+    memcpy(mds576, params().mds, sizeof(params().mds));
+    return LFPLUS_OK;
+}
+}
+
+// ---- device side of the set check -----------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
+    template <class T> T *as() { return (T *)p; }
+};
+struct SetRef { const int8_t *dig; u32 ncols; };   // device pointer to the exponent digits [n][ncols]
+struct DevCsc { DevBuf colptr, rowidx, val; };
+
+// transposes the caller's CSR matrices (n rows, ring coefficients) on the host and uploads them
+int upload_csc(lfplus_ctx *c, size_t n, u32 nM, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, std::vector<std::unique_ptr<DevCsc>> &out) {
+    for (u32 q = 0; q < nM; q++) {
+        if (!rowptr[q] || !col[q] || !val[q] || rowptr[q][0] != 0) return fail(c, LFPLUS_E_ARG, "matrix: null / malformed CSR");
+        const size_t nnz = rowptr[q][n];
+        std::vector<u32> cp(n + 1, 0), ri(nnz);
+        std::vector<u64> vv(nnz * D);
+        for (size_t r = 0; r < n; r++) {
+            if (rowptr[q][r + 1] < rowptr[q][r]) return fail(c, LFPLUS_E_ARG, "matrix: rowptr not monotone");
+            for (u32 k = rowptr[q][r]; k < rowptr[q][r + 1]; k++) {
+                if (col[q][k] >= n) return fail(c, LFPLUS_E_ARG, "matrix: column index out of range");
+                cp[col[q][k] + 1]++;
+            }
+        }
+        if (!canonical(val[q], nnz * D)) return fail(c, LFPLUS_E_ARG, "matrix: non-canonical word");
+        for (size_t i = 0; i < n; i++) cp[i + 1] += cp[i];
+        std::vector<u32> fill(cp.begin(), cp.end() - 1);
+        for (size_t r = 0; r < n; r++)
+            for (u32 k = rowptr[q][r]; k < rowptr[q][r + 1]; k++) {
+                const u32 dst = fill[col[q][k]]++;
+                ri[dst] = (u32)r;
+                memcpy(&vv[(size_t)dst * D], val[q] + (size_t)k * D, D * 8);
+            }
+        std::unique_ptr<DevCsc> m(new DevCsc);
+        if (m->colptr.alloc((n + 1) * 4) || m->rowidx.alloc(nnz * 4) || m->val.alloc(nnz * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
+        HIPCHK(c, hipMemcpyAsync(m->colptr.p, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(m->rowidx.p, ri.data(), nnz * 4, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(m->val.p, vv.data(), nnz * D * 8, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        out.push_back(std::move(m));
+    }
+    return LFPLUS_OK;
+}
+
+struct ScOut {          // device-side leftovers the range check reuses
+    DevBuf eqr;         // eq(r, .) Montgomery, n words
+    std::vector<std::unique_ptr<DevBuf>> w;   // w_q = M_q^T eq(r): n ring elements each
+    DevBuf part, small;
+};
+
+// In::set_check on device-resident monomial sets (matrix sets first, then vector sets, as setchk.rs:66-82 orders them)
+int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::vector<SetRef> &mats, const std::vector<SetRef> &vecs,
+                  const std::vector<std::unique_ptr<DevCsc>> &M, u64 *r_out, u64 *msgs, u64 *e_out, u64 *b_out, ScOut &so) {
+    const size_t n = (size_t)1 << nvars;
+    const u32 nmat = (u32)mats.size(), nvec = (u32)vecs.size(), nM = (u32)M.size();
+    if (nmat < 1) return fail(c, LFPLUS_E_ARG, "set_check: at least one matrix set (setchk.rs:63)");
+    const u32 ncols = mats[0].ncols;
+    for (auto &m : mats) if (m.ncols != ncols) return fail(c, LFPLUS_E_ARG, "set_check: matrix sets of different widths");
+    const u32 ntab = nmat * (2 * ncols + 1) + 3 * nvec;
+    DevBuf tabs[2], coefd;
+    if (tabs[0].alloc((size_t)ntab * n * 8) || tabs[1].alloc((size_t)ntab * n * 8) || coefd.alloc((size_t)(nmat + nvec) * ncols * 8) ||
+        so.eqr.alloc(n * 8) || so.part.alloc((size_t)std::max<size_t>(lfp::sc_round_blocks(n / 2) * 4, (size_t)lfp::eval_chunks(n) * ncols * 16) * 8) ||
+        so.small.alloc((size_t)((1 + nM) * nmat * ncols + nvec + 8) * D * 8))
+        return fail(c, LFPLUS_E_HIP, "hipMalloc (set check tables)");
+    std::vector<u64> alpha(nmat + nvec), cch(nvars);
+    for (u32 i = 0; i < nmat + nvec; i++) {
+        const SetRef &sr = i < nmat ? mats[i] : vecs[i - nmat];
+        const u32 cols = i < nmat ? ncols : 1, t0 = i < nmat ? i * (2 * ncols + 1) : nmat * (2 * ncols + 1) + 3 * (i - nmat);
+        for (u32 j = 0; j < nvars; j++) cch[j] = tr->challenge();
+        const u64 beta = tr->challenge();
+        lfp::PwTab pw;
+        u64 bp = 1;
+        for (int t = 0; t < 16; t++) { pw.p[t] = to_mont(bp); pw.q[t] = to_mont(fmul(bp, bp)); bp = fmul(bp, beta); }
+        lfp::launch_sc_tables(sr.dig, n, cols, pw, tabs[0].as<u64>() + (size_t)t0 * n, n, c->st);
+        lfp::EqPt pt;
+        for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(cch[j]); pt.nc[j] = to_mont(fsub(1, cch[j])); }
+        pt.one = to_mont(1);
+        lfp::launch_eq_build(pt, nvars, tabs[0].as<u64>() + (size_t)(t0 + 2 * cols) * n, c->st);
+        alpha[i] = tr->challenge();
+    }
+    const bool have_rc = nmat > 1;
+    const u64 rc = have_rc ? tr->challenge() : 1;
+    // coef[i][j] = rc^i alpha_i^j (vector set: rc^i alpha_i); without rc the closure returns after the first matrix set (setchk.rs:172-176)
+    std::vector<u64> coef((size_t)(nmat + nvec) * ncols, 0);
+    u64 rcp = 1;
+    for (u32 i = 0; i < nmat + nvec; i++) {
+        u64 ap = i < nmat ? 1 : alpha[i];
+        for (u32 j = 0; j < (i < nmat ? ncols : 1); j++) { coef[(size_t)i * ncols + j] = to_mont(fmul(rcp, ap)); ap = fmul(ap, alpha[i]); }
+        rcp = fmul(rcp, rc);
+    }
+    HIPCHK(c, hipMemcpyAsync(coefd.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, c->st));
+    lfp::ScDesc d = {nmat, ncols, nvec, have_rc ? nmat + nvec : 1};
+    // MLSumcheck::prove_as_subprotocol (latticefold utils/sumcheck.rs:53-80), degree 3
+    tr->absorb_const(nvars);
+    tr->absorb_const(3);
+    std::vector<u64> hpart((size_t)lfp::sc_round_blocks(n / 2) * 4);
+    int cur = 0;
+    size_t len = n;
+    for (u32 rnd = 0; rnd < nvars; rnd++) {
+        const size_t half = len / 2;
+        const u32 nb = lfp::sc_round_blocks(half);
+        lfp::launch_sc_round(tabs[cur].as<u64>(), n, half, d, coefd.as<u64>(), so.part.as<u64>(), c->st);
+        HIPCHK(c, hipMemcpyAsync(hpart.data(), so.part.p, (size_t)nb * 4 * 8, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        u64 *m = msgs + (size_t)rnd * 4 * D;
+        memset(m, 0, 4 * D * 8);
+        for (int x = 0; x < 4; x++) {
+            u64 s = 0;
+            for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 4 + x]);
+            m[x * D] = from_mont(s);
+        }
+        tr->absorb_ring(m, 4);
+        const u64 r = tr->challenge();
+        tr->absorb_const(r);
+        r_out[rnd] = r;
+        if (rnd + 1 < nvars) {   // fix_variables of every table into the other buffer (rows keep the stride n)
+            lfp::launch_sc_fix(tabs[cur].as<u64>(), tabs[cur ^ 1].as<u64>(), n, ntab, half, to_mont(r), c->st);
+            cur ^= 1;
+        }
+        len = half;
+    }
+    // Step 3 (setchk.rs:206-249): the sets at r, M_q * sets at r, the vector sets at r
+    lfp::EqPt pt;
+    for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(r_out[j]); pt.nc[j] = to_mont(fsub(1, r_out[j])); }
+    pt.one = to_mont(1);
+    lfp::launch_eq_build(pt, nvars, so.eqr.as<u64>(), c->st);
+    for (u32 q = 0; q < nM; q++) {
+        std::unique_ptr<DevBuf> w(new DevBuf);
+        if (w->alloc(n * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (M^T eq)");
+        lfp::launch_spmvT_eq(M[q]->colptr.as<u32>(), M[q]->rowidx.as<u32>(), M[q]->val.as<u64>(), so.eqr.as<u64>(), n, w->as<u64>(), c->st);
+        so.w.push_back(std::move(w));
+    }
+    u64 *ed = so.small.as<u64>(), *bd = ed + (size_t)(1 + nM) * nmat * ncols * D;
+    for (u32 i = 0; i < nmat; i++) {
+        lfp::launch_wmono(mats[i].dig, n, ncols, so.eqr.as<u64>(), 1, so.part.as<u64>(), ed + (size_t)i * ncols * D, c->st);
+        for (u32 q = 0; q < nM; q++)
+            lfp::launch_wmono(mats[i].dig, n, ncols, so.w[q]->as<u64>(), 16, so.part.as<u64>(), ed + ((size_t)(1 + q) * nmat + i) * ncols * D, c->st);
+    }
+    for (u32 i = 0; i < nvec; i++) lfp::launch_wmono(vecs[i].dig, n, 1, so.eqr.as<u64>(), 1, so.part.as<u64>(), bd + (size_t)i * D, c->st);
+    HIPCHK(c, hipMemcpyAsync(e_out, ed, (size_t)(1 + nM) * nmat * ncols * D * 8, hipMemcpyDeviceToHost, c->st));
+    if (nvec) HIPCHK(c, hipMemcpyAsync(b_out, bd, (size_t)nvec * D * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    tr->absorb_ring(e_out, (size_t)(1 + nM) * nmat * ncols);   // absorb_evaluations (setchk.rs:342-353)
+    tr->absorb_ring(b_out, nvec);
+    return LFPLUS_OK;
+}
+}  // namespace
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------------------------
+// In::set_check (setchk.rs:65-262) on monomial sets handed over as exponent digits (host arrays; int8 in (-8, 8), LFPLUS_ABSENT = a zero
+// entry): nmat matrices of n x ncols, nvec vectors of n entries, n = 2^nvars.
+extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t nvars, const int8_t *mat_digits, uint32_t nmat, uint32_t ncols,
+                                const int8_t *vec_digits, uint32_t nvec, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col,
+                                const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out) {
+    if (!c || !tr || !mat_digits || !nmat || !ncols || ncols > 64 || nvars < 1 || nvars > 28 || (nvec && !vec_digits) || !r_out || !msgs || !e_out || (nvec && !b_out) ||
+        (nM && (!rowptr || !col || !val)))
+        return fail(c, LFPLUS_E_ARG, "lfplus_set_check: bad arguments");
+    const size_t n = (size_t)1 << nvars;
+    for (size_t i = 0; i < (size_t)nmat * n * ncols + (size_t)nvec * n; i++) {
+        const int8_t d = i < (size_t)nmat * n * ncols ? mat_digits[i] : vec_digits[i - (size_t)nmat * n * ncols];
+        if (d != lfp::LFP_ABSENT && (d <= -8 || d >= 8)) return fail(c, LFPLUS_E_EXP_DOMAIN, "lfplus_set_check: digit outside (-8, 8)");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf dm, dv;
+    if (dm.alloc((size_t)nmat * n * ncols) || dv.alloc((size_t)nvec * n)) return fail(c, LFPLUS_E_HIP, "hipMalloc (sets)");
+    HIPCHK(c, hipMemcpyAsync(dm.p, mat_digits, (size_t)nmat * n * ncols, hipMemcpyHostToDevice, c->st));
+    if (nvec) HIPCHK(c, hipMemcpyAsync(dv.p, vec_digits, (size_t)nvec * n, hipMemcpyHostToDevice, c->st));
+    std::vector<SetRef> mats, vecs;
+    for (u32 i = 0; i < nmat; i++) mats.push_back({dm.as<int8_t>() + (size_t)i * n * ncols, ncols});
+    for (u32 i = 0; i < nvec; i++) vecs.push_back({dv.as<int8_t>() + (size_t)i * n, 1});
+    std::vector<std::unique_ptr<DevCsc>> M;
+    int rc = upload_csc(c, n, nM, rowptr, col, val, M);
+    if (rc) return rc;
+    ScOut so;
+    return set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so);
+}
+
+// Rg::range_check (rgchk.rs:81-186) on L resident instances: ctxs[l] holds the witness f_l and the results of lfplus_rg_from_f (D_f, tau,
+// m_tau) -- all on the same device, same n = 2^nvars and k.  Runs on ctxs[0]'s stream.
+extern "C" int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, uint32_t nM, const uint32_t *const *rowptr,
+                                  const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out,
+                                  uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out) {
+    if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
+    lfplus_ctx *c = ctxs[0];
+    if (!tr || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out || (nM && (!rowptr || !col || !val)))
+        return fail(c, LFPLUS_E_ARG, "lfplus_range_check: bad arguments");
+    const u64 n = c->n;
+    const u32 k = c->k;
+    if (!n || (n & (n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_range_check: n must be a power of two");
+    u32 nvars = 0;
+    while (((u64)1 << nvars) < n) nvars++;
+    for (u32 l = 0; l < L; l++)
+        if (!ctxs[l] || !ctxs[l]->have || ctxs[l]->n != n || ctxs[l]->nf != n || ctxs[l]->k != k || ctxs[l]->device != c->device)
+            return fail(c, LFPLUS_E_ARG, "lfplus_range_check: every instance needs lfplus_rg_from_f results of the same shape on the same device");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (u32 l = 1; l < L; l++) HIPCHK(c, hipStreamSynchronize(ctxs[l]->st));   // their from_f results are read from ctxs[0]'s stream
+    std::vector<SetRef> mats, vecs;   // rgchk.rs:87-96: all instances' M_f matrices, then all instances' m_tau
+    for (u32 l = 0; l < L; l++)
+        for (u32 ki = 0; ki < k; ki++) mats.push_back({ctxs[l]->Df + (size_t)ki * n * 16, 16});
+    for (u32 l = 0; l < L; l++) vecs.push_back({ctxs[l]->mtau, 1});
+    std::vector<std::unique_ptr<DevCsc>> M;
+    int rc = upload_csc(c, n, nM, rowptr, col, val, M);
+    if (rc) return rc;
+    ScOut so;
+    rc = set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so);
+    if (rc) return rc;
+    // evaluations at r (rgchk.rs:107-170): v / c[0] = f at r, a[0] = tau at r, b[0] = the set check's b; per matrix M_q: ct(M_q tau), M_q m_tau, M_q f
+    DevBuf ev;
+    const size_t per = (size_t)(1 + nM) * (1 + 2 * D) + D;   // words per instance: a | bb | c (v = c[0])
+    if (ev.alloc(L * per * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (evaluations)");
+    for (u32 l = 0; l < L; l++) {
+        u64 *ad = ev.as<u64>() + l * per, *bd = ad + (1 + nM), *cd = bd + (size_t)(1 + nM) * D;
+        lfp::launch_wring(ctxs[l]->f, n, so.eqr.as<u64>(), 1, so.part.as<u64>(), cd, c->st);
+        lfp::launch_wdot(so.eqr.as<u64>(), 1, 1, ctxs[l]->tau, n, so.part.as<u64>(), ad, c->st);
+        for (u32 q = 0; q < nM; q++) {
+            lfp::launch_wdot(so.w[q]->as<u64>(), 16, 0, ctxs[l]->tau, n, so.part.as<u64>(), ad + 1 + q, c->st);
+            lfp::launch_wmono(ctxs[l]->mtau, n, 1, so.w[q]->as<u64>(), 16, so.part.as<u64>(), bd + (size_t)(1 + q) * D, c->st);
+            lfp::launch_wring(ctxs[l]->f, n, so.w[q]->as<u64>(), 16, so.part.as<u64>(), cd + (size_t)(1 + q) * D, c->st);
+        }
+    }
+    std::vector<u64> h(L * per);
+    HIPCHK(c, hipMemcpyAsync(h.data(), ev.p, h.size() * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    for (u32 l = 0; l < L; l++) {
+        const u64 *ah = h.data() + l * per, *bh = ah + (1 + nM), *ch = bh + (size_t)(1 + nM) * D;
+        memcpy(a_out + (size_t)l * (1 + nM), ah, (1 + nM) * 8);
+        memcpy(bb_out + (size_t)l * (1 + nM) * D, bh, (size_t)(1 + nM) * D * 8);
+        memcpy(bb_out + (size_t)l * (1 + nM) * D, b_out + (size_t)l * D, D * 8);   // b[0] = out_rel.b[l]
+        memcpy(c_out + (size_t)l * (1 + nM) * D, ch, (size_t)(1 + nM) * D * 8);
+        memcpy(v_out + (size_t)l * D, ch, D * 8);                                    // "v is equal to c[0]" (rgchk.rs:123)
+    }
+    for (u32 l = 0; l < L; l++) {   // absorb_evaluations (rgchk.rs:333-338): a as constants, then c
+        for (u32 i = 0; i < 1 + nM; i++) tr->absorb_const(a_out[(size_t)l * (1 + nM) + i]);
+        tr->absorb_ring(c_out + (size_t)l * (1 + nM) * D, 1 + nM);
+    }
+    return LFPLUS_OK;
+}
+
+// ---- verifiers (host only: no GPU, no context) ------------------------------------------------------------------------------------------
+namespace {
+u64 ev_poly(const u64 *r, u64 x) { u64 acc = 0, pw = 1; for (int i = 0; i < D; i++) { acc = fadd(acc, fmul(r[i] % P, pw)); pw = fmul(pw, x); } return acc; }   // setchk.rs:47-59
+u64 eq_eval(const u64 *x, const u64 *y, u32 nv) {
+    u64 r = 1;
+    for (u32 i = 0; i < nv; i++) { const u64 xy = fmul(x[i], y[i]); r = fmul(r, fadd(fsub(fsub(fadd(xy, xy), x[i]), y[i]), 1)); }
+    return r;
+}
+// ct(psi b) with psi = sum_{0<i<8} i (X^i - X^(16-i)): the element with ct(psi exp(a)) = a for -8 < a < 8 (LatticeFold+ Lemma 2.2)
+u64 ct_psi(const u64 *b) {
+    u64 acc = 0;
+    for (int i = 1; i < D / 2; i++) { acc = fadd(acc, fmul((u64)i, b[i] % P)); acc = fsub(acc, fmul((u64)i, b[D - i] % P)); }
+    return acc;
+}
+// verify_as_subprotocol (latticefold utils/sumcheck.rs:84-104) for constant-polynomial messages
+int sumcheck_verify(lfplus_transcript *tr, u32 nv, u32 deg, const u64 *msgs, u64 *point, u64 *expected) {
+    tr->absorb_const(nv);
+    tr->absorb_const(deg);
+    u64 cur = 0;
+    for (u32 rnd = 0; rnd < nv; rnd++) {
+        const u64 *m = msgs + (size_t)rnd * (deg + 1) * D;
+        tr->absorb_ring(m, deg + 1);
+        const u64 r = tr->challenge();
+        tr->absorb_const(r);
+        point[rnd] = r;
+        u64 y[8];
+        for (u32 x = 0; x <= deg; x++) {
+            for (int cidx = 1; cidx < D; cidx++) if (m[x * D + cidx]) return 2;
+            y[x] = m[x * D] % P;
+        }
+        if (fadd(y[0], y[1]) != cur) return 1;
+        u64 res = 0;   // interpolate_uni_poly (sumcheck/verifier.rs:141-257)
+        for (u32 i = 0; i <= deg; i++) {
+            u64 num = 1, den = 1;
+            for (u32 j = 0; j <= deg; j++) if (j != i) { num = fmul(num, fsub(r, j)); den = fmul(den, fsub(i, j)); }
+            res = fadd(res, fmul(y[i], fmul(num, fpow(den, P - 2))));
+        }
+        cur = res;
+    }
+    *expected = cur;
+    return 0;
+}
+}  // namespace
+
+// Out::verify (setchk.rs:266-340).  LFPLUS_OK = accepted, LFPLUS_E_REJECT with *stage = 1 / 2 (sumcheck), 3 (final evaluation)
+extern "C" int lfplus_set_check_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t nmat, uint32_t ncols, uint32_t nvec, uint32_t nM, const uint64_t *msgs,
+                                       const uint64_t *e, const uint64_t *b, uint64_t *r_out, int *stage) {
+    if (!tr || !nmat || !msgs || !e || (nvec && !b) || !r_out || nvars < 1 || nvars > 32) return LFPLUS_E_ARG;
+    const u32 ncl = nmat + nvec;
+    std::vector<u64> cs((size_t)ncl * nvars), beta(ncl), alpha(ncl);
+    for (u32 i = 0; i < ncl; i++) {
+        for (u32 j = 0; j < nvars; j++) cs[(size_t)i * nvars + j] = tr->challenge();
+        beta[i] = tr->challenge();
+        alpha[i] = tr->challenge();
+    }
+    const u64 rc = nmat > 1 ? tr->challenge() : 1;
+    u64 v;
+    int st = sumcheck_verify(tr, nvars, 3, msgs, r_out, &v);
+    if (!st) {
+        tr->absorb_ring(e, (size_t)(1 + nM) * nmat * ncols);
+        tr->absorb_ring(b, nvec);
+        u64 ver = 0, rcp = 1;
+        for (u32 i = 0; i < nmat; i++) {
+            const u64 eq = eq_eval(&cs[(size_t)i * nvars], r_out, nvars), b2 = fmul(beta[i], beta[i]);
+            u64 sum = 0, ap = 1;
+            for (u32 j = 0; j < ncols; j++) {
+                const u64 *ej = e + ((size_t)i * ncols + j) * D;
+                const u64 e1 = ev_poly(ej, beta[i]), e2 = ev_poly(ej, b2);
+                sum = fadd(sum, fmul(fsub(fmul(e1, e1), e2), ap));
+                ap = fmul(ap, alpha[i]);
+            }
+            ver = fadd(ver, fmul(fmul(eq, sum), rcp));
+            rcp = fmul(rcp, rc);
+        }
+        for (u32 i = 0; i < nvec; i++) {
+            const u32 kk = nmat + i;
+            const u64 eq = eq_eval(&cs[(size_t)kk * nvars], r_out, nvars), b2 = fmul(beta[kk], beta[kk]);
+            const u64 e1 = ev_poly(b + (size_t)i * D, beta[kk]), e2 = ev_poly(b + (size_t)i * D, b2);
+            ver = fadd(ver, fmul(fmul(fmul(eq, alpha[kk]), fsub(fmul(e1, e1), e2)), rcp));
+            rcp = fmul(rcp, rc);
+        }
+        if (ver != v) st = 3;
+    }
+    if (stage) *stage = st;
+    return st ? LFPLUS_E_REJECT : LFPLUS_OK;
+}
+// Dcom::verify (rgchk.rs:193-258): stages 1..3 set check, 4 ct(psi b) != a, 5 ct(psi sum_i d'^i u_i) != v / c
+extern "C" int lfplus_range_check_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t L, uint32_t k, uint32_t nM, const uint64_t *msgs, const uint64_t *e,
+                                         const uint64_t *b, const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *cc, uint64_t *r_out, int *stage) {
+    if (!tr || !L || !k || !msgs || !e || !b || !v || !a || !bb || !cc || !r_out) return LFPLUS_E_ARG;
+    int st = 0;
+    int rc = lfplus_set_check_verify(tr, nvars, L * k, D, L, nM, msgs, e, b, r_out, &st);
+    if (rc == LFPLUS_E_ARG) return rc;
+    if (!st) {
+        for (u32 l = 0; l < L; l++) {
+            for (u32 i = 0; i < 1 + nM; i++) tr->absorb_const(a[(size_t)l * (1 + nM) + i]);
+            tr->absorb_ring(cc + (size_t)l * (1 + nM) * D, 1 + nM);
+        }
+        for (u32 l = 0; l < L && !st; l++) {
+            for (u32 i = 0; i < 1 + nM && !st; i++)
+                if (ct_psi(bb + ((size_t)l * (1 + nM) + i) * D) != a[(size_t)l * (1 + nM) + i] % P) st = 4;
+            for (u32 ni = 0; ni < 1 + nM && !st; ni++)
+                for (u32 t = 0; t < (u32)D && !st; t++) {
+                    u64 uc[D] = {0}, pw = 1;
+                    for (u32 i = 0; i < k; i++) {
+                        const u64 *u = e + ((((size_t)ni * L * k) + (size_t)k * l + i) * D + t) * D;
+                        for (int x = 0; x < D; x++) uc[x] = fadd(uc[x], fmul(u[x] % P, pw));
+                        pw = fmul(pw, D / 2);
+                    }
+                    const u64 want = ni == 0 ? v[(size_t)l * D + t] : cc[((size_t)l * (1 + nM) + ni) * D + t];
+                    if (ct_psi(uc) != want % P) st = 5;
+                }
+        }
+    }
+    if (stage) *stage = st;
+    return st ? LFPLUS_E_REJECT : LFPLUS_OK;
+}

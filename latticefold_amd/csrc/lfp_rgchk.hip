@@ -1,0 +1,226 @@
+// lfp_rgchk.hip -- gfx950 kernels of the LatticeFold+ monomial set check and range check on the Frog ring (coefficient form):
+//   In::set_check   crates/latticefold-plus/src/setchk.rs:65-262     Rg::range_check   src/rgchk.rs:81-186
+//
+// The coefficient ring's challenges are single F_p words, so the set-check sumcheck runs on tables of F_p words (ev(m, beta) of a unit
+// monomial X^e is beta^e: a 16-entry look-up; its square beta^2e another), kept in Montgomery form.  The evaluations of Step 3 -- multilinear
+// extensions of columns of monomials at the sumcheck point -- are sums of eq(r, row) binned by exponent: out[t] = sum over the rows with
+// exponent t (scalar weights), or sums of negacyclic rotations of ring weights (the M_i f rows: weights M_i^T eq).  Monomial sets cross
+// every interface as int8 exponent digits d in (-8, 8) (exp(d) = X^d, X^(16+d) for d < 0; lfplus.h); LFP_ABSENT marks a zero entry.
+// HBM-bound integer work; no MFMA.
+#include "lfp_kernels.h"
+#include "lfp_field.cuh"
+
+namespace lfp {
+static inline size_t cdiv(size_t a, size_t b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int exp_of(int8_t d) { return d >= 0 ? d : 16 + d; }
+
+// ---- tables of the sumcheck ----------------------------------------------------------------------------------------------------------
+// tab[2 col][row] = beta^e, tab[2 col + 1][row] = beta^(2e) (Montgomery), e the exponent of dig[row][col]; 0 for an absent entry
+__global__ void __launch_bounds__(256) k_sc_tables(const int8_t *dig, size_t n, u32 ncols, PwTab pw, u64 *tab, size_t ld) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * ncols) return;
+    const size_t row = i / ncols;
+    const u32 col = (u32)(i % ncols);
+    const int8_t d = dig[i];
+    u64 m = 0, q = 0;
+    if (d != LFP_ABSENT) {
+        const int e = exp_of(d);
+#pragma unroll
+        for (int t = 0; t < 16; t++) { m = e == t ? pw.p[t] : m; q = e == t ? pw.q[t] : q; }
+    }
+    tab[(size_t)(2 * col) * ld + row] = m;
+    tab[(size_t)(2 * col + 1) * ld + row] = q;
+}
+void launch_sc_tables(const int8_t *dig, size_t n, u32 ncols, const PwTab &pw, u64 *tab, size_t ld, hipStream_t s) {
+    hipLaunchKernelGGL(k_sc_tables, dim3((unsigned)cdiv(n * ncols, 256)), dim3(256), 0, s, dig, n, ncols, pw, tab, ld);
+}
+// eq[i] = prod_j (bit_j(i) ? c_j : 1 - c_j) (Montgomery; bit 0 <-> c[0]: build_eq_x_r)
+__global__ void __launch_bounds__(256) k_eq_build(EqPt pt, u32 nv, size_t n, u64 *eq) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u64 v = pt.one;
+    for (u32 j = 0; j < nv; j++) v = mont_mul(v, (i >> j) & 1 ? pt.c[j] : pt.nc[j]);
+    eq[i] = v;
+}
+void launch_eq_build(const EqPt &pt, u32 nv, u64 *eq, hipStream_t s) {
+    const size_t n = (size_t)1 << nv;
+    hipLaunchKernelGGL(k_eq_build, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, pt, nv, n, eq);
+}
+
+// sum over the block of four words per thread -> part[block][4] (mod p)
+__device__ __forceinline__ void block_sum4(u64 s[4], u64 *out) {
+    __shared__ u64 sm[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+        for (int o = 32; o; o >>= 1) s[x] = add_p(s[x], __shfl_xor(s[x], o));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int x = 0; x < 4; x++) sm[wave][x] = s[x];
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = add_p(add_p(sm[0][threadIdx.x], sm[1][threadIdx.x]), add_p(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+}
+// One round of the set-check sumcheck (prove_round, sumcheck/prover.rs:56-162, with the comb_fn of setchk.rs:160-197): for every pair of
+// entries the degree-3 round polynomial at X = 0..3,
+//     sum over the sets i entering the polynomial of  eq_i(X) * sum_j coef[i][j] (m_ij(X)^2 - m'_ij(X)),
+// coef[i][j] = rc^i alpha_i^j (a vector set: rc^i alpha_i).  part[block][4], Montgomery.
+__global__ void __launch_bounds__(256) k_sc_round(const u64 *tab, size_t ld, size_t half, ScDesc d, const u64 *coef, u64 *part) {
+    u64 s[4] = {0, 0, 0, 0};
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < half; b += (size_t)gridDim.x * 256) {
+        for (u32 i = 0; i < d.nsets_eff; i++) {
+            const u32 cols = i < d.nmat ? d.ncols : 1;
+            const u32 t0 = i < d.nmat ? i * (2 * d.ncols + 1) : d.nmat * (2 * d.ncols + 1) + 3 * (i - d.nmat);
+            u64 in[4] = {0, 0, 0, 0};
+            for (u32 j = 0; j < cols; j++) {
+                const u64 *tm = tab + (size_t)(t0 + 2 * j) * ld + 2 * b, *tq = tm + ld;
+                u64 m = tm[0], q = tq[0];
+                const u64 dm = sub_p(tm[1], m), dq = sub_p(tq[1], q), cf = coef[(size_t)i * d.ncols + j];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    in[x] = add_p(in[x], mont_mul(cf, sub_p(mont_mul(m, m), q)));
+                    m = add_p(m, dm);
+                    q = add_p(q, dq);
+                }
+            }
+            const u64 *te = tab + (size_t)(t0 + 2 * cols) * ld + 2 * b;
+            u64 e = te[0];
+            const u64 de = sub_p(te[1], e);
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                s[x] = add_p(s[x], mont_mul(e, in[x]));
+                e = add_p(e, de);
+            }
+        }
+    }
+    block_sum4(s, part + (size_t)blockIdx.x * 4);
+}
+u32 sc_round_blocks(size_t half) { size_t b = cdiv(half, 256); return (u32)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+void launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part, hipStream_t s) {
+    hipLaunchKernelGGL(k_sc_round, dim3(sc_round_blocks(half)), dim3(256), 0, s, tab, ld, half, d, coef, part);
+}
+// fix_variables of all tables: out[t][b] = in[t][2b] + r (in[t][2b+1] - in[t][2b])
+__global__ void __launch_bounds__(256) k_sc_fix(const u64 *in, u64 *out, size_t ld, size_t half, u64 rM) {
+    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= half) return;
+    const u64 *p = in + (size_t)blockIdx.y * ld + 2 * b;
+    const u64 lo = p[0], hi = p[1];
+    out[(size_t)blockIdx.y * ld + b] = add_p(lo, mont_mul(rM, sub_p(hi, lo)));
+}
+void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u64 rM, hipStream_t s) {
+    hipLaunchKernelGGL(k_sc_fix, dim3((unsigned)cdiv(half, 256), ntab), dim3(256), 0, s, in, out, ld, half, rM);
+}
+
+// ---- evaluations ---------------------------------------------------------------------------------------------------------------------
+// sum over the block of sixteen words per thread -> out[16]
+__device__ __forceinline__ void block_sum16(u64 acc[16], u64 *out) {
+    __shared__ u64 sm[4][16];
+#pragma unroll
+    for (int t = 0; t < 16; t++)
+        for (int o = 32; o; o >>= 1) acc[t] = add_p(acc[t], __shfl_xor(acc[t], o));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int t = 0; t < 16; t++) sm[wave][t] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 16) out[threadIdx.x] = add_p(add_p(sm[0][threadIdx.x], sm[1][threadIdx.x]), add_p(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+}
+// part[chunk][col][16] = sum over the chunk's rows of w[row] * X^e(dig[row][col]).  wstride 1: scalar weights (constant polynomials);
+// 16: ring weights -- coefficient t of w X^e is w[t - e] (t >= e), -w[t - e + 16] (t < e).  grid (chunks, ncols)
+__global__ void __launch_bounds__(256) k_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part) {
+    const u32 col = blockIdx.y;
+    u64 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) acc[t] = 0;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (size_t)gridDim.x * 256) {
+        const int8_t d = dig[row * ncols + col];
+        if (d == LFP_ABSENT) continue;
+        const int e = exp_of(d);
+        if (wstride == 1) {
+            const u64 v = w[row];
+#pragma unroll
+            for (int t = 0; t < 16; t++) acc[t] = add_p(acc[t], e == t ? v : 0);
+        } else {
+            const u64 *wr = w + row * 16;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const u64 v = wr[(t - e) & 15];
+                acc[t] = t >= e ? add_p(acc[t], v) : sub_p(acc[t], v);
+            }
+        }
+    }
+    block_sum16(acc, part + ((size_t)blockIdx.x * ncols + col) * 16);
+}
+// part[chunk][16] = sum over the chunk's rows of w[row] * f[row] (f: n ring elements, canonical).  wstride 1: scalar weights in Montgomery
+// form (eq tables); 16: ring weights, canonical (negacyclic products)
+__global__ void __launch_bounds__(256) k_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part) {
+    u64 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) acc[t] = 0;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (size_t)gridDim.x * 256) {
+        const u64 *fr = f + row * 16;
+        if (wstride == 1) {
+            const u64 v = w[row];
+#pragma unroll
+            for (int t = 0; t < 16; t++) acc[t] = add_p(acc[t], mont_mul(v, fr[t]));
+        } else {
+            const u64 *wr = w + row * 16;
+            for (int i = 0; i < 16; i++) {
+                const u64 wi = to_mont(wr[i]);
+                if (wi == 0) continue;
+#pragma unroll
+                for (int t = 0; t < 16; t++) {      // X^i * f: coefficient t gets f[t - i] (t >= i), -f[t - i + 16]
+                    const u64 pr = mont_mul(wi, fr[(t - i) & 15]);
+                    acc[t] = t >= i ? add_p(acc[t], pr) : sub_p(acc[t], pr);
+                }
+            }
+        }
+    }
+    block_sum16(acc, part + (size_t)blockIdx.x * 16);
+}
+// part[chunk] = sum of x[i * xstride] * y[i]; x Montgomery (x_mont) or canonical, y canonical: canonical sum
+__global__ void __launch_bounds__(256) k_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part) {
+    u64 s[4] = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const u64 xv = x[i * xstride];
+        s[0] = add_p(s[0], mont_mul(x_mont ? xv : to_mont(xv), y[i]));
+    }
+    block_sum4(s, part + (size_t)blockIdx.x * 4);
+}
+// out[o] = sum over chunks of part[chunk * stride + o] (o < nout), optionally taken out of Montgomery form
+__global__ void __launch_bounds__(256) k_sum_parts(const u64 *part, u32 chunks, size_t stride, u32 nout, int out_of_mont, u64 *out) {
+    const u32 o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= nout) return;
+    u64 s = 0;
+    for (u32 ch = 0; ch < chunks; ch++) s = add_p(s, part[(size_t)ch * stride + o]);
+    out[o] = out_of_mont ? from_mont(s) : s;
+}
+u32 eval_chunks(size_t n) { size_t b = cdiv(n, 256 * 8); return (u32)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
+void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
+    const u32 ch = eval_chunks(n);
+    hipLaunchKernelGGL(k_wmono, dim3(ch, ncols), dim3(256), 0, s, dig, n, ncols, w, wstride, part);
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)ncols * 16, 256)), dim3(256), 0, s, part, ch, (size_t)ncols * 16, ncols * 16, wstride == 1, out);
+}
+void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
+    const u32 ch = eval_chunks(n);
+    hipLaunchKernelGGL(k_wring, dim3(ch), dim3(256), 0, s, f, n, w, wstride, part);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, s, part, ch, (size_t)16, 16u, 0, out);
+}
+void launch_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part, u64 *out, hipStream_t s) {
+    const u32 ch = eval_chunks(n);
+    hipLaunchKernelGGL(k_wdot, dim3(ch), dim3(256), 0, s, x, xstride, x_mont, y, n, part);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, s, part, ch, (size_t)4, 1u, 0, out);
+}
+// w[c] = sum over the non-zeros (row, c) of M of M[row][c] * eq[row]: the transposed matrix in CSR form (colptr over c, rowidx, values
+// canonical), eq in Montgomery form -> w canonical ring elements.  thread = (c, coefficient)
+__global__ void __launch_bounds__(256) k_spmvT_eq(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 16) return;
+    const size_t c = i >> 4;
+    const u32 t = (u32)(i & 15);
+    u64 s = 0;
+    for (u32 k = colptr[c]; k < colptr[c + 1]; k++) s = add_p(s, mont_mul(eq[rowidx[k]], val[(size_t)k * 16 + t]));
+    w[i] = s;
+}
+void launch_spmvT_eq(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s) {
+    hipLaunchKernelGGL(k_spmvT_eq, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, s, colptr, rowidx, val, eq, n, w);
+}
+// tau (n canonical words) as n ring constants is never materialised: the M_i tau row needs sum_c w[c][0] tau[c] only (the constant term)
+}  // namespace lfp

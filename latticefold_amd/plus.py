@@ -26,7 +26,8 @@ class LfPlusError(RuntimeError):
         super().__init__(f"liblfhip (lfplus): {msg} ({code})")
 
 
-E_ARG, E_NO_DEVICE, E_HIP, E_EXP_DOMAIN, E_SMALL_N = -1, -2, -3, -4, -5
+E_ARG, E_NO_DEVICE, E_HIP, E_EXP_DOMAIN, E_SMALL_N, E_REJECT = -1, -2, -3, -4, -5, -6
+ABSENT = -128     # exponent digit of a zero entry of a monomial set (lfplus.h LFPLUS_ABSENT)
 
 
 def exported_symbols():
@@ -56,6 +57,21 @@ def _lib():
         L.lfplus_decompose.argtypes = [vp, C.c_uint64, u64p, u64p, C.c_uint32, u32pp, u32pp, u64pp, u64p, u64p, u64p, u64p, u64p, u64p]
         L.lfplus_tensor.argtypes = [vp, u64p, C.c_uint32, u64p]
         L.lfplus_tensor_product.argtypes = [vp, u64p, C.c_uint64, u64p, C.c_uint64, u64p]
+        u8p, vpp, ip = C.POINTER(C.c_uint8), C.POINTER(vp), C.POINTER(C.c_int)
+        L.lfplus_transcript_new.restype = vp
+        L.lfplus_transcript_clone.restype = vp
+        L.lfplus_transcript_clone.argtypes = [vp]
+        L.lfplus_transcript_free.argtypes = [vp]
+        L.lfplus_transcript_free.restype = None
+        L.lfplus_transcript_absorb.argtypes = [vp, u64p, C.c_size_t]
+        L.lfplus_transcript_challenge.argtypes = [vp, u64p]
+        L.lfplus_transcript_squeeze_bytes.argtypes = [vp, C.c_size_t, u8p]
+        L.lfplus_short_challenge.argtypes = [vp, u64p]
+        L.lfplus_poseidon_params.argtypes = [u64p, u64p]
+        L.lfplus_set_check.argtypes = [vp, vp, C.c_uint32, i8p, C.c_uint32, C.c_uint32, i8p, C.c_uint32, C.c_uint32, u32pp, u32pp, u64pp, u64p, u64p, u64p, u64p]
+        L.lfplus_set_check_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p, u64p, u64p, ip]
+        L.lfplus_range_check.argtypes = [vpp, C.c_uint32, vp, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 8
+        L.lfplus_range_check_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32] + [u64p] * 8 + [ip]
         _READY = True
     return L
 
@@ -179,6 +195,7 @@ class RgInstance:
             ctx.set_matrix(A)
         ctx.set_witness(f)
         ctx._chk(_lib().lfplus_rg_from_f(ctx.h, dparams.b, dparams.k, dparams.l))
+        ctx._k = dparams.k
         k, n, kappa = dparams.k, ctx.n, ctx.kappa
         Df = np.zeros((k, n, D), dtype=np.int8)
         com = np.zeros((k, kappa, D, D), dtype=np.uint64)
@@ -202,3 +219,110 @@ def exp(digits):
     out = np.zeros(dg.shape + (D,), dtype=np.uint64)
     np.put_along_axis(out, np.where(dg >= 0, dg, D + dg)[..., None], 1, axis=-1)
     return out
+
+
+# ---- the transcript-driven part (src/transcript.rs, setchk.rs, rgchk.rs:81-258) ------------------------------------------------------------
+def _csr_args(mats):
+    """mats: list of (rowptr uint32 [n+1], col uint32 [nnz], val uint64 [nnz][16])"""
+    keep = [(np.ascontiguousarray(r, dtype=np.uint32), np.ascontiguousarray(c, dtype=np.uint32), np.ascontiguousarray(v, dtype=np.uint64)) for r, c, v in mats]
+    u32p = C.POINTER(C.c_uint32)
+    n = max(1, len(keep))
+    return keep, (u32p * n)(*[k[0].ctypes.data_as(u32p) for k in keep]), (u32p * n)(*[k[1].ctypes.data_as(u32p) for k in keep]), \
+        (u64p * n)(*[k[2].ctypes.data_as(u64p) for k in keep])
+
+
+class PoseidonTranscript:
+    """PoseidonTranscript::<RqPoly>::empty::<FrogPoseidonConfig>() (src/transcript.rs:20-78); host object, no GPU needed"""
+
+    def __init__(self, h=None):
+        self.h = h if h is not None else _lib().lfplus_transcript_new()
+
+    def clone(self):
+        return PoseidonTranscript(_lib().lfplus_transcript_clone(self.h))
+
+    def absorb(self, ring):
+        a = np.ascontiguousarray(ring, dtype=np.uint64).reshape(-1, D)
+        _lib().lfplus_transcript_absorb(self.h, a.ctypes.data_as(u64p), a.shape[0])
+
+    def get_challenge(self):
+        o = C.c_uint64()
+        _lib().lfplus_transcript_challenge(self.h, C.byref(o))
+        return o.value
+
+    def squeeze_bytes(self, n):
+        o = np.zeros(n, dtype=np.uint8)
+        _lib().lfplus_transcript_squeeze_bytes(self.h, n, o.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return o
+
+    def short_challenge(self):
+        """utils::short_challenge(128, transcript) (src/utils.rs:87-101)"""
+        o = np.zeros(D, dtype=np.uint64)
+        _lib().lfplus_short_challenge(self.h, o.ctypes.data_as(u64p))
+        return o
+
+    def __del__(self):
+        try:
+            _lib().lfplus_transcript_free(self.h)
+        except Exception:
+            pass
+
+
+def poseidon_params():
+    ark, mds = np.zeros(720, dtype=np.uint64), np.zeros(576, dtype=np.uint64)
+    _lib().lfplus_poseidon_params(ark.ctypes.data_as(u64p), mds.ctypes.data_as(u64p))
+    return ark, mds
+
+
+def set_check(ctx, transcript, nvars, mat_digits, vec_digits=None, M=()):
+    """In::set_check (src/setchk.rs:65-262).  mat_digits (nmat, n, ncols) / vec_digits (nvec, n): exponent digits (int8; ABSENT = zero entry)
+    -> dict(r, msgs (nvars, 4, 16), e (1 + len(M), nmat, ncols, 16), b (nvec, 16))"""
+    md = np.ascontiguousarray(mat_digits, dtype=np.int8)
+    nmat, n, ncols = md.shape
+    vd = np.zeros((0, n), dtype=np.int8) if vec_digits is None else np.ascontiguousarray(vec_digits, dtype=np.int8)
+    nvec, nM = vd.shape[0], len(M)
+    keep, rp, cp, vp = _csr_args(M)
+    r, msgs = np.zeros(nvars, dtype=np.uint64), np.zeros((nvars, 4, D), dtype=np.uint64)
+    e, b = np.zeros((1 + nM, nmat, ncols, D), dtype=np.uint64), np.zeros((max(nvec, 1), D), dtype=np.uint64)
+    ctx._chk(_lib().lfplus_set_check(ctx.h, transcript.h, nvars, md.ctypes.data_as(i8p), nmat, ncols, vd.ctypes.data_as(i8p) if nvec else None, nvec, nM, rp, cp, vp,
+                                     r.ctypes.data_as(u64p), msgs.ctypes.data_as(u64p), e.ctypes.data_as(u64p), b.ctypes.data_as(u64p)))
+    return {"r": r, "msgs": msgs, "e": e, "b": b[:nvec]}
+
+
+def set_check_verify(transcript, nvars, out, nM=0):
+    """Out::verify (src/setchk.rs:266-340) on the host -> (accepted, stage, r)"""
+    e, b, msgs = (np.ascontiguousarray(out[k], dtype=np.uint64) for k in ("e", "b", "msgs"))
+    nmat, ncols, nvec = e.shape[1], e.shape[2], b.shape[0]
+    bb = b if nvec else np.zeros((1, D), dtype=np.uint64)
+    r, st = np.zeros(nvars, dtype=np.uint64), C.c_int()
+    rc = _lib().lfplus_set_check_verify(transcript.h, nvars, nmat, ncols, nvec, nM, msgs.ctypes.data_as(u64p), e.ctypes.data_as(u64p), bb.ctypes.data_as(u64p),
+                                        r.ctypes.data_as(u64p), C.byref(st))
+    if rc not in (0, E_REJECT):
+        raise LfPlusError(rc, "lfplus_set_check_verify")
+    return rc == 0, st.value, r
+
+
+def range_check(ctxs, transcript, M=()):
+    """Rg::range_check (src/rgchk.rs:81-186) over the resident RgInstances of `ctxs` (each after RgInstance.from_f) -> dict of the Dcom fields"""
+    L, nM, c0 = len(ctxs), len(M), ctxs[0]
+    n, k = c0.n, c0._k
+    nvars = n.bit_length() - 1
+    keep, rp, cp, vp = _csr_args(M)
+    hs = (C.c_void_p * L)(*[c.h for c in ctxs])
+    r, msgs = np.zeros(nvars, dtype=np.uint64), np.zeros((nvars, 4, D), dtype=np.uint64)
+    e, b = np.zeros((1 + nM, L * k, D, D), dtype=np.uint64), np.zeros((L, D), dtype=np.uint64)
+    v, a = np.zeros((L, D), dtype=np.uint64), np.zeros((L, 1 + nM), dtype=np.uint64)
+    bb, c = np.zeros((L, 1 + nM, D), dtype=np.uint64), np.zeros((L, 1 + nM, D), dtype=np.uint64)
+    c0._chk(_lib().lfplus_range_check(hs, L, transcript.h, nM, rp, cp, vp, *[x.ctypes.data_as(u64p) for x in (r, msgs, e, b, v, a, bb, c)]))
+    return {"r": r, "msgs": msgs, "e": e, "b": b, "v": v, "a": a, "bb": bb, "c": c, "k": k, "nvars": nvars}
+
+
+def range_check_verify(transcript, d):
+    """Dcom::verify (src/rgchk.rs:193-258) on the host -> (accepted, stage, r)"""
+    arr = {key: np.ascontiguousarray(d[key], dtype=np.uint64) for key in ("msgs", "e", "b", "v", "a", "bb", "c")}
+    L, nM = arr["b"].shape[0], arr["a"].shape[1] - 1
+    r, st = np.zeros(d["nvars"], dtype=np.uint64), C.c_int()
+    rc = _lib().lfplus_range_check_verify(transcript.h, d["nvars"], L, d["k"], nM, *[arr[key].ctypes.data_as(u64p) for key in ("msgs", "e", "b", "v", "a", "bb", "c")],
+                                          r.ctypes.data_as(u64p), C.byref(st))
+    if rc not in (0, E_REJECT):
+        raise LfPlusError(rc, "lfplus_range_check_verify")
+    return rc == 0, st.value, r

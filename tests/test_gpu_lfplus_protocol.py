@@ -1,0 +1,111 @@
+"""LatticeFold+ monomial set check and range check on the GPU (lfplus_set_check, lfplus_range_check; src/setchk.rs:65-262, src/rgchk.rs:81-186)
+against the oracle (oracle/lfp_protocol.c), word for word: sumcheck messages, the point, every evaluation; the transcripts end in the same
+state; the product's host verifier and the oracle's verifier accept the GPU proofs."""
+import numpy as np
+import pytest
+
+import lfp
+from latticefold_amd import plus
+
+pytestmark = pytest.mark.gpu
+P, D = plus.P, plus.D
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = plus.PlusContext(0)
+    yield c
+    c.close()
+
+
+def _ident(n, first=None):
+    rowptr, col = np.arange(n + 1, dtype=np.uint32), np.arange(n, dtype=np.uint32)
+    val = np.zeros((n, D), dtype=np.uint64)
+    val[:, 0] = 1
+    if first is not None:
+        val[0, 0] = first
+    return rowptr, col, val
+
+
+def _rand_csr(n, seed, per_row=2):
+    rng = np.random.default_rng(seed)
+    rowptr = np.arange(0, per_row * n + 1, per_row, dtype=np.uint32)
+    col = rng.integers(0, n, size=per_row * n).astype(np.uint32)
+    val = lfp.splitmix(seed, 0, per_row * n * D).reshape(-1, D)
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("nvars,nmat,ncols,nvec,nM", [(2, 1, 4, 0, 0), (2, 2, 4, 0, 0), (3, 2, 4, 2, 0), (5, 1, 16, 1, 1), (10, 3, 16, 2, 2), (13, 2, 16, 1, 1)])
+def test_set_check_matches_oracle(ctx, nvars, nmat, ncols, nvec, nM):
+    """shapes of setchk.rs:355-495 (one / batched / mixed sets) and of the range check (16 columns, vectors, M_i rows); random exponents,
+    a few absent entries (identity-like sparse sets)"""
+    n = 1 << nvars
+    rng = np.random.default_rng(nvars * 100 + nmat)
+    dig = rng.integers(-7, 8, size=(nmat, n, ncols)).astype(np.int8)
+    dense = lfp.exp_dense(dig)
+    if nvars <= 3:                        # sparse sets: absent entries are zero ring elements
+        mask = rng.random(dig.shape) < 0.4
+        dig[mask] = plus.ABSENT
+        dense[mask] = 0
+    vdig = rng.integers(-7, 8, size=(nvec, n)).astype(np.int8) if nvec else None
+    mats = [_ident(n, first=5)] + [_rand_csr(n, 7 + q) for q in range(1, nM)] if nM else []
+    to, tp = lfp.Transcript(), plus.PoseidonTranscript()
+    want = lfp.set_check(to, nvars, dense, lfp.exp_dense(vdig) if nvec else None, mats)
+    got = plus.set_check(ctx, tp, nvars, dig, vdig, mats)
+    for key in ("msgs", "r", "e", "b"):
+        assert (got[key] == want[key]).all(), key
+    assert tp.get_challenge() == to.challenge()            # the transcripts end in the same state
+    ok, stage, r = plus.set_check_verify(plus.PoseidonTranscript(), nvars, got, nM=nM)
+    assert ok and (r == got["r"]).all()
+    assert lfp.set_check_verify(lfp.Transcript(), nvars, got, nM=nM)[0] == 0
+
+
+def _witness(n, seed):
+    v = (lfp.splitmix(seed, 0, n * D) % np.uint64(63)).astype(np.int64) - 31
+    return np.where(v < 0, np.uint64(P) - (-v).astype(np.uint64), v.astype(np.uint64)).reshape(n, D)
+
+
+@pytest.mark.parametrize("L,nM,nvars", [(1, 0, 14), (1, 1, 14), (2, 1, 14), (1, 1, 15)])
+def test_range_check_matches_oracle(L, nM, nvars):
+    """rgchk.rs:340-433 (test_range_check: n = 2^15, kappa 1, k 2; test_range_check_mm: one matrix) and two instances as Mlin::mlin builds them:
+    RgInstance::from_f on the GPU, then the range check on the resident instances"""
+    n, kappa, k = 1 << nvars, 1, 2
+    dp = plus.DecompParameters.for_frog(k)
+    A = lfp.splitmix(1, 0, kappa * n * D).reshape(kappa, n, D)
+    ctxs, insts = [], []
+    try:
+        for l in range(L):
+            f = _witness(n, 20 + l)
+            c = plus.PlusContext(0)
+            rg = plus.RgInstance.from_f(c, f, A, dp)
+            ctxs.append(c)
+            insts.append({"Mf": lfp.exp_dense(rg.D_f), "tau": rg.tau, "mtau": lfp.exp_dense(rg.m_tau), "f": f})
+        mats = [_ident(n, first=2)] * nM
+        to, tp = lfp.Transcript(), plus.PoseidonTranscript()
+        want = lfp.range_check(to, nvars, insts, k, mats)
+        got = plus.range_check(ctxs, tp, mats)
+        for key in ("msgs", "r", "e", "b", "v", "a", "bb", "c"):
+            assert (got[key] == want[key]).all(), key
+        assert tp.get_challenge() == to.challenge()
+        ok, stage, r = plus.range_check_verify(plus.PoseidonTranscript(), got)
+        assert ok and stage == 0
+        assert lfp.range_check_verify(lfp.Transcript(), nvars, got, k)[0] == 0
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_argument_errors(ctx):
+    tp = plus.PoseidonTranscript()
+    dig = np.zeros((1, 4, 4), dtype=np.int8)
+    dig[0, 0, 0] = 8                      # outside (-8, 8): the reference's exp() returns None
+    with pytest.raises(plus.LfPlusError) as e:
+        plus.set_check(ctx, tp, 2, dig)
+    assert e.value.code == plus.E_EXP_DOMAIN
+    c2 = plus.PlusContext(0)
+    try:
+        with pytest.raises(plus.LfPlusError) as e:
+            plus.range_check([c2], tp) if setattr(c2, "_k", 2) is None else None
+        assert e.value.code == plus.E_ARG  # no resident RgInstance
+    finally:
+        c2.close()

@@ -1,0 +1,93 @@
+"""Host-only part of the LatticeFold+ slice of liblfhip.so (no GPU needed): the Frog PoseidonTranscript and the set-check / range-check
+VERIFIERS, against the reference-held KATs and against the oracle (oracle/lfp_protocol.c): the product's transcript produces the oracle's
+challenges, and the product's verifiers accept the oracle's proofs and reject tampered ones at the stage the oracle reports."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lfp
+from latticefold_amd import plus
+
+KATS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kats.json")))
+P, D = plus.P, plus.D
+
+
+def test_exported_symbols_include_the_protocol_slice():
+    lib = plus._lib()
+    for s in ("lfplus_transcript_new", "lfplus_set_check", "lfplus_set_check_verify", "lfplus_range_check", "lfplus_range_check_verify", "lfplus_short_challenge"):
+        assert s in plus.exported_symbols() and hasattr(lib, s)
+
+
+def test_product_poseidon_table_matches_reference_checksums():
+    k = KATS["poseidon_frog_params"]
+    ark, mds = plus.poseidon_params()
+    assert sum((i + 1) * int(v) for i, v in enumerate(ark)) % P == k["ark_checksum"]
+    assert sum((i + 1) * int(v) for i, v in enumerate(mds)) % P == k["mds_checksum"]
+    assert [int(x) for x in ark[:4]] == k["ark_first"]
+
+
+def test_transcript_equals_oracle_on_random_scripts():
+    rng = np.random.default_rng(3)
+    tp, to = plus.PoseidonTranscript(), lfp.Transcript()
+    for step in range(60):
+        op = rng.integers(0, 4)
+        if op == 0:
+            x = lfp.splitmix(100 + step, 0, int(rng.integers(1, 4)) * D).reshape(-1, D)
+            tp.absorb(x); to.absorb(x)
+        elif op == 1:
+            assert tp.get_challenge() == to.challenge()
+        elif op == 2:
+            n = int(rng.integers(1, 40))
+            assert (tp.squeeze_bytes(n) == to.squeeze_bytes(n)).all()
+        else:
+            assert (tp.short_challenge() == to.short_challenge()).all()
+    assert tp.clone().get_challenge() == to.clone().challenge()
+
+
+def _ident(n, first=None):
+    rowptr, col = np.arange(n + 1, dtype=np.uint32), np.arange(n, dtype=np.uint32)
+    val = np.zeros((n, D), dtype=np.uint64)
+    val[:, 0] = 1
+    if first is not None:
+        val[0, 0] = first
+    return rowptr, col, val
+
+
+def test_set_check_verifier_accepts_oracle_proofs_and_rejects_tampering():
+    n, nvars = 8, 3
+    rng = np.random.default_rng(1)
+    dig = rng.integers(-7, 8, size=(2, n, 4)).astype(np.int8)
+    vdig = rng.integers(-7, 8, size=(1, n)).astype(np.int8)
+    mats = [_ident(n, first=3)]
+    out = lfp.set_check(lfp.Transcript(), nvars, lfp.exp_dense(dig), lfp.exp_dense(vdig), mats)
+    ok, stage, r = plus.set_check_verify(plus.PoseidonTranscript(), nvars, out, nM=1)
+    assert ok and stage == 0 and (r == out["r"]).all()
+    for key, idx in (("e", (0, 1, 2, 5)), ("b", (0, 3)), ("msgs", (1, 2, 0)), ("msgs", (0, 0, 4))):
+        t = {k: v.copy() for k, v in out.items()}
+        t[key][idx] = (int(t[key][idx]) + 1) % P
+        ok_p, st_p, _ = plus.set_check_verify(plus.PoseidonTranscript(), nvars, t, nM=1)
+        rc_o, _ = lfp.set_check_verify(lfp.Transcript(), nvars, t, nM=1)
+        assert not ok_p and st_p == -rc_o, (key, st_p, rc_o)
+
+
+def test_range_check_verifier_accepts_oracle_proofs_and_rejects_tampering():
+    n, nvars, kappa, k = 1 << 14, 14, 1, 2
+    A = lfp.splitmix(5, 0, kappa * n * D).reshape(kappa, n, D)
+    v = (lfp.splitmix(6, 0, n * D) % np.uint64(63)).astype(np.int64) - 31
+    f = np.where(v < 0, np.uint64(P) - (-v).astype(np.uint64), v.astype(np.uint64)).reshape(n, D)
+    rg = lfp.rg_from_f(f, A, D // 2, k, 22)
+    tau_i = np.array([int(t) if int(t) <= P // 2 else int(t) - P for t in rg["tau"]], dtype=np.int8)
+    inst = {"Mf": lfp.exp_dense(rg["Df"]), "tau": rg["tau"], "mtau": lfp.exp_dense(tau_i), "f": f}
+    d = lfp.range_check(lfp.Transcript(), nvars, [inst], k, [_ident(n, first=2)])
+    d.update(k=k, nvars=nvars)
+    ok, stage, r = plus.range_check_verify(plus.PoseidonTranscript(), d)
+    assert ok and stage == 0 and (r == d["r"]).all()
+    for key, idx, want in (("a", (0, 1), 4), ("bb", (0, 0, 2), 4), ("v", (0, 7), 5), ("c", (0, 1, 9), 5), ("e", (0, 0, 3, 1), 3)):
+        t = dict(d)
+        t[key] = d[key].copy()
+        t[key][idx] = (int(t[key][idx]) + 1) % P
+        ok_p, st_p, _ = plus.range_check_verify(plus.PoseidonTranscript(), t)
+        assert not ok_p and st_p == want, (key, st_p)
+        assert lfp.range_check_verify(lfp.Transcript(), nvars, t, k)[0] == -want
