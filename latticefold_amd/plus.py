@@ -304,6 +304,8 @@ def set_check_verify(transcript, nvars, out, nM=0):
 def range_check(ctxs, transcript, M=()):
     """Rg::range_check (src/rgchk.rs:81-186) over the resident RgInstances of `ctxs` (each after RgInstance.from_f) -> dict of the Dcom fields"""
     L, nM, c0 = len(ctxs), len(M), ctxs[0]
+    if not c0.n or not getattr(c0, "_k", 0):
+        raise LfPlusError(E_ARG, "range_check: no resident RgInstance (run RgInstance.from_f first)")
     n, k = c0.n, c0._k
     nvars = n.bit_length() - 1
     keep, rp, cp, vp = _csr_args(M)

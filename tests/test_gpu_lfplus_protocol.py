@@ -56,8 +56,13 @@ def test_set_check_matches_oracle(ctx, nvars, nmat, ncols, nvec, nM):
         assert (got[key] == want[key]).all(), key
     assert tp.get_challenge() == to.challenge()            # the transcripts end in the same state
     ok, stage, r = plus.set_check_verify(plus.PoseidonTranscript(), nvars, got, nM=nM)
-    assert ok and (r == got["r"]).all()
-    assert lfp.set_check_verify(lfp.Transcript(), nvars, got, nM=nM)[0] == 0
+    rc_o = lfp.set_check_verify(lfp.Transcript(), nvars, got, nM=nM)[0]
+    if nmat == 1 and nvec:
+        # a quirk of the reference, restated literally: without a batching challenge (a single matrix set) the prover's closure returns after
+        # the first matrix set (setchk.rs:172-176), so vector sets never enter the sumcheck, while Out::verify adds their claims (setchk.rs:318-333)
+        assert not ok and stage == 3 and rc_o == -3
+    else:
+        assert ok and (r == got["r"]).all() and rc_o == 0
 
 
 def _witness(n, seed):
@@ -79,7 +84,7 @@ def test_range_check_matches_oracle(L, nM, nvars):
             c = plus.PlusContext(0)
             rg = plus.RgInstance.from_f(c, f, A, dp)
             ctxs.append(c)
-            insts.append({"Mf": lfp.exp_dense(rg.D_f), "tau": rg.tau, "mtau": lfp.exp_dense(rg.m_tau), "f": f})
+            insts.append({"Mf": lfp.exp_dense(rg.D_f), "tau": rg.tau, "mtau": lfp.exp_dense(rg.m_tau_exp), "f": f})
         mats = [_ident(n, first=2)] * nM
         to, tp = lfp.Transcript(), plus.PoseidonTranscript()
         want = lfp.range_check(to, nvars, insts, k, mats)
@@ -105,7 +110,7 @@ def test_argument_errors(ctx):
     c2 = plus.PlusContext(0)
     try:
         with pytest.raises(plus.LfPlusError) as e:
-            plus.range_check([c2], tp) if setattr(c2, "_k", 2) is None else None
-        assert e.value.code == plus.E_ARG  # no resident RgInstance
+            plus.range_check([c2], tp)      # no resident RgInstance
+        assert e.value.code == plus.E_ARG
     finally:
         c2.close()
