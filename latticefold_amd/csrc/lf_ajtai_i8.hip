@@ -397,6 +397,235 @@ __global__ void __launch_bounds__(64 * I8_WAVES) k_ajtai_i8(AjtaiI8Args a) {
     if ((threadIdx.x >> 6) < I8_WAVES / 2) i8_run<RD, RG, MTWA, NTW, ACH, EXACT, false, MTT, PROF>(a, smem);
     else i8_run<RD, RG, MTWB, NTW, ACH, EXACT, true, MTT, PROF>(a, smem);
 }
+// =====================================================================================================================================
+// k_ajtai_i8s -- the 24-ring, 13-row-tile shape (kappa 25 / 26) with SPECIALISED waves.  In-kernel clocks of k_ajtai_i8 above
+// (profiles/r03_i8prof_after.txt): the matrix pipe is busy only during the K-steps (3 x 1250 of 7000 cycles per tile); the operand build
+// and the tile copy cannot hide behind MFMAs of the same wave (in-order issue), and two MFMA waves per SIMD need all 256 registers for
+// accumulators, which leaves no room for a deeper pipeline.  Here a workgroup commits at most 8 digit planes (12 column tiles), so
+//   * waves 0-3 (one per SIMD) ONLY multiply: (7 | 6) x 6 tiles = 168 | 144 accumulators, B operands double-buffered across the K-steps,
+//     A operand rolling;
+//   * waves 4-7 (the other wave of each SIMD) ONLY produce: tile copy global -> registers -> LDS two tiles ahead (no accumulators, so the
+//     staging registers are free), digits two tiles ahead, Toeplitz vectors one tile ahead;
+// one s_barrier per tile hands the buffers over.  The K - 1 = 15 planes of a decomposition are two such workgroups (8 + 7 planes) that stream
+// the same tiles of A -- placed on one XCD eight dispatch slots apart, like the two witnesses of the paired launch, so A leaves HBM once.
+// =====================================================================================================================================
+constexpr int S_NPG = 8;                 // planes per workgroup
+constexpr int S_NT = S_NPG * 24 / 16;    // 12 column tiles
+constexpr int S_MT = 13;
+constexpr int S_ALDS = 10 * 256 * 16;    // padded tile (39 936 bytes) in LDS
+constexpr int S_VB = S_NPG * 2 * 48, S_DB = S_NPG * 25;
+size_t ajtai_i8s_lds_bytes() { return 2 * (size_t)S_ALDS + 2 * (size_t)S_VB * 8 + 2 * (size_t)S_DB * 8 + 3 * 24 * 8 * 4 + 256 * 4; }
+
+template <int MTW>
+__device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *smem, u32 mg, u32 ng, u32 T0, u32 T1, u32 slot) {
+    constexpr int RD = 24, KS = 3, VS = 48, HALF = 12, NTW = 6;
+    const u32 lane = threadIdx.x & 63;
+    const unsigned char *Al = smem;
+    const ull *V = (const ull *)(smem + 2 * S_ALDS);
+    u32 vb[NTW];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ni++) {
+        u32 n = (ng * NTW + ni) * 16 + (lane & 15);       // < 192 = 8 planes x 24: planes past NP hold zero digits
+        const u32 p = n / RD, co = n % RD;
+        vb[ni] = ((p * 2 + (co >= HALF ? 0u : 1u)) * VS + (RD - 1 - co + 2 * (lane >> 4))) * 8;
+    }
+    const u32 m_lo = mg * 7, ab0 = (m_lo * 64 + lane) * 16;
+    v4i acc[MTW][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MTW; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
+    if (T0 < T1) { lds_barrier(); lds_barrier(); }          // (the producers' prologue has two barriers of its own: every wave must arrive)
+    lds_barrier();                                          // hand-over: A[T0], V[T0] are in buffer 0
+    for (u32 T = T0; T < T1; T++) {
+        const u32 cur = (T - T0) & 1;
+        const unsigned char *Ac = Al + cur * S_ALDS;
+        const unsigned char *Vc = (const unsigned char *)(V + cur * S_VB);
+        v4i b[NTW], bn[NTW];
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++) {
+            const ull *q = (const ull *)(Vc + vb[ni]);
+            const ull lo = q[0], hi = q[1];
+            b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            v4i avn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0);
+#pragma unroll
+            for (int mi = 0; mi < MTW; mi++) {
+                const v4i av = avn;
+                if (mi + 1 < MTW) avn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + (mi + 1) * 1024);
+                if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ni++) {
+                        const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
+                        const ull lo = q[0], hi = q[1];
+                        bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
+                    }
+                }
+#pragma unroll
+                for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+            }
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MTW; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++)
+            *(v4i *)(a.part + ((((size_t)slot * S_MT + m_lo + mi) * S_NT + ng * NTW + ni) * 64 + lane) * 4) = acc[mi][ni];
+}
+
+// the producer waves: btid = 0 .. 255
+__device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *smem, const int32_t *planes, u32 k0, u32 NP, u32 T0, u32 T1, u32 slot) {
+    constexpr int RD = 24, VS = 48, HALF = 12, DS = 25, EPP = 96;
+    const u32 btid = threadIdx.x - 256;
+    unsigned char *Al = smem;
+    ull *V = (ull *)(smem + 2 * S_ALDS);
+    ull *Dl = V + 2 * S_VB;
+    int32_t *wl = (int32_t *)(Dl + 2 * S_DB);               // [3][24][8]
+    u32 *dsl = (u32 *)(wl + 3 * RD * 8);                    // digit sums [192]
+    const size_t a_tile = (size_t)3 * S_MT * 1024;
+    const u32 Tlast = a.ntiles - 1;
+    uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, y0, y1, y2, y3, y4, y5, y6, y7, y8, y9;
+#define LF_S_LOAD(P_, T_)                                                                                          \
+    do {                                                                                                           \
+        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + (size_t)btid * 16;     \
+        P_##0 = *(const uint4 *)(src_);            P_##1 = *(const uint4 *)(src_ + 4096);                          \
+        P_##2 = *(const uint4 *)(src_ + 2 * 4096); P_##3 = *(const uint4 *)(src_ + 3 * 4096);                      \
+        P_##4 = *(const uint4 *)(src_ + 4 * 4096); P_##5 = *(const uint4 *)(src_ + 5 * 4096);                      \
+        P_##6 = *(const uint4 *)(src_ + 6 * 4096); P_##7 = *(const uint4 *)(src_ + 7 * 4096);                      \
+        P_##8 = *(const uint4 *)(src_ + 8 * 4096); P_##9 = *(const uint4 *)(src_ + 9 * 4096);                      \
+    } while (0)
+#define LF_S_STORE(P_, buf_)                                                                                       \
+    do {                                                                                                           \
+        unsigned char *dst_ = Al + (buf_) * S_ALDS + (size_t)btid * 16;                                            \
+        *(uint4 *)(dst_) = P_##0;            *(uint4 *)(dst_ + 4096) = P_##1;                                      \
+        *(uint4 *)(dst_ + 2 * 4096) = P_##2; *(uint4 *)(dst_ + 3 * 4096) = P_##3;                                  \
+        *(uint4 *)(dst_ + 4 * 4096) = P_##4; *(uint4 *)(dst_ + 5 * 4096) = P_##5;                                  \
+        *(uint4 *)(dst_ + 6 * 4096) = P_##6; *(uint4 *)(dst_ + 7 * 4096) = P_##7;                                  \
+        *(uint4 *)(dst_ + 8 * 4096) = P_##8; *(uint4 *)(dst_ + 9 * 4096) = P_##9;                                  \
+    } while (0)
+    // staged witness words: thread btid < 192 owns word (coefficient btid / 8, column btid % 8) of a tile
+    const u32 wo = (u32)((size_t)(btid < 192 ? btid >> 3 : 23) * a.ld * 4);
+    int32_t wreg = 0;
+    auto load_w = [&](u32 T) {
+        const size_t j = (size_t)T * 8 + (btid & 7);
+        const bool ok = T < T1 && j < a.n;
+        const int32_t v = *(const int32_t *)((const char *)planes + (wo + (ok ? (u32)j * 4 : 0)));
+        wreg = ok ? v : 0;
+    };
+    auto store_w = [&](u32 buf) { if (btid < 192) wl[buf * RD * 8 + btid] = wreg; };
+    // digits: thread btid < 192 owns (plane, coefficient) = (btid / 24, btid % 24); planes >= NP get zero digits
+    const u32 gp = btid / RD, gc = btid % RD;
+    if (btid < 192) dsl[btid] = 0;
+    auto gen_d = [&](u32 wbuf, u32 dbuf) {
+        if (btid < 192) {
+            const int32_t *wp = wl + wbuf * RD * 8 + gc * 8;
+            const int4 w0 = *(const int4 *)(wp), w1 = *(const int4 *)(wp + 4);
+            const int32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            ull d = 0;
+            int sacc = 0;
+            if (gp < NP) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int dg = digit2_i8(w[q], k0 + gp);
+                    sacc += dg;
+                    d |= (ull)(unsigned char)dg << (8 * q);
+                }
+            }
+            Dl[dbuf * S_DB + gp * DS + gc] = d;
+            dsl[btid] += (u32)sacc;
+        }
+    };
+    // vectors: thread btid < 192 owns entry (H / L, e) of the planes btid / 96 + 2 round, round < 4
+    const u32 vp = btid / EPP, vr = btid % EPP;
+    u32 o0 = RD, o1 = RD, o2 = RD;
+    const bool vsub = vr >= (u32)VS;
+    {
+        const int dl = RD - 1 - (int)(vr % VS);
+        if (!vsub) {
+            if (dl >= -(HALF - 1) && dl <= RD - 1) { if (dl >= 0) o0 = dl; if (dl <= HALF - 1) o1 = dl + HALF; }
+        } else if (dl >= -(RD - 1) && dl <= HALF - 1) {
+            if (dl >= 0) o0 = dl;
+            if (dl <= -1) o1 = dl + RD;
+            if (dl <= -(HALF + 1)) o2 = dl + RD + HALF;
+        }
+    }
+    auto gen_v = [&](u32 dbuf, u32 vbuf) {
+        if (btid < 192) {
+#pragma unroll
+            for (int round = 0; round < S_NPG / 2; round++) {
+                const ull *D = Dl + dbuf * S_DB + (vp + 2 * round) * DS;
+                const ull xa = D[o0], xb = D[o1], xc = D[o2];
+                const ull t = swar_add(xb, xc);
+                V[vbuf * S_VB + (vp + 2 * round) * EPP + vr] = vsub ? swar_sub(xa, t) : swar_add(xa, t);
+            }
+        }
+    };
+    if (btid < 2 * S_NPG) Dl[btid * DS + RD] = 0;           // the zero words
+    if (T0 < T1) {
+        // prologue: A[T0] -> buffer 0, A[T0+1] in flight (x), w[T0 .. T0+2], D[T0], D[T0+1], V[T0]
+        LF_S_LOAD(y, T0);
+        load_w(T0); store_w(0);
+        load_w(T0 + 1); store_w(1);
+        load_w(T0 + 2); store_w(2);
+        LF_S_STORE(y, 0);
+        LF_S_LOAD(x, T0 + 1);
+        lds_barrier();                                      // (producer-internal, but s_barrier counts every wave of the workgroup: i8s_mma arrives too)
+        gen_d(0, 0);
+        gen_d(1, 1);
+        lds_barrier();
+        gen_v(0, 0);
+    }
+    lds_barrier();                                          // hand-over of buffer 0 (matches the multipliers' first barrier)
+    u32 w3 = 0;
+    for (u32 T = T0; T < T1; T += 2) {
+        // even tile of the pair: x holds A[T+1]; load A[T+2] into y
+        load_w(T + 3);                                       // (before the tile loads: its word is stored first, and the memory counter is in order)
+        LF_S_LOAD(y, T + 2);
+        gen_d(w3 >= 1 ? w3 - 1 : 2, 0);                     // digits of tile T+2 -> D[0] (held tile T)
+        gen_v(1, 1);                                        // vectors of tile T+1 from D[1]
+        LF_S_STORE(x, 1);                                   // A[T+1] -> buffer 1
+        store_w(w3);
+        w3 = w3 == 2 ? 0 : w3 + 1;
+        lds_barrier();
+        if (T + 1 >= T1) break;
+        // odd tile: y holds A[T+2]; load A[T+3] into x
+        load_w(T + 4);
+        LF_S_LOAD(x, T + 3);
+        gen_d(w3 >= 1 ? w3 - 1 : 2, 1);
+        gen_v(0, 0);
+        LF_S_STORE(y, 0);
+        store_w(w3);
+        w3 = w3 == 2 ? 0 : w3 + 1;
+        lds_barrier();
+    }
+#undef LF_S_LOAD
+#undef LF_S_STORE
+    if (btid < 192) a.dsum[(size_t)slot * 192 + btid] = (int)dsl[btid];   // (stride of 8 planes whatever NP is)
+}
+
+__global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // plane group g = planes [8 g, 8 g + 8) of the launch: block ids 16 q + 8 g + x, like the two witnesses of the paired launch
+    const u32 grp = a.sides == 2 ? (blockIdx.x >> 3) & 1 : 0;
+    const u32 chunk = a.sides == 2 ? ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7) : blockIdx.x;
+    const u32 slot = grp * a.nchunks + chunk;
+    const u32 T0 = chunk * a.tiles_per_wg;
+    const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
+    const u32 np_g = a.NP - S_NPG * grp < (u32)S_NPG ? a.NP - S_NPG * grp : (u32)S_NPG;
+    const u32 wave = threadIdx.x >> 6;
+    if (wave >= 4) i8s_build(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
+    else if (wave < 2) i8s_mma<7>(a, smem, 0, wave & 1, T0, T1, slot);
+    else i8s_mma<6>(a, smem, 1, wave & 1, T0, T1, slot);
+}
+
 // copies the per-phase clock totals of the last PROF launch: out[wave][0..6] cycles per phase, out[wave][7] = tiles
 int ajtai_i8_read_prof(unsigned long long *out64) { return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_i8_prof), sizeof(g_i8_prof)) == hipSuccess ? 0 : -1; }
 
@@ -434,11 +663,15 @@ __device__ __forceinline__ u64 s128_mod_small(__int128 v, u64 p) {
 // stage 2: y[plane][row][c_out] in coefficient form, canonical.  Element index e = plane * kappa_total + row0 + i;
 // soa != 0: out[c_out * NE + e] (NE = NP * kappa_total), else out[e * RD + c_out].  p_small = 0: the Goldilocks modulus.
 __global__ void __launch_bounds__(256) k_ajtai_i8_finish(const long long *sum, size_t per_wg, u32 MT, u32 NT, u32 NP, u32 kappa, u32 row0, u32 kappa_total,
-                                                         u32 RD, u32 NL, u64 p_small, int soa, u64 *coef_out, u64 *coef_out2) {
+                                                         u32 RD, u32 NL, u64 p_small, int soa, u64 *coef_out, u64 *coef_out2, u32 np_total, u32 grp_planes) {
     const u32 o = blockIdx.x * 256 + threadIdx.x;
     if (o >= NP * kappa * RD) return;
-    if (blockIdx.y) { sum += per_wg + (size_t)NP * RD; coef_out = coef_out2; }   // second witness of a two-sided launch
+    // blockIdx.y = 1: the second witness of a two-sided launch (its own output), or -- grp_planes != 0 -- the second plane group of
+    // k_ajtai_i8s (planes grp_planes .. np_total - 1 of the same output)
+    if (blockIdx.y) { sum += per_wg + (size_t)NP * RD; if (!grp_planes) coef_out = coef_out2; }
     const u32 co = o % RD, i = (o / RD) % kappa, p = o / (RD * kappa), HALF = RD / 2;
+    const u32 p_glob = p + blockIdx.y * grp_planes;
+    if (grp_planes && p_glob >= np_total) return;
     const u32 n = p * RD + co, nt = n >> 4, col = n & 15;
     // T = sum over inner elements of Rot(F)[.][c_out], F = sum over columns of the digit polynomials: the "-128" bias of the bytes of A
     const long long *F = sum + per_wg + (size_t)p * RD;
@@ -460,8 +693,8 @@ __global__ void __launch_bounds__(256) k_ajtai_i8_finish(const long long *sum, s
         tot += (__int128)(sum[(((size_t)mt * NT + nt) * 64 + ln) * 4 + reg] + 128 * Tsum) << (8 * u);
     }
     const u64 val = p_small ? s128_mod_small(tot, p_small) : fq_from_s128((u64)tot, (int64_t)(tot >> 64));
-    const size_t e = (size_t)p * kappa_total + row0 + i;
-    if (soa) coef_out[(size_t)co * ((size_t)NP * kappa_total) + e] = val;
+    const size_t e = (size_t)(grp_planes ? p_glob : p) * kappa_total + row0 + i;
+    if (soa) coef_out[(size_t)co * ((size_t)(grp_planes ? np_total : NP) * kappa_total) + e] = val;
     else coef_out[e * RD + co] = val;
 }
 
@@ -492,6 +725,27 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     a.part = part; a.dsum = dsum;
     if ((size_t)R.RD * ld * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit plane offsets in the kernel
     if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
+    // The 13-row-tile shape of the 24-ring with specialised waves (k_ajtai_i8s): plane groups of 8, two groups = paired workgroups
+    static const bool no_split = getenv("LF_I8_NO_SPLIT") != nullptr;
+    if (R.RD == 24 && MT == 13 && !planes2 && !no_split && !getenv("LF_I8_GUARDED") && !getenv("LF_I8_PROF")) {
+        const u32 groups = NP > (u32)S_NPG ? 2 : 1;
+        u32 per = nwg / groups;
+        if (groups == 2) per &= ~7u;
+        if (per >= 1) {
+            a.tiles_per_wg = (a.ntiles + per - 1) / per;
+            u32 nch = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+            if (groups == 2) nch = (nch + 7) & ~7u;
+            a.sides = groups; a.nchunks = nch; a.NT = S_NT;
+            static bool attr_s = false;
+            if (!attr_s) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8s, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_s = true; }
+            hipLaunchKernelGGL(k_ajtai_i8s, dim3(groups * nch), dim3(512), ajtai_i8s_lds_bytes(), s, a);
+            const size_t per_wg_s = (size_t)S_MT * S_NT * 256;
+            hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg_s + 192, 256), groups), dim3(256), 0, s, part, per_wg_s, dsum, 192u, nch, sum);
+            hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)S_NPG * kappa * 24, 256), groups), dim3(256), 0, s, sum, per_wg_s, (u32)S_MT, (u32)S_NT,
+                               (u32)S_NPG, kappa, row0, kappa_total, 24u, R.NL, R.p_small, R.soa_out, coef_out, (u64 *)nullptr, NP, (u32)S_NPG);
+            return (int)(groups * nch);
+        }
+    }
     // two witnesses: nwg / 2 chunks of columns (a multiple of 8, see i8_run), each run by a pair of workgroups
     const u32 sides = planes2 ? 2 : 1;
     u32 per_side = nwg / sides;
@@ -535,7 +789,7 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     const size_t per_wg = (size_t)MT * a.NT * 256;
     hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * R.RD, 256), sides), dim3(256), 0, s, part, per_wg, dsum, NP * R.RD, nchunks, sum);
     hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * R.RD, 256), sides), dim3(256), 0, s, sum, per_wg, MT, a.NT, NP, kappa, row0,
-                       kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out, coef_out2);
+                       kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out, coef_out2, NP, 0u);
     return (int)grid;
 }
 
