@@ -387,7 +387,7 @@ def main():
             want = "k_ajtai_i8" if i8 else ("bb::" if wl.ring == "babybear" else "") + "k_ajtai"
             for name, k in pmc.items():
                 base = name.split("<")[0]
-                if base == want and k["fetch_bytes_max_corrected"] is not None:
+                if (base == want or (i8 and base == want + "s")) and k["fetch_bytes_max_corrected"] is not None:   # (k_ajtai_i8s: the specialised-wave kernel of the 24-ring)
                     traffic = k["fetch_bytes_max_corrected"] + k["write_bytes_max"]   # per launch like `achieved`: the largest launch (the K-1 batch)
         except Exception:
             traffic = None

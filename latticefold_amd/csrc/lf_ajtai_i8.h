@@ -27,7 +27,9 @@ size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, uint32_t MT, uint32_t NT, uint32
 // workgroups placed on one XCD, so that A is fetched from HBM once for both (the two decompositions of a fold step).
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const int32_t *planes, size_t ld, size_t n, uint32_t kappa, uint32_t row0,
                     uint32_t kappa_total, uint32_t k0, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s,
-                    const int32_t *planes2 = nullptr, uint64_t *coef_out2 = nullptr);
+                    const int32_t *planes2 = nullptr, uint64_t *coef_out2 = nullptr, const uint32_t *bits = nullptr, size_t bits_nw = 0, uint32_t bits_rows = 0);
+// bits (optional): the bit-plane form of `planes` (lf_sv_rounds.h launch_sv_bits over the same columns: [RD][bits_rows][bits_nw] words); the
+// 24-ring / 13-row-tile kernel then cuts its digits from two words per (plane, coefficient) and tile instead of eight int32 values
 // measurement: per-phase shader-clock totals of the last launch made with LF_I8_PROF set (out64[8 waves][8]: 7 phases + tile count of workgroup 0)
 int ajtai_i8_read_prof(unsigned long long *out64);
 // v[k][c][q] = sum_j eq[q][j] * digit_k(planes[c][j]) on the matrix cores (Goldilocks; see lf_ajtai_i8.hip).  mode_bits: K binary digit planes,

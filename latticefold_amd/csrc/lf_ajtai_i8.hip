@@ -84,6 +84,9 @@ struct AjtaiI8Args {
     const int32_t *planes;   // [RD][ld], already offset to this rank's first column
     const int32_t *planes2;  // sides == 2: the second witness (same geometry)
     u32 sides, nchunks;      // workgroups = sides * nchunks; workgroup (side, chunk) writes slot side * nchunks + chunk of part / dsum
+    const u32 *bits;         // optional (k_ajtai_i8s): bit-plane form of the witness (lf_sv_rounds.h launch_sv_bits: [RD][bits_rows][bits_nw] words,
+    size_t bits_nw;          // row r < bits_rows - 1 = bit r of |v|, last row = sign bits; 32 positions per word) -- digits are then cut from two
+    u32 bits_rows;           // words per (plane, coefficient) instead of eight int32 values
     size_t ld, n;
     u32 MT, NT, k0, NP;
     u32 ntiles, tiles_per_wg;
@@ -416,7 +419,13 @@ constexpr int S_ALDS = 10 * 256 * 16;    // padded tile (39 936 bytes) in LDS
 constexpr int S_VB = S_NPG * 2 * 48, S_DB = S_NPG * 25;
 size_t ajtai_i8s_lds_bytes() { return 2 * (size_t)S_ALDS + 2 * (size_t)S_VB * 8 + 2 * (size_t)S_DB * 8 + 3 * 24 * 8 * 4 + 256 * 4; }
 
-template <int MTW>
+#define LF_S_STAMP(i_)                                                                   \
+    if (PROF) {                                                                          \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+        pt[i_] += now_ - pc;                                                             \
+        pc = now_;                                                                       \
+    }
+template <int MTW, bool PROF>
 __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *smem, u32 mg, u32 ng, u32 T0, u32 T1, u32 slot) {
     constexpr int RD = 24, KS = 3, VS = 48, HALF = 12, NTW = 6;
     const u32 lane = threadIdx.x & 63;
@@ -437,6 +446,8 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
         for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
     if (T0 < T1) { lds_barrier(); lds_barrier(); }          // (the producers' prologue has two barriers of its own: every wave must arrive)
     lds_barrier();                                          // hand-over: A[T0], V[T0] are in buffer 0
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    if (PROF) pc = __builtin_amdgcn_s_memtime();
     for (u32 T = T0; T < T1; T++) {
         const u32 cur = (T - T0) & 1;
         const unsigned char *Ac = Al + cur * S_ALDS;
@@ -450,11 +461,14 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
         }
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-            v4i avn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0);
+            // A operand: three rolling registers -- the read of row tile mi + 2 is issued before the MFMAs of row tile mi (an LDS read takes
+            // longer than the 96 cycles of one row tile's MFMAs while the producer waves store the next tile)
+            v4i avn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0), avnn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + 1024);
 #pragma unroll
             for (int mi = 0; mi < MTW; mi++) {
                 const v4i av = avn;
-                if (mi + 1 < MTW) avn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + (mi + 1) * 1024);
+                avn = avnn;
+                if (mi + 2 < MTW) avnn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + (mi + 2) * 1024);
                 if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
                     for (int ni = 0; ni < NTW; ni++) {
@@ -472,7 +486,13 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
                 for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
             }
         }
+        LF_S_STAMP(3);     // K-steps
         lds_barrier();
+        LF_S_STAMP(6);     // barrier
+    }
+    if (PROF && blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 7; i++) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
+        g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
     }
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
@@ -482,6 +502,7 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
 }
 
 // the producer waves: btid = 0 .. 255
+template <bool PROF, bool BITS>
 __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *smem, const int32_t *planes, u32 k0, u32 NP, u32 T0, u32 T1, u32 slot) {
     constexpr int RD = 24, VS = 48, HALF = 12, DS = 25, EPP = 96;
     const u32 btid = threadIdx.x - 256;
@@ -493,12 +514,30 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     const size_t a_tile = (size_t)3 * S_MT * 1024;
     const u32 Tlast = a.ntiles - 1;
     uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, y0, y1, y2, y3, y4, y5, y6, y7, y8, y9;
+    const u32 voff = btid * 16;
 #define LF_S_LOAD(P_, T_)                                                                                          \
-    do {                                                                                                           \
-        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + (size_t)btid * 16;     \
+    do {   /* uniform base (scalar registers) + 32-bit lane offset: one address register for the ten loads */     \
+        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
         P_##0 = *(const uint4 *)(src_);            P_##1 = *(const uint4 *)(src_ + 4096);                          \
         P_##2 = *(const uint4 *)(src_ + 2 * 4096); P_##3 = *(const uint4 *)(src_ + 3 * 4096);                      \
         P_##4 = *(const uint4 *)(src_ + 4 * 4096); P_##5 = *(const uint4 *)(src_ + 5 * 4096);                      \
+        P_##6 = *(const uint4 *)(src_ + 6 * 4096); P_##7 = *(const uint4 *)(src_ + 7 * 4096);                      \
+        P_##8 = *(const uint4 *)(src_ + 8 * 4096); P_##9 = *(const uint4 *)(src_ + 9 * 4096);                      \
+    } while (0)
+#define LF_S_LOAD_A(P_, T_)                                                                                        \
+    do {                                                                                                           \
+        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
+        P_##0 = *(const uint4 *)(src_);            P_##1 = *(const uint4 *)(src_ + 4096);                          \
+    } while (0)
+#define LF_S_LOAD_B(P_, T_)                                                                                        \
+    do {                                                                                                           \
+        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
+        P_##2 = *(const uint4 *)(src_ + 2 * 4096); P_##3 = *(const uint4 *)(src_ + 3 * 4096);                      \
+        P_##4 = *(const uint4 *)(src_ + 4 * 4096); P_##5 = *(const uint4 *)(src_ + 5 * 4096);                      \
+    } while (0)
+#define LF_S_LOAD_C(P_, T_)                                                                                        \
+    do {                                                                                                           \
+        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
         P_##6 = *(const uint4 *)(src_ + 6 * 4096); P_##7 = *(const uint4 *)(src_ + 7 * 4096);                      \
         P_##8 = *(const uint4 *)(src_ + 8 * 4096); P_##9 = *(const uint4 *)(src_ + 9 * 4096);                      \
     } while (0)
@@ -524,30 +563,58 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     // digits: thread btid < 192 owns (plane, coefficient) = (btid / 24, btid % 24); planes >= NP get zero digits
     const u32 gp = btid / RD, gc = btid % RD;
     if (btid < 192) dsl[btid] = 0;
+    // BITS: the magnitude bits of plane k0 + gp and the sign bits of coefficient gc, 8 columns = one byte of a bit-plane word each
+    u32 bmag = 0, bsgn = 0, bsh = 0;   // raw words + shift: cut at use time, so that nothing waits for the loads where they are issued
+    const size_t brow_m = ((size_t)(btid < 192 ? gc : 0) * a.bits_rows + (k0 + (gp < NP ? gp : 0))) * a.bits_nw;
+    const size_t brow_s = ((size_t)(btid < 192 ? gc : 0) * a.bits_rows + (a.bits_rows - 1)) * a.bits_nw;
+    auto load_bits = [&](u32 T) {     // tile T: byte T & 3 of word T >> 2 (tiles past the end: zero digits)
+        const u32 Tc = T < T1 ? T : T0;
+        bmag = a.bits[brow_m + (Tc >> 2)];
+        bsgn = a.bits[brow_s + (Tc >> 2)];
+        bsh = T < T1 && gp < NP ? 8 * (T & 3) : 32;          // (32: no digit)
+    };
+    auto gen_d_bits = [&](u32 dbuf) {
+        if (btid < 192) {
+            // 4 bits -> 4 bytes: (x * 0x204081) & 0x01010101;  biased digit byte = 4 + bit - 2 (bit & sign)
+            const u32 mg8 = bsh < 32 ? (bmag >> bsh) & 0xFF : 0, neg = mg8 & (bsgn >> (bsh & 31));
+            const u32 lo = ((mg8 & 15) * 0x204081u) & 0x01010101u, hi = ((mg8 >> 4) * 0x204081u) & 0x01010101u;
+            const u32 nlo = ((neg & 15) * 0x204081u) & 0x01010101u, nhi = ((neg >> 4) * 0x204081u) & 0x01010101u;
+            const u32 dlo = 0x04040404u + lo - 2 * nlo, dhi = 0x04040404u + hi - 2 * nhi;
+            Dl[dbuf * S_DB + gp * DS + gc] = (ull)dlo | ((ull)dhi << 32);
+            dsl[btid] += (u32)(__popc(mg8) - 2 * __popc(neg));
+        }
+    };
     auto gen_d = [&](u32 wbuf, u32 dbuf) {
+        if (BITS) { gen_d_bits(dbuf); return; }
         if (btid < 192) {
             const int32_t *wp = wl + wbuf * RD * 8 + gc * 8;
             const int4 w0 = *(const int4 *)(wp), w1 = *(const int4 *)(wp + 4);
             const int32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            ull d = 0;
+            ull d = 0x0404040404040404ull;                  // digits are kept BIASED by 4 (a byte in 3 .. 5): sums of up to three need no byte-wise carries
             int sacc = 0;
             if (gp < NP) {
+                d = 0;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int dg = digit2_i8(w[q], k0 + gp);
                     sacc += dg;
-                    d |= (ull)(unsigned char)dg << (8 * q);
+                    d |= (ull)(unsigned)(dg + 4) << (8 * q);
                 }
             }
             Dl[dbuf * S_DB + gp * DS + gc] = d;
             dsl[btid] += (u32)sacc;
         }
     };
-    // vectors: thread btid < 192 owns entry (H / L, e) of the planes btid / 96 + 2 round, round < 4
-    const u32 vp = btid / EPP, vr = btid % EPP;
-    u32 o0 = RD, o1 = RD, o2 = RD;
-    const bool vsub = vr >= (u32)VS;
-    {
+    // vectors: entry idx = btid + 256 round (round < 3) = (plane, H / L, e) = (idx / 96, (idx % 96) / 48, idx % 48); with biased digit bytes
+    //   H:  v = ((D[o0] + D[o1] + D[o2]) + 0x74..) ^ 0x80..      (bytes 12 + true value + 0x74 = 0x80 + true value)
+    //   L:  v = ((D[o0] + 0x84..) - (D[o1] + D[o2])) ^ 0x80..    (a missing term reads the biased zero word)
+    // plain 64-bit adds: no byte overflows (every byte stays between 0x7d and 0x8e), and the XOR turns 0x80 + t into the int8 t.
+    u32 vo[3];          // o0 | o1 << 8 | o2 << 16 | L << 24, offsets in words from the D buffer
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const u32 idx = btid + 256 * r, vp = idx / EPP, vr = idx % EPP;
+        u32 o0 = RD, o1 = RD, o2 = RD;
+        const bool vsub = vr >= (u32)VS;
         const int dl = RD - 1 - (int)(vr % VS);
         if (!vsub) {
             if (dl >= -(HALF - 1) && dl <= RD - 1) { if (dl >= 0) o0 = dl; if (dl <= HALF - 1) o1 = dl + HALF; }
@@ -556,61 +623,94 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
             if (dl <= -1) o1 = dl + RD;
             if (dl <= -(HALF + 1)) o2 = dl + RD + HALF;
         }
+        vo[r] = (vp * DS + o0) | ((vp * DS + o1) << 8) | ((vp * DS + o2) << 16) | (vsub ? 1u << 24 : 0u);
     }
+    static_assert(S_NPG * 25 <= 256, "8-bit vector source offsets");
     auto gen_v = [&](u32 dbuf, u32 vbuf) {
-        if (btid < 192) {
+        const ull *D = Dl + dbuf * S_DB;
+        ull xa[3], xb[3], xc[3];
 #pragma unroll
-            for (int round = 0; round < S_NPG / 2; round++) {
-                const ull *D = Dl + dbuf * S_DB + (vp + 2 * round) * DS;
-                const ull xa = D[o0], xb = D[o1], xc = D[o2];
-                const ull t = swar_add(xb, xc);
-                V[vbuf * S_VB + (vp + 2 * round) * EPP + vr] = vsub ? swar_sub(xa, t) : swar_add(xa, t);
-            }
+        for (int r = 0; r < 3; r++) { xa[r] = D[vo[r] & 0xFF]; xb[r] = D[(vo[r] >> 8) & 0xFF]; xc[r] = D[(vo[r] >> 16) & 0xFF]; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const ull t = xb[r] + xc[r];
+            const ull v = (vo[r] >> 24) ? (xa[r] + 0x8484848484848484ull) - t : (xa[r] + 0x7474747474747474ull) + t;
+            V[vbuf * S_VB + btid + 256 * r] = v ^ 0x8080808080808080ull;
         }
     };
-    if (btid < 2 * S_NPG) Dl[btid * DS + RD] = 0;           // the zero words
+    if (btid < 2 * S_NPG) Dl[btid * DS + RD] = 0x0404040404040404ull;   // the (biased) zero words
     if (T0 < T1) {
         // prologue: A[T0] -> buffer 0, A[T0+1] in flight (x), w[T0 .. T0+2], D[T0], D[T0+1], V[T0]
         LF_S_LOAD(y, T0);
-        load_w(T0); store_w(0);
-        load_w(T0 + 1); store_w(1);
-        load_w(T0 + 2); store_w(2);
+        if (!BITS) {
+            load_w(T0); store_w(0);
+            load_w(T0 + 1); store_w(1);
+            load_w(T0 + 2); store_w(2);
+        }
         LF_S_STORE(y, 0);
         LF_S_LOAD(x, T0 + 1);
         lds_barrier();                                      // (producer-internal, but s_barrier counts every wave of the workgroup: i8s_mma arrives too)
-        gen_d(0, 0);
-        gen_d(1, 1);
+        if (BITS) { load_bits(T0); gen_d(0, 0); load_bits(T0 + 1); gen_d(0, 1); load_bits(T0 + 2); }
+        else { gen_d(0, 0); gen_d(1, 1); }
         lds_barrier();
         gen_v(0, 0);
     }
     lds_barrier();                                          // hand-over of buffer 0 (matches the multipliers' first barrier)
     u32 w3 = 0;
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    if (PROF) pc = __builtin_amdgcn_s_memtime();
     for (u32 T = T0; T < T1; T += 2) {
         // even tile of the pair: x holds A[T+1]; load A[T+2] into y
-        load_w(T + 3);                                       // (before the tile loads: its word is stored first, and the memory counter is in order)
-        LF_S_LOAD(y, T + 2);
-        gen_d(w3 >= 1 ? w3 - 1 : 2, 0);                     // digits of tile T+2 -> D[0] (held tile T)
+        // (the tile copy's ten loads in three groups between the pieces of the build: the four producer waves share one 64-byte/clock
+        // load path -- a whole tile takes it 640 cycles -- and a wave that issues all ten at once sits in the queue that long)
+        if (!BITS) load_w(T + 3);                            // (before the tile loads: its word is stored first, and the memory counter is in order)
+        LF_S_LOAD_A(y, T + 2);
+        LF_S_STAMP(0);     // load issue
+        gen_d(w3 >= 1 ? w3 - 1 : 2, 0);                     // digits of tile T+2 -> D[0] (held tile T); BITS: from the words loaded one tile ago
+        if (BITS) load_bits(T + 3);
+        LF_S_LOAD_B(y, T + 2);
+        LF_S_STAMP(1);     // digits
         gen_v(1, 1);                                        // vectors of tile T+1 from D[1]
+        LF_S_LOAD_C(y, T + 2);
+        LF_S_STAMP(2);     // vectors
         LF_S_STORE(x, 1);                                   // A[T+1] -> buffer 1
-        store_w(w3);
+        if (!BITS) store_w(w3);
         w3 = w3 == 2 ? 0 : w3 + 1;
+        LF_S_STAMP(5);     // wait + LDS stores
         lds_barrier();
+        LF_S_STAMP(6);     // barrier
         if (T + 1 >= T1) break;
         // odd tile: y holds A[T+2]; load A[T+3] into x
-        load_w(T + 4);
-        LF_S_LOAD(x, T + 3);
+        if (!BITS) load_w(T + 4);
+        LF_S_LOAD_A(x, T + 3);
+        LF_S_STAMP(0);
         gen_d(w3 >= 1 ? w3 - 1 : 2, 1);
+        if (BITS) load_bits(T + 4);
+        LF_S_LOAD_B(x, T + 3);
+        LF_S_STAMP(1);
         gen_v(0, 0);
+        LF_S_LOAD_C(x, T + 3);
+        LF_S_STAMP(2);
         LF_S_STORE(y, 0);
-        store_w(w3);
+        if (!BITS) store_w(w3);
         w3 = w3 == 2 ? 0 : w3 + 1;
+        LF_S_STAMP(5);
         lds_barrier();
+        LF_S_STAMP(6);
+    }
+    if (PROF && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 7; i++) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
+        g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
     }
 #undef LF_S_LOAD
+#undef LF_S_LOAD_A
+#undef LF_S_LOAD_B
+#undef LF_S_LOAD_C
 #undef LF_S_STORE
     if (btid < 192) a.dsum[(size_t)slot * 192 + btid] = (int)dsl[btid];   // (stride of 8 planes whatever NP is)
 }
 
+template <bool PROF, bool BITS>
 __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // plane group g = planes [8 g, 8 g + 8) of the launch: block ids 16 q + 8 g + x, like the two witnesses of the paired launch
@@ -621,9 +721,9 @@ __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
     const u32 np_g = a.NP - S_NPG * grp < (u32)S_NPG ? a.NP - S_NPG * grp : (u32)S_NPG;
     const u32 wave = threadIdx.x >> 6;
-    if (wave >= 4) i8s_build(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
-    else if (wave < 2) i8s_mma<7>(a, smem, 0, wave & 1, T0, T1, slot);
-    else i8s_mma<6>(a, smem, 1, wave & 1, T0, T1, slot);
+    if (wave >= 4) i8s_build<PROF, BITS>(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
+    else if (wave < 2) i8s_mma<7, PROF>(a, smem, 0, wave & 1, T0, T1, slot);
+    else i8s_mma<6, PROF>(a, smem, 1, wave & 1, T0, T1, slot);
 }
 
 // copies the per-phase clock totals of the last PROF launch: out[wave][0..6] cycles per phase, out[wave][7] = tiles
@@ -717,8 +817,10 @@ size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT) { return (size_t)nwg * MT * 
 size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, u32 MT, u32 NT, u32 NP) { return 2 * ((size_t)MT * NT * 256 + (size_t)NP * R.RD); }   // (two sides)
 
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total,
-                    u32 k0, u32 NP, u32 nwg, int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s, const int32_t *planes2, u64 *coef_out2) {
+                    u32 k0, u32 NP, u32 nwg, int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s, const int32_t *planes2, u64 *coef_out2,
+                    const u32 *bits, size_t bits_nw, u32 bits_rows) {
     AjtaiI8Args a;
+    a.bits = nullptr; a.bits_nw = 0; a.bits_rows = 0;
     a.Ab = Ab; a.planes = planes; a.planes2 = planes2; a.ld = ld; a.n = n;
     a.MT = MT; a.NT = ajtai_i8_col_tiles(R, NP); a.k0 = k0; a.NP = NP;
     a.ntiles = (u32)((n + 7) / 8);
@@ -727,7 +829,8 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
     // The 13-row-tile shape of the 24-ring with specialised waves (k_ajtai_i8s): plane groups of 8, two groups = paired workgroups
     static const bool no_split = getenv("LF_I8_NO_SPLIT") != nullptr;
-    if (R.RD == 24 && MT == 13 && !planes2 && !no_split && !getenv("LF_I8_GUARDED") && !getenv("LF_I8_PROF")) {
+    if (R.RD == 24 && MT == 13 && !planes2 && !no_split && !getenv("LF_I8_GUARDED")) {
+        static const bool sprof = getenv("LF_I8_PROF") != nullptr;
         const u32 groups = NP > (u32)S_NPG ? 2 : 1;
         u32 per = nwg / groups;
         if (groups == 2) per &= ~7u;
@@ -737,8 +840,24 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
             if (groups == 2) nch = (nch + 7) & ~7u;
             a.sides = groups; a.nchunks = nch; a.NT = S_NT;
             static bool attr_s = false;
-            if (!attr_s) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8s, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_s = true; }
-            hipLaunchKernelGGL(k_ajtai_i8s, dim3(groups * nch), dim3(512), ajtai_i8s_lds_bytes(), s, a);
+            if (!attr_s) {
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_s = true;
+            }
+            // digits from the bit-plane form when the caller has it and digit plane k0 + NP - 1 is one of its magnitude rows
+            a.bits = bits; a.bits_nw = bits_nw; a.bits_rows = bits_rows;
+            // (opt-in, LF_I8_BITS=1: the multiplier waves bound the kernel -- 2 650-2 850 of 3 000 cycles per tile at 20.4 cycles per MFMA, the
+            // measured int8 issue rate -- so the cheaper digits change nothing: 2.00-2.07 vs 1.96-2.01 ms per launch at C4)
+            static const bool want_bits = getenv("LF_I8_BITS") != nullptr;
+            const bool ub = want_bits && bits != nullptr && k0 + NP <= bits_rows - 1;
+            const dim3 g(groups * nch), b(512);
+            const size_t lds_s = ajtai_i8s_lds_bytes();
+            if (sprof) { if (ub) hipLaunchKernelGGL((k_ajtai_i8s<true, true>), g, b, lds_s, s, a); else hipLaunchKernelGGL((k_ajtai_i8s<true, false>), g, b, lds_s, s, a); }
+            else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<false, true>), g, b, lds_s, s, a);
+            else hipLaunchKernelGGL((k_ajtai_i8s<false, false>), g, b, lds_s, s, a);
             const size_t per_wg_s = (size_t)S_MT * S_NT * 256;
             hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg_s + 192, 256), groups), dim3(256), 0, s, part, per_wg_s, dsum, 192u, nch, sum);
             hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)S_NPG * kappa * 24, 256), groups), dim3(256), 0, s, sum, per_wg_s, (u32)S_MT, (u32)S_NT,

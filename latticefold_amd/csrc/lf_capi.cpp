@@ -748,7 +748,10 @@ static int prep_ajtai_i8(lf_ctx *c) {
 }
 // digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev [NP][kappa][24] NTT form (PARTIAL when sharded)
 // planes2 / out_dev2 (optional): the same planes of a second witness, committed in the same launches (A streamed from HBM once for both)
-static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev, const int32_t *planes2 = nullptr, u64 *out_dev2 = nullptr) {
+// wit (optional): the witness `planes` belong to -- if its bit-plane form is at hand (built at the start of the fold step for the GEMM rounds) the
+// kernel cuts the digits from it
+static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev, const int32_t *planes2 = nullptr, u64 *out_dev2 = nullptr,
+                            const lf_witness *wit = nullptr) {
     const AjtaiI8Ring R = ajtai_i8_goldilocks();
     const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc), maxp = ajtai_i8_max_planes(R);
     const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
@@ -771,6 +774,16 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
         RET(commit_planes_i8(c, planes, ld, k0, NP, out_dev));
         return commit_planes_i8(c, planes2, ld, k0, NP, out_dev2);
     }
+    const u32 *bits = nullptr;
+    if (wit && !planes2 && c->A_col0 == 0 && planes == wit->planes && c->nA == c->N)
+        for (int sd = 0; sd < 2; sd++)
+            if (c->bits_wit[sd] == wit && c->bits_ptr[sd]) {
+                bits = c->bits_ptr[sd];
+                if (c->stream() != c->st_lane[1]) HIPCHK(hipStreamWaitEvent(c->stream(), c->bits_ev[sd], 0));
+                break;
+            }
+    const size_t bits_nw = (c->N + 511) / 512 * 16;          // words per row of the bit-plane form (positions padded to 512)
+    const u32 bits_rows = 16 * ((c->P.K + 15) / 16) + 1;
     for (u32 p0 = 0; p0 < NP; p0 += maxp) {
         const u32 np = NP - p0 < maxp ? NP - p0 : maxp;
         u64 *cf = coef + (size_t)24 * p0 * c->kappa;   // SoA block of this plane group: [24][np*kappa]
@@ -778,7 +791,7 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
             const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
             size_t ev = c->ev_begin(1);
             int g = launch_ajtai_i8(R, c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, cf, c->stream(),
-                                    planes2, planes2 ? cf + side_words : nullptr);
+                                    planes2, planes2 ? cf + side_words : nullptr, bits, bits_nw, bits_rows);
             c->ev_end(ev);
             if (g < 0) return LF_ERR_UNSUPPORTED;
         }
@@ -1567,7 +1580,7 @@ static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_o
     size_t ph = c->ev_begin(11);
     if (c->i8_nch && !c->tn.ajtai_valu) {
         // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
-        RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd));
+        RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd, nullptr, nullptr, wit));
     } else {
         RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * c->nA, &Fh));
         launch_bitplane_crt(c->dcrt, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());

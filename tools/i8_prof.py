@@ -21,7 +21,7 @@ lib = api._lib()
 lib.lf_debug_i8_prof.argtypes = [C.POINTER(C.c_uint64)]
 assert lib.lf_debug_i8_prof(out) == 0
 a = np.array(out[:], dtype=np.float64).reshape(8, 8)
-names = ["load issue + digits", "barrier 1", "Toeplitz vectors", "MFMA block", "wait vmcnt", "LDS stores", "barrier 2"]
+names = ["[0] load issue", "[1] digits / barrier 1", "[2] vectors", "[3] K-steps", "[4] wait vmcnt", "[5] LDS stores", "[6] barrier"]
 print("tiles per workgroup:", a[:, 7], " kernel stats:", ctx.kernel_stats())
 print("cycles per tile and wave (shader clock), waves 0..7:")
 for i, n in enumerate(names):
