@@ -1423,7 +1423,12 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
         memcpy(ev, od, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
+        if (round == 1) TL_MARK("  lin round 1");
+        if (round == 2) TL_MARK("  lin round 2");
+        if (round == 4) TL_MARK("  lin round 4");
+        if (round == 8) TL_MARK("  lin round 8");
     }
+    TL_MARK("  lin rounds done");
     if (u_dev) launch_fix_final(c->dcrt, cur, P.t * 8, f3c(point[P.s - 1]), u_dev, c->stream());   // n == 2 here (ld 2)
     return LF_OK;
 }
@@ -1474,6 +1479,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     RET(c->tbuf("red_partial", 256 * 4096, &partial));
     RET(c->tbuf("lin_small", 4096, &od));
     RET(build_z(c, wit->planes, 1, 0, head.data(), z));
+    TL_MARK("  lin z enqueued");
     std::vector<Fq3> beta(P.s);
     {
         HostTimer ht(c);
@@ -1487,6 +1493,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     // v, u at the sumcheck point (linearization.rs:126-139): u from the fully fixed Mz tables of the sumcheck (LF_LIN_U_EVAL=1: dot
     // products with eq(r) over the full tables), v from the witness planes
     const bool u_eval = c->tn.lin_u_eval;
+    TL_MARK("  lin Mz enqueued");
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72));
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;   // contiguous: v[3 ring] u[t ring]
@@ -1571,12 +1578,12 @@ struct SideState {
 // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A, then
 // y_0 = cm - sum_{k>=1} b^k y_k on the host.  Depends only on the witness and on cm -- not on the evaluation point.
 // `enqueue_only`: leave the result in flight on the lane's stream (finished later by decompose_commit_finish).
-static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_out, size_t *ev_out) {
+static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_out, size_t *ev_out, const char *ybuf = "dec_y") {
     const lf_params &P = c->P;
     size_t N = c->N;
     u32 K = P.K;
     u64 *Fh, *yd;
-    RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &yd));
+    RET(c->tbuf(ybuf, (size_t)K * P.kappa * 24, &yd));
     size_t ph = c->ev_begin(11);
     if (c->i8_nch && !c->tn.ajtai_valu) {
         // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
@@ -2507,6 +2514,16 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             // linearization -- so the left evaluations go first and the commit's results wait on the device
             RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
             RET(decompose_commit_enqueue_pair(c, w_acc, w_i, &ydL, &yd, &ev));
+        } else if (c->i8_nch && !c->tn.ajtai_valu && !c->tn.commits_first) {
+            // The left evaluations first, then the two commits back to back.  A commit workgroup fills its CU (registers, LDS): while one runs,
+            // the other lane's kernels have the 32 CUs it leaves free -- and the linearization is bandwidth-hungry exactly at its start (z, the
+            // three M z, its first rounds: 2.2 ms next to a commit, ~1.2 ms next to the evaluations), latency-bound afterwards.
+            size_t evL = 0;
+            RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+            RET(decompose_commit_enqueue(c, w_acc, &ydL, &evL));
+            RET(decompose_commit_enqueue(c, w_i, &yd, &ev, "dec_y2"));          // right commit behind it on the same stream
+            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, evL, decl));
+            ydL = nullptr;
         } else {
             RET(decompose_commit_enqueue(c, w_acc, &yd, &ev));
             RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));

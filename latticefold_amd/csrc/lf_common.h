@@ -66,6 +66,7 @@ struct Tunables {
     bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
     bool coef_valu = false;          // LF_COEF_VALU: v / v_s / theta evaluations of the digit planes on the VALU kernel (k_coef_eval) instead of the matrix cores
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
+    bool commits_first = false;      // LF_COMMITS_FIRST: round-2 order of the helper lane (left commit, left evaluations, right commit) instead of evaluations first
     bool i8_pair = false;            // LF_I8_PAIR: both decompositions' digit-plane commits in ONE launch (paired workgroups share the tiles of A in L2: A leaves
                                      // HBM once per step) instead of one launch per decomposition.  Opt-in: the same kernel time per step (4.2 vs 2 x 2.13 ms at C4), but
                                      // one 4 ms launch on 7/8 of the CUs slows the latency-bound linearization lane next to it (step 22.4 vs 21.8 ms)
@@ -104,6 +105,7 @@ struct Tunables {
         t.coef_valu = getenv("LF_COEF_VALU") != nullptr;
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
         t.i8_pair = getenv("LF_I8_PAIR") != nullptr;
+        t.commits_first = getenv("LF_COMMITS_FIRST") != nullptr;
         t.shard_two_lanes = getenv("LF_SHARD_TWO_LANES") != nullptr;
         t.shard_plain_rounds = getenv("LF_SHARD_PLAIN_ROUNDS") != nullptr;
         t.device_transcript = getenv("LF_DEVICE_TRANSCRIPT") != nullptr;
