@@ -76,6 +76,16 @@ int lfp_range_check(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, const ui
                     uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out);
 int lfp_range_check_verify(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned nM, const uint64_t *msgs, const uint64_t *e, const uint64_t *b,
                            const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c, uint64_t *r_out);
+/* Cm::prove (cm.rs:56-347) / CmProof::verify (:349-580); shapes in lfp_protocol.c */
+int lfp_cm_prove(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned ell, unsigned kappa, const uint64_t *const *Mf, const uint64_t *const *tau,
+                 const uint64_t *const *mtau, const uint64_t *const *f, const uint64_t *const *comMf, const uint64_t *const *fcoms, unsigned nM,
+                 const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out,
+                 uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, uint64_t *comh, uint64_t *pa, uint64_t *pb,
+                 uint64_t *ea, uint64_t *eb, uint64_t *g, uint64_t *cm_g, uint64_t *ro, uint64_t *vo);
+int lfp_cm_verify(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned ell, unsigned kappa, unsigned nM, const uint64_t *const *fcoms,
+                  const uint64_t *msgs, const uint64_t *e, const uint64_t *b, const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c,
+                  const uint64_t *comh, const uint64_t *pa, const uint64_t *pb, const uint64_t *ea, const uint64_t *eb, uint64_t *cm_g, uint64_t *ro,
+                  uint64_t *vo);
 #ifdef __cplusplus
 }
 #endif

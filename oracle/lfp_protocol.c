@@ -484,3 +484,299 @@ int lfp_range_check_verify(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, u
     }
     return 0;
 }
+
+/* ---- ring-valued sumcheck (MLSumcheck over RqPoly tables): messages are ring elements, challenges constants ------------------------------ */
+typedef void (*rcomb_fn)(const u64 *vals /* ntab x 16 */, void *ctx, u64 *out16);
+static void ring_sumcheck_prove(lfp_tr *tr, u64 **tab, unsigned ntab, unsigned nv, unsigned deg, rcomb_fn comb, void *ctx, u64 *msgs, u64 *point) {
+    absorb_const(tr, nv);
+    absorb_const(tr, deg);
+    size_t n = (size_t)1 << nv;
+    u64 *vals = (u64 *)malloc((size_t)ntab * D * sizeof(u64)), *step = (u64 *)malloc((size_t)ntab * D * sizeof(u64));
+    for (unsigned rnd = 0; rnd < nv; rnd++) {
+        size_t half = n >> 1;
+        u64 *m = msgs + (size_t)rnd * (deg + 1) * D, o[D];
+        memset(m, 0, (size_t)(deg + 1) * D * sizeof(u64));
+        for (size_t b = 0; b < half; b++) {
+            for (unsigned t = 0; t < ntab; t++)
+                for (int c = 0; c < D; c++) {
+                    vals[t * D + c] = tab[t][(2 * b) * D + c];
+                    step[t * D + c] = fsub(tab[t][(2 * b + 1) * D + c], tab[t][(2 * b) * D + c]);
+                }
+            for (unsigned x = 0; x <= deg; x++) {
+                if (x) for (unsigned i = 0; i < ntab * D; i++) vals[i] = fadd(vals[i], step[i]);
+                comb(vals, ctx, o);
+                radd(m + x * D, o);
+            }
+        }
+        lfp_tr_absorb(tr, m, deg + 1);
+        u64 r = lfp_tr_challenge(tr);
+        absorb_const(tr, r);
+        point[rnd] = r;
+        for (unsigned t = 0; t < ntab; t++)
+            for (size_t b = 0; b < half; b++)
+                for (int c = 0; c < D; c++) {
+                    u64 lo = tab[t][(2 * b) * D + c], hi = tab[t][(2 * b + 1) * D + c];
+                    tab[t][b * D + c] = fadd(lo, fmul(r, fsub(hi, lo)));
+                }
+        n = half;
+    }
+    free(vals); free(step);
+}
+static int ring_sumcheck_verify(lfp_tr *tr, unsigned nv, unsigned deg, const u64 *claimed16, const u64 *msgs, u64 *point, u64 *expected16) {
+    absorb_const(tr, nv);
+    absorb_const(tr, deg);
+    u64 cur[D];
+    memcpy(cur, claimed16, sizeof(cur));
+    for (unsigned rnd = 0; rnd < nv; rnd++) {
+        const u64 *m = msgs + (size_t)rnd * (deg + 1) * D;
+        lfp_tr_absorb(tr, m, deg + 1);
+        u64 r = lfp_tr_challenge(tr);
+        absorb_const(tr, r);
+        point[rnd] = r;
+        for (int c = 0; c < D; c++) {
+            u64 y[8];
+            for (unsigned x = 0; x <= deg; x++) y[x] = m[x * D + c] % P;
+            if (fadd(y[0], y[1]) != cur[c]) return -1;
+            cur[c] = interpolate(y, deg + 1, r);
+        }
+    }
+    memcpy(expected16, cur, sizeof(cur));
+    return 0;
+}
+static void rmul_acc(u64 *acc, const u64 *a, const u64 *b) { u64 t[D]; lfp_ring_mul(a, b, t); radd(acc, t); }
+
+/* ---- Cm::prove / CmProof::verify (cm.rs:56-347 / 349-580) ---------------------------------------------------------------------------------- */
+/* calculate_t_z (cm.rs:593-603): tensor(c) (x) s' (x) (1, d', .., d'^(l-1)) (x) (1, X, .., X^(d-1)), zero-padded to n ring elements */
+static int calc_t_z(const u64 *c, unsigned logk, const u64 *sp /* kd ring */, unsigned kd, unsigned ell, size_t n, u64 *out /* n*16, zeroed */) {
+    size_t tl = (size_t)1 << logk;
+    if (tl * kd * ell * D > n) return -1;     /* "t0 too large!" */
+    u64 *tc = (u64 *)malloc(tl * sizeof(u64));
+    lfp_tensor(c, logk, tc);
+    memset(out, 0, n * D * sizeof(u64));
+    for (size_t a = 0; a < tl; a++)
+        for (unsigned b = 0; b < kd; b++) {
+            u64 pw = 1;
+            for (unsigned i = 0; i < ell; i++) {
+                for (int m = 0; m < D; m++) {
+                    /* tensor_c[a] * s'[b] * d'^i * X^m: the short element scaled, then rotated by m (X^16 = -1) */
+                    u64 *o = out + (((a * kd + b) * ell + i) * D + m) * D;
+                    u64 sc = fmul(tc[a], pw);
+                    for (int t = 0; t < D; t++) {
+                        u64 v = fmul(sp[(size_t)b * D + t], sc);
+                        if (t + m < D) o[t + m] = v; else o[t + m - D] = fsub(0, v);
+                    }
+                }
+                pw = fmul(pw, D / 2);
+            }
+        }
+    free(tc);
+    return 0;
+}
+typedef struct { unsigned L, nM, ntab; const u64 *rcps; } cm_ctx;
+/* comb_fn of cm.rs:287-311: vals = [eq | per instance: tau, m_tau, f, h, then per matrix M tau, M m_tau, M f, M h | t0, t1] */
+static void cm_comb(const u64 *vals, void *vctx, u64 *out) {
+    const cm_ctx *c = (const cm_ctx *)vctx;
+    memset(out, 0, D * sizeof(u64));
+    unsigned per = 4 + 4 * c->nM;
+    for (unsigned l = 0; l < c->L; l++) {
+        unsigned l_idx = 1 + l * per;
+        u64 inner[D] = {0}, t[D];
+        for (unsigned j = 0; j < per; j++) rscale_add(inner, vals + (size_t)(l_idx + j) * D, c->rcps[l_idx - 1 + j]);
+        rmul_acc(out, vals, inner);                                   /* eq * (...) */
+        lfp_ring_mul(vals + (size_t)l_idx * D, vals + (size_t)(c->ntab - 2) * D, t);
+        rscale_add(out, t, c->rcps[c->ntab - 3]);                     /* (tau * t0) * rc^z_idx */
+        lfp_ring_mul(vals + (size_t)l_idx * D, vals + (size_t)(c->ntab - 1) * D, t);
+        rscale_add(out, t, c->rcps[c->ntab - 2]);
+    }
+}
+/* Cm::prove.  Inputs per instance l: Mf (k x n x 16 monomials, dense), tau (n), mtau (n ring), f (n ring), comMf (k x kappa x 16 ring), fcoms
+ * (3 x kappa ring: cm_f | C_Mf | cm_mtau).  Outputs: the range check's (r .. c as lfp_range_check), comh (L x kappa), sumcheck proofs pa / pb
+ * (nvars x 3 ring each), evals ea / eb (L x (1 + nM) x 4 ring), g (L x n ring), cm_g (L x kappa), ro (2 x nvars words: ro_a | ro_b), vo (L x (1 + nM)
+ * x 2 ring).  ell = DecompParameters::l. */
+int lfp_cm_prove(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned ell, unsigned kappa, const u64 *const *Mf, const u64 *const *tau,
+                 const u64 *const *mtau, const u64 *const *f, const u64 *const *comMf, const u64 *const *fcoms, unsigned nM, const uint32_t *const *rowptr,
+                 const uint32_t *const *col, const u64 *const *val, u64 *r_out, u64 *msgs, u64 *e_out, u64 *b_out, u64 *v_out, u64 *a_out, u64 *bb_out,
+                 u64 *c_out, u64 *comh, u64 *pa, u64 *pb, u64 *ea, u64 *eb, u64 *g, u64 *cm_g, u64 *ro, u64 *vo) {
+    size_t n = (size_t)1 << nvars;
+    int rc = lfp_range_check(tr, nvars, L, k, Mf, tau, mtau, f, nM, rowptr, col, val, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out);
+    if (rc) return rc;
+    u64 s[3][D], *sp = (u64 *)malloc((size_t)k * D * D * sizeof(u64));
+    for (int i = 0; i < 3; i++) lfp_short_challenge(tr, s[i]);
+    for (unsigned i = 0; i < k * D; i++) lfp_short_challenge(tr, sp + (size_t)i * D);
+    /* h = sum_ki M_f[ki] s'_ki (cm.rs:82-103); comh = sum_ki comM_f[ki] s'_ki (:105-126) */
+    u64 **h = (u64 **)malloc(L * sizeof(u64 *));
+    for (unsigned l = 0; l < L; l++) {
+        h[l] = (u64 *)calloc(n * D, sizeof(u64));
+        for (unsigned ki = 0; ki < k; ki++)
+            for (size_t row = 0; row < n; row++)
+                for (int j = 0; j < D; j++) rmul_acc(h[l] + row * D, Mf[l] + (((size_t)ki * n + row) * D + j) * D, sp + ((size_t)ki * D + j) * D);
+        for (unsigned i = 0; i < kappa; i++) {
+            u64 *o = comh + ((size_t)l * kappa + i) * D;
+            memset(o, 0, D * sizeof(u64));
+            for (unsigned ki = 0; ki < k; ki++)
+                for (int j = 0; j < D; j++) rmul_acc(o, comMf[l] + ((((size_t)ki * kappa + i) * D) + j) * D, sp + ((size_t)ki * D + j) * D);
+        }
+    }
+    lfp_tr_absorb(tr, comh, (size_t)L * kappa);
+    unsigned logk = 0;
+    while (((unsigned)1 << logk) < kappa) logk++;
+    u64 cz[2][32];
+    for (int z = 0; z < 2; z++) for (unsigned j = 0; j < logk; j++) cz[z][j] = lfp_tr_challenge(tr);
+    u64 *t0 = (u64 *)malloc(n * D * sizeof(u64)), *t1 = (u64 *)malloc(n * D * sizeof(u64));
+    if (calc_t_z(cz[0], logk, sp, k * D, ell, n, t0) || calc_t_z(cz[1], logk, sp, k * D, ell, n, t1)) return -7;
+    /* the two sumcheckers (cm.rs:201-347) */
+    unsigned per = 4 + 4 * nM, ntab = 1 + L * per + 2;
+    for (int pass = 0; pass < 2; pass++) {
+        u64 rcv = lfp_tr_challenge(tr), *rcps = (u64 *)malloc(ntab * sizeof(u64));
+        rcps[0] = 1;
+        for (unsigned i = 1; i < ntab; i++) rcps[i] = fmul(rcps[i - 1], rcv);
+        u64 **tab = (u64 **)malloc(ntab * sizeof(u64 *));
+        tab[0] = (u64 *)calloc(n * D, sizeof(u64));
+        { u64 *eq = build_eq(r_out, nvars); for (size_t i = 0; i < n; i++) tab[0][i * D] = eq[i]; free(eq); }
+        for (unsigned l = 0; l < L; l++) {
+            u64 **tl = tab + 1 + l * per;
+            for (unsigned j = 0; j < per; j++) tl[j] = (u64 *)calloc(n * D, sizeof(u64));
+            for (size_t i = 0; i < n; i++) tl[0][i * D] = tau[l][i] % P;
+            memcpy(tl[1], mtau[l], n * D * sizeof(u64));
+            memcpy(tl[2], f[l], n * D * sizeof(u64));
+            memcpy(tl[3], h[l], n * D * sizeof(u64));
+            for (unsigned q = 0; q < nM; q++) {
+                csr m = {n, rowptr[q], col[q], val[q]};
+                for (int j = 0; j < 4; j++) spmv_ring(&m, tl[j], tl[4 + 4 * q + j]);
+            }
+        }
+        tab[ntab - 2] = (u64 *)malloc(n * D * sizeof(u64)); memcpy(tab[ntab - 2], t0, n * D * sizeof(u64));
+        tab[ntab - 1] = (u64 *)malloc(n * D * sizeof(u64)); memcpy(tab[ntab - 1], t1, n * D * sizeof(u64));
+        cm_ctx ctx = {L, nM, ntab, rcps};
+        u64 *proof = pass ? pb : pa, *evs = pass ? eb : ea, *rop = ro + (size_t)pass * nvars;
+        ring_sumcheck_prove(tr, tab, ntab, nvars, 2, cm_comb, &ctx, proof, rop);
+        /* evals: every instance table at ro = the fully fixed tables (one entry left) */
+        for (unsigned l = 0; l < L; l++)
+            for (unsigned j = 0; j < per; j++) memcpy(evs + ((size_t)l * per + j) * D, tab[1 + l * per + j], D * sizeof(u64));
+        lfp_tr_absorb(tr, evs, (size_t)L * per);
+        for (unsigned t = 0; t < ntab; t++) free(tab[t]);
+        free(tab); free(rcps);
+    }
+    /* g = s0 tau + s1 m_tau + s2 f + h (cm.rs:164-181); x = CmProof::x (cm.rs:545-580) */
+    for (unsigned l = 0; l < L; l++) {
+        for (size_t i = 0; i < n; i++) {
+            u64 *o = g + ((size_t)l * n + i) * D, tr16[D] = {0};
+            memcpy(o, h[l] + i * D, D * sizeof(u64));
+            tr16[0] = tau[l][i] % P;
+            rmul_acc(o, s[0], tr16);
+            rmul_acc(o, s[1], mtau[l] + i * D);
+            rmul_acc(o, s[2], f[l] + i * D);
+        }
+        for (unsigned i = 0; i < kappa; i++) {
+            u64 *o = cm_g + ((size_t)l * kappa + i) * D;
+            memcpy(o, comh + ((size_t)l * kappa + i) * D, D * sizeof(u64));
+            rmul_acc(o, s[0], fcoms[l] + ((size_t)1 * kappa + i) * D);     /* C_Mf */
+            rmul_acc(o, s[1], fcoms[l] + ((size_t)2 * kappa + i) * D);     /* cm_mtau */
+            rmul_acc(o, s[2], fcoms[l] + ((size_t)0 * kappa + i) * D);     /* cm_f */
+        }
+        for (unsigned q = 0; q < 1 + nM; q++)
+            for (int pass = 0; pass < 2; pass++) {
+                const u64 *e4 = (pass ? eb : ea) + ((size_t)l * per + 4 * q) * D;
+                u64 *o = vo + (((size_t)l * (1 + nM) + q) * 2 + pass) * D;
+                memcpy(o, e4 + 3 * D, D * sizeof(u64));
+                rmul_acc(o, s[0], e4); rmul_acc(o, s[1], e4 + D); rmul_acc(o, s[2], e4 + 2 * D);
+            }
+        free(h[l]);
+    }
+    free(h); free(sp); free(t0); free(t1);
+    return 0;
+}
+/* CmProof::verify (cm.rs:349-543).  0 = accepted (cm_g / ro / vo are then the ComX of cm.rs:545-580, recomputed from the proof);
+ * -1..-5 range check, -6 a sumcheck, -8 final evaluation of a sumchecker */
+int lfp_cm_verify(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned ell, unsigned kappa, unsigned nM, const u64 *const *fcoms, const u64 *msgs,
+                  const u64 *e, const u64 *b, const u64 *v, const u64 *a, const u64 *bb, const u64 *c, const u64 *comh, const u64 *pa, const u64 *pb,
+                  const u64 *ea, const u64 *eb, u64 *cm_g, u64 *ro, u64 *vo) {
+    size_t n = (size_t)1 << nvars;
+    u64 *r = (u64 *)malloc(nvars * sizeof(u64));
+    int rc = lfp_range_check_verify(tr, nvars, L, k, nM, msgs, e, b, v, a, bb, c, r);
+    if (rc) { free(r); return rc; }
+    u64 s[3][D], *sp = (u64 *)malloc((size_t)k * D * D * sizeof(u64));
+    for (int i = 0; i < 3; i++) lfp_short_challenge(tr, s[i]);
+    for (unsigned i = 0; i < k * D; i++) lfp_short_challenge(tr, sp + (size_t)i * D);
+    lfp_tr_absorb(tr, comh, (size_t)L * kappa);
+    unsigned logk = 0;
+    while (((unsigned)1 << logk) < kappa) logk++;
+    u64 cz[2][32];
+    for (int z = 0; z < 2; z++) for (unsigned j = 0; j < logk; j++) cz[z][j] = lfp_tr_challenge(tr);
+    /* u[l][q] = sum over the instance's k 16 columns of e[q][..] * s'  (cm.rs:383-401) */
+    unsigned per = 4 + 4 * nM, z_idx = L * per;
+    u64 *u = (u64 *)calloc((size_t)L * (1 + nM) * D, sizeof(u64));
+    for (unsigned l = 0; l < L; l++)
+        for (unsigned q = 0; q < 1 + nM; q++)
+            for (unsigned j = 0; j < k * D; j++) rmul_acc(u + ((size_t)l * (1 + nM) + q) * D, e + (((size_t)q * L * k + (size_t)l * k) * D + j) * D, sp + (size_t)j * D);
+    size_t tl = (size_t)1 << logk;
+    u64 *tc0 = (u64 *)malloc(tl * sizeof(u64)), *tc1 = (u64 *)malloc(tl * sizeof(u64));
+    lfp_tensor(cz[0], logk, tc0); lfp_tensor(cz[1], logk, tc1);
+    u64 *tcch = (u64 *)calloc((size_t)2 * L * D, sizeof(u64));
+    for (unsigned l = 0; l < L; l++)
+        for (unsigned i = 0; i < kappa && i < tl; i++) {
+            rscale_add(tcch + ((size_t)0 * L + l) * D, comh + ((size_t)l * kappa + i) * D, tc0[i]);
+            rscale_add(tcch + ((size_t)1 * L + l) * D, comh + ((size_t)l * kappa + i) * D, tc1[i]);
+        }
+    u64 *t0 = (u64 *)malloc(n * D * sizeof(u64)), *t1 = (u64 *)malloc(n * D * sizeof(u64));
+    if (calc_t_z(cz[0], logk, sp, k * D, ell, n, t0) || calc_t_z(cz[1], logk, sp, k * D, ell, n, t1)) rc = -7;
+    for (int pass = 0; pass < 2 && !rc; pass++) {
+        u64 rcv = lfp_tr_challenge(tr), *rcps = (u64 *)malloc((z_idx + 2) * sizeof(u64));
+        rcps[0] = 1;
+        for (unsigned i = 1; i < z_idx + 2; i++) rcps[i] = fmul(rcps[i - 1], rcv);
+        u64 claim[D] = {0};
+        for (unsigned l = 0; l < L; l++) {
+            unsigned l_idx = l * per;
+            for (unsigned q = 0; q < 1 + nM; q++) {
+                unsigned idx = l_idx + 4 * q;
+                claim[0] = fadd(claim[0], fmul(a[(size_t)l * (1 + nM) + q] % P, rcps[idx]));
+                rscale_add(claim, bb + ((size_t)l * (1 + nM) + q) * D, rcps[idx + 1]);
+                rscale_add(claim, c + ((size_t)l * (1 + nM) + q) * D, rcps[idx + 2]);
+                rscale_add(claim, u + ((size_t)l * (1 + nM) + q) * D, rcps[idx + 3]);
+            }
+            rscale_add(claim, tcch + ((size_t)0 * L + l) * D, rcps[z_idx]);
+            rscale_add(claim, tcch + ((size_t)1 * L + l) * D, rcps[z_idx + 1]);
+        }
+        const u64 *proof = pass ? pb : pa, *evs = pass ? eb : ea;
+        u64 *rop = ro + (size_t)pass * nvars, expected[D];
+        if (ring_sumcheck_verify(tr, nvars, 2, claim, proof, rop, expected)) { rc = -6; free(rcps); break; }
+        u64 *eqo = build_eq(rop, nvars), t0r[D], t1r[D];
+        mle_eval_ring(t0, n, eqo, t0r);
+        mle_eval_ring(t1, n, eqo, t1r);
+        free(eqo);
+        lfp_tr_absorb(tr, evs, (size_t)L * per);
+        u64 eq = eq_eval(r, rop, nvars), ev16[D] = {0};
+        for (unsigned l = 0; l < L; l++) {
+            const u64 *el = evs + (size_t)l * per * D;
+            u64 inner[D] = {0};
+            for (unsigned j = 0; j < per; j++) rscale_add(inner, el + (size_t)j * D, rcps[l * per + j]);
+            rscale_add(ev16, inner, eq);
+            u64 t[D];
+            lfp_ring_mul(t0r, el, t); rscale_add(ev16, t, rcps[z_idx]);
+            lfp_ring_mul(t1r, el, t); rscale_add(ev16, t, rcps[z_idx + 1]);
+        }
+        if (memcmp(ev16, expected, sizeof(ev16))) rc = -8;
+        free(rcps);
+    }
+    if (!rc) {   /* CmProof::x */
+        unsigned q, pass;
+        for (unsigned l = 0; l < L; l++) {
+            for (unsigned i = 0; i < kappa; i++) {
+                u64 *o = cm_g + ((size_t)l * kappa + i) * D;
+                memcpy(o, comh + ((size_t)l * kappa + i) * D, D * sizeof(u64));
+                rmul_acc(o, s[0], fcoms[l] + ((size_t)1 * kappa + i) * D);
+                rmul_acc(o, s[1], fcoms[l] + ((size_t)2 * kappa + i) * D);
+                rmul_acc(o, s[2], fcoms[l] + ((size_t)0 * kappa + i) * D);
+            }
+            for (q = 0; q < 1 + nM; q++)
+                for (pass = 0; pass < 2; pass++) {
+                    const u64 *e4 = (pass ? eb : ea) + ((size_t)l * per + 4 * q) * D;
+                    u64 *o = vo + (((size_t)l * (1 + nM) + q) * 2 + pass) * D;
+                    memcpy(o, e4 + 3 * D, D * sizeof(u64));
+                    rmul_acc(o, s[0], e4); rmul_acc(o, s[1], e4 + D); rmul_acc(o, s[2], e4 + 2 * D);
+                }
+        }
+    }
+    free(r); free(sp); free(u); free(tc0); free(tc1); free(tcch); free(t0); free(t1);
+    return rc;
+}

@@ -264,3 +264,44 @@ def range_check_verify(tr, nvars, d, k):
     L, nM = arr["b"].shape[0], arr["a"].shape[1] - 1
     r = np.zeros(nvars, dtype=np.uint64)
     return _plib().lfp_range_check_verify(tr.h, nvars, L, k, nM, *[_p(arr[key].reshape(-1)) for key in ("msgs", "e", "b", "v", "a", "bb", "c")], _p(r)), r
+
+
+def cm_prove(tr, nvars, instances, k, ell, kappa, mats=()):
+    """Cm::prove (cm.rs:56-347).  instances: dicts with Mf, tau, mtau, f (as range_check) + comMf (k, kappa, 16, 16), fcoms (3, kappa, 16: cm_f | C_Mf | cm_mtau)"""
+    L, nM = len(instances), len(mats)
+    n = 1 << nvars
+    keep, rp, cp, vp = csr_args(mats)
+    keys = ("Mf", "tau", "mtau", "f", "comMf", "fcoms")
+    arrs = {key: [np.ascontiguousarray(i[key], dtype=np.uint64) for i in instances] for key in keys}
+    ptrs = {key: (u64p * L)(*[_p(a.reshape(-1)) for a in v]) for key, v in arrs.items()}
+    per = 4 + 4 * nM
+    o = {"r": np.zeros(nvars, dtype=np.uint64), "msgs": np.zeros((nvars, 4, D), dtype=np.uint64), "e": np.zeros((1 + nM, L * k, D, D), dtype=np.uint64),
+         "b": np.zeros((L, D), dtype=np.uint64), "v": np.zeros((L, D), dtype=np.uint64), "a": np.zeros((L, 1 + nM), dtype=np.uint64),
+         "bb": np.zeros((L, 1 + nM, D), dtype=np.uint64), "c": np.zeros((L, 1 + nM, D), dtype=np.uint64), "comh": np.zeros((L, kappa, D), dtype=np.uint64),
+         "pa": np.zeros((nvars, 3, D), dtype=np.uint64), "pb": np.zeros((nvars, 3, D), dtype=np.uint64), "ea": np.zeros((L, per, D), dtype=np.uint64),
+         "eb": np.zeros((L, per, D), dtype=np.uint64), "g": np.zeros((L, n, D), dtype=np.uint64), "cm_g": np.zeros((L, kappa, D), dtype=np.uint64),
+         "ro": np.zeros((2, nvars), dtype=np.uint64), "vo": np.zeros((L, 1 + nM, 2, D), dtype=np.uint64)}
+    L_ = _plib()
+    u32pp, u64pp = C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64p)
+    L_.lfp_cm_prove.argtypes = [C.c_void_p] + [C.c_uint] * 5 + [u64pp] * 6 + [C.c_uint, u32pp, u32pp, u64pp] + [u64p] * 17
+    rc = L_.lfp_cm_prove(tr.h, nvars, L, k, ell, kappa, *[ptrs[key] for key in keys], nM, rp, cp, vp,
+                         *[_p(o[key].reshape(-1)) for key in ("r", "msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb", "g", "cm_g", "ro", "vo")])
+    if rc:
+        raise ValueError(f"lfp_cm_prove: {rc}")
+    o.update(k=k, ell=ell, kappa=kappa, nvars=nvars)
+    return o
+
+
+def cm_verify(tr, proof, fcoms):
+    """CmProof::verify (cm.rs:349-580) -> (rc, dict(cm_g, ro, vo))"""
+    nvars, k, ell, kappa = proof["nvars"], proof["k"], proof["ell"], proof["kappa"]
+    L, nM = proof["b"].shape[0], proof["a"].shape[1] - 1
+    fc = [np.ascontiguousarray(x, dtype=np.uint64) for x in fcoms]
+    fptr = (u64p * L)(*[_p(x.reshape(-1)) for x in fc])
+    x = {"cm_g": np.zeros((L, kappa, D), dtype=np.uint64), "ro": np.zeros((2, nvars), dtype=np.uint64), "vo": np.zeros((L, 1 + nM, 2, D), dtype=np.uint64)}
+    L_ = _plib()
+    L_.lfp_cm_verify.argtypes = [C.c_void_p] + [C.c_uint] * 6 + [C.POINTER(u64p)] + [u64p] * 15
+    arr = {key: np.ascontiguousarray(proof[key], dtype=np.uint64) for key in ("msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb")}
+    rc = L_.lfp_cm_verify(tr.h, nvars, L, k, ell, kappa, nM, fptr, *[_p(arr[key].reshape(-1)) for key in ("msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb")],
+                          _p(x["cm_g"].reshape(-1)), _p(x["ro"].reshape(-1)), _p(x["vo"].reshape(-1)))
+    return rc, x

@@ -122,3 +122,35 @@ def test_range_check_completeness_and_soundness(L, nM):
         t = {kk: vv.copy() for kk, vv in d.items()}
         t[key][idx] = (int(t[key][idx]) + 1) % P
         assert lfp.range_check_verify(lfp.Transcript(), nvars, t, k)[0] != 0, key
+
+
+def _cm_instance(n, kappa, k, ell, A, seed):
+    v = (lfp.splitmix(seed + 1, 0, n * D) % np.uint64(63)).astype(np.int64) - 31
+    f = np.where(v < 0, np.uint64(P) - (-v).astype(np.uint64), v.astype(np.uint64)).reshape(n, D)
+    rg = lfp.rg_from_f(f, A, D // 2, k, ell)
+    tau_i = np.array([int(t) if int(t) <= P // 2 else int(t) - P for t in rg["tau"]], dtype=np.int8)
+    return {"Mf": lfp.exp_dense(rg["Df"]), "tau": rg["tau"], "mtau": lfp.exp_dense(tau_i), "f": f, "comMf": rg["comMf"],
+            "fcoms": np.stack([rg["cm_f"], rg["C_Mf"], rg["cm_mtau"]])}
+
+
+@pytest.mark.parametrize("L,nM,kappa,nvars", [(1, 0, 1, 14), (1, 1, 2, 15), (2, 1, 1, 14)])
+def test_cm_prove_completeness_and_soundness(L, nM, kappa, nvars):
+    """cm.rs:606-666 (test_com: n = 2^15, kappa 2, one matrix) and the two-instance shape Mlin::mlin feeds it: the restated CmProof::verify accepts,
+    recomputes the same ComX, and rejects tampered proofs; the double-commitment identity sum_x tau(x) t(x) = tensor(c) . comh holds"""
+    n, k, ell = 1 << nvars, 2, 22
+    A = lfp.splitmix(3, 0, kappa * n * D).reshape(kappa, n, D)
+    insts = [_cm_instance(n, kappa, k, ell, A, 30 + 7 * i) for i in range(L)]
+    mats = [_ident(n, first=2)] * nM
+    pr = lfp.cm_prove(lfp.Transcript(), nvars, insts, k, ell, kappa, mats)
+    rc, x = lfp.cm_verify(lfp.Transcript(), pr, [i["fcoms"] for i in insts])
+    assert rc == 0
+    for key in ("cm_g", "ro", "vo"):
+        assert (x[key] == pr[key]).all(), key
+    # g = s0 tau + s1 m_tau + s2 f + h commits to cm_g (the homomorphism the fold relies on): A g = cm_g
+    for l in range(L):
+        assert (lfp.commit(A, pr["g"][l]) == pr["cm_g"][l]).all()
+    for key, idx in (("comh", (0, 0, 1)), ("pa", (2, 1, 3)), ("pb", (0, 0, 0)), ("ea", (0, 2, 5)), ("eb", (L - 1, 3, 0)), ("a", (0, 0)), ("e", (0, 1, 2, 3))):
+        t = dict(pr)
+        t[key] = pr[key].copy()
+        t[key][idx] = (int(t[key][idx]) + 1) % P
+        assert lfp.cm_verify(lfp.Transcript(), t, [i["fcoms"] for i in insts])[0] != 0, key
