@@ -115,6 +115,24 @@ int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *t
 /* Dcom::verify (rgchk.rs:193-258), host only: stages 1-3 set check, 4 ct(psi b) != a, 5 ct(psi sum_i (d/2)^i u_i) != v / c */
 int lfplus_range_check_verify(lfplus_transcript *t, uint32_t nvars, uint32_t L, uint32_t k, uint32_t nM, const uint64_t *msgs, const uint64_t *e, const uint64_t *b,
                               const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c, uint64_t *r_out, int *stage);
+/* Cm::prove (src/cm.rs:56-347) over L resident instances (as lfplus_range_check; ell = DecompParameters::l): the range check, the folding
+ * challenges s (3) and s' (k d), h = M_f s' and comh, the two degree-2 ring-valued sumcheckers, the folded witness g = s0 tau + s1 m_tau + s2 f + h
+ * and the folded instance ComX (cm.rs:545-580).  Outputs: r .. c_out as lfplus_range_check; comh (L x kappa ring elements); pa / pb (nvars x 3 ring
+ * elements: the sumcheck messages); ea / eb (L x (4 + 4 nM) ring elements in the reference's table order: tau, m_tau, f, h, then per matrix M tau,
+ * M m_tau, M f, M h); cm_g (L x kappa); ro (ro_a | ro_b, 2 x nvars words); vo (L x (1 + nM) x 2).  g stays on the device in ctxs[l]
+ * (lfplus_cm_read_g: n ring elements); g_out may be null or receive L x n ring elements.  LFPLUS_E_ARG when t0 does not fit n (the reference panics). */
+int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *t, uint32_t ell, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col,
+                    const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out,
+                    uint64_t *c_out, uint64_t *comh, uint64_t *pa, uint64_t *pb, uint64_t *ea, uint64_t *eb, uint64_t *cm_g, uint64_t *ro, uint64_t *vo,
+                    uint64_t *g_out);
+int lfplus_cm_read_g(lfplus_ctx *ctx, uint64_t *g_out);
+/* CmProof::verify (cm.rs:349-543), host only.  fcoms[l] = cm_f | C_Mf | cm_mtau of instance l (kappa ring elements each).  LFPLUS_OK: accepted, and
+ * cm_g / ro / vo are the folded instance recomputed from the proof.  LFPLUS_E_REJECT with *stage = 1-5 (range check), 6 (a sumcheck round),
+ * 7 (t0 does not fit n), 8 (final evaluation of a sumchecker) */
+int lfplus_cm_verify(lfplus_transcript *t, uint32_t nvars, uint32_t L, uint32_t k, uint32_t ell, uint32_t kappa, uint32_t nM, const uint64_t *const *fcoms,
+                     const uint64_t *msgs, const uint64_t *e, const uint64_t *b, const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c,
+                     const uint64_t *comh, const uint64_t *pa, const uint64_t *pb, const uint64_t *ea, const uint64_t *eb, uint64_t *cm_g, uint64_t *ro,
+                     uint64_t *vo, int *stage);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     for (void *p : {(void *)c->A, (void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
-                    (void *)c->err_d})
+                    (void *)c->err_d, (void *)c->g})
         if (p) (void)hipFree(p);
     (void)hipStreamDestroy(c->st);
     delete c;

@@ -18,7 +18,7 @@ struct lfplus_ctx {
     u64 n = 0, nf = 0;
     // results of the last from_f
     int8_t *Df = nullptr, *mtau = nullptr;
-    u64 *comMf = nullptr, *tau = nullptr, *coms = nullptr;   // coms: cm_f | C_Mf | cm_mtau, kappa*16 each
+    u64 *comMf = nullptr, *tau = nullptr, *coms = nullptr;   // comMf: comM_f (k, kappa, 16, 16) | cm_f; coms: C_Mf | cm_mtau (kappa*16 words each)
     u32 k = 0, l = 0;
     size_t Df_cap = 0, comMf_cap = 0;
     // partial sums
@@ -26,6 +26,9 @@ struct lfplus_ctx {
     size_t part_cap = 0;
     u32 *err_d = nullptr;
     bool have = false;
+    // the folded witness of the last lfplus_cm_prove (cm.rs:164-181): n ring elements
+    u64 *g = nullptr;
+    u64 g_n = 0;
 };
 
 #define HIPCHK(c, x)                                                                        \

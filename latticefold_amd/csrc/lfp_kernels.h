@@ -67,6 +67,16 @@ void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, 
 // out[0] = sum_i x[i xstride] y[i]; part: eval_chunks(n) * 4
 void launch_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part, u64 *out, hipStream_t s);
 void launch_spmvT_eq(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s);
+// ---- Cm::prove (cm.rs:56-347)
+struct CmShort { int32_t v[3][16]; };     // the three folding challenges s (centred coefficients)
+struct CmDesc { u32 L, nM; };
+void launch_cm_materialize(const int8_t *dig, const u64 *tau, size_t n, u64 *out, hipStream_t s);
+void launch_to_mont(const u64 *in, size_t n, u64 *out, hipStream_t s);
+void launch_cm_h(const int8_t *Df, size_t n, u32 k, const int32_t *sp, u64 *h, hipStream_t s);
+void launch_cm_g(const u64 *tau, const int8_t *mtau, const u64 *f, const u64 *h, size_t n, const CmShort &s, u64 *g, hipStream_t st);
+u32 cm_round_blocks(size_t half);
+void launch_cm_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 *part /* blocks * 48 */, hipStream_t s);
+void launch_cm_fix(const u64 *in, size_t ld_in, u64 *out, size_t ld_out, u32 w, u32 ntab, size_t half, u64 rM, hipStream_t s);
 void launch_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt, hipStream_t s);
 void launch_tensor_product(const u64 *a, u64 m, const u64 *b, u64 n, u64 *out, hipStream_t s);
 }  // namespace lfp

@@ -142,7 +142,7 @@ struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
-    template <class T> T *as() { return (T *)p; }
+    template <class T> T *as() const { return (T *)p; }
 };
 struct SetRef { const int8_t *dig; u32 ncols; };   // device pointer to the exponent digits [n][ncols]
 struct DevCsc { DevBuf colptr, rowidx, val; };
@@ -316,13 +316,11 @@ extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t n
 
 // Rg::range_check (rgchk.rs:81-186) on L resident instances: ctxs[l] holds the witness f_l and the results of lfplus_rg_from_f (D_f, tau,
 // m_tau) -- all on the same device, same n = 2^nvars and k.  Runs on ctxs[0]'s stream.
-extern "C" int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, uint32_t nM, const uint32_t *const *rowptr,
-                                  const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out,
-                                  uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out) {
-    if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
+namespace {
+int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, const std::vector<std::unique_ptr<DevCsc>> &M, uint64_t *r_out, uint64_t *msgs,
+                     uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, ScOut &so) {
     lfplus_ctx *c = ctxs[0];
-    if (!tr || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out || (nM && (!rowptr || !col || !val)))
-        return fail(c, LFPLUS_E_ARG, "lfplus_range_check: bad arguments");
+    const u32 nM = (u32)M.size();
     const u64 n = c->n;
     const u32 k = c->k;
     if (!n || (n & (n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_range_check: n must be a power of two");
@@ -337,11 +335,7 @@ extern "C" int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_tr
     for (u32 l = 0; l < L; l++)
         for (u32 ki = 0; ki < k; ki++) mats.push_back({ctxs[l]->Df + (size_t)ki * n * 16, 16});
     for (u32 l = 0; l < L; l++) vecs.push_back({ctxs[l]->mtau, 1});
-    std::vector<std::unique_ptr<DevCsc>> M;
-    int rc = upload_csc(c, n, nM, rowptr, col, val, M);
-    if (rc) return rc;
-    ScOut so;
-    rc = set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so);
+    int rc = set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so);
     if (rc) return rc;
     // evaluations at r (rgchk.rs:107-170): v / c[0] = f at r, a[0] = tau at r, b[0] = the set check's b; per matrix M_q: ct(M_q tau), M_q m_tau, M_q f
     DevBuf ev;
@@ -373,6 +367,22 @@ extern "C" int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_tr
         tr->absorb_ring(c_out + (size_t)l * (1 + nM) * D, 1 + nM);
     }
     return LFPLUS_OK;
+}
+}  // namespace
+extern "C" int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, uint32_t nM, const uint32_t *const *rowptr,
+                                  const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out,
+                                  uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out) {
+    if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
+    lfplus_ctx *c = ctxs[0];
+    if (!tr || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out || (nM && (!rowptr || !col || !val)))
+        return fail(c, LFPLUS_E_ARG, "lfplus_range_check: bad arguments");
+    if (!c->n || (c->n & (c->n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_range_check: n must be a power of two");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<std::unique_ptr<DevCsc>> M;
+    int rc = upload_csc(c, c->n, nM, rowptr, col, val, M);
+    if (rc) return rc;
+    ScOut so;
+    return range_check_core(ctxs, L, tr, M, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, so);
 }
 
 // ---- verifiers (host only: no GPU, no context) ------------------------------------------------------------------------------------------
@@ -489,6 +499,387 @@ extern "C" int lfplus_range_check_verify(lfplus_transcript *tr, uint32_t nvars, 
                 }
         }
     }
+    if (stage) *stage = st;
+    return st ? LFPLUS_E_REJECT : LFPLUS_OK;
+}
+
+// ---- Cm::prove / CmProof::verify (cm.rs:56-347 / 349-580) ----------------------------------------------------------------------------------
+namespace {
+// negacyclic product mod X^16 + 1 of canonical elements, accumulated: acc += a * b
+void rmul_acc(u64 *acc, const u64 *a, const u64 *b) {
+    for (int i = 0; i < D; i++) {
+        if (!a[i]) continue;
+        for (int j = 0; j < D; j++) {
+            const u64 pr = fmul(a[i], b[j]);
+            if (i + j < D) acc[i + j] = fadd(acc[i + j], pr);
+            else acc[i + j - D] = fsub(acc[i + j - D], pr);
+        }
+    }
+}
+void rscale_acc(u64 *acc, const u64 *e, u64 s) { for (int i = 0; i < D; i++) acc[i] = fadd(acc[i], fmul(e[i] % P, s)); }
+// tensor (utils.rs:68-83)
+std::vector<u64> tensor(const u64 *c, u32 nv) {
+    std::vector<u64> t(1, 1);
+    for (u32 j = 0; j < nv; j++) {
+        std::vector<u64> nx(t.size() * 2);
+        for (size_t i = 0; i < t.size(); i++) { nx[i] = fmul(t[i], fsub(1, c[j])); nx[t.size() + i] = fmul(t[i], c[j]); }
+        t.swap(nx);
+    }
+    return t;
+}
+struct CmChallenges {
+    u64 s[3][D];
+    std::vector<u64> sp;       // k*16 short ring elements
+    u64 cz[2][32];
+    u32 logk;
+};
+// the challenges both sides draw after the range check (cm.rs:66-80 / 366-381); comh is absorbed between s' and c
+void cm_challenges(lfplus_transcript *tr, u32 k, u32 kappa, const u64 *comh, u32 L, CmChallenges &ch) {
+    auto sc = [&](u64 *o) {
+        uint8_t bs[D];
+        tr->squeeze_bytes(D, bs);
+        for (int i = 0; i < D; i++) { const int v = (int)bs[i] - 128; o[i] = v >= 0 ? (u64)v : P - (u64)(-v); }
+    };
+    for (int i = 0; i < 3; i++) sc(ch.s[i]);
+    ch.sp.resize((size_t)k * D * D);
+    for (u32 i = 0; i < k * D; i++) sc(&ch.sp[(size_t)i * D]);
+    (void)comh; (void)L; (void)kappa;
+}
+void cm_c_challenges(lfplus_transcript *tr, u32 kappa, CmChallenges &ch) {
+    ch.logk = 0;
+    while (((u32)1 << ch.logk) < kappa) ch.logk++;
+    for (int z = 0; z < 2; z++) for (u32 j = 0; j < ch.logk; j++) ch.cz[z][j] = tr->challenge();
+}
+// calculate_t_z (cm.rs:593-603): tensor(c) (x) s' (x) (1, d', .., d'^(l-1)) (x) (1, X, .., X^15), zero padded to n ring elements; the reference
+// panics when it does not fit ("t0 too large!")
+bool calc_t(const u64 *cz, u32 logk, const std::vector<u64> &sp, u32 kd, u32 ell, size_t n, std::vector<u64> &out) {
+    const size_t tl = (size_t)1 << logk;
+    if (tl * kd * ell * D > n) return false;
+    const std::vector<u64> tc = tensor(cz, logk);
+    out.assign(n * D, 0);
+    for (size_t a = 0; a < tl; a++)
+        for (u32 b = 0; b < kd; b++) {
+            u64 pw = 1;
+            for (u32 i = 0; i < ell; i++) {
+                const u64 sc = fmul(tc[a], pw);
+                for (int m = 0; m < D; m++) {
+                    u64 *o = &out[(((a * kd + b) * ell + i) * D + m) * D];
+                    for (int t = 0; t < D; t++) {
+                        const u64 v = fmul(sp[(size_t)b * D + t], sc);
+                        if (t + m < D) o[t + m] = v; else o[t + m - D] = fsub(0, v);
+                    }
+                }
+                pw = fmul(pw, D / 2);
+            }
+        }
+    return true;
+}
+// CmProof::x (cm.rs:545-580): cm_g = comh + s0 C_Mf + s1 cm_mtau + s2 cm_f, vo = e[4q + 3] + s0 e[4q] + s1 e[4q + 1] + s2 e[4q + 2] at ro_a and ro_b
+void cm_x(const CmChallenges &ch, u32 L, u32 kappa, u32 nM, const u64 *const *fcoms, const u64 *comh, const u64 *ea, const u64 *eb, u64 *cm_g, u64 *vo) {
+    const u32 per = 4 + 4 * nM;
+    for (u32 l = 0; l < L; l++) {
+        for (u32 i = 0; i < kappa; i++) {
+            u64 *o = cm_g + ((size_t)l * kappa + i) * D;
+            memcpy(o, comh + ((size_t)l * kappa + i) * D, D * 8);
+            rmul_acc(o, ch.s[0], fcoms[l] + ((size_t)1 * kappa + i) * D);
+            rmul_acc(o, ch.s[1], fcoms[l] + ((size_t)2 * kappa + i) * D);
+            rmul_acc(o, ch.s[2], fcoms[l] + ((size_t)0 * kappa + i) * D);
+        }
+        for (u32 q = 0; q < 1 + nM; q++)
+            for (int pass = 0; pass < 2; pass++) {
+                const u64 *e4 = (pass ? eb : ea) + ((size_t)l * per + 4 * q) * D;
+                u64 *o = vo + (((size_t)l * (1 + nM) + q) * 2 + pass) * D;
+                memcpy(o, e4 + 3 * D, D * 8);
+                rmul_acc(o, ch.s[0], e4); rmul_acc(o, ch.s[1], e4 + D); rmul_acc(o, ch.s[2], e4 + 2 * D);
+            }
+    }
+}
+struct DevCsr { DevBuf rowptr, col, valM; };
+}  // namespace
+
+// Cm::prove on L resident instances (as lfplus_range_check: ctxs[l] holds f_l, the commitment matrix and the from_f results; `ell` is
+// DecompParameters::l).  Outputs (host): the range check's r .. c exactly as lfplus_range_check writes them; comh L x kappa ring elements; the two
+// sumcheck proofs pa / pb (nvars x 3 ring elements); their evaluations ea / eb (L x (4 + 4 nM) ring elements, the reference's table order); the
+// folded instance x = (cm_g L x kappa, ro = ro_a | ro_b 2 x nvars words, vo L x (1 + nM) x 2).  The folded witness g_l stays on the device in
+// ctxs[l] (lfplus_cm_read_g); g_out, when not null, receives L x n ring elements.
+extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, uint32_t ell, uint32_t nM, const uint32_t *const *rowptr,
+                               const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out,
+                               uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, uint64_t *comh, uint64_t *pa, uint64_t *pb, uint64_t *ea,
+                               uint64_t *eb, uint64_t *cm_g, uint64_t *ro, uint64_t *vo, uint64_t *g_out) {
+    if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
+    lfplus_ctx *c = ctxs[0];
+    if (!tr || !ell || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out || !comh || !pa || !pb || !ea || !eb || !cm_g || !ro || !vo ||
+        (nM && (!rowptr || !col || !val)))
+        return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: bad arguments");
+    const size_t n = c->n;
+    if (!n || (n & (n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: n must be a power of two");
+    u32 nvars = 0;
+    while (((size_t)1 << nvars) < n) nvars++;
+    const u32 k = c->k, kappa = c->kappa;
+    for (u32 l = 0; l < L; l++)
+        if (!ctxs[l] || ctxs[l]->kappa != kappa) return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: instances of different shapes");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<std::unique_ptr<DevCsc>> M;
+    int rc = upload_csc(c, n, nM, rowptr, col, val, M);
+    if (rc) return rc;
+    ScOut so;
+    rc = range_check_core(ctxs, L, tr, M, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, so);
+    if (rc) return rc;
+    CmChallenges ch;
+    cm_challenges(tr, k, kappa, nullptr, L, ch);
+    // h_l = sum_ki M_f[ki] s'_ki (cm.rs:82-103) on the device; comh_l = sum_ki comM_f[ki] s'_ki (:105-126) on the host (k kappa 256 products)
+    std::vector<int32_t> spi((size_t)k * D * D);
+    for (size_t i = 0; i < spi.size(); i++) spi[i] = ch.sp[i] > P / 2 ? -(int32_t)(P - ch.sp[i]) : (int32_t)ch.sp[i];
+    DevBuf spd;
+    std::vector<std::unique_ptr<DevBuf>> h(L);
+    if (spd.alloc(spi.size() * 4)) return fail(c, LFPLUS_E_HIP, "hipMalloc (s')");
+    HIPCHK(c, hipMemcpyAsync(spd.p, spi.data(), spi.size() * 4, hipMemcpyHostToDevice, c->st));
+    std::vector<std::vector<u64>> fcoms(L, std::vector<u64>((size_t)3 * kappa * D));
+    std::vector<u64> comMf((size_t)k * kappa * D * D);
+    for (u32 l = 0; l < L; l++) {
+        h[l].reset(new DevBuf);
+        if (h[l]->alloc(n * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (h)");
+        lfp::launch_cm_h(ctxs[l]->Df, n, k, spd.as<int32_t>(), h[l]->as<u64>(), c->st);
+        HIPCHK(c, hipMemcpyAsync(comMf.data(), ctxs[l]->comMf, comMf.size() * 8, hipMemcpyDeviceToHost, c->st));
+        // fcoms[l] = cm_f | C_Mf | cm_mtau; the context keeps cm_f behind comM_f and C_Mf | cm_mtau in coms
+        HIPCHK(c, hipMemcpyAsync(fcoms[l].data(), ctxs[l]->comMf + comMf.size(), (size_t)kappa * D * 8, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(fcoms[l].data() + (size_t)kappa * D, ctxs[l]->coms, (size_t)2 * kappa * D * 8, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        for (u32 i = 0; i < kappa; i++) {
+            u64 *o = comh + ((size_t)l * kappa + i) * D;
+            memset(o, 0, D * 8);
+            for (u32 ki = 0; ki < k; ki++)
+                for (int j = 0; j < D; j++) rmul_acc(o, &comMf[((((size_t)ki * kappa + i) * D) + j) * D], &ch.sp[((size_t)ki * D + j) * D]);
+        }
+    }
+    tr->absorb_ring(comh, (size_t)L * kappa);
+    cm_c_challenges(tr, kappa, ch);
+    std::vector<u64> t0, t1;
+    if (!calc_t(ch.cz[0], ch.logk, ch.sp, k * D, ell, n, t0) || !calc_t(ch.cz[1], ch.logk, ch.sp, k * D, ell, n, t1))
+        return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: t0 too large (kappa' * k d * l * d > n; the reference panics, cm.rs:601)");
+    // tables.  Scalars (Montgomery): eq(r, .) | tau_l.  Ring (canonical): per instance m_tau, f, h, then per matrix M tau, M m_tau, M f, M h; then t0, t1
+    const u32 per = 4 + 4 * nM, nring = L * (per - 1), nS = 1 + L, nR = nring + 2;
+    DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring;
+    std::vector<std::unique_ptr<DevCsr>> Mr;
+    const u32 nb0 = lfp::cm_round_blocks(n / 2);
+    if (S0.alloc((size_t)nS * n * 8) || R0.alloc((size_t)nR * n * D * 8) || Sw[0].alloc((size_t)nS * (n / 2) * 8) || Sw[1].alloc((size_t)nS * (n / 4 + 1) * 8) ||
+        Rw[0].alloc((size_t)nR * (n / 2) * D * 8) || Rw[1].alloc((size_t)nR * (n / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
+        part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)))
+        return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm tables)");
+    for (u32 q = 0; q < nM; q++) {
+        const size_t nnz = rowptr[q][n];
+        std::unique_ptr<DevCsr> m(new DevCsr);
+        std::vector<u64> vM(nnz * D);
+        for (size_t i = 0; i < vM.size(); i++) vM[i] = to_mont(val[q][i]);
+        if (m->rowptr.alloc((n + 1) * 4) || m->col.alloc(nnz * 4) || m->valM.alloc(nnz * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
+        HIPCHK(c, hipMemcpyAsync(m->rowptr.p, rowptr[q], (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(m->col.p, col[q], nnz * 4, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(m->valM.p, vM.data(), vM.size() * 8, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        Mr.push_back(std::move(m));
+    }
+    u64 *S = S0.as<u64>(), *R = R0.as<u64>();
+    HIPCHK(c, hipMemcpyAsync(S, so.eqr.p, n * 8, hipMemcpyDeviceToDevice, c->st));
+    for (u32 l = 0; l < L; l++) {
+        u64 *base = R + (size_t)l * (per - 1) * n * D;
+        lfp::launch_to_mont(ctxs[l]->tau, n, S + (size_t)(1 + l) * n, c->st);
+        lfp::launch_cm_materialize(ctxs[l]->mtau, nullptr, n, base, c->st);
+        HIPCHK(c, hipMemcpyAsync(base + n * D, ctxs[l]->f, n * D * 8, hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(base + 2 * n * D, h[l]->p, n * D * 8, hipMemcpyDeviceToDevice, c->st));
+        if (nM) lfp::launch_cm_materialize(nullptr, ctxs[l]->tau, n, tauring.as<u64>(), c->st);
+        for (u32 q = 0; q < nM; q++) {
+            const DevCsr &m = *Mr[q];
+            u64 *mq = base + (size_t)(3 + 4 * q) * n * D;
+            lfp::launch_spmv_ring(m.rowptr.as<u32>(), m.col.as<u32>(), m.valM.as<u64>(), tauring.as<u64>(), n, mq, c->st);
+            for (int j = 0; j < 3; j++)
+                lfp::launch_spmv_ring(m.rowptr.as<u32>(), m.col.as<u32>(), m.valM.as<u64>(), base + (size_t)j * n * D, n, mq + (size_t)(1 + j) * n * D, c->st);
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(R + (size_t)nring * n * D, t0.data(), n * D * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(R + (size_t)(nring + 1) * n * D, t1.data(), n * D * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    // the two sumcheckers (cm.rs:201-347): same tables, different batching challenge rc; degree 2, ring-valued messages
+    const lfp::CmDesc desc = {L, nM};
+    std::vector<u64> hpart((size_t)nb0 * 48), rcps((size_t)L * per + 2), evh((size_t)nR * D + nS);
+    for (int pass = 0; pass < 2; pass++) {
+        const u64 rcv = tr->challenge();
+        u64 pw = 1;
+        for (size_t i = 0; i < rcps.size(); i++) { rcps[i] = to_mont(pw); pw = fmul(pw, rcv); }
+        HIPCHK(c, hipMemcpyAsync(rcpd.p, rcps.data(), rcps.size() * 8, hipMemcpyHostToDevice, c->st));
+        u64 *proof = pass ? pb : pa, *evs = pass ? eb : ea, *rop = ro + (size_t)pass * nvars;
+        tr->absorb_const(nvars);
+        tr->absorb_const(2);
+        const u64 *Sc = S, *Rc = R;
+        size_t ld = n, len = n;
+        int w = 0;
+        for (u32 rnd = 0; rnd < nvars; rnd++) {
+            const size_t half = len / 2;
+            const u32 nb = lfp::cm_round_blocks(half);
+            lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), part.as<u64>(), c->st);
+            HIPCHK(c, hipMemcpyAsync(hpart.data(), part.p, (size_t)nb * 48 * 8, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            u64 *m = proof + (size_t)rnd * 3 * D;
+            for (int x = 0; x < 3 * D; x++) {
+                u64 s = 0;
+                for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 48 + x]);
+                m[x] = s;              // canonical: every product of the kernel pairs one Montgomery operand with one canonical operand
+            }
+            tr->absorb_ring(m, 3);
+            const u64 r = tr->challenge();
+            tr->absorb_const(r);
+            rop[rnd] = r;
+            const size_t ldo = w == 0 ? n / 2 : n / 4 + 1;
+            lfp::launch_cm_fix(Sc, ld, Sw[w].as<u64>(), ldo, 1, nS, half, to_mont(r), c->st);
+            lfp::launch_cm_fix(Rc, ld, Rw[w].as<u64>(), ldo, D, nR, half, to_mont(r), c->st);
+            Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
+            len = half;
+        }
+        // evals (cm.rs:313-331): every instance table at ro = the fully fixed tables
+        DevBuf evd;
+        if (evd.alloc(evh.size() * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (evals)");
+        HIPCHK(c, hipMemcpy2DAsync(evd.p, D * 8, Rc, ld * D * 8, D * 8, nR, hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipMemcpy2DAsync(evd.as<u64>() + (size_t)nR * D, 8, Sc, ld * 8, 8, nS, hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(evh.data(), evd.p, evh.size() * 8, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        for (u32 l = 0; l < L; l++) {
+            u64 *el = evs + (size_t)l * per * D;
+            memset(el, 0, D * 8);
+            el[0] = from_mont(evh[(size_t)nR * D + 1 + l]);
+            memcpy(el + D, &evh[(size_t)l * (per - 1) * D], (size_t)(per - 1) * D * 8);
+        }
+        tr->absorb_ring(evs, (size_t)L * per);
+    }
+    // g_l = s0 tau + s1 m_tau + s2 f + h (cm.rs:164-181), kept on the device
+    lfp::CmShort cs;
+    for (int i = 0; i < 3; i++) for (int t = 0; t < D; t++) cs.v[i][t] = ch.s[i][t] > P / 2 ? -(int32_t)(P - ch.s[i][t]) : (int32_t)ch.s[i][t];
+    for (u32 l = 0; l < L; l++) {
+        lfplus_ctx *cl = ctxs[l];
+        if (cl->g_n != n) {
+            if (cl->g) { (void)hipFree(cl->g); cl->g = nullptr; cl->g_n = 0; }
+            HIPCHK(c, hipMalloc(&cl->g, n * D * 8));
+            cl->g_n = n;
+        }
+        lfp::launch_cm_g(cl->tau, cl->mtau, cl->f, h[l]->as<u64>(), n, cs, cl->g, c->st);
+        if (g_out) HIPCHK(c, hipMemcpyAsync(g_out + (size_t)l * n * D, cl->g, n * D * 8, hipMemcpyDeviceToHost, c->st));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    std::vector<const u64 *> fc(L);
+    for (u32 l = 0; l < L; l++) fc[l] = fcoms[l].data();
+    cm_x(ch, L, kappa, nM, fc.data(), comh, ea, eb, cm_g, vo);
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_cm_read_g(lfplus_ctx *c, uint64_t *g_out) {
+    if (!c || !g_out) return LFPLUS_E_ARG;
+    if (!c->g || !c->g_n) return fail(c, LFPLUS_E_ARG, "lfplus_cm_read_g: no folded witness (call lfplus_cm_prove)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(g_out, c->g, c->g_n * D * 8, hipMemcpyDeviceToHost));
+    return LFPLUS_OK;
+}
+
+// CmProof::verify (cm.rs:349-543), host only.  fcoms[l] = cm_f | C_Mf | cm_mtau of instance l (kappa ring elements each).  LFPLUS_OK = accepted and
+// cm_g / ro / vo hold the folded instance ComX (cm.rs:545-580) recomputed from the proof; LFPLUS_E_REJECT with *stage = 1..5 (range check), 6 (a
+// sumcheck round), 7 (t0 too large), 8 (final evaluation of a sumchecker)
+extern "C" int lfplus_cm_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t L, uint32_t k, uint32_t ell, uint32_t kappa, uint32_t nM, const uint64_t *const *fcoms,
+                                const uint64_t *msgs, const uint64_t *e, const uint64_t *b, const uint64_t *v, const uint64_t *a, const uint64_t *bb,
+                                const uint64_t *cc, const uint64_t *comh, const uint64_t *pa, const uint64_t *pb, const uint64_t *ea, const uint64_t *eb,
+                                uint64_t *cm_g, uint64_t *ro, uint64_t *vo, int *stage) {
+    if (!tr || !L || !k || !ell || !kappa || !fcoms || !comh || !pa || !pb || !ea || !eb || !cm_g || !ro || !vo || nvars < 1 || nvars > 32) return LFPLUS_E_ARG;
+    for (u32 l = 0; l < L; l++) if (!fcoms[l]) return LFPLUS_E_ARG;
+    const size_t n = (size_t)1 << nvars;
+    std::vector<u64> r(nvars);
+    int st = 0;
+    int rc = lfplus_range_check_verify(tr, nvars, L, k, nM, msgs, e, b, v, a, bb, cc, r.data(), &st);
+    if (rc == LFPLUS_E_ARG) return rc;
+    const u32 per = 4 + 4 * nM, z_idx = L * per;
+    CmChallenges ch;
+    if (!st) {
+        cm_challenges(tr, k, kappa, nullptr, L, ch);
+        tr->absorb_ring(comh, (size_t)L * kappa);
+        cm_c_challenges(tr, kappa, ch);
+    }
+    std::vector<u64> t0, t1;
+    if (!st && (!calc_t(ch.cz[0], ch.logk, ch.sp, k * D, ell, n, t0) || !calc_t(ch.cz[1], ch.logk, ch.sp, k * D, ell, n, t1))) st = 7;
+    if (!st) {
+        // u[l][q] = sum over the instance's k 16 set-check evaluations of e * s' (cm.rs:383-401); tensor(c_z) . comh_l
+        std::vector<u64> u((size_t)L * (1 + nM) * D, 0), tcch((size_t)2 * L * D, 0);
+        for (u32 l = 0; l < L; l++)
+            for (u32 q = 0; q < 1 + nM; q++)
+                for (u32 j = 0; j < k * D; j++) rmul_acc(&u[((size_t)l * (1 + nM) + q) * D], e + (((size_t)q * L * k + (size_t)l * k) * D + j) * D, &ch.sp[(size_t)j * D]);
+        for (int z = 0; z < 2; z++) {
+            const std::vector<u64> tc = tensor(ch.cz[z], ch.logk);
+            for (u32 l = 0; l < L; l++)
+                for (u32 i = 0; i < kappa && i < tc.size(); i++) rscale_acc(&tcch[((size_t)z * L + l) * D], comh + ((size_t)l * kappa + i) * D, tc[i]);
+        }
+        for (int pass = 0; pass < 2 && !st; pass++) {
+            const u64 rcv = tr->challenge();
+            std::vector<u64> rcps(z_idx + 2);
+            rcps[0] = 1;
+            for (u32 i = 1; i < z_idx + 2; i++) rcps[i] = fmul(rcps[i - 1], rcv);
+            u64 cur[D] = {0};
+            for (u32 l = 0; l < L; l++) {
+                for (u32 q = 0; q < 1 + nM; q++) {
+                    const u32 idx = l * per + 4 * q;
+                    const size_t o = (size_t)l * (1 + nM) + q;
+                    cur[0] = fadd(cur[0], fmul(a[o] % P, rcps[idx]));
+                    rscale_acc(cur, bb + o * D, rcps[idx + 1]);
+                    rscale_acc(cur, cc + o * D, rcps[idx + 2]);
+                    rscale_acc(cur, &u[o * D], rcps[idx + 3]);
+                }
+                rscale_acc(cur, &tcch[((size_t)0 * L + l) * D], rcps[z_idx]);
+                rscale_acc(cur, &tcch[((size_t)1 * L + l) * D], rcps[z_idx + 1]);
+            }
+            const u64 *proof = pass ? pb : pa, *evs = pass ? eb : ea;
+            u64 *rop = ro + (size_t)pass * nvars;
+            // verify_as_subprotocol with ring-valued messages: coefficient-wise, degree 2
+            tr->absorb_const(nvars);
+            tr->absorb_const(2);
+            for (u32 rnd = 0; rnd < nvars && !st; rnd++) {
+                const u64 *m = proof + (size_t)rnd * 3 * D;
+                tr->absorb_ring(m, 3);
+                const u64 x = tr->challenge();
+                tr->absorb_const(x);
+                rop[rnd] = x;
+                // Lagrange weights on the nodes 0, 1, 2
+                const u64 inv2 = fpow(2, P - 2), x1 = fsub(x, 1), x2 = fsub(x, 2);
+                const u64 w0 = fmul(fmul(x1, x2), inv2), w1 = fsub(0, fmul(x, x2)), w2 = fmul(fmul(x, x1), inv2);
+                for (int ci = 0; ci < D; ci++) {
+                    const u64 y0 = m[ci] % P, y1 = m[D + ci] % P, y2 = m[2 * D + ci] % P;
+                    if (fadd(y0, y1) != cur[ci]) { st = 6; break; }
+                    cur[ci] = fadd(fadd(fmul(y0, w0), fmul(y1, w1)), fmul(y2, w2));
+                }
+            }
+            if (st) break;
+            // t0, t1 at ro: fold the tables along the point, variable 0 first
+            u64 tz[2][D];
+            for (int z = 0; z < 2; z++) {
+                std::vector<u64> cur_t = z ? t1 : t0;
+                size_t len = n;
+                for (u32 j = 0; j < nvars; j++) {
+                    const size_t half = len / 2;
+                    for (size_t i = 0; i < half; i++)
+                        for (int ci = 0; ci < D; ci++) {
+                            const u64 lo = cur_t[(2 * i) * D + ci], hi = cur_t[(2 * i + 1) * D + ci];
+                            cur_t[i * D + ci] = fadd(lo, fmul(rop[j], fsub(hi, lo)));
+                        }
+                    len = half;
+                }
+                memcpy(tz[z], cur_t.data(), D * 8);
+            }
+            tr->absorb_ring(evs, (size_t)L * per);
+            const u64 eq = eq_eval(r.data(), rop, nvars);
+            u64 want[D] = {0};
+            for (u32 l = 0; l < L; l++) {
+                const u64 *el = evs + (size_t)l * per * D;
+                u64 inner[D] = {0}, t[D];
+                for (u32 j = 0; j < per; j++) rscale_acc(inner, el + (size_t)j * D, rcps[l * per + j]);
+                rscale_acc(want, inner, eq);
+                memset(t, 0, sizeof(t)); rmul_acc(t, tz[0], el); rscale_acc(want, t, rcps[z_idx]);
+                memset(t, 0, sizeof(t)); rmul_acc(t, tz[1], el); rscale_acc(want, t, rcps[z_idx + 1]);
+            }
+            if (memcmp(want, cur, sizeof(want))) st = 8;
+        }
+    }
+    if (!st) cm_x(ch, L, kappa, nM, fcoms, comh, ea, eb, cm_g, vo);
     if (stage) *stage = st;
     return st ? LFPLUS_E_REJECT : LFPLUS_OK;
 }

@@ -224,3 +224,129 @@ void launch_spmvT_eq(const u32 *colptr, const u32 *rowidx, const u64 *val, const
 }
 // tau (n canonical words) as n ring constants is never materialised: the M_i tau row needs sum_c w[c][0] tau[c] only (the constant term)
 }  // namespace lfp
+
+// ---- Cm::prove (cm.rs:56-347) -------------------------------------------------------------------------------------------------------------
+namespace lfp {
+// ring tables from the compact forms: out[row] = X^e(dig[row]) (mono != 0) or the constant tau[row]
+__global__ void __launch_bounds__(256) k_cm_materialize(const int8_t *dig, const u64 *tau, size_t n, u64 *out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 16) return;
+    const size_t row = i >> 4;
+    const int t = (int)(i & 15);
+    out[i] = dig ? (u64)(exp_of(dig[row]) == t) : (t == 0 ? tau[row] : 0);
+}
+void launch_cm_materialize(const int8_t *dig, const u64 *tau, size_t n, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_cm_materialize, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, s, dig, tau, n, out);
+}
+__global__ void __launch_bounds__(256) k_to_mont(const u64 *in, size_t n, u64 *out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = to_mont(in[i]);
+}
+void launch_to_mont(const u64 *in, size_t n, u64 *out, hipStream_t s) { hipLaunchKernelGGL(k_to_mont, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, in, n, out); }
+// h[row] = sum_{ki < k} sum_{j < 16} X^e(Df[ki][row][j]) * s'[ki][j]  (cm.rs:82-103): rotations of the short challenges (|coefficients| <= 128), exact
+// in int32; thread = (row, coefficient)
+__global__ void __launch_bounds__(256) k_cm_h(const int8_t *Df, size_t n, u32 k, const int32_t *sp /* [k][16][16] */, u64 *h) {
+    __shared__ int32_t ssp[16 * 16 * 16];
+    for (u32 i = threadIdx.x; i < k * 256; i += 256) ssp[i] = sp[i];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 16) return;
+    const size_t row = i >> 4;
+    const int t = (int)(i & 15);
+    int acc = 0;
+    for (u32 ki = 0; ki < k; ki++) {
+        const int8_t *d = Df + ((size_t)ki * n + row) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int e = exp_of(d[j]), v = ssp[(ki * 16 + j) * 16 + ((t - e) & 15)];
+            acc += t >= e ? v : -v;
+        }
+    }
+    h[i] = acc >= 0 ? (u64)acc : P - (u64)(-acc);
+}
+void launch_cm_h(const int8_t *Df, size_t n, u32 k, const int32_t *sp, u64 *h, hipStream_t s) {
+    hipLaunchKernelGGL(k_cm_h, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, s, Df, n, k, sp, h);
+}
+// g[row] = s0 tau[row] + s1 X^e(mtau[row]) + s2 f[row] + h[row]  (cm.rs:164-181); s: three short challenges as int32 [3][16]
+__global__ void __launch_bounds__(256) k_cm_g(const u64 *tau, const int8_t *mtau, const u64 *f, const u64 *h, size_t n, CmShort s, u64 *g) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 16) return;
+    const size_t row = i >> 4;
+    const int t = (int)(i & 15);
+    auto fe = [](int v) { return v >= 0 ? (u64)v : P - (u64)(-v); };
+    u64 acc = h[i];
+    acc = add_p(acc, mul_p(fe(s.v[0][t]), tau[row]));
+    const int e = exp_of(mtau[row]), r1 = s.v[1][(t - e) & 15];
+    acc = add_p(acc, fe(t >= e ? r1 : -r1));
+    const u64 *fr = f + row * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {          // s2[j] X^j * f: coefficient t gets s2[j] f[t - j] (t >= j), - s2[j] f[t - j + 16]
+        const u64 pr = mul_p(fe(s.v[2][j]), fr[(t - j) & 15]);
+        acc = t >= j ? add_p(acc, pr) : sub_p(acc, pr);
+    }
+    g[i] = acc;
+}
+void launch_cm_g(const u64 *tau, const int8_t *mtau, const u64 *f, const u64 *h, size_t n, const CmShort &s, u64 *g, hipStream_t st) {
+    hipLaunchKernelGGL(k_cm_g, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, st, tau, mtau, f, h, n, s, g);
+}
+// One round of a sumchecker of Cm::prove (cm.rs:201-347; comb_fn :287-311), degree 2.  Scalar tables (Montgomery): S[0] = eq(r, .), S[1 + l] = tau_l;
+// ring tables (canonical, [entry][16]): R[l * (per - 1) + j - 1] = table j >= 1 of instance l in the reference's order (m_tau, f, h, then per matrix
+// M tau, M m_tau, M f, M h), R[L (per - 1)] = t0, R[L (per - 1) + 1] = t1.  rcp[i] = rc^i (Montgomery).  thread = (pair, coefficient);
+// part[block][3][16] canonical.
+__global__ void __launch_bounds__(256) k_cm_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, CmDesc d, const u64 *rcp, u64 *part) {
+    const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const u32 per = 4 + 4 * d.nM, nring = d.L * (per - 1);
+    u64 s[3] = {0, 0, 0};
+    for (size_t b = (size_t)blockIdx.x * 16 + pl; b < half; b += (size_t)gridDim.x * 16) {
+        const u64 e0 = S[2 * b], e1 = S[2 * b + 1], e2 = add_p(e1, sub_p(e1, e0));
+        const u64 *t0p = R + ((size_t)nring * ldr + 2 * b) * 16 + c, *t1p = R + ((size_t)(nring + 1) * ldr + 2 * b) * 16 + c;
+        const u64 a0 = t0p[0], a1 = t0p[16], b0 = t1p[0], b1 = t1p[16];
+        const u64 rz = rcp[d.L * per], rz1 = rcp[d.L * per + 1];
+        // rz t0 + rz1 t1 at X = 0, 1, 2
+        const u64 z0 = add_p(mont_mul(rz, a0), mont_mul(rz1, b0)), z1 = add_p(mont_mul(rz, a1), mont_mul(rz1, b1)), z2 = add_p(z1, sub_p(z1, z0));
+        for (u32 l = 0; l < d.L; l++) {
+            const u64 *tp = S + (size_t)(1 + l) * lds + 2 * b;
+            const u64 m0 = tp[0], m1 = tp[1], m2 = add_p(m1, sub_p(m1, m0));     // tau (Montgomery) at X = 0, 1, 2
+            u64 in0 = 0, in1 = 0, in2 = 0;
+            if (c == 0) {                                                        // the constant tau as table 0: rcp[l per] tau
+                const u64 r0 = rcp[l * per];
+                in0 = mont_mul(r0, from_mont(m0)); in1 = mont_mul(r0, from_mont(m1)); in2 = mont_mul(r0, from_mont(m2));
+            }
+            for (u32 j = 1; j < per; j++) {
+                const u64 *rp = R + ((size_t)(l * (per - 1) + j - 1) * ldr + 2 * b) * 16 + c;
+                const u64 v0 = rp[0], v1 = rp[16], v2 = add_p(v1, sub_p(v1, v0)), rj = rcp[l * per + j];
+                in0 = add_p(in0, mont_mul(rj, v0)); in1 = add_p(in1, mont_mul(rj, v1)); in2 = add_p(in2, mont_mul(rj, v2));
+            }
+            s[0] = add_p(s[0], add_p(mont_mul(e0, in0), mont_mul(m0, z0)));
+            s[1] = add_p(s[1], add_p(mont_mul(e1, in1), mont_mul(m1, z1)));
+            s[2] = add_p(s[2], add_p(mont_mul(e2, in2), mont_mul(m2, z2)));
+        }
+    }
+    __shared__ u64 sm[3][16][16];
+    for (int x = 0; x < 3; x++) sm[x][pl][c] = s[x];
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const u32 x = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[x][p][cc]);
+        part[(size_t)blockIdx.x * 48 + threadIdx.x] = t;
+    }
+}
+u32 cm_round_blocks(size_t half) { size_t b = cdiv(half, 16); return (u32)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+void launch_cm_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 *part, hipStream_t s) {
+    hipLaunchKernelGGL(k_cm_round, dim3(cm_round_blocks(half)), dim3(256), 0, s, S, lds, R, ldr, half, d, rcp, part);
+}
+// fix_variables of tables of `w` words per entry: out[t][b][x] = in[t][2b][x] + r (in[t][2b+1][x] - in[t][2b][x]); r in Montgomery form (the words keep
+// whatever form they have)
+__global__ void __launch_bounds__(256) k_cm_fix(const u64 *in, size_t ld_in, u64 *out, size_t ld_out, u32 w, size_t half, u64 rM) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= half * w) return;
+    const size_t b = i / w, x = i % w;
+    const u64 *p = in + ((size_t)blockIdx.y * ld_in + 2 * b) * w + x;
+    const u64 lo = p[0], hi = p[w];
+    out[((size_t)blockIdx.y * ld_out + b) * w + x] = add_p(lo, mont_mul(rM, sub_p(hi, lo)));
+}
+void launch_cm_fix(const u64 *in, size_t ld_in, u64 *out, size_t ld_out, u32 w, u32 ntab, size_t half, u64 rM, hipStream_t s) {
+    hipLaunchKernelGGL(k_cm_fix, dim3((unsigned)cdiv(half * w, 256), ntab), dim3(256), 0, s, in, ld_in, out, ld_out, w, half, rM);
+}
+}  // namespace lfp

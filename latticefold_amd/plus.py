@@ -72,6 +72,9 @@ def _lib():
         L.lfplus_set_check_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p, u64p, u64p, ip]
         L.lfplus_range_check.argtypes = [vpp, C.c_uint32, vp, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 8
         L.lfplus_range_check_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32] + [u64p] * 8 + [ip]
+        L.lfplus_cm_prove.argtypes = [vpp, C.c_uint32, vp, C.c_uint32, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 17
+        L.lfplus_cm_read_g.argtypes = [vp, u64p]
+        L.lfplus_cm_verify.argtypes = [vp] + [C.c_uint32] * 6 + [u64pp] + [u64p] * 15 + [ip]
         _READY = True
     return L
 
@@ -328,3 +331,52 @@ def range_check_verify(transcript, d):
     if rc not in (0, E_REJECT):
         raise LfPlusError(rc, "lfplus_range_check_verify")
     return rc == 0, st.value, r
+
+
+def cm_prove(ctxs, transcript, ell, M=(), want_g=False):
+    """Cm::prove (src/cm.rs:56-347) over the resident RgInstances of `ctxs` -> dict of the CmProof fields (dcom = the range check's fields, comh,
+    sumcheck proofs pa / pb, evals ea / eb) and of the folded instance x = (cm_g, ro, vo); `g` (L, n, 16) when want_g, else it stays on the device"""
+    L, nM, c0 = len(ctxs), len(M), ctxs[0] if ctxs else None
+    if not ctxs or not c0.n or not getattr(c0, "_k", 0):
+        raise LfPlusError(E_ARG, "cm_prove: no resident RgInstance (run RgInstance.from_f first)")
+    n, k, kappa = c0.n, c0._k, c0.kappa
+    nvars = n.bit_length() - 1
+    per = 4 + 4 * nM
+    keep, rp, cp, vp = _csr_args(M)
+    hs = (C.c_void_p * L)(*[c.h for c in ctxs])
+    z = lambda *shape: np.zeros(shape, dtype=np.uint64)
+    o = {"r": z(nvars), "msgs": z(nvars, 4, D), "e": z(1 + nM, L * k, D, D), "b": z(L, D), "v": z(L, D), "a": z(L, 1 + nM), "bb": z(L, 1 + nM, D),
+         "c": z(L, 1 + nM, D), "comh": z(L, kappa, D), "pa": z(nvars, 3, D), "pb": z(nvars, 3, D), "ea": z(L, per, D), "eb": z(L, per, D),
+         "cm_g": z(L, kappa, D), "ro": z(2, nvars), "vo": z(L, 1 + nM, 2, D)}
+    g = z(L, n, D) if want_g else None
+    keys = ("r", "msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb", "cm_g", "ro", "vo")
+    c0._chk(_lib().lfplus_cm_prove(hs, L, transcript.h, ell, nM, rp, cp, vp, *[o[key].ctypes.data_as(u64p) for key in keys],
+                                   g.ctypes.data_as(u64p) if want_g else None))
+    o.update(k=k, ell=ell, kappa=kappa, nvars=nvars)
+    if want_g:
+        o["g"] = g
+    return o
+
+
+def cm_read_g(ctx):
+    """the folded witness g of the last cm_prove this context took part in: (n, 16) canonical words"""
+    g = np.zeros((ctx.n, D), dtype=np.uint64)
+    ctx._chk(_lib().lfplus_cm_read_g(ctx.h, g.ctypes.data_as(u64p)))
+    return g
+
+
+def cm_verify(transcript, proof, fcoms):
+    """CmProof::verify (src/cm.rs:349-543) on the host.  fcoms[l] = (3, kappa, 16): cm_f | C_Mf | cm_mtau -> (accepted, stage, dict(cm_g, ro, vo))"""
+    nvars, k, ell, kappa = proof["nvars"], proof["k"], proof["ell"], proof["kappa"]
+    keys = ("msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb")
+    arr = {key: np.ascontiguousarray(proof[key], dtype=np.uint64) for key in keys}
+    L, nM = arr["b"].shape[0], arr["a"].shape[1] - 1
+    fc = [np.ascontiguousarray(x, dtype=np.uint64) for x in fcoms]
+    fptr = (u64p * L)(*[x.ctypes.data_as(u64p) for x in fc])
+    x = {"cm_g": np.zeros((L, kappa, D), dtype=np.uint64), "ro": np.zeros((2, nvars), dtype=np.uint64), "vo": np.zeros((L, 1 + nM, 2, D), dtype=np.uint64)}
+    st = C.c_int()
+    rc = _lib().lfplus_cm_verify(transcript.h, nvars, L, k, ell, kappa, nM, fptr, *[arr[key].ctypes.data_as(u64p) for key in keys],
+                                 *[x[key].ctypes.data_as(u64p) for key in ("cm_g", "ro", "vo")], C.byref(st))
+    if rc not in (0, E_REJECT):
+        raise LfPlusError(rc, "lfplus_cm_verify")
+    return rc == 0, st.value, x

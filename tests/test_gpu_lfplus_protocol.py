@@ -114,3 +114,43 @@ def test_argument_errors(ctx):
         assert e.value.code == plus.E_ARG
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("L,nM,kappa,nvars,ring_coeffs", [(1, 0, 1, 14, False), (1, 1, 2, 15, False), (2, 1, 1, 14, False), (2, 2, 2, 15, False), (2, 2, 2, 15, True)])
+def test_cm_prove_matches_oracle(L, nM, kappa, nvars, ring_coeffs):
+    """cm.rs:606-666 (test_com: n = 2^15, kappa 2, k 2, one matrix) and the two-instance shape Mlin::mlin feeds Cm::prove: every proof field, the
+    folded instance and the folded witness equal the oracle's; both verifiers accept; the transcripts end in the same state"""
+    n, k = 1 << nvars, 2
+    dp = plus.DecompParameters.for_frog(k)
+    A = lfp.splitmix(3, 0, kappa * n * D).reshape(kappa, n, D)
+    ctxs, insts = [], []
+    try:
+        for l in range(L):
+            f = _witness(n, 40 + l)
+            c = plus.PlusContext(0)
+            rg = plus.RgInstance.from_f(c, f, A, dp)
+            ctxs.append(c)
+            insts.append({"Mf": lfp.exp_dense(rg.D_f), "tau": rg.tau, "mtau": lfp.exp_dense(rg.m_tau_exp), "f": f, "comMf": rg.comM_f,
+                          "fcoms": np.stack([rg.fcoms.cm_f, rg.fcoms.C_Mf, rg.fcoms.cm_mtau])})
+        rnd = _rand_csr(n, 9)
+        if not ring_coeffs:
+            rnd[2][:, 1:] = 0          # constant coefficients: ct(psi M exp(tau)) = M tau needs them (the reference's tests use the identity)
+        mats = [_ident(n, first=2), rnd][:nM]
+        to, tp = lfp.Transcript(), plus.PoseidonTranscript()
+        want = lfp.cm_prove(to, nvars, insts, k, dp.l, kappa, mats)
+        got = plus.cm_prove(ctxs, tp, dp.l, mats, want_g=True)
+        for key in ("msgs", "r", "e", "b", "v", "a", "bb", "c", "comh", "pa", "ea", "pb", "eb", "ro", "cm_g", "vo", "g"):
+            assert (got[key] == want[key]).all(), key
+        assert tp.get_challenge() == to.challenge()
+        for l in range(L):
+            assert (plus.cm_read_g(ctxs[l]) == want["g"][l]).all()
+        fcoms = [i["fcoms"] for i in insts]
+        ok, stage, x = plus.cm_verify(plus.PoseidonTranscript(), got, fcoms)
+        if ring_coeffs:                # an honest rejection: the range relation does not survive non-constant matrix coefficients
+            assert not ok and stage == 4 and lfp.cm_verify(lfp.Transcript(), got, fcoms)[0] == -4
+        else:
+            assert ok and stage == 0 and all((x[key] == got[key]).all() for key in ("cm_g", "ro", "vo"))
+            assert lfp.cm_verify(lfp.Transcript(), got, fcoms)[0] == 0
+    finally:
+        for c in ctxs:
+            c.close()

@@ -91,3 +91,38 @@ def test_range_check_verifier_accepts_oracle_proofs_and_rejects_tampering():
         ok_p, st_p, _ = plus.range_check_verify(plus.PoseidonTranscript(), t)
         assert not ok_p and st_p == want, (key, st_p)
         assert lfp.range_check_verify(lfp.Transcript(), nvars, t, k)[0] == -want
+
+
+def test_cm_verifier_accepts_oracle_proofs_and_rejects_tampering():
+    """CmProof::verify (cm.rs:349-543) of the product (host only) on proofs the oracle's Cm::prove wrote: same verdict, same stage, same folded instance"""
+    nvars, kappa, k, ell, L = 14, 1, 2, 22, 2
+    n = 1 << nvars
+    A = lfp.splitmix(3, 0, kappa * n * D).reshape(kappa, n, D)
+    insts = []
+    for i in range(L):
+        v = (lfp.splitmix(31 + 7 * i, 0, n * D) % np.uint64(63)).astype(np.int64) - 31
+        f = np.where(v < 0, np.uint64(P) - (-v).astype(np.uint64), v.astype(np.uint64)).reshape(n, D)
+        rg = lfp.rg_from_f(f, A, D // 2, k, ell)
+        tau_i = np.array([int(t) if int(t) <= P // 2 else int(t) - P for t in rg["tau"]], dtype=np.int8)
+        insts.append({"Mf": lfp.exp_dense(rg["Df"]), "tau": rg["tau"], "mtau": lfp.exp_dense(tau_i), "f": f, "comMf": rg["comMf"],
+                      "fcoms": np.stack([rg["cm_f"], rg["C_Mf"], rg["cm_mtau"]])})
+    fcoms = [i["fcoms"] for i in insts]
+    pr = lfp.cm_prove(lfp.Transcript(), nvars, insts, k, ell, kappa, [_ident(n, first=2)])
+    tp = plus.PoseidonTranscript()
+    ok, stage, x = plus.cm_verify(tp, pr, fcoms)
+    assert ok and stage == 0
+    for key in ("cm_g", "ro", "vo"):
+        assert (x[key] == pr[key]).all(), key
+    to = lfp.Transcript()
+    assert lfp.cm_verify(to, pr, fcoms)[0] == 0 and tp.get_challenge() == to.challenge()
+    for key, idx in (("comh", (0, 0, 1)), ("pa", (2, 1, 3)), ("pb", (0, 0, 0)), ("ea", (0, 2, 5)), ("eb", (1, 3, 0)), ("a", (0, 0)), ("e", (0, 1, 2, 3)),
+                     ("pa", (13, 2, 15))):
+        t = dict(pr)
+        t[key] = pr[key].copy()
+        t[key][idx] = (int(t[key][idx]) + 1) % P
+        ok_p, st_p, _ = plus.cm_verify(plus.PoseidonTranscript(), t, fcoms)
+        rc_o = lfp.cm_verify(lfp.Transcript(), t, fcoms)[0]
+        assert not ok_p and st_p == -rc_o, (key, st_p, rc_o)
+    # kappa' k d l d > n: "t0 too large!" (cm.rs:601) -> stage 7 on both sides
+    t = dict(pr, ell=64)
+    assert plus.cm_verify(plus.PoseidonTranscript(), t, fcoms)[1] == 7 and lfp.cm_verify(lfp.Transcript(), t, fcoms)[0] == -7
