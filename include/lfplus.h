@@ -53,6 +53,8 @@ const char *lfplus_last_error(const lfplus_ctx *ctx);
 
 /* Ajtai matrix A (kappa x n ring elements, row-major, coefficient form); stays resident in HBM.  kappa <= 64. */
 int lfplus_set_matrix(lfplus_ctx *ctx, const uint64_t *A, uint32_t kappa, uint64_t n);
+/* use the commitment matrix resident in `from` (same device) without copying it; `from` must outlive ctx's use of it */
+int lfplus_share_matrix(lfplus_ctx *ctx, lfplus_ctx *from);
 /* witness vector f (n ring elements); stays resident */
 int lfplus_set_witness(lfplus_ctx *ctx, const uint64_t *f, uint64_t n);
 
@@ -133,6 +135,25 @@ int lfplus_cm_verify(lfplus_transcript *t, uint32_t nvars, uint32_t L, uint32_t 
                      const uint64_t *msgs, const uint64_t *e, const uint64_t *b, const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c,
                      const uint64_t *comh, const uint64_t *pa, const uint64_t *pb, const uint64_t *ea, const uint64_t *eb, uint64_t *cm_g, uint64_t *ro,
                      uint64_t *vo, int *stage);
+
+/* ComR1CS::linearize (src/r1cs.rs:76-139) on the resident witness f (lfplus_set_witness; n = 2^nvars ring elements) and the R1CS matrices A, B, C
+ * (n x n, CSR, ring coefficients): g_q = M_q f, the degree-3 ring-valued sumcheck of eq(r, x) (g_A g_B - g_C)(x), evaluations at ro.
+ * Outputs: msgs (nvars x 4 ring elements), ro (nvars words), evals = v | va | vb | vc (4 ring elements). */
+int lfplus_r1cs_linearize(lfplus_ctx *ctx, lfplus_transcript *t, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val, uint64_t *msgs,
+                          uint64_t *ro, uint64_t *evals);
+/* ComR1CSProof::verify (r1cs.rs:141-162), host only: LFPLUS_E_REJECT with *stage = 1 (a sumcheck round) or 2 (e (va vb - vc) != s; the reference asserts) */
+int lfplus_r1cs_verify(lfplus_transcript *t, uint32_t nvars, const uint64_t *msgs, const uint64_t *evals, uint64_t *ro, int *stage);
+/* DecompProof::verify (src/decomp.rs:101-123), host only: *stage = 1 (C0 + B C1 != cm_f) or 2 (v0 + B v1 != v over `count` pairs of ring elements) */
+int lfplus_decomp_verify(const uint64_t *C0, const uint64_t *C1, uint32_t kappa, const uint64_t *v0, const uint64_t *v1, uint32_t count, const uint64_t *cm_f,
+                         const uint64_t *v, uint64_t B, int *stage);
+/* Mlin::mlin (src/mlin.rs:42-107) over the L resident witnesses of ctxs (same commitment matrix, n, device): RgInstance::from_f(b, k, l) on each, Cm::prove
+ * (outputs as lfplus_cm_prove), then the folded LinB2: cm_g_sum (kappa ring elements) and vo_sum ((1 + nM) x 2) on the host, g = sum_l g_l on the device where
+ * it REPLACES ctxs[0]'s resident witness (PlusProver::prove hands it to Decomp::decompose: plus.rs:90-95).  fcoms_out (may be null): L x 3 x kappa ring
+ * elements, cm_f | C_Mf | cm_mtau per instance (what CmProof::verify needs). */
+int lfplus_mlin(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *t, uint64_t b, uint32_t k, uint32_t l, uint32_t nM, const uint32_t *const *rowptr,
+                const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out, uint64_t *v_out,
+                uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, uint64_t *comh, uint64_t *pa, uint64_t *pb, uint64_t *ea, uint64_t *eb, uint64_t *cm_g,
+                uint64_t *ro, uint64_t *vo, uint64_t *fcoms_out, uint64_t *cm_g_sum, uint64_t *vo_sum);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
+    if (!c->own_A) c->A = nullptr;
     for (void *p : {(void *)c->A, (void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
                     (void *)c->err_d, (void *)c->g})
         if (p) (void)hipFree(p);
@@ -42,13 +43,7 @@ static int upload(lfplus_ctx *c, u64 **dst, const u64 *src, size_t words) {
     HIPCHK(c, hipStreamSynchronize(c->st));
     return LFPLUS_OK;
 }
-extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kappa, uint64_t n) {
-    if (!c || !A || !kappa || kappa > 64 || !n || n > (1ull << 32)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: bad shape");
-    if (!canonical(A, (size_t)kappa * n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: non-canonical word");
-    HIPCHK(c, hipSetDevice(c->device));
-    c->have = false;
-    int rc = upload(c, &c->A, A, (size_t)kappa * n * 16);
-    if (rc) return rc;
+static int shape_buffers(lfplus_ctx *c, u32 kappa, u64 n) {
     c->kappa = kappa;
     c->n = n;
     for (u64 **p : {&c->tau, &c->coms})
@@ -58,6 +53,27 @@ extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kapp
     HIPCHK(c, hipMalloc(&c->mtau, n));
     HIPCHK(c, hipMalloc(&c->coms, (size_t)3 * kappa * 16 * 8));
     return LFPLUS_OK;
+}
+extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kappa, uint64_t n) {
+    if (!c || !A || !kappa || kappa > 64 || !n || n > (1ull << 32)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: bad shape");
+    if (!canonical(A, (size_t)kappa * n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: non-canonical word");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have = false;
+    if (!c->own_A) { c->A = nullptr; c->own_A = true; }
+    int rc = upload(c, &c->A, A, (size_t)kappa * n * 16);
+    if (rc) return rc;
+    return shape_buffers(c, kappa, n);
+}
+// The commitment matrix of `from` (same device), not copied: PlusProver keeps one context per accumulated / fresh instance and one Ajtai matrix.
+// `from` must outlive every use of ctx's matrix.
+extern "C" int lfplus_share_matrix(lfplus_ctx *c, lfplus_ctx *from) {
+    if (!c || !from || c == from || !from->A || c->device != from->device) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrix: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have = false;
+    if (c->A && c->own_A) (void)hipFree(c->A);
+    c->A = from->A;
+    c->own_A = false;
+    return shape_buffers(c, from->kappa, from->n);
 }
 extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) {
     if (!c || !f || !n) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: bad arguments");

@@ -29,6 +29,7 @@ struct lfplus_ctx {
     // the folded witness of the last lfplus_cm_prove (cm.rs:164-181): n ring elements
     u64 *g = nullptr;
     u64 g_n = 0;
+    bool own_A = true;   // false: A belongs to another context (lfplus_share_matrix)
 };
 
 #define HIPCHK(c, x)                                                                        \

@@ -883,3 +883,184 @@ extern "C" int lfplus_cm_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t 
     if (stage) *stage = st;
     return st ? LFPLUS_E_REJECT : LFPLUS_OK;
 }
+
+// ---- ComR1CS::linearize / ComR1CSProof::verify (r1cs.rs:76-162), DecompProof::verify (decomp.rs:101-123), Mlin::mlin (mlin.rs:42-107) -----------
+namespace {
+int upload_csr(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, const u64 *val, DevCsr &m) {
+    if (!rowptr || !col || !val || rowptr[0] != 0) return fail(c, LFPLUS_E_ARG, "matrix: null / malformed CSR");
+    for (size_t r = 0; r < n; r++) if (rowptr[r + 1] < rowptr[r]) return fail(c, LFPLUS_E_ARG, "matrix: rowptr not monotone");
+    const size_t nnz = rowptr[n];
+    for (size_t i = 0; i < nnz; i++) if (col[i] >= n) return fail(c, LFPLUS_E_ARG, "matrix: column index out of range");
+    if (!canonical(val, nnz * D)) return fail(c, LFPLUS_E_ARG, "matrix: non-canonical word");
+    std::vector<u64> vM(nnz * D);
+    for (size_t i = 0; i < vM.size(); i++) vM[i] = to_mont(val[i]);
+    if (m.rowptr.alloc((n + 1) * 4) || m.col.alloc(nnz * 4) || m.valM.alloc(nnz * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
+    HIPCHK(c, hipMemcpyAsync(m.rowptr.p, rowptr, (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(m.col.p, col, nnz * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(m.valM.p, vM.data(), vM.size() * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return LFPLUS_OK;
+}
+}  // namespace
+
+// ComR1CS::linearize on the resident witness f (lfplus_set_witness; n = 2^nvars ring elements) and the three R1CS matrices (n x n, CSR, ring
+// coefficients; A, B, C in this order).  Outputs: msgs nvars x 4 ring elements (the degree-3 sumcheck), ro (nvars words), evals = v | va | vb | vc
+// (f, A f, B f, C f at ro)
+extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
+                                     uint64_t *msgs, uint64_t *ro, uint64_t *evals) {
+    if (!c) return LFPLUS_E_ARG;
+    if (!tr || !rowptr || !col || !val || !msgs || !ro || !evals) return fail(c, LFPLUS_E_ARG, "lfplus_r1cs_linearize: bad arguments");
+    const size_t n = c->nf;
+    if (!c->f || n < 2 || (n & (n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_r1cs_linearize: needs a resident witness of 2^nvars ring elements");
+    u32 nvars = 0;
+    while (((size_t)1 << nvars) < n) nvars++;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf E[2], G[2], part, small;
+    const u32 nb0 = lfp::cm_round_blocks(n / 2);
+    if (E[0].alloc(n * 8) || E[1].alloc(n / 2 * 8) || G[0].alloc((size_t)3 * n * D * 8) || G[1].alloc((size_t)3 * (n / 2) * D * 8) ||
+        part.alloc(std::max<size_t>((size_t)nb0 * 64, (size_t)lfp::eval_chunks(n) * D) * 8) || small.alloc(4 * D * 8))
+        return fail(c, LFPLUS_E_HIP, "hipMalloc (linearize tables)");
+    for (int q = 0; q < 3; q++) {
+        DevCsr m;
+        int rc = upload_csr(c, n, rowptr[q], col[q], val[q], m);
+        if (rc) return rc;
+        lfp::launch_spmv_ring(m.rowptr.as<u32>(), m.col.as<u32>(), m.valM.as<u64>(), c->f, n, G[0].as<u64>() + (size_t)q * n * D, c->st);
+        HIPCHK(c, hipStreamSynchronize(c->st));   // the matrix buffers die with this iteration
+    }
+    std::vector<u64> r(nvars);
+    for (u32 j = 0; j < nvars; j++) r[j] = tr->challenge();
+    lfp::EqPt pt;
+    for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(r[j]); pt.nc[j] = to_mont(fsub(1, r[j])); }
+    pt.one = to_mont(1);
+    lfp::launch_eq_build(pt, nvars, E[0].as<u64>(), c->st);
+    tr->absorb_const(nvars);
+    tr->absorb_const(3);
+    std::vector<u64> hpart((size_t)nb0 * 64);
+    // round 0 reads the full tables (stride n), later rounds ping-pong between the first halves of the two buffers
+    const u64 *Ec = E[0].as<u64>(), *Gc = G[0].as<u64>();
+    size_t ld = n, len = n;
+    int w = 1;
+    for (u32 rnd = 0; rnd < nvars; rnd++) {
+        const size_t half = len / 2;
+        const u32 nb = lfp::cm_round_blocks(half);
+        lfp::launch_r1cs_round(Ec, Gc, ld, half, part.as<u64>(), c->st);
+        HIPCHK(c, hipMemcpyAsync(hpart.data(), part.p, (size_t)nb * 64 * 8, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        u64 *m = msgs + (size_t)rnd * 4 * D;
+        for (int x = 0; x < 4 * D; x++) {
+            u64 s = 0;
+            for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 64 + x]);
+            m[x] = s;
+        }
+        tr->absorb_ring(m, 4);
+        const u64 x = tr->challenge();
+        tr->absorb_const(x);
+        ro[rnd] = x;
+        // in-place is not safe (entry b is written while 2b, 2b + 1 of another thread are read): alternate buffers; both hold n / 2 entries
+        const size_t ldo = n / 2;
+        u64 *Eo = w ? E[1].as<u64>() : E[0].as<u64>(), *Go = w ? G[1].as<u64>() : G[0].as<u64>();
+        lfp::launch_cm_fix(Ec, ld, Eo, ldo, 1, 1, half, to_mont(x), c->st);
+        lfp::launch_cm_fix(Gc, ld, Go, ldo, D, 3, half, to_mont(x), c->st);
+        Ec = Eo; Gc = Go; ld = ldo; w ^= 1;
+        len = half;
+    }
+    // v = f at ro; va, vb, vc = the fully fixed tables
+    for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(ro[j]); pt.nc[j] = to_mont(fsub(1, ro[j])); }
+    u64 *eqo = Ec == E[0].as<u64>() ? E[1].as<u64>() : E[0].as<u64>();   // n words needed: only E[0] is large enough
+    (void)eqo;
+    lfp::launch_eq_build(pt, nvars, E[0].as<u64>(), c->st);
+    lfp::launch_wring(c->f, n, E[0].as<u64>(), 1, part.as<u64>(), small.as<u64>(), c->st);
+    HIPCHK(c, hipMemcpy2DAsync(small.as<u64>() + D, D * 8, Gc, ld * D * 8, D * 8, 3, hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(evals, small.p, 4 * D * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    tr->absorb_ring(evals, 4);
+    return LFPLUS_OK;
+}
+// ComR1CSProof::verify, host only: stage 1 = a sumcheck round, 2 = e (va vb - vc) != s (the reference asserts, r1cs.rs:159)
+extern "C" int lfplus_r1cs_verify(lfplus_transcript *tr, uint32_t nvars, const uint64_t *msgs, const uint64_t *evals, uint64_t *ro, int *stage) {
+    if (!tr || !msgs || !evals || !ro || nvars < 1 || nvars > 32) return LFPLUS_E_ARG;
+    std::vector<u64> r(nvars);
+    for (u32 j = 0; j < nvars; j++) r[j] = tr->challenge();
+    int st = 0;
+    u64 cur[D] = {0};
+    tr->absorb_const(nvars);
+    tr->absorb_const(3);
+    for (u32 rnd = 0; rnd < nvars && !st; rnd++) {
+        const u64 *m = msgs + (size_t)rnd * 4 * D;
+        tr->absorb_ring(m, 4);
+        const u64 x = tr->challenge();
+        tr->absorb_const(x);
+        ro[rnd] = x;
+        u64 wgt[4];   // Lagrange weights on the nodes 0..3
+        for (u32 i = 0; i < 4; i++) {
+            u64 num = 1, den = 1;
+            for (u32 j = 0; j < 4; j++) if (j != i) { num = fmul(num, fsub(x, (u64)j)); den = fmul(den, fsub((u64)i, (u64)j)); }
+            wgt[i] = fmul(num, fpow(den, P - 2));
+        }
+        for (int ci = 0; ci < D; ci++) {
+            if (fadd(m[ci] % P, m[D + ci] % P) != cur[ci]) { st = 1; break; }
+            u64 v = 0;
+            for (int i = 0; i < 4; i++) v = fadd(v, fmul(m[i * D + ci] % P, wgt[i]));
+            cur[ci] = v;
+        }
+    }
+    if (!st) {
+        tr->absorb_ring(evals, 4);
+        const u64 e = eq_eval(r.data(), ro, nvars);
+        u64 t[D] = {0};
+        rmul_acc(t, evals + D, evals + 2 * D);
+        for (int i = 0; i < D; i++) if (fmul(e, fsub(t[i], evals[3 * D + i] % P)) != cur[i]) st = 2;
+    }
+    if (stage) *stage = st;
+    return st ? LFPLUS_E_REJECT : LFPLUS_OK;
+}
+// DecompProof::verify (decomp.rs:101-123), host only: C0 + B C1 = cm_f (stage 1) and v0 + B v1 = v over `count` pairs (stage 2)
+extern "C" int lfplus_decomp_verify(const uint64_t *C0, const uint64_t *C1, uint32_t kappa, const uint64_t *v0, const uint64_t *v1, uint32_t count, const uint64_t *cm_f,
+                                    const uint64_t *v, uint64_t B, int *stage) {
+    if (!C0 || !C1 || !v0 || !v1 || !cm_f || !v) return LFPLUS_E_ARG;
+    int st = 0;
+    for (size_t i = 0; i < (size_t)kappa * D && !st; i++)
+        if (fadd(C0[i] % P, fmul(B % P, C1[i] % P)) != cm_f[i] % P) st = 1;
+    for (size_t i = 0; i < (size_t)count * 2 * D && !st; i++)
+        if (fadd(v0[i] % P, fmul(B % P, v1[i] % P)) != v[i] % P) st = 2;
+    if (stage) *stage = st;
+    return st ? LFPLUS_E_REJECT : LFPLUS_OK;
+}
+// Mlin::mlin (mlin.rs:42-107): RgInstance::from_f on every resident witness, Cm::prove, then the folded LinB2: cm_g / vo summed over the instances
+// (host, outputs cm_g_sum kappa ring elements, vo_sum (1 + nM) x 2) and g = sum_l g_l on the device -- it becomes ctxs[0]'s resident witness
+// (Decomp::decompose reads it there: plus.rs:90-95).  The Cm outputs are lfplus_cm_prove's.
+extern "C" int lfplus_mlin(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, uint64_t b, uint32_t k, uint32_t l, uint32_t nM, const uint32_t *const *rowptr,
+                           const uint32_t *const *col, const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out, uint64_t *v_out,
+                           uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, uint64_t *comh, uint64_t *pa, uint64_t *pb, uint64_t *ea, uint64_t *eb, uint64_t *cm_g,
+                           uint64_t *ro, uint64_t *vo, uint64_t *fcoms_out, uint64_t *cm_g_sum, uint64_t *vo_sum) {
+    if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
+    lfplus_ctx *c = ctxs[0];
+    if (!cm_g_sum || !vo_sum || !cm_g || !vo) return fail(c, LFPLUS_E_ARG, "lfplus_mlin: bad arguments");
+    for (u32 i = 0; i < L; i++) {
+        if (!ctxs[i]) return fail(c, LFPLUS_E_ARG, "lfplus_mlin: null instance");
+        int rc = lfplus_rg_from_f(ctxs[i], b, k, l);
+        if (rc) { if (i) c->err = ctxs[i]->err; return rc; }
+    }
+    int rc = lfplus_cm_prove(ctxs, L, tr, l, nM, rowptr, col, val, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, comh, pa, pb, ea, eb, cm_g, ro, vo, nullptr);
+    if (rc) return rc;
+    const u32 kappa = c->kappa;
+    const size_t n = c->n;
+    if (fcoms_out)
+        for (u32 i = 0; i < L; i++) {
+            const size_t cw = (size_t)kappa * D;
+            HIPCHK(c, hipMemcpyAsync(fcoms_out + (size_t)i * 3 * cw, ctxs[i]->comMf + (size_t)k * kappa * D * D, cw * 8, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(fcoms_out + (size_t)i * 3 * cw + cw, ctxs[i]->coms, 2 * cw * 8, hipMemcpyDeviceToHost, c->st));
+        }
+    memset(cm_g_sum, 0, (size_t)kappa * D * 8);
+    memset(vo_sum, 0, (size_t)(1 + nM) * 2 * D * 8);
+    for (u32 i = 0; i < L; i++) {
+        for (size_t x = 0; x < (size_t)kappa * D; x++) cm_g_sum[x] = fadd(cm_g_sum[x], cm_g[(size_t)i * kappa * D + x]);
+        for (size_t x = 0; x < (size_t)(1 + nM) * 2 * D; x++) vo_sum[x] = fadd(vo_sum[x], vo[(size_t)i * (1 + nM) * 2 * D + x]);
+        if (i) lfp::launch_vec_add(c->g, ctxs[i]->g, n * D, c->st);
+    }
+    // the folded witness replaces ctxs[0]'s f: the RgInstance results of ctxs[0] no longer describe the resident witness
+    HIPCHK(c, hipMemcpyAsync(c->f, c->g, n * D * 8, hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->have = false;
+    return LFPLUS_OK;
+}

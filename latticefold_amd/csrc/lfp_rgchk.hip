@@ -350,3 +350,59 @@ void launch_cm_fix(const u64 *in, size_t ld_in, u64 *out, size_t ld_out, u32 w, 
     hipLaunchKernelGGL(k_cm_fix, dim3((unsigned)cdiv(half * w, 256), ntab), dim3(256), 0, s, in, ld_in, out, ld_out, w, half, rM);
 }
 }  // namespace lfp
+
+// ---- ComR1CS::linearize (r1cs.rs:76-139) ------------------------------------------------------------------------------------------------------
+namespace lfp {
+// One round of the degree-3 sumcheck of eq (ga gb - gc) (comb_fn r1cs.rs:95; ring products).  E: eq(r, .) Montgomery scalars; G: ga | gb | gc, canonical
+// ring tables [table][ld][16].  thread = (pair, coefficient); part[block][4][16] canonical.
+__global__ void __launch_bounds__(256) k_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part) {
+    const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    __shared__ u64 la[16][16], lb[16][16];
+    u64 s[4] = {0, 0, 0, 0};
+    for (size_t base = (size_t)blockIdx.x * 16; base < half; base += (size_t)gridDim.x * 16) {
+        const size_t b = base + pl;
+        const bool ok = b < half;
+        u64 ex = 0, de = 0, ax = 0, da = 0, bx = 0, db = 0, cx = 0, dc = 0;
+        if (ok) {
+            const u64 *ga = G + (2 * b) * 16 + c, *gb = ga + ld * 16, *gc = gb + ld * 16;
+            ex = E[2 * b]; de = sub_p(E[2 * b + 1], ex);
+            ax = ga[0]; da = sub_p(ga[16], ax);
+            bx = gb[0]; db = sub_p(gb[16], bx);
+            cx = gc[0]; dc = sub_p(gc[16], cx);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            if (x) { ex = add_p(ex, de); ax = add_p(ax, da); bx = add_p(bx, db); cx = add_p(cx, dc); }
+            la[pl][c] = to_mont(ax);
+            lb[pl][c] = bx;
+            __syncthreads();
+            u64 t = 0;
+#pragma unroll
+            for (u32 j = 0; j < 16; j++) {
+                const u64 pr = mont_mul(la[pl][j], lb[pl][(c - j) & 15]);
+                t = j <= c ? add_p(t, pr) : sub_p(t, pr);
+            }
+            s[x] = add_p(s[x], mont_mul(ex, sub_p(t, cx)));
+            __syncthreads();
+        }
+    }
+    __shared__ u64 sm[4][16][16];
+    for (int x = 0; x < 4; x++) sm[x][pl][c] = s[x];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const u32 x = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[x][p][cc]);
+        part[(size_t)blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
+void launch_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part, hipStream_t s) {
+    hipLaunchKernelGGL(k_r1cs_round, dim3(cm_round_blocks(half)), dim3(256), 0, s, E, G, ld, half, part);
+}
+// acc[i] = acc[i] + x[i] mod p
+__global__ void __launch_bounds__(256) k_vec_add(u64 *acc, const u64 *x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] = add_p(acc[i], x[i]);
+}
+void launch_vec_add(u64 *acc, const u64 *x, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_vec_add, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, acc, x, n); }
+}  // namespace lfp

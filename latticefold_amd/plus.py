@@ -74,6 +74,11 @@ def _lib():
         L.lfplus_range_check_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32] + [u64p] * 8 + [ip]
         L.lfplus_cm_prove.argtypes = [vpp, C.c_uint32, vp, C.c_uint32, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 17
         L.lfplus_cm_read_g.argtypes = [vp, u64p]
+        L.lfplus_share_matrix.argtypes = [vp, vp]
+        L.lfplus_r1cs_linearize.argtypes = [vp, vp, u32pp, u32pp, u64pp, u64p, u64p, u64p]
+        L.lfplus_r1cs_verify.argtypes = [vp, C.c_uint32, u64p, u64p, u64p, ip]
+        L.lfplus_decomp_verify.argtypes = [u64p, u64p, C.c_uint32, u64p, u64p, C.c_uint32, u64p, u64p, C.c_uint64, ip]
+        L.lfplus_mlin.argtypes = [vpp, C.c_uint32, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 19
         L.lfplus_cm_verify.argtypes = [vp] + [C.c_uint32] * 6 + [u64pp] + [u64p] * 15 + [ip]
         _READY = True
     return L
@@ -121,6 +126,11 @@ class PlusContext:
         self._chk(_lib().lfplus_set_matrix(self.h, p, A.shape[0], A.shape[1]))
         self.kappa, self.n = A.shape[0], A.shape[1]
 
+    def share_matrix(self, other):
+        """use `other`'s resident commitment matrix (no copy); `other` must stay open"""
+        self._chk(_lib().lfplus_share_matrix(self.h, other.h))
+        self.kappa, self.n = other.kappa, other.n
+
     def set_witness(self, f):
         f, p = _w(f)
         assert f.ndim == 2 and f.shape[1] == D
@@ -151,7 +161,8 @@ class PlusContext:
         -> dict(F0, F1 (n,16); C0, C1 (kappa,16); v0, v1 (1+len(M), 2, 16)): ((LinB0, LinB1), DecompProof) of the reference, flat"""
         if A is not None:
             self.set_matrix(A)
-        self.set_witness(f)
+        if f is not None:              # None: the resident witness (e.g. the folded g Mlin.mlin left there)
+            self.set_witness(f)
         r = np.ascontiguousarray(r, dtype=np.uint64)
         r_a, r_b = np.ascontiguousarray(r[:, 0]), np.ascontiguousarray(r[:, 1])
         keep = [(np.ascontiguousarray(a, dtype=np.uint32), np.ascontiguousarray(b, dtype=np.uint32), np.ascontiguousarray(v, dtype=np.uint64)) for a, b, v in M]
@@ -380,3 +391,224 @@ def cm_verify(transcript, proof, fcoms):
     if rc not in (0, E_REJECT):
         raise LfPlusError(rc, "lfplus_cm_verify")
     return rc == 0, st.value, x
+
+
+
+# ---- ComR1CS / Mlin / PlusProver / PlusVerifier (src/r1cs.rs, lin.rs, mlin.rs, plus.rs) ------------------------------------------------------
+@dataclass
+class LinParameters:
+    """lin.rs:24-28"""
+    kappa: int
+    decomp: DecompParameters
+
+
+@dataclass
+class PlusParameters:
+    """plus.rs:43-47"""
+    lin: LinParameters
+    B: int
+
+
+def _centre(x):
+    x = np.asarray(x, dtype=np.uint64)
+    neg = x > np.uint64(P // 2)
+    return np.where(neg, -((np.uint64(P) - x) * neg).astype(np.int64), (x * ~neg).astype(np.int64))
+
+
+def gadget_decompose(z, b, k):
+    """Vec<R>::gadget_decompose(b, k): element j -> its k balanced base-b digits (coefficient-wise, least significant first) at positions [j k, (j + 1) k)"""
+    cur = _centre(np.asarray(z, dtype=np.uint64).reshape(-1, D))
+    out = np.zeros((cur.shape[0], k, D), dtype=np.int64)
+    half = b // 2
+    for i in range(k):
+        q, rem = np.divmod(cur, b)                       # floor division: rem in [0, b)
+        hi = rem > half
+        rem, q = np.where(hi, rem - b, rem), np.where(hi, q + 1, q)
+        if b % 2 == 0:                                    # |rem| == b / 2 keeps the sign of the value (truncating division in the reference)
+            flip = (rem == half) & (cur < 0)
+            rem, q = np.where(flip, rem - b, rem), np.where(flip, q + 1, q)
+        out[:, i], cur = rem, q
+    out = out.reshape(-1, D)
+    return np.where(out < 0, np.uint64(P) - np.abs(out).astype(np.uint64), out.astype(np.uint64))
+
+
+def identity_csr(m):
+    """SparseMatrix::identity(m) as (rowptr, col, val[nnz][16])"""
+    val = np.zeros((m, D), dtype=np.uint64)
+    val[:, 0] = 1
+    return np.arange(m + 1, dtype=np.uint32), np.arange(m, dtype=np.uint32), val
+
+
+def gadget_decompose_csr(mat, b, k):
+    """SparseMatrix::gadget_decompose(b, k): rows x m -> rows x (m k) with (M G) gadget_decompose(z) = M z: coefficient c at column j becomes
+    c b^i at columns j k + i"""
+    rowptr, col, val = (np.asarray(x) for x in mat)
+    pw = [pow(b, i, P) for i in range(k)]
+    v = np.asarray(val, dtype=np.uint64).astype(object)
+    nv = np.stack([(v * pw[i]) % P for i in range(k)], axis=1).astype(np.uint64).reshape(-1, D)
+    ncol = (np.asarray(col, dtype=np.uint32)[:, None] * np.uint32(k) + np.arange(k, dtype=np.uint32)[None, :]).reshape(-1)
+    return (np.asarray(rowptr, dtype=np.uint32) * np.uint32(k)).astype(np.uint32), ncol.astype(np.uint32), nv
+
+
+def pad_rows(mat, n):
+    rowptr, col, val = mat
+    rowptr = np.asarray(rowptr, dtype=np.uint32)
+    return np.concatenate([rowptr, np.full(n + 1 - rowptr.size, rowptr[-1], dtype=np.uint32)]), col, val
+
+
+def r1cs_decomposed_square(r1cs, n, b, k):
+    """r1cs.rs:170-184: the three matrices gadget-decomposed (m -> m k columns) and padded to n rows"""
+    return tuple(pad_rows(gadget_decompose_csr(m, b, k), n) for m in r1cs)
+
+
+@dataclass
+class ComR1CS:
+    """r1cs.rs:21-58: r1cs = (A, B, C) CSR matrices (n x n), z the short witness, f = z.gadget_decompose(b, k), cm_f = A f"""
+    r1cs: tuple
+    z: np.ndarray
+    f: np.ndarray
+    cm_f: np.ndarray
+    l_in: int = 1
+
+    @staticmethod
+    def new(ctx, r1cs, z, l_in, b, k, A=None):
+        if A is not None:
+            ctx.set_matrix(A)
+        f = gadget_decompose(z, b, k)
+        return ComR1CS(tuple(r1cs), np.asarray(z, dtype=np.uint64), f, ctx.commit(f), l_in)
+
+    def matrices(self):
+        return list(self.r1cs)
+
+    def linearize(self, ctx, transcript):
+        """Linearize::linearize (r1cs.rs:76-139) on `ctx` (the witness becomes resident there) -> (LinB fields, ComR1CSProof fields)"""
+        ctx.set_witness(self.f)
+        n = self.f.shape[0]
+        nvars = n.bit_length() - 1
+        keep, rp, cp, vp = _csr_args(self.r1cs)
+        msgs, ro, ev = np.zeros((nvars, 4, D), dtype=np.uint64), np.zeros(nvars, dtype=np.uint64), np.zeros((4, D), dtype=np.uint64)
+        ctx._chk(_lib().lfplus_r1cs_linearize(ctx.h, transcript.h, rp, cp, vp, *[x.ctypes.data_as(u64p) for x in (msgs, ro, ev)]))
+        proof = {"msgs": msgs, "nvars": nvars, "r": ro, "evals": ev}
+        linb = {"f": self.f, "cm_f": self.cm_f, "r": ro, "v": ev}
+        return linb, proof
+
+
+def r1cs_verify(transcript, proof):
+    """ComR1CSProof::verify (r1cs.rs:141-162), host -> (accepted, stage, ro)"""
+    msgs, ev = (np.ascontiguousarray(proof[key], dtype=np.uint64) for key in ("msgs", "evals"))
+    ro, st = np.zeros(proof["nvars"], dtype=np.uint64), C.c_int()
+    rc = _lib().lfplus_r1cs_verify(transcript.h, proof["nvars"], msgs.ctypes.data_as(u64p), ev.ctypes.data_as(u64p), ro.ctypes.data_as(u64p), C.byref(st))
+    if rc not in (0, E_REJECT):
+        raise LfPlusError(rc, "lfplus_r1cs_verify")
+    return rc == 0, st.value, ro
+
+
+def decomp_verify(dproof, cm_f, v, B):
+    """DecompProof::verify (decomp.rs:101-123), host -> (accepted, stage)"""
+    arr = [np.ascontiguousarray(x, dtype=np.uint64) for x in (dproof["C0"], dproof["C1"], dproof["v0"], dproof["v1"], cm_f, v)]
+    st = C.c_int()
+    rc = _lib().lfplus_decomp_verify(arr[0].ctypes.data_as(u64p), arr[1].ctypes.data_as(u64p), arr[0].shape[0], arr[2].ctypes.data_as(u64p),
+                                     arr[3].ctypes.data_as(u64p), arr[2].shape[0], arr[4].ctypes.data_as(u64p), arr[5].ctypes.data_as(u64p), B, C.byref(st))
+    if rc not in (0, E_REJECT):
+        raise LfPlusError(rc, "lfplus_decomp_verify")
+    return rc == 0, st.value
+
+
+def mlin(ctxs, transcript, params, M=()):
+    """Mlin{lins, params}.mlin(&A, &M, transcript) (mlin.rs:42-107) over the resident witnesses of ctxs -> (LinB2X fields, CmProof fields).  The folded
+    witness g stays on the device as ctxs[0]'s resident witness."""
+    L, nM, c0 = len(ctxs), len(M), ctxs[0]
+    n, k, kappa, dp = c0.n, params.decomp.k, c0.kappa, params.decomp
+    nvars = n.bit_length() - 1
+    per = 4 + 4 * nM
+    keep, rp, cp, vp = _csr_args(M)
+    hs = (C.c_void_p * L)(*[c.h for c in ctxs])
+    z = lambda *shape: np.zeros(shape, dtype=np.uint64)
+    o = {"r": z(nvars), "msgs": z(nvars, 4, D), "e": z(1 + nM, L * k, D, D), "b": z(L, D), "v": z(L, D), "a": z(L, 1 + nM), "bb": z(L, 1 + nM, D),
+         "c": z(L, 1 + nM, D), "comh": z(L, kappa, D), "pa": z(nvars, 3, D), "pb": z(nvars, 3, D), "ea": z(L, per, D), "eb": z(L, per, D),
+         "cm_g": z(L, kappa, D), "ro": z(2, nvars), "vo": z(L, 1 + nM, 2, D), "fcoms": z(L, 3, kappa, D)}
+    x = {"cm_g": z(kappa, D), "vo": z(1 + nM, 2, D)}
+    keys = ("r", "msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb", "cm_g", "ro", "vo", "fcoms")
+    c0._chk(_lib().lfplus_mlin(hs, L, transcript.h, dp.b, dp.k, dp.l, nM, rp, cp, vp, *[o[key].ctypes.data_as(u64p) for key in keys],
+                               x["cm_g"].ctypes.data_as(u64p), x["vo"].ctypes.data_as(u64p)))
+    for c in ctxs:
+        c._k = k
+    o.update(k=k, ell=dp.l, kappa=kappa, nvars=nvars)
+    x["ro"] = o["ro"]
+    return x, o
+
+
+def _ro_pairs(ro):
+    """ComX.ro: Vec<(R, R)> -- the two sumcheck points as pairs of ring constants, (nvars, 2, 16)"""
+    out = np.zeros((ro.shape[1], 2, D), dtype=np.uint64)
+    out[:, 0, 0], out[:, 1, 0] = ro[0], ro[1]
+    return out
+
+
+class PlusProver:
+    """plus.rs:15-108.  One context per instance (2 accumulated + ncomp fresh); all share the Ajtai matrix of the first."""
+
+    def __init__(self, A, M, ncomp, params, transcript, device=0):
+        self.M, self.params, self.transcript = list(M), params, transcript
+        self.ctxs = [PlusContext(device) for _ in range(2 + ncomp)]
+        self.ctxs[0].set_matrix(A)
+        for c in self.ctxs[1:]:
+            c.share_matrix(self.ctxs[0])
+        self.acc = []          # the accumulated LinB witnesses (host copies of F0, F1)
+
+    @staticmethod
+    def init(A, M, ncomp, params, transcript, device=0):
+        return PlusProver(A, M, ncomp, params, transcript, device)
+
+    def close(self):
+        for c in reversed(self.ctxs):
+            c.close()
+        self.ctxs = []
+
+    def prove(self, comp):
+        """PlusProver::prove (plus.rs:77-108) -> PlusProof fields: linb2x, lproof, cmproof, dproof"""
+        nacc = len(self.acc)
+        if nacc + len(comp) > len(self.ctxs):
+            raise LfPlusError(E_ARG, "PlusProver.prove: more instances than contexts (ncomp)")
+        ctxs = self.ctxs[:nacc + len(comp)]
+        lproof = []
+        for i, ci in enumerate(comp):
+            _, lp = ci.linearize(ctxs[nacc + i], self.transcript)
+            lproof.append(lp)
+        for i, f in enumerate(self.acc):
+            ctxs[i].set_witness(f)
+        linb2x, cmproof = mlin(ctxs, self.transcript, self.params.lin, self.M)
+        dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.M)
+        self.acc = [dec["F0"], dec["F1"]]
+        dproof = {key: dec[key] for key in ("C0", "C1", "v0", "v1")}
+        return {"linb2x": linb2x, "lproof": lproof, "cmproof": cmproof, "dproof": dproof}
+
+
+class PlusVerifier:
+    """plus.rs:25-33, 110-146 (host only).  verify returns True, or False with .stage = (which proof, stage) -- the reference panics there"""
+
+    def __init__(self, A, M, params, transcript):
+        self.M, self.params, self.transcript = list(M), params, transcript
+        self.stage = None
+
+    @staticmethod
+    def init(A, M, params, transcript):
+        return PlusVerifier(A, M, params, transcript)
+
+    def verify(self, proof):
+        for i, lp in enumerate(proof["lproof"]):
+            ok, st, _ = r1cs_verify(self.transcript, lp)
+            if not ok:
+                self.stage = (f"lproof[{i}]", st)
+                return False
+        cm = proof["cmproof"]
+        ok, st, _ = cm_verify(self.transcript, cm, cm["fcoms"])
+        if not ok:
+            self.stage = ("cmproof", st)
+            return False
+        ok, st = decomp_verify(proof["dproof"], proof["linb2x"]["cm_g"], proof["linb2x"]["vo"], self.params.B)
+        if not ok:
+            self.stage = ("dproof", st)
+            return False
+        self.stage = None
+        return True

@@ -86,6 +86,12 @@ int lfp_cm_verify(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned e
                   const uint64_t *msgs, const uint64_t *e, const uint64_t *b, const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *c,
                   const uint64_t *comh, const uint64_t *pa, const uint64_t *pb, const uint64_t *ea, const uint64_t *eb, uint64_t *cm_g, uint64_t *ro,
                   uint64_t *vo);
+/* ComR1CS::linearize / ComR1CSProof::verify (r1cs.rs:76-162), DecompProof::verify (decomp.rs:101-123); shapes in lfp_protocol.c */
+int lfp_r1cs_linearize(lfp_tr *tr, unsigned nvars, const uint64_t *f, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
+                       uint64_t *msgs, uint64_t *ro, uint64_t *evals);
+int lfp_r1cs_verify(lfp_tr *tr, unsigned nvars, const uint64_t *msgs, const uint64_t *evals, uint64_t *ro);
+int lfp_decomp_verify(const uint64_t *C0, const uint64_t *C1, unsigned kappa, const uint64_t *v0, const uint64_t *v1, unsigned count, const uint64_t *cm_f,
+                      const uint64_t *v, uint64_t B);
 #ifdef __cplusplus
 }
 #endif

@@ -780,3 +780,59 @@ int lfp_cm_verify(lfp_tr *tr, unsigned nvars, unsigned L, unsigned k, unsigned e
     free(r); free(sp); free(u); free(tc0); free(tc1); free(tcch); free(t0); free(t1);
     return rc;
 }
+
+/* ---- ComR1CS::linearize / ComR1CSProof::verify (r1cs.rs:76-162) ----------------------------------------------------------------------------- */
+/* comb_fn of r1cs.rs:95: vals = [eq | ga | gb | gc] -> eq (ga gb - gc), ring products */
+static void r1cs_comb(const u64 *vals, void *ctx, u64 *out) {
+    (void)ctx;
+    u64 t[D];
+    lfp_ring_mul(vals + D, vals + 2 * D, t);
+    for (int i = 0; i < D; i++) t[i] = fsub(t[i], vals[3 * D + i]);
+    lfp_ring_mul(vals, t, out);
+}
+/* f: n = 2^nvars ring elements; the three R1CS matrices n x n in CSR form.  Outputs: msgs nvars x 4 ring elements (degree 3), ro nvars words, evals = v | va | vb
+ * | vc (4 ring elements: f, A f, B f, C f at ro) */
+int lfp_r1cs_linearize(lfp_tr *tr, unsigned nvars, const u64 *f, const uint32_t *const *rowptr, const uint32_t *const *col, const u64 *const *val, u64 *msgs,
+                       u64 *ro, u64 *evals) {
+    size_t n = (size_t)1 << nvars;
+    u64 *g[3], *tab[4], r[64];
+    for (int q = 0; q < 3; q++) {
+        csr m = {n, rowptr[q], col[q], val[q]};
+        g[q] = (u64 *)malloc(n * D * sizeof(u64));
+        spmv_ring(&m, f, g[q]);
+    }
+    for (unsigned j = 0; j < nvars; j++) r[j] = lfp_tr_challenge(tr);
+    u64 *eq = build_eq(r, nvars);
+    tab[0] = (u64 *)calloc(n * D, sizeof(u64));
+    for (size_t i = 0; i < n; i++) tab[0][i * D] = eq[i];
+    free(eq);
+    for (int q = 0; q < 3; q++) { tab[1 + q] = (u64 *)malloc(n * D * sizeof(u64)); memcpy(tab[1 + q], g[q], n * D * sizeof(u64)); }
+    ring_sumcheck_prove(tr, tab, 4, nvars, 3, r1cs_comb, NULL, msgs, ro);
+    u64 *eqo = build_eq(ro, nvars);
+    mle_eval_ring(f, n, eqo, evals);
+    for (int q = 0; q < 3; q++) mle_eval_ring(g[q], n, eqo, evals + (size_t)(1 + q) * D);
+    free(eqo);
+    lfp_tr_absorb(tr, evals, 4);
+    for (int q = 0; q < 3; q++) free(g[q]);
+    for (int t = 0; t < 4; t++) free(tab[t]);
+    return 0;
+}
+/* 0 accepted; -1 a sumcheck round; -2 e (va vb - vc) != s (r1cs.rs:159, an assert_eq in the reference) */
+int lfp_r1cs_verify(lfp_tr *tr, unsigned nvars, const u64 *msgs, const u64 *evals, u64 *ro) {
+    u64 r[64], zero[D] = {0}, s[D], t[D], want[D];
+    for (unsigned j = 0; j < nvars; j++) r[j] = lfp_tr_challenge(tr);
+    if (ring_sumcheck_verify(tr, nvars, 3, zero, msgs, ro, s)) return -1;
+    lfp_tr_absorb(tr, evals, 4);
+    u64 e = eq_eval(r, ro, nvars);
+    lfp_ring_mul(evals + D, evals + 2 * D, t);
+    for (int i = 0; i < D; i++) want[i] = fmul(e, fsub(t[i], evals[3 * D + i] % P));
+    return memcmp(want, s, sizeof(want)) ? -2 : 0;
+}
+/* DecompProof::verify (decomp.rs:101-123): C0 + B C1 = cm_f and v0 + B v1 = v (count pairs); 0 / -1 commitment / -2 evaluations */
+int lfp_decomp_verify(const u64 *C0, const u64 *C1, unsigned kappa, const u64 *v0, const u64 *v1, unsigned count, const u64 *cm_f, const u64 *v, u64 B) {
+    for (size_t i = 0; i < (size_t)kappa * D; i++)
+        if (fadd(C0[i] % P, fmul(B % P, C1[i] % P)) != cm_f[i] % P) return -1;
+    for (size_t i = 0; i < (size_t)count * 2 * D; i++)
+        if (fadd(v0[i] % P, fmul(B % P, v1[i] % P)) != v[i] % P) return -2;
+    return 0;
+}

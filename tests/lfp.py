@@ -305,3 +305,122 @@ def cm_verify(tr, proof, fcoms):
     rc = L_.lfp_cm_verify(tr.h, nvars, L, k, ell, kappa, nM, fptr, *[_p(arr[key].reshape(-1)) for key in ("msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb")],
                           _p(x["cm_g"].reshape(-1)), _p(x["ro"].reshape(-1)), _p(x["vo"].reshape(-1)))
     return rc, x
+
+
+# ---- ComR1CS::linearize, Mlin::mlin, PlusProver::prove, PlusVerifier::verify (r1cs.rs, mlin.rs, plus.rs) restated over the oracle's C pieces --------
+def r1cs_linearize(tr, nvars, f, r1cs):
+    keep, rp, cp, vp = csr_args(r1cs)
+    f = np.ascontiguousarray(f, dtype=np.uint64)
+    o = {"msgs": np.zeros((nvars, 4, D), dtype=np.uint64), "r": np.zeros(nvars, dtype=np.uint64), "evals": np.zeros((4, D), dtype=np.uint64)}
+    L_ = _plib()
+    u32pp, u64pp = C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64p)
+    L_.lfp_r1cs_linearize.argtypes = [C.c_void_p, C.c_uint, u64p, u32pp, u32pp, u64pp, u64p, u64p, u64p]
+    rc = L_.lfp_r1cs_linearize(tr.h, nvars, _p(f.reshape(-1)), rp, cp, vp, _p(o["msgs"].reshape(-1)), _p(o["r"]), _p(o["evals"].reshape(-1)))
+    assert rc == 0
+    o["nvars"] = nvars
+    return o
+
+
+def r1cs_verify(tr, proof):
+    L_ = _plib()
+    L_.lfp_r1cs_verify.argtypes = [C.c_void_p, C.c_uint, u64p, u64p, u64p]
+    msgs, ev = (np.ascontiguousarray(proof[key], dtype=np.uint64) for key in ("msgs", "evals"))
+    ro = np.zeros(proof["nvars"], dtype=np.uint64)
+    return L_.lfp_r1cs_verify(tr.h, proof["nvars"], _p(msgs.reshape(-1)), _p(ev.reshape(-1)), _p(ro)), ro
+
+
+def decomp_verify(dproof, cm_f, v, B):
+    L_ = _plib()
+    L_.lfp_decomp_verify.argtypes = [u64p, u64p, C.c_uint, u64p, u64p, C.c_uint, u64p, u64p, C.c_uint64]
+    arr = [np.ascontiguousarray(x, dtype=np.uint64) for x in (dproof["C0"], dproof["C1"], dproof["v0"], dproof["v1"], cm_f, v)]
+    return L_.lfp_decomp_verify(_p(arr[0].reshape(-1)), _p(arr[1].reshape(-1)), arr[0].shape[0], _p(arr[2].reshape(-1)), _p(arr[3].reshape(-1)), arr[2].shape[0],
+                                _p(arr[4].reshape(-1)), _p(arr[5].reshape(-1)), B)
+
+
+def gadget_decompose(z, b, k):
+    """Vec<R>::gadget_decompose(b, k) through lfp_balanced_digits (element j -> positions [j k, (j + 1) k), least significant digit first)"""
+    z = np.asarray(z, dtype=np.uint64).reshape(-1, D)
+    L_ = lib()
+    L_.lfp_balanced_digits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint, C.POINTER(C.c_int64)]
+    table = {}
+    for v in np.unique(z):
+        dg = (C.c_int64 * k)()
+        L_.lfp_balanced_digits(int(v), b, k, dg)
+        table[int(v)] = [int(x) % P for x in dg]
+    out = np.zeros((z.shape[0], k, D), dtype=np.uint64)
+    for v, dg in table.items():
+        mask = z == np.uint64(v)
+        for i in range(k):
+            out[:, i][mask] = dg[i]
+    return out.reshape(-1, D)
+
+
+def identity_csr(m):
+    val = np.zeros((m, D), dtype=np.uint64)
+    val[:, 0] = 1
+    return np.arange(m + 1, dtype=np.uint32), np.arange(m, dtype=np.uint32), val
+
+
+def r1cs_decomposed_square(r1cs, n, b, k):
+    """r1cs.rs:170-184 with SparseMatrix::gadget_decompose = right-multiplication by the gadget matrix (coefficient c at column j -> c b^i at j k + i)"""
+    out = []
+    for rowptr, col, val in r1cs:
+        nr, nc, nv = [0], [], []
+        for r in range(len(rowptr) - 1):
+            for t in range(rowptr[r], rowptr[r + 1]):
+                for i in range(k):
+                    nc.append(int(col[t]) * k + i)
+                    nv.append([(int(x) * pow(b, i, P)) % P for x in val[t]])
+            nr.append(len(nc))
+        nr += [len(nc)] * (n + 1 - len(nr))
+        out.append((np.array(nr, dtype=np.uint32), np.array(nc, dtype=np.uint32), np.array(nv, dtype=np.uint64).reshape(-1, D)))
+    return tuple(out)
+
+
+def addmod(a, b):
+    s = a + b                                     # wraps mod 2^64; a, b < p < 2^64 < 2p
+    return np.where((s < a) | (s >= np.uint64(P)), s - np.uint64(P), s)
+
+
+class PlusOracle:
+    """PlusProver (plus.rs:49-108): linearize every fresh instance, Mlin::mlin over accumulated + fresh, Decomp::decompose of the folded witness"""
+
+    def __init__(self, A, M, kappa, b, k, l, B, tr):
+        self.A, self.M, self.kappa, self.b, self.k, self.l, self.B, self.tr = np.ascontiguousarray(A, dtype=np.uint64), list(M), kappa, b, k, l, B, tr
+        self.acc = []
+
+    def prove(self, comps):
+        n = self.A.shape[1]
+        nvars = n.bit_length() - 1
+        lproof = [r1cs_linearize(self.tr, nvars, f, r1cs) for f, r1cs in comps]
+        lins = self.acc + [f for f, _ in comps]
+        insts = []
+        for f in lins:
+            rg = rg_from_f(f, self.A, self.b, self.k, self.l)
+            tau_i = np.array([int(t) if int(t) <= P // 2 else int(t) - P for t in rg["tau"]], dtype=np.int8)
+            insts.append({"Mf": exp_dense(rg["Df"]), "tau": rg["tau"], "mtau": exp_dense(tau_i), "f": f, "comMf": rg["comMf"],
+                          "fcoms": np.stack([rg["cm_f"], rg["C_Mf"], rg["cm_mtau"]])})
+        cm = cm_prove(self.tr, nvars, insts, self.k, self.l, self.kappa, self.M)
+        cm["fcoms"] = np.stack([i["fcoms"] for i in insts])
+        g, cm_g, vo = cm["g"][0], cm["cm_g"][0], cm["vo"][0]
+        for i in range(1, len(lins)):
+            g, cm_g, vo = addmod(g, cm["g"][i]), addmod(cm_g, cm["cm_g"][i]), addmod(vo, cm["vo"][i])
+        r_a, r_b = np.zeros((nvars, D), dtype=np.uint64), np.zeros((nvars, D), dtype=np.uint64)
+        r_a[:, 0], r_b[:, 0] = cm["ro"][0], cm["ro"][1]
+        dec = decompose(g, self.A, self.B, r_a, r_b, self.M)
+        self.acc = [dec["F0"], dec["F1"]]
+        return {"linb2x": {"cm_g": cm_g, "ro": cm["ro"], "vo": vo}, "lproof": lproof, "cmproof": cm, "dproof": {key: dec[key] for key in ("C0", "C1", "v0", "v1")},
+                "g": g}
+
+
+def plus_verify(tr, proof, B):
+    """PlusVerifier::verify (plus.rs:134-146) -> 0, or (which, rc)"""
+    for i, lp in enumerate(proof["lproof"]):
+        rc = r1cs_verify(tr, lp)[0]
+        if rc:
+            return (f"lproof[{i}]", rc)
+    rc = cm_verify(tr, proof["cmproof"], proof["cmproof"]["fcoms"])[0]
+    if rc:
+        return ("cmproof", rc)
+    rc = decomp_verify(proof["dproof"], proof["linb2x"]["cm_g"], proof["linb2x"]["vo"], B)
+    return ("dproof", rc) if rc else 0

@@ -126,3 +126,54 @@ def test_cm_verifier_accepts_oracle_proofs_and_rejects_tampering():
     # kappa' k d l d > n: "t0 too large!" (cm.rs:601) -> stage 7 on both sides
     t = dict(pr, ell=64)
     assert plus.cm_verify(plus.PoseidonTranscript(), t, fcoms)[1] == 7 and lfp.cm_verify(lfp.Transcript(), t, fcoms)[0] == -7
+
+
+def test_plus_verifier_accepts_oracle_proofs_and_rejects_tampering():
+    """PlusVerifier::verify (plus.rs:134-146) of the product, host only, over two rounds of the oracle's PlusProver: ComR1CSProof::verify, CmProof::verify and
+    DecompProof::verify agree with the oracle's verdicts and stages"""
+    from math import ceil, log, sqrt
+    n, k, kappa, L = 1 << 15, 4, 1, 3
+    a, c = 16 * 128 * L, 8 + 16 * k + 1
+    B = ceil((a + sqrt(a * a + 4 * a * c)) / 2) // 2
+    l = ceil(log(P) / log(8))
+    A = lfp.splitmix(22, 0, kappa * n * D).reshape(kappa, n, D)
+    r1cs = lfp.r1cs_decomposed_square((lfp.identity_csr(n // k),) * 3, n, B, k)
+    # the product's host-side R1CS helpers build the same matrices and the same gadget decomposition
+    mine = plus.r1cs_decomposed_square((plus.identity_csr(n // k),) * 3, n, B, k)
+    for m0, m1 in zip(r1cs, mine):
+        assert all((np.asarray(x) == np.asarray(y)).all() for x, y in zip(m0, m1))
+    rng = np.random.default_rng(6)
+    zs = []
+    for _ in range(3):
+        z = np.zeros((n // k, D), dtype=np.uint64)
+        z[:, 0] = rng.integers(0, 2, size=n // k)
+        zs.append(z)
+    zr = rng.integers(0, P, size=(64, D), dtype=np.uint64)
+    assert (plus.gadget_decompose(zr, B, k) == lfp.gadget_decompose(zr, B, k)).all()
+    assert (plus.gadget_decompose(zr, 8, 22) == lfp.gadget_decompose(zr, 8, 22)).all()
+    prover = lfp.PlusOracle(A, list(r1cs), kappa, 8, k, l, B, lfp.Transcript())
+    params = plus.PlusParameters(plus.LinParameters(kappa, plus.DecompParameters(8, k, l)), B)
+    ver, ts_o = plus.PlusVerifier.init(A, list(r1cs), params, plus.PoseidonTranscript()), lfp.Transcript()
+    for rnd, comps in enumerate(([zs[0], zs[1]], [zs[2]])):
+        proof = prover.prove([(lfp.gadget_decompose(z, B, k), r1cs) for z in comps])
+        if rnd == 0:
+            for where, key, idx, want in (("lproof", "msgs", (2, 1, 0), ("lproof[1]", 1)), ("lproof", "evals", (2, 3), ("lproof[1]", 2)),
+                                          ("cmproof", "pb", (4, 1, 2), ("cmproof", 6)), ("dproof", "v1", (1, 0, 3), ("dproof", 2)),
+                                          ("dproof", "C1", (0, 5), ("dproof", 1))):
+                t = dict(proof)
+                if where == "lproof":
+                    lp = dict(proof["lproof"][1])
+                    lp[key] = lp[key].copy()
+                    lp[key][idx] = (int(lp[key][idx]) + 1) % P
+                    t["lproof"] = [proof["lproof"][0], lp]
+                else:
+                    sub = dict(proof[where])
+                    sub[key] = sub[key].copy()
+                    sub[key][idx] = (int(sub[key][idx]) + 1) % P
+                    t[where] = sub
+                v2 = plus.PlusVerifier.init(A, list(r1cs), params, plus.PoseidonTranscript())
+                assert not v2.verify(t) and v2.stage == want, (where, key, v2.stage)
+                got = lfp.plus_verify(lfp.Transcript(), t, B)
+                assert got == (want[0], -want[1]), got
+        assert ver.verify(proof) and lfp.plus_verify(ts_o, proof, B) == 0
+    assert ver.transcript.get_challenge() == ts_o.challenge()

@@ -154,3 +154,57 @@ def test_cm_prove_completeness_and_soundness(L, nM, kappa, nvars):
         t[key] = pr[key].copy()
         t[key][idx] = (int(t[key][idx]) + 1) % P
         assert lfp.cm_verify(lfp.Transcript(), t, [i["fcoms"] for i in insts])[0] != 0, key
+
+
+def _r1cs_identity(n, k, B):
+    m = n // k
+    return lfp.r1cs_decomposed_square((lfp.identity_csr(m),) * 3, n, B, k)
+
+
+def test_r1cs_linearize_completeness_and_soundness():
+    """r1cs.rs:186-233 (test_linearization: identity constraint system, z = 1, gadget-decomposed), restated on the Frog ring with a 0/1 witness (z z = z)"""
+    n, nvars, k, b = 1 << 7, 7, 4, 2
+    r1cs = _r1cs_identity(n, k, b)
+    z = np.zeros((n // k, D), dtype=np.uint64)
+    z[::3, 0] = 1
+    f = lfp.gadget_decompose(z, b, k)
+    pr = lfp.r1cs_linearize(lfp.Transcript(), nvars, f, r1cs)
+    rc, ro = lfp.r1cs_verify(lfp.Transcript(), pr)
+    assert rc == 0 and (ro == pr["r"]).all()
+    # an unsatisfied system (z = 2: 2 * 2 != 2) is rejected: the claimed sum is no longer zero
+    z[:, 0] = 2
+    bad = lfp.r1cs_linearize(lfp.Transcript(), nvars, lfp.gadget_decompose(z, 8, k), _r1cs_identity(n, k, 8))
+    assert lfp.r1cs_verify(lfp.Transcript(), bad)[0] == -1
+    for key, idx, want in (("msgs", (0, 0, 0), -1), ("msgs", (3, 2, 5), -1), ("evals", (1, 0), -2), ("evals", (3, 2), -2)):
+        t = dict(pr)
+        t[key] = pr[key].copy()
+        t[key][idx] = (int(t[key][idx]) + 1) % P
+        assert lfp.r1cs_verify(lfp.Transcript(), t)[0] == want, key
+
+
+def test_plus_prove_and_verify_two_rounds():
+    """plus.rs:148-272 (test_prove / test_prove_multi) at a size the CPU restatement folds in seconds: kappa 1, k 4, n 2^15; two fresh instances in the
+    first round, one more folded into the accumulator in the second"""
+    from math import ceil, log, sqrt
+    n, k, kappa, L = 1 << 15, 4, 1, 3
+    a, c = 16 * 128 * L, 8 + 16 * k + 1                     # utils::estimate_bound(sop, L, d, k) (utils.rs:102-112)
+    B = ceil((a + sqrt(a * a + 4 * a * c)) / 2) // 2
+    l = ceil(log(P) / log(8))
+    A = lfp.splitmix(21, 0, kappa * n * D).reshape(kappa, n, D)
+    r1cs = _r1cs_identity(n, k, B)
+    rng = np.random.default_rng(5)
+
+    def comp():
+        z = np.zeros((n // k, D), dtype=np.uint64)
+        z[:, 0] = rng.integers(0, 2, size=n // k)
+        return lfp.gadget_decompose(z, B, k), r1cs
+
+    prover, ts_v = lfp.PlusOracle(A, list(r1cs), kappa, 8, k, l, B, lfp.Transcript()), lfp.Transcript()
+    for rnd, ncomp in enumerate((2, 1)):
+        proof = prover.prove([comp() for _ in range(ncomp)])
+        assert proof["cmproof"]["b"].shape[0] == (2 if rnd else 0) + ncomp
+        assert (lfp.commit(A, proof["g"]) == proof["linb2x"]["cm_g"]).all()
+        if rnd == 0:
+            t = dict(proof, dproof=dict(proof["dproof"], C0=(proof["dproof"]["C0"] + np.uint64(1)) % np.uint64(P)))
+            assert lfp.plus_verify(ts_v.clone(), t, B) == ("dproof", -1)
+        assert lfp.plus_verify(ts_v, proof, B) == 0
