@@ -97,6 +97,7 @@ int lfplus_transcript_challenge(lfplus_transcript *t, uint64_t *out);
 int lfplus_transcript_squeeze_bytes(lfplus_transcript *t, size_t n, uint8_t *out);
 int lfplus_short_challenge(lfplus_transcript *t, uint64_t *out16);
 int lfplus_poseidon_params(uint64_t *ark720, uint64_t *mds576);   /* the regenerated Frog table (checksummed against the reference's) */
+int lfplus_poseidon_permute(uint64_t *state24, int plain);        /* one permutation; plain != 0: the textbook form (self-test of the optimised one) */
 
 /* In::set_check (src/setchk.rs:65-262): nmat matrix sets of n x ncols unit monomials and nvec vector sets of n, n = 2^nvars, as exponent
  * digits (int8 in (-8, 8); LFPLUS_ABSENT = zero entry); nM matrices (n x n, CSR, ring coefficients) for the M_i f rows of Step 3.
@@ -136,6 +137,10 @@ int lfplus_cm_verify(lfplus_transcript *t, uint32_t nvars, uint32_t L, uint32_t 
                      const uint64_t *comh, const uint64_t *pa, const uint64_t *pb, const uint64_t *ea, const uint64_t *eb, uint64_t *cm_g, uint64_t *ro,
                      uint64_t *vo, int *stage);
 
+/* The constraint-system matrices (n x n, CSR, ring coefficients) made resident once: every entry point that takes (nM, rowptr, col, val) uses them when
+ * rowptr is NULL (nM must equal their number; for the multi-instance calls they are taken from ctxs[0]).  lfplus_set_matrices(ctx, n, 0, ..) drops them. */
+int lfplus_set_matrices(lfplus_ctx *ctx, uint64_t n, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val);
+int lfplus_share_matrices(lfplus_ctx *ctx, lfplus_ctx *from);   /* use `from`'s resident matrices (same device, no copy; `from` must outlive the use) */
 /* ComR1CS::linearize (src/r1cs.rs:76-139) on the resident witness f (lfplus_set_witness; n = 2^nvars ring elements) and the R1CS matrices A, B, C
  * (n x n, CSR, ring coefficients): g_q = M_q f, the degree-3 ring-valued sumcheck of eq(r, x) (g_A g_B - g_C)(x), evaluations at ro.
  * Outputs: msgs (nvars x 4 ring elements), ro (nvars words), evals = v | va | vb | vc (4 ring elements). */

@@ -28,6 +28,7 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     if (!c->own_A) c->A = nullptr;
+    c->drop_mats();
     for (void *p : {(void *)c->A, (void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
                     (void *)c->err_d, (void *)c->g})
         if (p) (void)hipFree(p);
@@ -267,7 +268,9 @@ static u64 to_mont(u64 a) { return (u64)((((unsigned __int128)a) << 64) % lfp::P
 extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
                                 const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1, uint64_t *v0,
                                 uint64_t *v1) {
-    if (!c || !r_a || !r_b || (nm && (!rowptr || !col || !val))) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: null argument");
+    if (!c || !r_a || !r_b || (nm && rowptr && (!col || !val))) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: null argument");
+    const bool resident = nm && !rowptr;   // the matrices lfplus_set_matrices left in the context
+    if (resident && (c->mats.size() != nm || c->mats_n != c->n)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: no resident matrices of this shape");
     if (!c->A || !c->f || c->nf != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: matrix / witness not set or of different length");
     const u64 n = c->n;
     if (n & (n - 1)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: n must be a power of two (nvars = log2(A.ncols))");
@@ -275,7 +278,7 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
     u32 nvars = 0;
     while (((u64)1 << nvars) < n) nvars++;
     if (!canonical(r_a, (size_t)nvars * 16) || !canonical(r_b, (size_t)nvars * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: non-canonical point");
-    for (u32 j = 0; j < nm; j++) {
+    for (u32 j = 0; j < nm && !resident; j++) {
         if (!rowptr[j] || !col[j] || !val[j] || rowptr[j][0] != 0) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: bad CSR");
         for (u64 r = 0; r < n; r++)
             if (rowptr[j][r + 1] < rowptr[j][r]) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: rowptr not monotone");
@@ -312,9 +315,18 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
         lfp::launch_replicate(Fi, vw, 2, tab + (size_t)(s * (1 + nm)) * 2 * vw, c->st);
     }
     for (u32 j = 0; j < nm; j++) {
-        const u32 nnz = rowptr[j][n];
         u32 *drp = nullptr, *dci = nullptr;
         u64 *dv = nullptr, *dy = nullptr;
+        if (resident) {
+            HIPCHK2(hipMalloc(&dy, vw * 8)); tofree.push_back(dy);
+            const LfpMatrix &mj = c->mats[j];
+            for (int s = 0; s < 2; s++) {
+                lfp::launch_spmv_ring(mj.rowptr, mj.col, mj.valM, s ? dF1 : dF0, n, dy, c->st);
+                lfp::launch_replicate(dy, vw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * vw, c->st);
+            }
+            continue;
+        }
+        const u32 nnz = rowptr[j][n];
         HIPCHK2(hipMalloc(&drp, (n + 1) * 4)); tofree.push_back(drp);
         HIPCHK2(hipMalloc(&dci, (size_t)(nnz ? nnz : 1) * 4)); tofree.push_back(dci);
         HIPCHK2(hipMalloc(&dv, (size_t)(nnz ? nnz : 1) * 16 * 8)); tofree.push_back(dv);

@@ -9,6 +9,20 @@
 using lfp::u32;
 using lfp::u64;
 
+// one n x n sparse matrix with ring coefficients, resident in both orientations
+struct LfpMatrix {
+    u32 *rowptr = nullptr, *col = nullptr;      // CSR
+    u64 *valM = nullptr;                        //   Montgomery coefficients (launch_spmv_ring)
+    u32 *colptr = nullptr, *rowidx = nullptr;   // CSC
+    u64 *valT = nullptr;                        //   canonical coefficients (launch_spmvT_eq)
+    size_t nnz = 0;
+    void release() {
+        for (void *p : {(void *)rowptr, (void *)col, (void *)valM, (void *)colptr, (void *)rowidx, (void *)valT})
+            if (p) (void)hipFree(p);
+        rowptr = col = colptr = rowidx = nullptr; valM = valT = nullptr; nnz = 0;
+    }
+};
+
 struct lfplus_ctx {
     int device = 0;
     hipStream_t st = nullptr;
@@ -29,7 +43,16 @@ struct lfplus_ctx {
     // the folded witness of the last lfplus_cm_prove (cm.rs:164-181): n ring elements
     u64 *g = nullptr;
     u64 g_n = 0;
-    bool own_A = true;   // false: A belongs to another context (lfplus_share_matrix)
+    bool own_A = true;
+    std::vector<LfpMatrix> mats;   // lfplus_set_matrices: the constraint-system matrices, uploaded once
+    u64 mats_n = 0;
+    bool own_mats = true;          // false: they belong to another context (lfplus_share_matrices)
+    void drop_mats() {
+        if (own_mats) for (LfpMatrix &m : mats) m.release();
+        mats.clear();
+        mats_n = 0;
+        own_mats = true;
+    }   // false: A belongs to another context (lfplus_share_matrix)
 };
 
 #define HIPCHK(c, x)                                                                        \

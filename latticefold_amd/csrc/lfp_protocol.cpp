@@ -34,7 +34,8 @@ struct Params {
 };
 const Params &params() { static const Params p; return p; }
 inline u64 pow7(u64 x) { u64 x2 = fmul(x, x), x4 = fmul(x2, x2); return fmul(fmul(x4, x2), x); }
-void permute(u64 *st) {
+// the definition (ark-crypto-primitives PoseidonSponge::permute): the self-test reference of permute()
+void permute_plain(u64 *st) {
     const Params &pp = params();
     u64 nw[W];
     for (int r = 0; r < RF + RP; r++) {
@@ -48,6 +49,137 @@ void permute(u64 *st) {
         }
         memcpy(st, nw, sizeof(nw));
     }
+}
+
+// ---- the permutation as it runs: Montgomery words, lazy row sums, sparse partial rounds ---------------------------------------------------
+// (a prove at n = 2^15 makes ~500 permutations; the plain form costs 80 us each on the host and was most of the wall time.)
+// Partial rounds through the factorisation M diag(1, E) = diag(1, E') [[e00, row], [col, I]] (Poseidon paper, appendix on optimised partial rounds; the
+// same construction as lf_host.cpp uses for the Goldilocks table): identical output, 47 instead of 576 multiplications per partial round.
+struct FastPerm {
+    u64 pinv, r2;                                  // p^-1 mod 2^64, 2^128 mod p
+    u64 ark[(RF + RP) * W], mds[W * W];            // Montgomery
+    u64 cst[RP][W], e00[RP], row[RP][W - 1], col[RP][W - 1], post[(W - 1) * (W - 1)];
+    inline u64 mm(u64 a, u64 b) const {            // a b 2^-64 mod p
+        const u128 t = (u128)a * b;
+        const u64 m = (u64)t * pinv, th = (u64)(t >> 64), mh = (u64)(((u128)m * P) >> 64);
+        return th >= mh ? th - mh : th + (P - mh);
+    }
+    // sum_j a[j] b[j] 2^-64 mod p, one reduction per sum
+    inline u64 dot(const u64 *a, const u64 *b, int n) const {
+        u128 lo = 0, hi = 0;
+        for (int j = 0; j < n; j++) { const u128 pr = (u128)a[j] * b[j]; lo += (u64)pr; hi += (u64)(pr >> 64); }
+        // value = lo + 2^64 hi: REDC(x) = x 2^-64 is linear, so reduce the two words separately
+        return fadd(redc(lo), small(hi));
+    }
+    static inline u64 small(u128 h) {              // h < 2^70 mod p without a 128-bit division: 2^64 = 2^64 - p (mod p)
+        u128 t = (u128)(u64)(h >> 64) * (u64)(0 - P) + (u64)h;
+        while (t >= P) t -= P;                     // t < 2^67: at most a few subtractions
+        return (u64)t;
+    }
+    inline u64 redc(u128 t) const {                // t 2^-64 mod p for any t < 2^128
+        const u64 m = (u64)t * pinv, th = (u64)(t >> 64), mh = (u64)(((u128)m * P) >> 64);
+        u64 r = th >= mh ? th - mh : th + (P - mh);   // th < 2^64 may exceed p
+        return r >= P ? r - P : r;
+    }
+    static bool mat_inv(const u64 *in, u64 *out, int n) {   // Gauss-Jordan over F_p, canonical words
+        std::vector<u64> M((size_t)n * 2 * n, 0);
+        for (int r = 0; r < n; r++) {
+            for (int c = 0; c < n; c++) M[(size_t)r * 2 * n + c] = in[r * n + c];
+            M[(size_t)r * 2 * n + n + r] = 1;
+        }
+        for (int cc = 0; cc < n; cc++) {
+            int piv = -1;
+            for (int r = cc; r < n; r++) if (M[(size_t)r * 2 * n + cc]) { piv = r; break; }
+            if (piv < 0) return false;
+            if (piv != cc) for (int c = 0; c < 2 * n; c++) std::swap(M[(size_t)piv * 2 * n + c], M[(size_t)cc * 2 * n + c]);
+            const u64 inv = fpow(M[(size_t)cc * 2 * n + cc], P - 2);
+            for (int c = 0; c < 2 * n; c++) M[(size_t)cc * 2 * n + c] = fmul(M[(size_t)cc * 2 * n + c], inv);
+            for (int r = 0; r < n; r++) {
+                const u64 f = M[(size_t)r * 2 * n + cc];
+                if (r == cc || !f) continue;
+                for (int c = 0; c < 2 * n; c++) M[(size_t)r * 2 * n + c] = fsub(M[(size_t)r * 2 * n + c], fmul(f, M[(size_t)cc * 2 * n + c]));
+            }
+        }
+        for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) out[r * n + c] = M[(size_t)r * 2 * n + n + c];
+        return true;
+    }
+    bool ok = false;
+    FastPerm() {
+        const Params &pp = params();
+        u64 x = 1;
+        for (int i = 0; i < 6; i++) x *= 2 - P * x;   // Newton: p^-1 mod 2^64
+        pinv = x;
+        r2 = to_mont(to_mont(1));
+        const int n = W - 1;
+        std::vector<u64> Eprev((size_t)n * n, 0), EprevInv((size_t)n * n, 0), eff((size_t)W * W), Eh((size_t)n * n), Ei((size_t)n * n);
+        for (int i = 0; i < n; i++) Eprev[(size_t)i * n + i] = EprevInv[(size_t)i * n + i] = 1;
+        for (int r = 0; r < RP; r++) {
+            const u64 *c = pp.ark + (size_t)(RF / 2 + r) * W;
+            cst[r][0] = to_mont(c[0]);
+            for (int i = 0; i < n; i++) {               // constants pulled through the deferred factor: c' = diag(1, Eprev^-1) c
+                u64 acc = 0;
+                for (int k = 0; k < n; k++) acc = fadd(acc, fmul(EprevInv[(size_t)i * n + k], c[1 + k]));
+                cst[r][1 + i] = to_mont(acc);
+            }
+            for (int i = 0; i < W; i++) {               // eff = M diag(1, Eprev)
+                eff[(size_t)i * W] = pp.mds[i * W];
+                for (int j = 0; j < n; j++) {
+                    u64 acc = 0;
+                    for (int k = 0; k < n; k++) acc = fadd(acc, fmul(pp.mds[i * W + 1 + k], Eprev[(size_t)k * n + j]));
+                    eff[(size_t)i * W + 1 + j] = acc;
+                }
+            }
+            for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Eh[(size_t)i * n + j] = eff[(size_t)(1 + i) * W + 1 + j];
+            if (!mat_inv(Eh.data(), Ei.data(), n)) return;   // (never for this table; permute() then keeps the plain form)
+            e00[r] = to_mont(eff[0]);
+            for (int j = 0; j < n; j++) row[r][j] = to_mont(eff[1 + j]);
+            for (int i = 0; i < n; i++) {
+                u64 acc = 0;
+                for (int k = 0; k < n; k++) acc = fadd(acc, fmul(Ei[(size_t)i * n + k], eff[(size_t)(1 + k) * W]));
+                col[r][i] = to_mont(acc);
+            }
+            Eprev = Eh;
+            EprevInv = Ei;
+        }
+        for (int i = 0; i < n * n; i++) post[i] = to_mont(Eprev[i]);
+        for (int i = 0; i < (RF + RP) * W; i++) ark[i] = to_mont(pp.ark[i]);
+        for (int i = 0; i < W * W; i++) mds[i] = to_mont(pp.mds[i]);
+        ok = true;
+    }
+    inline u64 sbox(u64 x) const { const u64 x2 = mm(x, x), x4 = mm(x2, x2); return mm(mm(x4, x2), x); }
+    inline void full_round(u64 *st, const u64 *a) const {
+        u64 nw[W];
+        for (int i = 0; i < W; i++) st[i] = sbox(fadd(st[i], a[i]));
+        for (int i = 0; i < W; i++) nw[i] = dot(st, mds + i * W, W);
+        memcpy(st, nw, sizeof(nw));
+    }
+    void run(u64 *st) const {
+        for (int i = 0; i < W; i++) st[i] = mm(st[i] % P, r2);
+        for (int r = 0; r < RF / 2; r++) full_round(st, ark + r * W);
+        for (int r = 0; r < RP; r++) {
+            for (int i = 0; i < W; i++) st[i] = fadd(st[i], cst[r][i]);
+            const u64 x0 = sbox(st[0]);
+            // y0 = e00 x0 + row . x[1..];  y_i = col_i x0 + x_i
+            u128 lo = (u128)e00[r] * x0, hi = (u64)(lo >> 64);
+            lo = (u64)lo;
+            for (int j = 0; j < W - 1; j++) { const u128 pr = (u128)row[r][j] * st[1 + j]; lo += (u64)pr; hi += (u64)(pr >> 64); }
+            for (int i = 0; i < W - 1; i++) st[1 + i] = fadd(st[1 + i], mm(col[r][i], x0));
+            st[0] = fadd(redc(lo), small(hi));
+        }
+        {
+            u64 nw[W - 1];
+            for (int i = 0; i < W - 1; i++) nw[i] = dot(st + 1, post + i * (W - 1), W - 1);
+            memcpy(st + 1, nw, sizeof(nw));
+        }
+        for (int r = RF / 2 + RP; r < RF + RP; r++) full_round(st, ark + r * W);
+        for (int i = 0; i < W; i++) st[i] = mm(st[i], 1);
+    }
+};
+const FastPerm &fastperm() { static const FastPerm f; return f; }
+void permute(u64 *st) {
+    const FastPerm &f = fastperm();
+    if (f.ok) f.run(st);
+    else permute_plain(st);
 }
 }  // namespace
 
@@ -128,6 +260,13 @@ int lfplus_short_challenge(lfplus_transcript *t, uint64_t *out16) {
     for (int i = 0; i < D; i++) { const int v = (int)bs[i] - 128; out16[i] = v >= 0 ? (u64)v : P - (u64)(-v); }
     return LFPLUS_OK;
 }
+// one permutation of a 24-word state (canonical words): plain != 0 runs the textbook definition, else the form the transcript uses
+int lfplus_poseidon_permute(uint64_t *state24, int plain) {
+    if (!state24) return LFPLUS_E_ARG;
+    for (int i = 0; i < W; i++) state24[i] %= P;
+    if (plain) permute_plain(state24); else permute(state24);
+    return LFPLUS_OK;
+}
 int lfplus_poseidon_params(uint64_t *ark720, uint64_t *mds576) {
     if (!ark720 || !mds576) return LFPLUS_E_ARG;
     memcpy(ark720, params().ark, sizeof(params().ark));
@@ -145,41 +284,67 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 struct SetRef { const int8_t *dig; u32 ncols; };   // device pointer to the exponent digits [n][ncols]
-struct DevCsc { DevBuf colptr, rowidx, val; };
-
-// transposes the caller's CSR matrices (n rows, ring coefficients) on the host and uploads them
-int upload_csc(lfplus_ctx *c, size_t n, u32 nM, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, std::vector<std::unique_ptr<DevCsc>> &out) {
-    for (u32 q = 0; q < nM; q++) {
-        if (!rowptr[q] || !col[q] || !val[q] || rowptr[q][0] != 0) return fail(c, LFPLUS_E_ARG, "matrix: null / malformed CSR");
-        const size_t nnz = rowptr[q][n];
-        std::vector<u32> cp(n + 1, 0), ri(nnz);
-        std::vector<u64> vv(nnz * D);
-        for (size_t r = 0; r < n; r++) {
-            if (rowptr[q][r + 1] < rowptr[q][r]) return fail(c, LFPLUS_E_ARG, "matrix: rowptr not monotone");
-            for (u32 k = rowptr[q][r]; k < rowptr[q][r + 1]; k++) {
-                if (col[q][k] >= n) return fail(c, LFPLUS_E_ARG, "matrix: column index out of range");
-                cp[col[q][k] + 1]++;
-            }
-        }
-        if (!canonical(val[q], nnz * D)) return fail(c, LFPLUS_E_ARG, "matrix: non-canonical word");
-        for (size_t i = 0; i < n; i++) cp[i + 1] += cp[i];
-        std::vector<u32> fill(cp.begin(), cp.end() - 1);
-        for (size_t r = 0; r < n; r++)
-            for (u32 k = rowptr[q][r]; k < rowptr[q][r + 1]; k++) {
-                const u32 dst = fill[col[q][k]]++;
-                ri[dst] = (u32)r;
-                memcpy(&vv[(size_t)dst * D], val[q] + (size_t)k * D, D * 8);
-            }
-        std::unique_ptr<DevCsc> m(new DevCsc);
-        if (m->colptr.alloc((n + 1) * 4) || m->rowidx.alloc(nnz * 4) || m->val.alloc(nnz * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
-        HIPCHK(c, hipMemcpyAsync(m->colptr.p, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(m->rowidx.p, ri.data(), nnz * 4, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(m->val.p, vv.data(), nnz * D * 8, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
-        out.push_back(std::move(m));
+// n x n CSR matrices (ring coefficients) -> device, both orientations; the transposition runs on the host, the Montgomery conversion on the device
+int upload_matrix(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, const u64 *val, LfpMatrix &m) {
+    if (!rowptr || !col || !val || rowptr[0] != 0) return fail(c, LFPLUS_E_ARG, "matrix: null / malformed CSR");
+    for (size_t r = 0; r < n; r++) if (rowptr[r + 1] < rowptr[r]) return fail(c, LFPLUS_E_ARG, "matrix: rowptr not monotone");
+    const size_t nnz = rowptr[n];
+    std::vector<u32> cp(n + 1, 0), ri(nnz);
+    for (size_t k = 0; k < nnz; k++) {
+        if (col[k] >= n) return fail(c, LFPLUS_E_ARG, "matrix: column index out of range");
+        cp[col[k] + 1]++;
     }
+    if (!canonical(val, nnz * D)) return fail(c, LFPLUS_E_ARG, "matrix: non-canonical word");
+    for (size_t i = 0; i < n; i++) cp[i + 1] += cp[i];
+    std::vector<u32> fill(cp.begin(), cp.end() - 1);
+    std::vector<u64> vv(nnz * D);
+    for (size_t r = 0; r < n; r++)
+        for (u32 k = rowptr[r]; k < rowptr[r + 1]; k++) {
+            const u32 dst = fill[col[k]]++;
+            ri[dst] = (u32)r;
+            memcpy(&vv[(size_t)dst * D], val + (size_t)k * D, D * 8);
+        }
+    m.nnz = nnz;
+    const size_t vb = (nnz ? nnz : 1) * D * 8, ib = (nnz ? nnz : 1) * 4;
+    if (hipMalloc(&m.rowptr, (n + 1) * 4) != hipSuccess || hipMalloc(&m.col, ib) != hipSuccess || hipMalloc(&m.valM, vb) != hipSuccess ||
+        hipMalloc(&m.colptr, (n + 1) * 4) != hipSuccess || hipMalloc(&m.rowidx, ib) != hipSuccess || hipMalloc(&m.valT, vb) != hipSuccess)
+        return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
+    HIPCHK(c, hipMemcpyAsync(m.rowptr, rowptr, (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(m.col, col, nnz * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(m.valT, val, nnz * D * 8, hipMemcpyHostToDevice, c->st));     // staged through valT, converted below
+    lfp::launch_to_mont(m.valT, nnz * D, m.valM, c->st);
+    HIPCHK(c, hipMemcpyAsync(m.colptr, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(m.rowidx, ri.data(), nnz * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(m.valT, vv.data(), nnz * D * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));   // the host staging vectors die here
     return LFPLUS_OK;
 }
+// the matrices of one call: the caller's CSR arrays uploaded for the duration of the call, or (rowptr == NULL) the set lfplus_set_matrices left in the context
+struct MatHold {
+    std::vector<LfpMatrix> own;
+    const LfpMatrix *m = nullptr;
+    u32 count = 0;
+    ~MatHold() { for (LfpMatrix &x : own) x.release(); }
+    int get(lfplus_ctx *c, size_t n, u32 nM, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val) {
+        count = nM;
+        if (!nM) return LFPLUS_OK;
+        if (!rowptr) {
+            if (c->mats.size() != nM || c->mats_n != n) return fail(c, LFPLUS_E_ARG, "no resident matrices of this shape (lfplus_set_matrices)");
+            m = c->mats.data();
+            return LFPLUS_OK;
+        }
+        if (!col || !val) return fail(c, LFPLUS_E_ARG, "matrix: null argument");
+        own.resize(nM);
+        for (u32 q = 0; q < nM; q++) {
+            int rc = upload_matrix(c, n, rowptr[q], col[q], val[q], own[q]);
+            if (rc) return rc;
+        }
+        m = own.data();
+        return LFPLUS_OK;
+    }
+    const LfpMatrix &operator[](u32 q) const { return m[q]; }
+    u32 size() const { return count; }
+};
 
 struct ScOut {          // device-side leftovers the range check reuses
     DevBuf eqr;         // eq(r, .) Montgomery, n words
@@ -189,7 +354,7 @@ struct ScOut {          // device-side leftovers the range check reuses
 
 // In::set_check on device-resident monomial sets (matrix sets first, then vector sets, as setchk.rs:66-82 orders them)
 int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::vector<SetRef> &mats, const std::vector<SetRef> &vecs,
-                  const std::vector<std::unique_ptr<DevCsc>> &M, u64 *r_out, u64 *msgs, u64 *e_out, u64 *b_out, ScOut &so) {
+                  const MatHold &M, u64 *r_out, u64 *msgs, u64 *e_out, u64 *b_out, ScOut &so) {
     const size_t n = (size_t)1 << nvars;
     const u32 nmat = (u32)mats.size(), nvec = (u32)vecs.size(), nM = (u32)M.size();
     if (nmat < 1) return fail(c, LFPLUS_E_ARG, "set_check: at least one matrix set (setchk.rs:63)");
@@ -266,7 +431,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     for (u32 q = 0; q < nM; q++) {
         std::unique_ptr<DevBuf> w(new DevBuf);
         if (w->alloc(n * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (M^T eq)");
-        lfp::launch_spmvT_eq(M[q]->colptr.as<u32>(), M[q]->rowidx.as<u32>(), M[q]->val.as<u64>(), so.eqr.as<u64>(), n, w->as<u64>(), c->st);
+        lfp::launch_spmvT_eq(M[q].colptr, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), n, w->as<u64>(), c->st);
         so.w.push_back(std::move(w));
     }
     u64 *ed = so.small.as<u64>(), *bd = ed + (size_t)(1 + nM) * nmat * ncols * D;
@@ -291,8 +456,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
 extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t nvars, const int8_t *mat_digits, uint32_t nmat, uint32_t ncols,
                                 const int8_t *vec_digits, uint32_t nvec, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col,
                                 const uint64_t *const *val, uint64_t *r_out, uint64_t *msgs, uint64_t *e_out, uint64_t *b_out) {
-    if (!c || !tr || !mat_digits || !nmat || !ncols || ncols > 64 || nvars < 1 || nvars > 28 || (nvec && !vec_digits) || !r_out || !msgs || !e_out || (nvec && !b_out) ||
-        (nM && (!rowptr || !col || !val)))
+    if (!c || !tr || !mat_digits || !nmat || !ncols || ncols > 64 || nvars < 1 || nvars > 28 || (nvec && !vec_digits) || !r_out || !msgs || !e_out || (nvec && !b_out))
         return fail(c, LFPLUS_E_ARG, "lfplus_set_check: bad arguments");
     const size_t n = (size_t)1 << nvars;
     for (size_t i = 0; i < (size_t)nmat * n * ncols + (size_t)nvec * n; i++) {
@@ -307,8 +471,8 @@ extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t n
     std::vector<SetRef> mats, vecs;
     for (u32 i = 0; i < nmat; i++) mats.push_back({dm.as<int8_t>() + (size_t)i * n * ncols, ncols});
     for (u32 i = 0; i < nvec; i++) vecs.push_back({dv.as<int8_t>() + (size_t)i * n, 1});
-    std::vector<std::unique_ptr<DevCsc>> M;
-    int rc = upload_csc(c, n, nM, rowptr, col, val, M);
+    MatHold M;
+    int rc = M.get(c, n, nM, rowptr, col, val);
     if (rc) return rc;
     ScOut so;
     return set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so);
@@ -317,7 +481,7 @@ extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t n
 // Rg::range_check (rgchk.rs:81-186) on L resident instances: ctxs[l] holds the witness f_l and the results of lfplus_rg_from_f (D_f, tau,
 // m_tau) -- all on the same device, same n = 2^nvars and k.  Runs on ctxs[0]'s stream.
 namespace {
-int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, const std::vector<std::unique_ptr<DevCsc>> &M, uint64_t *r_out, uint64_t *msgs,
+int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, const MatHold &M, uint64_t *r_out, uint64_t *msgs,
                      uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, ScOut &so) {
     lfplus_ctx *c = ctxs[0];
     const u32 nM = (u32)M.size();
@@ -374,12 +538,12 @@ extern "C" int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_tr
                                   uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out) {
     if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
     lfplus_ctx *c = ctxs[0];
-    if (!tr || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out || (nM && (!rowptr || !col || !val)))
+    if (!tr || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out)
         return fail(c, LFPLUS_E_ARG, "lfplus_range_check: bad arguments");
     if (!c->n || (c->n & (c->n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_range_check: n must be a power of two");
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<std::unique_ptr<DevCsc>> M;
-    int rc = upload_csc(c, c->n, nM, rowptr, col, val, M);
+    MatHold M;
+    int rc = M.get(c, c->n, nM, rowptr, col, val);
     if (rc) return rc;
     ScOut so;
     return range_check_core(ctxs, L, tr, M, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, so);
@@ -562,11 +726,12 @@ bool calc_t(const u64 *cz, u32 logk, const std::vector<u64> &sp, u32 kd, u32 ell
             u64 pw = 1;
             for (u32 i = 0; i < ell; i++) {
                 const u64 sc = fmul(tc[a], pw);
+                u64 e[D];                                   // tensor_c[a] d'^i s'[b]; its 16 rotations X^m e follow without products
+                for (int t = 0; t < D; t++) e[t] = fmul(sp[(size_t)b * D + t], sc);
                 for (int m = 0; m < D; m++) {
                     u64 *o = &out[(((a * kd + b) * ell + i) * D + m) * D];
                     for (int t = 0; t < D; t++) {
-                        const u64 v = fmul(sp[(size_t)b * D + t], sc);
-                        if (t + m < D) o[t + m] = v; else o[t + m - D] = fsub(0, v);
+                        if (t + m < D) o[t + m] = e[t]; else o[t + m - D] = fsub(0, e[t]);
                     }
                 }
                 pw = fmul(pw, D / 2);
@@ -594,7 +759,6 @@ void cm_x(const CmChallenges &ch, u32 L, u32 kappa, u32 nM, const u64 *const *fc
             }
     }
 }
-struct DevCsr { DevBuf rowptr, col, valM; };
 }  // namespace
 
 // Cm::prove on L resident instances (as lfplus_range_check: ctxs[l] holds f_l, the commitment matrix and the from_f results; `ell` is
@@ -608,8 +772,7 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
                                uint64_t *eb, uint64_t *cm_g, uint64_t *ro, uint64_t *vo, uint64_t *g_out) {
     if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
     lfplus_ctx *c = ctxs[0];
-    if (!tr || !ell || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out || !comh || !pa || !pb || !ea || !eb || !cm_g || !ro || !vo ||
-        (nM && (!rowptr || !col || !val)))
+    if (!tr || !ell || !r_out || !msgs || !e_out || !b_out || !v_out || !a_out || !bb_out || !c_out || !comh || !pa || !pb || !ea || !eb || !cm_g || !ro || !vo)
         return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: bad arguments");
     const size_t n = c->n;
     if (!n || (n & (n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: n must be a power of two");
@@ -619,8 +782,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     for (u32 l = 0; l < L; l++)
         if (!ctxs[l] || ctxs[l]->kappa != kappa) return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: instances of different shapes");
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<std::unique_ptr<DevCsc>> M;
-    int rc = upload_csc(c, n, nM, rowptr, col, val, M);
+    MatHold M;
+    int rc = M.get(c, n, nM, rowptr, col, val);
     if (rc) return rc;
     ScOut so;
     rc = range_check_core(ctxs, L, tr, M, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, so);
@@ -660,24 +823,11 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     // tables.  Scalars (Montgomery): eq(r, .) | tau_l.  Ring (canonical): per instance m_tau, f, h, then per matrix M tau, M m_tau, M f, M h; then t0, t1
     const u32 per = 4 + 4 * nM, nring = L * (per - 1), nS = 1 + L, nR = nring + 2;
     DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring;
-    std::vector<std::unique_ptr<DevCsr>> Mr;
     const u32 nb0 = lfp::cm_round_blocks(n / 2);
     if (S0.alloc((size_t)nS * n * 8) || R0.alloc((size_t)nR * n * D * 8) || Sw[0].alloc((size_t)nS * (n / 2) * 8) || Sw[1].alloc((size_t)nS * (n / 4 + 1) * 8) ||
         Rw[0].alloc((size_t)nR * (n / 2) * D * 8) || Rw[1].alloc((size_t)nR * (n / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
         part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm tables)");
-    for (u32 q = 0; q < nM; q++) {
-        const size_t nnz = rowptr[q][n];
-        std::unique_ptr<DevCsr> m(new DevCsr);
-        std::vector<u64> vM(nnz * D);
-        for (size_t i = 0; i < vM.size(); i++) vM[i] = to_mont(val[q][i]);
-        if (m->rowptr.alloc((n + 1) * 4) || m->col.alloc(nnz * 4) || m->valM.alloc(nnz * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
-        HIPCHK(c, hipMemcpyAsync(m->rowptr.p, rowptr[q], (n + 1) * 4, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(m->col.p, col[q], nnz * 4, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(m->valM.p, vM.data(), vM.size() * 8, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
-        Mr.push_back(std::move(m));
-    }
     u64 *S = S0.as<u64>(), *R = R0.as<u64>();
     HIPCHK(c, hipMemcpyAsync(S, so.eqr.p, n * 8, hipMemcpyDeviceToDevice, c->st));
     for (u32 l = 0; l < L; l++) {
@@ -688,11 +838,10 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         HIPCHK(c, hipMemcpyAsync(base + 2 * n * D, h[l]->p, n * D * 8, hipMemcpyDeviceToDevice, c->st));
         if (nM) lfp::launch_cm_materialize(nullptr, ctxs[l]->tau, n, tauring.as<u64>(), c->st);
         for (u32 q = 0; q < nM; q++) {
-            const DevCsr &m = *Mr[q];
+            const LfpMatrix &m = M[q];
             u64 *mq = base + (size_t)(3 + 4 * q) * n * D;
-            lfp::launch_spmv_ring(m.rowptr.as<u32>(), m.col.as<u32>(), m.valM.as<u64>(), tauring.as<u64>(), n, mq, c->st);
-            for (int j = 0; j < 3; j++)
-                lfp::launch_spmv_ring(m.rowptr.as<u32>(), m.col.as<u32>(), m.valM.as<u64>(), base + (size_t)j * n * D, n, mq + (size_t)(1 + j) * n * D, c->st);
+            lfp::launch_spmv_ring(m.rowptr, m.col, m.valM, tauring.as<u64>(), n, mq, c->st);
+            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr, m.col, m.valM, base + (size_t)j * n * D, n, mq + (size_t)(1 + j) * n * D, c->st);
         }
     }
     HIPCHK(c, hipMemcpyAsync(R + (size_t)nring * n * D, t0.data(), n * D * 8, hipMemcpyHostToDevice, c->st));
@@ -852,16 +1001,17 @@ extern "C" int lfplus_cm_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t 
             // t0, t1 at ro: fold the tables along the point, variable 0 first
             u64 tz[2][D];
             for (int z = 0; z < 2; z++) {
-                std::vector<u64> cur_t = z ? t1 : t0;
-                size_t len = n;
+                // only the first tl k d l d entries are non-zero: fold that prefix (an odd length pairs its last entry with a zero)
+                size_t nz = std::min(n, ((size_t)1 << ch.logk) * k * D * ell * D);
+                std::vector<u64> cur_t((z ? t1 : t0).begin(), (z ? t1 : t0).begin() + nz * D);
                 for (u32 j = 0; j < nvars; j++) {
-                    const size_t half = len / 2;
+                    const size_t half = (nz + 1) / 2;
                     for (size_t i = 0; i < half; i++)
                         for (int ci = 0; ci < D; ci++) {
-                            const u64 lo = cur_t[(2 * i) * D + ci], hi = cur_t[(2 * i + 1) * D + ci];
+                            const u64 lo = cur_t[(2 * i) * D + ci], hi = 2 * i + 1 < nz ? cur_t[(2 * i + 1) * D + ci] : 0;
                             cur_t[i * D + ci] = fadd(lo, fmul(rop[j], fsub(hi, lo)));
                         }
-                    len = half;
+                    nz = half;
                 }
                 memcpy(tz[z], cur_t.data(), D * 8);
             }
@@ -885,23 +1035,32 @@ extern "C" int lfplus_cm_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t 
 }
 
 // ---- ComR1CS::linearize / ComR1CSProof::verify (r1cs.rs:76-162), DecompProof::verify (decomp.rs:101-123), Mlin::mlin (mlin.rs:42-107) -----------
-namespace {
-int upload_csr(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, const u64 *val, DevCsr &m) {
-    if (!rowptr || !col || !val || rowptr[0] != 0) return fail(c, LFPLUS_E_ARG, "matrix: null / malformed CSR");
-    for (size_t r = 0; r < n; r++) if (rowptr[r + 1] < rowptr[r]) return fail(c, LFPLUS_E_ARG, "matrix: rowptr not monotone");
-    const size_t nnz = rowptr[n];
-    for (size_t i = 0; i < nnz; i++) if (col[i] >= n) return fail(c, LFPLUS_E_ARG, "matrix: column index out of range");
-    if (!canonical(val, nnz * D)) return fail(c, LFPLUS_E_ARG, "matrix: non-canonical word");
-    std::vector<u64> vM(nnz * D);
-    for (size_t i = 0; i < vM.size(); i++) vM[i] = to_mont(val[i]);
-    if (m.rowptr.alloc((n + 1) * 4) || m.col.alloc(nnz * 4) || m.valM.alloc(nnz * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
-    HIPCHK(c, hipMemcpyAsync(m.rowptr.p, rowptr, (n + 1) * 4, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(m.col.p, col, nnz * 4, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(m.valM.p, vM.data(), vM.size() * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+// The constraint-system matrices (n x n, CSR, ring coefficients), uploaded once: every entry point of this file that takes (rowptr, col, val) uses them when
+// rowptr is NULL (nM must then equal their number).  PlusProver keeps A, B, C of the R1CS here for linearize, the range check, Cm::prove and Decomp.
+extern "C" int lfplus_set_matrices(lfplus_ctx *c, uint64_t n, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val) {
+    if (!c) return LFPLUS_E_ARG;
+    if (!n || n > (1ull << 32) || nM > 64 || (nM && (!rowptr || !col || !val))) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrices: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->drop_mats();
+    std::vector<LfpMatrix> fresh(nM);
+    for (u32 q = 0; q < nM; q++) {
+        int rc = upload_matrix(c, n, rowptr[q], col[q], val[q], fresh[q]);
+        if (rc) { for (LfpMatrix &m : fresh) m.release(); return rc; }
+    }
+    c->mats.swap(fresh);
+    c->mats_n = n;
     return LFPLUS_OK;
 }
-}  // namespace
+
+// the resident matrices of `from` (same device), not copied; `from` must outlive ctx's use of them
+extern "C" int lfplus_share_matrices(lfplus_ctx *c, lfplus_ctx *from) {
+    if (!c || !from || c == from || c->device != from->device) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrices: bad arguments");
+    c->drop_mats();
+    c->mats = from->mats;
+    c->mats_n = from->mats_n;
+    c->own_mats = false;
+    return LFPLUS_OK;
+}
 
 // ComR1CS::linearize on the resident witness f (lfplus_set_witness; n = 2^nvars ring elements) and the three R1CS matrices (n x n, CSR, ring
 // coefficients; A, B, C in this order).  Outputs: msgs nvars x 4 ring elements (the degree-3 sumcheck), ro (nvars words), evals = v | va | vb | vc
@@ -909,7 +1068,7 @@ int upload_csr(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, const
 extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val,
                                      uint64_t *msgs, uint64_t *ro, uint64_t *evals) {
     if (!c) return LFPLUS_E_ARG;
-    if (!tr || !rowptr || !col || !val || !msgs || !ro || !evals) return fail(c, LFPLUS_E_ARG, "lfplus_r1cs_linearize: bad arguments");
+    if (!tr || !msgs || !ro || !evals) return fail(c, LFPLUS_E_ARG, "lfplus_r1cs_linearize: bad arguments");
     const size_t n = c->nf;
     if (!c->f || n < 2 || (n & (n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_r1cs_linearize: needs a resident witness of 2^nvars ring elements");
     u32 nvars = 0;
@@ -920,13 +1079,10 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     if (E[0].alloc(n * 8) || E[1].alloc(n / 2 * 8) || G[0].alloc((size_t)3 * n * D * 8) || G[1].alloc((size_t)3 * (n / 2) * D * 8) ||
         part.alloc(std::max<size_t>((size_t)nb0 * 64, (size_t)lfp::eval_chunks(n) * D) * 8) || small.alloc(4 * D * 8))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (linearize tables)");
-    for (int q = 0; q < 3; q++) {
-        DevCsr m;
-        int rc = upload_csr(c, n, rowptr[q], col[q], val[q], m);
-        if (rc) return rc;
-        lfp::launch_spmv_ring(m.rowptr.as<u32>(), m.col.as<u32>(), m.valM.as<u64>(), c->f, n, G[0].as<u64>() + (size_t)q * n * D, c->st);
-        HIPCHK(c, hipStreamSynchronize(c->st));   // the matrix buffers die with this iteration
-    }
+    MatHold M;
+    int rcm = M.get(c, n, 3, rowptr, col, val);
+    if (rcm) return rcm;
+    for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr, M[q].col, M[q].valM, c->f, n, G[0].as<u64>() + (size_t)q * n * D, c->st);
     std::vector<u64> r(nvars);
     for (u32 j = 0; j < nvars; j++) r[j] = tr->challenge();
     lfp::EqPt pt;

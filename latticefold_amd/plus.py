@@ -68,6 +68,7 @@ def _lib():
         L.lfplus_transcript_squeeze_bytes.argtypes = [vp, C.c_size_t, u8p]
         L.lfplus_short_challenge.argtypes = [vp, u64p]
         L.lfplus_poseidon_params.argtypes = [u64p, u64p]
+        L.lfplus_poseidon_permute.argtypes = [u64p, C.c_int]
         L.lfplus_set_check.argtypes = [vp, vp, C.c_uint32, i8p, C.c_uint32, C.c_uint32, i8p, C.c_uint32, C.c_uint32, u32pp, u32pp, u64pp, u64p, u64p, u64p, u64p]
         L.lfplus_set_check_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p, u64p, u64p, ip]
         L.lfplus_range_check.argtypes = [vpp, C.c_uint32, vp, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 8
@@ -75,6 +76,8 @@ def _lib():
         L.lfplus_cm_prove.argtypes = [vpp, C.c_uint32, vp, C.c_uint32, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 17
         L.lfplus_cm_read_g.argtypes = [vp, u64p]
         L.lfplus_share_matrix.argtypes = [vp, vp]
+        L.lfplus_set_matrices.argtypes = [vp, C.c_uint64, C.c_uint32, u32pp, u32pp, u64pp]
+        L.lfplus_share_matrices.argtypes = [vp, vp]
         L.lfplus_r1cs_linearize.argtypes = [vp, vp, u32pp, u32pp, u64pp, u64p, u64p, u64p]
         L.lfplus_r1cs_verify.argtypes = [vp, C.c_uint32, u64p, u64p, u64p, ip]
         L.lfplus_decomp_verify.argtypes = [u64p, u64p, C.c_uint32, u64p, u64p, C.c_uint32, u64p, u64p, C.c_uint64, ip]
@@ -131,6 +134,15 @@ class PlusContext:
         self._chk(_lib().lfplus_share_matrix(self.h, other.h))
         self.kappa, self.n = other.kappa, other.n
 
+    def set_matrices(self, M, n=None):
+        """make the constraint-system matrices resident (CSR triples); calls that get M = RESIDENT then use them without another upload"""
+        keep, rp, cp, vp = _csr_args(M)
+        self._chk(_lib().lfplus_set_matrices(self.h, n if n is not None else self.n, len(M), rp, cp, vp))
+        self._nres = len(M)
+
+    def share_matrices(self, other):
+        self._chk(_lib().lfplus_share_matrices(self.h, other.h))
+
     def set_witness(self, f):
         f, p = _w(f)
         assert f.ndim == 2 and f.shape[1] == D
@@ -165,12 +177,8 @@ class PlusContext:
             self.set_witness(f)
         r = np.ascontiguousarray(r, dtype=np.uint64)
         r_a, r_b = np.ascontiguousarray(r[:, 0]), np.ascontiguousarray(r[:, 1])
-        keep = [(np.ascontiguousarray(a, dtype=np.uint32), np.ascontiguousarray(b, dtype=np.uint32), np.ascontiguousarray(v, dtype=np.uint64)) for a, b, v in M]
-        u32p = C.POINTER(C.c_uint32)
-        nm = len(keep)
-        rp = (u32p * max(1, nm))(*[k[0].ctypes.data_as(u32p) for k in keep])
-        cp = (u32p * max(1, nm))(*[k[1].ctypes.data_as(u32p) for k in keep])
-        vp_ = (u64p * max(1, nm))(*[k[2].ctypes.data_as(u64p) for k in keep])
+        nm = len(M)
+        keep, rp, cp, vp_ = _csr_args(M)
         n, kappa = self.n, self.kappa
         out = {"F0": np.zeros((n, D), dtype=np.uint64), "F1": np.zeros((n, D), dtype=np.uint64), "C0": np.zeros((kappa, D), dtype=np.uint64),
                "C1": np.zeros((kappa, D), dtype=np.uint64), "v0": np.zeros((1 + nm, 2, D), dtype=np.uint64), "v1": np.zeros((1 + nm, 2, D), dtype=np.uint64)}
@@ -236,8 +244,18 @@ def exp(digits):
 
 
 # ---- the transcript-driven part (src/transcript.rs, setchk.rs, rgchk.rs:81-258) ------------------------------------------------------------
+class _Resident(tuple):
+    """M = RESIDENT(count): use the matrices lfplus_set_matrices left in the (first) context"""
+
+
+def RESIDENT(count):
+    return _Resident((None,) * count)
+
+
 def _csr_args(mats):
-    """mats: list of (rowptr uint32 [n+1], col uint32 [nnz], val uint64 [nnz][16])"""
+    """mats: list of (rowptr uint32 [n+1], col uint32 [nnz], val uint64 [nnz][16]), or RESIDENT(count)"""
+    if isinstance(mats, _Resident):
+        return [], None, None, None
     keep = [(np.ascontiguousarray(r, dtype=np.uint32), np.ascontiguousarray(c, dtype=np.uint32), np.ascontiguousarray(v, dtype=np.uint64)) for r, c, v in mats]
     u32p = C.POINTER(C.c_uint32)
     n = max(1, len(keep))
@@ -279,6 +297,16 @@ class PoseidonTranscript:
             _lib().lfplus_transcript_free(self.h)
         except Exception:
             pass
+
+
+def poseidon_permute(state, plain=False):
+    """one Poseidon permutation of 24 canonical words; plain: the textbook definition instead of the optimised form the transcript runs"""
+    st = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    assert st.shape == (24,)
+    rc = _lib().lfplus_poseidon_permute(st.ctypes.data_as(u64p), int(plain))
+    if rc:
+        raise LfPlusError(rc, "lfplus_poseidon_permute")
+    return st
 
 
 def poseidon_params():
@@ -480,12 +508,13 @@ class ComR1CS:
     def matrices(self):
         return list(self.r1cs)
 
-    def linearize(self, ctx, transcript):
-        """Linearize::linearize (r1cs.rs:76-139) on `ctx` (the witness becomes resident there) -> (LinB fields, ComR1CSProof fields)"""
+    def linearize(self, ctx, transcript, resident=False):
+        """Linearize::linearize (r1cs.rs:76-139) on `ctx` (the witness becomes resident there) -> (LinB fields, ComR1CSProof fields); resident: the three
+        matrices are the ones ctx.set_matrices / share_matrices left on the device"""
         ctx.set_witness(self.f)
         n = self.f.shape[0]
         nvars = n.bit_length() - 1
-        keep, rp, cp, vp = _csr_args(self.r1cs)
+        keep, rp, cp, vp = _csr_args(RESIDENT(3) if resident else self.r1cs)
         msgs, ro, ev = np.zeros((nvars, 4, D), dtype=np.uint64), np.zeros(nvars, dtype=np.uint64), np.zeros((4, D), dtype=np.uint64)
         ctx._chk(_lib().lfplus_r1cs_linearize(ctx.h, transcript.h, rp, cp, vp, *[x.ctypes.data_as(u64p) for x in (msgs, ro, ev)]))
         proof = {"msgs": msgs, "nvars": nvars, "r": ro, "evals": ev}
@@ -552,8 +581,11 @@ class PlusProver:
         self.M, self.params, self.transcript = list(M), params, transcript
         self.ctxs = [PlusContext(device) for _ in range(2 + ncomp)]
         self.ctxs[0].set_matrix(A)
+        self.ctxs[0].set_matrices(self.M)
         for c in self.ctxs[1:]:
             c.share_matrix(self.ctxs[0])
+            c.share_matrices(self.ctxs[0])
+        self.res = RESIDENT(len(self.M))
         self.acc = []          # the accumulated LinB witnesses (host copies of F0, F1)
 
     @staticmethod
@@ -573,12 +605,13 @@ class PlusProver:
         ctxs = self.ctxs[:nacc + len(comp)]
         lproof = []
         for i, ci in enumerate(comp):
-            _, lp = ci.linearize(ctxs[nacc + i], self.transcript)
+            same = len(self.M) == 3 and all(a is b for x, y in zip(ci.r1cs, self.M) for a, b in zip(x, y))   # (M = cr1cs.x.matrices() in every reference use)
+            _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same)
             lproof.append(lp)
         for i, f in enumerate(self.acc):
             ctxs[i].set_witness(f)
-        linb2x, cmproof = mlin(ctxs, self.transcript, self.params.lin, self.M)
-        dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.M)
+        linb2x, cmproof = mlin(ctxs, self.transcript, self.params.lin, self.res)
+        dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res)
         self.acc = [dec["F0"], dec["F1"]]
         dproof = {key: dec[key] for key in ("C0", "C1", "v0", "v1")}
         return {"linb2x": linb2x, "lproof": lproof, "cmproof": cmproof, "dproof": dproof}

@@ -28,6 +28,17 @@ def test_product_poseidon_table_matches_reference_checksums():
     assert [int(x) for x in ark[:4]] == k["ark_first"]
 
 
+def test_optimised_permutation_equals_the_definition_and_the_oracle():
+    """the transcript runs the permutation in Montgomery form with the partial rounds factored sparse: same output as the textbook form and as the oracle's"""
+    rng = np.random.default_rng(11)
+    L_ = lfp._plib()
+    states = [np.zeros(24, dtype=np.uint64), np.full(24, P - 1, dtype=np.uint64)] + [rng.integers(0, P, size=24, dtype=np.uint64) for _ in range(50)]
+    for st in states:
+        want = st.copy()
+        L_.lfp_poseidon_permute(lfp._p(want))
+        assert (plus.poseidon_permute(st) == want).all() and (plus.poseidon_permute(st, plain=True) == want).all()
+
+
 def test_transcript_equals_oracle_on_random_scripts():
     rng = np.random.default_rng(3)
     tp, to = plus.PoseidonTranscript(), lfp.Transcript()
