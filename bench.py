@@ -207,6 +207,43 @@ def phase_report(wl_name, timelines, host_ms):
     return out, src
 
 
+def lfplus_extra():
+    """SURVEY 8(f) row 4 next to the headline: one LatticeFold+ PlusProver::prove (crates/latticefold-plus/src/plus.rs:77-108) at the reference's test shape
+    (plus.rs:148-217: Frog ring, n = 2^15, kappa 2, k 2, two fresh R1CS instances), GPU prover + host verifier, after the timed region of the metric"""
+    from math import ceil, log
+    import numpy as np
+    from latticefold_amd import plus
+    n, kappa, k, B = 1 << 15, 2, 2, 6186                       # B = estimate_bound(2048, 3, 16, 2) + 1
+    ell = ceil(log(plus.P) / log(8))
+    rng = np.random.default_rng(1)
+    A = rng.integers(0, plus.P, size=(kappa, n, 16), dtype=np.uint64)
+    r1cs = plus.r1cs_decomposed_square((plus.identity_csr(n // k),) * 3, n, B, k)
+    params = plus.PlusParameters(plus.LinParameters(kappa, plus.DecompParameters(8, k, ell)), B)
+    zs = []
+    for _ in range(2):
+        z = np.zeros((n // k, 16), dtype=np.uint64)
+        z[:, 0] = rng.integers(0, 2, size=n // k)
+        zs.append(z)
+    best, proof = None, None
+    for _ in range(3):
+        prover = plus.PlusProver.init(A, list(r1cs), 2, params, plus.PoseidonTranscript())
+        try:
+            comps = [plus.ComR1CS.new(prover.ctxs[0], r1cs, z, 1, B, k) for z in zs]
+            t0 = time.perf_counter()
+            proof = prover.prove(comps)
+            dt = time.perf_counter() - t0
+        finally:
+            prover.close()
+        best = dt if best is None else min(best, dt)
+    t0 = time.perf_counter()
+    ok = plus.PlusVerifier.init(A, list(r1cs), params, plus.PoseidonTranscript()).verify(proof)
+    tv = time.perf_counter() - t0
+    return {"op": "PlusProver::prove", "ring": "Frog Z_p[X]/(X^16+1), coefficient form", "n": n, "kappa": kappa, "k": k, "fresh_instances": 2, "ms": 1e3 * best,
+            "host_verify_ms": 1e3 * tv, "verified": bool(ok), "cpu_oracle_ms": 2430.0,
+            "cpu_oracle_source": "profiles/r03b_lfplus_bench.txt (oracle/lfp*.c, one thread, not re-measured here)",
+            "parity": "bit-exact vs the in-repo oracle (tests/test_gpu_lfplus_prover.py); oracle pinned to the reference through the transcript KATs only"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +251,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lfplus", action="store_true", help="skip the LatticeFold+ PlusProver::prove timing (an extra key, not part of the metric)")
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
                          "stream does --steps steps, value counts all of them.  Default 1 = one prover, latency-honest ms_per_step")
@@ -470,6 +508,11 @@ def main():
             out["exchanges"] = exch
         if replicas_extra is not None:
             out["replicas"] = replicas_extra
+        if world == 1 and not args.no_lfplus:
+            try:
+                out["lfplus"] = lfplus_extra()
+            except Exception as e:   # a reported extra, outside the timed region
+                out["lfplus"] = {"op": "PlusProver::prove", "ms": None, "note": f"failed: {e!r}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl)

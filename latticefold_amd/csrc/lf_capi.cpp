@@ -2240,7 +2240,12 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             RET(c->tbuf("fold_mutab", (size_t)3 * K2 * 3 * 81 * 4, &mutab));
             launch_fold_round_lut_mu(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, mutab, K, d_mu, partial, od, c->stream());
         } else if (fmode == 3) launch_fold_round_lut(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, K, d_mu, partial, od, c->stream());
-        else if (fmode == 4) launch_fold_round_lut_fix(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
+        else if (fmode == 4 && c->dcrt.nu2p40 && !c->tn.fold_no_r4tab) {
+            u64 *r4sq, *r4mt;
+            RET(c->tbuf("fold_r4sq", (size_t)6561 * 4, &r4sq));
+            RET(c->tbuf("fold_r4mt", (size_t)K2 * 3 * 162 * 4, &r4mt));
+            launch_fold_round_lut_fix_tab(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), r4sq, r4mt, (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
+        } else if (fmode == 4) launch_fold_round_lut_fix(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else if (fmode == 1) launch_fold_round_fix(c->dcrt, a, prevF, prevld, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->stream());
         c->ev_end(ev);

@@ -1655,6 +1655,9 @@ void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int3
 //      the digit code replaces both the 4.8 GB k_fold_materialize2 pass and the table reads of this round
 //   4  round 4 on top of mode 3: the four round-3 entries 4p..4p+3 come from the same look-up table, are fixed with r and the pair
 //      is stored to Fsrc.out like in mode 1 (the first materialised tables are the m/8-entry ones)
+//   6  mode 4 without a single reduced product: a fixed entry is f = (1-r) L[c_lo] + r L[c_hi], one of 81^2 values, so its square comes from a 6561-entry
+//      table and mu_kd f = (mu_kd (1-r) L)[c_lo] + (mu_kd r L)[c_hi] from two 81-entry tables per table kd (k_fold_r4tab, rebuilt per step: they depend
+//      on r_3 and mu); the cubic's four sums are then P0..P3 = sum mu f0^3, mu f1 f0^2, mu f0 f1^2, mu f1^3 as in mode 3 -- four lazy products per table
 // (An earlier variant of mode 3 that rebuilt the entries with conditional modular additions measured slower than the separate pass.)
 struct FoldSrc {
     u64 *out; size_t ldo;                 // modes 1, 4: where the fixed pair is written (entries 2p, 2p+1)
@@ -1663,6 +1666,7 @@ struct FoldSrc {
     size_t n_planes;
     const u64 *lut;                       // [2][81][3]: sum_b (t_b - 1) W_b for code = sum_b t_b 3^b, then the squares of those
     const u64 *mutab;                     // mode 5: [3][2K*3][81][4] = mu_kd * value, mu_kd * value^2, mu_kd * value^3 (k_fold_mutab)
+    const u64 *sq4, *mt4;                 // mode 6: [81*81][4] squares of the fixed look-up values, [2K*3][2][81][4] = mu_kd (1 - r) L, mu_kd r L (k_fold_r4tab)
 };
 // per-table products of the 81 look-up values with mu_kd (round 3, mode 5): with them a table costs two lazy products instead of six
 template <bool NU>
@@ -1677,6 +1681,26 @@ __global__ void __launch_bounds__(128) k_fold_mutab(DevCrt t, const u64 *lut, co
     for (int q = 0; q < 3; q++) {
         u64 *o = mutab + (((size_t)q * nkd + kd) * 81 + code) * 4;
         o[0] = v[q].c[0]; o[1] = v[q].c[1]; o[2] = v[q].c[2]; o[3] = 0;
+    }
+}
+// tables of mode 6 (see above): sq[c_lo * 81 + c_hi] = ((1-r) L[c_lo] + r L[c_hi])^2,  mt[kd][0][c] = mu_kd (1-r) L[c],  mt[kd][1][c] = mu_kd r L[c]
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_r4tab(DevCrt t, const u64 *lut, Fq3Const r, const Fq3Const *mu_pow, u32 nkd, u64 *sq, u64 *mt) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const Fq3 rr = fq3_make(r.c[0], r.c[1], r.c[2]);
+    auto L = [&](u32 c) { return fq3_make(lut[3 * c], lut[3 * c + 1], lut[3 * c + 2]); };
+    if (i < 6561) {
+        const u32 c0 = i / 81, c1 = i % 81;
+        const Fq3 l0 = L(c0), f = fq3_add(l0, M3<NU>(fq3_sub(L(c1), l0), rr, t.nu)), sv = M3<NU>(f, f, t.nu);
+        u64 *o = sq + (size_t)i * 4;
+        o[0] = sv.c[0]; o[1] = sv.c[1]; o[2] = sv.c[2]; o[3] = 0;
+    } else if (i < 6561 + nkd * 162) {
+        const u32 j = i - 6561, kd = j / 162, w = (j % 162) / 81, c = j % 81;
+        const Fq3 l = L(c), rl = M3<NU>(l, rr, t.nu);
+        const Fq3Const mc = mu_pow[kd];
+        const Fq3 m = M3<NU>(fq3_make(mc.c[0], mc.c[1], mc.c[2]), w ? rl : fq3_sub(l, rl), t.nu);
+        u64 *o = mt + (((size_t)kd * 2 + w) * 81 + c) * 4;
+        o[0] = m.c[0]; o[1] = m.c[1]; o[2] = m.c[2]; o[3] = 0;
     }
 }
 // digit code of four consecutive plane entries at bit k: 40 + sum_b sign_b * bit_k(|v_b|) * 3^b
@@ -1701,13 +1725,13 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
     if (MODE == 1) { F -= 4 * a.pF0; src.out -= 2 * a.pF0; }   // fused fix: previous tables from entry 4 pF0, the fixed ones from entry 2 pF0
-    if (MODE == 4) src.out -= 2 * a.pF0;                         // first materialised tables of a rank's slice
+    if (MODE == 4 || MODE == 6) src.out -= 2 * a.pF0;            // first materialised tables of a rank's slice
     const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
     __shared__ u64 slut[MODE >= 3 ? 3 * 81 * 3 : 1];   // (mode 5 uses the values only)   // the 81 values, their squares, (mode 4) r times the values
     if (MODE >= 3) {
         for (u32 i = threadIdx.x; i < 2 * 81 * 3; i += 256) slut[i] = src.lut[i];
         __syncthreads();
-        if (MODE == 4) {   // fix_variables on look-up values needs no product per entry: f = g0 + r g1 - r g0
+        if (MODE == 4 || MODE == 6) {   // fix_variables on look-up values needs no product per entry: f = g0 + r g1 - r g0
             if (threadIdx.x < 81) {
                 Fq3 rv = M3<NU>(fq3_make(slut[3 * threadIdx.x], slut[3 * threadIdx.x + 1], slut[3 * threadIdx.x + 2]), rfix, nu);
                 slut[3 * (162 + threadIdx.x)] = rv.c[0]; slut[3 * (162 + threadIdx.x) + 1] = rv.c[1]; slut[3 * (162 + threadIdx.x) + 2] = rv.c[2];
@@ -1816,6 +1840,54 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             Fq3 a2 = fq3_add(fq3_sub(P2, fq3_add(P1, P1)), P0);
             Fq3 p12 = fq3_sub(P1, P2);
             Fq3 a3 = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12));
+            Q[0] = fq3_sub(P0, sp);
+            Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
+            Q[2] = fq3_add(fq3_add(a2, a2), a2);
+            Q[3] = a3;
+        } else if (NU && MODE == 6) {
+            LH5 A0, A1, A2, A3;
+            lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
+            Fq3 sp = fq3_zero(), su = fq3_zero();
+            for (u32 kd = kd0; kd < kd1; kd++) {
+                const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
+                const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)16 * p;
+                int32_t v[16];
+                if ((size_t)16 * p + 16 <= src.n_planes && (src.n_planes & 3) == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        int4 w = *(const int4 *)(pl + 4 * q);
+                        v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] = (size_t)16 * p + q < src.n_planes ? pl[q] : 0;
+                }
+                const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k), c2 = digit_code4(v + 8, k), c3 = digit_code4(v + 12, k);
+                // operands of the four lazy products: gathers, no multiplication
+                const u64 *q0 = src.sq4 + (size_t)(c0 * 81 + c1) * 4, *q1 = src.sq4 + (size_t)(c2 * 81 + c3) * 4;
+                const u64 *ma = src.mt4 + (size_t)kd * 2 * 81 * 4, *mb = ma + 81 * 4;
+                const ulonglong2 s0a = *(const ulonglong2 *)q0, s1a = *(const ulonglong2 *)q1;
+                const u64 s0c = q0[2], s1c = q1[2];
+                const ulonglong2 a0 = *(const ulonglong2 *)(ma + 4 * c0), b1 = *(const ulonglong2 *)(mb + 4 * c1);
+                const ulonglong2 a2 = *(const ulonglong2 *)(ma + 4 * c2), b3 = *(const ulonglong2 *)(mb + 4 * c3);
+                const u64 a0c = ma[4 * c0 + 2], b1c = mb[4 * c1 + 2], a2c = ma[4 * c2 + 2], b3c = mb[4 * c3 + 2];
+                // the fixed pair itself (stored for round 5)
+                const Fq3 f0 = fq3_add(lut3(c0), fq3_sub(lut3(162 + c1), lut3(162 + c0)));
+                const Fq3 f1 = fq3_add(lut3(c2), fq3_sub(lut3(162 + c3), lut3(162 + c2)));
+                u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
+                *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
+                *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
+                *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
+                const Fq3 tt = fq3_add(fq3_make(a0.x, a0.y, a0c), fq3_make(b1.x, b1.y, b1c)), uu = fq3_add(fq3_make(a2.x, a2.y, a2c), fq3_make(b3.x, b3.y, b3c));
+                const Fq3 s0 = fq3_make(s0a.x, s0a.y, s0c), s1 = fq3_make(s1a.x, s1a.y, s1c);
+                lh5_mac(A0, tt, s0); lh5_mac(A1, uu, s0); lh5_mac(A2, tt, s1); lh5_mac(A3, uu, s1);
+                sp = fq3_add(sp, tt); su = fq3_add(su, uu);
+            }
+            Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2), P3 = lh5_finish(A3);
+            Fq3 a1 = fq3_sub(P1, P0);                                           // sum mu f0^2 df
+            Fq3 a2 = fq3_add(fq3_sub(P2, fq3_add(P1, P1)), P0);                 // sum mu f0 df^2
+            Fq3 p12 = fq3_sub(P1, P2);
+            Fq3 a3 = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12)); // sum mu df^3
             Q[0] = fq3_sub(P0, sp);
             Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
             Q[2] = fq3_add(fq3_add(a2, a2), a2);
@@ -2538,6 +2610,17 @@ void launch_fold_round_lut_fix(const DevCrt &t, const FoldRoundArgs &a, const in
     src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
     src.out = Fout; src.ldo = ldout; src.r = r;
     launch_fold_round_mode<4>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
+}
+// the same through the product-free tables of mode 6 (sq_dev 6561*4 words, mt_dev 2K*3*2*81*4 words, filled here); NU = 2^40 only
+void launch_fold_round_lut_fix_tab(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                                   const u64 *lut_dev, Fq3Const r, u64 *sq_dev, u64 *mt_dev, u64 *Fout, size_t ldout, u32 K, const Fq3Const *mu_pow_dev,
+                                   u64 *partial, u64 *out, hipStream_t s) {
+    const u32 nkd = 2 * K * 3;
+    LF_LAUNCH(k_fold_r4tab, t.nu2p40, dim3((6561 + nkd * 162 + 255) / 256), dim3(256), s, t, lut_dev, r, mu_pow_dev, nkd, sq_dev, mt_dev);
+    FoldSrc src = {};
+    src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
+    src.out = Fout; src.ldo = ldout; src.r = r; src.sq4 = sq_dev; src.mt4 = mt_dev;
+    launch_fold_round_mode<6>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
 }
 // round message + fused fix_variables: Fprev [2K*3][24][ldprev] (entries 4p..4p+3 of every pair p) -> Fout [..][ldout]
 void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *Fprev, size_t ldprev, Fq3Const r, u64 *Fout, size_t ldout, u32 K,

@@ -6,7 +6,7 @@ cp $R/latticefold_amd/liblfhip.so /tmp/keep.so
 for i in 1 2 3; do
   for v in $1 $2 $3; do
     cp $R/$v $R/latticefold_amd/liblfhip.so
-    python $R/bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+    python $R/bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline --no-lfplus 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'], 3), round(d['phases_ms_per_step'].get('fold_finish', 0), 2))"
   done

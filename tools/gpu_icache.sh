@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ic_pass
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_INSTS_VALU SQ_BUSY_CYCLES \
-  --kernel-trace --output-format csv -d /tmp/ic_pass -o p -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --no-cpu-baseline >/dev/null 2>/tmp/ic_err.txt
+  --kernel-trace --output-format csv -d /tmp/ic_pass -o p -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --no-cpu-baseline --no-lfplus >/dev/null 2>/tmp/ic_err.txt
 f=$(find /tmp/ic_pass -name '*counter_collection.csv' | head -1)
 if [ -z "$f" ]; then tail -5 /tmp/ic_err.txt; rocprofv3 -L 2>/dev/null | grep -i -E "icache|ifetch" | head; exit 1; fi
 python - "$f" <<'PY'

@@ -10,11 +10,11 @@ python $R/bench.py --workload C3 --steps 5 --warmup 2 > $R/gpurun_out/${tag}_ben
 cd /tmp && export TMPDIR=/tmp
 for wl in C4 C3; do
   rm -rf /tmp/prof_$wl
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -o p -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline >/dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -o p -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-lfplus >/dev/null 2>&1
   f=$(find /tmp/prof_$wl -name '*kernel_stats.csv' | head -1)
   cp "$f" $R/gpurun_out/${tag}_$(echo $wl | tr A-Z a-z)_kernel_stats.csv
 done
 bash $R/tools/gpu_pmc.sh $tag C4
 bash $R/tools/gpu_pmc.sh $tag C3
-LF_TIMELINE=1 python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline 2>&1 | grep timeline | tail -32 > $R/gpurun_out/${tag}_timeline_c4.txt
+LF_TIMELINE=1 python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-lfplus 2>&1 | grep timeline | tail -32 > $R/gpurun_out/${tag}_timeline_c4.txt
 bash $R/tools/gpu_sq.sh $tag C4

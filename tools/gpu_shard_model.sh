@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 wl=${1:-C4}
 mkdir -p $R/gpurun_out
-python $R/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null > $R/gpurun_out/shard_g1.json
+python $R/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-lfplus 2>/dev/null > $R/gpurun_out/shard_g1.json
 for G in 2 4; do
   LF_FORCE_DEVICE=0 LF_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=$G --master-addr 127.0.0.1 --master-port $((29500+G)) \
      $R/bench.py --gpus $G --steps 4 --warmup 2 --workload $wl --parallelism shard 2>/dev/null | grep '^{' > $R/gpurun_out/shard_g$G.json
