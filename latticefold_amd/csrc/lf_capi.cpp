@@ -2054,6 +2054,10 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     const size_t lut_min = c->tn.lut_min;   // default 2^14 entries (measured: C2 6.65 -> 6.52 ms, 2^18 rows 10.7 -> 9.6 ms against 2^17)
     const size_t tab_min = c->tn.tab_min;   // pairs; rounds 1-2 as table look-ups above this
     const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !c->tn.fold_no_lut;
+    // rounds 4 and 5 from product-free tables over the digit codes (k_fold_round modes 6 and 7); with round 5 on the planes too, round 4 stores no tables
+    const bool use_r4tab = use_lut && c->dcrt.nu2p40 && !c->tn.fold_no_r4tab;
+    // (not when the persistent tail may take over at round 5: it starts from the materialised round-4 tables)
+    const bool use_r5 = use_r4tab && !c->tn.fold_no_r5tab && Gw == 1 && P.s >= 5 && (N & 3) == 0 && (c->tn.no_tail || m / 8 > c->tn.tail_n) && m / 32 >= c->tn.r5_min;
     u64 *d_lut = nullptr;
     c->sv_round_mask = 0;
     u32 *sv_bits[2] = {nullptr, nullptr};
@@ -2152,6 +2156,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             } else if (round > 3) {
                 u64 *fd = F[(round & 1) ? 0 : 1];  // round 4 -> F[1], round 5 -> F[0], ...
                 if (use_lut && round == 4) fmode = 4;
+                else if (use_r5 && round == 5) fmode = 7;
                 else if (fused && ldF >= fuse_min && ldF >= 4) { prevF = curF; prevld = ldF; fmode = 1; }
                 else launch_fix_many(c->dcrt, curF, ldF, fd, ldF / 2, ldF, K2 * 3 * 8, r, c->stream());
                 curF = fd; ldF = ldF / 2;
@@ -2240,11 +2245,19 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             RET(c->tbuf("fold_mutab", (size_t)3 * K2 * 3 * 81 * 4, &mutab));
             launch_fold_round_lut_mu(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, mutab, K, d_mu, partial, od, c->stream());
         } else if (fmode == 3) launch_fold_round_lut(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, K, d_mu, partial, od, c->stream());
-        else if (fmode == 4 && c->dcrt.nu2p40 && !c->tn.fold_no_r4tab) {
+        else if (fmode == 4 && use_r4tab) {
             u64 *r4sq, *r4mt;
             RET(c->tbuf("fold_r4sq", (size_t)6561 * 4, &r4sq));
             RET(c->tbuf("fold_r4mt", (size_t)K2 * 3 * 162 * 4, &r4mt));
-            launch_fold_round_lut_fix_tab(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), r4sq, r4mt, (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
+            launch_fold_round_lut_fix_tab(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), r4sq, r4mt, use_r5 ? nullptr : (u64 *)curF, ldF, K, d_mu, partial, od,
+                                          c->stream());
+        } else if (fmode == 7) {
+            u64 *r5xx, *r5yy, *r5mt;
+            RET(c->tbuf("fold_r5xx", (size_t)6561 * 4, &r5xx));
+            RET(c->tbuf("fold_r5yy", (size_t)6561 * 4, &r5yy));
+            RET(c->tbuf("fold_r5mt", (size_t)K2 * 3 * 324 * 4, &r5mt));
+            launch_fold_round_lut_fix5(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 3]), f3c(pt[round - 2]), r5xx, r5yy, r5mt, (u64 *)curF, ldF, K, d_mu, partial, od,
+                                       c->stream());
         } else if (fmode == 4) launch_fold_round_lut_fix(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else if (fmode == 1) launch_fold_round_fix(c->dcrt, a, prevF, prevld, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
         else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->stream());

@@ -58,7 +58,7 @@ int lf_ctx_device(const lf_ctx *ctx);
 // Test/diagnostic switches of the fold-step driver (environment variables): read ONCE at the start of every
 // lf_linearize / lf_fold_step call -- never inside the round loops.
 struct Tunables {
-    bool lin_u_eval = false, fold_unfused = false, fold_no_lut = false, fold_tab_r1 = false, fold_no_mutab = false, theta_eval = false, fold_no_r4tab = false;
+    bool lin_u_eval = false, fold_unfused = false, fold_no_lut = false, fold_tab_r1 = false, fold_no_mutab = false, theta_eval = false, fold_no_r4tab = false, fold_no_r5tab = false;
     bool force_exchange = false;     // LF_DIST_FORCE_EXCHANGE: run the sharded exchanges even with a 1-rank RCCL communicator (test hook)
     bool device_transcript = false;  // LF_DEVICE_TRANSCRIPT: Poseidon sponge of the tail rounds on the device (opt-in: slower than the host's)
     bool shard_plain_rounds = false; // LF_SHARD_PLAIN_ROUNDS: sharded folding rounds on materialised tables only (no fused fix / look-up-table rounds)
@@ -80,6 +80,7 @@ struct Tunables {
     int sv_rounds = 3;               // LF_FOLD_SV_ROUNDS: last round in GEMM form (1..3)
     bool no_tail = false;            // LF_NO_TAIL: keep one launch set + stream sync per tail round instead of the persistent tail kernel
     size_t fuse_min = 16384, lut_min = (size_t)1 << 17, tab_min = 16384;
+    size_t r5_min = 8192;            // LF_FOLD_R5_MIN: pairs of round 5 from which it runs on the planes (mode 7; measured: 2^16 rows slower, 2^20 faster)
     size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
     long lin_blocks = -1;            // -1: automatic
     static Tunables read(size_t lut_min_default) {
@@ -92,6 +93,7 @@ struct Tunables {
         t.fold_tab_r1 = getenv("LF_FOLD_TAB_R1") != nullptr;
         t.fold_no_mutab = getenv("LF_FOLD_NO_MUTAB") != nullptr;
         t.fold_no_r4tab = getenv("LF_FOLD_NO_R4TAB") != nullptr;
+        t.fold_no_r5tab = getenv("LF_FOLD_NO_R5TAB") != nullptr;
         t.theta_eval = getenv("LF_THETA_EVAL") != nullptr;
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;
         t.fold_no_sv = getenv("LF_FOLD_NO_SV") != nullptr;
@@ -116,6 +118,7 @@ struct Tunables {
         if ((e = getenv("LF_FOLD_TAB_MIN"))) t.tab_min = (size_t)atoll(e);
         if ((e = getenv("LF_LIN_BLOCKS"))) t.lin_blocks = atol(e);
         if ((e = getenv("LF_TAIL_N"))) t.tail_n = (size_t)atoll(e);
+        if ((e = getenv("LF_FOLD_R5_MIN"))) t.r5_min = (size_t)atoll(e);
         return t;
     }
 };

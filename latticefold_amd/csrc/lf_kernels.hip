@@ -1658,6 +1658,10 @@ void launch_fold_materialize(const DevCrt &t, const int32_t *planesL, const int3
 //   6  mode 4 without a single reduced product: a fixed entry is f = (1-r) L[c_lo] + r L[c_hi], one of 81^2 values, so its square comes from a 6561-entry
 //      table and mu_kd f = (mu_kd (1-r) L)[c_lo] + (mu_kd r L)[c_hi] from two 81-entry tables per table kd (k_fold_r4tab, rebuilt per step: they depend
 //      on r_3 and mu); the cubic's four sums are then P0..P3 = sum mu f0^3, mu f1 f0^2, mu f0 f1^2, mu f1^3 as in mode 3 -- four lazy products per table
+//   7  round 5 still from the planes: an entry of the m/16-entry tables is A'[c0] + B'[c1] + C'[c2] + D'[c3] = X + Y with four 81-entry tables
+//      ((1-r4)(1-r3) L, (1-r4) r3 L, r4 (1-r3) L, r4 r3 L), so its square is X^2 + Y^2 (two 6561-entry tables) + 2 X Y (the one reduced product left per
+//      entry) and mu_kd f four gathers; the fixed pair is stored for round 6.  Mode 6 then stores nothing (src.out = null): the 2.4 GB of m/8-entry tables
+//      are never written or read
 // (An earlier variant of mode 3 that rebuilt the entries with conditional modular additions measured slower than the separate pass.)
 struct FoldSrc {
     u64 *out; size_t ldo;                 // modes 1, 4: where the fixed pair is written (entries 2p, 2p+1)
@@ -1666,6 +1670,8 @@ struct FoldSrc {
     size_t n_planes;
     const u64 *lut;                       // [2][81][3]: sum_b (t_b - 1) W_b for code = sum_b t_b 3^b, then the squares of those
     const u64 *mutab;                     // mode 5: [3][2K*3][81][4] = mu_kd * value, mu_kd * value^2, mu_kd * value^3 (k_fold_mutab)
+    Fq3Const r_prev;                      // mode 7: the challenge fixed one round earlier (r_3; r = r_4)
+    const u64 *xx5, *yy5, *mt5;           // mode 7: [81*81][4] squares of the low / high halves of a fixed entry, [2K*3][4][81][4] = mu_kd {A', B', C', D'} (k_fold_r5tab)
     const u64 *sq4, *mt4;                 // mode 6: [81*81][4] squares of the fixed look-up values, [2K*3][2][81][4] = mu_kd (1 - r) L, mu_kd r L (k_fold_r4tab)
 };
 // per-table products of the 81 look-up values with mu_kd (round 3, mode 5): with them a table costs two lazy products instead of six
@@ -1703,6 +1709,29 @@ __global__ void __launch_bounds__(256) k_fold_r4tab(DevCrt t, const u64 *lut, Fq
         o[0] = m.c[0]; o[1] = m.c[1]; o[2] = m.c[2]; o[3] = 0;
     }
 }
+// tables of mode 7: T[0..3] = A', B', C', D' (see above); xx[c0 * 81 + c1] = (A'[c0] + B'[c1])^2, yy[c2 * 81 + c3] = (C'[c2] + D'[c3])^2, mt[kd][w][c] = mu_kd T[w][c]
+template <bool NU>
+__device__ __forceinline__ Fq3 r5_entry(const u64 *lut, u32 w, u32 c, Fq3 r3, Fq3 r4, u64 nu) {
+    const Fq3 l = fq3_make(lut[3 * c], lut[3 * c + 1], lut[3 * c + 2]), rl = M3<NU>(l, r3, nu), a = (w & 1) ? rl : fq3_sub(l, rl), ra = M3<NU>(a, r4, nu);
+    return (w & 2) ? ra : fq3_sub(a, ra);
+}
+template <bool NU>
+__global__ void __launch_bounds__(256) k_fold_r5tab(DevCrt t, const u64 *lut, Fq3Const r3c, Fq3Const r4c, const Fq3Const *mu_pow, u32 nkd, u64 *xx, u64 *yy, u64 *mt) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const Fq3 r3 = fq3_make(r3c.c[0], r3c.c[1], r3c.c[2]), r4 = fq3_make(r4c.c[0], r4c.c[1], r4c.c[2]);
+    if (i < 2 * 6561) {
+        const u32 hi = i / 6561, j = i % 6561, c0 = j / 81, c1 = j % 81;
+        const Fq3 f = fq3_add(r5_entry<NU>(lut, 2 * hi, c0, r3, r4, t.nu), r5_entry<NU>(lut, 2 * hi + 1, c1, r3, r4, t.nu)), sv = M3<NU>(f, f, t.nu);
+        u64 *o = (hi ? yy : xx) + (size_t)j * 4;
+        o[0] = sv.c[0]; o[1] = sv.c[1]; o[2] = sv.c[2]; o[3] = 0;
+    } else if (i < 2 * 6561 + nkd * 324) {
+        const u32 j = i - 2 * 6561, kd = j / 324, w = (j % 324) / 81, c = j % 81;
+        const Fq3Const mc = mu_pow[kd];
+        const Fq3 m = M3<NU>(fq3_make(mc.c[0], mc.c[1], mc.c[2]), r5_entry<NU>(lut, w, c, r3, r4, t.nu), t.nu);
+        u64 *o = mt + (((size_t)kd * 4 + w) * 81 + c) * 4;
+        o[0] = m.c[0]; o[1] = m.c[1]; o[2] = m.c[2]; o[3] = 0;
+    }
+}
 // digit code of four consecutive plane entries at bit k: 40 + sum_b sign_b * bit_k(|v_b|) * 3^b
 __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
     int code = 40;
@@ -1725,9 +1754,16 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     const u32 kd0 = blockIdx.z * per, kd1 = kd0 + per < nkd ? kd0 + per : nkd;
     if (MODE == 0) F -= 2 * a.pF0;  // the f-hat buffer starts at pair a.pF0 (sharded rounds hold only the rank's slice)
     if (MODE == 1) { F -= 4 * a.pF0; src.out -= 2 * a.pF0; }   // fused fix: previous tables from entry 4 pF0, the fixed ones from entry 2 pF0
-    if (MODE == 4 || MODE == 6) src.out -= 2 * a.pF0;            // first materialised tables of a rank's slice
+    if ((MODE == 4 || MODE == 6 || MODE == 7) && src.out) src.out -= 2 * a.pF0;   // first materialised tables of a rank's slice
     const Fq3 rfix = fq3_make(src.r.c[0], src.r.c[1], src.r.c[2]);
-    __shared__ u64 slut[MODE >= 3 ? 3 * 81 * 3 : 1];   // (mode 5 uses the values only)   // the 81 values, their squares, (mode 4) r times the values
+    __shared__ u64 slut[MODE == 7 ? 4 * 81 * 3 : (MODE >= 3 ? 3 * 81 * 3 : 1)];   // (mode 5 uses the values only)   // the 81 values, their squares, (mode 4) r times the values
+    if (MODE == 7) {   // the four tables A', B', C', D'
+        for (u32 i = threadIdx.x; i < 4 * 81; i += 256) {
+            const Fq3 e = r5_entry<NU>(src.lut, i / 81, i % 81, fq3_make(src.r_prev.c[0], src.r_prev.c[1], src.r_prev.c[2]), rfix, nu);
+            slut[3 * i] = e.c[0]; slut[3 * i + 1] = e.c[1]; slut[3 * i + 2] = e.c[2];
+        }
+        __syncthreads();
+    } else
     if (MODE >= 3) {
         for (u32 i = threadIdx.x; i < 2 * 81 * 3; i += 256) slut[i] = src.lut[i];
         __syncthreads();
@@ -1844,6 +1880,57 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
             Q[2] = fq3_add(fq3_add(a2, a2), a2);
             Q[3] = a3;
+        } else if (NU && MODE == 7) {
+            LH5 A0, A1, A2, A3;
+            lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
+            Fq3 sp = fq3_zero(), su = fq3_zero();
+            for (u32 kd = kd0; kd < kd1; kd++) {
+                const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
+                const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)32 * p;
+                const u64 *mt = src.mt5 + (size_t)kd * 4 * 81 * 4;
+                Fq3 fv[2], sq[2], mf[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {     // the two entries of the pair: plane entries 16 e .. 16 e + 15
+                    int32_t v[16];
+                    if ((size_t)32 * p + 16 * e + 16 <= src.n_planes && (src.n_planes & 3) == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            int4 w = *(const int4 *)(pl + 16 * e + 4 * q);
+                            v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] = (size_t)32 * p + 16 * e + q < src.n_planes ? pl[16 * e + q] : 0;
+                    }
+                    const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k), c2 = digit_code4(v + 8, k), c3 = digit_code4(v + 12, k);
+                    const u64 *qx = src.xx5 + (size_t)(c0 * 81 + c1) * 4, *qy = src.yy5 + (size_t)(c2 * 81 + c3) * 4;
+                    const ulonglong2 xa = *(const ulonglong2 *)qx, ya = *(const ulonglong2 *)qy;
+                    const u64 xc = qx[2], yc = qy[2];
+                    const ulonglong2 m0 = *(const ulonglong2 *)(mt + 4 * c0), m1 = *(const ulonglong2 *)(mt + 4 * (81 + c1));
+                    const ulonglong2 m2 = *(const ulonglong2 *)(mt + 4 * (162 + c2)), m3 = *(const ulonglong2 *)(mt + 4 * (243 + c3));
+                    const u64 m0c = mt[4 * c0 + 2], m1c = mt[4 * (81 + c1) + 2], m2c = mt[4 * (162 + c2) + 2], m3c = mt[4 * (243 + c3) + 2];
+                    const Fq3 X = fq3_add(lut3(c0), lut3(81 + c1)), Y = fq3_add(lut3(162 + c2), lut3(243 + c3));
+                    const Fq3 xy = fq3_mul_2p40(X, Y);
+                    fv[e] = fq3_add(X, Y);
+                    sq[e] = fq3_add(fq3_add(fq3_make(xa.x, xa.y, xc), fq3_make(ya.x, ya.y, yc)), fq3_add(xy, xy));
+                    mf[e] = fq3_add(fq3_add(fq3_make(m0.x, m0.y, m0c), fq3_make(m1.x, m1.y, m1c)), fq3_add(fq3_make(m2.x, m2.y, m2c), fq3_make(m3.x, m3.y, m3c)));
+                }
+                u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
+                *(ulonglong2 *)(op) = make_ulonglong2(fv[0].c[0], fv[1].c[0]);
+                *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(fv[0].c[1], fv[1].c[1]);
+                *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(fv[0].c[2], fv[1].c[2]);
+                lh5_mac(A0, mf[0], sq[0]); lh5_mac(A1, mf[1], sq[0]); lh5_mac(A2, mf[0], sq[1]); lh5_mac(A3, mf[1], sq[1]);
+                sp = fq3_add(sp, mf[0]); su = fq3_add(su, mf[1]);
+            }
+            Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2), P3 = lh5_finish(A3);
+            Fq3 a1 = fq3_sub(P1, P0);
+            Fq3 a2 = fq3_add(fq3_sub(P2, fq3_add(P1, P1)), P0);
+            Fq3 p12 = fq3_sub(P1, P2);
+            Fq3 a3 = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12));
+            Q[0] = fq3_sub(P0, sp);
+            Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
+            Q[2] = fq3_add(fq3_add(a2, a2), a2);
+            Q[3] = a3;
         } else if (NU && MODE == 6) {
             LH5 A0, A1, A2, A3;
             lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
@@ -1874,10 +1961,12 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 // the fixed pair itself (stored for round 5)
                 const Fq3 f0 = fq3_add(lut3(c0), fq3_sub(lut3(162 + c1), lut3(162 + c0)));
                 const Fq3 f1 = fq3_add(lut3(c2), fq3_sub(lut3(162 + c3), lut3(162 + c2)));
-                u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
-                *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
-                *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
-                *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
+                if (src.out) {      // (null when round 5 works from the planes as well: mode 7)
+                    u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
+                    *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
+                    *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
+                    *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
+                }
                 const Fq3 tt = fq3_add(fq3_make(a0.x, a0.y, a0c), fq3_make(b1.x, b1.y, b1c)), uu = fq3_add(fq3_make(a2.x, a2.y, a2c), fq3_make(b3.x, b3.y, b3c));
                 const Fq3 s0 = fq3_make(s0a.x, s0a.y, s0c), s1 = fq3_make(s1a.x, s1a.y, s1c);
                 lh5_mac(A0, tt, s0); lh5_mac(A1, uu, s0); lh5_mac(A2, tt, s1); lh5_mac(A3, uu, s1);
@@ -2621,6 +2710,17 @@ void launch_fold_round_lut_fix_tab(const DevCrt &t, const FoldRoundArgs &a, cons
     src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
     src.out = Fout; src.ldo = ldout; src.r = r; src.sq4 = sq_dev; src.mt4 = mt_dev;
     launch_fold_round_mode<6>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
+}
+// round 5 from the planes (mode 7): xx_dev / yy_dev 6561*4 words each, mt_dev 2K*3*4*81*4 words, filled here; r3 / r4 = the challenges of rounds 3 / 4
+void launch_fold_round_lut_fix5(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
+                                const u64 *lut_dev, Fq3Const r3, Fq3Const r4, u64 *xx_dev, u64 *yy_dev, u64 *mt_dev, u64 *Fout, size_t ldout, u32 K,
+                                const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
+    const u32 nkd = 2 * K * 3;
+    LF_LAUNCH(k_fold_r5tab, t.nu2p40, dim3((2 * 6561 + nkd * 324 + 255) / 256), dim3(256), s, t, lut_dev, r3, r4, mu_pow_dev, nkd, xx_dev, yy_dev, mt_dev);
+    FoldSrc src = {};
+    src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
+    src.out = Fout; src.ldo = ldout; src.r = r4; src.r_prev = r3; src.xx5 = xx_dev; src.yy5 = yy_dev; src.mt5 = mt_dev;
+    launch_fold_round_mode<7>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
 }
 // round message + fused fix_variables: Fprev [2K*3][24][ldprev] (entries 4p..4p+3 of every pair p) -> Fout [..][ldout]
 void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *Fprev, size_t ldprev, Fq3Const r, u64 *Fout, size_t ldout, u32 K,

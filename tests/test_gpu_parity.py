@@ -309,6 +309,15 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     monkeypatch.setenv("LF_FOLD_TAB_MIN", "1")     # ... and rounds 1-2 as gathers from the per-table coefficient tables
     monkeypatch.setenv("LF_FOLD_TAB_R1", "1")
     lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    # the product-free forms of rounds 4 and 5 (modes 6 and 7: squares and mu products of the fixed look-up values from tables over the digit codes),
+    # with round 5 still on the planes / on the stored round-4 tables / both through the older modes 4 and 1
+    for extra in ({"LF_FOLD_R5_MIN": "1"}, {"LF_FOLD_NO_R5TAB": "1"}, {"LF_FOLD_NO_R4TAB": "1"}):
+        for key, val in extra.items():
+            monkeypatch.setenv(key, val)
+        lc_x, w_x, proof_x = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+        for key in extra:
+            monkeypatch.delenv(key)
+        assert (proof_x == proof_o).all() and (lc_x == lc_o).all() and (w_x.f == f0_o).all(), extra
     monkeypatch.delenv("LF_FOLD_LUT_MIN")
     monkeypatch.delenv("LF_FOLD_TAB_MIN")
     monkeypatch.delenv("LF_FOLD_TAB_R1")
@@ -355,15 +364,19 @@ def test_fold_step_persistent_tail_matches_oracle(ctx, name, monkeypatch):
     all equal to the oracle's"""
     wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 5)
     lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
-    for tail_n, lut in (("16384", False), ("16", False), ("4", False), ("64", True), ("0", False)):
+    # lut: rounds 3-4 from the digit look-up tables (k_fold_round modes 3/5 and 4/6) and, when the tail starts later than round 5, round 5 from the
+    # planes as well (mode 7; LF_FOLD_R5_MIN=1 lifts its size threshold) -- a tail that starts AT round 5 needs the round-4 tables mode 6 then must store
+    for tail_n, lut in (("16384", False), ("16", False), ("4", False), ("64", True), ("16", True), ("0", False)):
         monkeypatch.setenv("LF_TAIL_N", tail_n)
         if lut:
             monkeypatch.setenv("LF_FOLD_LUT_MIN", "1")
             monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
+            monkeypatch.setenv("LF_FOLD_R5_MIN", "1")
         lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
         if lut:
             monkeypatch.delenv("LF_FOLD_LUT_MIN")
             monkeypatch.delenv("LF_FOLD_FUSE_MIN")
+            monkeypatch.delenv("LF_FOLD_R5_MIN")
         assert (proof == proof_o).all() and (lc == lc_o).all() and (w.f == f0_o).all(), (tail_n, lut)
     # SURVEY 8f rank 1: the tail rounds' Fiat-Shamir transcript on the DEVICE sponge (no host round trip at all); the host transcript
     # takes the sponge back afterwards (theta / eta absorbs, rho challenges), so any divergence shows in the proof and the folded instance
