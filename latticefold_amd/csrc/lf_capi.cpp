@@ -1393,12 +1393,17 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
             if (trc == LF_OK) { cur = fx[flip]; n = 2; break; }
             if (trc != LF_ERR_UNSUPPORTED) return trc;
         }
+        bool fused_now = false;
+        const u64 *prev = cur, *preve = cure;
+        size_t prevn = n;
         if (round > 1) {
             Fq3Const r = f3c(point[round - 2]);
             if (sharded) {
                 const size_t e0 = gr * (n / Gw), ecnt = n / Gw;   // this rank's entries of the previous tables -> entries [e0/2, (e0+ecnt)/2)
                 launch_fix_many(c->dcrt, cur + e0, n, fx[flip] + e0 / 2, n / 2, ecnt, P.t * 8, r, c->stream());
                 launch_fix_many(c->dcrt, cure + e0, n, fe[flip] + e0 / 2, n / 2, ecnt, 1, r, c->stream());
+            } else if (Gw == 1 && !c->tn.lin_unfused && n >= 8) {
+                fused_now = true;   // fix_variables inside the round kernel (one pass over the previous tables instead of a k_fix pass + a read)
             } else {
                 launch_fix_many(c->dcrt, cur, n, fx[flip], n / 2, n, P.t * 8, r, c->stream());
                 launch_fix_many(c->dcrt, cure, n, fe[flip], n / 2, n, 1, r, c->stream());
@@ -1418,7 +1423,9 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
             launch_lin_round(c->dcrt, c->desc, cur + 2 * p0, n, cure + 2 * p0, n, 2 * pcnt, deg, partial, od_dev, c->stream(), c->lin_blocks);
             RET(exchange_modsum_dev(c, od_dev, (size_t)(deg + 1) * 24));
             HIPCHK(hipMemcpyAsync(od, od_dev, (size_t)(deg + 1) * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
-        } else launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->stream(), c->lin_blocks);
+        } else if (fused_now)
+            launch_lin_round_fused(c->dcrt, c->desc, prev, prevn, preve, prevn, f3c(point[round - 2]), (u64 *)cur, n, (u64 *)cure, n, n, deg, partial, od, c->stream(), c->lin_blocks);
+        else launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->stream(), c->lin_blocks);
         RET(c->lane_sync());                                  // the message is in mapped host memory
         memcpy(ev, od, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);

@@ -134,6 +134,8 @@ struct LinCombDesc {  // CCS multiset structure for the linearization comb (nifs
 // of the other lane, which is the critical path, and yields to it by running on fewer workgroups
 void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
                       u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
+void launch_lin_round_fused(const DevCrt &t, const LinCombDesc &desc, const u64 *mz_prev, size_t ld_prev, const u64 *eq_prev, size_t ldeq_prev, Fq3Const r, u64 *mz_out,
+                            size_t ld_out, u64 *eq_out, size_t ldeq_out, size_t n, u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
 
 struct FoldRoundArgs {
     const u64 *eqL, *eqR, *eqB;  // fq3 tables [3][ld]

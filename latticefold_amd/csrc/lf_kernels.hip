@@ -1167,27 +1167,60 @@ __device__ __forceinline__ void add_poly_evals(Fq3 (&acc)[NP], const Fq3 *co, in
 
 // ---------------------------------------------------------------------------------------------------------
 // linearization sumcheck round (sumcheck/prover.rs:56-162 with comb = linearization/utils.rs:90-107)
-template <bool NU>
+// FUSED: fix_variables of the previous round's tables (mz / eq hold 2n entries per row, ld / ldeq their strides) with rfix happens here: pair p is built from
+// the entries 4p..4p+3 and stored to mzo / eqo (n entries per row) for the next round -- no separate k_fix pass over the tables
+struct LinFix { Fq3Const r; u64 *mzo; size_t ldo; u64 *eqo; size_t ldeo; };
+template <bool NU, bool FUSED>
 __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
-                                                   u32 deg, u64 *partial) {
+                                                   u32 deg, u64 *partial, LinFix fx) {
     u32 slot = blockIdx.y;
     size_t pairs = n / 2;
     Fq3 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    const Fq3 rfix = fq3_make(fx.r.c[0], fx.r.c[1], fx.r.c[2]);
+    // the fixed pair (entries 2p, 2p+1 of the new tables) of one F_{p^3} row: from the entries 4p..4p+3 of the previous one, stored when `out` is set
+    auto fixed_pair = [&](const u64 *row, size_t ldr, size_t p, u64 *out, size_t ldout, Fq3 &f0, Fq3 &f1) {
+        const u64 *fp = row + 4 * p;
+        const ulonglong2 a0 = *(const ulonglong2 *)(fp), a1 = *(const ulonglong2 *)(fp + ldr), a2 = *(const ulonglong2 *)(fp + 2 * ldr);
+        const ulonglong2 b0 = *(const ulonglong2 *)(fp + 2), b1 = *(const ulonglong2 *)(fp + ldr + 2), b2 = *(const ulonglong2 *)(fp + 2 * ldr + 2);
+        const Fq3 lo = fq3_make(a0.x, a1.x, a2.x), hi = fq3_make(b0.x, b1.x, b2.x);
+        f0 = fq3_add(lo, M3<NU>(fq3_sub(fq3_make(a0.y, a1.y, a2.y), lo), rfix, t.nu));
+        f1 = fq3_add(hi, M3<NU>(fq3_sub(fq3_make(b0.y, b1.y, b2.y), hi), rfix, t.nu));
+        if (out) {
+            u64 *op = out + 2 * p;
+            *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
+            *(ulonglong2 *)(op + ldout) = make_ulonglong2(f0.c[1], f1.c[1]);
+            *(ulonglong2 *)(op + 2 * ldout) = make_ulonglong2(f0.c[2], f1.c[2]);
+        }
+    };
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
         Fq3 v[4], st[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if ((u32)j < desc.t) {
                 const u64 *tb = mz + ((size_t)j * 24 + 3 * slot) * ld;
-                ulonglong2 a0 = *(const ulonglong2 *)(tb + 2 * p), a1 = *(const ulonglong2 *)(tb + ld + 2 * p), a2 = *(const ulonglong2 *)(tb + 2 * ld + 2 * p);
-                v[j] = fq3_make(a0.x, a1.x, a2.x);
-                st[j] = fq3_sub(fq3_make(a0.y, a1.y, a2.y), v[j]);
+                if (FUSED) {
+                    Fq3 f1;
+                    fixed_pair(tb, ld, p, fx.mzo + ((size_t)j * 24 + 3 * slot) * fx.ldo, fx.ldo, v[j], f1);
+                    st[j] = fq3_sub(f1, v[j]);
+                } else {
+                    ulonglong2 a0 = *(const ulonglong2 *)(tb + 2 * p), a1 = *(const ulonglong2 *)(tb + ld + 2 * p), a2 = *(const ulonglong2 *)(tb + 2 * ld + 2 * p);
+                    v[j] = fq3_make(a0.x, a1.x, a2.x);
+                    st[j] = fq3_sub(fq3_make(a0.y, a1.y, a2.y), v[j]);
+                }
             } else { v[j] = fq3_zero(); st[j] = fq3_zero(); }
         }
-        ulonglong2 e0 = *(const ulonglong2 *)(eq + 2 * p), e1 = *(const ulonglong2 *)(eq + ldeq + 2 * p), e2 = *(const ulonglong2 *)(eq + 2 * ldeq + 2 * p);
-        Fq3 ev = fq3_make(e0.x, e1.x, e2.x), es = fq3_sub(fq3_make(e0.y, e1.y, e2.y), ev);
+        Fq3 ev, es;
+        if (FUSED) {      // eq is one row shared by the 8 slot blocks: every block fixes it, block row 0 stores it
+            Fq3 e1v;
+            fixed_pair(eq, ldeq, p, slot == 0 ? fx.eqo : nullptr, fx.ldeo, ev, e1v);
+            es = fq3_sub(e1v, ev);
+        } else {
+            ulonglong2 e0 = *(const ulonglong2 *)(eq + 2 * p), e1 = *(const ulonglong2 *)(eq + ldeq + 2 * p), e2 = *(const ulonglong2 *)(eq + 2 * ldeq + 2 * p);
+            ev = fq3_make(e0.x, e1.x, e2.x);
+            es = fq3_sub(fq3_make(e0.y, e1.y, e2.y), ev);
+        }
 #pragma unroll
         for (int X = 0; X < 5; X++) {
             if ((u32)X <= deg) {
@@ -1229,7 +1262,22 @@ void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, s
     const u32 cap = max_blocks && max_blocks < RED_BLOCKS ? max_blocks : RED_BLOCKS;
     if (gb > cap) gb = cap;
     if (gb < 1) gb = 1;
-    LF_LAUNCH(k_lin_round, t.nu2p40, dim3(gb, 8), dim3(256), s, t, desc, mz, ld, eq, ldeq, n, deg, partial);
+    LinFix fx = {};
+    if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx);
+    else hipLaunchKernelGGL((k_lin_round<false, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((deg + 1) * 24), dim3(256), 0, s, partial, gb, 120, out);
+}
+// round message with fix_variables fused: mz_prev / eq_prev hold 2n entries per row (strides ld_prev / ldeq_prev); the tables fixed with r are written to
+// mz_out / eq_out (n entries per row, strides ld_out / ldeq_out) and the message is that of the fixed tables
+void launch_lin_round_fused(const DevCrt &t, const LinCombDesc &desc, const u64 *mz_prev, size_t ld_prev, const u64 *eq_prev, size_t ldeq_prev, Fq3Const r, u64 *mz_out,
+                            size_t ld_out, u64 *eq_out, size_t ldeq_out, size_t n, u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks) {
+    u32 gb = (u32)((n / 2 + 255) / 256);
+    const u32 cap = max_blocks && max_blocks < RED_BLOCKS ? max_blocks : RED_BLOCKS;
+    if (gb > cap) gb = cap;
+    if (gb < 1) gb = 1;
+    LinFix fx = {r, mz_out, ld_out, eq_out, ldeq_out};
+    if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx);
+    else hipLaunchKernelGGL((k_lin_round<false, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx);
     hipLaunchKernelGGL(k_reduce_rows, dim3((deg + 1) * 24), dim3(256), 0, s, partial, gb, 120, out);
 }
 
