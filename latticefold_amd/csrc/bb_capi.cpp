@@ -1356,7 +1356,12 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             RET(c->tbuf("fold_mutab", (size_t)3 * K2 * TAU * 81 * 12, &mutab));
             launch_fold_round_lut_mu(c->dev, a, S[0].planes, S[1].planes, N, d_lut, mutab, K, d_mup, partial, od, c->stream());
         } else if (lut_mode == 3) launch_fold_round_lut(c->dev, a, S[0].planes, S[1].planes, N, d_lut, K, d_mup, partial, od, c->stream());
-        else if (lut_mode == 4) launch_fold_round_lut_fix(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
+        else if (lut_mode == 4 && !c->tn.fold_no_r4tab) {
+            fe *r4sq, *r4mt;
+            RET(c->tbuf("fold_r4sq", (size_t)6561 * 12, &r4sq));
+            RET(c->tbuf("fold_r4mt", (size_t)K2 * TAU * 162 * 12, &r4mt));
+            launch_fold_round_lut_fix_tab(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, r4sq, r4mt, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
+        } else if (lut_mode == 4) launch_fold_round_lut_fix(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else if (fix_fused) launch_fold_round_fix(c->dev, a, prevF, prevld, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());
         c->ev_end(ev);

@@ -1192,7 +1192,7 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 // sum_b W_b * digit_k(plane[4j+b]) with four ternary digits -- one of 81 values independent of table and slot -- and comes from a look-up
 // table in LDS indexed by the digit code (lut: [81][9] words); mode 4 also fixes the four round-3 entries of a pair with r and stores the
 // first materialised tables (m/8 entries) like mode 1.  MODE 0: plain tables, MODE 1: fused fix (above).
-struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; const fe *mutab; };   // mutab: mode 5, [3][2K*9][81][12]
+struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; const fe *mutab; const fe *sq4; const fe *mt4; };   // mutab: mode 5, [3][2K*9][81][12]; sq4 / mt4: mode 6, [81*81][12] and [2K*9][2][81][12]
 __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
     int code = 40;
     const int w[4] = {1, 3, 9, 27};
@@ -1222,6 +1222,31 @@ __global__ void __launch_bounds__(128) k_fold_mutab(DevBb t, const fe *lut, cons
         for (int c = 0; c < 12; c++) o[c] = c < TAU ? v[q].c[c] : 0;
     }
 }
+// mode 6 (round 4 without a reduced product; the Goldilocks twin is lf::k_fold_r4tab): a fixed entry is f = L[c_lo] + (r L[c_hi] - r L[c_lo]), one of 81^2
+// values -- sq[c_lo * 81 + c_hi] = f^2, mt[tb][0][c] = M_tb (L[c] - r L[c]), mt[tb][1][c] = M_tb r L[c], so M_tb f = mt[tb][0][c_lo] + mt[tb][1][c_hi]
+template <bool NU2>
+__global__ void __launch_bounds__(256) k_fold_r4tab(DevBb t, const fe *lut, E9PreC rfix, const E9PreC *Mpre, u32 ntab, fe *sq, fe *mt) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    auto L = [&](u32 code) { E9 g; for (int c = 0; c < TAU; c++) g.c[c] = lut[TAU * code + c]; return g; };
+    if (i < 6561) {
+        const u32 c0 = i / 81, c1 = i % 81;
+        const E9 g0 = L(c0), r0 = e9_mul(g0, e9p(rfix)), r1 = e9_mul(L(c1), e9p(rfix));
+        E9 f;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) f.c[c] = fadd(g0.c[c], fsub(r1.c[c], r0.c[c]));
+        const E9 sv = e9_sqr_t<NU2>(f, t.nu);
+        fe *o = sq + (size_t)i * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) o[c] = c < TAU ? sv.c[c] : 0;
+    } else if (i < 6561 + ntab * 162) {
+        const u32 j = i - 6561, tb = j / 162, w = (j % 162) / 81, code = j % 81;
+        const E9 g = L(code), rl = e9_mul(g, e9p(rfix));
+        const E9 m = e9_mul(w ? rl : e9_sub(g, rl), e9p(Mpre[tb]));
+        fe *o = mt + (((size_t)tb * 2 + w) * 81 + code) * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) o[c] = c < TAU ? m.c[c] : 0;
+    }
+}
 template <bool NU2, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
                                                     fe *Fout, size_t ldo, FoldLut lt, i64 *partial) {
@@ -1230,7 +1255,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
     if (MODE >= 3) {
         for (u32 i = threadIdx.x; i < 2 * 81 * TAU; i += 256) slut[i] = lt.lut[i];
         __syncthreads();
-        if (MODE == 4) {   // fix_variables on look-up values needs no product per entry: f = g0 + r g1 - r g0
+        if (MODE == 4 || MODE == 6) {   // fix_variables on look-up values needs no product per entry: f = g0 + r g1 - r g0
             if (threadIdx.x < 81) {
                 E9 g;
 #pragma unroll
@@ -1242,9 +1267,10 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             __syncthreads();
         }
     }
-    i64 SP[MODE == 3 || MODE == 5 ? TAU : 1], SU[MODE == 3 || MODE == 5 ? TAU : 1];   // modes 3, 5: sum M f0, sum M f1
+    constexpr bool MONO = MODE == 3 || MODE == 5 || MODE == 6;   // the cubic in the monomial basis P0..P3 (binomials after the loop)
+    i64 SP[MONO ? TAU : 1], SU[MONO ? TAU : 1];   // sum M f0, sum M f1
     i64 P0s[MODE == 5 ? TAU : 1], P3s[MODE == 5 ? TAU : 1];                            // mode 5: sum M f0^3, sum M f1^3 (look-ups)
-    if (MODE == 3 || MODE == 5) {
+    if (MONO) {
 #pragma unroll
         for (int c = 0; c < TAU; c++) { SP[c] = 0; SU[c] = 0; }
     }
@@ -1266,7 +1292,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
         E9 f0, f1;
         if (MODE >= 3) {
-            constexpr int NE = MODE == 4 ? 16 : 8;      // plane entries behind one pair
+            constexpr int NE = (MODE == 4 || MODE == 6) ? 16 : 8;      // plane entries behind one pair
             const u32 side = tb / (TAU * K), k = (tb / TAU) % K, d = tb % TAU;
             const int32_t *pl = (side ? lt.planesR : lt.planesL) + (size_t)(8 * d + slot) * lt.n_planes + (size_t)NE * jj;
             int32_t v[NE];
@@ -1347,6 +1373,35 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
 #pragma unroll
                     for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(Fo + (size_t)c * ldo + 2 * jj) = make_int2(f0.c[c], f1.c[c]);
                 }
+                if (MODE == 6) {
+                    // the operands of the four lazy products are gathers: M f0 = mt[0][c0] + mt[1][c1], f0^2 = sq[c0, c1] (likewise f1 from c2, c3)
+                    auto ld = [&](const fe *base, u32 code, E9 &o) {
+                        const int4 *q = reinterpret_cast<const int4 *>(base + 12 * code);
+                        int4 a0 = q[0], a1 = q[1], a2 = q[2];
+                        o.c[0] = a0.x; o.c[1] = a0.y; o.c[2] = a0.z; o.c[3] = a0.w; o.c[4] = a1.x; o.c[5] = a1.y; o.c[6] = a1.z; o.c[7] = a1.w; o.c[8] = a2.x;
+                    };
+                    const fe *ma = lt.mt4 + (size_t)tb * 2 * 81 * 12, *mb = ma + 81 * 12;
+                    E9 xa, xb, ya, yb, s0, s1, tt, uu;
+                    ld(ma, c0, xa); ld(mb, c1, xb); ld(ma, c2, ya); ld(mb, c3, yb);
+                    ld(lt.sq4, c0 * 81 + c1, s0); ld(lt.sq4, c2 * 81 + c3, s1);
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) { tt.c[c] = fadd(xa.c[c], xb.c[c]); uu.c[c] = fadd(ya.c[c], yb.c[c]); }
+                    E9 s0n = e9_times_nu_t<NU2>(s0, t.nu), s1n = e9_times_nu_t<NU2>(s1, t.nu);
+                    i64 T[TAU];
+                    e9_mul_cols(tt, s0, s0n, T);
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) hl_add(C[c], T[c]);
+                    e9_mul_cols(uu, s0, s0n, T);
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) hl_add(C[TAU + c], T[c]);
+                    e9_mul_cols(tt, s1, s1n, T);
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) hl_add(C[2 * TAU + c], T[c]);
+                    e9_mul_cols(uu, s1, s1n, T);
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) { hl_add(C[3 * TAU + c], T[c]); SP[c] += tt.c[c]; SU[c] += uu.c[c]; }
+                    continue;
+                }
             }
         } else if (FIX) {
             E9 a0, a1, b0, b1;
@@ -1407,7 +1462,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         E9 c0, c1, c2, c3;
 #pragma unroll
         for (int c = 0; c < TAU; c++) {
-            if (MODE == 3 || MODE == 5) {
+            if (MONO) {
                 // C0 = P0 - sp, C1 = 3 (P1 - P0) - (su - sp), 3 C2 = 3 (P2 - 2 P1 + P0), C3 = P3 - 3 P2 + 3 P1 - P0   (values of a few p: one reduction)
                 i64 P0 = MODE == 5 ? (i64)fred(P0s[c]) : (i64)hl_finish(C[c]), P1 = hl_finish(C[TAU + c]), P2 = hl_finish(C[2 * TAU + c]);
                 i64 P3 = MODE == 5 ? (i64)fred(P3s[c]) : (i64)hl_finish(C[3 * TAU + c]);
@@ -1463,6 +1518,7 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
     do {                                                                        \
         if (mode == 1) BB_FR(N2, 1); else if (mode == 3) BB_FR(N2, 3);          \
         else if (mode == 4) BB_FR(N2, 4); else if (mode == 5) BB_FR(N2, 5);     \
+        else if (mode == 6) BB_FR(N2, 6);                                       \
         else BB_FR(N2, 0);                                                      \
     } while (0)
     if (nu2) BB_FRM(true); else BB_FRM(false);
@@ -1479,7 +1535,7 @@ void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ld
 void launch_fold_round_lut(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                            u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
     E9PreC none = {};
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 3, none, nullptr, 0, lt, partial, out, s);
 }
 // round 3 with per-table products of the look-up values (mutab_dev: 3 * 2K*9 * 81 * 12 words, filled by this call)
@@ -1489,14 +1545,26 @@ void launch_fold_round_lut_mu(const DevBb &t, const FoldArgs &a, const int32_t *
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_mutab<true>), dim3(ntab), dim3(128), 0, s, t, lut_dev, Mpre, ntab, mutab_dev);
     else hipLaunchKernelGGL((k_fold_mutab<false>), dim3(ntab), dim3(128), 0, s, t, lut_dev, Mpre, ntab, mutab_dev);
     E9PreC none = {};
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, mutab_dev};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, mutab_dev, nullptr, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 5, none, nullptr, 0, lt, partial, out, s);
 }
 void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                                hipStream_t s) {
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 4, e9pre_from_h9(r, ring.T.nu), Fout, ldout, lt, partial, out, s);
+}
+// round 4 through the product-free tables of mode 6 (sq_dev 6561*12 words, mt_dev 2K*9*2*81*12 words, filled by this call)
+void launch_fold_round_lut_fix_tab(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                                   const H9 &r, const BbHostRing &ring, fe *sq_dev, fe *mt_dev, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial,
+                                   u64 *out, hipStream_t s) {
+    const u32 ntab = 2 * K * TAU;
+    const E9PreC rp = e9pre_from_h9(r, ring.T.nu);
+    const u32 grid = (6561 + ntab * 162 + 255) / 256;
+    if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_r4tab<true>), dim3(grid), dim3(256), 0, s, t, lut_dev, rp, Mpre, ntab, sq_dev, mt_dev);
+    else hipLaunchKernelGGL((k_fold_r4tab<false>), dim3(grid), dim3(256), 0, s, t, lut_dev, rp, Mpre, ntab, sq_dev, mt_dev);
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, sq_dev, mt_dev};
+    launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 6, rp, Fout, ldout, lt, partial, out, s);
 }
 // the 81-entry table of modes 3 / 4: lut[code][c] = sum_b (t_b - 1) W_b[c], code = sum_b t_b 3^b, W = eq((r1, r2), .)
 void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 2 * 81 * 9: values, then squares */) {
