@@ -1274,6 +1274,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // rounds 3 and 4 of large unsharded instances never materialise the m/4-entry tables (k_fold_round modes 3 and 4)
     const size_t lut_min = c->tn.lut_min;   // default 2^15
     const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !c->tn.fold_no_lut;
+    // round 5 on the planes as well (mode 7): round 4 then stores no tables.  From 2^18 rows on, like the Goldilocks driver
+    const bool use_r5 = use_lut && !c->tn.fold_no_r4tab && !c->tn.fold_no_r5tab && P.s >= 5 && (N & 3) == 0 && m / 32 >= c->tn.r5_min;
     fe *d_lut = nullptr;
     int lut_mode = 0;
     for (u32 round = 1; round <= P.s; round++) {
@@ -1335,6 +1337,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                 } else if (round > 3) {
                     fe *fd = F[(round & 1) ? 0 : 1];   // round 4 -> F[1], round 5 -> F[0], ...
                     if (use_lut && round == 4) lut_mode = 4;
+                    else if (use_r5 && round == 5) lut_mode = 7;
                     else if (fused && ldF >= fuse_min && ldF >= 4 && nn * 2 == ldF) { prevF = curF; prevld = ldF; fix_fused = true; }
                     else launch_fix(c->dev, curF, ldF, fd, atl(ldF / 2), ldF, K2 * TAU * 8, r, c->stream());
                     curF = fd; ldF = atl(ldF / 2);
@@ -1360,7 +1363,15 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             fe *r4sq, *r4mt;
             RET(c->tbuf("fold_r4sq", (size_t)6561 * 12, &r4sq));
             RET(c->tbuf("fold_r4mt", (size_t)K2 * TAU * 162 * 12, &r4mt));
-            launch_fold_round_lut_fix_tab(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, r4sq, r4mt, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
+            launch_fold_round_lut_fix_tab(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, r4sq, r4mt, use_r5 ? nullptr : (fe *)curF, ldF, K, d_mup, partial, od,
+                                          c->stream());
+        } else if (lut_mode == 7) {
+            fe *r5xx, *r5yy, *r5mt;
+            RET(c->tbuf("fold_r5xx", (size_t)6561 * 12, &r5xx));
+            RET(c->tbuf("fold_r5yy", (size_t)6561 * 12, &r5yy));
+            RET(c->tbuf("fold_r5mt", (size_t)K2 * TAU * 324 * 12, &r5mt));
+            launch_fold_round_lut_fix5(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 3], pt[round - 2], c->ring, r5xx, r5yy, r5mt, (fe *)curF, ldF, K, d_mup, partial, od,
+                                       c->stream());
         } else if (lut_mode == 4) launch_fold_round_lut_fix(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else if (fix_fused) launch_fold_round_fix(c->dev, a, prevF, prevld, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());

@@ -1192,7 +1192,7 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 // sum_b W_b * digit_k(plane[4j+b]) with four ternary digits -- one of 81 values independent of table and slot -- and comes from a look-up
 // table in LDS indexed by the digit code (lut: [81][9] words); mode 4 also fixes the four round-3 entries of a pair with r and stores the
 // first materialised tables (m/8 entries) like mode 1.  MODE 0: plain tables, MODE 1: fused fix (above).
-struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; const fe *mutab; const fe *sq4; const fe *mt4; };   // mutab: mode 5, [3][2K*9][81][12]; sq4 / mt4: mode 6, [81*81][12] and [2K*9][2][81][12]
+struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; const fe *mutab; const fe *sq4; const fe *mt4; E9PreC rprev; const fe *xx5, *yy5, *mt5; };   // mutab: mode 5, [3][2K*9][81][12]; sq4 / mt4: mode 6, [81*81][12] and [2K*9][2][81][12]; rprev / xx5 / yy5 / mt5: mode 7 (r_3; [81*81][12] twice; [2K*9][4][81][12])
 __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
     int code = 40;
     const int w[4] = {1, 3, 9, 27};
@@ -1247,11 +1247,45 @@ __global__ void __launch_bounds__(256) k_fold_r4tab(DevBb t, const fe *lut, E9Pr
         for (int c = 0; c < 12; c++) o[c] = c < TAU ? m.c[c] : 0;
     }
 }
+// mode 7 (round 5 still from the planes; twin of lf::k_fold_r5tab): an entry of the m/16-entry tables is X + Y, X = T0[c0] + T1[c1], Y = T2[c2] + T3[c3] with
+// T = (1-r4)(1-r3) L, (1-r4) r3 L, r4 (1-r3) L, r4 r3 L;  xx[c0 * 81 + c1] = X^2, yy[c2 * 81 + c3] = Y^2, mt[tb][w][c] = M_tb T_w[c]
+__device__ __forceinline__ E9 r5_entry(const fe *lut, u32 w, u32 code, const E9PreC &r3, const E9PreC &r4) {
+    E9 g;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) g.c[c] = lut[TAU * code + c];
+    const E9 rl = e9_mul(g, e9p(r3)), a = (w & 1) ? rl : e9_sub(g, rl), ra = e9_mul(a, e9p(r4));
+    return (w & 2) ? ra : e9_sub(a, ra);
+}
+template <bool NU2>
+__global__ void __launch_bounds__(256) k_fold_r5tab(DevBb t, const fe *lut, E9PreC r3, E9PreC r4, const E9PreC *Mpre, u32 ntab, fe *xx, fe *yy, fe *mt) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * 6561) {
+        const u32 hi = i / 6561, j = i % 6561, c0 = j / 81, c1 = j % 81;
+        const E9 f = e9_add(r5_entry(lut, 2 * hi, c0, r3, r4), r5_entry(lut, 2 * hi + 1, c1, r3, r4)), sv = e9_sqr_t<NU2>(f, t.nu);
+        fe *o = (hi ? yy : xx) + (size_t)j * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) o[c] = c < TAU ? sv.c[c] : 0;
+    } else if (i < 2 * 6561 + ntab * 324) {
+        const u32 j = i - 2 * 6561, tb = j / 324, w = (j % 324) / 81, code = j % 81;
+        const E9 m = e9_mul(r5_entry(lut, w, code, r3, r4), e9p(Mpre[tb]));
+        fe *o = mt + (((size_t)tb * 4 + w) * 81 + code) * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) o[c] = c < TAU ? m.c[c] : 0;
+    }
+}
 template <bool NU2, int MODE>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
                                                     fe *Fout, size_t ldo, FoldLut lt, i64 *partial) {
     constexpr bool FIX = MODE == 1;
-    __shared__ fe slut[MODE >= 3 ? 3 * 81 * TAU : 1];   // the 81 values, their squares, (mode 4) r times the values
+    __shared__ fe slut[MODE == 7 ? 4 * 81 * TAU : (MODE >= 3 ? 3 * 81 * TAU : 1)];   // the 81 values, their squares, (modes 4, 6) r times the values; mode 7: T0..T3
+    if (MODE == 7) {
+        for (u32 i = threadIdx.x; i < 4 * 81; i += 256) {
+            const E9 e = r5_entry(lt.lut, i / 81, i % 81, lt.rprev, rfix);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) slut[TAU * i + c] = e.c[c];
+        }
+        __syncthreads();
+    } else
     if (MODE >= 3) {
         for (u32 i = threadIdx.x; i < 2 * 81 * TAU; i += 256) slut[i] = lt.lut[i];
         __syncthreads();
@@ -1267,7 +1301,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             __syncthreads();
         }
     }
-    constexpr bool MONO = MODE == 3 || MODE == 5 || MODE == 6;   // the cubic in the monomial basis P0..P3 (binomials after the loop)
+    constexpr bool MONO = MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7;   // the cubic in the monomial basis P0..P3 (binomials after the loop)
     i64 SP[MONO ? TAU : 1], SU[MONO ? TAU : 1];   // sum M f0, sum M f1
     i64 P0s[MODE == 5 ? TAU : 1], P3s[MODE == 5 ? TAU : 1];                            // mode 5: sum M f0^3, sum M f1^3 (look-ups)
     if (MONO) {
@@ -1292,7 +1326,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
         E9 f0, f1;
         if (MODE >= 3) {
-            constexpr int NE = (MODE == 4 || MODE == 6) ? 16 : 8;      // plane entries behind one pair
+            constexpr int NE = MODE == 7 ? 32 : ((MODE == 4 || MODE == 6) ? 16 : 8);      // plane entries behind one pair
             const u32 side = tb / (TAU * K), k = (tb / TAU) % K, d = tb % TAU;
             const int32_t *pl = (side ? lt.planesR : lt.planesL) + (size_t)(8 * d + slot) * lt.n_planes + (size_t)NE * jj;
             int32_t v[NE];
@@ -1305,6 +1339,52 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
             } else {
 #pragma unroll
                 for (int q = 0; q < NE; q++) v[q] = (size_t)NE * jj + q < lt.n_planes ? pl[q] : 0;
+            }
+            if (MODE == 7) {
+                auto ld = [&](const fe *base, u32 code, E9 &o) {
+                    const int4 *q = reinterpret_cast<const int4 *>(base + 12 * code);
+                    int4 a0 = q[0], a1 = q[1], a2 = q[2];
+                    o.c[0] = a0.x; o.c[1] = a0.y; o.c[2] = a0.z; o.c[3] = a0.w; o.c[4] = a1.x; o.c[5] = a1.y; o.c[6] = a1.z; o.c[7] = a1.w; o.c[8] = a2.x;
+                };
+                const fe *mt = lt.mt5 + (size_t)tb * 4 * 81 * 12;
+                E9 fv[2], sq[2], mf[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const u32 c0 = digit_code4(v + 16 * e, k), c1 = digit_code4(v + 16 * e + 4, k), c2 = digit_code4(v + 16 * e + 8, k), c3 = digit_code4(v + 16 * e + 12, k);
+                    const fe *t0 = slut + TAU * c0, *t1 = slut + TAU * (81 + c1), *t2 = slut + TAU * (162 + c2), *t3 = slut + TAU * (243 + c3);
+                    E9 X, Y, qx, qy, m0, m1, m2, m3;
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) { X.c[c] = fadd(t0[c], t1[c]); Y.c[c] = fadd(t2[c], t3[c]); }
+                    ld(lt.xx5, c0 * 81 + c1, qx); ld(lt.yy5, c2 * 81 + c3, qy);
+                    ld(mt, c0, m0); ld(mt, 81 + c1, m1); ld(mt, 162 + c2, m2); ld(mt, 243 + c3, m3);
+                    const E9 xy = e9_mul_t<NU2>(X, Y, t.nu);
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) {
+                        fv[e].c[c] = fadd(X.c[c], Y.c[c]);
+                        sq[e].c[c] = fadd(fadd(qx.c[c], qy.c[c]), fadd(xy.c[c], xy.c[c]));
+                        mf[e].c[c] = fadd(fadd(m0.c[c], m1.c[c]), fadd(m2.c[c], m3.c[c]));
+                    }
+                }
+                if (live) {
+                    fe *Fo = Fout + ((size_t)tb * RE + TAU * slot) * ldo;
+#pragma unroll
+                    for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(Fo + (size_t)c * ldo + 2 * jj) = make_int2(fv[0].c[c], fv[1].c[c]);
+                }
+                E9 s0n = e9_times_nu_t<NU2>(sq[0], t.nu), s1n = e9_times_nu_t<NU2>(sq[1], t.nu);
+                i64 T[TAU];
+                e9_mul_cols(mf[0], sq[0], s0n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) hl_add(C[c], T[c]);
+                e9_mul_cols(mf[1], sq[0], s0n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) hl_add(C[TAU + c], T[c]);
+                e9_mul_cols(mf[0], sq[1], s1n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) hl_add(C[2 * TAU + c], T[c]);
+                e9_mul_cols(mf[1], sq[1], s1n, T);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) { hl_add(C[3 * TAU + c], T[c]); SP[c] += mf[0].c[c]; SU[c] += mf[1].c[c]; }
+                continue;
             }
             if (MODE == 5) {
                 // per-table products of the look-up values: T1 = M L, T2 = M L^2, T3 = M L^3 (k_fold_mutab)
@@ -1368,7 +1448,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
                     f0.c[c] = fadd(g0[c], fsub(r1[c], r0[c]));
                     f1.c[c] = fadd(g2[c], fsub(r3[c], r2[c]));
                 }
-                if (live) {
+                if (live && Fout) {      // (Fout is null when round 5 works from the planes as well: mode 7)
                     fe *Fo = Fout + ((size_t)tb * RE + TAU * slot) * ldo;
 #pragma unroll
                     for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(Fo + (size_t)c * ldo + 2 * jj) = make_int2(f0.c[c], f1.c[c]);
@@ -1518,7 +1598,7 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
     do {                                                                        \
         if (mode == 1) BB_FR(N2, 1); else if (mode == 3) BB_FR(N2, 3);          \
         else if (mode == 4) BB_FR(N2, 4); else if (mode == 5) BB_FR(N2, 5);     \
-        else if (mode == 6) BB_FR(N2, 6);                                       \
+        else if (mode == 6) BB_FR(N2, 6); else if (mode == 7) BB_FR(N2, 7);     \
         else BB_FR(N2, 0);                                                      \
     } while (0)
     if (nu2) BB_FRM(true); else BB_FRM(false);
@@ -1535,7 +1615,7 @@ void launch_fold_round(const DevBb &t, const FoldArgs &a, const fe *F, size_t ld
 void launch_fold_round_lut(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                            u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
     E9PreC none = {};
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr, {}, nullptr, nullptr, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 3, none, nullptr, 0, lt, partial, out, s);
 }
 // round 3 with per-table products of the look-up values (mutab_dev: 3 * 2K*9 * 81 * 12 words, filled by this call)
@@ -1545,13 +1625,13 @@ void launch_fold_round_lut_mu(const DevBb &t, const FoldArgs &a, const int32_t *
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_mutab<true>), dim3(ntab), dim3(128), 0, s, t, lut_dev, Mpre, ntab, mutab_dev);
     else hipLaunchKernelGGL((k_fold_mutab<false>), dim3(ntab), dim3(128), 0, s, t, lut_dev, Mpre, ntab, mutab_dev);
     E9PreC none = {};
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, mutab_dev, nullptr, nullptr};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, mutab_dev, nullptr, nullptr, {}, nullptr, nullptr, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 5, none, nullptr, 0, lt, partial, out, s);
 }
 void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                const H9 &r, const BbHostRing &ring, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out,
                                hipStream_t s) {
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr, {}, nullptr, nullptr, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 4, e9pre_from_h9(r, ring.T.nu), Fout, ldout, lt, partial, out, s);
 }
 // round 4 through the product-free tables of mode 6 (sq_dev 6561*12 words, mt_dev 2K*9*2*81*12 words, filled by this call)
@@ -1563,8 +1643,20 @@ void launch_fold_round_lut_fix_tab(const DevBb &t, const FoldArgs &a, const int3
     const u32 grid = (6561 + ntab * 162 + 255) / 256;
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_r4tab<true>), dim3(grid), dim3(256), 0, s, t, lut_dev, rp, Mpre, ntab, sq_dev, mt_dev);
     else hipLaunchKernelGGL((k_fold_r4tab<false>), dim3(grid), dim3(256), 0, s, t, lut_dev, rp, Mpre, ntab, sq_dev, mt_dev);
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, sq_dev, mt_dev};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, sq_dev, mt_dev, {}, nullptr, nullptr, nullptr};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 6, rp, Fout, ldout, lt, partial, out, s);
+}
+// round 5 from the planes (mode 7): xx_dev / yy_dev 6561*12 words each, mt_dev 2K*9*4*81*12 words, filled by this call; r3 / r4: the challenges of rounds 3 / 4
+void launch_fold_round_lut_fix5(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
+                                const H9 &r3, const H9 &r4, const BbHostRing &ring, fe *xx_dev, fe *yy_dev, fe *mt_dev, fe *Fout, size_t ldout, u32 K,
+                                const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
+    const u32 ntab = 2 * K * TAU;
+    const E9PreC r3p = e9pre_from_h9(r3, ring.T.nu), r4p = e9pre_from_h9(r4, ring.T.nu);
+    const u32 grid = (2 * 6561 + ntab * 324 + 255) / 256;
+    if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_r5tab<true>), dim3(grid), dim3(256), 0, s, t, lut_dev, r3p, r4p, Mpre, ntab, xx_dev, yy_dev, mt_dev);
+    else hipLaunchKernelGGL((k_fold_r5tab<false>), dim3(grid), dim3(256), 0, s, t, lut_dev, r3p, r4p, Mpre, ntab, xx_dev, yy_dev, mt_dev);
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr, r3p, xx_dev, yy_dev, mt_dev};
+    launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 7, r4p, Fout, ldout, lt, partial, out, s);
 }
 // the 81-entry table of modes 3 / 4: lut[code][c] = sum_b (t_b - 1) W_b[c], code = sum_b t_b 3^b, W = eq((r1, r2), .)
 void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 2 * 81 * 9: values, then squares */) {

@@ -242,6 +242,14 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     monkeypatch.delenv("LF_FOLD_NO_LUT")
     monkeypatch.setenv("LF_FOLD_LUT_MIN", "1")
     lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    # rounds 4 / 5 from the product-free tables over the digit codes (modes 6 / 7), round 5 on the stored round-4 tables, and the older modes 4 / 1
+    for extra in ({"LF_FOLD_R5_MIN": "1"}, {"LF_FOLD_NO_R5TAB": "1"}, {"LF_FOLD_NO_R4TAB": "1"}):
+        for key, val in extra.items():
+            monkeypatch.setenv(key, val)
+        lc_x, w_x, proof_x = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+        for key in extra:
+            monkeypatch.delenv(key)
+        assert (proof_x == proof_o).all() and (lc_x == lc_o).all() and (w_x.f == f0_o).all(), extra
     monkeypatch.delenv("LF_FOLD_LUT_MIN")
     monkeypatch.delenv("LF_FOLD_FUSE_MIN")
     monkeypatch.setenv("LF_FOLD_UNFUSED", "1")
@@ -402,7 +410,11 @@ def test_fold_step_with_another_nonresidue(ctx, monkeypatch):
         monkeypatch.setenv("LF_FOLD_FUSE_MIN", "4")
         lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
         assert (proof_l == proof_o).all() and (lc_l == lc_o).all() and (w_l.f == f0_o).all()
+        monkeypatch.setenv("LF_FOLD_R5_MIN", "1")      # ... and round 5 from the planes (mode 7)
+        lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+        assert (proof_l == proof_o).all() and (lc_l == lc_o).all() and (w_l.f == f0_o).all()
     finally:
+        monkeypatch.delenv("LF_FOLD_R5_MIN", raising=False)
         monkeypatch.delenv("LF_FOLD_LUT_MIN", raising=False)
         monkeypatch.delenv("LF_FOLD_FUSE_MIN", raising=False)
         ctx.set_ring_tables(nr, y)
