@@ -237,9 +237,12 @@ def lfplus_extra():
         finally:
             prover.close()
         best = dt if best is None else min(best, dt)
-    t0 = time.perf_counter()
-    ok = plus.PlusVerifier.init(A, list(r1cs), params, plus.PoseidonTranscript()).verify(proof)
-    tv = time.perf_counter() - t0
+    tv, ok = None, True
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ok = plus.PlusVerifier.init(A, list(r1cs), params, plus.PoseidonTranscript()).verify(proof) and ok
+        dt = time.perf_counter() - t0
+        tv = dt if tv is None else min(tv, dt)
     return {"op": "PlusProver::prove", "ring": "Frog Z_p[X]/(X^16+1), coefficient form", "n": n, "kappa": kappa, "k": k, "fresh_instances": 2, "ms": 1e3 * best,
             "host_verify_ms": 1e3 * tv, "verified": bool(ok), "cpu_oracle_ms": 2430.0,
             "cpu_oracle_source": "profiles/r03b_lfplus_bench.txt (oracle/lfp*.c, one thread, not re-measured here)",

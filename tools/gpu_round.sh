@@ -16,5 +16,5 @@ for wl in C4 C3; do
 done
 bash $R/tools/gpu_pmc.sh $tag C4
 bash $R/tools/gpu_pmc.sh $tag C3
-LF_TIMELINE=1 python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-lfplus 2>&1 | grep timeline | tail -32 > $R/gpurun_out/${tag}_timeline_c4.txt
+LF_TIMELINE=1 python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-lfplus 2>&1 | grep "^\[timeline\]" | tail -32 > $R/gpurun_out/${tag}_timeline_c4.txt
 bash $R/tools/gpu_sq.sh $tag C4
