@@ -1675,21 +1675,23 @@ static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *
 
 // <X_a, Y_b> for na vectors X and nb vectors Y of n columns -> od (device, canonical): on the int8 matrix cores (lf_dot_i8.hip) unless
 // LF_DOT_VALU is set or the shape is not handled there
-static int dot_batch_dev(lf_ctx *c, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *dpart, u64 *od) {
+// (st / tag: a second call in flight on another stream uses its own scratch buffers)
+static int dot_batch_dev(lf_ctx *c, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *dpart, u64 *od, hipStream_t st = nullptr,
+                         const char *tag = "") {
+    if (!st) st = c->stream();
     if (!c->tn.dot_valu && n >= c->tn.dot_min && nb <= 3) {
         unsigned char *yb;
         int32_t *part;
         long long *tot;
-        RET(c->tbuf("dot_yb", dot_i8_yb_bytes(n + 1), &yb));            // (+1: an odd column slice starts one column early)
-        RET(c->tbuf("dot_i8_part", dot_i8_part_words(n + 1), &part));
-        RET(c->tbuf("dot_i8_tot", dot_i8_tot_words(), &tot));
+        RET(c->tbuf(std::string("dot_yb") + tag, dot_i8_yb_bytes(n + 1), &yb));            // (+1: an odd column slice starts one column early)
+        RET(c->tbuf(std::string("dot_i8_part") + tag, dot_i8_part_words(n + 1), &part));
+        RET(c->tbuf(std::string("dot_i8_tot") + tag, dot_i8_tot_words(), &tot));
         bool ok = true;
         for (u32 a0 = 0; a0 < na && ok; a0 += 16)
-            ok = launch_dot_batch_i8(c->dcrt, X + (size_t)a0 * 24 * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * 24,
-                                     c->stream()) == 0;
+            ok = launch_dot_batch_i8(c->dcrt, X + (size_t)a0 * 24 * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * 24, st) == 0;
         if (ok) return LF_OK;
     }
-    launch_dot_batch(c->dcrt, X, ldx, na, Y, ldy, nb, n, dpart, od, c->stream());
+    launch_dot_batch(c->dcrt, X, ldx, na, Y, ldy, nb, n, dpart, od, st);
     return LF_OK;
 }
 // the point-dependent half of LFDecompositionProver::prove (decomposition.rs:33-88): x_s, v_s, z_k, u_s
@@ -2323,7 +2325,20 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     {
         size_t c0, cnt;
         shard_slice(c, n, &c0, &cnt);
-        for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta + (size_t)sd * K * P.t * 24));
+        // the two sides stream their own 0.8 GB of z_k: side by side on the two streams (the helper lane's is idle here)
+        hipStream_t s1 = (t_lane == 0 && !c->tn.prep_one_stream && c->sh_world == 1 && c->st_lane[1]) ? c->st_lane[1] : c->stream();
+        if (s1 != c->stream()) {
+            if (!c->ev_prep[0]) { HIPCHK(hipEventCreateWithFlags(&c->ev_prep[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_prep[1], hipEventDisableTiming)); }
+            HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));           // q = M_j^T eq(r_o) is ready
+            HIPCHK(hipStreamWaitEvent(s1, c->ev_prep[0], 0));
+            u64 *dpart1;
+            RET(c->tbuf("dot_partial1", dot_partial_words(K, P.t), &dpart1));
+            RET(dot_batch_dev(c, S[1].z + c0, n, K, q + c0, n, P.t, cnt, dpart1, d_eta + (size_t)K * P.t * 24, s1, "_1"));
+            HIPCHK(hipEventRecord(c->ev_prep[1], s1));
+            RET(dot_batch_dev(c, S[0].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta));
+            HIPCHK(hipStreamWaitEvent(c->stream(), c->ev_prep[1], 0));
+        } else
+            for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta + (size_t)sd * K * P.t * 24));
         RET(exchange_modsum_dev(c, d_eta, (size_t)K2 * P.t * 24));
     }
     HIPCHK(hipMemcpyAsync(hp + (size_t)K2 * 72, d_eta, (size_t)K2 * P.t * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
