@@ -255,6 +255,27 @@ LF_HD void lh5_mac(LH5 &acc, Fq3 a, Fq3 b) {
         acc.c[i].h += t.h;
     }
 }
+// acc += a b + c d: the partial products of BOTH F_{p^3} products go into the same five column sums before they are folded to their (L, H) forms -- one
+// fold (the larger half of a lazy product's instructions: zero-extensions and 64-bit adds) per two products
+LF_HD void lh5_mac2(LH5 &acc, Fq3 a, Fq3 b, Fq3 c, Fq3 d) {
+    AccP s[5];
+    accp_set(s[0], a.c[0], b.c[0]);
+    accp_set(s[1], a.c[0], b.c[1]); accp_mad(s[1], a.c[1], b.c[0]);
+    accp_set(s[2], a.c[0], b.c[2]); accp_mad(s[2], a.c[1], b.c[1]); accp_mad(s[2], a.c[2], b.c[0]);
+    accp_set(s[3], a.c[1], b.c[2]); accp_mad(s[3], a.c[2], b.c[1]);
+    accp_set(s[4], a.c[2], b.c[2]);
+    accp_mad(s[0], c.c[0], d.c[0]);
+    accp_mad(s[1], c.c[0], d.c[1]); accp_mad(s[1], c.c[1], d.c[0]);
+    accp_mad(s[2], c.c[0], d.c[2]); accp_mad(s[2], c.c[1], d.c[1]); accp_mad(s[2], c.c[2], d.c[0]);
+    accp_mad(s[3], c.c[1], d.c[2]); accp_mad(s[3], c.c[2], d.c[1]);
+    accp_mad(s[4], c.c[2], d.c[2]);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        LH t = accp_lh(s[i]);
+        acc.c[i].l += t.l;
+        acc.c[i].h += t.h;
+    }
+}
 // signed wide value base + 2^32 h32 + 2^40 h40 with |terms| up to ~2^62: split before shifting
 LF_HD u64 fq_from_lin_wide(int64_t base, int64_t h32, int64_t h40) {
     typedef __int128 i128;

@@ -1026,12 +1026,22 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_
     Fq3 accg[TT];
 #pragma unroll
     for (int j = 0; j < TT; j++) { lh5_zero(acc[j]); accg[j] = fq3_zero(); }
-    for (u32 k = 0; k < K; k++) {
+    auto cf = [&](u32 k, int j) {
+        Fq3Const cc = coef[per_slot ? (size_t)(k * TT + j) * 8 + slot : (size_t)(k * TT + j)];   // per_slot: ring-element coefficients
+        return fq3_make(cc.c[0], cc.c[1], cc.c[2]);
+    };
+    u32 k = 0;
+    if (NU)
+        for (; k + 1 < K; k += 2) {      // two terms per lazy accumulation step: their partial products share the column sums (lh5_mac2)
+            Fq3 x0 = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i), x1 = ld3(z + (size_t)(k + 1) * 24 * ldz, ldz, slot, i);
+#pragma unroll
+            for (int j = 0; j < TT; j++) lh5_mac2(acc[j], x0, cf(k, j), x1, cf(k + 1, j));
+        }
+    for (; k < K; k++) {
         Fq3 x = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i);
 #pragma unroll
         for (int j = 0; j < TT; j++) {
-            Fq3Const cc = coef[per_slot ? (size_t)(k * TT + j) * 8 + slot : (size_t)(k * TT + j)];   // per_slot: ring-element coefficients
-            Fq3 cv = fq3_make(cc.c[0], cc.c[1], cc.c[2]);
+            Fq3 cv = cf(k, j);
             if (NU) lh5_mac(acc[j], x, cv);
             else accg[j] = fq3_add(accg[j], M3<NU>(x, cv, t.nu));
         }
@@ -1932,7 +1942,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             LH5 A0, A1, A2, A3;
             lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
             Fq3 sp = fq3_zero(), su = fq3_zero();
-            for (u32 kd = kd0; kd < kd1; kd++) {
+            for (u32 kd = kd0; kd < kd1; kd++) {     // (pairing the tables as in mode 6 needs 408 registers here)
                 const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
                 const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)32 * p;
                 const u64 *mt = src.mt5 + (size_t)kd * 4 * 81 * 4;
@@ -1983,7 +1993,8 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             LH5 A0, A1, A2, A3;
             lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
             Fq3 sp = fq3_zero(), su = fq3_zero();
-            for (u32 kd = kd0; kd < kd1; kd++) {
+            // operands of table kd's four lazy products: gathers, no multiplication (and the fixed pair stored for round 5)
+            auto gen = [&](u32 kd, Fq3 &tt, Fq3 &uu, Fq3 &s0, Fq3 &s1) {
                 const u32 side = kd / (3 * K), k = (kd / 3) % K, d = kd % 3;
                 const int32_t *pl = (side ? src.planesR : src.planesL) + (size_t)(d * 8 + slot) * src.n_planes + (size_t)16 * p;
                 int32_t v[16];
@@ -1998,7 +2009,6 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                     for (int q = 0; q < 16; q++) v[q] = (size_t)16 * p + q < src.n_planes ? pl[q] : 0;
                 }
                 const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k), c2 = digit_code4(v + 8, k), c3 = digit_code4(v + 12, k);
-                // operands of the four lazy products: gathers, no multiplication
                 const u64 *q0 = src.sq4 + (size_t)(c0 * 81 + c1) * 4, *q1 = src.sq4 + (size_t)(c2 * 81 + c3) * 4;
                 const u64 *ma = src.mt4 + (size_t)kd * 2 * 81 * 4, *mb = ma + 81 * 4;
                 const ulonglong2 s0a = *(const ulonglong2 *)q0, s1a = *(const ulonglong2 *)q1;
@@ -2006,19 +2016,31 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 const ulonglong2 a0 = *(const ulonglong2 *)(ma + 4 * c0), b1 = *(const ulonglong2 *)(mb + 4 * c1);
                 const ulonglong2 a2 = *(const ulonglong2 *)(ma + 4 * c2), b3 = *(const ulonglong2 *)(mb + 4 * c3);
                 const u64 a0c = ma[4 * c0 + 2], b1c = mb[4 * c1 + 2], a2c = ma[4 * c2 + 2], b3c = mb[4 * c3 + 2];
-                // the fixed pair itself (stored for round 5)
-                const Fq3 f0 = fq3_add(lut3(c0), fq3_sub(lut3(162 + c1), lut3(162 + c0)));
-                const Fq3 f1 = fq3_add(lut3(c2), fq3_sub(lut3(162 + c3), lut3(162 + c2)));
                 if (src.out) {      // (null when round 5 works from the planes as well: mode 7)
+                    const Fq3 f0 = fq3_add(lut3(c0), fq3_sub(lut3(162 + c1), lut3(162 + c0)));
+                    const Fq3 f1 = fq3_add(lut3(c2), fq3_sub(lut3(162 + c3), lut3(162 + c2)));
                     u64 *op = src.out + ((size_t)kd * 24 + 3 * slot) * src.ldo + 2 * p;
                     *(ulonglong2 *)(op) = make_ulonglong2(f0.c[0], f1.c[0]);
                     *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(f0.c[1], f1.c[1]);
                     *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(f0.c[2], f1.c[2]);
                 }
-                const Fq3 tt = fq3_add(fq3_make(a0.x, a0.y, a0c), fq3_make(b1.x, b1.y, b1c)), uu = fq3_add(fq3_make(a2.x, a2.y, a2c), fq3_make(b3.x, b3.y, b3c));
-                const Fq3 s0 = fq3_make(s0a.x, s0a.y, s0c), s1 = fq3_make(s1a.x, s1a.y, s1c);
-                lh5_mac(A0, tt, s0); lh5_mac(A1, uu, s0); lh5_mac(A2, tt, s1); lh5_mac(A3, uu, s1);
+                tt = fq3_add(fq3_make(a0.x, a0.y, a0c), fq3_make(b1.x, b1.y, b1c));
+                uu = fq3_add(fq3_make(a2.x, a2.y, a2c), fq3_make(b3.x, b3.y, b3c));
+                s0 = fq3_make(s0a.x, s0a.y, s0c);
+                s1 = fq3_make(s1a.x, s1a.y, s1c);
                 sp = fq3_add(sp, tt); su = fq3_add(su, uu);
+            };
+            u32 kd = kd0;
+            for (; kd + 1 < kd1; kd += 2) {     // two tables per iteration: their partial products share the column sums (lh5_mac2)
+                Fq3 tA, uA, xA, yA, tB, uB, xB, yB;
+                gen(kd, tA, uA, xA, yA);
+                gen(kd + 1, tB, uB, xB, yB);
+                lh5_mac2(A0, tA, xA, tB, xB); lh5_mac2(A1, uA, xA, uB, xB); lh5_mac2(A2, tA, yA, tB, yB); lh5_mac2(A3, uA, yA, uB, yB);
+            }
+            if (kd < kd1) {
+                Fq3 tA, uA, xA, yA;
+                gen(kd, tA, uA, xA, yA);
+                lh5_mac(A0, tA, xA); lh5_mac(A1, uA, xA); lh5_mac(A2, tA, yA); lh5_mac(A3, uA, yA);
             }
             Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2), P3 = lh5_finish(A3);
             Fq3 a1 = fq3_sub(P1, P0);                                           // sum mu f0^2 df
@@ -2070,6 +2092,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
             LH5 A0, A1, A2, A3;
             lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
             Fq3 sp = fq3_zero(), sq = fq3_zero();
+            // (pairing the tables of a step as in mode 6 -- lh5_mac2 -- costs this branch its second wave per SIMD: 268 registers with the fused fix)
             for (u32 kd = kd0; kd < kd1; kd++) {
                 Fq3 f0, df;
                 load_pair(kd, f0, df);
