@@ -2139,6 +2139,11 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
     size_t row = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z;
     if (threadIdx.x < 15) partial[row * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
 }
+// threads a round should have before its tables stop being split over blockIdx.z (LF_FOLD_CHUNK_THREADS; a thread walks its chunk of the 96 tables serially)
+static size_t fold_chunk_threads() {
+    static const size_t v = [] { const char *e = getenv("LF_FOLD_CHUNK_THREADS"); return e ? (size_t)atoll(e) : (size_t)131072; }();   // measured at C4: 65536 / 131072 / 262144 / 524288 -> 19.58 / 19.28 / 19.35 / 19.74 ms per step
+    return v;
+}
 template <int MODE>
 static void launch_fold_round_mode(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow_dev,
                                    const FoldSrc &src, u64 *partial, u64 *out, hipStream_t s) {
@@ -2152,7 +2157,7 @@ static void launch_fold_round_mode(const DevCrt &t, const FoldRoundArgs &a, cons
     for (u32 cc : cand) {
         if (cc > nkd) break;
         chunks = cc;
-        if (pairs * 8 * cc >= 65536) break;
+        if (pairs * 8 * cc >= fold_chunk_threads()) break;
     }
     while (gb * chunks > RED_BLOCKS && chunks > 1) chunks--;
     if (MODE >= 3) chunks = 1;   // the planes of one (side, d) serve all K tables: no table split (the driver uses these modes on large rounds only)
