@@ -169,7 +169,7 @@ def phase_report(wl_name, timelines, host_ms):
             stats[k] = (int(r["Calls"]), float(r["TotalDurationNs"]))
     # steps covered by each profile: the commit kernel runs twice per step
     def steps_of(tbl, get):
-        n = sum(get(v) for k, v in tbl.items() if k.startswith("k_ajtai_i8<"))
+        n = sum(get(v) for k, v in tbl.items() if k.startswith("k_ajtai_i8<") or k.startswith("k_ajtai_i8s<"))
         return max(1.0, n / 2.0)
     pmc_steps = steps_of(pmc, lambda v: v["launches"])
     st_steps = steps_of(stats, lambda v: v[0])
