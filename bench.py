@@ -244,7 +244,7 @@ def lfplus_extra():
         dt = time.perf_counter() - t0
         tv = dt if tv is None else min(tv, dt)
     return {"op": "PlusProver::prove", "ring": "Frog Z_p[X]/(X^16+1), coefficient form", "n": n, "kappa": kappa, "k": k, "fresh_instances": 2, "ms": 1e3 * best,
-            "host_verify_ms": 1e3 * tv, "verified": bool(ok), "cpu_oracle_ms": 2430.0,
+            "host_verify_ms": 1e3 * tv, "verified": bool(ok), "cpu_oracle_ms": 2417.0,
             "cpu_oracle_source": "profiles/r03b_lfplus_bench.txt (oracle/lfp*.c, one thread, not re-measured here)",
             "parity": "bit-exact vs the in-repo oracle (tests/test_gpu_lfplus_prover.py); oracle pinned to the reference through the transcript KATs only"}
 

@@ -29,6 +29,7 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     (void)hipStreamSynchronize(c->st);
     if (!c->own_A) c->A = nullptr;
     c->drop_mats();
+    c->pool.clear();
     for (void *p : {(void *)c->A, (void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
                     (void *)c->err_d, (void *)c->g})
         if (p) (void)hipFree(p);
@@ -293,11 +294,12 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
     u64 *buf = nullptr;
     // F0 | F1 | tables T*n | ping T*n/2 | rM nvars*32
     const size_t words = 2 * vw + (size_t)T * vw + (size_t)T * vw / 2 + (size_t)nvars * 32 + 64;
-    HIPCHK(c, hipMalloc(&buf, words * 8));
+    buf = (u64 *)c->pool.get(words * 8);
+    if (!buf) return fail(c, LFPLUS_E_HIP, "hipMalloc (decompose tables)");
     u64 *dF0 = buf, *dF1 = dF0 + vw, *tab = dF1 + vw, *ping = tab + (size_t)T * vw, *drM = ping + (size_t)T * vw / 2;
     int rc = LFPLUS_OK;
     std::vector<void *> tofree;
-    auto cleanup = [&]() { for (void *q : tofree) (void)hipFree(q); (void)hipFree(buf); };
+    auto cleanup = [&]() { for (void *q : tofree) c->pool.put(q); c->pool.put(buf); };
 #define HIPCHK2(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(e_); cleanup(); return LFPLUS_E_HIP; } } while (0)
     {
         std::vector<u64> rM((size_t)nvars * 32);
@@ -318,7 +320,7 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
         u32 *drp = nullptr, *dci = nullptr;
         u64 *dv = nullptr, *dy = nullptr;
         if (resident) {
-            HIPCHK2(hipMalloc(&dy, vw * 8)); tofree.push_back(dy);
+            dy = (u64 *)c->pool.get(vw * 8); if (!dy) { cleanup(); return fail(c, LFPLUS_E_HIP, "hipMalloc"); } tofree.push_back(dy);
             const LfpMatrix &mj = c->mats[j];
             for (int s = 0; s < 2; s++) {
                 lfp::launch_spmv_ring(mj.rowptr, mj.col, mj.valM, s ? dF1 : dF0, n, dy, c->st);

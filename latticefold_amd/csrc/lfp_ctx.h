@@ -23,6 +23,36 @@ struct LfpMatrix {
     }
 };
 
+// Scratch pool of a context: the protocol stages allocate their tables (up to ~1 GB at n = 2^18) anew in every call, and hipMalloc / hipFree of such blocks
+// cost milliseconds each; freed blocks are kept and handed out again (best fit, at most twice the request).  One thread per context at a time.
+struct LfpPool {
+    struct Blk { void *p; size_t bytes; bool busy; };
+    std::vector<Blk> blks;
+    void *get(size_t bytes) {
+        if (!bytes) bytes = 8;
+        int best = -1;
+        for (size_t i = 0; i < blks.size(); i++)
+            if (!blks[i].busy && blks[i].bytes >= bytes && blks[i].bytes <= 2 * bytes + (1u << 16) && (best < 0 || blks[i].bytes < blks[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0) { blks[(size_t)best].busy = true; return blks[(size_t)best].p; }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {      // out of memory: drop the idle blocks and retry once
+            for (size_t i = 0; i < blks.size();)
+                if (!blks[i].busy) { (void)hipFree(blks[i].p); blks.erase(blks.begin() + (long)i); } else i++;
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        }
+        blks.push_back({p, bytes, true});
+        return p;
+    }
+    void put(void *p) {
+        for (Blk &b : blks) if (b.p == p) { b.busy = false; return; }
+        if (p) (void)hipFree(p);
+    }
+    void clear() {
+        for (Blk &b : blks) (void)hipFree(b.p);
+        blks.clear();
+    }
+};
+
 struct lfplus_ctx {
     int device = 0;
     hipStream_t st = nullptr;
@@ -43,6 +73,7 @@ struct lfplus_ctx {
     // the folded witness of the last lfplus_cm_prove (cm.rs:164-181): n ring elements
     u64 *g = nullptr;
     u64 g_n = 0;
+    LfpPool pool;
     bool own_A = true;
     std::vector<LfpMatrix> mats;   // lfplus_set_matrices: the constraint-system matrices, uploaded once
     u64 mats_n = 0;

@@ -277,10 +277,25 @@ int lfplus_poseidon_params(uint64_t *ark720, uint64_t *mds576) {
 
 // ---- device side of the set check -----------------------------------------------------------------------------------------------------
 namespace {
+// scratch of one call: taken from the scratch pool of the context the entry point named (PoolScope), returned to it when the call ends
+thread_local lfplus_ctx *t_pool_ctx = nullptr;
+struct PoolScope {
+    lfplus_ctx *prev;
+    explicit PoolScope(lfplus_ctx *c) : prev(t_pool_ctx) { t_pool_ctx = c; }
+    ~PoolScope() { t_pool_ctx = prev; }
+};
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
+    lfplus_ctx *owner = nullptr;
+    ~DevBuf() {
+        if (!p) return;
+        if (owner) owner->pool.put(p); else (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        owner = t_pool_ctx;
+        if (owner) { p = owner->pool.get(bytes); return p ? 0 : -1; }
+        return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1;
+    }
     template <class T> T *as() const { return (T *)p; }
 };
 struct SetRef { const int8_t *dig; u32 ncols; };   // device pointer to the exponent digits [n][ncols]
@@ -464,6 +479,7 @@ extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t n
         if (d != lfp::LFP_ABSENT && (d <= -8 || d >= 8)) return fail(c, LFPLUS_E_EXP_DOMAIN, "lfplus_set_check: digit outside (-8, 8)");
     }
     HIPCHK(c, hipSetDevice(c->device));
+    PoolScope pool_scope(c);
     DevBuf dm, dv;
     if (dm.alloc((size_t)nmat * n * ncols) || dv.alloc((size_t)nvec * n)) return fail(c, LFPLUS_E_HIP, "hipMalloc (sets)");
     HIPCHK(c, hipMemcpyAsync(dm.p, mat_digits, (size_t)nmat * n * ncols, hipMemcpyHostToDevice, c->st));
@@ -542,6 +558,7 @@ extern "C" int lfplus_range_check(lfplus_ctx *const *ctxs, uint32_t L, lfplus_tr
         return fail(c, LFPLUS_E_ARG, "lfplus_range_check: bad arguments");
     if (!c->n || (c->n & (c->n - 1))) return fail(c, LFPLUS_E_ARG, "lfplus_range_check: n must be a power of two");
     HIPCHK(c, hipSetDevice(c->device));
+    PoolScope pool_scope(c);
     MatHold M;
     int rc = M.get(c, c->n, nM, rowptr, col, val);
     if (rc) return rc;
@@ -782,6 +799,7 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     for (u32 l = 0; l < L; l++)
         if (!ctxs[l] || ctxs[l]->kappa != kappa) return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: instances of different shapes");
     HIPCHK(c, hipSetDevice(c->device));
+    PoolScope pool_scope(c);
     MatHold M;
     int rc = M.get(c, n, nM, rowptr, col, val);
     if (rc) return rc;
@@ -1074,6 +1092,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     u32 nvars = 0;
     while (((size_t)1 << nvars) < n) nvars++;
     HIPCHK(c, hipSetDevice(c->device));
+    PoolScope pool_scope(c);
     DevBuf E[2], G[2], part, small;
     const u32 nb0 = lfp::cm_round_blocks(n / 2);
     if (E[0].alloc(n * 8) || E[1].alloc(n / 2 * 8) || G[0].alloc((size_t)3 * n * D * 8) || G[1].alloc((size_t)3 * (n / 2) * D * 8) ||
