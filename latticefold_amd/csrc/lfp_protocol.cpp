@@ -703,7 +703,7 @@ std::vector<u64> tensor(const u64 *c, u32 nv) {
     std::vector<u64> t(1, 1);
     for (u32 j = 0; j < nv; j++) {
         std::vector<u64> nx(t.size() * 2);
-        for (size_t i = 0; i < t.size(); i++) { nx[i] = fmul(t[i], fsub(1, c[j])); nx[t.size() + i] = fmul(t[i], c[j]); }
+        for (size_t i = 0; i < t.size(); i++) { nx[2 * i] = fmul(t[i], fsub(1, c[j])); nx[2 * i + 1] = fmul(t[i], c[j]); }   // tensor_product(result, [1 - c_j, c_j]): the new factor is the fast index (KAT utils.rs:118-131)
         t.swap(nx);
     }
     return t;

@@ -116,7 +116,8 @@ def test_argument_errors(ctx):
         c2.close()
 
 
-@pytest.mark.parametrize("L,nM,kappa,nvars,ring_coeffs", [(1, 0, 1, 14, False), (1, 1, 2, 15, False), (2, 1, 1, 14, False), (2, 2, 2, 15, False), (2, 2, 2, 15, True)])
+@pytest.mark.parametrize("L,nM,kappa,nvars,ring_coeffs", [(1, 0, 1, 14, False), (1, 1, 2, 15, False), (2, 1, 1, 14, False), (2, 2, 2, 15, False), (2, 2, 2, 15, True),
+                                                         (3, 1, 3, 16, False), (2, 0, 4, 16, False)])   # three instances, kappa not a power of two (tensor(c) has 4 entries, comh 3)
 def test_cm_prove_matches_oracle(L, nM, kappa, nvars, ring_coeffs):
     """cm.rs:606-666 (test_com: n = 2^15, kappa 2, k 2, one matrix) and the two-instance shape Mlin::mlin feeds Cm::prove: every proof field, the
     folded instance and the folded witness equal the oracle's; both verifiers accept; the transcripts end in the same state"""

@@ -104,9 +104,10 @@ def test_range_check_verifier_accepts_oracle_proofs_and_rejects_tampering():
         assert lfp.range_check_verify(lfp.Transcript(), nvars, t, k)[0] == -want
 
 
-def test_cm_verifier_accepts_oracle_proofs_and_rejects_tampering():
+@pytest.mark.parametrize("nvars,kappa", [(14, 1), (16, 4)])     # kappa 4: tensor(c) has two variables (their order matters: utils.rs:118-131)
+def test_cm_verifier_accepts_oracle_proofs_and_rejects_tampering(nvars, kappa):
     """CmProof::verify (cm.rs:349-543) of the product (host only) on proofs the oracle's Cm::prove wrote: same verdict, same stage, same folded instance"""
-    nvars, kappa, k, ell, L = 14, 1, 2, 22, 2
+    k, ell, L = 2, 22, 2
     n = 1 << nvars
     A = lfp.splitmix(3, 0, kappa * n * D).reshape(kappa, n, D)
     insts = []
@@ -127,7 +128,7 @@ def test_cm_verifier_accepts_oracle_proofs_and_rejects_tampering():
     to = lfp.Transcript()
     assert lfp.cm_verify(to, pr, fcoms)[0] == 0 and tp.get_challenge() == to.challenge()
     for key, idx in (("comh", (0, 0, 1)), ("pa", (2, 1, 3)), ("pb", (0, 0, 0)), ("ea", (0, 2, 5)), ("eb", (1, 3, 0)), ("a", (0, 0)), ("e", (0, 1, 2, 3)),
-                     ("pa", (13, 2, 15))):
+                     ("pa", (nvars - 1, 2, 15))):
         t = dict(pr)
         t[key] = pr[key].copy()
         t[key][idx] = (int(t[key][idx]) + 1) % P
