@@ -943,6 +943,23 @@ static bool lcccs_point(const lf_params &P, const u64 *lcccs, std::vector<H9> &p
 }
 
 // LFLinearizationProver::prove (nifs/linearization.rs:145-189)
+
+// T[k][c] = sum_i eq[i] digit_k(planes[c][i]) of the K binary digit planes -> out (device, canonical): on the int8 matrix cores (bb_dot_i8.hip) unless
+// LF_COEF_VALU is set or the shape is not handled there
+static int coef_eval_bits_dev(BbCtxImpl *c, const int32_t *planes, size_t n, const fe *eq, size_t ldeq, u32 K, i64 *partial, u64 *out) {
+    if (!c->tn.coef_valu && K <= 16 && n >= 64) {
+        unsigned char *EB;
+        int32_t *part;
+        long long *tot;
+        const u32 nwg = 256;
+        RET(c->tbuf("ce_eb", coef_eval_i8_eb_bytes(n), &EB));
+        RET(c->tbuf("ce_part", coef_eval_i8_part_words(nwg), &part));
+        RET(c->tbuf("ce_tot", coef_eval_i8_tot_words(), &tot));
+        if (launch_coef_eval_i8(planes, n, n, eq, ldeq, K, EB, nwg, part, tot, out, c->stream()) == 0) return LF_OK;
+    }
+    launch_coef_eval(c->dev, planes, n, eq, ldeq, K, 1, partial, out, c->stream());
+    return LF_OK;
+}
 static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witness *wit, u64 *lcccs_out, u64 *proof, fe **eq_r_keep) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n;
@@ -980,7 +997,7 @@ static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witn
         // the K digit-plane evaluations v_s[k] (the decomposition of this instance needs them at the same point anyway): v = sum_k 2^k v_s[k]
         u64 *vs;
         RET(c->tbuf("lin_vs", (size_t)P.K * TAU * RE + 8, &vs));
-        launch_coef_eval(c->dev, wit->planes, c->N, eqr, m, P.K, 1, partial, vs, c->stream());
+        RET(coef_eval_bits_dev(c, wit->planes, c->N, eqr, m, P.K, partial, vs));
         launch_vs_combine(vs, P.K, TAU * RE, od, c->stream());
         if (c->vs_keep) { c->vs_wit = wit; c->vs_eq = eqr; c->vs_dev = vs; }
     } else
@@ -1121,7 +1138,7 @@ static int dec_enqueue_evals(C *c, const u64 *lcccs, const std::vector<H9> &rpt,
         HIPCHK(hipMemcpyAsync(od, c->vs_dev, (size_t)K * TAU * RE * 8, hipMemcpyDeviceToDevice, c->stream()));
         c->vs_wit = nullptr;
     } else
-        launch_coef_eval(c->dev, wit->planes, N, eq_r, m, K, 1, partial, od, c->stream());
+        RET(coef_eval_bits_dev(c, wit->planes, N, eq_r, m, K, partial, od));
     HIPCHK(hipMemcpyAsync(pd.h_v, od, (size_t)K * TAU * RE * 8, hipMemcpyDeviceToHost, c->stream()));
     // z_k = x_s[k] || w_k ; u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     RET(build_z_async(c, wit->planes, K, 1, x_s, z));
@@ -1411,7 +1428,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // stand-alone evaluation.
     if (P.s >= 4 && curF && ldF == 2 && !c->tn.theta_eval) launch_fix_final(c->dev, curF, ldF, K2 * TAU * 8, e9pre_from_h9(pt[P.s - 1], c->ring.T.nu), d_theta, c->stream());
     else
-        for (int sd = 0; sd < 2; sd++) launch_coef_eval(c->dev, S[sd].planes, N, eq0, m, K, 1, red, d_theta + (size_t)sd * K * TAU * RE, c->stream());
+        for (int sd = 0; sd < 2; sd++) RET(coef_eval_bits_dev(c, S[sd].planes, N, eq0, m, K, red, d_theta + (size_t)sd * K * TAU * RE));
     HIPCHK(hipMemcpyAsync(hp, d_theta, nth * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventRecord(c->ev_side[0], c->stream()));
     for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE));

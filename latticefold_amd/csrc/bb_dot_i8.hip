@@ -219,4 +219,126 @@ int launch_dot_batch_i8(const DevBb &t, const fe *X, size_t ldx, u32 na, const f
     hipLaunchKernelGGL(k_bbdot_finish, dim3(na * nb * RE), dim3(64), 0, s, tot, na, nb, (u32)to_canon(t.nu), (u32)(rinv * rinv % BB_P), out);
     return 0;
 }
+
+// ---- T[k][c] = sum_i eq[i] * digit_k(planes[c][i]) (v_s of a decomposition, the linearization's v) on the matrix cores -------------------------------
+// The BabyBear form of lf::k_coef_eval_i8 (binary digit planes only): per coefficient c an exact int8 GEMM with rows = the K <= 16 planes (digits -1, 0, 1 cut
+// from the int32 plane words in registers), inner dimension = columns, matrix columns = the 36 balanced base-256 digits of the nine words of eq (packed once
+// per call).  Was lfbb::k_coef_eval: K * 9 masked 64-bit additions per column and coefficient on the VALU (0.65 ms per call at C3).
+__global__ void __launch_bounds__(256) k_bbce_pack_eq(const fe *eq, size_t ldeq, size_t n, size_t ldb, unsigned char *EB) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;     // four columns per thread
+    const u32 q = blockIdx.y;
+    if (i0 >= ldb) return;
+    u32 d[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) d[t] = i0 + t < n ? bbd_digits(eq[(size_t)q * ldeq + i0 + t]) : 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        *(u32 *)(EB + (size_t)(4 * q + u) * ldb + i0) = ((d[0] >> (8 * u)) & 0xFF) | (((d[1] >> (8 * u)) & 0xFF) << 8) | (((d[2] >> (8 * u)) & 0xFF) << 16) | (((d[3] >> (8 * u)) & 0xFF) << 24);
+}
+struct BbCeArgs {
+    const int32_t *planes;      // [72][ldp]
+    size_t ldp, n;
+    const unsigned char *EB;    // [36][ldb]
+    size_t ldb;
+    u32 rows;                   // K <= 16
+    u32 steps_per_wg;
+    int32_t *part;              // [wg][72][3][64][4]
+};
+__device__ __forceinline__ int bbce_digit(int32_t v, u32 k) {
+    const u32 m = v < 0 ? 0u - (u32)v : (u32)v;
+    const int d = (int)((m >> k) & 1);
+    return v < 0 ? -d : d;
+}
+// grid (workgroups over the columns, 3 groups of 24 coefficients); wave w of a workgroup owns the coefficients 24 y + 6 w .. + 5
+__global__ void __launch_bounds__(256) k_bbce_i8(BbCeArgs a) {
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, g = lane >> 4;
+    const size_t nsteps = (a.n + 63) / 64;
+    const size_t s0 = (size_t)blockIdx.x * a.steps_per_wg, s1 = s0 + a.steps_per_wg < nsteps ? s0 + a.steps_per_wg : nsteps;
+    v4i acc[6][3];
+#pragma unroll
+    for (int mi = 0; mi < 6; mi++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) acc[mi][nt] = v4i{0, 0, 0, 0};
+    const bool full16 = (a.ldp & 3) == 0 && (((size_t)a.planes) & 15) == 0;
+    for (size_t st = s0; st < s1; st++) {
+        const size_t j0 = st * 64 + 16 * g;           // this lane's 16 columns (EB is zero-padded to ldb, a multiple of 64)
+        v4i b[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) {
+            const u32 r = 16 * nt + row;
+            b[nt] = r < 36 ? *(const v4i *)(a.EB + (size_t)r * a.ldb + j0) : v4i{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int mi = 0; mi < 6; mi++) {
+            const u32 c = 24 * blockIdx.y + wave * 6 + mi;
+            const int32_t *pl = a.planes + (size_t)c * a.ldp + j0;
+            int32_t v[16];
+            if (full16 && j0 + 16 <= a.n) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int4 w = *(const int4 *)(pl + 4 * q);
+                    v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = j0 + q < a.n ? pl[q] : 0;
+            }
+            u32 w4[4] = {0, 0, 0, 0};
+            if (row < a.rows) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) w4[q >> 2] |= (u32)(unsigned char)bbce_digit(v[q], row) << (8 * (q & 3));
+            }
+            const v4i av = v4i{(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) acc[mi][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[mi][nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 6; mi++) {
+        const u32 c = 24 * blockIdx.y + wave * 6 + mi;
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) *(v4i *)(a.part + ((((size_t)blockIdx.x * 72 + c) * 3 + nt) * 64 + lane) * 4) = acc[mi][nt];
+    }
+}
+__global__ void __launch_bounds__(256) k_bbce_sum(const int32_t *part, u32 nwg, long long *tot) {
+    const size_t per = (size_t)72 * 3 * 256, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    long long s = 0;
+    for (u32 w = 0; w < nwg; w++) s += part[(size_t)w * per + i];
+    tot[i] = s;
+}
+// out[(k*72 + c)*9 + q] canonical: sum_u 256^u C[k][4q + u] is the Montgomery word of the evaluation (integer scaling keeps the Montgomery form)
+__global__ void __launch_bounds__(256) k_bbce_finish(const long long *tot, u32 K, u32 rinv, u64 *out) {
+    const u32 o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= K * 72 * 9) return;
+    const u32 q = o % 9, c = (o / 9) % 72, k = o / (9 * 72);
+    long long v = 0;
+#pragma unroll
+    for (u32 u = 0; u < 4; u++) {
+        const u32 col = 4 * q + u, nt = col >> 4, cl = col & 15, ln = cl + 16 * (k >> 2), reg = k & 3;
+        v += tot[(((size_t)c * 3 + nt) * 64 + ln) * 4 + reg] << (8 * u);      // |tot| <= n * 128: < 2^57 for n < 2^26
+    }
+    const long long Pm = (long long)BB_P;
+    out[o] = (u64)((v % Pm + Pm) % Pm) * rinv % BB_P;      // Montgomery word -> canonical: times 2^-32
+}
+size_t coef_eval_i8_eb_bytes(size_t n) { return 36 * (bdiv(n, 64) * 64) + 64; }
+size_t coef_eval_i8_part_words(u32 nwg) { return (size_t)nwg * 72 * 3 * 256; }
+size_t coef_eval_i8_tot_words() { return (size_t)72 * 3 * 256; }
+// planes [72][ldp] (n columns), eq [9][ldeq]; K <= 16 binary digit planes.  out[(k*72 + c)*9 + q] canonical (the layout of launch_coef_eval, mode_bits).
+// Returns 0, or -1 if the shape is not handled (the caller keeps lfbb::k_coef_eval).
+int launch_coef_eval_i8(const int32_t *planes, size_t ldp, size_t n, const fe *eq, size_t ldeq, u32 K, unsigned char *EB, u32 nwg, int32_t *part, long long *tot,
+                        u64 *out, hipStream_t s) {
+    if (!n || K < 1 || K > 16 || n >= ((size_t)1 << 26) || (((size_t)EB) & 15)) return -1;
+    const size_t ldb = bdiv(n, 64) * 64, nsteps = ldb / 64;
+    hipLaunchKernelGGL(k_bbce_pack_eq, dim3((unsigned)bdiv(ldb / 4, 256), 9), dim3(256), 0, s, eq, ldeq, n, ldb, EB);
+    if (nwg > nsteps) nwg = (u32)nsteps;
+    BbCeArgs a;
+    a.planes = planes; a.ldp = ldp; a.n = n; a.EB = EB; a.ldb = ldb; a.rows = K; a.part = part;
+    a.steps_per_wg = (u32)bdiv(nsteps, nwg);
+    const u32 grid = (u32)bdiv(nsteps, a.steps_per_wg);
+    hipLaunchKernelGGL(k_bbce_i8, dim3(grid, 3), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_bbce_sum, dim3((unsigned)bdiv((size_t)72 * 3 * 256, 256)), dim3(256), 0, s, part, grid, tot);
+    hipLaunchKernelGGL(k_bbce_finish, dim3((unsigned)bdiv((size_t)K * 72 * 9, 256)), dim3(256), 0, s, tot, K, (u32)bb_powmod(BB_R, BB_P - 2), out);
+    return 0;
+}
 }  // namespace lfbb

@@ -66,6 +66,13 @@ void launch_spmv_t_eq(const DevBb &t, const u32 *colptr, const u32 *rowidx, cons
 size_t red_partial_words(u32 nv);
 // the same on the int8 matrix cores (bb_dot_i8.hip), na <= 16, nb <= 3; scratch: YB bbdot_i8_yb_bytes(n), part bbdot_i8_part_words(n) int32,
 // tot bbdot_i8_tot_words() int64.  Returns 0, or -1 if the shape is not handled.
+// T[k][c] = sum_i eq[i] digit_k(planes[c][i]) of the K <= 16 binary digit planes on the matrix cores (bb_dot_i8.hip); scratch: EB coef_eval_i8_eb_bytes(n) (16-byte
+// aligned), part coef_eval_i8_part_words(nwg) int32, tot coef_eval_i8_tot_words() int64.  out as launch_coef_eval (mode_bits).  0, or -1 if the shape is not handled.
+size_t coef_eval_i8_eb_bytes(size_t n);
+size_t coef_eval_i8_part_words(u32 nwg);
+size_t coef_eval_i8_tot_words();
+int launch_coef_eval_i8(const int32_t *planes, size_t ldp, size_t n, const fe *eq, size_t ldeq, u32 K, unsigned char *EB, u32 nwg, int32_t *part, long long *tot,
+                        u64 *out, hipStream_t s);
 size_t bbdot_i8_yb_bytes(size_t n);
 size_t bbdot_i8_part_words(size_t n);
 size_t bbdot_i8_tot_words();
