@@ -55,6 +55,7 @@ struct BbCtxImpl {
     u64 *arena[2] = {nullptr, nullptr};   // pinned staging for the asynchronous decompositions (bump-allocated per step)
     size_t arena_words = 0, arena_used[2] = {0, 0};
     hipEvent_t ev_side[2] = {nullptr, nullptr};
+    hipEvent_t ev_prep[2] = {nullptr, nullptr};   // fold prepare: fork / join of the right side's chain on the other stream
     hipEvent_t ev_dec[4] = {nullptr, nullptr, nullptr, nullptr};   // decomposition milestones: [2*side + (0 commit, 1 evaluations)]
     int digit_mode = 0;   // balanced-digit rule (lf_set_digit_mode)
     Tunables tn;          // environment switches, re-read at the start of every linearize / fold_step
@@ -230,6 +231,7 @@ void BbCtx::destroy() {
     for (int l = 0; l < 2; l++) {
         if (c->arena[l]) (void)hipHostFree(c->arena[l]);
         if (c->ev_side[l]) (void)hipEventDestroy(c->ev_side[l]);
+        if (c->ev_prep[l]) (void)hipEventDestroy(c->ev_prep[l]);
         (void)hipStreamDestroy(c->st_lane[l]);
     }
     for (int l = 0; l < 4; l++)
@@ -1252,11 +1254,29 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("round_partial", fold_partial_words(m), &partial));
     od = c->round_out();
     if (!od) return LF_ERR_HIP;
-    for (int sd = 0; sd < 2; sd++) {
-        // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}   (folding.rs:208-226, utils.rs:524-546)
-        launch_lincomb_z(c->dev, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zz, c->stream());
-        launch_spmv_sum(c->dev, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zz, (size_t)RE * n, n, G[sd], m, c->stream());
-        launch_add_fhat_comb(c->dev, S[sd].planes, N, K, d_ap + (size_t)sd * K * TAU, G[sd], m, c->stream());
+    {
+        // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}   (folding.rs:208-226, utils.rs:524-546): the two sides are
+        // independent chains -- the right one runs on the other (idle) stream, as in the Goldilocks driver
+        hipStream_t s0 = c->stream(), s1 = (c->lane == 0 && !c->tn.prep_one_stream && c->sh_world == 1) ? c->st_lane[1] : s0;
+        fe *zz1 = zz;
+        if (s1 != s0) {
+            RET(c->tbuf("fold_zz1", (size_t)P.t * RE * n, &zz1));
+            for (int e = 0; e < 2; e++)
+                if (!c->ev_prep[e]) HIPCHK(hipEventCreateWithFlags(&c->ev_prep[e], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(c->ev_prep[0], s0));           // the challenge powers were uploaded on s0
+            HIPCHK(hipStreamWaitEvent(s1, c->ev_prep[0], 0));
+        }
+        for (int sd = 0; sd < 2; sd++) {
+            hipStream_t st = sd ? s1 : s0;
+            fe *zb = sd ? zz1 : zz;
+            launch_lincomb_z(c->dev, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zb, st);
+            launch_spmv_sum(c->dev, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zb, (size_t)RE * n, n, G[sd], m, st);
+            launch_add_fhat_comb(c->dev, S[sd].planes, N, K, d_ap + (size_t)sd * K * TAU, G[sd], m, st);
+        }
+        if (s1 != s0) {
+            HIPCHK(hipEventRecord(c->ev_prep[1], s1));
+            HIPCHK(hipStreamWaitEvent(s0, c->ev_prep[1], 0));
+        }
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     c->ev_end(ph);
