@@ -1589,7 +1589,8 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
     if (gb < 1) gb = 1;
     // enough threads to fill the chip (~128k): split the 2K*9 tables when there are few pairs
     u32 tch = 1;
-    while (tch < 32 && pairs * 8 * tch < (1u << 17)) tch *= 2;
+    static const size_t chunk_threads = [] { const char *e = getenv("LF_FOLD_CHUNK_THREADS"); return e ? (size_t)atoll(e) : ((size_t)1 << 17); }();
+    while (tch < 32 && pairs * 8 * tch < chunk_threads) tch *= 2;
     while (tch > 1 && (size_t)gb * tch > RED_BLOCKS) tch /= 2;
     const bool nu2 = t.nu == BB_TWO;
     if (mode >= 3) tch = 1;   // the planes of one (side, d) serve all K tables: no table split (large rounds only)
