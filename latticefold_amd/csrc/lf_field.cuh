@@ -276,6 +276,30 @@ LF_HD void lh5_mac2(LH5 &acc, Fq3 a, Fq3 b, Fq3 c, Fq3 d) {
         acc.c[i].h += t.h;
     }
 }
+// acc += sum_{i < N} a[i] b[i]: N products per fold of the column sums (N = 2: lh5_mac2; larger N where the operands fit in registers)
+template <int N>
+LF_HD void lh5_macn(LH5 &acc, const Fq3 (&a)[N], const Fq3 (&b)[N]) {
+    AccP s[5];
+    accp_set(s[0], a[0].c[0], b[0].c[0]);
+    accp_set(s[1], a[0].c[0], b[0].c[1]); accp_mad(s[1], a[0].c[1], b[0].c[0]);
+    accp_set(s[2], a[0].c[0], b[0].c[2]); accp_mad(s[2], a[0].c[1], b[0].c[1]); accp_mad(s[2], a[0].c[2], b[0].c[0]);
+    accp_set(s[3], a[0].c[1], b[0].c[2]); accp_mad(s[3], a[0].c[2], b[0].c[1]);
+    accp_set(s[4], a[0].c[2], b[0].c[2]);
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+        accp_mad(s[0], a[i].c[0], b[i].c[0]);
+        accp_mad(s[1], a[i].c[0], b[i].c[1]); accp_mad(s[1], a[i].c[1], b[i].c[0]);
+        accp_mad(s[2], a[i].c[0], b[i].c[2]); accp_mad(s[2], a[i].c[1], b[i].c[1]); accp_mad(s[2], a[i].c[2], b[i].c[0]);
+        accp_mad(s[3], a[i].c[1], b[i].c[2]); accp_mad(s[3], a[i].c[2], b[i].c[1]);
+        accp_mad(s[4], a[i].c[2], b[i].c[2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        LH t = accp_lh(s[i]);
+        acc.c[i].l += t.l;
+        acc.c[i].h += t.h;
+    }
+}
 // signed wide value base + 2^32 h32 + 2^40 h40 with |terms| up to ~2^62: split before shifting
 LF_HD u64 fq_from_lin_wide(int64_t base, int64_t h32, int64_t h40) {
     typedef __int128 i128;

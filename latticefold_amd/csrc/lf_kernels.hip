@@ -1031,12 +1031,24 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_
         return fq3_make(cc.c[0], cc.c[1], cc.c[2]);
     };
     u32 k = 0;
-    if (NU)
-        for (; k + 1 < K; k += 2) {      // two terms per lazy accumulation step: their partial products share the column sums (lh5_mac2)
+    if (NU) {
+        for (; k + 3 < K; k += 4) {      // four terms per fold of the column sums (lh5_macn): the fold is the larger half of a lazy product
+            Fq3 x[4], cv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[q] = ld3(z + (size_t)(k + q) * 24 * ldz, ldz, slot, i);
+#pragma unroll
+            for (int j = 0; j < TT; j++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) cv[q] = cf(k + q, j);
+                lh5_macn<4>(acc[j], x, cv);
+            }
+        }
+        for (; k + 1 < K; k += 2) {
             Fq3 x0 = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i), x1 = ld3(z + (size_t)(k + 1) * 24 * ldz, ldz, slot, i);
 #pragma unroll
             for (int j = 0; j < TT; j++) lh5_mac2(acc[j], x0, cf(k, j), x1, cf(k + 1, j));
         }
+    }
     for (; k < K; k++) {
         Fq3 x = ld3(z + (size_t)k * 24 * ldz, ldz, slot, i);
 #pragma unroll
