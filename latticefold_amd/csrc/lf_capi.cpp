@@ -2377,12 +2377,9 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     LF_TRACE(c, "theta/eta");
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     LF_TRACE(c, "fold_witness");
-    HIPCHK(hipStreamSynchronize(c->stream()));
-    *w_out = new lf_witness{c, npl, N, c->device, N * 24 * 4};
-    TL_MARK(" rho + fold_witness");
-    c->ev_end(ph);
 
-    // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521), host
+    // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
+    {
     HostTimer ht(c);
     u64 *o = lcccs_out;
     for (u32 i = 0; i < P.s; i++, o += 24) HostRing::from_fq3(pt[i], o);
@@ -2421,6 +2418,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         memset(o, 0, 24 * 8);
         for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * 24], part(i) + ((size_t)P.s + 3 + P.kappa + P.t + q2) * 24, tmp); HostRing::add(o, tmp, o); }
     }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    *w_out = new lf_witness{c, npl, N, c->device, N * 24 * 4};
+    TL_MARK(" rho + fold_witness");
+    c->ev_end(ph);
     return LF_OK;
 }
 
