@@ -191,6 +191,10 @@ struct lf_ctx {
     u32 *bits_ptr[2] = {nullptr, nullptr};
     hipEvent_t bits_ev[2] = {nullptr, nullptr};
     hipEvent_t ev_prep[2] = {nullptr, nullptr};   // fold prepare: fork / join of the right side's chain on the helper lane's stream
+    // linearization: the pass of the v_s evaluations over the witness starts on this stream while the last sumcheck rounds are still running (VsSplit)
+    hipStream_t st_aux = nullptr;
+    hipEvent_t ev_aux = nullptr;
+    u64 *h_aux = nullptr;   // pinned, 1 KB: the known part of the point
     unsigned sv_round_mask = 0;      // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
 
     int buf(const std::string &name, size_t bytes, void **out) {
@@ -434,6 +438,9 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->tail_counters) (void)hipFree(c->tail_counters);
     if (c->d_poseidon) (void)hipFree(c->d_poseidon);
     if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
+    if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
+    if (c->st_aux) (void)hipStreamDestroy(c->st_aux);
+    if (c->h_aux) (void)hipHostFree(c->h_aux);
     for (int i = 0; i < 2; i++) {
         if (c->ev_prep[i]) (void)hipEventDestroy(c->ev_prep[i]);
         if (c->bits_ev[i]) (void)hipEventDestroy(c->bits_ev[i]);
@@ -1359,11 +1366,13 @@ static Fq3 sc_round_transcript(Transcript &tr, const u64 *evals, u32 npts) {
 }
 
 static int lin_tail_rounds(lf_ctx *c, Transcript &tr, const u64 *cur, const u64 *cure, size_t n, u64 *tout, u64 *partial, u32 round, Fq3 *point,
-                           u64 *msgs, u32 deg);
+                           u64 *msgs, u32 deg, const std::function<void(u32)> *after_round);
 // linearization sumcheck on device tables mz [t][24][m] (left intact) and eq_beta [3][m]
 // `u_dev` (optional): the Mz tables fixed at the whole point, i.e. u_j = Mz_j(r) (t ring elements, canonical) -- the last fix of the
 // tables the rounds work on, so linearization.rs:136's evaluate_mles pass over the full tables is not needed.
-static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 *eqb, u64 *msgs /* s*(d+2) ring */, Fq3 *point, u64 *u_dev = nullptr) {
+// after_round (optional): called with the round number as soon as that round's challenge is known
+static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 *eqb, u64 *msgs /* s*(d+2) ring */, Fq3 *point, u64 *u_dev = nullptr,
+                            const std::function<void(u32)> *after_round = nullptr) {
     const lf_params &P = c->P;
     u32 deg = P.d + 1;
     size_t m = c->m;
@@ -1389,7 +1398,7 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     for (u32 round = 1; round <= P.s; round++) {
         // persistent tail (k_lin_tail): all remaining rounds in one launch once the tables are small, as in the folding sumcheck
         if (!sharded && !c->tn.no_tail && round >= 2 && n <= c->tn.tail_n && n >= 4 && P.s - round + 1 <= TAIL_MAX_ROUNDS) {
-            int trc = lin_tail_rounds(c, tr, cur, cure, n, fx[flip], partial, round, point, msgs, deg);
+            int trc = lin_tail_rounds(c, tr, cur, cure, n, fx[flip], partial, round, point, msgs, deg, after_round);
             if (trc == LF_OK) { cur = fx[flip]; n = 2; break; }
             if (trc != LF_ERR_UNSUPPORTED) return trc;
         }
@@ -1430,6 +1439,7 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
         memcpy(ev, od, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
+        if (after_round) (*after_round)(round);
         if (round == 1) TL_MARK("  lin round 1");
         if (round == 2) TL_MARK("  lin round 2");
         if (round == 4) TL_MARK("  lin round 4");
@@ -1501,8 +1511,54 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
     // products with eq(r) over the full tables), v from the witness planes
     const bool u_eval = c->tn.lin_u_eval;
     TL_MARK("  lin Mz enqueued");
-    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72));
-    RET(build_eq_dev(c, pt.data(), P.s, eqr));
+    // The K digit-plane evaluations v_s at the sumcheck point r are the longest piece between the last round and the absorb of v (0.5 of 0.7-1.0 ms at
+    // 2^20 rows, on the critical path of both lanes).  eq(r, i) = eq((r_1..r_J), i mod 2^J) * eq((r_J+1..r_s), i >> J): the pass over the witness only needs
+    // the first J coordinates, so it starts on a side stream as soon as round J's challenge is there (launch_sv_vs_blocks: one partial sum per block of 2^J
+    // positions) and runs under the last s - J rounds; afterwards 2^(s-J) weighted partial sums remain (launch_sv_vs_combine).
+    struct VsSplit {
+        bool armed = false, launched = false, failed = false;
+        u32 J = 0, nblocks = 0;
+        int sd = 0;
+        unsigned char *EB = nullptr;
+        int32_t *part = nullptr;
+        u64 *eqlo = nullptr, *scr = nullptr, *wts = nullptr;
+        Fq3Const *rd = nullptr;
+    } vsp;
+    if (P.b == 2 && c->sh_world == 1 && !c->tn.force_exchange && !c->tn.lin_v_direct && !c->tn.coef_valu && !c->tn.coef_planes && !c->tn.lin_vs_whole && P.s >= 12 &&
+        P.K <= 16) {
+        const u32 back = c->tn.lin_vs_back;                  // rounds before the last one after which the pass starts
+        const u32 J = P.s < back + 10 ? 10 : P.s - back;
+        const size_t bs = (size_t)1 << J;
+        for (int sd = 0; sd < 2; sd++)
+            if (c->bits_wit[sd] == wit && c->bits_ptr[sd] && J < P.s && c->N % bs == 0 && c->N / bs <= sv_vs_max_blocks(P.K) && c->N / bs >= 1) {
+                vsp.J = J; vsp.nblocks = (u32)(c->N / bs); vsp.sd = sd;
+                bool ok = c->tbuf("vs_eb", sv_eb_bytes(c->N / 2), &vsp.EB) == LF_OK && c->tbuf("vs_part_blocks", sv_vs_blocks_part_words(vsp.nblocks, P.K), &vsp.part) == LF_OK &&
+                          c->tbuf("vs_eqlo", 3 * bs, &vsp.eqlo) == LF_OK && c->tbuf("vs_eq_scratch", build_eq_scratch_words(J), &vsp.scr) == LF_OK &&
+                          c->tbuf("vs_wts", (size_t)3 * vsp.nblocks + 8, &vsp.wts) == LF_OK && c->tbuf("vs_eq_point", 64, &vsp.rd) == LF_OK;
+                if (ok && !c->st_aux) ok = hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking) == hipSuccess;
+                if (ok && !c->ev_aux) ok = hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) == hipSuccess;
+                if (ok && !c->h_aux) ok = hipHostMalloc((void **)&c->h_aux, 1024, hipHostMallocDefault) == hipSuccess;
+                vsp.armed = ok;
+                break;
+            }
+    }
+    const std::function<void(u32)> vs_hook = [&](u32 round) {
+        if (!vsp.armed || round != vsp.J) return;
+        Fq3Const *h = (Fq3Const *)c->h_aux;
+        for (u32 i = 0; i < vsp.J; i++) h[i] = f3c(pt[i]);
+        bool ok = hipMemcpyAsync(vsp.rd, h, vsp.J * sizeof(Fq3Const), hipMemcpyHostToDevice, c->st_aux) == hipSuccess;
+        if (ok) {
+            launch_build_eq2(c->dcrt, vsp.rd, vsp.J, vsp.scr, vsp.eqlo, c->st_aux);
+            ok = hipStreamWaitEvent(c->st_aux, c->bits_ev[vsp.sd], 0) == hipSuccess &&
+                 launch_sv_vs_blocks(c->bits_ptr[vsp.sd], c->N, vsp.eqlo, (size_t)1 << vsp.J, vsp.J, P.K, vsp.EB, vsp.part, c->st_aux) == 0 &&
+                 hipEventRecord(c->ev_aux, c->st_aux) == hipSuccess;
+        }
+        vsp.launched = ok;
+        vsp.failed = !ok;
+    };
+    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72, vsp.armed ? &vs_hook : nullptr));
+    if (vsp.failed) { (void)hipStreamSynchronize(c->st_aux); return LF_ERR_HIP; }
+    if (!vsp.launched) RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;   // contiguous: v[3 ring] u[t ring]
     {   // T[24][3] flat == v[3][8 slots][3]; sharded: each rank sums its index slice, partial sums exchanged on the device
         size_t i0, cnt;
@@ -1513,7 +1569,19 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
             // evaluation of the full coefficients: v = sum_k 2^k v_s[k]
             u64 *vs;
             RET(c->tbuf("lin_vs", (size_t)P.K * 72 + 8, &vs));
-            RET(coef_eval_dev(c, wit->planes, c->N, eqr, m, P.K, 1, partial, vs, c->N, wit));
+            if (vsp.launched) {
+                // w_b = eq((r_J+1..r_s), b): index bit j of the block number belongs to coordinate J + 1 + j
+                std::vector<u64> w((size_t)3 * vsp.nblocks);
+                for (u32 b = 0; b < vsp.nblocks; b++) {
+                    Fq3 acc = fq3_one();
+                    for (u32 j = 0; vsp.J + j < P.s; j++) acc = c->ring.mul3(acc, ((b >> j) & 1) ? pt[vsp.J + j] : fq3_sub(fq3_one(), pt[vsp.J + j]));
+                    w[3 * b] = acc.c[0]; w[3 * b + 1] = acc.c[1]; w[3 * b + 2] = acc.c[2];
+                }
+                RET(c->h2d_small(vsp.wts, w.data(), w.size() * 8));
+                HIPCHK(hipStreamWaitEvent(c->stream(), c->ev_aux, 0));
+                launch_sv_vs_combine(c->dcrt, vsp.part, vsp.nblocks, vsp.wts, P.K, vs, c->stream());
+            } else
+                RET(coef_eval_dev(c, wit->planes, c->N, eqr, m, P.K, 1, partial, vs, c->N, wit));
             launch_vs_combine(vs, P.K, od, c->stream());
             if (c->vs_keep) { c->vs_wit = wit; c->vs_eq = eqr; c->vs_dev = vs; }
         } else {
@@ -1526,6 +1594,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
         launch_dot_eq(c->dcrt, mz, m, P.t, eqr, m, m, partial, od, c->stream());
         RET(down_small(c, od, (size_t)P.t * 24, u));
     } else RET(down_small(c, od, 72 + (size_t)P.t * 24, v));
+    if (vsp.launched) RET(build_eq_dev(c, pt.data(), P.s, eqr));   // (the evaluations at r that follow need it; v did not)
     {
         HostTimer ht(c);
         tr.absorb_ring(v, 3);
@@ -1804,7 +1873,9 @@ static int upload_consts(lf_ctx *c, const std::string &name, const std::vector<F
 
 // Host side of the mailbox protocol of a persistent tail kernel (k_fold_tail / k_lin_tail): per round poll the message, run the transcript
 // (unless the device sponge does), write the challenge back.  msgs = slot of the first tail round's message, pt = its challenge.
-static int tail_host_rounds(lf_ctx *c, Transcript &tr, u32 epoch, u32 nr, u32 npts, bool dev_transcript, u64 *msgs, Fq3 *pt) {
+// after_round (optional): called with the 1-based round number once that round's challenge is known (round0 = number of the first tail round)
+static int tail_host_rounds(lf_ctx *c, Transcript &tr, u32 epoch, u32 nr, u32 npts, bool dev_transcript, u64 *msgs, Fq3 *pt,
+                            const std::function<void(u32)> *after_round = nullptr, u32 round0 = 0) {
     TailMail *mail = c->tail_mail;
     const auto t_start = std::chrono::steady_clock::now();
     double host_us = 0, wait_us = 0;
@@ -1835,6 +1906,7 @@ static int tail_host_rounds(lf_ctx *c, Transcript &tr, u32 epoch, u32 nr, u32 np
             mail->chal[i][0] = r.c[0]; mail->chal[i][1] = r.c[1]; mail->chal[i][2] = r.c[2];
             __atomic_store_n(&mail->chal_seq[i], epoch, __ATOMIC_RELEASE);
         }
+        if (after_round) (*after_round)(round0 + i);      // (behind the hand-over of the challenge: the device is not kept waiting)
         if (tl_on) { auto nw = std::chrono::steady_clock::now(); host_us += std::chrono::duration<double, std::micro>(nw - t_mark).count(); t_mark = nw; }
     }
     if (dev_transcript) tr.set_state((const u64 *)mail->sponge);   // the host transcript continues where the device sponge stopped
@@ -1853,7 +1925,7 @@ static int tail_sponge_to_device(lf_ctx *c, Transcript &tr, u64 **state_out) {
 }
 // Tail rounds `round`..s of the linearization sumcheck (k_lin_tail).  cur / cure = the Mz and eq tables of round-1 (n entries, ld n).
 static int lin_tail_rounds(lf_ctx *c, Transcript &tr, const u64 *cur, const u64 *cure, size_t n, u64 *tout, u64 *partial, u32 round, Fq3 *point,
-                           u64 *msgs, u32 deg) {
+                           u64 *msgs, u32 deg, const std::function<void(u32)> *after_round) {
     const lf_params &P = c->P;
     RET(c->tail_setup());
     LinTailArgs A;
@@ -1872,7 +1944,7 @@ static int lin_tail_rounds(lf_ctx *c, Transcript &tr, const u64 *cur, const u64 
     }
     if (launch_lin_tail(c->dcrt, c->desc, A, c->stream()) == 0) return LF_ERR_UNSUPPORTED;
     if (hipGetLastError() != hipSuccess) return LF_ERR_HIP;
-    return tail_host_rounds(c, tr, A.epoch, A.rounds, deg + 1, A.dev_transcript != 0, msgs + (size_t)(round - 1) * (deg + 1) * 24, &point[round - 1]);
+    return tail_host_rounds(c, tr, A.epoch, A.rounds, deg + 1, A.dev_transcript != 0, msgs + (size_t)(round - 1) * (deg + 1) * 24, &point[round - 1], after_round, round);
 }
 // Tail rounds `round`..s of the folding sumcheck in one persistent kernel (lf_kernels.hip: k_fold_tail).  On entry `a` / `curF`
 // describe the tables of round-1 (a.n entries each, leading dimension a.n) and pt[round-2] is the challenge that fixes them.

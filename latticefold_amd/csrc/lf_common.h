@@ -74,6 +74,8 @@ struct Tunables {
     size_t dot_min = 4096;           // LF_DOT_MIN: columns from which the int8 form of the inner products is used
     bool coef_planes = false;        // LF_COEF_PLANES: v_s of a fold step from the int32 planes (k_coef_eval_i8) instead of the bit planes (launch_sv_vs)
     bool dot_valu = false;           // LF_DOT_VALU: u_s / eta inner products on the 64-bit VALU kernel (k_dot_batch) instead of the int8 matrix cores
+    unsigned lin_vs_back = 6;        // LF_LIN_VS_BACK: the early v_s pass of the linearization starts after round s - this (2^this blocks of partial sums)
+    bool lin_vs_whole = false;       // LF_LIN_VS_WHOLE: the linearization's v_s evaluations in one piece after the last round (no early pass over the witness)
     bool lin_v_direct = false;       // LF_LIN_V_DIRECT: v of the linearization from the full coefficients instead of sum_k 2^k v_s[k]
     bool fold_no_sv = false;         // LF_FOLD_NO_SV: rounds 1-3 of the folding sumcheck on the VALU kernels instead of the int8 matrix-core GEMMs (lf_sv_rounds.hip)
     size_t sv_min = 65536;           // LF_FOLD_SV_MIN: pairs of a round from which the GEMM form is used
@@ -99,6 +101,8 @@ struct Tunables {
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;
         t.fold_no_sv = getenv("LF_FOLD_NO_SV") != nullptr;
         t.lin_v_direct = getenv("LF_LIN_V_DIRECT") != nullptr;
+        t.lin_vs_whole = getenv("LF_LIN_VS_WHOLE") != nullptr;
+        if ((e = getenv("LF_LIN_VS_BACK"))) t.lin_vs_back = (unsigned)atoi(e);
         t.dot_valu = getenv("LF_DOT_VALU") != nullptr;
         t.coef_planes = getenv("LF_COEF_PLANES") != nullptr;
         if ((e = getenv("LF_DOT_MIN"))) t.dot_min = (size_t)atoll(e);

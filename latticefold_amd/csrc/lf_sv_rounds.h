@@ -67,4 +67,9 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
 size_t sv_vs_part_words(size_t n, uint32_t K);
 size_t sv_vs_tot_words(uint32_t K);
 int launch_sv_vs(const uint32_t *bits, size_t n, const uint64_t *eq, size_t ldeq, uint32_t K, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *out, hipStream_t s);
+// the same in two steps (the pass over the witness starts before the point is complete): see lf_sv_rounds.hip
+size_t sv_vs_max_blocks(uint32_t K);
+size_t sv_vs_blocks_part_words(uint32_t nblocks, uint32_t K);
+int launch_sv_vs_blocks(const uint32_t *bits, size_t n, const uint64_t *eq_lo, size_t ldeq, uint32_t J, uint32_t K, unsigned char *EB, int32_t *part, hipStream_t s);
+void launch_sv_vs_combine(const DevCrt &t, const int32_t *part, uint32_t nblocks, const uint64_t *wts, uint32_t K, uint64_t *out, hipStream_t s);
 }  // namespace lf

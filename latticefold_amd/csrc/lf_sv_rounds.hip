@@ -114,6 +114,7 @@ struct SvGemmArgs {
     u32 ktiles;                 // tiles of 16 digit planes
     u32 nsides;                 // 2 witnesses (round GEMMs) or 1 (launch_sv_vs)
     u32 nsuper, super_per_chunk;   // super-steps of 512 positions (256 / V pairs)
+    u32 eb_mod;                 // 0, or: the eqB bytes repeat every eb_mod super-steps (launch_sv_vs_blocks: the weights of the low index bits only)
     u32 super0;                 // first super-step of the bit planes (a rank's pair slice of a sharded step; the eqB bytes start at its first pair)
     int32_t *part;              // [chunk][group][pair][3][64][4]
 };
@@ -174,10 +175,11 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
     // staging of the eqB bytes: piece t = 16 bytes of row t / (SPAIRS/16)
     v4i st[PPT];
     auto stage_load = [&](u32 u) {
+        const u32 ue = a.eb_mod ? u % a.eb_mod : u;
 #pragma unroll
         for (int i = 0; i < PPT; i++) {
             const u32 t = tid + i * NTH;
-            if (PIECES % NTH == 0 || t < PIECES) st[i] = *(const v4i *)(a.EB + (size_t)(t / (SPAIRS / 16)) * a.ldeb + (size_t)u * SPAIRS + 16 * (t % (SPAIRS / 16)));
+            if (PIECES % NTH == 0 || t < PIECES) st[i] = *(const v4i *)(a.EB + (size_t)(t / (SPAIRS / 16)) * a.ldeb + (size_t)ue * SPAIRS + 16 * (t % (SPAIRS / 16)));
         }
     };
     auto stage_store = [&](u32 buf) {
@@ -373,6 +375,7 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     a.EB = EB; a.ldeb = ldeb;
     a.nsuper = (u32)cdiv(wpairs * V, 256);
     a.super0 = (u32)(pair0 * V / 256);
+    a.eb_mod = 0;
     const u32 chunks = sv_chunks(V, a.nsuper, K);
     a.super_per_chunk = (u32)cdiv(a.nsuper, chunks);
     a.part = part;
@@ -428,6 +431,7 @@ int launch_sv_vs(const uint32_t *bits, size_t n, const uint64_t *eq, size_t ldeq
     a.EB = EB; a.ldeb = ldeb;
     a.nsuper = (u32)cdiv(npairs, 256);
     a.super0 = 0;
+    a.eb_mod = 0;
     const u32 chunks = sv_chunks_n(1, a.nsuper, K, 1);
     a.super_per_chunk = (u32)cdiv(a.nsuper, chunks);
     a.part = part;
@@ -436,5 +440,71 @@ int launch_sv_vs(const uint32_t *bits, size_t n, const uint64_t *eq, size_t ldeq
     hipLaunchKernelGGL(k_sv_sum, dim3((unsigned)cdiv(words / 4, 256)), dim3(256), 0, s, part, words, chunks, tot);
     hipLaunchKernelGGL(k_sv_vs_finish, dim3((unsigned)cdiv((size_t)K * 72, 256)), dim3(256), 0, s, tot, K, a.ktiles, out);
     return 0;
+}
+// The same evaluation in two steps, so that its pass over the witness can start BEFORE the evaluation point is complete: with the first J coordinates
+// r_1..r_J (low index bits) known, launch_sv_vs_blocks leaves per block b of 2^J positions the partial tiles of  T_b = sum_{i_lo} eq_lo[i_lo] digit_k(f[b 2^J + i_lo])
+// (eq_lo = eq((r_1..r_J), .), [3][ldeq], 2^J entries; one chunk of the GEMM per block, the eqB bytes repeat from block to block); once the other
+// coordinates are known, launch_sv_vs_combine adds  v_s[k][c] = sum_b w_b T_b  with w_b = eq((r_{J+1}..), b) (F_{p^3} weights, [nblocks][3] device words).
+// part: sv_vs_blocks_part_words(nblocks, K) int32 words, nblocks <= sv_vs_max_blocks(K); EB: sv_eb_bytes(2^(J-1)).  Returns 0, or -1 if the shape is not handled.
+size_t sv_vs_max_blocks(uint32_t) { return 256; }
+size_t sv_vs_blocks_part_words(uint32_t nblocks, uint32_t K) { return sv_vs_tot_words(K) * nblocks; }
+int launch_sv_vs_blocks(const uint32_t *bits, size_t n, const uint64_t *eq_lo, size_t ldeq, uint32_t J, uint32_t K, unsigned char *EB, int32_t *part, hipStream_t s) {
+    if (J < 10 || J > 24 || (n & (((size_t)1 << J) - 1)) || n == 0) return -1;
+    const size_t bs = (size_t)1 << J, nblocks = n / bs, lo_pairs = bs / 2;
+    if (nblocks > sv_vs_max_blocks(K) || !sv_shape_ok(1, n / 2, K)) return -1;
+    const size_t ldeb = sv_ldeb(lo_pairs);
+    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eq_lo, ldeq, lo_pairs, ldeb, 1, EB);
+    SvGemmArgs a;
+    a.bits[0] = bits; a.bits[1] = bits;
+    a.ktiles = (K + 15) / 16;
+    a.nsides = 1;
+    a.rows = 16 * a.ktiles + 1;
+    a.nw = sv_npad(n) / 32;
+    a.EB = EB; a.ldeb = ldeb;
+    a.nsuper = (u32)(n / 512);
+    a.super0 = 0;
+    a.eb_mod = (u32)(bs / 512);
+    a.super_per_chunk = a.eb_mod;
+    a.part = part;
+    hipLaunchKernelGGL((k_sv_gemm<1, 0>), dim3(24 * a.ktiles / (u32)sv_waves(1) * (u32)nblocks), dim3(64 * sv_waves(1)), 0, s, a);
+    return 0;
+}
+// one wave per output (k, c), lane = block b (the blocks are independent until the weighted sum): out[(k*24 + c)*3 + q]
+template <bool NU>
+__global__ void __launch_bounds__(64) k_sv_vs_combine(DevCrt t, const int32_t *part, u32 nblocks, size_t words, const u64 *wts, u32 K, u32 ktiles, u64 *out) {
+    const u32 o = blockIdx.x, lane = threadIdx.x;
+    const u32 c = o % 24, k = o / 24;
+    const u32 grp = c * ktiles + k / 16, krow = k & 15;
+    Fq3 acc = fq3_zero();
+    for (u32 b = lane; b < nblocks; b += 64) {
+        const int32_t *tot = part + (size_t)b * words;
+        u64 tq[3];
+#pragma unroll
+        for (u32 q = 0; q < 3; q++) {
+            __int128 v = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int32_t *base = tot + ((size_t)grp * 4 + (h ? 2 : 0)) * 768;
+#pragma unroll
+                for (u32 u = 0; u < 8; u++) {
+                    const u32 bp = 24 * h + 8 * q + u;
+                    v += (__int128)base[(bp >> 4) * 256 + ((bp & 15) + 16 * (krow >> 2)) * 4 + (krow & 3)] << (8 * u);
+                }
+            }
+            tq[q] = fq_from_s128((u64)v, (int64_t)(v >> 64));
+        }
+        acc = fq3_add(acc, fq3_mul<NU>(fq3_make(tq[0], tq[1], tq[2]), fq3_make(wts[3 * b], wts[3 * b + 1], wts[3 * b + 2]), t.nu));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < 3; q++) acc.c[q] = fq_add(acc.c[q], __shfl_down(acc.c[q], off, 64));
+    if (lane == 0) { out[(size_t)o * 3] = acc.c[0]; out[(size_t)o * 3 + 1] = acc.c[1]; out[(size_t)o * 3 + 2] = acc.c[2]; }
+}
+void launch_sv_vs_combine(const DevCrt &t, const int32_t *part, uint32_t nblocks, const uint64_t *wts, uint32_t K, uint64_t *out, hipStream_t s) {
+    const u32 ktiles = (K + 15) / 16;
+    const size_t words = sv_vs_tot_words(K);
+    if (t.nu2p40) hipLaunchKernelGGL((k_sv_vs_combine<true>), dim3(K * 24), dim3(64), 0, s, t, part, nblocks, words, wts, K, ktiles, out);
+    else hipLaunchKernelGGL((k_sv_vs_combine<false>), dim3(K * 24), dim3(64), 0, s, t, part, nblocks, words, wts, K, ktiles, out);
 }
 }  // namespace lf
