@@ -1484,31 +1484,35 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     int32_t *npl;
     RET(lf_planes_alloc(c->owner, N * RE * 4, &npl));
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
-    HIPCHK(hipStreamSynchronize(c->stream()));
-    *w_out = new lf_witness{c->owner, npl, N, lf_ctx_device(c->owner), N * RE * 4};
-    c->ev_end(ph);
 
-    // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521), host
+    // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
+    {
     HostTimer ht(c);
     u64 *o = lcccs_out;
     for (u32 i = 0; i < P.s; i++, o += RE) BbHostRing::from_h9(pt[i], o);
     {   // v_0 = rot_lin_combination(rho_coeff, theta) (cyclotomic-rings/src/rotation.rs:85-104)
+        // the rotations of a short challenge stay small signed integers (X^72 = X^36 - 1 adds at most one more term per step) and theta words are < 2^31:
+        // plain 64-bit integer multiply-accumulates, one reduction per output word (32 * 72 terms of < 2^31 * 2^12 fit easily)
+        std::vector<int64_t> acc((size_t)RE * TAU, 0);
         std::vector<u64> res((size_t)RE * TAU, 0);   // res[j] in F_{p^9}
         for (u32 i = 0; i < K2; i++) {
-            u64 rot[RE];
-            memcpy(rot, &rho_c[(size_t)i * RE], sizeof(rot));
+            int64_t rot[RE];
+            for (int j = 0; j < RE; j++) { const u64 rc = rho_c[(size_t)i * RE + j] % BB_P; rot[j] = rc > BB_P / 2 ? (int64_t)rc - (int64_t)BB_P : (int64_t)rc; }
             const u64 *th = theta + (size_t)i * TAU * RE;
             for (int bi = 0; bi < RE; bi++) {
                 const u64 *b = th + (size_t)TAU * bi;
-                for (int j = 0; j < RE; j++)
-                    if (rot[j])
-                        for (int q2 = 0; q2 < TAU; q2++) res[(size_t)j * TAU + q2] = hadd(res[(size_t)j * TAU + q2], hmul(b[q2], rot[j]));
-                u64 top = rot[RE - 1];   // multiply by X modulo X^72 - X^36 + 1
+                for (int j = 0; j < RE; j++) {
+                    const int64_t rj = rot[j];
+                    if (rj)
+                        for (int q2 = 0; q2 < TAU; q2++) acc[(size_t)j * TAU + q2] += (int64_t)b[q2] * rj;
+                }
+                const int64_t top = rot[RE - 1];   // multiply by X modulo X^72 - X^36 + 1
                 for (int j = RE - 1; j > 0; j--) rot[j] = rot[j - 1];
-                rot[0] = top ? BB_P - top : 0;
-                rot[RE / 2] = hadd(rot[RE / 2], top);
+                rot[0] = -top;
+                rot[RE / 2] += top;
             }
         }
+        for (size_t x = 0; x < res.size(); x++) { const int64_t r = acc[x] % (int64_t)BB_P; res[x] = (u64)(r < 0 ? r + (int64_t)BB_P : r); }
         memcpy(o, res.data(), res.size() * 8);
         o += (size_t)TAU * RE;
     }
@@ -1526,6 +1530,10 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         memset(o, 0, RE * 8);
         for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * RE], part(i) + ((size_t)P.s + TAU + P.kappa + P.t + q2) * RE, tmp); BbHostRing::add(o, tmp, o); }
     }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    *w_out = new lf_witness{c->owner, npl, N, lf_ctx_device(c->owner), N * RE * 4};
+    c->ev_end(ph);
     return LF_OK;
 }
 
