@@ -309,7 +309,9 @@ def main():
             # RCCL communicators owned by the library (device-buffer all-gathers + modular-sum kernel); LF_DIST_BACKEND=gloo: host transport
             transport = lfd.init_sharding(ctx, rank, world, "auto")
         ctx.load_ccs(wl)
-        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())  # generated on the device
+        # generated on the device.  A folding prover commits digit planes only: the Goldilocks context keeps A as byte planes alone (lfhip.h
+        # lf_ajtai_set_digits_only; the one general commitment of the set-up, cm_i of the witness, rebuilds the NTT form for that call)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed(), digits_only=(wl.ring == "goldilocks"))
         wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
         cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
         tr0 = api.PoseidonTranscript(ring=wl.ring)
@@ -384,6 +386,8 @@ def main():
             ex = {"transport": transport, "exchanges_per_step": n_ex / args.steps, "mean_us": us_tot / max(n_ex, 1), "max_us": us_max,
                   "note": "host-side latency of one exchange (enqueue of ncclAllGather + modular-sum kernel when the transport is rccl; the whole blocking "
                           "round trip for the host transport)"}
+        free_b, total_b = ctx.device_memory()
+        mem_info["hbm_in_use_gib"] = (total_b - free_b) / 2.0 ** 30   # whole device, this process being its only user: context, witnesses, torch's own few MB
         for st in extra:
             st[0].close()
         wit.free()
@@ -391,6 +395,7 @@ def main():
         return wl, elapsed, phases_acc, kstats, ex, timelines
 
     mode = args.parallelism
+    mem_info = {}
     shard = world > 1 and mode in ("auto", "shard")
     wl, elapsed, phases_acc, kstats, exch, timelines = measure(shard)
     replicas_extra = None
@@ -497,7 +502,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: {'GoldilocksRingNTT' if wl.ring == 'goldilocks' else 'BabyBearRingNTT'} R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
                                    f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world}: one fold stream, witness columns / table rows sharded by the high index bits (Ajtai commits, linearization and folding sumcheck rounds, v/u/eta evaluations), RCCL all-gather + modular sum per exchange" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
-                       "alg_bytes_per_step": alg, "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
+                       "alg_bytes_per_step": alg, "hbm_in_use_gib": round(mem_info.get("hbm_in_use_gib", 0.0), 2), "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
             "roofline": roof,
             "phases_ms_per_step": {k: v / args.steps for k, v in phases_acc.items()},
         }

@@ -118,6 +118,13 @@ int lf_linf_check(lf_ctx *, const uint64_t *f_ntt, size_t count, uint64_t bound,
  * the decomposition step (decomposition.rs:178-201): coefficient form, cut into bytes, in int8-MFMA operand order (lf_ajtai_i8.hip) --
  * 8*24*kappa*n bytes more for Goldilocks (4*72*kappa*n for BabyBear), built once here, never per step.  LF_AJTAI_VALU=1 in the
  * environment skips it and keeps those commitments on the integer-multiplier kernel. */
+/* Digits-only mode (set BEFORE load / generate; Goldilocks contexts, ignored under LF_AJTAI_VALU=1): a prover that only folds commits
+ * nothing but digit planes, so the context keeps the byte planes alone -- rows pass through one u64 row buffer on their way in
+ * (8*24*kappa*n bytes less: 4.9 GiB at C4).  A general commitment (lf_ajtai_commit, lf_witness_commit) still works: the NTT form is
+ * rebuilt from the bytes for that call and given back afterwards.  Switching it on for a loaded matrix drops the NTT copy at once. */
+int lf_ajtai_set_digits_only(lf_ctx *, int on);
+/* free / total bytes of the context's device as the HIP runtime reports them (hipMemGetInfo): what a caller sizes batches against */
+int lf_device_memory(lf_ctx *, size_t *free_bytes, size_t *total_bytes);
 int lf_ajtai_load(lf_ctx *, const uint64_t *A /* kappa*n ring elements, row-major, NTT form */, size_t kappa, size_t n);
 /* synthetic i.i.d. matrix generated on the device (bench; same stream as workload.Workload.ajtai_matrix) */
 int lf_ajtai_generate(lf_ctx *, uint64_t seed, size_t kappa, size_t n);

@@ -93,6 +93,8 @@ def _lib():
         L.lf_linf_check.argtypes = [vp, u64p, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_int), u64p]
         L.lf_ajtai_load.argtypes = [vp, u64p, C.c_size_t, C.c_size_t]
         L.lf_ajtai_generate.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t]
+        L.lf_ajtai_set_digits_only.argtypes = [vp, C.c_int]
+        L.lf_device_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.lf_ajtai_commit.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p]
         L.lf_modsum.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
         L.lf_modsum_ring.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p, C.c_int]
@@ -377,6 +379,12 @@ class Context:
             raise LfError(n, "lf_last_timeline")
         return [(names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode(), float(ms[i])) for i in range(n)]
 
+    def device_memory(self):
+        """(free, total) bytes of the device (lf_device_memory)"""
+        f, t = C.c_size_t(), C.c_size_t()
+        _chk(_lib().lf_device_memory(self.h, C.byref(f), C.byref(t)), "lf_device_memory")
+        return f.value, t.value
+
     def kernel_stats(self):
         f, a = C.c_float(), C.c_float()
         fn, an = C.c_int(), C.c_int()
@@ -387,8 +395,10 @@ class Context:
 class AjtaiCommitmentScheme:
     """commitment/commitment_scheme.rs:17-114.  The matrix lives on the device."""
 
-    def __init__(self, ctx, matrix=None, kappa=None, n=None, seed=None):
+    def __init__(self, ctx, matrix=None, kappa=None, n=None, seed=None, digits_only=False):
         self.ctx = ctx
+        if digits_only:          # the fold step commits digit planes only: keep the byte planes, not the NTT-form copy (lfhip.h)
+            _chk(_lib().lf_ajtai_set_digits_only(ctx.h, 1), "lf_ajtai_set_digits_only")
         if matrix is not None:  # AjtaiCommitmentScheme::new
             a, p = _a64(matrix)
             self._kappa, self._n = a.shape[0], a.shape[1]
@@ -396,6 +406,10 @@ class AjtaiCommitmentScheme:
         else:                    # synthetic i.i.d. matrix generated on the device (bench)
             self._kappa, self._n = kappa, n
             _chk(_lib().lf_ajtai_generate(ctx.h, seed, kappa, n), "lf_ajtai_generate")
+
+    def set_digits_only(self, on=True):
+        """keep / drop the NTT-form copy of A (lf_ajtai_set_digits_only): general commitments rebuild it from the byte planes per call"""
+        _chk(_lib().lf_ajtai_set_digits_only(self.ctx.h, 1 if on else 0), "lf_ajtai_set_digits_only")
 
     def kappa(self):
         return self._kappa

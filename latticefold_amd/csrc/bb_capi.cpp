@@ -1288,8 +1288,6 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // working tables (ping-pong): 5 special tables (eqL eqR eqB G1 G2 = 171 planes) + the 2K*9 materialised f-hat tables
     const size_t T5P = 3 * TAU + 2 * RE;
     fe *F[2], *T5[2];
-    RET(c->tbuf("fold_F0", (size_t)K2 * TAU * RE * atl(m / 4), &F[0]));   // f-hat is materialised only after two rounds
-    RET(c->tbuf("fold_F1", (size_t)K2 * TAU * RE * atl(m / 8), &F[1]));
     RET(c->tbuf("fold_T0", T5P * atl(m / 2), &T5[0]));
     RET(c->tbuf("fold_T1", T5P * atl(m / 4), &T5[1]));
     FoldArgs a;
@@ -1313,6 +1311,10 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     const bool use_lut = fused && P.s >= 4 && m / 4 >= lut_min && m / 4 >= 4 && !c->tn.fold_no_lut;
     // round 5 on the planes as well (mode 7): round 4 then stores no tables.  From 2^18 rows on, like the Goldilocks driver
     const bool use_r5 = use_lut && !c->tn.fold_no_r4tab && !c->tn.fold_no_r5tab && P.s >= 5 && (N & 3) == 0 && m / 32 >= c->tn.r5_min;
+    // f-hat is materialised after two rounds (m/4 entries, F[0]; round r > 3 writes its m/2^(r-1) entries to F[r odd ? 0 : 1]) -- or later: the
+    // look-up-table rounds store their first tables in round 4 (m/8, F[1]), with round 5 on the planes too in round 5 (m/16, F[0])
+    RET(c->tbuf("fold_F0", (size_t)K2 * TAU * RE * atl(use_lut ? m / 16 : m / 4), &F[0]));
+    RET(c->tbuf("fold_F1", (size_t)K2 * TAU * RE * atl(use_r5 ? m / 32 : m / 8), &F[1]));
     fe *d_lut = nullptr;
     int lut_mode = 0;
     for (u32 round = 1; round <= P.s; round++) {

@@ -13,6 +13,9 @@ inline AjtaiI8Ring ajtai_i8_goldilocks() { return AjtaiI8Ring{24, 8, 0, 1}; }
 inline AjtaiI8Ring ajtai_i8_babybear() { return AjtaiI8Ring{72, 4, 2013265921ull, 0}; }
 // A repacked once per matrix: row i of a row chunk (canonical coefficients, element (c, j) at coef[c*cs + j*js]) -> bytes in MFMA operand
 // order, MT = ajtai_i8_row_tiles(rows of the chunk)
+// the same from the NTT form of a Goldilocks row in one pass (dense inverse map + packing), and the way back to canonical coefficients [RD][n]
+void launch_ajtai_icrt_pack_i8(const uint64_t *icrt_mat, const uint64_t *ntt, size_t n, uint32_t i, uint32_t MT, unsigned char *Ab, hipStream_t s);
+void launch_ajtai_unpack_i8(const unsigned char *Ab, size_t n, uint32_t i, uint32_t MT, uint32_t RD, uint32_t NL, uint64_t *coef, hipStream_t s);
 void launch_ajtai_pack_i8(const uint64_t *coef, size_t cs, size_t js, size_t n, uint32_t i, uint32_t MT, uint32_t RD, uint32_t NL, unsigned char *Ab, hipStream_t s);
 uint32_t ajtai_i8_row_tiles(const AjtaiI8Ring &R, uint32_t kappa);
 uint32_t ajtai_i8_col_tiles(const AjtaiI8Ring &R, uint32_t NP);

@@ -79,6 +79,65 @@ void launch_ajtai_pack_i8(const u64 *coef, size_t cs, size_t js, size_t n, u32 i
     hipLaunchKernelGGL(k_ajtai_pack_i8, dim3((unsigned)cdiv(ntiles * KS * 4 * NL, 256)), dim3(256), 0, s, coef, cs, js, n, i, MT, KS, NL, ntiles, Ab);
 }
 
+// The Goldilocks set-up in one pass over a row: NTT form [24][n] -> coefficients (dense 24 x 24 inverse map, as k_icrt_dense) -> operand
+// bytes.  Block = 32 columns (4 tiles): inputs and the 24 x 32 coefficients go through LDS, nothing but the bytes is written.
+__global__ void __launch_bounds__(256) k_ajtai_icrt_pack_i8(const u64 *mat, const u64 *ntt, size_t n, u32 i, u32 MT, size_t ntiles, unsigned char *Ab) {
+    constexpr u32 KS = 3, NL = 8, per_tile = KS * 4 * NL;
+    __shared__ u64 M[24 * 24], X[24][32], Cf[24][33];
+    for (int t = threadIdx.x; t < 576; t += 256) M[t] = mat[t];
+    const size_t j0 = (size_t)blockIdx.x * 32;
+    for (int t = threadIdx.x; t < 768; t += 256) {
+        const u32 c = t >> 5, jj = t & 31;
+        X[c][jj] = j0 + jj < n ? ntt[(size_t)c * n + j0 + jj] : 0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 768; t += 256) {
+        const u32 r = t >> 5, jj = t & 31;
+        Acc a;
+        acc_set(a, M[r * 24], X[0][jj]);
+#pragma unroll
+        for (int c = 1; c < 24; c++) acc_mad(a, M[r * 24 + c], X[c][jj]);
+        Cf[r][jj] = acc_reduce(a);
+    }
+    __syncthreads();
+    for (u32 w = threadIdx.x; w < 4 * per_tile; w += 256) {
+        const u32 tl = w / per_tile, r = w % per_tile, u = r % NL, g = (r / NL) & 3, s = r / (4 * NL);
+        const size_t T = (size_t)blockIdx.x * 4 + tl;
+        if (T >= ntiles) continue;
+        const u32 m = NL * i + u, mt = m >> 4, lane = g * 16 + (m & 15), c0 = 8 * s + 2 * g;
+        u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const u64 v = Cf[c0 + (t >> 3)][tl * 8 + (t & 7)];   // columns past n hold zeros
+            o[t >> 2] |= (u32)((((v >> (8 * u)) & 0xFF) ^ 0x80)) << (8 * (t & 3));
+        }
+        *(uint4 *)(Ab + ((T * KS + s) * MT + mt) * 1024 + lane * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+void launch_ajtai_icrt_pack_i8(const u64 *icrt_mat, const u64 *ntt, size_t n, u32 i, u32 MT, unsigned char *Ab, hipStream_t s) {
+    const size_t ntiles = (n + 7) / 8;
+    hipLaunchKernelGGL(k_ajtai_icrt_pack_i8, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), 0, s, icrt_mat, ntt, n, i, MT, ntiles, Ab);
+}
+// and back (a context that dropped its NTT-form copy, lf_ajtai_release_ntt, and is asked for a general commitment): the canonical
+// coefficients of row i from the operand bytes, coef [24][n]
+__global__ void __launch_bounds__(256) k_ajtai_unpack_i8(const unsigned char *Ab, size_t n, u32 i, u32 MT, u32 KS, u32 NL, u64 *coef) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * KS * 8) return;
+    const size_t j = gid % n;
+    const u32 c = (u32)(gid / n), s = c >> 3, g = (c & 7) >> 1, t = ((c & 1) << 3) | (u32)(j & 7);
+    const size_t T = j >> 3;
+    u64 v = 0;
+    for (u32 u = 0; u < NL; u++) {
+        const u32 m = NL * i + u, mt = m >> 4, lane = g * 16 + (m & 15);
+        v |= (u64)(Ab[((T * KS + s) * MT + mt) * 1024 + lane * 16 + t] ^ 0x80) << (8 * u);
+    }
+    coef[(size_t)c * n + j] = v;
+}
+void launch_ajtai_unpack_i8(const unsigned char *Ab, size_t n, u32 i, u32 MT, u32 RD, u32 NL, u64 *coef, hipStream_t s) {
+    const u32 KS = RD / 8;
+    hipLaunchKernelGGL(k_ajtai_unpack_i8, dim3((unsigned)cdiv(n * RD, 256)), dim3(256), 0, s, Ab, n, i, MT, KS, NL, coef);
+}
+
 struct AjtaiI8Args {
     const unsigned char *Ab;
     const int32_t *planes;   // [RD][ld], already offset to this rank's first column

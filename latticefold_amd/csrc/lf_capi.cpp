@@ -144,7 +144,8 @@ struct lf_ctx {
     u64 *d_icrt = nullptr;
     // Ajtai (nA = columns held by this rank, starting at global column A_col0 of nA_total)
     LaneWorker lane1;
-    u64 *dA = nullptr;
+    u64 *dA = nullptr;              // NTT form (general commitments); absent in digits-only mode until one is asked for (need_dA)
+    bool A_loaded = false, digits_only = false;
     unsigned char *dAb = nullptr;   // the same matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 26
     u32 i8_nch = 0, i8_kc = 0;
     u32 kappa = 0;
@@ -206,6 +207,12 @@ struct lf_ctx {
         int rc = b->ensure(bytes);
         *out = b->p;
         return rc;
+    }
+    // give a set-up scratch buffer back (caller has synchronised the stream that used it)
+    void drop_buf(const std::string &name) {
+        std::lock_guard<std::mutex> g(buf_mu);
+        auto it = bufs.find(t_lane ? "lane1:" + name : name);
+        if (it != bufs.end()) { it->second.release(); bufs.erase(it); }
     }
     template <class T>
     int tbuf(const std::string &name, size_t count, T **out) {
@@ -421,6 +428,18 @@ void lf_ctx_destroy(lf_ctx *c) {
     (void)hipStreamSynchronize(c->st_lane[0]);
     (void)hipStreamSynchronize(c->st_lane[1]);
     free_ccs(c);
+    if (getenv("LF_MEM_REPORT")) {   // what the context held, largest first
+        std::vector<std::pair<size_t, std::string>> v;
+        size_t tot = 0;
+        for (auto &kv : c->bufs) { v.push_back({kv.second.bytes, kv.first}); tot += kv.second.bytes; }
+        const AjtaiI8Ring R = ajtai_i8_goldilocks();
+        const size_t ab = c->dAb ? (c->nA + 7) / 8 * (R.RD / 8) * ajtai_i8_row_tiles(R, c->i8_kc) * 1024 * c->i8_nch : 0;
+        v.push_back({ab, "(Ajtai byte planes)"});
+        v.push_back({c->dA ? (size_t)c->kappa * c->nA * 192 : 0, "(Ajtai NTT form)"});
+        std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+        fprintf(stderr, "[lf mem] named buffers %.2f GiB + Ajtai %.2f GiB\n", tot / 1073741824.0, (v.size() ? (ab + (c->dA ? (size_t)c->kappa * c->nA * 192 : 0)) : 0) / 1073741824.0);
+        for (size_t i = 0; i < v.size() && v[i].first >= ((size_t)16 << 20); i++) fprintf(stderr, "[lf mem]   %8.1f MiB  %s\n", v[i].first / 1048576.0, v[i].second.c_str());
+    }
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
     if (c->dAb) (void)hipFree(c->dAb);
@@ -518,7 +537,7 @@ int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *use
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
     if (c->bb) return c->bb->set_sharding(rank, world, cb, user);
     std::lock_guard<std::mutex> g(c->mu);
-    if (c->dA) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
+    if (c->A_loaded) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
     for (int l = 0; l < 2; l++) {
         c->comm[l].destroy();
         c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = cb; c->comm[l].user = user; c->comm[l].poisoned = false;
@@ -547,7 +566,7 @@ int lf_dist_init(lf_ctx *c, int rank, int world, const uint8_t *ids) {
     if (!c || !ids || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return LF_ERR_INVALID;
     if (c->bb) return c->bb->dist_init(rank, world, ids);
     std::lock_guard<std::mutex> g(c->mu);
-    if (c->dA) return LF_ERR_STATE;   // choose the sharding before loading/generating the Ajtai matrix
+    if (c->A_loaded) return LF_ERR_STATE;   // choose the sharding before loading/generating the Ajtai matrix
     HIPCHK(hipSetDevice(c->device));
     for (int l = 0; l < 2; l++) {
         c->comm[l].destroy();
@@ -731,10 +750,13 @@ static int shard_columns(lf_ctx *c, size_t n, size_t *col0, size_t *cnt) {
     return LF_OK;
 }
 // The int8 matrix-core commit kernel wants A in coefficient form, cut into bytes, in MFMA operand order: built once per matrix.
-static int prep_ajtai_i8(lf_ctx *c) {
+// (c->kappa, c->nA set.)  Rows arrive one at a time in NTT form (row_ntt [24][nA] on the device, prep_ajtai_i8_row): one fused pass -- dense
+// inverse map + byte packing -- per row, so a digits-only context never holds more than one u64 row of A.
+static bool want_ajtai_i8() { return !getenv("LF_AJTAI_VALU"); }
+static int prep_ajtai_i8_begin(lf_ctx *c) {
     if (c->dAb) { (void)hipFree(c->dAb); c->dAb = nullptr; }
     c->i8_nch = 0;
-    if (getenv("LF_AJTAI_VALU")) return LF_OK;
+    if (!want_ajtai_i8()) return LF_OK;
     const AjtaiI8Ring R = ajtai_i8_goldilocks();
     const u32 maxr = ajtai_i8_max_rows(R), nch = (c->kappa + maxr - 1) / maxr, kc = (c->kappa + nch - 1) / nch;
     const size_t ntiles = (c->nA + 7) / 8;
@@ -742,15 +764,67 @@ static int prep_ajtai_i8(lf_ctx *c) {
     const size_t chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
     HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch + ajtai_i8_slack_bytes()));
     HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch + ajtai_i8_slack_bytes(), c->stream()));
-    u64 *coef;
-    RET(c->tbuf("i8_prep_coef", 24 * c->nA, &coef));
-    for (u32 i = 0; i < c->kappa; i++) {
-        launch_icrt_dense(c->d_icrt, c->dA + (size_t)i * 24 * c->nA, coef, c->nA, c->stream());
-        launch_ajtai_pack_i8(coef, c->nA, 1, c->nA, i % kc, MT, R.RD, R.NL, c->dAb + (size_t)(i / kc) * chunk_bytes, c->stream());
-    }
-    HIPCHK(hipStreamSynchronize(c->stream()));
     c->i8_nch = nch;
     c->i8_kc = kc;
+    return LF_OK;
+}
+static void prep_ajtai_i8_row(lf_ctx *c, u32 i, const u64 *row_ntt) {
+    if (!c->i8_nch) return;
+    const AjtaiI8Ring R = ajtai_i8_goldilocks();
+    const u32 kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc);
+    const size_t chunk_bytes = (c->nA + 7) / 8 * (R.RD / 8) * MT * 1024;
+    launch_ajtai_icrt_pack_i8(c->d_icrt, row_ntt, c->nA, i % kc, MT, c->dAb + (size_t)(i / kc) * chunk_bytes, c->stream());
+}
+// The NTT-form copy for a general commitment (lf_ajtai_commit, lf_witness_commit, the LF_AJTAI_VALU step): rebuilt from the byte planes
+// when the context runs in digits-only mode or dropped it (lf_ajtai_release_ntt) -- the bytes are the canonical coefficients.
+static int need_dA(lf_ctx *c) {
+    if (!c->A_loaded) return LF_ERR_STATE;
+    if (c->dA) return LF_OK;
+    if (!c->i8_nch || !c->dAb) return LF_ERR_STATE;
+    const AjtaiI8Ring R = ajtai_i8_goldilocks();
+    const u32 kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc);
+    const size_t chunk_bytes = (c->nA + 7) / 8 * (R.RD / 8) * MT * 1024;
+    u64 *coef;
+    RET(c->tbuf("i8_prep_coef", 24 * c->nA, &coef));
+    HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->kappa * c->nA * 24 * 8));
+    for (u32 i = 0; i < c->kappa; i++) {
+        launch_ajtai_unpack_i8(c->dAb + (size_t)(i / kc) * chunk_bytes, c->nA, i % kc, MT, R.RD, R.NL, coef, c->stream());
+        launch_crt_fwd(c->dcrt, coef, c->dA + (size_t)i * 24 * c->nA, c->nA, c->stream());
+    }
+    return LF_OK;
+}
+// digits-only contexts give the copy back after the call that needed it
+static void done_dA(lf_ctx *c) {
+    if (c->digits_only && c->dA && c->i8_nch) {
+        (void)hipStreamSynchronize(c->stream());
+        (void)hipFree(c->dA);
+        c->dA = nullptr;
+        c->drop_buf("i8_prep_coef");
+    }
+}
+static int ajtai_install(lf_ctx *c, size_t kappa, size_t n, const uint64_t *A_host, uint64_t seed) {
+    size_t col0, cnt;
+    RET(shard_columns(c, n, &col0, &cnt));   // a sharded rank keeps only its column slice of the caller's matrix
+    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
+    c->A_loaded = false;
+    c->kappa = (u32)kappa;
+    c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
+    RET(prep_ajtai_i8_begin(c));
+    const bool keep = !(c->digits_only && c->i8_nch);
+    u64 *row = nullptr;
+    if (keep) HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * 24 * 8));
+    else RET(c->tbuf("i8_prep_row", 24 * cnt, &row));
+    if (keep && !A_host) launch_fill_ajtai(c->dA, (u32)kappa, cnt, n, col0, seed, c->stream());
+    for (size_t i = 0; i < kappa; i++) {
+        u64 *r = keep ? c->dA + i * 24 * cnt : row;
+        if (A_host) RET(up_ring(c, A_host + (i * n + col0) * 24, cnt, r));
+        else if (!keep) launch_fill_ajtai(r, 1, cnt, n, col0, seed, c->stream(), (u32)i);
+        prep_ajtai_i8_row(c, (u32)i, r);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream()));
+    c->drop_buf("i8_prep_row");
+    c->drop_buf("stage_aos");
+    c->A_loaded = true;
     return LF_OK;
 }
 // digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev [NP][kappa][24] NTT form (PARTIAL when sharded)
@@ -818,30 +892,28 @@ int lf_ajtai_load(lf_ctx *c, const uint64_t *A, size_t kappa, size_t n) {
     if (c->bb) return c->bb->ajtai_load(A, kappa, n);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    size_t col0, cnt;
-    RET(shard_columns(c, n, &col0, &cnt));   // a sharded rank keeps only its column slice of the caller's matrix
-    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * 24 * 8));
-    for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + (i * n + col0) * 24, cnt, c->dA + i * 24 * cnt));
-    HIPCHK(hipStreamSynchronize(c->stream()));
-    c->kappa = (u32)kappa;
-    c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
-    return prep_ajtai_i8(c);
+    return ajtai_install(c, kappa, n, A, 0);
 }
 int lf_ajtai_generate(lf_ctx *c, uint64_t seed, size_t kappa, size_t n) {
     if (!c || !kappa || !n || kappa > 128) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ajtai_generate(seed, kappa, n);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    size_t col0, cnt;
-    RET(shard_columns(c, n, &col0, &cnt));
-    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * 24 * 8));
-    launch_fill_ajtai(c->dA, (u32)kappa, cnt, n, col0, seed, c->stream());
-    HIPCHK(hipStreamSynchronize(c->stream()));
-    c->kappa = (u32)kappa;
-    c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
-    return prep_ajtai_i8(c);
+    return ajtai_install(c, kappa, n, nullptr, seed);
+}
+int lf_device_memory(lf_ctx *c, size_t *free_bytes, size_t *total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return LF_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
+    return LF_OK;
+}
+int lf_ajtai_set_digits_only(lf_ctx *c, int on) {
+    if (!c) return LF_ERR_INVALID;
+    if (c->bb) return on ? LF_ERR_UNSUPPORTED : LF_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->digits_only = on != 0;
+    if (c->digits_only && c->dA && c->i8_nch) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipStreamSynchronize(c->stream())); (void)hipFree(c->dA); c->dA = nullptr; }
+    return LF_OK;
 }
 static u32 ajtai_splits(size_t n) {
     // one block per (split, slot); aim for >= 4 blocks per CU, each split a multiple of the LDS tile
@@ -852,6 +924,7 @@ static u32 ajtai_splits(size_t n) {
 }
 // F: [batch][24][ldF] device, pointing at this rank's first column; out_dev: [batch][kappa][24] device AoS (PARTIAL when sharded)
 static int commit_dev(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
+    RET(need_dA(c));
     // One LDS tile holds the (A, F) rows of a launch: at most 48 rows of A (kappa up to 128 -- the reference's Goldilocks rows go up to
     // kappa = 99, benches/config.toml:158 -- is cut into equal row chunks) and as many witnesses as fit next to them.
     const u32 nch = (c->kappa + 47) / 48, kc = (c->kappa + nch - 1) / nch;
@@ -911,7 +984,7 @@ int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64
     if (!c || !f || !out || !batch) return LF_ERR_INVALID;
     if (c->bb) return c->bb->ajtai_commit(f, n, batch, out);
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->dA) return LF_ERR_STATE;
+    if (!c->A_loaded) return LF_ERR_STATE;
     if (n != c->nA_total) return LF_ERR_INVALID;  // CommitmentError::WrongWitnessLength(n, width)
     HIPCHK(hipSetDevice(c->device));
     u64 *F, *o;
@@ -922,7 +995,9 @@ int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64
     c->ev_reset();
     RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
     c->ev_collect();
-    return commit_download(c, o, batch * c->kappa * 24, out);
+    const int rc = commit_download(c, o, batch * c->kappa * 24, out);
+    done_dA(c);
+    return rc;
 }
 
 // column-sharded commit: the context holds only columns [col0, col0+n_local) of A (loaded with lf_ajtai_load on
@@ -1233,7 +1308,7 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     if (!c || !w || !cm_out || w->ctx != c) return LF_ERR_INVALID;
     if (c->bb) return c->bb->witness_commit(w, cm_out);
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->dA) return LF_ERR_STATE;
+    if (!c->A_loaded) return LF_ERR_STATE;
     if (w->N != c->nA_total) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
     u64 *d, *e, *o;
@@ -1243,7 +1318,9 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     launch_i32_to_coef(w->planes, d, w->N, c->stream());
     launch_crt_fwd(c->dcrt, d, e, w->N, c->stream());
     RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));
-    return commit_download(c, o, (size_t)c->kappa * 24, cm_out);
+    const int rc = commit_download(c, o, (size_t)c->kappa * 24, cm_out);
+    done_dA(c);
+    return rc;
 }
 // pool of recycled witness-plane buffers: process-wide (a witness may be freed after its context), keyed by device and size
 namespace {
@@ -2104,23 +2181,6 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     u64 *msgs = proof;
     std::vector<Fq3> pt(P.s);
     { HostTimer ht(c); sc_prologue(tr, P.s, deg); }
-    // working tables (ping-pong): 5 special tables + materialised f-hat
-    u64 *F[2], *T5[2];
-    size_t half = m / 2;
-    RET(c->tbuf("fold_F0", (size_t)K2 * 3 * 24 * (m / 4 ? m / 4 : 1), &F[0]));   // f-hat is materialised only after two rounds
-    RET(c->tbuf("fold_F1", (size_t)K2 * 3 * 24 * (m / 8 ? m / 8 : 1), &F[1]));
-    // T5 layout per buffer: eqL[3] eqR[3] eqB[3] G1[24] G2[24] = 57 planes
-    RET(c->tbuf("fold_T0", 57 * (half ? half : 1), &T5[0]));
-    RET(c->tbuf("fold_T1", 57 * (half / 2 ? half / 2 : 1), &T5[1]));
-    FoldRoundArgs a;
-    a.eqL = S[0].eq_r; a.eqR = S[1].eq_r; a.eqB = eqb; a.G1 = G[0]; a.G2 = G[1]; a.ld = m; a.n = m;
-    a.p0 = 0; a.pcnt = m / 2; a.pF0 = 0;
-    const u64 *curF = nullptr;
-    size_t ldF = 0;
-    int flip = 0;
-    // Sharded rounds (SURVEY 8e): rank g evaluates the pairs of its index slice (high bits: pairs (2j,2j+1) stay local, the
-    // f-hat tables exist only for that slice), the (D+1)-element partial messages are all-gathered and added mod p, every rank
-    // runs the same transcript.  Once fewer than 64 pairs per rank remain the f-hat slices are gathered and the tail is replicated.
     const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
     bool sharded = Gw > 1;
     // Rounds >= 4 with many pairs: fix_variables of the f-hat tables is fused into the (ALU-bound) round kernel,
@@ -2139,6 +2199,27 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     const bool use_r4tab = use_lut && c->dcrt.nu2p40 && !c->tn.fold_no_r4tab;
     // (not when the persistent tail may take over at round 5: it starts from the materialised round-4 tables)
     const bool use_r5 = use_r4tab && !c->tn.fold_no_r5tab && Gw == 1 && P.s >= 5 && (N & 3) == 0 && (c->tn.no_tail || m / 8 > c->tn.tail_n) && m / 32 >= c->tn.r5_min;
+    // working tables (ping-pong): 5 special tables + materialised f-hat
+    u64 *F[2], *T5[2];
+    size_t half = m / 2;
+    // f-hat is materialised after two rounds (m/4 entries, F[0]; round r > 3 writes its m/2^(r-1) entries to F[r odd ? 0 : 1]) -- or later: the
+    // look-up-table rounds store their first tables in round 4 (m/8, F[1]), with round 5 on the planes too in round 5 (m/16, F[0]).  Sized
+    // for what this step will write: 6.8 GiB -> 1.4 GiB at 2^20 rows.
+    const size_t f0_ent = use_lut ? m / 16 : m / 4, f1_ent = use_r5 ? m / 32 : m / 8;
+    RET(c->tbuf("fold_F0", (size_t)K2 * 3 * 24 * (f0_ent ? f0_ent : 1), &F[0]));
+    RET(c->tbuf("fold_F1", (size_t)K2 * 3 * 24 * (f1_ent ? f1_ent : 1), &F[1]));
+    // T5 layout per buffer: eqL[3] eqR[3] eqB[3] G1[24] G2[24] = 57 planes
+    RET(c->tbuf("fold_T0", 57 * (half ? half : 1), &T5[0]));
+    RET(c->tbuf("fold_T1", 57 * (half / 2 ? half / 2 : 1), &T5[1]));
+    FoldRoundArgs a;
+    a.eqL = S[0].eq_r; a.eqR = S[1].eq_r; a.eqB = eqb; a.G1 = G[0]; a.G2 = G[1]; a.ld = m; a.n = m;
+    a.p0 = 0; a.pcnt = m / 2; a.pF0 = 0;
+    const u64 *curF = nullptr;
+    size_t ldF = 0;
+    int flip = 0;
+    // Sharded rounds (SURVEY 8e): rank g evaluates the pairs of its index slice (high bits: pairs (2j,2j+1) stay local, the
+    // f-hat tables exist only for that slice), the (D+1)-element partial messages are all-gathered and added mod p, every rank
+    // runs the same transcript.  Once fewer than 64 pairs per rank remain the f-hat slices are gathered and the tail is replicated.
     u64 *d_lut = nullptr;
     c->sv_round_mask = 0;
     u32 *sv_bits[2] = {nullptr, nullptr};
@@ -2539,7 +2620,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     if (c->bb) return t->bb ? c->bb->fold_step(*t->bb, acc, w_acc, cm_i, w_i, lcccs_out, w_out, proof) : LF_ERR_INVALID;
     if (t->bb) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    if (!c->have_ccs || !c->A_loaded) return LF_ERR_STATE;
     const lf_params &P = c->P;
     if (c->kappa != P.kappa || c->nA_total != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
@@ -2714,7 +2795,7 @@ int lf_decomposition_prove(lf_ctx *c, lf_transcript *t, const uint64_t *lcccs, c
     if (c->bb) return t->bb ? c->bb->decomposition_prove(*t->bb, lcccs, wit, lcccs_s_out, dec_proof_out) : LF_ERR_INVALID;
     if (t->bb) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    if (!c->have_ccs || !c->A_loaded) return LF_ERR_STATE;
     const lf_params &P = c->P;
     if (c->kappa != P.kappa || c->nA_total != c->N || wit->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));

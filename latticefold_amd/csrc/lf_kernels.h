@@ -31,7 +31,7 @@ void launch_soa_to_aos(const u64 *soa, u64 *aos, size_t n, hipStream_t s);
 void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStream_t s);  // SplitMix64 stream (workload.py)
 // Ajtai matrix generated in place in plane layout, equal to AoS stream splitmix(seed)[((i*n+j)*24+w)]
 // columns [col0, col0+n) of the n_total-column matrix
-void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s);
+void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s, u32 row0 = 0);
 
 // sharded exchanges: modular sum of all-gathered partial vectors; re-layout of all-gathered table slices
 void launch_modsum(const u64 *parts, u32 nparts, size_t words, u64 *out, hipStream_t s);

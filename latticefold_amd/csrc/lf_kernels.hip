@@ -143,16 +143,17 @@ __global__ void __launch_bounds__(256) k_fill_uniform(u64 *dst, size_t words, u6
 void launch_fill_uniform(u64 *dst, size_t words, u64 seed, size_t start, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_uniform, dim3(grid_for(words, 4096)), dim3(256), 0, s, dst, words, seed, start);
 }
-__global__ void __launch_bounds__(256) k_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed) {
+__global__ void __launch_bounds__(256) k_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, u32 row0) {
     size_t total = (size_t)kappa * 24 * n;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
     for (; i < total; i += st) {
-        size_t j = i % n, w = (i / n) % 24, row = i / (24 * n);
+        size_t j = i % n, w = (i / n) % 24, row = row0 + i / (24 * n);
         A[i] = splitmix_fq(seed, (row * n_total + col0 + j) * 24 + w);
     }
 }
-void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s) {
-    hipLaunchKernelGGL(k_fill_ajtai, dim3(4096), dim3(256), 0, s, A, kappa, n, n_total, col0, seed);
+// rows [row0, row0 + kappa) of the synthetic matrix into A [kappa][24][n]
+void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0, u64 seed, hipStream_t s, u32 row0) {
+    hipLaunchKernelGGL(k_fill_ajtai, dim3(4096), dim3(256), 0, s, A, kappa, n, n_total, col0, seed, row0);
 }
 
 __device__ __forceinline__ u64 fq_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? 1 : LF_P - 1); }

@@ -137,3 +137,38 @@ def test_paired_commit_of_both_decompositions(name):
     finally:
         for k in ("LF_I8_PAIR", "LF_I8_WGS"):
             os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("name,how", [("T10", "matrix"), ("E99", "matrix"), ("T14", "seed"), ("G5", "seed")])
+def test_digits_only_context_matches_the_full_one(name, how):
+    """lf_ajtai_set_digits_only: the context keeps only the byte planes of A (rows pass through one u64 row buffer: fused inverse map +
+    packing).  Digit-plane commitments (the fold step), general commitments (NTT form rebuilt from the bytes for the call) and the
+    witness commitment must be word for word those of a context that holds both forms; switching the mode on afterwards drops the copy."""
+    for k in ("LF_AJTAI_VALU", "LF_I8_WGS", "LF_I8_GUARDED"):
+        os.environ.pop(k, None)
+    wl = make_workload(name)
+    from latticefold_amd.workload import splitmix_fq
+    f = splitmix_fq(99, 0, 2 * wl.N * 24).reshape(2, wl.N, 24)
+    out = {}
+    for mode in ("full", "digits", "late"):
+        ctx = api.Context(0, ring=wl.ring)
+        ctx.load_ccs(wl)
+        kw = dict(matrix=wl.ajtai_matrix()) if how == "matrix" else dict(kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+        scheme = api.AjtaiCommitmentScheme(ctx, digits_only=(mode == "digits"), **kw)
+        if mode == "late":
+            free0 = ctx.device_memory()[0]
+            scheme.set_digits_only(True)
+            copy_bytes = wl.kappa * wl.N * 24 * 8
+            if copy_bytes >= 32 << 20:   # (small buffers come out of the runtime's own sub-allocator: nothing to see in mem_get_info)
+                assert ctx.device_memory()[0] - free0 >= copy_bytes * 0.9      # the NTT-form copy went back to the driver
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        cm = wit.commit(scheme)
+        cccs = np.concatenate([cm, wl.x_ccs])
+        tr = api.PoseidonTranscript(ring=wl.ring)
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr)
+        dec = api.LFDecompositionProver.prove(ctx, acc, wit, tr)
+        out[mode] = (cm, scheme.commit_ntt(f[0]), dec[0], dec[1], scheme.commit_ntt(f[1]))
+        ctx.close()
+    for mode in ("digits", "late"):
+        for a, b in zip(out["full"], out[mode]):
+            assert (np.asarray(a) == np.asarray(b)).all(), mode
