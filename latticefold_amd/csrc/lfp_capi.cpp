@@ -33,6 +33,7 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     for (void *p : {(void *)c->A, (void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
                     (void *)c->err_d, (void *)c->g})
         if (p) (void)hipFree(p);
+    if (c->hpin) (void)hipHostFree(c->hpin);
     (void)hipStreamDestroy(c->st);
     delete c;
 }
@@ -82,6 +83,11 @@ extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) 
     if (!canonical(f, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
     c->have = false;
+    if (c->f && c->nf == n) {   // same length as the resident witness: overwrite it (no hipFree / hipMalloc round trip per instance)
+        HIPCHK(c, hipMemcpyAsync(c->f, f, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        return LFPLUS_OK;
+    }
     int rc = upload(c, &c->f, f, (size_t)n * 16);
     if (rc) return rc;
     c->nf = n;

@@ -74,6 +74,21 @@ struct lfplus_ctx {
     u64 *g = nullptr;
     u64 g_n = 0;
     LfpPool pool;
+    // pinned host staging of the per-round partial sums and other small downloads (a copy into pageable memory is staged and synchronised by
+    // the runtime: tens of microseconds per sumcheck round)
+    // -- and the round kernels write their block partials straight into it (mapped: no copy command between the kernel and the host's read)
+    u64 *hpin = nullptr, *hpin_dev = nullptr;
+    size_t hpin_words = 0;
+    u64 *pin(size_t words) {
+        if (words <= hpin_words) return hpin;
+        if (hpin) (void)hipHostFree(hpin);
+        hpin = nullptr; hpin_dev = nullptr; hpin_words = 0;
+        if (words < 65536) words = 65536;
+        if (hipHostMalloc((void **)&hpin, words * 8, hipHostMallocMapped) != hipSuccess) { hpin = nullptr; return nullptr; }
+        if (hipHostGetDevicePointer((void **)&hpin_dev, hpin, 0) != hipSuccess) { (void)hipHostFree(hpin); hpin = nullptr; hpin_dev = nullptr; return nullptr; }
+        hpin_words = words;
+        return hpin;
+    }
     bool own_A = true;
     std::vector<LfpMatrix> mats;   // lfplus_set_matrices: the constraint-system matrices, uploaded once
     u64 mats_n = 0;

@@ -56,8 +56,8 @@ struct EqPt { u64 c[32], nc[32], one; };   // c_j, 1 - c_j and 1, Montgomery
 struct ScDesc { u32 nmat, ncols, nvec, nsets_eff; };   // nsets_eff: sets entering the sumcheck polynomial (setchk.rs:160-197: all, or the first matrix set alone without a batching challenge)
 void launch_sc_tables(const int8_t *dig, size_t n, u32 ncols, const PwTab &pw, u64 *tab, size_t ld, hipStream_t s);
 void launch_eq_build(const EqPt &pt, u32 nv, u64 *eq, hipStream_t s);
-u32 sc_round_blocks(size_t half);
-void launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part /* sc_round_blocks * 4 */, hipStream_t s);
+u32 sc_round_max_blocks();
+u32 launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part /* sc_round_max_blocks * 4; returns the blocks used */, hipStream_t s);
 void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u64 rM, hipStream_t s);
 u32 eval_chunks(size_t n);
 // out[col][16] = sum_row w[row] X^e(dig[row][col]); wstride 1: scalar Montgomery weights (out canonical), 16: canonical ring weights.  part: eval_chunks(n) * ncols * 16

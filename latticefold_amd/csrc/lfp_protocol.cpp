@@ -4,11 +4,28 @@
 //   Rg::range_check / Dcom::verify      src/rgchk.rs:81-186 / 193-258
 // The Fiat-Shamir transcript stays on the host (one width-24 Poseidon permutation per 20 absorbed words; a sumcheck round moves four words
 // up and one down); every table and every evaluation lives on the device.  No CPU fallback: the provers return LFPLUS_E_NO_DEVICE / _HIP.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include "lf_host.h"
 #include "lfp_ctx.h"
 
+// LFPLUS_TIMELINE=1: wall-clock marks of the protocol stages on stderr (the stream is drained at every mark, so the stages do not overlap)
+struct LfpTl {
+    bool on = getenv("LFPLUS_TIMELINE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(lfplus_ctx *c, const char *what) {
+        if (!on) return;
+        if (c && c->st) (void)hipStreamSynchronize(c->st);
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[lfplus] %-34s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count());
+        t0 = t;
+    }
+};
+static LfpTl g_tl;
+#define LFP_MARK(c, w) g_tl.mark(c, w)
 namespace {
 typedef unsigned __int128 u128;
 constexpr u64 P = lfp::P;
@@ -378,7 +395,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     const u32 ntab = nmat * (2 * ncols + 1) + 3 * nvec;
     DevBuf tabs[2], coefd;
     if (tabs[0].alloc((size_t)ntab * n * 8) || tabs[1].alloc((size_t)ntab * n * 8) || coefd.alloc((size_t)(nmat + nvec) * ncols * 8) ||
-        so.eqr.alloc(n * 8) || so.part.alloc((size_t)std::max<size_t>(lfp::sc_round_blocks(n / 2) * 4, (size_t)lfp::eval_chunks(n) * ncols * 16) * 8) ||
+        so.eqr.alloc(n * 8) || so.part.alloc((size_t)lfp::eval_chunks(n) * ncols * 16 * 8) ||
         so.small.alloc((size_t)((1 + nM) * nmat * ncols + nvec + 8) * D * 8))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (set check tables)");
     std::vector<u64> alpha(nmat + nvec), cch(nvars);
@@ -409,18 +426,20 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     }
     HIPCHK(c, hipMemcpyAsync(coefd.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, c->st));
     lfp::ScDesc d = {nmat, ncols, nvec, have_rc ? nmat + nvec : 1};
+    LFP_MARK(c, "set check: tables");
     // MLSumcheck::prove_as_subprotocol (latticefold utils/sumcheck.rs:53-80), degree 3
     tr->absorb_const(nvars);
     tr->absorb_const(3);
-    std::vector<u64> hpart((size_t)lfp::sc_round_blocks(n / 2) * 4);
+    u64 *hpart = c->pin((size_t)lfp::sc_round_max_blocks() * 4);   // the kernels write their block partials into mapped host memory
+    if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
     int cur = 0;
     size_t len = n;
     for (u32 rnd = 0; rnd < nvars; rnd++) {
         const size_t half = len / 2;
-        const u32 nb = lfp::sc_round_blocks(half);
-        lfp::launch_sc_round(tabs[cur].as<u64>(), n, half, d, coefd.as<u64>(), so.part.as<u64>(), c->st);
-        HIPCHK(c, hipMemcpyAsync(hpart.data(), so.part.p, (size_t)nb * 4 * 8, hipMemcpyDeviceToHost, c->st));
+        auto tA = std::chrono::steady_clock::now();
+        const u32 nb = lfp::launch_sc_round(tabs[cur].as<u64>(), n, half, d, coefd.as<u64>(), c->hpin_dev, c->st);
         HIPCHK(c, hipStreamSynchronize(c->st));
+        auto tB = std::chrono::steady_clock::now();
         u64 *m = msgs + (size_t)rnd * 4 * D;
         memset(m, 0, 4 * D * 8);
         for (int x = 0; x < 4; x++) {
@@ -432,12 +451,16 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         const u64 r = tr->challenge();
         tr->absorb_const(r);
         r_out[rnd] = r;
+        auto tC = std::chrono::steady_clock::now();
         if (rnd + 1 < nvars) {   // fix_variables of every table into the other buffer (rows keep the stride n)
             lfp::launch_sc_fix(tabs[cur].as<u64>(), tabs[cur ^ 1].as<u64>(), n, ntab, half, to_mont(r), c->st);
             cur ^= 1;
         }
+        if (g_tl.on) fprintf(stderr, "[lfplus]   sc round %2u: gpu+sync %6.1f us, host %6.1f us, fix launch %5.1f us (nb %u)\n", rnd, std::chrono::duration<double, std::micro>(tB - tA).count(),
+                             std::chrono::duration<double, std::micro>(tC - tB).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tC).count(), nb);
         len = half;
     }
+    LFP_MARK(c, "set check: sumcheck rounds");
     // Step 3 (setchk.rs:206-249): the sets at r, M_q * sets at r, the vector sets at r
     lfp::EqPt pt;
     for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(r_out[j]); pt.nc[j] = to_mont(fsub(1, r_out[j])); }
@@ -461,6 +484,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     HIPCHK(c, hipStreamSynchronize(c->st));
     tr->absorb_ring(e_out, (size_t)(1 + nM) * nmat * ncols);   // absorb_evaluations (setchk.rs:342-353)
     tr->absorb_ring(b_out, nvec);
+    LFP_MARK(c, "set check: evaluations + absorb");
     return LFPLUS_OK;
 }
 }  // namespace
@@ -542,6 +566,7 @@ int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr,
         memcpy(c_out + (size_t)l * (1 + nM) * D, ch, (size_t)(1 + nM) * D * 8);
         memcpy(v_out + (size_t)l * D, ch, D * 8);                                    // "v is equal to c[0]" (rgchk.rs:123)
     }
+    LFP_MARK(c, "range check: evaluations");
     for (u32 l = 0; l < L; l++) {   // absorb_evaluations (rgchk.rs:333-338): a as constants, then c
         for (u32 i = 0; i < 1 + nM; i++) tr->absorb_const(a_out[(size_t)l * (1 + nM) + i]);
         tr->absorb_ring(c_out + (size_t)l * (1 + nM) * D, 1 + nM);
@@ -737,7 +762,7 @@ bool calc_t(const u64 *cz, u32 logk, const std::vector<u64> &sp, u32 kd, u32 ell
     const size_t tl = (size_t)1 << logk;
     if (tl * kd * ell * D > n) return false;
     const std::vector<u64> tc = tensor(cz, logk);
-    out.assign(n * D, 0);
+    out.assign(tl * kd * ell * D * D, 0);   // the non-zero prefix only: the other n - tl kd l d entries of t(z) are zero
     for (size_t a = 0; a < tl; a++)
         for (u32 b = 0; b < kd; b++) {
             u64 pw = 1;
@@ -808,6 +833,7 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     if (rc) return rc;
     CmChallenges ch;
     cm_challenges(tr, k, kappa, nullptr, L, ch);
+    LFP_MARK(c, "cm: challenges");
     // h_l = sum_ki M_f[ki] s'_ki (cm.rs:82-103) on the device; comh_l = sum_ki comM_f[ki] s'_ki (:105-126) on the host (k kappa 256 products)
     std::vector<int32_t> spi((size_t)k * D * D);
     for (size_t i = 0; i < spi.size(); i++) spi[i] = ch.sp[i] > P / 2 ? -(int32_t)(P - ch.sp[i]) : (int32_t)ch.sp[i];
@@ -835,9 +861,11 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     }
     tr->absorb_ring(comh, (size_t)L * kappa);
     cm_c_challenges(tr, kappa, ch);
+    LFP_MARK(c, "cm: h, com_h, c challenges");
     std::vector<u64> t0, t1;
     if (!calc_t(ch.cz[0], ch.logk, ch.sp, k * D, ell, n, t0) || !calc_t(ch.cz[1], ch.logk, ch.sp, k * D, ell, n, t1))
         return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: t0 too large (kappa' * k d * l * d > n; the reference panics, cm.rs:601)");
+    LFP_MARK(c, "cm: t(z) on the host");
     // tables.  Scalars (Montgomery): eq(r, .) | tau_l.  Ring (canonical): per instance m_tau, f, h, then per matrix M tau, M m_tau, M f, M h; then t0, t1
     const u32 per = 4 + 4 * nM, nring = L * (per - 1), nS = 1 + L, nR = nring + 2;
     DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring;
@@ -862,12 +890,16 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr, m.col, m.valM, base + (size_t)j * n * D, n, mq + (size_t)(1 + j) * n * D, c->st);
         }
     }
-    HIPCHK(c, hipMemcpyAsync(R + (size_t)nring * n * D, t0.data(), n * D * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(R + (size_t)(nring + 1) * n * D, t1.data(), n * D * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemsetAsync(R + (size_t)nring * n * D, 0, (size_t)2 * n * D * 8, c->st));   // t0 | t1: zero beyond the prefix the host computed
+    HIPCHK(c, hipMemcpyAsync(R + (size_t)nring * n * D, t0.data(), t0.size() * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(R + (size_t)(nring + 1) * n * D, t1.data(), t1.size() * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    LFP_MARK(c, "cm: tables");
     // the two sumcheckers (cm.rs:201-347): same tables, different batching challenge rc; degree 2, ring-valued messages
     const lfp::CmDesc desc = {L, nM};
-    std::vector<u64> hpart((size_t)nb0 * 48), rcps((size_t)L * per + 2), evh((size_t)nR * D + nS);
+    std::vector<u64> rcps((size_t)L * per + 2), evh((size_t)nR * D + nS);
+    u64 *hpart = c->pin((size_t)nb0 * 48);   // block partials land in mapped host memory
+    if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
     for (int pass = 0; pass < 2; pass++) {
         const u64 rcv = tr->challenge();
         u64 pw = 1;
@@ -882,9 +914,10 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         for (u32 rnd = 0; rnd < nvars; rnd++) {
             const size_t half = len / 2;
             const u32 nb = lfp::cm_round_blocks(half);
-            lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), part.as<u64>(), c->st);
-            HIPCHK(c, hipMemcpyAsync(hpart.data(), part.p, (size_t)nb * 48 * 8, hipMemcpyDeviceToHost, c->st));
+            auto tA = std::chrono::steady_clock::now();
+            lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), c->hpin_dev, c->st);
             HIPCHK(c, hipStreamSynchronize(c->st));
+            auto tB = std::chrono::steady_clock::now();
             u64 *m = proof + (size_t)rnd * 3 * D;
             for (int x = 0; x < 3 * D; x++) {
                 u64 s = 0;
@@ -900,6 +933,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             lfp::launch_cm_fix(Rc, ld, Rw[w].as<u64>(), ldo, D, nR, half, to_mont(r), c->st);
             Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
             len = half;
+            if (g_tl.on) fprintf(stderr, "[lfplus]   cm round %2u: gpu+sync %6.1f us, host + fix launches %6.1f us (nb %u)\n", rnd, std::chrono::duration<double, std::micro>(tB - tA).count(),
+                                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tB).count(), nb);
         }
         // evals (cm.rs:313-331): every instance table at ro = the fully fixed tables
         DevBuf evd;
@@ -915,6 +950,7 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             memcpy(el + D, &evh[(size_t)l * (per - 1) * D], (size_t)(per - 1) * D * 8);
         }
         tr->absorb_ring(evs, (size_t)L * per);
+        LFP_MARK(c, "cm: sumchecker");
     }
     // g_l = s0 tau + s1 m_tau + s2 f + h (cm.rs:164-181), kept on the device
     lfp::CmShort cs;
@@ -933,6 +969,7 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     std::vector<const u64 *> fc(L);
     for (u32 l = 0; l < L; l++) fc[l] = fcoms[l].data();
     cm_x(ch, L, kappa, nM, fc.data(), comh, ea, eb, cm_g, vo);
+    LFP_MARK(c, "cm: g, x");
     return LFPLUS_OK;
 }
 extern "C" int lfplus_cm_read_g(lfplus_ctx *c, uint64_t *g_out) {
@@ -1101,6 +1138,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     MatHold M;
     int rcm = M.get(c, n, 3, rowptr, col, val);
     if (rcm) return rcm;
+    LFP_MARK(c, "(before linearize)");
     for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr, M[q].col, M[q].valM, c->f, n, G[0].as<u64>() + (size_t)q * n * D, c->st);
     std::vector<u64> r(nvars);
     for (u32 j = 0; j < nvars; j++) r[j] = tr->challenge();
@@ -1110,7 +1148,8 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     lfp::launch_eq_build(pt, nvars, E[0].as<u64>(), c->st);
     tr->absorb_const(nvars);
     tr->absorb_const(3);
-    std::vector<u64> hpart((size_t)nb0 * 64);
+    u64 *hpart = c->pin((size_t)nb0 * 64);
+    if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
     // round 0 reads the full tables (stride n), later rounds ping-pong between the first halves of the two buffers
     const u64 *Ec = E[0].as<u64>(), *Gc = G[0].as<u64>();
     size_t ld = n, len = n;
@@ -1118,9 +1157,10 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     for (u32 rnd = 0; rnd < nvars; rnd++) {
         const size_t half = len / 2;
         const u32 nb = lfp::cm_round_blocks(half);
-        lfp::launch_r1cs_round(Ec, Gc, ld, half, part.as<u64>(), c->st);
-        HIPCHK(c, hipMemcpyAsync(hpart.data(), part.p, (size_t)nb * 64 * 8, hipMemcpyDeviceToHost, c->st));
+        auto tA = std::chrono::steady_clock::now();
+        lfp::launch_r1cs_round(Ec, Gc, ld, half, c->hpin_dev, c->st);   // block partials into mapped host memory
         HIPCHK(c, hipStreamSynchronize(c->st));
+        auto tB = std::chrono::steady_clock::now();
         u64 *m = msgs + (size_t)rnd * 4 * D;
         for (int x = 0; x < 4 * D; x++) {
             u64 s = 0;
@@ -1138,7 +1178,10 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
         lfp::launch_cm_fix(Gc, ld, Go, ldo, D, 3, half, to_mont(x), c->st);
         Ec = Eo; Gc = Go; ld = ldo; w ^= 1;
         len = half;
+        if (g_tl.on) fprintf(stderr, "[lfplus]   r1cs round %2u: gpu+sync %6.1f us, host + fix launches %6.1f us (nb %u)\n", rnd, std::chrono::duration<double, std::micro>(tB - tA).count(),
+                             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tB).count(), nb);
     }
+    LFP_MARK(c, "linearize: tables + rounds");
     // v = f at ro; va, vb, vc = the fully fixed tables
     for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(ro[j]); pt.nc[j] = to_mont(fsub(1, ro[j])); }
     u64 *eqo = Ec == E[0].as<u64>() ? E[1].as<u64>() : E[0].as<u64>();   // n words needed: only E[0] is large enough
@@ -1211,10 +1254,12 @@ extern "C" int lfplus_mlin(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcrip
     if (!ctxs || !L || !ctxs[0]) return LFPLUS_E_ARG;
     lfplus_ctx *c = ctxs[0];
     if (!cm_g_sum || !vo_sum || !cm_g || !vo) return fail(c, LFPLUS_E_ARG, "lfplus_mlin: bad arguments");
+    LFP_MARK(c, "(before mlin)");
     for (u32 i = 0; i < L; i++) {
         if (!ctxs[i]) return fail(c, LFPLUS_E_ARG, "lfplus_mlin: null instance");
         int rc = lfplus_rg_from_f(ctxs[i], b, k, l);
         if (rc) { if (i) c->err = ctxs[i]->err; return rc; }
+        LFP_MARK(ctxs[i], "mlin: from_f");
     }
     int rc = lfplus_cm_prove(ctxs, L, tr, l, nM, rowptr, col, val, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, comh, pa, pb, ea, eb, cm_g, ro, vo, nullptr);
     if (rc) return rc;

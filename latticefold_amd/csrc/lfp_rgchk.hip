@@ -63,39 +63,58 @@ __device__ __forceinline__ void block_sum4(u64 s[4], u64 *out) {
 // entries the degree-3 round polynomial at X = 0..3,
 //     sum over the sets i entering the polynomial of  eq_i(X) * sum_j coef[i][j] (m_ij(X)^2 - m'_ij(X)),
 // coef[i][j] = rc^i alpha_i^j (a vector set: rc^i alpha_i).  part[block][4], Montgomery.
-__global__ void __launch_bounds__(256) k_sc_round(const u64 *tab, size_t ld, size_t half, ScDesc d, const u64 *coef, u64 *part) {
+// thread = (pair, set, chunk of cc columns): the late rounds have few pairs and 66 columns each -- one thread per pair would walk them all
+// (~2000 dependent Montgomery products, 60 us whatever the size); sums mod p are exact, the split changes no word of the message
+__global__ void __launch_bounds__(256) k_sc_round(const u64 *tab, size_t ld, size_t half, ScDesc d, const u64 *coef, u64 *part, u32 cc) {
     u64 s[4] = {0, 0, 0, 0};
-    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < half; b += (size_t)gridDim.x * 256) {
-        for (u32 i = 0; i < d.nsets_eff; i++) {
-            const u32 cols = i < d.nmat ? d.ncols : 1;
-            const u32 t0 = i < d.nmat ? i * (2 * d.ncols + 1) : d.nmat * (2 * d.ncols + 1) + 3 * (i - d.nmat);
-            u64 in[4] = {0, 0, 0, 0};
-            for (u32 j = 0; j < cols; j++) {
-                const u64 *tm = tab + (size_t)(t0 + 2 * j) * ld + 2 * b, *tq = tm + ld;
-                u64 m = tm[0], q = tq[0];
-                const u64 dm = sub_p(tm[1], m), dq = sub_p(tq[1], q), cf = coef[(size_t)i * d.ncols + j];
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    in[x] = add_p(in[x], mont_mul(cf, sub_p(mont_mul(m, m), q)));
-                    m = add_p(m, dm);
-                    q = add_p(q, dq);
-                }
-            }
-            const u64 *te = tab + (size_t)(t0 + 2 * cols) * ld + 2 * b;
-            u64 e = te[0];
-            const u64 de = sub_p(te[1], e);
+    const u32 mats_eff = d.nsets_eff < d.nmat ? d.nsets_eff : d.nmat, vec_eff = d.nsets_eff - mats_eff, cpm = (d.ncols + cc - 1) / cc;
+    const size_t nchunks = (size_t)mats_eff * cpm + vec_eff, total = half * nchunks;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t b = idx % half;
+        const u32 ch = (u32)(idx / half);
+        u32 i, j0, j1;
+        if (ch < mats_eff * cpm) { i = ch / cpm; j0 = (ch % cpm) * cc; j1 = j0 + cc < d.ncols ? j0 + cc : d.ncols; }
+        else { i = d.nmat + (ch - mats_eff * cpm); j0 = 0; j1 = 1; }
+        const u32 cols = i < d.nmat ? d.ncols : 1;
+        const u32 t0 = i < d.nmat ? i * (2 * d.ncols + 1) : d.nmat * (2 * d.ncols + 1) + 3 * (i - d.nmat);
+        u64 in[4] = {0, 0, 0, 0};
+        for (u32 j = j0; j < j1; j++) {
+            const u64 *tm = tab + (size_t)(t0 + 2 * j) * ld + 2 * b, *tq = tm + ld;
+            u64 m = tm[0], q = tq[0];
+            const u64 dm = sub_p(tm[1], m), dq = sub_p(tq[1], q), cf = coef[(size_t)i * d.ncols + j];
 #pragma unroll
             for (int x = 0; x < 4; x++) {
-                s[x] = add_p(s[x], mont_mul(e, in[x]));
-                e = add_p(e, de);
+                in[x] = add_p(in[x], mont_mul(cf, sub_p(mont_mul(m, m), q)));
+                m = add_p(m, dm);
+                q = add_p(q, dq);
             }
+        }
+        const u64 *te = tab + (size_t)(t0 + 2 * cols) * ld + 2 * b;
+        u64 e = te[0];
+        const u64 de = sub_p(te[1], e);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            s[x] = add_p(s[x], mont_mul(e, in[x]));
+            e = add_p(e, de);
         }
     }
     block_sum4(s, part + (size_t)blockIdx.x * 4);
 }
-u32 sc_round_blocks(size_t half) { size_t b = cdiv(half, 256); return (u32)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
-void launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part, hipStream_t s) {
-    hipLaunchKernelGGL(k_sc_round, dim3(sc_round_blocks(half)), dim3(256), 0, s, tab, ld, half, d, coef, part);
+u32 sc_round_max_blocks() { return 512; }
+// returns the number of blocks = rows of part[.][4]
+u32 launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part, hipStream_t s) {
+    const u32 mats_eff = d.nsets_eff < d.nmat ? d.nsets_eff : d.nmat, vec_eff = d.nsets_eff - mats_eff;
+    // whole sets per thread while that still fills the chip (2 x 256 threads per CU), else chunks of 4 columns, else single columns
+    u32 cc = d.ncols;
+    if (half * (mats_eff + vec_eff) < ((size_t)1 << 17)) cc = 4;
+    if (half * ((size_t)mats_eff * ((d.ncols + 3) / 4) + vec_eff) < ((size_t)1 << 17)) cc = 1;
+    if (cc > d.ncols) cc = d.ncols;
+    const size_t total = half * ((size_t)mats_eff * ((d.ncols + cc - 1) / cc) + vec_eff);
+    size_t nb = cdiv(total, 256);
+    if (nb < 1) nb = 1;
+    if (nb > sc_round_max_blocks()) nb = sc_round_max_blocks();
+    hipLaunchKernelGGL(k_sc_round, dim3((unsigned)nb), dim3(256), 0, s, tab, ld, half, d, coef, part, cc);
+    return (u32)nb;
 }
 // fix_variables of all tables: out[t][b] = in[t][2b] + r (in[t][2b+1] - in[t][2b])
 __global__ void __launch_bounds__(256) k_sc_fix(const u64 *in, u64 *out, size_t ld, size_t half, u64 rM) {
@@ -332,7 +351,8 @@ __global__ void __launch_bounds__(256) k_cm_round(const u64 *S, size_t lds, cons
         part[(size_t)blockIdx.x * 48 + threadIdx.x] = t;
     }
 }
-u32 cm_round_blocks(size_t half) { size_t b = cdiv(half, 16); return (u32)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+// (the host adds the block partials -- 48 / 64 words each, read from mapped memory -- before it can run the transcript: one block per CU at most)
+u32 cm_round_blocks(size_t half) { size_t b = cdiv(half, 16); return (u32)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
 void launch_cm_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 *part, hipStream_t s) {
     hipLaunchKernelGGL(k_cm_round, dim3(cm_round_blocks(half)), dim3(256), 0, s, S, lds, R, ldr, half, d, rcp, part);
 }
