@@ -1581,8 +1581,15 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
         for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
-    for (u32 j = 0; j < P.t; j++)
-        launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->stream());
+    {
+        // a sharded rank evaluates and fixes the entries [rank m/G, (rank+1) m/G) of the Mz tables until the fixed slices are gathered (run_lin_sumcheck):
+        // it computes only those rows (z itself stays whole: a row refers to arbitrary columns)
+        const size_t Gw = (size_t)c->sh_world;
+        const bool rows_sliced = Gw > 1 && m / 2 >= Gw * 64 && !c->tn.lin_u_eval;
+        const size_t r0 = rows_sliced ? (size_t)c->sh_rank * (m / Gw) : 0, rcnt = rows_sliced ? m / Gw : m;
+        for (u32 j = 0; j < P.t; j++)
+            launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->stream(), r0, rcnt);
+    }
     std::vector<Fq3> pt(P.s);
     // v, u at the sumcheck point (linearization.rs:126-139): u from the fully fixed Mz tables of the sumcheck (LF_LIN_U_EVAL=1: dot
     // products with eq(r) over the full tables), v from the witness planes
@@ -1894,13 +1901,13 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
         }
     }
     // u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
-    for (u32 j = 0; j < P.t; j++)
-        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->stream());
     u64 *dpart;
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
     {
         size_t c0, cnt;
-        shard_slice(c, n, &c0, &cnt);   // sharded: dot products over this rank's column slice of z_k and q_j
+        shard_slice(c, n, &c0, &cnt);   // sharded: dot products over this rank's column slice of z_k and q_j -- and only that slice of q_j is computed
+        for (u32 j = 0; j < P.t; j++)
+            launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->stream(), c0, cnt);
         RET(dot_batch_dev(c, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od_u));
         RET(exchange_modsum_dev(c, od_u, (size_t)K * P.t * 24));
     }
@@ -2453,8 +2460,12 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("dec_small", 32 * 72 + 32 * 4 * 24 + 64, &sm));
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
-    for (u32 j = 0; j < P.t; j++)
-        launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, c->stream());
+    {
+        size_t c0, cnt;
+        shard_slice(c, n, &c0, &cnt);   // (sharded: the eta inner products below read this rank's column slice of q_j only)
+        for (u32 j = 0; j < P.t; j++)
+            launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, c->stream(), c0, cnt);
+    }
     // theta for both sides first, then eta; the host absorbs theta while the GPU still computes the eta dot products
     u64 *fsm;
     RET(c->tbuf("fold_small", (size_t)K2 * 72 + (size_t)K2 * P.t * 24 + 64, &fsm));

@@ -78,13 +78,13 @@ size_t build_eq_scratch_words(u32 nv);
 void launch_build_eq2(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *scratch, u64 *eq, hipStream_t s);
 // sparse mat-vec (a7): CSR rows m; z ring table [24][n]; out ring table [24][m]; accumulate != 0 adds into out
 void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *val /*[nnz][24] AoS*/, const u64 *z,
-                 size_t ldz, u64 *out, size_t m, int accumulate, hipStream_t s);
+                 size_t ldz, u64 *out, size_t m, int accumulate, hipStream_t s, size_t r0 = 0, size_t rcnt = (size_t)-1 /* all rows */);
 // out = sum_{j<nm} M_j z_j (nm <= 4), z_j = z + j*z_stride: one launch, one write of out
 void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z,
                      size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s);
 // q[col] = sum_{rows} eq[row] * val  (CSC: colptr over n columns, rowidx, val AoS)
 void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
-                      u64 *q, size_t n, hipStream_t s);
+                      u64 *q, size_t n, hipStream_t s, size_t c0 = 0, size_t ccnt = (size_t)-1 /* all columns */);
 // dots: out[a][b] = sum_i X_a[i] (.) Y_b[i] (ring tables, slot-wise), a < na, b < nb -> out AoS [na][nb][24]
 void launch_dot_batch(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n,
                       u64 *partial, u64 *out, hipStream_t s);

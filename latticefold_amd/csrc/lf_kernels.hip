@@ -801,10 +801,10 @@ void launch_build_eq2(const DevCrt &t, const Fq3Const *r_dev, u32 nv, u64 *scrat
 // mat_vec_mul (arith/utils.rs:52-65) on CSR
 template <bool NU>
 __global__ void __launch_bounds__(256) k_spmv(DevCrt t, const u32 *rowptr, const u32 *col, const u64 *val, const u64 *z, size_t ldz,
-                                              u64 *out, size_t m, int accumulate) {
-    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                              u64 *out, size_t m, int accumulate, size_t r0, size_t rcnt) {
+    size_t row = r0 + (size_t)blockIdx.x * 256 + threadIdx.x;   // rows [r0, r0 + rcnt): a sharded rank's slice of the output table (global layout)
     u32 slot = blockIdx.y;
-    if (row >= m) return;
+    if (row >= r0 + rcnt) return;
     Fq3 acc = accumulate ? ld3(out, m, slot, row) : fq3_zero();
     for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) {
         const u64 *v = val + (size_t)k * 24 + 3 * slot;
@@ -813,8 +813,10 @@ __global__ void __launch_bounds__(256) k_spmv(DevCrt t, const u32 *rowptr, const
     st3(out, m, slot, row, acc);
 }
 void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *val, const u64 *z, size_t ldz, u64 *out, size_t m,
-                 int accumulate, hipStream_t s) {
-    LF_LAUNCH(k_spmv, t.nu2p40, dim3(cdiv(m, 256), 8), dim3(256), s, t, rowptr, col, val, z, ldz, out, m, accumulate);
+                 int accumulate, hipStream_t s, size_t r0, size_t rcnt) {
+    if (rcnt == (size_t)-1) { r0 = 0; rcnt = m; }
+    if (!rcnt) return;
+    LF_LAUNCH(k_spmv, t.nu2p40, dim3(cdiv(rcnt, 256), 8), dim3(256), s, t, rowptr, col, val, z, ldz, out, m, accumulate, r0, rcnt);
 }
 // out = sum_{j<nm} M_j z_j in one pass (fold prepare: G = sum_j M_j (sum_k zeta_k^{j+1} z_k)): one launch and one write of the
 // output instead of nm launches that each read-modify-write it
@@ -846,10 +848,10 @@ void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u3
 }
 template <bool NU>
 __global__ void __launch_bounds__(256) k_spmv_t_eq(DevCrt t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
-                                                   u64 *q, size_t n) {
-    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                   u64 *q, size_t n, size_t c0, size_t ccnt) {
+    size_t c = c0 + (size_t)blockIdx.x * 256 + threadIdx.x;   // columns [c0, c0 + ccnt): the slice a sharded rank's inner products read
     u32 slot = blockIdx.y;
-    if (c >= n) return;
+    if (c >= c0 + ccnt) return;
     Fq3 acc = fq3_zero();
     for (u32 k = colptr[c]; k < colptr[c + 1]; k++) {
         const u64 *v = val + (size_t)k * 24 + 3 * slot;
@@ -859,8 +861,10 @@ __global__ void __launch_bounds__(256) k_spmv_t_eq(DevCrt t, const u32 *colptr, 
     st3(q, n, slot, c, acc);
 }
 void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m, u64 *q, size_t n,
-                      hipStream_t s) {
-    LF_LAUNCH(k_spmv_t_eq, t.nu2p40, dim3(cdiv(n, 256), 8), dim3(256), s, t, colptr, rowidx, val, eq, m, q, n);
+                      hipStream_t s, size_t c0, size_t ccnt) {
+    if (ccnt == (size_t)-1) { c0 = 0; ccnt = n; }
+    if (!ccnt) return;
+    LF_LAUNCH(k_spmv_t_eq, t.nu2p40, dim3(cdiv(ccnt, 256), 8), dim3(256), s, t, colptr, rowidx, val, eq, m, q, n, c0, ccnt);
 }
 
 // ---------------------------------------------------------------------------------------------------------
