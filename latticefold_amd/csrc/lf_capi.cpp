@@ -158,6 +158,8 @@ struct lf_ctx {
     lfdist::Comm &cm() { return comm[t_lane]; }
     // CCS
     bool have_ccs = false;
+    // sharded step: the columns of z this rank's row slice of the constraint matrices refers to (shard_col_range; (size_t)-1 = not computed)
+    size_t shc_r0 = (size_t)-1, shc_rcnt = 0, shc_lo = 0, shc_hi = 0;
     lf_params P{};
     size_t N = 0, m = 0, n = 0;
     std::vector<u32 *> d_rowptr, d_col, d_colptr, d_rowidx;
@@ -1190,6 +1192,7 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
         HIPCHK(hipMemcpy(dvT, vT.data(), nnz * 24 * 8, hipMemcpyHostToDevice));
     }
     c->have_ccs = true;
+    c->shc_r0 = (size_t)-1;
     return LF_OK;
 }
 int lf_spmv(lf_ctx *c, unsigned j, const uint64_t *z, uint64_t *out) {
@@ -1528,6 +1531,27 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
 }
 
 // z = head (x.. , h) || w where w comes from the planes; K = 1 & mode 0 for the full witness
+// Columns [*lo, *hi) of z that rows [r0, r0 + rcnt) of the t constraint matrices refer to -- from the device CSR, once per (CCS, slice).  A sharded rank
+// needs the z-space combinations (sum_k zeta_k z_k) only there: for column-local systems (R1CS rows over their own variables, the bench's identity /
+// diagonal matrices) that is its own n / G columns, for an arbitrary CCS the whole range -- never more work than the replicated step did.
+static int shard_col_range(lf_ctx *c, size_t r0, size_t rcnt, size_t *lo, size_t *hi) {
+    if (c->shc_r0 != r0 || c->shc_rcnt != rcnt) {
+        size_t mn = c->n, mx = 0;
+        std::vector<u32> rp(2), cl;
+        for (u32 j = 0; j < c->P.t; j++) {
+            HIPCHK(hipMemcpy(&rp[0], c->d_rowptr[j] + r0, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&rp[1], c->d_rowptr[j] + r0 + rcnt, 4, hipMemcpyDeviceToHost));
+            if (rp[1] <= rp[0]) continue;
+            cl.resize(rp[1] - rp[0]);
+            HIPCHK(hipMemcpy(cl.data(), c->d_col[j] + rp[0], cl.size() * 4, hipMemcpyDeviceToHost));
+            for (u32 v : cl) { if (v < mn) mn = v; if ((size_t)v + 1 > mx) mx = (size_t)v + 1; }
+        }
+        if (mx <= mn) { mn = 0; mx = 0; }
+        c->shc_r0 = r0; c->shc_rcnt = rcnt; c->shc_lo = mn; c->shc_hi = mx;
+    }
+    *lo = c->shc_lo; *hi = c->shc_hi;
+    return LF_OK;
+}
 static int build_z(lf_ctx *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads /* K*(l+1) ring AoS host */, u64 *z /* [K][24][n] */) {
     const lf_params &P = c->P;
     u32 hl = P.l + 1;
@@ -2156,6 +2180,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         RET(c->tbuf("fold_round_out", 5 * 24 + 8, &od_shard));
         od = od_shard;
     }
+    // sharded from round 1 on (the condition of the round loop below): the special tables live as entry slices until the hand-over to the replicated tail
+    const bool shard_tabs = c->sh_world > 1 && m / 2 >= (size_t)c->sh_world * 64;
+    const size_t g_r0 = shard_tabs ? (size_t)c->sh_rank * (m / (size_t)c->sh_world) : 0, g_rcnt = shard_tabs ? m / (size_t)c->sh_world : (size_t)-1;
+    size_t zc_lo = 0, zc_hi = n;
+    if (shard_tabs) RET(shard_col_range(c, g_r0, g_rcnt, &zc_lo, &zc_hi));
     {
         // G = sum_j M_j (sum_k zeta_k^{j+1} z_k)  +  sum_k sum_d alpha_k^{d+1} fhat_{k,d}: the two sides are independent chains -- the right one runs on
         // the (idle) stream of the helper lane next to the left one: the SpMV gathers of one side overlap the multiply-bound combination of the other
@@ -2170,9 +2199,10 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         for (int sd = 0; sd < 2; sd++) {
             hipStream_t st = sd ? s1 : s0;
             u64 *zb = sd ? zz1 : zz;
-            launch_lincomb_z(c->dcrt, S[sd].z, n, K, d_zp + (size_t)sd * K * P.t, P.t, n, zb, st);
-            launch_spmv_sum(c->dcrt, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zb, (size_t)24 * n, n, G[sd], m, st);
-            launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, st);
+            launch_lincomb_z(c->dcrt, S[sd].z + zc_lo, n, K, d_zp + (size_t)sd * K * P.t, P.t, zc_hi - zc_lo, zb + zc_lo, st);   // (sharded: the columns the rank's rows of G read)
+            // (a sharded rank evaluates and fixes only the entries [rank m/G, (rank+1) m/G) of the special tables until they are gathered: only those rows of G)
+            launch_spmv_sum(c->dcrt, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zb, (size_t)24 * n, n, G[sd], m, st, g_r0, g_rcnt);
+            launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, st, g_r0, g_rcnt);
         }
         if (s1 != s0) {
             HIPCHK(hipEventRecord(c->ev_prep[1], s1));
@@ -2257,7 +2287,20 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             if (use_sv && sv_two_streams && !sharded && (int)round <= c->tn.sv_rounds && round <= 3 && nn / 2 >= c->tn.sv_min && sv_shape_ok(1 << (round - 1), nn / 2, K))
                 sg = c->st_lane[1];
             sv_g_stream = sg;
-            if (round == 2) {   // sources are the five separate full-size tables
+            if (sharded) {
+                // this rank's entries [rank nn/G, (rank+1) nn/G) of the new tables come from its own entries of the old ones
+                const size_t j0 = gr * (nn / Gw), jc = nn / Gw;
+                if (round == 2) {
+                    launch_fix_many(c->dcrt, a.eqL + 2 * j0, a.ld, dst + j0, nn, 2 * jc, 1, r, sg);
+                    launch_fix_many(c->dcrt, a.eqR + 2 * j0, a.ld, dst + 3 * nn + j0, nn, 2 * jc, 1, r, sg);
+                    launch_fix_many(c->dcrt, a.eqB + 2 * j0, a.ld, dst + 6 * nn + j0, nn, 2 * jc, 1, r, sg);
+                    launch_fix_many(c->dcrt, a.G1 + 2 * j0, a.ld, dst + 9 * nn + j0, nn, 2 * jc, 8, r, sg);
+                    launch_fix_many(c->dcrt, a.G2 + 2 * j0, a.ld, dst + 33 * nn + j0, nn, 2 * jc, 8, r, sg);
+                } else {
+                    launch_fix_many(c->dcrt, a.eqL + 2 * j0, a.ld, dst + j0, nn, 2 * jc, 19, r, sg);
+                }
+                if (nn / 2 < Gw * 64) RET(gather_slices(c, dst, 57, nn));   // hand-over to the replicated tail: every rank needs the whole tables
+            } else if (round == 2) {   // sources are the five separate full-size tables
                 launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, sg);
                 launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, sg);
                 launch_fix_many(c->dcrt, a.eqB, a.ld, dst + 6 * nn, nn, a.n, 1, r, c->stream());

@@ -81,7 +81,7 @@ void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *
                  size_t ldz, u64 *out, size_t m, int accumulate, hipStream_t s, size_t r0 = 0, size_t rcnt = (size_t)-1 /* all rows */);
 // out = sum_{j<nm} M_j z_j (nm <= 4), z_j = z + j*z_stride: one launch, one write of out
 void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z,
-                     size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s);
+                     size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s, size_t r0 = 0, size_t rcnt = (size_t)-1 /* all rows */);
 // q[col] = sum_{rows} eq[row] * val  (CSC: colptr over n columns, rowidx, val AoS)
 void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
                       u64 *q, size_t n, hipStream_t s, size_t c0 = 0, size_t ccnt = (size_t)-1 /* all columns */);
@@ -103,7 +103,7 @@ void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq
                       u64 *out, hipStream_t s, u32 per_slot = 0);
 // G[row][slot] += sum_{k<K} sum_{d<3} apow[k][d] * digit_k(planes[8d+slot][row])   (rows < n_planes)
 void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow_dev /*K*3*/,
-                          u64 *G, size_t m, hipStream_t s);
+                          u64 *G, size_t m, hipStream_t s, size_t r0 = 0, size_t rcnt = (size_t)-1 /* all positions */);
 
 // ---- sumcheck (a10) ---------------------------------------------------------------------------------------------
 // generic in-place-free fix: ring tables and fq3 tables, new[j] = old[2j] + r*(old[2j+1]-old[2j])

@@ -822,10 +822,10 @@ void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *
 // output instead of nm launches that each read-modify-write it
 struct SpmvSet { const u32 *rowptr[4]; const u32 *col[4]; const u64 *val[4]; const u64 *z[4]; u32 nm; };
 template <bool NU>
-__global__ void __launch_bounds__(256) k_spmv_sum(DevCrt t, SpmvSet ms, size_t ldz, u64 *out, size_t m) {
-    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) k_spmv_sum(DevCrt t, SpmvSet ms, size_t ldz, u64 *out, size_t m, size_t r0, size_t rcnt) {
+    size_t row = r0 + (size_t)blockIdx.x * 256 + threadIdx.x;   // rows [r0, r0 + rcnt) of the m-row table
     u32 slot = blockIdx.y;
-    if (row >= m) return;
+    if (row >= r0 + rcnt) return;
     Fq3 acc = fq3_zero();
 #pragma unroll
     for (u32 j = 0; j < 4; j++) {
@@ -840,11 +840,13 @@ __global__ void __launch_bounds__(256) k_spmv_sum(DevCrt t, SpmvSet ms, size_t l
     st3(out, m, slot, row, acc);
 }
 void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z,
-                     size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s) {
+                     size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s, size_t r0, size_t rcnt) {
+    if (rcnt == (size_t)-1) { r0 = 0; rcnt = m; }
+    if (!rcnt) return;
     SpmvSet ms = {};
     ms.nm = nm;
     for (u32 j = 0; j < nm && j < 4; j++) { ms.rowptr[j] = rowptr[j]; ms.col[j] = col[j]; ms.val[j] = val[j]; ms.z[j] = z + (size_t)j * z_stride; }
-    LF_LAUNCH(k_spmv_sum, t.nu2p40, dim3(cdiv(m, 256), 8), dim3(256), s, t, ms, ldz, out, m);
+    LF_LAUNCH(k_spmv_sum, t.nu2p40, dim3(cdiv(rcnt, 256), 8), dim3(256), s, t, ms, ldz, out, m, r0, rcnt);
 }
 template <bool NU>
 __global__ void __launch_bounds__(256) k_spmv_t_eq(DevCrt t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
@@ -1067,6 +1069,7 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevCrt t, const u64 *z, size_
     for (int j = 0; j < TT; j++) st3(out + (size_t)j * 24 * ldz, ldz, slot, i, NU ? lh5_finish(acc[j]) : accg[j]);
 }
 void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq3Const *coef_dev, u32 tt, size_t n, u64 *out, hipStream_t s, u32 per_slot) {
+    if (!n) return;
 #define LF_LZ(N)                                                                                                                              \
     do {                                                                                                                                      \
         if (t.nu2p40) hipLaunchKernelGGL((k_lincomb_z<true, N>), dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, z, ldz, K, coef_dev, n, out, per_slot);    \
@@ -1084,7 +1087,7 @@ void launch_lincomb_z(const DevCrt &t, const u64 *z, size_t ldz, u32 K, const Fq
 // Nibble tables: sum_k apow[k][d] * digit_k(v) = sign(v) * sum_q T[d][q][(|v| >> 4q) & 15], T[d][q][val] = sum_{b<4, bit b of val} apow[4q+b][d]
 // (192 F_{p^3} values built in LDS per block): 12 look-ups and additions per row and slot instead of a 48-iteration bit loop.
 template <int NQ>   // nibbles of |v|: 4 for K <= 16 bit-planes, 8 for K <= 32
-__global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow, u64 *G, size_t m) {
+__global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow, u64 *G, size_t m, size_t r0, size_t r1) {
     __shared__ u64 T[3 * NQ * 16][4];
     for (u32 e = threadIdx.x; e < 3 * NQ * 16; e += 256) {
         u32 val = e % 16, q = (e / 16) % NQ, d = e / (16 * NQ);
@@ -1097,9 +1100,9 @@ __global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, si
         T[e][0] = sum.c[0]; T[e][1] = sum.c[1]; T[e][2] = sum.c[2]; T[e][3] = 0;
     }
     __syncthreads();
-    size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t row = r0 + (size_t)blockIdx.x * 256 + threadIdx.x;   // positions [r0, r1)
     u32 slot = blockIdx.y;
-    if (row >= n_planes) return;
+    if (row >= r1) return;
     Fq3 acc = ld3(G, m, slot, row);
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -1116,9 +1119,12 @@ __global__ void __launch_bounds__(256) k_add_fhat_comb(const int32_t *planes, si
     st3(G, m, slot, row, acc);
 }
 void launch_add_fhat_comb(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 K, const Fq3Const *apow_dev, u64 *G, size_t m,
-                          hipStream_t s) {
-    if (K <= 16) hipLaunchKernelGGL(k_add_fhat_comb<4>, dim3(cdiv(n_planes, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m);
-    else hipLaunchKernelGGL(k_add_fhat_comb<8>, dim3(cdiv(n_planes, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m);
+                          hipStream_t s, size_t r0, size_t rcnt) {
+    size_t r1 = rcnt == (size_t)-1 ? n_planes : (r0 + rcnt < n_planes ? r0 + rcnt : n_planes);   // positions [r0, r1) of the n_planes the witness covers
+    if (rcnt == (size_t)-1) r0 = 0;
+    if (r1 <= r0) return;
+    if (K <= 16) hipLaunchKernelGGL(k_add_fhat_comb<4>, dim3(cdiv(r1 - r0, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m, r0, r1);
+    else hipLaunchKernelGGL(k_add_fhat_comb<8>, dim3(cdiv(r1 - r0, 256), 8), dim3(256), 0, s, planes, n_planes, K, apow_dev, G, m, r0, r1);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ WORKER = textwrap.dedent('''
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     out = {}
     for name in os.environ["LF_CASES"].split(","):
-        wl = make_workload(name)
+        wl = make_workload(name.split("/")[0], ccs=name.split("/")[1]) if "/" in name else make_workload(name)   # "T12/multi": another constraint system
         def run(sharded):
             ctx = api.Context(0, ring=wl.ring)
             tr = lambda: api.PoseidonTranscript(ring=wl.ring)
@@ -62,7 +62,10 @@ def _free_port():
 # them -- in the sharded run on the ranks' pair slices, in the unsharded reference on whole tables
 @pytest.mark.parametrize("world,cases,two_lanes", [(2, "T10,G5,T12", False), (4, "T12", False), (2, "T12", True), (2, "B8,B10,BDP", False), (4, "B14", False),
                                                    (2, "T12,T14", "big"), (4, "T14", "big"), (2, "T12", "plain"), (8, "T14", "big"),
-                                                   (2, "T14", "gemm"), (8, "T14", "gemm")])
+                                                   (2, "T14", "gemm"), (8, "T14", "gemm"),
+                                                   # rows that refer to a neighbour's (and, wrapping round, to rank 0's) columns, and four matrices: the z-space
+                                                   # combinations of a rank cover the columns its rows of G read (shard_col_range), not just its own slice
+                                                   (2, "T10/multi,T12/deg3", False), (4, "T12/multi", "big")])
 def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
