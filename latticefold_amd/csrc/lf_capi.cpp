@@ -1535,6 +1535,8 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
 // needs the z-space combinations (sum_k zeta_k z_k) only there: for column-local systems (R1CS rows over their own variables, the bench's identity /
 // diagonal matrices) that is its own n / G columns, for an arbitrary CCS the whole range -- never more work than the replicated step did.
 static int shard_col_range(lf_ctx *c, size_t r0, size_t rcnt, size_t *lo, size_t *hi) {
+    static std::mutex mu;   // (the two lanes of a step may ask at the same time)
+    std::lock_guard<std::mutex> g(mu);
     if (c->shc_r0 != r0 || c->shc_rcnt != rcnt) {
         size_t mn = c->n, mx = 0;
         std::vector<u32> rp(2), cl;
@@ -1552,10 +1554,13 @@ static int shard_col_range(lf_ctx *c, size_t r0, size_t rcnt, size_t *lo, size_t
     *lo = c->shc_lo; *hi = c->shc_hi;
     return LF_OK;
 }
-static int build_z(lf_ctx *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads /* K*(l+1) ring AoS host */, u64 *z /* [K][24][n] */) {
+// w0 / wcnt (optional): only the witness columns [w0, w0 + wcnt) -- z columns l + 1 + w0 .. -- are built (a sharded rank's slice; the heads always)
+static int build_z(lf_ctx *c, const int32_t *planes, u32 K, int mode_bits, const u64 *heads /* K*(l+1) ring AoS host */, u64 *z /* [K][24][n] */,
+                   size_t w0 = 0, size_t wcnt = (size_t)-1) {
     const lf_params &P = c->P;
     u32 hl = P.l + 1;
-    launch_recompose_crt(c->dcrt, planes, c->N, P.wit_len, P.L, P.B, K, mode_bits, z, c->n, hl, c->stream());
+    if (wcnt == (size_t)-1) { w0 = 0; wcnt = P.wit_len; }
+    if (wcnt) launch_recompose_crt(c->dcrt, planes + w0 * P.L, c->N, (u32)wcnt, P.L, P.B, K, mode_bits, z, c->n, hl + w0, c->stream());
     // heads: write plane entries 0..l of each table
     std::vector<u64> h((size_t)K * 24 * hl);
     for (u32 k = 0; k < K; k++)
@@ -1881,7 +1886,23 @@ static int decompose_prepare_z(lf_ctx *c, const u64 *xh /* (l+1) elements: x_w |
     int rc = c->tbuf("z_" + std::string(side), (size_t)K * 24 * c->n, &z);
     if (rc == LF_OK) {
         compute_x_s(c, xh, x_s);
-        rc = build_z(c, wit->planes, K, 1, x_s, z);
+        // a sharded rank reads z_k in its column slice (the u_s / eta inner products) and in the columns its rows of G refer to (the z-space
+        // combination of fold prepare): it builds the range that covers both -- its own n / G columns for a column-local constraint system
+        size_t w0 = 0, wcnt = (size_t)-1;
+        const size_t Gw = (size_t)c->sh_world, hl = P.l + 1;
+        if (Gw > 1 && c->m / 2 >= Gw * 64) {
+            size_t c0, ccnt, lo, hi;
+            shard_slice(c, c->n, &c0, &ccnt);
+            rc = shard_col_range(c, (size_t)c->sh_rank * (c->m / Gw), c->m / Gw, &lo, &hi);
+            if (hi <= lo) { lo = c0; hi = c0 + ccnt; }
+            if (c0 < lo) lo = c0;
+            if (c0 + ccnt > hi) hi = c0 + ccnt;
+            w0 = lo > hl ? lo - hl : 0;
+            const size_t w1 = hi > hl ? hi - hl : 0;
+            wcnt = w1 > w0 ? w1 - w0 : 0;
+            if (w0 + wcnt > P.wit_len) wcnt = P.wit_len > w0 ? P.wit_len - w0 : 0;
+        }
+        if (rc == LF_OK) rc = build_z(c, wit->planes, K, 1, x_s, z, w0, wcnt);
     }
     if (rc == LF_OK && !S.z_ev && hipEventCreateWithFlags(&S.z_ev, hipEventDisableTiming) != hipSuccess) rc = LF_ERR_HIP;
     if (rc == LF_OK && hipEventRecord(S.z_ev, c->stream()) != hipSuccess) rc = LF_ERR_HIP;
