@@ -369,7 +369,13 @@ class Context:
     def fold_paths(self):
         m = C.c_uint()
         _chk(_lib().lf_last_fold_paths(self.h, C.byref(m)), "lf_last_fold_paths")
-        return m.value
+        return m.value & 0xFF
+
+    def lin_split_rounds(self):
+        """rounds of the last linearization sumcheck that ran in the split eq form (bits 8..15 of lf_last_fold_paths) -- test hook"""
+        m = C.c_uint()
+        _chk(_lib().lf_last_fold_paths(self.h, C.byref(m)), "lf_last_fold_paths")
+        return (m.value >> 8) & 0xFF
 
     def timeline(self):
         """[(mark, ms since the start of the step)] of the last fold step (wall clock of the calling thread)"""

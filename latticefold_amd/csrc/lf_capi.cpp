@@ -199,6 +199,7 @@ struct lf_ctx {
     hipEvent_t ev_aux = nullptr;
     u64 *h_aux = nullptr;   // pinned, 1 KB: the known part of the point
     unsigned sv_round_mask = 0;      // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
+    unsigned lin_split_rounds = 0;   // rounds of the last linearization sumcheck that ran in the split eq form (run_lin_sumcheck)
 
     int buf(const std::string &name, size_t bytes, void **out) {
         DevBuf *b;
@@ -1451,8 +1452,11 @@ static int lin_tail_rounds(lf_ctx *c, Transcript &tr, const u64 *cur, const u64 
 // `u_dev` (optional): the Mz tables fixed at the whole point, i.e. u_j = Mz_j(r) (t ring elements, canonical) -- the last fix of the
 // tables the rounds work on, so linearization.rs:136's evaluate_mles pass over the full tables is not needed.
 // after_round (optional): called with the round number as soon as that round's challenge is known
+// beta (optional): the point of eqb.  With it the large rounds of an unsharded run use the split form of the eq factor (k_lin_round SPLIT): the kernel sums
+// E_i[p] h(X, p) at d of the d + 2 points and the host completes the message -- g_i(X) = c_i eq(beta_i, X) T_i(X), T_i(1) from g_i(0) + g_i(1) = g_{i-1}(r_{i-1}),
+// the top point by extrapolation of the degree-d T_i -- in exact field arithmetic: the words of the reference's message.
 static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 *eqb, u64 *msgs /* s*(d+2) ring */, Fq3 *point, u64 *u_dev = nullptr,
-                            const std::function<void(u32)> *after_round = nullptr) {
+                            const std::function<void(u32)> *after_round = nullptr, const Fq3 *beta = nullptr) {
     const lf_params &P = c->P;
     u32 deg = P.d + 1;
     size_t m = c->m;
@@ -1475,7 +1479,31 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     bool sharded = Gw > 1 && m / 2 >= Gw * 64;
     u64 *od_dev = nullptr;
     if (Gw > 1) RET(c->tbuf("lin_round_out", 5 * 24 + 8, &od_dev));
+    // split form: while `split` is set, cure is the per-pair table E_i of the round i that ran last (in fe[(i - 1) & 1]) and c_lvl = c_i = prod_{k<i} eq(beta_k, r_k)
+    const u32 dT = P.d;                                          // degree of T_i; the message has degree dT + 1 = deg
+    bool split = beta && Gw == 1 && !c->tn.lin_no_split && !c->tn.lin_unfused && P.s >= 2 && m >= c->tn.lin_split_min && m >= 16 && dT >= 1 && deg <= 4;
+    Fq3 c_lvl = fq3_one();
+    auto f3zero = [](const Fq3 &x) { return !(x.c[0] | x.c[1] | x.c[2]); };
+    auto eq1 = [&](const Fq3 &b, const Fq3 &r) {   // eq(beta, r) = (1 - beta)(1 - r) + beta r
+        return fq3_add(c->ring.mul3(fq3_sub(fq3_one(), b), fq3_sub(fq3_one(), r)), c->ring.mul3(b, r));
+    };
+    if (split) RET(build_eq_dev(c, beta + 1, P.s - 1, fe[0]));   // E_1 = eq((beta_2..beta_s), .), m / 2 entries
+    c->lin_split_rounds = 0;
     for (u32 round = 1; round <= P.s; round++) {
+        if (split && round >= 2) {
+            // stay in the split form?  Not into the persistent tail, not below the size where it pays, not when c_i or beta_i cannot be divided by
+            const bool tail_next = !c->tn.no_tail && n <= c->tn.tail_n && n >= 4 && P.s - round + 1 <= TAIL_MAX_ROUNDS;
+            const Fq3 c_next = c->ring.mul3(c_lvl, eq1(beta[round - 2], point[round - 2]));
+            if (tail_next || n < 8 || n / 2 < c->tn.lin_split_min || f3zero(c_next) || f3zero(beta[round - 1])) {
+                // back to the ordinary table of the previous round's n entries: eq(beta, (r_1..r_{i-1}, b, p)) = c_i eq(beta_i, b) E_i[p] at entry 2p + b
+                u64 *ex;
+                RET(c->tbuf("lin_eexp", 3 * n, &ex));
+                const Fq3 bi = beta[round - 2];
+                launch_eq_expand(c->dcrt, cure, n / 2, n / 2, f3c(c->ring.mul3(c_lvl, fq3_sub(fq3_one(), bi))), f3c(c->ring.mul3(c_lvl, bi)), ex, n, c->stream());
+                cure = ex;
+                split = false;
+            } else c_lvl = c_next;
+        }
         // persistent tail (k_lin_tail): all remaining rounds in one launch once the tables are small, as in the folding sumcheck
         if (!sharded && !c->tn.no_tail && round >= 2 && n <= c->tn.tail_n && n >= 4 && P.s - round + 1 <= TAIL_MAX_ROUNDS) {
             int trc = lin_tail_rounds(c, tr, cur, cure, n, fx[flip], partial, round, point, msgs, deg, after_round);
@@ -1491,13 +1519,13 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
                 const size_t e0 = gr * (n / Gw), ecnt = n / Gw;   // this rank's entries of the previous tables -> entries [e0/2, (e0+ecnt)/2)
                 launch_fix_many(c->dcrt, cur + e0, n, fx[flip] + e0 / 2, n / 2, ecnt, P.t * 8, r, c->stream());
                 launch_fix_many(c->dcrt, cure + e0, n, fe[flip] + e0 / 2, n / 2, ecnt, 1, r, c->stream());
-            } else if (Gw == 1 && !c->tn.lin_unfused && n >= 8) {
+            } else if (split || (Gw == 1 && !c->tn.lin_unfused && n >= 8)) {
                 fused_now = true;   // fix_variables inside the round kernel (one pass over the previous tables instead of a k_fix pass + a read)
             } else {
                 launch_fix_many(c->dcrt, cur, n, fx[flip], n / 2, n, P.t * 8, r, c->stream());
                 launch_fix_many(c->dcrt, cure, n, fe[flip], n / 2, n, 1, r, c->stream());
             }
-            cur = fx[flip]; cure = fe[flip];
+            cur = fx[flip]; cure = split ? fe[(round - 1) & 1] : fe[flip];   // (split: E_round, one entry per pair of the new tables)
             flip ^= 1;
             n /= 2;
             if (sharded && n / 2 < Gw * 64) {   // hand-over to the replicated tail
@@ -1512,10 +1540,70 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
             launch_lin_round(c->dcrt, c->desc, cur + 2 * p0, n, cure + 2 * p0, n, 2 * pcnt, deg, partial, od_dev, c->stream(), c->lin_blocks);
             RET(exchange_modsum_dev(c, od_dev, (size_t)(deg + 1) * 24));
             HIPCHK(hipMemcpyAsync(od, od_dev, (size_t)(deg + 1) * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
+        } else if (split) {
+            // the points the kernel evaluates: all of 0..dT in round 1 (no previous message to take T(1) from), 0 and 2..dT afterwards
+            const u32 xmask = round == 1 ? (1u << (dT + 1)) - 1 : (((1u << (dT + 1)) - 1) & ~2u);
+            if (round == 1) launch_lin_round(c->dcrt, c->desc, cur, n, fe[0], n / 2, n, deg, partial, od, c->stream(), c->lin_blocks, xmask);
+            else launch_lin_round_fused(c->dcrt, c->desc, prev, prevn, preve, prevn / 2, f3c(point[round - 2]), (u64 *)cur, n, (u64 *)cure, n / 2, n, deg, partial, od, c->stream(),
+                                        c->lin_blocks, xmask);
+            if (round == 1) cure = fe[0];
         } else if (fused_now)
             launch_lin_round_fused(c->dcrt, c->desc, prev, prevn, preve, prevn, f3c(point[round - 2]), (u64 *)cur, n, (u64 *)cure, n, n, deg, partial, od, c->stream(), c->lin_blocks);
         else launch_lin_round(c->dcrt, c->desc, cur, n, cure, n, n, deg, partial, od, c->stream(), c->lin_blocks);
         RET(c->lane_sync());                                  // the message is in mapped host memory
+        if (split) {
+            // od[X][slot] = T(X) = sum_p E[p] h(X, p) at the evaluated X: complete the message g(X) = c_i eq(beta_i, X) T(X), X = 0..deg
+            HostTimer ht2(c);
+            c->lin_split_rounds++;
+            const Fq3 bi = beta[round - 1], obi = fq3_sub(fq3_one(), bi);
+            Fq3 wS[5];   // Lagrange weights of the previous message at r_{i-1} (nodes 0..deg)
+            Fq3 cinv = fq3_one(), binv = fq3_one();
+            if (round >= 2) {
+                const Fq3 x = point[round - 2];
+                for (u32 j = 0; j <= deg; j++) {
+                    Fq3 num = fq3_one();
+                    u64 den = 1;
+                    for (u32 k = 0; k <= deg; k++) {
+                        if (k == j) continue;
+                        num = c->ring.mul3(num, fq3_sub(x, fq3_make(k, 0, 0)));
+                        den = fq_mul(den, j > k ? (u64)(j - k) : LF_P - (u64)(k - j));
+                    }
+                    const u64 di = fq_inv(den);
+                    wS[j] = fq3_make(fq_mul(num.c[0], di), fq_mul(num.c[1], di), fq_mul(num.c[2], di));
+                }
+                cinv = c->ring.inv3(c_lvl);
+                binv = c->ring.inv3(bi);
+            }
+            const u64 *prev_ev = round >= 2 ? msgs + (size_t)(round - 2) * (deg + 1) * 24 : nullptr;
+            static const int binom[5][6] = {{1}, {1, 1}, {1, 2, 1}, {1, 3, 3, 1}, {1, 4, 6, 4, 1}};
+            for (u32 slot = 0; slot < 8; slot++) {
+                Fq3 T[5];
+                for (u32 X = 0; X <= dT; X++) T[X] = fq3_make(od[X * 24 + 3 * slot], od[X * 24 + 3 * slot + 1], od[X * 24 + 3 * slot + 2]);
+                if (round >= 2) {
+                    Fq3 S = fq3_zero();
+                    for (u32 j = 0; j <= deg; j++)
+                        S = fq3_add(S, c->ring.mul3(wS[j], fq3_make(prev_ev[j * 24 + 3 * slot], prev_ev[j * 24 + 3 * slot + 1], prev_ev[j * 24 + 3 * slot + 2])));
+                    // c (l(0) T(0) + l(1) T(1)) = S,  l(0) = 1 - beta_i, l(1) = beta_i
+                    T[1] = c->ring.mul3(fq3_sub(c->ring.mul3(S, cinv), c->ring.mul3(obi, T[0])), binv);
+                }
+                // T has degree dT: its value at dT + 1 from the dT + 1 below (the (dT+1)-th finite difference vanishes)
+                Fq3 top = fq3_zero();
+                for (u32 j = 0; j <= dT; j++) {
+                    Fq3 term = T[j];
+                    Fq3 acc = fq3_zero();
+                    for (int q = 0; q < binom[dT + 1][j]; q++) acc = fq3_add(acc, term);
+                    top = ((dT - j) & 1) ? fq3_sub(top, acc) : fq3_add(top, acc);
+                }
+                T[dT + 1] = top;
+                Fq3 l = obi;   // eq(beta_i, X) = (1 - beta_i) + X (2 beta_i - 1)
+                const Fq3 dl = fq3_sub(bi, obi);
+                for (u32 X = 0; X <= deg; X++) {
+                    const Fq3 g = c->ring.mul3(c->ring.mul3(c_lvl, l), T[X]);
+                    ev[X * 24 + 3 * slot] = g.c[0]; ev[X * 24 + 3 * slot + 1] = g.c[1]; ev[X * 24 + 3 * slot + 2] = g.c[2];
+                    l = fq3_add(l, dl);
+                }
+            }
+        } else
         memcpy(ev, od, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
@@ -1669,7 +1757,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
         vsp.launched = ok;
         vsp.failed = !ok;
     };
-    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72, vsp.armed ? &vs_hook : nullptr));
+    RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + 72, vsp.armed ? &vs_hook : nullptr, beta.data()));
     if (vsp.failed) { (void)hipStreamSynchronize(c->st_aux); return LF_ERR_HIP; }
     if (!vsp.launched) RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * 24, *u = v + 3 * 24;   // contiguous: v[3 ring] u[t ring]
@@ -3189,7 +3277,7 @@ int lf_last_timeline(lf_ctx *c, char *names, double *ms, int max_marks) {
 extern "C" int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_prof((unsigned long long *)out64) : LF_ERR_INVALID; }
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
-    *sv_round_mask = c->bb ? 0u : c->sv_round_mask;
+    *sv_round_mask = c->bb ? 0u : (c->sv_round_mask | (c->lin_split_rounds << 8));
     return LF_OK;
 }
 int lf_last_kernel_stats(lf_ctx *c, float *fold_ms, int *fold_n, float *aj_ms, int *aj_n) {

@@ -133,9 +133,11 @@ struct LinCombDesc {  // CCS multiset structure for the linearization comb (nifs
 // max_blocks (0 = default 256 per slot) bounds the grid: inside a fold step the linearization shares the GPU with the commit chain
 // of the other lane, which is the critical path, and yields to it by running on fewer workgroups
 void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
-                      u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
+                      u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0, u32 split_xmask = 0 /* see k_lin_round: eq = the per-pair table E_i */);
 void launch_lin_round_fused(const DevCrt &t, const LinCombDesc &desc, const u64 *mz_prev, size_t ld_prev, const u64 *eq_prev, size_t ldeq_prev, Fq3Const r, u64 *mz_out,
-                            size_t ld_out, u64 *eq_out, size_t ldeq_out, size_t n, u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
+                            size_t ld_out, u64 *eq_out, size_t ldeq_out, size_t n, u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0,
+                            u32 split_xmask = 0 /* eq_prev = E_{i-1}, eq_out = E_i (per pair) */);
+void launch_eq_expand(const DevCrt &t, const u64 *E, size_t lde, size_t pairs, Fq3Const w0, Fq3Const w1, u64 *out, size_t ldo, hipStream_t s);
 
 struct FoldRoundArgs {
     const u64 *eqL, *eqR, *eqB;  // fq3 tables [3][ld]

@@ -1203,9 +1203,13 @@ __device__ __forceinline__ void add_poly_evals(Fq3 (&acc)[NP], const Fq3 *co, in
 // FUSED: fix_variables of the previous round's tables (mz / eq hold 2n entries per row, ld / ldeq their strides) with rfix happens here: pair p is built from
 // the entries 4p..4p+3 and stored to mzo / eqo (n entries per row) for the next round -- no separate k_fix pass over the tables
 struct LinFix { Fq3Const r; u64 *mzo; size_t ldo; u64 *eqo; size_t ldeo; };
-template <bool NU, bool FUSED>
+// SPLIT (xmask != 0 at the launch): eq(beta, (r_1..r_{i-1}, X, x)) = c_i * eq(beta_i, X) * E_i[x] with E_i = eq((beta_{i+1}..beta_s), .), one entry per
+// PAIR and no X in it -- the kernel sums E_i[p] * h(X, p) for the X of `xmask` only (the host multiplies by c_i eq(beta_i, X), derives the value at X = 1
+// from the previous round's message and extrapolates the top one: exact field arithmetic, the same message words).  `eq` is then E_i (one entry per pair;
+// FUSED: E_{i-1}, whose pair sums are E_i, stored through fx.eqo).  Half the products per pair of the plain form.
+template <bool NU, bool FUSED, bool SPLIT>
 __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
-                                                   u32 deg, u64 *partial, LinFix fx) {
+                                                   u32 deg, u64 *partial, LinFix fx, u32 xmask) {
     u32 slot = blockIdx.y;
     size_t pairs = n / 2;
     Fq3 acc[5];
@@ -1245,6 +1249,14 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
             } else { v[j] = fq3_zero(); st[j] = fq3_zero(); }
         }
         Fq3 ev, es;
+        if (SPLIT) {
+            es = fq3_zero();
+            if (FUSED) {   // E_i[p] = E_{i-1}[2p] + E_{i-1}[2p+1]  (eq(beta_i, 0) + eq(beta_i, 1) = 1)
+                const ulonglong2 e0 = *(const ulonglong2 *)(eq + 2 * p), e1 = *(const ulonglong2 *)(eq + ldeq + 2 * p), e2 = *(const ulonglong2 *)(eq + 2 * ldeq + 2 * p);
+                ev = fq3_make(fq_add(e0.x, e0.y), fq_add(e1.x, e1.y), fq_add(e2.x, e2.y));
+                if (slot == 0) { fx.eqo[p] = ev.c[0]; fx.eqo[fx.ldeo + p] = ev.c[1]; fx.eqo[2 * fx.ldeo + p] = ev.c[2]; }
+            } else ev = fq3_make(eq[p], eq[ldeq + p], eq[2 * ldeq + p]);
+        } else
         if (FUSED) {      // eq is one row shared by the 8 slot blocks: every block fixes it, block row 0 stores it
             Fq3 e1v;
             fixed_pair(eq, ldeq, p, slot == 0 ? fx.eqo : nullptr, fx.ldeo, ev, e1v);
@@ -1257,6 +1269,11 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
 #pragma unroll
         for (int X = 0; X < 5; X++) {
             if ((u32)X <= deg) {
+                if (SPLIT && !((xmask >> X) & 1)) {   // (wave-uniform) not evaluated here: step the tables past it
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = fq3_add(v[j], st[j]);
+                    continue;
+                }
                 // comb = (sum_i c_i prod_{j in S_i} v_j) * eq ; table j belongs to multiset ms[j], first[j] marks its start
                 Fq3 res = fq3_zero(), term = fq3_zero();
                 int sgn = 0;
@@ -1289,28 +1306,51 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
     if (threadIdx.x < 15) partial[(size_t)blockIdx.x * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
 }
 size_t round_partial_words() { return (size_t)RED_BLOCKS * 120; }
+// leaving the split form: the ordinary eq table of a round's n entries from the per-pair table E,  out[2p + b] = w_b * E[p]  (w_b = c eq(beta_i, b))
+template <bool NU>
+__global__ void __launch_bounds__(256) k_eq_expand(DevCrt t, const u64 *E, size_t lde, size_t pairs, Fq3Const w0, Fq3Const w1, u64 *out, size_t ldo) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= pairs) return;
+    const Fq3 e = fq3_make(E[p], E[lde + p], E[2 * lde + p]);
+    const Fq3 a = M3<NU>(e, fq3_make(w0.c[0], w0.c[1], w0.c[2]), t.nu), b = M3<NU>(e, fq3_make(w1.c[0], w1.c[1], w1.c[2]), t.nu);
+    *(ulonglong2 *)(out + 2 * p) = make_ulonglong2(a.c[0], b.c[0]);
+    *(ulonglong2 *)(out + ldo + 2 * p) = make_ulonglong2(a.c[1], b.c[1]);
+    *(ulonglong2 *)(out + 2 * ldo + 2 * p) = make_ulonglong2(a.c[2], b.c[2]);
+}
+void launch_eq_expand(const DevCrt &t, const u64 *E, size_t lde, size_t pairs, Fq3Const w0, Fq3Const w1, u64 *out, size_t ldo, hipStream_t s) {
+    if (!pairs) return;
+    LF_LAUNCH(k_eq_expand, t.nu2p40, dim3(cdiv(pairs, 256)), dim3(256), s, t, E, lde, pairs, w0, w1, out, ldo);
+}
 void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n, u32 deg,
-                      u64 *partial, u64 *out, hipStream_t s, u32 max_blocks) {
+                      u64 *partial, u64 *out, hipStream_t s, u32 max_blocks, u32 xmask) {
     u32 gb = (u32)((n / 2 + 255) / 256);
     const u32 cap = max_blocks && max_blocks < RED_BLOCKS ? max_blocks : RED_BLOCKS;
     if (gb > cap) gb = cap;
     if (gb < 1) gb = 1;
     LinFix fx = {};
-    if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx);
-    else hipLaunchKernelGGL((k_lin_round<false, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx);
+    if (xmask) {
+        if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, false, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx, xmask);
+        else hipLaunchKernelGGL((k_lin_round<false, false, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx, xmask);
+    } else
+    if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, false, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx, 0u);
+    else hipLaunchKernelGGL((k_lin_round<false, false, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz, ld, eq, ldeq, n, deg, partial, fx, 0u);
     hipLaunchKernelGGL(k_reduce_rows, dim3((deg + 1) * 24), dim3(256), 0, s, partial, gb, 120, out);
 }
 // round message with fix_variables fused: mz_prev / eq_prev hold 2n entries per row (strides ld_prev / ldeq_prev); the tables fixed with r are written to
 // mz_out / eq_out (n entries per row, strides ld_out / ldeq_out) and the message is that of the fixed tables
 void launch_lin_round_fused(const DevCrt &t, const LinCombDesc &desc, const u64 *mz_prev, size_t ld_prev, const u64 *eq_prev, size_t ldeq_prev, Fq3Const r, u64 *mz_out,
-                            size_t ld_out, u64 *eq_out, size_t ldeq_out, size_t n, u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks) {
+                            size_t ld_out, u64 *eq_out, size_t ldeq_out, size_t n, u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks, u32 xmask) {
     u32 gb = (u32)((n / 2 + 255) / 256);
     const u32 cap = max_blocks && max_blocks < RED_BLOCKS ? max_blocks : RED_BLOCKS;
     if (gb > cap) gb = cap;
     if (gb < 1) gb = 1;
     LinFix fx = {r, mz_out, ld_out, eq_out, ldeq_out};
-    if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx);
-    else hipLaunchKernelGGL((k_lin_round<false, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx);
+    if (xmask) {
+        if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, true, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx, xmask);
+        else hipLaunchKernelGGL((k_lin_round<false, true, true>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx, xmask);
+    } else
+    if (t.nu2p40) hipLaunchKernelGGL((k_lin_round<true, true, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx, 0u);
+    else hipLaunchKernelGGL((k_lin_round<false, true, false>), dim3(gb, 8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n, deg, partial, fx, 0u);
     hipLaunchKernelGGL(k_reduce_rows, dim3((deg + 1) * 24), dim3(256), 0, s, partial, gb, 120, out);
 }
 

@@ -477,6 +477,45 @@ def test_fold_step_parity_general_ccs(ctx, name, ccs):
     assert rc == 0 and (lc_v == lc_g).all()
 
 
+@pytest.mark.parametrize("name,ccs", [("T8", "r1cs"), ("G5", "r1cs"), ("T10", "r1cs"), ("T8", "deg3"), ("T10", "multi"), ("G5", "deg3")])
+@pytest.mark.parametrize("env", [{"LF_LIN_SPLIT_MIN": "16"}, {"LF_LIN_SPLIT_MIN": "16", "LF_NO_TAIL": "1"}, {"LF_LIN_SPLIT_MIN": "64", "LF_TAIL_N": "64"},
+                                 {"LF_LIN_NO_SPLIT": "1"}])
+def test_linearization_split_eq_form(ctx, name, ccs, env, monkeypatch):
+    """the large linearization rounds sum E_i[p] h(X, p) at d of the d + 2 points and the host completes the message (run_lin_sumcheck): forced
+    onto small instances -- leaving the form into the persistent tail, into the plain rounds (LF_NO_TAIL), after one round only -- the
+    linearization proof and the LCCCS must stay the oracle's, for R1CS (d = 2), the degree-3 CCS (d = 3: three evaluated points, cubic
+    extrapolation) and matrices with two entries per row; LF_LIN_NO_SPLIT=1 is the plain form of every round"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    wl = make_workload(name, ccs=ccs)
+    inst = lfo.Instance(wl)
+    ctx.load_ccs(wl)
+    scheme = api.AjtaiCommitmentScheme(ctx, matrix=wl.ajtai_matrix())
+    f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
+    wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+    cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+    acc_g, linpr_g = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+    acc_o, linpr_o = inst.linearize(lfo.Transcript(), cccs, f_coeff)
+    bad = np.nonzero((linpr_g != linpr_o).any(axis=1))[0]
+    assert bad.size == 0, f"first differing proof elements {bad[:6]} (round = index // {wl.d + 2})"
+    assert (acc_g == acc_o).all()
+    nsplit = ctx.lin_split_rounds()         # rounds that really ran in the split form
+    if "LF_LIN_NO_SPLIT" in env:
+        assert nsplit == 0
+    elif "LF_NO_TAIL" in env:
+        assert nsplit == wl.s - 3           # rounds 1 .. s - 3: the form is left when a round's tables have fewer than LF_LIN_SPLIT_MIN = 16 entries
+    else:
+        assert 1 <= nsplit < wl.s
+    # an instance that does NOT satisfy the constraint system: the claimed sum of round 1 is not zero, the derived values must still be the true ones
+    w_bad = wl.w_ccs.copy(); w_bad[1, 0] = (int(w_bad[1, 0]) + 1) % lfo.P
+    f_bad = inst.witness_from_w_ccs(w_bad)
+    wit_b = api.Witness.from_w_ccs(ctx, w_bad)
+    cccs_b = np.concatenate([wit_b.commit(scheme), wl.x_ccs])
+    acc_gb, lin_gb = api.LFLinearizationProver.prove(ctx, cccs_b, wit_b, api.PoseidonTranscript())
+    acc_ob, lin_ob = inst.linearize(lfo.Transcript(), cccs_b, f_bad)
+    assert (lin_gb == lin_ob).all() and (acc_gb == acc_ob).all()
+
+
 def test_empty_and_degenerate_inputs(ctx):
     """count = 0 / single-element calls through the ABI (the reference's element-wise maps accept empty vectors)"""
     e = np.zeros((0, RE), dtype=np.uint64)
