@@ -1269,11 +1269,7 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
 #pragma unroll
         for (int X = 0; X < 5; X++) {
             if ((u32)X <= deg) {
-                if (SPLIT && !((xmask >> X) & 1)) {   // (wave-uniform) not evaluated here: step the tables past it
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] = fq3_add(v[j], st[j]);
-                    continue;
-                }
+                if (!SPLIT || ((xmask >> X) & 1)) {   // (wave-uniform; SPLIT: the points not in xmask are only stepped past)
                 // comb = (sum_i c_i prod_{j in S_i} v_j) * eq ; table j belongs to multiset ms[j], first[j] marks its start
                 Fq3 res = fq3_zero(), term = fq3_zero();
                 int sgn = 0;
@@ -1290,6 +1286,7 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
                 }
                 if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
                 acc[X] = fq3_add(acc[X], M3<NU>(res, ev, t.nu));
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = fq3_add(v[j], st[j]);
                 ev = fq3_add(ev, es);
