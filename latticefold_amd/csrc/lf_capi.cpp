@@ -2319,6 +2319,18 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         }
     }
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
+    // split form of the GEMM rounds (lf_sv_rounds.h): eqB fixed at r_1..r_{i-1} is c_i eq(beta_i, b) E_i[p] at entry 2p + b, E_i = eq((beta_{i+1}..beta_s), .) -- one
+    // value per pair, so the GEMM of round i runs against 24 digit columns instead of 48.  E_1 here, E_2 / E_3 as pair sums when their round comes.
+    u64 *svE[3] = {nullptr, nullptr, nullptr};
+    const bool sv_split = !c->tn.fold_sv_no_split && P.s >= 4 && m >= 256;
+    if (sv_split) {
+        RET(c->tbuf("fold_svE1", 3 * (m / 2), &svE[0]));
+        RET(c->tbuf("fold_svE2", 3 * (m / 4), &svE[1]));
+        RET(c->tbuf("fold_svE3", 3 * (m / 8), &svE[2]));
+        RET(build_eq_dev(c, beta.data() + 1, P.s - 1, svE[0]));
+    }
+    Fq3 sv_c = fq3_one();   // c_i = prod_{k<i} eq(beta_k, r_k)
+    u32 svE_level = 1;      // E_1 .. E_level exist
     LF_TRACE(c, "fold prepare");
     c->ev_end(ph);
     if (t_tl && t_tl->on) { (void)hipStreamSynchronize(c->stream()); TL_MARK(" fold prepare (synced)"); }
@@ -2529,7 +2541,26 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                 HIPCHK(hipEventRecord(c->ev_prep[1], sg));
                 g_ready = c->ev_prep[1];
             }
-            if (launch_sv_round(c->dcrt, svV, sv_bits[0], sv_bits[1], N, a.eqB, a.ld, a.p0, a.pcnt, K, d_mu, d_coef, sveb, svpart, svtot, svtp, gtmp, od, c->stream(), g_ready) != 0)
+            const u64 *Ei = nullptr;
+            size_t ldE = 0;
+            Fq3Const w01[2] = {};
+            if (sv_split) {
+                // (every GEMM round so far ran in order: rounds 1..round-1 are all GEMM rounds when this one is, their challenges are pt[0..round-2])
+                sv_c = fq3_one();
+                for (u32 k = 1; k < round; k++) {
+                    const Fq3 b = beta[k - 1], r = pt[k - 1];
+                    sv_c = c->ring.mul3(sv_c, fq3_add(c->ring.mul3(fq3_sub(fq3_one(), b), fq3_sub(fq3_one(), r)), c->ring.mul3(b, r)));
+                }
+                const Fq3 bi = beta[round - 1];
+                w01[0] = f3c(c->ring.mul3(sv_c, fq3_sub(fq3_one(), bi)));
+                w01[1] = f3c(c->ring.mul3(sv_c, bi));
+                for (; svE_level < round; svE_level++)   // E_{l+1} = pair sums of E_l
+                    launch_eq_pairsum(svE[svE_level - 1], m >> svE_level, m >> (svE_level + 1), svE[svE_level], m >> (svE_level + 1), c->stream());
+                const size_t ne = m >> round;   // entries of E_round
+                Ei = svE[round - 1]; ldE = ne;
+            }
+            if (launch_sv_round(c->dcrt, svV, sv_bits[0], sv_bits[1], N, a.eqB, a.ld, a.p0, a.pcnt, K, d_mu, d_coef, sveb, svpart, svtot, svtp, gtmp, od, c->stream(), g_ready,
+                                Ei, ldE, w01) != 0)
                 return LF_ERR_UNSUPPORTED;
             c->sv_round_mask |= 1u << (round - 1);
         } else

@@ -137,6 +137,7 @@ void launch_lin_round(const DevCrt &t, const LinCombDesc &desc, const u64 *mz, s
 void launch_lin_round_fused(const DevCrt &t, const LinCombDesc &desc, const u64 *mz_prev, size_t ld_prev, const u64 *eq_prev, size_t ldeq_prev, Fq3Const r, u64 *mz_out,
                             size_t ld_out, u64 *eq_out, size_t ldeq_out, size_t n, u32 deg, u64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0,
                             u32 split_xmask = 0 /* eq_prev = E_{i-1}, eq_out = E_i (per pair) */);
+void launch_eq_pairsum(const u64 *in, size_t ld_in, size_t n_out, u64 *out, size_t ld_out, hipStream_t s);
 void launch_eq_expand(const DevCrt &t, const u64 *E, size_t lde, size_t pairs, Fq3Const w0, Fq3Const w1, u64 *out, size_t ldo, hipStream_t s);
 
 struct FoldRoundArgs {

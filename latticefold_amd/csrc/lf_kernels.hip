@@ -1314,6 +1314,17 @@ __global__ void __launch_bounds__(256) k_eq_expand(DevCrt t, const u64 *E, size_
     *(ulonglong2 *)(out + ldo + 2 * p) = make_ulonglong2(a.c[1], b.c[1]);
     *(ulonglong2 *)(out + 2 * ldo + 2 * p) = make_ulonglong2(a.c[2], b.c[2]);
 }
+// E_{i+1}[p] = E_i[2p] + E_i[2p+1]  (per-pair eq tables of the split form: eq(beta, 0) + eq(beta, 1) = 1); [3][ld] planes
+__global__ void __launch_bounds__(256) k_eq_pairsum(const u64 *in, size_t ld_in, size_t n_out, u64 *out, size_t ld_out) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_out) return;
+    const u32 q = blockIdx.y;
+    const ulonglong2 a = *(const ulonglong2 *)(in + (size_t)q * ld_in + 2 * p);
+    out[(size_t)q * ld_out + p] = fq_add(a.x, a.y);
+}
+void launch_eq_pairsum(const u64 *in, size_t ld_in, size_t n_out, u64 *out, size_t ld_out, hipStream_t s) {
+    if (n_out) hipLaunchKernelGGL(k_eq_pairsum, dim3(cdiv(n_out, 256), 3), dim3(256), 0, s, in, ld_in, n_out, out, ld_out);
+}
 void launch_eq_expand(const DevCrt &t, const u64 *E, size_t lde, size_t pairs, Fq3Const w0, Fq3Const w1, u64 *out, size_t ldo, hipStream_t s) {
     if (!pairs) return;
     LF_LAUNCH(k_eq_expand, t.nu2p40, dim3(cdiv(pairs, 256)), dim3(256), s, t, E, lde, pairs, w0, w1, out, ldo);

@@ -61,7 +61,10 @@ struct DevCrt;
 struct Fq3Const;
 int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
                     const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
-                    hipStream_t s, hipEvent_t gpart_ready = nullptr);
+                    hipStream_t s, hipEvent_t gpart_ready = nullptr,
+                    // split form (optional): eqB(2p + h) = w01[h] * E[p] with ONE value E[p] per pair (E: [3][ldE], indexed by the global pair) -- the GEMM then runs
+                    // against the 24 digit columns of E (two column tiles instead of three) and the finish multiplies by w01[0], w01[1] (host pointers)
+                    const uint64_t *E = nullptr, size_t ldE = 0, const Fq3Const *w01 = nullptr);
 // v_s[k][c][q] = sum_i eq[q][i] * digit_k(planes[c][i]) of ONE witness from its bit-plane form (the two single pairs of the round-1 GEMM);
 // out[(k*24 + c)*3 + q] canonical.  Scratch: EB sv_eb_bytes(n / 2), part sv_vs_part_words(n, K), tot sv_vs_tot_words(K).  0, or -1 (shape).
 size_t sv_vs_part_words(size_t n, uint32_t K);

@@ -73,9 +73,10 @@ __global__ void __launch_bounds__(256) k_sv_bits(const int32_t *planes, size_t l
 __host__ __device__ constexpr int sv_slot_pair(int V, int j, int q) { return (j / (4 / V)) * (16 / V) + (j % (4 / V)) + (4 / V) * q; }
 
 // EB[(24 h + 8 q + u)][slot] = balanced base-256 digit u of eqB[q][2 pair + h] in slot order;  thread = (16 pairs, word q, half h);  ld = padded pairs
-__global__ void __launch_bounds__(256) k_sv_pack_eq(const u64 *eq, size_t ld, size_t npairs, size_t ldeb, int V, unsigned char *EB) {
+// single: eq holds ONE value per pair (the split form's E_i[p], see launch_sv_round): rows 8 q + u only (24 digit rows; the caller zeroes rows 24..31)
+__global__ void __launch_bounds__(256) k_sv_pack_eq(const u64 *eq, size_t ld, size_t npairs, size_t ldeb, int V, unsigned char *EB, int single) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, groups = ldeb / 16;
-    if (gid >= groups * 6) return;
+    if (gid >= groups * (single ? 3 : 6)) return;
     const u32 qh = (u32)(gid / groups), q = qh % 3, h = qh / 3;
     const size_t p0 = (gid % groups) * 16;
     u64 w[16];
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(256) k_sv_pack_eq(const u64 *eq, size_t ld, si
         const size_t pr = p0 + (size_t)sv_slot_pair(V, t >> 2, t & 3);
         // balanced base-256 digits d_u in [-128, 127] of a representative of the word mod p: sum_u d_u 256^u = E or E - p.  With
         // s = E' + 0x80..80 in [0, 2^64) the digits are (byte_u(s) - 128), i.e. byte_u(s) ^ 0x80 as int8 -- no bias column in the GEMM
-        const u64 e = pr < npairs ? eq[(size_t)q * ld + 2 * pr + h] : 0;
+        const u64 e = pr < npairs ? (single ? eq[(size_t)q * ld + pr] : eq[(size_t)q * ld + 2 * pr + h]) : 0;
         u64 sb = e + 0x8080808080808080ull;
         if (sb < e) sb += 0xFFFFFFFFull;          // wrapped past 2^64: take E - p instead (2^64 - p = 2^32 - 1)
         w[t] = sb ^ 0x8080808080808080ull;
@@ -134,8 +135,8 @@ __device__ __forceinline__ u32 sv_operand(const u32 (&Xf)[2 * V][4], const u32 (
         return (Xf[x][j] & Xf[y][j] & Xf[z][j]) & ((S[x][j] ^ S[y][j] ^ S[z][j]) | ONES4);
     }
 }
-template <int V, int BASE, int I>
-__device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][3], const v4i (&b)[3], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
+template <int V, int BASE, int I, int NT>
+__device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                              const u32 (&D)[2 * V][4]) {
     v4i av;
     av.x = (int)sv_operand<V, BASE + I>(Xf, S, D, 0);
@@ -143,34 +144,35 @@ __device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][3]
     av.z = (int)sv_operand<V, BASE + I>(Xf, S, D, 2);
     av.w = (int)sv_operand<V, BASE + I>(Xf, S, D, 3);
 #pragma unroll
-    for (int nt = 0; nt < 3; nt++) acc[I][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[I][nt], 0, 0, 0);
+    for (int nt = 0; nt < NT; nt++) acc[I][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[I][nt], 0, 0, 0);
 }
-template <int V, int BASE, int... I>
-__device__ __forceinline__ void sv_mfma_all(v4i (&acc)[sv_pairs_per_wave(V)][3], const v4i (&b)[3], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
+template <int V, int BASE, int NT, int... I>
+__device__ __forceinline__ void sv_mfma_all(v4i (&acc)[sv_pairs_per_wave(V)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                             const u32 (&D)[2 * V][4], std::integer_sequence<int, I...>) {
-    (sv_mfma_pair<V, BASE, I>(acc, b, Xf, S, D), ...);
+    (sv_mfma_pair<V, BASE, I, NT>(acc, b, Xf, S, D), ...);
 }
 
 // waves per block = groups that share the eqB bytes of a super-step through LDS (every group needs all of them: read from L2 once per block)
 constexpr int sv_waves(int V) { return V <= 2 ? 8 : 4; }
-template <int V, int PG>
+// NT = column tiles: 3 for the 48 digit columns of (eqB(2p), eqB(2p+1)), 2 for the 24 (+ 8 zero) columns of the split form's one value per pair
+template <int V, int PG, int NT = 3>
 __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_per_eu(V <= 2 ? 2 : 1, V <= 2 ? 2 : 1))) k_sv_gemm(SvGemmArgs a) {
     constexpr int NX = 2 * V, PW = sv_pairs_per_wave(V), NPR = sv_num_pairs(V), SS = 4 / V, RPW = 4 / V;   // sub-steps per super-step, registers per word
     constexpr int NW = sv_waves(V), NTH = 64 * NW;
     constexpr int SPAIRS = 256 / V, LROW = SPAIRS + 16;            // pairs (= bytes per eqB row) of a super-step; padded LDS row: conflict-free b128 reads
-    constexpr int PIECES = 48 * SPAIRS / 16, PPT = (PIECES + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][48][LROW];
+    constexpr int PIECES = 16 * NT * SPAIRS / 16, PPT = (PIECES + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][16 * NT][LROW];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, g = lane >> 4;
     const u32 ngroups = 24 * a.nsides * a.ktiles, gq = ngroups / NW;
     const u32 grp = (blockIdx.x % gq) * NW + wave, chunk = blockIdx.x / gq;
     const u32 kt = grp % a.ktiles, c = (grp / a.ktiles) % 24, side = grp / (a.ktiles * 24);
     const u32 *mrow = a.bits[side] + ((size_t)c * a.rows + 16 * kt + row) * a.nw;
     const u32 *srow = a.bits[side] + ((size_t)c * a.rows + a.rows - 1) * a.nw;
-    v4i acc[PW][3];
+    v4i acc[PW][NT];
 #pragma unroll
     for (int i = 0; i < PW; i++)
 #pragma unroll
-        for (int nt = 0; nt < 3; nt++) acc[i][nt] = v4i{0, 0, 0, 0};
+        for (int nt = 0; nt < NT; nt++) acc[i][nt] = v4i{0, 0, 0, 0};
     const u32 u0 = chunk * a.super_per_chunk, u1 = u0 + a.super_per_chunk < a.nsuper ? u0 + a.super_per_chunk : a.nsuper;
     // staging of the eqB bytes: piece t = 16 bytes of row t / (SPAIRS/16)
     v4i st[PPT];
@@ -203,11 +205,10 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
         ws4 = *(const uint4 *)(srow + ((size_t)un * 4 + g) * 4);
 #pragma unroll
         for (int ss = 0; ss < SS; ss++) {
-            v4i b[3];
+            v4i b[NT];
             const unsigned char *lb = &lds[buf][row][g * (64 / V) + 16 * ss];
-            b[0] = *(const v4i *)lb;
-            b[1] = *(const v4i *)(lb + 16 * LROW);
-            b[2] = *(const v4i *)(lb + 32 * LROW);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b[nt] = *(const v4i *)(lb + 16 * nt * LROW);
             u32 Xf[NX][4], S[NX][4], D[NX][4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -221,16 +222,16 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
                     D[x][j] = Xf[x][j] & (S[x][j] | ONES4);
                 }
             }
-            sv_mfma_all<V, PG * PW>(acc, b, Xf, S, D, std::make_integer_sequence<int, PW>{});
+            sv_mfma_all<V, PG * PW, NT>(acc, b, Xf, S, D, std::make_integer_sequence<int, PW>{});
         }
         stage_store(buf ^ 1);
         __syncthreads();
     }
-    int32_t *o = a.part + (((size_t)chunk * ngroups + grp) * NPR + (size_t)PG * PW) * 768;
+    int32_t *o = a.part + (((size_t)chunk * ngroups + grp) * NPR + (size_t)PG * PW) * (NT * 256);
 #pragma unroll
     for (int i = 0; i < PW; i++)
 #pragma unroll
-        for (int nt = 0; nt < 3; nt++) *(v4i *)(o + ((size_t)i * 3 + nt) * 256 + lane * 4) = acc[i][nt];
+        for (int nt = 0; nt < NT; nt++) *(v4i *)(o + ((size_t)i * NT + nt) * 256 + lane * 4) = acc[i][nt];
 }
 
 __global__ void __launch_bounds__(256) k_sv_sum(const int32_t *part, size_t words, u32 chunks, int32_t *tot) {
@@ -242,8 +243,10 @@ __global__ void __launch_bounds__(256) k_sv_sum(const int32_t *part, size_t word
 }
 
 // block = table T = (side, k, c), thread = pair pi
+// split (nt == 2): the tiles hold M' = sum_p E[p] (+-1 | 0) and M_h = w_h M' (w_h = c_i eq(beta_i, h): eqB(2p + h) = w_h E[p])
 template <bool NU>
-__global__ void __launch_bounds__(128) k_sv_finish1(DevCrt t, const int32_t *tot, u32 npr, u32 K, u32 ktiles, const u64 *coef, const Fq3Const *mu_pow, u64 *tp) {
+__global__ void __launch_bounds__(128) k_sv_finish1(DevCrt t, const int32_t *tot, u32 npr, u32 K, u32 ktiles, const u64 *coef, const Fq3Const *mu_pow, u64 *tp, u32 nt, Fq3Const w0,
+                                                    Fq3Const w1) {
     const u32 T = blockIdx.x, c = T % 24, k = (T / 24) % K, side = T / (24 * K);
     const u32 grp = (side * 24 + c) * ktiles + k / 16, krow = k & 15;
     __shared__ u64 sm[15][128];
@@ -252,7 +255,7 @@ __global__ void __launch_bounds__(128) k_sv_finish1(DevCrt t, const int32_t *tot
 #pragma unroll
     for (int e = 0; e < 5; e++) P[e] = fq3_zero();
     if (pi < npr) {
-        const int32_t *base = tot + ((size_t)grp * npr + pi) * 768;
+        const int32_t *base = tot + ((size_t)grp * npr + pi) * (nt * 256);
         auto cell = [&](u32 bp) { return (long long)base[(bp >> 4) * 256 + ((bp & 15) + 16 * (krow >> 2)) * 4 + (krow & 3)]; };
         Fq3 M[2];
 #pragma unroll
@@ -260,9 +263,15 @@ __global__ void __launch_bounds__(128) k_sv_finish1(DevCrt t, const int32_t *tot
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 __int128 v = 0;
-                for (u32 u = 0; u < 8; u++) v += (__int128)cell(24 * h + 8 * q + u) << (8 * u);
+                if (nt == 3 || h == 0)
+                    for (u32 u = 0; u < 8; u++) v += (__int128)cell(24 * h + 8 * q + u) << (8 * u);
                 M[h].c[q] = fq_from_s128((u64)v, (int64_t)(v >> 64));
             }
+        if (nt != 3) {
+            const Fq3 Mp = M[0];
+            M[0] = fq3_mul<NU>(Mp, fq3_make(w0.c[0], w0.c[1], w0.c[2]), t.nu);
+            M[1] = fq3_mul<NU>(Mp, fq3_make(w1.c[0], w1.c[1], w1.c[2]), t.nu);
+        }
         const Fq3 dM = fq3_sub(M[1], M[0]);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -318,10 +327,10 @@ __global__ void __launch_bounds__(1024) k_sv_finish2(const u64 *tp, u32 K, const
     }
 }
 
-template <int V, int PG>
+template <int V, int PG, int NT = 3>
 void launch_gemm_pg(const SvGemmArgs &a, u32 grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_sv_gemm<V, PG>), dim3(grid), dim3(64 * sv_waves(V)), 0, s, a);
-    if constexpr (PG + 1 < sv_num_pairs(V) / sv_pairs_per_wave(V)) launch_gemm_pg<V, PG + 1>(a, grid, s);
+    hipLaunchKernelGGL((k_sv_gemm<V, PG, NT>), dim3(grid), dim3(64 * sv_waves(V)), 0, s, a);
+    if constexpr (PG + 1 < sv_num_pairs(V) / sv_pairs_per_wave(V)) launch_gemm_pg<V, PG + 1, NT>(a, grid, s);
 }
 
 bool sv_shape_ok(int V, size_t npairs, uint32_t K) {
@@ -359,13 +368,19 @@ size_t sv_tp_words(uint32_t K) { return (size_t)2 * K * 24 * 15; }
 
 int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
                     const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
-                    hipStream_t s, hipEvent_t gpart_ready) {
+                    hipStream_t s, hipEvent_t gpart_ready, const uint64_t *E, size_t ldE, const Fq3Const *w01) {
     // pairs of the slice behind which witness positions exist (positions >= nplanes are zero digits: nothing to add)
     const size_t wall = cdiv(nplanes, 2 * (size_t)V);
     const size_t wpairs = pair0 >= wall ? 0 : (wall - pair0 < npairs ? wall - pair0 : npairs);
     if (!sv_shape_ok(V, npairs, K) || (pair0 * V) % 256) return -1;
     const size_t ldeb = sv_ldeb(npairs);
-    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eqB + 2 * pair0, ldeq, npairs, ldeb, V, EB);
+    const bool split = E != nullptr;
+    const u32 NT = split ? 2u : 3u;
+    if (split) {   // one value per pair: 24 digit rows + 8 zero rows = two column tiles instead of three
+        (void)hipMemsetAsync(EB + 24 * ldeb, 0, 8 * ldeb, s);
+        hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 3, 256)), dim3(256), 0, s, E + pair0, ldE, npairs, ldeb, V, EB, 1);
+    } else
+    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eqB + 2 * pair0, ldeq, npairs, ldeb, V, EB, 0);
     SvGemmArgs a;
     a.bits[0] = bitsL; a.bits[1] = bitsR;
     a.ktiles = (K + 15) / 16;
@@ -380,14 +395,20 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     a.super_per_chunk = (u32)cdiv(a.nsuper, chunks);
     a.part = part;
     const u32 grid = 48 * a.ktiles / (u32)sv_waves(V) * chunks;
+    if (split) {
+        if (V == 1) launch_gemm_pg<1, 0, 2>(a, grid, s);
+        else if (V == 2) launch_gemm_pg<2, 0, 2>(a, grid, s);
+        else launch_gemm_pg<4, 0, 2>(a, grid, s);
+    } else
     if (V == 1) launch_gemm_pg<1, 0>(a, grid, s);
     else if (V == 2) launch_gemm_pg<2, 0>(a, grid, s);
     else launch_gemm_pg<4, 0>(a, grid, s);
-    const size_t words = sv_tot_words(V, K);
+    const size_t words = sv_tot_words(V, K) / 3 * NT;
     hipLaunchKernelGGL(k_sv_sum, dim3((unsigned)cdiv(words / 4, 256)), dim3(256), 0, s, part, words, chunks, tot);
     const u32 npr = (u32)sv_num_pairs(V);
-    if (t.nu2p40) hipLaunchKernelGGL((k_sv_finish1<true>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp);
-    else hipLaunchKernelGGL((k_sv_finish1<false>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp);
+    const Fq3Const wz = {{0, 0, 0}}, w0 = split ? w01[0] : wz, w1 = split ? w01[1] : wz;
+    if (t.nu2p40) hipLaunchKernelGGL((k_sv_finish1<true>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp, NT, w0, w1);
+    else hipLaunchKernelGGL((k_sv_finish1<false>), dim3(2 * K * 24), dim3(128), 0, s, t, tot, npr, K, a.ktiles, coef, mu_pow, tp, NT, w0, w1);
     if (gpart_ready) (void)hipStreamWaitEvent(s, gpart_ready, 0);   // the G part was computed on another stream
     hipLaunchKernelGGL(k_sv_finish2, dim3(1), dim3(1024), 0, s, tp, K, gpart, out);
     return 0;
@@ -421,7 +442,7 @@ int launch_sv_vs(const uint32_t *bits, size_t n, const uint64_t *eq, size_t ldeq
     const size_t npairs = n / 2;
     if ((n & 1) || !sv_shape_ok(1, npairs, K)) return -1;
     const size_t ldeb = sv_ldeb(npairs);
-    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eq, ldeq, npairs, ldeb, 1, EB);
+    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eq, ldeq, npairs, ldeb, 1, EB, 0);
     SvGemmArgs a;
     a.bits[0] = bits; a.bits[1] = bits;
     a.ktiles = (K + 15) / 16;
@@ -453,7 +474,7 @@ int launch_sv_vs_blocks(const uint32_t *bits, size_t n, const uint64_t *eq_lo, s
     const size_t bs = (size_t)1 << J, nblocks = n / bs, lo_pairs = bs / 2;
     if (nblocks > sv_vs_max_blocks(K) || !sv_shape_ok(1, n / 2, K)) return -1;
     const size_t ldeb = sv_ldeb(lo_pairs);
-    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eq_lo, ldeq, lo_pairs, ldeb, 1, EB);
+    hipLaunchKernelGGL(k_sv_pack_eq, dim3((unsigned)cdiv(ldeb / 16 * 6, 256)), dim3(256), 0, s, eq_lo, ldeq, lo_pairs, ldeb, 1, EB, 0);
     SvGemmArgs a;
     a.bits[0] = bits; a.bits[1] = bits;
     a.ktiles = (K + 15) / 16;
