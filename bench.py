@@ -137,9 +137,9 @@ def _prof(kind, wl_name):
 PHASES = [
     ("linearization (lane 0)", (None, "linearization done"), ("k_lin_round", "k_lin_tail", "k_spmv<", "k_fix_final"), "latency: ~20 dependent launches + a host transcript hop per round"),
     ("digit-plane commits (lane 1)", (None, "lane 1 joined"), ("k_ajtai_i8", "k_sv_bits"), "int8 MFMA / LDS operand traffic (roofline above)"),
-    ("decomposition evaluations (both lanes)", (None, "lane 1 joined"), ("k_dot_i8", "k_dot_pack_y", "k_spmv_t_eq", "k_recompose_crt", "k_sv_gemm<1, 0>", "k_sv_vs_finish", "k_vs_combine", "k_eq_outer", "k_build_eq", "k_eq_pack_i8", "k_coef_eval_i8"), "HBM stream of z (int8 GEMM) + VALU"),
+    ("decomposition evaluations (both lanes)", (None, "lane 1 joined"), ("k_dot_i8", "k_dot_pack_y", "k_spmv_t_eq", "k_recompose_crt", "k_sv_gemm<1, 0>", "k_sv_gemm<1, 0, 3, true>", "k_sv_vs_finish", "k_vs_combine", "k_eq_outer", "k_build_eq", "k_eq_pack_i8", "k_coef_eval_i8"), "HBM stream of z (int8 GEMM) + VALU"),
     ("host: right absorb + folding challenges", ("lane 1 joined", "fold challenges"), (), "host Poseidon chain (GPU idle)"),
-    ("fold prepare + round 1 (int8 GEMM)", ("fold challenges", "round 1"), ("k_lincomb_z", "k_spmv_sum", "k_add_fhat_comb", "k_sv_pack_eq", "k_sv_sum", "k_sv_finish1", "k_sv_finish2"), "VALU (48 lazy products per column and slot in k_lincomb_z)"),
+    ("fold prepare + round 1 (int8 GEMM)", ("fold challenges", "round 1"), ("k_lincomb_z", "k_spmv_sum", "k_add_fhat_comb", "k_sv_pack_eq", "k_sv_sum", "k_sv_finish1", "k_sv_finish2", "k_sv_gemm<1, 0, 2", "k_sv_gemm<1, 0, 3, false>", "k_eq_pairsum"), "VALU (48 lazy products per column and slot in k_lincomb_z)"),
     ("fold rounds 2-3 (int8 GEMMs)", ("round 1", "round 3"), ("k_sv_gemm<2", "k_sv_gemm<4", "k_fold_round_g"), "VALU operand generation for the MFMAs"),
     ("fold rounds 4-6 (rounds 4-5 from tables over the digit codes, then a fused-fix round)", ("round 3", "round 6"),
      ("k_fold_round<true, 4>", "k_fold_round<true, 6>", "k_fold_round<true, 7>", "k_fold_round<true, 1>", "k_fold_r4tab", "k_fold_r5tab", "k_fold_mutab", "k_fold_round_lut"),

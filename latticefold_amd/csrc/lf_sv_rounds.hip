@@ -135,28 +135,33 @@ __device__ __forceinline__ u32 sv_operand(const u32 (&Xf)[2 * V][4], const u32 (
         return (Xf[x][j] & Xf[y][j] & Xf[z][j]) & ((S[x][j] ^ S[y][j] ^ S[z][j]) | ONES4);
     }
 }
-template <int V, int BASE, int I, int NT>
+// VS (launch_sv_vs*: V = 1, NT = 3): only the two single pairs are read afterwards, pair 0 against the digits of eq(2p) (columns 0..23: tiles 0, 1) and pair 2
+// against those of eq(2p+1) (columns 24..47: tiles 1, 2) -- 4 of the 12 MFMAs of a K-step
+template <int V, int BASE, int I, int NT, bool VS>
 __device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                              const u32 (&D)[2 * V][4]) {
+    if constexpr (VS && (I == 1 || I == 3)) return;
     v4i av;
     av.x = (int)sv_operand<V, BASE + I>(Xf, S, D, 0);
     av.y = (int)sv_operand<V, BASE + I>(Xf, S, D, 1);
     av.z = (int)sv_operand<V, BASE + I>(Xf, S, D, 2);
     av.w = (int)sv_operand<V, BASE + I>(Xf, S, D, 3);
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[I][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[I][nt], 0, 0, 0);
+    for (int nt = 0; nt < NT; nt++)
+        if (!VS || (I == 0 && nt < 2) || (I == 2 && nt > 0)) acc[I][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[I][nt], 0, 0, 0);
 }
-template <int V, int BASE, int NT, int... I>
+template <int V, int BASE, int NT, bool VS, int... I>
 __device__ __forceinline__ void sv_mfma_all(v4i (&acc)[sv_pairs_per_wave(V)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                             const u32 (&D)[2 * V][4], std::integer_sequence<int, I...>) {
-    (sv_mfma_pair<V, BASE, I, NT>(acc, b, Xf, S, D), ...);
+    (sv_mfma_pair<V, BASE, I, NT, VS>(acc, b, Xf, S, D), ...);
 }
 
 // waves per block = groups that share the eqB bytes of a super-step through LDS (every group needs all of them: read from L2 once per block)
 constexpr int sv_waves(int V) { return V <= 2 ? 8 : 4; }
 // NT = column tiles: 3 for the 48 digit columns of (eqB(2p), eqB(2p+1)), 2 for the 24 (+ 8 zero) columns of the split form's one value per pair
-template <int V, int PG, int NT = 3>
+template <int V, int PG, int NT = 3, bool VS = false>
 __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_per_eu(V <= 2 ? 2 : 1, V <= 2 ? 2 : 1))) k_sv_gemm(SvGemmArgs a) {
+    static_assert(!VS || (V == 1 && NT == 3 && PG == 0), "VS: the two single pairs of the round-1 shape");
     constexpr int NX = 2 * V, PW = sv_pairs_per_wave(V), NPR = sv_num_pairs(V), SS = 4 / V, RPW = 4 / V;   // sub-steps per super-step, registers per word
     constexpr int NW = sv_waves(V), NTH = 64 * NW;
     constexpr int SPAIRS = 256 / V, LROW = SPAIRS + 16;            // pairs (= bytes per eqB row) of a super-step; padded LDS row: conflict-free b128 reads
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
                     D[x][j] = Xf[x][j] & (S[x][j] | ONES4);
                 }
             }
-            sv_mfma_all<V, PG * PW, NT>(acc, b, Xf, S, D, std::make_integer_sequence<int, PW>{});
+            sv_mfma_all<V, PG * PW, NT, VS>(acc, b, Xf, S, D, std::make_integer_sequence<int, PW>{});
         }
         stage_store(buf ^ 1);
         __syncthreads();
@@ -456,7 +461,7 @@ int launch_sv_vs(const uint32_t *bits, size_t n, const uint64_t *eq, size_t ldeq
     const u32 chunks = sv_chunks_n(1, a.nsuper, K, 1);
     a.super_per_chunk = (u32)cdiv(a.nsuper, chunks);
     a.part = part;
-    hipLaunchKernelGGL((k_sv_gemm<1, 0>), dim3(24 * a.ktiles / (u32)sv_waves(1) * chunks), dim3(64 * sv_waves(1)), 0, s, a);
+    hipLaunchKernelGGL((k_sv_gemm<1, 0, 3, true>), dim3(24 * a.ktiles / (u32)sv_waves(1) * chunks), dim3(64 * sv_waves(1)), 0, s, a);
     const size_t words = sv_vs_tot_words(K);
     hipLaunchKernelGGL(k_sv_sum, dim3((unsigned)cdiv(words / 4, 256)), dim3(256), 0, s, part, words, chunks, tot);
     hipLaunchKernelGGL(k_sv_vs_finish, dim3((unsigned)cdiv((size_t)K * 72, 256)), dim3(256), 0, s, tot, K, a.ktiles, out);
@@ -487,7 +492,7 @@ int launch_sv_vs_blocks(const uint32_t *bits, size_t n, const uint64_t *eq_lo, s
     a.eb_mod = (u32)(bs / 512);
     a.super_per_chunk = a.eb_mod;
     a.part = part;
-    hipLaunchKernelGGL((k_sv_gemm<1, 0>), dim3(24 * a.ktiles / (u32)sv_waves(1) * (u32)nblocks), dim3(64 * sv_waves(1)), 0, s, a);
+    hipLaunchKernelGGL((k_sv_gemm<1, 0, 3, true>), dim3(24 * a.ktiles / (u32)sv_waves(1) * (u32)nblocks), dim3(64 * sv_waves(1)), 0, s, a);
     return 0;
 }
 // one wave per output (k, c), lane = block b (the blocks are independent until the weighted sum): out[(k*24 + c)*3 + q]
