@@ -1,9 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-bash tools/gpu_round.sh r03c > gpurun_out/r03c_round.log 2>&1
-bash tools/gpu_lfplus_prof.sh r03c 18 > gpurun_out/r03c_lfplus.log 2>&1
-python - <<'PY' > gpurun_out/r03c_rebuild.txt 2>&1
+bash tools/gpu_round.sh r03d > gpurun_out/r03d_round.log 2>&1
+bash tools/gpu_lfplus_prof.sh r03d 18 > gpurun_out/r03d_lfplus.log 2>&1
+python - <<'PY' > gpurun_out/r03d_rebuild.txt 2>&1
 import time, numpy as np
 from latticefold_amd import api
 from latticefold_amd.workload import make_workload
@@ -23,4 +23,5 @@ for i in range(2):
     t0=time.perf_counter(); cm2 = wit.commit(scheme); t1=time.perf_counter(); print("witness commit (resident NTT form): %.1f ms" % ((t1-t0)*1e3))
 print("same commitment:", bool((cm == cm2).all()))
 PY
-ls gpurun_out | grep r03c
+ls gpurun_out | grep r03d
+# the bench lines once more, now that the profiles of this tag exist (bench.py reads profiles/<tag>_*): copy gpurun_out/<tag>_* to profiles/ first when run by hand
