@@ -43,7 +43,8 @@ constexpr SvPair sv_pair(int V, int idx) {
             }
     return SvPair{0, 0};
 }
-constexpr int sv_pairs_per_wave(int V) { return V == 1 ? 4 : (V == 2 ? 10 : 20); }
+// digit monomials per wave and launch: bounded by the accumulator registers (4 per monomial and column tile); with two column tiles (split form) twice as many fit
+constexpr int sv_pairs_per_wave(int V, int NT = 3) { return V == 1 ? 4 : (V == 2 ? (NT == 2 ? 20 : 10) : (NT == 2 ? 40 : 20)); }
 
 bool sv_shape_ok(int V, size_t npairs, uint32_t K);
 size_t sv_eb_bytes(size_t npairs);                    // packed eqB pair bytes [48][padded pairs]

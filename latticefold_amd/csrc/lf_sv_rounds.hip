@@ -138,7 +138,7 @@ __device__ __forceinline__ u32 sv_operand(const u32 (&Xf)[2 * V][4], const u32 (
 // VS (launch_sv_vs*: V = 1, NT = 3): only the two single pairs are read afterwards, pair 0 against the digits of eq(2p) (columns 0..23: tiles 0, 1) and pair 2
 // against those of eq(2p+1) (columns 24..47: tiles 1, 2) -- 4 of the 12 MFMAs of a K-step
 template <int V, int BASE, int I, int NT, bool VS>
-__device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
+__device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V, NT)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                              const u32 (&D)[2 * V][4]) {
     if constexpr (VS && (I == 1 || I == 3)) return;
     v4i av;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void sv_mfma_pair(v4i (&acc)[sv_pairs_per_wave(V)][NT
         if (!VS || (I == 0 && nt < 2) || (I == 2 && nt > 0)) acc[I][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], acc[I][nt], 0, 0, 0);
 }
 template <int V, int BASE, int NT, bool VS, int... I>
-__device__ __forceinline__ void sv_mfma_all(v4i (&acc)[sv_pairs_per_wave(V)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
+__device__ __forceinline__ void sv_mfma_all(v4i (&acc)[sv_pairs_per_wave(V, NT)][NT], const v4i (&b)[NT], const u32 (&Xf)[2 * V][4], const u32 (&S)[2 * V][4],
                                             const u32 (&D)[2 * V][4], std::integer_sequence<int, I...>) {
     (sv_mfma_pair<V, BASE, I, NT, VS>(acc, b, Xf, S, D), ...);
 }
@@ -162,7 +162,7 @@ constexpr int sv_waves(int V) { return V <= 2 ? 8 : 4; }
 template <int V, int PG, int NT = 3, bool VS = false>
 __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_per_eu(V <= 2 ? 2 : 1, V <= 2 ? 2 : 1))) k_sv_gemm(SvGemmArgs a) {
     static_assert(!VS || (V == 1 && NT == 3 && PG == 0), "VS: the two single pairs of the round-1 shape");
-    constexpr int NX = 2 * V, PW = sv_pairs_per_wave(V), NPR = sv_num_pairs(V), SS = 4 / V, RPW = 4 / V;   // sub-steps per super-step, registers per word
+    constexpr int NX = 2 * V, PW = sv_pairs_per_wave(V, NT), NPR = sv_num_pairs(V), SS = 4 / V, RPW = 4 / V;   // sub-steps per super-step, registers per word
     constexpr int NW = sv_waves(V), NTH = 64 * NW;
     constexpr int SPAIRS = 256 / V, LROW = SPAIRS + 16;            // pairs (= bytes per eqB row) of a super-step; padded LDS row: conflict-free b128 reads
     constexpr int PIECES = 16 * NT * SPAIRS / 16, PPT = (PIECES + NTH - 1) / NTH;
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(1024) k_sv_finish2(const u64 *tp, u32 K, const
 template <int V, int PG, int NT = 3>
 void launch_gemm_pg(const SvGemmArgs &a, u32 grid, hipStream_t s) {
     hipLaunchKernelGGL((k_sv_gemm<V, PG, NT>), dim3(grid), dim3(64 * sv_waves(V)), 0, s, a);
-    if constexpr (PG + 1 < sv_num_pairs(V) / sv_pairs_per_wave(V)) launch_gemm_pg<V, PG + 1, NT>(a, grid, s);
+    if constexpr (PG + 1 < sv_num_pairs(V) / sv_pairs_per_wave(V, NT)) launch_gemm_pg<V, PG + 1, NT>(a, grid, s);
 }
 
 bool sv_shape_ok(int V, size_t npairs, uint32_t K) {
