@@ -2331,6 +2331,29 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     }
     Fq3 sv_c = fq3_one();   // c_i = prod_{k<i} eq(beta_k, r_k)
     u32 svE_level = 1;      // E_1 .. E_level exist
+    // the same form in the large table rounds after the GEMMs (k_fold_round SPLIT: three lazy products per table instead of four, the host completes the message);
+    // E_l for l >= 4 share one buffer
+    const bool fr_split = sv_split && c->sh_world == 1 && c->dcrt.nu2p40 && !c->tn.fold_rounds_no_split;
+    u64 *svE_rest = nullptr;
+    if (fr_split) RET(c->tbuf("fold_svE_rest", 3 * (m / 8) + 64, &svE_rest));
+    auto svE_ptr = [&](u32 l) -> u64 * {
+        if (l <= 3) return svE[l - 1];
+        size_t off = 0;
+        for (u32 q = 4; q < l; q++) off += 3 * (m >> q);
+        return svE_rest + off;
+    };
+    auto svE_ensure = [&](u32 l) {   // E_{q+1} = pair sums of E_q
+        for (; svE_level < l; svE_level++)
+            launch_eq_pairsum(svE_ptr(svE_level), m >> svE_level, m >> (svE_level + 1), svE_ptr(svE_level + 1), m >> (svE_level + 1), c->stream());
+    };
+    auto sv_c_at = [&](u32 round, const std::vector<Fq3> &ptv) {   // c_round from the challenges so far
+        Fq3 cc = fq3_one();
+        for (u32 k = 1; k < round; k++) {
+            const Fq3 b = beta[k - 1], r = ptv[k - 1];
+            cc = c->ring.mul3(cc, fq3_add(c->ring.mul3(fq3_sub(fq3_one(), b), fq3_sub(fq3_one(), r)), c->ring.mul3(b, r)));
+        }
+        return cc;
+    };
     LF_TRACE(c, "fold prepare");
     c->ev_end(ph);
     if (t_tl && t_tl->on) { (void)hipStreamSynchronize(c->stream()); TL_MARK(" fold prepare (synced)"); }
@@ -2502,6 +2525,20 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         if (sharded) { a.pcnt = a.n / 2 / Gw; a.p0 = gr * a.pcnt; a.pF0 = a.p0; }
         else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
     tables_ready:
+        // split form of this round's kernel?  (modes 1, 6, 7; c_i and beta_i must be invertible for the host's completion)
+        const u64 *Er = nullptr;
+        size_t ldEr = 0;
+        bool split_now = false;
+        // (mode 1, the fused-fix rounds after them, measured slower in this form: 0.55 against 0.51 ms per launch at C4 -- its four reduced products per table dominate)
+        if (fr_split && round >= 2 && !sharded && (fmode == 7 || (fmode == 4 && use_r4tab))) {
+            sv_c = sv_c_at(round, pt);
+            const Fq3 bi = beta[round - 1];
+            if ((sv_c.c[0] | sv_c.c[1] | sv_c.c[2]) && (bi.c[0] | bi.c[1] | bi.c[2])) {
+                svE_ensure(round);
+                Er = svE_ptr(round); ldEr = m >> round;
+                split_now = true;
+            }
+        }
         size_t ev = c->ev_begin(0);
         const int svV = 1 << (round - 1);
         if (use_sv && (int)round <= c->tn.sv_rounds && round <= 3 && a.pcnt >= c->tn.sv_min && sv_shape_ok(svV, a.pcnt, K) && (a.p0 * (size_t)svV) % 256 == 0) {
@@ -2546,16 +2583,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             Fq3Const w01[2] = {};
             if (sv_split) {
                 // (every GEMM round so far ran in order: rounds 1..round-1 are all GEMM rounds when this one is, their challenges are pt[0..round-2])
-                sv_c = fq3_one();
-                for (u32 k = 1; k < round; k++) {
-                    const Fq3 b = beta[k - 1], r = pt[k - 1];
-                    sv_c = c->ring.mul3(sv_c, fq3_add(c->ring.mul3(fq3_sub(fq3_one(), b), fq3_sub(fq3_one(), r)), c->ring.mul3(b, r)));
-                }
+                sv_c = sv_c_at(round, pt);
                 const Fq3 bi = beta[round - 1];
                 w01[0] = f3c(c->ring.mul3(sv_c, fq3_sub(fq3_one(), bi)));
                 w01[1] = f3c(c->ring.mul3(sv_c, bi));
-                for (; svE_level < round; svE_level++)   // E_{l+1} = pair sums of E_l
-                    launch_eq_pairsum(svE[svE_level - 1], m >> svE_level, m >> (svE_level + 1), svE[svE_level], m >> (svE_level + 1), c->stream());
+                svE_ensure(round);
                 const size_t ne = m >> round;   // entries of E_round
                 Ei = svE[round - 1]; ldE = ne;
             }
@@ -2602,17 +2634,22 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             RET(c->tbuf("fold_r4sq", (size_t)6561 * 4, &r4sq));
             RET(c->tbuf("fold_r4mt", (size_t)K2 * 3 * 162 * 4, &r4mt));
             launch_fold_round_lut_fix_tab(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), r4sq, r4mt, use_r5 ? nullptr : (u64 *)curF, ldF, K, d_mu, partial, od,
-                                          c->stream());
+                                          c->stream(), Er, ldEr);
         } else if (fmode == 7) {
             u64 *r5xx, *r5yy, *r5mt;
             RET(c->tbuf("fold_r5xx", (size_t)6561 * 4, &r5xx));
             RET(c->tbuf("fold_r5yy", (size_t)6561 * 4, &r5yy));
             RET(c->tbuf("fold_r5mt", (size_t)K2 * 3 * 324 * 4, &r5mt));
             launch_fold_round_lut_fix5(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 3]), f3c(pt[round - 2]), r5xx, r5yy, r5mt, (u64 *)curF, ldF, K, d_mu, partial, od,
-                                       c->stream());
+                                       c->stream(), Er, ldEr);
         } else if (fmode == 4) launch_fold_round_lut_fix(c->dcrt, a, S[0].planes, S[1].planes, N, d_lut, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
-        else if (fmode == 1) launch_fold_round_fix(c->dcrt, a, prevF, prevld, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream());
+        else if (fmode == 1) launch_fold_round_fix(c->dcrt, a, prevF, prevld, f3c(pt[round - 2]), (u64 *)curF, ldF, K, d_mu, partial, od, c->stream(), Er, ldEr);
         else launch_fold_round(c->dcrt, a, curF, ldF, K, d_mu, partial, od, c->stream());
+        if (split_now) {   // the G part of the message (eqL G1 + eqR G2 at X = 0..4) from its own kernel, behind the three sums of the table kernel
+            u64 *partial_g;
+            RET(c->tbuf("round_partial_g", round_partial_words(), &partial_g));
+            launch_fold_round_g(c->dcrt, a, partial_g, od + 120, c->stream());
+        }
         c->ev_end(ev);
         LF_TRACE(c, "fold round");
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * 24;
@@ -2621,6 +2658,45 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             HIPCHK(hipMemcpyAsync(od_host, od, (size_t)(deg + 1) * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
         }
         RET(c->lane_sync());                                  // message is in mapped host memory
+        if (split_now) {
+            // od_host[e][slot]: e = 0..2 the sums A_e = sum_p E[p] Q_e(p); od_host[120 + X * 24 + ..]: the G part at X = 0..4.  g(X) = c l(X) (A0 + A1 X + A2 X^2 + A3 X^3) + G(X),
+            // l(X) = eq(beta_i, X); A3 from g(0) + g(1) = (the previous message at its challenge)
+            HostTimer ht2(c);
+            const Fq3 bi = beta[round - 1], obi = fq3_sub(fq3_one(), bi), cinv = c->ring.inv3(sv_c), binv = c->ring.inv3(bi);
+            const Fq3 x = pt[round - 2];
+            Fq3 wS[5];
+            for (u32 j = 0; j <= deg; j++) {
+                Fq3 num = fq3_one();
+                u64 den = 1;
+                for (u32 k = 0; k <= deg; k++) {
+                    if (k == j) continue;
+                    num = c->ring.mul3(num, fq3_sub(x, fq3_make(k, 0, 0)));
+                    den = fq_mul(den, j > k ? (u64)(j - k) : LF_P - (u64)(k - j));
+                }
+                const u64 di = fq_inv(den);
+                wS[j] = fq3_make(fq_mul(num.c[0], di), fq_mul(num.c[1], di), fq_mul(num.c[2], di));
+            }
+            const u64 *pe = msgs + (size_t)(round - 2) * (deg + 1) * 24;
+            auto ld = [&](const u64 *b, u32 e, u32 slot) { return fq3_make(b[e * 24 + 3 * slot], b[e * 24 + 3 * slot + 1], b[e * 24 + 3 * slot + 2]); };
+            for (u32 slot = 0; slot < 8; slot++) {
+                Fq3 S = fq3_zero();
+                for (u32 j = 0; j <= deg; j++) S = fq3_add(S, c->ring.mul3(wS[j], ld(pe, j, slot)));
+                const Fq3 A0 = ld(od_host, 0, slot), A1 = ld(od_host, 1, slot), A2 = ld(od_host, 2, slot);
+                const u64 *gev = od_host + 120;
+                const Fq3 Gsum = fq3_add(ld(gev, 0, slot), ld(gev, 1, slot));                     // G(0) + G(1)
+                const Fq3 T1 = c->ring.mul3(fq3_sub(c->ring.mul3(fq3_sub(S, Gsum), cinv), c->ring.mul3(obi, A0)), binv);
+                const Fq3 A3 = fq3_sub(fq3_sub(fq3_sub(T1, A0), A1), A2);
+                Fq3 l = obi;
+                const Fq3 dl = fq3_sub(bi, obi);
+                for (u32 X = 0; X <= deg; X++) {
+                    const Fq3 xs = fq3_make(X, 0, 0);
+                    const Fq3 T = fq3_add(A0, c->ring.mul3(xs, fq3_add(A1, c->ring.mul3(xs, fq3_add(A2, c->ring.mul3(xs, A3))))));
+                    const Fq3 g = fq3_add(c->ring.mul3(c->ring.mul3(sv_c, l), T), ld(gev, X, slot));
+                    evs[X * 24 + 3 * slot] = g.c[0]; evs[X * 24 + 3 * slot + 1] = g.c[1]; evs[X * 24 + 3 * slot + 2] = g.c[2];
+                    l = fq3_add(l, dl);
+                }
+            }
+        } else
         memcpy(evs, od_host, (size_t)(deg + 1) * 24 * 8);
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);

@@ -62,6 +62,7 @@ int lf_ctx_device(const lf_ctx *ctx);
 // lf_linearize / lf_fold_step call -- never inside the round loops.
 struct Tunables {
     bool lin_u_eval = false, fold_unfused = false, fold_no_lut = false, fold_tab_r1 = false, fold_no_mutab = false, theta_eval = false, fold_no_r4tab = false, fold_no_r5tab = false, lin_unfused = false;
+    bool fold_rounds_no_split = false;   // LF_FOLD_ROUNDS_NO_SPLIT: the large table rounds (k_fold_round modes 1, 6, 7) evaluate all five points themselves (four lazy products per table)
     bool fold_sv_no_split = false;    // LF_FOLD_SV_NO_SPLIT: GEMM rounds against the digits of eqB(2p), eqB(2p+1) (three column tiles) instead of the per-pair E_i[p] (two)
     bool lin_no_split = false;        // LF_LIN_NO_SPLIT: linearization rounds on the full eq table (k_lin_round evaluates every point) instead of the split form
     size_t lin_split_min = 4096;      // LF_LIN_SPLIT_MIN: entries of a round's tables from which the split form is used
@@ -105,6 +106,7 @@ struct Tunables {
         t.lin_unfused = getenv("LF_LIN_UNFUSED") != nullptr;
         t.lin_no_split = getenv("LF_LIN_NO_SPLIT") != nullptr;
         t.fold_sv_no_split = getenv("LF_FOLD_SV_NO_SPLIT") != nullptr;
+        t.fold_rounds_no_split = getenv("LF_FOLD_ROUNDS_NO_SPLIT") != nullptr;
         if (const char *e = getenv("LF_LIN_SPLIT_MIN")) t.lin_split_min = (size_t)atoll(e);
         t.theta_eval = getenv("LF_THETA_EVAL") != nullptr;
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;

@@ -173,12 +173,12 @@ void launch_fold_round(const DevCrt &t, const FoldRoundArgs &a, const u64 *F, si
 // 4p..4p+3 of Fprev, stores the fixed pair to Fout for the next round
 void launch_fold_round_lut_fix_tab(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                    const u64 *lut_dev, Fq3Const r, u64 *sq_dev, u64 *mt_dev, u64 *Fout, size_t ldout, u32 K, const Fq3Const *mu_pow_dev,
-                                   u64 *partial, u64 *out, hipStream_t s);
+                                   u64 *partial, u64 *out, hipStream_t s, const u64 *E = nullptr, size_t ldE = 0 /* split form: the per-pair eq table, see k_fold_round */);
 void launch_fold_round_lut_fix5(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                 const u64 *lut_dev, Fq3Const r3, Fq3Const r4, u64 *xx_dev, u64 *yy_dev, u64 *mt_dev, u64 *Fout, size_t ldout, u32 K,
-                                const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s);
+                                const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s, const u64 *E = nullptr, size_t ldE = 0 /* split form: the per-pair eq table, see k_fold_round */);
 void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *Fprev, size_t ldprev, Fq3Const r, u64 *Fout, size_t ldout, u32 K,
-                           const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s);
+                           const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s, const u64 *E = nullptr, size_t ldE = 0 /* split form: the per-pair eq table, see k_fold_round */);
 // rounds 3 / 4 straight from the coefficient planes through the 81-entry digit look-up table lut_dev [81][3] (entry of code
 // sum_b t_b 3^b = sum_b (t_b - 1) W_b, W = eq((r1,r2), .)); round 4 also fixes with r3 and writes the m/8-entry tables
 void launch_fold_round_lut(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,

@@ -1802,6 +1802,7 @@ struct FoldSrc {
     Fq3Const r_prev;                      // mode 7: the challenge fixed one round earlier (r_3; r = r_4)
     const u64 *xx5, *yy5, *mt5;           // mode 7: [81*81][4] squares of the low / high halves of a fixed entry, [2K*3][4][81][4] = mu_kd {A', B', C', D'} (k_fold_r5tab)
     const u64 *sq4, *mt4;                 // mode 6: [81*81][4] squares of the fixed look-up values, [2K*3][2][81][4] = mu_kd (1 - r) L, mu_kd r L (k_fold_r4tab)
+    const u64 *E; size_t ldE;             // SPLIT kernels (modes 1, 6, 7): the per-pair eq table E_i [3][ldE] of the split form (run of the folding sumcheck in lf_capi.cpp)
 };
 // per-table products of the 81 look-up values with mu_kd (round 3, mode 5): with them a table costs two lazy products instead of six
 template <bool NU>
@@ -1873,9 +1874,15 @@ __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
     }
     return (u32)code;
 }
-template <bool NU, int MODE>
+// SPLIT (modes 1, 6, 7): eqB fixed at r_1..r_{i-1} is c_i eq(beta_i, b) E_i[p] at entry 2p + b, so the norm part of the message is c_i eq(beta_i, X) T(X) with
+// T(X) = sum_p E_i[p] (Q0 + Q1 X + Q2 X^2 + Q3 X^3)(p).  The kernel leaves  sum_p E_i[p] Q_e(p), e = 0..2  (three values per slot instead of five evaluations; the G part
+// comes from k_fold_round_g); the host takes sum E Q3 from g(0) + g(1) = the previous message at its challenge.  Q3 is the only coefficient that needs the
+// fourth lazy product of a table (P3): three products per table instead of four.
+template <bool NU, int MODE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, const u64 *F, size_t ldF, u32 K, const Fq3Const *mu_pow,
                                                     FoldSrc src, u64 *partial) {
+    static_assert(!SPLIT || (NU && (MODE == 1 || MODE == 6 || MODE == 7)), "split form: the large-round modes of the 2^40 non-residue path");
+    constexpr int NA = SPLIT ? 3 : 5;   // SPLIT: the G part comes from its own small kernel (k_fold_round_g) -- three live accumulators instead of five
     u32 slot = blockIdx.y;
     const size_t pend = a.p0 + a.pcnt;
     const u64 nu = t.nu;
@@ -1905,10 +1912,11 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
         }
     }
     auto lut3 = [&](u32 code) { return fq3_make(slut[3 * code], slut[3 * code + 1], slut[3 * code + 2]); };
-    Fq3 acc[5];
+    Fq3 acc[NA];
 #pragma unroll
-    for (int i = 0; i < 5; i++) acc[i] = fq3_zero();
+    for (int i = 0; i < NA; i++) acc[i] = fq3_zero();
     for (size_t p = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; p < pend; p += (size_t)gridDim.x * 256) {
+        if constexpr (!SPLIT)
         if (blockIdx.z == 0) fold_g13_evals<NU>(acc, a, slot, p, nu);   // per pair here: three more live F_{p^3} accumulators cost this kernel its occupancy (rounds 4-6: 5.0 -> 6.7 ms)
         // pair of table kd
         auto load_pair = [&](u32 kd, Fq3 &f0, Fq3 &df) {
@@ -2048,18 +2056,20 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 *(ulonglong2 *)(op) = make_ulonglong2(fv[0].c[0], fv[1].c[0]);
                 *(ulonglong2 *)(op + src.ldo) = make_ulonglong2(fv[0].c[1], fv[1].c[1]);
                 *(ulonglong2 *)(op + 2 * src.ldo) = make_ulonglong2(fv[0].c[2], fv[1].c[2]);
-                lh5_mac(A0, mf[0], sq[0]); lh5_mac(A1, mf[1], sq[0]); lh5_mac(A2, mf[0], sq[1]); lh5_mac(A3, mf[1], sq[1]);
+                lh5_mac(A0, mf[0], sq[0]); lh5_mac(A1, mf[1], sq[0]); lh5_mac(A2, mf[0], sq[1]);
+                if constexpr (!SPLIT) lh5_mac(A3, mf[1], sq[1]);
                 sp = fq3_add(sp, mf[0]); su = fq3_add(su, mf[1]);
             }
-            Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2), P3 = lh5_finish(A3);
+            Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2);
             Fq3 a1 = fq3_sub(P1, P0);
             Fq3 a2 = fq3_add(fq3_sub(P2, fq3_add(P1, P1)), P0);
-            Fq3 p12 = fq3_sub(P1, P2);
-            Fq3 a3 = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12));
             Q[0] = fq3_sub(P0, sp);
             Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
             Q[2] = fq3_add(fq3_add(a2, a2), a2);
-            Q[3] = a3;
+            if constexpr (!SPLIT) {
+                Fq3 P3 = lh5_finish(A3), p12 = fq3_sub(P1, P2);
+                Q[3] = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12));
+            } else Q[3] = fq3_zero();
         } else if (NU && MODE == 6) {
             LH5 A0, A1, A2, A3;
             lh5_zero(A0); lh5_zero(A1); lh5_zero(A2); lh5_zero(A3);
@@ -2106,22 +2116,25 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 Fq3 tA, uA, xA, yA, tB, uB, xB, yB;
                 gen(kd, tA, uA, xA, yA);
                 gen(kd + 1, tB, uB, xB, yB);
-                lh5_mac2(A0, tA, xA, tB, xB); lh5_mac2(A1, uA, xA, uB, xB); lh5_mac2(A2, tA, yA, tB, yB); lh5_mac2(A3, uA, yA, uB, yB);
+                lh5_mac2(A0, tA, xA, tB, xB); lh5_mac2(A1, uA, xA, uB, xB); lh5_mac2(A2, tA, yA, tB, yB);
+                if constexpr (!SPLIT) lh5_mac2(A3, uA, yA, uB, yB);
             }
             if (kd < kd1) {
                 Fq3 tA, uA, xA, yA;
                 gen(kd, tA, uA, xA, yA);
-                lh5_mac(A0, tA, xA); lh5_mac(A1, uA, xA); lh5_mac(A2, tA, yA); lh5_mac(A3, uA, yA);
+                lh5_mac(A0, tA, xA); lh5_mac(A1, uA, xA); lh5_mac(A2, tA, yA);
+                if constexpr (!SPLIT) lh5_mac(A3, uA, yA);
             }
-            Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2), P3 = lh5_finish(A3);
+            Fq3 P0 = lh5_finish(A0), P1 = lh5_finish(A1), P2 = lh5_finish(A2);
             Fq3 a1 = fq3_sub(P1, P0);                                           // sum mu f0^2 df
             Fq3 a2 = fq3_add(fq3_sub(P2, fq3_add(P1, P1)), P0);                 // sum mu f0 df^2
-            Fq3 p12 = fq3_sub(P1, P2);
-            Fq3 a3 = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12)); // sum mu df^3
             Q[0] = fq3_sub(P0, sp);
             Q[1] = fq3_sub(fq3_add(fq3_add(a1, a1), a1), fq3_sub(su, sp));
             Q[2] = fq3_add(fq3_add(a2, a2), a2);
-            Q[3] = a3;
+            if constexpr (!SPLIT) {
+                Fq3 P3 = lh5_finish(A3), p12 = fq3_sub(P1, P2);
+                Q[3] = fq3_add(fq3_sub(P3, P0), fq3_add(fq3_add(p12, p12), p12)); // sum mu df^3
+            } else Q[3] = fq3_zero();
         } else if (NU && MODE == 3) {
             // Both ends of a pair are look-up values, so their squares are too: with t = mu f0, u = mu f1 the four lazy sums
             //   P0 = sum t f0^2, P1 = sum u f0^2, P2 = sum t f1^2, P3 = sum u f1^2   (= sum mu f0^3, mu f0^2 f1, mu f0 f1^2, mu f1^3)
@@ -2171,14 +2184,16 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 Fq3 mu = fq3_make(mc.c[0], mc.c[1], mc.c[2]);
                 Fq3 f0s = fq3_mul_2p40(f0, f0), dfs = fq3_mul_2p40(df, df);
                 Fq3 pp = fq3_mul_2p40(mu, f0), qq = fq3_mul_2p40(mu, df);
-                lh5_mac(A0, pp, f0s); lh5_mac(A1, qq, f0s); lh5_mac(A2, pp, dfs); lh5_mac(A3, qq, dfs);
+                lh5_mac(A0, pp, f0s); lh5_mac(A1, qq, f0s); lh5_mac(A2, pp, dfs);
+                if constexpr (!SPLIT) lh5_mac(A3, qq, dfs);
                 sp = fq3_add(sp, pp); sq = fq3_add(sq, qq);
             }
             Fq3 t1 = lh5_finish(A1), t2 = lh5_finish(A2);
             Q[0] = fq3_sub(lh5_finish(A0), sp);
             Q[1] = fq3_sub(fq3_add(fq3_add(t1, t1), t1), sq);
             Q[2] = fq3_add(fq3_add(t2, t2), t2);
-            Q[3] = lh5_finish(A3);
+            if constexpr (!SPLIT) Q[3] = lh5_finish(A3);
+            else Q[3] = fq3_zero();
         } else {
             Q[0] = Q[1] = Q[2] = Q[3] = fq3_zero();
             for (u32 kd = kd0; kd < kd1; kd++) {
@@ -2198,17 +2213,21 @@ __global__ void __launch_bounds__(256) k_fold_round(DevCrt t, FoldRoundArgs a, c
                 Q[3] = fq3_add(Q[3], M3<NU>(c3, mu, nu));
             }
         }
-        fold_g2_finish<NU>(acc, Q, a, p, nu);
+        if constexpr (SPLIT) {
+            const Fq3 E = fq3_make(src.E[p], src.E[src.ldE + p], src.E[2 * src.ldE + p]);
+#pragma unroll
+            for (int e = 0; e < 3; e++) acc[e] = fq3_add(acc[e], M3<NU>(Q[e], E, nu));
+        } else fold_g2_finish<NU>(acc, Q, a, p, nu);
     }
     // partial row = blockIdx.x + gridDim.x * blockIdx.z
-    u64 vv[15];
+    u64 vv[3 * NA];
 #pragma unroll
-    for (int i = 0; i < 5; i++) { vv[3 * i] = acc[i].c[0]; vv[3 * i + 1] = acc[i].c[1]; vv[3 * i + 2] = acc[i].c[2]; }
-    __shared__ u64 red[15];
-    block_sum_store<15>(vv, red);
+    for (int i = 0; i < NA; i++) { vv[3 * i] = acc[i].c[0]; vv[3 * i + 1] = acc[i].c[1]; vv[3 * i + 2] = acc[i].c[2]; }
+    __shared__ u64 red[3 * NA];
+    block_sum_store<3 * NA>(vv, red);
     __syncthreads();
     size_t row = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z;
-    if (threadIdx.x < 15) partial[row * 120 + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
+    if (threadIdx.x < 3 * NA) partial[row * (24 * NA) + (threadIdx.x / 3) * 24 + 3 * slot + threadIdx.x % 3] = red[threadIdx.x];
 }
 // threads a round should have before its tables stop being split over blockIdx.z (LF_FOLD_CHUNK_THREADS; a thread walks its chunk of the 96 tables serially)
 static size_t fold_chunk_threads() {
@@ -2232,6 +2251,13 @@ static void launch_fold_round_mode(const DevCrt &t, const FoldRoundArgs &a, cons
     }
     while (gb * chunks > RED_BLOCKS && chunks > 1) chunks--;
     if (MODE >= 3) chunks = 1;   // the planes of one (side, d) serve all K tables: no table split (the driver uses these modes on large rounds only)
+    if constexpr (MODE == 1 || MODE == 6 || MODE == 7) {
+        if (src.E && t.nu2p40) {   // split form: three sums per slot (see k_fold_round); the caller adds the G part (launch_fold_round_g)
+            hipLaunchKernelGGL((k_fold_round<true, MODE, true>), dim3(gb, 8, chunks), dim3(256), 0, s, t, a, F, ldF, K, mu_pow_dev, src, partial);
+            hipLaunchKernelGGL(k_reduce_rows, dim3(3 * 24), dim3(256), 0, s, partial, gb * chunks, 72, out);
+            return;
+        }
+    }
     if (t.nu2p40) hipLaunchKernelGGL((k_fold_round<true, MODE>), dim3(gb, 8, chunks), dim3(256), 0, s, t, a, F, ldF, K, mu_pow_dev, src, partial);
     else hipLaunchKernelGGL((k_fold_round<false, MODE>), dim3(gb, 8, chunks), dim3(256), 0, s, t, a, F, ldF, K, mu_pow_dev, src, partial);
     hipLaunchKernelGGL(k_reduce_rows, dim3(5 * 24), dim3(256), 0, s, partial, gb * chunks, 120, out);
@@ -2850,30 +2876,30 @@ void launch_fold_round_lut_fix(const DevCrt &t, const FoldRoundArgs &a, const in
 // the same through the product-free tables of mode 6 (sq_dev 6561*4 words, mt_dev 2K*3*2*81*4 words, filled here); NU = 2^40 only
 void launch_fold_round_lut_fix_tab(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                    const u64 *lut_dev, Fq3Const r, u64 *sq_dev, u64 *mt_dev, u64 *Fout, size_t ldout, u32 K, const Fq3Const *mu_pow_dev,
-                                   u64 *partial, u64 *out, hipStream_t s) {
+                                   u64 *partial, u64 *out, hipStream_t s, const u64 *E, size_t ldE) {
     const u32 nkd = 2 * K * 3;
     LF_LAUNCH(k_fold_r4tab, t.nu2p40, dim3((6561 + nkd * 162 + 255) / 256), dim3(256), s, t, lut_dev, r, mu_pow_dev, nkd, sq_dev, mt_dev);
     FoldSrc src = {};
     src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
-    src.out = Fout; src.ldo = ldout; src.r = r; src.sq4 = sq_dev; src.mt4 = mt_dev;
+    src.out = Fout; src.ldo = ldout; src.r = r; src.sq4 = sq_dev; src.mt4 = mt_dev; src.E = E; src.ldE = ldE;
     launch_fold_round_mode<6>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
 }
 // round 5 from the planes (mode 7): xx_dev / yy_dev 6561*4 words each, mt_dev 2K*3*4*81*4 words, filled here; r3 / r4 = the challenges of rounds 3 / 4
 void launch_fold_round_lut_fix5(const DevCrt &t, const FoldRoundArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes,
                                 const u64 *lut_dev, Fq3Const r3, Fq3Const r4, u64 *xx_dev, u64 *yy_dev, u64 *mt_dev, u64 *Fout, size_t ldout, u32 K,
-                                const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
+                                const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s, const u64 *E, size_t ldE) {
     const u32 nkd = 2 * K * 3;
     LF_LAUNCH(k_fold_r5tab, t.nu2p40, dim3((2 * 6561 + nkd * 324 + 255) / 256), dim3(256), s, t, lut_dev, r3, r4, mu_pow_dev, nkd, xx_dev, yy_dev, mt_dev);
     FoldSrc src = {};
     src.planesL = planesL; src.planesR = planesR; src.n_planes = n_planes; src.lut = lut_dev;
-    src.out = Fout; src.ldo = ldout; src.r = r4; src.r_prev = r3; src.xx5 = xx_dev; src.yy5 = yy_dev; src.mt5 = mt_dev;
+    src.out = Fout; src.ldo = ldout; src.r = r4; src.r_prev = r3; src.xx5 = xx_dev; src.yy5 = yy_dev; src.mt5 = mt_dev; src.E = E; src.ldE = ldE;
     launch_fold_round_mode<7>(t, a, nullptr, 0, K, mu_pow_dev, src, partial, out, s);
 }
 // round message + fused fix_variables: Fprev [2K*3][24][ldprev] (entries 4p..4p+3 of every pair p) -> Fout [..][ldout]
 void launch_fold_round_fix(const DevCrt &t, const FoldRoundArgs &a, const u64 *Fprev, size_t ldprev, Fq3Const r, u64 *Fout, size_t ldout, u32 K,
-                           const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s) {
+                           const Fq3Const *mu_pow_dev, u64 *partial, u64 *out, hipStream_t s, const u64 *E, size_t ldE) {
     FoldSrc src = {};
-    src.out = Fout; src.ldo = ldout; src.r = r;
+    src.out = Fout; src.ldo = ldout; src.r = r; src.E = E; src.ldE = ldE;
     launch_fold_round_mode<1>(t, a, Fprev, ldprev, K, mu_pow_dev, src, partial, out, s);
 }
 

@@ -341,8 +341,13 @@ def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
     monkeypatch.setenv("LF_FOLD_SV_MIN", "64")
     monkeypatch.setenv("LF_DOT_MIN", "64")          # ... and the u_s / eta inner products as int8 GEMMs at this size too
     m = 1 << wl.s
+    # (the GEMMs run against one eq value per pair -- two column tiles -- unless LF_FOLD_SV_NO_SPLIT=1; rounds 4 and 5 from the tables over the digit codes leave three
+    # sums per slot and the host completes the message unless LF_FOLD_ROUNDS_NO_SPLIT=1: both forms, same words)
     for rounds, extra in ((1, {}), (2, {}), (3, {}), (2, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}), (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}),
-                          (3, {"LF_NO_TAIL": "1", "LF_FOLD_UNFUSED": "1"})):
+                          (3, {"LF_NO_TAIL": "1", "LF_FOLD_UNFUSED": "1"}), (3, {"LF_FOLD_SV_NO_SPLIT": "1"}),
+                          (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_R5_MIN": "1", "LF_NO_TAIL": "1"}),
+                          (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_R5_MIN": "1", "LF_NO_TAIL": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"}),
+                          (2, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_NO_R5TAB": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"})):
         monkeypatch.setenv("LF_FOLD_SV_ROUNDS", str(rounds))
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
