@@ -2530,7 +2530,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         size_t ldEr = 0;
         bool split_now = false;
         // (mode 1, the fused-fix rounds after them, measured slower in this form: 0.55 against 0.51 ms per launch at C4 -- its four reduced products per table dominate)
-        if (fr_split && round >= 2 && !sharded && (fmode == 7 || (fmode == 4 && use_r4tab))) {
+        if (fr_split && round >= 2 && !sharded && (fmode == 7 || (fmode == 4 && use_r4tab)) && a.pcnt >= c->tn.fold_split_min) {
             sv_c = sv_c_at(round, pt);
             const Fq3 bi = beta[round - 1];
             if ((sv_c.c[0] | sv_c.c[1] | sv_c.c[2]) && (bi.c[0] | bi.c[1] | bi.c[2])) {

@@ -65,7 +65,8 @@ struct Tunables {
     bool fold_rounds_no_split = false;   // LF_FOLD_ROUNDS_NO_SPLIT: the large table rounds (k_fold_round modes 1, 6, 7) evaluate all five points themselves (four lazy products per table)
     bool fold_sv_no_split = false;    // LF_FOLD_SV_NO_SPLIT: GEMM rounds against the digits of eqB(2p), eqB(2p+1) (three column tiles) instead of the per-pair E_i[p] (two)
     bool lin_no_split = false;        // LF_LIN_NO_SPLIT: linearization rounds on the full eq table (k_lin_round evaluates every point) instead of the split form
-    size_t lin_split_min = 4096;      // LF_LIN_SPLIT_MIN: entries of a round's tables from which the split form is used
+    size_t lin_split_min = (size_t)1 << 17;   // LF_LIN_SPLIT_MIN: entries of a round's tables from which the split form is used (at 2^16 rows the host's completion costs what the kernel saves)
+    size_t fold_split_min = 8192;     // LF_FOLD_SPLIT_MIN: pairs of a table round (modes 6 / 7) from which it runs in the split form
     bool force_exchange = false;     // LF_DIST_FORCE_EXCHANGE: run the sharded exchanges even with a 1-rank RCCL communicator (test hook)
     bool device_transcript = false;  // LF_DEVICE_TRANSCRIPT: Poseidon sponge of the tail rounds on the device (opt-in: slower than the host's)
     bool shard_plain_rounds = false; // LF_SHARD_PLAIN_ROUNDS: sharded folding rounds on materialised tables only (no fused fix / look-up-table rounds)
@@ -108,6 +109,7 @@ struct Tunables {
         t.fold_sv_no_split = getenv("LF_FOLD_SV_NO_SPLIT") != nullptr;
         t.fold_rounds_no_split = getenv("LF_FOLD_ROUNDS_NO_SPLIT") != nullptr;
         if (const char *e = getenv("LF_LIN_SPLIT_MIN")) t.lin_split_min = (size_t)atoll(e);
+        if (const char *e = getenv("LF_FOLD_SPLIT_MIN")) t.fold_split_min = (size_t)atoll(e);
         t.theta_eval = getenv("LF_THETA_EVAL") != nullptr;
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;
         t.fold_no_sv = getenv("LF_FOLD_NO_SV") != nullptr;

@@ -311,7 +311,9 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     lc_l, w_l, proof_l = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
     # the product-free forms of rounds 4 and 5 (modes 6 and 7: squares and mu products of the fixed look-up values from tables over the digit codes),
     # with round 5 still on the planes / on the stored round-4 tables / both through the older modes 4 and 1
-    for extra in ({"LF_FOLD_R5_MIN": "1"}, {"LF_FOLD_NO_R5TAB": "1"}, {"LF_FOLD_NO_R4TAB": "1"}):
+    # (LF_FOLD_SPLIT_MIN=1: rounds 4 / 5 in the split form -- three sums per slot, the host completes the message -- at this size too)
+    for extra in ({"LF_FOLD_R5_MIN": "1"}, {"LF_FOLD_R5_MIN": "1", "LF_FOLD_SPLIT_MIN": "1"}, {"LF_FOLD_NO_R5TAB": "1"}, {"LF_FOLD_NO_R5TAB": "1", "LF_FOLD_SPLIT_MIN": "1"},
+                  {"LF_FOLD_NO_R4TAB": "1"}):
         for key, val in extra.items():
             monkeypatch.setenv(key, val)
         lc_x, w_x, proof_x = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
@@ -345,7 +347,7 @@ def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
     # sums per slot and the host completes the message unless LF_FOLD_ROUNDS_NO_SPLIT=1: both forms, same words)
     for rounds, extra in ((1, {}), (2, {}), (3, {}), (2, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}), (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}),
                           (3, {"LF_NO_TAIL": "1", "LF_FOLD_UNFUSED": "1"}), (3, {"LF_FOLD_SV_NO_SPLIT": "1"}),
-                          (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_R5_MIN": "1", "LF_NO_TAIL": "1"}),
+                          (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_R5_MIN": "1", "LF_NO_TAIL": "1", "LF_FOLD_SPLIT_MIN": "1"}),
                           (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_R5_MIN": "1", "LF_NO_TAIL": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"}),
                           (2, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_NO_R5TAB": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"})):
         monkeypatch.setenv("LF_FOLD_SV_ROUNDS", str(rounds))
