@@ -142,9 +142,9 @@ PHASES = [
     ("fold prepare + round 1 (int8 GEMM)", ("fold challenges", "round 1"), ("k_lincomb_z", "k_spmv_sum", "k_add_fhat_comb", "k_sv_pack_eq", "k_sv_sum", "k_sv_finish1", "k_sv_finish2", "k_sv_gemm<1, 0, 2", "k_sv_gemm<1, 0, 3, false>", "k_eq_pairsum"), "VALU (48 lazy products per column and slot in k_lincomb_z)"),
     ("fold rounds 2-3 (int8 GEMMs)", ("round 1", "round 3"), ("k_sv_gemm<2", "k_sv_gemm<4", "k_fold_round_g"), "VALU operand generation for the MFMAs"),
     ("fold rounds 4-6 (rounds 4-5 from tables over the digit codes, then a fused-fix round)", ("round 3", "round 6"),
-     ("k_fold_round<true, 4>", "k_fold_round<true, 6>", "k_fold_round<true, 7>", "k_fold_round<true, 1>", "k_fold_r4tab", "k_fold_r5tab", "k_fold_mutab", "k_fold_round_lut"),
+     ("k_fold_round<true, 4", "k_fold_round<true, 6", "k_fold_round<true, 7", "k_fold_round<true, 1", "k_fold_r4tab", "k_fold_r5tab", "k_fold_mutab", "k_fold_round_lut"),
      "VALU issue: 4 lazy F_p^3 products per table pair in round 4 (no reduced product left), + 2 reduced in round 5, 6 + 4 from round 6 on"),
-    ("fold rounds 7-10", ("round 6", "round 10"), ("k_fold_round<true, 0>", "k_fix<", "k_reduce_rows"), "launch latency + host transcript"),
+    ("fold rounds 7-10", ("round 6", "round 10"), ("k_fold_round<true, 0", "k_fix<", "k_reduce_rows"), "launch latency + host transcript"),
     ("fold tail rounds (persistent kernel)", ("round 10", "fold sumcheck"), ("k_fold_tail",), "host transcript round trips through the mailbox"),
     ("theta / eta", ("fold sumcheck", "theta/eta"), (), "int8 inner products (counted under evaluations) + host absorb"),
     ("rho + folded witness + folded instance", ("theta/eta", "fold done"), ("k_fold_witness", "k_crt_fwd", "k_i32_to_coef", "k_coef_to_i32"), "int32 convolutions (VALU)"),
