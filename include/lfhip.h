@@ -283,9 +283,10 @@ int lf_last_kernel_stats(lf_ctx *, float *fold_round_ms, int *fold_round_launche
  * written (<= max_marks), or an error code < 0 */
 int lf_last_timeline(lf_ctx *, char *names /* 32 * max_marks */, double *ms, int max_marks);
 
-/* which rounds of the last folding sumcheck ran as int8 matrix-core GEMMs (bits 0..7: bit i-1 = round i; lf_sv_rounds.h) and, in bits 8..15, how
- * many rounds of the last linearization sumcheck ran in the split eq form -- test hook */
+/* which rounds of the last folding sumcheck ran as int8 matrix-core GEMMs (bit i-1 = round i; lf_sv_rounds.h) -- test hook */
 int lf_last_fold_paths(lf_ctx *, unsigned *sv_round_mask);
+/* how many rounds of the last linearization sumcheck ran in the split eq form -- test hook */
+int lf_last_lin_split_rounds(lf_ctx *, unsigned *rounds);
 
 /* NIFSVerifier::verify (nifs.rs:117-163) on the host: O(proof size), NO GPU and no lf_ctx needed.  The CCS enters only
  * through its shape (lf_params), the multisets S (S_off[q+1], S_idx) and the coefficients c (q ring elements) -- the

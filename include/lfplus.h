@@ -53,7 +53,8 @@ const char *lfplus_last_error(const lfplus_ctx *ctx);
 
 /* Ajtai matrix A (kappa x n ring elements, row-major, coefficient form); stays resident in HBM.  kappa <= 64. */
 int lfplus_set_matrix(lfplus_ctx *ctx, const uint64_t *A, uint32_t kappa, uint64_t n);
-/* use the commitment matrix resident in `from` (same device) without copying it; `from` must outlive ctx's use of it */
+/* use the commitment matrix resident in `from` (same device) without copying it; the allocation is reference-counted and lives until its last holder
+ * re-uploads or is destroyed */
 int lfplus_share_matrix(lfplus_ctx *ctx, lfplus_ctx *from);
 /* witness vector f (n ring elements); stays resident */
 int lfplus_set_witness(lfplus_ctx *ctx, const uint64_t *f, uint64_t n);
@@ -140,7 +141,7 @@ int lfplus_cm_verify(lfplus_transcript *t, uint32_t nvars, uint32_t L, uint32_t 
 /* The constraint-system matrices (n x n, CSR, ring coefficients) made resident once: every entry point that takes (nM, rowptr, col, val) uses them when
  * rowptr is NULL (nM must equal their number; for the multi-instance calls they are taken from ctxs[0]).  lfplus_set_matrices(ctx, n, 0, ..) drops them. */
 int lfplus_set_matrices(lfplus_ctx *ctx, uint64_t n, uint32_t nM, const uint32_t *const *rowptr, const uint32_t *const *col, const uint64_t *const *val);
-int lfplus_share_matrices(lfplus_ctx *ctx, lfplus_ctx *from);   /* use `from`'s resident matrices (same device, no copy; `from` must outlive the use) */
+int lfplus_share_matrices(lfplus_ctx *ctx, lfplus_ctx *from);   /* use `from`'s resident matrices (same device, no copy; reference-counted) */
 /* ComR1CS::linearize (src/r1cs.rs:76-139) on the resident witness f (lfplus_set_witness; n = 2^nvars ring elements) and the R1CS matrices A, B, C
  * (n x n, CSR, ring coefficients): g_q = M_q f, the degree-3 ring-valued sumcheck of eq(r, x) (g_A g_B - g_C)(x), evaluations at ro.
  * Outputs: msgs (nvars x 4 ring elements), ro (nvars words), evals = v | va | vb | vc (4 ring elements). */

@@ -154,6 +154,7 @@ def _lib():
         L.lf_phase_name.argtypes = [C.c_int]
         L.lf_verify_host.argtypes = [C.c_int, C.POINTER(Params), u32p, u32p, u64p, vp, u64p, u64p, u64p, u64p, C.POINTER(C.c_int)]
         L.lf_last_fold_paths.argtypes = [vp, C.POINTER(C.c_uint)]
+        L.lf_last_lin_split_rounds.argtypes = [vp, C.POINTER(C.c_uint)]
         L.lf_last_timeline.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.c_int]
         L.lf_last_kernel_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _LIB = L
@@ -369,13 +370,13 @@ class Context:
     def fold_paths(self):
         m = C.c_uint()
         _chk(_lib().lf_last_fold_paths(self.h, C.byref(m)), "lf_last_fold_paths")
-        return m.value & 0xFF
+        return m.value
 
     def lin_split_rounds(self):
-        """rounds of the last linearization sumcheck that ran in the split eq form (bits 8..15 of lf_last_fold_paths) -- test hook"""
+        """rounds of the last linearization sumcheck that ran in the split eq form -- test hook"""
         m = C.c_uint()
-        _chk(_lib().lf_last_fold_paths(self.h, C.byref(m)), "lf_last_fold_paths")
-        return (m.value >> 8) & 0xFF
+        _chk(_lib().lf_last_lin_split_rounds(self.h, C.byref(m)), "lf_last_lin_split_rounds")
+        return m.value
 
     def timeline(self):
         """[(mark, ms since the start of the step)] of the last fold step (wall clock of the calling thread)"""

@@ -27,10 +27,11 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
-    if (!c->own_A) c->A = nullptr;
+    c->A = nullptr;
+    c->A_ref.reset();      // frees the matrix unless another context still shares it
     c->drop_mats();
     c->pool.clear();
-    for (void *p : {(void *)c->A, (void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
+    for (void *p : {(void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
                     (void *)c->err_d, (void *)c->g})
         if (p) (void)hipFree(p);
     if (c->hpin) (void)hipHostFree(c->hpin);
@@ -62,20 +63,21 @@ extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kapp
     if (!canonical(A, (size_t)kappa * n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
     c->have = false;
-    if (!c->own_A) { c->A = nullptr; c->own_A = true; }
-    int rc = upload(c, &c->A, A, (size_t)kappa * n * 16);
+    u64 *fresh = nullptr;   // a new allocation: contexts sharing the previous matrix keep it alive through their own reference
+    int rc = upload(c, &fresh, A, (size_t)kappa * n * 16);
     if (rc) return rc;
+    c->A = fresh;
+    c->A_ref = std::shared_ptr<void>(fresh, [](void *p) { (void)hipFree(p); });
     return shape_buffers(c, kappa, n);
 }
 // The commitment matrix of `from` (same device), not copied: PlusProver keeps one context per accumulated / fresh instance and one Ajtai matrix.
-// `from` must outlive every use of ctx's matrix.
+// The allocation is reference-counted: it lives until the last context holding it re-uploads or is destroyed.
 extern "C" int lfplus_share_matrix(lfplus_ctx *c, lfplus_ctx *from) {
     if (!c || !from || c == from || !from->A || c->device != from->device) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrix: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     c->have = false;
-    if (c->A && c->own_A) (void)hipFree(c->A);
     c->A = from->A;
-    c->own_A = false;
+    c->A_ref = from->A_ref;
     return shape_buffers(c, from->kappa, from->n);
 }
 extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) {

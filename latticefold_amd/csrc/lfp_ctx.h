@@ -1,6 +1,7 @@
 // lfp_ctx.h -- the context of the LatticeFold+ slice (include/lfplus.h), shared by lfp_capi.cpp and lfp_protocol.cpp
 #pragma once
 #include <hip/hip_runtime.h>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/lfplus.h"
@@ -73,6 +74,7 @@ struct lfplus_ctx {
     // the folded witness of the last lfplus_cm_prove (cm.rs:164-181): n ring elements
     u64 *g = nullptr;
     u64 g_n = 0;
+    bool g_valid = false;   // false once lfplus_mlin has summed the instances' g into ctxs[0]->g (it is then the resident witness f, not g_0)
     LfpPool pool;
     // pinned host staging of the per-round partial sums and other small downloads (a copy into pageable memory is staged and synchronised by
     // the runtime: tens of microseconds per sumcheck round)
@@ -89,16 +91,22 @@ struct lfplus_ctx {
         hpin_words = words;
         return hpin;
     }
-    bool own_A = true;
+    // The commitment matrix and the constraint-system matrices may be shared between contexts (lfplus_share_matrix / lfplus_share_matrices: PlusProver keeps
+    // one context per instance and one copy of each): the device allocations are reference-counted, so a sharer stays valid when the context that uploaded
+    // them re-uploads or is destroyed -- the memory goes back to the driver with the last holder.  `A` and `mats` are the raw views the kernels take.
+    std::shared_ptr<void> A_ref;
+    struct MatsOwner {
+        std::vector<LfpMatrix> m;
+        ~MatsOwner() { for (LfpMatrix &x : m) x.release(); }
+    };
+    std::shared_ptr<MatsOwner> mats_ref;
     std::vector<LfpMatrix> mats;   // lfplus_set_matrices: the constraint-system matrices, uploaded once
     u64 mats_n = 0;
-    bool own_mats = true;          // false: they belong to another context (lfplus_share_matrices)
     void drop_mats() {
-        if (own_mats) for (LfpMatrix &m : mats) m.release();
+        mats_ref.reset();
         mats.clear();
         mats_n = 0;
-        own_mats = true;
-    }   // false: A belongs to another context (lfplus_share_matrix)
+    }
 };
 
 #define HIPCHK(c, x)                                                                        \

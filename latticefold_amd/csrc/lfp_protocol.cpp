@@ -639,6 +639,7 @@ int sumcheck_verify(lfplus_transcript *tr, u32 nv, u32 deg, const u64 *msgs, u64
 extern "C" int lfplus_set_check_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t nmat, uint32_t ncols, uint32_t nvec, uint32_t nM, const uint64_t *msgs,
                                        const uint64_t *e, const uint64_t *b, uint64_t *r_out, int *stage) {
     if (!tr || !nmat || !msgs || !e || (nvec && !b) || !r_out || nvars < 1 || nvars > 32) return LFPLUS_E_ARG;
+    if (nmat > 4096 || !ncols || ncols > 64 || nvec > 4096 || nM > 64) return LFPLUS_E_ARG;   // the parameter envelope of the provers (array lengths are the caller's contract: lfplus.h)
     const u32 ncl = nmat + nvec;
     std::vector<u64> cs((size_t)ncl * nvars), beta(ncl), alpha(ncl);
     for (u32 i = 0; i < ncl; i++) {
@@ -681,6 +682,7 @@ extern "C" int lfplus_set_check_verify(lfplus_transcript *tr, uint32_t nvars, ui
 extern "C" int lfplus_range_check_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t L, uint32_t k, uint32_t nM, const uint64_t *msgs, const uint64_t *e,
                                          const uint64_t *b, const uint64_t *v, const uint64_t *a, const uint64_t *bb, const uint64_t *cc, uint64_t *r_out, int *stage) {
     if (!tr || !L || !k || !msgs || !e || !b || !v || !a || !bb || !cc || !r_out) return LFPLUS_E_ARG;
+    if (L > 256 || k > 16 || nM > 64) return LFPLUS_E_ARG;
     int st = 0;
     int rc = lfplus_set_check_verify(tr, nvars, L * k, D, L, nM, msgs, e, b, r_out, &st);
     if (rc == LFPLUS_E_ARG) return rc;
@@ -963,6 +965,7 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             cl->g_n = n;
         }
         lfp::launch_cm_g(cl->tau, cl->mtau, cl->f, h[l]->as<u64>(), n, cs, cl->g, c->st);
+        cl->g_valid = true;
         if (g_out) HIPCHK(c, hipMemcpyAsync(g_out + (size_t)l * n * D, cl->g, n * D * 8, hipMemcpyDeviceToHost, c->st));
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -974,7 +977,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
 }
 extern "C" int lfplus_cm_read_g(lfplus_ctx *c, uint64_t *g_out) {
     if (!c || !g_out) return LFPLUS_E_ARG;
-    if (!c->g || !c->g_n) return fail(c, LFPLUS_E_ARG, "lfplus_cm_read_g: no folded witness (call lfplus_cm_prove)");
+    if (!c->g || !c->g_n || !c->g_valid)
+        return fail(c, LFPLUS_E_ARG, "lfplus_cm_read_g: no folded witness (call lfplus_cm_prove; after lfplus_mlin ctxs[0] holds the SUM of the instances' g as its resident witness)");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(g_out, c->g, c->g_n * D * 8, hipMemcpyDeviceToHost));
     return LFPLUS_OK;
@@ -988,6 +992,7 @@ extern "C" int lfplus_cm_verify(lfplus_transcript *tr, uint32_t nvars, uint32_t 
                                 const uint64_t *cc, const uint64_t *comh, const uint64_t *pa, const uint64_t *pb, const uint64_t *ea, const uint64_t *eb,
                                 uint64_t *cm_g, uint64_t *ro, uint64_t *vo, int *stage) {
     if (!tr || !L || !k || !ell || !kappa || !fcoms || !comh || !pa || !pb || !ea || !eb || !cm_g || !ro || !vo || nvars < 1 || nvars > 32) return LFPLUS_E_ARG;
+    if (L > 256 || k > 16 || ell > 64 || kappa > 64 || nM > 64) return LFPLUS_E_ARG;
     for (u32 l = 0; l < L; l++) if (!fcoms[l]) return LFPLUS_E_ARG;
     const size_t n = (size_t)1 << nvars;
     std::vector<u64> r(nvars);
@@ -1102,18 +1107,20 @@ extern "C" int lfplus_set_matrices(lfplus_ctx *c, uint64_t n, uint32_t nM, const
         int rc = upload_matrix(c, n, rowptr[q], col[q], val[q], fresh[q]);
         if (rc) { for (LfpMatrix &m : fresh) m.release(); return rc; }
     }
+    c->mats_ref = std::make_shared<lfplus_ctx::MatsOwner>();
+    c->mats_ref->m = fresh;      // the owner releases the device arrays with its last holder; c->mats is the view the kernels take
     c->mats.swap(fresh);
     c->mats_n = n;
     return LFPLUS_OK;
 }
 
-// the resident matrices of `from` (same device), not copied; `from` must outlive ctx's use of them
+// the resident matrices of `from` (same device), not copied; reference-counted like the commitment matrix
 extern "C" int lfplus_share_matrices(lfplus_ctx *c, lfplus_ctx *from) {
     if (!c || !from || c == from || c->device != from->device) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrices: bad arguments");
     c->drop_mats();
     c->mats = from->mats;
+    c->mats_ref = from->mats_ref;
     c->mats_n = from->mats_n;
-    c->own_mats = false;
     return LFPLUS_OK;
 }
 
@@ -1278,9 +1285,11 @@ extern "C" int lfplus_mlin(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcrip
         for (size_t x = 0; x < (size_t)(1 + nM) * 2 * D; x++) vo_sum[x] = fadd(vo_sum[x], vo[(size_t)i * (1 + nM) * 2 * D + x]);
         if (i) lfp::launch_vec_add(c->g, ctxs[i]->g, n * D, c->st);
     }
-    // the folded witness replaces ctxs[0]'s f: the RgInstance results of ctxs[0] no longer describe the resident witness
+    // the folded witness replaces ctxs[0]'s f: the RgInstance results of ctxs[0] no longer describe the resident witness, and its g buffer holds the
+    // sum, not g_0 (lfplus_cm_read_g on ctxs[0] is refused from here on; the other instances keep their g_l)
+    c->have = false;
+    c->g_valid = false;
     HIPCHK(c, hipMemcpyAsync(c->f, c->g, n * D * 8, hipMemcpyDeviceToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
-    c->have = false;
     return LFPLUS_OK;
 }

@@ -330,10 +330,35 @@ def set_check(ctx, transcript, nvars, mat_digits, vec_digits=None, M=()):
     return {"r": r, "msgs": msgs, "e": e, "b": b[:nvec]}
 
 
-def set_check_verify(transcript, nvars, out, nM=0):
-    """Out::verify (src/setchk.rs:266-340) on the host -> (accepted, stage, r)"""
-    e, b, msgs = (np.ascontiguousarray(out[k], dtype=np.uint64) for k in ("e", "b", "msgs"))
-    nmat, ncols, nvec = e.shape[1], e.shape[2], b.shape[0]
+def _shaped(proof, key, shape):
+    """a proof array as contiguous u64 words of exactly `shape` -- the C verifiers index raw pointers with the VERIFIER's parameters, so a proof whose arrays
+    are shorter than those parameters imply must be refused here (LFPLUS_E_ARG), never read"""
+    try:
+        a = np.ascontiguousarray(proof[key], dtype=np.uint64)
+    except (KeyError, TypeError, ValueError, OverflowError) as ex:
+        raise LfPlusError(E_ARG, f"malformed proof: field {key!r}: {ex}")
+    if a.shape != tuple(shape):
+        raise LfPlusError(E_ARG, f"malformed proof: field {key!r} has shape {a.shape}, the verifier's parameters require {tuple(shape)}")
+    return a
+
+
+def _nvars_ok(nvars):
+    if not isinstance(nvars, (int, np.integer)) or not 1 <= int(nvars) <= 32:
+        raise LfPlusError(E_ARG, "nvars outside [1, 32]")
+    return int(nvars)
+
+
+def set_check_verify(transcript, nvars, out, nM=0, nmat=None, ncols=None, nvec=None):
+    """Out::verify (src/setchk.rs:266-340) on the host -> (accepted, stage, r).  nvars and nM are the VERIFIER's; nmat / ncols / nvec default to the shape of
+    out["e"] / out["b"], and every array is checked against them before the C verifier sees a pointer"""
+    nvars = _nvars_ok(nvars)
+    e0, b0 = np.asarray(out["e"]), np.asarray(out["b"])
+    if e0.ndim != 4 or b0.ndim != 2:
+        raise LfPlusError(E_ARG, "malformed proof: e must be (1 + nM, nmat, ncols, 16), b (nvec, 16)")
+    nmat, ncols, nvec = (e0.shape[1] if nmat is None else nmat), (e0.shape[2] if ncols is None else ncols), (b0.shape[0] if nvec is None else nvec)
+    if nmat < 1 or ncols < 1:
+        raise LfPlusError(E_ARG, "malformed proof: no matrix set")
+    e, b, msgs = _shaped(out, "e", (1 + nM, nmat, ncols, D)), _shaped(out, "b", (nvec, D)), _shaped(out, "msgs", (nvars, 4, D))
     bb = b if nvec else np.zeros((1, D), dtype=np.uint64)
     r, st = np.zeros(nvars, dtype=np.uint64), C.c_int()
     rc = _lib().lfplus_set_check_verify(transcript.h, nvars, nmat, ncols, nvec, nM, msgs.ctypes.data_as(u64p), e.ctypes.data_as(u64p), bb.ctypes.data_as(u64p),
@@ -360,12 +385,24 @@ def range_check(ctxs, transcript, M=()):
     return {"r": r, "msgs": msgs, "e": e, "b": b, "v": v, "a": a, "bb": bb, "c": c, "k": k, "nvars": nvars}
 
 
-def range_check_verify(transcript, d):
-    """Dcom::verify (src/rgchk.rs:193-258) on the host -> (accepted, stage, r)"""
-    arr = {key: np.ascontiguousarray(d[key], dtype=np.uint64) for key in ("msgs", "e", "b", "v", "a", "bb", "c")}
-    L, nM = arr["b"].shape[0], arr["a"].shape[1] - 1
-    r, st = np.zeros(d["nvars"], dtype=np.uint64), C.c_int()
-    rc = _lib().lfplus_range_check_verify(transcript.h, d["nvars"], L, d["k"], nM, *[arr[key].ctypes.data_as(u64p) for key in ("msgs", "e", "b", "v", "a", "bb", "c")],
+def _dcom_arrays(d, nvars, L, k, nM):
+    """the Dcom fields (rgchk.rs:50-79) checked against the verifier's nvars, L, k, nM"""
+    return {"msgs": _shaped(d, "msgs", (nvars, 4, D)), "e": _shaped(d, "e", (1 + nM, L * k, D, D)), "b": _shaped(d, "b", (L, D)), "v": _shaped(d, "v", (L, D)),
+            "a": _shaped(d, "a", (L, 1 + nM)), "bb": _shaped(d, "bb", (L, 1 + nM, D)), "c": _shaped(d, "c", (L, 1 + nM, D))}
+
+
+def range_check_verify(transcript, d, nvars=None, L=None, k=None, nM=None):
+    """Dcom::verify (src/rgchk.rs:193-258) on the host -> (accepted, stage, r).  nvars / L / k / nM are the VERIFIER's parameters (a caller without its own
+    takes them from the proof's metadata -- fine for a self-check, not for an untrusted proof); every array is checked against them"""
+    nvars = _nvars_ok(d["nvars"] if nvars is None else nvars)
+    k = int(d["k"] if k is None else k)
+    L = int(np.asarray(d["b"]).shape[0] if L is None else L)
+    nM = int(np.asarray(d["a"]).shape[-1] - 1 if nM is None else nM)
+    if L < 1 or k < 1 or nM < 0:
+        raise LfPlusError(E_ARG, "range_check_verify: bad parameters")
+    arr = _dcom_arrays(d, nvars, L, k, nM)
+    r, st = np.zeros(nvars, dtype=np.uint64), C.c_int()
+    rc = _lib().lfplus_range_check_verify(transcript.h, nvars, L, k, nM, *[arr[key].ctypes.data_as(u64p) for key in ("msgs", "e", "b", "v", "a", "bb", "c")],
                                           r.ctypes.data_as(u64p), C.byref(st))
     if rc not in (0, E_REJECT):
         raise LfPlusError(rc, "lfplus_range_check_verify")
@@ -404,13 +441,24 @@ def cm_read_g(ctx):
     return g
 
 
-def cm_verify(transcript, proof, fcoms):
-    """CmProof::verify (src/cm.rs:349-543) on the host.  fcoms[l] = (3, kappa, 16): cm_f | C_Mf | cm_mtau -> (accepted, stage, dict(cm_g, ro, vo))"""
-    nvars, k, ell, kappa = proof["nvars"], proof["k"], proof["ell"], proof["kappa"]
+def cm_verify(transcript, proof, fcoms, nvars=None, L=None, k=None, ell=None, kappa=None, nM=None):
+    """CmProof::verify (src/cm.rs:349-543) on the host.  fcoms[l] = (3, kappa, 16): cm_f | C_Mf | cm_mtau -> (accepted, stage, dict(cm_g, ro, vo)).
+    nvars .. nM are the VERIFIER's parameters (CmProof::verify takes M.len() and the parameters from its own side, cm.rs:349-365); left None they come from
+    the proof's metadata, which only a self-check should do.  Every array is checked against them before the C verifier sees a pointer"""
+    nvars = _nvars_ok(proof["nvars"] if nvars is None else nvars)
+    k, ell, kappa = (int(proof[key] if val is None else val) for key, val in (("k", k), ("ell", ell), ("kappa", kappa)))
+    L = int(np.asarray(proof["b"]).shape[0] if L is None else L)
+    nM = int(np.asarray(proof["a"]).shape[-1] - 1 if nM is None else nM)
+    if L < 1 or not 1 <= k <= 16 or not 1 <= ell <= 64 or not 1 <= kappa <= 64 or not 0 <= nM <= 64:
+        raise LfPlusError(E_ARG, "cm_verify: parameters outside the envelope")
+    per = 4 + 4 * nM
     keys = ("msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb")
-    arr = {key: np.ascontiguousarray(proof[key], dtype=np.uint64) for key in keys}
-    L, nM = arr["b"].shape[0], arr["a"].shape[1] - 1
+    arr = _dcom_arrays(proof, nvars, L, k, nM)
+    arr.update(comh=_shaped(proof, "comh", (L, kappa, D)), pa=_shaped(proof, "pa", (nvars, 3, D)), pb=_shaped(proof, "pb", (nvars, 3, D)),
+               ea=_shaped(proof, "ea", (L, per, D)), eb=_shaped(proof, "eb", (L, per, D)))
     fc = [np.ascontiguousarray(x, dtype=np.uint64) for x in fcoms]
+    if len(fc) != L or any(x.shape != (3, kappa, D) for x in fc):
+        raise LfPlusError(E_ARG, f"cm_verify: fcoms must be {L} arrays of shape (3, {kappa}, 16)")
     fptr = (u64p * L)(*[x.ctypes.data_as(u64p) for x in fc])
     x = {"cm_g": np.zeros((L, kappa, D), dtype=np.uint64), "ro": np.zeros((2, nvars), dtype=np.uint64), "vo": np.zeros((L, 1 + nM, 2, D), dtype=np.uint64)}
     st = C.c_int()
@@ -522,19 +570,26 @@ class ComR1CS:
         return linb, proof
 
 
-def r1cs_verify(transcript, proof):
-    """ComR1CSProof::verify (r1cs.rs:141-162), host -> (accepted, stage, ro)"""
-    msgs, ev = (np.ascontiguousarray(proof[key], dtype=np.uint64) for key in ("msgs", "evals"))
-    ro, st = np.zeros(proof["nvars"], dtype=np.uint64), C.c_int()
-    rc = _lib().lfplus_r1cs_verify(transcript.h, proof["nvars"], msgs.ctypes.data_as(u64p), ev.ctypes.data_as(u64p), ro.ctypes.data_as(u64p), C.byref(st))
+def r1cs_verify(transcript, proof, nvars=None):
+    """ComR1CSProof::verify (r1cs.rs:141-162), host -> (accepted, stage, ro).  nvars: the VERIFIER's log2 n (None: the proof's own field, as the reference reads
+    `self.nvars` -- the arrays are checked against it either way)"""
+    nvars = _nvars_ok(proof["nvars"] if nvars is None else nvars)
+    msgs, ev = _shaped(proof, "msgs", (nvars, 4, D)), _shaped(proof, "evals", (4, D))
+    ro, st = np.zeros(nvars, dtype=np.uint64), C.c_int()
+    rc = _lib().lfplus_r1cs_verify(transcript.h, nvars, msgs.ctypes.data_as(u64p), ev.ctypes.data_as(u64p), ro.ctypes.data_as(u64p), C.byref(st))
     if rc not in (0, E_REJECT):
         raise LfPlusError(rc, "lfplus_r1cs_verify")
     return rc == 0, st.value, ro
 
 
-def decomp_verify(dproof, cm_f, v, B):
-    """DecompProof::verify (decomp.rs:101-123), host -> (accepted, stage)"""
-    arr = [np.ascontiguousarray(x, dtype=np.uint64) for x in (dproof["C0"], dproof["C1"], dproof["v0"], dproof["v1"], cm_f, v)]
+def decomp_verify(dproof, cm_f, v, B, kappa=None, nM=None):
+    """DecompProof::verify (decomp.rs:101-123), host -> (accepted, stage).  kappa / nM: the verifier's (None: the shape of cm_f / v); all six arrays must agree"""
+    cm_f, v = np.ascontiguousarray(cm_f, dtype=np.uint64), np.ascontiguousarray(v, dtype=np.uint64)
+    kappa = int(cm_f.shape[0] if kappa is None and cm_f.ndim == 2 else (kappa or 0))
+    count = int(v.shape[0] if nM is None and v.ndim == 3 else 1 + (nM or 0))
+    if kappa < 1 or cm_f.shape != (kappa, D) or v.shape != (count, 2, D):
+        raise LfPlusError(E_ARG, "decomp_verify: cm_f must be (kappa, 16) and v (1 + nM, 2, 16)")
+    arr = [_shaped(dproof, "C0", (kappa, D)), _shaped(dproof, "C1", (kappa, D)), _shaped(dproof, "v0", (count, 2, D)), _shaped(dproof, "v1", (count, 2, D)), cm_f, v]
     st = C.c_int()
     rc = _lib().lfplus_decomp_verify(arr[0].ctypes.data_as(u64p), arr[1].ctypes.data_as(u64p), arr[0].shape[0], arr[2].ctypes.data_as(u64p),
                                      arr[3].ctypes.data_as(u64p), arr[2].shape[0], arr[4].ctypes.data_as(u64p), arr[5].ctypes.data_as(u64p), B, C.byref(st))
@@ -587,6 +642,7 @@ class PlusProver:
             c.share_matrices(self.ctxs[0])
         self.res = RESIDENT(len(self.M))
         self.acc = []          # the accumulated LinB witnesses (host copies of F0, F1)
+        self.failed = None     # set when a prove() raised half way: the Fiat-Shamir transcript has advanced and the contexts hold a half-folded state
 
     @staticmethod
     def init(A, M, ncomp, params, transcript, device=0):
@@ -599,9 +655,19 @@ class PlusProver:
 
     def prove(self, comp):
         """PlusProver::prove (plus.rs:77-108) -> PlusProof fields: linb2x, lproof, cmproof, dproof"""
+        if self.failed is not None:
+            raise LfPlusError(E_ARG, f"PlusProver.prove: this prover failed in an earlier prove() ({self.failed}); its transcript and accumulator are half-advanced -- "
+                                     "build a new prover")
         nacc = len(self.acc)
         if nacc + len(comp) > len(self.ctxs):
             raise LfPlusError(E_ARG, "PlusProver.prove: more instances than contexts (ncomp)")
+        try:
+            return self._prove(comp, nacc)
+        except Exception as ex:      # the reference's prove() panics on these paths; here the object survives, so it must refuse to continue from this state
+            self.failed = repr(ex)
+            raise
+
+    def _prove(self, comp, nacc):
         ctxs = self.ctxs[:nacc + len(comp)]
         lproof = []
         for i, ci in enumerate(comp):
@@ -623,25 +689,48 @@ class PlusVerifier:
     def __init__(self, A, M, params, transcript):
         self.M, self.params, self.transcript = list(M), params, transcript
         self.stage = None
+        # the verifier's OWN shape parameters (plus.rs:110-146 passes &self.A, &self.M down; CmProof::verify sizes everything from them, cm.rs:349-365):
+        # nothing below is taken from the proof
+        A = np.asarray(A)
+        if A.ndim != 3 or A.shape[2] != D or A.shape[0] != params.lin.kappa or A.shape[1] < 2 or A.shape[1] & (A.shape[1] - 1):
+            raise LfPlusError(E_ARG, "PlusVerifier: A must be (kappa, n = 2^nvars, 16) with kappa = params.lin.kappa")
+        self.kappa, self.n = int(A.shape[0]), int(A.shape[1])
+        self.nvars = self.n.bit_length() - 1
 
     @staticmethod
     def init(A, M, params, transcript):
         return PlusVerifier(A, M, params, transcript)
 
     def verify(self, proof):
-        for i, lp in enumerate(proof["lproof"]):
-            ok, st, _ = r1cs_verify(self.transcript, lp)
+        """False with .stage = (which proof, stage); a proof whose arrays do not have the shapes this verifier's parameters imply is rejected as
+        ("malformed", message) before any C verifier reads it"""
+        dp, nM = self.params.lin.decomp, len(self.M)
+        try:
+            for i, lp in enumerate(proof["lproof"]):
+                ok, st, _ = r1cs_verify(self.transcript, lp, nvars=self.nvars)
+                if not ok:
+                    self.stage = (f"lproof[{i}]", st)
+                    return False
+            cm = proof["cmproof"]
+            L = int(np.asarray(cm["b"]).shape[0])      # the number of folded instances is the statement's (the reference: self.lins.len()); every array must agree with it
+            fcoms = np.ascontiguousarray(cm["fcoms"], dtype=np.uint64)
+            if fcoms.shape != (L, 3, self.kappa, D):
+                raise LfPlusError(E_ARG, "malformed proof: fcoms")
+            ok, st, _ = cm_verify(self.transcript, cm, list(fcoms), nvars=self.nvars, L=L, k=dp.k, ell=dp.l, kappa=self.kappa, nM=nM)
             if not ok:
-                self.stage = (f"lproof[{i}]", st)
+                self.stage = ("cmproof", st)
                 return False
-        cm = proof["cmproof"]
-        ok, st, _ = cm_verify(self.transcript, cm, cm["fcoms"])
-        if not ok:
-            self.stage = ("cmproof", st)
+            ok, st = decomp_verify(proof["dproof"], proof["linb2x"]["cm_g"], proof["linb2x"]["vo"], self.params.B, kappa=self.kappa, nM=nM)
+            if not ok:
+                self.stage = ("dproof", st)
+                return False
+        except LfPlusError as ex:
+            if ex.code != E_ARG:
+                raise
+            self.stage = ("malformed", str(ex))
             return False
-        ok, st = decomp_verify(proof["dproof"], proof["linb2x"]["cm_g"], proof["linb2x"]["vo"], self.params.B)
-        if not ok:
-            self.stage = ("dproof", st)
+        except (KeyError, TypeError, IndexError) as ex:
+            self.stage = ("malformed", repr(ex))
             return False
         self.stage = None
         return True

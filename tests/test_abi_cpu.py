@@ -23,6 +23,27 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(plus._lib(), n), f"liblfhip.so does not export {n}"
 
 
+def test_rust_binding_is_generated_from_the_headers():
+    """INTEGRATION.md section 1 / bindings/latticefold-hip-sys/src/lib.rs are the mechanical image of the two headers: regenerating gives the committed
+    text, every header symbol is declared exactly once, and the shared library exports each declared symbol"""
+    import importlib.util
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("gen_rust_bindings", os.path.join(root, "tools", "gen_rust_bindings.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text, fns = gen.generate()
+    assert open(gen.OUT).read() == text, "run tools/gen_rust_bindings.py --write"
+    doc = open(gen.DOC).read()
+    block = doc[doc.index(gen.BEGIN) + len(gen.BEGIN):doc.index(gen.END)]
+    assert block.strip() == ("```rust\n" + text + "```").strip(), "INTEGRATION.md binding block is stale: run tools/gen_rust_bindings.py --write"
+    from latticefold_amd import plus
+    declared = re.findall(r"pub fn (\w+)\(", text)
+    assert sorted(declared) == sorted(set(api.exported_symbols()) | set(plus.exported_symbols())) and len(declared) == len(set(declared))
+    lib = api._lib()
+    assert all(hasattr(lib, n) for n in declared)
+
+
 def test_lfplus_fails_loudly_without_a_gpu():
     import torch
     if torch.cuda.is_available():

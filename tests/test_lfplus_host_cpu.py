@@ -189,3 +189,53 @@ def test_plus_verifier_accepts_oracle_proofs_and_rejects_tampering():
                 assert got == (want[0], -want[1]), got
         assert ver.verify(proof) and lfp.plus_verify(ts_o, proof, B) == 0
     assert ver.transcript.get_challenge() == ts_o.challenge()
+
+
+def test_verifiers_refuse_malformed_proofs_instead_of_reading_past_them():
+    """The host verifiers are the one component that sees untrusted input: the C entry points index raw pointers with the shape parameters they are given, so
+    the wrappers must size every array from the VERIFIER's parameters and refuse (LFPLUS_E_ARG / stage "malformed") what does not fit -- never read it."""
+    z16 = lambda *s: np.zeros(s + (D,), dtype=np.uint64)
+    # ComR1CSProof with nvars = 32 but one round of messages
+    with pytest.raises(plus.LfPlusError) as e:
+        plus.r1cs_verify(plus.PoseidonTranscript(), {"nvars": 32, "msgs": z16(1, 4), "evals": z16(4)})
+    assert e.value.code == plus.E_ARG
+    with pytest.raises(plus.LfPlusError):
+        plus.r1cs_verify(plus.PoseidonTranscript(), {"nvars": 5, "msgs": z16(5, 4), "evals": z16(4)}, nvars=9)       # the verifier's nvars wins
+    # Out with a one-element e against nM = 100000
+    with pytest.raises(plus.LfPlusError) as e:
+        plus.set_check_verify(plus.PoseidonTranscript(), 4, {"e": z16(1, 1, 1), "b": z16(0), "msgs": z16(4, 4)}, nM=100000)
+    assert e.value.code == plus.E_ARG
+    # Dcom / CmProof: every field is checked against (nvars, L, k, nM, kappa)
+    nvars, L, k, nM, kappa = 6, 2, 2, 1, 1
+    per = 4 + 4 * nM
+    good = {"nvars": nvars, "k": k, "ell": 2, "kappa": kappa, "msgs": z16(nvars, 4), "e": z16(1 + nM, L * k, D), "b": z16(L), "v": z16(L),
+            "a": np.zeros((L, 1 + nM), dtype=np.uint64), "bb": z16(L, 1 + nM), "c": z16(L, 1 + nM), "comh": z16(L, kappa), "pa": z16(nvars, 3),
+            "pb": z16(nvars, 3), "ea": z16(L, per), "eb": z16(L, per)}
+    fcoms = [z16(3, kappa)] * L
+    assert plus.cm_verify(plus.PoseidonTranscript(), good, fcoms, nvars=nvars, L=L, k=k, ell=2, kappa=kappa, nM=nM)[0] is False      # well-formed, wrong: a verdict
+    for key in ("msgs", "e", "b", "v", "a", "bb", "c", "comh", "pa", "pb", "ea", "eb"):
+        bad = dict(good)
+        bad[key] = good[key][:-1] if good[key].shape[0] > 1 else good[key][..., :-1]
+        with pytest.raises(plus.LfPlusError) as e:
+            plus.cm_verify(plus.PoseidonTranscript(), bad, fcoms, nvars=nvars, L=L, k=k, ell=2, kappa=kappa, nM=nM)
+        assert e.value.code == plus.E_ARG, key
+    with pytest.raises(plus.LfPlusError):
+        plus.cm_verify(plus.PoseidonTranscript(), good, fcoms, nvars=nvars, L=L, k=k, ell=2, kappa=kappa, nM=3)          # more matrices on the verifier's side
+    with pytest.raises(plus.LfPlusError):
+        plus.range_check_verify(plus.PoseidonTranscript(), dict(good, nvars=20))                                          # metadata larger than the arrays
+    with pytest.raises(plus.LfPlusError):
+        plus.decomp_verify({"C0": z16(1), "C1": z16(1), "v0": z16(1, 2), "v1": z16(1, 2)}, z16(2), z16(1, 2), 7)
+    # PlusVerifier takes n, kappa from ITS matrix, k / ell from ITS parameters and nM from ITS matrix list
+    n = 1 << nvars
+    params = plus.PlusParameters(plus.LinParameters(kappa, plus.DecompParameters(8, k, 2)), 7)
+    ver = plus.PlusVerifier.init(np.zeros((kappa, n, D), dtype=np.uint64), [None] * nM, params, plus.PoseidonTranscript())
+    lp = {"nvars": 32, "msgs": z16(1, 4), "evals": z16(4)}
+    assert not ver.verify({"lproof": [lp], "cmproof": dict(good, fcoms=np.stack(fcoms)), "dproof": {}, "linb2x": {}}) and ver.stage[0] == "malformed"
+    cm_bad = dict(good, fcoms=np.stack(fcoms), nvars=3, k=9, kappa=7, ell=1)                                               # lying metadata is ignored: shapes rule
+    ver = plus.PlusVerifier.init(np.zeros((kappa, n, D), dtype=np.uint64), [None] * nM, params, plus.PoseidonTranscript())
+    assert not ver.verify({"lproof": [], "cmproof": cm_bad, "dproof": {"C0": z16(kappa), "C1": z16(kappa), "v0": z16(1 + nM, 2), "v1": z16(1 + nM, 2)},
+                           "linb2x": {"cm_g": z16(kappa), "vo": z16(1 + nM, 2)}}) and ver.stage[0] == "cmproof"
+    ver = plus.PlusVerifier.init(np.zeros((kappa, n, D), dtype=np.uint64), [None] * (nM + 2), params, plus.PoseidonTranscript())
+    assert not ver.verify({"lproof": [], "cmproof": dict(good, fcoms=np.stack(fcoms)), "dproof": {}, "linb2x": {}}) and ver.stage[0] == "malformed"
+    with pytest.raises(plus.LfPlusError):
+        plus.PlusVerifier.init(np.zeros((kappa + 1, n, D), dtype=np.uint64), [], params, plus.PoseidonTranscript())
