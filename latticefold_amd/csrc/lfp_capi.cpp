@@ -40,6 +40,43 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
 }
 extern "C" const char *lfplus_last_error(const lfplus_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+// ---- column sharding over `world` ranks, one GPU each (lfplus.h) ------------------------------------------------------------------------
+static int shard_geometry_ok(lfplus_ctx *c, int rank, int world) {
+    if (!c) return LFPLUS_E_ARG;
+    if (world < 1 || world > 64 || (world & (world - 1)) || rank < 0 || rank >= world) return fail(c, LFPLUS_E_ARG, "sharding: world must be a power of two <= 64, 0 <= rank < world");
+    if (c->A || c->f) return fail(c, LFPLUS_E_ARG, "sharding must be set before the matrix and the witness (a rank keeps only its columns of A)");
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_set_sharding(lfplus_ctx *c, int rank, int world, lfplus_exchange_fn cb, void *user) {
+    int rc = shard_geometry_ok(c, rank, world);
+    if (rc) return rc;
+    if (world > 1 && !cb) return fail(c, LFPLUS_E_ARG, "lfplus_set_sharding: no exchange callback");
+    c->sh = std::make_shared<LfpShard>();
+    c->sh->comm.rank = rank; c->sh->comm.world = world; c->sh->comm.cb = (lf_exchange_fn)cb; c->sh->comm.user = user;
+    c->rank = rank; c->world = world;
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_dist_unique_id(uint8_t *id128) { return lfdist::rccl_unique_id(id128) == 0 ? LFPLUS_OK : LFPLUS_E_HIP; }
+extern "C" int lfplus_dist_init(lfplus_ctx *c, int rank, int world, const uint8_t *id128) {
+    int rc = shard_geometry_ok(c, rank, world);
+    if (rc) return rc;
+    if (!id128) return fail(c, LFPLUS_E_ARG, "lfplus_dist_init: null id");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->sh = std::make_shared<LfpShard>();
+    if (lfdist::rccl_init(c->sh->comm, rank, world, id128) != 0) { c->sh.reset(); return fail(c, LFPLUS_E_HIP, "lfplus_dist_init: RCCL not loadable / ncclCommInitRank failed"); }
+    c->rank = rank; c->world = world;
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_dist_stats(lfplus_ctx *c, uint64_t *n_exchanges, double *total_us, double *max_us, int reset) {
+    if (!c) return LFPLUS_E_ARG;
+    lfdist::Comm zero, &cm = c->sh ? c->sh->comm : zero;
+    if (n_exchanges) *n_exchanges = cm.n_exchanges;
+    if (total_us) *total_us = cm.us_total;
+    if (max_us) *max_us = cm.us_max;
+    if (reset) { cm.n_exchanges = 0; cm.us_total = cm.us_max = 0; }
+    return LFPLUS_OK;
+}
+
 static int upload(lfplus_ctx *c, u64 **dst, const u64 *src, size_t words) {
     if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
     HIPCHK(c, hipMalloc(dst, words * 8));
@@ -59,7 +96,8 @@ static int shape_buffers(lfplus_ctx *c, u32 kappa, u64 n) {
     return LFPLUS_OK;
 }
 extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kappa, uint64_t n) {
-    if (!c || !A || !kappa || kappa > 64 || !n || n > (1ull << 32)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: bad shape");
+    if (!c || !A || !kappa || kappa > 64 || !n || n * (uint64_t)(c ? c->world : 1) > (1ull << 32)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: bad shape");
+    if (c->sharded() && (n & (n - 1) || n < 4 * (u64)c->world)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: a sharded context takes the rank's n / world columns, a power of two >= 4 world");
     if (!canonical(A, (size_t)kappa * n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
     c->have = false;
@@ -68,16 +106,21 @@ extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kapp
     if (rc) return rc;
     c->A = fresh;
     c->A_ref = std::shared_ptr<void>(fresh, [](void *p) { (void)hipFree(p); });
-    return shape_buffers(c, kappa, n);
+    c->nloc = n;
+    c->row0 = (u64)c->rank * n;
+    return shape_buffers(c, kappa, n * (u64)c->world);
 }
 // The commitment matrix of `from` (same device), not copied: PlusProver keeps one context per accumulated / fresh instance and one Ajtai matrix.
 // The allocation is reference-counted: it lives until the last context holding it re-uploads or is destroyed.
 extern "C" int lfplus_share_matrix(lfplus_ctx *c, lfplus_ctx *from) {
     if (!c || !from || c == from || !from->A || c->device != from->device) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrix: bad arguments");
+    if (c->f && from->sharded()) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrix: share a sharded matrix before the witness is set");
     HIPCHK(c, hipSetDevice(c->device));
     c->have = false;
     c->A = from->A;
     c->A_ref = from->A_ref;
+    c->sh = from->sh;          // the column slice of A fixes the shard geometry: sharers exchange over the same transport
+    c->rank = from->rank; c->world = from->world; c->nloc = from->nloc; c->row0 = from->row0;
     return shape_buffers(c, from->kappa, from->n);
 }
 extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) {
@@ -137,7 +180,7 @@ static void enqueue_phase1(lfplus_ctx *c, const u64 *v, u64 b, u32 k, const Plan
         u32 icnt = lfp::group_size(c->kappa - i0), k0 = 0;
         do {
             lfp::Phase1Args a;
-            a.f = v; a.A = c->A; a.n = c->n; a.kappa = c->kappa;
+            a.f = v; a.A = c->A; a.n = c->nloc; a.kappa = c->kappa;   // v: the rank's rows (all of them unsharded)
             a.i0 = i0; a.icnt = icnt;
             a.k = k; a.k0 = k0; a.kcnt = k ? lfp::group_size(k - k0) : 0;
             a.b = b; a.sh = log2_exact(b); a.J = p.J;
@@ -160,7 +203,7 @@ static int check_params(lfplus_ctx *c, u64 b, u32 k, u32 l) {
     return LFPLUS_OK;
 }
 static int prepare(lfplus_ctx *c, u32 k, const Plan &p) {
-    size_t dfb = (size_t)k * c->n * 16, cmw = p.nout_m + p.nout_f;
+    size_t dfb = (size_t)k * c->nloc * 16, cmw = p.nout_m + p.nout_f;
     if (c->Df_cap < dfb) {
         if (c->Df) (void)hipFree(c->Df);
         c->Df = nullptr; c->Df_cap = 0;
@@ -176,30 +219,61 @@ static int prepare(lfplus_ctx *c, u32 k, const Plan &p) {
     return ensure_part(c, (size_t)p.nblk * (p.nout_m + p.nout_f) + (size_t)p.nblk2 * 2 * p.nout_f);
 }
 // c->comMf: [comM_f (k, kappa, 16, 16) | cm_f (kappa, 16)];  c->coms: [C_Mf | cm_mtau]
-static void enqueue_from_f(lfplus_ctx *c, u64 b, u32 k, u32 l, const Plan &p) {
+// device vector of `words` canonical words: sum over the ranks mod p, in place (a sharded prover's partial commitments; drains the stream)
+static int xsum_dev(lfplus_ctx *c, u64 *d, size_t words) {
+    if (!c->sharded()) return LFPLUS_OK;
+    std::vector<u64> h(words);
+    HIPCHK(c, hipMemcpyAsync(h.data(), d, words * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    int rc = lfp_xsum(c, h.data(), words);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(d, h.data(), words * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));   // h is a local buffer
+    return LFPLUS_OK;
+}
+// Sharded: both passes run over the rank's columns of A and rows of f / tau; the partial comM_f | cm_f and C_Mf | cm_mtau are exchanged (one all-gather +
+// modular sum each: 2 per double commitment), and tau -- the gadget digits of the COMPLETE comM_f, a short non-zero prefix -- is rebuilt whole on every rank.
+static int enqueue_from_f(lfplus_ctx *c, u64 b, u32 k, u32 l, const Plan &p) {
     u64 *part1 = c->part, *part2 = part1 + (size_t)p.nblk * (p.nout_m + p.nout_f);
     size_t need = (size_t)c->kappa * k * 16 * l * 16;
+    const u32 nout1 = (u32)(p.nout_m + p.nout_f);
     (void)hipMemsetAsync(c->err_d, 0, 4, c->st);
     (void)hipMemsetAsync(c->tau + need, 0, (c->n - need) * 8, c->st);
-    enqueue_phase1(c, c->f, b, k, p, part1);
-    lfp::launch_reduce(part1, p.nblk, (u32)(p.nout_m + p.nout_f), c->comMf, (u32)p.nout_m, c->kappa, k, lfp::D / 2, l, c->tau, c->st);
+    enqueue_phase1(c, c->f + c->row0 * 16, b, k, p, part1);
+    if (!c->sharded()) {
+        lfp::launch_reduce(part1, p.nblk, nout1, c->comMf, (u32)p.nout_m, c->kappa, k, lfp::D / 2, l, c->tau, c->st);
+    } else {
+        lfp::launch_reduce(part1, p.nblk, nout1, c->comMf, 0, c->kappa, k, 2, 0, nullptr, c->st);
+        int rc = xsum_dev(c, c->comMf, nout1);
+        if (rc) return rc;
+        lfp::launch_reduce(c->comMf, 1, nout1, c->comMf, (u32)p.nout_m, c->kappa, k, lfp::D / 2, l, c->tau, c->st);   // one "block": the split of the summed comM_f
+        lfp::launch_mtau_all(c->tau, c->n, c->mtau, c->err_d, c->st);
+    }
     for (u32 i0 = 0; i0 < c->kappa;) {
         lfp::Phase2Args a;
-        a.A = c->A; a.tau = c->tau; a.n = c->n; a.kappa = c->kappa;
+        a.A = c->A; a.tau = c->tau + c->row0; a.n = c->nloc; a.kappa = c->kappa;
         a.i0 = i0; a.icnt = lfp::group_size(c->kappa - i0); a.J = p.J2;
-        a.mtau = c->mtau;
+        a.mtau = c->mtau + c->row0;
         a.part = part2;
         a.err = c->err_d;
         lfp::launch_phase2(a, p.nblk2, c->st);
         i0 += a.icnt;
     }
     lfp::launch_reduce(part2, p.nblk2, (u32)(2 * p.nout_f), c->coms, 0, c->kappa, k, 2, 0, nullptr, c->st);
+    return xsum_dev(c, c->coms, 2 * p.nout_f);
 }
 static int finish(lfplus_ctx *c) {
     u32 flag = 0;
     HIPCHK(c, hipMemcpyAsync(&flag, c->err_d, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
+    if (c->sharded()) {     // every rank must take the same branch: a digit outside the domain on ANY rank fails the call on all of them
+        std::vector<u64> all;
+        u64 mine = flag;
+        int rc = lfp_allgather(c, &mine, 1, all);
+        if (rc) return rc;
+        for (u64 x : all) flag |= (u32)x;
+    }
     if (flag) return fail(c, LFPLUS_E_EXP_DOMAIN, flag & 1 ? "lfplus_rg_from_f: a digit of f is outside (-d/2, d/2)" : "lfplus_rg_from_f: tau outside (-d/2, d/2)");
     return LFPLUS_OK;
 }
@@ -208,9 +282,9 @@ extern "C" int lfplus_rg_from_f(lfplus_ctx *c, uint64_t b, uint32_t k, uint32_t 
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     c->have = false;
-    Plan p = plan_for(c->n, c->kappa, k);
+    Plan p = plan_for(c->nloc, c->kappa, k);
     if ((rc = prepare(c, k, p))) return rc;
-    enqueue_from_f(c, b, k, l, p);
+    if ((rc = enqueue_from_f(c, b, k, l, p))) return rc;
     if ((rc = finish(c))) return rc;
     c->k = k;
     c->l = l;
@@ -221,12 +295,13 @@ extern "C" int lfplus_rg_from_f_timed(lfplus_ctx *c, uint64_t b, uint32_t k, uin
     if (!ms_avg || !iters) return fail(c, LFPLUS_E_ARG, "lfplus_rg_from_f_timed: bad arguments");
     int rc = lfplus_rg_from_f(c, b, k, l);   // warm-up + validation
     if (rc) return rc;
-    Plan p = plan_for(c->n, c->kappa, k);
+    if (c->sharded()) return fail(c, LFPLUS_E_ARG, "lfplus_rg_from_f_timed: unsharded contexts only (a sharded pass drains the stream at its two exchanges)");
+    Plan p = plan_for(c->nloc, c->kappa, k);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, hipEventRecord(e0, c->st));
-    for (u32 it = 0; it < iters; it++) enqueue_from_f(c, b, k, l, p);
+    for (u32 it = 0; it < iters; it++) (void)enqueue_from_f(c, b, k, l, p);
     HIPCHK(c, hipEventRecord(e1, c->st));
     HIPCHK(c, hipEventSynchronize(e1));
     float ms = 0;
@@ -239,6 +314,7 @@ extern "C" int lfplus_rg_from_f_timed(lfplus_ctx *c, uint64_t b, uint32_t k, uin
 extern "C" int lfplus_rg_read(lfplus_ctx *c, int8_t *Df, uint64_t *comMf, uint64_t *tau, int8_t *mtau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau) {
     if (!c) return LFPLUS_E_ARG;
     if (!c->have) return fail(c, LFPLUS_E_ARG, "lfplus_rg_read: no result (run lfplus_rg_from_f first)");
+    if (Df && c->sharded()) return fail(c, LFPLUS_E_ARG, "lfplus_rg_read: D_f of a sharded context exists per rank only (pass NULL)");
     HIPCHK(c, hipSetDevice(c->device));
     size_t cw = (size_t)c->kappa * 16;
     if (Df) HIPCHK(c, hipMemcpyAsync(Df, c->Df, (size_t)c->k * c->n * 16, hipMemcpyDeviceToHost, c->st));
@@ -256,12 +332,12 @@ extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint6
     if (!c->A || n != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_commit: matrix not set / length mismatch");
     if (!canonical(v, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_commit: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
-    Plan p = plan_for(c->n, c->kappa, 0);
+    Plan p = plan_for(c->nloc, c->kappa, 0);
     int rc = ensure_part(c, (size_t)p.nblk * p.nout_f + p.nout_f);
     if (rc) return rc;
-    u64 *dv = nullptr;
-    HIPCHK(c, hipMalloc(&dv, (size_t)n * 16 * 8));
-    (void)hipMemcpyAsync(dv, v, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st);
+    u64 *dv = nullptr;      // the rank's rows of v (all of them unsharded): partial commitment, summed over the ranks below
+    HIPCHK(c, hipMalloc(&dv, (size_t)c->nloc * 16 * 8));
+    (void)hipMemcpyAsync(dv, v + c->row0 * 16, (size_t)c->nloc * 16 * 8, hipMemcpyHostToDevice, c->st);
     u64 *res = c->part + (size_t)p.nblk * p.nout_f;
     enqueue_phase1(c, dv, 2, 0, p, c->part);
     lfp::launch_reduce(c->part, p.nblk, (u32)p.nout_f, res, 0, c->kappa, 0, 2, 0, nullptr, c->st);
@@ -270,7 +346,7 @@ extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint6
     (void)hipFree(dv);
     HIPCHK(c, e);
     HIPCHK(c, hipGetLastError());
-    return LFPLUS_OK;
+    return lfp_xsum(c, out, p.nout_f);
 }
 // r 2^64 mod p (Montgomery form) on the host
 static u64 to_mont(u64 a) { return (u64)((((unsigned __int128)a) << 64) % lfp::P); }

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include "../../include/lfplus.h"
+#include "lf_dist.h"
 #include "lfp_kernels.h"
 
 using lfp::u32;
@@ -54,13 +55,25 @@ struct LfpPool {
     }
 };
 
+// Column sharding of one prover over `world` ranks, one GPU each (BASELINE configs[4]): rank g owns rows [g n / world, (g + 1) n / world) of every
+// n-indexed object -- the high index bits, so sumcheck pairs (2j, 2j + 1) stay local for the first log2(n / world) rounds.  The transport is the main path's
+// (lf_dist.h: RCCL communicator or a host callback); the contexts of one PlusProver share it together with the commitment matrix.
+struct LfpShard {
+    lfdist::Comm comm;
+    ~LfpShard() { comm.destroy(); }
+};
+
 struct lfplus_ctx {
     int device = 0;
     hipStream_t st = nullptr;
     std::string err;
-    u64 *A = nullptr, *f = nullptr;
+    u64 *A = nullptr, *f = nullptr;   // sharded: A holds the rank's columns (kappa x nloc); f is the WHOLE witness (the host hands it to every rank)
     u32 kappa = 0;
-    u64 n = 0, nf = 0;
+    u64 n = 0, nf = 0;                // n: the GLOBAL width
+    std::shared_ptr<LfpShard> sh;
+    int rank = 0, world = 1;
+    u64 nloc = 0, row0 = 0;           // this rank's rows [row0, row0 + nloc); = (n, 0) unsharded.  Local in a sharded context: A, Df ([k][nloc][16]), g; whole: f, tau, mtau
+    bool sharded() const { return world > 1; }
     // results of the last from_f
     int8_t *Df = nullptr, *mtau = nullptr;
     u64 *comMf = nullptr, *tau = nullptr, *coms = nullptr;   // comMf: comM_f (k, kappa, 16, 16) | cm_f; coms: C_Mf | cm_mtau (kappa*16 words each)
@@ -126,5 +139,30 @@ static inline bool canonical(const u64 *w, size_t n) {
     for (size_t i = 0; i < n; i++)
         if (w[i] >= lfp::P) return false;
     return true;
+}
+// ---- exchanges of a sharded prover (no-ops when world == 1).  Every small exchange is "all-gather `words` u64 per rank, add the world vectors mod p" on host
+// buffers (the round messages and evaluations are summed on the host anyway); the two large ones (h and the folded g, n ring elements) are device all-gathers.
+static inline u64 lfp_addp(u64 a, u64 b) { unsigned __int128 s = (unsigned __int128)a + b; return (u64)(s >= lfp::P ? s - lfp::P : s); }
+static inline int lfp_xsum(lfplus_ctx *c, u64 *v, size_t words) {
+    if (!c->sharded() || !words) return LFPLUS_OK;
+    std::vector<u64> all((size_t)c->world * words);
+    if (c->sh->comm.allgather_host(v, all.data(), words, c->st) != 0) return fail(c, LFPLUS_E_HIP, "sharded prover: exchange failed");
+    for (size_t i = 0; i < words; i++) {
+        u64 s = 0;
+        for (int g = 0; g < c->world; g++) s = lfp_addp(s, all[(size_t)g * words + i]);
+        v[i] = s;
+    }
+    return LFPLUS_OK;
+}
+// every rank's `words` (host) -> all[world][words]
+static inline int lfp_allgather(lfplus_ctx *c, const u64 *mine, size_t words, std::vector<u64> &all) {
+    all.assign((size_t)c->world * words, 0);
+    if (c->sh->comm.allgather_host(mine, all.data(), words, c->st) != 0) return fail(c, LFPLUS_E_HIP, "sharded prover: exchange failed");
+    return LFPLUS_OK;
+}
+// device all-gather of the ranks' row slices (words per rank) into the whole vector, in row order
+static inline int lfp_allgather_dev(lfplus_ctx *c, const u64 *mine_dev, u64 *whole_dev, size_t words) {
+    if (c->sh->comm.allgather_dev(mine_dev, whole_dev, words, c->st) != 0) return fail(c, LFPLUS_E_HIP, "sharded prover: device all-gather failed");
+    return LFPLUS_OK;
 }
 

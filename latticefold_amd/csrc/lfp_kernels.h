@@ -39,6 +39,7 @@ struct Phase2Args {
 };
 void launch_phase1(const Phase1Args &a, u32 nblk, hipStream_t s);
 void launch_phase2(const Phase2Args &a, u32 nblk, hipStream_t s);
+void launch_mtau_all(const u64 *tau, u64 n, int8_t *mtau, u32 *err, hipStream_t s);
 // out[o] = sum over blocks of part[blk][o] mod p; with l != 0 the first nsplit outputs (comM_f, [k][kappa][16][16]) are also cut into
 // their l gadget digits: tau = split(hconcat(comM_f), n, base, l) (utils.rs:12-43), positions [0, kappa*k*16*l*16)
 void launch_reduce(const u64 *part, u32 nblk, u32 nout, u64 *out, u32 nsplit, u32 kappa, u32 k, u64 base, u32 l, u64 *tau, hipStream_t s);

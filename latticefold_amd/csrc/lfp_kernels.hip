@@ -395,6 +395,17 @@ void launch_phase1(const Phase1Args &a, u32 nblk, hipStream_t s) {
     else if (a.icnt == 2) launch_phase1_i<2>(a, nblk, s);
     else launch_phase1_i<4>(a, nblk, s);
 }
+// m_tau = exp(tau) as exponents for ALL n entries (a sharded prover: phase 2 writes only the rank's rows, the whole vector is the input of the M m_tau rows)
+__global__ void __launch_bounds__(256) k_mtau_all(const u64 *tau, u64 n, int8_t *mtau, u32 *err) {
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int64_t tc = centre(tau[j]);
+    if (tc <= -(D / 2) || tc >= D / 2) { atomicOr(err, 2u); tc = 0; }
+    mtau[j] = (int8_t)tc;
+}
+void launch_mtau_all(const u64 *tau, u64 n, int8_t *mtau, u32 *err, hipStream_t s) {
+    hipLaunchKernelGGL(k_mtau_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tau, n, mtau, err);
+}
 void launch_phase2(const Phase2Args &a, u32 nblk, hipStream_t s) {
     if (a.icnt == 1) hipLaunchKernelGGL(k_rg_phase2<1>, dim3(nblk), dim3(256), 0, s, a);
     else if (a.icnt == 2) hipLaunchKernelGGL(k_rg_phase2<2>, dim3(nblk), dim3(256), 0, s, a);

@@ -734,3 +734,72 @@ class PlusVerifier:
             return False
         self.stage = None
         return True
+
+
+# ---- deterministic synthetic workloads (numpy only: no oracle, no GPU) -----------------------------------------------------------------------
+# The shape of the reference's end-to-end bench (benches/e2e.rs:57-100: `setup_input(n, L, k, kappa)`: decomposed-square R1CS over identity matrices,
+# BinaryChoice witness, L fresh instances folded by one PlusProver::prove, B = estimate_bound(d * 128, L, d, k) / 2, l = ceil(log_{d/2} q)).
+# Differences, deliberate: the L instances are distinct (the bench clones one), the Ajtai matrix is i.i.d. from an indexable SplitMix64 stream.
+PLUS_CONFIGS = {
+    # name: (nvars, L, k, kappa)
+    "P12": (12, 2, 2, 1),        # tiny: unit tests of the sharded path (kappa k d l d = 11264 > n: from_f refuses it -- used with k = 1 shapes only)
+    "P15": (15, 3, 4, 1),        # kappa 1 keeps tau inside n = 2^15 (kappa k d l d = 22528)
+    "P16": (16, 3, 4, 2),        # benches/utils/mod.rs:282-301 PROTOCOL_SCALING[1] = (65536, 3, 4, 2)
+    "P17": (17, 3, 4, 2),        # PROTOCOL_SCALING[2] = (131072, 3, 4, 2): the reference's largest e2e row
+    "P20": (20, 3, 4, 2),        # BASELINE configs[4]: 2^20 rows (the same row extrapolated)
+}
+
+
+def estimate_bound(sop, L, d, k):
+    """utils::estimate_bound (utils.rs:102-112)"""
+    a, c = sop * L, d // 2 + d * k + 1
+    return math.ceil((a + math.sqrt(float(a * a + 4 * a * c))) / 2.0)
+
+
+def _splitmix_words(seed, start, count):
+    from .workload import _G, _M1, _M2
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed & (2**64 - 1)) + idx * _G
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+@dataclass
+class PlusWorkload:
+    name: str
+    nvars: int
+    L: int
+    k: int
+    kappa: int
+    B: int
+    l: int
+
+    @property
+    def n(self):
+        return 1 << self.nvars
+
+    def params(self):
+        return PlusParameters(LinParameters(self.kappa, DecompParameters(D // 2, self.k, self.l)), self.B)
+
+    def ajtai_matrix(self, cols=None):
+        """(kappa, n, 16) canonical words, or the column range cols = (c0, c1) of it (what a rank of a sharded prover uploads)"""
+        c0, c1 = cols if cols is not None else (0, self.n)
+        rows = [_splitmix_words(0xA17A2 + self.nvars, (i * self.n + c0) * D, (c1 - c0) * D) % np.uint64(P) for i in range(self.kappa)]
+        return np.stack(rows).reshape(self.kappa, c1 - c0, D)
+
+    def r1cs(self):
+        return r1cs_decomposed_square((identity_csr(self.n // self.k),) * 3, self.n, self.B, self.k)
+
+    def z(self, i):
+        """WitnessPattern::BinaryChoice: constant coefficient 0 / 1 (so z o z = z holds for the square system)"""
+        z = np.zeros((self.n // self.k, D), dtype=np.uint64)
+        z[:, 0] = _splitmix_words(0x2B1A0 + 977 * i + self.nvars, 0, self.n // self.k) >> np.uint64(63)
+        return z
+
+
+def make_plus_workload(name):
+    nvars, L, k, kappa = PLUS_CONFIGS[name]
+    B = estimate_bound(D * 128, L, D, k) // 2                                    # benches/e2e.rs:71
+    return PlusWorkload(name, nvars, L, k, kappa, B, math.ceil(math.log(float(P)) / math.log(D / 2)))
