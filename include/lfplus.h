@@ -51,7 +51,26 @@ int lfplus_ctx_create(int device, lfplus_ctx **out);
 void lfplus_ctx_destroy(lfplus_ctx *ctx);
 const char *lfplus_last_error(const lfplus_ctx *ctx);
 
-/* Ajtai matrix A (kappa x n ring elements, row-major, coefficient form); stays resident in HBM.  kappa <= 64. */
+/* ---- multi-GPU: one prover column-sharded over `world` ranks, one GPU each (BASELINE configs[4]) ------------------------------------------
+ * Rank g owns rows [g n / world, (g + 1) n / world) of every n-indexed object: its COLUMNS of the commitment matrix (lfplus_set_matrix then takes the
+ * kappa x n / world slice), its rows of D_f, of the set-check / Cm / linearization tables and of the folded witness g.  Witnesses (lfplus_set_witness, the
+ * F0 / F1 lfplus_decompose returns) are whole on every rank, as the host hands them over; tau and m_tau (a short non-zero prefix) are rebuilt whole.
+ * Exchanged, each as "all-gather + sum mod p": the partial commitments (2 per double commitment, 1 per lfplus_commit / lfplus_decompose), the partial
+ * sumcheck round messages of the first log2(n / world) rounds (then the tables are gathered, one entry per rank, and the last log2(world) rounds run
+ * replicated), the partial evaluations; all-gathered whole: h (per instance, only with constraint matrices) and the folded witness.  Every rank runs the
+ * identical transcript and returns the identical proof.  Call before lfplus_set_matrix; contexts that lfplus_share_matrix the matrix share the transport.
+ * n / world must be a power of two >= 4 world.  lfplus_set_sharding: host transport, `cb` must all-gather `words` u64 from every rank into
+ * recv_all[world * words] in rank order and return 0 (gloo in the tests).  lfplus_dist_init: an RCCL communicator owned by the library (one rank per GPU,
+ * xGMI) from a 128-byte ncclUniqueId that rank 0 obtains with lfplus_dist_unique_id and the launcher distributes; RCCL is loaded with dlopen. */
+typedef int (*lfplus_exchange_fn)(void *user, const uint64_t *send, uint64_t *recv_all, size_t words);
+int lfplus_set_sharding(lfplus_ctx *ctx, int rank, int world, lfplus_exchange_fn cb, void *user);
+int lfplus_dist_unique_id(uint8_t *id128);
+int lfplus_dist_init(lfplus_ctx *ctx, int rank, int world, const uint8_t *id128);
+/* exchange log of the context's transport: number of exchanges, summed and maximal host-side latency in microseconds (reset != 0 clears it) */
+int lfplus_dist_stats(lfplus_ctx *ctx, uint64_t *n_exchanges, double *total_us, double *max_us, int reset);
+
+/* Ajtai matrix A (kappa x n ring elements, row-major, coefficient form); stays resident in HBM.  kappa <= 64.  In a sharded context: the rank's columns,
+ * kappa x (n / world), and `n` is that local width. */
 int lfplus_set_matrix(lfplus_ctx *ctx, const uint64_t *A, uint32_t kappa, uint64_t n);
 /* use the commitment matrix resident in `from` (same device) without copying it; the allocation is reference-counted and lives until its last holder
  * re-uploads or is destroyed */

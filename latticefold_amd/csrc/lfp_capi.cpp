@@ -1,6 +1,8 @@
 // lfp_capi.cpp -- host driver + C ABI (include/lfplus.h) of the LatticeFold+ double commitment on the Frog ring.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/lfplus.h"
@@ -373,14 +375,17 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
         if (!canonical(val[j], (size_t)nnz * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: non-canonical coefficient");
     }
     HIPCHK(c, hipSetDevice(c->device));
+    // Sharded: the witness is whole on every rank (after lfplus_mlin: all-gathered), F0 / F1 are cut whole (element-wise, cheap) because the M_j F_i rows
+    // read arbitrary columns; the tables -- the rank's rows of F_i and of M_j F_i -- are fixed locally for the first log2(n / world) variables, gathered (one
+    // entry per table and rank) and finished replicated; the two commitments are partial sums over the rank's columns (one exchange).
     const u32 E = 2 * (1 + nm), T = 2 * E;        // vectors (F0, M_j F0 .., F1, M_j F1 ..), tables = one per vector and point
-    const size_t vw = (size_t)n * 16;
+    const size_t vw = (size_t)n * 16, nl = c->nloc, lw = nl * 16, r0w = c->row0 * 16;
     u64 *buf = nullptr;
-    // F0 | F1 | tables T*n | ping T*n/2 | rM nvars*32
-    const size_t words = 2 * vw + (size_t)T * vw + (size_t)T * vw / 2 + (size_t)nvars * 32 + 64;
+    // F0 | F1 | tables T*nloc | ping T*nloc/2 | rM nvars*32 | gathered tables T*world
+    const size_t words = 2 * vw + (size_t)T * lw + (size_t)T * lw / 2 + (size_t)nvars * 32 + 64 + (size_t)T * c->world * 16;
     buf = (u64 *)c->pool.get(words * 8);
     if (!buf) return fail(c, LFPLUS_E_HIP, "hipMalloc (decompose tables)");
-    u64 *dF0 = buf, *dF1 = dF0 + vw, *tab = dF1 + vw, *ping = tab + (size_t)T * vw, *drM = ping + (size_t)T * vw / 2;
+    u64 *dF0 = buf, *dF1 = dF0 + vw, *tab = dF1 + vw, *ping = tab + (size_t)T * lw, *drM = ping + (size_t)T * lw / 2, *gath = drM + (size_t)nvars * 32 + 64;
     int rc = LFPLUS_OK;
     std::vector<void *> tofree;
     auto cleanup = [&]() { for (void *q : tofree) c->pool.put(q); c->pool.put(buf); };
@@ -398,17 +403,17 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
     lfp::launch_decompose2(c->f, vw, B, dF0, dF1, c->st);
     for (int s = 0; s < 2; s++) {
         const u64 *Fi = s ? dF1 : dF0;
-        lfp::launch_replicate(Fi, vw, 2, tab + (size_t)(s * (1 + nm)) * 2 * vw, c->st);
+        lfp::launch_replicate(Fi + r0w, lw, 2, tab + (size_t)(s * (1 + nm)) * 2 * lw, c->st);
     }
     for (u32 j = 0; j < nm; j++) {
         u32 *drp = nullptr, *dci = nullptr;
         u64 *dv = nullptr, *dy = nullptr;
         if (resident) {
-            dy = (u64 *)c->pool.get(vw * 8); if (!dy) { cleanup(); return fail(c, LFPLUS_E_HIP, "hipMalloc"); } tofree.push_back(dy);
+            dy = (u64 *)c->pool.get(lw * 8); if (!dy) { cleanup(); return fail(c, LFPLUS_E_HIP, "hipMalloc"); } tofree.push_back(dy);
             const LfpMatrix &mj = c->mats[j];
             for (int s = 0; s < 2; s++) {
-                lfp::launch_spmv_ring(mj.rowptr, mj.col, mj.valM, s ? dF1 : dF0, n, dy, c->st);
-                lfp::launch_replicate(dy, vw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * vw, c->st);
+                lfp::launch_spmv_ring(mj.rowptr + c->row0, mj.col, mj.valM, s ? dF1 : dF0, nl, dy, c->st);
+                lfp::launch_replicate(dy, lw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * lw, c->st);
             }
             continue;
         }
@@ -416,7 +421,7 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
         HIPCHK2(hipMalloc(&drp, (n + 1) * 4)); tofree.push_back(drp);
         HIPCHK2(hipMalloc(&dci, (size_t)(nnz ? nnz : 1) * 4)); tofree.push_back(dci);
         HIPCHK2(hipMalloc(&dv, (size_t)(nnz ? nnz : 1) * 16 * 8)); tofree.push_back(dv);
-        HIPCHK2(hipMalloc(&dy, vw * 8)); tofree.push_back(dy);
+        HIPCHK2(hipMalloc(&dy, lw * 8)); tofree.push_back(dy);
         std::vector<u64> vM((size_t)nnz * 16);
         for (size_t i = 0; i < vM.size(); i++) vM[i] = to_mont(val[j][i]);
         HIPCHK2(hipMemcpyAsync(drp, rowptr[j], (n + 1) * 4, hipMemcpyHostToDevice, c->st));
@@ -424,17 +429,30 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
         HIPCHK2(hipMemcpyAsync(dv, vM.data(), vM.size() * 8, hipMemcpyHostToDevice, c->st));
         HIPCHK2(hipStreamSynchronize(c->st));   // vM is a local buffer
         for (int s = 0; s < 2; s++) {
-            lfp::launch_spmv_ring(drp, dci, dv, s ? dF1 : dF0, n, dy, c->st);
-            lfp::launch_replicate(dy, vw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * vw, c->st);
+            lfp::launch_spmv_ring(drp + c->row0, dci, dv, s ? dF1 : dF0, nl, dy, c->st);
+            lfp::launch_replicate(dy, lw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * lw, c->st);
         }
     }
     // fix_variables, variable 0 first, all T tables at once
     {
         u64 *cur = tab, *nxt = ping;
-        size_t len = n;
+        size_t len = nl;
         for (u32 k = 0; k < nvars; k++) {
+            if (c->sharded() && len == 1) {       // one entry per table left on every rank: gather them (entry index = rank: the high bits) and finish replicated
+                std::vector<u64> mine((size_t)T * 16), all, re((size_t)T * c->world * 16);
+                HIPCHK2(hipMemcpyAsync(mine.data(), cur, mine.size() * 8, hipMemcpyDeviceToHost, c->st));
+                HIPCHK2(hipStreamSynchronize(c->st));
+                if ((rc = lfp_allgather(c, mine.data(), mine.size(), all))) { cleanup(); return rc; }
+                for (u32 t = 0; t < T; t++)
+                    for (int g = 0; g < c->world; g++) memcpy(&re[((size_t)t * c->world + g) * 16], &all[((size_t)g * T + t) * 16], 16 * 8);
+                HIPCHK2(hipMemcpyAsync(gath, re.data(), re.size() * 8, hipMemcpyHostToDevice, c->st));
+                HIPCHK2(hipStreamSynchronize(c->st));
+                cur = gath; nxt = tab;
+                len = (size_t)c->world;
+            }
             lfp::launch_ring_fix(cur, nxt, T, len, drM + (size_t)k * 32, c->st);
             std::swap(cur, nxt);
+            if (nxt == gath) nxt = ping;
             len /= 2;
         }
         // cur: T ring elements, table index = (s*(1+nm) + j)*2 + point
@@ -443,14 +461,15 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
     }
     // commitments of the two parts
     {
-        Plan p = plan_for(c->n, c->kappa, 0);
+        Plan p = plan_for(c->nloc, c->kappa, 0);
         rc = ensure_part(c, (size_t)p.nblk * p.nout_f + 2 * p.nout_f);
         if (rc) { cleanup(); return rc; }
         u64 *res = c->part + (size_t)p.nblk * p.nout_f;
         for (int s = 0; s < 2; s++) {
-            enqueue_phase1(c, s ? dF1 : dF0, 2, 0, p, c->part);
+            enqueue_phase1(c, (s ? dF1 : dF0) + r0w, 2, 0, p, c->part);
             lfp::launch_reduce(c->part, p.nblk, (u32)p.nout_f, res + (size_t)s * p.nout_f, 0, c->kappa, 0, 2, 0, nullptr, c->st);
         }
+        if ((rc = xsum_dev(c, res, 2 * p.nout_f))) { cleanup(); return rc; }
         if (C0) HIPCHK2(hipMemcpyAsync(C0, res, p.nout_f * 8, hipMemcpyDeviceToHost, c->st));
         if (C1) HIPCHK2(hipMemcpyAsync(C1, res + p.nout_f, p.nout_f * 8, hipMemcpyDeviceToHost, c->st));
     }

@@ -379,24 +379,61 @@ struct MatHold {
 };
 
 struct ScOut {          // device-side leftovers the range check reuses
-    DevBuf eqr;         // eq(r, .) Montgomery, n words
-    std::vector<std::unique_ptr<DevBuf>> w;   // w_q = M_q^T eq(r): n ring elements each
+    DevBuf eqr;         // eq(r, .) Montgomery, n words (whole on every rank: M^T eq reads arbitrary rows)
+    std::vector<std::unique_ptr<DevBuf>> w;   // w_q = M_q^T eq(r): the rank's nloc ring elements each
     DevBuf part, small;
 };
+// eq(c, .) over the rank's rows [row0, row0 + nloc): the local index carries the low nv_loc variables, the rank the high ones, so the slice is the
+// nv_loc-variable table scaled by eq(c_hi, rank) (pt.one)
+lfp::EqPt eq_point(const u64 *cch, u32 nvars) {
+    lfp::EqPt pt;
+    for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(cch[j]); pt.nc[j] = to_mont(fsub(1, cch[j])); }
+    pt.one = to_mont(1);
+    return pt;
+}
+void eq_build_local(lfplus_ctx *c, const u64 *cch, u32 nvars, u64 *eq_loc) {
+    lfp::EqPt pt = eq_point(cch, nvars);
+    u32 nv_loc = nvars;
+    if (c->sharded()) {
+        nv_loc = 0;
+        while (((u64)1 << nv_loc) < c->nloc) nv_loc++;
+        u64 sc = 1;
+        for (u32 j = nv_loc; j < nvars; j++) sc = fmul(sc, ((u64)c->rank >> (j - nv_loc)) & 1 ? cch[j] : fsub(1, cch[j]));
+        pt.one = to_mont(sc);
+    }
+    lfp::launch_eq_build(pt, nv_loc, eq_loc, c->st);
+}
+// The last log2(world) rounds of a sharded sumcheck: every rank holds ONE entry of each of `ntab` tables of `w` words (device, row stride ld words); gather them and
+// lay them out as whole tables of `world` entries (entry index = rank: the high index bits) in `out` (device, ntab x world x w words, row stride world)
+int gather_tables(lfplus_ctx *c, const u64 *tab, size_t ld, u32 ntab, u32 w, u64 *out) {
+    std::vector<u64> mine((size_t)ntab * w), all, re((size_t)ntab * c->world * w);
+    HIPCHK(c, hipMemcpy2DAsync(mine.data(), (size_t)w * 8, tab, ld * w * 8, (size_t)w * 8, ntab, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    int rc = lfp_allgather(c, mine.data(), mine.size(), all);
+    if (rc) return rc;
+    for (u32 t = 0; t < ntab; t++)
+        for (int g = 0; g < c->world; g++) memcpy(&re[((size_t)t * c->world + g) * w], &all[((size_t)g * ntab + t) * w], (size_t)w * 8);
+    HIPCHK(c, hipMemcpyAsync(out, re.data(), re.size() * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));   // re is a local buffer
+    return LFPLUS_OK;
+}
 
 // In::set_check on device-resident monomial sets (matrix sets first, then vector sets, as setchk.rs:66-82 orders them)
 int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::vector<SetRef> &mats, const std::vector<SetRef> &vecs,
                   const MatHold &M, u64 *r_out, u64 *msgs, u64 *e_out, u64 *b_out, ScOut &so) {
-    const size_t n = (size_t)1 << nvars;
+    // Sharded (c->world > 1): the SetRefs point at the rank's rows; tables, rounds and evaluations run over those nl rows, the partial round messages and
+    // partial evaluations are summed over the ranks, and the last log2(world) rounds run replicated on gathered tables.
+    const size_t n = (size_t)1 << nvars, nl = c->sharded() ? (size_t)c->nloc : n;
+    if (c->sharded() && c->n != n) return fail(c, LFPLUS_E_ARG, "set_check: a sharded context checks sets of its own width n");
     const u32 nmat = (u32)mats.size(), nvec = (u32)vecs.size(), nM = (u32)M.size();
     if (nmat < 1) return fail(c, LFPLUS_E_ARG, "set_check: at least one matrix set (setchk.rs:63)");
     const u32 ncols = mats[0].ncols;
     for (auto &m : mats) if (m.ncols != ncols) return fail(c, LFPLUS_E_ARG, "set_check: matrix sets of different widths");
     const u32 ntab = nmat * (2 * ncols + 1) + 3 * nvec;
-    DevBuf tabs[2], coefd;
-    if (tabs[0].alloc((size_t)ntab * n * 8) || tabs[1].alloc((size_t)ntab * n * 8) || coefd.alloc((size_t)(nmat + nvec) * ncols * 8) ||
+    DevBuf tabs[2], coefd, tgath;
+    if (tabs[0].alloc((size_t)ntab * nl * 8) || tabs[1].alloc((size_t)ntab * nl * 8) || coefd.alloc((size_t)(nmat + nvec) * ncols * 8) ||
         so.eqr.alloc(n * 8) || so.part.alloc((size_t)lfp::eval_chunks(n) * ncols * 16 * 8) ||
-        so.small.alloc((size_t)((1 + nM) * nmat * ncols + nvec + 8) * D * 8))
+        so.small.alloc((size_t)((1 + nM) * nmat * ncols + nvec + 8) * D * 8) || (c->sharded() && tgath.alloc((size_t)ntab * c->world * 8)))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (set check tables)");
     std::vector<u64> alpha(nmat + nvec), cch(nvars);
     for (u32 i = 0; i < nmat + nvec; i++) {
@@ -407,11 +444,8 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         lfp::PwTab pw;
         u64 bp = 1;
         for (int t = 0; t < 16; t++) { pw.p[t] = to_mont(bp); pw.q[t] = to_mont(fmul(bp, bp)); bp = fmul(bp, beta); }
-        lfp::launch_sc_tables(sr.dig, n, cols, pw, tabs[0].as<u64>() + (size_t)t0 * n, n, c->st);
-        lfp::EqPt pt;
-        for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(cch[j]); pt.nc[j] = to_mont(fsub(1, cch[j])); }
-        pt.one = to_mont(1);
-        lfp::launch_eq_build(pt, nvars, tabs[0].as<u64>() + (size_t)(t0 + 2 * cols) * n, c->st);
+        lfp::launch_sc_tables(sr.dig, nl, cols, pw, tabs[0].as<u64>() + (size_t)t0 * nl, nl, c->st);
+        eq_build_local(c, cch.data(), nvars, tabs[0].as<u64>() + (size_t)(t0 + 2 * cols) * nl);
         alpha[i] = tr->challenge();
     }
     const bool have_rc = nmat > 1;
@@ -433,28 +467,46 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     u64 *hpart = c->pin((size_t)lfp::sc_round_max_blocks() * 4);   // the kernels write their block partials into mapped host memory
     if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
     int cur = 0;
-    size_t len = n;
+    size_t len = nl, ld = nl;
+    bool dist = c->sharded();
+    const u64 *tcur = tabs[0].as<u64>();
     for (u32 rnd = 0; rnd < nvars; rnd++) {
+        if (dist && len == 1) {      // one entry per table and rank left: gather, finish replicated
+            int rcg = gather_tables(c, tcur, ld, ntab, 1, tgath.as<u64>());
+            if (rcg) return rcg;
+            tcur = tgath.as<u64>();
+            ld = len = (size_t)c->world;
+            dist = false;
+        }
         const size_t half = len / 2;
         auto tA = std::chrono::steady_clock::now();
-        const u32 nb = lfp::launch_sc_round(tabs[cur].as<u64>(), n, half, d, coefd.as<u64>(), c->hpin_dev, c->st);
+        const u32 nb = lfp::launch_sc_round(tcur, ld, half, d, coefd.as<u64>(), c->hpin_dev, c->st);
         HIPCHK(c, hipStreamSynchronize(c->st));
         auto tB = std::chrono::steady_clock::now();
         u64 *m = msgs + (size_t)rnd * 4 * D;
         memset(m, 0, 4 * D * 8);
+        u64 sums[4];
         for (int x = 0; x < 4; x++) {
             u64 s = 0;
             for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 4 + x]);
-            m[x * D] = from_mont(s);
+            sums[x] = s;
         }
+        if (dist) { int rcx = lfp_xsum(c, sums, 4); if (rcx) return rcx; }
+        for (int x = 0; x < 4; x++) m[x * D] = from_mont(sums[x]);
         tr->absorb_ring(m, 4);
         const u64 r = tr->challenge();
         tr->absorb_const(r);
         r_out[rnd] = r;
         auto tC = std::chrono::steady_clock::now();
-        if (rnd + 1 < nvars) {   // fix_variables of every table into the other buffer (rows keep the stride n)
-            lfp::launch_sc_fix(tabs[cur].as<u64>(), tabs[cur ^ 1].as<u64>(), n, ntab, half, to_mont(r), c->st);
-            cur ^= 1;
+        if (rnd + 1 < nvars) {   // fix_variables of every table into the other buffer (rows keep their stride)
+            if (tcur == tgath.as<u64>() && c->sharded()) {      // the gathered tables have stride world: fix them into tabs[0] with the same stride
+                lfp::launch_sc_fix(tcur, tabs[0].as<u64>(), ld, ntab, half, to_mont(r), c->st);
+                cur = 0;
+            } else {
+                lfp::launch_sc_fix(tcur, tabs[cur ^ 1].as<u64>(), ld, ntab, half, to_mont(r), c->st);
+                cur ^= 1;
+            }
+            tcur = tabs[cur].as<u64>();
         }
         if (g_tl.on) fprintf(stderr, "[lfplus]   sc round %2u: gpu+sync %6.1f us, host %6.1f us, fix launch %5.1f us (nb %u)\n", rnd, std::chrono::duration<double, std::micro>(tB - tA).count(),
                              std::chrono::duration<double, std::micro>(tC - tB).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tC).count(), nb);
@@ -462,26 +514,30 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     }
     LFP_MARK(c, "set check: sumcheck rounds");
     // Step 3 (setchk.rs:206-249): the sets at r, M_q * sets at r, the vector sets at r
-    lfp::EqPt pt;
-    for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(r_out[j]); pt.nc[j] = to_mont(fsub(1, r_out[j])); }
-    pt.one = to_mont(1);
-    lfp::launch_eq_build(pt, nvars, so.eqr.as<u64>(), c->st);
-    for (u32 q = 0; q < nM; q++) {
+    const size_t row0 = c->sharded() ? (size_t)c->row0 : 0;
+    lfp::launch_eq_build(eq_point(r_out, nvars), nvars, so.eqr.as<u64>(), c->st);
+    const u64 *eql = so.eqr.as<u64>() + row0;      // eq(r, .) over the rank's rows
+    for (u32 q = 0; q < nM; q++) {                 // w_q = M_q^T eq(r) over the rank's COLUMNS (its rows of the vectors M_q multiplies); eq whole
         std::unique_ptr<DevBuf> w(new DevBuf);
-        if (w->alloc(n * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (M^T eq)");
-        lfp::launch_spmvT_eq(M[q].colptr, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), n, w->as<u64>(), c->st);
+        if (w->alloc(nl * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (M^T eq)");
+        lfp::launch_spmvT_eq(M[q].colptr + row0, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
         so.w.push_back(std::move(w));
     }
     u64 *ed = so.small.as<u64>(), *bd = ed + (size_t)(1 + nM) * nmat * ncols * D;
     for (u32 i = 0; i < nmat; i++) {
-        lfp::launch_wmono(mats[i].dig, n, ncols, so.eqr.as<u64>(), 1, so.part.as<u64>(), ed + (size_t)i * ncols * D, c->st);
+        lfp::launch_wmono(mats[i].dig, nl, ncols, eql, 1, so.part.as<u64>(), ed + (size_t)i * ncols * D, c->st);
         for (u32 q = 0; q < nM; q++)
-            lfp::launch_wmono(mats[i].dig, n, ncols, so.w[q]->as<u64>(), 16, so.part.as<u64>(), ed + ((size_t)(1 + q) * nmat + i) * ncols * D, c->st);
+            lfp::launch_wmono(mats[i].dig, nl, ncols, so.w[q]->as<u64>(), 16, so.part.as<u64>(), ed + ((size_t)(1 + q) * nmat + i) * ncols * D, c->st);
     }
-    for (u32 i = 0; i < nvec; i++) lfp::launch_wmono(vecs[i].dig, n, 1, so.eqr.as<u64>(), 1, so.part.as<u64>(), bd + (size_t)i * D, c->st);
+    for (u32 i = 0; i < nvec; i++) lfp::launch_wmono(vecs[i].dig, nl, 1, eql, 1, so.part.as<u64>(), bd + (size_t)i * D, c->st);
     HIPCHK(c, hipMemcpyAsync(e_out, ed, (size_t)(1 + nM) * nmat * ncols * D * 8, hipMemcpyDeviceToHost, c->st));
     if (nvec) HIPCHK(c, hipMemcpyAsync(b_out, bd, (size_t)nvec * D * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    {   // partial evaluations over the rank's rows -> sums over the ranks
+        int rcx = lfp_xsum(c, e_out, (size_t)(1 + nM) * nmat * ncols * D);
+        if (!rcx && nvec) rcx = lfp_xsum(c, b_out, (size_t)nvec * D);
+        if (rcx) return rcx;
+    }
     tr->absorb_ring(e_out, (size_t)(1 + nM) * nmat * ncols);   // absorb_evaluations (setchk.rs:342-353)
     tr->absorb_ring(b_out, nvec);
     LFP_MARK(c, "set check: evaluations + absorb");
@@ -509,8 +565,9 @@ extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t n
     HIPCHK(c, hipMemcpyAsync(dm.p, mat_digits, (size_t)nmat * n * ncols, hipMemcpyHostToDevice, c->st));
     if (nvec) HIPCHK(c, hipMemcpyAsync(dv.p, vec_digits, (size_t)nvec * n, hipMemcpyHostToDevice, c->st));
     std::vector<SetRef> mats, vecs;
-    for (u32 i = 0; i < nmat; i++) mats.push_back({dm.as<int8_t>() + (size_t)i * n * ncols, ncols});
-    for (u32 i = 0; i < nvec; i++) vecs.push_back({dv.as<int8_t>() + (size_t)i * n, 1});
+    const size_t r0 = c->sharded() ? (size_t)c->row0 : 0;     // a sharded context works on its rows of the sets (uploaded whole: they are int8)
+    for (u32 i = 0; i < nmat; i++) mats.push_back({dm.as<int8_t>() + ((size_t)i * n + r0) * ncols, ncols});
+    for (u32 i = 0; i < nvec; i++) vecs.push_back({dv.as<int8_t>() + (size_t)i * n + r0, 1});
     MatHold M;
     int rc = M.get(c, n, nM, rowptr, col, val);
     if (rc) return rc;
@@ -536,28 +593,35 @@ int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr,
     HIPCHK(c, hipSetDevice(c->device));
     for (u32 l = 1; l < L; l++) HIPCHK(c, hipStreamSynchronize(ctxs[l]->st));   // their from_f results are read from ctxs[0]'s stream
     std::vector<SetRef> mats, vecs;   // rgchk.rs:87-96: all instances' M_f matrices, then all instances' m_tau
+    const size_t nl = (size_t)c->nloc, row0 = (size_t)c->row0;      // the rank's rows (all of them unsharded); D_f is stored [k][nl][16]
     for (u32 l = 0; l < L; l++)
-        for (u32 ki = 0; ki < k; ki++) mats.push_back({ctxs[l]->Df + (size_t)ki * n * 16, 16});
-    for (u32 l = 0; l < L; l++) vecs.push_back({ctxs[l]->mtau, 1});
+        if (ctxs[l]->sh != c->sh || ctxs[l]->nloc != c->nloc) return fail(c, LFPLUS_E_ARG, "lfplus_range_check: instances of different shardings");
+    for (u32 l = 0; l < L; l++)
+        for (u32 ki = 0; ki < k; ki++) mats.push_back({ctxs[l]->Df + (size_t)ki * nl * 16, 16});
+    for (u32 l = 0; l < L; l++) vecs.push_back({ctxs[l]->mtau + row0, 1});
     int rc = set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so);
     if (rc) return rc;
     // evaluations at r (rgchk.rs:107-170): v / c[0] = f at r, a[0] = tau at r, b[0] = the set check's b; per matrix M_q: ct(M_q tau), M_q m_tau, M_q f
     DevBuf ev;
     const size_t per = (size_t)(1 + nM) * (1 + 2 * D) + D;   // words per instance: a | bb | c (v = c[0])
     if (ev.alloc(L * per * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (evaluations)");
+    const u64 *eql = so.eqr.as<u64>() + row0;
+    HIPCHK(c, hipMemsetAsync(ev.p, 0, L * per * 8, c->st));     // (bb[0] is not computed here: keep the summed words defined)
     for (u32 l = 0; l < L; l++) {
         u64 *ad = ev.as<u64>() + l * per, *bd = ad + (1 + nM), *cd = bd + (size_t)(1 + nM) * D;
-        lfp::launch_wring(ctxs[l]->f, n, so.eqr.as<u64>(), 1, so.part.as<u64>(), cd, c->st);
-        lfp::launch_wdot(so.eqr.as<u64>(), 1, 1, ctxs[l]->tau, n, so.part.as<u64>(), ad, c->st);
+        const u64 *fl = ctxs[l]->f + row0 * D, *taul = ctxs[l]->tau + row0;
+        lfp::launch_wring(fl, nl, eql, 1, so.part.as<u64>(), cd, c->st);
+        lfp::launch_wdot(eql, 1, 1, taul, nl, so.part.as<u64>(), ad, c->st);
         for (u32 q = 0; q < nM; q++) {
-            lfp::launch_wdot(so.w[q]->as<u64>(), 16, 0, ctxs[l]->tau, n, so.part.as<u64>(), ad + 1 + q, c->st);
-            lfp::launch_wmono(ctxs[l]->mtau, n, 1, so.w[q]->as<u64>(), 16, so.part.as<u64>(), bd + (size_t)(1 + q) * D, c->st);
-            lfp::launch_wring(ctxs[l]->f, n, so.w[q]->as<u64>(), 16, so.part.as<u64>(), cd + (size_t)(1 + q) * D, c->st);
+            lfp::launch_wdot(so.w[q]->as<u64>(), 16, 0, taul, nl, so.part.as<u64>(), ad + 1 + q, c->st);
+            lfp::launch_wmono(ctxs[l]->mtau + row0, nl, 1, so.w[q]->as<u64>(), 16, so.part.as<u64>(), bd + (size_t)(1 + q) * D, c->st);
+            lfp::launch_wring(fl, nl, so.w[q]->as<u64>(), 16, so.part.as<u64>(), cd + (size_t)(1 + q) * D, c->st);
         }
     }
     std::vector<u64> h(L * per);
     HIPCHK(c, hipMemcpyAsync(h.data(), ev.p, h.size() * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    if ((rc = lfp_xsum(c, h.data(), h.size()))) return rc;
     for (u32 l = 0; l < L; l++) {
         const u64 *ah = h.data() + l * per, *bh = ah + (1 + nM), *ch = bh + (size_t)(1 + nM) * D;
         memcpy(a_out + (size_t)l * (1 + nM), ah, (1 + nM) * 8);
@@ -845,10 +909,12 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     HIPCHK(c, hipMemcpyAsync(spd.p, spi.data(), spi.size() * 4, hipMemcpyHostToDevice, c->st));
     std::vector<std::vector<u64>> fcoms(L, std::vector<u64>((size_t)3 * kappa * D));
     std::vector<u64> comMf((size_t)k * kappa * D * D);
+    const size_t nl = (size_t)c->nloc, row0 = (size_t)c->row0;       // the rank's rows (= n, 0 unsharded)
+    const bool shd = c->sharded();
     for (u32 l = 0; l < L; l++) {
         h[l].reset(new DevBuf);
-        if (h[l]->alloc(n * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (h)");
-        lfp::launch_cm_h(ctxs[l]->Df, n, k, spd.as<int32_t>(), h[l]->as<u64>(), c->st);
+        if (h[l]->alloc(nl * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (h)");
+        lfp::launch_cm_h(ctxs[l]->Df, nl, k, spd.as<int32_t>(), h[l]->as<u64>(), c->st);
         HIPCHK(c, hipMemcpyAsync(comMf.data(), ctxs[l]->comMf, comMf.size() * 8, hipMemcpyDeviceToHost, c->st));
         // fcoms[l] = cm_f | C_Mf | cm_mtau; the context keeps cm_f behind comM_f and C_Mf | cm_mtau in coms
         HIPCHK(c, hipMemcpyAsync(fcoms[l].data(), ctxs[l]->comMf + comMf.size(), (size_t)kappa * D * 8, hipMemcpyDeviceToHost, c->st));
@@ -869,32 +935,48 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: t0 too large (kappa' * k d * l * d > n; the reference panics, cm.rs:601)");
     LFP_MARK(c, "cm: t(z) on the host");
     // tables.  Scalars (Montgomery): eq(r, .) | tau_l.  Ring (canonical): per instance m_tau, f, h, then per matrix M tau, M m_tau, M f, M h; then t0, t1
+    // Sharded: every table holds the rank's nl rows; the M_q x rows read x at arbitrary columns, so their inputs are whole vectors -- tau, m_tau and f are whole
+    // on every rank already, h is all-gathered (n ring elements per instance: the one large exchange of Cm::prove)
     const u32 per = 4 + 4 * nM, nring = L * (per - 1), nS = 1 + L, nR = nring + 2;
-    DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring;
-    const u32 nb0 = lfp::cm_round_blocks(n / 2);
-    if (S0.alloc((size_t)nS * n * 8) || R0.alloc((size_t)nR * n * D * 8) || Sw[0].alloc((size_t)nS * (n / 2) * 8) || Sw[1].alloc((size_t)nS * (n / 4 + 1) * 8) ||
-        Rw[0].alloc((size_t)nR * (n / 2) * D * 8) || Rw[1].alloc((size_t)nR * (n / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
-        part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)))
+    DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring, mtring, hwhole, Sg, Rg;
+    const u32 nb0 = lfp::cm_round_blocks(nl / 2);
+    if (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8) || Sw[0].alloc((size_t)nS * (nl / 2) * 8) || Sw[1].alloc((size_t)nS * (nl / 4 + 1) * 8) ||
+        Rw[0].alloc((size_t)nR * (nl / 2) * D * 8) || Rw[1].alloc((size_t)nR * (nl / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
+        part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)) || (nM && shd && (mtring.alloc(n * D * 8) || hwhole.alloc(n * D * 8))) ||
+        (shd && (Sg.alloc((size_t)nS * c->world * 8) || Rg.alloc((size_t)nR * c->world * D * 8))))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm tables)");
     u64 *S = S0.as<u64>(), *R = R0.as<u64>();
-    HIPCHK(c, hipMemcpyAsync(S, so.eqr.p, n * 8, hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(S, so.eqr.as<u64>() + row0, nl * 8, hipMemcpyDeviceToDevice, c->st));
     for (u32 l = 0; l < L; l++) {
-        u64 *base = R + (size_t)l * (per - 1) * n * D;
-        lfp::launch_to_mont(ctxs[l]->tau, n, S + (size_t)(1 + l) * n, c->st);
-        lfp::launch_cm_materialize(ctxs[l]->mtau, nullptr, n, base, c->st);
-        HIPCHK(c, hipMemcpyAsync(base + n * D, ctxs[l]->f, n * D * 8, hipMemcpyDeviceToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(base + 2 * n * D, h[l]->p, n * D * 8, hipMemcpyDeviceToDevice, c->st));
+        u64 *base = R + (size_t)l * (per - 1) * nl * D;
+        lfp::launch_to_mont(ctxs[l]->tau + row0, nl, S + (size_t)(1 + l) * nl, c->st);
+        lfp::launch_cm_materialize(ctxs[l]->mtau + row0, nullptr, nl, base, c->st);
+        HIPCHK(c, hipMemcpyAsync(base + nl * D, ctxs[l]->f + row0 * D, nl * D * 8, hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(base + 2 * nl * D, h[l]->p, nl * D * 8, hipMemcpyDeviceToDevice, c->st));
         if (nM) lfp::launch_cm_materialize(nullptr, ctxs[l]->tau, n, tauring.as<u64>(), c->st);
+        const u64 *xin[3] = {base, base + nl * D, base + 2 * nl * D};      // m_tau, f, h as whole vectors
+        if (nM && shd) {
+            lfp::launch_cm_materialize(ctxs[l]->mtau, nullptr, n, mtring.as<u64>(), c->st);
+            int rcg = lfp_allgather_dev(c, h[l]->as<u64>(), hwhole.as<u64>(), nl * D);
+            if (rcg) return rcg;
+            xin[0] = mtring.as<u64>(); xin[1] = ctxs[l]->f; xin[2] = hwhole.as<u64>();
+        }
         for (u32 q = 0; q < nM; q++) {
             const LfpMatrix &m = M[q];
-            u64 *mq = base + (size_t)(3 + 4 * q) * n * D;
-            lfp::launch_spmv_ring(m.rowptr, m.col, m.valM, tauring.as<u64>(), n, mq, c->st);
-            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr, m.col, m.valM, base + (size_t)j * n * D, n, mq + (size_t)(1 + j) * n * D, c->st);
+            u64 *mq = base + (size_t)(3 + 4 * q) * nl * D;
+            lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, tauring.as<u64>(), nl, mq, c->st);
+            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, xin[j], nl, mq + (size_t)(1 + j) * nl * D, c->st);
         }
     }
-    HIPCHK(c, hipMemsetAsync(R + (size_t)nring * n * D, 0, (size_t)2 * n * D * 8, c->st));   // t0 | t1: zero beyond the prefix the host computed
-    HIPCHK(c, hipMemcpyAsync(R + (size_t)nring * n * D, t0.data(), t0.size() * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(R + (size_t)(nring + 1) * n * D, t1.data(), t1.size() * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemsetAsync(R + (size_t)nring * nl * D, 0, (size_t)2 * nl * D * 8, c->st));   // t0 | t1: zero beyond the prefix the host computed
+    for (int z = 0; z < 2; z++) {        // the rank's rows of the non-zero prefix
+        const std::vector<u64> &tz = z ? t1 : t0;
+        const size_t pre = tz.size() / D;
+        if (pre > row0) {
+            const size_t cnt = std::min(pre - row0, nl);
+            HIPCHK(c, hipMemcpyAsync(R + (size_t)(nring + z) * nl * D, tz.data() + row0 * D, cnt * D * 8, hipMemcpyHostToDevice, c->st));
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->st));
     LFP_MARK(c, "cm: tables");
     // the two sumcheckers (cm.rs:201-347): same tables, different batching challenge rc; degree 2, ring-valued messages
@@ -911,9 +993,18 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         tr->absorb_const(nvars);
         tr->absorb_const(2);
         const u64 *Sc = S, *Rc = R;
-        size_t ld = n, len = n;
+        size_t ld = nl, len = nl;
         int w = 0;
+        bool dist = shd;
         for (u32 rnd = 0; rnd < nvars; rnd++) {
+            if (dist && len == 1) {      // one entry per table and rank left: gather (entry index = rank), finish replicated
+                int rcg = gather_tables(c, Sc, ld, nS, 1, Sg.as<u64>());
+                if (!rcg) rcg = gather_tables(c, Rc, ld, nR, D, Rg.as<u64>());
+                if (rcg) return rcg;
+                Sc = Sg.as<u64>(); Rc = Rg.as<u64>();
+                ld = len = (size_t)c->world;
+                dist = false;
+            }
             const size_t half = len / 2;
             const u32 nb = lfp::cm_round_blocks(half);
             auto tA = std::chrono::steady_clock::now();
@@ -926,11 +1017,12 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
                 for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 48 + x]);
                 m[x] = s;              // canonical: every product of the kernel pairs one Montgomery operand with one canonical operand
             }
+            if (dist) { int rcx = lfp_xsum(c, m, 3 * D); if (rcx) return rcx; }
             tr->absorb_ring(m, 3);
             const u64 r = tr->challenge();
             tr->absorb_const(r);
             rop[rnd] = r;
-            const size_t ldo = w == 0 ? n / 2 : n / 4 + 1;
+            const size_t ldo = w == 0 ? nl / 2 : nl / 4 + 1;
             lfp::launch_cm_fix(Sc, ld, Sw[w].as<u64>(), ldo, 1, nS, half, to_mont(r), c->st);
             lfp::launch_cm_fix(Rc, ld, Rw[w].as<u64>(), ldo, D, nR, half, to_mont(r), c->st);
             Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
@@ -959,14 +1051,22 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     for (int i = 0; i < 3; i++) for (int t = 0; t < D; t++) cs.v[i][t] = ch.s[i][t] > P / 2 ? -(int32_t)(P - ch.s[i][t]) : (int32_t)ch.s[i][t];
     for (u32 l = 0; l < L; l++) {
         lfplus_ctx *cl = ctxs[l];
-        if (cl->g_n != n) {
+        if (cl->g_n != nl) {          // the rank's rows of g
             if (cl->g) { (void)hipFree(cl->g); cl->g = nullptr; cl->g_n = 0; }
-            HIPCHK(c, hipMalloc(&cl->g, n * D * 8));
-            cl->g_n = n;
+            HIPCHK(c, hipMalloc(&cl->g, nl * D * 8));
+            cl->g_n = nl;
         }
-        lfp::launch_cm_g(cl->tau, cl->mtau, cl->f, h[l]->as<u64>(), n, cs, cl->g, c->st);
+        lfp::launch_cm_g(cl->tau + row0, cl->mtau + row0, cl->f + row0 * D, h[l]->as<u64>(), nl, cs, cl->g, c->st);
         cl->g_valid = true;
-        if (g_out) HIPCHK(c, hipMemcpyAsync(g_out + (size_t)l * n * D, cl->g, n * D * 8, hipMemcpyDeviceToHost, c->st));
+        if (g_out && !shd) HIPCHK(c, hipMemcpyAsync(g_out + (size_t)l * n * D, cl->g, n * D * 8, hipMemcpyDeviceToHost, c->st));
+        if (g_out && shd) {
+            DevBuf gw;
+            if (gw.alloc(n * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (g)");
+            int rcg = lfp_allgather_dev(c, cl->g, gw.as<u64>(), nl * D);
+            if (rcg) return rcg;
+            HIPCHK(c, hipMemcpyAsync(g_out + (size_t)l * n * D, gw.p, n * D * 8, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
     std::vector<const u64 *> fc(L);
@@ -980,7 +1080,17 @@ extern "C" int lfplus_cm_read_g(lfplus_ctx *c, uint64_t *g_out) {
     if (!c->g || !c->g_n || !c->g_valid)
         return fail(c, LFPLUS_E_ARG, "lfplus_cm_read_g: no folded witness (call lfplus_cm_prove; after lfplus_mlin ctxs[0] holds the SUM of the instances' g as its resident witness)");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(g_out, c->g, c->g_n * D * 8, hipMemcpyDeviceToHost));
+    if (!c->sharded()) {
+        HIPCHK(c, hipMemcpy(g_out, c->g, c->g_n * D * 8, hipMemcpyDeviceToHost));
+        return LFPLUS_OK;
+    }
+    PoolScope pool_scope(c);      // sharded: the ranks hold their rows of g -- collective: every rank must make this call
+    DevBuf gw;
+    if (gw.alloc(c->n * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (g)");
+    int rc = lfp_allgather_dev(c, c->g, gw.as<u64>(), c->nloc * D);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(g_out, gw.p, c->n * D * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
     return LFPLUS_OK;
 }
 
@@ -1137,31 +1247,42 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     while (((size_t)1 << nvars) < n) nvars++;
     HIPCHK(c, hipSetDevice(c->device));
     PoolScope pool_scope(c);
-    DevBuf E[2], G[2], part, small;
-    const u32 nb0 = lfp::cm_round_blocks(n / 2);
-    if (E[0].alloc(n * 8) || E[1].alloc(n / 2 * 8) || G[0].alloc((size_t)3 * n * D * 8) || G[1].alloc((size_t)3 * (n / 2) * D * 8) ||
-        part.alloc(std::max<size_t>((size_t)nb0 * 64, (size_t)lfp::eval_chunks(n) * D) * 8) || small.alloc(4 * D * 8))
+    // Sharded: the witness is whole, the three tables g_q = M_q f and eq(r, .) hold the rank's nl rows; partial round messages are summed over the ranks,
+    // the last log2(world) rounds run replicated on gathered tables, v = f(ro) is a partial sum over the rank's rows.
+    const size_t nl = c->sharded() ? (size_t)c->nloc : n, row0 = c->sharded() ? (size_t)c->row0 : 0;
+    if (c->sharded() && c->n != n) return fail(c, LFPLUS_E_ARG, "lfplus_r1cs_linearize: the witness of a sharded context has the matrix's (global) width");
+    DevBuf E[2], G[2], part, small, Eg, Gg;
+    const u32 nb0 = lfp::cm_round_blocks(nl / 2);
+    if (E[0].alloc(nl * 8) || E[1].alloc(nl / 2 * 8) || G[0].alloc((size_t)3 * nl * D * 8) || G[1].alloc((size_t)3 * (nl / 2) * D * 8) ||
+        part.alloc(std::max<size_t>((size_t)nb0 * 64, (size_t)lfp::eval_chunks(n) * D) * 8) || small.alloc(4 * D * 8) ||
+        (c->sharded() && (Eg.alloc((size_t)c->world * 8) || Gg.alloc((size_t)3 * c->world * D * 8))))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (linearize tables)");
     MatHold M;
     int rcm = M.get(c, n, 3, rowptr, col, val);
     if (rcm) return rcm;
     LFP_MARK(c, "(before linearize)");
-    for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr, M[q].col, M[q].valM, c->f, n, G[0].as<u64>() + (size_t)q * n * D, c->st);
+    for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr + row0, M[q].col, M[q].valM, c->f, nl, G[0].as<u64>() + (size_t)q * nl * D, c->st);
     std::vector<u64> r(nvars);
     for (u32 j = 0; j < nvars; j++) r[j] = tr->challenge();
-    lfp::EqPt pt;
-    for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(r[j]); pt.nc[j] = to_mont(fsub(1, r[j])); }
-    pt.one = to_mont(1);
-    lfp::launch_eq_build(pt, nvars, E[0].as<u64>(), c->st);
+    eq_build_local(c, r.data(), nvars, E[0].as<u64>());
     tr->absorb_const(nvars);
     tr->absorb_const(3);
     u64 *hpart = c->pin((size_t)nb0 * 64);
     if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
-    // round 0 reads the full tables (stride n), later rounds ping-pong between the first halves of the two buffers
+    // round 0 reads the full tables (stride nl), later rounds ping-pong between the first halves of the two buffers
     const u64 *Ec = E[0].as<u64>(), *Gc = G[0].as<u64>();
-    size_t ld = n, len = n;
+    size_t ld = nl, len = nl;
     int w = 1;
+    bool dist = c->sharded();
     for (u32 rnd = 0; rnd < nvars; rnd++) {
+        if (dist && len == 1) {      // one entry per table and rank left: gather (entry index = rank), finish replicated
+            int rcg = gather_tables(c, Ec, ld, 1, 1, Eg.as<u64>());
+            if (!rcg) rcg = gather_tables(c, Gc, ld, 3, D, Gg.as<u64>());
+            if (rcg) return rcg;
+            Ec = Eg.as<u64>(); Gc = Gg.as<u64>();
+            ld = len = (size_t)c->world;
+            dist = false;
+        }
         const size_t half = len / 2;
         const u32 nb = lfp::cm_round_blocks(half);
         auto tA = std::chrono::steady_clock::now();
@@ -1174,12 +1295,13 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
             for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 64 + x]);
             m[x] = s;
         }
+        if (dist) { int rcx = lfp_xsum(c, m, 4 * D); if (rcx) return rcx; }
         tr->absorb_ring(m, 4);
         const u64 x = tr->challenge();
         tr->absorb_const(x);
         ro[rnd] = x;
-        // in-place is not safe (entry b is written while 2b, 2b + 1 of another thread are read): alternate buffers; both hold n / 2 entries
-        const size_t ldo = n / 2;
+        // in-place is not safe (entry b is written while 2b, 2b + 1 of another thread are read): alternate buffers; both hold nl / 2 entries
+        const size_t ldo = nl / 2;
         u64 *Eo = w ? E[1].as<u64>() : E[0].as<u64>(), *Go = w ? G[1].as<u64>() : G[0].as<u64>();
         lfp::launch_cm_fix(Ec, ld, Eo, ldo, 1, 1, half, to_mont(x), c->st);
         lfp::launch_cm_fix(Gc, ld, Go, ldo, D, 3, half, to_mont(x), c->st);
@@ -1189,15 +1311,13 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
                              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tB).count(), nb);
     }
     LFP_MARK(c, "linearize: tables + rounds");
-    // v = f at ro; va, vb, vc = the fully fixed tables
-    for (u32 j = 0; j < nvars; j++) { pt.c[j] = to_mont(ro[j]); pt.nc[j] = to_mont(fsub(1, ro[j])); }
-    u64 *eqo = Ec == E[0].as<u64>() ? E[1].as<u64>() : E[0].as<u64>();   // n words needed: only E[0] is large enough
-    (void)eqo;
-    lfp::launch_eq_build(pt, nvars, E[0].as<u64>(), c->st);
-    lfp::launch_wring(c->f, n, E[0].as<u64>(), 1, part.as<u64>(), small.as<u64>(), c->st);
-    HIPCHK(c, hipMemcpy2DAsync(small.as<u64>() + D, D * 8, Gc, ld * D * 8, D * 8, 3, hipMemcpyDeviceToDevice, c->st));
+    // v = f at ro (a sum over the rank's rows); va, vb, vc = the fully fixed tables (replicated)
+    HIPCHK(c, hipMemcpy2DAsync(small.as<u64>() + D, D * 8, Gc, ld * D * 8, D * 8, 3, hipMemcpyDeviceToDevice, c->st));    // before E[0] / G are reused
+    eq_build_local(c, ro, nvars, E[0].as<u64>());
+    lfp::launch_wring(c->f + row0 * D, nl, E[0].as<u64>(), 1, part.as<u64>(), small.as<u64>(), c->st);
     HIPCHK(c, hipMemcpyAsync(evals, small.p, 4 * D * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    { int rcx = lfp_xsum(c, evals, D); if (rcx) return rcx; }
     tr->absorb_ring(evals, 4);
     return LFPLUS_OK;
 }
@@ -1283,13 +1403,17 @@ extern "C" int lfplus_mlin(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcrip
     for (u32 i = 0; i < L; i++) {
         for (size_t x = 0; x < (size_t)kappa * D; x++) cm_g_sum[x] = fadd(cm_g_sum[x], cm_g[(size_t)i * kappa * D + x]);
         for (size_t x = 0; x < (size_t)(1 + nM) * 2 * D; x++) vo_sum[x] = fadd(vo_sum[x], vo[(size_t)i * (1 + nM) * 2 * D + x]);
-        if (i) lfp::launch_vec_add(c->g, ctxs[i]->g, n * D, c->st);
+        if (i) lfp::launch_vec_add(c->g, ctxs[i]->g, (size_t)c->nloc * D, c->st);
     }
     // the folded witness replaces ctxs[0]'s f: the RgInstance results of ctxs[0] no longer describe the resident witness, and its g buffer holds the
     // sum, not g_0 (lfplus_cm_read_g on ctxs[0] is refused from here on; the other instances keep their g_l)
     c->have = false;
     c->g_valid = false;
-    HIPCHK(c, hipMemcpyAsync(c->f, c->g, n * D * 8, hipMemcpyDeviceToDevice, c->st));
+    if (!c->sharded()) HIPCHK(c, hipMemcpyAsync(c->f, c->g, n * D * 8, hipMemcpyDeviceToDevice, c->st));
+    else {        // a witness is whole on every rank (Decomp::decompose's M_j F_i rows read arbitrary columns): all-gather the rows of g
+        int rcg = lfp_allgather_dev(c, c->g, c->f, (size_t)c->nloc * D);
+        if (rcg) return rcg;
+    }
     HIPCHK(c, hipStreamSynchronize(c->st));
     return LFPLUS_OK;
 }

@@ -83,6 +83,10 @@ def _lib():
         L.lfplus_decomp_verify.argtypes = [u64p, u64p, C.c_uint32, u64p, u64p, C.c_uint32, u64p, u64p, C.c_uint64, ip]
         L.lfplus_mlin.argtypes = [vpp, C.c_uint32, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32pp, u32pp, u64pp] + [u64p] * 19
         L.lfplus_cm_verify.argtypes = [vp] + [C.c_uint32] * 6 + [u64pp] + [u64p] * 15 + [ip]
+        L.lfplus_set_sharding.argtypes = [vp, C.c_int, C.c_int, api.EXCHANGE_FN, vp]
+        L.lfplus_dist_unique_id.argtypes = [u8p]
+        L.lfplus_dist_init.argtypes = [vp, C.c_int, C.c_int, u8p]
+        L.lfplus_dist_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
         _READY = True
     return L
 
@@ -122,17 +126,47 @@ class PlusContext:
             _lib().lfplus_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
+    shard = (0, 1)     # (rank, world) of a column-sharded prover
+
+    def set_sharding(self, rank, world, allgather):
+        """Column sharding over a HOST transport (lfplus_set_sharding); call before set_matrix.  allgather(np.uint64[words]) -> np.uint64[world, words]
+        in rank order (latticefold_amd.dist.make_allgather)."""
+        def _cb(user, send, recv, words):
+            try:
+                mine = np.ctypeslib.as_array(send, shape=(words,)).copy()
+                out = np.ascontiguousarray(allgather(mine), dtype=np.uint64).reshape(world * words)
+                C.memmove(recv, out.ctypes.data, world * words * 8)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                import sys
+                print("lfplus exchange callback failed:", repr(e), file=sys.stderr)
+                return -1
+        self._exchange_cb = api.EXCHANGE_FN(_cb) if world > 1 else api.EXCHANGE_FN(0)
+        self._chk(_lib().lfplus_set_sharding(self.h, rank, world, self._exchange_cb, None))
+        self.shard = (rank, world)
+
+    def dist_init(self, rank, world, id128):
+        """Column sharding over RCCL (lfplus_dist_init): id128 = the bytes of an ncclUniqueId (plus.dist_unique_id() on rank 0, broadcast by the launcher)"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        self._chk(_lib().lfplus_dist_init(self.h, rank, world, buf))
+        self.shard = (rank, world)
+
+    def dist_stats(self, reset=False):
+        n, tot, mx = C.c_uint64(), C.c_double(), C.c_double()
+        self._chk(_lib().lfplus_dist_stats(self.h, C.byref(n), C.byref(tot), C.byref(mx), int(reset)))
+        return n.value, tot.value, mx.value
+
     def set_matrix(self, A):
-        """A: (kappa, n, 16) canonical words (Matrix<R>, coefficient form)"""
+        """A: (kappa, n, 16) canonical words (Matrix<R>, coefficient form); in a sharded context the rank's columns (kappa, n / world, 16)"""
         A, p = _w(A)
         assert A.ndim == 3 and A.shape[2] == D
         self._chk(_lib().lfplus_set_matrix(self.h, p, A.shape[0], A.shape[1]))
-        self.kappa, self.n = A.shape[0], A.shape[1]
+        self.kappa, self.n = A.shape[0], A.shape[1] * self.shard[1]
 
     def share_matrix(self, other):
-        """use `other`'s resident commitment matrix (no copy); `other` must stay open"""
+        """use `other`'s resident commitment matrix (no copy, reference-counted) -- and, for a sharded prover, its transport"""
         self._chk(_lib().lfplus_share_matrix(self.h, other.h))
-        self.kappa, self.n = other.kappa, other.n
+        self.kappa, self.n, self.shard = other.kappa, other.n, other.shard
 
     def set_matrices(self, M, n=None):
         """make the constraint-system matrices resident (CSR triples); calls that get M = RESIDENT then use them without another upload"""
@@ -231,6 +265,15 @@ class RgInstance:
     def M_f(self, ki, rows=slice(None)):
         """dense monomial matrix exp(D_f[ki]) for the given rows: (rows, 16 columns, 16 words)"""
         return exp(self.D_f[ki, rows])
+
+
+def dist_unique_id():
+    """an ncclUniqueId (128 bytes) for PlusContext.dist_init"""
+    buf = (C.c_uint8 * 128)()
+    rc = _lib().lfplus_dist_unique_id(buf)
+    if rc:
+        raise LfPlusError(rc, "lfplus_dist_unique_id: RCCL not loadable")
+    return bytes(buf)
 
 
 def exp(digits):
@@ -632,9 +675,18 @@ def _ro_pairs(ro):
 class PlusProver:
     """plus.rs:15-108.  One context per instance (2 accumulated + ncomp fresh); all share the Ajtai matrix of the first."""
 
-    def __init__(self, A, M, ncomp, params, transcript, device=0):
+    def __init__(self, A, M, ncomp, params, transcript, device=0, shard=None):
+        """shard = (rank, world, transport): a prover column-sharded over `world` ranks, one GPU each -- A is then the rank's column slice (kappa, n / world,
+        16); transport is an allgather callable (host transport: PlusContext.set_sharding) or the bytes of an ncclUniqueId (RCCL: PlusContext.dist_init).
+        Every rank makes the same calls with the same (whole) witnesses and gets the same proof."""
         self.M, self.params, self.transcript = list(M), params, transcript
         self.ctxs = [PlusContext(device) for _ in range(2 + ncomp)]
+        if shard is not None:
+            rank, world, transport = shard
+            if callable(transport):
+                self.ctxs[0].set_sharding(rank, world, transport)
+            else:
+                self.ctxs[0].dist_init(rank, world, transport)
         self.ctxs[0].set_matrix(A)
         self.ctxs[0].set_matrices(self.M)
         for c in self.ctxs[1:]:
@@ -645,8 +697,8 @@ class PlusProver:
         self.failed = None     # set when a prove() raised half way: the Fiat-Shamir transcript has advanced and the contexts hold a half-folded state
 
     @staticmethod
-    def init(A, M, ncomp, params, transcript, device=0):
-        return PlusProver(A, M, ncomp, params, transcript, device)
+    def init(A, M, ncomp, params, transcript, device=0, shard=None):
+        return PlusProver(A, M, ncomp, params, transcript, device, shard)
 
     def close(self):
         for c in reversed(self.ctxs):

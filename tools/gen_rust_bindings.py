@@ -51,7 +51,7 @@ def rust_type(ctype):
         r = SCALARS[name]
     elif name in OPAQUE or name in ("lf_params",):
         r = name
-    elif name == "lf_exchange_fn":
+    elif name in ("lf_exchange_fn", "lfplus_exchange_fn"):
         r = "lf_exchange_fn"
     else:
         raise ValueError(f"unknown C type {ctype!r}")
@@ -70,7 +70,7 @@ def split_params(s):
     for i, p in enumerate(x.strip() for x in s.split(",")):
         m = re.match(r"^(.*?)([A-Za-z_][A-Za-z_0-9]*)?$", p)
         ctype, name = m.group(1).strip(), m.group(2)
-        if name in SCALARS or name in OPAQUE or name in ("lf_params", "lf_exchange_fn", "unsigned", "const") or not ctype:   # unnamed parameter
+        if name in SCALARS or name in OPAQUE or name in ("lf_params", "lf_exchange_fn", "lfplus_exchange_fn", "unsigned", "const") or not ctype:   # unnamed parameter
             ctype, name = p, None
         if name is None:
             base = re.findall(r"[A-Za-z_][A-Za-z_0-9]*", ctype)[-1]
