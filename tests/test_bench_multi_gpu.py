@@ -22,7 +22,7 @@ def test_bench_two_ranks_one_gpu(mode, workload):
     env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", workload, "--parallelism", mode]
+           "--workload", workload, "--parallelism", mode, "--no-lfplus"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -43,7 +43,7 @@ def test_bench_two_ranks_one_gpu(mode, workload):
 def test_bench_default_for_n_gpus_is_the_sharded_config():
     """`bench.py --gpus 2` with no --parallelism runs BASELINE configs[3]'s shape: ONE fold stream sharded over the ranks
     (strong scaling), logs its exchanges and reports the replicas rate of the same GPUs as an extra key"""
-    env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo")
+    env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo", LF_LFPLUS_WORKLOADS="P16")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--workload", "T14"]
@@ -51,6 +51,9 @@ def test_bench_default_for_n_gpus_is_the_sharded_config():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("shard x2")
+    # BASELINE configs[4] next to it: the LatticeFold+ prove sharded over the same ranks, tied to the committed oracle fixture of its workload
+    run = d["lfplus"]["runs"][0]
+    assert run["ms"] > 0 and run["verified"] and run["matches_oracle_fixture"] and run["exchanges"]["count"] > 20 and run["parallelism"].startswith("shard x2")
     assert d["exchanges"]["exchanges_per_step"] > 10 and d["exchanges"]["transport"] == "host"
     assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
 
