@@ -151,6 +151,9 @@ struct AjtaiI8Args {
     u32 ntiles, tiles_per_wg;
     int32_t *part;           // [wg][MT][NT][64][4]
     int32_t *dsum;           // [wg][NP][RD]
+    u32 *sync;               // k_ajtai_i8s with two plane groups: one signed counter per column chunk (zeroed before the launch), see i8s_build; null = no coupling
+    u32 couple_w;            // window of the coupling, in tiles
+    u32 couple_e;            // the handshake runs every couple_e tiles (a power of two)
 };
 
 // dynamic LDS: A tiles 2 x a_lds | V 2 x NP x 2 x 2RD x 8 | D NP x RD x 8 | w 2 x RD x 8 x 4
@@ -697,6 +700,48 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
             V[vbuf * S_VB + btid + 256 * r] = v ^ 0x8080808080808080ull;
         }
     };
+    // Coupling of the two plane-group workgroups of a column chunk (blocks b and b ^ 8: same XCD, same tiles of A).  Uncoupled they drift apart -- the
+    // L2-resident tiles between a pair are gone after ~5 tile times (14 pairs share the 4 MB L2 of an XCD) -- and the one behind fetches A from HBM a second
+    // time: 6.1-7.7 GB per launch measured against the 5.36 GB of ONE pass.  The pair shares a signed counter lead = (tiles issued by group 0) - (tiles issued by
+    // group 1): before issuing a tile's loads a workgroup adds +-1 with ONE atomic performed in the XCD's L2 (workgroup scope: no trip to memory -- the agent-scope
+    // form of this handshake cost a memory round trip per tile and 0.4 ms per launch), and the value the atomic returns tells it how far AHEAD it is: beyond
+    // `couple_w` tiles it waits for its partner.  The returned value is consumed one tile later (the memory counter is in order: a use waits for every load issued
+    // before it, so the atomic goes ahead of the tile's ten copy loads).  Only the first producer wave does this, the others follow through the per-tile barrier.
+    // The workgroup BEHIND never waits, so the pair cannot deadlock; a workgroup that is done (or gives up after a bounded spin: the coupling is a traffic
+    // optimisation, never a correctness condition -- e.g. if the pair did not share an L2) moves the counter 2^20 tiles to its partner's side.
+    // Measured (C4, 224 workgroups, profiles/r04_i8_couple.txt): handshake every tile, window 3: 5.34 GB per launch, 2.14-2.18 ms against 1.99 uncoupled (the
+    // atomic's result is waited for in wave 4 every tile); every 4 tiles, window 4 (the default): 5.35 GB, 2.10 against 2.07-2.09 ms on the same box; every 8
+    // tiles: 5.7-6.8 GB (the pair drifts out of the L2 between handshakes).  So the second pass over A costs HBM traffic, not kernel time: the loop is bound by
+    // the matrix-pipe issue rate and the producers (profiles/r03_i8_notes.txt), and a launch moves 2.6 TB/s either way.
+    const u32 c_grp = (blockIdx.x >> 3) & 1, c_chunk = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
+    const bool cpl = a.sync != nullptr && a.sides == 2 && btid < 64;
+    int *const lead_p = (int *)a.sync + c_chunk;
+    const int c_sgn = c_grp ? -1 : 1;
+    bool coupled = cpl;
+    int c_old = 0;           // (lane 0) the counter before this workgroup's last increment
+    bool c_pending = false;
+    u32 c_tick = 0;          // tiles since the loop began: the handshake runs every couple_e tiles and counts couple_e tiles at once
+#define LF_S_COUPLE_RELEASE()                                                                                                        \
+    if (cpl && btid == 0) (void)__hip_atomic_fetch_add(lead_p, c_sgn * (1 << 20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define LF_S_COUPLE_STEP()                                                                                                           \
+    if (coupled && ((c_tick++) & (a.couple_e - 1)) == 0) {                                                                           \
+        if (c_pending) {                                                                                                             \
+            int ahead_ = c_sgn * __builtin_amdgcn_readfirstlane(c_old) + (int)a.couple_e;                                            \
+            int spins_ = 0;                                                                                                          \
+            while (ahead_ > (int)a.couple_w) {                                                                                       \
+                __builtin_amdgcn_s_sleep(8);                                                                                         \
+                ahead_ = c_sgn * __hip_atomic_load(lead_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                              \
+                if (++spins_ > 8192) { coupled = false; break; }                                                                     \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        if (coupled) {                                                                                                               \
+            if (btid == 0) c_old = __hip_atomic_fetch_add(lead_p, c_sgn * (int)a.couple_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            c_pending = true;                                                                                                        \
+        } else {                                                                                                                     \
+            LF_S_COUPLE_RELEASE();                                                                                                   \
+        }                                                                                                                            \
+    }
+    if (cpl && T0 >= T1) { LF_S_COUPLE_RELEASE(); }
     if (btid < 2 * S_NPG) Dl[btid * DS + RD] = 0x0404040404040404ull;   // the (biased) zero words
     if (T0 < T1) {
         // prologue: A[T0] -> buffer 0, A[T0+1] in flight (x), w[T0 .. T0+2], D[T0], D[T0+1], V[T0]
@@ -722,6 +767,7 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
         // even tile of the pair: x holds A[T+1]; load A[T+2] into y
         // (the tile copy's ten loads in three groups between the pieces of the build: the four producer waves share one 64-byte/clock
         // load path -- a whole tile takes it 640 cycles -- and a wave that issues all ten at once sits in the queue that long)
+        LF_S_COUPLE_STEP();
         if (!BITS) load_w(T + 3);                            // (before the tile loads: its word is stored first, and the memory counter is in order)
         LF_S_LOAD_A(y, T + 2);
         LF_S_STAMP(0);     // load issue
@@ -740,6 +786,7 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
         LF_S_STAMP(6);     // barrier
         if (T + 1 >= T1) break;
         // odd tile: y holds A[T+2]; load A[T+3] into x
+        LF_S_COUPLE_STEP();
         if (!BITS) load_w(T + 4);
         LF_S_LOAD_A(x, T + 3);
         LF_S_STAMP(0);
@@ -761,6 +808,9 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
         for (int i = 0; i < 7; i++) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
         g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
     }
+    if (coupled) { LF_S_COUPLE_RELEASE(); }   // done: the partner never waits for this workgroup again (a workgroup that gave up has released already)
+#undef LF_S_COUPLE_STEP
+#undef LF_S_COUPLE_RELEASE
 #undef LF_S_LOAD
 #undef LF_S_LOAD_A
 #undef LF_S_LOAD_B
@@ -883,7 +933,7 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     a.Ab = Ab; a.planes = planes; a.planes2 = planes2; a.ld = ld; a.n = n;
     a.MT = MT; a.NT = ajtai_i8_col_tiles(R, NP); a.k0 = k0; a.NP = NP;
     a.ntiles = (u32)((n + 7) / 8);
-    a.part = part; a.dsum = dsum;
+    a.part = part; a.dsum = dsum; a.sync = nullptr; a.couple_w = 0; a.couple_e = 1;
     if ((size_t)R.RD * ld * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit plane offsets in the kernel
     if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
     // The 13-row-tile shape of the 24-ring with specialised waves (k_ajtai_i8s): plane groups of 8, two groups = paired workgroups
@@ -914,6 +964,16 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
             const bool ub = want_bits && bits != nullptr && k0 + NP <= bits_rows - 1;
             const dim3 g(groups * nch), b(512);
             const size_t lds_s = ajtai_i8s_lds_bytes();
+            // two plane groups: couple the paired workgroups (i8s_build).  The counters live behind the digit sums this path uses (dsum holds nwg * NPmax * RD
+            // words, this kernel writes 192 per workgroup); every workgroup of the grid must be resident for the coupling to make progress: at most one per CU.
+            static const int cw = getenv("LF_I8_COUPLE_W") ? atoi(getenv("LF_I8_COUPLE_W")) : 4;      // (0 switches the coupling off)
+            if (groups == 2 && cw > 0 && g.x <= nwg && (size_t)nwg * 192 + g.x <= (size_t)nwg * ajtai_i8_max_planes(R) * R.RD && g.x <= 256) {
+                a.sync = (u32 *)(dsum + (size_t)nwg * 192);
+                a.couple_w = (u32)cw;
+                static const int ce = getenv("LF_I8_COUPLE_E") ? atoi(getenv("LF_I8_COUPLE_E")) : 4;
+                a.couple_e = ce >= 8 ? 8u : (ce >= 4 ? 4u : (ce >= 2 ? 2u : 1u));
+                (void)hipMemsetAsync(a.sync, 0, (size_t)nch * 4, s);      // one signed counter per column chunk (pair of workgroups)
+            }
             if (sprof) { if (ub) hipLaunchKernelGGL((k_ajtai_i8s<true, true>), g, b, lds_s, s, a); else hipLaunchKernelGGL((k_ajtai_i8s<true, false>), g, b, lds_s, s, a); }
             else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<false, true>), g, b, lds_s, s, a);
             else hipLaunchKernelGGL((k_ajtai_i8s<false, false>), g, b, lds_s, s, a);

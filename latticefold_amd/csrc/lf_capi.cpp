@@ -57,10 +57,16 @@ struct lf_transcript {
 struct Timeline {
     bool on;
     std::chrono::steady_clock::time_point t0;
-    std::vector<std::pair<const char *, double>> marks;
-    Timeline() : on(getenv("LF_TIMELINE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    std::vector<std::pair<const char *, double>> marks, marks1;   // marks1: the helper lane's thread ("L1: ..."), merged by time at the end of the step
+    Timeline() : on(getenv("LF_TIMELINE") != nullptr), t0(std::chrono::steady_clock::now()) { marks1.reserve(32); }
     void mark(const char *what) {   // always recorded (lf_last_timeline); printed only with LF_TIMELINE
         marks.push_back({what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()});
+    }
+    void mark1(const char *what) { marks1.push_back({what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()}); }
+    void merge() {
+        marks.insert(marks.end(), marks1.begin(), marks1.end());
+        marks1.clear();
+        std::stable_sort(marks.begin(), marks.end(), [](const std::pair<const char *, double> &a, const std::pair<const char *, double> &b) { return a.second < b.second; });
     }
     void dump() {
         if (!on) return;
@@ -194,6 +200,18 @@ struct lf_ctx {
     u32 *bits_ptr[2] = {nullptr, nullptr};
     hipEvent_t bits_ev[2] = {nullptr, nullptr};
     hipEvent_t ev_prep[2] = {nullptr, nullptr};   // fold prepare: fork / join of the right side's chain on the helper lane's stream
+    hipEvent_t ev_yR = nullptr, ev_yL = nullptr;  // the right / left commit's results are in h_pin2 (second / first half)
+    u64 *h_pin2 = nullptr;
+    size_t h_pin2_words = 0;
+    int pin2(size_t words) {
+        if (words <= h_pin2_words) return LF_OK;
+        if (h_pin2) (void)hipHostFree(h_pin2);
+        h_pin2 = nullptr; h_pin2_words = 0;
+        if (hipHostMalloc((void **)&h_pin2, words * 8) != hipSuccess) return LF_ERR_HIP;
+        h_pin2_words = words;
+        return LF_OK;
+    }
+    hipEvent_t ev_evals[2] = {nullptr, nullptr};  // right evaluations in two stages (decompose_evals, EvalStages): first / second half of the u_s downloaded
     // linearization: the pass of the v_s evaluations over the witness starts on this stream while the last sumcheck rounds are still running (VsSplit)
     hipStream_t st_aux = nullptr;
     hipEvent_t ev_aux = nullptr;
@@ -450,6 +468,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->d_icrt) (void)hipFree(c->d_icrt);
     for (int l = 0; l < 2; l++)
         if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
+    if (c->h_pin2) { (void)hipHostFree(c->h_pin2); c->h_pin2 = nullptr; }
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int l = 0; l < 2; l++)
         if (c->h_round[l]) (void)hipHostFree(c->h_round[l]);
@@ -1892,11 +1911,15 @@ static int decompose_commit_enqueue_pair(lf_ctx *c, const lf_witness *wit_l, con
     *ev_out = ph;
     return LF_OK;
 }
-static int decompose_commit_finish(lf_ctx *c, const u64 *cm, u64 *yd, size_t ev, u64 *proof) {
+// early / early_ev (optional): the commitments were already copied to this pinned buffer behind the commit (event early_ev)
+static int decompose_commit_finish(lf_ctx *c, const u64 *cm, u64 *yd, size_t ev, u64 *proof, const u64 *early = nullptr, hipEvent_t early_ev = nullptr) {
     const lf_params &P = c->P;
     u32 K = P.K;
     u64 *y_s = proof + (size_t)K * P.t * 24 + (size_t)K * 72 + (size_t)K * (P.l + 1) * 24;
-    RET(commit_download(c, yd, (size_t)(K - 1) * P.kappa * 24, y_s + (size_t)P.kappa * 24));
+    if (early && early_ev) {
+        HIPCHK(hipEventSynchronize(early_ev));
+        memcpy(y_s + (size_t)P.kappa * 24, early, (size_t)(K - 1) * P.kappa * 24 * 8);
+    } else RET(commit_download(c, yd, (size_t)(K - 1) * P.kappa * 24, y_s + (size_t)P.kappa * 24));
     c->ev_end(ev);
     // y_0 = cm - sum_{k>=1} b^k y_k, as the reference's fold (acc + y_i) * b
     std::vector<u64> acc((size_t)P.kappa * 24, 0);
@@ -1998,8 +2021,30 @@ static int decompose_prepare_z(lf_ctx *c, const u64 *xh /* (l+1) elements: x_w |
     S.z_state.store(rc == LF_OK ? 1 : -1, std::memory_order_release);
     return rc;
 }
+// The evaluations of a decomposition in two stages (the right side of a fold step): stage 0 = all v_s and the u_s of the parts k < ksplit, stage 1 = the
+// other u_s.  decompose_evals then enqueues both downloads and returns without waiting; decompose_evals_collect(stage) waits for that stage's event and
+// moves its words into the proof -- so the host can absorb the first K/2 parts (x_k, y_k, u_k, v_k: half of a ~1 ms sponge chain) while the GPU is
+// still computing the inner products of the second half.  The absorb order (decomposition.rs:65-83: part by part) is unchanged.
+struct EvalStages {
+    u32 ksplit = 0;
+    bool active = false;
+};
+static int decompose_evals_collect(lf_ctx *c, const EvalStages &st, int stage, u64 *proof) {
+    const lf_params &P = c->P;
+    const u32 K = P.K;
+    u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24;
+    HIPCHK(hipEventSynchronize(c->ev_evals[stage]));
+    const u64 *h = c->h_pin_ref();
+    if (stage == 0) {
+        memcpy(v_s, h, (size_t)K * 72 * 8);
+        memcpy(u_s, h + 32 * 72, (size_t)st.ksplit * P.t * 24 * 8);
+    } else {
+        memcpy(u_s + (size_t)st.ksplit * P.t * 24, h + 32 * 72 + (size_t)st.ksplit * P.t * 24, (size_t)(K - st.ksplit) * P.t * 24 * 8);
+    }
+    return LF_OK;
+}
 static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &rpt, const lf_witness *wit, const char *side,
-                           u64 *eq_r /* built already or nullptr */, SideState &S, u64 *proof) {
+                           u64 *eq_r /* built already or nullptr */, SideState &S, u64 *proof, EvalStages *stages = nullptr) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n, N = c->N;
     u32 K = P.K;
@@ -2021,6 +2066,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     if (S.z_state.load(std::memory_order_acquire) == 1) HIPCHK(hipStreamWaitEvent(c->stream(), S.z_ev, 0));
     else RET(decompose_prepare_z(c, xh, wit, side, S, proof));
     u64 *z = S.z;
+    if (t_lane == 0) TL_MARK("  evals: buffers + z");
     // v_s (decomposition.rs:204-211) from the coefficient planes
     {
         size_t i0, cnt;
@@ -2033,6 +2079,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
             RET(exchange_modsum_dev(c, od_v, (size_t)K * 72));
         }
     }
+    if (t_lane == 0) TL_MARK("  evals: v_s enqueued");
     // u_s[k][j] = <z_k, M_j^T eq(r)>   (decomposition.rs:214-256 restructured)
     u64 *dpart;
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
@@ -2041,6 +2088,25 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
         shard_slice(c, n, &c0, &cnt);   // sharded: dot products over this rank's column slice of z_k and q_j -- and only that slice of q_j is computed
         for (u32 j = 0; j < P.t; j++)
             launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq_r, m, q + (size_t)j * 24 * n, n, c->stream(), c0, cnt);
+        if (stages && c->sh_world == 1 && K >= 4 && !c->tn.evals_one_stage) {
+            // two stages: parts [0, K/2) and [K/2, K), each with its own download and event
+            const u32 ks = K / 2;
+            const size_t words = (size_t)32 * 72 + (size_t)K * P.t * 24;
+            RET(c->pin(words));
+            for (int e = 0; e < 2; e++)
+                if (!c->ev_evals[e]) HIPCHK(hipEventCreateWithFlags(&c->ev_evals[e], hipEventDisableTiming));
+            RET(dot_batch_dev(c, z + c0, n, ks, q + c0, n, P.t, cnt, dpart, od_u));
+            HIPCHK(hipMemcpyAsync(c->h_pin_ref(), od, ((size_t)32 * 72 + (size_t)ks * P.t * 24) * 8, hipMemcpyDeviceToHost, c->stream()));
+            HIPCHK(hipEventRecord(c->ev_evals[0], c->stream()));
+            RET(dot_batch_dev(c, z + c0 + (size_t)ks * 24 * n, n, K - ks, q + c0, n, P.t, cnt, dpart, od_u + (size_t)ks * P.t * 24));
+            HIPCHK(hipMemcpyAsync(c->h_pin_ref() + 32 * 72 + (size_t)ks * P.t * 24, od_u + (size_t)ks * P.t * 24, (size_t)(K - ks) * P.t * 24 * 8, hipMemcpyDeviceToHost, c->stream()));
+            HIPCHK(hipEventRecord(c->ev_evals[1], c->stream()));
+            stages->ksplit = ks;
+            stages->active = true;
+            LF_TRACE(c, "decompose evals (staged)");
+            c->ev_end(ph);
+            return LF_OK;
+        }
         RET(dot_batch_dev(c, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od_u));
         RET(exchange_modsum_dev(c, od_u, (size_t)K * P.t * 24));
     }
@@ -2060,13 +2126,14 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
 
 // transcript part of the decomposition (decomposition.rs:65-83): absorb x_k, y_k, u_k, v_k and build the K LCCCS.
 // No challenge is drawn here, so for the left instance it runs on a host thread while the GPU decomposes the right one.
-static double absorb_decomposition(const lf_params &P, Transcript &tr, const u64 *lcccs, const u64 *proof, SideState &S) {
+static double absorb_decomposition(const lf_params &P, Transcript &tr, const u64 *lcccs, const u64 *proof, SideState &S, u32 k0 = 0, u32 k1 = ~0u) {
     auto t0 = std::chrono::steady_clock::now();
     u32 K = P.K;
     const u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24, *x_s = v_s + (size_t)K * 72, *y_s = x_s + (size_t)K * (P.l + 1) * 24;
     size_t ll = lf_lcccs_len(&P);
-    S.lcccs.assign((size_t)K * ll * 24, 0);
-    for (u32 k = 0; k < K; k++) {
+    if (k1 > K) k1 = K;
+    if (k0 == 0) S.lcccs.assign((size_t)K * ll * 24, 0);
+    for (u32 k = k0; k < k1; k++) {
         const u64 *xk = x_s + (size_t)k * (P.l + 1) * 24, *yk = y_s + (size_t)k * P.kappa * 24;
         const u64 *uk = u_s + (size_t)k * P.t * 24, *vk = v_s + (size_t)k * 72;
         tr.absorb_ring(xk, P.l + 1);
@@ -2254,26 +2321,18 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         for (u32 i = 0; i < K2; i++) alpha[i] = tr.get_challenge();
         tr.absorb_label("zeta_s");
         for (u32 i = 0; i < K2; i++) zeta[i] = tr.get_challenge();
-        tr.absorb_label("mu_s");
-        for (u32 i = 0; i + 1 < K2; i++) mu[i] = tr.get_challenge();
-        mu[K2 - 1] = fq3_one();
-        tr.absorb_label("beta_s");
-        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
     }
-    TL_MARK(" fold challenges");
+    // The G tables need alpha and zeta only: their chains are enqueued HERE, and the host squeezes mu and beta (~100 permutations) while the GPU combines
+    // the z_k -- the challenge order of the transcript (alpha, zeta, mu, beta: folding/utils.rs:52-95) is untouched.
     size_t ph = c->ev_begin(13);
     // powers x^{j+1}
     std::vector<Fq3Const> mu_pow((size_t)K2 * 3), a_pow((size_t)K2 * 3), z_pow((size_t)K2 * P.t);
     for (u32 i = 0; i < K2; i++) {
-        Fq3 pm = mu[i], pa = alpha[i], pz = zeta[i];
-        for (u32 d = 0; d < 3; d++) {
-            mu_pow[(size_t)i * 3 + d] = f3c(pm); a_pow[(size_t)i * 3 + d] = f3c(pa);
-            pm = c->ring.mul3(pm, mu[i]); pa = c->ring.mul3(pa, alpha[i]);
-        }
+        Fq3 pa = alpha[i], pz = zeta[i];
+        for (u32 d = 0; d < 3; d++) { a_pow[(size_t)i * 3 + d] = f3c(pa); pa = c->ring.mul3(pa, alpha[i]); }
         for (u32 j = 0; j < P.t; j++) { z_pow[(size_t)i * P.t + j] = f3c(pz); pz = c->ring.mul3(pz, zeta[i]); }
     }
     Fq3Const *d_mu, *d_ap, *d_zp;
-    RET(upload_consts(c, "c_mu", mu_pow, &d_mu));
     RET(upload_consts(c, "c_ap", a_pow, &d_ap));
     RET(upload_consts(c, "c_zp", z_pow, &d_zp));
     u64 *G[2], *eqb, *zz, *partial, *od;
@@ -2318,6 +2377,20 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             HIPCHK(hipStreamWaitEvent(s0, c->ev_prep[1], 0));
         }
     }
+    {
+        HostTimer ht(c);
+        tr.absorb_label("mu_s");
+        for (u32 i = 0; i + 1 < K2; i++) mu[i] = tr.get_challenge();
+        mu[K2 - 1] = fq3_one();
+        tr.absorb_label("beta_s");
+        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
+    }
+    TL_MARK(" fold challenges");
+    for (u32 i = 0; i < K2; i++) {
+        Fq3 pm = mu[i];
+        for (u32 d = 0; d < 3; d++) { mu_pow[(size_t)i * 3 + d] = f3c(pm); pm = c->ring.mul3(pm, mu[i]); }
+    }
+    RET(upload_consts(c, "c_mu", mu_pow, &d_mu));
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     // split form of the GEMM rounds (lf_sv_rounds.h): eqB fixed at r_1..r_{i-1} is c_i eq(beta_i, b) E_i[p] at entry 2p + b, E_i = eq((beta_{i+1}..beta_s), .) -- one
     // value per pair, so the GEMM of round i runs against 24 digit columns instead of 48.  E_1 here, E_2 / E_3 as pair sums when their round comes.
@@ -2972,8 +3045,22 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             ~Publish() { int e = 0; s.z_state.compare_exchange_strong(e, -1, std::memory_order_release); }
         } publish{S[1]};
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
+        Timeline *const tl1 = &tl;
         u64 *yd = nullptr, *ydL = nullptr;
         size_t ev = 0;
+        // the right side's z_k depend on the witness and on x_w || h = x_ccs || 1 only, not on the point r: wherever they are built on this lane's stream,
+        // lane 0's u_s inner products wait for them (S[1].z_ev)
+        bool zr_done = c->tn.zr_pos == 4, yR_early = false;
+        const u64 *yR_host = nullptr;   // (4: the main thread builds them on lane 0's stream, first thing)
+        auto build_zr = [&]() {
+            if (zr_done) return;
+            zr_done = true;
+            std::vector<u64> xh((size_t)(P.l + 1) * 24);
+            memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
+            HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
+            (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
+        };
+        if (c->tn.zr_pos == 1) build_zr();
         if (commit_pair_possible(c)) {
             // both decompositions' commits in one pass over A.  Nothing needs y_L before the left decomposition is absorbed -- after the
             // linearization -- so the left evaluations go first and the commit's results wait on the device
@@ -2985,29 +3072,45 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             // three M z, its first rounds: 2.2 ms next to a commit, ~1.2 ms next to the evaluations), latency-bound afterwards.
             size_t evL = 0;
             RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+            tl1->mark1("L1: left evals down");
+            if (c->tn.zr_pos == 2) build_zr();
             RET(decompose_commit_enqueue(c, w_acc, &ydL, &evL));
+            // The download of a commit's results is enqueued right behind it -- ahead of whatever this stream is given next -- and its finish waits for that
+            // event only.  (Round 3 copied y_L behind the RIGHT commit: the left absorb, the head of a 2.3 ms host chain, started when both commits were done.)
+            const size_t ywords = (size_t)(P.K - 1) * P.kappa * 24;
+            const bool early = c->sh_world == 1 && !c->tn.no_early_y && c->pin2(2 * ywords) == LF_OK &&
+                               (c->ev_yL || hipEventCreateWithFlags(&c->ev_yL, hipEventDisableTiming) == hipSuccess) &&
+                               (c->ev_yR || hipEventCreateWithFlags(&c->ev_yR, hipEventDisableTiming) == hipSuccess);
+            bool yL_early = false;
+            if (early && hipMemcpyAsync(c->h_pin2, ydL, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yL, c->stream()) == hipSuccess)
+                yL_early = true;
+            if (c->tn.zr_pos == 3) build_zr();
             RET(decompose_commit_enqueue(c, w_i, &yd, &ev, "dec_y2"));          // right commit behind it on the same stream
-            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, evL, decl));
+            if (early && hipMemcpyAsync(c->h_pin2 + ywords, yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yR, c->stream()) == hipSuccess) {
+                yR_early = true;
+                yR_host = c->h_pin2 + ywords;
+            }
+            if (yL_early) build_zr();                                           // (default position: behind the right commit; host-side this is NOW, not after y_L has arrived)
+            tl1->mark1("L1: commits + z_R enqueued");
+            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, evL, decl, yL_early ? c->h_pin2 : nullptr, yL_early ? c->ev_yL : nullptr));
             ydL = nullptr;
+            tl1->mark1("L1: y_L down");
         } else {
             RET(decompose_commit_enqueue(c, w_acc, &yd, &ev));
             RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));
             RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
             RET(decompose_commit_enqueue(c, w_i, &yd, &ev));               // right commit in flight ...
         }
-        {   // ... and the right side's z_k behind it: they depend on the witness and on x_w || h = x_ccs || 1 only, not on the point r
-            std::vector<u64> xh((size_t)(P.l + 1) * 24);
-            memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
-            HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
-            (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
-        }
+        build_zr();   // (default: behind the right commit)
         if (ydL) {                                                      // paired commit: y_L from the device now (its phase timer closes here)
             RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, ev, decl));
             ev = c->ev_begin(11);
         }
         if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
+        tl1->mark1("L1: left absorb starts");
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
-        return decompose_commit_finish(c, cm_i, yd, ev, decr);          // cm of the linearized instance = cm_i.cm
+        tl1->mark1("L1: left absorb done");
+        return decompose_commit_finish(c, cm_i, yd, ev, decr, yR_early ? yR_host : nullptr, yR_early ? c->ev_yR : nullptr);   // cm of the linearized instance = cm_i.cm
     });
     {   // absorb_public_input (nifs.rs:175-197) -- after lane 1 has been started: the left decomposition does not depend on it
         HostTimer ht(c);
@@ -3017,28 +3120,46 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         tr.absorb_ring(cm_i, lf_cccs_len(&P));
     }
     TL_MARK("public input absorbed");
+    if (c->tn.zr_pos == 4) {   // the right side's z_k on THIS lane's stream, whose GPU time is mostly host hops between the linearization rounds
+        std::vector<u64> xh((size_t)(P.l + 1) * 24);
+        memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
+        HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
+        (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);
+    }
     c->vs_keep = true;
     rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
     c->vs_keep = false;
     TL_MARK("linearization done");
     lin_done_p.set_value(rc);
+    EvalStages est;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
         while (S[1].z_state.load(std::memory_order_acquire) == 0) std::this_thread::yield();   // published by lane 1 within its first millisecond (or -1)
-        rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr);
+        rc = decompose_evals(c, lin.data(), rR, w_i, "R", eq_r_R, S[1], decr, &est);
     }
     c->vs_wit = nullptr;
-    TL_MARK("right evals done");
+    TL_MARK(est.active ? "right evals enqueued" : "right evals done");
     int rc1 = c->lane1.wait();
     c->lin_blocks = 0;
     TL_MARK("lane 1 joined");
     if (rc == LF_OK) rc = rc1;
-    if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
+    if (rc == LF_OK && est.active) {
+        // the right decomposition is absorbed part by part (x_k, y_k, u_k, v_k): the first half as soon as its inner products are down, the second half
+        // of the inner products is still running on the GPU meanwhile
+        rc = decompose_evals_collect(c, est, 0, decr);
+        TL_MARK("right evals (first half) down");
+        if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1], 0, est.ksplit);
+        if (rc == LF_OK) rc = decompose_evals_collect(c, est, 1, decr);
+        TL_MARK("right evals done");
+        if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1], est.ksplit, P.K);
+    } else if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
+    if (rc != LF_OK && est.active) (void)hipStreamSynchronize(c->st_lane[0]);   // (nothing may still write the pinned staging when the step returns)
     }
     TL_MARK("right absorb done");
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->bits_wit[0] = c->bits_wit[1] = nullptr;
     TL_MARK("fold done");
+    tl.merge();
     tl.dump();
     c->tl_marks = tl.marks;
     t_tl = nullptr;

@@ -74,6 +74,9 @@ struct Tunables {
     bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
     bool coef_valu = false;          // LF_COEF_VALU: v / v_s / theta evaluations of the digit planes on the VALU kernel (k_coef_eval) instead of the matrix cores
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
+    bool no_early_y = false;         // LF_NO_EARLY_Y: the right commit's download behind everything else on the helper lane's stream (round-3 order)
+    bool evals_one_stage = true;     // LF_EVALS_TWO_STAGES=1: the right evaluations of a fold step in two downloads (the absorb of the first half overlaps the second half's inner products)
+    int zr_pos = 2;                  // LF_ZR_POS: where the helper lane builds the RIGHT side's z_k: 0 behind the right commit, 1 first thing, 2 behind the left evaluations, 3 between the commits
     bool commits_first = false;      // LF_COMMITS_FIRST: round-2 order of the helper lane (left commit, left evaluations, right commit) instead of evaluations first
     bool i8_pair = false;            // LF_I8_PAIR: both decompositions' digit-plane commits in ONE launch (paired workgroups share the tiles of A in L2: A leaves
                                      // HBM once per step) instead of one launch per decomposition.  Opt-in: the same kernel time per step (4.2 vs 2 x 2.13 ms at C4), but
@@ -127,6 +130,9 @@ struct Tunables {
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
         t.i8_pair = getenv("LF_I8_PAIR") != nullptr;
         t.commits_first = getenv("LF_COMMITS_FIRST") != nullptr;
+        if (const char *e = getenv("LF_ZR_POS")) t.zr_pos = atoi(e);
+        t.evals_one_stage = getenv("LF_EVALS_TWO_STAGES") == nullptr;
+        t.no_early_y = getenv("LF_NO_EARLY_Y") != nullptr;
         t.shard_two_lanes = getenv("LF_SHARD_TWO_LANES") != nullptr;
         t.shard_plain_rounds = getenv("LF_SHARD_PLAIN_ROUNDS") != nullptr;
         t.device_transcript = getenv("LF_DEVICE_TRANSCRIPT") != nullptr;

@@ -52,8 +52,16 @@ size_t sv_part_words(int V, size_t npairs, uint32_t K);   // int32 words of the 
 size_t sv_tot_words(int V, uint32_t K);               // int32 words of their sums
 size_t sv_tp_words(uint32_t K);                       // u64 words of the per-table polynomials
 // bit-plane form of a witness ([24][ldp] int32 planes, n positions, |v| < 2^K): rows of magnitude bits + one row of signs per coefficient
-size_t sv_bits_words(size_t n, uint32_t K);
-void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uint32_t *bits, hipStream_t s);
+size_t sv_bits_words(size_t n, uint32_t K, uint32_t rd = 24);   // rd: coefficients per ring element (24 / 72)
+void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uint32_t *bits, hipStream_t s, uint32_t rd = 24);
+// The GEMM stage alone, for the BabyBear backend (bb_sv_rounds.hip): rd coefficient groups per side, three column tiles of digit bytes EB[48][ldeb] in slot
+// order, all sv_num_pairs(V) digit monomials; the summed int32 tiles are left in tot (layout: lf_sv_rounds.hip).  0, or -1 (shape).
+size_t sv_tot_words_rd(uint32_t rd, int V, uint32_t K);
+size_t sv_part_words_rd(uint32_t rd, int V, uint32_t K);
+size_t sv_ldeb_pub(size_t npairs);
+__host__ __device__ constexpr int sv_slot_pair_pub(int V, int j, int q) { return (j / (4 / V)) * (16 / V) + (j % (4 / V)) + (4 / V) * q; }
+int launch_sv_gemm_tiles(uint32_t rd, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const unsigned char *EB, size_t ldeb, size_t npairs, uint32_t K,
+                         int32_t *part, int32_t *tot, hipStream_t s);
 // norm part of round log2(V)+1:  out[X*24 + 3*slot + q] = gpart[...] + sum_tables mu_T sum_p eqB(p)(X) (h_T^3 - h_T)(p)(X),  X = 0..4.
 // bitsL / bitsR: launch_sv_bits forms of the two witnesses (nplanes positions); eqB: [3][ldeq]; the launch covers the pairs [pair0, pair0 + npairs)
 // (a rank's slice of a sharded step: the partial messages of the ranks add up; gpart = the same slice's G part);

@@ -37,10 +37,10 @@ __device__ __forceinline__ u32 sv_writelane(u32 val, u32 lane, u32 old) {
     return old;
 #endif
 }
-__global__ void __launch_bounds__(256) k_sv_bits(const int32_t *planes, size_t ldp, size_t n, size_t npad, u32 rows, u32 *bits) {
+__global__ void __launch_bounds__(256) k_sv_bits(const int32_t *planes, size_t ldp, size_t n, size_t npad, u32 rows, u32 *bits, u32 rd) {
     const u32 lane = threadIdx.x & 63;
     const size_t wid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), per_c = npad / 512;
-    if (wid >= 24 * per_c) return;
+    if (wid >= rd * per_c) return;
     const u32 c = (u32)(wid / per_c);
     const size_t base = (wid % per_c) * 512;
     u32 klo[8], khi[8];
@@ -116,6 +116,7 @@ struct SvGemmArgs {
     u32 nsides;                 // 2 witnesses (round GEMMs) or 1 (launch_sv_vs)
     u32 nsuper, super_per_chunk;   // super-steps of 512 positions (256 / V pairs)
     u32 eb_mod;                 // 0, or: the eqB bytes repeat every eb_mod super-steps (launch_sv_vs_blocks: the weights of the low index bits only)
+    u32 rd;                     // coefficient groups per side: 24 (Goldilocks ring) / 72 (BabyBear ring, bb_sv_rounds.hip)
     u32 super0;                 // first super-step of the bit planes (a rank's pair slice of a sharded step; the eqB bytes start at its first pair)
     int32_t *part;              // [chunk][group][pair][3][64][4]
 };
@@ -168,9 +169,9 @@ __global__ void __launch_bounds__(64 * sv_waves(V)) __attribute__((amdgpu_waves_
     constexpr int PIECES = 16 * NT * SPAIRS / 16, PPT = (PIECES + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][16 * NT][LROW];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, g = lane >> 4;
-    const u32 ngroups = 24 * a.nsides * a.ktiles, gq = ngroups / NW;
+    const u32 ngroups = a.rd * a.nsides * a.ktiles, gq = ngroups / NW;
     const u32 grp = (blockIdx.x % gq) * NW + wave, chunk = blockIdx.x / gq;
-    const u32 kt = grp % a.ktiles, c = (grp / a.ktiles) % 24, side = grp / (a.ktiles * 24);
+    const u32 kt = grp % a.ktiles, c = (grp / a.ktiles) % a.rd, side = grp / (a.ktiles * a.rd);
     const u32 *mrow = a.bits[side] + ((size_t)c * a.rows + 16 * kt + row) * a.nw;
     const u32 *srow = a.bits[side] + ((size_t)c * a.rows + a.rows - 1) * a.nw;
     v4i acc[PW][NT];
@@ -344,15 +345,15 @@ bool sv_shape_ok(int V, size_t npairs, uint32_t K) {
 static size_t sv_ldeb(size_t npairs) { return (npairs + 255) / 256 * 256; }
 size_t sv_eb_bytes(size_t npairs) { return 48 * sv_ldeb(npairs) + 64; }
 static size_t sv_npad(size_t n) { return (n + 511) / 512 * 512; }
-size_t sv_bits_words(size_t n, uint32_t K) { return (size_t)24 * (16 * ((K + 15) / 16) + 1) * (sv_npad(n) / 32); }
-void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uint32_t *bits, hipStream_t s) {
+size_t sv_bits_words(size_t n, uint32_t K, uint32_t rd) { return (size_t)rd * (16 * ((K + 15) / 16) + 1) * (sv_npad(n) / 32); }
+void launch_sv_bits(const int32_t *planes, size_t ldp, size_t n, uint32_t K, uint32_t *bits, hipStream_t s, uint32_t rd) {
     const size_t npad = sv_npad(n);
-    hipLaunchKernelGGL(k_sv_bits, dim3((unsigned)cdiv(24 * (npad / 512), 4)), dim3(256), 0, s, planes, ldp, n, npad, 16 * ((K + 15) / 16) + 1, bits);
+    hipLaunchKernelGGL(k_sv_bits, dim3((unsigned)cdiv(rd * (npad / 512), 4)), dim3(256), 0, s, planes, ldp, n, npad, 16 * ((K + 15) / 16) + 1, bits, rd);
 }
 // chunks of super-steps (512 positions): the launches of the pair groups run one after the other, a block fills a CU (registers), so one launch
 // is one batch of at most 256 blocks
-static uint32_t sv_chunks_n(int V, size_t nsuper, uint32_t K, uint32_t nsides) {
-    const u32 ktiles = (K + 15) / 16, per_chunk = 24 * nsides * ktiles / (u32)sv_waves(V);
+static uint32_t sv_chunks_n(int V, size_t nsuper, uint32_t K, uint32_t nsides, uint32_t rd = 24) {
+    const u32 ktiles = (K + 15) / 16, per_chunk = rd * nsides * ktiles / (u32)sv_waves(V);
     if (nsuper == 0) return 1;
     size_t want = 256 / per_chunk;
     if (want > nsuper) want = nsuper;
@@ -364,12 +365,45 @@ uint32_t sv_chunks(int V, size_t nsuper, uint32_t K) { return sv_chunks_n(V, nsu
 size_t sv_tot_words(int V, uint32_t K) { return (size_t)48 * ((K + 15) / 16) * sv_num_pairs(V) * 768; }
 // sized for the largest chunk count of the shape: the launch clamps the pairs to the witness length and sv_chunks_n is not monotone in the
 // number of super-steps
-static uint32_t sv_max_chunks(int V, uint32_t K, uint32_t nsides) {
-    const u32 per_chunk = 24 * nsides * ((K + 15) / 16) / (u32)sv_waves(V);
+static uint32_t sv_max_chunks(int V, uint32_t K, uint32_t nsides, uint32_t rd = 24) {
+    const u32 per_chunk = rd * nsides * ((K + 15) / 16) / (u32)sv_waves(V);
     return per_chunk >= 256 ? 1 : 256 / per_chunk;
 }
 size_t sv_part_words(int V, size_t, uint32_t K) { return sv_tot_words(V, K) * sv_max_chunks(V, K, 2); }
 size_t sv_tp_words(uint32_t K) { return (size_t)2 * K * 24 * 15; }
+
+// ---- the GEMM stage alone, for the BabyBear backend (bb_sv_rounds.hip): rd coefficient groups per side, three column tiles of digit bytes EB[48][ldeb] (the
+// caller packed them in slot order, sv_slot_pair), all sv_num_pairs(V) digit monomials; leaves the summed tiles in tot:
+//   tot[((side * rd + c) * ktiles + kt) * npr + pi][tile][64 lanes][4]   (cell (digit plane row, digit column) as k_sv_finish1 reads it)
+size_t sv_tot_words_rd(uint32_t rd, int V, uint32_t K) { return (size_t)2 * rd * ((K + 15) / 16) * sv_num_pairs(V) * 768; }
+size_t sv_part_words_rd(uint32_t rd, int V, uint32_t K) { return sv_tot_words_rd(rd, V, K) * sv_max_chunks(V, K, 2, rd); }
+size_t sv_ldeb_pub(size_t npairs) { return (npairs + 255) / 256 * 256; }
+int launch_sv_gemm_tiles(uint32_t rd, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const unsigned char *EB, size_t ldeb, size_t npairs, uint32_t K,
+                         int32_t *part, int32_t *tot, hipStream_t s) {
+    if (!sv_shape_ok(V, npairs, K) || (2 * rd * ((K + 15) / 16)) % (u32)sv_waves(V)) return -1;
+    const size_t wall = cdiv(nplanes, 2 * (size_t)V), wpairs = wall < npairs ? wall : npairs;
+    SvGemmArgs a;
+    a.bits[0] = bitsL; a.bits[1] = bitsR;
+    a.ktiles = (K + 15) / 16;
+    a.nsides = 2;
+    a.rd = rd;
+    a.rows = 16 * a.ktiles + 1;
+    a.nw = sv_npad(nplanes) / 32;
+    a.EB = EB; a.ldeb = ldeb;
+    a.nsuper = (u32)cdiv(wpairs * V, 256);
+    a.super0 = 0;
+    a.eb_mod = 0;
+    const u32 chunks = sv_chunks_n(V, a.nsuper, K, 2, rd);
+    a.super_per_chunk = (u32)cdiv(a.nsuper, chunks);
+    a.part = part;
+    const u32 grid = 2 * rd * a.ktiles / (u32)sv_waves(V) * chunks;
+    if (V == 1) launch_gemm_pg<1, 0>(a, grid, s);
+    else if (V == 2) launch_gemm_pg<2, 0>(a, grid, s);
+    else launch_gemm_pg<4, 0>(a, grid, s);
+    const size_t words = sv_tot_words_rd(rd, V, K);
+    hipLaunchKernelGGL(k_sv_sum, dim3((unsigned)cdiv(words / 4, 256)), dim3(256), 0, s, part, words, chunks, tot);
+    return 0;
+}
 
 int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_t *bitsR, size_t nplanes, const uint64_t *eqB, size_t ldeq, size_t pair0, size_t npairs, uint32_t K,
                     const Fq3Const *mu_pow, const uint64_t *coef, unsigned char *EB, int32_t *part, int32_t *tot, uint64_t *tp, const uint64_t *gpart, uint64_t *out,
@@ -390,6 +424,7 @@ int launch_sv_round(const DevCrt &t, int V, const uint32_t *bitsL, const uint32_
     a.bits[0] = bitsL; a.bits[1] = bitsR;
     a.ktiles = (K + 15) / 16;
     a.nsides = 2;
+    a.rd = 24;
     a.rows = 16 * a.ktiles + 1;
     a.nw = sv_npad(nplanes) / 32;
     a.EB = EB; a.ldeb = ldeb;
@@ -452,6 +487,7 @@ int launch_sv_vs(const uint32_t *bits, size_t n, const uint64_t *eq, size_t ldeq
     a.bits[0] = bits; a.bits[1] = bits;
     a.ktiles = (K + 15) / 16;
     a.nsides = 1;
+    a.rd = 24;
     a.rows = 16 * a.ktiles + 1;
     a.nw = sv_npad(n) / 32;
     a.EB = EB; a.ldeb = ldeb;
@@ -484,6 +520,7 @@ int launch_sv_vs_blocks(const uint32_t *bits, size_t n, const uint64_t *eq_lo, s
     a.bits[0] = bits; a.bits[1] = bits;
     a.ktiles = (K + 15) / 16;
     a.nsides = 1;
+    a.rd = 24;
     a.rows = 16 * a.ktiles + 1;
     a.nw = sv_npad(n) / 32;
     a.EB = EB; a.ldeb = ldeb;

@@ -412,7 +412,7 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
             dy = (u64 *)c->pool.get(lw * 8); if (!dy) { cleanup(); return fail(c, LFPLUS_E_HIP, "hipMalloc"); } tofree.push_back(dy);
             const LfpMatrix &mj = c->mats[j];
             for (int s = 0; s < 2; s++) {
-                lfp::launch_spmv_ring(mj.rowptr + c->row0, mj.col, mj.valM, s ? dF1 : dF0, nl, dy, c->st);
+                lfp::launch_spmv_ring(mj.rowptr + c->row0, mj.col, mj.valM, s ? dF1 : dF0, nl, dy, c->st, mj.const_coef);
                 lfp::launch_replicate(dy, lw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * lw, c->st);
             }
             continue;
@@ -450,7 +450,9 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
                 cur = gath; nxt = tab;
                 len = (size_t)c->world;
             }
-            lfp::launch_ring_fix(cur, nxt, T, len, drM + (size_t)k * 32, c->st);
+            bool const_r = true;      // this variable's two coordinates are constants (always, for PlusProver's points): one product per word instead of 16
+            for (int w = 1; w < 16 && const_r; w++) const_r = !r_a[(size_t)k * 16 + w] && !r_b[(size_t)k * 16 + w];
+            lfp::launch_ring_fix(cur, nxt, T, len, drM + (size_t)k * 32, c->st, const_r);
             std::swap(cur, nxt);
             if (nxt == gath) nxt = ping;
             len /= 2;

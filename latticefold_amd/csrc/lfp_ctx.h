@@ -18,6 +18,7 @@ struct LfpMatrix {
     u32 *colptr = nullptr, *rowidx = nullptr;   // CSC
     u64 *valT = nullptr;                        //   canonical coefficients (launch_spmvT_eq)
     size_t nnz = 0;
+    bool const_coef = false;                    // every coefficient is a constant polynomial (launch_spmv_ring's one-product path)
     void release() {
         for (void *p : {(void *)rowptr, (void *)col, (void *)valM, (void *)colptr, (void *)rowidx, (void *)valT})
             if (p) (void)hipFree(p);

@@ -343,6 +343,18 @@ __global__ void __launch_bounds__(256) k_ring_fix(const u64 *in, u64 *out, u32 n
     const u64 diff = hi >= lo ? hi - lo : hi + (P - lo);
     out[((size_t)tab * half + j) * D + t] = add_p(lo, ring_mul_lane(r_s[tab & 1], diff, t));
 }
+// the same when both points' coordinate r is a constant polynomial (PlusProver's points are transcript challenges embedded as constants): a scalar product
+__global__ void __launch_bounds__(256) k_ring_fix_const(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM) {
+    const size_t g = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4), half = len / 2;
+    const int t = threadIdx.x & 15;
+    if (g >= (size_t)ntab * half) return;
+    const u32 tab = (u32)(g / half);
+    const size_t j = g % half;
+    const u64 *src = in + ((size_t)tab * len + 2 * j) * D;
+    const u64 lo = src[t], hi = src[D + t];
+    const u64 diff = hi >= lo ? hi - lo : hi + (P - lo);
+    out[((size_t)tab * half + j) * D + t] = add_p(lo, mont_mul(rM[(tab & 1) * D], diff));
+}
 // y = M x for a CSR matrix with ring-element coefficients (valM in Montgomery form); 16 lanes per row
 __global__ void __launch_bounds__(256) k_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y) {
     const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -356,6 +368,16 @@ __global__ void __launch_bounds__(256) k_spmv_ring(const u32 *rowptr, const u32 
         for (int s = 0; s < D; s++) aM[s] = valM[(size_t)k * D + s];
         acc = add_p(acc, ring_mul_lane(aM, xv, t));
     }
+    y[row * D + t] = acc;
+}
+// the same for a matrix whose coefficients are all CONSTANT polynomials (every R1CS the reference's benches and tests build: identity rows times gadget
+// powers b^i): one Montgomery product per non-zero and lane instead of the 16 of a negacyclic product
+__global__ void __launch_bounds__(256) k_spmv_ring_const(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y) {
+    const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int t = threadIdx.x & 15;
+    if (row >= nrows) return;
+    u64 acc = 0;
+    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) acc = add_p(acc, mont_mul(valM[(size_t)k * D], x[(size_t)col[k] * D + t]));
     y[row * D + t] = acc;
 }
 // dst[tab] = src for tab in 0..copies-1 (the tables of one vector, one per evaluation point)
@@ -417,12 +439,14 @@ void launch_reduce(const u64 *part, u32 nblk, u32 nout, u64 *out, u32 nsplit, u3
 void launch_decompose2(const u64 *f, size_t words, u64 B, u64 *F0, u64 *F1, hipStream_t s) {
     hipLaunchKernelGGL(k_decompose2, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, f, words, B, log2_exact(B), F0, F1);
 }
-void launch_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM, hipStream_t s) {
+void launch_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM, hipStream_t s, int const_r) {
     const size_t groups = (size_t)ntab * (len / 2);
-    hipLaunchKernelGGL(k_ring_fix, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, in, out, ntab, len, rM);
+    if (const_r) hipLaunchKernelGGL(k_ring_fix_const, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, in, out, ntab, len, rM);
+    else hipLaunchKernelGGL(k_ring_fix, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, in, out, ntab, len, rM);
 }
-void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s) {
-    hipLaunchKernelGGL(k_spmv_ring, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, s, rowptr, col, valM, x, nrows, y);
+void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s, int const_coef) {
+    if (const_coef) hipLaunchKernelGGL(k_spmv_ring_const, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, s, rowptr, col, valM, x, nrows, y);
+    else hipLaunchKernelGGL(k_spmv_ring, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, s, rowptr, col, valM, x, nrows, y);
 }
 void launch_replicate(const u64 *src, size_t words, u32 copies, u64 *dst, hipStream_t s) {
     hipLaunchKernelGGL(k_replicate, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src, words, copies, dst);

@@ -337,6 +337,9 @@ int upload_matrix(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, co
             memcpy(&vv[(size_t)dst * D], val + (size_t)k * D, D * 8);
         }
     m.nnz = nnz;
+    m.const_coef = true;
+    for (size_t k = 0; k < nnz && m.const_coef; k++)
+        for (int w = 1; w < D; w++) if (val[k * D + w]) { m.const_coef = false; break; }
     const size_t vb = (nnz ? nnz : 1) * D * 8, ib = (nnz ? nnz : 1) * 4;
     if (hipMalloc(&m.rowptr, (n + 1) * 4) != hipSuccess || hipMalloc(&m.col, ib) != hipSuccess || hipMalloc(&m.valM, vb) != hipSuccess ||
         hipMalloc(&m.colptr, (n + 1) * 4) != hipSuccess || hipMalloc(&m.rowidx, ib) != hipSuccess || hipMalloc(&m.valT, vb) != hipSuccess)
@@ -523,6 +526,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         lfp::launch_spmvT_eq(M[q].colptr + row0, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
         so.w.push_back(std::move(w));
     }
+    LFP_MARK(c, "set check: eq(r), M^T eq(r)");
     u64 *ed = so.small.as<u64>(), *bd = ed + (size_t)(1 + nM) * nmat * ncols * D;
     for (u32 i = 0; i < nmat; i++) {
         lfp::launch_wmono(mats[i].dig, nl, ncols, eql, 1, so.part.as<u64>(), ed + (size_t)i * ncols * D, c->st);
@@ -533,6 +537,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     HIPCHK(c, hipMemcpyAsync(e_out, ed, (size_t)(1 + nM) * nmat * ncols * D * 8, hipMemcpyDeviceToHost, c->st));
     if (nvec) HIPCHK(c, hipMemcpyAsync(b_out, bd, (size_t)nvec * D * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    LFP_MARK(c, "set check: evaluation passes");
     {   // partial evaluations over the rank's rows -> sums over the ranks
         int rcx = lfp_xsum(c, e_out, (size_t)(1 + nM) * nmat * ncols * D);
         if (!rcx && nvec) rcx = lfp_xsum(c, b_out, (size_t)nvec * D);
@@ -964,8 +969,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         for (u32 q = 0; q < nM; q++) {
             const LfpMatrix &m = M[q];
             u64 *mq = base + (size_t)(3 + 4 * q) * nl * D;
-            lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, tauring.as<u64>(), nl, mq, c->st);
-            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, xin[j], nl, mq + (size_t)(1 + j) * nl * D, c->st);
+            lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, tauring.as<u64>(), nl, mq, c->st, m.const_coef);
+            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, xin[j], nl, mq + (size_t)(1 + j) * nl * D, c->st, m.const_coef);
         }
     }
     HIPCHK(c, hipMemsetAsync(R + (size_t)nring * nl * D, 0, (size_t)2 * nl * D * 8, c->st));   // t0 | t1: zero beyond the prefix the host computed
@@ -1261,7 +1266,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     int rcm = M.get(c, n, 3, rowptr, col, val);
     if (rcm) return rcm;
     LFP_MARK(c, "(before linearize)");
-    for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr + row0, M[q].col, M[q].valM, c->f, nl, G[0].as<u64>() + (size_t)q * nl * D, c->st);
+    for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr + row0, M[q].col, M[q].valM, c->f, nl, G[0].as<u64>() + (size_t)q * nl * D, c->st, M[q].const_coef);
     std::vector<u64> r(nvars);
     for (u32 j = 0; j < nvars; j++) r[j] = tr->challenge();
     eq_build_local(c, r.data(), nvars, E[0].as<u64>());

@@ -142,30 +142,53 @@ __device__ __forceinline__ void block_sum16(u64 acc[16], u64 *out) {
     if (threadIdx.x < 16) out[threadIdx.x] = add_p(add_p(sm[0][threadIdx.x], sm[1][threadIdx.x]), add_p(sm[2][threadIdx.x], sm[3][threadIdx.x]));
 }
 // part[chunk][col][16] = sum over the chunk's rows of w[row] * X^e(dig[row][col]).  wstride 1: scalar weights (constant polynomials);
-// 16: ring weights -- coefficient t of w X^e is w[t - e] (t >= e), -w[t - e + 16] (t < e).  grid (chunks, ncols)
-__global__ void __launch_bounds__(256) k_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part) {
-    const u32 col = blockIdx.y;
-    u64 acc[16];
+// 16: ring weights -- coefficient t of w X^e is w[t - e] (t >= e), -w[t - e + 16] (t < e).
+// 16 lanes per row (lane t = coefficient t), ALL NC columns of the row per pass: the weight row is loaded once, coalesced (lane t reads word t), and the
+// rotation by the exponent is a 16-lane shuffle; a lane keeps one accumulator per column.  (First version: thread = row, grid.y = column -- every thread
+// gathered its 16 weight words with a data-dependent index from 64 different cache lines per instruction, and the 128 MB weight table of a 2^20-row
+// instance was read once per column: 39 ms of the 167 ms prove were the 48 evaluation passes of the set check.)
+template <int NC>
+__global__ void __launch_bounds__(256) k_wmono(const int8_t *dig, size_t dstride, size_t n, const u64 *w, u32 wstride, u64 *part, u32 pcols, u32 pc0) {
+    const int t = threadIdx.x & 15, r = threadIdx.x >> 4;
+    u64 acc[NC];
 #pragma unroll
-    for (int t = 0; t < 16; t++) acc[t] = 0;
-    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (size_t)gridDim.x * 256) {
-        const int8_t d = dig[row * ncols + col];
-        if (d == LFP_ABSENT) continue;
-        const int e = exp_of(d);
-        if (wstride == 1) {
-            const u64 v = w[row];
+    for (int c = 0; c < NC; c++) acc[c] = 0;
+    for (size_t row = (size_t)blockIdx.x * 16 + r; row < n; row += (size_t)gridDim.x * 16) {
+        const u64 wv = wstride == 1 ? w[row] : w[row * 16 + t];
+        int8_t d[NC];
+        if (NC == 16) {
+            const uint4 dv = *(const uint4 *)(dig + row * 16);
+            const u32 dw[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-            for (int t = 0; t < 16; t++) acc[t] = add_p(acc[t], e == t ? v : 0);
+            for (int c = 0; c < NC; c++) d[c] = (int8_t)(dw[c >> 2] >> (8 * (c & 3)));
         } else {
-            const u64 *wr = w + row * 16;
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const u64 v = wr[(t - e) & 15];
-                acc[t] = t >= e ? add_p(acc[t], v) : sub_p(acc[t], v);
+            for (int c = 0; c < NC; c++) d[c] = dig[row * dstride + c];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int e = exp_of(d[c]);
+            if (wstride == 1) {
+                acc[c] = add_p(acc[c], (d[c] != LFP_ABSENT && e == t) ? wv : 0);
+            } else {
+                const u64 v = __shfl(wv, (t - e) & 15, 16);
+                const u64 vv = d[c] != LFP_ABSENT ? v : 0;
+                acc[c] = t >= e ? add_p(acc[c], vv) : sub_p(acc[c], vv);
             }
         }
     }
-    block_sum16(acc, part + ((size_t)blockIdx.x * ncols + col) * 16);
+    // the 16 row groups of the block -> one sum per (column, coefficient)
+    __shared__ u64 sm[16][NC][16];
+#pragma unroll
+    for (int c = 0; c < NC; c++) sm[r][c][t] = acc[c];
+    __syncthreads();
+    for (int o = threadIdx.x; o < NC * 16; o += 256) {
+        const int c = o >> 4, tt = o & 15;
+        u64 sacc = 0;
+#pragma unroll
+        for (int g = 0; g < 16; g++) sacc = add_p(sacc, sm[g][c][tt]);
+        part[((size_t)blockIdx.x * pcols + pc0 + c) * 16 + tt] = sacc;
+    }
 }
 // part[chunk][16] = sum over the chunk's rows of w[row] * f[row] (f: n ring elements, canonical).  wstride 1: scalar weights in Montgomery
 // form (eq tables); 16: ring weights, canonical (negacyclic products)
@@ -211,10 +234,13 @@ __global__ void __launch_bounds__(256) k_sum_parts(const u64 *part, u32 chunks, 
     for (u32 ch = 0; ch < chunks; ch++) s = add_p(s, part[(size_t)ch * stride + o]);
     out[o] = out_of_mont ? from_mont(s) : s;
 }
-u32 eval_chunks(size_t n) { size_t b = cdiv(n, 256 * 8); return (u32)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
+u32 eval_chunks(size_t n) { size_t b = cdiv(n, 1024); return (u32)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }   // (256 blocks = one wave per SIMD: the passes were latency-bound)
 void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = eval_chunks(n);
-    hipLaunchKernelGGL(k_wmono, dim3(ch, ncols), dim3(256), 0, s, dig, n, ncols, w, wstride, part);
+    if (ncols == 16) hipLaunchKernelGGL((k_wmono<16>), dim3(ch), dim3(256), 0, s, dig, (size_t)16, n, w, wstride, part, 16u, 0u);
+    else {   // other widths: one column at a time (the range check's vector sets have one)
+        for (u32 c0 = 0; c0 < ncols; c0++) hipLaunchKernelGGL((k_wmono<1>), dim3(ch), dim3(256), 0, s, dig + c0, (size_t)ncols, n, w, wstride, part, ncols, c0);
+    }
     hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)ncols * 16, 256)), dim3(256), 0, s, part, ch, (size_t)ncols * 16, ncols * 16, wstride == 1, out);
 }
 void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
