@@ -3,6 +3,7 @@
 // Goldilocks driver in lf_capi.cpp (f-hat virtual, Mz restructured, f_0 in the coefficient domain), one stream, no
 // intra-step sharding.  Host <-> device traffic inside a fold step is O(proof size).
 #include "bb_capi.h"
+#include "lf_sv_rounds.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -58,6 +59,7 @@ struct BbCtxImpl {
     hipEvent_t ev_prep[2] = {nullptr, nullptr};   // fold prepare: fork / join of the right side's chain on the other stream
     hipEvent_t ev_dec[4] = {nullptr, nullptr, nullptr, nullptr};   // decomposition milestones: [2*side + (0 commit, 1 evaluations)]
     int digit_mode = 0;   // balanced-digit rule (lf_set_digit_mode)
+    unsigned sv_round_mask = 0;   // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i; lf_last_fold_paths)
     Tunables tn;          // environment switches, re-read at the start of every linearize / fold_step
     // v_s of the linearized instance computed inside the linearization (v = sum_k 2^k v_s[k]); reused by the right decomposition of the same fold step
     const lf_witness *vs_wit = nullptr;
@@ -1205,6 +1207,56 @@ static int upload_consts(C *c, const std::string &name, const std::vector<T> &v,
 }
 
 // LFFoldingProver::prove (nifs/folding.rs:42-130)
+// C_pi(X) of lf_sv_rounds.h for the V weights W_b = eq((r_1..), b) over F_{p^9}: coefficient table [pairs][4][9] (Montgomery words).  The BabyBear twin of
+// sv_build_coef in lf_capi.cpp: h = sum_x w_x(X) y_x, w_x = W_x (1 - X) (x < V), W_{x-V} X (x >= V); h^3 - h expanded over y^2 = b, y^3 = y.
+static E9 e9_from_h9(const H9 &h) { E9 r; for (int i = 0; i < TAU; i++) r.c[i] = from_canon(h.c[i]); return r; }
+static void bbsv_build_coef(int V, const E9 *W, fe nuM, std::vector<fe> &out) {
+    const int NX = 2 * V, NPR = lf::sv_num_pairs(V);
+    std::vector<E9> Cf((size_t)NPR * 4, e9_zero());
+    std::vector<lf::SvPair> prs(NPR);
+    for (int i = 0; i < NPR; i++) prs[i] = lf::sv_pair(V, i);
+    auto find = [&](unsigned s_, unsigned b_) {
+        for (int i = 0; i < NPR; i++)
+            if (prs[i].s == s_ && prs[i].b == b_) return i;
+        return -1;
+    };
+    std::vector<E9> wa(NX), wb(NX);
+    for (int x = 0; x < NX; x++) {
+        if (x < V) { wa[x] = W[x]; wb[x] = e9_neg(W[x]); }
+        else { wa[x] = e9_zero(); wb[x] = W[x - V]; }
+    }
+    auto mul = [&](const E9 &a, const E9 &b) { return e9_mul(a, b, nuM); };
+    for (int x = 0; x < NX; x++)
+        for (int y = x; y < NX; y++) {
+            const E9 p2[3] = {mul(wa[x], wa[y]), e9_add(mul(wa[x], wb[y]), mul(wb[x], wa[y])), mul(wb[x], wb[y])};
+            for (int z = y; z < NX; z++) {
+                E9 p3[4];
+                p3[0] = mul(p2[0], wa[z]);
+                p3[1] = e9_add(mul(p2[0], wb[z]), mul(p2[1], wa[z]));
+                p3[2] = e9_add(mul(p2[1], wb[z]), mul(p2[2], wa[z]));
+                p3[3] = mul(p2[2], wb[z]);
+                int mult, idx;
+                if (x == y && y == z) { mult = 1; idx = find(1u << x, 1u << x); }
+                else if (x == y) { mult = 3; idx = find(1u << z, (1u << x) | (1u << z)); }      // y_x^2 y_z = b_x y_z
+                else if (y == z) { mult = 3; idx = find(1u << x, (1u << x) | (1u << y)); }      // y_x y_y^2 = y_x b_y
+                else { mult = 6; const unsigned mk = (1u << x) | (1u << y) | (1u << z); idx = find(mk, mk); }
+                for (int e = 0; e < 4; e++) {
+                    E9 acc = e9_zero();
+                    for (int i = 0; i < mult; i++) acc = e9_add(acc, p3[e]);
+                    Cf[(size_t)idx * 4 + e] = e9_add(Cf[(size_t)idx * 4 + e], acc);
+                }
+            }
+        }
+    for (int x = 0; x < NX; x++) {   // - h
+        const int idx = find(1u << x, 1u << x);
+        Cf[(size_t)idx * 4] = e9_sub(Cf[(size_t)idx * 4], wa[x]);
+        Cf[(size_t)idx * 4 + 1] = e9_sub(Cf[(size_t)idx * 4 + 1], wb[x]);
+    }
+    out.resize((size_t)NPR * 4 * TAU);
+    for (size_t i = 0; i < (size_t)NPR * 4; i++)
+        for (int q = 0; q < TAU; q++) out[i * TAU + q] = Cf[i].c[q];
+}
+
 static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_witness **w_out, u64 *proof) {
     const lf_params &P = c->P;
     size_t m = c->m, n = c->n, N = c->N;
@@ -1317,6 +1369,14 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("fold_F1", (size_t)K2 * TAU * RE * atl(use_r5 ? m / 32 : m / 8), &F[1]));
     fe *d_lut = nullptr;
     int lut_mode = 0;
+    // Rounds 1..3 as exact int8 GEMMs on the matrix cores (bb_sv_rounds.hip: the norm part of the message from the bit-plane form of the witnesses, in the split
+    // eq form; the G part from the round kernel run without tables).  Unsharded steps whose witness fills whole super-steps.
+    const bool use_sv = Gw == 1 && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && P.s >= 4;
+    const size_t sv_min = c->tn.sv_min >= 65536 ? 16384 : c->tn.sv_min;   // (the default threshold is the Goldilocks driver's; a BabyBear pair carries three times the rows)
+    u32 *svbits[2] = {nullptr, nullptr};
+    fe *svE[3] = {nullptr, nullptr, nullptr};
+    u32 svE_level = 0;
+    c->sv_round_mask = 0;
     for (u32 round = 1; round <= P.s; round++) {
         bool fix_fused = false;
         lut_mode = 0;
@@ -1391,7 +1451,60 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         if (sharded) { a.pcnt = a.n / 2 / Gw; a.p0 = gr * a.pcnt; a.pF0 = a.p0; }
         else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
         size_t ev = c->ev_begin(0);
-        if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
+        const int svV = 1 << (round - 1);
+        bool sv_done = false;
+        if (use_sv && (int)round <= c->tn.sv_rounds && round <= 3 && a.pcnt >= sv_min && bbsv_shape_ok(svV, a.pcnt, K)) {
+            // weights W_b = eq((r_1..r_{i-1}), b), their digit-monomial coefficients, c_i = prod_{k<i} eq(beta_k, r_k), w_h = c_i eq(beta_i, h)
+            const fe nuM = from_canon(nu);
+            std::vector<E9> W((size_t)svV, e9_from_h9(h9_one()));
+            for (int b = 0; b < svV; b++)
+                for (u32 j = 0; j + 1 < round; j++) W[b] = e9_mul(W[b], e9_from_h9(((b >> j) & 1) ? pt[j] : h9_sub(h9_one(), pt[j])), nuM);
+            std::vector<fe> coef;
+            bbsv_build_coef(svV, W.data(), nuM, coef);
+            E9 cc = e9_from_h9(h9_one());
+            for (u32 k2 = 1; k2 < round; k2++) {
+                const E9 b = e9_from_h9(beta[k2 - 1]), r = e9_from_h9(pt[k2 - 1]), one = e9_from_h9(h9_one());
+                cc = e9_mul(cc, e9_add(e9_mul(e9_sub(one, b), e9_sub(one, r), nuM), e9_mul(b, r, nuM)), nuM);
+            }
+            const E9 bi = e9_from_h9(beta[round - 1]);
+            const E9 w0e = e9_mul(cc, e9_sub(e9_from_h9(h9_one()), bi), nuM), w1e = e9_mul(cc, bi, nuM);
+            E9C w0, w1;
+            for (int q = 0; q < TAU; q++) { w0.c[q] = w0e.c[q]; w1.c[q] = w1e.c[q]; }
+            fe *d_coef, *svtp;
+            u64 *gtmp;
+            unsigned char *sveb;
+            int32_t *svpart, *svtot;
+            RET(c->tbuf("sv_coef", coef.size() + 8, &d_coef));
+            RET(c->tbuf("sv_gtmp", (size_t)5 * RE + 8, &gtmp));
+            RET(c->tbuf("sv_tp", bbsv_tp_words(K), &svtp));
+            RET(c->tbuf("sv_eb", bbsv_eb_bytes(a.pcnt), &sveb));
+            RET(c->tbuf("sv_part", bbsv_part_words(svV, K), &svpart));
+            RET(c->tbuf("sv_tot", bbsv_tot_words(svV, K), &svtot));
+            HIPCHK(hipMemcpyAsync(d_coef, coef.data(), coef.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream()));
+            HIPCHK(hipStreamSynchronize(c->stream()));   // coef is a stack-lifetime buffer
+            if (!svbits[0])
+                for (int sd = 0; sd < 2; sd++) {
+                    RET(c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", bbsv_bits_words(N, K), &svbits[sd]));
+                    launch_bbsv_bits(S[sd].planes, N, N, K, svbits[sd], c->stream());
+                }
+            // E_i = eq((beta_{i+1}..beta_s), .): one value per pair; E_1 built, E_2 / E_3 pair sums
+            for (; svE_level < round; svE_level++) {
+                const size_t ne = m >> (svE_level + 1);
+                RET(c->tbuf(svE_level == 0 ? "sv_E1" : (svE_level == 1 ? "sv_E2" : "sv_E3"), (size_t)TAU * atl(ne), &svE[svE_level]));
+                if (svE_level == 0) RET(build_eq_dev(c, beta.data() + 1, P.s - 1, svE[0]));
+                else launch_bb_eq_pairsum(svE[svE_level - 1], atl(m >> svE_level), ne, svE[svE_level], atl(ne), c->stream());
+            }
+            i64 *gpartial;      // (the shared round buffer is sized for the m/8 pairs of round 3: this launch has up to m/2)
+            RET(c->tbuf("sv_gpartial", fold_partial_words(4 * m), &gpartial));
+            launch_fold_round(c->dev, a, nullptr, 0, 0, d_mup, gpartial, gtmp, c->stream());     // no tables: the G part alone (eqL G1 + eqR G2)
+            if (launch_bbsv_round(c->dev, svV, svbits[0], svbits[1], N, svE[round - 1], atl(m >> round), a.pcnt, K, d_mu, d_coef, w0, w1, sveb, svpart, svtot, svtp, gtmp, od,
+                                  c->stream()) == 0) {
+                sv_done = true;
+                c->sv_round_mask |= 1u << (round - 1);
+            }
+        }
+        if (sv_done) {}
+        else if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
         else if (lut_mode == 3 && !c->tn.fold_no_mutab) {
             fe *mutab;
@@ -1854,6 +1967,7 @@ int BbCtx::last_phase_ms(float *out) {
     for (int i = 0; i < NPH; i++) out[i] = p->phase_ms[i];
     return LF_OK;
 }
+unsigned BbCtx::fold_paths() const { return p->sv_round_mask; }
 int BbCtx::last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_n) {
     if (fold_ms) *fold_ms = p->k_fold_ms;
     if (fold_n) *fold_n = p->k_fold_n;

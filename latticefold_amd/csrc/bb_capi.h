@@ -71,6 +71,7 @@ struct BbCtx {
                       lf_witness **w_out, uint64_t *fold_proof_out);
     int last_phase_ms(float *out);
     int last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_n);
+    unsigned fold_paths() const;   // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
 };
 
 int bb_verify_host(const lf_params *p, const uint32_t *S_off, const uint32_t *S_idx, const uint64_t *c, BbTranscript &tr, const uint64_t *acc,

@@ -152,4 +152,15 @@ void launch_fold_round_lut_fix5(const DevBb &t, const FoldArgs &a, const int32_t
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev /*[2K][24]*/, int32_t *out,
                          hipStream_t s);
 
+// ---- rounds 1..3 of the folding sumcheck as int8 GEMMs (bb_sv_rounds.hip) ------------------------------------------------------------------------
+bool bbsv_shape_ok(int V, size_t npairs, u32 K);
+size_t bbsv_eb_bytes(size_t npairs);
+size_t bbsv_part_words(int V, u32 K);
+size_t bbsv_tot_words(int V, u32 K);
+size_t bbsv_tp_words(u32 K);
+size_t bbsv_bits_words(size_t n, u32 K);
+void launch_bbsv_bits(const int32_t *planes, size_t ldp, size_t n, u32 K, u32 *bits, hipStream_t s);
+void launch_bb_eq_pairsum(const fe *in, size_t ldi, size_t nout, fe *out, size_t ldo, hipStream_t s);
+int launch_bbsv_round(const DevBb &t, int V, const u32 *bitsL, const u32 *bitsR, size_t nplanes, const fe *E, size_t ldE, size_t npairs, u32 K, const E9C *mu_c,
+                      const fe *coef, const E9C &w0, const E9C &w1, unsigned char *EB, int32_t *part, int32_t *tot, fe *tp, const u64 *gpart, u64 *out, hipStream_t s);
 }  // namespace lfbb

@@ -3505,7 +3505,7 @@ int lf_last_timeline(lf_ctx *c, char *names, double *ms, int max_marks) {
 extern "C" int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_prof((unsigned long long *)out64) : LF_ERR_INVALID; }
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
-    *sv_round_mask = c->bb ? 0u : c->sv_round_mask;
+    *sv_round_mask = c->bb ? c->bb->fold_paths() : c->sv_round_mask;
     return LF_OK;
 }
 int lf_last_lin_split_rounds(lf_ctx *c, unsigned *rounds) {

@@ -226,13 +226,22 @@ __global__ void __launch_bounds__(256) k_wdot(const u64 *x, u32 xstride, int x_m
     }
     block_sum4(s, part + (size_t)blockIdx.x * 4);
 }
-// out[o] = sum over chunks of part[chunk * stride + o] (o < nout), optionally taken out of Montgomery form
-__global__ void __launch_bounds__(256) k_sum_parts(const u64 *part, u32 chunks, size_t stride, u32 nout, int out_of_mont, u64 *out) {
-    const u32 o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= nout) return;
+// out[o] = sum over chunks of part[chunk * stride + o] (o < nout), optionally taken out of Montgomery form.
+// block = 32 outputs x 32 chunk lanes (the first version walked the chunks with one thread per output: 256 - 1024 dependent loads, 0.25 ms per call and a
+// fifth of a 2^20-row prove in 130 calls)
+__global__ void __launch_bounds__(1024) k_sum_parts(const u64 *part, u32 chunks, size_t stride, u32 nout, int out_of_mont, u64 *out) {
+    __shared__ u64 sm[32][33];
+    const u32 ol = threadIdx.x & 31, cl = threadIdx.x >> 5, o = blockIdx.x * 32 + ol;
     u64 s = 0;
-    for (u32 ch = 0; ch < chunks; ch++) s = add_p(s, part[(size_t)ch * stride + o]);
-    out[o] = out_of_mont ? from_mont(s) : s;
+    if (o < nout)
+        for (u32 ch = cl; ch < chunks; ch += 32) s = add_p(s, part[(size_t)ch * stride + o]);
+    sm[cl][ol] = s;
+    __syncthreads();
+    if (cl == 0 && o < nout) {
+#pragma unroll
+        for (int g = 1; g < 32; g++) s = add_p(s, sm[g][ol]);
+        out[o] = out_of_mont ? from_mont(s) : s;
+    }
 }
 u32 eval_chunks(size_t n) { size_t b = cdiv(n, 1024); return (u32)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }   // (256 blocks = one wave per SIMD: the passes were latency-bound)
 void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
@@ -241,17 +250,17 @@ void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstr
     else {   // other widths: one column at a time (the range check's vector sets have one)
         for (u32 c0 = 0; c0 < ncols; c0++) hipLaunchKernelGGL((k_wmono<1>), dim3(ch), dim3(256), 0, s, dig + c0, (size_t)ncols, n, w, wstride, part, ncols, c0);
     }
-    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)ncols * 16, 256)), dim3(256), 0, s, part, ch, (size_t)ncols * 16, ncols * 16, wstride == 1, out);
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)ncols * 16, 32)), dim3(1024), 0, s, part, ch, (size_t)ncols * 16, ncols * 16, wstride == 1, out);
 }
 void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = eval_chunks(n);
     hipLaunchKernelGGL(k_wring, dim3(ch), dim3(256), 0, s, f, n, w, wstride, part);
-    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, s, part, ch, (size_t)16, 16u, 0, out);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1024), 0, s, part, ch, (size_t)16, 16u, 0, out);
 }
 void launch_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = eval_chunks(n);
     hipLaunchKernelGGL(k_wdot, dim3(ch), dim3(256), 0, s, x, xstride, x_mont, y, n, part);
-    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, s, part, ch, (size_t)4, 1u, 0, out);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1024), 0, s, part, ch, (size_t)4, 1u, 0, out);
 }
 // w[c] = sum over the non-zeros (row, c) of M of M[row][c] * eq[row]: the transposed matrix in CSR form (colptr over c, rowidx, values
 // canonical), eq in Montgomery form -> w canonical ring elements.  thread = (c, coefficient)

@@ -261,6 +261,32 @@ def test_fold_step_fused_fix_rounds_match_oracle(ctx, name, monkeypatch):
     assert (proof_u == proof_o).all() and (lc_u == lc_o).all()
 
 
+@pytest.mark.parametrize("name", ["B10", "B8", "BDP"])
+def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
+    """rounds 1..3 of the folding sumcheck as exact int8 GEMMs on the matrix cores (bb_sv_rounds.hip; from 16384 pairs on by default, LF_FOLD_SV_MIN lowers the
+    threshold): one, two and three rounds in that form, followed by the look-up-table rounds, the fused-fix rounds or plain tables -- identical proofs, all
+    equal to the oracle's (nifs/folding/utils.rs:273-325, utils/sumcheck/prover.rs:56-162)"""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 2)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    monkeypatch.setenv("LF_FOLD_SV_MIN", "64")
+    m = 1 << wl.s
+    for rounds, extra in ((1, {}), (2, {}), (3, {}), (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4"}), (2, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_R5_MIN": "1"}),
+                          (3, {"LF_FOLD_UNFUSED": "1"}), (3, {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_NO_R4TAB": "1"})):
+        monkeypatch.setenv("LF_FOLD_SV_ROUNDS", str(rounds))
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+        for k in extra:
+            monkeypatch.delenv(k)
+        want = sum(1 << (r - 1) for r in range(1, rounds + 1) if (m >> r) >= 64) if wl.s >= 4 and wl.N <= m and wl.N % 4 == 0 else 0
+        assert ctx.fold_paths() == want, (rounds, extra, ctx.fold_paths(), want)
+        bad = np.nonzero((proof != proof_o).any(axis=1))[0]
+        assert bad.size == 0 and (lc == lc_o).all() and (w.f == f0_o).all(), (rounds, extra, bad[:6])
+    monkeypatch.setenv("LF_FOLD_NO_SV", "1")
+    lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+    assert ctx.fold_paths() == 0 and (proof == proof_o).all()
+
+
 @pytest.mark.parametrize("name", ["B6", "B10", "BDP", "BD768"])
 def test_fold_step_int8_inner_products_match_oracle(ctx, name, monkeypatch):
     """u_s / eta as int8 GEMMs on the matrix cores (bb_dot_i8.hip; the driver uses them from 4096 columns on, LF_DOT_MIN lowers the

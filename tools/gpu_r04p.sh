@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+(timeout 900 python -m pytest tests/test_gpu_bb.py -x -q -k "gemm_rounds" 2>&1 | tail -25) > gpurun_out/r04p.txt
+(timeout 900 python -m pytest tests/test_gpu_bb.py -x -q 2>&1 | tail -5) >> gpurun_out/r04p.txt
+(timeout 900 python -m pytest tests/test_gpu_parity_scale.py -x -q -k "C3 or B14" 2>&1 | tail -5) >> gpurun_out/r04p.txt
+for e in A=1 LF_FOLD_NO_SV=1 A=1; do env $e timeout 300 python bench.py --workload C3 --steps 10 --warmup 2 --no-cpu-baseline --no-lfplus 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C3 $e ms/step %.3f'%d['ms_per_step'], d['phases_ms_per_step'])" >> gpurun_out/r04p.txt; done
+timeout 600 python tools/bench_lfplus.py --nvars 17 20 --k 4 --fresh 3 --rounds 3 2>/dev/null >> gpurun_out/r04p.txt
+cat gpurun_out/r04p.txt
