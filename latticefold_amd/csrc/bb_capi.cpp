@@ -1270,30 +1270,20 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         for (u32 i = 0; i < K2; i++) alpha[i] = tr.get_challenge();
         tr.absorb_label("zeta_s");
         for (u32 i = 0; i < K2; i++) zeta[i] = tr.get_challenge();
-        tr.absorb_label("mu_s");
-        for (u32 i = 0; i + 1 < K2; i++) mu[i] = tr.get_challenge();
-        mu[K2 - 1] = h9_one();
-        tr.absorb_label("beta_s");
-        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
     }
+    // The G tables need alpha and zeta only: their chains are enqueued here, and the host squeezes mu and beta while the GPU combines the z_k (the
+    // challenge order of the transcript -- alpha, zeta, mu, beta: folding/utils.rs:52-95 -- is untouched)
     size_t ph = c->ev_begin(13);
     // powers x^{j+1}
     std::vector<E9C> mu_c((size_t)K2 * TAU), a_pow((size_t)K2 * TAU);
     std::vector<E9PreC> mu_pre((size_t)K2 * TAU), z_pow((size_t)K2 * P.t);
     for (u32 i = 0; i < K2; i++) {
-        H9 pm = mu[i], pa = alpha[i], pz = zeta[i];
-        for (u32 d = 0; d < (u32)TAU; d++) {
-            mu_c[(size_t)i * TAU + d] = e9c_from_h9(pm);
-            mu_pre[(size_t)i * TAU + d] = e9pre_from_h9(pm, nu);
-            a_pow[(size_t)i * TAU + d] = e9c_from_h9(pa);
-            pm = c->ring.mul9(pm, mu[i]); pa = c->ring.mul9(pa, alpha[i]);
-        }
+        H9 pa = alpha[i], pz = zeta[i];
+        for (u32 d = 0; d < (u32)TAU; d++) { a_pow[(size_t)i * TAU + d] = e9c_from_h9(pa); pa = c->ring.mul9(pa, alpha[i]); }
         for (u32 j = 0; j < P.t; j++) { z_pow[(size_t)i * P.t + j] = e9pre_from_h9(pz, nu); pz = c->ring.mul9(pz, zeta[i]); }
     }
     E9C *d_mu, *d_ap;
     E9PreC *d_mup, *d_zp;
-    RET(upload_consts(c, "c_mu", mu_c, &d_mu));
-    RET(upload_consts(c, "c_mup", mu_pre, &d_mup));
     RET(upload_consts(c, "c_ap", a_pow, &d_ap));
     RET(upload_consts(c, "c_zp", z_pow, &d_zp));
     fe *G[2], *eqb, *zz;
@@ -1330,6 +1320,24 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             HIPCHK(hipStreamWaitEvent(s0, c->ev_prep[1], 0));
         }
     }
+    {
+        HostTimer ht(c);
+        tr.absorb_label("mu_s");
+        for (u32 i = 0; i + 1 < K2; i++) mu[i] = tr.get_challenge();
+        mu[K2 - 1] = h9_one();
+        tr.absorb_label("beta_s");
+        for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
+    }
+    for (u32 i = 0; i < K2; i++) {
+        H9 pm = mu[i];
+        for (u32 d = 0; d < (u32)TAU; d++) {
+            mu_c[(size_t)i * TAU + d] = e9c_from_h9(pm);
+            mu_pre[(size_t)i * TAU + d] = e9pre_from_h9(pm, nu);
+            pm = c->ring.mul9(pm, mu[i]);
+        }
+    }
+    RET(upload_consts(c, "c_mu", mu_c, &d_mu));
+    RET(upload_consts(c, "c_mup", mu_pre, &d_mup));
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     c->ev_end(ph);
 
@@ -1496,9 +1504,19 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             }
             i64 *gpartial;      // (the shared round buffer is sized for the m/8 pairs of round 3: this launch has up to m/2)
             RET(c->tbuf("sv_gpartial", fold_partial_words(4 * m), &gpartial));
-            launch_fold_round(c->dev, a, nullptr, 0, 0, d_mup, gpartial, gtmp, c->stream());     // no tables: the G part alone (eqL G1 + eqR G2)
+            // the G part (eqL G1 + eqR G2: the round kernel without tables) on the other, idle stream next to the GEMM chain
+            hipStream_t sg = (c->lane == 0 && !c->tn.prep_one_stream && c->st_lane[1]) ? c->st_lane[1] : c->stream();
+            hipEvent_t g_ready = nullptr;
+            if (sg != c->stream()) {
+                for (int e = 0; e < 2; e++)
+                    if (!c->ev_prep[e]) HIPCHK(hipEventCreateWithFlags(&c->ev_prep[e], hipEventDisableTiming));
+                HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));      // the special tables of this round were fixed on this stream
+                HIPCHK(hipStreamWaitEvent(sg, c->ev_prep[0], 0));
+            }
+            launch_fold_round(c->dev, a, nullptr, 0, 0, d_mup, gpartial, gtmp, sg);
+            if (sg != c->stream()) { HIPCHK(hipEventRecord(c->ev_prep[1], sg)); g_ready = c->ev_prep[1]; }
             if (launch_bbsv_round(c->dev, svV, svbits[0], svbits[1], N, svE[round - 1], atl(m >> round), a.pcnt, K, d_mu, d_coef, w0, w1, sveb, svpart, svtot, svtp, gtmp, od,
-                                  c->stream()) == 0) {
+                                  c->stream(), g_ready) == 0) {
                 sv_done = true;
                 c->sv_round_mask |= 1u << (round - 1);
             }

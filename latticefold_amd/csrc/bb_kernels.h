@@ -162,5 +162,5 @@ size_t bbsv_bits_words(size_t n, u32 K);
 void launch_bbsv_bits(const int32_t *planes, size_t ldp, size_t n, u32 K, u32 *bits, hipStream_t s);
 void launch_bb_eq_pairsum(const fe *in, size_t ldi, size_t nout, fe *out, size_t ldo, hipStream_t s);
 int launch_bbsv_round(const DevBb &t, int V, const u32 *bitsL, const u32 *bitsR, size_t nplanes, const fe *E, size_t ldE, size_t npairs, u32 K, const E9C *mu_c,
-                      const fe *coef, const E9C &w0, const E9C &w1, unsigned char *EB, int32_t *part, int32_t *tot, fe *tp, const u64 *gpart, u64 *out, hipStream_t s);
+                      const fe *coef, const E9C &w0, const E9C &w1, unsigned char *EB, int32_t *part, int32_t *tot, fe *tp, const u64 *gpart, u64 *out, hipStream_t s, hipEvent_t gpart_ready = nullptr);
 }  // namespace lfbb

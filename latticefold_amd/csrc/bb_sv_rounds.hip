@@ -138,7 +138,7 @@ void launch_bbsv_bits(const int32_t *planes, size_t ldp, size_t n, u32 K, u32 *b
 // E: E_i[9][ldE] (one value per pair), npairs pairs; coef: [sv_num_pairs(V)][4][9] Montgomery words (device); mu_c: [2K][9] constants mu_k^(d+1);
 // w0 / w1 = c_i eq(beta_i, 0 / 1).  Returns 0, or -1 when the shape is not handled (the caller keeps its VALU kernels).
 int launch_bbsv_round(const DevBb &t, int V, const u32 *bitsL, const u32 *bitsR, size_t nplanes, const fe *E, size_t ldE, size_t npairs, u32 K, const E9C *mu_c,
-                      const fe *coef, const E9C &w0, const E9C &w1, unsigned char *EB, int32_t *part, int32_t *tot, fe *tp, const u64 *gpart, u64 *out, hipStream_t s) {
+                      const fe *coef, const E9C &w0, const E9C &w1, unsigned char *EB, int32_t *part, int32_t *tot, fe *tp, const u64 *gpart, u64 *out, hipStream_t s, hipEvent_t gpart_ready) {
     if (!bbsv_shape_ok(V, npairs, K)) return -1;
     const size_t ldeb = lf::sv_ldeb_pub(npairs);
     (void)hipMemsetAsync(EB + 36 * ldeb, 0, 12 * ldeb, s);     // digit columns 36..47: none
@@ -147,6 +147,7 @@ int launch_bbsv_round(const DevBb &t, int V, const u32 *bitsL, const u32 *bitsR,
     const u32 npr = (u32)lf::sv_num_pairs(V), ktiles = (K + 15) / 16;
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_bbsv_finish1<true>), dim3(2 * K * RE), dim3(128), 0, s, t.nu, tot, npr, K, ktiles, coef, mu_c, tp, w0, w1);
     else hipLaunchKernelGGL((k_bbsv_finish1<false>), dim3(2 * K * RE), dim3(128), 0, s, t.nu, tot, npr, K, ktiles, coef, mu_c, tp, w0, w1);
+    if (gpart_ready) (void)hipStreamWaitEvent(s, gpart_ready, 0);   // the G part was computed on another stream
     hipLaunchKernelGGL(k_bbsv_finish2, dim3(1), dim3(384), 0, s, tp, K, gpart, out);
     return 0;
 }
