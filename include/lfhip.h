@@ -287,6 +287,9 @@ int lf_last_timeline(lf_ctx *, char *names /* 32 * max_marks */, double *ms, int
 int lf_last_fold_paths(lf_ctx *, unsigned *sv_round_mask);
 /* how many rounds of the last linearization sumcheck ran in the split eq form -- test hook */
 int lf_last_lin_split_rounds(lf_ctx *, unsigned *rounds);
+/* which table rounds of the last folding sumcheck ran in the split eq form (three lazy products per table, message completed on the host;
+ * bit i-1 = round i) -- test hook */
+int lf_last_fold_split_rounds(lf_ctx *, unsigned *round_mask);
 
 /* NIFSVerifier::verify (nifs.rs:117-163) on the host: O(proof size), NO GPU and no lf_ctx needed.  The CCS enters only
  * through its shape (lf_params), the multisets S (S_off[q+1], S_idx) and the coefficients c (q ring elements) -- the

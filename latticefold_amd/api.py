@@ -155,6 +155,7 @@ def _lib():
         L.lf_verify_host.argtypes = [C.c_int, C.POINTER(Params), u32p, u32p, u64p, vp, u64p, u64p, u64p, u64p, C.POINTER(C.c_int)]
         L.lf_last_fold_paths.argtypes = [vp, C.POINTER(C.c_uint)]
         L.lf_last_lin_split_rounds.argtypes = [vp, C.POINTER(C.c_uint)]
+        L.lf_last_fold_split_rounds.argtypes = [vp, C.POINTER(C.c_uint)]
         L.lf_last_timeline.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.c_int]
         L.lf_last_kernel_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _LIB = L
@@ -376,6 +377,12 @@ class Context:
         """rounds of the last linearization sumcheck that ran in the split eq form -- test hook"""
         m = C.c_uint()
         _chk(_lib().lf_last_lin_split_rounds(self.h, C.byref(m)), "lf_last_lin_split_rounds")
+        return m.value
+
+    def fold_split_rounds(self):
+        """mask (bit i-1 = round i) of the table rounds of the last folding sumcheck that ran in the split eq form -- test hook"""
+        m = C.c_uint()
+        _chk(_lib().lf_last_fold_split_rounds(self.h, C.byref(m)), "lf_last_fold_split_rounds")
         return m.value
 
     def timeline(self):

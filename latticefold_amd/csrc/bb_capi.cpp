@@ -59,6 +59,7 @@ struct BbCtxImpl {
     hipEvent_t ev_prep[2] = {nullptr, nullptr};   // fold prepare: fork / join of the right side's chain on the other stream
     hipEvent_t ev_dec[4] = {nullptr, nullptr, nullptr, nullptr};   // decomposition milestones: [2*side + (0 commit, 1 evaluations)]
     int digit_mode = 0;   // balanced-digit rule (lf_set_digit_mode)
+    unsigned fold_split_mask = 0;   // table rounds of the last folding sumcheck in the split eq form (lf_last_fold_split_rounds)
     unsigned sv_round_mask = 0;   // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i; lf_last_fold_paths)
     Tunables tn;          // environment switches, re-read at the start of every linearize / fold_step
     // v_s of the linearized instance computed inside the linearization (v = sum_k 2^k v_s[k]); reused by the right decomposition of the same fold step
@@ -341,6 +342,34 @@ static int shard_columns(C *c, size_t n, size_t *col0, size_t *cnt) {
 static H9 h9_load(const u64 *w) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = w[i] % BB_P; return r; }
 static H9 h9_one() { H9 r; memset(&r, 0, sizeof(r)); r.c[0] = 1; return r; }
 static H9 h9_sub(const H9 &a, const H9 &b) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = hsub(a.c[i], b.c[i]); return r; }
+static H9 h9_add(const H9 &a, const H9 &b) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = hadd(a.c[i], b.c[i]); return r; }
+static H9 h9_scale(const H9 &a, u64 k) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = hmul(a.c[i], k % BB_P); return r; }
+static bool h9_is_zero(const H9 &a) { u64 o = 0; for (int i = 0; i < TAU; i++) o |= a.c[i]; return o == 0; }
+// inverse in F_p[Y]/(Y^9 - nu): solve (multiplication by a) x = 1 by Gaussian elimination on the 9 x 9 matrix M[i][j] = [Y^i](a Y^j); false if a = 0
+static bool h9_inv(const H9 &a, u64 nu, H9 *out) {
+    u64 M[TAU][TAU + 1];
+    for (int i = 0; i < TAU; i++) {
+        for (int j = 0; j < TAU; j++) M[i][j] = i >= j ? a.c[i - j] % BB_P : hmul(nu % BB_P, a.c[TAU + i - j] % BB_P);
+        M[i][TAU] = i == 0;
+    }
+    for (int col = 0; col < TAU; col++) {
+        int piv = -1;
+        for (int r = col; r < TAU; r++)
+            if (M[r][col]) { piv = r; break; }
+        if (piv < 0) return false;
+        if (piv != col)
+            for (int j = 0; j <= TAU; j++) std::swap(M[piv][j], M[col][j]);
+        const u64 iv = hinv(M[col][col]);
+        for (int j = col; j <= TAU; j++) M[col][j] = hmul(M[col][j], iv);
+        for (int r = 0; r < TAU; r++) {
+            if (r == col || !M[r][col]) continue;
+            const u64 f = M[r][col];
+            for (int j = col; j <= TAU; j++) M[r][j] = hsub(M[r][j], hmul(f, M[col][j]));
+        }
+    }
+    for (int i = 0; i < TAU; i++) out->c[i] = M[i][TAU];
+    return true;
+}
 static bool is_diag(const u64 *e, H9 *out) {
     for (int k = 1; k < 8; k++)
         if (memcmp(e + TAU * k, e, TAU * 8)) return false;
@@ -1382,9 +1411,23 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     const bool use_sv = Gw == 1 && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && P.s >= 4;
     const size_t sv_min = c->tn.sv_min >= 65536 ? 16384 : c->tn.sv_min;   // (the default threshold is the Goldilocks driver's; a BabyBear pair carries three times the rows)
     u32 *svbits[2] = {nullptr, nullptr};
-    fe *svE[3] = {nullptr, nullptr, nullptr};
+    // E_i = eq((beta_{i+1}..beta_s), .): one value per pair of round i; E_1 built, E_2.. pair sums (GEMM rounds and the split table rounds)
+    fe *svE[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     u32 svE_level = 0;
+    auto svE_ensure = [&](u32 level) -> int {
+        static const char *const names[5] = {"sv_E1", "sv_E2", "sv_E3", "sv_E4", "sv_E5"};
+        for (; svE_level < level && svE_level < 5; svE_level++) {
+            const size_t ne = m >> (svE_level + 1);
+            RET(c->tbuf(names[svE_level], (size_t)TAU * atl(ne), &svE[svE_level]));
+            if (svE_level == 0) RET(build_eq_dev(c, beta.data() + 1, P.s - 1, svE[0]));
+            else launch_bb_eq_pairsum(svE[svE_level - 1], atl(m >> svE_level), ne, svE[svE_level], atl(ne), c->stream());
+        }
+        return LF_OK;
+    };
+    // rounds 4 / 5 in the split form (k_fold_round SPLIT): three lazy products per table, the host completes the message
+    const bool fr_split = Gw == 1 && !c->tn.fold_rounds_no_split && P.s >= 5;
     c->sv_round_mask = 0;
+    c->fold_split_mask = 0;
     for (u32 round = 1; round <= P.s; round++) {
         bool fix_fused = false;
         lut_mode = 0;
@@ -1495,13 +1538,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                     RET(c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", bbsv_bits_words(N, K), &svbits[sd]));
                     launch_bbsv_bits(S[sd].planes, N, N, K, svbits[sd], c->stream());
                 }
-            // E_i = eq((beta_{i+1}..beta_s), .): one value per pair; E_1 built, E_2 / E_3 pair sums
-            for (; svE_level < round; svE_level++) {
-                const size_t ne = m >> (svE_level + 1);
-                RET(c->tbuf(svE_level == 0 ? "sv_E1" : (svE_level == 1 ? "sv_E2" : "sv_E3"), (size_t)TAU * atl(ne), &svE[svE_level]));
-                if (svE_level == 0) RET(build_eq_dev(c, beta.data() + 1, P.s - 1, svE[0]));
-                else launch_bb_eq_pairsum(svE[svE_level - 1], atl(m >> svE_level), ne, svE[svE_level], atl(ne), c->stream());
-            }
+            RET(svE_ensure(round));
             i64 *gpartial;      // (the shared round buffer is sized for the m/8 pairs of round 3: this launch has up to m/2)
             RET(c->tbuf("sv_gpartial", fold_partial_words(4 * m), &gpartial));
             // the G part (eqL G1 + eqR G2: the round kernel without tables) on the other, idle stream next to the GEMM chain
@@ -1521,6 +1558,23 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                 c->sv_round_mask |= 1u << (round - 1);
             }
         }
+        // split form of this round's table kernel?  (modes 6 / 7; c_i and beta_i must be invertible for the host's completion)
+        bool split_now = false;
+        H9 sp_c = h9_one(), sp_cinv = h9_one(), sp_binv = h9_one();
+        const fe *Er = nullptr;
+        size_t ldEr = 0;
+        if (fr_split && !sv_done && round >= 2 && round <= 5 && !sharded && ((lut_mode == 4 && !c->tn.fold_no_r4tab) || lut_mode == 7) && a.pcnt >= c->tn.fold_split_min) {
+            for (u32 k2 = 1; k2 < round; k2++) {
+                const H9 b = beta[k2 - 1], r = pt[k2 - 1];
+                sp_c = c->ring.mul9(sp_c, h9_add(c->ring.mul9(h9_sub(h9_one(), b), h9_sub(h9_one(), r)), c->ring.mul9(b, r)));
+            }
+            if (h9_inv(sp_c, nu, &sp_cinv) && h9_inv(beta[round - 1], nu, &sp_binv)) {
+                RET(svE_ensure(round));
+                Er = svE[round - 1]; ldEr = atl(m >> round);
+                split_now = true;
+                c->fold_split_mask |= 1u << (round - 1);
+            }
+        }
         if (sv_done) {}
         else if (round == 1) launch_fold_round1(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, partial, od, c->stream());
         else if (round == 2) launch_fold_round2(c->dev, a, S[0].planes, S[1].planes, N, K, d_mu, pt[0], c->ring, partial, od, c->stream());
@@ -1534,20 +1588,65 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             RET(c->tbuf("fold_r4sq", (size_t)6561 * 12, &r4sq));
             RET(c->tbuf("fold_r4mt", (size_t)K2 * TAU * 162 * 12, &r4mt));
             launch_fold_round_lut_fix_tab(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, r4sq, r4mt, use_r5 ? nullptr : (fe *)curF, ldF, K, d_mup, partial, od,
-                                          c->stream());
+                                          c->stream(), Er, ldEr);
         } else if (lut_mode == 7) {
             fe *r5xx, *r5yy, *r5mt;
             RET(c->tbuf("fold_r5xx", (size_t)6561 * 12, &r5xx));
             RET(c->tbuf("fold_r5yy", (size_t)6561 * 12, &r5yy));
             RET(c->tbuf("fold_r5mt", (size_t)K2 * TAU * 324 * 12, &r5mt));
             launch_fold_round_lut_fix5(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 3], pt[round - 2], c->ring, r5xx, r5yy, r5mt, (fe *)curF, ldF, K, d_mup, partial, od,
-                                       c->stream());
+                                       c->stream(), Er, ldEr);
         } else if (lut_mode == 4) launch_fold_round_lut_fix(c->dev, a, S[0].planes, S[1].planes, N, d_lut, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else if (fix_fused) launch_fold_round_fix(c->dev, a, prevF, prevld, pt[round - 2], c->ring, (fe *)curF, ldF, K, d_mup, partial, od, c->stream());
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());
+        if (split_now) {   // the G part of the message (eqL G1 + eqR G2 at X = 0..4) from the round kernel run without tables, behind the three sums of the table kernel
+            i64 *gpartial;
+            RET(c->tbuf("sv_gpartial", fold_partial_words(4 * m), &gpartial));
+            launch_fold_round(c->dev, a, nullptr, 0, 0, d_mup, gpartial, od + 5 * RE, c->stream());
+        }
         c->ev_end(ev);
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;
         HIPCHK(hipStreamSynchronize(c->stream()));            // message is in mapped host memory
+        if (split_now) {
+            // od[e][slot] (e = 0..2): A_e = sum_p E[p] C_e(p); od[5 + X][slot]: the G part.  g(X) = c l(X) (A0 + A1 X + A2 X^2 + A3 X^3) + G(X), l(X) = eq(beta_i, X);
+            // A3 from g(0) + g(1) = the previous message at its challenge (interpolated: no assumption on the claimed sum)
+            HostTimer ht2(c);
+            const H9 bi = beta[round - 1], obi = h9_sub(h9_one(), bi), x = pt[round - 2];
+            H9 wS[5];
+            for (u32 j2 = 0; j2 <= deg; j2++) {
+                H9 num = h9_one();
+                u64 den = 1;
+                for (u32 k2 = 0; k2 <= deg; k2++) {
+                    if (k2 == j2) continue;
+                    H9 xk = x; xk.c[0] = hsub(xk.c[0], k2);
+                    num = c->ring.mul9(num, xk);
+                    den = hmul(den, j2 > k2 ? (u64)(j2 - k2) : BB_P - (u64)(k2 - j2));
+                }
+                wS[j2] = h9_scale(num, hinv(den));
+            }
+            H9 cl[5];   // c l(X)
+            {
+                H9 l = obi;
+                const H9 dl = h9_sub(bi, obi);
+                for (u32 X = 0; X <= deg; X++) { cl[X] = c->ring.mul9(sp_c, l); l = h9_add(l, dl); }
+            }
+            const u64 *pe = msgs + (size_t)(round - 2) * (deg + 1) * RE, *gev = od + 5 * RE;
+            auto ld = [&](const u64 *b, u32 e, u32 slot) { return h9_load(b + (size_t)e * RE + TAU * slot); };
+            for (u32 slot = 0; slot < 8; slot++) {
+                H9 Sv = ld(pe, 0, slot);
+                Sv = c->ring.mul9(wS[0], Sv);
+                for (u32 j2 = 1; j2 <= deg; j2++) Sv = h9_add(Sv, c->ring.mul9(wS[j2], ld(pe, j2, slot)));
+                const H9 A0 = ld(od, 0, slot), A1 = ld(od, 1, slot), A2 = ld(od, 2, slot);
+                const H9 Gsum = h9_add(ld(gev, 0, slot), ld(gev, 1, slot));
+                const H9 T1 = c->ring.mul9(h9_sub(c->ring.mul9(h9_sub(Sv, Gsum), sp_cinv), c->ring.mul9(obi, A0)), sp_binv);
+                const H9 A3 = h9_sub(h9_sub(h9_sub(T1, A0), A1), A2);
+                for (u32 X = 0; X <= deg; X++) {
+                    const H9 T = h9_add(A0, h9_scale(h9_add(A1, h9_scale(h9_add(A2, h9_scale(A3, X)), X)), X));
+                    const H9 g = h9_add(c->ring.mul9(cl[X], T), ld(gev, X, slot));
+                    memcpy(evs + (size_t)X * RE + TAU * slot, g.c, sizeof(g.c));
+                }
+            }
+        } else
         memcpy(evs, od, (size_t)(deg + 1) * RE * 8);
         if (sharded) RET(exchange_modsum(c, evs, (size_t)(deg + 1) * RE));
         HostTimer ht(c);
@@ -1986,6 +2085,7 @@ int BbCtx::last_phase_ms(float *out) {
     return LF_OK;
 }
 unsigned BbCtx::fold_paths() const { return p->sv_round_mask; }
+unsigned BbCtx::fold_split_rounds() const { return p->fold_split_mask; }
 int BbCtx::last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_n) {
     if (fold_ms) *fold_ms = p->k_fold_ms;
     if (fold_n) *fold_n = p->k_fold_n;

@@ -71,6 +71,7 @@ struct BbCtx {
                       lf_witness **w_out, uint64_t *fold_proof_out);
     int last_phase_ms(float *out);
     int last_kernel_stats(float *fold_ms, int *fold_n, float *aj_ms, int *aj_n);
+    unsigned fold_split_rounds() const;   // table rounds of the last folding sumcheck that ran in the split eq form
     unsigned fold_paths() const;   // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
 };
 

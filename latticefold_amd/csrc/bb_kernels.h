@@ -144,10 +144,10 @@ void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t 
                                hipStream_t s);
 void launch_fold_round_lut_fix_tab(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                    const H9 &r, const BbHostRing &ring, fe *sq_dev, fe *mt_dev, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial,
-                                   u64 *out, hipStream_t s);
+                                   u64 *out, hipStream_t s, const fe *Esp = nullptr, size_t ldEsp = 0);   // Esp: split form (k_fold_round SPLIT), E_i as [9][ldEsp]
 void launch_fold_round_lut_fix5(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                 const H9 &r3, const H9 &r4, const BbHostRing &ring, fe *xx_dev, fe *yy_dev, fe *mt_dev, fe *Fout, size_t ldout, u32 K,
-                                const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);
+                                const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s, const fe *Esp = nullptr, size_t ldEsp = 0);
 // folded witness in the coefficient domain: out[c][j] = sum_{i<2K} (rho_i * bitplane_i)(c) mod X^72 - X^36 + 1
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev /*[2K][24]*/, int32_t *out,
                          hipStream_t s);

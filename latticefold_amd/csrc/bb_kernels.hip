@@ -1192,7 +1192,7 @@ void launch_fold_materialize2(const DevBb &t, const int32_t *planesL, const int3
 // sum_b W_b * digit_k(plane[4j+b]) with four ternary digits -- one of 81 values independent of table and slot -- and comes from a look-up
 // table in LDS indexed by the digit code (lut: [81][9] words); mode 4 also fixes the four round-3 entries of a pair with r and stores the
 // first materialised tables (m/8 entries) like mode 1.  MODE 0: plain tables, MODE 1: fused fix (above).
-struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; const fe *mutab; const fe *sq4; const fe *mt4; E9PreC rprev; const fe *xx5, *yy5, *mt5; };   // mutab: mode 5, [3][2K*9][81][12]; sq4 / mt4: mode 6, [81*81][12] and [2K*9][2][81][12]; rprev / xx5 / yy5 / mt5: mode 7 (r_3; [81*81][12] twice; [2K*9][4][81][12])
+struct FoldLut { const int32_t *planesL, *planesR; size_t n_planes; const fe *lut; const fe *mutab; const fe *sq4; const fe *mt4; E9PreC rprev; const fe *xx5, *yy5, *mt5; const fe *Esp; size_t ldEsp; };   // mutab: mode 5, [3][2K*9][81][12]; sq4 / mt4: mode 6, [81*81][12] and [2K*9][2][81][12]; rprev / xx5 / yy5 / mt5: mode 7 (r_3; [81*81][12] twice; [2K*9][4][81][12])
 __device__ __forceinline__ u32 digit_code4(const int32_t *v, u32 k) {
     int code = 40;
     const int w[4] = {1, 3, 9, 27};
@@ -1273,9 +1273,15 @@ __global__ void __launch_bounds__(256) k_fold_r5tab(DevBb t, const fe *lut, E9Pr
         for (int c = 0; c < 12; c++) o[c] = c < TAU ? m.c[c] : 0;
     }
 }
-template <bool NU2, int MODE>
+// SPLIT (modes 6 / 7; the Goldilocks twin is lf::k_fold_round SPLIT): eqB fixed at r_1..r_{i-1} is c_i eq(beta_i, b) E_i[p] at entry 2p + b with
+// E_i = eq((beta_{i+1}..beta_s), .) one value per pair, so the norm part of the message is c_i eq(beta_i, X) (A0 + A1 X + A2 X^2 + A3 X^3),
+// A_e = sum_p E_i[p] C_e(p).  The kernel leaves A0..A2 in rows 0..2 of its message (rows 3, 4 zero) -- C3 is the one coefficient that needs the fourth lazy
+// product P3 of a table -- and no G part (that comes from the round kernel run without tables); the host takes A3 from g(0) + g(1) = the previous
+// message at its challenge (bb_capi.cpp).  lt.Esp = E_i as [9][lt.ldEsp].
+template <bool NU2, int MODE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const fe *F, size_t ldF, u32 K, const E9PreC *Mpre, E9PreC rfix,
                                                     fe *Fout, size_t ldo, FoldLut lt, i64 *partial) {
+    static_assert(!SPLIT || MODE == 6 || MODE == 7, "split form: modes 6 and 7");
     constexpr bool FIX = MODE == 1;
     __shared__ fe slut[MODE == 7 ? 4 * 81 * TAU : (MODE >= 3 ? 3 * 81 * TAU : 1)];   // the 81 values, their squares, (modes 4, 6) r times the values; mode 7: T0..T3
     if (MODE == 7) {
@@ -1380,10 +1386,12 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
                 for (int c = 0; c < TAU; c++) hl_add(C[TAU + c], T[c]);
                 e9_mul_cols(mf[0], sq[1], s1n, T);
 #pragma unroll
-                for (int c = 0; c < TAU; c++) hl_add(C[2 * TAU + c], T[c]);
-                e9_mul_cols(mf[1], sq[1], s1n, T);
+                for (int c = 0; c < TAU; c++) { hl_add(C[2 * TAU + c], T[c]); SP[c] += mf[0].c[c]; SU[c] += mf[1].c[c]; }
+                if (!SPLIT) {
+                    e9_mul_cols(mf[1], sq[1], s1n, T);
 #pragma unroll
-                for (int c = 0; c < TAU; c++) { hl_add(C[3 * TAU + c], T[c]); SP[c] += mf[0].c[c]; SU[c] += mf[1].c[c]; }
+                    for (int c = 0; c < TAU; c++) hl_add(C[3 * TAU + c], T[c]);
+                }
                 continue;
             }
             if (MODE == 5) {
@@ -1476,10 +1484,12 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
                     for (int c = 0; c < TAU; c++) hl_add(C[TAU + c], T[c]);
                     e9_mul_cols(tt, s1, s1n, T);
 #pragma unroll
-                    for (int c = 0; c < TAU; c++) hl_add(C[2 * TAU + c], T[c]);
-                    e9_mul_cols(uu, s1, s1n, T);
+                    for (int c = 0; c < TAU; c++) { hl_add(C[2 * TAU + c], T[c]); SP[c] += tt.c[c]; SU[c] += uu.c[c]; }
+                    if (!SPLIT) {
+                        e9_mul_cols(uu, s1, s1n, T);
 #pragma unroll
-                    for (int c = 0; c < TAU; c++) { hl_add(C[3 * TAU + c], T[c]); SP[c] += tt.c[c]; SU[c] += uu.c[c]; }
+                        for (int c = 0; c < TAU; c++) hl_add(C[3 * TAU + c], T[c]);
+                    }
                     continue;
                 }
             }
@@ -1536,6 +1546,18 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
     i64 acc[5 * TAU];
 #pragma unroll
     for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
+    if (live && SPLIT) {
+        E9 c0, c1, c2;
+#pragma unroll
+        for (int c = 0; c < TAU; c++) {
+            const i64 P0 = hl_finish(C[c]), P1 = hl_finish(C[TAU + c]), P2 = hl_finish(C[2 * TAU + c]), sp = fred(SP[c]), su = fred(SU[c]);
+            c0.c[c] = fred(P0 - sp); c1.c[c] = fred(3 * (P1 - P0) - (su - sp)); c2.c[c] = fred(3 * (P2 - 2 * P1 + P0));
+        }
+        const E9 E = ldq(lt.Esp, lt.ldEsp, j);
+        const E9 a0 = e9_mul_t<NU2>(c0, E, t.nu), a1 = e9_mul_t<NU2>(c1, E, t.nu), a2 = e9_mul_t<NU2>(c2, E, t.nu);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) { acc[c] = a0.c[c]; acc[TAU + c] = a1.c[c]; acc[2 * TAU + c] = a2.c[c]; }
+    } else
     if (live) {
         if (blockIdx.z == 0) fold_linear_part(t, a, slot, j, acc);
         // S(X) = C0 + C1 X + 3 C2 X^2 + C3 X^3
@@ -1594,16 +1616,20 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
     while (tch > 1 && (size_t)gb * tch > RED_BLOCKS) tch /= 2;
     const bool nu2 = t.nu == BB_TWO;
     if (mode >= 3) tch = 1;   // the planes of one (side, d) serve all K tables: no table split (large rounds only)
+    const bool split = lt.Esp != nullptr && (mode == 6 || mode == 7);
 #define BB_FR(N2, MD) hipLaunchKernelGGL((k_fold_round<N2, MD>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, rfix, Fout, ldo, lt, partial)
+#define BB_FRS(N2, MD) hipLaunchKernelGGL((k_fold_round<N2, MD, true>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, rfix, Fout, ldo, lt, partial)
 #define BB_FRM(N2)                                                              \
     do {                                                                        \
-        if (mode == 1) BB_FR(N2, 1); else if (mode == 3) BB_FR(N2, 3);          \
+        if (split && mode == 6) BB_FRS(N2, 6); else if (split) BB_FRS(N2, 7);   \
+        else if (mode == 1) BB_FR(N2, 1); else if (mode == 3) BB_FR(N2, 3);     \
         else if (mode == 4) BB_FR(N2, 4); else if (mode == 5) BB_FR(N2, 5);     \
         else if (mode == 6) BB_FR(N2, 6); else if (mode == 7) BB_FR(N2, 7);     \
         else BB_FR(N2, 0);                                                      \
     } while (0)
     if (nu2) BB_FRM(true); else BB_FRM(false);
 #undef BB_FRM
+#undef BB_FRS
 #undef BB_FR
     launch_reduce_rows(partial, gb * tch, 5 * RE, out, s);
 }
@@ -1638,25 +1664,25 @@ void launch_fold_round_lut_fix(const DevBb &t, const FoldArgs &a, const int32_t 
 // round 4 through the product-free tables of mode 6 (sq_dev 6561*12 words, mt_dev 2K*9*2*81*12 words, filled by this call)
 void launch_fold_round_lut_fix_tab(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                    const H9 &r, const BbHostRing &ring, fe *sq_dev, fe *mt_dev, fe *Fout, size_t ldout, u32 K, const E9PreC *Mpre, i64 *partial,
-                                   u64 *out, hipStream_t s) {
+                                   u64 *out, hipStream_t s, const fe *Esp, size_t ldEsp) {
     const u32 ntab = 2 * K * TAU;
     const E9PreC rp = e9pre_from_h9(r, ring.T.nu);
     const u32 grid = (6561 + ntab * 162 + 255) / 256;
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_r4tab<true>), dim3(grid), dim3(256), 0, s, t, lut_dev, rp, Mpre, ntab, sq_dev, mt_dev);
     else hipLaunchKernelGGL((k_fold_r4tab<false>), dim3(grid), dim3(256), 0, s, t, lut_dev, rp, Mpre, ntab, sq_dev, mt_dev);
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, sq_dev, mt_dev, {}, nullptr, nullptr, nullptr};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, sq_dev, mt_dev, {}, nullptr, nullptr, nullptr, Esp, ldEsp};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 6, rp, Fout, ldout, lt, partial, out, s);
 }
 // round 5 from the planes (mode 7): xx_dev / yy_dev 6561*12 words each, mt_dev 2K*9*4*81*12 words, filled by this call; r3 / r4: the challenges of rounds 3 / 4
 void launch_fold_round_lut_fix5(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                                 const H9 &r3, const H9 &r4, const BbHostRing &ring, fe *xx_dev, fe *yy_dev, fe *mt_dev, fe *Fout, size_t ldout, u32 K,
-                                const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s) {
+                                const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s, const fe *Esp, size_t ldEsp) {
     const u32 ntab = 2 * K * TAU;
     const E9PreC r3p = e9pre_from_h9(r3, ring.T.nu), r4p = e9pre_from_h9(r4, ring.T.nu);
     const u32 grid = (2 * 6561 + ntab * 324 + 255) / 256;
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_r5tab<true>), dim3(grid), dim3(256), 0, s, t, lut_dev, r3p, r4p, Mpre, ntab, xx_dev, yy_dev, mt_dev);
     else hipLaunchKernelGGL((k_fold_r5tab<false>), dim3(grid), dim3(256), 0, s, t, lut_dev, r3p, r4p, Mpre, ntab, xx_dev, yy_dev, mt_dev);
-    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr, r3p, xx_dev, yy_dev, mt_dev};
+    FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr, r3p, xx_dev, yy_dev, mt_dev, Esp, ldEsp};
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 7, r4p, Fout, ldout, lt, partial, out, s);
 }
 // the 81-entry table of modes 3 / 4: lut[code][c] = sum_b (t_b - 1) W_b[c], code = sum_b t_b 3^b, W = eq((r1, r2), .)

@@ -217,6 +217,7 @@ struct lf_ctx {
     hipEvent_t ev_aux = nullptr;
     u64 *h_aux = nullptr;   // pinned, 1 KB: the known part of the point
     unsigned sv_round_mask = 0;      // rounds of the last folding sumcheck that ran as int8 GEMMs (bit i-1 = round i)
+    unsigned fold_split_mask = 0;    // table rounds of the last folding sumcheck that ran in the split eq form (bit i-1 = round i)
     unsigned lin_split_rounds = 0;   // rounds of the last linearization sumcheck that ran in the split eq form (run_lin_sumcheck)
 
     int buf(const std::string &name, size_t bytes, void **out) {
@@ -2476,6 +2477,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // runs the same transcript.  Once fewer than 64 pairs per rank remain the f-hat slices are gathered and the tail is replicated.
     u64 *d_lut = nullptr;
     c->sv_round_mask = 0;
+    c->fold_split_mask = 0;
     u32 *sv_bits[2] = {nullptr, nullptr};
     const bool sv_two_streams = t_lane == 0 && !c->tn.prep_one_stream && Gw == 1;
     hipStream_t sv_g_stream = c->stream();
@@ -2610,6 +2612,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                 svE_ensure(round);
                 Er = svE_ptr(round); ldEr = m >> round;
                 split_now = true;
+                c->fold_split_mask |= 1u << (round - 1);
             }
         }
         size_t ev = c->ev_begin(0);
@@ -3506,6 +3509,11 @@ extern "C" int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
     *sv_round_mask = c->bb ? c->bb->fold_paths() : c->sv_round_mask;
+    return LF_OK;
+}
+int lf_last_fold_split_rounds(lf_ctx *c, unsigned *round_mask) {
+    if (!c || !round_mask) return LF_ERR_INVALID;
+    *round_mask = c->bb ? c->bb->fold_split_rounds() : c->fold_split_mask;
     return LF_OK;
 }
 int lf_last_lin_split_rounds(lf_ctx *c, unsigned *rounds) {

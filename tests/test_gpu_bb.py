@@ -287,6 +287,33 @@ def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
     assert ctx.fold_paths() == 0 and (proof == proof_o).all()
 
 
+@pytest.mark.parametrize("name", ["B10", "B8", "BDP"])
+def test_fold_step_split_table_rounds_match_oracle(ctx, name, monkeypatch):
+    """rounds 4 / 5 of the folding sumcheck in the split eq form (lfbb::k_fold_round SPLIT, modes 6 / 7: three lazy products per table, the G part from its own
+    launch, the fourth coefficient from g(0) + g(1) = the previous message at its challenge on the host): the same words as the oracle's messages
+    (nifs/folding/utils.rs:273-325, utils/sumcheck/prover.rs:56-162), after GEMM rounds and after the integer rounds, and identical with the form switched off"""
+    wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, 4)
+    lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
+    m = 1 << wl.s
+    base = {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_SPLIT_MIN": "1"}
+    r5_ok = wl.s >= 5 and wl.N % 4 == 0 and m // 32 >= 1
+    cases = [({}, 0b01000), ({"LF_FOLD_R5_MIN": "1"}, 0b11000 if r5_ok else 0b01000), ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_SV_MIN": "64"}, 0b11000 if r5_ok else 0b01000),
+             ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_NO_SV": "1"}, 0b11000 if r5_ok else 0b01000), ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"}, 0),
+             ({"LF_FOLD_NO_R4TAB": "1"}, 0)]
+    for extra, want in cases:
+        env = dict(base, **extra)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, tr_new())
+        for k in env:
+            monkeypatch.delenv(k)
+        if wl.s < 5 or m // 4 < 4:
+            want = 0
+        assert ctx.fold_split_rounds() == want, (extra, bin(ctx.fold_split_rounds()), bin(want))
+        bad = np.nonzero((proof != proof_o).any(axis=1))[0]
+        assert bad.size == 0 and (lc == lc_o).all() and (w.f == f0_o).all(), (extra, bad[:6])
+
+
 @pytest.mark.parametrize("name", ["B6", "B10", "BDP", "BD768"])
 def test_fold_step_int8_inner_products_match_oracle(ctx, name, monkeypatch):
     """u_s / eta as int8 GEMMs on the matrix cores (bb_dot_i8.hip; the driver uses them from 4096 columns on, LF_DOT_MIN lowers the
