@@ -1293,6 +1293,16 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     size_t ll = bb_lcccs_len(&P);
     const u64 nu = c->ring.T.nu;
     std::vector<H9> alpha(K2), zeta(K2), mu(K2), beta(P.s);
+    // the bit-plane form of the two witnesses (GEMM rounds below) needs no challenge: built while the host squeezes alpha and zeta
+    u32 *svbits[2] = {nullptr, nullptr};
+    {
+        const size_t sv_min0 = c->tn.sv_min >= 65536 ? 16384 : c->tn.sv_min;
+        if (c->sh_world == 1 && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && P.s >= 4 && c->tn.sv_rounds >= 1 && m / 2 >= sv_min0 && bbsv_shape_ok(1, m / 2, K))
+            for (int sd = 0; sd < 2; sd++) {
+                RET(c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", bbsv_bits_words(N, K), &svbits[sd]));
+                launch_bbsv_bits(S[sd].planes, N, N, K, svbits[sd], c->stream());
+            }
+    }
     {
         HostTimer ht(c);
         tr.absorb_label("alpha_s");
@@ -1410,7 +1420,6 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // eq form; the G part from the round kernel run without tables).  Unsharded steps whose witness fills whole super-steps.
     const bool use_sv = Gw == 1 && !c->tn.fold_no_sv && N <= m && (N & 3) == 0 && P.s >= 4;
     const size_t sv_min = c->tn.sv_min >= 65536 ? 16384 : c->tn.sv_min;   // (the default threshold is the Goldilocks driver's; a BabyBear pair carries three times the rows)
-    u32 *svbits[2] = {nullptr, nullptr};
     // E_i = eq((beta_{i+1}..beta_s), .): one value per pair of round i; E_1 built, E_2.. pair sums (GEMM rounds and the split table rounds)
     fe *svE[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     u32 svE_level = 0;
@@ -1539,8 +1548,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                     launch_bbsv_bits(S[sd].planes, N, N, K, svbits[sd], c->stream());
                 }
             RET(svE_ensure(round));
-            i64 *gpartial;      // (the shared round buffer is sized for the m/8 pairs of round 3: this launch has up to m/2)
-            RET(c->tbuf("sv_gpartial", fold_partial_words(4 * m), &gpartial));
+            i64 *gpartial;
+            RET(c->tbuf("sv_gpartial", red_partial_words(5 * RE), &gpartial));
             // the G part (eqL G1 + eqR G2: the round kernel without tables) on the other, idle stream next to the GEMM chain
             hipStream_t sg = (c->lane == 0 && !c->tn.prep_one_stream && c->st_lane[1]) ? c->st_lane[1] : c->stream();
             hipEvent_t g_ready = nullptr;
@@ -1550,7 +1559,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
                 HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));      // the special tables of this round were fixed on this stream
                 HIPCHK(hipStreamWaitEvent(sg, c->ev_prep[0], 0));
             }
-            launch_fold_round(c->dev, a, nullptr, 0, 0, d_mup, gpartial, gtmp, sg);
+            launch_fold_round_g(c->dev, a, gpartial, gtmp, sg);
             if (sg != c->stream()) { HIPCHK(hipEventRecord(c->ev_prep[1], sg)); g_ready = c->ev_prep[1]; }
             if (launch_bbsv_round(c->dev, svV, svbits[0], svbits[1], N, svE[round - 1], atl(m >> round), a.pcnt, K, d_mu, d_coef, w0, w1, sveb, svpart, svtot, svtp, gtmp, od,
                                   c->stream(), g_ready) == 0) {
@@ -1601,8 +1610,8 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         else launch_fold_round(c->dev, a, curF, ldF, K, d_mup, partial, od, c->stream());
         if (split_now) {   // the G part of the message (eqL G1 + eqR G2 at X = 0..4) from the round kernel run without tables, behind the three sums of the table kernel
             i64 *gpartial;
-            RET(c->tbuf("sv_gpartial", fold_partial_words(4 * m), &gpartial));
-            launch_fold_round(c->dev, a, nullptr, 0, 0, d_mup, gpartial, od + 5 * RE, c->stream());
+            RET(c->tbuf("sv_gpartial", red_partial_words(5 * RE), &gpartial));
+            launch_fold_round_g(c->dev, a, gpartial, od + 5 * RE, c->stream());
         }
         c->ev_end(ev);
         u64 *evs = msgs + (size_t)(round - 1) * (deg + 1) * RE;

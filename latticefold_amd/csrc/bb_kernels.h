@@ -114,6 +114,8 @@ struct FoldArgs {
     size_t p0, pcnt;             // pair range handled by this launch (all pairs: 0, n/2; a rank's slice when sharded)
     size_t pF0;                  // first pair held by the materialised f-hat buffer (general rounds)
 };
+// the G part of a round message alone (eqL G1 + eqR G2 at X = 0..4); partial: red_partial_words(5 * RE)
+void launch_fold_round_g(const DevBb &t, const FoldArgs &a, i64 *partial, u64 *out, hipStream_t s);
 // round 1 straight from the coefficient planes (f-hat virtual, b = 2); Mc = mu_k^(d+1), [2K][9] constants
 void launch_fold_round1(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
                         const E9C *Mc_dev, i64 *partial, u64 *out, hipStream_t s);

@@ -988,6 +988,24 @@ __device__ __forceinline__ void fold_store(i64 (&acc)[5 * TAU], u32 slot, i64 *p
         partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
     }
 }
+// the G part of a round message alone (eqL G1 + eqR G2 at X = 0..4): for the rounds whose norm part comes from elsewhere (int8 GEMM rounds, split table rounds).
+// thread = (pair, slot), ten F_{p^9} products; the table kernel run without tables costs five times as much (its accumulators leave it one wave per SIMD)
+__global__ void __launch_bounds__(256) k_fold_round_g(DevBb t, FoldArgs a, i64 *partial) {
+    const u32 slot = blockIdx.y;
+    i64 acc[5 * TAU];
+#pragma unroll
+    for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
+    const size_t pend = a.p0 + a.pcnt;
+    for (size_t j = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x; j < pend; j += (size_t)gridDim.x * 256) fold_linear_part(t, a, slot, j, acc);
+    fold_store(acc, slot, partial);
+}
+void launch_fold_round_g(const DevBb &t, const FoldArgs &a, i64 *partial, u64 *out, hipStream_t s) {
+    u32 gb = (u32)((a.pcnt + 255) / 256);
+    if (gb > RED_BLOCKS) gb = RED_BLOCKS;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(k_fold_round_g, dim3(gb, 8), dim3(256), 0, s, t, a, partial);
+    launch_reduce_rows(partial, gb, 5 * RE, out, s);
+}
 // round 1: f-hat entries are the base-2 digits themselves, so h(f0 + X (f1 - f0)) is a small integer (|.| <= 720) and
 // vanishes at X = 0, 1; S(X) = sum M[k][d] * h is accumulated as exact integer multiples of the (uniform) constants.
 __global__ void __launch_bounds__(256, 2) k_fold_round1(DevBb t, FoldArgs a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, u32 K,
