@@ -915,17 +915,38 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
     const fe *cur = mz, *cure = eqb;
     size_t n = m;
     int flip = 0;
+    // the R1CS shape has its own kernel with fix_variables fused in (bb_kernels.hip: k_lin_r1cs)
+    const bool r1cs = lin_desc_is_r1cs(c->desc) && deg == 3 && !c->tn.lin_no_r1cs;
     for (u32 round = 1; round <= P.s; round++) {
+        bool small = false;
+        if (r1cs && (round == 1 || n >= 4)) {
+            if (round == 1) launch_lin_r1cs(c->dev, cur, m, cure, m, n / 2, nullptr, nullptr, 0, nullptr, 0, partial, od, c->stream(), c->lin_blocks);
+            else {
+                const E9PreC r = e9pre_from_h9(point[round - 2], c->ring.T.nu);
+                const size_t ldp = round == 2 ? m : atl(n);
+                launch_lin_r1cs(c->dev, cur, ldp, cure, ldp, n / 4, &r, fx[flip], atl(n / 2), fq[flip], atl(n / 2), partial, od, c->stream(), c->lin_blocks);
+                cur = fx[flip]; cure = fq[flip];
+                flip ^= 1;
+                n /= 2;
+            }
+            small = true;   // (the message is on its way)
+        } else
         if (round > 1) {
             E9PreC r = e9pre_from_h9(point[round - 2], c->ring.T.nu);
-            launch_fix(c->dev, cur, n, fx[flip], atl(n / 2), n, P.t * 8, r, c->stream());
-            launch_fix(c->dev, cure, n, fq[flip], atl(n / 2), n, 1, r, c->stream());
+            const size_t ldp = round == 2 ? m : atl(n);
+            // small rounds (at most 256 pairs): fix + evaluation + reduction in one launch (they are launch-bound: four launches otherwise)
+            small = n >= 4 && n / 4 <= 256 && !c->tn.lin_no_small;
+            if (small) launch_lin_small(c->dev, c->desc, cur, ldp, cure, ldp, n, r, fx[flip], atl(n / 2), fq[flip], atl(n / 2), deg, od, c->stream());
+            else {
+                launch_fix(c->dev, cur, n, fx[flip], atl(n / 2), n, P.t * 8, r, c->stream());
+                launch_fix(c->dev, cure, n, fq[flip], atl(n / 2), n, 1, r, c->stream());
+            }
             cur = fx[flip]; cure = fq[flip];
             flip ^= 1;
             n /= 2;
         }
         size_t ld = round == 1 ? m : atl(n);
-        launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->stream(), c->lin_blocks);
+        if (!small) launch_lin_round(c->dev, c->desc, cur, ld, cure, ld, n, deg, partial, od, c->stream(), c->lin_blocks);
         u64 *ev = msgs + (size_t)(round - 1) * (deg + 1) * RE;
         HIPCHK(hipStreamSynchronize(c->stream()));            // the reduce kernel wrote the message into mapped host memory
         memcpy(ev, od, (size_t)(deg + 1) * RE * 8);

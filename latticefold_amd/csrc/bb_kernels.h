@@ -106,6 +106,14 @@ struct LinDesc {   // CCS multiset structure (nifs/linearization/utils.rs:90-107
 };
 void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg,
                       i64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
+// the R1CS shape (+ Mz_0 Mz_1 - Mz_2) in its own kernel; r != nullptr: fix_variables of the previous round fused in (mz / eq are then the previous tables, 4 * pairs
+// entries, and the fixed ones go to mz_out / eq_out); at most 256 pairs: the message goes straight to `out`, no reduction launch
+bool lin_desc_is_r1cs(const LinDesc &d);
+void launch_lin_r1cs(const DevBb &t, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t pairs, const E9PreC *r, fe *mz_out, size_t ld_out, fe *eq_out, size_t ldeq_out,
+                     i64 *partial, u64 *out, hipStream_t s, u32 max_blocks = 0);
+// a small round (n_prev / 4 <= 256 pairs) in one launch: fix of the previous tables with r (-> mz_out / eq_out, n_prev / 2 entries), evaluation, reduction; message to `out`
+void launch_lin_small(const DevBb &t, const LinDesc &desc, const fe *mz_prev, size_t ld_prev, const fe *eq_prev, size_t ldeq_prev, size_t n_prev, const E9PreC &r, fe *mz_out, size_t ld_out,
+                      fe *eq_out, size_t ldeq_out, u32 deg, u64 *out, hipStream_t s);
 
 struct FoldArgs {
     const fe *eqL, *eqR, *eqB;   // fq9 tables [9][ld]
@@ -113,6 +121,7 @@ struct FoldArgs {
     size_t ld, n;                // leading dimension / current length
     size_t p0, pcnt;             // pair range handled by this launch (all pairs: 0, n/2; a rank's slice when sharded)
     size_t pF0;                  // first pair held by the materialised f-hat buffer (general rounds)
+    u32 qsplit = 1;              // k_fold_round modes 0 / 1, small rounds: threads per pair (a power of two <= 16): thread q of a pair takes the tables tb0 + q, + qsplit, ..
 };
 // the G part of a round message alone (eqL G1 + eqR G2 at X = 0..4); partial: red_partial_words(5 * RE)
 void launch_fold_round_g(const DevBb &t, const FoldArgs &a, i64 *partial, u64 *out, hipStream_t s);

@@ -879,6 +879,46 @@ __device__ __forceinline__ E9 pick4(const E9 (&v)[4], u32 idx) {
     for (int c = 0; c < TAU; c++) r.c[c] = idx == 0 ? v[0].c[c] : (idx == 1 ? v[1].c[c] : (idx == 2 ? v[2].c[c] : v[3].c[c]));
     return r;
 }
+__device__ __forceinline__ E9 ldq(const fe *eq, size_t ld, size_t i) {
+    E9 r;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) r.c[c] = eq[(size_t)c * ld + i];
+    return r;
+}
+// one pair of one slot: v[q] = Mz_q at the pair's first entry, st[q] = the step to its second, e / es likewise for eq; adds g(X) into acc[X][9]
+__device__ __forceinline__ void lin_pair_eval(const DevBb &t, const LinDesc &desc, E9 (&v)[4], const E9 (&st)[4], E9 e, const E9 &es, u32 slot, u32 deg, i64 (&acc)[5 * TAU]) {
+    for (u32 X = 0; X <= deg; X++) {
+        if (X) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if ((u32)q < desc.t) v[q] = e9_add(v[q], st[q]);
+            e = e9_add(e, es);
+        }
+        E9 sum = e9_zero();
+        for (u32 i = 0; i < desc.q; i++) {
+            E9 term;
+            u32 k0 = desc.S_off[i], k1 = desc.S_off[i + 1];
+            term = pick4(v, desc.S_idx[k0]);
+            for (u32 k = k0 + 1; k < k1; k++) term = e9_mul(term, pick4(v, desc.S_idx[k]), t.nu);
+            if (desc.c_unit[i] == 1) sum = e9_add(sum, term);
+            else if (desc.c_unit[i] == -1) sum = e9_sub(sum, term);
+            else {
+                E9 cc;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) cc.c[c] = desc.c[i][TAU * slot + c];
+                sum = e9_add(sum, e9_mul(term, cc, t.nu));
+            }
+        }
+        E9 g = e9_mul(sum, e, t.nu);
+#pragma unroll
+        for (int c = 0; c < TAU; c++)
+            if (X == 0) acc[c] += g.c[c];
+            else if (X == 1) acc[TAU + c] += g.c[c];
+            else if (X == 2) acc[2 * TAU + c] += g.c[c];
+            else if (X == 3) acc[3 * TAU + c] += g.c[c];
+            else acc[4 * TAU + c] += g.c[c];
+    }
+}
 __global__ void __launch_bounds__(256) k_lin_round(DevBb t, LinDesc desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg,
                                                    i64 *partial) {
     u32 slot = blockIdx.y;
@@ -901,6 +941,7 @@ __global__ void __launch_bounds__(256) k_lin_round(DevBb t, LinDesc desc, const 
             for (int c = 0; c < TAU; c++) { a.c[c] = eq[(size_t)c * ldeq + 2 * j]; b.c[c] = eq[(size_t)c * ldeq + 2 * j + 1]; }
             e = a; es = e9_sub(b, a);
         }
+        // (the loop of lin_pair_eval, in place: as a call it costs this kernel its second wave per SIMD -- 256 instead of 231 registers)
         for (u32 X = 0; X <= deg; X++) {
             if (X) {
 #pragma unroll
@@ -941,6 +982,159 @@ __global__ void __launch_bounds__(256) k_lin_round(DevBb t, LinDesc desc, const 
         partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
     }
 }
+// The R1CS shape (t = 3, q = 2: + Mz_0 Mz_1 - Mz_2 -- every row of the benchmark configurations): g(X) = eq(X) (a b - c)(X) at X = 0..3, eight F_{p^9} products per
+// pair and slot with nothing interpreted -- the generic kernel above carries the multiset descriptor, a 4-way select per factor and 231 registers (415 us for the
+// 226 MB of round 1 at 2^18 rows; this one is bound by that traffic).  FIX: fix_variables of the previous round fused in -- the pair is read as four entries of the
+// previous tables, fixed with r and stored for the next round (mz_out / eq_out; the eq rows by the blocks of slot 0), so the tables make one trip per round.
+// DIRECT (one block per slot, at most 256 pairs): the block's sums are the message -- written canonical to `out` (mapped host memory), no reduction launch.
+template <bool FIX, bool DIRECT>
+__global__ void __launch_bounds__(256) k_lin_r1cs(DevBb t, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t pairs, E9PreC rfix, fe *mz_out, size_t ld_out, fe *eq_out,
+                                                  size_t ldeq_out, i64 *partial, u64 *out) {
+    const u32 slot = blockIdx.y;
+    i64 acc[4 * TAU];
+#pragma unroll
+    for (int i = 0; i < 4 * TAU; i++) acc[i] = 0;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < pairs; j += (size_t)gridDim.x * 256) {
+        E9 v[3], st[3], e, es;
+        if (FIX) {
+            const E9Pre R = e9p(rfix);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const fe *src = mz + ((size_t)q * RE + TAU * slot) * ld + 4 * j;
+                E9 p0, p1, p2, p3;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) {
+                    const int4 w = *reinterpret_cast<const int4 *>(src + (size_t)c * ld);
+                    p0.c[c] = w.x; p1.c[c] = w.y; p2.c[c] = w.z; p3.c[c] = w.w;
+                }
+                const E9 a = e9_add(p0, e9_mul(e9_sub(p1, p0), R)), b = e9_add(p2, e9_mul(e9_sub(p3, p2), R));
+                fe *dst = mz_out + ((size_t)q * RE + TAU * slot) * ld_out + 2 * j;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(dst + (size_t)c * ld_out) = make_int2(a.c[c], b.c[c]);
+                v[q] = a; st[q] = e9_sub(b, a);
+            }
+            E9 p0, p1, p2, p3;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) {
+                const int4 w = *reinterpret_cast<const int4 *>(eq + (size_t)c * ldeq + 4 * j);
+                p0.c[c] = w.x; p1.c[c] = w.y; p2.c[c] = w.z; p3.c[c] = w.w;
+            }
+            const E9 a = e9_add(p0, e9_mul(e9_sub(p1, p0), R)), b = e9_add(p2, e9_mul(e9_sub(p3, p2), R));
+            if (slot == 0) {
+#pragma unroll
+                for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(eq_out + (size_t)c * ldeq_out + 2 * j) = make_int2(a.c[c], b.c[c]);
+            }
+            e = a; es = e9_sub(b, a);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const fe *src = mz + ((size_t)q * RE + TAU * slot) * ld + 2 * j;
+                E9 a, b;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) {
+                    const int2 w = *reinterpret_cast<const int2 *>(src + (size_t)c * ld);
+                    a.c[c] = w.x; b.c[c] = w.y;
+                }
+                v[q] = a; st[q] = e9_sub(b, a);
+            }
+            E9 a, b;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) {
+                const int2 w = *reinterpret_cast<const int2 *>(eq + (size_t)c * ldeq + 2 * j);
+                a.c[c] = w.x; b.c[c] = w.y;
+            }
+            e = a; es = e9_sub(b, a);
+        }
+#pragma unroll
+        for (int X = 0; X < 4; X++) {
+            if (X) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) v[q] = e9_add(v[q], st[q]);
+                e = e9_add(e, es);
+            }
+            const E9 g = e9_mul(e9_sub(e9_mul(v[0], v[1], t.nu), v[2]), e, t.nu);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) acc[X * TAU + c] += g.c[c];
+        }
+    }
+    __shared__ i64 red[4 * TAU];
+    block_sum_store<4 * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < 5 * TAU) {
+        const u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
+        const i64 v = X < 4 ? red[threadIdx.x] : 0;
+        if (DIRECT) out[X * RE + TAU * slot + c] = to_canon(fred(v));
+        else partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + c] = v;
+    }
+}
+bool lin_desc_is_r1cs(const LinDesc &d) {
+    return d.t == 3 && d.q == 2 && d.S_off[0] == 0 && d.S_off[1] == 2 && d.S_off[2] == 3 && d.S_idx[0] == 0 && d.S_idx[1] == 1 && d.S_idx[2] == 2 && d.c_unit[0] == 1 && d.c_unit[1] == -1;
+}
+// one round of the R1CS shape: r == nullptr: the tables as they are (mz / eq hold 2 * pairs entries); else they are the previous round's (4 * pairs entries), fixed on the way
+void launch_lin_r1cs(const DevBb &t, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t pairs, const E9PreC *r, fe *mz_out, size_t ld_out, fe *eq_out, size_t ldeq_out,
+                     i64 *partial, u64 *out, hipStream_t s, u32 max_blocks) {
+    const E9PreC none = {};
+    u32 gb = (u32)((pairs + 255) / 256);
+    const u32 cap = max_blocks && max_blocks < RED_BLOCKS ? max_blocks : RED_BLOCKS;
+    if (gb > cap) gb = cap;
+    if (gb < 1) gb = 1;
+    if (pairs <= 256) {
+        if (r) hipLaunchKernelGGL((k_lin_r1cs<true, true>), dim3(1, 8), dim3(256), 0, s, t, mz, ld, eq, ldeq, pairs, *r, mz_out, ld_out, eq_out, ldeq_out, partial, out);
+        else hipLaunchKernelGGL((k_lin_r1cs<false, true>), dim3(1, 8), dim3(256), 0, s, t, mz, ld, eq, ldeq, pairs, none, mz_out, ld_out, eq_out, ldeq_out, partial, out);
+        return;
+    }
+    if (r) hipLaunchKernelGGL((k_lin_r1cs<true, false>), dim3(gb, 8), dim3(256), 0, s, t, mz, ld, eq, ldeq, pairs, *r, mz_out, ld_out, eq_out, ldeq_out, partial, out);
+    else hipLaunchKernelGGL((k_lin_r1cs<false, false>), dim3(gb, 8), dim3(256), 0, s, t, mz, ld, eq, ldeq, pairs, none, mz_out, ld_out, eq_out, ldeq_out, partial, out);
+    launch_reduce_rows(partial, gb, 5 * RE, out, s);
+}
+// Small rounds (at most 256 pairs): fix_variables of the previous round's tables with its challenge, the round evaluation and the reduction in ONE launch -- block = slot,
+// thread = pair; the fixed tables go to mz_out / eq_out for the next round, the message straight to `out` (mapped host memory, rows X > deg zero).  A round
+// of this size is launch- and latency-bound: four launches (two k_fix, the round, the reduction) become one.
+__global__ void __launch_bounds__(256) k_lin_small(DevBb t, LinDesc desc, const fe *mz_prev, size_t ld_prev, const fe *eq_prev, size_t ldeq_prev, size_t n_prev, E9PreC rfix,
+                                                   fe *mz_out, size_t ld_out, fe *eq_out, size_t ldeq_out, u32 deg, u64 *out) {
+    const u32 slot = blockIdx.x;
+    i64 acc[5 * TAU];
+#pragma unroll
+    for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
+    const size_t pairs = n_prev / 4, j = threadIdx.x;
+    if (j < pairs) {
+        const E9Pre R = e9p(rfix);
+        E9 v[4], st[4], e, es;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if ((u32)q < desc.t) {
+                const fe *src = mz_prev + (size_t)q * RE * ld_prev;
+                const E9 p0 = ld9(src, ld_prev, slot, 4 * j), p1 = ld9(src, ld_prev, slot, 4 * j + 1), p2 = ld9(src, ld_prev, slot, 4 * j + 2), p3 = ld9(src, ld_prev, slot, 4 * j + 3);
+                const E9 a = e9_add(p0, e9_mul(e9_sub(p1, p0), R)), b = e9_add(p2, e9_mul(e9_sub(p3, p2), R));
+                fe *dst = mz_out + ((size_t)q * RE + TAU * slot) * ld_out;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(dst + (size_t)c * ld_out + 2 * j) = make_int2(a.c[c], b.c[c]);
+                v[q] = a; st[q] = e9_sub(b, a);
+            } else { v[q] = e9_zero(); st[q] = e9_zero(); }
+        }
+        {
+            const E9 p0 = ldq(eq_prev, ldeq_prev, 4 * j), p1 = ldq(eq_prev, ldeq_prev, 4 * j + 1), p2 = ldq(eq_prev, ldeq_prev, 4 * j + 2), p3 = ldq(eq_prev, ldeq_prev, 4 * j + 3);
+            const E9 a = e9_add(p0, e9_mul(e9_sub(p1, p0), R)), b = e9_add(p2, e9_mul(e9_sub(p3, p2), R));
+            if (slot == 0) {
+#pragma unroll
+                for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(eq_out + (size_t)c * ldeq_out + 2 * j) = make_int2(a.c[c], b.c[c]);
+            }
+            e = a; es = e9_sub(b, a);
+        }
+        lin_pair_eval(t, desc, v, st, e, es, slot, deg, acc);
+    }
+    __shared__ i64 red[5 * TAU];
+    block_sum_store<5 * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < 5 * TAU) {
+        const u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
+        out[X * RE + TAU * slot + c] = to_canon(fred(red[threadIdx.x]));
+    }
+}
+void launch_lin_small(const DevBb &t, const LinDesc &desc, const fe *mz_prev, size_t ld_prev, const fe *eq_prev, size_t ldeq_prev, size_t n_prev, const E9PreC &r, fe *mz_out, size_t ld_out,
+                      fe *eq_out, size_t ldeq_out, u32 deg, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_lin_small, dim3(8), dim3(256), 0, s, t, desc, mz_prev, ld_prev, eq_prev, ldeq_prev, n_prev, r, mz_out, ld_out, eq_out, ldeq_out, deg, out);
+}
 void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t ld, const fe *eq, size_t ldeq, size_t n, u32 deg, i64 *partial,
                       u64 *out, hipStream_t s, u32 max_blocks) {
     u32 gb = (u32)((n / 2 + 255) / 256);
@@ -954,12 +1148,6 @@ void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t 
 // ---------------------------------------------------------------------------------------------------------
 // folding sumcheck (comb fn nifs/folding/utils.rs:273-325, b = 2):
 //   g(X) = eqL G1 + eqR G2 + eqB * sum_{k<2K} sum_{d<9} mu_k^{d+1} h(f_{k,d}),  h(f) = f (f^2 - 1)
-__device__ __forceinline__ E9 ldq(const fe *eq, size_t ld, size_t i) {
-    E9 r;
-#pragma unroll
-    for (int c = 0; c < TAU; c++) r.c[c] = eq[(size_t)c * ld + i];
-    return r;
-}
 // the eqL*G1 + eqR*G2 part at X = 0..4, added into acc[X][9]
 __device__ __forceinline__ void fold_linear_part(const DevBb &t, const FoldArgs &a, u32 slot, size_t j, i64 (&acc)[5 * TAU]) {
 #pragma unroll 1
@@ -1339,14 +1527,17 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
     u32 slot = blockIdx.y;
     const u32 ntab = 2 * K * TAU, per = (ntab + gridDim.z - 1) / gridDim.z;
     const u32 tb0 = blockIdx.z * per, tb1 = tb0 + per < ntab ? tb0 + per : ntab;
-    const size_t j = a.p0 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    // small rounds (modes 0 / 1): qsplit threads share a pair and split the block's tables between them -- everything after the table loop is linear in the
+    // sums, so the block reduction adds the shares up; a latency-bound thread then walks 1..5 tables instead of 9
+    const u32 Q = (MODE <= 1) ? a.qsplit : 1u, tq = (MODE <= 1) ? threadIdx.x % Q : 0u;
+    const size_t j = a.p0 + ((MODE <= 1) ? (size_t)blockIdx.x * (256 / Q) + threadIdx.x / Q : (size_t)blockIdx.x * 256 + threadIdx.x);
     const bool live = j < a.p0 + a.pcnt;
     const size_t jj = live ? j - a.pF0 : 0;   // index into the f-hat buffer (it starts at pair a.pF0 when sharded)
     HL C[4 * TAU];
 #pragma unroll
     for (int i = 0; i < 4 * TAU; i++) { C[i].hi = 0; C[i].lo = 0; }
 #pragma unroll 1
-    for (u32 tb = tb0; tb < tb1; tb++) {
+    for (u32 tb = tb0 + tq; tb < tb1; tb += Q) {
         const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
         E9 f0, f1;
         if (MODE >= 3) {
@@ -1577,7 +1768,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         for (int c = 0; c < TAU; c++) { acc[c] = a0.c[c]; acc[TAU + c] = a1.c[c]; acc[2 * TAU + c] = a2.c[c]; }
     } else
     if (live) {
-        if (blockIdx.z == 0) fold_linear_part(t, a, slot, j, acc);
+        if (blockIdx.z == 0 && tq == 0) fold_linear_part(t, a, slot, j, acc);
         // S(X) = C0 + C1 X + 3 C2 X^2 + C3 X^3
         E9 c0, c1, c2, c3;
 #pragma unroll
@@ -1627,6 +1818,11 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
     size_t pairs = a.pcnt;
     u32 gb = (u32)((pairs + 255) / 256);
     if (gb < 1) gb = 1;
+    FoldArgs a2 = a;
+    a2.qsplit = 1;
+    static const bool no_small = getenv("LF_FOLD_NO_SMALL") != nullptr;
+    if (mode <= 1 && pairs <= 128 && !no_small)
+        while (a2.qsplit < 16 && pairs * a2.qsplit * 2 <= 256) a2.qsplit *= 2;
     // enough threads to fill the chip (~128k): split the 2K*9 tables when there are few pairs
     u32 tch = 1;
     static const size_t chunk_threads = [] { const char *e = getenv("LF_FOLD_CHUNK_THREADS"); return e ? (size_t)atoll(e) : ((size_t)1 << 17); }();
@@ -1635,8 +1831,8 @@ static void launch_fold_round_impl(const DevBb &t, const FoldArgs &a, const fe *
     const bool nu2 = t.nu == BB_TWO;
     if (mode >= 3) tch = 1;   // the planes of one (side, d) serve all K tables: no table split (large rounds only)
     const bool split = lt.Esp != nullptr && (mode == 6 || mode == 7);
-#define BB_FR(N2, MD) hipLaunchKernelGGL((k_fold_round<N2, MD>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, rfix, Fout, ldo, lt, partial)
-#define BB_FRS(N2, MD) hipLaunchKernelGGL((k_fold_round<N2, MD, true>), dim3(gb, 8, tch), dim3(256), 0, s, t, a, F, ldF, K, Mpre, rfix, Fout, ldo, lt, partial)
+#define BB_FR(N2, MD) hipLaunchKernelGGL((k_fold_round<N2, MD>), dim3(gb, 8, tch), dim3(256), 0, s, t, a2, F, ldF, K, Mpre, rfix, Fout, ldo, lt, partial)
+#define BB_FRS(N2, MD) hipLaunchKernelGGL((k_fold_round<N2, MD, true>), dim3(gb, 8, tch), dim3(256), 0, s, t, a2, F, ldF, K, Mpre, rfix, Fout, ldo, lt, partial)
 #define BB_FRM(N2)                                                              \
     do {                                                                        \
         if (split && mode == 6) BB_FRS(N2, 6); else if (split) BB_FRS(N2, 7);   \

@@ -81,6 +81,9 @@ struct Tunables {
     bool i8_pair = false;            // LF_I8_PAIR: both decompositions' digit-plane commits in ONE launch (paired workgroups share the tiles of A in L2: A leaves
                                      // HBM once per step) instead of one launch per decomposition.  Opt-in: the same kernel time per step (4.2 vs 2 x 2.13 ms at C4), but
                                      // one 4 ms launch on 7/8 of the CUs slows the latency-bound linearization lane next to it (step 22.4 vs 21.8 ms)
+    bool lin_no_r1cs = false;        // LF_LIN_NO_R1CS: (BabyBear) the R1CS shape through the generic linearization round kernel
+    bool lin_no_small = false;       // LF_LIN_NO_SMALL: (BabyBear) small linearization rounds as separate fix / round / reduce launches
+    bool fold_no_small = false;      // LF_FOLD_NO_SMALL: (BabyBear) small folding rounds without the fused fix / in-block table split
     bool prep_one_stream = false;    // LF_PREP_ONE_STREAM: both sides of fold prepare on one stream
     size_t dot_min = 4096;           // LF_DOT_MIN: columns from which the int8 form of the inner products is used
     bool coef_planes = false;        // LF_COEF_PLANES: v_s of a fold step from the int32 planes (k_coef_eval_i8) instead of the bit planes (launch_sv_vs)
@@ -123,6 +126,9 @@ struct Tunables {
         t.coef_planes = getenv("LF_COEF_PLANES") != nullptr;
         if ((e = getenv("LF_DOT_MIN"))) t.dot_min = (size_t)atoll(e);
         t.prep_one_stream = getenv("LF_PREP_ONE_STREAM") != nullptr;
+        t.lin_no_small = getenv("LF_LIN_NO_SMALL") != nullptr;
+        t.lin_no_r1cs = getenv("LF_LIN_NO_R1CS") != nullptr;
+        t.fold_no_small = getenv("LF_FOLD_NO_SMALL") != nullptr;
         if ((e = getenv("LF_FOLD_SV_MIN"))) t.sv_min = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_SV_ROUNDS"))) t.sv_rounds = atoi(e);
         t.ajtai_valu = getenv("LF_AJTAI_VALU") != nullptr;

@@ -207,6 +207,28 @@ def test_linearization_parity(ctx, name):
     assert (acc_g == acc_o).all()
 
 
+@pytest.mark.parametrize("name", ["B6", "B10", "B14"])
+def test_linearization_kernel_forms_agree(ctx, name, monkeypatch):
+    """the linearization sumcheck through the R1CS kernel with fix_variables fused in (k_lin_r1cs; at most 256 pairs: message written by the round kernel itself),
+    through the generic multiset kernel with the small rounds in one launch (k_lin_small) and through the generic kernel with separate fix / round / reduce
+    launches: the same proof, the oracle's (nifs/linearization.rs:137-196, utils/sumcheck/prover.rs:56-162)"""
+    if name == "B14":   # (the oracle is slow at this size: the three forms against each other; the default form is pinned by the scale digests)
+        wl, inst, A, scheme = setup_case(ctx, name, 5)
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        acc_o, linpr_o = acc_g, linpr_g = api.LFLinearizationProver.prove(ctx, cccs, wit, tr_new())
+    else:
+        wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o = run_both(ctx, name, 5)
+    assert (linpr_g == linpr_o).all() and (acc_g == acc_o).all()
+    for env in ({"LF_LIN_NO_R1CS": "1"}, {"LF_LIN_NO_R1CS": "1", "LF_LIN_NO_SMALL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        acc_e, linpr_e = api.LFLinearizationProver.prove(ctx, cccs, wit, tr_new())
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (linpr_e == linpr_o).all() and (acc_e == acc_o).all(), env
+
+
 @pytest.mark.parametrize("name,seed", [("B6", 0), ("B6", 3), ("BDP", 0), ("B8", 1)])
 def test_fold_step_parity(ctx, name, seed):
     wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name, seed)
