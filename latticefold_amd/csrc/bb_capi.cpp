@@ -68,6 +68,15 @@ struct BbCtxImpl {
     u64 *vs_dev = nullptr;
     bool vs_keep = false;
     u32 lin_blocks = 0;   // grid bound of the linearization rounds while the commit chain runs on the other lane (0 = none)
+    // persistent sumcheck tails (k_lin_tail / k_fold_tail): host-mapped mailbox, created on first use
+    BbTailMail *tail_mail = nullptr;
+    u32 tail_epoch = 0;
+    int tail_init() {
+        if (tail_mail) return LF_OK;
+        HIPCHK(hipHostMalloc((void **)&tail_mail, sizeof(BbTailMail), hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: kernel and host talk through it while the kernel runs
+        memset(tail_mail, 0, sizeof(BbTailMail));
+        return LF_OK;
+    }
     u64 *h_round = nullptr;   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
     u64 *round_out() {
         if (!h_round && hipHostMalloc((void **)&h_round, 5 * RE * 8 * 2, hipHostMallocMapped) != hipSuccess) h_round = nullptr;
@@ -230,6 +239,7 @@ void BbCtx::destroy() {
     if (c->d_icrt) (void)hipFree(c->d_icrt);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_round) (void)hipHostFree(c->h_round);
+    if (c->tail_mail) (void)hipHostFree(c->tail_mail);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int l = 0; l < 2; l++) {
         if (c->arena[l]) (void)hipHostFree(c->arena[l]);
@@ -339,6 +349,21 @@ static int shard_columns(C *c, size_t n, size_t *col0, size_t *cnt) {
     *col0 = *cnt * c->sh_rank;
     return LF_OK;
 }
+// wall-clock marks of a fold step on stderr (LF_TIMELINE=1; measurement only)
+struct BbMarks {
+    bool on = false;
+    std::chrono::steady_clock::time_point t0;
+    double last = 0;
+    void start() { on = getenv("LF_TIMELINE") != nullptr; t0 = std::chrono::steady_clock::now(); last = 0; }
+    void mark(const char *what) {
+        if (!on) return;
+        const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[bb timeline] %-44s at %8.3f ms  (+%7.3f)\n", what, t, t - last);
+        last = t;
+    }
+};
+static BbMarks g_marks;
+#define BB_MARK(x) g_marks.mark(x)
 static H9 h9_load(const u64 *w) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = w[i] % BB_P; return r; }
 static H9 h9_one() { H9 r; memset(&r, 0, sizeof(r)); r.c[0] = 1; return r; }
 static H9 h9_sub(const H9 &a, const H9 &b) { H9 r; for (int i = 0; i < TAU; i++) r.c[i] = hsub(a.c[i], b.c[i]); return r; }
@@ -895,6 +920,42 @@ static H9 sc_round_transcript(BbTranscript &tr, const u64 *evals, u32 npts) {
 }
 static size_t atl(size_t x) { return x < 2 ? 2 : x; }   // leading dimensions stay even (8-byte pair loads)
 
+// Host side of a persistent tail (k_lin_tail / k_fold_tail): per round wait for the flags of all `groups` workgroups, hand the mailbox to `take` (which assembles the
+// message at msgs + i * msg_words), run the transcript, write the challenge back (not after the last round: nothing waits for it).  pt[i] = challenge of tail round i.
+template <class Take>
+static int bb_tail_host_rounds(C *c, BbTranscript &tr, u32 epoch, u32 nr, u32 groups, u32 npts, u64 *msgs, H9 *pt, Take take) {
+    BbTailMail *mail = c->tail_mail;
+    const auto t_start = std::chrono::steady_clock::now();
+    double wait_us = 0, host_us = 0;
+    auto t_mark = t_start;
+    for (u32 i = 0; i < nr; i++) {
+        u32 spins = 0;
+        for (u32 g = 0; g < groups; g++)
+            while (__atomic_load_n(&mail->msg_seq[i][g], __ATOMIC_ACQUIRE) != epoch) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xfff) == 0 && (__atomic_load_n(&mail->err, __ATOMIC_RELAXED) == epoch ||
+                                               std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 10.0)) {
+                    __atomic_store_n(&mail->abort_seq, epoch, __ATOMIC_RELEASE);   // the kernel gives up at its next wait
+                    (void)hipStreamSynchronize(c->stream());
+                    return LF_ERR_HIP;
+                }
+            }
+        if (g_marks.on) { const auto now = std::chrono::steady_clock::now(); wait_us += std::chrono::duration<double, std::micro>(now - t_mark).count(); t_mark = now; }
+        u64 *ev = msgs + (size_t)i * npts * RE;
+        take(mail, i, ev);
+        HostTimer ht(c);
+        pt[i] = sc_round_transcript(tr, ev, npts);
+        if (i + 1 < nr) {
+            const E9PreC r = e9pre_from_h9(pt[i], c->ring.T.nu);
+            for (int q = 0; q < TAU; q++) { mail->chal[i][q] = r.v[q]; mail->chal[i][TAU + q] = r.vn[q]; }
+            __atomic_store_n(&mail->chal_seq[i], epoch, __ATOMIC_RELEASE);
+        }
+        if (g_marks.on) { const auto now = std::chrono::steady_clock::now(); host_us += std::chrono::duration<double, std::micro>(now - t_mark).count(); t_mark = now; }
+    }
+    if (g_marks.on) fprintf(stderr, "[bb timeline]    tail: %u rounds, host transcript %.1f us, waiting for the GPU %.1f us\n", nr, host_us, wait_us);
+    return LF_OK;
+}
+
 // linearization sumcheck on device tables mz [t][72][m] (left intact) and eq_beta [9][m]
 // `u_dev` (optional): u_j = Mz_j(r), t ring elements (canonical), from the last fix of the tables the rounds work on
 static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb, u64 *msgs, H9 *point, u64 *u_dev = nullptr) {
@@ -919,6 +980,32 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
     const bool r1cs = lin_desc_is_r1cs(c->desc) && deg == 3 && !c->tn.lin_no_r1cs;
     for (u32 round = 1; round <= P.s; round++) {
         bool small = false;
+        // persistent tail: from the first round with at most 256 pairs on, ONE kernel runs all remaining rounds and talks to this thread through the mailbox
+        // (opt-in, LF_BB_LIN_TAIL=1: with the small rounds already one launch each -- k_lin_r1cs DIRECT -- the mailbox round trip over PCIe costs what the launch and
+        // the stream synchronisation did: 57 against 68 us per round in the timeline, no gain in the step time at C3)
+        if (r1cs && c->tn.bb_lin_tail && round >= 2 && n >= 4 && n / 4 <= 256 && !c->tn.no_tail && P.s - round + 1 <= BB_TAIL_MAX_ROUNDS) {
+            const u32 nr = P.s - round + 1;
+            RET(c->tail_init());
+            BbLinTailArgs A;
+            A.mz = cur; A.eq = cure; A.ld = A.ldeq = round == 2 ? m : atl(n); A.n0 = n; A.rounds = nr;
+            A.r_first = e9pre_from_h9(point[round - 2], c->ring.T.nu);
+            const size_t ldw = atl(n / 2);
+            RET(c->tbuf("lin_tail_w0", (size_t)3 * RE * ldw, &A.work[0]));
+            RET(c->tbuf("lin_tail_w1", (size_t)3 * RE * ldw, &A.work[1]));
+            RET(c->tbuf("lin_tail_e0", (size_t)8 * TAU * ldw, &A.eqw[0]));
+            RET(c->tbuf("lin_tail_e1", (size_t)8 * TAU * ldw, &A.eqw[1]));
+            HIPCHK(hipHostGetDevicePointer((void **)&A.mail, c->tail_mail, 0));
+            A.epoch = ++c->tail_epoch;
+            if (!A.epoch) A.epoch = ++c->tail_epoch;
+            launch_lin_tail(c->dev, A, c->stream());
+            RET(bb_tail_host_rounds(c, tr, A.epoch, nr, 8, deg + 1, msgs + (size_t)(round - 1) * (deg + 1) * RE, point + (round - 1),
+                                    [&](BbTailMail *mail, u32 i, u64 *ev) { memcpy(ev, (const void *)mail->msg[i], (size_t)(deg + 1) * RE * 8); }));
+            HIPCHK(hipStreamSynchronize(c->stream()));   // the kernel has written its last tables
+            if (__atomic_load_n(&c->tail_mail->err, __ATOMIC_RELAXED) == A.epoch) return LF_ERR_HIP;
+            cur = A.work[(nr - 1) & 1];
+            if (u_dev) launch_fix_final(c->dev, cur, ldw, P.t * 8, e9pre_from_h9(point[P.s - 1], c->ring.T.nu), u_dev, c->stream());   // two entries per row left
+            return LF_OK;
+        }
         if (r1cs && (round == 1 || n >= 4)) {
             if (round == 1) launch_lin_r1cs(c->dev, cur, m, cure, m, n / 2, nullptr, nullptr, 0, nullptr, 0, partial, od, c->stream(), c->lin_blocks);
             else {
@@ -952,6 +1039,7 @@ static int run_lin_sumcheck(C *c, BbTranscript &tr, const fe *mz, const fe *eqb,
         memcpy(ev, od, (size_t)(deg + 1) * RE * 8);
         HostTimer ht(c);
         point[round - 1] = sc_round_transcript(tr, ev, deg + 1);
+        if (round <= 4 || round == 8) { char nm[32]; snprintf(nm, sizeof nm, "  lin round %u", round); BB_MARK(nm); }
     }
     if (u_dev) launch_fix_final(c->dev, cur, 2, P.t * 8, e9pre_from_h9(point[P.s - 1], c->ring.T.nu), u_dev, c->stream());   // two entries per row left
     return LF_OK;
@@ -1030,7 +1118,9 @@ static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witn
     RET(c->tbuf("eq_r_R", TAU * m, &eqr));
     RET(c->tbuf("red_partial", red_partial_words(16 * RE * TAU), &partial));
     RET(c->tbuf("lin_small", 16 * RE * TAU, &od));
+    BB_MARK(" lin: buffers");
     RET(build_z(c, wit->planes, 1, 0, head.data(), z));
+    BB_MARK(" lin: z built (synced)");
     std::vector<H9> beta(P.s);
     {
         HostTimer ht(c);
@@ -1043,7 +1133,9 @@ static int linearize_impl(C *c, BbTranscript &tr, const u64 *cccs, const lf_witn
     // v, u at the sumcheck point (linearization.rs:126-139): u from the fully fixed Mz tables of the sumcheck (LF_LIN_U_EVAL=1: dot
     // products with eq(r) over the full tables), v from the witness planes
     const bool u_eval = c->tn.lin_u_eval;
+    BB_MARK(" lin: Mz enqueued");
     RET(run_lin_sumcheck(c, tr, mz, eqb, proof, pt.data(), u_eval ? nullptr : od + (size_t)TAU * RE));
+    BB_MARK(" lin: rounds done");
     RET(build_eq_dev(c, pt.data(), P.s, eqr));
     u64 *v = proof + (size_t)P.s * (P.d + 2) * RE, *u = v + (size_t)TAU * RE;   // contiguous
     c->vs_wit = nullptr;
@@ -1396,10 +1488,12 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
             pm = c->ring.mul9(pm, mu[i]);
         }
     }
+    BB_MARK(" fold challenges");
     RET(upload_consts(c, "c_mu", mu_c, &d_mu));
     RET(upload_consts(c, "c_mup", mu_pre, &d_mup));
     RET(build_eq_dev(c, beta.data(), P.s, eqb));
     c->ev_end(ph);
+    if (g_marks.on) { (void)hipStreamSynchronize(c->stream()); BB_MARK(" fold prepare (synced)"); }
 
     ph = c->ev_begin(14);
     u64 *msgs = proof;
@@ -1681,8 +1775,10 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         if (sharded) RET(exchange_modsum(c, evs, (size_t)(deg + 1) * RE));
         HostTimer ht(c);
         pt[round - 1] = sc_round_transcript(tr, evs, deg + 1);
+        if (round <= 6 || round == 10) { char nm[32]; snprintf(nm, sizeof nm, "  round %u", round); BB_MARK(nm); }
     }
     c->ev_end(ph);
+    BB_MARK(" fold sumcheck");
 
     ph = c->ev_begin(15);
     // theta, eta at r_0 (folding.rs:236-256)
@@ -1840,9 +1936,16 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     DecPending pdL, pdR;
     pdL.side = 0; pdR.side = 1;
     c->lane = 1;
-    int rc = dec_enqueue_commit(c, w_acc, pdL);
-    if (rc == LF_OK) rc = dec_enqueue_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
+    g_marks.start();
+    // (LF_BB_EVALS_FIRST=1: the left evaluations before the left commit -- the two large linearization rounds then run next to them instead of next to a commit)
+    int rc = LF_OK;
+    if (c->tn.bb_evals_first) rc = dec_enqueue_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
+    if (rc == LF_OK) rc = dec_enqueue_commit(c, w_acc, pdL);
+    BB_MARK("L1: left commit enqueued");
+    if (rc == LF_OK && !c->tn.bb_evals_first) rc = dec_enqueue_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl, pdL);
+    BB_MARK("L1: left evals enqueued");
     if (rc == LF_OK) rc = dec_enqueue_commit(c, w_i, pdR);
+    BB_MARK("L1: right commit enqueued");
     c->lane = 0;
     c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : 0u;
     {   // absorb_public_input (nifs.rs:175-197) -- while the GPU already works on the left decomposition
@@ -1853,7 +1956,9 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
         tr.absorb_ring(cm_i, bb_cccs_len(&P));
     }
     c->vs_keep = true;
+    BB_MARK("public input absorbed");
     if (rc == LF_OK) rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
+    BB_MARK("linearization done");
     c->vs_keep = false;
     std::vector<H9> rR;
     if (rc == LF_OK) {
@@ -1862,10 +1967,14 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
     }
     c->vs_wit = nullptr;
     c->lin_blocks = 0;
+    BB_MARK("right evals enqueued");
     if (rc == LF_OK) rc = dec_finish(c, tr, acc, S[0], decl, pdL);
+    BB_MARK("left absorb done");
     if (rc == LF_OK) rc = dec_finish(c, tr, lin.data(), S[1], decr, pdR);
+    BB_MARK("right absorb done");
     (void)hipStreamSynchronize(c->st_lane[1]);
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
+    BB_MARK("fold done");
     c->ev_end(tot);
     c->ev_collect();
     return rc;

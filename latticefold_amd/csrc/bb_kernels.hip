@@ -1067,6 +1067,112 @@ __global__ void __launch_bounds__(256) k_lin_r1cs(DevBb t, const fe *mz, size_t 
         else partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + c] = v;
     }
 }
+// ---- persistent tail of the linearization sumcheck ----------------------------------------------------------------------------------------------------------
+// Once a round has at most 256 pairs its cost is the launch, the stream synchronisation and the wake-up of the host thread (~85 us of wall clock for ~25 us of
+// kernel), not arithmetic.  k_lin_tail runs ALL remaining rounds in one launch: workgroup = slot; per round it waits for the previous challenge in the host-mapped
+// mailbox, fixes its slot's rows of the three tables and its private copy of the (slot-independent) eq table, evaluates the round polynomial and writes its rows
+// of the message straight into the mailbox; the host -- which keeps the Poseidon transcript -- polls the eight flags, absorbs, squeezes and writes the challenge
+// back.  The eight workgroups never exchange data (tables are slot-local, eq is recomputed privately), so no device-wide synchronisation exists at all.
+constexpr u64 BB_TAIL_TIMEOUT_TICKS = 300000000ull;   // wall_clock64 runs at 100 MHz: 3 s
+__device__ __forceinline__ void bb_wait_mem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ u32 bb_ld_sys_u32(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// thread 0 of a workgroup: wait for challenge idx of this launch.  false on abort / timeout
+__device__ bool bb_tail_wait_challenge(BbTailMail *mail, u32 idx, u32 epoch) {
+    const u64 t0 = wall_clock64();
+    for (u32 it = 0;; it++) {
+        if (bb_ld_sys_u32(&mail->chal_seq[idx]) == epoch) break;
+        if ((it & 63) == 63) {
+            if (bb_ld_sys_u32(&mail->abort_seq) == epoch) return false;
+            if (wall_clock64() - t0 > BB_TAIL_TIMEOUT_TICKS) {
+                __hip_atomic_store(&mail->err, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return true;   // (the challenge words -- written by the host before the flag -- are then read by 18 lanes at once: one PCIe read instead of 18 in a row)
+}
+__global__ void __launch_bounds__(256) k_lin_tail(DevBb t, BbLinTailArgs A) {
+    const u32 slot = blockIdx.x;
+    __shared__ int32_t s_r[2 * TAU + 2];
+    __shared__ u32 s_ok;
+    __shared__ i64 red[4 * TAU];
+    const fe *src = A.mz, *esrc = A.eq;
+    size_t lds = A.ld, ldes = A.ldeq, n = A.n0;
+    const size_t ldw = A.n0 / 2 < 2 ? 2 : A.n0 / 2;
+    E9PreC rc = A.r_first;
+    for (u32 rd = 0; rd < A.rounds; rd++) {
+        if (rd > 0) {
+            if (threadIdx.x == 0) s_ok = bb_tail_wait_challenge(A.mail, rd - 1, A.epoch) ? 1u : 0u;
+            __syncthreads();
+            if (!s_ok) return;
+            if (threadIdx.x < 2 * TAU) s_r[threadIdx.x] = __hip_atomic_load(&A.mail->chal[rd - 1][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < TAU; q++) { rc.v[q] = s_r[q]; rc.vn[q] = s_r[TAU + q]; }
+        }
+        const E9Pre R = e9p(rc);
+        fe *dst = A.work[rd & 1], *edst = A.eqw[rd & 1] + (size_t)slot * TAU * ldw;
+        i64 acc[4 * TAU];
+#pragma unroll
+        for (int i = 0; i < 4 * TAU; i++) acc[i] = 0;
+        const size_t pairs = n / 4;
+        for (size_t j = threadIdx.x; j < pairs; j += 256) {
+            E9 v[3], st[3], e, es;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const fe *sp = src + ((size_t)q * RE + TAU * slot) * lds + 4 * j;
+                E9 p0, p1, p2, p3;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) {
+                    const int4 w = *reinterpret_cast<const int4 *>(sp + (size_t)c * lds);
+                    p0.c[c] = w.x; p1.c[c] = w.y; p2.c[c] = w.z; p3.c[c] = w.w;
+                }
+                const E9 a = e9_add(p0, e9_mul(e9_sub(p1, p0), R)), b = e9_add(p2, e9_mul(e9_sub(p3, p2), R));
+                fe *dp = dst + ((size_t)q * RE + TAU * slot) * ldw + 2 * j;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(dp + (size_t)c * ldw) = make_int2(a.c[c], b.c[c]);
+                v[q] = a; st[q] = e9_sub(b, a);
+            }
+            {
+                E9 p0, p1, p2, p3;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) {
+                    const int4 w = *reinterpret_cast<const int4 *>(esrc + (size_t)c * ldes + 4 * j);
+                    p0.c[c] = w.x; p1.c[c] = w.y; p2.c[c] = w.z; p3.c[c] = w.w;
+                }
+                const E9 a = e9_add(p0, e9_mul(e9_sub(p1, p0), R)), b = e9_add(p2, e9_mul(e9_sub(p3, p2), R));
+#pragma unroll
+                for (int c = 0; c < TAU; c++) *reinterpret_cast<int2 *>(edst + (size_t)c * ldw + 2 * j) = make_int2(a.c[c], b.c[c]);
+                e = a; es = e9_sub(b, a);
+            }
+#pragma unroll
+            for (int X = 0; X < 4; X++) {
+                if (X) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) v[q] = e9_add(v[q], st[q]);
+                    e = e9_add(e, es);
+                }
+                const E9 g = e9_mul(e9_sub(e9_mul(v[0], v[1], t.nu), v[2]), e, t.nu);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) acc[X * TAU + c] += g.c[c];
+            }
+        }
+        block_sum_store<4 * TAU>(acc, red);
+        __syncthreads();
+        if (threadIdx.x < 5 * TAU) {
+            const u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
+            const u64 w = X < 4 ? (u64)to_canon(fred(red[threadIdx.x])) : 0ull;
+            __hip_atomic_store(&A.mail->msg[rd][X * RE + TAU * slot + c], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        bb_wait_mem();            // this wave's stores have completed: the message rows (write-through to host memory) before the flag, this round's table rows
+        __syncthreads();          // before the next round's loads by the other waves of the workgroup (same CU: no fence, as in the Goldilocks tail)
+        if (threadIdx.x == 0) __hip_atomic_store(&A.mail->msg_seq[rd][slot], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        src = dst; lds = ldw; esrc = edst; ldes = ldw; n /= 2;
+    }
+}
+void launch_lin_tail(const DevBb &t, const BbLinTailArgs &A, hipStream_t s) { hipLaunchKernelGGL(k_lin_tail, dim3(8), dim3(256), 0, s, t, A); }
+
 bool lin_desc_is_r1cs(const LinDesc &d) {
     return d.t == 3 && d.q == 2 && d.S_off[0] == 0 && d.S_off[1] == 2 && d.S_off[2] == 3 && d.S_idx[0] == 0 && d.S_idx[1] == 1 && d.S_idx[2] == 2 && d.c_unit[0] == 1 && d.c_unit[1] == -1;
 }

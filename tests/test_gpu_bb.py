@@ -220,7 +220,7 @@ def test_linearization_kernel_forms_agree(ctx, name, monkeypatch):
     else:
         wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o = run_both(ctx, name, 5)
     assert (linpr_g == linpr_o).all() and (acc_g == acc_o).all()
-    for env in ({"LF_LIN_NO_R1CS": "1"}, {"LF_LIN_NO_R1CS": "1", "LF_LIN_NO_SMALL": "1"}):
+    for env in ({"LF_LIN_NO_R1CS": "1"}, {"LF_LIN_NO_R1CS": "1", "LF_LIN_NO_SMALL": "1"}, {"LF_BB_LIN_TAIL": "1"}):   # (the last: persistent kernel + host mailbox, k_lin_tail)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         acc_e, linpr_e = api.LFLinearizationProver.prove(ctx, cccs, wit, tr_new())
