@@ -34,14 +34,25 @@ u64 hpow(u64 a, u64 e) {
 
 static H9 h9_zero() { H9 r; memset(&r, 0, sizeof(r)); return r; }
 static H9 h9_one() { H9 r = h9_zero(); r.c[0] = 1; return r; }
+// (inputs canonical: a product is < p^2 < 2^62, so four of them fit a 64-bit word -- the 81 products of an F_{p^9} product take 27 reductions instead of 81;
+// this is the host's ring arithmetic on proof-sized data: the folded instance, the challenge powers, the message completion of the split rounds)
 static H9 h9_mul_nu(const H9 &a, const H9 &b, u64 nu) {
-    u64 lo[TAU] = {0}, hi[TAU] = {0};
-    for (int i = 0; i < TAU; i++)
-        for (int j = 0; j < TAU; j++) {
-            u64 pr = hmul(a.c[i], b.c[j]);
-            if (i + j < TAU) lo[i + j] = hadd(lo[i + j], pr);
-            else hi[i + j - TAU] = hadd(hi[i + j - TAU], pr);
+    u64 lo[TAU], hi[TAU];
+    for (int k = 0; k < TAU; k++) {
+        u64 acc = 0, tot = 0;
+        int cnt = 0;
+        for (int i = 0; i <= k; i++) {
+            acc += a.c[i] * b.c[k - i];
+            if (++cnt == 4) { tot += acc % BB_P; acc = 0; cnt = 0; }
         }
+        lo[k] = (tot + acc % BB_P) % BB_P;
+        acc = 0; tot = 0; cnt = 0;
+        for (int i = k + 1; i < TAU; i++) {
+            acc += a.c[i] * b.c[k + TAU - i];
+            if (++cnt == 4) { tot += acc % BB_P; acc = 0; cnt = 0; }
+        }
+        hi[k] = (tot + acc % BB_P) % BB_P;
+    }
     H9 r;
     for (int k = 0; k < TAU; k++) r.c[k] = hadd(lo[k], hmul(nu, hi[k]));
     return r;
