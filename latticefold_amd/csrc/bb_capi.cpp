@@ -1813,12 +1813,15 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE));
     HIPCHK(hipMemcpyAsync(hp + nth, d_eta, net * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventSynchronize(c->ev_side[0]));
+    BB_MARK("  theta down");
     memcpy(theta, hp, nth * 8);
     {
         HostTimer ht(c);
         tr.absorb_ring(theta, (size_t)K2 * TAU);
     }
+    BB_MARK("  theta absorbed");
     HIPCHK(hipStreamSynchronize(c->stream()));
+    BB_MARK("  eta down");
     memcpy(eta, hp + nth, net * 8);
     std::vector<u64> rho_c((size_t)K2 * RE, 0), rho((size_t)K2 * RE);
     std::vector<int8_t> rho8((size_t)K2 * 24, 0);
@@ -1843,6 +1846,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     int32_t *npl;
     RET(lf_planes_alloc(c->owner, N * RE * 4, &npl));
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
+    BB_MARK("  eta absorbed, rho drawn, fold_witness enqueued");
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
     {
@@ -1890,6 +1894,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * RE], part(i) + ((size_t)P.s + TAU + P.kappa + P.t + q2) * RE, tmp); BbHostRing::add(o, tmp, o); }
     }
     }
+    BB_MARK("  folded instance on the host");
     HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c->owner, npl, N, lf_ctx_device(c->owner), N * RE * 4};
     c->ev_end(ph);

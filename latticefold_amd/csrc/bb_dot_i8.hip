@@ -300,12 +300,17 @@ __global__ void __launch_bounds__(256) k_bbce_i8(BbCeArgs a) {
         for (int nt = 0; nt < 3; nt++) *(v4i *)(a.part + ((((size_t)blockIdx.x * 72 + c) * 3 + nt) * 64 + lane) * 4) = acc[mi][nt];
     }
 }
+// block = 64 outputs x 4 groups of workgroups (a thread walks a quarter of the partial buffers; one thread per output: 61 us of serial adds at 256 workgroups)
 __global__ void __launch_bounds__(256) k_bbce_sum(const int32_t *part, u32 nwg, long long *tot) {
-    const size_t per = (size_t)72 * 3 * 256, i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per) return;
+    const size_t per = (size_t)72 * 3 * 256, i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const u32 g = threadIdx.x >> 6;
+    __shared__ long long sm[4][64];
     long long s = 0;
-    for (u32 w = 0; w < nwg; w++) s += part[(size_t)w * per + i];
-    tot[i] = s;
+    if (i < per)
+        for (u32 w = g; w < nwg; w += 4) s += part[(size_t)w * per + i];
+    sm[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && i < per) tot[i] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 // out[(k*72 + c)*9 + q] canonical: sum_u 256^u C[k][4q + u] is the Montgomery word of the evaluation (integer scaling keeps the Montgomery form)
 __global__ void __launch_bounds__(256) k_bbce_finish(const long long *tot, u32 K, u32 rinv, u64 *out) {
@@ -337,7 +342,7 @@ int launch_coef_eval_i8(const int32_t *planes, size_t ldp, size_t n, const fe *e
     a.steps_per_wg = (u32)bdiv(nsteps, nwg);
     const u32 grid = (u32)bdiv(nsteps, a.steps_per_wg);
     hipLaunchKernelGGL(k_bbce_i8, dim3(grid, 3), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_bbce_sum, dim3((unsigned)bdiv((size_t)72 * 3 * 256, 256)), dim3(256), 0, s, part, grid, tot);
+    hipLaunchKernelGGL(k_bbce_sum, dim3((unsigned)bdiv((size_t)72 * 3 * 256, 64)), dim3(256), 0, s, part, grid, tot);
     hipLaunchKernelGGL(k_bbce_finish, dim3((unsigned)bdiv((size_t)K * 72 * 9, 256)), dim3(256), 0, s, tot, K, (u32)bb_powmod(BB_R, BB_P - 2), out);
     return 0;
 }
