@@ -97,23 +97,28 @@ __global__ void __launch_bounds__(128) k_bbsv_finish1(fe nu, const int32_t *tot,
         for (int q = 0; q < TAU; q++) tp[((size_t)T * 5 + e) * TAU + q] = r.c[q];
     }
 }
-// thread = output i = X * 72 + 9 * slot + q:  out[i] = gpart[i] + sum_{side, k, d} TP[(side, k, 8 d + slot)](X)   (canonical words)
-__global__ void __launch_bounds__(384) k_bbsv_finish2(const fe *tp, u32 K, const u64 *gpart, u64 *out) {
-    const u32 i = threadIdx.x;
-    if (i >= 5 * RE) return;
-    const u32 X = i / RE, slot = (i % RE) / TAU, q = i % TAU;
-    i64 co[5] = {0, 0, 0, 0, 0};
-    for (u32 sk = 0; sk < 2 * K; sk++)
-        for (u32 d = 0; d < (u32)TAU; d++) {
-            const fe *p = tp + ((size_t)(sk * RE + 8 * d + slot) * 5) * TAU + q;
+// block = (slot, q), wave e = coefficient e of the polynomial: its 64 lanes add the 2K * 9 tables (side, k, 8 d + slot), then five threads evaluate at X = 0..4:
+// out[X * 72 + 9 * slot + q] = gpart[..] + sum_tables TP(X)   (canonical words).  (One block of 360 threads walking the 288 tables each took 65 us per round.)
+__global__ void __launch_bounds__(320) k_bbsv_finish2(const fe *tp, u32 K, const u64 *gpart, u64 *out) {
+    const u32 slot = blockIdx.x / TAU, q = blockIdx.x % TAU, e = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ i64 co[5];
+    i64 acc = 0;
+    for (u32 tb = lane; tb < 2 * K * (u32)TAU; tb += 64) {
+        const u32 sk = tb / TAU, d = tb % TAU;
+        acc += tp[((size_t)(sk * RE + 8 * d + slot) * 5 + e) * TAU + q];
+    }
 #pragma unroll
-            for (int e = 0; e < 5; e++) co[e] += p[TAU * e];
-        }
-    const fe xm = from_small((int32_t)X);
-    fe v = bbsv_red(co[4]);
-    for (int e = 3; e >= 0; e--) v = fadd(fmul(v, xm), bbsv_red(co[e]));
-    const u64 s = gpart[i] % BB_P + to_canon(v);
-    out[i] = s >= BB_P ? s - BB_P : s;
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down((long long)acc, off, 64);
+    if (lane == 0) co[e] = acc;
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const u32 X = threadIdx.x, i = X * RE + TAU * slot + q;
+        const fe xm = from_small((int32_t)X);
+        fe v = bbsv_red(co[4]);
+        for (int k = 3; k >= 0; k--) v = fadd(fmul(v, xm), bbsv_red(co[k]));
+        const u64 sres = gpart[i] % BB_P + to_canon(v);
+        out[i] = sres >= BB_P ? sres - BB_P : sres;
+    }
 }
 __global__ void __launch_bounds__(256) k_bb_eq_pairsum(const fe *in, size_t ldi, size_t nout, fe *out, size_t ldo) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -148,7 +153,7 @@ int launch_bbsv_round(const DevBb &t, int V, const u32 *bitsL, const u32 *bitsR,
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_bbsv_finish1<true>), dim3(2 * K * RE), dim3(128), 0, s, t.nu, tot, npr, K, ktiles, coef, mu_c, tp, w0, w1);
     else hipLaunchKernelGGL((k_bbsv_finish1<false>), dim3(2 * K * RE), dim3(128), 0, s, t.nu, tot, npr, K, ktiles, coef, mu_c, tp, w0, w1);
     if (gpart_ready) (void)hipStreamWaitEvent(s, gpart_ready, 0);   // the G part was computed on another stream
-    hipLaunchKernelGGL(k_bbsv_finish2, dim3(1), dim3(384), 0, s, tp, K, gpart, out);
+    hipLaunchKernelGGL(k_bbsv_finish2, dim3(8 * TAU), dim3(320), 0, s, tp, K, gpart, out);
     return 0;
 }
 }  // namespace lfbb

@@ -1971,19 +1971,22 @@ static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *
 // <X_a, Y_b> for na vectors X and nb vectors Y of n columns -> od (device, canonical): on the int8 matrix cores (lf_dot_i8.hip) unless
 // LF_DOT_VALU is set or the shape is not handled there
 // (st / tag: a second call in flight on another stream uses its own scratch buffers)
+// yb_pre (optional): the Y digits, already packed by launch_dot_pack_y for X vectors of this alignment (the eta products of the two sides share them)
 static int dot_batch_dev(lf_ctx *c, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *dpart, u64 *od, hipStream_t st = nullptr,
-                         const char *tag = "") {
+                         const char *tag = "", unsigned char *yb_pre = nullptr) {
     if (!st) st = c->stream();
     if (!c->tn.dot_valu && n >= c->tn.dot_min && nb <= 3) {
         unsigned char *yb;
         int32_t *part;
         long long *tot;
+        if (yb_pre) yb = yb_pre;
+        else
         RET(c->tbuf(std::string("dot_yb") + tag, dot_i8_yb_bytes(n + 1), &yb));            // (+1: an odd column slice starts one column early)
         RET(c->tbuf(std::string("dot_i8_part") + tag, dot_i8_part_words(n + 1), &part));
         RET(c->tbuf(std::string("dot_i8_tot") + tag, dot_i8_tot_words(), &tot));
         bool ok = true;
         for (u32 a0 = 0; a0 < na && ok; a0 += 16)
-            ok = launch_dot_batch_i8(c->dcrt, X + (size_t)a0 * 24 * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * 24, st) == 0;
+            ok = launch_dot_batch_i8(c->dcrt, X + (size_t)a0 * 24 * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * 24, st, yb_pre != nullptr) == 0;
         if (ok) return LF_OK;
     }
     launch_dot_batch(c->dcrt, X, ldx, na, Y, ldy, nb, n, dpart, od, st);
@@ -2796,11 +2799,22 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(c->tbuf("dec_small", 32 * 72 + 32 * 4 * 24 + 64, &sm));
     RET(c->tbuf("dot_partial", dot_partial_words(K, P.t), &dpart));
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
+    // the helper lane's stream is idle here: every second q_j = M_j^T eq(r_o) is gathered there (the gathers are latency-bound: 3 x 63 us in a row at C4)
+    hipStream_t s1f = (t_lane == 0 && !c->tn.prep_one_stream && c->sh_world == 1 && c->st_lane[1]) ? c->st_lane[1] : c->stream();
+    if (s1f != c->stream() && !c->ev_prep[0]) { HIPCHK(hipEventCreateWithFlags(&c->ev_prep[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_prep[1], hipEventDisableTiming)); }
     {
         size_t c0, cnt;
         shard_slice(c, n, &c0, &cnt);   // (sharded: the eta inner products below read this rank's column slice of q_j only)
+        if (s1f != c->stream() && P.t > 1) {
+            HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));           // eq(r_o) is built
+            HIPCHK(hipStreamWaitEvent(s1f, c->ev_prep[0], 0));
+        }
         for (u32 j = 0; j < P.t; j++)
-            launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, c->stream(), c0, cnt);
+            launch_spmv_t_eq(c->dcrt, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * 24 * n, n, (j & 1) ? s1f : c->stream(), c0, cnt);
+        if (s1f != c->stream() && P.t > 1) {
+            HIPCHK(hipEventRecord(c->ev_prep[1], s1f));
+            HIPCHK(hipStreamWaitEvent(c->stream(), c->ev_prep[1], 0));
+        }
     }
     // theta for both sides first, then eta; the host absorbs theta while the GPU still computes the eta dot products
     u64 *fsm;
@@ -2829,13 +2843,19 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         hipStream_t s1 = (t_lane == 0 && !c->tn.prep_one_stream && c->sh_world == 1 && c->st_lane[1]) ? c->st_lane[1] : c->stream();
         if (s1 != c->stream()) {
             if (!c->ev_prep[0]) { HIPCHK(hipEventCreateWithFlags(&c->ev_prep[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_prep[1], hipEventDisableTiming)); }
-            HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));           // q = M_j^T eq(r_o) is ready
+            // the digits of q are the same for both sides: packed once, before the streams part
+            unsigned char *ybq = nullptr;
+            if (!c->tn.dot_valu && cnt >= c->tn.dot_min && P.t <= 3 && K <= 16 && ((((size_t)(S[0].z + c0)) ^ ((size_t)(S[1].z + c0))) & 15) == 0) {
+                RET(c->tbuf("dot_yb", dot_i8_yb_bytes(n + 1), &ybq));
+                if (launch_dot_pack_y(S[0].z + c0, q + c0, n, P.t, cnt, ybq, c->stream()) != 0) ybq = nullptr;
+            }
+            HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));           // q = M_j^T eq(r_o) is ready (and packed)
             HIPCHK(hipStreamWaitEvent(s1, c->ev_prep[0], 0));
             u64 *dpart1;
             RET(c->tbuf("dot_partial1", dot_partial_words(K, P.t), &dpart1));
-            RET(dot_batch_dev(c, S[1].z + c0, n, K, q + c0, n, P.t, cnt, dpart1, d_eta + (size_t)K * P.t * 24, s1, "_1"));
+            RET(dot_batch_dev(c, S[1].z + c0, n, K, q + c0, n, P.t, cnt, dpart1, d_eta + (size_t)K * P.t * 24, s1, "_1", ybq));
             HIPCHK(hipEventRecord(c->ev_prep[1], s1));
-            RET(dot_batch_dev(c, S[0].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta));
+            RET(dot_batch_dev(c, S[0].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta, nullptr, "", ybq));
             HIPCHK(hipStreamWaitEvent(c->stream(), c->ev_prep[1], 0));
         } else
             for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z + c0, n, K, q + c0, n, P.t, cnt, dpart, d_eta + (size_t)sd * K * P.t * 24));
@@ -3082,7 +3102,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             // The download of a commit's results is enqueued right behind it -- ahead of whatever this stream is given next -- and its finish waits for that
             // event only.  (Round 3 copied y_L behind the RIGHT commit: the left absorb, the head of a 2.3 ms host chain, started when both commits were done.)
             const size_t ywords = (size_t)(P.K - 1) * P.kappa * 24;
-            const bool early = c->sh_world == 1 && !c->tn.no_early_y && c->pin2(2 * ywords) == LF_OK &&
+            const bool early = c->sh_world == 1 && !c->tn.force_exchange && !c->tn.no_early_y && c->pin2(2 * ywords) == LF_OK &&
                                (c->ev_yL || hipEventCreateWithFlags(&c->ev_yL, hipEventDisableTiming) == hipSuccess) &&
                                (c->ev_yR || hipEventCreateWithFlags(&c->ev_yR, hipEventDisableTiming) == hipSuccess);
             bool yL_early = false;

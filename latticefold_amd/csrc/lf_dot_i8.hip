@@ -215,8 +215,18 @@ static u32 dot_i8_chunks(size_t nsteps) {
 size_t dot_i8_part_words(size_t) { return (size_t)24 * 40 * 10240; }
 size_t dot_i8_tot_words() { return (size_t)24 * 10240; }
 // X [na][24][ldx], Y [nb][24][ldy], n columns; out[(a*nb + b)*24 + 3*slot + comp] canonical.  Returns 0, or -1 if the shape is not handled.
+// the Y digits alone (k_dot_pack_y), for a following launch_dot_batch_i8(.., y_packed = true) on vectors X with the same alignment: two X sets against the
+// same Y (the eta inner products of the two sides of a fold step) pack it once
+int launch_dot_pack_y(const u64 *X, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, hipStream_t s) {
+    if (nb < 1 || nb > 3 || n < 64 || (((size_t)X) & 7)) return -1;
+    const size_t lead = (((size_t)X) & 15) ? 1 : 0;
+    Y -= lead; n += lead;
+    const size_t ldq = dcdiv(n, 64) * 64;
+    hipLaunchKernelGGL(k_dot_pack_y, dim3((unsigned)dcdiv((size_t)nb * 24 * dcdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
+    return 0;
+}
 int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
-                        long long *tot, u64 *out, hipStream_t s) {
+                        long long *tot, u64 *out, hipStream_t s, bool y_packed) {
     if (na < 1 || na > 16 || nb < 1 || nb > 3 || n < 64 || (ldx & 1) || (((size_t)X) & 7)) return -1;
     // a column slice that starts at an odd column (a rank's slice of a sharded step): start one column earlier (16-byte aligned loads) and
     // give that column zero digits on the Y side
@@ -225,7 +235,7 @@ int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const
     const size_t ldq = dcdiv(n, 64) * 64;
     // exactness: a wave adds steps_per_chunk * 64 digit products of at most 2^14 into an int32 accumulator
     if (dcdiv(ldq / 64, dot_i8_chunks(ldq / 64)) >= 2048) return -1;
-    hipLaunchKernelGGL(k_dot_pack_y, dim3((unsigned)dcdiv((size_t)nb * 24 * dcdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
+    if (!y_packed) hipLaunchKernelGGL(k_dot_pack_y, dim3((unsigned)dcdiv((size_t)nb * 24 * dcdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
     DotI8Args a;
     a.X = X; a.ldx = ldx; a.n = n; a.na = na; a.YB = YB; a.ldq = ldq; a.nrows_y = 24 * nb;
     a.nsteps = (u32)(ldq / 64);

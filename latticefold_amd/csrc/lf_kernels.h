@@ -115,7 +115,9 @@ size_t dot_i8_yb_bytes(size_t n);
 size_t dot_i8_part_words(size_t n);
 size_t dot_i8_tot_words();
 int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
-                        long long *tot, u64 *out, hipStream_t s);
+                        long long *tot, u64 *out, hipStream_t s, bool y_packed = false);
+// the Y digits alone, for launch_dot_batch_i8(.., y_packed = true) calls on X vectors of the same alignment
+int launch_dot_pack_y(const u64 *X, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, hipStream_t s);
 void launch_vs_combine(const u64 *vs /* [K][72] */, u32 K, u64 *v /* [72] */, hipStream_t s);   // v = sum_k 2^k v_s[k]
 void launch_fix_final(const DevCrt &t, const u64 *in /* [rows3][3][2] */, u32 rows3, Fq3Const r, u64 *out /* [rows3][3] canonical */, hipStream_t s);
 
