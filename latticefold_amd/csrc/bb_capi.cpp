@@ -1236,21 +1236,25 @@ static int dec_enqueue_commit(C *c, const lf_witness *wit, DecPending &pd) {
 }
 // <X_a, Y_b> for na vectors X and nb vectors Y of n columns -> od (device, canonical): on the int8 matrix cores (bb_dot_i8.hip) unless
 // LF_DOT_VALU is set or the shape is not handled there
-static int dot_batch_dev(BbCtxImpl *c, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial, u64 *od) {
+// st / tag: another stream and its own scratch; yb_pre: the Y digits already packed (launch_dot_pack_y) for X vectors of this alignment
+static int dot_batch_dev(BbCtxImpl *c, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial, u64 *od, hipStream_t st = nullptr,
+                         const char *tag = "", unsigned char *yb_pre = nullptr) {
+    if (!st) st = c->stream();
     if (!c->tn.dot_valu && n >= c->tn.dot_min && nb <= 3) {
         unsigned char *yb;
         int32_t *part;
         long long *tot;
-        RET(c->tbuf("dot_yb", bbdot_i8_yb_bytes(n + 1), &yb));
-        RET(c->tbuf("dot_i8_part", bbdot_i8_part_words(n + 1), &part));
-        RET(c->tbuf("dot_i8_tot", bbdot_i8_tot_words(), &tot));
+        if (yb_pre) yb = yb_pre;
+        else RET(c->tbuf(std::string("dot_yb") + tag, bbdot_i8_yb_bytes(n + 1), &yb));
+        RET(c->tbuf(std::string("dot_i8_part") + tag, bbdot_i8_part_words(n + 1), &part));
+        RET(c->tbuf(std::string("dot_i8_tot") + tag, bbdot_i8_tot_words(), &tot));
         bool ok = true;
         for (u32 a0 = 0; a0 < na && ok; a0 += 16)
-            ok = launch_dot_batch_i8(c->dev, X + (size_t)a0 * RE * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * RE,
-                                     c->stream()) == 0;
+            ok = launch_dot_batch_i8(c->dev, X + (size_t)a0 * RE * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * RE, st,
+                                     yb_pre != nullptr) == 0;
         if (ok) return LF_OK;
     }
-    launch_dot_batch(c->dev, X, ldx, na, Y, ldy, nb, n, partial, od, c->stream());
+    launch_dot_batch(c->dev, X, ldx, na, Y, ldy, nb, n, partial, od, st);
     return LF_OK;
 }
 
@@ -1792,8 +1796,20 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     RET(c->tbuf("red_partial", red_partial_words(16 * RE * TAU), &red));
     RET(c->tbuf("dec_small", 16 * RE * TAU + 16 * 4 * RE, &sm));
     RET(build_eq_dev(c, pt.data(), P.s, eq0));
+    // the other stream is idle here: every second q_j = M_j^T eq(r_o) is gathered there, and the eta products of the right side run there (as in the Goldilocks driver)
+    hipStream_t s1f = (c->lane == 0 && !c->tn.prep_one_stream && c->sh_world == 1 && c->st_lane[1]) ? c->st_lane[1] : c->stream();
+    if (s1f != c->stream()) {
+        for (int e = 0; e < 2; e++)
+            if (!c->ev_prep[e]) HIPCHK(hipEventCreateWithFlags(&c->ev_prep[e], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));           // eq(r_o) is built
+        HIPCHK(hipStreamWaitEvent(s1f, c->ev_prep[0], 0));
+    }
     for (u32 j = 0; j < P.t; j++)
-        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * RE * n, n, c->stream());
+        launch_spmv_t_eq(c->dev, c->d_colptr[j], c->d_rowidx[j], c->d_valT[j], eq0, m, q + (size_t)j * RE * n, n, (j & 1) ? s1f : c->stream());
+    if (s1f != c->stream()) {
+        HIPCHK(hipEventRecord(c->ev_prep[1], s1f));
+        HIPCHK(hipStreamWaitEvent(c->stream(), c->ev_prep[1], 0));
+    }
     // theta for both sides first, then eta; the host absorbs theta while the GPU still computes the eta dot products
     u64 *fsm;
     size_t nth = (size_t)K2 * TAU * RE, net = (size_t)K2 * P.t * RE;
@@ -1810,7 +1826,22 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         for (int sd = 0; sd < 2; sd++) RET(coef_eval_bits_dev(c, S[sd].planes, N, eq0, m, K, red, d_theta + (size_t)sd * K * TAU * RE));
     HIPCHK(hipMemcpyAsync(hp, d_theta, nth * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventRecord(c->ev_side[0], c->stream()));
-    for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE));
+    if (s1f != c->stream()) {
+        unsigned char *ybq = nullptr;   // the digits of q are the same for both sides: packed once, before the streams part
+        if (!c->tn.dot_valu && n >= c->tn.dot_min && P.t <= 3 && K <= 16 && ((((size_t)S[0].z) ^ ((size_t)S[1].z)) & 7) == 0) {
+            RET(c->tbuf("dot_yb", bbdot_i8_yb_bytes(n + 1), &ybq));
+            if (launch_dot_pack_y(S[0].z, q, n, P.t, n, ybq, c->stream()) != 0) ybq = nullptr;
+        }
+        HIPCHK(hipEventRecord(c->ev_prep[0], c->stream()));           // q (and its digits) are ready
+        HIPCHK(hipStreamWaitEvent(s1f, c->ev_prep[0], 0));
+        i64 *red1;
+        RET(c->tbuf("red_partial1", red_partial_words(16 * RE * TAU), &red1));
+        RET(dot_batch_dev(c, S[1].z, n, K, q, n, P.t, n, red1, d_eta + (size_t)K * P.t * RE, s1f, "_1", ybq));
+        HIPCHK(hipEventRecord(c->ev_prep[1], s1f));
+        RET(dot_batch_dev(c, S[0].z, n, K, q, n, P.t, n, red, d_eta, nullptr, "", ybq));
+        HIPCHK(hipStreamWaitEvent(c->stream(), c->ev_prep[1], 0));
+    } else
+        for (int sd = 0; sd < 2; sd++) RET(dot_batch_dev(c, S[sd].z, n, K, q, n, P.t, n, red, d_eta + (size_t)sd * K * P.t * RE));
     HIPCHK(hipMemcpyAsync(hp + nth, d_eta, net * 8, hipMemcpyDeviceToHost, c->stream()));
     HIPCHK(hipEventSynchronize(c->ev_side[0]));
     BB_MARK("  theta down");

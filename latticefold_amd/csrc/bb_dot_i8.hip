@@ -197,8 +197,17 @@ static u64 bb_powmod(u64 a, u64 e) {
     return r;
 }
 // X [na][72][ldx], Y [nb][72][ldy] (centred Montgomery words), n columns; out[(a*nb + b)*72 + 9*slot + c] canonical.  0, or -1 (shape).
+// the Y digits alone, for launch_dot_batch_i8(.., y_packed = true) calls on X vectors of the same alignment (the eta products of the two sides of a fold step)
+int launch_dot_pack_y(const fe *X, const fe *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, hipStream_t s) {
+    if (nb < 1 || nb > 3 || n < 64 || (((size_t)X) & 3)) return -1;
+    const size_t lead = (((size_t)X) & 7) / 4;
+    Y -= lead; n += lead;
+    const size_t ldq = bdiv(n, 64) * 64;
+    hipLaunchKernelGGL(k_bbdot_pack_y, dim3((unsigned)bdiv((size_t)nb * RE * bdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
+    return 0;
+}
 int launch_dot_batch_i8(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
-                        long long *tot, u64 *out, hipStream_t s) {
+                        long long *tot, u64 *out, hipStream_t s, bool y_packed) {
     if (na < 1 || na > 16 || nb < 1 || nb > 3 || n < 64 || (ldx & 1) || (((size_t)X) & 3)) return -1;
     // a column slice that does not start on an 8-byte boundary: start one column earlier and give that column zero digits on the Y side
     const size_t lead = (((size_t)X) & 7) / 4;
@@ -206,7 +215,7 @@ int launch_dot_batch_i8(const DevBb &t, const fe *X, size_t ldx, u32 na, const f
     const size_t ldq = bdiv(n, 64) * 64;
     // exactness: a wave adds steps_per_chunk * 64 digit products of at most 2^14 into an int32 accumulator
     if (bdiv(ldq / 64, bbdot_chunks(ldq / 64)) >= 2048) return -1;
-    hipLaunchKernelGGL(k_bbdot_pack_y, dim3((unsigned)bdiv((size_t)nb * RE * bdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
+    if (!y_packed) hipLaunchKernelGGL(k_bbdot_pack_y, dim3((unsigned)bdiv((size_t)nb * RE * bdiv(ldq / 64, 8), 4)), dim3(256), 0, s, Y, ldy, nb, n, lead, ldq, YB);
     BbDotArgs a;
     a.X = X; a.ldx = ldx; a.n = n; a.na = na; a.YB = YB; a.ldq = ldq; a.nrows_y = 36 * nb;
     a.nsteps = (u32)(ldq / 64);

@@ -77,7 +77,8 @@ size_t bbdot_i8_yb_bytes(size_t n);
 size_t bbdot_i8_part_words(size_t n);
 size_t bbdot_i8_tot_words();
 int launch_dot_batch_i8(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
-                        long long *tot, u64 *out, hipStream_t s);
+                        long long *tot, u64 *out, hipStream_t s, bool y_packed = false);
+int launch_dot_pack_y(const fe *X, const fe *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, hipStream_t s);
 void launch_dot_batch(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *Y, size_t ldy, u32 nb, size_t n, i64 *partial,
                       u64 *out /*[na][nb][72] canonical*/, hipStream_t s);
 void launch_dot_eq(const DevBb &t, const fe *X, size_t ldx, u32 na, const fe *eq, size_t ldeq, size_t n, i64 *partial,

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+(timeout 1500 python -m pytest tests/test_gpu_bb.py -x -q 2>&1 | tail -3) > gpurun_out/q5.txt
+(timeout 900 python -m pytest tests/test_gpu_parity_scale.py -x -q -k "C3 or B14" 2>&1 | tail -2) >> gpurun_out/q5.txt
+for e in A=1 LF_PREP_ONE_STREAM=1 A=1 LF_PREP_ONE_STREAM=1; do env $e timeout 300 python bench.py --workload C3 --steps 10 --warmup 2 --no-cpu-baseline --no-lfplus 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C3 $e ms/step %.3f'%d['ms_per_step'], {k:round(v,2) for k,v in d['phases_ms_per_step'].items()})" >> gpurun_out/q5.txt; done
+cat gpurun_out/q5.txt
