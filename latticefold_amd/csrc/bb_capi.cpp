@@ -1887,25 +1887,27 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     {   // v_0 = rot_lin_combination(rho_coeff, theta) (cyclotomic-rings/src/rotation.rs:85-104)
         // the rotations of a short challenge stay small signed integers (X^72 = X^36 - 1 adds at most one more term per step) and theta words are < 2^31:
         // plain 64-bit integer multiply-accumulates, one reduction per output word (32 * 72 terms of < 2^31 * 2^12 fit easily)
-        std::vector<int64_t> acc((size_t)RE * TAU, 0);
+        // As one polynomial product per i: full[a + b] += rho_a theta_b over the (at most 24 non-zero) coefficients of rho and all of theta -- the inner loop is one
+        // contiguous multiply-add over theta's 72 x 9 words -- and ONE reduction of the degree-142 product by X^72 = X^36 - 1 at the end (the rotation-by-rotation
+        // form walked 72 x 72 pairs per i with rotations that fill up: twice the multiply-adds, none of them contiguous).  |full| < 72 * 32 * 2^5 * 2^31 < 2^48.
+        std::vector<int64_t> acc((size_t)(2 * RE) * TAU, 0);
         std::vector<u64> res((size_t)RE * TAU, 0);   // res[j] in F_{p^9}
         for (u32 i = 0; i < K2; i++) {
-            int64_t rot[RE];
-            for (int j = 0; j < RE; j++) { const u64 rc = rho_c[(size_t)i * RE + j] % BB_P; rot[j] = rc > BB_P / 2 ? (int64_t)rc - (int64_t)BB_P : (int64_t)rc; }
             const u64 *th = theta + (size_t)i * TAU * RE;
-            for (int bi = 0; bi < RE; bi++) {
-                const u64 *b = th + (size_t)TAU * bi;
-                for (int j = 0; j < RE; j++) {
-                    const int64_t rj = rot[j];
-                    if (rj)
-                        for (int q2 = 0; q2 < TAU; q2++) acc[(size_t)j * TAU + q2] += (int64_t)b[q2] * rj;
-                }
-                const int64_t top = rot[RE - 1];   // multiply by X modulo X^72 - X^36 + 1
-                for (int j = RE - 1; j > 0; j--) rot[j] = rot[j - 1];
-                rot[0] = -top;
-                rot[RE / 2] += top;
+            for (int a = 0; a < RE; a++) {
+                const u64 rc = rho_c[(size_t)i * RE + a] % BB_P;
+                const int64_t ra = rc > BB_P / 2 ? (int64_t)rc - (int64_t)BB_P : (int64_t)rc;
+                if (!ra) continue;
+                int64_t *dst = acc.data() + (size_t)a * TAU;
+                for (int x = 0; x < RE * TAU; x++) dst[x] += (int64_t)th[x] * ra;
             }
         }
+        for (int d = 2 * RE - 2; d >= RE; d--)
+            for (int q2 = 0; q2 < TAU; q2++) {
+                const int64_t v = acc[(size_t)d * TAU + q2];
+                acc[(size_t)(d - RE / 2) * TAU + q2] += v;
+                acc[(size_t)(d - RE) * TAU + q2] -= v;
+            }
         for (size_t x = 0; x < res.size(); x++) { const int64_t r = acc[x] % (int64_t)BB_P; res[x] = (u64)(r < 0 ? r + (int64_t)BB_P : r); }
         memcpy(o, res.data(), res.size() * 8);
         o += (size_t)TAU * RE;
