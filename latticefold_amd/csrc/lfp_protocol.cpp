@@ -11,6 +11,7 @@
 #include <memory>
 #include "lf_host.h"
 #include "lfp_ctx.h"
+static constexpr uint32_t LFP_HOST_SUM_BLOCKS = 256;   // block partials the host adds per round; rounds with more workgroups add theirs on the device (launch_reduce)
 
 // LFPLUS_TIMELINE=1: wall-clock marks of the protocol stages on stderr (the stream is drained at every mark, so the stages do not overlap)
 struct LfpTl {
@@ -1013,13 +1014,18 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             const size_t half = len / 2;
             const u32 nb = lfp::cm_round_blocks(half);
             auto tA = std::chrono::steady_clock::now();
-            lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), c->hpin_dev, c->st);
+            // up to 256 blocks write their partial sums straight into mapped host memory (the host adds them); the large rounds need more workgroups than that to
+            // reach the HBM rate (6.3 GB of tables in round 0 at 2^20 rows: 5.4 ms with 256 blocks, 1.8 ms with 4096) and add theirs on the device
+            const bool dev_sum = nb > LFP_HOST_SUM_BLOCKS;
+            lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), dev_sum ? part.as<u64>() : c->hpin_dev, c->st);
+            if (dev_sum) lfp::launch_reduce(part.as<u64>(), nb, 48, c->hpin_dev, 0, c->kappa, 0, 2, 0, nullptr, c->st);
             HIPCHK(c, hipStreamSynchronize(c->st));
             auto tB = std::chrono::steady_clock::now();
             u64 *m = proof + (size_t)rnd * 3 * D;
+            const u32 nbh = dev_sum ? 1u : nb;
             for (int x = 0; x < 3 * D; x++) {
                 u64 s = 0;
-                for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 48 + x]);
+                for (u32 b = 0; b < nbh; b++) s = fadd(s, hpart[(size_t)b * 48 + x]);
                 m[x] = s;              // canonical: every product of the kernel pairs one Montgomery operand with one canonical operand
             }
             if (dist) { int rcx = lfp_xsum(c, m, 3 * D); if (rcx) return rcx; }
@@ -1291,13 +1297,16 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
         const size_t half = len / 2;
         const u32 nb = lfp::cm_round_blocks(half);
         auto tA = std::chrono::steady_clock::now();
-        lfp::launch_r1cs_round(Ec, Gc, ld, half, c->hpin_dev, c->st);   // block partials into mapped host memory
+        const bool dev_sum = nb > LFP_HOST_SUM_BLOCKS;     // (as in Cm::prove: small rounds write block partials into mapped host memory, large ones add them on the device)
+        lfp::launch_r1cs_round(Ec, Gc, ld, half, dev_sum ? part.as<u64>() : c->hpin_dev, c->st);
+        if (dev_sum) lfp::launch_reduce(part.as<u64>(), nb, 64, c->hpin_dev, 0, c->kappa, 0, 2, 0, nullptr, c->st);
         HIPCHK(c, hipStreamSynchronize(c->st));
         auto tB = std::chrono::steady_clock::now();
         u64 *m = msgs + (size_t)rnd * 4 * D;
+        const u32 nbh = dev_sum ? 1u : nb;
         for (int x = 0; x < 4 * D; x++) {
             u64 s = 0;
-            for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 64 + x]);
+            for (u32 b = 0; b < nbh; b++) s = fadd(s, hpart[(size_t)b * 64 + x]);
             m[x] = s;
         }
         if (dist) { int rcx = lfp_xsum(c, m, 4 * D); if (rcx) return rcx; }

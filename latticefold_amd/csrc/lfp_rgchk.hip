@@ -387,7 +387,13 @@ __global__ void __launch_bounds__(256) k_cm_round(const u64 *S, size_t lds, cons
     }
 }
 // (the host adds the block partials -- 48 / 64 words each, read from mapped memory -- before it can run the transcript: one block per CU at most)
-u32 cm_round_blocks(size_t half) { size_t b = cdiv(half, 16); return (u32)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
+// workgroups of a sumcheck round (16 pairs per workgroup and pass; up to 2048: one per CU leaves a memory-bound round at 1/3 of the HBM rate).  Above 256 the
+// driver adds the block partials on the device (launch_reduce) instead of on the host.  LFPLUS_ROUND_BLOCKS moves the cap
+u32 cm_round_blocks(size_t half) {
+    static const size_t cap = [] { const char *e = getenv("LFPLUS_ROUND_BLOCKS"); const long v = e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 65535 ? v : 2048); }();
+    size_t b = cdiv(half, 16);
+    return (u32)(b < 1 ? 1 : (b > cap ? cap : b));
+}
 void launch_cm_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 *part, hipStream_t s) {
     hipLaunchKernelGGL(k_cm_round, dim3(cm_round_blocks(half)), dim3(256), 0, s, S, lds, R, ldr, half, d, rcp, part);
 }
