@@ -233,7 +233,9 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
         wl = plus.make_plus_workload(name)
         r1cs, zs = wl.r1cs(), [wl.z(i) for i in range(wl.L)]
         A = wl.ajtai_matrix(column_shard(wl.n, rank, world) if world > 1 else None)     # a rank uploads its columns only
-        best, proof, exch = None, None, None
+        # iteration 0: the witnesses cross PCIe inside the timed call and F0 / F1 come back to the host (`ms_host_io`); iterations 1, 2: inputs resident
+        # (PlusProver.preload) and the accumulator left on the device (lfplus_decompose_resident) -- the contract's timed region (`ms`)
+        best, proof, exch, host_io = None, None, None, None
         for it in range(3):
             shard = None
             if world > 1:      # a fresh RCCL communicator per prover; under the gloo test hook (two ranks on one GPU) the host transport
@@ -241,6 +243,9 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
             prover = plus.PlusProver.init(A, list(r1cs), max(1, wl.L - 2), wl.params(), plus.PoseidonTranscript(), device, shard)
             try:
                 comps = [plus.ComR1CS.new(prover.ctxs[0], r1cs, z, 1, wl.B, wl.k) for z in zs]
+                if it > 0:
+                    prover.device_acc = True
+                    prover.preload(comps)
                 if dist is not None:
                     dist.barrier()
                 prover.ctxs[0].dist_stats(reset=True)
@@ -250,7 +255,10 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
                 exch = prover.ctxs[0].dist_stats()
             finally:
                 prover.close()
-            best = dt if best is None else min(best, dt)
+            if it == 0:
+                host_io = dt
+            else:
+                best = dt if best is None else min(best, dt)
         if dist is not None:      # the slowest rank's best time
             import torch
             t = torch.tensor([best], dtype=torch.float64)
@@ -258,7 +266,9 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
                 t = t.cuda()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             best = float(t.item())
-        rec = {"workload": f"{name}: n = 2^{wl.nvars}, L = {wl.L} fresh instances, k = {wl.k}, kappa = {wl.kappa}, B = {wl.B}", "ms": 1e3 * best}
+        rec = {"workload": f"{name}: n = 2^{wl.nvars}, L = {wl.L} fresh instances, k = {wl.k}, kappa = {wl.kappa}, B = {wl.B}", "ms": 1e3 * best,
+               "ms_host_io": 1e3 * host_io,
+               "io": "ms: witnesses resident before the call, (F0, F1) left on the device; ms_host_io (first call, also the warm-up): L witnesses uploaded and F0, F1 downloaded inside"}
         if rank == 0:
             tv, ok = None, True
             Av = A if world == 1 else np.zeros((wl.kappa, wl.n, 16), dtype=np.uint64)      # (the verifier reads the matrix's shape only)

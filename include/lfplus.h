@@ -95,6 +95,13 @@ int lfplus_rg_from_f_timed(lfplus_ctx *ctx, uint64_t b, uint32_t k, uint32_t l, 
 int lfplus_decompose(lfplus_ctx *ctx, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
                      const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1, uint64_t *v0,
                      uint64_t *v1);
+/* The same, with the parts left on the device: F0 / F1 become the resident witnesses of dst0 / dst1 (contexts of the same device and width; `ctx` itself may be
+ * one of them -- its witness, the folded g, is consumed first).  The accumulator of a folding prover (plus.rs:96-103: the two LinB of one prove are inputs of the
+ * next) then never crosses PCIe: 2 x 134 MB down and up again per prove at 2^20 rows.  lfplus_get_witness reads a context's resident witness back. */
+int lfplus_decompose_resident(lfplus_ctx *ctx, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
+                              const uint32_t *const *col, const uint64_t *const *val, lfplus_ctx *dst0, lfplus_ctx *dst1, uint64_t *C0, uint64_t *C1,
+                              uint64_t *v0, uint64_t *v1);
+int lfplus_get_witness(lfplus_ctx *ctx, uint64_t *f_out /* n * 16 words */, uint64_t n);
 
 /* Matrix::try_mul_vec: out (kappa*16 words) = A * v for a general vector of n ring elements (host pointer) */
 int lfplus_commit(lfplus_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *out);

@@ -352,10 +352,14 @@ extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint6
 }
 // r 2^64 mod p (Montgomery form) on the host
 static u64 to_mont(u64 a) { return (u64)((((unsigned __int128)a) << 64) % lfp::P); }
-extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
-                                const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1, uint64_t *v0,
-                                uint64_t *v1) {
+// dst0 / dst1 (optional): contexts that receive F0 / F1 as their resident witnesses (device-to-device; `c` itself is allowed: its witness is consumed first)
+static int decompose_impl(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
+                          const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1, uint64_t *v0,
+                          uint64_t *v1, lfplus_ctx *dst0, lfplus_ctx *dst1) {
     if (!c || !r_a || !r_b || (nm && rowptr && (!col || !val))) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: null argument");
+    for (lfplus_ctx *d : {dst0, dst1})
+        if (d && (d->device != c->device || d->n != c->n)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose_resident: the receiving context is on another device or has another width");
+    if (dst0 && dst0 == dst1) return fail(c, LFPLUS_E_ARG, "lfplus_decompose_resident: F0 and F1 need two contexts");
     const bool resident = nm && !rowptr;   // the matrices lfplus_set_matrices left in the context
     if (resident && (c->mats.size() != nm || c->mats_n != c->n)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: no resident matrices of this shape");
     if (!c->A || !c->f || c->nf != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: matrix / witness not set or of different length");
@@ -477,10 +481,40 @@ extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, 
     }
     if (F0) HIPCHK2(hipMemcpyAsync(F0, dF0, vw * 8, hipMemcpyDeviceToHost, c->st));
     if (F1) HIPCHK2(hipMemcpyAsync(F1, dF1, vw * 8, hipMemcpyDeviceToHost, c->st));
+    for (int s2 = 0; s2 < 2; s2++) {     // the parts as resident witnesses of the receiving contexts (all on c's stream: the source of F0 / F1 -- c->f -- was read above)
+        lfplus_ctx *d = s2 ? dst1 : dst0;
+        if (!d) continue;
+        if (!d->f || d->nf != n) {
+            if (d->f) { (void)hipFree(d->f); d->f = nullptr; d->nf = 0; }
+            HIPCHK2(hipMalloc(&d->f, vw * 8));
+            d->nf = n;
+        }
+        d->have = false;
+        HIPCHK2(hipMemcpyAsync(d->f, s2 ? dF1 : dF0, vw * 8, hipMemcpyDeviceToDevice, c->st));
+    }
     HIPCHK2(hipStreamSynchronize(c->st));
     HIPCHK2(hipGetLastError());
 #undef HIPCHK2
     cleanup();
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_decompose(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
+                                const uint32_t *const *col, const uint64_t *const *val, uint64_t *F0, uint64_t *F1, uint64_t *C0, uint64_t *C1, uint64_t *v0,
+                                uint64_t *v1) {
+    return decompose_impl(c, B, r_a, r_b, nm, rowptr, col, val, F0, F1, C0, C1, v0, v1, nullptr, nullptr);
+}
+extern "C" int lfplus_decompose_resident(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const uint64_t *r_b, uint32_t nm, const uint32_t *const *rowptr,
+                                         const uint32_t *const *col, const uint64_t *const *val, lfplus_ctx *dst0, lfplus_ctx *dst1, uint64_t *C0, uint64_t *C1,
+                                         uint64_t *v0, uint64_t *v1) {
+    if (!dst0 || !dst1) return fail(c, LFPLUS_E_ARG, "lfplus_decompose_resident: null receiving context");
+    return decompose_impl(c, B, r_a, r_b, nm, rowptr, col, val, nullptr, nullptr, C0, C1, v0, v1, dst0, dst1);
+}
+extern "C" int lfplus_get_witness(lfplus_ctx *c, uint64_t *f_out, uint64_t n) {
+    if (!c || !f_out) return fail(c, LFPLUS_E_ARG, "lfplus_get_witness: null argument");
+    if (!c->f || c->nf != n) return fail(c, LFPLUS_E_ARG, "lfplus_get_witness: no resident witness of this length");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(f_out, c->f, (size_t)n * 16 * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
     return LFPLUS_OK;
 }
 extern "C" int lfplus_tensor(lfplus_ctx *c, const uint64_t *r, uint32_t n, uint64_t *out) {

@@ -243,7 +243,12 @@ __global__ void __launch_bounds__(1024) k_sum_parts(const u64 *part, u32 chunks,
         out[o] = out_of_mont ? from_mont(s) : s;
     }
 }
-u32 eval_chunks(size_t n) { size_t b = cdiv(n, 1024); return (u32)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }   // (256 blocks = one wave per SIMD: the passes were latency-bound)
+// (256 blocks = one wave per SIMD: the passes were latency-bound; LFPLUS_EVAL_CHUNKS moves the cap)
+u32 eval_chunks(size_t n) {
+    static const size_t cap = [] { const char *e = getenv("LFPLUS_EVAL_CHUNKS"); const long v = e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 65535 ? v : 1024); }();
+    size_t b = cdiv(n, 256);
+    return (u32)(b < 1 ? 1 : (b > cap ? cap : b));
+}
 void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = eval_chunks(n);
     if (ncols == 16) hipLaunchKernelGGL((k_wmono<16>), dim3(ch), dim3(256), 0, s, dig, (size_t)16, n, w, wstride, part, 16u, 0u);

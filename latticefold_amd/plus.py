@@ -55,6 +55,8 @@ def _lib():
         L.lfplus_commit.argtypes = [vp, u64p, C.c_uint64, u64p]
         u32pp, u64pp = C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64p)
         L.lfplus_decompose.argtypes = [vp, C.c_uint64, u64p, u64p, C.c_uint32, u32pp, u32pp, u64pp, u64p, u64p, u64p, u64p, u64p, u64p]
+        L.lfplus_decompose_resident.argtypes = [vp, C.c_uint64, u64p, u64p, C.c_uint32, u32pp, u32pp, u64pp, vp, vp, u64p, u64p, u64p, u64p]
+        L.lfplus_get_witness.argtypes = [vp, u64p, C.c_uint64]
         L.lfplus_tensor.argtypes = [vp, u64p, C.c_uint32, u64p]
         L.lfplus_tensor_product.argtypes = [vp, u64p, C.c_uint64, u64p, C.c_uint64, u64p]
         u8p, vpp, ip = C.POINTER(C.c_uint8), C.POINTER(vp), C.POINTER(C.c_int)
@@ -202,9 +204,16 @@ class PlusContext:
         self._chk(_lib().lfplus_tensor_product(self.h, pa, a.size, pb, b.size, out.ctypes.data_as(u64p)))
         return out
 
-    def decompose(self, f, A, B, r, M=()):
+    def get_witness(self):
+        """the context's resident witness (n, 16), read back from the device"""
+        out = np.zeros((self.n, D), dtype=np.uint64)
+        self._chk(_lib().lfplus_get_witness(self.h, out.ctypes.data_as(u64p), self.n))
+        return out
+
+    def decompose(self, f, A, B, r, M=(), into=None):
         """Decomp{f, r, M}.decompose(&A, B) (decomp.rs:32-99).  r: (nvars, 2, 16) pairs of ring elements; M: CSR matrices (rowptr, col, val[nnz][16]).
-        -> dict(F0, F1 (n,16); C0, C1 (kappa,16); v0, v1 (1+len(M), 2, 16)): ((LinB0, LinB1), DecompProof) of the reference, flat"""
+        -> dict(F0, F1 (n,16); C0, C1 (kappa,16); v0, v1 (1+len(M), 2, 16)): ((LinB0, LinB1), DecompProof) of the reference, flat.
+        into = (ctx0, ctx1): F0 / F1 stay on the device as the resident witnesses of those contexts (lfplus_decompose_resident) and are not returned"""
         if A is not None:
             self.set_matrix(A)
         if f is not None:              # None: the resident witness (e.g. the folded g Mlin.mlin left there)
@@ -214,8 +223,13 @@ class PlusContext:
         nm = len(M)
         keep, rp, cp, vp_ = _csr_args(M)
         n, kappa = self.n, self.kappa
-        out = {"F0": np.zeros((n, D), dtype=np.uint64), "F1": np.zeros((n, D), dtype=np.uint64), "C0": np.zeros((kappa, D), dtype=np.uint64),
-               "C1": np.zeros((kappa, D), dtype=np.uint64), "v0": np.zeros((1 + nm, 2, D), dtype=np.uint64), "v1": np.zeros((1 + nm, 2, D), dtype=np.uint64)}
+        out = {"C0": np.zeros((kappa, D), dtype=np.uint64), "C1": np.zeros((kappa, D), dtype=np.uint64), "v0": np.zeros((1 + nm, 2, D), dtype=np.uint64),
+               "v1": np.zeros((1 + nm, 2, D), dtype=np.uint64)}
+        if into is not None:
+            self._chk(_lib().lfplus_decompose_resident(self.h, B, r_a.ctypes.data_as(u64p), r_b.ctypes.data_as(u64p), nm, rp, cp, vp_, into[0].h, into[1].h,
+                                                       *[out[k].ctypes.data_as(u64p) for k in ("C0", "C1", "v0", "v1")]))
+            return out
+        out["F0"], out["F1"] = np.zeros((n, D), dtype=np.uint64), np.zeros((n, D), dtype=np.uint64)
         self._chk(_lib().lfplus_decompose(self.h, B, r_a.ctypes.data_as(u64p), r_b.ctypes.data_as(u64p), nm, rp, cp, vp_,
                                           *[out[k].ctypes.data_as(u64p) for k in ("F0", "F1", "C0", "C1", "v0", "v1")]))
         return out
@@ -599,10 +613,11 @@ class ComR1CS:
     def matrices(self):
         return list(self.r1cs)
 
-    def linearize(self, ctx, transcript, resident=False):
+    def linearize(self, ctx, transcript, resident=False, preloaded=False):
         """Linearize::linearize (r1cs.rs:76-139) on `ctx` (the witness becomes resident there) -> (LinB fields, ComR1CSProof fields); resident: the three
-        matrices are the ones ctx.set_matrices / share_matrices left on the device"""
-        ctx.set_witness(self.f)
+        matrices are the ones ctx.set_matrices / share_matrices left on the device; preloaded: ctx.set_witness(self.f) was already called (PlusProver.preload)"""
+        if not preloaded:
+            ctx.set_witness(self.f)
         n = self.f.shape[0]
         nvars = n.bit_length() - 1
         keep, rp, cp, vp = _csr_args(RESIDENT(3) if resident else self.r1cs)
@@ -693,7 +708,9 @@ class PlusProver:
             c.share_matrix(self.ctxs[0])
             c.share_matrices(self.ctxs[0])
         self.res = RESIDENT(len(self.M))
-        self.acc = []          # the accumulated LinB witnesses (host copies of F0, F1)
+        self.acc = []          # the accumulated LinB witnesses: host copies of F0, F1 -- or, with device_acc, the markers "ctx0" / "ctx1" (they live in ctxs[0] / ctxs[1])
+        self.device_acc = False   # True: the accumulator never leaves the device between proves (lfplus_decompose_resident); accumulator() reads it back
+        self._preloaded = None
         self.failed = None     # set when a prove() raised half way: the Fiat-Shamir transcript has advanced and the contexts hold a half-folded state
 
     @staticmethod
@@ -704,6 +721,22 @@ class PlusProver:
         for c in reversed(self.ctxs):
             c.close()
         self.ctxs = []
+
+    def preload(self, comp):
+        """upload the witnesses of the instances the next prove(comp) will fold into their contexts now (a pipeline has them on the device already: the timed region
+        of bench.py starts after this, as the contract's "inputs resident in HBM" asks)"""
+        nacc = len(self.acc)
+        if nacc + len(comp) > len(self.ctxs):
+            raise LfPlusError(E_ARG, "PlusProver.preload: more instances than contexts (ncomp)")
+        for i, ci in enumerate(comp):
+            self.ctxs[nacc + i].set_witness(ci.f)
+        self._preloaded = [ci.f for ci in comp]
+
+    def accumulator(self):
+        """(F0, F1) of the last prove as host arrays"""
+        if self.device_acc and self.acc:
+            return self.ctxs[0].get_witness(), self.ctxs[1].get_witness()
+        return tuple(self.acc)
 
     def prove(self, comp):
         """PlusProver::prove (plus.rs:77-108) -> PlusProof fields: linb2x, lproof, cmproof, dproof"""
@@ -722,15 +755,22 @@ class PlusProver:
     def _prove(self, comp, nacc):
         ctxs = self.ctxs[:nacc + len(comp)]
         lproof = []
+        pre = self._preloaded is not None and len(self._preloaded) == len(comp) and all(a is ci.f for a, ci in zip(self._preloaded, comp))
+        self._preloaded = None
         for i, ci in enumerate(comp):
             same = len(self.M) == 3 and all(a is b for x, y in zip(ci.r1cs, self.M) for a, b in zip(x, y))   # (M = cr1cs.x.matrices() in every reference use)
-            _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same)
+            _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same, preloaded=pre)
             lproof.append(lp)
         for i, f in enumerate(self.acc):
-            ctxs[i].set_witness(f)
+            if not isinstance(f, str):     # (device_acc: F0 / F1 of the last prove are the resident witnesses of ctxs[0] / ctxs[1] already)
+                ctxs[i].set_witness(f)
         linb2x, cmproof = mlin(ctxs, self.transcript, self.params.lin, self.res)
-        dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res)
-        self.acc = [dec["F0"], dec["F1"]]
+        if self.device_acc:
+            dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res, into=(self.ctxs[0], self.ctxs[1]))
+            self.acc = ["ctx0", "ctx1"]
+        else:
+            dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res)
+            self.acc = [dec["F0"], dec["F1"]]
         dproof = {key: dec[key] for key in ("C0", "C1", "v0", "v1")}
         return {"linb2x": linb2x, "lproof": lproof, "cmproof": cmproof, "dproof": dproof}
 

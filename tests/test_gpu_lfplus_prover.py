@@ -49,10 +49,11 @@ def test_r1cs_linearize_matches_oracle(nvars, k, b):
         ctx.close()
 
 
-@pytest.mark.parametrize("kappa,k,rounds", [(2, 2, (2,)), (1, 4, (2, 1, 1))])
-def test_plus_prover_matches_oracle(kappa, k, rounds):
+@pytest.mark.parametrize("kappa,k,rounds,device_acc", [(2, 2, (2,), False), (1, 4, (2, 1, 1), False), (1, 4, (2, 1, 1), True)])
+def test_plus_prover_matches_oracle(kappa, k, rounds, device_acc):
     """plus.rs:148-272: test_prove (n = 2^15, kappa 2, k 2, two fresh instances, one round) and the accumulating shape of test_prove_multi (k 4; kappa 1
-    keeps tau inside n = 2^15) over three rounds"""
+    keeps tau inside n = 2^15) over three rounds.  device_acc: the witnesses are preloaded (PlusProver.preload) and the accumulator (F0, F1) stays on the
+    device between the proves (lfplus_decompose_resident; read back with lfplus_get_witness) -- the same proofs and the same accumulator"""
     n, L = 1 << 15, 3
     B = _bound(L, k) + 1 if k == 2 else _bound(L, k) // 2
     l = ceil(log(P) / log(8))
@@ -62,6 +63,7 @@ def test_plus_prover_matches_oracle(kappa, k, rounds):
     params = plus.PlusParameters(plus.LinParameters(kappa, plus.DecompParameters(8, k, l)), B)
     oracle = lfp.PlusOracle(A, list(r1cs), kappa, 8, k, l, B, lfp.Transcript())
     prover = plus.PlusProver.init(A, list(r1cs), 1, params, plus.PoseidonTranscript())
+    prover.device_acc = device_acc
     ver, ts_o = plus.PlusVerifier.init(A, list(r1cs), params, plus.PoseidonTranscript()), lfp.Transcript()
     try:
         for ncomp in rounds:
@@ -72,14 +74,18 @@ def test_plus_prover_matches_oracle(kappa, k, rounds):
                 zs.append(z)
             want = oracle.prove([(lfp.gadget_decompose(z, B, k), r1cs) for z in zs])
             comps = [plus.ComR1CS.new(prover.ctxs[0], r1cs, z, 1, B, k) for z in zs]
+            if device_acc:
+                prover.preload(comps)
             got = prover.prove(comps)
             for i in range(ncomp):
                 _same(got["lproof"][i], want["lproof"][i], ("msgs", "r", "evals"), f"lproof[{i}]")
             _same(got["cmproof"], want["cmproof"], CM_KEYS, "cmproof")
             _same(got["linb2x"], want["linb2x"], ("cm_g", "ro", "vo"), "linb2x")
             _same(got["dproof"], want["dproof"], ("C0", "C1", "v0", "v1"), "dproof")
+            acc = prover.accumulator()
+            assert not device_acc or prover.acc == ["ctx0", "ctx1"]
             for i in range(2):
-                assert (prover.acc[i] == oracle.acc[i]).all()
+                assert (acc[i] == oracle.acc[i]).all()
             assert ver.verify(got), ver.stage
             assert lfp.plus_verify(ts_o, got, B) == 0
         assert prover.transcript.get_challenge() == oracle.tr.challenge()
