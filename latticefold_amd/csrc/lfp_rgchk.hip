@@ -100,7 +100,10 @@ __global__ void __launch_bounds__(256) k_sc_round(const u64 *tab, size_t ld, siz
     }
     block_sum4(s, part + (size_t)blockIdx.x * 4);
 }
-u32 sc_round_max_blocks() { return 512; }
+u32 sc_round_max_blocks() {      // (4 words of partial sums per block for the host: the cap is about occupancy; LFPLUS_SC_BLOCKS moves it)
+    static const u32 cap = [] { const char *e = getenv("LFPLUS_SC_BLOCKS"); const long v = e ? atol(e) : 0; return (u32)(v >= 1 && v <= 65535 ? v : 2048); }();
+    return cap;
+}
 // returns the number of blocks = rows of part[.][4]
 u32 launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part, hipStream_t s) {
     const u32 mats_eff = d.nsets_eff < d.nmat ? d.nsets_eff : d.nmat, vec_eff = d.nsets_eff - mats_eff;
@@ -147,12 +150,28 @@ __device__ __forceinline__ void block_sum16(u64 acc[16], u64 *out) {
 // rotation by the exponent is a 16-lane shuffle; a lane keeps one accumulator per column.  (First version: thread = row, grid.y = column -- every thread
 // gathered its 16 weight words with a data-dependent index from 64 different cache lines per instruction, and the 128 MB weight table of a 2^20-row
 // instance was read once per column: 39 ms of the 167 ms prove were the 48 evaluation passes of the set check.)
+// (sums are kept as lazy 96-bit integers: a subtraction adds p - v, one reduction per accumulator at the end -- add_p AND sub_p per item, 13 of its 17 integer
+// instructions, were what the pass spent its time on; at most 2^20 rows per lane: the sums stay below 2^84)
+struct Acc96 { u32 a0, a1, a2; };
+__device__ __forceinline__ void acc96_add(Acc96 &a, u64 v) {
+    const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+    asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+        : "+v"(a.a0), "+v"(a.a1), "+v"(a.a2)
+        : "v"(v0), "v"(v1)
+        : "vcc");
+}
+__device__ __forceinline__ u64 acc96_red(const Acc96 &a) {   // (a2 2^64 + lo) mod p
+    u64 lo = ((u64)a.a1 << 32) | a.a0;
+    if (lo >= P) lo -= P;
+    return add_p(mont_mul((u64)a.a2, R2), lo);
+}
+// (the rotation as a barrel shifter of four DPP row rotations instead of the 16-lane shuffle: correct, and 16.2 instead of 10.2 ms for the 48 passes at 2^20 rows)
 template <int NC>
 __global__ void __launch_bounds__(256) k_wmono(const int8_t *dig, size_t dstride, size_t n, const u64 *w, u32 wstride, u64 *part, u32 pcols, u32 pc0) {
     const int t = threadIdx.x & 15, r = threadIdx.x >> 4;
-    u64 acc[NC];
+    Acc96 acc[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) acc[c] = 0;
+    for (int c = 0; c < NC; c++) acc[c] = Acc96{0, 0, 0};
     for (size_t row = (size_t)blockIdx.x * 16 + r; row < n; row += (size_t)gridDim.x * 16) {
         const u64 wv = wstride == 1 ? w[row] : w[row * 16 + t];
         int8_t d[NC];
@@ -169,18 +188,18 @@ __global__ void __launch_bounds__(256) k_wmono(const int8_t *dig, size_t dstride
         for (int c = 0; c < NC; c++) {
             const int e = exp_of(d[c]);
             if (wstride == 1) {
-                acc[c] = add_p(acc[c], (d[c] != LFP_ABSENT && e == t) ? wv : 0);
+                acc96_add(acc[c], (d[c] != LFP_ABSENT && e == t) ? wv : 0);
             } else {
                 const u64 v = __shfl(wv, (t - e) & 15, 16);
-                const u64 vv = d[c] != LFP_ABSENT ? v : 0;
-                acc[c] = t >= e ? add_p(acc[c], vv) : sub_p(acc[c], vv);
+                const u64 vs = t >= e ? v : (v ? P - v : 0);      // - v mod p
+                acc96_add(acc[c], d[c] != LFP_ABSENT ? vs : 0);
             }
         }
     }
     // the 16 row groups of the block -> one sum per (column, coefficient)
     __shared__ u64 sm[16][NC][16];
 #pragma unroll
-    for (int c = 0; c < NC; c++) sm[r][c][t] = acc[c];
+    for (int c = 0; c < NC; c++) sm[r][c][t] = acc96_red(acc[c]);
     __syncthreads();
     for (int o = threadIdx.x; o < NC * 16; o += 256) {
         const int c = o >> 4, tt = o & 15;
