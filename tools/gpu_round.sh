@@ -22,7 +22,7 @@ bash $R/tools/gpu_sq.sh $tag C4
 bash $R/tools/gpu_step_trace.sh $tag C3
 bash $R/tools/gpu_step_trace.sh $tag C4
 # LatticeFold+ at 2^20 rows: stage timeline and kernel stats
-cd $R; LFPLUS_TIMELINE=1 timeout 600 python tools/bench_lfplus.py --nvars 20 --k 4 --fresh 3 --rounds 1 2>&1 | grep -v "round " | tail -26 > gpurun_out/${tag}_lfplus_p20.txt
+cd $R; LFPLUS_TIMELINE=1 timeout 600 python tools/bench_lfplus.py --nvars 20 --k 4 --fresh 3 --rounds 1 --resident 2>&1 | grep -v "round " | tail -26 > gpurun_out/${tag}_lfplus_p20.txt
 cd /tmp; rm -rf /tmp/prof_lfp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lfp -o p -- python $R/tools/bench_lfplus.py --nvars 20 --k 4 --fresh 3 --rounds 2 >/dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lfp -o p -- python $R/tools/bench_lfplus.py --nvars 20 --k 4 --fresh 3 --rounds 2 --resident >/dev/null 2>&1
 f=$(find /tmp/prof_lfp -name '*kernel_stats.csv' | head -1); cp "$f" $R/gpurun_out/${tag}_lfplus_ks_p20.csv
