@@ -358,6 +358,10 @@ def test_fold_step_gemm_rounds_match_oracle(ctx, name, monkeypatch):
             monkeypatch.delenv(k)
         want = sum(1 << (r - 1) for r in range(1, rounds + 1) if (m >> r) >= 64)
         assert ctx.fold_paths() == want, (rounds, extra, ctx.fold_paths())
+        if "LF_FOLD_ROUNDS_NO_SPLIT" in extra or "LF_FOLD_SPLIT_MIN" not in extra:      # (the default threshold is far above these sizes)
+            assert ctx.fold_split_rounds() == 0, (extra, ctx.fold_split_rounds())
+        elif wl.s >= 5 and wl.N % 4 == 0:                                               # rounds 4 and 5 took the split form (lf_last_fold_split_rounds)
+            assert ctx.fold_split_rounds() == 0b11000, (extra, bin(ctx.fold_split_rounds()))
         assert (proof == proof_o).all() and (lc == lc_o).all() and (w.f == f0_o).all(), (rounds, extra)
     monkeypatch.setenv("LF_FOLD_NO_SV", "1")
     lc, w, proof = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
