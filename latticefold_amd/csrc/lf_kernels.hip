@@ -848,25 +848,34 @@ void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u3
     for (u32 j = 0; j < nm && j < 4; j++) { ms.rowptr[j] = rowptr[j]; ms.col[j] = col[j]; ms.val[j] = val[j]; ms.z[j] = z + (size_t)j * z_stride; }
     LF_LAUNCH(k_spmv_sum, t.nu2p40, dim3(cdiv(rcnt, 256), 8), dim3(256), s, t, ms, ldz, out, m, r0, rcnt);
 }
+// block = 32 columns x 8 slots, the slots of a column side by side: a wave reads the 24 coefficient words of eight non-zeros as one contiguous 1.5 KB run (with
+// thread = column and one slot per block a load instruction touched 64 cache lines for 24 bytes each, eight blocks re-reading them: 63 us for 100 MB at 2^18
+// columns), the eq words of a row once for its eight slots; the sums cross LDS so that the stores are runs of 32 columns per output row.
 template <bool NU>
 __global__ void __launch_bounds__(256) k_spmv_t_eq(DevCrt t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
                                                    u64 *q, size_t n, size_t c0, size_t ccnt) {
-    size_t c = c0 + (size_t)blockIdx.x * 256 + threadIdx.x;   // columns [c0, c0 + ccnt): the slice a sharded rank's inner products read
-    u32 slot = blockIdx.y;
-    if (c >= c0 + ccnt) return;
+    const u32 cl = threadIdx.x >> 3, slot = threadIdx.x & 7;
+    const size_t cb = c0 + (size_t)blockIdx.x * 32, c = cb + cl;   // columns [c0, c0 + ccnt): the slice a sharded rank's inner products read
+    __shared__ u64 sm[24][33];
     Fq3 acc = fq3_zero();
-    for (u32 k = colptr[c]; k < colptr[c + 1]; k++) {
-        const u64 *v = val + (size_t)k * 24 + 3 * slot;
-        size_t r = rowidx[k];
-        acc = fq3_add(acc, M3<NU>(fq3_make(v[0], v[1], v[2]), fq3_make(eq[r], eq[m + r], eq[2 * m + r]), t.nu));
+    if (c < c0 + ccnt)
+        for (u32 k = colptr[c]; k < colptr[c + 1]; k++) {
+            const u64 *v = val + (size_t)k * 24 + 3 * slot;
+            size_t r = rowidx[k];
+            acc = fq3_add(acc, M3<NU>(fq3_make(v[0], v[1], v[2]), fq3_make(eq[r], eq[m + r], eq[2 * m + r]), t.nu));
+        }
+    sm[3 * slot][cl] = acc.c[0]; sm[3 * slot + 1][cl] = acc.c[1]; sm[3 * slot + 2][cl] = acc.c[2];
+    __syncthreads();
+    for (u32 o = threadIdx.x; o < 24 * 32; o += 256) {
+        const u32 row = o >> 5, cc = o & 31;
+        if (cb + cc < c0 + ccnt) q[(size_t)row * n + cb + cc] = sm[row][cc];
     }
-    st3(q, n, slot, c, acc);
 }
 void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m, u64 *q, size_t n,
                       hipStream_t s, size_t c0, size_t ccnt) {
     if (ccnt == (size_t)-1) { c0 = 0; ccnt = n; }
     if (!ccnt) return;
-    LF_LAUNCH(k_spmv_t_eq, t.nu2p40, dim3(cdiv(ccnt, 256), 8), dim3(256), s, t, colptr, rowidx, val, eq, m, q, n, c0, ccnt);
+    LF_LAUNCH(k_spmv_t_eq, t.nu2p40, dim3(cdiv(ccnt, 32)), dim3(256), s, t, colptr, rowidx, val, eq, m, q, n, c0, ccnt);
 }
 
 // ---------------------------------------------------------------------------------------------------------
