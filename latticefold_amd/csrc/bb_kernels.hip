@@ -610,25 +610,33 @@ void launch_spmv_sum(const DevBb &t, u32 nm, const u32 *const *rowptr, const u32
     for (u32 j = 0; j < nm && j < 4; j++) { ms.rowptr[j] = rowptr[j]; ms.col[j] = col[j]; ms.val[j] = val[j]; ms.z[j] = z + (size_t)j * z_stride; }
     hipLaunchKernelGGL(k_spmv_sum, dim3(cdiv(m, 256), 8), dim3(256), 0, s, t, ms, ldz, out, m);
 }
-// q[col] = sum_{rows} eq[row] * val  (CSC)
+// q[col] = sum_{rows} eq[row] * val  (CSC).  block = 32 columns x 8 slots, the slots of a column side by side (contiguous reads of the 72 coefficient words of a
+// non-zero, the eq words of a row shared by its eight slots); the sums cross LDS so that the stores are runs of 32 columns per output row (as lf::k_spmv_t_eq)
 __global__ void __launch_bounds__(256) k_spmv_t_eq(DevBb t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m,
                                                    fe *q, size_t n) {
-    size_t c0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    u32 slot = blockIdx.y;
-    if (c0 >= n) return;
+    const u32 cl = threadIdx.x >> 3, slot = threadIdx.x & 7;
+    const size_t cb = (size_t)blockIdx.x * 32, c0 = cb + cl;
+    __shared__ fe sm[RE][33];
     E9 acc = e9_zero();
-    for (u32 k = colptr[c0]; k < colptr[c0 + 1]; k++) {
-        E9 v, e;
-        size_t r = rowidx[k];
+    if (c0 < n)
+        for (u32 k = colptr[c0]; k < colptr[c0 + 1]; k++) {
+            E9 v, e;
+            size_t r = rowidx[k];
 #pragma unroll
-        for (int c = 0; c < TAU; c++) { v.c[c] = val[(size_t)k * RE + TAU * slot + c]; e.c[c] = eq[(size_t)c * m + r]; }
-        acc = e9_add(acc, e9_mul(v, e, t.nu));
+            for (int c = 0; c < TAU; c++) { v.c[c] = val[(size_t)k * RE + TAU * slot + c]; e.c[c] = eq[(size_t)c * m + r]; }
+            acc = e9_add(acc, e9_mul(v, e, t.nu));
+        }
+#pragma unroll
+    for (int c = 0; c < TAU; c++) sm[TAU * slot + c][cl] = acc.c[c];
+    __syncthreads();
+    for (u32 o = threadIdx.x; o < RE * 32; o += 256) {
+        const u32 row = o >> 5, cc = o & 31;
+        if (cb + cc < n) q[(size_t)row * n + cb + cc] = sm[row][cc];
     }
-    st9(q, n, slot, c0, acc);
 }
 void launch_spmv_t_eq(const DevBb &t, const u32 *colptr, const u32 *rowidx, const fe *val, const fe *eq, size_t m, fe *q, size_t n,
                       hipStream_t s) {
-    hipLaunchKernelGGL(k_spmv_t_eq, dim3(cdiv(n, 256), 8), dim3(256), 0, s, t, colptr, rowidx, val, eq, m, q, n);
+    hipLaunchKernelGGL(k_spmv_t_eq, dim3(cdiv(n, 32)), dim3(256), 0, s, t, colptr, rowidx, val, eq, m, q, n);
 }
 
 // batched inner products (evaluate_mles, utils/mle_helpers.rs:65-88, restructured as dot products)
