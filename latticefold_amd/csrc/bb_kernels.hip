@@ -51,9 +51,23 @@ __device__ __forceinline__ E9Pre e9p(const E9PreC &k) { E9Pre r; for (int i = 0;
 __device__ __forceinline__ fe fred(i64 s) { return fmul(mred(s), BB_R2C); }
 
 // sum of un-reduced product columns kept as (sum of high halves, sum of low halves); value = Montgomery-reduced total
-struct HL { i64 hi, lo; };
-__device__ __forceinline__ void hl_add(HL &a, i64 T) { a.hi += (T >> 32); a.lo += (i64)(u32)T; }
-__device__ __forceinline__ fe hl_finish(const HL &a) { return fadd(fred(a.hi), mred(a.lo)); }   // |hi|,|lo| sums < 2^62
+// (round 4: one signed 96-bit integer in three registers -- add with carry, carry, carry -- instead of two 64-bit sums: three instructions per column instead
+// of five and 9 registers less per lazy sum of an F_{p^9} product)
+struct HL { u32 a0, a1; int32_t a2; };
+__device__ __forceinline__ void hl_zero(HL &a) { a.a0 = 0; a.a1 = 0; a.a2 = 0; }
+__device__ __forceinline__ void hl_add(HL &a, i64 T) {
+    const u32 t0 = (u32)T, t1 = (u32)((u64)T >> 32);
+    const int32_t t2 = (int32_t)t1 >> 31;                     // sign extension word
+    asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, %2, %5, vcc"
+        : "+v"(a.a0), "+v"(a.a1), "+v"(a.a2)
+        : "v"(t0), "v"(t1), "v"(t2)
+        : "vcc");
+}
+// V = a2 2^64 + a1 2^32 + a0 (a2 signed): V 2^-32 mod p = a2 2^32 + a1 + a0 2^-32, centred Montgomery word like mred of the total
+__device__ __forceinline__ fe hl_finish(const HL &a) {
+    const i64 mid = (i64)a.a1;                                // < 2^32 < 2.2 p
+    return fadd(fadd(from_small(a.a2), fred(mid)), mred((i64)a.a0));
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // reductions: every thread holds NV signed 64-bit partial sums (of centred words)
@@ -486,7 +500,7 @@ __global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, 
     bool active = threadIdx.x < nout;
     HL acc[TAU];   // lazy: no Montgomery reduction inside the column loop
 #pragma unroll
-    for (int c = 0; c < TAU; c++) { acc[c].hi = 0; acc[c].lo = 0; }
+    for (int c = 0; c < TAU; c++) hl_zero(acc[c]);
     for (size_t jt = j0; jt < j1; jt += AJ_T) {
         u32 rowsA = kappa * TAU;
         for (u32 idx = threadIdx.x; idx < rowsA * AJ_T; idx += 256) {
@@ -1649,7 +1663,7 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
     const size_t jj = live ? j - a.pF0 : 0;   // index into the f-hat buffer (it starts at pair a.pF0 when sharded)
     HL C[4 * TAU];
 #pragma unroll
-    for (int i = 0; i < 4 * TAU; i++) { C[i].hi = 0; C[i].lo = 0; }
+    for (int i = 0; i < 4 * TAU; i++) hl_zero(C[i]);
 #pragma unroll 1
     for (u32 tb = tb0 + tq; tb < tb1; tb += Q) {
         const fe *Ft = F + ((size_t)tb * RE + TAU * slot) * ldF;
