@@ -1692,7 +1692,9 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
         H9 sp_c = h9_one(), sp_cinv = h9_one(), sp_binv = h9_one();
         const fe *Er = nullptr;
         size_t ldEr = 0;
-        if (fr_split && !sv_done && round >= 2 && round <= 5 && !sharded && ((lut_mode == 4 && !c->tn.fold_no_r4tab) || lut_mode == 7) && a.pcnt >= c->tn.fold_split_min) {
+        // (round 5 from the planes runs on two lanes per pair -- k_fold_round5_2l: all four products, unsplit -- unless LF_FOLD_R5_ONE_LANE=1)
+        if (fr_split && !sv_done && round >= 2 && round <= 5 && !sharded && ((lut_mode == 4 && !c->tn.fold_no_r4tab) || (lut_mode == 7 && c->tn.fold_r5_one_lane)) &&
+            a.pcnt >= c->tn.fold_split_min) {
             for (u32 k2 = 1; k2 < round; k2++) {
                 const H9 b = beta[k2 - 1], r = pt[k2 - 1];
                 sp_c = c->ring.mul9(sp_c, h9_add(c->ring.mul9(h9_sub(h9_one(), b), h9_sub(h9_one(), r)), c->ring.mul9(b, r)));

@@ -1276,6 +1276,19 @@ void launch_lin_round(const DevBb &t, const LinDesc &desc, const fe *mz, size_t 
 // ---------------------------------------------------------------------------------------------------------
 // folding sumcheck (comb fn nifs/folding/utils.rs:273-325, b = 2):
 //   g(X) = eqL G1 + eqR G2 + eqB * sum_{k<2K} sum_{d<9} mu_k^{d+1} h(f_{k,d}),  h(f) = f (f^2 - 1)
+// block sum of 32-bit words (a thread holds ONE pair's contribution: centred words, widened one at a time -- 45 registers instead of 90 in the epilogue)
+template <int NV>
+__device__ __forceinline__ void block_sum_store_fe(const fe (&v)[NV], i64 *dst) {
+    __shared__ i64 sm[4][NV];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        i64 s = wave_sum((i64)v[i]);
+        if (lane == 0) sm[wave][i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256) dst[i] = sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i];
+}
 // the eqL*G1 + eqR*G2 part at X = 0..4, added into acc[X][9]
 __device__ __forceinline__ void fold_linear_part(const DevBb &t, const FoldArgs &a, u32 slot, size_t j, i64 (&acc)[5 * TAU]) {
 #pragma unroll 1
@@ -1935,6 +1948,150 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         partial[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
     }
 }
+// Round 5 from the planes on TWO lanes per pair (mode 7's arithmetic, another thread mapping).  k_fold_round<., 7> keeps a whole pair in one thread: three or four
+// lazy sums (27 - 36 x 96 bits), both entries' look-ups and their products -- 298 registers, one wave per SIMD next to twelve L2 gathers per pair and table:
+// 2.2 ms for 8 192 pairs at C3 when round 4 (mode 6, two waves) takes 1.25 ms for twice as many.  Here lane e of a pair builds entry e only (X, Y, X Y, f^2, M f:
+// half the gathers and one reduced product per lane), gets the other entry's M f from its neighbour (nine lane swaps) and forms the two lazy products that use ITS
+// f^2: (M f_e)(f_e^2) and (M f_{1-e})(f_e^2) -- P0, P1 on lane 0, P3, P2 on lane 1: all four products of the cubic, balanced, so the round runs unsplit with the
+// G part inside.  Lane 0 collects the four sums at the end and finishes the pair as the MONO epilogue of k_fold_round does.
+template <bool NU2>
+__global__ void __launch_bounds__(256) k_fold_round5_2l(DevBb t, FoldArgs a, u32 K, E9PreC rfix, fe *Fout, size_t ldo, FoldLut lt, i64 *partial) {
+    __shared__ fe slut[4 * 81 * TAU];
+    for (u32 i = threadIdx.x; i < 4 * 81; i += 256) {
+        const E9 e = r5_entry(lt.lut, i / 81, i % 81, lt.rprev, rfix);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) slut[TAU * i + c] = e.c[c];
+    }
+    __syncthreads();
+    const u32 slot = blockIdx.y, en = threadIdx.x & 1;
+    const u32 ntab = 2 * K * TAU;
+    const size_t j = a.p0 + (size_t)blockIdx.x * 128 + (threadIdx.x >> 1);
+    const bool live = j < a.p0 + a.pcnt;
+    const size_t jj = live ? j - a.pF0 : 0;
+    HL CA[TAU], CB[TAU];
+    i64 SM[TAU];
+#pragma unroll
+    for (int c = 0; c < TAU; c++) { hl_zero(CA[c]); hl_zero(CB[c]); SM[c] = 0; }
+    auto ld = [&](const fe *base, u32 code, E9 &o) {
+        const int4 *q = reinterpret_cast<const int4 *>(base + 12 * code);
+        int4 a0 = q[0], a1 = q[1], a2 = q[2];
+        o.c[0] = a0.x; o.c[1] = a0.y; o.c[2] = a0.z; o.c[3] = a0.w; o.c[4] = a1.x; o.c[5] = a1.y; o.c[6] = a1.z; o.c[7] = a1.w; o.c[8] = a2.x;
+    };
+#pragma unroll 1
+    for (u32 tb = 0; tb < ntab; tb++) {
+        const u32 side = tb / (TAU * K), k = (tb / TAU) % K, d = tb % TAU;
+        const size_t pos = (size_t)32 * jj + 16 * en;
+        const int32_t *pl = (side ? lt.planesR : lt.planesL) + (size_t)(8 * d + slot) * lt.n_planes + pos;
+        int32_t v[16];
+        if (pos + 16 <= lt.n_planes && (lt.n_planes & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int4 w4 = *reinterpret_cast<const int4 *>(pl + 4 * q);
+                v[4 * q] = w4.x; v[4 * q + 1] = w4.y; v[4 * q + 2] = w4.z; v[4 * q + 3] = w4.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = pos + q < lt.n_planes ? pl[q] : 0;
+        }
+        const u32 c0 = digit_code4(v, k), c1 = digit_code4(v + 4, k), c2 = digit_code4(v + 8, k), c3 = digit_code4(v + 12, k);
+        const fe *t0 = slut + TAU * c0, *t1 = slut + TAU * (81 + c1), *t2 = slut + TAU * (162 + c2), *t3 = slut + TAU * (243 + c3);
+        const fe *mt = lt.mt5 + (size_t)tb * 4 * 81 * 12;
+        // (in stages with scheduling barriers between them: hoisting all twelve loads of the body to its top costs the second wave per SIMD)
+        E9 sq, mf, mfo;
+        {
+            E9 m0, m1;
+            ld(mt, c0, m0); ld(mt, 81 + c1, m1);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) mf.c[c] = fadd(m0.c[c], m1.c[c]);
+            ld(mt, 162 + c2, m0); ld(mt, 243 + c3, m1);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) mf.c[c] = fadd(mf.c[c], fadd(m0.c[c], m1.c[c]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            E9 X, Y;
+#pragma unroll
+            for (int c = 0; c < TAU; c++) { X.c[c] = fadd(t0[c], t1[c]); Y.c[c] = fadd(t2[c], t3[c]); }
+            if (live) {
+                fe *Fo = Fout + ((size_t)tb * RE + TAU * slot) * ldo + 2 * jj + en;
+#pragma unroll
+                for (int c = 0; c < TAU; c++) Fo[(size_t)c * ldo] = fadd(X.c[c], Y.c[c]);
+            }
+            sq = e9_mul_t<NU2>(X, Y, t.nu);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            E9 qx, qy;
+            ld(lt.xx5, c0 * 81 + c1, qx); ld(lt.yy5, c2 * 81 + c3, qy);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) sq.c[c] = fadd(fadd(qx.c[c], qy.c[c]), fadd(sq.c[c], sq.c[c]));
+        }
+#pragma unroll
+        for (int c = 0; c < TAU; c++) {
+            mfo.c[c] = __shfl_xor(mf.c[c], 1);
+            SM[c] += mf.c[c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const E9 sn = e9_times_nu_t<NU2>(sq, t.nu);
+        i64 T[TAU];
+        e9_mul_cols(mf, sq, sn, T);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) hl_add(CA[c], T[c]);
+        e9_mul_cols(mfo, sq, sn, T);
+#pragma unroll
+        for (int c = 0; c < TAU; c++) hl_add(CB[c], T[c]);
+    }
+    // lane 0: P0 = CA, P1 = CB, sp = SM; lane 1: P3 = CA, P2 = CB, su = SM
+    fe acc[5 * TAU];      // (32-bit words and one side of the G part at a time: this epilogue, not the table loop, set the kernel's register count)
+#pragma unroll
+    for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
+    E9 c0, c1, c2, c3;
+#pragma unroll
+    for (int c = 0; c < TAU; c++) {
+        const fe pa = hl_finish(CA[c]), pb = hl_finish(CB[c]), sm = fred(SM[c]);
+        const fe oa = __shfl_xor(pa, 1), ob = __shfl_xor(pb, 1), om = __shfl_xor(sm, 1);
+        const i64 P0 = pa, P1 = pb, P2 = ob, P3 = oa, sp = sm, su = om;     // (meaningful on lane 0)
+        c0.c[c] = fred(P0 - sp); c1.c[c] = fred(3 * (P1 - P0) - (su - sp));
+        c2.c[c] = fred(3 * (P2 - 2 * P1 + P0)); c3.c[c] = fred(P3 - 3 * P2 + 3 * P1 - P0);
+    }
+    if (live && en == 0) {
+        E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1);
+        E9 es = e9_sub(e1, e0), e = e0;
+#pragma unroll
+        for (int X = 0; X < 5; X++) {
+            if (X) e = e9_add(e, es);
+            E9 sv;
+#pragma unroll
+            for (int c = 0; c < TAU; c++)
+                sv.c[c] = fred((i64)c0.c[c] + (i64)c1.c[c] * X + (i64)c2.c[c] * (X * X) + (i64)c3.c[c] * (X * X * X));
+            E9 pr = e9_mul_t<NU2>(sv, e, t.nu);
+#pragma unroll
+            for (int c = 0; c < TAU; c++) acc[X * TAU + c] = pr.c[c];
+        }
+#pragma unroll 1
+        for (int side = 0; side < 2; side++) {       // the G part: eqL G1 + eqR G2 at X = 0..4
+            const fe *eq = side ? a.eqR : a.eqL;
+            const fe *G = side ? a.G2 : a.G1;
+            E9 q0 = ldq(eq, a.ld, 2 * j), q1 = ldq(eq, a.ld, 2 * j + 1);
+            E9 g0 = ld9(G, a.ld, slot, 2 * j), g1 = ld9(G, a.ld, slot, 2 * j + 1);
+            E9 qs = e9_sub(q1, q0), gs = e9_sub(g1, g0);
+#pragma unroll
+            for (int X = 0; X < 5; X++) {
+                if (X) { q0 = e9_add(q0, qs); g0 = e9_add(g0, gs); }
+                E9 p = e9_mul(q0, g0, t.nu);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) acc[X * TAU + c] = fadd(acc[X * TAU + c], p.c[c]);
+            }
+        }
+    }
+    __shared__ i64 red[5 * TAU];
+    block_sum_store_fe<5 * TAU>(acc, red);
+    __syncthreads();
+    if (threadIdx.x < 5 * TAU) {
+        u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
+        partial[(size_t)blockIdx.x * (5 * RE) + X * RE + TAU * slot + c] = red[threadIdx.x];
+    }
+}
 // rows of `partial` a general round may write (one block per 256 pairs, times the table chunks)
 size_t fold_partial_words(size_t m) {
     size_t rows = m / 8 / 256;          // the largest general round (round 3) has m/8 pairs
@@ -2025,6 +2182,14 @@ void launch_fold_round_lut_fix5(const DevBb &t, const FoldArgs &a, const int32_t
     if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_r5tab<true>), dim3(grid), dim3(256), 0, s, t, lut_dev, r3p, r4p, Mpre, ntab, xx_dev, yy_dev, mt_dev);
     else hipLaunchKernelGGL((k_fold_r5tab<false>), dim3(grid), dim3(256), 0, s, t, lut_dev, r3p, r4p, Mpre, ntab, xx_dev, yy_dev, mt_dev);
     FoldLut lt = {planesL, planesR, n_planes, lut_dev, nullptr, nullptr, nullptr, r3p, xx_dev, yy_dev, mt_dev, Esp, ldEsp};
+    static const bool one_lane = getenv("LF_FOLD_R5_ONE_LANE") != nullptr;
+    if (!Esp && !one_lane && Fout) {     // (unsplit callers: two lanes per pair, k_fold_round5_2l)
+        const u32 gb = (u32)((a.pcnt + 127) / 128);
+        if (t.nu == BB_TWO) hipLaunchKernelGGL((k_fold_round5_2l<true>), dim3(gb, 8), dim3(256), 0, s, t, a, K, r4p, Fout, ldout, lt, partial);
+        else hipLaunchKernelGGL((k_fold_round5_2l<false>), dim3(gb, 8), dim3(256), 0, s, t, a, K, r4p, Fout, ldout, lt, partial);
+        launch_reduce_rows(partial, gb, 5 * RE, out, s);
+        return;
+    }
     launch_fold_round_impl(t, a, nullptr, 0, K, Mpre, 7, r4p, Fout, ldout, lt, partial, out, s);
 }
 // the 81-entry table of modes 3 / 4: lut[code][c] = sum_b (t_b - 1) W_b[c], code = sum_b t_b 3^b, W = eq((r1, r2), .)

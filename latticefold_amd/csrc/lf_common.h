@@ -81,6 +81,7 @@ struct Tunables {
     bool i8_pair = false;            // LF_I8_PAIR: both decompositions' digit-plane commits in ONE launch (paired workgroups share the tiles of A in L2: A leaves
                                      // HBM once per step) instead of one launch per decomposition.  Opt-in: the same kernel time per step (4.2 vs 2 x 2.13 ms at C4), but
                                      // one 4 ms launch on 7/8 of the CUs slows the latency-bound linearization lane next to it (step 22.4 vs 21.8 ms)
+    bool fold_r5_one_lane = false;   // LF_FOLD_R5_ONE_LANE: (BabyBear) round 5 from the planes with one thread per pair (k_fold_round mode 7, split form) instead of two lanes per pair
     bool bb_lin_tail = false;        // LF_BB_LIN_TAIL: (BabyBear) persistent kernel for the small linearization rounds (k_lin_tail)
     bool bb_evals_first = false;     // LF_BB_EVALS_FIRST: (BabyBear) lane 1 runs the left evaluations before the left commit
     bool lin_no_r1cs = false;        // LF_LIN_NO_R1CS: (BabyBear) the R1CS shape through the generic linearization round kernel
@@ -132,6 +133,7 @@ struct Tunables {
         t.lin_no_r1cs = getenv("LF_LIN_NO_R1CS") != nullptr;
         t.bb_evals_first = getenv("LF_BB_EVALS_FIRST") != nullptr;
         t.bb_lin_tail = getenv("LF_BB_LIN_TAIL") != nullptr;
+        t.fold_r5_one_lane = getenv("LF_FOLD_R5_ONE_LANE") != nullptr;
         t.fold_no_small = getenv("LF_FOLD_NO_SMALL") != nullptr;
         if ((e = getenv("LF_FOLD_SV_MIN"))) t.sv_min = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_SV_ROUNDS"))) t.sv_rounds = atoi(e);

@@ -319,9 +319,11 @@ def test_fold_step_split_table_rounds_match_oracle(ctx, name, monkeypatch):
     m = 1 << wl.s
     base = {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_SPLIT_MIN": "1"}
     r5_ok = wl.s >= 5 and wl.N % 4 == 0 and m // 32 >= 1
-    cases = [({}, 0b01000), ({"LF_FOLD_R5_MIN": "1"}, 0b11000 if r5_ok else 0b01000), ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_SV_MIN": "64"}, 0b11000 if r5_ok else 0b01000),
-             ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_NO_SV": "1"}, 0b11000 if r5_ok else 0b01000), ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"}, 0),
-             ({"LF_FOLD_NO_R4TAB": "1"}, 0)]
+    # (round 5 from the planes: two lanes per pair and unsplit by default -- k_fold_round5_2l --, the one-thread split form with LF_FOLD_R5_ONE_LANE=1)
+    one = {"LF_FOLD_R5_MIN": "1", "LF_FOLD_R5_ONE_LANE": "1"}
+    cases = [({}, 0b01000), ({"LF_FOLD_R5_MIN": "1"}, 0b01000), (one, 0b11000 if r5_ok else 0b01000), (dict(one, LF_FOLD_SV_MIN="64"), 0b11000 if r5_ok else 0b01000),
+             (dict(one, LF_FOLD_NO_SV="1"), 0b11000 if r5_ok else 0b01000), ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_SV_MIN": "64"}, 0b01000),
+             ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"}, 0), (dict(one, LF_FOLD_ROUNDS_NO_SPLIT="1"), 0), ({"LF_FOLD_NO_R4TAB": "1"}, 0)]
     for extra, want in cases:
         env = dict(base, **extra)
         for k, v in env.items():
