@@ -1893,7 +1893,9 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
 #pragma unroll
         for (int c = 0; c < TAU; c++) hl_add(C[3 * TAU + c], T[c]);
     }
-    i64 acc[5 * TAU];
+    // (a thread holds ONE pair's contribution: 32-bit words, the G part one side at a time -- as 45 64-bit sums next to fold_linear_part's operands this epilogue,
+    // not the table loop, set the register count of every mode: 256 + 42..186 -> see the resource table in profiles/r04c_bb_fold_regs.txt)
+    fe acc[5 * TAU];
 #pragma unroll
     for (int i = 0; i < 5 * TAU; i++) acc[i] = 0;
     if (live && SPLIT) {
@@ -1909,39 +1911,57 @@ __global__ void __launch_bounds__(256) k_fold_round(DevBb t, FoldArgs a, const f
         for (int c = 0; c < TAU; c++) { acc[c] = a0.c[c]; acc[TAU + c] = a1.c[c]; acc[2 * TAU + c] = a2.c[c]; }
     } else
     if (live) {
-        if (blockIdx.z == 0 && tq == 0) fold_linear_part(t, a, slot, j, acc);
         // S(X) = C0 + C1 X + 3 C2 X^2 + C3 X^3
-        E9 c0, c1, c2, c3;
+        {
+            E9 c0, c1, c2, c3;
 #pragma unroll
-        for (int c = 0; c < TAU; c++) {
-            if (MONO) {
-                // C0 = P0 - sp, C1 = 3 (P1 - P0) - (su - sp), 3 C2 = 3 (P2 - 2 P1 + P0), C3 = P3 - 3 P2 + 3 P1 - P0   (values of a few p: one reduction)
-                i64 P0 = MODE == 5 ? (i64)fred(P0s[c]) : (i64)hl_finish(C[c]), P1 = hl_finish(C[TAU + c]), P2 = hl_finish(C[2 * TAU + c]);
-                i64 P3 = MODE == 5 ? (i64)fred(P3s[c]) : (i64)hl_finish(C[3 * TAU + c]);
-                i64 sp = fred(SP[c]), su = fred(SU[c]);
-                c0.c[c] = fred(P0 - sp); c1.c[c] = fred(3 * (P1 - P0) - (su - sp));
-                c2.c[c] = fred(3 * (P2 - 2 * P1 + P0)); c3.c[c] = fred(P3 - 3 * P2 + 3 * P1 - P0);
-            } else {
-                c0.c[c] = hl_finish(C[c]); c1.c[c] = hl_finish(C[TAU + c]);
-                c2.c[c] = fred(3 * (i64)hl_finish(C[2 * TAU + c])); c3.c[c] = hl_finish(C[3 * TAU + c]);
+            for (int c = 0; c < TAU; c++) {
+                if (MONO) {
+                    // C0 = P0 - sp, C1 = 3 (P1 - P0) - (su - sp), 3 C2 = 3 (P2 - 2 P1 + P0), C3 = P3 - 3 P2 + 3 P1 - P0   (values of a few p: one reduction)
+                    i64 P0 = MODE == 5 ? (i64)fred(P0s[c]) : (i64)hl_finish(C[c]), P1 = hl_finish(C[TAU + c]), P2 = hl_finish(C[2 * TAU + c]);
+                    i64 P3 = MODE == 5 ? (i64)fred(P3s[c]) : (i64)hl_finish(C[3 * TAU + c]);
+                    i64 sp = fred(SP[c]), su = fred(SU[c]);
+                    c0.c[c] = fred(P0 - sp); c1.c[c] = fred(3 * (P1 - P0) - (su - sp));
+                    c2.c[c] = fred(3 * (P2 - 2 * P1 + P0)); c3.c[c] = fred(P3 - 3 * P2 + 3 * P1 - P0);
+                } else {
+                    c0.c[c] = hl_finish(C[c]); c1.c[c] = hl_finish(C[TAU + c]);
+                    c2.c[c] = fred(3 * (i64)hl_finish(C[2 * TAU + c])); c3.c[c] = hl_finish(C[3 * TAU + c]);
+                }
+            }
+            E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1);
+            E9 es = e9_sub(e1, e0), e = e0;
+#pragma unroll
+            for (int X = 0; X < 5; X++) {
+                if (X) e = e9_add(e, es);
+                E9 sv;
+#pragma unroll
+                for (int c = 0; c < TAU; c++)
+                    sv.c[c] = fred((i64)c0.c[c] + (i64)c1.c[c] * X + (i64)c2.c[c] * (X * X) + (i64)c3.c[c] * (X * X * X));
+                E9 pr = e9_mul_t<NU2>(sv, e, t.nu);
+#pragma unroll
+                for (int c = 0; c < TAU; c++) acc[X * TAU + c] = pr.c[c];
             }
         }
-        E9 e0 = ldq(a.eqB, a.ld, 2 * j), e1 = ldq(a.eqB, a.ld, 2 * j + 1);
-        E9 es = e9_sub(e1, e0), e = e0;
+        if (blockIdx.z == 0 && tq == 0) {
+#pragma unroll 1
+            for (int side = 0; side < 2; side++) {       // the G part: eqL G1 + eqR G2 at X = 0..4
+                const fe *eq = side ? a.eqR : a.eqL;
+                const fe *G = side ? a.G2 : a.G1;
+                E9 q0 = ldq(eq, a.ld, 2 * j), q1 = ldq(eq, a.ld, 2 * j + 1);
+                E9 g0 = ld9(G, a.ld, slot, 2 * j), g1 = ld9(G, a.ld, slot, 2 * j + 1);
+                E9 qs = e9_sub(q1, q0), gs = e9_sub(g1, g0);
 #pragma unroll
-        for (int X = 0; X < 5; X++) {
-            if (X) e = e9_add(e, es);
-            E9 sv;
+                for (int X = 0; X < 5; X++) {
+                    if (X) { q0 = e9_add(q0, qs); g0 = e9_add(g0, gs); }
+                    E9 p = e9_mul(q0, g0, t.nu);
 #pragma unroll
-            for (int c = 0; c < TAU; c++)
-                sv.c[c] = fred((i64)c0.c[c] + (i64)c1.c[c] * X + (i64)c2.c[c] * (X * X) + (i64)c3.c[c] * (X * X * X));
-            E9 pr = e9_mul_t<NU2>(sv, e, t.nu);
-#pragma unroll
-            for (int c = 0; c < TAU; c++) acc[X * TAU + c] += pr.c[c];
+                    for (int c = 0; c < TAU; c++) acc[X * TAU + c] = fadd(acc[X * TAU + c], p.c[c]);
+                }
+            }
         }
     }
     __shared__ i64 red[5 * TAU];
-    block_sum_store<5 * TAU>(acc, red);
+    block_sum_store_fe<5 * TAU>(acc, red);
     __syncthreads();
     if (threadIdx.x < 5 * TAU) {
         u32 X = threadIdx.x / TAU, c = threadIdx.x % TAU;
