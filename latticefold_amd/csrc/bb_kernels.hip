@@ -783,25 +783,29 @@ __global__ void __launch_bounds__(256) k_lincomb_z(DevBb t, const fe *z, size_t 
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     u32 slot = blockIdx.y;
     if (i >= n) return;
-    i64 acc[4 * TAU];
+    // (the K products of an output stay lazy: their nine un-reduced column sums are added as 96-bit integers and reduced once -- nine Montgomery reductions per
+    // output instead of nine per product)
+    HL acc[4 * TAU];
 #pragma unroll
-    for (int q = 0; q < 4 * TAU; q++) acc[q] = 0;
+    for (int q = 0; q < 4 * TAU; q++) hl_zero(acc[q]);
 #pragma unroll 1
     for (u32 k = 0; k < K; k++) {
         E9 zk = ld9(z + (size_t)k * RE * ldz, ldz, slot, i);
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if ((u32)j < tt) {
-                E9 p = e9_mul(zk, e9p(coef[per_slot ? (size_t)(k * tt + j) * 8 + slot : (size_t)(k * tt + j)]));
+                const E9Pre cf = e9p(coef[per_slot ? (size_t)(k * tt + j) * 8 + slot : (size_t)(k * tt + j)]);
+                i64 T[TAU];
+                e9_mul_cols(zk, cf.v, cf.vn, T);
 #pragma unroll
-                for (int c = 0; c < TAU; c++) acc[j * TAU + c] += p.c[c];
+                for (int c = 0; c < TAU; c++) hl_add(acc[j * TAU + c], T[c]);
             }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if ((u32)j < tt) {
 #pragma unroll
-            for (int c = 0; c < TAU; c++) out[((size_t)j * RE + TAU * slot + c) * ldz + i] = fred(acc[j * TAU + c]);
+            for (int c = 0; c < TAU; c++) out[((size_t)j * RE + TAU * slot + c) * ldz + i] = hl_finish(acc[j * TAU + c]);
         }
 }
 void launch_lincomb_z(const DevBb &t, const fe *z, size_t ldz, u32 K, const E9PreC *coef, u32 tt, size_t n, fe *out, hipStream_t s, u32 per_slot) {
