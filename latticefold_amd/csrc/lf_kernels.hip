@@ -1217,6 +1217,13 @@ struct LinFix { Fq3Const r; u64 *mzo; size_t ldo; u64 *eqo; size_t ldeo; };
 // PAIR and no X in it -- the kernel sums E_i[p] * h(X, p) for the X of `xmask` only (the host multiplies by c_i eq(beta_i, X), derives the value at X = 1
 // from the previous round's message and extrapolates the top one: exact field arithmetic, the same message words).  `eq` is then E_i (one entry per pair;
 // FUSED: E_{i-1}, whose pair sums are E_i, stored through fx.eqo).  Half the products per pair of the plain form.
+// c_i[3 slot ..] of the by-value descriptor, read from the kernel-argument segment itself (constant memory; the descriptor is the second argument of every kernel
+// that takes it, behind DevCrt): indexing the by-value copy with i and slot would put it in scratch
+__device__ __forceinline__ const u64 *lin_desc_coef(const LinCombDesc &, u32 i, u32 slot) {
+    constexpr size_t off = (sizeof(DevCrt) + alignof(LinCombDesc) - 1) / alignof(LinCombDesc) * alignof(LinCombDesc);
+    const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+    return (const u64 *)(ka + off + offsetof(LinCombDesc, c)) + (size_t)i * 24 + 3 * slot;
+}
 template <bool NU, bool FUSED, bool SPLIT>
 __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, const u64 *mz, size_t ld, const u64 *eq, size_t ldeq, size_t n,
                                                    u32 deg, u64 *partial, LinFix fx, u32 xmask) {
@@ -1241,6 +1248,17 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
             *(ulonglong2 *)(op + 2 * ldout) = make_ulonglong2(f0.c[2], f1.c[2]);
         }
     };
+    // the unit coefficients of the tables' multisets, selected once (a dynamically indexed field of the by-value descriptor makes the compiler keep a copy of it in
+    // scratch memory: 128 bytes per lane, read twenty times per pair)
+    int cu_j[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u32 i = desc.ms[j];
+        int r = desc.c_unit[0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) r = i == (u32)q ? desc.c_unit[q] : r;
+        cu_j[j] = r;
+    }
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
         Fq3 v[4], st[4];
 #pragma unroll
@@ -1288,14 +1306,22 @@ __global__ void __launch_bounds__(256) k_lin_round(DevCrt t, LinCombDesc desc, c
                     if ((u32)j < desc.t) {
                         if (desc.first[j]) {  // wave-uniform
                             if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
-                            u32 i = desc.ms[j];
-                            if (desc.c_unit[i]) { term = v[j]; sgn = desc.c_unit[i]; }
-                            else { term = M3<NU>(fq3_make(desc.c[i][3 * slot], desc.c[i][3 * slot + 1], desc.c[i][3 * slot + 2]), v[j], t.nu); sgn = 1; }
+                            if (cu_j[j]) { term = v[j]; sgn = cu_j[j]; }
+                            else {
+                                const u64 *cp = lin_desc_coef(desc, desc.ms[j], slot);
+                                term = M3<NU>(fq3_make(cp[0], cp[1], cp[2]), v[j], t.nu); sgn = 1;
+                            }
                         } else term = M3<NU>(term, v[j], t.nu);
                     }
                 }
                 if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
-                acc[X] = fq3_add(acc[X], M3<NU>(res, ev, t.nu));
+                // (the loop over X stays rolled -- its body is seven products --, so acc[X] would be a dynamically indexed array: 120 bytes of scratch per lane)
+                const Fq3 gx = M3<NU>(res, ev, t.nu);
+                if (X == 0) acc[0] = fq3_add(acc[0], gx);
+                else if (X == 1) acc[1] = fq3_add(acc[1], gx);
+                else if (X == 2) acc[2] = fq3_add(acc[2], gx);
+                else if (X == 3) acc[3] = fq3_add(acc[3], gx);
+                else acc[4] = fq3_add(acc[4], gx);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = fq3_add(v[j], st[j]);
@@ -2740,7 +2766,12 @@ __global__ void __launch_bounds__(256) k_lin_tail(DevCrt t, LinCombDesc desc, Li
                         }
                     }
                     if (sgn) res = sgn < 0 ? fq3_sub(res, term) : fq3_add(res, term);
-                    acc[X] = fq3_add(acc[X], M3<NU>(res, ev, nu));
+                    const Fq3 gx = M3<NU>(res, ev, nu);      // (no acc[X]: the rolled loop would index the array dynamically -> scratch, as in k_lin_round)
+                    if (X == 0) acc[0] = fq3_add(acc[0], gx);
+                    else if (X == 1) acc[1] = fq3_add(acc[1], gx);
+                    else if (X == 2) acc[2] = fq3_add(acc[2], gx);
+                    else if (X == 3) acc[3] = fq3_add(acc[3], gx);
+                    else acc[4] = fq3_add(acc[4], gx);
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = fq3_add(v[j], st[j]);
                     ev = fq3_add(ev, es);
