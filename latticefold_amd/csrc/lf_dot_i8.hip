@@ -147,16 +147,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned char *yb = a.YB + (size_t)slot * 72 * a.ldq;
     const u32 last = s1 > s0 ? s1 - 1 : s0;
     auto colw = [&](u32 st) { return (size_t)(st < last ? st : last) * 64; };   // clamped: the tail re-loads the last step
-    u64 xa[16], xn[16];
-    v4i ba[5], bn[5];
+    // TWO K-steps in flight (the accumulators live in AGPRs, so 256 - 153 vector registers were idle: one step ahead left a wave -- the only one of its SIMD --
+    // with 8 KB outstanding, and the kernel at 2.5 TB/s)
+    u64 xa[16], xn[16], xm[16];
+    v4i ba[5], bn[5], bm[5];
     dot_load_x(xrow, colw(s0), g, a.n, xlive, xa); dot_load_y(yb, a.ldq, colw(s0) + 16 * g, row, a.nrows_y, ba);
-    for (u32 st = s0; st < s1; st++) {
-        dot_load_x(xrow, colw(st + 1), g, a.n, xlive, xn); dot_load_y(yb, a.ldq, colw(st + 1) + 16 * g, row, a.nrows_y, bn);   // next K-step in flight
+    dot_load_x(xrow, colw(s0 + 1), g, a.n, xlive && s0 + 1 < s1, xn); dot_load_y(yb, a.ldq, colw(s0 + 1) + 16 * g, row, a.nrows_y, bn);
+    // (three buffers in rotation, the loop unrolled by three: a register copy of a buffer would wait for its load at the end of the very step that issued it.  No
+    // exits inside the trip -- control flow around the MFMA block makes the compiler copy the tied accumulators: 359 spilled registers --: the last trip is padded
+    // with steps whose X words are zero)
+    auto ldx = [&](u32 st, u64 (&dst)[16]) { dot_load_x(xrow, colw(st), g, a.n, xlive && st < s1, dst); };
+    for (u32 st = s0; st < s1; st += 3) {
+        ldx(st + 2, xm); dot_load_y(yb, a.ldq, colw(st + 2) + 16 * g, row, a.nrows_y, bm);   // two K-steps ahead
         dot_step(acc, xa, ba);
-#pragma unroll
-        for (int t = 0; t < 16; t++) xa[t] = xn[t];
-#pragma unroll
-        for (int nt = 0; nt < 5; nt++) ba[nt] = bn[nt];
+        ldx(st + 3, xa); dot_load_y(yb, a.ldq, colw(st + 3) + 16 * g, row, a.nrows_y, ba);
+        dot_step(acc, xn, bn);
+        ldx(st + 4, xn); dot_load_y(yb, a.ldq, colw(st + 4) + 16 * g, row, a.nrows_y, bn);
+        dot_step(acc, xm, bm);
     }
     int32_t *o = a.part + ((size_t)unit * a.chunks + chunk) * (8 * 5 * 256);
 #pragma unroll
