@@ -75,6 +75,9 @@ void launch_cm_materialize(const int8_t *dig, const u64 *tau, size_t n, u64 *out
 void launch_to_mont(const u64 *in, size_t n, u64 *out, hipStream_t s);
 void launch_cm_h(const int8_t *Df, size_t n, u32 k, const int32_t *sp, u64 *h, hipStream_t s);
 void launch_cm_g(const u64 *tau, const int8_t *mtau, const u64 *f, const u64 *h, size_t n, const CmShort &s, u64 *g, hipStream_t st);
+// the round with fix_variables of the previous round fused in (S / R: the previous tables, 4 entries per new pair; the fixed tables go to So / Ro, ld_o entries per table)
+void launch_cm_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 rM, u64 *So, u64 *Ro, size_t ld_o, u64 *part,
+                           hipStream_t s);
 u32 cm_round_blocks(size_t half);
 void launch_cm_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 *part /* blocks * 48 */, hipStream_t s);
 void launch_cm_fix(const u64 *in, size_t ld_in, u64 *out, size_t ld_out, u32 w, u32 ntab, size_t half, u64 rM, hipStream_t s);

@@ -1002,6 +1002,12 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         size_t ld = nl, len = nl;
         int w = 0;
         bool dist = shd;
+        // unsharded: fix_variables is deferred into the next round's kernel (k_cm_round_fused: one read of the previous tables, one write of the fixed ones, one
+        // launch per round); `pending` = the challenge whose fix has not been applied to Sc / Rc yet.  LFPLUS_CM_UNFUSED=1: separate k_cm_fix passes.
+        static const bool unfused = getenv("LFPLUS_CM_UNFUSED") != nullptr;
+        const bool fuse = !shd && !unfused;
+        bool pending = false;
+        u64 rpend = 0;
         for (u32 rnd = 0; rnd < nvars; rnd++) {
             if (dist && len == 1) {      // one entry per table and rank left: gather (entry index = rank), finish replicated
                 int rcg = gather_tables(c, Sc, ld, nS, 1, Sg.as<u64>());
@@ -1011,13 +1017,21 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
                 ld = len = (size_t)c->world;
                 dist = false;
             }
-            const size_t half = len / 2;
+            const size_t half = pending ? len / 4 : len / 2;       // pairs this round evaluates
             const u32 nb = lfp::cm_round_blocks(half);
             auto tA = std::chrono::steady_clock::now();
             // up to 256 blocks write their partial sums straight into mapped host memory (the host adds them); the large rounds need more workgroups than that to
             // reach the HBM rate (6.3 GB of tables in round 0 at 2^20 rows: 5.4 ms with 256 blocks, 1.8 ms with 4096) and add theirs on the device
             const bool dev_sum = nb > LFP_HOST_SUM_BLOCKS;
-            lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), dev_sum ? part.as<u64>() : c->hpin_dev, c->st);
+            u64 *pdst = dev_sum ? part.as<u64>() : c->hpin_dev;
+            if (pending) {
+                const size_t ldo = w == 0 ? nl / 2 : nl / 4 + 1;
+                lfp::launch_cm_round_fused(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), to_mont(rpend), Sw[w].as<u64>(), Rw[w].as<u64>(), ldo, pdst, c->st);
+                Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
+                len /= 2;
+                pending = false;
+            } else
+                lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), pdst, c->st);
             if (dev_sum) lfp::launch_reduce(part.as<u64>(), nb, 48, c->hpin_dev, 0, c->kappa, 0, 2, 0, nullptr, c->st);
             HIPCHK(c, hipStreamSynchronize(c->st));
             auto tB = std::chrono::steady_clock::now();
@@ -1033,11 +1047,14 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             const u64 r = tr->challenge();
             tr->absorb_const(r);
             rop[rnd] = r;
-            const size_t ldo = w == 0 ? nl / 2 : nl / 4 + 1;
-            lfp::launch_cm_fix(Sc, ld, Sw[w].as<u64>(), ldo, 1, nS, half, to_mont(r), c->st);
-            lfp::launch_cm_fix(Rc, ld, Rw[w].as<u64>(), ldo, D, nR, half, to_mont(r), c->st);
-            Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
-            len = half;
+            if (fuse && rnd + 1 < nvars) { pending = true; rpend = r; }     // (the last challenge is applied below: the evaluations need the fully fixed tables)
+            else {
+                const size_t ldo = w == 0 ? nl / 2 : nl / 4 + 1;
+                lfp::launch_cm_fix(Sc, ld, Sw[w].as<u64>(), ldo, 1, nS, half, to_mont(r), c->st);
+                lfp::launch_cm_fix(Rc, ld, Rw[w].as<u64>(), ldo, D, nR, half, to_mont(r), c->st);
+                Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
+                len = half;
+            }
             if (g_tl.on) fprintf(stderr, "[lfplus]   cm round %2u: gpu+sync %6.1f us, host + fix launches %6.1f us (nb %u)\n", rnd, std::chrono::duration<double, std::micro>(tB - tA).count(),
                                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tB).count(), nb);
         }

@@ -410,6 +410,69 @@ __global__ void __launch_bounds__(256) k_cm_round(const u64 *S, size_t lds, cons
         part[(size_t)blockIdx.x * 48 + threadIdx.x] = t;
     }
 }
+// The same round with fix_variables of the PREVIOUS round fused in: S / R are the previous tables (2 * half pairs of entries: 4 per new pair), every value is
+// fixed with rM (Montgomery) on the way -- f = lo + r (hi - lo) -- and stored to So / Ro (ld_o entries per table) for the next round.  A table entry is used by
+// exactly one thread of the round kernel, so the separate k_cm_fix pass (read T, write T/2) and the round's own read (T/2) become one read of T and one write of
+// T/2: a fifth of a sumchecker's traffic, and one launch per round instead of three.
+__global__ void __launch_bounds__(256) k_cm_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, CmDesc d, const u64 *rcp, u64 rM, u64 *So, u64 *Ro,
+                                                        size_t ld_o, u64 *part) {
+    const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const u32 per = 4 + 4 * d.nM, nring = d.L * (per - 1);
+    u64 s[3] = {0, 0, 0};
+    auto fixw = [&](u64 lo, u64 hi) { return add_p(lo, mont_mul(rM, sub_p(hi, lo))); };
+    // ring table `tb` at the new pair b: the two fixed entries (stored), coefficient c
+    auto ringpair = [&](u32 tb, size_t b, u64 &v0, u64 &v1) {
+        const u64 *rp = R + ((size_t)tb * ldr + 4 * b) * 16 + c;
+        v0 = fixw(rp[0], rp[16]); v1 = fixw(rp[32], rp[48]);
+        u64 *op = Ro + ((size_t)tb * ld_o + 2 * b) * 16 + c;
+        op[0] = v0; op[16] = v1;
+    };
+    auto scalpair = [&](u32 tb, size_t b, u64 &v0, u64 &v1) {
+        const u64 *sp = S + (size_t)tb * lds + 4 * b;
+        v0 = fixw(sp[0], sp[1]); v1 = fixw(sp[2], sp[3]);
+        if (c == 0) { So[(size_t)tb * ld_o + 2 * b] = v0; So[(size_t)tb * ld_o + 2 * b + 1] = v1; }
+    };
+    for (size_t b = (size_t)blockIdx.x * 16 + pl; b < half; b += (size_t)gridDim.x * 16) {
+        u64 e0, e1, a0, a1, b0, b1;
+        scalpair(0, b, e0, e1);
+        const u64 e2 = add_p(e1, sub_p(e1, e0));
+        ringpair(nring, b, a0, a1); ringpair(nring + 1, b, b0, b1);
+        const u64 rz = rcp[d.L * per], rz1 = rcp[d.L * per + 1];
+        const u64 z0 = add_p(mont_mul(rz, a0), mont_mul(rz1, b0)), z1 = add_p(mont_mul(rz, a1), mont_mul(rz1, b1)), z2 = add_p(z1, sub_p(z1, z0));
+        for (u32 l = 0; l < d.L; l++) {
+            u64 m0, m1;
+            scalpair(1 + l, b, m0, m1);
+            const u64 m2 = add_p(m1, sub_p(m1, m0));
+            u64 in0 = 0, in1 = 0, in2 = 0;
+            if (c == 0) {
+                const u64 r0 = rcp[l * per];
+                in0 = mont_mul(r0, from_mont(m0)); in1 = mont_mul(r0, from_mont(m1)); in2 = mont_mul(r0, from_mont(m2));
+            }
+            for (u32 j = 1; j < per; j++) {
+                u64 v0, v1;
+                ringpair(l * (per - 1) + j - 1, b, v0, v1);
+                const u64 v2 = add_p(v1, sub_p(v1, v0)), rj = rcp[l * per + j];
+                in0 = add_p(in0, mont_mul(rj, v0)); in1 = add_p(in1, mont_mul(rj, v1)); in2 = add_p(in2, mont_mul(rj, v2));
+            }
+            s[0] = add_p(s[0], add_p(mont_mul(e0, in0), mont_mul(m0, z0)));
+            s[1] = add_p(s[1], add_p(mont_mul(e1, in1), mont_mul(m1, z1)));
+            s[2] = add_p(s[2], add_p(mont_mul(e2, in2), mont_mul(m2, z2)));
+        }
+    }
+    __shared__ u64 sm[3][16][16];
+    for (int x = 0; x < 3; x++) sm[x][pl][c] = s[x];
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const u32 x = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[x][p][cc]);
+        part[(size_t)blockIdx.x * 48 + threadIdx.x] = t;
+    }
+}
+void launch_cm_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 rM, u64 *So, u64 *Ro, size_t ld_o, u64 *part,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_cm_round_fused, dim3(cm_round_blocks(half)), dim3(256), 0, s, S, lds, R, ldr, half, d, rcp, rM, So, Ro, ld_o, part);
+}
 // (the host adds the block partials -- 48 / 64 words each, read from mapped memory -- before it can run the transcript: one block per CU at most)
 // workgroups of a sumcheck round (16 pairs per workgroup and pass; up to 2048: one per CU leaves a memory-bound round at 1/3 of the HBM rate).  Above 256 the
 // driver adds the block partials on the device (launch_reduce) instead of on the host.  LFPLUS_ROUND_BLOCKS moves the cap
