@@ -1302,6 +1302,11 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     size_t ld = nl, len = nl;
     int w = 1;
     bool dist = c->sharded();
+    // unsharded: fix_variables is deferred into the next round's kernel (k_r1cs_round_fused), as in Cm::prove
+    static const bool unfused = getenv("LFPLUS_CM_UNFUSED") != nullptr;
+    const bool fuse = !c->sharded() && !unfused;
+    bool pending = false;
+    u64 xpend = 0;
     for (u32 rnd = 0; rnd < nvars; rnd++) {
         if (dist && len == 1) {      // one entry per table and rank left: gather (entry index = rank), finish replicated
             int rcg = gather_tables(c, Ec, ld, 1, 1, Eg.as<u64>());
@@ -1311,11 +1316,20 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
             ld = len = (size_t)c->world;
             dist = false;
         }
-        const size_t half = len / 2;
+        const size_t half = pending ? len / 4 : len / 2;
         const u32 nb = lfp::cm_round_blocks(half);
         auto tA = std::chrono::steady_clock::now();
         const bool dev_sum = nb > LFP_HOST_SUM_BLOCKS;     // (as in Cm::prove: small rounds write block partials into mapped host memory, large ones add them on the device)
-        lfp::launch_r1cs_round(Ec, Gc, ld, half, dev_sum ? part.as<u64>() : c->hpin_dev, c->st);
+        u64 *pdst = dev_sum ? part.as<u64>() : c->hpin_dev;
+        if (pending) {
+            const size_t ldo = nl / 2;
+            u64 *Eo = w ? E[1].as<u64>() : E[0].as<u64>(), *Go = w ? G[1].as<u64>() : G[0].as<u64>();
+            lfp::launch_r1cs_round_fused(Ec, Gc, ld, half, to_mont(xpend), Eo, Go, ldo, pdst, c->st);
+            Ec = Eo; Gc = Go; ld = ldo; w ^= 1;
+            len /= 2;
+            pending = false;
+        } else
+            lfp::launch_r1cs_round(Ec, Gc, ld, half, pdst, c->st);
         if (dev_sum) lfp::launch_reduce(part.as<u64>(), nb, 64, c->hpin_dev, 0, c->kappa, 0, 2, 0, nullptr, c->st);
         HIPCHK(c, hipStreamSynchronize(c->st));
         auto tB = std::chrono::steady_clock::now();
@@ -1331,13 +1345,16 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
         const u64 x = tr->challenge();
         tr->absorb_const(x);
         ro[rnd] = x;
-        // in-place is not safe (entry b is written while 2b, 2b + 1 of another thread are read): alternate buffers; both hold nl / 2 entries
-        const size_t ldo = nl / 2;
-        u64 *Eo = w ? E[1].as<u64>() : E[0].as<u64>(), *Go = w ? G[1].as<u64>() : G[0].as<u64>();
-        lfp::launch_cm_fix(Ec, ld, Eo, ldo, 1, 1, half, to_mont(x), c->st);
-        lfp::launch_cm_fix(Gc, ld, Go, ldo, D, 3, half, to_mont(x), c->st);
-        Ec = Eo; Gc = Go; ld = ldo; w ^= 1;
-        len = half;
+        if (fuse && rnd + 1 < nvars) { pending = true; xpend = x; }
+        else {
+            // in-place is not safe (entry b is written while 2b, 2b + 1 of another thread are read): alternate buffers; both hold nl / 2 entries
+            const size_t ldo = nl / 2;
+            u64 *Eo = w ? E[1].as<u64>() : E[0].as<u64>(), *Go = w ? G[1].as<u64>() : G[0].as<u64>();
+            lfp::launch_cm_fix(Ec, ld, Eo, ldo, 1, 1, half, to_mont(x), c->st);
+            lfp::launch_cm_fix(Gc, ld, Go, ldo, D, 3, half, to_mont(x), c->st);
+            Ec = Eo; Gc = Go; ld = ldo; w ^= 1;
+            len = half;
+        }
         if (g_tl.on) fprintf(stderr, "[lfplus]   r1cs round %2u: gpu+sync %6.1f us, host + fix launches %6.1f us (nb %u)\n", rnd, std::chrono::duration<double, std::micro>(tB - tA).count(),
                              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tB).count(), nb);
     }

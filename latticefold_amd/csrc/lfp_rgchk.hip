@@ -544,6 +544,62 @@ __global__ void __launch_bounds__(256) k_r1cs_round(const u64 *E, const u64 *G, 
         part[(size_t)blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
+// the same round with fix_variables of the previous round fused in (as k_cm_round_fused): E / G are the previous tables (4 entries per new pair), fixed with rM on
+// the way and stored to Eo / Go (ld_o entries per table)
+__global__ void __launch_bounds__(256) k_r1cs_round_fused(const u64 *E, const u64 *G, size_t ld, size_t half, u64 rM, u64 *Eo, u64 *Go, size_t ld_o, u64 *part) {
+    const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    __shared__ u64 la[16][16], lb[16][16];
+    u64 s[4] = {0, 0, 0, 0};
+    auto fixw = [&](u64 lo, u64 hi) { return add_p(lo, mont_mul(rM, sub_p(hi, lo))); };
+    for (size_t base = (size_t)blockIdx.x * 16; base < half; base += (size_t)gridDim.x * 16) {
+        const size_t b = base + pl;
+        const bool ok = b < half;
+        u64 ex = 0, de = 0, ax = 0, da = 0, bx = 0, db = 0, cx = 0, dc = 0;
+        if (ok) {
+            const u64 e0 = fixw(E[4 * b], E[4 * b + 1]), e1 = fixw(E[4 * b + 2], E[4 * b + 3]);
+            if (c == 0) { Eo[2 * b] = e0; Eo[2 * b + 1] = e1; }
+            ex = e0; de = sub_p(e1, e0);
+            u64 v0[3], v1[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const u64 *gp = G + ((size_t)q * ld + 4 * b) * 16 + c;
+                v0[q] = fixw(gp[0], gp[16]); v1[q] = fixw(gp[32], gp[48]);
+                u64 *op = Go + ((size_t)q * ld_o + 2 * b) * 16 + c;
+                op[0] = v0[q]; op[16] = v1[q];
+            }
+            ax = v0[0]; da = sub_p(v1[0], ax);
+            bx = v0[1]; db = sub_p(v1[1], bx);
+            cx = v0[2]; dc = sub_p(v1[2], cx);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            if (x) { ex = add_p(ex, de); ax = add_p(ax, da); bx = add_p(bx, db); cx = add_p(cx, dc); }
+            la[pl][c] = to_mont(ax);
+            lb[pl][c] = bx;
+            __syncthreads();
+            u64 t = 0;
+#pragma unroll
+            for (u32 j = 0; j < 16; j++) {
+                const u64 pr = mont_mul(la[pl][j], lb[pl][(c - j) & 15]);
+                t = j <= c ? add_p(t, pr) : sub_p(t, pr);
+            }
+            s[x] = add_p(s[x], mont_mul(ex, sub_p(t, cx)));
+            __syncthreads();
+        }
+    }
+    __shared__ u64 sm[4][16][16];
+    for (int x = 0; x < 4; x++) sm[x][pl][c] = s[x];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const u32 x = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[x][p][cc]);
+        part[(size_t)blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
+void launch_r1cs_round_fused(const u64 *E, const u64 *G, size_t ld, size_t half, u64 rM, u64 *Eo, u64 *Go, size_t ld_o, u64 *part, hipStream_t s) {
+    hipLaunchKernelGGL(k_r1cs_round_fused, dim3(cm_round_blocks(half)), dim3(256), 0, s, E, G, ld, half, rM, Eo, Go, ld_o, part);
+}
 void launch_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part, hipStream_t s) {
     hipLaunchKernelGGL(k_r1cs_round, dim3(cm_round_blocks(half)), dim3(256), 0, s, E, G, ld, half, part);
 }
