@@ -2897,6 +2897,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     LF_TRACE(c, "theta/eta");
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     LF_TRACE(c, "fold_witness");
+    TL_MARK("  eta absorbed, rho drawn, fold_witness enqueued");
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
     {
@@ -2939,6 +2940,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         for (u32 i = 0; i < K2; i++) { c->ring.mul_ntt(&rho[(size_t)i * 24], part(i) + ((size_t)P.s + 3 + P.kappa + P.t + q2) * 24, tmp); HostRing::add(o, tmp, o); }
     }
     }
+    TL_MARK("  folded instance on the host");
     HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c, npl, N, c->device, N * 24 * 4};
     TL_MARK(" rho + fold_witness");
