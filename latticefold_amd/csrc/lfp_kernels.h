@@ -81,6 +81,12 @@ void launch_cm_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, s
 u32 cm_round_blocks(size_t half);
 void launch_cm_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, const CmDesc &d, const u64 *rcp, u64 *part /* blocks * 48 */, hipStream_t s);
 void launch_cm_fix(const u64 *in, size_t ld_in, u64 *out, size_t ld_out, u32 w, u32 ntab, size_t half, u64 rM, hipStream_t s);
+// the sumcheckers through batched tables (S2 = eq | V, R2 = U | Z: lfp_rgchk.hip); evaluations of ring tables at the point of `eq` (part: cm_eval_chunks(n) * ntab * 16)
+void launch_cm_combine(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t n, const CmDesc &d, const u64 *rcp, u64 *S2, u64 *R2, size_t ld2, hipStream_t s);
+void launch_cm2_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, u64 *part /* blocks * 48 */, hipStream_t s);
+void launch_cm2_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, u64 rM, u64 *So, u64 *Ro, size_t ld_o, u64 *part, hipStream_t s);
+u32 cm_eval_chunks(size_t n);
+void launch_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, u64 *part, u64 *out, hipStream_t s);
 // ---- ComR1CS::linearize (r1cs.rs:76-139): degree-3 round of eq (ga gb - gc); part: cm_round_blocks(half) * 64
 void launch_r1cs_round_fused(const u64 *E, const u64 *G, size_t ld, size_t half, u64 rM, u64 *Eo, u64 *Go, size_t ld_o, u64 *part, hipStream_t s);   // + fix_variables of the previous round (E / G: previous tables)
 void launch_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part, hipStream_t s);

@@ -944,12 +944,19 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     // Sharded: every table holds the rank's nl rows; the M_q x rows read x at arbitrary columns, so their inputs are whole vectors -- tau, m_tau and f are whole
     // on every rank already, h is all-gathered (n ring elements per instance: the one large exchange of Cm::prove)
     const u32 per = 4 + 4 * nM, nring = L * (per - 1), nS = 1 + L, nR = nring + 2;
-    DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring, mtring, hwhole, Sg, Rg;
+    // The sumcheckers run over the BATCHED tables (eq, V | U, Z: lfp_rgchk.hip, k_cm_combine): kS = kR = 2 tables per round instead of nS and nR.
+    // LFPLUS_CM_FULL=1 keeps the rounds over all the instance tables (the reference's own shape; the parity tests run both)
+    const bool cm_full = getenv("LFPLUS_CM_FULL") != nullptr;      // (read per call: the tests flip it)
+    const bool batched = !cm_full;
+    const u32 kS = batched ? 2 : nS, kR = batched ? 2 : nR;
+    DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring, mtring, hwhole, Sg, Rg, S2, R2, eqro, evpart;
     const u32 nb0 = lfp::cm_round_blocks(nl / 2);
-    if (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8) || Sw[0].alloc((size_t)nS * (nl / 2) * 8) || Sw[1].alloc((size_t)nS * (nl / 4 + 1) * 8) ||
-        Rw[0].alloc((size_t)nR * (nl / 2) * D * 8) || Rw[1].alloc((size_t)nR * (nl / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
+    if (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8) || Sw[0].alloc((size_t)kS * (nl / 2) * 8) || Sw[1].alloc((size_t)kS * (nl / 4 + 1) * 8) ||
+        Rw[0].alloc((size_t)kR * (nl / 2) * D * 8) || Rw[1].alloc((size_t)kR * (nl / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
         part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)) || (nM && shd && (mtring.alloc(n * D * 8) || hwhole.alloc(n * D * 8))) ||
-        (shd && (Sg.alloc((size_t)nS * c->world * 8) || Rg.alloc((size_t)nR * c->world * D * 8))))
+        (shd && (Sg.alloc((size_t)kS * c->world * 8) || Rg.alloc((size_t)kR * c->world * D * 8))) ||
+        (batched && (S2.alloc((size_t)2 * nl * 8) || R2.alloc((size_t)2 * nl * D * 8) || eqro.alloc(nl * 8) ||
+                     evpart.alloc(std::max((size_t)lfp::cm_eval_chunks(nl) * nring * D, (size_t)lfp::eval_chunks(nl) * 4) * 8))))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm tables)");
     u64 *S = S0.as<u64>(), *R = R0.as<u64>();
     HIPCHK(c, hipMemcpyAsync(S, so.eqr.as<u64>() + row0, nl * 8, hipMemcpyDeviceToDevice, c->st));
@@ -999,6 +1006,10 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         tr->absorb_const(nvars);
         tr->absorb_const(2);
         const u64 *Sc = S, *Rc = R;
+        if (batched) {
+            lfp::launch_cm_combine(S, nl, R, nl, nl, desc, rcpd.as<u64>(), S2.as<u64>(), R2.as<u64>(), nl, c->st);
+            Sc = S2.as<u64>(); Rc = R2.as<u64>();
+        }
         size_t ld = nl, len = nl;
         int w = 0;
         bool dist = shd;
@@ -1010,8 +1021,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         u64 rpend = 0;
         for (u32 rnd = 0; rnd < nvars; rnd++) {
             if (dist && len == 1) {      // one entry per table and rank left: gather (entry index = rank), finish replicated
-                int rcg = gather_tables(c, Sc, ld, nS, 1, Sg.as<u64>());
-                if (!rcg) rcg = gather_tables(c, Rc, ld, nR, D, Rg.as<u64>());
+                int rcg = gather_tables(c, Sc, ld, kS, 1, Sg.as<u64>());
+                if (!rcg) rcg = gather_tables(c, Rc, ld, kR, D, Rg.as<u64>());
                 if (rcg) return rcg;
                 Sc = Sg.as<u64>(); Rc = Rg.as<u64>();
                 ld = len = (size_t)c->world;
@@ -1026,11 +1037,14 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             u64 *pdst = dev_sum ? part.as<u64>() : c->hpin_dev;
             if (pending) {
                 const size_t ldo = w == 0 ? nl / 2 : nl / 4 + 1;
-                lfp::launch_cm_round_fused(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), to_mont(rpend), Sw[w].as<u64>(), Rw[w].as<u64>(), ldo, pdst, c->st);
+                if (batched) lfp::launch_cm2_round_fused(Sc, ld, Rc, ld, half, to_mont(rpend), Sw[w].as<u64>(), Rw[w].as<u64>(), ldo, pdst, c->st);
+                else lfp::launch_cm_round_fused(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), to_mont(rpend), Sw[w].as<u64>(), Rw[w].as<u64>(), ldo, pdst, c->st);
                 Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
                 len /= 2;
                 pending = false;
-            } else
+            } else if (batched)
+                lfp::launch_cm2_round(Sc, ld, Rc, ld, half, pdst, c->st);
+            else
                 lfp::launch_cm_round(Sc, ld, Rc, ld, half, desc, rcpd.as<u64>(), pdst, c->st);
             if (dev_sum) lfp::launch_reduce(part.as<u64>(), nb, 48, c->hpin_dev, 0, c->kappa, 0, 2, 0, nullptr, c->st);
             HIPCHK(c, hipStreamSynchronize(c->st));
@@ -1048,10 +1062,11 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
             tr->absorb_const(r);
             rop[rnd] = r;
             if (fuse && rnd + 1 < nvars) { pending = true; rpend = r; }     // (the last challenge is applied below: the evaluations need the fully fixed tables)
+            else if (batched && rnd + 1 == nvars) len = half;               // (batched: the evaluations come from the original tables, nothing reads a last fix)
             else {
                 const size_t ldo = w == 0 ? nl / 2 : nl / 4 + 1;
-                lfp::launch_cm_fix(Sc, ld, Sw[w].as<u64>(), ldo, 1, nS, half, to_mont(r), c->st);
-                lfp::launch_cm_fix(Rc, ld, Rw[w].as<u64>(), ldo, D, nR, half, to_mont(r), c->st);
+                lfp::launch_cm_fix(Sc, ld, Sw[w].as<u64>(), ldo, 1, kS, half, to_mont(r), c->st);
+                lfp::launch_cm_fix(Rc, ld, Rw[w].as<u64>(), ldo, D, kR, half, to_mont(r), c->st);
                 Sc = Sw[w].as<u64>(); Rc = Rw[w].as<u64>(); ld = ldo; w ^= 1;
                 len = half;
             }
@@ -1061,10 +1076,22 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         // evals (cm.rs:313-331): every instance table at ro = the fully fixed tables
         DevBuf evd;
         if (evd.alloc(evh.size() * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (evals)");
-        HIPCHK(c, hipMemcpy2DAsync(evd.p, D * 8, Rc, ld * D * 8, D * 8, nR, hipMemcpyDeviceToDevice, c->st));
-        HIPCHK(c, hipMemcpy2DAsync(evd.as<u64>() + (size_t)nR * D, 8, Sc, ld * 8, 8, nS, hipMemcpyDeviceToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(evh.data(), evd.p, evh.size() * 8, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (batched) {     // T(ro) = sum_b eq(ro, b) T(b) over the rank's rows of the ORIGINAL instance tables (ring) and of the tau_l (scalars, Montgomery)
+            eq_build_local(c, rop, nvars, eqro.as<u64>());
+            lfp::launch_cm_evals(R, nl, nl, eqro.as<u64>(), nring, evpart.as<u64>(), evd.as<u64>(), c->st);
+            for (u32 l = 0; l < L; l++)
+                lfp::launch_wdot(eqro.as<u64>(), 1, 1, S + (size_t)(1 + l) * nl, nl, evpart.as<u64>(), evd.as<u64>() + (size_t)nR * D + 1 + l, c->st);
+            HIPCHK(c, hipMemcpyAsync(evh.data(), evd.p, evh.size() * 8, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            int rcx = lfp_xsum(c, evh.data(), (size_t)nring * D);
+            if (!rcx) rcx = lfp_xsum(c, evh.data() + (size_t)nR * D + 1, L);
+            if (rcx) return rcx;
+        } else {
+            HIPCHK(c, hipMemcpy2DAsync(evd.p, D * 8, Rc, ld * D * 8, D * 8, nR, hipMemcpyDeviceToDevice, c->st));
+            HIPCHK(c, hipMemcpy2DAsync(evd.as<u64>() + (size_t)nR * D, 8, Sc, ld * 8, 8, nS, hipMemcpyDeviceToDevice, c->st));
+            HIPCHK(c, hipMemcpyAsync(evh.data(), evd.p, evh.size() * 8, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+        }
         for (u32 l = 0; l < L; l++) {
             u64 *el = evs + (size_t)l * per * D;
             memset(el, 0, D * 8);

@@ -497,6 +497,109 @@ __global__ void __launch_bounds__(256) k_cm_fix(const u64 *in, size_t ld_in, u64
 void launch_cm_fix(const u64 *in, size_t ld_in, u64 *out, size_t ld_out, u32 w, u32 ntab, size_t half, u64 rM, hipStream_t s) {
     hipLaunchKernelGGL(k_cm_fix, dim3((unsigned)cdiv(half * w, 256), ntab), dim3(256), 0, s, in, ld_in, out, ld_out, w, half, rM);
 }
+// ---- the sumcheckers through BATCHED tables.  The combination function (cm.rs:287-311) is linear in the instance tables:
+//     eq(b) sum_l sum_j rc^(l per + j) T_lj(b)  +  sum_l tau_l(b) (rc^(L per) t0(b) + rc^(L per + 1) t1(b))   =   eq(b) U(b) + V(b) Z(b)
+// with U = sum_lj rc^(l per + j) T_lj (ring), V = sum_l tau_l (scalar), Z = rc^(L per) t0 + rc^(L per + 1) t1 (ring), and fix_variables is linear as well: the round
+// messages of the sumcheck over (eq, V | U, Z) ARE the messages of the sumcheck over the 1 + L scalar and L (per - 1) + 2 ring tables, word for word (exact field
+// arithmetic), at two ring tables per round instead of 47 (L = 3, three matrices).  The evaluations of the instance tables at the final point, which the
+// reference reads off its fully fixed tables (cm.rs:313-331), are eq(ro, .)-weighted sums over the ORIGINAL tables: one more pass over them (k_cm_evals).
+// Per sumchecker at 2^20 rows: one read of the tables to combine + one to evaluate (2 x 6.3 GB) instead of ~3 x 6.3 GB spread over 20 rounds of 47-table kernels.
+// thread = (row, coefficient).  S2 = eq | V (ld2 entries each), R2 = U | Z
+__global__ void __launch_bounds__(256) k_cm_combine(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t n, CmDesc d, const u64 *rcp, u64 *S2, u64 *R2, size_t ld2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 16) return;
+    const size_t row = i >> 4;
+    const u32 c = (u32)(i & 15);
+    const u32 per = 4 + 4 * d.nM, nring = d.L * (per - 1);
+    u64 u = 0, v = 0;
+    for (u32 l = 0; l < d.L; l++) {
+        const u64 m = S[(size_t)(1 + l) * lds + row];
+        v = add_p(v, m);
+        if (c == 0) u = add_p(u, mont_mul(rcp[l * per], from_mont(m)));          // the constant tau_l as table 0 of the instance
+        const u64 *rp = R + ((size_t)(l * (per - 1)) * ldr + row) * 16 + c;
+#pragma unroll 5
+        for (u32 j = 1; j < per; j++) u = add_p(u, mont_mul(rcp[l * per + j], rp[(size_t)(j - 1) * ldr * 16]));
+    }
+    const u64 t0 = R[((size_t)nring * ldr + row) * 16 + c], t1 = R[((size_t)(nring + 1) * ldr + row) * 16 + c];
+    R2[row * 16 + c] = u;
+    R2[(ld2 + row) * 16 + c] = add_p(mont_mul(rcp[d.L * per], t0), mont_mul(rcp[d.L * per + 1], t1));
+    if (c == 0) { S2[row] = S[row]; S2[ld2 + row] = v; }
+}
+void launch_cm_combine(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t n, const CmDesc &d, const u64 *rcp, u64 *S2, u64 *R2, size_t ld2, hipStream_t s) {
+    hipLaunchKernelGGL(k_cm_combine, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, s, S, lds, R, ldr, n, d, rcp, S2, R2, ld2);
+}
+// One round over the batched tables: sum over the pairs of eq U + V Z at X = 0, 1, 2.  FUSED: S / R are the previous round's tables (4 entries per new pair), fixed
+// with rM on the way and stored to So / Ro (as k_cm_round_fused).  thread = (pair, coefficient); part[block][3][16] canonical
+template <bool FUSED>
+__global__ void __launch_bounds__(256) k_cm2_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, u64 rM, u64 *So, u64 *Ro, size_t ld_o, u64 *part) {
+    const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    u64 s[3] = {0, 0, 0};
+    auto fixw = [&](u64 lo, u64 hi) { return add_p(lo, mont_mul(rM, sub_p(hi, lo))); };
+    for (size_t b = (size_t)blockIdx.x * 16 + pl; b < half; b += (size_t)gridDim.x * 16) {
+        u64 sv[2][2], rv[2][2];
+#pragma unroll
+        for (u32 tb = 0; tb < 2; tb++) {
+            if (FUSED) {
+                const u64 *sp = S + (size_t)tb * lds + 4 * b, *rp = R + ((size_t)tb * ldr + 4 * b) * 16 + c;
+                sv[tb][0] = fixw(sp[0], sp[1]); sv[tb][1] = fixw(sp[2], sp[3]);
+                rv[tb][0] = fixw(rp[0], rp[16]); rv[tb][1] = fixw(rp[32], rp[48]);
+                if (c == 0) { So[(size_t)tb * ld_o + 2 * b] = sv[tb][0]; So[(size_t)tb * ld_o + 2 * b + 1] = sv[tb][1]; }
+                u64 *op = Ro + ((size_t)tb * ld_o + 2 * b) * 16 + c;
+                op[0] = rv[tb][0]; op[16] = rv[tb][1];
+            } else {
+                const u64 *sp = S + (size_t)tb * lds + 2 * b, *rp = R + ((size_t)tb * ldr + 2 * b) * 16 + c;
+                sv[tb][0] = sp[0]; sv[tb][1] = sp[1];
+                rv[tb][0] = rp[0]; rv[tb][1] = rp[16];
+            }
+        }
+        const u64 e2 = add_p(sv[0][1], sub_p(sv[0][1], sv[0][0])), v2 = add_p(sv[1][1], sub_p(sv[1][1], sv[1][0]));
+        const u64 u2 = add_p(rv[0][1], sub_p(rv[0][1], rv[0][0])), z2 = add_p(rv[1][1], sub_p(rv[1][1], rv[1][0]));
+        s[0] = add_p(s[0], add_p(mont_mul(sv[0][0], rv[0][0]), mont_mul(sv[1][0], rv[1][0])));
+        s[1] = add_p(s[1], add_p(mont_mul(sv[0][1], rv[0][1]), mont_mul(sv[1][1], rv[1][1])));
+        s[2] = add_p(s[2], add_p(mont_mul(e2, u2), mont_mul(v2, z2)));
+    }
+    __shared__ u64 sm[3][16][16];
+    for (int x = 0; x < 3; x++) sm[x][pl][c] = s[x];
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const u32 x = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[x][p][cc]);
+        part[(size_t)blockIdx.x * 48 + threadIdx.x] = t;
+    }
+}
+void launch_cm2_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, u64 *part, hipStream_t s) {
+    hipLaunchKernelGGL((k_cm2_round<false>), dim3(cm_round_blocks(half)), dim3(256), 0, s, S, lds, R, ldr, half, (u64)0, (u64 *)nullptr, (u64 *)nullptr, (size_t)0, part);
+}
+void launch_cm2_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, u64 rM, u64 *So, u64 *Ro, size_t ld_o, u64 *part, hipStream_t s) {
+    hipLaunchKernelGGL((k_cm2_round<true>), dim3(cm_round_blocks(half)), dim3(256), 0, s, S, lds, R, ldr, half, rM, So, Ro, ld_o, part);
+}
+// part[chunk][table][16] = sum over the chunk's rows of eq[row] * T_table[row] (eq Montgomery, tables canonical): the evaluations of `ntab` ring tables at the
+// point eq was built from.  grid (chunks, tables); thread = (row lane, coefficient): a wave reads 512 contiguous bytes of the table per step
+__global__ void __launch_bounds__(256) k_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, u64 *part) {
+    const u32 c = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const u64 *T = R + (size_t)blockIdx.y * ldr * 16;
+    u64 acc = 0;
+#pragma unroll 4
+    for (size_t row = (size_t)blockIdx.x * 16 + rl; row < n; row += (size_t)gridDim.x * 16) acc = add_p(acc, mont_mul(eq[row], T[row * 16 + c]));
+    __shared__ u64 sm[16][16];
+    sm[rl][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[p][threadIdx.x]);
+        part[((size_t)blockIdx.x * ntab + blockIdx.y) * 16 + threadIdx.x] = t;
+    }
+}
+u32 cm_eval_chunks(size_t n) {
+    const size_t b = cdiv(n, 16 * 64);      // 64 rows per thread and chunk at least
+    return (u32)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+void launch_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, u64 *part, u64 *out, hipStream_t s) {
+    const u32 ch = cm_eval_chunks(n);
+    hipLaunchKernelGGL(k_cm_evals, dim3(ch, ntab), dim3(256), 0, s, R, ldr, n, eq, ntab, part);
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)ntab * 16, 32)), dim3(1024), 0, s, part, ch, (size_t)ntab * 16, ntab * 16, 0, out);
+}
 }  // namespace lfp
 
 // ---- ComR1CS::linearize (r1cs.rs:76-139) ------------------------------------------------------------------------------------------------------

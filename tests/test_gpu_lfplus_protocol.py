@@ -118,9 +118,16 @@ def test_argument_errors(ctx):
 
 @pytest.mark.parametrize("L,nM,kappa,nvars,ring_coeffs", [(1, 0, 1, 14, False), (1, 1, 2, 15, False), (2, 1, 1, 14, False), (2, 2, 2, 15, False), (2, 2, 2, 15, True),
                                                          (3, 1, 3, 16, False), (2, 0, 4, 16, False)])   # three instances, kappa not a power of two (tensor(c) has 4 entries, comh 3)
-def test_cm_prove_matches_oracle(L, nM, kappa, nvars, ring_coeffs):
+@pytest.mark.parametrize("all_tables", [False, True])
+def test_cm_prove_matches_oracle(L, nM, kappa, nvars, ring_coeffs, all_tables, monkeypatch):
     """cm.rs:606-666 (test_com: n = 2^15, kappa 2, k 2, one matrix) and the two-instance shape Mlin::mlin feeds Cm::prove: every proof field, the
-    folded instance and the folded witness equal the oracle's; both verifiers accept; the transcripts end in the same state"""
+    folded instance and the folded witness equal the oracle's; both verifiers accept; the transcripts end in the same state.
+    all_tables: the sumcheckers' rounds over every instance table (LFPLUS_CM_FULL=1, the reference's shape) instead of the batched tables eq U + V Z with the
+    evaluations taken from the original tables (the default) -- the same proof either way"""
+    if all_tables:
+        monkeypatch.setenv("LFPLUS_CM_FULL", "1")
+    else:
+        monkeypatch.delenv("LFPLUS_CM_FULL", raising=False)
     n, k = 1 << nvars, 2
     dp = plus.DecompParameters.for_frog(k)
     A = lfp.splitmix(3, 0, kappa * n * D).reshape(kappa, n, D)
