@@ -132,18 +132,6 @@ void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u6
 }
 
 // ---- evaluations ---------------------------------------------------------------------------------------------------------------------
-// sum over the block of sixteen words per thread -> out[16]
-__device__ __forceinline__ void block_sum16(u64 acc[16], u64 *out) {
-    __shared__ u64 sm[4][16];
-#pragma unroll
-    for (int t = 0; t < 16; t++)
-        for (int o = 32; o; o >>= 1) acc[t] = add_p(acc[t], __shfl_xor(acc[t], o));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0)
-        for (int t = 0; t < 16; t++) sm[wave][t] = acc[t];
-    __syncthreads();
-    if (threadIdx.x < 16) out[threadIdx.x] = add_p(add_p(sm[0][threadIdx.x], sm[1][threadIdx.x]), add_p(sm[2][threadIdx.x], sm[3][threadIdx.x]));
-}
 // part[chunk][col][16] = sum over the chunk's rows of w[row] * X^e(dig[row][col]).  wstride 1: scalar weights (constant polynomials);
 // 16: ring weights -- coefficient t of w X^e is w[t - e] (t >= e), -w[t - e + 16] (t < e).
 // 16 lanes per row (lane t = coefficient t), ALL NC columns of the row per pass: the weight row is loaded once, coalesced (lane t reads word t), and the
@@ -210,31 +198,51 @@ __global__ void __launch_bounds__(256) k_wmono(const int8_t *dig, size_t dstride
     }
 }
 // part[chunk][16] = sum over the chunk's rows of w[row] * f[row] (f: n ring elements, canonical).  wstride 1: scalar weights in Montgomery
-// form (eq tables); 16: ring weights, canonical (negacyclic products)
-__global__ void __launch_bounds__(256) k_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part) {
-    u64 acc[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) acc[t] = 0;
-    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (size_t)gridDim.x * 256) {
-        const u64 *fr = f + row * 16;
-        if (wstride == 1) {
-            const u64 v = w[row];
-#pragma unroll
-            for (int t = 0; t < 16; t++) acc[t] = add_p(acc[t], mont_mul(v, fr[t]));
+// form (eq tables); 16: ring weights, canonical (negacyclic products).  thread = (row lane, coefficient): a wave reads 512 contiguous bytes of f per step; the
+// terms are lazy 160-bit sums over ALL the rows of the thread (acc160_*), one reduction at the end.  Ring weights: coefficient t of w f = sum_j w[j] f[t - j]
+// (j <= t), - w[j] f[t - j + 16] (j > t): signed terms in two's complement, made non-negative by the multiple rows * 16 p 2^64 of p 2^64 added at the end; both
+// operands canonical, so the reduced sum (x 2^-64) goes back through to_mont.  (First version: thread = row, 16 x 16 mont_mul + add_p / sub_p per row: 0.25 ms per
+// pass at 2^20 rows.)
+template <bool RINGW>
+__global__ void __launch_bounds__(256) k_wring(const u64 *f, size_t n, const u64 *w, u64 *part) {
+    const u32 c = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    __shared__ u64 lw[16][16], lf[16][16];
+    Acc160 acc;
+    acc160_zero(acc);
+    u64 rows = 0;
+    for (size_t base = (size_t)blockIdx.x * 16; base < n; base += (size_t)gridDim.x * 16) {
+        const size_t row = base + rl;
+        const bool ok = row < n;
+        if (!RINGW) {
+            if (ok) acc160_mad(acc, w[row], f[row * 16 + c]);
         } else {
-            const u64 *wr = w + row * 16;
-            for (int i = 0; i < 16; i++) {
-                const u64 wi = to_mont(wr[i]);
-                if (wi == 0) continue;
+            lw[rl][c] = ok ? w[row * 16 + c] : 0;
+            lf[rl][c] = ok ? f[row * 16 + c] : 0;
+            __syncthreads();
 #pragma unroll
-                for (int t = 0; t < 16; t++) {      // X^i * f: coefficient t gets f[t - i] (t >= i), -f[t - i + 16]
-                    const u64 pr = mont_mul(wi, fr[(t - i) & 15]);
-                    acc[t] = t >= i ? add_p(acc[t], pr) : sub_p(acc[t], pr);
-                }
-            }
+            for (u32 j = 0; j < 16; j++) acc160_mad_signed(acc, lw[rl][j], lf[rl][(c - j) & 15], j > c);
+            rows++;
+            __syncthreads();
         }
     }
-    block_sum16(acc, part + (size_t)blockIdx.x * 16);
+    u64 v;
+    if (RINGW) {      // + rows * 16 p * 2^64, then (sum 2^-64) 2^64
+        const u64 x = rows << 4, lo = x * P, hi = __umul64hi(x, P);
+        asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, %2, %5, vcc"
+            : "+v"(acc.a[2]), "+v"(acc.a[3]), "+v"(acc.a[4])
+            : "v"((u32)lo), "v"((u32)(lo >> 32)), "v"((u32)hi)
+            : "vcc");
+        v = to_mont(acc160_red(acc));
+    } else
+        v = acc160_red(acc);
+    __shared__ u64 sm[16][16];
+    sm[rl][c] = v;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[p][threadIdx.x]);
+        part[(size_t)blockIdx.x * 16 + threadIdx.x] = t;
+    }
 }
 // part[chunk] = sum of x[i * xstride] * y[i]; x Montgomery (x_mont) or canonical, y canonical: canonical sum
 __global__ void __launch_bounds__(256) k_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part) {
@@ -278,7 +286,8 @@ void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstr
 }
 void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = eval_chunks(n);
-    hipLaunchKernelGGL(k_wring, dim3(ch), dim3(256), 0, s, f, n, w, wstride, part);
+    if (wstride == 1) hipLaunchKernelGGL((k_wring<false>), dim3(ch), dim3(256), 0, s, f, n, w, part);
+    else hipLaunchKernelGGL((k_wring<true>), dim3(ch), dim3(256), 0, s, f, n, w, part);
     hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1024), 0, s, part, ch, (size_t)16, 16u, 0, out);
 }
 void launch_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part, u64 *out, hipStream_t s) {
@@ -512,16 +521,18 @@ __global__ void __launch_bounds__(256) k_cm_combine(const u64 *S, size_t lds, co
     const u32 c = (u32)(i & 15);
     const u32 per = 4 + 4 * d.nM, nring = d.L * (per - 1);
     u64 u = 0, v = 0;
+    Acc160 ua;                // the L (per - 1) products rc^i T_i(row) as one lazy sum
+    acc160_zero(ua);
     for (u32 l = 0; l < d.L; l++) {
         const u64 m = S[(size_t)(1 + l) * lds + row];
         v = add_p(v, m);
         if (c == 0) u = add_p(u, mont_mul(rcp[l * per], from_mont(m)));          // the constant tau_l as table 0 of the instance
         const u64 *rp = R + ((size_t)(l * (per - 1)) * ldr + row) * 16 + c;
 #pragma unroll 5
-        for (u32 j = 1; j < per; j++) u = add_p(u, mont_mul(rcp[l * per + j], rp[(size_t)(j - 1) * ldr * 16]));
+        for (u32 j = 1; j < per; j++) acc160_mad(ua, rcp[l * per + j], rp[(size_t)(j - 1) * ldr * 16]);
     }
     const u64 t0 = R[((size_t)nring * ldr + row) * 16 + c], t1 = R[((size_t)(nring + 1) * ldr + row) * 16 + c];
-    R2[row * 16 + c] = u;
+    R2[row * 16 + c] = add_p(u, acc160_red(ua));
     R2[(ld2 + row) * 16 + c] = add_p(mont_mul(rcp[d.L * per], t0), mont_mul(rcp[d.L * per + 1], t1));
     if (c == 0) { S2[row] = S[row]; S2[ld2 + row] = v; }
 }
@@ -579,11 +590,12 @@ void launch_cm2_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, 
 __global__ void __launch_bounds__(256) k_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, u64 *part) {
     const u32 c = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const u64 *T = R + (size_t)blockIdx.y * ldr * 16;
-    u64 acc = 0;
+    Acc160 acc;
+    acc160_zero(acc);
 #pragma unroll 4
-    for (size_t row = (size_t)blockIdx.x * 16 + rl; row < n; row += (size_t)gridDim.x * 16) acc = add_p(acc, mont_mul(eq[row], T[row * 16 + c]));
+    for (size_t row = (size_t)blockIdx.x * 16 + rl; row < n; row += (size_t)gridDim.x * 16) acc160_mad(acc, eq[row], T[row * 16 + c]);
     __shared__ u64 sm[16][16];
-    sm[rl][c] = acc;
+    sm[rl][c] = acc160_red(acc);
     __syncthreads();
     if (threadIdx.x < 16) {
         u64 t = 0;
@@ -606,37 +618,31 @@ void launch_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab
 namespace lfp {
 // One round of the degree-3 sumcheck of eq (ga gb - gc) (comb_fn r1cs.rs:95; ring products).  E: eq(r, .) Montgomery scalars; G: ga | gb | gc, canonical
 // ring tables [table][ld][16].  thread = (pair, coefficient); part[block][4][16] canonical.
-__global__ void __launch_bounds__(256) k_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part) {
-    const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    __shared__ u64 la[16][16], lb[16][16];
-    u64 s[4] = {0, 0, 0, 0};
-    for (size_t base = (size_t)blockIdx.x * 16; base < half; base += (size_t)gridDim.x * 16) {
-        const size_t b = base + pl;
-        const bool ok = b < half;
-        u64 ex = 0, de = 0, ax = 0, da = 0, bx = 0, db = 0, cx = 0, dc = 0;
-        if (ok) {
-            const u64 *ga = G + (2 * b) * 16 + c, *gb = ga + ld * 16, *gc = gb + ld * 16;
-            ex = E[2 * b]; de = sub_p(E[2 * b + 1], ex);
-            ax = ga[0]; da = sub_p(ga[16], ax);
-            bx = gb[0]; db = sub_p(gb[16], bx);
-            cx = gc[0]; dc = sub_p(gc[16], cx);
-        }
+// The pair's four evaluations.  ga(X) gb(X) is quadratic in X: the three negacyclic products P(0) = a0 b0, P(1) = a1 b1, P(inf) = (a1 - a0)(b1 - b0) give
+// P(2) = 2 P(1) - P(0) + 2 P(inf) and P(3) = 3 P(1) - 2 P(0) + 6 P(inf) (exact mod p: the words of the message are those of four products); the 16 terms of a
+// product coefficient are one lazy signed sum (acc160_mad_signed) with a single reduction.  First version: four products of 16 mont_mul + add_p / sub_p each --
+// 0.77 ms for the first round at 2^20 rows against 0.06 ms of table traffic.
+__device__ __forceinline__ u64 r1cs_negacyclic(const u64 (*la)[16], const u64 (*lb)[16], u32 pl, u32 c) {
+    Acc160 n;
+    acc160_bias16(n);
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            if (x) { ex = add_p(ex, de); ax = add_p(ax, da); bx = add_p(bx, db); cx = add_p(cx, dc); }
-            la[pl][c] = to_mont(ax);
-            lb[pl][c] = bx;
-            __syncthreads();
-            u64 t = 0;
-#pragma unroll
-            for (u32 j = 0; j < 16; j++) {
-                const u64 pr = mont_mul(la[pl][j], lb[pl][(c - j) & 15]);
-                t = j <= c ? add_p(t, pr) : sub_p(t, pr);
-            }
-            s[x] = add_p(s[x], mont_mul(ex, sub_p(t, cx)));
-            __syncthreads();
-        }
-    }
+    for (u32 j = 0; j < 16; j++) acc160_mad_signed(n, la[pl][j], lb[pl][(c - j) & 15], j > c);
+    return acc160_red(n);
+}
+__device__ __forceinline__ void r1cs_pair_eval(u64 (*la)[16][16], u64 (*lb)[16][16], u32 pl, u32 c, u64 e0, u64 de, u64 a0, u64 a1, u64 b0, u64 b1, u64 c0, u64 dc, u64 s[4]) {
+    la[0][pl][c] = to_mont(a0); la[1][pl][c] = to_mont(a1); la[2][pl][c] = to_mont(sub_p(a1, a0));
+    lb[0][pl][c] = b0; lb[1][pl][c] = b1; lb[2][pl][c] = sub_p(b1, b0);
+    __syncthreads();
+    const u64 p0 = r1cs_negacyclic(la[0], lb[0], pl, c), p1 = r1cs_negacyclic(la[1], lb[1], pl, c), pi = r1cs_negacyclic(la[2], lb[2], pl, c);
+    __syncthreads();
+    const u64 d = add_p(p1, pi), t2 = sub_p(add_p(d, d), p0), pi2 = add_p(pi, pi), t3 = add_p(add_p(t2, sub_p(p1, p0)), add_p(pi2, pi2));
+    const u64 e1 = add_p(e0, de), e2 = add_p(e1, de), e3 = add_p(e2, de), c1 = add_p(c0, dc), c2 = add_p(c1, dc), c3 = add_p(c2, dc);
+    s[0] = add_p(s[0], mont_mul(e0, sub_p(p0, c0)));
+    s[1] = add_p(s[1], mont_mul(e1, sub_p(p1, c1)));
+    s[2] = add_p(s[2], mont_mul(e2, sub_p(t2, c2)));
+    s[3] = add_p(s[3], mont_mul(e3, sub_p(t3, c3)));
+}
+__device__ __forceinline__ void r1cs_block_store(u64 s[4], u32 pl, u32 c, u64 *part) {
     __shared__ u64 sm[4][16][16];
     for (int x = 0; x < 4; x++) sm[x][pl][c] = s[x];
     __syncthreads();
@@ -647,22 +653,40 @@ __global__ void __launch_bounds__(256) k_r1cs_round(const u64 *E, const u64 *G, 
         part[(size_t)blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
+__global__ void __launch_bounds__(256) k_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part) {
+    const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    __shared__ u64 la[3][16][16], lb[3][16][16];
+    u64 s[4] = {0, 0, 0, 0};
+    for (size_t base = (size_t)blockIdx.x * 16; base < half; base += (size_t)gridDim.x * 16) {
+        const size_t b = base + pl;
+        u64 e0 = 0, de = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, dc = 0;
+        if (b < half) {
+            const u64 *ga = G + (2 * b) * 16 + c, *gb = ga + ld * 16, *gc = gb + ld * 16;
+            e0 = E[2 * b]; de = sub_p(E[2 * b + 1], e0);
+            a0 = ga[0]; a1 = ga[16];
+            b0 = gb[0]; b1 = gb[16];
+            c0 = gc[0]; dc = sub_p(gc[16], c0);
+        }
+        r1cs_pair_eval(la, lb, pl, c, e0, de, a0, a1, b0, b1, c0, dc, s);
+    }
+    r1cs_block_store(s, pl, c, part);
+}
 // the same round with fix_variables of the previous round fused in (as k_cm_round_fused): E / G are the previous tables (4 entries per new pair), fixed with rM on
 // the way and stored to Eo / Go (ld_o entries per table)
 __global__ void __launch_bounds__(256) k_r1cs_round_fused(const u64 *E, const u64 *G, size_t ld, size_t half, u64 rM, u64 *Eo, u64 *Go, size_t ld_o, u64 *part) {
     const u32 c = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    __shared__ u64 la[16][16], lb[16][16];
+    __shared__ u64 la[3][16][16], lb[3][16][16];
     u64 s[4] = {0, 0, 0, 0};
     auto fixw = [&](u64 lo, u64 hi) { return add_p(lo, mont_mul(rM, sub_p(hi, lo))); };
     for (size_t base = (size_t)blockIdx.x * 16; base < half; base += (size_t)gridDim.x * 16) {
         const size_t b = base + pl;
-        const bool ok = b < half;
-        u64 ex = 0, de = 0, ax = 0, da = 0, bx = 0, db = 0, cx = 0, dc = 0;
-        if (ok) {
-            const u64 e0 = fixw(E[4 * b], E[4 * b + 1]), e1 = fixw(E[4 * b + 2], E[4 * b + 3]);
+        u64 e0 = 0, de = 0, c0 = 0, dc = 0;
+        u64 v0[3] = {0, 0, 0}, v1[3] = {0, 0, 0};
+        if (b < half) {
+            e0 = fixw(E[4 * b], E[4 * b + 1]);
+            const u64 e1 = fixw(E[4 * b + 2], E[4 * b + 3]);
             if (c == 0) { Eo[2 * b] = e0; Eo[2 * b + 1] = e1; }
-            ex = e0; de = sub_p(e1, e0);
-            u64 v0[3], v1[3];
+            de = sub_p(e1, e0);
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const u64 *gp = G + ((size_t)q * ld + 4 * b) * 16 + c;
@@ -670,35 +694,11 @@ __global__ void __launch_bounds__(256) k_r1cs_round_fused(const u64 *E, const u6
                 u64 *op = Go + ((size_t)q * ld_o + 2 * b) * 16 + c;
                 op[0] = v0[q]; op[16] = v1[q];
             }
-            ax = v0[0]; da = sub_p(v1[0], ax);
-            bx = v0[1]; db = sub_p(v1[1], bx);
-            cx = v0[2]; dc = sub_p(v1[2], cx);
+            c0 = v0[2]; dc = sub_p(v1[2], c0);
         }
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            if (x) { ex = add_p(ex, de); ax = add_p(ax, da); bx = add_p(bx, db); cx = add_p(cx, dc); }
-            la[pl][c] = to_mont(ax);
-            lb[pl][c] = bx;
-            __syncthreads();
-            u64 t = 0;
-#pragma unroll
-            for (u32 j = 0; j < 16; j++) {
-                const u64 pr = mont_mul(la[pl][j], lb[pl][(c - j) & 15]);
-                t = j <= c ? add_p(t, pr) : sub_p(t, pr);
-            }
-            s[x] = add_p(s[x], mont_mul(ex, sub_p(t, cx)));
-            __syncthreads();
-        }
+        r1cs_pair_eval(la, lb, pl, c, e0, de, v0[0], v1[0], v0[1], v1[1], c0, dc, s);
     }
-    __shared__ u64 sm[4][16][16];
-    for (int x = 0; x < 4; x++) sm[x][pl][c] = s[x];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const u32 x = threadIdx.x >> 4, cc = threadIdx.x & 15;
-        u64 t = 0;
-        for (int p = 0; p < 16; p++) t = add_p(t, sm[x][p][cc]);
-        part[(size_t)blockIdx.x * 64 + threadIdx.x] = t;
-    }
+    r1cs_block_store(s, pl, c, part);
 }
 void launch_r1cs_round_fused(const u64 *E, const u64 *G, size_t ld, size_t half, u64 rM, u64 *Eo, u64 *Go, size_t ld_o, u64 *part, hipStream_t s) {
     hipLaunchKernelGGL(k_r1cs_round_fused, dim3(cm_round_blocks(half)), dim3(256), 0, s, E, G, ld, half, rM, Eo, Go, ld_o, part);

@@ -6,7 +6,7 @@ mkdir -p $R/gpurun_out
 cd $R
 timeout 1500 python -m pytest tests/test_gpu_lfplus_protocol.py tests/test_gpu_lfplus_prover.py tests/test_gpu_lfplus_scale.py tests/test_dist_shard_lfplus.py -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1
 tail -5 gpurun_out/${tag}_tests.log
-for v in batched full; do
+for v in ${2:-batched full}; do
   if [ $v = full ]; then export LFPLUS_CM_FULL=1; else unset LFPLUS_CM_FULL; fi
   timeout 600 python tools/bench_lfplus.py --nvars 20 --rounds 3 --k 4 --fresh 3 --resident > gpurun_out/${tag}_p20_$v.txt 2>&1
   grep -E "gpu_prove_ms" gpurun_out/${tag}_p20_$v.txt | cut -c1-260
