@@ -68,6 +68,7 @@ void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, 
 // out[0] = sum_i x[i xstride] y[i]; part: eval_chunks(n) * 4
 void launch_wdot(const u64 *x, u32 xstride, int x_mont, const u64 *y, size_t n, u64 *part, u64 *out, hipStream_t s);
 void launch_spmvT_eq(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s);
+void launch_spmvT_eq_const(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s);   // scalar w (Montgomery): constant-coefficient M
 // ---- Cm::prove (cm.rs:56-347)
 struct CmShort { int32_t v[3][16]; };     // the three folding challenges s (centred coefficients)
 struct CmDesc { u32 L, nM; };

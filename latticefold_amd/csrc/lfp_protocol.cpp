@@ -385,6 +385,8 @@ struct MatHold {
 struct ScOut {          // device-side leftovers the range check reuses
     DevBuf eqr;         // eq(r, .) Montgomery, n words (whole on every rank: M^T eq reads arbitrary rows)
     std::vector<std::unique_ptr<DevBuf>> w;   // w_q = M_q^T eq(r): the rank's nloc ring elements each
+    bool wscalar = false;                     // every M_q has constant coefficients: w_q holds nloc SCALARS (Montgomery) -- eq is scalar, so w_q is constant too, and
+                                              // every sum weighted by it takes the scalar-weight form (no negacyclic rotations, an eighth of the weight traffic)
     DevBuf part, small;
 };
 // eq(c, .) over the rank's rows [row0, row0 + nloc): the local index carries the low nv_loc variables, the rank the high ones, so the slice is the
@@ -521,10 +523,14 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     const size_t row0 = c->sharded() ? (size_t)c->row0 : 0;
     lfp::launch_eq_build(eq_point(r_out, nvars), nvars, so.eqr.as<u64>(), c->st);
     const u64 *eql = so.eqr.as<u64>() + row0;      // eq(r, .) over the rank's rows
+    so.wscalar = nM > 0 && !getenv("LFPLUS_RING_WEIGHTS");
+    for (u32 q = 0; q < nM; q++) so.wscalar = so.wscalar && M[q].const_coef;
+    const u32 wst = so.wscalar ? 1 : 16;
     for (u32 q = 0; q < nM; q++) {                 // w_q = M_q^T eq(r) over the rank's COLUMNS (its rows of the vectors M_q multiplies); eq whole
         std::unique_ptr<DevBuf> w(new DevBuf);
-        if (w->alloc(nl * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (M^T eq)");
-        lfp::launch_spmvT_eq(M[q].colptr + row0, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
+        if (w->alloc(nl * wst * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (M^T eq)");
+        if (so.wscalar) lfp::launch_spmvT_eq_const(M[q].colptr + row0, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
+        else lfp::launch_spmvT_eq(M[q].colptr + row0, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
         so.w.push_back(std::move(w));
     }
     LFP_MARK(c, "set check: eq(r), M^T eq(r)");
@@ -532,7 +538,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     for (u32 i = 0; i < nmat; i++) {
         lfp::launch_wmono(mats[i].dig, nl, ncols, eql, 1, so.part.as<u64>(), ed + (size_t)i * ncols * D, c->st);
         for (u32 q = 0; q < nM; q++)
-            lfp::launch_wmono(mats[i].dig, nl, ncols, so.w[q]->as<u64>(), 16, so.part.as<u64>(), ed + ((size_t)(1 + q) * nmat + i) * ncols * D, c->st);
+            lfp::launch_wmono(mats[i].dig, nl, ncols, so.w[q]->as<u64>(), wst, so.part.as<u64>(), ed + ((size_t)(1 + q) * nmat + i) * ncols * D, c->st);
     }
     for (u32 i = 0; i < nvec; i++) lfp::launch_wmono(vecs[i].dig, nl, 1, eql, 1, so.part.as<u64>(), bd + (size_t)i * D, c->st);
     HIPCHK(c, hipMemcpyAsync(e_out, ed, (size_t)(1 + nM) * nmat * ncols * D * 8, hipMemcpyDeviceToHost, c->st));
@@ -619,9 +625,10 @@ int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr,
         lfp::launch_wring(fl, nl, eql, 1, so.part.as<u64>(), cd, c->st);
         lfp::launch_wdot(eql, 1, 1, taul, nl, so.part.as<u64>(), ad, c->st);
         for (u32 q = 0; q < nM; q++) {
-            lfp::launch_wdot(so.w[q]->as<u64>(), 16, 0, taul, nl, so.part.as<u64>(), ad + 1 + q, c->st);
-            lfp::launch_wmono(ctxs[l]->mtau + row0, nl, 1, so.w[q]->as<u64>(), 16, so.part.as<u64>(), bd + (size_t)(1 + q) * D, c->st);
-            lfp::launch_wring(fl, nl, so.w[q]->as<u64>(), 16, so.part.as<u64>(), cd + (size_t)(1 + q) * D, c->st);
+            const u32 wst = so.wscalar ? 1 : 16;       // scalar weights are in Montgomery form, ring weights canonical
+            lfp::launch_wdot(so.w[q]->as<u64>(), wst, so.wscalar ? 1 : 0, taul, nl, so.part.as<u64>(), ad + 1 + q, c->st);
+            lfp::launch_wmono(ctxs[l]->mtau + row0, nl, 1, so.w[q]->as<u64>(), wst, so.part.as<u64>(), bd + (size_t)(1 + q) * D, c->st);
+            lfp::launch_wring(fl, nl, so.w[q]->as<u64>(), wst, so.part.as<u64>(), cd + (size_t)(1 + q) * D, c->st);
         }
     }
     std::vector<u64> h(L * per);

@@ -306,6 +306,17 @@ __global__ void __launch_bounds__(256) k_spmvT_eq(const u32 *colptr, const u32 *
     for (u32 k = colptr[c]; k < colptr[c + 1]; k++) s = add_p(s, mont_mul(eq[rowidx[k]], val[(size_t)k * 16 + t]));
     w[i] = s;
 }
+// constant-coefficient matrices: w[c] is a constant polynomial -- its coefficient 0 as ONE scalar, in Montgomery form like eq itself
+__global__ void __launch_bounds__(256) k_spmvT_eq_const(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w) {
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    u64 s = 0;
+    for (u32 k = colptr[c]; k < colptr[c + 1]; k++) s = add_p(s, mont_mul(eq[rowidx[k]], val[(size_t)k * 16]));
+    w[c] = to_mont(s);
+}
+void launch_spmvT_eq_const(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s) {
+    hipLaunchKernelGGL(k_spmvT_eq_const, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, colptr, rowidx, val, eq, n, w);
+}
 void launch_spmvT_eq(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s) {
     hipLaunchKernelGGL(k_spmvT_eq, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, s, colptr, rowidx, val, eq, n, w);
 }

@@ -70,10 +70,15 @@ def _witness(n, seed):
     return np.where(v < 0, np.uint64(P) - (-v).astype(np.uint64), v.astype(np.uint64)).reshape(n, D)
 
 
-@pytest.mark.parametrize("L,nM,nvars", [(1, 0, 14), (1, 1, 14), (2, 1, 14), (1, 1, 15)])
-def test_range_check_matches_oracle(L, nM, nvars):
+@pytest.mark.parametrize("L,nM,nvars,ring_weights", [(1, 0, 14, False), (1, 1, 14, False), (2, 1, 14, False), (1, 1, 15, False), (2, 1, 14, True)])
+def test_range_check_matches_oracle(L, nM, nvars, ring_weights, monkeypatch):
     """rgchk.rs:340-433 (test_range_check: n = 2^15, kappa 1, k 2; test_range_check_mm: one matrix) and two instances as Mlin::mlin builds them:
-    RgInstance::from_f on the GPU, then the range check on the resident instances"""
+    RgInstance::from_f on the GPU, then the range check on the resident instances.  ring_weights: w = M^T eq(r) kept as ring elements although the matrix has
+    constant coefficients (LFPLUS_RING_WEIGHTS=1: the form matrices with ring coefficients take) -- the same evaluations as the scalar weights of the default"""
+    if ring_weights:
+        monkeypatch.setenv("LFPLUS_RING_WEIGHTS", "1")
+    else:
+        monkeypatch.delenv("LFPLUS_RING_WEIGHTS", raising=False)
     n, kappa, k = 1 << nvars, 1, 2
     dp = plus.DecompParameters.for_frog(k)
     A = lfp.splitmix(1, 0, kappa * n * D).reshape(kappa, n, D)
