@@ -63,6 +63,8 @@ void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u6
 u32 eval_chunks(size_t n);
 // out[col][16] = sum_row w[row] X^e(dig[row][col]); wstride 1: scalar Montgomery weights (out canonical), 16: canonical ring weights.  part: eval_chunks(n) * ncols * 16
 void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s);
+// 16 columns against nw <= 4 SCALAR weight tables (Montgomery) in one pass (exponent histogram): out[q * ostride + col * 16 + t]; part: nw * eval_chunks(n) * 256 words
+void launch_whist16(const int8_t *dig, size_t n, const u64 *const *w, u32 nw, u64 *part, u64 *out, size_t ostride, hipStream_t s);
 // out[16] = sum_row w[row] f[row]; part: eval_chunks(n) * 16
 void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s);
 // out[0] = sum_i x[i xstride] y[i]; part: eval_chunks(n) * 4

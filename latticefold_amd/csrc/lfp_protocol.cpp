@@ -438,7 +438,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     const u32 ntab = nmat * (2 * ncols + 1) + 3 * nvec;
     DevBuf tabs[2], coefd, tgath;
     if (tabs[0].alloc((size_t)ntab * nl * 8) || tabs[1].alloc((size_t)ntab * nl * 8) || coefd.alloc((size_t)(nmat + nvec) * ncols * 8) ||
-        so.eqr.alloc(n * 8) || so.part.alloc((size_t)lfp::eval_chunks(n) * ncols * 16 * 8) ||
+        so.eqr.alloc(n * 8) || so.part.alloc((size_t)lfp::eval_chunks(n) * ncols * 16 * 8 * 4) ||      // (x 4: launch_whist16 takes four weight tables per pass)
         so.small.alloc((size_t)((1 + nM) * nmat * ncols + nvec + 8) * D * 8) || (c->sharded() && tgath.alloc((size_t)ntab * c->world * 8)))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (set check tables)");
     std::vector<u64> alpha(nmat + nvec), cch(nvars);
@@ -535,7 +535,17 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     }
     LFP_MARK(c, "set check: eq(r), M^T eq(r)");
     u64 *ed = so.small.as<u64>(), *bd = ed + (size_t)(1 + nM) * nmat * ncols * D;
+    // every weight table scalar (eq(r) always is; the w_q when the M_q have constant coefficients) and 16 columns: the exponent-histogram pass, four tables at a time
+    const bool hist = ncols == 16 && (nM == 0 || so.wscalar) && !getenv("LFPLUS_NO_HIST");
     for (u32 i = 0; i < nmat; i++) {
+        if (hist) {
+            std::vector<const u64 *> wt(1 + nM);
+            wt[0] = eql;
+            for (u32 q = 0; q < nM; q++) wt[1 + q] = so.w[q]->as<u64>();
+            for (u32 q0 = 0; q0 < 1 + nM; q0 += 4)
+                lfp::launch_whist16(mats[i].dig, nl, wt.data() + q0, std::min(4u, 1 + nM - q0), so.part.as<u64>(), ed + ((size_t)q0 * nmat + i) * ncols * D, (size_t)nmat * ncols * D, c->st);
+            continue;
+        }
         lfp::launch_wmono(mats[i].dig, nl, ncols, eql, 1, so.part.as<u64>(), ed + (size_t)i * ncols * D, c->st);
         for (u32 q = 0; q < nM; q++)
             lfp::launch_wmono(mats[i].dig, nl, ncols, so.w[q]->as<u64>(), wst, so.part.as<u64>(), ed + ((size_t)(1 + q) * nmat + i) * ncols * D, c->st);

@@ -270,6 +270,54 @@ __global__ void __launch_bounds__(1024) k_sum_parts(const u64 *part, u32 chunks,
         out[o] = out_of_mont ? from_mont(s) : s;
     }
 }
+// Scalar weights, 16 columns, up to four weight tables at once: sum_row w_q[row] X^e(dig[row][col]) is a HISTOGRAM over the exponent -- bucket (col, e) collects the
+// weights of the rows whose entry is X^e.  thread = (row, column); a bucket is two 64-bit LDS counters (sums of the low and of the high 32-bit halves of the
+// weights: exact for 2^32 rows) fed by ds_add_u64; the digits are decoded once for all the weight tables.  The lane-per-coefficient form above (k_wmono, wstride 1)
+// has 16 lanes per row of which one adds a non-zero word per column: 0.14 ms per pass and weight table at 2^20 rows, 48 passes per set check.
+// part[q][chunk][col][16], canonical residues of the (Montgomery-form) sums; LDS layout [q][e][col] with 17 columns: the 16 columns of a row fall into distinct banks,
+// the four rows of a wave are shifted against each other
+struct WPtrs { const u64 *w[4]; };
+__global__ void __launch_bounds__(256) k_whist16(const int8_t *dig, size_t n, WPtrs wp, u32 nw, u64 *part, size_t pstride) {
+    __shared__ unsigned long long h[4][16][17][2];
+    for (u32 i = threadIdx.x; i < 4 * 16 * 17 * 2; i += 256) (&h[0][0][0][0])[i] = 0;
+    __syncthreads();
+    const u32 col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+#pragma unroll 2
+    for (size_t row = (size_t)blockIdx.x * 16 + rl; row < n; row += (size_t)gridDim.x * 16) {
+        const int8_t d = dig[row * 16 + col];
+        if (d == LFP_ABSENT) continue;
+        const int e = exp_of(d);
+        for (u32 q = 0; q < nw; q++) {
+            const u64 v = wp.w[q][row];
+            (void)__hip_atomic_fetch_add(&h[q][e][col][0], (unsigned long long)(u32)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_add(&h[q][e][col][1], (unsigned long long)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    const u32 t = threadIdx.x & 15, c = threadIdx.x >> 4;
+    for (u32 q = 0; q < nw; q++) {
+        const unsigned __int128 T = (unsigned __int128)h[q][t][c][0] + ((unsigned __int128)h[q][t][c][1] << 32);
+        u64 lo = (u64)T;
+        if (lo >= P) lo -= P;
+        part[q * pstride + ((size_t)blockIdx.x * 16 + c) * 16 + t] = add_p(mont_mul((u64)(T >> 64), R2), lo);
+    }
+}
+// out[q * ostride + o] = sum over chunks of part[q * pstride + chunk * nout + o], taken out of Montgomery form (k_sum_parts with a weight-table index in grid.y)
+__global__ void __launch_bounds__(1024) k_sum_parts_q(const u64 *part, u32 chunks, size_t pstride, u32 nout, u64 *out, size_t ostride) {
+    __shared__ u64 sm[32][33];
+    const u32 ol = threadIdx.x & 31, cl = threadIdx.x >> 5, o = blockIdx.x * 32 + ol;
+    part += (size_t)blockIdx.y * pstride;
+    u64 s = 0;
+    if (o < nout)
+        for (u32 ch = cl; ch < chunks; ch += 32) s = add_p(s, part[(size_t)ch * nout + o]);
+    sm[cl][ol] = s;
+    __syncthreads();
+    if (cl == 0 && o < nout) {
+#pragma unroll
+        for (int g = 1; g < 32; g++) s = add_p(s, sm[g][ol]);
+        out[(size_t)blockIdx.y * ostride + o] = from_mont(s);
+    }
+}
 // (256 blocks = one wave per SIMD: the passes were latency-bound; LFPLUS_EVAL_CHUNKS moves the cap)
 u32 eval_chunks(size_t n) {
     static const size_t cap = [] { const char *e = getenv("LFPLUS_EVAL_CHUNKS"); const long v = e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 65535 ? v : 1024); }();
@@ -283,6 +331,14 @@ void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstr
         for (u32 c0 = 0; c0 < ncols; c0++) hipLaunchKernelGGL((k_wmono<1>), dim3(ch), dim3(256), 0, s, dig + c0, (size_t)ncols, n, w, wstride, part, ncols, c0);
     }
     hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)ncols * 16, 32)), dim3(1024), 0, s, part, ch, (size_t)ncols * 16, ncols * 16, wstride == 1, out);
+}
+// the 16 columns of a monomial matrix against nw <= 4 scalar weight tables (Montgomery): out[q * ostride + col * 16 + t]; part: nw * eval_chunks(n) * 256 words
+void launch_whist16(const int8_t *dig, size_t n, const u64 *const *w, u32 nw, u64 *part, u64 *out, size_t ostride, hipStream_t s) {
+    const u32 ch = eval_chunks(n);
+    WPtrs wp = {{nullptr, nullptr, nullptr, nullptr}};
+    for (u32 q = 0; q < nw; q++) wp.w[q] = w[q];
+    hipLaunchKernelGGL(k_whist16, dim3(ch), dim3(256), 0, s, dig, n, wp, nw, part, (size_t)ch * 256);
+    hipLaunchKernelGGL(k_sum_parts_q, dim3(8, nw), dim3(1024), 0, s, part, ch, (size_t)ch * 256, 256u, out, ostride);
 }
 void launch_wring(const u64 *f, size_t n, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = eval_chunks(n);
