@@ -416,7 +416,7 @@ static int decompose_impl(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const 
             dy = (u64 *)c->pool.get(lw * 8); if (!dy) { cleanup(); return fail(c, LFPLUS_E_HIP, "hipMalloc"); } tofree.push_back(dy);
             const LfpMatrix &mj = c->mats[j];
             for (int s = 0; s < 2; s++) {
-                lfp::launch_spmv_ring(mj.rowptr + c->row0, mj.col, mj.valM, s ? dF1 : dF0, nl, dy, c->st, mj.const_coef);
+                lfp::launch_spmv_ring(mj.rowptr + c->row0, mj.col, mj.spmv_vals(), s ? dF1 : dF0, nl, dy, c->st, mj.const_coef);
                 lfp::launch_replicate(dy, lw, 2, tab + (size_t)(s * (1 + nm) + 1 + j) * 2 * lw, c->st);
             }
             continue;

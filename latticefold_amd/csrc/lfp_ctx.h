@@ -19,10 +19,13 @@ struct LfpMatrix {
     u64 *valT = nullptr;                        //   canonical coefficients (launch_spmvT_eq)
     size_t nnz = 0;
     bool const_coef = false;                    // every coefficient is a constant polynomial (launch_spmv_ring's one-product path)
+    u64 *valMc = nullptr, *valTc = nullptr;     //   const_coef: the constant terms alone, one word per non-zero (valM / valT hold a 128-byte ring element per non-zero,
+                                                //   of which the one-product kernels would fetch a whole line for 8 bytes)
+    const u64 *spmv_vals() const { return const_coef ? valMc : valM; }
     void release() {
-        for (void *p : {(void *)rowptr, (void *)col, (void *)valM, (void *)colptr, (void *)rowidx, (void *)valT})
+        for (void *p : {(void *)rowptr, (void *)col, (void *)valM, (void *)colptr, (void *)rowidx, (void *)valT, (void *)valMc, (void *)valTc})
             if (p) (void)hipFree(p);
-        rowptr = col = colptr = rowidx = nullptr; valM = valT = nullptr; nnz = 0;
+        rowptr = col = colptr = rowidx = nullptr; valM = valT = valMc = valTc = nullptr; nnz = 0;
     }
 };
 

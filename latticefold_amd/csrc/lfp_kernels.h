@@ -48,7 +48,7 @@ inline u32 group_size(u32 left) { return left >= 4 ? 4 : left >= 2 ? 2 : 1; }
 // Decomp::decompose (decomp.rs:32-99): base-B split, fix_variables over ring tables, sparse mat-vec with ring coefficients
 void launch_decompose2(const u64 *f, size_t words, u64 B, u64 *F0, u64 *F1, hipStream_t s);
 void launch_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *rM /* [2][16] Montgomery */, hipStream_t s, int const_r = 0);   // const_r: both coordinates are constant polynomials
-void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s, int const_coef = 0);   // const_coef: every coefficient is a constant polynomial
+void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s, int const_coef = 0);   // const_coef: every coefficient is a constant polynomial AND valM holds the constant terms alone, one word per non-zero (LfpMatrix::spmv_vals)
 void launch_replicate(const u64 *src, size_t words, u32 copies, u64 *dst, hipStream_t s);
 // ---- set check / range check (lfp_rgchk.hip; setchk.rs:65-262, rgchk.rs:81-186) ----------------------------------------------------------
 constexpr int8_t LFP_ABSENT = -128;   // a zero entry of a monomial set (an absent sparse-matrix coefficient)

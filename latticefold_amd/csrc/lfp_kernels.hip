@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) k_spmv_ring_const(const u32 *rowptr, cons
     const int t = threadIdx.x & 15;
     if (row >= nrows) return;
     u64 acc = 0;
-    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) acc = add_p(acc, mont_mul(valM[(size_t)k * D], x[(size_t)col[k] * D + t]));
+    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) acc = add_p(acc, mont_mul(valM[k], x[(size_t)col[k] * D + t]));      // valM: one word per non-zero (LfpMatrix::valMc)
     y[row * D + t] = acc;
 }
 // dst[tab] = src for tab in 0..copies-1 (the tables of one vector, one per evaluation point)

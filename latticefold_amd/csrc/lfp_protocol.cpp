@@ -352,6 +352,13 @@ int upload_matrix(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, co
     HIPCHK(c, hipMemcpyAsync(m.colptr, cp.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(m.rowidx, ri.data(), nnz * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(m.valT, vv.data(), nnz * D * 8, hipMemcpyHostToDevice, c->st));
+    if (m.const_coef) {
+        if (hipMalloc(&m.valMc, (nnz ? nnz : 1) * 8) != hipSuccess || hipMalloc(&m.valTc, (nnz ? nnz : 1) * 8) != hipSuccess) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
+        if (nnz) {
+            HIPCHK(c, hipMemcpy2DAsync(m.valMc, 8, m.valM, D * 8, 8, nnz, hipMemcpyDeviceToDevice, c->st));
+            HIPCHK(c, hipMemcpy2DAsync(m.valTc, 8, m.valT, D * 8, 8, nnz, hipMemcpyDeviceToDevice, c->st));
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->st));   // the host staging vectors die here
     return LFPLUS_OK;
 }
@@ -529,7 +536,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     for (u32 q = 0; q < nM; q++) {                 // w_q = M_q^T eq(r) over the rank's COLUMNS (its rows of the vectors M_q multiplies); eq whole
         std::unique_ptr<DevBuf> w(new DevBuf);
         if (w->alloc(nl * wst * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (M^T eq)");
-        if (so.wscalar) lfp::launch_spmvT_eq_const(M[q].colptr + row0, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
+        if (so.wscalar) lfp::launch_spmvT_eq_const(M[q].colptr + row0, M[q].rowidx, M[q].valTc, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
         else lfp::launch_spmvT_eq(M[q].colptr + row0, M[q].rowidx, M[q].valT, so.eqr.as<u64>(), nl, w->as<u64>(), c->st);
         so.w.push_back(std::move(w));
     }
@@ -994,8 +1001,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         for (u32 q = 0; q < nM; q++) {
             const LfpMatrix &m = M[q];
             u64 *mq = base + (size_t)(3 + 4 * q) * nl * D;
-            lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, tauring.as<u64>(), nl, mq, c->st, m.const_coef);
-            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.valM, xin[j], nl, mq + (size_t)(1 + j) * nl * D, c->st, m.const_coef);
+            lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.spmv_vals(), tauring.as<u64>(), nl, mq, c->st, m.const_coef);
+            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.spmv_vals(), xin[j], nl, mq + (size_t)(1 + j) * nl * D, c->st, m.const_coef);
         }
     }
     HIPCHK(c, hipMemsetAsync(R + (size_t)nring * nl * D, 0, (size_t)2 * nl * D * 8, c->st));   // t0 | t1: zero beyond the prefix the host computed
@@ -1333,7 +1340,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     int rcm = M.get(c, n, 3, rowptr, col, val);
     if (rcm) return rcm;
     LFP_MARK(c, "(before linearize)");
-    for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr + row0, M[q].col, M[q].valM, c->f, nl, G[0].as<u64>() + (size_t)q * nl * D, c->st, M[q].const_coef);
+    for (u32 q = 0; q < 3; q++) lfp::launch_spmv_ring(M[q].rowptr + row0, M[q].col, M[q].spmv_vals(), c->f, nl, G[0].as<u64>() + (size_t)q * nl * D, c->st, M[q].const_coef);
     std::vector<u64> r(nvars);
     for (u32 j = 0; j < nvars; j++) r[j] = tr->challenge();
     eq_build_local(c, r.data(), nvars, E[0].as<u64>());

@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) k_spmvT_eq_const(const u32 *colptr, const
     const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     u64 s = 0;
-    for (u32 k = colptr[c]; k < colptr[c + 1]; k++) s = add_p(s, mont_mul(eq[rowidx[k]], val[(size_t)k * 16]));
+    for (u32 k = colptr[c]; k < colptr[c + 1]; k++) s = add_p(s, mont_mul(eq[rowidx[k]], val[k]));      // val: one word per non-zero (LfpMatrix::valTc)
     w[c] = to_mont(s);
 }
 void launch_spmvT_eq_const(const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t n, u64 *w, hipStream_t s) {
