@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include "lf_host.h"
 #include "lfp_ctx.h"
@@ -392,6 +393,7 @@ struct MatHold {
 struct ScOut {          // device-side leftovers the range check reuses
     DevBuf eqr;         // eq(r, .) Montgomery, n words (whole on every rank: M^T eq reads arbitrary rows)
     std::vector<std::unique_ptr<DevBuf>> w;   // w_q = M_q^T eq(r): the rank's nloc ring elements each
+    std::function<void(lfplus_transcript *)> absorb;      // the absorb of the evaluations, for a caller that deferred it (set_check_dev's defer_absorb)
     bool wscalar = false;                     // every M_q has constant coefficients: w_q holds nloc SCALARS (Montgomery) -- eq is scalar, so w_q is constant too, and
                                               // every sum weighted by it takes the scalar-weight form (no negacyclic rotations, an eighth of the weight traffic)
     DevBuf part, small;
@@ -433,7 +435,7 @@ int gather_tables(lfplus_ctx *c, const u64 *tab, size_t ld, u32 ntab, u32 w, u64
 
 // In::set_check on device-resident monomial sets (matrix sets first, then vector sets, as setchk.rs:66-82 orders them)
 int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::vector<SetRef> &mats, const std::vector<SetRef> &vecs,
-                  const MatHold &M, u64 *r_out, u64 *msgs, u64 *e_out, u64 *b_out, ScOut &so) {
+                  const MatHold &M, u64 *r_out, u64 *msgs, u64 *e_out, u64 *b_out, ScOut &so, bool defer_absorb = false) {
     // Sharded (c->world > 1): the SetRefs point at the rank's rows; tables, rounds and evaluations run over those nl rows, the partial round messages and
     // partial evaluations are summed over the ranks, and the last log2(world) rounds run replicated on gathered tables.
     const size_t n = (size_t)1 << nvars, nl = c->sharded() ? (size_t)c->nloc : n;
@@ -567,9 +569,14 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         if (!rcx && nvec) rcx = lfp_xsum(c, b_out, (size_t)nvec * D);
         if (rcx) return rcx;
     }
-    tr->absorb_ring(e_out, (size_t)(1 + nM) * nmat * ncols);   // absorb_evaluations (setchk.rs:342-353)
-    tr->absorb_ring(b_out, nvec);
-    LFP_MARK(c, "set check: evaluations + absorb");
+    so.absorb = [=](lfplus_transcript *t) {                    // absorb_evaluations (setchk.rs:342-353): 3 ms of Poseidon at the range check's shape (768 ring elements)
+        t->absorb_ring(e_out, (size_t)(1 + nM) * nmat * ncols);
+        t->absorb_ring(b_out, nvec);
+    };
+    if (!defer_absorb) {       // (the range check enqueues its own evaluation passes first and absorbs while they run)
+        so.absorb(tr);
+        LFP_MARK(c, "set check: evaluations + absorb");
+    }
     return LFPLUS_OK;
 }
 }  // namespace
@@ -628,7 +635,7 @@ int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr,
     for (u32 l = 0; l < L; l++)
         for (u32 ki = 0; ki < k; ki++) mats.push_back({ctxs[l]->Df + (size_t)ki * nl * 16, 16});
     for (u32 l = 0; l < L; l++) vecs.push_back({ctxs[l]->mtau + row0, 1});
-    int rc = set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so);
+    int rc = set_check_dev(c, tr, nvars, mats, vecs, M, r_out, msgs, e_out, b_out, so, true);
     if (rc) return rc;
     // evaluations at r (rgchk.rs:107-170): v / c[0] = f at r, a[0] = tau at r, b[0] = the set check's b; per matrix M_q: ct(M_q tau), M_q m_tau, M_q f
     DevBuf ev;
@@ -650,6 +657,8 @@ int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr,
     }
     std::vector<u64> h(L * per);
     HIPCHK(c, hipMemcpyAsync(h.data(), ev.p, h.size() * 8, hipMemcpyDeviceToHost, c->st));
+    so.absorb(tr);             // the set check's evaluations: host Poseidon while the passes above run
+    LFP_MARK(c, "set check: evaluations absorbed (range check passes enqueued)");
     HIPCHK(c, hipStreamSynchronize(c->st));
     if ((rc = lfp_xsum(c, h.data(), h.size()))) return rc;
     for (u32 l = 0; l < L; l++) {
@@ -960,10 +969,6 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     tr->absorb_ring(comh, (size_t)L * kappa);
     cm_c_challenges(tr, kappa, ch);
     LFP_MARK(c, "cm: h, com_h, c challenges");
-    std::vector<u64> t0, t1;
-    if (!calc_t(ch.cz[0], ch.logk, ch.sp, k * D, ell, n, t0) || !calc_t(ch.cz[1], ch.logk, ch.sp, k * D, ell, n, t1))
-        return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: t0 too large (kappa' * k d * l * d > n; the reference panics, cm.rs:601)");
-    LFP_MARK(c, "cm: t(z) on the host");
     // tables.  Scalars (Montgomery): eq(r, .) | tau_l.  Ring (canonical): per instance m_tau, f, h, then per matrix M tau, M m_tau, M f, M h; then t0, t1
     // Sharded: every table holds the rank's nl rows; the M_q x rows read x at arbitrary columns, so their inputs are whole vectors -- tau, m_tau and f are whole
     // on every rank already, h is all-gathered (n ring elements per instance: the one large exchange of Cm::prove)
@@ -1006,6 +1011,11 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         }
     }
     HIPCHK(c, hipMemsetAsync(R + (size_t)nring * nl * D, 0, (size_t)2 * nl * D * 8, c->st));   // t0 | t1: zero beyond the prefix the host computed
+    // t(z) on the host (0.8 ms at k = 4) while the device builds the instance tables enqueued above
+    std::vector<u64> t0, t1;
+    if (!calc_t(ch.cz[0], ch.logk, ch.sp, k * D, ell, n, t0) || !calc_t(ch.cz[1], ch.logk, ch.sp, k * D, ell, n, t1))
+        return fail(c, LFPLUS_E_ARG, "lfplus_cm_prove: t0 too large (kappa' * k d * l * d > n; the reference panics, cm.rs:601)");
+    LFP_MARK(c, "cm: table launches, t(z) on the host");
     for (int z = 0; z < 2; z++) {        // the rank's rows of the non-zero prefix
         const std::vector<u64> &tz = z ? t1 : t0;
         const size_t pre = tz.size() / D;
