@@ -61,6 +61,7 @@ u32 sc_round_max_blocks();
 u32 launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part /* sc_round_max_blocks * 4; returns the blocks used */, hipStream_t s);
 void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u64 rM, hipStream_t s);
 u32 eval_chunks(size_t n);
+void launch_sum_parts(const u64 *part, u32 chunks, size_t stride, u32 nout, u64 *out, hipStream_t s);      // out[o] = sum_chunk part[chunk * stride + o]
 // out[col][16] = sum_row w[row] X^e(dig[row][col]); wstride 1: scalar Montgomery weights (out canonical), 16: canonical ring weights.  part: eval_chunks(n) * ncols * 16
 void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s);
 // 16 columns against nw <= 4 SCALAR weight tables (Montgomery) in one pass (exponent histogram): out[q * ostride + col * 16 + t]; part: nw * eval_chunks(n) * 256 words

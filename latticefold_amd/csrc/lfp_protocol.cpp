@@ -451,6 +451,16 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         so.small.alloc((size_t)((1 + nM) * nmat * ncols + nvec + 8) * D * 8) || (c->sharded() && tgath.alloc((size_t)ntab * c->world * 8)))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (set check tables)");
     std::vector<u64> alpha(nmat + nvec), cch(nvars);
+    // Round 0 ahead of time.  The round polynomial is sum_i rc^i S_i(X), S_i = the sum over the pairs of eq_i (sum_j alpha_i^j (m_ij^2 - m'_ij)): S_i needs set i's tables
+    // and alpha_i only, not the batching challenge rc drawn after the last set -- so set i's share of round 0 is enqueued right behind its tables, under the ~0.2 ms
+    // of Poseidon the host spends on the next set's nvars + 2 challenges, and the message is combined on the host once rc is known (the same field elements).
+    // (Without rc -- a single matrix set -- the reference's closure has its own shape, see coef below: the round runs in the loop as before.)
+    const bool early = nmat > 1 && nl >= 2 && !(c->sharded() && nl < 2) && !getenv("LFPLUS_SC_NO_EARLY");
+    DevBuf coefA;
+    std::vector<u64> coefAh((size_t)(nmat + nvec) * ncols, 0);
+    u64 *hpart = c->pin(std::max((size_t)lfp::sc_round_max_blocks() * 4, (size_t)(nmat + nvec) * 4));   // the kernels write their block partials into mapped host memory
+    if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
+    if (early && coefA.alloc(coefAh.size() * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (set check coefficients)");
     for (u32 i = 0; i < nmat + nvec; i++) {
         const SetRef &sr = i < nmat ? mats[i] : vecs[i - nmat];
         const u32 cols = i < nmat ? ncols : 1, t0 = i < nmat ? i * (2 * ncols + 1) : nmat * (2 * ncols + 1) + 3 * (i - nmat);
@@ -462,6 +472,14 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         lfp::launch_sc_tables(sr.dig, nl, cols, pw, tabs[0].as<u64>() + (size_t)t0 * nl, nl, c->st);
         eq_build_local(c, cch.data(), nvars, tabs[0].as<u64>() + (size_t)(t0 + 2 * cols) * nl);
         alpha[i] = tr->challenge();
+        if (early) {
+            u64 ap = i < nmat ? 1 : alpha[i];
+            for (u32 j = 0; j < cols; j++) { coefAh[(size_t)i * ncols + j] = to_mont(ap); ap = fmul(ap, alpha[i]); }
+            HIPCHK(c, hipMemcpyAsync(coefA.as<u64>() + (size_t)i * ncols, &coefAh[(size_t)i * ncols], cols * 8, hipMemcpyHostToDevice, c->st));
+            const lfp::ScDesc di = i < nmat ? lfp::ScDesc{1, ncols, 0, 1} : lfp::ScDesc{0, ncols, 1, 1};      // the one set, its tables at the origin
+            const u32 nbi = lfp::launch_sc_round(tabs[0].as<u64>() + (size_t)t0 * nl, nl, nl / 2, di, coefA.as<u64>() + (size_t)i * ncols, so.part.as<u64>(), c->st);
+            lfp::launch_sum_parts(so.part.as<u64>(), nbi, 4, 4, c->hpin_dev + (size_t)i * 4, c->st);
+        }
     }
     const bool have_rc = nmat > 1;
     const u64 rc = have_rc ? tr->challenge() : 1;
@@ -479,8 +497,6 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     // MLSumcheck::prove_as_subprotocol (latticefold utils/sumcheck.rs:53-80), degree 3
     tr->absorb_const(nvars);
     tr->absorb_const(3);
-    u64 *hpart = c->pin((size_t)lfp::sc_round_max_blocks() * 4);   // the kernels write their block partials into mapped host memory
-    if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
     int cur = 0;
     size_t len = nl, ld = nl;
     bool dist = c->sharded();
@@ -495,7 +511,8 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         }
         const size_t half = len / 2;
         auto tA = std::chrono::steady_clock::now();
-        const u32 nb = lfp::launch_sc_round(tcur, ld, half, d, coefd.as<u64>(), c->hpin_dev, c->st);
+        const bool pre = early && rnd == 0;           // the sets' shares S_i are in hpart[i][4] already (Montgomery): the message is sum_i rc^i S_i
+        const u32 nb = pre ? 0 : lfp::launch_sc_round(tcur, ld, half, d, coefd.as<u64>(), c->hpin_dev, c->st);
         HIPCHK(c, hipStreamSynchronize(c->st));
         auto tB = std::chrono::steady_clock::now();
         u64 *m = msgs + (size_t)rnd * 4 * D;
@@ -503,7 +520,11 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         u64 sums[4];
         for (int x = 0; x < 4; x++) {
             u64 s = 0;
-            for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 4 + x]);
+            if (pre) {
+                u64 rp = 1;
+                for (u32 i = 0; i < nmat + nvec; i++) { s = fadd(s, fmul(rp, hpart[(size_t)i * 4 + x])); rp = fmul(rp, rc); }
+            } else
+                for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 4 + x]);
             sums[x] = s;
         }
         if (dist) { int rcx = lfp_xsum(c, sums, 4); if (rcx) return rcx; }

@@ -324,6 +324,10 @@ u32 eval_chunks(size_t n) {
     size_t b = cdiv(n, 256);
     return (u32)(b < 1 ? 1 : (b > cap ? cap : b));
 }
+// out[o] = sum over `chunks` rows of part[chunk * stride + o], o < nout (words kept in the form they have)
+void launch_sum_parts(const u64 *part, u32 chunks, size_t stride, u32 nout, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)nout, 32)), dim3(1024), 0, s, part, chunks, stride, nout, 0, out);
+}
 void launch_wmono(const int8_t *dig, size_t n, u32 ncols, const u64 *w, u32 wstride, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = eval_chunks(n);
     if (ncols == 16) hipLaunchKernelGGL((k_wmono<16>), dim3(ch), dim3(256), 0, s, dig, (size_t)16, n, w, wstride, part, 16u, 0u);

@@ -36,9 +36,15 @@ def _rand_csr(n, seed, per_row=2):
 
 
 @pytest.mark.parametrize("nvars,nmat,ncols,nvec,nM", [(2, 1, 4, 0, 0), (2, 2, 4, 0, 0), (3, 2, 4, 2, 0), (5, 1, 16, 1, 1), (10, 3, 16, 2, 2), (13, 2, 16, 1, 1)])
-def test_set_check_matches_oracle(ctx, nvars, nmat, ncols, nvec, nM):
+@pytest.mark.parametrize("round0_ahead", [True, False])
+def test_set_check_matches_oracle(ctx, nvars, nmat, ncols, nvec, nM, round0_ahead, monkeypatch):
     """shapes of setchk.rs:355-495 (one / batched / mixed sets) and of the range check (16 columns, vectors, M_i rows); random exponents,
-    a few absent entries (identity-like sparse sets)"""
+    a few absent entries (identity-like sparse sets).  round0_ahead: every set's share of round 0 is computed behind its tables and the message combined with
+    the batching challenge on the host (the default with more than one matrix set); False (LFPLUS_SC_NO_EARLY=1): round 0 in the loop, over all the sets"""
+    if round0_ahead:
+        monkeypatch.delenv("LFPLUS_SC_NO_EARLY", raising=False)
+    else:
+        monkeypatch.setenv("LFPLUS_SC_NO_EARLY", "1")
     n = 1 << nvars
     rng = np.random.default_rng(nvars * 100 + nmat)
     dig = rng.integers(-7, 8, size=(nmat, n, ncols)).astype(np.int8)
