@@ -636,7 +636,9 @@ extern "C" int lfplus_set_check(lfplus_ctx *c, lfplus_transcript *tr, uint32_t n
 // m_tau) -- all on the same device, same n = 2^nvars and k.  Runs on ctxs[0]'s stream.
 namespace {
 int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr, const MatHold &M, uint64_t *r_out, uint64_t *msgs,
-                     uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, ScOut &so) {
+                     uint64_t *e_out, uint64_t *b_out, uint64_t *v_out, uint64_t *a_out, uint64_t *bb_out, uint64_t *c_out, ScOut &so,
+                     const std::function<int()> &before_absorb = nullptr) {      // before_absorb: device work of the caller that needs no challenge -- enqueued ahead of the 3 ms of
+                                                                                  // host Poseidon that absorb the set check's evaluations
     lfplus_ctx *c = ctxs[0];
     const u32 nM = (u32)M.size();
     const u64 n = c->n;
@@ -678,6 +680,7 @@ int range_check_core(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcript *tr,
     }
     std::vector<u64> h(L * per);
     HIPCHK(c, hipMemcpyAsync(h.data(), ev.p, h.size() * 8, hipMemcpyDeviceToHost, c->st));
+    if (before_absorb) { const int rcb = before_absorb(); if (rcb) return rcb; }
     so.absorb(tr);             // the set check's evaluations: host Poseidon while the passes above run
     LFP_MARK(c, "set check: evaluations absorbed (range check passes enqueued)");
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -955,7 +958,54 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     int rc = M.get(c, n, nM, rowptr, col, val);
     if (rc) return rc;
     ScOut so;
-    rc = range_check_core(ctxs, L, tr, M, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, so);
+    const size_t nl = (size_t)c->nloc, row0 = (size_t)c->row0;       // the rank's rows (= n, 0 unsharded)
+    const bool shd = c->sharded();
+    // tables of the sumcheckers.  Scalars (Montgomery): eq(r, .) | tau_l.  Ring (canonical): per instance m_tau, f, h, then per matrix M tau, M m_tau, M f, M h; then t0, t1
+    // Sharded: every table holds the rank's nl rows; the M_q x rows read x at arbitrary columns, so their inputs are whole vectors -- tau, m_tau and f are whole
+    // on every rank already, h is all-gathered (n ring elements per instance: the one large exchange of Cm::prove)
+    const u32 per = 4 + 4 * nM, nring = L * (per - 1), nS = 1 + L, nR = nring + 2;
+    // The sumcheckers run over the BATCHED tables (eq, V | U, Z: lfp_rgchk.hip, k_cm_combine): kS = kR = 2 tables per round instead of nS and nR.
+    // LFPLUS_CM_FULL=1 keeps the rounds over all the instance tables (the reference's own shape; the parity tests run both)
+    const bool cm_full = getenv("LFPLUS_CM_FULL") != nullptr;      // (read per call: the tests flip it)
+    const bool batched = !cm_full;
+    const u32 kS = batched ? 2 : nS, kR = batched ? 2 : nR;
+    DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring, mtring, hwhole, Sg, Rg, S2, R2, eqro, evpart;
+    const u32 nb0 = lfp::cm_round_blocks(nl / 2);
+    u64 *S = nullptr, *R = nullptr;
+    // Everything of the tables that needs no challenge of Cm::prove -- eq(r, .), tau, m_tau, f and their products with the M_q: three quarters of the table work --
+    // is enqueued from inside the range check, ahead of the host's absorb of the set check's evaluations (before_absorb); h, M_q h, t0 and t1 follow below
+    auto tables_early = [&]() -> int {
+        if (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8) || Sw[0].alloc((size_t)kS * (nl / 2) * 8) || Sw[1].alloc((size_t)kS * (nl / 4 + 1) * 8) ||
+            Rw[0].alloc((size_t)kR * (nl / 2) * D * 8) || Rw[1].alloc((size_t)kR * (nl / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
+            part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)) || (nM && shd && (mtring.alloc(n * D * 8) || hwhole.alloc(n * D * 8))) ||
+            (shd && (Sg.alloc((size_t)kS * c->world * 8) || Rg.alloc((size_t)kR * c->world * D * 8))) ||
+            (batched && (S2.alloc((size_t)2 * nl * 8) || R2.alloc((size_t)2 * nl * D * 8) || eqro.alloc(nl * 8) ||
+                         evpart.alloc(std::max((size_t)lfp::cm_eval_chunks(nl) * nring * D, (size_t)lfp::eval_chunks(nl) * 4) * 8))))
+            return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm tables)");
+        S = S0.as<u64>(); R = R0.as<u64>();
+        HIPCHK(c, hipMemcpyAsync(S, so.eqr.as<u64>() + row0, nl * 8, hipMemcpyDeviceToDevice, c->st));
+        for (u32 l = 0; l < L; l++) {
+            u64 *base = R + (size_t)l * (per - 1) * nl * D;
+            lfp::launch_to_mont(ctxs[l]->tau + row0, nl, S + (size_t)(1 + l) * nl, c->st);
+            lfp::launch_cm_materialize(ctxs[l]->mtau + row0, nullptr, nl, base, c->st);
+            HIPCHK(c, hipMemcpyAsync(base + nl * D, ctxs[l]->f + row0 * D, nl * D * 8, hipMemcpyDeviceToDevice, c->st));
+            if (!nM) continue;
+            lfp::launch_cm_materialize(nullptr, ctxs[l]->tau, n, tauring.as<u64>(), c->st);
+            const u64 *xin[2] = {base, base + nl * D};      // m_tau, f as whole vectors
+            if (shd) {
+                lfp::launch_cm_materialize(ctxs[l]->mtau, nullptr, n, mtring.as<u64>(), c->st);
+                xin[0] = mtring.as<u64>(); xin[1] = ctxs[l]->f;
+            }
+            for (u32 q = 0; q < nM; q++) {
+                const LfpMatrix &m = M[q];
+                u64 *mq = base + (size_t)(3 + 4 * q) * nl * D;
+                lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.spmv_vals(), tauring.as<u64>(), nl, mq, c->st, m.const_coef);
+                for (int j = 0; j < 2; j++) lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.spmv_vals(), xin[j], nl, mq + (size_t)(1 + j) * nl * D, c->st, m.const_coef);
+            }
+        }
+        return LFPLUS_OK;
+    };
+    rc = range_check_core(ctxs, L, tr, M, r_out, msgs, e_out, b_out, v_out, a_out, bb_out, c_out, so, tables_early);
     if (rc) return rc;
     CmChallenges ch;
     cm_challenges(tr, k, kappa, nullptr, L, ch);
@@ -969,8 +1019,6 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     HIPCHK(c, hipMemcpyAsync(spd.p, spi.data(), spi.size() * 4, hipMemcpyHostToDevice, c->st));
     std::vector<std::vector<u64>> fcoms(L, std::vector<u64>((size_t)3 * kappa * D));
     std::vector<u64> comMf((size_t)k * kappa * D * D);
-    const size_t nl = (size_t)c->nloc, row0 = (size_t)c->row0;       // the rank's rows (= n, 0 unsharded)
-    const bool shd = c->sharded();
     for (u32 l = 0; l < L; l++) {
         h[l].reset(new DevBuf);
         if (h[l]->alloc(nl * D * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (h)");
@@ -990,45 +1038,19 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     tr->absorb_ring(comh, (size_t)L * kappa);
     cm_c_challenges(tr, kappa, ch);
     LFP_MARK(c, "cm: h, com_h, c challenges");
-    // tables.  Scalars (Montgomery): eq(r, .) | tau_l.  Ring (canonical): per instance m_tau, f, h, then per matrix M tau, M m_tau, M f, M h; then t0, t1
-    // Sharded: every table holds the rank's nl rows; the M_q x rows read x at arbitrary columns, so their inputs are whole vectors -- tau, m_tau and f are whole
-    // on every rank already, h is all-gathered (n ring elements per instance: the one large exchange of Cm::prove)
-    const u32 per = 4 + 4 * nM, nring = L * (per - 1), nS = 1 + L, nR = nring + 2;
-    // The sumcheckers run over the BATCHED tables (eq, V | U, Z: lfp_rgchk.hip, k_cm_combine): kS = kR = 2 tables per round instead of nS and nR.
-    // LFPLUS_CM_FULL=1 keeps the rounds over all the instance tables (the reference's own shape; the parity tests run both)
-    const bool cm_full = getenv("LFPLUS_CM_FULL") != nullptr;      // (read per call: the tests flip it)
-    const bool batched = !cm_full;
-    const u32 kS = batched ? 2 : nS, kR = batched ? 2 : nR;
-    DevBuf S0, R0, Sw[2], Rw[2], rcpd, part, tauring, mtring, hwhole, Sg, Rg, S2, R2, eqro, evpart;
-    const u32 nb0 = lfp::cm_round_blocks(nl / 2);
-    if (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8) || Sw[0].alloc((size_t)kS * (nl / 2) * 8) || Sw[1].alloc((size_t)kS * (nl / 4 + 1) * 8) ||
-        Rw[0].alloc((size_t)kR * (nl / 2) * D * 8) || Rw[1].alloc((size_t)kR * (nl / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
-        part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)) || (nM && shd && (mtring.alloc(n * D * 8) || hwhole.alloc(n * D * 8))) ||
-        (shd && (Sg.alloc((size_t)kS * c->world * 8) || Rg.alloc((size_t)kR * c->world * D * 8))) ||
-        (batched && (S2.alloc((size_t)2 * nl * 8) || R2.alloc((size_t)2 * nl * D * 8) || eqro.alloc(nl * 8) ||
-                     evpart.alloc(std::max((size_t)lfp::cm_eval_chunks(nl) * nring * D, (size_t)lfp::eval_chunks(nl) * 4) * 8))))
-        return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm tables)");
-    u64 *S = S0.as<u64>(), *R = R0.as<u64>();
-    HIPCHK(c, hipMemcpyAsync(S, so.eqr.as<u64>() + row0, nl * 8, hipMemcpyDeviceToDevice, c->st));
+    // the challenge-dependent rest of the tables: h_l and the M_q h_l
     for (u32 l = 0; l < L; l++) {
         u64 *base = R + (size_t)l * (per - 1) * nl * D;
-        lfp::launch_to_mont(ctxs[l]->tau + row0, nl, S + (size_t)(1 + l) * nl, c->st);
-        lfp::launch_cm_materialize(ctxs[l]->mtau + row0, nullptr, nl, base, c->st);
-        HIPCHK(c, hipMemcpyAsync(base + nl * D, ctxs[l]->f + row0 * D, nl * D * 8, hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(base + 2 * nl * D, h[l]->p, nl * D * 8, hipMemcpyDeviceToDevice, c->st));
-        if (nM) lfp::launch_cm_materialize(nullptr, ctxs[l]->tau, n, tauring.as<u64>(), c->st);
-        const u64 *xin[3] = {base, base + nl * D, base + 2 * nl * D};      // m_tau, f, h as whole vectors
+        const u64 *hin = base + 2 * nl * D;
         if (nM && shd) {
-            lfp::launch_cm_materialize(ctxs[l]->mtau, nullptr, n, mtring.as<u64>(), c->st);
             int rcg = lfp_allgather_dev(c, h[l]->as<u64>(), hwhole.as<u64>(), nl * D);
             if (rcg) return rcg;
-            xin[0] = mtring.as<u64>(); xin[1] = ctxs[l]->f; xin[2] = hwhole.as<u64>();
+            hin = hwhole.as<u64>();
         }
         for (u32 q = 0; q < nM; q++) {
             const LfpMatrix &m = M[q];
-            u64 *mq = base + (size_t)(3 + 4 * q) * nl * D;
-            lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.spmv_vals(), tauring.as<u64>(), nl, mq, c->st, m.const_coef);
-            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.spmv_vals(), xin[j], nl, mq + (size_t)(1 + j) * nl * D, c->st, m.const_coef);
+            lfp::launch_spmv_ring(m.rowptr + row0, m.col, m.spmv_vals(), hin, nl, base + (size_t)(3 + 4 * q + 3) * nl * D, c->st, m.const_coef);
         }
     }
     HIPCHK(c, hipMemsetAsync(R + (size_t)nring * nl * D, 0, (size_t)2 * nl * D * 8, c->st));   // t0 | t1: zero beyond the prefix the host computed
