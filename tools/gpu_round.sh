@@ -6,7 +6,7 @@ tag=${1:-r02}
 mkdir -p $R/gpurun_out
 python $R/bench.py > $R/gpurun_out/${tag}_bench_c4.json 2> $R/gpurun_out/${tag}_bench_c4.err
 python $R/bench.py --workload C2 --steps 20 --warmup 3 > $R/gpurun_out/${tag}_bench_c2.json 2>/dev/null
-python $R/bench.py --workload C3 --steps 5 --warmup 2 > $R/gpurun_out/${tag}_bench_c3.json 2>/dev/null
+python $R/bench.py --workload C3 --steps 10 --warmup 2 > $R/gpurun_out/${tag}_bench_c3.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 for wl in C4 C3; do
   rm -rf /tmp/prof_$wl
