@@ -18,6 +18,7 @@ extern "C" int lfplus_ctx_create(int device, lfplus_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return LFPLUS_E_NO_DEVICE;
     lfplus_ctx *c = new lfplus_ctx;
     c->device = device;
+    c->pool.device = device;
     if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->err_d, 4) != hipSuccess) {
         delete c;
         return LFPLUS_E_HIP;
@@ -40,6 +41,8 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     (void)hipStreamDestroy(c->st);
     delete c;
 }
+// Releases the scratch blocks that destroyed contexts left in the process-wide cache (lfp_ctx.h::LfpDevCache); device < 0: on every device
+extern "C" void lfplus_scratch_trim(int device) { LfpDevCache::inst().trim(device); }
 extern "C" const char *lfplus_last_error(const lfplus_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 // ---- column sharding over `world` ranks, one GPU each (lfplus.h) ------------------------------------------------------------------------

@@ -1,5 +1,8 @@
 // lfp_ctx.h -- the context of the LatticeFold+ slice (include/lfplus.h), shared by lfp_capi.cpp and lfp_protocol.cpp
 #pragma once
+#include <cstdio>
+#include <mutex>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <memory>
 #include <string>
@@ -29,22 +32,77 @@ struct LfpMatrix {
     }
 };
 
+// Idle scratch blocks of DESTROYED contexts, per device, for the whole process: a prover is a handful of contexts, and a caller that builds one prover per proof (the
+// reference's benches do; so does bench.py) would otherwise pay hipMalloc for every table of every prove -- ~30 allocations, 17 GB at 2^20 rows, several milliseconds
+// inside the timed call.  A context's pool looks here before it asks the driver, and hands its blocks over when the context is destroyed.  Bounded (LFPLUS_CACHE_GB,
+// default 64; 0 switches it off); lfplus_scratch_trim() releases everything.  Blocks are never freed at process exit (the runtime may be gone by then).
+struct LfpDevCache {
+    struct Blk { void *p; size_t bytes; int device; };
+    std::mutex mu;
+    std::vector<Blk> blks;
+    size_t total = 0, cap = 0;
+    LfpDevCache() {
+        const char *e = getenv("LFPLUS_CACHE_GB");
+        const long gb = e ? atol(e) : 64;
+        cap = gb > 0 ? (size_t)gb << 30 : 0;
+    }
+    static LfpDevCache &inst() { static LfpDevCache *c = new LfpDevCache; return *c; }
+    void *take(int device, size_t bytes, size_t *got) {      // best fit, at most twice the request (as the pools)
+        std::lock_guard<std::mutex> g(mu);
+        int best = -1;
+        for (size_t i = 0; i < blks.size(); i++)
+            if (blks[i].device == device && blks[i].bytes >= bytes && blks[i].bytes <= 2 * bytes + (1u << 16) && (best < 0 || blks[i].bytes < blks[(size_t)best].bytes)) best = (int)i;
+        if (best < 0) return nullptr;
+        void *p = blks[(size_t)best].p;
+        *got = blks[(size_t)best].bytes;
+        total -= *got;
+        blks.erase(blks.begin() + best);
+        return p;
+    }
+    void give(int device, void *p, size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (total + bytes <= cap) { blks.push_back({p, bytes, device}); total += bytes; return; }
+        }
+        (void)hipFree(p);
+    }
+    void trim(int device) {                                  // device < 0: every device
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < blks.size();)
+                if (device < 0 || blks[i].device == device) { drop.push_back(blks[i]); total -= blks[i].bytes; blks.erase(blks.begin() + (long)i); } else i++;
+        }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (Blk &b : drop) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+        (void)hipSetDevice(cur);
+    }
+};
+
 // Scratch pool of a context: the protocol stages allocate their tables (up to ~1 GB at n = 2^18) anew in every call, and hipMalloc / hipFree of such blocks
 // cost milliseconds each; freed blocks are kept and handed out again (best fit, at most twice the request).  One thread per context at a time.
 struct LfpPool {
     struct Blk { void *p; size_t bytes; bool busy; };
     std::vector<Blk> blks;
+    int device = 0;
     void *get(size_t bytes) {
         if (!bytes) bytes = 8;
         int best = -1;
         for (size_t i = 0; i < blks.size(); i++)
             if (!blks[i].busy && blks[i].bytes >= bytes && blks[i].bytes <= 2 * bytes + (1u << 16) && (best < 0 || blks[i].bytes < blks[(size_t)best].bytes)) best = (int)i;
         if (best >= 0) { blks[(size_t)best].busy = true; return blks[(size_t)best].p; }
+        size_t got = 0;
+        if (void *q = LfpDevCache::inst().take(device, bytes, &got)) { blks.push_back({q, got, true}); return q; }
         void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) {      // out of memory: drop the idle blocks and retry once
-            for (size_t i = 0; i < blks.size();)
-                if (!blks[i].busy) { (void)hipFree(blks[i].p); blks.erase(blks.begin() + (long)i); } else i++;
-            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (getenv("LFPLUS_POOL_TRACE")) fprintf(stderr, "[lfplus pool] miss %zu bytes (%zu blocks held)\n", bytes, blks.size());
+        if (hipMalloc(&p, bytes) != hipSuccess) {      // out of memory: drop the idle blocks (the process-wide cache first) and retry once
+            LfpDevCache::inst().trim(device);
+            if (hipMalloc(&p, bytes) != hipSuccess) {
+                for (size_t i = 0; i < blks.size();)
+                    if (!blks[i].busy) { (void)hipFree(blks[i].p); blks.erase(blks.begin() + (long)i); } else i++;
+                if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+            }
         }
         blks.push_back({p, bytes, true});
         return p;
@@ -53,8 +111,8 @@ struct LfpPool {
         for (Blk &b : blks) if (b.p == p) { b.busy = false; return; }
         if (p) (void)hipFree(p);
     }
-    void clear() {
-        for (Blk &b : blks) (void)hipFree(b.p);
+    void clear() {                                           // (the context is being destroyed, its stream drained: the blocks go to the process-wide cache)
+        for (Blk &b : blks) LfpDevCache::inst().give(device, b.p, b.bytes);
         blks.clear();
     }
 };

@@ -1379,6 +1379,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     while (((size_t)1 << nvars) < n) nvars++;
     HIPCHK(c, hipSetDevice(c->device));
     PoolScope pool_scope(c);
+    LFP_MARK(c, "(linearize: entry)");
     // Sharded: the witness is whole, the three tables g_q = M_q f and eq(r, .) hold the rank's nl rows; partial round messages are summed over the ranks,
     // the last log2(world) rounds run replicated on gathered tables, v = f(ro) is a partial sum over the rank's rows.
     const size_t nl = c->sharded() ? (size_t)c->nloc : n, row0 = c->sharded() ? (size_t)c->row0 : 0;
@@ -1389,6 +1390,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
         part.alloc(std::max<size_t>((size_t)nb0 * 64, (size_t)lfp::eval_chunks(n) * D) * 8) || small.alloc(4 * D * 8) ||
         (c->sharded() && (Eg.alloc((size_t)c->world * 8) || Gg.alloc((size_t)3 * c->world * D * 8))))
         return fail(c, LFPLUS_E_HIP, "hipMalloc (linearize tables)");
+    LFP_MARK(c, "(linearize: allocs)");
     MatHold M;
     int rcm = M.get(c, n, 3, rowptr, col, val);
     if (rcm) return rcm;
@@ -1471,6 +1473,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     HIPCHK(c, hipStreamSynchronize(c->st));
     { int rcx = lfp_xsum(c, evals, D); if (rcx) return rcx; }
     tr->absorb_ring(evals, 4);
+    LFP_MARK(c, "linearize: v = f(ro), absorb");
     return LFPLUS_OK;
 }
 // ComR1CSProof::verify, host only: stage 1 = a sumcheck round, 2 = e (va vb - vc) != s (the reference asserts, r1cs.rs:159)

@@ -45,6 +45,8 @@ def _lib():
         L.lfplus_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.lfplus_ctx_destroy.argtypes = [vp]
         L.lfplus_ctx_destroy.restype = None
+        L.lfplus_scratch_trim.argtypes = [C.c_int]
+        L.lfplus_scratch_trim.restype = None
         L.lfplus_last_error.argtypes = [vp]
         L.lfplus_last_error.restype = C.c_char_p
         L.lfplus_set_matrix.argtypes = [vp, u64p, C.c_uint32, C.c_uint64]
@@ -109,6 +111,11 @@ class DecompParameters:
     def for_frog(k, b=D // 2):
         """l = ceil(log_{d/2} q) as every reference call site computes it (rgchk.rs:369-371, benches/double_commitment.rs:68-70)"""
         return DecompParameters(b, k, math.ceil(math.log(float(P)) / math.log(D / 2)))
+
+
+def scratch_trim(device=-1):
+    """Frees the scratch blocks destroyed contexts left in the process-wide cache (lfplus_scratch_trim; device < 0: every device)"""
+    _lib().lfplus_scratch_trim(int(device))
 
 
 class PlusContext:
