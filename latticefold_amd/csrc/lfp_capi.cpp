@@ -33,10 +33,9 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     c->A = nullptr;
     c->A_ref.reset();      // frees the matrix unless another context still shares it
     c->drop_mats();
-    c->pool.clear();
-    for (void *p : {(void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part,
-                    (void *)c->err_d, (void *)c->g})
-        if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->f, (void *)c->Df, (void *)c->mtau, (void *)c->comMf, (void *)c->tau, (void *)c->coms, (void *)c->part, (void *)c->g}) c->own_free(p);
+    c->pool.clear();       // (every block is idle now: they go to the process-wide cache)
+    if (c->err_d) (void)hipFree(c->err_d);
     if (c->hpin) (void)hipHostFree(c->hpin);
     (void)hipStreamDestroy(c->st);
     delete c;
@@ -93,11 +92,11 @@ static int shape_buffers(lfplus_ctx *c, u32 kappa, u64 n) {
     c->kappa = kappa;
     c->n = n;
     for (u64 **p : {&c->tau, &c->coms})
-        if (*p) { (void)hipFree(*p); *p = nullptr; }
-    if (c->mtau) { (void)hipFree(c->mtau); c->mtau = nullptr; }
-    HIPCHK(c, hipMalloc(&c->tau, n * 8));
-    HIPCHK(c, hipMalloc(&c->mtau, n));
-    HIPCHK(c, hipMalloc(&c->coms, (size_t)3 * kappa * 16 * 8));
+        if (*p) { c->own_free(*p); *p = nullptr; }
+    if (c->mtau) { c->own_free(c->mtau); c->mtau = nullptr; }
+    HIPCHK(c, c->own_alloc(&c->tau, n * 8));
+    HIPCHK(c, c->own_alloc(&c->mtau, n));
+    HIPCHK(c, c->own_alloc(&c->coms, (size_t)3 * kappa * 16 * 8));
     return LFPLUS_OK;
 }
 extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kappa, uint64_t n) {
@@ -138,8 +137,11 @@ extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) 
         HIPCHK(c, hipStreamSynchronize(c->st));
         return LFPLUS_OK;
     }
-    int rc = upload(c, &c->f, f, (size_t)n * 16);
-    if (rc) return rc;
+    c->own_free(c->f);
+    c->f = nullptr; c->nf = 0;
+    HIPCHK(c, c->own_alloc(&c->f, (size_t)n * 16 * 8));
+    HIPCHK(c, hipMemcpyAsync(c->f, f, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
     c->nf = n;
     return LFPLUS_OK;
 }
@@ -172,10 +174,10 @@ static Plan plan_for(u64 n, u32 kappa, u32 k) {
 }
 static int ensure_part(lfplus_ctx *c, size_t words) {
     if (c->part_cap >= words) return LFPLUS_OK;
-    if (c->part) (void)hipFree(c->part);
+    c->own_free(c->part);
     c->part = nullptr;
     c->part_cap = 0;
-    HIPCHK(c, hipMalloc(&c->part, words * 8));
+    HIPCHK(c, c->own_alloc(&c->part, words * 8));
     c->part_cap = words;
     return LFPLUS_OK;
 }
@@ -210,15 +212,15 @@ static int check_params(lfplus_ctx *c, u64 b, u32 k, u32 l) {
 static int prepare(lfplus_ctx *c, u32 k, const Plan &p) {
     size_t dfb = (size_t)k * c->nloc * 16, cmw = p.nout_m + p.nout_f;
     if (c->Df_cap < dfb) {
-        if (c->Df) (void)hipFree(c->Df);
+        c->own_free(c->Df);
         c->Df = nullptr; c->Df_cap = 0;
-        HIPCHK(c, hipMalloc(&c->Df, dfb));
+        HIPCHK(c, c->own_alloc(&c->Df, dfb));
         c->Df_cap = dfb;
     }
     if (c->comMf_cap < cmw) {
-        if (c->comMf) (void)hipFree(c->comMf);
+        c->own_free(c->comMf);
         c->comMf = nullptr; c->comMf_cap = 0;
-        HIPCHK(c, hipMalloc(&c->comMf, cmw * 8));
+        HIPCHK(c, c->own_alloc(&c->comMf, cmw * 8));
         c->comMf_cap = cmw;
     }
     return ensure_part(c, (size_t)p.nblk * (p.nout_m + p.nout_f) + (size_t)p.nblk2 * 2 * p.nout_f);
@@ -488,8 +490,8 @@ static int decompose_impl(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const 
         lfplus_ctx *d = s2 ? dst1 : dst0;
         if (!d) continue;
         if (!d->f || d->nf != n) {
-            if (d->f) { (void)hipFree(d->f); d->f = nullptr; d->nf = 0; }
-            HIPCHK2(hipMalloc(&d->f, vw * 8));
+            if (d->f) { d->own_free(d->f); d->f = nullptr; d->nf = 0; }
+            HIPCHK2(d->own_alloc(&d->f, vw * 8));
             d->nf = n;
         }
         d->have = false;

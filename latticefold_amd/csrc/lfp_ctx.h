@@ -151,6 +151,10 @@ struct lfplus_ctx {
     u64 g_n = 0;
     bool g_valid = false;   // false once lfplus_mlin has summed the instances' g into ctxs[0]->g (it is then the resident witness f, not g_0)
     LfpPool pool;
+    // the context's own long-lived buffers (the from_f results, the witness, g) come from the pool too and stay busy until they are replaced or the context dies:
+    // with the pool they end up in the process-wide cache instead of going back to the driver (a prover per proof allocated ~10 of them inside every prove)
+    template <class T> hipError_t own_alloc(T **p, size_t bytes) { *p = (T *)pool.get(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
+    void own_free(void *p) { if (p) pool.put(p); }
     // pinned host staging of the per-round partial sums and other small downloads (a copy into pageable memory is staged and synchronised by
     // the runtime: tens of microseconds per sumcheck round)
     // -- and the round kernels write their block partials straight into it (mapped: no copy command between the kernel and the host's read)

@@ -1184,8 +1184,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     for (u32 l = 0; l < L; l++) {
         lfplus_ctx *cl = ctxs[l];
         if (cl->g_n != nl) {          // the rank's rows of g
-            if (cl->g) { (void)hipFree(cl->g); cl->g = nullptr; cl->g_n = 0; }
-            HIPCHK(c, hipMalloc(&cl->g, nl * D * 8));
+            if (cl->g) { cl->own_free(cl->g); cl->g = nullptr; cl->g_n = 0; }
+            HIPCHK(c, cl->own_alloc(&cl->g, nl * D * 8));
             cl->g_n = nl;
         }
         lfp::launch_cm_g(cl->tau + row0, cl->mtau + row0, cl->f + row0 * D, h[l]->as<u64>(), nl, cs, cl->g, c->st);
