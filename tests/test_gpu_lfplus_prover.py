@@ -91,3 +91,5 @@ def test_plus_prover_matches_oracle(kappa, k, rounds, device_acc):
         assert prover.transcript.get_challenge() == oracle.tr.challenge()
     finally:
         prover.close()
+        if device_acc:             # the contexts' blocks went to the process-wide scratch cache: release them once here (later provers allocate afresh)
+            plus.scratch_trim(0)
