@@ -119,7 +119,7 @@ def cpu_baseline(target_wl, budget_s=25.0):
     }
 
 
-PROF_TAGS = ("r04d", "r04c", "r04b", "r04", "r03d", "r03c", "r03b", "r03a", "r02d")     # profiles/<tag>_pmc_<wl>.json, <tag>_<wl>_kernel_stats.csv, <tag>_sq_<wl>.json: newest first
+PROF_TAGS = ("r04e", "r04d", "r04c", "r04b", "r04", "r03d", "r03c", "r03b", "r03a", "r02d")     # profiles/<tag>_pmc_<wl>.json, <tag>_<wl>_kernel_stats.csv, <tag>_sq_<wl>.json: newest first
 
 
 def _prof(kind, wl_name):
