@@ -402,10 +402,16 @@ __global__ void __launch_bounds__(256) k_to_mont(const u64 *in, size_t n, u64 *o
 }
 void launch_to_mont(const u64 *in, size_t n, u64 *out, hipStream_t s) { hipLaunchKernelGGL(k_to_mont, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, in, n, out); }
 // h[row] = sum_{ki < k} sum_{j < 16} X^e(Df[ki][row][j]) * s'[ki][j]  (cm.rs:82-103): rotations of the short challenges (|coefficients| <= 128), exact
-// in int32; thread = (row, coefficient)
+// in int32; thread = (row, coefficient).  The LDS copy of s'[ki][j] is the 32-entry negacyclic extension ext[m] = -v[m] (m < 16), v[m - 16] (m >= 16): coefficient
+// t of X^e v is ext[16 + t - e], one read without the wrap test; a row's 16 digits come in one 16-byte load and exp(d) = d & 15 for the digits in (-8, 8)
+// (first version: 16 byte loads per row and ki, index mask, compare and negate per term -- 0.33 ms per instance at 2^20 rows and k = 4)
 __global__ void __launch_bounds__(256) k_cm_h(const int8_t *Df, size_t n, u32 k, const int32_t *sp /* [k][16][16] */, u64 *h) {
-    __shared__ int32_t ssp[16 * 16 * 16];
-    for (u32 i = threadIdx.x; i < k * 256; i += 256) ssp[i] = sp[i];
+    __shared__ int32_t ext[16 * 16 * 32];
+    for (u32 i = threadIdx.x; i < k * 512; i += 256) {
+        const u32 kj = i >> 5, m = i & 31;
+        const int32_t v = sp[kj * 16 + (m & 15)];
+        ext[i] = m < 16 ? -v : v;
+    }
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * 16) return;
@@ -413,11 +419,13 @@ __global__ void __launch_bounds__(256) k_cm_h(const int8_t *Df, size_t n, u32 k,
     const int t = (int)(i & 15);
     int acc = 0;
     for (u32 ki = 0; ki < k; ki++) {
-        const int8_t *d = Df + ((size_t)ki * n + row) * 16;
+        const uint4 dv = *(const uint4 *)(Df + ((size_t)ki * n + row) * 16);
+        const u32 dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        const int32_t *ek = ext + ki * 512 + 16 + t;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const int e = exp_of(d[j]), v = ssp[(ki * 16 + j) * 16 + ((t - e) & 15)];
-            acc += t >= e ? v : -v;
+            const int e = (int)((dw[j >> 2] >> (8 * (j & 3))) & 15u);
+            acc += ek[j * 32 - e];
         }
     }
     h[i] = acc >= 0 ? (u64)acc : P - (u64)(-acc);
