@@ -433,23 +433,40 @@ __global__ void __launch_bounds__(256) k_cm_h(const int8_t *Df, size_t n, u32 k,
 void launch_cm_h(const int8_t *Df, size_t n, u32 k, const int32_t *sp, u64 *h, hipStream_t s) {
     hipLaunchKernelGGL(k_cm_h, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, s, Df, n, k, sp, h);
 }
-// g[row] = s0 tau[row] + s1 X^e(mtau[row]) + s2 f[row] + h[row]  (cm.rs:164-181); s: three short challenges as int32 [3][16]
+// g[row] = s0 tau[row] + s1 X^e(mtau[row]) + s2 f[row] + h[row]  (cm.rs:164-181); s: three short challenges as int32 [3][16].
+// The challenges are small signed integers: |s| * f < 2^95, so the 17 products of a coefficient (s0[t] tau and the 16 terms of the negacyclic s2 f) are summed as
+// plain 128-bit integers, positive and negative terms apart, and reduced once each ((hi 2^64 + lo) mod p = hi 2^64 + lo: mont_mul(hi, 2^128) + lo).
+// (First version: mul_p = two Montgomery products per term, 34 per coefficient: 0.59 ms per instance at 2^20 rows against 0.1 ms of traffic.)
+__device__ __forceinline__ u64 red128(unsigned __int128 x) {      // x < 2^100
+    u64 lo = (u64)x;
+    if (lo >= P) lo -= P;
+    return add_p(mont_mul((u64)(x >> 64), R2), lo);
+}
 __global__ void __launch_bounds__(256) k_cm_g(const u64 *tau, const int8_t *mtau, const u64 *f, const u64 *h, size_t n, CmShort s, u64 *g) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * 16) return;
     const size_t row = i >> 4;
     const int t = (int)(i & 15);
     auto fe = [](int v) { return v >= 0 ? (u64)v : P - (u64)(-v); };
-    u64 acc = h[i];
-    acc = add_p(acc, mul_p(fe(s.v[0][t]), tau[row]));
-    const int e = exp_of(mtau[row]), r1 = s.v[1][(t - e) & 15];
-    acc = add_p(acc, fe(t >= e ? r1 : -r1));
+    unsigned __int128 pos = 0, neg = 0;
+    {
+        const int s0 = s.v[0][t];
+        const unsigned __int128 pr = (unsigned __int128)(u64)(s0 < 0 ? -(long long)s0 : (long long)s0) * tau[row];
+        pos += s0 < 0 ? 0 : pr;
+        neg += s0 < 0 ? pr : 0;
+    }
     const u64 *fr = f + row * 16;
 #pragma unroll
     for (int j = 0; j < 16; j++) {          // s2[j] X^j * f: coefficient t gets s2[j] f[t - j] (t >= j), - s2[j] f[t - j + 16]
-        const u64 pr = mul_p(fe(s.v[2][j]), fr[(t - j) & 15]);
-        acc = t >= j ? add_p(acc, pr) : sub_p(acc, pr);
+        const int sv = s.v[2][j];
+        const bool ng = (sv < 0) != (t < j);
+        const unsigned __int128 pr = (unsigned __int128)(u64)(sv < 0 ? -(long long)sv : (long long)sv) * fr[(t - j) & 15];
+        pos += ng ? 0 : pr;
+        neg += ng ? pr : 0;
     }
+    u64 acc = add_p(h[i], sub_p(red128(pos), red128(neg)));
+    const int e = exp_of(mtau[row]), r1 = s.v[1][(t - e) & 15];
+    acc = add_p(acc, fe(t >= e ? r1 : -r1));
     g[i] = acc;
 }
 void launch_cm_g(const u64 *tau, const int8_t *mtau, const u64 *f, const u64 *h, size_t n, const CmShort &s, u64 *g, hipStream_t st) {
