@@ -119,16 +119,17 @@ def cpu_baseline(target_wl, budget_s=25.0):
     }
 
 
-PROF_TAGS = ("r04e", "r04d", "r04c", "r04b", "r04", "r03d", "r03c", "r03b", "r03a", "r02d")     # profiles/<tag>_pmc_<wl>.json, <tag>_<wl>_kernel_stats.csv, <tag>_sq_<wl>.json: newest first
-
-
 def _prof(kind, wl_name):
-    """first existing committed profile of this kind for the workload: (path, tag) or (None, None)"""
-    for tag in PROF_TAGS:
-        f = {"pmc": f"{tag}_pmc_{wl_name}.json", "stats": f"{tag}_{wl_name}_kernel_stats.csv", "sq": f"{tag}_sq_{wl_name}.json"}[kind]
-        path = os.path.join(ROOT, "profiles", f)
-        if os.path.exists(path):
-            return path, tag
+    """the committed profile of this kind for the workload, as named by profiles/latest.json -- the manifest tools/gpu_round.sh writes for ONE profiling round
+    (tools/write_profile_manifest.py), so that pmc / kernel stats / SQ counters always belong to the same code state: (path, tag) or (None, None)"""
+    try:
+        man = json.load(open(os.path.join(ROOT, "profiles", "latest.json")))
+        f = man["files"].get(kind, {}).get(wl_name)
+        path = f and os.path.join(ROOT, "profiles", f)
+        if path and os.path.exists(path):
+            return path, man["tag"]
+    except Exception:
+        pass
     return None, None
 
 
@@ -233,17 +234,21 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
         wl = plus.make_plus_workload(name)
         r1cs, zs = wl.r1cs(), [wl.z(i) for i in range(wl.L)]
         A = wl.ajtai_matrix(column_shard(wl.n, rank, world) if world > 1 else None)     # a rank uploads its columns only
-        # iteration 0: the witnesses cross PCIe inside the timed call and F0 / F1 come back to the host (`ms_host_io`); iterations 1, 2: inputs resident
-        # (PlusProver.preload) and the accumulator left on the device (lfplus_decompose_resident) -- the contract's timed region (`ms`)
+        # iteration 0: untimed warm-up (first hipMalloc of every table, kernel load, empty scratch cache).  Then NREP warm runs of each form:
+        # host I/O (`ms_host_io`): the witnesses cross PCIe inside the timed call and F0 / F1 come back to the host -- the region the reference's
+        # PlusProver::prove signature implies for a first fold, and the region `cpu_oracle_ms` covers;
+        # resident (`ms`, the contract's timed region): inputs resident (PlusProver.preload), the accumulator left on the device (lfplus_decompose_resident).
+        NREP = 3
         best, proof, exch, host_io = None, None, None, None
-        for it in range(3):
+        for it in range(1 + 2 * NREP):
+            resident = it > NREP
             shard = None
             if world > 1:      # a fresh RCCL communicator per prover; under the gloo test hook (two ranks on one GPU) the host transport
                 shard = (rank, world, _bcast_id(plus, dist, rank) if dist.get_backend() == "nccl" else make_allgather(dist.new_group()))
             prover = plus.PlusProver.init(A, list(r1cs), max(1, wl.L - 2), wl.params(), plus.PoseidonTranscript(), device, shard)
             try:
                 comps = [plus.ComR1CS.new(prover.ctxs[0], r1cs, z, 1, wl.B, wl.k) for z in zs]
-                if it > 0:
+                if resident:
                     prover.device_acc = True
                     prover.preload(comps)
                 if dist is not None:
@@ -256,9 +261,11 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
             finally:
                 prover.close()
             if it == 0:
-                host_io = dt
-            else:
+                continue
+            if resident:
                 best = dt if best is None else min(best, dt)
+            else:
+                host_io = dt if host_io is None else min(host_io, dt)
         if dist is not None:      # the slowest rank's best time
             import torch
             t = torch.tensor([best], dtype=torch.float64)
@@ -268,7 +275,8 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
             best = float(t.item())
         rec = {"workload": f"{name}: n = 2^{wl.nvars}, L = {wl.L} fresh instances, k = {wl.k}, kappa = {wl.kappa}, B = {wl.B}", "ms": 1e3 * best,
                "ms_host_io": 1e3 * host_io,
-               "io": "ms: witnesses resident before the call, (F0, F1) left on the device; ms_host_io (first call, also the warm-up): L witnesses uploaded and F0, F1 downloaded inside"}
+               "io": f"one untimed warm-up, then the min of {NREP} warm runs of each form.  ms: witnesses resident before the call, (F0, F1) left on the device; "
+                     "ms_host_io: L witnesses uploaded and F0, F1 downloaded inside the call"}
         if rank == 0:
             tv, ok = None, True
             Av = A if world == 1 else np.zeros((wl.kappa, wl.n, 16), dtype=np.uint64)      # (the verifier reads the matrix's shape only)
@@ -283,12 +291,16 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
                 sha = hashlib.sha256(np.ascontiguousarray(proof["linb2x"]["cm_g"], dtype=np.uint64).tobytes()).hexdigest()
                 rec["matches_oracle_fixture"] = sha == gold[name].get("linb2x_cm_g")
                 rec["cpu_oracle_ms"] = 1e3 * gold[name]["oracle_seconds"]["prove"]
-                rec["cpu_oracle_source"] = "tests/golden/lfplus_digests.json (oracle/lfp*.c, one thread, timed on the GPU box's host when the fixture was made; not re-measured here)"
+                rec["cpu_oracle_source"] = ("tests/golden/lfplus_digests.json: oracle/lfp*.c, one thread, timed on the host that made the fixture (oracle_host in the fixture; "
+                                            "P15-P17 and P20 were made on different hosts) -- not re-measured here")
+                rec["cpu_oracle_region"] = "the whole PlusProver::prove from host witnesses to host (F0, F1): compare with ms_host_io, not with ms"
         if world > 1:
             rec["parallelism"] = f"shard x{world}: double commitments, sumcheck tables and evaluations over the ranks' rows, RCCL all-gather + modular sum"
             rec["exchanges"] = {"count": exch[0], "total_us": exch[1], "max_us": exch[2]}
         rows.append(rec)
-    return {"op": "PlusProver::prove", "ring": "Frog Z_p[X]/(X^16+1), coefficient form", "runs": rows,
+    held = plus.scratch_bytes(device)
+    plus.scratch_trim(device)          # the provers are gone: give their idle scratch back to the driver before the caller returns to the main path
+    return {"op": "PlusProver::prove", "ring": "Frog Z_p[X]/(X^16+1), coefficient form", "runs": rows, "scratch_cache_bytes_released": held,
             "parity": "bit-exact vs the in-repo oracle (tests/test_gpu_lfplus_scale.py, tests/test_dist_shard_lfplus.py against committed oracle-only digests); the oracle "
                       "is pinned to the reference through the transcript KATs only"}
 
@@ -374,12 +386,16 @@ def main():
         scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed(), digits_only=(wl.ring == "goldilocks"))
         wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
         cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        # accumulator = linearized copy (benches/utils.rs:637-655).  Both calls start from a FRESH transcript, exactly as tests/tools/make_scale_digests.py drives the
+        # oracle: the proof of every timed step is then the proof whose digests are committed in tests/golden/scale_digests.json (checked after the timed loop)
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript(ring=wl.ring))
         tr0 = api.PoseidonTranscript(ring=wl.ring)
-        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr0)  # accumulator = linearized copy (benches/utils.rs:637-655)
+        last = {}
 
         def step():
             lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr0.clone())
             w0.free()
+            last["lc"], last["proof"] = lc, proof
             return proof
 
         # extra streams (opt-in): independent instances with their own context, witness and accumulator on the same GPU
@@ -446,6 +462,19 @@ def main():
             ex = {"transport": transport, "exchanges_per_step": n_ex / args.steps, "mean_us": us_tot / max(n_ex, 1), "max_us": us_max,
                   "note": "host-side latency of one exchange (enqueue of ncclAllGather + modular-sum kernel when the transport is rccl; the whole blocking "
                           "round trip for the host transport)"}
+        # the proof of the LAST TIMED step against the committed oracle-only fixture of this workload (seed 0: rank 0 of a replica run, every rank of a sharded one)
+        fixture_info.clear()
+        if (shard or rank == 0) and last:
+            try:
+                import hashlib
+                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "scale_digests.json"))).get(wl.name)
+                if gold:
+                    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
+                    fixture_info.update(matches_oracle_fixture=bool(sha(last["proof"]) == gold.get("proof") and sha(last["lc"]) == gold.get("lcccs_out")),
+                                        fixture="tests/golden/scale_digests.json[%s]: sha256 of the whole proof and of the folded LCCCS of the last timed step "
+                                                "(oracle-only fixture, tests/tools/make_scale_digests.py)" % wl.name)
+            except Exception as e:      # (a missing fixture is not a bench failure)
+                fixture_info.update(matches_oracle_fixture=None, fixture=f"not checked: {e!r}")
         free_b, total_b = ctx.device_memory()
         mem_info["hbm_in_use_gib"] = (total_b - free_b) / 2.0 ** 30   # whole device, this process being its only user: context, witnesses, torch's own few MB
         for st in extra:
@@ -455,7 +484,7 @@ def main():
         return wl, elapsed, phases_acc, kstats, ex, timelines
 
     mode = args.parallelism
-    mem_info = {}
+    mem_info, fixture_info = {}, {}
     shard = world > 1 and mode in ("auto", "shard")
     wl, elapsed, phases_acc, kstats, exch, timelines = measure(shard)
     replicas_extra = None
@@ -592,6 +621,7 @@ def main():
             "roofline": roof,
             "phases_ms_per_step": {k: v / args.steps for k, v in phases_acc.items()},
         }
+        out["config"].update(fixture_info)
         if wl.ring == "goldilocks" and not shard and args.streams == 1:
             try:
                 ph, ph_src = phase_report(wl.name.lower(), timelines, phases_acc.get("host_transcript", 0.0) / args.steps)

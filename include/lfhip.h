@@ -31,6 +31,15 @@ extern "C" {
 
 #define LF_RING_WORDS 24
 
+/* ABI version: bumped whenever an existing entry point changes meaning (additions alone do not bump it).  lf_abi_version() returns the constant the
+ * library was built with; a binding compares it with the LFHIP_ABI_VERSION it was generated from.
+ *   5  lf_last_fold_paths: *sv_round_mask is the GEMM-round mask alone on both rings (bits 8..15 used to carry the split-round count of the
+ *      linearization on Goldilocks, and BabyBear contexts returned 0): the count moved to lf_last_lin_split_rounds, the table rounds' mask to
+ *      lf_last_fold_split_rounds.  lf_debug_i8_prof is declared (it was exported without a prototype).
+ *   4  (round 3) first numbered state of this header. */
+#define LFHIP_ABI_VERSION 5
+int lf_abi_version(void);
+
 enum {
     LF_OK = 0,
     LF_ERR_INVALID = -1,        /* bad argument / CommitmentError::WrongWitnessLength (commitment.rs:14-27),
@@ -283,8 +292,12 @@ int lf_last_kernel_stats(lf_ctx *, float *fold_round_ms, int *fold_round_launche
  * written (<= max_marks), or an error code < 0 */
 int lf_last_timeline(lf_ctx *, char *names /* 32 * max_marks */, double *ms, int max_marks);
 
-/* which rounds of the last folding sumcheck ran as int8 matrix-core GEMMs (bit i-1 = round i; lf_sv_rounds.h) -- test hook */
+/* which rounds of the last folding sumcheck ran as int8 matrix-core GEMMs (bit i-1 = round i; lf_sv_rounds.h) -- test hook.
+ * ABI 5: the mask only, on both rings (see LFHIP_ABI_VERSION above for the old packing) */
 int lf_last_fold_paths(lf_ctx *, unsigned *sv_round_mask);
+/* diagnostic: cycle counters of the int8 commit kernel's producer / multiplier waves when the library was built with -DLF_I8_PROF (tools/i8_prof.py);
+ * 64 words, all zero in a normal build */
+int lf_debug_i8_prof(uint64_t *out64);
 /* how many rounds of the last linearization sumcheck ran in the split eq form -- test hook */
 int lf_last_lin_split_rounds(lf_ctx *, unsigned *rounds);
 /* which table rounds of the last folding sumcheck ran in the split eq form (three lazy products per table, message completed on the host;

@@ -50,9 +50,12 @@ typedef struct lfplus_ctx lfplus_ctx;
 int lfplus_ctx_create(int device, lfplus_ctx **out);
 void lfplus_ctx_destroy(lfplus_ctx *ctx);
 /* Scratch memory (tables of the protocol stages) is pooled per context and, when a context is destroyed, kept in a process-wide per-device cache for the next
- * contexts (a prover built per proof would otherwise pay hipMalloc for every table inside every prove).  Bounded by LFPLUS_CACHE_GB (default 64, 0 = off);
- * this call frees what the cache holds on `device` (< 0: on every device).  No counterpart in the reference (the Rust allocator owns its Vecs). */
+ * contexts (a prover built per proof would otherwise pay hipMalloc for every table inside every prove).  Bounded per device: LFPLUS_CACHE_GB when set (0 = off),
+ * otherwise min(32 GB, a quarter of the device's memory).  Every allocator of the library releases the cache and retries before it reports out-of-memory.
+ * lfplus_scratch_trim frees what the cache holds on `device` (< 0: on every device); lfplus_scratch_bytes returns the bytes it holds there now.
+ * No counterpart in the reference (the Rust allocator owns its Vecs). */
 void lfplus_scratch_trim(int device);
+size_t lfplus_scratch_bytes(int device);
 const char *lfplus_last_error(const lfplus_ctx *ctx);
 
 /* ---- multi-GPU: one prover column-sharded over `world` ranks, one GPU each (BASELINE configs[4]) ------------------------------------------

@@ -172,6 +172,13 @@ def dist_unique_ids():
     return out
 
 
+def abi_version():
+    """LFHIP_ABI_VERSION the library was built with (include/lfhip.h)"""
+    L = _lib()
+    L.lf_abi_version.restype = C.c_int
+    return int(L.lf_abi_version())
+
+
 def exported_symbols():
     """Every symbol include/lfhip.h declares (used by the CPU-side ABI test)."""
     import re

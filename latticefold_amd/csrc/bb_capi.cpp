@@ -181,7 +181,7 @@ static int install_tables(C *c, u64 nonres, const u64 *y) {
     std::vector<fe> mat((size_t)D * D);
     for (int i = 0; i < D; i++)
         for (int j = 0; j < D; j++) mat[(size_t)i * D + j] = from_canon(T.icrt[i][j]);
-    if (!c->d_icrt) HIPCHK(hipMalloc((void **)&c->d_icrt, mat.size() * sizeof(fe)));
+    if (!c->d_icrt) HIPCHK(lf_dev_malloc(&c->d_icrt, mat.size() * sizeof(fe)));
     HIPCHK(hipMemcpy(c->d_icrt, mat.data(), mat.size() * sizeof(fe), hipMemcpyHostToDevice));
     return LF_OK;
 }
@@ -523,7 +523,7 @@ static int prep_ajtai_i8(C *c) {
     const size_t ntiles = (c->nA + 7) / 8;
     const u32 MT = lf::ajtai_i8_row_tiles(R, kc);
     const size_t chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
-    HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch + lf::ajtai_i8_slack_bytes()));
+    HIPCHK(lf_dev_malloc(&c->dAb, chunk_bytes * nch + lf::ajtai_i8_slack_bytes()));
     HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch + lf::ajtai_i8_slack_bytes(), c->stream()));
     fe *coef;
     u64 *canon;
@@ -584,7 +584,7 @@ int BbCtx::ajtai_load(const uint64_t *A, size_t kappa, size_t n) {
     size_t col0, cnt;
     RET(shard_columns(c, n, &col0, &cnt));   // a sharded rank keeps only its column slice of the caller's matrix
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * RE * sizeof(fe)));
+    HIPCHK(lf_dev_malloc(&c->dA, kappa * cnt * RE * sizeof(fe)));
     for (size_t i = 0; i < kappa; i++) RET(up_ring(c, A + (i * n + col0) * RE, cnt, c->dA + i * RE * cnt));
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
@@ -599,7 +599,7 @@ int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
     size_t col0, cnt;
     RET(shard_columns(c, n, &col0, &cnt));
     if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
-    HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * RE * sizeof(fe)));
+    HIPCHK(lf_dev_malloc(&c->dA, kappa * cnt * RE * sizeof(fe)));
     launch_fill_ajtai(c->dA, (u32)kappa, cnt, n, col0, seed, c->stream());
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->kappa = (u32)kappa;
@@ -760,7 +760,7 @@ int BbCtx::ccs_load(const lf_params *P, const uint32_t *const *rowptr, const uin
     }
     auto dalloc = [](auto &vec, size_t bytes) -> void * {   // registered in the context at once: a failure half-way leaks nothing
         void *ptr = nullptr;
-        if (hipMalloc(&ptr, bytes) != hipSuccess) return nullptr;
+        if (lf_dev_malloc(&ptr, bytes) != hipSuccess) return nullptr;
         vec.push_back((typename std::remove_reference<decltype(vec)>::type::value_type)ptr);
         return ptr;
     };
@@ -808,7 +808,7 @@ int BbCtx::spmv(unsigned j, const uint64_t *z, uint64_t *out) {
 // ---- witnesses -----------------------------------------------------------------------------------------------------------
 static int witness_from_coef_table(C *c, const fe *coef_dev, lf_witness **out) {
     int32_t *pl;
-    HIPCHK(hipMalloc((void **)&pl, c->N * RE * 4));
+    HIPCHK(lf_dev_malloc(&pl, c->N * RE * 4));
     int *viol;
     if (c->tbuf("small_dev", 4096, (u64 **)&viol) != LF_OK) { (void)hipFree(pl); return LF_ERR_HIP; }
     (void)hipMemsetAsync(viol, 0, 4, c->stream());

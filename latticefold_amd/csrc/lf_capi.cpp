@@ -285,7 +285,7 @@ struct lf_ctx {
         HIPCHK(hipGetDeviceProperties(&pr, device));
         num_cus = pr.multiProcessorCount;
         void *d = nullptr;
-        HIPCHK(hipMalloc(&d, 4096));
+        HIPCHK(lf_dev_malloc(&d, 4096));
         HIPCHK(hipMemset(d, 0, 4096));
         tail_counters = (u32 *)d;
         tail_dev_chal = (u64 *)((char *)d + 1024);
@@ -298,7 +298,7 @@ struct lf_ctx {
         if (d_poseidon) return LF_OK;
         const u64 *a, *m;
         Transcript::params(&a, &m);
-        HIPCHK(hipMalloc((void **)&d_poseidon, (720 + 576) * 8));
+        HIPCHK(lf_dev_malloc(&d_poseidon, (720 + 576) * 8));
         HIPCHK(hipMemcpy(d_poseidon, a, 720 * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_poseidon + 720, m, 576 * 8, hipMemcpyHostToDevice));
         return LF_OK;
@@ -387,7 +387,7 @@ static int install_tables(lf_ctx *c, u64 nonres, const u64 *y) {
     if (build_crt_tables(nonres, y, T) != 0) return LF_ERR_BAD_TABLES;
     c->ring.T = T;
     c->dcrt = make_dev_crt(T);
-    if (!c->d_icrt) HIPCHK(hipMalloc((void **)&c->d_icrt, 576 * 8));
+    if (!c->d_icrt) HIPCHK(lf_dev_malloc(&c->d_icrt, 576 * 8));
     HIPCHK(hipMemcpy(c->d_icrt, &T.icrt[0][0], 576 * 8, hipMemcpyHostToDevice));
     return LF_OK;
 }
@@ -785,7 +785,7 @@ static int prep_ajtai_i8_begin(lf_ctx *c) {
     const size_t ntiles = (c->nA + 7) / 8;
     const u32 MT = ajtai_i8_row_tiles(R, kc);
     const size_t chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
-    HIPCHK(hipMalloc((void **)&c->dAb, chunk_bytes * nch + ajtai_i8_slack_bytes()));
+    HIPCHK(lf_dev_malloc(&c->dAb, chunk_bytes * nch + ajtai_i8_slack_bytes()));
     HIPCHK(hipMemsetAsync(c->dAb, 0, chunk_bytes * nch + ajtai_i8_slack_bytes(), c->stream()));
     c->i8_nch = nch;
     c->i8_kc = kc;
@@ -809,7 +809,7 @@ static int need_dA(lf_ctx *c) {
     const size_t chunk_bytes = (c->nA + 7) / 8 * (R.RD / 8) * MT * 1024;
     u64 *coef;
     RET(c->tbuf("i8_prep_coef", 24 * c->nA, &coef));
-    HIPCHK(hipMalloc((void **)&c->dA, (size_t)c->kappa * c->nA * 24 * 8));
+    HIPCHK(lf_dev_malloc(&c->dA, (size_t)c->kappa * c->nA * 24 * 8));
     for (u32 i = 0; i < c->kappa; i++) {
         launch_ajtai_unpack_i8(c->dAb + (size_t)(i / kc) * chunk_bytes, c->nA, i % kc, MT, R.RD, R.NL, coef, c->stream());
         launch_crt_fwd(c->dcrt, coef, c->dA + (size_t)i * 24 * c->nA, c->nA, c->stream());
@@ -835,7 +835,7 @@ static int ajtai_install(lf_ctx *c, size_t kappa, size_t n, const uint64_t *A_ho
     RET(prep_ajtai_i8_begin(c));
     const bool keep = !(c->digits_only && c->i8_nch);
     u64 *row = nullptr;
-    if (keep) HIPCHK(hipMalloc((void **)&c->dA, kappa * cnt * 24 * 8));
+    if (keep) HIPCHK(lf_dev_malloc(&c->dA, kappa * cnt * 24 * 8));
     else RET(c->tbuf("i8_prep_row", 24 * cnt, &row));
     if (keep && !A_host) launch_fill_ajtai(c->dA, (u32)kappa, cnt, n, col0, seed, c->stream());
     for (size_t i = 0; i < kappa; i++) {
@@ -1184,7 +1184,7 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
     // every device array is registered in the context as soon as it exists, so a failure half-way leaks nothing (free_ccs frees them)
     auto dalloc = [](auto &vec, size_t bytes) -> void * {
         void *ptr = nullptr;
-        if (hipMalloc(&ptr, bytes) != hipSuccess) return nullptr;
+        if (lf_dev_malloc(&ptr, bytes) != hipSuccess) return nullptr;
         vec.push_back((typename std::remove_reference<decltype(vec)>::type::value_type)ptr);
         return ptr;
     };
@@ -1235,7 +1235,7 @@ int lf_spmv(lf_ctx *c, unsigned j, const uint64_t *z, uint64_t *out) {
 // ---- witnesses ---------------------------------------------------------------------------------------------------------
 static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] canonical */, lf_witness **out) {
     int32_t *pl;
-    HIPCHK(hipMalloc((void **)&pl, c->N * 24 * 4));
+    HIPCHK(lf_dev_malloc(&pl, c->N * 24 * 4));
     int *viol;
     if (c->tbuf("small_dev", 4096, (u64 **)&viol) != LF_OK) { (void)hipFree(pl); return LF_ERR_HIP; }
     (void)hipMemsetAsync(viol, 0, 4, c->stream());
@@ -1362,7 +1362,7 @@ int lf_planes_alloc(lf_ctx *c, size_t bytes, int32_t **out) {
                 return LF_OK;
             }
     }
-    return hipMalloc((void **)out, bytes) == hipSuccess ? LF_OK : LF_ERR_HIP;
+    return lf_dev_malloc(out, bytes) == hipSuccess ? LF_OK : LF_ERR_HIP;
 }
 static void planes_release_dev(int device, size_t bytes, int32_t *p) {
     if (!p) return;
@@ -3528,7 +3528,8 @@ int lf_last_timeline(lf_ctx *c, char *names, double *ms, int max_marks) {
 }
 // measurement hook of tools/gpu_i8prof.sh (not part of the prover interface, not declared in lfhip.h): per-phase clock totals of the last commit
 // launch made with LF_I8_PROF set
-extern "C" int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_prof((unsigned long long *)out64) : LF_ERR_INVALID; }
+int lf_abi_version(void) { return LFHIP_ABI_VERSION; }
+int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_prof((unsigned long long *)out64) : LF_ERR_INVALID; }
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
     *sv_round_mask = c->bb ? c->bb->fold_paths() : c->sv_round_mask;

@@ -17,6 +17,19 @@
         if (rc__ != LF_OK) return rc__; \
     } while (0)
 
+// Device allocation of the main path: when the driver is out of memory, the idle scratch blocks that destroyed LatticeFold+ contexts left in the
+// process-wide cache (lfp_ctx.h LfpDevCache) are released and the request retried -- one process may run both provers, and that cache is invisible to hipMalloc.
+extern "C" void lfplus_scratch_trim(int device);
+template <class T> static inline hipError_t lf_dev_malloc(T **p, size_t bytes) {
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return e;
+    lfplus_scratch_trim(dev);
+    return hipMalloc((void **)p, bytes);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -30,7 +43,7 @@ struct DevBuf {
         const size_t slack = (b >> 3) < ((size_t)8 << 20) ? (b >> 3) : ((size_t)8 << 20);
         size_t want = b + slack + 256;
         if (hipMalloc(&p, want) != hipSuccess) {
-            if (hipMalloc(&p, b) != hipSuccess) return LF_ERR_HIP;
+            if (lf_dev_malloc(&p, b) != hipSuccess) return LF_ERR_HIP;
             want = b;
         }
         bytes = want;

@@ -19,7 +19,7 @@ extern "C" int lfplus_ctx_create(int device, lfplus_ctx **out) {
     lfplus_ctx *c = new lfplus_ctx;
     c->device = device;
     c->pool.device = device;
-    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->err_d, 4) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || lfp_dev_malloc(&c->err_d, 4) != hipSuccess) {
         delete c;
         return LFPLUS_E_HIP;
     }
@@ -42,6 +42,7 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
 }
 // Releases the scratch blocks that destroyed contexts left in the process-wide cache (lfp_ctx.h::LfpDevCache); device < 0: on every device
 extern "C" void lfplus_scratch_trim(int device) { LfpDevCache::inst().trim(device); }
+extern "C" size_t lfplus_scratch_bytes(int device) { return LfpDevCache::inst().held(device); }
 extern "C" const char *lfplus_last_error(const lfplus_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 // ---- column sharding over `world` ranks, one GPU each (lfplus.h) ------------------------------------------------------------------------
@@ -83,7 +84,7 @@ extern "C" int lfplus_dist_stats(lfplus_ctx *c, uint64_t *n_exchanges, double *t
 
 static int upload(lfplus_ctx *c, u64 **dst, const u64 *src, size_t words) {
     if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
-    HIPCHK(c, hipMalloc(dst, words * 8));
+    HIPCHK(c, lfp_dev_malloc(dst, words * 8));
     HIPCHK(c, hipMemcpyAsync(*dst, src, words * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     return LFPLUS_OK;
@@ -343,7 +344,7 @@ extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint6
     int rc = ensure_part(c, (size_t)p.nblk * p.nout_f + p.nout_f);
     if (rc) return rc;
     u64 *dv = nullptr;      // the rank's rows of v (all of them unsharded): partial commitment, summed over the ranks below
-    HIPCHK(c, hipMalloc(&dv, (size_t)c->nloc * 16 * 8));
+    HIPCHK(c, lfp_dev_malloc(&dv, (size_t)c->nloc * 16 * 8));
     (void)hipMemcpyAsync(dv, v + c->row0 * 16, (size_t)c->nloc * 16 * 8, hipMemcpyHostToDevice, c->st);
     u64 *res = c->part + (size_t)p.nblk * p.nout_f;
     enqueue_phase1(c, dv, 2, 0, p, c->part);
@@ -427,10 +428,10 @@ static int decompose_impl(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const 
             continue;
         }
         const u32 nnz = rowptr[j][n];
-        HIPCHK2(hipMalloc(&drp, (n + 1) * 4)); tofree.push_back(drp);
-        HIPCHK2(hipMalloc(&dci, (size_t)(nnz ? nnz : 1) * 4)); tofree.push_back(dci);
-        HIPCHK2(hipMalloc(&dv, (size_t)(nnz ? nnz : 1) * 16 * 8)); tofree.push_back(dv);
-        HIPCHK2(hipMalloc(&dy, lw * 8)); tofree.push_back(dy);
+        HIPCHK2(lfp_dev_malloc(&drp, (n + 1) * 4)); tofree.push_back(drp);
+        HIPCHK2(lfp_dev_malloc(&dci, (size_t)(nnz ? nnz : 1) * 4)); tofree.push_back(dci);
+        HIPCHK2(lfp_dev_malloc(&dv, (size_t)(nnz ? nnz : 1) * 16 * 8)); tofree.push_back(dv);
+        HIPCHK2(lfp_dev_malloc(&dy, lw * 8)); tofree.push_back(dy);
         std::vector<u64> vM((size_t)nnz * 16);
         for (size_t i = 0; i < vM.size(); i++) vM[i] = to_mont(val[j][i]);
         HIPCHK2(hipMemcpyAsync(drp, rowptr[j], (n + 1) * 4, hipMemcpyHostToDevice, c->st));
@@ -486,19 +487,24 @@ static int decompose_impl(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const 
     }
     if (F0) HIPCHK2(hipMemcpyAsync(F0, dF0, vw * 8, hipMemcpyDeviceToHost, c->st));
     if (F1) HIPCHK2(hipMemcpyAsync(F1, dF1, vw * 8, hipMemcpyDeviceToHost, c->st));
+    lfplus_ctx *publish[2] = {nullptr, nullptr};
     for (int s2 = 0; s2 < 2; s2++) {     // the parts as resident witnesses of the receiving contexts (all on c's stream: the source of F0 / F1 -- c->f -- was read above)
         lfplus_ctx *d = s2 ? dst1 : dst0;
         if (!d) continue;
-        if (!d->f || d->nf != n) {
-            if (d->f) { d->own_free(d->f); d->f = nullptr; d->nf = 0; }
+        const bool reuse = d->f && (d->nf == n || (s2 && d == dst0));
+        if (!reuse) {
+            if (d->f) { d->own_free(d->f); d->f = nullptr; }
+            d->nf = 0;
             HIPCHK2(d->own_alloc(&d->f, vw * 8));
-            d->nf = n;
         }
         d->have = false;
+        d->nf = 0;                        // no resident witness until the copy has COMPLETED: a failure below must not leave a length-n witness of undefined content
         HIPCHK2(hipMemcpyAsync(d->f, s2 ? dF1 : dF0, vw * 8, hipMemcpyDeviceToDevice, c->st));
+        publish[s2] = d;
     }
     HIPCHK2(hipStreamSynchronize(c->st));
     HIPCHK2(hipGetLastError());
+    for (lfplus_ctx *d : publish) if (d) d->nf = n;
 #undef HIPCHK2
     cleanup();
     return LFPLUS_OK;
@@ -527,7 +533,7 @@ extern "C" int lfplus_tensor(lfplus_ctx *c, const uint64_t *r, uint32_t n, uint6
     HIPCHK(c, hipSetDevice(c->device));
     u64 *buf = nullptr;
     size_t len = (size_t)1 << n;
-    HIPCHK(c, hipMalloc(&buf, 2 * len * 8));
+    HIPCHK(c, lfp_dev_malloc(&buf, 2 * len * 8));
     u64 *cur = buf, *nxt = buf + len, one = 1;
     (void)hipMemcpyAsync(cur, &one, 8, hipMemcpyHostToDevice, c->st);
     for (u32 i = 0; i < n; i++) {
@@ -550,7 +556,7 @@ extern "C" int lfplus_tensor_product(lfplus_ctx *c, const uint64_t *a, uint64_t 
     if (m * n > (1ull << 30)) return fail(c, LFPLUS_E_ARG, "lfplus_tensor_product: too large");
     HIPCHK(c, hipSetDevice(c->device));
     u64 *buf = nullptr;
-    HIPCHK(c, hipMalloc(&buf, (m + n + m * n) * 8));
+    HIPCHK(c, lfp_dev_malloc(&buf, (m + n + m * n) * 8));
     std::vector<u64> ha(a, a + m), hb(b, b + n);
     for (auto &x : ha) x %= lfp::P;
     for (auto &x : hb) x %= lfp::P;

@@ -1,5 +1,6 @@
 // lfp_ctx.h -- the context of the LatticeFold+ slice (include/lfplus.h), shared by lfp_capi.cpp and lfp_protocol.cpp
 #pragma once
+#include <cstdint>
 #include <cstdio>
 #include <mutex>
 #include <cstdlib>
@@ -34,18 +35,39 @@ struct LfpMatrix {
 
 // Idle scratch blocks of DESTROYED contexts, per device, for the whole process: a prover is a handful of contexts, and a caller that builds one prover per proof (the
 // reference's benches do; so does bench.py) would otherwise pay hipMalloc for every table of every prove -- ~30 allocations, 17 GB at 2^20 rows, several milliseconds
-// inside the timed call.  A context's pool looks here before it asks the driver, and hands its blocks over when the context is destroyed.  Bounded (LFPLUS_CACHE_GB,
-// default 64; 0 switches it off); lfplus_scratch_trim() releases everything.  Blocks are never freed at process exit (the runtime may be gone by then).
+// inside the timed call.  A context's pool looks here before it asks the driver, and hands its blocks over when the context is destroyed.  Bounded PER DEVICE:
+// LFPLUS_CACHE_GB when set (0 switches the cache off), otherwise a quarter of that device's memory (hipMemGetInfo total) and never more than 32 GB -- the memory is
+// invisible to every other allocator in the process, so it must stay a minority share on any part.  lfplus_scratch_trim() releases everything; the main path's
+// allocators (lf_common.h lf_dev_malloc) and this slice's own (lfp_dev_malloc below) call it before they report out-of-memory.  Blocks are never freed at process
+// exit (the runtime may be gone by then).
 struct LfpDevCache {
     struct Blk { void *p; size_t bytes; int device; };
     std::mutex mu;
     std::vector<Blk> blks;
-    size_t total = 0, cap = 0;
+    std::vector<size_t> total, cap;                          // per device; cap[d] == SIZE_MAX: not asked yet
+    long env_gb = -1;
     LfpDevCache() {
         const char *e = getenv("LFPLUS_CACHE_GB");
-        const long gb = e ? atol(e) : 64;
-        cap = gb > 0 ? (size_t)gb << 30 : 0;
+        if (e) env_gb = atol(e) > 0 ? atol(e) : 0;
     }
+    size_t cap_of(int device) {                              // (mu held)
+        if (device < 0) return 0;
+        if ((size_t)device >= cap.size()) { cap.resize((size_t)device + 1, SIZE_MAX); total.resize((size_t)device + 1, 0); }
+        if (cap[(size_t)device] == SIZE_MAX) {
+            if (env_gb >= 0) cap[(size_t)device] = (size_t)env_gb << 30;
+            else {
+                size_t fr = 0, tot = 0;
+                int cur = 0;
+                (void)hipGetDevice(&cur);
+                const bool ok = hipSetDevice(device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess;
+                (void)hipSetDevice(cur);
+                const size_t quarter = ok ? tot / 4 : 0, lim = (size_t)32 << 30;
+                cap[(size_t)device] = quarter < lim ? quarter : lim;
+            }
+        }
+        return cap[(size_t)device];
+    }
+    size_t held(int device) { std::lock_guard<std::mutex> g(mu); return device >= 0 && (size_t)device < total.size() ? total[(size_t)device] : 0; }
     static LfpDevCache &inst() { static LfpDevCache *c = new LfpDevCache; return *c; }
     void *take(int device, size_t bytes, size_t *got) {      // best fit, at most twice the request (as the pools)
         std::lock_guard<std::mutex> g(mu);
@@ -55,14 +77,15 @@ struct LfpDevCache {
         if (best < 0) return nullptr;
         void *p = blks[(size_t)best].p;
         *got = blks[(size_t)best].bytes;
-        total -= *got;
+        total[(size_t)device] -= *got;
         blks.erase(blks.begin() + best);
         return p;
     }
     void give(int device, void *p, size_t bytes) {
         {
             std::lock_guard<std::mutex> g(mu);
-            if (total + bytes <= cap) { blks.push_back({p, bytes, device}); total += bytes; return; }
+            const size_t lim = cap_of(device);
+            if (device >= 0 && total[(size_t)device] + bytes <= lim) { blks.push_back({p, bytes, device}); total[(size_t)device] += bytes; return; }
         }
         (void)hipFree(p);
     }
@@ -71,7 +94,7 @@ struct LfpDevCache {
         {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < blks.size();)
-                if (device < 0 || blks[i].device == device) { drop.push_back(blks[i]); total -= blks[i].bytes; blks.erase(blks.begin() + (long)i); } else i++;
+                if (device < 0 || blks[i].device == device) { drop.push_back(blks[i]); total[(size_t)blks[i].device] -= blks[i].bytes; blks.erase(blks.begin() + (long)i); } else i++;
         }
         int cur = 0;
         (void)hipGetDevice(&cur);
@@ -79,6 +102,17 @@ struct LfpDevCache {
         (void)hipSetDevice(cur);
     }
 };
+
+// hipMalloc of this slice outside the pools (matrices, per-call tables): out of memory => release the idle cache of the device and retry once
+template <class T> static inline hipError_t lfp_dev_malloc(T **p, size_t bytes) {
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return e;
+    LfpDevCache::inst().trim(dev);
+    return hipMalloc((void **)p, bytes);
+}
 
 // Scratch pool of a context: the protocol stages allocate their tables (up to ~1 GB at n = 2^18) anew in every call, and hipMalloc / hipFree of such blocks
 // cost milliseconds each; freed blocks are kept and handed out again (best fit, at most twice the request).  One thread per context at a time.

@@ -313,7 +313,7 @@ struct DevBuf {
     int alloc(size_t bytes) {
         owner = t_pool_ctx;
         if (owner) { p = owner->pool.get(bytes); return p ? 0 : -1; }
-        return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1;
+        return lfp_dev_malloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1;
     }
     template <class T> T *as() const { return (T *)p; }
 };
@@ -343,8 +343,8 @@ int upload_matrix(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, co
     for (size_t k = 0; k < nnz && m.const_coef; k++)
         for (int w = 1; w < D; w++) if (val[k * D + w]) { m.const_coef = false; break; }
     const size_t vb = (nnz ? nnz : 1) * D * 8, ib = (nnz ? nnz : 1) * 4;
-    if (hipMalloc(&m.rowptr, (n + 1) * 4) != hipSuccess || hipMalloc(&m.col, ib) != hipSuccess || hipMalloc(&m.valM, vb) != hipSuccess ||
-        hipMalloc(&m.colptr, (n + 1) * 4) != hipSuccess || hipMalloc(&m.rowidx, ib) != hipSuccess || hipMalloc(&m.valT, vb) != hipSuccess)
+    if (lfp_dev_malloc(&m.rowptr, (n + 1) * 4) != hipSuccess || lfp_dev_malloc(&m.col, ib) != hipSuccess || lfp_dev_malloc(&m.valM, vb) != hipSuccess ||
+        lfp_dev_malloc(&m.colptr, (n + 1) * 4) != hipSuccess || lfp_dev_malloc(&m.rowidx, ib) != hipSuccess || lfp_dev_malloc(&m.valT, vb) != hipSuccess)
         return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
     HIPCHK(c, hipMemcpyAsync(m.rowptr, rowptr, (n + 1) * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(m.col, col, nnz * 4, hipMemcpyHostToDevice, c->st));
@@ -354,7 +354,7 @@ int upload_matrix(lfplus_ctx *c, size_t n, const u32 *rowptr, const u32 *col, co
     HIPCHK(c, hipMemcpyAsync(m.rowidx, ri.data(), nnz * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(m.valT, vv.data(), nnz * D * 8, hipMemcpyHostToDevice, c->st));
     if (m.const_coef) {
-        if (hipMalloc(&m.valMc, (nnz ? nnz : 1) * 8) != hipSuccess || hipMalloc(&m.valTc, (nnz ? nnz : 1) * 8) != hipSuccess) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
+        if (lfp_dev_malloc(&m.valMc, (nnz ? nnz : 1) * 8) != hipSuccess || lfp_dev_malloc(&m.valTc, (nnz ? nnz : 1) * 8) != hipSuccess) return fail(c, LFPLUS_E_HIP, "hipMalloc (matrix)");
         if (nnz) {
             HIPCHK(c, hipMemcpy2DAsync(m.valMc, 8, m.valM, D * 8, 8, nnz, hipMemcpyDeviceToDevice, c->st));
             HIPCHK(c, hipMemcpy2DAsync(m.valTc, 8, m.valT, D * 8, 8, nnz, hipMemcpyDeviceToDevice, c->st));
@@ -1092,7 +1092,7 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         bool dist = shd;
         // unsharded: fix_variables is deferred into the next round's kernel (k_cm_round_fused: one read of the previous tables, one write of the fixed ones, one
         // launch per round); `pending` = the challenge whose fix has not been applied to Sc / Rc yet.  LFPLUS_CM_UNFUSED=1: separate k_cm_fix passes.
-        static const bool unfused = getenv("LFPLUS_CM_UNFUSED") != nullptr;
+        const bool unfused = getenv("LFPLUS_CM_UNFUSED") != nullptr;   // (read per call, like the other switches)
         const bool fuse = !shd && !unfused;
         bool pending = false;
         u64 rpend = 0;
@@ -1409,7 +1409,7 @@ extern "C" int lfplus_r1cs_linearize(lfplus_ctx *c, lfplus_transcript *tr, const
     int w = 1;
     bool dist = c->sharded();
     // unsharded: fix_variables is deferred into the next round's kernel (k_r1cs_round_fused), as in Cm::prove
-    static const bool unfused = getenv("LFPLUS_CM_UNFUSED") != nullptr;
+    const bool unfused = getenv("LFPLUS_CM_UNFUSED") != nullptr;   // (read per call, like the other switches)
     const bool fuse = !c->sharded() && !unfused;
     bool pending = false;
     u64 xpend = 0;

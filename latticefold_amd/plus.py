@@ -47,6 +47,8 @@ def _lib():
         L.lfplus_ctx_destroy.restype = None
         L.lfplus_scratch_trim.argtypes = [C.c_int]
         L.lfplus_scratch_trim.restype = None
+        L.lfplus_scratch_bytes.argtypes = [C.c_int]
+        L.lfplus_scratch_bytes.restype = C.c_size_t
         L.lfplus_last_error.argtypes = [vp]
         L.lfplus_last_error.restype = C.c_char_p
         L.lfplus_set_matrix.argtypes = [vp, u64p, C.c_uint32, C.c_uint64]
@@ -111,6 +113,11 @@ class DecompParameters:
     def for_frog(k, b=D // 2):
         """l = ceil(log_{d/2} q) as every reference call site computes it (rgchk.rs:369-371, benches/double_commitment.rs:68-70)"""
         return DecompParameters(b, k, math.ceil(math.log(float(P)) / math.log(D / 2)))
+
+
+def scratch_bytes(device=0):
+    """Bytes of idle scratch the process-wide cache holds on `device` (lfplus_scratch_bytes)"""
+    return int(_lib().lfplus_scratch_bytes(int(device)))
 
 
 def scratch_trim(device=-1):

@@ -23,6 +23,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(plus._lib(), n), f"liblfhip.so does not export {n}"
 
 
+def test_abi_version_matches_the_header():
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "lfhip.h")).read()
+    assert api.abi_version() == int(re.search(r"#define LFHIP_ABI_VERSION (\d+)", hdr).group(1)) >= 5
+
+
 def test_rust_binding_is_generated_from_the_headers():
     """INTEGRATION.md section 1 / bindings/latticefold-hip-sys/src/lib.rs are the mechanical image of the two headers: regenerating gives the committed
     text, every header symbol is declared exactly once, and the shared library exports each declared symbol"""

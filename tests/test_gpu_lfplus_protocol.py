@@ -139,6 +139,24 @@ def test_cm_prove_matches_oracle(L, nM, kappa, nvars, ring_coeffs, all_tables, m
         monkeypatch.setenv("LFPLUS_CM_FULL", "1")
     else:
         monkeypatch.delenv("LFPLUS_CM_FULL", raising=False)
+    monkeypatch.delenv("LFPLUS_CM_UNFUSED", raising=False)
+    _cm_prove_case(L, nM, kappa, nvars, ring_coeffs)
+
+
+@pytest.mark.parametrize("L,nM,kappa,nvars", [(2, 1, 1, 14), (2, 2, 2, 15), (3, 1, 3, 16)])
+@pytest.mark.parametrize("all_tables", [False, True])
+def test_cm_prove_unfused_fix_matches_oracle(L, nM, kappa, nvars, all_tables, monkeypatch):
+    """The sumcheckers of Cm::prove defer fix_variables into the next round's kernel (k_cm_round_fused / k_cm2_round<true>); LFPLUS_CM_UNFUSED=1 runs the separate
+    k_cm_fix passes instead.  The switch is read on every call, so both forms are compared with the oracle here (the default form is the test above)."""
+    monkeypatch.setenv("LFPLUS_CM_UNFUSED", "1")
+    if all_tables:
+        monkeypatch.setenv("LFPLUS_CM_FULL", "1")
+    else:
+        monkeypatch.delenv("LFPLUS_CM_FULL", raising=False)
+    _cm_prove_case(L, nM, kappa, nvars, False)
+
+
+def _cm_prove_case(L, nM, kappa, nvars, ring_coeffs):
     n, k = 1 << nvars, 2
     dp = plus.DecompParameters.for_frog(k)
     A = lfp.splitmix(3, 0, kappa * n * D).reshape(kappa, n, D)

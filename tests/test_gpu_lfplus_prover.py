@@ -25,9 +25,14 @@ def _same(got, want, keys, where):
 CM_KEYS = ("msgs", "r", "e", "b", "v", "a", "bb", "c", "comh", "pa", "ea", "pb", "eb", "ro", "cm_g", "vo", "fcoms")
 
 
-@pytest.mark.parametrize("nvars,k,b", [(7, 4, 2), (12, 2, 8)])
-def test_r1cs_linearize_matches_oracle(nvars, k, b):
-    """r1cs.rs:186-233 (test_linearization) and a larger shape; a ring-coefficient matrix makes the products genuinely polynomial"""
+@pytest.mark.parametrize("nvars,k,b,unfused", [(7, 4, 2, False), (12, 2, 8, False), (12, 2, 8, True), (14, 2, 8, True)])
+def test_r1cs_linearize_matches_oracle(nvars, k, b, unfused, monkeypatch):
+    """r1cs.rs:186-233 (test_linearization) and a larger shape; a ring-coefficient matrix makes the products genuinely polynomial.
+    unfused: LFPLUS_CM_UNFUSED=1 (read per call) -- fix_variables as its own pass instead of deferred into the next round's kernel (k_r1cs_round_fused)"""
+    if unfused:
+        monkeypatch.setenv("LFPLUS_CM_UNFUSED", "1")
+    else:
+        monkeypatch.delenv("LFPLUS_CM_UNFUSED", raising=False)
     n = 1 << nvars
     r1cs = list(plus.r1cs_decomposed_square((plus.identity_csr(n // k),) * 3, n, b, k))
     rng = np.random.default_rng(3)
@@ -93,3 +98,26 @@ def test_plus_prover_matches_oracle(kappa, k, rounds, device_acc):
         prover.close()
         if device_acc:             # the contexts' blocks went to the process-wide scratch cache: release them once here (later provers allocate afresh)
             plus.scratch_trim(0)
+
+
+def test_scratch_cache_is_bounded_and_released(monkeypatch):
+    """lfp_ctx.h LfpDevCache: a destroyed context leaves its scratch in the process-wide cache (so that a prover per proof does not pay hipMalloc again), the
+    cache is bounded by min(32 GB, a quarter of the device's memory) per device, lfplus_scratch_bytes reports it and lfplus_scratch_trim gives it back to the
+    driver -- the main path's allocators call the same trim before they report out-of-memory (lf_common.h lf_dev_malloc)"""
+    import torch
+    plus.scratch_trim(0)
+    assert plus.scratch_bytes(0) == 0
+    n = 1 << 14
+    rng = np.random.default_rng(5)
+    ctx = plus.PlusContext(0)
+    try:
+        ctx.set_witness(rng.integers(0, 31, size=(n, D), dtype=np.uint64))
+    finally:
+        ctx.close()
+    held = plus.scratch_bytes(0)
+    total = torch.cuda.get_device_properties(0).total_memory
+    assert n * D * 8 <= held <= min(32 << 30, total // 4)
+    free0 = torch.cuda.mem_get_info(0)[0]
+    plus.scratch_trim(0)
+    assert plus.scratch_bytes(0) == 0
+    assert torch.cuda.mem_get_info(0)[0] >= free0 + held - (64 << 20)      # the blocks went back to the driver (other allocations may move a little)

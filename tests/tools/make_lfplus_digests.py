@@ -60,6 +60,8 @@ def run(name):
     assert lfp.plus_verify(lfp.Transcript(), proof, wl.B) == 0, "the oracle's verifier rejects the oracle's proof"
     d["oracle_seconds"] = {"setup": round(t1 - t0, 1), "prove": round(t2 - t1, 1), "verify": round(time.time() - t2, 1)}
     d["workload"] = {"name": name, "nvars": wl.nvars, "L": wl.L, "k": wl.k, "kappa": wl.kappa, "B": wl.B, "l": wl.l}
+    import platform
+    d["oracle_host"] = os.environ.get("LF_ORACLE_HOST", platform.node() or "unknown host") + ", one thread"      # where oracle_seconds was measured (bench.py quotes it)
     print(name, d["oracle_seconds"], flush=True)
     return d
 

@@ -26,3 +26,4 @@ cd $R; LFPLUS_TIMELINE=1 timeout 600 python tools/bench_lfplus.py --nvars 20 --k
 cd /tmp; rm -rf /tmp/prof_lfp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lfp -o p -- python $R/tools/bench_lfplus.py --nvars 20 --k 4 --fresh 3 --rounds 2 --resident >/dev/null 2>&1
 f=$(find /tmp/prof_lfp -name '*kernel_stats.csv' | head -1); cp "$f" $R/gpurun_out/${tag}_lfplus_ks_p20.csv
+python $R/tools/write_profile_manifest.py $tag $R/gpurun_out   # the manifest bench.py reads (copy it into profiles/ together with the <tag>_* files)
