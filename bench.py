@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not announce the next step's instance (lf_prefetch_instance): every step computes its whole right decomposition itself")
     ap.add_argument("--no-lfplus", action="store_true", help="skip the LatticeFold+ PlusProver::prove timing (an extra key, not part of the metric)")
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
@@ -374,6 +375,7 @@ def main():
     def measure(shard):
         """setup (untimed: everything resident in HBM), W warm-up steps, K timed steps bracketed by barrier + synchronize; max over ranks"""
         wl = make_workload(args.workload, seed=0 if shard else rank)
+        use_prefetch = not args.no_prefetch and not shard and wl.ring == "goldilocks"
         ctx = api.Context(local_rank, ring=wl.ring)
         transport = None
         if shard:
@@ -393,6 +395,8 @@ def main():
         last = {}
 
         def step():
+            if use_prefetch:      # the hint of include/lfhip.h, once per step INSIDE the timed loop: this step prepares the next step's right side (same shapes, no reuse
+                ctx.prefetch_instance(cccs, wit)      # beyond that one step; the first timed step consumes what the last warm-up step prepared, the last timed step prepares in vain)
             lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr0.clone())
             w0.free()
             last["lc"], last["proof"] = lc, proof
@@ -475,6 +479,15 @@ def main():
                                                 "(oracle-only fixture, tests/tools/make_scale_digests.py)" % wl.name)
             except Exception as e:      # (a missing fixture is not a bench failure)
                 fixture_info.update(matches_oracle_fixture=None, fixture=f"not checked: {e!r}")
+        if use_prefetch:
+            pi, pu, pd = ctx.prefetch_stats()
+            fixture_info["prefetch"] = {"enqueued": pi, "used": pu, "dropped": pd,
+                                        "note": "lf_prefetch_instance before every step (warm-up and timed): the step enqueues the challenge-independent half of the NEXT step's right "
+                                                "decomposition (bit planes, z_k, K-1 digit-plane commits of w_i: decomposition.rs:159-201) on a side stream while its own launches are "
+                                                "latency-bound; every step still executes one such half (for its successor) inside the timed region, results are used exactly once, "
+                                                "proofs are bit-identical (tests/test_gpu_prefetch.py).  --no-prefetch: every step computes its own right side inside its first phase"}
+        else:
+            fixture_info["prefetch"] = None
         free_b, total_b = ctx.device_memory()
         mem_info["hbm_in_use_gib"] = (total_b - free_b) / 2.0 ** 30   # whole device, this process being its only user: context, witnesses, torch's own few MB
         for st in extra:

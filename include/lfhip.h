@@ -149,7 +149,8 @@ int lf_modsum_ring(const uint64_t *parts, size_t nparts, size_t words, uint64_t 
 /* Intra-step sharding of one fold step over `world` (power of two) ranks, one GPU each.  Must be set before the Ajtai matrix is
  * loaded/generated: each rank then keeps columns [rank*n/world, (rank+1)*n/world) of A.  Witnesses, CCS and all O(n) vectors are
  * replicated; sharded are the Ajtai commitments (partial commitments all-gathered + added mod p) and the folding-sumcheck rounds
- * (index slice by the high bits; partial round messages all-gathered + added; f-hat slices gathered once < 64 pairs per rank remain).
+ * (index slice by the high bits; partial round messages all-gathered + added; the table slices are gathered -- one all-gather per sumcheck -- once the
+ * tables are down to LF_SHARD_LIN_MIN = 16384 / LF_SHARD_FOLD_MIN = 2048 entries, at most m / 16, or fewer than 64 pairs per rank remain).
  * Every rank runs the identical transcript and returns the identical proof.  `cb` must all-gather `words` u64 from every rank
  * into recv_all[world*words] in rank order and return 0 (RCCL/xGMI via torch.distributed in latticefold_amd/dist.py). */
 typedef int (*lf_exchange_fn)(void *user, const uint64_t *send, uint64_t *recv_all, size_t words);
@@ -160,8 +161,15 @@ int lf_set_sharding(lf_ctx *, int rank, int world, lf_exchange_fn cb, void *user
  * library has no link-time dependency on it); LF_ERR_UNSUPPORTED if it is not installed.  Same ordering rule as lf_set_sharding: before the
  * Ajtai matrix is loaded.  A rank whose step fails aborts the communicator so that its peers error out instead of waiting forever. */
 int lf_dist_unique_id(uint8_t *id128);
-/* ids = TWO unique ids (2 x 128 bytes): the two lanes of a fold step exchange concurrently and each gets its own communicator */
+/* ids = TWO unique ids (2 x 128 bytes): the two lanes of a fold step exchange concurrently and each gets its own communicator.
+ * Start-up self-check: lf_dist_init runs the first collectives of both communicators concurrently from the two threads of a fold step, each on its lane's
+ * stream, and checks every word received.  Passed: sharded steps run the threaded two-lane schedule.  Wrong words: the communicators stay usable, one
+ * host thread issues every exchange.  No completion within LF_DIST_HANDSHAKE_MS (default 20000): both communicators are aborted and LF_ERR_STATE is
+ * returned -- make fresh ids and call again with LF_DIST_NO_HANDSHAKE=1 in the environment (the conservative schedule).
+ * lf_dist_two_lanes(ctx, -1) reports the outcome (1 = threaded schedule), (ctx, 0 / 1) overrides it: EVERY rank must run the same schedule, so a launcher
+ * combines the ranks' outcomes (minimum) and sets the result on all of them (latticefold_amd/dist.py does). */
 int lf_dist_init(lf_ctx *, int rank, int world, const uint8_t *ids);
+int lf_dist_two_lanes(lf_ctx *, int set);
 /* host transport with one callback per lane (the callbacks run on different threads, possibly at the same time: give each its own
  * ordered channel, e.g. two process groups); lf_set_sharding installs the same callback for both, which is only safe if it is
  * order-independent */
@@ -266,6 +274,17 @@ int lf_linearize(lf_ctx *, lf_transcript *, const uint64_t *cccs, const lf_witne
 /* NIFSProver::prove (nifs.rs:48-103): one fold step.  w_out receives the folded witness handle. */
 int lf_fold_step(lf_ctx *, lf_transcript *, const uint64_t *acc_lcccs, const lf_witness *w_acc, const uint64_t *cm_i_cccs,
                  const lf_witness *w_i, uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof_out);
+/* Hint for a chain of fold steps (no counterpart in the reference, whose prove() is one synchronous CPU call): the NEXT step's fresh instance.
+ * The challenge-independent half of the right decomposition -- the digit planes of w_i, their K - 1 Ajtai commitments y_k (k >= 1), z_k = x_s[k] || w_k
+ * (nifs/decomposition.rs:159-201: functions of w_i and x_ccs alone; no transcript challenge enters) -- is a third of a step's GPU work, and the tail of a step
+ * (small sumcheck rounds, host transcript) leaves the GPU nearly idle.  Call this BEFORE the lf_fold_step that precedes the step folding (cm_next, w_next):
+ * that step enqueues the work for (cm_next, w_next) on a side stream once its own launches are latency-bound, and the following lf_fold_step uses the
+ * results if -- and only if -- it is called with that very witness handle (pointer and serial number) and the same x_ccs; otherwise they are discarded
+ * and it computes everything itself.  One request, one result, one consumer: nothing is kept across more than one step boundary, proofs are bit-identical
+ * with and without the hint.  w_next must stay alive and unchanged until that step has run.  Contexts / shapes without a prefetch path (BabyBear, sharded,
+ * VALU commits) accept and ignore the hint.  lf_prefetch_stats: how many requests were enqueued, used, dropped (any pointer may be NULL). */
+int lf_prefetch_instance(lf_ctx *, const uint64_t *cm_next_cccs, const lf_witness *w_next);
+int lf_prefetch_stats(lf_ctx *, unsigned *issued, unsigned *consumed, unsigned *dropped);
 
 /* The two other sub-provers of the reference as entry points of their own (the reference exposes all three as public traits).
  * LFDecompositionProver::prove (nifs/decomposition.rs:33-88): dec_proof_out = u_s[K][t] | v_s[K][tau] | x_s[K][l+1] | y_s[K][kappa]

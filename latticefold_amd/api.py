@@ -141,6 +141,8 @@ def _lib():
         L.lf_sumcheck_lin_end.argtypes = [vp]
         L.lf_linearize.argtypes = [vp, vp, u64p, vp, u64p, u64p]
         L.lf_fold_step.argtypes = [vp, vp, u64p, vp, u64p, vp, u64p, C.POINTER(vp), u64p]
+        L.lf_prefetch_instance.argtypes = [vp, u64p, vp]
+        L.lf_prefetch_stats.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.lf_device_sponge.argtypes = [vp, u32p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u64p]
         L.lf_sumcheck_fold_begin.argtypes = [vp, u64p, u64p]
         L.lf_sumcheck_fold_round.argtypes = [vp, u64p, u64p]
@@ -277,6 +279,16 @@ class Context:
         _chk(_lib().lf_dist_init(self.h, rank, world, buf), "lf_dist_init")
         self.shard = (rank, world)
 
+    def dist_two_lanes(self, set=-1):
+        """lf_dist_two_lanes: 1 when sharded steps run the threaded two-lane schedule (the outcome of lf_dist_init's self-check); set = 0 / 1 overrides it --
+        every rank must use the same value"""
+        L = _lib()
+        L.lf_dist_two_lanes.argtypes = [C.c_void_p, C.c_int]
+        rc = L.lf_dist_two_lanes(self.h, int(set))
+        if rc < 0:
+            raise LfError(rc, "lf_dist_two_lanes")
+        return rc
+
     def dist_stats(self, reset=False):
         """(number of exchanges, total us, max us) of the context's exchange log"""
         n, tot, mx = C.c_uint64(), C.c_double(), C.c_double()
@@ -374,6 +386,17 @@ class Context:
         out = (C.c_float * 8)()
         _chk(_lib().lf_last_phase_ms(self.h, out), "lf_last_phase_ms")
         return {_lib().lf_phase_name(i).decode(): float(out[i]) for i in range(8)}
+
+    def prefetch_instance(self, cm_next, w_next):
+        """lf_prefetch_instance: announce the fresh instance of the step AFTER the next NIFSProver.prove on this context (a hint; see include/lfhip.h)"""
+        a, p = _a64(cm_next)
+        _chk(_lib().lf_prefetch_instance(self.h, p, w_next.h), "lf_prefetch_instance")
+
+    def prefetch_stats(self):
+        """(enqueued, used, dropped) prefetch requests of this context"""
+        i, u, d = C.c_uint(), C.c_uint(), C.c_uint()
+        _chk(_lib().lf_prefetch_stats(self.h, C.byref(i), C.byref(u), C.byref(d)), "lf_prefetch_stats")
+        return i.value, u.value, d.value
 
     def fold_paths(self):
         m = C.c_uint()

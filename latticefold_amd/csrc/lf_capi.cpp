@@ -43,7 +43,8 @@ static bool lf_trace_on() { static int v = -1; if (v < 0) v = getenv("LF_TRACE")
         }                                                                             \
     } while (0)
 
-static thread_local int t_lane = 0;  // 0 = caller thread, 1 = helper thread running the left decomposition
+static thread_local int t_lane = 0;  // 0 = caller thread, 1 = helper thread running the left decomposition, 2 = the prefetch of the NEXT step's right side (lf_prefetch_instance)
+constexpr int LF_NLANES = 3;
 
 struct lf_transcript {
     Transcript t;
@@ -132,7 +133,7 @@ struct LaneWorker {
 struct lf_ctx {
     lfbb::BbCtx *bb = nullptr;   // BabyBearRingNTT backend (ring 1): every entry point forwards to it
     int device = 0;
-    hipStream_t st_lane[2] = {nullptr, nullptr};
+    hipStream_t st_lane[LF_NLANES] = {nullptr, nullptr, nullptr};   // [2]: created by the first prefetch
     int digit_mode = 0;   // balanced-digit rule of base-B decompositions (lf_set_digit_mode)
     ExtBasis xb;          // external coordinate basis of F_{p^tau} (lf_set_ext_basis); identity by default
     Tunables tn;          // environment switches, re-read at the start of every lf_linearize / lf_fold_step
@@ -158,6 +159,8 @@ struct lf_ctx {
     size_t nA = 0, nA_total = 0, A_col0 = 0;
     // intra-step sharding: rank/world and the all-gather callback supplied by the host language
     int sh_rank = 0, sh_world = 1;   // mirror comm.rank / comm.world
+    bool two_lanes_ok = false;       // the transport's two channels have been seen working concurrently (lf_dist_init's handshake; two host callbacks): a sharded
+                                     // step then runs the threaded two-lane schedule unless LF_SHARD_TWO_LANES=0
     // exchange layer, one per lane: the two lanes of a fold step exchange concurrently (lane 0: linearization rounds and right evaluations,
     // lane 1: commits and left evaluations) and collectives of ONE communicator must be issued in the same order on every rank
     lfdist::Comm comm[2];
@@ -172,8 +175,8 @@ struct lf_ctx {
     std::vector<u64 *> d_val, d_valT;
     LinCombDesc desc{};
     std::map<std::string, DevBuf> bufs;
-    u64 *h_pin_lane[2] = {nullptr, nullptr};
-    size_t h_pin_words_lane[2] = {0, 0};
+    u64 *h_pin_lane[LF_NLANES] = {nullptr, nullptr, nullptr};
+    size_t h_pin_words_lane[LF_NLANES] = {0, 0, 0};
     // lin sumcheck ABI state
     int sc_round = -1;
     size_t sc_n = 0;
@@ -220,11 +223,49 @@ struct lf_ctx {
     unsigned fold_split_mask = 0;    // table rounds of the last folding sumcheck that ran in the split eq form (bit i-1 = round i)
     unsigned lin_split_rounds = 0;   // rounds of the last linearization sumcheck that ran in the split eq form (run_lin_sumcheck)
 
+    // lf_prefetch_instance: the challenge-independent half of the RIGHT decomposition of the NEXT fold step (decomposition.rs:159-201: its digit planes in
+    // bit-plane form, the K vectors z_k = x_s[k] || w_k and the K - 1 digit-plane commitments depend on w_i and x_ccs only), enqueued on a third stream while
+    // the running step is in its latency-bound part.  One request -> one result -> consumed by exactly one fold step (or dropped): nothing survives a step.
+    struct Prefetch {
+        // request (lf_prefetch_instance), taken up by the running / next fold step at its trigger point
+        bool req = false;
+        const lf_witness *req_wit = nullptr;
+        uint64_t req_id = 0;
+        std::vector<u64> req_x;          // x_ccs || 1: (l + 1) ring elements (NTT form)
+        // result: valid for the witness (pointer AND serial number) and public input it was made for
+        bool have = false;
+        int parity = 0;                  // z / bit planes are double-buffered: the consuming step reads one set while the next prefetch writes the other
+        const lf_witness *wit = nullptr;
+        uint64_t wit_id = 0;
+        std::vector<u64> x, x_s;         // x_ccs || 1 it was made for; x_s of the proof (K (l+1) ring elements)
+        u32 *bits = nullptr;
+        u64 *z = nullptr, *yd = nullptr;
+        u64 *y_host = nullptr;           // pinned: (K - 1) kappa ring elements
+        size_t y_words = 0;
+        hipEvent_t ev_done = nullptr;
+        EvPair ev_k[2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // HIP events around the commit kernel, per parity (counted in the CONSUMING step's kernel statistics)
+        bool ev_k_used = false;
+        int wr = 0;                      // parity the prefetch being enqueued writes
+        unsigned issued = 0, consumed = 0, dropped = 0;   // counters (lf_prefetch_stats)
+        void destroy() {
+            if (y_host) (void)hipHostFree(y_host);
+            if (ev_done) (void)hipEventDestroy(ev_done);
+            for (EvPair &e : ev_k) {
+                if (e.a) (void)hipEventDestroy(e.a);
+                if (e.b) (void)hipEventDestroy(e.b);
+                e = {nullptr, nullptr};
+            }
+            y_host = nullptr; ev_done = nullptr;
+        }
+    } pf;
+    int pf_inuse = -1;                   // parity of the prefetch buffers the running step reads (-1: none)
+    int pf_kernel_counted = -1;          // (parity, or -1) this step consumed a prefetch: its commit kernel's events are added to the step's statistics (ev_collect)
+
     int buf(const std::string &name, size_t bytes, void **out) {
         DevBuf *b;
         {
             std::lock_guard<std::mutex> g(buf_mu);
-            b = &bufs[t_lane ? "lane1:" + name : name];  // std::map nodes are stable
+            b = &bufs[t_lane ? (t_lane == 1 ? "lane1:" : "lane2:") + name : name];  // std::map nodes are stable
         }
         int rc = b->ensure(bytes);
         *out = b->p;
@@ -233,7 +274,7 @@ struct lf_ctx {
     // give a set-up scratch buffer back (caller has synchronised the stream that used it)
     void drop_buf(const std::string &name) {
         std::lock_guard<std::mutex> g(buf_mu);
-        auto it = bufs.find(t_lane ? "lane1:" + name : name);
+        auto it = bufs.find(t_lane ? (t_lane == 1 ? "lane1:" : "lane2:") + name : name);
         if (it != bufs.end()) { it->second.release(); bufs.erase(it); }
     }
     template <class T>
@@ -245,8 +286,8 @@ struct lf_ctx {
     }
     // Small host-to-device uploads inside a step (challenge powers, look-up tables, evaluation points) go through a pinned ring per lane:
     // the copy is truly asynchronous and the caller's stack / vector buffer is free at once -- no stream synchronisation per upload.
-    unsigned char *stage[2] = {nullptr, nullptr};
-    size_t stage_off[2] = {0, 0};
+    unsigned char *stage[LF_NLANES] = {nullptr, nullptr, nullptr};
+    size_t stage_off[LF_NLANES] = {0, 0, 0};
     static constexpr size_t STAGE_BYTES = (size_t)1 << 20;
     int h2d_small(void *dst, const void *src, size_t bytes) {
         unsigned char *&ring = stage[t_lane];
@@ -267,7 +308,7 @@ struct lf_ctx {
         HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream()));
         return LF_OK;
     }
-    u64 *h_round[2] = {nullptr, nullptr};   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
+    u64 *h_round[LF_NLANES] = {nullptr, nullptr, nullptr};   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
     u64 *round_out() {
         u64 *&p = h_round[t_lane];
         if (!p && hipHostMalloc((void **)&p, 5 * 24 * 8 * 2, hipHostMallocMapped) != hipSuccess) p = nullptr;
@@ -328,6 +369,10 @@ struct lf_ctx {
     }
     // timed-launch helpers: tag 0 = fold round kernels, 1 = ajtai, 10+i = phase i
     size_t ev_begin(int tag) {
+        if (t_lane == 2) {   // the prefetch lane: not part of the running step's statistics (its kernels may outlive the step)
+            if (tag == 1 && pf.ev_k[pf.wr].a && !pf.ev_k_used) { pf.ev_k_used = true; (void)hipEventRecord(pf.ev_k[pf.wr].a, stream()); return (size_t)-2; }
+            return (size_t)-1;
+        }
         std::lock_guard<std::mutex> g(ev_mu);
         if (ev_used == ev_pool.size()) {
             EvPair e;
@@ -341,6 +386,8 @@ struct lf_ctx {
         return i;
     }
     void ev_end(size_t i) {
+        if (i == (size_t)-1) return;
+        if (i == (size_t)-2) { (void)hipEventRecord(pf.ev_k[pf.wr].b, stream()); return; }
         std::lock_guard<std::mutex> g(ev_mu);
         (void)hipEventRecord(ev_pool[i].b, stream());
     }
@@ -360,6 +407,11 @@ struct lf_ctx {
             if (tg.first == 0) { k_fold_ms += ms; k_fold_n++; }
             else if (tg.first == 1) { k_ajtai_ms += ms; k_ajtai_n++; }
             else if (tg.first >= 10 && tg.first < 10 + LF_N_PHASES) phase_ms[tg.first - 10] += ms;
+        }
+        if (pf_kernel_counted >= 0) {   // the right commit of this step ran ahead (prefetch): its kernel belongs to this step's statistics
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pf.ev_k[pf_kernel_counted].a, pf.ev_k[pf_kernel_counted].b) == hipSuccess) { k_ajtai_ms += ms; k_ajtai_n++; phase_ms[1] += ms; }
+            pf_kernel_counted = -1;
         }
         phase_ms[6] = (float)host_tr_ms;
     }
@@ -420,7 +472,9 @@ int lf_ctx_create(lf_ctx **out, int device) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         const bool prio = !getenv("LF_NO_PRIO");
-        if (hipStreamCreateWithPriority(&c->st_lane[0], hipStreamDefault, prio ? least : 0) != hipSuccess ||
+        // (LF_LANE0_MID=1: lane 0 on the middle priority, so that the prefetch stream -- lowest -- yields to it too)
+        const int p0 = getenv("LF_LANE0_MID") ? (least + greatest) / 2 : least;
+        if (hipStreamCreateWithPriority(&c->st_lane[0], hipStreamDefault, prio ? p0 : 0) != hipSuccess ||
             hipStreamCreateWithPriority(&c->st_lane[1], hipStreamDefault, prio ? greatest : 0) != hipSuccess) { delete c; return LF_ERR_HIP; }
     }
     if (!getenv("LF_SPIN_ALL")) (void)hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming);
@@ -449,6 +503,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->bb) { c->bb->destroy(); delete c; return; }
     (void)hipStreamSynchronize(c->st_lane[0]);
     (void)hipStreamSynchronize(c->st_lane[1]);
+    if (c->st_lane[2]) (void)hipStreamSynchronize(c->st_lane[2]);
     free_ccs(c);
     if (getenv("LF_MEM_REPORT")) {   // what the context held, largest first
         std::vector<std::pair<size_t, std::string>> v;
@@ -465,13 +520,13 @@ void lf_ctx_destroy(lf_ctx *c) {
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dA) (void)hipFree(c->dA);
     if (c->dAb) (void)hipFree(c->dAb);
-    for (int l = 0; l < 2; l++) if (c->stage[l]) (void)hipHostFree(c->stage[l]);
+    for (int l = 0; l < LF_NLANES; l++) if (c->stage[l]) (void)hipHostFree(c->stage[l]);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
-    for (int l = 0; l < 2; l++)
+    for (int l = 0; l < LF_NLANES; l++)
         if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
     if (c->h_pin2) { (void)hipHostFree(c->h_pin2); c->h_pin2 = nullptr; }
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (int l = 0; l < 2; l++)
+    for (int l = 0; l < LF_NLANES; l++)
         if (c->h_round[l]) (void)hipHostFree(c->h_round[l]);
     if (c->ev_block) (void)hipEventDestroy(c->ev_block);
     c->comm[0].destroy();
@@ -489,6 +544,8 @@ void lf_ctx_destroy(lf_ctx *c) {
     }
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
+    if (c->st_lane[2]) (void)hipStreamDestroy(c->st_lane[2]);
+    c->pf.destroy();
     delete c;
 }
 int lf_set_ring_tables(lf_ctx *c, uint64_t nonres, const uint64_t *y) {
@@ -566,6 +623,7 @@ int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *use
         c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = cb; c->comm[l].user = user; c->comm[l].poisoned = false;
     }
     c->sh_rank = rank; c->sh_world = world;
+    c->two_lanes_ok = false;                 // one channel: one thread issues every exchange
     return LF_OK;
 }
 // all-gather `words` canonical words from every rank and add them mod p (RCCL has no modular reduction): host buffer ...
@@ -585,6 +643,68 @@ static int exchange_modsum_dev(lf_ctx *c, u64 *inout_dev, size_t words) {
     return LF_OK;
 }
 int lf_dist_unique_id(uint8_t *id128) { return lfdist::rccl_unique_id(id128); }
+// Start-up self-check of the two-lane schedule (lf_dist_init): the FIRST collectives of both communicators are issued concurrently by the two threads that issue
+// them in a fold step -- lane 0 by the caller, lane 1 by the helper thread -- each on its lane's stream, four rounds of all-gathers with rank-, lane- and
+// round-dependent words, and every word received is checked.  Passed: the step runs the threaded schedule (LF_SHARD_TWO_LANES unset).  Wrong words: the
+// communicators stay usable and one host thread issues every exchange (the conservative schedule).  No completion within the time limit
+// (LF_DIST_HANDSHAKE_MS, default 20 s): both communicators are aborted and LF_ERR_STATE is returned -- the launcher makes fresh ids and calls lf_dist_init
+// again with LF_DIST_NO_HANDSHAKE=1 (latticefold_amd/dist.py does).
+static int dist_handshake(lf_ctx *c) {
+    c->two_lanes_ok = false;
+    if (getenv("LF_DIST_NO_HANDSHAKE")) return LF_OK;
+    const int W = c->sh_world, R = c->sh_rank, ITER = 4;
+    const size_t words = 64, per_it = words * (size_t)(W + 1);
+    long limit_ms = 20000;
+    if (const char *e = getenv("LF_DIST_HANDSHAKE_MS")) limit_ms = atol(e);
+    u64 *dbuf[2] = {nullptr, nullptr}, *hbuf[2] = {nullptr, nullptr};
+    for (int l = 0; l < 2; l++) {
+        if (lf_dev_malloc(&dbuf[l], per_it * ITER * 8) != hipSuccess || hipHostMalloc((void **)&hbuf[l], per_it * ITER * 8) != hipSuccess) {
+            for (int q = 0; q < 2; q++) { if (dbuf[q]) (void)hipFree(dbuf[q]); if (hbuf[q]) (void)hipHostFree(hbuf[q]); }
+            return LF_ERR_HIP;
+        }
+    }
+    auto word = [](int g, int lane, int it, size_t w) { return ((u64)(g + 1) * 0x9E3779B97F4A7C15ull) ^ ((u64)lane << 40) ^ ((u64)it << 32) ^ (u64)w; };
+    auto run = [&](int lane) -> int {
+        const int keep = t_lane;
+        t_lane = lane;
+        int rc = hipSetDevice(c->device) == hipSuccess ? LF_OK : LF_ERR_HIP;
+        for (int it = 0; it < ITER && rc == LF_OK; it++) {
+            u64 *hs = hbuf[lane] + per_it * it, *ds = dbuf[lane] + per_it * it;
+            for (size_t w = 0; w < words; w++) hs[w] = word(R, lane, it, w);
+            if (hipMemcpyAsync(ds, hs, words * 8, hipMemcpyHostToDevice, c->stream()) != hipSuccess) { rc = LF_ERR_HIP; break; }
+            rc = c->cm().allgather_dev(ds, ds + words, words, c->stream());
+            if (rc == LF_OK && hipMemcpyAsync(hs + words, ds + words, words * W * 8, hipMemcpyDeviceToHost, c->stream()) != hipSuccess) rc = LF_ERR_HIP;
+        }
+        t_lane = keep;
+        return rc;
+    };
+    c->lane1.submit([&]() -> int { return run(1); });
+    int rc = run(0);
+    const int rc1 = c->lane1.wait();
+    if (rc == LF_OK) rc = rc1;
+    bool timed_out = false;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(limit_ms);
+    for (int l = 0; l < 2 && rc == LF_OK && !timed_out; l++)
+        for (;;) {
+            const hipError_t q = hipStreamQuery(c->st_lane[l]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { rc = LF_ERR_HIP; break; }
+            if (std::chrono::steady_clock::now() > deadline) { timed_out = true; break; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    if (timed_out || rc != LF_OK) {      // the collectives may never complete: tear the communicators down (the buffers stay allocated -- a kernel may still hold them)
+        c->comm[0].abort_peers(); c->comm[1].abort_peers();
+        return LF_ERR_STATE;
+    }
+    bool ok = true;
+    for (int l = 0; l < 2 && ok; l++)
+        for (int it = 0; it < ITER && ok; it++)
+            for (int g2 = 0; g2 < W && ok; g2++)
+                for (size_t w = 0; w < words && ok; w++) ok = hbuf[l][per_it * it + words + (size_t)g2 * words + w] == word(g2, l, it, w);
+    for (int l = 0; l < 2; l++) { (void)hipFree(dbuf[l]); (void)hipHostFree(hbuf[l]); c->comm[l].n_exchanges = 0; c->comm[l].us_total = 0; c->comm[l].us_max = 0; }
+    c->two_lanes_ok = ok;
+    return LF_OK;
+}
 int lf_dist_init(lf_ctx *c, int rank, int world, const uint8_t *ids) {
     if (!c || !ids || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return LF_ERR_INVALID;
     if (c->bb) return c->bb->dist_init(rank, world, ids);
@@ -596,7 +716,14 @@ int lf_dist_init(lf_ctx *c, int rank, int world, const uint8_t *ids) {
         RET(lfdist::rccl_init(c->comm[l], rank, world, ids + 128 * l));
     }
     c->sh_rank = rank; c->sh_world = world;
-    return LF_OK;
+    return dist_handshake(c);
+}
+int lf_dist_two_lanes(lf_ctx *c, int set) {
+    if (!c) return LF_ERR_INVALID;
+    if (c->bb) return 0;                      // (the BabyBear driver exchanges from one thread only)
+    std::lock_guard<std::mutex> g(c->mu);
+    if (set == 0 || set == 1) c->two_lanes_ok = set == 1;
+    return c->two_lanes_ok ? 1 : 0;
 }
 // per-lane callbacks (host transport): the two lanes of a fold step exchange concurrently, so each needs its own ordered channel
 int lf_set_sharding_lanes(lf_ctx *c, int rank, int world, lf_exchange_fn cb0, void *user0, lf_exchange_fn cb1, void *user1) {
@@ -605,6 +732,7 @@ int lf_set_sharding_lanes(lf_ctx *c, int rank, int world, lf_exchange_fn cb0, vo
     if (c->bb) return LF_OK;   // the BabyBear driver exchanges from one thread only
     std::lock_guard<std::mutex> g(c->mu);
     c->comm[1].cb = cb1; c->comm[1].user = user1;
+    c->two_lanes_ok = (cb1 != cb0 || user1 != user0);   // two ordered channels supplied by the host language: the threaded schedule is the default
     return LF_OK;
 }
 int lf_dist_stats(lf_ctx *c, uint64_t *n_exchanges, double *total_us, double *max_us, int reset) {
@@ -855,7 +983,7 @@ static int ajtai_install(lf_ctx *c, size_t kappa, size_t n, const uint64_t *A_ho
 // wit (optional): the witness `planes` belong to -- if its bit-plane form is at hand (built at the start of the fold step for the GEMM rounds) the
 // kernel cuts the digits from it
 static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev, const int32_t *planes2 = nullptr, u64 *out_dev2 = nullptr,
-                            const lf_witness *wit = nullptr) {
+                            const lf_witness *wit = nullptr, const u32 *bits_in = nullptr /* the bit-plane form of `planes`, made on this stream */) {
     const AjtaiI8Ring R = ajtai_i8_goldilocks();
     const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc), maxp = ajtai_i8_max_planes(R);
     const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
@@ -878,8 +1006,8 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
         RET(commit_planes_i8(c, planes, ld, k0, NP, out_dev));
         return commit_planes_i8(c, planes2, ld, k0, NP, out_dev2);
     }
-    const u32 *bits = nullptr;
-    if (wit && !planes2 && c->A_col0 == 0 && planes == wit->planes && c->nA == c->N)
+    const u32 *bits = bits_in;
+    if (!bits && wit && !planes2 && c->A_col0 == 0 && planes == wit->planes && c->nA == c->N)
         for (int sd = 0; sd < 2; sd++)
             if (c->bits_wit[sd] == wit && c->bits_ptr[sd]) {
                 bits = c->bits_ptr[sd];
@@ -984,6 +1112,16 @@ static void shard_slice(const lf_ctx *c, size_t n, size_t *i0, size_t *cnt) {
     *i0 = lo;
     *cnt = lo + per > n ? n - lo : per;
 }
+// Sharded sumchecks: tables of `n` entries stay sharded while every rank keeps at least 64 pairs AND the tables are larger than the hand-over size of the
+// sumcheck (kind 0 linearization, 1 folding; Tunables::shard_lin_min / shard_fold_min, never above m / 16 so that small instances still exercise the sharded
+// rounds).  Every rank evaluates the same predicate on the same numbers: the ranks leave the sharded form in the same round.
+static bool shard_keep(const lf_ctx *c, int kind, size_t n) {
+    const size_t Gw = (size_t)c->sh_world;
+    if (Gw <= 1 || n / 2 < Gw * 64) return false;
+    size_t thr = kind ? c->tn.shard_fold_min : c->tn.shard_lin_min;
+    if (thr > (c->m >> 4)) thr = c->m >> 4;
+    return n > thr;
+}
 // all-gather the ranks' column slices of `planes` tables stored with GLOBAL layout [plane][n] (rank g holds entries
 // [g*n/G, (g+1)*n/G) of every plane) and fill in the others' slices
 static int gather_slices(lf_ctx *c, u64 *buf, size_t planes, size_t n) {
@@ -994,6 +1132,30 @@ static int gather_slices(lf_ctx *c, u64 *buf, size_t planes, size_t n) {
     HIPCHK(hipMemcpy2DAsync(gtmp, lcl * 8, buf + (size_t)c->sh_rank * lcl, n * 8, lcl * 8, planes, hipMemcpyDeviceToDevice, c->stream()));
     RET(c->cm().allgather_dev(gtmp, gall, words, c->stream()));
     launch_gather_relayout(gall, (u32)Gw, planes, lcl, buf, c->stream());
+    return LF_OK;
+}
+// Several table sets in ONE exchange (the hand-over of a sharded sumcheck to its replicated rounds): part i is this rank's `lcl` entries of `planes` rows
+// at src (row stride src_ld) and becomes the full tables dst [planes][G lcl] on every rank.  src may lie inside dst (the payload is staged first).
+struct GatherPart { const u64 *src; size_t src_ld; u64 *dst; size_t planes; };
+static int gather_parts(lf_ctx *c, const GatherPart *parts, int np, size_t lcl) {
+    const size_t Gw = (size_t)c->sh_world;
+    size_t ptot = 0;
+    for (int i = 0; i < np; i++) ptot += parts[i].planes;
+    const size_t words = ptot * lcl;
+    u64 *gall, *gtmp;
+    RET(c->tbuf("sh_gather_tab", words * Gw, &gall));
+    RET(c->tbuf("sh_gather_tmp", words, &gtmp));
+    size_t p0 = 0;
+    for (int i = 0; i < np; i++) {
+        HIPCHK(hipMemcpy2DAsync(gtmp + p0 * lcl, lcl * 8, parts[i].src, parts[i].src_ld * 8, lcl * 8, parts[i].planes, hipMemcpyDeviceToDevice, c->stream()));
+        p0 += parts[i].planes;
+    }
+    RET(c->cm().allgather_dev(gtmp, gall, words, c->stream()));
+    p0 = 0;
+    for (int i = 0; i < np; i++) {
+        launch_gather_relayout_part(gall, (u32)Gw, ptot, p0, parts[i].planes, lcl, parts[i].dst, c->stream());
+        p0 += parts[i].planes;
+    }
     return LF_OK;
 }
 int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
@@ -1496,7 +1658,7 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
     // and evaluates only those; the (deg+1)-element partial messages are all-gathered and added mod p on the device.  Below 64 pairs per
     // rank the slices are gathered and the tail rounds are replicated.
     const size_t Gw = (size_t)c->sh_world, gr = (size_t)c->sh_rank;
-    bool sharded = Gw > 1 && m / 2 >= Gw * 64;
+    bool sharded = shard_keep(c, 0, m);
     u64 *od_dev = nullptr;
     if (Gw > 1) RET(c->tbuf("lin_round_out", 5 * 24 + 8, &od_dev));
     // split form: while `split` is set, cure is the per-pair table E_i of the round i that ran last (in fe[(i - 1) & 1]) and c_lvl = c_i = prod_{k<i} eq(beta_k, r_k)
@@ -1548,9 +1710,10 @@ static int run_lin_sumcheck(lf_ctx *c, Transcript &tr, const u64 *mz, const u64 
             cur = fx[flip]; cure = split ? fe[(round - 1) & 1] : fe[flip];   // (split: E_round, one entry per pair of the new tables)
             flip ^= 1;
             n /= 2;
-            if (sharded && n / 2 < Gw * 64) {   // hand-over to the replicated tail
-                RET(gather_slices(c, (u64 *)cur, (size_t)P.t * 24, n));
-                RET(gather_slices(c, (u64 *)cure, 3, n));
+            if (sharded && !shard_keep(c, 0, n)) {   // hand-over to the replicated rounds: the Mz tables and eq in one exchange
+                const size_t lcl = n / Gw;
+                const GatherPart gp[2] = {{cur + gr * lcl, n, (u64 *)cur, (size_t)P.t * 24}, {cure + gr * lcl, n, (u64 *)cure, 3}};
+                RET(gather_parts(c, gp, 2, lcl));
                 sharded = false;
             }
         }
@@ -1722,7 +1885,7 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
         // a sharded rank evaluates and fixes the entries [rank m/G, (rank+1) m/G) of the Mz tables until the fixed slices are gathered (run_lin_sumcheck):
         // it computes only those rows (z itself stays whole: a row refers to arbitrary columns)
         const size_t Gw = (size_t)c->sh_world;
-        const bool rows_sliced = Gw > 1 && m / 2 >= Gw * 64 && !c->tn.lin_u_eval;
+        const bool rows_sliced = shard_keep(c, 0, m) && !c->tn.lin_u_eval;
         const size_t r0 = rows_sliced ? (size_t)c->sh_rank * (m / Gw) : 0, rcnt = rows_sliced ? m / Gw : m;
         for (u32 j = 0; j < P.t; j++)
             launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->stream(), r0, rcnt);
@@ -1869,6 +2032,7 @@ struct SideState {
     std::atomic<int> z_state{0};
     hipEvent_t z_ev = nullptr;
     u32 *sv_bits = nullptr;  // bit-plane form of the witness planes for the GEMM rounds of the folding sumcheck (lf_sv_rounds.h), if built ahead
+    ~SideState() { if (z_ev) (void)hipEventDestroy(z_ev); }   // (2 = z, x_s came from lf_prefetch_instance: the step's streams already wait for it)
 };
 
 // LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
@@ -2006,7 +2170,7 @@ static int decompose_prepare_z(lf_ctx *c, const u64 *xh /* (l+1) elements: x_w |
         // combination of fold prepare): it builds the range that covers both -- its own n / G columns for a column-local constraint system
         size_t w0 = 0, wcnt = (size_t)-1;
         const size_t Gw = (size_t)c->sh_world, hl = P.l + 1;
-        if (Gw > 1 && c->m / 2 >= Gw * 64) {
+        if (shard_keep(c, 1, c->m)) {
             size_t c0, ccnt, lo, hi;
             shard_slice(c, c->n, &c0, &ccnt);
             rc = shard_col_range(c, (size_t)c->sh_rank * (c->m / Gw), c->m / Gw, &lo, &hi);
@@ -2026,6 +2190,58 @@ static int decompose_prepare_z(lf_ctx *c, const u64 *xh /* (l+1) elements: x_w |
     S.z_state.store(rc == LF_OK ? 1 : -1, std::memory_order_release);
     return rc;
 }
+// The work of lf_prefetch_instance: bit planes, z_k / x_s and the K - 1 digit-plane commitments of the NEXT step's right witness, enqueued on lane 2's stream by
+// the thread of the running step (t_lane is switched for the duration: stream, buffers and staging are the prefetch lane's own).  Never fails the running step:
+// an error just leaves no result.
+static int prefetch_enqueue(lf_ctx *c) {
+    lf_ctx::Prefetch &pf = c->pf;
+    if (!pf.req) return LF_OK;
+    pf.req = false;
+    const lf_params &P = c->P;
+    const lf_witness *wit = pf.req_wit;
+    const u32 K = P.K;
+    // what the default fold step of a large unsharded instance runs: digit commits on the matrix cores over the whole witness, bit planes for the GEMM rounds
+    if (c->sh_world > 1 || !c->i8_nch || c->tn.ajtai_valu || c->tn.commits_first || c->tn.i8_pair || c->tn.force_exchange || P.b != 2 || c->A_col0 != 0 || c->nA != c->N ||
+        wit->N != c->N || (c->N & 3) || c->N > c->m || K < 2) { pf.dropped++; return LF_OK; }
+    struct LaneSwitch { int old; LaneSwitch() : old(t_lane) { t_lane = 2; } ~LaneSwitch() { t_lane = old; } } ls;
+    if (!c->st_lane[2]) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCHK(hipStreamCreateWithPriority(&c->st_lane[2], hipStreamDefault, getenv("LF_NO_PRIO") ? 0 : least));
+    }
+    const int wr = c->pf_inuse == 0 ? 1 : 0;
+    pf.wr = wr; pf.ev_k_used = false; pf.have = false;
+    if (!pf.ev_done) HIPCHK(hipEventCreateWithFlags(&pf.ev_done, hipEventDisableTiming));
+    if (!pf.ev_k[wr].a) { HIPCHK(hipEventCreate(&pf.ev_k[wr].a)); HIPCHK(hipEventCreate(&pf.ev_k[wr].b)); }
+    u32 *bits;
+    u64 *z, *yd;
+    RET(c->tbuf(wr ? "pf_bits1" : "pf_bits0", sv_bits_words(c->N, K), &bits));
+    RET(c->tbuf(wr ? "pf_z1" : "pf_z0", (size_t)K * 24 * c->n, &z));
+    RET(c->tbuf("pf_y", (size_t)K * P.kappa * 24, &yd));
+    const size_t ywords = (size_t)(K - 1) * P.kappa * 24;
+    if (pf.y_words < ywords) {
+        if (pf.y_host) { HIPCHK(hipStreamSynchronize(c->stream())); (void)hipHostFree(pf.y_host); pf.y_host = nullptr; pf.y_words = 0; }
+        HIPCHK(hipHostMalloc((void **)&pf.y_host, ywords * 8));
+        pf.y_words = ywords;
+    }
+    launch_sv_bits(wit->planes, c->N, c->N, K, bits, c->stream());
+    pf.x_s.assign((size_t)K * (P.l + 1) * 24, 0);
+    compute_x_s(c, pf.req_x.data(), pf.x_s.data());
+    RET(build_z(c, wit->planes, K, 1, pf.x_s.data(), z));
+    RET(commit_planes_i8(c, wit->planes, c->N, 1, K - 1, yd, nullptr, nullptr, nullptr, bits));
+    HIPCHK(hipMemcpyAsync(pf.y_host, yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()));
+    HIPCHK(hipEventRecord(pf.ev_done, c->stream()));
+    pf.have = true; pf.parity = wr; pf.wit = wit; pf.wit_id = pf.req_id; pf.x = pf.req_x; pf.bits = bits; pf.z = z; pf.yd = yd;
+    pf.issued++;
+    return LF_OK;
+}
+static void pf_trigger(lf_ctx *c, int point) {
+    if (c->pf.req && point >= c->tn.pf_at) {   // (the first trigger point at or after LF_PF_AT that the step reaches)
+        if (prefetch_enqueue(c) != LF_OK) { c->pf.have = false; c->pf.dropped++; (void)hipGetLastError(); }
+        TL_MARK("  prefetch enqueued");
+    }
+}
+
 // The evaluations of a decomposition in two stages (the right side of a fold step): stage 0 = all v_s and the u_s of the parts k < ksplit, stage 1 = the
 // other u_s.  decompose_evals then enqueues both downloads and returns without waiting; decompose_evals_collect(stage) waits for that stage's event and
 // moves its words into the proof -- so the host can absorb the first K/2 parts (x_k, y_k, u_k, v_k: half of a ~1 ms sponge chain) while the GPU is
@@ -2069,7 +2285,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     size_t ph = c->ev_begin(12);
     // z_k: built here unless the other lane has published it already (it does not depend on the point)
     if (S.z_state.load(std::memory_order_acquire) == 1) HIPCHK(hipStreamWaitEvent(c->stream(), S.z_ev, 0));
-    else RET(decompose_prepare_z(c, xh, wit, side, S, proof));
+    else if (S.z_state.load(std::memory_order_acquire) != 2) RET(decompose_prepare_z(c, xh, wit, side, S, proof));
     u64 *z = S.z;
     if (t_lane == 0) TL_MARK("  evals: buffers + z");
     // v_s (decomposition.rs:204-211) from the coefficient planes
@@ -2080,8 +2296,8 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
             HIPCHK(hipMemcpyAsync(od_v, c->vs_dev, (size_t)K * 72 * 8, hipMemcpyDeviceToDevice, c->stream()));
             c->vs_wit = nullptr;
         } else {
+            if (c->sh_world > 1) HIPCHK(hipMemsetAsync(od, 0, (32 * 72 + 32 * 4 * 24) * 8, c->stream()));   // (one exchange carries v_s and u_s: the gaps of the buffer must be canonical)
             RET(coef_eval_dev(c, wit->planes + i0, cnt, eq_r + i0, m, K, 1, partial, od_v, N, c->sh_world == 1 ? wit : nullptr));
-            RET(exchange_modsum_dev(c, od_v, (size_t)K * 72));
         }
     }
     if (t_lane == 0) TL_MARK("  evals: v_s enqueued");
@@ -2113,7 +2329,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
             return LF_OK;
         }
         RET(dot_batch_dev(c, z + c0, n, K, q + c0, n, P.t, cnt, dpart, od_u));
-        RET(exchange_modsum_dev(c, od_u, (size_t)K * P.t * 24));
+        RET(exchange_modsum_dev(c, od, (size_t)32 * 72 + (size_t)K * P.t * 24));   // sharded: the partial v_s and u_s of this rank's slices, ONE all-gather + modular sum
     }
     // one download (one stream synchronisation) for both result sets
     {
@@ -2354,7 +2570,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         od = od_shard;
     }
     // sharded from round 1 on (the condition of the round loop below): the special tables live as entry slices until the hand-over to the replicated tail
-    const bool shard_tabs = c->sh_world > 1 && m / 2 >= (size_t)c->sh_world * 64;
+    const bool shard_tabs = shard_keep(c, 1, m);
     const size_t g_r0 = shard_tabs ? (size_t)c->sh_rank * (m / (size_t)c->sh_world) : 0, g_rcnt = shard_tabs ? m / (size_t)c->sh_world : (size_t)-1;
     size_t zc_lo = 0, zc_hi = n;
     if (shard_tabs) RET(shard_col_range(c, g_r0, g_rcnt, &zc_lo, &zc_hi));
@@ -2391,6 +2607,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
     }
     TL_MARK(" fold challenges");
+    pf_trigger(c, 3);
     for (u32 i = 0; i < K2; i++) {
         Fq3 pm = mu[i];
         for (u32 d = 0; d < 3; d++) { mu_pow[(size_t)i * 3 + d] = f3c(pm); pm = c->ring.mul3(pm, mu[i]); }
@@ -2504,6 +2721,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             Fq3Const r = f3c(pt[round - 2]);
             size_t nn = a.n / 2;
             u64 *dst = T5[flip];
+            const bool handover = sharded && !shard_keep(c, 1, nn);   // this round's fix is the last one on slices: the tables are gathered, the rounds from here on replicated
             // GEMM rounds (below): the norm part needs eqB only, the G part the other four tables -- their fixes (and the G kernel) run on the
             // helper lane's idle stream next to the GEMM chain
             hipStream_t sg = c->stream();
@@ -2522,7 +2740,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
                 } else {
                     launch_fix_many(c->dcrt, a.eqL + 2 * j0, a.ld, dst + j0, nn, 2 * jc, 19, r, sg);
                 }
-                if (nn / 2 < Gw * 64) RET(gather_slices(c, dst, 57, nn));   // hand-over to the replicated tail: every rank needs the whole tables
+                if (handover && round <= 3) RET(gather_slices(c, dst, 57, nn));   // (the f-hat tables are still virtual: the special tables alone; later rounds gather both in one exchange below)
             } else if (round == 2) {   // sources are the five separate full-size tables
                 launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 1, r, sg);
                 launch_fix_many(c->dcrt, a.eqR, a.ld, dst + 3 * nn, nn, a.n, 1, r, sg);
@@ -2536,22 +2754,16 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             } else {            // source is the previous 57-plane buffer (same layout): one launch over its 19 F_{p^3} rows
                 launch_fix_many(c->dcrt, a.eqL, a.ld, dst, nn, a.n, 19, r, c->stream());
             }
-            if (sharded && nn / 2 < Gw * 64) {
-                // transition to the replicated tail: gather the fixed f-hat slices (if they exist yet)
+            if (handover) {
+                // transition to the replicated rounds: the 57 special planes and the fixed f-hat slices in ONE all-gather (RCCL over xGMI), interleaved into full tables
                 if (round > 3) {
                     u64 *fd = F[(round & 1) ? 0 : 1];
                     size_t lcl = ldF / 2;  // local entries after this fix
                     launch_fix_many(c->dcrt, curF, ldF, fd, lcl, ldF, K2 * 3 * 8, r, c->stream());
-                    size_t planes = (size_t)K2 * 3 * 24, words = planes * lcl;
-                    // all-gather the ranks' slices on the device (RCCL over xGMI) and interleave them into full tables
-                    u64 *gall, *gtmp;
-                    RET(c->tbuf("sh_gather_tab", words * Gw, &gall));
-                    RET(c->tbuf("sh_gather_tmp", words, &gtmp));
-                    HIPCHK(hipMemcpyAsync(gtmp, fd, words * 8, hipMemcpyDeviceToDevice, c->stream()));   // fd is also the destination
-                    RET(c->cm().allgather_dev(gtmp, gall, words, c->stream()));
-                    u64 *fo = fd;  // same parity as an ordinary fix output, so the ping-pong of the following rounds stays valid
-                    launch_gather_relayout(gall, (u32)Gw, planes, lcl, fo, c->stream());
-                    curF = fo; ldF = nn;
+                    // fd is source (local layout [planes][lcl]) and destination (full tables, the parity an ordinary fix output has: the ping-pong of the following rounds stays valid)
+                    const GatherPart gp[2] = {{dst + gr * lcl, nn, dst, 57}, {fd, lcl, fd, (size_t)K2 * 3 * 24}};
+                    RET(gather_parts(c, gp, 2, lcl));
+                    curF = fd; ldF = nn;
                     sharded = false;
                     a.eqL = dst; a.eqR = dst + 3 * nn; a.eqB = dst + 6 * nn; a.G1 = dst + 9 * nn; a.G2 = dst + 33 * nn;
                     a.ld = nn; a.n = nn; a.p0 = 0; a.pcnt = nn / 2; a.pF0 = 0;
@@ -2600,7 +2812,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             a.ld = nn; a.n = nn;
             flip ^= 1;
         }
-        if (sharded && a.n / 2 < Gw * 64) sharded = false;   // (round 1 of a tiny instance)
+        if (sharded && !shard_keep(c, 1, a.n)) sharded = false;   // (round 1 of a tiny instance)
         if (sharded) { a.pcnt = a.n / 2 / Gw; a.p0 = gr * a.pcnt; a.pF0 = a.p0; }
         else { a.p0 = 0; a.pcnt = a.n / 2; a.pF0 = 0; }
     tables_ready:
@@ -2785,9 +2997,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         if (round == 3) TL_MARK("  round 3");
         if (round == 6) TL_MARK("  round 6");
         if (round == 10) TL_MARK("  round 10");
+        if (round <= 29) pf_trigger(c, 10 + (int)round);
     }
     TL_MARK(" fold sumcheck");
     c->ev_end(ph);
+    pf_trigger(c, 40);
 
     ph = c->ev_begin(15);
     // theta, eta at r_0 (folding.rs:236-256)
@@ -2898,6 +3112,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
     LF_TRACE(c, "fold_witness");
     TL_MARK("  eta absorbed, rho drawn, fold_witness enqueued");
+    pf_trigger(c, 50);
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
     {
@@ -3019,7 +3234,8 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : ((c->N >= ((size_t)1 << 19) && !(c->i8_nch && !c->tn.ajtai_valu)) ? 16u : 0u);
     int rc;
     std::vector<Fq3> rR;
-    if (c->sh_world > 1 && !c->tn.shard_two_lanes) {
+    const bool shard_threads = c->tn.shard_two_lanes == 1 || (c->tn.shard_two_lanes < 0 && c->two_lanes_ok);
+    if (c->sh_world > 1 && !shard_threads) {
         // Sharded step: ONE host thread issues every exchange in program order (collectives of the ranks can then never cross), the two
         // streams still overlap the right commit with the linearization rounds on the GPU.  (LF_SHARD_TWO_LANES=1: the threaded schedule
         // below with one communicator per lane.)
@@ -3050,6 +3266,26 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
     } else {
     c->bits_wit[0] = c->bits_wit[1] = nullptr;
+    // lf_prefetch_instance: did the previous step prepare THIS right side?  The result is used once or dropped -- here, whatever happens next
+    bool pf_use = false;
+    c->pf_inuse = -1;
+    if (c->pf.have) {
+        lf_ctx::Prefetch &pf = c->pf;
+        pf.have = false;
+        const bool same = pf.wit == w_i && pf.wit_id == w_i->id && pf.x.size() == (size_t)(P.l + 1) * 24 &&
+                          memcmp(pf.x.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8) == 0;
+        const bool path = c->i8_nch && !c->tn.ajtai_valu && !c->tn.commits_first && !commit_pair_possible(c) && !c->tn.force_exchange && c->tn.zr_pos != 4;
+        if (same && path && hipStreamWaitEvent(c->st_lane[0], pf.ev_done, 0) == hipSuccess && hipStreamWaitEvent(c->st_lane[1], pf.ev_done, 0) == hipSuccess) {
+            pf_use = true;
+            pf.consumed++;
+            c->pf_inuse = pf.parity;
+            c->pf_kernel_counted = pf.ev_k_used ? pf.parity : -1;
+            S[1].z = pf.z;
+            memcpy(decr + (size_t)P.K * P.t * 24 + (size_t)P.K * 72, pf.x_s.data(), pf.x_s.size() * 8);
+            S[1].z_state.store(2, std::memory_order_release);
+            TL_MARK("prefetched right side taken");
+        } else pf.dropped++;
+    }
     if (!c->tn.fold_no_sv && !c->tn.force_exchange && c->N <= c->m && (c->N & 3) == 0 && !c->tn.fold_tab_r1 && (c->m >> 1) >= c->tn.sv_min) {
         // bit-plane form of both witnesses (GEMM rounds of the folding sumcheck, v_s evaluations): first thing on the helper lane's stream,
         // enqueued from here so that the events below are recorded before anybody can wait for them
@@ -3058,6 +3294,8 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             u32 *bits;
             if (c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(c->N, P.K), &bits) != LF_OK) break;
             if (!c->bits_ev[sd] && hipEventCreateWithFlags(&c->bits_ev[sd], hipEventDisableTiming) != hipSuccess) break;
+            if (sd == 1 && pf_use) bits = c->pf.bits;      // (made by the prefetch; both streams of this step already wait for it)
+            else
             launch_sv_bits(ws[sd]->planes, c->N, c->N, P.K, bits, c->st_lane[1]);
             if (hipEventRecord(c->bits_ev[sd], c->st_lane[1]) != hipSuccess) break;
             c->bits_wit[sd] = ws[sd]; c->bits_ptr[sd] = bits;
@@ -3076,7 +3314,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         size_t ev = 0;
         // the right side's z_k depend on the witness and on x_w || h = x_ccs || 1 only, not on the point r: wherever they are built on this lane's stream,
         // lane 0's u_s inner products wait for them (S[1].z_ev)
-        bool zr_done = c->tn.zr_pos == 4, yR_early = false;
+        bool zr_done = c->tn.zr_pos == 4 || pf_use, yR_early = false;
         const u64 *yR_host = nullptr;   // (4: the main thread builds them on lane 0's stream, first thing)
         auto build_zr = [&]() {
             if (zr_done) return;
@@ -3111,10 +3349,16 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             if (early && hipMemcpyAsync(c->h_pin2, ydL, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yL, c->stream()) == hipSuccess)
                 yL_early = true;
             if (c->tn.zr_pos == 3) build_zr();
+            if (pf_use) {                                                       // the right commit ran ahead (lf_prefetch_instance): its results are on the host
+                yR_early = true;
+                yR_host = c->pf.y_host;
+                ev = (size_t)-1;
+            } else {
             RET(decompose_commit_enqueue(c, w_i, &yd, &ev, "dec_y2"));          // right commit behind it on the same stream
             if (early && hipMemcpyAsync(c->h_pin2 + ywords, yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yR, c->stream()) == hipSuccess) {
                 yR_early = true;
                 yR_host = c->h_pin2 + ywords;
+            }
             }
             if (yL_early) build_zr();                                           // (default position: behind the right commit; host-side this is NOW, not after y_L has arrived)
             tl1->mark1("L1: commits + z_R enqueued");
@@ -3136,7 +3380,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         tl1->mark1("L1: left absorb starts");
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
         tl1->mark1("L1: left absorb done");
-        return decompose_commit_finish(c, cm_i, yd, ev, decr, yR_early ? yR_host : nullptr, yR_early ? c->ev_yR : nullptr);   // cm of the linearized instance = cm_i.cm
+        return decompose_commit_finish(c, cm_i, yd, ev, decr, yR_early ? yR_host : nullptr, yR_early ? (pf_use ? c->pf.ev_done : c->ev_yR) : nullptr);   // cm of the linearized instance = cm_i.cm
     });
     {   // absorb_public_input (nifs.rs:175-197) -- after lane 1 has been started: the left decomposition does not depend on it
         HostTimer ht(c);
@@ -3157,6 +3401,9 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     c->vs_keep = false;
     TL_MARK("linearization done");
     lin_done_p.set_value(rc);
+    // From here the host runs a serial Poseidon chain (left absorb, right absorb, folding challenges: ~2.4 ms at 2^20 rows) next to which the GPU only has the
+    // right evaluations (0.5 ms): the window in which the next step's right side is prepared (lf_prefetch_instance; its stream has the lowest priority)
+    if (rc == LF_OK) pf_trigger(c, 0);
     EvalStages est;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
@@ -3165,10 +3412,12 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     }
     c->vs_wit = nullptr;
     TL_MARK(est.active ? "right evals enqueued" : "right evals done");
+    if (rc == LF_OK) pf_trigger(c, 1);
     int rc1 = c->lane1.wait();
     c->lin_blocks = 0;
     TL_MARK("lane 1 joined");
     if (rc == LF_OK) rc = rc1;
+    if (rc == LF_OK) pf_trigger(c, 2);
     if (rc == LF_OK && est.active) {
         // the right decomposition is absorbed part by part (x_k, y_k, u_k, v_k): the first half as soon as its inner products are down, the second half
         // of the inner products is still running on the GPU meanwhile
@@ -3184,6 +3433,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     TL_MARK("right absorb done");
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->bits_wit[0] = c->bits_wit[1] = nullptr;
+    if (c->pf.req) { c->pf.req = false; c->pf.dropped++; }   // (no trigger point reached: a request does not outlive the step it was made for)
     TL_MARK("fold done");
     tl.merge();
     tl.dump();
@@ -3529,6 +3779,37 @@ int lf_last_timeline(lf_ctx *c, char *names, double *ms, int max_marks) {
 // measurement hook of tools/gpu_i8prof.sh (not part of the prover interface, not declared in lfhip.h): per-phase clock totals of the last commit
 // launch made with LF_I8_PROF set
 int lf_abi_version(void) { return LFHIP_ABI_VERSION; }
+int lf_prefetch_instance(lf_ctx *c, const uint64_t *cm_next, const lf_witness *w_next) {
+    if (LF_XB(c) && cm_next && c->have_ccs_any()) {
+        XB x(c);
+        const lf_params &P = c->params_any();
+        return lf_prefetch_instance(c, x.ring_in(cm_next, lf_cccs_len_ring(&P, lf_ctx_ring(c))), w_next);
+    }
+    if (!c || !cm_next || !w_next || w_next->ctx != c) return LF_ERR_INVALID;
+    if (c->bb) return LF_OK;                       // (a hint: the BabyBear backend has no prefetch path and ignores it)
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs || !c->A_loaded) return LF_ERR_STATE;
+    const lf_params &P = c->P;
+    if (w_next->N != c->N) return LF_ERR_INVALID;
+    lf_ctx::Prefetch &pf = c->pf;
+    if (pf.req) pf.dropped++;                      // (a second request before any step ran replaces the first)
+    pf.req = true;
+    pf.req_wit = w_next;
+    pf.req_id = w_next->id;
+    pf.req_x.assign((size_t)(P.l + 1) * 24, 0);
+    memcpy(pf.req_x.data(), cm_next + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
+    HostRing::from_u64(1, pf.req_x.data() + (size_t)P.l * 24);
+    return LF_OK;
+}
+int lf_prefetch_stats(lf_ctx *c, unsigned *issued, unsigned *consumed, unsigned *dropped) {
+    if (!c) return LF_ERR_INVALID;
+    if (c->bb) { if (issued) *issued = 0; if (consumed) *consumed = 0; if (dropped) *dropped = 0; return LF_OK; }
+    std::lock_guard<std::mutex> g(c->mu);
+    if (issued) *issued = c->pf.issued;
+    if (consumed) *consumed = c->pf.consumed;
+    if (dropped) *dropped = c->pf.dropped;
+    return LF_OK;
+}
 int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_prof((unsigned long long *)out64) : LF_ERR_INVALID; }
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;

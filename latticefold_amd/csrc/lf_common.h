@@ -4,6 +4,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/lfhip.h"
 
 #define HIPCHK(x)                                    \
@@ -56,12 +58,19 @@ struct DevBuf {
     }
 };
 
+// process-wide serial number of witnesses: a handle that was freed and whose address a later witness reuses is a DIFFERENT witness (lf_prefetch_instance
+// recognises the witness it prepared by pointer and serial number)
+inline uint64_t lf_next_witness_id() {
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1, std::memory_order_relaxed);
+}
 struct lf_witness {
     lf_ctx *ctx;      // identity only (compared, never dereferenced by lf_witness_free: a witness may outlive its context)
     int32_t *planes;  // [d][N] centred integer coefficients (d = 24 Goldilocks, 72 BabyBear)
     size_t N;
     int device;          // device the planes live on
     size_t plane_bytes;  // size of the planes allocation (pool key)
+    uint64_t id = lf_next_witness_id();
 };
 
 // Device buffers of witness planes are recycled through a small per-context pool: a fold step produces one folded witness and
@@ -83,7 +92,11 @@ struct Tunables {
     bool force_exchange = false;     // LF_DIST_FORCE_EXCHANGE: run the sharded exchanges even with a 1-rank RCCL communicator (test hook)
     bool device_transcript = false;  // LF_DEVICE_TRANSCRIPT: Poseidon sponge of the tail rounds on the device (opt-in: slower than the host's)
     bool shard_plain_rounds = false; // LF_SHARD_PLAIN_ROUNDS: sharded folding rounds on materialised tables only (no fused fix / look-up-table rounds)
-    bool shard_two_lanes = false;    // LF_SHARD_TWO_LANES: threaded two-lane schedule also in a sharded step (default there: one host thread)
+    int shard_two_lanes = -1;        // LF_SHARD_TWO_LANES: 1 = threaded two-lane schedule in a sharded step, 0 = one host thread issues every exchange, unset (-1) = two lanes
+                                     // when the transport has proved that its two channels work concurrently (lf_dist_init's handshake / two host callbacks)
+    size_t shard_lin_min = 16384;    // LF_SHARD_LIN_MIN: a sharded linearization sumcheck hands over to the replicated rounds once its tables have this many entries or fewer
+                                     // (a round there is a ~30 us launch: an exchange costs as much as it saves); never above m / 16
+    size_t shard_fold_min = 2048;    // LF_SHARD_FOLD_MIN: the same for the folding sumcheck (96 tables per entry: rounds stay worth sharding down to the persistent tail's size)
     bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
     bool coef_valu = false;          // LF_COEF_VALU: v / v_s / theta evaluations of the digit planes on the VALU kernel (k_coef_eval) instead of the matrix cores
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
@@ -115,6 +128,10 @@ struct Tunables {
     size_t r5_min = 8192;            // LF_FOLD_R5_MIN: pairs of round 5 from which it runs on the planes (mode 7; measured: 2^16 rows slower, 2^20 faster)
     size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
     long lin_blocks = -1;            // -1: automatic
+    int pf_at = 0;                   // LF_PF_AT: the first point at or after which a fold step enqueues the prefetch of the next right side (lf_prefetch_instance): 0 when its
+                                     // linearization is done (the host's absorb chain starts, the GPU has only the right evaluations left), 1 after the right evaluations,
+                                     // 2 when the two lanes have joined, 3 after the folding challenges, 10 + r after round r of the folding sumcheck, 40 after the sumcheck,
+                                     // 50 with the folded witness
     static Tunables read(size_t lut_min_default) {
         Tunables t;
         t.lut_min = lut_min_default;
@@ -158,7 +175,9 @@ struct Tunables {
         if (const char *e = getenv("LF_ZR_POS")) t.zr_pos = atoi(e);
         t.evals_one_stage = getenv("LF_EVALS_TWO_STAGES") == nullptr;
         t.no_early_y = getenv("LF_NO_EARLY_Y") != nullptr;
-        t.shard_two_lanes = getenv("LF_SHARD_TWO_LANES") != nullptr;
+        if ((e = getenv("LF_SHARD_TWO_LANES"))) t.shard_two_lanes = atoi(e) != 0;
+        if ((e = getenv("LF_SHARD_LIN_MIN"))) t.shard_lin_min = (size_t)atoll(e);
+        if ((e = getenv("LF_SHARD_FOLD_MIN"))) t.shard_fold_min = (size_t)atoll(e);
         t.shard_plain_rounds = getenv("LF_SHARD_PLAIN_ROUNDS") != nullptr;
         t.device_transcript = getenv("LF_DEVICE_TRANSCRIPT") != nullptr;
         t.force_exchange = getenv("LF_DIST_FORCE_EXCHANGE") != nullptr;
@@ -168,6 +187,7 @@ struct Tunables {
         if ((e = getenv("LF_LIN_BLOCKS"))) t.lin_blocks = atol(e);
         if ((e = getenv("LF_TAIL_N"))) t.tail_n = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_R5_MIN"))) t.r5_min = (size_t)atoll(e);
+        if ((e = getenv("LF_PF_AT"))) t.pf_at = atoi(e);
         return t;
     }
 };

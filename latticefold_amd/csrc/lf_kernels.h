@@ -36,6 +36,7 @@ void launch_fill_ajtai(u64 *A, u32 kappa, size_t n, size_t n_total, size_t col0,
 // sharded exchanges: modular sum of all-gathered partial vectors; re-layout of all-gathered table slices
 void launch_modsum(const u64 *parts, u32 nparts, size_t words, u64 *out, hipStream_t s);
 void launch_gather_relayout(const u64 *all, u32 nranks, size_t planes, size_t lcl, u64 *full, hipStream_t s);
+void launch_gather_relayout_part(const u64 *all, u32 nranks, size_t planes_tot, size_t p0, size_t planes, size_t lcl, u64 *full, hipStream_t s);
 
 void launch_selftest_field(u64 seed, u32 n, u64 *mism_dev, hipStream_t s);  // arithmetic self-test, see lf_kernels.hip
 

@@ -93,6 +93,17 @@ void launch_gather_relayout(const u64 *all, u32 nranks, size_t planes, size_t lc
     size_t tot = (size_t)nranks * planes * lcl;
     if (tot) hipLaunchKernelGGL(k_gather_relayout, dim3(cdiv(tot, 256)), dim3(256), 0, s, all, nranks, planes, lcl, full);
 }
+// the same for ONE table set of a payload that carries several ([rank][planes_tot][lcl], this set = planes [p0, p0 + planes)): one all-gather per hand-over
+__global__ void __launch_bounds__(256) k_gather_relayout_part(const u64 *all, u32 nranks, size_t planes_tot, size_t p0, size_t planes, size_t lcl, u64 *full) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, tot = (size_t)nranks * planes * lcl;
+    if (i >= tot) return;
+    size_t j = i % lcl, w = (i / lcl) % planes, rk = i / (lcl * planes);
+    full[w * (nranks * lcl) + rk * lcl + j] = all[(rk * planes_tot + p0 + w) * lcl + j];
+}
+void launch_gather_relayout_part(const u64 *all, u32 nranks, size_t planes_tot, size_t p0, size_t planes, size_t lcl, u64 *full, hipStream_t s) {
+    size_t tot = (size_t)nranks * planes * lcl;
+    if (tot) hipLaunchKernelGGL(k_gather_relayout_part, dim3(cdiv(tot, 256)), dim3(256), 0, s, all, nranks, planes_tot, p0, planes, lcl, full);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // layout

@@ -61,7 +61,25 @@ def init_sharding(ctx, rank, world, transport="auto"):
                 ids = [b""]
         dist.broadcast_object_list(ids, src=0)
         if ids[0]:
-            ctx.dist_init(rank, world, ids[0])
+            # lf_dist_init checks the two-lane schedule itself (both communicators' first collectives issued concurrently from the two threads of a fold step).
+            # Every rank must run the SAME schedule: the ranks' outcomes are combined (minimum); a rank whose handshake timed out has lost its communicators,
+            # so then every rank makes new ones from fresh ids, without the handshake, and the conservative one-thread schedule is used
+            try:
+                ctx.dist_init(rank, world, ids[0])
+                mine = ctx.dist_two_lanes()
+            except api.LfError:
+                mine = -1
+            t = torch.tensor([mine], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            agreed = int(t.item())
+            if agreed < 0:
+                import os
+                ids = [api.dist_unique_ids() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                os.environ["LF_DIST_NO_HANDSHAKE"] = "1"
+                ctx.dist_init(rank, world, ids[0])
+                agreed = 0
+            ctx.dist_two_lanes(agreed)
             return "rccl"
         transport = "host"
     if transport == "host":

@@ -65,7 +65,12 @@ def _free_port():
                                                    (2, "T14", "gemm"), (8, "T14", "gemm"),
                                                    # rows that refer to a neighbour's (and, wrapping round, to rank 0's) columns, and four matrices: the z-space
                                                    # combinations of a rank cover the columns its rows of G read (shard_col_range), not just its own slice
-                                                   (2, "T10/multi,T12/deg3", False), (4, "T12/multi", "big")])
+                                                   (2, "T10/multi,T12/deg3", False), (4, "T12/multi", "big"),
+                                                   # one host thread issues every exchange (the schedule of a transport with ONE channel, or LF_SHARD_TWO_LANES=0)
+                                                   (2, "T12", "one"), (4, "T14", "one"),
+                                                   # the hand-over sizes of round 5: off (only the 64-pairs-per-rank rule of the earlier rounds: the slices are gathered
+                                                   # late) and large (gathered after the first fix)
+                                                   (4, "T14", "deep"), (2, "T14", "early")])
 def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -76,7 +81,13 @@ def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
         env.update(LF_FOLD_SV_MIN="64", LF_DOT_MIN="64", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")   # (LF_DOT_MIN: the int8 inner products on the ranks' column slices, odd first columns included)
     elif two_lanes == "plain":
         env.update(LF_SHARD_PLAIN_ROUNDS="1", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
-    elif two_lanes:   # the threaded two-lane schedule with one exchange channel per lane (default in a sharded step: one host thread)
+    elif two_lanes == "one":
+        env["LF_SHARD_TWO_LANES"] = "0"
+    elif two_lanes == "deep":
+        env.update(LF_SHARD_LIN_MIN="0", LF_SHARD_FOLD_MIN="0", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
+    elif two_lanes == "early":
+        env.update(LF_SHARD_LIN_MIN="1048576", LF_SHARD_FOLD_MIN="1048576", LF_FOLD_LUT_MIN="128", LF_FOLD_FUSE_MIN="64", LF_FOLD_TAB_MIN="64")
+    elif two_lanes:   # the threaded two-lane schedule with one exchange channel per lane, forced (it is the default when the transport has two channels, as here)
         env["LF_SHARD_TWO_LANES"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]

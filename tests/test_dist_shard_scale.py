@@ -49,11 +49,16 @@ WORKER = textwrap.dedent('''
             wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
             cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
             acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+            if sharded:
+                ctx.dist_stats(reset=True)
             lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+            if sharded:
+                n_ex = ctx.dist_stats()[0]          # exchanges of the fold step alone
             d = _digests(wl, acc, lc, w0.f, proof)
             d["transport"] = transport
             if sharded:
-                d["exchanges"] = ctx.dist_stats()[0]
+                d["exchanges"] = n_ex
+                d["two_lanes"] = ctx.dist_two_lanes()
             ctx.close()
             return d
         ref = run(False) if os.environ.get("LF_WITH_REF") else None
@@ -94,7 +99,7 @@ def _launch(tmp_path, world, cases, env_extra, timeout):
 SECTIONS = ("acc", "lcccs_out", "f0_ntt", "proof_lin", "proof_dec_left", "proof_dec_right", "proof_fold_msgs", "proof_theta", "proof_eta", "proof")
 
 
-@pytest.mark.parametrize("world,name", [(2, "T18"), (4, "T18"), (2, "C4"), (4, "C4"), (2, "C3")])
+@pytest.mark.parametrize("world,name", [(2, "T18"), (4, "T18"), (8, "T18"), (2, "C4"), (4, "C4"), (8, "C4"), (2, "C3")])
 def test_sharded_fold_step_matches_committed_oracle_digests(tmp_path, world, name):
     gold = _gold()
     if name not in gold:
@@ -106,6 +111,9 @@ def test_sharded_fold_step_matches_committed_oracle_digests(tmp_path, world, nam
         bad = [k for k in SECTIONS if got[k] != gold[name][k]]
         assert not bad, f"{name} sharded x{world}, rank {r}: sections differing from the oracle fixture: {bad}"
         assert got["exchanges"] > 0          # the step really exchanged partial results
+        if name in ("T18", "C4"):            # Goldilocks: two commits, one exchange per sharded round (the tables are handed over at 16384 / 2048 entries), one per
+            assert got["exchanges"] <= 24, got["exchanges"]      # hand-over, v, one per side for v_s + u_s, eta -- 38 before round 5
+            assert got["two_lanes"] == 1     # two channels (one process group per lane): the threaded schedule is the default
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

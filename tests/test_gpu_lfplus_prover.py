@@ -104,20 +104,23 @@ def test_scratch_cache_is_bounded_and_released(monkeypatch):
     """lfp_ctx.h LfpDevCache: a destroyed context leaves its scratch in the process-wide cache (so that a prover per proof does not pay hipMalloc again), the
     cache is bounded by min(32 GB, a quarter of the device's memory) per device, lfplus_scratch_bytes reports it and lfplus_scratch_trim gives it back to the
     driver -- the main path's allocators call the same trim before they report out-of-memory (lf_common.h lf_dev_malloc)"""
-    import torch
+    from latticefold_amd import api
     plus.scratch_trim(0)
     assert plus.scratch_bytes(0) == 0
     n = 1 << 14
     rng = np.random.default_rng(5)
-    ctx = plus.PlusContext(0)
+    main = api.Context(0)                    # (the main path's context: lf_device_memory = hipMemGetInfo)
     try:
-        ctx.set_witness(rng.integers(0, 31, size=(n, D), dtype=np.uint64))
+        ctx = plus.PlusContext(0)
+        try:
+            ctx.set_witness(rng.integers(0, 31, size=(n, D), dtype=np.uint64))
+        finally:
+            ctx.close()
+        held = plus.scratch_bytes(0)
+        free0, total = main.device_memory()
+        assert n * D * 8 <= held <= min(32 << 30, total // 4)
+        plus.scratch_trim(0)
+        assert plus.scratch_bytes(0) == 0
+        assert main.device_memory()[0] >= free0 + held - (64 << 20)      # the blocks went back to the driver (other allocations may move a little)
     finally:
-        ctx.close()
-    held = plus.scratch_bytes(0)
-    total = torch.cuda.get_device_properties(0).total_memory
-    assert n * D * 8 <= held <= min(32 << 30, total // 4)
-    free0 = torch.cuda.mem_get_info(0)[0]
-    plus.scratch_trim(0)
-    assert plus.scratch_bytes(0) == 0
-    assert torch.cuda.mem_get_info(0)[0] >= free0 + held - (64 << 20)      # the blocks went back to the driver (other allocations may move a little)
+        main.close()
