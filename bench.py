@@ -328,7 +328,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prefetch", action="store_true", help="do not announce the next step's instance (lf_prefetch_instance): every step computes its whole right decomposition itself")
+    ap.add_argument("--prefetch", action="store_true", help="announce the next step's instance before every step (lf_prefetch_instance): the step prepares the next right decomposition's "
+                    "challenge-independent half.  Off by default: measured 0.8-1.9 ms SLOWER per C4 step at every trigger point (gpurun r5c/r5d, DESIGN 10): the chip has no idle CUs to give")
+    ap.add_argument("--no-prefetch", action="store_true", help="(default) every step computes its whole right decomposition itself")
     ap.add_argument("--no-lfplus", action="store_true", help="skip the LatticeFold+ PlusProver::prove timing (an extra key, not part of the metric)")
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
@@ -375,7 +377,7 @@ def main():
     def measure(shard):
         """setup (untimed: everything resident in HBM), W warm-up steps, K timed steps bracketed by barrier + synchronize; max over ranks"""
         wl = make_workload(args.workload, seed=0 if shard else rank)
-        use_prefetch = not args.no_prefetch and not shard and wl.ring == "goldilocks"
+        use_prefetch = args.prefetch and not args.no_prefetch and not shard and wl.ring == "goldilocks"
         ctx = api.Context(local_rank, ring=wl.ring)
         transport = None
         if shard:

@@ -240,22 +240,28 @@ struct lf_ctx {
         std::vector<u64> x, x_s;         // x_ccs || 1 it was made for; x_s of the proof (K (l+1) ring elements)
         u32 *bits = nullptr;
         u64 *z = nullptr, *yd = nullptr;
-        u64 *y_host = nullptr;           // pinned: (K - 1) kappa ring elements
-        size_t y_words = 0;
-        hipEvent_t ev_done = nullptr;
+        u64 *y_host[2] = {nullptr, nullptr};   // pinned: (K - 1) kappa ring elements, per parity (the consuming step's lane 1 reads one while the next prefetch fills the other)
+        size_t y_words[2] = {0, 0};
+        hipEvent_t ev_done[2] = {nullptr, nullptr};   // per parity: recorded behind the download of y
+        int part = 0;                    // parts of the request enqueued so far: 1 = bit planes + z_k (LF_PF_AT), 2 = + commits and their download (LF_PF_AT2)
         EvPair ev_k[2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // HIP events around the commit kernel, per parity (counted in the CONSUMING step's kernel statistics)
         bool ev_k_used = false;
         int wr = 0;                      // parity the prefetch being enqueued writes
+        u32 *w_bits = nullptr;           // buffers / x_s of the prefetch being enqueued (published with `have`)
+        u64 *w_z = nullptr, *w_yd = nullptr;
+        std::vector<u64> w_x_s;
         unsigned issued = 0, consumed = 0, dropped = 0;   // counters (lf_prefetch_stats)
         void destroy() {
-            if (y_host) (void)hipHostFree(y_host);
-            if (ev_done) (void)hipEventDestroy(ev_done);
+            for (int i = 0; i < 2; i++) {
+                if (y_host[i]) (void)hipHostFree(y_host[i]);
+                if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+                y_host[i] = nullptr; ev_done[i] = nullptr; y_words[i] = 0;
+            }
             for (EvPair &e : ev_k) {
                 if (e.a) (void)hipEventDestroy(e.a);
                 if (e.b) (void)hipEventDestroy(e.b);
                 e = {nullptr, nullptr};
             }
-            y_host = nullptr; ev_done = nullptr;
         }
     } pf;
     int pf_inuse = -1;                   // parity of the prefetch buffers the running step reads (-1: none)
@@ -2193,53 +2199,60 @@ static int decompose_prepare_z(lf_ctx *c, const u64 *xh /* (l+1) elements: x_w |
 // The work of lf_prefetch_instance: bit planes, z_k / x_s and the K - 1 digit-plane commitments of the NEXT step's right witness, enqueued on lane 2's stream by
 // the thread of the running step (t_lane is switched for the duration: stream, buffers and staging are the prefetch lane's own).  Never fails the running step:
 // an error just leaves no result.
-static int prefetch_enqueue(lf_ctx *c) {
+static int prefetch_enqueue(lf_ctx *c, int upto) {
     lf_ctx::Prefetch &pf = c->pf;
-    if (!pf.req) return LF_OK;
-    pf.req = false;
+    if (!pf.req || pf.part >= upto) return LF_OK;
     const lf_params &P = c->P;
     const lf_witness *wit = pf.req_wit;
     const u32 K = P.K;
-    // what the default fold step of a large unsharded instance runs: digit commits on the matrix cores over the whole witness, bit planes for the GEMM rounds
-    if (c->sh_world > 1 || !c->i8_nch || c->tn.ajtai_valu || c->tn.commits_first || c->tn.i8_pair || c->tn.force_exchange || P.b != 2 || c->A_col0 != 0 || c->nA != c->N ||
-        wit->N != c->N || (c->N & 3) || c->N > c->m || K < 2) { pf.dropped++; return LF_OK; }
     struct LaneSwitch { int old; LaneSwitch() : old(t_lane) { t_lane = 2; } ~LaneSwitch() { t_lane = old; } } ls;
-    if (!c->st_lane[2]) {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIPCHK(hipStreamCreateWithPriority(&c->st_lane[2], hipStreamDefault, getenv("LF_NO_PRIO") ? 0 : least));
+    if (pf.part == 0) {
+        // what the default fold step of a large unsharded instance runs: digit commits on the matrix cores over the whole witness, bit planes for the GEMM rounds
+        if (c->sh_world > 1 || !c->i8_nch || c->tn.ajtai_valu || c->tn.commits_first || c->tn.i8_pair || c->tn.force_exchange || P.b != 2 || c->A_col0 != 0 || c->nA != c->N ||
+            wit->N != c->N || (c->N & 3) || c->N > c->m || K < 2) { pf.req = false; pf.dropped++; return LF_OK; }
+        if (!c->st_lane[2]) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            HIPCHK(hipStreamCreateWithPriority(&c->st_lane[2], hipStreamDefault, getenv("LF_NO_PRIO") ? 0 : least));
+        }
+        const int wr = c->pf_inuse == 0 ? 1 : 0;
+        pf.wr = wr; pf.ev_k_used = false; pf.have = false;
+        if (!pf.ev_done[wr]) HIPCHK(hipEventCreateWithFlags(&pf.ev_done[wr], hipEventDisableTiming));
+        if (!pf.ev_k[wr].a) { HIPCHK(hipEventCreate(&pf.ev_k[wr].a)); HIPCHK(hipEventCreate(&pf.ev_k[wr].b)); }
+        RET(c->tbuf(wr ? "pf_bits1" : "pf_bits0", sv_bits_words(c->N, K), &pf.w_bits));
+        RET(c->tbuf(wr ? "pf_z1" : "pf_z0", (size_t)K * 24 * c->n, &pf.w_z));
+        RET(c->tbuf(wr ? "pf_y1" : "pf_y0", (size_t)K * P.kappa * 24, &pf.w_yd));
+        const size_t ywords = (size_t)(K - 1) * P.kappa * 24;
+        if (pf.y_words[wr] < ywords) {
+            if (pf.y_host[wr]) { HIPCHK(hipStreamSynchronize(c->stream())); (void)hipHostFree(pf.y_host[wr]); pf.y_host[wr] = nullptr; pf.y_words[wr] = 0; }
+            HIPCHK(hipHostMalloc((void **)&pf.y_host[wr], ywords * 8));
+            pf.y_words[wr] = ywords;
+        }
+        launch_sv_bits(wit->planes, c->N, c->N, K, pf.w_bits, c->stream());
+        pf.w_x_s.assign((size_t)K * (P.l + 1) * 24, 0);
+        compute_x_s(c, pf.req_x.data(), pf.w_x_s.data());
+        RET(build_z(c, wit->planes, K, 1, pf.w_x_s.data(), pf.w_z));
+        pf.part = 1;
     }
-    const int wr = c->pf_inuse == 0 ? 1 : 0;
-    pf.wr = wr; pf.ev_k_used = false; pf.have = false;
-    if (!pf.ev_done) HIPCHK(hipEventCreateWithFlags(&pf.ev_done, hipEventDisableTiming));
-    if (!pf.ev_k[wr].a) { HIPCHK(hipEventCreate(&pf.ev_k[wr].a)); HIPCHK(hipEventCreate(&pf.ev_k[wr].b)); }
-    u32 *bits;
-    u64 *z, *yd;
-    RET(c->tbuf(wr ? "pf_bits1" : "pf_bits0", sv_bits_words(c->N, K), &bits));
-    RET(c->tbuf(wr ? "pf_z1" : "pf_z0", (size_t)K * 24 * c->n, &z));
-    RET(c->tbuf("pf_y", (size_t)K * P.kappa * 24, &yd));
-    const size_t ywords = (size_t)(K - 1) * P.kappa * 24;
-    if (pf.y_words < ywords) {
-        if (pf.y_host) { HIPCHK(hipStreamSynchronize(c->stream())); (void)hipHostFree(pf.y_host); pf.y_host = nullptr; pf.y_words = 0; }
-        HIPCHK(hipHostMalloc((void **)&pf.y_host, ywords * 8));
-        pf.y_words = ywords;
+    if (upto >= 2) {
+        const int wr = pf.wr;
+        const size_t ywords = (size_t)(K - 1) * P.kappa * 24;
+        RET(commit_planes_i8(c, wit->planes, c->N, 1, K - 1, pf.w_yd, nullptr, nullptr, nullptr, pf.w_bits));
+        HIPCHK(hipMemcpyAsync(pf.y_host[wr], pf.w_yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()));
+        HIPCHK(hipEventRecord(pf.ev_done[wr], c->stream()));
+        pf.have = true; pf.parity = wr; pf.wit = wit; pf.wit_id = pf.req_id; pf.x = pf.req_x; pf.x_s = pf.w_x_s; pf.bits = pf.w_bits; pf.z = pf.w_z; pf.yd = pf.w_yd;
+        pf.issued++;
+        pf.req = false; pf.part = 0;
     }
-    launch_sv_bits(wit->planes, c->N, c->N, K, bits, c->stream());
-    pf.x_s.assign((size_t)K * (P.l + 1) * 24, 0);
-    compute_x_s(c, pf.req_x.data(), pf.x_s.data());
-    RET(build_z(c, wit->planes, K, 1, pf.x_s.data(), z));
-    RET(commit_planes_i8(c, wit->planes, c->N, 1, K - 1, yd, nullptr, nullptr, nullptr, bits));
-    HIPCHK(hipMemcpyAsync(pf.y_host, yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()));
-    HIPCHK(hipEventRecord(pf.ev_done, c->stream()));
-    pf.have = true; pf.parity = wr; pf.wit = wit; pf.wit_id = pf.req_id; pf.x = pf.req_x; pf.bits = bits; pf.z = z; pf.yd = yd;
-    pf.issued++;
     return LF_OK;
 }
 static void pf_trigger(lf_ctx *c, int point) {
-    if (c->pf.req && point >= c->tn.pf_at) {   // (the first trigger point at or after LF_PF_AT that the step reaches)
-        if (prefetch_enqueue(c) != LF_OK) { c->pf.have = false; c->pf.dropped++; (void)hipGetLastError(); }
-        TL_MARK("  prefetch enqueued");
-    }
+    // (the first trigger point at or after LF_PF_AT that the step reaches enqueues the bit planes and z_k, the first at or after LF_PF_AT2 the commits)
+    if (!c->pf.req) return;
+    const int upto = point >= c->tn.pf_at2 ? 2 : point >= c->tn.pf_at ? 1 : 0;
+    if (upto <= c->pf.part) return;
+    if (prefetch_enqueue(c, upto) != LF_OK) { c->pf.have = false; c->pf.req = false; c->pf.part = 0; c->pf.dropped++; (void)hipGetLastError(); }
+    TL_MARK(upto == 2 ? "  prefetch: commits enqueued" : "  prefetch: bit planes + z enqueued");
 }
 
 // The evaluations of a decomposition in two stages (the right side of a fold step): stage 0 = all v_s and the u_s of the parts k < ksplit, stage 1 = the
@@ -3275,7 +3288,8 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         const bool same = pf.wit == w_i && pf.wit_id == w_i->id && pf.x.size() == (size_t)(P.l + 1) * 24 &&
                           memcmp(pf.x.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8) == 0;
         const bool path = c->i8_nch && !c->tn.ajtai_valu && !c->tn.commits_first && !commit_pair_possible(c) && !c->tn.force_exchange && c->tn.zr_pos != 4;
-        if (same && path && hipStreamWaitEvent(c->st_lane[0], pf.ev_done, 0) == hipSuccess && hipStreamWaitEvent(c->st_lane[1], pf.ev_done, 0) == hipSuccess) {
+        if (same && path && hipStreamWaitEvent(c->st_lane[0], pf.ev_done[pf.parity], 0) == hipSuccess &&
+            hipStreamWaitEvent(c->st_lane[1], pf.ev_done[pf.parity], 0) == hipSuccess) {
             pf_use = true;
             pf.consumed++;
             c->pf_inuse = pf.parity;
@@ -3351,7 +3365,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             if (c->tn.zr_pos == 3) build_zr();
             if (pf_use) {                                                       // the right commit ran ahead (lf_prefetch_instance): its results are on the host
                 yR_early = true;
-                yR_host = c->pf.y_host;
+                yR_host = c->pf.y_host[c->pf_inuse];
                 ev = (size_t)-1;
             } else {
             RET(decompose_commit_enqueue(c, w_i, &yd, &ev, "dec_y2"));          // right commit behind it on the same stream
@@ -3380,7 +3394,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         tl1->mark1("L1: left absorb starts");
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
         tl1->mark1("L1: left absorb done");
-        return decompose_commit_finish(c, cm_i, yd, ev, decr, yR_early ? yR_host : nullptr, yR_early ? (pf_use ? c->pf.ev_done : c->ev_yR) : nullptr);   // cm of the linearized instance = cm_i.cm
+        return decompose_commit_finish(c, cm_i, yd, ev, decr, yR_early ? yR_host : nullptr, yR_early ? (pf_use ? c->pf.ev_done[c->pf_inuse] : c->ev_yR) : nullptr);   // cm of the linearized instance = cm_i.cm
     });
     {   // absorb_public_input (nifs.rs:175-197) -- after lane 1 has been started: the left decomposition does not depend on it
         HostTimer ht(c);
@@ -3433,7 +3447,7 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     TL_MARK("right absorb done");
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->bits_wit[0] = c->bits_wit[1] = nullptr;
-    if (c->pf.req) { c->pf.req = false; c->pf.dropped++; }   // (no trigger point reached: a request does not outlive the step it was made for)
+    if (c->pf.req) { c->pf.req = false; c->pf.part = 0; c->pf.dropped++; }   // (not every trigger point reached: a request does not outlive the step it was made for)
     TL_MARK("fold done");
     tl.merge();
     tl.dump();
@@ -3794,6 +3808,7 @@ int lf_prefetch_instance(lf_ctx *c, const uint64_t *cm_next, const lf_witness *w
     lf_ctx::Prefetch &pf = c->pf;
     if (pf.req) pf.dropped++;                      // (a second request before any step ran replaces the first)
     pf.req = true;
+    pf.part = 0;
     pf.req_wit = w_next;
     pf.req_id = w_next->id;
     pf.req_x.assign((size_t)(P.l + 1) * 24, 0);

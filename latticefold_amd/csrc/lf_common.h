@@ -132,6 +132,7 @@ struct Tunables {
                                      // linearization is done (the host's absorb chain starts, the GPU has only the right evaluations left), 1 after the right evaluations,
                                      // 2 when the two lanes have joined, 3 after the folding challenges, 10 + r after round r of the folding sumcheck, 40 after the sumcheck,
                                      // 50 with the folded witness
+    int pf_at2 = 0;                  // LF_PF_AT2: same scale, for the second part of the prefetch (the K - 1 digit-plane commits); the first part is the bit planes and z_k
     static Tunables read(size_t lut_min_default) {
         Tunables t;
         t.lut_min = lut_min_default;
@@ -187,7 +188,9 @@ struct Tunables {
         if ((e = getenv("LF_LIN_BLOCKS"))) t.lin_blocks = atol(e);
         if ((e = getenv("LF_TAIL_N"))) t.tail_n = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_R5_MIN"))) t.r5_min = (size_t)atoll(e);
-        if ((e = getenv("LF_PF_AT"))) t.pf_at = atoi(e);
+        if ((e = getenv("LF_PF_AT"))) t.pf_at = t.pf_at2 = atoi(e);
+        if ((e = getenv("LF_PF_AT2"))) t.pf_at2 = atoi(e);
+        if (t.pf_at2 < t.pf_at) t.pf_at2 = t.pf_at;
         return t;
     }
 };

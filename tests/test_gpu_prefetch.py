@@ -40,8 +40,15 @@ def _chain(ctx, wl, scheme, wits, cccs, steps, hint):
     return out
 
 
-@pytest.mark.parametrize("name,pf_at", [("T10", 0), ("T12", 0), ("T12", 1), ("T12", 2), ("T12", 3), ("T12", 13), ("T12", 16), ("T12", 40), ("T12", 50), ("T14", 0), ("T14", 17)])
+@pytest.mark.parametrize("name,pf_at", [("T10", 0), ("T10", (0, 2)), ("T10", (2, 50)), ("T12", 0), ("T12", 1), ("T12", 2), ("T12", 3), ("T12", 13), ("T12", 16), ("T12", 40), ("T12", 50),
+                                        ("T12", (0, 17)), ("T12", (2, 16)), ("T12", (2, 40)), ("T12", (12, 50)), ("T14", 0), ("T14", 17), ("T14", (2, 17))])
 def test_prefetched_chain_is_bit_identical_and_matches_oracle(name, pf_at, monkeypatch):
+    # LF_PF_AT: where the step enqueues the bit planes and z_k of the next right side; LF_PF_AT2 (default: the same point): where it enqueues the commits
+    if isinstance(pf_at, tuple):
+        monkeypatch.setenv("LF_PF_AT2", str(pf_at[1]))
+        pf_at = pf_at[0]
+    else:
+        monkeypatch.delenv("LF_PF_AT2", raising=False)
     monkeypatch.setenv("LF_PF_AT", str(pf_at))
     wl = make_workload(name)
     ctx = api.Context(0)
