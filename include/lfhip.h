@@ -176,6 +176,13 @@ int lf_dist_two_lanes(lf_ctx *, int set);
 int lf_set_sharding_lanes(lf_ctx *, int rank, int world, lf_exchange_fn cb0, void *user0, lf_exchange_fn cb1, void *user1);
 /* exchange log of the context: number of exchanges, summed and maximal host-side latency in microseconds (reset != 0 clears it) */
 int lf_dist_stats(lf_ctx *, uint64_t *n_exchanges, double *total_us, double *max_us, int reset);
+/* u64 words this rank contributed to its exchanges so far (an all-gather delivers (world - 1) times as many to it); reset != 0 clears the counter */
+int lf_dist_stats_words(lf_ctx *, uint64_t *words_sent, int reset);
+/* TIMING MODEL, not a transport: the context behaves as rank `rank` of `world` with no peers -- every kernel and host stage does that rank's share, every
+ * exchange is enqueued in the lane's stream with zeros standing in for the peers' words, the schedule is the threaded two-lane one.  The "proofs" such a
+ * context returns are meaningless; it exists so that the per-rank compute time of a G-way sharded step can be measured on a box with one GPU
+ * (tools/shard_model.py).  Goldilocks contexts only; same ordering rule as lf_set_sharding. */
+int lf_set_sharding_model(lf_ctx *, int rank, int world);
 
 /* ---- a8/a9/a11: eq table and batched MLE evaluation (sumcheck/utils.rs:100-170, mle_helpers.rs:65-88) */
 /* point = nv challenges in F_{p^3} (3 words each): the reference's points are always diagonal embeddings

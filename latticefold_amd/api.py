@@ -295,6 +295,22 @@ class Context:
         _chk(_lib().lf_dist_stats(self.h, C.byref(n), C.byref(tot), C.byref(mx), int(reset)), "lf_dist_stats")
         return n.value, tot.value, mx.value
 
+    def set_sharding_model(self, rank, world):
+        """lf_set_sharding_model: a TIMING model of rank `rank` of `world` with no peers (zeros stand in for their words).  What such a context returns is not
+        a proof; tools/shard_model.py measures a rank's share of a sharded step with it on a one-GPU box."""
+        L = _lib()
+        L.lf_set_sharding_model.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _chk(L.lf_set_sharding_model(self.h, int(rank), int(world)), "lf_set_sharding_model")
+        self.shard = (rank, world)
+
+    def dist_stats_words(self, reset=False):
+        """u64 words this rank contributed to its exchanges (lf_dist_stats_words)"""
+        L = _lib()
+        L.lf_dist_stats_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        w = C.c_uint64()
+        _chk(L.lf_dist_stats_words(self.h, C.byref(w), int(reset)), "lf_dist_stats_words")
+        return w.value
+
     def mem_info(self):
         f, t = C.c_size_t(), C.c_size_t()
         _chk(_lib().lf_mem_info(self.h, C.byref(f), C.byref(t)), "lf_mem_info")

@@ -626,10 +626,33 @@ int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *use
     if (c->A_loaded) return LF_ERR_STATE;  // choose the sharding before loading/generating the Ajtai matrix
     for (int l = 0; l < 2; l++) {
         c->comm[l].destroy();
-        c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = cb; c->comm[l].user = user; c->comm[l].poisoned = false;
+        c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = cb; c->comm[l].user = user; c->comm[l].poisoned = false; c->comm[l].model = false;
     }
     c->sh_rank = rank; c->sh_world = world;
     c->two_lanes_ok = false;                 // one channel: one thread issues every exchange
+    return LF_OK;
+}
+// Timing model of ONE rank of a sharded run on a box with one GPU (tools/shard_model.py): rank `rank` of `world` with no peers.  Every kernel and every host
+// stage does exactly the share of the work that rank would do, every exchange is enqueued in the lane's stream (the peers' words are zeros), the two-lane
+// schedule is the one a passed lf_dist_init self-check selects.  What the step returns is NOT a proof (the peers' partial sums are missing).
+int lf_set_sharding_model(lf_ctx *c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return LF_ERR_INVALID;
+    if (c->bb) return LF_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->A_loaded) return LF_ERR_STATE;
+    for (int l = 0; l < 2; l++) {
+        c->comm[l].destroy();
+        c->comm[l].rank = rank; c->comm[l].world = world; c->comm[l].cb = nullptr; c->comm[l].user = nullptr; c->comm[l].poisoned = false; c->comm[l].model = world > 1;
+    }
+    c->sh_rank = rank; c->sh_world = world;
+    c->two_lanes_ok = world > 1;
+    return LF_OK;
+}
+int lf_dist_stats_words(lf_ctx *c, uint64_t *words_sent, int reset) {
+    if (!c || !words_sent) return LF_ERR_INVALID;
+    if (c->bb) { *words_sent = 0; return LF_OK; }
+    *words_sent = c->comm[0].words_sent + c->comm[1].words_sent;
+    if (reset) c->comm[0].words_sent = c->comm[1].words_sent = 0;
     return LF_OK;
 }
 // all-gather `words` canonical words from every rank and add them mod p (RCCL has no modular reduction): host buffer ...

@@ -72,7 +72,7 @@ int rccl_init(Comm &c, int rank, int world, const uint8_t *id128) {
     memcpy(id.internal, id128, 128);
     ncclComm_t comm = nullptr;
     if (r.CommInitRank(&comm, world, id, rank) != ncclSuccess) return LF_ERR_HIP;
-    c.rank = rank; c.world = world; c.cb = nullptr; c.user = nullptr; c.nccl = comm; c.poisoned = false;
+    c.rank = rank; c.world = world; c.cb = nullptr; c.user = nullptr; c.nccl = comm; c.poisoned = false; c.model = false;
     return LF_OK;
 }
 int Comm::ensure_stage(size_t words) {
@@ -94,6 +94,11 @@ int Comm::allgather_dev(const uint64_t *send_dev, uint64_t *recv_all_dev, size_t
     if (poisoned) return LF_ERR_STATE;
     if (world <= 1 && !nccl) return hipMemcpyAsync(recv_all_dev, send_dev, words * 8, hipMemcpyDeviceToDevice, s) == hipSuccess ? LF_OK : LF_ERR_HIP;
     Stopwatch sw(*this);
+    words_sent += words;
+    if (model) {   // timing model: zeros from the absent peers, this rank's words in its slot -- device-side and in-stream like the RCCL path
+        if (hipMemsetAsync(recv_all_dev, 0, (size_t)world * words * 8, s) != hipSuccess) return LF_ERR_HIP;
+        return hipMemcpyAsync(recv_all_dev + (size_t)rank * words, send_dev, words * 8, hipMemcpyDeviceToDevice, s) == hipSuccess ? LF_OK : LF_ERR_HIP;
+    }
     if (nccl) {   // in-stream: no host synchronisation at all
         return rccl().AllGather(send_dev, recv_all_dev, words, ncclUint64, (ncclComm_t)nccl, s) == ncclSuccess ? LF_OK : LF_ERR_HIP;
     }
@@ -111,6 +116,12 @@ int Comm::allgather_host(const uint64_t *send, uint64_t *recv_all, size_t words,
     if (poisoned) return LF_ERR_STATE;
     if (world <= 1) { memcpy(recv_all, send, words * 8); return LF_OK; }
     Stopwatch sw(*this);
+    words_sent += words;
+    if (model) {
+        memset(recv_all, 0, (size_t)world * words * 8);
+        memcpy(recv_all + (size_t)rank * words, send, words * 8);
+        return LF_OK;
+    }
     if (nccl) {
         const size_t tot = (size_t)world * words;
         int rc = ensure_stage(tot + words);

@@ -19,6 +19,8 @@ struct Comm {
     lf_exchange_fn cb = nullptr;     // host transport (lf_set_sharding)
     void *user = nullptr;
     void *nccl = nullptr;            // ncclComm_t (lf_dist_init)
+    bool model = false;              // lf_set_sharding_model: no peers -- an all-gather puts this rank's words into its slot and zeros into the others (a TIMING
+                                     // model of rank `rank` of `world` alone on a GPU: every kernel does a rank's share of the work, the results are not a proof)
     bool poisoned = false;           // set by abort_peers(): every later exchange returns LF_ERR_STATE (the step that failed is lost; shard a fresh context)
     uint64_t *d_stage = nullptr;     // device staging for host-buffer exchanges over RCCL / device-buffer exchanges over the callback
     size_t d_stage_words = 0;
@@ -26,6 +28,7 @@ struct Comm {
     size_t h_stage_words = 0;
     // per-exchange latency log (host wall clock around enqueue + completion)
     uint64_t n_exchanges = 0;
+    uint64_t words_sent = 0;         // u64 words this rank contributed, summed over its exchanges (an all-gather delivers (world - 1) x as many to it)
     double us_total = 0, us_max = 0;
 
     bool active() const { return world > 1; }

@@ -99,3 +99,51 @@ def test_sharded_fold_step_equals_unsharded(tmp_path, world, cases, two_lanes):
         assert all(x.split(":")[0] == r["ref"].split(":")[0] for x in r["ranks"]), (name, r)
         if two_lanes == "gemm":   # every rank and the unsharded reference ran rounds 1-3 as GEMMs (fold_paths mask behind the digest)
             assert r["ref"].endswith(":7") and all(x.endswith(":7") for x in r["ranks"]), r
+
+
+def test_model_transport_runs_a_ranks_share_and_counts_its_exchanges():
+    """lf_set_sharding_model (tools/shard_model.py): rank r of G with no peers.  The step must run to completion with the exchange count and the
+    words of a real G-way run's rank (zeros stand in for the peers, so the result is not a proof and is not compared); world 1 is the plain context."""
+    import numpy as np
+    from latticefold_amd import api
+    from latticefold_amd.workload import make_workload
+    wl = make_workload("T14")
+
+    def run(rank, world):
+        ctx = api.Context(0)
+        try:
+            ctx.set_sharding_model(rank, world)
+            ctx.load_ccs(wl)
+            scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+            wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+            cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+            tr = api.PoseidonTranscript()
+            acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr)
+            ctx.dist_stats(reset=True); ctx.dist_stats_words(reset=True)
+            lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr)
+            return ctx.dist_stats()[0], ctx.dist_stats_words(), proof
+        finally:
+            ctx.close()
+
+    n1, w1, p1 = run(0, 1)
+    assert n1 == 0 and w1 == 0
+    ctx = api.Context(0)
+    try:
+        ctx.load_ccs(wl)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+        wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+        tr = api.PoseidonTranscript()
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr)
+        _, _, p0 = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr)
+    finally:
+        ctx.close()
+    assert (p0 == p1).all()                       # world 1: no model, the ordinary step
+    counts = [run(r, 4) for r in (0, 3)]
+    assert counts[0][0] == counts[1][0] > 8 and counts[0][1] == counts[1][1] > 0   # every rank issues the same exchanges with the same sizes
+    ctx = api.Context(0)
+    try:
+        with pytest.raises(api.LfError):
+            ctx.set_sharding_model(4, 4)
+    finally:
+        ctx.close()

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Per-rank compute time of a G-way sharded fold step, measured on ONE GPU.
+
+    python tools/shard_model.py [--workload C4] [--steps 6] [--warmup 2] [--ranks 0] [--worlds 1,2,4,8] [--timeline]
+
+For each G the context is rank r of G with the model transport (lf_set_sharding_model): every kernel and host stage does that rank's share of the
+work, every exchange is enqueued in its lane's stream (zeros stand in for the peers' words), the schedule is the threaded two-lane one.  The GPU is
+the rank's alone -- unlike G processes sharing the device (tools/gpu_shard_model.sh), where the serialised kernels and the blocking gloo round trips
+of the test transport are what one measures.  The "proofs" are meaningless (the peers' partial sums are missing); only the time is read.
+
+    t(G) = t_rank(G)                            measured here (compute + launch + host transcript + in-stream enqueue of every exchange)
+         + n_small(G) * t_lat                   latency of a small all-gather over xGMI that the model transport does not pay (not measurable here)
+         + gathered_bytes(G) * (G-1)/G / bw     the hand-over all-gathers of table slices
+
+The second and third terms are printed for an assumed t_lat / bw (flags), labelled as assumptions."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C4")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--ranks", default="0", help="ranks to model per world: a list, or 'all'")
+    ap.add_argument("--t-lat-us", type=float, default=25.0, help="ASSUMED latency of one small RCCL all-gather over xGMI beyond its enqueue (us)")
+    ap.add_argument("--bw-gbs", type=float, default=100.0, help="ASSUMED per-rank all-gather bandwidth for the table hand-overs (GB/s)")
+    ap.add_argument("--timeline", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch  # noqa: F401  (maps the ROCm runtime the way bench.py does)
+    from latticefold_amd import api
+    from latticefold_amd.workload import make_workload
+
+    wl = make_workload(args.workload)
+    out = []
+    for G in [int(x) for x in args.worlds.split(",")]:
+        ranks = range(G) if args.ranks == "all" else [int(r) for r in args.ranks.split(",") if int(r) < G]
+        for r in ranks:
+            ctx = api.Context(0)
+            try:
+                if G > 1:
+                    ctx.set_sharding_model(r, G)
+                ctx.load_ccs(wl)
+                scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+                wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+                cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
+                tr = api.PoseidonTranscript()
+                acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr)
+                w_acc = wit
+                made = []
+
+                def step():
+                    nonlocal acc, w_acc
+                    lc, w0, _proof = api.NIFSProver.prove(ctx, acc, w_acc, cccs, wit, tr)
+                    made.append(w0)
+                    while len(made) > 2:
+                        made.pop(0).free()
+                    acc, w_acc = lc, w0
+
+                for _ in range(args.warmup):
+                    step()
+                ctx.dist_stats(reset=True)
+                ctx.dist_stats_words(reset=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3 / args.steps
+                n_ex, us_tot, us_max = ctx.dist_stats()
+                words = ctx.dist_stats_words()
+                rec = {"workload": wl.name, "world": G, "rank": r, "ms_per_step": ms, "exchanges_per_step": n_ex / args.steps,
+                       "enqueue_us_mean": us_tot / max(n_ex, 1), "enqueue_us_max": us_max, "sent_bytes_per_step": words * 8 / args.steps,
+                       "phases_ms": ctx.phase_ms()}
+                if G > 1:
+                    lat = rec["exchanges_per_step"] * args.t_lat_us / 1e3
+                    bw = rec["sent_bytes_per_step"] * (G - 1) / (args.bw_gbs * 1e9) * 1e3
+                    rec["model"] = {"t_lat_us_ASSUMED": args.t_lat_us, "bw_gbs_ASSUMED": args.bw_gbs, "latency_ms": lat, "transfer_ms": bw,
+                                    "t_ms": ms + lat + bw}
+                if args.timeline:
+                    rec["timeline"] = ctx.timeline()
+                out.append(rec)
+                print(json.dumps(rec), flush=True)
+            finally:
+                ctx.close()
+    base = next((o["ms_per_step"] for o in out if o["world"] == 1), None)
+    for o in out:
+        t = o.get("model", {}).get("t_ms", o["ms_per_step"])
+        sp = f"  speed-up vs G=1 {base / t:.2f}x" if base else ""
+        print(f"# G={o['world']} rank {o['rank']}: measured {o['ms_per_step']:.2f} ms/step, {o['exchanges_per_step']:.0f} exchanges, "
+              f"{o['sent_bytes_per_step'] / 1e6:.1f} MB sent -> model {t:.2f} ms{sp}")
+
+
+if __name__ == "__main__":
+    main()
