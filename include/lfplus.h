@@ -88,6 +88,13 @@ int lfplus_set_witness(lfplus_ctx *ctx, const uint64_t *f, uint64_t n);
 /* RgInstance::from_f on the resident (A, f).  b >= 2 (digits must land in (-8, 8): b <= 14), 1 <= k <= 16, 1 <= l <= 64.
  * Results stay on the device until lfplus_rg_read. */
 int lfplus_rg_from_f(lfplus_ctx *ctx, uint64_t b, uint32_t k, uint32_t l);
+/* The same pass enqueued on the context's second stream; returns at once.  from_f needs the witness, the matrix and the parameters only -- no challenge --
+ * so a prover issues it as soon as the witness is resident and lets it run next to the linearization's latency-bound sumcheck rounds (Mlin::mlin calls
+ * from_f after every linearization, mlin.rs:52-60; the order is not observable).  lfplus_rg_from_f / lfplus_mlin with the same parameters collect the result
+ * and report the pass's errors; every other call that touches the witness or the from_f buffers waits for the pass first (lfplus_join_async does only that).
+ * A sharded context ignores the hint.  LFPLUS_NO_ASYNC_FROM_F=1 in the environment turns the hint off. */
+int lfplus_rg_from_f_async(lfplus_ctx *ctx, uint64_t b, uint32_t k, uint32_t l);
+int lfplus_join_async(lfplus_ctx *ctx);
 /* Any pointer may be NULL.  Df: k*n*16 int8 (D_f[k_i][n_i][d_i]); comMf: k*kappa*16*16 words (comM_f[k_i][row][column] ring elements);
  * tau: n words; mtau: n int8 (exponent digits of m_tau); cm_f / C_Mf / cm_mtau: kappa*16 words each. */
 int lfplus_rg_read(lfplus_ctx *ctx, int8_t *Df, uint64_t *comMf, uint64_t *tau, int8_t *mtau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau);
@@ -131,7 +138,8 @@ int lfplus_transcript_challenge(lfplus_transcript *t, uint64_t *out);
 int lfplus_transcript_squeeze_bytes(lfplus_transcript *t, size_t n, uint8_t *out);
 int lfplus_short_challenge(lfplus_transcript *t, uint64_t *out16);
 int lfplus_poseidon_params(uint64_t *ark720, uint64_t *mds576);   /* the regenerated Frog table (checksummed against the reference's) */
-int lfplus_poseidon_permute(uint64_t *state24, int plain);        /* one permutation; plain != 0: the textbook form (self-test of the optimised one) */
+int lfplus_poseidon_permute(uint64_t *state24, int plain);        /* one permutation; plain = 1: the textbook form, 2: the scalar sparse form, 0: what the transcript runs (self-tests) */
+int lfplus_poseidon_simd(void);                                   /* 1 when the transcript's permutation runs on the host's AVX-512 IFMA lanes (lfp_poseidon_simd.cc) */
 
 /* In::set_check (src/setchk.rs:65-262): nmat matrix sets of n x ncols unit monomials and nvec vector sets of n, n = 2^nvars, as exponent
  * digits (int8 in (-8, 8); LFPLUS_ABSENT = zero entry); nM matrices (n x n, CSR, ring coefficients) for the M_i f rows of Step 3.

@@ -23,6 +23,16 @@ extern "C" int lfplus_ctx_create(int device, lfplus_ctx **out) {
         delete c;
         return LFPLUS_E_HIP;
     }
+    {   // the second stream (lfplus_rg_from_f_async) exists from the start -- creating a stream costs ~2 ms, which would land inside the first prove -- and has
+        // the lowest priority: its pass fills the gaps of the latency-bound sumcheck rounds on `st`, it must not delay their kernels
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&c->ev_ff, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->st2) (void)hipStreamDestroy(c->st2);
+            c->st2 = nullptr; c->ev_ff = nullptr;      // (no second stream: the hint is ignored)
+        }
+    }
     *out = c;
     return LFPLUS_OK;
 }
@@ -30,6 +40,8 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
+    if (c->st2) { (void)hipStreamSynchronize(c->st2); (void)hipStreamDestroy(c->st2); }
+    if (c->ev_ff) (void)hipEventDestroy(c->ev_ff);
     c->A = nullptr;
     c->A_ref.reset();      // frees the matrix unless another context still shares it
     c->drop_mats();
@@ -100,11 +112,13 @@ static int shape_buffers(lfplus_ctx *c, u32 kappa, u64 n) {
     HIPCHK(c, c->own_alloc(&c->coms, (size_t)3 * kappa * 16 * 8));
     return LFPLUS_OK;
 }
+static void ff_join(lfplus_ctx *c);
 extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kappa, uint64_t n) {
     if (!c || !A || !kappa || kappa > 64 || !n || n * (uint64_t)(c ? c->world : 1) > (1ull << 32)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: bad shape");
     if (c->sharded() && (n & (n - 1) || n < 4 * (u64)c->world)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: a sharded context takes the rank's n / world columns, a power of two >= 4 world");
     if (!canonical(A, (size_t)kappa * n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
+    ff_join(c);
     c->have = false;
     u64 *fresh = nullptr;   // a new allocation: contexts sharing the previous matrix keep it alive through their own reference
     int rc = upload(c, &fresh, A, (size_t)kappa * n * 16);
@@ -132,6 +146,7 @@ extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) 
     if (!c || !f || !n) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: bad arguments");
     if (!canonical(f, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
+    ff_join(c);     // (an asynchronous from_f may still read the witness that is being replaced)
     c->have = false;
     if (c->f && c->nf == n) {   // same length as the resident witness: overwrite it (no hipFree / hipMalloc round trip per instance)
         HIPCHK(c, hipMemcpyAsync(c->f, f, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st));
@@ -285,10 +300,52 @@ static int finish(lfplus_ctx *c) {
     if (flag) return fail(c, LFPLUS_E_EXP_DOMAIN, flag & 1 ? "lfplus_rg_from_f: a digit of f is outside (-d/2, d/2)" : "lfplus_rg_from_f: tau outside (-d/2, d/2)");
     return LFPLUS_OK;
 }
+// An asynchronous from_f in flight (lfplus_rg_from_f_async): wait for it and publish its result -- or, if it failed, leave the context without one (the
+// caller that needs a result runs the synchronous pass and gets the error there).
+static void ff_join(lfplus_ctx *c) {
+    if (!c || !c->ff_pending) return;
+    c->ff_pending = false;
+    if (hipStreamSynchronize(c->st2) != hipSuccess) { (void)hipGetLastError(); return; }
+    const std::string keep = c->err;
+    if (finish(c) == LFPLUS_OK) { c->k = c->ff_k; c->l = c->ff_l; c->have = true; }
+    else c->err = keep;
+}
+extern "C" int lfplus_join_async(lfplus_ctx *c) { if (!c) return LFPLUS_E_ARG; ff_join(c); return LFPLUS_OK; }
+// RgInstance::from_f of the resident witness, enqueued on the context's SECOND stream; returns at once.  The pass needs the witness, the matrix and the
+// parameters only -- no challenge -- so a prover issues it as soon as the witness is resident and lets it run next to the linearization's latency-bound
+// sumcheck rounds (rgchk.rs:260-331 is called from Mlin::mlin, mlin.rs:52-60, after every linearization: the order of the results is not observable).
+// lfplus_rg_from_f with the same parameters collects the result (errors of the pass are reported there); any other call that touches the witness or the
+// from_f buffers waits for it first.  A sharded context ignores the hint (its pass exchanges through the host: the synchronous call does the work).
+extern "C" int lfplus_rg_from_f_async(lfplus_ctx *c, uint64_t b, uint32_t k, uint32_t l) {
+    int rc = check_params(c, b, k, l);
+    if (rc) return rc;
+    if (c->sharded() || !c->st2 || !c->ev_ff || getenv("LFPLUS_NO_ASYNC_FROM_F")) return LFPLUS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    ff_join(c);
+    c->have = false;
+    Plan p = plan_for(c->nloc, c->kappa, k);
+    if ((rc = prepare(c, k, p))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_ff, c->st));            // behind whatever made the witness resident
+    HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_ff, 0));
+    std::swap(c->st, c->st2);
+    rc = enqueue_from_f(c, b, k, l, p);
+    std::swap(c->st, c->st2);
+    if (rc) { (void)hipStreamSynchronize(c->st2); return rc; }
+    c->ff_pending = true; c->ff_b = b; c->ff_k = k; c->ff_l = l;
+    return LFPLUS_OK;
+}
 extern "C" int lfplus_rg_from_f(lfplus_ctx *c, uint64_t b, uint32_t k, uint32_t l) {
     int rc = check_params(c, b, k, l);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->ff_pending && c->ff_b == b && c->ff_k == k && c->ff_l == l) {      // issued ahead (lfplus_rg_from_f_async): collect it
+        c->ff_pending = false;
+        HIPCHK(c, hipStreamSynchronize(c->st2));
+        if ((rc = finish(c))) return rc;
+        c->k = k; c->l = l; c->have = true;
+        return LFPLUS_OK;
+    }
+    ff_join(c);
     c->have = false;
     Plan p = plan_for(c->nloc, c->kappa, k);
     if ((rc = prepare(c, k, p))) return rc;
@@ -321,6 +378,7 @@ extern "C" int lfplus_rg_from_f_timed(lfplus_ctx *c, uint64_t b, uint32_t k, uin
 }
 extern "C" int lfplus_rg_read(lfplus_ctx *c, int8_t *Df, uint64_t *comMf, uint64_t *tau, int8_t *mtau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau) {
     if (!c) return LFPLUS_E_ARG;
+    ff_join(c);
     if (!c->have) return fail(c, LFPLUS_E_ARG, "lfplus_rg_read: no result (run lfplus_rg_from_f first)");
     if (Df && c->sharded()) return fail(c, LFPLUS_E_ARG, "lfplus_rg_read: D_f of a sharded context exists per rank only (pass NULL)");
     HIPCHK(c, hipSetDevice(c->device));
@@ -340,6 +398,7 @@ extern "C" int lfplus_commit(lfplus_ctx *c, const uint64_t *v, uint64_t n, uint6
     if (!c->A || n != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_commit: matrix not set / length mismatch");
     if (!canonical(v, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_commit: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
+    ff_join(c);
     Plan p = plan_for(c->nloc, c->kappa, 0);
     int rc = ensure_part(c, (size_t)p.nblk * p.nout_f + p.nout_f);
     if (rc) return rc;
@@ -366,6 +425,7 @@ static int decompose_impl(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const 
     for (lfplus_ctx *d : {dst0, dst1})
         if (d && (d->device != c->device || d->n != c->n)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose_resident: the receiving context is on another device or has another width");
     if (dst0 && dst0 == dst1) return fail(c, LFPLUS_E_ARG, "lfplus_decompose_resident: F0 and F1 need two contexts");
+    for (lfplus_ctx *d : {c, dst0, dst1}) ff_join(d);
     const bool resident = nm && !rowptr;   // the matrices lfplus_set_matrices left in the context
     if (resident && (c->mats.size() != nm || c->mats_n != c->n)) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: no resident matrices of this shape");
     if (!c->A || !c->f || c->nf != c->n) return fail(c, LFPLUS_E_ARG, "lfplus_decompose: matrix / witness not set or of different length");

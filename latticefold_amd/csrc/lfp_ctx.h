@@ -180,6 +180,13 @@ struct lfplus_ctx {
     size_t part_cap = 0;
     u32 *err_d = nullptr;
     bool have = false;
+    // lfplus_rg_from_f_async: the double commitment of the resident witness in flight on a second stream (it needs no challenge: PlusProver issues it while the
+    // linearization's latency-bound rounds run on `st`); lfplus_rg_from_f with the same parameters collects it, anything else that touches the buffers joins it first
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_ff = nullptr;
+    bool ff_pending = false;
+    u64 ff_b = 0;
+    u32 ff_k = 0, ff_l = 0;
     // the folded witness of the last lfplus_cm_prove (cm.rs:164-181): n ring elements
     u64 *g = nullptr;
     u64 g_n = 0;

@@ -12,6 +12,7 @@
 #include <memory>
 #include "lf_host.h"
 #include "lfp_ctx.h"
+#include "lfp_poseidon_simd.h"
 static constexpr uint32_t LFP_HOST_SUM_BLOCKS = 256;   // block partials the host adds per round; rounds with more workgroups add theirs on the device (launch_reduce)
 
 // LFPLUS_TIMELINE=1: wall-clock marks of the protocol stages on stderr (the stream is drained at every mark, so the stages do not overlap)
@@ -164,7 +165,20 @@ struct FastPerm {
         for (int i = 0; i < (RF + RP) * W; i++) ark[i] = to_mont(pp.ark[i]);
         for (int i = 0; i < W * W; i++) mds[i] = to_mont(pp.mds[i]);
         ok = true;
+        // AVX-512 IFMA lanes (lfp_poseidon_simd.cc) when the CPU has them; LFPLUS_POSEIDON_SCALAR=1 keeps this scalar form
+        if (lfp_psimd::supported() && !getenv("LFPLUS_POSEIDON_SCALAR")) {
+            std::vector<u64> cstP((size_t)RP * W), e00P(RP), rowP((size_t)RP * n), colP((size_t)RP * n), postP((size_t)n * n);
+            for (int r = 0; r < RP; r++) {
+                e00P[r] = from_mont(e00[r]);
+                for (int i = 0; i < W; i++) cstP[(size_t)r * W + i] = from_mont(cst[r][i]);
+                for (int i = 0; i < n; i++) { rowP[(size_t)r * n + i] = from_mont(row[r][i]); colP[(size_t)r * n + i] = from_mont(col[r][i]); }
+            }
+            for (int i = 0; i < n * n; i++) postP[i] = from_mont(post[i]);
+            lfp_psimd::build(P, pp.ark, pp.mds, cstP.data(), e00P.data(), rowP.data(), colP.data(), postP.data());
+            simd = true;
+        }
     }
+    bool simd = false;
     inline u64 sbox(u64 x) const { const u64 x2 = mm(x, x), x4 = mm(x2, x2); return mm(mm(x4, x2), x); }
     inline void full_round(u64 *st, const u64 *a) const {
         u64 nw[W];
@@ -197,7 +211,8 @@ struct FastPerm {
 const FastPerm &fastperm() { static const FastPerm f; return f; }
 void permute(u64 *st) {
     const FastPerm &f = fastperm();
-    if (f.ok) f.run(st);
+    if (f.simd) lfp_psimd::permute(st);
+    else if (f.ok) f.run(st);
     else permute_plain(st);
 }
 }  // namespace
@@ -279,13 +294,18 @@ int lfplus_short_challenge(lfplus_transcript *t, uint64_t *out16) {
     for (int i = 0; i < D; i++) { const int v = (int)bs[i] - 128; out16[i] = v >= 0 ? (u64)v : P - (u64)(-v); }
     return LFPLUS_OK;
 }
-// one permutation of a 24-word state (canonical words): plain != 0 runs the textbook definition, else the form the transcript uses
+// one permutation of a 24-word state (canonical words): plain = 1 runs the textbook definition, 2 the scalar sparse form (FastPerm), 0 the form the transcript uses
+// (the AVX-512 IFMA lanes of lfp_poseidon_simd.cc when the CPU has them, else FastPerm)
 int lfplus_poseidon_permute(uint64_t *state24, int plain) {
     if (!state24) return LFPLUS_E_ARG;
     for (int i = 0; i < W; i++) state24[i] %= P;
-    if (plain) permute_plain(state24); else permute(state24);
+    if (plain == 1) permute_plain(state24);
+    else if (plain == 2 && fastperm().ok) fastperm().run(state24);
+    else permute(state24);
     return LFPLUS_OK;
 }
+// 1 when the transcript's permutation runs on the AVX-512 IFMA lanes
+int lfplus_poseidon_simd(void) { return fastperm().simd ? 1 : 0; }
 int lfplus_poseidon_params(uint64_t *ark720, uint64_t *mds576) {
     if (!ark720 || !mds576) return LFPLUS_E_ARG;
     memcpy(ark720, params().ark, sizeof(params().ark));

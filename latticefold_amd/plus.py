@@ -54,6 +54,8 @@ def _lib():
         L.lfplus_set_matrix.argtypes = [vp, u64p, C.c_uint32, C.c_uint64]
         L.lfplus_set_witness.argtypes = [vp, u64p, C.c_uint64]
         L.lfplus_rg_from_f.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.lfplus_rg_from_f_async.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.lfplus_join_async.argtypes = [vp]
         L.lfplus_rg_read.argtypes = [vp, i8p, u64p, u64p, i8p, u64p, u64p, u64p]
         L.lfplus_rg_from_f_timed.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         L.lfplus_commit.argtypes = [vp, u64p, C.c_uint64, u64p]
@@ -248,6 +250,13 @@ class PlusContext:
                                           *[out[k].ctypes.data_as(u64p) for k in ("F0", "F1", "C0", "C1", "v0", "v1")]))
         return out
 
+    def rg_from_f_async(self, dparams):
+        """lfplus_rg_from_f_async: RgInstance::from_f of the resident witness on the context's second stream (collected by rg_from_f / mlin with the same parameters)"""
+        self._chk(_lib().lfplus_rg_from_f_async(self.h, dparams.b, dparams.k, dparams.l))
+
+    def join_async(self):
+        self._chk(_lib().lfplus_join_async(self.h))
+
     def time_rg_from_f(self, dparams, iters):
         ms = C.c_double()
         self._chk(_lib().lfplus_rg_from_f_timed(self.h, dparams.b, dparams.k, dparams.l, iters, C.byref(ms)))
@@ -370,8 +379,16 @@ class PoseidonTranscript:
             pass
 
 
+def poseidon_simd():
+    """True when the transcript's permutation runs on the host's AVX-512 IFMA lanes (lfp_poseidon_simd.cc)"""
+    L = _lib()
+    L.lfplus_poseidon_simd.restype = C.c_int
+    return bool(L.lfplus_poseidon_simd())
+
+
 def poseidon_permute(state, plain=False):
-    """one Poseidon permutation of 24 canonical words; plain: the textbook definition instead of the optimised form the transcript runs"""
+    """one Poseidon permutation of 24 canonical words; plain = True / 1: the textbook definition, 2: the scalar sparse form, False / 0: the form the
+    transcript runs (AVX-512 IFMA lanes when the CPU has them)"""
     st = np.ascontiguousarray(state, dtype=np.uint64).copy()
     assert st.shape == (24,)
     rc = _lib().lfplus_poseidon_permute(st.ctypes.data_as(u64p), int(plain))
@@ -627,11 +644,15 @@ class ComR1CS:
     def matrices(self):
         return list(self.r1cs)
 
-    def linearize(self, ctx, transcript, resident=False, preloaded=False):
+    def linearize(self, ctx, transcript, resident=False, preloaded=False, from_f_hint=None):
         """Linearize::linearize (r1cs.rs:76-139) on `ctx` (the witness becomes resident there) -> (LinB fields, ComR1CSProof fields); resident: the three
-        matrices are the ones ctx.set_matrices / share_matrices left on the device; preloaded: ctx.set_witness(self.f) was already called (PlusProver.preload)"""
+        matrices are the ones ctx.set_matrices / share_matrices left on the device; preloaded: ctx.set_witness(self.f) was already called (PlusProver.preload);
+        from_f_hint: DecompParameters of the Mlin::mlin that follows -- the double commitment of this witness is enqueued on the context's second stream now
+        (lfplus_rg_from_f_async) and runs next to the sumcheck rounds"""
         if not preloaded:
             ctx.set_witness(self.f)
+        if from_f_hint is not None:
+            ctx.rg_from_f_async(from_f_hint)
         n = self.f.shape[0]
         nvars = n.bit_length() - 1
         keep, rp, cp, vp = _csr_args(RESIDENT(3) if resident else self.r1cs)
@@ -771,13 +792,17 @@ class PlusProver:
         lproof = []
         pre = self._preloaded is not None and len(self._preloaded) == len(comp) and all(a is ci.f for a, ci in zip(self._preloaded, comp))
         self._preloaded = None
-        for i, ci in enumerate(comp):
-            same = len(self.M) == 3 and all(a is b for x, y in zip(ci.r1cs, self.M) for a, b in zip(x, y))   # (M = cr1cs.x.matrices() in every reference use)
-            _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same, preloaded=pre)
-            lproof.append(lp)
+        # RgInstance::from_f of every instance (Mlin::mlin, mlin.rs:52-60) needs no challenge: each is enqueued on its context's second stream as soon as the
+        # witness is resident and runs next to the linearizations' latency-bound rounds; lfplus_mlin collects the results
+        dp = self.params.lin.decomp
         for i, f in enumerate(self.acc):
             if not isinstance(f, str):     # (device_acc: F0 / F1 of the last prove are the resident witnesses of ctxs[0] / ctxs[1] already)
                 ctxs[i].set_witness(f)
+            ctxs[i].rg_from_f_async(dp)
+        for i, ci in enumerate(comp):
+            same = len(self.M) == 3 and all(a is b for x, y in zip(ci.r1cs, self.M) for a, b in zip(x, y))   # (M = cr1cs.x.matrices() in every reference use)
+            _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same, preloaded=pre, from_f_hint=dp)
+            lproof.append(lp)
         linb2x, cmproof = mlin(ctxs, self.transcript, self.params.lin, self.res)
         if self.device_acc:
             dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res, into=(self.ctxs[0], self.ctxs[1]))

@@ -94,7 +94,7 @@ def _launch(tmp_path, world, cases, env_extra, timeout):
 
 
 def _fields(d):
-    return {k: v for k, v in d.items() if k not in ("oracle_seconds", "workload", "first_words", "exchanges")}
+    return {k: v for k, v in d.items() if k not in ("oracle_seconds", "oracle_host", "workload", "first_words", "exchanges")}
 
 
 @pytest.mark.parametrize("world,cases,rounds", [(2, "S14.2.2.1,S15.3.4.1", 3), (4, "S14.2.2.1", 2), (8, "S15.2.2.1", 1)])

@@ -40,7 +40,7 @@ def gold(name):
     g = json.load(open(GOLD))
     if name not in g:
         pytest.skip(f"no golden digest for {name}")
-    return {k: v for k, v in g[name].items() if k not in ("oracle_seconds", "workload", "first_words")}
+    return {k: v for k, v in g[name].items() if k not in ("oracle_seconds", "oracle_host", "workload", "first_words")}
 
 
 def prove(wl, device=0):

@@ -37,6 +37,51 @@ def test_optimised_permutation_equals_the_definition_and_the_oracle():
         want = st.copy()
         L_.lfp_poseidon_permute(lfp._p(want))
         assert (plus.poseidon_permute(st) == want).all() and (plus.poseidon_permute(st, plain=True) == want).all()
+        assert (plus.poseidon_permute(st, plain=2) == want).all()
+
+
+def test_ifma_lanes_of_the_frog_permutation_equal_the_scalar_forms():
+    """lfp_poseidon_simd.cc (AVX-512 IFMA, Montgomery words with R = 2^104): the form the transcript runs on hosts that have the instructions.  Sparse states,
+    words next to p, long chains (a wrong carry shows up after a few permutations) -- against the textbook definition and the scalar sparse form; and a whole
+    transcript script gives the same challenges with LFPLUS_POSEIDON_SCALAR=1 in a fresh process."""
+    rng = np.random.default_rng(5)
+    states = []
+    for k in range(300):
+        st = rng.integers(0, P, size=24, dtype=np.uint64)
+        if k % 5 == 0:
+            st[rng.integers(0, 24, size=12)] = 0
+        if k % 7 == 0:
+            st[rng.integers(0, 24, size=8)] = np.uint64(P - 1 - (k % 3))
+        if k % 11 == 0:
+            st[:] = np.uint64(k & 1)
+        states.append(st)
+    for st in states:
+        a = plus.poseidon_permute(st)
+        assert (a == plus.poseidon_permute(st, plain=2)).all()
+    for st in states[:40]:
+        assert (plus.poseidon_permute(st) == plus.poseidon_permute(st, plain=True)).all()
+    st = states[1].copy()
+    ref = st.copy()
+    for _ in range(2000):
+        st = plus.poseidon_permute(st)
+        ref = plus.poseidon_permute(ref, plain=2)
+    assert (st == ref).all()
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from latticefold_amd import plus\n"
+            "t = plus.PoseidonTranscript(); rng = np.random.default_rng(3)\n"
+            "out = []\n"
+            "for i in range(40):\n"
+            "    t.absorb(rng.integers(0, plus.P, size=(1 + i %% 5, 16), dtype=np.uint64)); out.append(int(t.get_challenge()))\n"
+            "print(int(plus.poseidon_simd()), out)\n") % os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    runs = []
+    for env in ({}, {"LFPLUS_POSEIDON_SCALAR": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, **env}, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(r.stdout.strip().split(" ", 1))
+    assert runs[1][0] == "0" and runs[0][1] == runs[1][1]
+    if not plus.poseidon_simd():
+        pytest.skip("this host has no AVX-512 IFMA: the scalar form is what runs (compared with itself)")
 
 
 def test_transcript_equals_oracle_on_random_scripts():
