@@ -60,6 +60,10 @@ void launch_eq_build(const EqPt &pt, u32 nv, u64 *eq, hipStream_t s);
 u32 sc_round_max_blocks();
 u32 launch_sc_round(const u64 *tab, size_t ld, size_t half, const ScDesc &d, const u64 *coef, u64 *part /* sc_round_max_blocks * 4; returns the blocks used */, hipStream_t s);
 void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u64 rM, hipStream_t s);
+// the same round / fix + round from the exponent digits of ONE set (ncols 16 or 1; returns the blocks used, 0 = shape not handled): no beta^e tables exist
+u32 launch_sc_round0_dig(const int8_t *dig, size_t n, u32 ncols, const PwTab &pw, const u64 *eq, const u64 *coef, u64 *part, hipStream_t s);
+u32 launch_sc_fix_round_dig(const int8_t *dig, size_t n, u32 ncols, const PwTab &pw, const u64 *eq, u64 rM, u64 *tab /* the set's 2 ncols + 1 tables */, size_t ld,
+                            const u64 *coef, u64 *part, hipStream_t s);
 u32 eval_chunks(size_t n);
 void launch_sum_parts(const u64 *part, u32 chunks, size_t stride, u32 nout, u64 *out, hipStream_t s);      // out[o] = sum_chunk part[chunk * stride + o]
 // out[col][16] = sum_row w[row] X^e(dig[row][col]); wstride 1: scalar Montgomery weights (out canonical), 16: canonical ring weights.  part: eval_chunks(n) * ncols * 16

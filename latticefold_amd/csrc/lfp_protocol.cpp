@@ -481,6 +481,10 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     u64 *hpart = c->pin(std::max((size_t)lfp::sc_round_max_blocks() * 4, (size_t)(nmat + nvec) * 4));   // the kernels write their block partials into mapped host memory
     if (!hpart) return fail(c, LFPLUS_E_HIP, "hipHostMalloc (round partials)");
     if (early && coefA.alloc(coefAh.size() * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (set check coefficients)");
+    // Rounds 0 and 1 straight from the exponent digits (lfp_rgchk.hip: k_sc_round0_dig, k_sc_fix_round_dig): the beta^e / beta^2e tables of n entries are
+    // never written -- the first tables that exist are the n / 2-entry ones of the fused "fix at r_0 + round 1" pass.  LFPLUS_SC_TABLES=1: the table form.
+    const bool from_dig = early && !c->sharded() && nl >= 8 && (ncols == 16 || ncols == 1) && !getenv("LFPLUS_SC_TABLES");
+    std::vector<lfp::PwTab> pws(from_dig ? nmat + nvec : 0);
     for (u32 i = 0; i < nmat + nvec; i++) {
         const SetRef &sr = i < nmat ? mats[i] : vecs[i - nmat];
         const u32 cols = i < nmat ? ncols : 1, t0 = i < nmat ? i * (2 * ncols + 1) : nmat * (2 * ncols + 1) + 3 * (i - nmat);
@@ -489,7 +493,8 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         lfp::PwTab pw;
         u64 bp = 1;
         for (int t = 0; t < 16; t++) { pw.p[t] = to_mont(bp); pw.q[t] = to_mont(fmul(bp, bp)); bp = fmul(bp, beta); }
-        lfp::launch_sc_tables(sr.dig, nl, cols, pw, tabs[0].as<u64>() + (size_t)t0 * nl, nl, c->st);
+        if (from_dig) pws[i] = pw;
+        else lfp::launch_sc_tables(sr.dig, nl, cols, pw, tabs[0].as<u64>() + (size_t)t0 * nl, nl, c->st);
         eq_build_local(c, cch.data(), nvars, tabs[0].as<u64>() + (size_t)(t0 + 2 * cols) * nl);
         alpha[i] = tr->challenge();
         if (early) {
@@ -497,7 +502,10 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
             for (u32 j = 0; j < cols; j++) { coefAh[(size_t)i * ncols + j] = to_mont(ap); ap = fmul(ap, alpha[i]); }
             HIPCHK(c, hipMemcpyAsync(coefA.as<u64>() + (size_t)i * ncols, &coefAh[(size_t)i * ncols], cols * 8, hipMemcpyHostToDevice, c->st));
             const lfp::ScDesc di = i < nmat ? lfp::ScDesc{1, ncols, 0, 1} : lfp::ScDesc{0, ncols, 1, 1};      // the one set, its tables at the origin
-            const u32 nbi = lfp::launch_sc_round(tabs[0].as<u64>() + (size_t)t0 * nl, nl, nl / 2, di, coefA.as<u64>() + (size_t)i * ncols, so.part.as<u64>(), c->st);
+            const u32 nbi = from_dig ? lfp::launch_sc_round0_dig(sr.dig, nl, cols, pw, tabs[0].as<u64>() + (size_t)(t0 + 2 * cols) * nl, coefA.as<u64>() + (size_t)i * ncols,
+                                                                  so.part.as<u64>(), c->st)
+                                     : lfp::launch_sc_round(tabs[0].as<u64>() + (size_t)t0 * nl, nl, nl / 2, di, coefA.as<u64>() + (size_t)i * ncols, so.part.as<u64>(), c->st);
+            if (!nbi) return fail(c, LFPLUS_E_ARG, "set_check: set width not handled by the digit rounds");
             lfp::launch_sum_parts(so.part.as<u64>(), nbi, 4, 4, c->hpin_dev + (size_t)i * 4, c->st);
         }
     }
@@ -532,7 +540,8 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         const size_t half = len / 2;
         auto tA = std::chrono::steady_clock::now();
         const bool pre = early && rnd == 0;           // the sets' shares S_i are in hpart[i][4] already (Montgomery): the message is sum_i rc^i S_i
-        const u32 nb = pre ? 0 : lfp::launch_sc_round(tcur, ld, half, d, coefd.as<u64>(), c->hpin_dev, c->st);
+        const bool pre1 = from_dig && rnd == 1;       // ... and round 1's shares (rc^i inside their coefficients) came with the fused fix: the message is their sum
+        const u32 nb = pre || pre1 ? 0 : lfp::launch_sc_round(tcur, ld, half, d, coefd.as<u64>(), c->hpin_dev, c->st);
         HIPCHK(c, hipStreamSynchronize(c->st));
         auto tB = std::chrono::steady_clock::now();
         u64 *m = msgs + (size_t)rnd * 4 * D;
@@ -543,6 +552,8 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
             if (pre) {
                 u64 rp = 1;
                 for (u32 i = 0; i < nmat + nvec; i++) { s = fadd(s, fmul(rp, hpart[(size_t)i * 4 + x])); rp = fmul(rp, rc); }
+            } else if (pre1) {
+                for (u32 i = 0; i < nmat + nvec; i++) s = fadd(s, hpart[(size_t)i * 4 + x]);
             } else
                 for (u32 b = 0; b < nb; b++) s = fadd(s, hpart[(size_t)b * 4 + x]);
             sums[x] = s;
@@ -554,6 +565,17 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
         tr->absorb_const(r);
         r_out[rnd] = r;
         auto tC = std::chrono::steady_clock::now();
+        if (from_dig && rnd == 0) {   // fix at r_0 from the digits, fused with round 1 (set by set: each has its own digits and power table)
+            for (u32 i = 0; i < nmat + nvec; i++) {
+                const SetRef &sr = i < nmat ? mats[i] : vecs[i - nmat];
+                const u32 cols = i < nmat ? ncols : 1, t0 = i < nmat ? i * (2 * ncols + 1) : nmat * (2 * ncols + 1) + 3 * (i - nmat);
+                const u32 nbi = lfp::launch_sc_fix_round_dig(sr.dig, nl, cols, pws[i], tabs[0].as<u64>() + (size_t)(t0 + 2 * cols) * nl, to_mont(r),
+                                                             tabs[1].as<u64>() + (size_t)t0 * nl, nl, coefd.as<u64>() + (size_t)i * ncols, so.part.as<u64>(), c->st);
+                lfp::launch_sum_parts(so.part.as<u64>(), nbi, 4, 4, c->hpin_dev + (size_t)i * 4, c->st);
+            }
+            cur = 1;
+            tcur = tabs[1].as<u64>();
+        } else
         if (rnd + 1 < nvars) {   // fix_variables of every table into the other buffer (rows keep their stride)
             if (tcur == tgath.as<u64>() && c->sharded()) {      // the gathered tables have stride world: fix them into tabs[0] with the same stride
                 lfp::launch_sc_fix(tcur, tabs[0].as<u64>(), ld, ntab, half, to_mont(r), c->st);

@@ -131,6 +131,136 @@ void launch_sc_fix(const u64 *in, u64 *out, size_t ld, u32 ntab, size_t half, u6
     hipLaunchKernelGGL(k_sc_fix, dim3((unsigned)cdiv(half, 256), ntab), dim3(256), 0, s, in, out, ld, half, rM);
 }
 
+// ---- the first two rounds straight from the exponent digits ------------------------------------------------------------------------------
+// A set's 2 ncols scalar tables beta^e, beta^2e are look-ups of one byte per entry: materialising them (k_sc_tables: 33 tables of n words per matrix set,
+// 3.3 GB at n = 2^20 with 12 sets) and streaming them through round 0, the first fix and round 1 was 10 GB of traffic for 0.2 GB of digits.  Round 0 and the
+// fused "fix at r_0 + round 1" read the digits instead (17-entry power table in LDS, entry 16 = the absent monomial); the first tables that exist are the
+// n/2-entry ones the fused pass writes.  Same field elements: every sum is exact mod p.
+struct DigPow {
+    u64 p[17], q[17];
+};
+__device__ __forceinline__ void digpow_load(const PwTab &pw, DigPow *sm) {
+    if (threadIdx.x < 16) { sm->p[threadIdx.x] = pw.p[threadIdx.x]; sm->q[threadIdx.x] = pw.q[threadIdx.x]; }
+    if (threadIdx.x == 16) { sm->p[16] = 0; sm->q[16] = 0; }
+    __syncthreads();
+}
+__device__ __forceinline__ u32 dig_index(int8_t d) { return d == LFP_ABSENT ? 16u : (u32)exp_of(d); }
+// the bytes of row `row`, columns j0 .. j0 + 15 (fewer at the end of a narrow set), as exponent indices
+template <int NC>
+__device__ __forceinline__ void dig_row(const int8_t *dig, size_t row, u32 (&e)[NC]) {
+    if (NC == 16) {
+        const uint4 w = *(const uint4 *)(dig + row * 16);
+        const u32 ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) e[j] = dig_index((int8_t)(ww[j >> 2] >> (8 * (j & 3))));
+    } else {
+#pragma unroll
+        for (int j = 0; j < NC; j++) e[j] = dig_index(dig[row * NC + j]);
+    }
+}
+// one set's share of round 0: part[block][4] = sum over the block's pairs of eq(X) sum_j coef[j] (m_j(X)^2 - q_j(X)), X = 0..3
+template <int NC>
+__global__ void __launch_bounds__(256) k_sc_round0_dig(const int8_t *dig, size_t half, PwTab pw, const u64 *eq, const u64 *coef, u64 *part) {
+    __shared__ DigPow T;
+    __shared__ u64 cf[NC];
+    if (threadIdx.x < NC) cf[threadIdx.x] = coef[threadIdx.x];
+    digpow_load(pw, &T);
+    u64 s[4] = {0, 0, 0, 0};
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < half; b += (size_t)gridDim.x * 256) {
+        u32 e0[NC], e1[NC];
+        dig_row<NC>(dig, 2 * b, e0);
+        dig_row<NC>(dig, 2 * b + 1, e1);
+        u64 in[4] = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int j = 0; j < NC; j++) {
+            u64 m = T.p[e0[j]], q = T.q[e0[j]];
+            const u64 dm = sub_p(T.p[e1[j]], m), dq = sub_p(T.q[e1[j]], q), c = cf[j];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                in[x] = add_p(in[x], mont_mul(c, sub_p(mont_mul(m, m), q)));
+                m = add_p(m, dm);
+                q = add_p(q, dq);
+            }
+        }
+        const ulonglong2 ee = *(const ulonglong2 *)(eq + 2 * b);
+        u64 ev = ee.x;
+        const u64 de = sub_p(ee.y, ev);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            s[x] = add_p(s[x], mont_mul(ev, in[x]));
+            ev = add_p(ev, de);
+        }
+    }
+    block_sum4(s, part + (size_t)blockIdx.x * 4);
+}
+u32 launch_sc_round0_dig(const int8_t *dig, size_t n, u32 ncols, const PwTab &pw, const u64 *eq, const u64 *coef, u64 *part, hipStream_t s) {
+    const size_t half = n / 2;
+    size_t nb = cdiv(half, 256);
+    if (nb < 1) nb = 1;
+    if (nb > sc_round_max_blocks()) nb = sc_round_max_blocks();
+    if (ncols == 16) hipLaunchKernelGGL((k_sc_round0_dig<16>), dim3((unsigned)nb), dim3(256), 0, s, dig, half, pw, eq, coef, part);
+    else if (ncols == 1) hipLaunchKernelGGL((k_sc_round0_dig<1>), dim3((unsigned)nb), dim3(256), 0, s, dig, half, pw, eq, coef, part);
+    else return 0;
+    return (u32)nb;
+}
+// fix_variables at r of the set's (virtual) n-entry tables -> its 2 NC + 1 tables of n / 2 entries (written: tab[t][.], stride ld), and the set's share of the
+// NEXT round from those values: thread = four consecutive rows = one pair of the fixed tables
+template <int NC>
+__global__ void __launch_bounds__(256) k_sc_fix_round_dig(const int8_t *dig, size_t quarter, PwTab pw, const u64 *eq, u64 rM, u64 *tab, size_t ld, const u64 *coef,
+                                                          u64 *part) {
+    __shared__ DigPow T;
+    __shared__ u64 cf[NC];
+    if (threadIdx.x < NC) cf[threadIdx.x] = coef[threadIdx.x];
+    digpow_load(pw, &T);
+    u64 s[4] = {0, 0, 0, 0};
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < quarter; c += (size_t)gridDim.x * 256) {
+        u32 e0[NC], e1[NC], e2[NC], e3[NC];
+        dig_row<NC>(dig, 4 * c, e0);
+        dig_row<NC>(dig, 4 * c + 1, e1);
+        dig_row<NC>(dig, 4 * c + 2, e2);
+        dig_row<NC>(dig, 4 * c + 3, e3);
+        u64 in[4] = {0, 0, 0, 0};
+#pragma unroll 2
+        for (int j = 0; j < NC; j++) {
+            const u64 ma = T.p[e0[j]], mc = T.p[e2[j]], qa = T.q[e0[j]], qc = T.q[e2[j]];
+            const u64 m0 = add_p(ma, mont_mul(rM, sub_p(T.p[e1[j]], ma))), m1 = add_p(mc, mont_mul(rM, sub_p(T.p[e3[j]], mc)));
+            const u64 q0 = add_p(qa, mont_mul(rM, sub_p(T.q[e1[j]], qa))), q1 = add_p(qc, mont_mul(rM, sub_p(T.q[e3[j]], qc)));
+            *(ulonglong2 *)(tab + (size_t)(2 * j) * ld + 2 * c) = ulonglong2{m0, m1};
+            *(ulonglong2 *)(tab + (size_t)(2 * j + 1) * ld + 2 * c) = ulonglong2{q0, q1};
+            u64 m = m0, q = q0;
+            const u64 dm = sub_p(m1, m0), dq = sub_p(q1, q0), cc = cf[j];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                in[x] = add_p(in[x], mont_mul(cc, sub_p(mont_mul(m, m), q)));
+                m = add_p(m, dm);
+                q = add_p(q, dq);
+            }
+        }
+        const ulonglong2 ea = *(const ulonglong2 *)(eq + 4 * c), eb = *(const ulonglong2 *)(eq + 4 * c + 2);
+        const u64 f0 = add_p(ea.x, mont_mul(rM, sub_p(ea.y, ea.x))), f1 = add_p(eb.x, mont_mul(rM, sub_p(eb.y, eb.x)));
+        *(ulonglong2 *)(tab + (size_t)(2 * NC) * ld + 2 * c) = ulonglong2{f0, f1};
+        u64 ev = f0;
+        const u64 de = sub_p(f1, f0);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            s[x] = add_p(s[x], mont_mul(ev, in[x]));
+            ev = add_p(ev, de);
+        }
+    }
+    block_sum4(s, part + (size_t)blockIdx.x * 4);
+}
+u32 launch_sc_fix_round_dig(const int8_t *dig, size_t n, u32 ncols, const PwTab &pw, const u64 *eq, u64 rM, u64 *tab, size_t ld, const u64 *coef, u64 *part,
+                            hipStream_t s) {
+    const size_t quarter = n / 4;
+    size_t nb = cdiv(quarter, 256);
+    if (nb < 1) nb = 1;
+    if (nb > sc_round_max_blocks()) nb = sc_round_max_blocks();
+    if (ncols == 16) hipLaunchKernelGGL((k_sc_fix_round_dig<16>), dim3((unsigned)nb), dim3(256), 0, s, dig, quarter, pw, eq, rM, tab, ld, coef, part);
+    else if (ncols == 1) hipLaunchKernelGGL((k_sc_fix_round_dig<1>), dim3((unsigned)nb), dim3(256), 0, s, dig, quarter, pw, eq, rM, tab, ld, coef, part);
+    else return 0;
+    return (u32)nb;
+}
+
 // ---- evaluations ---------------------------------------------------------------------------------------------------------------------
 // part[chunk][col][16] = sum over the chunk's rows of w[row] * X^e(dig[row][col]).  wstride 1: scalar weights (constant polynomials);
 // 16: ring weights -- coefficient t of w X^e is w[t - e] (t >= e), -w[t - e + 16] (t < e).

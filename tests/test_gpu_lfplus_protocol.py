@@ -71,6 +71,30 @@ def test_set_check_matches_oracle(ctx, nvars, nmat, ncols, nvec, nM, round0_ahea
         assert ok and (r == got["r"]).all() and rc_o == 0
 
 
+@pytest.mark.parametrize("nvars,nmat,nvec,nM", [(3, 2, 0, 0), (4, 3, 2, 0), (6, 2, 1, 1), (11, 4, 2, 2)])
+def test_set_check_digit_rounds_equal_table_rounds(ctx, nvars, nmat, nvec, nM, monkeypatch):
+    """Rounds 0 and 1 of the set check read the exponent digits (k_sc_round0_dig, k_sc_fix_round_dig: 16-column matrix sets and vector sets, absent entries as
+    the zero monomial); LFPLUS_SC_TABLES=1 (read per call) materialises the beta^e tables first.  Both forms against the oracle, word for word."""
+    n = 1 << nvars
+    rng = np.random.default_rng(nvars * 7 + nmat)
+    dig = rng.integers(-7, 8, size=(nmat, n, 16)).astype(np.int8)
+    dense = lfp.exp_dense(dig)
+    mask = rng.random(dig.shape) < 0.3
+    dig[mask] = plus.ABSENT
+    dense[mask] = 0
+    vdig = rng.integers(-7, 8, size=(nvec, n)).astype(np.int8) if nvec else None
+    mats = [_ident(n, first=5)] + [_rand_csr(n, 7 + q) for q in range(1, nM)] if nM else []
+    want = lfp.set_check(lfp.Transcript(), nvars, dense, lfp.exp_dense(vdig) if nvec else None, mats)
+    for tables in (False, True):
+        if tables:
+            monkeypatch.setenv("LFPLUS_SC_TABLES", "1")
+        else:
+            monkeypatch.delenv("LFPLUS_SC_TABLES", raising=False)
+        got = plus.set_check(ctx, plus.PoseidonTranscript(), nvars, dig, vdig, mats)
+        for key in ("msgs", "r", "e", "b"):
+            assert (got[key] == want[key]).all(), (key, tables)
+
+
 def _witness(n, seed):
     v = (lfp.splitmix(seed, 0, n * D) % np.uint64(63)).astype(np.int64) - 31
     return np.where(v < 0, np.uint64(P) - (-v).astype(np.uint64), v.astype(np.uint64)).reshape(n, D)
