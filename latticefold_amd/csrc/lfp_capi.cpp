@@ -142,22 +142,30 @@ extern "C" int lfplus_share_matrix(lfplus_ctx *c, lfplus_ctx *from) {
     c->rank = from->rank; c->world = from->world; c->nloc = from->nloc; c->row0 = from->row0;
     return shape_buffers(c, from->kappa, from->n);
 }
+// The words are checked on the DEVICE, behind the upload (a host scan of a 2^20-row witness costs 5 ms, twice its upload): a non-canonical word fails the call
+// and leaves the context WITHOUT a resident witness.
 extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) {
     if (!c || !f || !n) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: bad arguments");
-    if (!canonical(f, (size_t)n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
     ff_join(c);     // (an asynchronous from_f may still read the witness that is being replaced)
     c->have = false;
-    if (c->f && c->nf == n) {   // same length as the resident witness: overwrite it (no hipFree / hipMalloc round trip per instance)
-        HIPCHK(c, hipMemcpyAsync(c->f, f, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
-        return LFPLUS_OK;
+    if (!(c->f && c->nf == n)) {   // (same length as the resident witness: overwrite it, no hipFree / hipMalloc round trip per instance)
+        c->own_free(c->f);
+        c->f = nullptr; c->nf = 0;
+        HIPCHK(c, c->own_alloc(&c->f, (size_t)n * 16 * 8));
     }
-    c->own_free(c->f);
-    c->f = nullptr; c->nf = 0;
-    HIPCHK(c, c->own_alloc(&c->f, (size_t)n * 16 * 8));
+    c->nf = 0;
+    u32 flag = 0;
+    HIPCHK(c, hipMemsetAsync(c->err_d, 0, 4, c->st));
     HIPCHK(c, hipMemcpyAsync(c->f, f, (size_t)n * 16 * 8, hipMemcpyHostToDevice, c->st));
+    lfp::launch_check_canonical(c->f, (size_t)n * 16, c->err_d, 4u, c->st);
+    HIPCHK(c, hipMemcpyAsync(&flag, c->err_d, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    if (flag & 4u) {
+        c->own_free(c->f);
+        c->f = nullptr;
+        return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: non-canonical word");
+    }
     c->nf = n;
     return LFPLUS_OK;
 }

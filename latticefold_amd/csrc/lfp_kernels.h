@@ -99,6 +99,7 @@ void launch_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab
 void launch_r1cs_round_fused(const u64 *E, const u64 *G, size_t ld, size_t half, u64 rM, u64 *Eo, u64 *Go, size_t ld_o, u64 *part, hipStream_t s);   // + fix_variables of the previous round (E / G: previous tables)
 void launch_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part, hipStream_t s);
 void launch_vec_add(u64 *acc, const u64 *x, size_t n, hipStream_t s);
+void launch_check_canonical(const u64 *x /* 16-byte aligned */, size_t n, u32 *flag, u32 bit, hipStream_t s);
 void launch_tensor_level(const u64 *cur, u64 len, u64 r, u64 *nxt, hipStream_t s);
 void launch_tensor_product(const u64 *a, u64 m, const u64 *b, u64 n, u64 *out, hipStream_t s);
 }  // namespace lfp

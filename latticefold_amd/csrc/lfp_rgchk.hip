@@ -938,4 +938,19 @@ __global__ void __launch_bounds__(256) k_vec_add(u64 *acc, const u64 *x, size_t 
     if (i < n) acc[i] = add_p(acc[i], x[i]);
 }
 void launch_vec_add(u64 *acc, const u64 *x, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_vec_add, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, acc, x, n); }
+// *flag |= bit if any of the n words is not a canonical residue (an uploaded vector is checked where it lands: a host scan of a 2^20-row witness costs more than its upload)
+__global__ void __launch_bounds__(256) k_check_canonical(const u64 *x, size_t n, u32 *flag, u32 bit) {
+    bool bad = false;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (size_t)gridDim.x * 512) {
+        if (i + 1 < n) { const ulonglong2 v = *(const ulonglong2 *)(x + i); bad |= v.x >= P || v.y >= P; }
+        else bad |= x[i] >= P;
+    }
+    if (bad) atomicOr(flag, bit);
+}
+void launch_check_canonical(const u64 *x, size_t n, u32 *flag, u32 bit, hipStream_t s) {
+    size_t nb = cdiv(n, 512 * 8);
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_check_canonical, dim3((unsigned)nb), dim3(256), 0, s, x, n, flag, bit);
+}
 }  // namespace lfp

@@ -226,10 +226,11 @@ class PlusContext:
         self._chk(_lib().lfplus_get_witness(self.h, out.ctypes.data_as(u64p), self.n))
         return out
 
-    def decompose(self, f, A, B, r, M=(), into=None):
+    def decompose(self, f, A, B, r, M=(), into=None, out_bufs=None):
         """Decomp{f, r, M}.decompose(&A, B) (decomp.rs:32-99).  r: (nvars, 2, 16) pairs of ring elements; M: CSR matrices (rowptr, col, val[nnz][16]).
         -> dict(F0, F1 (n,16); C0, C1 (kappa,16); v0, v1 (1+len(M), 2, 16)): ((LinB0, LinB1), DecompProof) of the reference, flat.
-        into = (ctx0, ctx1): F0 / F1 stay on the device as the resident witnesses of those contexts (lfplus_decompose_resident) and are not returned"""
+        into = (ctx0, ctx1): F0 / F1 stay on the device as the resident witnesses of those contexts (lfplus_decompose_resident) and are not returned;
+        out_bufs = (F0, F1): host arrays to receive them (already touched: a download into fresh pages is page-fault-bound, 10 ms instead of 2.4 per 2^20 rows)"""
         if A is not None:
             self.set_matrix(A)
         if f is not None:              # None: the resident witness (e.g. the folded g Mlin.mlin left there)
@@ -245,7 +246,10 @@ class PlusContext:
             self._chk(_lib().lfplus_decompose_resident(self.h, B, r_a.ctypes.data_as(u64p), r_b.ctypes.data_as(u64p), nm, rp, cp, vp_, into[0].h, into[1].h,
                                                        *[out[k].ctypes.data_as(u64p) for k in ("C0", "C1", "v0", "v1")]))
             return out
-        out["F0"], out["F1"] = np.zeros((n, D), dtype=np.uint64), np.zeros((n, D), dtype=np.uint64)
+        if out_bufs is not None and all(isinstance(b, np.ndarray) and b.shape == (n, D) and b.dtype == np.uint64 and b.flags.c_contiguous for b in out_bufs):
+            out["F0"], out["F1"] = out_bufs
+        else:
+            out["F0"], out["F1"] = np.zeros((n, D), dtype=np.uint64), np.zeros((n, D), dtype=np.uint64)
         self._chk(_lib().lfplus_decompose(self.h, B, r_a.ctypes.data_as(u64p), r_b.ctypes.data_as(u64p), nm, rp, cp, vp_,
                                           *[out[k].ctypes.data_as(u64p) for k in ("F0", "F1", "C0", "C1", "v0", "v1")]))
         return out
@@ -795,20 +799,70 @@ class PlusProver:
         # RgInstance::from_f of every instance (Mlin::mlin, mlin.rs:52-60) needs no challenge: each is enqueued on its context's second stream as soon as the
         # witness is resident and runs next to the linearizations' latency-bound rounds; lfplus_mlin collects the results
         dp = self.params.lin.decomp
-        for i, f in enumerate(self.acc):
-            if not isinstance(f, str):     # (device_acc: F0 / F1 of the last prove are the resident witnesses of ctxs[0] / ctxs[1] already)
-                ctxs[i].set_witness(f)
-            ctxs[i].rg_from_f_async(dp)
-        for i, ci in enumerate(comp):
-            same = len(self.M) == 3 and all(a is b for x, y in zip(ci.r1cs, self.M) for a, b in zip(x, y))   # (M = cr1cs.x.matrices() in every reference use)
-            _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same, preloaded=pre, from_f_hint=dp)
-            lproof.append(lp)
+        # Witnesses that are still on the host (the accumulator of a prover without device_acc, fresh instances that were not preloaded) cross PCIe on a worker
+        # thread, one after the other, while this thread linearizes the instances that have arrived (an upload is 2.4 ms per 2^20-row witness, a linearization
+        # 2.3 ms): only the first upload is exposed.  Sharded provers upload in line (their contexts exchange from this thread).
+        ups = [(ctxs[i], f) for i, f in enumerate(self.acc) if not isinstance(f, str)]      # (device_acc: F0 / F1 of the last prove are resident in ctxs[0] / ctxs[1] already)
+        if not pre:
+            ups += [(ctxs[nacc + i], ci.f) for i, ci in enumerate(comp)]
+        arrived, up_err, outs = {}, [], []
+        want_outs = not self.device_acc      # (F0, F1) come back to the host: their buffers are allocated AND touched by the worker while the GPU works
+        if (ups or want_outs) and self.ctxs[0].shard[1] == 1 and not os.environ.get("LFPLUS_SERIAL_UPLOADS"):
+            import threading
+            for cx, _ in ups:
+                arrived[id(cx)] = threading.Event()
+
+            def _upload():
+                try:
+                    for cx, f in ups:
+                        cx.set_witness(f)
+                        arrived[id(cx)].set()
+                    if want_outs:
+                        outs.extend(np.zeros((ctxs[0].n, D), dtype=np.uint64) for _ in range(2))
+                        for b in outs:
+                            b[::32, 0] = 0           # one word per 4 KiB page (32 rows of 128 bytes): the pages exist before the download needs them
+                        outs_ready.set()
+                except Exception as ex:      # (reported by the thread that waits for the witness)
+                    up_err.append(ex)
+                    for ev in arrived.values():
+                        ev.set()
+            outs_ready = threading.Event()
+            th = threading.Thread(target=_upload, daemon=True)
+            th.start()
+        else:
+            th = None
+            for cx, f in ups:
+                cx.set_witness(f)
+
+        def _wait(cx):
+            ev = arrived.get(id(cx))
+            if ev is not None:
+                ev.wait()
+                if up_err:
+                    raise up_err[0]
+        try:
+            for i in range(nacc):
+                _wait(ctxs[i])
+                ctxs[i].rg_from_f_async(dp)
+            for i, ci in enumerate(comp):
+                same = len(self.M) == 3 and all(a is b for x, y in zip(ci.r1cs, self.M) for a, b in zip(x, y))   # (M = cr1cs.x.matrices() in every reference use)
+                _wait(ctxs[nacc + i])
+                _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same, preloaded=True, from_f_hint=dp)
+                lproof.append(lp)
+        except Exception:
+            if th is not None:               # (never leave the worker writing into contexts the caller is about to close)
+                th.join()
+            raise
         linb2x, cmproof = mlin(ctxs, self.transcript, self.params.lin, self.res)
         if self.device_acc:
             dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res, into=(self.ctxs[0], self.ctxs[1]))
             self.acc = ["ctx0", "ctx1"]
         else:
-            dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res)
+            if th is not None:
+                th.join()
+                if up_err:
+                    raise up_err[0]
+            dec = ctxs[0].decompose(None, None, self.params.B, _ro_pairs(linb2x["ro"]), self.res, out_bufs=tuple(outs) if len(outs) == 2 else None)
             self.acc = [dec["F0"], dec["F1"]]
         dproof = {key: dec[key] for key in ("C0", "C1", "v0", "v1")}
         return {"linb2x": linb2x, "lproof": lproof, "cmproof": cmproof, "dproof": dproof}

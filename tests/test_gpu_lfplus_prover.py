@@ -124,3 +124,71 @@ def test_scratch_cache_is_bounded_and_released(monkeypatch):
         assert main.device_memory()[0] >= free0 + held - (64 << 20)      # the blocks went back to the driver (other allocations may move a little)
     finally:
         main.close()
+
+
+def test_set_witness_checks_the_words_on_the_device_and_prover_uploads_in_the_background(monkeypatch):
+    """lfplus_set_witness checks canonicity behind the upload (k_check_canonical): a word >= p anywhere fails the call with LFPLUS_E_ARG and leaves no resident
+    witness.  PlusProver uploads host witnesses on a worker thread while it linearizes the ones that have arrived: same proof as with LFPLUS_SERIAL_UPLOADS=1
+    and as with preloaded witnesses; an upload that fails surfaces as the prove's error."""
+    n = 1 << 12
+    rng = np.random.default_rng(9)
+    ctx = plus.PlusContext(0)
+    try:
+        good = rng.integers(0, 31, size=(n, D), dtype=np.uint64)
+        ctx.set_witness(good)
+        ctx.n = n                                       # (no matrix in this context: get_witness sizes its buffer from it)
+        assert (ctx.get_witness() == good).all()
+        for pos in ((0, 0), (n - 1, D - 1), (n // 2 + 1, 3)):
+            bad = good.copy()
+            bad[pos] = np.uint64(plus.P + (pos[1] % 2))
+            with pytest.raises(plus.LfPlusError) as e:
+                ctx.set_witness(bad)
+            assert e.value.code == plus.E_ARG
+            with pytest.raises(plus.LfPlusError):
+                ctx.get_witness()                       # nothing resident after a refused upload
+        ctx.set_witness(good)
+        assert (ctx.get_witness() == good).all()
+    finally:
+        ctx.close()
+    wl = plus.make_plus_workload("P15")
+    A, r1cs = wl.ajtai_matrix(), wl.r1cs()
+
+    def run(mode):
+        if mode == "serial":
+            monkeypatch.setenv("LFPLUS_SERIAL_UPLOADS", "1")
+        else:
+            monkeypatch.delenv("LFPLUS_SERIAL_UPLOADS", raising=False)
+        prover = plus.PlusProver.init(A, list(r1cs), max(1, wl.L - 2), wl.params(), plus.PoseidonTranscript(), 0)
+        try:
+            comps = [plus.ComR1CS.new(prover.ctxs[0], r1cs, wl.z(i), 1, wl.B, wl.k) for i in range(wl.L)]
+            if mode == "preload":
+                prover.preload(comps)
+            p1 = prover.prove(comps)
+            p2 = prover.prove(comps[:1])              # second fold: the host accumulator (F0, F1) goes up on the worker thread as well
+            return p1, p2, prover.accumulator(), prover.transcript.get_challenge()
+        finally:
+            prover.close()
+
+    def flat(x):
+        if isinstance(x, dict):
+            return [v for k in sorted(x) for v in flat(x[k])]
+        if isinstance(x, (list, tuple)):
+            return [v for y in x for v in flat(y)]
+        return [np.asarray(x)]
+    ref = run("thread")
+    for mode in ("serial", "preload"):
+        got = run(mode)
+        assert got[3] == ref[3]
+        for a, b in zip(flat(ref[:3]), flat(got[:3])):
+            assert a.shape == b.shape and (a == b).all(), mode
+    prover = plus.PlusProver.init(A, list(r1cs), max(1, wl.L - 2), wl.params(), plus.PoseidonTranscript(), 0)
+    try:
+        comps = [plus.ComR1CS.new(prover.ctxs[0], r1cs, wl.z(i), 1, wl.B, wl.k) for i in range(wl.L)]
+        comps[1].f = comps[1].f.copy()
+        comps[1].f[5, 5] = np.uint64(plus.P)
+        with pytest.raises(plus.LfPlusError):
+            prover.prove(comps)
+        with pytest.raises(plus.LfPlusError):
+            prover.prove(comps)                        # a failed prover refuses to continue
+    finally:
+        prover.close()
