@@ -46,21 +46,17 @@ def test_probe_output_switches_product_and_oracle_together(tmp_path):
             finally:
                 ctx.close()
 
-        def oracle():
-            inst = lfo.Instance(wl)
-            f = inst.witness_from_w_ccs(wl.w_ccs)
-            A = wl.ajtai_matrix()
-            cccs = np.concatenate([lfo.ajtai_commit(A, wl.kappa, wl.N, lfo.crt(f)).reshape(-1, 24), wl.x_ccs]) if False else None
-            return inst, f, A
         cal = load_probe(str(path))
         got = product(cal)
         base = product(None)
         cal.apply_oracle(lfo)
         assert (got[0] == lfo.crt(x)).all() and (got[1] == lfo.decompose(ties, 1 << 16, 4, 0)).all()
         assert not (base[0] == got[0]).all() and not (base[1] == got[1]).all()          # the calibration really moved the product
-        inst, f, A = oracle()
+        inst, A = lfo.Instance(wl), wl.ajtai_matrix()
+        f = inst.witness_from_w_ccs(wl.w_ccs)
         to = lfo.Transcript()
         cccs = got[2]
+        assert (cccs[:wl.kappa] == lfo.ajtai_commit(A, wl.kappa, wl.N, lfo.crt(f))).all()      # the commitment under the calibrated CRT
         acc_o, _ = inst.linearize(to, cccs, f)
         lc_o, f0_o, proof_o = inst.fold_step(to, A, acc_o, f, cccs, f)
         assert (got[3] == lc_o).all() and (got[4] == proof_o).all() and (got[5] == f0_o).all()
