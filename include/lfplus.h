@@ -75,6 +75,11 @@ int lfplus_dist_unique_id(uint8_t *id128);
 int lfplus_dist_init(lfplus_ctx *ctx, int rank, int world, const uint8_t *id128);
 /* exchange log of the context's transport: number of exchanges, summed and maximal host-side latency in microseconds (reset != 0 clears it) */
 int lfplus_dist_stats(lfplus_ctx *ctx, uint64_t *n_exchanges, double *total_us, double *max_us, int reset);
+/* u64 words this rank contributed to its exchanges (reset != 0 clears the counter) */
+int lfplus_dist_stats_words(lfplus_ctx *ctx, uint64_t *words_sent, int reset);
+/* TIMING MODEL, not a transport (as lf_set_sharding_model in lfhip.h): rank `rank` of `world` with no peers; zeros stand in for their words.  The "proofs" of such a
+ * prover are meaningless; tools/shard_model.py --lfplus measures a rank's share of a sharded PlusProver::prove with it on a one-GPU box. */
+int lfplus_set_sharding_model(lfplus_ctx *ctx, int rank, int world);
 
 /* Ajtai matrix A (kappa x n ring elements, row-major, coefficient form); stays resident in HBM.  kappa <= 64.  In a sharded context: the rank's columns,
  * kappa x (n / world), and `n` is that local width. */

@@ -76,6 +76,22 @@ extern "C" int lfplus_set_sharding(lfplus_ctx *c, int rank, int world, lfplus_ex
     c->rank = rank; c->world = world;
     return LFPLUS_OK;
 }
+// TIMING MODEL (as lf_set_sharding_model, include/lfhip.h): the context is rank `rank` of `world` with no peers -- every kernel and host stage does that rank's
+// share, every exchange gets zeros for the peers' words.  What such a prover returns is not a proof; tools/shard_model.py --lfplus measures a rank's share with it.
+extern "C" int lfplus_set_sharding_model(lfplus_ctx *c, int rank, int world) {
+    int rc = shard_geometry_ok(c, rank, world);
+    if (rc) return rc;
+    c->sh = std::make_shared<LfpShard>();
+    c->sh->comm.rank = rank; c->sh->comm.world = world; c->sh->comm.model = world > 1;
+    c->rank = rank; c->world = world;
+    return LFPLUS_OK;
+}
+extern "C" int lfplus_dist_stats_words(lfplus_ctx *c, uint64_t *words_sent, int reset) {
+    if (!c || !words_sent) return LFPLUS_E_ARG;
+    *words_sent = c->sh ? c->sh->comm.words_sent : 0;
+    if (reset && c->sh) c->sh->comm.words_sent = 0;
+    return LFPLUS_OK;
+}
 extern "C" int lfplus_dist_unique_id(uint8_t *id128) { return lfdist::rccl_unique_id(id128) == 0 ? LFPLUS_OK : LFPLUS_E_HIP; }
 extern "C" int lfplus_dist_init(lfplus_ctx *c, int rank, int world, const uint8_t *id128) {
     int rc = shard_geometry_ok(c, rank, world);

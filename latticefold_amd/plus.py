@@ -147,6 +147,20 @@ class PlusContext:
 
     shard = (0, 1)     # (rank, world) of a column-sharded prover
 
+    def set_sharding_model(self, rank, world):
+        """lfplus_set_sharding_model: a TIMING model of rank `rank` of `world` with no peers (tools/shard_model.py --lfplus); what such a prover returns is not a proof"""
+        L = _lib()
+        L.lfplus_set_sharding_model.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._chk(L.lfplus_set_sharding_model(self.h, int(rank), int(world)))
+        self.shard = (rank, world)
+
+    def dist_stats_words(self, reset=False):
+        L = _lib()
+        L.lfplus_dist_stats_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        w = C.c_uint64()
+        self._chk(L.lfplus_dist_stats_words(self.h, C.byref(w), int(reset)))
+        return w.value
+
     def set_sharding(self, rank, world, allgather):
         """Column sharding over a HOST transport (lfplus_set_sharding); call before set_matrix.  allgather(np.uint64[words]) -> np.uint64[world, words]
         in rank order (latticefold_amd.dist.make_allgather)."""
@@ -740,7 +754,9 @@ class PlusProver:
         self.ctxs = [PlusContext(device) for _ in range(2 + ncomp)]
         if shard is not None:
             rank, world, transport = shard
-            if callable(transport):
+            if transport == "model":
+                self.ctxs[0].set_sharding_model(rank, world)
+            elif callable(transport):
                 self.ctxs[0].set_sharding(rank, world, transport)
             else:
                 self.ctxs[0].dist_init(rank, world, transport)

@@ -94,7 +94,7 @@ print(json.dumps({"same": a == b, "exchanges": n}))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["same"] and d["exchanges"] >= 8, d
+    assert d["same"] and d["exchanges"] >= 5, d      # (round 5: v_s and u_s share one exchange, one gather per hand-over)
 
 
 def test_bench_streams_mode_single_rank():
