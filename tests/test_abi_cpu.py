@@ -180,3 +180,15 @@ def test_ring_helpers_and_sizes():
     assert L.lf_transcript_new_ring(5) is None
     L.lf_strerror.restype = C.c_char_p
     assert b"reject" in L.lf_strerror(-8)
+
+
+def test_switch_table_is_current():
+    """SWITCHES.md is the generated list of every environment switch the library reads (tools/list_switches.py): regenerating gives the committed text"""
+    import importlib.util
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("list_switches", os.path.join(root, "tools", "list_switches.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert open(os.path.join(root, "SWITCHES.md")).read() == mod.render(), "run tools/list_switches.py --write"
+    rows, _ = mod.collect()
+    assert len(rows) > 70 and all(text for _d, text, _w in rows.values())
