@@ -329,7 +329,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true", help="announce the next step's instance before every step (lf_prefetch_instance): the step prepares the next right decomposition's "
-                    "challenge-independent half.  Off by default: measured 0.8-1.9 ms SLOWER per C4 step at every trigger point (gpurun r5c/r5d, DESIGN 10): the chip has no idle CUs to give")
+                    "challenge-independent half.  Off by default: measured 0.8-1.9 ms SLOWER per C4 step at every trigger point (profiles/r05_prefetch_ab_c4.txt, DESIGN 5): the chip has no idle CUs to give")
     ap.add_argument("--no-prefetch", action="store_true", help="(default) every step computes its whole right decomposition itself")
     ap.add_argument("--no-lfplus", action="store_true", help="skip the LatticeFold+ PlusProver::prove timing (an extra key, not part of the metric)")
     ap.add_argument("--streams", type=int, default=1,
