@@ -80,6 +80,11 @@ void launch_spmvT_eq_const(const u32 *colptr, const u32 *rowidx, const u64 *val,
 struct CmShort { int32_t v[3][16]; };     // the three folding challenges s (centred coefficients)
 struct CmDesc { u32 L, nM; };
 void launch_cm_materialize(const int8_t *dig, const u64 *tau, size_t n, u64 *out, hipStream_t s);
+// compact instance tables of Cm::prove: m_tau as exponent bytes, M_q tau as scalars (lfp_rgchk.hip)
+struct CmCompact { const int8_t *mtau[8]; const u64 *mts; size_t ldm; };      // mts[(l nM + q) ldm + row], canonical
+struct CmTabList { uint16_t idx[64]; };
+void launch_spmv_scalar_const(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s);
+void launch_spmv_mono_const(const u32 *rowptr, const u32 *col, const u64 *valM, const int8_t *dig, size_t nrows, u64 *y, hipStream_t s);
 void launch_to_mont(const u64 *in, size_t n, u64 *out, hipStream_t s);
 void launch_cm_h(const int8_t *Df, size_t n, u32 k, const int32_t *sp, u64 *h, hipStream_t s);
 void launch_cm_g(const u64 *tau, const int8_t *mtau, const u64 *f, const u64 *h, size_t n, const CmShort &s, u64 *g, hipStream_t st);
@@ -95,6 +100,9 @@ void launch_cm2_round(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t
 void launch_cm2_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t half, u64 rM, u64 *So, u64 *Ro, size_t ld_o, u64 *part, hipStream_t s);
 u32 cm_eval_chunks(size_t n);
 void launch_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, u64 *part, u64 *out, hipStream_t s);
+void launch_cm_combine_c(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t n, const CmDesc &d, const u64 *rcp, const CmCompact &cc, u64 *S2, u64 *R2, size_t ld2, hipStream_t s);
+void launch_cm_evals_c(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, const CmTabList &dense, u32 ndense, const CmCompact &cc, u32 L, u32 nM, u32 per, u64 *part,
+                       u64 *out, hipStream_t s);
 // ---- ComR1CS::linearize (r1cs.rs:76-139): degree-3 round of eq (ga gb - gc); part: cm_round_blocks(half) * 64
 void launch_r1cs_round_fused(const u64 *E, const u64 *G, size_t ld, size_t half, u64 rM, u64 *Eo, u64 *Go, size_t ld_o, u64 *part, hipStream_t s);   // + fix_variables of the previous round (E / G: previous tables)
 void launch_r1cs_round(const u64 *E, const u64 *G, size_t ld, size_t half, u64 *part, hipStream_t s);

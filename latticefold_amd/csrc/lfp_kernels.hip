@@ -380,6 +380,28 @@ __global__ void __launch_bounds__(256) k_spmv_ring_const(const u32 *rowptr, cons
     for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) acc = add_p(acc, mont_mul(valM[k], x[(size_t)col[k] * D + t]));      // valM: one word per non-zero (LfpMatrix::valMc)
     y[row * D + t] = acc;
 }
+// Constant-coefficient matrix times a vector in COMPACT form (Cm::prove's tau and m_tau: one word / one exponent byte per row instead of a 128-byte ring element):
+// y[row] = sum_k M[row][col_k] tau[col_k] (a scalar: the product is a constant polynomial) ...
+__global__ void __launch_bounds__(256) k_spmv_scalar_const(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    u64 acc = 0;
+    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) acc = add_p(acc, mont_mul(valM[k], x[col[k]]));
+    y[row] = acc;
+}
+// ... and y[row] = sum_k M[row][col_k] X^e(dig[col_k]) (a ring element: coefficient t collects the non-zeros whose monomial is X^t); thread = (row, coefficient)
+__global__ void __launch_bounds__(256) k_spmv_mono_const(const u32 *rowptr, const u32 *col, const u64 *valM, const int8_t *dig, size_t nrows, u64 *y) {
+    const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int t = threadIdx.x & 15;
+    if (row >= nrows) return;
+    u64 acc = 0;
+    for (u32 k = rowptr[row]; k < rowptr[row + 1]; k++) {
+        const int8_t d = dig[col[k]];
+        const int e = d >= 0 ? d : 16 + d;
+        if (e == t) acc = add_p(acc, mont_mul(valM[k], 1));
+    }
+    y[row * D + t] = acc;
+}
 // dst[tab] = src for tab in 0..copies-1 (the tables of one vector, one per evaluation point)
 __global__ void __launch_bounds__(256) k_replicate(const u64 *src, size_t words, u32 copies, u64 *dst) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -447,6 +469,12 @@ void launch_ring_fix(const u64 *in, u64 *out, u32 ntab, size_t len, const u64 *r
 void launch_spmv_ring(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s, int const_coef) {
     if (const_coef) hipLaunchKernelGGL(k_spmv_ring_const, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, s, rowptr, col, valM, x, nrows, y);
     else hipLaunchKernelGGL(k_spmv_ring, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, s, rowptr, col, valM, x, nrows, y);
+}
+void launch_spmv_scalar_const(const u32 *rowptr, const u32 *col, const u64 *valM, const u64 *x, size_t nrows, u64 *y, hipStream_t s) {
+    hipLaunchKernelGGL(k_spmv_scalar_const, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, rowptr, col, valM, x, nrows, y);
+}
+void launch_spmv_mono_const(const u32 *rowptr, const u32 *col, const u64 *valM, const int8_t *dig, size_t nrows, u64 *y, hipStream_t s) {
+    hipLaunchKernelGGL(k_spmv_mono_const, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, s, rowptr, col, valM, dig, nrows, y);
 }
 void launch_replicate(const u64 *src, size_t words, u32 copies, u64 *dst, hipStream_t s) {
     hipLaunchKernelGGL(k_replicate, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src, words, copies, dst);

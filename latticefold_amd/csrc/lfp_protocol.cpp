@@ -1071,6 +1071,14 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     // is enqueued from inside the range check, ahead of the host's absorb of the set check's evaluations (before_absorb); h, M_q h, t0 and t1 follow below
     // (instance tables built ahead -- lfplus_cm_tables_async -- live in ctxs[0]'s own buffers; they are used when this call has their shape and the resident matrices)
     const bool pre = !shd && !rowptr && c->cmpre.S && c->cmpre.R && c->cmpre.n == n && c->cmpre.L == L && c->cmpre.nM == nM && c->cmpre.by.size() == L;
+    // Compact instance tables (lfp_rgchk.hip, k_cm_combine_c): m_tau stays the exponent bytes from_f left, M_q tau a column of scalars -- valid when every M_q has
+    // constant coefficients; the batched, unsharded form only (LFPLUS_CM_DENSE=1: every table as ring elements)
+    bool compact = batched && !shd && !pre && L <= 8 && L * nM <= 64 && nring <= 64 && !getenv("LFPLUS_CM_DENSE");
+    for (u32 q = 0; q < nM; q++) compact = compact && M[q].const_coef;
+    DevBuf mtsb;
+    lfp::CmCompact cc = {};
+    lfp::CmTabList dense_list = {};
+    u32 ndense = 0;
     auto tables_early = [&]() -> int {
         if ((!pre && (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8))) || Sw[0].alloc((size_t)kS * (nl / 2) * 8) || Sw[1].alloc((size_t)kS * (nl / 4 + 1) * 8) ||
             Rw[0].alloc((size_t)kR * (nl / 2) * D * 8) || Rw[1].alloc((size_t)kR * (nl / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
@@ -1082,8 +1090,28 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         S = S0.as<u64>(); R = R0.as<u64>();
         if (pre) { S = c->cmpre.S; R = c->cmpre.R; }
         HIPCHK(c, hipMemcpyAsync(S, so.eqr.as<u64>() + row0, nl * 8, hipMemcpyDeviceToDevice, c->st));
+        if (compact) {
+            if (nM && mtsb.alloc((size_t)L * nM * nl * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm scalar tables)");
+            cc.mts = mtsb.as<u64>(); cc.ldm = nl;
+            for (u32 l = 0; l < L; l++) cc.mtau[l] = ctxs[l]->mtau;
+            for (u32 l = 0; l < L; l++)
+                for (u32 j = 1; j < per; j++)
+                    if (j != 1 && !(j >= 4 && ((j - 4) & 3) == 0)) dense_list.idx[ndense++] = (uint16_t)(l * (per - 1) + j - 1);
+        }
         for (u32 l = 0; l < L; l++) {
             u64 *base = R + (size_t)l * (per - 1) * nl * D;
+            if (compact) {      // f as a ring table; M_q tau as scalars, M_q m_tau from the exponent bytes, M_q f
+                lfp::launch_to_mont(ctxs[l]->tau, nl, S + (size_t)(1 + l) * nl, c->st);
+                HIPCHK(c, hipMemcpyAsync(base + nl * D, ctxs[l]->f, nl * D * 8, hipMemcpyDeviceToDevice, c->st));
+                for (u32 q = 0; q < nM; q++) {
+                    const LfpMatrix &m = M[q];
+                    u64 *mq = base + (size_t)(3 + 4 * q) * nl * D;
+                    lfp::launch_spmv_scalar_const(m.rowptr, m.col, m.spmv_vals(), ctxs[l]->tau, nl, mtsb.as<u64>() + ((size_t)l * nM + q) * nl, c->st);
+                    lfp::launch_spmv_mono_const(m.rowptr, m.col, m.spmv_vals(), ctxs[l]->mtau, nl, mq + (size_t)1 * nl * D, c->st);
+                    lfp::launch_spmv_ring(m.rowptr, m.col, m.spmv_vals(), ctxs[l]->f, nl, mq + (size_t)2 * nl * D, c->st, 1);
+                }
+                continue;
+            }
             if (pre && c->cmpre.by[l] == ctxs[l] && ctxs[l]->ev_cmt && ctxs[l]->cmt_valid) {      // built ahead on the instance's second stream (lfplus_cm_tables_async): wait for it, use it once
                 HIPCHK(c, hipStreamWaitEvent(c->st, ctxs[l]->ev_cmt, 0));
                 c->cmpre.by[l] = nullptr;
@@ -1189,6 +1217,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         tr->absorb_const(2);
         const u64 *Sc = S, *Rc = R;
         if (batched) {
+            if (compact) lfp::launch_cm_combine_c(S, nl, R, nl, nl, desc, rcpd.as<u64>(), cc, S2.as<u64>(), R2.as<u64>(), nl, c->st);
+            else
             lfp::launch_cm_combine(S, nl, R, nl, nl, desc, rcpd.as<u64>(), S2.as<u64>(), R2.as<u64>(), nl, c->st);
             Sc = S2.as<u64>(); Rc = R2.as<u64>();
         }
@@ -1260,6 +1290,8 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
         if (evd.alloc(evh.size() * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (evals)");
         if (batched) {     // T(ro) = sum_b eq(ro, b) T(b) over the rank's rows of the ORIGINAL instance tables (ring) and of the tau_l (scalars, Montgomery)
             eq_build_local(c, rop, nvars, eqro.as<u64>());
+            if (compact) lfp::launch_cm_evals_c(R, nl, nl, eqro.as<u64>(), nring, dense_list, ndense, cc, L, nM, per, evpart.as<u64>(), evd.as<u64>(), c->st);
+            else
             lfp::launch_cm_evals(R, nl, nl, eqro.as<u64>(), nring, evpart.as<u64>(), evd.as<u64>(), c->st);
             for (u32 l = 0; l < L; l++)
                 lfp::launch_wdot(eqro.as<u64>(), 1, 1, S + (size_t)(1 + l) * nl, nl, evpart.as<u64>(), evd.as<u64>() + (size_t)nR * D + 1 + l, c->st);

@@ -833,6 +833,90 @@ u32 cm_eval_chunks(size_t n) {
     const size_t b = cdiv(n, 16 * 64);      // 64 rows per thread and chunk at least
     return (u32)(b < 1 ? 1 : (b > 64 ? 64 : b));
 }
+// ---- compact instance tables (round 5) ----------------------------------------------------------------------------------------------------
+// Per instance, table 0 (m_tau) is a column of unit monomials and tables 3 + 4q (M_q tau, M_q with constant coefficients) are columns of scalars: 128-byte ring
+// elements whose content is one exponent byte / one word.  The two streaming passes of a sumchecker read them in that form (12 of 47 tables at L = 3, nM = 3: a
+// quarter of the bytes); the arithmetic is the dense kernels' -- the same lazy products, against 0 / 1 / the scalar -- so every word of the proof is unchanged.
+__global__ void __launch_bounds__(256) k_cm_combine_c(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t n, CmDesc d, const u64 *rcp, CmCompact cc, u64 *S2, u64 *R2,
+                                                      size_t ld2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 16) return;
+    const size_t row = i >> 4;
+    const u32 c = (u32)(i & 15);
+    const u32 per = 4 + 4 * d.nM, nring = d.L * (per - 1);
+    u64 u = 0, v = 0;
+    Acc160 ua;
+    acc160_zero(ua);
+    for (u32 l = 0; l < d.L; l++) {
+        const u64 m = S[(size_t)(1 + l) * lds + row];
+        v = add_p(v, m);
+        if (c == 0) u = add_p(u, mont_mul(rcp[l * per], from_mont(m)));
+        const u64 *rp = R + ((size_t)(l * (per - 1)) * ldr + row) * 16 + c;
+        acc160_mad(ua, rcp[l * per + 1], (u64)((u32)exp_of(cc.mtau[l][row]) == c));                       // m_tau: X^e
+        acc160_mad(ua, rcp[l * per + 2], rp[(size_t)1 * ldr * 16]);                                      // f
+        acc160_mad(ua, rcp[l * per + 3], rp[(size_t)2 * ldr * 16]);                                      // h
+        for (u32 q = 0; q < d.nM; q++) {
+            const u32 j = 4 + 4 * q;
+            acc160_mad(ua, rcp[l * per + j], c == 0 ? cc.mts[((size_t)l * d.nM + q) * cc.ldm + row] : 0);   // M_q tau: a scalar
+#pragma unroll
+            for (u32 x = 1; x < 4; x++) acc160_mad(ua, rcp[l * per + j + x], rp[(size_t)(j + x - 1) * ldr * 16]);
+        }
+    }
+    const u64 t0 = R[((size_t)nring * ldr + row) * 16 + c], t1 = R[((size_t)(nring + 1) * ldr + row) * 16 + c];
+    R2[row * 16 + c] = add_p(u, acc160_red(ua));
+    R2[(ld2 + row) * 16 + c] = add_p(mont_mul(rcp[d.L * per], t0), mont_mul(rcp[d.L * per + 1], t1));
+    if (c == 0) { S2[row] = S[row]; S2[ld2 + row] = v; }
+}
+void launch_cm_combine_c(const u64 *S, size_t lds, const u64 *R, size_t ldr, size_t n, const CmDesc &d, const u64 *rcp, const CmCompact &cc, u64 *S2, u64 *R2, size_t ld2,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_cm_combine_c, dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, s, S, lds, R, ldr, n, d, rcp, cc, S2, R2, ld2);
+}
+// evaluations of the DENSE tables named in `list` only (part / out keep the layout of launch_cm_evals: slot = table index; the other slots are the caller's)
+__global__ void __launch_bounds__(256) k_cm_evals_list(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, CmTabList list, u64 *part) {
+    const u32 c = threadIdx.x & 15, rl = threadIdx.x >> 4, tab = list.idx[blockIdx.y];
+    const u64 *T = R + (size_t)tab * ldr * 16;
+    Acc160 acc;
+    acc160_zero(acc);
+#pragma unroll 4
+    for (size_t row = (size_t)blockIdx.x * 16 + rl; row < n; row += (size_t)gridDim.x * 16) acc160_mad(acc, eq[row], T[row * 16 + c]);
+    __shared__ u64 sm[16][16];
+    sm[rl][c] = acc160_red(acc);
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        u64 t = 0;
+        for (int p = 0; p < 16; p++) t = add_p(t, sm[p][threadIdx.x]);
+        part[((size_t)blockIdx.x * ntab + tab) * 16 + threadIdx.x] = t;
+    }
+}
+// the scalar tables: part[blk][y] = sum over the block's rows of eq[row] mts[y][row]; finish: out[tab(y)][0] = the sum, coefficients 1..15 = 0
+__global__ void __launch_bounds__(256) k_cm_evals_scalar(const u64 *mts, size_t ldm, size_t n, const u64 *eq, u32 nt, u64 *part) {
+    u64 s[4] = {0, 0, 0, 0};
+    const u64 *y = mts + (size_t)blockIdx.y * ldm;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s[0] = add_p(s[0], mont_mul(eq[i], y[i]));
+    block_sum4(s, part + ((size_t)blockIdx.x * nt + blockIdx.y) * 4);
+}
+__global__ void __launch_bounds__(256) k_cm_evals_scalar_fin(const u64 *part, u32 chunks, u32 nt, CmTabList tabs, u64 *out) {
+    const u32 y = blockIdx.x, c = threadIdx.x & 15;
+    if (threadIdx.x >= 16) return;
+    u64 s = 0;
+    if (c == 0)
+        for (u32 ch = 0; ch < chunks; ch++) s = add_p(s, part[((size_t)ch * nt + y) * 4]);
+    out[(size_t)tabs.idx[y] * 16 + c] = s;
+}
+void launch_cm_evals_c(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, const CmTabList &dense, u32 ndense, const CmCompact &cc, u32 L, u32 nM, u32 per,
+                       u64 *part, u64 *out, hipStream_t s) {
+    const u32 ch = cm_eval_chunks(n);
+    hipLaunchKernelGGL(k_cm_evals_list, dim3(ch, ndense), dim3(256), 0, s, R, ldr, n, eq, ntab, dense, part);
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((size_t)ntab * 16, 32)), dim3(1024), 0, s, part, ch, (size_t)ntab * 16, ntab * 16, 0, out);   // (the compact slots: overwritten below)
+    for (u32 l = 0; l < L; l++) launch_wmono(cc.mtau[l], n, 1, eq, 1, part, out + (size_t)l * (per - 1) * 16, s);          // sum_row eq[row] X^e(row): the exponent histogram
+    if (nM) {
+        CmTabList tabs;
+        const u32 nt = L * nM, chs = eval_chunks(n);
+        for (u32 l = 0; l < L; l++) for (u32 q = 0; q < nM; q++) tabs.idx[l * nM + q] = (uint16_t)(l * (per - 1) + 3 + 4 * q);
+        hipLaunchKernelGGL(k_cm_evals_scalar, dim3(chs, nt), dim3(256), 0, s, cc.mts, cc.ldm, n, eq, nt, part);
+        hipLaunchKernelGGL(k_cm_evals_scalar_fin, dim3(nt), dim3(256), 0, s, part, chs, nt, tabs, out);
+    }
+}
 void launch_cm_evals(const u64 *R, size_t ldr, size_t n, const u64 *eq, u32 ntab, u64 *part, u64 *out, hipStream_t s) {
     const u32 ch = cm_eval_chunks(n);
     hipLaunchKernelGGL(k_cm_evals, dim3(ch, ntab), dim3(256), 0, s, R, ldr, n, eq, ntab, part);

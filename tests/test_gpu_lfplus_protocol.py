@@ -180,6 +180,23 @@ def test_cm_prove_unfused_fix_matches_oracle(L, nM, kappa, nvars, all_tables, mo
     _cm_prove_case(L, nM, kappa, nvars, False)
 
 
+@pytest.mark.parametrize("L,nM,kappa,nvars", [(1, 1, 2, 15), (2, 2, 2, 15), (3, 1, 3, 16), (3, 3, 2, 15)])
+def test_cm_prove_dense_tables_match_oracle(L, nM, kappa, nvars, monkeypatch):
+    """By default the batched sumcheckers read m_tau as exponent bytes and the M_q tau as scalars when every M_q has constant coefficients (k_cm_combine_c,
+    launch_cm_evals_c; the default form is test_cm_prove_matches_oracle above); LFPLUS_CM_DENSE=1 (read per call) materialises every table as ring elements."""
+    monkeypatch.setenv("LFPLUS_CM_DENSE", "1")
+    monkeypatch.delenv("LFPLUS_CM_FULL", raising=False)
+    monkeypatch.delenv("LFPLUS_CM_UNFUSED", raising=False)
+    _cm_prove_case(L, nM, kappa, nvars, False)
+
+
+def test_cm_prove_compact_tables_three_matrices(monkeypatch):
+    """the bench's shape in small: three instances, three constant-coefficient matrices (12 of 47 tables compact)"""
+    for key in ("LFPLUS_CM_DENSE", "LFPLUS_CM_FULL", "LFPLUS_CM_UNFUSED"):
+        monkeypatch.delenv(key, raising=False)
+    _cm_prove_case(3, 3, 2, 15, False)
+
+
 def _cm_prove_case(L, nM, kappa, nvars, ring_coeffs):
     n, k = 1 << nvars, 2
     dp = plus.DecompParameters.for_frog(k)
