@@ -13,6 +13,7 @@ SRC = os.path.join(ROOT, "latticefold_amd", "csrc")
 # meanings of the switches whose reading site carries no comment of its own
 EXTRA = {
     "LFPLUS_CACHE_GB": "cap of the per-device scratch cache destroyed LatticeFold+ contexts leave behind (default min(32 GB, 1/4 of HBM))",
+    "LFPLUS_CM_DENSE": "Cm::prove keeps every instance table as ring elements (no compact exponent-byte / scalar tables)",
     "LFPLUS_EVAL_CHUNKS": "blocks of the set check's evaluation passes",
     "LFPLUS_NO_ASYNC_CM_TABLES": "lfplus_cm_tables_async becomes a no-op (the instance tables of Cm::prove are built inside it)",
     "LFPLUS_NO_ASYNC_FROM_F": "lfplus_rg_from_f_async becomes a no-op (from_f runs inside lfplus_mlin)",
