@@ -630,8 +630,9 @@ def main():
             "config": {"workload": f"{wl.name}: {'GoldilocksRingNTT' if wl.ring == 'goldilocks' else 'BabyBearRingNTT'} R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
                                    f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world}: one fold stream, witness columns / table rows sharded by the high index bits (Ajtai commits, linearization and folding sumcheck rounds, v/u/eta evaluations), RCCL all-gather + modular sum per exchange" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
                        "alg_bytes_per_step": alg, "hbm_in_use_gib": round(mem_info.get("hbm_in_use_gib", 0.0), 2),
-                       "folded_witness": "the timed step leaves the folded witness on the device as int32 coefficient planes (what the next step reads); its NTT form f_0 and w_ccs, "
-                                         "which Witness::from_f builds inside prove (arith.rs:299-313), are materialised by lf_witness_get_f / _get_w_ccs on demand (0.1-0.2 ms, parity-checked through get_f)",
+                       "folded_witness": ("LF_LAZY_FROM_F=1: the timed step leaves the folded witness as int32 coefficient planes only; f_0 (NTT form) and w_ccs are built on demand" if os.environ.get("LF_LAZY_FROM_F") else
+                                          "Witness::from_f in full inside the timed step (arith.rs:299-313): the folded witness leaves the step as int32 coefficient planes (f_coeff, what the next step reads), "
+                                          "f_0 in NTT form and w_ccs, all three on the device (lf_witness_get_f / _get_w_ccs only download)"),
                        "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
             "roofline": roof,
             "phases_ms_per_step": {k: v / args.steps for k, v in phases_acc.items()},

@@ -871,6 +871,7 @@ int BbCtx::witness_get_f(const lf_witness *w, uint64_t *out) {
     C *c = p;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    if (w->f_ntt) return down_ring(c, (const fe *)w->f_ntt, w->N, out);      // built inside the fold step that produced this witness
     fe *d, *e;
     RET(c->tbuf("io_c", w->N * RE, &d));
     RET(c->tbuf("io_b", w->N * RE, &e));
@@ -883,6 +884,7 @@ int BbCtx::witness_get_w_ccs(const lf_witness *w, uint64_t *out) {
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
+    if (w->w_ccs && w->w_bytes == (size_t)c->P.wit_len * RE * sizeof(fe)) return down_ring(c, (const fe *)w->w_ccs, c->P.wit_len, out);
     fe *e;
     RET(c->tbuf("io_b", (size_t)c->P.wit_len * RE, &e));
     launch_recompose_crt(c->dev, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->stream());
@@ -1879,6 +1881,15 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     int32_t *npl;
     RET(lf_planes_alloc(c->owner, N * RE * 4, &npl));
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
+    // Witness::from_f (arith.rs:299-313): f = CRT(f_coeff) and w_ccs = CRT(recompose(f_coeff, B, L)) of the folded witness, behind compute_f_0 on the same stream
+    fe *nf = nullptr, *nw = nullptr;
+    const size_t nf_bytes = N * RE * sizeof(fe), nw_bytes = (size_t)P.wit_len * RE * sizeof(fe);
+    if (!c->tn.lazy_from_f) {
+        RET(lf_planes_alloc(c->owner, nf_bytes, (int32_t **)&nf));
+        RET(lf_planes_alloc(c->owner, nw_bytes, (int32_t **)&nw));
+        launch_recompose_crt(c->dev, npl, N, (u32)N, 1, P.B, 1, 0, nf, N, 0, c->stream());
+        launch_recompose_crt(c->dev, npl, N, P.wit_len, P.L, P.B, 1, 0, nw, P.wit_len, 0, c->stream());
+    }
     BB_MARK("  eta absorbed, rho drawn, fold_witness enqueued");
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
@@ -1932,6 +1943,7 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     BB_MARK("  folded instance on the host");
     HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c->owner, npl, N, lf_ctx_device(c->owner), N * RE * 4};
+    if (nf) { (*w_out)->f_ntt = (uint64_t *)nf; (*w_out)->f_bytes = nf_bytes; (*w_out)->w_ccs = (uint64_t *)nw; (*w_out)->w_bytes = nw_bytes; }
     c->ev_end(ph);
     return LF_OK;
 }

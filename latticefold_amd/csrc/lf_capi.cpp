@@ -1499,6 +1499,7 @@ int lf_witness_get_f(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     if (c->bb) return c->bb->witness_get_f(w, out);
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    if (w->f_ntt) return down_ring(c, w->f_ntt, w->N, out);      // built inside the fold step that produced this witness
     u64 *d, *e;
     RET(c->tbuf("io_c", w->N * 24, &d));
     RET(c->tbuf("io_b", w->N * 24, &e));
@@ -1513,6 +1514,7 @@ int lf_witness_get_w_ccs(lf_ctx *c, const lf_witness *w, uint64_t *out) {
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_ccs) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
+    if (w->w_ccs && w->w_bytes == (size_t)c->P.wit_len * 24 * 8) return down_ring(c, w->w_ccs, c->P.wit_len, out);
     u64 *e;
     RET(c->tbuf("io_b", (size_t)c->P.wit_len * 24, &e));
     launch_recompose_crt(c->dcrt, w->planes, w->N, c->P.wit_len, c->P.L, c->P.B, 1, 0, e, c->P.wit_len, 0, c->stream());
@@ -1559,7 +1561,7 @@ static void planes_release_dev(int device, size_t bytes, int32_t *p) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
-        if (g_pool.size() < 3) { g_pool.push_back({device, bytes, p}); return; }
+        if (g_pool.size() < 9) { g_pool.push_back({device, bytes, p}); return; }   // planes, f and w_ccs of up to three witnesses
     }
     (void)hipFree(p);
 }
@@ -1575,6 +1577,8 @@ void lf_witness_free(lf_witness *w) {
     // the context may be gone already (callers close contexts before their witnesses): use only what the handle itself carries
     (void)hipSetDevice(w->device);
     planes_release_dev(w->device, w->plane_bytes, w->planes);
+    planes_release_dev(w->device, w->f_bytes, (int32_t *)w->f_ntt);
+    planes_release_dev(w->device, w->w_bytes, (int32_t *)w->w_ccs);
     delete w;
 }
 
@@ -3146,6 +3150,15 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     RET(lf_planes_alloc(c, N * 24 * 4, &npl));
     LF_TRACE(c, "theta/eta");
     launch_fold_witness(S[0].planes, S[1].planes, N, K, d_rho, npl, c->stream());
+    // Witness::from_f (arith.rs:299-313): f = CRT(f_coeff) and w_ccs = CRT(recompose(f_coeff, B, L)) of the folded witness, behind compute_f_0 on the same stream
+    u64 *nf = nullptr, *nw = nullptr;
+    const size_t nf_bytes = N * 24 * 8, nw_bytes = (size_t)P.wit_len * 24 * 8;
+    if (!c->tn.lazy_from_f) {
+        RET(lf_planes_alloc(c, nf_bytes, (int32_t **)&nf));
+        RET(lf_planes_alloc(c, nw_bytes, (int32_t **)&nw));
+        launch_recompose_crt(c->dcrt, npl, N, (u32)N, 1, P.B, 1, 0, nf, N, 0, c->stream());
+        launch_recompose_crt(c->dcrt, npl, N, P.wit_len, P.L, P.B, 1, 0, nw, P.wit_len, 0, c->stream());
+    }
     LF_TRACE(c, "fold_witness");
     TL_MARK("  eta absorbed, rho drawn, fold_witness enqueued");
     pf_trigger(c, 50);
@@ -3194,6 +3207,7 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     TL_MARK("  folded instance on the host");
     HIPCHK(hipStreamSynchronize(c->stream()));
     *w_out = new lf_witness{c, npl, N, c->device, N * 24 * 4};
+    if (nf) { (*w_out)->f_ntt = nf; (*w_out)->f_bytes = nf_bytes; (*w_out)->w_ccs = nw; (*w_out)->w_bytes = nw_bytes; }
     TL_MARK(" rho + fold_witness");
     c->ev_end(ph);
     return LF_OK;

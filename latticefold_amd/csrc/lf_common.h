@@ -71,6 +71,12 @@ struct lf_witness {
     int device;          // device the planes live on
     size_t plane_bytes;  // size of the planes allocation (pool key)
     uint64_t id = lf_next_witness_id();
+    // Witness::from_f (arith.rs:299-313) also builds f (NTT form) and w_ccs: a fold step materialises both behind compute_f_0 (LF_LAZY_FROM_F=1: on demand, in
+    // lf_witness_get_f / _get_w_ccs); device buffers from the same pool as the planes, null when not materialised
+    uint64_t *f_ntt = nullptr;
+    size_t f_bytes = 0;
+    uint64_t *w_ccs = nullptr;
+    size_t w_bytes = 0;
 };
 
 // Device buffers of witness planes are recycled through a small per-context pool: a fold step produces one folded witness and
@@ -128,6 +134,7 @@ struct Tunables {
     size_t r5_min = 8192;            // LF_FOLD_R5_MIN: pairs of round 5 from which it runs on the planes (mode 7; measured: 2^16 rows slower, 2^20 faster)
     size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
     long lin_blocks = -1;            // -1: automatic
+    bool lazy_from_f = false;        // LF_LAZY_FROM_F: a fold step leaves the folded witness as coefficient planes only; f (NTT form) and w_ccs are built by lf_witness_get_f / _get_w_ccs
     int pf_at = 0;                   // LF_PF_AT: the first point at or after which a fold step enqueues the prefetch of the next right side (lf_prefetch_instance): 0 when its
                                      // linearization is done (the host's absorb chain starts, the GPU has only the right evaluations left), 1 after the right evaluations,
                                      // 2 when the two lanes have joined, 3 after the folding challenges, 10 + r after round r of the folding sumcheck, 40 after the sumcheck,
@@ -172,6 +179,7 @@ struct Tunables {
         t.coef_valu = getenv("LF_COEF_VALU") != nullptr;
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
         t.i8_pair = getenv("LF_I8_PAIR") != nullptr;
+        t.lazy_from_f = getenv("LF_LAZY_FROM_F") != nullptr;
         t.commits_first = getenv("LF_COMMITS_FIRST") != nullptr;
         if (const char *e = getenv("LF_ZR_POS")) t.zr_pos = atoi(e);
         t.evals_one_stage = getenv("LF_EVALS_TWO_STAGES") == nullptr;

@@ -1,13 +1,24 @@
 // lf_poseidon_simd.cc -- see lf_poseidon_simd.h.  Plain host C++ (compiled with the AVX-512 IFMA target for this file only;
 // every entry point is reached through the run-time check psimd::supported()).
 //
-// Arithmetic: a 64-bit word a = a0 + 2^52 a1 (a1 < 2^12).  vpmadd52{l,h}uq multiply the low 52 bits of their operands, so the
-// un-split word serves as a0.  A product a*b is the sum of
-//      weight 2^0   : lo52(a0 b0)
-//      weight 2^52  : hi52(a0 b0) + lo52(a0 b1) + lo52(a1 b0)
-//      weight 2^104 : hi52(a0 b1) + hi52(a1 b0) + lo52(a1 b1)
-// and sums of up to 24 products stay below 2^60 per weight class: seven IFMAs per product, no carry handling.  The value
-// W0 + 2^52 W52 + 2^104 W104 is reduced once with 2^64 = 2^32 - 1, 2^96 = -1 (so 2^104 = -2^8) mod p.
+// Arithmetic.  vpmadd52{l,h}uq multiply the low 52 bits of their operands.  A product a * b with a = a0 + 2^52 a1 (a1 < 2^13,
+// the un-split word serves as a0) and b = bl + 2^32 bh (32-bit halves) is
+//      a * bl = lo52(a0 bl) + 2^52 (hi52(a0 bl) + a1 bl)          (a1 bl < 2^46: its low part is the whole product)
+// and the same for bh at weight 2^32: SIX IFMAs, four weight classes
+//      value = A0 + 2^52 A52 + 2^32 (B0 + 2^52 B52),
+// and sums of up to 46 products (+ a seed) stay below 2^58 (A0, B0) / 2^51 (A52, B52): no carry handling, one reduction per
+// output word.  Measured on the EPYC 9575F of the GPU box (profiles/r05_host_poseidon.txt): IFMA issues 2 per cycle, and the
+// permutation was bound by the LATENCY of what surrounds the products -- compare -> mask -> masked-add carry chains in the
+// reduction (55 cycles per dependent product in the S-box layers) and the scalar word-0 chain of the partial rounds.  Hence:
+//  * a field element lives as a PAIR (u, v), value = u + 2^32 v, u < 2^33, v < 2^32 + 137 (not canonical, not even below 2^64).
+//    The reduction (reduce_uv) cuts the four classes into 32-bit chunks c_k of weight 2^(32k), folds them with
+//    2^64 = 2^32 - 1, 2^96 = -1 (mod p) into U + 2^32 W, adds a multiple of p that makes both positive, and
+//    propagates two small carries with shifts: 27 one-cycle operations, dependency depth 11, no compares.  (u, v) is exactly
+//    the multiplier form (bl, bh) of the next product; the multiplicand form costs five more operations (prep_a);
+//  * the partial rounds: scalar chain of word 0 with ONE product and one reduction per round next to the S-box; everything
+//    else of round r+1's input (D, constants, sum_{i<r} G X_i) is prepared off the chain -- the triangle of cross terms is
+//    accumulated by the vector unit (E, in memory, one column per round together with the closing map's column F) and read
+//    back one lane per round.
 #include "lf_poseidon_simd.h"
 
 #include <immintrin.h>
@@ -28,12 +39,15 @@ constexpr int NX = W + RP;   // columns of the closing map: 24 state words + 22 
 struct Tables {
     alignas(64) u64 mds0[W][W], mds1[W][W];     // [j][i] = M[i][j] and its top 12 bits
     alignas(64) u64 arkf[RF][W];                // constants of the full rounds
+    alignas(64) u64 ark0[RF][W], ark1[RF][W];   // ... as the seed of the mat-vec before them: low 52 bits / top 12 bits
     // partial rounds in scalar form (see permute): D = SX x, s0_{r+1} = D_r + K_r + sum_{i<=r} G[r][i] X_i,
     // closing map  state' = FIN [x ; X] + FK
     alignas(64) u64 sx0[W][W], sx1[W][W];       // [j][r] = coefficient of state word j in D_r (column 0 and lanes >= 22 zero)
     alignas(64) u64 fin0[NX][W], fin1[NX][W];   // [j][i]: columns 0..23 state words, 24..45 the S-box outputs X_r; lane 0 zero
-    alignas(64) u64 fk0[W], fk1[W];             // constant of the closing map (52-bit / top-12-bit halves)
+    alignas(64) u64 fk0[W], fk1[W];             // constant of the closing map (52-bit / top-12-bit halves), + the constants of the full round behind it
+    alignas(64) u64 e0[RP][W], e1[RP][W];       // [r][q] = G[q][r] for q >= r + 2 (the cross terms the vector unit accumulates), else 0
     u64 cst0[RP], K[RP], G[RP][RP];
+    u64 Kc[RP];                                 // K_q + cst0[q + 1] (the next round's constant of word 0 rides along)
 };
 Tables T;
 
@@ -68,46 +82,52 @@ inline u64 add_loose(u64 a, u64 b) {   // a below 2^64, b canonical; result belo
     u64 c = __builtin_add_overflow(a, b, &r);
     return r + (EPS & (0 - c));
 }
-inline u64 submod(u64 a, u64 b) { return a - b + (P & (0 - (u64)(a < b))); }
 inline u64 sbox_loose(u64 x) {
     u64 x2 = mul_loose(x, x), x3 = mul_loose(x2, x), x4 = mul_loose(x2, x2);
     return mul_loose(x4, x3);
 }
 
-// W0 (< 2^60) + 2^52 W52 (W52 < 2^60) - 2^8 W104 (W104 < 2^30)  ->  canonical residue
-inline V reduce(V w0, V w52, V w104) {
-    const V eps = _mm512_set1_epi64((long long)EPS), pp = _mm512_set1_epi64((long long)P), one = _mm512_set1_epi64(1);
-    V sh = _mm512_slli_epi64(w52, 52);
-    V lo = _mm512_add_epi64(w0, sh);
-    __mmask8 c1 = _mm512_cmplt_epu64_mask(lo, sh);
-    V hi = _mm512_srli_epi64(w52, 12);
-    hi = _mm512_mask_add_epi64(hi, c1, hi, one);            // < 2^48 + 1
-    V hh = _mm512_srli_epi64(hi, 32), hl = _mm512_and_si512(hi, eps);
-    __mmask8 b = _mm512_cmplt_epu64_mask(lo, hh);
-    V t0 = _mm512_sub_epi64(lo, hh);
-    t0 = _mm512_mask_sub_epi64(t0, b, t0, eps);             // borrow: the wrap added 2^64 = eps
-    V t1 = _mm512_sub_epi64(_mm512_slli_epi64(hl, 32), hl); // hl * (2^32 - 1)
-    V r = _mm512_add_epi64(t0, t1);
-    __mmask8 c = _mm512_cmplt_epu64_mask(r, t1);
-    r = _mm512_mask_add_epi64(r, c, r, eps);
-    V s = _mm512_slli_epi64(w104, 8);
-    __mmask8 b2 = _mm512_cmplt_epu64_mask(r, s);
-    r = _mm512_sub_epi64(r, s);
-    r = _mm512_mask_sub_epi64(r, b2, r, eps);
-    __mmask8 g = _mm512_cmpge_epu64_mask(r, pp);
-    return _mm512_mask_sub_epi64(r, g, r, pp);
+struct UV { V u, v; };   // value = u + 2^32 v  (u < 2^33, v < 2^32 + 137)
+
+inline V vsrl(V a, int n) { return _mm512_srli_epi64(a, n); }
+inline V vsll(V a, int n) { return _mm512_slli_epi64(a, n); }
+inline V vadd64(V a, V b) { return _mm512_add_epi64(a, b); }
+inline V vsub64(V a, V b) { return _mm512_sub_epi64(a, b); }
+inline V vand(V a, V b) { return _mm512_and_si512(a, b); }
+
+// A0 + 2^52 A52 + 2^32 (B0 + 2^52 B52)  (A0, B0 < 2^58, A52, B52 < 2^51)  ->  (u, v), u in [2^32 - 137, 2^33), v < 2^32 + 137.
+// 27 operations, dependency depth 11.  Chunks of weight 2^0, 2^32, 2^64, 2^96 (the upper ones are left up to 39 bits wide):
+//   c0 = A0 mod 2^32,  c1 = (A0 >> 32) + 2^20 (A52 mod 2^12) + (B0 mod 2^32),  c2 = (A52 >> 12) + (B0 >> 32) + 2^20 (B52 mod 2^12),  c3 = B52 >> 12
+// and c0 + 2^32 c1 + 2^64 c2 + 2^96 c3 = (c0 - c2 - c3) + 2^32 (c1 + c2)  (mod p).  Adding p = (2^41 + 1) + 2^32 (2^32 - 513) makes both
+// parts positive; U = c0 - c2 - c3 + 2^41 + 1 < 2^42 passes its upper bits to W, W's upper bits wh <= 137 come back through
+// 2^64 wh = 2^32 wh - wh: - wh to u (which borrows 2^32 from v so that it cannot go negative), + wh to v.
+inline UV reduce_uv(V A0, V A52, V B0, V B52) {
+    const V eps = _mm512_set1_epi64((long long)EPS), m12 = _mm512_set1_epi64(0xfff);
+    const V biasU = _mm512_set1_epi64((1LL << 41) + 1), biasW = _mm512_set1_epi64((1LL << 32) - 513);
+    const V two32 = _mm512_set1_epi64(1LL << 32), one = _mm512_set1_epi64(1);
+    V c1 = vadd64(vadd64(vsrl(A0, 32), vsll(vand(A52, m12), 20)), vand(B0, eps));
+    V c2 = vadd64(vadd64(vsrl(A52, 12), vsrl(B0, 32)), vsll(vand(B52, m12), 20));
+    V c3 = vsrl(B52, 12);
+    V U = vsub64(vsub64(vadd64(vand(A0, eps), biasU), c2), c3);    // (2^41 - 2^40.01, 2^41 + 2^32 + 1)
+    V W1 = vadd64(vadd64(vadd64(c1, biasW), c2), vsrl(U, 32));     // [2^32 - 259, 2^39.1)
+    V wh = vsrl(W1, 32);                                            // 0 .. 137 (0 only with W1 >= 2^32 - 259)
+    UV r;
+    r.u = vsub64(_mm512_ternarylogic_epi64(U, eps, two32, 0xEA), wh);   // (U mod 2^32) + 2^32 - wh
+    r.v = vadd64(vand(W1, eps), vsub64(wh, one));                       // (W1 mod 2^32) + wh - 1
+    return r;
 }
-inline V vmul(V a, V b) {
+// multiplicand form of (u, v): the word whose low 52 bits are the value's, and the value's bits from 52 up
+inline void prep_a(const UV &x, V &wa, V &a1) {
+    wa = vadd64(x.u, vsll(x.v, 32));
+    a1 = vsrl(vadd64(x.v, vsrl(x.u, 32)), 20);
+}
+inline UV vmul(V wa, V a1, const UV &b) {
     const V z = _mm512_setzero_si512();
-    V a1 = _mm512_srli_epi64(a, 52), b1 = _mm512_srli_epi64(b, 52);
-    V w0 = _mm512_madd52lo_epu64(z, a, b);
-    V w52 = _mm512_madd52hi_epu64(z, a, b);
-    V w52b = _mm512_madd52lo_epu64(z, a, b1);
-    V w52c = _mm512_madd52lo_epu64(z, a1, b);
-    V w104 = _mm512_madd52hi_epu64(z, a, b1);
-    V w104b = _mm512_madd52hi_epu64(z, a1, b);
-    V w104c = _mm512_madd52lo_epu64(z, a1, b1);
-    return reduce(w0, _mm512_add_epi64(_mm512_add_epi64(w52, w52b), w52c), _mm512_add_epi64(_mm512_add_epi64(w104, w104b), w104c));
+    V a0 = _mm512_madd52lo_epu64(z, wa, b.u);
+    V a52 = _mm512_madd52lo_epu64(_mm512_madd52hi_epu64(z, wa, b.u), a1, b.u);
+    V b0 = _mm512_madd52lo_epu64(z, wa, b.v);
+    V b52 = _mm512_madd52lo_epu64(_mm512_madd52hi_epu64(z, wa, b.v), a1, b.v);
+    return reduce_uv(a0, a52, b0, b52);
 }
 inline V vadd(V a, V b) {   // canonical + canonical -> canonical
     const V eps = _mm512_set1_epi64((long long)EPS), pp = _mm512_set1_epi64((long long)P);
@@ -117,56 +137,98 @@ inline V vadd(V a, V b) {   // canonical + canonical -> canonical
     r = _mm512_mask_add_epi64(r, c, r, eps);                // wrapped: + 2^64 - p
     return _mm512_mask_sub_epi64(r, (__mmask8)(g & ~c), r, pp);
 }
+// (u, v) -> canonical word
+inline V to_canon(const UV &x) {
+    const V eps = _mm512_set1_epi64((long long)EPS), pp = _mm512_set1_epi64((long long)P);
+    V vv = vadd64(x.v, vsrl(x.u, 32));                      // value = (u mod 2^32) + 2^32 vv, vv < 2^32 + 9
+    V lo = vadd64(vand(x.u, eps), vsll(vv, 32));            // mod 2^64; the part above is (vv >> 32) 2^64 = (vv >> 32) eps
+    V t = _mm512_mullo_epi64(vsrl(vv, 32), eps);            // 0 or eps (vv >> 32 is 0 or 1: one multiply is cheaper to write than a mask here)
+    V r = vadd64(lo, t);
+    __mmask8 c = _mm512_cmplt_epu64_mask(r, t);
+    r = _mm512_mask_add_epi64(r, c, r, eps);
+    __mmask8 g = _mm512_cmpge_epu64_mask(r, pp);
+    return _mm512_mask_sub_epi64(r, g, r, pp);
+}
 
-// out = sum_j col_j * x_j (+ seed) for ncols columns given column-wise (t0[j] = column j, t1[j] = its top 12 bits);
-// xl/xh = the words x_j and their top 12 bits
-inline void matvec_n(const u64 (*t0)[W], const u64 (*t1)[W], int ncols, const u64 *xl, const u64 *xh, const V *seed0, const V *seed52, V out[3]) {
-    const V z = _mm512_setzero_si512();
-    V a0[3], a52[3], a52b[3], a52c[3], a104[3], a104b[3], a104c[3];
-    for (int g = 0; g < 3; g++) {
-        a0[g] = seed0 ? seed0[g] : z;
-        a52[g] = seed52 ? seed52[g] : z;
-        a52b[g] = a52c[g] = a104[g] = a104b[g] = a104c[g] = z;
-    }
-    for (int j = 0; j < ncols; j++) {
-        V b = _mm512_set1_epi64((long long)xl[j]), b1 = _mm512_set1_epi64((long long)xh[j]);
-#pragma GCC unroll 3
+// lazy accumulators of a mat-vec with 24 output words: six classes x three registers
+struct Acc {
+    V a0[3], a52[3], a52b[3], b0[3], b52[3], b52b[3];
+    inline void init(const u64 *seed0, const u64 *seed52) {   // seed = seed0 + 2^52 seed52 (both given per output word), or none
+        const V z = _mm512_setzero_si512();
         for (int g = 0; g < 3; g++) {
-            V m = _mm512_load_si512((const void *)(t0[j] + 8 * g)), m1 = _mm512_load_si512((const void *)(t1[j] + 8 * g));
-            a0[g] = _mm512_madd52lo_epu64(a0[g], m, b);
-            a52[g] = _mm512_madd52hi_epu64(a52[g], m, b);
-            a52b[g] = _mm512_madd52lo_epu64(a52b[g], m, b1);
-            a52c[g] = _mm512_madd52lo_epu64(a52c[g], m1, b);
-            a104[g] = _mm512_madd52hi_epu64(a104[g], m, b1);
-            a104b[g] = _mm512_madd52hi_epu64(a104b[g], m1, b);
-            a104c[g] = _mm512_madd52lo_epu64(a104c[g], m1, b1);
+            a0[g] = seed0 ? _mm512_load_si512((const void *)(seed0 + 8 * g)) : z;
+            a52[g] = seed52 ? _mm512_load_si512((const void *)(seed52 + 8 * g)) : z;
+            a52b[g] = b0[g] = b52[g] = b52b[g] = z;
         }
     }
-    for (int g = 0; g < 3; g++)
-        out[g] = reduce(a0[g], _mm512_add_epi64(_mm512_add_epi64(a52[g], a52b[g]), a52c[g]),
-                        _mm512_add_epi64(_mm512_add_epi64(a104[g], a104b[g]), a104c[g]));
-}
-inline void split_words(const V x[3], u64 *xl, u64 *xh) {
+    // += column * x; col0 = the column's words (their low 52 bits are used), col1 = their top 12 bits; (xu, xv) = x
+    inline void col(const u64 *col0, const u64 *col1, u64 xu, u64 xv) {
+        V bl = _mm512_set1_epi64((long long)xu), bh = _mm512_set1_epi64((long long)xv);
+#pragma GCC unroll 3
+        for (int g = 0; g < 3; g++) {
+            V m = _mm512_load_si512((const void *)(col0 + 8 * g)), m1 = _mm512_load_si512((const void *)(col1 + 8 * g));
+            a0[g] = _mm512_madd52lo_epu64(a0[g], m, bl);
+            a52[g] = _mm512_madd52hi_epu64(a52[g], m, bl);
+            a52b[g] = _mm512_madd52lo_epu64(a52b[g], m1, bl);
+            b0[g] = _mm512_madd52lo_epu64(b0[g], m, bh);
+            b52[g] = _mm512_madd52hi_epu64(b52[g], m, bh);
+            b52b[g] = _mm512_madd52lo_epu64(b52b[g], m1, bh);
+        }
+    }
+    inline void finish(UV out[3]) const {
+        for (int g = 0; g < 3; g++) out[g] = reduce_uv(a0[g], vadd64(a52[g], a52b[g]), b0[g], vadd64(b52[g], b52b[g]));
+    }
+};
+// the same in memory, four classes (the two parts of the 2^52 classes share an accumulator): the cross terms of the partial rounds
+struct AccMem {
+    alignas(64) u64 a0[W], a52[W], b0[W], b52[W];
+    inline void clear() { memset(this, 0, sizeof(*this)); }
+    inline void col(const u64 *col0, const u64 *col1, u64 xu, u64 xv, int g0) {
+        V bl = _mm512_set1_epi64((long long)xu), bh = _mm512_set1_epi64((long long)xv);
+        for (int g = g0; g < 3; g++) {
+            V m = _mm512_load_si512((const void *)(col0 + 8 * g)), m1 = _mm512_load_si512((const void *)(col1 + 8 * g));
+            V x0 = _mm512_load_si512((const void *)(a0 + 8 * g)), x52 = _mm512_load_si512((const void *)(a52 + 8 * g));
+            V y0 = _mm512_load_si512((const void *)(b0 + 8 * g)), y52 = _mm512_load_si512((const void *)(b52 + 8 * g));
+            x0 = _mm512_madd52lo_epu64(x0, m, bl);
+            x52 = _mm512_madd52lo_epu64(_mm512_madd52hi_epu64(x52, m, bl), m1, bl);
+            y0 = _mm512_madd52lo_epu64(y0, m, bh);
+            y52 = _mm512_madd52lo_epu64(_mm512_madd52hi_epu64(y52, m, bh), m1, bh);
+            _mm512_store_si512((void *)(a0 + 8 * g), x0);
+            _mm512_store_si512((void *)(a52 + 8 * g), x52);
+            _mm512_store_si512((void *)(b0 + 8 * g), y0);
+            _mm512_store_si512((void *)(b52 + 8 * g), y52);
+        }
+    }
+};
+inline void store_uv(const UV x[3], u64 *xu, u64 *xv) {
     for (int g = 0; g < 3; g++) {
-        _mm512_store_si512((void *)(xl + 8 * g), x[g]);
-        _mm512_store_si512((void *)(xh + 8 * g), _mm512_srli_epi64(x[g], 52));
+        _mm512_store_si512((void *)(xu + 8 * g), x[g].u);
+        _mm512_store_si512((void *)(xv + 8 * g), x[g].v);
     }
 }
-// x <- M x for a 24 x 24 matrix
-inline void matvec(const u64 (*t0)[W], const u64 (*t1)[W], V x[3]) {
-    alignas(64) u64 xl[W], xh[W];
-    split_words(x, xl, xh);
-    matvec_n(t0, t1, W, xl, xh, nullptr, nullptr, x);
+// x <- M x (+ seed) for a 24 x 24 matrix
+inline void matvec(const u64 (*t0)[W], const u64 (*t1)[W], UV x[3], const u64 *seed0, const u64 *seed52) {
+    alignas(64) u64 xu[W], xv[W];
+    store_uv(x, xu, xv);
+    Acc A;
+    A.init(seed0, seed52);
+    for (int j = 0; j < W; j++) A.col(t0[j], t1[j], xu[j], xv[j]);
+    A.finish(x);
 }
 
-inline void full_round(V x[3], const u64 *ark) {
-    V t[3], x2[3], x3[3], x4[3];
-    for (int g = 0; g < 3; g++) t[g] = vadd(x[g], _mm512_load_si512((const void *)(ark + 8 * g)));
-    for (int g = 0; g < 3; g++) x2[g] = vmul(t[g], t[g]);
-    for (int g = 0; g < 3; g++) x3[g] = vmul(x2[g], t[g]);
-    for (int g = 0; g < 3; g++) x4[g] = vmul(x2[g], x2[g]);
-    for (int g = 0; g < 3; g++) x[g] = vmul(x4[g], x3[g]);
-    matvec(T.mds0, T.mds1, x);
+// S-box layer and MDS of a full round; the round constants were added by the producer of x (as the seed of its mat-vec), the
+// constants of the NEXT full round are this mat-vec's seed
+inline void full_round(UV x[3], const u64 *seed0, const u64 *seed52) {
+    UV x2[3], x3[3], x4[3];
+    V wa[3], a1[3];
+    for (int g = 0; g < 3; g++) prep_a(x[g], wa[g], a1[g]);
+    for (int g = 0; g < 3; g++) x2[g] = vmul(wa[g], a1[g], x[g]);
+    for (int g = 0; g < 3; g++) prep_a(x2[g], wa[g], a1[g]);
+    for (int g = 0; g < 3; g++) x3[g] = vmul(wa[g], a1[g], x[g]);
+    for (int g = 0; g < 3; g++) x4[g] = vmul(wa[g], a1[g], x2[g]);
+    for (int g = 0; g < 3; g++) prep_a(x4[g], wa[g], a1[g]);
+    for (int g = 0; g < 3; g++) x[g] = vmul(wa[g], a1[g], x3[g]);
+    matvec(T.mds0, T.mds1, x, seed0, seed52);
 }
 }  // namespace
 
@@ -185,6 +247,7 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
     for (int r = 0; r < RF; r++) {
         int src = r < RF / 2 ? r : RP + r;
         memcpy(T.arkf[r], ark + (size_t)src * W, W * 8);
+        for (int i = 0; i < W; i++) { T.ark0[r][i] = T.arkf[r][i] & ((1ULL << 52) - 1); T.ark1[r][i] = T.arkf[r][i] >> 52; }
     }
     // Symbolic run of the 22 sparse partial rounds.  Every state word 1..23 is an affine form over
     //   [ x_1..x_23 (words on entry) | X_0..X_21 (S-box outputs of word 0) | 1 ]
@@ -220,57 +283,74 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
             for (int k = 0; k < n; k++) a = addmod(a, mulmod(post[i * n + k], form[k][b]));
             if (b < n) { T.fin0[1 + b][1 + i] = a; T.fin1[1 + b][1 + i] = a >> 52; }
             else if (b < n + RP) { T.fin0[W + (b - n)][1 + i] = a; T.fin1[W + (b - n)][1 + i] = a >> 52; }
-            else { T.fk0[1 + i] = a & ((1ULL << 52) - 1); T.fk1[1 + i] = a >> 52; }
+            else {   // the closing map's constant plus the constants of the full round that follows it
+                a = addmod(a, T.arkf[RF / 2][1 + i]);
+                T.fk0[1 + i] = a & ((1ULL << 52) - 1); T.fk1[1 + i] = a >> 52;
+            }
         }
+    for (int r = 0; r < RP; r++) {
+        T.Kc[r] = r + 1 < RP ? addmod(T.K[r], T.cst0[r + 1]) : T.K[r];
+        for (int q = r + 2; q < RP; q++) { T.e0[r][q] = T.G[q][r]; T.e1[r][q] = T.G[q][r] >> 52; }
+    }
 }
 
 void permute(u64 st[24]) {
-    V x[3];
-    for (int g = 0; g < 3; g++) x[g] = _mm512_loadu_si512((const void *)(st + 8 * g));
-    for (int r = 0; r < RF / 2; r++) full_round(x, T.arkf[r]);
-    // Partial rounds (tables: see build).  The only sequential part is the scalar chain of word 0: three dependent multiplies
-    // of the S-box and one more per round; the contributions of X_r to the later rounds are pushed into their lazy
-    // 192-bit accumulators off the critical path.
-    alignas(64) u64 xl[NX], xh[NX], d[W];
-    split_words(x, xl, xh);
-    V dv[3];
-    matvec_n(T.sx0, T.sx1, W, xl, xh, nullptr, nullptr, dv);
-    for (int g = 0; g < 3; g++) _mm512_store_si512((void *)(d + 8 * g), dv[g]);
-    u64 lo[RP], mid[RP], hi[RP];
-    for (int r = 0; r < RP; r++) {
-        u128 t = (u128)d[r] + T.K[r];
-        lo[r] = (u64)t; mid[r] = (u64)(t >> 64); hi[r] = 0;
-    }
-    u64 s0 = xl[0];
-    for (int r = 0; r < RP; r++) {
-        u64 X = sbox_loose(add_loose(s0, T.cst0[r]));
-        xl[W + r] = X; xh[W + r] = X >> 52;
-        {   // this round's own term closes s0_{r+1}
-            u128 pr = (u128)T.G[r][r] * X;
-            u128 t = (u128)lo[r] + (u64)pr;
-            u128 t2 = (u128)mid[r] + (u64)(pr >> 64) + (u64)(t >> 64);
-            u64 h = hi[r] + (u64)(t2 >> 64);
-            u64 v = reduce128_loose((u64)t, (u64)t2), sh = h << 32;   // minus h * 2^32: 2^128 = -2^32 (mod p)
-            s0 = v - sh - (EPS & (0 - (u64)(v < sh)));                 // borrow: the wrap added 2^64 = eps
-        }
-        for (int q = r + 1; q < RP; q++) {
-            u128 pr = (u128)T.G[q][r] * X;
-            u128 t = (u128)lo[q] + (u64)pr;
-            lo[q] = (u64)t;
-            t = (u128)mid[q] + (u64)(pr >> 64) + (u64)(t >> 64);
-            mid[q] = (u64)t;
-            hi[q] += (u64)(t >> 64);
-        }
-    }
-    V seed0[3], seed52[3];
+    const V eps = _mm512_set1_epi64((long long)EPS);
+    UV x[3];
     for (int g = 0; g < 3; g++) {
-        seed0[g] = _mm512_load_si512((const void *)(T.fk0 + 8 * g));
-        seed52[g] = _mm512_load_si512((const void *)(T.fk1 + 8 * g));
+        V w = vadd(_mm512_loadu_si512((const void *)(st + 8 * g)), _mm512_load_si512((const void *)(T.arkf[0] + 8 * g)));
+        x[g].u = vand(w, eps);
+        x[g].v = vsrl(w, 32);
     }
-    matvec_n(T.fin0, T.fin1, NX, xl, xh, seed0, seed52, x);      // lane 0 of every column is zero
-    x[0] = _mm512_mask_set1_epi64(x[0], 0x01, (long long)canon(s0));
-    for (int r = RF / 2; r < RF; r++) full_round(x, T.arkf[r]);
-    for (int g = 0; g < 3; g++) _mm512_storeu_si512((void *)(st + 8 * g), x[g]);
+    for (int r = 0; r < RF / 2; r++) full_round(x, r + 1 < RF / 2 ? T.ark0[r + 1] : nullptr, r + 1 < RF / 2 ? T.ark1[r + 1] : nullptr);
+    // Partial rounds (tables: see build):  X_r = sbox(s_r),  s_{r+1} = base_r + G[r][r] X_r  on the scalar chain, with
+    //   base_r = D_r + K_r + cst0_{r+1} + sum_{i <= r-2} G[r][i] X_i + G[r][r-1] X_{r-1}
+    // prepared while the S-box of round r runs: the sum over i <= r-2 is lane r of the vector accumulator E (one column per
+    // round, issued a round before it is read), the last cross term one scalar product.  X_r's column of the closing map is
+    // accumulated in the same place (F).
+    alignas(64) u64 xu[W], xv[W], du[W], dv[W];
+    store_uv(x, xu, xv);
+    {
+        Acc D;
+        D.init(nullptr, nullptr);
+        for (int j = 0; j < W; j++) D.col(T.sx0[j], T.sx1[j], xu[j], xv[j]);
+        UV d[3];
+        D.finish(d);
+        store_uv(d, du, dv);
+    }
+    Acc F;
+    F.init(T.fk0, T.fk1);
+    for (int j = 0; j < W; j++) F.col(T.fin0[j], T.fin1[j], xu[j], xv[j]);   // lane 0 of every column is zero
+    AccMem E;
+    E.clear();
+    auto loose = [](u128 t) { return reduce128_loose((u64)t, (u64)(t >> 64)); };
+    u64 s = add_loose(loose((u128)xu[0] + ((u128)xv[0] << 32)), T.cst0[0]);
+    u64 base = loose((u128)du[0] + ((u128)dv[0] << 32) + T.Kc[0]);
+    for (int r = 0; r < RP; r++) {
+        // next round's base without its X_r term: lane r + 1 of E is complete (its last term came from X_{r-1}, stored a round ago) -- read BEFORE this
+        // round's column is added, so that the read does not wait for this round's stores; 2^84 B52 = 2^84 (B52 mod 2^12) - (B52 >> 12)
+        u64 lp = 0;
+        if (r + 1 < RP) {
+            const int q = r + 1;
+            u128 part = (u128)E.a0[q] + ((u128)E.a52[q] << 52) + ((u128)E.b0[q] << 32) + ((u128)(E.b52[q] & 0xfff) << 84) + ((u128)P << 40)
+                        - (E.b52[q] >> 12) + du[q] + ((u128)dv[q] << 32) + T.Kc[q];
+            lp = loose(part);
+        }
+        const u64 X = sbox_loose(s);
+        s = loose((u128)T.G[r][r] * X + base);                      // (2^64 - 1)^2 + 2^64 - 1 < 2^128
+        if (r + 1 < RP) base = loose((u128)T.G[r + 1][r] * X + lp);
+        const u64 Xu = X & EPS, Xv = X >> 32;
+        F.col(T.fin0[W + r], T.fin1[W + r], Xu, Xv);
+        if (r + 2 < RP) E.col(T.e0[r], T.e1[r], Xu, Xv, (r + 2) >> 3);
+    }
+    F.finish(x);
+    {   // word 0 of the closing map is the chain's last value; the constants of the next full round ride along
+        u64 s0 = add_loose(s, T.arkf[RF / 2][0]);
+        x[0].u = _mm512_mask_set1_epi64(x[0].u, 0x01, (long long)(s0 & EPS));
+        x[0].v = _mm512_mask_set1_epi64(x[0].v, 0x01, (long long)(s0 >> 32));
+    }
+    for (int r = RF / 2; r < RF; r++) full_round(x, r + 1 < RF ? T.ark0[r + 1] : nullptr, r + 1 < RF ? T.ark1[r + 1] : nullptr);
+    for (int g = 0; g < 3; g++) _mm512_storeu_si512((void *)(st + 8 * g), to_canon(x[g]));
 }
 
 }  // namespace psimd
