@@ -40,6 +40,8 @@ struct Tables {
     alignas(64) u64 arks[RF][W];      // ... times R: the seed of the mat-vec in front of that round
     alignas(64) u64 sx[W][W];         // [j][r] = coefficient of state word j in D_r (column 0 and lanes >= 22 zero)
     alignas(64) u64 fin[NX][W];       // closing map, [j][i]: columns 0..23 state words, 24..45 the S-box outputs X_r; lane 0 zero
+    alignas(64) u64 sxm[W][W];        // SX M (rows 0..21) and row 0 of M in lane 22: D and word 0 straight from the S-box outputs of the last full round
+    alignas(64) u64 finm[W][W];       // (state columns of the closing map) M
     alignas(64) u64 fks[W];           // its constant + the constants of the full round behind it, times R
     alignas(64) u64 e[RP][W];         // [r][q] = G[q][r] for q >= r + 2 (the cross terms the vector unit accumulates), else 0
     u32 cst0[RP], Gd[RP], Gs[RP];     // constant of word 0, G[r][r], G[r][r-1]
@@ -146,12 +148,15 @@ inline void matvec(const u64 (*M)[W], V x[3], const u64 *seed) {
 }
 // S-box layer and MDS of a full round; the round constants were added by the producer of x (as the seed of its mat-vec), the
 // constants of the NEXT full round are this mat-vec's seed
-inline void full_round(V x[3], const u64 *seed) {
+inline void sbox_layer(V x[3]) {
     V x2[3], x3[3], x4[3];
     for (int g = 0; g < 3; g++) x2[g] = vmul(x[g], x[g]);
     for (int g = 0; g < 3; g++) x3[g] = vmul(x2[g], x[g]);
     for (int g = 0; g < 3; g++) x4[g] = vmul(x2[g], x2[g]);
     for (int g = 0; g < 3; g++) x[g] = vmul(x4[g], x3[g]);
+}
+inline void full_round(V x[3], const u64 *seed) {
+    sbox_layer(x);
     matvec(T.mds, x, seed);
 }
 // canonical host arithmetic for build()
@@ -186,9 +191,11 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
     //   state' = diag(1, post) [s0_22 ; x + CX X + ck] (one closing mat-vec over [x ; X]).
     const int n = W - 1, NB = n + RP + 1;   // basis size
     static u64 form[W - 1][W - 1 + RP + 1];
-    static u64 G[RP][RP], K[RP];
+    static u64 G[RP][RP], K[RP], sxc[W][W], finc[W][W];
     memset(form, 0, sizeof(form));
     memset(G, 0, sizeof(G));
+    memset(sxc, 0, sizeof(sxc));
+    memset(finc, 0, sizeof(finc));
     for (int i = 0; i < n; i++) { form[i][i] = 1; form[i][NB - 1] = cst[0 * W + 1 + i] % P; }
     for (int r = 0; r < RP; r++) {
         T.cst0[r] = to_mont(cst[r * W]);
@@ -198,7 +205,7 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
             for (int i = 0; i < n; i++) a = hadd(a, hmul(row[r * n + i] % P, form[i][b]));
             dotf[b] = a;
         }
-        for (int j = 0; j < n; j++) T.sx[1 + j][r] = to_mont(dotf[j]);
+        for (int j = 0; j < n; j++) { T.sx[1 + j][r] = to_mont(dotf[j]); sxc[1 + j][r] = dotf[j]; }
         for (int i = 0; i < r; i++) G[r][i] = dotf[n + i];
         G[r][r] = e00[r] % P;
         K[r] = dotf[NB - 1];
@@ -212,7 +219,7 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
         for (int b = 0; b < NB; b++) {
             u64 a = 0;
             for (int k = 0; k < n; k++) a = hadd(a, hmul(post[i * n + k] % P, form[k][b]));
-            if (b < n) T.fin[1 + b][1 + i] = to_mont(a);
+            if (b < n) { T.fin[1 + b][1 + i] = to_mont(a); finc[1 + b][1 + i] = a; }
             else if (b < n + RP) T.fin[W + (b - n)][1 + i] = to_mont(a);
             else T.fks[1 + i] = to_mont(sadd(to_mont(a), (u32)T.arkf[RF / 2][1 + i]));   // (constant + next round's constant) R
         }
@@ -222,6 +229,19 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
         T.Kc[r] = sadd(to_mont(K[r]), r + 1 < RP ? T.cst0[r + 1] : 0);
         for (int q = r + 2; q < RP; q++) T.e[r][q] = to_mont(G[q][r]);
     }
+    // The mat-vec of the full round in front of the partial rounds is folded into what consumes its output: x = M s, D = (SX M) s, closing-map part
+    // (FIN_x M) s, word 0 = (row 0 of M) s in lane 22 of the D table: two mat-vecs over s instead of three
+    for (int j = 0; j < W; j++)
+        for (int r = 0; r < W; r++) {
+            u64 a = 0, b = 0;
+            for (int i = 0; i < W; i++) {
+                a = hadd(a, hmul(sxc[i][r], mds[i * W + j] % P));
+                b = hadd(b, hmul(finc[i][r], mds[i * W + j] % P));
+            }
+            if (r == RP) a = mds[0 * W + j] % P;
+            T.sxm[j][r] = to_mont(a);
+            T.finm[j][r] = to_mont(b);
+        }
 }
 
 void permute(u64 st[24]) {
@@ -229,20 +249,21 @@ void permute(u64 st[24]) {
     V x[3];
     for (int g = 0; g < 3; g++)   // to Montgomery form, + the constants of the first round
         x[g] = vadd(vmul(_mm512_loadu_si512((const void *)(st + 8 * g)), r2), _mm512_load_si512((const void *)(T.arkf[0] + 8 * g)));
-    for (int r = 0; r < RF / 2; r++) full_round(x, r + 1 < RF / 2 ? T.arks[r + 1] : nullptr);
+    for (int r = 0; r + 1 < RF / 2; r++) full_round(x, T.arks[r + 1]);
+    sbox_layer(x);      // the last full round of the first half: its mat-vec is folded into the tables below
     alignas(64) u64 xs[W], d[W];
     for (int g = 0; g < 3; g++) _mm512_store_si512((void *)(xs + 8 * g), x[g]);
     {
         Acc D;
         D.init(nullptr);
-        for (int j = 0; j < W; j += 2) D.col2(T.sx[j], T.sx[j + 1], xs[j], xs[j + 1]);
+        for (int j = 0; j < W; j += 2) D.col2(T.sxm[j], T.sxm[j + 1], xs[j], xs[j + 1]);
         V dv[3];
         D.finish(dv);
         for (int g = 0; g < 3; g++) _mm512_store_si512((void *)(d + 8 * g), dv[g]);
     }
     Acc F;
     F.init(T.fks);
-    for (int j = 0; j < W; j += 2) F.col2(T.fin[j], T.fin[j + 1], xs[j], xs[j + 1]);   // lane 0 of every column is zero
+    for (int j = 0; j < W; j += 2) F.col2(T.finm[j], T.finm[j + 1], xs[j], xs[j + 1]);   // lane 0 of every column is zero
     AccMem E;
     E.clear();
     // sum of Montgomery products (below 2^67) -> Montgomery form of the sum
@@ -251,7 +272,7 @@ void permute(u64 st[24]) {
         u64 r = (u64)((t + (u128)m * P) >> 32);     // < 2^36
         return (u32)(r % P);
     };
-    u32 s = sadd((u32)xs[0], T.cst0[0]);
+    u32 s = sadd((u32)d[RP], T.cst0[0]);               // word 0 of the state: lane 22 of the D table
     u32 base = sadd((u32)d[0], T.Kc[0]);
     for (int r = 0; r < RP; r++) {
         // next round's base without its X_r term (lane r + 1 of E is complete: its last term came from X_{r-1}, stored a round ago)

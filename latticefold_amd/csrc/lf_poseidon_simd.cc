@@ -44,6 +44,8 @@ struct Tables {
     // closing map  state' = FIN [x ; X] + FK
     alignas(64) u64 sx0[W][W], sx1[W][W];       // [j][r] = coefficient of state word j in D_r (column 0 and lanes >= 22 zero)
     alignas(64) u64 fin0[NX][W], fin1[NX][W];   // [j][i]: columns 0..23 state words, 24..45 the S-box outputs X_r; lane 0 zero
+    alignas(64) u64 sxm0[W][W], sxm1[W][W];     // SX M (rows 0..21) and row 0 of M in lane 22: D and word 0 straight from the S-box outputs of the last full round
+    alignas(64) u64 finm0[W][W], finm1[W][W];   // (state columns of the closing map) M
     alignas(64) u64 fk0[W], fk1[W];             // constant of the closing map (52-bit / top-12-bit halves), + the constants of the full round behind it
     alignas(64) u64 e0[RP][W], e1[RP][W];       // [r][q] = G[q][r] for q >= r + 2 (the cross terms the vector unit accumulates), else 0
     u64 cst0[RP], K[RP], G[RP][RP];
@@ -218,7 +220,7 @@ inline void matvec(const u64 (*t0)[W], const u64 (*t1)[W], UV x[3], const u64 *s
 
 // S-box layer and MDS of a full round; the round constants were added by the producer of x (as the seed of its mat-vec), the
 // constants of the NEXT full round are this mat-vec's seed
-inline void full_round(UV x[3], const u64 *seed0, const u64 *seed52) {
+inline void sbox_layer(UV x[3]) {
     UV x2[3], x3[3], x4[3];
     V wa[3], a1[3];
     for (int g = 0; g < 3; g++) prep_a(x[g], wa[g], a1[g]);
@@ -228,6 +230,9 @@ inline void full_round(UV x[3], const u64 *seed0, const u64 *seed52) {
     for (int g = 0; g < 3; g++) x4[g] = vmul(wa[g], a1[g], x2[g]);
     for (int g = 0; g < 3; g++) prep_a(x4[g], wa[g], a1[g]);
     for (int g = 0; g < 3; g++) x[g] = vmul(wa[g], a1[g], x3[g]);
+}
+inline void full_round(UV x[3], const u64 *seed0, const u64 *seed52) {
+    sbox_layer(x);
     matvec(T.mds0, T.mds1, x, seed0, seed52);
 }
 }  // namespace
@@ -292,6 +297,20 @@ void build(const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00, const
         T.Kc[r] = r + 1 < RP ? addmod(T.K[r], T.cst0[r + 1]) : T.K[r];
         for (int q = r + 2; q < RP; q++) { T.e0[r][q] = T.G[q][r]; T.e1[r][q] = T.G[q][r] >> 52; }
     }
+    // The mat-vec of the full round in front of the partial rounds is folded into what consumes its output: x = M s, D = SX x = (SX M) s,
+    // closing-map part = FIN_x x = (FIN_x M) s, word 0 = (row 0 of M) s (lane 22 of the D table): two mat-vecs over s instead of three
+    for (int j = 0; j < W; j++) {
+        for (int r = 0; r < W; r++) {
+            u64 a = 0, b = 0;
+            for (int i = 0; i < W; i++) {
+                a = addmod(a, mulmod(T.sx0[i][r], mds[i * W + j]));
+                b = addmod(b, mulmod(T.fin0[i][r], mds[i * W + j]));
+            }
+            if (r == RP) a = mds[0 * W + j];
+            T.sxm0[j][r] = a; T.sxm1[j][r] = a >> 52;
+            T.finm0[j][r] = b; T.finm1[j][r] = b >> 52;
+        }
+    }
 }
 
 void permute(u64 st[24]) {
@@ -302,7 +321,8 @@ void permute(u64 st[24]) {
         x[g].u = vand(w, eps);
         x[g].v = vsrl(w, 32);
     }
-    for (int r = 0; r < RF / 2; r++) full_round(x, r + 1 < RF / 2 ? T.ark0[r + 1] : nullptr, r + 1 < RF / 2 ? T.ark1[r + 1] : nullptr);
+    for (int r = 0; r + 1 < RF / 2; r++) full_round(x, T.ark0[r + 1], T.ark1[r + 1]);
+    sbox_layer(x);      // the last full round of the first half: its mat-vec is folded into the tables below
     // Partial rounds (tables: see build):  X_r = sbox(s_r),  s_{r+1} = base_r + G[r][r] X_r  on the scalar chain, with
     //   base_r = D_r + K_r + cst0_{r+1} + sum_{i <= r-2} G[r][i] X_i + G[r][r-1] X_{r-1}
     // prepared while the S-box of round r runs: the sum over i <= r-2 is lane r of the vector accumulator E (one column per
@@ -313,18 +333,18 @@ void permute(u64 st[24]) {
     {
         Acc D;
         D.init(nullptr, nullptr);
-        for (int j = 0; j < W; j++) D.col(T.sx0[j], T.sx1[j], xu[j], xv[j]);
+        for (int j = 0; j < W; j++) D.col(T.sxm0[j], T.sxm1[j], xu[j], xv[j]);
         UV d[3];
         D.finish(d);
         store_uv(d, du, dv);
     }
     Acc F;
     F.init(T.fk0, T.fk1);
-    for (int j = 0; j < W; j++) F.col(T.fin0[j], T.fin1[j], xu[j], xv[j]);   // lane 0 of every column is zero
+    for (int j = 0; j < W; j++) F.col(T.finm0[j], T.finm1[j], xu[j], xv[j]);  // lane 0 of every column is zero
     AccMem E;
     E.clear();
     auto loose = [](u128 t) { return reduce128_loose((u64)t, (u64)(t >> 64)); };
-    u64 s = add_loose(loose((u128)xu[0] + ((u128)xv[0] << 32)), T.cst0[0]);
+    u64 s = add_loose(loose((u128)du[RP] + ((u128)dv[RP] << 32)), T.cst0[0]);      // word 0 of the state: lane 22 of the D table
     u64 base = loose((u128)du[0] + ((u128)dv[0] << 32) + T.Kc[0]);
     for (int r = 0; r < RP; r++) {
         // next round's base without its X_r term: lane r + 1 of E is complete (its last term came from X_{r-1}, stored a round ago) -- read BEFORE this

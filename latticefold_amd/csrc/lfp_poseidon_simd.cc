@@ -39,6 +39,8 @@ struct Tables {
     alignas(64) u64 arkf[RF][W];                // constants of the full rounds, 2^104 form
     alignas(64) u64 sx0[W][W], sx1[W][W];       // [j][r]: coefficient of state word j in D_r, times 2^-40 (2^104 form): D comes out in 2^64 form
     alignas(64) u64 fin0[NX][W], fin1[NX][W];   // closing map: columns 0..23 state words (2^104 form), 24..45 the S-box outputs X_r (given in 2^64 form: times 2^40)
+    alignas(64) u64 sxm0[W][W], sxm1[W][W];     // SX M (rows 0..21) and row 0 of M in lane 22, times 2^-40: D and word 0 (2^64 form) straight from the S-box outputs of the last full round
+    alignas(64) u64 finm0[W][W], finm1[W][W];   // (state columns of the closing map) M
     alignas(64) u64 fk[W];                      // constant of the closing map (2^104 form), added after the reduction
     alignas(64) u64 e0[RP][W], e1[RP][W];       // [r][q] = G[q][r] for q >= r + 2 (the cross terms the vector unit accumulates, raw 2^64-form words), else 0
     u64 cst0[RP], K[RP], G[RP][RP];             // scalar chain, 2^64 form
@@ -182,13 +184,16 @@ inline void split_words(const V x[3], u64 *xl, u64 *xh) {
         _mm512_store_si512((void *)(xh + 8 * g), _mm512_srli_epi64(x[g], 32));
     }
 }
-inline void full_round(V x[3], const u64 *ark) {
+inline void sbox_layer(V x[3], const u64 *ark) {
     V t[3], x2[3], x3[3], x4[3];
     for (int g = 0; g < 3; g++) t[g] = vadd(x[g], _mm512_load_si512((const void *)(ark + 8 * g)));
     for (int g = 0; g < 3; g++) x2[g] = vmul(t[g], t[g]);
     for (int g = 0; g < 3; g++) x3[g] = vmul(x2[g], t[g]);
     for (int g = 0; g < 3; g++) x4[g] = vmul(x2[g], x2[g]);
     for (int g = 0; g < 3; g++) x[g] = vmul(x4[g], x3[g]);
+}
+inline void full_round(V x[3], const u64 *ark) {
+    sbox_layer(x, ark);
     alignas(64) u64 xl[W], xh[W];
     split_words(x, xl, xh);
     Acc A;
@@ -230,8 +235,10 @@ void build(u64 p, const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00
     // Symbolic run of the 22 sparse partial rounds (as lf_poseidon_simd.cc): every state word 1..23 is an affine form over
     //   [ x_1..x_23 (words on entry) | X_0..X_21 (S-box outputs of word 0) | 1 ]
     const int n = W - 1, NB = n + RP + 1;
-    static u64 form[W - 1][W - 1 + RP + 1];
+    static u64 form[W - 1][W - 1 + RP + 1], sxc[W][W], finc[W][W];
     memset(form, 0, sizeof(form));
+    memset(sxc, 0, sizeof(sxc));
+    memset(finc, 0, sizeof(finc));
     for (int i = 0; i < n; i++) { form[i][i] = 1; form[i][NB - 1] = cst[0 * W + 1 + i] % p; }
     for (int r = 0; r < RP; r++) {
         T.cst0[r] = to64(cst[r * W]);
@@ -243,6 +250,7 @@ void build(u64 p, const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00
         }
         for (int j = 0; j < n; j++) {
             const u64 v = to104(mulmod(dotf[j], i40));
+            sxc[1 + j][r] = dotf[j];
             T.sx0[1 + j][r] = v;
             T.sx1[1 + j][r] = v >> 52;
         }
@@ -258,7 +266,7 @@ void build(u64 p, const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00
         for (int b = 0; b < NB; b++) {
             u64 a = 0;
             for (int k = 0; k < n; k++) a = addmod(a, mulmod(post[i * n + k] % p, form[k][b]));
-            if (b < n) { const u64 v = to104(a); T.fin0[1 + b][1 + i] = v; T.fin1[1 + b][1 + i] = v >> 52; }
+            if (b < n) { const u64 v = to104(a); T.fin0[1 + b][1 + i] = v; T.fin1[1 + b][1 + i] = v >> 52; finc[1 + b][1 + i] = a; }
             else if (b < n + RP) { const u64 v = shl_mod(a, 144); T.fin0[W + (b - n)][1 + i] = v; T.fin1[W + (b - n)][1 + i] = v >> 52; }   // x 2^104 x 2^40
             else T.fk[1 + i] = to104(a);
         }
@@ -266,13 +274,28 @@ void build(u64 p, const u64 *ark, const u64 *mds, const u64 *cst, const u64 *e00
         T.Kc[r] = r + 1 < RP ? addmod(T.K[r], T.cst0[r + 1]) : T.K[r];
         for (int q = r + 2; q < RP; q++) { T.e0[r][q] = T.G[q][r]; T.e1[r][q] = T.G[q][r] >> 52; }
     }
+    // The mat-vec of the full round in front of the partial rounds is folded into what consumes its output: x = M s, D = (SX M) s, closing-map part
+    // (FIN_x M) s, word 0 = (row 0 of M) s in lane 22 of the D table (so it arrives in 2^64 form like D): two mat-vecs over s instead of three
+    for (int j = 0; j < W; j++)
+        for (int r = 0; r < W; r++) {
+            u64 a = 0, b = 0;
+            for (int i = 0; i < W; i++) {
+                a = addmod(a, mulmod(sxc[i][r], mds[i * W + j] % p));
+                b = addmod(b, mulmod(finc[i][r], mds[i * W + j] % p));
+            }
+            if (r == RP) a = mds[0 * W + j] % p;
+            const u64 va = to104(mulmod(a, i40)), vb = to104(b);
+            T.sxm0[j][r] = va; T.sxm1[j][r] = va >> 52;
+            T.finm0[j][r] = vb; T.finm1[j][r] = vb >> 52;
+        }
 }
 
 void permute(u64 st[24]) {
     V x[3];
     const V r2 = _mm512_set1_epi64((long long)T.r2_104);
     for (int g = 0; g < 3; g++) x[g] = vmul(_mm512_loadu_si512((const void *)(st + 8 * g)), r2);      // -> 2^104 form
-    for (int r = 0; r < RF / 2; r++) full_round(x, T.arkf[r]);
+    for (int r = 0; r + 1 < RF / 2; r++) full_round(x, T.arkf[r]);
+    sbox_layer(x, T.arkf[RF / 2 - 1]);      // the last full round of the first half: its mat-vec is folded into the tables below
     // Partial rounds (tables: see build), everything on the chain in 2^64 form:  X_r = sbox(s_r),  s_{r+1} = base_r + G[r][r] X_r  with
     //   base_r = D_r + K_r + cst0_{r+1} + sum_{i <= r-2} G[r][i] X_i + G[r][r-1] X_{r-1}
     // prepared while the S-box of round r runs: the sum over i <= r-2 is lane r of the vector accumulator E (raw products, one column per
@@ -282,17 +305,17 @@ void permute(u64 st[24]) {
     {
         Acc D;
         D.init();
-        for (int j = 0; j < W; j++) D.col(T.sx0[j], T.sx1[j], xl[j], xh[j]);        // D_r in 2^64 form (the tables carry 2^-40)
+        for (int j = 0; j < W; j++) D.col(T.sxm0[j], T.sxm1[j], xl[j], xh[j]);      // D_r (and word 0 in lane 22) in 2^64 form (the tables carry 2^-40)
         V dv[3];
         D.finish(dv);
         for (int g = 0; g < 3; g++) _mm512_store_si512((void *)(d + 8 * g), dv[g]);
     }
     Acc F;
     F.init();
-    for (int j = 0; j < W; j++) F.col(T.fin0[j], T.fin1[j], xl[j], xh[j]);          // lane 0 of every column is zero
+    for (int j = 0; j < W; j++) F.col(T.finm0[j], T.finm1[j], xl[j], xh[j]);        // lane 0 of every column is zero
     AccMem E;
     E.clear();
-    u64 s = addmod(mm(xl[0] | (xh[0] << 32), T.two24), T.cst0[0]);                   // word 0: 2^104 form -> 2^64 form, + its first constant
+    u64 s = addmod(d[RP], T.cst0[0]);                                                // word 0 (lane 22 of the D table, 2^64 form) + its first constant
     u64 base = addmod(d[0], T.Kc[0]);
     for (int r = 0; r < RP; r++) {
         // next round's base without its X_r term: lane r + 1 of E is complete (its last term came from X_{r-1}, stored a round ago) -- read before this
