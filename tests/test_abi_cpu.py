@@ -122,6 +122,21 @@ def test_simd_permutation_equals_scalar_and_plain():
         assert (a < np.uint64(P)).all()
 
 
+def test_simd_permutation_chain_matches_scalar():
+    """3000 chained permutations through the transcript's path (AVX-512 IFMA lanes when the CPU has them: elements as (u, v) pairs with a
+    compare-free reduction, lf_poseidon_simd.cc) and through the scalar sparse form: every intermediate state feeds the next one, so 3000
+    different non-canonical internal representations are exercised; compared every 250 steps and at the end"""
+    P = api.P
+    st = np.array([(i * 0x9E3779B97F4A7C15 + 12345) % P for i in range(24)], dtype=np.uint64)
+    ref = st.copy()
+    for i in range(3000):
+        st = api.poseidon_permute(st, 0)
+        ref = api.poseidon_permute(ref, 2)
+        if i % 250 == 0:
+            assert (st == ref).all(), i
+    assert (st == ref).all() and (st < np.uint64(P)).all()
+
+
 def test_scalar_transcript_env_gives_same_challenges():
     import subprocess, sys, os
     code = ("import numpy as np, sys; sys.path.insert(0, %r); from latticefold_amd import api; t = api.PoseidonTranscript(); "
