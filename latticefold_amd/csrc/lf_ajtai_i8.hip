@@ -487,9 +487,9 @@ size_t ajtai_i8s_lds_bytes() { return 2 * (size_t)S_ALDS + 2 * (size_t)S_VB * 8 
         pt[i_] += now_ - pc;                                                             \
         pc = now_;                                                                       \
     }
-template <int MTW, bool PROF>
+template <int MTW, int NTW, bool PROF>
 __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *smem, u32 mg, u32 ng, u32 T0, u32 T1, u32 slot) {
-    constexpr int RD = 24, KS = 3, VS = 48, HALF = 12, NTW = 6;
+    constexpr int RD = 24, KS = 3, VS = 48, HALF = 12;
     const u32 lane = threadIdx.x & 63;
     const unsigned char *Al = smem;
     const ull *V = (const ull *)(smem + 2 * S_ALDS);
@@ -706,7 +706,7 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     // group 1): before issuing a tile's loads a workgroup adds +-1 with ONE atomic performed in the XCD's L2 (workgroup scope: no trip to memory -- the agent-scope
     // form of this handshake cost a memory round trip per tile and 0.4 ms per launch), and the value the atomic returns tells it how far AHEAD it is: beyond
     // `couple_w` tiles it waits for its partner.  The returned value is consumed one tile later (the memory counter is in order: a use waits for every load issued
-    // before it, so the atomic goes ahead of the tile's ten copy loads).  Only the first producer wave does this, the others follow through the per-tile barrier.
+    // before it, so the atomic goes ahead of the tile's ten copy loads).  Only ONE producer wave does this (the last: see CPL0), the others follow through the per-tile barrier.
     // The workgroup BEHIND never waits, so the pair cannot deadlock; a workgroup that is done (or gives up after a bounded spin: the coupling is a traffic
     // optimisation, never a correctness condition -- e.g. if the pair did not share an L2) moves the counter 2^20 tiles to its partner's side.
     // Measured (C4, 224 workgroups, profiles/r04_i8_couple.txt): handshake every tile, window 3: 5.34 GB per launch, 2.14-2.18 ms against 1.99 uncoupled (the
@@ -714,7 +714,8 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     // tiles: 5.7-6.8 GB (the pair drifts out of the L2 between handshakes).  So the second pass over A costs HBM traffic, not kernel time: the loop is bound by
     // the matrix-pipe issue rate and the producers (profiles/r03_i8_notes.txt), and a launch moves 2.6 TB/s either way.
     const u32 c_grp = (blockIdx.x >> 3) & 1, c_chunk = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
-    const bool cpl = a.sync != nullptr && a.sides == 2 && btid < 64;
+    constexpr u32 CPL0 = 192;     // the handshake runs in the LAST producer wave: it has no digits to cut (192 (plane, coefficient) items) and waits ~1 200 cycles per tile anyway
+    const bool cpl = a.sync != nullptr && a.sides == 2 && btid >= CPL0;
     int *const lead_p = (int *)a.sync + c_chunk;
     const int c_sgn = c_grp ? -1 : 1;
     bool coupled = cpl;
@@ -722,7 +723,7 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     bool c_pending = false;
     u32 c_tick = 0;          // tiles since the loop began: the handshake runs every couple_e tiles and counts couple_e tiles at once
 #define LF_S_COUPLE_RELEASE()                                                                                                        \
-    if (cpl && btid == 0) (void)__hip_atomic_fetch_add(lead_p, c_sgn * (1 << 20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cpl && btid == CPL0) (void)__hip_atomic_fetch_add(lead_p, c_sgn * (1 << 20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #define LF_S_COUPLE_STEP()                                                                                                           \
     if (coupled && ((c_tick++) & (a.couple_e - 1)) == 0) {                                                                           \
         if (c_pending) {                                                                                                             \
@@ -735,7 +736,7 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
             }                                                                                                                        \
         }                                                                                                                            \
         if (coupled) {                                                                                                               \
-            if (btid == 0) c_old = __hip_atomic_fetch_add(lead_p, c_sgn * (int)a.couple_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            if (btid == CPL0) c_old = __hip_atomic_fetch_add(lead_p, c_sgn * (int)a.couple_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
             c_pending = true;                                                                                                        \
         } else {                                                                                                                     \
             LF_S_COUPLE_RELEASE();                                                                                                   \
@@ -819,7 +820,9 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     if (btid < 192) a.dsum[(size_t)slot * 192 + btid] = (int)dsl[btid];   // (stride of 8 planes whatever NP is)
 }
 
-template <bool PROF, bool BITS>
+// COLS: the four multiplier waves split the 12 column tiles (13 x 3 tiles each: 39 MFMAs per K-step and wave) instead of 2 x 2 blocks of (7 | 6) x 6 tiles
+// (42 / 36: the 7-row waves bound the tile); every wave then reads all 13 row tiles of A from LDS (64 operand-tile reads per K-step instead of 50)
+template <bool PROF, bool BITS, bool COLS = false>
 __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // plane group g = planes [8 g, 8 g + 8) of the launch: block ids 16 q + 8 g + x, like the two witnesses of the paired launch
@@ -831,8 +834,9 @@ __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     const u32 np_g = a.NP - S_NPG * grp < (u32)S_NPG ? a.NP - S_NPG * grp : (u32)S_NPG;
     const u32 wave = threadIdx.x >> 6;
     if (wave >= 4) i8s_build<PROF, BITS>(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
-    else if (wave < 2) i8s_mma<7, PROF>(a, smem, 0, wave & 1, T0, T1, slot);
-    else i8s_mma<6, PROF>(a, smem, 1, wave & 1, T0, T1, slot);
+    else if (COLS) i8s_mma<13, 3, PROF>(a, smem, 0, wave, T0, T1, slot);
+    else if (wave < 2) i8s_mma<7, 6, PROF>(a, smem, 0, wave & 1, T0, T1, slot);
+    else i8s_mma<6, 6, PROF>(a, smem, 1, wave & 1, T0, T1, slot);
 }
 
 // copies the per-phase clock totals of the last PROF launch: out[wave][0..6] cycles per phase, out[wave][7] = tiles
@@ -974,8 +978,19 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
                 a.couple_e = ce >= 8 ? 8u : (ce >= 4 ? 4u : (ce >= 2 ? 2u : 1u));
                 (void)hipMemsetAsync(a.sync, 0, (size_t)nch * 4, s);      // one signed counter per column chunk (pair of workgroups)
             }
-            if (sprof) { if (ub) hipLaunchKernelGGL((k_ajtai_i8s<true, true>), g, b, lds_s, s, a); else hipLaunchKernelGGL((k_ajtai_i8s<true, false>), g, b, lds_s, s, a); }
+            // LF_I8_COLS=1 (read per launch: the tests flip it): the column split of the multiplier waves.  Measured at C4 (profiles/r05b_i8_variants.txt): the tile
+            // takes 3 070 instead of 3 115 cycles (with LF_I8_BITS=1: 2 852) but the launch takes the same 1.94-1.98 ms -- the shader clock follows the matrix
+            // pipe's duty cycle down (1.85 -> 1.69 GHz): the kernel is at the power-managed MFMA rate, not at an issue bottleneck.  Opt-in.
+            const bool cols = getenv("LF_I8_COLS") != nullptr;
+            if (sprof) {
+                if (ub && cols) hipLaunchKernelGGL((k_ajtai_i8s<true, true, true>), g, b, lds_s, s, a);
+                else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<true, true>), g, b, lds_s, s, a);
+                else if (cols) hipLaunchKernelGGL((k_ajtai_i8s<true, false, true>), g, b, lds_s, s, a);
+                else hipLaunchKernelGGL((k_ajtai_i8s<true, false>), g, b, lds_s, s, a);
+            }
+            else if (ub && cols) hipLaunchKernelGGL((k_ajtai_i8s<false, true, true>), g, b, lds_s, s, a);
             else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<false, true>), g, b, lds_s, s, a);
+            else if (cols) hipLaunchKernelGGL((k_ajtai_i8s<false, false, true>), g, b, lds_s, s, a);
             else hipLaunchKernelGGL((k_ajtai_i8s<false, false>), g, b, lds_s, s, a);
             const size_t per_wg_s = (size_t)S_MT * S_NT * 256;
             hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg_s + 192, 256), groups), dim3(256), 0, s, part, per_wg_s, dsum, 192u, nch, sum);
