@@ -542,7 +542,7 @@ static int prep_ajtai_i8(C *c) {
 // digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev canonical u64 [NP][kappa][72], NTT form (PARTIAL when sharded)
 static int commit_planes_i8(C *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev) {
     const lf::AjtaiI8Ring R = lf::ajtai_i8_babybear();
-    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = lf::ajtai_i8_row_tiles(R, kc), maxp = lf::ajtai_i8_max_planes(R);
+    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = lf::ajtai_i8_row_tiles(R, kc), maxp = lf::ajtai_i8_max_planes_mt(R, MT);
     const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
     u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 224;   // 7/8 of the CUs: see the Goldilocks backend
     if (nwg > ntiles) nwg = (u32)ntiles;

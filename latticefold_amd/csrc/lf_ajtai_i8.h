@@ -21,6 +21,7 @@ uint32_t ajtai_i8_row_tiles(const AjtaiI8Ring &R, uint32_t kappa);
 uint32_t ajtai_i8_col_tiles(const AjtaiI8Ring &R, uint32_t NP);
 uint32_t ajtai_i8_max_rows(const AjtaiI8Ring &R);
 uint32_t ajtai_i8_max_planes(const AjtaiI8Ring &R);
+uint32_t ajtai_i8_max_planes_mt(const AjtaiI8Ring &R, uint32_t MT);   // ... for this row-tile count (the specialised kernels take two plane groups of 8 per launch)
 size_t ajtai_i8_slack_bytes();   // readable bytes required behind the packed matrix (the tile copy of the kernel is unconditional)
 size_t ajtai_i8_part_words(uint32_t nwg, uint32_t MT, uint32_t NT);
 size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, uint32_t MT, uint32_t NT, uint32_t NP);

@@ -839,6 +839,327 @@ __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     else i8s_mma<6, 6, PROF>(a, smem, 1, wave & 1, T0, T1, slot);
 }
 
+// =====================================================================================================================================
+// k_ajtai_i8x -- the specialised-wave design of k_ajtai_i8s with the geometry as template parameters; instantiated for the 72-ring with 4 row
+// tiles (BabyBear, kappa 13..16).  In-kernel clocks of the unspecialised kernel at C3 (profiles/r05b_i8prof_c3_before.txt): 12 570 cycles per
+// 8-column tile for 360 MFMAs per SIMD (7 344 at the measured issue rate): loads, digits, vectors and stores (~3 000 cycles) run in lock step
+// in all eight waves and leave the matrix pipe idle.  Here waves 0-3 (one per SIMD) only multiply -- 4 row tiles x 9 of the 36 column tiles
+// each, 144 accumulators -- and waves 4-7 only produce (tile copy two tiles ahead, digits two ahead, Toeplitz vectors one ahead), one s_barrier
+// per tile; a workgroup commits 8 planes, the 15 planes of a decomposition are two workgroups paired on one XCD, coupled through an L2 counter.
+template <int RD, int MT>
+struct SX {
+    static constexpr int NPG = 8, KS = RD / 8, VS = 2 * RD, HALF = RD / 2, DS = RD + 1, EPP = 4 * RD;
+    static constexpr int NT = NPG * RD / 16;                  // column tiles of a plane group
+    static constexpr int TILE = KS * MT * 1024;               // bytes of a tile of A
+    static constexpr int NLD = (TILE + 4095) / 4096;          // 16-byte loads per producer thread and tile
+    static constexpr int ALDS = NLD * 4096;
+    static constexpr int VB = NPG * 2 * VS, DB = NPG * DS;    // 64-bit words
+    static constexpr int NW = RD * 8, NWR = (NW + 255) / 256; // staged witness words per tile, rounds of 256 threads
+    static constexpr int NDI = NPG * RD, NDR = (NDI + 255) / 256;   // (plane, coefficient) digit items
+    static constexpr int NVR = VB / 256;                      // rounds of the vector build
+    static_assert(VB % 256 == 0 && NPG * DS < 1024, "vector rounds / 10-bit source offsets");
+    static constexpr size_t lds_bytes() { return 2 * (size_t)ALDS + 2 * (size_t)VB * 8 + 2 * (size_t)DB * 8 + 3 * (size_t)NW * 4 + (size_t)NDI * 4; }
+};
+template <int RD, int MT, int NTW, bool PROF>
+__device__ __forceinline__ void i8x_mma(const AjtaiI8Args &a, unsigned char *smem, u32 ng, u32 T0, u32 T1, u32 slot) {
+    typedef SX<RD, MT> G;
+    constexpr int KS = G::KS, VS = G::VS, HALF = G::HALF;
+    const u32 lane = threadIdx.x & 63;
+    const unsigned char *Al = smem;
+    const ull *V = (const ull *)(smem + 2 * G::ALDS);
+    u32 vb[NTW];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ni++) {
+        u32 n = (ng * NTW + ni) * 16 + (lane & 15);       // < 8 planes x RD: planes past NP hold zero digits
+        const u32 p = n / RD, co = n % RD;
+        vb[ni] = ((p * 2 + (co >= (u32)HALF ? 0u : 1u)) * VS + (RD - 1 - co + 2 * (lane >> 4))) * 8;
+    }
+    const u32 ab0 = lane * 16;
+    v4i acc[MT][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MT; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
+    if (T0 < T1) { lds_barrier(); lds_barrier(); }          // (the producers' prologue has two barriers of its own: every wave must arrive)
+    lds_barrier();                                          // hand-over: A[T0], V[T0] are in buffer 0
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    if (PROF) pc = __builtin_amdgcn_s_memtime();
+    for (u32 T = T0; T < T1; T++) {
+        const u32 cur = (T - T0) & 1;
+        const unsigned char *Ac = Al + cur * G::ALDS;
+        const unsigned char *Vc = (const unsigned char *)(V + cur * G::VB);
+        v4i b[NTW], bn[NTW];
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++) {
+            const ull *q = (const ull *)(Vc + vb[ni]);
+            const ull lo = q[0], hi = q[1];
+            b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            v4i avn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0), avnn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + 1024);
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                const v4i av = avn;
+                avn = avnn;
+                if (mi + 2 < MT) avnn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + (mi + 2) * 1024);
+                if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ni++) {
+                        const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
+                        const ull lo = q[0], hi = q[1];
+                        bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
+                    }
+                }
+#pragma unroll
+                for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+            }
+        }
+        LF_S_STAMP(3);     // K-steps
+        lds_barrier();
+        LF_S_STAMP(6);     // barrier
+    }
+    if (PROF && blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 7; i++) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
+        g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++)
+            *(v4i *)(a.part + ((((size_t)slot * MT + mi) * G::NT + ng * NTW + ni) * 64 + lane) * 4) = acc[mi][ni];
+}
+// the producer waves: btid = 0 .. 255
+template <int RD, int MT, bool PROF>
+__device__ __forceinline__ void i8x_build(const AjtaiI8Args &a, unsigned char *smem, const int32_t *planes, u32 k0, u32 NP, u32 T0, u32 T1, u32 slot) {
+    typedef SX<RD, MT> G;
+    constexpr int VS = G::VS, HALF = G::HALF, DS = G::DS, EPP = G::EPP, NLD = G::NLD, NWR = G::NWR, NDR = G::NDR, NVR = G::NVR, NW = G::NW, NDI = G::NDI;
+    constexpr int LA = NLD < 2 ? NLD : 2, LB = NLD < 6 ? NLD : 6;      // the tile copy's loads in three groups: [0, LA), [LA, LB), [LB, NLD)
+    const u32 btid = threadIdx.x - 256;
+    unsigned char *Al = smem;
+    ull *V = (ull *)(smem + 2 * G::ALDS);
+    ull *Dl = V + 2 * G::VB;
+    int32_t *wl = (int32_t *)(Dl + 2 * G::DB);               // [3][RD][8]
+    u32 *dsl = (u32 *)(wl + 3 * NW);                        // digit sums [NDI]
+    const size_t a_tile = (size_t)G::TILE;
+    const u32 Tlast = a.ntiles - 1;
+    // (named scalars, not arrays: a staging array that a lambda or a loop can address ends up in scratch memory)
+    uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, y0, y1, y2, y3, y4, y5, y6, y7, y8, y9;
+    static_assert(NLD <= 10, "ten staging registers per tile copy");
+    const u32 voff = btid * 16;
+#define LF_X_LD1(P_, q_, I0_, I1_) if ((q_) >= (I0_) && (q_) < (I1_)) P_##q_ = *(const uint4 *)(src_ + (q_) * 4096);
+#define LF_X_LOAD(P_, T_, I0_, I1_)                                                                                \
+    do {                                                                                                           \
+        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
+        LF_X_LD1(P_, 0, I0_, I1_) LF_X_LD1(P_, 1, I0_, I1_) LF_X_LD1(P_, 2, I0_, I1_) LF_X_LD1(P_, 3, I0_, I1_) LF_X_LD1(P_, 4, I0_, I1_)      \
+        LF_X_LD1(P_, 5, I0_, I1_) LF_X_LD1(P_, 6, I0_, I1_) LF_X_LD1(P_, 7, I0_, I1_) LF_X_LD1(P_, 8, I0_, I1_) LF_X_LD1(P_, 9, I0_, I1_)      \
+    } while (0)
+#define LF_X_ST1(P_, q_) if ((q_) < NLD) *(uint4 *)(dst_ + (q_) * 4096) = P_##q_;
+#define LF_X_STORE(P_, buf_)                                                                                       \
+    do {                                                                                                           \
+        unsigned char *dst_ = Al + (buf_) * G::ALDS + (size_t)btid * 16;                                           \
+        LF_X_ST1(P_, 0) LF_X_ST1(P_, 1) LF_X_ST1(P_, 2) LF_X_ST1(P_, 3) LF_X_ST1(P_, 4) LF_X_ST1(P_, 5) LF_X_ST1(P_, 6) LF_X_ST1(P_, 7) LF_X_ST1(P_, 8) LF_X_ST1(P_, 9) \
+    } while (0)
+    // staged witness words: item = btid + 256 r < 8 RD is word (coefficient item / 8, column item % 8) of a tile
+    static_assert(NWR <= 3, "three staged words per thread");
+    int32_t wr0 = 0, wr1 = 0, wr2 = 0;
+#define LF_X_LW1(r_, W_)                                                                                           \
+    if ((r_) < NWR) {                                                                                              \
+        const u32 item_ = btid + 256 * (r_), cf_ = item_ < (u32)NW ? item_ >> 3 : RD - 1;                          \
+        const int32_t v_ = *(const int32_t *)((const char *)planes + ((u32)((size_t)cf_ * a.ld * 4) + (ok_ ? (u32)j_ * 4 : 0))); \
+        W_ = ok_ ? v_ : 0;                                                                                         \
+    }
+#define LF_X_LOADW(T_)                                                                                             \
+    do {                                                                                                           \
+        const size_t j_ = (size_t)(T_) * 8 + (btid & 7);                                                           \
+        const bool ok_ = (T_) < T1 && j_ < a.n;                                                                    \
+        LF_X_LW1(0, wr0) LF_X_LW1(1, wr1) LF_X_LW1(2, wr2)                                                         \
+    } while (0)
+#define LF_X_SW1(r_, W_) if ((r_) < NWR && btid + 256 * (r_) < (u32)NW) wl[(buf_) * NW + btid + 256 * (r_)] = W_;
+#define LF_X_STOREW(B_)                                                                                            \
+    do {                                                                                                           \
+        const u32 buf_ = (B_);                                                                                     \
+        LF_X_SW1(0, wr0) LF_X_SW1(1, wr1) LF_X_SW1(2, wr2)                                                         \
+    } while (0)
+    // digits: item = btid + 256 r < 8 RD is (plane, coefficient) = (item / RD, item % RD); planes >= NP get zero digits
+#pragma unroll
+    for (int r = 0; r < NDR; r++) { const u32 item = btid + 256 * r; if (item < (u32)NDI) dsl[item] = 0; }
+    auto gen_d = [&](u32 wbuf, u32 dbuf) {
+#pragma unroll
+        for (int r = 0; r < NDR; r++) {
+            const u32 item = btid + 256 * r;
+            if (item < (u32)NDI) {
+                const u32 gp = item / RD, gc = item % RD;
+                const int32_t *wp = wl + wbuf * NW + gc * 8;
+                const int4 w0 = *(const int4 *)(wp), w1 = *(const int4 *)(wp + 4);
+                const int32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                ull d = 0x0404040404040404ull;                  // digits are kept BIASED by 4 (a byte in 3 .. 5): sums of up to three need no byte-wise carries
+                int sacc = 0;
+                if (gp < NP) {
+                    d = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int dg = digit2_i8(w[q], k0 + gp);
+                        sacc += dg;
+                        d |= (ull)(unsigned)(dg + 4) << (8 * q);
+                    }
+                }
+                Dl[dbuf * G::DB + gp * DS + gc] = d;
+                dsl[item] += (u32)sacc;
+            }
+        }
+    };
+    // vectors: entry idx = btid + 256 r = (plane, H / L, e) = (idx / EPP, (idx % EPP) / VS, idx % VS), see i8s_build
+    u32 vo[NVR];          // o0 | o1 << 10 | o2 << 20 | L << 30, offsets in words from the D buffer
+#pragma unroll
+    for (int r = 0; r < NVR; r++) {
+        const u32 idx = btid + 256 * r, vp = idx / EPP, vr = idx % EPP;
+        u32 o0 = RD, o1 = RD, o2 = RD;
+        const bool vsub = vr >= (u32)VS;
+        const int dl = RD - 1 - (int)(vr % VS);
+        if (!vsub) {
+            if (dl >= -(HALF - 1) && dl <= RD - 1) { if (dl >= 0) o0 = dl; if (dl <= HALF - 1) o1 = dl + HALF; }
+        } else if (dl >= -(RD - 1) && dl <= HALF - 1) {
+            if (dl >= 0) o0 = dl;
+            if (dl <= -1) o1 = dl + RD;
+            if (dl <= -(HALF + 1)) o2 = dl + RD + HALF;
+        }
+        vo[r] = (vp * DS + o0) | ((vp * DS + o1) << 10) | ((vp * DS + o2) << 20) | (vsub ? 1u << 30 : 0u);
+    }
+    auto gen_v = [&](u32 dbuf, u32 vbuf) {
+        const ull *D = Dl + dbuf * G::DB;
+#pragma unroll
+        for (int r = 0; r < NVR; r++) {
+            const ull xa = D[vo[r] & 0x3FF], xb = D[(vo[r] >> 10) & 0x3FF], xc = D[(vo[r] >> 20) & 0x3FF];
+            const ull t = xb + xc;
+            const ull v = (vo[r] >> 30) ? (xa + 0x8484848484848484ull) - t : (xa + 0x7474747474747474ull) + t;
+            V[vbuf * G::VB + btid + 256 * r] = v ^ 0x8080808080808080ull;
+        }
+    };
+    // coupling of the two plane-group workgroups of a column chunk: as in i8s_build (the handshake runs in the last producer wave)
+    constexpr u32 CPL0 = 192;
+    const u32 c_grp = (blockIdx.x >> 3) & 1, c_chunk = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
+    const bool cpl = a.sync != nullptr && a.sides == 2 && btid >= CPL0;
+    int *const lead_p = (int *)a.sync + c_chunk;
+    const int c_sgn = c_grp ? -1 : 1;
+    bool coupled = cpl;
+    int c_old = 0;
+    bool c_pending = false;
+    u32 c_tick = 0;
+#define LF_X_COUPLE_RELEASE()                                                                                                        \
+    if (cpl && btid == CPL0) (void)__hip_atomic_fetch_add(lead_p, c_sgn * (1 << 20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define LF_X_COUPLE_STEP()                                                                                                           \
+    if (coupled && ((c_tick++) & (a.couple_e - 1)) == 0) {                                                                           \
+        if (c_pending) {                                                                                                             \
+            int ahead_ = c_sgn * __builtin_amdgcn_readfirstlane(c_old) + (int)a.couple_e;                                            \
+            int spins_ = 0;                                                                                                          \
+            while (ahead_ > (int)a.couple_w) {                                                                                       \
+                __builtin_amdgcn_s_sleep(8);                                                                                         \
+                ahead_ = c_sgn * __hip_atomic_load(lead_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                              \
+                if (++spins_ > 8192) { coupled = false; break; }                                                                     \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        if (coupled) {                                                                                                               \
+            if (btid == CPL0) c_old = __hip_atomic_fetch_add(lead_p, c_sgn * (int)a.couple_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            c_pending = true;                                                                                                        \
+        } else {                                                                                                                     \
+            LF_X_COUPLE_RELEASE();                                                                                                   \
+        }                                                                                                                            \
+    }
+    if (cpl && T0 >= T1) { LF_X_COUPLE_RELEASE(); }
+    if (btid < 2 * G::NPG) Dl[btid * DS + RD] = 0x0404040404040404ull;   // the (biased) zero words of both D buffers
+    if (T0 < T1) {
+        // prologue: A[T0] -> buffer 0, A[T0+1] in flight (x), w[T0 .. T0+2], D[T0], D[T0+1], V[T0]
+        LF_X_LOAD(y, T0, 0, NLD);
+        LF_X_LOADW(T0); LF_X_STOREW(0);
+        LF_X_LOADW(T0 + 1); LF_X_STOREW(1);
+        LF_X_LOADW(T0 + 2); LF_X_STOREW(2);
+        LF_X_STORE(y, 0);
+        LF_X_LOAD(x, T0 + 1, 0, NLD);
+        lds_barrier();
+        gen_d(0, 0); gen_d(1, 1);
+        lds_barrier();
+        gen_v(0, 0);
+    }
+    lds_barrier();                                          // hand-over of buffer 0 (matches the multipliers' first barrier)
+    u32 w3 = 0;
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    if (PROF) pc = __builtin_amdgcn_s_memtime();
+    for (u32 T = T0; T < T1; T += 2) {
+        // even tile of the pair: x holds A[T+1]; load A[T+2] into y
+        LF_X_COUPLE_STEP();
+        LF_X_LOADW(T + 3);
+        LF_X_LOAD(y, T + 2, 0, LA);
+        LF_S_STAMP(0);     // load issue
+        gen_d(w3 >= 1 ? w3 - 1 : 2, 0);                     // digits of tile T+2 -> D[0]
+        LF_X_LOAD(y, T + 2, LA, LB);
+        LF_S_STAMP(1);     // digits
+        gen_v(1, 1);                                        // vectors of tile T+1 from D[1]
+        LF_X_LOAD(y, T + 2, LB, NLD);
+        LF_S_STAMP(2);     // vectors
+        LF_X_STORE(x, 1);                                   // A[T+1] -> buffer 1
+        LF_X_STOREW(w3);
+        w3 = w3 == 2 ? 0 : w3 + 1;
+        LF_S_STAMP(5);     // wait + LDS stores
+        lds_barrier();
+        LF_S_STAMP(6);     // barrier
+        if (T + 1 >= T1) break;
+        // odd tile: y holds A[T+2]; load A[T+3] into x
+        LF_X_COUPLE_STEP();
+        LF_X_LOADW(T + 4);
+        LF_X_LOAD(x, T + 3, 0, LA);
+        LF_S_STAMP(0);
+        gen_d(w3 >= 1 ? w3 - 1 : 2, 1);
+        LF_X_LOAD(x, T + 3, LA, LB);
+        LF_S_STAMP(1);
+        gen_v(0, 0);
+        LF_X_LOAD(x, T + 3, LB, NLD);
+        LF_S_STAMP(2);
+        LF_X_STORE(y, 0);
+        LF_X_STOREW(w3);
+        w3 = w3 == 2 ? 0 : w3 + 1;
+        LF_S_STAMP(5);
+        lds_barrier();
+        LF_S_STAMP(6);
+    }
+    if (PROF && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 7; i++) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
+        g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
+    }
+    if (coupled) { LF_X_COUPLE_RELEASE(); }
+#undef LF_X_COUPLE_STEP
+#undef LF_X_COUPLE_RELEASE
+#undef LF_X_LOAD
+#undef LF_X_STORE
+#undef LF_X_LD1
+#undef LF_X_ST1
+#undef LF_X_LW1
+#undef LF_X_LOADW
+#undef LF_X_SW1
+#undef LF_X_STOREW
+#pragma unroll
+    for (int r = 0; r < NDR; r++) { const u32 item = btid + 256 * r; if (item < (u32)NDI) a.dsum[(size_t)slot * NDI + item] = (int)dsl[item]; }
+}
+template <int RD, int MT, bool PROF>
+__global__ void __launch_bounds__(512) k_ajtai_i8x(AjtaiI8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef SX<RD, MT> G;
+    const u32 grp = a.sides == 2 ? (blockIdx.x >> 3) & 1 : 0;
+    const u32 chunk = a.sides == 2 ? ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7) : blockIdx.x;
+    const u32 slot = grp * a.nchunks + chunk;
+    const u32 T0 = chunk * a.tiles_per_wg;
+    const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
+    const u32 np_g = a.NP - G::NPG * grp < (u32)G::NPG ? a.NP - G::NPG * grp : (u32)G::NPG;
+    const u32 wave = threadIdx.x >> 6;
+    if (wave >= 4) i8x_build<RD, MT, PROF>(a, smem, a.planes, a.k0 + G::NPG * grp, np_g, T0, T1, slot);
+    else i8x_mma<RD, MT, G::NT / 4, PROF>(a, smem, wave, T0, T1, slot);
+}
+
 // copies the per-phase clock totals of the last PROF launch: out[wave][0..6] cycles per phase, out[wave][7] = tiles
 int ajtai_i8_read_prof(unsigned long long *out64) { return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_i8_prof), sizeof(g_i8_prof)) == hipSuccess ? 0 : -1; }
 
@@ -916,6 +1237,9 @@ static u32 ach_for(u32 RD, u32 MT) {   // 16-byte chunks of an A tile per thread
     return bytes <= 2 * 8192 ? 2 : (bytes <= 3 * 8192 ? 3 : 5);
 }
 u32 ajtai_i8_max_planes(const AjtaiI8Ring &R) { return R.RD == 24 ? 15 : 8; }     // digit planes per launch (accumulators, LDS, rounds of the vector build)
+// ... for a given row-tile count: the specialised kernels (k_ajtai_i8s: 24-ring, 13 row tiles; k_ajtai_i8x: 72-ring, 4 row tiles) run two plane groups of 8 in one launch
+static bool i8x_enabled() { return !getenv("LF_I8_NO_SPLIT") && !getenv("LF_I8_GUARDED"); }
+u32 ajtai_i8_max_planes_mt(const AjtaiI8Ring &R, u32 MT) { return R.RD == 72 && MT == 4 && i8x_enabled() ? 15u : ajtai_i8_max_planes(R); }
 size_t ajtai_i8_lds_bytes(const AjtaiI8Ring &R, u32 MT, u32 NP) {
     (void)NP;   // the buffers have the strides of the largest plane count
     const size_t maxnp = ajtai_i8_max_planes(R);
@@ -939,7 +1263,44 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     a.ntiles = (u32)((n + 7) / 8);
     a.part = part; a.dsum = dsum; a.sync = nullptr; a.couple_w = 0; a.couple_e = 1;
     if ((size_t)R.RD * ld * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit plane offsets in the kernel
-    if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes(R) || NP == 0) return -1;
+    if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes_mt(R, MT) || NP == 0) return -1;
+    // The 4-row-tile shape of the 72-ring with specialised waves (k_ajtai_i8x): plane groups of 8, two groups = paired, coupled workgroups
+    if (R.RD == 72 && MT == 4 && !planes2 && i8x_enabled()) {
+        typedef SX<72, 4> G;
+        static const bool xprof = getenv("LF_I8_PROF") != nullptr;
+        const u32 groups = NP > (u32)G::NPG ? 2 : 1;
+        u32 per = nwg / groups;
+        if (groups == 2) per &= ~7u;
+        if (per >= 1) {
+            a.tiles_per_wg = (a.ntiles + per - 1) / per;
+            u32 nch = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+            if (groups == 2) nch = (nch + 7) & ~7u;
+            a.sides = groups; a.nchunks = nch; a.NT = G::NT;
+            static bool attr_x = false;
+            if (!attr_x) {
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8x<72, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8x<72, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_x = true;
+            }
+            const dim3 g(groups * nch), b(512);
+            // the coupling counters live behind the digit sums this path uses (G::NDI per workgroup; the caller sizes dsum for ajtai_i8_max_planes_mt = 15 planes)
+            static const int cw = getenv("LF_I8_COUPLE_W") ? atoi(getenv("LF_I8_COUPLE_W")) : 4;
+            if (groups == 2 && cw > 0 && g.x <= nwg && (size_t)nwg * G::NDI + g.x <= (size_t)nwg * 15 * R.RD && g.x <= 256) {
+                a.sync = (u32 *)(dsum + (size_t)nwg * G::NDI);
+                a.couple_w = (u32)cw;
+                static const int ce = getenv("LF_I8_COUPLE_E") ? atoi(getenv("LF_I8_COUPLE_E")) : 4;
+                a.couple_e = ce >= 8 ? 8u : (ce >= 4 ? 4u : (ce >= 2 ? 2u : 1u));
+                (void)hipMemsetAsync(a.sync, 0, (size_t)nch * 4, s);
+            }
+            if (xprof) hipLaunchKernelGGL((k_ajtai_i8x<72, 4, true>), g, b, G::lds_bytes(), s, a);
+            else hipLaunchKernelGGL((k_ajtai_i8x<72, 4, false>), g, b, G::lds_bytes(), s, a);
+            const size_t per_wg_x = (size_t)4 * G::NT * 256;
+            hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg_x + G::NDI, 256), groups), dim3(256), 0, s, part, per_wg_x, dsum, (u32)G::NDI, nch, sum);
+            hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)G::NPG * kappa * 72, 256), groups), dim3(256), 0, s, sum, per_wg_x, 4u, (u32)G::NT,
+                               (u32)G::NPG, kappa, row0, kappa_total, 72u, R.NL, R.p_small, R.soa_out, coef_out, (u64 *)nullptr, NP, (u32)G::NPG);
+            return (int)(groups * nch);
+        }
+    }
     // The 13-row-tile shape of the 24-ring with specialised waves (k_ajtai_i8s): plane groups of 8, two groups = paired workgroups
     static const bool no_split = getenv("LF_I8_NO_SPLIT") != nullptr;
     if (R.RD == 24 && MT == 13 && !planes2 && !no_split && !getenv("LF_I8_GUARDED")) {
@@ -1032,7 +1393,12 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
         else if (mh <= 4) LF_I8_LAUNCH(24, 2, 4, 4, 6, 3, false);
         else LF_I8_LAUNCH(24, 2, 7, 7, 6, 5, false);
     } else {            // 1 row group (<= 4 row tiles) x 8 column groups of 5 tiles (72 x 8 planes = 36 tiles)
-        if (MT == 4 && !guarded) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5, true);     // kappa 13 .. 16
+        static const bool prof72 = getenv("LF_I8_PROF") != nullptr;
+        if (MT == 4 && !guarded && prof72) {
+            static bool attr_p = false;
+            if (!attr_p) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<72, 1, 4, 4, 5, 5, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_p = true; }
+            hipLaunchKernelGGL((k_ajtai_i8<72, 1, 4, 4, 5, 5, true, true>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);
+        } else if (MT == 4 && !guarded) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5, true);     // kappa 13 .. 16
         else if (MT <= 1) LF_I8_LAUNCH(72, 1, 1, 1, 5, 2, false);
         else if (MT <= 2) LF_I8_LAUNCH(72, 1, 2, 2, 5, 3, false);
         else if (MT <= 4) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5, false);

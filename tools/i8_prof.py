@@ -8,14 +8,14 @@ import numpy as np
 from latticefold_amd import api
 from latticefold_amd.workload import make_workload
 wl = make_workload(sys.argv[1] if len(sys.argv) > 1 else "C4")
-ctx = api.Context(0)
+ctx = api.Context(0, ring=wl.ring)
 ctx.load_ccs(wl)
 scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=7)
 wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
 cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
-acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript(ring=wl.ring))
 for _ in range(2):
-    api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+    api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript(ring=wl.ring))
 out = (C.c_uint64 * 64)()
 lib = api._lib()
 lib.lf_debug_i8_prof.argtypes = [C.POINTER(C.c_uint64)]
