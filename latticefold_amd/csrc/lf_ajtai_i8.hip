@@ -508,8 +508,8 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
         for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
     if (T0 < T1) { lds_barrier(); lds_barrier(); }          // (the producers' prologue has two barriers of its own: every wave must arrive)
     lds_barrier();                                          // hand-over: A[T0], V[T0] are in buffer 0
-    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
-    if (PROF) pc = __builtin_amdgcn_s_memtime();
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0, pc0 = 0, pr0 = 0;
+    if (PROF) { pc = pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     for (u32 T = T0; T < T1; T++) {
         const u32 cur = (T - T0) & 1;
         const unsigned char *Ac = Al + cur * S_ALDS;
@@ -553,8 +553,19 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
         LF_S_STAMP(6);     // barrier
     }
     if (PROF && blockIdx.x == 0 && lane == 0) {
-        for (int i = 0; i < 7; i++) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
+        for (int i = 0; i < 7; i++) if (i != 4) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
         g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
+    }
+    if (PROF && threadIdx.x == 0 && T0 < T1) {
+        // column 4 (unused by this kernel's stamps) carries per-workgroup loop statistics: row 0 = workgroup 0's loop in 100 MHz ticks, row 1 / 2 = max / (2^62 - min)
+        // of the loop's shader cycles over the workgroups, row 3 = their sum, row 4 = max of the 100 MHz ticks, row 5 = workgroups counted (the tool zeroes the table first)
+        const unsigned long long dc = __builtin_amdgcn_s_memtime() - pc0, dr = __builtin_amdgcn_s_memrealtime() - pr0;
+        if (blockIdx.x == 0) g_i8_prof[0][4] = dr;
+        atomicMax(&g_i8_prof[1][4], dc);
+        atomicMax(&g_i8_prof[2][4], (1ull << 62) - dc);
+        atomicAdd(&g_i8_prof[3][4], dc);
+        atomicMax(&g_i8_prof[4][4], dr);
+        atomicAdd(&g_i8_prof[5][4], 1ull);
     }
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
@@ -806,7 +817,7 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
         LF_S_STAMP(6);
     }
     if (PROF && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-        for (int i = 0; i < 7; i++) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
+        for (int i = 0; i < 7; i++) if (i != 4) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
         g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
     }
     if (coupled) { LF_S_COUPLE_RELEASE(); }   // done: the partner never waits for this workgroup again (a workgroup that gave up has released already)
@@ -1344,6 +1355,8 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
             // pipe's duty cycle down (1.85 -> 1.69 GHz): the kernel is at the power-managed MFMA rate, not at an issue bottleneck.  Opt-in.
             const bool cols = getenv("LF_I8_COLS") != nullptr;
             if (sprof) {
+                static const unsigned long long zeros[64] = {0};
+                (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_i8_prof), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, s);
                 if (ub && cols) hipLaunchKernelGGL((k_ajtai_i8s<true, true, true>), g, b, lds_s, s, a);
                 else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<true, true>), g, b, lds_s, s, a);
                 else if (cols) hipLaunchKernelGGL((k_ajtai_i8s<true, false, true>), g, b, lds_s, s, a);

@@ -26,4 +26,9 @@ print("tiles per workgroup:", a[:, 7], " kernel stats:", ctx.kernel_stats())
 print("cycles per tile and wave (shader clock), waves 0..7:")
 for i, n in enumerate(names):
     print("  %-22s" % n, " ".join("%7.0f" % (a[w, i] / max(a[w, 7], 1)) for w in range(8)))
-print("  %-22s" % "sum", " ".join("%7.0f" % (a[w, :7].sum() / max(a[w, 7], 1)) for w in range(8)))
+print("  %-22s" % "sum", " ".join("%7.0f" % ((a[w, :4].sum() + a[w, 5:7].sum()) / max(a[w, 7], 1)) for w in range(8)))
+if a[5, 4] > 0:    # k_ajtai_i8s: per-workgroup loop statistics of the LAST profiled launch (column 4)
+    nwg, tiles = a[5, 4], max(a[0, 7], 1)
+    cmax, cmin, cmean = a[1, 4], float(2**62) - a[2, 4], a[3, 4] / nwg
+    print("workgroups %d: loop cycles per tile min / mean / max = %.0f / %.0f / %.0f;  workgroup 0: %.1f us at the 100 MHz counter -> shader clock %.3f GHz;  slowest workgroup %.1f us"
+          % (nwg, cmin / tiles, cmean / tiles, cmax / tiles, a[0, 4] / 100.0, (a[0, :4].sum() + a[0, 5:7].sum()) / max(a[0, 4], 1) / 10.0, a[4, 4] / 100.0))
