@@ -1330,13 +1330,20 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_s = true;
             }
             // digits from the bit-plane form when the caller has it and digit plane k0 + NP - 1 is one of its magnitude rows
             a.bits = bits; a.bits_nw = bits_nw; a.bits_rows = bits_rows;
-            // (opt-in, LF_I8_BITS=1: the multiplier waves bound the kernel -- 2 650-2 850 of 3 000 cycles per tile at 20.4 cycles per MFMA, the
+            // (LF_I8_BITS, round 3: the multiplier waves bound the kernel -- 2 650-2 850 of 3 000 cycles per tile at 20.4 cycles per MFMA, the
             // measured int8 issue rate -- so the cheaper digits change nothing: 2.00-2.07 vs 1.96-2.01 ms per launch at C4)
-            static const bool want_bits = getenv("LF_I8_BITS") != nullptr;
+            // (round 5, after the handshake moved to the last producer wave: bits + column split is the fastest form at C4 by 0.1 ms per step, profiles/r05c_i8_ab.txt --
+            // both on by default, LF_I8_BITS=0 / LF_I8_COLS=0 switch them off; read per launch: the tests flip them)
+            const char *e_bits = getenv("LF_I8_BITS");
+            const bool want_bits = !(e_bits && e_bits[0] == '0');
             const bool ub = want_bits && bits != nullptr && k0 + NP <= bits_rows - 1;
             const dim3 g(groups * nch), b(512);
             const size_t lds_s = ajtai_i8s_lds_bytes();
@@ -1350,10 +1357,11 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
                 a.couple_e = ce >= 8 ? 8u : (ce >= 4 ? 4u : (ce >= 2 ? 2u : 1u));
                 (void)hipMemsetAsync(a.sync, 0, (size_t)nch * 4, s);      // one signed counter per column chunk (pair of workgroups)
             }
-            // LF_I8_COLS=1 (read per launch: the tests flip it): the column split of the multiplier waves.  Measured at C4 (profiles/r05b_i8_variants.txt): the tile
+            // LF_I8_COLS (default on, =0 off): the column split of the multiplier waves.  Measured at C4 (profiles/r05b_i8_variants.txt): the tile
             // takes 3 070 instead of 3 115 cycles (with LF_I8_BITS=1: 2 852) but the launch takes the same 1.94-1.98 ms -- the shader clock follows the matrix
-            // pipe's duty cycle down (1.85 -> 1.69 GHz): the kernel is at the power-managed MFMA rate, not at an issue bottleneck.  Opt-in.
-            const bool cols = getenv("LF_I8_COLS") != nullptr;
+            // pipe's duty cycle down (1.82 -> 1.69 GHz, profiles/r05c_i8_clock.txt): the kernel is at the power-managed MFMA rate, not at an issue bottleneck.
+            const char *e_cols = getenv("LF_I8_COLS");
+            const bool cols = !(e_cols && e_cols[0] == '0');
             if (sprof) {
                 static const unsigned long long zeros[64] = {0};
                 (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_i8_prof), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, s);

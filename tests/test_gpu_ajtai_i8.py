@@ -19,7 +19,7 @@ def _y_s(ctx, wl, wit, acc):
 
 
 def _setup(name, valu, env=None):
-    for k in ("LF_AJTAI_VALU", "LF_I8_WGS", "LF_I8_GUARDED", "LF_I8_COLS"):
+    for k in ("LF_AJTAI_VALU", "LF_I8_WGS", "LF_I8_GUARDED", "LF_I8_COLS", "LF_I8_BITS"):
         os.environ.pop(k, None)
     if valu:
         os.environ["LF_AJTAI_VALU"] = "1"
@@ -44,14 +44,16 @@ def test_digit_plane_commits_match_valu_kernel_and_oracle(name):
     tr = lambda: api.PoseidonTranscript(ring=wl0.ring)
     out = {}
     try:
-        for mode in ("i8", "valu", "guarded", "cols"):     # cols: the column split of the specialised kernel's multiplier waves (LF_I8_COLS, 13-row-tile shapes)
-            wl, ctx, scheme = _setup(name, mode == "valu", {"LF_I8_GUARDED": "1"} if mode == "guarded" else ({"LF_I8_COLS": "1"} if mode == "cols" else None))
+        # nocols / nobits: the specialised 24-ring kernel (13-row-tile shapes) with the 2 x 2 split of its multiplier waves / with digits cut from the int32 planes
+        envs = {"guarded": {"LF_I8_GUARDED": "1"}, "nocols": {"LF_I8_COLS": "0"}, "nobits": {"LF_I8_BITS": "0", "LF_I8_COLS": "0"}}
+        for mode in ("i8", "valu", "guarded", "nocols", "nobits"):
+            wl, ctx, scheme = _setup(name, mode == "valu", envs.get(mode))
             wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
             cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
             acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
             out[mode] = api.LFDecompositionProver.prove(ctx, acc, wit, tr())
             ctx.close()
-        for mode in ("valu", "guarded", "cols"):
+        for mode in ("valu", "guarded", "nocols", "nobits"):
             assert (out["i8"][0] == out[mode][0]).all() and (out["i8"][1] == out[mode][1]).all(), mode
         inst = O.Instance(wl)
         f_coeff = inst.witness_from_w_ccs(wl.w_ccs)
@@ -59,7 +61,7 @@ def test_digit_plane_commits_match_valu_kernel_and_oracle(name):
         want = inst.decomposition_prove(O.Transcript(), wl.ajtai_matrix(), acc_o, f_coeff)
         assert (out["i8"][1] == want[1]).all() and (out["i8"][0] == want[0]).all()
     finally:
-        for k in ("LF_AJTAI_VALU", "LF_I8_GUARDED", "LF_I8_COLS"):
+        for k in ("LF_AJTAI_VALU", "LF_I8_GUARDED", "LF_I8_COLS", "LF_I8_BITS"):
             os.environ.pop(k, None)
 
 
@@ -144,7 +146,7 @@ def test_digits_only_context_matches_the_full_one(name, how):
     """lf_ajtai_set_digits_only: the context keeps only the byte planes of A (rows pass through one u64 row buffer: fused inverse map +
     packing).  Digit-plane commitments (the fold step), general commitments (NTT form rebuilt from the bytes for the call) and the
     witness commitment must be word for word those of a context that holds both forms; switching the mode on afterwards drops the copy."""
-    for k in ("LF_AJTAI_VALU", "LF_I8_WGS", "LF_I8_GUARDED", "LF_I8_COLS"):
+    for k in ("LF_AJTAI_VALU", "LF_I8_WGS", "LF_I8_GUARDED", "LF_I8_COLS", "LF_I8_BITS"):
         os.environ.pop(k, None)
     wl = make_workload(name)
     from latticefold_amd.workload import splitmix_fq

@@ -35,8 +35,8 @@ EXTRA = {
     "LF_FOLD_NO_LUT": "rounds 3-4 of the folding sumcheck on materialised m/4-entry tables", "LF_FOLD_NO_MUTAB": "round 3 without the mu-premultiplied look-up tables",
     "LF_FOLD_NO_R4TAB": "round 4 without the product-free digit-code tables (mode 6)", "LF_FOLD_NO_R5TAB": "round 5 from materialised tables instead of the planes (mode 7)",
     "LF_FOLD_TAB_MIN": "pairs from which rounds 1-2 run as table look-ups (default 16384)", "LF_FOLD_TAB_R1": "round 1 as a table look-up round (disables the GEMM rounds)",
-    "LF_FOLD_UNFUSED": "separate k_fix pass before every folding round", "LF_I8_BITS": "commit kernel cuts its digits from the bit-plane form (producers faster, multipliers then bind)",
-    "LF_I8_COLS": "commit kernel: the four multiplier waves split the 12 column tiles (13 x 3 each) instead of 2 x 2 blocks of (7 | 6) x 6 tiles (fewer cycles, same time: opt-in)", "LF_I8_COUPLE_W": "window (tiles) a commit workgroup may run ahead of its paired plane-group workgroup (default 4; 0 switches the coupling off)", "LF_I8_COUPLE_E": "tiles between two handshakes of the paired commit workgroups (default 4)", "LF_I8_GUARDED": "commit kernel instantiation with guarded tile loads",
+    "LF_FOLD_UNFUSED": "separate k_fix pass before every folding round", "LF_I8_BITS": "=0: commit kernel cuts its digits from the int32 planes instead of the bit-plane form of a fold step (default since round 5)",
+    "LF_I8_COLS": "=0: commit kernel with 2 x 2 blocks of (7 | 6) x 6 tiles per multiplier wave instead of the column split (13 x 3 tiles each; default since round 5)", "LF_I8_COUPLE_W": "window (tiles) a commit workgroup may run ahead of its paired plane-group workgroup (default 4; 0 switches the coupling off)", "LF_I8_COUPLE_E": "tiles between two handshakes of the paired commit workgroups (default 4)", "LF_I8_GUARDED": "commit kernel instantiation with guarded tile loads",
     "LF_I8_NO_SPLIT": "commit kernel without the producer / multiplier wave specialisation (k_ajtai_i8 for every shape)", "LF_I8_PROF": "in-kernel cycle counters of the commit kernel (tools/i8_prof.py)",
     "LF_LANE0_MID": "lane 0's stream on the middle priority (so that the prefetch stream yields to it too)", "LF_LIN_BLOCKS": "workgroups of the linearization round kernels (default automatic)",
     "LF_LIN_UNFUSED": "separate k_fix pass before every linearization round", "LF_LIN_U_EVAL": "u of the linearization from stand-alone evaluations instead of the last fix of the sumcheck tables",
