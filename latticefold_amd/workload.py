@@ -51,6 +51,11 @@ CONFIGS = {
     "BDP": (7, 32, 4, 1 << 8, 2, 8, 4, "babybear"),
     "B21": (8, 128, 2, 1 << 16, 2, 16, 21, "babybear"),    # kappa > 16: two row chunks of the int8 commit kernel (11 + 10 rows -> 3 row tiles each)
     "B32": (7, 64, 2, 1 << 16, 2, 16, 32, "babybear"),     # the backend's largest kappa: 2 x 16 rows
+    # shapes of the specialised BabyBear commit kernel (k_ajtai_i8x: 4 row tiles = kappa 13..16): a padded row tile (kappa 13), one plane group only (K 8 -> 7
+    # planes), a ragged last column tile (N = 2 * 333 columns)
+    "B13": (8, 128, 2, 1 << 16, 2, 16, 13, "babybear"),
+    "BK8": (9, 128, 4, 1 << 8, 2, 8, 16, "babybear"),
+    "B333": (10, 333, 2, 1 << 16, 2, 16, 15, "babybear"),
     "BD768": (12, 766, 2, 1 << 16, 2, 16, 4, "babybear"),   # n = 768: 12 chunks of the int8 inner products where n + 1 gives 7 (bb_dot_i8.hip)
 }
 

@@ -32,7 +32,7 @@ def _setup(name, valu, env=None):
     return wl, ctx, scheme
 
 
-@pytest.mark.parametrize("name", ["T8", "T10", "G5", "E22", "E99", "T14", "B6", "B10", "BDP", "B21", "B32", "B14"])
+@pytest.mark.parametrize("name", ["T8", "T10", "G5", "E22", "E99", "T14", "B6", "B10", "BDP", "B21", "B32", "B14", "B13", "BK8", "B333"])
 def test_digit_plane_commits_match_valu_kernel_and_oracle(name):
     """both rings: the exact-count instantiations (13 row tiles: the 25-row chunks of E99; BabyBear kappa 13..16 -> 4 row tiles: B14),
     the generic guarded ones (everything else), row chunks (E99: 4 x 25 rows; B21 / B32: 2 chunks) and plane groups (E22: 16 + 5; BabyBear: 8 + 7)"""
