@@ -1,6 +1,6 @@
 #!/bin/bash
 # (GPU box) schedule sweep of the C4 step after the host-Poseidon speed-up (phase 1 is now GPU-bound): lane-1 order, z_R position, commit workgroups
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; out=gpurun_out/s3s_sweep.txt; : > $out
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; out=gpurun_out/schedule_sweep.txt; : > $out
 run() { # label, env...
   local label="$1"; shift
   for rep in 1 2; do
