@@ -501,12 +501,64 @@ def main():
     mode = args.parallelism
     mem_info, fixture_info = {}, {}
     shard = world > 1 and mode in ("auto", "shard")
-    wl, elapsed, phases_acc, kstats, exch, timelines = measure(shard)
-    replicas_extra = None
-    if shard and mode == "auto":   # the independent-streams rate of the same GPUs, reported next to the sharded headline
-        _, el_r, _, _, _, _ = measure(False)
-        replicas_extra = {"value": world * args.steps / el_r, "unit": "steps/s", "ms_per_step": el_r / args.steps * 1e3, "scaling": "weak",
-                          "parallelism": f"replicas x{world}: one independent fold stream per GPU, no data-path collective"}
+    replicas_extra, shard_note = None, None
+    if shard:
+        # N > 1, default: the sharded step (BASELINE configs[3]) is the headline.  It has never run on more than one GPU, so it must not be able to cost the
+        # run its number: the independent replicas (no data-path collective) are measured FIRST; the sharded measurement then runs under a watchdog, the ranks agree
+        # on its outcome through the rendezvous store (not through the communicator that may be the broken part), and on any failure or time-out every rank falls back
+        # to the replicas line ("scaling": "weak", the reason in `note`) and leaves without touching the process group again.
+        res_r = measure(False) if mode == "auto" else None
+        if res_r is not None:
+            replicas_extra = {"value": world * args.steps / res_r[1], "unit": "steps/s", "ms_per_step": res_r[1] / args.steps * 1e3, "scaling": "weak",
+                              "parallelism": f"replicas x{world}: one independent fold stream per GPU, no data-path collective"}
+        box = {}
+
+        def _run_shard():
+            try:
+                torch.cuda.set_device(local_rank)
+                if os.environ.get("LF_BENCH_FORCE_SHARD_FAIL") == str(rank):      # (test hook: this rank's sharded measurement fails)
+                    raise RuntimeError("forced failure of the sharded measurement (LF_BENCH_FORCE_SHARD_FAIL)")
+                box["r"] = measure(True)
+            except BaseException as e:      # noqa: BLE001 -- anything: the fallback decides
+                box["e"] = repr(e)
+        dbg = os.environ.get("LF_BENCH_DEBUG")
+        if dbg:
+            import faulthandler
+            faulthandler.dump_traceback_later(float(dbg), exit=False)
+            print(f"[bench rank {rank}] sharded attempt starts", file=sys.stderr, flush=True)
+        th = threading.Thread(target=_run_shard, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("LF_SHARD_TIMEOUT", "420")))
+        ok_here = (not th.is_alive()) and "r" in box
+        if dbg:
+            print(f"[bench rank {rank}] sharded attempt: alive={th.is_alive()} ok={ok_here} err={box.get('e')}", file=sys.stderr, flush=True)
+        all_ok = ok_here
+        try:      # agreement over the rendezvous store -- through a client connection of its own: the process group's client may be blocked inside the stuck measurement
+            from datetime import timedelta
+            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world_size=world, is_master=False, wait_for_workers=False,
+                                  timeout=timedelta(seconds=float(os.environ.get("LF_SHARD_AGREE_TIMEOUT", "120"))))
+            store.set(f"lf_shard_ok_{rank}", "1" if ok_here else "0")
+            keys = [f"lf_shard_ok_{r}" for r in range(world)]
+            store.wait(keys, timedelta(seconds=float(os.environ.get("LF_SHARD_AGREE_TIMEOUT", "120"))))
+            all_ok = all(store.get(k) == b"1" for k in keys)
+        except Exception as e:      # a peer never reported: it is stuck or dead
+            all_ok = False
+            box.setdefault("e", f"no agreement with the peers: {e!r}")
+        if all_ok:
+            wl, elapsed, phases_acc, kstats, exch, timelines = box["r"]
+        else:
+            shard_note = "sharded step not measured (" + (box.get("e") or ("timed out" if th.is_alive() else "a peer rank failed")) + "): the headline is the replicas rate"
+            if res_r is None:
+                if rank == 0:
+                    print("bench.py: " + shard_note + "; --parallelism shard has no fallback", file=sys.stderr)
+                os._exit(4)
+            if rank == 0:
+                line = _headline_fallback(args, world, res_r[0], res_r[1], False, None)
+                line["note"] = shard_note
+                print(json.dumps(line), flush=True)
+            os._exit(0)      # the communicator may be unusable: no further collective, no destroy_process_group
+    else:
+        wl, elapsed, phases_acc, kstats, exch, timelines = measure(False)
 
     # BASELINE configs[4]: the 2^20-row LatticeFold+ prove sharded over the same GPUs (an extra key; every rank takes part).  A watchdog bounds it: an exchange
     # that never completes must not cost the headline -- the ranks then drop the key and go on.

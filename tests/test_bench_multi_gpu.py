@@ -106,3 +106,17 @@ def test_bench_streams_mode_single_rank():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and "2 independent streams" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
+
+
+def test_bench_falls_back_to_replicas_when_the_sharded_step_fails():
+    """The sharded step has never run on more than one GPU: `bench.py --gpus N` measures the replicas first and runs the sharded measurement under a watchdog;
+    here rank 1's sharded measurement fails (test hook), rank 0's then never completes -- both ranks agree through the rendezvous store, rank 0 prints the
+    replicas line ("weak", the reason in `note`) and both leave with exit code 0"""
+    env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo", LF_BENCH_FORCE_SHARD_FAIL="1", LF_SHARD_TIMEOUT="25", LF_SHARD_AGREE_TIMEOUT="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "T14", "--no-lfplus"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "weak" and d["n_gpus"] == 2 and d["value"] > 0 and "sharded step not measured" in d["note"]
