@@ -612,8 +612,67 @@ static u32 ajtai_splits(size_t n) {
     if (s > 128) s = 128;
     return (u32)s;
 }
+// General commitments from the resident byte planes of A (lf_ajtai_i8g.hip, shared with the Goldilocks backend): commit_ntt for `batch` vectors
+// F [batch][72][ldF] in NTT form (pointing at this rank's first column), or Witness::commit for the centred int32 planes of a witness handle
+// (F null, batch 1).  Five balanced base-128 digit planes cover the centred 31-bit residues.  out_dev: canonical u64 [batch][kappa][72], NTT form.
+static int commit_dev_i8g(C *c, const fe *F, size_t ldF, u32 batch, const int32_t *planes, size_t ldp, u64 *out_dev, bool timed) {
+    if (!c->i8_nch || !c->dAb) return LF_ERR_STATE;
+    const lf::AjtaiI8Ring R = lf::ajtai_i8_babybear();
+    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = lf::ajtai_i8_row_tiles(R, kc);
+    const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
+    const u32 NP = planes ? lf::ajtai_i8g_planes_i32() : lf::ajtai_i8g_planes_general(R);
+    const char *e_wgs = getenv("LF_I8G_WGS");           // (test hook: workgroups of the general commit kernel; default one per CU)
+    const u32 nwg = e_wgs && atoi(e_wgs) > 0 ? (u32)atoi(e_wgs) : 256;
+    size_t pw, dw, sw;
+    if (lf::ajtai_i8g_scratch(R, MT, c->nA, NP, nwg, &pw, &dw, &sw) != 0) return LF_ERR_UNSUPPORTED;
+    unsigned long long *pre;
+    int32_t *part, *dsum, *ipl = nullptr;
+    long long *sum;
+    u64 *co;
+    fe *cf, *ntt, *slice = nullptr, *coef = nullptr;
+    int *viol = nullptr;
+    RET(c->tbuf("i8g_pre", (size_t)NP * RE * ntiles, &pre));
+    RET(c->tbuf("i8g_part", pw, &part));
+    RET(c->tbuf("i8g_dsum", dw, &dsum));
+    RET(c->tbuf("i8g_sum", sw, &sum));
+    RET(c->tbuf("i8g_co", (size_t)RE * c->kappa, &co));
+    RET(c->tbuf("i8g_cf", (size_t)RE * c->kappa, &cf));
+    RET(c->tbuf("i8g_ntt", (size_t)RE * c->kappa, &ntt));
+    if (!planes) {
+        RET(c->tbuf("i8g_coef", (size_t)RE * c->nA, &coef));
+        RET(c->tbuf("i8g_ipl", (size_t)RE * c->nA, &ipl));
+        RET(c->tbuf("i8g_viol", 16, &viol));
+        if (ldF != c->nA) RET(c->tbuf("i8g_slice", (size_t)RE * c->nA, &slice));
+    }
+    for (u32 b = 0; b < batch; b++) {
+        if (planes) lf::launch_i8g_cut_i32(planes, ldp, c->nA, RE, NP, pre, ntiles, c->stream());
+        else {
+            const fe *Fb = F + (size_t)b * RE * ldF;
+            if (slice) {   // a sharded rank: its column slice of the vector, compact
+                HIPCHK(hipMemcpy2DAsync(slice, c->nA * sizeof(fe), Fb, ldF * sizeof(fe), c->nA * sizeof(fe), RE, hipMemcpyDeviceToDevice, c->stream()));
+                Fb = slice;
+            }
+            launch_icrt_dense(c->d_icrt, Fb, coef, c->nA, c->stream());
+            launch_coef_to_i32(coef, ipl, c->nA, 0xFFFFFFFFu, viol, c->stream());    // centred residues (|v| <= (p - 1) / 2 < 2^30: the bound never trips)
+            lf::launch_i8g_cut_i32(ipl, c->nA, c->nA, RE, NP, pre, ntiles, c->stream());
+        }
+        for (u32 ch = 0; ch < nch; ch++) {
+            const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
+            size_t ev = timed ? c->ev_begin(1) : 0;
+            const int g = lf::launch_ajtai_i8g(R, c->dAb + (size_t)ch * chunk_bytes, MT, pre, ntiles, c->nA, kn, row0, c->kappa, NP, nwg, part, dsum, sum, co, c->stream());
+            if (timed) c->ev_end(ev);
+            if (g < 0) return LF_ERR_UNSUPPORTED;
+        }
+        launch_aos_to_soa(co, cf, c->kappa, c->stream());       // canonical -> Montgomery planes
+        launch_crt_fwd(c->dev, cf, ntt, c->kappa, c->stream());
+        launch_soa_to_aos(ntt, out_dev + (size_t)b * c->kappa * RE, c->kappa, c->stream());
+    }
+    return LF_OK;
+}
+static bool want_ajtai_i8g(const C *c) { return c->i8_nch && c->dAb && !getenv("LF_AJTAI_VALU") && !getenv("LF_COMMIT_VALU"); }
 // F: [batch][72][ldF]; out_dev: canonical u64 [batch][kappa][72]
 static int commit_dev(C *c, const fe *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
+    if (want_ajtai_i8g(c)) return commit_dev_i8g(c, F, ldF, batch, nullptr, 0, out_dev, timed);
     u32 maxb = 256 / c->kappa;
     if (maxb > 16) maxb = 16;    // LDS: (kappa + 2*batch) rows of 289 words
     if (maxb < 1) return LF_ERR_UNSUPPORTED;
@@ -901,6 +960,13 @@ int BbCtx::witness_commit(const lf_witness *w, uint64_t *cm_out) {
     RET(c->tbuf("io_c", w->N * RE, &d));
     RET(c->tbuf("io_b", w->N * RE, &e));
     RET(c->tbuf("io_o", (size_t)c->kappa * RE, &o));
+    if (want_ajtai_i8g(c)) {     // the int32 planes of the handle are the operand
+        c->ev_reset();
+        RET(commit_dev_i8g(c, nullptr, 0, 1, w->planes + c->A_col0, w->N, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
+        c->ev_collect();
+        RET(down_small(c, o, (size_t)c->kappa * RE, cm_out));
+        return exchange_modsum(c, cm_out, (size_t)c->kappa * RE);
+    }
     launch_i32_to_coef(w->planes, d, w->N, c->stream());
     launch_crt_fwd(c->dev, d, e, w->N, c->stream());
     RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));

@@ -34,6 +34,23 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, 
                     const int32_t *planes2 = nullptr, uint64_t *coef_out2 = nullptr, const uint32_t *bits = nullptr, size_t bits_nw = 0, uint32_t bits_rows = 0);
 // bits (optional): the bit-plane form of `planes` (lf_sv_rounds.h launch_sv_bits over the same columns: [RD][bits_rows][bits_nw] words); the
 // 24-ring / 13-row-tile kernel then cuts its digits from two words per (plane, coefficient) and tile instead of eight int32 values
+// ---- general commitments on the same byte planes of A (lf_ajtai_i8g.hip): AjtaiCommitmentScheme::commit_ntt (commitment_scheme.rs:37-54,75-77),
+// Witness::commit (arith.rs:357-362).  f arrives as balanced base-128 digit words (launch_i8g_cut_*: pre [NP][RD][ldw], ldw >= ceil(n / 8)),
+// NP = ajtai_i8g_planes_general (an arbitrary element) or ajtai_i8g_planes_i32 (centred coefficients that fit an int32).
+uint32_t ajtai_i8g_planes_general(const AjtaiI8Ring &R);
+uint32_t ajtai_i8g_planes_i32();
+void launch_i8g_cut_u64(const uint64_t *coef /* [RD][ld] canonical */, size_t ld, size_t n, uint64_t p_small, uint32_t RD, uint32_t NP, unsigned long long *pre, size_t ldw,
+                        hipStream_t s);
+// ... straight from the NTT form of a Goldilocks vector f [24][ld] (dense inverse map icrt_mat [24][24] on the device)
+void launch_i8g_cut_ntt(const uint64_t *icrt_mat, const uint64_t *ntt, size_t ld, size_t n, uint32_t NP, unsigned long long *pre, size_t ldw, hipStream_t s);
+void launch_i8g_cut_i32(const int32_t *planes /* [RD][ld] centred */, size_t ld, size_t n, uint32_t RD, uint32_t NP, unsigned long long *pre, size_t ldw, hipStream_t s);
+// scratch sizes (int32 / int32 / int64 words) for a launch with these parameters; -1: shape not handled
+int ajtai_i8g_scratch(const AjtaiI8Ring &R, uint32_t MT, size_t n, uint32_t NP, uint32_t nwg, size_t *part_words, size_t *dsum_words, size_t *sum_words);
+// rows [row0, row0 + kappa) of the commitment (one packed row chunk of A with MT row tiles) in coefficient form, canonical, into coef_out
+// (element row0 + i of kappa_total; SoA [RD][kappa_total] or AoS per R.soa_out).  Returns the grid size or -1.
+int launch_ajtai_i8g(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const unsigned long long *pre, size_t ldw, size_t n, uint32_t kappa, uint32_t row0,
+                     uint32_t kappa_total, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s);
+int ajtai_i8g_read_prof(unsigned long long *out64);   // ... of the last general-commit launch made with LF_I8G_PROF set
 // measurement: per-phase shader-clock totals of the last launch made with LF_I8_PROF set (out64[8 waves][8]: 7 phases + tile count of workgroup 0)
 int ajtai_i8_read_prof(unsigned long long *out64);
 // v[k][c][q] = sum_j eq[q][j] * digit_k(planes[c][j]) on the matrix cores (Goldilocks; see lf_ajtai_i8.hip).  mode_bits: K binary digit planes,

@@ -1102,8 +1102,48 @@ static u32 ajtai_splits(size_t n) {
     if (s > 128) s = 128;
     return (u32)s;
 }
+// General commitments from the resident byte planes of A (lf_ajtai_i8g.hip): AjtaiCommitmentScheme::commit_ntt (commitment_scheme.rs:37-54,75-77) for
+// `batch` vectors F [batch][24][ldF] in NTT form (pointing at this rank's first column), or Witness::commit (arith.rs:357-362) for the centred int32
+// coefficient planes of a witness handle (F null, batch 1).  out_dev: [batch][kappa][24] NTT form, AoS (PARTIAL when sharded).
+static int commit_dev_i8g(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, const int32_t *planes, size_t ldp, u64 *out_dev, bool timed) {
+    if (!c->A_loaded || !c->i8_nch || !c->dAb) return LF_ERR_STATE;
+    const AjtaiI8Ring R = ajtai_i8_goldilocks();
+    const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc);
+    const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
+    const u32 NP = planes ? ajtai_i8g_planes_i32() : ajtai_i8g_planes_general(R);
+    const char *e_wgs = getenv("LF_I8G_WGS");           // (test hook: workgroups of the general commit kernel; default one per CU)
+    const u32 nwg = e_wgs && atoi(e_wgs) > 0 ? (u32)atoi(e_wgs) : 256;
+    size_t pw, dw, sw;
+    if (ajtai_i8g_scratch(R, MT, c->nA, NP, nwg, &pw, &dw, &sw) != 0) return LF_ERR_UNSUPPORTED;
+    unsigned long long *pre;
+    int32_t *part, *dsum;
+    long long *sum;
+    u64 *coef, *ntt;
+    RET(c->tbuf("i8g_pre", (size_t)NP * 24 * ntiles, &pre));
+    RET(c->tbuf("i8g_part", pw, &part));
+    RET(c->tbuf("i8g_dsum", dw, &dsum));
+    RET(c->tbuf("i8g_sum", sw, &sum));
+    RET(c->tbuf("i8g_coef", (size_t)24 * c->kappa, &coef));
+    RET(c->tbuf("i8g_ntt", (size_t)24 * c->kappa, &ntt));
+    for (u32 b = 0; b < batch; b++) {
+        if (planes) launch_i8g_cut_i32(planes, ldp, c->nA, 24, NP, pre, ntiles, c->stream());
+        else launch_i8g_cut_ntt(c->d_icrt, F + (size_t)b * 24 * ldF, ldF, c->nA, NP, pre, ntiles, c->stream());
+        for (u32 ch = 0; ch < nch; ch++) {
+            const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
+            size_t ev = timed ? c->ev_begin(1) : 0;
+            const int g = launch_ajtai_i8g(R, c->dAb + (size_t)ch * chunk_bytes, MT, pre, ntiles, c->nA, kn, row0, c->kappa, NP, nwg, part, dsum, sum, coef, c->stream());
+            if (timed) c->ev_end(ev);
+            if (g < 0) return LF_ERR_UNSUPPORTED;
+        }
+        launch_crt_fwd(c->dcrt, coef, ntt, c->kappa, c->stream());
+        launch_soa_to_aos(ntt, out_dev + (size_t)b * c->kappa * 24, c->kappa, c->stream());
+    }
+    return LF_OK;
+}
+static bool want_ajtai_i8g(const lf_ctx *c) { return c->i8_nch && c->dAb && !getenv("LF_AJTAI_VALU") && !getenv("LF_COMMIT_VALU"); }
 // F: [batch][24][ldF] device, pointing at this rank's first column; out_dev: [batch][kappa][24] device AoS (PARTIAL when sharded)
 static int commit_dev(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
+    if (want_ajtai_i8g(c)) return commit_dev_i8g(c, F, ldF, batch, nullptr, 0, out_dev, timed);
     RET(need_dA(c));
     // One LDS tile holds the (A, F) rows of a launch: at most 48 rows of A (kappa up to 128 -- the reference's Goldilocks rows go up to
     // kappa = 99, benches/config.toml:158 -- is cut into equal row chunks) and as many witnesses as fit next to them.
@@ -1529,9 +1569,15 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     if (w->N != c->nA_total) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
     u64 *d, *e, *o;
+    RET(c->tbuf("io_o", (size_t)c->kappa * 24, &o));
+    if (want_ajtai_i8g(c)) {     // the int32 planes of the handle are the operand: five base-128 digit planes, no NTT of the witness
+        c->ev_reset();
+        RET(commit_dev_i8g(c, nullptr, 0, 1, w->planes + c->A_col0, w->N, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
+        c->ev_collect();
+        return commit_download(c, o, (size_t)c->kappa * 24, cm_out);
+    }
     RET(c->tbuf("io_c", w->N * 24, &d));
     RET(c->tbuf("io_b", w->N * 24, &e));
-    RET(c->tbuf("io_o", (size_t)c->kappa * 24, &o));
     launch_i32_to_coef(w->planes, d, w->N, c->stream());
     launch_crt_fwd(c->dcrt, d, e, w->N, c->stream());
     RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));
@@ -3862,7 +3908,10 @@ int lf_prefetch_stats(lf_ctx *c, unsigned *issued, unsigned *consumed, unsigned 
     if (dropped) *dropped = c->pf.dropped;
     return LF_OK;
 }
-int lf_debug_i8_prof(uint64_t *out64) { return out64 ? ajtai_i8_read_prof((unsigned long long *)out64) : LF_ERR_INVALID; }
+int lf_debug_i8_prof(uint64_t *out64) {   // (LF_I8G_PROF set: the table of the general-commit kernel instead)
+    if (!out64) return LF_ERR_INVALID;
+    return getenv("LF_I8G_PROF") ? ajtai_i8g_read_prof((unsigned long long *)out64) : ajtai_i8_read_prof((unsigned long long *)out64);
+}
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
     *sv_round_mask = c->bb ? c->bb->fold_paths() : c->sv_round_mask;
