@@ -305,6 +305,38 @@ def lfplus_extra(world=1, rank=0, dist=None, device=0):
                       "is pinned to the reference through the transcript KATs only"}
 
 
+def ajtai_extra(device=0):
+    """The reference's own Ajtai bench rows (crates/latticefold/benches/ajtai.rs:15-31 "CommitNTT", build.rs:454-465): one AjtaiCommitmentScheme::commit_ntt
+    of a full-range vector, batch 1, at benches/config.toml:715 (GoldilocksRingNTT, kappa 20, n 2^20) and :670 (BabyBearRingNTT, kappa 15, n 2^20).  (Witness::commit
+    of the bench workload's own resident witness is timed next to the fold steps and appended to the same key.)  ms = HIP events around the whole device side of one commitment
+    (digit pass, int8 contraction k_ajtai_i8g, recombination, CRT of the kappa outputs); inputs resident (the upload of f is outside), matrix generated on the device.
+    frac = SURVEY 8(d) bytes (kappa + 1) N E over that time and the 8 TB/s HBM peak."""
+    import numpy as np
+    from latticefold_amd import api
+    rows = []
+    for ring, kappa, lg, ref in (("goldilocks", 20, 20, "benches/config.toml:715"), ("babybear", 15, 20, "benches/config.toml:670")):
+        rec = {"op": "AjtaiCommitmentScheme::commit_ntt", "ring": ring, "kappa": kappa, "n": 1 << lg, "reference_row": ref}
+        try:
+            ctx = api.Context(device, ring=ring)
+            n, E = 1 << lg, (192 if ring == "goldilocks" else 288)
+            p = 0xFFFFFFFF00000001 if ring == "goldilocks" else 15 * 2**27 + 1
+            sch = api.AjtaiCommitmentScheme(ctx, kappa=kappa, n=n, seed=0xA17A1)
+            f = np.random.default_rng(7).integers(0, p, size=(n, ctx.RE), dtype=np.uint64)
+            ms = []
+            for _ in range(4):
+                sch.commit_ntt(f)
+                ms.append(ctx.kernel_stats()["ajtai_ms"])
+            alg = (kappa + 1) * n * E
+            rec.update({"ms": min(ms[1:]), "ms_runs": ms[1:], "alg_bytes": alg, "achieved_GBps": alg / (min(ms[1:]) * 1e-3) / 1e9, "frac": alg / (min(ms[1:]) * 1e-3) / 8e12,
+                        "kernel": "k_ajtai_i8g (lf_ajtai_i8g.hip): exact int8 contraction of the byte planes of A with 10 (Goldilocks) / 5 (BabyBear) balanced base-128 digit planes of f"})
+            ctx.close()
+        except Exception as e:   # a reported extra: never lose the headline over it
+            rec["ms"] = None
+            rec["note"] = f"failed: {e!r}"
+        rows.append(rec)
+    return rows
+
+
 def _headline_fallback(args, world, wl, elapsed, shard, lfplus):
     """the metric line without the reporting extras (used only when the sharded LatticeFold+ extra hangs: the process group is unusable afterwards)"""
     sps = (1 if shard else world) * args.steps / elapsed
@@ -331,6 +363,7 @@ def main():
     ap.add_argument("--prefetch", action="store_true", help="announce the next step's instance before every step (lf_prefetch_instance): the step prepares the next right decomposition's "
                     "challenge-independent half.  Off by default: measured 0.8-1.9 ms SLOWER per C4 step at every trigger point (profiles/r05_prefetch_ab_c4.txt, DESIGN 5): the chip has no idle CUs to give")
     ap.add_argument("--no-prefetch", action="store_true", help="(default) every step computes its whole right decomposition itself")
+    ap.add_argument("--no-ajtai", action="store_true", help="skip the reference's Ajtai bench rows (commit_ntt at benches/config.toml:715 / :670; an extra key, not part of the metric)")
     ap.add_argument("--no-lfplus", action="store_true", help="skip the LatticeFold+ PlusProver::prove timing (an extra key, not part of the metric)")
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
@@ -492,6 +525,20 @@ def main():
             fixture_info["prefetch"] = None
         free_b, total_b = ctx.device_memory()
         mem_info["hbm_in_use_gib"] = (total_b - free_b) / 2.0 ** 30   # whole device, this process being its only user: context, witnesses, torch's own few MB
+        if world == 1 and not shard and not args.no_ajtai:
+            # Witness::commit (arith.rs:357-362) of the bench's own resident witness: the cm_i every fresh instance of a real chain needs.  After the timed loop
+            # (a reported extra); device side of the call (HIP events: digit pass of the int32 planes, int8 contraction, recombination, CRT)
+            try:
+                wms = []
+                for _ in range(4):
+                    wit.commit(scheme)
+                    wms.append(ctx.kernel_stats()["ajtai_ms"])
+                alg_w = (wl.kappa + 1) * wl.N * (192 if wl.ring == "goldilocks" else 288)
+                mem_info["witness_commit"] = {"op": "Witness::commit", "workload": wl.name, "kappa": wl.kappa, "n": wl.N, "ms": min(wms[1:]), "ms_runs": wms[1:], "alg_bytes": alg_w,
+                                              "achieved_GBps": alg_w / (min(wms[1:]) * 1e-3) / 1e9, "frac": alg_w / (min(wms[1:]) * 1e-3) / 8e12,
+                                              "kernel": "k_ajtai_i8g (5 balanced base-128 digit planes of the handle's int32 coefficients)"}
+            except Exception as e:
+                mem_info["witness_commit"] = {"op": "Witness::commit", "ms": None, "note": f"failed: {e!r}"}
         for st in extra:
             st[0].close()
         wit.free()
@@ -635,8 +682,11 @@ def main():
             kernels["k_ajtai"]["alg_bytes_8d_per_launch"] = bytes_8d
             kernels["k_ajtai"]["alg_bytes_per_launch"] = a_bytes
             kernels["k_ajtai"]["achieved_GBps"] = a_bytes / aj_t / 1e9 if aj_ms else 0.0
-            kernels["k_ajtai_i8"] = kernels.pop("k_ajtai")
-            dom = "k_ajtai_i8"
+            # the instantiation that is launched (lf_ajtai_i8.hip launch_ajtai_i8): the specialised-wave kernels for the 13-row-tile shape of the 24-ring and the
+            # 4-row-tile shape of the 72-ring, the generic one otherwise
+            mt = -(-NL * -(-wl.kappa // row_chunks) // 16)
+            dom = "k_ajtai_i8s<false,true,true>" if (RD, mt) == (24, 13) else ("k_ajtai_i8x<72,4>" if (RD, mt) == (72, 4) else "k_ajtai_i8")
+            kernels[dom] = kernels.pop("k_ajtai")
             tops = 2 * macs / aj_t / 1e12 if aj_ms else 0.0
             gbps_8d = bytes_8d / aj_t / 1e9 if aj_ms else 0.0
             roof = {"bound": "hbm", "kernel": dom, "achieved": gbps_8d, "peak": peak, "unit": "GB/s", "frac": gbps_8d / peak, "alg_bytes_per_launch": bytes_8d,
@@ -719,6 +769,10 @@ def main():
             out["exchanges"] = exch
         if replicas_extra is not None:
             out["replicas"] = replicas_extra
+        if world == 1 and not args.no_ajtai:
+            out["ajtai"] = ajtai_extra()
+            if "witness_commit" in mem_info:
+                out["ajtai"].append(mem_info["witness_commit"])
         if world == 1 and not args.no_lfplus:
             try:
                 out["lfplus"] = lfplus_extra()

@@ -36,6 +36,8 @@ struct BbCtxImpl {
     BbHostRing ring;
     DevBb dev;
     fe *d_icrt = nullptr;
+    fe *d_icrt_sp_val = nullptr;    // the rows of the inverse CRT map in compressed form ([72][8] values / columns), null when a row has more than 8 entries
+    u32 *d_icrt_sp_col = nullptr;
     fe *dA = nullptr;
     unsigned char *dAb = nullptr;   // the same matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 16
     u32 i8_nch = 0, i8_kc = 0;
@@ -183,6 +185,26 @@ static int install_tables(C *c, u64 nonres, const u64 *y) {
         for (int j = 0; j < D; j++) mat[(size_t)i * D + j] = from_canon(T.icrt[i][j]);
     if (!c->d_icrt) HIPCHK(lf_dev_malloc(&c->d_icrt, mat.size() * sizeof(fe)));
     HIPCHK(hipMemcpy(c->d_icrt, mat.data(), mat.size() * sizeof(fe), hipMemcpyHostToDevice));
+    // compressed rows for the digit pass of the general commitment (k_i8g_cut_ntt): the shipped tables have one entry per slot
+    std::vector<fe> sv((size_t)D * 8, 0);
+    std::vector<u32> sc((size_t)D * 8, 0xFFFFFFFFu);
+    bool sparse = true;
+    for (int r = 0; r < D && sparse; r++) {
+        int q = 0;
+        for (int col = 0; col < D; col++)
+            if (T.icrt[r][col]) {
+                if (q == 8) { sparse = false; break; }
+                sv[(size_t)r * 8 + q] = mat[(size_t)r * D + col]; sc[(size_t)r * 8 + q] = (u32)col; q++;
+            }
+    }
+    if (sparse) {
+        if (!c->d_icrt_sp_val) { HIPCHK(lf_dev_malloc(&c->d_icrt_sp_val, sv.size() * sizeof(fe))); HIPCHK(lf_dev_malloc(&c->d_icrt_sp_col, sc.size() * sizeof(u32))); }
+        HIPCHK(hipMemcpy(c->d_icrt_sp_val, sv.data(), sv.size() * sizeof(fe), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_icrt_sp_col, sc.data(), sc.size() * sizeof(u32), hipMemcpyHostToDevice));
+    } else if (c->d_icrt_sp_val) {
+        (void)hipFree(c->d_icrt_sp_val); (void)hipFree(c->d_icrt_sp_col);
+        c->d_icrt_sp_val = nullptr; c->d_icrt_sp_col = nullptr;
+    }
     return LF_OK;
 }
 int BbCtx::create(BbCtx **out, lf_ctx *owner, int device) {
@@ -237,6 +259,7 @@ void BbCtx::destroy() {
     if (c->dA) (void)hipFree(c->dA);
     if (c->dAb) (void)hipFree(c->dAb);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
+    if (c->d_icrt_sp_val) { (void)hipFree(c->d_icrt_sp_val); (void)hipFree(c->d_icrt_sp_col); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_round) (void)hipHostFree(c->h_round);
     if (c->tail_mail) (void)hipHostFree(c->tail_mail);
@@ -626,11 +649,10 @@ static int commit_dev_i8g(C *c, const fe *F, size_t ldF, u32 batch, const int32_
     size_t pw, dw, sw;
     if (lf::ajtai_i8g_scratch(R, MT, c->nA, NP, nwg, &pw, &dw, &sw) != 0) return LF_ERR_UNSUPPORTED;
     unsigned long long *pre;
-    int32_t *part, *dsum, *ipl = nullptr;
+    int32_t *part, *dsum;
     long long *sum;
     u64 *co;
-    fe *cf, *ntt, *slice = nullptr, *coef = nullptr;
-    int *viol = nullptr;
+    fe *cf, *ntt;
     RET(c->tbuf("i8g_pre", (size_t)NP * RE * ntiles, &pre));
     RET(c->tbuf("i8g_part", pw, &part));
     RET(c->tbuf("i8g_dsum", dw, &dsum));
@@ -638,34 +660,19 @@ static int commit_dev_i8g(C *c, const fe *F, size_t ldF, u32 batch, const int32_
     RET(c->tbuf("i8g_co", (size_t)RE * c->kappa, &co));
     RET(c->tbuf("i8g_cf", (size_t)RE * c->kappa, &cf));
     RET(c->tbuf("i8g_ntt", (size_t)RE * c->kappa, &ntt));
-    if (!planes) {
-        RET(c->tbuf("i8g_coef", (size_t)RE * c->nA, &coef));
-        RET(c->tbuf("i8g_ipl", (size_t)RE * c->nA, &ipl));
-        RET(c->tbuf("i8g_viol", 16, &viol));
-        if (ldF != c->nA) RET(c->tbuf("i8g_slice", (size_t)RE * c->nA, &slice));
-    }
     for (u32 b = 0; b < batch; b++) {
+        const size_t ev = timed ? c->ev_begin(1) : 0;   // the whole device side of one commitment: digit pass, contraction, recombination, CRT
         if (planes) lf::launch_i8g_cut_i32(planes, ldp, c->nA, RE, NP, pre, ntiles, c->stream());
-        else {
-            const fe *Fb = F + (size_t)b * RE * ldF;
-            if (slice) {   // a sharded rank: its column slice of the vector, compact
-                HIPCHK(hipMemcpy2DAsync(slice, c->nA * sizeof(fe), Fb, ldF * sizeof(fe), c->nA * sizeof(fe), RE, hipMemcpyDeviceToDevice, c->stream()));
-                Fb = slice;
-            }
-            launch_icrt_dense(c->d_icrt, Fb, coef, c->nA, c->stream());
-            launch_coef_to_i32(coef, ipl, c->nA, 0xFFFFFFFFu, viol, c->stream());    // centred residues (|v| <= (p - 1) / 2 < 2^30: the bound never trips)
-            lf::launch_i8g_cut_i32(ipl, c->nA, c->nA, RE, NP, pre, ntiles, c->stream());
-        }
+        else launch_i8g_cut_ntt(c->d_icrt, c->d_icrt_sp_val, c->d_icrt_sp_col, F + (size_t)b * RE * ldF, ldF, c->nA, NP, pre, ntiles, c->stream());
         for (u32 ch = 0; ch < nch; ch++) {
             const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
-            size_t ev = timed ? c->ev_begin(1) : 0;
             const int g = lf::launch_ajtai_i8g(R, c->dAb + (size_t)ch * chunk_bytes, MT, pre, ntiles, c->nA, kn, row0, c->kappa, NP, nwg, part, dsum, sum, co, c->stream());
-            if (timed) c->ev_end(ev);
             if (g < 0) return LF_ERR_UNSUPPORTED;
         }
         launch_aos_to_soa(co, cf, c->kappa, c->stream());       // canonical -> Montgomery planes
         launch_crt_fwd(c->dev, cf, ntt, c->kappa, c->stream());
         launch_soa_to_aos(ntt, out_dev + (size_t)b * c->kappa * RE, c->kappa, c->stream());
+        if (timed) c->ev_end(ev);
     }
     return LF_OK;
 }

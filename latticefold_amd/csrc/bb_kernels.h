@@ -37,6 +37,10 @@ void launch_reduce_rows(const i64 *partial, u32 nblocks, u32 nv, u64 *out_canon,
 // ---- CRT / ICRT ------------------------------------------------------------------------------------------------
 void launch_crt_fwd(const DevBb &t, const fe *coef, fe *ntt, size_t n, hipStream_t s);
 void launch_icrt_dense(const fe *icrt_mat /*72*72*/, const fe *ntt, fe *coef, size_t n, hipStream_t s);
+// digit pass of a general commitment (lf_ajtai_i8g.hip) from the NTT form f [72][ld]: inverse CRT map (dense, or its compressed rows sp_val / sp_col [72][8] when
+// no row has more than 8 entries) -> centred residues -> NP balanced base-128 digit words pre [NP][72][ldw]
+void launch_i8g_cut_ntt(const fe *icrt_mat, const fe *sp_val, const u32 *sp_col, const fe *ntt, size_t ld, size_t n, u32 NP, unsigned long long *pre, size_t ldw,
+                        hipStream_t s);
 
 // ---- decomposition ---------------------------------------------------------------------------------------------
 void launch_decompose(const fe *coef, size_t n, u64 base, u32 digits, int layout, fe *out, hipStream_t s, int mode = 0);

@@ -262,6 +262,75 @@ __global__ void __launch_bounds__(256) k_icrt_dense(const fe *mat, const fe *ntt
 void launch_icrt_dense(const fe *mat, const fe *ntt, fe *coef, size_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_icrt_dense, dim3(cdiv(n, 256)), dim3(256), 0, s, mat, ntt, coef, n);
 }
+// The digit pass of a general commitment (lf_ajtai_i8g.hip) straight from the NTT form: f [72][ld] -> coefficients (inverse CRT map through LDS) -> centred
+// residues -> NP balanced base-128 digit words per (coefficient, 8 columns): pre [NP][72][ldw], byte = 64 + digit.  Block = 32 columns (4 tiles).
+// The inverse map is data: `mat` is its dense 72 x 72 matrix; when every row has at most 8 non-zero entries (the shipped tables: one per slot) the
+// compressed rows sp_val / sp_col [72][8] make an output 8 products instead of 72.
+__global__ void __launch_bounds__(256) k_i8g_cut_ntt(const fe *mat, const fe *sp_val, const u32 *sp_col, const fe *ntt, size_t ld, size_t n, u32 NP, size_t ntiles,
+                                                     unsigned long long *pre, size_t ldw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cut[];
+    fe *M = (fe *)smem_cut;                                      // dense: [72][72]; compressed: [72][8]
+    u32 *MC = (u32 *)(M + (sp_val ? RE * 8 : RE * RE));          // compressed: [72][8] columns
+    fe *X = (fe *)(MC + (sp_val ? RE * 8 : 0));                  // [73][32] (row 72: zeros, the operand of a missing entry)
+    int32_t *Cf = (int32_t *)(X + 73 * 32);                      // [72][33] centred residues
+    if (sp_val) {
+        for (int t = threadIdx.x; t < RE * 8; t += 256) { M[t] = sp_val[t]; MC[t] = sp_col[t] < (u32)RE ? sp_col[t] : RE; }
+    } else
+        for (int t = threadIdx.x; t < RE * RE; t += 256) M[t] = mat[t];
+    if (threadIdx.x < 32) X[RE * 32 + threadIdx.x] = 0;
+    const size_t j0 = (size_t)blockIdx.x * 32;
+    for (int t = threadIdx.x; t < RE * 32; t += 256) {
+        const u32 c = t >> 5, jj = t & 31;
+        X[c * 32 + jj] = j0 + jj < n ? ntt[(size_t)c * ld + j0 + jj] : 0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < RE * 32; t += 256) {
+        const u32 r = t >> 5, jj = t & 31;
+        fe v;
+        if (sp_val) {
+            i64 acc = 0;                                         // eight products: exact in 64 bits
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc += (i64)M[r * 8 + q] * (i64)X[MC[r * 8 + q] * 32 + jj];
+            v = mred(acc);
+        } else {
+            i64 tot = 0;
+            for (int g = 0; g < 8; g++) {
+                i64 acc = 0;
+#pragma unroll
+                for (int c = 0; c < 9; c++) acc += (i64)M[r * RE + 9 * g + c] * (i64)X[(9 * g + c) * 32 + jj];
+                tot += mred(acc);
+            }
+            v = fred(tot);
+        }
+        const u32 cv = to_canon(v);
+        Cf[r * 33 + jj] = cv > (BB_P - 1) / 2 ? (int32_t)cv - (int32_t)BB_P : (int32_t)cv;
+    }
+    __syncthreads();
+    for (u32 item = threadIdx.x; item < (u32)RE * 4; item += 256) {
+        const u32 c = item >> 2, tl = item & 3;
+        const size_t T = (size_t)blockIdx.x * 4 + tl;
+        if (T >= ntiles) continue;
+        int32_t x[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = Cf[c * 33 + tl * 8 + q];
+        for (u32 k = 0; k < NP; k++) {
+            unsigned long long w = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int32_t t = x[q] + 64;
+                w |= (unsigned long long)(t & 127) << (8 * q);
+                x[q] = t >> 7;
+            }
+            pre[((size_t)k * RE + c) * ldw + T] = w;
+        }
+    }
+}
+void launch_i8g_cut_ntt(const fe *icrt_mat, const fe *sp_val, const u32 *sp_col, const fe *ntt, size_t ld, size_t n, u32 NP, unsigned long long *pre, size_t ldw,
+                        hipStream_t s) {
+    const size_t ntiles = (n + 7) / 8;
+    const size_t lds = (sp_val ? (size_t)RE * 8 * 8 : (size_t)RE * RE * 4) + 73 * 32 * 4 + 72 * 33 * 4;
+    if (n) hipLaunchKernelGGL(k_i8g_cut_ntt, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), lds, s, icrt_mat, sp_val, sp_col, ntt, ld, n, NP, ntiles, pre, ldw);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // balanced decomposition on coefficient tables, power-of-two base (stark_rings::balanced_decomposition; call sites

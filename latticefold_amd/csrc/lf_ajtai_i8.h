@@ -42,7 +42,9 @@ uint32_t ajtai_i8g_planes_i32();
 void launch_i8g_cut_u64(const uint64_t *coef /* [RD][ld] canonical */, size_t ld, size_t n, uint64_t p_small, uint32_t RD, uint32_t NP, unsigned long long *pre, size_t ldw,
                         hipStream_t s);
 // ... straight from the NTT form of a Goldilocks vector f [24][ld] (dense inverse map icrt_mat [24][24] on the device)
-void launch_i8g_cut_ntt(const uint64_t *icrt_mat, const uint64_t *ntt, size_t ld, size_t n, uint32_t NP, unsigned long long *pre, size_t ldw, hipStream_t s);
+// sp_val / sp_col (optional, [24][8]): the rows of the same map in compressed form when none has more than 8 non-zero entries (column 0xFFFFFFFF = no entry)
+void launch_i8g_cut_ntt(const uint64_t *icrt_mat, const uint64_t *sp_val, const uint32_t *sp_col, const uint64_t *ntt, size_t ld, size_t n, uint32_t NP,
+                        unsigned long long *pre, size_t ldw, hipStream_t s);
 void launch_i8g_cut_i32(const int32_t *planes /* [RD][ld] centred */, size_t ld, size_t n, uint32_t RD, uint32_t NP, unsigned long long *pre, size_t ldw, hipStream_t s);
 // scratch sizes (int32 / int32 / int64 words) for a launch with these parameters; -1: shape not handled
 int ajtai_i8g_scratch(const AjtaiI8Ring &R, uint32_t MT, size_t n, uint32_t NP, uint32_t nwg, size_t *part_words, size_t *dsum_words, size_t *sum_words);

@@ -462,11 +462,19 @@ __global__ void __launch_bounds__(256) k_i8g_cut(const void *src, size_t ld, siz
         pre[((size_t)k * RD + c) * ldw + T] = w;
     }
 }
-// The Goldilocks digit pass straight from the NTT form: f [24][ld] -> coefficients (dense 24 x 24 inverse map through LDS, as k_ajtai_icrt_pack_i8)
-// -> digit words.  Block = 32 columns (4 tiles).
-__global__ void __launch_bounds__(256) k_i8g_cut_ntt(const u64 *mat, const u64 *ntt, size_t ld, size_t n, u32 NP, size_t ntiles, ull *pre, size_t ldw) {
-    __shared__ u64 M[24 * 24], X[24][32], Cf[24][33];
-    for (int t = threadIdx.x; t < 576; t += 256) M[t] = mat[t];
+// The Goldilocks digit pass straight from the NTT form: f [24][ld] -> coefficients (the inverse CRT map through LDS, as k_ajtai_icrt_pack_i8) -> digit
+// words.  Block = 32 columns (4 tiles).  The inverse map is data (lf_set_ring_tables): `mat` is its dense 24 x 24 matrix; when every row has at most 8 non-zero
+// entries -- the shipped tables: one per slot -- the host also passes the compressed rows sp_val / sp_col [24][8] (column 0xFFFFFFFF = no entry) and an
+// output costs 8 lazy 64 x 64 products instead of 24 (the dense pass was 0.5 ms of a 2.0 ms commitment at 2^20 columns: integer-multiplier-bound).
+__global__ void __launch_bounds__(256) k_i8g_cut_ntt(const u64 *mat, const u64 *sp_val, const u32 *sp_col, const u64 *ntt, size_t ld, size_t n, u32 NP, size_t ntiles,
+                                                     ull *pre, size_t ldw) {
+    __shared__ u64 M[24 * 24], X[25][32], Cf[24][33];
+    __shared__ u32 MC[24 * 8];
+    if (sp_val) {
+        if (threadIdx.x < 192) { M[threadIdx.x] = sp_val[threadIdx.x]; MC[threadIdx.x] = sp_col[threadIdx.x] < 24 ? sp_col[threadIdx.x] : 24; }
+        if (threadIdx.x < 32) X[24][threadIdx.x] = 0;           // (row 24: the operand of a missing entry)
+    } else
+        for (int t = threadIdx.x; t < 576; t += 256) M[t] = mat[t];
     const size_t j0 = (size_t)blockIdx.x * 32;
     for (int t = threadIdx.x; t < 768; t += 256) {
         const u32 c = t >> 5, jj = t & 31;
@@ -476,9 +484,15 @@ __global__ void __launch_bounds__(256) k_i8g_cut_ntt(const u64 *mat, const u64 *
     for (int t = threadIdx.x; t < 768; t += 256) {
         const u32 r = t >> 5, jj = t & 31;
         Acc a;
-        acc_set(a, M[r * 24], X[0][jj]);
+        if (sp_val) {
+            acc_set(a, M[r * 8], X[MC[r * 8]][jj]);
 #pragma unroll
-        for (int c = 1; c < 24; c++) acc_mad(a, M[r * 24 + c], X[c][jj]);
+            for (int q = 1; q < 8; q++) acc_mad(a, M[r * 8 + q], X[MC[r * 8 + q]][jj]);
+        } else {
+            acc_set(a, M[r * 24], X[0][jj]);
+#pragma unroll
+            for (int c = 1; c < 24; c++) acc_mad(a, M[r * 24 + c], X[c][jj]);
+        }
         Cf[r][jj] = acc_reduce(a);
     }
     __syncthreads();
@@ -503,9 +517,10 @@ __global__ void __launch_bounds__(256) k_i8g_cut_ntt(const u64 *mat, const u64 *
         pre[((size_t)k * 24 + c) * ldw + T] = w;
     }
 }
-void launch_i8g_cut_ntt(const u64 *icrt_mat, const u64 *ntt, size_t ld, size_t n, u32 NP, unsigned long long *pre, size_t ldw, hipStream_t s) {
+void launch_i8g_cut_ntt(const u64 *icrt_mat, const u64 *sp_val, const u32 *sp_col, const u64 *ntt, size_t ld, size_t n, u32 NP, unsigned long long *pre, size_t ldw,
+                        hipStream_t s) {
     const size_t ntiles = (n + 7) / 8;
-    hipLaunchKernelGGL(k_i8g_cut_ntt, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), 0, s, icrt_mat, ntt, ld, n, NP, ntiles, pre, ldw);
+    hipLaunchKernelGGL(k_i8g_cut_ntt, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), 0, s, icrt_mat, sp_val, sp_col, ntt, ld, n, NP, ntiles, pre, ldw);
 }
 void launch_i8g_cut_u64(const u64 *coef, size_t ld, size_t n, u64 p_small, u32 RD, u32 NP, unsigned long long *pre, size_t ldw, hipStream_t s) {
     const size_t ntiles = (n + 7) / 8;

@@ -149,6 +149,8 @@ struct lf_ctx {
     HostRing ring;
     DevCrt dcrt;
     u64 *d_icrt = nullptr;
+    u64 *d_icrt_sp_val = nullptr;   // the rows of the inverse CRT map in compressed form ([24][8] values / columns), null when a row has more than 8 entries
+    u32 *d_icrt_sp_col = nullptr;
     // Ajtai (nA = columns held by this rank, starting at global column A_col0 of nA_total)
     LaneWorker lane1;
     u64 *dA = nullptr;              // NTT form (general commitments); absent in digits-only mode until one is asked for (need_dA)
@@ -447,6 +449,27 @@ static int install_tables(lf_ctx *c, u64 nonres, const u64 *y) {
     c->dcrt = make_dev_crt(T);
     if (!c->d_icrt) HIPCHK(lf_dev_malloc(&c->d_icrt, 576 * 8));
     HIPCHK(hipMemcpy(c->d_icrt, &T.icrt[0][0], 576 * 8, hipMemcpyHostToDevice));
+    // compressed rows for the digit pass of the general commitment (lf_ajtai_i8g.hip k_i8g_cut_ntt): the shipped tables have one entry per slot
+    u64 sv[24 * 8];
+    u32 sc[24 * 8];
+    bool sparse = true;
+    for (int r = 0; r < 24 && sparse; r++) {
+        int q = 0;
+        for (int col = 0; col < 24; col++)
+            if (T.icrt[r][col]) {
+                if (q == 8) { sparse = false; break; }
+                sv[r * 8 + q] = T.icrt[r][col]; sc[r * 8 + q] = (u32)col; q++;
+            }
+        for (; q < 8; q++) { sv[r * 8 + q] = 0; sc[r * 8 + q] = 0xFFFFFFFFu; }
+    }
+    if (sparse) {
+        if (!c->d_icrt_sp_val) { HIPCHK(lf_dev_malloc(&c->d_icrt_sp_val, sizeof(sv))); HIPCHK(lf_dev_malloc(&c->d_icrt_sp_col, sizeof(sc))); }
+        HIPCHK(hipMemcpy(c->d_icrt_sp_val, sv, sizeof(sv), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_icrt_sp_col, sc, sizeof(sc), hipMemcpyHostToDevice));
+    } else if (c->d_icrt_sp_val) {
+        (void)hipFree(c->d_icrt_sp_val); (void)hipFree(c->d_icrt_sp_col);
+        c->d_icrt_sp_val = nullptr; c->d_icrt_sp_col = nullptr;
+    }
     return LF_OK;
 }
 
@@ -528,6 +551,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->dAb) (void)hipFree(c->dAb);
     for (int l = 0; l < LF_NLANES; l++) if (c->stage[l]) (void)hipHostFree(c->stage[l]);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
+    if (c->d_icrt_sp_val) { (void)hipFree(c->d_icrt_sp_val); (void)hipFree(c->d_icrt_sp_col); }
     for (int l = 0; l < LF_NLANES; l++)
         if (c->h_pin_lane[l]) (void)hipHostFree(c->h_pin_lane[l]);
     if (c->h_pin2) { (void)hipHostFree(c->h_pin2); c->h_pin2 = nullptr; }
@@ -1126,17 +1150,17 @@ static int commit_dev_i8g(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, const 
     RET(c->tbuf("i8g_coef", (size_t)24 * c->kappa, &coef));
     RET(c->tbuf("i8g_ntt", (size_t)24 * c->kappa, &ntt));
     for (u32 b = 0; b < batch; b++) {
+        const size_t ev = timed ? c->ev_begin(1) : 0;   // the whole device side of one commitment: digit pass, contraction, recombination, CRT
         if (planes) launch_i8g_cut_i32(planes, ldp, c->nA, 24, NP, pre, ntiles, c->stream());
-        else launch_i8g_cut_ntt(c->d_icrt, F + (size_t)b * 24 * ldF, ldF, c->nA, NP, pre, ntiles, c->stream());
+        else launch_i8g_cut_ntt(c->d_icrt, c->d_icrt_sp_val, c->d_icrt_sp_col, F + (size_t)b * 24 * ldF, ldF, c->nA, NP, pre, ntiles, c->stream());
         for (u32 ch = 0; ch < nch; ch++) {
             const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
-            size_t ev = timed ? c->ev_begin(1) : 0;
             const int g = launch_ajtai_i8g(R, c->dAb + (size_t)ch * chunk_bytes, MT, pre, ntiles, c->nA, kn, row0, c->kappa, NP, nwg, part, dsum, sum, coef, c->stream());
-            if (timed) c->ev_end(ev);
             if (g < 0) return LF_ERR_UNSUPPORTED;
         }
         launch_crt_fwd(c->dcrt, coef, ntt, c->kappa, c->stream());
         launch_soa_to_aos(ntt, out_dev + (size_t)b * c->kappa * 24, c->kappa, c->stream());
+        if (timed) c->ev_end(ev);
     }
     return LF_OK;
 }
