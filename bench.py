@@ -337,6 +337,80 @@ def ajtai_extra(device=0):
     return rows
 
 
+def ivc_extra(name, steps, device=0, headline_ms=None):
+    """A real chain (crates/latticefold/examples/e2e.rs, nifs/tests.rs:58-117 made a loop): every step takes a NEW witness of the workload's constraint system from
+    host memory (workload.chain_w_ccs), ingests it (Witness::from_w_ccs, arith.rs:230-248: upload, ICRT, gadget decomposition), commits it (Witness::commit,
+    arith.rs:357-362: the int8 general commit), folds it into the carried accumulator (NIFSProver::prove) and frees what the step replaced.  Wall clock over `steps`
+    steps after two warm-up steps, bracketed by device synchronisation; parts = host wall time of the three calls.  The witnesses are generated before the loop."""
+    import hashlib
+    import numpy as np
+    import torch
+    from latticefold_amd import api
+    from latticefold_amd.workload import chain_w_ccs, make_workload
+    rec = {"op": "chain: from_w_ccs + Witness::commit + NIFSProver::prove per step", "workload": name, "steps": steps}
+    try:
+        wl = make_workload(name)
+        ctx = api.Context(device, ring=wl.ring)
+        ctx.load_ccs(wl)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
+        tr = lambda: api.PoseidonTranscript(ring=wl.ring)
+        warm = 2
+        ws = [np.ascontiguousarray(chain_w_ccs(wl, j)) for j in range(1, warm + steps + 1)]
+        w_acc = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+        acc, _ = api.LFLinearizationProver.prove(ctx, np.concatenate([w_acc.commit(scheme), wl.x_ccs]), w_acc, tr())
+        parts = {"ingest": 0.0, "commit": 0.0, "fold": 0.0}
+        norm_max, last = 0, None
+        t_start = None
+        for j, w in enumerate(ws):
+            if j == warm:
+                torch.cuda.synchronize(device)
+                parts = {k: 0.0 for k in parts}
+                t_start = time.perf_counter()
+            t0 = time.perf_counter()
+            w_j = api.Witness.from_w_ccs(ctx, w)
+            t1 = time.perf_counter()
+            cccs = np.concatenate([w_j.commit(scheme), wl.x_ccs])
+            t2 = time.perf_counter()
+            lc, w_next, proof = api.NIFSProver.prove(ctx, acc, w_acc, cccs, w_j, tr())
+            t3 = time.perf_counter()
+            parts["ingest"] += t1 - t0; parts["commit"] += t2 - t1; parts["fold"] += t3 - t2
+            w_j.free(); w_acc.free()
+            acc, w_acc, last = lc, w_next, proof
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t_start
+        ok, mx = ctx.linf_check(w_acc.f, wl.B // 2)     # (after the timed region)
+        rec.update({"ms_per_step": elapsed / steps * 1e3, "steps_per_s": steps / elapsed, "parts_ms_per_step": {k: v / steps * 1e3 for k, v in parts.items()},
+                    "witness_upload_bytes_per_step": int(ws[0].nbytes), "folded_norm_below_B_half": bool(ok), "folded_norm": int(mx),
+                    "headline_ms_per_step": headline_ms, "over_headline_ms": (elapsed / steps * 1e3 - headline_ms) if headline_ms else None})
+        try:   # tie the chain to the oracle-only fixture where one exists for this workload (tests/golden/chain_digests.json): replay its steps from a fresh accumulator
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "chain_digests.json"))).get(name)
+            if gold:
+                w_a = api.Witness.from_w_ccs(ctx, wl.w_ccs)
+                a, _ = api.LFLinearizationProver.prove(ctx, np.concatenate([w_a.commit(scheme), wl.x_ccs]), w_a, tr())
+                good = True
+                for j, g in enumerate(gold["steps"], start=1):
+                    w_j = api.Witness.from_w_ccs(ctx, chain_w_ccs(wl, j))
+                    lc, w_n, proof = api.NIFSProver.prove(ctx, a, w_a, np.concatenate([w_j.commit(scheme), wl.x_ccs]), w_j, tr())
+                    good = good and hashlib.sha256(np.ascontiguousarray(proof, dtype=np.uint64).tobytes()).hexdigest() == g["proof"]
+                    w_j.free(); w_a.free()
+                    a, w_a = lc, w_n
+                rec["matches_oracle_chain_fixture"] = bool(good)
+                rec["fixture"] = f"tests/golden/chain_digests.json[{name}]: {len(gold['steps'])} steps, oracle only (tests/tools/make_chain_digests.py)"
+                w_a.free()
+            else:
+                rec["matches_oracle_chain_fixture"] = None
+                rec["fixture"] = "none at this size (tests/test_gpu_chain.py checks C4 chains through the oracle's verifier, the commitment opening and the norm)"
+        except Exception as e:
+            rec["matches_oracle_chain_fixture"] = None
+            rec["fixture"] = f"not checked: {e!r}"
+        w_acc.free()
+        ctx.close()
+    except Exception as e:   # a reported extra: never lose the headline over it
+        rec["ms_per_step"] = None
+        rec["note"] = f"failed: {e!r}"
+    return rec
+
+
 def _headline_fallback(args, world, wl, elapsed, shard, lfplus):
     """the metric line without the reporting extras (used only when the sharded LatticeFold+ extra hangs: the process group is unusable afterwards)"""
     sps = (1 if shard else world) * args.steps / elapsed
@@ -360,10 +434,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prefetch", action="store_true", help="announce the next step's instance before every step (lf_prefetch_instance): the step prepares the next right decomposition's "
-                    "challenge-independent half.  Off by default: measured 0.8-1.9 ms SLOWER per C4 step at every trigger point (profiles/r05_prefetch_ab_c4.txt, DESIGN 5): the chip has no idle CUs to give")
-    ap.add_argument("--no-prefetch", action="store_true", help="(default) every step computes its whole right decomposition itself")
     ap.add_argument("--no-ajtai", action="store_true", help="skip the reference's Ajtai bench rows (commit_ntt at benches/config.toml:715 / :670; an extra key, not part of the metric)")
+    ap.add_argument("--chain", type=int, default=8, help="steps of the chained-folding extra key `ivc` (every step ingests and commits a new witness and folds it into the "
+                                                         "carried accumulator; run for the bench workload and for C2); 0 = skip")
     ap.add_argument("--no-lfplus", action="store_true", help="skip the LatticeFold+ PlusProver::prove timing (an extra key, not part of the metric)")
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
@@ -410,7 +483,6 @@ def main():
     def measure(shard):
         """setup (untimed: everything resident in HBM), W warm-up steps, K timed steps bracketed by barrier + synchronize; max over ranks"""
         wl = make_workload(args.workload, seed=0 if shard else rank)
-        use_prefetch = args.prefetch and not args.no_prefetch and not shard and wl.ring == "goldilocks"
         ctx = api.Context(local_rank, ring=wl.ring)
         transport = None
         if shard:
@@ -418,9 +490,8 @@ def main():
             # RCCL communicators owned by the library (device-buffer all-gathers + modular-sum kernel); LF_DIST_BACKEND=gloo: host transport
             transport = lfd.init_sharding(ctx, rank, world, "auto")
         ctx.load_ccs(wl)
-        # generated on the device.  A folding prover commits digit planes only: the Goldilocks context keeps A as byte planes alone (lfhip.h
-        # lf_ajtai_set_digits_only; the one general commitment of the set-up, cm_i of the witness, rebuilds the NTT form for that call)
-        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed(), digits_only=(wl.ring == "goldilocks"))
+        # generated on the device (the context keeps it as int8 byte planes only: lfhip.h)
+        scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
         wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
         cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
         # accumulator = linearized copy (benches/utils.rs:637-655).  Both calls start from a FRESH transcript, exactly as tests/tools/make_scale_digests.py drives the
@@ -430,8 +501,6 @@ def main():
         last = {}
 
         def step():
-            if use_prefetch:      # the hint of include/lfhip.h, once per step INSIDE the timed loop: this step prepares the next step's right side (same shapes, no reuse
-                ctx.prefetch_instance(cccs, wit)      # beyond that one step; the first timed step consumes what the last warm-up step prepared, the last timed step prepares in vain)
             lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr0.clone())
             w0.free()
             last["lc"], last["proof"] = lc, proof
@@ -514,15 +583,6 @@ def main():
                                                 "(oracle-only fixture, tests/tools/make_scale_digests.py)" % wl.name)
             except Exception as e:      # (a missing fixture is not a bench failure)
                 fixture_info.update(matches_oracle_fixture=None, fixture=f"not checked: {e!r}")
-        if use_prefetch:
-            pi, pu, pd = ctx.prefetch_stats()
-            fixture_info["prefetch"] = {"enqueued": pi, "used": pu, "dropped": pd,
-                                        "note": "lf_prefetch_instance before every step (warm-up and timed): the step enqueues the challenge-independent half of the NEXT step's right "
-                                                "decomposition (bit planes, z_k, K-1 digit-plane commits of w_i: decomposition.rs:159-201) on a side stream while its own launches are "
-                                                "latency-bound; every step still executes one such half (for its successor) inside the timed region, results are used exactly once, "
-                                                "proofs are bit-identical (tests/test_gpu_prefetch.py).  --no-prefetch: every step computes its own right side inside its first phase"}
-        else:
-            fixture_info["prefetch"] = None
         free_b, total_b = ctx.device_memory()
         mem_info["hbm_in_use_gib"] = (total_b - free_b) / 2.0 ** 30   # whole device, this process being its only user: context, witnesses, torch's own few MB
         if world == 1 and not shard and not args.no_ajtai:
@@ -647,7 +707,7 @@ def main():
         }
         # the batched commit is the largest single kernel (two launches per step); the twenty fold-round launches together are of the same order and are
         # listed next to it in `kernels`.  Fixed choice: the two totals are within a few per cent of each other, so a max() would flip from run to run.
-        i8 = wl.b == 2 and not os.environ.get("LF_AJTAI_VALU")   # digit-plane commits on the int8 matrix cores (lf_ajtai_i8.hip), both rings
+        i8 = wl.b == 2   # digit-plane commits on the int8 matrix cores (lf_ajtai_i8.hip), both rings
         dom = "k_ajtai"
         peak = 8000.0
         # HBM traffic of the dominant kernel from the PMC passes (collected separately, as rocprofv3 requires; see profiles/)
@@ -732,8 +792,7 @@ def main():
             "config": {"workload": f"{wl.name}: {'GoldilocksRingNTT' if wl.ring == 'goldilocks' else 'BabyBearRingNTT'} R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
                                    f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world}: one fold stream, witness columns / table rows sharded by the high index bits (Ajtai commits, linearization and folding sumcheck rounds, v/u/eta evaluations), RCCL all-gather + modular sum per exchange" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
                        "alg_bytes_per_step": alg, "hbm_in_use_gib": round(mem_info.get("hbm_in_use_gib", 0.0), 2),
-                       "folded_witness": ("LF_LAZY_FROM_F=1: the timed step leaves the folded witness as int32 coefficient planes only; f_0 (NTT form) and w_ccs are built on demand" if os.environ.get("LF_LAZY_FROM_F") else
-                                          "Witness::from_f in full inside the timed step (arith.rs:299-313): the folded witness leaves the step as int32 coefficient planes (f_coeff, what the next step reads), "
+                       "folded_witness": ("Witness::from_f in full inside the timed step (arith.rs:299-313): the folded witness leaves the step as int32 coefficient planes (f_coeff, what the next step reads), "
                                           "f_0 in NTT form and w_ccs, all three on the device (lf_witness_get_f / _get_w_ccs only download)"),
                        "parity": "bit-exact vs in-repo CPU oracle; CRT/digit tables not yet confirmed against stark-rings@886a89f"},
             "roofline": roof,
@@ -773,6 +832,10 @@ def main():
             out["ajtai"] = ajtai_extra()
             if "witness_commit" in mem_info:
                 out["ajtai"].append(mem_info["witness_commit"])
+        if world == 1 and args.chain > 0 and args.streams == 1:
+            out["ivc"] = [ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3)]
+            if wl.name != "C2" and wl.ring == "goldilocks":
+                out["ivc"].append(ivc_extra("C2", args.chain, local_rank))
         if world == 1 and not args.no_lfplus:
             try:
                 out["lfplus"] = lfplus_extra()

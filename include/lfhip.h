@@ -123,15 +123,10 @@ int lf_linf_check(lf_ctx *, const uint64_t *f_ntt, size_t count, uint64_t bound,
 /* ---- a5: AjtaiCommitmentScheme::{new, commit, commit_ntt} (commitment_scheme.rs:23-77) -------- */
 /* kappa <= 128 (Goldilocks: more than 48 rows of A are committed in equal row chunks, one LDS tile each) / 32 (BabyBear);
  * larger -> LF_ERR_INVALID */
-/* Besides the NTT-form copy (general commitments) both calls build a second resident form of A for the digit-plane commitments of
- * the decomposition step (decomposition.rs:178-201): coefficient form, cut into bytes, in int8-MFMA operand order (lf_ajtai_i8.hip) --
- * 8*24*kappa*n bytes more for Goldilocks (4*72*kappa*n for BabyBear), built once here, never per step.  LF_AJTAI_VALU=1 in the
- * environment skips it and keeps those commitments on the integer-multiplier kernel. */
-/* Digits-only mode (set BEFORE load / generate; Goldilocks contexts, ignored under LF_AJTAI_VALU=1): a prover that only folds commits
- * nothing but digit planes, so the context keeps the byte planes alone -- rows pass through one u64 row buffer on their way in
- * (8*24*kappa*n bytes less: 4.9 GiB at C4).  A general commitment (lf_ajtai_commit, lf_witness_commit) still works: the NTT form is
- * rebuilt from the bytes for that call and given back afterwards.  Switching it on for a loaded matrix drops the NTT copy at once. */
-int lf_ajtai_set_digits_only(lf_ctx *, int on);
+/* The context keeps A in ONE resident form: coefficient form, cut into bytes, in int8-MFMA operand order (lf_ajtai_i8.hip) -- 8*24*kappa*n bytes for
+ * Goldilocks, 4*72*kappa*n for BabyBear, built once here (rows pass through one row buffer on their way in), never per step.  The digit-plane commitments
+ * of the decomposition step (decomposition.rs:178-201) and the general commitments below (commit_ntt, Witness::commit: lf_ajtai_i8g.hip) both stream it;
+ * there is no NTT-form copy and no integer-multiplier commit kernel any more. */
 /* free / total bytes of the context's device as the HIP runtime reports them (hipMemGetInfo): what a caller sizes batches against */
 int lf_device_memory(lf_ctx *, size_t *free_bytes, size_t *total_bytes);
 int lf_ajtai_load(lf_ctx *, const uint64_t *A /* kappa*n ring elements, row-major, NTT form */, size_t kappa, size_t n);
@@ -281,17 +276,6 @@ int lf_linearize(lf_ctx *, lf_transcript *, const uint64_t *cccs, const lf_witne
 /* NIFSProver::prove (nifs.rs:48-103): one fold step.  w_out receives the folded witness handle. */
 int lf_fold_step(lf_ctx *, lf_transcript *, const uint64_t *acc_lcccs, const lf_witness *w_acc, const uint64_t *cm_i_cccs,
                  const lf_witness *w_i, uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof_out);
-/* Hint for a chain of fold steps (no counterpart in the reference, whose prove() is one synchronous CPU call): the NEXT step's fresh instance.
- * The challenge-independent half of the right decomposition -- the digit planes of w_i, their K - 1 Ajtai commitments y_k (k >= 1), z_k = x_s[k] || w_k
- * (nifs/decomposition.rs:159-201: functions of w_i and x_ccs alone; no transcript challenge enters) -- is a third of a step's GPU work, and the tail of a step
- * (small sumcheck rounds, host transcript) leaves the GPU nearly idle.  Call this BEFORE the lf_fold_step that precedes the step folding (cm_next, w_next):
- * that step enqueues the work for (cm_next, w_next) on a side stream once its own launches are latency-bound, and the following lf_fold_step uses the
- * results if -- and only if -- it is called with that very witness handle (pointer and serial number) and the same x_ccs; otherwise they are discarded
- * and it computes everything itself.  One request, one result, one consumer: nothing is kept across more than one step boundary, proofs are bit-identical
- * with and without the hint.  w_next must stay alive and unchanged until that step has run.  Contexts / shapes without a prefetch path (BabyBear, sharded,
- * VALU commits) accept and ignore the hint.  lf_prefetch_stats: how many requests were enqueued, used, dropped (any pointer may be NULL). */
-int lf_prefetch_instance(lf_ctx *, const uint64_t *cm_next_cccs, const lf_witness *w_next);
-int lf_prefetch_stats(lf_ctx *, unsigned *issued, unsigned *consumed, unsigned *dropped);
 
 /* The two other sub-provers of the reference as entry points of their own (the reference exposes all three as public traits).
  * LFDecompositionProver::prove (nifs/decomposition.rs:33-88): dec_proof_out = u_s[K][t] | v_s[K][tau] | x_s[K][l+1] | y_s[K][kappa]

@@ -100,11 +100,6 @@ int lfplus_rg_from_f(lfplus_ctx *ctx, uint64_t b, uint32_t k, uint32_t l);
  * A sharded context ignores the hint.  LFPLUS_NO_ASYNC_FROM_F=1 in the environment turns the hint off. */
 int lfplus_rg_from_f_async(lfplus_ctx *ctx, uint64_t b, uint32_t k, uint32_t l);
 int lfplus_join_async(lfplus_ctx *ctx);
-/* The challenge-free three quarters of Cm::prove's instance tables for instance l of L (tau_l, m_tau, f and M_q tau, M_q m_tau, M_q f over the nM RESIDENT matrices:
- * cm.rs:201-260 builds them inside prove, nothing in them depends on the transcript), enqueued on ctxs[l]'s second stream behind its from_f.  The buffers belong to
- * ctxs[0]; the next lfplus_cm_prove / lfplus_mlin over the same contexts, L, nM and resident matrices waits for them instead of building them.  A slot is used once
- * and only while the witness and from_f results it was built from are current.  Sharded contexts: a no-op.  LFPLUS_NO_ASYNC_CM_TABLES=1 turns it off. */
-int lfplus_cm_tables_async(lfplus_ctx *const *ctxs, uint32_t L, uint32_t l, uint32_t nM);
 /* Any pointer may be NULL.  Df: k*n*16 int8 (D_f[k_i][n_i][d_i]); comMf: k*kappa*16*16 words (comM_f[k_i][row][column] ring elements);
  * tau: n words; mtau: n int8 (exponent digits of m_tau); cm_f / C_Mf / cm_mtau: kappa*16 words each. */
 int lfplus_rg_read(lfplus_ctx *ctx, int8_t *Df, uint64_t *comMf, uint64_t *tau, int8_t *mtau, uint64_t *cm_f, uint64_t *C_Mf, uint64_t *cm_mtau);

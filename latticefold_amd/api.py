@@ -93,7 +93,6 @@ def _lib():
         L.lf_linf_check.argtypes = [vp, u64p, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_int), u64p]
         L.lf_ajtai_load.argtypes = [vp, u64p, C.c_size_t, C.c_size_t]
         L.lf_ajtai_generate.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t]
-        L.lf_ajtai_set_digits_only.argtypes = [vp, C.c_int]
         L.lf_device_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.lf_ajtai_commit.argtypes = [vp, u64p, C.c_size_t, C.c_size_t, u64p]
         L.lf_modsum.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
@@ -141,8 +140,6 @@ def _lib():
         L.lf_sumcheck_lin_end.argtypes = [vp]
         L.lf_linearize.argtypes = [vp, vp, u64p, vp, u64p, u64p]
         L.lf_fold_step.argtypes = [vp, vp, u64p, vp, u64p, vp, u64p, C.POINTER(vp), u64p]
-        L.lf_prefetch_instance.argtypes = [vp, u64p, vp]
-        L.lf_prefetch_stats.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.lf_device_sponge.argtypes = [vp, u32p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u64p]
         L.lf_sumcheck_fold_begin.argtypes = [vp, u64p, u64p]
         L.lf_sumcheck_fold_round.argtypes = [vp, u64p, u64p]
@@ -403,17 +400,6 @@ class Context:
         _chk(_lib().lf_last_phase_ms(self.h, out), "lf_last_phase_ms")
         return {_lib().lf_phase_name(i).decode(): float(out[i]) for i in range(8)}
 
-    def prefetch_instance(self, cm_next, w_next):
-        """lf_prefetch_instance: announce the fresh instance of the step AFTER the next NIFSProver.prove on this context (a hint; see include/lfhip.h)"""
-        a, p = _a64(cm_next)
-        _chk(_lib().lf_prefetch_instance(self.h, p, w_next.h), "lf_prefetch_instance")
-
-    def prefetch_stats(self):
-        """(enqueued, used, dropped) prefetch requests of this context"""
-        i, u, d = C.c_uint(), C.c_uint(), C.c_uint()
-        _chk(_lib().lf_prefetch_stats(self.h, C.byref(i), C.byref(u), C.byref(d)), "lf_prefetch_stats")
-        return i.value, u.value, d.value
-
     def fold_paths(self):
         m = C.c_uint()
         _chk(_lib().lf_last_fold_paths(self.h, C.byref(m)), "lf_last_fold_paths")
@@ -455,10 +441,8 @@ class Context:
 class AjtaiCommitmentScheme:
     """commitment/commitment_scheme.rs:17-114.  The matrix lives on the device."""
 
-    def __init__(self, ctx, matrix=None, kappa=None, n=None, seed=None, digits_only=False):
+    def __init__(self, ctx, matrix=None, kappa=None, n=None, seed=None):
         self.ctx = ctx
-        if digits_only:          # the fold step commits digit planes only: keep the byte planes, not the NTT-form copy (lfhip.h)
-            _chk(_lib().lf_ajtai_set_digits_only(ctx.h, 1), "lf_ajtai_set_digits_only")
         if matrix is not None:  # AjtaiCommitmentScheme::new
             a, p = _a64(matrix)
             self._kappa, self._n = a.shape[0], a.shape[1]
@@ -466,10 +450,6 @@ class AjtaiCommitmentScheme:
         else:                    # synthetic i.i.d. matrix generated on the device (bench)
             self._kappa, self._n = kappa, n
             _chk(_lib().lf_ajtai_generate(ctx.h, seed, kappa, n), "lf_ajtai_generate")
-
-    def set_digits_only(self, on=True):
-        """keep / drop the NTT-form copy of A (lf_ajtai_set_digits_only): general commitments rebuild it from the byte planes per call"""
-        _chk(_lib().lf_ajtai_set_digits_only(self.ctx.h, 1 if on else 0), "lf_ajtai_set_digits_only")
 
     def kappa(self):
         return self._kappa

@@ -38,7 +38,7 @@ struct BbCtxImpl {
     fe *d_icrt = nullptr;
     fe *d_icrt_sp_val = nullptr;    // the rows of the inverse CRT map in compressed form ([72][8] values / columns), null when a row has more than 8 entries
     u32 *d_icrt_sp_col = nullptr;
-    fe *dA = nullptr;
+    fe *dA = nullptr;               // the matrix in NTT form while it is being installed (freed once the byte planes are packed)
     unsigned char *dAb = nullptr;   // the same matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 16
     u32 i8_nch = 0, i8_kc = 0;
     u32 kappa = 0;
@@ -285,14 +285,14 @@ int BbCtx::set_ring_tables(uint64_t nonres, const uint64_t *y) {
 int BbCtx::set_sharding(int rank, int world, lf_exchange_fn cb, void *user) {
     if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0 || (world > 1 && !cb)) return LF_ERR_INVALID;
     std::lock_guard<std::mutex> g(p->mu);
-    if (p->dA) return LF_ERR_STATE;   // choose the sharding before loading/generating the Ajtai matrix
+    if (p->dAb) return LF_ERR_STATE;   // choose the sharding before loading/generating the Ajtai matrix
     p->comm.destroy();
     p->comm.rank = p->sh_rank = rank; p->comm.world = p->sh_world = world; p->comm.cb = cb; p->comm.user = user;
     return LF_OK;
 }
 int BbCtx::dist_init(int rank, int world, const uint8_t *id128) {
     std::lock_guard<std::mutex> g(p->mu);
-    if (p->dA) return LF_ERR_STATE;
+    if (p->dAb) return LF_ERR_STATE;
     HIPCHK(hipSetDevice(p->device));
     p->comm.destroy();
     RET(lfdist::rccl_init(p->comm, rank, world, id128));
@@ -540,7 +540,6 @@ int BbCtx::linf_check(const uint64_t *f_ntt, size_t count, uint64_t bound, int u
 static int prep_ajtai_i8(C *c) {
     if (c->dAb) { (void)hipFree(c->dAb); c->dAb = nullptr; }
     c->i8_nch = 0;
-    if (getenv("LF_AJTAI_VALU")) return LF_OK;
     const lf::AjtaiI8Ring R = lf::ajtai_i8_babybear();
     const u32 maxr = lf::ajtai_i8_max_rows(R), nch = (c->kappa + maxr - 1) / maxr, kc = (c->kappa + nch - 1) / nch;
     const size_t ntiles = (c->nA + 7) / 8;
@@ -560,6 +559,9 @@ static int prep_ajtai_i8(C *c) {
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->i8_nch = nch;
     c->i8_kc = kc;
+    // the byte planes are the only resident form of A: digit-plane and general commitments (lf_ajtai_i8.hip / lf_ajtai_i8g.hip) both stream them
+    (void)hipFree(c->dA);
+    c->dA = nullptr;
     return LF_OK;
 }
 // digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev canonical u64 [NP][kappa][72], NTT form (PARTIAL when sharded)
@@ -569,13 +571,14 @@ static int commit_planes_i8(C *c, const int32_t *planes, size_t ld, u32 k0, u32 
     const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
     u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 224;   // 7/8 of the CUs: see the Goldilocks backend
     if (nwg > ntiles) nwg = (u32)ntiles;
+    const u32 nslots = nwg < 16 ? 16 : nwg;    // (two plane groups run as 2 x 8 chunks at least: launch_ajtai_i8)
     int32_t *part, *dsum;
     long long *sum;
     u64 *coef;
     fe *cf, *ntt;
     const u32 NTmax = lf::ajtai_i8_col_tiles(R, maxp);
-    RET(c->tbuf("i8_part", lf::ajtai_i8_part_words(nwg, MT, NTmax), &part));
-    RET(c->tbuf("i8_dsum", (size_t)nwg * maxp * R.RD, &dsum));
+    RET(c->tbuf("i8_part", lf::ajtai_i8_part_words(nslots, MT, NTmax), &part));
+    RET(c->tbuf("i8_dsum", (size_t)nslots * maxp * R.RD, &dsum));
     RET(c->tbuf("i8_sum", lf::ajtai_i8_sum_words(R, MT, NTmax, maxp), &sum));
     RET(c->tbuf("i8_coef", (size_t)RE * NP * c->kappa, &coef));
     RET(c->tbuf("i8_cf", (size_t)RE * NP * c->kappa, &cf));
@@ -629,12 +632,6 @@ int BbCtx::ajtai_generate(uint64_t seed, size_t kappa, size_t n) {
     c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
     return prep_ajtai_i8(c);
 }
-static u32 ajtai_splits(size_t n) {
-    size_t s = n / 256;
-    if (s < 1) s = 1;
-    if (s > 128) s = 128;
-    return (u32)s;
-}
 // General commitments from the resident byte planes of A (lf_ajtai_i8g.hip, shared with the Goldilocks backend): commit_ntt for `batch` vectors
 // F [batch][72][ldF] in NTT form (pointing at this rank's first column), or Witness::commit for the centred int32 planes of a witness handle
 // (F null, batch 1).  Five balanced base-128 digit planes cover the centred 31-bit residues.  out_dev: canonical u64 [batch][kappa][72], NTT form.
@@ -676,28 +673,12 @@ static int commit_dev_i8g(C *c, const fe *F, size_t ldF, u32 batch, const int32_
     }
     return LF_OK;
 }
-static bool want_ajtai_i8g(const C *c) { return c->i8_nch && c->dAb && !getenv("LF_AJTAI_VALU") && !getenv("LF_COMMIT_VALU"); }
 // F: [batch][72][ldF]; out_dev: canonical u64 [batch][kappa][72]
-static int commit_dev(C *c, const fe *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
-    if (want_ajtai_i8g(c)) return commit_dev_i8g(c, F, ldF, batch, nullptr, 0, out_dev, timed);
-    u32 maxb = 256 / c->kappa;
-    if (maxb > 16) maxb = 16;    // LDS: (kappa + 2*batch) rows of 289 words
-    if (maxb < 1) return LF_ERR_UNSUPPORTED;
-    u32 splits = ajtai_splits(c->nA);
-    i64 *partial;
-    RET(c->tbuf("ajtai_partial", ajtai_partial_words(c->kappa, maxb, splits), &partial));
-    for (u32 b0 = 0; b0 < batch; b0 += maxb) {
-        u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
-        size_t ev = timed ? c->ev_begin(1) : 0;
-        launch_ajtai(c->dev, c->dA, c->kappa, c->nA, F + (size_t)b0 * RE * ldF, ldF, nb, splits, partial, out_dev + (size_t)b0 * c->kappa * RE, c->stream());
-        if (timed) c->ev_end(ev);
-    }
-    return LF_OK;
-}
+static int commit_dev(C *c, const fe *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) { return commit_dev_i8g(c, F, ldF, batch, nullptr, 0, out_dev, timed); }
 int BbCtx::ajtai_commit(const uint64_t *f, size_t n, size_t batch, uint64_t *out) {
     C *c = p;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->dA) return LF_ERR_STATE;
+    if (!c->dAb) return LF_ERR_STATE;
     if (n != c->nA_total) return LF_ERR_INVALID;   // CommitmentError::WrongWitnessLength(n, width)
     HIPCHK(hipSetDevice(c->device));
     fe *F;
@@ -959,24 +940,15 @@ int BbCtx::witness_get_w_ccs(const lf_witness *w, uint64_t *out) {
 int BbCtx::witness_commit(const lf_witness *w, uint64_t *cm_out) {
     C *c = p;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->dA) return LF_ERR_STATE;
+    if (!c->dAb) return LF_ERR_STATE;
     if (w->N != c->nA_total) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    fe *d, *e;
     u64 *o;
-    RET(c->tbuf("io_c", w->N * RE, &d));
-    RET(c->tbuf("io_b", w->N * RE, &e));
     RET(c->tbuf("io_o", (size_t)c->kappa * RE, &o));
-    if (want_ajtai_i8g(c)) {     // the int32 planes of the handle are the operand
-        c->ev_reset();
-        RET(commit_dev_i8g(c, nullptr, 0, 1, w->planes + c->A_col0, w->N, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
-        c->ev_collect();
-        RET(down_small(c, o, (size_t)c->kappa * RE, cm_out));
-        return exchange_modsum(c, cm_out, (size_t)c->kappa * RE);
-    }
-    launch_i32_to_coef(w->planes, d, w->N, c->stream());
-    launch_crt_fwd(c->dev, d, e, w->N, c->stream());
-    RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));
+    // the int32 planes of the handle are the operand
+    c->ev_reset();
+    RET(commit_dev_i8g(c, nullptr, 0, 1, w->planes + c->A_col0, w->N, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
+    c->ev_collect();
     RET(down_small(c, o, (size_t)c->kappa * RE, cm_out));
     return exchange_modsum(c, cm_out, (size_t)c->kappa * RE);
 }
@@ -1289,21 +1261,15 @@ static int dec_enqueue_commit(C *c, const lf_witness *wit, DecPending &pd) {
     const lf_params &P = c->P;
     size_t N = c->N;
     u32 K = P.K;
-    fe *Fh;
     u64 *yd;
     RET(c->tbuf("dec_y", (size_t)K * P.kappa * RE, &yd));
     pd.h_y = c->arena_alloc((size_t)(K - 1) * P.kappa * RE);
     if (!pd.h_y) return LF_ERR_HIP;
     // commit_witnesses (decomposition.rs:178-201): NTT of the K-1 upper bit-planes, one batched pass over A
     pd.ph_commit = c->ev_begin(11);
-    if (c->i8_nch && !c->tn.ajtai_valu && P.b == 2) {
-        // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
-        RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd));
-    } else {
-        RET(c->tbuf("dec_fhat", (size_t)(K - 1) * RE * c->nA, &Fh));
-        launch_bitplane_crt(c->dev, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());   // this rank's column slice only
-        RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
-    }
+    if (!c->i8_nch || P.b != 2) return LF_ERR_UNSUPPORTED;
+    // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
+    RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd));
     HIPCHK(hipMemcpyAsync(pd.h_y, yd, (size_t)(K - 1) * P.kappa * RE * 8, hipMemcpyDeviceToHost, c->stream()));
     c->ev_end(pd.ph_commit);
     HIPCHK(hipEventRecord(c->ev_dec[2 * pd.side], c->stream()));
@@ -1957,12 +1923,10 @@ static int fold_impl(C *c, BbTranscript &tr, SideState *S, u64 *lcccs_out, lf_wi
     // Witness::from_f (arith.rs:299-313): f = CRT(f_coeff) and w_ccs = CRT(recompose(f_coeff, B, L)) of the folded witness, behind compute_f_0 on the same stream
     fe *nf = nullptr, *nw = nullptr;
     const size_t nf_bytes = N * RE * sizeof(fe), nw_bytes = (size_t)P.wit_len * RE * sizeof(fe);
-    if (!c->tn.lazy_from_f) {
-        RET(lf_planes_alloc(c->owner, nf_bytes, (int32_t **)&nf));
-        RET(lf_planes_alloc(c->owner, nw_bytes, (int32_t **)&nw));
-        launch_recompose_crt(c->dev, npl, N, (u32)N, 1, P.B, 1, 0, nf, N, 0, c->stream());
-        launch_recompose_crt(c->dev, npl, N, P.wit_len, P.L, P.B, 1, 0, nw, P.wit_len, 0, c->stream());
-    }
+    RET(lf_planes_alloc(c->owner, nf_bytes, (int32_t **)&nf));
+    RET(lf_planes_alloc(c->owner, nw_bytes, (int32_t **)&nw));
+    launch_recompose_crt(c->dev, npl, N, (u32)N, 1, P.B, 1, 0, nf, N, 0, c->stream());
+    launch_recompose_crt(c->dev, npl, N, P.wit_len, P.L, P.B, 1, 0, nw, P.wit_len, 0, c->stream());
     BB_MARK("  eta absorbed, rho drawn, fold_witness enqueued");
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
@@ -2039,7 +2003,7 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
                      uint64_t *lcccs_out, lf_witness **w_out, uint64_t *proof) {
     C *c = p;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    if (!c->have_ccs || !c->dAb) return LF_ERR_STATE;
     const lf_params &P = c->P;
     if (c->kappa != P.kappa || c->nA_total != c->N || w_acc->N != c->N || w_i->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
@@ -2110,7 +2074,7 @@ int BbCtx::fold_step(BbTranscript &tr, const uint64_t *acc, const lf_witness *w_
 int BbCtx::decomposition_prove(BbTranscript &tr, const uint64_t *lcccs, const lf_witness *wit, uint64_t *lcccs_s_out, uint64_t *dec_proof_out) {
     C *c = p;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->have_ccs || !c->dA) return LF_ERR_STATE;
+    if (!c->have_ccs || !c->dAb) return LF_ERR_STATE;
     const lf_params &P = c->P;
     if (c->kappa != P.kappa || c->nA_total != c->N || wit->N != c->N) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));

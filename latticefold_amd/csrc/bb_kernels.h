@@ -47,16 +47,12 @@ void launch_decompose(const fe *coef, size_t n, u64 base, u32 digits, int layout
 void launch_recompose(const fe *in, size_t n_out, u64 base, u32 digits, fe *out, hipStream_t s);
 void launch_coef_to_i32(const fe *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s);
 void launch_i32_to_coef(const int32_t *planes, fe *coef, size_t n, hipStream_t s);
-void launch_bitplane_crt(const DevBb &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out, hipStream_t s);
 void launch_recompose_crt(const DevBb &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K, int mode_bits,
                           fe *out, size_t ldz, size_t off, hipStream_t s);
 void launch_linf(const fe *coef, size_t n, u64 *out_max, hipStream_t s);
 
 // ---- Ajtai -----------------------------------------------------------------------------------------------------
-size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits);
 // out: canonical u64 AoS [batch][kappa][72]
-void launch_ajtai(const DevBb &t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits, i64 *partial,
-                  u64 *out, hipStream_t s);
 
 // ---- MLE / eq ----------------------------------------------------------------------------------------------------
 void launch_build_eq(const DevBb &t, const E9PreC *r_dev /*nv*/, const E9PreC *omr_dev /*nv: 1-r*/, u32 nv, fe *eq, hipStream_t s);

@@ -432,33 +432,6 @@ __device__ __forceinline__ int digit2(int32_t v, u32 k) {
 }
 __device__ __forceinline__ fe fe_from_digit(int d) { return d == 0 ? 0 : (d > 0 ? BB_ONE : -BB_ONE); }
 
-// One thread per (element j, residue class r of the coefficient index): a(X) = sum_r X^r A_r(X^9) and the CRT works class by class
-// (crt_store), so a thread needs only the 8 plane entries c = r + 9 v; it walks the bit-planes k and writes 8 words per plane.
-// 9x the threads of an element-per-thread layout and ~40 registers instead of 174: the kernel runs at the HBM write rate.
-__global__ void __launch_bounds__(256) k_bitplane_crt(DevBb t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out) {
-    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const u32 r = blockIdx.y;
-    if (j >= n) return;
-    int32_t v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = planes[(size_t)(r + TAU * q) * ld + j];
-    int plane[8];
-    fe tw[8];
-#pragma unroll
-    for (int p = 0; p < 8; p++) { plane[p] = TAU * t.slot_of_pos[p] + t.pos[r][p]; tw[p] = t.tw[r][p]; }
-    for (u32 k = k0; k < k1; k++) {
-        fe x[8], A[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = fe_from_digit(digit2(v[q], k));
-        crt8(x, A, t);
-        fe *o = out + (size_t)(k - k0) * RE * n;
-#pragma unroll
-        for (int p = 0; p < 8; p++) o[(size_t)plane[p] * n + j] = r == 0 ? A[p] : fmul(tw[p], A[p]);
-    }
-}
-void launch_bitplane_crt(const DevBb &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, fe *out, hipStream_t s) {
-    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256), TAU), dim3(256), 0, s, t, planes, ld, n, k0, k1, out);
-}
 
 struct BPow { fe v[8]; };
 // thread = (element i, residue class r of the coefficient index, table k): 8 coefficients c = r + 9 q, one crt8 (see k_bitplane_crt)
@@ -545,87 +518,6 @@ void launch_recompose_crt(const DevBb &t, const int32_t *planes, size_t n_planes
                        ldz, off);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Ajtai commit (commitment_scheme.rs:37-54 -> Matrix::checked_mul_vec): C[k][i] = sum_j A[i][j] (.) F_k[j].  Per slot a
-// skinny GEMM (kappa x n) * (n x batch) over F_{p^9}.  Block = one slot x one j-split; tiles of AJ_T columns of A, F and
-// nu*F are staged in LDS with coalesced loads (the nu pre-multiplication is amortised over the kappa uses); thread
-// (i,k) runs the 81-mad column products from LDS and keeps nine signed 64-bit sums of reduced words.
-constexpr int AJ_T = 32;
-constexpr int AJ_REC = TAU;                  // words per (row, column) record
-constexpr int AJ_ROW = AJ_T * AJ_REC + 1;    // +1 word: rows of consecutive k fall into different LDS banks
-template <bool NU2>
-__global__ void __launch_bounds__(256) k_ajtai(DevBb t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits,
-                                               i64 *partial) {
-    extern __shared__ fe lds[];
-    fe *sA = lds;                                    // [kappa][AJ_ROW]
-    fe *sF = sA + (size_t)kappa * AJ_ROW;            // [batch][AJ_ROW]
-    fe *sFn = sF + (size_t)batch * AJ_ROW;           // nu * F
-    u32 slot = blockIdx.y, split = blockIdx.x;
-    size_t per = (n + splits - 1) / splits;
-    per = (per + AJ_T - 1) / AJ_T * AJ_T;
-    size_t j0 = (size_t)split * per, j1 = j0 + per < n ? j0 + per : n;
-    u32 nout = kappa * batch;
-    u32 oi = threadIdx.x / batch, ok = threadIdx.x % batch;
-    bool active = threadIdx.x < nout;
-    HL acc[TAU];   // lazy: no Montgomery reduction inside the column loop
-#pragma unroll
-    for (int c = 0; c < TAU; c++) hl_zero(acc[c]);
-    for (size_t jt = j0; jt < j1; jt += AJ_T) {
-        u32 rowsA = kappa * TAU;
-        for (u32 idx = threadIdx.x; idx < rowsA * AJ_T; idx += 256) {
-            u32 jj = idx % AJ_T, r = idx / AJ_T, i = r / TAU, c = r % TAU;
-            size_t j = jt + jj;
-            sA[(size_t)i * AJ_ROW + jj * AJ_REC + c] = j < j1 ? A[((size_t)i * RE + TAU * slot + c) * n + j] : 0;
-        }
-        u32 rowsF = batch * TAU;
-        for (u32 idx = threadIdx.x; idx < rowsF * AJ_T; idx += 256) {
-            u32 jj = idx % AJ_T, r = idx / AJ_T, k = r / TAU, c = r % TAU;
-            size_t j = jt + jj;
-            fe v = j < j1 ? F[((size_t)k * RE + TAU * slot + c) * ldF + j] : 0;
-            sF[(size_t)k * AJ_ROW + jj * AJ_REC + c] = v;
-            sFn[(size_t)k * AJ_ROW + jj * AJ_REC + c] = NU2 ? centre(2 * v) : fmul(v, t.nu);
-        }
-        __syncthreads();
-        if (active) {
-            const fe *pa = sA + (size_t)oi * AJ_ROW, *pf = sF + (size_t)ok * AJ_ROW, *pn = sFn + (size_t)ok * AJ_ROW;
-#pragma unroll 2
-            for (int jj = 0; jj < AJ_T; jj++) {
-                E9 a, b, bn;
-#pragma unroll
-                for (int c = 0; c < TAU; c++) { a.c[c] = pa[jj * AJ_REC + c]; b.c[c] = pf[jj * AJ_REC + c]; bn.c[c] = pn[jj * AJ_REC + c]; }
-                i64 T[TAU];
-                e9_mul_cols(a, b, bn, T);
-#pragma unroll
-                for (int c = 0; c < TAU; c++) hl_add(acc[c], T[c]);
-            }
-        }
-        __syncthreads();
-    }
-    if (active) {
-        // partial[split][slot][i][k][9]
-        i64 *o = partial + ((((size_t)split * 8 + slot) * kappa + oi) * batch + ok) * TAU;
-#pragma unroll
-        for (int c = 0; c < TAU; c++) o[c] = hl_finish(acc[c]);
-    }
-}
-// out[k][i][9*slot+c] = canonical sum over splits
-__global__ void __launch_bounds__(256) k_ajtai_reduce(const i64 *partial, u32 kappa, u32 batch, u32 splits, u64 *out) {
-    u32 idx = blockIdx.x * 256 + threadIdx.x;
-    u32 total = 8 * kappa * batch * TAU;
-    if (idx >= total) return;
-    u32 c = idx % TAU, k = (idx / TAU) % batch, i = (idx / (TAU * batch)) % kappa, slot = idx / (TAU * batch * kappa);
-    i64 acc = 0;
-    for (u32 s = 0; s < splits; s++) acc += partial[((((size_t)s * 8 + slot) * kappa + i) * batch + k) * TAU + c] % (i64)BB_P;
-    out[((size_t)k * kappa + i) * RE + TAU * slot + c] = to_canon(fred(acc));
-}
-size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) { return (size_t)splits * 8 * kappa * batch * TAU; }
-void launch_ajtai(const DevBb &t, const fe *A, u32 kappa, size_t n, const fe *F, size_t ldF, u32 batch, u32 splits, i64 *partial, u64 *out,
-                  hipStream_t s) {
-    size_t shm = ((size_t)kappa + 2 * (size_t)batch) * AJ_ROW * sizeof(fe);
-    if (t.nu == BB_TWO) hipLaunchKernelGGL((k_ajtai<true>), dim3(splits, 8), dim3(256), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-    else hipLaunchKernelGGL((k_ajtai<false>), dim3(splits, 8), dim3(256), shm, s, t, A, kappa, n, F, ldF, batch, splits, partial);
-    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * kappa * batch * TAU, 256)), dim3(256), 0, s, partial, kappa, batch, splits, out);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // eq(x, r) table over {0,1}^nv, LSB-first (build_eq_x_r, utils/sumcheck/utils.rs:100-170): entry i =

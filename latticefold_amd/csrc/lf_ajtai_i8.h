@@ -13,9 +13,8 @@ inline AjtaiI8Ring ajtai_i8_goldilocks() { return AjtaiI8Ring{24, 8, 0, 1}; }
 inline AjtaiI8Ring ajtai_i8_babybear() { return AjtaiI8Ring{72, 4, 2013265921ull, 0}; }
 // A repacked once per matrix: row i of a row chunk (canonical coefficients, element (c, j) at coef[c*cs + j*js]) -> bytes in MFMA operand
 // order, MT = ajtai_i8_row_tiles(rows of the chunk)
-// the same from the NTT form of a Goldilocks row in one pass (dense inverse map + packing), and the way back to canonical coefficients [RD][n]
+// the same from the NTT form of a Goldilocks row in one pass (dense inverse map + packing)
 void launch_ajtai_icrt_pack_i8(const uint64_t *icrt_mat, const uint64_t *ntt, size_t n, uint32_t i, uint32_t MT, unsigned char *Ab, hipStream_t s);
-void launch_ajtai_unpack_i8(const unsigned char *Ab, size_t n, uint32_t i, uint32_t MT, uint32_t RD, uint32_t NL, uint64_t *coef, hipStream_t s);
 void launch_ajtai_pack_i8(const uint64_t *coef, size_t cs, size_t js, size_t n, uint32_t i, uint32_t MT, uint32_t RD, uint32_t NL, unsigned char *Ab, hipStream_t s);
 uint32_t ajtai_i8_row_tiles(const AjtaiI8Ring &R, uint32_t kappa);
 uint32_t ajtai_i8_col_tiles(const AjtaiI8Ring &R, uint32_t NP);
@@ -27,11 +26,9 @@ size_t ajtai_i8_part_words(uint32_t nwg, uint32_t MT, uint32_t NT);
 size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, uint32_t MT, uint32_t NT, uint32_t NP);
 // commitments of the digit planes k0 .. k0+NP-1 of `planes` ([RD][ld] int32) under rows [row0, row0+kappa) of A (one packed row chunk with MT
 // row tiles): coefficient-form results into coef_out (element plane*kappa_total + row).  Returns the grid size or -1.
-// planes2 / coef_out2 (optional): the same planes of a SECOND witness in the same launch -- nwg / 2 column chunks, each run by a pair of
-// workgroups placed on one XCD, so that A is fetched from HBM once for both (the two decompositions of a fold step).
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const int32_t *planes, size_t ld, size_t n, uint32_t kappa, uint32_t row0,
                     uint32_t kappa_total, uint32_t k0, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s,
-                    const int32_t *planes2 = nullptr, uint64_t *coef_out2 = nullptr, const uint32_t *bits = nullptr, size_t bits_nw = 0, uint32_t bits_rows = 0);
+                    const uint32_t *bits = nullptr, size_t bits_nw = 0, uint32_t bits_rows = 0);
 // bits (optional): the bit-plane form of `planes` (lf_sv_rounds.h launch_sv_bits over the same columns: [RD][bits_rows][bits_nw] words); the
 // 24-ring / 13-row-tile kernel then cuts its digits from two words per (plane, coefficient) and tile instead of eight int32 values
 // ---- general commitments on the same byte planes of A (lf_ajtai_i8g.hip): AjtaiCommitmentScheme::commit_ntt (commitment_scheme.rs:37-54,75-77),
@@ -39,8 +36,6 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, 
 // NP = ajtai_i8g_planes_general (an arbitrary element) or ajtai_i8g_planes_i32 (centred coefficients that fit an int32).
 uint32_t ajtai_i8g_planes_general(const AjtaiI8Ring &R);
 uint32_t ajtai_i8g_planes_i32();
-void launch_i8g_cut_u64(const uint64_t *coef /* [RD][ld] canonical */, size_t ld, size_t n, uint64_t p_small, uint32_t RD, uint32_t NP, unsigned long long *pre, size_t ldw,
-                        hipStream_t s);
 // ... straight from the NTT form of a Goldilocks vector f [24][ld] (dense inverse map icrt_mat [24][24] on the device)
 // sp_val / sp_col (optional, [24][8]): the rows of the same map in compressed form when none has more than 8 non-zero entries (column 0xFFFFFFFF = no entry)
 void launch_i8g_cut_ntt(const uint64_t *icrt_mat, const uint64_t *sp_val, const uint32_t *sp_col, const uint64_t *ntt, size_t ld, size_t n, uint32_t NP,

@@ -118,31 +118,10 @@ void launch_ajtai_icrt_pack_i8(const u64 *icrt_mat, const u64 *ntt, size_t n, u3
     const size_t ntiles = (n + 7) / 8;
     hipLaunchKernelGGL(k_ajtai_icrt_pack_i8, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), 0, s, icrt_mat, ntt, n, i, MT, ntiles, Ab);
 }
-// and back (a context that dropped its NTT-form copy, lf_ajtai_release_ntt, and is asked for a general commitment): the canonical
-// coefficients of row i from the operand bytes, coef [24][n]
-__global__ void __launch_bounds__(256) k_ajtai_unpack_i8(const unsigned char *Ab, size_t n, u32 i, u32 MT, u32 KS, u32 NL, u64 *coef) {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= n * KS * 8) return;
-    const size_t j = gid % n;
-    const u32 c = (u32)(gid / n), s = c >> 3, g = (c & 7) >> 1, t = ((c & 1) << 3) | (u32)(j & 7);
-    const size_t T = j >> 3;
-    u64 v = 0;
-    for (u32 u = 0; u < NL; u++) {
-        const u32 m = NL * i + u, mt = m >> 4, lane = g * 16 + (m & 15);
-        v |= (u64)(Ab[((T * KS + s) * MT + mt) * 1024 + lane * 16 + t] ^ 0x80) << (8 * u);
-    }
-    coef[(size_t)c * n + j] = v;
-}
-void launch_ajtai_unpack_i8(const unsigned char *Ab, size_t n, u32 i, u32 MT, u32 RD, u32 NL, u64 *coef, hipStream_t s) {
-    const u32 KS = RD / 8;
-    hipLaunchKernelGGL(k_ajtai_unpack_i8, dim3((unsigned)cdiv(n * RD, 256)), dim3(256), 0, s, Ab, n, i, MT, KS, NL, coef);
-}
-
 struct AjtaiI8Args {
     const unsigned char *Ab;
     const int32_t *planes;   // [RD][ld], already offset to this rank's first column
-    const int32_t *planes2;  // sides == 2: the second witness (same geometry)
-    u32 sides, nchunks;      // workgroups = sides * nchunks; workgroup (side, chunk) writes slot side * nchunks + chunk of part / dsum
+    u32 sides, nchunks;      // specialised kernels: plane groups (1 / 2) and column chunks -- workgroup (group, chunk) writes slot group * nchunks + chunk of part / dsum
     const u32 *bits;         // optional (k_ajtai_i8s): bit-plane form of the witness (lf_sv_rounds.h launch_sv_bits: [RD][bits_rows][bits_nw] words,
     size_t bits_nw;          // row r < bits_rows - 1 = bit r of |v|, last row = sign bits; 32 positions per word) -- digits are then cut from two
     u32 bits_rows;           // words per (plane, coefficient) instead of eight int32 values
@@ -199,13 +178,8 @@ __device__ __forceinline__ void i8_run(const AjtaiI8Args &a, unsigned char *smem
     constexpr int PPR = 512 / EPP;                              // planes per round of the vector build (5 / 1)
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mg = wave / CG, ng = wave % CG;
     const u32 MT = EXACT ? (u32)MTT : a.MT, NT = a.NT, NP = a.NP;
-    // Two witnesses in one launch (both decompositions of a fold step): the workgroups (0, chunk) and (1, chunk) stream the same tiles of A.
-    // Block ids 16 q + 8 side + x land on the same XCD (round-robin over 8) eight dispatch slots apart, so the second one finds the tiles in
-    // that XCD's L2: A leaves HBM once per step instead of twice.
-    u32 side = 0, chunk = blockIdx.x;
-    if (a.sides == 2) { side = (blockIdx.x >> 3) & 1; chunk = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7); }
-    const int32_t *planes = side ? a.planes2 : a.planes;
-    const u32 slot = side * a.nchunks + chunk;
+    const u32 chunk = blockIdx.x, slot = chunk;
+    const int32_t *planes = a.planes;
     const size_t a_tile = (size_t)KS * MT * 1024;              // bytes of a tile in HBM
     constexpr size_t a_lds = (size_t)ACH * 512 * 16;           // ... and its padded stride in LDS
     unsigned char *Al = smem;                                   // [2][a_lds]
@@ -831,9 +805,10 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     if (btid < 192) a.dsum[(size_t)slot * 192 + btid] = (int)dsl[btid];   // (stride of 8 planes whatever NP is)
 }
 
-// COLS: the four multiplier waves split the 12 column tiles (13 x 3 tiles each: 39 MFMAs per K-step and wave) instead of 2 x 2 blocks of (7 | 6) x 6 tiles
-// (42 / 36: the 7-row waves bound the tile); every wave then reads all 13 row tiles of A from LDS (64 operand-tile reads per K-step instead of 50)
-template <bool PROF, bool BITS, bool COLS = false>
+// The four multiplier waves split the 12 column tiles: 13 x 3 tiles each, 39 MFMAs per K-step and wave.  (Rounds 3-5 also carried a 2 x 2 split into (7 | 6) x 6
+// tiles -- 42 / 36 MFMAs, the 7-row waves bound the tile -- and a build that cut digits from the int32 planes when the bit planes were at hand; the column split
+// with bit-plane digits was the fastest form at C4 by 0.1 ms per step, profiles/r05c_i8_ab.txt, and is the only one left.)
+template <bool PROF, bool BITS>
 __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // plane group g = planes [8 g, 8 g + 8) of the launch: block ids 16 q + 8 g + x, like the two witnesses of the paired launch
@@ -845,9 +820,7 @@ __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     const u32 np_g = a.NP - S_NPG * grp < (u32)S_NPG ? a.NP - S_NPG * grp : (u32)S_NPG;
     const u32 wave = threadIdx.x >> 6;
     if (wave >= 4) i8s_build<PROF, BITS>(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
-    else if (COLS) i8s_mma<13, 3, PROF>(a, smem, 0, wave, T0, T1, slot);
-    else if (wave < 2) i8s_mma<7, 6, PROF>(a, smem, 0, wave & 1, T0, T1, slot);
-    else i8s_mma<6, 6, PROF>(a, smem, 1, wave & 1, T0, T1, slot);
+    else i8s_mma<13, 3, PROF>(a, smem, 0, wave, T0, T1, slot);
 }
 
 // =====================================================================================================================================
@@ -1208,12 +1181,11 @@ __device__ __forceinline__ u64 s128_mod_small(__int128 v, u64 p) {
 // stage 2: y[plane][row][c_out] in coefficient form, canonical.  Element index e = plane * kappa_total + row0 + i;
 // soa != 0: out[c_out * NE + e] (NE = NP * kappa_total), else out[e * RD + c_out].  p_small = 0: the Goldilocks modulus.
 __global__ void __launch_bounds__(256) k_ajtai_i8_finish(const long long *sum, size_t per_wg, u32 MT, u32 NT, u32 NP, u32 kappa, u32 row0, u32 kappa_total,
-                                                         u32 RD, u32 NL, u64 p_small, int soa, u64 *coef_out, u64 *coef_out2, u32 np_total, u32 grp_planes) {
+                                                         u32 RD, u32 NL, u64 p_small, int soa, u64 *coef_out, u32 np_total, u32 grp_planes) {
     const u32 o = blockIdx.x * 256 + threadIdx.x;
     if (o >= NP * kappa * RD) return;
-    // blockIdx.y = 1: the second witness of a two-sided launch (its own output), or -- grp_planes != 0 -- the second plane group of
-    // k_ajtai_i8s (planes grp_planes .. np_total - 1 of the same output)
-    if (blockIdx.y) { sum += per_wg + (size_t)NP * RD; if (!grp_planes) coef_out = coef_out2; }
+    // blockIdx.y = 1: the second plane group of the specialised kernels (planes grp_planes .. np_total - 1 of the same output)
+    if (blockIdx.y) sum += per_wg + (size_t)NP * RD;
     const u32 co = o % RD, i = (o / RD) % kappa, p = o / (RD * kappa), HALF = RD / 2;
     const u32 p_glob = p + blockIdx.y * grp_planes;
     if (grp_planes && p_glob >= np_total) return;
@@ -1249,8 +1221,7 @@ static u32 ach_for(u32 RD, u32 MT) {   // 16-byte chunks of an A tile per thread
 }
 u32 ajtai_i8_max_planes(const AjtaiI8Ring &R) { return R.RD == 24 ? 15 : 8; }     // digit planes per launch (accumulators, LDS, rounds of the vector build)
 // ... for a given row-tile count: the specialised kernels (k_ajtai_i8s: 24-ring, 13 row tiles; k_ajtai_i8x: 72-ring, 4 row tiles) run two plane groups of 8 in one launch
-static bool i8x_enabled() { return !getenv("LF_I8_NO_SPLIT") && !getenv("LF_I8_GUARDED"); }
-u32 ajtai_i8_max_planes_mt(const AjtaiI8Ring &R, u32 MT) { return R.RD == 72 && MT == 4 && i8x_enabled() ? 15u : ajtai_i8_max_planes(R); }
+u32 ajtai_i8_max_planes_mt(const AjtaiI8Ring &R, u32 MT) { return R.RD == 72 && MT == 4 ? 15u : ajtai_i8_max_planes(R); }
 size_t ajtai_i8_lds_bytes(const AjtaiI8Ring &R, u32 MT, u32 NP) {
     (void)NP;   // the buffers have the strides of the largest plane count
     const size_t maxnp = ajtai_i8_max_planes(R);
@@ -1265,171 +1236,109 @@ size_t ajtai_i8_part_words(u32 nwg, u32 MT, u32 NT) { return (size_t)nwg * MT * 
 size_t ajtai_i8_sum_words(const AjtaiI8Ring &R, u32 MT, u32 NT, u32 NP) { return 2 * ((size_t)MT * NT * 256 + (size_t)NP * R.RD); }   // (two sides)
 
 int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const int32_t *planes, size_t ld, size_t n, u32 kappa, u32 row0, u32 kappa_total,
-                    u32 k0, u32 NP, u32 nwg, int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s, const int32_t *planes2, u64 *coef_out2,
-                    const u32 *bits, size_t bits_nw, u32 bits_rows) {
+                    u32 k0, u32 NP, u32 nwg, int32_t *part, int32_t *dsum, long long *sum, u64 *coef_out, hipStream_t s, const u32 *bits, size_t bits_nw, u32 bits_rows) {
     AjtaiI8Args a;
     a.bits = nullptr; a.bits_nw = 0; a.bits_rows = 0;
-    a.Ab = Ab; a.planes = planes; a.planes2 = planes2; a.ld = ld; a.n = n;
+    a.Ab = Ab; a.planes = planes; a.ld = ld; a.n = n;
     a.MT = MT; a.NT = ajtai_i8_col_tiles(R, NP); a.k0 = k0; a.NP = NP;
     a.ntiles = (u32)((n + 7) / 8);
     a.part = part; a.dsum = dsum; a.sync = nullptr; a.couple_w = 0; a.couple_e = 1;
+    a.sides = 1;
     if ((size_t)R.RD * ld * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit plane offsets in the kernel
-    if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes_mt(R, MT) || NP == 0) return -1;
-    // The 4-row-tile shape of the 72-ring with specialised waves (k_ajtai_i8x): plane groups of 8, two groups = paired, coupled workgroups
-    if (R.RD == 72 && MT == 4 && !planes2 && i8x_enabled()) {
+    if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes_mt(R, MT) || NP == 0 || nwg == 0) return -1;
+    static const bool prof = getenv("LF_I8_PROF") != nullptr;
+    static const int cw = getenv("LF_I8_COUPLE_W") ? atoi(getenv("LF_I8_COUPLE_W")) : 4;      // window of the pair coupling in tiles (0 switches the coupling off)
+    static const int ce_env = getenv("LF_I8_COUPLE_E") ? atoi(getenv("LF_I8_COUPLE_E")) : 4;  // the handshake runs every ... tiles
+    const u32 ce = ce_env >= 8 ? 8u : (ce_env >= 4 ? 4u : (ce_env >= 2 ? 2u : 1u));
+    // The specialised-wave kernels: the 13-row-tile shape of the 24-ring (k_ajtai_i8s) and the 4-row-tile shape of the 72-ring (k_ajtai_i8x).  Plane groups of 8;
+    // two groups = paired workgroups on one XCD, coupled through an L2 counter (i8s_build).  Every workgroup of the grid must be resident for the coupling to make
+    // progress: at most one per CU.
+    const bool spec_s = R.RD == 24 && MT == 13, spec_x = R.RD == 72 && MT == 4;
+    if (spec_s || spec_x) {
         typedef SX<72, 4> G;
-        static const bool xprof = getenv("LF_I8_PROF") != nullptr;
-        const u32 groups = NP > (u32)G::NPG ? 2 : 1;
+        const u32 NPG = 8, ndi = spec_s ? 192u : (u32)G::NDI, NTg = spec_s ? (u32)S_NT : (u32)G::NT;
+        const u32 groups = NP > NPG ? 2 : 1;
+        // column chunks per plane group; two groups: a multiple of 8 (the block id -> (group, chunk) map of the kernels; trailing chunks run empty), so a launch
+        // has up to 16 workgroups even when fewer were asked for -- the caller sizes part / dsum for max(nwg, 16) slots
         u32 per = nwg / groups;
-        if (groups == 2) per &= ~7u;
-        if (per >= 1) {
+        if (groups == 2 && per >= 8) per &= ~7u;
+        if (per < 1) per = 1;
+        {
             a.tiles_per_wg = (a.ntiles + per - 1) / per;
             u32 nch = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
             if (groups == 2) nch = (nch + 7) & ~7u;
-            a.sides = groups; a.nchunks = nch; a.NT = G::NT;
-            static bool attr_x = false;
-            if (!attr_x) {
+            a.sides = groups; a.nchunks = nch; a.NT = NTg;
+            static bool attr_set = false;
+            if (!attr_set) {
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8x<72, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8x<72, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_x = true;
-            }
-            const dim3 g(groups * nch), b(512);
-            // the coupling counters live behind the digit sums this path uses (G::NDI per workgroup; the caller sizes dsum for ajtai_i8_max_planes_mt = 15 planes)
-            static const int cw = getenv("LF_I8_COUPLE_W") ? atoi(getenv("LF_I8_COUPLE_W")) : 4;
-            if (groups == 2 && cw > 0 && g.x <= nwg && (size_t)nwg * G::NDI + g.x <= (size_t)nwg * 15 * R.RD && g.x <= 256) {
-                a.sync = (u32 *)(dsum + (size_t)nwg * G::NDI);
-                a.couple_w = (u32)cw;
-                static const int ce = getenv("LF_I8_COUPLE_E") ? atoi(getenv("LF_I8_COUPLE_E")) : 4;
-                a.couple_e = ce >= 8 ? 8u : (ce >= 4 ? 4u : (ce >= 2 ? 2u : 1u));
-                (void)hipMemsetAsync(a.sync, 0, (size_t)nch * 4, s);
-            }
-            if (xprof) hipLaunchKernelGGL((k_ajtai_i8x<72, 4, true>), g, b, G::lds_bytes(), s, a);
-            else hipLaunchKernelGGL((k_ajtai_i8x<72, 4, false>), g, b, G::lds_bytes(), s, a);
-            const size_t per_wg_x = (size_t)4 * G::NT * 256;
-            hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg_x + G::NDI, 256), groups), dim3(256), 0, s, part, per_wg_x, dsum, (u32)G::NDI, nch, sum);
-            hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)G::NPG * kappa * 72, 256), groups), dim3(256), 0, s, sum, per_wg_x, 4u, (u32)G::NT,
-                               (u32)G::NPG, kappa, row0, kappa_total, 72u, R.NL, R.p_small, R.soa_out, coef_out, (u64 *)nullptr, NP, (u32)G::NPG);
-            return (int)(groups * nch);
-        }
-    }
-    // The 13-row-tile shape of the 24-ring with specialised waves (k_ajtai_i8s): plane groups of 8, two groups = paired workgroups
-    static const bool no_split = getenv("LF_I8_NO_SPLIT") != nullptr;
-    if (R.RD == 24 && MT == 13 && !planes2 && !no_split && !getenv("LF_I8_GUARDED")) {
-        static const bool sprof = getenv("LF_I8_PROF") != nullptr;
-        const u32 groups = NP > (u32)S_NPG ? 2 : 1;
-        u32 per = nwg / groups;
-        if (groups == 2) per &= ~7u;
-        if (per >= 1) {
-            a.tiles_per_wg = (a.ntiles + per - 1) / per;
-            u32 nch = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-            if (groups == 2) nch = (nch + 7) & ~7u;
-            a.sides = groups; a.nchunks = nch; a.NT = S_NT;
-            static bool attr_s = false;
-            if (!attr_s) {
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void *)k_ajtai_i8s<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_s = true;
+                attr_set = true;
             }
-            // digits from the bit-plane form when the caller has it and digit plane k0 + NP - 1 is one of its magnitude rows
-            a.bits = bits; a.bits_nw = bits_nw; a.bits_rows = bits_rows;
-            // (LF_I8_BITS, round 3: the multiplier waves bound the kernel -- 2 650-2 850 of 3 000 cycles per tile at 20.4 cycles per MFMA, the
-            // measured int8 issue rate -- so the cheaper digits change nothing: 2.00-2.07 vs 1.96-2.01 ms per launch at C4)
-            // (round 5, after the handshake moved to the last producer wave: bits + column split is the fastest form at C4 by 0.1 ms per step, profiles/r05c_i8_ab.txt --
-            // both on by default, LF_I8_BITS=0 / LF_I8_COLS=0 switch them off; read per launch: the tests flip them)
-            const char *e_bits = getenv("LF_I8_BITS");
-            const bool want_bits = !(e_bits && e_bits[0] == '0');
-            const bool ub = want_bits && bits != nullptr && k0 + NP <= bits_rows - 1;
             const dim3 g(groups * nch), b(512);
-            const size_t lds_s = ajtai_i8s_lds_bytes();
-            // two plane groups: couple the paired workgroups (i8s_build).  The counters live behind the digit sums this path uses (dsum holds nwg * NPmax * RD
-            // words, this kernel writes 192 per workgroup); every workgroup of the grid must be resident for the coupling to make progress: at most one per CU.
-            static const int cw = getenv("LF_I8_COUPLE_W") ? atoi(getenv("LF_I8_COUPLE_W")) : 4;      // (0 switches the coupling off)
-            if (groups == 2 && cw > 0 && g.x <= nwg && (size_t)nwg * 192 + g.x <= (size_t)nwg * ajtai_i8_max_planes(R) * R.RD && g.x <= 256) {
-                a.sync = (u32 *)(dsum + (size_t)nwg * 192);
+            // the coupling counters live behind the digit sums this path uses (ndi words per workgroup; the caller sizes dsum for the largest plane count)
+            if (groups == 2 && cw > 0 && g.x <= nwg && (size_t)nwg * ndi + g.x <= (size_t)nwg * ajtai_i8_max_planes_mt(R, MT) * R.RD && g.x <= 256) {
+                a.sync = (u32 *)(dsum + (size_t)nwg * ndi);
                 a.couple_w = (u32)cw;
-                static const int ce = getenv("LF_I8_COUPLE_E") ? atoi(getenv("LF_I8_COUPLE_E")) : 4;
-                a.couple_e = ce >= 8 ? 8u : (ce >= 4 ? 4u : (ce >= 2 ? 2u : 1u));
+                a.couple_e = ce;
                 (void)hipMemsetAsync(a.sync, 0, (size_t)nch * 4, s);      // one signed counter per column chunk (pair of workgroups)
             }
-            // LF_I8_COLS (default on, =0 off): the column split of the multiplier waves.  Measured at C4 (profiles/r05b_i8_variants.txt): the tile
-            // takes 3 070 instead of 3 115 cycles (with LF_I8_BITS=1: 2 852) but the launch takes the same 1.94-1.98 ms -- the shader clock follows the matrix
-            // pipe's duty cycle down (1.82 -> 1.69 GHz, profiles/r05c_i8_clock.txt): the kernel is at the power-managed MFMA rate, not at an issue bottleneck.
-            const char *e_cols = getenv("LF_I8_COLS");
-            const bool cols = !(e_cols && e_cols[0] == '0');
-            if (sprof) {
+            if (prof) {
                 static const unsigned long long zeros[64] = {0};
                 (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_i8_prof), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, s);
-                if (ub && cols) hipLaunchKernelGGL((k_ajtai_i8s<true, true, true>), g, b, lds_s, s, a);
-                else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<true, true>), g, b, lds_s, s, a);
-                else if (cols) hipLaunchKernelGGL((k_ajtai_i8s<true, false, true>), g, b, lds_s, s, a);
-                else hipLaunchKernelGGL((k_ajtai_i8s<true, false>), g, b, lds_s, s, a);
             }
-            else if (ub && cols) hipLaunchKernelGGL((k_ajtai_i8s<false, true, true>), g, b, lds_s, s, a);
-            else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<false, true>), g, b, lds_s, s, a);
-            else if (cols) hipLaunchKernelGGL((k_ajtai_i8s<false, false, true>), g, b, lds_s, s, a);
-            else hipLaunchKernelGGL((k_ajtai_i8s<false, false>), g, b, lds_s, s, a);
-            const size_t per_wg_s = (size_t)S_MT * S_NT * 256;
-            hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg_s + 192, 256), groups), dim3(256), 0, s, part, per_wg_s, dsum, 192u, nch, sum);
-            hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)S_NPG * kappa * 24, 256), groups), dim3(256), 0, s, sum, per_wg_s, (u32)S_MT, (u32)S_NT,
-                               (u32)S_NPG, kappa, row0, kappa_total, 24u, R.NL, R.p_small, R.soa_out, coef_out, (u64 *)nullptr, NP, (u32)S_NPG);
+            if (spec_x) {
+                if (prof) hipLaunchKernelGGL((k_ajtai_i8x<72, 4, true>), g, b, G::lds_bytes(), s, a);
+                else hipLaunchKernelGGL((k_ajtai_i8x<72, 4, false>), g, b, G::lds_bytes(), s, a);
+            } else {
+                // digits from the bit-plane form when the caller has it and digit plane k0 + NP - 1 is one of its magnitude rows
+                a.bits = bits; a.bits_nw = bits_nw; a.bits_rows = bits_rows;
+                const bool ub = bits != nullptr && k0 + NP <= bits_rows - 1;
+                const size_t lds_s = ajtai_i8s_lds_bytes();
+                if (prof && ub) hipLaunchKernelGGL((k_ajtai_i8s<true, true>), g, b, lds_s, s, a);
+                else if (prof) hipLaunchKernelGGL((k_ajtai_i8s<true, false>), g, b, lds_s, s, a);
+                else if (ub) hipLaunchKernelGGL((k_ajtai_i8s<false, true>), g, b, lds_s, s, a);
+                else hipLaunchKernelGGL((k_ajtai_i8s<false, false>), g, b, lds_s, s, a);
+            }
+            const size_t per_wg = (size_t)MT * NTg * 256;
+            hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + ndi, 256), groups), dim3(256), 0, s, part, per_wg, dsum, ndi, nch, sum);
+            hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NPG * kappa * R.RD, 256), groups), dim3(256), 0, s, sum, per_wg, MT, NTg, NPG, kappa, row0,
+                               kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out, NP, NPG);
             return (int)(groups * nch);
         }
     }
-    // two witnesses: nwg / 2 chunks of columns (a multiple of 8, see i8_run), each run by a pair of workgroups
-    const u32 sides = planes2 ? 2 : 1;
-    u32 per_side = nwg / sides;
-    if (sides == 2) {
-        per_side &= ~7u;
-        if (per_side == 0 || !coef_out2) return -1;
-    }
-    a.tiles_per_wg = (a.ntiles + per_side - 1) / per_side;
-    u32 nchunks = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-    if (sides == 2) nchunks = (nchunks + 7) & ~7u;   // (trailing chunks past the last tile run empty)
-    a.sides = sides; a.nchunks = nchunks;
-
-    const u32 grid = sides * nchunks;
+    // every other shape: the generic kernel (all eight waves build and multiply), guarded instantiations by row-tile count
+    if (NP > ajtai_i8_max_planes(R)) return -1;
+    a.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
+    const u32 nchunks = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    a.nchunks = nchunks;
+    const u32 grid = nchunks;
     const size_t lds = ajtai_i8_lds_bytes(R, MT, NP);
-#define LF_I8_LAUNCH(RD, RG, MTWA, MTWB, NTW, ACH, EXACT)                                                                           \
+#define LF_I8_LAUNCH(RD, RG, MTWA, MTWB, NTW, ACH)                                                                                  \
     do {                                                                                                                           \
         static bool attr_set = false;                                                                                              \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<RD, RG, MTWA, MTWB, NTW, ACH, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL((k_ajtai_i8<RD, RG, MTWA, MTWB, NTW, ACH, EXACT>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);         \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<RD, RG, MTWA, MTWB, NTW, ACH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((k_ajtai_i8<RD, RG, MTWA, MTWB, NTW, ACH, false>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);         \
     } while (0)
-    const bool guarded = getenv("LF_I8_GUARDED") != nullptr;   // A/B switch: the generic guarded instantiation for every shape
     if (R.RD == 24) {   // 2 row groups x 4 column groups of 6 tiles (24 x 16 planes = 24 tiles)
         const u32 mh = (MT + 1) / 2;
-        static const bool prof = getenv("LF_I8_PROF") != nullptr;
-        if (MT == 13 && !guarded && prof) {
-            static bool attr_p = false;
-            if (!attr_p) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<24, 2, 7, 6, 6, 5, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_p = true; }
-            hipLaunchKernelGGL((k_ajtai_i8<24, 2, 7, 6, 6, 5, true, true>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);
-        } else if (MT == 13 && !guarded) LF_I8_LAUNCH(24, 2, 7, 6, 6, 5, true);    // kappa 25 / 26: 7 + 6 row tiles, branch-free
-        else if (mh <= 2) LF_I8_LAUNCH(24, 2, 2, 2, 6, 2, false);
-        else if (mh <= 4) LF_I8_LAUNCH(24, 2, 4, 4, 6, 3, false);
-        else LF_I8_LAUNCH(24, 2, 7, 7, 6, 5, false);
+        if (mh <= 2) LF_I8_LAUNCH(24, 2, 2, 2, 6, 2);
+        else if (mh <= 4) LF_I8_LAUNCH(24, 2, 4, 4, 6, 3);
+        else LF_I8_LAUNCH(24, 2, 7, 7, 6, 5);
     } else {            // 1 row group (<= 4 row tiles) x 8 column groups of 5 tiles (72 x 8 planes = 36 tiles)
-        static const bool prof72 = getenv("LF_I8_PROF") != nullptr;
-        if (MT == 4 && !guarded && prof72) {
-            static bool attr_p = false;
-            if (!attr_p) { (void)hipFuncSetAttribute((const void *)k_ajtai_i8<72, 1, 4, 4, 5, 5, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_p = true; }
-            hipLaunchKernelGGL((k_ajtai_i8<72, 1, 4, 4, 5, 5, true, true>), dim3(grid), dim3(64 * I8_WAVES), lds, s, a);
-        } else if (MT == 4 && !guarded) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5, true);     // kappa 13 .. 16
-        else if (MT <= 1) LF_I8_LAUNCH(72, 1, 1, 1, 5, 2, false);
-        else if (MT <= 2) LF_I8_LAUNCH(72, 1, 2, 2, 5, 3, false);
-        else if (MT <= 4) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5, false);
+        if (MT <= 1) LF_I8_LAUNCH(72, 1, 1, 1, 5, 2);
+        else if (MT <= 2) LF_I8_LAUNCH(72, 1, 2, 2, 5, 3);
+        else if (MT <= 4) LF_I8_LAUNCH(72, 1, 4, 4, 5, 5);
         else return -1;
     }
 #undef LF_I8_LAUNCH
     const size_t per_wg = (size_t)MT * a.NT * 256;
-    hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * R.RD, 256), sides), dim3(256), 0, s, part, per_wg, dsum, NP * R.RD, nchunks, sum);
-    hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * R.RD, 256), sides), dim3(256), 0, s, sum, per_wg, MT, a.NT, NP, kappa, row0,
-                       kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out, coef_out2, NP, 0u);
+    hipLaunchKernelGGL(k_ajtai_i8_sum, dim3((unsigned)cdiv(per_wg + NP * R.RD, 256), 1), dim3(256), 0, s, part, per_wg, dsum, NP * R.RD, nchunks, sum);
+    hipLaunchKernelGGL(k_ajtai_i8_finish, dim3((unsigned)cdiv((size_t)NP * kappa * R.RD, 256), 1), dim3(256), 0, s, sum, per_wg, MT, a.NT, NP, kappa, row0,
+                       kappa_total, R.RD, R.NL, R.p_small, R.soa_out, coef_out, NP, 0u);
     return (int)grid;
 }
 

@@ -433,8 +433,8 @@ __global__ void __launch_bounds__(256) k_ajtai_i8g_finish(const long long *sum, 
     else out[e * RD + co] = val;
 }
 
-// ---- the digit pass: 8 columns of one coefficient per thread -> NP words.  SRC 0: canonical u64 coefficients (modulus p, 0 = Goldilocks),
-// SRC 1: centred int32 coefficients.  coef (c, j) at src[c * ld + j]; columns past n hold zero digits.
+// ---- the digit pass of centred int32 coefficients (a witness handle's planes): 8 columns of one coefficient per thread -> NP words.  coef (c, j) at
+// src[c * ld + j]; columns past n hold zero digits.  (SRC 0, canonical u64 coefficients, is the same pass for callers that hold them.)
 template <int SRC>
 __global__ void __launch_bounds__(256) k_i8g_cut(const void *src, size_t ld, size_t n, u64 p_small, u32 RD, u32 NP, size_t ntiles, ull *pre, size_t ldw) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -521,10 +521,6 @@ void launch_i8g_cut_ntt(const u64 *icrt_mat, const u64 *sp_val, const u32 *sp_co
                         hipStream_t s) {
     const size_t ntiles = (n + 7) / 8;
     hipLaunchKernelGGL(k_i8g_cut_ntt, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), 0, s, icrt_mat, sp_val, sp_col, ntt, ld, n, NP, ntiles, pre, ldw);
-}
-void launch_i8g_cut_u64(const u64 *coef, size_t ld, size_t n, u64 p_small, u32 RD, u32 NP, unsigned long long *pre, size_t ldw, hipStream_t s) {
-    const size_t ntiles = (n + 7) / 8;
-    hipLaunchKernelGGL(k_i8g_cut<0>, dim3((unsigned)cdiv(ntiles * RD, 256)), dim3(256), 0, s, (const void *)coef, ld, n, p_small, RD, NP, ntiles, pre, ldw);
 }
 void launch_i8g_cut_i32(const int32_t *planes, size_t ld, size_t n, u32 RD, u32 NP, unsigned long long *pre, size_t ldw, hipStream_t s) {
     const size_t ntiles = (n + 7) / 8;

@@ -43,8 +43,8 @@ static bool lf_trace_on() { static int v = -1; if (v < 0) v = getenv("LF_TRACE")
         }                                                                             \
     } while (0)
 
-static thread_local int t_lane = 0;  // 0 = caller thread, 1 = helper thread running the left decomposition, 2 = the prefetch of the NEXT step's right side (lf_prefetch_instance)
-constexpr int LF_NLANES = 3;
+static thread_local int t_lane = 0;  // 0 = caller thread, 1 = helper thread running the left decomposition
+constexpr int LF_NLANES = 2;
 
 struct lf_transcript {
     Transcript t;
@@ -133,7 +133,7 @@ struct LaneWorker {
 struct lf_ctx {
     lfbb::BbCtx *bb = nullptr;   // BabyBearRingNTT backend (ring 1): every entry point forwards to it
     int device = 0;
-    hipStream_t st_lane[LF_NLANES] = {nullptr, nullptr, nullptr};   // [2]: created by the first prefetch
+    hipStream_t st_lane[LF_NLANES] = {nullptr, nullptr};
     int digit_mode = 0;   // balanced-digit rule of base-B decompositions (lf_set_digit_mode)
     ExtBasis xb;          // external coordinate basis of F_{p^tau} (lf_set_ext_basis); identity by default
     Tunables tn;          // environment switches, re-read at the start of every lf_linearize / lf_fold_step
@@ -153,14 +153,14 @@ struct lf_ctx {
     u32 *d_icrt_sp_col = nullptr;
     // Ajtai (nA = columns held by this rank, starting at global column A_col0 of nA_total)
     LaneWorker lane1;
-    u64 *dA = nullptr;              // NTT form (general commitments); absent in digits-only mode until one is asked for (need_dA)
-    bool A_loaded = false, digits_only = false;
-    unsigned char *dAb = nullptr;   // the same matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 26
+    bool A_loaded = false;
+    unsigned char *dAb = nullptr;   // the matrix in coefficient form, bytes in int8-MFMA operand order (lf_ajtai_i8.hip); row chunks of <= 26
     u32 i8_nch = 0, i8_kc = 0;
     u32 kappa = 0;
     size_t nA = 0, nA_total = 0, A_col0 = 0;
     // intra-step sharding: rank/world and the all-gather callback supplied by the host language
     int sh_rank = 0, sh_world = 1;   // mirror comm.rank / comm.world
+    int agreed_two_lanes = -1;       // lf_dist_init's handshake: the schedule ALL ranks agreed on (1 threaded / 0 one thread); -1 = no handshake ran (host transports, model)
     bool two_lanes_ok = false;       // the transport's two channels have been seen working concurrently (lf_dist_init's handshake; two host callbacks): a sharded
                                      // step then runs the threaded two-lane schedule unless LF_SHARD_TWO_LANES=0
     // exchange layer, one per lane: the two lanes of a fold step exchange concurrently (lane 0: linearization rounds and right evaluations,
@@ -177,8 +177,8 @@ struct lf_ctx {
     std::vector<u64 *> d_val, d_valT;
     LinCombDesc desc{};
     std::map<std::string, DevBuf> bufs;
-    u64 *h_pin_lane[LF_NLANES] = {nullptr, nullptr, nullptr};
-    size_t h_pin_words_lane[LF_NLANES] = {0, 0, 0};
+    u64 *h_pin_lane[LF_NLANES] = {nullptr, nullptr};
+    size_t h_pin_words_lane[LF_NLANES] = {0, 0};
     // lin sumcheck ABI state
     int sc_round = -1;
     size_t sc_n = 0;
@@ -225,49 +225,6 @@ struct lf_ctx {
     unsigned fold_split_mask = 0;    // table rounds of the last folding sumcheck that ran in the split eq form (bit i-1 = round i)
     unsigned lin_split_rounds = 0;   // rounds of the last linearization sumcheck that ran in the split eq form (run_lin_sumcheck)
 
-    // lf_prefetch_instance: the challenge-independent half of the RIGHT decomposition of the NEXT fold step (decomposition.rs:159-201: its digit planes in
-    // bit-plane form, the K vectors z_k = x_s[k] || w_k and the K - 1 digit-plane commitments depend on w_i and x_ccs only), enqueued on a third stream while
-    // the running step is in its latency-bound part.  One request -> one result -> consumed by exactly one fold step (or dropped): nothing survives a step.
-    struct Prefetch {
-        // request (lf_prefetch_instance), taken up by the running / next fold step at its trigger point
-        bool req = false;
-        const lf_witness *req_wit = nullptr;
-        uint64_t req_id = 0;
-        std::vector<u64> req_x;          // x_ccs || 1: (l + 1) ring elements (NTT form)
-        // result: valid for the witness (pointer AND serial number) and public input it was made for
-        bool have = false;
-        int parity = 0;                  // z / bit planes are double-buffered: the consuming step reads one set while the next prefetch writes the other
-        const lf_witness *wit = nullptr;
-        uint64_t wit_id = 0;
-        std::vector<u64> x, x_s;         // x_ccs || 1 it was made for; x_s of the proof (K (l+1) ring elements)
-        u32 *bits = nullptr;
-        u64 *z = nullptr, *yd = nullptr;
-        u64 *y_host[2] = {nullptr, nullptr};   // pinned: (K - 1) kappa ring elements, per parity (the consuming step's lane 1 reads one while the next prefetch fills the other)
-        size_t y_words[2] = {0, 0};
-        hipEvent_t ev_done[2] = {nullptr, nullptr};   // per parity: recorded behind the download of y
-        int part = 0;                    // parts of the request enqueued so far: 1 = bit planes + z_k (LF_PF_AT), 2 = + commits and their download (LF_PF_AT2)
-        EvPair ev_k[2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // HIP events around the commit kernel, per parity (counted in the CONSUMING step's kernel statistics)
-        bool ev_k_used = false;
-        int wr = 0;                      // parity the prefetch being enqueued writes
-        u32 *w_bits = nullptr;           // buffers / x_s of the prefetch being enqueued (published with `have`)
-        u64 *w_z = nullptr, *w_yd = nullptr;
-        std::vector<u64> w_x_s;
-        unsigned issued = 0, consumed = 0, dropped = 0;   // counters (lf_prefetch_stats)
-        void destroy() {
-            for (int i = 0; i < 2; i++) {
-                if (y_host[i]) (void)hipHostFree(y_host[i]);
-                if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
-                y_host[i] = nullptr; ev_done[i] = nullptr; y_words[i] = 0;
-            }
-            for (EvPair &e : ev_k) {
-                if (e.a) (void)hipEventDestroy(e.a);
-                if (e.b) (void)hipEventDestroy(e.b);
-                e = {nullptr, nullptr};
-            }
-        }
-    } pf;
-    int pf_inuse = -1;                   // parity of the prefetch buffers the running step reads (-1: none)
-    int pf_kernel_counted = -1;          // (parity, or -1) this step consumed a prefetch: its commit kernel's events are added to the step's statistics (ev_collect)
 
     int buf(const std::string &name, size_t bytes, void **out) {
         DevBuf *b;
@@ -294,8 +251,8 @@ struct lf_ctx {
     }
     // Small host-to-device uploads inside a step (challenge powers, look-up tables, evaluation points) go through a pinned ring per lane:
     // the copy is truly asynchronous and the caller's stack / vector buffer is free at once -- no stream synchronisation per upload.
-    unsigned char *stage[LF_NLANES] = {nullptr, nullptr, nullptr};
-    size_t stage_off[LF_NLANES] = {0, 0, 0};
+    unsigned char *stage[LF_NLANES] = {nullptr, nullptr};
+    size_t stage_off[LF_NLANES] = {0, 0};
     static constexpr size_t STAGE_BYTES = (size_t)1 << 20;
     int h2d_small(void *dst, const void *src, size_t bytes) {
         unsigned char *&ring = stage[t_lane];
@@ -316,7 +273,7 @@ struct lf_ctx {
         HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream()));
         return LF_OK;
     }
-    u64 *h_round[LF_NLANES] = {nullptr, nullptr, nullptr};   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
+    u64 *h_round[LF_NLANES] = {nullptr, nullptr};   // pinned + device-mapped: sumcheck round kernels write their message straight to the host
     u64 *round_out() {
         u64 *&p = h_round[t_lane];
         if (!p && hipHostMalloc((void **)&p, 5 * 24 * 8 * 2, hipHostMallocMapped) != hipSuccess) p = nullptr;
@@ -377,10 +334,6 @@ struct lf_ctx {
     }
     // timed-launch helpers: tag 0 = fold round kernels, 1 = ajtai, 10+i = phase i
     size_t ev_begin(int tag) {
-        if (t_lane == 2) {   // the prefetch lane: not part of the running step's statistics (its kernels may outlive the step)
-            if (tag == 1 && pf.ev_k[pf.wr].a && !pf.ev_k_used) { pf.ev_k_used = true; (void)hipEventRecord(pf.ev_k[pf.wr].a, stream()); return (size_t)-2; }
-            return (size_t)-1;
-        }
         std::lock_guard<std::mutex> g(ev_mu);
         if (ev_used == ev_pool.size()) {
             EvPair e;
@@ -395,7 +348,6 @@ struct lf_ctx {
     }
     void ev_end(size_t i) {
         if (i == (size_t)-1) return;
-        if (i == (size_t)-2) { (void)hipEventRecord(pf.ev_k[pf.wr].b, stream()); return; }
         std::lock_guard<std::mutex> g(ev_mu);
         (void)hipEventRecord(ev_pool[i].b, stream());
     }
@@ -415,11 +367,6 @@ struct lf_ctx {
             if (tg.first == 0) { k_fold_ms += ms; k_fold_n++; }
             else if (tg.first == 1) { k_ajtai_ms += ms; k_ajtai_n++; }
             else if (tg.first >= 10 && tg.first < 10 + LF_N_PHASES) phase_ms[tg.first - 10] += ms;
-        }
-        if (pf_kernel_counted >= 0) {   // the right commit of this step ran ahead (prefetch): its kernel belongs to this step's statistics
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, pf.ev_k[pf_kernel_counted].a, pf.ev_k[pf_kernel_counted].b) == hipSuccess) { k_ajtai_ms += ms; k_ajtai_n++; phase_ms[1] += ms; }
-            pf_kernel_counted = -1;
         }
         phase_ms[6] = (float)host_tr_ms;
     }
@@ -501,8 +448,7 @@ int lf_ctx_create(lf_ctx **out, int device) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         const bool prio = !getenv("LF_NO_PRIO");
-        // (LF_LANE0_MID=1: lane 0 on the middle priority, so that the prefetch stream -- lowest -- yields to it too)
-        const int p0 = getenv("LF_LANE0_MID") ? (least + greatest) / 2 : least;
+        const int p0 = least;
         if (hipStreamCreateWithPriority(&c->st_lane[0], hipStreamDefault, prio ? p0 : 0) != hipSuccess ||
             hipStreamCreateWithPriority(&c->st_lane[1], hipStreamDefault, prio ? greatest : 0) != hipSuccess) { delete c; return LF_ERR_HIP; }
     }
@@ -532,7 +478,6 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->bb) { c->bb->destroy(); delete c; return; }
     (void)hipStreamSynchronize(c->st_lane[0]);
     (void)hipStreamSynchronize(c->st_lane[1]);
-    if (c->st_lane[2]) (void)hipStreamSynchronize(c->st_lane[2]);
     free_ccs(c);
     if (getenv("LF_MEM_REPORT")) {   // what the context held, largest first
         std::vector<std::pair<size_t, std::string>> v;
@@ -541,13 +486,11 @@ void lf_ctx_destroy(lf_ctx *c) {
         const AjtaiI8Ring R = ajtai_i8_goldilocks();
         const size_t ab = c->dAb ? (c->nA + 7) / 8 * (R.RD / 8) * ajtai_i8_row_tiles(R, c->i8_kc) * 1024 * c->i8_nch : 0;
         v.push_back({ab, "(Ajtai byte planes)"});
-        v.push_back({c->dA ? (size_t)c->kappa * c->nA * 192 : 0, "(Ajtai NTT form)"});
         std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
-        fprintf(stderr, "[lf mem] named buffers %.2f GiB + Ajtai %.2f GiB\n", tot / 1073741824.0, (v.size() ? (ab + (c->dA ? (size_t)c->kappa * c->nA * 192 : 0)) : 0) / 1073741824.0);
+        fprintf(stderr, "[lf mem] named buffers %.2f GiB + Ajtai %.2f GiB\n", tot / 1073741824.0, ab / 1073741824.0);
         for (size_t i = 0; i < v.size() && v[i].first >= ((size_t)16 << 20); i++) fprintf(stderr, "[lf mem]   %8.1f MiB  %s\n", v[i].first / 1048576.0, v[i].second.c_str());
     }
     for (auto &kv : c->bufs) kv.second.release();
-    if (c->dA) (void)hipFree(c->dA);
     if (c->dAb) (void)hipFree(c->dAb);
     for (int l = 0; l < LF_NLANES; l++) if (c->stage[l]) (void)hipHostFree(c->stage[l]);
     if (c->d_icrt) (void)hipFree(c->d_icrt);
@@ -574,8 +517,6 @@ void lf_ctx_destroy(lf_ctx *c) {
     }
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
-    if (c->st_lane[2]) (void)hipStreamDestroy(c->st_lane[2]);
-    c->pf.destroy();
     delete c;
 }
 int lf_set_ring_tables(lf_ctx *c, uint64_t nonres, const uint64_t *y) {
@@ -654,6 +595,7 @@ int lf_set_sharding(lf_ctx *c, int rank, int world, lf_exchange_fn cb, void *use
     }
     c->sh_rank = rank; c->sh_world = world;
     c->two_lanes_ok = false;                 // one channel: one thread issues every exchange
+    c->agreed_two_lanes = -1;
     return LF_OK;
 }
 // Timing model of ONE rank of a sharded run on a box with one GPU (tools/shard_model.py): rank `rank` of `world` with no peers.  Every kernel and every host
@@ -670,6 +612,7 @@ int lf_set_sharding_model(lf_ctx *c, int rank, int world) {
     }
     c->sh_rank = rank; c->sh_world = world;
     c->two_lanes_ok = world > 1;
+    c->agreed_two_lanes = -1;
     return LF_OK;
 }
 int lf_dist_stats_words(lf_ctx *c, uint64_t *words_sent, int reset) {
@@ -754,6 +697,36 @@ static int dist_handshake(lf_ctx *c) {
         for (int it = 0; it < ITER && ok; it++)
             for (int g2 = 0; g2 < W && ok; g2++)
                 for (size_t w = 0; w < words && ok; w++) ok = hbuf[l][per_it * it + words + (size_t)g2 * words + w] == word(g2, l, it, w);
+    // The ranks must AGREE on the schedule: the threaded one splits the exchanges of a step over comm[0] and comm[1], the one-thread schedule issues all of them
+    // on comm[0] -- ranks that chose differently would issue different collective sequences and hang.  So the verdict is exchanged inside the library (one more
+    // all-gather on comm[0], one issuing thread: the form that works whatever the check found) and the minimum wins; a rank's own LF_SHARD_TWO_LANES=0 / =1 enters
+    // it too (2 = forced on, 1 = check passed, 0 = off / failed: forced-on survives only if every rank forced it), so a C or Rust caller of lf_dist_init needs no
+    // agreement of its own (the Python launcher's MIN-reduce is no longer what correctness rests on).
+    {
+        const char *e = getenv("LF_SHARD_TWO_LANES");
+        const u64 mine = e ? (atoi(e) != 0 ? 2 : 0) : (ok ? 1 : 0);
+        u64 *hs = hbuf[0], *ds = dbuf[0];
+        hs[0] = mine;
+        const int keep = t_lane;
+        t_lane = 0;
+        int rc2 = hipMemcpyAsync(ds, hs, 8, hipMemcpyHostToDevice, c->stream()) == hipSuccess ? LF_OK : LF_ERR_HIP;
+        if (rc2 == LF_OK) rc2 = c->cm().allgather_dev(ds, ds + 1, 1, c->stream());
+        if (rc2 == LF_OK && hipMemcpyAsync(hs + 1, ds + 1, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream()) != hipSuccess) rc2 = LF_ERR_HIP;
+        bool late = false;
+        for (; rc2 == LF_OK;) {
+            const hipError_t q = hipStreamQuery(c->stream());
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { rc2 = LF_ERR_HIP; break; }
+            if (std::chrono::steady_clock::now() > deadline) { late = true; break; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        t_lane = keep;
+        if (late || rc2 != LF_OK) { c->comm[0].abort_peers(); c->comm[1].abort_peers(); return LF_ERR_STATE; }
+        u64 mn = 2;
+        for (int g2 = 0; g2 < W; g2++) mn = hs[1 + g2] < mn ? hs[1 + g2] : mn;
+        ok = mn >= 1;                                          // every rank either passed the check or forces the threaded schedule
+        c->agreed_two_lanes = ok ? 1 : 0;                      // what the sharded step follows (lf_fold_step), whatever this rank's environment says later
+    }
     for (int l = 0; l < 2; l++) { (void)hipFree(dbuf[l]); (void)hipHostFree(hbuf[l]); c->comm[l].n_exchanges = 0; c->comm[l].us_total = 0; c->comm[l].us_max = 0; }
     c->two_lanes_ok = ok;
     return LF_OK;
@@ -775,7 +748,7 @@ int lf_dist_two_lanes(lf_ctx *c, int set) {
     if (!c) return LF_ERR_INVALID;
     if (c->bb) return 0;                      // (the BabyBear driver exchanges from one thread only)
     std::lock_guard<std::mutex> g(c->mu);
-    if (set == 0 || set == 1) c->two_lanes_ok = set == 1;
+    if (set == 0 || set == 1) { c->two_lanes_ok = set == 1; c->agreed_two_lanes = set; }   // (the caller sets the same value on every rank)
     return c->two_lanes_ok ? 1 : 0;
 }
 // per-lane callbacks (host transport): the two lanes of a fold step exchange concurrently, so each needs its own ordered channel
@@ -785,6 +758,7 @@ int lf_set_sharding_lanes(lf_ctx *c, int rank, int world, lf_exchange_fn cb0, vo
     if (c->bb) return LF_OK;   // the BabyBear driver exchanges from one thread only
     std::lock_guard<std::mutex> g(c->mu);
     c->comm[1].cb = cb1; c->comm[1].user = user1;
+    c->agreed_two_lanes = -1;
     c->two_lanes_ok = (cb1 != cb0 || user1 != user0);   // two ordered channels supplied by the host language: the threaded schedule is the default
     return LF_OK;
 }
@@ -953,14 +927,13 @@ static int shard_columns(lf_ctx *c, size_t n, size_t *col0, size_t *cnt) {
     *col0 = *cnt * c->sh_rank;
     return LF_OK;
 }
-// The int8 matrix-core commit kernel wants A in coefficient form, cut into bytes, in MFMA operand order: built once per matrix.
-// (c->kappa, c->nA set.)  Rows arrive one at a time in NTT form (row_ntt [24][nA] on the device, prep_ajtai_i8_row): one fused pass -- dense
-// inverse map + byte packing -- per row, so a digits-only context never holds more than one u64 row of A.
-static bool want_ajtai_i8() { return !getenv("LF_AJTAI_VALU"); }
+// A lives on the device in ONE form: coefficient form, cut into bytes, in MFMA operand order (lf_ajtai_i8.hip) -- what the digit-plane commitments of a fold
+// step (k_ajtai_i8s) and the general commitments (lf_ajtai_i8g.hip: commit_ntt, Witness::commit) both stream.  Built once per matrix: rows arrive one at a time
+// in NTT form (row_ntt [24][nA] on the device), one fused pass -- inverse CRT map + byte packing -- per row, so the context never holds more than one u64 row.
+// (Rounds 2-5 also kept the NTT form, 4.9 GiB at C4, for a 64-bit VALU commit kernel; the int8 general commit retired both.)
 static int prep_ajtai_i8_begin(lf_ctx *c) {
     if (c->dAb) { (void)hipFree(c->dAb); c->dAb = nullptr; }
     c->i8_nch = 0;
-    if (!want_ajtai_i8()) return LF_OK;
     const AjtaiI8Ring R = ajtai_i8_goldilocks();
     const u32 maxr = ajtai_i8_max_rows(R), nch = (c->kappa + maxr - 1) / maxr, kc = (c->kappa + nch - 1) / nch;
     const size_t ntiles = (c->nA + 7) / 8;
@@ -973,57 +946,24 @@ static int prep_ajtai_i8_begin(lf_ctx *c) {
     return LF_OK;
 }
 static void prep_ajtai_i8_row(lf_ctx *c, u32 i, const u64 *row_ntt) {
-    if (!c->i8_nch) return;
     const AjtaiI8Ring R = ajtai_i8_goldilocks();
     const u32 kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc);
     const size_t chunk_bytes = (c->nA + 7) / 8 * (R.RD / 8) * MT * 1024;
     launch_ajtai_icrt_pack_i8(c->d_icrt, row_ntt, c->nA, i % kc, MT, c->dAb + (size_t)(i / kc) * chunk_bytes, c->stream());
 }
-// The NTT-form copy for a general commitment (lf_ajtai_commit, lf_witness_commit, the LF_AJTAI_VALU step): rebuilt from the byte planes
-// when the context runs in digits-only mode or dropped it (lf_ajtai_release_ntt) -- the bytes are the canonical coefficients.
-static int need_dA(lf_ctx *c) {
-    if (!c->A_loaded) return LF_ERR_STATE;
-    if (c->dA) return LF_OK;
-    if (!c->i8_nch || !c->dAb) return LF_ERR_STATE;
-    const AjtaiI8Ring R = ajtai_i8_goldilocks();
-    const u32 kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc);
-    const size_t chunk_bytes = (c->nA + 7) / 8 * (R.RD / 8) * MT * 1024;
-    u64 *coef;
-    RET(c->tbuf("i8_prep_coef", 24 * c->nA, &coef));
-    HIPCHK(lf_dev_malloc(&c->dA, (size_t)c->kappa * c->nA * 24 * 8));
-    for (u32 i = 0; i < c->kappa; i++) {
-        launch_ajtai_unpack_i8(c->dAb + (size_t)(i / kc) * chunk_bytes, c->nA, i % kc, MT, R.RD, R.NL, coef, c->stream());
-        launch_crt_fwd(c->dcrt, coef, c->dA + (size_t)i * 24 * c->nA, c->nA, c->stream());
-    }
-    return LF_OK;
-}
-// digits-only contexts give the copy back after the call that needed it
-static void done_dA(lf_ctx *c) {
-    if (c->digits_only && c->dA && c->i8_nch) {
-        (void)hipStreamSynchronize(c->stream());
-        (void)hipFree(c->dA);
-        c->dA = nullptr;
-        c->drop_buf("i8_prep_coef");
-    }
-}
 static int ajtai_install(lf_ctx *c, size_t kappa, size_t n, const uint64_t *A_host, uint64_t seed) {
     size_t col0, cnt;
     RET(shard_columns(c, n, &col0, &cnt));   // a sharded rank keeps only its column slice of the caller's matrix
-    if (c->dA) { (void)hipFree(c->dA); c->dA = nullptr; }
     c->A_loaded = false;
     c->kappa = (u32)kappa;
     c->nA = cnt; c->nA_total = n; c->A_col0 = col0;
     RET(prep_ajtai_i8_begin(c));
-    const bool keep = !(c->digits_only && c->i8_nch);
     u64 *row = nullptr;
-    if (keep) HIPCHK(lf_dev_malloc(&c->dA, kappa * cnt * 24 * 8));
-    else RET(c->tbuf("i8_prep_row", 24 * cnt, &row));
-    if (keep && !A_host) launch_fill_ajtai(c->dA, (u32)kappa, cnt, n, col0, seed, c->stream());
+    RET(c->tbuf("i8_prep_row", 24 * cnt, &row));
     for (size_t i = 0; i < kappa; i++) {
-        u64 *r = keep ? c->dA + i * 24 * cnt : row;
-        if (A_host) RET(up_ring(c, A_host + (i * n + col0) * 24, cnt, r));
-        else if (!keep) launch_fill_ajtai(r, 1, cnt, n, col0, seed, c->stream(), (u32)i);
-        prep_ajtai_i8_row(c, (u32)i, r);
+        if (A_host) RET(up_ring(c, A_host + (i * n + col0) * 24, cnt, row));
+        else launch_fill_ajtai(row, 1, cnt, n, col0, seed, c->stream(), (u32)i);
+        prep_ajtai_i8_row(c, (u32)i, row);
     }
     HIPCHK(hipStreamSynchronize(c->stream()));
     c->drop_buf("i8_prep_row");
@@ -1032,11 +972,9 @@ static int ajtai_install(lf_ctx *c, size_t kappa, size_t n, const uint64_t *A_ho
     return LF_OK;
 }
 // digit planes k0 .. k0+NP-1 of `planes` (this rank's column slice) -> out_dev [NP][kappa][24] NTT form (PARTIAL when sharded)
-// planes2 / out_dev2 (optional): the same planes of a second witness, committed in the same launches (A streamed from HBM once for both)
 // wit (optional): the witness `planes` belong to -- if its bit-plane form is at hand (built at the start of the fold step for the GEMM rounds) the
 // kernel cuts the digits from it
-static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev, const int32_t *planes2 = nullptr, u64 *out_dev2 = nullptr,
-                            const lf_witness *wit = nullptr, const u32 *bits_in = nullptr /* the bit-plane form of `planes`, made on this stream */) {
+static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0, u32 NP, u64 *out_dev, const lf_witness *wit = nullptr) {
     const AjtaiI8Ring R = ajtai_i8_goldilocks();
     const u32 nch = c->i8_nch, kc = c->i8_kc, MT = ajtai_i8_row_tiles(R, kc), maxp = ajtai_i8_max_planes(R);
     const size_t ntiles = (c->nA + 7) / 8, chunk_bytes = ntiles * (R.RD / 8) * MT * 1024;
@@ -1045,22 +983,19 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
     // (measured 256 / 240 / 224 / 192 / 160 / 128 workgroups: 26.1 / 26.3 / 25.0 / 25.1 / 26.1 / 28.2 ms).
     u32 nwg = c->tn.i8_wgs > 0 ? (u32)c->tn.i8_wgs : 224;
     if (nwg > ntiles) nwg = (u32)ntiles;
+    const u32 nslots = nwg < 16 ? 16 : nwg;    // (two plane groups run as 2 x 8 chunks at least: launch_ajtai_i8)
     int32_t *part, *dsum;
     long long *sum;
     u64 *coef, *ntt;
     const u32 NTmax = ajtai_i8_col_tiles(R, maxp);
-    RET(c->tbuf("i8_part", ajtai_i8_part_words(nwg, MT, NTmax), &part));
-    RET(c->tbuf("i8_dsum", (size_t)nwg * maxp * R.RD, &dsum));
+    RET(c->tbuf("i8_part", ajtai_i8_part_words(nslots, MT, NTmax), &part));
+    RET(c->tbuf("i8_dsum", (size_t)nslots * maxp * R.RD, &dsum));
     RET(c->tbuf("i8_sum", ajtai_i8_sum_words(R, MT, NTmax, maxp), &sum));
     const size_t side_words = (size_t)24 * NP * c->kappa;
-    RET(c->tbuf("i8_coef", 2 * side_words, &coef));
-    RET(c->tbuf("i8_ntt", 2 * side_words, &ntt));
-    if (planes2 && (nwg / 2 < 8 || !out_dev2)) {   // too few column tiles for paired workgroups: one witness after the other
-        RET(commit_planes_i8(c, planes, ld, k0, NP, out_dev));
-        return commit_planes_i8(c, planes2, ld, k0, NP, out_dev2);
-    }
-    const u32 *bits = bits_in;
-    if (!bits && wit && !planes2 && c->A_col0 == 0 && planes == wit->planes && c->nA == c->N)
+    RET(c->tbuf("i8_coef", side_words, &coef));
+    RET(c->tbuf("i8_ntt", side_words, &ntt));
+    const u32 *bits = nullptr;
+    if (wit && c->A_col0 == 0 && planes == wit->planes && c->nA == c->N)
         for (int sd = 0; sd < 2; sd++)
             if (c->bits_wit[sd] == wit && c->bits_ptr[sd]) {
                 bits = c->bits_ptr[sd];
@@ -1076,17 +1011,13 @@ static int commit_planes_i8(lf_ctx *c, const int32_t *planes, size_t ld, u32 k0,
             const u32 row0 = ch * kc, kn = c->kappa - row0 < kc ? c->kappa - row0 : kc;
             size_t ev = c->ev_begin(1);
             int g = launch_ajtai_i8(R, c->dAb + (size_t)ch * chunk_bytes, MT, planes, ld, c->nA, kn, row0, c->kappa, k0 + p0, np, nwg, part, dsum, sum, cf, c->stream(),
-                                    planes2, planes2 ? cf + side_words : nullptr, bits, bits_nw, bits_rows);
+                                    bits, bits_nw, bits_rows);
             c->ev_end(ev);
             if (g < 0) return LF_ERR_UNSUPPORTED;
         }
         const size_t ne = (size_t)np * c->kappa;
         launch_crt_fwd(c->dcrt, cf, ntt, ne, c->stream());
         launch_soa_to_aos(ntt, out_dev + (size_t)p0 * c->kappa * 24, ne, c->stream());
-        if (planes2) {
-            launch_crt_fwd(c->dcrt, cf + side_words, ntt + side_words, ne, c->stream());
-            launch_soa_to_aos(ntt + side_words, out_dev2 + (size_t)p0 * c->kappa * 24, ne, c->stream());
-        }
     }
     return LF_OK;
 }
@@ -1110,21 +1041,6 @@ int lf_device_memory(lf_ctx *c, size_t *free_bytes, size_t *total_bytes) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
     return LF_OK;
-}
-int lf_ajtai_set_digits_only(lf_ctx *c, int on) {
-    if (!c) return LF_ERR_INVALID;
-    if (c->bb) return on ? LF_ERR_UNSUPPORTED : LF_OK;
-    std::lock_guard<std::mutex> g(c->mu);
-    c->digits_only = on != 0;
-    if (c->digits_only && c->dA && c->i8_nch) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipStreamSynchronize(c->stream())); (void)hipFree(c->dA); c->dA = nullptr; }
-    return LF_OK;
-}
-static u32 ajtai_splits(size_t n) {
-    // one block per (split, slot); aim for >= 4 blocks per CU, each split a multiple of the LDS tile
-    size_t s = n / 256;
-    if (s < 1) s = 1;
-    if (s > 128) s = 128;
-    return (u32)s;
 }
 // General commitments from the resident byte planes of A (lf_ajtai_i8g.hip): AjtaiCommitmentScheme::commit_ntt (commitment_scheme.rs:37-54,75-77) for
 // `batch` vectors F [batch][24][ldF] in NTT form (pointing at this rank's first column), or Witness::commit (arith.rs:357-362) for the centred int32
@@ -1164,34 +1080,8 @@ static int commit_dev_i8g(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, const 
     }
     return LF_OK;
 }
-static bool want_ajtai_i8g(const lf_ctx *c) { return c->i8_nch && c->dAb && !getenv("LF_AJTAI_VALU") && !getenv("LF_COMMIT_VALU"); }
 // F: [batch][24][ldF] device, pointing at this rank's first column; out_dev: [batch][kappa][24] device AoS (PARTIAL when sharded)
-static int commit_dev(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) {
-    if (want_ajtai_i8g(c)) return commit_dev_i8g(c, F, ldF, batch, nullptr, 0, out_dev, timed);
-    RET(need_dA(c));
-    // One LDS tile holds the (A, F) rows of a launch: at most 48 rows of A (kappa up to 128 -- the reference's Goldilocks rows go up to
-    // kappa = 99, benches/config.toml:158 -- is cut into equal row chunks) and as many witnesses as fit next to them.
-    const u32 nch = (c->kappa + 47) / 48, kc = (c->kappa + nch - 1) / nch;
-    u32 maxb = 448 / kc;
-    if (maxb > 64 - kc) maxb = 64 - kc;
-    if (maxb < 1) return LF_ERR_UNSUPPORTED;
-    u32 splits = ajtai_splits(c->nA);
-    u64 *partial, *tmp = nullptr;
-    RET(c->tbuf("ajtai_partial", ajtai_partial_words(kc, maxb, splits), &partial));
-    if (nch > 1) RET(c->tbuf("ajtai_chunk_out", (size_t)maxb * kc * 24, &tmp));
-    for (u32 i0 = 0; i0 < c->kappa; i0 += kc) {
-        const u32 kn = c->kappa - i0 < kc ? c->kappa - i0 : kc;
-        for (u32 b0 = 0; b0 < batch; b0 += maxb) {
-            u32 nb = batch - b0 < maxb ? batch - b0 : maxb;
-            size_t ev = timed ? c->ev_begin(1) : 0;
-            u64 *dst = nch > 1 ? tmp : out_dev + (size_t)b0 * c->kappa * 24;
-            launch_ajtai(c->dcrt, c->dA + (size_t)i0 * 24 * c->nA, kn, c->nA, F + (size_t)b0 * 24 * ldF, ldF, nb, splits, partial, dst, c->stream());
-            if (nch > 1) launch_scatter_rows(tmp, nb, kn, c->kappa, i0, out_dev + (size_t)b0 * c->kappa * 24, c->stream());
-            if (timed) c->ev_end(ev);
-        }
-    }
-    return LF_OK;
-}
+static int commit_dev(lf_ctx *c, const u64 *F, size_t ldF, u32 batch, u64 *out_dev, bool timed) { return commit_dev_i8g(c, F, ldF, batch, nullptr, 0, out_dev, timed); }
 // download a (partial) commitment and, when sharded, all-gather + add the partials mod p
 static int commit_download(lf_ctx *c, const u64 *dev, size_t words, u64 *host) {
     RET(exchange_modsum_dev(c, (u64 *)dev, words));   // sharded: ncclAllGather of the partial commitments + k_modsum, in stream
@@ -1273,9 +1163,7 @@ int lf_ajtai_commit(lf_ctx *c, const uint64_t *f, size_t n, size_t batch, uint64
     c->ev_reset();
     RET(commit_dev(c, F + c->A_col0, n, (u32)batch, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
     c->ev_collect();
-    const int rc = commit_download(c, o, batch * c->kappa * 24, out);
-    done_dA(c);
-    return rc;
+    return commit_download(c, o, batch * c->kappa * 24, out);
 }
 
 // column-sharded commit: the context holds only columns [col0, col0+n_local) of A (loaded with lf_ajtai_load on
@@ -1592,22 +1480,13 @@ int lf_witness_commit(lf_ctx *c, const lf_witness *w, uint64_t *cm_out) {
     if (!c->A_loaded) return LF_ERR_STATE;
     if (w->N != c->nA_total) return LF_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    u64 *d, *e, *o;
+    u64 *o;
     RET(c->tbuf("io_o", (size_t)c->kappa * 24, &o));
-    if (want_ajtai_i8g(c)) {     // the int32 planes of the handle are the operand: five base-128 digit planes, no NTT of the witness
-        c->ev_reset();
-        RET(commit_dev_i8g(c, nullptr, 0, 1, w->planes + c->A_col0, w->N, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
-        c->ev_collect();
-        return commit_download(c, o, (size_t)c->kappa * 24, cm_out);
-    }
-    RET(c->tbuf("io_c", w->N * 24, &d));
-    RET(c->tbuf("io_b", w->N * 24, &e));
-    launch_i32_to_coef(w->planes, d, w->N, c->stream());
-    launch_crt_fwd(c->dcrt, d, e, w->N, c->stream());
-    RET(commit_dev(c, e + c->A_col0, w->N, 1, o, false));
-    const int rc = commit_download(c, o, (size_t)c->kappa * 24, cm_out);
-    done_dA(c);
-    return rc;
+    // the int32 planes of the handle are the operand: five base-128 digit planes, no NTT of the witness
+    c->ev_reset();
+    RET(commit_dev_i8g(c, nullptr, 0, 1, w->planes + c->A_col0, w->N, o, true));   // timed: lf_last_kernel_stats reports the stand-alone kernel
+    c->ev_collect();
+    return commit_download(c, o, (size_t)c->kappa * 24, cm_out);
 }
 // pool of recycled witness-plane buffers: process-wide (a witness may be freed after its context), keyed by device and size
 namespace {
@@ -2135,7 +2014,7 @@ struct SideState {
     std::atomic<int> z_state{0};
     hipEvent_t z_ev = nullptr;
     u32 *sv_bits = nullptr;  // bit-plane form of the witness planes for the GEMM rounds of the folding sumcheck (lf_sv_rounds.h), if built ahead
-    ~SideState() { if (z_ev) (void)hipEventDestroy(z_ev); }   // (2 = z, x_s came from lf_prefetch_instance: the step's streams already wait for it)
+    ~SideState() { if (z_ev) (void)hipEventDestroy(z_ev); }
 };
 
 // LFDecompositionProver::prove (nifs/decomposition.rs:33-88)
@@ -2146,36 +2025,13 @@ static int decompose_commit_enqueue(lf_ctx *c, const lf_witness *wit, u64 **yd_o
     const lf_params &P = c->P;
     size_t N = c->N;
     u32 K = P.K;
-    u64 *Fh, *yd;
+    u64 *yd;
     RET(c->tbuf(ybuf, (size_t)K * P.kappa * 24, &yd));
     size_t ph = c->ev_begin(11);
-    if (c->i8_nch && !c->tn.ajtai_valu) {
-        // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
-        RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd, nullptr, nullptr, wit));
-    } else {
-        RET(c->tbuf("dec_fhat", (size_t)(K - 1) * 24 * c->nA, &Fh));
-        launch_bitplane_crt(c->dcrt, wit->planes + c->A_col0, N, c->nA, 1, K, Fh, c->stream());
-        RET(commit_dev(c, Fh, c->nA, K - 1, yd, true));
-    }
+    if (!c->i8_nch) return LF_ERR_STATE;
+    // int8 matrix cores: digits straight from the coefficient planes, no bit-plane NTTs (this rank's column slice when sharded)
+    RET(commit_planes_i8(c, wit->planes + c->A_col0, N, 1, K - 1, yd, wit));
     *yd_out = yd;
-    *ev_out = ph;
-    return LF_OK;
-}
-// commit_witnesses of BOTH decompositions of a fold step in one pass over A (they depend on the two witnesses only): the digit planes of
-// wit_l and wit_r through the same launches of the int8 kernel, paired workgroups sharing the tiles of A in L2.  false: the shape / mode has no
-// such form (the caller commits one side after the other).
-static bool commit_pair_possible(lf_ctx *c) {
-    return c->i8_nch && !c->tn.ajtai_valu && c->tn.i8_pair && (c->nA + 7) / 8 >= 16;
-}
-static int decompose_commit_enqueue_pair(lf_ctx *c, const lf_witness *wit_l, const lf_witness *wit_r, u64 **ydl_out, u64 **ydr_out, size_t *ev_out) {
-    const lf_params &P = c->P;
-    u32 K = P.K;
-    u64 *ydl, *ydr;
-    RET(c->tbuf("dec_y", (size_t)K * P.kappa * 24, &ydl));
-    RET(c->tbuf("dec_y2", (size_t)K * P.kappa * 24, &ydr));
-    size_t ph = c->ev_begin(11);
-    RET(commit_planes_i8(c, wit_l->planes + c->A_col0, c->N, 1, K - 1, ydl, wit_r->planes + c->A_col0, ydr));
-    *ydl_out = ydl; *ydr_out = ydr;
     *ev_out = ph;
     return LF_OK;
 }
@@ -2293,65 +2149,6 @@ static int decompose_prepare_z(lf_ctx *c, const u64 *xh /* (l+1) elements: x_w |
     S.z_state.store(rc == LF_OK ? 1 : -1, std::memory_order_release);
     return rc;
 }
-// The work of lf_prefetch_instance: bit planes, z_k / x_s and the K - 1 digit-plane commitments of the NEXT step's right witness, enqueued on lane 2's stream by
-// the thread of the running step (t_lane is switched for the duration: stream, buffers and staging are the prefetch lane's own).  Never fails the running step:
-// an error just leaves no result.
-static int prefetch_enqueue(lf_ctx *c, int upto) {
-    lf_ctx::Prefetch &pf = c->pf;
-    if (!pf.req || pf.part >= upto) return LF_OK;
-    const lf_params &P = c->P;
-    const lf_witness *wit = pf.req_wit;
-    const u32 K = P.K;
-    struct LaneSwitch { int old; LaneSwitch() : old(t_lane) { t_lane = 2; } ~LaneSwitch() { t_lane = old; } } ls;
-    if (pf.part == 0) {
-        // what the default fold step of a large unsharded instance runs: digit commits on the matrix cores over the whole witness, bit planes for the GEMM rounds
-        if (c->sh_world > 1 || !c->i8_nch || c->tn.ajtai_valu || c->tn.commits_first || c->tn.i8_pair || c->tn.force_exchange || P.b != 2 || c->A_col0 != 0 || c->nA != c->N ||
-            wit->N != c->N || (c->N & 3) || c->N > c->m || K < 2) { pf.req = false; pf.dropped++; return LF_OK; }
-        if (!c->st_lane[2]) {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            HIPCHK(hipStreamCreateWithPriority(&c->st_lane[2], hipStreamDefault, getenv("LF_NO_PRIO") ? 0 : least));
-        }
-        const int wr = c->pf_inuse == 0 ? 1 : 0;
-        pf.wr = wr; pf.ev_k_used = false; pf.have = false;
-        if (!pf.ev_done[wr]) HIPCHK(hipEventCreateWithFlags(&pf.ev_done[wr], hipEventDisableTiming));
-        if (!pf.ev_k[wr].a) { HIPCHK(hipEventCreate(&pf.ev_k[wr].a)); HIPCHK(hipEventCreate(&pf.ev_k[wr].b)); }
-        RET(c->tbuf(wr ? "pf_bits1" : "pf_bits0", sv_bits_words(c->N, K), &pf.w_bits));
-        RET(c->tbuf(wr ? "pf_z1" : "pf_z0", (size_t)K * 24 * c->n, &pf.w_z));
-        RET(c->tbuf(wr ? "pf_y1" : "pf_y0", (size_t)K * P.kappa * 24, &pf.w_yd));
-        const size_t ywords = (size_t)(K - 1) * P.kappa * 24;
-        if (pf.y_words[wr] < ywords) {
-            if (pf.y_host[wr]) { HIPCHK(hipStreamSynchronize(c->stream())); (void)hipHostFree(pf.y_host[wr]); pf.y_host[wr] = nullptr; pf.y_words[wr] = 0; }
-            HIPCHK(hipHostMalloc((void **)&pf.y_host[wr], ywords * 8));
-            pf.y_words[wr] = ywords;
-        }
-        launch_sv_bits(wit->planes, c->N, c->N, K, pf.w_bits, c->stream());
-        pf.w_x_s.assign((size_t)K * (P.l + 1) * 24, 0);
-        compute_x_s(c, pf.req_x.data(), pf.w_x_s.data());
-        RET(build_z(c, wit->planes, K, 1, pf.w_x_s.data(), pf.w_z));
-        pf.part = 1;
-    }
-    if (upto >= 2) {
-        const int wr = pf.wr;
-        const size_t ywords = (size_t)(K - 1) * P.kappa * 24;
-        RET(commit_planes_i8(c, wit->planes, c->N, 1, K - 1, pf.w_yd, nullptr, nullptr, nullptr, pf.w_bits));
-        HIPCHK(hipMemcpyAsync(pf.y_host[wr], pf.w_yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()));
-        HIPCHK(hipEventRecord(pf.ev_done[wr], c->stream()));
-        pf.have = true; pf.parity = wr; pf.wit = wit; pf.wit_id = pf.req_id; pf.x = pf.req_x; pf.x_s = pf.w_x_s; pf.bits = pf.w_bits; pf.z = pf.w_z; pf.yd = pf.w_yd;
-        pf.issued++;
-        pf.req = false; pf.part = 0;
-    }
-    return LF_OK;
-}
-static void pf_trigger(lf_ctx *c, int point) {
-    // (the first trigger point at or after LF_PF_AT that the step reaches enqueues the bit planes and z_k, the first at or after LF_PF_AT2 the commits)
-    if (!c->pf.req) return;
-    const int upto = point >= c->tn.pf_at2 ? 2 : point >= c->tn.pf_at ? 1 : 0;
-    if (upto <= c->pf.part) return;
-    if (prefetch_enqueue(c, upto) != LF_OK) { c->pf.have = false; c->pf.req = false; c->pf.part = 0; c->pf.dropped++; (void)hipGetLastError(); }
-    TL_MARK(upto == 2 ? "  prefetch: commits enqueued" : "  prefetch: bit planes + z enqueued");
-}
-
 // The evaluations of a decomposition in two stages (the right side of a fold step): stage 0 = all v_s and the u_s of the parts k < ksplit, stage 1 = the
 // other u_s.  decompose_evals then enqueues both downloads and returns without waiting; decompose_evals_collect(stage) waits for that stage's event and
 // moves its words into the proof -- so the host can absorb the first K/2 parts (x_k, y_k, u_k, v_k: half of a ~1 ms sponge chain) while the GPU is
@@ -2717,7 +2514,6 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         for (u32 i = 0; i < P.s; i++) beta[i] = tr.get_challenge();
     }
     TL_MARK(" fold challenges");
-    pf_trigger(c, 3);
     for (u32 i = 0; i < K2; i++) {
         Fq3 pm = mu[i];
         for (u32 d = 0; d < 3; d++) { mu_pow[(size_t)i * 3 + d] = f3c(pm); pm = c->ring.mul3(pm, mu[i]); }
@@ -3107,11 +2903,9 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
         if (round == 3) TL_MARK("  round 3");
         if (round == 6) TL_MARK("  round 6");
         if (round == 10) TL_MARK("  round 10");
-        if (round <= 29) pf_trigger(c, 10 + (int)round);
     }
     TL_MARK(" fold sumcheck");
     c->ev_end(ph);
-    pf_trigger(c, 40);
 
     ph = c->ev_begin(15);
     // theta, eta at r_0 (folding.rs:236-256)
@@ -3223,15 +3017,12 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
     // Witness::from_f (arith.rs:299-313): f = CRT(f_coeff) and w_ccs = CRT(recompose(f_coeff, B, L)) of the folded witness, behind compute_f_0 on the same stream
     u64 *nf = nullptr, *nw = nullptr;
     const size_t nf_bytes = N * 24 * 8, nw_bytes = (size_t)P.wit_len * 24 * 8;
-    if (!c->tn.lazy_from_f) {
-        RET(lf_planes_alloc(c, nf_bytes, (int32_t **)&nf));
-        RET(lf_planes_alloc(c, nw_bytes, (int32_t **)&nw));
-        launch_recompose_crt(c->dcrt, npl, N, (u32)N, 1, P.B, 1, 0, nf, N, 0, c->stream());
-        launch_recompose_crt(c->dcrt, npl, N, P.wit_len, P.L, P.B, 1, 0, nw, P.wit_len, 0, c->stream());
-    }
+    RET(lf_planes_alloc(c, nf_bytes, (int32_t **)&nf));
+    RET(lf_planes_alloc(c, nw_bytes, (int32_t **)&nw));
+    launch_recompose_crt(c->dcrt, npl, N, (u32)N, 1, P.B, 1, 0, nf, N, 0, c->stream());
+    launch_recompose_crt(c->dcrt, npl, N, P.wit_len, P.L, P.B, 1, 0, nw, P.wit_len, 0, c->stream());
     LF_TRACE(c, "fold_witness");
     TL_MARK("  eta absorbed, rho drawn, fold_witness enqueued");
-    pf_trigger(c, 50);
 
     // compute_v0_u0_x0_cm_0 (folding/utils.rs:460-521) on the host while the GPU folds the witness
     {
@@ -3351,10 +3142,11 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     // Large instances: lane 1 (two commits back to back) is the critical path and lane 0 has several ms of slack, so the
     // linearization rounds run on 16 workgroups per slot and leave the CUs to the commit kernels (C4: 44.6 -> 43.7 ms/step).
     // (with the digit-plane commits on the matrix cores lane 1 is no longer the critical path: no bound then -- C4 27.2 -> 26.1 ms/step)
-    c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : ((c->N >= ((size_t)1 << 19) && !(c->i8_nch && !c->tn.ajtai_valu)) ? 16u : 0u);
+    c->lin_blocks = c->tn.lin_blocks >= 0 ? (u32)c->tn.lin_blocks : 0u;
     int rc;
     std::vector<Fq3> rR;
-    const bool shard_threads = c->tn.shard_two_lanes == 1 || (c->tn.shard_two_lanes < 0 && c->two_lanes_ok);
+    // (after an RCCL handshake the agreed value decides: a rank-local environment switch must not make this rank issue a different collective sequence)
+    const bool shard_threads = c->agreed_two_lanes >= 0 ? c->agreed_two_lanes == 1 : (c->tn.shard_two_lanes == 1 || (c->tn.shard_two_lanes < 0 && c->two_lanes_ok));
     if (c->sh_world > 1 && !shard_threads) {
         // Sharded step: ONE host thread issues every exchange in program order (collectives of the ranks can then never cross), the two
         // streams still overlap the right commit with the linearization rounds on the GPU.  (LF_SHARD_TWO_LANES=1: the threaded schedule
@@ -3386,27 +3178,6 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         if (rc == LF_OK) c->host_tr_ms += absorb_decomposition(P, tr, lin.data(), decr, S[1]);
     } else {
     c->bits_wit[0] = c->bits_wit[1] = nullptr;
-    // lf_prefetch_instance: did the previous step prepare THIS right side?  The result is used once or dropped -- here, whatever happens next
-    bool pf_use = false;
-    c->pf_inuse = -1;
-    if (c->pf.have) {
-        lf_ctx::Prefetch &pf = c->pf;
-        pf.have = false;
-        const bool same = pf.wit == w_i && pf.wit_id == w_i->id && pf.x.size() == (size_t)(P.l + 1) * 24 &&
-                          memcmp(pf.x.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8) == 0;
-        const bool path = c->i8_nch && !c->tn.ajtai_valu && !c->tn.commits_first && !commit_pair_possible(c) && !c->tn.force_exchange && c->tn.zr_pos != 4;
-        if (same && path && hipStreamWaitEvent(c->st_lane[0], pf.ev_done[pf.parity], 0) == hipSuccess &&
-            hipStreamWaitEvent(c->st_lane[1], pf.ev_done[pf.parity], 0) == hipSuccess) {
-            pf_use = true;
-            pf.consumed++;
-            c->pf_inuse = pf.parity;
-            c->pf_kernel_counted = pf.ev_k_used ? pf.parity : -1;
-            S[1].z = pf.z;
-            memcpy(decr + (size_t)P.K * P.t * 24 + (size_t)P.K * 72, pf.x_s.data(), pf.x_s.size() * 8);
-            S[1].z_state.store(2, std::memory_order_release);
-            TL_MARK("prefetched right side taken");
-        } else pf.dropped++;
-    }
     if (!c->tn.fold_no_sv && !c->tn.force_exchange && c->N <= c->m && (c->N & 3) == 0 && !c->tn.fold_tab_r1 && (c->m >> 1) >= c->tn.sv_min) {
         // bit-plane form of both witnesses (GEMM rounds of the folding sumcheck, v_s evaluations): first thing on the helper lane's stream,
         // enqueued from here so that the events below are recorded before anybody can wait for them
@@ -3415,8 +3186,6 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
             u32 *bits;
             if (c->tbuf(sd ? "sv_bits_R" : "sv_bits_L", sv_bits_words(c->N, P.K), &bits) != LF_OK) break;
             if (!c->bits_ev[sd] && hipEventCreateWithFlags(&c->bits_ev[sd], hipEventDisableTiming) != hipSuccess) break;
-            if (sd == 1 && pf_use) bits = c->pf.bits;      // (made by the prefetch; both streams of this step already wait for it)
-            else
             launch_sv_bits(ws[sd]->planes, c->N, c->N, P.K, bits, c->st_lane[1]);
             if (hipEventRecord(c->bits_ev[sd], c->st_lane[1]) != hipSuccess) break;
             c->bits_wit[sd] = ws[sd]; c->bits_ptr[sd] = bits;
@@ -3433,75 +3202,45 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         Timeline *const tl1 = &tl;
         u64 *yd = nullptr, *ydL = nullptr;
         size_t ev = 0;
-        // the right side's z_k depend on the witness and on x_w || h = x_ccs || 1 only, not on the point r: wherever they are built on this lane's stream,
-        // lane 0's u_s inner products wait for them (S[1].z_ev)
-        bool zr_done = c->tn.zr_pos == 4 || pf_use, yR_early = false;
-        const u64 *yR_host = nullptr;   // (4: the main thread builds them on lane 0's stream, first thing)
-        auto build_zr = [&]() {
-            if (zr_done) return;
-            zr_done = true;
+        // the right side's z_k depend on the witness and on x_w || h = x_ccs || 1 only, not on the point r: they are built on this lane's stream behind the left
+        // evaluations, and lane 0's u_s inner products wait for them (S[1].z_ev)
+        bool yR_early = false;
+        const u64 *yR_host = nullptr;
+        // The left evaluations first, then the two commits back to back.  A commit workgroup fills its CU (registers, LDS): while one runs,
+        // the other lane's kernels have the 32 CUs it leaves free -- and the linearization is bandwidth-hungry exactly at its start (z, the
+        // three M z, its first rounds: 2.2 ms next to a commit, ~1.2 ms next to the evaluations), latency-bound afterwards.
+        size_t evL = 0;
+        RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
+        tl1->mark1("L1: left evals down");
+        {
             std::vector<u64> xh((size_t)(P.l + 1) * 24);
             memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
             HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
             (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);   // on failure lane 0 builds them itself
-        };
-        if (c->tn.zr_pos == 1) build_zr();
-        if (commit_pair_possible(c)) {
-            // both decompositions' commits in one pass over A.  Nothing needs y_L before the left decomposition is absorbed -- after the
-            // linearization -- so the left evaluations go first and the commit's results wait on the device
-            RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
-            RET(decompose_commit_enqueue_pair(c, w_acc, w_i, &ydL, &yd, &ev));
-        } else if (c->i8_nch && !c->tn.ajtai_valu && !c->tn.commits_first) {
-            // The left evaluations first, then the two commits back to back.  A commit workgroup fills its CU (registers, LDS): while one runs,
-            // the other lane's kernels have the 32 CUs it leaves free -- and the linearization is bandwidth-hungry exactly at its start (z, the
-            // three M z, its first rounds: 2.2 ms next to a commit, ~1.2 ms next to the evaluations), latency-bound afterwards.
-            size_t evL = 0;
-            RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
-            tl1->mark1("L1: left evals down");
-            if (c->tn.zr_pos == 2) build_zr();
-            RET(decompose_commit_enqueue(c, w_acc, &ydL, &evL));
-            // The download of a commit's results is enqueued right behind it -- ahead of whatever this stream is given next -- and its finish waits for that
-            // event only.  (Round 3 copied y_L behind the RIGHT commit: the left absorb, the head of a 2.3 ms host chain, started when both commits were done.)
-            const size_t ywords = (size_t)(P.K - 1) * P.kappa * 24;
-            const bool early = c->sh_world == 1 && !c->tn.force_exchange && !c->tn.no_early_y && c->pin2(2 * ywords) == LF_OK &&
-                               (c->ev_yL || hipEventCreateWithFlags(&c->ev_yL, hipEventDisableTiming) == hipSuccess) &&
-                               (c->ev_yR || hipEventCreateWithFlags(&c->ev_yR, hipEventDisableTiming) == hipSuccess);
-            bool yL_early = false;
-            if (early && hipMemcpyAsync(c->h_pin2, ydL, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yL, c->stream()) == hipSuccess)
-                yL_early = true;
-            if (c->tn.zr_pos == 3) build_zr();
-            if (pf_use) {                                                       // the right commit ran ahead (lf_prefetch_instance): its results are on the host
-                yR_early = true;
-                yR_host = c->pf.y_host[c->pf_inuse];
-                ev = (size_t)-1;
-            } else {
-            RET(decompose_commit_enqueue(c, w_i, &yd, &ev, "dec_y2"));          // right commit behind it on the same stream
-            if (early && hipMemcpyAsync(c->h_pin2 + ywords, yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yR, c->stream()) == hipSuccess) {
-                yR_early = true;
-                yR_host = c->h_pin2 + ywords;
-            }
-            }
-            if (yL_early) build_zr();                                           // (default position: behind the right commit; host-side this is NOW, not after y_L has arrived)
-            tl1->mark1("L1: commits + z_R enqueued");
-            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, evL, decl, yL_early ? c->h_pin2 : nullptr, yL_early ? c->ev_yL : nullptr));
-            ydL = nullptr;
-            tl1->mark1("L1: y_L down");
-        } else {
-            RET(decompose_commit_enqueue(c, w_acc, &yd, &ev));
-            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, yd, ev, decl));
-            RET(decompose_evals(c, acc, rL, w_acc, "L", nullptr, S[0], decl));
-            RET(decompose_commit_enqueue(c, w_i, &yd, &ev));               // right commit in flight ...
         }
-        build_zr();   // (default: behind the right commit)
-        if (ydL) {                                                      // paired commit: y_L from the device now (its phase timer closes here)
-            RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, ev, decl));
-            ev = c->ev_begin(11);
+        RET(decompose_commit_enqueue(c, w_acc, &ydL, &evL));
+        // The download of a commit's results is enqueued right behind it -- ahead of whatever this stream is given next -- and its finish waits for that
+        // event only.  (Round 3 copied y_L behind the RIGHT commit: the left absorb, the head of a 2.3 ms host chain, started when both commits were done.)
+        const size_t ywords = (size_t)(P.K - 1) * P.kappa * 24;
+        const bool early = c->sh_world == 1 && !c->tn.force_exchange && c->pin2(2 * ywords) == LF_OK &&
+                           (c->ev_yL || hipEventCreateWithFlags(&c->ev_yL, hipEventDisableTiming) == hipSuccess) &&
+                           (c->ev_yR || hipEventCreateWithFlags(&c->ev_yR, hipEventDisableTiming) == hipSuccess);
+        bool yL_early = false;
+        if (early && hipMemcpyAsync(c->h_pin2, ydL, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yL, c->stream()) == hipSuccess)
+            yL_early = true;
+        RET(decompose_commit_enqueue(c, w_i, &yd, &ev, "dec_y2"));          // right commit behind it on the same stream
+        if (early && hipMemcpyAsync(c->h_pin2 + ywords, yd, ywords * 8, hipMemcpyDeviceToHost, c->stream()) == hipSuccess && hipEventRecord(c->ev_yR, c->stream()) == hipSuccess) {
+            yR_early = true;
+            yR_host = c->h_pin2 + ywords;
         }
+        tl1->mark1("L1: commits + z_R enqueued");
+        RET(decompose_commit_finish(c, acc + ((size_t)P.s + 3) * 24, ydL, evL, decl, yL_early ? c->h_pin2 : nullptr, yL_early ? c->ev_yL : nullptr));
+        tl1->mark1("L1: y_L down");
         if (lin_done.get() != LF_OK) return LF_OK;                      // (the main thread reports its own error)
         tl1->mark1("L1: left absorb starts");
         absorb_decomposition(P, tr, acc, decl, S[0]);                   // ... while the host absorbs the left decomposition
         tl1->mark1("L1: left absorb done");
-        return decompose_commit_finish(c, cm_i, yd, ev, decr, yR_early ? yR_host : nullptr, yR_early ? (pf_use ? c->pf.ev_done[c->pf_inuse] : c->ev_yR) : nullptr);   // cm of the linearized instance = cm_i.cm
+        return decompose_commit_finish(c, cm_i, yd, ev, decr, yR_early ? yR_host : nullptr, yR_early ? c->ev_yR : nullptr);   // cm of the linearized instance = cm_i.cm
     });
     {   // absorb_public_input (nifs.rs:175-197) -- after lane 1 has been started: the left decomposition does not depend on it
         HostTimer ht(c);
@@ -3511,20 +3250,13 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
         tr.absorb_ring(cm_i, lf_cccs_len(&P));
     }
     TL_MARK("public input absorbed");
-    if (c->tn.zr_pos == 4) {   // the right side's z_k on THIS lane's stream, whose GPU time is mostly host hops between the linearization rounds
-        std::vector<u64> xh((size_t)(P.l + 1) * 24);
-        memcpy(xh.data(), cm_i + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
-        HostRing::from_u64(1, xh.data() + (size_t)P.l * 24);
-        (void)decompose_prepare_z(c, xh.data(), w_i, "R", S[1], decr);
-    }
     c->vs_keep = true;
     rc = linearize_impl(c, tr, cm_i, w_i, lin.data(), lin_proof, &eq_r_R);
     c->vs_keep = false;
     TL_MARK("linearization done");
     lin_done_p.set_value(rc);
     // From here the host runs a serial Poseidon chain (left absorb, right absorb, folding challenges: ~2.4 ms at 2^20 rows) next to which the GPU only has the
-    // right evaluations (0.5 ms): the window in which the next step's right side is prepared (lf_prefetch_instance; its stream has the lowest priority)
-    if (rc == LF_OK) pf_trigger(c, 0);
+    // right evaluations (0.5 ms)
     EvalStages est;
     if (rc == LF_OK) {
         lcccs_point(P, lin.data(), rR);
@@ -3533,12 +3265,10 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     }
     c->vs_wit = nullptr;
     TL_MARK(est.active ? "right evals enqueued" : "right evals done");
-    if (rc == LF_OK) pf_trigger(c, 1);
     int rc1 = c->lane1.wait();
     c->lin_blocks = 0;
     TL_MARK("lane 1 joined");
     if (rc == LF_OK) rc = rc1;
-    if (rc == LF_OK) pf_trigger(c, 2);
     if (rc == LF_OK && est.active) {
         // the right decomposition is absorbed part by part (x_k, y_k, u_k, v_k): the first half as soon as its inner products are down, the second half
         // of the inner products is still running on the GPU meanwhile
@@ -3554,7 +3284,6 @@ int lf_fold_step(lf_ctx *c, lf_transcript *t, const uint64_t *acc, const lf_witn
     TL_MARK("right absorb done");
     if (rc == LF_OK) rc = fold_impl(c, tr, S, lcccs_out, w_out, foldp);
     c->bits_wit[0] = c->bits_wit[1] = nullptr;
-    if (c->pf.req) { c->pf.req = false; c->pf.part = 0; c->pf.dropped++; }   // (not every trigger point reached: a request does not outlive the step it was made for)
     TL_MARK("fold done");
     tl.merge();
     tl.dump();
@@ -3900,38 +3629,6 @@ int lf_last_timeline(lf_ctx *c, char *names, double *ms, int max_marks) {
 // measurement hook of tools/gpu_i8prof.sh (not part of the prover interface, not declared in lfhip.h): per-phase clock totals of the last commit
 // launch made with LF_I8_PROF set
 int lf_abi_version(void) { return LFHIP_ABI_VERSION; }
-int lf_prefetch_instance(lf_ctx *c, const uint64_t *cm_next, const lf_witness *w_next) {
-    if (LF_XB(c) && cm_next && c->have_ccs_any()) {
-        XB x(c);
-        const lf_params &P = c->params_any();
-        return lf_prefetch_instance(c, x.ring_in(cm_next, lf_cccs_len_ring(&P, lf_ctx_ring(c))), w_next);
-    }
-    if (!c || !cm_next || !w_next || w_next->ctx != c) return LF_ERR_INVALID;
-    if (c->bb) return LF_OK;                       // (a hint: the BabyBear backend has no prefetch path and ignores it)
-    std::lock_guard<std::mutex> g(c->mu);
-    if (!c->have_ccs || !c->A_loaded) return LF_ERR_STATE;
-    const lf_params &P = c->P;
-    if (w_next->N != c->N) return LF_ERR_INVALID;
-    lf_ctx::Prefetch &pf = c->pf;
-    if (pf.req) pf.dropped++;                      // (a second request before any step ran replaces the first)
-    pf.req = true;
-    pf.part = 0;
-    pf.req_wit = w_next;
-    pf.req_id = w_next->id;
-    pf.req_x.assign((size_t)(P.l + 1) * 24, 0);
-    memcpy(pf.req_x.data(), cm_next + (size_t)P.kappa * 24, (size_t)P.l * 24 * 8);
-    HostRing::from_u64(1, pf.req_x.data() + (size_t)P.l * 24);
-    return LF_OK;
-}
-int lf_prefetch_stats(lf_ctx *c, unsigned *issued, unsigned *consumed, unsigned *dropped) {
-    if (!c) return LF_ERR_INVALID;
-    if (c->bb) { if (issued) *issued = 0; if (consumed) *consumed = 0; if (dropped) *dropped = 0; return LF_OK; }
-    std::lock_guard<std::mutex> g(c->mu);
-    if (issued) *issued = c->pf.issued;
-    if (consumed) *consumed = c->pf.consumed;
-    if (dropped) *dropped = c->pf.dropped;
-    return LF_OK;
-}
 int lf_debug_i8_prof(uint64_t *out64) {   // (LF_I8G_PROF set: the table of the general-commit kernel instead)
     if (!out64) return LF_ERR_INVALID;
     return getenv("LF_I8G_PROF") ? ajtai_i8g_read_prof((unsigned long long *)out64) : ajtai_i8_read_prof((unsigned long long *)out64);

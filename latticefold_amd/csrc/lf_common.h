@@ -103,16 +103,9 @@ struct Tunables {
     size_t shard_lin_min = 16384;    // LF_SHARD_LIN_MIN: a sharded linearization sumcheck hands over to the replicated rounds once its tables have this many entries or fewer
                                      // (a round there is a ~30 us launch: an exchange costs as much as it saves); never above m / 16
     size_t shard_fold_min = 2048;    // LF_SHARD_FOLD_MIN: the same for the folding sumcheck (96 tables per entry: rounds stay worth sharding down to the persistent tail's size)
-    bool ajtai_valu = false;         // LF_AJTAI_VALU: digit-plane commits on the 64-bit VALU kernel (k_ajtai) instead of the int8 matrix-core kernel
     bool coef_valu = false;          // LF_COEF_VALU: v / v_s / theta evaluations of the digit planes on the VALU kernel (k_coef_eval) instead of the matrix cores
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
-    bool no_early_y = false;         // LF_NO_EARLY_Y: the right commit's download behind everything else on the helper lane's stream (round-3 order)
     bool evals_one_stage = true;     // LF_EVALS_TWO_STAGES=1: the right evaluations of a fold step in two downloads (the absorb of the first half overlaps the second half's inner products)
-    int zr_pos = 2;                  // LF_ZR_POS: where the helper lane builds the RIGHT side's z_k: 0 behind the right commit, 1 first thing, 2 behind the left evaluations, 3 between the commits
-    bool commits_first = false;      // LF_COMMITS_FIRST: round-2 order of the helper lane (left commit, left evaluations, right commit) instead of evaluations first
-    bool i8_pair = false;            // LF_I8_PAIR: both decompositions' digit-plane commits in ONE launch (paired workgroups share the tiles of A in L2: A leaves
-                                     // HBM once per step) instead of one launch per decomposition.  Opt-in: the same kernel time per step (4.2 vs 2 x 2.13 ms at C4), but
-                                     // one 4 ms launch on 7/8 of the CUs slows the latency-bound linearization lane next to it (step 22.4 vs 21.8 ms)
     bool fold_r5_one_lane = false;   // LF_FOLD_R5_ONE_LANE: (BabyBear) round 5 from the planes with one thread per pair (k_fold_round mode 7, split form) instead of two lanes per pair
     bool bb_lin_tail = false;        // LF_BB_LIN_TAIL: (BabyBear) persistent kernel for the small linearization rounds (k_lin_tail)
     bool bb_evals_first = false;     // LF_BB_EVALS_FIRST: (BabyBear) lane 1 runs the left evaluations before the left commit
@@ -134,12 +127,6 @@ struct Tunables {
     size_t r5_min = 8192;            // LF_FOLD_R5_MIN: pairs of round 5 from which it runs on the planes (mode 7; measured: 2^16 rows slower, 2^20 faster)
     size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
     long lin_blocks = -1;            // -1: automatic
-    bool lazy_from_f = false;        // LF_LAZY_FROM_F: a fold step leaves the folded witness as coefficient planes only; f (NTT form) and w_ccs are built by lf_witness_get_f / _get_w_ccs
-    int pf_at = 0;                   // LF_PF_AT: the first point at or after which a fold step enqueues the prefetch of the next right side (lf_prefetch_instance): 0 when its
-                                     // linearization is done (the host's absorb chain starts, the GPU has only the right evaluations left), 1 after the right evaluations,
-                                     // 2 when the two lanes have joined, 3 after the folding challenges, 10 + r after round r of the folding sumcheck, 40 after the sumcheck,
-                                     // 50 with the folded witness
-    int pf_at2 = 0;                  // LF_PF_AT2: same scale, for the second part of the prefetch (the K - 1 digit-plane commits); the first part is the bit planes and z_k
     static Tunables read(size_t lut_min_default) {
         Tunables t;
         t.lut_min = lut_min_default;
@@ -175,15 +162,9 @@ struct Tunables {
         t.fold_no_small = getenv("LF_FOLD_NO_SMALL") != nullptr;
         if ((e = getenv("LF_FOLD_SV_MIN"))) t.sv_min = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_SV_ROUNDS"))) t.sv_rounds = atoi(e);
-        t.ajtai_valu = getenv("LF_AJTAI_VALU") != nullptr;
         t.coef_valu = getenv("LF_COEF_VALU") != nullptr;
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
-        t.i8_pair = getenv("LF_I8_PAIR") != nullptr;
-        t.lazy_from_f = getenv("LF_LAZY_FROM_F") != nullptr;
-        t.commits_first = getenv("LF_COMMITS_FIRST") != nullptr;
-        if (const char *e = getenv("LF_ZR_POS")) t.zr_pos = atoi(e);
         t.evals_one_stage = getenv("LF_EVALS_TWO_STAGES") == nullptr;
-        t.no_early_y = getenv("LF_NO_EARLY_Y") != nullptr;
         if ((e = getenv("LF_SHARD_TWO_LANES"))) t.shard_two_lanes = atoi(e) != 0;
         if ((e = getenv("LF_SHARD_LIN_MIN"))) t.shard_lin_min = (size_t)atoll(e);
         if ((e = getenv("LF_SHARD_FOLD_MIN"))) t.shard_fold_min = (size_t)atoll(e);
@@ -196,9 +177,6 @@ struct Tunables {
         if ((e = getenv("LF_LIN_BLOCKS"))) t.lin_blocks = atol(e);
         if ((e = getenv("LF_TAIL_N"))) t.tail_n = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_R5_MIN"))) t.r5_min = (size_t)atoll(e);
-        if ((e = getenv("LF_PF_AT"))) t.pf_at = t.pf_at2 = atoi(e);
-        if ((e = getenv("LF_PF_AT2"))) t.pf_at2 = atoi(e);
-        if (t.pf_at2 < t.pf_at) t.pf_at2 = t.pf_at;
         return t;
     }
 };

@@ -56,7 +56,6 @@ void launch_recompose(const u64 *in, size_t n_out, u64 base, u32 digits, u64 *ou
 void launch_coef_to_i32(const u64 *coef, int32_t *planes, size_t n, u32 bound, int *viol, hipStream_t s);
 void launch_i32_to_coef(const int32_t *planes, u64 *coef, size_t n, hipStream_t s);
 // NTT of bit-plane k (k0 <= k < k1) of every element: out[(k-k0)][24][n]
-void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s);
 // z-vector tails: out_k[off + i] = CRT( sum_l B^l * digit_k(planes[i*L + l]) ) for k < K (mode_bits = 1), or the
 // full value (mode_bits = 0, K = 1).  out_k = out + k*24*ldz.
 void launch_recompose_crt(const DevCrt &t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, u64 B, u32 K,
@@ -66,11 +65,7 @@ void launch_linf(const u64 *coef, size_t n, u64 *out_max, hipStream_t s);
 
 // ---- Ajtai commit (a5) -----------------------------------------------------------------------------------------
 // partial[split][slot][i][k][3]; then reduce -> out AoS-ish [k][i][24] (device), canonical
-size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits);
 // row-chunked commits (kappa > 48): tmp [batch][kc][24] -> out [batch][kappa][24] at row i0
-void launch_scatter_rows(const u64 *tmp, u32 batch, u32 kc, u32 kappa, u32 i0, u64 *out, hipStream_t s);
-void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits,
-                  u64 *partial, u64 *out, hipStream_t s);
 
 // ---- MLE / eq (a8, a9, a11) --------------------------------------------------------------------------------------
 void launch_build_eq(const DevCrt &t, const Fq3Const *r_dev /*nv*/, u32 nv, u64 *eq /*[3][1<<nv]*/, hipStream_t s);

@@ -393,38 +393,6 @@ __device__ __forceinline__ int digit2(int32_t v, u32 k) {
     return v < 0 ? -d : d;
 }
 
-// thread = (element j, residue class u of the coefficient index): a(X) = sum_u X^u A_u(X^3) is transformed class by class
-// (crt_store_ternary), so a thread needs the 8 plane entries c = 3 v + u only and writes 8 words per bit-plane
-__global__ void __launch_bounds__(256) k_bitplane_crt(DevCrt t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out) {
-    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const u32 u = blockIdx.y;
-    if (j >= n) return;
-    int32_t v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = planes[(size_t)(3 * q + u) * ld + j];
-    int plane[8];
-    u64 tw[8];
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-        int s3 = 3 * t.slot_of_pos[p];
-        plane[p] = u == 0 ? s3 : (u == 1 ? s3 + t.pos1[p] : s3 + t.pos2[p]);
-        tw[p] = u == 1 ? t.tw1[p] : t.tw2[p];
-    }
-    for (u32 k = k0; k < k1; k++) {
-        int x[8];
-        u64 A[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = digit2(v[q], k);
-        crt8_ternary(x, A, t);
-        u64 *o = out + (size_t)(k - k0) * 24 * n;
-#pragma unroll
-        for (int p = 0; p < 8; p++) o[(size_t)plane[p] * n + j] = u == 0 ? A[p] : fq_mul(tw[p], A[p]);
-    }
-}
-void launch_bitplane_crt(const DevCrt &t, const int32_t *planes, size_t ld, size_t n, u32 k0, u32 k1, u64 *out, hipStream_t s) {
-    if (n && k1 > k0) hipLaunchKernelGGL(k_bitplane_crt, dim3(cdiv(n, 256), 3), dim3(256), 0, s, t, planes, ld, n, k0, k1, out);
-}
-
 struct BPow { u64 v[8]; };
 __global__ void __launch_bounds__(256) k_recompose_crt(DevCrt t, const int32_t *planes, size_t n_planes, u32 wit_len, u32 L, BPow bp,
                                                         u32 K, int mode_bits, u64 *out, size_t ldz, size_t off) {
@@ -517,12 +485,8 @@ __device__ __forceinline__ void st3(u64 *tab, size_t ld, u32 slot, size_t i, Fq3
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Ajtai commit (commitment_scheme.rs:37-54 -> Matrix::checked_mul_vec): C[k][i] = sum_j A[i][j] (.) F_k[j].
-// Per slot this is a skinny GEMM (kappa x n) * (n x batch) over F_{p^3}.  Block = one slot x one j-split;
-// (A,F) tiles of JT columns are staged in LDS with coalesced loads; each thread owns up to two (i,k) outputs
-// and keeps the five schoolbook column sums of the F_{p^3} product as un-reduced 160-bit accumulators for the
-// whole j-range (one reduction per output at the very end).
-constexpr u32 RED_BLOCKS_AJ = 128;   // kappa + batch <= 64 per launch
+// Lazy F_{p^3} inner products: the five schoolbook column sums of a product as un-reduced 160-bit accumulators over a whole range, one reduction per output.
+// (The Ajtai commitments themselves run on the int8 matrix cores: lf_ajtai_i8.hip, lf_ajtai_i8g.hip.)
 struct Acc5 { AccP s[5]; };  // the five schoolbook column sums of an F_{p^3} product, un-reduced
 __device__ __forceinline__ void acc5_zero(Acc5 &a) {
 #pragma unroll
@@ -542,188 +506,6 @@ __device__ __forceinline__ Fq3 acc5_finish(const Acc5 &a, u64 nu) {
     r.c[1] = fq_add(accp_reduce(a.s[1]), fq_mul_nu<NU>(accp_reduce(a.s[4]), nu));
     r.c[2] = accp_reduce(a.s[2]);
     return r;
-}
-constexpr int AJ_THREADS = 512;  // 8 waves per block, two blocks per CU (LDS): four wave-slots per SIMD
-// Toom-3 at the F_{p^3} level with lazy accumulation.  For a = a0 + a1 Y + a2 Y^2 (same for b) the product
-// r(Y) = a(Y) b(Y) (degree 4) is determined by the five pointwise products at Y = 0, 1, -1, 2, inf.  Those five products are
-// summed over the whole j-range un-reduced (AccP), so one multiply-accumulate costs 20 v_mad_u64_u32 (schoolbook 36,
-// Karatsuba 24); the evaluations a(1), a(-1), a(2) are formed once per staged element while the tile is written to LDS, and
-// the interpolation (with its divisions by 2 and 3) plus the reduction Y^3 = nu happen once per output at the very end.
-struct Acc6 { AccP s[5]; };
-// LDS tile: one 48-byte record {a(0), a(1), a(-1), a(2), a(inf), pad} per (row, column): two ds_read_b128 + one ds_read_b64.
-// Row stride = AJ_T*48 + 16 bytes: rows of one 16-lane read group fall into distinct 16-byte slots (conflict-free).
-constexpr int AJ_T = 32;                          // columns per tile
-constexpr int AJ_ROWB = AJ_T * 48 + 16;           // bytes per row
-// SIMD balance.  A CU places the waves of a workgroup round-robin on its four SIMDs (tools/wave_place.hip): two co-resident
-// 7-wave blocks (26 x 15 = 390 outputs, one thread each) always leave two SIMDs with four full-cost waves and two with
-// three, i.e. 12.2 useful wave-loads on 16 wave-slots.  Layout used instead when 384 <= nout <= 448: 8 waves per block;
-// waves 0-3 carry 256 outputs, one thread each (`nfull`); waves 4-7 carry the next 128 outputs (`rem`) on TQ = 2 lanes each,
-// lane q taking columns q, q+2, .. of the tile -- half the multiply phase.  Every SIMD then holds 2 x (1 + 1/2) = 3
-// wave-loads.  The TQ partial sums of such an output are separate rows of `tailp` and are added by k_ajtai_reduce (the
-// interpolation is linear); outputs beyond nfull + rem (6 of 390) go to the dot-product kernel k_ajtai_tail.
-// TQ = 1 / rem = 0 is the plain one-thread-per-output map used for every other shape.
-template <bool NU, int NT>
-__global__ void __launch_bounds__(NT, 4) k_ajtai(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits,
-                                                         u32 nfull, u32 rem, u32 TQ, u64 *partial, u64 *tailp) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const u32 slot = blockIdx.y, split = blockIdx.x;
-    const u32 rows = kappa + batch;
-    const u32 nout = kappa * batch;
-    size_t per = (n + splits - 1) / splits;
-    per = (per + AJ_T - 1) / AJ_T * AJ_T;
-    size_t j0 = (size_t)split * per, j1 = j0 + per < n ? j0 + per : n;
-    Acc6 acc;
-#pragma unroll
-    for (int i = 0; i < 5; i++) accp_zero(acc.s[i]);
-    const bool is_tail = threadIdx.x >= nfull;                 // wave-uniform (nfull is a multiple of 64)
-    const u32 tl = threadIdx.x - nfull, tq = is_tail ? tl % TQ : 0;
-    const u32 o0 = is_tail ? nfull + tl / TQ : threadIdx.x;
-    const u32 i0 = o0 / batch, k0 = o0 % batch;
-    const bool active = is_tail ? tl < rem * TQ : true;
-    const unsigned char *pa = smem + (size_t)(active ? i0 : 0) * AJ_ROWB;
-    const unsigned char *pf = smem + (size_t)(active ? kappa + k0 : kappa) * AJ_ROWB;
-    const u32 nthr = blockDim.x;
-    for (size_t jt = j0; jt < j1; jt += AJ_T) {
-        __syncthreads();
-        for (u32 idx = threadIdx.x; idx < rows * AJ_T; idx += nthr) {
-            u32 jj = idx % AJ_T, r = idx / AJ_T;
-            size_t j = jt + jj;
-            u64 v0 = 0, v1 = 0, v2 = 0;
-            if (j < j1) {
-                const bool isA = r < kappa;
-                const size_t ldr = isA ? n : ldF;
-                const u64 *src = isA ? A + ((size_t)r * 24 + 3 * slot) * n : F + ((size_t)(r - kappa) * 24 + 3 * slot) * ldF;
-                v0 = src[j]; v1 = src[ldr + j]; v2 = src[2 * ldr + j];
-            }
-            u64 e02 = fq_add(v0, v2);                                   // a0 + a2
-            u64 d1 = fq_add(v1, v1), q2 = fq_add(v2, v2);
-            u64 at2 = fq_add(fq_add(v0, d1), fq_add(q2, q2));           // a(2) = a0 + 2 a1 + 4 a2
-            ulonglong2 *dstp = (ulonglong2 *)(smem + (size_t)r * AJ_ROWB + jj * 48);
-            dstp[0] = make_ulonglong2(v0, fq_add(e02, v1));             // a(0), a(1)
-            dstp[1] = make_ulonglong2(fq_sub(e02, v1), at2);            // a(-1), a(2)
-            *(u64 *)(dstp + 2) = v2;                                    // a(inf)
-        }
-        __syncthreads();
-        if (!is_tail) {
-#pragma unroll 4
-            for (int jj = 0; jj < AJ_T; jj++) {
-                const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
-                ulonglong2 x0 = xa[0], x1 = xa[1], y0 = yf[0], y1 = yf[1];
-                u64 x2 = *(const u64 *)(xa + 2), y2 = *(const u64 *)(yf + 2);
-                accp_mad(acc.s[0], x0.x, y0.x); accp_mad(acc.s[1], x0.y, y0.y);
-                accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
-                accp_mad(acc.s[4], x2, y2);
-            }
-        } else if (active && TQ == 2) {
-#pragma unroll 4
-            for (int jj = (int)tq; jj < AJ_T; jj += 2) {
-                const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
-                ulonglong2 x0 = xa[0], x1 = xa[1], y0 = yf[0], y1 = yf[1];
-                u64 x2 = *(const u64 *)(xa + 2), y2 = *(const u64 *)(yf + 2);
-                accp_mad(acc.s[0], x0.x, y0.x); accp_mad(acc.s[1], x0.y, y0.y);
-                accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
-                accp_mad(acc.s[4], x2, y2);
-            }
-        } else if (active) {
-            for (u32 jj = tq; jj < (u32)AJ_T; jj += TQ) {
-                const ulonglong2 *xa = (const ulonglong2 *)(pa + jj * 48), *yf = (const ulonglong2 *)(pf + jj * 48);
-                ulonglong2 x0 = xa[0], x1 = xa[1], y0 = yf[0], y1 = yf[1];
-                u64 x2 = *(const u64 *)(xa + 2), y2 = *(const u64 *)(yf + 2);
-                accp_mad(acc.s[0], x0.x, y0.x); accp_mad(acc.s[1], x0.y, y0.y);
-                accp_mad(acc.s[2], x1.x, y1.x); accp_mad(acc.s[3], x1.y, y1.y);
-                accp_mad(acc.s[4], x2, y2);
-            }
-        }
-    }
-    // full waves: partial[split][slot][o][3];  ragged wave: tailp[split*TQ + q][slot][o - nfull][3]
-    u64 *dst = is_tail ? tailp + (((size_t)split * TQ + tq) * 8 + slot) * rem * 3 - (size_t)nfull * 3 : partial + ((size_t)split * 8 + slot) * nout * 3;
-    if (active) {
-        const u64 INV2 = 0x7FFFFFFF80000001ULL;   // (p+1)/2
-        const u64 INV3 = 0xAAAAAAAA00000001ULL;   // (2p+1)/3
-        u64 p0 = accp_reduce(acc.s[0]), p1 = accp_reduce(acc.s[1]), pm1 = accp_reduce(acc.s[2]);
-        u64 p2 = accp_reduce(acc.s[3]), pinf = accp_reduce(acc.s[4]);
-        u64 r0 = p0, r4 = pinf;
-        u64 r2 = fq_sub(fq_sub(fq_mul(fq_add(p1, pm1), INV2), r0), r4);
-        u64 t2 = fq_mul(fq_sub(p1, pm1), INV2);                                            // r1 + r3
-        u64 r2x4 = fq_add(fq_add(r2, r2), fq_add(r2, r2));
-        u64 r4x16 = fq_mul(r4, 16);
-        u64 t3 = fq_mul(fq_sub(fq_sub(fq_sub(p2, r0), r2x4), r4x16), INV2);                // r1 + 4 r3
-        u64 r3 = fq_mul(fq_sub(t3, t2), INV3);
-        u64 r1 = fq_sub(t2, r3);
-        u64 c0 = fq_add(r0, fq_mul_nu<NU>(r3, t.nu));
-        u64 c1 = fq_add(r1, fq_mul_nu<NU>(r4, t.nu));
-        u64 c2 = r2;
-        dst[(size_t)o0 * 3] = c0; dst[(size_t)o0 * 3 + 1] = c1; dst[(size_t)o0 * 3 + 2] = c2;
-    }
-}
-// out[k][i][3*slot+c] = sum_split partial   (outputs o < nmain; those >= nfull have splits * TQ rows in tailp)
-__global__ void __launch_bounds__(256) k_ajtai_reduce(const u64 *partial, const u64 *tailp, u32 kappa, u32 batch, u32 splits, u32 nmain, u32 nfull,
-                                                      u32 TQ, u64 *out) {
-    u32 idx = blockIdx.x * 256 + threadIdx.x;
-    u32 nout = kappa * batch;
-    if (idx >= 8 * nmain * 3) return;
-    u32 c = idx % 3, o = (idx / 3) % nmain, slot = idx / (3 * nmain);
-    u64 acc = 0;
-    if (o < nfull) {
-        for (u32 sp = 0; sp < splits; sp++) acc = fq_add(acc, partial[(((size_t)sp * 8 + slot) * nout + o) * 3 + c]);
-    } else {
-        u32 rem = nmain - nfull;
-        for (u32 sp = 0; sp < splits * TQ; sp++) acc = fq_add(acc, tailp[(((size_t)sp * 8 + slot) * rem + (o - nfull)) * 3 + c]);
-    }
-    u32 i = o / batch, k = o % batch;
-    out[((size_t)k * kappa + i) * 24 + 3 * slot + c] = acc;
-}
-// the nout - nmain outputs that do not fill a wave: plain lazy dot products over j, one (output, slot) per block column
-template <bool NU>
-__global__ void __launch_bounds__(256) k_ajtai_tail(DevCrt t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 o_start, u64 *partial) {
-    // grid (8 slots, tail outputs, column blocks): the linear workgroup id is slot + 8 * (tail + ntail * block), so the tail outputs of one
-    // (slot, column block) -- which usually share their row of A -- run back to back on the same XCD and find that row in its L2
-    u32 slot = blockIdx.x, o = o_start + blockIdx.y;
-    u32 i = o / batch, k = o % batch;
-    const u64 *Ai = A + (size_t)i * 24 * n, *Fk = F + (size_t)k * 24 * ldF;
-    Acc5 acc;
-    acc5_zero(acc);
-    for (size_t j = (size_t)blockIdx.z * 256 + threadIdx.x; j < n; j += (size_t)gridDim.z * 256) {
-        Fq3 x = ld3(Ai, n, slot, j), y = ld3(Fk, ldF, slot, j);
-        acc5_mac(acc, x.c, y.c);
-    }
-    Fq3 r = acc5_finish<NU>(acc, t.nu);
-    u64 v[3] = {r.c[0], r.c[1], r.c[2]};
-    // partial[block][ tail_index*24 + 3*slot + c ]
-    block_sum_store<3>(v, partial + (size_t)blockIdx.z * (gridDim.y * 24) + (size_t)blockIdx.y * 24 + 3 * slot);
-}
-__global__ void __launch_bounds__(256) k_ajtai_tail_reduce(const u64 *partial, u32 nblocks, u32 ntail, u32 o_start, u32 kappa, u32 batch, u64 *out) {
-    u32 idx = blockIdx.x;  // one block per (tail output, word)
-    u32 tix = idx / 24, w = idx % 24;
-    u64 acc[1] = {0};
-    for (u32 b = threadIdx.x; b < nblocks; b += 256) acc[0] = fq_add(acc[0], partial[(size_t)b * (ntail * 24) + idx]);
-    u32 o = o_start + tix, i = o / batch, k = o % batch;
-    block_sum_store<1>(acc, out + ((size_t)k * kappa + i) * 24 + w);
-}
-size_t ajtai_partial_words(u32 kappa, u32 batch, u32 splits) {
-    size_t a = (size_t)splits * 8 * kappa * batch * 3, b = (size_t)RED_BLOCKS_AJ * 64 * 24, tl = (size_t)splits * 512 * 8 * 3;
-    return a + b + tl;
-}
-void launch_ajtai(const DevCrt &t, const u64 *A, u32 kappa, size_t n, const u64 *F, size_t ldF, u32 batch, u32 splits, u64 *partial, u64 *out,
-                  hipStream_t s) {
-    u32 nout = kappa * batch;
-    // one (i,k) output per thread; callers keep kappa*batch <= 448 (commit_dev), any excess goes to the dot-product tail
-    u32 nmain = nout < 448u ? nout : 448u;
-    size_t shm = (size_t)(kappa + batch) * AJ_ROWB;
-    u32 nfull = nmain, rem = 0, TQ = 1, nthr = (nmain + 63) / 64 * 64;
-    if (nout >= 384 && nout <= 448) { nfull = 256; rem = 128; TQ = 2; nthr = 512; nmain = 384; }   // SIMD-balanced layout (see k_ajtai)
-    u64 *tailp = partial + (size_t)splits * 8 * kappa * batch * 3 + (size_t)RED_BLOCKS_AJ * 64 * 24;
-    if (t.nu2p40) hipLaunchKernelGGL((k_ajtai<true, AJ_THREADS>), dim3(splits, 8), dim3(nthr), shm, s, t, A, kappa, n, F, ldF, batch, splits, nfull, rem, TQ, partial, tailp);
-    else hipLaunchKernelGGL((k_ajtai<false, AJ_THREADS>), dim3(splits, 8), dim3(nthr), shm, s, t, A, kappa, n, F, ldF, batch, splits, nfull, rem, TQ, partial, tailp);
-    hipLaunchKernelGGL(k_ajtai_reduce, dim3(cdiv((size_t)8 * nmain * 3, 256)), dim3(256), 0, s, partial, tailp, kappa, batch, splits, nmain, nfull, TQ, out);
-    if (nmain < nout) {
-        u32 ntail = nout - nmain;
-        u64 *tp = partial + (size_t)splits * 8 * kappa * batch * 3;
-        u32 gb = (u32)((n + 255) / 256);
-        if (gb > RED_BLOCKS_AJ) gb = RED_BLOCKS_AJ;
-        LF_LAUNCH(k_ajtai_tail, t.nu2p40, dim3(8, ntail, gb), dim3(256), s, t, A, kappa, n, F, ldF, batch, nmain, tp);
-        hipLaunchKernelGGL(k_ajtai_tail_reduce, dim3(ntail * 24), dim3(256), 0, s, tp, gb, ntail, nmain, kappa, batch, out);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -3030,16 +2812,6 @@ __global__ void __launch_bounds__(256) k_fold_witness(const int32_t *planesL, co
 void launch_fold_witness(const int32_t *planesL, const int32_t *planesR, size_t n, u32 K, const int8_t *rho_dev, int32_t *out, hipStream_t s) {
     if (K <= 16) hipLaunchKernelGGL(k_fold_witness<4>, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho_dev, out);
     else hipLaunchKernelGGL(k_fold_witness<8>, dim3(cdiv(n, 256)), dim3(256), 0, s, planesL, planesR, n, K, rho_dev, out);
-}
-// commitments of a row chunk [i0, i0 + kc) of A computed into tmp [batch][kc][24] -> their place in out [batch][kappa][24]
-__global__ void __launch_bounds__(256) k_scatter_rows(const u64 *tmp, u32 batch, u32 kc, u32 kappa, u32 i0, u64 *out) {
-    u32 i = blockIdx.x * 256 + threadIdx.x, tot = batch * kc * 24;
-    if (i >= tot) return;
-    u32 w = i % 24, r = (i / 24) % kc, b = i / (24 * kc);
-    out[((size_t)b * kappa + i0 + r) * 24 + w] = tmp[i];
-}
-void launch_scatter_rows(const u64 *tmp, u32 batch, u32 kc, u32 kappa, u32 i0, u64 *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_scatter_rows, dim3(cdiv((size_t)batch * kc * 24, 256)), dim3(256), 0, s, tmp, batch, kc, kappa, i0, out);
 }
 
 }  // namespace lf

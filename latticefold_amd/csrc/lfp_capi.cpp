@@ -42,9 +42,6 @@ extern "C" void lfplus_ctx_destroy(lfplus_ctx *c) {
     (void)hipStreamSynchronize(c->st);
     if (c->st2) { (void)hipStreamSynchronize(c->st2); (void)hipStreamDestroy(c->st2); }
     if (c->ev_ff) (void)hipEventDestroy(c->ev_ff);
-    if (c->ev_cmt) (void)hipEventDestroy(c->ev_cmt);
-    if (c->cmpre.R) (void)hipDeviceSynchronize();      // (other instances' second streams may still be writing into this context's table buffers; they may be gone already)
-    c->own_free(c->cmpre.S); c->own_free(c->cmpre.R); c->own_free(c->cm_tauring);
     c->A = nullptr;
     c->A_ref.reset();      // frees the matrix unless another context still shares it
     c->drop_mats();
@@ -138,7 +135,7 @@ extern "C" int lfplus_set_matrix(lfplus_ctx *c, const uint64_t *A, uint32_t kapp
     if (!canonical(A, (size_t)kappa * n * 16)) return fail(c, LFPLUS_E_ARG, "lfplus_set_matrix: non-canonical word");
     HIPCHK(c, hipSetDevice(c->device));
     ff_join(c);
-    c->have = false; c->cmt_valid = false;
+    c->have = false;
     u64 *fresh = nullptr;   // a new allocation: contexts sharing the previous matrix keep it alive through their own reference
     int rc = upload(c, &fresh, A, (size_t)kappa * n * 16);
     if (rc) return rc;
@@ -154,7 +151,7 @@ extern "C" int lfplus_share_matrix(lfplus_ctx *c, lfplus_ctx *from) {
     if (!c || !from || c == from || !from->A || c->device != from->device) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrix: bad arguments");
     if (c->f && from->sharded()) return fail(c, LFPLUS_E_ARG, "lfplus_share_matrix: share a sharded matrix before the witness is set");
     HIPCHK(c, hipSetDevice(c->device));
-    c->have = false; c->cmt_valid = false;
+    c->have = false;
     c->A = from->A;
     c->A_ref = from->A_ref;
     c->sh = from->sh;          // the column slice of A fixes the shard geometry: sharers exchange over the same transport
@@ -167,7 +164,7 @@ extern "C" int lfplus_set_witness(lfplus_ctx *c, const uint64_t *f, uint64_t n) 
     if (!c || !f || !n) return fail(c, LFPLUS_E_ARG, "lfplus_set_witness: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     ff_join(c);     // (an asynchronous from_f may still read the witness that is being replaced)
-    c->have = false; c->cmt_valid = false;
+    c->have = false;
     if (!(c->f && c->nf == n)) {   // (same length as the resident witness: overwrite it, no hipFree / hipMalloc round trip per instance)
         c->own_free(c->f);
         c->f = nullptr; c->nf = 0;
@@ -349,7 +346,7 @@ extern "C" int lfplus_rg_from_f_async(lfplus_ctx *c, uint64_t b, uint32_t k, uin
     if (c->sharded() || !c->st2 || !c->ev_ff || getenv("LFPLUS_NO_ASYNC_FROM_F")) return LFPLUS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     ff_join(c);
-    c->have = false; c->cmt_valid = false;
+    c->have = false;
     Plan p = plan_for(c->nloc, c->kappa, k);
     if ((rc = prepare(c, k, p))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_ff, c->st));            // behind whatever made the witness resident
@@ -373,7 +370,7 @@ extern "C" int lfplus_rg_from_f(lfplus_ctx *c, uint64_t b, uint32_t k, uint32_t 
         return LFPLUS_OK;
     }
     ff_join(c);
-    c->have = false; c->cmt_valid = false;
+    c->have = false;
     Plan p = plan_for(c->nloc, c->kappa, k);
     if ((rc = prepare(c, k, p))) return rc;
     if ((rc = enqueue_from_f(c, b, k, l, p))) return rc;
@@ -584,7 +581,7 @@ static int decompose_impl(lfplus_ctx *c, uint64_t B, const uint64_t *r_a, const 
             d->nf = 0;
             HIPCHK2(d->own_alloc(&d->f, vw * 8));
         }
-        d->have = false; d->cmt_valid = false;
+        d->have = false;
         d->nf = 0;                        // no resident witness until the copy has COMPLETED: a failure below must not leave a length-n witness of undefined content
         HIPCHK2(hipMemcpyAsync(d->f, s2 ? dF1 : dF0, vw * 8, hipMemcpyDeviceToDevice, c->st));
         publish[s2] = d;

@@ -184,18 +184,6 @@ struct lfplus_ctx {
     // linearization's latency-bound rounds run on `st`); lfplus_rg_from_f with the same parameters collects it, anything else that touches the buffers joins it first
     hipStream_t st2 = nullptr;
     hipEvent_t ev_ff = nullptr;
-    // lfplus_cm_tables_async: the challenge-free three quarters of Cm::prove's instance tables (m_tau, f, tau and their products with the M_q), written behind the
-    // from_f on the instance's second stream into buffers that ctxs[0] owns until the next lfplus_cm_prove consumes them
-    hipEvent_t ev_cmt = nullptr;
-    bool cmt_valid = false;          // this context's slot of the tables was built from its CURRENT witness and from_f results (cleared wherever `have` is)
-    u64 *cm_tauring = nullptr;       // this instance's tau as ring elements (input of M_q tau)
-    size_t cm_tauring_n = 0;
-    struct CmPre {                   // (meaningful in ctxs[0])
-        u64 *S = nullptr, *R = nullptr;      // S: (1 + L) n scalars (eq | tau_l, Montgomery); R: (L (3 + 4 nM) + 2) n ring elements
-        size_t n = 0;
-        u32 L = 0, nM = 0;
-        std::vector<lfplus_ctx *> by;        // by[l] = the context whose tables sit in slot l (nullptr: not built)
-    } cmpre;
     bool ff_pending = false;
     u64 ff_b = 0;
     u32 ff_k = 0, ff_l = 0;

@@ -974,59 +974,6 @@ void cm_x(const CmChallenges &ch, u32 L, u32 kappa, u32 nM, const u64 *const *fc
 }
 }  // namespace
 
-// The challenge-free part of Cm::prove's instance tables for instance `l` of L (cm.rs:201-260 builds them inside prove; nothing in them depends on the transcript):
-// tau_l (Montgomery scalars), m_tau, f and M_q tau, M_q m_tau, M_q f for the nM RESIDENT matrices -- enqueued on ctxs[l]'s second stream behind its from_f
-// (lfplus_rg_from_f_async, or a finished lfplus_rg_from_f), so that they are built while the linearizations' latency-bound rounds leave the GPU idle.  The buffers
-// belong to ctxs[0] and are consumed by the next lfplus_cm_prove over the same contexts, L and nM with resident matrices; anything that replaces the witness or the
-// from_f results of ctxs[l] first waits for the stream (ff_join) and the slot is rebuilt by lfplus_cm_prove itself.  Unsharded contexts only (else a no-op).
-extern "C" int lfplus_cm_tables_async(lfplus_ctx *const *ctxs, uint32_t L, uint32_t l, uint32_t nM) {
-    if (!ctxs || !L || l >= L || !ctxs[0] || !ctxs[l]) return LFPLUS_E_ARG;
-    lfplus_ctx *c0 = ctxs[0], *cl = ctxs[l];
-    if (c0->sharded() || cl->sharded() || !cl->st2 || getenv("LFPLUS_NO_ASYNC_CM_TABLES")) return LFPLUS_OK;
-    if (!(cl->ff_pending || cl->have) || !cl->f || cl->n != c0->n || cl->device != c0->device) return fail(c0, LFPLUS_E_ARG, "lfplus_cm_tables_async: instance without from_f results");
-    if (nM && (cl->mats.size() != nM || cl->mats_n != cl->n)) return fail(c0, LFPLUS_E_ARG, "lfplus_cm_tables_async: needs the resident matrices (lfplus_set_matrices / share_matrices)");
-    HIPCHK(c0, hipSetDevice(c0->device));
-    const size_t n = c0->n;
-    const u32 per = 4 + 4 * nM, nS = 1 + L, nR = L * (per - 1) + 2;
-    lfplus_ctx::CmPre &P = c0->cmpre;
-    if (P.n != n || P.L != L || P.nM != nM || !P.S || !P.R) {        // another shape: every slot is void
-        (void)hipDeviceSynchronize();      // (slots of the old shape may still be written by their instances' second streams)
-        c0->own_free(P.S); c0->own_free(P.R);
-        P.S = P.R = nullptr; P.n = 0; P.by.clear();
-        HIPCHK(c0, c0->own_alloc(&P.S, (size_t)nS * n * 8));
-        HIPCHK(c0, c0->own_alloc(&P.R, (size_t)nR * n * D * 8));
-        P.n = n; P.L = L; P.nM = nM; P.by.assign(L, nullptr);
-    }
-    if (nM && cl->cm_tauring_n != n) {
-        cl->own_free(cl->cm_tauring);
-        cl->cm_tauring = nullptr; cl->cm_tauring_n = 0;
-        HIPCHK(c0, cl->own_alloc(&cl->cm_tauring, n * D * 8));
-        cl->cm_tauring_n = n;
-    }
-    if (!cl->ev_cmt) HIPCHK(c0, hipEventCreateWithFlags(&cl->ev_cmt, hipEventDisableTiming));
-    hipStream_t s2 = cl->st2;
-    if (!cl->ff_pending) {                      // from_f ran on the first stream: order the second one behind it
-        HIPCHK(c0, hipEventRecord(cl->ev_ff, cl->st));
-        HIPCHK(c0, hipStreamWaitEvent(s2, cl->ev_ff, 0));
-    }
-    u64 *base = P.R + (size_t)l * (per - 1) * n * D;
-    lfp::launch_to_mont(cl->tau, n, P.S + (size_t)(1 + l) * n, s2);
-    lfp::launch_cm_materialize(cl->mtau, nullptr, n, base, s2);
-    HIPCHK(c0, hipMemcpyAsync(base + n * D, cl->f, n * D * 8, hipMemcpyDeviceToDevice, s2));
-    if (nM) {
-        lfp::launch_cm_materialize(nullptr, cl->tau, n, cl->cm_tauring, s2);
-        const u64 *xin[3] = {cl->cm_tauring, base, base + n * D};
-        for (u32 q = 0; q < nM; q++) {
-            const LfpMatrix &m = cl->mats[q];
-            u64 *mq = base + (size_t)(3 + 4 * q) * n * D;
-            for (int j = 0; j < 3; j++) lfp::launch_spmv_ring(m.rowptr, m.col, m.spmv_vals(), xin[j], n, mq + (size_t)j * n * D, s2, m.const_coef);
-        }
-    }
-    HIPCHK(c0, hipEventRecord(cl->ev_cmt, s2));
-    P.by[l] = cl;
-    cl->cmt_valid = true;
-    return LFPLUS_OK;
-}
 // Cm::prove on L resident instances (as lfplus_range_check: ctxs[l] holds f_l, the commitment matrix and the from_f results; `ell` is
 // DecompParameters::l).  Outputs (host): the range check's r .. c exactly as lfplus_range_check writes them; comh L x kappa ring elements; the two
 // sumcheck proofs pa / pb (nvars x 3 ring elements); their evaluations ea / eb (L x (4 + 4 nM) ring elements, the reference's table order); the
@@ -1069,18 +1016,16 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
     u64 *S = nullptr, *R = nullptr;
     // Everything of the tables that needs no challenge of Cm::prove -- eq(r, .), tau, m_tau, f and their products with the M_q: three quarters of the table work --
     // is enqueued from inside the range check, ahead of the host's absorb of the set check's evaluations (before_absorb); h, M_q h, t0 and t1 follow below
-    // (instance tables built ahead -- lfplus_cm_tables_async -- live in ctxs[0]'s own buffers; they are used when this call has their shape and the resident matrices)
-    const bool pre = !shd && !rowptr && c->cmpre.S && c->cmpre.R && c->cmpre.n == n && c->cmpre.L == L && c->cmpre.nM == nM && c->cmpre.by.size() == L;
     // Compact instance tables (lfp_rgchk.hip, k_cm_combine_c): m_tau stays the exponent bytes from_f left, M_q tau a column of scalars -- valid when every M_q has
     // constant coefficients; the batched, unsharded form only (LFPLUS_CM_DENSE=1: every table as ring elements)
-    bool compact = batched && !shd && !pre && L <= 8 && L * nM <= 64 && nring <= 64 && !getenv("LFPLUS_CM_DENSE");
+    bool compact = batched && !shd && L <= 8 && L * nM <= 64 && nring <= 64 && !getenv("LFPLUS_CM_DENSE");
     for (u32 q = 0; q < nM; q++) compact = compact && M[q].const_coef;
     DevBuf mtsb;
     lfp::CmCompact cc = {};
     lfp::CmTabList dense_list = {};
     u32 ndense = 0;
     auto tables_early = [&]() -> int {
-        if ((!pre && (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8))) || Sw[0].alloc((size_t)kS * (nl / 2) * 8) || Sw[1].alloc((size_t)kS * (nl / 4 + 1) * 8) ||
+        if (S0.alloc((size_t)nS * nl * 8) || R0.alloc((size_t)nR * nl * D * 8) || Sw[0].alloc((size_t)kS * (nl / 2) * 8) || Sw[1].alloc((size_t)kS * (nl / 4 + 1) * 8) ||
             Rw[0].alloc((size_t)kR * (nl / 2) * D * 8) || Rw[1].alloc((size_t)kR * (nl / 4 + 1) * D * 8) || rcpd.alloc((size_t)(L * per + 2) * 8) ||
             part.alloc((size_t)nb0 * 48 * 8) || (nM && tauring.alloc(n * D * 8)) || (nM && shd && (mtring.alloc(n * D * 8) || hwhole.alloc(n * D * 8))) ||
             (shd && (Sg.alloc((size_t)kS * c->world * 8) || Rg.alloc((size_t)kR * c->world * D * 8))) ||
@@ -1088,7 +1033,6 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
                          evpart.alloc(std::max((size_t)lfp::cm_eval_chunks(nl) * nring * D, (size_t)lfp::eval_chunks(nl) * 4) * 8))))
             return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm tables)");
         S = S0.as<u64>(); R = R0.as<u64>();
-        if (pre) { S = c->cmpre.S; R = c->cmpre.R; }
         HIPCHK(c, hipMemcpyAsync(S, so.eqr.as<u64>() + row0, nl * 8, hipMemcpyDeviceToDevice, c->st));
         if (compact) {
             if (nM && mtsb.alloc((size_t)L * nM * nl * 8)) return fail(c, LFPLUS_E_HIP, "hipMalloc (Cm scalar tables)");
@@ -1112,13 +1056,6 @@ extern "C" int lfplus_cm_prove(lfplus_ctx *const *ctxs, uint32_t L, lfplus_trans
                 }
                 continue;
             }
-            if (pre && c->cmpre.by[l] == ctxs[l] && ctxs[l]->ev_cmt && ctxs[l]->cmt_valid) {      // built ahead on the instance's second stream (lfplus_cm_tables_async): wait for it, use it once
-                HIPCHK(c, hipStreamWaitEvent(c->st, ctxs[l]->ev_cmt, 0));
-                c->cmpre.by[l] = nullptr;
-                ctxs[l]->cmt_valid = false;
-                continue;
-            }
-            if (pre) c->cmpre.by[l] = nullptr;
             lfp::launch_to_mont(ctxs[l]->tau + row0, nl, S + (size_t)(1 + l) * nl, c->st);
             lfp::launch_cm_materialize(ctxs[l]->mtau + row0, nullptr, nl, base, c->st);
             HIPCHK(c, hipMemcpyAsync(base + nl * D, ctxs[l]->f + row0 * D, nl * D * 8, hipMemcpyDeviceToDevice, c->st));
@@ -1699,7 +1636,7 @@ extern "C" int lfplus_mlin(lfplus_ctx *const *ctxs, uint32_t L, lfplus_transcrip
     }
     // the folded witness replaces ctxs[0]'s f: the RgInstance results of ctxs[0] no longer describe the resident witness, and its g buffer holds the
     // sum, not g_0 (lfplus_cm_read_g on ctxs[0] is refused from here on; the other instances keep their g_l)
-    c->have = false; c->cmt_valid = false;
+    c->have = false;
     c->g_valid = false;
     if (!c->sharded()) HIPCHK(c, hipMemcpyAsync(c->f, c->g, n * D * 8, hipMemcpyDeviceToDevice, c->st));
     else {        // a witness is whole on every rank (Decomp::decompose's M_j F_i rows read arbitrary columns): all-gather the rows of g

@@ -66,7 +66,6 @@ def _lib():
         L.lfplus_tensor.argtypes = [vp, u64p, C.c_uint32, u64p]
         L.lfplus_tensor_product.argtypes = [vp, u64p, C.c_uint64, u64p, C.c_uint64, u64p]
         u8p, vpp, ip = C.POINTER(C.c_uint8), C.POINTER(vp), C.POINTER(C.c_int)
-        L.lfplus_cm_tables_async.argtypes = [vpp, C.c_uint32, C.c_uint32, C.c_uint32]
         L.lfplus_transcript_new.restype = vp
         L.lfplus_transcript_clone.restype = vp
         L.lfplus_transcript_clone.argtypes = [vp]
@@ -663,7 +662,7 @@ class ComR1CS:
     def matrices(self):
         return list(self.r1cs)
 
-    def linearize(self, ctx, transcript, resident=False, preloaded=False, from_f_hint=None, after_hint=None):
+    def linearize(self, ctx, transcript, resident=False, preloaded=False, from_f_hint=None):
         """Linearize::linearize (r1cs.rs:76-139) on `ctx` (the witness becomes resident there) -> (LinB fields, ComR1CSProof fields); resident: the three
         matrices are the ones ctx.set_matrices / share_matrices left on the device; preloaded: ctx.set_witness(self.f) was already called (PlusProver.preload);
         from_f_hint: DecompParameters of the Mlin::mlin that follows -- the double commitment of this witness is enqueued on the context's second stream now
@@ -672,8 +671,6 @@ class ComR1CS:
             ctx.set_witness(self.f)
         if from_f_hint is not None:
             ctx.rg_from_f_async(from_f_hint)
-            if after_hint is not None:
-                after_hint()
         n = self.f.shape[0]
         nvars = n.bit_length() - 1
         keep, rp, cp, vp = _csr_args(RESIDENT(3) if resident else self.r1cs)
@@ -860,21 +857,13 @@ class PlusProver:
                 if up_err:
                     raise up_err[0]
         try:
-            hs = (C.c_void_p * len(ctxs))(*[cx.h for cx in ctxs])
-
-            def _tables(i):      # behind the from_f on the same stream: the challenge-free instance tables of Cm::prove (lfplus_cm_tables_async).  Opt-in
-                # (LFPLUS_ASYNC_CM_TABLES=1): measured neutral at 2^20 rows (33.15 vs 32.89 ms, gpurun r5n) -- the linearizations leave no idle GPU time once
-                # from_f runs next to them; the 2.9 ms of SpMVs only move from the range check into the linearizations' bandwidth-bound rounds
-                if isinstance(self.res, _Resident) and os.environ.get("LFPLUS_ASYNC_CM_TABLES"):
-                    ctxs[0]._chk(_lib().lfplus_cm_tables_async(hs, len(ctxs), i, len(self.M)))
             for i in range(nacc):
                 _wait(ctxs[i])
                 ctxs[i].rg_from_f_async(dp)
-                _tables(i)
             for i, ci in enumerate(comp):
                 same = len(self.M) == 3 and all(a is b for x, y in zip(ci.r1cs, self.M) for a, b in zip(x, y))   # (M = cr1cs.x.matrices() in every reference use)
                 _wait(ctxs[nacc + i])
-                _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same, preloaded=True, from_f_hint=dp, after_hint=lambda i=i: _tables(nacc + i))
+                _, lp = ci.linearize(ctxs[nacc + i], self.transcript, resident=same, preloaded=True, from_f_hint=dp)
                 lproof.append(lp)
         except Exception:
             if th is not None:               # (never leave the worker writing into contexts the caller is about to close)

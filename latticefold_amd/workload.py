@@ -197,6 +197,25 @@ class Workload:
         return lin + 2 * dec + fold
 
 
+def chain_w_ccs(wl, j: int) -> np.ndarray:
+    """The witness of step j >= 1 of an IVC-style chain under the workload's FIXED constraint system (bench.py --chain, tests/test_gpu_chain.py,
+    tests/tools/make_chain_digests.py).  The bench R1CS is A = B = I, C = diag(z_base) (arith/r1cs.rs:170-186): row i demands z_i * z_i = z_base_i * z_i
+    slot by slot, so every vector whose slots are each either 0 or the base witness's slot satisfies it.  Step j keeps slot k of element i iff bit k of
+    splitmix64(0x1C0C + 1000 j + seed, i) is set (about half of the slots); x_ccs and the constant 1 stay as they are.  j = 0 is the base witness."""
+    if j == 0:
+        return wl.w_ccs
+    _p, RE, tau = RINGS[wl.ring]
+    slots = RE // tau
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, wl.wit_len + 1, dtype=np.uint64)
+        z = np.uint64((0x1C0C + 1000 * j + wl.seed) & (2**64 - 1)) + idx * _G
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    keep = ((z[:, None] >> np.arange(slots, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)     # [wit_len][slots]
+    return np.where(np.repeat(keep, tau, axis=1), wl.w_ccs, np.uint64(0))
+
+
 def make_workload(name: str, seed: int = 0, kappa: int = None, ccs: str = "r1cs", l: int = 1) -> Workload:
     """ccs = "r1cs": the reference bench shape (A = B = I, C = diag(z); 1 nnz/row);
        ccs = "deg3": the reference's degree-three non-scalar CCS (arith/ccs.rs:14-43): t = 4, M = (I, I, I, diag(z^2)),

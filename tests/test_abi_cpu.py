@@ -206,4 +206,4 @@ def test_switch_table_is_current():
     spec.loader.exec_module(mod)
     assert open(os.path.join(root, "SWITCHES.md")).read() == mod.render(), "run tools/list_switches.py --write"
     rows, _ = mod.collect()
-    assert len(rows) > 70 and all(text for _d, text, _w in rows.values())
+    assert len(rows) > 30 and all(text for _d, text, _w in rows.values())

@@ -26,7 +26,7 @@ def _oracle(ring):
 
 
 def _ctx(ring, env=None):
-    for k in ("LF_AJTAI_VALU", "LF_COMMIT_VALU", "LF_I8G_WGS"):
+    for k in ("LF_I8G_WGS",):
         os.environ.pop(k, None)
     for k, v in (env or {}).items():
         os.environ[k] = v
@@ -115,20 +115,3 @@ def test_witness_commit_from_int32_planes(name):
         assert (w2.commit(scheme) == O.ajtai_commit(A, wl.kappa, wl.N, O.crt(fc))).all()
     finally:
         ctx.close()
-
-
-@pytest.mark.parametrize("ring", ["goldilocks", "babybear"])
-def test_matches_the_valu_kernel(ring):
-    """the 64-bit VALU commit (LF_COMMIT_VALU=1) and the matrix-core commit agree on a batch"""
-    p = P_G if ring == "goldilocks" else P_B
-    out = {}
-    for mode, env in (("i8g", None), ("valu", {"LF_COMMIT_VALU": "1"})):
-        ctx = _ctx(ring, env)
-        try:
-            A = _rnd(3, p, 11, 515, ctx.RE)
-            f = _rnd(4, p, 3, 515, ctx.RE)
-            out[mode] = api.AjtaiCommitmentScheme(ctx, matrix=A).commit_ntt(f)
-        finally:
-            os.environ.pop("LF_COMMIT_VALU", None)
-            ctx.close()
-    assert (out["i8g"] == out["valu"]).all()

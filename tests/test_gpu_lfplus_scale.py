@@ -54,14 +54,8 @@ def prove(wl, device=0):
         prover.close()
 
 
-@pytest.mark.parametrize("name", ["P15", "P16", "P17", "P20", "P16+tables"])
-def test_plus_prover_matches_committed_oracle_digests(name, monkeypatch):
-    # "+tables": the opt-in early build of Cm::prove's challenge-free instance tables on the instances' second streams (lfplus_cm_tables_async)
-    if name.endswith("+tables"):
-        monkeypatch.setenv("LFPLUS_ASYNC_CM_TABLES", "1")
-        name = name.split("+")[0]
-    else:
-        monkeypatch.delenv("LFPLUS_ASYNC_CM_TABLES", raising=False)
+@pytest.mark.parametrize("name", ["P15", "P16", "P17", "P20"])
+def test_plus_prover_matches_committed_oracle_digests(name):
     want = gold(name)
     wl = plus.make_plus_workload(name)
     proof, acc, ch, A, r1cs = prove(wl)

@@ -226,17 +226,14 @@ def test_fold_step_parity(ctx, name, seed):
 @pytest.mark.parametrize("name", ["T8"])
 def test_fold_step_builds_f_and_w_ccs_of_the_folded_witness(ctx, name, monkeypatch):
     """Witness::from_f (arith.rs:299-313) builds f_coeff, f (NTT form) and w_ccs inside prove: a fold step materialises all three behind compute_f_0
-    (LF_LAZY_FROM_F=1: the planes only, f and w_ccs on demand).  Both forms against the oracle's f_0 and its recomposition."""
+    -- against the oracle's f_0 and its recomposition."""
     wl, inst, A, f_coeff, wit, cccs, acc_g, _, acc_o, _ = run_both(ctx, name)
     lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
     w_ccs_o = lfo.crt(lfo.recompose(lfo.icrt(f0_o), wl.B, wl.L))
-    for lazy in (False, True):
-        if lazy:
-            monkeypatch.setenv("LF_LAZY_FROM_F", "1")
-        lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
-        assert (proof_g == proof_o).all() and (lc_g == lc_o).all()
-        assert (w0.f == f0_o).all() and (w0.f_coeff == lfo.icrt(f0_o)).all() and (w0.w_ccs == w_ccs_o).all()
-        w0.free()
+    lc_g, w0, proof_g = api.NIFSProver.prove(ctx, acc_g, wit, cccs, wit, api.PoseidonTranscript())
+    assert (proof_g == proof_o).all() and (lc_g == lc_o).all()
+    assert (w0.f == f0_o).all() and (w0.f_coeff == lfo.icrt(f0_o)).all() and (w0.w_ccs == w_ccs_o).all()
+    w0.free()
 
 
 @pytest.mark.parametrize("name", ["D5120", "D10240"])

@@ -15,7 +15,6 @@ EXTRA = {
     "LFPLUS_CACHE_GB": "cap of the per-device scratch cache destroyed LatticeFold+ contexts leave behind (default min(32 GB, 1/4 of HBM))",
     "LFPLUS_CM_DENSE": "Cm::prove keeps every instance table as ring elements (no compact exponent-byte / scalar tables)",
     "LFPLUS_EVAL_CHUNKS": "blocks of the set check's evaluation passes",
-    "LFPLUS_NO_ASYNC_CM_TABLES": "lfplus_cm_tables_async becomes a no-op (the instance tables of Cm::prove are built inside it)",
     "LFPLUS_NO_ASYNC_FROM_F": "lfplus_rg_from_f_async becomes a no-op (from_f runs inside lfplus_mlin)",
     "LFPLUS_NO_HIST": "Step-3 evaluations of the set check with one weight table at a time (k_wmono) instead of the exponent-histogram pass (k_whist16)",
     "LFPLUS_POOL_TRACE": "log every scratch-pool allocation",
@@ -37,8 +36,8 @@ EXTRA = {
     "LF_FOLD_TAB_MIN": "pairs from which rounds 1-2 run as table look-ups (default 16384)", "LF_FOLD_TAB_R1": "round 1 as a table look-up round (disables the GEMM rounds)",
     "LF_FOLD_UNFUSED": "separate k_fix pass before every folding round", "LF_I8_BITS": "=0: commit kernel cuts its digits from the int32 planes instead of the bit-plane form of a fold step (default since round 5)",
     "LF_I8_COLS": "=0: commit kernel with 2 x 2 blocks of (7 | 6) x 6 tiles per multiplier wave instead of the column split (13 x 3 tiles each; default since round 5)", "LF_I8_COUPLE_W": "window (tiles) a commit workgroup may run ahead of its paired plane-group workgroup (default 4; 0 switches the coupling off)", "LF_I8_COUPLE_E": "tiles between two handshakes of the paired commit workgroups (default 4)", "LF_I8_GUARDED": "commit kernel instantiation with guarded tile loads",
-    "LF_I8_NO_SPLIT": "commit kernel without the producer / multiplier wave specialisation (k_ajtai_i8 for every shape)", "LF_I8_PROF": "in-kernel cycle counters of the commit kernel (tools/i8_prof.py)",
-    "LF_LANE0_MID": "lane 0's stream on the middle priority (so that the prefetch stream yields to it too)", "LF_LIN_BLOCKS": "workgroups of the linearization round kernels (default automatic)",
+    "LF_I8G_PROF": "in-kernel cycle counters of the general commit kernel k_ajtai_i8g (tools/i8g_prof.py; lf_debug_i8_prof then returns its table)", "LF_I8_PROF": "in-kernel cycle counters of the commit kernel (tools/i8_prof.py)",
+    "LF_LIN_BLOCKS": "workgroups of the linearization round kernels (default automatic)",
     "LF_LIN_UNFUSED": "separate k_fix pass before every linearization round", "LF_LIN_U_EVAL": "u of the linearization from stand-alone evaluations instead of the last fix of the sumcheck tables",
     "LF_NO_PRIO": "equal stream priorities for the two lanes", "LF_POSEIDON_AVX2": "(BabyBear) AVX2 lanes even when AVX-512 IFMA is present", "LF_POSEIDON_SCALAR": "scalar Poseidon permutation on the host",
     "LF_SPIN_ALL": "spin-wait on every stream synchronisation (no blocking event)", "LF_THETA_EVAL": "theta from stand-alone evaluations instead of the last fix of the folding tables",
