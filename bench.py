@@ -434,6 +434,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("LF_WORKLOAD", "C4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ccs", choices=["r1cs", "multi4", "multi16", "deg3"], default="r1cs",
+                    help="constraint-system shape (workload.make_workload): the reference bench's 1-nnz R1CS (default, the metric's configuration); multi4 / multi16 = 4 / 16 entries "
+                         "per row at pseudo-random columns, ring-valued entries in C (general CSR SpMV, arith/utils.rs:52-65); deg3 = the reference's degree-three CCS "
+                         "(arith/ccs.rs:14-43: t = 4, S = {{0,1,2},{3}})")
     ap.add_argument("--no-ajtai", action="store_true", help="skip the reference's Ajtai bench rows (commit_ntt at benches/config.toml:715 / :670; an extra key, not part of the metric)")
     ap.add_argument("--chain", type=int, default=8, help="steps of the chained-folding extra key `ivc` (every step ingests and commits a new witness and folds it into the "
                                                          "carried accumulator; run for the bench workload and for C2); 0 = skip")
@@ -482,7 +486,7 @@ def main():
 
     def measure(shard):
         """setup (untimed: everything resident in HBM), W warm-up steps, K timed steps bracketed by barrier + synchronize; max over ranks"""
-        wl = make_workload(args.workload, seed=0 if shard else rank)
+        wl = make_workload(args.workload, seed=0 if shard else rank, ccs=args.ccs)
         ctx = api.Context(local_rank, ring=wl.ring)
         transport = None
         if shard:
@@ -511,7 +515,7 @@ def main():
         for sidx in range(1, max(1, args.streams)):
             if shard:
                 raise SystemExit("--streams > 1 is a replicas-only mode")
-            wl_s = make_workload(args.workload, seed=1000 * sidx + rank)
+            wl_s = make_workload(args.workload, seed=1000 * sidx + rank, ccs=args.ccs)
             ctx_s = api.Context(local_rank, ring=wl_s.ring)
             ctx_s.load_ccs(wl_s)
             sch_s = api.AjtaiCommitmentScheme(ctx_s, kappa=wl_s.kappa, n=wl_s.N, seed=wl_s.ajtai_seed())
@@ -575,12 +579,13 @@ def main():
         if (shard or rank == 0) and last:
             try:
                 import hashlib
-                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "scale_digests.json"))).get(wl.name)
+                fkey = wl.name if args.ccs == "r1cs" else f"{wl.name}/{args.ccs}"
+                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "scale_digests.json"))).get(fkey)
                 if gold:
                     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
                     fixture_info.update(matches_oracle_fixture=bool(sha(last["proof"]) == gold.get("proof") and sha(last["lc"]) == gold.get("lcccs_out")),
                                         fixture="tests/golden/scale_digests.json[%s]: sha256 of the whole proof and of the folded LCCCS of the last timed step "
-                                                "(oracle-only fixture, tests/tools/make_scale_digests.py)" % wl.name)
+                                                "(oracle-only fixture, tests/tools/make_scale_digests.py)" % fkey)
             except Exception as e:      # (a missing fixture is not a bench failure)
                 fixture_info.update(matches_oracle_fixture=None, fixture=f"not checked: {e!r}")
         free_b, total_b = ctx.device_memory()
@@ -790,7 +795,7 @@ def main():
             "dtype": "u64" if wl.ring == "goldilocks" else "u32 (31-bit Montgomery)",
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: {'GoldilocksRingNTT' if wl.ring == 'goldilocks' else 'BabyBearRingNTT'} R1CS->CCS, m=N=2^{wl.s} rows, wit_len={wl.wit_len}, L={wl.L}, B=2^{wl.B.bit_length() - 1}, "
-                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}", "parallelism": (f"shard x{world}: one fold stream, witness columns / table rows sharded by the high index bits (Ajtai commits, linearization and folding sumcheck rounds, v/u/eta evaluations), RCCL all-gather + modular sum per exchange" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
+                                   f"b={wl.b}, K={wl.K}, kappa={wl.kappa}, t={wl.t}" + ("" if args.ccs == "r1cs" else f", constraint system '{args.ccs}' (nnz per matrix {[int(len(c)) for c in wl.col]}, degree {wl.d}) -- NOT the metric's configuration"), "parallelism": (f"shard x{world}: one fold stream, witness columns / table rows sharded by the high index bits (Ajtai commits, linearization and folding sumcheck rounds, v/u/eta evaluations), RCCL all-gather + modular sum per exchange" if shard else f"replicas x{world}" + (f", {args.streams} independent streams per GPU" if args.streams > 1 else "")),
                        "alg_bytes_per_step": alg, "hbm_in_use_gib": round(mem_info.get("hbm_in_use_gib", 0.0), 2),
                        "folded_witness": ("Witness::from_f in full inside the timed step (arith.rs:299-313): the folded witness leaves the step as int32 coefficient planes (f_coeff, what the next step reads), "
                                           "f_0 in NTT form and w_ccs, all three on the device (lf_witness_get_f / _get_w_ccs only download)"),
@@ -832,7 +837,7 @@ def main():
             out["ajtai"] = ajtai_extra()
             if "witness_commit" in mem_info:
                 out["ajtai"].append(mem_info["witness_commit"])
-        if world == 1 and args.chain > 0 and args.streams == 1:
+        if world == 1 and args.chain > 0 and args.streams == 1 and args.ccs == "r1cs":
             out["ivc"] = [ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3)]
             if wl.name != "C2" and wl.ring == "goldilocks":
                 out["ivc"].append(ivc_extra("C2", args.chain, local_rank))

@@ -228,6 +228,7 @@ void lf_transcript_absorb_fq(lf_transcript *, const uint64_t *x, size_t n);     
 void lf_transcript_absorb_ring(lf_transcript *, const uint64_t *elems, size_t n); /* absorb_slice */
 void lf_transcript_get_challenge(lf_transcript *, uint64_t *fq3_out);
 void lf_transcript_get_short_challenge(lf_transcript *, uint64_t *coeff_out);
+void lf_transcript_squeeze_bytes(lf_transcript *, uint8_t *out, size_t n);         /* Transcript::squeeze_bytes (poseidon.rs:62-64): what a Rust impl of the trait over this handle needs */
 void lf_poseidon_params(uint64_t *ark /* 720 */, uint64_t *mds /* 576 */);
 /* one Poseidon permutation on 24 words; plain = 0: the transcript's path (sparse-matrix partial rounds; AVX-512 IFMA / AVX2
  * lanes chosen at run time, LF_POSEIDON_SCALAR=1 disables them), 1: the textbook round loop, 2: the scalar sparse-matrix code.

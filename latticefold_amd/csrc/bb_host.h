@@ -65,8 +65,9 @@ class BbTranscript {
     // external-basis hook, as lf::Transcript::set_basis (T, Ti: 9x9 row-major, ext = T int; nullptr = off)
     void set_basis(const u64 *T, const u64 *Ti) { bT_ = T; bTi_ = Ti; }
 
+    void squeeze(u64 *out, size_t n);   // raw field elements of the sponge (lf_transcript_squeeze_bytes)
+
   private:
-    void squeeze(u64 *out, size_t n);
     u64 st_[24];
     bool squeezing_;
     int idx_;

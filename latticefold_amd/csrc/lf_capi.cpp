@@ -1563,6 +1563,17 @@ void lf_transcript_get_short_challenge(lf_transcript *t, uint64_t *o) {
     if (t->bb) t->bb->get_short_challenge(o);
     else t->t.get_short_challenge(o);
 }
+void lf_transcript_squeeze_bytes(lf_transcript *t, uint8_t *out, size_t n) {
+    // CryptographicSponge::squeeze_bytes of the arkworks-0.4 PoseidonSponge (Transcript::squeeze_bytes, transcript/poseidon.rs:62-64): ceil(n / usable) field
+    // elements, usable = (modulus bits - 1) / 8 low little-endian bytes of each (7 Goldilocks, 3 BabyBear), truncated to n
+    if (!t || !out || !n) return;
+    const size_t usable = t->bb ? 3 : 7, ne = (n + usable - 1) / usable;
+    std::vector<u64> e(ne);
+    if (t->bb) t->bb->squeeze(e.data(), ne);
+    else t->t.squeeze(e.data(), ne);
+    for (size_t i = 0, o = 0; i < ne && o < n; i++)
+        for (size_t j = 0; j < usable && o < n; j++) out[o++] = (uint8_t)(e[i] >> (8 * j));
+}
 void lf_poseidon_permute(uint64_t *state, int plain) {
     if (plain == 2) Transcript::permute_scalar(state);
     else if (plain) Transcript::permute_plain(state);

@@ -83,8 +83,9 @@ class Transcript {
     void set_basis(const u64 *T, const u64 *Ti) { bT_ = T; bTi_ = Ti; }
     void set_state(const u64 in[26]) { for (int i = 0; i < 24; i++) st_[i] = in[i]; idx_ = (int)in[24]; squeezing_ = in[25] != 0; }
 
+    void squeeze(u64 *out, size_t n);   // raw field elements of the sponge (lf_transcript_squeeze_bytes)
+
   private:
-    void squeeze(u64 *out, size_t n);
     u64 st_[24];
     bool squeezing_;
     int idx_;

@@ -94,29 +94,85 @@ def default_nonres(ring: str) -> int:
     return 1 << 40 if ring == "goldilocks" else 2
 
 
+_EPS = np.uint64(0xFFFFFFFF)
+_M32 = np.uint64(0xFFFFFFFF)
+_S32 = np.uint64(32)
+
+
+def _gl_mul_block(a, b):
+    with np.errstate(over="ignore"):
+        a0, a1, b0, b1 = a & _M32, a >> _S32, b & _M32, b >> _S32
+        lo, m1, m2, hi = a0 * b0, a1 * b0, a0 * b1, a1 * b1
+        mid = m1 + m2
+        cmid = (mid < m1).astype(np.uint64)
+        L = lo + (mid << _S32)
+        c1 = (L < lo).astype(np.uint64)
+        H = hi + (mid >> _S32) + (cmid << _S32) + c1                   # the 128-bit product is (H, L); H < 2^64 always
+        h0, h1 = H & _M32, H >> _S32
+        t0 = L - h1
+        t0 = np.where(L < h1, t0 - _EPS, t0)                            # borrow: 2^64 = 2^32 - 1
+        t1 = h0 * _EPS
+        r = t0 + t1
+        r = np.where(r < t1, r + _EPS, r)
+        r = np.where(r >= np.uint64(P), r - np.uint64(P), r)
+    return r
+
+
+def gl_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """element-wise product of canonical Goldilocks residues (uint64 arrays, broadcasting), vectorised: 32-bit limbs, then 2^64 = 2^32 - 1, 2^96 = -1 (mod p).
+    Large operands go through in cache-sized blocks of the leading axis (the ~25 temporaries of a 10^8-element call thrash memory: 130 s against 6 s)."""
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    shape = np.broadcast_shapes(a.shape, b.shape)
+    if len(shape) == 0 or int(np.prod(shape)) <= (1 << 20):
+        return _gl_mul_block(a, b)
+    a = np.broadcast_to(a, shape)
+    b = np.broadcast_to(b, shape)
+    out = np.empty(shape, dtype=np.uint64)
+    per = max(1, int(np.prod(shape[1:])))
+    step = max(1, (1 << 19) // per)
+    for i in range(0, shape[0], step):
+        out[i:i + step] = _gl_mul_block(a[i:i + step], b[i:i + step])
+    return out
+
+
+def _fp_mul(a, b, ring):
+    if ring == "goldilocks":
+        return gl_mul(a, b)
+    p = np.uint64(RINGS[ring][0])
+    return (np.asarray(a, dtype=np.uint64) * np.asarray(b, dtype=np.uint64)) % p          # 31-bit residues: the product fits 62 bits
+
+
+def _fp_add(a, b, ring):
+    p = np.uint64(RINGS[ring][0])
+    with np.errstate(over="ignore"):
+        r = a + b
+        if ring == "goldilocks":
+            r = np.where((r < a) | (r >= p), r - p, r)
+        else:
+            r = np.where(r >= p, r - p, r)
+    return r
+
+
 def ring_mul_ntt(a: np.ndarray, b: np.ndarray, ring: str = "goldilocks") -> np.ndarray:
-    """slot-wise product of NTT-form ring elements (a, b: (..., d) uint64) in F_{p^tau} = F_p[Y]/(Y^tau - nonres);
-    plain Python integers -- for building small test workloads only"""
+    """slot-wise product of NTT-form ring elements (a, b: (..., d) uint64, broadcasting over the leading axes) in F_{p^tau} = F_p[Y]/(Y^tau - nonres);
+    vectorised numpy (schoolbook over the tau coordinates, 32-bit limb products for the 64-bit prime): any size"""
     p, d, tau = RINGS[ring]
-    nu = default_nonres(ring)
-    a2 = np.asarray(a, dtype=np.uint64).reshape(-1, 8, tau)
-    b2 = np.asarray(b, dtype=np.uint64).reshape(-1, 8, tau)
-    out = np.zeros_like(a2)
-    for e in range(a2.shape[0]):
-        for k in range(8):
-            x = [int(v) for v in a2[e, k]]
-            y = [int(v) for v in b2[e, k]]
-            r = [0] * tau
-            for i in range(tau):
-                if not x[i]:
-                    continue
-                for j in range(tau):
-                    if i + j < tau:
-                        r[i + j] += x[i] * y[j]
-                    else:
-                        r[i + j - tau] += nu * x[i] * y[j]
-            out[e, k] = [v % p for v in r]
-    return out.reshape(np.asarray(a).shape)
+    nu = np.uint64(default_nonres(ring))
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    shape = np.broadcast_shapes(a.shape, b.shape)
+    a2 = np.broadcast_to(a, shape).reshape(-1, 8, tau)
+    b2 = np.broadcast_to(b, shape).reshape(-1, 8, tau)
+    out = np.zeros(a2.shape, dtype=np.uint64)
+    for i in range(tau):
+        for j in range(tau):
+            t = _fp_mul(a2[:, :, i], b2[:, :, j], ring)
+            if i + j >= tau:
+                t = _fp_mul(t, nu, ring)
+            k = (i + j) % tau
+            out[:, :, k] = _fp_add(out[:, :, k], t, ring)
+    return out.reshape(shape)
 
 
 @dataclass
@@ -221,7 +277,9 @@ def make_workload(name: str, seed: int = 0, kappa: int = None, ccs: str = "r1cs"
        ccs = "deg3": the reference's degree-three non-scalar CCS (arith/ccs.rs:14-43): t = 4, M = (I, I, I, diag(z^2)),
                      S = {{0,1,2},{3}}, c = (1,-1), d = 3;
        ccs = "multi": an R1CS with 2 nnz/row and non-identity values: (A z)_i = z_i + z_{i+1}, B = I,
-                      (C z)_i = z_i * (z_i + z_{i+1})  (satisfied by construction).  Small sizes only (Python integers)."""
+                      (C z)_i = z_i * (z_i + z_{i+1})  (satisfied by construction);
+       ccs = "multi4" / "multi16": 4 / 16 entries per row at pseudo-random columns with scalar coefficients 1..7 in A, ring-valued entries in C (any size:
+                      vectorised generators)."""
     cfg = CONFIGS[name]
     s, wit_len, L, B, b, K, kap = cfg[:7]
     ring = cfg[7] if len(cfg) > 7 else "goldilocks"
@@ -263,6 +321,27 @@ def make_workload(name: str, seed: int = 0, kappa: int = None, ccs: str = "r1cs"
         wl.rowptr = [rp2, rp.copy(), rp2.copy()]
         wl.col = [ci2, ci.copy(), ci2.copy()]
         wl.val = [vA, ident.copy(), np.ascontiguousarray(zc)]
+    elif ccs in ("multi4", "multi16"):
+        # A general sparse R1CS at any size: k entries per row at pseudo-random columns with small non-unit scalar coefficients,
+        #   (A z)_i = sum_j a_ij z_c(i,j),   B = I,   (C z)_i = sum_j (a_ij z_i) z_c(i,j) = z_i (A z)_i      -- satisfied by construction for every witness family
+        # that keeps z_i fixed (the values of C are ring elements with eight distinct slots: a genuinely ring-valued SpMV)
+        k = int(ccs[5:])
+        assert rows >= k
+        with np.errstate(over="ignore"):
+            idx = np.arange(1, rows * k + 1, dtype=np.uint64)
+            h = np.uint64((0xCC5 + seed) & (2**64 - 1)) + idx * _G
+            h = (h ^ (h >> np.uint64(30))) * _M1
+            h = (h ^ (h >> np.uint64(27))) * _M2
+            h = h ^ (h >> np.uint64(31))
+        cols = (h % np.uint64(rows)).astype(np.uint32)                      # [rows * k]
+        coef = ((h >> np.uint64(40)) % np.uint64(7) + np.uint64(1))          # a_ij in 1 .. 7
+        rpk = np.minimum(k * np.arange(m + 1, dtype=np.uint64), np.uint64(k * rows)).astype(np.uint32)
+        vA = np.zeros((rows * k, RE), dtype=np.uint64)
+        vA[:, 0::_tau] = coef[:, None]
+        vC = _fp_mul(np.repeat(z[:rows], k, axis=0), coef[:, None], ring)    # a_ij * z_i, slot by slot (scalar times element)
+        wl.rowptr = [rpk, rp.copy(), rpk.copy()]
+        wl.col = [cols, ci.copy(), cols.copy()]
+        wl.val = [vA, ident.copy(), np.ascontiguousarray(vC)]
     elif ccs != "r1cs":
         raise ValueError(ccs)
     return wl

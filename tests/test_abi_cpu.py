@@ -207,3 +207,25 @@ def test_switch_table_is_current():
     assert open(os.path.join(root, "SWITCHES.md")).read() == mod.render(), "run tools/list_switches.py --write"
     rows, _ = mod.collect()
     assert len(rows) > 30 and all(text for _d, text, _w in rows.values())
+
+
+def test_transcript_squeeze_bytes_matches_the_short_challenge():
+    """lf_transcript_squeeze_bytes = CryptographicSponge::squeeze_bytes of the reference's PoseidonSponge (7 / 3 usable bytes per field element): squeeze_bytes(18) on a
+    clone gives the bytes whose 24 six-bit fields minus 32 are get_short_challenge's coefficients (rings/goldilocks.rs, rings/babybear.rs challenge sets; KAT-pinned)"""
+    import ctypes as C
+    lib = api._lib()
+    lib.lf_transcript_squeeze_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
+    lib.lf_transcript_squeeze_bytes.restype = None
+    for ring, p, words in (("goldilocks", 0xFFFFFFFF00000001, 24), ("babybear", 15 * 2**27 + 1, 72)):
+        t = api.PoseidonTranscript(ring=ring)
+        t.absorb_slice(np.arange(3 * words, dtype=np.uint64).reshape(3, words) % np.uint64(p))
+        t2 = t.clone()
+        want = t.get_short_challenge()
+        buf = (C.c_uint8 * 18)()
+        lib.lf_transcript_squeeze_bytes(t2.h, buf, 18)
+        bs = bytes(buf)
+        got = []
+        for g in range(6):
+            w = bs[3 * g] | (bs[3 * g + 1] << 8) | (bs[3 * g + 2] << 16)
+            got += [((w >> (6 * j)) & 63) - 32 for j in range(4)]
+        assert [int(v) if int(v) < p // 2 else int(v) - p for v in want[:24]] == got

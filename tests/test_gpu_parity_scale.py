@@ -30,8 +30,8 @@ def _oracle(ring):
     return O
 
 
-def _setup(name):
-    wl = make_workload(name)
+def _setup(name, ccs="r1cs"):
+    wl = make_workload(name, ccs=ccs)
     ctx = api.Context(0, ring=wl.ring)
     ctx.load_ccs(wl)
     scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())   # same stream as wl.ajtai_matrix()
@@ -126,6 +126,42 @@ def test_fold_step_matches_committed_oracle_digests(name):
         got = _digests(wl, acc, lc, w0.f, proof)
         bad = [k for k in want if got[k] != want[k]]
         assert not bad, f"{name}: sections differing from the oracle fixture: {bad}"
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("name,ccs", [("C2", "multi4"), ("C2", "multi16"), ("C2", "deg3"), ("B14", "multi4")])
+def test_general_ccs_fold_step_matches_committed_oracle_digests(name, ccs):
+    """SURVEY 8(f) row 2 at scale: general sparse matrices (4 / 16 entries per row at pseudo-random columns, ring-valued entries in C: arith/utils.rs:52-65 mat_vec_mul
+    as a real CSR SpMV) and the reference's degree-three CCS (arith/ccs.rs:14-43, t = 4) at 2^16 rows -- complete fold steps vs oracle-only fixtures, section by section"""
+    want = _gold(f"{name}/{ccs}")
+    wl, ctx, scheme, wit, cccs = _setup(name, ccs)
+    try:
+        tr = lambda: api.PoseidonTranscript(ring=wl.ring)
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr())
+        lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, tr())
+        got = _digests(wl, acc, lc, w0.f, proof)
+        bad = [k for k in want if got[k] != want[k]]
+        assert not bad, f"{name}/{ccs}: sections differing from the oracle fixture: {bad}"
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("ccs", ["multi4", "multi16", "deg3"])
+def test_general_ccs_fold_step_properties_at_c4(ccs):
+    """the same constraint systems at the metric's size (2^20 rows; no oracle run fits there): the oracle's restated verifier accepts the proof and reproduces the folded
+    LCCCS (O(proof) work plus M_j^T eq: the constraint matrices enter the check), the folded witness opens the folded commitment, its norm stays below B/2"""
+    import lfo
+    wl, ctx, scheme, wit, cccs = _setup("C4", ccs)
+    try:
+        acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, api.PoseidonTranscript())
+        lc, w0, proof = api.NIFSProver.prove(ctx, acc, wit, cccs, wit, api.PoseidonTranscript())
+        inst = lfo.Instance(wl)
+        rc, lc_v = inst.verify(lfo.Transcript(), acc, cccs, proof)
+        assert rc == 0 and (lc_v == lc).all()
+        assert (w0.commit(scheme) == lc[wl.s + 3: wl.s + 3 + wl.kappa]).all()
+        ok, mx = ctx.linf_check(w0.f, wl.B // 2)
+        assert ok, mx
     finally:
         ctx.close()
 

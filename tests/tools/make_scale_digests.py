@@ -1,7 +1,7 @@
 """Generates tests/golden/scale_digests.json: SHA-256 digests of one complete fold step (`NIFSProver::prove`) at the BASELINE sizes,
 computed by the CPU ORACLE ONLY (oracle/liblfo*.so -- no GPU, no product code beyond the numpy workload generator).
 
-    python tests/tools/make_scale_digests.py [names...]        default: C2 T18 C4 B14 C3
+    python tests/tools/make_scale_digests.py [names...]        default: C2 T18 C4 B14 C3;   name/ccs (C2/multi4, C2/multi16, C2/deg3): general constraint systems
 
 Inputs are the deterministic synthetic workloads of latticefold_amd/workload.py (the same ones bench.py runs): acc = linearization of
 the instance under a fresh transcript, then fold_step(acc, w, cm_i, w) under a fresh transcript, exactly the call sequence of the
@@ -45,9 +45,11 @@ def sections(wl, acc, lc, f0, proof):
     }
 
 
-def run(name):
+def run(name, ccs="r1cs"):
+    """ccs: the constraint-system shape of workload.make_workload ("r1cs": the bench's 1-nnz R1CS; "multi4" / "multi16": 4 / 16 entries per row at random
+    columns; "deg3": the reference's degree-three CCS) -- stored under the key name/ccs"""
     from latticefold_amd.workload import make_workload
-    wl = make_workload(name)
+    wl = make_workload(name, ccs=ccs)
     if wl.ring == "goldilocks":
         import lfo as O
     else:
@@ -64,8 +66,8 @@ def run(name):
     t2 = time.time()
     d = sections(wl, acc, lc, f0, proof)
     d["oracle_seconds"] = {"setup": round(t1 - t0, 1), "fold_step": round(t2 - t1, 1), "threads": O.lib().lfo_num_threads()}
-    d["workload"] = {"name": name, "ring": wl.ring, "s": wl.s, "kappa": wl.kappa, "K": wl.K, "L": wl.L, "B": wl.B}
-    print(name, d["oracle_seconds"], flush=True)
+    d["workload"] = {"name": name, "ccs": ccs, "ring": wl.ring, "s": wl.s, "kappa": wl.kappa, "K": wl.K, "L": wl.L, "B": wl.B, "t": wl.t, "nnz": [int(len(c)) for c in wl.col]}
+    print(name, ccs, d["oracle_seconds"], flush=True)
     return d
 
 
@@ -73,5 +75,6 @@ if __name__ == "__main__":
     names = sys.argv[1:] or ["C2", "T18", "C4", "B14", "C3"]
     out = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for n in names:
-        out[n] = run(n)
+        base, _, ccs = n.partition("/")
+        out[n] = run(base, ccs or "r1cs")
         json.dump(out, open(OUT, "w"), indent=1, sort_keys=True)
