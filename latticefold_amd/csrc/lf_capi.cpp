@@ -169,6 +169,7 @@ struct lf_ctx {
     lfdist::Comm &cm() { return comm[t_lane]; }
     // CCS
     bool have_ccs = false;
+    bool ccs_general = false;   // some constraint matrix has more than ~1.5 entries per (non-empty) row: M z runs on k_spmv_rows (whole-element gathers from an element-major z)
     // sharded step: the columns of z this rank's row slice of the constraint matrices refers to (shard_col_range; (size_t)-1 = not computed)
     size_t shc_r0 = (size_t)-1, shc_rcnt = 0, shc_lo = 0, shc_hi = 0;
     lf_params P{};
@@ -1355,6 +1356,12 @@ int lf_ccs_load(lf_ctx *c, const lf_params *p, const uint32_t *const *rowptr, co
         HIPCHK(hipMemcpy(dri, ri.data(), nnz * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dvT, vT.data(), nnz * 24 * 8, hipMemcpyHostToDevice));
     }
+    {
+        const size_t rows_used = n < m ? n : m;
+        c->ccs_general = false;
+        for (u32 jj = 0; jj < p->t; jj++)
+            if ((size_t)rowptr[jj][m] * 2 > rows_used * 3) c->ccs_general = true;
+    }
     c->have_ccs = true;
     c->shc_r0 = (size_t)-1;
     return LF_OK;
@@ -1371,6 +1378,11 @@ int lf_spmv(lf_ctx *c, unsigned j, const uint64_t *z, uint64_t *out) {
     RET(c->tbuf("io_a", c->n * 24, &zd));
     RET(c->tbuf("io_b", c->m * 24, &od));
     RET(up_ring(c, z, c->n, zd));
+    if (c->ccs_general) {
+        u64 *zaos;
+        RET(c->tbuf("spmv_zaos", c->n * 24, &zaos));
+        launch_spmv_rows(c->dcrt, 1, &c->d_rowptr[j], &c->d_col[j], &c->d_val[j], zd, 0, c->n, zaos, od, c->m, 0, c->stream());
+    } else
     launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], zd, c->n, od, c->m, 0, c->stream());
     return down_ring(c, od, c->m, out);
 }
@@ -1880,6 +1892,13 @@ static int linearize_impl(lf_ctx *c, Transcript &tr, const u64 *cccs, const lf_w
         const size_t Gw = (size_t)c->sh_world;
         const bool rows_sliced = shard_keep(c, 0, m) && !c->tn.lin_u_eval;
         const size_t r0 = rows_sliced ? (size_t)c->sh_rank * (m / Gw) : 0, rcnt = rows_sliced ? m / Gw : m;
+        if (c->ccs_general) {      // general matrices: whole-element gathers from one element-major copy of z
+            u64 *zaos;
+            RET(c->tbuf("spmv_zaos", (size_t)P.t * n * 24, &zaos));
+            launch_soa_to_aos(z, zaos, n, c->stream());
+            for (u32 j = 0; j < P.t; j++)
+                launch_spmv_rows(c->dcrt, 1, &c->d_rowptr[j], &c->d_col[j], &c->d_val[j], nullptr, 0, n, zaos, mz + (size_t)j * 24 * m, m, 0, c->stream(), r0, rcnt);
+        } else
         for (u32 j = 0; j < P.t; j++)
             launch_spmv(c->dcrt, c->d_rowptr[j], c->d_col[j], c->d_val[j], z, n, mz + (size_t)j * 24 * m, m, 0, c->stream(), r0, rcnt);
     }
@@ -2109,18 +2128,23 @@ static int coef_eval_dev(lf_ctx *c, const int32_t *planes, size_t n, const u64 *
 static int dot_batch_dev(lf_ctx *c, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, u64 *dpart, u64 *od, hipStream_t st = nullptr,
                          const char *tag = "", unsigned char *yb_pre = nullptr) {
     if (!st) st = c->stream();
-    if (!c->tn.dot_valu && n >= c->tn.dot_min && nb <= 3) {
+    if (!c->tn.dot_valu && n >= c->tn.dot_min && nb <= 4) {
         unsigned char *yb;
         int32_t *part;
         long long *tot;
-        if (yb_pre) yb = yb_pre;
+        if (yb_pre && nb <= 3) yb = yb_pre;
         else
         RET(c->tbuf(std::string("dot_yb") + tag, dot_i8_yb_bytes(n + 1), &yb));            // (+1: an odd column slice starts one column early)
         RET(c->tbuf(std::string("dot_i8_part") + tag, dot_i8_part_words(n + 1), &part));
         RET(c->tbuf(std::string("dot_i8_tot") + tag, dot_i8_tot_words(), &tot));
         bool ok = true;
-        for (u32 a0 = 0; a0 < na && ok; a0 += 16)
-            ok = launch_dot_batch_i8(c->dcrt, X + (size_t)a0 * 24 * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y, ldy, nb, n, yb, part, tot, od + (size_t)a0 * nb * 24, st, yb_pre != nullptr) == 0;
+        // a launch takes at most three vectors Y (their 72 digit rows fill its column tiles): the four matrices of a degree-three CCS (arith/ccs.rs:14-43) go in two
+        // groups of two (the 64-bit VALU kernel this shape used to fall back to took 4 x 1.03 ms of a 19.3 ms C4 step)
+        const u32 gsz = nb <= 3 ? nb : 2;
+        for (u32 b0 = 0; b0 < nb && ok; b0 += gsz)
+            for (u32 a0 = 0; a0 < na && ok; a0 += 16)
+                ok = launch_dot_batch_i8(c->dcrt, X + (size_t)a0 * 24 * ldx, ldx, na - a0 < 16 ? na - a0 : 16, Y + (size_t)b0 * 24 * ldy, ldy, nb - b0 < gsz ? nb - b0 : gsz, n, yb, part, tot,
+                                         od + (size_t)a0 * nb * 24, st, yb_pre != nullptr && nb <= 3, nb, b0) == 0;
         if (ok) return LF_OK;
     }
     launch_dot_batch(c->dcrt, X, ldx, na, Y, ldy, nb, n, dpart, od, st);
@@ -2508,6 +2532,11 @@ static int fold_impl(lf_ctx *c, Transcript &tr, SideState *S /* [2] */, u64 *lcc
             u64 *zb = sd ? zz1 : zz;
             launch_lincomb_z(c->dcrt, S[sd].z + zc_lo, n, K, d_zp + (size_t)sd * K * P.t, P.t, zc_hi - zc_lo, zb + zc_lo, st);   // (sharded: the columns the rank's rows of G read)
             // (a sharded rank evaluates and fixes only the entries [rank m/G, (rank+1) m/G) of the special tables until they are gathered: only those rows of G)
+            if (c->ccs_general) {
+                u64 *zaos;
+                RET(c->tbuf(sd ? "spmv_zaos_R" : "spmv_zaos_L", (size_t)P.t * n * 24, &zaos));
+                launch_spmv_rows(c->dcrt, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zb, (size_t)24 * n, n, zaos, G[sd], m, 0, st, g_r0, g_rcnt);
+            } else
             launch_spmv_sum(c->dcrt, P.t, c->d_rowptr.data(), c->d_col.data(), c->d_val.data(), zb, (size_t)24 * n, n, G[sd], m, st, g_r0, g_rcnt);
             launch_add_fhat_comb(c->dcrt, S[sd].planes, N, K, d_ap + (size_t)sd * K * 3, G[sd], m, st, g_r0, g_rcnt);
         }

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) k_dot_i8_sum(const int32_t *part, u32 chu
 
 // block = output (a, b, slot, comp), thread = (cz, digit u):  out[(a*nb + b)*24 + 3*slot + comp] = sum over (cz, cq) with cz + cq = comp (mod 3) of
 // nu^[cz+cq >= 3] * sum_{u,v} 256^(u+v) tot[slot, cz][u][a][(b, cq, v)]
-__global__ void __launch_bounds__(32) k_dot_i8_finish(const long long *tot, u32 na, u32 nb, u64 nu, u64 *out) {
+__global__ void __launch_bounds__(32) k_dot_i8_finish(const long long *tot, u32 na, u32 nb, u64 nu, u64 *out, u32 nb_out, u32 b0) {
     __shared__ u64 sm[24];
     const u32 o = blockIdx.x, t = threadIdx.x;
     const u32 comp = o % 3, slot = (o % 24) / 3, b = (o / 24) % nb, av = o / (24 * nb);
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(32) k_dot_i8_finish(const long long *tot, u32 
     if (t == 0) {
         u64 res = 0;
         for (int i = 0; i < 24; i++) res = fq_add(res, sm[i]);
-        out[o] = fq_canon(res);
+        out[((size_t)av * nb_out + b0 + b) * 24 + 3 * slot + comp] = fq_canon(res);   // (nb_out, b0: this launch's Y vectors are b0 .. b0 + nb - 1 of nb_out)
     }
 }
 
@@ -233,7 +233,8 @@ int launch_dot_pack_y(const u64 *X, const u64 *Y, size_t ldy, u32 nb, size_t n, 
     return 0;
 }
 int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
-                        long long *tot, u64 *out, hipStream_t s, bool y_packed) {
+                        long long *tot, u64 *out, hipStream_t s, bool y_packed, u32 nb_out, u32 b0) {
+    if (!nb_out) nb_out = nb;
     if (na < 1 || na > 16 || nb < 1 || nb > 3 || n < 64 || (ldx & 1) || (((size_t)X) & 7)) return -1;
     // a column slice that starts at an odd column (a rank's slice of a sharded step): start one column earlier (16-byte aligned loads) and
     // give that column zero digits on the Y side
@@ -251,7 +252,7 @@ int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const
     a.part = part;
     hipLaunchKernelGGL(k_dot_i8, dim3((unsigned)dcdiv(a.chunks, 4) * 24), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_dot_i8_sum, dim3(40, 24), dim3(256), 0, s, part, a.chunks, tot);
-    hipLaunchKernelGGL(k_dot_i8_finish, dim3(na * nb * 24), dim3(32), 0, s, tot, na, nb, t.nu, out);
+    hipLaunchKernelGGL(k_dot_i8_finish, dim3(na * nb * 24), dim3(32), 0, s, tot, na, nb, t.nu, out, nb_out, b0);
     return 0;
 }
 }  // namespace lf

@@ -79,6 +79,10 @@ void launch_spmv(const DevCrt &t, const u32 *rowptr, const u32 *col, const u64 *
 void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z,
                      size_t z_stride, size_t ldz, u64 *out, size_t m, hipStream_t s, size_t r0 = 0, size_t rcnt = (size_t)-1 /* all rows */);
 // q[col] = sum_{rows} eq[row] * val  (CSC: colptr over n columns, rowidx, val AoS)
+// general matrices (more than ~1.5 entries per row): block = 32 rows x 8 slots, z gathered as whole elements from an element-major copy (zaos: scratch of
+// nm * n * 24 words; z = nm plane-major vectors [24][n], z_stride words apart, or null when zaos holds the copies already).  out = (accumulate ? out : 0) + sum_j M_j z_j
+void launch_spmv_rows(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z, size_t z_stride, size_t n,
+                      u64 *zaos, u64 *out, size_t m, int accumulate, hipStream_t s, size_t r0 = 0, size_t rcnt = (size_t)-1);
 void launch_spmv_t_eq(const DevCrt &t, const u32 *colptr, const u32 *rowidx, const u64 *val, const u64 *eq, size_t m,
                       u64 *q, size_t n, hipStream_t s, size_t c0 = 0, size_t ccnt = (size_t)-1 /* all columns */);
 // dots: out[a][b] = sum_i X_a[i] (.) Y_b[i] (ring tables, slot-wise), a < na, b < nb -> out AoS [na][nb][24]
@@ -111,7 +115,9 @@ size_t dot_i8_yb_bytes(size_t n);
 size_t dot_i8_part_words(size_t n);
 size_t dot_i8_tot_words();
 int launch_dot_batch_i8(const DevCrt &t, const u64 *X, size_t ldx, u32 na, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, int32_t *part,
-                        long long *tot, u64 *out, hipStream_t s, bool y_packed = false);
+                        long long *tot, u64 *out, hipStream_t s, bool y_packed = false, u32 nb_out = 0, u32 b0 = 0);
+// (nb_out, b0: the nb vectors Y are vectors b0 .. b0 + nb - 1 of a set of nb_out -- outputs land at (a * nb_out + b0 + b) -- so that a set of more than three is
+// run in groups; 0 = nb)
 // the Y digits alone, for launch_dot_batch_i8(.., y_packed = true) calls on X vectors of the same alignment
 int launch_dot_pack_y(const u64 *X, const u64 *Y, size_t ldy, u32 nb, size_t n, unsigned char *YB, hipStream_t s);
 void launch_vs_combine(const u64 *vs /* [K][72] */, u32 K, u64 *v /* [72] */, hipStream_t s);   // v = sum_k 2^k v_s[k]

@@ -642,6 +642,56 @@ void launch_spmv_sum(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u3
     for (u32 j = 0; j < nm && j < 4; j++) { ms.rowptr[j] = rowptr[j]; ms.col[j] = col[j]; ms.val[j] = val[j]; ms.z[j] = z + (size_t)j * z_stride; }
     LF_LAUNCH(k_spmv_sum, t.nu2p40, dim3(cdiv(rcnt, 256), 8), dim3(256), s, t, ms, ldz, out, m, r0, rcnt);
 }
+// General matrices (several entries per row at arbitrary columns, ring-valued entries: arith/utils.rs:52-65 as a real CSR SpMV).  k_spmv / k_spmv_sum above are the
+// shape of the reference's bench matrices (one entry per row, neighbouring rows at neighbouring columns): thread = (row, one slot per block), z plane-major.  With k
+// entries per row at random columns that mapping reads 24 bytes out of every 192-byte entry, eight blocks over, and gathers every word of z from a line of its
+// own: 4.84 ms per k_spmv_sum at 2^18 rows x 16 entries (0.7 TB/s of useful bytes).  Here block = 32 rows x 8 slots, the slots of a row side by side: a wave reads
+// eight whole entries as one 1.5 KB run and gathers z as whole 192-byte ELEMENTS from an element-major copy zaos [n][24] (launch_soa_to_aos, once per vector);
+// the sums cross LDS so that the stores are runs of 32 rows per output plane.  out = (accumulate ? out : 0) + sum_{j<nm} M_j z_j.
+struct SpmvRowsSet { const u32 *rowptr[4]; const u32 *col[4]; const u64 *val[4]; const u64 *zaos[4]; u32 nm; };
+template <bool NU>
+__global__ void __launch_bounds__(256) k_spmv_rows(DevCrt t, SpmvRowsSet ms, u64 *out, size_t m, int accumulate, size_t r0, size_t rcnt) {
+    const u32 rl = threadIdx.x >> 3, slot = threadIdx.x & 7;
+    const size_t rb = r0 + (size_t)blockIdx.x * 32, row = rb + rl;
+    __shared__ u64 sm[24][33];
+    Fq3 acc = fq3_zero();
+    if (row < r0 + rcnt) {
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) {
+            if (j < ms.nm) {
+                const u32 *rp = ms.rowptr[j], *cl = ms.col[j];
+                const u64 *za = ms.zaos[j] + 3 * slot;
+                for (u32 k = rp[row]; k < rp[row + 1]; k++) {
+                    const u64 *v = ms.val[j] + (size_t)k * 24 + 3 * slot, *zz = za + (size_t)cl[k] * 24;
+                    acc = fq3_add(acc, M3<NU>(fq3_make(v[0], v[1], v[2]), fq3_make(zz[0], zz[1], zz[2]), t.nu));
+                }
+            }
+        }
+    }
+    sm[3 * slot][rl] = acc.c[0]; sm[3 * slot + 1][rl] = acc.c[1]; sm[3 * slot + 2][rl] = acc.c[2];
+    __syncthreads();
+    for (u32 o = threadIdx.x; o < 24 * 32; o += 256) {
+        const u32 pl = o >> 5, rr = o & 31;
+        if (rb + rr < r0 + rcnt) {
+            u64 *dst = out + (size_t)pl * m + rb + rr;
+            *dst = accumulate ? fq_add(*dst, sm[pl][rr]) : sm[pl][rr];
+        }
+    }
+}
+// z: nm vectors [24][ldz] plane-major, z_stride words apart (n columns each); zaos: scratch of nm * n * 24 words
+void launch_spmv_rows(const DevCrt &t, u32 nm, const u32 *const *rowptr, const u32 *const *col, const u64 *const *val, const u64 *z, size_t z_stride, size_t n,
+                      u64 *zaos, u64 *out, size_t m, int accumulate, hipStream_t s, size_t r0, size_t rcnt) {
+    if (rcnt == (size_t)-1) { r0 = 0; rcnt = m; }
+    if (!rcnt || !nm) return;
+    SpmvRowsSet ms = {};
+    ms.nm = nm;
+    for (u32 j = 0; j < nm && j < 4; j++) {
+        u64 *za = zaos + (size_t)j * n * 24;
+        if (z) launch_soa_to_aos(z + (size_t)j * z_stride, za, n, s);        // (z null: zaos holds the element-major copies already)
+        ms.rowptr[j] = rowptr[j]; ms.col[j] = col[j]; ms.val[j] = val[j]; ms.zaos[j] = za;
+    }
+    LF_LAUNCH(k_spmv_rows, t.nu2p40, dim3(cdiv(rcnt, 32)), dim3(256), s, t, ms, out, m, accumulate, r0, rcnt);
+}
 // block = 32 columns x 8 slots, the slots of a column side by side: a wave reads the 24 coefficient words of eight non-zeros as one contiguous 1.5 KB run (with
 // thread = column and one slot per block a load instruction touched 64 cache lines for 24 bytes each, eight blocks re-reading them: 63 us for 100 MB at 2^18
 // columns), the eq words of a row once for its eight slots; the sums cross LDS so that the stores are runs of 32 columns per output row.
