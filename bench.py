@@ -441,6 +441,8 @@ def main():
     ap.add_argument("--no-ajtai", action="store_true", help="skip the reference's Ajtai bench rows (commit_ntt at benches/config.toml:715 / :670; an extra key, not part of the metric)")
     ap.add_argument("--chain", type=int, default=8, help="steps of the chained-folding extra key `ivc` (every step ingests and commits a new witness and folds it into the "
                                                          "carried accumulator; run for the bench workload and for C2); 0 = skip")
+    ap.add_argument("--no-shard-model", action="store_true", help="skip the extra key `shard_model` (N=1: the predicted per-rank ms of --gpus 2/4/8 --parallelism shard, "
+                                                                  "latticefold_amd/shard_model.py: rank 0 measured with the model transport + assumed xGMI terms)")
     ap.add_argument("--no-lfplus", action="store_true", help="skip the LatticeFold+ PlusProver::prove timing (an extra key, not part of the metric)")
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in throughput mode: S independent fold streams per GPU (S contexts driven by S host threads); every "
@@ -633,17 +635,10 @@ def main():
                 box["r"] = measure(True)
             except BaseException as e:      # noqa: BLE001 -- anything: the fallback decides
                 box["e"] = repr(e)
-        dbg = os.environ.get("LF_BENCH_DEBUG")
-        if dbg:
-            import faulthandler
-            faulthandler.dump_traceback_later(float(dbg), exit=False)
-            print(f"[bench rank {rank}] sharded attempt starts", file=sys.stderr, flush=True)
         th = threading.Thread(target=_run_shard, daemon=True)
         th.start()
         th.join(float(os.environ.get("LF_SHARD_TIMEOUT", "420")))
         ok_here = (not th.is_alive()) and "r" in box
-        if dbg:
-            print(f"[bench rank {rank}] sharded attempt: alive={th.is_alive()} ok={ok_here} err={box.get('e')}", file=sys.stderr, flush=True)
         all_ok = ok_here
         try:      # agreement over the rendezvous store -- through a client connection of its own: the process group's client may be blocked inside the stuck measurement
             from datetime import timedelta
@@ -685,7 +680,7 @@ def main():
                 box["r"] = {"op": "PlusProver::prove", "runs": None, "note": f"failed: {e!r}"}
         th = threading.Thread(target=_run, daemon=True)
         th.start()
-        th.join(float(os.environ.get("LF_LFPLUS_TIMEOUT", "240")))
+        th.join(240.0)
         lfplus_sharded = box.get("r", {"op": "PlusProver::prove", "runs": None, "note": "timed out (watchdog): dropped"})
         if th.is_alive():      # a stuck collective: nothing after this point may touch the process group again
             if rank == 0:
@@ -841,6 +836,12 @@ def main():
             out["ivc"] = [ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3)]
             if wl.name != "C2" and wl.ring == "goldilocks":
                 out["ivc"].append(ivc_extra("C2", args.chain, local_rank))
+        if world == 1 and not args.no_shard_model and args.streams == 1 and args.ccs == "r1cs" and wl.ring == "goldilocks":
+            try:   # the prediction the driver's SCALE run (strong scaling of ONE fold stream) can be checked against
+                from latticefold_amd.shard_model import model_summary
+                out["shard_model"] = model_summary(wl, (2, 4, 8), steps=4, warmup=2, device=local_rank, base_ms=elapsed / args.steps * 1e3)
+            except Exception as e:
+                out["shard_model"] = {"note": f"failed: {e!r}"}
         if world == 1 and not args.no_lfplus:
             try:
                 out["lfplus"] = lfplus_extra()

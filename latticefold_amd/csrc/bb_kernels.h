@@ -116,34 +116,6 @@ void launch_lin_r1cs(const DevBb &t, const fe *mz, size_t ld, const fe *eq, size
 void launch_lin_small(const DevBb &t, const LinDesc &desc, const fe *mz_prev, size_t ld_prev, const fe *eq_prev, size_t ldeq_prev, size_t n_prev, const E9PreC &r, fe *mz_out, size_t ld_out,
                       fe *eq_out, size_t ldeq_out, u32 deg, u64 *out, hipStream_t s);
 
-// ---- persistent tails of the two sumchecks (no launch and no stream synchronisation per round; the Goldilocks twins are lf::k_lin_tail / k_fold_tail) ----------------
-// Host-mapped mailbox (hipHostMallocMapped).  GPU -> host: the message of tail round i, each workgroup its own rows, valid once all msg_seq[i][..] == epoch;
-// host -> GPU: the challenge answering tail round i (ready-made E9PreC words), valid once chal_seq[i] == epoch.  Every wait on either side is bounded by a wall-clock
-// timeout (err / abort_seq), so a lost partner cannot hang the other.
-constexpr u32 BB_TAIL_MAX_ROUNDS = 32;
-constexpr u32 BB_TAIL_MAX_GROUPS = 64;       // workgroups that report per round (linearization: the 8 slots; folding: 8 slots x table chunks)
-struct BbTailMail {
-    u64 msg[BB_TAIL_MAX_ROUNDS][5 * RE];                  // linearization tail: the message itself (canonical words, rows X)
-    long long part[BB_TAIL_MAX_ROUNDS][BB_TAIL_MAX_GROUPS][5 * TAU];   // folding tail: per-workgroup sums (Montgomery words, added and reduced by the host)
-    u32 msg_seq[BB_TAIL_MAX_ROUNDS][BB_TAIL_MAX_GROUPS];
-    int32_t chal[BB_TAIL_MAX_ROUNDS][2 * TAU + 2];
-    u32 chal_seq[BB_TAIL_MAX_ROUNDS];
-    u32 abort_seq;                                        // host: = epoch to make the kernel give up
-    u32 err;                                              // device: = epoch when a wait timed out
-};
-struct BbLinTailArgs {     // R1CS shape only (k_lin_r1cs is its per-round form)
-    const fe *mz;          // Mz tables [3][72][ld] of the round BEFORE the tail, n0 entries
-    const fe *eq;          // eq table [9][ldeq] of that round
-    size_t ld, ldeq, n0;
-    u32 rounds;            // tail rounds; tail round j works on n0 >> (j + 1) entries
-    E9PreC r_first;        // challenge answering the round before the tail
-    fe *work[2];           // [3][72][n0 / 2] each: the fixed tables, ping-pong (the rows of a slot belong to that slot's workgroup)
-    fe *eqw[2];            // [8][9][n0 / 2] each: private fixed eq tables of the workgroups
-    BbTailMail *mail;      // device address of the mailbox
-    u32 epoch;             // > 0, different for every launch
-};
-void launch_lin_tail(const DevBb &t, const BbLinTailArgs &A, hipStream_t s);
-
 struct FoldArgs {
     const fe *eqL, *eqR, *eqB;   // fq9 tables [9][ld]
     const fe *G1, *G2;           // ring tables [72][ld]
@@ -174,8 +146,6 @@ void launch_fold_round_fix(const DevBb &t, const FoldArgs &a, const fe *Fprev, s
 // rounds 3 / 4 straight from the coefficient planes through the 81-entry digit look-up table (build_fold_lut, device copy lut_dev):
 // round 3 touches no table, round 4 fixes with r3 and writes the m/8-entry tables
 void build_fold_lut(const H9 &r1, const H9 &r2, const BbHostRing &ring, fe *lut_host /* 81 * 9 */);
-void launch_fold_round_lut(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
-                           u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);
 // round 3 with per-table products M_tb * {value, value^2, value^3} of the look-up values (mutab_dev: 3 * 2K*9 * 81 * 12 words, filled here)
 void launch_fold_round_lut_mu(const DevBb &t, const FoldArgs &a, const int32_t *planesL, const int32_t *planesR, size_t n_planes, const fe *lut_dev,
                               fe *mutab_dev, u32 K, const E9PreC *Mpre, i64 *partial, u64 *out, hipStream_t s);

@@ -9,7 +9,8 @@
 //     Rot(f_k) a (24 N) x (24 (K-1)) int8 matrix, the product an exact int32 GEMM per column chunk;
 //   * y = sum_u 2^(8u) (C[(i,u)] + 128 * colsum) mod p, once per output (k_ajtai_i8_reduce), then one CRT of kappa (K-1) elements.
 // kappa = 26, K = 16 at 2^20 columns: 208 x 360 outputs, 1.9e12 int8 MACs per decomposition instead of 1.6e10 lazy 64 x 64 MACs on the
-// quarter-rate integer multiplier (k_ajtai: 7.1 ms, VALU-issue-bound).  No bit-plane NTTs are needed either (k_bitplane_crt).
+// quarter-rate integer multiplier (the 64-bit VALU kernel of rounds 1-3 took 7.1 ms, issue-bound; removed in round 6).  No bit-plane NTTs are needed either.
+// General vectors (commit_ntt, Witness::commit) take the same byte planes of A through lf_ajtai_i8g.hip.
 //
 // Operands.  A is repacked ONCE per matrix (k_ajtai_pack_i8) into MFMA operand order, so a tile of 8 columns (192 inner elements =
 // 3 K-steps of 64) is one contiguous block copied to LDS.  Rot(f) is never materialised: X^c_in * f is Toeplitz in (c_out - c_in) apart
@@ -1248,8 +1249,7 @@ int launch_ajtai_i8(const AjtaiI8Ring &R, const unsigned char *Ab, u32 MT, const
     if ((R.RD != 24 && R.RD != 72) || kappa > ajtai_i8_max_rows(R) || R.NL * kappa > 16 * MT || MT > 13 || NP > ajtai_i8_max_planes_mt(R, MT) || NP == 0 || nwg == 0) return -1;
     static const bool prof = getenv("LF_I8_PROF") != nullptr;
     static const int cw = getenv("LF_I8_COUPLE_W") ? atoi(getenv("LF_I8_COUPLE_W")) : 4;      // window of the pair coupling in tiles (0 switches the coupling off)
-    static const int ce_env = getenv("LF_I8_COUPLE_E") ? atoi(getenv("LF_I8_COUPLE_E")) : 4;  // the handshake runs every ... tiles
-    const u32 ce = ce_env >= 8 ? 8u : (ce_env >= 4 ? 4u : (ce_env >= 2 ? 2u : 1u));
+    const u32 ce = 4;      // the handshake runs every 4 tiles (measured: every tile costs 0.1 ms per launch, every 8 lets the pair drift out of the L2)
     // The specialised-wave kernels: the 13-row-tile shape of the 24-ring (k_ajtai_i8s) and the 4-row-tile shape of the 72-ring (k_ajtai_i8x).  Plane groups of 8;
     // two groups = paired workgroups on one XCD, coupled through an L2 counter (i8s_build).  Every workgroup of the grid must be resident for the coupling to make
     // progress: at most one per CU.

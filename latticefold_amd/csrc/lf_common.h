@@ -58,8 +58,8 @@ struct DevBuf {
     }
 };
 
-// process-wide serial number of witnesses: a handle that was freed and whose address a later witness reuses is a DIFFERENT witness (lf_prefetch_instance
-// recognises the witness it prepared by pointer and serial number)
+// process-wide serial number of witnesses: a handle that was freed and whose address a later witness reuses is a DIFFERENT witness (caches keyed
+// by a witness -- the bit-plane form a step builds -- compare pointer and serial number)
 inline uint64_t lf_next_witness_id() {
     static std::atomic<uint64_t> next{1};
     return next.fetch_add(1, std::memory_order_relaxed);
@@ -71,8 +71,8 @@ struct lf_witness {
     int device;          // device the planes live on
     size_t plane_bytes;  // size of the planes allocation (pool key)
     uint64_t id = lf_next_witness_id();
-    // Witness::from_f (arith.rs:299-313) also builds f (NTT form) and w_ccs: a fold step materialises both behind compute_f_0 (LF_LAZY_FROM_F=1: on demand, in
-    // lf_witness_get_f / _get_w_ccs); device buffers from the same pool as the planes, null when not materialised
+    // Witness::from_f (arith.rs:299-313) also builds f (NTT form) and w_ccs: a fold step materialises both behind compute_f_0; witnesses made by
+    // lf_witness_from_* build them on demand (lf_witness_get_f / _get_w_ccs); device buffers from the same pool as the planes, null when not materialised
     uint64_t *f_ntt = nullptr;
     size_t f_bytes = 0;
     uint64_t *w_ccs = nullptr;
@@ -89,7 +89,7 @@ int lf_ctx_device(const lf_ctx *ctx);
 // Test/diagnostic switches of the fold-step driver (environment variables): read ONCE at the start of every
 // lf_linearize / lf_fold_step call -- never inside the round loops.
 struct Tunables {
-    bool lin_u_eval = false, fold_unfused = false, fold_no_lut = false, fold_tab_r1 = false, fold_no_mutab = false, theta_eval = false, fold_no_r4tab = false, fold_no_r5tab = false, lin_unfused = false;
+    bool lin_u_eval = false, fold_unfused = false, fold_no_lut = false, fold_tab_r1 = false, theta_eval = false, fold_no_r4tab = false, fold_no_r5tab = false;
     bool fold_rounds_no_split = false;   // LF_FOLD_ROUNDS_NO_SPLIT: the large table rounds (k_fold_round modes 1, 6, 7) evaluate all five points themselves (four lazy products per table)
     bool fold_sv_no_split = false;    // LF_FOLD_SV_NO_SPLIT: GEMM rounds against the digits of eqB(2p), eqB(2p+1) (three column tiles) instead of the per-pair E_i[p] (two)
     bool lin_no_split = false;        // LF_LIN_NO_SPLIT: linearization rounds on the full eq table (k_lin_round evaluates every point) instead of the split form
@@ -103,22 +103,11 @@ struct Tunables {
     size_t shard_lin_min = 16384;    // LF_SHARD_LIN_MIN: a sharded linearization sumcheck hands over to the replicated rounds once its tables have this many entries or fewer
                                      // (a round there is a ~30 us launch: an exchange costs as much as it saves); never above m / 16
     size_t shard_fold_min = 2048;    // LF_SHARD_FOLD_MIN: the same for the folding sumcheck (96 tables per entry: rounds stay worth sharding down to the persistent tail's size)
-    bool coef_valu = false;          // LF_COEF_VALU: v / v_s / theta evaluations of the digit planes on the VALU kernel (k_coef_eval) instead of the matrix cores
     long i8_wgs = 0;                 // LF_I8_WGS: workgroups of the int8 commit kernel (0: one per CU)
-    bool evals_one_stage = true;     // LF_EVALS_TWO_STAGES=1: the right evaluations of a fold step in two downloads (the absorb of the first half overlaps the second half's inner products)
-    bool fold_r5_one_lane = false;   // LF_FOLD_R5_ONE_LANE: (BabyBear) round 5 from the planes with one thread per pair (k_fold_round mode 7, split form) instead of two lanes per pair
-    bool bb_lin_tail = false;        // LF_BB_LIN_TAIL: (BabyBear) persistent kernel for the small linearization rounds (k_lin_tail)
-    bool bb_evals_first = false;     // LF_BB_EVALS_FIRST: (BabyBear) lane 1 runs the left evaluations before the left commit
     bool lin_no_r1cs = false;        // LF_LIN_NO_R1CS: (BabyBear) the R1CS shape through the generic linearization round kernel
     bool lin_no_small = false;       // LF_LIN_NO_SMALL: (BabyBear) small linearization rounds as separate fix / round / reduce launches
-    bool fold_no_small = false;      // LF_FOLD_NO_SMALL: (BabyBear) small folding rounds without the fused fix / in-block table split
-    bool prep_one_stream = false;    // LF_PREP_ONE_STREAM: both sides of fold prepare on one stream
     size_t dot_min = 4096;           // LF_DOT_MIN: columns from which the int8 form of the inner products is used
-    bool coef_planes = false;        // LF_COEF_PLANES: v_s of a fold step from the int32 planes (k_coef_eval_i8) instead of the bit planes (launch_sv_vs)
     bool dot_valu = false;           // LF_DOT_VALU: u_s / eta inner products on the 64-bit VALU kernel (k_dot_batch) instead of the int8 matrix cores
-    unsigned lin_vs_back = 6;        // LF_LIN_VS_BACK: the early v_s pass of the linearization starts after round s - this (2^this blocks of partial sums)
-    bool lin_vs_whole = false;       // LF_LIN_VS_WHOLE: the linearization's v_s evaluations in one piece after the last round (no early pass over the witness)
-    bool lin_v_direct = false;       // LF_LIN_V_DIRECT: v of the linearization from the full coefficients instead of sum_k 2^k v_s[k]
     bool fold_no_sv = false;         // LF_FOLD_NO_SV: rounds 1-3 of the folding sumcheck on the VALU kernels instead of the int8 matrix-core GEMMs (lf_sv_rounds.hip)
     size_t sv_min = 65536;           // LF_FOLD_SV_MIN: pairs of a round from which the GEMM form is used
     int sv_rounds = 3;               // LF_FOLD_SV_ROUNDS: last round in GEMM form (1..3)
@@ -126,7 +115,6 @@ struct Tunables {
     size_t fuse_min = 16384, lut_min = (size_t)1 << 17, tab_min = 16384;
     size_t r5_min = 8192;            // LF_FOLD_R5_MIN: pairs of round 5 from which it runs on the planes (mode 7; measured: 2^16 rows slower, 2^20 faster)
     size_t tail_n = 2048;            // LF_TAIL_N: table entries from which the persistent tail kernel takes over
-    long lin_blocks = -1;            // -1: automatic
     static Tunables read(size_t lut_min_default) {
         Tunables t;
         t.lut_min = lut_min_default;
@@ -135,10 +123,8 @@ struct Tunables {
         t.fold_unfused = getenv("LF_FOLD_UNFUSED") != nullptr;
         t.fold_no_lut = getenv("LF_FOLD_NO_LUT") != nullptr;
         t.fold_tab_r1 = getenv("LF_FOLD_TAB_R1") != nullptr;
-        t.fold_no_mutab = getenv("LF_FOLD_NO_MUTAB") != nullptr;
         t.fold_no_r4tab = getenv("LF_FOLD_NO_R4TAB") != nullptr;
         t.fold_no_r5tab = getenv("LF_FOLD_NO_R5TAB") != nullptr;
-        t.lin_unfused = getenv("LF_LIN_UNFUSED") != nullptr;
         t.lin_no_split = getenv("LF_LIN_NO_SPLIT") != nullptr;
         t.fold_sv_no_split = getenv("LF_FOLD_SV_NO_SPLIT") != nullptr;
         t.fold_rounds_no_split = getenv("LF_FOLD_ROUNDS_NO_SPLIT") != nullptr;
@@ -147,24 +133,13 @@ struct Tunables {
         t.theta_eval = getenv("LF_THETA_EVAL") != nullptr;
         t.no_tail = getenv("LF_NO_TAIL") != nullptr;
         t.fold_no_sv = getenv("LF_FOLD_NO_SV") != nullptr;
-        t.lin_v_direct = getenv("LF_LIN_V_DIRECT") != nullptr;
-        t.lin_vs_whole = getenv("LF_LIN_VS_WHOLE") != nullptr;
-        if ((e = getenv("LF_LIN_VS_BACK"))) t.lin_vs_back = (unsigned)atoi(e);
         t.dot_valu = getenv("LF_DOT_VALU") != nullptr;
-        t.coef_planes = getenv("LF_COEF_PLANES") != nullptr;
         if ((e = getenv("LF_DOT_MIN"))) t.dot_min = (size_t)atoll(e);
-        t.prep_one_stream = getenv("LF_PREP_ONE_STREAM") != nullptr;
         t.lin_no_small = getenv("LF_LIN_NO_SMALL") != nullptr;
         t.lin_no_r1cs = getenv("LF_LIN_NO_R1CS") != nullptr;
-        t.bb_evals_first = getenv("LF_BB_EVALS_FIRST") != nullptr;
-        t.bb_lin_tail = getenv("LF_BB_LIN_TAIL") != nullptr;
-        t.fold_r5_one_lane = getenv("LF_FOLD_R5_ONE_LANE") != nullptr;
-        t.fold_no_small = getenv("LF_FOLD_NO_SMALL") != nullptr;
         if ((e = getenv("LF_FOLD_SV_MIN"))) t.sv_min = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_SV_ROUNDS"))) t.sv_rounds = atoi(e);
-        t.coef_valu = getenv("LF_COEF_VALU") != nullptr;
         if ((e = getenv("LF_I8_WGS"))) t.i8_wgs = atol(e);
-        t.evals_one_stage = getenv("LF_EVALS_TWO_STAGES") == nullptr;
         if ((e = getenv("LF_SHARD_TWO_LANES"))) t.shard_two_lanes = atoi(e) != 0;
         if ((e = getenv("LF_SHARD_LIN_MIN"))) t.shard_lin_min = (size_t)atoll(e);
         if ((e = getenv("LF_SHARD_FOLD_MIN"))) t.shard_fold_min = (size_t)atoll(e);
@@ -174,7 +149,6 @@ struct Tunables {
         if ((e = getenv("LF_FOLD_FUSE_MIN"))) t.fuse_min = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_LUT_MIN"))) t.lut_min = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_TAB_MIN"))) t.tab_min = (size_t)atoll(e);
-        if ((e = getenv("LF_LIN_BLOCKS"))) t.lin_blocks = atol(e);
         if ((e = getenv("LF_TAIL_N"))) t.tail_n = (size_t)atoll(e);
         if ((e = getenv("LF_FOLD_R5_MIN"))) t.r5_min = (size_t)atoll(e);
         return t;

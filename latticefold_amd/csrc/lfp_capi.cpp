@@ -197,7 +197,7 @@ static Plan plan_for(u64 n, u32 kappa, u32 k) {
     // phase 1 is register-bound at 2 waves / SIMD (176 VGPRs for 2 rows x 4 digit planes): two blocks per CU = 512 blocks (measured
     // best of 512 / 768 / 1024, LFP_BLOCKS1 overrides), and not below 128 rows per block (a block's partial sums are k*kappa*256 words:
     // fewer, longer blocks keep that traffic well under the input's)
-    static const long env1 = getenv("LFP_BLOCKS1") ? atol(getenv("LFP_BLOCKS1")) : 0, env2 = getenv("LFP_BLOCKS2") ? atol(getenv("LFP_BLOCKS2")) : 0;
+    constexpr long env1 = 0, env2 = 0;   // (blocks of the two phases: the defaults below)
     u64 J = (n + 511) / 512;
     if (J < 128) J = 128;
     if (env1 > 0) J = (n + env1 - 1) / env1;
@@ -343,7 +343,7 @@ extern "C" int lfplus_join_async(lfplus_ctx *c) { if (!c) return LFPLUS_E_ARG; f
 extern "C" int lfplus_rg_from_f_async(lfplus_ctx *c, uint64_t b, uint32_t k, uint32_t l) {
     int rc = check_params(c, b, k, l);
     if (rc) return rc;
-    if (c->sharded() || !c->st2 || !c->ev_ff || getenv("LFPLUS_NO_ASYNC_FROM_F")) return LFPLUS_OK;
+    if (c->sharded() || !c->st2 || !c->ev_ff) return LFPLUS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     ff_join(c);
     c->have = false;

@@ -129,7 +129,6 @@ struct LfpPool {
         size_t got = 0;
         if (void *q = LfpDevCache::inst().take(device, bytes, &got)) { blks.push_back({q, got, true}); return q; }
         void *p = nullptr;
-        if (getenv("LFPLUS_POOL_TRACE")) fprintf(stderr, "[lfplus pool] miss %zu bytes (%zu blocks held)\n", bytes, blks.size());
         if (hipMalloc(&p, bytes) != hipSuccess) {      // out of memory: drop the idle blocks (the process-wide cache first) and retry once
             LfpDevCache::inst().trim(device);
             if (hipMalloc(&p, bytes) != hipSuccess) {

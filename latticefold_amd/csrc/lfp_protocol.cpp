@@ -608,7 +608,7 @@ int set_check_dev(lfplus_ctx *c, lfplus_transcript *tr, u32 nvars, const std::ve
     LFP_MARK(c, "set check: eq(r), M^T eq(r)");
     u64 *ed = so.small.as<u64>(), *bd = ed + (size_t)(1 + nM) * nmat * ncols * D;
     // every weight table scalar (eq(r) always is; the w_q when the M_q have constant coefficients) and 16 columns: the exponent-histogram pass, four tables at a time
-    const bool hist = ncols == 16 && (nM == 0 || so.wscalar) && !getenv("LFPLUS_NO_HIST");
+    const bool hist = ncols == 16 && (nM == 0 || so.wscalar);
     for (u32 i = 0; i < nmat; i++) {
         if (hist) {
             std::vector<const u64 *> wt(1 + nM);

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_sc_round(const u64 *tab, size_t ld, siz
     block_sum4(s, part + (size_t)blockIdx.x * 4);
 }
 u32 sc_round_max_blocks() {      // (4 words of partial sums per block for the host: the cap is about occupancy; LFPLUS_SC_BLOCKS moves it)
-    static const u32 cap = [] { const char *e = getenv("LFPLUS_SC_BLOCKS"); const long v = e ? atol(e) : 0; return (u32)(v >= 1 && v <= 65535 ? v : 2048); }();
+    constexpr u32 cap = 2048;
     return cap;
 }
 // returns the number of blocks = rows of part[.][4]
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(1024) k_sum_parts_q(const u64 *part, u32 chunk
 }
 // (256 blocks = one wave per SIMD: the passes were latency-bound; LFPLUS_EVAL_CHUNKS moves the cap)
 u32 eval_chunks(size_t n) {
-    static const size_t cap = [] { const char *e = getenv("LFPLUS_EVAL_CHUNKS"); const long v = e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 65535 ? v : 1024); }();
+    constexpr size_t cap = 1024;
     size_t b = cdiv(n, 256);
     return (u32)(b < 1 ? 1 : (b > cap ? cap : b));
 }
@@ -712,7 +712,7 @@ void launch_cm_round_fused(const u64 *S, size_t lds, const u64 *R, size_t ldr, s
 // workgroups of a sumcheck round (16 pairs per workgroup and pass; up to 2048: one per CU leaves a memory-bound round at 1/3 of the HBM rate).  Above 256 the
 // driver adds the block partials on the device (launch_reduce) instead of on the host.  LFPLUS_ROUND_BLOCKS moves the cap
 u32 cm_round_blocks(size_t half) {
-    static const size_t cap = [] { const char *e = getenv("LFPLUS_ROUND_BLOCKS"); const long v = e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 65535 ? v : 2048); }();
+    constexpr size_t cap = 2048;
     size_t b = cdiv(half, 16);
     return (u32)(b < 1 ? 1 : (b > cap ? cap : b));
 }

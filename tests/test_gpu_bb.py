@@ -220,7 +220,7 @@ def test_linearization_kernel_forms_agree(ctx, name, monkeypatch):
     else:
         wl, inst, A, f_coeff, wit, cccs, acc_g, linpr_g, acc_o, linpr_o = run_both(ctx, name, 5)
     assert (linpr_g == linpr_o).all() and (acc_g == acc_o).all()
-    for env in ({"LF_LIN_NO_R1CS": "1"}, {"LF_LIN_NO_R1CS": "1", "LF_LIN_NO_SMALL": "1"}, {"LF_BB_LIN_TAIL": "1"}):   # (the last: persistent kernel + host mailbox, k_lin_tail)
+    for env in ({"LF_LIN_NO_R1CS": "1"}, {"LF_LIN_NO_R1CS": "1", "LF_LIN_NO_SMALL": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         acc_e, linpr_e = api.LFLinearizationProver.prove(ctx, cccs, wit, tr_new())
@@ -331,12 +331,9 @@ def test_fold_step_split_table_rounds_match_oracle(ctx, name, monkeypatch):
     lc_o, f0_o, proof_o = inst.fold_step(lfo.Transcript(), A, acc_o, f_coeff, cccs, f_coeff)
     m = 1 << wl.s
     base = {"LF_FOLD_LUT_MIN": "1", "LF_FOLD_FUSE_MIN": "4", "LF_FOLD_SPLIT_MIN": "1"}
-    r5_ok = wl.s >= 5 and wl.N % 4 == 0 and m // 32 >= 1
-    # (round 5 from the planes: two lanes per pair and unsplit by default -- k_fold_round5_2l --, the one-thread split form with LF_FOLD_R5_ONE_LANE=1)
-    one = {"LF_FOLD_R5_MIN": "1", "LF_FOLD_R5_ONE_LANE": "1"}
-    cases = [({}, 0b01000), ({"LF_FOLD_R5_MIN": "1"}, 0b01000), (one, 0b11000 if r5_ok else 0b01000), (dict(one, LF_FOLD_SV_MIN="64"), 0b11000 if r5_ok else 0b01000),
-             (dict(one, LF_FOLD_NO_SV="1"), 0b11000 if r5_ok else 0b01000), ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_SV_MIN": "64"}, 0b01000),
-             ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"}, 0), (dict(one, LF_FOLD_ROUNDS_NO_SPLIT="1"), 0), ({"LF_FOLD_NO_R4TAB": "1"}, 0)]
+    # (round 5 from the planes: two lanes per pair, unsplit -- k_fold_round5_2l)
+    cases = [({}, 0b01000), ({"LF_FOLD_R5_MIN": "1"}, 0b01000), ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_SV_MIN": "64"}, 0b01000),
+             ({"LF_FOLD_R5_MIN": "1", "LF_FOLD_ROUNDS_NO_SPLIT": "1"}, 0), ({"LF_FOLD_NO_R4TAB": "1"}, 0)]
     for extra, want in cases:
         env = dict(base, **extra)
         for k, v in env.items():

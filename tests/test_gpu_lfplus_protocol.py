@@ -183,7 +183,8 @@ def test_cm_prove_unfused_fix_matches_oracle(L, nM, kappa, nvars, all_tables, mo
 @pytest.mark.parametrize("L,nM,kappa,nvars", [(1, 1, 2, 15), (2, 2, 2, 15), (3, 1, 3, 16), (3, 3, 2, 15)])
 def test_cm_prove_dense_tables_match_oracle(L, nM, kappa, nvars, monkeypatch):
     """By default the batched sumcheckers read m_tau as exponent bytes and the M_q tau as scalars when every M_q has constant coefficients (k_cm_combine_c,
-    launch_cm_evals_c; the default form is test_cm_prove_matches_oracle above); LFPLUS_CM_DENSE=1 (read per call) materialises every table as ring elements."""
+    launch_cm_evals_c; the default form is test_cm_prove_matches_oracle above); LFPLUS_CM_DENSE=1 (read per call) materialises every table as ring elements --
+    the form a sharded prove and shapes beyond the compact form's limits (L > 8, more than 64 tables) run."""
     monkeypatch.setenv("LFPLUS_CM_DENSE", "1")
     monkeypatch.delenv("LFPLUS_CM_FULL", raising=False)
     monkeypatch.delenv("LFPLUS_CM_UNFUSED", raising=False)

@@ -14,33 +14,19 @@ SRC = os.path.join(ROOT, "latticefold_amd", "csrc")
 EXTRA = {
     "LFPLUS_CACHE_GB": "cap of the per-device scratch cache destroyed LatticeFold+ contexts leave behind (default min(32 GB, 1/4 of HBM))",
     "LFPLUS_CM_DENSE": "Cm::prove keeps every instance table as ring elements (no compact exponent-byte / scalar tables)",
-    "LFPLUS_EVAL_CHUNKS": "blocks of the set check's evaluation passes",
-    "LFPLUS_NO_ASYNC_FROM_F": "lfplus_rg_from_f_async becomes a no-op (from_f runs inside lfplus_mlin)",
-    "LFPLUS_NO_HIST": "Step-3 evaluations of the set check with one weight table at a time (k_wmono) instead of the exponent-histogram pass (k_whist16)",
-    "LFPLUS_POOL_TRACE": "log every scratch-pool allocation",
     "LFPLUS_POSEIDON_SCALAR": "Frog transcript on the scalar sparse permutation (FastPerm) instead of the AVX-512 IFMA lanes",
     "LFPLUS_RING_WEIGHTS": "M_q^T eq(r) as ring elements even when every M_q has constant coefficients",
-    "LFPLUS_ROUND_BLOCKS": "workgroups of the ring-valued round kernels",
-    "LFPLUS_SC_BLOCKS": "workgroup cap of the set check's round kernels (default 2048)",
     "LFPLUS_SC_NO_EARLY": "round 0 of the set check inside the loop over all sets instead of per set behind its tables",
     "LFPLUS_SC_TABLES": "materialise the beta^e / beta^2e tables of the set check (k_sc_tables) instead of running rounds 0-1 from the exponent digits",
     "LFPLUS_TIMELINE": "wall-clock marks of the protocol stages on stderr (the stream is drained at every mark)",
-    "LFP_BLOCKS1": "blocks of from_f's phase 1 (default 512)", "LFP_BLOCKS2": "blocks of from_f's phase 2 (default 1024)",
-    "LF_DIST_HANDSHAKE_MS": "time limit of lf_dist_init's concurrent-collectives self-check (default 20000)",
     "LF_DIST_NO_HANDSHAKE": "skip that self-check: one host thread issues every exchange",
-    "LF_FOLD_CHUNK_THREADS": "(BabyBear) threads per table chunk of the small folding rounds",
     "LF_FOLD_FUSE_MIN": "entries from which fix_variables is fused into the folding round kernel (default 16384)",
     "LF_FOLD_LUT_MIN": "entries (m/4) from which rounds 3-4 run from the 81-entry look-up table (default 2^17; 2^14 in lf_fold_step)",
-    "LF_FOLD_NO_LUT": "rounds 3-4 of the folding sumcheck on materialised m/4-entry tables", "LF_FOLD_NO_MUTAB": "round 3 without the mu-premultiplied look-up tables",
+    "LF_FOLD_NO_LUT": "rounds 3-4 of the folding sumcheck on materialised m/4-entry tables",
     "LF_FOLD_NO_R4TAB": "round 4 without the product-free digit-code tables (mode 6)", "LF_FOLD_NO_R5TAB": "round 5 from materialised tables instead of the planes (mode 7)",
     "LF_FOLD_TAB_MIN": "pairs from which rounds 1-2 run as table look-ups (default 16384)", "LF_FOLD_TAB_R1": "round 1 as a table look-up round (disables the GEMM rounds)",
-    "LF_FOLD_UNFUSED": "separate k_fix pass before every folding round", "LF_I8_BITS": "=0: commit kernel cuts its digits from the int32 planes instead of the bit-plane form of a fold step (default since round 5)",
-    "LF_I8_COLS": "=0: commit kernel with 2 x 2 blocks of (7 | 6) x 6 tiles per multiplier wave instead of the column split (13 x 3 tiles each; default since round 5)", "LF_I8_COUPLE_W": "window (tiles) a commit workgroup may run ahead of its paired plane-group workgroup (default 4; 0 switches the coupling off)", "LF_I8_COUPLE_E": "tiles between two handshakes of the paired commit workgroups (default 4)", "LF_I8_GUARDED": "commit kernel instantiation with guarded tile loads",
-    "LF_I8G_PROF": "in-kernel cycle counters of the general commit kernel k_ajtai_i8g (tools/i8g_prof.py; lf_debug_i8_prof then returns its table)", "LF_I8_PROF": "in-kernel cycle counters of the commit kernel (tools/i8_prof.py)",
-    "LF_LIN_BLOCKS": "workgroups of the linearization round kernels (default automatic)",
-    "LF_LIN_UNFUSED": "separate k_fix pass before every linearization round", "LF_LIN_U_EVAL": "u of the linearization from stand-alone evaluations instead of the last fix of the sumcheck tables",
-    "LF_NO_PRIO": "equal stream priorities for the two lanes", "LF_POSEIDON_AVX2": "(BabyBear) AVX2 lanes even when AVX-512 IFMA is present", "LF_POSEIDON_SCALAR": "scalar Poseidon permutation on the host",
-    "LF_SPIN_ALL": "spin-wait on every stream synchronisation (no blocking event)", "LF_THETA_EVAL": "theta from stand-alone evaluations instead of the last fix of the folding tables",
+    "LF_FOLD_UNFUSED": "separate k_fix pass before every folding round", "LF_I8_COUPLE_W": "window (tiles) a commit workgroup may run ahead of its paired plane-group workgroup (default 4; 0 switches the coupling off)", "LF_I8_GUARDED": "commit kernel instantiation with guarded tile loads",
+    "LF_I8G_PROF": "in-kernel cycle counters of the general commit kernel k_ajtai_i8g (tools/i8g_prof.py; lf_debug_i8_prof then returns its table)", "LF_I8_PROF": "in-kernel cycle counters of the commit kernel (tools/i8_prof.py)", "LF_LIN_U_EVAL": "u of the linearization from stand-alone evaluations instead of the last fix of the sumcheck tables", "LF_POSEIDON_AVX2": "(BabyBear) AVX2 lanes even when AVX-512 IFMA is present", "LF_POSEIDON_SCALAR": "scalar Poseidon permutation on the host", "LF_THETA_EVAL": "theta from stand-alone evaluations instead of the last fix of the folding tables",
     "LF_TIMELINE": "wall-clock marks of a fold step on stderr (lf_last_timeline carries them without it)", "LF_TRACE": "per-stage kernel error checks with a label",
 }
 

@@ -37,9 +37,8 @@ def main():
     args = ap.parse_args()
     if args.lfplus:
         return main_lfplus(args)
-    import numpy as np
     import torch  # noqa: F401  (maps the ROCm runtime the way bench.py does)
-    from latticefold_amd import api
+    from latticefold_amd.shard_model import model_rank
     from latticefold_amd.workload import make_workload
 
     wl = make_workload(args.workload)
@@ -47,53 +46,9 @@ def main():
     for G in [int(x) for x in args.worlds.split(",")]:
         ranks = range(G) if args.ranks == "all" else [int(r) for r in args.ranks.split(",") if int(r) < G]
         for r in ranks:
-            ctx = api.Context(0)
-            try:
-                if G > 1:
-                    ctx.set_sharding_model(r, G)
-                ctx.load_ccs(wl)
-                scheme = api.AjtaiCommitmentScheme(ctx, kappa=wl.kappa, n=wl.N, seed=wl.ajtai_seed())
-                wit = api.Witness.from_w_ccs(ctx, wl.w_ccs)
-                cccs = np.concatenate([wit.commit(scheme), wl.x_ccs])
-                tr = api.PoseidonTranscript()
-                acc, _ = api.LFLinearizationProver.prove(ctx, cccs, wit, tr)
-                w_acc = wit
-                made = []
-
-                def step():
-                    nonlocal acc, w_acc
-                    lc, w0, _proof = api.NIFSProver.prove(ctx, acc, w_acc, cccs, wit, tr)
-                    made.append(w0)
-                    while len(made) > 2:
-                        made.pop(0).free()
-                    acc, w_acc = lc, w0
-
-                for _ in range(args.warmup):
-                    step()
-                ctx.dist_stats(reset=True)
-                ctx.dist_stats_words(reset=True)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    step()
-                torch.cuda.synchronize()
-                ms = (time.perf_counter() - t0) * 1e3 / args.steps
-                n_ex, us_tot, us_max = ctx.dist_stats()
-                words = ctx.dist_stats_words()
-                rec = {"workload": wl.name, "world": G, "rank": r, "ms_per_step": ms, "exchanges_per_step": n_ex / args.steps,
-                       "enqueue_us_mean": us_tot / max(n_ex, 1), "enqueue_us_max": us_max, "sent_bytes_per_step": words * 8 / args.steps,
-                       "phases_ms": ctx.phase_ms()}
-                if G > 1:
-                    lat = rec["exchanges_per_step"] * args.t_lat_us / 1e3
-                    bw = rec["sent_bytes_per_step"] * (G - 1) / (args.bw_gbs * 1e9) * 1e3
-                    rec["model"] = {"t_lat_us_ASSUMED": args.t_lat_us, "bw_gbs_ASSUMED": args.bw_gbs, "latency_ms": lat, "transfer_ms": bw,
-                                    "t_ms": ms + lat + bw}
-                if args.timeline:
-                    rec["timeline"] = ctx.timeline()
-                out.append(rec)
-                print(json.dumps(rec), flush=True)
-            finally:
-                ctx.close()
+            rec = model_rank(wl, G, r, args.steps, args.warmup, 0, args.t_lat_us, args.bw_gbs, args.timeline)
+            out.append(rec)
+            print(json.dumps(rec), flush=True)
     base = next((o["ms_per_step"] for o in out if o["world"] == 1), None)
     for o in out:
         t = o.get("model", {}).get("t_ms", o["ms_per_step"])
