@@ -337,7 +337,7 @@ def ajtai_extra(device=0):
     return rows
 
 
-def ivc_extra(name, steps, device=0, headline_ms=None):
+def ivc_extra(name, steps, device=0, headline_ms=None, overlap=True):
     """A real chain (crates/latticefold/examples/e2e.rs, nifs/tests.rs:58-117 made a loop): every step takes a NEW witness of the workload's constraint system from
     host memory (workload.chain_w_ccs), ingests it (Witness::from_w_ccs, arith.rs:230-248: upload, ICRT, gadget decomposition), commits it (Witness::commit,
     arith.rs:357-362: the int8 general commit), folds it into the carried accumulator (NIFSProver::prove) and frees what the step replaced.  Wall clock over `steps`
@@ -347,7 +347,9 @@ def ivc_extra(name, steps, device=0, headline_ms=None):
     import torch
     from latticefold_amd import api
     from latticefold_amd.workload import chain_w_ccs, make_workload
-    rec = {"op": "chain: from_w_ccs + Witness::commit + NIFSProver::prove per step", "workload": name, "steps": steps}
+    rec = {"op": "chain: from_w_ccs + Witness::commit + NIFSProver::prove per step", "workload": name, "steps": steps,
+           "ingestion": "overlapped: witness j+1 uploaded / decomposed on the context's lowest-priority stream while step j folds (lf_witness_from_w_ccs_begin)" if overlap
+                        else "blocking: Witness::from_w_ccs between the steps"}
     try:
         wl = make_workload(name)
         ctx = api.Context(device, ring=wl.ring)
@@ -361,16 +363,19 @@ def ivc_extra(name, steps, device=0, headline_ms=None):
         parts = {"ingest": 0.0, "commit": 0.0, "fold": 0.0}
         norm_max, last = 0, None
         t_start = None
+        pending = api.Witness.from_w_ccs_begin(ctx, ws[0]) if overlap else None
         for j, w in enumerate(ws):
             if j == warm:
                 torch.cuda.synchronize(device)
                 parts = {k: 0.0 for k in parts}
                 t_start = time.perf_counter()
             t0 = time.perf_counter()
-            w_j = api.Witness.from_w_ccs(ctx, w)
+            w_j = pending.result() if overlap else api.Witness.from_w_ccs(ctx, w)      # overlap: "ingest" = what is left to wait for
             t1 = time.perf_counter()
             cccs = np.concatenate([w_j.commit(scheme), wl.x_ccs])
             t2 = time.perf_counter()
+            if overlap and j + 1 < len(ws):
+                pending = api.Witness.from_w_ccs_begin(ctx, ws[j + 1])                    # the next witness crosses PCIe and is decomposed while this step folds
             lc, w_next, proof = api.NIFSProver.prove(ctx, acc, w_acc, cccs, w_j, tr())
             t3 = time.perf_counter()
             parts["ingest"] += t1 - t0; parts["commit"] += t2 - t1; parts["fold"] += t3 - t2
@@ -833,7 +838,7 @@ def main():
             if "witness_commit" in mem_info:
                 out["ajtai"].append(mem_info["witness_commit"])
         if world == 1 and args.chain > 0 and args.streams == 1 and args.ccs == "r1cs":
-            out["ivc"] = [ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3)]
+            out["ivc"] = [ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3), ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3, overlap=False)]
             if wl.name != "C2" and wl.ring == "goldilocks":
                 out["ivc"].append(ivc_extra("C2", args.chain, local_rank))
         if world == 1 and not args.no_shard_model and args.streams == 1 and args.ccs == "r1cs" and wl.ring == "goldilocks":

@@ -334,6 +334,17 @@ impl<NTT: SuitableRing> HipWitness<NTT> {
         Self::make(ctx, &flatten(w_ccs), sys::lf_witness_from_w_ccs, "lf_witness_from_w_ccs")
     }
 
+    /// The same witness built NEXT TO a running fold step (a chain's next instance): the PCIe upload, the ICRT and the gadget decomposition run on a worker
+    /// thread and the context's lowest-priority stream; [`HipPendingWitness::wait`] hands the witness over.
+    pub fn from_w_ccs_begin(ctx: &Arc<HipContext>, w_ccs: &[NTT]) -> Result<HipPendingWitness<NTT>, HipError> {
+        assert_eq!(w_ccs.len(), ctx.params()?.wit_len as usize);
+        let words = flatten(w_ccs).into_boxed_slice();
+        let mut job = core::ptr::null_mut();
+        // SAFETY: `words` holds wit_len elements and lives in the returned value until the job has finished
+        chk(unsafe { sys::lf_witness_from_w_ccs_begin(ctx.raw, words.as_ptr(), &mut job) }, "lf_witness_from_w_ccs_begin")?;
+        Ok(HipPendingWitness { ctx: ctx.clone(), job, _words: words, _r: PhantomData })
+    }
+
     /// `Witness::from_f::<P>(f)` (arith.rs:299-313)
     pub fn from_f(ctx: &Arc<HipContext>, f: &[NTT]) -> Result<Self, HipError> {
         Self::make(ctx, &flatten(f), sys::lf_witness_from_f, "lf_witness_from_f")
@@ -382,6 +393,35 @@ impl<NTT: SuitableRing> HipWitness<NTT> {
             chk(sys::lf_linf_check(self.ctx.raw, f.as_ptr(), n, bound, 0, &mut ok, &mut mx), "lf_linf_check")?;
         }
         Ok(ok != 0)
+    }
+}
+
+/// A witness being ingested next to a fold step ([`HipWitness::from_w_ccs_begin`]); owns the host words the job reads.
+pub struct HipPendingWitness<NTT> {
+    ctx: Arc<HipContext>,
+    job: *mut sys::lf_witness_job,
+    _words: Box<[u64]>,
+    _r: PhantomData<NTT>,
+}
+// SAFETY: the job handle is only ever passed to lf_witness_job_finish, once
+unsafe impl<NTT> Send for HipPendingWitness<NTT> {}
+
+impl<NTT> HipPendingWitness<NTT> {
+    pub fn wait(mut self) -> Result<HipWitness<NTT>, HipError> {
+        let mut raw = core::ptr::null_mut();
+        let job = core::mem::replace(&mut self.job, core::ptr::null_mut());
+        // SAFETY: job came from lf_witness_from_w_ccs_begin and is finished exactly once
+        chk(unsafe { sys::lf_witness_job_finish(job, &mut raw) }, "lf_witness_job_finish")?;
+        Ok(HipWitness { ctx: self.ctx.clone(), raw, _r: PhantomData })
+    }
+}
+
+impl<NTT> Drop for HipPendingWitness<NTT> {
+    fn drop(&mut self) {
+        if !self.job.is_null() {
+            // SAFETY: an abandoned job: wait for the worker (it reads `_words`), free what it made
+            unsafe { sys::lf_witness_job_finish(self.job, core::ptr::null_mut()) };
+        }
     }
 }
 

@@ -211,6 +211,13 @@ size_t lf_proof_len_ring(const lf_params *, int ring);
 
 /* ---- Witness (arith.rs:230-338) ------------------------------------------------------------------ */
 int lf_witness_from_w_ccs(lf_ctx *, const uint64_t *w_ccs /* wit_len NTT */, lf_witness **out); /* from_w_ccs */
+/* The same witness, built NEXT TO a running fold step (a chain's next instance, examples/e2e.rs made a loop): _begin starts the PCIe upload, the ICRT and
+ * the gadget decomposition on a worker thread and the context's lowest-priority stream (buffers of its own) and returns at once; _finish waits, hands the
+ * witness over and frees the job (out = NULL: abandon it).  w_ccs must stay valid until _finish returns; do not reload the constraint system meanwhile.
+ * Goldilocks contexts in the default basis overlap with lf_fold_step; other configurations run the blocking call on the worker (same result). */
+typedef struct lf_witness_job lf_witness_job;
+int lf_witness_from_w_ccs_begin(lf_ctx *, const uint64_t *w_ccs /* wit_len NTT */, lf_witness_job **job);
+int lf_witness_job_finish(lf_witness_job *job, lf_witness **out);
 int lf_witness_from_f_coeff(lf_ctx *, const uint64_t *f_coeff /* N coeff-form */, lf_witness **out);
 int lf_witness_from_f(lf_ctx *, const uint64_t *f_ntt /* N NTT */, lf_witness **out);           /* from_f */
 int lf_witness_get_f_coeff(lf_ctx *, const lf_witness *, uint64_t *out /* N */);

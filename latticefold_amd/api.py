@@ -472,6 +472,42 @@ class AjtaiCommitmentScheme:
     commit = commit_ntt
 
 
+class PendingWitness:
+    """a witness being ingested on the context's lowest-priority stream (lf_witness_from_w_ccs_begin / lf_witness_job_finish); keeps the host words alive until
+    the job has finished"""
+
+    def __init__(self, ctx, w_ccs):
+        self.ctx = ctx
+        self._keep, p = _a64(w_ccs)
+        self._job = C.c_void_p()
+        L = _lib()
+        L.lf_witness_from_w_ccs_begin.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.lf_witness_job_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        _chk(L.lf_witness_from_w_ccs_begin(ctx.h, p, C.byref(self._job)), "lf_witness_from_w_ccs_begin")
+
+    def result(self):
+        if not self._job:
+            raise RuntimeError("the job was finished already")
+        h = C.c_void_p()
+        job, self._job = self._job, None
+        rc = _lib().lf_witness_job_finish(job, C.byref(h))
+        self._keep = None
+        _chk(rc, "lf_witness_job_finish")
+        return Witness(self.ctx, h)
+
+    def abandon(self):
+        if self._job:
+            job, self._job = self._job, None
+            _lib().lf_witness_job_finish(job, None)
+            self._keep = None
+
+    def __del__(self):
+        try:
+            self.abandon()
+        except Exception:
+            pass
+
+
 class Witness:
     """arith.rs:213-362; device-resident (centred f_coeff planes)."""
 
@@ -484,6 +520,11 @@ class Witness:
         h = C.c_void_p()
         _chk(_lib().lf_witness_from_w_ccs(ctx.h, p, C.byref(h)), "lf_witness_from_w_ccs")
         return cls(ctx, h)
+
+    @classmethod
+    def from_w_ccs_begin(cls, ctx, w_ccs):
+        """lf_witness_from_w_ccs_begin: start building the witness next to whatever the context runs (a fold step); `.result()` waits and returns the Witness"""
+        return PendingWitness(ctx, w_ccs)
 
     @classmethod
     def from_f_coeff(cls, ctx, f_coeff):

@@ -81,7 +81,8 @@ int lf_ctx_create(lf_ctx **out, int device) {
         const bool prio = true;
         const int p0 = least;
         if (hipStreamCreateWithPriority(&c->st_lane[0], hipStreamDefault, prio ? p0 : 0) != hipSuccess ||
-            hipStreamCreateWithPriority(&c->st_lane[1], hipStreamDefault, prio ? greatest : 0) != hipSuccess) { delete c; return LF_ERR_HIP; }
+            hipStreamCreateWithPriority(&c->st_lane[1], hipStreamDefault, prio ? greatest : 0) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->st_io, hipStreamDefault, least) != hipSuccess) { delete c; return LF_ERR_HIP; }
     }
     (void)hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming);
     u64 nr, y[24];
@@ -109,6 +110,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     if (c->bb) { c->bb->destroy(); delete c; return; }
     (void)hipStreamSynchronize(c->st_lane[0]);
     (void)hipStreamSynchronize(c->st_lane[1]);
+    if (c->st_io) (void)hipStreamSynchronize(c->st_io);
     free_ccs(c);
     for (auto &kv : c->bufs) kv.second.release();
     if (c->dAb) (void)hipFree(c->dAb);
@@ -137,6 +139,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     }
     (void)hipStreamDestroy(c->st_lane[0]);
     (void)hipStreamDestroy(c->st_lane[1]);
+    if (c->st_io) (void)hipStreamDestroy(c->st_io);
     delete c;
 }
 int lf_set_ring_tables(lf_ctx *c, uint64_t nonres, const uint64_t *y) {
@@ -983,14 +986,8 @@ static int witness_from_coef_table(lf_ctx *c, const u64 *coef_dev /* [24][N] can
     *out = w;
     return LF_OK;
 }
-int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
-    if (LF_XB(c) && w_ccs && c->have_ccs_any()) { XB x(c); return lf_witness_from_w_ccs(c, x.ring_in(w_ccs, c->params_any().wit_len), out); }
-    if (!c || !w_ccs || !out) return LF_ERR_INVALID;
-    if (c->bb) return c->bb->witness_from_w_ccs(w_ccs, out);
-    std::lock_guard<std::mutex> g(c->mu);
-    if (!c->have_ccs) return LF_ERR_STATE;
-    HIPCHK(hipSetDevice(c->device));
-    // Witness::from_w_ccs, arith.rs:230-248: ICRT -> gadget_decompose(B, L)
+// Witness::from_w_ccs, arith.rs:230-248: ICRT -> gadget_decompose(B, L); on the calling thread's lane (its stream, its buffers)
+static int witness_from_w_ccs_lane(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
     u64 *a, *b, *d;
     RET(c->tbuf("io_a", (size_t)c->P.wit_len * 24, &a));
     RET(c->tbuf("io_b", (size_t)c->P.wit_len * 24, &b));
@@ -999,6 +996,44 @@ int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
     launch_icrt_dense(c->d_icrt, a, b, c->P.wit_len, c->stream());
     launch_decompose(b, c->P.wit_len, c->P.B, c->P.L, 0, d, c->stream(), c->digit_mode);
     return witness_from_coef_table(c, d, out);
+}
+// ---- ingestion next to a running fold step (a chain's next witness: upload over PCIe, ICRT and gadget decomposition on the lowest-priority stream while the
+// step before it folds).  Goldilocks contexts in the default basis run it on lane 2 (own stream, own buffers, c->io_mu instead of c->mu: the constraint system
+// must not be reloaded meanwhile); every other configuration runs the blocking call on the worker thread -- the same witness, no overlap promised.
+struct lf_witness_job {
+    std::future<int> fut;
+    lf_witness *w = nullptr;
+};
+int lf_witness_from_w_ccs_begin(lf_ctx *c, const uint64_t *w_ccs, lf_witness_job **job) {
+    if (!c || !w_ccs || !job) return LF_ERR_INVALID;
+    if (!c->have_ccs_any()) return LF_ERR_STATE;
+    lf_witness_job *j = new lf_witness_job();
+    j->fut = std::async(std::launch::async, [c, w_ccs, j]() -> int {
+        if (c->bb || c->xb.on) return lf_witness_from_w_ccs(c, w_ccs, &j->w);
+        std::lock_guard<std::mutex> g(c->io_mu);
+        if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;
+        t_lane = 2;
+        return witness_from_w_ccs_lane(c, w_ccs, &j->w);
+    });
+    *job = j;
+    return LF_OK;
+}
+int lf_witness_job_finish(lf_witness_job *job, lf_witness **out) {
+    if (!job) return LF_ERR_INVALID;
+    const int rc = job->fut.valid() ? job->fut.get() : LF_ERR_STATE;
+    if (rc == LF_OK && out) *out = job->w;
+    else if (job->w) lf_witness_free(job->w);      // (a caller that abandons the job passes out = NULL)
+    delete job;
+    return rc;
+}
+int lf_witness_from_w_ccs(lf_ctx *c, const uint64_t *w_ccs, lf_witness **out) {
+    if (LF_XB(c) && w_ccs && c->have_ccs_any()) { XB x(c); return lf_witness_from_w_ccs(c, x.ring_in(w_ccs, c->params_any().wit_len), out); }
+    if (!c || !w_ccs || !out) return LF_ERR_INVALID;
+    if (c->bb) return c->bb->witness_from_w_ccs(w_ccs, out);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ccs) return LF_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    return witness_from_w_ccs_lane(c, w_ccs, out);
 }
 int lf_witness_from_f_coeff(lf_ctx *c, const uint64_t *f_coeff, lf_witness **out) {
     if (!c || !f_coeff || !out) return LF_ERR_INVALID;

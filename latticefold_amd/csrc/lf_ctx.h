@@ -137,7 +137,9 @@ struct lf_ctx {
     Tunables tn;          // environment switches, re-read at the start of every lf_linearize / lf_fold_step
     u32 lin_blocks = 0;   // grid bound of the linearization rounds while a fold step's commit chain runs on the other lane (0 = none)
     std::mutex mu, buf_mu, ev_mu;
-    hipStream_t stream() const { return st_lane[t_lane]; }
+    hipStream_t st_io = nullptr;   // lane 2: witness ingestion next to a running fold step (lf_witness_from_w_ccs_begin), lowest priority; own buffers ("lane2:" names)
+    std::mutex io_mu;              // one ingestion at a time per context
+    hipStream_t stream() const { return t_lane == 2 ? st_io : st_lane[t_lane]; }
     // the same facts for either backend (the external-basis marshalling is ring-agnostic)
     bool have_ccs_any() const { return bb ? bb->have_ccs() : have_ccs; }
     const lf_params &params_any() const { return bb ? bb->params() : P; }

@@ -100,7 +100,7 @@ print(json.dumps({"same": a == b, "exchanges": n}))
 def test_bench_streams_mode_single_rank():
     """opt-in throughput mode: 2 independent fold streams on one GPU from one process"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "T12", "--streams", "2",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-ajtai", "--no-lfplus", "--no-shard-model", "--chain", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -112,7 +112,7 @@ def test_bench_falls_back_to_replicas_when_the_sharded_step_fails():
     """The sharded step has never run on more than one GPU: `bench.py --gpus N` measures the replicas first and runs the sharded measurement under a watchdog;
     here rank 1's sharded measurement fails (test hook), rank 0's then never completes -- both ranks agree through the rendezvous store, rank 0 prints the
     replicas line ("weak", the reason in `note`) and both leave with exit code 0"""
-    env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo", LF_BENCH_FORCE_SHARD_FAIL="1", LF_SHARD_TIMEOUT="25", LF_SHARD_AGREE_TIMEOUT="60")
+    env = dict(os.environ, LF_FORCE_DEVICE="0", LF_DIST_BACKEND="gloo", LF_BENCH_FORCE_SHARD_FAIL="1", LF_SHARD_TIMEOUT="8", LF_SHARD_AGREE_TIMEOUT="60")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--workload", "T14", "--no-lfplus"]

@@ -23,7 +23,7 @@ SCALARS = {
     "int": "c_int", "unsigned": "c_uint", "unsigned int": "c_uint", "char": "c_char", "float": "f32", "double": "f64", "void": "c_void",
     "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "int8_t": "i8", "int32_t": "i32", "int64_t": "i64",
 }
-OPAQUE = ["lf_ctx", "lf_witness", "lf_transcript", "lfplus_ctx", "lfplus_transcript"]
+OPAQUE = ["lf_ctx", "lf_witness", "lf_witness_job", "lf_transcript", "lfplus_ctx", "lfplus_transcript"]
 KEYWORDS = {"in": "inp", "type": "ty", "ref": "r", "fn": "f", "mod": "m", "box": "b", "use": "u", "loop": "lp", "match": "mt", "move": "mv", "self": "this"}
 
 

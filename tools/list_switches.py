@@ -54,12 +54,12 @@ def collect():
                 seen.add(env)
                 if env not in rows:
                     c = re.search(r"//\s*(.*)$", ln)
-                    rows[env] = ("unset", EXTRA.get(env) or (c.group(1).strip() if c else ""), f"{fn}:{n}")
+                    rows[env] = ("unset", EXTRA.get(env) or (c.group(1).strip() if c else ""), fn)
     py = {}
     for fn in ("bench.py", os.path.join("latticefold_amd", "plus.py"), os.path.join("latticefold_amd", "api.py"), os.path.join("latticefold_amd", "dist.py")):
         for n, ln in enumerate(open(os.path.join(ROOT, fn)).read().splitlines(), 1):
             for env in re.findall(r'environ(?:\.get)?\(?\[?"((?:LF|LFPLUS)_[A-Z0-9_]+)"', ln):
-                py.setdefault(env, f"{fn}:{n}")
+                py.setdefault(env, fn)
     return rows, py
 
 
