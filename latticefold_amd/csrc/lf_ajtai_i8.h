@@ -47,7 +47,8 @@ int ajtai_i8g_scratch(const AjtaiI8Ring &R, uint32_t MT, size_t n, uint32_t NP, 
 // (element row0 + i of kappa_total; SoA [RD][kappa_total] or AoS per R.soa_out).  Returns the grid size or -1.
 int launch_ajtai_i8g(const AjtaiI8Ring &R, const unsigned char *Ab, uint32_t MT, const unsigned long long *pre, size_t ldw, size_t n, uint32_t kappa, uint32_t row0,
                      uint32_t kappa_total, uint32_t NP, uint32_t nwg, int32_t *part, int32_t *dsum, long long *sum, uint64_t *coef_out, hipStream_t s);
-int ajtai_i8g_read_prof(unsigned long long *out64);   // ... of the last general-commit launch made with LF_I8G_PROF set
+int ajtai_i8g_read_prof(unsigned long long *out64);
+int ajtai_i8g_read_wg(unsigned int *out512);   // (LF_I8G_PROF) loop duration of every workgroup of the last general commit, 100 MHz ticks   // ... of the last general-commit launch made with LF_I8G_PROF set
 // measurement: per-phase shader-clock totals of the last launch made with LF_I8_PROF set (out64[8 waves][8]: 7 phases + tile count of workgroup 0)
 int ajtai_i8_read_prof(unsigned long long *out64);
 // v[k][c][q] = sum_j eq[q][j] * digit_k(planes[c][j]) on the matrix cores (Goldilocks; see lf_ajtai_i8.hip).  mode_bits: K binary digit planes,

@@ -48,6 +48,7 @@ struct AjtaiI8GArgs {
 
 // PROF: per-phase shader-clock totals of every wave of workgroup 0 (LF_I8G_PROF=1; a measurement instantiation, tools/i8g_prof.py): [wave][phase], [wave][7] = tiles
 __device__ unsigned long long g_i8g_prof[8][8];
+__device__ unsigned int g_i8g_wg[512];    // PROF: loop duration of every workgroup in 100 MHz ticks (tools/i8g_prof.py prints them by half and XCD)
 #define LF_G_STAMP(i_)                                                                   \
     if (PROF) {                                                                          \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
@@ -55,30 +56,37 @@ __device__ unsigned long long g_i8g_prof[8][8];
         pc = now_;                                                                       \
     }
 int ajtai_i8g_read_prof(unsigned long long *out64) { return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_i8g_prof), sizeof(g_i8g_prof)) == hipSuccess ? 0 : -1; }
+int ajtai_i8g_read_wg(unsigned int *out512) { return hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_i8g_wg), sizeof(g_i8g_wg)) == hipSuccess ? 0 : -1; }
 // geometry: ring degree RD, at most MTW row tiles per workgroup, NTW column tiles per multiplier wave
 template <int RD, int MTW, int NTW>
 struct GX {
     static constexpr int KS = RD / 8, VS = 2 * RD, HALF = RD / 2, DS = RD + 2, EPP = 4 * RD;   // a row of D: RD digit words, the zero word, the negation constant
     static constexpr int NT = 4 * NTW;                            // column tiles of a workgroup
     static constexpr int NPMAX = NT * 16 / RD;                    // planes they hold
-    static constexpr int NLDMAX = (KS * MTW * 1024 + 4095) / 4096;   // 16-byte loads per producer thread and tile
-    static constexpr int ALDS = NLDMAX * 4096;
+    static constexpr int NCH = KS * MTW;                          // 1 KiB pieces of the workgroup's part of a tile of A (one global_load_lds_dwordx4 of a wave each)
+    static constexpr int ALDS = NCH * 1024;
+    static constexpr int NBA = RD <= 24 ? 4 : 3;                  // LDS ring of A tiles: tile T is multiplied while tiles T + 1 .. T + NBA - 1 land
+    static constexpr int NVT = 192;                               // threads of the three vector waves (4 - 6); wave 7 only copies
     static constexpr int VB = NPMAX * 2 * VS, DB = NPMAX * DS;    // 64-bit words of a V / D buffer
-    static constexpr int NDI = NPMAX * RD, NDR = (NDI + 255) / 256;
-    static constexpr int NVR = (VB + 255) / 256;
-    static_assert(NLDMAX <= 10 && NPMAX * DS < 1024 && 2 * NPMAX * VS * 8 < 65536, "staging registers / packed offsets");
-    static constexpr size_t lds_bytes() { return 2 * (size_t)ALDS + 2 * (size_t)VB * 8 + 16 + 2 * (size_t)DB * 8 + 16; }   // (+ the spare word)
+    static constexpr int NDI = NPMAX * RD, NDR = (NDI + NVT - 1) / NVT;
+    static constexpr int NVR = (VB + NVT - 1) / NVT;
+    static_assert((NBA - 2) * NCH <= 63 && NPMAX * DS < 1024 && 2 * NPMAX * VS * 8 < 65536, "vmcnt range / packed offsets");
+    static constexpr size_t lds_bytes() { return (size_t)NBA * ALDS + 2 * (size_t)VB * 8 + 16 + 2 * (size_t)DB * 8 + 16; }   // (+ the spare words)
+    static_assert(lds_bytes() <= 160 * 1024, "LDS of a CU");
 };
 
 // ---- multiplier waves (0-3): wave ng owns column tiles [ng NTW, (ng + 1) NTW) and all mth row tiles of the workgroup's half
-template <int RD, int MTW, int NTW, bool EXACT, bool PROF>
+// MTH: the half's row tiles at compile time (loops, operand strides and the accumulator array are exact), 0 = any number <= MTW at run time (wave-uniform guards)
+template <int RD, int MTW, int NTW, int MTH, bool PROF>
 __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *smem, u32 ng, u32 mth_rt, u32 nsub, u32 T0, u32 T1, int32_t *part) {
     typedef GX<RD, MTW, NTW> G;
     constexpr int KS = G::KS, VS = G::VS, HALF = G::HALF, NT = G::NT;
+    constexpr bool EXACT = MTH > 0;
+    constexpr int ML = EXACT ? MTH : MTW;
     const u32 lane = threadIdx.x & 63;
-    const u32 mth = EXACT ? (u32)MTW : mth_rt;
+    const u32 mth = EXACT ? (u32)MTH : mth_rt;
     const unsigned char *Al = smem;
-    const ull *V = (const ull *)(smem + 2 * G::ALDS);
+    const ull *V = (const ull *)(smem + G::NBA * G::ALDS);
     u32 vb[NTW];
 #pragma unroll
     for (int ni = 0; ni < NTW; ni++) {
@@ -92,18 +100,18 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
     const size_t per_slot = (size_t)mth * NT * 256;
     if (T0 < T1) lds_barrier();                                 // the producers' prologue has a barrier of its own: every wave must arrive
     lds_barrier();                                              // hand-over: A[T0], V[T0] are in buffer 0
-    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
-    if (PROF) pc = __builtin_amdgcn_s_memtime();
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0, pr0 = 0;
+    if (PROF) { pc = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     for (u32 sub = 0; sub < nsub; sub++) {
         const u32 Tb = T0 + sub * a.ft, Te = Tb + a.ft < T1 ? Tb + a.ft : T1;
-        v4i acc[MTW][NTW];
+        v4i acc[ML][NTW];
 #pragma unroll
-        for (int mi = 0; mi < MTW; mi++)
+        for (int mi = 0; mi < ML; mi++)
 #pragma unroll
             for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
         for (u32 T = Tb; T < Te; T++) {
             const u32 cur = (T - T0) & 1;
-            const unsigned char *Ac = Al + cur * G::ALDS + ab0;
+            const unsigned char *Ac = Al + ((T - T0) % G::NBA) * G::ALDS + ab0;
             const unsigned char *Vc = (const unsigned char *)(V + cur * G::VB);
             v4i b[NTW], bn[NTW];
 #pragma unroll
@@ -118,11 +126,11 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
                 // A operand: rolling registers, the read of row tile mi + 2 is issued before the MFMAs of row tile mi
                 v4i avn = *(const v4i *)(As), avnn = *(const v4i *)(As + (mth > 1 ? 1024 : 0));
 #pragma unroll
-                for (int mi = 0; mi < MTW; mi++) {
+                for (int mi = 0; mi < ML; mi++) {
                     const v4i av = avn;
                     avn = avnn;
-                    if (mi + 2 < MTW) avnn = *(const v4i *)(As + (EXACT || (u32)(mi + 2) < mth ? (mi + 2) * 1024 : 0));
-                    if (mi == (MTW > 1 ? 1 : 0) && s + 1 < KS) {   // the next K-step's B operands, behind the first row tiles of this one
+                    if (mi + 2 < ML) avnn = *(const v4i *)(As + (EXACT || (u32)(mi + 2) < mth ? (mi + 2) * 1024 : 0));
+                    if (mi == (ML > 1 ? 1 : 0) && s + 1 < KS) {   // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
                         for (int ni = 0; ni < NTW; ni++) {
                             const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
@@ -147,75 +155,99 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
         }
         int32_t *dst = part + sub * per_slot;
 #pragma unroll
-        for (int mi = 0; mi < MTW; mi++)
+        for (int mi = 0; mi < ML; mi++)
 #pragma unroll
             for (int ni = 0; ni < NTW; ni++)
                 if (EXACT || (u32)mi < mth) *(v4i *)(dst + (((size_t)mi * NT + ng * NTW + ni) * 64 + lane) * 4) = acc[mi][ni];
     }
     for (u32 pad = (T1 - T0) & 3; pad & 3; pad++) lds_barrier();   // the producers' loop runs whole trips of four tiles
+    if (PROF && lane == 0 && ng == 0) {                          // slot [4] of waves 1 .. 3: the loop in 100 MHz ticks -- workgroup 0, the slowest workgroup, the sum over all
+        const unsigned long long dr = __builtin_amdgcn_s_memrealtime() - pr0;
+        if (blockIdx.x == 0) g_i8g_prof[1][4] = dr;
+        if (blockIdx.x < 512) g_i8g_wg[blockIdx.x] = (unsigned int)dr;
+        atomicMax(&g_i8g_prof[2][4], dr);
+        atomicAdd(&g_i8g_prof[3][4], dr);
+    }
+    if (PROF && blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 7; i++) if (i != 4) g_i8g_prof[threadIdx.x >> 6][i] = pt[i];
+        g_i8g_prof[threadIdx.x >> 6][7] = T1 - T0;
+    }
+}
+
+// ---- copy wave (7): the workgroup's part of every tile of A straight from HBM into the LDS ring (global_load_lds_dwordx4: 1 KiB per instruction, no staging
+// registers, no ds_write pass).  The wave touches LDS through nothing else: the compiler's wait-count pass makes any ds_read of a wave wait for that wave's
+// LDS-DMA in flight (it cannot tell the buffers apart), which is why the vector waves below do not copy.  Counted waits: tile T + 1 has landed when at most
+// (NBA - 2) tiles' pieces are outstanding.
+typedef __attribute__((address_space(1))) const void *i8g_gptr;
+typedef __attribute__((address_space(3))) void *i8g_lptr;
+template <int RD, int MTW, int NTW, int MTH, bool PROF>
+__device__ __forceinline__ void i8g_copy(const AjtaiI8GArgs &a, unsigned char *smem, u32 m_lo, u32 mth_rt, u32 T0, u32 T1) {
+    typedef GX<RD, MTW, NTW> G;
+    constexpr int KS = G::KS, NBA = G::NBA;
+    constexpr int NCH = KS * (MTH > 0 ? MTH : MTW);             // pieces issued per tile (the counted waits need a compile-time number)
+    const u32 mth = MTH > 0 ? (u32)MTH : mth_rt;
+    const u32 lane = threadIdx.x & 63;
+    const size_t a_tile = (size_t)KS * a.MT * 1024;
+    const u32 Tlast = a.ntiles - 1;
+    const u32 nch = KS * mth;                                   // pieces of this half (MTH = 0: a half with fewer row tiles than MTW re-copies piece 0 in its spare slots: same bytes, same place)
+    // piece c = (K-step c / mth, row tile c % mth): LDS offset 1024 c (the image the multipliers read: [KS][mth][64 lanes][16]), global offset inside a tile:
+    auto issue = [&](u32 T, u32 buf) {
+        const unsigned char *src = a.Ab + (size_t)(T < Tlast ? T : Tlast) * a_tile + (size_t)m_lo * 1024 + lane * 16;
+        unsigned char *dst = smem + (size_t)buf * G::ALDS;
+        u32 s = 0, r = 0;                                       // (wave-uniform counters: no division per piece)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const bool in = MTH > 0 || (u32)c < nch;
+            const u32 go = in ? (s * a.MT + r) * 1024 : 0, lo = in ? (u32)c * 1024 : 0;
+            __builtin_amdgcn_global_load_lds((i8g_gptr)(src + go), (i8g_lptr)(dst + lo), 16, 0, 0);
+            if (++r == mth) { r = 0; s++; }
+        }
+    };
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    if (T0 < T1) {
+#pragma unroll
+        for (int q = 0; q + 1 < NBA; q++) issue(T0 + q, q);     // tiles T0 .. T0 + NBA - 2 -> buffers 0 .. NBA - 2
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBA - 2) * NCH) : "memory");   // tile T0 has landed
+        lds_barrier();                                          // (the vector waves' prologue barrier)
+    }
+    lds_barrier();                                              // hand-over of buffer 0
+    if (PROF) pc = __builtin_amdgcn_s_memtime();
+    u32 buf = NBA - 1;                                          // buffer of tile T + NBA - 1
+    const u32 Tend = T0 + ((T1 - T0 + 3) & ~3u);                // whole trips of four tiles, like the vector waves
+    for (u32 T = T0; T < Tend; T++) {
+        issue(T + NBA - 1, buf);                                // into the buffer the multipliers left at the last barrier (tile T - 1)
+        buf = buf + 1 == (u32)NBA ? 0 : buf + 1;
+        LF_G_STAMP(1);     /* issue */
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBA - 2) * NCH) : "memory");   // tile T + 1 has landed
+        LF_G_STAMP(5);     /* wait for the tile */
+        lds_barrier();
+        LF_G_STAMP(6);     /* barrier */
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing may land in LDS after the workgroup has gone
     if (PROF && blockIdx.x == 0 && lane == 0) {
         for (int i = 0; i < 7; i++) g_i8g_prof[threadIdx.x >> 6][i] = pt[i];
         g_i8g_prof[threadIdx.x >> 6][7] = T1 - T0;
     }
 }
 
-// ---- producer waves (4-7): btid = 0 .. 255
+// ---- vector waves (4-6): btid = 0 .. 191 -- digit words of the tile two ahead into D, Toeplitz vectors of the next tile into V
 template <int RD, int MTW, int NTW, bool PROF>
-__device__ __forceinline__ void i8g_build(const AjtaiI8GArgs &a, unsigned char *smem, u32 m_lo, u32 mth, u32 T0, u32 T1, int32_t *dsum_slot) {
+__device__ __forceinline__ void i8g_build(const AjtaiI8GArgs &a, unsigned char *smem, u32 T0, u32 T1, int32_t *dsum_slot) {
     typedef GX<RD, MTW, NTW> G;
-    constexpr int KS = G::KS, VS = G::VS, HALF = G::HALF, DS = G::DS, EPP = G::EPP, NDR = G::NDR, NVR = G::NVR, NDI = G::NDI;
+    constexpr int VS = G::VS, HALF = G::HALF, DS = G::DS, EPP = G::EPP, NDR = G::NDR, NVR = G::NVR, NDI = G::NDI, NVT = G::NVT;
     const u32 btid = threadIdx.x - 256;
-    unsigned char *Al = smem;
-    ull *V = (ull *)(smem + 2 * G::ALDS);
+    ull *V = (ull *)(smem + G::NBA * G::ALDS);
     ull *Dl = V + 2 * G::VB + 2;                               // (two pad words behind the V buffers)
-    const size_t a_tile = (size_t)KS * a.MT * 1024;
-    const u32 Tlast = a.ntiles - 1;
-    // the workgroup's part of a tile of A: KS runs of mth KB (K-step s: row tiles m_lo .. m_lo + mth - 1), copied as 16-byte chunks
-    // idx = q * 256 + btid < KS mth 64 to LDS offset 16 idx (chunks past the end re-read chunk 0 and land behind the used part of the buffer)
-    const u32 total16 = KS * mth * 64;
-    u32 so0 = 0, so1 = 0, so2 = 0, so3 = 0, so4 = 0, so5 = 0, so6 = 0, so7 = 0, so8 = 0, so9 = 0;
-#define LF_G_SO(q_)                                                                                                  \
-    if ((q_) < G::NLDMAX) {                                                                                          \
-        const u32 idx_ = (q_) * 256 + btid, idc_ = idx_ < total16 ? idx_ : 0, s_ = idc_ / (mth * 64), o_ = idc_ - s_ * (mth * 64); \
-        so##q_ = (s_ * a.MT + m_lo) * 1024 + o_ * 16;                                                                \
-    }
-    LF_G_SO(0) LF_G_SO(1) LF_G_SO(2) LF_G_SO(3) LF_G_SO(4) LF_G_SO(5) LF_G_SO(6) LF_G_SO(7) LF_G_SO(8) LF_G_SO(9)
-#undef LF_G_SO
-    // FOUR register sets a, b, c, d: the tile copy runs four tiles ahead (tile T + 4 is requested while tile T is multiplied and tile T + 1 goes to LDS).
-    // With two sets (the k_ajtai_i8x scheme: loads consumed 1.5 - 2 tiles after their issue) the loop was bound by the loaded HBM latency: a 21 KB half
-    // tile per iteration and ~32 KB in flight per CU gave 3 300 cycles per tile, 1.77 ms per C4 commitment.
-    uint4 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9;
-    a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = a8 = a9 = b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = b8 = b9 = make_uint4(0, 0, 0, 0);
-    c0 = c1 = c2 = c3 = c4 = c5 = c6 = c7 = c8 = c9 = d0 = d1 = d2 = d3 = d4 = d5 = d6 = d7 = d8 = d9 = make_uint4(0, 0, 0, 0);
-    // (loads and stores carry NO run-time control flow: a guarded load is waited for at its join -- the first version guarded them by the half's chunk
-    // count and every load of the tile copy was preceded by s_waitcnt vmcnt(0): 6 500 cycles per tile.  A half with fewer row tiles than MTW re-reads
-    // chunk 0 in its spare slots and stores it behind the used part of the LDS buffer.)
-#define LF_G_LD1(P_, q_, I0_, I1_) if ((q_) < G::NLDMAX && (q_) >= (I0_) && (q_) < (I1_)) P_##q_ = *(const uint4 *)(src_ + so##q_);
-#define LF_G_LOAD(P_, T_, I0_, I1_)                                                                                \
-    do {                                                                                                           \
-        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile;                         \
-        LF_G_LD1(P_, 0, I0_, I1_) LF_G_LD1(P_, 1, I0_, I1_) LF_G_LD1(P_, 2, I0_, I1_) LF_G_LD1(P_, 3, I0_, I1_) LF_G_LD1(P_, 4, I0_, I1_)      \
-        LF_G_LD1(P_, 5, I0_, I1_) LF_G_LD1(P_, 6, I0_, I1_) LF_G_LD1(P_, 7, I0_, I1_) LF_G_LD1(P_, 8, I0_, I1_) LF_G_LD1(P_, 9, I0_, I1_)      \
-    } while (0)
-#define LF_G_ST1(P_, q_) if ((q_) < G::NLDMAX) *(uint4 *)(dst_ + (q_) * 4096) = P_##q_;
-#define LF_G_STORE(P_, buf_)                                                                                       \
-    do {                                                                                                           \
-        unsigned char *dst_ = Al + (buf_) * G::ALDS + (size_t)btid * 16;                                           \
-        LF_G_ST1(P_, 0) LF_G_ST1(P_, 1) LF_G_ST1(P_, 2) LF_G_ST1(P_, 3) LF_G_ST1(P_, 4) LF_G_ST1(P_, 5) LF_G_ST1(P_, 6) LF_G_ST1(P_, 7) LF_G_ST1(P_, 8) LF_G_ST1(P_, 9) \
-    } while (0)
-    constexpr int LB = G::NLDMAX < 4 ? G::NLDMAX : 4;           // the tile copy's loads in two groups, around the vector build
-    // digit words: item = btid + 256 r < NDI is (plane, coefficient) = (item / RD, item % RD); planes >= NP hold zero digits
+    // digit words: item = btid + NVT r < NDI is (plane, coefficient) = (item / RD, item % RD); planes >= NP hold zero digits
     static_assert(NDR <= 2, "two digit words per thread");
-    // raw words (the "no digit" select happens at use time, so that nothing waits for the loads where they are issued), TWO sets: the vector-memory counter
-    // is in order, so a word used k iterations after its load forces every OLDER load to have landed -- the digit words of tile T + 4 are requested as the
-    // first load of iteration T and used in iteration T + 2, when only the tile copies requested before iteration T (tiles <= T + 3 ... of two iterations
-    // ago: <= T + 1 from the user's point of view) have to be complete anyway
-    // (FOUR named sets, one per unrolled iteration: every set then has exactly one load per trip of the loop.  With two sets, each loaded twice per trip, the
-    // register allocator gave the two loads different registers and joined them with a copy at the loop's back edge -- a copy that waits for the load)
+    // raw words (the "no digit" select happens at use time, so that nothing waits for the loads where they are issued), FOUR named sets, one per unrolled
+    // iteration: every set has exactly one load per trip of the loop (with two sets, each loaded twice per trip, the register allocator gave the two loads
+    // different registers and joined them with a copy at the loop's back edge -- a copy that waits for the load).  The words of tile T + 4 are requested in
+    // iteration T and used in iteration T + 2.
     ull dA0 = ZW, dA1 = ZW, dB0 = ZW, dB1 = ZW, dC0 = ZW, dC1 = ZW, dD0 = ZW, dD1 = ZW;
     bool kA0 = false, kA1 = false, kB0 = false, kB1 = false, kC0 = false, kC1 = false, kD0 = false, kD1 = false;
     int dsum0 = 0, dsum1 = 0;   // digit sums of this thread's (plane, coefficient) items over the workgroup's columns
-    const u32 it0 = btid, it1 = btid + 256;
+    const u32 it0 = btid, it1 = btid + NVT;
     const bool ok0 = it0 < (u32)NDI && it0 / RD < a.NP, ok1 = NDR > 1 && it1 < (u32)NDI && it1 / RD < a.NP;
     // LDS word of an item inside a D buffer; threads without an item write the spare word behind the two buffers (no control flow around the stores)
     const bool has0 = it0 < (u32)NDI, has1 = NDR > 1 && it1 < (u32)NDI;
@@ -235,7 +267,7 @@ __device__ __forceinline__ void i8g_build(const AjtaiI8GArgs &a, unsigned char *
     };
 #define LF_G_LOADD(S_, T_) load_d((T_), d##S_##0, d##S_##1, k##S_##0, k##S_##1)
 #define LF_G_GEND(S_, buf_) gen_d((buf_), d##S_##0, d##S_##1, k##S_##0, k##S_##1)
-    // vectors: entry idx = btid + 256 r < VB = (plane, H / L', e) = (idx / EPP, (idx % EPP) / VS, idx % VS), d = RD - 1 - e;
+    // vectors: entry idx = btid + NVT r < VB = (plane, H / L', e) = (idx / EPP, (idx % EPP) / VS, idx % VS), d = RD - 1 - e;
     //   H : v = D[oa] + D[ob]            (f[d], f[d + RD/2]; a missing term reads the biased zero word)
     //   L': v = ~D[oa] + NEGC            (d >= 0: 0xC0.. - D[oa] = -f[d])      or      D[oa] + D[ob]     (d < 0: f[d + RD], f[d + 3 RD/2])
     // bytes are 64 + digit: a sum is 128 + value, 0xC0 - byte is 128 - digit; no byte carries or borrows; the XOR with 0x80 gives the int8.
@@ -244,7 +276,7 @@ __device__ __forceinline__ void i8g_build(const AjtaiI8GArgs &a, unsigned char *
     u32 vo[NVR];          // oa | ob << 10 | neg << 20, offsets in words from the D buffer
 #pragma unroll
     for (int r = 0; r < NVR; r++) {
-        const u32 idx = btid + 256 * r, idc = idx < (u32)G::VB ? idx : 0, vp = idc / EPP, vr = idc % EPP;
+        const u32 idx = btid + NVT * r, idc = idx < (u32)G::VB ? idx : 0, vp = idc / EPP, vr = idc % EPP;
         u32 oa = RD, ob = RD, neg = 0;
         const int dl = RD - 1 - (int)(vr % VS);
         if (vr < (u32)VS) {
@@ -264,64 +296,48 @@ __device__ __forceinline__ void i8g_build(const AjtaiI8GArgs &a, unsigned char *
         for (int r = 0; r < NVR; r++) {
             const ull mk = 0ull - (ull)(vo[r] >> 20);
             const ull v = ((xa[r] ^ mk) + xb[r]) ^ 0x8080808080808080ull;
-            // (the last round of a buffer that is not a multiple of 256 words: the spare threads write the pad word behind the V buffers)
-            V[(G::VB & 255) == 0 || btid + 256 * r < (u32)G::VB ? vbuf * G::VB + btid + 256 * r : 2 * G::VB] = v;
+            // (the last round of a buffer that is not a multiple of NVT words: the spare threads write the pad word behind the V buffers)
+            V[(G::VB % NVT) == 0 || btid + NVT * r < (u32)G::VB ? vbuf * G::VB + btid + NVT * r : 2 * G::VB] = v;
         }
     };
     if (btid < 2 * G::NPMAX) { Dl[btid * DS + RD] = ZW; Dl[btid * DS + RD + 1] = NEGC; }   // the biased zero word and the negation constant of every row of both D buffers
     if (T0 < T1) {
-        // prologue: A[T0] -> buffer 0; A[T0+1 .. T0+3] in flight (b, c, d); D[T0], D[T0+1]; digit words of T0+2, T0+3 in flight (sets A, B); V[T0]
+        // prologue: D[T0], D[T0+1]; digit words of T0+2, T0+3 in flight (sets C, D); V[T0]
         LF_G_LOADD(A, T0);
         LF_G_LOADD(B, T0 + 1);
-        LF_G_LOAD(a, T0, 0, G::NLDMAX);
         LF_G_GEND(A, 0);
         LF_G_GEND(B, 1);
         LF_G_LOADD(C, T0 + 2);
         LF_G_LOADD(D, T0 + 3);
-        LF_G_LOAD(b, T0 + 1, 0, G::NLDMAX);
-        LF_G_LOAD(c, T0 + 2, 0, G::NLDMAX);
-        LF_G_LOAD(d, T0 + 3, 0, G::NLDMAX);
-        LF_G_STORE(a, 0);
         lds_barrier();
         gen_v(0, 0);
-        // Every load of the prologue lands before the loop starts (once per workgroup: a few microseconds).  The compiler's wait-count pass merges the
-        // pending-load state of the loop's back edge with the state at its entry and waits for the YOUNGER of the two at every use: the prologue (whose loads
-        // the scheduler reorders freely) made the first of the four unrolled iterations wait for the loads issued one iteration earlier -- a full HBM latency
-        // every fourth tile.  With nothing pending at the entry only the steady-state distances of the back edge remain.
+        // Every load of the prologue lands before the loop starts: the compiler's wait-count pass merges the pending-load state of the loop's back edge with the
+        // state at its entry and waits for the YOUNGER of the two at every use; with nothing pending at the entry only the steady-state distances remain.
         __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), expcnt / lgkmcnt untouched
     }
     lds_barrier();                                              // hand-over of buffer 0 (matches the multipliers' first barrier)
-    // iteration of tile Tt (buffer parity PB_ = (Tt - T0) & 1; digit-word sets DU_ used / DL_ loaded): digits of tile Tt + 2 -> D[PB_] (it held
-    // tile Tt), request the digit words of tile Tt + 4 and tile Tt + 4 itself into the register set that is free (LS_), vectors of tile Tt + 1 from
-    // D[1 - PB_], set SS_ (tile Tt + 1) -> A buffer 1 - PB_
-#define LF_G_ITER(LS_, SS_, DU_, DL_, Tt_, PB_)                                                                    \
+    // iteration of tile Tt (buffer parity PB_ = (Tt - T0) & 1; digit-word sets DU_ used / DL_ loaded): digits of tile Tt + 2 -> D[PB_] (it held tile Tt), request
+    // the digit words of tile Tt + 4, vectors of tile Tt + 1 from D[1 - PB_]
+#define LF_G_ITER(DU_, DL_, Tt_, PB_)                                                                              \
     do {                                                                                                           \
         LF_G_GEND(DU_, PB_);                                                                                       \
         LF_G_STAMP(0);     /* digits (waits for the words requested two tiles ago) */                              \
         LF_G_LOADD(DL_, (Tt_) + 4);                                                                                \
-        LF_G_LOAD(LS_, (Tt_) + 4, 0, LB);                                                                          \
-        LF_G_STAMP(1);     /* load issue 1 */                                                                      \
         gen_v(1 - (PB_), 1 - (PB_));                                                                               \
         LF_G_STAMP(2);     /* vectors */                                                                           \
-        LF_G_LOAD(LS_, (Tt_) + 4, LB, G::NLDMAX);                                                                  \
-        LF_G_STAMP(4);     /* load issue 2 */                                                                      \
-        LF_G_STORE(SS_, 1 - (PB_));                                                                                \
-        LF_G_STAMP(5);     /* wait for the tile requested three tiles ago + LDS stores */                          \
         lds_barrier();                                                                                             \
         LF_G_STAMP(6);     /* barrier */                                                                           \
     } while (0)
     unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
     if (PROF) pc = __builtin_amdgcn_s_memtime();
     for (u32 T = T0; T < T1; T += 4) {
-        // (digit words: iteration i uses the set requested two iterations ago and requests tile T + 4 into the set freed two iterations ago)
         // NO early exit inside a trip: the structurizer funnels a `break` through the loop's latch, and the wait-count pass then merges "left after the
-        // second iteration" into the state of the back edge -- the first iteration of every trip waited for loads issued one iteration earlier (a full
-        // HBM latency every fourth tile).  A chunk runs a multiple of four iterations; the spare ones copy clamped tiles into buffers nobody reads and
-        // carry zero digits, and the multiplier waves take part in their barriers (i8g_mma).
-        LF_G_ITER(a, b, C, A, T, 0);
-        LF_G_ITER(b, c, D, B, T + 1, 1);
-        LF_G_ITER(c, d, A, C, T + 2, 0);
-        LF_G_ITER(d, a, B, D, T + 3, 1);
+        // second iteration" into the state of the back edge.  A chunk runs a multiple of four iterations; the spare ones carry zero digits, and the
+        // multiplier and copy waves take part in their barriers.
+        LF_G_ITER(C, A, T, 0);
+        LF_G_ITER(D, B, T + 1, 1);
+        LF_G_ITER(A, C, T + 2, 0);
+        LF_G_ITER(B, D, T + 3, 1);
     }
 #undef LF_G_ITER
 #undef LF_G_LOADD
@@ -330,10 +346,6 @@ __device__ __forceinline__ void i8g_build(const AjtaiI8GArgs &a, unsigned char *
         for (int i = 0; i < 7; i++) g_i8g_prof[threadIdx.x >> 6][i] = pt[i];
         g_i8g_prof[threadIdx.x >> 6][7] = T1 - T0;
     }
-#undef LF_G_LOAD
-#undef LF_G_STORE
-#undef LF_G_LD1
-#undef LF_G_ST1
     if (dsum_slot) {
         if (has0) dsum_slot[it0] = dsum0;
         if (has1) dsum_slot[it1] = dsum1;
@@ -349,9 +361,19 @@ __global__ void __launch_bounds__(512) k_ajtai_i8g(AjtaiI8GArgs a) {
     const u32 T0 = chunk * a.tpw[h], T1 = T0 + a.tpw[h] < a.ntiles ? T0 + a.tpw[h] : a.ntiles;
     const u32 wave = threadIdx.x >> 6;
     int32_t *part = a.part[h] + (size_t)chunk * nsub * mth * G::NT * 256;
-    if (wave >= 4) i8g_build<RD, MTW, NTW, PROF>(a, smem, a.m_lo[h], mth, T0, T1, h == 0 ? a.dsum + (size_t)chunk * G::NDI : nullptr);
-    else if (mth == (u32)MTW) i8g_mma<RD, MTW, NTW, true, PROF>(a, smem, wave, mth, nsub, T0, T1, part);
-    else i8g_mma<RD, MTW, NTW, false, PROF>(a, smem, wave, mth, nsub, T0, T1, part);
+    if (wave >= 4 && wave < 7) { i8g_build<RD, MTW, NTW, PROF>(a, smem, T0, T1, h == 0 ? a.dsum + (size_t)chunk * G::NDI : nullptr); return; }
+    // the half's row-tile count at compile time where it is one of the usual ones (7 + 6 at kappa 26, 5 + 5 at kappa 20, 4 + 4 at kappa 16): exact loops, no spare pieces
+#define LF_G_ROLE(MTH_)                                                                                             \
+    do {                                                                                                           \
+        if (wave == 7) i8g_copy<RD, MTW, NTW, MTH_, PROF>(a, smem, a.m_lo[h], mth, T0, T1);                        \
+        else i8g_mma<RD, MTW, NTW, MTH_, PROF>(a, smem, wave, mth, nsub, T0, T1, part);                            \
+    } while (0)
+    if (mth == (u32)MTW) LF_G_ROLE(MTW);
+    else if (MTW > 1 && mth == (u32)(MTW - 1)) LF_G_ROLE((MTW > 1 ? MTW - 1 : 1));
+    else if (MTW > 2 && mth == (u32)(MTW - 2)) LF_G_ROLE((MTW > 2 ? MTW - 2 : 1));
+    else if (MTW > 3 && mth == (u32)(MTW - 3)) LF_G_ROLE((MTW > 3 ? MTW - 3 : 1));
+    else LF_G_ROLE(0);
+#undef LF_G_ROLE
 }
 
 // sum layout: [S0: mth0 NT 256][S1: mth1 NT 256][F: NDI] -- the partial tiles of each row half over its slots, the digit sums over the first half's chunks
@@ -555,9 +577,9 @@ bool g_plan(const AjtaiI8Ring &R, u32 MT, size_t n, u32 NP, u32 nwg, GPlan *g) {
     if (g->halves == 2) { g->mth[0] = (MT + 1) / 2; g->mth[1] = MT - g->mth[0]; }
     else { g->mth[0] = MT; g->mth[1] = 0; }
     g->m_lo[0] = 0; g->m_lo[1] = g->mth[0];
-    // the same number of workgroups for both halves: a tile costs a half with 7 row tiles what it costs one with 6 (the producer waves -- tile copy, Toeplitz
-    // vectors -- and the multiplier waves are balanced at ~2 000 cycles per tile either way, profiles/r06_i8g_prof.txt)
-    u32 w0 = g->halves == 2 ? nwg / 2 : nwg;
+    // workgroups in proportion to the halves' cost per tile: the multiplier waves' MFMAs and the copy wave's bytes scale with the row tiles, the barrier and the
+    // B operands do not -- measured per tile at kappa 26 (7 + 6 row tiles): 1.24 / 1.15 us with 10 planes, 1.02 / 0.92 with 5 (tools/i8g_prof.py): ~ mth + 5
+    u32 w0 = g->halves == 2 ? (nwg * (g->mth[0] + 5) + (MT + 10) / 2) / (MT + 10) : nwg;
     if (g->halves == 2) { if (w0 < 1) w0 = 1; if (w0 > nwg - 1) w0 = nwg - 1; }
     const u32 w[2] = {w0, g->halves == 2 ? nwg - w0 : 0};
     g->ft = (u32)(0x7FFFFFFFull / (16384ull * R.RD * 8));

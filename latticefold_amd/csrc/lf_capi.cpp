@@ -1253,6 +1253,8 @@ int lf_debug_i8_prof(uint64_t *out64) {   // (LF_I8G_PROF set: the table of the 
     if (!out64) return LF_ERR_INVALID;
     return getenv("LF_I8G_PROF") ? ajtai_i8g_read_prof((unsigned long long *)out64) : ajtai_i8_read_prof((unsigned long long *)out64);
 }
+// (not part of the ABI: tools/i8g_prof.py) per-workgroup loop durations of the last profiled general commit
+extern "C" int lfdbg_i8g_wg(unsigned int *out512) { return out512 ? ajtai_i8g_read_wg(out512) : -1; }
 int lf_last_fold_paths(lf_ctx *c, unsigned *sv_round_mask) {
     if (!c || !sv_round_mask) return LF_ERR_INVALID;
     *sv_round_mask = c->bb ? c->bb->fold_paths() : c->sv_round_mask;
