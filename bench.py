@@ -170,7 +170,7 @@ def phase_report(wl_name, timelines, host_ms):
             stats[k] = (int(r["Calls"]), float(r["TotalDurationNs"]))
     # steps covered by each profile: the commit kernel runs twice per step
     def steps_of(tbl, get):
-        n = sum(get(v) for k, v in tbl.items() if k.startswith("k_ajtai_i8<") or k.startswith("k_ajtai_i8s<"))
+        n = sum(get(v) for k, v in tbl.items() if k.startswith(("k_ajtai_i8<", "k_ajtai_i8s<", "k_ajtai_i8x<")))
         return max(1.0, n / 2.0)
     pmc_steps = steps_of(pmc, lambda v: v["launches"])
     st_steps = steps_of(stats, lambda v: v[0])
@@ -723,7 +723,7 @@ def main():
             want = "k_ajtai_i8" if i8 else ("bb::" if wl.ring == "babybear" else "") + "k_ajtai"
             for name, k in pmc.items():
                 base = name.split("<")[0]
-                if (base == want or (i8 and base == want + "s")) and k["fetch_bytes_max_corrected"] is not None:   # (k_ajtai_i8s: the specialised-wave kernel of the 24-ring)
+                if (base == want or (i8 and base in (want + "s", want + "x"))) and k["fetch_bytes_max_corrected"] is not None:   # (k_ajtai_i8s / _i8x: the specialised-wave kernels of the 24- / 72-ring)
                     traffic = k["fetch_bytes_max_corrected"] + k["write_bytes_max"]   # per launch like `achieved`: the largest launch (the K-1 batch)
         except Exception:
             traffic = None
@@ -750,7 +750,7 @@ def main():
             # the instantiation that is launched (lf_ajtai_i8.hip launch_ajtai_i8): the specialised-wave kernels for the 13-row-tile shape of the 24-ring and the
             # 4-row-tile shape of the 72-ring, the generic one otherwise
             mt = -(-NL * -(-wl.kappa // row_chunks) // 16)
-            dom = "k_ajtai_i8s<false,true,true>" if (RD, mt) == (24, 13) else ("k_ajtai_i8x<72,4>" if (RD, mt) == (72, 4) else "k_ajtai_i8")
+            dom = "k_ajtai_i8s<false, true>" if (RD, mt) == (24, 13) else ("k_ajtai_i8x<72, 4, false>" if (RD, mt) == (72, 4) else "k_ajtai_i8")   # (as rocprofv3 prints them)
             kernels[dom] = kernels.pop("k_ajtai")
             tops = 2 * macs / aj_t / 1e12 if aj_ms else 0.0
             gbps_8d = bytes_8d / aj_t / 1e9 if aj_ms else 0.0
@@ -841,7 +841,7 @@ def main():
             out["ivc"] = [ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3), ivc_extra(wl.name, args.chain, local_rank, elapsed / args.steps * 1e3, overlap=False)]
             if wl.name != "C2" and wl.ring == "goldilocks":
                 out["ivc"].append(ivc_extra("C2", args.chain, local_rank))
-        if world == 1 and not args.no_shard_model and args.streams == 1 and args.ccs == "r1cs" and wl.ring == "goldilocks":
+        if world == 1 and not args.no_shard_model and args.streams == 1 and args.ccs == "r1cs" and wl.ring == "goldilocks" and wl.m >= (1 << 18):   # (a step worth sharding)
             try:   # the prediction the driver's SCALE run (strong scaling of ONE fold stream) can be checked against
                 from latticefold_amd.shard_model import model_summary
                 out["shard_model"] = model_summary(wl, (2, 4, 8), steps=4, warmup=2, device=local_rank, base_ms=elapsed / args.steps * 1e3)

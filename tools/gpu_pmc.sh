@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -o p -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --no-cpu-baseline --no-lfplus >/dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -o p -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --no-cpu-baseline --no-lfplus --no-ajtai --no-shard-model --chain 0 >/dev/null 2>&1
   f=$(find /tmp/pmc_$ctr -name '*counter_collection.csv' | head -1)
   cp "$f" $R/gpurun_out/pmc_${tag}_${ctr}.csv
 done

@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=${1:-rXX}; wl=${2:-C3}
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/prof_tr
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tr -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 2 --no-cpu-baseline --no-lfplus >/dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tr -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 2 --no-cpu-baseline --no-lfplus --no-ajtai --no-shard-model --chain 0 >/dev/null 2>&1
 f=$(find /tmp/prof_tr -name '*kernel_trace.csv' | head -1)
 cd $R; python - "$f" <<'PY' > gpurun_out/${tag}_step_trace_$(echo $wl | tr A-Z a-z).txt
 import csv,sys
