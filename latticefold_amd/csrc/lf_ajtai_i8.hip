@@ -496,31 +496,60 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
             const ull lo = q[0], hi = q[1];
             b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
         }
+        if (MTW == S_MT) {
+            // all 13 row tiles in one wave (the column split): the tile image is dense, piece q = s MTW + mi at 1024 q, and the A operand rolls through two registers
+            // ACROSS the K-steps -- the read of piece q + 2 is issued before the MFMAs of piece q (an LDS read takes longer than one piece's MFMAs while the producer
+            // waves store the next tile), only the first two reads of a tile are waited for
+            v4i avn = *(const v4i *)(Ac + ab0), avnn = *(const v4i *)(Ac + ab0 + 1024);
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            // A operand: three rolling registers -- the read of row tile mi + 2 is issued before the MFMAs of row tile mi (an LDS read takes
-            // longer than the 96 cycles of one row tile's MFMAs while the producer waves store the next tile)
-            v4i avn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0), avnn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + 1024);
-#pragma unroll
-            for (int mi = 0; mi < MTW; mi++) {
+            for (int q = 0; q < KS * MTW; q++) {
+                const int s = q / MTW, mi = q % MTW;
                 const v4i av = avn;
                 avn = avnn;
-                if (mi + 2 < MTW) avnn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + (mi + 2) * 1024);
+                if (q + 2 < KS * MTW) avnn = *(const v4i *)(Ac + ab0 + (q + 2) * 1024);
                 if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
                     for (int ni = 0; ni < NTW; ni++) {
-                        const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
-                        const ull lo = q[0], hi = q[1];
+                        const ull *qv = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
+                        const ull lo = qv[0], hi = qv[1];
                         bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
                     }
                 }
 #pragma unroll
                 for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if (s + 1 < KS) {
+                if (mi == MTW - 1 && s + 1 < KS) {
 #pragma unroll
-                for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                    for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                // A operand: three rolling registers -- the read of row tile mi + 2 is issued before the MFMAs of row tile mi (an LDS read takes
+                // longer than the 96 cycles of one row tile's MFMAs while the producer waves store the next tile)
+                v4i avn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0), avnn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + 1024);
+#pragma unroll
+                for (int mi = 0; mi < MTW; mi++) {
+                    const v4i av = avn;
+                    avn = avnn;
+                    if (mi + 2 < MTW) avnn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + (mi + 2) * 1024);
+                    if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
+#pragma unroll
+                        for (int ni = 0; ni < NTW; ni++) {
+                            const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
+                            const ull lo = q[0], hi = q[1];
+                            bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
+                        }
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s + 1 < KS) {
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                }
             }
         }
         LF_S_STAMP(3);     // K-steps
@@ -880,29 +909,30 @@ __device__ __forceinline__ void i8x_mma(const AjtaiI8Args &a, unsigned char *sme
             const ull lo = q[0], hi = q[1];
             b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
         }
+        {   // the A operand rolls through two registers ACROSS the K-steps (the tile image is dense: piece q = s MT + mi at 1024 q): the read of piece q + 2 is issued
+            // before the MFMAs of piece q, so only the first two reads of a tile are waited for -- restarting the roll at every K-step exposed an LDS latency KS times per tile
+            v4i avn = *(const v4i *)(Ac + ab0), avnn = *(const v4i *)(Ac + ab0 + 1024);
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            v4i avn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0), avnn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + 1024);
-#pragma unroll
-            for (int mi = 0; mi < MT; mi++) {
+            for (int q = 0; q < KS * MT; q++) {
+                const int s = q / MT, mi = q % MT;
                 const v4i av = avn;
                 avn = avnn;
-                if (mi + 2 < MT) avnn = *(const v4i *)(Ac + (size_t)s * MT * 1024 + ab0 + (mi + 2) * 1024);
+                if (q + 2 < KS * MT) avnn = *(const v4i *)(Ac + ab0 + (q + 2) * 1024);
                 if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
                     for (int ni = 0; ni < NTW; ni++) {
-                        const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
-                        const ull lo = q[0], hi = q[1];
+                        const ull *qv = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
+                        const ull lo = qv[0], hi = qv[1];
                         bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
                     }
                 }
 #pragma unroll
                 for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if (s + 1 < KS) {
+                if (mi == MT - 1 && s + 1 < KS) {
 #pragma unroll
-                for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                    for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                }
             }
         }
         LF_S_STAMP(3);     // K-steps

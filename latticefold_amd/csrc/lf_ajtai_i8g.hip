@@ -120,33 +120,62 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
                 const ull lo = q[0], hi = q[1];
                 b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
             }
+            if (EXACT) {
+                // the image of the half tile is dense ([KS][mth][64 lanes][16]): row tile mi of K-step s is piece q = s ML + mi at Ac + 1024 q.  The A operand rolls
+                // through two registers ACROSS the K-steps: the read of piece q + 2 is issued before the MFMAs of piece q, so only the first two reads of a tile
+                // are waited for (restarting the roll at every K-step exposed an LDS latency three times per tile)
+                v4i avn = *(const v4i *)(Ac), avnn = *(const v4i *)(Ac + (KS * ML > 1 ? 1024 : 0));
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                const unsigned char *As = Ac + (size_t)s * mth * 1024;
-                // A operand: rolling registers, the read of row tile mi + 2 is issued before the MFMAs of row tile mi
-                v4i avn = *(const v4i *)(As), avnn = *(const v4i *)(As + (mth > 1 ? 1024 : 0));
-#pragma unroll
-                for (int mi = 0; mi < ML; mi++) {
+                for (int q = 0; q < KS * ML; q++) {
+                    const int s = q / ML, mi = q % ML;
                     const v4i av = avn;
                     avn = avnn;
-                    if (mi + 2 < ML) avnn = *(const v4i *)(As + (EXACT || (u32)(mi + 2) < mth ? (mi + 2) * 1024 : 0));
+                    if (q + 2 < KS * ML) avnn = *(const v4i *)(Ac + (q + 2) * 1024);
                     if (mi == (ML > 1 ? 1 : 0) && s + 1 < KS) {   // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
                         for (int ni = 0; ni < NTW; ni++) {
-                            const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
-                            const ull lo = q[0], hi = q[1];
+                            const ull *qv = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
+                            const ull lo = qv[0], hi = qv[1];
                             bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
                         }
                     }
-                    if (EXACT || (u32)mi < mth) {                  // (wave-uniform)
 #pragma unroll
-                        for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
-                    }
+                    for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                if (s + 1 < KS) {
+                    if (mi == ML - 1 && s + 1 < KS) {
 #pragma unroll
-                    for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                        for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const unsigned char *As = Ac + (size_t)s * mth * 1024;
+                    // A operand: rolling registers, the read of row tile mi + 2 is issued before the MFMAs of row tile mi
+                    v4i avn = *(const v4i *)(As), avnn = *(const v4i *)(As + (mth > 1 ? 1024 : 0));
+#pragma unroll
+                    for (int mi = 0; mi < ML; mi++) {
+                        const v4i av = avn;
+                        avn = avnn;
+                        if (mi + 2 < ML) avnn = *(const v4i *)(As + (EXACT || (u32)(mi + 2) < mth ? (mi + 2) * 1024 : 0));
+                        if (mi == (ML > 1 ? 1 : 0) && s + 1 < KS) {   // the next K-step's B operands, behind the first row tiles of this one
+#pragma unroll
+                            for (int ni = 0; ni < NTW; ni++) {
+                                const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
+                                const ull lo = q[0], hi = q[1];
+                                bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
+                            }
+                        }
+                        if (EXACT || (u32)mi < mth) {                  // (wave-uniform)
+#pragma unroll
+                            for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (s + 1 < KS) {
+#pragma unroll
+                        for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                    }
                 }
             }
             LF_G_STAMP(3);     // K-steps

@@ -105,6 +105,7 @@ static void free_ccs(lf_ctx *c) {
 static void planes_pool_drop(int device);
 void lf_ctx_destroy(lf_ctx *c) {
     if (!c) return;
+    while (c->io_jobs.load() > 0) std::this_thread::yield();   // ingestion workers still use the context (their handles may be finished later: lf_witness_job_finish needs no context)
     (void)hipSetDevice(c->device);
     planes_pool_drop(c->device);
     if (c->bb) { c->bb->destroy(); delete c; return; }
@@ -1008,7 +1009,9 @@ int lf_witness_from_w_ccs_begin(lf_ctx *c, const uint64_t *w_ccs, lf_witness_job
     if (!c || !w_ccs || !job) return LF_ERR_INVALID;
     if (!c->have_ccs_any()) return LF_ERR_STATE;
     lf_witness_job *j = new lf_witness_job();
+    c->io_jobs.fetch_add(1);
     j->fut = std::async(std::launch::async, [c, w_ccs, j]() -> int {
+        struct Done { lf_ctx *c; ~Done() { c->io_jobs.fetch_sub(1); } } done{c};
         if (c->bb || c->xb.on) return lf_witness_from_w_ccs(c, w_ccs, &j->w);
         std::lock_guard<std::mutex> g(c->io_mu);
         if (hipSetDevice(c->device) != hipSuccess) return LF_ERR_HIP;

@@ -139,6 +139,7 @@ struct lf_ctx {
     std::mutex mu, buf_mu, ev_mu;
     hipStream_t st_io = nullptr;   // lane 2: witness ingestion next to a running fold step (lf_witness_from_w_ccs_begin), lowest priority; own buffers ("lane2:" names)
     std::mutex io_mu;              // one ingestion at a time per context
+    std::atomic<int> io_jobs{0};   // ingestion jobs whose worker has not finished (lf_ctx_destroy waits for them)
     hipStream_t stream() const { return t_lane == 2 ? st_io : st_lane[t_lane]; }
     // the same facts for either backend (the external-basis marshalling is ring-agnostic)
     bool have_ccs_any() const { return bb ? bb->have_ccs() : have_ccs; }
