@@ -462,25 +462,27 @@ size_t ajtai_i8s_lds_bytes() { return 2 * (size_t)S_ALDS + 2 * (size_t)S_VB * 8 
         pt[i_] += now_ - pc;                                                             \
         pc = now_;                                                                       \
     }
-template <int MTW, int NTW, bool PROF>
+// NTU <= NTW: column tiles of this wave that hold planes of the launch (the last wave of a 7-plane group: 2 of 3 -- the MFMAs of a tile nobody reads are not issued:
+// the kernel runs at the power-managed rate of the matrix pipe, fewer MFMAs are the one thing that buys time)
+template <int MTW, int NTW, bool PROF, int NTU = NTW>
 __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *smem, u32 mg, u32 ng, u32 T0, u32 T1, u32 slot) {
     constexpr int RD = 24, KS = 3, VS = 48, HALF = 12;
     const u32 lane = threadIdx.x & 63;
     const unsigned char *Al = smem;
     const ull *V = (const ull *)(smem + 2 * S_ALDS);
-    u32 vb[NTW];
+    u32 vb[NTU];
 #pragma unroll
-    for (int ni = 0; ni < NTW; ni++) {
+    for (int ni = 0; ni < NTU; ni++) {
         u32 n = (ng * NTW + ni) * 16 + (lane & 15);       // < 192 = 8 planes x 24: planes past NP hold zero digits
         const u32 p = n / RD, co = n % RD;
         vb[ni] = ((p * 2 + (co >= HALF ? 0u : 1u)) * VS + (RD - 1 - co + 2 * (lane >> 4))) * 8;
     }
     const u32 m_lo = mg * 7, ab0 = (m_lo * 64 + lane) * 16;
-    v4i acc[MTW][NTW];
+    v4i acc[MTW][NTU];
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
+        for (int ni = 0; ni < NTU; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
     if (T0 < T1) { lds_barrier(); lds_barrier(); }          // (the producers' prologue has two barriers of its own: every wave must arrive)
     lds_barrier();                                          // hand-over: A[T0], V[T0] are in buffer 0
     unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0, pc0 = 0, pr0 = 0;
@@ -489,9 +491,9 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
         const u32 cur = (T - T0) & 1;
         const unsigned char *Ac = Al + cur * S_ALDS;
         const unsigned char *Vc = (const unsigned char *)(V + cur * S_VB);
-        v4i b[NTW], bn[NTW];
+        v4i b[NTU], bn[NTU];
 #pragma unroll
-        for (int ni = 0; ni < NTW; ni++) {
+        for (int ni = 0; ni < NTU; ni++) {
             const ull *q = (const ull *)(Vc + vb[ni]);
             const ull lo = q[0], hi = q[1];
             b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
@@ -509,18 +511,18 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
                 if (q + 2 < KS * MTW) avnn = *(const v4i *)(Ac + ab0 + (q + 2) * 1024);
                 if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
-                    for (int ni = 0; ni < NTW; ni++) {
+                    for (int ni = 0; ni < NTU; ni++) {
                         const ull *qv = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
                         const ull lo = qv[0], hi = qv[1];
                         bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
                     }
                 }
 #pragma unroll
-                for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NTU; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (mi == MTW - 1 && s + 1 < KS) {
 #pragma unroll
-                    for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                    for (int ni = 0; ni < NTU; ni++) b[ni] = bn[ni];
                 }
             }
         } else {
@@ -536,19 +538,19 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
                     if (mi + 2 < MTW) avnn = *(const v4i *)(Ac + (size_t)s * S_MT * 1024 + ab0 + (mi + 2) * 1024);
                     if (mi == 1 && s + 1 < KS) {               // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
-                        for (int ni = 0; ni < NTW; ni++) {
+                        for (int ni = 0; ni < NTU; ni++) {
                             const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
                             const ull lo = q[0], hi = q[1];
                             bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
                         }
                     }
 #pragma unroll
-                    for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NTU; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (s + 1 < KS) {
 #pragma unroll
-                    for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                    for (int ni = 0; ni < NTU; ni++) b[ni] = bn[ni];
                 }
             }
         }
@@ -574,7 +576,7 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
 #pragma unroll
     for (int mi = 0; mi < MTW; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NTW; ni++)
+        for (int ni = 0; ni < NTU; ni++)
             *(v4i *)(a.part + ((((size_t)slot * S_MT + m_lo + mi) * S_NT + ng * NTW + ni) * 64 + lane) * 4) = acc[mi][ni];
 }
 
@@ -850,6 +852,7 @@ __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     const u32 np_g = a.NP - S_NPG * grp < (u32)S_NPG ? a.NP - S_NPG * grp : (u32)S_NPG;
     const u32 wave = threadIdx.x >> 6;
     if (wave >= 4) i8s_build<PROF, BITS>(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
+    else if (wave == 3 && np_g * 24 <= (3 * 3 + 2) * 16) i8s_mma<13, 3, PROF, 2>(a, smem, 0, wave, T0, T1, slot);   // 7 planes = 168 columns: the group's twelfth column tile is never read
     else i8s_mma<13, 3, PROF>(a, smem, 0, wave, T0, T1, slot);
 }
 

@@ -77,7 +77,8 @@ struct GX {
 
 // ---- multiplier waves (0-3): wave ng owns column tiles [ng NTW, (ng + 1) NTW) and all mth row tiles of the workgroup's half
 // MTH: the half's row tiles at compile time (loops, operand strides and the accumulator array are exact), 0 = any number <= MTW at run time (wave-uniform guards)
-template <int RD, int MTW, int NTW, int MTH, bool PROF>
+// NTU <= NTW: column tiles of this wave that hold planes of the commitment (10 planes x 24 = 15 tiles: the last wave multiplies 3 of its 4)
+template <int RD, int MTW, int NTW, int MTH, bool PROF, int NTU = NTW>
 __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *smem, u32 ng, u32 mth_rt, u32 nsub, u32 T0, u32 T1, int32_t *part) {
     typedef GX<RD, MTW, NTW> G;
     constexpr int KS = G::KS, VS = G::VS, HALF = G::HALF, NT = G::NT;
@@ -87,9 +88,9 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
     const u32 mth = EXACT ? (u32)MTH : mth_rt;
     const unsigned char *Al = smem;
     const ull *V = (const ull *)(smem + G::NBA * G::ALDS);
-    u32 vb[NTW];
+    u32 vb[NTU];
 #pragma unroll
-    for (int ni = 0; ni < NTW; ni++) {
+    for (int ni = 0; ni < NTU; ni++) {
         const u32 n = (ng * NTW + ni) * 16 + (lane & 15);
         u32 p = n / RD;
         const u32 co = n % RD;
@@ -104,18 +105,18 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
     if (PROF) { pc = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     for (u32 sub = 0; sub < nsub; sub++) {
         const u32 Tb = T0 + sub * a.ft, Te = Tb + a.ft < T1 ? Tb + a.ft : T1;
-        v4i acc[ML][NTW];
+        v4i acc[ML][NTU];
 #pragma unroll
         for (int mi = 0; mi < ML; mi++)
 #pragma unroll
-            for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
+            for (int ni = 0; ni < NTU; ni++) acc[mi][ni] = v4i{0, 0, 0, 0};
         for (u32 T = Tb; T < Te; T++) {
             const u32 cur = (T - T0) & 1;
             const unsigned char *Ac = Al + ((T - T0) % G::NBA) * G::ALDS + ab0;
             const unsigned char *Vc = (const unsigned char *)(V + cur * G::VB);
-            v4i b[NTW], bn[NTW];
+            v4i b[NTU], bn[NTU];
 #pragma unroll
-            for (int ni = 0; ni < NTW; ni++) {
+            for (int ni = 0; ni < NTU; ni++) {
                 const ull *q = (const ull *)(Vc + vb[ni]);
                 const ull lo = q[0], hi = q[1];
                 b[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
@@ -133,18 +134,18 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
                     if (q + 2 < KS * ML) avnn = *(const v4i *)(Ac + (q + 2) * 1024);
                     if (mi == (ML > 1 ? 1 : 0) && s + 1 < KS) {   // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
-                        for (int ni = 0; ni < NTW; ni++) {
+                        for (int ni = 0; ni < NTU; ni++) {
                             const ull *qv = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
                             const ull lo = qv[0], hi = qv[1];
                             bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
                         }
                     }
 #pragma unroll
-                    for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NTU; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (mi == ML - 1 && s + 1 < KS) {
 #pragma unroll
-                        for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                        for (int ni = 0; ni < NTU; ni++) b[ni] = bn[ni];
                     }
                 }
             } else {
@@ -160,7 +161,7 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
                         if (mi + 2 < ML) avnn = *(const v4i *)(As + (EXACT || (u32)(mi + 2) < mth ? (mi + 2) * 1024 : 0));
                         if (mi == (ML > 1 ? 1 : 0) && s + 1 < KS) {   // the next K-step's B operands, behind the first row tiles of this one
 #pragma unroll
-                            for (int ni = 0; ni < NTW; ni++) {
+                            for (int ni = 0; ni < NTU; ni++) {
                                 const ull *q = (const ull *)(Vc + vb[ni] + (s + 1) * 64);
                                 const ull lo = q[0], hi = q[1];
                                 bn[ni] = v4i{(int)(u32)lo, (int)(u32)(lo >> 32), (int)(u32)hi, (int)(u32)(hi >> 32)};
@@ -168,13 +169,13 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
                         }
                         if (EXACT || (u32)mi < mth) {                  // (wave-uniform)
 #pragma unroll
-                            for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
+                            for (int ni = 0; ni < NTU; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[ni], acc[mi][ni], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (s + 1 < KS) {
 #pragma unroll
-                        for (int ni = 0; ni < NTW; ni++) b[ni] = bn[ni];
+                        for (int ni = 0; ni < NTU; ni++) b[ni] = bn[ni];
                     }
                 }
             }
@@ -186,7 +187,7 @@ __device__ __forceinline__ void i8g_mma(const AjtaiI8GArgs &a, unsigned char *sm
 #pragma unroll
         for (int mi = 0; mi < ML; mi++)
 #pragma unroll
-            for (int ni = 0; ni < NTW; ni++)
+            for (int ni = 0; ni < NTU; ni++)
                 if (EXACT || (u32)mi < mth) *(v4i *)(dst + (((size_t)mi * NT + ng * NTW + ni) * 64 + lane) * 4) = acc[mi][ni];
     }
     for (u32 pad = (T1 - T0) & 3; pad & 3; pad++) lds_barrier();   // the producers' loop runs whole trips of four tiles
@@ -391,10 +392,12 @@ __global__ void __launch_bounds__(512) k_ajtai_i8g(AjtaiI8GArgs a) {
     const u32 wave = threadIdx.x >> 6;
     int32_t *part = a.part[h] + (size_t)chunk * nsub * mth * G::NT * 256;
     if (wave >= 4 && wave < 7) { i8g_build<RD, MTW, NTW, PROF>(a, smem, T0, T1, h == 0 ? a.dsum + (size_t)chunk * G::NDI : nullptr); return; }
+    const u32 nt_used = (a.NP * RD + 15) / 16;                  // column tiles that hold planes (the rest of the workgroup's NT tiles is padding nobody reads)
     // the half's row-tile count at compile time where it is one of the usual ones (7 + 6 at kappa 26, 5 + 5 at kappa 20, 4 + 4 at kappa 16): exact loops, no spare pieces
 #define LF_G_ROLE(MTH_)                                                                                             \
     do {                                                                                                           \
         if (wave == 7) i8g_copy<RD, MTW, NTW, MTH_, PROF>(a, smem, a.m_lo[h], mth, T0, T1);                        \
+        else if (NTW > 1 && wave == 3 && nt_used == 4 * NTW - 1) i8g_mma<RD, MTW, NTW, MTH_, PROF, (NTW > 1 ? NTW - 1 : 1)>(a, smem, wave, mth, nsub, T0, T1, part);   \
         else i8g_mma<RD, MTW, NTW, MTH_, PROF>(a, smem, wave, mth, nsub, T0, T1, part);                            \
     } while (0)
     if (mth == (u32)MTW) LF_G_ROLE(MTW);
