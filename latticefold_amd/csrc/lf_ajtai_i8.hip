@@ -454,7 +454,11 @@ constexpr int S_NT = S_NPG * 24 / 16;    // 12 column tiles
 constexpr int S_MT = 13;
 constexpr int S_ALDS = 10 * 256 * 16;    // padded tile (39 936 bytes) in LDS
 constexpr int S_VB = S_NPG * 2 * 48, S_DB = S_NPG * 25;
-size_t ajtai_i8s_lds_bytes() { return 2 * (size_t)S_ALDS + 2 * (size_t)S_VB * 8 + 2 * (size_t)S_DB * 8 + 3 * 24 * 8 * 4 + 256 * 4; }
+constexpr int S_NBA = 3;                 // LDS ring of A tiles: tile T is multiplied while tiles T + 1, T + 2 land (LDS-DMA from the copy wave)
+constexpr int S_NCH = 3 * S_MT;          // 1 KiB pieces of a tile
+constexpr int S_NVT = 192;               // threads of the three vector waves (4 - 6)
+size_t ajtai_i8s_lds_bytes() { return S_NBA * (size_t)S_ALDS + 2 * (size_t)S_VB * 8 + 2 * (size_t)S_DB * 8 + 3 * 24 * 8 * 4 + 256 * 4; }
+static_assert(S_NBA * S_ALDS + 2 * S_VB * 8 + 2 * S_DB * 8 + 3 * 24 * 8 * 4 + 256 * 4 <= 160 * 1024 && (S_NBA - 2) * S_NCH <= 63, "LDS of a CU / vmcnt range");
 
 #define LF_S_STAMP(i_)                                                                   \
     if (PROF) {                                                                          \
@@ -469,7 +473,7 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
     constexpr int RD = 24, KS = 3, VS = 48, HALF = 12;
     const u32 lane = threadIdx.x & 63;
     const unsigned char *Al = smem;
-    const ull *V = (const ull *)(smem + 2 * S_ALDS);
+    const ull *V = (const ull *)(smem + S_NBA * S_ALDS);
     u32 vb[NTU];
 #pragma unroll
     for (int ni = 0; ni < NTU; ni++) {
@@ -489,7 +493,7 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
     if (PROF) { pc = pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     for (u32 T = T0; T < T1; T++) {
         const u32 cur = (T - T0) & 1;
-        const unsigned char *Ac = Al + cur * S_ALDS;
+        const unsigned char *Ac = Al + ((T - T0) % S_NBA) * S_ALDS;
         const unsigned char *Vc = (const unsigned char *)(V + cur * S_VB);
         v4i b[NTU], bn[NTU];
 #pragma unroll
@@ -580,55 +584,60 @@ __device__ __forceinline__ void i8s_mma(const AjtaiI8Args &a, unsigned char *sme
             *(v4i *)(a.part + ((((size_t)slot * S_MT + m_lo + mi) * S_NT + ng * NTW + ni) * 64 + lane) * 4) = acc[mi][ni];
 }
 
-// the producer waves: btid = 0 .. 255
+// ---- copy wave (7): every tile of A straight from HBM / L2 into the LDS ring (global_load_lds_dwordx4: 1 KiB per instruction, no staging registers, no ds_write
+// pass -- the register-staged copy cost the four producer waves ~1 000 of their 2 500 busy cycles per tile and the power that goes with them).  The wave touches LDS
+// through nothing else: the compiler makes every ds_read of a wave wait for that wave's LDS-DMA in flight.  Counted waits: tile T + 1 has landed when at most one tile's
+// pieces are outstanding.
+typedef __attribute__((address_space(1))) const void *i8s_gptr;
+typedef __attribute__((address_space(3))) void *i8s_lptr;
+template <bool PROF>
+__device__ __forceinline__ void i8s_copy(const AjtaiI8Args &a, unsigned char *smem, u32 T0, u32 T1) {
+    const u32 lane = threadIdx.x & 63;
+    const size_t a_tile = (size_t)3 * S_MT * 1024;
+    const u32 Tlast = a.ntiles - 1;
+    auto issue = [&](u32 T, u32 buf) {
+        const unsigned char *src = a.Ab + (size_t)(T < Tlast ? T : Tlast) * a_tile + lane * 16;
+        unsigned char *dst = smem + (size_t)buf * S_ALDS;
+#pragma unroll
+        for (int c = 0; c < S_NCH; c++) __builtin_amdgcn_global_load_lds((i8s_gptr)(src + c * 1024), (i8s_lptr)(dst + c * 1024), 16, 0, 0);
+    };
+    unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    if (T0 < T1) {
+        issue(T0, 0);
+        issue(T0 + 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S_NBA - 2) * S_NCH) : "memory");   // tile T0 has landed
+        lds_barrier();                                      // (the vector waves' two prologue barriers)
+        lds_barrier();
+    }
+    lds_barrier();                                          // hand-over of buffer 0
+    if (PROF) pc = __builtin_amdgcn_s_memtime();
+    u32 buf = S_NBA - 1;
+    for (u32 T = T0; T < T1; T++) {
+        issue(T + S_NBA - 1, buf);                          // into the buffer the multipliers left at the last barrier (tile T - 1)
+        buf = buf + 1 == (u32)S_NBA ? 0 : buf + 1;
+        LF_S_STAMP(0);     // LDS-DMA issue
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S_NBA - 2) * S_NCH) : "memory");   // tile T + 1 has landed
+        LF_S_STAMP(5);     // wait for the tile
+        lds_barrier();
+        LF_S_STAMP(6);     // barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing may land in LDS after the workgroup has gone
+    if (PROF && blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 7; i++) if (i != 4) g_i8_prof[threadIdx.x >> 6][i] = pt[i];
+        g_i8_prof[threadIdx.x >> 6][7] = T1 - T0;
+    }
+}
+
+// ---- vector waves (4-6): btid = 0 .. 191 -- digits two tiles ahead, Toeplitz vectors one tile ahead, the pair handshake
 template <bool PROF, bool BITS>
 __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *smem, const int32_t *planes, u32 k0, u32 NP, u32 T0, u32 T1, u32 slot) {
-    constexpr int RD = 24, VS = 48, HALF = 12, DS = 25, EPP = 96;
+    constexpr int RD = 24, VS = 48, HALF = 12, DS = 25, EPP = 96, NVT = S_NVT, NVR = S_VB / S_NVT;
+    static_assert(S_VB % S_NVT == 0, "vector entries per thread");
     const u32 btid = threadIdx.x - 256;
-    unsigned char *Al = smem;
-    ull *V = (ull *)(smem + 2 * S_ALDS);
+    ull *V = (ull *)(smem + S_NBA * S_ALDS);
     ull *Dl = V + 2 * S_VB;
     int32_t *wl = (int32_t *)(Dl + 2 * S_DB);               // [3][24][8]
     u32 *dsl = (u32 *)(wl + 3 * RD * 8);                    // digit sums [192]
-    const size_t a_tile = (size_t)3 * S_MT * 1024;
-    const u32 Tlast = a.ntiles - 1;
-    uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, y0, y1, y2, y3, y4, y5, y6, y7, y8, y9;
-    const u32 voff = btid * 16;
-#define LF_S_LOAD(P_, T_)                                                                                          \
-    do {   /* uniform base (scalar registers) + 32-bit lane offset: one address register for the ten loads */     \
-        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
-        P_##0 = *(const uint4 *)(src_);            P_##1 = *(const uint4 *)(src_ + 4096);                          \
-        P_##2 = *(const uint4 *)(src_ + 2 * 4096); P_##3 = *(const uint4 *)(src_ + 3 * 4096);                      \
-        P_##4 = *(const uint4 *)(src_ + 4 * 4096); P_##5 = *(const uint4 *)(src_ + 5 * 4096);                      \
-        P_##6 = *(const uint4 *)(src_ + 6 * 4096); P_##7 = *(const uint4 *)(src_ + 7 * 4096);                      \
-        P_##8 = *(const uint4 *)(src_ + 8 * 4096); P_##9 = *(const uint4 *)(src_ + 9 * 4096);                      \
-    } while (0)
-#define LF_S_LOAD_A(P_, T_)                                                                                        \
-    do {                                                                                                           \
-        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
-        P_##0 = *(const uint4 *)(src_);            P_##1 = *(const uint4 *)(src_ + 4096);                          \
-    } while (0)
-#define LF_S_LOAD_B(P_, T_)                                                                                        \
-    do {                                                                                                           \
-        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
-        P_##2 = *(const uint4 *)(src_ + 2 * 4096); P_##3 = *(const uint4 *)(src_ + 3 * 4096);                      \
-        P_##4 = *(const uint4 *)(src_ + 4 * 4096); P_##5 = *(const uint4 *)(src_ + 5 * 4096);                      \
-    } while (0)
-#define LF_S_LOAD_C(P_, T_)                                                                                        \
-    do {                                                                                                           \
-        const unsigned char *src_ = a.Ab + (size_t)((T_) < Tlast ? (T_) : Tlast) * a_tile + voff;                  \
-        P_##6 = *(const uint4 *)(src_ + 6 * 4096); P_##7 = *(const uint4 *)(src_ + 7 * 4096);                      \
-        P_##8 = *(const uint4 *)(src_ + 8 * 4096); P_##9 = *(const uint4 *)(src_ + 9 * 4096);                      \
-    } while (0)
-#define LF_S_STORE(P_, buf_)                                                                                       \
-    do {                                                                                                           \
-        unsigned char *dst_ = Al + (buf_) * S_ALDS + (size_t)btid * 16;                                            \
-        *(uint4 *)(dst_) = P_##0;            *(uint4 *)(dst_ + 4096) = P_##1;                                      \
-        *(uint4 *)(dst_ + 2 * 4096) = P_##2; *(uint4 *)(dst_ + 3 * 4096) = P_##3;                                  \
-        *(uint4 *)(dst_ + 4 * 4096) = P_##4; *(uint4 *)(dst_ + 5 * 4096) = P_##5;                                  \
-        *(uint4 *)(dst_ + 6 * 4096) = P_##6; *(uint4 *)(dst_ + 7 * 4096) = P_##7;                                  \
-        *(uint4 *)(dst_ + 8 * 4096) = P_##8; *(uint4 *)(dst_ + 9 * 4096) = P_##9;                                  \
-    } while (0)
     // staged witness words: thread btid < 192 owns word (coefficient btid / 8, column btid % 8) of a tile
     const u32 wo = (u32)((size_t)(btid < 192 ? btid >> 3 : 23) * a.ld * 4);
     int32_t wreg = 0;
@@ -684,14 +693,14 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
             dsl[btid] += (u32)sacc;
         }
     };
-    // vectors: entry idx = btid + 256 round (round < 3) = (plane, H / L, e) = (idx / 96, (idx % 96) / 48, idx % 48); with biased digit bytes
+    // vectors: entry idx = btid + 192 round (round < 4) = (plane, H / L, e) = (idx / 96, (idx % 96) / 48, idx % 48); with biased digit bytes
     //   H:  v = ((D[o0] + D[o1] + D[o2]) + 0x74..) ^ 0x80..      (bytes 12 + true value + 0x74 = 0x80 + true value)
     //   L:  v = ((D[o0] + 0x84..) - (D[o1] + D[o2])) ^ 0x80..    (a missing term reads the biased zero word)
     // plain 64-bit adds: no byte overflows (every byte stays between 0x7d and 0x8e), and the XOR turns 0x80 + t into the int8 t.
-    u32 vo[3];          // o0 | o1 << 8 | o2 << 16 | L << 24, offsets in words from the D buffer
+    u32 vo[NVR];        // o0 | o1 << 8 | o2 << 16 | L << 24, offsets in words from the D buffer
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const u32 idx = btid + 256 * r, vp = idx / EPP, vr = idx % EPP;
+    for (int r = 0; r < NVR; r++) {
+        const u32 idx = btid + NVT * r, vp = idx / EPP, vr = idx % EPP;
         u32 o0 = RD, o1 = RD, o2 = RD;
         const bool vsub = vr >= (u32)VS;
         const int dl = RD - 1 - (int)(vr % VS);
@@ -707,14 +716,14 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     static_assert(S_NPG * 25 <= 256, "8-bit vector source offsets");
     auto gen_v = [&](u32 dbuf, u32 vbuf) {
         const ull *D = Dl + dbuf * S_DB;
-        ull xa[3], xb[3], xc[3];
+        ull xa[NVR], xb[NVR], xc[NVR];
 #pragma unroll
-        for (int r = 0; r < 3; r++) { xa[r] = D[vo[r] & 0xFF]; xb[r] = D[(vo[r] >> 8) & 0xFF]; xc[r] = D[(vo[r] >> 16) & 0xFF]; }
+        for (int r = 0; r < NVR; r++) { xa[r] = D[vo[r] & 0xFF]; xb[r] = D[(vo[r] >> 8) & 0xFF]; xc[r] = D[(vo[r] >> 16) & 0xFF]; }
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < NVR; r++) {
             const ull t = xb[r] + xc[r];
             const ull v = (vo[r] >> 24) ? (xa[r] + 0x8484848484848484ull) - t : (xa[r] + 0x7474747474747474ull) + t;
-            V[vbuf * S_VB + btid + 256 * r] = v ^ 0x8080808080808080ull;
+            V[vbuf * S_VB + btid + NVT * r] = v ^ 0x8080808080808080ull;
         }
     };
     // Coupling of the two plane-group workgroups of a column chunk (blocks b and b ^ 8: same XCD, same tiles of A).  Uncoupled they drift apart -- the
@@ -731,7 +740,7 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     // tiles: 5.7-6.8 GB (the pair drifts out of the L2 between handshakes).  So the second pass over A costs HBM traffic, not kernel time: the loop is bound by
     // the matrix-pipe issue rate and the producers (profiles/r03_i8_notes.txt), and a launch moves 2.6 TB/s either way.
     const u32 c_grp = (blockIdx.x >> 3) & 1, c_chunk = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
-    constexpr u32 CPL0 = 192;     // the handshake runs in the LAST producer wave: it has no digits to cut (192 (plane, coefficient) items) and waits ~1 200 cycles per tile anyway
+    constexpr u32 CPL0 = 128;     // the handshake runs in the LAST vector wave (wave 6): its barrier holds the whole workgroup -- the copy wave included -- back when the pair has to wait
     const bool cpl = a.sync != nullptr && a.sides == 2 && btid >= CPL0;
     int *const lead_p = (int *)a.sync + c_chunk;
     const int c_sgn = c_grp ? -1 : 1;
@@ -762,16 +771,13 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     if (cpl && T0 >= T1) { LF_S_COUPLE_RELEASE(); }
     if (btid < 2 * S_NPG) Dl[btid * DS + RD] = 0x0404040404040404ull;   // the (biased) zero words
     if (T0 < T1) {
-        // prologue: A[T0] -> buffer 0, A[T0+1] in flight (x), w[T0 .. T0+2], D[T0], D[T0+1], V[T0]
-        LF_S_LOAD(y, T0);
+        // prologue: w[T0 .. T0+2], D[T0], D[T0+1], V[T0]  (two barriers: the multiplier and copy waves arrive at them too)
         if (!BITS) {
             load_w(T0); store_w(0);
             load_w(T0 + 1); store_w(1);
             load_w(T0 + 2); store_w(2);
         }
-        LF_S_STORE(y, 0);
-        LF_S_LOAD(x, T0 + 1);
-        lds_barrier();                                      // (producer-internal, but s_barrier counts every wave of the workgroup: i8s_mma arrives too)
+        lds_barrier();
         if (BITS) { load_bits(T0); gen_d(0, 0); load_bits(T0 + 1); gen_d(0, 1); load_bits(T0 + 2); }
         else { gen_d(0, 0); gen_d(1, 1); }
         lds_barrier();
@@ -782,43 +788,31 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pc = 0;
     if (PROF) pc = __builtin_amdgcn_s_memtime();
     for (u32 T = T0; T < T1; T += 2) {
-        // even tile of the pair: x holds A[T+1]; load A[T+2] into y
-        // (the tile copy's ten loads in three groups between the pieces of the build: the four producer waves share one 64-byte/clock
-        // load path -- a whole tile takes it 640 cycles -- and a wave that issues all ten at once sits in the queue that long)
+        // even tile of the pair
         LF_S_COUPLE_STEP();
-        if (!BITS) load_w(T + 3);                            // (before the tile loads: its word is stored first, and the memory counter is in order)
-        LF_S_LOAD_A(y, T + 2);
-        LF_S_STAMP(0);     // load issue
+        if (!BITS) load_w(T + 3);
+        LF_S_STAMP(0);     // handshake
         gen_d(w3 >= 1 ? w3 - 1 : 2, 0);                     // digits of tile T+2 -> D[0] (held tile T); BITS: from the words loaded one tile ago
         if (BITS) load_bits(T + 3);
-        LF_S_LOAD_B(y, T + 2);
         LF_S_STAMP(1);     // digits
         gen_v(1, 1);                                        // vectors of tile T+1 from D[1]
-        LF_S_LOAD_C(y, T + 2);
         LF_S_STAMP(2);     // vectors
-        LF_S_STORE(x, 1);                                   // A[T+1] -> buffer 1
         if (!BITS) store_w(w3);
         w3 = w3 == 2 ? 0 : w3 + 1;
-        LF_S_STAMP(5);     // wait + LDS stores
         lds_barrier();
         LF_S_STAMP(6);     // barrier
         if (T + 1 >= T1) break;
-        // odd tile: y holds A[T+2]; load A[T+3] into x
+        // odd tile
         LF_S_COUPLE_STEP();
         if (!BITS) load_w(T + 4);
-        LF_S_LOAD_A(x, T + 3);
         LF_S_STAMP(0);
         gen_d(w3 >= 1 ? w3 - 1 : 2, 1);
         if (BITS) load_bits(T + 4);
-        LF_S_LOAD_B(x, T + 3);
         LF_S_STAMP(1);
         gen_v(0, 0);
-        LF_S_LOAD_C(x, T + 3);
         LF_S_STAMP(2);
-        LF_S_STORE(y, 0);
         if (!BITS) store_w(w3);
         w3 = w3 == 2 ? 0 : w3 + 1;
-        LF_S_STAMP(5);
         lds_barrier();
         LF_S_STAMP(6);
     }
@@ -829,11 +823,6 @@ __device__ __forceinline__ void i8s_build(const AjtaiI8Args &a, unsigned char *s
     if (coupled) { LF_S_COUPLE_RELEASE(); }   // done: the partner never waits for this workgroup again (a workgroup that gave up has released already)
 #undef LF_S_COUPLE_STEP
 #undef LF_S_COUPLE_RELEASE
-#undef LF_S_LOAD
-#undef LF_S_LOAD_A
-#undef LF_S_LOAD_B
-#undef LF_S_LOAD_C
-#undef LF_S_STORE
     if (btid < 192) a.dsum[(size_t)slot * 192 + btid] = (int)dsl[btid];   // (stride of 8 planes whatever NP is)
 }
 
@@ -851,7 +840,8 @@ __global__ void __launch_bounds__(512) k_ajtai_i8s(AjtaiI8Args a) {
     const u32 T1 = T0 + a.tiles_per_wg < a.ntiles ? T0 + a.tiles_per_wg : a.ntiles;
     const u32 np_g = a.NP - S_NPG * grp < (u32)S_NPG ? a.NP - S_NPG * grp : (u32)S_NPG;
     const u32 wave = threadIdx.x >> 6;
-    if (wave >= 4) i8s_build<PROF, BITS>(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
+    if (wave == 7) i8s_copy<PROF>(a, smem, T0, T1);
+    else if (wave >= 4) i8s_build<PROF, BITS>(a, smem, a.planes, a.k0 + S_NPG * grp, np_g, T0, T1, slot);
     else if (wave == 3 && np_g * 24 <= (3 * 3 + 2) * 16) i8s_mma<13, 3, PROF, 2>(a, smem, 0, wave, T0, T1, slot);   // 7 planes = 168 columns: the group's twelfth column tile is never read
     else i8s_mma<13, 3, PROF>(a, smem, 0, wave, T0, T1, slot);
 }

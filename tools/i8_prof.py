@@ -21,9 +21,9 @@ lib = api._lib()
 lib.lf_debug_i8_prof.argtypes = [C.POINTER(C.c_uint64)]
 assert lib.lf_debug_i8_prof(out) == 0
 a = np.array(out[:], dtype=np.float64).reshape(8, 8)
-names = ["[0] load issue", "[1] digits / barrier 1", "[2] vectors", "[3] K-steps", "[4] wait vmcnt", "[5] LDS stores", "[6] barrier"]
+names = ["[0] handshake | DMA issue", "[1] digits", "[2] vectors", "[3] K-steps", "[4] (workgroup statistics)", "[5] wait for tile T+1", "[6] barrier"]
 print("tiles per workgroup:", a[:, 7], " kernel stats:", ctx.kernel_stats())
-print("cycles per tile and wave (shader clock), waves 0..7:")
+print("cycles per tile and wave (shader clock), waves 0..7 (0-3 multiply, 4-6 digits + vectors, 7 copies A; i8x: 4-7 produce):")
 for i, n in enumerate(names):
     print("  %-22s" % n, " ".join("%7.0f" % (a[w, i] / max(a[w, 7], 1)) for w in range(8)))
 print("  %-22s" % "sum", " ".join("%7.0f" % ((a[w, :4].sum() + a[w, 5:7].sum()) / max(a[w, 7], 1)) for w in range(8)))
