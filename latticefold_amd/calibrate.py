@@ -69,6 +69,7 @@ class Calibration:
     ext_basis: np.ndarray          # (3, 3) T with external = T internal (identity when the crate's basis is the binomial one)
     digit_mode: int                # 0 / 1 (lf_set_digit_mode)
     serialized_words_le: bool      # the probe's serialized element is its 24 flat words as little-endian u64, nothing else (what lf_wire.cpp assumes)
+    digit_mode_ambiguous: bool = False   # the probe's digit cases held no tie / negative-remainder case: both rules reproduce them and mode 0 was taken unverified
     extra: dict = field(default_factory=dict)
 
     def apply(self, ctx):
@@ -186,4 +187,9 @@ def load_probe(src):
         flat = b"".join(int(w).to_bytes(8, "little") for w in se["flat_words"])
         ser_ok = int(se["len"]) == len(flat) and bytes(se["bytes"]) == flat
     extra = {k: v for k, v in d.items() if k.startswith(("babybear", "frog", "ext_mul_tensor_babybear"))}
-    return Calibration(nonres=nonres, y=np.array(y_int, dtype=np.uint64), ext_basis=T, digit_mode=modes[0], serialized_words_le=ser_ok, extra=extra)
+    if len(modes) > 1:
+        import warnings
+        warnings.warn("probe 'digit_cases' do not separate the two digit rules (no tie or negative-remainder case among them): lf_set_digit_mode 0 is taken "
+                      "UNVERIFIED -- add a value of the form k B + B / 2 to tools/probe_stark_rings.rs", stacklevel=2)
+    return Calibration(nonres=nonres, y=np.array(y_int, dtype=np.uint64), ext_basis=T, digit_mode=modes[0], serialized_words_le=ser_ok, extra=extra,
+                       digit_mode_ambiguous=len(modes) > 1)

@@ -566,6 +566,7 @@ static int decompose_evals(lf_ctx *c, const u64 *lcccs, const std::vector<Fq3> &
     u64 *u_s = proof, *v_s = u_s + (size_t)K * P.t * 24;
     u64 *partial, *od, *q;
     RET(c->tbuf("red_partial", 256 * 4096, &partial));
+    if (K > 32 || P.t > 4) return LF_ERR_UNSUPPORTED;       // the fixed layout of dec_small below (v_s: 32 x 72 words, u_s: 32 x 4 elements); lf_ccs_load enforces the same envelope
     RET(c->tbuf("dec_small", 32 * 72 + 32 * 4 * 24 + 64, &od));
     RET(c->tbuf("dec_q", (size_t)P.t * 24 * n, &q));
     u64 *od_v = od, *od_u = od + 32 * 72;

@@ -135,3 +135,19 @@ def test_inconsistent_probe_output_is_refused(oracle_state):
     bad = json.loads(json.dumps(d))
     bad["serialized_element"]["bytes"][3] ^= 1
     assert not load_probe(bad).serialized_words_le                      # reported, not fatal: the wire layout is lf_wire.cpp's business
+
+
+def test_digit_cases_that_do_not_separate_the_rules_are_flagged(oracle_state):
+    """a probe whose digit cases hold no tie / negative-remainder value fits both digit rules: the loader says so instead of silently taking rule 0"""
+    nr0, y0 = oracle_state
+    text, _ = synth_probe_text(nr0, y0, 0)
+    d = json.loads(text.replace("(", "[").replace(")", "]"))
+    assert not load_probe(d).digit_mode_ambiguous
+    from latticefold_amd.calibrate import balanced_digits
+    sgn = lambda x: x % P
+    d["digit_cases"] = [[v, [sgn(x) for x in balanced_digits(v, 1 << 16, 4, 0)], [sgn(x) for x in balanced_digits(v, 2, 16, 0)]] for v in (0, 1, 5, 1000)
+                        if balanced_digits(v, 1 << 16, 4, 0) == balanced_digits(v, 1 << 16, 4, 1) and balanced_digits(v, 2, 16, 0) == balanced_digits(v, 2, 16, 1)]
+    assert d["digit_cases"]
+    with pytest.warns(UserWarning, match="do not separate"):
+        cal = load_probe(d)
+    assert cal.digit_mode_ambiguous and cal.digit_mode == 0
